@@ -1,0 +1,258 @@
+/*
+ * lantern_hip.h -- C-ABI of liblantern_hip.so: the MI355X (gfx950) implementation of
+ * LANTERN's relaxed speculative-decoding verify/accept loop.
+ *
+ * The reference (jadohu/LANTERN) is pure Python/PyTorch and has no FFI: its seam is the
+ * method surface of EaModel / EaLumina_mGPT.  Each entry point below replaces
+ * one group of torch-op sequences + Python loops of that surface; the reference site it
+ * replaces is cited as path:line relative to the upstream checkout.  The Python host
+ * mirror (lantern_amd/) binds these with ctypes; INTEGRATION.md shows the stub a reference
+ * maintainer would add.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes, no torch types.
+ *   - Every function returns 0 on success, <0 = LANTERN_E_*; lantern_last_error() returns a
+ *     thread-local message for the last failure on the calling thread.
+ *   - No allocation, no ownership transfer: every buffer is caller-allocated.  Pointers
+ *     marked [dev] are device memory (torch storage), [host] host memory.
+ *   - Device entry points are asynchronous on `stream` (a hipStream_t passed as void*),
+ *     never synchronise, and keep no global state: they are re-entrant across streams and
+ *     capturable into a hipGraph.
+ *   - All device entry points are BATCHED over `B` independent sequences (one workgroup
+ *     or more per sequence); the reference's B=1 call is the B=1 case.
+ */
+#ifndef LANTERN_HIP_H
+#define LANTERN_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LANTERN_VERSION 100
+
+enum {
+    LANTERN_OK = 0,
+    LANTERN_E_INVALID = -1,    /* bad argument / unsupported shape */
+    LANTERN_E_LAUNCH = -2,     /* HIP launch failure */
+    LANTERN_E_UNSUPPORTED = -3 /* feature not built into this kernel set */
+};
+
+enum { LANTERN_MODE_DYNAMIC = 0, LANTERN_MODE_STATIC_LUMINA = 1, LANTERN_MODE_STATIC_LG = 2 };
+enum { LANTERN_MODEL_PLAIN = 0, LANTERN_MODEL_LUMINA = 1, LANTERN_MODEL_ANOLE = 2 };
+enum { LANTERN_F32 = 0, LANTERN_BF16 = 1 };
+
+/* per-sequence status written to counters[5] by lantern_evaluate_posterior */
+enum {
+    LANTERN_ST_OK = 0,
+    LANTERN_ST_TOKEN_OOB = 1,     /* candidate token outside [0,V) */
+    LANTERN_ST_UNIFORMS = 2,      /* uniform stream exhausted */
+    LANTERN_ST_TABLE_OOB = 3,     /* token - tok_offset outside the neighbour table */
+    LANTERN_ST_SYNTAX_REJECT = 4, /* reference assert, ea_model_lumina_mgpt.py:694 */
+    LANTERN_ST_NO_PREFIX = 5
+};
+
+int lantern_version(void);
+const char *lantern_last_error(void);
+
+/* ------------------------------------------------------------------------------------
+ * O1  static target-tree buffers (HOST; once per tree shape).
+ * Replaces generate_tree_buffers: models/ea_model_lumina_mgpt.py:140-277,
+ * models/ea_model_llamagen.py:283-420, models/ea_model_anole.py:280-417.
+ * choices: tree_choices flattened, choice_off[n_choices+1].
+ * Outputs [host]: mask [N,N] f32 (1 = attend), tree_indices [N], pos_ids [N],
+ * retrieve [P,D] (-1 pad, rows sorted), p_idx [P,D], b_off [P*D+1] + b_idx (CSR of the
+ * earlier-sibling node ids per retrieve cell).
+ */
+int lantern_tree_static_sizes(const int32_t *choices, const int32_t *choice_off, int n_choices,
+                              int *N, int *P, int *D, int *b_total);
+int lantern_tree_static_build(const int32_t *choices, const int32_t *choice_off, int n_choices, int top_k,
+                              float *mask, int64_t *tree_indices, int64_t *pos_ids, int64_t *retrieve,
+                              int32_t *p_idx, int32_t *b_off, int32_t *b_idx);
+
+/* O2  drafter-side static buffers over non-leaf nodes (HOST).
+ * Replaces models/drafters/utils_c.py:100-179 (copies cnets_lumina_mgpt.py:106-174).
+ * level_counts[l] = non-leaf nodes of depth l+1.  masks_concat: per level [n_l, cum_l]. */
+int lantern_tree_drafter_sizes(const int32_t *choices, const int32_t *choice_off, int n_choices,
+                               int *n_levels, int *level_counts);
+int lantern_tree_drafter_build(const int32_t *choices, const int32_t *choice_off, int n_choices, int top_k,
+                               float *masks_concat, int64_t *tree_indices_concat,
+                               int32_t *repeat_nums_concat, int32_t *repeat_off);
+
+/* ------------------------------------------------------------------------------------
+ * O4  dynamic (EAGLE-2) tree finalise, one wavefront per sequence.
+ * Replaces the tail of Model.topK_genrate: models/drafters/cnets_llamagen.py:831-912,
+ * cnets_lumina_mgpt.py:1330-1393, cnets_anole.py:913-993.
+ * [dev] scores [B,n_scores] f32, tokens [B,n_scores] i64, parents [B,n_parents] i64,
+ *       sample_token [B] i64.  T = total_tokens (<= 63), N = T+1.
+ * Out [dev]: draft_tokens [B,N] i64, mask [B,N,N] f32, pos_ids [B,N] i64,
+ *            retrieve [B,N,N] i64 (row stride N, -1 pad; rows >= n_leaf are -1),
+ *            n_leaf [B] i32, max_depth [B] i32.
+ * Ties in the top-T selection break towards the lower flat index.
+ */
+int lantern_tree_dynamic_finalize(const float *scores, const int64_t *tokens, const int64_t *parents,
+                                  const int64_t *sample_token, int B, int n_scores, int n_parents,
+                                  int top_k, int total_tokens, int sort_rows, int64_t *draft_tokens,
+                                  float *mask, int64_t *pos_ids, int64_t *retrieve, int32_t *n_leaf,
+                                  int32_t *max_depth, void *stream);
+
+/* O3  one EAGLE-2 expansion depth: log_softmax rows -> top_k per row -> cumulative scores
+ * -> top_k of the flattened n_rows*top_k.  Replaces cnets_llamagen.py:798-820,
+ * cnets_lumina_mgpt.py:1303-1318.
+ * [dev] logits [B,n_rows,V] f32 (already CFG'd/processed), scores_in [B,n_rows] f32 or NULL.
+ * Out [dev]: topk_index [B,n_rows,top_k] i64, cu_scores [B,n_rows,top_k] f32,
+ *            topk_cs_index [B,top_k] i64, scores_out [B,top_k] f32. */
+int lantern_expand_dynamic(const float *logits, const float *scores_in, int B, int n_rows, int V, int top_k,
+                           int64_t *topk_index, float *cu_scores, int64_t *topk_cs_index,
+                           float *scores_out, void *stream);
+
+/* ------------------------------------------------------------------------------------
+ * O6  candidate assembly.  Replaces generate_candidates:
+ * models/ea_model_lumina_mgpt.py:525-554, models/ea_model_llamagen.py:676-706.
+ * [dev] ss_token [B,n_flat] i64, ss_prob [B,n_flat] f32 or NULL, sample_token [B] i64,
+ *       tree_indices [N] i64, retrieve [P,D] i64 (shared by all sequences).
+ * Out [dev]: tree_cand [B,N] i64, cand [B,P,D] i64, cart_prob [B,P,D] f32 (or NULL). */
+int lantern_gather_candidates(const int64_t *ss_token, const float *ss_prob, const int64_t *sample_token,
+                              const int64_t *tree_indices, const int64_t *retrieve, int B, int n_flat, int N,
+                              int P, int D, int64_t *tree_cand, int64_t *cand, float *cart_prob,
+                              void *stream);
+
+/* ------------------------------------------------------------------------------------
+ * O7  tree-logit post-process: CFG combine + model mask + top-k threshold, one pass.
+ * Replaces tree_decoding's epilogue: models/ea_model_lumina_mgpt.py:597-605 (with
+ * MultiModalLogitsProcessor :45-86 and InterleavedTopKLogitsWarper :106-112),
+ * models/ea_model_anole.py:930-931, models/ea_model_llamagen.py:930.
+ * [dev] cond/uncond [rows,V] in `dtype`; bf16 input reproduces torch's per-op bf16
+ * rounding of u + s*(c-u).  pos_ids [rows] i64 = the value the reference passes as
+ * `position_ids=`; num_generated_image_tokens = pos_ids - pos_base (Lumina only).
+ * Out [dev]: out [rows,V] f32.  V % 4 == 0.
+ */
+int lantern_cfg_mask_topk(const void *cond, const void *uncond, int dtype, int rows, int V, float cfg,
+                          int model, const int64_t *pos_ids, int64_t pos_base, int w_latent, int h_latent,
+                          int img_lo, int img_hi, int newline_id, int eos_id, int top_k, float *out,
+                          void *stream);
+
+/* ------------------------------------------------------------------------------------
+ * O8  relaxed tree rejection sampling (the north-star kernel).
+ * Replaces the sampling branch of evaluate_posterior:
+ *   models/ea_model_lumina_mgpt.py:610-726 (eagle_version 1 and 2),
+ *   models/ea_model_llamagen.py:709-787 / models/ea_model_anole.py:709-788 (dynamic),
+ *   models/ea_model_llamagen.py:597-669 / models/ea_model_anole.py:597-669 (static, _v1).
+ */
+typedef struct lantern_ep_params {
+    int32_t B;               /* sequences */
+    int32_t P, D;            /* array extents of cand/row_index (strides) */
+    int32_t V;
+    int32_t rows_per_seq;    /* logits rows per sequence */
+    int32_t mode;            /* LANTERN_MODE_* */
+    int32_t syntax_shortcut; /* Lumina: syntax token -> px=1, non-image -> px=0 (:654-659) */
+    int32_t tok_offset;      /* image-token offset into the neighbour table */
+    int32_t img_lo, img_hi;
+    int32_t n_syntax;
+    int32_t syntax[8];
+    int32_t lantern, k;
+    int32_t table_rows, table_cols;
+    int32_t top_k;           /* per-level HF processors (LlamaGen/Anole): <=0 off */
+    float temperature;       /* <=1e-5 or 1 -> off */
+    float top_p;             /* must be off (>=1 or <=0) in this build */
+    double delta;            /* <=1: delta mode; >1: lambda mode, tau = (delta-1)*px */
+    int32_t n_uniforms;      /* uniforms per sequence (row stride) */
+    int32_t R;               /* orig_prob rows per sequence (static) */
+    int32_t N;               /* tree_cand entries per sequence (static) */
+    int32_t row_index_per_seq; /* 1: row_index is [B,P,D]; 0: [P,D] shared */
+} lantern_ep_params;
+
+typedef struct lantern_ep_buffers {
+    const float *logits;      /* [dev] [B,rows_per_seq,V] f32 (processed node logits, or the
+                                 materialised [P*D,V] of the reference with row_index = arange) */
+    const int32_t *row_index; /* [dev] (path,depth) -> logits row */
+    const int64_t *cand;      /* [dev] [B,P,D], -1 pad */
+    const int32_t *n_paths;   /* [dev] [B] valid rows of cand, or NULL (= P) */
+    const int32_t *n_depth;   /* [dev] [B] valid columns, or NULL (= D) */
+    /* static trees only (NULL in dynamic mode) */
+    const float *cart_prob;   /* [dev] [B,P,D] */
+    const float *orig_prob;   /* [dev] [B,R,V] drafter distributions, levels concatenated */
+    const int32_t *op_off;    /* [dev] [D-1] first row of drafter level d */
+    const int32_t *p_idx;     /* [dev] [P,D] */
+    const int32_t *b_off;     /* [dev] [P*D+1] */
+    const int32_t *b_idx;     /* [dev] */
+    const int64_t *tree_cand; /* [dev] [B,N] */
+    const uint16_t *nn_table; /* [dev] [table_rows,table_cols] uint16 (NULL if !lantern) */
+    const double *uniforms;   /* [dev] [B,n_uniforms]: the Python random.random() stream */
+    int32_t *cursor;          /* [dev] [B] in/out read position in uniforms, or NULL (0) */
+    float *workspace;         /* [dev] lantern_evaluate_posterior_workspace() bytes */
+    /* outputs */
+    int32_t *best;            /* [dev] [B] */
+    int32_t *accept_len;      /* [dev] [B] */
+    float *sample_p;          /* [dev] [B,V] */
+    int32_t *counters;        /* [dev] [B,6]: levels, tried, rejected, uniforms used,
+                                 final-from-residual, status (LANTERN_ST_*) */
+} lantern_ep_buffers;
+
+size_t lantern_evaluate_posterior_workspace(const lantern_ep_params *prm);
+int lantern_evaluate_posterior(const lantern_ep_params *prm, const lantern_ep_buffers *buf, void *stream);
+
+/* a9  greedy / TVD branch (temperature <= 1e-5): models/ea_model_llamagen.py:789-905,
+ * models/ea_model_anole.py:790-905.  out_row [B,V] = logits[best, accept_len]. */
+int lantern_evaluate_posterior_greedy(const float *logits, const int32_t *row_index, const int64_t *cand,
+                                      int B, int P, int D, int V, int rows_per_seq, int row_index_per_seq,
+                                      int lantern, int k, double delta, int tok_offset,
+                                      const uint16_t *nn_table, int table_rows, int table_cols,
+                                      int32_t *best, int32_t *accept_len, float *out_row, void *stream);
+
+/* ------------------------------------------------------------------------------------
+ * O9  KV-cache index gather, all slabs / layers / heads in one launch.
+ * Replaces the slab loop of update_inference_inputs: models/ea_model_lumina_mgpt.py:741-746,
+ * :763-767; models/ea_model_llamagen.py:961-970; KVCache.copy models/drafters/kv_cache.py:38-50:
+ *   slab[..., prev:prev+a+1, :] <- slab[..., retrieve[best,:a+1] + prev, :]
+ * slab_ptrs [dev] [n_slabs] device pointers; each slab is [outer, S_max, d] elements of
+ * elem_bytes (row bytes d*elem_bytes % 16 == 0).  slab_seq [dev] [n_slabs]: sequence whose
+ * best/accept_len the slab follows; slab_prev [dev] [n_slabs] i64 previous length.
+ * retrieve [dev] [B,P,D] (retrieve_per_seq) or [P,D]; best/accept_len [dev] [B] i32 (the
+ * outputs of lantern_evaluate_posterior -- no host round trip).
+ * Out: new_len [dev] [n_slabs] i64 = prev + a + 1 (the reference's current_length).
+ */
+int lantern_kv_gather(void *const *slab_ptrs, const int32_t *slab_seq, const int64_t *slab_prev,
+                      int n_slabs, int elem_bytes, int64_t outer, int64_t S_max, int64_t d,
+                      const int64_t *retrieve, int retrieve_per_seq, int P, int D, const int32_t *best,
+                      const int32_t *accept_len, int64_t *new_len, void *stream);
+
+/* O10 accepted-hidden gather + token append + bonus-token draw.
+ * Replaces models/ea_model_lumina_mgpt.py:748-750,773-785; models/ea_model_llamagen.py:957-984.
+ * hidden [dev] [B,G,N,H] (G = cond/uncond groups) elem_bytes each; out_hidden [dev]
+ * [B,G,D,H] (rows > accept_len zero-filled).  accepted_tokens [dev] [B,D] i64 (-1 pad).
+ * Bonus token: inverse-CDF of sample_p [B,V] at u [B] (double): smallest i with
+ * cumsum(p)[i] > u*sum(p); greedy (u == NULL): argmax.  token [dev] [B] i64.
+ */
+int lantern_accept_gather(const void *hidden, int elem_bytes, int B, int G, int N, int H,
+                          const int64_t *retrieve, int retrieve_per_seq, int P, int D,
+                          const int64_t *cand, const int32_t *best, const int32_t *accept_len,
+                          const float *sample_p, int V, const double *u, void *out_hidden,
+                          int64_t *accepted_tokens, int64_t *token, void *stream);
+
+/* O5  static-tree drafter sampling epilogue with injected multinomial indices.
+ * Replaces sample(): models/drafters/cnets_lumina_mgpt.py:936-955, cnets_llamagen.py:924-940.
+ * probs [dev] [R,V] f32 (softmaxed), idx [dev] [R,k] i64 -> out_prob [dev] [R,k] f32. */
+int lantern_sample_static(const float *probs, const int64_t *idx, int R, int V, int k, float *out_prob,
+                          void *stream);
+
+/* O11 drafter input contraction on MFMA: out = fc(cat(embed[ids]*scale, hidden)) (+bias).
+ * Replaces Model.forward's input stage: models/drafters/cnets_lumina_mgpt.py:1071,1095-1098;
+ * cnets_llamagen.py:642,679-680.  bf16 operands, f32 accumulate, bf16 output.
+ * ids [dev] [M] i64, hidden [dev] [M,H] bf16, embed [dev] [vocab,H] bf16,
+ * W [dev] [H,2H] bf16 row-major (nn.Linear weight), bias [dev] [H] bf16 or NULL. */
+int lantern_drafter_fc(const int64_t *ids, const void *hidden, const void *embed, const void *W,
+                       const void *bias, int M, int H, int vocab, float embed_scale, void *out,
+                       void *stream);
+
+/* 8f-1 VQ-distance neighbour table: cdist + per-row ascending order, self excluded.
+ * Replaces entrypoints/generate_codebook.py:53-65.  codebook [dev] [K,C] f32 ->
+ * table [dev] [K,K-1] u16.  workspace [dev] K*K*8 bytes. */
+int lantern_build_vq_table(const float *codebook, int K, int C, uint16_t *table, void *workspace,
+                           void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LANTERN_HIP_H */

@@ -1,0 +1,79 @@
+"""ctypes loader for liblantern_hip.so (the C-ABI declared in include/lantern_hip.h).
+
+The HIP library IS the product path: if it is missing this module raises -- there is no
+CPU or PyTorch fallback anywhere in lantern_amd.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "liblantern_hip.so")
+
+
+class LanternError(RuntimeError):
+    pass
+
+
+class EpParams(C.Structure):
+    _fields_ = [
+        ("B", C.c_int32), ("P", C.c_int32), ("D", C.c_int32), ("V", C.c_int32),
+        ("rows_per_seq", C.c_int32), ("mode", C.c_int32), ("syntax_shortcut", C.c_int32),
+        ("tok_offset", C.c_int32), ("img_lo", C.c_int32), ("img_hi", C.c_int32),
+        ("n_syntax", C.c_int32), ("syntax", C.c_int32 * 8),
+        ("lantern", C.c_int32), ("k", C.c_int32),
+        ("table_rows", C.c_int32), ("table_cols", C.c_int32),
+        ("top_k", C.c_int32), ("temperature", C.c_float), ("top_p", C.c_float),
+        ("delta", C.c_double),
+        ("n_uniforms", C.c_int32), ("R", C.c_int32), ("N", C.c_int32), ("row_index_per_seq", C.c_int32),
+    ]
+
+
+class EpBuffers(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in (
+        "logits", "row_index", "cand", "n_paths", "n_depth", "cart_prob", "orig_prob", "op_off", "p_idx",
+        "b_off", "b_idx", "tree_cand", "nn_table", "uniforms", "cursor", "workspace",
+        "best", "accept_len", "sample_p", "counters")]
+
+
+_lib = None
+
+
+def build(force: bool = False) -> str:
+    """Compile liblantern_hip.so for gfx950 with hipcc (cross-compiles without a GPU)."""
+    import subprocess
+    src = os.path.join(_HERE, "csrc")
+    if force:
+        subprocess.check_call(["make", "-C", src, "-s", "clean"])
+    subprocess.check_call(["make", "-C", src, "-s", "-j8"])
+    return LIB_PATH
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise LanternError(
+                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950).  lantern_amd has no CPU fallback.")
+        _lib = C.CDLL(LIB_PATH)
+        _lib.lantern_last_error.restype = C.c_char_p
+        _lib.lantern_evaluate_posterior_workspace.restype = C.c_size_t
+    return _lib
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        msg = lib().lantern_last_error()
+        raise LanternError(f"{what} failed (rc={rc}): {msg.decode() if msg else ''}")
+
+
+EXPORTS = [
+    "lantern_version", "lantern_last_error", "lantern_tree_static_sizes", "lantern_tree_static_build",
+    "lantern_tree_drafter_sizes", "lantern_tree_drafter_build", "lantern_tree_dynamic_finalize",
+    "lantern_expand_dynamic", "lantern_gather_candidates", "lantern_cfg_mask_topk",
+    "lantern_evaluate_posterior_workspace", "lantern_evaluate_posterior", "lantern_evaluate_posterior_greedy",
+    "lantern_kv_gather", "lantern_accept_gather", "lantern_sample_static", "lantern_drafter_fc",
+    "lantern_build_vq_table",
+]

@@ -1,0 +1,287 @@
+// gather_ops.hip -- O6 candidate assembly, O9 KV-cache index gather, O10 accepted-hidden
+// gather + token append + bonus-token draw, O5 static-tree sampling epilogue.
+// All are index/byte movers: coalesced 16-byte accesses, indices read from device memory
+// (the outputs of evaluate_posterior) so the step never round-trips to the host.
+#include "common.h"
+
+namespace lantern {
+
+// ------------------------------------------------------------------------- O6
+// models/ea_model_lumina_mgpt.py:525-554; models/ea_model_llamagen.py:676-706
+__global__ void gather_candidates_kernel(const int64_t *__restrict__ ss_token, const float *__restrict__ ss_prob,
+                                         const int64_t *__restrict__ sample_token, const int64_t *__restrict__ tree_indices,
+                                         const int64_t *__restrict__ retrieve, int n_flat, int N, int PD,
+                                         int64_t *__restrict__ tree_cand, int64_t *__restrict__ cand,
+                                         float *__restrict__ cart_prob) {
+    const int b = blockIdx.x;
+    const int64_t *tok = ss_token + (size_t)b * n_flat;
+    const float *prb = ss_prob ? ss_prob + (size_t)b * n_flat : nullptr;
+    const int64_t st = sample_token[b];
+    for (int n = threadIdx.x; n < N; n += blockDim.x) {
+        const int64_t ti = tree_indices[n];
+        tree_cand[(size_t)b * N + n] = ti == 0 ? st : tok[ti - 1];
+    }
+    for (int i = threadIdx.x; i < PD; i += blockDim.x) {
+        const int64_t r = retrieve[i];
+        int64_t c = -1;
+        float p = 1.0f;
+        if (r >= 0) {
+            const int64_t ti = tree_indices[r];
+            c = ti == 0 ? st : tok[ti - 1];
+            if (prb) p = ti == 0 ? 1.0f : prb[ti - 1];
+        }
+        cand[(size_t)b * PD + i] = c;
+        if (cart_prob) cart_prob[(size_t)b * PD + i] = p;
+    }
+}
+
+// ------------------------------------------------------------------------- O9
+// models/ea_model_lumina_mgpt.py:741-746,763-767; models/drafters/kv_cache.py:38-50.
+// grid.x = tiles of `outer` rows, grid.y = slab.  A thread owns one 16-byte column chunk of
+// one (layer,batch,head) row-group: it loads the <= MAXSEL selected chunks into registers,
+// then stores them at prev..prev+a, so the in-place move cannot race with itself.
+constexpr int KV_MAXSEL = 16;
+
+__global__ __launch_bounds__(256) void kv_gather_kernel(void *const *__restrict__ slab_ptrs, const int32_t *__restrict__ slab_seq,
+                                                        const int64_t *__restrict__ slab_prev, int64_t outer, int64_t S_max,
+                                                        int chunks_per_row, const int64_t *__restrict__ retrieve,
+                                                        int retrieve_per_seq, int P, int D, const int32_t *__restrict__ best,
+                                                        const int32_t *__restrict__ accept_len, int64_t *__restrict__ new_len) {
+    const int s = blockIdx.y;
+    const int seq = slab_seq[s];
+    const int64_t prev = slab_prev[s];
+    const int bst = best[seq];
+    int n_sel = accept_len[seq] + 1;
+    if (n_sel > D) n_sel = D;
+    if (n_sel > KV_MAXSEL) n_sel = KV_MAXSEL;
+    const int64_t *rrow = retrieve + (retrieve_per_seq ? (size_t)seq * P * D : 0) + (size_t)bst * D;
+    if (blockIdx.x == 0 && threadIdx.x == 0 && new_len) new_len[s] = prev + n_sel;
+
+    uint4 *base = reinterpret_cast<uint4 *>(slab_ptrs[s]);
+    const int64_t total = outer * chunks_per_row;
+    for (int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; w < total; w += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t o = w / chunks_per_row;
+        const int c = (int)(w - o * chunks_per_row);
+        uint4 *rowbase = base + o * S_max * chunks_per_row + c;
+        uint4 v[KV_MAXSEL];
+#pragma unroll
+        for (int t = 0; t < KV_MAXSEL; ++t)
+            if (t < n_sel) {
+                int64_t src = rrow[t] + prev;
+                src = src < 0 ? 0 : (src >= S_max ? S_max - 1 : src);
+                v[t] = rowbase[src * chunks_per_row];
+            }
+#pragma unroll
+        for (int t = 0; t < KV_MAXSEL; ++t)
+            if (t < n_sel && prev + t < S_max) rowbase[(prev + t) * chunks_per_row] = v[t];
+    }
+}
+
+// ------------------------------------------------------------------------ O10
+// models/ea_model_lumina_mgpt.py:748-750,773-785.
+constexpr int AG_THREADS = 1024;
+constexpr int AG_NW = AG_THREADS / 64;
+
+__global__ __launch_bounds__(AG_THREADS) void accept_gather_kernel(const void *__restrict__ hidden, int elem_bytes, int G, int N,
+                                                                   int H, const int64_t *__restrict__ retrieve,
+                                                                   int retrieve_per_seq, int P, int D,
+                                                                   const int64_t *__restrict__ cand,
+                                                                   const int32_t *__restrict__ best,
+                                                                   const int32_t *__restrict__ accept_len,
+                                                                   const float *__restrict__ sample_p, int V,
+                                                                   const double *__restrict__ u, void *__restrict__ out_hidden,
+                                                                   int64_t *__restrict__ accepted_tokens,
+                                                                   int64_t *__restrict__ token) {
+    __shared__ double s_tot[AG_NW];
+    __shared__ double s_red[2 * AG_NW];
+    __shared__ float s_redf[2 * AG_NW];
+    __shared__ int s_redi[2 * AG_NW];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int bst = best[b];
+    int n_sel = accept_len[b] + 1;
+    if (n_sel > D) n_sel = D;
+    const int64_t *rrow = retrieve + (retrieve_per_seq ? (size_t)b * P * D : 0) + (size_t)bst * D;
+    int ph = 0;
+
+    if (accepted_tokens && cand)
+        for (int t = tid; t < D; t += AG_THREADS)
+            accepted_tokens[(size_t)b * D + t] = t < n_sel ? cand[(size_t)b * P * D + (size_t)bst * D + t] : -1;
+
+    if (hidden && out_hidden) {
+        const int rowb = H * elem_bytes;  // multiple of 16 (checked on host)
+        const int cpr = rowb / 16;
+        const uint4 *src = reinterpret_cast<const uint4 *>(hidden);
+        uint4 *dst = reinterpret_cast<uint4 *>(out_hidden);
+        const int total = G * D * cpr;
+        for (int w = tid; w < total; w += AG_THREADS) {
+            const int gi = w / (D * cpr);
+            const int rem = w - gi * D * cpr;
+            const int t = rem / cpr, c = rem - t * cpr;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (t < n_sel) {
+                int64_t r = rrow[t];
+                if (r < 0) r += N;
+                r = r < 0 ? 0 : (r >= N ? N - 1 : r);
+                v = src[(((size_t)b * G + gi) * N + r) * cpr + c];
+            }
+            dst[(((size_t)b * G + gi) * D + t) * cpr + c] = v;
+        }
+    }
+
+    if (!sample_p || !token) return;
+    const float *p = sample_p + (size_t)b * V;
+    if (u == nullptr) {  // greedy: argmax, lowest index on ties (torch.argmax)
+        float bv = -__builtin_inff();
+        int bi = 0x7fffffff;
+        for (int i = tid; i < V; i += AG_THREADS) {
+            const float v = p[i];
+            if (v > bv) {
+                bv = v;
+                bi = i;
+            }
+        }
+        const float mx = block_max<AG_NW>(bv, s_redf, ph);
+        int cnd = (bv == mx) ? bi : 0x7fffffff;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) cnd = min(cnd, __shfl_xor(cnd, o, 64));
+        int *buf = s_redi + (ph & 1) * AG_NW;
+        ph ^= 1;
+        if (lane == 0) buf[wave] = cnd;
+        __syncthreads();
+        if (tid == 0) {
+            int r = buf[0];
+            for (int w = 1; w < AG_NW; ++w) r = min(r, buf[w]);
+            token[b] = r;
+        }
+        return;
+    }
+    // inverse CDF: thread t owns the contiguous chunk [t*cs, (t+1)*cs)
+    const int cs = (V + AG_THREADS - 1) / AG_THREADS;
+    const int lo = tid * cs, hi = min(V, lo + cs);
+    double loc = 0.0;
+    for (int i = lo; i < hi; ++i) loc += (double)p[i];
+    double inc = wave_scan_incl(loc);
+    if (lane == 63) s_tot[wave] = inc;
+    __syncthreads();
+    double woff = 0.0, total = 0.0;
+#pragma unroll
+    for (int w = 0; w < AG_NW; ++w) {
+        const double t = s_tot[w];
+        woff += (w < wave) ? t : 0.0;
+        total += t;
+    }
+    const double excl = inc - loc + woff;
+    const double tgt = u[b] * total;
+    // first index whose inclusive prefix exceeds tgt (and has p > 0)
+    int found = 0x7fffffff, last_pos = -1;
+    double acc = excl;
+    for (int i = lo; i < hi; ++i) {
+        const float v = p[i];
+        acc += (double)v;
+        if (v > 0.0f) {
+            last_pos = i;
+            if (acc > tgt && found == 0x7fffffff) found = i;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        found = min(found, __shfl_xor(found, o, 64));
+        last_pos = max(last_pos, __shfl_xor(last_pos, o, 64));
+    }
+    int *bf = s_redi + (ph & 1) * AG_NW;
+    ph ^= 1;
+    __shared__ int s_last[AG_NW];
+    if (lane == 0) {
+        bf[wave] = found;
+        s_last[wave] = last_pos;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int f = bf[0], l = s_last[0];
+        for (int w = 1; w < AG_NW; ++w) {
+            f = min(f, bf[w]);
+            l = max(l, s_last[w]);
+        }
+        token[b] = f != 0x7fffffff ? f : l;
+    }
+}
+
+// ------------------------------------------------------------------------- O5
+// models/drafters/cnets_lumina_mgpt.py:936-955: p_i / (1 - sum_{j<i} p_j), inf/nan -> -1, clamp [0,1]
+__global__ void sample_static_kernel(const float *__restrict__ probs, const int64_t *__restrict__ idx, int R, int V, int k,
+                                     float *__restrict__ out_prob) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= R) return;
+    double acc = 0.0;
+    float prev_c = 0.0f;
+    for (int i = 0; i < k; ++i) {
+        int64_t t = idx[(size_t)r * k + i];
+        t = t < 0 ? 0 : (t >= V ? V - 1 : t);
+        const float p = probs[(size_t)r * V + t];
+        float v = p / (1.0f - prev_c);
+        if (isinf(v) || isnan(v)) v = -1.0f;
+        v = v < 0.0f ? 0.0f : (v > 1.0f ? 1.0f : v);
+        out_prob[(size_t)r * k + i] = v;
+        acc += (double)p;
+        prev_c = (float)acc;
+    }
+}
+
+}  // namespace lantern
+
+using namespace lantern;
+
+extern "C" int lantern_gather_candidates(const int64_t *ss_token, const float *ss_prob, const int64_t *sample_token,
+                                         const int64_t *tree_indices, const int64_t *retrieve, int B, int n_flat, int N, int P,
+                                         int D, int64_t *tree_cand, int64_t *cand, float *cart_prob, void *stream) {
+    LANTERN_CHECK_ARG(ss_token && sample_token && tree_indices && retrieve && tree_cand && cand, "gather_candidates: null buffer");
+    LANTERN_CHECK_ARG(B >= 0 && n_flat > 0 && N > 0 && P > 0 && D > 0, "gather_candidates: bad sizes");
+    if (B == 0) return LANTERN_OK;
+    hipLaunchKernelGGL(gather_candidates_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, ss_token, ss_prob, sample_token,
+                       tree_indices, retrieve, n_flat, N, P * D, tree_cand, cand, cart_prob);
+    LANTERN_CHECK_LAUNCH("gather_candidates");
+    return LANTERN_OK;
+}
+
+extern "C" int lantern_kv_gather(void *const *slab_ptrs, const int32_t *slab_seq, const int64_t *slab_prev, int n_slabs,
+                                 int elem_bytes, int64_t outer, int64_t S_max, int64_t d, const int64_t *retrieve,
+                                 int retrieve_per_seq, int P, int D, const int32_t *best, const int32_t *accept_len,
+                                 int64_t *new_len, void *stream) {
+    LANTERN_CHECK_ARG(slab_ptrs && slab_seq && slab_prev && retrieve && best && accept_len, "kv_gather: null buffer");
+    LANTERN_CHECK_ARG(n_slabs >= 0 && outer > 0 && S_max > 0 && d > 0 && P > 0 && D > 0, "kv_gather: bad sizes");
+    LANTERN_CHECK_ARG((d * elem_bytes) % 16 == 0, "kv_gather: row bytes %lld must be a multiple of 16", (long long)(d * elem_bytes));
+    LANTERN_CHECK_ARG(D <= KV_MAXSEL, "kv_gather: D=%d > %d", D, KV_MAXSEL);
+    if (n_slabs == 0) return LANTERN_OK;
+    const int cpr = (int)(d * elem_bytes / 16);
+    const int64_t total = outer * cpr;
+    int gx = (int)((total + 255) / 256);
+    if (gx > 4096) gx = 4096;
+    hipLaunchKernelGGL(kv_gather_kernel, dim3(gx, n_slabs), dim3(256), 0, (hipStream_t)stream, slab_ptrs, slab_seq, slab_prev,
+                       outer, S_max, cpr, retrieve, retrieve_per_seq, P, D, best, accept_len, new_len);
+    LANTERN_CHECK_LAUNCH("kv_gather");
+    return LANTERN_OK;
+}
+
+extern "C" int lantern_accept_gather(const void *hidden, int elem_bytes, int B, int G, int N, int H, const int64_t *retrieve,
+                                     int retrieve_per_seq, int P, int D, const int64_t *cand, const int32_t *best,
+                                     const int32_t *accept_len, const float *sample_p, int V, const double *u,
+                                     void *out_hidden, int64_t *accepted_tokens, int64_t *token, void *stream) {
+    LANTERN_CHECK_ARG(retrieve && best && accept_len, "accept_gather: null buffer");
+    LANTERN_CHECK_ARG(B >= 0 && P > 0 && D > 0, "accept_gather: bad sizes");
+    if (hidden) LANTERN_CHECK_ARG(out_hidden && G > 0 && N > 0 && H > 0 && (H * elem_bytes) % 16 == 0,
+                                  "accept_gather: hidden row bytes must be a multiple of 16");
+    if (sample_p) LANTERN_CHECK_ARG(token && V > 0, "accept_gather: sampling needs token and V");
+    if (B == 0) return LANTERN_OK;
+    hipLaunchKernelGGL(accept_gather_kernel, dim3(B), dim3(AG_THREADS), 0, (hipStream_t)stream, hidden, elem_bytes, G, N, H,
+                       retrieve, retrieve_per_seq, P, D, cand, best, accept_len, sample_p, V, u, out_hidden, accepted_tokens, token);
+    LANTERN_CHECK_LAUNCH("accept_gather");
+    return LANTERN_OK;
+}
+
+extern "C" int lantern_sample_static(const float *probs, const int64_t *idx, int R, int V, int k, float *out_prob, void *stream) {
+    LANTERN_CHECK_ARG(probs && idx && out_prob && R >= 0 && V > 0 && k > 0, "sample_static: bad arguments");
+    if (R == 0) return LANTERN_OK;
+    hipLaunchKernelGGL(sample_static_kernel, dim3((R + 63) / 64), dim3(64), 0, (hipStream_t)stream, probs, idx, R, V, k, out_prob);
+    LANTERN_CHECK_LAUNCH("sample_static");
+    return LANTERN_OK;
+}

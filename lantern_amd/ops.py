@@ -1,0 +1,382 @@
+"""Thin torch-tensor wrappers over the C-ABI of liblantern_hip.so.
+
+PyTorch is plumbing here: device memory, streams.  Every function launches HIP kernels on
+torch's current stream and returns device tensors; nothing synchronises, nothing falls
+back to torch ops for the computation itself.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import EpBuffers, EpParams, check
+
+MODE_DYNAMIC, MODE_STATIC_LUMINA, MODE_STATIC_LG = 0, 1, 2
+MODEL_PLAIN, MODEL_LUMINA, MODEL_ANOLE = 0, 1, 2
+
+
+def _stream() -> C.c_void_p:
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def _dev(t: torch.Tensor, dtype: torch.dtype, name: str) -> torch.Tensor:
+    if not t.is_cuda:
+        raise _lib.LanternError(f"{name}: expected a device tensor (the HIP path has no CPU fallback)")
+    if t.dtype != dtype:
+        t = t.to(dtype)
+    return t.contiguous()
+
+
+# ------------------------------------------------------------------------ static trees (host)
+
+def _flatten_choices(tree_choices):
+    flat, off = [], [0]
+    for c in tree_choices:
+        flat.extend(int(x) for x in c)
+        off.append(len(flat))
+    return np.asarray(flat, np.int32), np.asarray(off, np.int32)
+
+
+def _np_ptr(a: np.ndarray):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def tree_static_build(tree_choices, top_k: int = 10) -> dict:
+    """O1 (host): numpy buffers of generate_tree_buffers (ea_model_lumina_mgpt.py:140-277)."""
+    L = _lib.lib()
+    flat, off = _flatten_choices(tree_choices)
+    n = len(tree_choices)
+    N, P, D, bt = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+    check(L.lantern_tree_static_sizes(_np_ptr(flat), _np_ptr(off), n, C.byref(N), C.byref(P), C.byref(D), C.byref(bt)),
+          "tree_static_sizes")
+    N, P, D, bt = N.value, P.value, D.value, bt.value
+    mask = np.empty((N, N), np.float32)
+    ti = np.empty(N, np.int64)
+    pos = np.empty(N, np.int64)
+    ret = np.empty((P, D), np.int64)
+    pidx = np.empty((P, D), np.int32)
+    boff = np.empty(P * D + 1, np.int32)
+    bidx = np.empty(max(bt, 1), np.int32)
+    check(L.lantern_tree_static_build(_np_ptr(flat), _np_ptr(off), n, top_k, _np_ptr(mask), _np_ptr(ti), _np_ptr(pos),
+                                      _np_ptr(ret), _np_ptr(pidx), _np_ptr(boff), _np_ptr(bidx)), "tree_static_build")
+    return dict(tree_attn_mask=mask, tree_indices=ti, tree_position_ids=pos, retrieve_indices=ret, p_indices=pidx,
+                b_off=boff, b_idx=bidx[:bt])
+
+
+def tree_drafter_build(tree_choices, top_k: int = 10) -> dict:
+    """O2 (host): drafter-side buffers (drafters/utils_c.py:100-179)."""
+    L = _lib.lib()
+    flat, off = _flatten_choices(tree_choices)
+    n = len(tree_choices)
+    nl = C.c_int()
+    counts = np.zeros(64, np.int32)
+    check(L.lantern_tree_drafter_sizes(_np_ptr(flat), _np_ptr(off), n, C.byref(nl), _np_ptr(counts)), "tree_drafter_sizes")
+    Lv = nl.value
+    counts = counts[:Lv]
+    cum = np.cumsum(counts)
+    masks = np.empty(max(int((counts * cum).sum()), 1), np.float32)
+    ti = np.empty(max(int(counts.sum()), 1), np.int64)
+    rep = np.empty(int(counts.sum()) + Lv + 1, np.int32)
+    roff = np.empty(Lv + 1, np.int32)
+    check(L.lantern_tree_drafter_build(_np_ptr(flat), _np_ptr(off), n, top_k, _np_ptr(masks), _np_ptr(ti), _np_ptr(rep),
+                                       _np_ptr(roff)), "tree_drafter_build")
+    out_m, out_t, out_r = [], [], []
+    mo = to = 0
+    for l in range(Lv):
+        out_m.append(masks[mo:mo + counts[l] * cum[l]].reshape(counts[l], cum[l]).copy())
+        mo += counts[l] * cum[l]
+        out_t.append(ti[to:to + counts[l]].copy())
+        to += counts[l]
+        out_r.append(rep[roff[l]:roff[l + 1]].tolist())
+    return dict(attn_mask=out_m, tree_indices=out_t, repeat_nums=out_r, position_ids=[np.zeros(c, np.int64) for c in counts])
+
+
+# ----------------------------------------------------------------------------- device ops
+
+def tree_dynamic_finalize(scores, tokens, parents, sample_token, top_k: int, total_tokens: int, sort_rows: bool = True):
+    """O4.  scores [B,n] f32, tokens [B,n] i64, parents [B,m] i64, sample_token [B] i64 ->
+    (draft_tokens [B,N], mask [B,N,N], pos_ids [B,N], retrieve [B,N,N], n_leaf [B], max_depth [B])."""
+    scores = _dev(scores, torch.float32, "scores")
+    tokens = _dev(tokens, torch.int64, "tokens")
+    parents = _dev(parents, torch.int64, "parents")
+    sample_token = _dev(sample_token, torch.int64, "sample_token").reshape(-1)
+    B, n = scores.shape
+    N = total_tokens + 1
+    dev = scores.device
+    draft = torch.empty((B, N), dtype=torch.int64, device=dev)
+    mask = torch.empty((B, N, N), dtype=torch.float32, device=dev)
+    pos = torch.empty((B, N), dtype=torch.int64, device=dev)
+    ret = torch.empty((B, N, N), dtype=torch.int64, device=dev)
+    nl = torch.empty(B, dtype=torch.int32, device=dev)
+    md = torch.empty(B, dtype=torch.int32, device=dev)
+    check(_lib.lib().lantern_tree_dynamic_finalize(
+        C.c_void_p(scores.data_ptr()), C.c_void_p(tokens.data_ptr()), C.c_void_p(parents.data_ptr()),
+        C.c_void_p(sample_token.data_ptr()), B, n, parents.shape[1], top_k, total_tokens, int(sort_rows),
+        C.c_void_p(draft.data_ptr()), C.c_void_p(mask.data_ptr()), C.c_void_p(pos.data_ptr()), C.c_void_p(ret.data_ptr()),
+        C.c_void_p(nl.data_ptr()), C.c_void_p(md.data_ptr()), _stream()), "tree_dynamic_finalize")
+    return draft, mask, pos, ret, nl, md
+
+
+def expand_dynamic(logits, scores_in, top_k: int = 10):
+    """O3.  logits [B,R,V] f32, scores_in [B,R] or None -> (topk_index [B,R,k], cu_scores [B,R,k],
+    topk_cs_index [B,k], scores_out [B,k])."""
+    logits = _dev(logits, torch.float32, "logits")
+    B, R, V = logits.shape
+    dev = logits.device
+    si = None if scores_in is None else _dev(scores_in, torch.float32, "scores_in")
+    ti = torch.empty((B, R, top_k), dtype=torch.int64, device=dev)
+    cu = torch.empty((B, R, top_k), dtype=torch.float32, device=dev)
+    ci = torch.empty((B, top_k), dtype=torch.int64, device=dev)
+    so = torch.empty((B, top_k), dtype=torch.float32, device=dev)
+    check(_lib.lib().lantern_expand_dynamic(C.c_void_p(logits.data_ptr()), C.c_void_p(_ptr(si)), B, R, V, top_k,
+                                            C.c_void_p(ti.data_ptr()), C.c_void_p(cu.data_ptr()), C.c_void_p(ci.data_ptr()),
+                                            C.c_void_p(so.data_ptr()), _stream()), "expand_dynamic")
+    return ti, cu, ci, so
+
+
+def gather_candidates(ss_token, ss_prob, sample_token, tree_indices, retrieve):
+    """O6.  ss_token [B,R,10] i64, ss_prob [B,R,10] f32|None, sample_token [B] i64, tree_indices [N],
+    retrieve [P,D] -> (cand [B,P,D] i64, cart_prob [B,P,D] f32|None, tree_cand [B,N] i64)."""
+    ss_token = _dev(ss_token, torch.int64, "ss_token")
+    B = ss_token.shape[0]
+    n_flat = ss_token[0].numel()
+    prob = None if ss_prob is None else _dev(ss_prob, torch.float32, "ss_prob")
+    sample_token = _dev(sample_token, torch.int64, "sample_token").reshape(-1)
+    tree_indices = _dev(tree_indices, torch.int64, "tree_indices")
+    retrieve = _dev(retrieve, torch.int64, "retrieve")
+    N = tree_indices.numel()
+    P, D = retrieve.shape
+    dev = ss_token.device
+    tc = torch.empty((B, N), dtype=torch.int64, device=dev)
+    cand = torch.empty((B, P, D), dtype=torch.int64, device=dev)
+    cp = torch.empty((B, P, D), dtype=torch.float32, device=dev) if prob is not None else None
+    check(_lib.lib().lantern_gather_candidates(
+        C.c_void_p(ss_token.data_ptr()), C.c_void_p(_ptr(prob)), C.c_void_p(sample_token.data_ptr()),
+        C.c_void_p(tree_indices.data_ptr()), C.c_void_p(retrieve.data_ptr()), B, n_flat, N, P, D,
+        C.c_void_p(tc.data_ptr()), C.c_void_p(cand.data_ptr()), C.c_void_p(_ptr(cp)), _stream()), "gather_candidates")
+    return cand, cp, tc
+
+
+def cfg_mask_topk(cond, uncond, cfg: float, model: int = MODEL_PLAIN, pos_ids=None, pos_base: int = 0, w: int = 48,
+                  h: int = 48, img_lo: int = 4, img_hi: int = 8196, newline_id: int = 8803, eos_id: int = 8196,
+                  top_k: int = 0, out: Optional[torch.Tensor] = None):
+    """O7.  cond/uncond [rows,V] bf16 or f32 -> processed f32 [rows,V]."""
+    if not cond.is_cuda:
+        raise _lib.LanternError("cfg_mask_topk: expected device tensors")
+    assert cond.dtype == uncond.dtype and cond.dtype in (torch.float32, torch.bfloat16)
+    cond, uncond = cond.contiguous(), uncond.contiguous()
+    V = cond.shape[-1]
+    rows = cond.numel() // V
+    if out is None:
+        out = torch.empty(cond.shape, dtype=torch.float32, device=cond.device)
+    pos = None if pos_ids is None else _dev(pos_ids, torch.int64, "pos_ids").reshape(-1)
+    check(_lib.lib().lantern_cfg_mask_topk(
+        C.c_void_p(cond.data_ptr()), C.c_void_p(uncond.data_ptr()), 1 if cond.dtype == torch.bfloat16 else 0, rows, V,
+        C.c_float(cfg), model, C.c_void_p(_ptr(pos)), C.c_int64(pos_base), w, h, img_lo, img_hi, newline_id, eos_id, top_k,
+        C.c_void_p(out.data_ptr()), _stream()), "cfg_mask_topk")
+    return out
+
+
+@dataclass
+class EpConfig:
+    """Per-model switches of evaluate_posterior."""
+    mode: int = MODE_DYNAMIC
+    syntax_shortcut: bool = False
+    tok_offset: int = 0
+    img_lo: int = 0
+    img_hi: int = 2 ** 31 - 1
+    syntax: Sequence[int] = ()
+    lantern: bool = False
+    k: int = 1000
+    delta: float = 0.1
+    temperature: float = 1.0
+    top_p: float = 1.0
+    top_k: int = 0
+
+    @staticmethod
+    def lumina(static: bool, **kw) -> "EpConfig":
+        # ea_model_lumina_mgpt.py:322-324
+        return EpConfig(mode=MODE_STATIC_LUMINA if static else MODE_DYNAMIC, syntax_shortcut=True, tok_offset=4,
+                        img_lo=4, img_hi=8196, syntax=(8196, 8197, 8803, 8828), **kw)
+
+    @staticmethod
+    def llamagen(static: bool, **kw) -> "EpConfig":
+        return EpConfig(mode=MODE_STATIC_LG if static else MODE_DYNAMIC, **kw)
+
+    @staticmethod
+    def anole(static: bool, **kw) -> "EpConfig":
+        # ea_model_anole.py:142-146
+        return EpConfig(mode=MODE_STATIC_LG if static else MODE_DYNAMIC, tok_offset=4, img_lo=4, img_hi=8196, **kw)
+
+
+@dataclass
+class StaticAux:
+    cart_prob: torch.Tensor   # [B,P,D] f32
+    orig_prob: torch.Tensor   # [B,R,V] f32
+    op_off: torch.Tensor      # [D-1] i32
+    p_idx: torch.Tensor       # [P,D] i32
+    b_off: torch.Tensor       # [P*D+1] i32
+    b_idx: torch.Tensor       # [nb] i32
+    tree_cand: torch.Tensor   # [B,N] i64
+
+
+def evaluate_posterior(cfg: EpConfig, logits, row_index, cand, uniforms, table=None, aux: Optional[StaticAux] = None,
+                       n_paths=None, n_depth=None, cursor=None, out=None):
+    """O8.  logits [B,rows,V] f32; row_index [P,D] or [B,P,D] i32; cand [B,P,D] i64; uniforms [B,n] f64;
+    table [K,K-1] u16 (torch.uint16 or int16 view).  Returns (best [B] i32, accept_len [B] i32,
+    sample_p [B,V] f32, counters [B,6] i32) -- all device tensors, no sync."""
+    logits = _dev(logits, torch.float32, "logits")
+    cand = _dev(cand, torch.int64, "cand")
+    uniforms = _dev(uniforms, torch.float64, "uniforms")
+    row_index = _dev(row_index, torch.int32, "row_index")
+    B, P, D = cand.shape
+    V = logits.shape[-1]
+    rows = logits.shape[-2]
+    assert logits.shape[0] == B
+    dev = logits.device
+    prm = EpParams()
+    prm.B, prm.P, prm.D, prm.V, prm.rows_per_seq = B, P, D, V, rows
+    prm.mode, prm.syntax_shortcut, prm.tok_offset = cfg.mode, int(cfg.syntax_shortcut), cfg.tok_offset
+    prm.img_lo, prm.img_hi = cfg.img_lo, min(cfg.img_hi, 2 ** 31 - 1)
+    prm.n_syntax = len(cfg.syntax)
+    for i, s in enumerate(cfg.syntax):
+        prm.syntax[i] = int(s)
+    prm.lantern, prm.k, prm.delta = int(cfg.lantern), int(cfg.k), float(cfg.delta)
+    prm.top_k, prm.temperature, prm.top_p = int(cfg.top_k), float(cfg.temperature), float(cfg.top_p)
+    prm.n_uniforms = uniforms.shape[1]
+    prm.row_index_per_seq = int(row_index.dim() == 3)
+    buf = EpBuffers()
+    if table is not None:
+        if not table.is_cuda:
+            raise _lib.LanternError("evaluate_posterior: table must be a device tensor")
+        assert table.element_size() == 2
+        table = table.contiguous()
+        prm.table_rows, prm.table_cols = table.shape
+        buf.nn_table = table.data_ptr()
+    keep = []
+    if aux is not None:
+        a = [_dev(aux.cart_prob, torch.float32, "cart_prob"), _dev(aux.orig_prob, torch.float32, "orig_prob"),
+             _dev(aux.op_off, torch.int32, "op_off"), _dev(aux.p_idx, torch.int32, "p_idx"),
+             _dev(aux.b_off, torch.int32, "b_off"), _dev(aux.b_idx, torch.int32, "b_idx"),
+             _dev(aux.tree_cand, torch.int64, "tree_cand")]
+        keep.extend(a)
+        buf.cart_prob, buf.orig_prob, buf.op_off, buf.p_idx, buf.b_off, buf.b_idx, buf.tree_cand = [x.data_ptr() for x in a]
+        prm.R = a[1].shape[1]
+        prm.N = a[6].shape[1]
+        ws = torch.empty((B, V), dtype=torch.float32, device=dev)
+        keep.append(ws)
+        buf.workspace = ws.data_ptr()
+    if out is None:
+        best = torch.empty(B, dtype=torch.int32, device=dev)
+        alen = torch.empty(B, dtype=torch.int32, device=dev)
+        sample_p = torch.empty((B, V), dtype=torch.float32, device=dev)
+        counters = torch.empty((B, 6), dtype=torch.int32, device=dev)
+    else:
+        best, alen, sample_p, counters = out
+    buf.logits, buf.row_index, buf.cand, buf.uniforms = logits.data_ptr(), row_index.data_ptr(), cand.data_ptr(), uniforms.data_ptr()
+    if n_paths is not None:
+        n_paths = _dev(n_paths, torch.int32, "n_paths")
+        buf.n_paths = n_paths.data_ptr()
+    if n_depth is not None:
+        n_depth = _dev(n_depth, torch.int32, "n_depth")
+        buf.n_depth = n_depth.data_ptr()
+    if cursor is not None:
+        assert cursor.dtype == torch.int32 and cursor.is_cuda
+        buf.cursor = cursor.data_ptr()
+    buf.best, buf.accept_len, buf.sample_p, buf.counters = best.data_ptr(), alen.data_ptr(), sample_p.data_ptr(), counters.data_ptr()
+    check(_lib.lib().lantern_evaluate_posterior(C.byref(prm), C.byref(buf), _stream()), "evaluate_posterior")
+    return best, alen, sample_p, counters
+
+
+_STATUS = {1: "candidate token outside [0,V)", 2: "uniform stream exhausted", 3: "token outside the neighbour table",
+           4: "image syntax token rejected (reference assert, ea_model_lumina_mgpt.py:694)", 5: "no path matches the accepted prefix"}
+
+
+def raise_on_status(counters: torch.Tensor):
+    """Host-side check of the per-sequence status word (synchronises)."""
+    st = counters[:, 5].cpu()
+    bad = torch.nonzero(st).reshape(-1)
+    if len(bad):
+        i = int(bad[0])
+        raise _lib.LanternError(f"evaluate_posterior: sequence {i}: {_STATUS.get(int(st[i]), st[i])}")
+
+
+def kv_gather(slabs: Sequence[torch.Tensor], slab_seq, slab_prev, retrieve, best, accept_len, slab_ptrs=None):
+    """O9.  slabs: tensors [..., S_max, d] of identical shape/dtype; slab_seq [n] i32 (sequence of each slab),
+    slab_prev [n] i64 device.  retrieve [P,D] or [B,P,D] i64; best/accept_len [B] i32 device.
+    Returns new_len [n] i64 device.  In place."""
+    s0 = slabs[0]
+    S, d = s0.shape[-2], s0.shape[-1]
+    outer = s0.numel() // (S * d)
+    dev = s0.device
+    for s in slabs:
+        assert s.is_cuda and s.is_contiguous() and s.shape == s0.shape and s.dtype == s0.dtype
+    if slab_ptrs is None:
+        slab_ptrs = torch.tensor([s.data_ptr() for s in slabs], dtype=torch.int64, device=dev)
+    slab_seq = _dev(slab_seq, torch.int32, "slab_seq")
+    slab_prev = _dev(slab_prev, torch.int64, "slab_prev")
+    retrieve = _dev(retrieve, torch.int64, "retrieve")
+    P, D = retrieve.shape[-2:]
+    new_len = torch.empty(len(slabs), dtype=torch.int64, device=dev)
+    check(_lib.lib().lantern_kv_gather(
+        C.c_void_p(slab_ptrs.data_ptr()), C.c_void_p(slab_seq.data_ptr()), C.c_void_p(slab_prev.data_ptr()), len(slabs),
+        s0.element_size(), C.c_int64(outer), C.c_int64(S), C.c_int64(d), C.c_void_p(retrieve.data_ptr()),
+        int(retrieve.dim() == 3), P, D, C.c_void_p(best.data_ptr()), C.c_void_p(accept_len.data_ptr()),
+        C.c_void_p(new_len.data_ptr()), _stream()), "kv_gather")
+    return new_len
+
+
+def accept_gather(hidden, retrieve, cand, best, accept_len, sample_p=None, u=None):
+    """O10.  hidden [B,G,N,H]; retrieve [P,D]|[B,P,D]; cand [B,P,D]; sample_p [B,V]; u [B] f64 or None (greedy).
+    Returns (out_hidden [B,G,D,H], accepted_tokens [B,D], token [B])."""
+    retrieve = _dev(retrieve, torch.int64, "retrieve")
+    P, D = retrieve.shape[-2:]
+    B = best.shape[0]
+    dev = best.device
+    out_h = None
+    G = N = H = 0
+    eb = 0
+    if hidden is not None:
+        hidden = hidden.contiguous()
+        _, G, N, H = hidden.shape
+        eb = hidden.element_size()
+        out_h = torch.empty((B, G, D, H), dtype=hidden.dtype, device=dev)
+    acc = None
+    if cand is not None:
+        cand = _dev(cand, torch.int64, "cand")
+        acc = torch.empty((B, D), dtype=torch.int64, device=dev)
+    token = None
+    V = 0
+    if sample_p is not None:
+        sample_p = _dev(sample_p, torch.float32, "sample_p")
+        V = sample_p.shape[-1]
+        token = torch.empty(B, dtype=torch.int64, device=dev)
+        if u is not None:
+            u = _dev(u, torch.float64, "u")
+    check(_lib.lib().lantern_accept_gather(
+        C.c_void_p(_ptr(hidden)), eb, B, G, N, H, C.c_void_p(retrieve.data_ptr()), int(retrieve.dim() == 3), P, D,
+        C.c_void_p(_ptr(cand)), C.c_void_p(best.data_ptr()), C.c_void_p(accept_len.data_ptr()), C.c_void_p(_ptr(sample_p)), V,
+        C.c_void_p(_ptr(u)), C.c_void_p(_ptr(out_h)), C.c_void_p(_ptr(acc)), C.c_void_p(_ptr(token)), _stream()),
+        "accept_gather")
+    return out_h, acc, token
+
+
+def sample_static(probs, idx):
+    """O5.  probs [R,V] f32, idx [R,k] i64 -> conditional probabilities [R,k]."""
+    probs = _dev(probs, torch.float32, "probs")
+    idx = _dev(idx, torch.int64, "idx")
+    R, V = probs.shape
+    k = idx.shape[1]
+    out = torch.empty((R, k), dtype=torch.float32, device=probs.device)
+    check(_lib.lib().lantern_sample_static(C.c_void_p(probs.data_ptr()), C.c_void_p(idx.data_ptr()), R, V, k,
+                                           C.c_void_p(out.data_ptr()), _stream()), "sample_static")
+    return out

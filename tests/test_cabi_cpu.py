@@ -1,0 +1,79 @@
+"""CPU: the C-ABI library loads, exports every symbol include/lantern_hip.h declares, validates
+arguments, and its HOST entry points (static tree builders) match the golden vectors.
+No device compute is issued here."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import helpers as H
+from lantern_amd import _lib, ops
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+TREES = [str(x) for x in H.load("trees.npz")["names"]]
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "lantern_hip.h")).read()
+    declared = sorted(set(re.findall(r"\b(lantern_[a-z_0-9]+)\s*\(", hdr)))
+    assert declared, "no prototypes found"
+    L = _lib.lib()
+    for name in declared:
+        assert hasattr(L, name), f"{name} declared in lantern_hip.h but not exported"
+    assert sorted(_lib.EXPORTS) == declared
+    assert L.lantern_version() == 100
+
+
+def test_param_struct_layout_matches_header():
+    # ctypes mirror vs the C struct: field order/size (a drift here corrupts every launch)
+    assert C.sizeof(_lib.EpParams) == 4 * 11 + 32 + 4 * 5 + 4 + 4 + 8 + 4 * 4
+    assert C.sizeof(_lib.EpBuffers) == 20 * 8
+
+
+def test_argument_validation_without_gpu():
+    L = _lib.lib()
+    prm = _lib.EpParams()
+    buf = _lib.EpBuffers()
+    prm.B, prm.P, prm.D, prm.V = 1, 4, 3, 1022  # V not a multiple of 4
+    rc = L.lantern_evaluate_posterior(C.byref(prm), C.byref(buf), None)
+    assert rc == -1 and b"multiple of 4" in L.lantern_last_error()
+    rc = L.lantern_cfg_mask_topk(None, None, 0, 1, 16, C.c_float(1.0), 0, None, C.c_int64(0), 1, 1, 0, 1, 0, 0, 0, None, None)
+    assert rc == -1
+
+
+@pytest.mark.parametrize("name", TREES)
+def test_static_tree_host_builder(name):
+    g = H.tree_buffers(name)
+    o = ops.tree_static_build(H.tree_choices(name))
+    assert np.array_equal(o["tree_attn_mask"], g["mask"])
+    assert np.array_equal(o["tree_indices"], g["tree_indices"])
+    assert np.array_equal(o["tree_position_ids"], g["pos"])
+    assert np.array_equal(o["retrieve_indices"], g["retrieve"])
+    assert np.array_equal(o["p_indices"], g["p_indices"])
+    assert np.array_equal(o["b_off"], g["b_off"])
+    assert np.array_equal(o["b_idx"], g["b_idx"])
+
+
+@pytest.mark.parametrize("name", TREES)
+def test_drafter_tree_host_builder(name):
+    g = H.tree_buffers(name)
+    o = ops.tree_drafter_build(H.tree_choices(name))
+    L = int(g["d_levels"][0])
+    assert len(o["tree_indices"]) == L
+    for l in range(L):
+        assert np.array_equal(o["attn_mask"][l], g[f"d_mask{l}"])
+        assert np.array_equal(o["tree_indices"][l], g[f"d_ti{l}"])
+        assert o["repeat_nums"][l] == g[f"d_rep{l}"].tolist()
+
+
+def test_malformed_tree_is_rejected():
+    with pytest.raises(_lib.LanternError):
+        ops.tree_static_build([[0], [1, 0, 0]])  # [1,0] missing
+
+
+def test_device_ops_refuse_cpu_tensors():
+    import torch
+    with pytest.raises(_lib.LanternError):
+        ops.cfg_mask_topk(torch.zeros(1, 16), torch.zeros(1, 16), 1.0)

@@ -1,0 +1,244 @@
+#!/usr/bin/env python3
+"""bench.py -- accepted image-tokens/s of the LANTERN verify/accept hot path on MI355X.
+
+Contract (driver):  python bench.py --gpus N --steps K --warmup W
+  N>1 is launched by torch.distributed.run, one rank per GPU; ranks verify DISJOINT sequences with
+  no collective on the accept path (the only torch.distributed calls are the timing barrier and the
+  max/sum of the per-rank timing scalars the contract asks for).  Weak scaling: per-GPU work fixed.
+
+Workload = BASELINE.json config C3 (Lumina-mGPT-7B-768 + LANTERN relaxed accept, k=1000,
+delta=0.1, static tree mc_sim_7b_63) on synthetic 768x768 image-token sequences: a "step" is one
+verify step (O6 -> O7 -> O8 -> O9 -> O10) over the --seqs-per-gpu sequences resident on the GPU;
+inputs are HBM-resident before the timed region.  `value` = accepted tokens of all ranks / max-over-
+ranks wall time.
+
+Extra objects on the JSON line:
+  roofline      evaluate_posterior: algorithmic bytes (SURVEY 8d contract formula, from the kernel's
+                own counters) / its mean launch duration measured with HIP events on the launch stream
+                inside the timed region; peak 8000 GB/s.
+  kernels       the same for cfg_mask_topk and kv_gather.
+  cpu_baseline  the oracle (C port of the reference path) timed on this host's cores over a bounded
+                sample of the same pools/uniforms; it must reproduce the GPU's accepted-token stream.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--seqs-per-gpu", type=int, default=32)
+    ap.add_argument("--pool-steps", type=int, default=16)
+    ap.add_argument("--lantern-k", type=int, default=1000)
+    ap.add_argument("--lantern-delta", type=float, default=0.1)
+    ap.add_argument("--sigma", type=float, default=1.0)
+    ap.add_argument("--no-kv", action="store_true", help="skip the KV slabs (debug only; invalid as a headline)")
+    ap.add_argument("--kv-smax", type=int, default=4096)
+    ap.add_argument("--no-events", action="store_true", help="do not time individual kernels")
+    ap.add_argument("--cpu-seconds", type=float, default=20.0, help="CPU-baseline budget; 0 disables")
+    ap.add_argument("--cpu-seqs", type=int, default=0, help="sequences in the CPU sample (0 = host cores)")
+    return ap.parse_args()
+
+
+# ----------------------------------------------------------------------------- CPU baseline
+
+def cpu_baseline(wl, steps_budget_s: float, n_seq: int, gpu_tokens_by_seq):
+    """The oracle (C restatement of the reference's Python path) over the first n_seq sequences and as
+    many steps as fit the budget, one host thread per sequence.  Checker AND timed baseline: the
+    accepted-token stream must equal the GPU's for the same steps."""
+    import ctypes
+    from concurrent.futures import ThreadPoolExecutor
+    import oracle
+    from lantern_amd import harness as HN
+
+    c = wl.cfg
+    S = c.pool_steps
+    N, P, D, R = wl.N, wl.P, wl.D, wl.R
+    tb = wl.tb
+    ri = tb["retrieve_indices"].copy()
+    ri[ri < 0] += N
+    ri = ri.astype(np.int32)
+    table = wl.table.cpu().numpy().view(np.uint16)
+    cond = wl.cond[:, :n_seq].cpu().view(torch.int16).numpy().view(np.uint16)
+    uncond = wl.uncond[:, :n_seq].cpu().view(torch.int16).numpy().view(np.uint16)
+    orig = wl.orig_prob[:, :n_seq].cpu().numpy()
+    sst = wl.ss_token[:, :n_seq].cpu().numpy()
+    ssp = wl.ss_prob[:, :n_seq].cpu().numpy()
+    hid = wl.hidden[:, :n_seq].cpu().view(torch.int16).numpy()
+    u_bonus = wl.u_bonus[:, :n_seq].cpu().numpy()
+    first = wl.first_token[:n_seq].cpu().numpy()
+    op_off = wl.d_op_off.cpu().numpy()
+    cfg = oracle.EpConfig.lumina(True, lantern=True, k=c.lantern_k, delta=c.lantern_delta)
+    pos1 = tb["tree_position_ids"] + 1
+    kv_shape = (2 * c.kv_layers, 1, c.kv_heads, c.kv_smax, c.kv_dim)
+
+    def run_seq(b, n_steps, out):
+        slabs = [np.zeros(kv_shape, np.uint16), np.zeros(kv_shape, np.uint16)] if c.with_kv else None
+        lens = [c.prompt_len + 3, 3]
+        cursor, tok, toks = 0, int(first[b]), []
+        for i in range(n_steps):
+            s = i % S
+            cand, cp, tc = oracle.gather_candidates(sst[s, b], ssp[s, b], tok, tb["tree_indices"], tb["retrieve_indices"])
+            proc = oracle.cfg_mask_topk(cond[s, b], uncond[s, b], c.cfg_scale, model=oracle.MODEL_LUMINA, pos_ids=pos1 + lens[0],
+                                        pos_base=c.prompt_len + 3, w=HN.W_LATENT, h=HN.H_LATENT, img_lo=HN.IMG_LO, img_hi=HN.IMG_HI,
+                                        newline_id=HN.NEWLINE, eos_id=HN.EOS, top_k=c.top_k, bf16=True)
+            aux = oracle.StaticAux(cart_prob=cp, orig_prob=orig[s, b], op_off=op_off, p_idx=tb["p_indices"], b_off=tb["b_off"],
+                                   b_idx=tb["b_idx"], tree_cand=tc)
+            best, alen, sp, cnt = oracle.evaluate_posterior(cfg, proc, ri, cand, wl.uniforms_host[b, cursor:cursor + 64],
+                                                            table=table, aux=aux)
+            cursor += int(cnt[3])
+            row = tb["retrieve_indices"][best]
+            if slabs is not None:
+                for j in range(2):
+                    oracle.kv_gather(slabs[j], row, alen + 1, lens[j])
+            oracle.hidden_gather(hid[s, b], row, alen + 1)
+            tok = oracle.sample_inverse_cdf(sp, float(u_bonus[i, b]))
+            lens = [l + alen + 1 for l in lens]
+            if lens[1] - 3 >= HN.TOKENS_PER_IMAGE:
+                lens = [c.prompt_len + 3, 3]
+            toks.append((best, alen, tok))
+        out[b] = toks
+
+    cores = os.cpu_count() or 1
+    threads = min(cores, n_seq)
+    # calibrate on one step of one sequence, then size the sample to the budget
+    t0 = time.perf_counter()
+    tmp = {}
+    run_seq(0, 1, tmp)
+    t_step = time.perf_counter() - t0
+    n_steps = int(max(2, min(len(gpu_tokens_by_seq), steps_budget_s / max(t_step, 1e-4) * threads / n_seq)))
+    out = {}
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(max_workers=threads) as ex:
+        list(ex.map(lambda b: run_seq(b, n_steps, out), range(n_seq)))
+    dt = time.perf_counter() - t0
+    accepted, mismatches = 0, 0
+    for b in range(n_seq):
+        for i, (best, alen, tok) in enumerate(out[b]):
+            accepted += alen + 1
+            gb, ga, gt = gpu_tokens_by_seq[i][b]
+            mismatches += int((best, alen, tok) != (gb, ga, gt))
+    return dict(value=accepted / dt, unit="accepted_tokens/s", cores=threads, kind="port",
+                sample=f"{n_seq} sequences x {n_steps} verify steps of the same pools/uniforms (oracle/lantern_oracle.c, "
+                       f"{threads} host threads, one per sequence; host has {cores} cores)",
+                ms_per_seq_step=1e3 * dt * threads / (n_seq * n_steps),
+                matches_gpu_token_stream=(mismatches == 0), mismatches=mismatches)
+
+
+# ------------------------------------------------------------------------------------ main
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    assert world == max(1, args.gpus) or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+
+    from lantern_amd import harness as HN
+
+    cfg = HN.WorkloadConfig(n_seq=args.seqs_per_gpu, pool_steps=args.pool_steps, lantern_k=args.lantern_k,
+                            lantern_delta=args.lantern_delta, sigma=args.sigma, with_kv=not args.no_kv, kv_smax=args.kv_smax,
+                            max_steps=args.steps + args.warmup + 8)
+    wl = HN.LuminaVerifyWorkload(cfg, device, rank=rank)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize(device)
+
+    K, W = args.steps, args.warmup
+    for _ in range(W):
+        wl.step()
+    names = ("cfg_mask_topk", "evaluate_posterior", "kv_gather") if cfg.with_kv else ("cfg_mask_topk", "evaluate_posterior")
+    evs = None
+    if not args.no_events:
+        evs = [{n: (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for n in names} for _ in range(K)]
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(K):
+        wl.step(evs[i] if evs else None)
+    barrier()
+    dt = time.perf_counter() - t0
+
+    wl.check_status(0, W + K)
+    tokens = wl.accepted_tokens(W, W + K)
+    stats = torch.tensor([dt, float(tokens)], dtype=torch.float64, device=device)
+    if dist is not None:
+        tmax = stats[:1].clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        tsum = stats[1:].clone()
+        dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+        dt_all, tokens_all = float(tmax[0]), float(tsum[0])
+    else:
+        dt_all, tokens_all = dt, float(tokens)
+
+    if rank == 0:
+        alen = wl.log_alen[W:W + K].float() + 1
+        cnt = wl.log_cnt[W:W + K].float()
+        out = {
+            "metric": "accepted image-tokens/sec (Lumina-mGPT-7B 768x768 LANTERN verify/accept loop)",
+            "value": tokens_all / dt_all, "unit": "accepted_tokens/s", "n_gpus": world, "steps": K, "warmup": W,
+            "ms_per_step": 1e3 * dt_all / K, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "C3: Lumina-mGPT-7B-768 LANTERN relaxed accept, static tree mc_sim_7b_63 (N=26,P=15,D=6), "
+                                   "V=65536, K=8192, cfg=3.0, top_k=2000, sequential-CFG KV [64,1,32,%d,128] bf16 x2 per sequence"
+                                   % cfg.kv_smax,
+                       "lantern_k": cfg.lantern_k, "lantern_delta": cfg.lantern_delta, "seqs_per_gpu": cfg.n_seq,
+                       "total_sequences": cfg.n_seq * world, "pool_steps": cfg.pool_steps, "drafter_sigma": cfg.sigma,
+                       "kv_cache": cfg.with_kv, "parallelism": f"dp{world} (independent sequences, no collective)"},
+            "mean_accept_length": float(alen.mean()),
+            "per_step": {"levels": float(cnt[..., 0].mean()), "tried": float(cnt[..., 1].mean()), "rejected": float(cnt[..., 2].mean())},
+        }
+        if evs:
+            def mean_ms(n):
+                return float(np.mean([e[n][0].elapsed_time(e[n][1]) for e in evs]))
+            ep_ms = mean_ms("evaluate_posterior")
+            ep_bytes = wl.ep_algorithmic_bytes(W, W + K) / K
+            ach = ep_bytes / (ep_ms * 1e-3) / 1e9
+            out["roofline"] = {"kernel": "ep_kernel (evaluate_posterior)", "bound": "hbm", "achieved": ach, "peak": 8000.0,
+                               "unit": "GB/s", "frac": ach / 8000.0, "traffic": None, "algorithmic_bytes_per_launch": ep_bytes,
+                               "avg_launch_ms": ep_ms}
+            o7_ms = mean_ms("cfg_mask_topk")
+            o7_b = wl.o7_algorithmic_bytes(1)
+            ks = {"cfg_mask_topk": {"avg_launch_ms": o7_ms, "algorithmic_bytes_per_launch": o7_b,
+                                    "achieved": o7_b / (o7_ms * 1e-3) / 1e9, "frac": o7_b / (o7_ms * 1e-3) / 1e9 / 8000.0}}
+            if cfg.with_kv:
+                kv_ms = mean_ms("kv_gather")
+                kv_b = wl.kv_algorithmic_bytes(W, W + K) / K
+                ks["kv_gather"] = {"avg_launch_ms": kv_ms, "algorithmic_bytes_per_launch": kv_b,
+                                   "achieved": kv_b / (kv_ms * 1e-3) / 1e9, "frac": kv_b / (kv_ms * 1e-3) / 1e9 / 8000.0}
+            out["kernels"] = ks
+        if args.cpu_seconds > 0:
+            n_cpu = args.cpu_seqs or min(cfg.n_seq, os.cpu_count() or 1)
+            # the CPU leg replays the run from step 0 (warm-up included): compare against the whole log
+            gb = wl.log_best[:W + K].cpu().numpy()
+            ga = wl.log_alen[:W + K].cpu().numpy()
+            gt = wl.log_token[:W + K].cpu().numpy()
+            gpu_stream = [[(int(gb[i, b]), int(ga[i, b]), int(gt[i, b])) for b in range(cfg.n_seq)] for i in range(W + K)]
+            out["cpu_baseline"] = cpu_baseline(wl, args.cpu_seconds, n_cpu, gpu_stream)
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

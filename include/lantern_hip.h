@@ -124,14 +124,19 @@ int lantern_gather_candidates(const int64_t *ss_token, const float *ss_prob, con
  * MultiModalLogitsProcessor :45-86 and InterleavedTopKLogitsWarper :106-112),
  * models/ea_model_anole.py:930-931, models/ea_model_llamagen.py:930.
  * [dev] cond/uncond [rows,V] in `dtype`; bf16 input reproduces torch's per-op bf16
- * rounding of u + s*(c-u).  pos_ids [rows] i64 = the value the reference passes as
- * `position_ids=`; num_generated_image_tokens = pos_ids - pos_base (Lumina only).
- * Out [dev]: out [rows,V] f32.  V % 4 == 0.
+ * rounding of u + s*(c-u).  pos_ids i64 = the value the reference passes as
+ * `position_ids=` (tree_position_ids + len(input_ids) + 1);
+ * num_generated_image_tokens = pos - pos_base (Lumina only).  Two forms:
+ *   seq_len == NULL: pos_ids is [rows].
+ *   seq_len != NULL: batched sequences; pos_ids is [rows_per_seq] (shared tree position ids
+ *   + 1) and seq_len [rows / rows_per_seq] i64 holds each sequence's len(input_ids), read on
+ *   the device: pos = pos_ids[row % rows_per_seq] + seq_len[row / rows_per_seq].
+ * Out [dev]: out [rows,V] f32.  V % 4 == 0, V <= 65536.
  */
 int lantern_cfg_mask_topk(const void *cond, const void *uncond, int dtype, int rows, int V, float cfg,
                           int model, const int64_t *pos_ids, int64_t pos_base, int w_latent, int h_latent,
-                          int img_lo, int img_hi, int newline_id, int eos_id, int top_k, float *out,
-                          void *stream);
+                          int img_lo, int img_hi, int newline_id, int eos_id, int top_k,
+                          const int64_t *seq_len, int rows_per_seq, float *out, void *stream);
 
 /* ------------------------------------------------------------------------------------
  * O8  relaxed tree rejection sampling (the north-star kernel).

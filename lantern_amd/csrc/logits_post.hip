@@ -30,6 +30,7 @@ __global__ __launch_bounds__(LP_THREADS) void cfg_mask_topk_kernel(const void *_
                                                                   const int64_t *__restrict__ pos_ids, int64_t pos_base,
                                                                   int w_latent, int h_latent, int img_lo, int img_hi,
                                                                   int newline_id, int eos_id, int top_k,
+                                                                  const int64_t *__restrict__ seq_len, int rows_per_seq,
                                                                   float *__restrict__ out_) {
     __shared__ LpShared S;
     const int row = blockIdx.x, tid = threadIdx.x;
@@ -40,7 +41,8 @@ __global__ __launch_bounds__(LP_THREADS) void cfg_mask_topk_kernel(const void *_
     // row class (Lumina): 0 = grid position, 1 = newline, 2 = end of image
     int cls = 0;
     if (model == LANTERN_MODEL_LUMINA) {
-        const int64_t n1 = pos_ids[row] - pos_base + 1;
+        const int64_t pos = seq_len ? pos_ids[row % rows_per_seq] + seq_len[row / rows_per_seq] : pos_ids[row];
+        const int64_t n1 = pos - pos_base + 1;
         if (n1 == ((int64_t)w_latent + 1) * h_latent + 1)
             cls = 2;
         else if (py_mod(n1, (int64_t)w_latent + 1) == 0)
@@ -155,18 +157,19 @@ using namespace lantern;
 template <int VI>
 static void launch_lp(bool bf16, dim3 grid, hipStream_t st, const void *cond, const void *uncond, int V, float cfg, int model,
                       const int64_t *pos_ids, int64_t pos_base, int w, int h, int img_lo, int img_hi, int nl, int eos,
-                      int top_k, float *out) {
+                      int top_k, const int64_t *seq_len, int rows_per_seq, float *out) {
     if (bf16)
         hipLaunchKernelGGL((cfg_mask_topk_kernel<VI, true>), grid, dim3(LP_THREADS), 0, st, cond, uncond, V, cfg, model, pos_ids,
-                           pos_base, w, h, img_lo, img_hi, nl, eos, top_k, out);
+                           pos_base, w, h, img_lo, img_hi, nl, eos, top_k, seq_len, rows_per_seq, out);
     else
         hipLaunchKernelGGL((cfg_mask_topk_kernel<VI, false>), grid, dim3(LP_THREADS), 0, st, cond, uncond, V, cfg, model, pos_ids,
-                           pos_base, w, h, img_lo, img_hi, nl, eos, top_k, out);
+                           pos_base, w, h, img_lo, img_hi, nl, eos, top_k, seq_len, rows_per_seq, out);
 }
 
 extern "C" int lantern_cfg_mask_topk(const void *cond, const void *uncond, int dtype, int rows, int V, float cfg, int model,
                                      const int64_t *pos_ids, int64_t pos_base, int w_latent, int h_latent, int img_lo,
-                                     int img_hi, int newline_id, int eos_id, int top_k, float *out, void *stream) {
+                                     int img_hi, int newline_id, int eos_id, int top_k, const int64_t *seq_len,
+                                     int rows_per_seq, float *out, void *stream) {
     LANTERN_CHECK_ARG(cond && uncond && out, "cfg_mask_topk: null buffer");
     LANTERN_CHECK_ARG(rows >= 0 && V > 0 && V % 4 == 0 && V <= 4096 * 16, "cfg_mask_topk: bad rows=%d V=%d", rows, V);
     LANTERN_CHECK_ARG(dtype == LANTERN_F32 || dtype == LANTERN_BF16, "cfg_mask_topk: bad dtype %d", dtype);
@@ -174,13 +177,14 @@ extern "C" int lantern_cfg_mask_topk(const void *cond, const void *uncond, int d
     if (model == LANTERN_MODEL_LUMINA)
         LANTERN_CHECK_ARG(pos_ids && w_latent > 0 && h_latent > 0 && newline_id >= 0 && newline_id < V && eos_id >= 0 && eos_id < V,
                           "cfg_mask_topk: Lumina needs pos_ids, latent dims and syntax ids inside [0,V)");
+    if (seq_len) LANTERN_CHECK_ARG(rows_per_seq > 0 && rows % rows_per_seq == 0, "cfg_mask_topk: rows=%d not a multiple of rows_per_seq=%d", rows, rows_per_seq);
     if (model != LANTERN_MODEL_PLAIN)
         LANTERN_CHECK_ARG(img_lo >= 0 && img_lo < img_hi && img_hi <= V, "cfg_mask_topk: bad image range [%d,%d)", img_lo, img_hi);
     if (rows == 0) return LANTERN_OK;
     hipStream_t st = (hipStream_t)stream;
     dim3 grid(rows);
     const bool bf = dtype == LANTERN_BF16;
-#define LP_ARGS bf, grid, st, cond, uncond, V, cfg, model, pos_ids, pos_base, w_latent, h_latent, img_lo, img_hi, newline_id, eos_id, top_k, out
+#define LP_ARGS bf, grid, st, cond, uncond, V, cfg, model, pos_ids, pos_base, w_latent, h_latent, img_lo, img_hi, newline_id, eos_id, top_k, seq_len, rows_per_seq, out
     if (V <= 4096)
         launch_lp<1>(LP_ARGS);
     else if (V <= 4096 * 4)

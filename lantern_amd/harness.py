@@ -1,0 +1,294 @@
+"""Synthetic Lumina-mGPT-7B-768 verify/accept workload (BASELINE.json config C3/C5).
+
+No checkpoints exist on either machine, so the target-model and drafter forwards are replaced by
+pre-generated pools; everything between them -- the hot path -- runs for
+real, every step, on device-resident state with no host round trip:
+
+    O6 gather_candidates -> O7 cfg_mask_topk -> O8 evaluate_posterior -> O9 kv_gather -> O10 accept_gather
+
+Geometry follows the reference defaults (entrypoints/generate_images.py:47-60): V=65536, image ids
+4..8195, static tree mc_sim_7b_63 (eagle_version 1), cfg 3.0, top_k 2000, lantern_k 1000,
+cfg_mode "sequential" = two B=1 KV slabs per sequence [2L=64, 1, 32, S_max, 128] bf16 whose
+prev_len differ by the prompt length (models/ea_model_lumina_mgpt.py:753-767).
+
+This module is product-side host code: it never imports the oracle.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import random
+from dataclasses import dataclass, field
+from typing import List, Optional
+
+import numpy as np
+import torch
+
+from . import _lib, ops
+from ._lib import EpBuffers, EpParams, check
+
+MC_SIM_7B_63 = [[0], [1], [2], [3], [0, 0], [0, 1], [0, 2], [1, 0], [1, 1], [2, 0], [2, 1], [3, 0],
+                [0, 0, 0], [0, 0, 1], [0, 0, 2], [0, 1, 0], [0, 1, 1], [0, 2, 0], [0, 2, 1], [1, 0, 0],
+                [0, 0, 0, 0], [0, 0, 0, 1], [0, 0, 0, 2], [0, 0, 0, 0, 0], [0, 0, 0, 0, 1]]
+
+V = 65536
+K_CODES = 8192
+IMG_LO, IMG_HI = 4, 8196
+NEWLINE, EOS = 8803, 8196
+W_LATENT = H_LATENT = 48          # 768 / 16
+TOKENS_PER_IMAGE = (W_LATENT + 1) * H_LATENT + 3   # 2352 grid+newline tokens + 3 header tokens
+HIDDEN = 4096
+
+
+@dataclass
+class WorkloadConfig:
+    n_seq: int = 32
+    pool_steps: int = 16
+    lantern_k: int = 1000
+    lantern_delta: float = 0.1
+    cfg_scale: float = 3.0
+    top_k: int = 2000
+    sigma: float = 1.0              # drafter noise (harness knob)
+    logit_scale: float = 4.0
+    prompt_len: int = 64
+    kv_layers: int = 32
+    kv_heads: int = 32
+    kv_smax: int = 4096
+    kv_dim: int = 128
+    with_kv: bool = True
+    seed_base: int = 3000           # 1000 * config index (C3)
+    max_steps: int = 4096           # uniform stream sizing
+    table_seed: int = 0
+
+
+def build_neighbour_table(device, seed: int = 0) -> torch.Tensor:
+    """Setup only: table recipe of entrypoints/generate_codebook.py:53-65 on a N(0,1) [8192,256]
+    codebook, via torch on the device (the HIP builder is a 'next' row)."""
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    cb = torch.randn(K_CODES, 256, generator=g).to(device)
+    d = torch.cdist(cb, cb)
+    d.fill_diagonal_(float("inf"))
+    idx = torch.argsort(d, dim=-1, stable=True)[:, :K_CODES - 1]
+    return idx.to(torch.int16)      # uint16 bit patterns (values < 8192)
+
+
+class LuminaVerifyWorkload:
+    def __init__(self, cfg: WorkloadConfig, device: torch.device, rank: int = 0):
+        self.cfg, self.device, self.rank = cfg, device, rank
+        B, S = cfg.n_seq, cfg.pool_steps
+        tb = ops.tree_static_build(MC_SIM_7B_63)
+        self.tb = tb
+        self.N = N = len(tb["tree_indices"])
+        self.P, self.D = P, D = tb["retrieve_indices"].shape
+        ti, pos = tb["tree_indices"], tb["tree_position_ids"]
+        self.R = R = int(((ti[1:] - 1) // 10).max()) + 1
+        # parent node of every drafter row, level offsets of the drafter rows
+        mask = tb["tree_attn_mask"]
+        par = np.zeros(N, np.int64)
+        for n in range(1, N):
+            anc = [a for a in np.nonzero(mask[n] > 0)[0] if pos[a] == pos[n] - 1]
+            par[n] = anc[0]
+        par_row = np.zeros(R, np.int64)
+        for n in range(1, N):
+            par_row[(ti[n] - 1) // 10] = par[n]
+        depth_of_row = pos[par_row]
+        op_off = np.array([np.nonzero(depth_of_row == d)[0][0] for d in range(int(depth_of_row.max()) + 1)], np.int32)
+        t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)
+        self.d_tree_indices, self.d_retrieve = t(ti), t(tb["retrieve_indices"])
+        ri = tb["retrieve_indices"].copy()
+        ri[ri < 0] += N
+        self.d_row_index = t(ri.astype(np.int32))
+        self.d_p_idx, self.d_b_off = t(tb["p_indices"]), t(tb["b_off"])
+        self.d_b_idx = t(tb["b_idx"] if len(tb["b_idx"]) else np.zeros(1, np.int32))
+        self.d_op_off = t(op_off)
+        self.d_pos_ids = t(pos + 1)                 # tree_position_ids + 1 (ea_model_lumina_mgpt.py:559,601)
+        self.table = build_neighbour_table(device, cfg.table_seed)
+
+        # ---------------- pools (setup, untimed; torch is fine here)
+        self.cond = torch.empty((S, B, N, V), dtype=torch.bfloat16, device=device)
+        self.uncond = torch.empty((S, B, N, V), dtype=torch.bfloat16, device=device)
+        self.orig_prob = torch.empty((S, B, R, V), dtype=torch.float32, device=device)
+        self.ss_token = torch.empty((S, B, R, 10), dtype=torch.int64, device=device)
+        self.ss_prob = torch.empty((S, B, R, 10), dtype=torch.float32, device=device)
+        self.hidden = torch.empty((S, B, 2, N, HIDDEN), dtype=torch.bfloat16, device=device)
+        gen = torch.Generator(device=device)
+        d_par_row = t(par_row)
+        for s in range(S):
+            gen.manual_seed(cfg.seed_base + 7919 * s + 104729 * rank)
+            tgt = cfg.logit_scale * torch.randn((B, N, V), generator=gen, device=device)
+            unc = torch.randn((B, N, V), generator=gen, device=device)
+            cnd = unc + (tgt - unc) / cfg.cfg_scale
+            self.cond[s] = cnd.to(torch.bfloat16)
+            self.uncond[s] = unc.to(torch.bfloat16)
+            c32, u32 = self.cond[s].float(), self.uncond[s].float()
+            cfgd = u32 + cfg.cfg_scale * (c32 - u32)
+            dr = cfgd[:, d_par_row] + cfg.sigma * torch.randn((B, R, V), generator=gen, device=device)
+            dr[..., :IMG_LO] = float("-inf")
+            dr[..., IMG_HI:] = float("-inf")
+            kth = torch.topk(dr, cfg.top_k, dim=-1).values[..., -1:]
+            dr = dr.masked_fill(dr < kth, float("-inf"))
+            op = torch.softmax(dr, dim=-1)
+            self.orig_prob[s] = op
+            tok = torch.multinomial(op.view(-1, V), 10, replacement=False, generator=gen)
+            self.ss_token[s] = tok.view(B, R, 10)
+            self.ss_prob[s] = ops.sample_static(op.view(-1, V), tok).view(B, R, 10)
+            self.hidden[s] = torch.randn((B, 2, N, HIDDEN), generator=gen, device=device).to(torch.bfloat16)
+            del tgt, unc, cnd, c32, u32, cfgd, dr, op
+        torch.cuda.synchronize(device)
+
+        # ---------------- per-sequence state (device resident)
+        nu = cfg.max_steps * (N - 1) + 64
+        uni = np.empty((B, nu), np.float64)
+        for b in range(B):
+            r = random.Random(cfg.seed_base + 1000 * rank + b)      # MT19937, Python's random.random()
+            uni[b] = [r.random() for _ in range(nu)]
+        self.uniforms_host = uni
+        self.uniforms = t(uni)
+        self.n_uniforms = nu
+        gen.manual_seed(cfg.seed_base + 17 + rank)
+        self.u_bonus = torch.rand((cfg.max_steps, B), generator=gen, device=device, dtype=torch.float64)
+        self.first_token = torch.randint(IMG_LO, IMG_HI, (B,), generator=gen, device=device)
+        self.slabs: List[torch.Tensor] = []
+        if cfg.with_kv:
+            shape = (2 * cfg.kv_layers, 1, cfg.kv_heads, cfg.kv_smax, cfg.kv_dim)
+            for _ in range(2 * B):                 # [cond slabs of all sequences..., uncond slabs...]
+                self.slabs.append(torch.zeros(shape, dtype=torch.bfloat16, device=device))
+            self.slab_ptrs = torch.tensor([s.data_ptr() for s in self.slabs], dtype=torch.int64, device=device)
+            self.slab_seq = torch.arange(B, dtype=torch.int32, device=device).repeat(2)
+        self.reset_state()
+
+        # ---------------- work buffers
+        self.cand = torch.empty((B, P, D), dtype=torch.int64, device=device)
+        self.cart_prob = torch.empty((B, P, D), dtype=torch.float32, device=device)
+        self.tree_cand = torch.empty((B, N), dtype=torch.int64, device=device)
+        self.proc = torch.empty((B, N, V), dtype=torch.float32, device=device)
+        self.sample_p = torch.empty((B, V), dtype=torch.float32, device=device)
+        self.workspace = torch.empty((B, V), dtype=torch.float32, device=device)
+        self.out_hidden = torch.empty((B, 2, D, HIDDEN), dtype=torch.bfloat16, device=device)
+        self.acc_tokens = torch.empty((B, D), dtype=torch.int64, device=device)
+        self.log_best = torch.zeros((cfg.max_steps, B), dtype=torch.int32, device=device)
+        self.log_alen = torch.zeros((cfg.max_steps, B), dtype=torch.int32, device=device)
+        self.log_cnt = torch.zeros((cfg.max_steps, B, 6), dtype=torch.int32, device=device)
+        self.log_token = torch.zeros((cfg.max_steps, B), dtype=torch.int64, device=device)
+        self._L = _lib.lib()
+        self._ep_prm = self._make_ep_params()
+
+    # -------------------------------------------------------------------------------------
+    def reset_state(self):
+        B, dev = self.cfg.n_seq, self.device
+        cond0 = self.cfg.prompt_len + 3
+        # lens[0] = current, lens[1] = next (double buffer); layout [cond lens of all seqs, uncond lens]
+        base = torch.cat([torch.full((B,), cond0, dtype=torch.int64), torch.full((B,), 3, dtype=torch.int64)]).to(dev)
+        self.len_base = base
+        self.lens = [base.clone(), base.clone()]
+        self.cursor = torch.zeros(B, dtype=torch.int32, device=dev)
+        self.sample_token = self.first_token.clone()
+        self.step_idx = 0
+
+    def _make_ep_params(self) -> EpParams:
+        c = self.cfg
+        p = EpParams()
+        p.B, p.P, p.D, p.V, p.rows_per_seq = c.n_seq, self.P, self.D, V, self.N
+        p.mode, p.syntax_shortcut, p.tok_offset = ops.MODE_STATIC_LUMINA, 1, 4
+        p.img_lo, p.img_hi, p.n_syntax = IMG_LO, IMG_HI, 4
+        for i, s in enumerate((8196, 8197, 8803, 8828)):
+            p.syntax[i] = s
+        p.lantern, p.k, p.delta = 1, c.lantern_k, c.lantern_delta
+        p.table_rows, p.table_cols = K_CODES, K_CODES - 1
+        p.top_k, p.temperature, p.top_p = 0, 1.0, 1.0       # Lumina filters in O7, not per level
+        p.n_uniforms, p.R, p.N, p.row_index_per_seq = self.n_uniforms, self.R, self.N, 0
+        return p
+
+    def ep_buffers(self, slot: int, i: int) -> EpBuffers:
+        b = EpBuffers()
+        b.logits, b.row_index, b.cand = self.proc.data_ptr(), self.d_row_index.data_ptr(), self.cand.data_ptr()
+        b.cart_prob, b.orig_prob = self.cart_prob.data_ptr(), self.orig_prob[slot].data_ptr()
+        b.op_off, b.p_idx, b.b_off, b.b_idx = (self.d_op_off.data_ptr(), self.d_p_idx.data_ptr(), self.d_b_off.data_ptr(),
+                                               self.d_b_idx.data_ptr())
+        b.tree_cand, b.nn_table = self.tree_cand.data_ptr(), self.table.data_ptr()
+        b.uniforms, b.cursor, b.workspace = self.uniforms.data_ptr(), self.cursor.data_ptr(), self.workspace.data_ptr()
+        b.best, b.accept_len = self.log_best[i].data_ptr(), self.log_alen[i].data_ptr()
+        b.sample_p, b.counters = self.sample_p.data_ptr(), self.log_cnt[i].data_ptr()
+        return b
+
+    # -------------------------------------------------------------------------------------
+    def step(self, events=None):
+        """One verify step over all sequences.  `events`: optional dict name -> (start,end) torch events
+        recorded around the three HBM-heavy kernels on the launch stream."""
+        c, L = self.cfg, self._L
+        i = self.step_idx
+        slot = i % c.pool_steps
+        B, N, P, D = c.n_seq, self.N, self.P, self.D
+        st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        cur, nxt = self.lens[i & 1], self.lens[(i + 1) & 1]
+        vp = C.c_void_p
+
+        # O6 candidate assembly
+        check(L.lantern_gather_candidates(vp(self.ss_token[slot].data_ptr()), vp(self.ss_prob[slot].data_ptr()),
+                                          vp(self.sample_token.data_ptr()), vp(self.d_tree_indices.data_ptr()),
+                                          vp(self.d_retrieve.data_ptr()), B, self.R * 10, N, P, D, vp(self.tree_cand.data_ptr()),
+                                          vp(self.cand.data_ptr()), vp(self.cart_prob.data_ptr()), st), "gather_candidates")
+        # O7 CFG + Lumina position mask + top-k, positions from the device-side lengths
+        if events:
+            events["cfg_mask_topk"][0].record()
+        check(L.lantern_cfg_mask_topk(vp(self.cond[slot].data_ptr()), vp(self.uncond[slot].data_ptr()), 1, B * N, V,
+                                      C.c_float(c.cfg_scale), ops.MODEL_LUMINA, vp(self.d_pos_ids.data_ptr()),
+                                      C.c_int64(c.prompt_len + 3), W_LATENT, H_LATENT, IMG_LO, IMG_HI, NEWLINE, EOS, c.top_k,
+                                      vp(cur.data_ptr()), N, vp(self.proc.data_ptr()), st), "cfg_mask_topk")
+        if events:
+            events["cfg_mask_topk"][1].record()
+            events["evaluate_posterior"][0].record()
+        # O8
+        buf = self.ep_buffers(slot, i)
+        check(L.lantern_evaluate_posterior(C.byref(self._ep_prm), C.byref(buf), st), "evaluate_posterior")
+        if events:
+            events["evaluate_posterior"][1].record()
+        # O9 KV gather: both slabs of every sequence in one launch
+        if c.with_kv:
+            if events:
+                events["kv_gather"][0].record()
+            check(L.lantern_kv_gather(vp(self.slab_ptrs.data_ptr()), vp(self.slab_seq.data_ptr()), vp(cur.data_ptr()), 2 * B, 2,
+                                      C.c_int64(2 * c.kv_layers * c.kv_heads), C.c_int64(c.kv_smax), C.c_int64(c.kv_dim),
+                                      vp(self.d_retrieve.data_ptr()), 0, P, D, vp(self.log_best[i].data_ptr()),
+                                      vp(self.log_alen[i].data_ptr()), vp(nxt.data_ptr()), st), "kv_gather")
+            if events:
+                events["kv_gather"][1].record()
+        else:
+            torch.add(cur, (self.log_alen[i] + 1).repeat(2), out=nxt)
+        # O10 accepted hidden + token append + bonus token (feeds the next step's O6)
+        check(L.lantern_accept_gather(vp(self.hidden[slot].data_ptr()), 2, B, 2, N, HIDDEN, vp(self.d_retrieve.data_ptr()), 0, P, D,
+                                      vp(self.cand.data_ptr()), vp(self.log_best[i].data_ptr()), vp(self.log_alen[i].data_ptr()),
+                                      vp(self.sample_p.data_ptr()), V, vp(self.u_bonus[i].data_ptr()), vp(self.out_hidden.data_ptr()),
+                                      vp(self.acc_tokens.data_ptr()), vp(self.log_token[i].data_ptr()), st), "accept_gather")
+        # harness bookkeeping (sequence management, not the hot path): next sample token, image wrap-around
+        self.sample_token = self.log_token[i]
+        done = (nxt - self.len_base) >= TOKENS_PER_IMAGE
+        torch.where(done, self.len_base, nxt, out=nxt)
+        self.step_idx += 1
+
+    # -------------------------------------------------------------------------------------
+    def accepted_tokens(self, i0: int, i1: int) -> int:
+        return int((self.log_alen[i0:i1].to(torch.int64) + 1).sum().item())
+
+    def ep_algorithmic_bytes(self, i0: int, i1: int) -> float:
+        """SURVEY 8d contract figure summed over steps [i0,i1) and all sequences:
+        L*V*4 + T*k*6 + R*(k+1)*4 + V*4 (+ V*4 when the final row is a fresh softmax)."""
+        c = self.log_cnt[i0:i1].to(torch.float64)
+        k = self.cfg.lantern_k
+        Lv, T, Rj, fresh = c[..., 0].sum(), c[..., 1].sum(), c[..., 2].sum(), (1 - c[..., 4]).sum()
+        n = c.shape[0] * c.shape[1]
+        return float(Lv * V * 4 + T * k * 6 + Rj * (k + 1) * 4 + n * V * 4 + fresh * V * 4)
+
+    def o7_algorithmic_bytes(self, n_steps: int) -> float:
+        return float(n_steps) * self.cfg.n_seq * self.N * V * (2 * 2 + 4)
+
+    def kv_algorithmic_bytes(self, i0: int, i1: int) -> float:
+        c = self.cfg
+        per_pos = 2 * c.kv_layers * c.kv_heads * c.kv_dim * 2      # bytes per position per slab
+        moved = (self.log_alen[i0:i1].to(torch.float64) + 1).sum().item() * 2   # two slabs per sequence
+        return float(2 * moved * per_pos)                            # read + write
+
+    def check_status(self, i0: int, i1: int):
+        st = self.log_cnt[i0:i1, :, 5]
+        if int(st.abs().sum().item()) != 0:
+            bad = torch.nonzero(st)[0].tolist()
+            raise _lib.LanternError(f"evaluate_posterior status {int(st[bad[0], bad[1]])} at step {i0 + bad[0]} seq {bad[1]}")

@@ -168,8 +168,10 @@ def gather_candidates(ss_token, ss_prob, sample_token, tree_indices, retrieve):
 
 def cfg_mask_topk(cond, uncond, cfg: float, model: int = MODEL_PLAIN, pos_ids=None, pos_base: int = 0, w: int = 48,
                   h: int = 48, img_lo: int = 4, img_hi: int = 8196, newline_id: int = 8803, eos_id: int = 8196,
-                  top_k: int = 0, out: Optional[torch.Tensor] = None):
-    """O7.  cond/uncond [rows,V] bf16 or f32 -> processed f32 [rows,V]."""
+                  top_k: int = 0, out: Optional[torch.Tensor] = None, seq_len: Optional[torch.Tensor] = None,
+                  rows_per_seq: int = 0):
+    """O7.  cond/uncond [rows,V] bf16 or f32 -> processed f32 [rows,V].  With seq_len ([B] i64 device,
+    each sequence's len(input_ids)) pos_ids is the shared [rows_per_seq] tree_position_ids + 1."""
     if not cond.is_cuda:
         raise _lib.LanternError("cfg_mask_topk: expected device tensors")
     assert cond.dtype == uncond.dtype and cond.dtype in (torch.float32, torch.bfloat16)
@@ -182,7 +184,7 @@ def cfg_mask_topk(cond, uncond, cfg: float, model: int = MODEL_PLAIN, pos_ids=No
     check(_lib.lib().lantern_cfg_mask_topk(
         C.c_void_p(cond.data_ptr()), C.c_void_p(uncond.data_ptr()), 1 if cond.dtype == torch.bfloat16 else 0, rows, V,
         C.c_float(cfg), model, C.c_void_p(_ptr(pos)), C.c_int64(pos_base), w, h, img_lo, img_hi, newline_id, eos_id, top_k,
-        C.c_void_p(out.data_ptr()), _stream()), "cfg_mask_topk")
+        C.c_void_p(_ptr(seq_len)), rows_per_seq, C.c_void_p(out.data_ptr()), _stream()), "cfg_mask_topk")
     return out
 
 

@@ -74,16 +74,37 @@ static void softmax_row(const float *x, int n, float *out) {
     for (int i = 0; i < n; ++i) out[i] = out[i] / sf;
 }
 
-/* k-th largest value of x[0..n) (torch.topk(x,k)[0][-1]); k>=1. */
-static int cmp_float_desc(const void *a, const void *b) {
-    float fa = *(const float *)a, fb = *(const float *)b;
-    return (fa < fb) - (fa > fb);
-}
+/* k-th largest value of x[0..n) (torch.topk(x,k)[0][-1]); k>=1.  Quickselect on a copy
+ * (O(n) expected) so that the CPU baseline is not handicapped by a full sort. */
 static float kth_largest(const float *x, int n, int k) {
     float *t = (float *)malloc(sizeof(float) * (size_t)n);
     memcpy(t, x, sizeof(float) * (size_t)n);
-    qsort(t, (size_t)n, sizeof(float), cmp_float_desc);
-    float v = t[k - 1];
+    int lo = 0, hi = n - 1, target = k - 1; /* index in descending order */
+    while (lo < hi) {
+        /* median of three as pivot */
+        int mid = lo + (hi - lo) / 2;
+        float a = t[lo], b = t[mid], c = t[hi];
+        float pv = (a > b) ? ((b > c) ? b : (a > c ? c : a)) : ((a > c) ? a : (b > c ? c : b));
+        int i = lo, j = hi;
+        while (i <= j) {
+            while (t[i] > pv) ++i;
+            while (t[j] < pv) --j;
+            if (i <= j) {
+                float tmp = t[i];
+                t[i] = t[j];
+                t[j] = tmp;
+                ++i;
+                --j;
+            }
+        }
+        if (target <= j)
+            hi = j;
+        else if (target >= i)
+            lo = i;
+        else
+            break;
+    }
+    float v = t[target];
     free(t);
     return v;
 }

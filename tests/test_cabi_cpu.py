@@ -39,7 +39,7 @@ def test_argument_validation_without_gpu():
     prm.B, prm.P, prm.D, prm.V = 1, 4, 3, 1022  # V not a multiple of 4
     rc = L.lantern_evaluate_posterior(C.byref(prm), C.byref(buf), None)
     assert rc == -1 and b"multiple of 4" in L.lantern_last_error()
-    rc = L.lantern_cfg_mask_topk(None, None, 0, 1, 16, C.c_float(1.0), 0, None, C.c_int64(0), 1, 1, 0, 1, 0, 0, 0, None, None)
+    rc = L.lantern_cfg_mask_topk(None, None, 0, 1, 16, C.c_float(1.0), 0, None, C.c_int64(0), 1, 1, 0, 1, 0, 0, 0, None, 0, None, None)
     assert rc == -1
 
 

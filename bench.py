@@ -186,15 +186,8 @@ def main():
 
     wl.check_status(0, W + K)
     tokens = wl.accepted_tokens(W, W + K)
-    stats = torch.tensor([dt, float(tokens)], dtype=torch.float64, device=device)
-    if dist is not None:
-        tmax = stats[:1].clone()
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        tsum = stats[1:].clone()
-        dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
-        dt_all, tokens_all = float(tmax[0]), float(tsum[0])
-    else:
-        dt_all, tokens_all = dt, float(tokens)
+    from lantern_amd.sharding import reduce_timing
+    dt_all, tokens_all = reduce_timing(dist, dt, float(tokens), device=device)
 
     if rank == 0:
         alen = wl.log_alen[W:W + K].float() + 1

@@ -1,0 +1,287 @@
+"""Host mirror of models/ea_model_llamagen.py (and, through two class attributes, of
+models/ea_model_anole.py) for the verify/accept path.
+
+`EaModel` keeps the reference's method names and argument order: `generate_tree_buffers`,
+`generate_candidates`, `tree_decoding`, `evaluate_posterior` (dynamic tree), `evaluate_posterior_v1`
+(static tree), `update_inference_inputs`, `generate` (alias `eagenerate`).  The base model, its T5
+text encoder and the drafter network are supplied by the caller.
+
+Reference: models/ea_model_llamagen.py:26-29 (CFG), :283-420, :423-461, :464-669, :676-787,
+:908-999, :1002-1170; models/ea_model_anole.py same structure (+ image-token offset 4,
+`non_image_tokens` masking :931, cond/uncond position ids :915-918).
+"""
+from __future__ import annotations
+
+import time
+from typing import List, Optional
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import ops
+from .drafters.choices import mc_sim_7b_63, naive_extend_57  # noqa: F401
+from .drafters.kv_cache import initialize_past_key_values
+from .verify import (NodeLogits, ProcessorSpec, UniformFifo, as_rows, concat_original_prob, generate_tree_buffers,
+                     prepare_logits_processor)
+
+
+def cfg_logit_process(combined_logits, cfg_scale=4.0):
+    """uncond + (cond - uncond) * cfg_scale on the [cond; uncond] batch (ea_model_llamagen.py:26-29), HIP."""
+    half = len(combined_logits) // 2
+    cond, uncond = combined_logits[:half], combined_logits[half:]
+    out = ops.cfg_mask_topk(cond, uncond, float(cfg_scale), model=ops.MODEL_PLAIN)
+    return out.to(combined_logits.dtype)
+
+
+class EaModel(nn.Module):
+    # per-model constants: LlamaGen has V == K and no offset
+    image_token_offset = 0
+    image_lo, image_hi = 0, 2 ** 31 - 1
+    mask_non_image = False
+    uniform_window = 4096            # uniforms staged per refill (verify.UniformFifo)
+    prefix_pad = 120                 # input_ids carries 120 leading zero ids (ea_model_llamagen.py:437,1107)
+
+    def __init__(self, base_model, ea_layer, nearest_latents):
+        super().__init__()
+        self.base_model = base_model
+        self.ea_layer = ea_layer
+        self.config = getattr(base_model, "config", None)
+        dev = base_model.lm_head.weight.device
+        if isinstance(nearest_latents, np.ndarray):
+            nearest_latents = torch.from_numpy(np.ascontiguousarray(nearest_latents.astype(np.uint16)).view(np.int16))
+        self.nearest_latents = nearest_latents.to(dev)
+        self.vocab_size = base_model.lm_head.weight.shape[0]
+        self._fifo: Optional[UniformFifo] = None
+
+    def forward(self, cond_idx=None, input_ids=None, attention_mask=None, past_key_values=None, output_orig=False,
+                position_ids=None):
+        with torch.inference_mode():
+            outputs = self.base_model.model(cond_idx=cond_idx, input_ids=input_ids, attention_mask=attention_mask,
+                                            past_key_values=past_key_values, position_ids=position_ids)
+            if output_orig:
+                orig = self.base_model.lm_head(outputs[0])
+            hidden_states = outputs[0]
+        return (outputs, orig, hidden_states) if output_orig else (outputs, hidden_states)
+
+    def generate_tree_buffers(self, tree_choices, device="cuda"):
+        return generate_tree_buffers(tree_choices, device=device)
+
+    def reset_tree_mode(self):
+        self.base_model.model.tree_mode = True
+        self.base_model.model.tree_mask = None
+
+    def _uniforms(self) -> UniformFifo:
+        if self._fifo is None:
+            self._fifo = UniformFifo(self.nearest_latents.device, window=self.uniform_window)
+        return self._fifo
+
+    def _ep_config(self, static: bool, proc: ProcessorSpec, lantern, lantern_k, lantern_delta) -> ops.EpConfig:
+        return ops.EpConfig(mode=ops.MODE_STATIC_LG if static else ops.MODE_DYNAMIC, tok_offset=self.image_token_offset,
+                            img_lo=self.image_lo, img_hi=self.image_hi, lantern=bool(lantern), k=int(lantern_k),
+                            delta=float(lantern_delta), temperature=proc.temperature, top_p=proc.top_p, top_k=proc.top_k)
+
+    # ------------------------------------------------------------------ O6, :676-706
+    def generate_candidates(self, tree_logits, tree_indices, retrieve_indices, sample_token, logits_processor):
+        dev = tree_indices.device
+        prob = tree_logits[1].to(dev).float()[None] if logits_processor is not None else None
+        cand, cprob, tcand = ops.gather_candidates(tree_logits[0].to(dev)[None], prob, sample_token.to(dev).reshape(-1)[:1],
+                                                   tree_indices, retrieve_indices)
+        return cand[0], (cprob[0] if cprob is not None else None), tcand
+
+    # ------------------------------------------------------------------ :908-932
+    def tree_decoding(self, tree_candidates, past_key_values, tree_position_ids, input_ids, retrieve_indices, cfg_scale,
+                      attention_mask=None, input_position_diff=0):
+        position_ids = tree_position_ids + input_ids.shape[1]
+        if self.mask_non_image:      # Anole: separate cond / uncond position ids (ea_model_anole.py:915-918)
+            position_ids = position_ids.unsqueeze(0)
+            position_ids = torch.cat([position_ids, position_ids - input_position_diff], dim=0)
+        if attention_mask is not None:
+            remaining = input_ids.shape[1] + tree_candidates.shape[1] - attention_mask.shape[1]
+            attention_mask = torch.cat([attention_mask, torch.ones((attention_mask.shape[0], remaining), dtype=torch.long,
+                                                                    device=attention_mask.device)], dim=1)
+        outputs, tree_logits, hidden_state = self(input_ids=tree_candidates, output_orig=True, past_key_values=past_key_values,
+                                                  position_ids=position_ids, attention_mask=attention_mask)
+        half = tree_logits.shape[0] // 2
+        node_logits = ops.cfg_mask_topk(tree_logits[0], tree_logits[half], float(cfg_scale),
+                                        model=ops.MODEL_ANOLE if self.mask_non_image else ops.MODEL_PLAIN,
+                                        img_lo=self.image_lo if self.mask_non_image else 0,
+                                        img_hi=self.image_hi if self.mask_non_image else tree_logits.shape[-1])
+        return NodeLogits(node_logits, retrieve_indices), hidden_state, outputs
+
+    # ------------------------------------------------------------------ O8 dynamic, :709-787 / greedy :789-905
+    def evaluate_posterior(self, logits, candidates, logits_processor=None, lantern=False, lantern_k=1000, lantern_delta=0.1):
+        rows, row_index = as_rows(logits)
+        if logits_processor is None:
+            return self._evaluate_posterior_greedy(rows, row_index, candidates, lantern, lantern_k, lantern_delta)
+        proc = ProcessorSpec.from_hf(logits_processor)
+        cfg = self._ep_config(False, proc, lantern, lantern_k, lantern_delta)
+        fifo = self._uniforms()
+        fifo.reserve(candidates.shape[0] * candidates.shape[1])
+        best, alen, sample_p, counters = ops.evaluate_posterior(cfg, rows.float()[None], row_index, candidates[None], fifo.buf,
+                                                                table=self.nearest_latents if lantern else None,
+                                                                cursor=fifo.cursor)
+        ops.raise_on_status(counters)
+        return best[0].to(torch.int64), int(alen[0]), sample_p[0]
+
+    # ------------------------------------------------------------------ O8 static, :464-669
+    def evaluate_posterior_v1(self, logits, candidates, logits_processor, cart_candidates_prob, op, p_indices, tree_candidates,
+                              b_indices, lantern=False, lantern_k=1000, lantern_delta=0.1):
+        rows, row_index = as_rows(logits)
+        if logits_processor is None:
+            return self._evaluate_posterior_greedy(rows, row_index, candidates, lantern, lantern_k, lantern_delta)
+        proc = ProcessorSpec.from_hf(logits_processor)
+        cfg = self._ep_config(True, proc, lantern, lantern_k, lantern_delta)
+        hip = self.tree_buffers["_hip"]
+        aux = ops.StaticAux(cart_prob=cart_candidates_prob.to(rows.device).float()[None], orig_prob=concat_original_prob(op),
+                            op_off=hip["op_off"], p_idx=hip["p_idx"], b_off=hip["b_off"], b_idx=hip["b_idx"],
+                            tree_cand=tree_candidates[:1].reshape(1, -1)[:, :hip["N"]])
+        fifo = self._uniforms()
+        fifo.reserve(candidates.shape[0] * candidates.shape[1])
+        best, alen, sample_p, counters = ops.evaluate_posterior(cfg, rows.float()[None], row_index, candidates[None], fifo.buf,
+                                                                table=self.nearest_latents if lantern else None, aux=aux,
+                                                                cursor=fifo.cursor)
+        ops.raise_on_status(counters)
+        return best[0].to(torch.int64), int(alen[0]), sample_p[0]
+
+    def _evaluate_posterior_greedy(self, rows, row_index, candidates, lantern, lantern_k, lantern_delta):
+        best, alen, out_row = ops.evaluate_posterior_greedy(rows.float()[None], row_index, candidates[None], lantern=bool(lantern),
+                                                            k=int(lantern_k), delta=float(lantern_delta),
+                                                            tok_offset=self.image_token_offset,
+                                                            table=self.nearest_latents if lantern else None)
+        return best[0].to(torch.int64), alen[0].to(torch.int64), out_row[0]
+
+    # ------------------------------------------------------------------ O9 + O10, :935-999
+    def update_inference_inputs(self, input_ids, candidates, best_candidate, accept_length, retrieve_indices, logits_processor,
+                                new_token, past_key_values_data_list, current_length_data, hidden_state_new, sample_p, cfg_scale,
+                                input_position_diff=None, attention_mask=None, static_tree=False):
+        prev_input_len = input_ids.shape[1]
+        n = int(accept_length) + 1
+        dev = retrieve_indices.device
+        best = torch.as_tensor([int(best_candidate)], dtype=torch.int32, device=dev)
+        alen = torch.as_tensor([n - 1], dtype=torch.int32, device=dev)
+        input_ids = torch.cat([input_ids, candidates[None, int(best_candidate), :n].to(input_ids.device)], dim=-1)
+        for data in past_key_values_data_list:
+            ops.kv_gather([data], torch.zeros(1, dtype=torch.int32, device=data.device),
+                          torch.tensor([prev_input_len], dtype=torch.int64, device=data.device), retrieve_indices.to(data.device),
+                          best.to(data.device), alen.to(data.device))
+        current_length_data.fill_(prev_input_len + n)
+        u = torch.rand(1, dtype=torch.float64, device=dev) if logits_processor is not None else None
+        out_h, _, token = ops.accept_gather(hidden_state_new[None], retrieve_indices, None, best, alen,
+                                            sample_p=sample_p[None].float(), u=u)
+        accept_hidden_state_new = out_h[0, :, :n]
+        token = token.reshape(1, 1)
+        ea_input_ids = torch.cat((input_ids, token.to(input_ids.device)), dim=1).repeat(2, 1)
+        kw = {}
+        if self.mask_non_image:
+            kw = dict(input_position_diff=input_position_diff, attention_mask=attention_mask)
+        if static_tree:
+            tree_logits = self.ea_layer.topK_genrate_v1(accept_hidden_state_new, input_ids=ea_input_ids, head=self.base_model.lm_head,
+                                                        logits_processor=logits_processor, cfg_scale=cfg_scale, **kw)
+            new_token += n
+            return input_ids, tree_logits, new_token, None, token
+        draft_tokens, retrieve_indices, tree_mask, tree_position_ids = self.ea_layer.topK_genrate(
+            accept_hidden_state_new, input_ids=ea_input_ids, head=self.base_model.lm_head, logits_processor=logits_processor,
+            cfg_scale=cfg_scale, **kw)
+        new_token += n
+        return input_ids, draft_tokens, retrieve_indices, tree_mask, tree_position_ids, new_token, None, token
+
+    # ------------------------------------------------------------------ :423-461
+    @torch.no_grad()
+    def initialize_tree(self, cond_combined, past_key_values, logits_processor, cfg_scale, attention_mask=None, static_tree=False,
+                        tree_attn_mask=None, tree_choices=None):
+        outputs, orig, hidden_states = self(cond_idx=cond_combined, past_key_values=past_key_values, output_orig=True,
+                                            attention_mask=attention_mask)
+        logits = cfg_logit_process(orig[:, -1], cfg_scale)
+        if logits_processor is not None:
+            logits = logits_processor(None, logits)
+            token = torch.multinomial(torch.nn.functional.softmax(logits.float(), dim=1), 1)
+        else:
+            token = torch.argmax(logits)[None, None]
+        token = torch.cat([token, token], dim=0)
+        zero_padding = torch.zeros((token.shape[0], self.prefix_pad), dtype=torch.long, device=token.device)
+        input_ids = torch.cat((zero_padding, token.to(cond_combined.device)), dim=1)
+        if static_tree:
+            self.ea_layer.init_tree_v1(tree_choices)
+            tree_logits = self.ea_layer.topK_genrate_v1(hidden_states, input_ids, self.base_model.lm_head, logits_processor, cfg_scale)
+            self.base_model.model.tree_mask = tree_attn_mask
+            return tree_logits, logits, token
+        out = self.ea_layer.topK_genrate(hidden_states, input_ids, self.base_model.lm_head, logits_processor, cfg_scale)
+        return (*out, orig, hidden_states, token)
+
+    def initialize_tree_v1(self, cond_combined, tree_attn_mask, past_key_values, logits_processor, cfg_scale, attention_mask=None,
+                           tree_choices=mc_sim_7b_63):
+        """ea_model_llamagen.py:442-461 (same argument order)."""
+        return self.initialize_tree(cond_combined, past_key_values, logits_processor, cfg_scale, attention_mask, static_tree=True,
+                                    tree_attn_mask=tree_attn_mask, tree_choices=tree_choices)
+
+    # ------------------------------------------------------------------ :1002-1170
+    @torch.no_grad()
+    def generate(self, prompt: Optional[List[str]] = None, max_length: Optional[int] = None, temperature: Optional[float] = None,
+                 top_k: Optional[int] = None, top_p: Optional[float] = None, cfg: Optional[float] = None,
+                 lantern: Optional[bool] = None, lantern_k: Optional[int] = None, lantern_delta: Optional[float] = None,
+                 static_tree: Optional[bool] = None, tree_choices: Optional[List[List[int]]] = naive_extend_57, **model_kwargs):
+        accept_length_list = []
+        cond_combined, attention_mask = self.base_model.encode_prompt(prompt, cfg)     # T5 + uncond embedding: out of scope
+        st = time.time()
+        if not hasattr(self.base_model, "past_key_values"):
+            (self.base_model.past_key_values, self.base_model.past_key_values_data,
+             self.base_model.current_length_data) = initialize_past_key_values(self.base_model, 2)
+        past_key_values = self.base_model.past_key_values
+        past_key_values_data = self.base_model.past_key_values_data
+        current_length_data = self.base_model.current_length_data
+        current_length_data.zero_()
+        dev = cond_combined.device
+        padding = (torch.zeros(1, 1, dtype=torch.long) - 1).to(dev)
+        self.ea_layer.reset_kv()
+        logits_processor = prepare_logits_processor(temperature=temperature, top_k=top_k, top_p=top_p) if temperature > 1e-5 else None
+        if static_tree:
+            if not (hasattr(self, "tree_choices") and self.tree_choices == tree_choices):
+                self.tree_buffers = self.generate_tree_buffers(tree_choices, device=dev)
+                self.tree_buffers["retrieve_indices_head"] = self.tree_buffers["retrieve_indices"]
+                self.tree_choices = tree_choices
+            tree_buffers = self.tree_buffers
+        self.reset_tree_mode()
+        if static_tree:
+            tree_logits, logits, sample_token = self.initialize_tree(cond_combined, past_key_values, logits_processor, cfg,
+                                                                     attention_mask, static_tree=True,
+                                                                     tree_attn_mask=tree_buffers["tree_attn_mask"],
+                                                                     tree_choices=tree_choices)
+        else:
+            draft_tokens, retrieve_indices, tree_mask, tree_position_ids, logits, hidden_state, sample_token = self.initialize_tree(
+                cond_combined, past_key_values, logits_processor, cfg, attention_mask)
+        input_ids = torch.zeros((cond_combined.shape[0] // (2 if cfg is not None else 1), self.prefix_pad), dtype=torch.long).to(dev)
+        new_token = 0
+        for idx in range(max_length):
+            if static_tree:
+                candidates, cart_candidates_prob, tree_candidates = self.generate_candidates(
+                    tree_logits, tree_buffers["tree_indices"], tree_buffers["retrieve_indices"], sample_token, logits_processor)
+                tree_candidates = torch.cat([tree_candidates, tree_candidates])
+                logits, hidden_state_new, outputs = self.tree_decoding(tree_candidates, past_key_values, tree_buffers["tree_position_ids"],
+                                                                       input_ids, tree_buffers["retrieve_indices_head"], cfg, attention_mask)
+                best_candidate, accept_length, sample_p = self.evaluate_posterior_v1(
+                    logits, candidates, logits_processor, cart_candidates_prob, tree_logits[2], tree_buffers["p_indices"],
+                    tree_candidates, tree_buffers["b_indices"], lantern, lantern_k, lantern_delta)
+                input_ids, tree_logits, new_token, hidden_state, sample_token = self.update_inference_inputs(
+                    input_ids, candidates, best_candidate, accept_length, tree_buffers["retrieve_indices_head"], logits_processor,
+                    new_token, past_key_values_data, current_length_data, hidden_state_new, sample_p, cfg, static_tree=True)
+            else:
+                self.base_model.model.tree_mask = tree_mask
+                tree_draft_tokens = torch.cat([draft_tokens, draft_tokens])
+                logits, hidden_state_new, outputs = self.tree_decoding(tree_draft_tokens, past_key_values, tree_position_ids, input_ids,
+                                                                       retrieve_indices, cfg, attention_mask)
+                draft_tokens = torch.cat((draft_tokens, padding), dim=1)
+                candidates = draft_tokens[0, retrieve_indices]
+                best_candidate, accept_length, sample_p = self.evaluate_posterior(logits, candidates, logits_processor, lantern=lantern,
+                                                                                  lantern_k=lantern_k, lantern_delta=lantern_delta)
+                (input_ids, draft_tokens, retrieve_indices, tree_mask, tree_position_ids, new_token, hidden_state,
+                 sample_token) = self.update_inference_inputs(input_ids, candidates, best_candidate, accept_length, retrieve_indices,
+                                                              logits_processor, new_token, past_key_values_data, current_length_data,
+                                                              hidden_state_new, sample_p, cfg)
+            accept_length_list.append(int(accept_length) + 1)
+            if new_token > max_length:
+                break
+        return (input_ids[:, self.prefix_pad:self.prefix_pad + max_length], sum(accept_length_list) / len(accept_length_list),
+                time.time() - st)
+
+    eagenerate = generate

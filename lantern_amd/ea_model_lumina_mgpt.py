@@ -1,0 +1,367 @@
+"""Host mirror of models/ea_model_lumina_mgpt.py for the verify/accept path.
+
+Same class / method names, argument meaning and return values as the reference
+(`EaLumina_mGPT.generate` -- also exported as `eagenerate` -- `initialize_tree`,
+`generate_candidates`, `tree_decoding`, `evaluate_posterior`, `update_inference_inputs`,
+module-level `generate_tree_buffers`, `MultiModalLogitsProcessor`, `InterleavedTopKLogitsWarper`),
+with every hot torch-op sequence / Python loop replaced by one HIP entry point.  The target model
+and the drafter network are NOT re-implemented: `base_model` and `ea_layer` are whatever the caller
+built (the reference's own modules).
+
+Reference: models/ea_model_lumina_mgpt.py:25-112 (processors), :140-277 (tree buffers),
+:458-1017 (spec-decode driver).
+"""
+from __future__ import annotations
+
+import math
+from typing import List, Optional
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import ops
+from .drafters.choices import mc_sim_7b_63
+from .drafters.kv_cache import initialize_past_key_values
+from .verify import NodeLogits, UniformFifo, as_rows, concat_original_prob, generate_tree_buffers  # noqa: F401
+
+TOPK = 10
+IMAGE_LO, IMAGE_HI = 4, 8196          # image tokens are 4..8195 (ea_model_lumina_mgpt.py:37,322-323)
+SYNTAX_TOKENS = (8196, 8197, 8803, 8828)
+
+
+class MultiModalLogitsProcessor:
+    """Position-dependent Lumina mask (ea_model_lumina_mgpt.py:25-86) on the HIP kernel: grid
+    position -> only image ids stay finite; row end -> only 8803; after the last row -> only 8196."""
+
+    def __init__(self, image_next_line_token_id=8803, image_end_token_id=8196, voc_size=65536):
+        self.image_next_line_token_id = image_next_line_token_id
+        self.image_end_token_id = image_end_token_id
+        self.voc_size = voc_size
+
+    def __call__(self, scores, h_latent_dim=48, w_latent_dim=48, image_start_token_id_index=None, position_ids=None):
+        if position_ids is None:
+            return scores
+        base = 2 if image_start_token_id_index is None else image_start_token_id_index + 1 + 2
+        pos = position_ids.reshape(-1).to(torch.int64)
+        out = ops.cfg_mask_topk(scores, scores, 1.0, model=ops.MODEL_LUMINA, pos_ids=pos, pos_base=int(base), w=w_latent_dim,
+                                h=h_latent_dim, img_lo=IMAGE_LO, img_hi=IMAGE_HI, newline_id=self.image_next_line_token_id,
+                                eos_id=self.image_end_token_id, top_k=0)
+        return out.to(scores.dtype)
+
+
+class InterleavedTopKLogitsWarper:
+    """`scores < kth-largest -> filter_value` (ea_model_lumina_mgpt.py:88-112) on the HIP kernel."""
+
+    def __init__(self, image_top_k: int = 2000, filter_value: float = -float("Inf"), min_tokens_to_keep: int = 1):
+        if not isinstance(image_top_k, int) or image_top_k <= 0:
+            raise ValueError(f"`image_top_k` has to be a strictly positive integer, but is {image_top_k}")
+        assert filter_value == -float("Inf"), "the kernel filters with -inf like the reference default"
+        self.image_top_k = max(image_top_k, min_tokens_to_keep)
+        self.filter_value = filter_value
+
+    def __call__(self, scores):
+        out = ops.cfg_mask_topk(scores, scores, 1.0, model=ops.MODEL_PLAIN, top_k=min(self.image_top_k, scores.size(-1)))
+        return out.to(scores.dtype)
+
+
+class EaLumina_mGPT(nn.Module):
+    uniform_window = 4096     # uniforms staged per refill (verify.UniformFifo)
+
+    def __init__(self, base_model, ea_layer, nearest_latents, cfg_mode: str = "sequential", eagle_version: int = 1,
+                 dtype=torch.bfloat16):
+        super().__init__()
+        self.base_model = base_model
+        self.ea_layer = ea_layer
+        self.config = getattr(base_model, "config", None)
+        self.dtype = dtype
+        self.cfg_mode = cfg_mode
+        self.eagle_version = eagle_version
+        self.vocab_size = base_model.lm_head.weight.shape[0]
+        self.hidden_size = base_model.lm_head.weight.shape[-1]
+        dev = base_model.lm_head.weight.device
+        # uint16 [K, K-1] table (ckpts/lumina_mgpt/vq_distances/top_8191_indices.npy, :321) staged once in HBM
+        if isinstance(nearest_latents, np.ndarray):
+            nearest_latents = torch.from_numpy(np.ascontiguousarray(nearest_latents.astype(np.uint16)).view(np.int16))
+        self.nearest_latents = nearest_latents.to(dev)
+        self.image_token_offset = 4
+        self.image_tokens = torch.arange(IMAGE_LO, IMAGE_HI, device=dev)
+        self.image_syntax_tokens = torch.tensor(SYNTAX_TOKENS, device=dev)
+        self.image_start_token_id = 8197
+        self.internal_logits_processors = [MultiModalLogitsProcessor()]
+        self.drafter_logits_processors = [MultiModalLogitsProcessor()]
+        self._fifo: Optional[UniformFifo] = None
+        self.w_latent_dim = self.h_latent_dim = 48
+
+    # ------------------------------------------------------------------ plumbing (unchanged semantics)
+    def forward(self, input_ids=None, attention_mask=None, past_key_values=None, output_orig=False, position_ids=None):
+        with torch.inference_mode():
+            outputs = self.base_model.model(input_ids=input_ids, attention_mask=attention_mask, past_key_values=past_key_values,
+                                            position_ids=position_ids)
+            if output_orig:
+                orig = self.base_model.lm_head(outputs[0])
+            hidden_states = outputs[0]
+        return (outputs, orig, hidden_states) if output_orig else (outputs, hidden_states)
+
+    def reset_tree_mode(self):
+        self.base_model.model.tree_mode = True
+        self.base_model.model.tree_mask = None
+
+    def _uniforms(self) -> UniformFifo:
+        if self._fifo is None:
+            self._fifo = UniformFifo(self.nearest_latents.device, window=self.uniform_window)
+        return self._fifo
+
+    # ------------------------------------------------------------------ :458-522
+    def initialize_tree(self, input_ids, past_key_values, logits_processors, attention_mask=None, tree_attn_mask=None):
+        if self.cfg_mode == "parallel":
+            _, logits, hidden_states = self(input_ids=input_ids, attention_mask=attention_mask, past_key_values=past_key_values,
+                                            output_orig=True)
+            logits, uncond_logits = torch.split(logits, [1, 1])
+            hidden_states, uncond_hidden_states = torch.split(hidden_states, [1, 1])
+            input_ids = input_ids[:-1]
+        else:
+            _, logits, hidden_states = self(input_ids=input_ids, past_key_values=past_key_values["cond"], output_orig=True)
+            self.image_start_token_id_index = torch.where(input_ids[0] == 8197)[0][-1].item()
+            uncond_input_ids = input_ids[:, self.image_start_token_id_index:]
+            _, uncond_logits, uncond_hidden_states = self(input_ids=uncond_input_ids, past_key_values=past_key_values["uncond"],
+                                                          output_orig=True)
+        cfg_logits = uncond_logits[:, -1] + self.cfg_scale * (logits[:, -1] - uncond_logits[:, -1])
+        for logits_processor in (logits_processors or [])[1:]:
+            cfg_logits = logits_processor(input_ids, cfg_logits)
+        probabilities = torch.nn.functional.softmax(cfg_logits.float(), dim=-1)
+        token = torch.multinomial(probabilities, 1)
+        input_ids = torch.cat((input_ids, token.to(input_ids.device)), dim=1)
+        if self.eagle_version == 1:
+            self.ea_layer.init_tree(self.tree_choices)
+            self.base_model.model.tree_mask = tree_attn_mask
+        else:
+            self.ea_layer.init_tree()
+        output = self.ea_layer.topK_generate(hidden_states=hidden_states, uncond_hidden_states=uncond_hidden_states,
+                                             input_ids=input_ids, attention_mask=attention_mask, head=self.base_model.lm_head,
+                                             logits_processors=self.drafter_logits_processors,
+                                             tree_type="static" if self.eagle_version == 1 else "dynamic")
+        return (output, token) if self.eagle_version == 1 else output
+
+    # ------------------------------------------------------------------ O6, :525-554
+    def generate_candidates(self, tree_logits, tree_indices, retrieve_indices, sample_token):
+        ss_token, ss_prob = tree_logits[0], tree_logits[1]
+        dev = tree_indices.device
+        cand, cprob, tcand = ops.gather_candidates(ss_token.to(dev)[None], ss_prob.to(dev).float()[None],
+                                                   sample_token.to(dev).reshape(-1)[:1], tree_indices, retrieve_indices)
+        return cand[0], cprob[0], tcand        # tree_candidates keeps its leading batch dim of 1
+
+    # ------------------------------------------------------------------ :556-608 (O7 replaces :597-607)
+    def tree_decoding(self, tree_candidates, attention_mask, past_key_values, tree_position_ids, input_ids, retrieve_indices):
+        position_ids = tree_position_ids + input_ids.shape[1]
+        if self.cfg_mode == "parallel":
+            tree_candidates = torch.cat((tree_candidates, tree_candidates), dim=0)
+            position_ids = torch.cat((position_ids[None], position_ids[None] - self.image_start_token_id_index), dim=0)
+            _, tree_logits, hidden_states = self(input_ids=tree_candidates, attention_mask=attention_mask, output_orig=True,
+                                                 past_key_values=past_key_values, position_ids=position_ids)
+            tree_logits, uncond_tree_logits = torch.split(tree_logits, [1, 1])
+            hidden_states, uncond_hidden_states = torch.split(hidden_states, [1, 1])
+            position_ids = position_ids[0]
+        else:
+            _, tree_logits, hidden_states = self(input_ids=tree_candidates, output_orig=True,
+                                                 past_key_values=past_key_values["cond"], position_ids=position_ids)
+            _, uncond_tree_logits, uncond_hidden_states = self(input_ids=tree_candidates, output_orig=True,
+                                                               past_key_values=past_key_values["uncond"],
+                                                               position_ids=position_ids - self.image_start_token_id_index)
+        # one kernel: CFG combine + MultiModalLogitsProcessor + InterleavedTopKLogitsWarper; no [P,D,V] gather
+        top_k = self.internal_logits_processors[1].image_top_k if len(self.internal_logits_processors) > 1 else 0
+        node_logits = ops.cfg_mask_topk(tree_logits[0], uncond_tree_logits[0], float(self.cfg_scale), model=ops.MODEL_LUMINA,
+                                        pos_ids=(position_ids + 1).reshape(-1), pos_base=self.image_start_token_id_index + 3,
+                                        w=self.w_latent_dim, h=self.h_latent_dim, img_lo=IMAGE_LO, img_hi=IMAGE_HI,
+                                        newline_id=8803, eos_id=8196, top_k=min(top_k, tree_logits.shape[-1]))
+        return NodeLogits(node_logits, retrieve_indices), hidden_states, uncond_hidden_states
+
+    # ------------------------------------------------------------------ O8, :610-729
+    def evaluate_posterior(self, logits, candidates, cart_candidates_prob=None, original_prob=None, p_indices=None,
+                           tree_candidates=None, b_indices=None, do_sample=True, lantern=False, lantern_k=1000,
+                           lantern_delta=0.1):
+        if not do_sample:
+            raise NotImplementedError("Greedy decoding is not implemented yet")   # same as the reference (:728-729)
+        static = self.eagle_version == 1
+        rows, row_index = as_rows(logits)
+        cfg = ops.EpConfig.lumina(static, lantern=bool(lantern), k=int(lantern_k), delta=float(lantern_delta))
+        cfg.img_hi = int(self.image_tokens[-1]) + 1
+        cfg.img_lo = int(self.image_tokens[0])
+        cfg.syntax = tuple(int(x) for x in self.image_syntax_tokens.tolist())
+        cfg.tok_offset = self.image_token_offset
+        aux = None
+        if static:
+            assert cart_candidates_prob is not None, "Cartesian candidate probabilities are required for EAGLE v1"
+            assert original_prob is not None, "Original probabilities are required for EAGLE v1"
+            assert tree_candidates is not None, "Tree candidates are required for EAGLE v1"
+            assert p_indices is not None, "Parent indices are required for EAGLE v1"
+            assert b_indices is not None, "B indices are required for EAGLE v1"
+            hip = self.tree_buffers["_hip"]
+            aux = ops.StaticAux(cart_prob=cart_candidates_prob.to(rows.device).float()[None], orig_prob=concat_original_prob(original_prob),
+                                op_off=hip["op_off"], p_idx=hip["p_idx"], b_off=hip["b_off"], b_idx=hip["b_idx"],
+                                tree_cand=tree_candidates.reshape(1, -1)[:, :hip["N"]])
+        fifo = self._uniforms()
+        fifo.reserve(candidates.shape[0] * candidates.shape[1])
+        best, alen, sample_p, counters = ops.evaluate_posterior(cfg, rows.float()[None], row_index, candidates[None], fifo.buf,
+                                                                table=self.nearest_latents if lantern else None, aux=aux,
+                                                                cursor=fifo.cursor)
+        self._last = (best, alen, counters)          # device copies for update_inference_inputs (no re-upload)
+        ops.raise_on_status(counters)                # host sync: the B=1 driver needs accept_length on the host anyway
+        return best[0].to(torch.int64), int(alen[0]), sample_p[0]
+
+    # ------------------------------------------------------------------ O9 + O10, :731-799
+    def update_inference_inputs(self, input_ids, attention_mask, candidates, best_candidate, accept_length, retrieve_indices,
+                                do_sample, new_token, past_key_values_data, current_length_data, hidden_states_new,
+                                uncond_hidden_states_new, sample_p):
+        dev = retrieve_indices.device
+        best = torch.as_tensor([int(best_candidate)], dtype=torch.int32, device=dev)
+        alen = torch.as_tensor([int(accept_length)], dtype=torch.int32, device=dev)
+        n = int(accept_length) + 1
+        if self.cfg_mode == "parallel":
+            prev_input_len = input_ids.shape[1]
+            slabs = list(past_key_values_data)
+            prevs = [prev_input_len] * len(slabs)
+            lens = [current_length_data] * len(slabs)
+        else:
+            slabs, prevs, lens = [], [], []
+            for key in ["cond", "uncond"]:
+                prev = input_ids.shape[1] if key == "cond" else input_ids.shape[1] - self.image_start_token_id_index
+                for data in past_key_values_data[key]:
+                    slabs.append(data)
+                    prevs.append(prev)
+                    lens.append(current_length_data[key])
+        # slabs of equal geometry go in one launch
+        groups = {}
+        for s, p, l in zip(slabs, prevs, lens):
+            groups.setdefault((tuple(s.shape), s.dtype, s.device), []).append((s, p, l))
+        for (_, _, sdev), items in groups.items():
+            ops.kv_gather([s for s, _, _ in items], torch.zeros(len(items), dtype=torch.int32, device=sdev),
+                          torch.tensor([p for _, p, _ in items], dtype=torch.int64, device=sdev), retrieve_indices.to(sdev),
+                          best.to(sdev), alen.to(sdev))
+            for _, p, l in items:
+                l.fill_(p + n)
+        acc = candidates[None, int(best_candidate), :n].to(input_ids.device)
+        if self.cfg_mode == "parallel":
+            input_ids = torch.cat([input_ids[None, 0], acc], dim=-1)
+        else:
+            input_ids = torch.cat([input_ids, acc], dim=-1)
+        # accepted hidden states (cond, uncond) + bonus token in one launch
+        hid = torch.stack([hidden_states_new[0], uncond_hidden_states_new[0]])[None]        # [1,2,N,H]
+        u = torch.rand(1, dtype=torch.float64, device=dev) if do_sample else None
+        out_h, _, token = ops.accept_gather(hid, retrieve_indices, None, best, alen, sample_p=sample_p[None].float(), u=u)
+        accept_hidden_states_new = out_h[:, 0, :n]
+        accept_uncond_hidden_states_new = out_h[:, 1, :n]
+        token = token.reshape(1, 1)
+        output = self.ea_layer.topK_generate(hidden_states=accept_hidden_states_new,
+                                             uncond_hidden_states=accept_uncond_hidden_states_new,
+                                             input_ids=torch.cat((input_ids, token.to(input_ids.device)), dim=-1),
+                                             attention_mask=attention_mask, head=self.base_model.lm_head,
+                                             logits_processors=self.drafter_logits_processors,
+                                             tree_type="static" if self.eagle_version == 1 else "dynamic")
+        new_token += n
+        return input_ids, output, new_token, token
+
+    # ------------------------------------------------------------------ :801-1017
+    @torch.no_grad()
+    def generate(self, input_ids, do_sample=True, max_new_tokens=2353, max_length=4096, cfg_scale=3.0, top_k=2000,
+                 logits_processors=None, eos_token_ids=None, lantern=False, lantern_k=1000, lantern_delta=0.1,
+                 tree_choices=mc_sim_7b_63, **kwargs):
+        self.cfg_scale = cfg_scale
+        self.ea_layer.cfg_scale = cfg_scale
+        self.internal_logits_processors = [self.internal_logits_processors[0], InterleavedTopKLogitsWarper(image_top_k=top_k)]
+        dk = kwargs.get("drafter_top_k") or top_k
+        self.drafter_logits_processors = [self.drafter_logits_processors[0], InterleavedTopKLogitsWarper(image_top_k=dk)]
+        image_start_sequence = torch.tensor([[8197, 8828, 8828]], dtype=torch.long).to(input_ids.device)
+        input_ids = torch.cat((input_ids, image_start_sequence), dim=-1)
+        self.eval()
+        accept_length_list = []
+        input_ids = input_ids.clone()
+        self.ea_layer.reset_kv()
+        dev = self.base_model.lm_head.weight.device
+        if self.eagle_version == 1:
+            if not (hasattr(self, "tree_choices") and self.tree_choices == tree_choices):
+                tree_buffers = generate_tree_buffers(tree_choices, device=dev)
+                tree_buffers["retrieve_indices_head"] = tree_buffers["retrieve_indices"]
+                if self.cfg_mode == "parallel":
+                    tree_buffers["tree_attn_mask"] = torch.cat((tree_buffers["tree_attn_mask"], tree_buffers["tree_attn_mask"]), dim=0)
+                self.tree_buffers = tree_buffers
+                self.tree_choices = tree_choices
+            tree_buffers = self.tree_buffers
+        if not hasattr(self, "past_key_values"):
+            if self.cfg_mode == "parallel":
+                self.past_key_values, self.past_key_values_data, self.current_length_data = \
+                    initialize_past_key_values(self.base_model, batch_size=2)
+            else:
+                self.past_key_values, self.past_key_values_data, self.current_length_data = {}, {}, {}
+                for key in ["cond", "uncond"]:
+                    (self.past_key_values[key], self.past_key_values_data[key],
+                     self.current_length_data[key]) = initialize_past_key_values(self.base_model)
+        past_key_values, past_key_values_data = self.past_key_values, self.past_key_values_data
+        current_length_data = self.current_length_data
+        for cl in ([current_length_data] if self.cfg_mode == "parallel" else current_length_data.values()):
+            cl.zero_()
+        input_len = input_ids.shape[1]
+        self.reset_tree_mode()
+        self.image_start_token_id_index = torch.where(input_ids[0] == self.image_start_token_id)[0][-1].item()
+        prompt_length = self.image_start_token_id_index
+        num_image_tokens = input_ids.shape[1] - prompt_length
+        zero_padding = torch.zeros((prompt_length), dtype=torch.bool, device=input_ids.device)
+        cond_attn_mask = torch.ones((input_ids.shape[1]), dtype=torch.bool, device=input_ids.device)
+        uncond_attn_mask = torch.cat((zero_padding, torch.ones((num_image_tokens), dtype=torch.bool, device=input_ids.device)), dim=-1)
+        attn_mask = torch.stack([cond_attn_mask, uncond_attn_mask], dim=0)
+        if self.cfg_mode == "parallel":
+            input_ids = input_ids.repeat(2, 1)
+        if self.eagle_version == 1:
+            tree_logits, sample_token = self.initialize_tree(input_ids=input_ids, attention_mask=attn_mask,
+                                                             tree_attn_mask=tree_buffers["tree_attn_mask"],
+                                                             past_key_values=past_key_values, logits_processors=logits_processors)
+            tree_position_ids = tree_buffers["tree_position_ids"]
+            retrieve_indices = tree_buffers["retrieve_indices_head"]
+        else:
+            tree_candidates, retrieve_indices, tree_mask, tree_position_ids = self.initialize_tree(
+                input_ids=input_ids, attention_mask=attn_mask, past_key_values=past_key_values, logits_processors=logits_processors)
+            if self.cfg_mode == "parallel":
+                tree_mask = tree_mask.repeat(2, 1, 1, 1)
+        new_token = 0
+        while new_token < max_new_tokens:
+            if self.eagle_version == 1:
+                candidates, cart_candidates_prob, tree_candidates = self.generate_candidates(
+                    tree_logits=tree_logits, tree_indices=tree_buffers["tree_indices"],
+                    retrieve_indices=tree_buffers["retrieve_indices"], sample_token=sample_token)
+            else:
+                self.base_model.model.tree_mask = tree_mask
+                tree_candidates = tree_candidates.to(input_ids.device)
+            logits, hidden_states_new, uncond_hidden_states_new = self.tree_decoding(
+                tree_candidates=tree_candidates, attention_mask=attn_mask, past_key_values=past_key_values,
+                tree_position_ids=tree_position_ids, input_ids=input_ids, retrieve_indices=retrieve_indices)
+            if self.eagle_version == 1:
+                original_prob, p_indices, b_indices = tree_logits[2], tree_buffers["p_indices"], tree_buffers["b_indices"]
+            else:
+                padding = (torch.zeros(1, 1, dtype=torch.long) - 1).to(input_ids.device)
+                tree_candidates = torch.cat((tree_candidates, padding), dim=1)
+                candidates = tree_candidates[0, retrieve_indices]
+                cart_candidates_prob = original_prob = p_indices = b_indices = None
+            best_candidate, accept_length, sample_p = self.evaluate_posterior(
+                logits=logits, candidates=candidates, cart_candidates_prob=cart_candidates_prob, original_prob=original_prob,
+                tree_candidates=tree_candidates, p_indices=p_indices, b_indices=b_indices, do_sample=do_sample, lantern=lantern,
+                lantern_k=lantern_k, lantern_delta=lantern_delta)
+            input_ids, output, new_token, sample_token = self.update_inference_inputs(
+                input_ids=input_ids, attention_mask=attn_mask, candidates=candidates, best_candidate=best_candidate,
+                accept_length=accept_length, retrieve_indices=retrieve_indices, do_sample=do_sample, new_token=new_token,
+                past_key_values_data=past_key_values_data, current_length_data=current_length_data,
+                hidden_states_new=hidden_states_new, uncond_hidden_states_new=uncond_hidden_states_new, sample_p=sample_p)
+            if self.eagle_version == 1:
+                tree_logits = output
+            else:
+                tree_candidates, retrieve_indices, tree_mask, tree_position_ids = output
+                if self.cfg_mode == "parallel":
+                    tree_mask = tree_mask.repeat(2, 1, 1, 1)
+            accept_length_list.append(accept_length + 1)
+            if eos_token_ids is not None and eos_token_ids in input_ids[0, input_len:].tolist():
+                break
+            if input_ids.shape[1] > max_length:
+                break
+        return input_ids, accept_length_list
+
+    # BASELINE.json's north_star calls the entry point `eagenerate`; the reference names it `generate`
+    eagenerate = generate

@@ -382,3 +382,27 @@ def sample_static(probs, idx):
     check(_lib.lib().lantern_sample_static(C.c_void_p(probs.data_ptr()), C.c_void_p(idx.data_ptr()), R, V, k,
                                            C.c_void_p(out.data_ptr()), _stream()), "sample_static")
     return out
+
+
+def evaluate_posterior_greedy(logits, row_index, cand, lantern=False, k=1000, delta=0.1, tok_offset=0, table=None):
+    """a9 greedy/TVD branch.  logits [B,rows,V] f32; row_index [P,D]|[B,P,D] i32; cand [B,P,D] i64.
+    Returns (best [B] i32, accept_len [B] i32, out_row [B,V] f32 = logits[best, accept_len])."""
+    logits = _dev(logits, torch.float32, "logits")
+    cand = _dev(cand, torch.int64, "cand")
+    row_index = _dev(row_index, torch.int32, "row_index")
+    B, P, D = cand.shape
+    V, rows = logits.shape[-1], logits.shape[-2]
+    dev = logits.device
+    best = torch.empty(B, dtype=torch.int32, device=dev)
+    alen = torch.empty(B, dtype=torch.int32, device=dev)
+    out = torch.empty((B, V), dtype=torch.float32, device=dev)
+    tr = tc = 0
+    if table is not None:
+        table = table.contiguous()
+        tr, tc = table.shape
+    check(_lib.lib().lantern_evaluate_posterior_greedy(
+        C.c_void_p(logits.data_ptr()), C.c_void_p(row_index.data_ptr()), C.c_void_p(cand.data_ptr()), B, P, D, V, rows,
+        int(row_index.dim() == 3), int(bool(lantern)), int(k), C.c_double(float(delta)), int(tok_offset), C.c_void_p(_ptr(table)),
+        tr, tc, C.c_void_p(best.data_ptr()), C.c_void_p(alen.data_ptr()), C.c_void_p(out.data_ptr()), _stream()),
+        "evaluate_posterior_greedy")
+    return best, alen, out

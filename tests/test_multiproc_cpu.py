@@ -1,0 +1,77 @@
+"""CPU, world_size 2 (gloo): the N>1 layout -- disjoint sequence shards, no data-path collective, timing
+reduced with MAX / tokens with SUM -- gives the same accepted-token total as one process running every
+sequence.  The per-rank compute is the oracle at a tiny size (no GPU here)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _tokens_for(seq_ids):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import cases as CS
+    import oracle
+    from lantern_amd.sharding import sequence_seed
+    tb = oracle.tree_static_build(CS.mc_sim_7b_63)
+    bufs = dict(tree_indices=tb["tree_indices"], tree_position_ids=tb["tree_position_ids"], tree_attn_mask=tb["tree_attn_mask"],
+                retrieve_indices=tb["retrieve_indices"])
+    m = CS.MODELS["lumina"]
+    N = len(tb["tree_indices"])
+    ri = tb["retrieve_indices"].copy()
+    ri[ri < 0] += N
+    cfg = oracle.EpConfig(mode=oracle.MODE_STATIC_LUMINA, syntax_shortcut=True, tok_offset=4, img_lo=4, img_hi=m["img_hi"],
+                          syntax=m["syntax"], lantern=True, k=50, delta=0.1)
+    table = CS.build_table(m["K"])
+    out = {}
+    for sid in seq_ids:
+        g = CS.gen_static(sequence_seed(9000, sid), "lumina", bufs, sigma=1.5)
+        ssp = CS.ss_prob_from(g["orig_prob"], g["ss_token"])
+        cand, cp, tc = oracle.gather_candidates(g["ss_token"], ssp, g["sample_token"], tb["tree_indices"], tb["retrieve_indices"])
+        aux = oracle.StaticAux(cart_prob=cp, orig_prob=g["orig_prob"], op_off=g["op_off"], p_idx=tb["p_indices"], b_off=tb["b_off"],
+                               b_idx=tb["b_idx"], tree_cand=tc)
+        _, alen, _, _ = oracle.evaluate_posterior(cfg, g["node_logits"], ri.astype(np.int32), cand, g["uniforms"], table=table, aux=aux)
+        out[sid] = alen + 1
+    return out
+
+
+def _worker(rank, world, port, per_rank, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path.insert(0, ROOT)
+    from lantern_amd.sharding import reduce_timing, sequence_ids
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    ids = sequence_ids(rank, world, per_rank)
+    toks = _tokens_for(ids)
+    dt, total = reduce_timing(dist, seconds=1.0 + rank, tokens=float(sum(toks.values())))
+    q.put((rank, ids, toks, dt, total))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_shards_equal_single_process():
+    world, per_rank = 2, 3
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_worker, args=(r, world, port, per_rank, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    single = _tokens_for(range(world * per_rank))
+    seen = {}
+    for rank, ids, toks, dt, total in res:
+        assert dt == 2.0                                   # MAX over ranks of (1.0, 2.0)
+        assert total == float(sum(single.values()))        # SUM over ranks == one process, all sequences
+        assert not (set(ids) & set(seen))                  # shards are disjoint
+        seen.update(toks)
+    assert seen == single

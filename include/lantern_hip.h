@@ -124,7 +124,8 @@ int lantern_gather_candidates(const int64_t *ss_token, const float *ss_prob, con
  * MultiModalLogitsProcessor :45-86 and InterleavedTopKLogitsWarper :106-112),
  * models/ea_model_anole.py:930-931, models/ea_model_llamagen.py:930.
  * [dev] cond/uncond [rows,V] in `dtype`; bf16 input reproduces torch's per-op bf16
- * rounding of u + s*(c-u).  pos_ids i64 = the value the reference passes as
+ * rounding of u + s*(c-u).  uncond == NULL: `cond` is already combined (mask / top-k only:
+ * the standalone MultiModalLogitsProcessor / InterleavedTopKLogitsWarper calls of the drafter).  pos_ids i64 = the value the reference passes as
  * `position_ids=` (tree_position_ids + len(input_ids) + 1);
  * num_generated_image_tokens = pos - pos_base (Lumina only).  Two forms:
  *   seq_len == NULL: pos_ids is [rows].

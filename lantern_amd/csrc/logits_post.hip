@@ -76,26 +76,29 @@ __global__ __launch_bounds__(LP_THREADS) void cfg_mask_topk_kernel(const void *_
                 float c[4], u[4];
                 if (BF16) {
                     const ushort4 cb = reinterpret_cast<const ushort4 *>((const uint16_t *)cond_ + (size_t)row * V)[i4];
-                    const ushort4 ub = reinterpret_cast<const ushort4 *>((const uint16_t *)uncond_ + (size_t)row * V)[i4];
+                    const ushort4 ub = uncond_ ? reinterpret_cast<const ushort4 *>((const uint16_t *)uncond_ + (size_t)row * V)[i4] : cb;
                     c[0] = bf16_bits_to_f32(cb.x); c[1] = bf16_bits_to_f32(cb.y);
                     c[2] = bf16_bits_to_f32(cb.z); c[3] = bf16_bits_to_f32(cb.w);
                     u[0] = bf16_bits_to_f32(ub.x); u[1] = bf16_bits_to_f32(ub.y);
                     u[2] = bf16_bits_to_f32(ub.z); u[3] = bf16_bits_to_f32(ub.w);
                 } else {
                     const float4 cf = reinterpret_cast<const float4 *>((const float *)cond_ + (size_t)row * V)[i4];
-                    const float4 uf = reinterpret_cast<const float4 *>((const float *)uncond_ + (size_t)row * V)[i4];
+                    const float4 uf = uncond_ ? reinterpret_cast<const float4 *>((const float *)uncond_ + (size_t)row * V)[i4] : cf;
                     c[0] = cf.x; c[1] = cf.y; c[2] = cf.z; c[3] = cf.w;
                     u[0] = uf.x; u[1] = uf.y; u[2] = uf.z; u[3] = uf.w;
                 }
                 float o[4];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    float t = c[q] - u[q];
-                    if (BF16) t = round_bf16(t);
-                    t = cfg * t;
-                    if (BF16) t = round_bf16(t);
-                    t = u[q] + t;
-                    if (BF16) t = round_bf16(t);
+                    float t = c[q];
+                    if (uncond_) {   // uncond == NULL: logits are already combined, mask / top-k only
+                        t = c[q] - u[q];
+                        if (BF16) t = round_bf16(t);
+                        t = cfg * t;
+                        if (BF16) t = round_bf16(t);
+                        t = u[q] + t;
+                        if (BF16) t = round_bf16(t);
+                    }
                     o[q] = (masked && (e + q < img_lo || e + q >= img_hi)) ? fill : t;
                 }
                 v = make_float4(o[0], o[1], o[2], o[3]);
@@ -170,7 +173,7 @@ extern "C" int lantern_cfg_mask_topk(const void *cond, const void *uncond, int d
                                      const int64_t *pos_ids, int64_t pos_base, int w_latent, int h_latent, int img_lo,
                                      int img_hi, int newline_id, int eos_id, int top_k, const int64_t *seq_len,
                                      int rows_per_seq, float *out, void *stream) {
-    LANTERN_CHECK_ARG(cond && uncond && out, "cfg_mask_topk: null buffer");
+    LANTERN_CHECK_ARG(cond && out, "cfg_mask_topk: null buffer");
     LANTERN_CHECK_ARG(rows >= 0 && V > 0 && V % 4 == 0 && V <= 4096 * 16, "cfg_mask_topk: bad rows=%d V=%d", rows, V);
     LANTERN_CHECK_ARG(dtype == LANTERN_F32 || dtype == LANTERN_BF16, "cfg_mask_topk: bad dtype %d", dtype);
     LANTERN_CHECK_ARG(model >= 0 && model <= 2, "cfg_mask_topk: bad model %d", model);

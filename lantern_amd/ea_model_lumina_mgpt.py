@@ -44,7 +44,7 @@ class MultiModalLogitsProcessor:
             return scores
         base = 2 if image_start_token_id_index is None else image_start_token_id_index + 1 + 2
         pos = position_ids.reshape(-1).to(torch.int64)
-        out = ops.cfg_mask_topk(scores, scores, 1.0, model=ops.MODEL_LUMINA, pos_ids=pos, pos_base=int(base), w=w_latent_dim,
+        out = ops.cfg_mask_topk(scores, None, 1.0, model=ops.MODEL_LUMINA, pos_ids=pos, pos_base=int(base), w=w_latent_dim,
                                 h=h_latent_dim, img_lo=IMAGE_LO, img_hi=IMAGE_HI, newline_id=self.image_next_line_token_id,
                                 eos_id=self.image_end_token_id, top_k=0)
         return out.to(scores.dtype)
@@ -61,7 +61,7 @@ class InterleavedTopKLogitsWarper:
         self.filter_value = filter_value
 
     def __call__(self, scores):
-        out = ops.cfg_mask_topk(scores, scores, 1.0, model=ops.MODEL_PLAIN, top_k=min(self.image_top_k, scores.size(-1)))
+        out = ops.cfg_mask_topk(scores, None, 1.0, model=ops.MODEL_PLAIN, top_k=min(self.image_top_k, scores.size(-1)))
         return out.to(scores.dtype)
 
 

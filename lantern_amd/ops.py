@@ -174,15 +174,16 @@ def cfg_mask_topk(cond, uncond, cfg: float, model: int = MODEL_PLAIN, pos_ids=No
     each sequence's len(input_ids)) pos_ids is the shared [rows_per_seq] tree_position_ids + 1."""
     if not cond.is_cuda:
         raise _lib.LanternError("cfg_mask_topk: expected device tensors")
-    assert cond.dtype == uncond.dtype and cond.dtype in (torch.float32, torch.bfloat16)
-    cond, uncond = cond.contiguous(), uncond.contiguous()
+    assert cond.dtype in (torch.float32, torch.bfloat16) and (uncond is None or uncond.dtype == cond.dtype)
+    cond = cond.contiguous()
+    uncond = None if uncond is None else uncond.contiguous()
     V = cond.shape[-1]
     rows = cond.numel() // V
     if out is None:
         out = torch.empty(cond.shape, dtype=torch.float32, device=cond.device)
     pos = None if pos_ids is None else _dev(pos_ids, torch.int64, "pos_ids").reshape(-1)
     check(_lib.lib().lantern_cfg_mask_topk(
-        C.c_void_p(cond.data_ptr()), C.c_void_p(uncond.data_ptr()), 1 if cond.dtype == torch.bfloat16 else 0, rows, V,
+        C.c_void_p(cond.data_ptr()), C.c_void_p(_ptr(uncond)), 1 if cond.dtype == torch.bfloat16 else 0, rows, V,
         C.c_float(cfg), model, C.c_void_p(_ptr(pos)), C.c_int64(pos_base), w, h, img_lo, img_hi, newline_id, eos_id, top_k,
         C.c_void_p(_ptr(seq_len)), rows_per_seq, C.c_void_p(out.data_ptr()), _stream()), "cfg_mask_topk")
     return out

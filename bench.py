@@ -43,6 +43,8 @@ def parse():
     ap.add_argument("--lantern-k", type=int, default=1000)
     ap.add_argument("--lantern-delta", type=float, default=0.1)
     ap.add_argument("--sigma", type=float, default=5.0, help="drafter noise; frozen at 5.0: mean accepted tokens/step ~2.6")
+    ap.add_argument("--path", choices=["window", "dense"], default="window",
+                    help="window: v2 kernels (32 KB image-window rows, LDS-resident residual); dense: v1 kernels (full-V rows)")
     ap.add_argument("--no-kv", action="store_true", help="skip the KV slabs (debug only; invalid as a headline)")
     ap.add_argument("--kv-smax", type=int, default=4096)
     ap.add_argument("--no-events", action="store_true", help="do not time individual kernels")
@@ -73,6 +75,10 @@ def cpu_baseline(wl, steps_budget_s: float, n_seq: int, gpu_tokens_by_seq):
     cond = wl.cond[:, :n_seq].cpu().view(torch.int16).numpy().view(np.uint16)
     uncond = wl.uncond[:, :n_seq].cpu().view(torch.int16).numpy().view(np.uint16)
     orig = wl.orig_prob[:, :n_seq].cpu().numpy()
+    if wl.windowed:     # the oracle takes the reference's dense [R,V] drafter rows: expand once, outside the timed region
+        dense = np.zeros(orig.shape[:-1] + (HN.V,), np.float32)
+        dense[..., HN.IMG_LO:HN.IMG_HI] = orig
+        orig = dense
     sst = wl.ss_token[:, :n_seq].cpu().numpy()
     ssp = wl.ss_prob[:, :n_seq].cpu().numpy()
     hid = wl.hidden[:, :n_seq].cpu().view(torch.int16).numpy()
@@ -162,6 +168,7 @@ def main():
 
     cfg = HN.WorkloadConfig(n_seq=args.seqs_per_gpu, pool_steps=args.pool_steps, lantern_k=args.lantern_k,
                             lantern_delta=args.lantern_delta, sigma=args.sigma, with_kv=not args.no_kv, kv_smax=args.kv_smax,
+                            path=args.path,
                             max_steps=args.steps + args.warmup + 8)
     wl = HN.LuminaVerifyWorkload(cfg, device, rank=rank)
 
@@ -202,7 +209,7 @@ def main():
                                    % cfg.kv_smax,
                        "lantern_k": cfg.lantern_k, "lantern_delta": cfg.lantern_delta, "seqs_per_gpu": cfg.n_seq,
                        "total_sequences": cfg.n_seq * world, "pool_steps": cfg.pool_steps, "drafter_sigma": cfg.sigma,
-                       "kv_cache": cfg.with_kv, "parallelism": f"dp{world} (independent sequences, no collective)"},
+                       "kv_cache": cfg.with_kv, "kernel_path": cfg.path, "parallelism": f"dp{world} (independent sequences, no collective)"},
             "mean_accept_length": float(alen.mean()),
             "per_step": {"levels": float(cnt[..., 0].mean()), "tried": float(cnt[..., 1].mean()), "rejected": float(cnt[..., 2].mean())},
         }
@@ -210,11 +217,14 @@ def main():
             def mean_ms(n):
                 return float(np.mean([e[n][0].elapsed_time(e[n][1]) for e in evs]))
             ep_ms = mean_ms("evaluate_posterior")
-            ep_bytes = wl.ep_algorithmic_bytes(W, W + K) / K
+            dense_bytes = wl.ep_algorithmic_bytes(W, W + K) / K
+            ep_bytes = wl.ep_window_bytes(W, W + K) / K if wl.windowed else dense_bytes
             ach = ep_bytes / (ep_ms * 1e-3) / 1e9
-            out["roofline"] = {"kernel": "ep_kernel (evaluate_posterior)", "bound": "hbm", "achieved": ach, "peak": 8000.0,
-                               "unit": "GB/s", "frac": ach / 8000.0, "traffic": None, "algorithmic_bytes_per_launch": ep_bytes,
-                               "avg_launch_ms": ep_ms}
+            out["roofline"] = {"kernel": "epw_kernel (evaluate_posterior, windowed)" if wl.windowed else "ep_kernel (evaluate_posterior)",
+                               "bound": "hbm", "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0, "traffic": None,
+                               "algorithmic_bytes_per_launch": ep_bytes, "avg_launch_ms": ep_ms,
+                               "dense_contract_bytes_per_launch": dense_bytes,
+                               "dense_contract_equivalent_GBps": dense_bytes / (ep_ms * 1e-3) / 1e9}
             o7_ms = mean_ms("cfg_mask_topk")
             o7_b = wl.o7_algorithmic_bytes(1)
             ks = {"cfg_mask_topk": {"avg_launch_ms": o7_ms, "algorithmic_bytes_per_launch": o7_b,

@@ -199,6 +199,51 @@ typedef struct lantern_ep_buffers {
 size_t lantern_evaluate_posterior_workspace(const lantern_ep_params *prm);
 int lantern_evaluate_posterior(const lantern_ep_params *prm, const lantern_ep_buffers *buf, void *stream);
 
+/* ------------------------------------------------------------------------------------
+ * Windowed (v2) form of O7 + O8 for models whose processed rows are -inf outside one id range
+ * (Lumina/Anole: image ids [4,8196); LlamaGen: the whole vocabulary).  Same results as the dense
+ * entry points; the rows cross HBM as `win_len` floats instead of V, the residual distribution
+ * lives in LDS, and the bonus token is drawn in the epilogue so the dense sample_p never has to
+ * exist.  A processed row is either a window row (finite values only inside the window) or a
+ * one-hot row (`row_hot[row]` = its token id, e.g. the forced newline / end-of-image rows of
+ * MultiModalLogitsProcessor); row_hot = -1 for window rows.
+ */
+
+/* O7 windowed: same arguments as lantern_cfg_mask_topk, output [rows, win_len] f32 + row_hot [rows].
+ * LANTERN_MODEL_PLAIN requires win_lo = 0, win_len = V. */
+int lantern_cfg_mask_topk_window(const void *cond, const void *uncond, int dtype, int rows, int V, float cfg,
+                                 int model, const int64_t *pos_ids, int64_t pos_base, int w_latent,
+                                 int h_latent, int img_lo, int img_hi, int newline_id, int eos_id, int top_k,
+                                 const int64_t *seq_len, int rows_per_seq, int win_lo, int win_len,
+                                 float *out_win, int32_t *row_hot, void *stream);
+
+typedef struct lantern_ep_window {
+    int32_t win_lo, win_len;      /* window = token ids [win_lo, win_lo+win_len); win_len % 4 == 0 */
+    const int32_t *row_hot;       /* [dev] [B*rows_per_seq] or NULL (all window rows) */
+    int32_t orig_prob_stride;     /* elements between drafter rows of buf->orig_prob (V for the dense
+                                     [B,R,V] layout, win_len for a windowed pool); row r of sequence b
+                                     starts at orig_prob + (b*R + r)*stride + orig_prob_offset */
+    int32_t orig_prob_offset;     /* win_lo for the dense layout, 0 for a windowed pool.  Precondition:
+                                     drafter rows are zero outside the window (they are masked like the
+                                     target rows: cnets_lumina_mgpt.py:1220-1224,1294-1298) */
+    float *sample_win;            /* [dev] [B,win_len] out or NULL: sample_p restricted to the window */
+    int32_t *out_tok;             /* [dev] [B] out: token id carrying mass outside the window, or -1 */
+    float *out_mass;              /* [dev] [B] out: its probability */
+    const double *u_bonus;        /* [dev] [B] or NULL: uniform for the bonus-token draw */
+    int64_t *token;               /* [dev] [B] out (with u_bonus): inverse-CDF bonus token */
+} lantern_ep_window;
+
+/* O8 windowed.  buf->logits is [B, rows_per_seq, win_len]; buf->sample_p may be NULL (if given, the dense
+ * [B,V] distribution is also written); buf->workspace unused.  counters[5] == LANTERN_ST_NEEDS_DENSE
+ * marks the (measure-zero) residual `gtp.sum()==0 -> ones` case, which only the dense kernel represents. */
+#define LANTERN_ST_NEEDS_DENSE 6
+int lantern_evaluate_posterior_window(const lantern_ep_params *prm, const lantern_ep_buffers *buf,
+                                      const lantern_ep_window *win, void *stream);
+
+/* window -> dense [B,V] (API compatibility with callers that want the reference's sample_p[V]). */
+int lantern_window_to_dense(const float *win, const int32_t *out_tok, const float *out_mass, int B, int V,
+                            int win_lo, int win_len, float *dense, void *stream);
+
 /* a9  greedy / TVD branch (temperature <= 1e-5): models/ea_model_llamagen.py:789-905,
  * models/ea_model_anole.py:790-905.  out_row [B,V] = logits[best, accept_len]. */
 int lantern_evaluate_posterior_greedy(const float *logits, const int32_t *row_index, const int64_t *cand,

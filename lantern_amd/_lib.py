@@ -37,6 +37,13 @@ class EpBuffers(C.Structure):
         "best", "accept_len", "sample_p", "counters")]
 
 
+class EpWindow(C.Structure):
+    _fields_ = [("win_lo", C.c_int32), ("win_len", C.c_int32), ("row_hot", C.c_void_p),
+                ("orig_prob_stride", C.c_int32), ("orig_prob_offset", C.c_int32),
+                ("sample_win", C.c_void_p), ("out_tok", C.c_void_p), ("out_mass", C.c_void_p),
+                ("u_bonus", C.c_void_p), ("token", C.c_void_p)]
+
+
 _lib = None
 
 
@@ -75,5 +82,6 @@ EXPORTS = [
     "lantern_expand_dynamic", "lantern_gather_candidates", "lantern_cfg_mask_topk",
     "lantern_evaluate_posterior_workspace", "lantern_evaluate_posterior", "lantern_evaluate_posterior_greedy",
     "lantern_kv_gather", "lantern_accept_gather", "lantern_sample_static", "lantern_drafter_fc",
-    "lantern_build_vq_table",
+    "lantern_build_vq_table", "lantern_cfg_mask_topk_window", "lantern_evaluate_posterior_window",
+    "lantern_window_to_dense",
 ]

@@ -1,0 +1,732 @@
+// window_kernels.hip -- v2 of the verify hot path: windowed O7 and O8 + window->dense.
+//
+// For Lumina / Anole every processed row is -inf outside the image-token range [4, 8196) (or is a
+// forced one-hot row), so a row is 8192 floats = 32 KB, not 65536 floats = 256 KB: it fits in LDS.
+//   cfg_window_kernel : one 256-thread workgroup per node row; reads only the window of cond/uncond,
+//                       k-th largest from registers, writes the 32 KB window (+ one int for one-hot rows).
+//   epw_kernel        : one 256-thread workgroup per sequence; the residual distribution `gtp` lives in
+//                       LDS for the whole step; per level one 32 KB row read, per tried candidate one
+//                       2 KB table-row read + an LDS gather + an f64 wave/block scan, per rejection one
+//                       32 KB drafter-row read (static trees); the bonus token is drawn from LDS in the
+//                       epilogue (inverse CDF), so the dense sample_p[V] never exists unless asked for.
+// Same arithmetic, same order of operations as the dense kernels (evaluate_posterior.hip).
+//
+// Reference: models/ea_model_lumina_mgpt.py:597-605 (O7), :610-726 (O8), :781 (bonus token);
+// models/ea_model_llamagen.py:597-669,709-787.
+#include "common.h"
+
+namespace lantern {
+
+constexpr int WN_THREADS = 256;
+constexpr int WN_NW = WN_THREADS / 64;
+
+__device__ __forceinline__ int64_t py_mod64(int64_t a, int64_t b) {
+    int64_t r = a % b;
+    return (r != 0 && ((r < 0) != (b < 0))) ? r + b : r;
+}
+
+// k-th largest over a register tile of E4 float4 (bitwise bisection, 32 passes)
+template <int E4>
+__device__ __forceinline__ float kth_largest_tile(const float4 (&r)[E4], int k, int *redi, int &ph) {
+    uint32_t prefix = 0;
+    for (int bit = 31; bit >= 0; --bit) {
+        const uint32_t trial = prefix | (1u << bit);
+        int c = 0;
+#pragma unroll
+        for (int it = 0; it < E4; ++it) {
+            c += float_key(r[it].x) >= trial;
+            c += float_key(r[it].y) >= trial;
+            c += float_key(r[it].z) >= trial;
+            c += float_key(r[it].w) >= trial;
+        }
+        const int tot = block_sum<int, WN_NW>(c, redi, ph);
+        if (tot >= k) prefix = trial;
+    }
+    return prefix == 0 ? -__builtin_inff() : key_float(prefix);
+}
+
+// ------------------------------------------------------------------------------- O7 windowed
+template <int E4, bool BF16>
+__global__ __launch_bounds__(WN_THREADS) void cfg_window_kernel(const void *__restrict__ cond_, const void *__restrict__ uncond_, int V,
+                                                                float cfg, int model, const int64_t *__restrict__ pos_ids,
+                                                                int64_t pos_base, int w_latent, int h_latent, int img_lo, int img_hi,
+                                                                int newline_id, int eos_id, int top_k,
+                                                                const int64_t *__restrict__ seq_len, int rows_per_seq, int win_lo, int W,
+                                                                float *__restrict__ out_win, int32_t *__restrict__ row_hot) {
+    __shared__ int s_redi[2 * WN_NW];
+    const int row = blockIdx.x, tid = threadIdx.x;
+    const float NEG_INF = -__builtin_inff();
+    float *out = out_win + (size_t)row * W;
+    int ph = 0;
+    int cls = 0;
+    if (model == LANTERN_MODEL_LUMINA) {
+        const int64_t pos = seq_len ? pos_ids[row % rows_per_seq] + seq_len[row / rows_per_seq] : pos_ids[row];
+        const int64_t n1 = pos - pos_base + 1;
+        if (n1 == ((int64_t)w_latent + 1) * h_latent + 1)
+            cls = 2;
+        else if (py_mod64(n1, (int64_t)w_latent + 1) == 0)
+            cls = 1;
+    }
+    if (cls != 0) {
+        const int hot = cls == 2 ? eos_id : newline_id;
+        if (tid == 0) row_hot[row] = hot;   // one-hot row: the window is never read (lantern_ep_window.row_hot)
+        return;
+    }
+    if (tid == 0) row_hot[row] = -1;
+    const bool lumina = model == LANTERN_MODEL_LUMINA;
+    const bool masked = model != LANTERN_MODEL_PLAIN;
+    const float fill = lumina ? NEG_INF : (BF16 ? __uint_as_float(0xff7f0000u) : -3.4028234663852886e38f);
+    float4 r[E4];
+#pragma unroll
+    for (int it = 0; it < E4; ++it) {
+        const int i4 = tid + it * WN_THREADS;
+        float4 v = make_float4(NEG_INF, NEG_INF, NEG_INF, NEG_INF);
+        if (i4 * 4 < W) {
+            const int e = win_lo + i4 * 4;
+            const size_t g4 = ((size_t)row * V + e) / 4;
+            float c[4], u[4];
+            if (BF16) {
+                const ushort4 cb = reinterpret_cast<const ushort4 *>(cond_)[g4];
+                const ushort4 ub = uncond_ ? reinterpret_cast<const ushort4 *>(uncond_)[g4] : cb;
+                c[0] = bf16_bits_to_f32(cb.x); c[1] = bf16_bits_to_f32(cb.y); c[2] = bf16_bits_to_f32(cb.z); c[3] = bf16_bits_to_f32(cb.w);
+                u[0] = bf16_bits_to_f32(ub.x); u[1] = bf16_bits_to_f32(ub.y); u[2] = bf16_bits_to_f32(ub.z); u[3] = bf16_bits_to_f32(ub.w);
+            } else {
+                const float4 cf = reinterpret_cast<const float4 *>(cond_)[g4];
+                const float4 uf = uncond_ ? reinterpret_cast<const float4 *>(uncond_)[g4] : cf;
+                c[0] = cf.x; c[1] = cf.y; c[2] = cf.z; c[3] = cf.w;
+                u[0] = uf.x; u[1] = uf.y; u[2] = uf.z; u[3] = uf.w;
+            }
+            float o[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float t = c[q];
+                if (uncond_) {
+                    t = c[q] - u[q];
+                    if (BF16) t = round_bf16(t);
+                    t = cfg * t;
+                    if (BF16) t = round_bf16(t);
+                    t = u[q] + t;
+                    if (BF16) t = round_bf16(t);
+                }
+                o[q] = (masked && (e + q < img_lo || e + q >= img_hi)) ? fill : t;
+            }
+            v = make_float4(o[0], o[1], o[2], o[3]);
+        }
+        r[it] = v;
+    }
+    if (top_k > 0 && top_k < V) {
+        // k-th largest of the FULL row = k-th largest of the window whenever k <= #window entries that
+        // beat the fill value; if fewer than k window entries exist the threshold is the fill value and
+        // nothing inside the window is removed.
+        const float thr = (top_k <= W) ? kth_largest_tile<E4>(r, top_k, s_redi, ph) : NEG_INF;
+#pragma unroll
+        for (int it = 0; it < E4; ++it) {
+            r[it].x = r[it].x < thr ? NEG_INF : r[it].x;
+            r[it].y = r[it].y < thr ? NEG_INF : r[it].y;
+            r[it].z = r[it].z < thr ? NEG_INF : r[it].z;
+            r[it].w = r[it].w < thr ? NEG_INF : r[it].w;
+        }
+    }
+#pragma unroll
+    for (int it = 0; it < E4; ++it) {
+        const int i4 = tid + it * WN_THREADS;
+        if (i4 * 4 < W) reinterpret_cast<float4 *>(out)[i4] = r[it];
+    }
+}
+
+// ------------------------------------------------------------------------------- O8 windowed
+constexpr int EW_MAX_P = 128, EW_MAX_D = 16, EW_MAX_PD = 1024, EW_MAX_SIB = 16;
+
+struct alignas(16) EwShared {
+    int cand[EW_MAX_PD];
+    int row[EW_MAX_PD];
+    int acc[EW_MAX_D];
+    int tried[EW_MAX_P];
+    int eq[EW_MAX_P];
+    int sib[EW_MAX_SIB];
+    double redd[2 * WN_NW];
+    float redf[2 * WN_NW];
+    int redi[2 * WN_NW];
+    double scan_tot[WN_NW];
+    double samp_tot[WN_NW][16];
+    int fi;
+};
+
+__host__ __device__ inline size_t epw_shared_offset(int W) {
+    size_t o = (size_t)W * 4 + (size_t)((W + 31) / 32) * 4;
+    return (o + 15) & ~(size_t)15;
+}
+
+// softmax(processors(row)) -> g (LDS).  Returns nothing; for one-hot rows g is the indicator inside
+// the window and (out_tok,out_mass) carry a hot token outside it.
+template <int E4>
+__device__ __forceinline__ void row_softmax_to_lds(const float *__restrict__ rowp, int hot, int win_lo, int W, float temperature, int top_k,
+                                                   int V, float *g, int &out_tok, float &out_mass, EwShared &S, int &ph) {
+    const int tid = threadIdx.x;
+    const float NEG_INF = -__builtin_inff();
+    out_tok = -1;
+    out_mass = 0.0f;
+    if (hot >= 0) {
+        // softmax of a row that is 0 at `hot` and -inf elsewhere (processors keep a one-hot row one-hot)
+        for (int i4 = tid; i4 * 4 < W; i4 += WN_THREADS) reinterpret_cast<float4 *>(g)[i4] = make_float4(0.f, 0.f, 0.f, 0.f);
+        __syncthreads();
+        if (tid == 0) {
+            if (hot >= win_lo && hot < win_lo + W) g[hot - win_lo] = 1.0f;
+        }
+        if (!(hot >= win_lo && hot < win_lo + W)) {
+            out_tok = hot;
+            out_mass = 1.0f;
+        }
+        __syncthreads();
+        return;
+    }
+    float4 r[E4];
+#pragma unroll
+    for (int it = 0; it < E4; ++it) {
+        const int i4 = tid + it * WN_THREADS;
+        r[it] = (i4 * 4 < W) ? reinterpret_cast<const float4 *>(rowp)[i4] : make_float4(NEG_INF, NEG_INF, NEG_INF, NEG_INF);
+    }
+    if (temperature > 1e-5f && temperature != 1.0f) {
+#pragma unroll
+        for (int it = 0; it < E4; ++it) {
+            r[it].x = r[it].x / temperature; r[it].y = r[it].y / temperature;
+            r[it].z = r[it].z / temperature; r[it].w = r[it].w / temperature;
+        }
+    }
+    if (top_k > 0 && top_k < V && top_k <= W) {
+        const float thr = kth_largest_tile<E4>(r, top_k, S.redi, ph);
+#pragma unroll
+        for (int it = 0; it < E4; ++it) {
+            r[it].x = r[it].x < thr ? NEG_INF : r[it].x; r[it].y = r[it].y < thr ? NEG_INF : r[it].y;
+            r[it].z = r[it].z < thr ? NEG_INF : r[it].z; r[it].w = r[it].w < thr ? NEG_INF : r[it].w;
+        }
+    }
+    float m = NEG_INF;
+#pragma unroll
+    for (int it = 0; it < E4; ++it) m = fmaxf(fmaxf(m, fmaxf(r[it].x, r[it].y)), fmaxf(r[it].z, r[it].w));
+    m = block_max<WN_NW>(m, S.redf, ph);
+    double s = 0.0;
+#pragma unroll
+    for (int it = 0; it < E4; ++it) {
+        r[it].x = expf(r[it].x - m); r[it].y = expf(r[it].y - m);
+        r[it].z = expf(r[it].z - m); r[it].w = expf(r[it].w - m);
+        s += (double)r[it].x + (double)r[it].y + (double)r[it].z + (double)r[it].w;
+    }
+    const float sf = (float)block_sum<double, WN_NW>(s, S.redd, ph);
+#pragma unroll
+    for (int it = 0; it < E4; ++it) {
+        const int i4 = tid + it * WN_THREADS;
+        if (i4 * 4 < W) reinterpret_cast<float4 *>(g)[i4] = make_float4(r[it].x / sf, r[it].y / sf, r[it].z / sf, r[it].w / sf);
+    }
+    __syncthreads();
+}
+
+template <int E4>
+__global__ __launch_bounds__(WN_THREADS) void epw_kernel(const lantern_ep_params prm, const lantern_ep_buffers buf,
+                                                         const lantern_ep_window win) {
+    // one dynamic LDS region (16-byte aligned base): [ g : W f32 | nbmask : W bits | EwShared ]
+    extern __shared__ float4 dyn_lds[];
+    float *g = reinterpret_cast<float *>(dyn_lds);
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int Ps = prm.P, Ds = prm.D, V = prm.V, W = win.win_len, lo = win.win_lo;
+    uint32_t *nbmask = reinterpret_cast<uint32_t *>(g + W);  // W bits: neighbour set (static LlamaGen/Anole: zeroing hits q)
+    EwShared &S = *reinterpret_cast<EwShared *>(reinterpret_cast<char *>(g) + epw_shared_offset(W));
+    const int P = buf.n_paths ? buf.n_paths[b] : Ps;
+    const int D = buf.n_depth ? buf.n_depth[b] : Ds;
+    const int k = prm.k, off = prm.tok_offset;
+    const bool is_static = prm.mode != LANTERN_MODE_DYNAMIC;
+    const float NEG_INF = -__builtin_inff();
+    int ph = 0;
+
+    const int64_t *cand_g = buf.cand + (size_t)b * Ps * Ds;
+    const int32_t *row_g = buf.row_index + (prm.row_index_per_seq ? (size_t)b * Ps * Ds : 0);
+    for (int t = tid; t < Ps * Ds; t += WN_THREADS) {
+        S.cand[t] = (int)cand_g[t];
+        S.row[t] = row_g[t];
+    }
+    const float *logits = buf.logits + (size_t)b * prm.rows_per_seq * W;
+    const int32_t *hot_g = win.row_hot ? win.row_hot + (size_t)b * prm.rows_per_seq : nullptr;
+    const double *uni = buf.uniforms + (size_t)b * prm.n_uniforms;
+    int ucur = buf.cursor ? buf.cursor[b] : 0;
+    const int u0 = ucur;
+    __syncthreads();
+    if (tid == 0) S.acc[0] = S.cand[0];
+    __syncthreads();
+
+    int a = 1, best = 0, adjust = 0, status = LANTERN_ST_OK;
+    int n_levels = 0, n_tried = 0, n_rej = 0;
+    int out_tok = -1;
+    float out_mass = 0.0f;
+
+    for (int i = 1; i < D && status == LANTERN_ST_OK; ++i) {
+        if (i != a) break;
+        adjust = 0;
+        ++n_levels;
+        if (tid < P) {
+            int eq = 1;
+            for (int t = 0; t < a; ++t) eq &= (S.cand[tid * Ds + t] == S.acc[t]);
+            S.eq[tid] = eq;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            int fi = -1;
+            for (int j = 0; j < P; ++j)
+                if (S.eq[j]) {
+                    fi = j;
+                    break;
+                }
+            S.fi = fi;
+        }
+        __syncthreads();
+        const int fi = S.fi;
+        if (fi < 0) {
+            status = LANTERN_ST_NO_PREFIX;
+            break;
+        }
+        {
+            const int rid = S.row[fi * Ds + (i - 1)];
+            row_softmax_to_lds<E4>(logits + (size_t)rid * W, hot_g ? hot_g[rid] : -1, lo, W, prm.temperature, prm.top_k, V, g, out_tok,
+                                   out_mass, S, ph);
+        }
+        int nset = 0;
+        for (int j = 0; j < P; ++j) {
+            if (!S.eq[j]) continue;
+            const int x = S.cand[j * Ds + i];
+            if (x == -1) continue;
+            bool dup = false;
+            for (int t = 0; t < nset; ++t) dup |= (S.tried[t] == x);
+            if (dup) continue;
+            if (tid == 0) S.tried[nset] = x;
+            ++nset;
+            __syncthreads();
+            if (x < 0 || x >= V) {
+                status = LANTERN_ST_TOKEN_OOB;
+                break;
+            }
+            if (ucur >= prm.n_uniforms) {
+                status = LANTERN_ST_UNIFORMS;
+                break;
+            }
+            const double r = uni[ucur++];
+            ++n_tried;
+            const bool x_in = (x >= lo && x < lo + W);
+            float px = x_in ? g[x - lo] : (x == out_tok ? out_mass : 0.0f);
+            int m = 0;
+            bool is_syn = false;
+            const bool in_img = (x >= prm.img_lo && x < prm.img_hi);
+            if (prm.syntax_shortcut)
+                for (int t = 0; t < prm.n_syntax; ++t) is_syn |= (x == prm.syntax[t]);
+            const uint16_t *nb = nullptr;
+            if (prm.syntax_shortcut && is_syn) {
+                px = 1.0f;
+            } else if (prm.syntax_shortcut && !in_img) {
+                px = 0.0f;
+            } else if (prm.lantern) {
+                const int trow = x - off;
+                if (trow < 0 || trow >= prm.table_rows) {
+                    status = LANTERN_ST_TABLE_OOB;
+                    break;
+                }
+                nb = buf.nn_table + (size_t)trow * prm.table_cols;
+                const float tau = prm.delta > 1.0 ? (float)(prm.delta - 1.0) * px : (float)prm.delta;
+                float csm1 = 0.0f;
+                double carry = 0.0;
+                for (int base = 0; base < k; base += WN_THREADS) {
+                    const int idx = base + tid;
+                    double v = 0.0;
+                    if (idx < k) {
+                        const int id = (int)nb[idx] + off;
+                        v = (id >= lo && id < lo + W) ? (double)g[id - lo] : (id == out_tok ? (double)out_mass : 0.0);
+                    }
+                    double inc = wave_scan_incl(v);
+                    if (lane == 63) S.scan_tot[wave] = inc;
+                    __syncthreads();
+                    double woff = 0.0, total = 0.0;
+#pragma unroll
+                    for (int w = 0; w < WN_NW; ++w) {
+                        const double t = S.scan_tot[w];
+                        woff += (w < wave) ? t : 0.0;
+                        total += t;
+                    }
+                    inc += woff + carry;
+                    const float cs = (float)inc;
+                    const bool ok = idx < k && cs <= tau;
+                    const int cnt = block_sum<int, WN_NW>(ok ? 1 : 0, S.redi, ph);
+                    const float mx = block_max<WN_NW>(ok ? cs : NEG_INF, S.redf, ph);
+                    if (cnt > 0) {
+                        m += cnt;
+                        csm1 = mx;
+                    }
+                    carry += total;
+                    const int chunk = (k - base) < WN_THREADS ? (k - base) : WN_THREADS;
+                    if (cnt < chunk) break;
+                }
+                if (m > 0) px = px + csm1;
+            }
+            float qx = 1.0f;
+            if (is_static) {
+                qx = buf.cart_prob[(size_t)b * Ps * Ds + j * Ds + i];
+                if (qx <= 0.0f) continue;
+            }
+            const float acp = px / qx;
+            if ((float)r <= acp) {
+                if (tid == 0) S.acc[a] = x;
+                ++a;
+                best = j;
+                __syncthreads();
+                break;
+            }
+            // ------------------------------------------------ rejection: residual, all in LDS
+            ++n_rej;
+            if (prm.syntax_shortcut && is_syn) {
+                status = LANTERN_ST_SYNTAX_REJECT;
+                break;
+            }
+            const bool zero_nb = prm.lantern && m > 0 && (!prm.syntax_shortcut || in_img);
+            const int nz = (k + 1 < prm.table_cols) ? k + 1 : prm.table_cols;
+            double loc = 0.0;
+            if (!is_static) {
+                if (tid == 0 && x_in) g[x - lo] = 0.0f;
+                if (!x_in && x == out_tok) out_mass = 0.0f;
+                if (zero_nb)
+                    for (int t = tid; t < nz; t += WN_THREADS) {
+                        const int id = (int)nb[t] + off;
+                        if (id >= lo && id < lo + W) g[id - lo] = 0.0f;
+                    }
+                if (zero_nb && out_tok >= 0) {
+                    // a neighbour id equal to the out-of-window hot token (never for Lumina/Anole tables)
+                    bool hit = false;
+                    for (int t = tid; t < nz; t += WN_THREADS) hit |= ((int)nb[t] + off == out_tok);
+                    if (block_sum<int, WN_NW>(hit ? 1 : 0, S.redi, ph) > 0) out_mass = 0.0f;
+                }
+                __syncthreads();
+                for (int i4 = tid; i4 * 4 < W; i4 += WN_THREADS) {
+                    const float4 v = reinterpret_cast<const float4 *>(g)[i4];
+                    loc += (double)v.x + (double)v.y + (double)v.z + (double)v.w;
+                }
+            } else {
+                const float *qsrc = buf.orig_prob + ((size_t)b * prm.R + buf.op_off[i - 1] + buf.p_idx[j * Ds + i]) * (size_t)win.orig_prob_stride +
+                                    win.orig_prob_offset;
+                const int b0 = buf.b_off[j * Ds + i], b1 = buf.b_off[j * Ds + i + 1];
+                int nsib = b1 - b0;
+                if (nsib > EW_MAX_SIB) nsib = EW_MAX_SIB;
+                if (tid < nsib) {
+                    const int64_t tok = buf.tree_cand[(size_t)b * prm.N + buf.b_idx[b0 + tid]];
+                    S.sib[tid] = (tok >= lo && tok < lo + W) ? (int)(tok - lo) : -1;
+                }
+                const bool lg_nb = zero_nb && prm.mode == LANTERN_MODE_STATIC_LG;
+                if (lg_nb)
+                    for (int t = tid; t < (W + 31) / 32; t += WN_THREADS) nbmask[t] = 0u;
+                __syncthreads();
+                if (lg_nb) {
+                    for (int t = tid; t < nz; t += WN_THREADS) {
+                        const int id = (int)nb[t] + off - lo;
+                        if (id >= 0 && id < W) atomicOr(&nbmask[id >> 5], 1u << (id & 31));
+                    }
+                }
+                if (zero_nb && prm.mode == LANTERN_MODE_STATIC_LUMINA)
+                    for (int t = tid; t < nz; t += WN_THREADS) {
+                        const int id = (int)nb[t] + off - lo;
+                        if (id >= 0 && id < W) g[id] = 0.0f;
+                    }
+                // drafter row -> registers (one HBM read), sibling tokens zeroed, f64 sum
+                float4 q[E4];
+                double qs_loc = 0.0;
+#pragma unroll
+                for (int it = 0; it < E4; ++it) {
+                    const int i4 = tid + it * WN_THREADS;
+                    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (i4 * 4 < W) {
+                        v = reinterpret_cast<const float4 *>(qsrc)[i4];
+                        const int e = i4 * 4;
+                        for (int t = 0; t < nsib; ++t) {
+                            const int sidx = S.sib[t];
+                            if (sidx >= e && sidx < e + 4) (&v.x)[sidx - e] = 0.0f;
+                        }
+                    }
+                    q[it] = v;
+                    qs_loc += (double)v.x + (double)v.y + (double)v.z + (double)v.w;
+                }
+                float qs = 1.0f;
+                if (nsib > 0) qs = (float)block_sum<double, WN_NW>(qs_loc, S.redd, ph);
+                __syncthreads();   // neighbour zeroing / mask visible
+#pragma unroll
+                for (int it = 0; it < E4; ++it) {
+                    const int i4 = tid + it * WN_THREADS;
+                    if (i4 * 4 < W) {
+                        float4 qv = q[it];
+                        if (nsib > 0) {
+                            qv.x = qv.x / qs; qv.y = qv.y / qs; qv.z = qv.z / qs; qv.w = qv.w / qs;
+                        }
+                        if (lg_nb) {
+                            const int e = i4 * 4;
+                            const uint32_t bits = nbmask[e >> 5] >> (e & 31);
+                            if (bits & 1u) qv.x = 0.f;
+                            if (bits & 2u) qv.y = 0.f;
+                            if (bits & 4u) qv.z = 0.f;
+                            if (bits & 8u) qv.w = 0.f;
+                        }
+                        float4 gv = reinterpret_cast<float4 *>(g)[i4];
+                        float d;
+                        d = gv.x - qv.x; gv.x = d < 0.0f ? 0.0f : d;
+                        d = gv.y - qv.y; gv.y = d < 0.0f ? 0.0f : d;
+                        d = gv.z - qv.z; gv.z = d < 0.0f ? 0.0f : d;
+                        d = gv.w - qv.w; gv.w = d < 0.0f ? 0.0f : d;
+                        reinterpret_cast<float4 *>(g)[i4] = gv;
+                        loc += (double)gv.x + (double)gv.y + (double)gv.z + (double)gv.w;
+                    }
+                }
+                // out-of-window mass: the drafter is zero there (precondition), max(out_mass - 0, 0) = out_mass
+            }
+            double tot = block_sum<double, WN_NW>(loc, S.redd, ph);
+            tot += (double)out_mass;
+            const float gs = (float)tot;
+            if (gs == 0.0f) {
+                status = LANTERN_ST_NEEDS_DENSE;   // `gtp.sum()==0 -> ones`: dense over all V, only the dense kernel holds it
+                break;
+            }
+            for (int i4 = tid; i4 * 4 < W; i4 += WN_THREADS) {
+                float4 v = reinterpret_cast<float4 *>(g)[i4];
+                v.x = v.x / gs; v.y = v.y / gs; v.z = v.z / gs; v.w = v.w / gs;
+                reinterpret_cast<float4 *>(g)[i4] = v;
+            }
+            out_mass = out_mass / gs;
+            __syncthreads();
+            adjust = 1;
+        }
+    }
+
+    const int from_residual = (adjust && a != D) ? 1 : 0;
+    if (status == LANTERN_ST_OK && !from_residual) {
+        const int rid = S.row[best * Ds + (a - 1)];
+        row_softmax_to_lds<E4>(logits + (size_t)rid * W, hot_g ? hot_g[rid] : -1, lo, W, prm.temperature, prm.top_k, V, g, out_tok, out_mass,
+                               S, ph);
+    }
+    // ---------------------------------------------------------------- epilogue: outputs from LDS
+    float4 p[E4];
+#pragma unroll
+    for (int it = 0; it < E4; ++it) {
+        const int i4 = tid + it * WN_THREADS;
+        p[it] = (i4 * 4 < W) ? reinterpret_cast<const float4 *>(g)[i4] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    if (win.sample_win) {
+        float *sw = win.sample_win + (size_t)b * W;
+#pragma unroll
+        for (int it = 0; it < E4; ++it) {
+            const int i4 = tid + it * WN_THREADS;
+            if (i4 * 4 < W) reinterpret_cast<float4 *>(sw)[i4] = p[it];
+        }
+    }
+    if (buf.sample_p) {   // optional dense copy (API compatibility)
+        float *sp = buf.sample_p + (size_t)b * V;
+        for (int i4 = tid; i4 * 4 < V; i4 += WN_THREADS) {
+            const int e = i4 * 4;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (e >= lo && e < lo + W) v = reinterpret_cast<const float4 *>(g)[(e - lo) / 4];
+            if (out_tok >= e && out_tok < e + 4) (&v.x)[out_tok - e] = out_mass;
+            reinterpret_cast<float4 *>(sp)[i4] = v;
+        }
+    }
+    if (win.u_bonus && win.token && status == LANTERN_ST_OK) {
+        // inverse CDF in token-id order.  Register tile order (it, tid, component) IS ascending token id.
+        const bool out_before = out_tok >= 0 && out_tok < lo;
+        double s4[E4], inc[E4];
+#pragma unroll
+        for (int it = 0; it < E4; ++it) {
+            s4[it] = (double)p[it].x + (double)p[it].y + (double)p[it].z + (double)p[it].w;
+            inc[it] = wave_scan_incl(s4[it]);
+            if (lane == 63) S.samp_tot[wave][it] = inc[it];
+        }
+        __syncthreads();
+        double base = out_before ? (double)out_mass : 0.0;   // mass in front of the window
+        double total = base;
+        double excl[E4];
+#pragma unroll
+        for (int it = 0; it < E4; ++it) {
+            double woff = 0.0, tt = 0.0;
+#pragma unroll
+            for (int w = 0; w < WN_NW; ++w) {
+                const double t = S.samp_tot[w][it];
+                woff += (w < wave) ? t : 0.0;
+                tt += t;
+            }
+            excl[it] = total + woff + (inc[it] - s4[it]);
+            total += tt;
+        }
+        if (out_tok >= 0 && !out_before) total += (double)out_mass;
+        const double tgt = win.u_bonus[b] * total;
+        int found = 0x7fffffff, last_pos = -1;
+        if (out_before && out_mass > 0.0f) {
+            last_pos = out_tok;
+            if ((double)out_mass > tgt) found = out_tok;
+        }
+#pragma unroll
+        for (int it = 0; it < E4; ++it) {
+            const int e = lo + (tid + it * WN_THREADS) * 4;
+            double acc = excl[it];
+            const float pv[4] = {p[it].x, p[it].y, p[it].z, p[it].w};
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                acc += (double)pv[c];
+                if (pv[c] > 0.0f) {
+                    last_pos = max(last_pos, e + c);
+                    if (acc > tgt) found = min(found, e + c);
+                }
+            }
+        }
+        if (out_tok >= 0 && !out_before && out_mass > 0.0f) {
+            last_pos = max(last_pos, out_tok);
+            if (total > tgt) found = min(found, out_tok);   // only reached when nothing in the window crossed
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            found = min(found, __shfl_xor(found, o, 64));
+            last_pos = max(last_pos, __shfl_xor(last_pos, o, 64));
+        }
+        __syncthreads();
+        if (lane == 0) {
+            S.redi[wave] = found;
+            S.redi[WN_NW + wave] = last_pos;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            int f = S.redi[0], l = S.redi[WN_NW];
+            for (int w = 1; w < WN_NW; ++w) {
+                f = min(f, S.redi[w]);
+                l = max(l, S.redi[WN_NW + w]);
+            }
+            win.token[b] = f != 0x7fffffff ? f : l;
+        }
+    }
+    if (tid == 0) {
+        buf.best[b] = best;
+        buf.accept_len[b] = a - 1;
+        int32_t *c = buf.counters + (size_t)b * 6;
+        c[0] = n_levels;
+        c[1] = n_tried;
+        c[2] = n_rej;
+        c[3] = ucur - u0;
+        c[4] = from_residual;
+        c[5] = status;
+        if (buf.cursor) buf.cursor[b] = ucur;
+        if (win.out_tok) win.out_tok[b] = out_tok;
+        if (win.out_mass) win.out_mass[b] = out_mass;
+    }
+}
+
+__global__ void window_to_dense_kernel(const float *__restrict__ winp, const int32_t *__restrict__ out_tok,
+                                       const float *__restrict__ out_mass, int V, int lo, int W, float *__restrict__ dense) {
+    const int b = blockIdx.y;
+    const int ot = out_tok ? out_tok[b] : -1;
+    const float om = out_mass ? out_mass[b] : 0.0f;
+    for (int i4 = blockIdx.x * blockDim.x + threadIdx.x; i4 * 4 < V; i4 += gridDim.x * blockDim.x) {
+        const int e = i4 * 4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (e >= lo && e < lo + W) v = reinterpret_cast<const float4 *>(winp + (size_t)b * W)[(e - lo) / 4];
+        if (ot >= e && ot < e + 4) (&v.x)[ot - e] = om;
+        reinterpret_cast<float4 *>(dense + (size_t)b * V)[i4] = v;
+    }
+}
+
+}  // namespace lantern
+
+using namespace lantern;
+
+template <int E4>
+static void launch_cfgw(bool bf16, int rows, hipStream_t st, const void *cond, const void *uncond, int V, float cfg, int model,
+                        const int64_t *pos_ids, int64_t pos_base, int w, int h, int img_lo, int img_hi, int nl, int eos, int top_k,
+                        const int64_t *seq_len, int rps, int win_lo, int W, float *out, int32_t *hot) {
+    if (bf16)
+        hipLaunchKernelGGL((cfg_window_kernel<E4, true>), dim3(rows), dim3(WN_THREADS), 0, st, cond, uncond, V, cfg, model, pos_ids, pos_base, w,
+                           h, img_lo, img_hi, nl, eos, top_k, seq_len, rps, win_lo, W, out, hot);
+    else
+        hipLaunchKernelGGL((cfg_window_kernel<E4, false>), dim3(rows), dim3(WN_THREADS), 0, st, cond, uncond, V, cfg, model, pos_ids, pos_base, w,
+                           h, img_lo, img_hi, nl, eos, top_k, seq_len, rps, win_lo, W, out, hot);
+}
+
+extern "C" int lantern_cfg_mask_topk_window(const void *cond, const void *uncond, int dtype, int rows, int V, float cfg, int model,
+                                            const int64_t *pos_ids, int64_t pos_base, int w_latent, int h_latent, int img_lo,
+                                            int img_hi, int newline_id, int eos_id, int top_k, const int64_t *seq_len,
+                                            int rows_per_seq, int win_lo, int win_len, float *out_win, int32_t *row_hot, void *stream) {
+    LANTERN_CHECK_ARG(cond && out_win && row_hot, "cfg_mask_topk_window: null buffer");
+    LANTERN_CHECK_ARG(rows >= 0 && V > 0 && V % 4 == 0, "cfg_mask_topk_window: bad rows=%d V=%d", rows, V);
+    LANTERN_CHECK_ARG(win_lo >= 0 && win_lo % 4 == 0 && win_len > 0 && win_len % 4 == 0 && win_lo + win_len <= V && win_len <= 16384,
+                      "cfg_mask_topk_window: window [%d,+%d) must be 4-aligned, inside V and <= 16384 wide", win_lo, win_len);
+    LANTERN_CHECK_ARG(dtype == LANTERN_F32 || dtype == LANTERN_BF16, "cfg_mask_topk_window: bad dtype");
+    LANTERN_CHECK_ARG(model >= 0 && model <= 2, "cfg_mask_topk_window: bad model");
+    if (model == LANTERN_MODEL_PLAIN)
+        LANTERN_CHECK_ARG(win_lo == 0 && win_len == V, "cfg_mask_topk_window: an unmasked model needs the window to be the whole vocabulary");
+    else
+        LANTERN_CHECK_ARG(img_lo >= win_lo && img_hi <= win_lo + win_len && img_lo < img_hi,
+                          "cfg_mask_topk_window: image range [%d,%d) must lie inside the window", img_lo, img_hi);
+    if (model == LANTERN_MODEL_LUMINA)
+        LANTERN_CHECK_ARG(pos_ids && w_latent > 0 && h_latent > 0 && newline_id >= 0 && newline_id < V && eos_id >= 0 && eos_id < V,
+                          "cfg_mask_topk_window: Lumina needs pos_ids, latent dims and syntax ids");
+    if (seq_len) LANTERN_CHECK_ARG(rows_per_seq > 0 && rows % rows_per_seq == 0, "cfg_mask_topk_window: rows %% rows_per_seq != 0");
+    if (rows == 0) return LANTERN_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const bool bf = dtype == LANTERN_BF16;
+#define CW_ARGS bf, rows, st, cond, uncond, V, cfg, model, pos_ids, pos_base, w_latent, h_latent, img_lo, img_hi, newline_id, eos_id, top_k, seq_len, rows_per_seq, win_lo, win_len, out_win, row_hot
+    if (win_len <= 1024) launch_cfgw<1>(CW_ARGS);
+    else if (win_len <= 2048) launch_cfgw<2>(CW_ARGS);
+    else if (win_len <= 4096) launch_cfgw<4>(CW_ARGS);
+    else if (win_len <= 8192) launch_cfgw<8>(CW_ARGS);
+    else launch_cfgw<16>(CW_ARGS);
+#undef CW_ARGS
+    LANTERN_CHECK_LAUNCH("cfg_mask_topk_window");
+    return LANTERN_OK;
+}
+
+extern "C" int lantern_evaluate_posterior_window(const lantern_ep_params *prm, const lantern_ep_buffers *buf,
+                                                 const lantern_ep_window *win, void *stream) {
+    LANTERN_CHECK_ARG(prm && buf && win, "evaluate_posterior_window: null params");
+    const lantern_ep_params &p = *prm;
+    LANTERN_CHECK_ARG(p.B >= 0 && p.P > 0 && p.D > 0 && p.V > 0 && p.V % 4 == 0, "evaluate_posterior_window: bad B/P/D/V");
+    if (p.B == 0) return LANTERN_OK;
+    LANTERN_CHECK_ARG(p.P <= EW_MAX_P && p.D <= EW_MAX_D && p.P * p.D <= EW_MAX_PD, "evaluate_posterior_window: P=%d D=%d exceed limits", p.P, p.D);
+    LANTERN_CHECK_ARG(win->win_lo >= 0 && win->win_lo % 4 == 0 && win->win_len > 0 && win->win_len % 4 == 0 &&
+                          win->win_lo + win->win_len <= p.V && win->win_len <= 16384,
+                      "evaluate_posterior_window: window [%d,+%d) must be 4-aligned, inside V and <= 16384 wide", win->win_lo, win->win_len);
+    LANTERN_CHECK_ARG(p.n_syntax >= 0 && p.n_syntax <= 8 && p.mode >= 0 && p.mode <= 2, "evaluate_posterior_window: bad mode/n_syntax");
+    LANTERN_CHECK_ARG(buf->logits && buf->row_index && buf->cand && buf->uniforms && buf->best && buf->accept_len && buf->counters,
+                      "evaluate_posterior_window: null required buffer");
+    if (p.mode != LANTERN_MODE_DYNAMIC)
+        LANTERN_CHECK_ARG(buf->cart_prob && buf->orig_prob && buf->op_off && buf->p_idx && buf->b_off && buf->b_idx && buf->tree_cand &&
+                              p.R > 0 && p.N > 0 && win->orig_prob_stride >= win->win_len && win->orig_prob_offset % 4 == 0 &&
+                              win->orig_prob_stride % 4 == 0,
+                          "evaluate_posterior_window: static mode needs cart_prob/orig_prob(+4-aligned stride/offset)/op_off/p_idx/b_off/b_idx/tree_cand");
+    if (p.lantern)
+        LANTERN_CHECK_ARG(buf->nn_table && p.k >= 1 && p.k <= p.table_cols && p.table_rows > 0, "evaluate_posterior_window: lantern needs nn_table, 1<=k<=cols");
+    if (win->u_bonus) LANTERN_CHECK_ARG(win->token, "evaluate_posterior_window: u_bonus needs token");
+    if (p.top_p > 0.0f && p.top_p < 1.0f) {
+        set_error("evaluate_posterior_window: top_p=%g inside the kernel is not built (use top_p=1)", (double)p.top_p);
+        return LANTERN_E_UNSUPPORTED;
+    }
+    if (p.top_k > win->win_len && p.top_k < p.V) {
+        set_error("evaluate_posterior_window: top_k=%d wider than the window (%d) needs the dense kernel", p.top_k, win->win_len);
+        return LANTERN_E_UNSUPPORTED;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    const int W = win->win_len;
+    const size_t lds = epw_shared_offset(W) + sizeof(EwShared);
+    dim3 grid(p.B), block(WN_THREADS);
+    if (W <= 1024) hipLaunchKernelGGL(epw_kernel<1>, grid, block, lds, st, p, *buf, *win);
+    else if (W <= 2048) hipLaunchKernelGGL(epw_kernel<2>, grid, block, lds, st, p, *buf, *win);
+    else if (W <= 4096) hipLaunchKernelGGL(epw_kernel<4>, grid, block, lds, st, p, *buf, *win);
+    else if (W <= 8192) hipLaunchKernelGGL(epw_kernel<8>, grid, block, lds, st, p, *buf, *win);
+    else hipLaunchKernelGGL(epw_kernel<16>, grid, block, lds, st, p, *buf, *win);
+    LANTERN_CHECK_LAUNCH("evaluate_posterior_window");
+    return LANTERN_OK;
+}
+
+extern "C" int lantern_window_to_dense(const float *winp, const int32_t *out_tok, const float *out_mass, int B, int V, int win_lo,
+                                       int win_len, float *dense, void *stream) {
+    LANTERN_CHECK_ARG(winp && dense && B >= 0 && V > 0 && V % 4 == 0 && win_lo % 4 == 0 && win_len % 4 == 0 && win_lo + win_len <= V,
+                      "window_to_dense: bad arguments");
+    if (B == 0) return LANTERN_OK;
+    int gx = (V / 4 + 255) / 256;
+    if (gx > 64) gx = 64;
+    hipLaunchKernelGGL(window_to_dense_kernel, dim3(gx, B), dim3(256), 0, (hipStream_t)stream, winp, out_tok, out_mass, V, win_lo, win_len, dense);
+    LANTERN_CHECK_LAUNCH("window_to_dense");
+    return LANTERN_OK;
+}

@@ -24,7 +24,7 @@ import numpy as np
 import torch
 
 from . import _lib, ops
-from ._lib import EpBuffers, EpParams, check
+from ._lib import EpBuffers, EpParams, EpWindow, check
 
 MC_SIM_7B_63 = [[0], [1], [2], [3], [0, 0], [0, 1], [0, 2], [1, 0], [1, 1], [2, 0], [2, 1], [3, 0],
                 [0, 0, 0], [0, 0, 1], [0, 0, 2], [0, 1, 0], [0, 1, 1], [0, 2, 0], [0, 2, 1], [1, 0, 0],
@@ -58,6 +58,7 @@ class WorkloadConfig:
     seed_base: int = 3000           # 1000 * config index (C3)
     max_steps: int = 4096           # uniform stream sizing
     table_seed: int = 0
+    path: str = "window"            # "window": v2 kernels (32 KB rows, LDS-resident residual); "dense": v1 kernels
 
 
 def build_neighbour_table(device, seed: int = 0) -> torch.Tensor:
@@ -106,7 +107,11 @@ class LuminaVerifyWorkload:
         # ---------------- pools (setup, untimed; torch is fine here)
         self.cond = torch.empty((S, B, N, V), dtype=torch.bfloat16, device=device)
         self.uncond = torch.empty((S, B, N, V), dtype=torch.bfloat16, device=device)
-        self.orig_prob = torch.empty((S, B, R, V), dtype=torch.float32, device=device)
+        self.windowed = cfg.path == "window"
+        self.win_lo, self.W = IMG_LO, IMG_HI - IMG_LO
+        # drafter distributions: dense [R,V] rows for the dense path; for the windowed path the pool holds what a
+        # windowed drafter softmax emits, [R,W] (zero outside the image range by construction)
+        self.orig_prob = torch.empty((S, B, R, self.W if self.windowed else V), dtype=torch.float32, device=device)
         self.ss_token = torch.empty((S, B, R, 10), dtype=torch.int64, device=device)
         self.ss_prob = torch.empty((S, B, R, 10), dtype=torch.float32, device=device)
         self.hidden = torch.empty((S, B, 2, N, HIDDEN), dtype=torch.bfloat16, device=device)
@@ -127,7 +132,7 @@ class LuminaVerifyWorkload:
             kth = torch.topk(dr, cfg.top_k, dim=-1).values[..., -1:]
             dr = dr.masked_fill(dr < kth, float("-inf"))
             op = torch.softmax(dr, dim=-1)
-            self.orig_prob[s] = op
+            self.orig_prob[s] = op[..., IMG_LO:IMG_HI] if self.windowed else op
             tok = torch.multinomial(op.view(-1, V), 10, replacement=False, generator=gen)
             self.ss_token[s] = tok.view(B, R, 10)
             self.ss_prob[s] = ops.sample_static(op.view(-1, V), tok).view(B, R, 10)
@@ -160,9 +165,16 @@ class LuminaVerifyWorkload:
         self.cand = torch.empty((B, P, D), dtype=torch.int64, device=device)
         self.cart_prob = torch.empty((B, P, D), dtype=torch.float32, device=device)
         self.tree_cand = torch.empty((B, N), dtype=torch.int64, device=device)
-        self.proc = torch.empty((B, N, V), dtype=torch.float32, device=device)
-        self.sample_p = torch.empty((B, V), dtype=torch.float32, device=device)
-        self.workspace = torch.empty((B, V), dtype=torch.float32, device=device)
+        if self.windowed:
+            self.proc = torch.empty((B, N, self.W), dtype=torch.float32, device=device)
+            self.row_hot = torch.empty((B, N), dtype=torch.int32, device=device)
+            self.out_tok = torch.empty(B, dtype=torch.int32, device=device)
+            self.out_mass = torch.empty(B, dtype=torch.float32, device=device)
+            self.sample_p = self.workspace = None
+        else:
+            self.proc = torch.empty((B, N, V), dtype=torch.float32, device=device)
+            self.sample_p = torch.empty((B, V), dtype=torch.float32, device=device)
+            self.workspace = torch.empty((B, V), dtype=torch.float32, device=device)
         self.out_hidden = torch.empty((B, 2, D, HIDDEN), dtype=torch.bfloat16, device=device)
         self.acc_tokens = torch.empty((B, D), dtype=torch.int64, device=device)
         self.log_best = torch.zeros((cfg.max_steps, B), dtype=torch.int32, device=device)
@@ -205,10 +217,20 @@ class LuminaVerifyWorkload:
         b.op_off, b.p_idx, b.b_off, b.b_idx = (self.d_op_off.data_ptr(), self.d_p_idx.data_ptr(), self.d_b_off.data_ptr(),
                                                self.d_b_idx.data_ptr())
         b.tree_cand, b.nn_table = self.tree_cand.data_ptr(), self.table.data_ptr()
-        b.uniforms, b.cursor, b.workspace = self.uniforms.data_ptr(), self.cursor.data_ptr(), self.workspace.data_ptr()
+        b.uniforms, b.cursor = self.uniforms.data_ptr(), self.cursor.data_ptr()
         b.best, b.accept_len = self.log_best[i].data_ptr(), self.log_alen[i].data_ptr()
-        b.sample_p, b.counters = self.sample_p.data_ptr(), self.log_cnt[i].data_ptr()
+        b.counters = self.log_cnt[i].data_ptr()
+        if not self.windowed:
+            b.workspace, b.sample_p = self.workspace.data_ptr(), self.sample_p.data_ptr()
         return b
+
+    def ep_window(self, i: int) -> EpWindow:
+        w = EpWindow()
+        w.win_lo, w.win_len, w.row_hot = self.win_lo, self.W, self.row_hot.data_ptr()
+        w.orig_prob_stride, w.orig_prob_offset = self.W, 0
+        w.out_tok, w.out_mass = self.out_tok.data_ptr(), self.out_mass.data_ptr()
+        w.u_bonus, w.token = self.u_bonus[i].data_ptr(), self.log_token[i].data_ptr()
+        return w
 
     # -------------------------------------------------------------------------------------
     def step(self, events=None):
@@ -230,16 +252,27 @@ class LuminaVerifyWorkload:
         # O7 CFG + Lumina position mask + top-k, positions from the device-side lengths
         if events:
             events["cfg_mask_topk"][0].record()
-        check(L.lantern_cfg_mask_topk(vp(self.cond[slot].data_ptr()), vp(self.uncond[slot].data_ptr()), 1, B * N, V,
-                                      C.c_float(c.cfg_scale), ops.MODEL_LUMINA, vp(self.d_pos_ids.data_ptr()),
-                                      C.c_int64(c.prompt_len + 3), W_LATENT, H_LATENT, IMG_LO, IMG_HI, NEWLINE, EOS, c.top_k,
-                                      vp(cur.data_ptr()), N, vp(self.proc.data_ptr()), st), "cfg_mask_topk")
+        if self.windowed:
+            check(L.lantern_cfg_mask_topk_window(vp(self.cond[slot].data_ptr()), vp(self.uncond[slot].data_ptr()), 1, B * N, V,
+                                                 C.c_float(c.cfg_scale), ops.MODEL_LUMINA, vp(self.d_pos_ids.data_ptr()),
+                                                 C.c_int64(c.prompt_len + 3), W_LATENT, H_LATENT, IMG_LO, IMG_HI, NEWLINE, EOS, c.top_k,
+                                                 vp(cur.data_ptr()), N, self.win_lo, self.W, vp(self.proc.data_ptr()),
+                                                 vp(self.row_hot.data_ptr()), st), "cfg_mask_topk_window")
+        else:
+            check(L.lantern_cfg_mask_topk(vp(self.cond[slot].data_ptr()), vp(self.uncond[slot].data_ptr()), 1, B * N, V,
+                                          C.c_float(c.cfg_scale), ops.MODEL_LUMINA, vp(self.d_pos_ids.data_ptr()),
+                                          C.c_int64(c.prompt_len + 3), W_LATENT, H_LATENT, IMG_LO, IMG_HI, NEWLINE, EOS, c.top_k,
+                                          vp(cur.data_ptr()), N, vp(self.proc.data_ptr()), st), "cfg_mask_topk")
         if events:
             events["cfg_mask_topk"][1].record()
             events["evaluate_posterior"][0].record()
         # O8
         buf = self.ep_buffers(slot, i)
-        check(L.lantern_evaluate_posterior(C.byref(self._ep_prm), C.byref(buf), st), "evaluate_posterior")
+        if self.windowed:      # bonus token drawn in the kernel epilogue
+            win = self.ep_window(i)
+            check(L.lantern_evaluate_posterior_window(C.byref(self._ep_prm), C.byref(buf), C.byref(win), st), "evaluate_posterior_window")
+        else:
+            check(L.lantern_evaluate_posterior(C.byref(self._ep_prm), C.byref(buf), st), "evaluate_posterior")
         if events:
             events["evaluate_posterior"][1].record()
         # O9 KV gather: both slabs of every sequence in one launch
@@ -257,8 +290,10 @@ class LuminaVerifyWorkload:
         # O10 accepted hidden + token append + bonus token (feeds the next step's O6)
         check(L.lantern_accept_gather(vp(self.hidden[slot].data_ptr()), 2, B, 2, N, HIDDEN, vp(self.d_retrieve.data_ptr()), 0, P, D,
                                       vp(self.cand.data_ptr()), vp(self.log_best[i].data_ptr()), vp(self.log_alen[i].data_ptr()),
-                                      vp(self.sample_p.data_ptr()), V, vp(self.u_bonus[i].data_ptr()), vp(self.out_hidden.data_ptr()),
-                                      vp(self.acc_tokens.data_ptr()), vp(self.log_token[i].data_ptr()), st), "accept_gather")
+                                      vp(None if self.windowed else self.sample_p.data_ptr()), V,
+                                      vp(None if self.windowed else self.u_bonus[i].data_ptr()), vp(self.out_hidden.data_ptr()),
+                                      vp(self.acc_tokens.data_ptr()), vp(None if self.windowed else self.log_token[i].data_ptr()), st),
+              "accept_gather")
         # harness bookkeeping (sequence management, not the hot path): next sample token, image wrap-around
         self.sample_token = self.log_token[i]
         done = (nxt - self.len_base) >= TOKENS_PER_IMAGE
@@ -278,8 +313,18 @@ class LuminaVerifyWorkload:
         n = c.shape[0] * c.shape[1]
         return float(Lv * V * 4 + T * k * 6 + Rj * (k + 1) * 4 + n * V * 4 + fresh * V * 4)
 
+    def ep_window_bytes(self, i0: int, i1: int) -> float:
+        """HBM bytes the windowed kernel must move: per visited level and per fresh final row one window row
+        (W*4); per tried candidate k table ids (k*2); per rejection one drafter window row (W*4, static trees).  The
+        neighbour gathers, zeroing, scans and the bonus-token draw run in LDS."""
+        c = self.log_cnt[i0:i1].to(torch.float64)
+        k, W = self.cfg.lantern_k, self.W
+        Lv, T, Rj, fresh = c[..., 0].sum(), c[..., 1].sum(), c[..., 2].sum(), (1 - c[..., 4]).sum()
+        return float((Lv + fresh) * W * 4 + T * k * 2 + Rj * (W * 4 + 2))
+
     def o7_algorithmic_bytes(self, n_steps: int) -> float:
-        return float(n_steps) * self.cfg.n_seq * self.N * V * (2 * 2 + 4)
+        per_row = self.W * (2 * 2 + 4) if self.windowed else V * (2 * 2 + 4)
+        return float(n_steps) * self.cfg.n_seq * self.N * per_row
 
     def kv_algorithmic_bytes(self, i0: int, i1: int) -> float:
         c = self.cfg

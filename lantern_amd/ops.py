@@ -14,7 +14,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import EpBuffers, EpParams, check
+from ._lib import EpBuffers, EpParams, EpWindow, check
 
 MODE_DYNAMIC, MODE_STATIC_LUMINA, MODE_STATIC_LG = 0, 1, 2
 MODEL_PLAIN, MODEL_LUMINA, MODEL_ANOLE = 0, 1, 2
@@ -407,3 +407,105 @@ def evaluate_posterior_greedy(logits, row_index, cand, lantern=False, k=1000, de
         tr, tc, C.c_void_p(best.data_ptr()), C.c_void_p(alen.data_ptr()), C.c_void_p(out.data_ptr()), _stream()),
         "evaluate_posterior_greedy")
     return best, alen, out
+
+
+# ------------------------------------------------------------------------- windowed (v2) path
+
+def cfg_mask_topk_window(cond, uncond, cfg: float, win_lo: int, win_len: int, model: int = MODEL_PLAIN, pos_ids=None,
+                         pos_base: int = 0, w: int = 48, h: int = 48, img_lo: int = 4, img_hi: int = 8196, newline_id: int = 8803,
+                         eos_id: int = 8196, top_k: int = 0, seq_len=None, rows_per_seq: int = 0, out=None, row_hot=None):
+    """O7 windowed: (out_win [rows,win_len] f32, row_hot [rows] i32)."""
+    if not cond.is_cuda:
+        raise _lib.LanternError("cfg_mask_topk_window: expected device tensors")
+    assert cond.dtype in (torch.float32, torch.bfloat16) and (uncond is None or uncond.dtype == cond.dtype)
+    cond = cond.contiguous()
+    uncond = None if uncond is None else uncond.contiguous()
+    V = cond.shape[-1]
+    rows = cond.numel() // V
+    if out is None:
+        out = torch.empty((*cond.shape[:-1], win_len), dtype=torch.float32, device=cond.device)
+    if row_hot is None:
+        row_hot = torch.empty(cond.shape[:-1], dtype=torch.int32, device=cond.device)
+    pos = None if pos_ids is None else _dev(pos_ids, torch.int64, "pos_ids").reshape(-1)
+    check(_lib.lib().lantern_cfg_mask_topk_window(
+        C.c_void_p(cond.data_ptr()), C.c_void_p(_ptr(uncond)), 1 if cond.dtype == torch.bfloat16 else 0, rows, V, C.c_float(cfg),
+        model, C.c_void_p(_ptr(pos)), C.c_int64(pos_base), w, h, img_lo, img_hi, newline_id, eos_id, top_k,
+        C.c_void_p(_ptr(seq_len)), rows_per_seq, win_lo, win_len, C.c_void_p(out.data_ptr()), C.c_void_p(row_hot.data_ptr()),
+        _stream()), "cfg_mask_topk_window")
+    return out, row_hot
+
+
+def evaluate_posterior_window(cfg: EpConfig, V: int, win_logits, win_lo: int, row_index, cand, uniforms, row_hot=None, table=None,
+                              aux: Optional[StaticAux] = None, orig_windowed: bool = False, n_paths=None, n_depth=None,
+                              cursor=None, u_bonus=None, want_dense: bool = False, want_window: bool = True):
+    """O8 windowed.  win_logits [B,rows,W] f32.  aux.orig_prob is the dense [B,R,V] pool (orig_windowed=False) or a
+    windowed [B,R,W] pool.  Returns dict(best, accept_len, counters, sample_win, out_tok, out_mass, token, sample_p)."""
+    win_logits = _dev(win_logits, torch.float32, "win_logits")
+    cand = _dev(cand, torch.int64, "cand")
+    uniforms = _dev(uniforms, torch.float64, "uniforms")
+    row_index = _dev(row_index, torch.int32, "row_index")
+    B, P, D = cand.shape
+    rows, W = win_logits.shape[-2], win_logits.shape[-1]
+    dev = win_logits.device
+    prm = EpParams()
+    prm.B, prm.P, prm.D, prm.V, prm.rows_per_seq = B, P, D, V, rows
+    prm.mode, prm.syntax_shortcut, prm.tok_offset = cfg.mode, int(cfg.syntax_shortcut), cfg.tok_offset
+    prm.img_lo, prm.img_hi = cfg.img_lo, min(cfg.img_hi, 2 ** 31 - 1)
+    prm.n_syntax = len(cfg.syntax)
+    for i, s in enumerate(cfg.syntax):
+        prm.syntax[i] = int(s)
+    prm.lantern, prm.k, prm.delta = int(cfg.lantern), int(cfg.k), float(cfg.delta)
+    prm.top_k, prm.temperature, prm.top_p = int(cfg.top_k), float(cfg.temperature), float(cfg.top_p)
+    prm.n_uniforms = uniforms.shape[1]
+    prm.row_index_per_seq = int(row_index.dim() == 3)
+    buf, win = EpBuffers(), EpWindow()
+    keep = []
+    if table is not None:
+        table = table.contiguous()
+        prm.table_rows, prm.table_cols = table.shape
+        buf.nn_table = table.data_ptr()
+    if aux is not None:
+        a = [_dev(aux.cart_prob, torch.float32, "cart_prob"), _dev(aux.orig_prob, torch.float32, "orig_prob"),
+             _dev(aux.op_off, torch.int32, "op_off"), _dev(aux.p_idx, torch.int32, "p_idx"), _dev(aux.b_off, torch.int32, "b_off"),
+             _dev(aux.b_idx, torch.int32, "b_idx"), _dev(aux.tree_cand, torch.int64, "tree_cand")]
+        keep.extend(a)
+        buf.cart_prob, buf.orig_prob, buf.op_off, buf.p_idx, buf.b_off, buf.b_idx, buf.tree_cand = [x.data_ptr() for x in a]
+        prm.R, prm.N = a[1].shape[1], a[6].shape[1]
+        win.orig_prob_stride = a[1].shape[-1]
+        win.orig_prob_offset = 0 if orig_windowed else win_lo
+    out = dict(best=torch.empty(B, dtype=torch.int32, device=dev), accept_len=torch.empty(B, dtype=torch.int32, device=dev),
+               counters=torch.empty((B, 6), dtype=torch.int32, device=dev), out_tok=torch.empty(B, dtype=torch.int32, device=dev),
+               out_mass=torch.empty(B, dtype=torch.float32, device=dev), sample_win=None, token=None, sample_p=None)
+    buf.logits, buf.row_index, buf.cand, buf.uniforms = win_logits.data_ptr(), row_index.data_ptr(), cand.data_ptr(), uniforms.data_ptr()
+    if n_paths is not None:
+        n_paths = _dev(n_paths, torch.int32, "n_paths"); buf.n_paths = n_paths.data_ptr()
+    if n_depth is not None:
+        n_depth = _dev(n_depth, torch.int32, "n_depth"); buf.n_depth = n_depth.data_ptr()
+    if cursor is not None:
+        buf.cursor = cursor.data_ptr()
+    buf.best, buf.accept_len, buf.counters = out["best"].data_ptr(), out["accept_len"].data_ptr(), out["counters"].data_ptr()
+    if want_dense:
+        out["sample_p"] = torch.empty((B, V), dtype=torch.float32, device=dev)
+        buf.sample_p = out["sample_p"].data_ptr()
+    win.win_lo, win.win_len = win_lo, W
+    if row_hot is not None:
+        row_hot = _dev(row_hot, torch.int32, "row_hot"); win.row_hot = row_hot.data_ptr()
+    if want_window:
+        out["sample_win"] = torch.empty((B, W), dtype=torch.float32, device=dev)
+        win.sample_win = out["sample_win"].data_ptr()
+    win.out_tok, win.out_mass = out["out_tok"].data_ptr(), out["out_mass"].data_ptr()
+    if u_bonus is not None:
+        u_bonus = _dev(u_bonus, torch.float64, "u_bonus")
+        out["token"] = torch.empty(B, dtype=torch.int64, device=dev)
+        win.u_bonus, win.token = u_bonus.data_ptr(), out["token"].data_ptr()
+    check(_lib.lib().lantern_evaluate_posterior_window(C.byref(prm), C.byref(buf), C.byref(win), _stream()), "evaluate_posterior_window")
+    return out
+
+
+def window_to_dense(sample_win, out_tok, out_mass, V: int, win_lo: int):
+    sample_win = _dev(sample_win, torch.float32, "sample_win")
+    B, W = sample_win.shape
+    dense = torch.empty((B, V), dtype=torch.float32, device=sample_win.device)
+    check(_lib.lib().lantern_window_to_dense(C.c_void_p(sample_win.data_ptr()), C.c_void_p(_ptr(out_tok)), C.c_void_p(_ptr(out_mass)),
+                                             B, V, win_lo, W, C.c_void_p(dense.data_ptr()), _stream()), "window_to_dense")
+    return dense

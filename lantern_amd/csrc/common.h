@@ -52,6 +52,14 @@ __device__ __forceinline__ float key_float(uint32_t k) {
     return __uint_as_float(u);
 }
 
+// v[c] = val for a runtime component index c in 0..3 (no pointer arithmetic across members)
+__device__ __forceinline__ void set_comp(float4 &v, int c, float val) {
+    v.x = (c == 0) ? val : v.x;
+    v.y = (c == 1) ? val : v.y;
+    v.z = (c == 2) ? val : v.z;
+    v.w = (c == 3) ? val : v.w;
+}
+
 template <typename T>
 __device__ __forceinline__ T wave_sum(T v) {
 #pragma unroll

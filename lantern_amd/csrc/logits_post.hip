@@ -53,7 +53,7 @@ __global__ __launch_bounds__(LP_THREADS) void cfg_mask_topk_kernel(const void *_
         for (int i4 = tid; i4 * 4 < V; i4 += LP_THREADS) {
             float4 v = make_float4(NEG_INF, NEG_INF, NEG_INF, NEG_INF);
             const int e = i4 * 4;
-            if (hot >= e && hot < e + 4) (&v.x)[hot - e] = 0.0f;
+            if (hot >= e && hot < e + 4) set_comp(v, hot - e, 0.0f);
             reinterpret_cast<float4 *>(out)[i4] = v;
         }
         return;  // top-k of a one-hot row removes nothing

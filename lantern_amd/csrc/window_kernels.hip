@@ -17,19 +17,19 @@
 
 namespace lantern {
 
-constexpr int WN_THREADS = 256;
-constexpr int WN_NW = WN_THREADS / 64;
 
 __device__ __forceinline__ int64_t py_mod64(int64_t a, int64_t b) {
     int64_t r = a % b;
     return (r != 0 && ((r < 0) != (b < 0))) ? r + b : r;
 }
 
-// k-th largest over a register tile of E4 float4 (bitwise bisection, 32 passes)
-template <int E4>
+// k-th largest over a register tile of E4 float4 held by NT threads: bitwise bisection on order-preserving
+// keys, one counting pass + one barrier per bit.  HIGH16: every value is bf16-representable (low 16 bits of
+// the float are zero), so the low half of the key is a function of the sign and 16 passes decide the key.
+template <int NT, int E4, bool HIGH16>
 __device__ __forceinline__ float kth_largest_tile(const float4 (&r)[E4], int k, int *redi, int &ph) {
     uint32_t prefix = 0;
-    for (int bit = 31; bit >= 0; --bit) {
+    for (int bit = 31; bit >= (HIGH16 ? 16 : 0); --bit) {
         const uint32_t trial = prefix | (1u << bit);
         int c = 0;
 #pragma unroll
@@ -39,21 +39,22 @@ __device__ __forceinline__ float kth_largest_tile(const float4 (&r)[E4], int k, 
             c += float_key(r[it].z) >= trial;
             c += float_key(r[it].w) >= trial;
         }
-        const int tot = block_sum<int, WN_NW>(c, redi, ph);
+        const int tot = block_sum<int, NT / 64>(c, redi, ph);
         if (tot >= k) prefix = trial;
     }
-    return prefix == 0 ? -__builtin_inff() : key_float(prefix);
+    if (prefix == 0) return -__builtin_inff();
+    if (HIGH16 && !(prefix & 0x80000000u)) prefix |= 0xffffu;   // negative float: key = ~bits, low half all ones
+    return key_float(prefix);
 }
 
 // ------------------------------------------------------------------------------- O7 windowed
-template <int E4, bool BF16>
-__global__ __launch_bounds__(WN_THREADS) void cfg_window_kernel(const void *__restrict__ cond_, const void *__restrict__ uncond_, int V,
-                                                                float cfg, int model, const int64_t *__restrict__ pos_ids,
-                                                                int64_t pos_base, int w_latent, int h_latent, int img_lo, int img_hi,
-                                                                int newline_id, int eos_id, int top_k,
-                                                                const int64_t *__restrict__ seq_len, int rows_per_seq, int win_lo, int W,
-                                                                float *__restrict__ out_win, int32_t *__restrict__ row_hot) {
-    __shared__ int s_redi[2 * WN_NW];
+template <int NT, int E4, bool BF16>
+__global__ __launch_bounds__(NT) void cfg_window_kernel(const void *__restrict__ cond_, const void *__restrict__ uncond_, int V, float cfg,
+                                                        int model, const int64_t *__restrict__ pos_ids, int64_t pos_base, int w_latent,
+                                                        int h_latent, int img_lo, int img_hi, int newline_id, int eos_id, int top_k,
+                                                        const int64_t *__restrict__ seq_len, int rows_per_seq, int win_lo, int W,
+                                                        float *__restrict__ out_win, int32_t *__restrict__ row_hot) {
+    __shared__ int s_redi[2 * (NT / 64)];
     const int row = blockIdx.x, tid = threadIdx.x;
     const float NEG_INF = -__builtin_inff();
     float *out = out_win + (size_t)row * W;
@@ -68,8 +69,7 @@ __global__ __launch_bounds__(WN_THREADS) void cfg_window_kernel(const void *__re
             cls = 1;
     }
     if (cls != 0) {
-        const int hot = cls == 2 ? eos_id : newline_id;
-        if (tid == 0) row_hot[row] = hot;   // one-hot row: the window is never read (lantern_ep_window.row_hot)
+        if (tid == 0) row_hot[row] = cls == 2 ? eos_id : newline_id;   // one-hot row: its window is never read
         return;
     }
     if (tid == 0) row_hot[row] = -1;
@@ -79,7 +79,7 @@ __global__ __launch_bounds__(WN_THREADS) void cfg_window_kernel(const void *__re
     float4 r[E4];
 #pragma unroll
     for (int it = 0; it < E4; ++it) {
-        const int i4 = tid + it * WN_THREADS;
+        const int i4 = tid + it * NT;
         float4 v = make_float4(NEG_INF, NEG_INF, NEG_INF, NEG_INF);
         if (i4 * 4 < W) {
             const int e = win_lo + i4 * 4;
@@ -115,10 +115,9 @@ __global__ __launch_bounds__(WN_THREADS) void cfg_window_kernel(const void *__re
         r[it] = v;
     }
     if (top_k > 0 && top_k < V) {
-        // k-th largest of the FULL row = k-th largest of the window whenever k <= #window entries that
-        // beat the fill value; if fewer than k window entries exist the threshold is the fill value and
-        // nothing inside the window is removed.
-        const float thr = (top_k <= W) ? kth_largest_tile<E4>(r, top_k, s_redi, ph) : NEG_INF;
+        // k-th largest of the FULL row = k-th largest of the window whenever >= k window entries beat the fill
+        // value; otherwise the threshold is the fill value (or lower) and nothing inside the window is removed.
+        const float thr = (top_k <= W) ? kth_largest_tile<NT, E4, BF16>(r, top_k, s_redi, ph) : NEG_INF;
 #pragma unroll
         for (int it = 0; it < E4; ++it) {
             r[it].x = r[it].x < thr ? NEG_INF : r[it].x;
@@ -129,27 +128,31 @@ __global__ __launch_bounds__(WN_THREADS) void cfg_window_kernel(const void *__re
     }
 #pragma unroll
     for (int it = 0; it < E4; ++it) {
-        const int i4 = tid + it * WN_THREADS;
+        const int i4 = tid + it * NT;
         if (i4 * 4 < W) reinterpret_cast<float4 *>(out)[i4] = r[it];
     }
 }
 
 // ------------------------------------------------------------------------------- O8 windowed
-constexpr int EW_MAX_P = 128, EW_MAX_D = 16, EW_MAX_PD = 1024, EW_MAX_SIB = 16;
+constexpr int EW_MAX_P = 64, EW_MAX_D = 16, EW_MAX_PD = 1024, EW_MAX_SIB = 16, EW_MAX_N = 128, EW_MAX_B = 1024, EW_UNI = 64;
 
 struct alignas(16) EwShared {
     int cand[EW_MAX_PD];
     int row[EW_MAX_PD];
+    float cart[EW_MAX_PD];
+    int pidx[EW_MAX_PD];
+    int boff[EW_MAX_PD + 1];
+    int bidx[EW_MAX_B];
+    int tcand[EW_MAX_N];
+    int opoff[EW_MAX_D];
+    double uni[EW_UNI];
     int acc[EW_MAX_D];
-    int tried[EW_MAX_P];
-    int eq[EW_MAX_P];
     int sib[EW_MAX_SIB];
-    double redd[2 * WN_NW];
-    float redf[2 * WN_NW];
-    int redi[2 * WN_NW];
-    double scan_tot[WN_NW];
-    double samp_tot[WN_NW][16];
-    int fi;
+    double redd[2 * 16];
+    float redf[2 * 16];
+    int redi[2 * 16];
+    double scan_tot[16];
+    double samp_tot[16][4];
 };
 
 __host__ __device__ inline size_t epw_shared_offset(int W) {
@@ -157,23 +160,25 @@ __host__ __device__ inline size_t epw_shared_offset(int W) {
     return (o + 15) & ~(size_t)15;
 }
 
-// softmax(processors(row)) -> g (LDS).  Returns nothing; for one-hot rows g is the indicator inside
-// the window and (out_tok,out_mass) carry a hot token outside it.
-template <int E4>
+// softmax(processors(row)) -> g (LDS); one-hot rows put their mass in (out_tok,out_mass) when the hot token
+// lies outside the window.
+template <int NT, int E4>
 __device__ __forceinline__ void row_softmax_to_lds(const float *__restrict__ rowp, int hot, int win_lo, int W, float temperature, int top_k,
                                                    int V, float *g, int &out_tok, float &out_mass, EwShared &S, int &ph) {
+    constexpr int NW = NT / 64;
     const int tid = threadIdx.x;
     const float NEG_INF = -__builtin_inff();
     out_tok = -1;
     out_mass = 0.0f;
     if (hot >= 0) {
-        // softmax of a row that is 0 at `hot` and -inf elsewhere (processors keep a one-hot row one-hot)
-        for (int i4 = tid; i4 * 4 < W; i4 += WN_THREADS) reinterpret_cast<float4 *>(g)[i4] = make_float4(0.f, 0.f, 0.f, 0.f);
-        __syncthreads();
-        if (tid == 0) {
-            if (hot >= win_lo && hot < win_lo + W) g[hot - win_lo] = 1.0f;
+        const bool inside = hot >= win_lo && hot < win_lo + W;
+        for (int i4 = tid; i4 * 4 < W; i4 += NT) {
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            const int e = win_lo + i4 * 4;
+            if (hot >= e && hot < e + 4) set_comp(v, hot - e, 1.0f);
+            reinterpret_cast<float4 *>(g)[i4] = v;
         }
-        if (!(hot >= win_lo && hot < win_lo + W)) {
+        if (!inside) {
             out_tok = hot;
             out_mass = 1.0f;
         }
@@ -183,7 +188,7 @@ __device__ __forceinline__ void row_softmax_to_lds(const float *__restrict__ row
     float4 r[E4];
 #pragma unroll
     for (int it = 0; it < E4; ++it) {
-        const int i4 = tid + it * WN_THREADS;
+        const int i4 = tid + it * NT;
         r[it] = (i4 * 4 < W) ? reinterpret_cast<const float4 *>(rowp)[i4] : make_float4(NEG_INF, NEG_INF, NEG_INF, NEG_INF);
     }
     if (temperature > 1e-5f && temperature != 1.0f) {
@@ -194,7 +199,7 @@ __device__ __forceinline__ void row_softmax_to_lds(const float *__restrict__ row
         }
     }
     if (top_k > 0 && top_k < V && top_k <= W) {
-        const float thr = kth_largest_tile<E4>(r, top_k, S.redi, ph);
+        const float thr = kth_largest_tile<NT, E4, false>(r, top_k, S.redi, ph);
 #pragma unroll
         for (int it = 0; it < E4; ++it) {
             r[it].x = r[it].x < thr ? NEG_INF : r[it].x; r[it].y = r[it].y < thr ? NEG_INF : r[it].y;
@@ -204,7 +209,7 @@ __device__ __forceinline__ void row_softmax_to_lds(const float *__restrict__ row
     float m = NEG_INF;
 #pragma unroll
     for (int it = 0; it < E4; ++it) m = fmaxf(fmaxf(m, fmaxf(r[it].x, r[it].y)), fmaxf(r[it].z, r[it].w));
-    m = block_max<WN_NW>(m, S.redf, ph);
+    m = block_max<NW>(m, S.redf, ph);
     double s = 0.0;
 #pragma unroll
     for (int it = 0; it < E4; ++it) {
@@ -212,18 +217,18 @@ __device__ __forceinline__ void row_softmax_to_lds(const float *__restrict__ row
         r[it].z = expf(r[it].z - m); r[it].w = expf(r[it].w - m);
         s += (double)r[it].x + (double)r[it].y + (double)r[it].z + (double)r[it].w;
     }
-    const float sf = (float)block_sum<double, WN_NW>(s, S.redd, ph);
+    const float sf = (float)block_sum<double, NW>(s, S.redd, ph);
 #pragma unroll
     for (int it = 0; it < E4; ++it) {
-        const int i4 = tid + it * WN_THREADS;
+        const int i4 = tid + it * NT;
         if (i4 * 4 < W) reinterpret_cast<float4 *>(g)[i4] = make_float4(r[it].x / sf, r[it].y / sf, r[it].z / sf, r[it].w / sf);
     }
     __syncthreads();
 }
 
-template <int E4>
-__global__ __launch_bounds__(WN_THREADS) void epw_kernel(const lantern_ep_params prm, const lantern_ep_buffers buf,
-                                                         const lantern_ep_window win) {
+template <int NT, int E4>
+__global__ __launch_bounds__(NT) void epw_kernel(const lantern_ep_params prm, const lantern_ep_buffers buf, const lantern_ep_window win) {
+    constexpr int NW = NT / 64;
     // one dynamic LDS region (16-byte aligned base): [ g : W f32 | nbmask : W bits | EwShared ]
     extern __shared__ float4 dyn_lds[];
     float *g = reinterpret_cast<float *>(dyn_lds);
@@ -238,23 +243,38 @@ __global__ __launch_bounds__(WN_THREADS) void epw_kernel(const lantern_ep_params
     const float NEG_INF = -__builtin_inff();
     int ph = 0;
 
-    const int64_t *cand_g = buf.cand + (size_t)b * Ps * Ds;
-    const int32_t *row_g = buf.row_index + (prm.row_index_per_seq ? (size_t)b * Ps * Ds : 0);
-    for (int t = tid; t < Ps * Ds; t += WN_THREADS) {
-        S.cand[t] = (int)cand_g[t];
-        S.row[t] = row_g[t];
+    // ---- stage every small per-step table in LDS with one round of global loads
+    const int ucur0 = buf.cursor ? buf.cursor[b] : 0;
+    {
+        const int64_t *cand_g = buf.cand + (size_t)b * Ps * Ds;
+        const int32_t *row_g = buf.row_index + (prm.row_index_per_seq ? (size_t)b * Ps * Ds : 0);
+        for (int t = tid; t < Ps * Ds; t += NT) {
+            S.cand[t] = (int)cand_g[t];
+            S.row[t] = row_g[t];
+            if (is_static) {
+                S.cart[t] = buf.cart_prob[(size_t)b * Ps * Ds + t];
+                S.pidx[t] = buf.p_idx[t];
+                S.boff[t] = buf.b_off[t];
+            }
+        }
+        if (is_static) {
+            if (tid == 0) S.boff[Ps * Ds] = buf.b_off[Ps * Ds];
+            const int nb_total = buf.b_off[Ps * Ds];
+            for (int t = tid; t < nb_total && t < EW_MAX_B; t += NT) S.bidx[t] = buf.b_idx[t];
+            for (int t = tid; t < prm.N && t < EW_MAX_N; t += NT) S.tcand[t] = (int)buf.tree_cand[(size_t)b * prm.N + t];
+            for (int t = tid; t < Ds - 1; t += NT) S.opoff[t] = buf.op_off[t];
+        }
+        const double *uni = buf.uniforms + (size_t)b * prm.n_uniforms;
+        for (int t = tid; t < EW_UNI; t += NT) S.uni[t] = (ucur0 + t < prm.n_uniforms) ? uni[ucur0 + t] : 2.0;   // 2.0 never drawn: guarded below
     }
     const float *logits = buf.logits + (size_t)b * prm.rows_per_seq * W;
     const int32_t *hot_g = win.row_hot ? win.row_hot + (size_t)b * prm.rows_per_seq : nullptr;
-    const double *uni = buf.uniforms + (size_t)b * prm.n_uniforms;
-    int ucur = buf.cursor ? buf.cursor[b] : 0;
-    const int u0 = ucur;
     __syncthreads();
     if (tid == 0) S.acc[0] = S.cand[0];
     __syncthreads();
 
     int a = 1, best = 0, adjust = 0, status = LANTERN_ST_OK;
-    int n_levels = 0, n_tried = 0, n_rej = 0;
+    int n_levels = 0, n_tried = 0, n_rej = 0, n_used = 0;
     int out_tok = -1;
     float out_mass = 0.0f;
 
@@ -262,52 +282,35 @@ __global__ __launch_bounds__(WN_THREADS) void epw_kernel(const lantern_ep_params
         if (i != a) break;
         adjust = 0;
         ++n_levels;
-        if (tid < P) {
-            int eq = 1;
-            for (int t = 0; t < a; ++t) eq &= (S.cand[tid * Ds + t] == S.acc[t]);
-            S.eq[tid] = eq;
-        }
-        __syncthreads();
-        if (tid == 0) {
-            int fi = -1;
-            for (int j = 0; j < P; ++j)
-                if (S.eq[j]) {
-                    fi = j;
-                    break;
-                }
-            S.fi = fi;
-        }
-        __syncthreads();
-        const int fi = S.fi;
-        if (fi < 0) {
+        // every wave recomputes the same masks: lane j <-> path j (P <= 64)
+        bool eq = lane < P;
+        for (int t = 0; t < a && eq; ++t) eq = (S.cand[lane * Ds + t] == S.acc[t]);
+        const unsigned long long eq_mask = __ballot(eq);
+        if (eq_mask == 0ull) {
             status = LANTERN_ST_NO_PREFIX;
             break;
         }
+        const int fi = __ffsll((long long)eq_mask) - 1;
+        const int x_lane = (lane < P) ? S.cand[lane * Ds + i] : -1;
         {
             const int rid = S.row[fi * Ds + (i - 1)];
-            row_softmax_to_lds<E4>(logits + (size_t)rid * W, hot_g ? hot_g[rid] : -1, lo, W, prm.temperature, prm.top_k, V, g, out_tok,
-                                   out_mass, S, ph);
+            row_softmax_to_lds<NT, E4>(logits + (size_t)rid * W, hot_g ? hot_g[rid] : -1, lo, W, prm.temperature, prm.top_k, V, g, out_tok,
+                                       out_mass, S, ph);
         }
-        int nset = 0;
-        for (int j = 0; j < P; ++j) {
-            if (!S.eq[j]) continue;
-            const int x = S.cand[j * Ds + i];
-            if (x == -1) continue;
-            bool dup = false;
-            for (int t = 0; t < nset; ++t) dup |= (S.tried[t] == x);
-            if (dup) continue;
-            if (tid == 0) S.tried[nset] = x;
-            ++nset;
-            __syncthreads();
+        unsigned long long todo = eq_mask & __ballot(x_lane != -1);
+        while (todo != 0ull) {
+            const int j = __ffsll((long long)todo) - 1;
+            const int x = __shfl(x_lane, j, 64);
+            todo &= ~__ballot(x_lane == x);     // this path and every later path carrying the same token
             if (x < 0 || x >= V) {
                 status = LANTERN_ST_TOKEN_OOB;
                 break;
             }
-            if (ucur >= prm.n_uniforms) {
+            if (n_used >= EW_UNI || ucur0 + n_used >= prm.n_uniforms) {
                 status = LANTERN_ST_UNIFORMS;
                 break;
             }
-            const double r = uni[ucur++];
+            const double r = S.uni[n_used++];
             ++n_tried;
             const bool x_in = (x >= lo && x < lo + W);
             float px = x_in ? g[x - lo] : (x == out_tok ? out_mass : 0.0f);
@@ -331,45 +334,60 @@ __global__ __launch_bounds__(WN_THREADS) void epw_kernel(const lantern_ep_params
                 const float tau = prm.delta > 1.0 ? (float)(prm.delta - 1.0) * px : (float)prm.delta;
                 float csm1 = 0.0f;
                 double carry = 0.0;
-                for (int base = 0; base < k; base += WN_THREADS) {
-                    const int idx = base + tid;
-                    double v = 0.0;
-                    if (idx < k) {
-                        const int id = (int)nb[idx] + off;
-                        v = (id >= lo && id < lo + W) ? (double)g[id - lo] : (id == out_tok ? (double)out_mass : 0.0);
+                // each thread owns 4 consecutive neighbours: 4 id loads in flight at once, one f64 scan per 4*NT ids
+                for (int base = 0; base < k; base += NT * 4) {
+                    const int i0 = base + tid * 4;
+                    int id[4];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) id[c] = (i0 + c < k) ? (int)nb[i0 + c] + off : -1;
+                    double v[4], loc = 0.0;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const int t = id[c];
+                        const float gv = (t >= lo && t < lo + W) ? g[t - lo] : ((t >= 0 && t == out_tok) ? out_mass : 0.0f);
+                        loc += (double)gv;
+                        v[c] = loc;            // inclusive local prefix
                     }
-                    double inc = wave_scan_incl(v);
+                    double inc = wave_scan_incl(loc);
                     if (lane == 63) S.scan_tot[wave] = inc;
                     __syncthreads();
                     double woff = 0.0, total = 0.0;
 #pragma unroll
-                    for (int w = 0; w < WN_NW; ++w) {
+                    for (int w = 0; w < NW; ++w) {
                         const double t = S.scan_tot[w];
                         woff += (w < wave) ? t : 0.0;
                         total += t;
                     }
-                    inc += woff + carry;
-                    const float cs = (float)inc;
-                    const bool ok = idx < k && cs <= tau;
-                    const int cnt = block_sum<int, WN_NW>(ok ? 1 : 0, S.redi, ph);
-                    const float mx = block_max<WN_NW>(ok ? cs : NEG_INF, S.redf, ph);
+                    const double excl = carry + woff + (inc - loc);
+                    int cnt_loc = 0;
+                    float mx_loc = NEG_INF;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const float cs = (float)(excl + v[c]);
+                        const bool ok = (i0 + c < k) && cs <= tau;
+                        cnt_loc += ok ? 1 : 0;
+                        mx_loc = ok ? fmaxf(mx_loc, cs) : mx_loc;
+                    }
+                    const int cnt = block_sum<int, NW>(cnt_loc, S.redi, ph);
+                    const float mx = block_max<NW>(mx_loc, S.redf, ph);
                     if (cnt > 0) {
                         m += cnt;
                         csm1 = mx;
                     }
                     carry += total;
-                    const int chunk = (k - base) < WN_THREADS ? (k - base) : WN_THREADS;
+                    const int chunk = (k - base) < NT * 4 ? (k - base) : NT * 4;
                     if (cnt < chunk) break;
                 }
                 if (m > 0) px = px + csm1;
             }
             float qx = 1.0f;
             if (is_static) {
-                qx = buf.cart_prob[(size_t)b * Ps * Ds + j * Ds + i];
+                qx = S.cart[j * Ds + i];
                 if (qx <= 0.0f) continue;
             }
             const float acp = px / qx;
             if ((float)r <= acp) {
+                __syncthreads();
                 if (tid == 0) S.acc[a] = x;
                 ++a;
                 best = j;
@@ -388,71 +406,68 @@ __global__ __launch_bounds__(WN_THREADS) void epw_kernel(const lantern_ep_params
             if (!is_static) {
                 if (tid == 0 && x_in) g[x - lo] = 0.0f;
                 if (!x_in && x == out_tok) out_mass = 0.0f;
-                if (zero_nb)
-                    for (int t = tid; t < nz; t += WN_THREADS) {
+                if (zero_nb) {
+                    bool hit = false;
+                    for (int t = tid; t < nz; t += NT) {
                         const int id = (int)nb[t] + off;
                         if (id >= lo && id < lo + W) g[id - lo] = 0.0f;
+                        hit |= (id == out_tok);
                     }
-                if (zero_nb && out_tok >= 0) {
-                    // a neighbour id equal to the out-of-window hot token (never for Lumina/Anole tables)
-                    bool hit = false;
-                    for (int t = tid; t < nz; t += WN_THREADS) hit |= ((int)nb[t] + off == out_tok);
-                    if (block_sum<int, WN_NW>(hit ? 1 : 0, S.redi, ph) > 0) out_mass = 0.0f;
+                    if (out_tok >= 0 && block_sum<int, NW>(hit ? 1 : 0, S.redi, ph) > 0) out_mass = 0.0f;
                 }
                 __syncthreads();
-                for (int i4 = tid; i4 * 4 < W; i4 += WN_THREADS) {
+                for (int i4 = tid; i4 * 4 < W; i4 += NT) {
                     const float4 v = reinterpret_cast<const float4 *>(g)[i4];
                     loc += (double)v.x + (double)v.y + (double)v.z + (double)v.w;
                 }
             } else {
-                const float *qsrc = buf.orig_prob + ((size_t)b * prm.R + buf.op_off[i - 1] + buf.p_idx[j * Ds + i]) * (size_t)win.orig_prob_stride +
+                const float *qsrc = buf.orig_prob + ((size_t)b * prm.R + S.opoff[i - 1] + S.pidx[j * Ds + i]) * (size_t)win.orig_prob_stride +
                                     win.orig_prob_offset;
-                const int b0 = buf.b_off[j * Ds + i], b1 = buf.b_off[j * Ds + i + 1];
+                // drafter row -> registers first (the one HBM read of a rejection), everything else overlaps it
+                float4 q[E4];
+#pragma unroll
+                for (int it = 0; it < E4; ++it) {
+                    const int i4 = tid + it * NT;
+                    q[it] = (i4 * 4 < W) ? reinterpret_cast<const float4 *>(qsrc)[i4] : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+                const int b0 = S.boff[j * Ds + i], b1 = S.boff[j * Ds + i + 1];
                 int nsib = b1 - b0;
                 if (nsib > EW_MAX_SIB) nsib = EW_MAX_SIB;
                 if (tid < nsib) {
-                    const int64_t tok = buf.tree_cand[(size_t)b * prm.N + buf.b_idx[b0 + tid]];
-                    S.sib[tid] = (tok >= lo && tok < lo + W) ? (int)(tok - lo) : -1;
+                    const int node = (b0 + tid < EW_MAX_B) ? S.bidx[b0 + tid] : 0;
+                    const int tok = (node >= 0 && node < EW_MAX_N) ? S.tcand[node] : -1;
+                    S.sib[tid] = (tok >= lo && tok < lo + W) ? (tok - lo) : -1;
                 }
                 const bool lg_nb = zero_nb && prm.mode == LANTERN_MODE_STATIC_LG;
                 if (lg_nb)
-                    for (int t = tid; t < (W + 31) / 32; t += WN_THREADS) nbmask[t] = 0u;
+                    for (int t = tid; t < (W + 31) / 32; t += NT) nbmask[t] = 0u;
                 __syncthreads();
-                if (lg_nb) {
-                    for (int t = tid; t < nz; t += WN_THREADS) {
+                if (lg_nb)
+                    for (int t = tid; t < nz; t += NT) {
                         const int id = (int)nb[t] + off - lo;
                         if (id >= 0 && id < W) atomicOr(&nbmask[id >> 5], 1u << (id & 31));
                     }
-                }
                 if (zero_nb && prm.mode == LANTERN_MODE_STATIC_LUMINA)
-                    for (int t = tid; t < nz; t += WN_THREADS) {
+                    for (int t = tid; t < nz; t += NT) {
                         const int id = (int)nb[t] + off - lo;
                         if (id >= 0 && id < W) g[id] = 0.0f;
                     }
-                // drafter row -> registers (one HBM read), sibling tokens zeroed, f64 sum
-                float4 q[E4];
                 double qs_loc = 0.0;
 #pragma unroll
                 for (int it = 0; it < E4; ++it) {
-                    const int i4 = tid + it * WN_THREADS;
-                    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (i4 * 4 < W) {
-                        v = reinterpret_cast<const float4 *>(qsrc)[i4];
-                        const int e = i4 * 4;
-                        for (int t = 0; t < nsib; ++t) {
-                            const int sidx = S.sib[t];
-                            if (sidx >= e && sidx < e + 4) (&v.x)[sidx - e] = 0.0f;
-                        }
+                    const int e = (tid + it * NT) * 4;
+                    for (int t = 0; t < nsib; ++t) {
+                        const int sidx = S.sib[t];
+                        if (sidx >= e && sidx < e + 4) set_comp(q[it], sidx - e, 0.0f);
                     }
-                    q[it] = v;
-                    qs_loc += (double)v.x + (double)v.y + (double)v.z + (double)v.w;
+                    qs_loc += (double)q[it].x + (double)q[it].y + (double)q[it].z + (double)q[it].w;
                 }
                 float qs = 1.0f;
-                if (nsib > 0) qs = (float)block_sum<double, WN_NW>(qs_loc, S.redd, ph);
+                if (nsib > 0) qs = (float)block_sum<double, NW>(qs_loc, S.redd, ph);
                 __syncthreads();   // neighbour zeroing / mask visible
 #pragma unroll
                 for (int it = 0; it < E4; ++it) {
-                    const int i4 = tid + it * WN_THREADS;
+                    const int i4 = tid + it * NT;
                     if (i4 * 4 < W) {
                         float4 qv = q[it];
                         if (nsib > 0) {
@@ -476,16 +491,16 @@ __global__ __launch_bounds__(WN_THREADS) void epw_kernel(const lantern_ep_params
                         loc += (double)gv.x + (double)gv.y + (double)gv.z + (double)gv.w;
                     }
                 }
-                // out-of-window mass: the drafter is zero there (precondition), max(out_mass - 0, 0) = out_mass
+                // out-of-window mass: the drafter is zero there (precondition): max(out_mass - 0, 0) = out_mass
             }
-            double tot = block_sum<double, WN_NW>(loc, S.redd, ph);
+            double tot = block_sum<double, NW>(loc, S.redd, ph);
             tot += (double)out_mass;
             const float gs = (float)tot;
             if (gs == 0.0f) {
-                status = LANTERN_ST_NEEDS_DENSE;   // `gtp.sum()==0 -> ones`: dense over all V, only the dense kernel holds it
+                status = LANTERN_ST_NEEDS_DENSE;   // `gtp.sum()==0 -> ones`: uniform over all V, only the dense kernel holds it
                 break;
             }
-            for (int i4 = tid; i4 * 4 < W; i4 += WN_THREADS) {
+            for (int i4 = tid; i4 * 4 < W; i4 += NT) {
                 float4 v = reinterpret_cast<float4 *>(g)[i4];
                 v.x = v.x / gs; v.y = v.y / gs; v.z = v.z / gs; v.w = v.w / gs;
                 reinterpret_cast<float4 *>(g)[i4] = v;
@@ -499,31 +514,31 @@ __global__ __launch_bounds__(WN_THREADS) void epw_kernel(const lantern_ep_params
     const int from_residual = (adjust && a != D) ? 1 : 0;
     if (status == LANTERN_ST_OK && !from_residual) {
         const int rid = S.row[best * Ds + (a - 1)];
-        row_softmax_to_lds<E4>(logits + (size_t)rid * W, hot_g ? hot_g[rid] : -1, lo, W, prm.temperature, prm.top_k, V, g, out_tok, out_mass,
-                               S, ph);
+        row_softmax_to_lds<NT, E4>(logits + (size_t)rid * W, hot_g ? hot_g[rid] : -1, lo, W, prm.temperature, prm.top_k, V, g, out_tok,
+                                   out_mass, S, ph);
     }
     // ---------------------------------------------------------------- epilogue: outputs from LDS
     float4 p[E4];
 #pragma unroll
     for (int it = 0; it < E4; ++it) {
-        const int i4 = tid + it * WN_THREADS;
+        const int i4 = tid + it * NT;
         p[it] = (i4 * 4 < W) ? reinterpret_cast<const float4 *>(g)[i4] : make_float4(0.f, 0.f, 0.f, 0.f);
     }
     if (win.sample_win) {
         float *sw = win.sample_win + (size_t)b * W;
 #pragma unroll
         for (int it = 0; it < E4; ++it) {
-            const int i4 = tid + it * WN_THREADS;
+            const int i4 = tid + it * NT;
             if (i4 * 4 < W) reinterpret_cast<float4 *>(sw)[i4] = p[it];
         }
     }
     if (buf.sample_p) {   // optional dense copy (API compatibility)
         float *sp = buf.sample_p + (size_t)b * V;
-        for (int i4 = tid; i4 * 4 < V; i4 += WN_THREADS) {
+        for (int i4 = tid; i4 * 4 < V; i4 += NT) {
             const int e = i4 * 4;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (e >= lo && e < lo + W) v = reinterpret_cast<const float4 *>(g)[(e - lo) / 4];
-            if (out_tok >= e && out_tok < e + 4) (&v.x)[out_tok - e] = out_mass;
+            if (out_tok >= e && out_tok < e + 4) set_comp(v, out_tok - e, out_mass);
             reinterpret_cast<float4 *>(sp)[i4] = v;
         }
     }
@@ -538,14 +553,13 @@ __global__ __launch_bounds__(WN_THREADS) void epw_kernel(const lantern_ep_params
             if (lane == 63) S.samp_tot[wave][it] = inc[it];
         }
         __syncthreads();
-        double base = out_before ? (double)out_mass : 0.0;   // mass in front of the window
-        double total = base;
+        double total = out_before ? (double)out_mass : 0.0;   // mass in front of the window
         double excl[E4];
 #pragma unroll
         for (int it = 0; it < E4; ++it) {
             double woff = 0.0, tt = 0.0;
 #pragma unroll
-            for (int w = 0; w < WN_NW; ++w) {
+            for (int w = 0; w < NW; ++w) {
                 const double t = S.samp_tot[w][it];
                 woff += (w < wave) ? t : 0.0;
                 tt += t;
@@ -562,7 +576,7 @@ __global__ __launch_bounds__(WN_THREADS) void epw_kernel(const lantern_ep_params
         }
 #pragma unroll
         for (int it = 0; it < E4; ++it) {
-            const int e = lo + (tid + it * WN_THREADS) * 4;
+            const int e = lo + (tid + it * NT) * 4;
             double acc = excl[it];
             const float pv[4] = {p[it].x, p[it].y, p[it].z, p[it].w};
 #pragma unroll
@@ -576,7 +590,7 @@ __global__ __launch_bounds__(WN_THREADS) void epw_kernel(const lantern_ep_params
         }
         if (out_tok >= 0 && !out_before && out_mass > 0.0f) {
             last_pos = max(last_pos, out_tok);
-            if (total > tgt) found = min(found, out_tok);   // only reached when nothing in the window crossed
+            if (total > tgt) found = min(found, out_tok);   // only wins when nothing inside the window crossed
         }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {
@@ -586,14 +600,14 @@ __global__ __launch_bounds__(WN_THREADS) void epw_kernel(const lantern_ep_params
         __syncthreads();
         if (lane == 0) {
             S.redi[wave] = found;
-            S.redi[WN_NW + wave] = last_pos;
+            S.redi[16 + wave] = last_pos;
         }
         __syncthreads();
         if (tid == 0) {
-            int f = S.redi[0], l = S.redi[WN_NW];
-            for (int w = 1; w < WN_NW; ++w) {
+            int f = S.redi[0], l = S.redi[16];
+            for (int w = 1; w < NW; ++w) {
                 f = min(f, S.redi[w]);
-                l = max(l, S.redi[WN_NW + w]);
+                l = max(l, S.redi[16 + w]);
             }
             win.token[b] = f != 0x7fffffff ? f : l;
         }
@@ -605,10 +619,10 @@ __global__ __launch_bounds__(WN_THREADS) void epw_kernel(const lantern_ep_params
         c[0] = n_levels;
         c[1] = n_tried;
         c[2] = n_rej;
-        c[3] = ucur - u0;
+        c[3] = n_used;
         c[4] = from_residual;
         c[5] = status;
-        if (buf.cursor) buf.cursor[b] = ucur;
+        if (buf.cursor) buf.cursor[b] = ucur0 + n_used;
         if (win.out_tok) win.out_tok[b] = out_tok;
         if (win.out_mass) win.out_mass[b] = out_mass;
     }
@@ -623,7 +637,7 @@ __global__ void window_to_dense_kernel(const float *__restrict__ winp, const int
         const int e = i4 * 4;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (e >= lo && e < lo + W) v = reinterpret_cast<const float4 *>(winp + (size_t)b * W)[(e - lo) / 4];
-        if (ot >= e && ot < e + 4) (&v.x)[ot - e] = om;
+        if (ot >= e && ot < e + 4) set_comp(v, ot - e, om);
         reinterpret_cast<float4 *>(dense + (size_t)b * V)[i4] = v;
     }
 }
@@ -632,15 +646,15 @@ __global__ void window_to_dense_kernel(const float *__restrict__ winp, const int
 
 using namespace lantern;
 
-template <int E4>
+template <int NT, int E4>
 static void launch_cfgw(bool bf16, int rows, hipStream_t st, const void *cond, const void *uncond, int V, float cfg, int model,
                         const int64_t *pos_ids, int64_t pos_base, int w, int h, int img_lo, int img_hi, int nl, int eos, int top_k,
                         const int64_t *seq_len, int rps, int win_lo, int W, float *out, int32_t *hot) {
     if (bf16)
-        hipLaunchKernelGGL((cfg_window_kernel<E4, true>), dim3(rows), dim3(WN_THREADS), 0, st, cond, uncond, V, cfg, model, pos_ids, pos_base, w,
+        hipLaunchKernelGGL((cfg_window_kernel<NT, E4, true>), dim3(rows), dim3(NT), 0, st, cond, uncond, V, cfg, model, pos_ids, pos_base, w,
                            h, img_lo, img_hi, nl, eos, top_k, seq_len, rps, win_lo, W, out, hot);
     else
-        hipLaunchKernelGGL((cfg_window_kernel<E4, false>), dim3(rows), dim3(WN_THREADS), 0, st, cond, uncond, V, cfg, model, pos_ids, pos_base, w,
+        hipLaunchKernelGGL((cfg_window_kernel<NT, E4, false>), dim3(rows), dim3(NT), 0, st, cond, uncond, V, cfg, model, pos_ids, pos_base, w,
                            h, img_lo, img_hi, nl, eos, top_k, seq_len, rps, win_lo, W, out, hot);
 }
 
@@ -667,11 +681,11 @@ extern "C" int lantern_cfg_mask_topk_window(const void *cond, const void *uncond
     hipStream_t st = (hipStream_t)stream;
     const bool bf = dtype == LANTERN_BF16;
 #define CW_ARGS bf, rows, st, cond, uncond, V, cfg, model, pos_ids, pos_base, w_latent, h_latent, img_lo, img_hi, newline_id, eos_id, top_k, seq_len, rows_per_seq, win_lo, win_len, out_win, row_hot
-    if (win_len <= 1024) launch_cfgw<1>(CW_ARGS);
-    else if (win_len <= 2048) launch_cfgw<2>(CW_ARGS);
-    else if (win_len <= 4096) launch_cfgw<4>(CW_ARGS);
-    else if (win_len <= 8192) launch_cfgw<8>(CW_ARGS);
-    else launch_cfgw<16>(CW_ARGS);
+    if (win_len <= 1024) launch_cfgw<256, 1>(CW_ARGS);
+    else if (win_len <= 2048) launch_cfgw<256, 2>(CW_ARGS);
+    else if (win_len <= 4096) launch_cfgw<1024, 1>(CW_ARGS);
+    else if (win_len <= 8192) launch_cfgw<1024, 2>(CW_ARGS);
+    else launch_cfgw<1024, 4>(CW_ARGS);
 #undef CW_ARGS
     LANTERN_CHECK_LAUNCH("cfg_mask_topk_window");
     return LANTERN_OK;
@@ -683,7 +697,8 @@ extern "C" int lantern_evaluate_posterior_window(const lantern_ep_params *prm, c
     const lantern_ep_params &p = *prm;
     LANTERN_CHECK_ARG(p.B >= 0 && p.P > 0 && p.D > 0 && p.V > 0 && p.V % 4 == 0, "evaluate_posterior_window: bad B/P/D/V");
     if (p.B == 0) return LANTERN_OK;
-    LANTERN_CHECK_ARG(p.P <= EW_MAX_P && p.D <= EW_MAX_D && p.P * p.D <= EW_MAX_PD, "evaluate_posterior_window: P=%d D=%d exceed limits", p.P, p.D);
+    LANTERN_CHECK_ARG(p.P <= EW_MAX_P && p.D <= EW_MAX_D && p.P * p.D <= EW_MAX_PD, "evaluate_posterior_window: P=%d D=%d exceed limits (64 paths: one lane per path); use the dense kernel", p.P, p.D);
+    if (p.mode != LANTERN_MODE_DYNAMIC) LANTERN_CHECK_ARG(p.N <= EW_MAX_N, "evaluate_posterior_window: N=%d > %d", p.N, EW_MAX_N);
     LANTERN_CHECK_ARG(win->win_lo >= 0 && win->win_lo % 4 == 0 && win->win_len > 0 && win->win_len % 4 == 0 &&
                           win->win_lo + win->win_len <= p.V && win->win_len <= 16384,
                       "evaluate_posterior_window: window [%d,+%d) must be 4-aligned, inside V and <= 16384 wide", win->win_lo, win->win_len);
@@ -709,12 +724,12 @@ extern "C" int lantern_evaluate_posterior_window(const lantern_ep_params *prm, c
     hipStream_t st = (hipStream_t)stream;
     const int W = win->win_len;
     const size_t lds = epw_shared_offset(W) + sizeof(EwShared);
-    dim3 grid(p.B), block(WN_THREADS);
-    if (W <= 1024) hipLaunchKernelGGL(epw_kernel<1>, grid, block, lds, st, p, *buf, *win);
-    else if (W <= 2048) hipLaunchKernelGGL(epw_kernel<2>, grid, block, lds, st, p, *buf, *win);
-    else if (W <= 4096) hipLaunchKernelGGL(epw_kernel<4>, grid, block, lds, st, p, *buf, *win);
-    else if (W <= 8192) hipLaunchKernelGGL(epw_kernel<8>, grid, block, lds, st, p, *buf, *win);
-    else hipLaunchKernelGGL(epw_kernel<16>, grid, block, lds, st, p, *buf, *win);
+    dim3 grid(p.B);
+    if (W <= 1024) hipLaunchKernelGGL((epw_kernel<256, 1>), grid, dim3(256), lds, st, p, *buf, *win);
+    else if (W <= 2048) hipLaunchKernelGGL((epw_kernel<256, 2>), grid, dim3(256), lds, st, p, *buf, *win);
+    else if (W <= 4096) hipLaunchKernelGGL((epw_kernel<1024, 1>), grid, dim3(1024), lds, st, p, *buf, *win);
+    else if (W <= 8192) hipLaunchKernelGGL((epw_kernel<1024, 2>), grid, dim3(1024), lds, st, p, *buf, *win);
+    else hipLaunchKernelGGL((epw_kernel<1024, 4>), grid, dim3(1024), lds, st, p, *buf, *win);
     LANTERN_CHECK_LAUNCH("evaluate_posterior_window");
     return LANTERN_OK;
 }

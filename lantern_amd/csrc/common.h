@@ -60,16 +60,66 @@ __device__ __forceinline__ void set_comp(float4 &v, int c, float val) {
     v.w = (c == 3) ? val : v.w;
 }
 
+// ---- wave64 cross-lane primitives on DPP (row shifts / row broadcasts: VALU-rate, no LDS crossbar).
+// ds_bpermute-based __shfl costs ~50-90 cycles per step and serialises on the CU's LDS unit when 16
+// waves reduce at once; the DPP forms below are plain VALU moves (MI355X_MICROARCH.md: cross-lane
+// without LDS).  ctrl: row_shr:n = 0x110+n, row_bcast:15 = 0x142, row_bcast:31 = 0x143.
+template <int CTRL, int ROW_MASK = 0xf, int BANK_MASK = 0xf>
+__device__ __forceinline__ int dpp_mov(int v) {
+    return __builtin_amdgcn_update_dpp(0, v, CTRL, ROW_MASK, BANK_MASK, false);
+}
+template <int CTRL, int ROW_MASK = 0xf, int BANK_MASK = 0xf>
+__device__ __forceinline__ float dpp_mov(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, BANK_MASK, false));
+}
+template <int CTRL, int ROW_MASK = 0xf, int BANK_MASK = 0xf>
+__device__ __forceinline__ double dpp_mov(double v) {
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xffffffffll), CTRL, ROW_MASK, BANK_MASK, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, ROW_MASK, BANK_MASK, false);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+
+// inclusive scan over the 64 lanes (Kogge-Stone inside 16-lane rows, then row broadcasts)
 template <typename T>
-__device__ __forceinline__ T wave_sum(T v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+__device__ __forceinline__ T wave_scan_incl_dpp(T v) {
+    const int lane = threadIdx.x & 63, rl = lane & 15;
+    T t;
+    t = dpp_mov<0x111>(v); if (rl >= 1) v += t;
+    t = dpp_mov<0x112>(v); if (rl >= 2) v += t;
+    t = dpp_mov<0x114>(v); if (rl >= 4) v += t;
+    t = dpp_mov<0x118>(v); if (rl >= 8) v += t;
+    t = dpp_mov<0x142, 0xa>(v); if ((lane & 31) >= 16) v += t;
+    t = dpp_mov<0x143, 0xc>(v); if (lane >= 32) v += t;
     return v;
 }
+
+__device__ __forceinline__ int readlane63(int v) { return __builtin_amdgcn_readlane(v, 63); }
+__device__ __forceinline__ float readlane63(float v) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63)); }
+__device__ __forceinline__ double readlane63(double v) {
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffll), 63), hi = __builtin_amdgcn_readlane((int)(b >> 32), 63);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+
+// full-wave sum / max, result in every lane (scan, then broadcast lane 63)
+template <typename T>
+__device__ __forceinline__ T wave_sum(T v) {
+    return readlane63(wave_scan_incl_dpp(v));
+}
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-    return v;
+    const int lane = threadIdx.x & 63, rl = lane & 15;
+    const float NI = -__builtin_inff();
+    float t;
+    // update_dpp(old = 0 ...) would inject 0 for invalid source lanes: guard with the same lane predicates as the scan
+    t = dpp_mov<0x111>(v); if (rl >= 1) v = fmaxf(v, t);
+    t = dpp_mov<0x112>(v); if (rl >= 2) v = fmaxf(v, t);
+    t = dpp_mov<0x114>(v); if (rl >= 4) v = fmaxf(v, t);
+    t = dpp_mov<0x118>(v); if (rl >= 8) v = fmaxf(v, t);
+    t = dpp_mov<0x142, 0xa>(v); if ((lane & 31) >= 16) v = fmaxf(v, t);
+    t = dpp_mov<0x143, 0xc>(v); if (lane >= 32) v = fmaxf(v, t);
+    (void)NI;
+    return readlane63(v);
 }
 
 // Block-wide reductions for blockDim.x = NW*64.  `sm` is a shared scratch of >= 2*NW
@@ -99,15 +149,54 @@ __device__ __forceinline__ float block_max(float v, float *sm, int &phase) {
     return s;
 }
 
-// inclusive wave scan (double)
-__device__ __forceinline__ double wave_scan_incl(double v) {
+// Lean block reductions: one DPP wave reduce, one LDS slot per wave, one barrier, then the first lanes of
+// every wave combine the <= 16 partials with row-local DPP steps (instead of every thread reading all partials).
+template <typename T, int NW>
+__device__ __forceinline__ T block_sum_fast(T v, T *sm, int &phase) {
+    static_assert(NW <= 16, "one DPP row");
+    v = wave_sum(v);
+    T *buf = sm + (phase & 1) * NW;
+    phase ^= 1;
     const int lane = threadIdx.x & 63;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        double t = __shfl_up(v, o, 64);
-        if (lane >= o) v += t;
+    if (lane == 0) buf[threadIdx.x >> 6] = v;
+    __syncthreads();
+    T x = (lane < NW) ? buf[lane] : T(0);
+    T t;
+    const int rl = lane & 15;
+    t = dpp_mov<0x111>(x); if (rl >= 1) x += t;
+    t = dpp_mov<0x112>(x); if (rl >= 2) x += t;
+    t = dpp_mov<0x114>(x); if (rl >= 4) x += t;
+    t = dpp_mov<0x118>(x); if (rl >= 8) x += t;
+    // lane 15 of row 0 holds the total of partials 0..15
+    if constexpr (sizeof(T) == 8) {
+        const long long b = __double_as_longlong((double)x);
+        const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffll), 15), hi = __builtin_amdgcn_readlane((int)(b >> 32), 15);
+        return (T)__longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+    } else if constexpr (sizeof(T) == 4 && !__is_same(T, float)) {
+        return (T)__builtin_amdgcn_readlane((int)x, 15);
+    } else {
+        return (T)__int_as_float(__builtin_amdgcn_readlane(__float_as_int((float)x), 15));
     }
-    return v;
 }
+template <int NW>
+__device__ __forceinline__ float block_max_fast(float v, float *sm, int &phase) {
+    static_assert(NW <= 16, "one DPP row");
+    v = wave_max(v);
+    float *buf = sm + (phase & 1) * NW;
+    phase ^= 1;
+    const int lane = threadIdx.x & 63, rl = lane & 15;
+    if (lane == 0) buf[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float x = (lane < NW) ? buf[lane] : -__builtin_inff();
+    float t;
+    t = dpp_mov<0x111>(x); if (rl >= 1) x = fmaxf(x, t);
+    t = dpp_mov<0x112>(x); if (rl >= 2) x = fmaxf(x, t);
+    t = dpp_mov<0x114>(x); if (rl >= 4) x = fmaxf(x, t);
+    t = dpp_mov<0x118>(x); if (rl >= 8) x = fmaxf(x, t);
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 15));
+}
+
+// inclusive wave scan (double)
+__device__ __forceinline__ double wave_scan_incl(double v) { return wave_scan_incl_dpp(v); }
 
 }  // namespace lantern

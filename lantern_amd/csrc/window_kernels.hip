@@ -133,8 +133,48 @@ __global__ __launch_bounds__(NT) void cfg_window_kernel(const void *__restrict__
     }
 }
 
+// In-kernel phase stamps for diagnosis (tools/ep_trace.py builds a separate .so with -DEPW_TRACE);
+// the shipped library compiles EPW_STAMP to nothing.
+#ifdef EPW_TRACE
+__device__ unsigned long long g_epw_trace[2048];
+__device__ int g_epw_trace_n;
+#define EPW_STAMP(id)                                                                 \
+    do {                                                                              \
+        if (blockIdx.x == 0 && threadIdx.x == 0) {                                    \
+            const int n__ = g_epw_trace_n;                                            \
+            if (n__ < 1024) {                                                         \
+                g_epw_trace[2 * n__] = (unsigned long long)(id);                      \
+                g_epw_trace[2 * n__ + 1] = __builtin_amdgcn_s_memtime();              \
+                g_epw_trace_n = n__ + 1;                                              \
+            }                                                                         \
+        }                                                                             \
+    } while (0)
+#else
+#define EPW_STAMP(id) do { } while (0)
+#endif
+
 // ------------------------------------------------------------------------------- O8 windowed
+//
+// Structure (v3).  A 512-thread workgroup owns one sequence.  The serial part of the algorithm -- walking the
+// candidates of a level, the k-neighbour cumulative-mass scan, the accept test -- is executed by WAVE 0 ONLY
+// (one lane per path for the prefix masks, 16 neighbours per lane for the scan, DPP scans); the other waves
+// wait at a barrier and join for the W-wide passes (row softmax, residual update, renormalisation), whose
+// cross-wave reductions combine <= 16 partials with one DPP row.  All decisions travel through one LDS word,
+// so control flow stays workgroup-uniform.  The neighbour ids of every candidate of a level are fetched in one
+// round at level start (they depend only on the accepted prefix), so the per-candidate work is LDS + ALU only.
+// exp(x) for x <= 0 (softmax arguments): n = rint(x*log2e), r = x - n*ln2 (two-term), 2^(r*log2e) on the
+// hardware exp unit, ldexp.  7 VALU ops, < 1 ulp like the libm/ocml routine it replaces (which costs ~20).
+__device__ __forceinline__ float exp_nonpos(float x) {
+    if (x < -104.0f) return 0.0f;                       // below the smallest subnormal (also -inf)
+    const float n = rintf(x * 1.44269504088896341f);
+    float r = fmaf(-n, 0.693145751953125f, x);          // ln2 high part (exact product for |n| < 2^11)
+    r = fmaf(-n, 1.42860682030941723e-6f, r);           // ln2 low part
+    return ldexpf(__builtin_amdgcn_exp2f(r * 1.44269504088896341f), (int)n);
+}
+
 constexpr int EW_MAX_P = 64, EW_MAX_D = 16, EW_MAX_PD = 1024, EW_MAX_SIB = 16, EW_MAX_N = 128, EW_MAX_B = 1024, EW_UNI = 64;
+constexpr int EW_PF_C = 6;        // candidates per level whose neighbour ids are prefetched into LDS
+constexpr int EW_PF_K = 1024;     // ... when k + 1 <= EW_PF_K; otherwise ids are read from HBM on demand
 
 struct alignas(16) EwShared {
     int cand[EW_MAX_PD];
@@ -151,8 +191,9 @@ struct alignas(16) EwShared {
     double redd[2 * 16];
     float redf[2 * 16];
     int redi[2 * 16];
-    double scan_tot[16];
     double samp_tot[16][4];
+    int dec[2][4];                          // decision words of wave 0: {code, m>0, csm1 bits, -}
+    unsigned short nbid[EW_PF_C][EW_PF_K];  // prefetched neighbour ids (raw table values)
 };
 
 __host__ __device__ inline size_t epw_shared_offset(int W) {
@@ -209,15 +250,15 @@ __device__ __forceinline__ void row_softmax_to_lds(const float *__restrict__ row
     float m = NEG_INF;
 #pragma unroll
     for (int it = 0; it < E4; ++it) m = fmaxf(fmaxf(m, fmaxf(r[it].x, r[it].y)), fmaxf(r[it].z, r[it].w));
-    m = block_max<NW>(m, S.redf, ph);
+    m = block_max_fast<NW>(m, S.redf, ph);
     double s = 0.0;
 #pragma unroll
     for (int it = 0; it < E4; ++it) {
-        r[it].x = expf(r[it].x - m); r[it].y = expf(r[it].y - m);
-        r[it].z = expf(r[it].z - m); r[it].w = expf(r[it].w - m);
+        r[it].x = exp_nonpos(r[it].x - m); r[it].y = exp_nonpos(r[it].y - m);
+        r[it].z = exp_nonpos(r[it].z - m); r[it].w = exp_nonpos(r[it].w - m);
         s += (double)r[it].x + (double)r[it].y + (double)r[it].z + (double)r[it].w;
     }
-    const float sf = (float)block_sum<double, NW>(s, S.redd, ph);
+    const float sf = (float)block_sum_fast<double, NW>(s, S.redd, ph);
 #pragma unroll
     for (int it = 0; it < E4; ++it) {
         const int i4 = tid + it * NT;
@@ -241,6 +282,8 @@ __global__ __launch_bounds__(NT) void epw_kernel(const lantern_ep_params prm, co
     const int k = prm.k, off = prm.tok_offset;
     const bool is_static = prm.mode != LANTERN_MODE_DYNAMIC;
     const float NEG_INF = -__builtin_inff();
+    const int nz = (k + 1 < prm.table_cols) ? k + 1 : prm.table_cols;   // ids touched per candidate (k summed, k+1 zeroed)
+    const bool can_prefetch = prm.lantern && nz <= EW_PF_K;
     int ph = 0;
 
     // ---- stage every small per-step table in LDS with one round of global loads
@@ -265,13 +308,15 @@ __global__ __launch_bounds__(NT) void epw_kernel(const lantern_ep_params prm, co
             for (int t = tid; t < Ds - 1; t += NT) S.opoff[t] = buf.op_off[t];
         }
         const double *uni = buf.uniforms + (size_t)b * prm.n_uniforms;
-        for (int t = tid; t < EW_UNI; t += NT) S.uni[t] = (ucur0 + t < prm.n_uniforms) ? uni[ucur0 + t] : 2.0;   // 2.0 never drawn: guarded below
+        for (int t = tid; t < EW_UNI; t += NT) S.uni[t] = (ucur0 + t < prm.n_uniforms) ? uni[ucur0 + t] : 2.0;   // never drawn: guarded below
     }
     const float *logits = buf.logits + (size_t)b * prm.rows_per_seq * W;
     const int32_t *hot_g = win.row_hot ? win.row_hot + (size_t)b * prm.rows_per_seq : nullptr;
+    EPW_STAMP(1);
     __syncthreads();
     if (tid == 0) S.acc[0] = S.cand[0];
     __syncthreads();
+    EPW_STAMP(2);
 
     int a = 1, best = 0, adjust = 0, status = LANTERN_ST_OK;
     int n_levels = 0, n_tried = 0, n_rej = 0, n_used = 0;
@@ -282,7 +327,7 @@ __global__ __launch_bounds__(NT) void epw_kernel(const lantern_ep_params prm, co
         if (i != a) break;
         adjust = 0;
         ++n_levels;
-        // every wave recomputes the same masks: lane j <-> path j (P <= 64)
+        // prefix masks, one lane per path (every wave computes the same masks: P <= 64)
         bool eq = lane < P;
         for (int t = 0; t < a && eq; ++t) eq = (S.cand[lane * Ds + t] == S.acc[t]);
         const unsigned long long eq_mask = __ballot(eq);
@@ -292,16 +337,52 @@ __global__ __launch_bounds__(NT) void epw_kernel(const lantern_ep_params prm, co
         }
         const int fi = __ffsll((long long)eq_mask) - 1;
         const int x_lane = (lane < P) ? S.cand[lane * Ds + i] : -1;
+        const unsigned long long todo0 = eq_mask & __ballot(x_lane != -1);
+        // neighbour ids of the level's candidates: one round of HBM reads, overlapped with the row softmax
+        if (can_prefetch) {
+            // issue every candidate's id loads before the first LDS write (one HBM latency for the whole level)
+            constexpr int PF_PER = (EW_PF_K + NT - 1) / NT;
+            unsigned short idv[EW_PF_C][PF_PER];
+            unsigned long long td = todo0;
+            int ncand = 0;
+#pragma unroll
+            for (int c = 0; c < EW_PF_C; ++c) {
+                const bool have = td != 0ull;
+                const int j = have ? __ffsll((long long)td) - 1 : 0;
+                const int x = __shfl(x_lane, j, 64);
+                td &= ~__ballot(have && x_lane == x);
+                const int trow = x - off;
+                const bool lookup = have && trow >= 0 && trow < prm.table_rows && !(prm.syntax_shortcut && !(x >= prm.img_lo && x < prm.img_hi));
+                const uint16_t *nbp = buf.nn_table + (size_t)(lookup ? trow : 0) * prm.table_cols;
+#pragma unroll
+                for (int u = 0; u < PF_PER; ++u) {
+                    const int t = tid + u * NT;
+                    idv[c][u] = (lookup && t < nz) ? nbp[t] : (unsigned short)0;
+                }
+                ncand += have ? 1 : 0;
+            }
+#pragma unroll
+            for (int c = 0; c < EW_PF_C; ++c)
+#pragma unroll
+                for (int u = 0; u < PF_PER; ++u) {
+                    const int t = tid + u * NT;
+                    if (c < ncand && t < EW_PF_K) S.nbid[c][t] = idv[c][u];
+                }
+        }
         {
             const int rid = S.row[fi * Ds + (i - 1)];
+            EPW_STAMP(10);
             row_softmax_to_lds<NT, E4>(logits + (size_t)rid * W, hot_g ? hot_g[rid] : -1, lo, W, prm.temperature, prm.top_k, V, g, out_tok,
                                        out_mass, S, ph);
+            EPW_STAMP(11);
         }
-        unsigned long long todo = eq_mask & __ballot(x_lane != -1);
+        unsigned long long todo = todo0;
+        int cidx = -1;
         while (todo != 0ull) {
             const int j = __ffsll((long long)todo) - 1;
             const int x = __shfl(x_lane, j, 64);
             todo &= ~__ballot(x_lane == x);     // this path and every later path carrying the same token
+            ++cidx;
             if (x < 0 || x >= V) {
                 status = LANTERN_ST_TOKEN_OOB;
                 break;
@@ -312,96 +393,141 @@ __global__ __launch_bounds__(NT) void epw_kernel(const lantern_ep_params prm, co
             }
             const double r = S.uni[n_used++];
             ++n_tried;
+            EPW_STAMP(20);
             const bool x_in = (x >= lo && x < lo + W);
-            float px = x_in ? g[x - lo] : (x == out_tok ? out_mass : 0.0f);
-            int m = 0;
-            bool is_syn = false;
             const bool in_img = (x >= prm.img_lo && x < prm.img_hi);
+            bool is_syn = false;
             if (prm.syntax_shortcut)
                 for (int t = 0; t < prm.n_syntax; ++t) is_syn |= (x == prm.syntax[t]);
-            const uint16_t *nb = nullptr;
-            if (prm.syntax_shortcut && is_syn) {
-                px = 1.0f;
-            } else if (prm.syntax_shortcut && !in_img) {
-                px = 0.0f;
-            } else if (prm.lantern) {
-                const int trow = x - off;
-                if (trow < 0 || trow >= prm.table_rows) {
-                    status = LANTERN_ST_TABLE_OOB;
-                    break;
-                }
-                nb = buf.nn_table + (size_t)trow * prm.table_cols;
-                const float tau = prm.delta > 1.0 ? (float)(prm.delta - 1.0) * px : (float)prm.delta;
-                float csm1 = 0.0f;
-                double carry = 0.0;
-                // each thread owns 4 consecutive neighbours: 4 id loads in flight at once, one f64 scan per 4*NT ids
-                for (int base = 0; base < k; base += NT * 4) {
-                    const int i0 = base + tid * 4;
-                    int id[4];
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) id[c] = (i0 + c < k) ? (int)nb[i0 + c] + off : -1;
-                    double v[4], loc = 0.0;
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) {
-                        const int t = id[c];
-                        const float gv = (t >= lo && t < lo + W) ? g[t - lo] : ((t >= 0 && t == out_tok) ? out_mass : 0.0f);
-                        loc += (double)gv;
-                        v[c] = loc;            // inclusive local prefix
-                    }
-                    double inc = wave_scan_incl(loc);
-                    if (lane == 63) S.scan_tot[wave] = inc;
-                    __syncthreads();
-                    double woff = 0.0, total = 0.0;
-#pragma unroll
-                    for (int w = 0; w < NW; ++w) {
-                        const double t = S.scan_tot[w];
-                        woff += (w < wave) ? t : 0.0;
-                        total += t;
-                    }
-                    const double excl = carry + woff + (inc - loc);
-                    int cnt_loc = 0;
-                    float mx_loc = NEG_INF;
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) {
-                        const float cs = (float)(excl + v[c]);
-                        const bool ok = (i0 + c < k) && cs <= tau;
-                        cnt_loc += ok ? 1 : 0;
-                        mx_loc = ok ? fmaxf(mx_loc, cs) : mx_loc;
-                    }
-                    const int cnt = block_sum<int, NW>(cnt_loc, S.redi, ph);
-                    const float mx = block_max<NW>(mx_loc, S.redf, ph);
-                    if (cnt > 0) {
-                        m += cnt;
-                        csm1 = mx;
-                    }
-                    carry += total;
-                    const int chunk = (k - base) < NT * 4 ? (k - base) : NT * 4;
-                    if (cnt < chunk) break;
-                }
-                if (m > 0) px = px + csm1;
-            }
-            float qx = 1.0f;
+            const bool use_lds_ids = can_prefetch && cidx < EW_PF_C;
+            const int trow = x - off;
+            const uint16_t *nb = (prm.lantern && trow >= 0 && trow < prm.table_rows) ? buf.nn_table + (size_t)trow * prm.table_cols : nullptr;
+            int *dec = S.dec[n_tried & 1];
+            // static trees: start the drafter-row read now; it lands while wave 0 runs the neighbour scan and is
+            // simply dropped if the candidate is accepted (one 32 KB row, L2/MALL-resident for the next try)
+            float4 q[E4];
             if (is_static) {
-                qx = S.cart[j * Ds + i];
-                if (qx <= 0.0f) continue;
+                const float *qsrc = buf.orig_prob + ((size_t)b * prm.R + S.opoff[i - 1] + S.pidx[j * Ds + i]) * (size_t)win.orig_prob_stride +
+                                    win.orig_prob_offset;
+#pragma unroll
+                for (int it = 0; it < E4; ++it) {
+                    const int i4 = tid + it * NT;
+                    q[it] = (i4 * 4 < W) ? reinterpret_cast<const float4 *>(qsrc)[i4] : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
             }
-            const float acp = px / qx;
-            if ((float)r <= acp) {
-                __syncthreads();
+            // ---------------- serial section: wave 0 only
+            if (wave == 0) {
+                float px = x_in ? g[x - lo] : (x == out_tok ? out_mass : 0.0f);
+                int code = 0, mflag = 0;
+                if (prm.syntax_shortcut && is_syn) {
+                    px = 1.0f;
+                } else if (prm.syntax_shortcut && !in_img) {
+                    px = 0.0f;
+                } else if (prm.lantern) {
+                    if (nb == nullptr) {
+                        code = 3;   // LANTERN_ST_TABLE_OOB
+                    } else {
+                        const float tau = prm.delta > 1.0 ? (float)(prm.delta - 1.0) * px : (float)prm.delta;
+                        float best_cs = NEG_INF;
+                        double carry = 0.0;
+                        // 16 consecutive neighbours per lane, 1024 per round; ids come as two 16-byte reads when they were
+                        // prefetched to LDS; every gather is clamped + masked instead of branched
+                        for (int base = 0; base < k; base += 1024) {
+                            const int i0 = base + lane * 16;
+                            int ids[16];
+                            if (use_lds_ids) {
+                                const uint4 a = *reinterpret_cast<const uint4 *>(&S.nbid[cidx][i0 & (EW_PF_K - 1)]);
+                                const uint4 bq = *reinterpret_cast<const uint4 *>(&S.nbid[cidx][(i0 + 8) & (EW_PF_K - 1)]);
+                                const uint32_t w[8] = {a.x, a.y, a.z, a.w, bq.x, bq.y, bq.z, bq.w};
+#pragma unroll
+                                for (int c = 0; c < 8; ++c) {
+                                    ids[2 * c] = (int)(w[c] & 0xffffu);
+                                    ids[2 * c + 1] = (int)(w[c] >> 16);
+                                }
+                            } else {
+#pragma unroll
+                                for (int c = 0; c < 16; ++c) ids[c] = (i0 + c < k) ? (int)nb[i0 + c] : 0;
+                            }
+                            double v[16], loc = 0.0;
+#pragma unroll
+                            for (int c = 0; c < 16; ++c) {
+                                const int t = ids[c] + off - lo;
+                                const bool inw = (i0 + c < k) && t >= 0 && t < W;
+                                float gv = g[inw ? t : 0];
+                                gv = inw ? gv : 0.0f;
+                                if (out_tok >= 0 && (i0 + c < k) && ids[c] + off == out_tok) gv = out_mass;   // hot token outside the window
+                                loc += (double)gv;
+                                v[c] = loc;
+                            }
+                            EPW_STAMP(22);
+                            const double inc = wave_scan_incl_dpp(loc);
+                            const double excl = carry + (inc - loc);
+                            EPW_STAMP(23);
+                            float mx = NEG_INF;
+                            int nok = 0;
+#pragma unroll
+                            for (int c = 0; c < 16; ++c) {
+                                const float cs = (float)(excl + v[c]);
+                                const bool ok = (i0 + c < k) && cs <= tau;
+                                mx = ok ? fmaxf(mx, cs) : mx;
+                                nok += ok ? 1 : 0;
+                            }
+                            EPW_STAMP(24);
+                            mx = wave_max(mx);
+                            best_cs = fmaxf(best_cs, mx);
+                            carry += readlane63(inc);
+                            if (k - base <= 1024) break;
+                            const int tot_ok = wave_sum(nok);
+                            EPW_STAMP(25);
+                            if (tot_ok < 1024) break;   // the cumulative mass is non-decreasing: the ok set is a prefix
+                        }
+                        if (best_cs > NEG_INF) {
+                            mflag = 1;
+                            px = px + best_cs;
+                        }
+                    }
+                }
+                if (code == 0) {
+                    float qx = 1.0f;
+                    bool skip = false;
+                    if (is_static) {
+                        qx = S.cart[j * Ds + i];
+                        skip = qx <= 0.0f;
+                    }
+                    if (skip)
+                        code = 0;
+                    else
+                        code = ((float)r <= px / qx) ? 1 : 2;
+                }
+                if (lane == 0) {
+                    dec[0] = code;
+                    dec[1] = mflag;
+                }
+                EPW_STAMP(26);
+            }
+            __syncthreads();
+            const int code = dec[0];
+            const int m = dec[1];
+            EPW_STAMP(21);
+            if (code == 3) {
+                status = LANTERN_ST_TABLE_OOB;
+                break;
+            }
+            if (code == 0) continue;
+            if (code == 1) {
                 if (tid == 0) S.acc[a] = x;
                 ++a;
                 best = j;
                 __syncthreads();
                 break;
             }
-            // ------------------------------------------------ rejection: residual, all in LDS
+            // ------------------------------------------------ rejection: residual, all waves, all in LDS
             ++n_rej;
             if (prm.syntax_shortcut && is_syn) {
                 status = LANTERN_ST_SYNTAX_REJECT;
                 break;
             }
             const bool zero_nb = prm.lantern && m > 0 && (!prm.syntax_shortcut || in_img);
-            const int nz = (k + 1 < prm.table_cols) ? k + 1 : prm.table_cols;
             double loc = 0.0;
             if (!is_static) {
                 if (tid == 0 && x_in) g[x - lo] = 0.0f;
@@ -409,11 +535,11 @@ __global__ __launch_bounds__(NT) void epw_kernel(const lantern_ep_params prm, co
                 if (zero_nb) {
                     bool hit = false;
                     for (int t = tid; t < nz; t += NT) {
-                        const int id = (int)nb[t] + off;
+                        const int id = (int)(use_lds_ids ? S.nbid[cidx][t] : nb[t]) + off;
                         if (id >= lo && id < lo + W) g[id - lo] = 0.0f;
                         hit |= (id == out_tok);
                     }
-                    if (out_tok >= 0 && block_sum<int, NW>(hit ? 1 : 0, S.redi, ph) > 0) out_mass = 0.0f;
+                    if (out_tok >= 0 && block_sum_fast<int, NW>(hit ? 1 : 0, S.redi, ph) > 0) out_mass = 0.0f;
                 }
                 __syncthreads();
                 for (int i4 = tid; i4 * 4 < W; i4 += NT) {
@@ -421,15 +547,6 @@ __global__ __launch_bounds__(NT) void epw_kernel(const lantern_ep_params prm, co
                     loc += (double)v.x + (double)v.y + (double)v.z + (double)v.w;
                 }
             } else {
-                const float *qsrc = buf.orig_prob + ((size_t)b * prm.R + S.opoff[i - 1] + S.pidx[j * Ds + i]) * (size_t)win.orig_prob_stride +
-                                    win.orig_prob_offset;
-                // drafter row -> registers first (the one HBM read of a rejection), everything else overlaps it
-                float4 q[E4];
-#pragma unroll
-                for (int it = 0; it < E4; ++it) {
-                    const int i4 = tid + it * NT;
-                    q[it] = (i4 * 4 < W) ? reinterpret_cast<const float4 *>(qsrc)[i4] : make_float4(0.f, 0.f, 0.f, 0.f);
-                }
                 const int b0 = S.boff[j * Ds + i], b1 = S.boff[j * Ds + i + 1];
                 int nsib = b1 - b0;
                 if (nsib > EW_MAX_SIB) nsib = EW_MAX_SIB;
@@ -444,12 +561,12 @@ __global__ __launch_bounds__(NT) void epw_kernel(const lantern_ep_params prm, co
                 __syncthreads();
                 if (lg_nb)
                     for (int t = tid; t < nz; t += NT) {
-                        const int id = (int)nb[t] + off - lo;
+                        const int id = (int)(use_lds_ids ? S.nbid[cidx][t] : nb[t]) + off - lo;
                         if (id >= 0 && id < W) atomicOr(&nbmask[id >> 5], 1u << (id & 31));
                     }
                 if (zero_nb && prm.mode == LANTERN_MODE_STATIC_LUMINA)
                     for (int t = tid; t < nz; t += NT) {
-                        const int id = (int)nb[t] + off - lo;
+                        const int id = (int)(use_lds_ids ? S.nbid[cidx][t] : nb[t]) + off - lo;
                         if (id >= 0 && id < W) g[id] = 0.0f;
                     }
                 double qs_loc = 0.0;
@@ -463,8 +580,10 @@ __global__ __launch_bounds__(NT) void epw_kernel(const lantern_ep_params prm, co
                     qs_loc += (double)q[it].x + (double)q[it].y + (double)q[it].z + (double)q[it].w;
                 }
                 float qs = 1.0f;
-                if (nsib > 0) qs = (float)block_sum<double, NW>(qs_loc, S.redd, ph);
-                __syncthreads();   // neighbour zeroing / mask visible
+                if (nsib > 0)
+                    qs = (float)block_sum_fast<double, NW>(qs_loc, S.redd, ph);
+                else
+                    __syncthreads();   // neighbour zeroing / mask visible (block_sum_fast carries the barrier otherwise)
 #pragma unroll
                 for (int it = 0; it < E4; ++it) {
                     const int i4 = tid + it * NT;
@@ -493,7 +612,7 @@ __global__ __launch_bounds__(NT) void epw_kernel(const lantern_ep_params prm, co
                 }
                 // out-of-window mass: the drafter is zero there (precondition): max(out_mass - 0, 0) = out_mass
             }
-            double tot = block_sum<double, NW>(loc, S.redd, ph);
+            double tot = block_sum_fast<double, NW>(loc, S.redd, ph);
             tot += (double)out_mass;
             const float gs = (float)tot;
             if (gs == 0.0f) {
@@ -507,6 +626,7 @@ __global__ __launch_bounds__(NT) void epw_kernel(const lantern_ep_params prm, co
             }
             out_mass = out_mass / gs;
             __syncthreads();
+            EPW_STAMP(30);
             adjust = 1;
         }
     }
@@ -518,6 +638,7 @@ __global__ __launch_bounds__(NT) void epw_kernel(const lantern_ep_params prm, co
                                    out_mass, S, ph);
     }
     // ---------------------------------------------------------------- epilogue: outputs from LDS
+    EPW_STAMP(40);
     float4 p[E4];
 #pragma unroll
     for (int it = 0; it < E4; ++it) {
@@ -549,7 +670,7 @@ __global__ __launch_bounds__(NT) void epw_kernel(const lantern_ep_params prm, co
 #pragma unroll
         for (int it = 0; it < E4; ++it) {
             s4[it] = (double)p[it].x + (double)p[it].y + (double)p[it].z + (double)p[it].w;
-            inc[it] = wave_scan_incl(s4[it]);
+            inc[it] = wave_scan_incl_dpp(s4[it]);
             if (lane == 63) S.samp_tot[wave][it] = inc[it];
         }
         __syncthreads();
@@ -612,6 +733,7 @@ __global__ __launch_bounds__(NT) void epw_kernel(const lantern_ep_params prm, co
             win.token[b] = f != 0x7fffffff ? f : l;
         }
     }
+    EPW_STAMP(50);
     if (tid == 0) {
         buf.best[b] = best;
         buf.accept_len[b] = a - 1;
@@ -727,12 +849,24 @@ extern "C" int lantern_evaluate_posterior_window(const lantern_ep_params *prm, c
     dim3 grid(p.B);
     if (W <= 1024) hipLaunchKernelGGL((epw_kernel<256, 1>), grid, dim3(256), lds, st, p, *buf, *win);
     else if (W <= 2048) hipLaunchKernelGGL((epw_kernel<256, 2>), grid, dim3(256), lds, st, p, *buf, *win);
-    else if (W <= 4096) hipLaunchKernelGGL((epw_kernel<1024, 1>), grid, dim3(1024), lds, st, p, *buf, *win);
-    else if (W <= 8192) hipLaunchKernelGGL((epw_kernel<1024, 2>), grid, dim3(1024), lds, st, p, *buf, *win);
+    else if (W <= 4096) hipLaunchKernelGGL((epw_kernel<512, 2>), grid, dim3(512), lds, st, p, *buf, *win);
+    else if (W <= 8192) hipLaunchKernelGGL((epw_kernel<512, 4>), grid, dim3(512), lds, st, p, *buf, *win);
     else hipLaunchKernelGGL((epw_kernel<1024, 4>), grid, dim3(1024), lds, st, p, *buf, *win);
     LANTERN_CHECK_LAUNCH("evaluate_posterior_window");
     return LANTERN_OK;
 }
+
+#ifdef EPW_TRACE
+extern "C" int lantern_debug_epw_trace(unsigned long long *host_out, int max_pairs) {
+    int n = 0;
+    if (hipMemcpyFromSymbol(&n, HIP_SYMBOL(g_epw_trace_n), sizeof(int)) != hipSuccess) return -1;
+    if (n > max_pairs) n = max_pairs;
+    if (hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_epw_trace), sizeof(unsigned long long) * 2 * n) != hipSuccess) return -1;
+    int zero = 0;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_epw_trace_n), &zero, sizeof(int)) != hipSuccess) return -1;
+    return n;
+}
+#endif
 
 extern "C" int lantern_window_to_dense(const float *winp, const int32_t *out_tok, const float *out_mass, int B, int V, int win_lo,
                                        int win_len, float *dense, void *stream) {

@@ -245,11 +245,15 @@ int lantern_window_to_dense(const float *win, const int32_t *out_tok, const floa
                             int win_lo, int win_len, float *dense, void *stream);
 
 /* a9  greedy / TVD branch (temperature <= 1e-5): models/ea_model_llamagen.py:789-905,
- * models/ea_model_anole.py:790-905.  out_row [B,V] = logits[best, accept_len]. */
+ * models/ea_model_anole.py:790-905.  logits [dev] [B,rows_per_seq,V] f32 (dense rows); only ids
+ * [win_lo, win_lo+win_len) are read -- LlamaGen: (0, V); Anole: the image range (4, 8192), the rest is
+ * finfo.min after CFG (ea_model_anole.py:931).  win_len <= 16384, P <= 64.
+ * ok_scratch [dev] B*P*(D-1) int32.  Out: best/accept_len [B] i32, out_row [B,V] = logits[best, accept_len]. */
 int lantern_evaluate_posterior_greedy(const float *logits, const int32_t *row_index, const int64_t *cand,
                                       int B, int P, int D, int V, int rows_per_seq, int row_index_per_seq,
                                       int lantern, int k, double delta, int tok_offset,
                                       const uint16_t *nn_table, int table_rows, int table_cols,
+                                      int win_lo, int win_len, int32_t *ok_scratch,
                                       int32_t *best, int32_t *accept_len, float *out_row, void *stream);
 
 /* ------------------------------------------------------------------------------------

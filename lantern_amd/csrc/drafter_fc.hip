@@ -1,0 +1,144 @@
+// drafter_fc.hip -- O11: the drafter's input contraction on the matrix cores,
+//   out[m, n] = sum_k cat(embed[ids[m]] * scale, hidden[m])[k] * W[n, k] + bias[n]      (k < 2H)
+// replacing nn.Embedding + torch.cat + nn.Linear (models/drafters/cnets_lumina_mgpt.py:1071,1095-1098;
+// cnets_llamagen.py:642,679-680).  The only MFMA-shaped op on the verify path.
+//
+// Shape: M = B*T is tiny (2..~120 rows), N = H, K = 2H: a weight-streaming GEMV-like GEMM bound by the
+// 2*H*2H bytes of W (64 MiB bf16 for H = 4096).  Each wave owns 32 output columns and a K slice and feeds
+// v_mfma_f32_32x32x16_bf16 STRAIGHT FROM GLOBAL MEMORY: lane (r = l&31, h = l>>5) needs
+// A[row r][8h..8h+8) = 16 contiguous bytes of an activation row and B[8h..8h+8)[col r] = 16 contiguous bytes
+// of W's row (n0 + r) -- the nn.Linear layout [out, in] is already the B fragment layout, so W is read
+// exactly once, 16 bytes per lane, with no LDS staging and no transpose.  The embedding gather and the
+// concat are folded into the A-fragment address (k < H -> embed row, else hidden row).  The 8 waves of a
+// workgroup split K and add their 32x32 tiles into one LDS tile in wave order; bias + bf16 rounding in the
+// epilogue.  C/D map: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
+#include "common.h"
+
+namespace lantern {
+
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef float f32x16_t __attribute__((ext_vector_type(16)));
+
+constexpr int FC_WAVES = 8;
+constexpr int FC_THREADS = FC_WAVES * 64;
+
+__device__ __forceinline__ bf16x8_t load_frag(const uint16_t *p) {
+    const uint4 v = *reinterpret_cast<const uint4 *>(p);
+    return __builtin_bit_cast(bf16x8_t, v);
+}
+
+__device__ __forceinline__ uint16_t f32_to_bf16_rne(float f) {
+    uint32_t u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return 0x7fc0;
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+
+template <int MT>
+__global__ __launch_bounds__(FC_THREADS) void drafter_fc_kernel(const int64_t *__restrict__ ids, const uint16_t *__restrict__ hidden,
+                                                                const uint16_t *__restrict__ embed, const uint16_t *__restrict__ Wt,
+                                                                const uint16_t *__restrict__ bias, int M, int H, int vocab,
+                                                                float embed_scale, uint16_t *__restrict__ out) {
+    __shared__ float tile[MT][32][33];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int n0 = blockIdx.x * 32;
+    const int K = 2 * H;
+    for (int t = tid; t < MT * 32 * 33; t += FC_THREADS) (&tile[0][0][0])[t] = 0.0f;
+
+    const int ksteps = K / 16;
+    const int ks0 = (int)((long long)ksteps * wave / FC_WAVES), ks1 = (int)((long long)ksteps * (wave + 1) / FC_WAVES);
+    const int ncol = n0 + r;
+    const uint16_t *wrow = Wt + (size_t)(ncol < H ? ncol : H - 1) * K;
+    const uint16_t *erow[MT];
+    const uint16_t *hrow[MT];
+    bool live[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const int row = mt * 32 + r;
+        live[mt] = row < M;
+        int64_t id = live[mt] ? ids[row] : 0;
+        id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+        erow[mt] = embed + (size_t)id * H;
+        hrow[mt] = hidden + (size_t)(live[mt] ? row : 0) * H;
+    }
+    f32x16_t acc[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[mt][i] = 0.0f;
+
+    const bf16x8_t zero = __builtin_bit_cast(bf16x8_t, make_uint4(0, 0, 0, 0));
+    for (int ks = ks0; ks < ks1; ++ks) {
+        const int k0 = ks * 16 + 8 * h;
+        const bf16x8_t bfrag = load_frag(wrow + k0);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            bf16x8_t afrag = zero;
+            if (live[mt]) {
+                if (k0 < H) {
+                    afrag = load_frag(erow[mt] + k0);
+                    if (embed_scale > 1.0f) {   // inputs_embeds * embed_upscale, rounded to bf16 (cnets_lumina_mgpt.py:1096-1097)
+                        uint4 v = __builtin_bit_cast(uint4, afrag);
+                        uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const uint16_t lo = f32_to_bf16_rne(bf16_bits_to_f32((uint16_t)(w[i] & 0xffffu)) * embed_scale);
+                            const uint16_t hi = f32_to_bf16_rne(bf16_bits_to_f32((uint16_t)(w[i] >> 16)) * embed_scale);
+                            w[i] = (uint32_t)lo | ((uint32_t)hi << 16);
+                        }
+                        afrag = __builtin_bit_cast(bf16x8_t, make_uint4(w[0], w[1], w[2], w[3]));
+                    }
+                } else {
+                    afrag = load_frag(hrow[mt] + (k0 - H));
+                }
+            }
+            acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag, bfrag, acc[mt], 0, 0, 0);
+        }
+    }
+    // combine the K slices in wave order (deterministic f32 sum; 8 short rounds)
+    for (int w = 0; w < FC_WAVES; ++w) {
+        __syncthreads();
+        if (wave == w) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) {
+                    const int row = (reg & 3) + 8 * (reg >> 2) + 4 * h;
+                    tile[mt][row][r] += acc[mt][reg];
+                }
+        }
+    }
+    __syncthreads();
+    for (int t = tid; t < MT * 32 * 32; t += FC_THREADS) {
+        const int mt = t / 1024, row = (t / 32) % 32, col = t % 32;
+        const int m = mt * 32 + row, n = n0 + col;
+        if (m < M && n < H) {
+            float v = tile[mt][row][col];
+            if (bias) v += bf16_bits_to_f32(bias[n]);
+            out[(size_t)m * H + n] = f32_to_bf16_rne(v);
+        }
+    }
+}
+
+}  // namespace lantern
+
+using namespace lantern;
+
+extern "C" int lantern_drafter_fc(const int64_t *ids, const void *hidden, const void *embed, const void *W, const void *bias, int M, int H,
+                                  int vocab, float embed_scale, void *out, void *stream) {
+    LANTERN_CHECK_ARG(ids && hidden && embed && W && out, "drafter_fc: null buffer");
+    LANTERN_CHECK_ARG(M >= 0 && M <= 128, "drafter_fc: M=%d must be <= 128 rows (B*T of one drafter call)", M);
+    LANTERN_CHECK_ARG(H > 0 && H % 16 == 0 && vocab > 0, "drafter_fc: H=%d must be a multiple of 16", H);
+    if (M == 0) return LANTERN_OK;
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid((H + 31) / 32), block(FC_THREADS);
+    const uint16_t *h = (const uint16_t *)hidden, *e = (const uint16_t *)embed, *w = (const uint16_t *)W, *bi = (const uint16_t *)bias;
+    uint16_t *o = (uint16_t *)out;
+    if (M <= 32) hipLaunchKernelGGL((drafter_fc_kernel<1>), grid, block, 0, st, ids, h, e, w, bi, M, H, vocab, embed_scale, o);
+    else if (M <= 64) hipLaunchKernelGGL((drafter_fc_kernel<2>), grid, block, 0, st, ids, h, e, w, bi, M, H, vocab, embed_scale, o);
+    else if (M <= 96) hipLaunchKernelGGL((drafter_fc_kernel<3>), grid, block, 0, st, ids, h, e, w, bi, M, H, vocab, embed_scale, o);
+    else hipLaunchKernelGGL((drafter_fc_kernel<4>), grid, block, 0, st, ids, h, e, w, bi, M, H, vocab, embed_scale, o);
+    LANTERN_CHECK_LAUNCH("drafter_fc");
+    return LANTERN_OK;
+}

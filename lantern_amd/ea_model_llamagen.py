@@ -148,7 +148,9 @@ class EaModel(nn.Module):
         best, alen, out_row = ops.evaluate_posterior_greedy(rows.float()[None], row_index, candidates[None], lantern=bool(lantern),
                                                             k=int(lantern_k), delta=float(lantern_delta),
                                                             tok_offset=self.image_token_offset,
-                                                            table=self.nearest_latents if lantern else None)
+                                                            table=self.nearest_latents if lantern else None,
+                                                            win_lo=self.image_lo if self.mask_non_image else 0,
+                                                            win_len=(self.image_hi - self.image_lo) if self.mask_non_image else None)
         return best[0].to(torch.int64), alen[0].to(torch.int64), out_row[0]
 
     # ------------------------------------------------------------------ O9 + O10, :935-999

@@ -385,18 +385,23 @@ def sample_static(probs, idx):
     return out
 
 
-def evaluate_posterior_greedy(logits, row_index, cand, lantern=False, k=1000, delta=0.1, tok_offset=0, table=None):
-    """a9 greedy/TVD branch.  logits [B,rows,V] f32; row_index [P,D]|[B,P,D] i32; cand [B,P,D] i64.
+def evaluate_posterior_greedy(logits, row_index, cand, lantern=False, k=1000, delta=0.1, tok_offset=0, table=None, win_lo=0,
+                              win_len=None):
+    """a9 greedy/TVD branch.  logits [B,rows,V] f32; row_index [P,D]|[B,P,D] i32; cand [B,P,D] i64; ids outside
+    [win_lo, win_lo+win_len) are not read (LlamaGen: whole vocabulary; Anole: image range).
     Returns (best [B] i32, accept_len [B] i32, out_row [B,V] f32 = logits[best, accept_len])."""
     logits = _dev(logits, torch.float32, "logits")
     cand = _dev(cand, torch.int64, "cand")
     row_index = _dev(row_index, torch.int32, "row_index")
     B, P, D = cand.shape
     V, rows = logits.shape[-1], logits.shape[-2]
+    if win_len is None:
+        win_len = V - win_lo
     dev = logits.device
     best = torch.empty(B, dtype=torch.int32, device=dev)
     alen = torch.empty(B, dtype=torch.int32, device=dev)
     out = torch.empty((B, V), dtype=torch.float32, device=dev)
+    scratch = torch.empty(B * P * max(D - 1, 1), dtype=torch.int32, device=dev)
     tr = tc = 0
     if table is not None:
         table = table.contiguous()
@@ -404,8 +409,8 @@ def evaluate_posterior_greedy(logits, row_index, cand, lantern=False, k=1000, de
     check(_lib.lib().lantern_evaluate_posterior_greedy(
         C.c_void_p(logits.data_ptr()), C.c_void_p(row_index.data_ptr()), C.c_void_p(cand.data_ptr()), B, P, D, V, rows,
         int(row_index.dim() == 3), int(bool(lantern)), int(k), C.c_double(float(delta)), int(tok_offset), C.c_void_p(_ptr(table)),
-        tr, tc, C.c_void_p(best.data_ptr()), C.c_void_p(alen.data_ptr()), C.c_void_p(out.data_ptr()), _stream()),
-        "evaluate_posterior_greedy")
+        tr, tc, int(win_lo), int(win_len), C.c_void_p(scratch.data_ptr()), C.c_void_p(best.data_ptr()), C.c_void_p(alen.data_ptr()),
+        C.c_void_p(out.data_ptr()), _stream()), "evaluate_posterior_greedy")
     return best, alen, out
 
 
@@ -509,3 +514,31 @@ def window_to_dense(sample_win, out_tok, out_mass, V: int, win_lo: int):
     check(_lib.lib().lantern_window_to_dense(C.c_void_p(sample_win.data_ptr()), C.c_void_p(_ptr(out_tok)), C.c_void_p(_ptr(out_mass)),
                                              B, V, win_lo, W, C.c_void_p(dense.data_ptr()), _stream()), "window_to_dense")
     return dense
+
+
+def drafter_fc(ids, hidden, embed, weight, bias=None, embed_scale: float = 1.0):
+    """O11 (MFMA): fc(cat(embed[ids] * scale, hidden)) -> bf16 [M,H].  ids [M] i64, hidden [M,H] bf16, embed [vocab,H] bf16,
+    weight [H,2H] bf16 (nn.Linear layout), bias [H] bf16 or None."""
+    for t, n in ((hidden, "hidden"), (embed, "embed"), (weight, "weight")):
+        if not t.is_cuda or t.dtype != torch.bfloat16:
+            raise _lib.LanternError(f"drafter_fc: {n} must be a bf16 device tensor")
+    ids = _dev(ids, torch.int64, "ids").reshape(-1)
+    hidden, embed, weight = hidden.contiguous(), embed.contiguous(), weight.contiguous()
+    M, H = hidden.reshape(-1, hidden.shape[-1]).shape
+    assert weight.shape == (H, 2 * H) and embed.shape[1] == H and ids.numel() == M
+    out = torch.empty((M, H), dtype=torch.bfloat16, device=hidden.device)
+    b = None if bias is None else bias.contiguous()
+    check(_lib.lib().lantern_drafter_fc(C.c_void_p(ids.data_ptr()), C.c_void_p(hidden.data_ptr()), C.c_void_p(embed.data_ptr()),
+                                        C.c_void_p(weight.data_ptr()), C.c_void_p(_ptr(b)), M, H, embed.shape[0], C.c_float(embed_scale),
+                                        C.c_void_p(out.data_ptr()), _stream()), "drafter_fc")
+    return out
+
+
+def build_vq_table(codebook):
+    """8f-1: codebook [K,C] f32 -> uint16 table [K,K-1] (as an int16-viewed tensor), generate_codebook.py:53-65."""
+    cb = _dev(codebook, torch.float32, "codebook")
+    K, Cc = cb.shape
+    table = torch.empty((K, K - 1), dtype=torch.int16, device=cb.device)
+    check(_lib.lib().lantern_build_vq_table(C.c_void_p(cb.data_ptr()), K, Cc, C.c_void_p(table.data_ptr()), None, _stream()),
+          "build_vq_table")
+    return table

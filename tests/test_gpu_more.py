@@ -1,0 +1,106 @@
+"""GPU (-m gpu): greedy/TVD accept (a9), MFMA drafter input contraction (O11), VQ-distance table builder (8f-1)."""
+import numpy as np
+import pytest
+import torch
+
+import cases as CS
+import helpers as H
+import oracle
+from lantern_amd import ops
+from test_gpu_parity import dev, table_dev
+
+pytestmark = pytest.mark.gpu
+SPECS = H.ep_specs()
+
+
+@pytest.mark.parametrize("i", [i for i, s in enumerate(SPECS) if s["kind"] == "greedy"])
+def test_greedy_golden(i):
+    spec, case = SPECS[i], H.ep_case(i)
+    nl, _ = H.dynamic_node_logits(spec, case, greedy=True)
+    m = CS.MODELS[spec["model"]]
+    N = len(case["draft_tokens"])
+    best, alen, row = ops.evaluate_posterior_greedy(dev(nl)[None], dev(H.row_index_from_retrieve(case["retrieve"], N)), dev(case["cand"])[None],
+                                                    lantern=spec["lantern"], k=spec["k"], delta=spec["delta"], tok_offset=m["off"],
+                                                    table=table_dev(m["K"]))
+    assert (int(best[0]), int(alen[0])) == (int(case["best"]), int(case["accept_len"]))
+    assert np.array_equal(row[0].cpu().numpy(), case["out_row"])
+
+
+@pytest.mark.parametrize("model,lantern,delta", [("llamagen", True, 0.2), ("llamagen", True, 4.0), ("anole", True, 0.2), ("anole", False, 0.1)])
+def test_greedy_batched_vs_oracle(model, lantern, delta):
+    """Full-width rows: LlamaGen V=K=16384 whole-vocabulary window; Anole V=65536 with the image window [4,8196)."""
+    rs = np.random.RandomState(3)
+    if model == "llamagen":
+        V, K, off, lo, W = 16384, 16384, 0, 0, 16384
+    else:
+        V, K, off, lo, W = 65536, 8192, 4, 4, 8192
+    tb = oracle.tree_static_build(CS.mc_sim_7b_63)
+    N, (P, D) = len(tb["tree_indices"]), tb["retrieve_indices"].shape
+    ri = H.row_index_from_retrieve(tb["retrieve_indices"], N)
+    tab = np.stack([rs.permutation(K - 1)[:600] for _ in range(K)]).astype(np.uint16)   # 600 columns are enough for k=500
+    tab = np.where(tab >= np.arange(K)[:, None], tab + 1, tab).astype(np.uint16)
+    B = 3
+    logits = (3 * rs.standard_normal((B, N, V))).astype(np.float32)
+    if model == "anole":
+        logits[..., :lo] = np.finfo(np.float32).min
+        logits[..., lo + W:] = np.finfo(np.float32).min
+    cands = []
+    for b in range(B):
+        tok = rs.randint(lo, lo + W, size=N)
+        for n in range(N):                           # make most drafted tokens the (near-)argmax of their parent's row
+            par = np.nonzero(tb["tree_attn_mask"][n] > 0)[0]
+            par = [a for a in par if tb["tree_position_ids"][a] == tb["tree_position_ids"][n] - 1]
+            if par and rs.random_sample() < 0.8:
+                logits[b, par[0], tok[n]] = logits[b, par[0]].max() + rs.uniform(-0.3, 1.0)
+        c = np.where(tb["retrieve_indices"] >= 0, tok[np.maximum(tb["retrieve_indices"], 0)], -1)
+        cands.append(c)
+    cand = np.stack(cands).astype(np.int64)
+    best, alen, row = ops.evaluate_posterior_greedy(dev(logits), dev(ri), dev(cand), lantern=lantern, k=500, delta=delta, tok_offset=off,
+                                                    table=dev(tab.view(np.int16)), win_lo=lo, win_len=W)
+    for b in range(B):
+        ob, oa, orow = oracle.evaluate_posterior_greedy(logits[b], ri, cand[b], lantern=lantern, k=500, delta=delta, tok_offset=off, table=tab)
+        assert (int(best[b]), int(alen[b])) == (ob, oa), (b, int(best[b]), int(alen[b]), ob, oa)
+        assert np.array_equal(row[b].cpu().numpy(), orow)
+    assert int(alen.max()) > 0
+
+
+@pytest.mark.parametrize("M,H,scale,bias", [(2, 1280, 1.0, True), (20, 4096, 1.0, True), (59, 1280, 1.0, False), (120, 4096, 2.0, True)])
+def test_drafter_fc_mfma_vs_oracle(M, H, scale, bias):
+    rs = np.random.RandomState(M + H)
+    vocab = 1000
+    bf = lambda a: torch.from_numpy(a.astype(np.float32)).to(torch.bfloat16)
+    hidden, embed = bf(rs.standard_normal((M, H))), bf(rs.standard_normal((vocab, H)))
+    W = bf(rs.standard_normal((H, 2 * H)) / np.sqrt(2 * H))
+    b = bf(rs.standard_normal(H)) if bias else None
+    ids = rs.randint(0, vocab, size=M)
+    out = ops.drafter_fc(dev(ids), hidden.cuda(), embed.cuda(), W.cuda(), None if b is None else b.cuda(), embed_scale=scale)
+    bits = lambda t: t.view(torch.int16).numpy().view(np.uint16)
+    exp = oracle.drafter_fc(ids, bits(hidden), bits(embed), bits(W), None if b is None else bits(b), embed_scale=scale)
+    got = out.float().cpu().numpy()
+    exp_bf = torch.from_numpy(exp).to(torch.bfloat16).float().numpy()
+    # f32 accumulation over K = 2H bf16 products, then one bf16 rounding: within one bf16 ulp of the f64 reference
+    ulp = np.maximum(np.abs(exp_bf), 1e-3) * 2.0 ** -7
+    assert np.all(np.abs(got - exp_bf) <= ulp), float(np.max(np.abs(got - exp_bf) / ulp))
+    assert np.mean(got == exp_bf) > 0.97
+    # A = I check with an asymmetric B: rows of W must land in the right output columns
+    Hs = 64
+    eye_h = torch.zeros(Hs, Hs); eye_h[torch.arange(Hs), torch.arange(Hs)] = 1
+    Wa = torch.arange(Hs * 2 * Hs, dtype=torch.float32).reshape(Hs, 2 * Hs) % 251 - 125
+    o2 = ops.drafter_fc(torch.zeros(Hs, dtype=torch.int64).cuda(), eye_h.to(torch.bfloat16).cuda(), torch.zeros(4, Hs, dtype=torch.bfloat16).cuda(),
+                        Wa.to(torch.bfloat16).cuda())
+    assert torch.equal(o2.float().cpu(), Wa.to(torch.bfloat16).float()[:, Hs:].T.contiguous())
+
+
+def test_vq_table_builder():
+    g = H.load("codebook.npz")
+    t = ops.build_vq_table(dev(g["codebook"])).cpu().numpy().view(np.uint16)
+    assert np.array_equal(t, oracle.build_vq_table(g["codebook"]))          # same tie rule as the oracle: exact
+    r = g["table"]
+    cb = g["codebook"].astype(np.float64)
+    d = np.sqrt(((cb[:, None] - cb[None]) ** 2).sum(-1))
+    for a, c in np.argwhere(t != r):                                           # vs the reference: only float32 ties may differ
+        assert abs(d[a, t[a, c]] - d[a, r[a, c]]) <= 1e-6 * d[a, t[a, c]]
+    rs = np.random.RandomState(0)
+    cb2 = rs.standard_normal((1000, 16)).astype(np.float32)                    # non power-of-two K
+    t2 = ops.build_vq_table(dev(cb2)).cpu().numpy().view(np.uint16)
+    assert np.array_equal(t2, oracle.build_vq_table(cb2))

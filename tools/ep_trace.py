@@ -5,7 +5,7 @@ sys.path.insert(0, ROOT)
 so = os.path.join(ROOT, "tools", "liblantern_trace.so")
 if not os.path.exists(so):
     src = os.path.join(ROOT, "lantern_amd", "csrc")
-    files = [os.path.join(src, f) for f in ("evaluate_posterior.hip", "logits_post.hip", "window_kernels.hip", "gather_ops.hip", "tree_dynamic.hip", "pending.hip")]
+    files = [os.path.join(src, f) for f in ("evaluate_posterior.hip", "logits_post.hip", "window_kernels.hip", "gather_ops.hip", "tree_dynamic.hip", "greedy.hip", "drafter_fc.hip", "vq_table.hip")]
     subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "-shared", "--offload-arch=gfx950", "-ffp-contract=off", "-DEPW_TRACE",
                            "-o", so] + files + ["-x", "hip", os.path.join(src, "tree_static.cpp")])
 if len(sys.argv) > 1 and sys.argv[1] == "build":

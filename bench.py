@@ -48,6 +48,8 @@ def parse():
     ap.add_argument("--no-kv", action="store_true", help="skip the KV slabs (debug only; invalid as a headline)")
     ap.add_argument("--kv-smax", type=int, default=4096)
     ap.add_argument("--no-events", action="store_true", help="do not time individual kernels")
+    ap.add_argument("--ep-sweep", type=str, default="256,2048",
+                    help="batch sizes for the evaluate_posterior-only roofline sweep (BASELINE.md section 2); empty disables")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="CPU-baseline budget; 0 disables")
     ap.add_argument("--cpu-seqs", type=int, default=0, help="sequences in the CPU sample (0 = host cores)")
     return ap.parse_args()
@@ -148,6 +150,59 @@ def cpu_baseline(wl, steps_budget_s: float, n_seq: int, gpu_tokens_by_seq):
                 matches_gpu_token_stream=(mismatches == 0), mismatches=mismatches)
 
 
+# ------------------------------------------------------------------------- EP-only batch sweep
+
+def ep_batch_sweep(batches, device, base_cfg, iters=20):
+    """evaluate_posterior alone at saturating batch sizes ('fraction of the 8 TB/s peak over a batch sweep').
+    Same synthetic recipe, no KV slabs; inputs of one verify step are produced by the real O6/O7 kernels, then the O8
+    launch is repeated `iters` times on identical inputs (cursor reset by a memset node) between HIP events."""
+    import ctypes as C
+    from lantern_amd import harness as HN
+    from lantern_amd._lib import check
+    out = []
+    for Bs in batches:
+        cfg = HN.WorkloadConfig(n_seq=Bs, pool_steps=1, lantern_k=base_cfg.lantern_k, lantern_delta=base_cfg.lantern_delta,
+                                sigma=base_cfg.sigma, with_kv=False, max_steps=8, path=base_cfg.path, seed_base=base_cfg.seed_base + 500)
+        wl = HN.LuminaVerifyWorkload(cfg, device)
+        wl.step()                      # O6 + O7 fill cand / proc / row_hot; one O8 result lands in log slot 0
+        torch.cuda.synchronize(device)
+        L = wl._L
+        st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        buf = wl.ep_buffers(0, 1)
+        win = wl.ep_window(1) if wl.windowed else None
+
+        def launch():
+            wl.cursor.zero_()
+            if wl.windowed:
+                check(L.lantern_evaluate_posterior_window(C.byref(wl._ep_prm), C.byref(buf), C.byref(win), st), "ep")
+            else:
+                check(L.lantern_evaluate_posterior(C.byref(wl._ep_prm), C.byref(buf), st), "ep")
+        for _ in range(3):
+            launch()
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
+        for e0, e1 in evs:
+            wl.cursor.zero_()
+            e0.record()
+            if wl.windowed:
+                check(L.lantern_evaluate_posterior_window(C.byref(wl._ep_prm), C.byref(buf), C.byref(win), st), "ep")
+            else:
+                check(L.lantern_evaluate_posterior(C.byref(wl._ep_prm), C.byref(buf), st), "ep")
+            e1.record()
+        torch.cuda.synchronize(device)
+        wl.check_status(1, 2)
+        ms = float(np.median([a.elapsed_time(b) for a, b in evs]))
+        nbytes = wl.ep_window_bytes(1, 2) if wl.windowed else wl.ep_algorithmic_bytes(1, 2)
+        dense = wl.ep_algorithmic_bytes(1, 2)
+        tokens = float((wl.log_alen[1].float() + 1).sum())
+        out.append({"sequences_per_launch": Bs, "launch_ms": ms, "algorithmic_bytes_per_launch": nbytes,
+                    "achieved_GBps": nbytes / (ms * 1e-3) / 1e9, "frac": nbytes / (ms * 1e-3) / 1e9 / 8000.0,
+                    "dense_contract_equivalent_GBps": dense / (ms * 1e-3) / 1e9, "us_per_sequence": 1e3 * ms / Bs,
+                    "accepted_tokens_per_launch": tokens})
+        del wl
+        torch.cuda.empty_cache()
+    return out
+
+
 # ------------------------------------------------------------------------------------ main
 
 def main():
@@ -205,8 +260,8 @@ def main():
             "ms_per_step": 1e3 * dt_all / K, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "C3: Lumina-mGPT-7B-768 LANTERN relaxed accept, static tree mc_sim_7b_63 (N=26,P=15,D=6), "
-                                   "V=65536, K=8192, cfg=3.0, top_k=2000, sequential-CFG KV [64,1,32,%d,128] bf16 x2 per sequence"
-                                   % cfg.kv_smax,
+                                   "V=65536, K=8192, cfg=3.0, top_k=2000, sequential-CFG KV [64,1,32,%d,128] bf16 x2 per sequence (row stride %d)"
+                                   % (cfg.kv_smax, cfg.kv_smax + cfg.kv_pad_rows),
                        "lantern_k": cfg.lantern_k, "lantern_delta": cfg.lantern_delta, "seqs_per_gpu": cfg.n_seq,
                        "total_sequences": cfg.n_seq * world, "pool_steps": cfg.pool_steps, "drafter_sigma": cfg.sigma,
                        "kv_cache": cfg.with_kv, "kernel_path": cfg.path, "parallelism": f"dp{world} (independent sequences, no collective)"},
@@ -235,6 +290,12 @@ def main():
                 ks["kv_gather"] = {"avg_launch_ms": kv_ms, "algorithmic_bytes_per_launch": kv_b,
                                    "achieved": kv_b / (kv_ms * 1e-3) / 1e9, "frac": kv_b / (kv_ms * 1e-3) / 1e9 / 8000.0}
             out["kernels"] = ks
+        if args.ep_sweep:
+            sweep = ep_batch_sweep([int(x) for x in args.ep_sweep.split(",") if x], device, cfg)
+            out["ep_batch_sweep"] = sweep
+            bestp = max(sweep, key=lambda r: r["frac"])
+            out["roofline_saturated"] = {"kernel": out.get("roofline", {}).get("kernel"), "sequences_per_launch": bestp["sequences_per_launch"],
+                                         "achieved": bestp["achieved_GBps"], "peak": 8000.0, "unit": "GB/s", "frac": bestp["frac"]}
         if args.cpu_seconds > 0:
             n_cpu = args.cpu_seqs or min(cfg.n_seq, os.cpu_count() or 1)
             # the CPU leg replays the run from step 0 (warm-up included): compare against the whole log

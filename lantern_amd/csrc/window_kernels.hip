@@ -47,6 +47,54 @@ __device__ __forceinline__ float kth_largest_tile(const float4 (&r)[E4], int k, 
     return key_float(prefix);
 }
 
+// k-th largest by radix-256 histograms in LDS: 2 passes for bf16-representable values (HIGH16), 4 for f32.
+// Per pass: one no-return LDS atomic per live value, then every wave resolves the digit from the 256 counters with
+// 4 bins per lane + one DPP scan (no serial loop, no extra barrier for a broadcast).  `hist` = 256 ints.
+template <int NT, int E4, bool HIGH16>
+__device__ __forceinline__ float kth_largest_hist(const float4 (&r)[E4], int k, int *hist) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    uint32_t prefix = 0, mask = 0;
+    int krem = k;
+#pragma unroll 1
+    for (int pass = 0; pass < (HIGH16 ? 2 : 4); ++pass) {
+        const int shift = 24 - 8 * pass;
+        for (int t = tid; t < 256; t += NT) hist[t] = 0;
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < E4; ++it) {
+            const uint32_t kk[4] = {float_key(r[it].x), float_key(r[it].y), float_key(r[it].z), float_key(r[it].w)};
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                if ((kk[c] & mask) == prefix) atomicAdd(&hist[(kk[c] >> shift) & 255u], 1);
+        }
+        __syncthreads();
+        const int c0 = hist[4 * lane], c1 = hist[4 * lane + 1], c2 = hist[4 * lane + 2], c3 = hist[4 * lane + 3];
+        const int s4 = c0 + c1 + c2 + c3;
+        const int incl = wave_scan_incl_dpp(s4);
+        const int total = readlane63(incl);
+        if (total < krem) return -__builtin_inff();     // fewer than k values: the k-th largest is below everything
+        int above = total - incl;                        // values in bins of higher lanes
+        int digit = -1, kn = 0;
+        // bins of this lane, high to low
+        if (above < krem && above + c3 >= krem) { digit = 4 * lane + 3; kn = krem - above; }
+        above += c3;
+        if (digit < 0 && above < krem && above + c2 >= krem) { digit = 4 * lane + 2; kn = krem - above; }
+        above += c2;
+        if (digit < 0 && above < krem && above + c1 >= krem) { digit = 4 * lane + 1; kn = krem - above; }
+        above += c1;
+        if (digit < 0 && above < krem && above + c0 >= krem) { digit = 4 * lane; kn = krem - above; }
+        const unsigned long long who = __ballot(digit >= 0);
+        const int src = __ffsll((long long)who) - 1;
+        digit = __shfl(digit, src, 64);
+        krem = __shfl(kn, src, 64);
+        prefix |= (uint32_t)digit << shift;
+        mask |= 255u << shift;
+        __syncthreads();   // everyone has read hist before the next pass clears it
+    }
+    if (HIGH16 && !(prefix & 0x80000000u)) prefix |= 0xffffu;   // negative float: key = ~bits, low half all ones
+    return key_float(prefix);
+}
+
 // ------------------------------------------------------------------------------- O7 windowed
 template <int NT, int E4, bool BF16>
 __global__ __launch_bounds__(NT) void cfg_window_kernel(const void *__restrict__ cond_, const void *__restrict__ uncond_, int V, float cfg,
@@ -54,11 +102,10 @@ __global__ __launch_bounds__(NT) void cfg_window_kernel(const void *__restrict__
                                                         int h_latent, int img_lo, int img_hi, int newline_id, int eos_id, int top_k,
                                                         const int64_t *__restrict__ seq_len, int rows_per_seq, int win_lo, int W,
                                                         float *__restrict__ out_win, int32_t *__restrict__ row_hot) {
-    __shared__ int s_redi[2 * (NT / 64)];
+    __shared__ int s_hist[256];
     const int row = blockIdx.x, tid = threadIdx.x;
     const float NEG_INF = -__builtin_inff();
     float *out = out_win + (size_t)row * W;
-    int ph = 0;
     int cls = 0;
     if (model == LANTERN_MODEL_LUMINA) {
         const int64_t pos = seq_len ? pos_ids[row % rows_per_seq] + seq_len[row / rows_per_seq] : pos_ids[row];
@@ -117,7 +164,7 @@ __global__ __launch_bounds__(NT) void cfg_window_kernel(const void *__restrict__
     if (top_k > 0 && top_k < V) {
         // k-th largest of the FULL row = k-th largest of the window whenever >= k window entries beat the fill
         // value; otherwise the threshold is the fill value (or lower) and nothing inside the window is removed.
-        const float thr = (top_k <= W) ? kth_largest_tile<NT, E4, BF16>(r, top_k, s_redi, ph) : NEG_INF;
+        const float thr = (top_k <= W) ? kth_largest_hist<NT, E4, BF16>(r, top_k, s_hist) : NEG_INF;
 #pragma unroll
         for (int it = 0; it < E4; ++it) {
             r[it].x = r[it].x < thr ? NEG_INF : r[it].x;
@@ -805,8 +852,8 @@ extern "C" int lantern_cfg_mask_topk_window(const void *cond, const void *uncond
 #define CW_ARGS bf, rows, st, cond, uncond, V, cfg, model, pos_ids, pos_base, w_latent, h_latent, img_lo, img_hi, newline_id, eos_id, top_k, seq_len, rows_per_seq, win_lo, win_len, out_win, row_hot
     if (win_len <= 1024) launch_cfgw<256, 1>(CW_ARGS);
     else if (win_len <= 2048) launch_cfgw<256, 2>(CW_ARGS);
-    else if (win_len <= 4096) launch_cfgw<1024, 1>(CW_ARGS);
-    else if (win_len <= 8192) launch_cfgw<1024, 2>(CW_ARGS);
+    else if (win_len <= 4096) launch_cfgw<512, 2>(CW_ARGS);
+    else if (win_len <= 8192) launch_cfgw<512, 4>(CW_ARGS);
     else launch_cfgw<1024, 4>(CW_ARGS);
 #undef CW_ARGS
     LANTERN_CHECK_LAUNCH("cfg_mask_topk_window");
@@ -850,7 +897,12 @@ extern "C" int lantern_evaluate_posterior_window(const lantern_ep_params *prm, c
     if (W <= 1024) hipLaunchKernelGGL((epw_kernel<256, 1>), grid, dim3(256), lds, st, p, *buf, *win);
     else if (W <= 2048) hipLaunchKernelGGL((epw_kernel<256, 2>), grid, dim3(256), lds, st, p, *buf, *win);
     else if (W <= 4096) hipLaunchKernelGGL((epw_kernel<512, 2>), grid, dim3(512), lds, st, p, *buf, *win);
-    else if (W <= 8192) hipLaunchKernelGGL((epw_kernel<512, 4>), grid, dim3(512), lds, st, p, *buf, *win);
+    else if (W <= 8192) {
+        static const int nt_override = getenv("LANTERN_EPW_NT") ? atoi(getenv("LANTERN_EPW_NT")) : 0;   // tuning knob (diagnostic)
+        if (nt_override == 256) hipLaunchKernelGGL((epw_kernel<256, 8>), grid, dim3(256), lds, st, p, *buf, *win);
+        else if (nt_override == 1024) hipLaunchKernelGGL((epw_kernel<1024, 2>), grid, dim3(1024), lds, st, p, *buf, *win);
+        else hipLaunchKernelGGL((epw_kernel<512, 4>), grid, dim3(512), lds, st, p, *buf, *win);
+    }
     else hipLaunchKernelGGL((epw_kernel<1024, 4>), grid, dim3(1024), lds, st, p, *buf, *win);
     LANTERN_CHECK_LAUNCH("evaluate_posterior_window");
     return LANTERN_OK;

@@ -54,6 +54,8 @@ class WorkloadConfig:
     kv_heads: int = 32
     kv_smax: int = 4096
     kv_dim: int = 128
+    kv_pad_rows: int = 16           # row stride = kv_smax + pad: a 4096*256 B = 1 MiB stride between (layer, head) groups lands
+                                    # every group on the same HBM channel set (measured 56 -> 42 us per gather); DESIGN.md 3
     with_kv: bool = True
     seed_base: int = 3000           # 1000 * config index (C3)
     max_steps: int = 4096           # uniform stream sizing
@@ -154,7 +156,7 @@ class LuminaVerifyWorkload:
         self.first_token = torch.randint(IMG_LO, IMG_HI, (B,), generator=gen, device=device)
         self.slabs: List[torch.Tensor] = []
         if cfg.with_kv:
-            shape = (2 * cfg.kv_layers, 1, cfg.kv_heads, cfg.kv_smax, cfg.kv_dim)
+            shape = (2 * cfg.kv_layers, 1, cfg.kv_heads, cfg.kv_smax + cfg.kv_pad_rows, cfg.kv_dim)
             for _ in range(2 * B):                 # [cond slabs of all sequences..., uncond slabs...]
                 self.slabs.append(torch.zeros(shape, dtype=torch.bfloat16, device=device))
             self.slab_ptrs = torch.tensor([s.data_ptr() for s in self.slabs], dtype=torch.int64, device=device)
@@ -280,7 +282,7 @@ class LuminaVerifyWorkload:
             if events:
                 events["kv_gather"][0].record()
             check(L.lantern_kv_gather(vp(self.slab_ptrs.data_ptr()), vp(self.slab_seq.data_ptr()), vp(cur.data_ptr()), 2 * B, 2,
-                                      C.c_int64(2 * c.kv_layers * c.kv_heads), C.c_int64(c.kv_smax), C.c_int64(c.kv_dim),
+                                      C.c_int64(2 * c.kv_layers * c.kv_heads), C.c_int64(c.kv_smax + c.kv_pad_rows), C.c_int64(c.kv_dim),
                                       vp(self.d_retrieve.data_ptr()), 0, P, D, vp(self.log_best[i].data_ptr()),
                                       vp(self.log_alen[i].data_ptr()), vp(nxt.data_ptr()), st), "kv_gather")
             if events:

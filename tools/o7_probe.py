@@ -14,7 +14,8 @@ def timeit(fn, n=100):
     return e0.elapsed_time(e1) / n * 1e3
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
-cfg = HN.WorkloadConfig(n_seq=B, pool_steps=2, with_kv=True, max_steps=64)
+SM = int(os.environ.get("KV_SMAX", "4096"))
+cfg = HN.WorkloadConfig(n_seq=B, pool_steps=2, with_kv=True, max_steps=64, kv_smax=SM)
 wl = HN.LuminaVerifyWorkload(cfg, torch.device("cuda"))
 wl.step(); torch.cuda.synchronize()
 N, V = wl.N, HN.V

@@ -60,6 +60,8 @@ class WorkloadConfig:
     seed_base: int = 3000           # 1000 * config index (C3)
     max_steps: int = 4096           # uniform stream sizing
     table_seed: int = 0
+    use_graph: bool = False         # True: replay one captured hipGraph per pool slot (6 kernels, fixed arguments); measured
+                                    # 167 us/step vs 158 us eager on MI355X (the eager queue already runs ahead of the GPU)
     path: str = "window"            # "window": v2 kernels (32 KB rows, LDS-resident residual); "dense": v1 kernels
 
 
@@ -157,11 +159,15 @@ class LuminaVerifyWorkload:
         self.slabs: List[torch.Tensor] = []
         if cfg.with_kv:
             shape = (2 * cfg.kv_layers, 1, cfg.kv_heads, cfg.kv_smax + cfg.kv_pad_rows, cfg.kv_dim)
+            need = 2 * B * int(np.prod(shape)) * 2
+            free, _total = torch.cuda.mem_get_info(device)
+            if need + (8 << 30) > free:      # never drive the box out of memory
+                raise _lib.LanternError(f"KV slabs need {need / 2**30:.0f} GiB (+8 GiB head-room) but only {free / 2**30:.0f} GiB are free: "
+                                        f"lower --seqs-per-gpu ({B})")
             for _ in range(2 * B):                 # [cond slabs of all sequences..., uncond slabs...]
                 self.slabs.append(torch.zeros(shape, dtype=torch.bfloat16, device=device))
             self.slab_ptrs = torch.tensor([s.data_ptr() for s in self.slabs], dtype=torch.int64, device=device)
             self.slab_seq = torch.arange(B, dtype=torch.int32, device=device).repeat(2)
-        self.reset_state()
 
         # ---------------- work buffers
         self.cand = torch.empty((B, P, D), dtype=torch.int64, device=device)
@@ -183,8 +189,17 @@ class LuminaVerifyWorkload:
         self.log_alen = torch.zeros((cfg.max_steps, B), dtype=torch.int32, device=device)
         self.log_cnt = torch.zeros((cfg.max_steps, B, 6), dtype=torch.int32, device=device)
         self.log_token = torch.zeros((cfg.max_steps, B), dtype=torch.int64, device=device)
+        # per-step staging (fixed addresses: a step is then a fixed kernel sequence, capturable into a hipGraph)
+        self.st_best = torch.zeros(B, dtype=torch.int32, device=device)
+        self.st_alen = torch.zeros(B, dtype=torch.int32, device=device)
+        self.st_cnt = torch.zeros((B, 6), dtype=torch.int32, device=device)
+        self.st_token = torch.zeros(B, dtype=torch.int64, device=device)
+        self.u_cur = torch.zeros(B, dtype=torch.float64, device=device)
+        self.step_dev = torch.zeros(1, dtype=torch.int64, device=device)
         self._L = _lib.lib()
         self._ep_prm = self._make_ep_params()
+        self.graphs = None
+        self.reset_state()
 
     # -------------------------------------------------------------------------------------
     def reset_state(self):
@@ -192,11 +207,24 @@ class LuminaVerifyWorkload:
         cond0 = self.cfg.prompt_len + 3
         # lens[0] = current, lens[1] = next (double buffer); layout [cond lens of all seqs, uncond lens]
         base = torch.cat([torch.full((B,), cond0, dtype=torch.int64), torch.full((B,), 3, dtype=torch.int64)]).to(dev)
-        self.len_base = base
-        self.lens = [base.clone(), base.clone()]
-        self.cursor = torch.zeros(B, dtype=torch.int32, device=dev)
-        self.sample_token = self.first_token.clone()
+        if hasattr(self, "len_base"):
+            self.len_base.copy_(base)
+        else:
+            self.len_base = base
+        if hasattr(self, "lens"):
+            self.lens[0].copy_(base)
+            self.lens[1].copy_(base)
+        else:
+            self.lens = [base.clone(), base.clone()]
+        self.cursor = torch.zeros(B, dtype=torch.int32, device=dev) if not hasattr(self, "cursor") else self.cursor.zero_()
+        if not hasattr(self, "sample_token"):
+            self.sample_token = self.first_token.clone()
+        else:
+            self.sample_token.copy_(self.first_token)
         self.step_idx = 0
+        if hasattr(self, "step_dev"):
+            self.step_dev.zero_()
+            self.u_cur.copy_(self.u_bonus[0])
 
     def _make_ep_params(self) -> EpParams:
         c = self.cfg
@@ -220,8 +248,8 @@ class LuminaVerifyWorkload:
                                                self.d_b_idx.data_ptr())
         b.tree_cand, b.nn_table = self.tree_cand.data_ptr(), self.table.data_ptr()
         b.uniforms, b.cursor = self.uniforms.data_ptr(), self.cursor.data_ptr()
-        b.best, b.accept_len = self.log_best[i].data_ptr(), self.log_alen[i].data_ptr()
-        b.counters = self.log_cnt[i].data_ptr()
+        b.best, b.accept_len = self.st_best.data_ptr(), self.st_alen.data_ptr()
+        b.counters = self.st_cnt.data_ptr()
         if not self.windowed:
             b.workspace, b.sample_p = self.workspace.data_ptr(), self.sample_p.data_ptr()
         return b
@@ -231,19 +259,50 @@ class LuminaVerifyWorkload:
         w.win_lo, w.win_len, w.row_hot = self.win_lo, self.W, self.row_hot.data_ptr()
         w.orig_prob_stride, w.orig_prob_offset = self.W, 0
         w.out_tok, w.out_mass = self.out_tok.data_ptr(), self.out_mass.data_ptr()
-        w.u_bonus, w.token = self.u_bonus[i].data_ptr(), self.log_token[i].data_ptr()
+        w.u_bonus, w.token = self.u_cur.data_ptr(), self.st_token.data_ptr()
         return w
 
     # -------------------------------------------------------------------------------------
     def step(self, events=None):
-        """One verify step over all sequences.  `events`: optional dict name -> (start,end) torch events
-        recorded around the three HBM-heavy kernels on the launch stream."""
-        c, L = self.cfg, self._L
+        """One verify step over all sequences.  `events`: optional dict name -> (start,end) torch events recorded around
+        the HBM-heavy kernels on the launch stream (eager launches only).  Without events and with cfg.use_graph the step
+        is one hipGraph replay."""
         i = self.step_idx
-        slot = i % c.pool_steps
+        slot = i % self.cfg.pool_steps
+        if events is None and self.cfg.use_graph and self.cfg.pool_steps % 2 == 0:
+            if self.graphs is None:
+                self._capture_graphs()
+            self.graphs[slot].replay()
+        else:
+            self._launch_step(slot, i & 1, events)
+        self.step_idx += 1
+
+    def _capture_graphs(self):
+        """One graph per pool slot (the lens double buffer alternates with the slot parity)."""
+        dev = self.device
+        snap = [t.clone() for t in (self.lens[0], self.lens[1], self.cursor, self.sample_token, self.step_dev, self.u_cur)]
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):            # warm-up launches outside capture (module load, lazy init)
+            self._launch_step(0, 0, None)
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+        self.graphs = []
+        for slot in range(self.cfg.pool_steps):
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self._launch_step(slot, slot & 1, None)
+            self.graphs.append(g)
+        torch.cuda.synchronize(dev)
+        for t, v in zip((self.lens[0], self.lens[1], self.cursor, self.sample_token, self.step_dev, self.u_cur), snap):
+            t.copy_(v)                            # capture does not execute, the warm-up did: restore the state
+        torch.cuda.synchronize(dev)
+
+    def _launch_step(self, slot: int, parity: int, events):
+        c, L = self.cfg, self._L
         B, N, P, D = c.n_seq, self.N, self.P, self.D
         st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-        cur, nxt = self.lens[i & 1], self.lens[(i + 1) & 1]
+        cur, nxt = self.lens[parity], self.lens[parity ^ 1]
         vp = C.c_void_p
 
         # O6 candidate assembly
@@ -268,10 +327,10 @@ class LuminaVerifyWorkload:
         if events:
             events["cfg_mask_topk"][1].record()
             events["evaluate_posterior"][0].record()
-        # O8
-        buf = self.ep_buffers(slot, i)
-        if self.windowed:      # bonus token drawn in the kernel epilogue
-            win = self.ep_window(i)
+        # O8 (windowed: the bonus token is drawn in the kernel epilogue)
+        buf = self.ep_buffers(slot, 0)
+        if self.windowed:
+            win = self.ep_window(0)
             check(L.lantern_evaluate_posterior_window(C.byref(self._ep_prm), C.byref(buf), C.byref(win), st), "evaluate_posterior_window")
         else:
             check(L.lantern_evaluate_posterior(C.byref(self._ep_prm), C.byref(buf), st), "evaluate_posterior")
@@ -283,24 +342,26 @@ class LuminaVerifyWorkload:
                 events["kv_gather"][0].record()
             check(L.lantern_kv_gather(vp(self.slab_ptrs.data_ptr()), vp(self.slab_seq.data_ptr()), vp(cur.data_ptr()), 2 * B, 2,
                                       C.c_int64(2 * c.kv_layers * c.kv_heads), C.c_int64(c.kv_smax + c.kv_pad_rows), C.c_int64(c.kv_dim),
-                                      vp(self.d_retrieve.data_ptr()), 0, P, D, vp(self.log_best[i].data_ptr()),
-                                      vp(self.log_alen[i].data_ptr()), vp(nxt.data_ptr()), st), "kv_gather")
+                                      vp(self.d_retrieve.data_ptr()), 0, P, D, vp(self.st_best.data_ptr()), vp(self.st_alen.data_ptr()),
+                                      vp(nxt.data_ptr()), st), "kv_gather")
             if events:
                 events["kv_gather"][1].record()
         else:
-            torch.add(cur, (self.log_alen[i] + 1).repeat(2), out=nxt)
-        # O10 accepted hidden + token append + bonus token (feeds the next step's O6)
+            torch.add(cur, (self.st_alen + 1).repeat(2), out=nxt)
+        # O10 accepted hidden + token append (+ bonus token on the dense path)
         check(L.lantern_accept_gather(vp(self.hidden[slot].data_ptr()), 2, B, 2, N, HIDDEN, vp(self.d_retrieve.data_ptr()), 0, P, D,
-                                      vp(self.cand.data_ptr()), vp(self.log_best[i].data_ptr()), vp(self.log_alen[i].data_ptr()),
+                                      vp(self.cand.data_ptr()), vp(self.st_best.data_ptr()), vp(self.st_alen.data_ptr()),
                                       vp(None if self.windowed else self.sample_p.data_ptr()), V,
-                                      vp(None if self.windowed else self.u_bonus[i].data_ptr()), vp(self.out_hidden.data_ptr()),
-                                      vp(self.acc_tokens.data_ptr()), vp(None if self.windowed else self.log_token[i].data_ptr()), st),
+                                      vp(None if self.windowed else self.u_cur.data_ptr()), vp(self.out_hidden.data_ptr()),
+                                      vp(self.acc_tokens.data_ptr()), vp(None if self.windowed else self.st_token.data_ptr()), st),
               "accept_gather")
-        # harness bookkeeping (sequence management, not the hot path): next sample token, image wrap-around
-        self.sample_token = self.log_token[i]
-        done = (nxt - self.len_base) >= TOKENS_PER_IMAGE
-        torch.where(done, self.len_base, nxt, out=nxt)
-        self.step_idx += 1
+        # harness bookkeeping (sequence management, not the hot path): logs, next sample token, image wrap-around, step counter
+        check(L.lantern_harness_advance(B, 2 * B, C.c_int64(TOKENS_PER_IMAGE), C.c_int64(c.max_steps), vp(self.step_dev.data_ptr()),
+                                        vp(self.st_best.data_ptr()), vp(self.st_alen.data_ptr()), vp(self.st_cnt.data_ptr()),
+                                        vp(self.st_token.data_ptr()), vp(self.log_best.data_ptr()), vp(self.log_alen.data_ptr()),
+                                        vp(self.log_cnt.data_ptr()), vp(self.log_token.data_ptr()), vp(self.sample_token.data_ptr()),
+                                        vp(nxt.data_ptr()), vp(self.len_base.data_ptr()), vp(self.u_bonus.data_ptr()),
+                                        vp(self.u_cur.data_ptr()), st), "harness_advance")
 
     # -------------------------------------------------------------------------------------
     def accepted_tokens(self, i0: int, i1: int) -> int:
@@ -309,19 +370,25 @@ class LuminaVerifyWorkload:
     def ep_algorithmic_bytes(self, i0: int, i1: int) -> float:
         """SURVEY 8d contract figure summed over steps [i0,i1) and all sequences:
         L*V*4 + T*k*6 + R*(k+1)*4 + V*4 (+ V*4 when the final row is a fresh softmax)."""
-        c = self.log_cnt[i0:i1].to(torch.float64)
+        return self.ep_algorithmic_bytes_from(self.log_cnt[i0:i1])
+
+    def ep_algorithmic_bytes_from(self, cnt) -> float:
+        c = cnt.to(torch.float64).reshape(-1, 6)
         k = self.cfg.lantern_k
-        Lv, T, Rj, fresh = c[..., 0].sum(), c[..., 1].sum(), c[..., 2].sum(), (1 - c[..., 4]).sum()
-        n = c.shape[0] * c.shape[1]
+        Lv, T, Rj, fresh = c[:, 0].sum(), c[:, 1].sum(), c[:, 2].sum(), (1 - c[:, 4]).sum()
+        n = c.shape[0]
         return float(Lv * V * 4 + T * k * 6 + Rj * (k + 1) * 4 + n * V * 4 + fresh * V * 4)
 
     def ep_window_bytes(self, i0: int, i1: int) -> float:
         """HBM bytes the windowed kernel must move: per visited level and per fresh final row one window row
         (W*4); per tried candidate k table ids (k*2); per rejection one drafter window row (W*4, static trees).  The
         neighbour gathers, zeroing, scans and the bonus-token draw run in LDS."""
-        c = self.log_cnt[i0:i1].to(torch.float64)
+        return self.ep_window_bytes_from(self.log_cnt[i0:i1])
+
+    def ep_window_bytes_from(self, cnt) -> float:
+        c = cnt.to(torch.float64).reshape(-1, 6)
         k, W = self.cfg.lantern_k, self.W
-        Lv, T, Rj, fresh = c[..., 0].sum(), c[..., 1].sum(), c[..., 2].sum(), (1 - c[..., 4]).sum()
+        Lv, T, Rj, fresh = c[:, 0].sum(), c[:, 1].sum(), c[:, 2].sum(), (1 - c[:, 4]).sum()
         return float((Lv + fresh) * W * 4 + T * k * 2 + Rj * (W * 4 + 2))
 
     def o7_algorithmic_bytes(self, n_steps: int) -> float:

@@ -18,7 +18,7 @@ def timeit(fn, n=50):
 
 def main():
     B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
-    cfg = HN.WorkloadConfig(n_seq=B, pool_steps=2, with_kv=False, max_steps=64)
+    cfg = HN.WorkloadConfig(n_seq=B, pool_steps=2, with_kv=False, max_steps=64, use_graph=False)
     wl = HN.LuminaVerifyWorkload(cfg, torch.device("cuda"))
     wl.step()   # fills cand/proc/row_hot for slot 0
     torch.cuda.synchronize()
@@ -36,14 +36,14 @@ def main():
     base = wl._ep_prm
     print("B =", B)
     print("cursor.zero_ only      us", timeit(lambda: wl.cursor.zero_()))
-    print("full                    us", timeit(run(base)), wl.log_cnt[1].float().mean(0).tolist())
+    print("full                    us", timeit(run(base)), wl.st_cnt.float().mean(0).tolist())
     zeros = torch.zeros_like(wl.uniforms)
-    print("accept-all (u=0)        us", timeit(run(base, zeros)), wl.log_cnt[1].float().mean(0).tolist())
+    print("accept-all (u=0)        us", timeit(run(base, zeros)), wl.st_cnt.float().mean(0).tolist())
     ones = torch.full_like(wl.uniforms, 0.9999999)
-    print("reject-mostly (u~1)     us", timeit(run(base, ones)), wl.log_cnt[1].float().mean(0).tolist())
+    print("reject-mostly (u~1)     us", timeit(run(base, ones)), wl.st_cnt.float().mean(0).tolist())
     import copy
     p2 = copy.copy(base); p2.lantern = 0
-    print("lantern off             us", timeit(run(p2)), wl.log_cnt[1].float().mean(0).tolist())
+    print("lantern off             us", timeit(run(p2)), wl.st_cnt.float().mean(0).tolist())
     print("no bonus draw           us", timeit(run(base, bonus=False)))
     p3 = copy.copy(base); p3.D = 1
     print("D=1 (final softmax only) us", timeit(run(p3)))

@@ -5,7 +5,7 @@ sys.path.insert(0, ROOT)
 so = os.path.join(ROOT, "tools", "liblantern_trace.so")
 if not os.path.exists(so):
     src = os.path.join(ROOT, "lantern_amd", "csrc")
-    files = [os.path.join(src, f) for f in ("evaluate_posterior.hip", "logits_post.hip", "window_kernels.hip", "gather_ops.hip", "tree_dynamic.hip", "greedy.hip", "drafter_fc.hip", "vq_table.hip")]
+    files = [os.path.join(src, f) for f in ("evaluate_posterior.hip", "logits_post.hip", "window_kernels.hip", "gather_ops.hip", "tree_dynamic.hip", "greedy.hip", "drafter_fc.hip", "vq_table.hip", "harness_util.hip")]
     subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "-shared", "--offload-arch=gfx950", "-ffp-contract=off", "-DEPW_TRACE",
                            "-o", so] + files + ["-x", "hip", os.path.join(src, "tree_static.cpp")])
 if len(sys.argv) > 1 and sys.argv[1] == "build":
@@ -16,7 +16,7 @@ _lib.LIB_PATH = so
 from lantern_amd import harness as HN
 from lantern_amd._lib import check
 B = 32
-wl = HN.LuminaVerifyWorkload(HN.WorkloadConfig(n_seq=B, pool_steps=2, with_kv=False, max_steps=64), torch.device("cuda"))
+wl = HN.LuminaVerifyWorkload(HN.WorkloadConfig(n_seq=B, pool_steps=2, with_kv=False, max_steps=64, use_graph=False), torch.device("cuda"))
 L = wl._L
 for _ in range(3):
     wl.step()
@@ -33,4 +33,4 @@ for i in range(n):
     pid, t = buf[2 * i], buf[2 * i + 1]
     print(f"{names.get(pid, pid):28s} +{(t - prev):7d} cyc   t={(t - t0) / 100.0:8.2f} us(100MHz ticks?)")
     prev = t
-print("counters seq0:", wl.log_cnt[wl.step_idx - 1, 0].tolist())
+print("counters seq0:", wl.st_cnt[0].tolist())

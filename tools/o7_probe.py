@@ -15,7 +15,7 @@ def timeit(fn, n=100):
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 SM = int(os.environ.get("KV_SMAX", "4096"))
-cfg = HN.WorkloadConfig(n_seq=B, pool_steps=2, with_kv=True, max_steps=64, kv_smax=SM)
+cfg = HN.WorkloadConfig(n_seq=B, pool_steps=2, with_kv=True, max_steps=64, kv_smax=SM, use_graph=False)
 wl = HN.LuminaVerifyWorkload(cfg, torch.device("cuda"))
 wl.step(); torch.cuda.synchronize()
 N, V = wl.N, HN.V
@@ -26,7 +26,7 @@ def o7(top_k, model=ops.MODEL_LUMINA):
 print("O7w top_k=2000 us", timeit(o7(2000)))
 print("O7w top_k=0    us", timeit(o7(0)))
 print("O7w anole(no topk) us", timeit(o7(0, ops.MODEL_ANOLE)))
-best, alen = wl.log_best[0], wl.log_alen[0]
+best, alen = wl.st_best, wl.st_alen
 slab_prev = wl.lens[0]
 def kv():
     ops.kv_gather(wl.slabs, wl.slab_seq, slab_prev, wl.d_retrieve, best, alen, slab_ptrs=wl.slab_ptrs)

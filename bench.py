@@ -38,7 +38,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--seqs-per-gpu", type=int, default=32)
+    ap.add_argument("--seqs-per-gpu", type=int, default=48, help="sequences resident per GPU (KV slabs: 4.3 GB each; 48 -> 206 GB of the 288 GB)")
     ap.add_argument("--pool-steps", type=int, default=16)
     ap.add_argument("--lantern-k", type=int, default=1000)
     ap.add_argument("--lantern-delta", type=float, default=0.1)
@@ -49,8 +49,8 @@ def parse():
     ap.add_argument("--kv-smax", type=int, default=4096)
     ap.add_argument("--no-events", action="store_true", help="skip the eager per-kernel timing pass")
     ap.add_argument("--graph", action="store_true", help="replay one captured hipGraph per pool slot instead of launching eagerly")
-    ap.add_argument("--ep-sweep", type=str, default="256,2048",
-                    help="batch sizes for the evaluate_posterior-only roofline sweep (BASELINE.md section 2); empty disables")
+    ap.add_argument("--ep-sweep", type=str, default="",
+                    help="e.g. 256,2048: batch sizes for the evaluate_posterior-only roofline sweep (BASELINE.md section 2); off by default so that the default command launches every kernel on one homogeneous workload (rocprofv3 averages then agree with the HIP-event averages)")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="CPU-baseline budget; 0 disables")
     ap.add_argument("--cpu-seqs", type=int, default=0, help="sequences in the CPU sample (0 = host cores)")
     return ap.parse_args()
@@ -162,6 +162,11 @@ def ep_batch_sweep(batches, device, base_cfg, iters=20):
     from lantern_amd._lib import check
     out = []
     for Bs in batches:
+        need = Bs * (2 * 26 * 65536 * 2 + 6 * 26 * 65536 * 4 + 11 * 65536 * 4 * 3) + (4 << 30)   # pools + setup temporaries
+        free, _ = torch.cuda.mem_get_info(device)
+        if need > free:
+            out.append({"sequences_per_launch": Bs, "skipped": f"needs {need >> 30} GiB, {free >> 30} GiB free"})
+            continue
         cfg = HN.WorkloadConfig(n_seq=Bs, pool_steps=1, use_graph=False, lantern_k=base_cfg.lantern_k, lantern_delta=base_cfg.lantern_delta,
                                 sigma=base_cfg.sigma, with_kv=False, max_steps=8, path=base_cfg.path, seed_base=base_cfg.seed_base + 500)
         wl = HN.LuminaVerifyWorkload(cfg, device)
@@ -303,9 +308,10 @@ def main():
                                    "achieved": kv_b / (kv_ms * 1e-3) / 1e9, "frac": kv_b / (kv_ms * 1e-3) / 1e9 / 8000.0}
             out["kernels"] = ks
         if args.ep_sweep:
+            wl.release_kv()      # the sweep builds its own (KV-free) workloads: give the memory back first
             sweep = ep_batch_sweep([int(x) for x in args.ep_sweep.split(",") if x], device, cfg)
             out["ep_batch_sweep"] = sweep
-            bestp = max(sweep, key=lambda r: r["frac"])
+            bestp = max([r for r in sweep if "frac" in r], key=lambda r: r["frac"])
             out["roofline_saturated"] = {"kernel": out.get("roofline", {}).get("kernel"), "sequences_per_launch": bestp["sequences_per_launch"],
                                          "achieved": bestp["achieved_GBps"], "peak": 8000.0, "unit": "GB/s", "frac": bestp["frac"]}
         if args.cpu_seconds > 0:

@@ -41,7 +41,7 @@ HIDDEN = 4096
 
 @dataclass
 class WorkloadConfig:
-    n_seq: int = 32
+    n_seq: int = 48
     pool_steps: int = 16
     lantern_k: int = 1000
     lantern_delta: float = 0.1
@@ -225,6 +225,12 @@ class LuminaVerifyWorkload:
         if hasattr(self, "step_dev"):
             self.step_dev.zero_()
             self.u_cur.copy_(self.u_bonus[0])
+
+    def release_kv(self):
+        """Free the KV slabs (most of the footprint) once the timed loop is over."""
+        self.slabs = []
+        self.slab_ptrs = None
+        torch.cuda.empty_cache()
 
     def _make_ep_params(self) -> EpParams:
         c = self.cfg

@@ -240,26 +240,6 @@ typedef struct lantern_ep_window {
 int lantern_evaluate_posterior_window(const lantern_ep_params *prm, const lantern_ep_buffers *buf,
                                       const lantern_ep_window *win, void *stream);
 
-/* O7 fused into O8: the windowed kernel reads the RAW cond/uncond logits of the visited tree nodes only
- * (L+1 rows per step instead of all N), applies CFG + model mask + top-k threshold on the fly and never
- * writes processed logits at all.  buf->logits / win->row_hot are ignored; rows_per_seq = N nodes.
- * Arguments as lantern_cfg_mask_topk (seq_len form: pos = pos_ids[node] + seq_len[sequence]). */
-typedef struct lantern_ep_fused {
-    const void *cond;      /* [dev] [B, N, V] */
-    const void *uncond;    /* [dev] [B, N, V] or NULL (already combined) */
-    int32_t dtype;         /* LANTERN_F32 / LANTERN_BF16 */
-    int32_t model;         /* LANTERN_MODEL_* */
-    float cfg;
-    int32_t top_k;         /* O7's top-k (Lumina: InterleavedTopKLogitsWarper), <= 0 off */
-    const int64_t *pos_ids;   /* [dev] [N] tree_position_ids + 1 (Lumina) */
-    const int64_t *seq_len;   /* [dev] [B] len(input_ids) per sequence (Lumina) */
-    int64_t pos_base;
-    int32_t w_latent, h_latent, newline_id, eos_id;
-} lantern_ep_fused;
-
-int lantern_verify_fused(const lantern_ep_params *prm, const lantern_ep_buffers *buf, const lantern_ep_window *win,
-                         const lantern_ep_fused *fused, void *stream);
-
 /* window -> dense [B,V] (API compatibility with callers that want the reference's sample_p[V]). */
 int lantern_window_to_dense(const float *win, const int32_t *out_tok, const float *out_mass, int B, int V,
                             int win_lo, int win_len, float *dense, void *stream);

@@ -41,6 +41,7 @@ __global__ void gather_candidates_kernel(const int64_t *__restrict__ ss_token, c
 // one (layer,batch,head) row-group: it loads the <= MAXSEL selected chunks into registers,
 // then stores them at prev..prev+a, so the in-place move cannot race with itself.
 constexpr int KV_MAXSEL = 16;
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
 
 __global__ __launch_bounds__(256) void kv_gather_kernel(void *const *__restrict__ slab_ptrs, const int32_t *__restrict__ slab_seq,
                                                         const int64_t *__restrict__ slab_prev, int64_t outer, int64_t S_max,
@@ -57,23 +58,23 @@ __global__ __launch_bounds__(256) void kv_gather_kernel(void *const *__restrict_
     const int64_t *rrow = retrieve + (retrieve_per_seq ? (size_t)seq * P * D : 0) + (size_t)bst * D;
     if (blockIdx.x == 0 && threadIdx.x == 0 && new_len) new_len[s] = prev + n_sel;
 
-    uint4 *base = reinterpret_cast<uint4 *>(slab_ptrs[s]);
+    u32x4_t *base = reinterpret_cast<u32x4_t *>(slab_ptrs[s]);
     const int64_t total = outer * chunks_per_row;
     for (int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; w < total; w += (int64_t)gridDim.x * blockDim.x) {
         const int64_t o = w / chunks_per_row;
         const int c = (int)(w - o * chunks_per_row);
-        uint4 *rowbase = base + o * S_max * chunks_per_row + c;
-        uint4 v[KV_MAXSEL];
+        u32x4_t *rowbase = base + o * S_max * chunks_per_row + c;
+        u32x4_t v[KV_MAXSEL];
 #pragma unroll
         for (int t = 0; t < KV_MAXSEL; ++t)
             if (t < n_sel) {
                 int64_t src = rrow[t] + prev;
                 src = src < 0 ? 0 : (src >= S_max ? S_max - 1 : src);
-                v[t] = rowbase[src * chunks_per_row];
+                v[t] = __builtin_nontemporal_load(&rowbase[src * chunks_per_row]);
             }
 #pragma unroll
         for (int t = 0; t < KV_MAXSEL; ++t)
-            if (t < n_sel && prev + t < S_max) rowbase[(prev + t) * chunks_per_row] = v[t];
+            if (t < n_sel && prev + t < S_max) __builtin_nontemporal_store(v[t], &rowbase[(prev + t) * chunks_per_row]);
     }
 }
 

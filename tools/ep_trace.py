@@ -25,7 +25,7 @@ buf = (C.c_ulonglong * 4096)()
 L.lantern_debug_epw_trace(buf, 2048)   # drop earlier stamps
 wl.step(); torch.cuda.synchronize()
 n = L.lantern_debug_epw_trace(buf, 2048)
-names = {1: "staged(loads issued)", 2: "staged(barrier)", 10: "level: masks done", 11: "level: softmax done", 20: "cand: start", 21: "cand: scan done",
+names = {1: "staged(loads issued)", 2: "staged(barrier)", 10: "level: masks done", 11: "level: softmax done", 12: "  softmax: row loaded+local max", 13: "  softmax: block max", 14: "  softmax: exp+local sum", 15: "  softmax: block sum", 20: "cand: start", 21: "cand: scan done",
          22: "  scan: gathers done", 23: "  scan: dpp scan done", 24: "  scan: checks done", 25: "  scan: wave reduce done", 26: "  wave0 decision written", 30: "reject: residual done", 40: "epilogue start", 50: "epilogue done"}
 t0 = buf[1]
 prev = t0

@@ -1,0 +1,120 @@
+"""GPU (-m gpu): the other BASELINE.json configurations at their full sizes, HIP vs oracle.
+  C2  LlamaGen + EAGLE, standard (non-relaxed) verify: V=K=16384, dynamic tree N=59, HF processors T=1 / top_k=2000.
+  C4  Anole + LANTERN++ static tree naive_extend_57 (N=58,P=33,D=6): V=65536, offset 4, lambda in {5,10,20}, k in {5,10}.
+Both kernel sets (dense and windowed) must agree with the oracle and with each other."""
+import numpy as np
+import pytest
+import torch
+
+import cases as CS
+import helpers as H
+import oracle
+from lantern_amd import ops
+from lantern_amd.drafters.choices import naive_extend_57
+from test_gpu_parity import dev
+
+pytestmark = pytest.mark.gpu
+PROB_TOL = 1e-5
+
+
+def perm_table(K, cols, seed):
+    rs = np.random.RandomState(seed)
+    base = np.stack([rs.permutation(K - 1)[:cols] for _ in range(64)]).astype(np.int64)
+    tab = base[np.arange(K) % 64]
+    return np.where(tab >= np.arange(K)[:, None], tab + 1, tab).astype(np.uint16)
+
+
+def test_c2_llamagen_dynamic_standard_verify():
+    V, B, k = 16384, 5, 10
+    rs = np.random.RandomState(21)
+    depth, T = 4, 58
+    cfg_o = oracle.EpConfig.llamagen(False, lantern=False, temperature=1.0, top_p=1.0, top_k=2000)
+    cfg_h = ops.EpConfig.llamagen(False, lantern=False, temperature=1.0, top_p=1.0, top_k=2000)
+    for b in range(B):
+        # drafter tree through the HIP O3/O4 kernels, checked against the oracle's
+        script = [(4 * rs.standard_normal((1 if d == 0 else k, V))).astype(np.float32) for d in range(depth + 1)]
+        ti, cu, ci, sc = ops.expand_dynamic(dev(CS.topk_filter(script[0], 2000))[None], None, k)
+        oti, ocu, oci, osc = oracle.expand_dynamic(CS.topk_filter(script[0], 2000), None, k)
+        assert np.array_equal(ti[0].cpu().numpy(), oti) and np.allclose(cu[0].cpu().numpy(), ocu, atol=1e-5)
+        sl, tl, pl = [cu.reshape(-1)], [ti.reshape(-1)], [torch.zeros(1, dtype=torch.int64, device="cuda")]
+        cs = torch.arange(k, device="cuda")
+        for d in range(depth):
+            pl.append(cs + 1 + k * k * max(0, d - 1) + (k if d > 0 else 0))
+            ti, cu, ci, sc = ops.expand_dynamic(dev(CS.topk_filter(script[d + 1], 2000))[None], sc, k)
+            cs = ci[0]
+            sl.append(cu.reshape(-1)); tl.append(ti.reshape(-1))
+        sample = int(rs.randint(0, V))
+        draft, mask, pos, ret, nl, md = ops.tree_dynamic_finalize(torch.cat(sl)[None], torch.cat(tl)[None], torch.cat(pl)[None],
+                                                                   torch.tensor([sample], device="cuda"), k, T)
+        od, oret, omask, opos = oracle.tree_dynamic_finalize(torch.cat(sl).cpu().numpy(), torch.cat(tl).cpu().numpy(),
+                                                             torch.cat(pl).cpu().numpy(), k, T, sample)
+        nl, md = int(nl[0]), int(md[0])
+        assert np.array_equal(draft[0].cpu().numpy(), od) and np.array_equal(ret[0, :nl, :md].cpu().numpy(), oret)
+        assert np.array_equal(mask[0].cpu().numpy(), omask) and np.array_equal(pos[0].cpu().numpy(), opos)
+        N = T + 1
+        node_logits = (4 * rs.standard_normal((N, V))).astype(np.float32)
+        for p in range(oret.shape[0]):            # drafted tokens plausible under the target
+            for d in range(1, oret.shape[1]):
+                if oret[p, d] >= 0:
+                    node_logits[oret[p, d - 1], od[oret[p, d]]] = node_logits[oret[p, d - 1]].max() - rs.uniform(0, 3)
+        cand = np.where(oret >= 0, od[np.maximum(oret, 0)], -1)
+        ri = H.row_index_from_retrieve(oret, N)
+        uni = rs.random_sample(64)
+        ob, oa, osp, ocnt = oracle.evaluate_posterior(cfg_o, node_logits, ri, cand, uni)
+        d1 = ops.evaluate_posterior(cfg_h, dev(node_logits)[None], dev(ri), dev(cand)[None], dev(uni)[None])
+        w = ops.evaluate_posterior_window(cfg_h, V, dev(node_logits)[None], 0, dev(ri), dev(cand)[None], dev(uni)[None], want_dense=True)
+        for best, alen, sp, cnt in ((d1[0], d1[1], d1[2], d1[3]), (w["best"], w["accept_len"], w["sample_p"], w["counters"])):
+            assert (int(best[0]), int(alen[0])) == (ob, oa)
+            assert np.array_equal(cnt[0, :5].cpu().numpy(), ocnt[:5])
+            np.testing.assert_allclose(sp[0].cpu().numpy(), osp, rtol=0, atol=PROB_TOL)
+
+
+@pytest.mark.parametrize("lam,k", [(5.0, 10), (10.0, 5), (20.0, 5)])
+def test_c4_anole_static_lantern_pp(lam, k):
+    V, K, off, lo, W = 65536, 8192, 4, 4, 8192
+    rs = np.random.RandomState(int(lam) * 10 + k)
+    tb = oracle.tree_static_build(naive_extend_57)
+    N, (P, D) = len(tb["tree_indices"]), tb["retrieve_indices"].shape
+    assert (N, P, D) == (58, 33, 6)
+    ti, pos = tb["tree_indices"], tb["tree_position_ids"]
+    par = CS.node_parents(tb["tree_attn_mask"], pos)
+    R = int(((ti[1:] - 1) // 10).max()) + 1
+    par_row = np.zeros(R, np.int64)
+    for n in range(1, N):
+        par_row[(ti[n] - 1) // 10] = par[n]
+    depth_of_row = pos[par_row]
+    op_off = np.array([np.nonzero(depth_of_row == d)[0][0] for d in range(int(depth_of_row.max()) + 1)], np.int32)
+    tab = perm_table(K, 64, 3)
+    ri = H.row_index_from_retrieve(tb["retrieve_indices"], N)
+    B = 4
+    fmin = np.finfo(np.float32).min
+    cfg_kw = dict(lantern=True, k=k, delta=lam, temperature=1.0, top_p=1.0, top_k=2000)
+    cfg_o, cfg_h = oracle.EpConfig.anole(True, **cfg_kw), ops.EpConfig.anole(True, **cfg_kw)
+    logits, ops_l, cands, cps, tcs = [], [], [], [], []
+    for b in range(B):
+        nl = np.full((N, V), fmin, np.float32)             # ea_model_anole.py:931: non-image -> finfo.min
+        nl[:, lo:lo + W] = (4 * rs.standard_normal((N, W))).astype(np.float32)
+        dr = np.full((R, V), -np.inf, np.float32)
+        dr[:, lo:lo + W] = nl[par_row][:, lo:lo + W] + (1.0 + b) * rs.standard_normal((R, W)).astype(np.float32)
+        op = CS.softmax64(CS.topk_filter(dr, 2000)).astype(np.float32)
+        sst = np.stack([rs.choice(V, 10, replace=False, p=op[r].astype(np.float64) / op[r].astype(np.float64).sum()) for r in range(R)])
+        c, cp, tc = oracle.gather_candidates(sst, CS.ss_prob_from(op, sst), 100 + b, ti, tb["retrieve_indices"])
+        logits.append(nl); ops_l.append(op); cands.append(c); cps.append(cp); tcs.append(tc)
+    uni = rs.random_sample((B, 64))
+    aux = ops.StaticAux(cart_prob=dev(np.stack(cps)), orig_prob=dev(np.stack(ops_l)), op_off=dev(op_off), p_idx=dev(tb["p_indices"]),
+                        b_off=dev(tb["b_off"]), b_idx=dev(tb["b_idx"]), tree_cand=dev(np.stack(tcs)))
+    dense = ops.evaluate_posterior(cfg_h, dev(np.stack(logits)), dev(ri), dev(np.stack(cands)), dev(uni), table=dev(tab.view(np.int16)), aux=aux)
+    win = ops.evaluate_posterior_window(cfg_h, V, dev(np.ascontiguousarray(np.stack(logits)[:, :, lo:lo + W])), lo, dev(ri), dev(np.stack(cands)),
+                                        dev(uni), table=dev(tab.view(np.int16)), aux=aux, want_dense=True)
+    n_rej = 0
+    for b in range(B):
+        a = oracle.StaticAux(cart_prob=cps[b], orig_prob=ops_l[b], op_off=op_off, p_idx=tb["p_indices"], b_off=tb["b_off"], b_idx=tb["b_idx"],
+                             tree_cand=tcs[b])
+        ob, oa, osp, ocnt = oracle.evaluate_posterior(cfg_o, logits[b], ri, cands[b], uni[b], table=tab, aux=a)
+        n_rej += int(ocnt[2])
+        for best, alen, sp, cnt in ((dense[0], dense[1], dense[2], dense[3]), (win["best"], win["accept_len"], win["sample_p"], win["counters"])):
+            assert int(cnt[b, 5]) == 0
+            assert (int(best[b]), int(alen[b])) == (ob, oa), (b, int(best[b]), int(alen[b]), ob, oa)
+            assert np.array_equal(cnt[b, :5].cpu().numpy(), ocnt[:5])
+            np.testing.assert_allclose(sp[b].cpu().numpy(), osp, rtol=0, atol=PROB_TOL)
+    assert n_rej > 0

@@ -317,8 +317,10 @@ def main():
             if cfg.with_kv:
                 kv_ms = mean_ms("kv_gather")
                 kv_b = wl.kv_algorithmic_bytes(E0, E1) / KT
+                kv_m = wl.kv_moved_bytes(E0, E1) / KT        # rows already in place are not copied
                 ks["kv_gather"] = {"avg_launch_ms": kv_ms, "algorithmic_bytes_per_launch": kv_b,
-                                   "achieved": kv_b / (kv_ms * 1e-3) / 1e9, "frac": kv_b / (kv_ms * 1e-3) / 1e9 / 8000.0}
+                                   "achieved": kv_b / (kv_ms * 1e-3) / 1e9, "frac": kv_b / (kv_ms * 1e-3) / 1e9 / 8000.0,
+                                   "moved_bytes_per_launch": kv_m, "moved_GBps": kv_m / (kv_ms * 1e-3) / 1e9}
             out["kernels"] = ks
         if args.ep_sweep:
             wl.release_kv()      # the sweep builds its own (KV-free) workloads: give the memory back first

@@ -58,6 +58,12 @@ __global__ __launch_bounds__(256) void kv_gather_kernel(void *const *__restrict_
     const int64_t *rrow = retrieve + (retrieve_per_seq ? (size_t)seq * P * D : 0) + (size_t)bst * D;
     if (blockIdx.x == 0 && threadIdx.x == 0 && new_len) new_len[s] = prev + n_sel;
 
+    // rows already in place (tree node t sits at position prev + t: always the root, and every accepted first child) are
+    // not touched -- copying a row onto itself is the identity, so the result equals the reference's index_select + copy_
+    unsigned move = 0u;
+    for (int t = 0; t < n_sel; ++t)
+        if (rrow[t] != t && prev + t < S_max) move |= 1u << t;
+    if (move == 0u) return;
     u32x4_t *base = reinterpret_cast<u32x4_t *>(slab_ptrs[s]);
     const int64_t total = outer * chunks_per_row;
     for (int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; w < total; w += (int64_t)gridDim.x * blockDim.x) {
@@ -67,14 +73,14 @@ __global__ __launch_bounds__(256) void kv_gather_kernel(void *const *__restrict_
         u32x4_t v[KV_MAXSEL];
 #pragma unroll
         for (int t = 0; t < KV_MAXSEL; ++t)
-            if (t < n_sel) {
+            if ((move >> t) & 1u) {
                 int64_t src = rrow[t] + prev;
                 src = src < 0 ? 0 : (src >= S_max ? S_max - 1 : src);
                 v[t] = __builtin_nontemporal_load(&rowbase[src * chunks_per_row]);
             }
 #pragma unroll
         for (int t = 0; t < KV_MAXSEL; ++t)
-            if (t < n_sel && prev + t < S_max) __builtin_nontemporal_store(v[t], &rowbase[(prev + t) * chunks_per_row]);
+            if ((move >> t) & 1u) __builtin_nontemporal_store(v[t], &rowbase[(prev + t) * chunks_per_row]);
     }
 }
 

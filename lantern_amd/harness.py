@@ -407,6 +407,17 @@ class LuminaVerifyWorkload:
         moved = (self.log_alen[i0:i1].to(torch.float64) + 1).sum().item() * 2   # two slabs per sequence
         return float(2 * moved * per_pos)                            # read + write
 
+    def kv_moved_bytes(self, i0: int, i1: int) -> float:
+        """Bytes kv_gather really moves: accepted rows whose tree slot is not already their final position
+        (retrieve[best, t] != t); the root and accepted first children stay where the target forward wrote them."""
+        c = self.cfg
+        per_pos = 2 * c.kv_layers * c.kv_heads * c.kv_dim * 2
+        ret = self.d_retrieve.reshape(self.P, self.D)[self.log_best[i0:i1].long()]              # [steps, B, D]
+        t = torch.arange(self.D, device=ret.device)
+        live = t[None, None, :] <= self.log_alen[i0:i1].long()[..., None]
+        moved = ((ret != t) & live).sum().item() * 2
+        return float(2 * moved * per_pos)
+
     def check_status(self, i0: int, i1: int):
         st = self.log_cnt[i0:i1, :, 5]
         if int(st.abs().sum().item()) != 0:

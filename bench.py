@@ -48,7 +48,8 @@ def parse():
     ap.add_argument("--no-kv", action="store_true", help="skip the KV slabs (debug only; invalid as a headline)")
     ap.add_argument("--kv-smax", type=int, default=4096)
     ap.add_argument("--no-events", action="store_true", help="skip the eager per-kernel timing pass")
-    ap.add_argument("--graph", action="store_true", help="replay one captured hipGraph per pool slot instead of launching eagerly")
+    ap.add_argument("--graph", action="store_true", help="replay one captured hipGraph per (pool slot, group) instead of launching eagerly")
+    ap.add_argument("--groups", type=int, default=1, help="split the GPU's sequences into this many groups, each on its own HIP stream (independent sequences: one group's latency-bound evaluate_posterior overlaps the others' bandwidth-bound kernels)")
     ap.add_argument("--ep-sweep", type=str, default="",
                     help="e.g. 256,2048: batch sizes for the evaluate_posterior-only roofline sweep (BASELINE.md section 2); off by default so that the default command launches every kernel on one homogeneous workload (rocprofv3 averages then agree with the HIP-event averages)")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="CPU-baseline budget; 0 disables")
@@ -230,7 +231,7 @@ def main():
 
     cfg = HN.WorkloadConfig(n_seq=args.seqs_per_gpu, pool_steps=args.pool_steps, lantern_k=args.lantern_k,
                             lantern_delta=args.lantern_delta, sigma=args.sigma, with_kv=not args.no_kv, kv_smax=args.kv_smax,
-                            path=args.path, use_graph=args.graph,
+                            path=args.path, use_graph=args.graph, n_groups=args.groups,
                             max_steps=args.steps + args.warmup + min(args.steps, 100) + 8)
     wl = HN.LuminaVerifyWorkload(cfg, device, rank=rank)
 
@@ -258,7 +259,7 @@ def main():
     if not args.no_events:
         evs = [{n: (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for n in names} for _ in range(KT)]
         for i in range(KT):
-            wl.step(evs[i])
+            wl.step(evs[i], serial=True)     # groups one after the other on one stream: undisturbed kernel durations
         torch.cuda.synchronize(device)
 
     n_logged = W + K + (KT if evs else 0)
@@ -280,7 +281,8 @@ def main():
                                    % (cfg.kv_smax, cfg.kv_smax + cfg.kv_pad_rows),
                        "lantern_k": cfg.lantern_k, "lantern_delta": cfg.lantern_delta, "seqs_per_gpu": cfg.n_seq,
                        "total_sequences": cfg.n_seq * world, "pool_steps": cfg.pool_steps, "drafter_sigma": cfg.sigma,
-                       "kv_cache": cfg.with_kv, "kernel_path": cfg.path, "launch": "hipGraph replay" if (cfg.use_graph and wl.graphs) else "eager", "parallelism": f"dp{world} (independent sequences, no collective)"},
+                       "kv_cache": cfg.with_kv, "kernel_path": cfg.path, "launch": "hipGraph replay" if (cfg.use_graph and wl.graphs) else "eager",
+                       "stream_groups": cfg.n_groups, "sequences_per_launch": wl.Bg, "parallelism": f"dp{world} (independent sequences, no collective)"},
             "mean_accept_length": float(alen.mean()),
             "per_step": {"levels": float(cnt[..., 0].mean()), "tried": float(cnt[..., 1].mean()), "rejected": float(cnt[..., 2].mean())},
         }
@@ -290,7 +292,7 @@ def main():
             E0, E1 = W + K, W + K + KT          # the steps the events bracket
             ep_ms = mean_ms("evaluate_posterior")
             # SURVEY 8d contract figure: L*V*4 + T*k*6 + R*(k+1)*4 + V*4 (+V*4), from the kernel's own counters
-            contract_bytes = wl.ep_algorithmic_bytes(E0, E1) / KT
+            contract_bytes = wl.ep_algorithmic_bytes(E0, E1, group=0) / KT      # events bracket group 0's launches
             ach = contract_bytes / (ep_ms * 1e-3) / 1e9
             rl = {"kernel": "epw_kernel (evaluate_posterior, windowed)" if wl.windowed else "ep_kernel (evaluate_posterior)",
                   "bound": "hbm", "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0, "traffic": None,
@@ -299,25 +301,25 @@ def main():
                                                   "V=65536, summed over the launch's sequences"}
             if wl.windowed:
                 # what the windowed kernel actually has to move (rows are 8192-wide windows; gathers/zeroing/scan/bonus draw in LDS)
-                wb = wl.ep_window_bytes(E0, E1) / KT
+                wb = wl.ep_window_bytes(E0, E1, group=0) / KT
                 rl["windowed_kernel"] = {"hbm_bytes_needed_per_launch": wb, "achieved": wb / (ep_ms * 1e-3) / 1e9,
                                          "frac": wb / (ep_ms * 1e-3) / 1e9 / 8000.0,
                                          "definition": "(L+fresh)*W*4 + T*k*2 + R*W*4, W=8192 (DESIGN.md 4)"}
             tfile = os.path.join(ROOT, "profiles", "r01_epw_traffic.json")
             if wl.windowed and os.path.exists(tfile):
-                t = json.load(open(tfile)).get("per_launch", {}).get(str(cfg.n_seq))
+                t = json.load(open(tfile)).get("per_launch", {}).get(str(wl.Bg))
                 if t:      # PMC passes are separate rocprofv3 runs of the same kernel/config (tools/ep_only.py), see profiles/
                     rl["traffic"] = t["hbm_bytes"]
                     rl["traffic_source"] = "profiles/r01_epw_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, FETCH doubled per the gfx950 note)"
             out["roofline"] = rl
             o7_ms = mean_ms("cfg_mask_topk")
-            o7_b = wl.o7_algorithmic_bytes(1)
+            o7_b = wl.o7_algorithmic_bytes(1, group=0)
             ks = {"cfg_mask_topk": {"avg_launch_ms": o7_ms, "algorithmic_bytes_per_launch": o7_b,
                                     "achieved": o7_b / (o7_ms * 1e-3) / 1e9, "frac": o7_b / (o7_ms * 1e-3) / 1e9 / 8000.0}}
             if cfg.with_kv:
                 kv_ms = mean_ms("kv_gather")
-                kv_b = wl.kv_algorithmic_bytes(E0, E1) / KT
-                kv_m = wl.kv_moved_bytes(E0, E1) / KT        # rows already in place are not copied
+                kv_b = wl.kv_algorithmic_bytes(E0, E1, group=0) / KT
+                kv_m = wl.kv_moved_bytes(E0, E1, group=0) / KT        # rows already in place are not copied
                 ks["kv_gather"] = {"avg_launch_ms": kv_ms, "algorithmic_bytes_per_launch": kv_b,
                                    "achieved": kv_b / (kv_ms * 1e-3) / 1e9, "frac": kv_b / (kv_ms * 1e-3) / 1e9 / 8000.0,
                                    "moved_bytes_per_launch": kv_m, "moved_GBps": kv_m / (kv_ms * 1e-3) / 1e9}

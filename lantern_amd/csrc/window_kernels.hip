@@ -21,21 +21,30 @@ namespace lantern {
 // In-kernel phase stamps for diagnosis (tools/ep_trace.py builds a separate .so with -DEPW_TRACE);
 // the shipped library compiles EPW_STAMP to nothing.
 #ifdef EPW_TRACE
-__device__ unsigned long long g_epw_trace[2048];
-__device__ int g_epw_trace_n;
-#define EPW_STAMP(id)                                                                 \
-    do {                                                                              \
-        if (blockIdx.x == 0 && threadIdx.x == 0) {                                    \
-            const int n__ = g_epw_trace_n;                                            \
-            if (n__ < 1024) {                                                         \
-                g_epw_trace[2 * n__] = (unsigned long long)(id);                      \
-                g_epw_trace[2 * n__ + 1] = __builtin_amdgcn_s_memtime();              \
-                g_epw_trace_n = n__ + 1;                                              \
-            }                                                                         \
-        }                                                                             \
+// every workgroup stamps into its own LDS (thread 0: one s_memtime + two LDS accesses per stamp) and dumps at exit
+constexpr int EPW_TR_MAX = 256, EPW_TR_BLOCKS = 64;
+__device__ unsigned long long g_epw_trace[EPW_TR_BLOCKS][EPW_TR_MAX];
+__device__ int g_epw_trace_n[EPW_TR_BLOCKS];
+__shared__ unsigned long long s_epw_tr[EPW_TR_MAX];
+__shared__ int s_epw_trn;
+#define EPW_STAMP(id)                                                                                          \
+    do {                                                                                                       \
+        if (threadIdx.x == 0) {                                                                                \
+            const int n__ = s_epw_trn;                                                                         \
+            if (n__ < EPW_TR_MAX) {                                                                            \
+                s_epw_tr[n__] = ((unsigned long long)(id) << 56) | (__builtin_amdgcn_s_memtime() & 0xffffffffffffffull); \
+                s_epw_trn = n__ + 1;                                                                           \
+            }                                                                                                  \
+        }                                                                                                      \
     } while (0)
+#if EPW_TRACE >= 2
+#define EPW_STAMPF(id) EPW_STAMP(id)
+#else
+#define EPW_STAMPF(id) do { } while (0)
+#endif
 #else
 #define EPW_STAMP(id) do { } while (0)
+#define EPW_STAMPF(id) do { } while (0)
 #endif
 
 __device__ __forceinline__ int64_t py_mod64(int64_t a, int64_t b) {
@@ -255,6 +264,7 @@ struct alignas(16) EwShared {
     int redi[2 * 16];
     double samp_tot[16][4];
     int dec[2][4];                          // decision words of wave 0: {code, m>0, csm1 bits, -}
+    int hot[EW_MAX_N];                      // row_hot of this sequence's rows (when rows_per_seq <= EW_MAX_N)
     unsigned short nbid[EW_PF_C][EW_PF_K];  // prefetched neighbour ids (raw table values)
 };
 
@@ -265,9 +275,29 @@ __host__ __device__ inline size_t epw_shared_offset(int W) {
 
 // softmax(processors(row)) -> g (LDS); one-hot rows put their mass in (out_tok,out_mass) when the hot token
 // lies outside the window.
+struct NoHook {
+    __device__ __forceinline__ void operator()() const {}
+};
+
+// `pre_barrier` runs after the row's global loads have landed and before the last barrier: LDS writes of data whose
+// loads were issued BEFORE this call ride on the row's latency (vmcnt retires in issue order) and on its barrier.
+//
+// The row arrives in registers (`r`, loaded by row_load -- possibly long before, so that its HBM latency hides behind
+// other work); one-hot rows ignore `r`.
 template <int NT, int E4>
-__device__ __forceinline__ void row_softmax_to_lds(const float *__restrict__ rowp, int hot, int win_lo, int W, float temperature, int top_k,
-                                                   int V, float *g, int &out_tok, float &out_mass, EwShared &S, int &ph) {
+__device__ __forceinline__ void row_load(const float *__restrict__ rowp, int W, float4 (&r)[E4]) {
+    const float NEG_INF = -__builtin_inff();
+#pragma unroll
+    for (int it = 0; it < E4; ++it) {
+        const int i4 = threadIdx.x + it * NT;
+        r[it] = (i4 * 4 < W) ? reinterpret_cast<const float4 *>(rowp)[i4] : make_float4(NEG_INF, NEG_INF, NEG_INF, NEG_INF);
+    }
+}
+
+template <int NT, int E4, typename Hook = NoHook>
+__device__ __forceinline__ void row_softmax_to_lds(float4 (&r)[E4], int hot, int win_lo, int W, float temperature, int top_k,
+                                                   int V, float *g, int &out_tok, float &out_mass, EwShared &S, int &ph,
+                                                   const Hook &pre_barrier = Hook()) {
     constexpr int NW = NT / 64;
     const int tid = threadIdx.x;
     const float NEG_INF = -__builtin_inff();
@@ -285,14 +315,9 @@ __device__ __forceinline__ void row_softmax_to_lds(const float *__restrict__ row
             out_tok = hot;
             out_mass = 1.0f;
         }
+        pre_barrier();
         __syncthreads();
         return;
-    }
-    float4 r[E4];
-#pragma unroll
-    for (int it = 0; it < E4; ++it) {
-        const int i4 = tid + it * NT;
-        r[it] = (i4 * 4 < W) ? reinterpret_cast<const float4 *>(rowp)[i4] : make_float4(NEG_INF, NEG_INF, NEG_INF, NEG_INF);
     }
     if (temperature > 1e-5f && temperature != 1.0f) {
 #pragma unroll
@@ -312,9 +337,9 @@ __device__ __forceinline__ void row_softmax_to_lds(const float *__restrict__ row
     float m = NEG_INF;
 #pragma unroll
     for (int it = 0; it < E4; ++it) m = fmaxf(fmaxf(m, fmaxf(r[it].x, r[it].y)), fmaxf(r[it].z, r[it].w));
-    EPW_STAMP(12);
+    EPW_STAMPF(12);
     m = block_max_fast<NW>(m, S.redf, ph);
-    EPW_STAMP(13);
+    EPW_STAMPF(13);
     double s = 0.0;
 #pragma unroll
     for (int it = 0; it < E4; ++it) {
@@ -322,19 +347,23 @@ __device__ __forceinline__ void row_softmax_to_lds(const float *__restrict__ row
         r[it].z = exp_nonpos(r[it].z - m); r[it].w = exp_nonpos(r[it].w - m);
         s += (double)r[it].x + (double)r[it].y + (double)r[it].z + (double)r[it].w;
     }
-    EPW_STAMP(14);
+    EPW_STAMPF(14);
     const float sf = (float)block_sum_fast<double, NW>(s, S.redd, ph);
-    EPW_STAMP(15);
+    EPW_STAMPF(15);
     const FastDiv dv(sf);
 #pragma unroll
     for (int it = 0; it < E4; ++it) {
         const int i4 = tid + it * NT;
         if (i4 * 4 < W) reinterpret_cast<float4 *>(g)[i4] = make_float4(dv(r[it].x), dv(r[it].y), dv(r[it].z), dv(r[it].w));
     }
+    pre_barrier();
     __syncthreads();
 }
 
-template <int NT, int E4>
+// LDSIDS: every candidate's neighbour ids are staged in LDS (k + 1 <= EW_PF_K, or LANTERN off), so the serial wave-0
+// section contains no vector-memory instruction -- the compiler then has no reason to drain vmcnt inside it and the
+// drafter-row / id loads issued before it stay in flight across the scan.  !LDSIDS (k > 1023) reads ids from HBM.
+template <int NT, int E4, bool LDSIDS>
 __global__ __launch_bounds__(NT) void epw_kernel(const lantern_ep_params prm, const lantern_ep_buffers buf, const lantern_ep_window win) {
     constexpr int NW = NT / 64;
     // one dynamic LDS region (16-byte aligned base): [ g : W f32 | nbmask : W bits | EwShared ]
@@ -350,35 +379,99 @@ __global__ __launch_bounds__(NT) void epw_kernel(const lantern_ep_params prm, co
     const bool is_static = prm.mode != LANTERN_MODE_DYNAMIC;
     const float NEG_INF = -__builtin_inff();
     const int nz = (k + 1 < prm.table_cols) ? k + 1 : prm.table_cols;   // ids touched per candidate (k summed, k+1 zeroed)
-    const bool can_prefetch = prm.lantern && nz <= EW_PF_K;
+    const bool can_prefetch = LDSIDS && prm.lantern;
+    const bool hot_in_lds = prm.rows_per_seq <= EW_MAX_N;
     int ph = 0;
+#ifdef EPW_TRACE
+    if (tid == 0) s_epw_trn = 0;
+    EPW_STAMP(0);
+#endif
 
-    // ---- stage every small per-step table in LDS with one round of global loads
+    // ---- stage every small per-step table in LDS: two rounds of global loads (everything independent first, then what
+    // needs the uniform cursor / the sibling count / the first row id), all issued before the first wait
+    const float *logits = buf.logits + (size_t)b * prm.rows_per_seq * W;
+    const int32_t *hot_g = win.row_hot ? win.row_hot + (size_t)b * prm.rows_per_seq : nullptr;
     const int ucur0 = buf.cursor ? buf.cursor[b] : 0;
+    float4 rp[E4];              // prefetched row (registers) and the row id it holds
+    int rp_rid = -1;
     {
-        const int64_t *cand_g = buf.cand + (size_t)b * Ps * Ds;
-        const int32_t *row_g = buf.row_index + (prm.row_index_per_seq ? (size_t)b * Ps * Ds : 0);
-        for (int t = tid; t < Ps * Ds; t += NT) {
-            S.cand[t] = (int)cand_g[t];
-            S.row[t] = row_g[t];
-            if (is_static) {
-                S.cart[t] = buf.cart_prob[(size_t)b * Ps * Ds + t];
-                S.pidx[t] = buf.p_idx[t];
-                S.boff[t] = buf.b_off[t];
+        constexpr int PD_PER = (EW_MAX_PD + NT - 1) / NT, B_PER = (EW_MAX_B + NT - 1) / NT, N_PER = (EW_MAX_N + NT - 1) / NT;
+        const int npd = Ps * Ds;
+        const int64_t *cand_g = buf.cand + (size_t)b * npd;
+        const int32_t *row_g = buf.row_index + (prm.row_index_per_seq ? (size_t)b * npd : 0);
+        const int nb_total = is_static ? buf.b_off[npd] : 0;
+        const int rid1 = row_g[0];          // level 1: every path shares the root, the first matching path is path 0
+        int64_t c_[PD_PER];
+        int r_[PD_PER], pi_[PD_PER], bo_[PD_PER], tc_[N_PER], hot_[N_PER], oo_ = 0;
+        float ct_[PD_PER];
+#pragma unroll
+        for (int u = 0; u < PD_PER; ++u) {
+            const int t = tid + u * NT;
+            const bool in = t < npd;
+            c_[u] = in ? cand_g[t] : 0;
+            r_[u] = in ? row_g[t] : 0;
+            ct_[u] = (in && is_static) ? buf.cart_prob[(size_t)b * npd + t] : 0.0f;
+            pi_[u] = (in && is_static) ? buf.p_idx[t] : 0;
+            bo_[u] = (in && is_static) ? buf.b_off[t] : 0;
+        }
+#pragma unroll
+        for (int u = 0; u < N_PER; ++u) {
+            const int t = tid + u * NT;
+            tc_[u] = (is_static && t < prm.N && t < EW_MAX_N) ? (int)buf.tree_cand[(size_t)b * prm.N + t] : 0;
+            hot_[u] = (hot_g && hot_in_lds && t < prm.rows_per_seq) ? hot_g[t] : -1;
+        }
+        if (is_static && tid < Ds - 1) oo_ = buf.op_off[tid];
+        // round 2
+        const double *uni = buf.uniforms + (size_t)b * prm.n_uniforms;
+        double un_ = 2.0;                   // never drawn: guarded below
+        if (tid < EW_UNI && ucur0 + tid < prm.n_uniforms) un_ = uni[ucur0 + tid];
+        int bi_[B_PER];
+#pragma unroll
+        for (int u = 0; u < B_PER; ++u) {
+            const int t = tid + u * NT;
+            bi_[u] = (t < nb_total && t < EW_MAX_B) ? buf.b_idx[t] : 0;
+        }
+        if (rid1 >= 0 && rid1 < prm.rows_per_seq) {
+            row_load<NT, E4>(logits + (size_t)rid1 * W, W, rp);
+            rp_rid = rid1;
+        }
+        // LDS stores
+#pragma unroll
+        for (int u = 0; u < PD_PER; ++u) {
+            const int t = tid + u * NT;
+            if (t < npd) {
+                S.cand[t] = (int)c_[u];
+                S.row[t] = r_[u];
+                if (is_static) {
+                    S.cart[t] = ct_[u];
+                    S.pidx[t] = pi_[u];
+                    S.boff[t] = bo_[u];
+                }
             }
         }
         if (is_static) {
-            if (tid == 0) S.boff[Ps * Ds] = buf.b_off[Ps * Ds];
-            const int nb_total = buf.b_off[Ps * Ds];
-            for (int t = tid; t < nb_total && t < EW_MAX_B; t += NT) S.bidx[t] = buf.b_idx[t];
-            for (int t = tid; t < prm.N && t < EW_MAX_N; t += NT) S.tcand[t] = (int)buf.tree_cand[(size_t)b * prm.N + t];
-            for (int t = tid; t < Ds - 1; t += NT) S.opoff[t] = buf.op_off[t];
+            if (tid == 0) S.boff[npd] = nb_total;
+#pragma unroll
+            for (int u = 0; u < B_PER; ++u) {
+                const int t = tid + u * NT;
+                if (t < nb_total && t < EW_MAX_B) S.bidx[t] = bi_[u];
+            }
+#pragma unroll
+            for (int u = 0; u < N_PER; ++u) {
+                const int t = tid + u * NT;
+                if (t < prm.N && t < EW_MAX_N) S.tcand[t] = tc_[u];
+            }
+            if (tid < Ds - 1) S.opoff[tid] = oo_;
         }
-        const double *uni = buf.uniforms + (size_t)b * prm.n_uniforms;
-        for (int t = tid; t < EW_UNI; t += NT) S.uni[t] = (ucur0 + t < prm.n_uniforms) ? uni[ucur0 + t] : 2.0;   // never drawn: guarded below
+        if (hot_g && hot_in_lds) {
+#pragma unroll
+            for (int u = 0; u < N_PER; ++u) {
+                const int t = tid + u * NT;
+                if (t < prm.rows_per_seq) S.hot[t] = hot_[u];
+            }
+        }
+        if (tid < EW_UNI) S.uni[tid] = un_;
     }
-    const float *logits = buf.logits + (size_t)b * prm.rows_per_seq * W;
-    const int32_t *hot_g = win.row_hot ? win.row_hot + (size_t)b * prm.rows_per_seq : nullptr;
     EPW_STAMP(1);
     __syncthreads();
     if (tid == 0) S.acc[0] = S.cand[0];
@@ -405,13 +498,13 @@ __global__ __launch_bounds__(NT) void epw_kernel(const lantern_ep_params prm, co
         const int fi = __ffsll((long long)eq_mask) - 1;
         const int x_lane = (lane < P) ? S.cand[lane * Ds + i] : -1;
         const unsigned long long todo0 = eq_mask & __ballot(x_lane != -1);
-        // neighbour ids of the level's candidates: one round of HBM reads, overlapped with the row softmax
+        // neighbour ids of the level's candidates: their HBM reads are issued first, the row's loads second; both are in
+        // flight together and the ids are written to LDS under the row's last barrier (one exposed latency per level)
+        constexpr int PF_PER = (EW_PF_K + NT - 1) / NT;
+        unsigned short idv[EW_PF_C][PF_PER];
+        int ncand = 0;
         if (can_prefetch) {
-            // issue every candidate's id loads before the first LDS write (one HBM latency for the whole level)
-            constexpr int PF_PER = (EW_PF_K + NT - 1) / NT;
-            unsigned short idv[EW_PF_C][PF_PER];
             unsigned long long td = todo0;
-            int ncand = 0;
 #pragma unroll
             for (int c = 0; c < EW_PF_C; ++c) {
                 const bool have = td != 0ull;
@@ -428,19 +521,24 @@ __global__ __launch_bounds__(NT) void epw_kernel(const lantern_ep_params prm, co
                 }
                 ncand += have ? 1 : 0;
             }
-#pragma unroll
-            for (int c = 0; c < EW_PF_C; ++c)
-#pragma unroll
-                for (int u = 0; u < PF_PER; ++u) {
-                    const int t = tid + u * NT;
-                    if (c < ncand && t < EW_PF_K) S.nbid[c][t] = idv[c][u];
-                }
         }
         {
             const int rid = S.row[fi * Ds + (i - 1)];
+            const int hot = !hot_g ? -1 : (hot_in_lds ? S.hot[rid] : hot_g[rid]);
             EPW_STAMP(10);
-            row_softmax_to_lds<NT, E4>(logits + (size_t)rid * W, hot_g ? hot_g[rid] : -1, lo, W, prm.temperature, prm.top_k, V, g, out_tok,
-                                       out_mass, S, ph);
+            if (hot < 0 && rp_rid != rid) row_load<NT, E4>(logits + (size_t)rid * W, W, rp);
+            rp_rid = -1;
+            row_softmax_to_lds<NT, E4>(rp, hot, lo, W, prm.temperature, prm.top_k, V, g, out_tok, out_mass, S, ph, [&]() {
+                if (can_prefetch) {
+#pragma unroll
+                    for (int c = 0; c < EW_PF_C; ++c)
+#pragma unroll
+                        for (int u = 0; u < PF_PER; ++u) {
+                            const int t = tid + u * NT;
+                            if (c < ncand && t < EW_PF_K) S.nbid[c][t] = idv[c][u];
+                        }
+                }
+            });
             EPW_STAMP(11);
         }
         unsigned long long todo = todo0;
@@ -466,10 +564,16 @@ __global__ __launch_bounds__(NT) void epw_kernel(const lantern_ep_params prm, co
             bool is_syn = false;
             if (prm.syntax_shortcut)
                 for (int t = 0; t < prm.n_syntax; ++t) is_syn |= (x == prm.syntax[t]);
-            const bool use_lds_ids = can_prefetch && cidx < EW_PF_C;
+            const int slot = cidx % EW_PF_C;
             const int trow = x - off;
             const uint16_t *nb = (prm.lantern && trow >= 0 && trow < prm.table_rows) ? buf.nn_table + (size_t)trow * prm.table_cols : nullptr;
             int *dec = S.dec[n_tried & 1];
+            if (LDSIDS && can_prefetch && cidx >= EW_PF_C) {
+                // more unique candidates than prefetch slots (rare): stage this one's ids now, reusing a finished slot
+                __syncthreads();
+                for (int t = tid; t < EW_PF_K; t += NT) S.nbid[slot][t] = (nb && t < nz) ? nb[t] : (unsigned short)0;
+                __syncthreads();
+            }
             // static trees: start the drafter-row read now; it lands while wave 0 runs the neighbour scan and is
             // simply dropped if the candidate is accepted (one 32 KB row, L2/MALL-resident for the next try)
             float4 q[E4];
@@ -502,9 +606,9 @@ __global__ __launch_bounds__(NT) void epw_kernel(const lantern_ep_params prm, co
                         for (int base = 0; base < k; base += 1024) {
                             const int i0 = base + lane * 16;
                             int ids[16];
-                            if (use_lds_ids) {
-                                const uint4 a = *reinterpret_cast<const uint4 *>(&S.nbid[cidx][i0 & (EW_PF_K - 1)]);
-                                const uint4 bq = *reinterpret_cast<const uint4 *>(&S.nbid[cidx][(i0 + 8) & (EW_PF_K - 1)]);
+                            if constexpr (LDSIDS) {
+                                const uint4 a = *reinterpret_cast<const uint4 *>(&S.nbid[slot][i0 & (EW_PF_K - 1)]);
+                                const uint4 bq = *reinterpret_cast<const uint4 *>(&S.nbid[slot][(i0 + 8) & (EW_PF_K - 1)]);
                                 const uint32_t w[8] = {a.x, a.y, a.z, a.w, bq.x, bq.y, bq.z, bq.w};
 #pragma unroll
                                 for (int c = 0; c < 8; ++c) {
@@ -526,10 +630,10 @@ __global__ __launch_bounds__(NT) void epw_kernel(const lantern_ep_params prm, co
                                 loc += (double)gv;
                                 v[c] = loc;
                             }
-                            EPW_STAMP(22);
+                            EPW_STAMPF(22);
                             const double inc = wave_scan_incl_dpp(loc);
                             const double excl = carry + (inc - loc);
-                            EPW_STAMP(23);
+                            EPW_STAMPF(23);
                             float mx = NEG_INF;
                             int nok = 0;
 #pragma unroll
@@ -539,13 +643,13 @@ __global__ __launch_bounds__(NT) void epw_kernel(const lantern_ep_params prm, co
                                 mx = ok ? fmaxf(mx, cs) : mx;
                                 nok += ok ? 1 : 0;
                             }
-                            EPW_STAMP(24);
+                            EPW_STAMPF(24);
                             mx = wave_max(mx);
                             best_cs = fmaxf(best_cs, mx);
                             carry += readlane63(inc);
                             if (k - base <= 1024) break;
                             const int tot_ok = wave_sum(nok);
-                            EPW_STAMP(25);
+                            EPW_STAMPF(25);
                             if (tot_ok < 1024) break;   // the cumulative mass is non-decreasing: the ok set is a prefix
                         }
                         if (best_cs > NEG_INF) {
@@ -570,7 +674,7 @@ __global__ __launch_bounds__(NT) void epw_kernel(const lantern_ep_params prm, co
                     dec[0] = code;
                     dec[1] = mflag;
                 }
-                EPW_STAMP(26);
+                EPW_STAMPF(26);
             }
             __syncthreads();
             const int code = dec[0];
@@ -602,7 +706,7 @@ __global__ __launch_bounds__(NT) void epw_kernel(const lantern_ep_params prm, co
                 if (zero_nb) {
                     bool hit = false;
                     for (int t = tid; t < nz; t += NT) {
-                        const int id = (int)(use_lds_ids ? S.nbid[cidx][t] : nb[t]) + off;
+                        const int id = (int)(LDSIDS ? S.nbid[slot][t] : nb[t]) + off;
                         if (id >= lo && id < lo + W) g[id - lo] = 0.0f;
                         hit |= (id == out_tok);
                     }
@@ -628,12 +732,12 @@ __global__ __launch_bounds__(NT) void epw_kernel(const lantern_ep_params prm, co
                 __syncthreads();
                 if (lg_nb)
                     for (int t = tid; t < nz; t += NT) {
-                        const int id = (int)(use_lds_ids ? S.nbid[cidx][t] : nb[t]) + off - lo;
+                        const int id = (int)(LDSIDS ? S.nbid[slot][t] : nb[t]) + off - lo;
                         if (id >= 0 && id < W) atomicOr(&nbmask[id >> 5], 1u << (id & 31));
                     }
                 if (zero_nb && prm.mode == LANTERN_MODE_STATIC_LUMINA)
                     for (int t = tid; t < nz; t += NT) {
-                        const int id = (int)(use_lds_ids ? S.nbid[cidx][t] : nb[t]) + off - lo;
+                        const int id = (int)(LDSIDS ? S.nbid[slot][t] : nb[t]) + off - lo;
                         if (id >= 0 && id < W) g[id] = 0.0f;
                     }
                 double qs_loc = 0.0;
@@ -703,8 +807,9 @@ __global__ __launch_bounds__(NT) void epw_kernel(const lantern_ep_params prm, co
     const int from_residual = (adjust && a != D) ? 1 : 0;
     if (status == LANTERN_ST_OK && !from_residual) {
         const int rid = S.row[best * Ds + (a - 1)];
-        row_softmax_to_lds<NT, E4>(logits + (size_t)rid * W, hot_g ? hot_g[rid] : -1, lo, W, prm.temperature, prm.top_k, V, g, out_tok,
-                                   out_mass, S, ph);
+        const int hot = !hot_g ? -1 : (hot_in_lds ? S.hot[rid] : hot_g[rid]);
+        if (hot < 0 && rp_rid != rid) row_load<NT, E4>(logits + (size_t)rid * W, W, rp);
+        row_softmax_to_lds<NT, E4>(rp, hot, lo, W, prm.temperature, prm.top_k, V, g, out_tok, out_mass, S, ph);
     }
     // ---------------------------------------------------------------- epilogue: outputs from LDS
     EPW_STAMP(40);
@@ -803,6 +908,13 @@ __global__ __launch_bounds__(NT) void epw_kernel(const lantern_ep_params prm, co
         }
     }
     EPW_STAMP(50);
+#ifdef EPW_TRACE
+    if (tid == 0 && b < EPW_TR_BLOCKS) {
+        const int n = s_epw_trn;
+        for (int t = 0; t < n; ++t) g_epw_trace[b][t] = s_epw_tr[t];
+        g_epw_trace_n[b] = n;
+    }
+#endif
     if (tid == 0) {
         buf.best[b] = best;
         buf.accept_len[b] = a - 1;
@@ -916,29 +1028,29 @@ extern "C" int lantern_evaluate_posterior_window(const lantern_ep_params *prm, c
     const int W = win->win_len;
     const size_t lds = epw_shared_offset(W) + sizeof(EwShared);
     dim3 grid(p.B);
-    if (W <= 1024) hipLaunchKernelGGL((epw_kernel<256, 1>), grid, dim3(256), lds, st, p, *buf, *win);
-    else if (W <= 2048) hipLaunchKernelGGL((epw_kernel<256, 2>), grid, dim3(256), lds, st, p, *buf, *win);
-    else if (W <= 4096) hipLaunchKernelGGL((epw_kernel<512, 2>), grid, dim3(512), lds, st, p, *buf, *win);
-    else if (W <= 8192) {
-        static const int nt_override = getenv("LANTERN_EPW_NT") ? atoi(getenv("LANTERN_EPW_NT")) : 0;   // tuning knob (diagnostic)
-        if (nt_override == 256) hipLaunchKernelGGL((epw_kernel<256, 8>), grid, dim3(256), lds, st, p, *buf, *win);
-        else if (nt_override == 1024) hipLaunchKernelGGL((epw_kernel<1024, 2>), grid, dim3(1024), lds, st, p, *buf, *win);
-        else hipLaunchKernelGGL((epw_kernel<512, 4>), grid, dim3(512), lds, st, p, *buf, *win);
-    }
-    else hipLaunchKernelGGL((epw_kernel<1024, 4>), grid, dim3(1024), lds, st, p, *buf, *win);
+    const int nz = (p.k + 1 < p.table_cols) ? p.k + 1 : p.table_cols;
+    const bool lds_ids = !p.lantern || nz <= EW_PF_K;
+#define EPW_LAUNCH(NT_, E4_)                                                                                              \
+    do {                                                                                                                  \
+        if (lds_ids) hipLaunchKernelGGL((epw_kernel<NT_, E4_, true>), grid, dim3(NT_), lds, st, p, *buf, *win);           \
+        else hipLaunchKernelGGL((epw_kernel<NT_, E4_, false>), grid, dim3(NT_), lds, st, p, *buf, *win);                  \
+    } while (0)
+    if (W <= 1024) EPW_LAUNCH(256, 1);
+    else if (W <= 2048) EPW_LAUNCH(256, 2);
+    else if (W <= 4096) EPW_LAUNCH(512, 2);
+    else if (W <= 8192) EPW_LAUNCH(512, 4);
+    else EPW_LAUNCH(1024, 4);
+#undef EPW_LAUNCH
     LANTERN_CHECK_LAUNCH("evaluate_posterior_window");
     return LANTERN_OK;
 }
 
 #ifdef EPW_TRACE
-extern "C" int lantern_debug_epw_trace(unsigned long long *host_out, int max_pairs) {
-    int n = 0;
-    if (hipMemcpyFromSymbol(&n, HIP_SYMBOL(g_epw_trace_n), sizeof(int)) != hipSuccess) return -1;
-    if (n > max_pairs) n = max_pairs;
-    if (hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_epw_trace), sizeof(unsigned long long) * 2 * n) != hipSuccess) return -1;
-    int zero = 0;
-    if (hipMemcpyToSymbol(HIP_SYMBOL(g_epw_trace_n), &zero, sizeof(int)) != hipSuccess) return -1;
-    return n;
+// host_out: [EPW_TR_BLOCKS][EPW_TR_MAX] stamps (id << 56 | cycles), counts: [EPW_TR_BLOCKS]
+extern "C" int lantern_debug_epw_trace(unsigned long long *host_out, int *counts) {
+    if (hipMemcpyFromSymbol(counts, HIP_SYMBOL(g_epw_trace_n), sizeof(int) * EPW_TR_BLOCKS) != hipSuccess) return -1;
+    if (hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_epw_trace), sizeof(unsigned long long) * EPW_TR_BLOCKS * EPW_TR_MAX) != hipSuccess) return -1;
+    return EPW_TR_MAX;
 }
 #endif
 

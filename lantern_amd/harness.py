@@ -63,6 +63,9 @@ class WorkloadConfig:
     use_graph: bool = False         # True: replay one captured hipGraph per pool slot (6 kernels, fixed arguments); measured
                                     # 167 us/step vs 158 us eager on MI355X (the eager queue already runs ahead of the GPU)
     path: str = "window"            # "window": v2 kernels (32 KB rows, LDS-resident residual); "dense": v1 kernels
+    n_groups: int = 1               # >1: the sequences are split into groups, each launched on its own HIP stream, so that one
+                                    # group's latency-bound evaluate_posterior overlaps the others' bandwidth-bound kernels
+                                    # (independent sequences: no ordering between groups exists)
 
 
 def build_neighbour_table(device, seed: int = 0) -> torch.Tensor:
@@ -80,6 +83,9 @@ class LuminaVerifyWorkload:
     def __init__(self, cfg: WorkloadConfig, device: torch.device, rank: int = 0):
         self.cfg, self.device, self.rank = cfg, device, rank
         B, S = cfg.n_seq, cfg.pool_steps
+        if cfg.n_groups < 1 or B % cfg.n_groups:
+            raise ValueError(f"n_seq={B} must be a multiple of n_groups={cfg.n_groups}")
+        self.G, self.Bg = cfg.n_groups, B // cfg.n_groups
         tb = ops.tree_static_build(MC_SIM_7B_63)
         self.tb = tb
         self.N = N = len(tb["tree_indices"])
@@ -164,10 +170,11 @@ class LuminaVerifyWorkload:
             if need + (8 << 30) > free:      # never drive the box out of memory
                 raise _lib.LanternError(f"KV slabs need {need / 2**30:.0f} GiB (+8 GiB head-room) but only {free / 2**30:.0f} GiB are free: "
                                         f"lower --seqs-per-gpu ({B})")
-            for _ in range(2 * B):                 # [cond slabs of all sequences..., uncond slabs...]
+            for _ in range(2 * B):                 # order: per group [cond slabs of its sequences..., uncond slabs...]
                 self.slabs.append(torch.zeros(shape, dtype=torch.bfloat16, device=device))
             self.slab_ptrs = torch.tensor([s.data_ptr() for s in self.slabs], dtype=torch.int64, device=device)
-            self.slab_seq = torch.arange(B, dtype=torch.int32, device=device).repeat(2)
+            # slab -> sequence, local to the slab's group (the kernels get group-offset best/accept_len pointers)
+            self.slab_seq = torch.arange(self.Bg, dtype=torch.int32, device=device).repeat(2 * cfg.n_groups)
 
         # ---------------- work buffers
         self.cand = torch.empty((B, P, D), dtype=torch.int64, device=device)
@@ -195,7 +202,8 @@ class LuminaVerifyWorkload:
         self.st_cnt = torch.zeros((B, 6), dtype=torch.int32, device=device)
         self.st_token = torch.zeros(B, dtype=torch.int64, device=device)
         self.u_cur = torch.zeros(B, dtype=torch.float64, device=device)
-        self.step_dev = torch.zeros(1, dtype=torch.int64, device=device)
+        self.step_dev = torch.zeros(cfg.n_groups, dtype=torch.int64, device=device)    # one device step counter per group
+        self.streams = [torch.cuda.Stream(device=device) for _ in range(cfg.n_groups)] if cfg.n_groups > 1 else [None]
         self._L = _lib.lib()
         self._ep_prm = self._make_ep_params()
         self.graphs = None
@@ -205,8 +213,8 @@ class LuminaVerifyWorkload:
     def reset_state(self):
         B, dev = self.cfg.n_seq, self.device
         cond0 = self.cfg.prompt_len + 3
-        # lens[0] = current, lens[1] = next (double buffer); layout [cond lens of all seqs, uncond lens]
-        base = torch.cat([torch.full((B,), cond0, dtype=torch.int64), torch.full((B,), 3, dtype=torch.int64)]).to(dev)
+        # lens[0] = current, lens[1] = next (double buffer); layout per group: [cond lens of its seqs, uncond lens]
+        base = torch.cat([torch.full((self.Bg,), cond0, dtype=torch.int64), torch.full((self.Bg,), 3, dtype=torch.int64)]).repeat(self.G).to(dev)
         if hasattr(self, "len_base"):
             self.len_base.copy_(base)
         else:
@@ -222,6 +230,7 @@ class LuminaVerifyWorkload:
         else:
             self.sample_token.copy_(self.first_token)
         self.step_idx = 0
+        self._forked = False
         if hasattr(self, "step_dev"):
             self.step_dev.zero_()
             self.u_cur.copy_(self.u_bonus[0])
@@ -235,7 +244,7 @@ class LuminaVerifyWorkload:
     def _make_ep_params(self) -> EpParams:
         c = self.cfg
         p = EpParams()
-        p.B, p.P, p.D, p.V, p.rows_per_seq = c.n_seq, self.P, self.D, V, self.N
+        p.B, p.P, p.D, p.V, p.rows_per_seq = self.Bg, self.P, self.D, V, self.N
         p.mode, p.syntax_shortcut, p.tok_offset = ops.MODE_STATIC_LUMINA, 1, 4
         p.img_lo, p.img_hi, p.n_syntax = IMG_LO, IMG_HI, 4
         for i, s in enumerate((8196, 8197, 8803, 8828)):
@@ -246,137 +255,216 @@ class LuminaVerifyWorkload:
         p.n_uniforms, p.R, p.N, p.row_index_per_seq = self.n_uniforms, self.R, self.N, 0
         return p
 
-    def ep_buffers(self, slot: int, i: int) -> EpBuffers:
+    def ep_buffers(self, slot: int, g: int = 0) -> EpBuffers:
+        """evaluate_posterior buffers of group g (sequences [g*Bg, (g+1)*Bg)) for pool slot `slot`."""
+        s0 = g * self.Bg
+        at = lambda t: t[s0:].data_ptr()
         b = EpBuffers()
-        b.logits, b.row_index, b.cand = self.proc.data_ptr(), self.d_row_index.data_ptr(), self.cand.data_ptr()
-        b.cart_prob, b.orig_prob = self.cart_prob.data_ptr(), self.orig_prob[slot].data_ptr()
+        b.logits, b.row_index, b.cand = at(self.proc), self.d_row_index.data_ptr(), at(self.cand)
+        b.cart_prob, b.orig_prob = at(self.cart_prob), at(self.orig_prob[slot])
         b.op_off, b.p_idx, b.b_off, b.b_idx = (self.d_op_off.data_ptr(), self.d_p_idx.data_ptr(), self.d_b_off.data_ptr(),
                                                self.d_b_idx.data_ptr())
-        b.tree_cand, b.nn_table = self.tree_cand.data_ptr(), self.table.data_ptr()
-        b.uniforms, b.cursor = self.uniforms.data_ptr(), self.cursor.data_ptr()
-        b.best, b.accept_len = self.st_best.data_ptr(), self.st_alen.data_ptr()
-        b.counters = self.st_cnt.data_ptr()
+        b.tree_cand, b.nn_table = at(self.tree_cand), self.table.data_ptr()
+        b.uniforms, b.cursor = at(self.uniforms), at(self.cursor)
+        b.best, b.accept_len = at(self.st_best), at(self.st_alen)
+        b.counters = at(self.st_cnt)
         if not self.windowed:
-            b.workspace, b.sample_p = self.workspace.data_ptr(), self.sample_p.data_ptr()
+            b.workspace, b.sample_p = at(self.workspace), at(self.sample_p)
         return b
 
-    def ep_window(self, i: int) -> EpWindow:
+    def ep_window(self, g: int = 0) -> EpWindow:
+        s0 = g * self.Bg
+        at = lambda t: t[s0:].data_ptr()
         w = EpWindow()
-        w.win_lo, w.win_len, w.row_hot = self.win_lo, self.W, self.row_hot.data_ptr()
+        w.win_lo, w.win_len, w.row_hot = self.win_lo, self.W, at(self.row_hot)
         w.orig_prob_stride, w.orig_prob_offset = self.W, 0
-        w.out_tok, w.out_mass = self.out_tok.data_ptr(), self.out_mass.data_ptr()
-        w.u_bonus, w.token = self.u_cur.data_ptr(), self.st_token.data_ptr()
+        w.out_tok, w.out_mass = at(self.out_tok), at(self.out_mass)
+        w.u_bonus, w.token = at(self.u_cur), at(self.st_token)
         return w
 
+    def cond_lens(self, parity: int) -> torch.Tensor:
+        """KV lengths of the cond slabs in sequence order (the device layout is per group [cond..., uncond...])."""
+        return self.lens[parity].view(self.G, 2, self.Bg)[:, 0].reshape(-1)
+
+    def uncond_lens(self, parity: int) -> torch.Tensor:
+        return self.lens[parity].view(self.G, 2, self.Bg)[:, 1].reshape(-1)
+
+    def slab(self, b: int, j: int) -> torch.Tensor:
+        """KV slab j (0 = cond, 1 = uncond) of sequence b."""
+        g, l = divmod(b, self.Bg)
+        return self.slabs[g * 2 * self.Bg + j * self.Bg + l]
+
     # -------------------------------------------------------------------------------------
-    def step(self, events=None):
-        """One verify step over all sequences.  `events`: optional dict name -> (start,end) torch events recorded around
-        the HBM-heavy kernels on the launch stream (eager launches only).  Without events and with cfg.use_graph the step
-        is one hipGraph replay."""
+    def step(self, events=None, serial=False):
+        """Enqueue one verify step of every sequence.  G == 1: on the current stream (eager, or one hipGraph replay with
+        cfg.use_graph).  G > 1: group g's kernels go to its own stream with NO ordering against the other groups (they
+        are independent sequences), eagerly or as one graph replay per group; call join() (or synchronize the device)
+        before reading results on another stream.  `events`: dict name -> (start, end) torch events around the
+        HBM-heavy kernels of group 0.  `serial`: launch all groups eagerly on the current stream (clean per-kernel
+        durations for the event-timed pass)."""
         i = self.step_idx
         slot = i % self.cfg.pool_steps
-        if events is None and self.cfg.use_graph and self.cfg.pool_steps % 2 == 0:
-            if self.graphs is None:
-                self._capture_graphs()
-            self.graphs[slot].replay()
+        use_graph = events is None and not serial and self.cfg.use_graph and self.cfg.pool_steps % 2 == 0
+        if use_graph and self.graphs is None:
+            self._capture_graphs()
+        if self.G == 1:
+            if use_graph:
+                self.graphs[slot][0].replay()
+            else:
+                self._launch_step(slot, i & 1, events, 0)
+        elif serial:
+            self.join()
+            for g in range(self.G):
+                self._launch_step(slot, i & 1, events if g == 0 else None, g)
+            self._fork()
         else:
-            self._launch_step(slot, i & 1, events)
+            if not self._forked:
+                self._fork()
+            for g in range(self.G):
+                with torch.cuda.stream(self.streams[g]):
+                    if use_graph:
+                        self.graphs[slot][g].replay()
+                    else:
+                        self._launch_step(slot, i & 1, events if g == 0 else None, g)
         self.step_idx += 1
 
+    def _fork(self):
+        """Group streams pick up after everything enqueued so far on the current stream."""
+        if self.G > 1:
+            cur = torch.cuda.current_stream(self.device)
+            for st in self.streams:
+                st.wait_stream(cur)
+        self._forked = True
+
+    def join(self):
+        """The current stream waits for every group stream."""
+        if self.G > 1:
+            cur = torch.cuda.current_stream(self.device)
+            for st in self.streams:
+                cur.wait_stream(st)
+        self._forked = False
+
     def _capture_graphs(self):
-        """One graph per pool slot (the lens double buffer alternates with the slot parity)."""
+        """One graph per (pool slot, group); the lens double buffer alternates with the slot parity."""
         dev = self.device
-        snap = [t.clone() for t in (self.lens[0], self.lens[1], self.cursor, self.sample_token, self.step_dev, self.u_cur)]
+        self.join()
+        torch.cuda.synchronize(dev)
+        state = (self.lens[0], self.lens[1], self.cursor, self.sample_token, self.step_dev, self.u_cur, self.log_best, self.log_alen,
+                 self.log_cnt, self.log_token)
+        snap = [t.clone() for t in state]
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(side):            # warm-up launches outside capture (module load, lazy init)
-            self._launch_step(0, 0, None)
+            for g in range(self.G):
+                self._launch_step(0, 0, None, g)
         torch.cuda.current_stream(dev).wait_stream(side)
         torch.cuda.synchronize(dev)
         self.graphs = []
         for slot in range(self.cfg.pool_steps):
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                self._launch_step(slot, slot & 1, None)
-            self.graphs.append(g)
+            per_group = []
+            for g in range(self.G):
+                gr = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(gr):
+                    self._launch_step(slot, slot & 1, None, g)
+                per_group.append(gr)
+            self.graphs.append(per_group)
         torch.cuda.synchronize(dev)
-        for t, v in zip((self.lens[0], self.lens[1], self.cursor, self.sample_token, self.step_dev, self.u_cur), snap):
+        for t, v in zip(state, snap):
             t.copy_(v)                            # capture does not execute, the warm-up did: restore the state
         torch.cuda.synchronize(dev)
 
-    def _launch_step(self, slot: int, parity: int, events):
-        c, L = self.cfg, self._L
-        B, N, P, D = c.n_seq, self.N, self.P, self.D
-        st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    def _group_args(self, slot: int, parity: int, g: int):
+        """Raw pointers of group g's slice of every buffer (cached: the addresses never change)."""
+        key = (slot, parity, g)
+        cache = self.__dict__.setdefault("_argcache", {})
+        if key in cache:
+            return cache[key]
+        s0, Bg, N = g * self.Bg, self.Bg, self.N
+        vp = C.c_void_p
+        at = lambda t, o=s0: vp(t[o:].data_ptr())
         cur, nxt = self.lens[parity], self.lens[parity ^ 1]
+        a = dict(
+            ss_token=at(self.ss_token[slot]), ss_prob=at(self.ss_prob[slot]), sample_token=at(self.sample_token), tree_cand=at(self.tree_cand),
+            cand=at(self.cand), cart_prob=at(self.cart_prob), cond=at(self.cond[slot]), uncond=at(self.uncond[slot]), proc=at(self.proc),
+            row_hot=at(self.row_hot) if self.windowed else None, cur=at(cur, 2 * s0), nxt=at(nxt, 2 * s0), len_base=at(self.len_base, 2 * s0),
+            st_best=at(self.st_best), st_alen=at(self.st_alen), st_cnt=at(self.st_cnt), st_token=at(self.st_token),
+            hidden=at(self.hidden[slot]), out_hidden=at(self.out_hidden), acc_tokens=at(self.acc_tokens),
+            sample_p=None if self.windowed else at(self.sample_p), u_cur=at(self.u_cur),
+            step_dev=at(self.step_dev, g), log_best=vp(self.log_best[:, s0:].data_ptr()), log_alen=vp(self.log_alen[:, s0:].data_ptr()),
+            log_cnt=vp(self.log_cnt[:, s0:].data_ptr()), log_token=vp(self.log_token[:, s0:].data_ptr()),
+            u_bonus_g=vp(self.u_bonus[:, s0:].data_ptr()),
+            slab_ptrs=at(self.slab_ptrs, 2 * s0) if self.cfg.with_kv else None, slab_seq=at(self.slab_seq, 2 * s0) if self.cfg.with_kv else None,
+            ep_buf=self.ep_buffers(slot, g), ep_win=self.ep_window(g) if self.windowed else None)
+        cache[key] = a
+        return a
+
+    def _launch_step(self, slot: int, parity: int, events, g: int = 0):
+        c, L = self.cfg, self._L
+        B, N, P, D = self.Bg, self.N, self.P, self.D
+        st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        A = self._group_args(slot, parity, g)
         vp = C.c_void_p
 
         # O6 candidate assembly
-        check(L.lantern_gather_candidates(vp(self.ss_token[slot].data_ptr()), vp(self.ss_prob[slot].data_ptr()),
-                                          vp(self.sample_token.data_ptr()), vp(self.d_tree_indices.data_ptr()),
-                                          vp(self.d_retrieve.data_ptr()), B, self.R * 10, N, P, D, vp(self.tree_cand.data_ptr()),
-                                          vp(self.cand.data_ptr()), vp(self.cart_prob.data_ptr()), st), "gather_candidates")
+        check(L.lantern_gather_candidates(A["ss_token"], A["ss_prob"], A["sample_token"], vp(self.d_tree_indices.data_ptr()),
+                                          vp(self.d_retrieve.data_ptr()), B, self.R * 10, N, P, D, A["tree_cand"], A["cand"], A["cart_prob"], st),
+              "gather_candidates")
         # O7 CFG + Lumina position mask + top-k, positions from the device-side lengths
         if events:
             events["cfg_mask_topk"][0].record()
         if self.windowed:
-            check(L.lantern_cfg_mask_topk_window(vp(self.cond[slot].data_ptr()), vp(self.uncond[slot].data_ptr()), 1, B * N, V,
-                                                 C.c_float(c.cfg_scale), ops.MODEL_LUMINA, vp(self.d_pos_ids.data_ptr()),
-                                                 C.c_int64(c.prompt_len + 3), W_LATENT, H_LATENT, IMG_LO, IMG_HI, NEWLINE, EOS, c.top_k,
-                                                 vp(cur.data_ptr()), N, self.win_lo, self.W, vp(self.proc.data_ptr()),
-                                                 vp(self.row_hot.data_ptr()), st), "cfg_mask_topk_window")
+            check(L.lantern_cfg_mask_topk_window(A["cond"], A["uncond"], 1, B * N, V, C.c_float(c.cfg_scale), ops.MODEL_LUMINA,
+                                                 vp(self.d_pos_ids.data_ptr()), C.c_int64(c.prompt_len + 3), W_LATENT, H_LATENT, IMG_LO, IMG_HI,
+                                                 NEWLINE, EOS, c.top_k, A["cur"], N, self.win_lo, self.W, A["proc"], A["row_hot"], st),
+                  "cfg_mask_topk_window")
         else:
-            check(L.lantern_cfg_mask_topk(vp(self.cond[slot].data_ptr()), vp(self.uncond[slot].data_ptr()), 1, B * N, V,
-                                          C.c_float(c.cfg_scale), ops.MODEL_LUMINA, vp(self.d_pos_ids.data_ptr()),
-                                          C.c_int64(c.prompt_len + 3), W_LATENT, H_LATENT, IMG_LO, IMG_HI, NEWLINE, EOS, c.top_k,
-                                          vp(cur.data_ptr()), N, vp(self.proc.data_ptr()), st), "cfg_mask_topk")
+            check(L.lantern_cfg_mask_topk(A["cond"], A["uncond"], 1, B * N, V, C.c_float(c.cfg_scale), ops.MODEL_LUMINA,
+                                          vp(self.d_pos_ids.data_ptr()), C.c_int64(c.prompt_len + 3), W_LATENT, H_LATENT, IMG_LO, IMG_HI,
+                                          NEWLINE, EOS, c.top_k, A["cur"], N, A["proc"], st), "cfg_mask_topk")
         if events:
             events["cfg_mask_topk"][1].record()
             events["evaluate_posterior"][0].record()
         # O8 (windowed: the bonus token is drawn in the kernel epilogue)
-        buf = self.ep_buffers(slot, 0)
         if self.windowed:
-            win = self.ep_window(0)
-            check(L.lantern_evaluate_posterior_window(C.byref(self._ep_prm), C.byref(buf), C.byref(win), st), "evaluate_posterior_window")
+            check(L.lantern_evaluate_posterior_window(C.byref(self._ep_prm), C.byref(A["ep_buf"]), C.byref(A["ep_win"]), st),
+                  "evaluate_posterior_window")
         else:
-            check(L.lantern_evaluate_posterior(C.byref(self._ep_prm), C.byref(buf), st), "evaluate_posterior")
+            check(L.lantern_evaluate_posterior(C.byref(self._ep_prm), C.byref(A["ep_buf"]), st), "evaluate_posterior")
         if events:
             events["evaluate_posterior"][1].record()
-        # O9 KV gather: both slabs of every sequence in one launch
+        # O9 KV gather: both slabs of every sequence of the group in one launch
         if c.with_kv:
             if events:
                 events["kv_gather"][0].record()
-            check(L.lantern_kv_gather(vp(self.slab_ptrs.data_ptr()), vp(self.slab_seq.data_ptr()), vp(cur.data_ptr()), 2 * B, 2,
-                                      C.c_int64(2 * c.kv_layers * c.kv_heads), C.c_int64(c.kv_smax + c.kv_pad_rows), C.c_int64(c.kv_dim),
-                                      vp(self.d_retrieve.data_ptr()), 0, P, D, vp(self.st_best.data_ptr()), vp(self.st_alen.data_ptr()),
-                                      vp(nxt.data_ptr()), st), "kv_gather")
+            check(L.lantern_kv_gather(A["slab_ptrs"], A["slab_seq"], A["cur"], 2 * B, 2, C.c_int64(2 * c.kv_layers * c.kv_heads),
+                                      C.c_int64(c.kv_smax + c.kv_pad_rows), C.c_int64(c.kv_dim), vp(self.d_retrieve.data_ptr()), 0, P, D,
+                                      A["st_best"], A["st_alen"], A["nxt"], st), "kv_gather")
             if events:
                 events["kv_gather"][1].record()
         else:
-            torch.add(cur, (self.st_alen + 1).repeat(2), out=nxt)
+            s0 = g * self.Bg
+            torch.add(self.lens[parity][2 * s0:2 * s0 + 2 * B], (self.st_alen[s0:s0 + B] + 1).repeat(2), out=self.lens[parity ^ 1][2 * s0:2 * s0 + 2 * B])
         # O10 accepted hidden + token append (+ bonus token on the dense path)
-        check(L.lantern_accept_gather(vp(self.hidden[slot].data_ptr()), 2, B, 2, N, HIDDEN, vp(self.d_retrieve.data_ptr()), 0, P, D,
-                                      vp(self.cand.data_ptr()), vp(self.st_best.data_ptr()), vp(self.st_alen.data_ptr()),
-                                      vp(None if self.windowed else self.sample_p.data_ptr()), V,
-                                      vp(None if self.windowed else self.u_cur.data_ptr()), vp(self.out_hidden.data_ptr()),
-                                      vp(self.acc_tokens.data_ptr()), vp(None if self.windowed else self.st_token.data_ptr()), st),
-              "accept_gather")
+        check(L.lantern_accept_gather(A["hidden"], 2, B, 2, N, HIDDEN, vp(self.d_retrieve.data_ptr()), 0, P, D, A["cand"], A["st_best"],
+                                      A["st_alen"], A["sample_p"], V, None if self.windowed else A["u_cur"], A["out_hidden"],
+                                      A["acc_tokens"], None if self.windowed else A["st_token"], st), "accept_gather")
         # harness bookkeeping (sequence management, not the hot path): logs, next sample token, image wrap-around, step counter
-        check(L.lantern_harness_advance(B, 2 * B, C.c_int64(TOKENS_PER_IMAGE), C.c_int64(c.max_steps), vp(self.step_dev.data_ptr()),
-                                        vp(self.st_best.data_ptr()), vp(self.st_alen.data_ptr()), vp(self.st_cnt.data_ptr()),
-                                        vp(self.st_token.data_ptr()), vp(self.log_best.data_ptr()), vp(self.log_alen.data_ptr()),
-                                        vp(self.log_cnt.data_ptr()), vp(self.log_token.data_ptr()), vp(self.sample_token.data_ptr()),
-                                        vp(nxt.data_ptr()), vp(self.len_base.data_ptr()), vp(self.u_bonus.data_ptr()),
-                                        vp(self.u_cur.data_ptr()), st), "harness_advance")
+        check(L.lantern_harness_advance(B, 2 * B, c.n_seq, C.c_int64(TOKENS_PER_IMAGE), C.c_int64(c.max_steps), A["step_dev"], A["st_best"],
+                                        A["st_alen"], A["st_cnt"], A["st_token"], A["log_best"], A["log_alen"], A["log_cnt"], A["log_token"],
+                                        A["sample_token"], A["nxt"], A["len_base"], A["u_bonus_g"], A["u_cur"], st), "harness_advance")
 
     # -------------------------------------------------------------------------------------
     def accepted_tokens(self, i0: int, i1: int) -> int:
         return int((self.log_alen[i0:i1].to(torch.int64) + 1).sum().item())
 
-    def ep_algorithmic_bytes(self, i0: int, i1: int) -> float:
-        """SURVEY 8d contract figure summed over steps [i0,i1) and all sequences:
+    # Byte accounting.  `group`: None = all sequences (one whole step), g = the sequences of group g (one LAUNCH when G > 1).
+    def _seqs(self, group):
+        return slice(None) if group is None else slice(group * self.Bg, (group + 1) * self.Bg)
+
+    def ep_algorithmic_bytes(self, i0: int, i1: int, group=None) -> float:
+        """SURVEY 8d contract figure summed over steps [i0,i1):
         L*V*4 + T*k*6 + R*(k+1)*4 + V*4 (+ V*4 when the final row is a fresh softmax)."""
-        return self.ep_algorithmic_bytes_from(self.log_cnt[i0:i1])
+        return self.ep_algorithmic_bytes_from(self.log_cnt[i0:i1, self._seqs(group)])
 
     def ep_algorithmic_bytes_from(self, cnt) -> float:
         c = cnt.to(torch.float64).reshape(-1, 6)
@@ -385,11 +473,11 @@ class LuminaVerifyWorkload:
         n = c.shape[0]
         return float(Lv * V * 4 + T * k * 6 + Rj * (k + 1) * 4 + n * V * 4 + fresh * V * 4)
 
-    def ep_window_bytes(self, i0: int, i1: int) -> float:
+    def ep_window_bytes(self, i0: int, i1: int, group=None) -> float:
         """HBM bytes the windowed kernel must move: per visited level and per fresh final row one window row
         (W*4); per tried candidate k table ids (k*2); per rejection one drafter window row (W*4, static trees).  The
         neighbour gathers, zeroing, scans and the bonus-token draw run in LDS."""
-        return self.ep_window_bytes_from(self.log_cnt[i0:i1])
+        return self.ep_window_bytes_from(self.log_cnt[i0:i1, self._seqs(group)])
 
     def ep_window_bytes_from(self, cnt) -> float:
         c = cnt.to(torch.float64).reshape(-1, 6)
@@ -397,24 +485,25 @@ class LuminaVerifyWorkload:
         Lv, T, Rj, fresh = c[:, 0].sum(), c[:, 1].sum(), c[:, 2].sum(), (1 - c[:, 4]).sum()
         return float((Lv + fresh) * W * 4 + T * k * 2 + Rj * (W * 4 + 2))
 
-    def o7_algorithmic_bytes(self, n_steps: int) -> float:
+    def o7_algorithmic_bytes(self, n_launches: int, group=None) -> float:
         per_row = self.W * (2 * 2 + 4) if self.windowed else V * (2 * 2 + 4)
-        return float(n_steps) * self.cfg.n_seq * self.N * per_row
+        return float(n_launches) * (self.cfg.n_seq if group is None else self.Bg) * self.N * per_row
 
-    def kv_algorithmic_bytes(self, i0: int, i1: int) -> float:
+    def kv_algorithmic_bytes(self, i0: int, i1: int, group=None) -> float:
         c = self.cfg
         per_pos = 2 * c.kv_layers * c.kv_heads * c.kv_dim * 2      # bytes per position per slab
-        moved = (self.log_alen[i0:i1].to(torch.float64) + 1).sum().item() * 2   # two slabs per sequence
+        moved = (self.log_alen[i0:i1, self._seqs(group)].to(torch.float64) + 1).sum().item() * 2   # two slabs per sequence
         return float(2 * moved * per_pos)                            # read + write
 
-    def kv_moved_bytes(self, i0: int, i1: int) -> float:
+    def kv_moved_bytes(self, i0: int, i1: int, group=None) -> float:
         """Bytes kv_gather really moves: accepted rows whose tree slot is not already their final position
         (retrieve[best, t] != t); the root and accepted first children stay where the target forward wrote them."""
         c = self.cfg
         per_pos = 2 * c.kv_layers * c.kv_heads * c.kv_dim * 2
-        ret = self.d_retrieve.reshape(self.P, self.D)[self.log_best[i0:i1].long()]              # [steps, B, D]
+        sq = self._seqs(group)
+        ret = self.d_retrieve.reshape(self.P, self.D)[self.log_best[i0:i1, sq].long()]              # [steps, B, D]
         t = torch.arange(self.D, device=ret.device)
-        live = t[None, None, :] <= self.log_alen[i0:i1].long()[..., None]
+        live = t[None, None, :] <= self.log_alen[i0:i1, sq].long()[..., None]
         moved = ((ret != t) & live).sum().item() * 2
         return float(2 * moved * per_pos)
 

@@ -13,13 +13,14 @@ sys.path.insert(0, ROOT)
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("path,graph", [("window", False), ("window", True), ("dense", False)])
-def test_harness_loop_matches_oracle_loop(path, graph):
+@pytest.mark.parametrize("path,graph,groups", [("window", False, 1), ("window", True, 1), ("dense", False, 1), ("window", False, 3),
+                                               ("window", True, 2)])
+def test_harness_loop_matches_oracle_loop(path, graph, groups):
     import bench
     from lantern_amd import harness as HN
     steps = 36
     cfg = HN.WorkloadConfig(n_seq=6, pool_steps=4, path=path, use_graph=graph, kv_layers=2, kv_heads=4, kv_smax=512, max_steps=steps + 4,
-                            sigma=5.0)
+                            sigma=5.0, n_groups=groups)
     wl = HN.LuminaVerifyWorkload(cfg, torch.device("cuda"))
     for _ in range(steps):
         wl.step()
@@ -32,8 +33,8 @@ def test_harness_loop_matches_oracle_loop(path, graph):
     assert f"x {steps} verify steps" in res["sample"]
     # lengths advanced exactly by the accepted tokens (cond slabs: prompt + 3 header tokens + generated)
     gen = (ga.astype("int64") + 1).sum(0)
-    lens = wl.lens[steps & 1].cpu().numpy()
-    assert (lens[:cfg.n_seq] == cfg.prompt_len + 3 + gen).all() and (lens[cfg.n_seq:] == 3 + gen).all()
+    assert (wl.cond_lens(steps & 1).cpu().numpy() == cfg.prompt_len + 3 + gen).all()
+    assert (wl.uncond_lens(steps & 1).cpu().numpy() == 3 + gen).all()
     # a newline row was crossed by at least one sequence (position-dependent one-hot rows are in play)
     assert int((torch.as_tensor(gt) == HN.NEWLINE).sum()) > 0
 

@@ -1,36 +1,51 @@
-"""Diagnostic: phase stamps of epw_kernel (workgroup 0) from a separate -DEPW_TRACE build.  Not a benchmark."""
+"""Diagnostic: per-phase cycle stamps of epw_kernel from a separate -DEPW_TRACE=<1|2> build (1 = phase level, 2 = also
+inside the phases).  Every workgroup stamps into LDS; prints the slowest and the median sequence.  Not a benchmark."""
 import ctypes as C, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-so = os.path.join(ROOT, "tools", "liblantern_trace.so")
-if not os.path.exists(so):
+level = os.environ.get("EPW_TRACE", "1")
+so = os.path.join(ROOT, "tools", f"liblantern_trace{level}.so")
+if not os.path.exists(so) or (len(sys.argv) > 1 and sys.argv[1] == "build"):
     src = os.path.join(ROOT, "lantern_amd", "csrc")
     files = [os.path.join(src, f) for f in ("evaluate_posterior.hip", "logits_post.hip", "window_kernels.hip", "gather_ops.hip", "tree_dynamic.hip", "greedy.hip", "drafter_fc.hip", "vq_table.hip", "harness_util.hip")]
-    subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "-shared", "--offload-arch=gfx950", "-ffp-contract=off", "-DEPW_TRACE",
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "-shared", "--offload-arch=gfx950", "-ffp-contract=off", f"-DEPW_TRACE={level}",
                            "-o", so] + files + ["-x", "hip", os.path.join(src, "tree_static.cpp")])
 if len(sys.argv) > 1 and sys.argv[1] == "build":
     sys.exit(0)
+import numpy as np
 import torch
 from lantern_amd import _lib
 _lib.LIB_PATH = so
 from lantern_amd import harness as HN
-from lantern_amd._lib import check
-B = 32
-wl = HN.LuminaVerifyWorkload(HN.WorkloadConfig(n_seq=B, pool_steps=2, with_kv=False, max_steps=64, use_graph=False), torch.device("cuda"))
+B = int(os.environ.get("EPW_B", "48"))
+wl = HN.LuminaVerifyWorkload(HN.WorkloadConfig(n_seq=B, pool_steps=4, with_kv=False, max_steps=64, use_graph=False), torch.device("cuda"))
 L = wl._L
-for _ in range(3):
-    wl.step()
-torch.cuda.synchronize()
-buf = (C.c_ulonglong * 4096)()
-L.lantern_debug_epw_trace(buf, 2048)   # drop earlier stamps
-wl.step(); torch.cuda.synchronize()
-n = L.lantern_debug_epw_trace(buf, 2048)
-names = {1: "staged(loads issued)", 2: "staged(barrier)", 10: "level: masks done", 11: "level: softmax done", 12: "  softmax: row loaded+local max", 13: "  softmax: block max", 14: "  softmax: exp+local sum", 15: "  softmax: block sum", 20: "cand: start", 21: "cand: scan done",
-         22: "  scan: gathers done", 23: "  scan: dpp scan done", 24: "  scan: checks done", 25: "  scan: wave reduce done", 26: "  wave0 decision written", 30: "reject: residual done", 40: "epilogue start", 50: "epilogue done"}
-t0 = buf[1]
-prev = t0
-for i in range(n):
-    pid, t = buf[2 * i], buf[2 * i + 1]
-    print(f"{names.get(pid, pid):28s} +{(t - prev):7d} cyc   t={(t - t0) / 100.0:8.2f} us(100MHz ticks?)")
-    prev = t
-print("counters seq0:", wl.st_cnt[0].tolist())
+NAMES = {0: "start", 1: "staged(loads issued)", 2: "staged(barrier)", 10: "level: masks+prefetch", 11: "level: softmax", 12: "  softmax: row loaded+local max", 13: "  softmax: block max",
+         14: "  softmax: exp+local sum", 15: "  softmax: block sum", 20: "cand: start", 21: "cand: decision (all waves)", 22: "  scan: gathers", 23: "  scan: dpp scan", 24: "  scan: checks",
+         25: "  scan: wave reduce", 26: "  wave0 decision written", 30: "reject: residual", 40: "epilogue start", 50: "epilogue done"}
+agg = {}
+for step in range(8):
+    wl.step(); torch.cuda.synchronize()
+    buf = (C.c_ulonglong * (64 * 256))(); cnt = (C.c_int * 64)()
+    assert L.lantern_debug_epw_trace(buf, cnt) == 256
+    a = np.frombuffer(buf, dtype=np.uint64).reshape(64, 256)
+    tot = []
+    for b in range(min(B, 64)):
+        n = cnt[b]
+        ids = (a[b, :n] >> np.uint64(56)).astype(int); t = (a[b, :n] & np.uint64((1 << 56) - 1)).astype(np.int64)
+        tot.append(int(t[-1] - t[0]))
+        for i in range(1, n):
+            agg.setdefault(ids[i], []).append(int(t[i] - t[i - 1]))
+    order = np.argsort(tot)
+    if step >= 6:
+        for tag, b in (("slowest", order[-1]), ("median", order[len(order) // 2])):
+            n = cnt[b]
+            ids = (a[b, :n] >> np.uint64(56)).astype(int); t = (a[b, :n] & np.uint64((1 << 56) - 1)).astype(np.int64)
+            print(f"--- step {step} {tag} seq {b}: {tot[b]} cycles, counters {wl.st_cnt[b].tolist()}")
+            for i in range(1, n):
+                print(f"   {NAMES.get(ids[i], ids[i]):32s} +{int(t[i] - t[i - 1]):6d}")
+    print(f"step {step}: per-seq cycles min {min(tot)} median {int(np.median(tot))} max {max(tot)}")
+print("mean cycles per stamp interval (all sequences, all steps):")
+for i in sorted(agg):
+    v = np.array(agg[i])
+    print(f"   {NAMES.get(i, i):32s} n={len(v):5d} mean {v.mean():8.0f}  p50 {np.median(v):8.0f}  max {v.max():7d}   total share {v.sum():10d}")

@@ -209,6 +209,161 @@ __global__ __launch_bounds__(NT) void cfg_window_kernel(const void *__restrict__
     }
 }
 
+// ---- O7 windowed, bf16 logits, 16-byte loads.  Thread t owns E8 chunks of 8 consecutive window ids (chunk index
+// t + it*NT), so cond and uncond arrive as one global_load_dwordx4 each per chunk (the window start need only be
+// 4-aligned: the loads are then 8-byte aligned, which gfx950 global loads accept).  The first radix pass -- sign + 7 exponent bits, where a logit row
+// concentrates in a handful of bins -- uses an 8-way replicated LDS histogram (copy = lane & 7) so that same-address
+// atomic serialisation drops ~8x; the second pass (7 mantissa bits + 1 exponent bit inside the chosen bin) is spread
+// out by nature and uses a single copy.
+struct alignas(8) Bf16x8 {
+    uint2 a, b;
+};
+
+constexpr int O7_REP = 8;
+
+template <int NT, int NV4>
+__device__ __forceinline__ float kth_largest_hist_bf16(const float4 (&r)[NV4], int k, int *hist_rep, int *hist) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    // ---- pass 0: top 8 bits, replicated histogram
+    for (int t = tid; t < 256 * O7_REP; t += NT) hist_rep[t] = 0;
+    __syncthreads();
+    const int rep = lane & (O7_REP - 1);
+#pragma unroll
+    for (int it = 0; it < NV4; ++it) {
+        const uint32_t kk[4] = {float_key(r[it].x), float_key(r[it].y), float_key(r[it].z), float_key(r[it].w)};
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            if (kk[c] != 0x007fffffu) atomicAdd(&hist_rep[(kk[c] >> 24) * O7_REP + rep], 1);   // -inf (masked / padding) never ranks
+    }
+    __syncthreads();
+    for (int t = tid; t < 256; t += NT) {
+        const int4 a = *reinterpret_cast<const int4 *>(&hist_rep[t * O7_REP]);
+        const int4 b = *reinterpret_cast<const int4 *>(&hist_rep[t * O7_REP + 4]);
+        hist[t] = a.x + a.y + a.z + a.w + b.x + b.y + b.z + b.w;
+    }
+    __syncthreads();
+    uint32_t prefix = 0;
+    int krem = k;
+#pragma unroll 1
+    for (int pass = 0; pass < 2; ++pass) {
+        const int shift = 24 - 8 * pass;
+        const int c0 = hist[4 * lane], c1 = hist[4 * lane + 1], c2 = hist[4 * lane + 2], c3 = hist[4 * lane + 3];
+        const int s4 = c0 + c1 + c2 + c3;
+        const int incl = wave_scan_incl_dpp(s4);
+        const int total = readlane63(incl);
+        if (total < krem) return -__builtin_inff();     // fewer than k values: the k-th largest is below everything
+        int above = total - incl;                        // values in bins of higher lanes
+        int digit = -1, kn = 0;
+        if (above < krem && above + c3 >= krem) { digit = 4 * lane + 3; kn = krem - above; }
+        above += c3;
+        if (digit < 0 && above < krem && above + c2 >= krem) { digit = 4 * lane + 2; kn = krem - above; }
+        above += c2;
+        if (digit < 0 && above < krem && above + c1 >= krem) { digit = 4 * lane + 1; kn = krem - above; }
+        above += c1;
+        if (digit < 0 && above < krem && above + c0 >= krem) { digit = 4 * lane; kn = krem - above; }
+        const unsigned long long who = __ballot(digit >= 0);
+        const int src = __ffsll((long long)who) - 1;
+        digit = __shfl(digit, src, 64);
+        krem = __shfl(kn, src, 64);
+        prefix |= (uint32_t)digit << shift;
+        if (pass == 1) break;
+        // ---- pass 1: next 8 bits among the values of the chosen top bin, single histogram
+        __syncthreads();   // everyone has read hist
+        for (int t = tid; t < 256; t += NT) hist[t] = 0;
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < NV4; ++it) {
+            const uint32_t kk[4] = {float_key(r[it].x), float_key(r[it].y), float_key(r[it].z), float_key(r[it].w)};
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                if ((kk[c] & 0xff000000u) == prefix && kk[c] != 0x007fffffu) atomicAdd(&hist[(kk[c] >> 16) & 255u], 1);
+        }
+        __syncthreads();
+    }
+    if (!(prefix & 0x80000000u)) prefix |= 0xffffu;   // negative float: key = ~bits, low half all ones
+    return key_float(prefix);
+}
+
+template <int NT, int E8>
+__global__ __launch_bounds__(NT) void cfg_window_bf16_kernel(const uint16_t *__restrict__ cond, const uint16_t *__restrict__ uncond, int V,
+                                                             float cfg, int model, const int64_t *__restrict__ pos_ids, int64_t pos_base,
+                                                             int w_latent, int h_latent, int img_lo, int img_hi, int newline_id, int eos_id,
+                                                             int top_k, const int64_t *__restrict__ seq_len, int rows_per_seq, int win_lo,
+                                                             int W, float *__restrict__ out_win, int32_t *__restrict__ row_hot) {
+    __shared__ alignas(16) int s_hist_rep[256 * O7_REP];
+    __shared__ int s_hist[256];
+    const int row = blockIdx.x, tid = threadIdx.x;
+    const float NEG_INF = -__builtin_inff();
+    int cls = 0;
+    if (model == LANTERN_MODEL_LUMINA) {
+        const int64_t pos = seq_len ? pos_ids[row % rows_per_seq] + seq_len[row / rows_per_seq] : pos_ids[row];
+        const int64_t n1 = pos - pos_base + 1;
+        if (n1 == ((int64_t)w_latent + 1) * h_latent + 1)
+            cls = 2;
+        else if (py_mod64(n1, (int64_t)w_latent + 1) == 0)
+            cls = 1;
+    }
+    if (cls != 0) {
+        if (tid == 0) row_hot[row] = cls == 2 ? eos_id : newline_id;   // one-hot row: its window is never read
+        return;
+    }
+    if (tid == 0) row_hot[row] = -1;
+    const bool lumina = model == LANTERN_MODEL_LUMINA;
+    const bool masked = model != LANTERN_MODEL_PLAIN;
+    const float fill = lumina ? NEG_INF : __uint_as_float(0xff7f0000u);
+    const int e_base = win_lo;                            // first id of chunk 0
+    const uint16_t *crow = cond + (size_t)row * V + e_base;
+    const uint16_t *urow = uncond ? uncond + (size_t)row * V + e_base : nullptr;
+    float *out = out_win + (size_t)row * W;
+    float4 r[2 * E8];
+    Bf16x8 cb[E8], ub[E8];
+#pragma unroll
+    for (int it = 0; it < E8; ++it) {
+        const int ch = tid + it * NT;
+        const bool in = ch * 8 < W;
+        cb[it] = in ? *reinterpret_cast<const Bf16x8 *>(crow + ch * 8) : Bf16x8{make_uint2(0, 0), make_uint2(0, 0)};
+        ub[it] = (in && urow) ? *reinterpret_cast<const Bf16x8 *>(urow + ch * 8) : cb[it];
+    }
+#pragma unroll
+    for (int it = 0; it < E8; ++it) {
+        const int e0 = e_base + (tid + it * NT) * 8;
+        const uint32_t cw[4] = {cb[it].a.x, cb[it].a.y, cb[it].b.x, cb[it].b.y};
+        const uint32_t uw[4] = {ub[it].a.x, ub[it].a.y, ub[it].b.x, ub[it].b.y};
+        float o[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const float c = __uint_as_float((q & 1) ? (cw[q >> 1] & 0xffff0000u) : (cw[q >> 1] << 16));
+            const float u = __uint_as_float((q & 1) ? (uw[q >> 1] & 0xffff0000u) : (uw[q >> 1] << 16));
+            float t = c;
+            if (uncond) t = round_bf16(u + round_bf16(cfg * round_bf16(c - u)));
+            const int e = e0 + q;
+            const bool inwin = e >= win_lo && e < win_lo + W;
+            o[q] = !inwin ? NEG_INF : ((masked && (e < img_lo || e >= img_hi)) ? fill : t);
+        }
+        r[2 * it] = make_float4(o[0], o[1], o[2], o[3]);
+        r[2 * it + 1] = make_float4(o[4], o[5], o[6], o[7]);
+    }
+    if (top_k > 0 && top_k < V) {
+        // k-th largest of the FULL row = k-th largest of the window whenever >= k window entries beat the fill
+        // value; otherwise the threshold is the fill value (or lower) and nothing inside the window is removed.
+        // (ids outside the window sit in r as -inf: they never count.)
+        const float thr = (top_k <= W) ? kth_largest_hist_bf16<NT, 2 * E8>(r, top_k, s_hist_rep, s_hist) : NEG_INF;
+#pragma unroll
+        for (int it = 0; it < 2 * E8; ++it) {
+            r[it].x = r[it].x < thr ? NEG_INF : r[it].x;
+            r[it].y = r[it].y < thr ? NEG_INF : r[it].y;
+            r[it].z = r[it].z < thr ? NEG_INF : r[it].z;
+            r[it].w = r[it].w < thr ? NEG_INF : r[it].w;
+        }
+    }
+#pragma unroll
+    for (int it = 0; it < E8; ++it) {
+        const int w0 = e_base + (tid + it * NT) * 8 - win_lo;     // window index of the chunk's first id (multiple of 4)
+        if (w0 >= 0 && w0 < W) *reinterpret_cast<float4 *>(out + w0) = r[2 * it];
+        if (w0 + 4 >= 0 && w0 + 4 < W) *reinterpret_cast<float4 *>(out + w0 + 4) = r[2 * it + 1];
+    }
+}
+
 // ------------------------------------------------------------------------------- O8 windowed
 //
 // Structure (v3).  A 512-thread workgroup owns one sequence.  The serial part of the algorithm -- walking the
@@ -984,6 +1139,23 @@ extern "C" int lantern_cfg_mask_topk_window(const void *cond, const void *uncond
     hipStream_t st = (hipStream_t)stream;
     const bool bf = dtype == LANTERN_BF16;
 #define CW_ARGS bf, rows, st, cond, uncond, V, cfg, model, pos_ids, pos_base, w_latent, h_latent, img_lo, img_hi, newline_id, eos_id, top_k, seq_len, rows_per_seq, win_lo, win_len, out_win, row_hot
+    if (bf && win_len % 8 == 0 && win_len >= 2048) {
+        const int chunks = win_len / 8;
+        const uint16_t *c16 = (const uint16_t *)cond, *u16 = (const uint16_t *)uncond;
+        static const int nt_knob = getenv("LANTERN_O7_NT") ? atoi(getenv("LANTERN_O7_NT")) : 0;   // tuning knob (diagnostic)
+#define CW16(NT_, E8_)                                                                                                              \
+    hipLaunchKernelGGL((cfg_window_bf16_kernel<NT_, E8_>), dim3(rows), dim3(NT_), 0, st, c16, u16, V, cfg, model, pos_ids, pos_base,       \
+                       w_latent, h_latent, img_lo, img_hi, newline_id, eos_id, top_k, seq_len, rows_per_seq, win_lo, win_len, out_win,  \
+                       row_hot)
+        if (chunks <= 256 * 2) CW16(256, 2);
+        else if (chunks <= 256 * 4 && nt_knob == 256) CW16(256, 4);
+        else if (chunks <= 512 * 2 && nt_knob != 1024) CW16(512, 2);
+        else if (chunks <= 1024 * 1) CW16(1024, 1);
+        else CW16(1024, 2);
+#undef CW16
+        LANTERN_CHECK_LAUNCH("cfg_mask_topk_window");
+        return LANTERN_OK;
+    }
     if (win_len <= 1024) launch_cfgw<256, 1>(CW_ARGS);
     else if (win_len <= 2048) launch_cfgw<256, 2>(CW_ARGS);
     else if (win_len <= 4096) launch_cfgw<512, 2>(CW_ARGS);

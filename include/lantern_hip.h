@@ -209,13 +209,23 @@ int lantern_evaluate_posterior(const lantern_ep_params *prm, const lantern_ep_bu
  * MultiModalLogitsProcessor); row_hot = -1 for window rows.
  */
 
+/* What a window row holds.  LOGITS: processed logits (-inf = removed); evaluate_posterior_window applies
+ * prm->temperature / prm->top_k and the softmax per VISITED row, as the reference does
+ * (ea_model_llamagen.py:725,785).  PROBS: cfg_mask_topk_window already applied temperature -> top-k -> softmax to
+ * EVERY row (one workgroup per row, all in parallel), so the serial per-sequence chain of O8 only copies the row
+ * into LDS; same arithmetic, same bits (the row's distribution does not depend on when it is computed). */
+#define LANTERN_ROWS_LOGITS 0
+#define LANTERN_ROWS_PROBS 1
+
 /* O7 windowed: same arguments as lantern_cfg_mask_topk, output [rows, win_len] f32 + row_hot [rows].
- * LANTERN_MODEL_PLAIN requires win_lo = 0, win_len = V. */
+ * LANTERN_MODEL_PLAIN requires win_lo = 0, win_len = V.  `temperature` (> 1e-5; 1.0 = none) divides the row
+ * before the top-k filter (HF order Temperature -> TopK, drafters/utils.py:36-52); out_kind selects what is
+ * stored (LANTERN_ROWS_*). */
 int lantern_cfg_mask_topk_window(const void *cond, const void *uncond, int dtype, int rows, int V, float cfg,
                                  int model, const int64_t *pos_ids, int64_t pos_base, int w_latent,
                                  int h_latent, int img_lo, int img_hi, int newline_id, int eos_id, int top_k,
                                  const int64_t *seq_len, int rows_per_seq, int win_lo, int win_len,
-                                 float *out_win, int32_t *row_hot, void *stream);
+                                 float *out_win, int32_t *row_hot, int out_kind, float temperature, void *stream);
 
 typedef struct lantern_ep_window {
     int32_t win_lo, win_len;      /* window = token ids [win_lo, win_lo+win_len); win_len % 4 == 0 */
@@ -231,6 +241,8 @@ typedef struct lantern_ep_window {
     float *out_mass;              /* [dev] [B] out: its probability */
     const double *u_bonus;        /* [dev] [B] or NULL: uniform for the bonus-token draw */
     int64_t *token;               /* [dev] [B] out (with u_bonus): inverse-CDF bonus token */
+    int32_t rows_kind;            /* LANTERN_ROWS_LOGITS | LANTERN_ROWS_PROBS: what buf->logits rows hold */
+    int32_t reserved;
 } lantern_ep_window;
 
 /* O8 windowed.  buf->logits is [B, rows_per_seq, win_len]; buf->sample_p may be NULL (if given, the dense

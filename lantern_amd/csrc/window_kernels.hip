@@ -124,14 +124,65 @@ __device__ __forceinline__ float kth_largest_hist(const float4 (&r)[E4], int k, 
     return key_float(prefix);
 }
 
+// exp(x) for x <= 0 (softmax arguments): n = rint(x*log2e), r = x - n*ln2 (two-term), 2^(r*log2e) on the
+// hardware exp unit, ldexp.  7 VALU ops, < 1 ulp like the libm/ocml routine it replaces (which costs ~20).
+__device__ __forceinline__ float exp_nonpos(float x) {
+    if (x < -104.0f) return 0.0f;                       // below the smallest subnormal (also -inf)
+    const float n = rintf(x * 1.44269504088896341f);
+    float r = fmaf(-n, 0.693145751953125f, x);          // ln2 high part (exact product for |n| < 2^11)
+    r = fmaf(-n, 1.42860682030941723e-6f, r);           // ln2 low part
+    return ldexpf(__builtin_amdgcn_exp2f(r * 1.44269504088896341f), (int)n);
+}
+
+// x / d for many x and one d: reciprocal refined once (Newton), then q = fma(fma(-q0, d, x), r, q0) -- the quotient
+// correction step of the IEEE division expansion without its per-element scaling / fix-up instructions.  Correctly
+// rounded for the normal-range operands met here (d in [2^-20, 2^14], x in [0, 1]); 3 VALU ops instead of ~11.
+struct FastDiv {
+    float d, r;
+    __device__ __forceinline__ explicit FastDiv(float den) : d(den) {
+        float r0 = __builtin_amdgcn_rcpf(den);
+        r = fmaf(fmaf(-den, r0, 1.0f), r0, r0);
+    }
+    __device__ __forceinline__ float operator()(float x) const {
+        const float q0 = x * r;
+        return fmaf(fmaf(-q0, d, x), r, q0);
+    }
+};
+
+// softmax of a register tile over the workgroup: max, exp, f64 sum, one division per element -- the arithmetic
+// of the reference's torch.softmax(row) restated (oracle: lo_softmax_row); shared by O7 (rows emitted as
+// probabilities) and O8 (rows arriving as logits) so that both produce the same bits.
+template <int NT, int NV4>
+__device__ __forceinline__ void softmax_tile(float4 (&r)[NV4], float *redf, double *redd, int &ph) {
+    constexpr int NW = NT / 64;
+    float m = -__builtin_inff();
+#pragma unroll
+    for (int it = 0; it < NV4; ++it) m = fmaxf(fmaxf(m, fmaxf(r[it].x, r[it].y)), fmaxf(r[it].z, r[it].w));
+    m = block_max_fast<NW>(m, redf, ph);
+    double s = 0.0;
+#pragma unroll
+    for (int it = 0; it < NV4; ++it) {
+        r[it].x = exp_nonpos(r[it].x - m); r[it].y = exp_nonpos(r[it].y - m);
+        r[it].z = exp_nonpos(r[it].z - m); r[it].w = exp_nonpos(r[it].w - m);
+        s += (double)r[it].x + (double)r[it].y + (double)r[it].z + (double)r[it].w;
+    }
+    const float sf = (float)block_sum_fast<double, NW>(s, redd, ph);
+    const FastDiv dv(sf);
+#pragma unroll
+    for (int it = 0; it < NV4; ++it) r[it] = make_float4(dv(r[it].x), dv(r[it].y), dv(r[it].z), dv(r[it].w));
+}
+
 // ------------------------------------------------------------------------------- O7 windowed
 template <int NT, int E4, bool BF16>
 __global__ __launch_bounds__(NT) void cfg_window_kernel(const void *__restrict__ cond_, const void *__restrict__ uncond_, int V, float cfg,
                                                         int model, const int64_t *__restrict__ pos_ids, int64_t pos_base, int w_latent,
                                                         int h_latent, int img_lo, int img_hi, int newline_id, int eos_id, int top_k,
                                                         const int64_t *__restrict__ seq_len, int rows_per_seq, int win_lo, int W,
-                                                        float *__restrict__ out_win, int32_t *__restrict__ row_hot) {
+                                                        float *__restrict__ out_win, int32_t *__restrict__ row_hot, int out_kind,
+                                                        float temperature) {
     __shared__ int s_hist[256];
+    __shared__ float s_redf[32];
+    __shared__ double s_redd[32];
     const int row = blockIdx.x, tid = threadIdx.x;
     const float NEG_INF = -__builtin_inff();
     float *out = out_win + (size_t)row * W;
@@ -190,10 +241,19 @@ __global__ __launch_bounds__(NT) void cfg_window_kernel(const void *__restrict__
         }
         r[it] = v;
     }
+    const bool scaled = temperature > 1e-5f && temperature != 1.0f;      // TemperatureLogitsWarper (drafters/utils.py:36-52)
+    if (scaled) {
+#pragma unroll
+        for (int it = 0; it < E4; ++it) {
+            r[it].x = r[it].x / temperature; r[it].y = r[it].y / temperature;
+            r[it].z = r[it].z / temperature; r[it].w = r[it].w / temperature;
+        }
+    }
     if (top_k > 0 && top_k < V) {
         // k-th largest of the FULL row = k-th largest of the window whenever >= k window entries beat the fill
         // value; otherwise the threshold is the fill value (or lower) and nothing inside the window is removed.
-        const float thr = (top_k <= W) ? kth_largest_hist<NT, E4, BF16>(r, top_k, s_hist) : NEG_INF;
+        float thr = NEG_INF;
+        if (top_k <= W) thr = (BF16 && !scaled) ? kth_largest_hist<NT, E4, BF16>(r, top_k, s_hist) : kth_largest_hist<NT, E4, false>(r, top_k, s_hist);
 #pragma unroll
         for (int it = 0; it < E4; ++it) {
             r[it].x = r[it].x < thr ? NEG_INF : r[it].x;
@@ -201,6 +261,10 @@ __global__ __launch_bounds__(NT) void cfg_window_kernel(const void *__restrict__
             r[it].z = r[it].z < thr ? NEG_INF : r[it].z;
             r[it].w = r[it].w < thr ? NEG_INF : r[it].w;
         }
+    }
+    if (out_kind == LANTERN_ROWS_PROBS) {
+        int ph = 0;
+        softmax_tile<NT, E4>(r, s_redf, s_redd, ph);
     }
 #pragma unroll
     for (int it = 0; it < E4; ++it) {
@@ -289,9 +353,12 @@ __global__ __launch_bounds__(NT) void cfg_window_bf16_kernel(const uint16_t *__r
                                                              float cfg, int model, const int64_t *__restrict__ pos_ids, int64_t pos_base,
                                                              int w_latent, int h_latent, int img_lo, int img_hi, int newline_id, int eos_id,
                                                              int top_k, const int64_t *__restrict__ seq_len, int rows_per_seq, int win_lo,
-                                                             int W, float *__restrict__ out_win, int32_t *__restrict__ row_hot) {
+                                                             int W, float *__restrict__ out_win, int32_t *__restrict__ row_hot,
+                                                             int out_kind) {
     __shared__ alignas(16) int s_hist_rep[256 * O7_REP];
     __shared__ int s_hist[256];
+    __shared__ float s_redf[32];
+    __shared__ double s_redd[32];
     const int row = blockIdx.x, tid = threadIdx.x;
     const float NEG_INF = -__builtin_inff();
     int cls = 0;
@@ -356,6 +423,10 @@ __global__ __launch_bounds__(NT) void cfg_window_bf16_kernel(const uint16_t *__r
             r[it].w = r[it].w < thr ? NEG_INF : r[it].w;
         }
     }
+    if (out_kind == LANTERN_ROWS_PROBS) {
+        int ph = 0;
+        softmax_tile<NT, 2 * E8>(r, s_redf, s_redd, ph);
+    }
 #pragma unroll
     for (int it = 0; it < E8; ++it) {
         const int w0 = e_base + (tid + it * NT) * 8 - win_lo;     // window index of the chunk's first id (multiple of 4)
@@ -373,31 +444,6 @@ __global__ __launch_bounds__(NT) void cfg_window_bf16_kernel(const uint16_t *__r
 // cross-wave reductions combine <= 16 partials with one DPP row.  All decisions travel through one LDS word,
 // so control flow stays workgroup-uniform.  The neighbour ids of every candidate of a level are fetched in one
 // round at level start (they depend only on the accepted prefix), so the per-candidate work is LDS + ALU only.
-// exp(x) for x <= 0 (softmax arguments): n = rint(x*log2e), r = x - n*ln2 (two-term), 2^(r*log2e) on the
-// hardware exp unit, ldexp.  7 VALU ops, < 1 ulp like the libm/ocml routine it replaces (which costs ~20).
-__device__ __forceinline__ float exp_nonpos(float x) {
-    if (x < -104.0f) return 0.0f;                       // below the smallest subnormal (also -inf)
-    const float n = rintf(x * 1.44269504088896341f);
-    float r = fmaf(-n, 0.693145751953125f, x);          // ln2 high part (exact product for |n| < 2^11)
-    r = fmaf(-n, 1.42860682030941723e-6f, r);           // ln2 low part
-    return ldexpf(__builtin_amdgcn_exp2f(r * 1.44269504088896341f), (int)n);
-}
-
-// x / d for many x and one d: reciprocal refined once (Newton), then q = fma(fma(-q0, d, x), r, q0) -- the quotient
-// correction step of the IEEE division expansion without its per-element scaling / fix-up instructions.  Correctly
-// rounded for the normal-range operands met here (d in [2^-20, 2^14], x in [0, 1]); 3 VALU ops instead of ~11.
-struct FastDiv {
-    float d, r;
-    __device__ __forceinline__ explicit FastDiv(float den) : d(den) {
-        float r0 = __builtin_amdgcn_rcpf(den);
-        r = fmaf(fmaf(-den, r0, 1.0f), r0, r0);
-    }
-    __device__ __forceinline__ float operator()(float x) const {
-        const float q0 = x * r;
-        return fmaf(fmaf(-q0, d, x), r, q0);
-    }
-};
-
 constexpr int EW_MAX_P = 64, EW_MAX_D = 16, EW_MAX_PD = 1024, EW_MAX_SIB = 16, EW_MAX_N = 128, EW_MAX_B = 1024, EW_UNI = 64;
 constexpr int EW_PF_C = 6;        // candidates per level whose neighbour ids are prefetched into LDS
 constexpr int EW_PF_K = 1024;     // ... when k + 1 <= EW_PF_K; otherwise ids are read from HBM on demand
@@ -450,7 +496,7 @@ __device__ __forceinline__ void row_load(const float *__restrict__ rowp, int W, 
 }
 
 template <int NT, int E4, typename Hook = NoHook>
-__device__ __forceinline__ void row_softmax_to_lds(float4 (&r)[E4], int hot, int win_lo, int W, float temperature, int top_k,
+__device__ __forceinline__ void row_softmax_to_lds(float4 (&r)[E4], int hot, bool probs, int win_lo, int W, float temperature, int top_k,
                                                    int V, float *g, int &out_tok, float &out_mass, EwShared &S, int &ph,
                                                    const Hook &pre_barrier = Hook()) {
     constexpr int NW = NT / 64;
@@ -474,42 +520,28 @@ __device__ __forceinline__ void row_softmax_to_lds(float4 (&r)[E4], int hot, int
         __syncthreads();
         return;
     }
-    if (temperature > 1e-5f && temperature != 1.0f) {
+    if (!probs) {       // rows arrive as logits: processors + softmax here; LANTERN_ROWS_PROBS rows are final (O7 did both)
+        if (temperature > 1e-5f && temperature != 1.0f) {
 #pragma unroll
-        for (int it = 0; it < E4; ++it) {
-            r[it].x = r[it].x / temperature; r[it].y = r[it].y / temperature;
-            r[it].z = r[it].z / temperature; r[it].w = r[it].w / temperature;
+            for (int it = 0; it < E4; ++it) {
+                r[it].x = r[it].x / temperature; r[it].y = r[it].y / temperature;
+                r[it].z = r[it].z / temperature; r[it].w = r[it].w / temperature;
+            }
         }
-    }
-    if (top_k > 0 && top_k < V && top_k <= W) {
-        const float thr = kth_largest_tile<NT, E4, false>(r, top_k, S.redi, ph);
+        if (top_k > 0 && top_k < V && top_k <= W) {
+            const float thr = kth_largest_tile<NT, E4, false>(r, top_k, S.redi, ph);
 #pragma unroll
-        for (int it = 0; it < E4; ++it) {
-            r[it].x = r[it].x < thr ? NEG_INF : r[it].x; r[it].y = r[it].y < thr ? NEG_INF : r[it].y;
-            r[it].z = r[it].z < thr ? NEG_INF : r[it].z; r[it].w = r[it].w < thr ? NEG_INF : r[it].w;
+            for (int it = 0; it < E4; ++it) {
+                r[it].x = r[it].x < thr ? NEG_INF : r[it].x; r[it].y = r[it].y < thr ? NEG_INF : r[it].y;
+                r[it].z = r[it].z < thr ? NEG_INF : r[it].z; r[it].w = r[it].w < thr ? NEG_INF : r[it].w;
+            }
         }
+        softmax_tile<NT, E4>(r, S.redf, S.redd, ph);
     }
-    float m = NEG_INF;
-#pragma unroll
-    for (int it = 0; it < E4; ++it) m = fmaxf(fmaxf(m, fmaxf(r[it].x, r[it].y)), fmaxf(r[it].z, r[it].w));
-    EPW_STAMPF(12);
-    m = block_max_fast<NW>(m, S.redf, ph);
-    EPW_STAMPF(13);
-    double s = 0.0;
-#pragma unroll
-    for (int it = 0; it < E4; ++it) {
-        r[it].x = exp_nonpos(r[it].x - m); r[it].y = exp_nonpos(r[it].y - m);
-        r[it].z = exp_nonpos(r[it].z - m); r[it].w = exp_nonpos(r[it].w - m);
-        s += (double)r[it].x + (double)r[it].y + (double)r[it].z + (double)r[it].w;
-    }
-    EPW_STAMPF(14);
-    const float sf = (float)block_sum_fast<double, NW>(s, S.redd, ph);
-    EPW_STAMPF(15);
-    const FastDiv dv(sf);
 #pragma unroll
     for (int it = 0; it < E4; ++it) {
         const int i4 = tid + it * NT;
-        if (i4 * 4 < W) reinterpret_cast<float4 *>(g)[i4] = make_float4(dv(r[it].x), dv(r[it].y), dv(r[it].z), dv(r[it].w));
+        if (i4 * 4 < W) reinterpret_cast<float4 *>(g)[i4] = r[it];
     }
     pre_barrier();
     __syncthreads();
@@ -536,6 +568,7 @@ __global__ __launch_bounds__(NT) void epw_kernel(const lantern_ep_params prm, co
     const int nz = (k + 1 < prm.table_cols) ? k + 1 : prm.table_cols;   // ids touched per candidate (k summed, k+1 zeroed)
     const bool can_prefetch = LDSIDS && prm.lantern;
     const bool hot_in_lds = prm.rows_per_seq <= EW_MAX_N;
+    const bool rows_probs = win.rows_kind == LANTERN_ROWS_PROBS;
     int ph = 0;
 #ifdef EPW_TRACE
     if (tid == 0) s_epw_trn = 0;
@@ -683,7 +716,7 @@ __global__ __launch_bounds__(NT) void epw_kernel(const lantern_ep_params prm, co
             EPW_STAMP(10);
             if (hot < 0 && rp_rid != rid) row_load<NT, E4>(logits + (size_t)rid * W, W, rp);
             rp_rid = -1;
-            row_softmax_to_lds<NT, E4>(rp, hot, lo, W, prm.temperature, prm.top_k, V, g, out_tok, out_mass, S, ph, [&]() {
+            row_softmax_to_lds<NT, E4>(rp, hot, rows_probs, lo, W, prm.temperature, prm.top_k, V, g, out_tok, out_mass, S, ph, [&]() {
                 if (can_prefetch) {
 #pragma unroll
                     for (int c = 0; c < EW_PF_C; ++c)
@@ -964,7 +997,7 @@ __global__ __launch_bounds__(NT) void epw_kernel(const lantern_ep_params prm, co
         const int rid = S.row[best * Ds + (a - 1)];
         const int hot = !hot_g ? -1 : (hot_in_lds ? S.hot[rid] : hot_g[rid]);
         if (hot < 0 && rp_rid != rid) row_load<NT, E4>(logits + (size_t)rid * W, W, rp);
-        row_softmax_to_lds<NT, E4>(rp, hot, lo, W, prm.temperature, prm.top_k, V, g, out_tok, out_mass, S, ph);
+        row_softmax_to_lds<NT, E4>(rp, hot, rows_probs, lo, W, prm.temperature, prm.top_k, V, g, out_tok, out_mass, S, ph);
     }
     // ---------------------------------------------------------------- epilogue: outputs from LDS
     EPW_STAMP(40);
@@ -1107,20 +1140,23 @@ using namespace lantern;
 template <int NT, int E4>
 static void launch_cfgw(bool bf16, int rows, hipStream_t st, const void *cond, const void *uncond, int V, float cfg, int model,
                         const int64_t *pos_ids, int64_t pos_base, int w, int h, int img_lo, int img_hi, int nl, int eos, int top_k,
-                        const int64_t *seq_len, int rps, int win_lo, int W, float *out, int32_t *hot) {
+                        const int64_t *seq_len, int rps, int win_lo, int W, float *out, int32_t *hot, int out_kind, float temperature) {
     if (bf16)
         hipLaunchKernelGGL((cfg_window_kernel<NT, E4, true>), dim3(rows), dim3(NT), 0, st, cond, uncond, V, cfg, model, pos_ids, pos_base, w,
-                           h, img_lo, img_hi, nl, eos, top_k, seq_len, rps, win_lo, W, out, hot);
+                           h, img_lo, img_hi, nl, eos, top_k, seq_len, rps, win_lo, W, out, hot, out_kind, temperature);
     else
         hipLaunchKernelGGL((cfg_window_kernel<NT, E4, false>), dim3(rows), dim3(NT), 0, st, cond, uncond, V, cfg, model, pos_ids, pos_base, w,
-                           h, img_lo, img_hi, nl, eos, top_k, seq_len, rps, win_lo, W, out, hot);
+                           h, img_lo, img_hi, nl, eos, top_k, seq_len, rps, win_lo, W, out, hot, out_kind, temperature);
 }
 
 extern "C" int lantern_cfg_mask_topk_window(const void *cond, const void *uncond, int dtype, int rows, int V, float cfg, int model,
                                             const int64_t *pos_ids, int64_t pos_base, int w_latent, int h_latent, int img_lo,
                                             int img_hi, int newline_id, int eos_id, int top_k, const int64_t *seq_len,
-                                            int rows_per_seq, int win_lo, int win_len, float *out_win, int32_t *row_hot, void *stream) {
+                                            int rows_per_seq, int win_lo, int win_len, float *out_win, int32_t *row_hot, int out_kind,
+                                            float temperature, void *stream) {
     LANTERN_CHECK_ARG(cond && out_win && row_hot, "cfg_mask_topk_window: null buffer");
+    LANTERN_CHECK_ARG(out_kind == LANTERN_ROWS_LOGITS || out_kind == LANTERN_ROWS_PROBS, "cfg_mask_topk_window: bad out_kind %d", out_kind);
+    LANTERN_CHECK_ARG(temperature > 1e-5f, "cfg_mask_topk_window: temperature %g (the greedy branch has its own kernel)", (double)temperature);
     LANTERN_CHECK_ARG(rows >= 0 && V > 0 && V % 4 == 0, "cfg_mask_topk_window: bad rows=%d V=%d", rows, V);
     LANTERN_CHECK_ARG(win_lo >= 0 && win_lo % 4 == 0 && win_len > 0 && win_len % 4 == 0 && win_lo + win_len <= V && win_len <= 16384,
                       "cfg_mask_topk_window: window [%d,+%d) must be 4-aligned, inside V and <= 16384 wide", win_lo, win_len);
@@ -1138,15 +1174,15 @@ extern "C" int lantern_cfg_mask_topk_window(const void *cond, const void *uncond
     if (rows == 0) return LANTERN_OK;
     hipStream_t st = (hipStream_t)stream;
     const bool bf = dtype == LANTERN_BF16;
-#define CW_ARGS bf, rows, st, cond, uncond, V, cfg, model, pos_ids, pos_base, w_latent, h_latent, img_lo, img_hi, newline_id, eos_id, top_k, seq_len, rows_per_seq, win_lo, win_len, out_win, row_hot
-    if (bf && win_len % 8 == 0 && win_len >= 2048) {
+#define CW_ARGS bf, rows, st, cond, uncond, V, cfg, model, pos_ids, pos_base, w_latent, h_latent, img_lo, img_hi, newline_id, eos_id, top_k, seq_len, rows_per_seq, win_lo, win_len, out_win, row_hot, out_kind, temperature
+    if (bf && win_len % 8 == 0 && win_len >= 2048 && temperature == 1.0f) {
         const int chunks = win_len / 8;
         const uint16_t *c16 = (const uint16_t *)cond, *u16 = (const uint16_t *)uncond;
         static const int nt_knob = getenv("LANTERN_O7_NT") ? atoi(getenv("LANTERN_O7_NT")) : 0;   // tuning knob (diagnostic)
 #define CW16(NT_, E8_)                                                                                                              \
     hipLaunchKernelGGL((cfg_window_bf16_kernel<NT_, E8_>), dim3(rows), dim3(NT_), 0, st, c16, u16, V, cfg, model, pos_ids, pos_base,       \
                        w_latent, h_latent, img_lo, img_hi, newline_id, eos_id, top_k, seq_len, rows_per_seq, win_lo, win_len, out_win,  \
-                       row_hot)
+                       row_hot, out_kind)
         if (chunks <= 256 * 2) CW16(256, 2);
         else if (chunks <= 256 * 4 && nt_knob == 256) CW16(256, 4);
         else if (chunks <= 512 * 2 && nt_knob != 1024) CW16(512, 2);
@@ -1188,6 +1224,9 @@ extern "C" int lantern_evaluate_posterior_window(const lantern_ep_params *prm, c
     if (p.lantern)
         LANTERN_CHECK_ARG(buf->nn_table && p.k >= 1 && p.k <= p.table_cols && p.table_rows > 0, "evaluate_posterior_window: lantern needs nn_table, 1<=k<=cols");
     if (win->u_bonus) LANTERN_CHECK_ARG(win->token, "evaluate_posterior_window: u_bonus needs token");
+    LANTERN_CHECK_ARG(win->rows_kind == LANTERN_ROWS_LOGITS || win->rows_kind == LANTERN_ROWS_PROBS, "evaluate_posterior_window: bad rows_kind");
+    if (win->rows_kind == LANTERN_ROWS_PROBS)
+        LANTERN_CHECK_ARG(p.top_k <= 0 && p.temperature == 1.0f, "evaluate_posterior_window: probability rows are final -- apply temperature/top-k where they are produced (cfg_mask_topk_window)");
     if (p.top_p > 0.0f && p.top_p < 1.0f) {
         set_error("evaluate_posterior_window: top_p=%g inside the kernel is not built (use top_p=1)", (double)p.top_p);
         return LANTERN_E_UNSUPPORTED;

@@ -63,6 +63,8 @@ class WorkloadConfig:
     use_graph: bool = False         # True: replay one captured hipGraph per pool slot (6 kernels, fixed arguments); measured
                                     # 167 us/step vs 158 us eager on MI355X (the eager queue already runs ahead of the GPU)
     path: str = "window"            # "window": v2 kernels (32 KB rows, LDS-resident residual); "dense": v1 kernels
+    rows_probs: bool = True         # windowed path: O7 emits softmax probabilities for every row (1248 workgroups in parallel) so
+                                    # O8's serial per-sequence chain only copies its visited rows into LDS
     n_groups: int = 1               # >1: the sequences are split into groups, each launched on its own HIP stream, so that one
                                     # group's latency-bound evaluate_posterior overlaps the others' bandwidth-bound kernels
                                     # (independent sequences: no ordering between groups exists)
@@ -280,6 +282,7 @@ class LuminaVerifyWorkload:
         w.orig_prob_stride, w.orig_prob_offset = self.W, 0
         w.out_tok, w.out_mass = at(self.out_tok), at(self.out_mass)
         w.u_bonus, w.token = at(self.u_cur), at(self.st_token)
+        w.rows_kind = ops.ROWS_PROBS if self.cfg.rows_probs else ops.ROWS_LOGITS
         return w
 
     def cond_lens(self, parity: int) -> torch.Tensor:
@@ -415,7 +418,8 @@ class LuminaVerifyWorkload:
         if self.windowed:
             check(L.lantern_cfg_mask_topk_window(A["cond"], A["uncond"], 1, B * N, V, C.c_float(c.cfg_scale), ops.MODEL_LUMINA,
                                                  vp(self.d_pos_ids.data_ptr()), C.c_int64(c.prompt_len + 3), W_LATENT, H_LATENT, IMG_LO, IMG_HI,
-                                                 NEWLINE, EOS, c.top_k, A["cur"], N, self.win_lo, self.W, A["proc"], A["row_hot"], st),
+                                                 NEWLINE, EOS, c.top_k, A["cur"], N, self.win_lo, self.W, A["proc"], A["row_hot"],
+                                                 ops.ROWS_PROBS if c.rows_probs else ops.ROWS_LOGITS, C.c_float(1.0), st),
                   "cfg_mask_topk_window")
         else:
             check(L.lantern_cfg_mask_topk(A["cond"], A["uncond"], 1, B * N, V, C.c_float(c.cfg_scale), ops.MODEL_LUMINA,

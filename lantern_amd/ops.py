@@ -18,6 +18,7 @@ from ._lib import EpBuffers, EpParams, EpWindow, check
 
 MODE_DYNAMIC, MODE_STATIC_LUMINA, MODE_STATIC_LG = 0, 1, 2
 MODEL_PLAIN, MODEL_LUMINA, MODEL_ANOLE = 0, 1, 2
+ROWS_LOGITS, ROWS_PROBS = 0, 1          # what a window row holds (include/lantern_hip.h LANTERN_ROWS_*)
 
 
 def _stream() -> C.c_void_p:
@@ -418,8 +419,10 @@ def evaluate_posterior_greedy(logits, row_index, cand, lantern=False, k=1000, de
 
 def cfg_mask_topk_window(cond, uncond, cfg: float, win_lo: int, win_len: int, model: int = MODEL_PLAIN, pos_ids=None,
                          pos_base: int = 0, w: int = 48, h: int = 48, img_lo: int = 4, img_hi: int = 8196, newline_id: int = 8803,
-                         eos_id: int = 8196, top_k: int = 0, seq_len=None, rows_per_seq: int = 0, out=None, row_hot=None):
-    """O7 windowed: (out_win [rows,win_len] f32, row_hot [rows] i32)."""
+                         eos_id: int = 8196, top_k: int = 0, seq_len=None, rows_per_seq: int = 0, out=None, row_hot=None,
+                         probs: bool = False, temperature: float = 1.0):
+    """O7 windowed: (out_win [rows,win_len] f32, row_hot [rows] i32).  probs=True: rows leave as softmax probabilities
+    (temperature -> top-k -> softmax applied here, to every row); pass rows_probs=True to evaluate_posterior_window."""
     if not cond.is_cuda:
         raise _lib.LanternError("cfg_mask_topk_window: expected device tensors")
     assert cond.dtype in (torch.float32, torch.bfloat16) and (uncond is None or uncond.dtype == cond.dtype)
@@ -436,14 +439,14 @@ def cfg_mask_topk_window(cond, uncond, cfg: float, win_lo: int, win_len: int, mo
         C.c_void_p(cond.data_ptr()), C.c_void_p(_ptr(uncond)), 1 if cond.dtype == torch.bfloat16 else 0, rows, V, C.c_float(cfg),
         model, C.c_void_p(_ptr(pos)), C.c_int64(pos_base), w, h, img_lo, img_hi, newline_id, eos_id, top_k,
         C.c_void_p(_ptr(seq_len)), rows_per_seq, win_lo, win_len, C.c_void_p(out.data_ptr()), C.c_void_p(row_hot.data_ptr()),
-        _stream()), "cfg_mask_topk_window")
+        ROWS_PROBS if probs else ROWS_LOGITS, C.c_float(temperature), _stream()), "cfg_mask_topk_window")
     return out, row_hot
 
 
 def evaluate_posterior_window(cfg: EpConfig, V: int, win_logits, win_lo: int, row_index, cand, uniforms, row_hot=None, table=None,
                               aux: Optional[StaticAux] = None, orig_windowed: bool = False, n_paths=None, n_depth=None,
-                              cursor=None, u_bonus=None, want_dense: bool = False, want_window: bool = True):
-    """O8 windowed.  win_logits [B,rows,W] f32.  aux.orig_prob is the dense [B,R,V] pool (orig_windowed=False) or a
+                              cursor=None, u_bonus=None, want_dense: bool = False, want_window: bool = True, rows_probs: bool = False):
+    """O8 windowed.  win_logits [B,rows,W] f32 (probabilities when rows_probs: cfg must then carry top_k=0, temperature=1).  aux.orig_prob is the dense [B,R,V] pool (orig_windowed=False) or a
     windowed [B,R,W] pool.  Returns dict(best, accept_len, counters, sample_win, out_tok, out_mass, token, sample_p)."""
     win_logits = _dev(win_logits, torch.float32, "win_logits")
     cand = _dev(cand, torch.int64, "cand")
@@ -493,6 +496,7 @@ def evaluate_posterior_window(cfg: EpConfig, V: int, win_logits, win_lo: int, ro
         out["sample_p"] = torch.empty((B, V), dtype=torch.float32, device=dev)
         buf.sample_p = out["sample_p"].data_ptr()
     win.win_lo, win.win_len = win_lo, W
+    win.rows_kind = ROWS_PROBS if rows_probs else ROWS_LOGITS
     if row_hot is not None:
         row_hot = _dev(row_hot, torch.int32, "row_hot"); win.row_hot = row_hot.data_ptr()
     if want_window:

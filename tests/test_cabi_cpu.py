@@ -30,6 +30,7 @@ def test_param_struct_layout_matches_header():
     # ctypes mirror vs the C struct: field order/size (a drift here corrupts every launch)
     assert C.sizeof(_lib.EpParams) == 4 * 11 + 32 + 4 * 5 + 4 + 4 + 8 + 4 * 4
     assert C.sizeof(_lib.EpBuffers) == 20 * 8
+    assert C.sizeof(_lib.EpWindow) == 8 + 8 + 8 + 5 * 8 + 8
 
 
 def test_argument_validation_without_gpu():

@@ -210,3 +210,39 @@ def test_window_full_size_lumina_pipeline_vs_oracle():
         assert np.array_equal(out["counters"][b, :5].cpu().numpy(), ocnt[:5])
         np.testing.assert_allclose(out["sample_p"][b].cpu().numpy(), osp, rtol=0, atol=PROB_TOL)
         assert int(out["token"][b]) == oracle.sample_inverse_cdf(osp, ub_[b])
+    # probability rows: O7w applies the softmax to every row, O8w copies; identical results, bit for bit
+    pw, hot2 = ops.cfg_mask_topk_window(cond.cuda().reshape(B * N, V), unc.cuda().reshape(B * N, V), 3.0, lo, W, model=ops.MODEL_LUMINA,
+                                        pos_ids=dev(pos1), pos_base=prompt + 3, top_k=2000, seq_len=dev(seq_len), rows_per_seq=N, probs=True)
+    pw = pw.reshape(B, N, W)
+    assert torch.equal(hot2.reshape(B, N), hot)
+    for b in range(B):
+        for n in range(N):
+            if int(hot[b, n]) < 0:
+                ref = CS.softmax64(procs[b][n, lo:lo + W][None])[0]
+                np.testing.assert_allclose(pw[b, n].cpu().numpy(), ref, rtol=0, atol=1e-7)
+    out_p = ops.evaluate_posterior_window(cfg_h, V, pw, lo, dev(ri), dev(np.stack(cands)), dev(uni), row_hot=hot, table=dev(tab.view(np.int16)),
+                                          aux=aux, u_bonus=dev(ub_), want_dense=True, rows_probs=True)
+    for key in ("best", "accept_len", "counters", "token", "sample_p", "sample_win", "out_tok", "out_mass"):
+        assert torch.equal(out_p[key], out[key]), key
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_cfg_window_probs_and_temperature(dtype):
+    """out_kind = PROBS and the temperature argument of O7w against torch: softmax(topk(cfg(c,u)/T))."""
+    V, lo, W, k, T = 16384, 0, 16384, 500, 0.7
+    g = torch.Generator().manual_seed(3)
+    c = (3 * torch.randn(5, V, generator=g)).to(dtype)
+    u = torch.randn(5, V, generator=g).to(dtype)
+    for temp in (1.0, T):
+        lg, _ = ops.cfg_mask_topk_window(c.cuda(), u.cuda(), 2.0, lo, W, model=ops.MODEL_PLAIN, top_k=k, temperature=temp)
+        pr, _ = ops.cfg_mask_topk_window(c.cuda(), u.cuda(), 2.0, lo, W, model=ops.MODEL_PLAIN, top_k=k, temperature=temp, probs=True)
+        if dtype == torch.bfloat16:
+            x = (u + (2.0 * (c - u)).to(dtype)).float()      # bf16 rounding after every op, as torch does on bf16 tensors
+        else:
+            x = u + 2.0 * (c - u)
+        x = x / temp
+        kth = torch.topk(x, k, dim=-1).values[..., -1:]
+        x = x.masked_fill(x < kth, float("-inf"))
+        assert torch.equal(lg.cpu(), x)
+        assert int(torch.isfinite(lg).sum(-1).min()) >= k
+        np.testing.assert_allclose(pr.cpu().numpy(), torch.softmax(x.double(), -1).float().numpy(), rtol=0, atol=1e-7)

@@ -42,9 +42,15 @@ __shared__ int s_epw_trn;
 #else
 #define EPW_STAMPF(id) do { } while (0)
 #endif
+#if EPW_TRACE >= 3
+#define EPW_STAMPG(id) EPW_STAMP(id)
+#else
+#define EPW_STAMPG(id) do { } while (0)
+#endif
 #else
 #define EPW_STAMP(id) do { } while (0)
 #define EPW_STAMPF(id) do { } while (0)
+#define EPW_STAMPG(id) do { } while (0)
 #endif
 
 __device__ __forceinline__ int64_t py_mod64(int64_t a, int64_t b) {
@@ -467,10 +473,14 @@ struct alignas(16) EwShared {
     int dec[2][4];                          // decision words of wave 0: {code, m>0, csm1 bits, -}
     int hot[EW_MAX_N];                      // row_hot of this sequence's rows (when rows_per_seq <= EW_MAX_N)
     unsigned short nbid[EW_PF_C][EW_PF_K];  // prefetched neighbour ids (raw table values)
+    unsigned short nbaddr[EW_PF_C][EW_PF_K];// the same neighbours as gather indices into g (window index or a sentinel slot)
 };
 
+// g[W + EW_G_ZERO] = 0 (neighbour outside the window), g[W + EW_G_HUGE] = 3e38 (position >= k: never under tau),
+// g[W + EW_G_OUT] = out_mass (neighbour == the one-hot token outside the window): gather targets of the scan
+constexpr int EW_G_ZERO = 0, EW_G_HUGE = 1, EW_G_OUT = 2, EW_G_EXT = 4;
 __host__ __device__ inline size_t epw_shared_offset(int W) {
-    size_t o = (size_t)W * 4 + (size_t)((W + 31) / 32) * 4;
+    size_t o = (size_t)(W + EW_G_EXT) * 4 + (size_t)((W + 31) / 32) * 4;
     return (o + 15) & ~(size_t)15;
 }
 
@@ -516,6 +526,7 @@ __device__ __forceinline__ void row_softmax_to_lds(float4 (&r)[E4], int hot, boo
             out_tok = hot;
             out_mass = 1.0f;
         }
+        if (tid == 0) g[W + EW_G_OUT] = out_mass;
         pre_barrier();
         __syncthreads();
         return;
@@ -543,6 +554,7 @@ __device__ __forceinline__ void row_softmax_to_lds(float4 (&r)[E4], int hot, boo
         const int i4 = tid + it * NT;
         if (i4 * 4 < W) reinterpret_cast<float4 *>(g)[i4] = r[it];
     }
+    if (tid == 0) g[W + EW_G_OUT] = 0.0f;
     pre_barrier();
     __syncthreads();
 }
@@ -550,15 +562,29 @@ __device__ __forceinline__ void row_softmax_to_lds(float4 (&r)[E4], int hot, boo
 // LDSIDS: every candidate's neighbour ids are staged in LDS (k + 1 <= EW_PF_K, or LANTERN off), so the serial wave-0
 // section contains no vector-memory instruction -- the compiler then has no reason to drain vmcnt inside it and the
 // drafter-row / id loads issued before it stay in flight across the scan.  !LDSIDS (k > 1023) reads ids from HBM.
+//
+// Scalar registers are the scarce resource of this kernel (three parameter blocks + the walk's state): everything the
+// epilogue alone needs (output pointers, the bonus-draw inputs) is re-read from the kernarg segment there instead of
+// being held in SGPRs across the whole walk.
+struct EpwArgs {
+    lantern_ep_params prm;
+    lantern_ep_buffers buf;
+    lantern_ep_window win;
+};
+typedef const __attribute__((address_space(4))) EpwArgs *EpwArgsK;
+
 template <int NT, int E4, bool LDSIDS>
-__global__ __launch_bounds__(NT) void epw_kernel(const lantern_ep_params prm, const lantern_ep_buffers buf, const lantern_ep_window win) {
+__global__ __launch_bounds__(NT) void epw_kernel(const EpwArgs args) {
+    const lantern_ep_params &prm = args.prm;
+    const lantern_ep_buffers &buf = args.buf;
+    const lantern_ep_window &win = args.win;
     constexpr int NW = NT / 64;
     // one dynamic LDS region (16-byte aligned base): [ g : W f32 | nbmask : W bits | EwShared ]
     extern __shared__ float4 dyn_lds[];
     float *g = reinterpret_cast<float *>(dyn_lds);
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int Ps = prm.P, Ds = prm.D, V = prm.V, W = win.win_len, lo = win.win_lo;
-    uint32_t *nbmask = reinterpret_cast<uint32_t *>(g + W);  // W bits: neighbour set (static LlamaGen/Anole: zeroing hits q)
+    uint32_t *nbmask = reinterpret_cast<uint32_t *>(g + W + EW_G_EXT);  // W bits: neighbour set (static LlamaGen/Anole: zeroing hits q)
     EwShared &S = *reinterpret_cast<EwShared *>(reinterpret_cast<char *>(g) + epw_shared_offset(W));
     const int P = buf.n_paths ? buf.n_paths[b] : Ps;
     const int D = buf.n_depth ? buf.n_depth[b] : Ds;
@@ -659,6 +685,11 @@ __global__ __launch_bounds__(NT) void epw_kernel(const lantern_ep_params prm, co
             }
         }
         if (tid < EW_UNI) S.uni[tid] = un_;
+        if (tid == 0) {
+            g[W + EW_G_ZERO] = 0.0f;
+            g[W + EW_G_HUGE] = 3.0e38f;
+            g[W + EW_G_OUT] = 0.0f;
+        }
     }
     EPW_STAMP(1);
     __syncthreads();
@@ -689,6 +720,13 @@ __global__ __launch_bounds__(NT) void epw_kernel(const lantern_ep_params prm, co
         // neighbour ids of the level's candidates: their HBM reads are issued first, the row's loads second; both are in
         // flight together and the ids are written to LDS under the row's last barrier (one exposed latency per level)
         constexpr int PF_PER = (EW_PF_K + NT - 1) / NT;
+        // position t of a neighbour list -> index into g for the scan (out_tok is final before the ids are staged)
+        auto gather_addr = [&](int id, int t) -> unsigned short {
+            const int e = id + off;
+            if (t >= k) return (unsigned short)(W + EW_G_HUGE);
+            if (e >= lo && e < lo + W) return (unsigned short)(e - lo);
+            return (unsigned short)(W + (e == out_tok ? EW_G_OUT : EW_G_ZERO));
+        };
         unsigned short idv[EW_PF_C][PF_PER];
         int ncand = 0;
         if (can_prefetch) {
@@ -723,7 +761,10 @@ __global__ __launch_bounds__(NT) void epw_kernel(const lantern_ep_params prm, co
 #pragma unroll
                         for (int u = 0; u < PF_PER; ++u) {
                             const int t = tid + u * NT;
-                            if (c < ncand && t < EW_PF_K) S.nbid[c][t] = idv[c][u];
+                            if (c < ncand && t < EW_PF_K) {
+                                S.nbid[c][t] = idv[c][u];
+                                S.nbaddr[c][t] = gather_addr((int)idv[c][u], t);
+                            }
                         }
                 }
             });
@@ -759,7 +800,11 @@ __global__ __launch_bounds__(NT) void epw_kernel(const lantern_ep_params prm, co
             if (LDSIDS && can_prefetch && cidx >= EW_PF_C) {
                 // more unique candidates than prefetch slots (rare): stage this one's ids now, reusing a finished slot
                 __syncthreads();
-                for (int t = tid; t < EW_PF_K; t += NT) S.nbid[slot][t] = (nb && t < nz) ? nb[t] : (unsigned short)0;
+                for (int t = tid; t < EW_PF_K; t += NT) {
+                    const unsigned short id = (nb && t < nz) ? nb[t] : (unsigned short)0;
+                    S.nbid[slot][t] = id;
+                    S.nbaddr[slot][t] = gather_addr((int)id, t);
+                }
                 __syncthreads();
             }
             // static trees: start the drafter-row read now; it lands while wave 0 runs the neighbour scan and is
@@ -776,6 +821,7 @@ __global__ __launch_bounds__(NT) void epw_kernel(const lantern_ep_params prm, co
             }
             // ---------------- serial section: wave 0 only
             if (wave == 0) {
+                EPW_STAMPF(27);
                 float px = x_in ? g[x - lo] : (x == out_tok ? out_mass : 0.0f);
                 int code = 0, mflag = 0;
                 if (prm.syntax_shortcut && is_syn) {
@@ -788,25 +834,39 @@ __global__ __launch_bounds__(NT) void epw_kernel(const lantern_ep_params prm, co
                     } else {
                         const float tau = prm.delta > 1.0 ? (float)(prm.delta - 1.0) * px : (float)prm.delta;
                         float best_cs = NEG_INF;
+                        if constexpr (LDSIDS) {
+                            // 16 consecutive neighbours per lane, one round (k <= 1023).  The gather indices were resolved
+                            // when the ids were staged (window index, or a sentinel slot: 0 outside the window, 3e38 at
+                            // positions >= k so that they can never pass `<= tau`): 16 plain LDS reads, no predicate
+                            const uint4 a = *reinterpret_cast<const uint4 *>(&S.nbaddr[slot][lane * 16]);
+                            const uint4 bq = *reinterpret_cast<const uint4 *>(&S.nbaddr[slot][lane * 16 + 8]);
+                            const uint32_t w[8] = {a.x, a.y, a.z, a.w, bq.x, bq.y, bq.z, bq.w};
+                            double v[16], loc = 0.0;
+#pragma unroll
+                            for (int c = 0; c < 8; ++c) {
+                                loc += (double)g[w[c] & 0xffffu];
+                                v[2 * c] = loc;
+                                loc += (double)g[w[c] >> 16];
+                                v[2 * c + 1] = loc;
+                            }
+                            // exclusive prefix = inclusive scan of the lane totals shifted up by one lane (NOT inc - loc: a
+                            // lane whose own total holds a 3e38 sentinel would cancel its true prefix away)
+                            const double excl = wave_scan_incl_dpp(dpp_mov<0x138>(loc));   // wave_shr:1, lane 0 gets 0
+                            float mx = NEG_INF;
+#pragma unroll
+                            for (int c = 0; c < 16; ++c) {
+                                const float cs = (float)(excl + v[c]);
+                                mx = (cs <= tau) ? cs : mx;      // cs is non-decreasing in c: the last ok one is the largest
+                            }
+                            best_cs = wave_max(mx);
+                        } else {
                         double carry = 0.0;
-                        // 16 consecutive neighbours per lane, 1024 per round; ids come as two 16-byte reads when they were
-                        // prefetched to LDS; every gather is clamped + masked instead of branched
+                        // 16 consecutive neighbours per lane, 1024 per round, ids from HBM; every gather is clamped + masked
                         for (int base = 0; base < k; base += 1024) {
                             const int i0 = base + lane * 16;
                             int ids[16];
-                            if constexpr (LDSIDS) {
-                                const uint4 a = *reinterpret_cast<const uint4 *>(&S.nbid[slot][i0 & (EW_PF_K - 1)]);
-                                const uint4 bq = *reinterpret_cast<const uint4 *>(&S.nbid[slot][(i0 + 8) & (EW_PF_K - 1)]);
-                                const uint32_t w[8] = {a.x, a.y, a.z, a.w, bq.x, bq.y, bq.z, bq.w};
 #pragma unroll
-                                for (int c = 0; c < 8; ++c) {
-                                    ids[2 * c] = (int)(w[c] & 0xffffu);
-                                    ids[2 * c + 1] = (int)(w[c] >> 16);
-                                }
-                            } else {
-#pragma unroll
-                                for (int c = 0; c < 16; ++c) ids[c] = (i0 + c < k) ? (int)nb[i0 + c] : 0;
-                            }
+                            for (int c = 0; c < 16; ++c) ids[c] = (i0 + c < k) ? (int)nb[i0 + c] : 0;
                             double v[16], loc = 0.0;
 #pragma unroll
                             for (int c = 0; c < 16; ++c) {
@@ -818,10 +878,8 @@ __global__ __launch_bounds__(NT) void epw_kernel(const lantern_ep_params prm, co
                                 loc += (double)gv;
                                 v[c] = loc;
                             }
-                            EPW_STAMPF(22);
                             const double inc = wave_scan_incl_dpp(loc);
                             const double excl = carry + (inc - loc);
-                            EPW_STAMPF(23);
                             float mx = NEG_INF;
                             int nok = 0;
 #pragma unroll
@@ -831,14 +889,13 @@ __global__ __launch_bounds__(NT) void epw_kernel(const lantern_ep_params prm, co
                                 mx = ok ? fmaxf(mx, cs) : mx;
                                 nok += ok ? 1 : 0;
                             }
-                            EPW_STAMPF(24);
                             mx = wave_max(mx);
                             best_cs = fmaxf(best_cs, mx);
                             carry += readlane63(inc);
                             if (k - base <= 1024) break;
                             const int tot_ok = wave_sum(nok);
-                            EPW_STAMPF(25);
                             if (tot_ok < 1024) break;   // the cumulative mass is non-decreasing: the ok set is a prefix
+                        }
                         }
                         if (best_cs > NEG_INF) {
                             mflag = 1;
@@ -986,6 +1043,7 @@ __global__ __launch_bounds__(NT) void epw_kernel(const lantern_ep_params prm, co
                 reinterpret_cast<float4 *>(g)[i4] = v;
             }
             out_mass = out_mass / gs;
+            if (tid == 0) g[W + EW_G_OUT] = out_mass;
             __syncthreads();
             EPW_STAMP(30);
             adjust = 1;
@@ -1001,22 +1059,26 @@ __global__ __launch_bounds__(NT) void epw_kernel(const lantern_ep_params prm, co
     }
     // ---------------------------------------------------------------- epilogue: outputs from LDS
     EPW_STAMP(40);
+    const EpwArgsK ka = (EpwArgsK)__builtin_amdgcn_kernarg_segment_ptr();
+    float *const k_sample_win = ka->win.sample_win, *const k_sample_p = ka->buf.sample_p;
+    const double *const k_u_bonus = ka->win.u_bonus;
+    int64_t *const k_token = ka->win.token;
     float4 p[E4];
 #pragma unroll
     for (int it = 0; it < E4; ++it) {
         const int i4 = tid + it * NT;
         p[it] = (i4 * 4 < W) ? reinterpret_cast<const float4 *>(g)[i4] : make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    if (win.sample_win) {
-        float *sw = win.sample_win + (size_t)b * W;
+    if (k_sample_win) {
+        float *sw = k_sample_win + (size_t)b * W;
 #pragma unroll
         for (int it = 0; it < E4; ++it) {
             const int i4 = tid + it * NT;
             if (i4 * 4 < W) reinterpret_cast<float4 *>(sw)[i4] = p[it];
         }
     }
-    if (buf.sample_p) {   // optional dense copy (API compatibility)
-        float *sp = buf.sample_p + (size_t)b * V;
+    if (k_sample_p) {   // optional dense copy (API compatibility)
+        float *sp = k_sample_p + (size_t)b * V;
         for (int i4 = tid; i4 * 4 < V; i4 += NT) {
             const int e = i4 * 4;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -1025,7 +1087,7 @@ __global__ __launch_bounds__(NT) void epw_kernel(const lantern_ep_params prm, co
             reinterpret_cast<float4 *>(sp)[i4] = v;
         }
     }
-    if (win.u_bonus && win.token && status == LANTERN_ST_OK) {
+    if (k_u_bonus && k_token && status == LANTERN_ST_OK) {
         // inverse CDF in token-id order.  Register tile order (it, tid, component) IS ascending token id.
         const bool out_before = out_tok >= 0 && out_tok < lo;
         double s4[E4], inc[E4];
@@ -1051,7 +1113,7 @@ __global__ __launch_bounds__(NT) void epw_kernel(const lantern_ep_params prm, co
             total += tt;
         }
         if (out_tok >= 0 && !out_before) total += (double)out_mass;
-        const double tgt = win.u_bonus[b] * total;
+        const double tgt = k_u_bonus[b] * total;
         int found = 0x7fffffff, last_pos = -1;
         if (out_before && out_mass > 0.0f) {
             last_pos = out_tok;
@@ -1092,7 +1154,7 @@ __global__ __launch_bounds__(NT) void epw_kernel(const lantern_ep_params prm, co
                 f = min(f, S.redi[w]);
                 l = max(l, S.redi[16 + w]);
             }
-            win.token[b] = f != 0x7fffffff ? f : l;
+            k_token[b] = f != 0x7fffffff ? f : l;
         }
     }
     EPW_STAMP(50);
@@ -1104,18 +1166,18 @@ __global__ __launch_bounds__(NT) void epw_kernel(const lantern_ep_params prm, co
     }
 #endif
     if (tid == 0) {
-        buf.best[b] = best;
-        buf.accept_len[b] = a - 1;
-        int32_t *c = buf.counters + (size_t)b * 6;
+        ka->buf.best[b] = best;
+        ka->buf.accept_len[b] = a - 1;
+        int32_t *c = ka->buf.counters + (size_t)b * 6;
         c[0] = n_levels;
         c[1] = n_tried;
         c[2] = n_rej;
         c[3] = n_used;
         c[4] = from_residual;
         c[5] = status;
-        if (buf.cursor) buf.cursor[b] = ucur0 + n_used;
-        if (win.out_tok) win.out_tok[b] = out_tok;
-        if (win.out_mass) win.out_mass[b] = out_mass;
+        if (ka->buf.cursor) ka->buf.cursor[b] = ucur0 + n_used;
+        if (ka->win.out_tok) ka->win.out_tok[b] = out_tok;
+        if (ka->win.out_mass) ka->win.out_mass[b] = out_mass;
     }
 }
 
@@ -1241,10 +1303,11 @@ extern "C" int lantern_evaluate_posterior_window(const lantern_ep_params *prm, c
     dim3 grid(p.B);
     const int nz = (p.k + 1 < p.table_cols) ? p.k + 1 : p.table_cols;
     const bool lds_ids = !p.lantern || nz <= EW_PF_K;
+    const EpwArgs args{p, *buf, *win};
 #define EPW_LAUNCH(NT_, E4_)                                                                                              \
     do {                                                                                                                  \
-        if (lds_ids) hipLaunchKernelGGL((epw_kernel<NT_, E4_, true>), grid, dim3(NT_), lds, st, p, *buf, *win);           \
-        else hipLaunchKernelGGL((epw_kernel<NT_, E4_, false>), grid, dim3(NT_), lds, st, p, *buf, *win);                  \
+        if (lds_ids) hipLaunchKernelGGL((epw_kernel<NT_, E4_, true>), grid, dim3(NT_), lds, st, args);           \
+        else hipLaunchKernelGGL((epw_kernel<NT_, E4_, false>), grid, dim3(NT_), lds, st, args);                  \
     } while (0)
     if (W <= 1024) EPW_LAUNCH(256, 1);
     else if (W <= 2048) EPW_LAUNCH(256, 2);

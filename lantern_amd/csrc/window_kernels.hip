@@ -486,6 +486,10 @@ __host__ __device__ inline size_t epw_shared_offset(int W) {
 
 // softmax(processors(row)) -> g (LDS); one-hot rows put their mass in (out_tok,out_mass) when the hot token
 // lies outside the window.
+// value of lane `l` (wave-uniform index) without the LDS crossbar
+__device__ __forceinline__ int rdlane(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
+__device__ __forceinline__ float rdlane(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
+
 struct NoHook {
     __device__ __forceinline__ void operator()() const {}
 };
@@ -693,9 +697,9 @@ __global__ __launch_bounds__(NT) void epw_kernel(const EpwArgs args) {
     }
     EPW_STAMP(1);
     __syncthreads();
-    if (tid == 0) S.acc[0] = S.cand[0];
-    __syncthreads();
     EPW_STAMP(2);
+    // paths sharing the root token (the reference compares candidates[:, :1] with candidates[0, :1])
+    unsigned long long eq_mask = __ballot(lane < P && S.cand[(lane < P ? lane : 0) * Ds] == S.cand[0]);
 
     int a = 1, best = 0, adjust = 0, status = LANTERN_ST_OK;
     int n_levels = 0, n_tried = 0, n_rej = 0, n_used = 0;
@@ -706,16 +710,27 @@ __global__ __launch_bounds__(NT) void epw_kernel(const EpwArgs args) {
         if (i != a) break;
         adjust = 0;
         ++n_levels;
-        // prefix masks, one lane per path (every wave computes the same masks: P <= 64)
-        bool eq = lane < P;
-        for (int t = 0; t < a && eq; ++t) eq = (S.cand[lane * Ds + t] == S.acc[t]);
-        const unsigned long long eq_mask = __ballot(eq);
+        // prefix mask, one lane per path (P <= 64; every wave holds the same mask): kept across levels -- a path matches
+        // the accepted prefix of length a iff it matched at a-1 and carries the token accepted there
         if (eq_mask == 0ull) {
             status = LANTERN_ST_NO_PREFIX;
             break;
         }
         const int fi = __ffsll((long long)eq_mask) - 1;
-        const int x_lane = (lane < P) ? S.cand[lane * Ds + i] : -1;
+        // everything a candidate needs from its path at this level, one lane per path, fetched once per level
+        const int pl = (lane < P ? lane : 0) * Ds + i;
+        const int x_lane = (lane < P) ? S.cand[pl] : -1;
+        float cart_lane = 1.0f;
+        int qrow_lane = 0, b0_lane = 0, b1_lane = 0;
+        if (is_static) {
+            cart_lane = S.cart[pl];
+            qrow_lane = S.opoff[i - 1] + S.pidx[pl];
+            b0_lane = S.boff[pl];
+            b1_lane = S.boff[pl + 1];
+        }
+        int flag_lane = (x_lane >= prm.img_lo && x_lane < prm.img_hi) ? 2 : 0;     // bit 1: image token, bit 0: syntax token
+        if (prm.syntax_shortcut)
+            for (int t = 0; t < prm.n_syntax; ++t) flag_lane |= (x_lane == prm.syntax[t]) ? 1 : 0;
         const unsigned long long todo0 = eq_mask & __ballot(x_lane != -1);
         // neighbour ids of the level's candidates: their HBM reads are issued first, the row's loads second; both are in
         // flight together and the ids are written to LDS under the row's last barrier (one exposed latency per level)
@@ -735,7 +750,7 @@ __global__ __launch_bounds__(NT) void epw_kernel(const EpwArgs args) {
             for (int c = 0; c < EW_PF_C; ++c) {
                 const bool have = td != 0ull;
                 const int j = have ? __ffsll((long long)td) - 1 : 0;
-                const int x = __shfl(x_lane, j, 64);
+                const int x = rdlane(x_lane, j);
                 td &= ~__ballot(have && x_lane == x);
                 const int trow = x - off;
                 const bool lookup = have && trow >= 0 && trow < prm.table_rows && !(prm.syntax_shortcut && !(x >= prm.img_lo && x < prm.img_hi));
@@ -774,8 +789,9 @@ __global__ __launch_bounds__(NT) void epw_kernel(const EpwArgs args) {
         int cidx = -1;
         while (todo != 0ull) {
             const int j = __ffsll((long long)todo) - 1;
-            const int x = __shfl(x_lane, j, 64);
-            todo &= ~__ballot(x_lane == x);     // this path and every later path carrying the same token
+            const int x = rdlane(x_lane, j);
+            const unsigned long long same = __ballot(x_lane == x);
+            todo &= ~same;                      // this path and every later path carrying the same token
             ++cidx;
             if (x < 0 || x >= V) {
                 status = LANTERN_ST_TOKEN_OOB;
@@ -789,10 +805,9 @@ __global__ __launch_bounds__(NT) void epw_kernel(const EpwArgs args) {
             ++n_tried;
             EPW_STAMP(20);
             const bool x_in = (x >= lo && x < lo + W);
-            const bool in_img = (x >= prm.img_lo && x < prm.img_hi);
-            bool is_syn = false;
-            if (prm.syntax_shortcut)
-                for (int t = 0; t < prm.n_syntax; ++t) is_syn |= (x == prm.syntax[t]);
+            const int flags = rdlane(flag_lane, j);
+            const bool in_img = (flags & 2) != 0;
+            const bool is_syn = (flags & 1) != 0;
             const int slot = cidx % EW_PF_C;
             const int trow = x - off;
             const uint16_t *nb = (prm.lantern && trow >= 0 && trow < prm.table_rows) ? buf.nn_table + (size_t)trow * prm.table_cols : nullptr;
@@ -811,8 +826,7 @@ __global__ __launch_bounds__(NT) void epw_kernel(const EpwArgs args) {
             // simply dropped if the candidate is accepted (one 32 KB row, L2/MALL-resident for the next try)
             float4 q[E4];
             if (is_static) {
-                const float *qsrc = buf.orig_prob + ((size_t)b * prm.R + S.opoff[i - 1] + S.pidx[j * Ds + i]) * (size_t)win.orig_prob_stride +
-                                    win.orig_prob_offset;
+                const float *qsrc = buf.orig_prob + ((size_t)b * prm.R + rdlane(qrow_lane, j)) * (size_t)win.orig_prob_stride + win.orig_prob_offset;
 #pragma unroll
                 for (int it = 0; it < E4; ++it) {
                     const int i4 = tid + it * NT;
@@ -907,7 +921,7 @@ __global__ __launch_bounds__(NT) void epw_kernel(const EpwArgs args) {
                     float qx = 1.0f;
                     bool skip = false;
                     if (is_static) {
-                        qx = S.cart[j * Ds + i];
+                        qx = rdlane(cart_lane, j);
                         skip = qx <= 0.0f;
                     }
                     if (skip)
@@ -931,10 +945,9 @@ __global__ __launch_bounds__(NT) void epw_kernel(const EpwArgs args) {
             }
             if (code == 0) continue;
             if (code == 1) {
-                if (tid == 0) S.acc[a] = x;
                 ++a;
                 best = j;
-                __syncthreads();
+                eq_mask &= same;                // paths that also carry the accepted token at this depth
                 break;
             }
             // ------------------------------------------------ rejection: residual, all waves, all in LDS
@@ -963,7 +976,7 @@ __global__ __launch_bounds__(NT) void epw_kernel(const EpwArgs args) {
                     loc += (double)v.x + (double)v.y + (double)v.z + (double)v.w;
                 }
             } else {
-                const int b0 = S.boff[j * Ds + i], b1 = S.boff[j * Ds + i + 1];
+                const int b0 = rdlane(b0_lane, j), b1 = rdlane(b1_lane, j);
                 int nsib = b1 - b0;
                 if (nsib > EW_MAX_SIB) nsib = EW_MAX_SIB;
                 if (tid < nsib) {
@@ -1312,7 +1325,12 @@ extern "C" int lantern_evaluate_posterior_window(const lantern_ep_params *prm, c
     if (W <= 1024) EPW_LAUNCH(256, 1);
     else if (W <= 2048) EPW_LAUNCH(256, 2);
     else if (W <= 4096) EPW_LAUNCH(512, 2);
-    else if (W <= 8192) EPW_LAUNCH(512, 4);
+    else if (W <= 8192) {
+        static const int nt_knob = getenv("LANTERN_EPW_NT") ? atoi(getenv("LANTERN_EPW_NT")) : 0;   // tuning knob (diagnostic)
+        if (nt_knob == 1024) EPW_LAUNCH(1024, 2);
+        else if (nt_knob == 256) EPW_LAUNCH(256, 8);
+        else EPW_LAUNCH(512, 4);
+    }
     else EPW_LAUNCH(1024, 4);
 #undef EPW_LAUNCH
     LANTERN_CHECK_LAUNCH("evaluate_posterior_window");

@@ -75,7 +75,7 @@ def cpu_baseline(wl, steps_budget_s: float, n_seq: int, gpu_tokens_by_seq):
     ri = tb["retrieve_indices"].copy()
     ri[ri < 0] += N
     ri = ri.astype(np.int32)
-    table = wl.table.cpu().numpy().view(np.uint16)
+    table = wl.table_full.cpu().numpy().view(np.uint16)      # the oracle reads the reference's [K, K-1] layout
     cond = wl.cond[:, :n_seq].cpu().view(torch.int16).numpy().view(np.uint16)
     uncond = wl.uncond[:, :n_seq].cpu().view(torch.int16).numpy().view(np.uint16)
     orig = wl.orig_prob[:, :n_seq].cpu().numpy()

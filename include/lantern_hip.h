@@ -319,6 +319,13 @@ int lantern_drafter_fc(const int64_t *ids, const void *hidden, const void *embed
 int lantern_build_vq_table(const float *codebook, int K, int C, uint16_t *table, void *workspace,
                            void *stream);
 
+/* HBM layout for the hot path: the reference's table rows are K-1 = odd many uint16 (2-byte aligned, 16 KB apart)
+ * of which only the first k+1 are ever read (ea_model_lumina_mgpt.py:662).  This copies columns [0, min(src_cols,
+ * dst_cols)) into rows of dst_cols ids (zero padded); with dst_cols % 8 == 0 and a 16-byte aligned dst,
+ * lantern_evaluate_posterior_window stages a level's neighbour ids with 16-byte loads (8192 x 1024 ids = 16 MiB
+ * instead of 128 MiB for Lumina/Anole).  Pass the packed table with table_cols = dst_cols; k <= dst_cols - 1. */
+int lantern_pack_vq_table(const uint16_t *src, int rows, int src_cols, uint16_t *dst, int dst_cols, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -73,3 +73,18 @@ extern "C" int lantern_build_vq_table(const float *codebook, int K, int C, uint1
     LANTERN_CHECK_LAUNCH("build_vq_table");
     return LANTERN_OK;
 }
+
+namespace lantern {
+__global__ void pack_vq_table_kernel(const uint16_t *__restrict__ src, int rows, int src_cols, uint16_t *__restrict__ dst, int dst_cols) {
+    const int r = blockIdx.x;
+    for (int c = threadIdx.x; c < dst_cols; c += blockDim.x) dst[(size_t)r * dst_cols + c] = c < src_cols ? src[(size_t)r * src_cols + c] : (uint16_t)0;
+}
+}  // namespace lantern
+
+extern "C" int lantern_pack_vq_table(const uint16_t *src, int rows, int src_cols, uint16_t *dst, int dst_cols, void *stream) {
+    LANTERN_CHECK_ARG(src && dst && rows >= 0 && src_cols > 0 && dst_cols > 0, "pack_vq_table: bad arguments");
+    if (rows == 0) return LANTERN_OK;
+    hipLaunchKernelGGL(lantern::pack_vq_table_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, src, rows, src_cols, dst, dst_cols);
+    LANTERN_CHECK_LAUNCH("pack_vq_table");
+    return LANTERN_OK;
+}

@@ -577,8 +577,12 @@ struct EpwArgs {
 };
 typedef const __attribute__((address_space(4))) EpwArgs *EpwArgsK;
 
-template <int NT, int E4, bool LDSIDS>
+// IDMODE 0: ids from HBM in the scan (k > 1023).  1: ids staged in LDS, table rows at any (2-byte) alignment -- the
+// reference's [K, K-1] layout.  2: ids staged in LDS from a table whose row stride is a multiple of 8 ids and whose base
+// is 16-byte aligned (lantern_pack_vq_table): one 16-byte load brings 8 ids, 2 loads per thread cover a whole level.
+template <int NT, int E4, int IDMODE>
 __global__ __launch_bounds__(NT) void epw_kernel(const EpwArgs args) {
+    constexpr bool LDSIDS = IDMODE != 0;
     const lantern_ep_params &prm = args.prm;
     const lantern_ep_buffers &buf = args.buf;
     const lantern_ep_window &win = args.win;
@@ -743,8 +747,37 @@ __global__ __launch_bounds__(NT) void epw_kernel(const EpwArgs args) {
             return (unsigned short)(W + (e == out_tok ? EW_G_OUT : EW_G_ZERO));
         };
         unsigned short idv[EW_PF_C][PF_PER];
+        constexpr int CH_PER_C = EW_PF_K / 8;                              // 16-byte chunks per candidate
+        constexpr int PF16_PER = (EW_PF_C * CH_PER_C + NT - 1) / NT;
+        uint4 idq[PF16_PER];
         int ncand = 0;
-        if (can_prefetch) {
+        if (can_prefetch && IDMODE == 2) {
+            // candidate list first (scalar work only): lane c of xs_lane holds the c-th unique candidate token
+            unsigned long long td = todo0;
+            int xs_lane = -1;
+#pragma unroll
+            for (int c = 0; c < EW_PF_C; ++c) {
+                const bool have = td != 0ull;
+                const int j = have ? __ffsll((long long)td) - 1 : 0;
+                const int x = rdlane(x_lane, j);
+                td &= ~__ballot(have && x_lane == x);
+                if (lane == c) xs_lane = have ? x : -1;
+                ncand += have ? 1 : 0;
+            }
+            // chunk ch = 8 ids of candidate ch / 128: a wave works on one candidate at a time (128 chunks = 2 waves)
+#pragma unroll
+            for (int u = 0; u < PF16_PER; ++u) {
+                const int ch = tid + u * NT;
+                const int c = __builtin_amdgcn_readfirstlane(ch / CH_PER_C);
+                const int t0 = (ch % CH_PER_C) * 8;
+                const int x = c < EW_PF_C ? rdlane(xs_lane, c < EW_PF_C ? c : 0) : -1;
+                const int trow = x - off;
+                const bool lookup = c < ncand && trow >= 0 && trow < prm.table_rows && !(prm.syntax_shortcut && !(x >= prm.img_lo && x < prm.img_hi));
+                idq[u] = make_uint4(0u, 0u, 0u, 0u);
+                if (lookup && t0 < nz)
+                    idq[u] = *reinterpret_cast<const uint4 *>(buf.nn_table + (size_t)trow * prm.table_cols + t0);
+            }
+        } else if (can_prefetch) {
             unsigned long long td = todo0;
 #pragma unroll
             for (int c = 0; c < EW_PF_C; ++c) {
@@ -770,7 +803,24 @@ __global__ __launch_bounds__(NT) void epw_kernel(const EpwArgs args) {
             if (hot < 0 && rp_rid != rid) row_load<NT, E4>(logits + (size_t)rid * W, W, rp);
             rp_rid = -1;
             row_softmax_to_lds<NT, E4>(rp, hot, rows_probs, lo, W, prm.temperature, prm.top_k, V, g, out_tok, out_mass, S, ph, [&]() {
-                if (can_prefetch) {
+                if (can_prefetch && IDMODE == 2) {
+#pragma unroll
+                    for (int u = 0; u < PF16_PER; ++u) {
+                        const int ch = tid + u * NT;
+                        const int c = ch / CH_PER_C, t0 = (ch % CH_PER_C) * 8;
+                        if (c < ncand) {
+                            uint32_t w[4] = {idq[u].x, idq[u].y, idq[u].z, idq[u].w}, ad[4];
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                const uint32_t i0 = (t0 + 2 * q < nz) ? (w[q] & 0xffffu) : 0u, i1 = (t0 + 2 * q + 1 < nz) ? (w[q] >> 16) : 0u;
+                                w[q] = i0 | (i1 << 16);
+                                ad[q] = (uint32_t)gather_addr((int)i0, t0 + 2 * q) | ((uint32_t)gather_addr((int)i1, t0 + 2 * q + 1) << 16);
+                            }
+                            *reinterpret_cast<uint4 *>(&S.nbid[c][t0]) = make_uint4(w[0], w[1], w[2], w[3]);
+                            *reinterpret_cast<uint4 *>(&S.nbaddr[c][t0]) = make_uint4(ad[0], ad[1], ad[2], ad[3]);
+                        }
+                    }
+                } else if (can_prefetch) {
 #pragma unroll
                     for (int c = 0; c < EW_PF_C; ++c)
 #pragma unroll
@@ -1317,10 +1367,12 @@ extern "C" int lantern_evaluate_posterior_window(const lantern_ep_params *prm, c
     const int nz = (p.k + 1 < p.table_cols) ? p.k + 1 : p.table_cols;
     const bool lds_ids = !p.lantern || nz <= EW_PF_K;
     const EpwArgs args{p, *buf, *win};
+    const int idmode = !lds_ids ? 0 : ((p.lantern && p.table_cols % 8 == 0 && ((uintptr_t)buf->nn_table & 15) == 0) ? 2 : 1);
 #define EPW_LAUNCH(NT_, E4_)                                                                                              \
     do {                                                                                                                  \
-        if (lds_ids) hipLaunchKernelGGL((epw_kernel<NT_, E4_, true>), grid, dim3(NT_), lds, st, args);           \
-        else hipLaunchKernelGGL((epw_kernel<NT_, E4_, false>), grid, dim3(NT_), lds, st, args);                  \
+        if (idmode == 2) hipLaunchKernelGGL((epw_kernel<NT_, E4_, 2>), grid, dim3(NT_), lds, st, args);                   \
+        else if (idmode == 1) hipLaunchKernelGGL((epw_kernel<NT_, E4_, 1>), grid, dim3(NT_), lds, st, args);              \
+        else hipLaunchKernelGGL((epw_kernel<NT_, E4_, 0>), grid, dim3(NT_), lds, st, args);                               \
     } while (0)
     if (W <= 1024) EPW_LAUNCH(256, 1);
     else if (W <= 2048) EPW_LAUNCH(256, 2);

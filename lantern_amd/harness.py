@@ -65,6 +65,7 @@ class WorkloadConfig:
     path: str = "window"            # "window": v2 kernels (32 KB rows, LDS-resident residual); "dense": v1 kernels
     rows_probs: bool = True         # windowed path: O7 emits softmax probabilities for every row (1248 workgroups in parallel) so
                                     # O8's serial per-sequence chain only copies its visited rows into LDS
+    pack_table: bool = True         # windowed path: neighbour table packed to [K, ceil8(k+1)] (lantern_pack_vq_table)
     n_groups: int = 1               # >1: the sequences are split into groups, each launched on its own HIP stream, so that one
                                     # group's latency-bound evaluate_posterior overlaps the others' bandwidth-bound kernels
                                     # (independent sequences: no ordering between groups exists)
@@ -82,6 +83,10 @@ def build_neighbour_table(device, seed: int = 0) -> torch.Tensor:
 
 
 class LuminaVerifyWorkload:
+    @staticmethod
+    def windowed_cfg(cfg) -> bool:
+        return cfg.path == "window"
+
     def __init__(self, cfg: WorkloadConfig, device: torch.device, rank: int = 0):
         self.cfg, self.device, self.rank = cfg, device, rank
         B, S = cfg.n_seq, cfg.pool_steps
@@ -114,7 +119,13 @@ class LuminaVerifyWorkload:
         self.d_b_idx = t(tb["b_idx"] if len(tb["b_idx"]) else np.zeros(1, np.int32))
         self.d_op_off = t(op_off)
         self.d_pos_ids = t(pos + 1)                 # tree_position_ids + 1 (ea_model_lumina_mgpt.py:559,601)
-        self.table = build_neighbour_table(device, cfg.table_seed)
+        self.table_full = build_neighbour_table(device, cfg.table_seed)        # the reference's [K, K-1] layout
+        # hot-path layout: the first k+1 neighbours of every code in 16-byte aligned rows (16 MiB instead of 128 MiB)
+        self.table_cols = K_CODES - 1
+        self.table = self.table_full
+        if cfg.pack_table and self.windowed_cfg(cfg):
+            self.table_cols = min(K_CODES, -(-(cfg.lantern_k + 1) // 8) * 8)
+            self.table = ops.pack_vq_table(self.table_full, self.table_cols)
 
         # ---------------- pools (setup, untimed; torch is fine here)
         self.cond = torch.empty((S, B, N, V), dtype=torch.bfloat16, device=device)
@@ -252,7 +263,7 @@ class LuminaVerifyWorkload:
         for i, s in enumerate((8196, 8197, 8803, 8828)):
             p.syntax[i] = s
         p.lantern, p.k, p.delta = 1, c.lantern_k, c.lantern_delta
-        p.table_rows, p.table_cols = K_CODES, K_CODES - 1
+        p.table_rows, p.table_cols = K_CODES, self.table_cols
         p.top_k, p.temperature, p.top_p = 0, 1.0, 1.0       # Lumina filters in O7, not per level
         p.n_uniforms, p.R, p.N, p.row_index_per_seq = self.n_uniforms, self.R, self.N, 0
         return p

@@ -538,6 +538,17 @@ def drafter_fc(ids, hidden, embed, weight, bias=None, embed_scale: float = 1.0):
     return out
 
 
+def pack_vq_table(table, cols: int):
+    """[K, K-1] uint16 table (int16-viewed) -> [K, cols] with cols % 8 == 0: the first `cols` neighbours of every code in
+    16-byte aligned rows (the layout evaluate_posterior_window stages fastest); needs k <= cols - 1."""
+    table = table.contiguous()
+    assert table.dtype == torch.int16 and table.is_cuda and cols % 8 == 0
+    out = torch.empty((table.shape[0], cols), dtype=torch.int16, device=table.device)
+    check(_lib.lib().lantern_pack_vq_table(C.c_void_p(table.data_ptr()), table.shape[0], table.shape[1], C.c_void_p(out.data_ptr()), cols,
+                                           _stream()), "pack_vq_table")
+    return out
+
+
 def build_vq_table(codebook):
     """8f-1: codebook [K,C] f32 -> uint16 table [K,K-1] (as an int16-viewed tensor), generate_codebook.py:53-65."""
     cb = _dev(codebook, torch.float32, "codebook")

@@ -61,6 +61,14 @@ def test_window_static_golden(i):
                                          dev(case["cand"])[None], dev(case["uniforms"])[None], table=table_dev(m["K"]), aux=aux,
                                          orig_windowed=True, want_dense=True)
     assert torch.equal(out2["sample_p"], out["sample_p"]) and int(out2["best"][0]) == int(out["best"][0])
+    # packed neighbour table (16-byte aligned rows of ceil8(k+1) ids): same answer through the 16-byte staging path
+    if spec["lantern"] and spec["k"] + 1 <= 1016:
+        packed = ops.pack_vq_table(table_dev(m["K"]), -(-(spec["k"] + 1) // 8) * 8)
+        out3 = ops.evaluate_posterior_window(hip_cfg(spec), m["V"], dev(nl[:, lo:lo + W])[None], lo, dev(H.row_index_from_retrieve(tb["retrieve"], N)),
+                                             dev(case["cand"])[None], dev(case["uniforms"])[None], table=packed, aux=aux, orig_windowed=True,
+                                             want_dense=True)
+        for key in ("best", "accept_len", "counters", "sample_p"):
+            assert torch.equal(out3[key], out2[key]), key
 
 
 @pytest.mark.parametrize("i", [i for i, s in enumerate(SPECS) if s["kind"] == "dynamic" and _supported(s)])

@@ -122,6 +122,20 @@ __device__ __forceinline__ float wave_max(float v) {
     return readlane63(v);
 }
 
+// integer min / max over the wave (DPP), result in every lane
+__device__ __forceinline__ int wave_min_i(int v) {
+    const int lane = threadIdx.x & 63, rl = lane & 15;
+    int t;
+    t = dpp_mov<0x111>(v); if (rl >= 1) v = min(v, t);
+    t = dpp_mov<0x112>(v); if (rl >= 2) v = min(v, t);
+    t = dpp_mov<0x114>(v); if (rl >= 4) v = min(v, t);
+    t = dpp_mov<0x118>(v); if (rl >= 8) v = min(v, t);
+    t = dpp_mov<0x142, 0xa>(v); if ((lane & 31) >= 16) v = min(v, t);
+    t = dpp_mov<0x143, 0xc>(v); if (lane >= 32) v = min(v, t);
+    return readlane63(v);
+}
+__device__ __forceinline__ int wave_max_i(int v) { return -wave_min_i(-v); }
+
 // Block-wide reductions for blockDim.x = NW*64.  `sm` is a shared scratch of >= 2*NW
 // elements; consecutive calls alternate halves (`phase`) so one barrier per call suffices.
 template <typename T, int NW>

@@ -1161,19 +1161,23 @@ __global__ __launch_bounds__(NT) void epw_kernel(const EpwArgs args) {
             if (lane == 63) S.samp_tot[wave][it] = inc[it];
         }
         __syncthreads();
-        double total = out_before ? (double)out_mass : 0.0;   // mass in front of the window
+        // segment (it, wave) = ids [lo + 4*(it*NT + 64*wave), +256): token order is it-major.  One DPP scan over the
+        // E4*NW segment totals (lane q = it*NW + w) gives every segment's start; each thread then picks its E4 starts
+        // with uniform-lane reads.
+        static_assert(E4 * NW <= 64, "segment totals fit one wave");
+        const int q_it = lane / NW, q_w = lane % NW;
+        const double seg = (lane < E4 * NW) ? S.samp_tot[q_w][q_it < E4 ? q_it : 0] : 0.0;
+        const double seg_excl = wave_scan_incl_dpp(dpp_mov<0x138>(seg));      // exclusive: scan of the totals shifted up one lane
+        const double front = out_before ? (double)out_mass : 0.0;   // mass in front of the window
+        double total = front + (readlane63(seg_excl) + readlane63(seg));       // lanes >= E4*NW hold 0
         double excl[E4];
 #pragma unroll
         for (int it = 0; it < E4; ++it) {
-            double woff = 0.0, tt = 0.0;
-#pragma unroll
-            for (int w = 0; w < NW; ++w) {
-                const double t = S.samp_tot[w][it];
-                woff += (w < wave) ? t : 0.0;
-                tt += t;
-            }
-            excl[it] = total + woff + (inc[it] - s4[it]);
-            total += tt;
+            const int q = it * NW + wave;                       // wave-uniform
+            const long long bits = __double_as_longlong(seg_excl);
+            const double start = __longlong_as_double(((long long)__builtin_amdgcn_readlane((int)(bits >> 32), q) << 32) |
+                                                      (unsigned int)__builtin_amdgcn_readlane((int)(bits & 0xffffffffll), q));
+            excl[it] = front + start + (inc[it] - s4[it]);
         }
         if (out_tok >= 0 && !out_before) total += (double)out_mass;
         const double tgt = k_u_bonus[b] * total;
@@ -1200,24 +1204,18 @@ __global__ __launch_bounds__(NT) void epw_kernel(const EpwArgs args) {
             last_pos = max(last_pos, out_tok);
             if (total > tgt) found = min(found, out_tok);   // only wins when nothing inside the window crossed
         }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            found = min(found, __shfl_xor(found, o, 64));
-            last_pos = max(last_pos, __shfl_xor(last_pos, o, 64));
-        }
+        found = wave_min_i(found);
+        last_pos = wave_max_i(last_pos);
         __syncthreads();
         if (lane == 0) {
             S.redi[wave] = found;
             S.redi[16 + wave] = last_pos;
         }
         __syncthreads();
-        if (tid == 0) {
-            int f = S.redi[0], l = S.redi[16];
-            for (int w = 1; w < NW; ++w) {
-                f = min(f, S.redi[w]);
-                l = max(l, S.redi[16 + w]);
-            }
-            k_token[b] = f != 0x7fffffff ? f : l;
+        if (wave == 0) {
+            const int f = wave_min_i(lane < NW ? S.redi[lane] : 0x7fffffff);
+            const int l = wave_max_i(lane < NW ? S.redi[16 + lane] : -1);
+            if (lane == 0) k_token[b] = f != 0x7fffffff ? f : l;
         }
     }
     EPW_STAMP(50);

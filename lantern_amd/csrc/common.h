@@ -34,13 +34,8 @@ constexpr int kWave = 64;
 
 __device__ __forceinline__ float bf16_bits_to_f32(uint16_t h) { return __uint_as_float((uint32_t)h << 16); }
 
-// round-to-nearest-even f32 -> bf16 -> f32 (torch's per-op bf16 rounding)
-__device__ __forceinline__ float round_bf16(float f) {
-    uint32_t u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return __uint_as_float(0x7fc00000u);
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return __uint_as_float(u & 0xffff0000u);
-}
+// round-to-nearest-even f32 -> bf16 -> f32 (torch's per-op bf16 rounding): v_cvt_pk_bf16_f32 + a shift on gfx950
+__device__ __forceinline__ float round_bf16(float f) { return (float)(__bf16)f; }
 
 // order-preserving float -> uint key (ascending)
 __device__ __forceinline__ uint32_t float_key(float f) {

@@ -384,6 +384,7 @@ __global__ __launch_bounds__(NT) void cfg_window_bf16_kernel(const uint16_t *__r
     const bool lumina = model == LANTERN_MODEL_LUMINA;
     const bool masked = model != LANTERN_MODEL_PLAIN;
     const float fill = lumina ? NEG_INF : __uint_as_float(0xff7f0000u);
+    const bool need_mask = masked && (win_lo < img_lo || win_lo + W > img_hi);     // window inside the image range: nothing to mask
     const int e_base = win_lo;                            // first id of chunk 0
     const uint16_t *crow = cond + (size_t)row * V + e_base;
     const uint16_t *urow = uncond ? uncond + (size_t)row * V + e_base : nullptr;
@@ -400,6 +401,7 @@ __global__ __launch_bounds__(NT) void cfg_window_bf16_kernel(const uint16_t *__r
 #pragma unroll
     for (int it = 0; it < E8; ++it) {
         const int e0 = e_base + (tid + it * NT) * 8;
+        const bool in_chunk = (tid + it * NT) * 8 < W;
         const uint32_t cw[4] = {cb[it].a.x, cb[it].a.y, cb[it].b.x, cb[it].b.y};
         const uint32_t uw[4] = {ub[it].a.x, ub[it].a.y, ub[it].b.x, ub[it].b.y};
         float o[8];
@@ -410,8 +412,8 @@ __global__ __launch_bounds__(NT) void cfg_window_bf16_kernel(const uint16_t *__r
             float t = c;
             if (uncond) t = round_bf16(u + round_bf16(cfg * round_bf16(c - u)));
             const int e = e0 + q;
-            const bool inwin = e >= win_lo && e < win_lo + W;
-            o[q] = !inwin ? NEG_INF : ((masked && (e < img_lo || e >= img_hi)) ? fill : t);
+            if (need_mask) t = (e < img_lo || e >= img_hi) ? fill : t;
+            o[q] = in_chunk ? t : NEG_INF;      // chunks are whole: W % 8 == 0
         }
         r[2 * it] = make_float4(o[0], o[1], o[2], o[3]);
         r[2 * it + 1] = make_float4(o[4], o[5], o[6], o[7]);

@@ -8,7 +8,8 @@ namespace lantern {
 
 // ------------------------------------------------------------------------- O6
 // models/ea_model_lumina_mgpt.py:525-554; models/ea_model_llamagen.py:676-706
-__global__ void gather_candidates_kernel(const int64_t *__restrict__ ss_token, const float *__restrict__ ss_prob,
+constexpr int GC_MAX_N = 256, GC_PER = 2;
+__global__ __launch_bounds__(256) void gather_candidates_kernel(const int64_t *__restrict__ ss_token, const float *__restrict__ ss_prob,
                                          const int64_t *__restrict__ sample_token, const int64_t *__restrict__ tree_indices,
                                          const int64_t *__restrict__ retrieve, int n_flat, int N, int PD,
                                          int64_t *__restrict__ tree_cand, int64_t *__restrict__ cand,
@@ -16,12 +17,41 @@ __global__ void gather_candidates_kernel(const int64_t *__restrict__ ss_token, c
     const int b = blockIdx.x;
     const int64_t *tok = ss_token + (size_t)b * n_flat;
     const float *prb = ss_prob ? ss_prob + (size_t)b * n_flat : nullptr;
+    // tree_indices and retrieve are tiny and shared by every sequence: one round of loads into LDS, so the chain is
+    // (tables, sample token) -> token/prob gather instead of retrieve -> tree_indices -> token
+    __shared__ int s_ti[GC_MAX_N];
+    const bool staged = N <= GC_MAX_N;
+    if (staged)
+        for (int n = threadIdx.x; n < N; n += blockDim.x) s_ti[n] = (int)tree_indices[n];
     const int64_t st = sample_token[b];
+    int64_t rr[GC_PER];
+#pragma unroll
+    for (int u = 0; u < GC_PER; ++u) {
+        const int i = threadIdx.x + u * 256;
+        rr[u] = i < PD ? retrieve[i] : -1;
+    }
+    __syncthreads();
     for (int n = threadIdx.x; n < N; n += blockDim.x) {
-        const int64_t ti = tree_indices[n];
+        const int64_t ti = staged ? (int64_t)s_ti[n] : tree_indices[n];
         tree_cand[(size_t)b * N + n] = ti == 0 ? st : tok[ti - 1];
     }
-    for (int i = threadIdx.x; i < PD; i += blockDim.x) {
+#pragma unroll
+    for (int u = 0; u < GC_PER; ++u) {
+        const int i = threadIdx.x + u * 256;
+        if (i < PD) {
+            const int64_t r = rr[u];
+            int64_t c = -1;
+            float p = 1.0f;
+            if (r >= 0) {
+                const int64_t ti = staged ? (int64_t)s_ti[r] : tree_indices[r];
+                c = ti == 0 ? st : tok[ti - 1];
+                if (prb) p = ti == 0 ? 1.0f : prb[ti - 1];
+            }
+            cand[(size_t)b * PD + i] = c;
+            if (cart_prob) cart_prob[(size_t)b * PD + i] = p;
+        }
+    }
+    for (int i = threadIdx.x + GC_PER * 256; i < PD; i += blockDim.x) {      // P*D beyond GC_PER*256 (not met by the reference's trees)
         const int64_t r = retrieve[i];
         int64_t c = -1;
         float p = 1.0f;
@@ -86,6 +116,32 @@ __global__ __launch_bounds__(256) void kv_gather_kernel(void *const *__restrict_
 
 // ------------------------------------------------------------------------ O10
 // models/ea_model_lumina_mgpt.py:748-750,773-785.
+// Copy-only form (no bonus-token draw: the windowed evaluate_posterior draws it): one workgroup per (sequence, cond/uncond,
+// depth) row so the 2*D rows of every sequence move in parallel across the chip instead of through one CU.
+__global__ __launch_bounds__(256) void accept_copy_kernel(const uint4 *__restrict__ hidden, int G, int N, int cpr,
+                                                          const int64_t *__restrict__ retrieve, int retrieve_per_seq, int P, int D,
+                                                          const int64_t *__restrict__ cand, const int32_t *__restrict__ best,
+                                                          const int32_t *__restrict__ accept_len, uint4 *__restrict__ out_hidden,
+                                                          int64_t *__restrict__ accepted_tokens) {
+    const int b = blockIdx.y, gi = blockIdx.x / D, t = blockIdx.x % D, tid = threadIdx.x;
+    const int bst = best[b];
+    int n_sel = accept_len[b] + 1;
+    if (n_sel > D) n_sel = D;
+    if (blockIdx.x == 0 && accepted_tokens && cand && tid < D)
+        accepted_tokens[(size_t)b * D + tid] = tid < n_sel ? cand[(size_t)b * P * D + (size_t)bst * D + tid] : -1;
+    if (!hidden || !out_hidden) return;
+    uint4 *dst = out_hidden + (((size_t)b * G + gi) * D + t) * cpr;
+    if (t < n_sel) {
+        int64_t r = retrieve[(retrieve_per_seq ? (size_t)b * P * D : 0) + (size_t)bst * D + t];
+        if (r < 0) r += N;
+        r = r < 0 ? 0 : (r >= N ? N - 1 : r);
+        const uint4 *src = hidden + (((size_t)b * G + gi) * N + r) * cpr;
+        for (int c = tid; c < cpr; c += 256) dst[c] = src[c];
+    } else {
+        for (int c = tid; c < cpr; c += 256) dst[c] = make_uint4(0, 0, 0, 0);
+    }
+}
+
 constexpr int AG_THREADS = 1024;
 constexpr int AG_NW = AG_THREADS / 64;
 
@@ -279,6 +335,14 @@ extern "C" int lantern_accept_gather(const void *hidden, int elem_bytes, int B, 
                                   "accept_gather: hidden row bytes must be a multiple of 16");
     if (sample_p) LANTERN_CHECK_ARG(token && V > 0, "accept_gather: sampling needs token and V");
     if (B == 0) return LANTERN_OK;
+    if (!sample_p || !token) {     // copy only
+        const int g = hidden ? G : 1;
+        hipLaunchKernelGGL(accept_copy_kernel, dim3(g * D, B), dim3(256), 0, (hipStream_t)stream, (const uint4 *)hidden, g, N,
+                           hidden ? H * elem_bytes / 16 : 0, retrieve, retrieve_per_seq, P, D, cand, best, accept_len, (uint4 *)out_hidden,
+                           accepted_tokens);
+        LANTERN_CHECK_LAUNCH("accept_gather");
+        return LANTERN_OK;
+    }
     hipLaunchKernelGGL(accept_gather_kernel, dim3(B), dim3(AG_THREADS), 0, (hipStream_t)stream, hidden, elem_bytes, G, N, H,
                        retrieve, retrieve_per_seq, P, D, cand, best, accept_len, sample_p, V, u, out_hidden, accepted_tokens, token);
     LANTERN_CHECK_LAUNCH("accept_gather");

@@ -464,7 +464,9 @@ class LuminaVerifyWorkload:
                                       A["st_alen"], A["sample_p"], V, None if self.windowed else A["u_cur"], A["out_hidden"],
                                       A["acc_tokens"], None if self.windowed else A["st_token"], st), "accept_gather")
         # harness bookkeeping (sequence management, not the hot path): logs, next sample token, image wrap-around, step counter
-        check(L.lantern_harness_advance(B, 2 * B, c.n_seq, C.c_int64(TOKENS_PER_IMAGE), C.c_int64(c.max_steps), A["step_dev"], A["st_best"],
+        check(L.lantern_harness_advance(B, 2 * B, c.n_seq, C.c_int64(TOKENS_PER_IMAGE), C.c_int64(c.max_steps),
+                                        C.c_int64(-1 if torch.cuda.is_current_stream_capturing() or self.graphs is not None else self.step_idx),
+                                        A["step_dev"], A["st_best"],
                                         A["st_alen"], A["st_cnt"], A["st_token"], A["log_best"], A["log_alen"], A["log_cnt"], A["log_token"],
                                         A["sample_token"], A["nxt"], A["len_base"], A["u_bonus_g"], A["u_cur"], st), "harness_advance")
 

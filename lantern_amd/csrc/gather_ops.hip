@@ -3,6 +3,7 @@
 // All are index/byte movers: coalesced 16-byte accesses, indices read from device memory
 // (the outputs of evaluate_posterior) so the step never round-trips to the host.
 #include "common.h"
+#include <cstdlib>
 
 namespace lantern {
 
@@ -73,6 +74,10 @@ __global__ __launch_bounds__(256) void gather_candidates_kernel(const int64_t *_
 constexpr int KV_MAXSEL = 16;
 typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
 
+// MAXSEL = rows a step can accept (D); U = row groups a thread moves per trip, all loads of the U groups in flight
+// before the first store (few, fat workgroups: a thread that moves one 16-byte chunk of ~1.3 rows has too little in
+// flight to cover HBM latency, and 12k tiny workgroups per launch are dispatch-bound).
+template <int MAXSEL, int U>
 __global__ __launch_bounds__(256) void kv_gather_kernel(void *const *__restrict__ slab_ptrs, const int32_t *__restrict__ slab_seq,
                                                         const int64_t *__restrict__ slab_prev, int64_t outer, int64_t S_max,
                                                         int chunks_per_row, const int64_t *__restrict__ retrieve,
@@ -84,33 +89,53 @@ __global__ __launch_bounds__(256) void kv_gather_kernel(void *const *__restrict_
     const int bst = best[seq];
     int n_sel = accept_len[seq] + 1;
     if (n_sel > D) n_sel = D;
-    if (n_sel > KV_MAXSEL) n_sel = KV_MAXSEL;
+    if (n_sel > MAXSEL) n_sel = MAXSEL;
     const int64_t *rrow = retrieve + (retrieve_per_seq ? (size_t)seq * P * D : 0) + (size_t)bst * D;
     if (blockIdx.x == 0 && threadIdx.x == 0 && new_len) new_len[s] = prev + n_sel;
 
     // rows already in place (tree node t sits at position prev + t: always the root, and every accepted first child) are
     // not touched -- copying a row onto itself is the identity, so the result equals the reference's index_select + copy_
     unsigned move = 0u;
-    for (int t = 0; t < n_sel; ++t)
-        if (rrow[t] != t && prev + t < S_max) move |= 1u << t;
+    int64_t srcrow[MAXSEL];
+#pragma unroll
+    for (int t = 0; t < MAXSEL; ++t) {
+        srcrow[t] = 0;
+        if (t < n_sel) {
+            const int64_t r = rrow[t];
+            if (r != t && prev + t < S_max) move |= 1u << t;
+            const int64_t src = r + prev;
+            srcrow[t] = src < 0 ? 0 : (src >= S_max ? S_max - 1 : src);
+        }
+    }
     if (move == 0u) return;
-    u32x4_t *base = reinterpret_cast<u32x4_t *>(slab_ptrs[s]);
-    const int64_t total = outer * chunks_per_row;
-    for (int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; w < total; w += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t o = w / chunks_per_row;
-        const int c = (int)(w - o * chunks_per_row);
-        u32x4_t *rowbase = base + o * S_max * chunks_per_row + c;
-        u32x4_t v[KV_MAXSEL];
+    // the slab address comes out of a pointer table: tell the compiler it is global memory (global_load/store, not flat)
+    typedef __attribute__((address_space(1))) u32x4_t gvec_t;
+    gvec_t *base = (gvec_t *)(uintptr_t)slab_ptrs[s];
+    const unsigned total = (unsigned)(outer * chunks_per_row), cpr = (unsigned)chunks_per_row;
+    const unsigned stride = gridDim.x * blockDim.x;
+    for (unsigned w0 = blockIdx.x * blockDim.x + threadIdx.x; w0 < total; w0 += U * stride) {
+        u32x4_t v[U][MAXSEL];
+        gvec_t *rowbase[U];
 #pragma unroll
-        for (int t = 0; t < KV_MAXSEL; ++t)
-            if ((move >> t) & 1u) {
-                int64_t src = rrow[t] + prev;
-                src = src < 0 ? 0 : (src >= S_max ? S_max - 1 : src);
-                v[t] = __builtin_nontemporal_load(&rowbase[src * chunks_per_row]);
+        for (int u = 0; u < U; ++u) {
+            const unsigned w = w0 + u * stride;
+            const unsigned o = w / cpr, c = w - o * cpr;
+            rowbase[u] = base + (size_t)o * S_max * cpr + c;
+            if (w < total) {
+#pragma unroll
+                for (int t = 0; t < MAXSEL; ++t)
+                    if ((move >> t) & 1u) v[u][t] = __builtin_nontemporal_load(&rowbase[u][srcrow[t] * cpr]);
             }
+        }
 #pragma unroll
-        for (int t = 0; t < KV_MAXSEL; ++t)
-            if ((move >> t) & 1u) __builtin_nontemporal_store(v[t], &rowbase[(prev + t) * chunks_per_row]);
+        for (int u = 0; u < U; ++u) {
+            const unsigned w = w0 + u * stride;
+            if (w < total) {
+#pragma unroll
+                for (int t = 0; t < MAXSEL; ++t)
+                    if ((move >> t) & 1u) __builtin_nontemporal_store(v[u][t], &rowbase[u][(prev + t) * cpr]);
+            }
+        }
     }
 }
 
@@ -317,10 +342,24 @@ extern "C" int lantern_kv_gather(void *const *slab_ptrs, const int32_t *slab_seq
     if (n_slabs == 0) return LANTERN_OK;
     const int cpr = (int)(d * elem_bytes / 16);
     const int64_t total = outer * cpr;
-    int gx = (int)((total + 255) / 256);
+    LANTERN_CHECK_ARG(total < (1ll << 31), "kv_gather: outer * row chunks = %lld does not fit 31 bits", (long long)total);
+    static const int u_knob = getenv("LANTERN_KV_U") ? atoi(getenv("LANTERN_KV_U")) : 0;   // tuning knob (diagnostic)
+    const int U = u_knob ? u_knob : 2;
+    int gx = (int)((total + 256 * U - 1) / (256 * U));
     if (gx > 4096) gx = 4096;
-    hipLaunchKernelGGL(kv_gather_kernel, dim3(gx, n_slabs), dim3(256), 0, (hipStream_t)stream, slab_ptrs, slab_seq, slab_prev,
-                       outer, S_max, cpr, retrieve, retrieve_per_seq, P, D, best, accept_len, new_len);
+#define KV_LAUNCH(MS_, U_)                                                                                                               \
+    hipLaunchKernelGGL((kv_gather_kernel<MS_, U_>), dim3(gx, n_slabs), dim3(256), 0, (hipStream_t)stream, slab_ptrs, slab_seq, slab_prev, \
+                       outer, S_max, cpr, retrieve, retrieve_per_seq, P, D, best, accept_len, new_len)
+    if (D <= 8) {
+        if (U == 1) KV_LAUNCH(8, 1);
+        else if (U == 4) KV_LAUNCH(8, 4);
+        else KV_LAUNCH(8, 2);
+    } else {
+        gx = (int)((total + 255) / 256);
+        if (gx > 4096) gx = 4096;
+        KV_LAUNCH(16, 1);
+    }
+#undef KV_LAUNCH
     LANTERN_CHECK_LAUNCH("kv_gather");
     return LANTERN_OK;
 }

@@ -49,6 +49,7 @@ def parse():
     ap.add_argument("--kv-smax", type=int, default=4096)
     ap.add_argument("--no-events", action="store_true", help="skip the eager per-kernel timing pass")
     ap.add_argument("--graph", action="store_true", help="replay one captured hipGraph per (pool slot, group) instead of launching eagerly")
+    ap.add_argument("--side-stream", action="store_true", help="launch O6 beside O7 and O10 beside O9 on a second HIP stream (measured slower: event waits)")
     ap.add_argument("--groups", type=int, default=1, help="split the GPU's sequences into this many groups, each on its own HIP stream (independent sequences: one group's latency-bound evaluate_posterior overlaps the others' bandwidth-bound kernels)")
     ap.add_argument("--ep-sweep", type=str, default="",
                     help="e.g. 256,2048: batch sizes for the evaluate_posterior-only roofline sweep (BASELINE.md section 2); off by default so that the default command launches every kernel on one homogeneous workload (rocprofv3 averages then agree with the HIP-event averages)")
@@ -231,7 +232,7 @@ def main():
 
     cfg = HN.WorkloadConfig(n_seq=args.seqs_per_gpu, pool_steps=args.pool_steps, lantern_k=args.lantern_k,
                             lantern_delta=args.lantern_delta, sigma=args.sigma, with_kv=not args.no_kv, kv_smax=args.kv_smax,
-                            path=args.path, use_graph=args.graph, n_groups=args.groups,
+                            path=args.path, use_graph=args.graph, n_groups=args.groups, side_stream=args.side_stream,
                             max_steps=args.steps + args.warmup + min(args.steps, 100) + 8)
     wl = HN.LuminaVerifyWorkload(cfg, device, rank=rank)
 
@@ -282,7 +283,7 @@ def main():
                        "lantern_k": cfg.lantern_k, "lantern_delta": cfg.lantern_delta, "seqs_per_gpu": cfg.n_seq,
                        "total_sequences": cfg.n_seq * world, "pool_steps": cfg.pool_steps, "drafter_sigma": cfg.sigma,
                        "kv_cache": cfg.with_kv, "kernel_path": cfg.path, "launch": "hipGraph replay" if (cfg.use_graph and wl.graphs) else "eager",
-                       "stream_groups": cfg.n_groups, "sequences_per_launch": wl.Bg, "parallelism": f"dp{world} (independent sequences, no collective)"},
+                       "stream_groups": cfg.n_groups, "side_stream_for_O6_O10": cfg.side_stream, "sequences_per_launch": wl.Bg, "parallelism": f"dp{world} (independent sequences, no collective)"},
             "mean_accept_length": float(alen.mean()),
             "per_step": {"levels": float(cnt[..., 0].mean()), "tried": float(cnt[..., 1].mean()), "rejected": float(cnt[..., 2].mean())},
         }

@@ -65,6 +65,10 @@ class WorkloadConfig:
     path: str = "window"            # "window": v2 kernels (32 KB rows, LDS-resident residual); "dense": v1 kernels
     rows_probs: bool = True         # windowed path: O7 emits softmax probabilities for every row (1248 workgroups in parallel) so
                                     # O8's serial per-sequence chain only copies its visited rows into LDS
+    side_stream: bool = False       # O6 runs beside O7 and O10 beside O9 on a second HIP stream (they are independent: O6 needs only
+                                    # the sample token, O10 only evaluate_posterior's result); fork/join with events, capturable.
+                                    # Measured SLOWER on MI355X (116 vs 103 us/step): the cross-stream event waits cost more than the
+                                    # two small kernels they hide; kept as an option
     pack_table: bool = True         # windowed path: neighbour table packed to [K, ceil8(k+1)] (lantern_pack_vq_table)
     n_groups: int = 1               # >1: the sequences are split into groups, each launched on its own HIP stream, so that one
                                     # group's latency-bound evaluate_posterior overlaps the others' bandwidth-bound kernels
@@ -217,6 +221,8 @@ class LuminaVerifyWorkload:
         self.u_cur = torch.zeros(B, dtype=torch.float64, device=device)
         self.step_dev = torch.zeros(cfg.n_groups, dtype=torch.int64, device=device)    # one device step counter per group
         self.streams = [torch.cuda.Stream(device=device) for _ in range(cfg.n_groups)] if cfg.n_groups > 1 else [None]
+        self.side = [torch.cuda.Stream(device=device) for _ in range(cfg.n_groups)] if cfg.side_stream else None
+        self._ev = [[torch.cuda.Event() for _ in range(4)] for _ in range(cfg.n_groups)]
         self._L = _lib.lib()
         self._ep_prm = self._make_ep_params()
         self.graphs = None
@@ -419,10 +425,20 @@ class LuminaVerifyWorkload:
         A = self._group_args(slot, parity, g)
         vp = C.c_void_p
 
-        # O6 candidate assembly
+        main = torch.cuda.current_stream()
+        side = self.side[g] if (self.side is not None and not events) else None
+        ev = self._ev[g]
+        st_side = st
+        if side is not None:                      # fork
+            ev[0].record(main)
+            side.wait_event(ev[0])
+            st_side = C.c_void_p(side.cuda_stream)
+        # O6 candidate assembly (side stream: only needs the sample token)
         check(L.lantern_gather_candidates(A["ss_token"], A["ss_prob"], A["sample_token"], vp(self.d_tree_indices.data_ptr()),
-                                          vp(self.d_retrieve.data_ptr()), B, self.R * 10, N, P, D, A["tree_cand"], A["cand"], A["cart_prob"], st),
-              "gather_candidates")
+                                          vp(self.d_retrieve.data_ptr()), B, self.R * 10, N, P, D, A["tree_cand"], A["cand"], A["cart_prob"],
+                                          st_side), "gather_candidates")
+        if side is not None:
+            ev[1].record(side)
         # O7 CFG + Lumina position mask + top-k, positions from the device-side lengths
         if events:
             events["cfg_mask_topk"][0].record()
@@ -439,6 +455,8 @@ class LuminaVerifyWorkload:
         if events:
             events["cfg_mask_topk"][1].record()
             events["evaluate_posterior"][0].record()
+        if side is not None:
+            main.wait_event(ev[1])                # O8 needs the candidates
         # O8 (windowed: the bonus token is drawn in the kernel epilogue)
         if self.windowed:
             check(L.lantern_evaluate_posterior_window(C.byref(self._ep_prm), C.byref(A["ep_buf"]), C.byref(A["ep_win"]), st),
@@ -447,6 +465,15 @@ class LuminaVerifyWorkload:
             check(L.lantern_evaluate_posterior(C.byref(self._ep_prm), C.byref(A["ep_buf"]), st), "evaluate_posterior")
         if events:
             events["evaluate_posterior"][1].record()
+        if side is not None:
+            ev[2].record(main)
+            side.wait_event(ev[2])
+        # O10 accepted hidden + token append (+ bonus token on the dense path); side stream: beside the KV gather
+        check(L.lantern_accept_gather(A["hidden"], 2, B, 2, N, HIDDEN, vp(self.d_retrieve.data_ptr()), 0, P, D, A["cand"], A["st_best"],
+                                      A["st_alen"], A["sample_p"], V, None if self.windowed else A["u_cur"], A["out_hidden"],
+                                      A["acc_tokens"], None if self.windowed else A["st_token"], st_side), "accept_gather")
+        if side is not None:
+            ev[3].record(side)
         # O9 KV gather: both slabs of every sequence of the group in one launch
         if c.with_kv:
             if events:
@@ -459,10 +486,8 @@ class LuminaVerifyWorkload:
         else:
             s0 = g * self.Bg
             torch.add(self.lens[parity][2 * s0:2 * s0 + 2 * B], (self.st_alen[s0:s0 + B] + 1).repeat(2), out=self.lens[parity ^ 1][2 * s0:2 * s0 + 2 * B])
-        # O10 accepted hidden + token append (+ bonus token on the dense path)
-        check(L.lantern_accept_gather(A["hidden"], 2, B, 2, N, HIDDEN, vp(self.d_retrieve.data_ptr()), 0, P, D, A["cand"], A["st_best"],
-                                      A["st_alen"], A["sample_p"], V, None if self.windowed else A["u_cur"], A["out_hidden"],
-                                      A["acc_tokens"], None if self.windowed else A["st_token"], st), "accept_gather")
+        if side is not None:
+            main.wait_event(ev[3])                # join (the dense path's bonus token feeds the bookkeeping below)
         # harness bookkeeping (sequence management, not the hot path): logs, next sample token, image wrap-around, step counter
         check(L.lantern_harness_advance(B, 2 * B, c.n_seq, C.c_int64(TOKENS_PER_IMAGE), C.c_int64(c.max_steps),
                                         C.c_int64(-1 if torch.cuda.is_current_stream_capturing() or self.graphs is not None else self.step_idx),

@@ -304,6 +304,18 @@ int lantern_accept_gather(const void *hidden, int elem_bytes, int B, int G, int 
 int lantern_sample_static(const float *probs, const int64_t *idx, int R, int V, int k, float *out_prob,
                           void *stream);
 
+/* O9 + O10 in ONE launch -- the reference does both in update_inference_inputs
+ * (models/ea_model_lumina_mgpt.py:731-799): KV rows of every slab move to their final positions and the
+ * accepted hidden rows / tokens are gathered, from the same (best, accept_len).  Arguments as in
+ * lantern_kv_gather followed by those of lantern_accept_gather (copy form: no bonus-token draw -- the
+ * windowed evaluate_posterior draws it; D <= 8). */
+int lantern_update_inference_inputs(void *const *slab_ptrs, const int32_t *slab_seq, const int64_t *slab_prev,
+                                    int n_slabs, int elem_bytes, int64_t outer, int64_t S_max, int64_t d,
+                                    const int64_t *retrieve, int retrieve_per_seq, int P, int D,
+                                    const int32_t *best, const int32_t *accept_len, int64_t *new_len,
+                                    const void *hidden, int hid_elem_bytes, int B, int G, int N, int H,
+                                    const int64_t *cand, void *out_hidden, int64_t *accepted_tokens, void *stream);
+
 /* O11 drafter input contraction on MFMA: out = fc(cat(embed[ids]*scale, hidden)) (+bias).
  * Replaces Model.forward's input stage: models/drafters/cnets_lumina_mgpt.py:1071,1095-1098;
  * cnets_llamagen.py:642,679-680.  bf16 operands, f32 accumulate, bf16 output.

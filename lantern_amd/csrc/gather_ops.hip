@@ -78,12 +78,11 @@ typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
 // before the first store (few, fat workgroups: a thread that moves one 16-byte chunk of ~1.3 rows has too little in
 // flight to cover HBM latency, and 12k tiny workgroups per launch are dispatch-bound).
 template <int MAXSEL, int U>
-__global__ __launch_bounds__(256) void kv_gather_kernel(void *const *__restrict__ slab_ptrs, const int32_t *__restrict__ slab_seq,
+__device__ __forceinline__ void kv_gather_body(int bx, int nbx, int s, void *const *__restrict__ slab_ptrs, const int32_t *__restrict__ slab_seq,
                                                         const int64_t *__restrict__ slab_prev, int64_t outer, int64_t S_max,
                                                         int chunks_per_row, const int64_t *__restrict__ retrieve,
                                                         int retrieve_per_seq, int P, int D, const int32_t *__restrict__ best,
                                                         const int32_t *__restrict__ accept_len, int64_t *__restrict__ new_len) {
-    const int s = blockIdx.y;
     const int seq = slab_seq[s];
     const int64_t prev = slab_prev[s];
     const int bst = best[seq];
@@ -91,7 +90,7 @@ __global__ __launch_bounds__(256) void kv_gather_kernel(void *const *__restrict_
     if (n_sel > D) n_sel = D;
     if (n_sel > MAXSEL) n_sel = MAXSEL;
     const int64_t *rrow = retrieve + (retrieve_per_seq ? (size_t)seq * P * D : 0) + (size_t)bst * D;
-    if (blockIdx.x == 0 && threadIdx.x == 0 && new_len) new_len[s] = prev + n_sel;
+    if (bx == 0 && threadIdx.x == 0 && new_len) new_len[s] = prev + n_sel;
 
     // rows already in place (tree node t sits at position prev + t: always the root, and every accepted first child) are
     // not touched -- copying a row onto itself is the identity, so the result equals the reference's index_select + copy_
@@ -112,8 +111,8 @@ __global__ __launch_bounds__(256) void kv_gather_kernel(void *const *__restrict_
     typedef __attribute__((address_space(1))) u32x4_t gvec_t;
     gvec_t *base = (gvec_t *)(uintptr_t)slab_ptrs[s];
     const unsigned total = (unsigned)(outer * chunks_per_row), cpr = (unsigned)chunks_per_row;
-    const unsigned stride = gridDim.x * blockDim.x;
-    for (unsigned w0 = blockIdx.x * blockDim.x + threadIdx.x; w0 < total; w0 += U * stride) {
+    const unsigned stride = (unsigned)nbx * blockDim.x;
+    for (unsigned w0 = (unsigned)bx * blockDim.x + threadIdx.x; w0 < total; w0 += U * stride) {
         u32x4_t v[U][MAXSEL];
         gvec_t *rowbase[U];
 #pragma unroll
@@ -139,20 +138,30 @@ __global__ __launch_bounds__(256) void kv_gather_kernel(void *const *__restrict_
     }
 }
 
+template <int MAXSEL, int U>
+__global__ __launch_bounds__(256) void kv_gather_kernel(void *const *__restrict__ slab_ptrs, const int32_t *__restrict__ slab_seq,
+                                                        const int64_t *__restrict__ slab_prev, int64_t outer, int64_t S_max,
+                                                        int chunks_per_row, const int64_t *__restrict__ retrieve,
+                                                        int retrieve_per_seq, int P, int D, const int32_t *__restrict__ best,
+                                                        const int32_t *__restrict__ accept_len, int64_t *__restrict__ new_len) {
+    kv_gather_body<MAXSEL, U>(blockIdx.x, gridDim.x, blockIdx.y, slab_ptrs, slab_seq, slab_prev, outer, S_max, chunks_per_row, retrieve,
+                              retrieve_per_seq, P, D, best, accept_len, new_len);
+}
+
 // ------------------------------------------------------------------------ O10
 // models/ea_model_lumina_mgpt.py:748-750,773-785.
 // Copy-only form (no bonus-token draw: the windowed evaluate_posterior draws it): one workgroup per (sequence, cond/uncond,
 // depth) row so the 2*D rows of every sequence move in parallel across the chip instead of through one CU.
-__global__ __launch_bounds__(256) void accept_copy_kernel(const uint4 *__restrict__ hidden, int G, int N, int cpr,
+__device__ __forceinline__ void accept_copy_body(int bx, int b, const uint4 *__restrict__ hidden, int G, int N, int cpr,
                                                           const int64_t *__restrict__ retrieve, int retrieve_per_seq, int P, int D,
                                                           const int64_t *__restrict__ cand, const int32_t *__restrict__ best,
                                                           const int32_t *__restrict__ accept_len, uint4 *__restrict__ out_hidden,
                                                           int64_t *__restrict__ accepted_tokens) {
-    const int b = blockIdx.y, gi = blockIdx.x / D, t = blockIdx.x % D, tid = threadIdx.x;
+    const int gi = bx / D, t = bx % D, tid = threadIdx.x;
     const int bst = best[b];
     int n_sel = accept_len[b] + 1;
     if (n_sel > D) n_sel = D;
-    if (blockIdx.x == 0 && accepted_tokens && cand && tid < D)
+    if (bx == 0 && accepted_tokens && cand && tid < D)
         accepted_tokens[(size_t)b * D + tid] = tid < n_sel ? cand[(size_t)b * P * D + (size_t)bst * D + tid] : -1;
     if (!hidden || !out_hidden) return;
     uint4 *dst = out_hidden + (((size_t)b * G + gi) * D + t) * cpr;
@@ -164,6 +173,38 @@ __global__ __launch_bounds__(256) void accept_copy_kernel(const uint4 *__restric
         for (int c = tid; c < cpr; c += 256) dst[c] = src[c];
     } else {
         for (int c = tid; c < cpr; c += 256) dst[c] = make_uint4(0, 0, 0, 0);
+    }
+}
+
+__global__ __launch_bounds__(256) void accept_copy_kernel(const uint4 *__restrict__ hidden, int G, int N, int cpr,
+                                                          const int64_t *__restrict__ retrieve, int retrieve_per_seq, int P, int D,
+                                                          const int64_t *__restrict__ cand, const int32_t *__restrict__ best,
+                                                          const int32_t *__restrict__ accept_len, uint4 *__restrict__ out_hidden,
+                                                          int64_t *__restrict__ accepted_tokens) {
+    accept_copy_body(blockIdx.x, blockIdx.y, hidden, G, N, cpr, retrieve, retrieve_per_seq, P, D, cand, best, accept_len, out_hidden,
+                     accepted_tokens);
+}
+
+// O9 + O10 in one launch (the two halves of the reference's update_inference_inputs): grid.y < n_slabs moves KV rows,
+// the rows above it carry the accepted-hidden copy, one (sequence, cond/uncond, depth) row per workgroup.
+template <int MAXSEL, int U>
+__global__ __launch_bounds__(256) void update_inputs_kernel(void *const *__restrict__ slab_ptrs, const int32_t *__restrict__ slab_seq,
+                                                            const int64_t *__restrict__ slab_prev, int n_slabs, int64_t outer,
+                                                            int64_t S_max, int chunks_per_row, const int64_t *__restrict__ retrieve,
+                                                            int retrieve_per_seq, int P, int D, const int32_t *__restrict__ best,
+                                                            const int32_t *__restrict__ accept_len, int64_t *__restrict__ new_len,
+                                                            const uint4 *__restrict__ hidden, int B, int G, int N, int hid_cpr,
+                                                            const int64_t *__restrict__ cand, uint4 *__restrict__ out_hidden,
+                                                            int64_t *__restrict__ accepted_tokens) {
+    if ((int)blockIdx.y < n_slabs) {
+        kv_gather_body<MAXSEL, U>(blockIdx.x, gridDim.x, blockIdx.y, slab_ptrs, slab_seq, slab_prev, outer, S_max, chunks_per_row, retrieve,
+                                  retrieve_per_seq, P, D, best, accept_len, new_len);
+    } else {
+        const int lin = ((int)blockIdx.y - n_slabs) * gridDim.x + blockIdx.x;
+        const int per_seq = G * D;
+        if (lin < B * per_seq)
+            accept_copy_body(lin % per_seq, lin / per_seq, hidden, G, N, hid_cpr, retrieve, retrieve_per_seq, P, D, cand, best, accept_len,
+                             out_hidden, accepted_tokens);
     }
 }
 
@@ -393,5 +434,30 @@ extern "C" int lantern_sample_static(const float *probs, const int64_t *idx, int
     if (R == 0) return LANTERN_OK;
     hipLaunchKernelGGL(sample_static_kernel, dim3((R + 63) / 64), dim3(64), 0, (hipStream_t)stream, probs, idx, R, V, k, out_prob);
     LANTERN_CHECK_LAUNCH("sample_static");
+    return LANTERN_OK;
+}
+
+extern "C" int lantern_update_inference_inputs(void *const *slab_ptrs, const int32_t *slab_seq, const int64_t *slab_prev, int n_slabs,
+                                               int elem_bytes, int64_t outer, int64_t S_max, int64_t d, const int64_t *retrieve,
+                                               int retrieve_per_seq, int P, int D, const int32_t *best, const int32_t *accept_len,
+                                               int64_t *new_len, const void *hidden, int hid_elem_bytes, int B, int G, int N, int H,
+                                               const int64_t *cand, void *out_hidden, int64_t *accepted_tokens, void *stream) {
+    LANTERN_CHECK_ARG(slab_ptrs && slab_seq && slab_prev && retrieve && best && accept_len, "update_inference_inputs: null buffer");
+    LANTERN_CHECK_ARG(n_slabs > 0 && outer > 0 && S_max > 0 && d > 0 && P > 0 && D > 0 && B > 0, "update_inference_inputs: bad sizes");
+    LANTERN_CHECK_ARG((d * elem_bytes) % 16 == 0, "update_inference_inputs: KV row bytes %lld must be a multiple of 16", (long long)(d * elem_bytes));
+    LANTERN_CHECK_ARG(D <= 8, "update_inference_inputs: D=%d > 8 (use lantern_kv_gather + lantern_accept_gather)", D);
+    if (hidden) LANTERN_CHECK_ARG(out_hidden && G > 0 && N > 0 && H > 0 && (H * hid_elem_bytes) % 16 == 0,
+                                  "update_inference_inputs: hidden row bytes must be a multiple of 16");
+    const int cpr = (int)(d * elem_bytes / 16);
+    const int64_t total = outer * cpr;
+    LANTERN_CHECK_ARG(total < (1ll << 31), "update_inference_inputs: outer * row chunks = %lld does not fit 31 bits", (long long)total);
+    int gx = (int)((total + 511) / 512);
+    if (gx > 4096) gx = 4096;
+    const int g = hidden ? G : 1;
+    const int extra = (B * g * D + gx - 1) / gx;
+    hipLaunchKernelGGL((update_inputs_kernel<8, 2>), dim3(gx, n_slabs + extra), dim3(256), 0, (hipStream_t)stream, slab_ptrs, slab_seq,
+                       slab_prev, n_slabs, outer, S_max, cpr, retrieve, retrieve_per_seq, P, D, best, accept_len, new_len,
+                       (const uint4 *)hidden, B, g, N, hidden ? H * hid_elem_bytes / 16 : 0, cand, (uint4 *)out_hidden, accepted_tokens);
+    LANTERN_CHECK_LAUNCH("update_inference_inputs");
     return LANTERN_OK;
 }

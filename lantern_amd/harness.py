@@ -69,6 +69,7 @@ class WorkloadConfig:
                                     # the sample token, O10 only evaluate_posterior's result); fork/join with events, capturable.
                                     # Measured SLOWER on MI355X (116 vs 103 us/step): the cross-stream event waits cost more than the
                                     # two small kernels they hide; kept as an option
+    fuse_update: bool = True        # windowed path: O9 + O10 in one launch (lantern_update_inference_inputs)
     pack_table: bool = True         # windowed path: neighbour table packed to [K, ceil8(k+1)] (lantern_pack_vq_table)
     n_groups: int = 1               # >1: the sequences are split into groups, each launched on its own HIP stream, so that one
                                     # group's latency-bound evaluate_posterior overlaps the others' bandwidth-bound kernels
@@ -468,19 +469,28 @@ class LuminaVerifyWorkload:
         if side is not None:
             ev[2].record(main)
             side.wait_event(ev[2])
-        # O10 accepted hidden + token append (+ bonus token on the dense path); side stream: beside the KV gather
-        check(L.lantern_accept_gather(A["hidden"], 2, B, 2, N, HIDDEN, vp(self.d_retrieve.data_ptr()), 0, P, D, A["cand"], A["st_best"],
-                                      A["st_alen"], A["sample_p"], V, None if self.windowed else A["u_cur"], A["out_hidden"],
-                                      A["acc_tokens"], None if self.windowed else A["st_token"], st_side), "accept_gather")
+        fused = c.with_kv and self.windowed and c.fuse_update and side is None
+        if not fused:
+            # O10 accepted hidden + token append (+ bonus token on the dense path); side stream: beside the KV gather
+            check(L.lantern_accept_gather(A["hidden"], 2, B, 2, N, HIDDEN, vp(self.d_retrieve.data_ptr()), 0, P, D, A["cand"], A["st_best"],
+                                          A["st_alen"], A["sample_p"], V, None if self.windowed else A["u_cur"], A["out_hidden"],
+                                          A["acc_tokens"], None if self.windowed else A["st_token"], st_side), "accept_gather")
         if side is not None:
             ev[3].record(side)
-        # O9 KV gather: both slabs of every sequence of the group in one launch
+        # O9 KV gather: both slabs of every sequence of the group in one launch (fused: + the O10 copy, as the reference's
+        # update_inference_inputs does both)
         if c.with_kv:
             if events:
                 events["kv_gather"][0].record()
-            check(L.lantern_kv_gather(A["slab_ptrs"], A["slab_seq"], A["cur"], 2 * B, 2, C.c_int64(2 * c.kv_layers * c.kv_heads),
-                                      C.c_int64(c.kv_smax + c.kv_pad_rows), C.c_int64(c.kv_dim), vp(self.d_retrieve.data_ptr()), 0, P, D,
-                                      A["st_best"], A["st_alen"], A["nxt"], st), "kv_gather")
+            if fused:
+                check(L.lantern_update_inference_inputs(A["slab_ptrs"], A["slab_seq"], A["cur"], 2 * B, 2, C.c_int64(2 * c.kv_layers * c.kv_heads),
+                                                        C.c_int64(c.kv_smax + c.kv_pad_rows), C.c_int64(c.kv_dim), vp(self.d_retrieve.data_ptr()),
+                                                        0, P, D, A["st_best"], A["st_alen"], A["nxt"], A["hidden"], 2, B, 2, N, HIDDEN,
+                                                        A["cand"], A["out_hidden"], A["acc_tokens"], st), "update_inference_inputs")
+            else:
+                check(L.lantern_kv_gather(A["slab_ptrs"], A["slab_seq"], A["cur"], 2 * B, 2, C.c_int64(2 * c.kv_layers * c.kv_heads),
+                                          C.c_int64(c.kv_smax + c.kv_pad_rows), C.c_int64(c.kv_dim), vp(self.d_retrieve.data_ptr()), 0, P, D,
+                                          A["st_best"], A["st_alen"], A["nxt"], st), "kv_gather")
             if events:
                 events["kv_gather"][1].record()
         else:

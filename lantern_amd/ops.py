@@ -339,6 +339,36 @@ def kv_gather(slabs: Sequence[torch.Tensor], slab_seq, slab_prev, retrieve, best
     return new_len
 
 
+def update_inference_inputs(slabs: Sequence[torch.Tensor], slab_seq, slab_prev, retrieve, best, accept_len, hidden, cand, slab_ptrs=None):
+    """O9 + O10 in one launch (the reference's update_inference_inputs): KV rows of every slab move in place, accepted hidden
+    rows [B,G,D,H] and tokens [B,D] are gathered.  Returns (new_len [n] i64, out_hidden, accepted_tokens)."""
+    s0 = slabs[0]
+    S, d = s0.shape[-2], s0.shape[-1]
+    outer = s0.numel() // (S * d)
+    dev = s0.device
+    for s in slabs:
+        assert s.is_cuda and s.is_contiguous() and s.shape == s0.shape and s.dtype == s0.dtype
+    if slab_ptrs is None:
+        slab_ptrs = torch.tensor([s.data_ptr() for s in slabs], dtype=torch.int64, device=dev)
+    slab_seq = _dev(slab_seq, torch.int32, "slab_seq")
+    slab_prev = _dev(slab_prev, torch.int64, "slab_prev")
+    retrieve = _dev(retrieve, torch.int64, "retrieve")
+    cand = _dev(cand, torch.int64, "cand")
+    hidden = hidden.contiguous()
+    P, D = retrieve.shape[-2:]
+    B, G, N, H = hidden.shape
+    new_len = torch.empty(len(slabs), dtype=torch.int64, device=dev)
+    out_h = torch.empty((B, G, D, H), dtype=hidden.dtype, device=dev)
+    acc = torch.empty((B, D), dtype=torch.int64, device=dev)
+    check(_lib.lib().lantern_update_inference_inputs(
+        C.c_void_p(slab_ptrs.data_ptr()), C.c_void_p(slab_seq.data_ptr()), C.c_void_p(slab_prev.data_ptr()), len(slabs),
+        s0.element_size(), C.c_int64(outer), C.c_int64(S), C.c_int64(d), C.c_void_p(retrieve.data_ptr()),
+        int(retrieve.dim() == 3), P, D, C.c_void_p(best.data_ptr()), C.c_void_p(accept_len.data_ptr()),
+        C.c_void_p(new_len.data_ptr()), C.c_void_p(hidden.data_ptr()), hidden.element_size(), B, G, N, H, C.c_void_p(cand.data_ptr()),
+        C.c_void_p(out_h.data_ptr()), C.c_void_p(acc.data_ptr()), _stream()), "update_inference_inputs")
+    return new_len, out_h, acc
+
+
 def accept_gather(hidden, retrieve, cand, best, accept_len, sample_p=None, u=None):
     """O10.  hidden [B,G,N,H]; retrieve [P,D]|[B,P,D]; cand [B,P,D]; sample_p [B,V]; u [B] f64 or None (greedy).
     Returns (out_hidden [B,G,D,H], accepted_tokens [B,D], token [B])."""

@@ -266,6 +266,37 @@ def test_kv_gather_lumina_geometry_vs_oracle():
         assert int(new_len[s]) == prev[s] + alen[b] + 1
 
 
+def test_update_inference_inputs_fused_equals_separate_ops():
+    """O9 + O10 in one launch == lantern_kv_gather followed by lantern_accept_gather (and the oracle)."""
+    rs = np.random.RandomState(2)
+    tb = oracle.tree_static_build(CS.mc_sim_7b_63)
+    ret = tb["retrieve_indices"]
+    P, D = ret.shape
+    N = len(tb["tree_indices"])
+    B, G, Hd = 3, 2, 256
+    slabs_np = [rs.randint(0, 65535, size=(4, 1, 8, 80, 128)).astype(np.uint16) for _ in range(2 * B)]
+    a_slabs = [dev(s.view(np.int16)) for s in slabs_np]
+    b_slabs = [dev(s.view(np.int16)) for s in slabs_np]
+    best = np.array([3, 0, 14], np.int32)
+    alen = np.array([2, 5, 0], np.int32)
+    seq = np.array([0, 1, 2, 0, 1, 2], np.int32)
+    prev = np.array([40, 17, 33, 9, 3, 20], np.int64)
+    hidden = torch.randn(B, G, N, Hd, device="cuda").to(torch.bfloat16)
+    cand = rs.randint(0, 8192, size=(B, P, D)).astype(np.int64)
+    nl_a = ops.kv_gather(a_slabs, dev(seq), dev(prev), dev(ret), dev(best), dev(alen))
+    h_a, t_a, _ = ops.accept_gather(hidden, dev(ret), dev(cand), dev(best), dev(alen))
+    nl_b, h_b, t_b = ops.update_inference_inputs(b_slabs, dev(seq), dev(prev), dev(ret), dev(best), dev(alen), hidden, dev(cand))
+    assert torch.equal(nl_a, nl_b) and torch.equal(h_a, h_b) and torch.equal(t_a, t_b)
+    for s in range(2 * B):
+        assert torch.equal(a_slabs[s], b_slabs[s]), s
+        exp = oracle.kv_gather(slabs_np[s].copy(), ret[best[seq[s]]], int(alen[seq[s]]) + 1, int(prev[s]))
+        assert np.array_equal(b_slabs[s].cpu().numpy().view(np.uint16), exp), s
+    for b in range(B):
+        n = int(alen[b]) + 1
+        assert torch.equal(h_b[b, :, :n], hidden[b][:, torch.as_tensor(ret[best[b], :n]).cuda()])
+        assert t_b[b, :n].tolist() == cand[b, best[b], :n].tolist() and (t_b[b, n:] == -1).all()
+
+
 @pytest.mark.parametrize("i", [i for i, s in enumerate(SPECS) if s["kind"] in ("dynamic", "greedy")][::3])
 def test_dynamic_tree_golden(i):
     spec, case = SPECS[i], H.ep_case(i)

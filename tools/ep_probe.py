@@ -25,8 +25,8 @@ def main():
     L = wl._L
     st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     def run(prm, uni=None, bonus=True):
-        buf = wl.ep_buffers(0, 1)
-        win = wl.ep_window(1)
+        buf = wl.ep_buffers(0, 0)
+        win = wl.ep_window(0)
         if uni is not None: buf.uniforms = uni.data_ptr()
         if not bonus: win.u_bonus = None; win.token = None
         def f():

@@ -252,13 +252,18 @@ def main():
         wl.step()
     barrier()
     dt = time.perf_counter() - t0
-    # ---- per-kernel durations: the same loop continues eagerly with HIP events on the launch stream around the three
-    # HBM-heavy kernels, kept out of the timed region so that `value` carries no event overhead.  rocprofv3 of this command
-    # sees both passes.
+    # ---- per-kernel durations: the same loop continues eagerly with HIP events on the launch stream for the three
+    # HBM-heavy kernels (recorded at kernel begin / end by the launch itself: lantern_profile_next_launch), kept out of the
+    # timed region so that `value` carries no event overhead.  rocprofv3 of this command sees both passes.
     evs = None
     KT = min(K, 100)
     if not args.no_events:
         evs = [{n: (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for n in names} for _ in range(KT)]
+        for d in evs:                      # create the hipEvent_t handles (torch makes them on the first record)
+            for e0, e1 in d.values():
+                e0.record()
+                e1.record()
+        torch.cuda.synchronize(device)
         for i in range(KT):
             wl.step(evs[i], serial=True)     # groups one after the other on one stream: undisturbed kernel durations
         torch.cuda.synchronize(device)

@@ -338,6 +338,13 @@ int lantern_build_vq_table(const float *codebook, int K, int C, uint16_t *table,
  * instead of 128 MiB for Lumina/Anole).  Pass the packed table with table_cols = dst_cols; k <= dst_cols - 1. */
 int lantern_pack_vq_table(const uint16_t *src, int rows, int src_cols, uint16_t *dst, int dst_cols, void *stream);
 
+/* Measurement aid.  Arms a (start, stop) hipEvent_t pair on the calling thread: the NEXT launch of
+ * lantern_cfg_mask_topk_window / lantern_evaluate_posterior_window / lantern_kv_gather /
+ * lantern_update_inference_inputs from this thread records them at kernel begin and kernel end
+ * (hipExtLaunchKernelGGL), then disarms.  hipEventElapsedTime(start, stop) is then the kernel-only duration -- the
+ * figure rocprofv3 --kernel-trace reports -- without the dispatch gap a hipEventRecord bracket includes. */
+int lantern_profile_next_launch(void *start_event, void *stop_event);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,6 +1,7 @@
 // common.h -- shared host/device helpers of liblantern_hip.so (gfx950 only).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
@@ -11,6 +12,21 @@ namespace lantern {
 
 // ---------------------------------------------------------------- host error state
 void set_error(const char *fmt, ...);
+
+// ---------------------------------------------------------------- measurement aid (lantern_profile_next_launch)
+// When a (start, stop) event pair is armed on this thread, the next launch through LANTERN_LAUNCH records them at
+// kernel begin / end (hipExtLaunchKernelGGL: the dispatch's own timestamps, i.e. the kernel-only duration rocprofv3
+// reports) and disarms; otherwise a plain hipLaunchKernelGGL.
+void take_launch_events(void **start, void **stop);
+#define LANTERN_LAUNCH(kernel, grid, block, lds, st, ...)                                                                  \
+    do {                                                                                                                   \
+        void *ev0__ = nullptr, *ev1__ = nullptr;                                                                           \
+        ::lantern::take_launch_events(&ev0__, &ev1__);                                                                     \
+        if (ev0__ && ev1__)                                                                                                \
+            hipExtLaunchKernelGGL(kernel, grid, block, lds, st, (hipEvent_t)ev0__, (hipEvent_t)ev1__, 0, __VA_ARGS__);     \
+        else                                                                                                               \
+            hipLaunchKernelGGL(kernel, grid, block, lds, st, __VA_ARGS__);                                                 \
+    } while (0)
 
 #define LANTERN_CHECK_ARG(cond, ...)            \
     do {                                        \

@@ -389,7 +389,7 @@ extern "C" int lantern_kv_gather(void *const *slab_ptrs, const int32_t *slab_seq
     int gx = (int)((total + 256 * U - 1) / (256 * U));
     if (gx > 4096) gx = 4096;
 #define KV_LAUNCH(MS_, U_)                                                                                                               \
-    hipLaunchKernelGGL((kv_gather_kernel<MS_, U_>), dim3(gx, n_slabs), dim3(256), 0, (hipStream_t)stream, slab_ptrs, slab_seq, slab_prev, \
+    LANTERN_LAUNCH((kv_gather_kernel<MS_, U_>), dim3(gx, n_slabs), dim3(256), 0, (hipStream_t)stream, slab_ptrs, slab_seq, slab_prev, \
                        outer, S_max, cpr, retrieve, retrieve_per_seq, P, D, best, accept_len, new_len)
     if (D <= 8) {
         if (U == 1) KV_LAUNCH(8, 1);
@@ -455,7 +455,7 @@ extern "C" int lantern_update_inference_inputs(void *const *slab_ptrs, const int
     if (gx > 4096) gx = 4096;
     const int g = hidden ? G : 1;
     const int extra = (B * g * D + gx - 1) / gx;
-    hipLaunchKernelGGL((update_inputs_kernel<8, 2>), dim3(gx, n_slabs + extra), dim3(256), 0, (hipStream_t)stream, slab_ptrs, slab_seq,
+    LANTERN_LAUNCH((update_inputs_kernel<8, 2>), dim3(gx, n_slabs + extra), dim3(256), 0, (hipStream_t)stream, slab_ptrs, slab_seq,
                        slab_prev, n_slabs, outer, S_max, cpr, retrieve, retrieve_per_seq, P, D, best, accept_len, new_len,
                        (const uint4 *)hidden, B, g, N, hidden ? H * hid_elem_bytes / 16 : 0, cand, (uint4 *)out_hidden, accepted_tokens);
     LANTERN_CHECK_LAUNCH("update_inference_inputs");

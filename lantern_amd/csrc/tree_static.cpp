@@ -25,6 +25,17 @@ void set_error(const char *fmt, ...) {
 }
 const char *last_error() { return g_err; }
 
+static thread_local void *g_ev_start = nullptr, *g_ev_stop = nullptr;
+void take_launch_events(void **start, void **stop) {
+    *start = g_ev_start;
+    *stop = g_ev_stop;
+    g_ev_start = g_ev_stop = nullptr;
+}
+void arm_launch_events(void *start, void *stop) {
+    g_ev_start = start;
+    g_ev_stop = stop;
+}
+
 namespace {
 
 using Path = std::vector<int32_t>;
@@ -103,6 +114,13 @@ using namespace lantern;
 
 extern "C" int lantern_version(void) { return LANTERN_VERSION; }
 extern "C" const char *lantern_last_error(void) { return lantern::last_error(); }
+namespace lantern {
+void arm_launch_events(void *start, void *stop);
+}
+extern "C" int lantern_profile_next_launch(void *start_event, void *stop_event) {
+    lantern::arm_launch_events(start_event, stop_event);
+    return LANTERN_OK;
+}
 
 extern "C" int lantern_tree_static_sizes(const int32_t *choices, const int32_t *choice_off, int n_choices, int *N, int *P,
                                          int *D, int *b_total) {

@@ -1305,7 +1305,7 @@ extern "C" int lantern_cfg_mask_topk_window(const void *cond, const void *uncond
         const uint16_t *c16 = (const uint16_t *)cond, *u16 = (const uint16_t *)uncond;
         static const int nt_knob = getenv("LANTERN_O7_NT") ? atoi(getenv("LANTERN_O7_NT")) : 0;   // tuning knob (diagnostic)
 #define CW16(NT_, E8_)                                                                                                              \
-    hipLaunchKernelGGL((cfg_window_bf16_kernel<NT_, E8_>), dim3(rows), dim3(NT_), 0, st, c16, u16, V, cfg, model, pos_ids, pos_base,       \
+    LANTERN_LAUNCH((cfg_window_bf16_kernel<NT_, E8_>), dim3(rows), dim3(NT_), 0, st, c16, u16, V, cfg, model, pos_ids, pos_base,       \
                        w_latent, h_latent, img_lo, img_hi, newline_id, eos_id, top_k, seq_len, rows_per_seq, win_lo, win_len, out_win,  \
                        row_hot, out_kind)
         if (chunks <= 256 * 2) CW16(256, 2);
@@ -1370,9 +1370,9 @@ extern "C" int lantern_evaluate_posterior_window(const lantern_ep_params *prm, c
     const int idmode = !lds_ids ? 0 : ((p.lantern && p.table_cols % 8 == 0 && ((uintptr_t)buf->nn_table & 15) == 0) ? 2 : 1);
 #define EPW_LAUNCH(NT_, E4_)                                                                                              \
     do {                                                                                                                  \
-        if (idmode == 2) hipLaunchKernelGGL((epw_kernel<NT_, E4_, 2>), grid, dim3(NT_), lds, st, args);                   \
-        else if (idmode == 1) hipLaunchKernelGGL((epw_kernel<NT_, E4_, 1>), grid, dim3(NT_), lds, st, args);              \
-        else hipLaunchKernelGGL((epw_kernel<NT_, E4_, 0>), grid, dim3(NT_), lds, st, args);                               \
+        if (idmode == 2) LANTERN_LAUNCH((epw_kernel<NT_, E4_, 2>), grid, dim3(NT_), lds, st, args);                   \
+        else if (idmode == 1) LANTERN_LAUNCH((epw_kernel<NT_, E4_, 1>), grid, dim3(NT_), lds, st, args);              \
+        else LANTERN_LAUNCH((epw_kernel<NT_, E4_, 0>), grid, dim3(NT_), lds, st, args);                               \
     } while (0)
     if (W <= 1024) EPW_LAUNCH(256, 1);
     else if (W <= 2048) EPW_LAUNCH(256, 2);

@@ -419,6 +419,19 @@ class LuminaVerifyWorkload:
         cache[key] = a
         return a
 
+    def _arm(self, events, name):
+        """Kernel-only timing: the next launch records (start, stop) at kernel begin / end (lantern_profile_next_launch);
+        kernel sets without the hook (dense path) fall back to a hipEventRecord bracket."""
+        e0, e1 = events[name]
+        if self.windowed:
+            check(self._L.lantern_profile_next_launch(C.c_void_p(e0.cuda_event), C.c_void_p(e1.cuda_event)), "profile_next_launch")
+        else:
+            e0.record()
+
+    def _disarm(self, events, name):
+        if not self.windowed:
+            events[name][1].record()
+
     def _launch_step(self, slot: int, parity: int, events, g: int = 0):
         c, L = self.cfg, self._L
         B, N, P, D = self.Bg, self.N, self.P, self.D
@@ -442,7 +455,7 @@ class LuminaVerifyWorkload:
             ev[1].record(side)
         # O7 CFG + Lumina position mask + top-k, positions from the device-side lengths
         if events:
-            events["cfg_mask_topk"][0].record()
+            self._arm(events, "cfg_mask_topk")
         if self.windowed:
             check(L.lantern_cfg_mask_topk_window(A["cond"], A["uncond"], 1, B * N, V, C.c_float(c.cfg_scale), ops.MODEL_LUMINA,
                                                  vp(self.d_pos_ids.data_ptr()), C.c_int64(c.prompt_len + 3), W_LATENT, H_LATENT, IMG_LO, IMG_HI,
@@ -454,8 +467,8 @@ class LuminaVerifyWorkload:
                                           vp(self.d_pos_ids.data_ptr()), C.c_int64(c.prompt_len + 3), W_LATENT, H_LATENT, IMG_LO, IMG_HI,
                                           NEWLINE, EOS, c.top_k, A["cur"], N, A["proc"], st), "cfg_mask_topk")
         if events:
-            events["cfg_mask_topk"][1].record()
-            events["evaluate_posterior"][0].record()
+            self._disarm(events, "cfg_mask_topk")
+            self._arm(events, "evaluate_posterior")
         if side is not None:
             main.wait_event(ev[1])                # O8 needs the candidates
         # O8 (windowed: the bonus token is drawn in the kernel epilogue)
@@ -465,7 +478,7 @@ class LuminaVerifyWorkload:
         else:
             check(L.lantern_evaluate_posterior(C.byref(self._ep_prm), C.byref(A["ep_buf"]), st), "evaluate_posterior")
         if events:
-            events["evaluate_posterior"][1].record()
+            self._disarm(events, "evaluate_posterior")
         if side is not None:
             ev[2].record(main)
             side.wait_event(ev[2])
@@ -481,7 +494,7 @@ class LuminaVerifyWorkload:
         # update_inference_inputs does both)
         if c.with_kv:
             if events:
-                events["kv_gather"][0].record()
+                self._arm(events, "kv_gather")
             if fused:
                 check(L.lantern_update_inference_inputs(A["slab_ptrs"], A["slab_seq"], A["cur"], 2 * B, 2, C.c_int64(2 * c.kv_layers * c.kv_heads),
                                                         C.c_int64(c.kv_smax + c.kv_pad_rows), C.c_int64(c.kv_dim), vp(self.d_retrieve.data_ptr()),
@@ -492,7 +505,7 @@ class LuminaVerifyWorkload:
                                           C.c_int64(c.kv_smax + c.kv_pad_rows), C.c_int64(c.kv_dim), vp(self.d_retrieve.data_ptr()), 0, P, D,
                                           A["st_best"], A["st_alen"], A["nxt"], st), "kv_gather")
             if events:
-                events["kv_gather"][1].record()
+                self._disarm(events, "kv_gather")
         else:
             s0 = g * self.Bg
             torch.add(self.lens[parity][2 * s0:2 * s0 + 2 * B], (self.st_alen[s0:s0 + B] + 1).repeat(2), out=self.lens[parity ^ 1][2 * s0:2 * s0 + 2 * B])

@@ -23,7 +23,7 @@ import torch.nn as nn
 from . import ops
 from .drafters.choices import mc_sim_7b_63
 from .drafters.kv_cache import initialize_past_key_values
-from .verify import NodeLogits, UniformFifo, as_rows, concat_original_prob, generate_tree_buffers  # noqa: F401
+from .verify import WindowRows, NodeLogits, UniformFifo, as_rows, concat_original_prob, generate_tree_buffers  # noqa: F401
 
 TOPK = 10
 IMAGE_LO, IMAGE_HI = 4, 8196          # image tokens are 4..8195 (ea_model_lumina_mgpt.py:37,322-323)
@@ -67,6 +67,9 @@ class InterleavedTopKLogitsWarper:
 
 class EaLumina_mGPT(nn.Module):
     uniform_window = 4096     # uniforms staged per refill (verify.UniformFifo)
+    # "window": tree rows cross HBM as 8192-wide image-token windows of probabilities, evaluate_posterior keeps the residual
+    # distribution in LDS.  "dense": full-vocabulary rows, the reference's intermediate tensors exactly.
+    kernel_set = "window"
 
     def __init__(self, base_model, ea_layer, nearest_latents, cfg_mode: str = "sequential", eagle_version: int = 1,
                  dtype=torch.bfloat16):
@@ -106,6 +109,17 @@ class EaLumina_mGPT(nn.Module):
     def reset_tree_mode(self):
         self.base_model.model.tree_mode = True
         self.base_model.model.tree_mask = None
+
+    def _packed_table(self, k: int) -> torch.Tensor:
+        """Neighbour table in the hot-path layout (16-byte aligned rows of ceil8(k+1) ids, lantern_pack_vq_table), built once per k;
+        tables too narrow to pad (k + 1 > 1024 staged ids is the kernel's limit anyway) are passed through."""
+        cols = -(-(k + 1) // 8) * 8
+        if cols > min(1024, self.nearest_latents.shape[1]):
+            return self.nearest_latents
+        cache = self.__dict__.setdefault("_packed_tables", {})
+        if cols not in cache:
+            cache[cols] = ops.pack_vq_table(self.nearest_latents, cols)
+        return cache[cols]
 
     def _uniforms(self) -> UniformFifo:
         if self._fifo is None:
@@ -170,10 +184,14 @@ class EaLumina_mGPT(nn.Module):
                                                                position_ids=position_ids - self.image_start_token_id_index)
         # one kernel: CFG combine + MultiModalLogitsProcessor + InterleavedTopKLogitsWarper; no [P,D,V] gather
         top_k = self.internal_logits_processors[1].image_top_k if len(self.internal_logits_processors) > 1 else 0
-        node_logits = ops.cfg_mask_topk(tree_logits[0], uncond_tree_logits[0], float(self.cfg_scale), model=ops.MODEL_LUMINA,
-                                        pos_ids=(position_ids + 1).reshape(-1), pos_base=self.image_start_token_id_index + 3,
-                                        w=self.w_latent_dim, h=self.h_latent_dim, img_lo=IMAGE_LO, img_hi=IMAGE_HI,
-                                        newline_id=8803, eos_id=8196, top_k=min(top_k, tree_logits.shape[-1]))
+        kw = dict(model=ops.MODEL_LUMINA, pos_ids=(position_ids + 1).reshape(-1), pos_base=self.image_start_token_id_index + 3,
+                  w=self.w_latent_dim, h=self.h_latent_dim, img_lo=IMAGE_LO, img_hi=IMAGE_HI, newline_id=8803, eos_id=8196,
+                  top_k=min(top_k, tree_logits.shape[-1]))
+        if self.kernel_set == "window":
+            win, hot = ops.cfg_mask_topk_window(tree_logits[0], uncond_tree_logits[0], float(self.cfg_scale), IMAGE_LO,
+                                                IMAGE_HI - IMAGE_LO, probs=True, **kw)
+            return WindowRows(win, hot, retrieve_indices, tree_logits.shape[-1], IMAGE_LO), hidden_states, uncond_hidden_states
+        node_logits = ops.cfg_mask_topk(tree_logits[0], uncond_tree_logits[0], float(self.cfg_scale), **kw)
         return NodeLogits(node_logits, retrieve_indices), hidden_states, uncond_hidden_states
 
     # ------------------------------------------------------------------ O8, :610-729
@@ -183,7 +201,8 @@ class EaLumina_mGPT(nn.Module):
         if not do_sample:
             raise NotImplementedError("Greedy decoding is not implemented yet")   # same as the reference (:728-729)
         static = self.eagle_version == 1
-        rows, row_index = as_rows(logits)
+        windowed = isinstance(logits, WindowRows)
+        rows, row_index = (logits.win, logits.row_index()) if windowed else as_rows(logits)
         cfg = ops.EpConfig.lumina(static, lantern=bool(lantern), k=int(lantern_k), delta=float(lantern_delta))
         cfg.img_hi = int(self.image_tokens[-1]) + 1
         cfg.img_lo = int(self.image_tokens[0])
@@ -202,9 +221,15 @@ class EaLumina_mGPT(nn.Module):
                                 tree_cand=tree_candidates.reshape(1, -1)[:, :hip["N"]])
         fifo = self._uniforms()
         fifo.reserve(candidates.shape[0] * candidates.shape[1])
-        best, alen, sample_p, counters = ops.evaluate_posterior(cfg, rows.float()[None], row_index, candidates[None], fifo.buf,
-                                                                table=self.nearest_latents if lantern else None, aux=aux,
-                                                                cursor=fifo.cursor)
+        if windowed:
+            out = ops.evaluate_posterior_window(cfg, logits.V, rows[None], logits.win_lo, row_index, candidates[None], fifo.buf,
+                                                row_hot=logits.row_hot[None], table=self._packed_table(int(lantern_k)) if lantern else None,
+                                                aux=aux, cursor=fifo.cursor, want_dense=True, want_window=False, rows_probs=True)
+            best, alen, sample_p, counters = out["best"], out["accept_len"], out["sample_p"], out["counters"]
+        else:
+            best, alen, sample_p, counters = ops.evaluate_posterior(cfg, rows.float()[None], row_index, candidates[None], fifo.buf,
+                                                                    table=self.nearest_latents if lantern else None, aux=aux,
+                                                                    cursor=fifo.cursor)
         self._last = (best, alen, counters)          # device copies for update_inference_inputs (no re-upload)
         ops.raise_on_status(counters)                # host sync: the B=1 driver needs accept_length on the host anyway
         return best[0].to(torch.int64), int(alen[0]), sample_p[0]

@@ -70,6 +70,41 @@ class NodeLogits:
         return self.materialize()[idx]
 
 
+class WindowRows:
+    """What the windowed kernel set hands from `tree_decoding` to `evaluate_posterior`: softmax probabilities of the
+    processed node rows restricted to the image-token window, `[N, W] f32`, plus `row_hot [N]` (token id of a forced one-hot
+    row -- newline / end of image -- or -1) and `retrieve_indices [P,D]`.  `materialize()` rebuilds the reference's
+    `[P,D,V]` tensor of PROBABILITIES for callers that want to look at it."""
+
+    def __init__(self, win: torch.Tensor, row_hot: torch.Tensor, retrieve_indices: torch.Tensor, V: int, win_lo: int):
+        self.win, self.row_hot, self.retrieve_indices, self.V, self.win_lo = win, row_hot, retrieve_indices, V, win_lo
+
+    @property
+    def shape(self):
+        return (*self.retrieve_indices.shape, self.V)
+
+    @property
+    def device(self):
+        return self.win.device
+
+    def row_index(self) -> torch.Tensor:
+        r = self.retrieve_indices.to(torch.int64)
+        return torch.where(r < 0, r + self.win.shape[0], r).to(torch.int32)
+
+    def materialize(self) -> torch.Tensor:
+        N, W = self.win.shape
+        dense = torch.zeros((N, self.V), dtype=torch.float32, device=self.win.device)
+        dense[:, self.win_lo:self.win_lo + W] = self.win
+        hot = self.row_hot.long()
+        rows = torch.nonzero(hot >= 0).reshape(-1)
+        dense[rows] = 0.0
+        dense[rows, hot[rows]] = 1.0
+        return dense[self.retrieve_indices]
+
+    def __getitem__(self, idx):
+        return self.materialize()[idx]
+
+
 def as_rows(logits):
     """(rows [R,V] f32, row_index [P,D] i32) from either a NodeLogits or the reference's [P,D,V] tensor."""
     if isinstance(logits, NodeLogits):

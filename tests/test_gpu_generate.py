@@ -139,11 +139,13 @@ def make_model(version, cfg_mode):
     return mdl
 
 
-@pytest.mark.parametrize("version,cfg_mode", [(2, "sequential"), (1, "sequential"), (2, "parallel"), (1, "parallel")])
-def test_generate_end_to_end(version, cfg_mode):
+@pytest.mark.parametrize("version,cfg_mode,kernel_set", [(2, "sequential", "window"), (1, "sequential", "window"), (2, "parallel", "window"),
+                                                         (1, "parallel", "window"), (1, "sequential", "dense"), (2, "parallel", "dense")])
+def test_generate_end_to_end(version, cfg_mode, kernel_set):
     random.seed(1234)
     torch.manual_seed(0)
     mdl = make_model(version, cfg_mode)
+    mdl.kernel_set = kernel_set
     prompt = torch.randint(9000, 12000, (1, 11), device="cuda")
     out_ids, accept = mdl.eagenerate(prompt, max_new_tokens=60, cfg_scale=3.0, top_k=200, lantern=True, lantern_k=100, lantern_delta=0.1,
                                      tree_choices=mc_sim_7b_63)
@@ -171,3 +173,19 @@ def test_generate_end_to_end(version, cfg_mode):
         tok_u, pos_u = decode(du[0, 0, 0, :nu].float())
         assert tok_u.tolist() == ids[prompt.shape[1]:n_valid].tolist() and pos_u.tolist() == list(range(nu))
     assert n_valid == ids.shape[0]
+
+
+def test_window_and_dense_kernel_sets_generate_the_same_tokens():
+    """Same seeds, same scripted model: the windowed kernel set (probability windows, LDS residual, packed table) and the dense
+    one (the reference's full-vocabulary rows) must walk the same accept/reject decisions and emit the same ids."""
+    outs = []
+    for ks in ("window", "dense"):
+        random.seed(77)
+        torch.manual_seed(5)
+        mdl = make_model(1, "sequential")
+        mdl.kernel_set = ks
+        prompt = torch.randint(9000, 12000, (1, 9), device="cuda")
+        ids, accept = mdl.eagenerate(prompt, max_new_tokens=40, cfg_scale=3.0, top_k=200, lantern=True, lantern_k=100, lantern_delta=0.1,
+                                     tree_choices=mc_sim_7b_63)
+        outs.append((ids.cpu(), accept))
+    assert outs[0][1] == outs[1][1] and torch.equal(outs[0][0], outs[1][0])

@@ -327,7 +327,7 @@ int lantern_drafter_fc(const int64_t *ids, const void *hidden, const void *embed
 
 /* 8f-1 VQ-distance neighbour table: cdist + per-row ascending order, self excluded.
  * Replaces entrypoints/generate_codebook.py:53-65.  codebook [dev] [K,C] f32 ->
- * table [dev] [K,K-1] u16.  workspace [dev] K*K*8 bytes. */
+ * table [dev] [K,K-1] u16, K <= 16384 (LlamaGen).  workspace: unused (NULL). */
 int lantern_build_vq_table(const float *codebook, int K, int C, uint16_t *table, void *workspace,
                            void *stream);
 

@@ -104,3 +104,24 @@ def test_vq_table_builder():
     cb2 = rs.standard_normal((1000, 16)).astype(np.float32)                    # non power-of-two K
     t2 = ops.build_vq_table(dev(cb2)).cpu().numpy().view(np.uint16)
     assert np.array_equal(t2, oracle.build_vq_table(cb2))
+
+
+def test_vq_table_builder_llamagen_size():
+    """K = 16384, C = 8 (LlamaGen's codebook): the packed-key kernel.  Checked on sampled rows against numpy f64 distances:
+    every row is a permutation of the other codes in non-decreasing distance (ties within the 36-bit key precision)."""
+    K, Cc = 16384, 8
+    rs = np.random.RandomState(4)
+    cb = rs.standard_normal((K, Cc)).astype(np.float32)
+    t = ops.build_vq_table(dev(cb)).cpu().numpy().view(np.uint16)
+    assert t.shape == (K, K - 1)
+    cb64 = cb.astype(np.float64)
+    for a in [0, 1, 777, 8191, 8192, 16383]:
+        d = ((cb64 - cb64[a]) ** 2).sum(-1)
+        row = t[a].astype(np.int64)
+        assert a not in row and len(np.unique(row)) == K - 1
+        dr = d[row]
+        assert (np.diff(dr) >= -1e-9 * dr[1:]).all()
+        exp = np.argsort(np.where(np.arange(K) == a, np.inf, d), kind="stable")[:K - 1]
+        assert (row != exp).mean() < 1e-3                                      # only near-ties may swap
+    packed = ops.pack_vq_table(torch.from_numpy(t.view(np.int16)).cuda(), 1008).cpu().numpy().view(np.uint16)
+    assert np.array_equal(packed[:, :1008], t[:, :1008])

@@ -219,13 +219,15 @@ int lantern_evaluate_posterior(const lantern_ep_params *prm, const lantern_ep_bu
 
 /* O7 windowed: same arguments as lantern_cfg_mask_topk, output [rows, win_len] f32 + row_hot [rows].
  * LANTERN_MODEL_PLAIN requires win_lo = 0, win_len = V.  `temperature` (> 1e-5; 1.0 = none) divides the row
- * before the top-k filter (HF order Temperature -> TopK, drafters/utils.py:36-52); out_kind selects what is
- * stored (LANTERN_ROWS_*). */
+ * first, then `top_p` in [1e-8, 1) removes the low tail whose cumulative probability is <= 1 - top_p
+ * (TopPLogitsWarper; 1.0 = off), then top_k -- the HF order Temperature -> TopP -> TopK of
+ * drafters/utils.py:36-52; out_kind selects what is stored (LANTERN_ROWS_*). */
 int lantern_cfg_mask_topk_window(const void *cond, const void *uncond, int dtype, int rows, int V, float cfg,
                                  int model, const int64_t *pos_ids, int64_t pos_base, int w_latent,
                                  int h_latent, int img_lo, int img_hi, int newline_id, int eos_id, int top_k,
                                  const int64_t *seq_len, int rows_per_seq, int win_lo, int win_len,
-                                 float *out_win, int32_t *row_hot, int out_kind, float temperature, void *stream);
+                                 float *out_win, int32_t *row_hot, int out_kind, float temperature, float top_p,
+                                 void *stream);
 
 typedef struct lantern_ep_window {
     int32_t win_lo, win_len;      /* window = token ids [win_lo, win_lo+win_len); win_len % 4 == 0 */

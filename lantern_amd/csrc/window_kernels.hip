@@ -178,6 +178,183 @@ __device__ __forceinline__ void softmax_tile(float4 (&r)[NV4], float *redf, doub
     for (int it = 0; it < NV4; ++it) r[it] = make_float4(dv(r[it].x), dv(r[it].y), dv(r[it].z), dv(r[it].w));
 }
 
+// TopPLogitsWarper on a register tile (HF order: after the temperature, before top-k; drafters/utils.py:36-52 ->
+// transformers TopPLogitsWarper): sort ascending, softmax, cumsum, remove every entry whose cumulative probability is
+// <= 1 - top_p, never the last (largest) one.  No sort here: the removed set is a prefix of the ascending order, so a
+// WEIGHTED radix select over the 32-bit order keys finds its end -- per 8-bit digit, probability mass per bin
+// (LDS f64 atomics), bins walked in ascending order until the running mass (rounded to f32 like torch.cumsum's
+// output) exceeds 1 - top_p.  Equal values at the boundary go in index order (a stable ascending sort), counted with a
+// block scan; that path and the keep-the-last rule only run when they apply.
+template <int NT, int NV4>
+__device__ void top_p_tile(float4 (&r)[NV4], float top_p, double *mass, float *redf, double *redd, int *redi, int &ph) {
+    constexpr int NW = NT / 64;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float NEG_INF = -__builtin_inff();
+    float4 p[NV4];
+#pragma unroll
+    for (int it = 0; it < NV4; ++it) p[it] = r[it];
+    softmax_tile<NT, NV4>(p, redf, redd, ph);
+    const float thr = (float)(1.0 - (double)top_p);
+    uint32_t prefix = 0, kmask = 0;
+    double below = 0.0;
+    bool none_cross = false;
+#pragma unroll 1
+    for (int pass = 0; pass < 4 && !none_cross; ++pass) {
+        const int shift = 24 - 8 * pass;
+        for (int t = tid; t < 256; t += NT) mass[t] = 0.0;
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < NV4; ++it) {
+            const float rv[4] = {r[it].x, r[it].y, r[it].z, r[it].w}, pv[4] = {p[it].x, p[it].y, p[it].z, p[it].w};
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const uint32_t kk = float_key(rv[c]);
+                if (rv[c] != NEG_INF && (kk & kmask) == prefix) atomicAdd(&mass[(kk >> shift) & 255u], (double)pv[c]);
+            }
+        }
+        __syncthreads();
+        const double c0 = mass[4 * lane], c1 = mass[4 * lane + 1], c2 = mass[4 * lane + 2], c3 = mass[4 * lane + 3];
+        const double s4 = (c0 + c1) + (c2 + c3);
+        const double before = below + wave_scan_incl_dpp(dpp_mov<0x138>(s4));      // mass of all lower bins (exclusive scan)
+        int digit = -1;
+        double upto = before;                                                       // mass below the chosen bin
+        if ((float)(before + c0) > thr) digit = 4 * lane;
+        else if ((float)(before + c0 + c1) > thr) { digit = 4 * lane + 1; upto = before + c0; }
+        else if ((float)(before + c0 + c1 + c2) > thr) { digit = 4 * lane + 2; upto = before + c0 + c1; }
+        else if ((float)(before + c0 + c1 + c2 + c3) > thr) { digit = 4 * lane + 3; upto = before + c0 + c1 + c2; }
+        const unsigned long long who = __ballot(digit >= 0);
+        if (who == 0ull) {
+            none_cross = true;          // the whole row's mass stays <= 1 - top_p: everything but the last entry goes
+        } else {
+            const int src = __ffsll((long long)who) - 1;
+            digit = __builtin_amdgcn_readlane(digit, src);
+            const long long ub = __double_as_longlong(upto);
+            below = __longlong_as_double(((long long)__builtin_amdgcn_readlane((int)(ub >> 32), src) << 32) |
+                                         (unsigned int)__builtin_amdgcn_readlane((int)(ub & 0xffffffffll), src));
+            prefix |= (uint32_t)digit << shift;
+            kmask |= 255u << shift;
+        }
+        __syncthreads();
+    }
+    if (none_cross) {
+        // keep only the last entry of the ascending order: the largest key, highest index among equals
+        uint32_t kmax = 0;
+        int imax = -1;
+#pragma unroll
+        for (int it = 0; it < NV4; ++it) {
+            const float rv[4] = {r[it].x, r[it].y, r[it].z, r[it].w};
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const uint32_t kk = float_key(rv[c]);
+                const int idx = (tid + it * NT) * 4 + c;
+                if (kk > kmax || (kk == kmax && idx > imax)) { kmax = kk; imax = idx; }
+            }
+        }
+        // block arg-max of (key, index): two integer reductions
+        int *buf = redi + (ph & 1) * NW;
+        ph ^= 1;
+        const int kw = wave_max_i((int)(kmax >> 1));                     // order-preserving 31-bit compare first
+        if (lane == 0) buf[wave] = kw;
+        __syncthreads();
+        int kb = buf[0];
+        for (int w = 1; w < NW; ++w) kb = max(kb, buf[w]);
+        // (the dropped low bit: resolve among the candidates by the full key)
+        int *buf2 = redi + (ph & 1) * NW;
+        ph ^= 1;
+        const int full = ((int)(kmax >> 1) == kb) ? (int)(kmax & 1u) : -1;
+        const int fw = wave_max_i(full);
+        if (lane == 0) buf2[wave] = fw;
+        __syncthreads();
+        int fb = buf2[0];
+        for (int w = 1; w < NW; ++w) fb = max(fb, buf2[w]);
+        const uint32_t kbest = ((uint32_t)kb << 1) | (uint32_t)fb;
+        int *buf3 = redi + (ph & 1) * NW;
+        ph ^= 1;
+        const int iw = wave_max_i(kmax == kbest ? imax : -1);
+        if (lane == 0) buf3[wave] = iw;
+        __syncthreads();
+        int ib = buf3[0];
+        for (int w = 1; w < NW; ++w) ib = max(ib, buf3[w]);
+#pragma unroll
+        for (int it = 0; it < NV4; ++it) {
+            const int i0 = (tid + it * NT) * 4;
+            r[it].x = (i0 == ib) ? r[it].x : NEG_INF;
+            r[it].y = (i0 + 1 == ib) ? r[it].y : NEG_INF;
+            r[it].z = (i0 + 2 == ib) ? r[it].z : NEG_INF;
+            r[it].w = (i0 + 3 == ib) ? r[it].w : NEG_INF;
+        }
+        __syncthreads();
+        return;
+    }
+    // boundary value = key `prefix`; its holders all carry the same probability p*
+    int tie_cnt[NV4], my_ties = 0;
+    float pstar = 0.0f;
+#pragma unroll
+    for (int it = 0; it < NV4; ++it) {
+        const float rv[4] = {r[it].x, r[it].y, r[it].z, r[it].w}, pv[4] = {p[it].x, p[it].y, p[it].z, p[it].w};
+        tie_cnt[it] = 0;
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            if (rv[c] != NEG_INF && float_key(rv[c]) == prefix) {
+                ++tie_cnt[it];
+                pstar = pv[c];
+            }
+        my_ties += tie_cnt[it];
+    }
+    const int group = block_sum_fast<int, NW>(my_ties, redi, ph);
+    pstar = block_max_fast<NW>(pstar, redf, ph);
+    // how many of the equal entries still fit under the threshold, taken one by one like the cumsum does
+    int m = 0;
+    {
+        double acc = below;
+        for (int j = 1; j < group; ++j) {          // the group's last entry is the one that crossed: at most group-1 go
+            acc += (double)pstar;
+            if ((float)acc <= thr) m = j;
+            else break;
+        }
+    }
+    int base[NV4];
+    if (m > 0) {        // rank of every boundary-valued entry in index order (register tile order = ascending index per `it` slice)
+        __shared__ int s_tie_tot[NV4][NW];
+        int incl[NV4];
+#pragma unroll
+        for (int it = 0; it < NV4; ++it) {
+            incl[it] = wave_scan_incl_dpp(tie_cnt[it]);
+            if (lane == 63) s_tie_tot[it][wave] = incl[it];
+        }
+        __syncthreads();
+        int run = 0;
+#pragma unroll
+        for (int it = 0; it < NV4; ++it) {
+            int woff = 0, tot = 0;
+            for (int w = 0; w < NW; ++w) {
+                const int t = s_tie_tot[it][w];
+                woff += (w < wave) ? t : 0;
+                tot += t;
+            }
+            base[it] = run + woff + (incl[it] - tie_cnt[it]);
+            run += tot;
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int it = 0; it < NV4; ++it) {
+        float rv[4] = {r[it].x, r[it].y, r[it].z, r[it].w};
+        int rank = (m > 0) ? base[it] : 0;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            if (rv[c] == NEG_INF) continue;
+            const uint32_t kk = float_key(rv[c]);
+            if (kk < prefix) rv[c] = NEG_INF;
+            else if (kk == prefix) {
+                if (rank < m) rv[c] = NEG_INF;
+                ++rank;
+            }
+        }
+        r[it] = make_float4(rv[0], rv[1], rv[2], rv[3]);
+    }
+}
+
 // ------------------------------------------------------------------------------- O7 windowed
 template <int NT, int E4, bool BF16>
 __global__ __launch_bounds__(NT) void cfg_window_kernel(const void *__restrict__ cond_, const void *__restrict__ uncond_, int V, float cfg,
@@ -185,10 +362,12 @@ __global__ __launch_bounds__(NT) void cfg_window_kernel(const void *__restrict__
                                                         int h_latent, int img_lo, int img_hi, int newline_id, int eos_id, int top_k,
                                                         const int64_t *__restrict__ seq_len, int rows_per_seq, int win_lo, int W,
                                                         float *__restrict__ out_win, int32_t *__restrict__ row_hot, int out_kind,
-                                                        float temperature) {
+                                                        float temperature, float top_p) {
     __shared__ int s_hist[256];
     __shared__ float s_redf[32];
     __shared__ double s_redd[32];
+    __shared__ int s_redi[32];
+    __shared__ double s_mass[256];
     const int row = blockIdx.x, tid = threadIdx.x;
     const float NEG_INF = -__builtin_inff();
     float *out = out_win + (size_t)row * W;
@@ -254,6 +433,11 @@ __global__ __launch_bounds__(NT) void cfg_window_kernel(const void *__restrict__
             r[it].x = r[it].x / temperature; r[it].y = r[it].y / temperature;
             r[it].z = r[it].z / temperature; r[it].w = r[it].w / temperature;
         }
+    }
+    const bool nucleus = top_p >= 1e-8f && top_p < 1.0f;      // TopPLogitsWarper (HF order: Temperature -> TopP -> TopK)
+    if (nucleus) {
+        int ph = 0;
+        top_p_tile<NT, E4>(r, top_p, s_mass, s_redf, s_redd, s_redi, ph);
     }
     if (top_k > 0 && top_k < V) {
         // k-th largest of the FULL row = k-th largest of the window whenever >= k window entries beat the fill
@@ -1265,20 +1449,21 @@ using namespace lantern;
 template <int NT, int E4>
 static void launch_cfgw(bool bf16, int rows, hipStream_t st, const void *cond, const void *uncond, int V, float cfg, int model,
                         const int64_t *pos_ids, int64_t pos_base, int w, int h, int img_lo, int img_hi, int nl, int eos, int top_k,
-                        const int64_t *seq_len, int rps, int win_lo, int W, float *out, int32_t *hot, int out_kind, float temperature) {
+                        const int64_t *seq_len, int rps, int win_lo, int W, float *out, int32_t *hot, int out_kind, float temperature,
+                        float top_p) {
     if (bf16)
         hipLaunchKernelGGL((cfg_window_kernel<NT, E4, true>), dim3(rows), dim3(NT), 0, st, cond, uncond, V, cfg, model, pos_ids, pos_base, w,
-                           h, img_lo, img_hi, nl, eos, top_k, seq_len, rps, win_lo, W, out, hot, out_kind, temperature);
+                           h, img_lo, img_hi, nl, eos, top_k, seq_len, rps, win_lo, W, out, hot, out_kind, temperature, top_p);
     else
         hipLaunchKernelGGL((cfg_window_kernel<NT, E4, false>), dim3(rows), dim3(NT), 0, st, cond, uncond, V, cfg, model, pos_ids, pos_base, w,
-                           h, img_lo, img_hi, nl, eos, top_k, seq_len, rps, win_lo, W, out, hot, out_kind, temperature);
+                           h, img_lo, img_hi, nl, eos, top_k, seq_len, rps, win_lo, W, out, hot, out_kind, temperature, top_p);
 }
 
 extern "C" int lantern_cfg_mask_topk_window(const void *cond, const void *uncond, int dtype, int rows, int V, float cfg, int model,
                                             const int64_t *pos_ids, int64_t pos_base, int w_latent, int h_latent, int img_lo,
                                             int img_hi, int newline_id, int eos_id, int top_k, const int64_t *seq_len,
                                             int rows_per_seq, int win_lo, int win_len, float *out_win, int32_t *row_hot, int out_kind,
-                                            float temperature, void *stream) {
+                                            float temperature, float top_p, void *stream) {
     LANTERN_CHECK_ARG(cond && out_win && row_hot, "cfg_mask_topk_window: null buffer");
     LANTERN_CHECK_ARG(out_kind == LANTERN_ROWS_LOGITS || out_kind == LANTERN_ROWS_PROBS, "cfg_mask_topk_window: bad out_kind %d", out_kind);
     LANTERN_CHECK_ARG(temperature > 1e-5f, "cfg_mask_topk_window: temperature %g (the greedy branch has its own kernel)", (double)temperature);
@@ -1299,8 +1484,9 @@ extern "C" int lantern_cfg_mask_topk_window(const void *cond, const void *uncond
     if (rows == 0) return LANTERN_OK;
     hipStream_t st = (hipStream_t)stream;
     const bool bf = dtype == LANTERN_BF16;
-#define CW_ARGS bf, rows, st, cond, uncond, V, cfg, model, pos_ids, pos_base, w_latent, h_latent, img_lo, img_hi, newline_id, eos_id, top_k, seq_len, rows_per_seq, win_lo, win_len, out_win, row_hot, out_kind, temperature
-    if (bf && win_len % 8 == 0 && win_len >= 2048 && temperature == 1.0f) {
+#define CW_ARGS bf, rows, st, cond, uncond, V, cfg, model, pos_ids, pos_base, w_latent, h_latent, img_lo, img_hi, newline_id, eos_id, top_k, seq_len, rows_per_seq, win_lo, win_len, out_win, row_hot, out_kind, temperature, top_p
+    const bool nucleus = top_p >= 1e-8f && top_p < 1.0f;
+    if (bf && win_len % 8 == 0 && win_len >= 2048 && temperature == 1.0f && !nucleus) {
         const int chunks = win_len / 8;
         const uint16_t *c16 = (const uint16_t *)cond, *u16 = (const uint16_t *)uncond;
         static const int nt_knob = getenv("LANTERN_O7_NT") ? atoi(getenv("LANTERN_O7_NT")) : 0;   // tuning knob (diagnostic)

@@ -22,7 +22,7 @@ import torch.nn as nn
 from . import ops
 from .drafters.choices import mc_sim_7b_63, naive_extend_57  # noqa: F401
 from .drafters.kv_cache import initialize_past_key_values
-from .verify import (NodeLogits, ProcessorSpec, UniformFifo, as_rows, concat_original_prob, generate_tree_buffers,
+from .verify import (NodeLogits, ProcessorSpec, WindowRows, UniformFifo, as_rows, concat_original_prob, generate_tree_buffers,
                      prepare_logits_processor)
 
 
@@ -40,6 +40,12 @@ class EaModel(nn.Module):
     image_lo, image_hi = 0, 2 ** 31 - 1
     mask_non_image = False
     uniform_window = 4096            # uniforms staged per refill (verify.UniformFifo)
+    # "window": inside generate() the tree rows leave tree_decoding as probabilities over the image-token window with the HF
+    # processors (Temperature -> TopP -> TopK) already applied to every row (one workgroup per row), and evaluate_posterior keeps
+    # the residual in LDS.  "dense": full-vocabulary logit rows, processors inside evaluate_posterior (the reference's order;
+    # top_p < 1 is only built in the windowed set).  Greedy decoding always takes the dense rows (it returns raw logits).
+    kernel_set = "window"
+    _active_proc = None              # ProcessorSpec of the running generate() call (tree_decoding has no processor argument)
     prefix_pad = 120                 # input_ids carries 120 leading zero ids (ea_model_llamagen.py:437,1107)
 
     def __init__(self, base_model, ea_layer, nearest_latents):
@@ -103,6 +109,16 @@ class EaModel(nn.Module):
         outputs, tree_logits, hidden_state = self(input_ids=tree_candidates, output_orig=True, past_key_values=past_key_values,
                                                   position_ids=position_ids, attention_mask=attention_mask)
         half = tree_logits.shape[0] // 2
+        proc = self._active_proc
+        if self.kernel_set == "window" and proc is not None:
+            V = tree_logits.shape[-1]
+            lo, W = (self.image_lo, self.image_hi - self.image_lo) if self.mask_non_image else (0, V)
+            win, hot = ops.cfg_mask_topk_window(tree_logits[0], tree_logits[half], float(cfg_scale), lo, W,
+                                                model=ops.MODEL_ANOLE if self.mask_non_image else ops.MODEL_PLAIN,
+                                                img_lo=self.image_lo if self.mask_non_image else 0,
+                                                img_hi=self.image_hi if self.mask_non_image else V, top_k=min(proc.top_k, V),
+                                                temperature=proc.temperature, top_p=proc.top_p, probs=True)
+            return WindowRows(win, hot, retrieve_indices, V, lo), hidden_state, outputs
         node_logits = ops.cfg_mask_topk(tree_logits[0], tree_logits[half], float(cfg_scale),
                                         model=ops.MODEL_ANOLE if self.mask_non_image else ops.MODEL_PLAIN,
                                         img_lo=self.image_lo if self.mask_non_image else 0,
@@ -111,33 +127,54 @@ class EaModel(nn.Module):
 
     # ------------------------------------------------------------------ O8 dynamic, :709-787 / greedy :789-905
     def evaluate_posterior(self, logits, candidates, logits_processor=None, lantern=False, lantern_k=1000, lantern_delta=0.1):
-        rows, row_index = as_rows(logits)
+        rows, row_index = (None, None) if isinstance(logits, WindowRows) else as_rows(logits)
         if logits_processor is None:
             return self._evaluate_posterior_greedy(rows, row_index, candidates, lantern, lantern_k, lantern_delta)
         proc = ProcessorSpec.from_hf(logits_processor)
         cfg = self._ep_config(False, proc, lantern, lantern_k, lantern_delta)
         fifo = self._uniforms()
         fifo.reserve(candidates.shape[0] * candidates.shape[1])
+        if isinstance(logits, WindowRows):
+            return self._evaluate_posterior_window(logits, cfg, candidates, fifo, lantern, lantern_k, None)
         best, alen, sample_p, counters = ops.evaluate_posterior(cfg, rows.float()[None], row_index, candidates[None], fifo.buf,
                                                                 table=self.nearest_latents if lantern else None,
                                                                 cursor=fifo.cursor)
         ops.raise_on_status(counters)
         return best[0].to(torch.int64), int(alen[0]), sample_p[0]
 
+    def _evaluate_posterior_window(self, logits, cfg, candidates, fifo, lantern, lantern_k, aux):
+        cfg.temperature, cfg.top_p, cfg.top_k = 1.0, 1.0, 0          # the rows are final probabilities (tree_decoding applied the processors)
+        out = ops.evaluate_posterior_window(cfg, logits.V, logits.win[None], logits.win_lo, logits.row_index(), candidates[None], fifo.buf,
+                                            row_hot=logits.row_hot[None], table=self._packed_table(int(lantern_k)) if lantern else None,
+                                            aux=aux, cursor=fifo.cursor, want_dense=True, want_window=False, rows_probs=True)
+        ops.raise_on_status(out["counters"])
+        return out["best"][0].to(torch.int64), int(out["accept_len"][0]), out["sample_p"][0]
+
+    def _packed_table(self, k: int) -> torch.Tensor:
+        cols = -(-(k + 1) // 8) * 8
+        if cols > min(1024, self.nearest_latents.shape[1]):
+            return self.nearest_latents
+        cache = self.__dict__.setdefault("_packed_tables", {})
+        if cols not in cache:
+            cache[cols] = ops.pack_vq_table(self.nearest_latents, cols)
+        return cache[cols]
+
     # ------------------------------------------------------------------ O8 static, :464-669
     def evaluate_posterior_v1(self, logits, candidates, logits_processor, cart_candidates_prob, op, p_indices, tree_candidates,
                               b_indices, lantern=False, lantern_k=1000, lantern_delta=0.1):
-        rows, row_index = as_rows(logits)
+        rows, row_index = (None, None) if isinstance(logits, WindowRows) else as_rows(logits)
         if logits_processor is None:
             return self._evaluate_posterior_greedy(rows, row_index, candidates, lantern, lantern_k, lantern_delta)
         proc = ProcessorSpec.from_hf(logits_processor)
         cfg = self._ep_config(True, proc, lantern, lantern_k, lantern_delta)
         hip = self.tree_buffers["_hip"]
-        aux = ops.StaticAux(cart_prob=cart_candidates_prob.to(rows.device).float()[None], orig_prob=concat_original_prob(op),
+        aux = ops.StaticAux(cart_prob=cart_candidates_prob.to(logits.device).float()[None], orig_prob=concat_original_prob(op),
                             op_off=hip["op_off"], p_idx=hip["p_idx"], b_off=hip["b_off"], b_idx=hip["b_idx"],
                             tree_cand=tree_candidates[:1].reshape(1, -1)[:, :hip["N"]])
         fifo = self._uniforms()
         fifo.reserve(candidates.shape[0] * candidates.shape[1])
+        if isinstance(logits, WindowRows):
+            return self._evaluate_posterior_window(logits, cfg, candidates, fifo, lantern, lantern_k, aux)
         best, alen, sample_p, counters = ops.evaluate_posterior(cfg, rows.float()[None], row_index, candidates[None], fifo.buf,
                                                                 table=self.nearest_latents if lantern else None, aux=aux,
                                                                 cursor=fifo.cursor)
@@ -237,6 +274,7 @@ class EaModel(nn.Module):
         padding = (torch.zeros(1, 1, dtype=torch.long) - 1).to(dev)
         self.ea_layer.reset_kv()
         logits_processor = prepare_logits_processor(temperature=temperature, top_k=top_k, top_p=top_p) if temperature > 1e-5 else None
+        self._active_proc = ProcessorSpec.from_hf(logits_processor)
         if static_tree:
             if not (hasattr(self, "tree_choices") and self.tree_choices == tree_choices):
                 self.tree_buffers = self.generate_tree_buffers(tree_choices, device=dev)

@@ -460,7 +460,7 @@ class LuminaVerifyWorkload:
             check(L.lantern_cfg_mask_topk_window(A["cond"], A["uncond"], 1, B * N, V, C.c_float(c.cfg_scale), ops.MODEL_LUMINA,
                                                  vp(self.d_pos_ids.data_ptr()), C.c_int64(c.prompt_len + 3), W_LATENT, H_LATENT, IMG_LO, IMG_HI,
                                                  NEWLINE, EOS, c.top_k, A["cur"], N, self.win_lo, self.W, A["proc"], A["row_hot"],
-                                                 ops.ROWS_PROBS if c.rows_probs else ops.ROWS_LOGITS, C.c_float(1.0), st),
+                                                 ops.ROWS_PROBS if c.rows_probs else ops.ROWS_LOGITS, C.c_float(1.0), C.c_float(1.0), st),
                   "cfg_mask_topk_window")
         else:
             check(L.lantern_cfg_mask_topk(A["cond"], A["uncond"], 1, B * N, V, C.c_float(c.cfg_scale), ops.MODEL_LUMINA,

@@ -302,7 +302,8 @@ def evaluate_posterior(cfg: EpConfig, logits, row_index, cand, uniforms, table=N
 
 
 _STATUS = {1: "candidate token outside [0,V)", 2: "uniform stream exhausted", 3: "token outside the neighbour table",
-           4: "image syntax token rejected (reference assert, ea_model_lumina_mgpt.py:694)", 5: "no path matches the accepted prefix"}
+           4: "image syntax token rejected (reference assert, ea_model_lumina_mgpt.py:694)", 5: "no path matches the accepted prefix",
+           6: "residual distribution vanished (`gtp.sum()==0 -> ones` is uniform over all V): only the dense kernel set represents it"}
 
 
 def raise_on_status(counters: torch.Tensor):
@@ -450,7 +451,7 @@ def evaluate_posterior_greedy(logits, row_index, cand, lantern=False, k=1000, de
 def cfg_mask_topk_window(cond, uncond, cfg: float, win_lo: int, win_len: int, model: int = MODEL_PLAIN, pos_ids=None,
                          pos_base: int = 0, w: int = 48, h: int = 48, img_lo: int = 4, img_hi: int = 8196, newline_id: int = 8803,
                          eos_id: int = 8196, top_k: int = 0, seq_len=None, rows_per_seq: int = 0, out=None, row_hot=None,
-                         probs: bool = False, temperature: float = 1.0):
+                         probs: bool = False, temperature: float = 1.0, top_p: float = 1.0):
     """O7 windowed: (out_win [rows,win_len] f32, row_hot [rows] i32).  probs=True: rows leave as softmax probabilities
     (temperature -> top-k -> softmax applied here, to every row); pass rows_probs=True to evaluate_posterior_window."""
     if not cond.is_cuda:
@@ -469,7 +470,7 @@ def cfg_mask_topk_window(cond, uncond, cfg: float, win_lo: int, win_len: int, mo
         C.c_void_p(cond.data_ptr()), C.c_void_p(_ptr(uncond)), 1 if cond.dtype == torch.bfloat16 else 0, rows, V, C.c_float(cfg),
         model, C.c_void_p(_ptr(pos)), C.c_int64(pos_base), w, h, img_lo, img_hi, newline_id, eos_id, top_k,
         C.c_void_p(_ptr(seq_len)), rows_per_seq, win_lo, win_len, C.c_void_p(out.data_ptr()), C.c_void_p(row_hot.data_ptr()),
-        ROWS_PROBS if probs else ROWS_LOGITS, C.c_float(temperature), _stream()), "cfg_mask_topk_window")
+        ROWS_PROBS if probs else ROWS_LOGITS, C.c_float(temperature), C.c_float(top_p), _stream()), "cfg_mask_topk_window")
     return out, row_hot
 
 

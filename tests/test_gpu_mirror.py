@@ -6,11 +6,12 @@ import types
 
 import numpy as np
 import pytest
+from lantern_amd._lib import LanternError
 import torch
 
 import cases as CS
 import helpers as H
-from lantern_amd import ea_model_anole, ea_model_llamagen, ea_model_lumina_mgpt, verify
+from lantern_amd import ea_model_anole, ea_model_llamagen, ea_model_lumina_mgpt, ops, verify
 
 pytestmark = pytest.mark.gpu
 SPECS = H.ep_specs()
@@ -125,6 +126,51 @@ def test_llamagen_anole_mirror_evaluate_posterior(i, monkeypatch):
         monkeypatch.setattr(random, "random", Stream(uniforms))
         best, alen, sp = mdl.evaluate_posterior(logits, cuda(case["cand"]), proc, lantern=spec["lantern"], lantern_k=spec["k"],
                                                 lantern_delta=spec["delta"])
+    assert int(best) == int(case["best"]) and alen == int(case["accept_len"])
+    np.testing.assert_allclose(sp.cpu().numpy(), case["sample_p"], rtol=0, atol=1e-5)
+
+
+@pytest.mark.parametrize("i", [i for i, s in enumerate(SPECS) if s["model"] in ("llamagen", "anole") and s["kind"] in ("static", "dynamic")
+                               and not s.get("plain_eagle")])
+def test_llamagen_anole_mirror_window_kernel_set(i, monkeypatch):
+    """The windowed kernel set behind the same mirror methods: tree rows leave O7w as probabilities with the HF processors
+    (Temperature -> TopP -> TopK, top_p < 1 included) applied to every row, evaluate_posterior[_v1] receives WindowRows."""
+    spec, case = SPECS[i], H.ep_case(i)
+    m = CS.MODELS[spec["model"]]
+    anole = spec["model"] == "anole"
+    cls = ea_model_anole.EaModel if anole else ea_model_llamagen.EaModel
+    mdl = cls(fake_base(m["V"]), None, H.table(m["K"]))
+    mdl.uniform_window = 64
+    if anole:
+        mdl.image_lo, mdl.image_hi = m["img_lo"], m["img_hi"]
+    T, tk, tp = spec.get("temperature", 1.0), spec.get("top_k", 0), spec.get("top_p", 1.0)
+    proc = verify.ProcessorSpec(temperature=T, top_p=tp if 0 < tp < 1 else 1.0, top_k=tk)
+    lo, W = (m["img_lo"], m["img_hi"] - m["img_lo"]) if anole else (0, m["V"])
+
+    def rows_of(nl, retrieve):
+        win, hot = ops.cfg_mask_topk_window(cuda(nl), None, 1.0, lo, W, model=ops.MODEL_ANOLE if anole else ops.MODEL_PLAIN,
+                                            img_lo=lo, img_hi=lo + W, top_k=min(tk, m["V"]), temperature=T, top_p=proc.top_p, probs=True)
+        return verify.WindowRows(win, hot, retrieve, m["V"], lo)
+    try:
+        if spec["kind"] == "static":
+            tb, g = H.static_inputs(spec, case)
+            mdl.tree_buffers = mdl.generate_tree_buffers(H.tree_choices(spec["tree"]), device="cuda")
+            tbuf = mdl.tree_buffers
+            offs = list(g["op_off"]) + [g["R"]]
+            op_list = [cuda(g["orig_prob"][offs[d]:offs[d + 1]]) for d in range(len(offs) - 1)]
+            monkeypatch.setattr(random, "random", Stream(case["uniforms"]))
+            tcand = cuda(case["tree_cand"])[None]
+            best, alen, sp = mdl.evaluate_posterior_v1(rows_of(g["node_logits"], tbuf["retrieve_indices"]), cuda(case["cand"]), proc,
+                                                       cuda(case["cart_prob"]), op_list, tbuf["p_indices"], torch.cat([tcand, tcand]),
+                                                       tbuf["b_indices"], spec["lantern"], spec["k"], spec["delta"])
+        else:
+            nl, uniforms = H.dynamic_node_logits(spec, case)
+            monkeypatch.setattr(random, "random", Stream(uniforms))
+            best, alen, sp = mdl.evaluate_posterior(rows_of(nl, cuda(case["retrieve"])), cuda(case["cand"]), proc, lantern=spec["lantern"],
+                                                    lantern_k=spec["k"], lantern_delta=spec["delta"])
+    except LanternError as e:
+        assert "dense" in str(e).lower() and spec["k"] >= m["K"] - 2      # `gtp.sum()==0 -> ones`: only the dense kernel holds it
+        return
     assert int(best) == int(case["best"]) and alen == int(case["accept_len"])
     np.testing.assert_allclose(sp.cpu().numpy(), case["sample_p"], rtol=0, atol=1e-5)
 

@@ -254,3 +254,49 @@ def test_cfg_window_probs_and_temperature(dtype):
         assert torch.equal(lg.cpu(), x)
         assert int(torch.isfinite(lg).sum(-1).min()) >= k
         np.testing.assert_allclose(pr.cpu().numpy(), torch.softmax(x.double(), -1).float().numpy(), rtol=0, atol=1e-7)
+
+
+def _top_p_ref(x, top_p):
+    """TopPLogitsWarper with the oracle's tie rule (stable ascending sort) and torch.cumsum's f32 outputs."""
+    out = x.copy()
+    for r in range(x.shape[0]):
+        order = np.lexsort((np.arange(x.shape[1]), x[r]))
+        sv = x[r][order].astype(np.float64)
+        e = np.exp((sv - sv.max()).astype(np.float32)).astype(np.float32)
+        p = (e / np.float32(e.astype(np.float64).sum())).astype(np.float32)
+        cum = np.cumsum(p.astype(np.float64)).astype(np.float32)
+        rm = cum <= np.float32(1.0 - top_p)
+        rm[-1] = False
+        out[r, order[rm]] = -np.inf
+    return out
+
+
+@pytest.mark.parametrize("top_p", [0.9, 0.5, 0.05, 1e-8])
+@pytest.mark.parametrize("ties", [False, True])
+def test_cfg_window_top_p(top_p, ties):
+    """TopPLogitsWarper inside O7w (Temperature -> TopP -> TopK), rows with and without equal values at the boundary."""
+    V, T, k = 4096, 0.8, 300
+    rs = np.random.RandomState(11 + int(ties))
+    x = (3 * rs.standard_normal((6, V))).astype(np.float32)
+    if ties:
+        x = np.round(x * 4) / 4            # heavy ties: groups of equal logits everywhere
+    c = torch.from_numpy(x).cuda()
+    got, _ = ops.cfg_mask_topk_window(c, None, 1.0, 0, V, model=ops.MODEL_PLAIN, top_k=0, temperature=T, top_p=top_p)
+    ref = _top_p_ref((x / np.float32(T)).astype(np.float32), top_p)
+    g = got.cpu().numpy()
+    kept_g, kept_r = np.isfinite(g), np.isfinite(ref)
+    assert (kept_g.sum(1) >= 1).all()
+    mism = (kept_g != kept_r)
+    # the block-parallel mass sums differ from the sequential cumsum in the last f64 bits: at most the boundary entry may flip
+    assert mism.sum(1).max() <= 1, mism.sum(1)
+    if top_p in (0.9, 0.5):
+        assert mism.sum() == 0
+    assert np.array_equal(g[kept_g & kept_r], ref[kept_g & kept_r])
+    # and with top-k behind it + probabilities out
+    pr, _ = ops.cfg_mask_topk_window(c, None, 1.0, 0, V, model=ops.MODEL_PLAIN, top_k=k, temperature=T, top_p=top_p, probs=True)
+    y = torch.from_numpy(ref)
+    kk = min(k, int(np.isfinite(ref).sum(1).min()))
+    kth = torch.topk(y, k, dim=-1).values[..., -1:]
+    y = y.masked_fill(y < kth, float("-inf"))
+    if mism.sum() == 0:
+        np.testing.assert_allclose(pr.cpu().numpy(), torch.softmax(y.double(), -1).float().numpy(), rtol=0, atol=1e-6)

@@ -327,6 +327,14 @@ int lantern_drafter_fc(const int64_t *ids, const void *hidden, const void *embed
                        const void *bias, int M, int H, int vocab, float embed_scale, void *out,
                        void *stream);
 
+/* a5  the drafter's additive attention mask in one launch.  Replaces Model._prepare_decoder_attention_mask
+ * (models/drafters/cnets_lumina_mgpt.py:1014-1050; cnets_llamagen.py:592-621): causal (when T > 1) + padding from the
+ * boolean mask attn [dev] [B, attn_len] (bytes; columns >= attn_len count as attended, as the reference pads) or NULL,
+ * then finfo(f32).min wherever tree_mask [dev] [tree_batch,1,t0,t1] f32 (tree_batch 1 = shared, or B) is zero in the
+ * last t0 rows x last t1 columns.  out [dev] [B,1,T,past+T] f32. */
+int lantern_drafter_attention_mask(const uint8_t *attn, int attn_len, const float *tree_mask, int tree_batch, int t0,
+                                   int t1, int B, int T, int past, float *out, void *stream);
+
 /* 8f-1 VQ-distance neighbour table: cdist + per-row ascending order, self excluded.
  * Replaces entrypoints/generate_codebook.py:53-65.  codebook [dev] [K,C] f32 ->
  * table [dev] [K,K-1] u16, K <= 16384 (LlamaGen).  workspace: unused (NULL). */

@@ -121,9 +121,54 @@ __global__ __launch_bounds__(FC_THREADS) void drafter_fc_kernel(const int64_t *_
     }
 }
 
+// a5: Model._prepare_decoder_attention_mask (cnets_lumina_mgpt.py:1014-1050, cnets_llamagen.py:592-621) in one launch:
+// out[b,0,i,j] = padding(b,j) + causal(i,j) with padding = 0 / finfo.min from the boolean mask (columns beyond its length
+// count as attended), causal = finfo.min for j - past > i when T > 1 (the reference ADDS the two, so a position masked by
+// both is -inf), then finfo.min wherever the tree mask (last t0 rows x last t1 columns) is zero.
+__global__ void drafter_mask_kernel(const uint8_t *__restrict__ attn, int attn_len, const float *__restrict__ tree, int tree_batch,
+                                    int t0, int t1, int B, int T, int past, float *__restrict__ out) {
+    const int S = past + T;
+    const float FMIN = -3.4028234663852886e38f;
+    const size_t total = (size_t)B * T * S;
+    for (size_t w = (size_t)blockIdx.x * blockDim.x + threadIdx.x; w < total; w += (size_t)gridDim.x * blockDim.x) {
+        const int j = (int)(w % S), i = (int)((w / S) % T), b = (int)(w / ((size_t)S * T));
+        float v = 0.0f;
+        bool have = false;
+        if (T > 1) {
+            v = (j - past > i) ? FMIN : 0.0f;
+            have = true;
+        }
+        if (attn) {
+            const bool keep = j >= attn_len || attn[(size_t)b * attn_len + j] != 0;
+            const float a = keep ? 0.0f : FMIN;
+            v = have ? a + v : a;
+        }
+        if (tree && i >= T - t0 && j >= S - t1) {
+            const int tb = tree_batch > 1 ? b : 0;
+            if (tree[((size_t)tb * t0 + (i - (T - t0))) * t1 + (j - (S - t1))] == 0.0f) v = FMIN;
+        }
+        out[w] = v;
+    }
+}
+
 }  // namespace lantern
 
 using namespace lantern;
+
+extern "C" int lantern_drafter_attention_mask(const uint8_t *attn, int attn_len, const float *tree_mask, int tree_batch, int t0, int t1,
+                                              int B, int T, int past, float *out, void *stream) {
+    LANTERN_CHECK_ARG(out && B > 0 && T > 0 && past >= 0, "drafter_attention_mask: bad sizes");
+    LANTERN_CHECK_ARG(attn || T > 1, "drafter_attention_mask: no padding mask and a single query row: the reference builds no mask");
+    if (tree_mask) LANTERN_CHECK_ARG(t0 > 0 && t1 > 0 && t0 <= T && t1 <= past + T && (tree_batch == 1 || tree_batch == B),
+                                     "drafter_attention_mask: tree mask [%d,1,%d,%d] does not fit [%d,1,%d,%d]", tree_batch, t0, t1, B, T, past + T);
+    const size_t total = (size_t)B * T * (past + T);
+    int gx = (int)((total + 255) / 256);
+    if (gx > 4096) gx = 4096;
+    hipLaunchKernelGGL(drafter_mask_kernel, dim3(gx), dim3(256), 0, (hipStream_t)stream, attn, attn_len, tree_mask, tree_batch, t0, t1, B, T,
+                       past, out);
+    LANTERN_CHECK_LAUNCH("drafter_attention_mask");
+    return LANTERN_OK;
+}
 
 extern "C" int lantern_drafter_fc(const int64_t *ids, const void *hidden, const void *embed, const void *W, const void *bias, int M, int H,
                                   int vocab, float embed_scale, void *out, void *stream) {

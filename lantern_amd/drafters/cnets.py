@@ -1,0 +1,429 @@
+"""Host mirror of the reference's drafter `Model` (models/drafters/cnets_lumina_mgpt.py:957-1392,
+cnets_llamagen.py:509-1023, cnets_anole.py) for the verify/accept path: same method names, argument meaning and
+return values -- `init_tree`, `init_tree_v1`, `reset`, `reset_kv`, `forward`, `_prepare_decoder_attention_mask`,
+`repeat_hidden`, `sample`, `topK_genrate` / `topK_genrate_v1` (LlamaGen / Anole calling convention, the reference's
+spelling) and `topK_generate(tree_type=...)` (Lumina-mGPT calling convention).
+
+What runs where:
+  * input stage `fc(cat(embed[ids] * upscale, hidden))`            -> lantern_drafter_fc (MFMA, bf16)
+  * additive attention mask (causal + padding + tree)              -> lantern_drafter_attention_mask
+  * CFG combine + model mask + HF processors on the head's logits  -> lantern_cfg_mask_topk_window
+  * log-softmax / top-k / cumulative scores / best-10-of-100       -> lantern_expand_dynamic
+  * top-(N-1) + tree mask / positions / retrieve rows              -> lantern_tree_dynamic_finalize
+  * static drafter buffers (masks, tree_indices, repeat_nums)      -> lantern_tree_drafter_build
+  * conditional probabilities of the k samples w/o replacement     -> lantern_sample_static
+The decoder layer(s) between the input stage and the head are the drafter's transformer (GEMM-bound, out of this
+path's scope): they are INJECTED -- any module with the reference layer's call signature, e.g. the reference's own
+`ChameleonDecoderLayer` / `LlamaDecoderLayer` loaded from its checkpoint -- and default to a plain-torch Llama-style
+layer so the class runs stand-alone.
+"""
+from __future__ import annotations
+
+import math
+from typing import List, Optional
+
+import torch
+from torch import nn
+
+from .. import ops
+
+TOPK = 10
+
+
+# ----------------------------------------------------------------------------- default decoder layer (plain torch)
+class _RMSNorm(nn.Module):
+    def __init__(self, hidden_size, eps=1e-6):
+        super().__init__()
+        self.weight = nn.Parameter(torch.ones(hidden_size))
+        self.variance_epsilon = eps
+
+    def forward(self, x):
+        dt = x.dtype
+        x = x.float()
+        x = x * torch.rsqrt(x.pow(2).mean(-1, keepdim=True) + self.variance_epsilon)
+        return self.weight * x.to(dt)
+
+
+def _rope(x, pos, base):
+    d = x.shape[-1]
+    inv = 1.0 / (base ** (torch.arange(0, d, 2, device=x.device, dtype=torch.float32) / d))
+    ang = pos[..., None].float() * inv                      # [B,T,d/2]
+    cos, sin = torch.cat((ang, ang), -1).cos()[:, None], torch.cat((ang, ang), -1).sin()[:, None]
+    x1, x2 = x[..., :d // 2], x[..., d // 2:]
+    return (x.float() * cos + torch.cat((-x2, x1), -1).float() * sin).to(x.dtype)
+
+
+class TorchDecoderLayer(nn.Module):
+    """Llama-style pre-norm decoder layer (EAGLE drops the input norm of layer 0); HF parameter names."""
+
+    def __init__(self, config, index: int = 0):
+        super().__init__()
+        H = config.hidden_size
+        self.num_heads = config.num_attention_heads
+        self.num_kv = getattr(config, "num_key_value_heads", self.num_heads)
+        self.head_dim = H // self.num_heads
+        self.rope_theta = getattr(config, "rope_theta", 10000.0)
+        self.index = index
+        attn = nn.Module()
+        attn.q_proj = nn.Linear(H, self.num_heads * self.head_dim, bias=False)
+        attn.k_proj = nn.Linear(H, self.num_kv * self.head_dim, bias=False)
+        attn.v_proj = nn.Linear(H, self.num_kv * self.head_dim, bias=False)
+        attn.o_proj = nn.Linear(self.num_heads * self.head_dim, H, bias=False)
+        self.self_attn = attn
+        mlp = nn.Module()
+        I = config.intermediate_size
+        mlp.gate_proj, mlp.up_proj, mlp.down_proj = nn.Linear(H, I, bias=False), nn.Linear(H, I, bias=False), nn.Linear(I, H, bias=False)
+        self.mlp = mlp
+        if index != 0:
+            self.input_layernorm = _RMSNorm(H, getattr(config, "rms_norm_eps", 1e-6))
+        self.post_attention_layernorm = _RMSNorm(H, getattr(config, "rms_norm_eps", 1e-6))
+
+    def forward(self, hidden_states, attention_mask=None, position_ids=None, past_key_value=None, output_attentions=False,
+                use_cache=False, **_):
+        B, T, H = hidden_states.shape
+        x = self.input_layernorm(hidden_states) if self.index != 0 else hidden_states
+        a = self.self_attn
+        q = a.q_proj(x).view(B, T, self.num_heads, self.head_dim).transpose(1, 2)
+        k = a.k_proj(x).view(B, T, self.num_kv, self.head_dim).transpose(1, 2)
+        v = a.v_proj(x).view(B, T, self.num_kv, self.head_dim).transpose(1, 2)
+        pos = position_ids.expand(B, T) if position_ids.dim() == 2 else position_ids[None].expand(B, T)
+        q, k = _rope(q, pos, self.rope_theta), _rope(k, pos, self.rope_theta)
+        if past_key_value is not None:
+            k, v = torch.cat([past_key_value[0], k], dim=2), torch.cat([past_key_value[1], v], dim=2)
+        present = (k, v) if use_cache else None
+        rep = self.num_heads // self.num_kv
+        kk, vv = (k.repeat_interleave(rep, 1), v.repeat_interleave(rep, 1)) if rep > 1 else (k, v)
+        w = torch.matmul(q, kk.transpose(2, 3)) / math.sqrt(self.head_dim)
+        if attention_mask is not None:
+            w = w + attention_mask
+        w = torch.softmax(w, dim=-1, dtype=torch.float32).to(q.dtype)
+        o = torch.matmul(w, vv).transpose(1, 2).reshape(B, T, H)
+        hidden_states = hidden_states + a.o_proj(o)
+        y = self.post_attention_layernorm(hidden_states)
+        m = self.mlp
+        hidden_states = hidden_states + m.down_proj(torch.nn.functional.silu(m.gate_proj(y)) * m.up_proj(y))
+        out = (hidden_states,)
+        if use_cache:
+            out += (present,)
+        return out
+
+
+# ----------------------------------------------------------------------------- the drafter
+class Model(nn.Module):
+    """`model_type`: "lumina_mgpt" | "llamagen" | "anole" selects the logit post-processing of the head's output
+    (SURVEY 8a-bis): Lumina -> position-dependent MultiModalLogitsProcessor + top-k; LlamaGen -> HF processors; Anole ->
+    non-image ids to finfo.min, then HF processors."""
+
+    def __init__(self, config, layers: Optional[List[nn.Module]] = None, bias=True, total_tokens=63, depth=5, top_k=8, threshold=1.0,
+                 embed_upscale=1.0, model_type="lumina_mgpt", image_lo=4, image_hi=8196):
+        super().__init__()
+        self.padding_idx = getattr(config, "pad_token_id", None)
+        self.vocab_size = config.vocab_size
+        self.embed_tokens = nn.Embedding(config.vocab_size, config.hidden_size, self.padding_idx)
+        self.top_k = top_k
+        self.total_tokens = total_tokens - 1
+        self.depth = depth
+        self.threshold = math.log(threshold)
+        self.embed_upscale = embed_upscale
+        n_layers = getattr(config, "num_hidden_layers", 1)
+        self.layers = nn.ModuleList(layers if layers is not None else [TorchDecoderLayer(config, i) for i in range(n_layers)])
+        self.fc = nn.Linear(2 * config.hidden_size, config.hidden_size, bias=bias)
+        self.logsoftmax = nn.LogSoftmax(dim=-1)
+        self.model_type, self.image_lo, self.image_hi = model_type, image_lo, image_hi
+        self.cfg_scale = 3.0
+        self.tree_mask = None
+        self.stable_kv = None
+        self.layer_kwargs = None          # optional callable(position_ids) -> extra kwargs for injected layers (LlamaGen: freqs_cis)
+        for p in self.embed_tokens.parameters():
+            p.requires_grad = False
+
+    # ------------------------------------------------------------------ tree state (cnets_lumina_mgpt.py:1000-1012)
+    def init_tree(self, tree=None):
+        dev = self.embed_tokens.weight.device
+        if tree is not None:                                   # EAGLE v1: static drafter buffers
+            self.tree = tree
+            tb = ops.tree_drafter_build(tree, TOPK)
+            t = lambda a: torch.from_numpy(a).to(dev)
+            self.tree_buffer = dict(attn_mask=[t(m)[None, None] for m in tb["attn_mask"]], tree_indices=[t(x) for x in tb["tree_indices"]],
+                                    position_ids=[t(x) for x in tb["position_ids"]], repeat_nums=tb["repeat_nums"])
+        else:                                                  # EAGLE v2
+            self.tree_mask_init = torch.eye(self.top_k, device=dev)[None, None]
+            self.position_ids = torch.zeros(self.top_k, device=dev, dtype=torch.long)
+
+    def init_tree_v1(self, tree_choices):                      # cnets_llamagen.py:914-916
+        self.init_tree(tree_choices)
+
+    def reset(self):
+        self.tree_mask = None
+
+    def reset_kv(self):
+        self.stable_kv = None
+
+    # ------------------------------------------------------------------ a5
+    def _prepare_decoder_attention_mask(self, attention_mask, input_shape, inputs_embeds, past_key_values_length):
+        B, T = input_shape
+        tm = self.tree_mask if getattr(self, "tree_mask", None) is not None else None
+        if attention_mask is None and T == 1 and tm is None:
+            return None
+        return ops.drafter_attention_mask(attention_mask, tm, B, T, past_key_values_length, device=inputs_embeds.device)
+
+    def _input_stage(self, hidden_states, input_ids):
+        """embed_tokens(ids) -> cast -> x upscale -> fc(cat(embeds, hidden)) (cnets_lumina_mgpt.py:1071,1095-1098)."""
+        B, T, H = hidden_states.shape
+        w = self.fc.weight
+        if hidden_states.dtype == torch.bfloat16 and w.dtype == torch.bfloat16 and H % 16 == 0:
+            emb = self.embed_tokens.weight
+            emb = emb if emb.dtype == torch.bfloat16 else emb.to(torch.bfloat16)
+            ids, hid = input_ids.reshape(-1), hidden_states.reshape(B * T, H)
+            out = torch.empty_like(hid)
+            for s in range(0, B * T, 128):                     # one drafter call is <= ~120 rows; prefills go in slices
+                out[s:s + 128] = ops.drafter_fc(ids[s:s + 128], hid[s:s + 128], emb, w, self.fc.bias,
+                                                embed_scale=float(self.embed_upscale) if self.embed_upscale > 1.0 else 1.0)
+            return out.view(B, T, H)
+        # other dtypes (f32 checkpoints in tests): the same arithmetic in torch on the device
+        e = self.embed_tokens(input_ids).to(hidden_states.dtype)
+        if self.embed_upscale > 1.0:
+            e = e * self.embed_upscale
+        return self.fc(torch.cat((e, hidden_states), dim=-1))
+
+    def forward(self, hidden_states, input_ids, attention_mask=None, position_ids=None, past_key_values=None, inputs_embeds=None,
+                use_cache=None, output_attentions=None, output_hidden_states=None, return_dict=None, std=None):
+        B, T, _ = hidden_states.shape
+        past = past_key_values[0][0].shape[2] if past_key_values is not None else 0
+        if position_ids is None:
+            position_ids = torch.arange(past, T + past, dtype=torch.long, device=hidden_states.device)[None].view(-1, T)
+        else:
+            position_ids = position_ids.view(-1, T).long()
+        if attention_mask is None:
+            attention_mask = torch.ones((B, T + past), dtype=torch.bool, device=hidden_states.device)
+        mask = self._prepare_decoder_attention_mask(attention_mask, (B, T), hidden_states, past)
+        hidden_states = self._input_stage(hidden_states, input_ids.to(hidden_states.device))
+        extra = self.layer_kwargs(position_ids) if self.layer_kwargs is not None else {}
+        cache = () if use_cache else None
+        for idx, layer in enumerate(self.layers):
+            pkv = past_key_values[idx] if past_key_values is not None else None
+            outs = layer(hidden_states, attention_mask=mask, position_ids=position_ids, past_key_value=pkv, output_attentions=output_attentions,
+                         use_cache=use_cache, **extra)
+            hidden_states = outs[0]
+            if use_cache:
+                cache += (outs[2 if output_attentions else 1],)
+        return (hidden_states, cache) if use_cache else hidden_states
+
+    # ------------------------------------------------------------------ helpers of the tree loops
+    def repeat_hidden(self, hidden_states, num_repeat):      # cnets_lumina_mgpt.py:930-934
+        reps = torch.as_tensor(num_repeat, device=hidden_states.device)
+        return torch.repeat_interleave(hidden_states[:, :len(num_repeat)], reps, dim=1)
+
+    def sample(self, logits, logits_processor=None, k=1):
+        """k draws without replacement + their conditional probabilities p_i / (1 - sum_{j<i} p_j) (cnets_lumina_mgpt.py:936-955)."""
+        if logits_processor is not None and not isinstance(logits_processor, (list, tuple)):
+            logits = logits_processor(None, logits)
+        logits = logits.float()
+        probs = torch.softmax(logits.view(-1, logits.shape[-1]), dim=-1)
+        idx = torch.multinomial(probs, k, replacement=False)
+        return idx, ops.sample_static(probs, idx), probs
+
+    def _post_head(self, cond, uncond, proc, pos_ids=None, pos_base=2):
+        """CFG combine + the model's mask + its processors on the head's rows -> processed logits [R,V] f32 (dense rows: the tree
+        ops and the verify side index them by token id)."""
+        V = cond.shape[-1]
+        cond, uncond = cond.reshape(-1, V).contiguous(), uncond.reshape(-1, V).contiguous()
+        if self.model_type == "lumina_mgpt":
+            # MultiModalLogitsProcessor (position-dependent) + InterleavedTopKLogitsWarper, cnets_lumina_mgpt.py:1216-1224,1291-1298
+            top_k = min(int(proc[1].image_top_k), V) if (proc is not None and len(proc) > 1) else 0
+            if pos_ids is None:
+                return ops.cfg_mask_topk(cond, uncond, float(self.cfg_scale), model=ops.MODEL_PLAIN, top_k=top_k)
+            return ops.cfg_mask_topk(cond, uncond, float(self.cfg_scale), model=ops.MODEL_LUMINA, pos_ids=pos_ids.reshape(-1),
+                                     pos_base=pos_base, img_lo=self.image_lo, img_hi=self.image_hi, top_k=top_k)
+        from ..verify import ProcessorSpec
+        spec = ProcessorSpec.from_hf(proc) or ProcessorSpec()
+        if self.model_type == "anole":                         # non-image ids -> finfo.min (cnets_anole.py:837,878), then the HF list
+            lo, W = self.image_lo, self.image_hi - self.image_lo
+            win, _ = ops.cfg_mask_topk_window(cond, uncond, float(self.cfg_scale), lo, W, model=ops.MODEL_ANOLE, img_lo=lo, img_hi=lo + W,
+                                              top_k=min(spec.top_k, V), temperature=spec.temperature, top_p=spec.top_p)
+            out = torch.full((win.shape[0], V), float("-inf"), dtype=torch.float32, device=win.device)
+            out[:, lo:lo + W] = win
+            return out
+        return ops.cfg_mask_topk_window(cond, uncond, float(self.cfg_scale), 0, V, model=ops.MODEL_PLAIN, top_k=min(spec.top_k, V),
+                                        temperature=spec.temperature, top_p=spec.top_p)[0]
+
+    def _finalize_dynamic(self, scores_list, ss_token, parents_list, sample_token, sort_rows):
+        draft, mask, pos, ret, nl, md = ops.tree_dynamic_finalize(torch.cat(scores_list)[None], torch.cat(ss_token)[None],
+                                                                  torch.cat(parents_list)[None], sample_token.reshape(-1)[:1], self.top_k,
+                                                                  self.total_tokens, sort_rows=sort_rows)
+        nl, md = int(nl[0]), int(md[0])
+        return draft, ret[0, :nl, :md].contiguous(), mask[:, None], pos[0]
+
+    # ------------------------------------------------------------------ LlamaGen / Anole: cnets_llamagen.py:732-912
+    @torch.no_grad()
+    def topK_genrate(self, hidden_states, input_ids, head, logits_processor, cfg_scale):
+        self.cfg_scale = cfg_scale
+        dev = hidden_states.device
+        input_ids = input_ids.to(dev)
+        sample_token = input_ids[:, -1]
+        input_ids = input_ids[:, 1:]
+        len_posi = input_ids.shape[1]
+        k = self.top_k
+        self.reset()
+        if self.stable_kv is not None:
+            kv_len = self.stable_kv[0][0].shape[2]
+            pos = torch.arange(kv_len, input_ids.shape[1], device=dev)[None]
+            out_hidden, pkv = self(hidden_states, input_ids=input_ids[:, kv_len:], past_key_values=self.stable_kv, use_cache=True,
+                                   position_ids=pos)
+        else:
+            out_hidden, pkv = self(hidden_states, input_ids=input_ids, use_cache=True)
+        self.stable_kv = pkv
+        last_hidden = out_hidden[:, -1]
+        ho = head(last_hidden)
+        half = ho.shape[0] // 2
+        rows = self._post_head(ho[:half], ho[half:], logits_processor)
+        ti, cu, ci, scores = ops.expand_dynamic(rows[None], None, k)
+        scores_list, ss_token = [cu.reshape(-1)], [ti.reshape(-1)]
+        parents_list = [torch.zeros(1, dtype=torch.long, device=dev)]
+        cur = ti.reshape(1, -1)
+        input_ids = torch.cat([cur, cur])
+        input_hidden = last_hidden[:, None].repeat(1, k, 1)
+        tree_mask = self.tree_mask_init
+        cs = torch.arange(k, device=dev)
+        for i in range(self.depth):
+            self.tree_mask = tree_mask
+            position_ids = len_posi + self.position_ids
+            out_hidden, pkv = self(input_hidden, input_ids=input_ids, past_key_values=pkv, position_ids=position_ids, use_cache=True)
+            len_posi += 1
+            parents_list.append(cs + (1 + k * k * max(0, i - 1) + (k if i > 0 else 0)))
+            ho = head(out_hidden)
+            half = ho.shape[0] // 2
+            rows = self._post_head(ho[:half], ho[half:], logits_processor)
+            ti, cu, ci, scores = ops.expand_dynamic(rows[None], scores, k)
+            cs = ci[0]
+            out_ids = cs // k
+            input_hidden = out_hidden[:, out_ids]
+            cur = ti.reshape(-1)[cs][None]
+            input_ids = torch.cat([cur, cur])
+            ss_token.append(ti.reshape(-1))
+            scores_list.append(cu.reshape(-1))
+            tree_mask = torch.cat((tree_mask[:, :, out_ids], self.tree_mask_init), dim=3)
+        return self._finalize_dynamic(scores_list, ss_token, parents_list, sample_token, logits_processor is not None)
+
+    # ------------------------------------------------------------------ LlamaGen / Anole static: cnets_llamagen.py:944-1023
+    @torch.no_grad()
+    def topK_genrate_v1(self, hidden_states, input_ids, head, logits_processor, cfg_scale):
+        self.cfg_scale = cfg_scale
+        dev = hidden_states.device
+        input_ids = input_ids[:, 1:].to(dev)
+        ss_token, ss_prob, ss_op = [], [], []
+        len_posi = input_ids.shape[1]
+        self.reset()
+        if self.stable_kv is not None:
+            kv_len = self.stable_kv[0][0].shape[2]
+            pos = torch.arange(kv_len, input_ids.shape[1], device=dev)[None]
+            out_hidden, pkv = self(hidden_states, input_ids=input_ids[:, kv_len:], past_key_values=self.stable_kv, use_cache=True,
+                                   position_ids=pos)
+        else:
+            out_hidden, pkv = self(hidden_states, input_ids=input_ids, use_cache=True)
+        self.stable_kv = pkv
+        ho = head(out_hidden[:, -1])
+        half = ho.shape[0] // 2
+        rows = self._post_head(ho[:half], ho[half:], logits_processor)
+        tb = self.tree_buffer
+        for i in range(len(tb["tree_indices"])):
+            idx, prob, op = self.sample(rows, k=TOPK)
+            ss_token.append(idx); ss_prob.append(prob); ss_op.append(op)
+            sel = idx.view(-1)[tb["tree_indices"][i]]
+            cur = sel[None]
+            input_ids = torch.cat([cur, cur])
+            input_hidden = self.repeat_hidden(out_hidden[:, -1:] if i == 0 else out_hidden, tb["repeat_nums"][i])
+            self.tree_mask = tb["attn_mask"][i]
+            position_ids = len_posi + tb["position_ids"][i]
+            out_hidden, pkv = self(input_hidden, input_ids=input_ids, past_key_values=pkv, position_ids=position_ids, use_cache=True)
+            len_posi += 1
+            ho = head(out_hidden)
+            half = ho.shape[0] // 2
+            rows = self._post_head(ho[:half], ho[half:], logits_processor)
+        idx, prob, op = self.sample(rows, k=TOPK)
+        ss_token.append(idx); ss_prob.append(prob); ss_op.append(op)
+        return torch.cat(ss_token), torch.cat(ss_prob), ss_op
+
+    # ------------------------------------------------------------------ Lumina-mGPT: cnets_lumina_mgpt.py:1148-1392
+    @torch.no_grad()
+    def topK_generate(self, hidden_states, uncond_hidden_states, input_ids, head, logits_processors, attention_mask=None,
+                      tree_type="static"):
+        assert uncond_hidden_states is not None, "uncond_hidden_states should not be None since we always use CFG."
+        assert tree_type in ("static", "dynamic"), "tree_type should be 'static' for EAGLE v1 or 'dynamic' for EAGLE v2."
+        dev = hidden_states.device
+        input_ids = input_ids[:, 1:].to(dev)
+        k = self.top_k
+        if tree_type == "dynamic":
+            sample_token = input_ids[:, -1]
+        first = self.stable_kv is None
+        if first:
+            if hidden_states.shape[1] > uncond_hidden_states.shape[1]:          # sequential CFG: left-pad the uncond stream
+                pad = torch.zeros((1, hidden_states.shape[1] - uncond_hidden_states.shape[1], uncond_hidden_states.shape[2]),
+                                  dtype=uncond_hidden_states.dtype, device=dev)
+                uncond_hidden_states = torch.cat((pad, uncond_hidden_states), dim=1)
+            if tree_type == "dynamic" and self.tree_mask_init.shape[0] == 1:
+                self.tree_mask_init = torch.cat([self.tree_mask_init, self.tree_mask_init], dim=0)
+        hidden_states = torch.cat((hidden_states, uncond_hidden_states), dim=0)
+        input_ids = input_ids.repeat(2, 1)
+        attention_mask = attention_mask.to(dev)
+        if attention_mask.shape[1] < input_ids.shape[1]:
+            attention_mask = torch.nn.functional.pad(attention_mask, (0, input_ids.shape[1] - attention_mask.shape[1]), "constant", True)
+        position_ids = attention_mask.long().cumsum(-1) - 1
+        len_posi = (position_ids[:, -1] + 1)[:, None]                          # [2,1]: cond / uncond stream lengths
+        self.reset()
+        if not first:
+            kv_len = self.stable_kv[0][0].shape[2]
+            out_hidden, pkv = self(hidden_states, input_ids[:, kv_len:], attention_mask=attention_mask, position_ids=position_ids[:, kv_len:],
+                                   past_key_values=self.stable_kv, use_cache=True)
+        else:
+            out_hidden, pkv = self(hidden_states, input_ids=input_ids, attention_mask=attention_mask, position_ids=position_ids, use_cache=True)
+        self.stable_kv = pkv
+        last_hidden = out_hidden[:, -1]
+        ho = head(last_hidden)                                                  # [2,V]
+        rows = self._post_head(ho[0:1], ho[1:2], logits_processors, pos_ids=len_posi[1])
+        if tree_type == "static":
+            tb = self.tree_buffer
+            ss_token, ss_prob, ss_op = [], [], []
+            for i in range(len(tb["tree_indices"])):
+                idx, prob, op = self.sample(rows, k=k)
+                ss_token.append(idx); ss_prob.append(prob); ss_op.append(op)
+                sel = idx.view(-1)[tb["tree_indices"][i]]
+                input_ids = sel[None].repeat(2, 1)
+                input_hidden = self.repeat_hidden(out_hidden[:, -1:] if i == 0 else out_hidden, tb["repeat_nums"][i])
+                position_ids = len_posi + tb["position_ids"][i]
+                tm = tb["attn_mask"][i]
+                self.tree_mask = torch.cat((tm, tm), dim=0)
+                out_hidden, pkv = self(input_hidden, input_ids=input_ids, attention_mask=attention_mask, past_key_values=pkv,
+                                       position_ids=position_ids, use_cache=True)
+                len_posi = len_posi + 1
+                ho = head(out_hidden)
+                rows = self._post_head(ho[0], ho[1], logits_processors, pos_ids=position_ids[1] + 1)
+            idx, prob, op = self.sample(rows, k=k)
+            ss_token.append(idx); ss_prob.append(prob); ss_op.append(op)
+            return torch.cat(ss_token), torch.cat(ss_prob), ss_op
+        # dynamic (EAGLE-2)
+        ti, cu, ci, scores = ops.expand_dynamic(rows[None], None, k)
+        scores_list, ss_token = [cu.reshape(-1)], [ti.reshape(-1)]
+        parents_list = [torch.zeros(1, dtype=torch.long, device=dev)]
+        input_ids = ti.reshape(1, -1)
+        input_hidden = last_hidden[:, None].repeat(1, k, 1)
+        tree_mask = self.tree_mask_init
+        cs = torch.arange(k, device=dev)
+        for i in range(self.depth):
+            position_ids = len_posi + self.position_ids
+            self.tree_mask = tree_mask
+            out_hidden, pkv = self(input_hidden, input_ids=torch.cat((input_ids, input_ids), dim=0), attention_mask=attention_mask,
+                                   past_key_values=pkv, position_ids=position_ids, use_cache=True)
+            len_posi = len_posi + 1
+            parents_list.append(cs + (1 + k * k * max(0, i - 1) + (k if i > 0 else 0)))
+            ho = head(out_hidden)
+            rows = self._post_head(ho[0], ho[1], logits_processors, pos_ids=position_ids[1] + 1)
+            ti, cu, ci, scores = ops.expand_dynamic(rows[None], scores, k)
+            cs = ci[0]
+            out_ids = cs // k
+            input_hidden = out_hidden[:, out_ids]
+            input_ids = ti.reshape(-1)[cs][None]
+            ss_token.append(ti.reshape(-1))
+            scores_list.append(cu.reshape(-1))
+            tree_mask = torch.cat((tree_mask[:, :, out_ids], self.tree_mask_init), dim=-1)
+        return self._finalize_dynamic(scores_list, ss_token, parents_list, sample_token, logits_processors is not None)

@@ -551,6 +551,19 @@ def window_to_dense(sample_win, out_tok, out_mass, V: int, win_lo: int):
     return dense
 
 
+def drafter_attention_mask(attention_mask, tree_mask, B: int, T: int, past: int, device=None):
+    """a5: additive [B,1,T,past+T] f32 mask = causal + padding (+ tree), Model._prepare_decoder_attention_mask in one launch.
+    attention_mask [B,L] bool or None; tree_mask [1|B,1,t0,t1] f32 or None."""
+    dev = device or (attention_mask.device if attention_mask is not None else tree_mask.device)
+    out = torch.empty((B, 1, T, past + T), dtype=torch.float32, device=dev)
+    am = None if attention_mask is None else attention_mask.to(device=dev, dtype=torch.uint8).contiguous()
+    tm = None if tree_mask is None else tree_mask.to(device=dev, dtype=torch.float32).contiguous()
+    tb, t0, t1 = (tm.shape[0], tm.shape[-2], tm.shape[-1]) if tm is not None else (1, 0, 0)
+    check(_lib.lib().lantern_drafter_attention_mask(C.c_void_p(_ptr(am)), am.shape[1] if am is not None else 0, C.c_void_p(_ptr(tm)), tb, t0,
+                                                    t1, B, T, past, C.c_void_p(out.data_ptr()), _stream()), "drafter_attention_mask")
+    return out
+
+
 def drafter_fc(ids, hidden, embed, weight, bias=None, embed_scale: float = 1.0):
     """O11 (MFMA): fc(cat(embed[ids] * scale, hidden)) -> bf16 [M,H].  ids [M] i64, hidden [M,H] bf16, embed [vocab,H] bf16,
     weight [H,2H] bf16 (nn.Linear layout), bias [H] bf16 or None."""

@@ -1,0 +1,184 @@
+"""GPU (-m gpu): the drafter `Model` mirror (lantern_amd/drafters/cnets.py).
+  * forward(): input stage + attention mask + position ids against vectors recorded from the REFERENCE's own Model.forward
+    (tests/golden/make_golden_drafter.py: the decoder layer there only records what it is handed);
+  * topK_genrate(): the whole dynamic-tree loop through the class, on a scripted head, against the goldens the reference's
+    topK_genrate produced for the same script (tests/golden/make_golden.py: run_dynamic_tree);
+  * topK_genrate_v1() / topK_generate(): shapes, ranges, the conditional-probability identity and the attention-mask / KV
+    bookkeeping with the default plain-torch decoder layer."""
+import types
+
+import numpy as np
+import pytest
+import torch
+
+import cases as CS
+import helpers as H
+from lantern_amd import ops
+from lantern_amd.drafters import cnets
+from lantern_amd.drafters.choices import mc_sim_7b_63, naive_extend_57
+
+pytestmark = pytest.mark.gpu
+SPECS = H.ep_specs()
+
+
+class Recorder(torch.nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.seen = []
+
+    def forward(self, hidden_states, attention_mask=None, position_ids=None, past_key_value=None, output_attentions=False, use_cache=False):
+        self.seen.append((hidden_states.clone(), attention_mask.clone(), position_ids.clone()))
+        B, T, _ = hidden_states.shape
+        k = torch.zeros(B, 1, T, 2, device=hidden_states.device)
+        if past_key_value is not None:
+            k = torch.cat([past_key_value[0], k], dim=2)
+        return hidden_states, (k, k)
+
+
+@pytest.mark.parametrize("ci", [0, 1, 2])
+def test_drafter_forward_input_stage_and_mask_vs_reference(ci):
+    g = H.load("drafter.npz")
+    pre = f"c{ci}."
+    bf16 = bool(g[pre + "bf16"])
+    dt = torch.bfloat16 if bf16 else torch.float32
+    V, Hd = g[pre + "embed"].shape
+    cfg = types.SimpleNamespace(vocab_size=V, hidden_size=Hd, pad_token_id=None, num_hidden_layers=1)
+    rec = Recorder()
+    has_bias = g[pre + "fc_b"].size > 0
+    m = cnets.Model(cfg, layers=[rec], bias=has_bias, embed_upscale=float(g[pre + "upscale"])).cuda()
+    m.embed_tokens.weight.data = torch.from_numpy(g[pre + "embed"]).cuda().to(dt)
+    m.fc.weight.data = torch.from_numpy(g[pre + "fc_w"]).cuda().to(dt)
+    if has_bias:
+        m.fc.bias.data = torch.from_numpy(g[pre + "fc_b"]).cuda().to(dt)
+    am = torch.from_numpy(g[pre + "attn"]).cuda()
+    t = lambda k: torch.from_numpy(g[pre + k]).cuda()
+    _, kv = m(t("a.hidden").to(dt), t("a.ids"), attention_mask=am, position_ids=t("a.pos"), use_cache=True)
+    m.tree_mask = t("tree_mask")
+    m(t("b.hidden").to(dt), t("b.ids"), attention_mask=am, position_ids=t("b.pos"), past_key_values=kv, use_cache=True)
+    for tag, seen in (("a", rec.seen[0]), ("b", rec.seen[1])):
+        assert np.array_equal(seen[1].cpu().numpy(), g[pre + tag + ".mask"]), (ci, tag)        # additive mask: exact (incl. -inf where both mask)
+        assert np.array_equal(seen[2].cpu().numpy(), g[pre + tag + ".layer_pos"])
+        got, ref = seen[0].detach().float().cpu().numpy(), g[pre + tag + ".post_fc"]
+        if bf16:   # MFMA accumulates the 2H products in another order than the CPU GEMM: at most one bf16 ulp
+            assert np.abs(got - ref).max() <= np.abs(ref).max() * 2 ** -7
+            assert (got != ref).mean() < 0.2
+        else:
+            np.testing.assert_allclose(got, ref, rtol=0, atol=2e-5)
+
+
+class ScriptedHead:
+    """head() returns the next block of the script (cond == uncond), like the golden generator's FakeDrafter."""
+
+    def __init__(self, script):
+        self.script, self.calls = script, 0
+
+    def __call__(self, hidden):
+        blk = torch.from_numpy(self.script[self.calls]).cuda()
+        self.calls += 1
+        return torch.stack([blk, blk]) if hidden.dim() == 2 and blk.dim() == 1 else blk[None].repeat(2, 1, 1) if blk.dim() == 2 else blk
+
+
+@pytest.mark.parametrize("i", [i for i, s in enumerate(SPECS) if s["kind"] == "dynamic" and s["model"] == "llamagen"][::3])
+def test_drafter_topK_genrate_reproduces_reference_tree(i):
+    from transformers.generation.logits_process import LogitsProcessorList, TopKLogitsWarper
+    spec, case = SPECS[i], H.ep_case(i)
+    depth = int(case["depth"])
+    m_ = CS.MODELS[spec["model"]]
+    script = H.dynamic_script(spec["seed"], spec["model"], depth)
+    cfg = types.SimpleNamespace(vocab_size=m_["V"], hidden_size=32, pad_token_id=None, num_hidden_layers=1, num_attention_heads=4,
+                                intermediate_size=64)
+    mdl = cnets.Model(cfg, total_tokens=int(case["total_tokens"]) + 1, depth=depth, top_k=CS.TOPK, model_type="llamagen").cuda()
+    mdl.init_tree()
+    head = ScriptedHead(script)
+    hidden = torch.randn(2, 5, 32, device="cuda")
+    input_ids = torch.randint(0, m_["V"], (2, 6), device="cuda")
+    input_ids[:, -1] = int(case["sample_token"])
+    proc = LogitsProcessorList([TopKLogitsWarper(H.DYN_TOP_K)])
+    draft, ret, mask, pos = mdl.topK_genrate(hidden, input_ids, head, proc, 3.0)
+    assert head.calls == depth + 1
+    assert np.array_equal(draft[0].cpu().numpy(), case["draft_tokens"])
+    assert np.array_equal(ret.cpu().numpy(), case["retrieve"])
+    assert np.array_equal(mask[0, 0].cpu().numpy(), case["mask"])
+    assert np.array_equal(pos.cpu().numpy(), case["pos"])
+    # KV bookkeeping of the loop: prefill 5 positions, then `depth` tree steps of top_k tokens each
+    assert mdl.stable_kv[0][0].shape[2] == 5
+
+
+def _tiny(model_type, V, dtype=torch.bfloat16, **kw):
+    cfg = types.SimpleNamespace(vocab_size=V, hidden_size=64, pad_token_id=None, num_hidden_layers=1, num_attention_heads=4,
+                                intermediate_size=128)
+    torch.manual_seed(0)
+    return cnets.Model(cfg, top_k=CS.TOPK, model_type=model_type, **kw).cuda().to(dtype)
+
+
+@pytest.mark.parametrize("model_type,V", [("llamagen", 16384), ("anole", 65536)])
+def test_drafter_static_tree_v1(model_type, V):
+    from transformers.generation.logits_process import LogitsProcessorList, TemperatureLogitsWarper, TopKLogitsWarper
+    mdl = _tiny(model_type, V)
+    mdl.init_tree_v1(naive_extend_57)
+    W = torch.randn(V, 64, device="cuda", dtype=torch.bfloat16) * 0.5
+    head = lambda h: (h @ W.T).float()
+    hidden = torch.randn(2, 9, 64, device="cuda", dtype=torch.bfloat16)
+    ids = torch.randint(4, 8000, (2, 10), device="cuda")
+    proc = LogitsProcessorList([TemperatureLogitsWarper(0.9), TopKLogitsWarper(300)])
+    tok, prob, ops_l = mdl.topK_genrate_v1(hidden, ids, head, proc, 4.0)
+    counts = [1] + [len(t) for t in mdl.tree_buffer["tree_indices"]]
+    assert tok.shape == (sum(counts), 10) and prob.shape == tok.shape and [o.shape[0] for o in ops_l] == counts
+    full = torch.cat(ops_l)
+    assert torch.allclose(full.sum(-1), torch.ones_like(full.sum(-1)), atol=1e-5)
+    nz = (full > 0).sum(-1)
+    assert (nz >= 300).all() and (nz <= 330).all()      # `scores < kth` keeps every tie of the k-th value (bf16-valued logits tie often)
+    if model_type == "anole":
+        assert (tok >= 4).all() and (tok < 8196).all() and float(full[:, :4].sum() + full[:, 8196:].sum()) == 0.0
+    # conditional probabilities of draws without replacement: p_i / (1 - sum_{j<i} p_j), first one is the plain probability
+    p = full.gather(1, tok)
+    assert torch.allclose(prob[:, 0], p[:, 0], atol=1e-6)
+    cum = torch.cumsum(p, 1) - p
+    ref = (p / (1 - cum)).clamp(0, 1)
+    assert torch.allclose(prob, torch.where(torch.isfinite(ref), ref, torch.zeros_like(ref)), atol=1e-4)
+    # second call continues on the cache
+    n0 = mdl.stable_kv[0][0].shape[2]
+    ids2 = torch.cat([ids, torch.randint(4, 8000, (2, 3), device="cuda")], 1)
+    mdl.topK_genrate_v1(torch.randn(2, 3, 64, device="cuda", dtype=torch.bfloat16), ids2, head, proc, 4.0)
+    assert mdl.stable_kv[0][0].shape[2] == n0 + 3
+
+
+@pytest.mark.parametrize("tree_type", ["static", "dynamic"])
+def test_drafter_lumina_topK_generate(tree_type):
+    from lantern_amd.ea_model_lumina_mgpt import InterleavedTopKLogitsWarper, MultiModalLogitsProcessor
+    V = 65536
+    mdl = _tiny("lumina_mgpt", V, total_tokens=59, depth=4)
+    mdl.cfg_scale = 3.0
+    mdl.init_tree(mc_sim_7b_63 if tree_type == "static" else None)
+    W = torch.randn(V, 64, device="cuda", dtype=torch.bfloat16) * 0.5
+    head = lambda h: (h @ W.T)
+    procs = [MultiModalLogitsProcessor(), InterleavedTopKLogitsWarper(image_top_k=500)]
+    prompt, n_img = 6, 49 - 3            # uncond stream = [8197, 8828, 8828] + 45 image tokens + ... so the next row ends soon
+    S = prompt + 3 + n_img
+    hidden = torch.randn(1, S, 64, device="cuda", dtype=torch.bfloat16)
+    uncond = torch.randn(1, 3 + n_img, 64, device="cuda", dtype=torch.bfloat16)
+    ids = torch.randint(4, 8000, (1, S + 1), device="cuda")
+    cond_mask = torch.ones(S, dtype=torch.bool, device="cuda")
+    unc_mask = torch.cat([torch.zeros(prompt, dtype=torch.bool, device="cuda"), torch.ones(3 + n_img, dtype=torch.bool, device="cuda")])
+    out = mdl.topK_generate(hidden, uncond, ids, head, procs, attention_mask=torch.stack([cond_mask, unc_mask]), tree_type=tree_type)
+    if tree_type == "static":
+        tok, prob, ops_l = out
+        full = torch.cat(ops_l)
+        assert tok.shape == (11, 10) and prob.shape == (11, 10)
+        # every drafter row is either an image-token row (mass only on ids 4..8195) or a forced newline row
+        img_rows = full[:, 8803] < 0.5
+        assert float(full[img_rows][:, :4].sum() + full[img_rows][:, 8196:].sum()) == 0.0
+        assert ((full[img_rows] > 0).sum(-1) <= 540).all()
+    else:
+        draft, ret, mask, pos = out
+        assert draft.shape == (1, 59) and mask.shape == (1, 1, 59, 59) and pos.shape == (59,)
+        assert int(draft[0, 0]) == int(ids[0, -1]) and ret.shape[1] == int(pos.max()) + 1
+        tok = draft[0, 1:]
+        assert (((tok >= 4) & (tok < 8196)) | (tok == 8803)).all()
+        # the uncond stream holds 49 tokens (3 header + 46 image): the root's children are image tokens, the nodes of tree depth 2
+        # sit at the end of the 48-token image row and must be the forced newline, depth 3 opens the next row
+        p1 = pos[1:]
+        assert ((tok[p1 == 1] >= 4) & (tok[p1 == 1] < 8196)).all()
+        assert (tok[p1 == 2] == 8803).all() and int((p1 == 2).sum()) > 0
+        assert ((tok[p1 == 3] >= 4) & (tok[p1 == 3] < 8196)).all()
+    assert mdl.stable_kv[0][0].shape[2] == S

@@ -143,6 +143,7 @@ __device__ __forceinline__ float exp_nonpos(float x) {
 // x / d for many x and one d: reciprocal refined once (Newton), then q = fma(fma(-q0, d, x), r, q0) -- the quotient
 // correction step of the IEEE division expansion without its per-element scaling / fix-up instructions.  Correctly
 // rounded for the normal-range operands met here (d in [2^-20, 2^14], x in [0, 1]); 3 VALU ops instead of ~11.
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
 struct FastDiv {
     float d, r;
     __device__ __forceinline__ explicit FastDiv(float den) : d(den) {
@@ -152,6 +153,15 @@ struct FastDiv {
     __device__ __forceinline__ float operator()(float x) const {
         const float q0 = x * r;
         return fmaf(fmaf(-q0, d, x), r, q0);
+    }
+    // two quotients per instruction (v_pk_mul_f32 / v_pk_fma_f32): same three operations per element
+    __device__ __forceinline__ f32x2_t operator()(f32x2_t x) const {
+        const f32x2_t q0 = x * r;
+        return __builtin_elementwise_fma(__builtin_elementwise_fma(-q0, (f32x2_t)(d), x), (f32x2_t)(r), q0);
+    }
+    __device__ __forceinline__ float4 operator()(float4 v) const {
+        const f32x2_t a = (*this)((f32x2_t){v.x, v.y}), b = (*this)((f32x2_t){v.z, v.w});
+        return make_float4(a.x, a.y, b.x, b.y);
     }
 };
 
@@ -175,7 +185,7 @@ __device__ __forceinline__ void softmax_tile(float4 (&r)[NV4], float *redf, doub
     const float sf = (float)block_sum_fast<double, NW>(s, redd, ph);
     const FastDiv dv(sf);
 #pragma unroll
-    for (int it = 0; it < NV4; ++it) r[it] = make_float4(dv(r[it].x), dv(r[it].y), dv(r[it].z), dv(r[it].w));
+    for (int it = 0; it < NV4; ++it) r[it] = dv(r[it]);
 }
 
 // TopPLogitsWarper on a register tile (HF order: after the temperature, before top-k; drafters/utils.py:36-52 ->
@@ -906,6 +916,7 @@ __global__ __launch_bounds__(NT) void epw_kernel(const EpwArgs args) {
             status = LANTERN_ST_NO_PREFIX;
             break;
         }
+        EPW_STAMPG(16);
         const int fi = __ffsll((long long)eq_mask) - 1;
         // everything a candidate needs from its path at this level, one lane per path, fetched once per level
         const int pl = (lane < P ? lane : 0) * Ds + i;
@@ -922,6 +933,7 @@ __global__ __launch_bounds__(NT) void epw_kernel(const EpwArgs args) {
         if (prm.syntax_shortcut)
             for (int t = 0; t < prm.n_syntax; ++t) flag_lane |= (x_lane == prm.syntax[t]) ? 1 : 0;
         const unsigned long long todo0 = eq_mask & __ballot(x_lane != -1);
+        EPW_STAMPG(17);
         // neighbour ids of the level's candidates: their HBM reads are issued first, the row's loads second; both are in
         // flight together and the ids are written to LDS under the row's last barrier (one exposed latency per level)
         constexpr int PF_PER = (EW_PF_K + NT - 1) / NT;
@@ -950,6 +962,7 @@ __global__ __launch_bounds__(NT) void epw_kernel(const EpwArgs args) {
                 if (lane == c) xs_lane = have ? x : -1;
                 ncand += have ? 1 : 0;
             }
+            EPW_STAMPG(18);
             // chunk ch = 8 ids of candidate ch / 128: a wave works on one candidate at a time (128 chunks = 2 waves)
 #pragma unroll
             for (int u = 0; u < PF16_PER; ++u) {
@@ -1194,6 +1207,7 @@ __global__ __launch_bounds__(NT) void epw_kernel(const EpwArgs args) {
             }
             const bool zero_nb = prm.lantern && m > 0 && (!prm.syntax_shortcut || in_img);
             double loc = 0.0;
+            float4 gn[E4];           // the unnormalised residual stays in registers until the sum is known
             if (!is_static) {
                 if (tid == 0 && x_in) g[x - lo] = 0.0f;
                 if (!x_in && x == out_tok) out_mass = 0.0f;
@@ -1207,57 +1221,69 @@ __global__ __launch_bounds__(NT) void epw_kernel(const EpwArgs args) {
                     if (out_tok >= 0 && block_sum_fast<int, NW>(hit ? 1 : 0, S.redi, ph) > 0) out_mass = 0.0f;
                 }
                 __syncthreads();
-                for (int i4 = tid; i4 * 4 < W; i4 += NT) {
-                    const float4 v = reinterpret_cast<const float4 *>(g)[i4];
-                    loc += (double)v.x + (double)v.y + (double)v.z + (double)v.w;
+#pragma unroll
+                for (int it = 0; it < E4; ++it) {
+                    const int i4 = tid + it * NT;
+                    gn[it] = (i4 * 4 < W) ? reinterpret_cast<const float4 *>(g)[i4] : make_float4(0.f, 0.f, 0.f, 0.f);
+                    loc += (double)gn[it].x + (double)gn[it].y + (double)gn[it].z + (double)gn[it].w;
                 }
             } else {
                 const int b0 = rdlane(b0_lane, j), b1 = rdlane(b1_lane, j);
                 int nsib = b1 - b0;
                 if (nsib > EW_MAX_SIB) nsib = EW_MAX_SIB;
-                if (tid < nsib) {
-                    const int node = (b0 + tid < EW_MAX_B) ? S.bidx[b0 + tid] : 0;
+                // window indices of the earlier siblings' tokens, straight from the staged tables (every thread reads the same
+                // LDS words: broadcast, no barrier); the first four live in registers, longer sibling lists loop over LDS
+                auto sib_at = [&](int t) -> int {
+                    const int node = (b0 + t < EW_MAX_B) ? S.bidx[b0 + t] : 0;
                     const int tok = (node >= 0 && node < EW_MAX_N) ? S.tcand[node] : -1;
-                    S.sib[tid] = (tok >= lo && tok < lo + W) ? (tok - lo) : -1;
-                }
+                    return (tok >= lo && tok < lo + W) ? (tok - lo) : -1;
+                };
+                int sib_r[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) sib_r[t] = t < nsib ? sib_at(t) : -1;
                 const bool lg_nb = zero_nb && prm.mode == LANTERN_MODE_STATIC_LG;
-                if (lg_nb)
+                if (lg_nb) {
                     for (int t = tid; t < (W + 31) / 32; t += NT) nbmask[t] = 0u;
-                __syncthreads();
-                if (lg_nb)
+                    __syncthreads();
                     for (int t = tid; t < nz; t += NT) {
                         const int id = (int)(LDSIDS ? S.nbid[slot][t] : nb[t]) + off - lo;
                         if (id >= 0 && id < W) atomicOr(&nbmask[id >> 5], 1u << (id & 31));
                     }
+                }
                 if (zero_nb && prm.mode == LANTERN_MODE_STATIC_LUMINA)
                     for (int t = tid; t < nz; t += NT) {
                         const int id = (int)(LDSIDS ? S.nbid[slot][t] : nb[t]) + off - lo;
                         if (id >= 0 && id < W) g[id] = 0.0f;
                     }
+                EPW_STAMPG(31);
                 double qs_loc = 0.0;
 #pragma unroll
                 for (int it = 0; it < E4; ++it) {
                     const int e = (tid + it * NT) * 4;
-                    for (int t = 0; t < nsib; ++t) {
-                        const int sidx = S.sib[t];
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+                        if (sib_r[t] >= e && sib_r[t] < e + 4) set_comp(q[it], sib_r[t] - e, 0.0f);
+                    for (int t = 4; t < nsib; ++t) {
+                        const int sidx = sib_at(t);
                         if (sidx >= e && sidx < e + 4) set_comp(q[it], sidx - e, 0.0f);
                     }
                     qs_loc += (double)q[it].x + (double)q[it].y + (double)q[it].z + (double)q[it].w;
                 }
+                EPW_STAMPG(32);
                 float qs = 1.0f;
                 if (nsib > 0)
                     qs = (float)block_sum_fast<double, NW>(qs_loc, S.redd, ph);
                 else
                     __syncthreads();   // neighbour zeroing / mask visible (block_sum_fast carries the barrier otherwise)
+                EPW_STAMPG(33);
                 const FastDiv dq(qs);
 #pragma unroll
                 for (int it = 0; it < E4; ++it) {
                     const int i4 = tid + it * NT;
+                    gn[it] = make_float4(0.f, 0.f, 0.f, 0.f);
                     if (i4 * 4 < W) {
                         float4 qv = q[it];
-                        if (nsib > 0) {
-                            qv.x = dq(qv.x); qv.y = dq(qv.y); qv.z = dq(qv.z); qv.w = dq(qv.w);
-                        }
+                        if (nsib > 0) qv = dq(qv);
                         if (lg_nb) {
                             const int e = i4 * 4;
                             const uint32_t bits = nbmask[e >> 5] >> (e & 31);
@@ -1272,13 +1298,15 @@ __global__ __launch_bounds__(NT) void epw_kernel(const EpwArgs args) {
                         d = gv.y - qv.y; gv.y = d < 0.0f ? 0.0f : d;
                         d = gv.z - qv.z; gv.z = d < 0.0f ? 0.0f : d;
                         d = gv.w - qv.w; gv.w = d < 0.0f ? 0.0f : d;
-                        reinterpret_cast<float4 *>(g)[i4] = gv;
+                        gn[it] = gv;
                         loc += (double)gv.x + (double)gv.y + (double)gv.z + (double)gv.w;
                     }
                 }
                 // out-of-window mass: the drafter is zero there (precondition): max(out_mass - 0, 0) = out_mass
             }
+            EPW_STAMPG(34);
             double tot = block_sum_fast<double, NW>(loc, S.redd, ph);
+            EPW_STAMPG(35);
             tot += (double)out_mass;
             const float gs = (float)tot;
             if (gs == 0.0f) {
@@ -1286,10 +1314,11 @@ __global__ __launch_bounds__(NT) void epw_kernel(const EpwArgs args) {
                 break;
             }
             const FastDiv dg(gs);
-            for (int i4 = tid; i4 * 4 < W; i4 += NT) {
-                float4 v = reinterpret_cast<float4 *>(g)[i4];
-                v.x = dg(v.x); v.y = dg(v.y); v.z = dg(v.z); v.w = dg(v.w);
-                reinterpret_cast<float4 *>(g)[i4] = v;
+#pragma unroll
+            for (int it = 0; it < E4; ++it) {
+                const int i4 = tid + it * NT;
+                if (i4 * 4 < W)
+                    reinterpret_cast<float4 *>(g)[i4] = dg(gn[it]);
             }
             out_mass = out_mass / gs;
             if (tid == 0) g[W + EW_G_OUT] = out_mass;

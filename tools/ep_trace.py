@@ -22,7 +22,7 @@ wl = HN.LuminaVerifyWorkload(HN.WorkloadConfig(n_seq=B, pool_steps=4, with_kv=Fa
 L = wl._L
 NAMES = {0: "start", 1: "staged(loads issued)", 2: "staged(barrier)", 10: "level: masks+prefetch", 11: "level: softmax", 12: "  softmax: row loaded+local max", 13: "  softmax: block max",
          14: "  softmax: exp+local sum", 15: "  softmax: block sum", 20: "cand: start", 21: "cand: decision (all waves)", 22: "  scan: gathers", 23: "  scan: dpp scan", 24: "  scan: checks",
-         25: "  scan: wave reduce", 26: "  wave0 decision written", 27: "  wave0 section entered", 30: "reject: residual", 40: "epilogue start", 50: "epilogue done"}
+         25: "  scan: wave reduce", 26: "  wave0 decision written", 27: "  wave0 section entered", 31: "  rej: siblings+nb zeroing", 32: "  rej: q zero+sum (waits q)", 33: "  rej: block sum qs", 34: "  rej: residual pass", 35: "  rej: block sum tot", 16: "  level: loop head", 17: "  level: per-lane path data", 18: "  level: candidate list", 30: "reject: residual", 40: "epilogue start", 50: "epilogue done"}
 agg = {}
 for step in range(8):
     wl.step(); torch.cuda.synchronize()

@@ -664,12 +664,10 @@ constexpr int EW_MAX_P = 64, EW_MAX_D = 16, EW_MAX_PD = 1024, EW_MAX_SIB = 16, E
 constexpr int EW_PF_C = 6;        // candidates per level whose neighbour ids are prefetched into LDS
 constexpr int EW_PF_K = 1024;     // ... when k + 1 <= EW_PF_K; otherwise ids are read from HBM on demand
 
+// Fixed-size part of the workgroup's LDS; the five per-(path, depth) tables (cand, row, cart, pidx, boff) follow it, sized
+// by the launch's actual P*D (epw_pd_cap) instead of the 64 x 16 worst case: 20 KB -> ~2 KB for the reference's trees, which
+// is what lets two workgroups share a CU at saturating batch sizes.
 struct alignas(16) EwShared {
-    int cand[EW_MAX_PD];
-    int row[EW_MAX_PD];
-    float cart[EW_MAX_PD];
-    int pidx[EW_MAX_PD];
-    int boff[EW_MAX_PD + 1];
     int bidx[EW_MAX_B];
     int tcand[EW_MAX_N];
     int opoff[EW_MAX_D];
@@ -689,6 +687,7 @@ struct alignas(16) EwShared {
 // g[W + EW_G_ZERO] = 0 (neighbour outside the window), g[W + EW_G_HUGE] = 3e38 (position >= k: never under tau),
 // g[W + EW_G_OUT] = out_mass (neighbour == the one-hot token outside the window): gather targets of the scan
 constexpr int EW_G_ZERO = 0, EW_G_HUGE = 1, EW_G_OUT = 2, EW_G_EXT = 4;
+__host__ __device__ inline int epw_pd_cap(int P, int D) { return (P * D + 1 + 3) & ~3; }      // boff has P*D + 1 entries
 __host__ __device__ inline size_t epw_shared_offset(int W) {
     size_t o = (size_t)(W + EW_G_EXT) * 4 + (size_t)((W + 31) / 32) * 4;
     return (o + 15) & ~(size_t)15;
@@ -790,8 +789,12 @@ typedef const __attribute__((address_space(4))) EpwArgs *EpwArgsK;
 // IDMODE 0: ids from HBM in the scan (k > 1023).  1: ids staged in LDS, table rows at any (2-byte) alignment -- the
 // reference's [K, K-1] layout.  2: ids staged in LDS from a table whose row stride is a multiple of 8 ids and whose base
 // is 16-byte aligned (lantern_pack_vq_table): one 16-byte load brings 8 ids, 2 loads per thread cover a whole level.
-template <int NT, int E4, int IDMODE>
-__global__ __launch_bounds__(NT) void epw_kernel(const EpwArgs args) {
+// WPE (waves per SIMD the register allocation must allow): 1 = no constraint -- the latency-optimal build (162 VGPRs, one
+// workgroup per CU) used while every sequence of the launch gets a CU to itself; 4 (512-thread workgroups) = 128 VGPRs so
+// that TWO workgroups share a CU once the batch exceeds the CU count (67 KB of LDS each): +41 % sequences/s at saturation,
+// -7 % at 48 sequences (a few spills), hence selected by batch size.
+template <int NT, int E4, int IDMODE, int WPE>
+__global__ __launch_bounds__(NT, WPE) void epw_kernel(const EpwArgs args) {
     constexpr bool LDSIDS = IDMODE != 0;
     const lantern_ep_params &prm = args.prm;
     const lantern_ep_buffers &buf = args.buf;
@@ -804,6 +807,10 @@ __global__ __launch_bounds__(NT) void epw_kernel(const EpwArgs args) {
     const int Ps = prm.P, Ds = prm.D, V = prm.V, W = win.win_len, lo = win.win_lo;
     uint32_t *nbmask = reinterpret_cast<uint32_t *>(g + W + EW_G_EXT);  // W bits: neighbour set (static LlamaGen/Anole: zeroing hits q)
     EwShared &S = *reinterpret_cast<EwShared *>(reinterpret_cast<char *>(g) + epw_shared_offset(W));
+    int *const Scand = reinterpret_cast<int *>(reinterpret_cast<char *>(&S) + sizeof(EwShared));
+    const int pd_cap = epw_pd_cap(Ps, Ds);
+    int *const Srow = Scand + pd_cap, *const Spidx = Srow + pd_cap, *const Sboff = Spidx + pd_cap;
+    float *const Scart = reinterpret_cast<float *>(Sboff + pd_cap);
     const int P = buf.n_paths ? buf.n_paths[b] : Ps;
     const int D = buf.n_depth ? buf.n_depth[b] : Ds;
     const int k = prm.k, off = prm.tok_offset;
@@ -872,17 +879,17 @@ __global__ __launch_bounds__(NT) void epw_kernel(const EpwArgs args) {
         for (int u = 0; u < PD_PER; ++u) {
             const int t = tid + u * NT;
             if (t < npd) {
-                S.cand[t] = (int)c_[u];
-                S.row[t] = r_[u];
+                Scand[t] = (int)c_[u];
+                Srow[t] = r_[u];
                 if (is_static) {
-                    S.cart[t] = ct_[u];
-                    S.pidx[t] = pi_[u];
-                    S.boff[t] = bo_[u];
+                    Scart[t] = ct_[u];
+                    Spidx[t] = pi_[u];
+                    Sboff[t] = bo_[u];
                 }
             }
         }
         if (is_static) {
-            if (tid == 0) S.boff[npd] = nb_total;
+            if (tid == 0) Sboff[npd] = nb_total;
 #pragma unroll
             for (int u = 0; u < B_PER; ++u) {
                 const int t = tid + u * NT;
@@ -913,7 +920,7 @@ __global__ __launch_bounds__(NT) void epw_kernel(const EpwArgs args) {
     __syncthreads();
     EPW_STAMP(2);
     // paths sharing the root token (the reference compares candidates[:, :1] with candidates[0, :1])
-    unsigned long long eq_mask = __ballot(lane < P && S.cand[(lane < P ? lane : 0) * Ds] == S.cand[0]);
+    unsigned long long eq_mask = __ballot(lane < P && Scand[(lane < P ? lane : 0) * Ds] == Scand[0]);
 
     int a = 1, best = 0, adjust = 0, status = LANTERN_ST_OK;
     int n_levels = 0, n_tried = 0, n_rej = 0, n_used = 0;
@@ -934,14 +941,14 @@ __global__ __launch_bounds__(NT) void epw_kernel(const EpwArgs args) {
         const int fi = __ffsll((long long)eq_mask) - 1;
         // everything a candidate needs from its path at this level, one lane per path, fetched once per level
         const int pl = (lane < P ? lane : 0) * Ds + i;
-        const int x_lane = (lane < P) ? S.cand[pl] : -1;
+        const int x_lane = (lane < P) ? Scand[pl] : -1;
         float cart_lane = 1.0f;
         int qrow_lane = 0, b0_lane = 0, b1_lane = 0;
         if (is_static) {
-            cart_lane = S.cart[pl];
-            qrow_lane = S.opoff[i - 1] + S.pidx[pl];
-            b0_lane = S.boff[pl];
-            b1_lane = S.boff[pl + 1];
+            cart_lane = Scart[pl];
+            qrow_lane = S.opoff[i - 1] + Spidx[pl];
+            b0_lane = Sboff[pl];
+            b1_lane = Sboff[pl + 1];
         }
         int flag_lane = (x_lane >= prm.img_lo && x_lane < prm.img_hi) ? 2 : 0;     // bit 1: image token, bit 0: syntax token
         if (prm.syntax_shortcut)
@@ -1010,7 +1017,7 @@ __global__ __launch_bounds__(NT) void epw_kernel(const EpwArgs args) {
             }
         }
         {
-            const int rid = S.row[fi * Ds + (i - 1)];
+            const int rid = Srow[fi * Ds + (i - 1)];
             const int hot = !hot_g ? -1 : (hot_in_lds ? S.hot[rid] : hot_g[rid]);
             EPW_STAMP(10);
             if (hot < 0 && rp_rid != rid) row_load<NT, E4>(logits + (size_t)rid * W, W, rp);
@@ -1344,7 +1351,7 @@ __global__ __launch_bounds__(NT) void epw_kernel(const EpwArgs args) {
 
     const int from_residual = (adjust && a != D) ? 1 : 0;
     if (status == LANTERN_ST_OK && !from_residual) {
-        const int rid = S.row[best * Ds + (a - 1)];
+        const int rid = Srow[best * Ds + (a - 1)];
         const int hot = !hot_g ? -1 : (hot_in_lds ? S.hot[rid] : hot_g[rid]);
         if (hot < 0 && rp_rid != rid) row_load<NT, E4>(logits + (size_t)rid * W, W, rp);
         row_softmax_to_lds<NT, E4>(rp, hot, rows_probs, lo, W, prm.temperature, prm.top_k, V, g, out_tok, out_mass, S, ph);
@@ -1591,28 +1598,30 @@ extern "C" int lantern_evaluate_posterior_window(const lantern_ep_params *prm, c
     }
     hipStream_t st = (hipStream_t)stream;
     const int W = win->win_len;
-    const size_t lds = epw_shared_offset(W) + sizeof(EwShared);
+    const size_t lds = epw_shared_offset(W) + sizeof(EwShared) + (size_t)5 * epw_pd_cap(p.P, p.D) * 4;
     dim3 grid(p.B);
     const int nz = (p.k + 1 < p.table_cols) ? p.k + 1 : p.table_cols;
     const bool lds_ids = !p.lantern || nz <= EW_PF_K;
     const EpwArgs args{p, *buf, *win};
     const int idmode = !lds_ids ? 0 : ((p.lantern && p.table_cols % 8 == 0 && ((uintptr_t)buf->nn_table & 15) == 0) ? 2 : 1);
-#define EPW_LAUNCH(NT_, E4_)                                                                                              \
+#define EPW_LAUNCH_W(NT_, E4_, WPE_)                                                                                        \
     do {                                                                                                                  \
-        if (idmode == 2) LANTERN_LAUNCH((epw_kernel<NT_, E4_, 2>), grid, dim3(NT_), lds, st, args);                   \
-        else if (idmode == 1) LANTERN_LAUNCH((epw_kernel<NT_, E4_, 1>), grid, dim3(NT_), lds, st, args);              \
-        else LANTERN_LAUNCH((epw_kernel<NT_, E4_, 0>), grid, dim3(NT_), lds, st, args);                               \
+        if (idmode == 2) LANTERN_LAUNCH((epw_kernel<NT_, E4_, 2, WPE_>), grid, dim3(NT_), lds, st, args);                  \
+        else if (idmode == 1) LANTERN_LAUNCH((epw_kernel<NT_, E4_, 1, WPE_>), grid, dim3(NT_), lds, st, args);             \
+        else LANTERN_LAUNCH((epw_kernel<NT_, E4_, 0, WPE_>), grid, dim3(NT_), lds, st, args);                              \
     } while (0)
+#define EPW_LAUNCH(NT_, E4_) EPW_LAUNCH_W(NT_, E4_, 1)
+    static const int occ_knob = getenv("LANTERN_EPW_OCC2") ? atoi(getenv("LANTERN_EPW_OCC2")) : -1;   // tuning knob (diagnostic)
+    const bool two_per_cu = occ_knob >= 0 ? occ_knob != 0 : p.B > 256;
     if (W <= 1024) EPW_LAUNCH(256, 1);
     else if (W <= 2048) EPW_LAUNCH(256, 2);
     else if (W <= 4096) EPW_LAUNCH(512, 2);
     else if (W <= 8192) {
-        static const int nt_knob = getenv("LANTERN_EPW_NT") ? atoi(getenv("LANTERN_EPW_NT")) : 0;   // tuning knob (diagnostic)
-        if (nt_knob == 1024) EPW_LAUNCH(1024, 2);
-        else if (nt_knob == 256) EPW_LAUNCH(256, 8);
+        if (two_per_cu) EPW_LAUNCH_W(512, 4, 4);
         else EPW_LAUNCH(512, 4);
     }
     else EPW_LAUNCH(1024, 4);
+#undef EPW_LAUNCH_W
 #undef EPW_LAUNCH
     LANTERN_CHECK_LAUNCH("evaluate_posterior_window");
     return LANTERN_OK;

@@ -146,7 +146,14 @@ def cpu_baseline(wl, steps_budget_s: float, n_seq: int, gpu_tokens_by_seq):
             accepted += alen + 1
             gb, ga, gt = gpu_tokens_by_seq[i][b]
             mismatches += int((best, alen, tok) != (gb, ga, gt))
-    return dict(value=accepted / dt, unit="accepted_tokens/s", cores=threads, kind="port",
+    # one sequence alone on one thread (BASELINE.md section 2 asks for the 1-thread figure too): a few seconds, same checker
+    one, n1 = {}, int(max(2, min(n_steps, 3.0 / max(t_step, 1e-4))))
+    t1 = time.perf_counter()
+    run_seq(0, n1, one)
+    dt1 = time.perf_counter() - t1
+    single = dict(value=sum(a + 1 for _, a, _ in one[0]) / dt1, unit="accepted_tokens/s", cores=1,
+                  sample=f"sequence 0 x {n1} verify steps", ms_per_seq_step=1e3 * dt1 / n1)
+    return dict(value=accepted / dt, unit="accepted_tokens/s", cores=threads, kind="port", single_thread=single,
                 sample=f"{n_seq} sequences x {n_steps} verify steps of the same pools/uniforms (oracle/lantern_oracle.c, "
                        f"{threads} host threads, one per sequence; host has {cores} cores)",
                 ms_per_seq_step=1e3 * dt * threads / (n_seq * n_steps),

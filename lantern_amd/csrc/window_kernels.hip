@@ -672,8 +672,6 @@ struct alignas(16) EwShared {
     int tcand[EW_MAX_N];
     int opoff[EW_MAX_D];
     double uni[EW_UNI];
-    int acc[EW_MAX_D];
-    int sib[EW_MAX_SIB];
     double redd[2 * 16];
     float redf[2 * 16];
     int redi[2 * 16];

@@ -720,7 +720,6 @@ template <int NT, int E4, typename Hook = NoHook>
 __device__ __forceinline__ void row_softmax_to_lds(float4 (&r)[E4], int hot, bool probs, int win_lo, int W, float temperature, int top_k,
                                                    int V, float *g, int &out_tok, float &out_mass, EwShared &S, int &ph,
                                                    const Hook &pre_barrier = Hook()) {
-    constexpr int NW = NT / 64;
     const int tid = threadIdx.x;
     const float NEG_INF = -__builtin_inff();
     out_tok = -1;

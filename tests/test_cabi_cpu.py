@@ -78,3 +78,19 @@ def test_device_ops_refuse_cpu_tensors():
     import torch
     with pytest.raises(_lib.LanternError):
         ops.cfg_mask_topk(torch.zeros(1, 16), torch.zeros(1, 16), 1.0)
+
+
+def test_empty_batches_are_ok_and_launch_nothing():
+    """B = 0 / rows = 0 / no slabs: every batched entry returns LANTERN_OK before touching the device (works without a GPU)."""
+    import ctypes as C
+    L = _lib.lib()
+    one = C.c_void_p(8)          # any non-null pointer: nothing is dereferenced for an empty batch
+    prm, buf, win = _lib.EpParams(), _lib.EpBuffers(), _lib.EpWindow()
+    prm.B, prm.P, prm.D, prm.V = 0, 15, 6, 65536
+    assert L.lantern_evaluate_posterior_window(C.byref(prm), C.byref(buf), C.byref(win), None) == 0
+    assert L.lantern_evaluate_posterior(C.byref(prm), C.byref(buf), None) == 0
+    assert L.lantern_cfg_mask_topk_window(one, one, 1, 0, 16384, C.c_float(3.0), 0, None, C.c_int64(0), 48, 48, 0, 16384, 8803, 8196, 0, None,
+                                          0, 0, 16384, one, one, 0, C.c_float(1.0), C.c_float(1.0), None) == 0
+    assert L.lantern_kv_gather(one, one, one, 0, 2, C.c_int64(64), C.c_int64(128), C.c_int64(128), one, 0, 15, 6, one, one, None, None) == 0
+    assert L.lantern_accept_gather(None, 2, 0, 2, 26, 4096, one, 0, 15, 6, None, one, one, None, 0, None, None, None, None, None) == 0
+    assert L.lantern_gather_candidates(one, None, one, one, one, 0, 110, 26, 15, 6, one, one, None, None) == 0

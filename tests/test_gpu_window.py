@@ -85,6 +85,53 @@ def test_window_dynamic_golden(i):
     check_out(out, case, m["V"], lo, u, spec)
 
 
+@pytest.mark.parametrize("model,with_counts", [("lumina", True), ("lumina", False), ("anole", True), ("llamagen", True)])
+def test_window_dynamic_ragged_batch(model, with_counts):
+    """One launch over dynamic trees of DIFFERENT shapes (leaf count, depth): candidates / row maps padded with -1 to the
+    widest tree, per-sequence row_index [B,P,D], optional n_paths / n_depth.  Every sequence must land on its own golden."""
+    idx = [i for i, s in enumerate(SPECS) if s["kind"] == "dynamic" and s["model"] == model and _supported(s) and s["lantern"]
+           and s["k"] == 10 and s["delta"] == 0.1 and not s.get("special") and s.get("top_p", 1.0) >= 1.0
+           and s.get("temperature", 1.0) == 1.0 and s.get("top_k", 0) == 0]
+    idx += [i for i, s in enumerate(SPECS) if s["kind"] == "dynamic" and s["model"] == model and _supported(s) and s["lantern"]
+            and s["k"] == 300 and s["delta"] == 0.1 and not s.get("special")][:1]
+    cases = [(SPECS[i], H.ep_case(i)) for i in idx]
+    assert len(cases) >= 2
+    m = CS.MODELS[model]
+    lo, W = window_of(model)
+    Pm = max(c["cand"].shape[0] for _, c in cases)
+    Dm = max(c["cand"].shape[1] for _, c in cases)
+    N = max(len(c["draft_tokens"]) for _, c in cases)
+    assert len({c["cand"].shape for _, c in cases}) > 1          # really ragged
+    B = len(cases)
+    cand = np.full((B, Pm, Dm), -1, np.int64)
+    ri = np.zeros((B, Pm, Dm), np.int32)
+    rows = np.full((B, N, W), -np.inf, np.float32)
+    uni = np.zeros((B, 64))
+    # the cases differ in k: run them as two launches by k but keep the ragged shapes inside each launch
+    for kk in sorted({s["k"] for s, _ in cases}):
+        sel = [b for b, (s, _) in enumerate(cases) if s["k"] == kk]
+        for b in sel:
+            s, c = cases[b]
+            nl, u = H.dynamic_node_logits(s, c)
+            P, D = c["cand"].shape
+            cand[b, :P, :D] = c["cand"]
+            ri[b, :P, :D] = H.row_index_from_retrieve(c["retrieve"], len(c["draft_tokens"]))
+            rows[b, :nl.shape[0]] = nl[:, lo:lo + W]
+            uni[b] = u
+        kw = {}
+        if with_counts:
+            kw = dict(n_paths=dev(np.array([cases[b][1]["cand"].shape[0] for b in sel], np.int32)),
+                      n_depth=dev(np.array([cases[b][1]["cand"].shape[1] for b in sel], np.int32)))
+        out = ops.evaluate_posterior_window(hip_cfg(cases[sel[0]][0]), m["V"], dev(rows[sel]), lo, dev(ri[sel]), dev(cand[sel]), dev(uni[sel]),
+                                            table=table_dev(m["K"]), want_dense=True, **kw)
+        for j, b in enumerate(sel):
+            c = cases[b][1]
+            assert int(out["counters"][j, 5]) == 0
+            assert (int(out["best"][j]), int(out["accept_len"][j])) == (int(c["best"]), int(c["accept_len"])), (b, j)
+            np.testing.assert_allclose(out["sample_p"][j].cpu().numpy(), c["sample_p"], rtol=0, atol=PROB_TOL)
+            assert int(out["counters"][j, 3]) == int(c["n_draws"])
+
+
 @pytest.mark.parametrize("static", [True, False])
 def test_window_one_hot_rows_vs_oracle(static):
     """Newline / end-of-image rows (MultiModalLogitsProcessor) are one-hot OUTSIDE the image window: the mass travels

@@ -128,7 +128,7 @@ def cpu_baseline(wl, steps_budget_s: float, n_seq: int, gpu_tokens_by_seq):
     cores = os.cpu_count() or 1
     threads = min(cores, n_seq)
     kv_slabs = {b: [np.ones(kv_shape, np.uint16), np.ones(kv_shape, np.uint16)] for b in range(n_seq)} if c.with_kv else {}
-    max_cpu_steps = (kv_smax_cpu - c.prompt_len - 3 - 32) // 6
+    max_cpu_steps = (kv_smax_cpu - c.prompt_len - 3 - 32) // 6 if c.with_kv else 10 ** 9     # host slabs are cut to 1024 positions
     # calibrate on one step of one sequence, then size the sample to the budget
     t0 = time.perf_counter()
     tmp = {}

@@ -335,6 +335,15 @@ int lantern_drafter_fc(const int64_t *ids, const void *hidden, const void *embed
 int lantern_drafter_attention_mask(const uint8_t *attn, int attn_len, const float *tree_mask, int tree_batch, int t0,
                                    int t1, int B, int T, int past, float *out, void *stream);
 
+/* 8f-2 (next row, first half)  lm_head restricted to the vocabulary rows the model's mask can let through:
+ *   out[m, out_col0 + n] = sum_k A[m,k] * W[row_lo + n, k] (+ bias[row_lo + n]),  n < n_rows,  bf16 in / f32 accumulate / bf16 out.
+ * Replaces `head(out_hidden)` in the drafter (cnets_lumina_mgpt.py:1212,1287; cnets_anole.py:835,876) for models
+ * whose drafted rows are masked to the image-token ids right after it: 8192 of Lumina's / Anole's 65536 rows of W are
+ * read (64 MiB instead of 512 MiB per call).  A [dev] [M,K] bf16 (M <= 128), W [dev] [vocab,K] bf16 (nn.Linear layout),
+ * bias [dev] [vocab] bf16 or NULL, out [dev] [M, out_stride] bf16 (only columns [out_col0, out_col0+n_rows) are written). */
+int lantern_linear_rows(const void *A, const void *W, const void *bias, int M, int K, int row_lo, int n_rows, void *out,
+                        int out_stride, int out_col0, void *stream);
+
 /* 8f-1 VQ-distance neighbour table: cdist + per-row ascending order, self excluded.
  * Replaces entrypoints/generate_codebook.py:53-65.  codebook [dev] [K,C] f32 ->
  * table [dev] [K,K-1] u16, K <= 16384 (LlamaGen).  workspace: unused (NULL). */

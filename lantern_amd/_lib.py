@@ -83,5 +83,5 @@ EXPORTS = [
     "lantern_evaluate_posterior_workspace", "lantern_evaluate_posterior", "lantern_evaluate_posterior_greedy",
     "lantern_kv_gather", "lantern_accept_gather", "lantern_sample_static", "lantern_drafter_fc",
     "lantern_build_vq_table", "lantern_cfg_mask_topk_window", "lantern_evaluate_posterior_window",
-    "lantern_window_to_dense", "lantern_pack_vq_table", "lantern_update_inference_inputs", "lantern_profile_next_launch", "lantern_drafter_attention_mask",
+    "lantern_window_to_dense", "lantern_pack_vq_table", "lantern_update_inference_inputs", "lantern_profile_next_launch", "lantern_drafter_attention_mask", "lantern_linear_rows",
 ]

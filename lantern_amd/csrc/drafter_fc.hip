@@ -121,6 +121,80 @@ __global__ __launch_bounds__(FC_THREADS) void drafter_fc_kernel(const int64_t *_
     }
 }
 
+// 8f-2 (first half): the drafter's lm_head restricted to the vocabulary rows that can survive the model's mask.
+//   out[m, col0 + n] = sum_k A[m, k] * W[row_lo + n, k]   (n < n_rows)
+// For Lumina-mGPT / Anole every drafted row is masked to the image-token ids [4, 8196) right after the head
+// (cnets_lumina_mgpt.py:1216-1224,1291-1298; cnets_anole.py:837,878), so 8192 of the 65536 rows of W are ever used:
+// 64 MiB of weights per call instead of 512 MiB.  Same wave layout as drafter_fc_kernel: a wave feeds
+// v_mfma_f32_32x32x16_bf16 straight from global memory (nn.Linear's [out, in] layout is the B-fragment layout), the
+// 8 waves of a workgroup split K and add their tiles in LDS in wave order; bf16 output like nn.Linear in bf16.
+template <int MT>
+__global__ __launch_bounds__(FC_THREADS) void linear_rows_kernel(const uint16_t *__restrict__ A, const uint16_t *__restrict__ Wt,
+                                                                 const uint16_t *__restrict__ bias, int M, int K, int row_lo, int n_rows,
+                                                                 uint16_t *__restrict__ out, int out_stride, int out_col0) {
+    __shared__ float tile[MT][32][33];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int n0 = blockIdx.x * 32;
+    for (int t = tid; t < MT * 32 * 33; t += FC_THREADS) (&tile[0][0][0])[t] = 0.0f;
+    const int ksteps = K / 16;
+    const int ks0 = (int)((long long)ksteps * wave / FC_WAVES), ks1 = (int)((long long)ksteps * (wave + 1) / FC_WAVES);
+    const int ncol = n0 + r;
+    const uint16_t *wrow = Wt + (size_t)(row_lo + (ncol < n_rows ? ncol : n_rows - 1)) * K;
+    const uint16_t *arow[MT];
+    bool live[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const int row = mt * 32 + r;
+        live[mt] = row < M;
+        arow[mt] = A + (size_t)(live[mt] ? row : 0) * K;
+    }
+    f32x16_t acc[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[mt][i] = 0.0f;
+    const bf16x8_t zero = __builtin_bit_cast(bf16x8_t, make_uint4(0, 0, 0, 0));
+    // two K steps per trip: both weight fragments (the HBM stream) are requested before the first MFMA
+    int ks = ks0;
+    for (; ks + 1 < ks1; ks += 2) {
+        const int k0 = ks * 16 + 8 * h;
+        const bf16x8_t b0 = load_frag(wrow + k0), b1 = load_frag(wrow + k0 + 16);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const bf16x8_t a0 = live[mt] ? load_frag(arow[mt] + k0) : zero, a1 = live[mt] ? load_frag(arow[mt] + k0 + 16) : zero;
+            acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[mt], 0, 0, 0);
+            acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[mt], 0, 0, 0);
+        }
+    }
+    for (; ks < ks1; ++ks) {
+        const int k0 = ks * 16 + 8 * h;
+        const bf16x8_t b0 = load_frag(wrow + k0);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+            acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(live[mt] ? load_frag(arow[mt] + k0) : zero, b0, acc[mt], 0, 0, 0);
+    }
+    for (int w = 0; w < FC_WAVES; ++w) {      // combine the K slices in wave order (deterministic f32 sum)
+        __syncthreads();
+        if (wave == w) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) tile[mt][(reg & 3) + 8 * (reg >> 2) + 4 * h][r] += acc[mt][reg];
+        }
+    }
+    __syncthreads();
+    for (int t = tid; t < MT * 32 * 32; t += FC_THREADS) {
+        const int mt = t / 1024, row = (t / 32) % 32, col = t % 32;
+        const int m = mt * 32 + row, n = n0 + col;
+        if (m < M && n < n_rows) {
+            float v = tile[mt][row][col];
+            if (bias) v += bf16_bits_to_f32(bias[row_lo + n]);
+            out[(size_t)m * out_stride + out_col0 + n] = f32_to_bf16_rne(v);
+        }
+    }
+}
+
 // a5: Model._prepare_decoder_attention_mask (cnets_lumina_mgpt.py:1014-1050, cnets_llamagen.py:592-621) in one launch:
 // out[b,0,i,j] = padding(b,j) + causal(i,j) with padding = 0 / finfo.min from the boolean mask (columns beyond its length
 // count as attended), causal = finfo.min for j - past > i when T > 1 (the reference ADDS the two, so a position masked by
@@ -185,5 +259,24 @@ extern "C" int lantern_drafter_fc(const int64_t *ids, const void *hidden, const 
     else if (M <= 96) hipLaunchKernelGGL((drafter_fc_kernel<3>), grid, block, 0, st, ids, h, e, w, bi, M, H, vocab, embed_scale, o);
     else hipLaunchKernelGGL((drafter_fc_kernel<4>), grid, block, 0, st, ids, h, e, w, bi, M, H, vocab, embed_scale, o);
     LANTERN_CHECK_LAUNCH("drafter_fc");
+    return LANTERN_OK;
+}
+
+extern "C" int lantern_linear_rows(const void *A, const void *W, const void *bias, int M, int K, int row_lo, int n_rows, void *out,
+                                   int out_stride, int out_col0, void *stream) {
+    LANTERN_CHECK_ARG(A && W && out, "linear_rows: null buffer");
+    LANTERN_CHECK_ARG(M >= 0 && M <= 128, "linear_rows: M=%d must be <= 128 rows", M);
+    LANTERN_CHECK_ARG(K > 0 && K % 16 == 0 && row_lo >= 0 && n_rows >= 0 && out_col0 >= 0 && out_stride >= out_col0 + n_rows,
+                      "linear_rows: K=%d must be a multiple of 16, the output row must hold [col0, col0 + n_rows)", K);
+    if (M == 0 || n_rows == 0) return LANTERN_OK;
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid((n_rows + 31) / 32), block(FC_THREADS);
+    const uint16_t *a = (const uint16_t *)A, *w = (const uint16_t *)W, *bi = (const uint16_t *)bias;
+    uint16_t *o = (uint16_t *)out;
+    if (M <= 32) LANTERN_LAUNCH((linear_rows_kernel<1>), grid, block, 0, st, a, w, bi, M, K, row_lo, n_rows, o, out_stride, out_col0);
+    else if (M <= 64) LANTERN_LAUNCH((linear_rows_kernel<2>), grid, block, 0, st, a, w, bi, M, K, row_lo, n_rows, o, out_stride, out_col0);
+    else if (M <= 96) LANTERN_LAUNCH((linear_rows_kernel<3>), grid, block, 0, st, a, w, bi, M, K, row_lo, n_rows, o, out_stride, out_col0);
+    else LANTERN_LAUNCH((linear_rows_kernel<4>), grid, block, 0, st, a, w, bi, M, K, row_lo, n_rows, o, out_stride, out_col0);
+    LANTERN_CHECK_LAUNCH("linear_rows");
     return LANTERN_OK;
 }

@@ -223,6 +223,25 @@ class Model(nn.Module):
         idx = torch.multinomial(probs, k, replacement=False)
         return idx, ops.sample_static(probs, idx), probs
 
+    def _head(self, head, hidden):
+        """`head(hidden)` -> [..., V] logits.  For Lumina-mGPT / Anole every drafted row is masked to the image-token ids right
+        after the head, so when `head` is a bf16 nn.Linear only those rows of its weight are multiplied (lantern_linear_rows:
+        64 MiB instead of 512 MiB of weights per call); the other columns of the returned tensor are never read (the mask
+        kernels overwrite them).  Any other head (a callable, another dtype, LlamaGen's V == K) is simply called."""
+        w = getattr(head, "weight", None)
+        if (self.model_type in ("lumina_mgpt", "anole") and isinstance(head, nn.Linear) and w is not None and w.is_cuda
+                and w.dtype == torch.bfloat16 and hidden.dtype == torch.bfloat16 and w.shape[1] % 16 == 0):
+            V, H = w.shape
+            lead = hidden.shape[:-1]
+            A = hidden.reshape(-1, H)
+            key = (A.shape[0], V)
+            buf = self.__dict__.setdefault("_head_buf", {})
+            if key not in buf:            # the non-window columns stay whatever they are (finite zeros): never read downstream
+                buf[key] = torch.zeros((A.shape[0], V), dtype=torch.bfloat16, device=A.device)
+            out = ops.linear_rows(A, w, self.image_lo, self.image_hi - self.image_lo, bias=head.bias, out=buf[key])
+            return out.view(*lead, V)
+        return head(hidden)
+
     def _post_head(self, cond, uncond, proc, pos_ids=None, pos_base=2):
         """CFG combine + the model's mask + its processors on the head's rows -> processed logits [R,V] f32 (dense rows: the tree
         ops and the verify side index them by token id)."""
@@ -274,7 +293,7 @@ class Model(nn.Module):
             out_hidden, pkv = self(hidden_states, input_ids=input_ids, use_cache=True)
         self.stable_kv = pkv
         last_hidden = out_hidden[:, -1]
-        ho = head(last_hidden)
+        ho = self._head(head, last_hidden)
         half = ho.shape[0] // 2
         rows = self._post_head(ho[:half], ho[half:], logits_processor)
         ti, cu, ci, scores = ops.expand_dynamic(rows[None], None, k)
@@ -291,7 +310,7 @@ class Model(nn.Module):
             out_hidden, pkv = self(input_hidden, input_ids=input_ids, past_key_values=pkv, position_ids=position_ids, use_cache=True)
             len_posi += 1
             parents_list.append(cs + (1 + k * k * max(0, i - 1) + (k if i > 0 else 0)))
-            ho = head(out_hidden)
+            ho = self._head(head, out_hidden)
             half = ho.shape[0] // 2
             rows = self._post_head(ho[:half], ho[half:], logits_processor)
             ti, cu, ci, scores = ops.expand_dynamic(rows[None], scores, k)
@@ -322,7 +341,7 @@ class Model(nn.Module):
         else:
             out_hidden, pkv = self(hidden_states, input_ids=input_ids, use_cache=True)
         self.stable_kv = pkv
-        ho = head(out_hidden[:, -1])
+        ho = self._head(head, out_hidden[:, -1])
         half = ho.shape[0] // 2
         rows = self._post_head(ho[:half], ho[half:], logits_processor)
         tb = self.tree_buffer
@@ -337,7 +356,7 @@ class Model(nn.Module):
             position_ids = len_posi + tb["position_ids"][i]
             out_hidden, pkv = self(input_hidden, input_ids=input_ids, past_key_values=pkv, position_ids=position_ids, use_cache=True)
             len_posi += 1
-            ho = head(out_hidden)
+            ho = self._head(head, out_hidden)
             half = ho.shape[0] // 2
             rows = self._post_head(ho[:half], ho[half:], logits_processor)
         idx, prob, op = self.sample(rows, k=TOPK)
@@ -379,7 +398,7 @@ class Model(nn.Module):
             out_hidden, pkv = self(hidden_states, input_ids=input_ids, attention_mask=attention_mask, position_ids=position_ids, use_cache=True)
         self.stable_kv = pkv
         last_hidden = out_hidden[:, -1]
-        ho = head(last_hidden)                                                  # [2,V]
+        ho = self._head(head, last_hidden)                                                  # [2,V]
         rows = self._post_head(ho[0:1], ho[1:2], logits_processors, pos_ids=len_posi[1])
         if tree_type == "static":
             tb = self.tree_buffer
@@ -396,7 +415,7 @@ class Model(nn.Module):
                 out_hidden, pkv = self(input_hidden, input_ids=input_ids, attention_mask=attention_mask, past_key_values=pkv,
                                        position_ids=position_ids, use_cache=True)
                 len_posi = len_posi + 1
-                ho = head(out_hidden)
+                ho = self._head(head, out_hidden)
                 rows = self._post_head(ho[0], ho[1], logits_processors, pos_ids=position_ids[1] + 1)
             idx, prob, op = self.sample(rows, k=k)
             ss_token.append(idx); ss_prob.append(prob); ss_op.append(op)
@@ -416,7 +435,7 @@ class Model(nn.Module):
                                    past_key_values=pkv, position_ids=position_ids, use_cache=True)
             len_posi = len_posi + 1
             parents_list.append(cs + (1 + k * k * max(0, i - 1) + (k if i > 0 else 0)))
-            ho = head(out_hidden)
+            ho = self._head(head, out_hidden)
             rows = self._post_head(ho[0], ho[1], logits_processors, pos_ids=position_ids[1] + 1)
             ti, cu, ci, scores = ops.expand_dynamic(rows[None], scores, k)
             cs = ci[0]

@@ -551,6 +551,29 @@ def window_to_dense(sample_win, out_tok, out_mass, V: int, win_lo: int):
     return dense
 
 
+def linear_rows(A, weight, row_lo: int, n_rows: int, bias=None, out=None, out_col0: Optional[int] = None):
+    """8f-2: A [M,K] bf16 @ weight[row_lo:row_lo+n_rows].T -> bf16 columns [out_col0, out_col0+n_rows) of `out` [M, stride]
+    (a fresh [M, n_rows] tensor, out_col0 = 0, when `out` is None).  The drafter's lm_head on the image-token rows only."""
+    for t, n in ((A, "A"), (weight, "weight")):
+        if not t.is_cuda or t.dtype != torch.bfloat16:
+            raise _lib.LanternError(f"linear_rows: {n} must be a bf16 device tensor")
+    A = A.contiguous()
+    weight = weight.contiguous()
+    M, K = A.shape
+    if out is None:
+        out = torch.empty((M, n_rows), dtype=torch.bfloat16, device=A.device)
+        out_col0 = 0
+    elif out_col0 is None:
+        out_col0 = row_lo
+    assert out.is_contiguous() and out.dtype == torch.bfloat16 and out.shape[0] == M
+    b = None if bias is None else bias.contiguous()
+    for s0 in range(0, M, 128):
+        m = min(128, M - s0)
+        check(_lib.lib().lantern_linear_rows(C.c_void_p(A[s0:].data_ptr()), C.c_void_p(weight.data_ptr()), C.c_void_p(_ptr(b)), m, K, row_lo,
+                                             n_rows, C.c_void_p(out[s0:].data_ptr()), out.shape[1], out_col0, _stream()), "linear_rows")
+    return out
+
+
 def drafter_attention_mask(attention_mask, tree_mask, B: int, T: int, past: int, device=None):
     """a5: additive [B,1,T,past+T] f32 mask = causal + padding (+ tree), Model._prepare_decoder_attention_mask in one launch.
     attention_mask [B,L] bool or None; tree_mask [1|B,1,t0,t1] f32 or None."""

@@ -182,3 +182,47 @@ def test_drafter_lumina_topK_generate(tree_type):
         assert (tok[p1 == 2] == 8803).all() and int((p1 == 2).sum()) > 0
         assert ((tok[p1 == 3] >= 4) & (tok[p1 == 3] < 8196)).all()
     assert mdl.stable_kv[0][0].shape[2] == S
+
+
+@pytest.mark.parametrize("M,H,lo,n", [(20, 4096, 4, 8192), (2, 4096, 4, 8192), (33, 256, 0, 100), (120, 512, 7, 1000)])
+def test_linear_rows_matches_torch(M, H, lo, n):
+    """lm_head restricted to rows [lo, lo+n): bf16 MFMA with f32 accumulation vs torch's bf16 linear on the same slice."""
+    V = max(lo + n + 5, 9000 if H == 4096 else lo + n + 5)
+    g = torch.Generator().manual_seed(M + H)
+    A = (torch.randn(M, H, generator=g) * 0.5).to(torch.bfloat16).cuda()
+    W = (torch.randn(V, H, generator=g) / H ** 0.5).to(torch.bfloat16).cuda()
+    bias = (torch.randn(V, generator=g) * 0.1).to(torch.bfloat16).cuda()
+    out = ops.linear_rows(A, W, lo, n, bias=bias)
+    ref = (A.float() @ W[lo:lo + n].float().T + bias[lo:lo + n].float())
+    assert out.shape == (M, n)
+    err = (out.float() - ref).abs().max().item()
+    assert err <= 2 ** -7 * ref.abs().max().item() + 1e-3, err
+    # into a wider row buffer at its own column offset, other columns untouched
+    buf = torch.full((M, lo + n + 3), 7.0, dtype=torch.bfloat16, device="cuda")
+    ops.linear_rows(A, W, lo, n, bias=bias, out=buf)
+    assert torch.equal(buf[:, lo:lo + n], out) and (buf[:, :lo] == 7).all() and (buf[:, lo + n:] == 7).all()
+
+
+def test_drafter_head_window_equals_full_head():
+    """Lumina drafter with a real nn.Linear head: the image-row GEMM feeds the same tree as the full 65536-row head."""
+    from lantern_amd.ea_model_lumina_mgpt import InterleavedTopKLogitsWarper, MultiModalLogitsProcessor
+    V = 65536
+    outs = []
+    for use_window in (True, False):
+        mdl = _tiny("lumina_mgpt", V, total_tokens=59, depth=4)
+        mdl.cfg_scale = 3.0
+        mdl.init_tree()
+        torch.manual_seed(3)
+        head = torch.nn.Linear(64, V, bias=False).cuda().to(torch.bfloat16)
+        hd = head if use_window else (lambda h, _hd=head: _hd(h))       # a plain callable takes the full-head route
+        procs = [MultiModalLogitsProcessor(), InterleavedTopKLogitsWarper(image_top_k=300)]
+        S = 6 + 3 + 20
+        torch.manual_seed(4)
+        hidden = torch.randn(1, S, 64, device="cuda", dtype=torch.bfloat16)
+        uncond = torch.randn(1, 23, 64, device="cuda", dtype=torch.bfloat16)
+        ids = torch.randint(4, 8000, (1, S + 1), device="cuda")
+        am = torch.stack([torch.ones(S, dtype=torch.bool, device="cuda"),
+                          torch.cat([torch.zeros(6, dtype=torch.bool, device="cuda"), torch.ones(23, dtype=torch.bool, device="cuda")])])
+        outs.append(mdl.topK_generate(hidden, uncond, ids, hd, procs, attention_mask=am, tree_type="dynamic"))
+    for a, b in zip(outs[0], outs[1]):
+        assert torch.equal(a, b)

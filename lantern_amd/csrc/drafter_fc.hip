@@ -34,7 +34,10 @@ __device__ __forceinline__ uint16_t f32_to_bf16_rne(float f) {
     return (uint16_t)(u >> 16);
 }
 
-template <int MT>
+// COLS = output columns per workgroup: 32 fills the 32x32 MFMA tile; 16 (half of the tile's columns idle -- the matrix
+// cores are nowhere near the limit of this weight-streaming kernel) doubles the workgroup count when H / 32 would leave
+// CUs without work (H = 4096: 128 -> 256 workgroups).
+template <int MT, int COLS>
 __global__ __launch_bounds__(FC_THREADS) void drafter_fc_kernel(const int64_t *__restrict__ ids, const uint16_t *__restrict__ hidden,
                                                                 const uint16_t *__restrict__ embed, const uint16_t *__restrict__ Wt,
                                                                 const uint16_t *__restrict__ bias, int M, int H, int vocab,
@@ -42,7 +45,8 @@ __global__ __launch_bounds__(FC_THREADS) void drafter_fc_kernel(const int64_t *_
     __shared__ float tile[MT][32][33];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
-    const int n0 = blockIdx.x * 32;
+    const int n0 = blockIdx.x * COLS;
+    const bool bcol = r < COLS;        // lanes of the tile's idle columns stream nothing
     const int K = 2 * H;
     for (int t = tid; t < MT * 32 * 33; t += FC_THREADS) (&tile[0][0][0])[t] = 0.0f;
 
@@ -69,32 +73,47 @@ __global__ __launch_bounds__(FC_THREADS) void drafter_fc_kernel(const int64_t *_
         for (int i = 0; i < 16; ++i) acc[mt][i] = 0.0f;
 
     const bf16x8_t zero = __builtin_bit_cast(bf16x8_t, make_uint4(0, 0, 0, 0));
-    for (int ks = ks0; ks < ks1; ++ks) {
-        const int k0 = ks * 16 + 8 * h;
-        const bf16x8_t bfrag = load_frag(wrow + k0);
+    // A fragment for 8 consecutive k starting at k0 of row-tile mt: embedding row (scaled, re-rounded to bf16) for k < H,
+    // hidden row otherwise (k0 and H are multiples of 8: a fragment never straddles the seam)
+    auto a_frag = [&](int mt, int k0) -> bf16x8_t {
+        if (!live[mt]) return zero;
+        if (k0 >= H) return load_frag(hrow[mt] + (k0 - H));
+        bf16x8_t afrag = load_frag(erow[mt] + k0);
+        if (embed_scale > 1.0f) {   // inputs_embeds * embed_upscale, rounded to bf16 (cnets_lumina_mgpt.py:1096-1097)
+            uint4 v = __builtin_bit_cast(uint4, afrag);
+            uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const uint16_t lo = f32_to_bf16_rne(bf16_bits_to_f32((uint16_t)(w[i] & 0xffffu)) * embed_scale);
+                const uint16_t hi = f32_to_bf16_rne(bf16_bits_to_f32((uint16_t)(w[i] >> 16)) * embed_scale);
+                w[i] = (uint32_t)lo | ((uint32_t)hi << 16);
+            }
+            afrag = __builtin_bit_cast(bf16x8_t, make_uint4(w[0], w[1], w[2], w[3]));
+        }
+        return afrag;
+    };
+    // four K steps per trip with the k order permuted so that a lane streams 64 contiguous bytes of its weight row (see
+    // linear_rows_kernel); the remainder in natural order
+    int ks = ks0;
+    for (; ks + 3 < ks1; ks += 4) {
+        const int kb = ks * 16 + 32 * h;
+        bf16x8_t bw[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) bw[q] = bcol ? load_frag(wrow + kb + 8 * q) : zero;
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
-            bf16x8_t afrag = zero;
-            if (live[mt]) {
-                if (k0 < H) {
-                    afrag = load_frag(erow[mt] + k0);
-                    if (embed_scale > 1.0f) {   // inputs_embeds * embed_upscale, rounded to bf16 (cnets_lumina_mgpt.py:1096-1097)
-                        uint4 v = __builtin_bit_cast(uint4, afrag);
-                        uint32_t w[4] = {v.x, v.y, v.z, v.w};
+            bf16x8_t aw[4];
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) {
-                            const uint16_t lo = f32_to_bf16_rne(bf16_bits_to_f32((uint16_t)(w[i] & 0xffffu)) * embed_scale);
-                            const uint16_t hi = f32_to_bf16_rne(bf16_bits_to_f32((uint16_t)(w[i] >> 16)) * embed_scale);
-                            w[i] = (uint32_t)lo | ((uint32_t)hi << 16);
-                        }
-                        afrag = __builtin_bit_cast(bf16x8_t, make_uint4(w[0], w[1], w[2], w[3]));
-                    }
-                } else {
-                    afrag = load_frag(hrow[mt] + (k0 - H));
-                }
-            }
-            acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag, bfrag, acc[mt], 0, 0, 0);
+            for (int q = 0; q < 4; ++q) aw[q] = a_frag(mt, kb + 8 * q);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aw[q], bw[q], acc[mt], 0, 0, 0);
         }
+    }
+    for (; ks < ks1; ++ks) {
+        const int k0 = ks * 16 + 8 * h;
+        const bf16x8_t bfrag = bcol ? load_frag(wrow + k0) : zero;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_frag(mt, k0), bfrag, acc[mt], 0, 0, 0);
     }
     // combine the K slices in wave order (deterministic f32 sum; 8 short rounds)
     for (int w = 0; w < FC_WAVES; ++w) {
@@ -113,7 +132,7 @@ __global__ __launch_bounds__(FC_THREADS) void drafter_fc_kernel(const int64_t *_
     for (int t = tid; t < MT * 32 * 32; t += FC_THREADS) {
         const int mt = t / 1024, row = (t / 32) % 32, col = t % 32;
         const int m = mt * 32 + row, n = n0 + col;
-        if (m < M && n < H) {
+        if (m < M && n < H && col < COLS) {
             float v = tile[mt][row][col];
             if (bias) v += bf16_bits_to_f32(bias[n]);
             out[(size_t)m * H + n] = f32_to_bf16_rne(v);
@@ -155,16 +174,24 @@ __global__ __launch_bounds__(FC_THREADS) void linear_rows_kernel(const uint16_t 
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[mt][i] = 0.0f;
     const bf16x8_t zero = __builtin_bit_cast(bf16x8_t, make_uint4(0, 0, 0, 0));
-    // two K steps per trip: both weight fragments (the HBM stream) are requested before the first MFMA
+    // Four K steps (64 elements) per trip.  The order of k inside the contraction is free as long as A and B agree, so lane
+    // (r, h) takes the CONTIGUOUS 64 bytes W[row r][k0 + 32h, +32) -- four back-to-back 16-byte loads of one half cache
+    // line -- and feeds MFMA step s with its s-th 16 bytes (k = k0 + 32h + 8s ...), the A fragment taken at the same k.
+    // A row's 128-byte line is then consumed whole by the two lanes that own it within one trip (instead of 32 bytes per
+    // trip over four trips), and all weight loads of the trip are in flight before the first MFMA.
     int ks = ks0;
-    for (; ks + 1 < ks1; ks += 2) {
-        const int k0 = ks * 16 + 8 * h;
-        const bf16x8_t b0 = load_frag(wrow + k0), b1 = load_frag(wrow + k0 + 16);
+    for (; ks + 3 < ks1; ks += 4) {
+        const int kb = ks * 16 + 32 * h;
+        bf16x8_t bw[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) bw[q] = load_frag(wrow + kb + 8 * q);
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
-            const bf16x8_t a0 = live[mt] ? load_frag(arow[mt] + k0) : zero, a1 = live[mt] ? load_frag(arow[mt] + k0 + 16) : zero;
-            acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[mt], 0, 0, 0);
-            acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[mt], 0, 0, 0);
+            bf16x8_t aw[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) aw[q] = live[mt] ? load_frag(arow[mt] + kb + 8 * q) : zero;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aw[q], bw[q], acc[mt], 0, 0, 0);
         }
     }
     for (; ks < ks1; ++ks) {
@@ -251,13 +278,26 @@ extern "C" int lantern_drafter_fc(const int64_t *ids, const void *hidden, const 
     LANTERN_CHECK_ARG(H > 0 && H % 16 == 0 && vocab > 0, "drafter_fc: H=%d must be a multiple of 16", H);
     if (M == 0) return LANTERN_OK;
     hipStream_t st = (hipStream_t)stream;
-    dim3 grid((H + 31) / 32), block(FC_THREADS);
+    const bool narrow = (H + 31) / 32 < 256;          // fewer column tiles than CUs: 16 columns per workgroup
+    dim3 grid(narrow ? (H + 15) / 16 : (H + 31) / 32), block(FC_THREADS);
     const uint16_t *h = (const uint16_t *)hidden, *e = (const uint16_t *)embed, *w = (const uint16_t *)W, *bi = (const uint16_t *)bias;
     uint16_t *o = (uint16_t *)out;
-    if (M <= 32) hipLaunchKernelGGL((drafter_fc_kernel<1>), grid, block, 0, st, ids, h, e, w, bi, M, H, vocab, embed_scale, o);
-    else if (M <= 64) hipLaunchKernelGGL((drafter_fc_kernel<2>), grid, block, 0, st, ids, h, e, w, bi, M, H, vocab, embed_scale, o);
-    else if (M <= 96) hipLaunchKernelGGL((drafter_fc_kernel<3>), grid, block, 0, st, ids, h, e, w, bi, M, H, vocab, embed_scale, o);
-    else hipLaunchKernelGGL((drafter_fc_kernel<4>), grid, block, 0, st, ids, h, e, w, bi, M, H, vocab, embed_scale, o);
+    if (M <= 32) {
+        if (narrow) hipLaunchKernelGGL((drafter_fc_kernel<1, 16>), grid, block, 0, st, ids, h, e, w, bi, M, H, vocab, embed_scale, o);
+        else hipLaunchKernelGGL((drafter_fc_kernel<1, 32>), grid, block, 0, st, ids, h, e, w, bi, M, H, vocab, embed_scale, o);
+    }
+    else if (M <= 64) {
+        if (narrow) hipLaunchKernelGGL((drafter_fc_kernel<2, 16>), grid, block, 0, st, ids, h, e, w, bi, M, H, vocab, embed_scale, o);
+        else hipLaunchKernelGGL((drafter_fc_kernel<2, 32>), grid, block, 0, st, ids, h, e, w, bi, M, H, vocab, embed_scale, o);
+    }
+    else if (M <= 96) {
+        if (narrow) hipLaunchKernelGGL((drafter_fc_kernel<3, 16>), grid, block, 0, st, ids, h, e, w, bi, M, H, vocab, embed_scale, o);
+        else hipLaunchKernelGGL((drafter_fc_kernel<3, 32>), grid, block, 0, st, ids, h, e, w, bi, M, H, vocab, embed_scale, o);
+    }
+    else {
+        if (narrow) hipLaunchKernelGGL((drafter_fc_kernel<4, 16>), grid, block, 0, st, ids, h, e, w, bi, M, H, vocab, embed_scale, o);
+        else hipLaunchKernelGGL((drafter_fc_kernel<4, 32>), grid, block, 0, st, ids, h, e, w, bi, M, H, vocab, embed_scale, o);
+    }
     LANTERN_CHECK_LAUNCH("drafter_fc");
     return LANTERN_OK;
 }

@@ -333,9 +333,12 @@ def main():
                 kv_ms = mean_ms("kv_gather")
                 kv_b = wl.kv_algorithmic_bytes(E0, E1, group=0) / KT
                 kv_m = wl.kv_moved_bytes(E0, E1, group=0) / KT        # rows already in place are not copied
-                ks["kv_gather"] = {"avg_launch_ms": kv_ms, "algorithmic_bytes_per_launch": kv_b,
-                                   "achieved": kv_b / (kv_ms * 1e-3) / 1e9, "frac": kv_b / (kv_ms * 1e-3) / 1e9 / 8000.0,
-                                   "moved_bytes_per_launch": kv_m, "moved_GBps": kv_m / (kv_ms * 1e-3) / 1e9}
+                # `achieved` counts the bytes the kernel really moves (rows already in place are skipped); the contract figure of
+                # SURVEY 8d (every accepted row read + written) is kept beside it as an equivalent rate
+                ks["kv_gather"] = {"avg_launch_ms": kv_ms, "algorithmic_bytes_per_launch": kv_m,
+                                   "achieved": kv_m / (kv_ms * 1e-3) / 1e9, "frac": kv_m / (kv_ms * 1e-3) / 1e9 / 8000.0,
+                                   "contract_bytes_per_launch": kv_b, "contract_equivalent_GBps": kv_b / (kv_ms * 1e-3) / 1e9,
+                                   "includes": "accepted-hidden copy (O10) in the same launch" if (wl.windowed and cfg.fuse_update) else None}
             out["kernels"] = ks
         if args.ep_sweep:
             wl.release_kv()      # the sweep builds its own (KV-free) workloads: give the memory back first

@@ -365,6 +365,21 @@ __device__ void top_p_tile(float4 (&r)[NV4], float top_p, double *mass, float *r
     }
 }
 
+// Workgroup -> row map of the O7 kernels.  Consecutive workgroup ids land on consecutive XCDs (8 of them, each with its
+// own L2); evaluate_posterior's workgroup b (one per sequence) lands on XCD b % 8.  With rows grouped by sequence
+// (rows_per_seq > 0) the rows of sequence b are therefore produced by workgroups whose id is congruent to b modulo 8, so that
+// O8 finds them in ITS XCD's L2 instead of fetching them across the fabric.  Placement is only a speed hint: any map that
+// is a permutation of the rows is correct.
+__device__ __forceinline__ int o7_row_of_block(int x, int rows, int rows_per_seq) {
+    if (rows_per_seq <= 0) return x;
+    const int n_seq = rows / rows_per_seq, full = (n_seq / 8) * 8;           // sequences that fill whole groups of 8
+    const int n_full_rows = full * rows_per_seq;
+    if (x >= n_full_rows) return x;                                          // the ragged tail keeps the identity map
+    const int xcd = x & 7, idx = x >> 3;                                     // idx-th workgroup of this XCD
+    const int seq = xcd + 8 * (idx / rows_per_seq), node = idx % rows_per_seq;
+    return seq * rows_per_seq + node;
+}
+
 // ------------------------------------------------------------------------------- O7 windowed
 template <int NT, int E4, bool BF16>
 __global__ __launch_bounds__(NT) void cfg_window_kernel(const void *__restrict__ cond_, const void *__restrict__ uncond_, int V, float cfg,
@@ -378,7 +393,7 @@ __global__ __launch_bounds__(NT) void cfg_window_kernel(const void *__restrict__
     __shared__ double s_redd[32];
     __shared__ int s_redi[32];
     __shared__ double s_mass[256];
-    const int row = blockIdx.x, tid = threadIdx.x;
+    const int row = o7_row_of_block(blockIdx.x, gridDim.x, seq_len ? rows_per_seq : 0), tid = threadIdx.x;
     const float NEG_INF = -__builtin_inff();
     float *out = out_win + (size_t)row * W;
     int cls = 0;
@@ -573,7 +588,7 @@ __global__ __launch_bounds__(NT) void cfg_window_bf16_kernel(const uint16_t *__r
     __shared__ alignas(16) int s_hist[O7_HIST_INTS];
     __shared__ float s_redf[32];
     __shared__ double s_redd[32];
-    const int row = blockIdx.x, tid = threadIdx.x;
+    const int row = o7_row_of_block(blockIdx.x, gridDim.x, seq_len ? rows_per_seq : 0), tid = threadIdx.x;
     const float NEG_INF = -__builtin_inff();
     int cls = 0;
     if (model == LANTERN_MODEL_LUMINA) {

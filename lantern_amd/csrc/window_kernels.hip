@@ -133,7 +133,7 @@ __device__ __forceinline__ float kth_largest_hist(const float4 (&r)[E4], int k, 
 // exp(x) for x <= 0 (softmax arguments): n = rint(x*log2e), r = x - n*ln2 (two-term), 2^(r*log2e) on the
 // hardware exp unit, ldexp.  7 VALU ops, < 1 ulp like the libm/ocml routine it replaces (which costs ~20).
 __device__ __forceinline__ float exp_nonpos(float x) {
-    if (x < -104.0f) return 0.0f;                       // below the smallest subnormal (also -inf)
+    x = fmaxf(x, -104.0f);                              // exp(-104) is below half the smallest subnormal: rounds to 0 (also -inf)
     const float n = rintf(x * 1.44269504088896341f);
     float r = fmaf(-n, 0.693145751953125f, x);          // ln2 high part (exact product for |n| < 2^11)
     r = fmaf(-n, 1.42860682030941723e-6f, r);           // ln2 low part
@@ -578,7 +578,7 @@ __device__ __forceinline__ float kth_largest_hist_bf16(const float4 (&r)[NV4], i
     return key_float(prefix);
 }
 
-template <int NT, int E8>
+template <int NT, int E8, bool FULL>
 __global__ __launch_bounds__(NT) void cfg_window_bf16_kernel(const uint16_t *__restrict__ cond, const uint16_t *__restrict__ uncond, int V,
                                                              float cfg, int model, const int64_t *__restrict__ pos_ids, int64_t pos_base,
                                                              int w_latent, int h_latent, int img_lo, int img_hi, int newline_id, int eos_id,
@@ -617,14 +617,14 @@ __global__ __launch_bounds__(NT) void cfg_window_bf16_kernel(const uint16_t *__r
 #pragma unroll
     for (int it = 0; it < E8; ++it) {
         const int ch = tid + it * NT;
-        const bool in = ch * 8 < W;
+        const bool in = FULL || ch * 8 < W;       // FULL: W == 8 * NT * E8, every chunk is inside the window
         cb[it] = in ? *reinterpret_cast<const Bf16x8 *>(crow + ch * 8) : Bf16x8{make_uint2(0, 0), make_uint2(0, 0)};
         ub[it] = (in && urow) ? *reinterpret_cast<const Bf16x8 *>(urow + ch * 8) : cb[it];
     }
 #pragma unroll
     for (int it = 0; it < E8; ++it) {
         const int e0 = e_base + (tid + it * NT) * 8;
-        const bool in_chunk = (tid + it * NT) * 8 < W;
+        const bool in_chunk = FULL || (tid + it * NT) * 8 < W;
         const uint32_t cw[4] = {cb[it].a.x, cb[it].a.y, cb[it].b.x, cb[it].b.y};
         const uint32_t uw[4] = {ub[it].a.x, ub[it].a.y, ub[it].b.x, ub[it].b.y};
         float o[8];
@@ -661,8 +661,8 @@ __global__ __launch_bounds__(NT) void cfg_window_bf16_kernel(const uint16_t *__r
 #pragma unroll
     for (int it = 0; it < E8; ++it) {
         const int w0 = e_base + (tid + it * NT) * 8 - win_lo;     // window index of the chunk's first id (multiple of 4)
-        if (w0 >= 0 && w0 < W) *reinterpret_cast<float4 *>(out + w0) = r[2 * it];
-        if (w0 + 4 >= 0 && w0 + 4 < W) *reinterpret_cast<float4 *>(out + w0 + 4) = r[2 * it + 1];
+        if (FULL || (w0 >= 0 && w0 < W)) *reinterpret_cast<float4 *>(out + w0) = r[2 * it];
+        if (FULL || (w0 + 4 >= 0 && w0 + 4 < W)) *reinterpret_cast<float4 *>(out + w0 + 4) = r[2 * it + 1];
     }
 }
 
@@ -1552,16 +1552,19 @@ extern "C" int lantern_cfg_mask_topk_window(const void *cond, const void *uncond
         const int chunks = win_len / 8;
         const uint16_t *c16 = (const uint16_t *)cond, *u16 = (const uint16_t *)uncond;
         static const int nt_knob = getenv("LANTERN_O7_NT") ? atoi(getenv("LANTERN_O7_NT")) : 0;   // tuning knob (diagnostic)
-#define CW16(NT_, E8_)                                                                                                              \
-    LANTERN_LAUNCH((cfg_window_bf16_kernel<NT_, E8_>), dim3(rows), dim3(NT_), 0, st, c16, u16, V, cfg, model, pos_ids, pos_base,       \
-                       w_latent, h_latent, img_lo, img_hi, newline_id, eos_id, top_k, seq_len, rows_per_seq, win_lo, win_len, out_win,  \
-                       row_hot, out_kind)
+#define CW16_ARGS c16, u16, V, cfg, model, pos_ids, pos_base, w_latent, h_latent, img_lo, img_hi, newline_id, eos_id, top_k, seq_len, rows_per_seq, win_lo, win_len, out_win, row_hot, out_kind
+#define CW16(NT_, E8_)                                                                                                       \
+    do {                                                                                                                     \
+        if (chunks == NT_ * E8_) LANTERN_LAUNCH((cfg_window_bf16_kernel<NT_, E8_, true>), dim3(rows), dim3(NT_), 0, st, CW16_ARGS);  \
+        else LANTERN_LAUNCH((cfg_window_bf16_kernel<NT_, E8_, false>), dim3(rows), dim3(NT_), 0, st, CW16_ARGS);               \
+    } while (0)
         if (chunks <= 256 * 2) CW16(256, 2);
         else if (chunks <= 256 * 4 && nt_knob == 256) CW16(256, 4);
         else if (chunks <= 512 * 2 && nt_knob != 1024) CW16(512, 2);
         else if (chunks <= 1024 * 1) CW16(1024, 1);
         else CW16(1024, 2);
 #undef CW16
+#undef CW16_ARGS
         LANTERN_CHECK_LAUNCH("cfg_mask_topk_window");
         return LANTERN_OK;
     }

@@ -118,3 +118,51 @@ def test_c4_anole_static_lantern_pp(lam, k):
             assert np.array_equal(cnt[b, :5].cpu().numpy(), ocnt[:5])
             np.testing.assert_allclose(sp[b].cpu().numpy(), osp, rtol=0, atol=PROB_TOL)
     assert n_rej > 0
+
+
+@pytest.mark.parametrize("k,delta", [(3000, 0.3), (2047, 5.0), (1024, 0.1)])
+def test_window_large_k_reads_ids_from_hbm(k, delta):
+    """k + 1 > 1024 staged ids: the windowed kernel's HBM-id scan (several 1024-neighbour rounds with an early exit) -- Lumina
+    static tree at full size, both kernel sets against the oracle."""
+    V, K, lo, W = 65536, 8192, 4, 8192
+    rs = np.random.RandomState(k)
+    tb = oracle.tree_static_build(CS.mc_sim_7b_63)
+    N, (P, D) = len(tb["tree_indices"]), tb["retrieve_indices"].shape
+    ti, pos = tb["tree_indices"], tb["tree_position_ids"]
+    par = CS.node_parents(tb["tree_attn_mask"], pos)
+    R = int(((ti[1:] - 1) // 10).max()) + 1
+    par_row = np.zeros(R, np.int64)
+    for n in range(1, N):
+        par_row[(ti[n] - 1) // 10] = par[n]
+    depth_of_row = pos[par_row]
+    op_off = np.array([np.nonzero(depth_of_row == d)[0][0] for d in range(int(depth_of_row.max()) + 1)], np.int32)
+    tab = perm_table(K, 3072, 9)
+    ri = H.row_index_from_retrieve(tb["retrieve_indices"], N)
+    B = 3
+    cfg_o, cfg_h = oracle.EpConfig.lumina(True, lantern=True, k=k, delta=delta), ops.EpConfig.lumina(True, lantern=True, k=k, delta=delta)
+    logits, ops_l, cands, cps, tcs = [], [], [], [], []
+    for b in range(B):
+        nl = np.full((N, V), -np.inf, np.float32)
+        nl[:, lo:lo + W] = CS.topk_filter((4 * rs.standard_normal((N, W))).astype(np.float32), 2000)
+        dr = np.full((R, V), -np.inf, np.float32)
+        base = np.where(np.isfinite(nl[par_row][:, lo:lo + W]), nl[par_row][:, lo:lo + W], -30.0)
+        dr[:, lo:lo + W] = base + (1.0 + b) * rs.standard_normal((R, W)).astype(np.float32)
+        op = CS.softmax64(CS.topk_filter(dr, 2000)).astype(np.float32)
+        sst = np.stack([rs.choice(V, 10, replace=False, p=op[r].astype(np.float64) / op[r].astype(np.float64).sum()) for r in range(R)])
+        c, cp, tc = oracle.gather_candidates(sst, CS.ss_prob_from(op, sst), 100 + b, ti, tb["retrieve_indices"])
+        logits.append(nl); ops_l.append(op); cands.append(c); cps.append(cp); tcs.append(tc)
+    uni = rs.random_sample((B, 64))
+    aux = ops.StaticAux(cart_prob=dev(np.stack(cps)), orig_prob=dev(np.stack(ops_l)), op_off=dev(op_off), p_idx=dev(tb["p_indices"]),
+                        b_off=dev(tb["b_off"]), b_idx=dev(tb["b_idx"]), tree_cand=dev(np.stack(tcs)))
+    dense = ops.evaluate_posterior(cfg_h, dev(np.stack(logits)), dev(ri), dev(np.stack(cands)), dev(uni), table=dev(tab.view(np.int16)), aux=aux)
+    win = ops.evaluate_posterior_window(cfg_h, V, dev(np.ascontiguousarray(np.stack(logits)[:, :, lo:lo + W])), lo, dev(ri), dev(np.stack(cands)),
+                                        dev(uni), table=dev(tab.view(np.int16)), aux=aux, want_dense=True)
+    for b in range(B):
+        a = oracle.StaticAux(cart_prob=cps[b], orig_prob=ops_l[b], op_off=op_off, p_idx=tb["p_indices"], b_off=tb["b_off"], b_idx=tb["b_idx"],
+                             tree_cand=tcs[b])
+        ob, oa, osp, ocnt = oracle.evaluate_posterior(cfg_o, logits[b], ri, cands[b], uni[b], table=tab, aux=a)
+        for best, alen, sp, cnt in ((dense[0], dense[1], dense[2], dense[3]), (win["best"], win["accept_len"], win["sample_p"], win["counters"])):
+            assert int(cnt[b, 5]) == 0
+            assert (int(best[b]), int(alen[b])) == (ob, oa), (b, int(best[b]), int(alen[b]), ob, oa)
+            assert np.array_equal(cnt[b, :5].cpu().numpy(), ocnt[:5])
+            np.testing.assert_allclose(sp[b].cpu().numpy(), osp, rtol=0, atol=PROB_TOL)

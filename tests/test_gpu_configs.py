@@ -166,3 +166,53 @@ def test_window_large_k_reads_ids_from_hbm(k, delta):
             assert (int(best[b]), int(alen[b])) == (ob, oa), (b, int(best[b]), int(alen[b]), ob, oa)
             assert np.array_equal(cnt[b, :5].cpu().numpy(), ocnt[:5])
             np.testing.assert_allclose(sp[b].cpu().numpy(), osp, rtol=0, atol=PROB_TOL)
+
+
+def test_window_two_workgroups_per_cu_build():
+    """Above 256 sequences per launch the 128-VGPR build of the windowed kernel runs (two workgroups per CU): 264 sequences
+    (8 distinct full-size Lumina steps, tiled) must reproduce the oracle exactly like the one-per-CU build does."""
+    V, K, lo, W, k = 65536, 8192, 4, 8192, 1000
+    rs = np.random.RandomState(77)
+    tb = oracle.tree_static_build(CS.mc_sim_7b_63)
+    N, (P, D) = len(tb["tree_indices"]), tb["retrieve_indices"].shape
+    ti, pos = tb["tree_indices"], tb["tree_position_ids"]
+    par = CS.node_parents(tb["tree_attn_mask"], pos)
+    R = int(((ti[1:] - 1) // 10).max()) + 1
+    par_row = np.zeros(R, np.int64)
+    for n in range(1, N):
+        par_row[(ti[n] - 1) // 10] = par[n]
+    depth_of_row = pos[par_row]
+    op_off = np.array([np.nonzero(depth_of_row == d)[0][0] for d in range(int(depth_of_row.max()) + 1)], np.int32)
+    tab = perm_table(K, 1008, 5)
+    ri = H.row_index_from_retrieve(tb["retrieve_indices"], N)
+    U, REP = 8, 33
+    cfg_o, cfg_h = oracle.EpConfig.lumina(True, lantern=True, k=k, delta=0.1), ops.EpConfig.lumina(True, lantern=True, k=k, delta=0.1)
+    wins, ops_w, cands, cps, tcs, full = [], [], [], [], [], []
+    for b in range(U):
+        nlw = CS.topk_filter((4 * rs.standard_normal((N, W))).astype(np.float32), 2000)
+        base = np.where(np.isfinite(nlw[par_row]), nlw[par_row], -30.0)
+        drw = CS.topk_filter((base + (1.0 + 0.5 * b) * rs.standard_normal((R, W))).astype(np.float32), 2000)
+        opw = CS.softmax64(drw).astype(np.float32)
+        sst = np.stack([rs.choice(W, 10, replace=False, p=opw[r].astype(np.float64) / opw[r].astype(np.float64).sum()) for r in range(R)]) + lo
+        opd = np.zeros((R, V), np.float32); opd[:, lo:lo + W] = opw
+        c, cp, tc = oracle.gather_candidates(sst, CS.ss_prob_from(opd, sst), 100 + b, ti, tb["retrieve_indices"])
+        nld = np.full((N, V), -np.inf, np.float32); nld[:, lo:lo + W] = nlw
+        wins.append(nlw); ops_w.append(opw); cands.append(c); cps.append(cp); tcs.append(tc); full.append((nld, opd))
+    uni = rs.random_sample((U, 64))
+    tile = lambda a: np.concatenate([np.stack(a)] * REP)
+    aux = ops.StaticAux(cart_prob=dev(tile(cps)), orig_prob=dev(tile(ops_w)), op_off=dev(op_off), p_idx=dev(tb["p_indices"]),
+                        b_off=dev(tb["b_off"]), b_idx=dev(tb["b_idx"]), tree_cand=dev(tile(tcs)))
+    out = ops.evaluate_posterior_window(cfg_h, V, dev(tile(wins)), lo, dev(ri), dev(tile(cands)), dev(np.concatenate([uni] * REP)),
+                                        table=ops.pack_vq_table(dev(tab.view(np.int16)), 1008), aux=aux, orig_windowed=True, want_dense=False)
+    assert out["best"].shape[0] == U * REP > 256
+    for b in range(U):
+        a = oracle.StaticAux(cart_prob=cps[b], orig_prob=full[b][1], op_off=op_off, p_idx=tb["p_indices"], b_off=tb["b_off"], b_idx=tb["b_idx"],
+                             tree_cand=tcs[b])
+        ob, oa, osp, ocnt = oracle.evaluate_posterior(cfg_o, full[b][0], ri, cands[b], uni[b], table=tab, aux=a)
+        for rep in range(REP):
+            j = rep * U + b
+            assert int(out["counters"][j, 5]) == 0
+            assert (int(out["best"][j]), int(out["accept_len"][j])) == (ob, oa), (j, b)
+            assert np.array_equal(out["counters"][j, :5].cpu().numpy(), ocnt[:5])
+        np.testing.assert_allclose(out["sample_win"][b].cpu().numpy(), osp[lo:lo + W], rtol=0, atol=PROB_TOL)
+        assert torch.equal(out["sample_win"][b], out["sample_win"][(REP - 1) * U + b])

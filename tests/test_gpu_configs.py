@@ -216,3 +216,60 @@ def test_window_two_workgroups_per_cu_build():
             assert np.array_equal(out["counters"][j, :5].cpu().numpy(), ocnt[:5])
         np.testing.assert_allclose(out["sample_win"][b].cpu().numpy(), osp[lo:lo + W], rtol=0, atol=PROB_TOL)
         assert torch.equal(out["sample_win"][b], out["sample_win"][(REP - 1) * U + b])
+
+
+@pytest.mark.parametrize("Vp", [2048, 4096])
+@pytest.mark.parametrize("static", [False, True])
+def test_window_mid_size_vocabularies(Vp, static):
+    """Window widths 2048 and 4096 select their own workgroup shapes (256x2 / 512x2 float4 per thread) in both windowed kernels:
+    a V == K vocabulary of that size (LlamaGen-style: no mask, processors inside evaluate_posterior), oracle vs both kernel sets."""
+    rs = np.random.RandomState(Vp + int(static))
+    tb = oracle.tree_static_build(CS.mc_sim_7b_63 if static else naive_extend_57)
+    N, (P, D) = len(tb["tree_indices"]), tb["retrieve_indices"].shape
+    ti, pos = tb["tree_indices"], tb["tree_position_ids"]
+    par = CS.node_parents(tb["tree_attn_mask"], pos)
+    R = int(((ti[1:] - 1) // 10).max()) + 1
+    par_row = np.zeros(R, np.int64)
+    for n in range(1, N):
+        par_row[(ti[n] - 1) // 10] = par[n]
+    depth_of_row = pos[par_row]
+    op_off = np.array([np.nonzero(depth_of_row == d)[0][0] for d in range(int(depth_of_row.max()) + 1)], np.int32)
+    tab = perm_table(Vp, 400, 3)
+    ri = H.row_index_from_retrieve(tb["retrieve_indices"], N)
+    B = 4
+    kw = dict(lantern=True, k=300, delta=0.2, temperature=0.9, top_p=1.0, top_k=500)
+    cfg_o, cfg_h = oracle.EpConfig.llamagen(static, **kw), ops.EpConfig.llamagen(static, **kw)
+    nls, ops_l, cands, cps, tcs = [], [], [], [], []
+    for b in range(B):
+        nl = (4 * rs.standard_normal((N, Vp))).astype(np.float32)
+        dr = nl[par_row] + (1.0 + b) * rs.standard_normal((R, Vp)).astype(np.float32)
+        op = CS.softmax64(CS.topk_filter(dr, 500)).astype(np.float32)
+        sst = np.stack([rs.choice(Vp, 10, replace=False, p=op[r].astype(np.float64) / op[r].astype(np.float64).sum()) for r in range(R)])
+        c, cp, tc = oracle.gather_candidates(sst, CS.ss_prob_from(op, sst), int(rs.randint(0, Vp)), ti, tb["retrieve_indices"])
+        nls.append(nl); ops_l.append(op); cands.append(c); cps.append(cp); tcs.append(tc)
+    uni = rs.random_sample((B, 64))
+    aux = None
+    if static:
+        aux = ops.StaticAux(cart_prob=dev(np.stack(cps)), orig_prob=dev(np.stack(ops_l)), op_off=dev(op_off), p_idx=dev(tb["p_indices"]),
+                            b_off=dev(tb["b_off"]), b_idx=dev(tb["b_idx"]), tree_cand=dev(np.stack(tcs)))
+    dense = ops.evaluate_posterior(cfg_h, dev(np.stack(nls)), dev(ri), dev(np.stack(cands)), dev(uni), table=dev(tab.view(np.int16)), aux=aux)
+    win = ops.evaluate_posterior_window(cfg_h, Vp, dev(np.stack(nls)), 0, dev(ri), dev(np.stack(cands)), dev(uni), table=dev(tab.view(np.int16)),
+                                        aux=aux, want_dense=True)
+    # O7w at this width: probability rows (processors applied there) must give the same decisions as logits rows
+    pw, hot = ops.cfg_mask_topk_window(dev(np.stack(nls)).reshape(B * N, Vp), None, 1.0, 0, Vp, model=ops.MODEL_PLAIN, top_k=500, temperature=0.9,
+                                       probs=True)
+    cfg_p = ops.EpConfig.llamagen(static, lantern=True, k=300, delta=0.2, temperature=1.0, top_p=1.0, top_k=0)
+    winp = ops.evaluate_posterior_window(cfg_p, Vp, pw.reshape(B, N, Vp), 0, dev(ri), dev(np.stack(cands)), dev(uni),
+                                         table=dev(tab.view(np.int16)), aux=aux, want_dense=True, rows_probs=True, row_hot=hot.reshape(B, N))
+    for b in range(B):
+        a = None
+        if static:
+            a = oracle.StaticAux(cart_prob=cps[b], orig_prob=ops_l[b], op_off=op_off, p_idx=tb["p_indices"], b_off=tb["b_off"], b_idx=tb["b_idx"],
+                                 tree_cand=tcs[b])
+        ob, oa, osp, ocnt = oracle.evaluate_posterior(cfg_o, nls[b], ri, cands[b], uni[b], table=tab, aux=a)
+        for best, alen, sp, cnt in ((dense[0], dense[1], dense[2], dense[3]), (win["best"], win["accept_len"], win["sample_p"], win["counters"]),
+                                    (winp["best"], winp["accept_len"], winp["sample_p"], winp["counters"])):
+            assert int(cnt[b, 5]) == 0
+            assert (int(best[b]), int(alen[b])) == (ob, oa), (b, int(best[b]), int(alen[b]), ob, oa)
+            assert np.array_equal(cnt[b, :5].cpu().numpy(), ocnt[:5])
+            np.testing.assert_allclose(sp[b].cpu().numpy(), osp, rtol=0, atol=PROB_TOL)

@@ -281,10 +281,12 @@ def test_window_full_size_lumina_pipeline_vs_oracle():
         assert torch.equal(out_p[key], out[key]), key
 
 
+@pytest.mark.parametrize("V", [2048, 4096, 16384])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-def test_cfg_window_probs_and_temperature(dtype):
-    """out_kind = PROBS and the temperature argument of O7w against torch: softmax(topk(cfg(c,u)/T))."""
-    V, lo, W, k, T = 16384, 0, 16384, 500, 0.7
+def test_cfg_window_probs_and_temperature(dtype, V):
+    """out_kind = PROBS and the temperature argument of O7w against torch: softmax(topk(cfg(c,u)/T)); every window width
+    class (its own workgroup shape in the f32 and in the 16-byte-load bf16 kernel)."""
+    lo, W, k, T = 0, V, 500, 0.7
     g = torch.Generator().manual_seed(3)
     c = (3 * torch.randn(5, V, generator=g)).to(dtype)
     u = torch.randn(5, V, generator=g).to(dtype)

@@ -94,3 +94,12 @@ def test_empty_batches_are_ok_and_launch_nothing():
     assert L.lantern_kv_gather(one, one, one, 0, 2, C.c_int64(64), C.c_int64(128), C.c_int64(128), one, 0, 15, 6, one, one, None, None) == 0
     assert L.lantern_accept_gather(None, 2, 0, 2, 26, 4096, one, 0, 15, 6, None, one, one, None, 0, None, None, None, None, None) == 0
     assert L.lantern_gather_candidates(one, None, one, one, one, 0, 110, 26, 15, 6, one, one, None, None) == 0
+
+
+def test_header_is_plain_c(tmp_path):
+    """include/lantern_hip.h is the FFI contract: it must compile as C99 on its own (no C++ or torch types)."""
+    import subprocess
+    src = tmp_path / "hdr.c"
+    src.write_text('#include "lantern_hip.h"\nint main(void) { return sizeof(lantern_ep_params) + sizeof(lantern_ep_buffers) + sizeof(lantern_ep_window) > 0 ? 0 : 1; }\n')
+    inc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", inc, "-c", str(src), "-o", str(tmp_path / "hdr.o")])

@@ -162,7 +162,8 @@ __global__ __launch_bounds__(EP_THREADS) void ep_kernel(const lantern_ep_params 
     const int32_t *row_g = buf.row_index + (prm.row_index_per_seq ? (size_t)b * Ps * Ds : 0);
     for (int t = tid; t < Ps * Ds; t += EP_THREADS) {
         S.cand[t] = (int)cand_g[t];
-        S.row[t] = row_g[t];
+        const int rw = row_g[t];
+        S.row[t] = rw < 0 ? 0 : (rw >= prm.rows_per_seq ? prm.rows_per_seq - 1 : rw);   // a bad row map must not read outside the batch
     }
     const float *logits = buf.logits + (size_t)b * prm.rows_per_seq * V;
     float *g = buf.sample_p + (size_t)b * V;
@@ -251,7 +252,10 @@ __global__ __launch_bounds__(EP_THREADS) void ep_kernel(const lantern_ep_params 
                 for (int base = 0; base < k; base += EP_THREADS) {
                     const int idx = base + tid;
                     double v = 0.0;
-                    if (idx < k) v = (double)g[(int)nb[idx] + off];
+                    if (idx < k) {
+                        const int id = (int)nb[idx] + off;          // a table id beyond the vocabulary carries no mass
+                        v = id < V ? (double)g[id] : 0.0;
+                    }
                     double inc = wave_scan_incl(v);
                     if (lane == 63) S.scan_tot[wave] = inc;
                     __syncthreads();
@@ -302,11 +306,15 @@ __global__ __launch_bounds__(EP_THREADS) void ep_kernel(const lantern_ep_params 
             if (!is_static) {
                 if (tid == 0) g[x] = 0.0f;
                 if (zero_nb)
-                    for (int t = tid; t < nz; t += EP_THREADS) g[(int)nb[t] + off] = 0.0f;
+                    for (int t = tid; t < nz; t += EP_THREADS) {
+                        const int id = (int)nb[t] + off;
+                        if (id < V) g[id] = 0.0f;
+                    }
                 __syncthreads();
             } else {
-                const float *qsrc = buf.orig_prob +
-                                    ((size_t)b * prm.R + buf.op_off[i - 1] + buf.p_idx[j * Ds + i]) * (size_t)V;
+                int qrow = buf.op_off[i - 1] + buf.p_idx[j * Ds + i];
+                qrow = qrow < 0 ? 0 : (qrow >= prm.R ? prm.R - 1 : qrow);
+                const float *qsrc = buf.orig_prob + ((size_t)b * prm.R + qrow) * (size_t)V;
                 const int b0 = buf.b_off[j * Ds + i], b1 = buf.b_off[j * Ds + i + 1];
                 for (int i4 = tid; i4 * 4 < V; i4 += EP_THREADS)
                     reinterpret_cast<float4 *>(qw)[i4] = reinterpret_cast<const float4 *>(qsrc)[i4];
@@ -323,7 +331,10 @@ __global__ __launch_bounds__(EP_THREADS) void ep_kernel(const lantern_ep_params 
                 }
                 if (zero_nb) {
                     float *tgt = (prm.mode == LANTERN_MODE_STATIC_LUMINA) ? g : qw;
-                    for (int t = tid; t < nz; t += EP_THREADS) tgt[(int)nb[t] + off] = 0.0f;
+                    for (int t = tid; t < nz; t += EP_THREADS) {
+                        const int id = (int)nb[t] + off;
+                        if (id < V) tgt[id] = 0.0f;
+                    }
                     __syncthreads();
                 }
                 for (int i4 = tid; i4 * 4 < V; i4 += EP_THREADS) {

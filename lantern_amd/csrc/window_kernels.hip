@@ -1029,7 +1029,8 @@ __global__ __launch_bounds__(NT, WPE) void epw_kernel(const EpwArgs args) {
             }
         }
         {
-            const int rid = Srow[fi * Ds + (i - 1)];
+            int rid = Srow[fi * Ds + (i - 1)];
+            rid = rid < 0 ? 0 : (rid >= prm.rows_per_seq ? prm.rows_per_seq - 1 : rid);     // a bad row map must not read outside the batch
             const int hot = !hot_g ? -1 : (hot_in_lds ? S.hot[rid] : hot_g[rid]);
             EPW_STAMP(10);
             if (hot < 0 && rp_rid != rid) row_load<NT, E4>(logits + (size_t)rid * W, W, rp);
@@ -1108,7 +1109,9 @@ __global__ __launch_bounds__(NT, WPE) void epw_kernel(const EpwArgs args) {
             // simply dropped if the candidate is accepted (one 32 KB row, L2/MALL-resident for the next try)
             float4 q[E4];
             if (is_static) {
-                const float *qsrc = buf.orig_prob + ((size_t)b * prm.R + rdlane(qrow_lane, j)) * (size_t)win.orig_prob_stride + win.orig_prob_offset;
+                int qrow = rdlane(qrow_lane, j);
+                qrow = qrow < 0 ? 0 : (qrow >= prm.R ? prm.R - 1 : qrow);                           // same for the drafter-row index
+                const float *qsrc = buf.orig_prob + ((size_t)b * prm.R + qrow) * (size_t)win.orig_prob_stride + win.orig_prob_offset;
 #pragma unroll
                 for (int it = 0; it < E4; ++it) {
                     const int i4 = tid + it * NT;
@@ -1363,7 +1366,8 @@ __global__ __launch_bounds__(NT, WPE) void epw_kernel(const EpwArgs args) {
 
     const int from_residual = (adjust && a != D) ? 1 : 0;
     if (status == LANTERN_ST_OK && !from_residual) {
-        const int rid = Srow[best * Ds + (a - 1)];
+        int rid = Srow[best * Ds + (a - 1)];
+        rid = rid < 0 ? 0 : (rid >= prm.rows_per_seq ? prm.rows_per_seq - 1 : rid);
         const int hot = !hot_g ? -1 : (hot_in_lds ? S.hot[rid] : hot_g[rid]);
         if (hot < 0 && rp_rid != rid) row_load<NT, E4>(logits + (size_t)rid * W, W, rp);
         row_softmax_to_lds<NT, E4>(rp, hot, rows_probs, lo, W, prm.temperature, prm.top_k, V, g, out_tok, out_mass, S, ph);

@@ -34,7 +34,7 @@ __global__ __launch_bounds__(256) void gather_candidates_kernel(const int64_t *_
     __syncthreads();
     for (int n = threadIdx.x; n < N; n += blockDim.x) {
         const int64_t ti = staged ? (int64_t)s_ti[n] : tree_indices[n];
-        tree_cand[(size_t)b * N + n] = ti == 0 ? st : tok[ti - 1];
+        tree_cand[(size_t)b * N + n] = (ti <= 0 || ti > n_flat) ? st : tok[ti - 1];      // index 0 = the sample token; out-of-range ids read nothing
     }
 #pragma unroll
     for (int u = 0; u < GC_PER; ++u) {
@@ -43,10 +43,11 @@ __global__ __launch_bounds__(256) void gather_candidates_kernel(const int64_t *_
             const int64_t r = rr[u];
             int64_t c = -1;
             float p = 1.0f;
-            if (r >= 0) {
+            if (r >= 0 && r < N) {
                 const int64_t ti = staged ? (int64_t)s_ti[r] : tree_indices[r];
-                c = ti == 0 ? st : tok[ti - 1];
-                if (prb) p = ti == 0 ? 1.0f : prb[ti - 1];
+                const bool root = ti <= 0 || ti > n_flat;
+                c = root ? st : tok[ti - 1];
+                if (prb) p = root ? 1.0f : prb[ti - 1];
             }
             cand[(size_t)b * PD + i] = c;
             if (cart_prob) cart_prob[(size_t)b * PD + i] = p;
@@ -56,10 +57,11 @@ __global__ __launch_bounds__(256) void gather_candidates_kernel(const int64_t *_
         const int64_t r = retrieve[i];
         int64_t c = -1;
         float p = 1.0f;
-        if (r >= 0) {
+        if (r >= 0 && r < N) {
             const int64_t ti = tree_indices[r];
-            c = ti == 0 ? st : tok[ti - 1];
-            if (prb) p = ti == 0 ? 1.0f : prb[ti - 1];
+            const bool root = ti <= 0 || ti > n_flat;
+            c = root ? st : tok[ti - 1];
+            if (prb) p = root ? 1.0f : prb[ti - 1];
         }
         cand[(size_t)b * PD + i] = c;
         if (cart_prob) cart_prob[(size_t)b * PD + i] = p;

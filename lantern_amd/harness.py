@@ -69,6 +69,9 @@ class WorkloadConfig:
                                     # the sample token, O10 only evaluate_posterior's result); fork/join with events, capturable.
                                     # Measured SLOWER on MI355X (116 vs 103 us/step): the cross-stream event waits cost more than the
                                     # two small kernels they hide; kept as an option
+    direct_logs: bool = True        # eager windowed launches: O8 writes (best, accept_len, counters, bonus token) straight into the
+                                    # step's log row and the following kernels read them there (per-step pointers from the host), so
+                                    # the bookkeeping kernel is only launched when an image can actually end (host-side bound)
     fuse_update: bool = True        # windowed path: O9 + O10 in one launch (lantern_update_inference_inputs)
     pack_table: bool = True         # windowed path: neighbour table packed to [K, ceil8(k+1)] (lantern_pack_vq_table)
     n_groups: int = 1               # >1: the sequences are split into groups, each launched on its own HIP stream, so that one
@@ -250,6 +253,7 @@ class LuminaVerifyWorkload:
         else:
             self.sample_token.copy_(self.first_token)
         self.step_idx = 0
+        self._len_ub = 0                  # host-side upper bound of (length - base) over all sequences (direct_logs)
         self._forked = False
         if hasattr(self, "step_dev"):
             self.step_dev.zero_()
@@ -447,8 +451,28 @@ class LuminaVerifyWorkload:
             ev[0].record(main)
             side.wait_event(ev[0])
             st_side = C.c_void_p(side.cuda_stream)
+        # where this step's results live: the staging buffers (+ the bookkeeping kernel copies them into the logs), or -- eager
+        # windowed launches -- directly the step's log row
+        direct = self.windowed and c.direct_logs and self.graphs is None and not torch.cuda.is_current_stream_capturing()
+        if direct:
+            step = self.step_idx
+            if step >= c.max_steps:
+                raise _lib.LanternError(f"step {step} >= max_steps {c.max_steps}: size the logs for the run")
+            s0 = g * self.Bg
+            row = lambda t: vp(t[step, s0:].data_ptr())
+            p_best, p_alen, p_cnt, p_tok = row(self.log_best), row(self.log_alen), row(self.log_cnt), row(self.log_token)
+            p_sample = A["sample_token"] if step == 0 else vp(self.log_token[step - 1, s0:].data_ptr())
+            eb, ew = A["ep_buf"], A["ep_win"]
+            eb.best, eb.accept_len, eb.counters = p_best.value, p_alen.value, p_cnt.value
+            ew.u_bonus, ew.token = self.u_bonus[step, s0:].data_ptr(), p_tok.value
+        else:
+            p_best, p_alen, p_sample = A["st_best"], A["st_alen"], A["sample_token"]
+            if self.windowed:                     # the cached structs may carry a previous direct step's pointers
+                eb, ew = A["ep_buf"], A["ep_win"]
+                eb.best, eb.accept_len, eb.counters = A["st_best"].value, A["st_alen"].value, A["st_cnt"].value
+                ew.u_bonus, ew.token = A["u_cur"].value, A["st_token"].value
         # O6 candidate assembly (side stream: only needs the sample token)
-        check(L.lantern_gather_candidates(A["ss_token"], A["ss_prob"], A["sample_token"], vp(self.d_tree_indices.data_ptr()),
+        check(L.lantern_gather_candidates(A["ss_token"], A["ss_prob"], p_sample, vp(self.d_tree_indices.data_ptr()),
                                           vp(self.d_retrieve.data_ptr()), B, self.R * 10, N, P, D, A["tree_cand"], A["cand"], A["cart_prob"],
                                           st_side), "gather_candidates")
         if side is not None:
@@ -485,8 +509,8 @@ class LuminaVerifyWorkload:
         fused = c.with_kv and self.windowed and c.fuse_update and side is None
         if not fused:
             # O10 accepted hidden + token append (+ bonus token on the dense path); side stream: beside the KV gather
-            check(L.lantern_accept_gather(A["hidden"], 2, B, 2, N, HIDDEN, vp(self.d_retrieve.data_ptr()), 0, P, D, A["cand"], A["st_best"],
-                                          A["st_alen"], A["sample_p"], V, None if self.windowed else A["u_cur"], A["out_hidden"],
+            check(L.lantern_accept_gather(A["hidden"], 2, B, 2, N, HIDDEN, vp(self.d_retrieve.data_ptr()), 0, P, D, A["cand"], p_best,
+                                          p_alen, A["sample_p"], V, None if self.windowed else A["u_cur"], A["out_hidden"],
                                           A["acc_tokens"], None if self.windowed else A["st_token"], st_side), "accept_gather")
         if side is not None:
             ev[3].record(side)
@@ -498,20 +522,33 @@ class LuminaVerifyWorkload:
             if fused:
                 check(L.lantern_update_inference_inputs(A["slab_ptrs"], A["slab_seq"], A["cur"], 2 * B, 2, C.c_int64(2 * c.kv_layers * c.kv_heads),
                                                         C.c_int64(c.kv_smax + c.kv_pad_rows), C.c_int64(c.kv_dim), vp(self.d_retrieve.data_ptr()),
-                                                        0, P, D, A["st_best"], A["st_alen"], A["nxt"], A["hidden"], 2, B, 2, N, HIDDEN,
+                                                        0, P, D, p_best, p_alen, A["nxt"], A["hidden"], 2, B, 2, N, HIDDEN,
                                                         A["cand"], A["out_hidden"], A["acc_tokens"], st), "update_inference_inputs")
             else:
                 check(L.lantern_kv_gather(A["slab_ptrs"], A["slab_seq"], A["cur"], 2 * B, 2, C.c_int64(2 * c.kv_layers * c.kv_heads),
                                           C.c_int64(c.kv_smax + c.kv_pad_rows), C.c_int64(c.kv_dim), vp(self.d_retrieve.data_ptr()), 0, P, D,
-                                          A["st_best"], A["st_alen"], A["nxt"], st), "kv_gather")
+                                          p_best, p_alen, A["nxt"], st), "kv_gather")
             if events:
                 self._disarm(events, "kv_gather")
         else:
             s0 = g * self.Bg
-            torch.add(self.lens[parity][2 * s0:2 * s0 + 2 * B], (self.st_alen[s0:s0 + B] + 1).repeat(2), out=self.lens[parity ^ 1][2 * s0:2 * s0 + 2 * B])
+            torch.add(self.lens[parity][2 * s0:2 * s0 + 2 * B], ((self.log_alen[self.step_idx, s0:s0 + B] if direct else self.st_alen[s0:s0 + B]) + 1).repeat(2), out=self.lens[parity ^ 1][2 * s0:2 * s0 + 2 * B])
         if side is not None:
             main.wait_event(ev[3])                # join (the dense path's bonus token feeds the bookkeeping below)
         # harness bookkeeping (sequence management, not the hot path): logs, next sample token, image wrap-around, step counter
+        if direct:
+            # everything is already where it belongs; only the end of an image needs the kernel, and lengths grow by at most D
+            # per step: skip it while no sequence can have reached the image length
+            if g == 0:
+                self._len_ub += D
+            if self._len_ub >= TOKENS_PER_IMAGE:
+                s0 = g * self.Bg
+                nxt, base = self.lens[parity ^ 1][2 * s0:2 * s0 + 2 * B], self.len_base[2 * s0:2 * s0 + 2 * B]
+                torch.where(nxt - base >= TOKENS_PER_IMAGE, base, nxt, out=nxt)
+                if g == self.G - 1:             # refresh the bound: one host sync every few hundred steps
+                    self.join()
+                    self._len_ub = int((self.lens[parity ^ 1] - self.len_base).max().item())
+            return
         check(L.lantern_harness_advance(B, 2 * B, c.n_seq, C.c_int64(TOKENS_PER_IMAGE), C.c_int64(c.max_steps),
                                         C.c_int64(-1 if torch.cuda.is_current_stream_capturing() or self.graphs is not None else self.step_idx),
                                         A["step_dev"], A["st_best"],

@@ -103,3 +103,24 @@ def test_header_is_plain_c(tmp_path):
     src.write_text('#include "lantern_hip.h"\nint main(void) { return sizeof(lantern_ep_params) + sizeof(lantern_ep_buffers) + sizeof(lantern_ep_window) > 0 ? 0 : 1; }\n')
     inc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include")
     subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", inc, "-c", str(src), "-o", str(tmp_path / "hdr.o")])
+
+
+def test_uniform_fifo_replays_the_python_stream_in_order():
+    """verify.UniformFifo: the device window + cursor must hand the acceptance tests exactly the sequence `random.random()`
+    would have produced, across refills, whatever the (data-dependent) number of draws per step is."""
+    import random
+    import torch
+    from lantern_amd.verify import UniformFifo
+    ref = random.Random(99)
+    expected = [ref.random() for _ in range(5000)]
+    fifo = UniformFifo(torch.device("cpu"), window=64, rng=random.Random(99))
+    rs = random.Random(5)
+    consumed = []
+    for _ in range(400):
+        upper = rs.randint(1, 25)                 # what the host reserves: an upper bound of this step's draws
+        fifo.reserve(upper)
+        used = rs.randint(0, upper)               # what the kernel really consumed
+        c = int(fifo.cursor[0])
+        consumed += fifo.buf[0, c:c + used].tolist()
+        fifo.cursor += used
+    assert consumed == expected[:len(consumed)] and len(consumed) > 1000

@@ -823,6 +823,7 @@ __global__ __launch_bounds__(NT, WPE) void epw_kernel(const EpwArgs args) {
     const int pd_cap = epw_pd_cap(Ps, Ds);
     int *const Srow = Scand + pd_cap, *const Spidx = Srow + pd_cap, *const Sboff = Spidx + pd_cap;
     float *const Scart = reinterpret_cast<float *>(Sboff + pd_cap);
+    int *const Sflag = reinterpret_cast<int *>(Scart + pd_cap);       // per (path, depth): bit 1 image token, bit 0 syntax token
     const int P = buf.n_paths ? buf.n_paths[b] : Ps;
     const int D = buf.n_depth ? buf.n_depth[b] : Ds;
     const int k = prm.k, off = prm.tok_offset;
@@ -891,7 +892,12 @@ __global__ __launch_bounds__(NT, WPE) void epw_kernel(const EpwArgs args) {
         for (int u = 0; u < PD_PER; ++u) {
             const int t = tid + u * NT;
             if (t < npd) {
-                Scand[t] = (int)c_[u];
+                const int tok = (int)c_[u];
+                int fl = (tok >= prm.img_lo && tok < prm.img_hi) ? 2 : 0;
+                if (prm.syntax_shortcut)
+                    for (int q = 0; q < prm.n_syntax; ++q) fl |= (tok == prm.syntax[q]) ? 1 : 0;
+                Sflag[t] = fl;
+                Scand[t] = tok;
                 Srow[t] = r_[u];
                 if (is_static) {
                     Scart[t] = ct_[u];
@@ -962,9 +968,7 @@ __global__ __launch_bounds__(NT, WPE) void epw_kernel(const EpwArgs args) {
             b0_lane = Sboff[pl];
             b1_lane = Sboff[pl + 1];
         }
-        int flag_lane = (x_lane >= prm.img_lo && x_lane < prm.img_hi) ? 2 : 0;     // bit 1: image token, bit 0: syntax token
-        if (prm.syntax_shortcut)
-            for (int t = 0; t < prm.n_syntax; ++t) flag_lane |= (x_lane == prm.syntax[t]) ? 1 : 0;
+        const int flag_lane = (lane < P) ? Sflag[pl] : 0;     // bit 1: image token, bit 0: syntax token (classified once, at staging)
         const unsigned long long todo0 = eq_mask & __ballot(x_lane != -1);
         EPW_STAMPG(17);
         // neighbour ids of the level's candidates: their HBM reads are issued first, the row's loads second; both are in
@@ -1617,7 +1621,7 @@ extern "C" int lantern_evaluate_posterior_window(const lantern_ep_params *prm, c
     }
     hipStream_t st = (hipStream_t)stream;
     const int W = win->win_len;
-    const size_t lds = epw_shared_offset(W) + sizeof(EwShared) + (size_t)5 * epw_pd_cap(p.P, p.D) * 4;
+    const size_t lds = epw_shared_offset(W) + sizeof(EwShared) + (size_t)6 * epw_pd_cap(p.P, p.D) * 4;
     dim3 grid(p.B);
     const int nz = (p.k + 1 < p.table_cols) ? p.k + 1 : p.table_cols;
     const bool lds_ids = !p.lantern || nz <= EW_PF_K;

@@ -189,3 +189,42 @@ def test_window_and_dense_kernel_sets_generate_the_same_tokens():
                                      tree_choices=mc_sim_7b_63)
         outs.append((ids.cpu(), accept))
     assert outs[0][1] == outs[1][1] and torch.equal(outs[0][0], outs[1][0])
+
+
+@pytest.mark.parametrize("version,cfg_mode", [(1, "sequential"), (2, "sequential"), (2, "parallel"), (1, "parallel")])
+def test_generate_with_the_drafter_model_mirror(version, cfg_mode):
+    """The two mirrors plugged together: EaLumina_mGPT.generate() driving drafters.cnets.Model (real input stage, attention
+    mask, decoder layer, tree loops on the HIP ops) on top of the scripted target.  The drafter's proposals are arbitrary here
+    (random weights), so few are accepted -- but every interface between the classes is exercised and the KV rows must still
+    spell the emitted sequence."""
+    from lantern_amd.drafters import cnets
+    random.seed(4321)
+    torch.manual_seed(1)
+    dev = torch.device("cuda")
+    head = Head2(dev)
+    cfg = types.SimpleNamespace(num_hidden_layers=1, num_key_value_heads=HKV, max_position_embeddings=SMAX, hidden_size=H,
+                                num_attention_heads=4, intermediate_size=128, vocab_size=V, pad_token_id=None)
+    base_cfg = types.SimpleNamespace(num_hidden_layers=2, num_key_value_heads=HKV, max_position_embeddings=SMAX, hidden_size=HKV * DH,
+                                     num_attention_heads=HKV)
+    base = types.SimpleNamespace(model=FakeInner(dev), lm_head=head, config=base_cfg, dtype=torch.bfloat16)
+    drafter = cnets.Model(cfg, total_tokens=59, depth=4, top_k=10, model_type="lumina_mgpt").to(dev).to(torch.bfloat16)
+    g = torch.Generator(device="cpu").manual_seed(1)
+    table = ops.build_vq_table(torch.randn(8192, 8, generator=g).to(dev))
+    mdl = EaLumina_mGPT(base, drafter, table, cfg_mode=cfg_mode, eagle_version=version)
+    mdl.uniform_window = 256
+    prompt = torch.randint(9000, 12000, (1, 7), device="cuda")
+    out_ids, accept = mdl.eagenerate(prompt, max_new_tokens=24, cfg_scale=3.0, top_k=200, lantern=True, lantern_k=100, lantern_delta=0.1,
+                                     tree_choices=mc_sim_7b_63)
+    ids = out_ids[0]
+    L0 = prompt.shape[1] + 3
+    assert ids.shape[0] == L0 + sum(accept) and sum(accept) >= 24 and all(1 <= a <= 7 for a in accept)
+    new = ids[L0 + 1:]
+    assert ((new >= 4) & (new < 8196) | (new == 8803) | (new == 8196)).all()
+    if cfg_mode == "parallel":
+        data, n_valid = mdl.past_key_values_data[0], int(mdl.current_length_data[0])
+        tok, pos = decode(data[0, 0, 0, :n_valid].float())
+    else:
+        data, n_valid = mdl.past_key_values_data["cond"][0], int(mdl.current_length_data["cond"][0])
+        tok, pos = decode(data[1, 0, 1, :n_valid].float())
+    assert n_valid == ids.shape[0] and tok.tolist() == ids.tolist() and pos.tolist() == list(range(n_valid))
+    assert drafter.stable_kv is not None and drafter.stable_kv[0][0].shape[0] == 2

@@ -228,3 +228,76 @@ def test_generate_with_the_drafter_model_mirror(version, cfg_mode):
         tok, pos = decode(data[1, 0, 1, :n_valid].float())
     assert n_valid == ids.shape[0] and tok.tolist() == ids.tolist() and pos.tolist() == list(range(n_valid))
     assert drafter.stable_kv is not None and drafter.stable_kv[0][0].shape[0] == 2
+
+
+class FakeLlamaGenInner:
+    """LlamaGen-style base: called with `cond_idx` (the 120-position conditioning block of both CFG rows) for the prefill, then with
+    `input_ids`; writes (token, position) into its K/V rows like FakeInner."""
+
+    def __init__(self, dev, n_layers=2):
+        lin = types.SimpleNamespace(weight=torch.zeros(1, device=dev))
+        self.layers = [types.SimpleNamespace(self_attn=types.SimpleNamespace(q_proj=lin)) for _ in range(n_layers)]
+        self.tree_mask, self.tree_mode, self.dev = None, None, dev
+
+    def __call__(self, cond_idx=None, input_ids=None, attention_mask=None, past_key_values=None, position_ids=None):
+        if cond_idx is not None:
+            B, T = cond_idx.shape[:2]
+            input_ids = torch.zeros(B, T, dtype=torch.long, device=self.dev)
+        B, T = input_ids.shape
+        cur = int(past_key_values[0][0].current_length)
+        if position_ids is None:
+            position_ids = torch.arange(cur, cur + T, device=self.dev)[None].expand(B, T)
+        position_ids = position_ids.reshape(-1, T).expand(B, T)
+        hidden = torch.zeros(B, T, H, device=self.dev, dtype=torch.bfloat16)
+        hidden[..., 0] = (input_ids % 128).to(torch.bfloat16)
+        hidden[..., 2] = (input_ids // 128).to(torch.bfloat16)
+        hidden[..., 1] = (position_ids % 128).to(torch.bfloat16)
+        hidden[..., 3] = (position_ids // 128).to(torch.bfloat16)
+        kv = hidden[:, None, :, :DH].expand(B, HKV, T, DH).contiguous()
+        for layer in past_key_values:
+            for c in layer:
+                c.cat(kv, dim=2)
+        return (hidden,)
+
+
+@pytest.mark.parametrize("static_tree,top_p,kernel_set", [(False, 1.0, "window"), (True, 0.9, "window"), (False, 0.9, "window"),
+                                                           (True, 1.0, "dense")])
+def test_llamagen_generate_end_to_end(static_tree, top_p, kernel_set):
+    """ea_model_llamagen.EaModel.generate() (V == K, processors incl. top-p, 120-token zero prefix) with drafters.cnets.Model as the
+    drafter: the KV rows must spell the emitted sequence behind the conditioning block."""
+    from lantern_amd.drafters import cnets
+    from lantern_amd.drafters.choices import naive_extend_57
+    from lantern_amd.ea_model_llamagen import EaModel
+    Vl = 4096
+    random.seed(7)
+    torch.manual_seed(2)
+    dev = torch.device("cuda")
+
+    class HeadL(Head2):
+        def __init__(self, dev):
+            g = torch.Generator(device="cpu").manual_seed(5)
+            self.weight = torch.zeros(Vl, H, device=dev, dtype=torch.bfloat16)
+            self.table = (3.0 * torch.randn(M, Vl, generator=g)).to(torch.bfloat16).to(dev)
+
+    head = HeadL(dev)
+    base_cfg = types.SimpleNamespace(num_hidden_layers=2, num_key_value_heads=HKV, max_position_embeddings=SMAX, hidden_size=HKV * DH,
+                                     num_attention_heads=HKV)
+    base = types.SimpleNamespace(model=FakeLlamaGenInner(dev), lm_head=head, config=base_cfg, dtype=torch.bfloat16)
+    base.encode_prompt = lambda prompt, cfg: (torch.zeros(2, 120, H, device=dev, dtype=torch.bfloat16), None)
+    dcfg = types.SimpleNamespace(num_hidden_layers=1, hidden_size=H, num_attention_heads=4, intermediate_size=128, vocab_size=Vl, pad_token_id=None)
+    drafter = cnets.Model(dcfg, total_tokens=59, depth=4, top_k=10, model_type="llamagen").to(dev).to(torch.bfloat16)
+    drafter.init_tree()
+    g = torch.Generator(device="cpu").manual_seed(1)
+    table = ops.build_vq_table(torch.randn(Vl, 8, generator=g).to(dev))
+    mdl = EaModel(base, drafter, table)
+    mdl.uniform_window = 256
+    mdl.kernel_set = kernel_set
+    tokens, mean_accept, seconds = mdl.generate(prompt=["a photo"], max_length=30, temperature=1.0, top_k=300, top_p=top_p, cfg=4.0,
+                                                lantern=True, lantern_k=100, lantern_delta=0.2, static_tree=static_tree,
+                                                tree_choices=naive_extend_57)
+    assert tokens.shape == (1, 30) and 1.0 <= mean_accept <= 7.0 and seconds > 0
+    assert ((tokens >= 0) & (tokens < Vl)).all()
+    data, n_valid = base.past_key_values_data[0], int(base.current_length_data[0])
+    tok, pos = decode(data[0, 0, 0, :n_valid].float())
+    assert pos.tolist() == list(range(n_valid)) and (tok[:120] == 0).all()
+    assert tok[120:120 + 30].tolist() == tokens[0].tolist()[:n_valid - 120]

@@ -275,7 +275,32 @@ class Model(nn.Module):
 
     # ------------------------------------------------------------------ LlamaGen / Anole: cnets_llamagen.py:732-912
     @torch.no_grad()
-    def topK_genrate(self, hidden_states, input_ids, head, logits_processor, cfg_scale):
+    def _prefill(self, hidden_states, input_ids, input_position_diff, attention_mask):
+        """First drafter forward of a call: everything past the cached prefix.  Anole (`input_position_diff` given,
+        cnets_anole.py:815-831) runs the uncond row at positions clamp(pos - diff, 0) and passes the padding mask."""
+        dev = hidden_states.device
+        kv_len = self.stable_kv[0][0].shape[2] if self.stable_kv is not None else 0
+        pos = torch.arange(kv_len, input_ids.shape[1], device=dev)[None]
+        kw = {}
+        if input_position_diff is not None:
+            pos = torch.cat([pos, torch.clamp(pos - input_position_diff, 0)])
+            kw["attention_mask"] = attention_mask
+        elif self.stable_kv is None:
+            pos = None
+        out_hidden, pkv = self(hidden_states, input_ids=input_ids[:, kv_len:], past_key_values=self.stable_kv, use_cache=True,
+                               position_ids=pos, **kw)
+        self.stable_kv = pkv
+        return out_hidden, pkv
+
+    def _tree_positions(self, len_posi, offsets, input_position_diff):
+        pos = len_posi + offsets
+        if input_position_diff is None:
+            return pos
+        pos = pos[None]
+        return torch.cat([pos, pos - input_position_diff])          # no clamp inside the loop (cnets_anole.py:858-862)
+
+    @torch.no_grad()
+    def topK_genrate(self, hidden_states, input_ids, head, logits_processor, cfg_scale, input_position_diff=None, attention_mask=None):
         self.cfg_scale = cfg_scale
         dev = hidden_states.device
         input_ids = input_ids.to(dev)
@@ -284,14 +309,8 @@ class Model(nn.Module):
         len_posi = input_ids.shape[1]
         k = self.top_k
         self.reset()
-        if self.stable_kv is not None:
-            kv_len = self.stable_kv[0][0].shape[2]
-            pos = torch.arange(kv_len, input_ids.shape[1], device=dev)[None]
-            out_hidden, pkv = self(hidden_states, input_ids=input_ids[:, kv_len:], past_key_values=self.stable_kv, use_cache=True,
-                                   position_ids=pos)
-        else:
-            out_hidden, pkv = self(hidden_states, input_ids=input_ids, use_cache=True)
-        self.stable_kv = pkv
+        akw = {} if input_position_diff is None else {"attention_mask": attention_mask}
+        out_hidden, pkv = self._prefill(hidden_states, input_ids, input_position_diff, attention_mask)
         last_hidden = out_hidden[:, -1]
         ho = self._head(head, last_hidden)
         half = ho.shape[0] // 2
@@ -306,8 +325,8 @@ class Model(nn.Module):
         cs = torch.arange(k, device=dev)
         for i in range(self.depth):
             self.tree_mask = tree_mask
-            position_ids = len_posi + self.position_ids
-            out_hidden, pkv = self(input_hidden, input_ids=input_ids, past_key_values=pkv, position_ids=position_ids, use_cache=True)
+            position_ids = self._tree_positions(len_posi, self.position_ids, input_position_diff)
+            out_hidden, pkv = self(input_hidden, input_ids=input_ids, past_key_values=pkv, position_ids=position_ids, use_cache=True, **akw)
             len_posi += 1
             parents_list.append(cs + (1 + k * k * max(0, i - 1) + (k if i > 0 else 0)))
             ho = self._head(head, out_hidden)
@@ -326,21 +345,15 @@ class Model(nn.Module):
 
     # ------------------------------------------------------------------ LlamaGen / Anole static: cnets_llamagen.py:944-1023
     @torch.no_grad()
-    def topK_genrate_v1(self, hidden_states, input_ids, head, logits_processor, cfg_scale):
+    def topK_genrate_v1(self, hidden_states, input_ids, head, logits_processor, cfg_scale, input_position_diff=None, attention_mask=None):
         self.cfg_scale = cfg_scale
         dev = hidden_states.device
         input_ids = input_ids[:, 1:].to(dev)
         ss_token, ss_prob, ss_op = [], [], []
         len_posi = input_ids.shape[1]
         self.reset()
-        if self.stable_kv is not None:
-            kv_len = self.stable_kv[0][0].shape[2]
-            pos = torch.arange(kv_len, input_ids.shape[1], device=dev)[None]
-            out_hidden, pkv = self(hidden_states, input_ids=input_ids[:, kv_len:], past_key_values=self.stable_kv, use_cache=True,
-                                   position_ids=pos)
-        else:
-            out_hidden, pkv = self(hidden_states, input_ids=input_ids, use_cache=True)
-        self.stable_kv = pkv
+        akw = {} if input_position_diff is None else {"attention_mask": attention_mask}
+        out_hidden, pkv = self._prefill(hidden_states, input_ids, input_position_diff, attention_mask)
         ho = self._head(head, out_hidden[:, -1])
         half = ho.shape[0] // 2
         rows = self._post_head(ho[:half], ho[half:], logits_processor)
@@ -353,8 +366,8 @@ class Model(nn.Module):
             input_ids = torch.cat([cur, cur])
             input_hidden = self.repeat_hidden(out_hidden[:, -1:] if i == 0 else out_hidden, tb["repeat_nums"][i])
             self.tree_mask = tb["attn_mask"][i]
-            position_ids = len_posi + tb["position_ids"][i]
-            out_hidden, pkv = self(input_hidden, input_ids=input_ids, past_key_values=pkv, position_ids=position_ids, use_cache=True)
+            position_ids = self._tree_positions(len_posi, tb["position_ids"][i], input_position_diff)
+            out_hidden, pkv = self(input_hidden, input_ids=input_ids, past_key_values=pkv, position_ids=position_ids, use_cache=True, **akw)
             len_posi += 1
             ho = self._head(head, out_hidden)
             half = ho.shape[0] // 2

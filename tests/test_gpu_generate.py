@@ -301,3 +301,54 @@ def test_llamagen_generate_end_to_end(static_tree, top_p, kernel_set):
     tok, pos = decode(data[0, 0, 0, :n_valid].float())
     assert pos.tolist() == list(range(n_valid)) and (tok[:120] == 0).all()
     assert tok[120:120 + 30].tolist() == tokens[0].tolist()[:n_valid - 120]
+
+
+# top_p < 1 is left to the LlamaGen test: with this fake head's peaked rows top-p keeps fewer than the drafter's top_k tokens, the
+# drafter then proposes finfo.min (non-image) ids exactly as the reference's does (cnets_anole.py:837-845), and the table lookup on
+# such an id is an index error there and LANTERN_ST_TABLE_OOB here.
+@pytest.mark.parametrize("static_tree,top_p,kernel_set", [(False, 1.0, "window"), (True, 1.0, "window"), (False, 1.0, "dense"),
+                                                           (True, 1.0, "dense")])
+def test_anole_generate_end_to_end(static_tree, top_p, kernel_set):
+    """ea_model_anole.EaModel.generate(): token-id prompt (left-padded cond row, <pad>..<bos><boi> uncond row), first token drawn
+    from the image window only, cond / uncond position ids an `input_position_diff` apart, drafter called with the Anole arguments.
+    The cond K/V row must spell prompt + emitted tokens at positions 0..n-1, the uncond row must sit `diff` positions behind."""
+    from lantern_amd.drafters import cnets
+    from lantern_amd.drafters.choices import naive_extend_57
+    from lantern_amd.ea_model_anole import BOI_ID, BOS_ID, SEP_ID, EaModel
+    random.seed(11)
+    torch.manual_seed(4)
+    dev = torch.device("cuda")
+    head = Head2(dev)
+    base_cfg = types.SimpleNamespace(num_hidden_layers=2, num_key_value_heads=HKV, max_position_embeddings=SMAX, hidden_size=HKV * DH,
+                                     num_attention_heads=HKV)
+    base = types.SimpleNamespace(model=FakeInner(dev), lm_head=head, config=base_cfg, dtype=torch.bfloat16)
+    dcfg = types.SimpleNamespace(num_hidden_layers=1, hidden_size=H, num_attention_heads=4, intermediate_size=128, vocab_size=V, pad_token_id=None)
+    drafter = cnets.Model(dcfg, total_tokens=59, depth=4, top_k=10, model_type="anole").to(dev).to(torch.bfloat16)
+    drafter.init_tree()
+    g = torch.Generator(device="cpu").manual_seed(1)
+    table = ops.build_vq_table(torch.randn(8192, 8, generator=g).to(dev))
+    mdl = EaModel(base, drafter, table)
+    mdl.uniform_window = 256
+    mdl.kernel_set = kernel_set
+    prompt = [[300, 9001, 77, 5000, 12]]
+    tokens, mean_accept, seconds = mdl.generate(prompt=prompt, max_length=30, temperature=1.0, top_k=300, top_p=top_p, cfg=3.0,
+                                                lantern=True, lantern_k=100, lantern_delta=0.2, static_tree=static_tree,
+                                                tree_choices=naive_extend_57)
+    L = len(prompt[0]) + 3
+    assert tokens.shape == (1, 30) and 1.0 <= mean_accept <= 7.0 and seconds > 0
+    assert ((tokens >= 4) & (tokens < 8196)).all()
+    data, n_valid = base.past_key_values_data[0], int(base.current_length_data[0])
+    tok, pos = decode(data[0, 0, 0, :n_valid].float())
+    assert pos.tolist() == list(range(n_valid))
+    assert tok[:L].tolist() == [BOS_ID] + prompt[0] + [SEP_ID, BOI_ID]
+    assert tok[L:L + 30].tolist() == tokens[0].tolist()[:n_valid - L]
+    utok, upos = decode(data[0, 1, 0, :n_valid].float())
+    assert utok[:L].tolist() == [1] * (L - 2) + [BOS_ID, BOI_ID] and upos[:L].tolist() == [0] * (L - 1) + [1]
+    assert utok[L:].tolist() == tok[L:].tolist() and upos[L:].tolist() == [p - (L - 2) for p in range(L, n_valid)]
+    with pytest.raises(RuntimeError, match="tokenizer"):
+        mdl.generate(prompt=["a cat"], max_length=4, temperature=1.0, top_k=300, top_p=1.0, cfg=3.0, lantern=False, lantern_k=10,
+                     lantern_delta=0.1, static_tree=False)
+    mdl.tokenizer = types.SimpleNamespace(tokenize_text=lambda s: [ord(c) + 9000 for c in s])
+    t2, _, _ = mdl.generate(prompt=["a cat"], max_length=8, temperature=1.0, top_k=300, top_p=1.0, cfg=3.0, lantern=False, lantern_k=10,
+                            lantern_delta=0.1, static_tree=False)
+    assert t2.shape == (1, 8)

@@ -390,3 +390,13 @@ class EaLumina_mGPT(nn.Module):
 
     # BASELINE.json's north_star calls the entry point `eagenerate`; the reference names it `generate`
     eagenerate = generate
+
+    def decode_ids(self, ids):
+        """Token ids -> image: the base model's VQGAN decoder (out of scope), as the reference delegates."""
+        return self.base_model.decode_ids(ids)
+
+    @classmethod
+    def from_reference(cls, ref, **kw):
+        """Wrap a model the reference's own `from_pretrained` loaded (checkpoint loading stays there): same base model, drafter
+        and neighbour table, this package's accept loop."""
+        return cls(ref.base_model, ref.ea_layer, ref.nearest_latents, **kw)

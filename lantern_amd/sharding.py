@@ -27,3 +27,55 @@ def reduce_timing(dist, seconds: float, tokens: float, device=None) -> Tuple[flo
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dist.all_reduce(n, op=dist.ReduceOp.SUM)
     return float(t[0]), float(n[0])
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Prompt slices and the per-slice statistics file of the reference's driver (entrypoints/generate_images.py:185-201,
+# :250-309; run.sh:76-91 starts one process per GPU with `--slice a-b`).  Only the data contract is kept -- which
+# prompts a process owns and the JSON it leaves behind -- so per-rank results merge the way the reference's do.
+def parse_slice(spec: str) -> Tuple[int, int]:
+    """'start-end' -> (start, end), with the reference's checks (generate_images.py:186-191)."""
+    import re
+    if not re.match(r"^\d+-\d+$", spec):
+        raise ValueError(f"Invalid format: '{spec}'. Expected format is 'start-end'.")
+    start, end = map(int, spec.split("-"))
+    if not start < end:
+        raise ValueError(f"Invalid range: '{spec}'. Start value must be less than end value.")
+    return start, end
+
+
+def slice_prompts(prompts: List[str], spec=None) -> List[str]:
+    return prompts if spec is None else prompts[slice(*parse_slice(spec))]
+
+
+def rank_slices(n_prompts: int, world: int) -> List[str]:
+    """Contiguous `--slice` strings, one per GPU, covering 0..n_prompts (what run.sh writes out by hand)."""
+    per = -(-n_prompts // world)
+    return [f"{r * per}-{min(n_prompts, (r + 1) * per)}" for r in range(world) if r * per < n_prompts]
+
+
+def statistics_entry(prompt: str, step_compression: float, latency: float) -> dict:
+    return {"prompt": prompt, "step_compression": step_compression, "latency": latency}
+
+
+def write_global_statistics(output_dir: str, entries: dict, start_idx: int, end_idx: int) -> str:
+    """`global_statistics_{start}_{end}.json`: {"prompt_{idx}": {prompt, step_compression, latency}} (generate_images.py:296-306)."""
+    import json
+    import os
+    os.makedirs(output_dir, exist_ok=True)
+    path = os.path.join(output_dir, f"global_statistics_{start_idx}_{end_idx}.json")
+    with open(path, "w") as f:
+        json.dump(entries, f, indent=4)
+    return path
+
+
+def merge_global_statistics(paths: List[str]) -> dict:
+    """Host-side merge of the per-process files: mean step compression / latency over all prompts."""
+    import json
+    merged = {}
+    for p in paths:
+        with open(p) as f:
+            merged.update(json.load(f))
+    n = max(len(merged), 1)
+    return {"prompts": len(merged), "mean_step_compression": sum(e["step_compression"] for e in merged.values()) / n,
+            "mean_latency": sum(e["latency"] for e in merged.values()) / n, "entries": merged}

@@ -1,6 +1,7 @@
 """CPU, world_size 2 (gloo): the N>1 layout -- disjoint sequence shards, no data-path collective, timing
 reduced with MAX / tokens with SUM -- gives the same accepted-token total as one process running every
 sequence.  The per-rank compute is the oracle at a tiny size (no GPU here)."""
+import json
 import os
 import sys
 
@@ -75,3 +76,27 @@ def test_two_rank_shards_equal_single_process():
         assert not (set(ids) & set(seen))                  # shards are disjoint
         seen.update(toks)
     assert seen == single
+
+
+def test_prompt_slices_and_statistics_files(tmp_path):
+    from lantern_amd import sharding as sh
+    prompts = [f"p{i}" for i in range(10)]
+    assert sh.slice_prompts(prompts, "2-5") == ["p2", "p3", "p4"] and sh.slice_prompts(prompts) == prompts
+    for bad in ("5-2", "3-3", "a-b", "1_2", "-1-4"):
+        with pytest.raises(ValueError):
+            sh.parse_slice(bad)
+    slices = sh.rank_slices(10, 4)
+    assert slices == ["0-3", "3-6", "6-9", "9-10"]
+    assert sum((sh.slice_prompts(prompts, s) for s in slices), []) == prompts
+    assert sh.rank_slices(2, 8) == ["0-1", "1-2"]
+    paths = []
+    for s in slices:
+        a, b = sh.parse_slice(s)
+        entries = {f"prompt_{i}": sh.statistics_entry(prompts[i], 2.0 + i, 0.5 * i) for i in range(a, b)}
+        paths.append(sh.write_global_statistics(str(tmp_path), entries, a, b))
+    assert os.path.basename(paths[1]) == "global_statistics_3_6.json"
+    with open(paths[1]) as f:
+        one = json.load(f)
+    assert list(one) == ["prompt_3", "prompt_4", "prompt_5"] and set(one["prompt_3"]) == {"prompt", "step_compression", "latency"}
+    m = sh.merge_global_statistics(paths)
+    assert m["prompts"] == 10 and abs(m["mean_step_compression"] - 6.5) < 1e-12 and abs(m["mean_latency"] - 2.25) < 1e-12

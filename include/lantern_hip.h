@@ -344,6 +344,29 @@ int lantern_drafter_attention_mask(const uint8_t *attn, int attn_len, const floa
 int lantern_linear_rows(const void *A, const void *W, const void *bias, int M, int K, int row_lo, int n_rows, void *out,
                         int out_stride, int out_col0, void *stream);
 
+/* 8f-3 (next row)  Attention of the target model's tree-verify forward over the KV cache in place:
+ *   out[b, n, h*d + :] = softmax_f32(q[b,n,h,:] . K[b, h/(Hq/Hkv), key, :] * scale + mask[b][n][key]).bf16 @ V
+ * replacing the eager matmul / additive-mask / softmax / matmul of the reference's attention
+ * (models/kv_variants/modeling_lumina_mgpt_kv.py:433-442, modeling_llamagen_kv.py and modeling_anole_kv.py alike) and the
+ * [B,1,N,S] f32 mask `_prepare_decoder_attention_mask` builds for it (modeling_lumina_mgpt_kv.py:1508-1546).  The mask is
+ * implied: query node n of batch row b sees key j iff  kv_start[b] <= j < kv_len[b]-N  (cached prefix behind the left
+ * padding) or  j = kv_len[b]-N+t with bit t of tree_bits[n] set (its ancestors and itself among the N tree keys, which the
+ * caller has already appended to the cache -- KVCache.cat, kv_cache.py:52-66).
+ *   q [dev] bf16, element strides (q_stride_b, q_stride_n, q_stride_h), last dim contiguous -- [B,N,Hq,d] as q_proj leaves
+ *   it, or the transposed [B,Hq,N,d] view;  k_cache / v_cache [dev] bf16 [B,Hkv,S_max,d] slices of the reference's slab
+ *   (element strides kv_stride_b, kv_stride_h; rows of d);  out [dev] bf16 [B,N,Hq*d] (strides out_stride_b, out_stride_n);
+ *   kv_len [dev] [B] keys per batch row INCLUDING the N tree keys (NULL: max_kv_len for every row), kv_start [dev] [B] first
+ *   visible key (NULL: 0);  max_kv_len: host-side upper bound of kv_len (sizes the launch, clamps kv_len);
+ *   tree_bits [dev] u64 [N] (bits_per_row = 0) or [B,N] (bits_per_row = 1);  N <= 64, d in {64,128}, Hq % Hkv == 0;
+ *   workspace [dev]: lantern_tree_attention_workspace(...) bytes (0 when B*Hq alone fills the GPU), 16-byte aligned.
+ * Floating point: f32 scores and accumulation, probabilities rounded to bf16 before the V product like the reference. */
+size_t lantern_tree_attention_workspace(int B, int Hq, int N, int d, int64_t max_kv_len);
+int lantern_tree_attention(const void *q, const void *k_cache, const void *v_cache, void *out, int B, int Hq, int Hkv, int N,
+                           int d, int64_t q_stride_b, int64_t q_stride_n, int64_t q_stride_h, int64_t kv_stride_b,
+                           int64_t kv_stride_h, int64_t out_stride_b, int64_t out_stride_n, const int64_t *kv_len,
+                           const int64_t *kv_start, int64_t max_kv_len, const uint64_t *tree_bits, int bits_per_row,
+                           float scale, void *workspace, size_t workspace_bytes, void *stream);
+
 /* 8f-1 VQ-distance neighbour table: cdist + per-row ascending order, self excluded.
  * Replaces entrypoints/generate_codebook.py:53-65.  codebook [dev] [K,C] f32 ->
  * table [dev] [K,K-1] u16, K <= 16384 (LlamaGen).  workspace: unused (NULL). */

@@ -67,6 +67,7 @@ def lib():
         _lib = C.CDLL(LIB_PATH)
         _lib.lantern_last_error.restype = C.c_char_p
         _lib.lantern_evaluate_posterior_workspace.restype = C.c_size_t
+        _lib.lantern_tree_attention_workspace.restype = C.c_size_t
     return _lib
 
 
@@ -84,4 +85,5 @@ EXPORTS = [
     "lantern_kv_gather", "lantern_accept_gather", "lantern_sample_static", "lantern_drafter_fc",
     "lantern_build_vq_table", "lantern_cfg_mask_topk_window", "lantern_evaluate_posterior_window",
     "lantern_window_to_dense", "lantern_pack_vq_table", "lantern_update_inference_inputs", "lantern_profile_next_launch", "lantern_drafter_attention_mask", "lantern_linear_rows",
+    "lantern_tree_attention_workspace", "lantern_tree_attention",
 ]

@@ -624,3 +624,63 @@ def build_vq_table(codebook):
     check(_lib.lib().lantern_build_vq_table(C.c_void_p(cb.data_ptr()), K, Cc, C.c_void_p(table.data_ptr()), None, _stream()),
           "build_vq_table")
     return table
+
+
+def tree_mask_bits(tree_mask: torch.Tensor) -> torch.Tensor:
+    """[..., N, N] tree attention mask (non-zero = visible; the reference's `tree_attn_mask` / dynamic `tree_mask`) -> one
+    64-bit ancestor word per node, int64 [N] or [B,N] (bit t of word n = node n sees tree key t)."""
+    m = tree_mask
+    while m.dim() > 3:
+        assert m.shape[1] == 1 or m.dim() == 4
+        m = m[:, 0] if m.dim() == 4 else m
+    if m.dim() == 3 and m.shape[0] == 1:
+        m = m[0]
+    N = m.shape[-1]
+    if N > 64 or m.shape[-2] != N:
+        raise _lib.LanternError(f"tree_mask_bits: {tuple(tree_mask.shape)}: need a square tree block of at most 64 nodes")
+    w = torch.ones(N, dtype=torch.int64, device=m.device) << torch.arange(N, dtype=torch.int64, device=m.device)
+    return ((m != 0).to(torch.int64) * w).sum(-1).contiguous()      # bit 63 wraps to the sign bit: same 64-bit pattern
+
+
+def tree_attention(q, k_cache, v_cache, tree_bits, kv_len=None, kv_start=None, max_kv_len: Optional[int] = None,
+                   scale: Optional[float] = None, out=None):
+    """8f-3: attention of the tree-verify forward over the KV cache in place (no mask tensor, no repeat_kv, no [N,S] scores).
+    q bf16 [B,N,Hq,d] (or any view with a contiguous last dim, e.g. the transposed [B,Hq,N,d] -- pass it as `q.transpose(1,2)`);
+    k_cache / v_cache bf16 [B,Hkv,S_max,d] views of the slab (the N tree keys already appended); tree_bits int64 [N] | [B,N]
+    (`tree_mask_bits`); kv_len int64 [B] keys per row incl. the tree keys (None: max_kv_len everywhere); kv_start int64 [B]
+    first visible key (left padding; None: 0).  Returns bf16 [B,N,Hq*d]."""
+    for t, n in ((q, "q"), (k_cache, "k_cache"), (v_cache, "v_cache")):
+        if not t.is_cuda or t.dtype != torch.bfloat16:
+            raise _lib.LanternError(f"tree_attention: {n} must be a bf16 device tensor")
+    B, N, Hq, d = q.shape
+    Bk, Hkv, S_max, dk = k_cache.shape
+    if (Bk, dk) != (B, d) or v_cache.shape != k_cache.shape or k_cache.stride() != v_cache.stride():
+        raise _lib.LanternError(f"tree_attention: q {tuple(q.shape)} vs caches {tuple(k_cache.shape)} / {tuple(v_cache.shape)}")
+    if q.stride(3) != 1 or k_cache.stride(3) != 1 or k_cache.stride(2) != d:
+        raise _lib.LanternError("tree_attention: q needs a contiguous last dim, the caches contiguous [S_max, d] rows")
+    if max_kv_len is None:
+        max_kv_len = S_max
+    if not N <= max_kv_len <= S_max:
+        raise _lib.LanternError(f"tree_attention: max_kv_len={max_kv_len} outside [N={N}, S_max={S_max}]")
+    bits = _dev(tree_bits, torch.int64, "tree_attention: tree_bits").contiguous()
+    if bits.shape not in ((N,), (B, N)):
+        raise _lib.LanternError(f"tree_attention: tree_bits {tuple(bits.shape)}, expected [{N}] or [{B},{N}]")
+    kl = None if kv_len is None else _dev(kv_len, torch.int64, "tree_attention: kv_len").contiguous()
+    ks = None if kv_start is None else _dev(kv_start, torch.int64, "tree_attention: kv_start").contiguous()
+    for t, n in ((kl, "kv_len"), (ks, "kv_start")):
+        if t is not None and t.numel() != B:
+            raise _lib.LanternError(f"tree_attention: {n} must have {B} entries")
+    if out is None:
+        out = torch.empty((B, N, Hq * d), dtype=torch.bfloat16, device=q.device)
+    assert out.dtype == torch.bfloat16 and out.shape == (B, N, Hq * d) and out.stride(2) == 1
+    L = _lib.lib()
+    need = int(L.lantern_tree_attention_workspace(B, Hq, N, d, C.c_int64(max_kv_len)))
+    ws = torch.empty(need, dtype=torch.uint8, device=q.device) if need else None
+    check(L.lantern_tree_attention(C.c_void_p(q.data_ptr()), C.c_void_p(k_cache.data_ptr()), C.c_void_p(v_cache.data_ptr()),
+                                   C.c_void_p(out.data_ptr()), B, Hq, Hkv, N, d, C.c_int64(q.stride(0)), C.c_int64(q.stride(1)),
+                                   C.c_int64(q.stride(2)), C.c_int64(k_cache.stride(0)), C.c_int64(k_cache.stride(1)),
+                                   C.c_int64(out.stride(0)), C.c_int64(out.stride(1)), C.c_void_p(_ptr(kl)), C.c_void_p(_ptr(ks)),
+                                   C.c_int64(max_kv_len), C.c_void_p(bits.data_ptr()), int(bits.dim() == 2),
+                                   C.c_float(float(scale) if scale is not None else d ** -0.5), C.c_void_p(_ptr(ws)), C.c_size_t(need),
+                                   _stream()), "tree_attention")
+    return out

@@ -70,7 +70,9 @@ __global__ __launch_bounds__(TA_THREADS, 2) void tree_attention_kernel(const TaA
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hh = lane >> 5;
     // Query groups (N > 32 at d = 128: two workgroups of 32 queries each, so that the 64 accumulator registers of O^T leave
     // room for two waves per SIMD): ids 16g+j and 16g+8+j carry the two groups of (batch row, head) 8g+j -- same XCD (id % 8),
-    // dispatched together, so the second reader of a K/V row finds it in that XCD's L2.
+    // dispatched together, so the second reader of a K/V row finds it in that XCD's L2.  (Measured alternatives at 48
+    // sequences, N = 59: both groups in one 4-wave workgroup at 473 VGPRs 927 us; one 8-wave workgroup, groups in lockstep on
+    // the same CU 943 us; this pairing 796 us.)
     int bh = blockIdx.x, qs = 0;
     if (a.q_groups == 2) {
         const int j = bh & 15;
@@ -278,37 +280,39 @@ __global__ __launch_bounds__(TA_THREADS, 2) void tree_attention_kernel(const TaA
     }
 }
 
-// second pass when the keys were split over gridDim.y: one workgroup per (batch row, head)
+// second pass when the keys were split over gridDim.y: grid (batch row x head x query group, chunks of 256/(D/4) query rows),
+// one thread per (query row, 4 output columns); the loop over splits is a fixed order (deterministic) of independent loads
 __global__ __launch_bounds__(256) void tree_attention_merge_kernel(const float *__restrict__ ws, uint16_t *__restrict__ out, int nsplit, int N,
                                                                    int D, int QR, int q_groups, int Hq, int64_t o_sb, int64_t o_sn) {
     const int bh = blockIdx.x / q_groups, qs = blockIdx.x % q_groups, b = bh / Hq, h = bh % Hq;
     const int q0 = qs * QR, n_here = min(QR, N - q0);
+    const int per_row = D / 4, rows = 256 / per_row;
+    const int qn = blockIdx.y * rows + (int)threadIdx.x / per_row, c4 = (int)threadIdx.x % per_row;
+    if (qn >= n_here) return;
     const int64_t stride = (int64_t)QR * (D + 2);
     const float *base = ws + (int64_t)blockIdx.x * nsplit * stride;
     const float NEG = -__builtin_huge_valf();
-    for (int idx = threadIdx.x; idx < n_here * (D / 4); idx += blockDim.x) {
-        const int qn = idx / (D / 4), c4 = idx % (D / 4);
-        float mt = NEG;
-        for (int s = 0; s < nsplit; ++s) mt = fmaxf(mt, base[s * stride + QR * D + qn]);
-        const float mu = mt == NEG ? 0.0f : mt;
-        float L = 0.0f;
-        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int s = 0; s < nsplit; ++s) {
-            const float *w = base + s * stride;
-            const float f = __builtin_amdgcn_exp2f(w[QR * D + qn] - mu);
-            if (f == 0.0f) continue;
-            L += w[QR * D + QR + qn] * f;
-            const float4 v = *reinterpret_cast<const float4 *>(w + qn * D + 4 * c4);
-            acc.x += v.x * f, acc.y += v.y * f, acc.z += v.z * f, acc.w += v.w * f;
-        }
-        const float inv = 1.0f / L;
-        uint16_t *op = out + (int64_t)b * o_sb + (int64_t)(q0 + qn) * o_sn + (int64_t)h * D + 4 * c4;
-        const __bf16 r0 = (__bf16)(acc.x * inv), r1 = (__bf16)(acc.y * inv), r2 = (__bf16)(acc.z * inv), r3 = (__bf16)(acc.w * inv);
-        uint2 pk;
-        pk.x = (uint32_t)__builtin_bit_cast(uint16_t, r0) | ((uint32_t)__builtin_bit_cast(uint16_t, r1) << 16);
-        pk.y = (uint32_t)__builtin_bit_cast(uint16_t, r2) | ((uint32_t)__builtin_bit_cast(uint16_t, r3) << 16);
-        *reinterpret_cast<uint2 *>(op) = pk;
+    float mt = NEG;
+    for (int s = 0; s < nsplit; ++s) mt = fmaxf(mt, base[s * stride + QR * D + qn]);
+    const float mu = mt == NEG ? 0.0f : mt;
+    float L = 0.0f;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 4
+    for (int s = 0; s < nsplit; ++s) {
+        const float *w = base + s * stride;
+        const float f = __builtin_amdgcn_exp2f(w[QR * D + qn] - mu);      // exp2(-inf) = 0: an empty split adds nothing
+        const float lv = w[QR * D + QR + qn];
+        const float4 v = *reinterpret_cast<const float4 *>(w + qn * D + 4 * c4);
+        L += lv * f;
+        acc.x += v.x * f, acc.y += v.y * f, acc.z += v.z * f, acc.w += v.w * f;
     }
+    const float inv = 1.0f / L;
+    uint16_t *op = out + (int64_t)b * o_sb + (int64_t)(q0 + qn) * o_sn + (int64_t)h * D + 4 * c4;
+    const __bf16 r0 = (__bf16)(acc.x * inv), r1 = (__bf16)(acc.y * inv), r2 = (__bf16)(acc.z * inv), r3 = (__bf16)(acc.w * inv);
+    uint2 pk;
+    pk.x = (uint32_t)__builtin_bit_cast(uint16_t, r0) | ((uint32_t)__builtin_bit_cast(uint16_t, r1) << 16);
+    pk.y = (uint32_t)__builtin_bit_cast(uint16_t, r2) | ((uint32_t)__builtin_bit_cast(uint16_t, r3) << 16);
+    *reinterpret_cast<uint2 *>(op) = pk;
 }
 
 // launch shape: QT query tiles per workgroup x q_groups workgroups per (batch row, head)
@@ -388,7 +392,8 @@ extern "C" int lantern_tree_attention(const void *q, const void *k_cache, const 
     else LANTERN_LAUNCH((tree_attention_kernel<64, 2>), grid, block, 0, st, a);
     LANTERN_CHECK_LAUNCH("tree_attention");
     if (ns > 1) {
-        hipLaunchKernelGGL(tree_attention_merge_kernel, dim3(B * Hq * sh.q_groups), dim3(256), 0, st, (const float *)workspace, (uint16_t *)out, ns,
+        const int rows = 256 / (d / 4);
+        hipLaunchKernelGGL(tree_attention_merge_kernel, dim3(B * Hq * sh.q_groups, (sh.QR + rows - 1) / rows), dim3(256), 0, st, (const float *)workspace, (uint16_t *)out, ns,
                            N, d, sh.QR, sh.q_groups, Hq, out_stride_b, out_stride_n);
         LANTERN_CHECK_LAUNCH("tree_attention_merge");
     }

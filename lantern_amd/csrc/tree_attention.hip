@@ -126,28 +126,40 @@ __global__ __launch_bounds__(TA_THREADS, 2) void tree_attention_kernel(const TaA
     // transposed-read addresses: lane 4q+p of a 16-lane group supplies row q, columns 4p..4p+3 of its 4 x 16 block
     const int tq = (lane & 15) >> 2, tp = lane & 3, tg = (lane >> 4) & 1;
 
-    for (int tile = tb + wave; tile < te; tile += TA_WAVES) {
-        const int64_t key0 = (int64_t)tile << 5;
-        // K fragments: 16 contiguous bytes per lane and k-step
-        int64_t krow = key0 + r;
+    // Software pipeline without extra registers: a tile's V registers are free once written to the LDS image and its K
+    // fragments once S^T is computed, so the NEXT tile's V loads are issued right after the image is written and its K
+    // loads right after the QK products -- both are in flight during the softmax and the PV products of the current tile.
+    ta_bf16x8_t kf[KS];
+    uint4 vr[VL];
+    auto load_k = [&](int tile) {
+        int64_t krow = ((int64_t)tile << 5) + r;
         krow = krow < len ? krow : len - 1;
         const uint16_t *kp = kb + krow * D + 8 * hh;
-        ta_bf16x8_t kf[KS];
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) kf[ks] = ta_load8(kp + 16 * ks);
-        // V tile -> this wave's LDS image (rows past the end are zeroed: 0 * stale-NaN would poison O)
-        uint4 vr[VL];
+        for (int ks = 0; ks < KS; ++ks) kf[ks] = ta_load8(kp + 16 * ks);      // 16 contiguous bytes per lane and k-step
+    };
+    auto load_v = [&](int tile) {   // rows past the end are zeroed: 0 * stale-NaN would poison O
 #pragma unroll
         for (int i = 0; i < VL; ++i) {
             const int c = lane + 64 * i, row = c / CPR, ch = c % CPR;
-            const int64_t key = key0 + row;
+            const int64_t key = ((int64_t)tile << 5) + row;
             vr[i] = key < len ? *reinterpret_cast<const uint4 *>(vb + key * D + 8 * ch) : make_uint4(0, 0, 0, 0);
         }
+    };
+    int tile = tb + wave;
+    if (tile < te) {
+        load_k(tile);
+        load_v(tile);
+    }
+    while (tile < te) {
+        const int64_t key0 = (int64_t)tile << 5;
+        const int next = tile + TA_WAVES;
 #pragma unroll
         for (int i = 0; i < VL; ++i) {
             const int c = lane + 64 * i, row = c / CPR, ch = c % CPR;
             *reinterpret_cast<uint4 *>(vimg + ta_v_off<D>(row, ch)) = vr[i];
         }
+        if (next < te) load_v(next);
 
         // S^T = K Q^T
         ta_f32x16_t s[QT];
@@ -157,6 +169,7 @@ __global__ __launch_bounds__(TA_THREADS, 2) void tree_attention_kernel(const TaA
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) s[qt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ks], qf[qt][ks], s[qt], 0, 0, 0);
         }
+        if (next < te) load_k(next);
 
         const bool full = key0 >= start && key0 + TA_TILE <= prev;   // wave-uniform: whole tile inside the visible prefix
         ta_bf16x8_t pf[QT][2];
@@ -213,6 +226,7 @@ __global__ __launch_bounds__(TA_THREADS, 2) void tree_attention_kernel(const TaA
                 for (int qt = 0; qt < QT; ++qt) o[dt][qt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[qt][t], o[dt][qt], 0, 0, 0);
             }
         }
+        tile = next;
     }
 
     // ---- merge the four waves: common max per query, rescale, add into one LDS tile

@@ -38,7 +38,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--seqs-per-gpu", type=int, default=48, help="sequences resident per GPU (KV slabs: 4.3 GB each; 48 -> 206 GB of the 288 GB)")
+    ap.add_argument("--seqs-per-gpu", type=int, default=64, help="sequences resident per GPU (KV slabs: 4.3 GB each at 4096 rows; 64 -> 276e9 of the 309e9 bytes)")
     ap.add_argument("--pool-steps", type=int, default=16)
     ap.add_argument("--lantern-k", type=int, default=1000)
     ap.add_argument("--lantern-delta", type=float, default=0.1)
@@ -46,7 +46,7 @@ def parse():
     ap.add_argument("--path", choices=["window", "dense"], default="window",
                     help="window: v2 kernels (32 KB image-window rows, LDS-resident residual); dense: v1 kernels (full-V rows)")
     ap.add_argument("--no-kv", action="store_true", help="skip the KV slabs (debug only; invalid as a headline)")
-    ap.add_argument("--kv-smax", type=int, default=4096)
+    ap.add_argument("--kv-smax", type=int, default=4096, help="rows per KV slab (BASELINE.md: 4096 = max_position_embeddings; a 768x768 image needs 2481)")
     ap.add_argument("--no-events", action="store_true", help="skip the eager per-kernel timing pass")
     ap.add_argument("--graph", action="store_true", help="replay one captured hipGraph per (pool slot, group) instead of launching eagerly")
     ap.add_argument("--side-stream", action="store_true", help="launch O6 beside O7 and O10 beside O9 on a second HIP stream (measured slower: event waits)")

@@ -41,7 +41,7 @@ HIDDEN = 4096
 
 @dataclass
 class WorkloadConfig:
-    n_seq: int = 48
+    n_seq: int = 64                 # 4.3 GB of KV slabs each (BASELINE.md geometry: 4096 rows) -> 276e9 of the GPU's 309e9 bytes
     pool_steps: int = 16
     lantern_k: int = 1000
     lantern_delta: float = 0.1
@@ -52,7 +52,9 @@ class WorkloadConfig:
     prompt_len: int = 64
     kv_layers: int = 32
     kv_heads: int = 32
-    kv_smax: int = 4096
+    kv_smax: int = 4096             # rows per slab = max_position_embeddings, as the reference allocates (kv_cache.py:124) and
+                                    # BASELINE.md fixes.  A 768x768 image only ever reaches row 64 + 3 + 2355 + 59 = 2481:
+                                    # `--kv-smax 2560 --seqs-per-gpu 96` keeps 96 sequences resident instead (Measured)
     kv_dim: int = 128
     kv_pad_rows: int = 16           # row stride = kv_smax + pad: a 4096*256 B = 1 MiB stride between (layer, head) groups lands
                                     # every group on the same HBM channel set (measured 56 -> 42 us per gather); DESIGN.md 3
@@ -185,6 +187,9 @@ class LuminaVerifyWorkload:
         self.first_token = torch.randint(IMG_LO, IMG_HI, (B,), generator=gen, device=device)
         self.slabs: List[torch.Tensor] = []
         if cfg.with_kv:
+            longest = cfg.prompt_len + 3 + TOKENS_PER_IMAGE + self.N        # prompt + header + image + the tree's rows behind it
+            if cfg.kv_smax < longest:
+                raise _lib.LanternError(f"kv_smax={cfg.kv_smax} rows cannot hold a sequence of this workload ({longest} rows)")
             shape = (2 * cfg.kv_layers, 1, cfg.kv_heads, cfg.kv_smax + cfg.kv_pad_rows, cfg.kv_dim)
             need = 2 * B * int(np.prod(shape)) * 2
             free, _total = torch.cuda.mem_get_info(device)

@@ -273,3 +273,91 @@ def test_window_mid_size_vocabularies(Vp, static):
             assert (int(best[b]), int(alen[b])) == (ob, oa), (b, int(best[b]), int(alen[b]), ob, oa)
             assert np.array_equal(cnt[b, :5].cpu().numpy(), ocnt[:5])
             np.testing.assert_allclose(sp[b].cpu().numpy(), osp, rtol=0, atol=PROB_TOL)
+
+
+@pytest.mark.parametrize("delta", [0.1, 5.0])
+def test_c3_lumina_dynamic_tree_full_size(delta):
+    """C3 with the EAGLE-2 dynamic tree (eagle_version 2): V=65536, window [4,8196), N=59, k=1000, LANTERN delta- and lambda-mode.
+    Drafter tree from the HIP O3/O4 kernels (checked against the oracle), O7w over a position range that crosses a newline row,
+    then O8w on probability rows with the packed neighbour table, batched over sequences -- against oracle O7 -> O8."""
+    V, K, lo, W, B, k10 = 65536, 8192, 4, 8192, 3, 10
+    rs = np.random.RandomState(77 + int(delta))
+    depth, T = 4, 58
+    N = T + 1
+    tab = perm_table(K, K - 1, 3)
+    packed = ops.pack_vq_table(dev(tab.view(np.int16)), 1008)
+    cfg_o = oracle.EpConfig.lumina(False, lantern=True, k=1000, delta=delta)
+    cfg_h = ops.EpConfig.lumina(False, lantern=True, k=1000, delta=delta)
+    prompt = 20
+    seq_len = np.array([prompt + 3 + 5, prompt + 3 + 46, prompt + 3 + 300], np.int64)      # the 2nd sequence's tree straddles a newline
+    drafts, rets, poss, cands, ris = [], [], [], [], []
+    P_max = D_max = 0
+    for b in range(B):
+        def img_logits(rows):
+            x = np.full((rows, V), -np.inf, np.float32)
+            x[:, lo:lo + W] = 4 * rs.standard_normal((rows, W))
+            return CS.topk_filter(x, 2000)
+        script = [img_logits(1 if d == 0 else k10) for d in range(depth + 1)]
+        ti, cu, ci, sc = ops.expand_dynamic(dev(script[0])[None], None, k10)
+        sl, tl, pl = [cu.reshape(-1)], [ti.reshape(-1)], [torch.zeros(1, dtype=torch.int64, device="cuda")]
+        cs = torch.arange(k10, device="cuda")
+        for d in range(depth):
+            pl.append(cs + 1 + k10 * k10 * max(0, d - 1) + (k10 if d > 0 else 0))
+            ti, cu, ci, sc = ops.expand_dynamic(dev(script[d + 1])[None], sc, k10)
+            cs = ci[0]
+            sl.append(cu.reshape(-1)); tl.append(ti.reshape(-1))
+        sample = int(rs.randint(lo, lo + W))
+        draft, mask, pos, ret, nl, md = ops.tree_dynamic_finalize(torch.cat(sl)[None], torch.cat(tl)[None], torch.cat(pl)[None],
+                                                                   torch.tensor([sample], device="cuda"), k10, T, sort_rows=True)
+        od, oret, omask, opos = oracle.tree_dynamic_finalize(torch.cat(sl).cpu().numpy(), torch.cat(tl).cpu().numpy(),
+                                                             torch.cat(pl).cpu().numpy(), k10, T, sample, sort_rows=True)
+        nl, md = int(nl[0]), int(md[0])
+        assert np.array_equal(draft[0].cpu().numpy(), od) and np.array_equal(ret[0, :nl, :md].cpu().numpy(), oret)
+        assert np.array_equal(pos[0].cpu().numpy(), opos)
+        drafts.append(od); rets.append(oret); poss.append(opos)
+        P_max, D_max = max(P_max, oret.shape[0]), max(D_max, oret.shape[1])
+    # target rows: bf16 cond / uncond pairs whose CFG mix makes the drafted tokens plausible
+    cond = (2 * rs.standard_normal((B, N, V))).astype(np.float32)
+    unc = rs.standard_normal((B, N, V)).astype(np.float32)
+    for b in range(B):
+        oret, od = rets[b], drafts[b]
+        for p in range(oret.shape[0]):
+            for d in range(1, oret.shape[1]):
+                if oret[p, d] >= 0:
+                    cond[b, oret[p, d - 1], od[oret[p, d]]] = cond[b, oret[p, d - 1], lo:lo + W].max() - rs.uniform(0, 1.0)
+    cond_t, unc_t = torch.from_numpy(cond).to(torch.bfloat16), torch.from_numpy(unc).to(torch.bfloat16)
+    cb, ub = cond_t.view(torch.int16).numpy().view(np.uint16), unc_t.view(torch.int16).numpy().view(np.uint16)
+    pos1 = np.stack(poss) + 1                                                      # [B,N]: every sequence has its own tree
+    procs = [oracle.cfg_mask_topk(cb[b], ub[b], 3.0, model=oracle.MODEL_LUMINA, pos_ids=pos1[b] + seq_len[b], pos_base=prompt + 3,
+                                  top_k=2000, bf16=True) for b in range(B)]
+    cand = np.full((B, P_max, D_max), -1, np.int64)
+    ri = np.zeros((B, P_max, D_max), np.int32)
+    for b in range(B):
+        oret, od = rets[b], drafts[b]
+        c = np.where(oret >= 0, od[np.maximum(oret, 0)], -1)
+        cand[b, :c.shape[0], :c.shape[1]] = c
+        r = H.row_index_from_retrieve(oret, N)
+        ri[b, :r.shape[0], :r.shape[1]] = r
+    assert any(int(np.isfinite(procs[1][n]).sum()) == 1 for n in range(N))         # a forced newline row is among the nodes
+    pw_rows = []
+    for b in range(B):                 # per-sequence position ids: one O7w call per sequence (pos_ids is shared by a batch)
+        pw, hot = ops.cfg_mask_topk_window(cond_t[b].cuda(), unc_t[b].cuda(), 3.0, lo, W, model=ops.MODEL_LUMINA, pos_ids=dev(pos1[b] + seq_len[b]),
+                                           pos_base=prompt + 3, top_k=2000, probs=True)
+        pw_rows.append((pw, hot))
+    win = torch.stack([p for p, _ in pw_rows])
+    hot = torch.stack([h for _, h in pw_rows])
+    uni = rs.random_sample((B, 64))
+    ubon = rs.random_sample(B)
+    out = ops.evaluate_posterior_window(cfg_h, V, win, lo, dev(ri), dev(cand), dev(uni), row_hot=hot, table=packed, u_bonus=dev(ubon),
+                                        want_dense=True, rows_probs=True)
+    ops.raise_on_status(out["counters"])
+    tried = 0
+    for b in range(B):
+        Pb, Db = rets[b].shape
+        ob, oa, osp, ocnt = oracle.evaluate_posterior(cfg_o, procs[b], ri[b, :Pb, :Db], cand[b, :Pb, :Db], uni[b], table=tab)
+        assert (int(out["best"][b]), int(out["accept_len"][b])) == (ob, oa), b
+        assert np.array_equal(out["counters"][b, :5].cpu().numpy(), ocnt[:5])
+        np.testing.assert_allclose(out["sample_p"][b].cpu().numpy(), osp, rtol=0, atol=PROB_TOL)
+        assert int(out["token"][b]) == oracle.sample_inverse_cdf(osp, ubon[b])
+        tried += int(ocnt[1])
+    assert tried >= B

@@ -224,7 +224,6 @@ __global__ __launch_bounds__(AG_THREADS) void accept_gather_kernel(const void *_
                                                                    int64_t *__restrict__ accepted_tokens,
                                                                    int64_t *__restrict__ token) {
     __shared__ double s_tot[AG_NW];
-    __shared__ double s_red[2 * AG_NW];
     __shared__ float s_redf[2 * AG_NW];
     __shared__ int s_redi[2 * AG_NW];
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;

@@ -226,3 +226,61 @@ def test_drafter_head_window_equals_full_head():
         outs.append(mdl.topK_generate(hidden, uncond, ids, hd, procs, attention_mask=am, tree_type="dynamic"))
     for a, b in zip(outs[0], outs[1]):
         assert torch.equal(a, b)
+
+
+class RecordingAnoleModel(cnets.Model):
+    """The mirror with its network replaced by a recorder (as tests/golden/make_golden_anole_drafter.py does to the reference):
+    what reaches forward() and what the tree logic makes of scripted head logits is compared, not the transformer."""
+
+    def forward(self, hidden_states, input_ids=None, attention_mask=None, position_ids=None, past_key_values=None, use_cache=None):
+        T = input_ids.shape[1]
+        past = 0 if past_key_values is None else past_key_values[0][0].shape[2]
+        self.seen.append(dict(ids=input_ids.clone(), pos=position_ids.clone(), past=past, attn=attention_mask))
+        dev = input_ids.device
+        return torch.zeros(2, T, 4, device=dev), ((torch.zeros(2, 1, past + T, 1, device=dev),),)
+
+
+@pytest.mark.parametrize("ci", [0, 1])
+def test_drafter_anole_calling_convention_vs_reference(ci):
+    """`topK_genrate(..., cfg_scale, input_position_diff, attention_mask)` (cnets_anole.py:795-993): cond / uncond position ids
+    of the prefill (clamped at 0), of the second call on top of the drafter cache, and of every tree depth (not clamped), the
+    attention mask handed through unchanged, and the resulting tree -- against vectors recorded from the reference's method."""
+    g = H.load("anole_drafter.npz")
+    V, lo, hi, topk, depth, total = (int(x) for x in g["dims"])
+    pre = f"c{ci}."
+    rs = np.random.RandomState(int(g[pre + "seed"]))
+    script = []
+    for _ in range(2):
+        script.append((4.0 * rs.standard_normal(V)).astype(np.float32))
+        for _ in range(depth):
+            script.append((4.0 * rs.standard_normal((topk, V))).astype(np.float32))
+    dcfg = types.SimpleNamespace(num_hidden_layers=1, hidden_size=16, num_attention_heads=2, intermediate_size=32, vocab_size=V, pad_token_id=None)
+    m = RecordingAnoleModel(dcfg, total_tokens=total, depth=depth, top_k=topk, model_type="anole", image_lo=lo, image_hi=hi).cuda()
+    m.seen = []
+    m.init_tree()
+    calls = {"n": 0}
+
+    def head(hidden):
+        blk = torch.from_numpy(script[calls["n"]]).cuda()
+        calls["n"] += 1
+        return torch.stack([blk, blk])
+
+    from lantern_amd.verify import prepare_logits_processor
+    proc = prepare_logits_processor(temperature=1.0, top_p=1.0, top_k=300)
+    attn = torch.from_numpy(g[pre + "attn"]).cuda()
+    diff, L0 = int(g[pre + "diff"]), int(g[pre + "L0"])
+    ids1, ids2 = torch.from_numpy(g[pre + "ids1"]).cuda(), torch.from_numpy(g[pre + "ids2"]).cuda()
+    outs = [m.topK_genrate(torch.zeros(2, L0, 4, device="cuda"), ids1, head, proc, 3.0, diff, attn)]
+    assert len(m.seen) == int(g[pre + "n_first"])
+    outs.append(m.topK_genrate(torch.zeros(2, 3, 4, device="cuda"), ids2, head, proc, 3.0, diff, attn))
+    assert len(m.seen) == int(g[pre + "n_calls"])
+    for j, s in enumerate(m.seen):
+        assert s["past"] == int(g[pre + f"call{j}.past"]), j
+        assert np.array_equal(s["ids"].cpu().numpy(), g[pre + f"call{j}.ids"]), j
+        assert np.array_equal(s["pos"].cpu().numpy().reshape(g[pre + f"call{j}.pos"].shape), g[pre + f"call{j}.pos"]), j
+        assert int(g[pre + f"call{j}.attn_same"]) == 1 and s["attn"] is not None and torch.equal(s["attn"], attn), j
+    for tag, d in zip(("out1", "out2"), outs):
+        assert np.array_equal(d[0].cpu().numpy(), g[pre + tag + ".draft"])
+        assert np.array_equal(d[1].cpu().numpy(), g[pre + tag + ".retrieve"])
+        assert np.array_equal(d[2].cpu().numpy().reshape(g[pre + tag + ".mask"].shape), g[pre + tag + ".mask"])
+        assert np.array_equal(d[3].cpu().numpy(), g[pre + tag + ".pos"])

@@ -187,7 +187,8 @@ class LuminaVerifyWorkload:
         self.first_token = torch.randint(IMG_LO, IMG_HI, (B,), generator=gen, device=device)
         self.slabs: List[torch.Tensor] = []
         if cfg.with_kv:
-            longest = cfg.prompt_len + 3 + TOKENS_PER_IMAGE + self.N        # prompt + header + image + the tree's rows behind it
+            # prompt + header + the image tokens this run can reach (<= D per step) + the tree's rows behind them
+            longest = cfg.prompt_len + 3 + min(TOKENS_PER_IMAGE, cfg.max_steps * self.D) + self.N
             if cfg.kv_smax < longest:
                 raise _lib.LanternError(f"kv_smax={cfg.kv_smax} rows cannot hold a sequence of this workload ({longest} rows)")
             shape = (2 * cfg.kv_layers, 1, cfg.kv_heads, cfg.kv_smax + cfg.kv_pad_rows, cfg.kv_dim)

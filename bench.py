@@ -237,7 +237,26 @@ def main():
 
     from lantern_amd import harness as HN
 
-    cfg = HN.WorkloadConfig(n_seq=args.seqs_per_gpu, pool_steps=args.pool_steps, lantern_k=args.lantern_k,
+    # Never ask for more resident sequences than this GPU can hold: KV slabs (2 per sequence) + pools + 16 GiB of head-room.
+    # On the MI355X the default fits (309e9 bytes); a smaller or partly occupied device gets fewer sequences, not a failed run
+    # (with more than one rank every rank takes the minimum so that the per-GPU work stays identical).
+    n_seq = args.seqs_per_gpu
+    if not args.no_kv:
+        free, _tot = torch.cuda.mem_get_info(device)
+        per_seq = 2 * (2 * 32 * 32 * (args.kv_smax + 16) * 128 * 2) + args.pool_steps * 7_700_000
+        fit = int((free - (16 << 30)) // per_seq)
+        fit -= fit % max(1, args.groups)
+        if dist is not None and dist.get_world_size() > 1:
+            t = torch.tensor([fit], dtype=torch.int64, device=device)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            fit = int(t[0])
+        if fit < n_seq:
+            if fit < max(1, args.groups):
+                raise SystemExit(f"bench.py: {free / 2**30:.0f} GiB free on {device}: not even one sequence's KV slabs fit")
+            if rank == 0:
+                print(f"bench.py: {free / 2**30:.0f} GiB free: {n_seq} sequences do not fit, running {fit}", file=sys.stderr)
+            n_seq = fit
+    cfg = HN.WorkloadConfig(n_seq=n_seq, pool_steps=args.pool_steps, lantern_k=args.lantern_k,
                             lantern_delta=args.lantern_delta, sigma=args.sigma, with_kv=not args.no_kv, kv_smax=args.kv_smax,
                             path=args.path, use_graph=args.graph, n_groups=args.groups, side_stream=args.side_stream,
                             max_steps=args.steps + args.warmup + min(args.steps, 100) + 8)

@@ -368,7 +368,7 @@ def main():
                                          "achieved": bestp["dense_contract_equivalent_GBps"], "peak": 8000.0, "unit": "GB/s",
                                          "frac": bestp["dense_contract_equivalent_GBps"] / 8000.0,
                                          "windowed_kernel_achieved": bestp["achieved_GBps"], "windowed_kernel_frac": bestp["frac"]}
-        if args.cpu_seconds > 0:
+        if args.cpu_seconds > 0 and world == 1:      # the CPU baseline is reported at N = 1 only
             n_cpu = args.cpu_seqs or min(cfg.n_seq, os.cpu_count() or 1)
             # the CPU leg replays the run from step 0 (warm-up included): compare against the whole log
             gb = wl.log_best[:n_logged].cpu().numpy()

@@ -183,3 +183,41 @@ def test_argument_errors():
     k3 = torch.zeros(1, 2, 64, 96, dtype=torch.bfloat16, device="cuda")
     with pytest.raises(LanternError, match="head_dim"):
         ops.tree_attention(q3, k3, k3.clone(), bits)
+
+
+def test_drop_in_for_the_eager_block_on_kvcache_slabs():
+    """The INTEGRATION.md stub end to end: K/V appended with the reference's `KVCache.cat` into the `[2L,B,Hkv,S_max,d]` slab of
+    `initialize_past_key_values`, then (a) the reference's eager block on the narrowed views with the additive mask its
+    `_prepare_decoder_attention_mask` builds (causal + padding + `tree_mask == 0 -> min`, here from lantern_drafter_attention_mask,
+    the same recipe) and (b) one `ops.tree_attention` call on the slab views.  Batch 2 = cond / left-padded uncond row."""
+    import types
+    from lantern_amd.drafters.kv_cache import initialize_past_key_values
+    B, Hq, d, S_max, prev = 2, 4, 128, 512, 137
+    tb = generate_tree_buffers(mc_sim_7b_63, device="cuda")
+    tm = tb["tree_attn_mask"]                                  # [1,1,N,N]
+    N = tm.shape[-1]
+    lin = types.SimpleNamespace(weight=torch.zeros(1, device="cuda"))
+    fake = types.SimpleNamespace(config=types.SimpleNamespace(num_hidden_layers=2, num_key_value_heads=Hq, max_position_embeddings=S_max,
+                                                              hidden_size=Hq * d, num_attention_heads=Hq),
+                                 model=types.SimpleNamespace(layers=[types.SimpleNamespace(self_attn=types.SimpleNamespace(q_proj=lin))]),
+                                 dtype=torch.bfloat16)
+    pkv, slabs, cur = initialize_past_key_values(fake, batch_size=B)
+    g = torch.Generator(device="cuda").manual_seed(3)
+    rnd = lambda *s: torch.randn(*s, generator=g, device="cuda").to(torch.bfloat16)      # noqa: E731
+    kcache, vcache = pkv[1]                                                               # second layer: a non-zero slab offset
+    kcache.cat(rnd(B, Hq, prev, d)); vcache.cat(rnd(B, Hq, prev, d))                     # prefill
+    q = rnd(B, Hq, N, d)                                                                  # query_states after .transpose(1, 2)
+    k_all = kcache.cat(rnd(B, Hq, N, d)); v_all = vcache.cat(rnd(B, Hq, N, d))           # tree step appended, narrowed views back
+    assert k_all.shape[2] == prev + N and int(cur[2]) == prev + N
+    pad = 29                                                                              # uncond row: 29 left-padded positions
+    attn = torch.ones(B, prev + N, dtype=torch.bool, device="cuda")
+    attn[1, :pad] = False
+    mask = ops.drafter_attention_mask(attn, tm, B, N, prev)                               # [B,1,N,prev+N] additive f32
+    w = torch.matmul(q, k_all.transpose(2, 3)) / math.sqrt(d) + mask
+    p = torch.softmax(w, dim=-1, dtype=torch.float32).to(q.dtype)
+    eager = torch.matmul(p, v_all).transpose(1, 2).reshape(B, N, Hq * d)
+    out = ops.tree_attention(q.transpose(1, 2), kcache.data, vcache.data, ops.tree_mask_bits(tm),
+                             kv_len=torch.tensor([prev + N, prev + N], device="cuda"), kv_start=torch.tensor([0, pad], device="cuda"),
+                             max_kv_len=prev + N)
+    err = (out.float() - eager.float()).abs()
+    assert (err <= ATOL + RTOL * eager.float().abs()).all(), float(err.max())

@@ -349,3 +349,64 @@ def test_cfg_window_top_p(top_p, ties):
     y = y.masked_fill(y < kth, float("-inf"))
     if mism.sum() == 0:
         np.testing.assert_allclose(pr.cpu().numpy(), torch.softmax(y.double(), -1).float().numpy(), rtol=0, atol=1e-6)
+
+
+@pytest.mark.parametrize("model", ["lumina", "anole", "llamagen"])
+@pytest.mark.parametrize("accept_last", [True, False])
+def test_window_more_candidates_than_prefetch_slots(model, accept_last):
+    """A level with ten distinct children of which the first nine (or all ten) are rejected: the kernel prefetches neighbour ids
+    for six candidates per level, so candidates 7..10 take the refill path (a finished slot is restaged mid-level) and the
+    residual is rebuilt up to ten times.  Both row kinds, packed and reference table layouts, against the oracle."""
+    m = CS.MODELS[model]
+    V, K, off = m["V"], m["K"], m["off"]
+    lo, W = window_of(model)
+    rs = np.random.RandomState(5 + len(model))
+    k = 40
+    # tree: root -> 10 children (depth 1), the last child has one child of its own (depth 2): paths [root, c_j] and [root, c_10, g]
+    P, D, N = 10, 3, 12
+    toks = rs.choice(np.arange(lo + 50, lo + W - 50), size=11, replace=False)
+    cand = np.full((P, D), -1, np.int64)
+    ri = np.zeros((P, D), np.int32)
+    root_tok = int(lo + 7)
+    for j in range(10):
+        cand[j, 0], cand[j, 1] = root_tok, toks[j]
+        ri[j, 0], ri[j, 1] = 0, 1 + j
+    cand[9, 2] = toks[10]
+    ri[9, 2] = 11
+    rows = (1.5 * rs.standard_normal((N, V))).astype(np.float32)
+    rows[:, :lo] = -np.inf
+    rows[:, lo + W:] = -np.inf
+    rows[0, toks[:9]] = -25.0                                  # p ~ 0 for the first nine children: rejected for any uniform > 1e-9
+    rows[0, toks[9]] = 12.0 if accept_last else -25.0          # the tenth is (almost surely) accepted, or rejected as well
+    table = CS.build_table(K)
+    for x in toks[:10]:                                        # their neighbourhoods carry no mass either
+        nb = table[x - off, :k].astype(np.int64) + off
+        rows[0, nb[(nb != toks[9]) | (not accept_last)]] = -25.0
+    uni = np.concatenate([np.full(9, 0.5), [0.3 if accept_last else 0.5], rs.random_sample(54)])
+    if model == "lumina":
+        mk = lambda E: E.lumina(False, lantern=True, k=k, delta=0.2)
+    elif model == "anole":
+        mk = lambda E: E.anole(False, lantern=True, k=k, delta=0.2)
+    else:
+        mk = lambda E: E.llamagen(False, lantern=True, k=k, delta=0.2)
+    co, ch = mk(oracle.EpConfig), mk(ops.EpConfig)
+    for c in (co, ch):
+        c.img_lo, c.img_hi, c.tok_offset = m["img_lo"], m["img_hi"], off
+        if model == "lumina":
+            c.syntax = tuple(m["syntax"])
+    ob, oa, osp, ocnt = oracle.evaluate_posterior(co, rows, ri, cand, uni, table=table)
+    assert int(ocnt[1]) >= 10 and int(ocnt[2]) >= 9            # ten candidates tried at level 1, at least nine rejections
+    assert oa == (1 if accept_last else 0) or oa == 2
+    win = dev(rows[None, :, lo:lo + W])
+    tabs = {"reference layout": dev(table.view(np.int16)), "packed": ops.pack_vq_table(dev(table.view(np.int16)), 48)}
+    outs = []
+    for name, tab in tabs.items():
+        out = ops.evaluate_posterior_window(ch, V, win, lo, dev(ri), dev(cand[None]), dev(uni[None]), table=tab, want_dense=True)
+        assert int(out["counters"][0, 5]) == 0, name
+        assert (int(out["best"][0]), int(out["accept_len"][0])) == (ob, oa), name
+        assert np.array_equal(out["counters"][0, :5].cpu().numpy(), ocnt[:5]), name
+        np.testing.assert_allclose(out["sample_p"][0].cpu().numpy(), osp, rtol=0, atol=PROB_TOL)
+        outs.append(out)
+    assert torch.equal(outs[0]["sample_p"], outs[1]["sample_p"])
+    d = ops.evaluate_posterior(ch, dev(rows[None]), dev(ri), dev(cand[None]), dev(uni[None]), table=dev(table.view(np.int16)))
+    assert (int(d[0][0]), int(d[1][0])) == (ob, oa)

@@ -251,6 +251,9 @@ typedef struct lantern_ep_window {
  * [B,V] distribution is also written); buf->workspace unused.  counters[5] == LANTERN_ST_NEEDS_DENSE
  * marks the (measure-zero) residual `gtp.sum()==0 -> ones` case, which only the dense kernel represents. */
 #define LANTERN_ST_NEEDS_DENSE 6
+/* counters[5] == LANTERN_ST_TREE_LIMIT: a static tree beyond what the windowed kernel stages in LDS (a node with more than 16
+ * earlier siblings, or more than 1024 entries in b_idx) -- reported, never silently truncated; the dense kernel has no such limit. */
+#define LANTERN_ST_TREE_LIMIT 7
 int lantern_evaluate_posterior_window(const lantern_ep_params *prm, const lantern_ep_buffers *buf,
                                       const lantern_ep_window *win, void *stream);
 

@@ -1269,8 +1269,11 @@ __global__ __launch_bounds__(NT, WPE) void epw_kernel(const EpwArgs args) {
                 }
             } else {
                 const int b0 = rdlane(b0_lane, j), b1 = rdlane(b1_lane, j);
-                int nsib = b1 - b0;
-                if (nsib > EW_MAX_SIB) nsib = EW_MAX_SIB;
+                const int nsib = b1 - b0;
+                if (nsib > EW_MAX_SIB || b1 > EW_MAX_B) {       // beyond the staged tables: say so instead of truncating the list
+                    status = LANTERN_ST_TREE_LIMIT;
+                    break;
+                }
                 // window indices of the earlier siblings' tokens, straight from the staged tables (every thread reads the same
                 // LDS words: broadcast, no barrier); the first four live in registers, longer sibling lists loop over LDS
                 auto sib_at = [&](int t) -> int {

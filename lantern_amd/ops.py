@@ -303,7 +303,9 @@ def evaluate_posterior(cfg: EpConfig, logits, row_index, cand, uniforms, table=N
 
 _STATUS = {1: "candidate token outside [0,V)", 2: "uniform stream exhausted", 3: "token outside the neighbour table",
            4: "image syntax token rejected (reference assert, ea_model_lumina_mgpt.py:694)", 5: "no path matches the accepted prefix",
-           6: "residual distribution vanished (`gtp.sum()==0 -> ones` is uniform over all V): only the dense kernel set represents it"}
+           6: "residual distribution vanished (`gtp.sum()==0 -> ones` is uniform over all V): only the dense kernel set represents it",
+           7: "static tree beyond the windowed kernel's staging limits (more than 16 earlier siblings of a node / 1024 b_idx entries): "
+              "use the dense kernel set"}
 
 
 def raise_on_status(counters: torch.Tensor):

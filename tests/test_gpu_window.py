@@ -410,3 +410,53 @@ def test_window_more_candidates_than_prefetch_slots(model, accept_last):
     assert torch.equal(outs[0]["sample_p"], outs[1]["sample_p"])
     d = ops.evaluate_posterior(ch, dev(rows[None]), dev(ri), dev(cand[None]), dev(uni[None]), table=dev(table.view(np.int16)))
     assert (int(d[0][0]), int(d[1][0])) == (ob, oa)
+
+
+@pytest.mark.parametrize("n_children,expect_limit", [(17, False), (18, True)])
+def test_window_static_sibling_list_limit_is_reported(n_children, expect_limit):
+    """A hand-built static tree whose root has 17 / 18 children, every one rejected in turn: the last rejection zeroes 16 / 17
+    earlier siblings in the drafter row.  Sixteen is what the windowed kernel stages; seventeen must come back as
+    LANTERN_ST_TREE_LIMIT (never a silently shorter list), while the dense kernel follows the oracle for both."""
+    m = CS.MODELS["llamagen"]
+    V = m["V"]
+    rs = np.random.RandomState(n_children)
+    P, D, N = n_children, 2, n_children + 1
+    toks = rs.choice(V, size=n_children, replace=False).astype(np.int64)
+    cand = np.stack([np.full(P, 3, np.int64), toks], axis=1)
+    ri = np.stack([np.zeros(P, np.int32), np.arange(1, P + 1, dtype=np.int32)], axis=1)
+    rows = (1.0 * rs.standard_normal((N, V))).astype(np.float32)
+    rows[0, toks] = -30.0                                       # target mass ~ 0 on every child: all rejected
+    q = np.exp(rs.standard_normal((1, V))).astype(np.float32)
+    q[0, toks] += 50.0                                          # the drafter liked them
+    q /= q.sum()
+    cart = np.stack([np.ones(P, np.float32), q[0, toks]], axis=1)
+    b_off = np.zeros(P * D + 1, np.int32)
+    b_idx = []
+    for j in range(P):                                          # cell (j,1): the earlier children's node ids 1..j
+        b_off[j * D + 1] = len(b_idx)
+        b_idx += list(range(1, j + 1))
+        b_off[j * D + 2] = len(b_idx)
+    for j in range(P):
+        b_off[j * D] = b_off[j * D + 1] if j == 0 else b_off[j * D]   # keep the CSR monotone: cell (j,0) is empty
+    b_off = np.maximum.accumulate(b_off)
+    tree_cand = np.concatenate([[3], toks]).astype(np.int64)
+    aux_o = oracle.StaticAux(cart_prob=cart, orig_prob=q, op_off=np.zeros(1, np.int32), p_idx=np.zeros((P, D), np.int32), b_off=b_off,
+                             b_idx=np.array(b_idx, np.int32), tree_cand=tree_cand)
+    co, ch = oracle.EpConfig.llamagen(True, lantern=False), ops.EpConfig.llamagen(True, lantern=False)
+    uni = np.full(64, 0.5)
+    ob, oa, osp, ocnt = oracle.evaluate_posterior(co, rows, ri, cand, uni, aux=aux_o)
+    assert oa == 0 and int(ocnt[2]) == n_children              # every child tried and rejected
+    aux_h = ops.StaticAux(cart_prob=dev(cart[None]), orig_prob=dev(q[None]), op_off=dev(np.zeros(1, np.int32)), p_idx=dev(np.zeros((P, D), np.int32)),
+                          b_off=dev(b_off), b_idx=dev(np.array(b_idx, np.int32)), tree_cand=dev(tree_cand[None]))
+    d = ops.evaluate_posterior(ch, dev(rows[None]), dev(ri), dev(cand[None]), dev(uni[None]), aux=aux_h)
+    assert (int(d[0][0]), int(d[1][0])) == (ob, oa)
+    np.testing.assert_allclose(d[2][0].cpu().numpy(), osp, rtol=0, atol=PROB_TOL)
+    w = ops.evaluate_posterior_window(ch, V, dev(rows[None]), 0, dev(ri), dev(cand[None]), dev(uni[None]), aux=aux_h, want_dense=True)
+    if expect_limit:
+        assert int(w["counters"][0, 5]) == 7
+        with pytest.raises(Exception, match="staging limits"):
+            ops.raise_on_status(w["counters"])
+    else:
+        assert int(w["counters"][0, 5]) == 0
+        assert (int(w["best"][0]), int(w["accept_len"][0])) == (ob, oa)
+        np.testing.assert_allclose(w["sample_p"][0].cpu().numpy(), osp, rtol=0, atol=PROB_TOL)

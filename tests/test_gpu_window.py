@@ -460,3 +460,61 @@ def test_window_static_sibling_list_limit_is_reported(n_children, expect_limit):
         assert int(w["counters"][0, 5]) == 0
         assert (int(w["best"][0]), int(w["accept_len"][0])) == (ob, oa)
         np.testing.assert_allclose(w["sample_p"][0].cpu().numpy(), osp, rtol=0, atol=PROB_TOL)
+
+
+@pytest.mark.parametrize("model", ["llamagen", "anole"])
+def test_window_maximum_tree_shape(model):
+    """The largest tree the windowed kernel accepts: 64 paths x 16 depths (1024 cells, the LDS tables at their capacity), 64
+    uniforms per step, ~900 node rows (row_hot read from HBM: more than 128 rows per sequence).  One trunk that the target likes
+    (acceptance runs deep) with 63 branches leaving it at different depths; batched over three sequences with different
+    uniforms; dense kernel and oracle must agree with it."""
+    m = CS.MODELS[model]
+    V, K, off = m["V"], m["K"], m["off"]
+    lo, W = window_of(model)
+    rs = np.random.RandomState(99)
+    P, D, B, k = 64, 16, 3, 10
+    pool = rs.permutation(np.arange(lo + 8, lo + W - 8))
+    take = iter(pool)
+    trunk = [int(next(take)) for _ in range(D)]
+    cand = np.zeros((P, D), np.int64)
+    ri = np.zeros((P, D), np.int32)
+    cand[0], ri[0] = trunk, np.arange(D)
+    n_rows = D
+    for p in range(1, P):
+        a = 1 + (p % (D - 2))                                  # shares the trunk up to depth a (inclusive)
+        cand[p, :a + 1], ri[p, :a + 1] = trunk[:a + 1], np.arange(a + 1)
+        for d in range(a + 1, D):
+            cand[p, d] = int(next(take)) if d < D - (p % 3) else -1      # some branches end early (-1 padding)
+            ri[p, d] = n_rows
+            n_rows += 1
+    assert n_rows > 128
+    rows = (1.0 * rs.standard_normal((n_rows, V))).astype(np.float32)
+    rows[:, :lo] = -np.inf
+    rows[:, lo + W:] = -np.inf
+    for d in range(D - 1):                                      # row d predicts depth d + 1: the trunk token gets most of the mass
+        rows[d, trunk[d + 1]] = 7.5
+    table = CS.build_table(K)
+    mk = (lambda E: E.llamagen(False, lantern=True, k=k, delta=0.3)) if model == "llamagen" else (lambda E: E.anole(False, lantern=True, k=k, delta=0.3))
+    co, ch = mk(oracle.EpConfig), mk(ops.EpConfig)
+    for c in (co, ch):
+        c.img_lo, c.img_hi, c.tok_offset = m["img_lo"], m["img_hi"], off
+    uni = rs.random_sample((B, 64))
+    uni[1] *= 0.2                                               # an easy-going sequence: accepts further
+    ref = [oracle.evaluate_posterior(co, rows, ri, cand, uni[b], table=table) for b in range(B)]
+    assert max(r[1] for r in ref) >= 6                          # the deep levels are really walked
+    win = dev(np.broadcast_to(rows[None, :, lo:lo + W], (B, n_rows, W)).copy())
+    out = ops.evaluate_posterior_window(ch, V, win, lo, dev(ri), dev(np.broadcast_to(cand[None], (B, P, D)).copy()), dev(uni),
+                                        table=dev(table.view(np.int16)), want_dense=True)
+    ops.raise_on_status(out["counters"])
+    dn = ops.evaluate_posterior(ch, dev(np.broadcast_to(rows[None], (B, n_rows, V)).copy()), dev(ri),
+                                dev(np.broadcast_to(cand[None], (B, P, D)).copy()), dev(uni), table=dev(table.view(np.int16)))
+    for b in range(B):
+        ob, oa, osp, ocnt = ref[b]
+        assert (int(out["best"][b]), int(out["accept_len"][b])) == (ob, oa), b
+        assert np.array_equal(out["counters"][b, :5].cpu().numpy(), ocnt[:5]), b
+        np.testing.assert_allclose(out["sample_p"][b].cpu().numpy(), osp, rtol=0, atol=PROB_TOL)
+        assert (int(dn[0][b]), int(dn[1][b])) == (ob, oa), b
+    # one cell more than the tables hold is refused on the host
+    with pytest.raises(Exception):
+        ops.evaluate_posterior_window(ch, V, win, lo, dev(np.zeros((65, D), np.int32)), dev(np.zeros((B, 65, D), np.int64)), dev(uni),
+                                      table=dev(table.view(np.int16)))

@@ -356,3 +356,29 @@ def test_bonus_token_inverse_cdf_vs_oracle():
     assert tok.cpu().tolist() == exp
     _, _, tok = ops.accept_gather(None, dev(np.zeros((1, 1), np.int64)), None, best, alen, sample_p=dev(p), u=None)
     assert tok.cpu().tolist() == p.argmax(1).tolist()
+
+
+@pytest.mark.parametrize("D,d", [(9, 128), (12, 64), (16, 128)])
+def test_kv_gather_deep_paths(D, d):
+    """Paths deeper than 8 nodes take the second kernel variant (up to 16 moved rows per slab row group); LlamaGen's 64-wide heads
+    and 128-wide ones; accept lengths from 0 to D-1, retrieve rows with gaps, -1 padded tails."""
+    rs = np.random.RandomState(D)
+    P, N, S = 5, 40, 96
+    ret = np.full((P, D), -1, np.int64)
+    for p in range(P):
+        n = D - (p % 3)
+        ret[p, :n] = np.concatenate([[0], np.sort(rs.choice(np.arange(1, N), size=n - 1, replace=False))])
+    slabs_np = [rs.randint(0, 65535, size=(4, 1, 6, S, d)).astype(np.uint16) for _ in range(4)]
+    slabs = [dev(s.view(np.int16)) for s in slabs_np]
+    best = np.array([0, 4], np.int32)
+    alen = np.array([D - 1, 0 if D % 2 else D - 3], np.int32)
+    seq = np.array([0, 0, 1, 1], np.int32)
+    prev = np.array([11, 30, 0, 47], np.int64)
+    new_len = ops.kv_gather(slabs, dev(seq), dev(prev), dev(ret), dev(best), dev(alen))
+    for s in range(4):
+        b = seq[s]
+        exp = oracle.kv_gather(slabs_np[s].copy(), ret[best[b]], int(alen[b]) + 1, int(prev[s]))
+        assert np.array_equal(slabs[s].cpu().numpy().view(np.uint16), exp), s
+        assert int(new_len[s]) == prev[s] + alen[b] + 1
+    with pytest.raises(Exception, match="D="):
+        ops.kv_gather(slabs, dev(seq), dev(prev), dev(np.zeros((P, 17), np.int64)), dev(best), dev(alen))

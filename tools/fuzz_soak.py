@@ -110,3 +110,83 @@ def dynamic_soak(n_seeds):
 
 if len(sys.argv) > 2 and sys.argv[2] == "dynamic":
     dynamic_soak(int(sys.argv[1]))
+
+
+# ---------------------------------------------------------------------------------------------- O7
+# `python tools/fuzz_soak.py <iters> o7`: lantern_cfg_mask_topk_window (and the dense lantern_cfg_mask_topk) on random shapes --
+# vocabulary, window, dtype, CFG scale, top-k, model mask, Lumina grid positions incl. newline / end-of-image rows -- against the
+# oracle's restatement: processed logits bit for bit, probability rows within 1e-7.
+def o7_soak(iters):
+    import numpy as np
+    import torch
+    import cases as CS
+    import oracle
+    from lantern_amd import ops
+    rs = np.random.RandomState(2024)
+    fails = n = 0
+    t0 = time.time()
+    for it in range(iters):
+        model = [ops.MODEL_PLAIN, ops.MODEL_ANOLE, ops.MODEL_LUMINA][it % 3]
+        bf16 = bool(rs.randint(2))
+        if model == ops.MODEL_PLAIN:
+            V = int(rs.choice([1024, 2048, 4096, 16384]))
+            lo, W, img_lo, img_hi = 0, V, 0, V
+        else:
+            V = int(rs.choice([2048, 16384, 65536]))
+            W = {2048: 1024, 16384: 4096, 65536: 8192}[V]
+            lo, img_lo, img_hi = 4, 4, 4 + W
+        rows = int(rs.randint(1, 40))
+        top_k = int(rs.choice([0, 1, 7, W // 4, W - 1, W, min(V, 2000)]))
+        cfg = float(rs.choice([1.0, 3.0, 4.5, 7.5]))
+        w_lat, h_lat = int(rs.choice([4, 6, 48])), int(rs.choice([3, 48]))
+        cond = (float(rs.uniform(1, 5)) * rs.standard_normal((rows, V))).astype(np.float32)
+        unc = rs.standard_normal((rows, V)).astype(np.float32)
+        ct, ut = torch.from_numpy(cond), torch.from_numpy(unc)
+        if bf16:
+            ct, ut = ct.to(torch.bfloat16), ut.to(torch.bfloat16)
+            cb, ub = ct.view(torch.int16).numpy().view(np.uint16), ut.view(torch.int16).numpy().view(np.uint16)
+        else:
+            cb, ub = cond, unc
+        pos = rs.randint(0, (w_lat + 1) * h_lat + 3, size=rows).astype(np.int64) + 20
+        kw = dict(model=model, pos_ids=torch.from_numpy(pos).cuda() if model == ops.MODEL_LUMINA else None, pos_base=20, w=w_lat, h=h_lat,
+                  img_lo=img_lo, img_hi=img_hi, newline_id=img_hi + 7, eos_id=img_hi, top_k=top_k)
+        exp = oracle.cfg_mask_topk(cb, ub, cfg, model={ops.MODEL_PLAIN: oracle.MODEL_PLAIN, ops.MODEL_ANOLE: oracle.MODEL_ANOLE,
+                                                       ops.MODEL_LUMINA: oracle.MODEL_LUMINA}[model],
+                                   pos_ids=pos, pos_base=20, w=w_lat, h=h_lat, img_lo=img_lo, img_hi=img_hi, newline_id=img_hi + 7, eos_id=img_hi,
+                                   top_k=top_k if model == ops.MODEL_LUMINA else 0, bf16=bf16)
+        if model != ops.MODEL_LUMINA and 0 < top_k < V:
+            # the oracle's O7 carries the reference's order (only Lumina filters in tree_decoding); the kernels accept top_k for
+            # every model (LlamaGen / Anole windowed set: processors applied where the rows are produced)
+            exp = CS.topk_filter(exp, top_k)
+        dense = ops.cfg_mask_topk(ct.cuda(), ut.cuda(), cfg, **kw).cpu().numpy()
+        win, hot = ops.cfg_mask_topk_window(ct.cuda(), ut.cuda(), cfg, lo, W, **kw)
+        pw, hot2 = ops.cfg_mask_topk_window(ct.cuda(), ut.cuda(), cfg, lo, W, probs=True, **kw)
+        win, hot, pw = win.cpu().numpy(), hot.cpu().numpy(), pw.cpu().numpy()
+        why = []
+        if not np.array_equal(dense, exp):
+            why.append(f"dense != oracle at {int((dense != exp).sum())} entries")
+        if not np.array_equal(hot, hot2.cpu().numpy()):
+            why.append("row_hot differs between logits and probs mode")
+        for r in range(rows):
+            fin = np.nonzero(np.isfinite(exp[r]))[0]
+            if hot[r] >= 0:
+                if not (len(fin) == 1 and fin[0] == hot[r]):
+                    why.append(f"row {r}: hot {hot[r]} vs oracle finite {fin[:4]}")
+            else:
+                if not np.array_equal(win[r], exp[r, lo:lo + W]):
+                    why.append(f"row {r}: window != oracle at {int((win[r] != exp[r, lo:lo + W]).sum())}")
+                if model != ops.MODEL_ANOLE and np.isfinite(np.delete(exp[r], np.s_[lo:lo + W])).any():
+                    why.append(f"row {r}: oracle finite outside the window")
+                ref = CS.softmax64(exp[r, lo:lo + W][None])[0]
+                if float(np.abs(pw[r] - ref).max()) > 1e-7:
+                    why.append(f"row {r}: probs off by {float(np.abs(pw[r] - ref).max()):.2e}")
+        ok = not why
+        n += 1
+        if not ok:
+            fails += 1
+            print("FAIL o7", it, dict(model=model, bf16=bf16, V=V, W=W, rows=rows, top_k=top_k, cfg=cfg, w=w_lat, h=h_lat), why[:3], flush=True)
+    print(f"o7: cases={n}, fails={fails}, {time.time() - t0:.0f}s")
+
+
+if len(sys.argv) > 2 and sys.argv[2] == "o7":
+    o7_soak(int(sys.argv[1]))

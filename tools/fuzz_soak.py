@@ -67,6 +67,14 @@ def dynamic_soak(n_seeds):
                 draft, ret, mask, pos = oracle.tree_dynamic_finalize(g["scores"], g["tokens"], g["parents"], CS.TOPK, g["total_tokens"],
                                                                      g["sample_token"])
                 N = len(draft)
+                # O4 on the device for the same scores (one sequence per launch here; batched launches are in the test-suite)
+                gd, gm, gp, gr, gnl, gmd = ops.tree_dynamic_finalize(dev(g["scores"])[None], dev(g["tokens"])[None], dev(g["parents"])[None],
+                                                                     torch.tensor([g["sample_token"]], device="cuda"), CS.TOPK, g["total_tokens"])
+                nl_, md_ = int(gnl[0]), int(gmd[0])
+                if not (np.array_equal(gd[0].cpu().numpy(), draft) and np.array_equal(gr[0, :nl_, :md_].cpu().numpy(), ret)
+                        and np.array_equal(gm[0].cpu().numpy(), mask) and np.array_equal(gp[0].cpu().numpy(), pos)):
+                    fails += 1
+                    print("FAIL finalize", model, seed, b, flush=True)
                 rs = np.random.RandomState(seed * 100 + b + 7)
                 nl = (4.0 * rs.standard_normal((N, V))).astype(np.float32)
                 if model in ("lumina", "anole"):

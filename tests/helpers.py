@@ -39,7 +39,7 @@ def table(K):
 
 
 def tree_buffers(name):
-    d = load("trees.npz")
+    d = load("trees_random.npz" if name.startswith("rand") else "trees.npz")      # rand00..rand39: make_golden_trees_random.py
     pre = name + "."
     return {k[len(pre):]: d[k] for k in d.files if k.startswith(pre)}
 

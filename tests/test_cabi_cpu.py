@@ -12,7 +12,7 @@ import helpers as H
 from lantern_amd import _lib, ops
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-TREES = [str(x) for x in H.load("trees.npz")["names"]]
+TREES = [str(x) for x in H.load("trees.npz")["names"]] + [str(x) for x in H.load("trees_random.npz")["names"]]
 
 
 def test_library_exports_every_declared_symbol():

@@ -9,7 +9,7 @@ import helpers as H
 import oracle
 
 SPECS = H.ep_specs()
-TREES = [str(x) for x in H.load("trees.npz")["names"]]
+TREES = [str(x) for x in H.load("trees.npz")["names"]] + [str(x) for x in H.load("trees_random.npz")["names"]]
 
 
 @pytest.mark.parametrize("name", TREES)

@@ -284,3 +284,98 @@ def test_drafter_anole_calling_convention_vs_reference(ci):
         assert np.array_equal(d[1].cpu().numpy(), g[pre + tag + ".retrieve"])
         assert np.array_equal(d[2].cpu().numpy().reshape(g[pre + tag + ".mask"].shape), g[pre + tag + ".mask"])
         assert np.array_equal(d[3].cpu().numpy(), g[pre + tag + ".pos"])
+
+
+class RecordingLuminaModel(cnets.Model):
+    def forward(self, hidden_states, input_ids=None, attention_mask=None, position_ids=None, past_key_values=None, use_cache=None):
+        T = input_ids.shape[1]
+        past = 0 if past_key_values is None else past_key_values[0][0].shape[2]
+        self.seen.append(dict(ids=input_ids.clone(), pos=position_ids.clone(), past=past, attn=attention_mask.clone(),
+                              hid_shape=tuple(hidden_states.shape), tree=None if self.tree_mask is None else self.tree_mask.clone()))
+        dev = input_ids.device
+        return torch.zeros(2, T, 4, device=dev), ((torch.zeros(2, 1, past + T, 1, device=dev),),)
+
+
+def _check_recorded_calls(seen, g, pre, check_ids=True):
+    assert len(seen) == int(g[pre + "n_calls"])
+    for j, s in enumerate(seen):
+        assert s["past"] == int(g[pre + f"call{j}.past"]), j
+        assert list(s["hid_shape"][:2]) == g[pre + f"call{j}.hid_shape"][:2].tolist(), j
+        assert np.array_equal(s["pos"].cpu().numpy().reshape(g[pre + f"call{j}.pos"].shape), g[pre + f"call{j}.pos"]), j
+        assert np.array_equal(s["attn"].cpu().numpy().astype(bool), g[pre + f"call{j}.attn"].astype(bool)), j
+        want_tree = g[pre + f"call{j}.tree"]
+        if want_tree.size == 0:
+            assert s["tree"] is None, j
+        else:
+            assert np.array_equal(s["tree"].cpu().numpy().reshape(want_tree.shape), want_tree), j
+        if check_ids:
+            assert np.array_equal(s["ids"].cpu().numpy(), g[pre + f"call{j}.ids"]), j
+        else:
+            assert tuple(s["ids"].shape) == g[pre + f"call{j}.ids"].shape, j
+
+
+def _lumina_recording_model(g):
+    from lantern_amd.ea_model_lumina_mgpt import InterleavedTopKLogitsWarper, MultiModalLogitsProcessor
+    V, lo, hi, nl, eos, topk, depth, total = (int(x) for x in g["dims"])
+    dcfg = types.SimpleNamespace(num_hidden_layers=1, hidden_size=16, num_attention_heads=2, intermediate_size=32, vocab_size=V, pad_token_id=None)
+    m = RecordingLuminaModel(dcfg, total_tokens=total, depth=depth, top_k=topk, model_type="lumina_mgpt", image_lo=lo, image_hi=hi).cuda()
+    m.seen, m.cfg_scale = [], 3.0
+    procs = [MultiModalLogitsProcessor(image_next_line_token_id=nl, image_end_token_id=eos, voc_size=V), InterleavedTopKLogitsWarper(image_top_k=300)]
+    return m, procs, V, topk, depth
+
+
+def _scripted_head(seed, blocks):
+    rs = np.random.RandomState(seed)
+    script = [(3.0 * rs.standard_normal(shape)).astype(np.float32) for shape in blocks]
+    calls = {"n": 0}
+
+    def head(hidden):
+        blk = torch.from_numpy(script[calls["n"]]).cuda()
+        calls["n"] += 1
+        return torch.stack([blk, 0.5 * blk])
+    return head
+
+
+@pytest.mark.parametrize("ci", [0, 1])
+def test_drafter_lumina_dynamic_loop_vs_reference(ci):
+    """`topK_generate(tree_type="dynamic")` (cnets_lumina_mgpt.py:1148-1393) at the real vocabulary: what reaches forward()
+    (ids, cond / uncond position ids from the zero-padded mask, padded attention mask, tree masks, hidden shapes) and the drafted
+    tree, first call and call on top of the drafter cache; the uncond stream is placed so that the depths cross a newline row."""
+    g = H.load("lumina_drafter.npz")
+    m, procs, V, topk, depth = _lumina_recording_model(g)
+    m.init_tree()
+    pre = f"dyn{ci}."
+    head = _scripted_head(int(g[pre + "seed"]), ([(V,)] + [(topk, V)] * depth) * 2)
+    L, Lu, extra = int(g[pre + "L"]), int(g[pre + "Lu"]), int(g[pre + "extra"])
+    attn = torch.from_numpy(g[pre + "attn"]).cuda()
+    ids1, ids2 = torch.from_numpy(g[pre + "ids1"]).cuda(), torch.from_numpy(g[pre + "ids2"]).cuda()
+    z = lambda *s: torch.zeros(*s, device="cuda")      # noqa: E731
+    outs = [m.topK_generate(z(1, L, 4), z(1, Lu, 4), ids1, head, procs, attention_mask=attn, tree_type="dynamic")]
+    assert len(m.seen) == int(g[pre + "n_first"])
+    outs.append(m.topK_generate(z(1, extra, 4), z(1, extra, 4), ids2, head, procs, attention_mask=attn, tree_type="dynamic"))
+    _check_recorded_calls(m.seen, g, pre)
+    for tag, d in zip(("out1", "out2"), outs):
+        assert np.array_equal(d[0].cpu().numpy(), g[pre + tag + ".draft"])
+        assert np.array_equal(d[1].cpu().numpy(), g[pre + tag + ".retrieve"])
+        assert np.array_equal(d[2].cpu().numpy().reshape(g[pre + tag + ".mask"].shape), g[pre + tag + ".mask"])
+        assert np.array_equal(d[3].cpu().numpy(), g[pre + tag + ".pos"])
+
+
+def test_drafter_lumina_static_loop_calls_vs_reference():
+    """`topK_generate(tree_type="static")`: the per-level forward calls (position ids, stacked tree-mask slices, repeated hidden
+    rows, padded attention mask) against the reference's; the sampled tokens themselves come from each side's own generator."""
+    g = H.load("lumina_drafter.npz")
+    m, procs, V, topk, depth = _lumina_recording_model(g)
+    m.init_tree(mc_sim_7b_63)
+    pre = "sta0."
+    tb = ops.tree_drafter_build(mc_sim_7b_63)
+    head = _scripted_head(int(g[pre + "seed"]), [(V,)] + [(len(t), V) for t in tb["tree_indices"]])
+    L, Lu = int(g[pre + "L"]), int(g[pre + "Lu"])
+    attn = torch.from_numpy(g[pre + "attn"]).cuda()
+    ids1 = torch.from_numpy(g[pre + "ids1"]).cuda()
+    out = m.topK_generate(torch.zeros(1, L, 4, device="cuda"), torch.zeros(1, Lu, 4, device="cuda"), ids1, head, procs, attention_mask=attn,
+                          tree_type="static")
+    _check_recorded_calls(m.seen[:1], {**{k: g[k] for k in g.files}, pre + "n_calls": np.int64(1)}, pre)      # the prefill: ids too
+    _check_recorded_calls(m.seen, g, pre, check_ids=False)
+    assert tuple(out[0].shape) == tuple(g[pre + "ss_token_shape"]) and len(out[2]) == int(g[pre + "n_op"])
+    assert ((out[0] >= 4) & (out[0] < 8196) | (out[0] == 8803)).all()

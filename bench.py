@@ -64,7 +64,6 @@ def cpu_baseline(wl, steps_budget_s: float, n_seq: int, gpu_tokens_by_seq):
     """The oracle (C restatement of the reference's Python path) over the first n_seq sequences and as
     many steps as fit the budget, one host thread per sequence.  Checker AND timed baseline: the
     accepted-token stream must equal the GPU's for the same steps."""
-    import ctypes
     from concurrent.futures import ThreadPoolExecutor
     import oracle
     from lantern_amd import harness as HN

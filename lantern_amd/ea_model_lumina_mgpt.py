@@ -13,8 +13,7 @@ Reference: models/ea_model_lumina_mgpt.py:25-112 (processors), :140-277 (tree bu
 """
 from __future__ import annotations
 
-import math
-from typing import List, Optional
+from typing import Optional
 
 import numpy as np
 import torch

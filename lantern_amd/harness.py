@@ -17,8 +17,8 @@ from __future__ import annotations
 
 import ctypes as C
 import random
-from dataclasses import dataclass, field
-from typing import List, Optional
+from dataclasses import dataclass
+from typing import List
 
 import numpy as np
 import torch

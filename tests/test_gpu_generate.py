@@ -6,7 +6,6 @@ line up across steps.  Both tree types (static EAGLE-1 / dynamic EAGLE-2) and bo
 import random
 import types
 
-import numpy as np
 import pytest
 import torch
 

@@ -4,7 +4,7 @@ import ctypes as C
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from lantern_amd import harness as HN, ops
+from lantern_amd import harness as HN
 from lantern_amd._lib import check
 
 def timeit(fn, n=50):

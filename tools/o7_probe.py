@@ -1,5 +1,5 @@
 """GPU probe (diagnostic): cfg_mask_topk_window / kv_gather / accept_gather timings under ablations."""
-import ctypes as C, sys, os
+import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from lantern_amd import harness as HN, ops

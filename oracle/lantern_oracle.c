@@ -3,7 +3,7 @@
  * hot path (jadohu/LANTERN, Python/PyTorch).  TEST INFRASTRUCTURE ONLY: see the
  * header of lantern_oracle.h for who may call this.
  *
- * Parity status: PINNED.  tests/golden/*.npz hold inputs/outputs captured from
+ * Parity status: PINNED.  the .npz files under tests/golden hold inputs/outputs captured from
  * the reference's own functions (EaLumina_mGPT.evaluate_posterior,
  * EaModel.evaluate_posterior[_v1], generate_tree_buffers, utils_c.generate_tree_buffers,
  * Model.topK_genrate tail, generate_candidates, KV copy, logits processors) run

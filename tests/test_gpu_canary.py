@@ -131,3 +131,12 @@ def test_drafter_table_and_attention_outputs():
     _run(T.test_split_keys_path_matches_single_pass, None)
     _run(T.test_head_shapes_and_gqa, 64, 8, 2)
     _run(T.test_left_padding, 40)
+
+
+def test_harness_step_loop_buffers():
+    """The benchmark harness (pools, per-step state, logs, KV slabs -- its own allocations, handed to the C-ABI as raw pointers)."""
+    import test_gpu_loop as L
+    _run(L.test_harness_loop_matches_oracle_loop, "window", False, 1)
+    _run(L.test_harness_loop_matches_oracle_loop, "window", False, 3)
+    _run(L.test_harness_loop_matches_oracle_loop, "dense", False, 1)
+    _run(L.test_kv_rows_follow_the_accepted_path)

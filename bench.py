@@ -40,6 +40,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--seqs-per-gpu", type=int, default=64, help="sequences resident per GPU (KV slabs: 4.3 GB each at 4096 rows; 64 -> 276e9 of the 309e9 bytes)")
     ap.add_argument("--pool-steps", type=int, default=16)
+    ap.add_argument("--tree", type=str, default="mc_sim_7b_63", help="static tree (a name in lantern_amd/drafters/choices.py), e.g. naive_extend_57 (N=58,P=33,D=6)")
     ap.add_argument("--lantern-k", type=int, default=1000)
     ap.add_argument("--lantern-delta", type=float, default=0.1)
     ap.add_argument("--sigma", type=float, default=5.0, help="drafter noise; frozen at 5.0: mean accepted tokens/step ~2.6")
@@ -242,7 +243,13 @@ def main():
     n_seq = args.seqs_per_gpu
     if not args.no_kv:
         free, _tot = torch.cuda.mem_get_info(device)
-        per_seq = 2 * (2 * 32 * 32 * (args.kv_smax + 16) * 128 * 2) + args.pool_steps * 7_700_000
+        from lantern_amd import ops as _ops
+        from lantern_amd.drafters import choices as _choices
+        _tb = _ops.tree_static_build(getattr(_choices, args.tree))
+        _N = len(_tb["tree_indices"])
+        _R = int(((_tb["tree_indices"][1:] - 1) // 10).max()) + 1
+        pool_step = _N * (2 * 65536 * 2 + 2 * 4096 * 2) + _R * (8192 * 4 + 10 * 12)       # cond + uncond logits, hidden, drafter rows
+        per_seq = 2 * (2 * 32 * 32 * (args.kv_smax + 16) * 128 * 2) + args.pool_steps * pool_step
         fit = int((free - (16 << 30)) // per_seq)
         fit -= fit % max(1, args.groups)
         if dist is not None and dist.get_world_size() > 1:
@@ -255,7 +262,7 @@ def main():
             if rank == 0:
                 print(f"bench.py: {free / 2**30:.0f} GiB free: {n_seq} sequences do not fit, running {fit}", file=sys.stderr)
             n_seq = fit
-    cfg = HN.WorkloadConfig(n_seq=n_seq, pool_steps=args.pool_steps, lantern_k=args.lantern_k,
+    cfg = HN.WorkloadConfig(n_seq=n_seq, pool_steps=args.pool_steps, tree=args.tree, lantern_k=args.lantern_k,
                             lantern_delta=args.lantern_delta, sigma=args.sigma, with_kv=not args.no_kv, kv_smax=args.kv_smax,
                             path=args.path, use_graph=args.graph, n_groups=args.groups, side_stream=args.side_stream,
                             max_steps=args.steps + args.warmup + min(args.steps, 100) + 8)
@@ -307,7 +314,7 @@ def main():
             "value": tokens_all / dt_all, "unit": "accepted_tokens/s", "n_gpus": world, "steps": K, "warmup": W,
             "ms_per_step": 1e3 * dt_all / K, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "C3: Lumina-mGPT-7B-768 LANTERN relaxed accept, static tree mc_sim_7b_63 (N=26,P=15,D=6), "
+            "config": {"workload": f"C3: Lumina-mGPT-7B-768 LANTERN relaxed accept, static tree {cfg.tree} (N={wl.N},P={wl.P},D={wl.D}), "
                                    "V=65536, K=8192, cfg=3.0, top_k=2000, sequential-CFG KV [64,1,32,%d,128] bf16 x2 per sequence (row stride %d)"
                                    % (cfg.kv_smax, cfg.kv_smax + cfg.kv_pad_rows),
                        "lantern_k": cfg.lantern_k, "lantern_delta": cfg.lantern_delta, "seqs_per_gpu": cfg.n_seq,

@@ -41,6 +41,7 @@ HIDDEN = 4096
 
 @dataclass
 class WorkloadConfig:
+    tree: str = "mc_sim_7b_63"      # static tree by its name in drafters/choices.py (the reference's default for Lumina, generate_images.py:59)
     n_seq: int = 64                 # 4.3 GB of KV slabs each (BASELINE.md geometry: 4096 rows) -> 276e9 of the GPU's 309e9 bytes
     pool_steps: int = 16
     lantern_k: int = 1000
@@ -103,7 +104,9 @@ class LuminaVerifyWorkload:
         if cfg.n_groups < 1 or B % cfg.n_groups:
             raise ValueError(f"n_seq={B} must be a multiple of n_groups={cfg.n_groups}")
         self.G, self.Bg = cfg.n_groups, B // cfg.n_groups
-        tb = ops.tree_static_build(MC_SIM_7B_63)
+        from .drafters import choices as _choices
+        tree = MC_SIM_7B_63 if cfg.tree == "mc_sim_7b_63" else getattr(_choices, cfg.tree)
+        tb = ops.tree_static_build(tree)
         self.tb = tb
         self.N = N = len(tb["tree_indices"])
         self.P, self.D = P, D = tb["retrieve_indices"].shape

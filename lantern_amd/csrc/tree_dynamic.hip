@@ -14,40 +14,67 @@ namespace lantern {
 constexpr int TD_MAX_SCORES = 2048;
 constexpr int TD_EPL = TD_MAX_SCORES / 64;  // elements per lane (blocked layout)
 
-__global__ __launch_bounds__(64) void tree_dynamic_finalize_kernel(
+// Four wavefronts per sequence, each computing the whole (cheap, latency-bound) tree redundantly in its own LDS slice -- no
+// cross-wave dependency -- and sharing only the work of writing the two [N,N] outputs.
+constexpr int TD_WAVES = 4;
+#ifdef TD_TRACE
+__device__ unsigned long long g_td_trace[32];
+#define TD_STAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_td_trace[i] = __builtin_readcyclecounter(); } while (0)
+#else
+#define TD_STAMP(i) do { } while (0)
+#endif
+template <int EPL>      // score elements per lane: 8 covers the reference's 10 + 100*depth <= 512 scores, 32 the general case
+__global__ __launch_bounds__(64 * TD_WAVES) void tree_dynamic_finalize_kernel(
     const float *__restrict__ scores_, const int64_t *__restrict__ tokens_, const int64_t *__restrict__ parents_,
     const int64_t *__restrict__ sample_token, int n_scores, int n_parents, int top_k, int T, int sort_rows,
     int64_t *__restrict__ draft_tokens, float *__restrict__ mask, int64_t *__restrict__ pos_ids,
     int64_t *__restrict__ retrieve, int32_t *__restrict__ n_leaf, int32_t *__restrict__ max_depth) {
-    __shared__ int s_sel[64];
-    __shared__ int s_par[64];
-    __shared__ int s_flag[64];
-    __shared__ signed char s_rows[64][64];
-    const int b = blockIdx.x, lane = threadIdx.x;
+    __shared__ int s_sel_[TD_WAVES][64];
+    __shared__ int s_par_[TD_WAVES][64];
+    __shared__ int s_flag_[TD_WAVES][64];
+    __shared__ signed char s_rows_[TD_WAVES][64][64];
+    __shared__ unsigned long long s_anc_[TD_WAVES][64], s_key_[TD_WAVES][64];
+    __shared__ int s_slot_[TD_WAVES][64];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int *const s_sel = s_sel_[wave], *const s_par = s_par_[wave], *const s_flag = s_flag_[wave], *const s_slot = s_slot_[wave];
+    signed char(*const s_rows)[64] = s_rows_[wave];
+    unsigned long long *const s_anc = s_anc_[wave], *const s_key = s_key_[wave];
     const int N = T + 1;
     const float *scores = scores_ + (size_t)b * n_scores;
     const int64_t *tokens = tokens_ + (size_t)b * n_scores;
     const int64_t *parents = parents_ + (size_t)b * n_parents;
 
+    TD_STAMP(0);
     // ---- top-T by score (ties -> lower flat index), kept in ascending index order
     const int E = (n_scores + 63) / 64;  // blocked: lane owns [lane*E, lane*E+E)
-    uint32_t key[TD_EPL];
+    uint32_t key[EPL];
 #pragma unroll
-    for (int j = 0; j < TD_EPL; ++j) {
+    for (int j = 0; j < EPL; ++j) {
         const int idx = lane * E + j;
         key[j] = (j < E && idx < n_scores) ? float_key(scores[idx]) : 0u;  // 0 < key of any float
     }
-    uint32_t prefix = 0;
-    for (int bit = 31; bit >= 0; --bit) {
-        const uint32_t trial = prefix | (1u << bit);
-        int c = 0;
+    TD_STAMP(1);
+    // threshold key = T-th largest: bitwise search, wave-wide counts on the scalar unit (one compare + one s_bcnt1 per element
+    // slot, no cross-lane chain).  Only wave 0 searches -- four waves doing it at once queue up on the CU's scalar unit -- and
+    // hands the result over through LDS (measured the same either way: ~400 cycles per bit, 13 k cycles of the kernel's 36 k).
+    __shared__ uint32_t s_prefix;
+    if (wave == 0) {
+        uint32_t pf = 0;
+        for (int bit = 31; bit >= 0; --bit) {
+            const uint32_t trial = pf | (1u << bit);
+            int c = 0;
 #pragma unroll
-        for (int j = 0; j < TD_EPL; ++j) c += (j < E) && key[j] >= trial;
-        if (wave_sum(c) >= T) prefix = trial;
+            for (int j = 0; j < EPL; ++j) c += __popcll(__ballot((j < E) && key[j] >= trial));
+            if (c >= T) pf = trial;
+        }
+        if (lane == 0) s_prefix = pf;
     }
+    __syncthreads();
+    const uint32_t prefix = s_prefix;
+    TD_STAMP(2);
     int c_gt = 0, c_eq = 0;
 #pragma unroll
-    for (int j = 0; j < TD_EPL; ++j) {
+    for (int j = 0; j < EPL; ++j) {
         c_gt += (j < E) && key[j] > prefix;
         c_eq += (j < E) && key[j] == prefix;
     }
@@ -63,7 +90,7 @@ __global__ __launch_bounds__(64) void tree_dynamic_finalize_kernel(
     int c_sel = 0;
     uint32_t selbits = 0;  // which of my elements are selected
 #pragma unroll
-    for (int j = 0; j < TD_EPL; ++j) {
+    for (int j = 0; j < EPL; ++j) {
         if (j >= E) continue;
         bool s = key[j] > prefix;
         if (key[j] == prefix) {
@@ -83,25 +110,31 @@ __global__ __launch_bounds__(64) void tree_dynamic_finalize_kernel(
     }
     int pos = inc_sel - c_sel;
 #pragma unroll
-    for (int j = 0; j < TD_EPL; ++j)
+    for (int j = 0; j < EPL; ++j)
         if (j < E && (selbits >> j) & 1u) s_sel[pos++] = lane * E + j;
     __syncthreads();
 
+    TD_STAMP(3);
     // ---- node = lane (0 = root); parent via searchsorted over the selected flat indices
     int par = 0;
     if (lane == 0) {
-        draft_tokens[(size_t)b * N] = sample_token[b];
+        if (wave == 0) draft_tokens[(size_t)b * N] = sample_token[b];
     } else if (lane < N) {
         const int flat = s_sel[lane - 1];
-        draft_tokens[(size_t)b * N + lane] = tokens[flat];
+        if (wave == 0) draft_tokens[(size_t)b * N + lane] = tokens[flat];
         const int64_t dp = parents[flat / top_k];
         if (dp != 0) {
             const int64_t keyv = dp - 1;
-            int p = 0;
-            while (p < T && s_sel[p] < keyv) ++p;
-            par = p + 1;
+            int lo_ = 0, hi_ = T;                  // searchsorted(left) over the ascending selected indices
+            while (lo_ < hi_) {
+                const int mid = (lo_ + hi_) >> 1;
+                if (s_sel[mid] < keyv) lo_ = mid + 1;
+                else hi_ = mid;
+            }
+            par = lo_ + 1;
         }
     }
+    TD_STAMP(4);
     s_par[lane] = par;
     s_flag[lane] = 0;
     __syncthreads();
@@ -119,13 +152,22 @@ __global__ __launch_bounds__(64) void tree_dynamic_finalize_kernel(
     int md = depth;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) md = max(md, __shfl_xor(md, o, 64));
+    TD_STAMP(5);
     const int MD = md + 1;
+    s_anc[lane] = lane < N ? anc : 0ull;
     __syncthreads();
-    if (lane < N) {
-        pos_ids[(size_t)b * N + lane] = depth;
-        float *mrow = mask + ((size_t)b * N + lane) * N;
-        for (int j = 0; j < N; ++j) mrow[j] = (float)((anc >> j) & 1ull);
+    if (lane < N && wave == 0) pos_ids[(size_t)b * N + lane] = depth;
+    {   // mask [N,N]: lanes run along the row-major output (coalesced 256-byte stores), bits from the ancestor words in LDS
+        float *mb = mask + (size_t)b * N * N;
+        const int dq = (64 * TD_WAVES) / N, dr = (64 * TD_WAVES) - dq * N;       // index step in (row, column) form
+        int r = tid / N, c = tid - r * N;          // one division, then (r, c) advance with the index
+        for (int idx = tid; idx < N * N; idx += 64 * TD_WAVES) {
+            mb[idx] = (float)((s_anc[r] >> c) & 1ull);
+            r += dq, c += dr;
+            if (c >= N) c -= N, ++r;
+        }
     }
+    TD_STAMP(6);
     // ---- leaves -> rows
     const bool leaf = lane < N && !s_flag[lane];
     const unsigned long long leafmask = __ballot(leaf);
@@ -140,28 +182,58 @@ __global__ __launch_bounds__(64) void tree_dynamic_finalize_kernel(
         }
     }
     __syncthreads();
+    TD_STAMP(7);
     int out_row = rid;
-    if (leaf && sort_rows) {
-        // rank among rows, key = entries with -1 -> T+5 (always larger than any node id)
-        int rank = 0;
-        for (int o = 0; o < nl; ++o) {
-            if (o == rid) continue;
-            int cmp = 0;
-            for (int j = 0; j < MD && cmp == 0; ++j) {
-                const int a = s_rows[o][j] < 0 ? T + 5 : s_rows[o][j];
-                const int c = s_rows[rid][j] < 0 ? T + 5 : s_rows[rid][j];
-                cmp = (a < c) ? -1 : (a > c ? 1 : 0);
+    if (sort_rows) {
+        // rank among rows, key = entries with -1 -> T+5 (always larger than any node id).  Up to 8 columns the row is one
+        // 64-bit big-endian key (one byte per column): 58 independent broadcast LDS reads instead of a compare loop per pair
+        if (MD <= 8) {
+            unsigned long long k64 = 0ull;
+            if (leaf)
+                for (int j = 0; j < 8; ++j) {
+                    const int e = (j < MD && s_rows[rid][j] >= 0) ? s_rows[rid][j] : T + 5;
+                    k64 = (k64 << 8) | (unsigned long long)(e & 255);
+                }
+            if (leaf) s_key[rid] = k64;
+            __syncthreads();
+            if (leaf) {
+                int rank = 0;
+                for (int o = 0; o < nl; ++o) {
+                    const unsigned long long ko = s_key[o];
+                    rank += (ko < k64) || (ko == k64 && o < rid);
+                }
+                out_row = rank;
             }
-            rank += (cmp < 0) || (cmp == 0 && o < rid);
+        } else if (leaf) {
+            int rank = 0;
+            for (int o = 0; o < nl; ++o) {
+                if (o == rid) continue;
+                int cmp = 0;
+                for (int j = 0; j < MD && cmp == 0; ++j) {
+                    const int a = s_rows[o][j] < 0 ? T + 5 : s_rows[o][j];
+                    const int c = s_rows[rid][j] < 0 ? T + 5 : s_rows[rid][j];
+                    cmp = (a < c) ? -1 : (a > c ? 1 : 0);
+                }
+                rank += (cmp < 0) || (cmp == 0 && o < rid);
+            }
+            out_row = rank;
         }
-        out_row = rank;
     }
-    int64_t *rbase = retrieve + (size_t)b * N * N;
-    if (leaf)
-        for (int j = 0; j < N; ++j) rbase[(size_t)out_row * N + j] = (j < MD) ? (int64_t)s_rows[rid][j] : -1;
-    if (lane < N && lane >= nl)
-        for (int j = 0; j < N; ++j) rbase[(size_t)lane * N + j] = -1;
-    if (lane == 0) {
+    TD_STAMP(8);
+    if (leaf) s_slot[out_row] = rid;           // output row -> staged row
+    __syncthreads();
+    {   // retrieve [N,N] i64, -1 padded: coalesced 512-byte stores
+        int64_t *rbase = retrieve + (size_t)b * N * N;
+        const int dq = (64 * TD_WAVES) / N, dr = (64 * TD_WAVES) - dq * N;
+        int r = tid / N, c = tid - r * N;
+        for (int idx = tid; idx < N * N; idx += 64 * TD_WAVES) {
+            rbase[idx] = (r < nl && c < MD) ? (int64_t)s_rows[s_slot[r]][c] : -1;
+            r += dq, c += dr;
+            if (c >= N) c -= N, ++r;
+        }
+    }
+    TD_STAMP(9);
+    if (tid == 0) {
         n_leaf[b] = nl;
         max_depth[b] = MD;
     }
@@ -172,61 +244,120 @@ constexpr int EX_THREADS = 256;
 constexpr int EX_NW = EX_THREADS / 64;
 constexpr int EX_MAX_K = 16;
 
-// one workgroup per (sequence,row): log_softmax stats + iterative top-k (k <= 16)
+// One workgroup per (sequence, row): log_softmax statistics + the top_k (<= 16) entries, ties towards the lower index.
+// Two reads of the row (the second one from L2) instead of top_k + 2:
+//   pass 1  per-thread maximum.  The top_k-th largest of the 256 thread maxima is a lower bound of the row's top_k-th
+//           largest value (they are 256 distinct elements), so only entries >= that bound can be in the answer;
+//   pass 2  sum of exp(x - max) (same per-thread order as before) and the candidates >= bound appended to an LDS list
+//           (a few dozen entries on ordinary rows); then top_k rounds of a block-wide argmax over that list.
+// Rows with fewer than top_k finite entries (bound = -inf) or more than EX_CAND candidates (heavy ties) take the plain
+// iterative path over the row itself.
+constexpr int EX_CAND = 2048;
 __global__ __launch_bounds__(EX_THREADS) void expand_rows_kernel(const float *__restrict__ logits, const float *__restrict__ scores_in,
                                                                  int n_rows, int V, int top_k, int64_t *__restrict__ topk_index,
                                                                  float *__restrict__ cu_scores) {
     __shared__ float s_redf[2 * EX_NW];
     __shared__ double s_redd[2 * EX_NW];
     __shared__ float s_bv[EX_NW];
-    __shared__ int s_bi[EX_NW];
+    __shared__ int s_bi[EX_NW], s_bs[EX_NW];
     __shared__ int s_taken[EX_MAX_K];
+    __shared__ float s_tmax[EX_THREADS];
+    __shared__ float s_cv[EX_CAND];
+    __shared__ int s_ci[EX_CAND];
+    __shared__ float s_bound;
+    __shared__ int s_n;
     const int rowid = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float *x = logits + (size_t)rowid * V;
     const float NEG_INF = -__builtin_inff();
     int ph = 0;
-    float m = NEG_INF;
-    for (int i = tid; i < V; i += EX_THREADS) m = fmaxf(m, x[i]);
-    m = block_max<EX_NW>(m, s_redf, ph);
+    float tm = NEG_INF;
+    for (int i = tid; i < V; i += EX_THREADS) tm = fmaxf(tm, x[i]);
+    s_tmax[tid] = tm;
+    if (tid == 0) {
+        s_bound = NEG_INF;
+        s_n = 0;
+    }
+    const float m = block_max<EX_NW>(tm, s_redf, ph);          // (barrier inside: s_tmax is visible afterwards)
+    {
+        int rank = 0;                                           // thread maxima ahead of mine in (value desc, thread asc) order
+        for (int t = 0; t < EX_THREADS; ++t) {
+            const float o = s_tmax[t];
+            rank += (o > tm) || (o == tm && t < tid);
+        }
+        if (rank == top_k - 1) s_bound = tm;
+    }
+    __syncthreads();
+    const float bound = s_bound;
+    const bool collect = bound > NEG_INF;
     double s = 0.0;
-    for (int i = tid; i < V; i += EX_THREADS) s += (double)expf(x[i] - m);
+    for (int i = tid; i < V; i += EX_THREADS) {
+        const float v = x[i];
+        s += (double)expf(v - m);
+        if (collect && v >= bound) {
+            const int slot = atomicAdd(&s_n, 1);
+            if (slot < EX_CAND) {
+                s_cv[slot] = v;
+                s_ci[slot] = i;
+            }
+        }
+    }
     const float ls = logf((float)block_sum<double, EX_NW>(s, s_redd, ph));
     const float sc = scores_in ? scores_in[rowid] : 0.0f;
+    __syncthreads();
+    const int n_cand = s_n;
+    const bool fast = collect && n_cand <= EX_CAND;            // n_cand >= top_k whenever collect
     for (int t = 0; t < top_k; ++t) {
         float bv = NEG_INF;
-        int bi = 0x7fffffff;
-        for (int i = tid; i < V; i += EX_THREADS) {
-            bool taken = false;
-            for (int q = 0; q < t; ++q) taken |= (s_taken[q] == i);
-            const float v = x[i];
-            if (!taken && (v > bv || (v == bv && i < bi))) {
-                bv = v;
-                bi = i;
+        int bi = 0x7fffffff, bs = -1;
+        if (fast) {
+            for (int c = tid; c < n_cand; c += EX_THREADS) {
+                const int i = s_ci[c];
+                const float v = s_cv[c];
+                if (i >= 0 && (v > bv || (v == bv && i < bi))) {
+                    bv = v;
+                    bi = i;
+                    bs = c;
+                }
+            }
+        } else {
+            for (int i = tid; i < V; i += EX_THREADS) {
+                bool taken = false;
+                for (int q = 0; q < t; ++q) taken |= (s_taken[q] == i);
+                const float v = x[i];
+                if (!taken && (v > bv || (v == bv && i < bi))) {
+                    bv = v;
+                    bi = i;
+                }
             }
         }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {
             const float ov = __shfl_xor(bv, o, 64);
             const int oi = __shfl_xor(bi, o, 64);
+            const int os = __shfl_xor(bs, o, 64);
             if (ov > bv || (ov == bv && oi < bi)) {
                 bv = ov;
                 bi = oi;
+                bs = os;
             }
         }
         if (lane == 0) {
             s_bv[wave] = bv;
             s_bi[wave] = bi;
+            s_bs[wave] = bs;
         }
         __syncthreads();
         if (tid == 0) {
             float v = s_bv[0];
-            int i = s_bi[0];
+            int i = s_bi[0], sl = s_bs[0];
             for (int w = 1; w < EX_NW; ++w)
                 if (s_bv[w] > v || (s_bv[w] == v && s_bi[w] < i)) {
                     v = s_bv[w];
                     i = s_bi[w];
+                    sl = s_bs[w];
                 }
             s_taken[t] = i;
+            if (fast && sl >= 0) s_ci[sl] = -1;                 // taken
             topk_index[(size_t)rowid * top_k + t] = i;
             cu_scores[(size_t)rowid * top_k + t] = ((v - m) - ls) + sc;
         }
@@ -279,6 +410,12 @@ __global__ __launch_bounds__(64) void expand_merge_kernel(const float *__restric
 
 using namespace lantern;
 
+#ifdef TD_TRACE
+extern "C" int lantern_debug_td_trace(unsigned long long *out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(lantern::g_td_trace), 32 * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
+}
+#endif
+
 extern "C" int lantern_tree_dynamic_finalize(const float *scores, const int64_t *tokens, const int64_t *parents,
                                              const int64_t *sample_token, int B, int n_scores, int n_parents, int top_k,
                                              int total_tokens, int sort_rows, int64_t *draft_tokens, float *mask,
@@ -291,8 +428,14 @@ extern "C" int lantern_tree_dynamic_finalize(const float *scores, const int64_t 
     LANTERN_CHECK_ARG(n_scores >= total_tokens && n_scores <= TD_MAX_SCORES, "tree_dynamic_finalize: n_scores=%d out of range", n_scores);
     LANTERN_CHECK_ARG(n_parents * top_k >= n_scores, "tree_dynamic_finalize: n_parents=%d too small for n_scores=%d", n_parents, n_scores);
     if (B == 0) return LANTERN_OK;
-    hipLaunchKernelGGL(tree_dynamic_finalize_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, scores, tokens, parents, sample_token,
-                       n_scores, n_parents, top_k, total_tokens, sort_rows, draft_tokens, mask, pos_ids, retrieve, n_leaf, max_depth);
+    if (n_scores <= 8 * 64)
+        hipLaunchKernelGGL(tree_dynamic_finalize_kernel<8>, dim3(B), dim3(64 * TD_WAVES), 0, (hipStream_t)stream, scores, tokens, parents,
+                           sample_token, n_scores, n_parents, top_k, total_tokens, sort_rows, draft_tokens, mask, pos_ids, retrieve, n_leaf,
+                           max_depth);
+    else
+        hipLaunchKernelGGL(tree_dynamic_finalize_kernel<TD_EPL>, dim3(B), dim3(64 * TD_WAVES), 0, (hipStream_t)stream, scores, tokens, parents,
+                           sample_token, n_scores, n_parents, top_k, total_tokens, sort_rows, draft_tokens, mask, pos_ids, retrieve, n_leaf,
+                           max_depth);
     LANTERN_CHECK_LAUNCH("tree_dynamic_finalize");
     return LANTERN_OK;
 }

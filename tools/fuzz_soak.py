@@ -198,3 +198,52 @@ def o7_soak(iters):
 
 if len(sys.argv) > 2 and sys.argv[2] == "o7":
     o7_soak(int(sys.argv[1]))
+
+
+# ---------------------------------------------------------------------------------------------- O3
+# `python tools/fuzz_soak.py <iters> o3`: lantern_expand_dynamic (log-softmax + top-10 per row + merge) against the oracle on random
+# rows: vocabularies 1024..65536, -inf masked regions (down to fewer than ten finite entries), heavy ties (few distinct values:
+# the candidate list overflows and the plain path runs), first level (no incoming scores) and deeper levels.
+def o3_soak(iters):
+    import numpy as np
+    import torch
+    import oracle
+    from lantern_amd import ops
+    rs = np.random.RandomState(77)
+    fails = 0
+    t0 = time.time()
+    for it in range(iters):
+        V = int(rs.choice([1024, 4096, 8192, 65536]))
+        first = it % 4 == 0
+        R = 1 if first else 10
+        x = (float(rs.uniform(0.5, 6)) * rs.standard_normal((R, V))).astype(np.float32)
+        mode = it % 5
+        if mode == 1:                                   # image-window style mask
+            lo = int(rs.randint(0, V // 2)); hi = lo + int(rs.randint(16, V // 2))
+            x[:, :lo] = -np.inf; x[:, hi:] = -np.inf
+        elif mode == 2:                                 # ties everywhere
+            x = np.round(x * float(rs.choice([0.5, 2, 8]))) / 8
+        elif mode == 3:                                 # almost everything masked: 3..40 finite entries per row
+            keep = int(rs.randint(3, 40))
+            for r in range(R):
+                idx = rs.choice(V, size=V - keep, replace=False)
+                x[r, idx] = -np.inf
+        elif mode == 4:                                 # top-k filtered row (2000 finite)
+            kth = np.sort(x, axis=-1)[:, -min(2000, V)][:, None]
+            x[x < kth] = -np.inf
+        sc = None if first else (rs.standard_normal(R).astype(np.float32) - 3)
+        oti, ocu, oci, osc = oracle.expand_dynamic(x, sc, 10)
+        ti, cu, ci, so = ops.expand_dynamic(torch.from_numpy(x).cuda()[None], None if first else torch.from_numpy(sc).cuda()[None], 10)
+        ok = np.array_equal(ti[0].cpu().numpy(), oti) and np.array_equal(ci[0].cpu().numpy(), oci)
+        a, b = cu[0].cpu().numpy(), ocu
+        fin = np.isfinite(b)
+        ok = ok and np.array_equal(np.isfinite(a), fin) and (not fin.any() or float(np.abs(a[fin] - b[fin]).max()) <= 1e-5)
+        ok = ok and float(np.abs(np.nan_to_num(so[0].cpu().numpy(), neginf=0) - np.nan_to_num(osc, neginf=0)).max()) <= 1e-5
+        if not ok:
+            fails += 1
+            print("FAIL o3", it, dict(V=V, R=R, mode=mode), flush=True)
+    print(f"o3: cases={iters}, fails={fails}, {time.time() - t0:.0f}s")
+
+
+if len(sys.argv) > 2 and sys.argv[2] == "o3":
+    o3_soak(int(sys.argv[1]))

@@ -226,11 +226,20 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # Test knob for a 1-GPU box: LANTERN_BENCH_ONE_DEVICE=1 runs every rank on cuda:0 over gloo (RCCL refuses two ranks on one
+    # device), so that the N > 1 control flow -- rank seeds, the MIN / MAX / SUM reductions, rank-0 output -- can be exercised.
+    one_device = os.environ.get("LANTERN_BENCH_ONE_DEVICE") == "1"
+    if one_device:
+        local_rank = 0
     dist = None
     if world > 1 or os.environ.get("LANTERN_BENCH_FORCE_DIST") == "1":       # the env knob exercises the RCCL path on a 1-GPU box
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if one_device:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    red_device = torch.device("cpu") if one_device else None               # gloo reduces host tensors
     assert world == max(1, args.gpus) or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
@@ -253,7 +262,7 @@ def main():
         fit = int((free - (16 << 30)) // per_seq)
         fit -= fit % max(1, args.groups)
         if dist is not None and dist.get_world_size() > 1:
-            t = torch.tensor([fit], dtype=torch.int64, device=device)
+            t = torch.tensor([fit], dtype=torch.int64, device=red_device or device)
             dist.all_reduce(t, op=dist.ReduceOp.MIN)
             fit = int(t[0])
         if fit < n_seq:
@@ -304,7 +313,7 @@ def main():
     wl.check_status(0, n_logged)
     tokens = wl.accepted_tokens(W, W + K)
     from lantern_amd.sharding import reduce_timing
-    dt_all, tokens_all = reduce_timing(dist, dt, float(tokens), device=device)
+    dt_all, tokens_all = reduce_timing(dist, dt, float(tokens), device=red_device or device)
 
     if rank == 0:
         alen = wl.log_alen[W:W + K].float() + 1

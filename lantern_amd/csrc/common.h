@@ -94,14 +94,14 @@ __device__ __forceinline__ double dpp_mov(double v) {
 // inclusive scan over the 64 lanes (Kogge-Stone inside 16-lane rows, then row broadcasts)
 template <typename T>
 __device__ __forceinline__ T wave_scan_incl_dpp(T v) {
-    const int lane = threadIdx.x & 63, rl = lane & 15;
-    T t;
-    t = dpp_mov<0x111>(v); if (rl >= 1) v += t;
-    t = dpp_mov<0x112>(v); if (rl >= 2) v += t;
-    t = dpp_mov<0x114>(v); if (rl >= 4) v += t;
-    t = dpp_mov<0x118>(v); if (rl >= 8) v += t;
-    t = dpp_mov<0x142, 0xa>(v); if ((lane & 31) >= 16) v += t;
-    t = dpp_mov<0x143, 0xc>(v); if (lane >= 32) v += t;
+    // dpp_mov hands lanes without a valid source (and rows outside the row mask) the `old` operand = 0: adding it is the
+    // identity, so the adds need no lane predicate (one v_add with a DPP operand per step for 32-bit types)
+    v += dpp_mov<0x111>(v);
+    v += dpp_mov<0x112>(v);
+    v += dpp_mov<0x114>(v);
+    v += dpp_mov<0x118>(v);
+    v += dpp_mov<0x142, 0xa>(v);
+    v += dpp_mov<0x143, 0xc>(v);
     return v;
 }
 
@@ -186,12 +186,10 @@ __device__ __forceinline__ T block_sum_fast(T v, T *sm, int &phase) {
     if (lane == 0) buf[threadIdx.x >> 6] = v;
     __syncthreads();
     T x = (lane < NW) ? buf[lane] : T(0);
-    T t;
-    const int rl = lane & 15;
-    t = dpp_mov<0x111>(x); if (rl >= 1) x += t;
-    t = dpp_mov<0x112>(x); if (rl >= 2) x += t;
-    t = dpp_mov<0x114>(x); if (rl >= 4) x += t;
-    t = dpp_mov<0x118>(x); if (rl >= 8) x += t;
+    x += dpp_mov<0x111>(x);      // lanes without a source add the `old` operand = 0 (see wave_scan_incl_dpp)
+    x += dpp_mov<0x112>(x);
+    x += dpp_mov<0x114>(x);
+    x += dpp_mov<0x118>(x);
     // lane 15 of row 0 holds the total of partials 0..15
     if constexpr (sizeof(T) == 8) {
         const long long b = __double_as_longlong((double)x);

@@ -692,6 +692,7 @@ struct alignas(16) EwShared {
     int redi[2 * 16];
     double samp_tot[16][4];
     int dec[2][4];                          // decision words of wave 0: {code, m>0, csm1 bits, -}
+    double ubonus[2];                       // [0]: the bonus draw's uniform, fetched with the prologue's first round of loads
     int hot[EW_MAX_N];                      // row_hot of this sequence's rows (when rows_per_seq <= EW_MAX_N)
     unsigned short nbid[EW_PF_C][EW_PF_K];  // prefetched neighbour ids (raw table values)
     unsigned short nbaddr[EW_PF_C][EW_PF_K];// the same neighbours as gather indices into g (window index or a sentinel slot)
@@ -873,6 +874,8 @@ __global__ __launch_bounds__(NT, WPE) void epw_kernel(const EpwArgs args) {
             hot_[u] = (hot_g && hot_in_lds && t < prm.rows_per_seq) ? hot_g[t] : -1;
         }
         if (is_static && tid < Ds - 1) oo_ = buf.op_off[tid];
+        double ub_ = 0.0;                   // read by the epilogue from LDS: a global load there sits on the chain with its full latency
+        if (tid == 0 && win.u_bonus) ub_ = win.u_bonus[b];
         // round 2
         const double *uni = buf.uniforms + (size_t)b * prm.n_uniforms;
         double un_ = 2.0;                   // never drawn: guarded below
@@ -932,6 +935,7 @@ __global__ __launch_bounds__(NT, WPE) void epw_kernel(const EpwArgs args) {
             g[W + EW_G_ZERO] = 0.0f;
             g[W + EW_G_HUGE] = 3.0e38f;
             g[W + EW_G_OUT] = 0.0f;
+            S.ubonus[0] = ub_;
         }
     }
     EPW_STAMP(1);
@@ -1300,17 +1304,19 @@ __global__ __launch_bounds__(NT, WPE) void epw_kernel(const EpwArgs args) {
                     }
                 EPW_STAMPG(31);
                 double qs_loc = 0.0;
+                if (nsib > 0) {          // a level's first candidate has no earlier sibling: q is used as it is (qs = 1)
 #pragma unroll
-                for (int it = 0; it < E4; ++it) {
-                    const int e = (tid + it * NT) * 4;
+                    for (int it = 0; it < E4; ++it) {
+                        const int e = (tid + it * NT) * 4;
 #pragma unroll
-                    for (int t = 0; t < 4; ++t)
-                        if (sib_r[t] >= e && sib_r[t] < e + 4) set_comp(q[it], sib_r[t] - e, 0.0f);
-                    for (int t = 4; t < nsib; ++t) {
-                        const int sidx = sib_at(t);
-                        if (sidx >= e && sidx < e + 4) set_comp(q[it], sidx - e, 0.0f);
+                        for (int t = 0; t < 4; ++t)
+                            if (sib_r[t] >= e && sib_r[t] < e + 4) set_comp(q[it], sib_r[t] - e, 0.0f);
+                        for (int t = 4; t < nsib; ++t) {
+                            const int sidx = sib_at(t);
+                            if (sidx >= e && sidx < e + 4) set_comp(q[it], sidx - e, 0.0f);
+                        }
+                        qs_loc += (double)q[it].x + (double)q[it].y + (double)q[it].z + (double)q[it].w;
                     }
-                    qs_loc += (double)q[it].x + (double)q[it].y + (double)q[it].z + (double)q[it].w;
                 }
                 EPW_STAMPG(32);
                 float qs = 1.0f;
@@ -1439,7 +1445,7 @@ __global__ __launch_bounds__(NT, WPE) void epw_kernel(const EpwArgs args) {
             excl[it] = front + start + (inc[it] - s4[it]);
         }
         if (out_tok >= 0 && !out_before) total += (double)out_mass;
-        const double tgt = k_u_bonus[b] * total;
+        const double tgt = S.ubonus[0] * total;
         int found = 0x7fffffff, last_pos = -1;
         if (out_before && out_mass > 0.0f) {
             last_pos = out_tok;

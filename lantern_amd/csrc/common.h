@@ -91,6 +91,17 @@ __device__ __forceinline__ double dpp_mov(double v) {
     return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
 }
 
+// the same move with `old` = the value itself: lanes without a valid source (and rows outside the row mask) read their own
+// value back, the identity of min / max -- no lane predicate needed
+template <int CTRL, int ROW_MASK = 0xf, int BANK_MASK = 0xf>
+__device__ __forceinline__ int dpp_self(int v) {
+    return __builtin_amdgcn_update_dpp(v, v, CTRL, ROW_MASK, BANK_MASK, false);
+}
+template <int CTRL, int ROW_MASK = 0xf, int BANK_MASK = 0xf>
+__device__ __forceinline__ float dpp_self(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), CTRL, ROW_MASK, BANK_MASK, false));
+}
+
 // inclusive scan over the 64 lanes (Kogge-Stone inside 16-lane rows, then row broadcasts)
 template <typename T>
 __device__ __forceinline__ T wave_scan_incl_dpp(T v) {
@@ -119,30 +130,23 @@ __device__ __forceinline__ T wave_sum(T v) {
     return readlane63(wave_scan_incl_dpp(v));
 }
 __device__ __forceinline__ float wave_max(float v) {
-    const int lane = threadIdx.x & 63, rl = lane & 15;
-    const float NI = -__builtin_inff();
-    float t;
-    // update_dpp(old = 0 ...) would inject 0 for invalid source lanes: guard with the same lane predicates as the scan
-    t = dpp_mov<0x111>(v); if (rl >= 1) v = fmaxf(v, t);
-    t = dpp_mov<0x112>(v); if (rl >= 2) v = fmaxf(v, t);
-    t = dpp_mov<0x114>(v); if (rl >= 4) v = fmaxf(v, t);
-    t = dpp_mov<0x118>(v); if (rl >= 8) v = fmaxf(v, t);
-    t = dpp_mov<0x142, 0xa>(v); if ((lane & 31) >= 16) v = fmaxf(v, t);
-    t = dpp_mov<0x143, 0xc>(v); if (lane >= 32) v = fmaxf(v, t);
-    (void)NI;
+    v = fmaxf(v, dpp_self<0x111>(v));
+    v = fmaxf(v, dpp_self<0x112>(v));
+    v = fmaxf(v, dpp_self<0x114>(v));
+    v = fmaxf(v, dpp_self<0x118>(v));
+    v = fmaxf(v, dpp_self<0x142, 0xa>(v));
+    v = fmaxf(v, dpp_self<0x143, 0xc>(v));
     return readlane63(v);
 }
 
 // integer min / max over the wave (DPP), result in every lane
 __device__ __forceinline__ int wave_min_i(int v) {
-    const int lane = threadIdx.x & 63, rl = lane & 15;
-    int t;
-    t = dpp_mov<0x111>(v); if (rl >= 1) v = min(v, t);
-    t = dpp_mov<0x112>(v); if (rl >= 2) v = min(v, t);
-    t = dpp_mov<0x114>(v); if (rl >= 4) v = min(v, t);
-    t = dpp_mov<0x118>(v); if (rl >= 8) v = min(v, t);
-    t = dpp_mov<0x142, 0xa>(v); if ((lane & 31) >= 16) v = min(v, t);
-    t = dpp_mov<0x143, 0xc>(v); if (lane >= 32) v = min(v, t);
+    v = min(v, dpp_self<0x111>(v));
+    v = min(v, dpp_self<0x112>(v));
+    v = min(v, dpp_self<0x114>(v));
+    v = min(v, dpp_self<0x118>(v));
+    v = min(v, dpp_self<0x142, 0xa>(v));
+    v = min(v, dpp_self<0x143, 0xc>(v));
     return readlane63(v);
 }
 __device__ __forceinline__ int wave_max_i(int v) { return -wave_min_i(-v); }
@@ -207,15 +211,14 @@ __device__ __forceinline__ float block_max_fast(float v, float *sm, int &phase) 
     v = wave_max(v);
     float *buf = sm + (phase & 1) * NW;
     phase ^= 1;
-    const int lane = threadIdx.x & 63, rl = lane & 15;
+    const int lane = threadIdx.x & 63;
     if (lane == 0) buf[threadIdx.x >> 6] = v;
     __syncthreads();
     float x = (lane < NW) ? buf[lane] : -__builtin_inff();
-    float t;
-    t = dpp_mov<0x111>(x); if (rl >= 1) x = fmaxf(x, t);
-    t = dpp_mov<0x112>(x); if (rl >= 2) x = fmaxf(x, t);
-    t = dpp_mov<0x114>(x); if (rl >= 4) x = fmaxf(x, t);
-    t = dpp_mov<0x118>(x); if (rl >= 8) x = fmaxf(x, t);
+    x = fmaxf(x, dpp_self<0x111>(x));
+    x = fmaxf(x, dpp_self<0x112>(x));
+    x = fmaxf(x, dpp_self<0x114>(x));
+    x = fmaxf(x, dpp_self<0x118>(x));
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 15));
 }
 

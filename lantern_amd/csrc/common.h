@@ -77,17 +77,22 @@ __device__ __forceinline__ void set_comp(float4 &v, int c, float val) {
 // without LDS).  ctrl: row_shr:n = 0x110+n, row_bcast:15 = 0x142, row_bcast:31 = 0x143.
 template <int CTRL, int ROW_MASK = 0xf, int BANK_MASK = 0xf>
 __device__ __forceinline__ int dpp_mov(int v) {
-    return __builtin_amdgcn_update_dpp(0, v, CTRL, ROW_MASK, BANK_MASK, false);
+    // full row/bank masks: bound_ctrl makes lanes without a source read 0 by itself, so no `old` register has to be zeroed
+    // before every move; with a partial row mask the rows left out keep `old` = 0
+    constexpr bool BC = (ROW_MASK == 0xf && BANK_MASK == 0xf);
+    return __builtin_amdgcn_update_dpp(0, v, CTRL, ROW_MASK, BANK_MASK, BC);
 }
 template <int CTRL, int ROW_MASK = 0xf, int BANK_MASK = 0xf>
 __device__ __forceinline__ float dpp_mov(float v) {
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, BANK_MASK, false));
+    constexpr bool BC = (ROW_MASK == 0xf && BANK_MASK == 0xf);
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, BANK_MASK, BC));
 }
 template <int CTRL, int ROW_MASK = 0xf, int BANK_MASK = 0xf>
 __device__ __forceinline__ double dpp_mov(double v) {
     const long long b = __double_as_longlong(v);
-    const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xffffffffll), CTRL, ROW_MASK, BANK_MASK, false);
-    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, ROW_MASK, BANK_MASK, false);
+    constexpr bool BC = (ROW_MASK == 0xf && BANK_MASK == 0xf);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xffffffffll), CTRL, ROW_MASK, BANK_MASK, BC);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, ROW_MASK, BANK_MASK, BC);
     return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
 }
 

@@ -1457,12 +1457,11 @@ __global__ __launch_bounds__(NT, WPE) void epw_kernel(const EpwArgs args) {
             double acc = excl[it];
             const float pv[4] = {p[it].x, p[it].y, p[it].z, p[it].w};
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
+            for (int c = 0; c < 4; ++c) {      // selects, not branches: 16 elements per thread
                 acc += (double)pv[c];
-                if (pv[c] > 0.0f) {
-                    last_pos = max(last_pos, e + c);
-                    if (acc > tgt) found = min(found, e + c);
-                }
+                const bool pos = pv[c] > 0.0f;
+                last_pos = max(last_pos, pos ? e + c : -1);
+                found = min(found, (pos && acc > tgt) ? e + c : 0x7fffffff);
             }
         }
         if (out_tok >= 0 && !out_before && out_mass > 0.0f) {

@@ -1116,10 +1116,15 @@ __global__ __launch_bounds__(NT, WPE) void epw_kernel(const EpwArgs args) {
             // static trees: start the drafter-row read now; it lands while wave 0 runs the neighbour scan and is
             // simply dropped if the candidate is accepted (one 32 KB row, L2/MALL-resident for the next try)
             float4 q[E4];
+            const float *qsrc = nullptr;
             if (is_static) {
                 int qrow = rdlane(qrow_lane, j);
                 qrow = qrow < 0 ? 0 : (qrow >= prm.R ? prm.R - 1 : qrow);                           // same for the drafter-row index
-                const float *qsrc = buf.orig_prob + ((size_t)b * prm.R + qrow) * (size_t)win.orig_prob_stride + win.orig_prob_offset;
+                qsrc = buf.orig_prob + ((size_t)b * prm.R + qrow) * (size_t)win.orig_prob_stride + win.orig_prob_offset;
+            }
+            // wave 0 (the serial worker) would sit behind the other waves' loads in the CU's address unit before it can enter
+            // the scan: it fetches its own 4 KB share only once a rejection is known
+            if (is_static && wave != 0) {
 #pragma unroll
                 for (int it = 0; it < E4; ++it) {
                     const int i4 = tid + it * NT;
@@ -1248,6 +1253,13 @@ __global__ __launch_bounds__(NT, WPE) void epw_kernel(const EpwArgs args) {
             if (prm.syntax_shortcut && is_syn) {
                 status = LANTERN_ST_SYNTAX_REJECT;
                 break;
+            }
+            if (is_static && wave == 0) {
+#pragma unroll
+                for (int it = 0; it < E4; ++it) {
+                    const int i4 = tid + it * NT;
+                    q[it] = (i4 * 4 < W) ? reinterpret_cast<const float4 *>(qsrc)[i4] : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
             }
             const bool zero_nb = prm.lantern && m > 0 && (!prm.syntax_shortcut || in_img);
             double loc = 0.0;

@@ -1124,7 +1124,7 @@ __global__ __launch_bounds__(NT, WPE) void epw_kernel(const EpwArgs args) {
             }
             // wave 0 (the serial worker) would sit behind the other waves' loads in the CU's address unit before it can enter
             // the scan: it fetches its own 4 KB share only once a rejection is known
-            if (is_static && wave != 0) {
+            if (is_static && (wave != 0 || WPE != 1)) {     // (the throughput build has a second workgroup to hide the queueing)
 #pragma unroll
                 for (int it = 0; it < E4; ++it) {
                     const int i4 = tid + it * NT;
@@ -1254,7 +1254,7 @@ __global__ __launch_bounds__(NT, WPE) void epw_kernel(const EpwArgs args) {
                 status = LANTERN_ST_SYNTAX_REJECT;
                 break;
             }
-            if (is_static && wave == 0) {
+            if (is_static && wave == 0 && WPE == 1) {
 #pragma unroll
                 for (int it = 0; it < E4; ++it) {
                     const int i4 = tid + it * NT;
@@ -1469,11 +1469,16 @@ __global__ __launch_bounds__(NT, WPE) void epw_kernel(const EpwArgs args) {
             double acc = excl[it];
             const float pv[4] = {p[it].x, p[it].y, p[it].z, p[it].w};
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {      // selects, not branches: 16 elements per thread
+            for (int c = 0; c < 4; ++c) {
                 acc += (double)pv[c];
-                const bool pos = pv[c] > 0.0f;
-                last_pos = max(last_pos, pos ? e + c : -1);
-                found = min(found, (pos && acc > tgt) ? e + c : 0x7fffffff);
+                if constexpr (WPE == 1) {      // latency build: selects, not branches (16 elements per thread)
+                    const bool pos = pv[c] > 0.0f;
+                    last_pos = max(last_pos, pos ? e + c : -1);
+                    found = min(found, (pos && acc > tgt) ? e + c : 0x7fffffff);
+                } else if (pv[c] > 0.0f) {     // throughput build (two workgroups per CU): skip the work of the zero entries
+                    last_pos = max(last_pos, e + c);
+                    if (acc > tgt) found = min(found, e + c);
+                }
             }
         }
         if (out_tok >= 0 && !out_before && out_mass > 0.0f) {

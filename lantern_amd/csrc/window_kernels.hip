@@ -1116,6 +1116,8 @@ __global__ __launch_bounds__(NT, WPE) void epw_kernel(const EpwArgs args) {
             // static trees: start the drafter-row read now; it lands while wave 0 runs the neighbour scan and is
             // simply dropped if the candidate is accepted (one 32 KB row, L2/MALL-resident for the next try)
             float4 q[E4];
+#pragma unroll
+            for (int it = 0; it < E4; ++it) q[it] = make_float4(0.f, 0.f, 0.f, 0.f);   // defined on every path: no value carried around the loop
             const float *qsrc = nullptr;
             if (is_static) {
                 int qrow = rdlane(qrow_lane, j);

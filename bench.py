@@ -17,6 +17,10 @@ Extra objects on the JSON line:
                 own counters) / its mean launch duration measured with HIP events on the launch stream
                 inside the timed region; peak 8000 GB/s.
   kernels       the same for cfg_mask_topk and kv_gather.
+  roofline_saturated / ep_batch_sweep
+                evaluate_posterior alone at --ep-sweep sequences per launch (default 256 = one workgroup per CU), measured after
+                the timed region: BASELINE.md states the 60 % roofline target at the saturating batch size, which the 64 KV-resident
+                sequences of the step loop cannot reach (4.3 GB of KV slabs each).
   cpu_baseline  the oracle (C port of the reference path) timed on this host's cores over a bounded
                 sample of the same pools/uniforms; it must reproduce the GPU's accepted-token stream.
 """
@@ -52,8 +56,11 @@ def parse():
     ap.add_argument("--graph", action="store_true", help="replay one captured hipGraph per (pool slot, group) instead of launching eagerly")
     ap.add_argument("--side-stream", action="store_true", help="launch O6 beside O7 and O10 beside O9 on a second HIP stream (measured slower: event waits)")
     ap.add_argument("--groups", type=int, default=1, help="split the GPU's sequences into this many groups, each on its own HIP stream (independent sequences: one group's latency-bound evaluate_posterior overlaps the others' bandwidth-bound kernels)")
-    ap.add_argument("--ep-sweep", type=str, default="",
-                    help="e.g. 256,2048: batch sizes for the evaluate_posterior-only roofline sweep (BASELINE.md section 2); off by default so that the default command launches every kernel on one homogeneous workload (rocprofv3 averages then agree with the HIP-event averages)")
+    ap.add_argument("--ep-sweep", type=str, default="256",
+                    help="e.g. 256,2048: batch sizes for the evaluate_posterior-only roofline sweep (BASELINE.md section 2: the 60 %% target is "
+                         "stated 'at the saturating batch size'), run by rank 0 AFTER the timed region and the event pass, KV slabs released first; "
+                         "default 256 = one workgroup per CU (`roofline_saturated` on the JSON line).  Pass '' under rocprofv3 so that every "
+                         "kernel is launched on one homogeneous workload (its averages then agree with the HIP-event averages)")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="CPU-baseline budget; 0 disables")
     ap.add_argument("--cpu-seqs", type=int, default=0, help="sequences in the CPU sample (0 = host cores)")
     return ap.parse_args()
@@ -378,11 +385,14 @@ def main():
             wl.release_kv()      # the sweep builds its own (KV-free) workloads: give the memory back first
             sweep = ep_batch_sweep([int(x) for x in args.ep_sweep.split(",") if x], device, cfg)
             out["ep_batch_sweep"] = sweep
-            bestp = max([r for r in sweep if "frac" in r], key=lambda r: r["dense_contract_equivalent_GBps"])
-            out["roofline_saturated"] = {"kernel": out.get("roofline", {}).get("kernel"), "sequences_per_launch": bestp["sequences_per_launch"],
-                                         "achieved": bestp["dense_contract_equivalent_GBps"], "peak": 8000.0, "unit": "GB/s",
-                                         "frac": bestp["dense_contract_equivalent_GBps"] / 8000.0,
-                                         "windowed_kernel_achieved": bestp["achieved_GBps"], "windowed_kernel_frac": bestp["frac"]}
+            done = [r for r in sweep if "frac" in r]
+            bestp = max(done, key=lambda r: r["dense_contract_equivalent_GBps"]) if done else None
+            if bestp:
+                out["roofline_saturated"] = {"kernel": out.get("roofline", {}).get("kernel"), "sequences_per_launch": bestp["sequences_per_launch"],
+                                             "achieved": bestp["dense_contract_equivalent_GBps"], "peak": 8000.0, "unit": "GB/s",
+                                             "frac": bestp["dense_contract_equivalent_GBps"] / 8000.0, "avg_launch_ms": bestp["launch_ms"],
+                                             "windowed_kernel_achieved": bestp["achieved_GBps"], "windowed_kernel_frac": bestp["frac"],
+                                             "note": "evaluate_posterior alone on one verify step's inputs (no KV slabs resident), measured after the timed region"}
         if args.cpu_seconds > 0 and world == 1:      # the CPU baseline is reported at N = 1 only
             n_cpu = args.cpu_seqs or min(cfg.n_seq, os.cpu_count() or 1)
             # the CPU leg replays the run from step 0 (warm-up included): compare against the whole log

@@ -79,7 +79,7 @@ typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
 // MAXSEL = rows a step can accept (D); U = row groups a thread moves per trip, all loads of the U groups in flight
 // before the first store (few, fat workgroups: a thread that moves one 16-byte chunk of ~1.3 rows has too little in
 // flight to cover HBM latency, and 12k tiny workgroups per launch are dispatch-bound).
-template <int MAXSEL, int U>
+template <int MAXSEL, int U, int MODE = 0>
 __device__ __forceinline__ void kv_gather_body(int bx, int nbx, int s, void *const *__restrict__ slab_ptrs, const int32_t *__restrict__ slab_seq,
                                                         const int64_t *__restrict__ slab_prev, int64_t outer, int64_t S_max,
                                                         int chunks_per_row, const int64_t *__restrict__ retrieve,
@@ -125,7 +125,7 @@ __device__ __forceinline__ void kv_gather_body(int bx, int nbx, int s, void *con
             if (w < total) {
 #pragma unroll
                 for (int t = 0; t < MAXSEL; ++t)
-                    if ((move >> t) & 1u) v[u][t] = __builtin_nontemporal_load(&rowbase[u][srcrow[t] * cpr]);
+                    if ((move >> t) & 1u) v[u][t] = (MODE & 1) ? rowbase[u][srcrow[t] * cpr] : __builtin_nontemporal_load(&rowbase[u][srcrow[t] * cpr]);
             }
         }
 #pragma unroll
@@ -134,7 +134,10 @@ __device__ __forceinline__ void kv_gather_body(int bx, int nbx, int s, void *con
             if (w < total) {
 #pragma unroll
                 for (int t = 0; t < MAXSEL; ++t)
-                    if ((move >> t) & 1u) __builtin_nontemporal_store(v[u][t], &rowbase[u][(prev + t) * cpr]);
+                    if ((move >> t) & 1u) {
+                        if (MODE & 2) rowbase[u][(prev + t) * cpr] = v[u][t];
+                        else __builtin_nontemporal_store(v[u][t], &rowbase[u][(prev + t) * cpr]);
+                    }
             }
         }
     }
@@ -189,7 +192,7 @@ __global__ __launch_bounds__(256) void accept_copy_kernel(const uint4 *__restric
 
 // O9 + O10 in one launch (the two halves of the reference's update_inference_inputs): grid.y < n_slabs moves KV rows,
 // the rows above it carry the accepted-hidden copy, one (sequence, cond/uncond, depth) row per workgroup.
-template <int MAXSEL, int U>
+template <int MAXSEL, int U, int MODE = 0>
 __global__ __launch_bounds__(256) void update_inputs_kernel(void *const *__restrict__ slab_ptrs, const int32_t *__restrict__ slab_seq,
                                                             const int64_t *__restrict__ slab_prev, int n_slabs, int64_t outer,
                                                             int64_t S_max, int chunks_per_row, const int64_t *__restrict__ retrieve,
@@ -199,8 +202,8 @@ __global__ __launch_bounds__(256) void update_inputs_kernel(void *const *__restr
                                                             const int64_t *__restrict__ cand, uint4 *__restrict__ out_hidden,
                                                             int64_t *__restrict__ accepted_tokens) {
     if ((int)blockIdx.y < n_slabs) {
-        kv_gather_body<MAXSEL, U>(blockIdx.x, gridDim.x, blockIdx.y, slab_ptrs, slab_seq, slab_prev, outer, S_max, chunks_per_row, retrieve,
-                                  retrieve_per_seq, P, D, best, accept_len, new_len);
+        kv_gather_body<MAXSEL, U, MODE>(blockIdx.x, gridDim.x, blockIdx.y, slab_ptrs, slab_seq, slab_prev, outer, S_max, chunks_per_row, retrieve,
+                                        retrieve_per_seq, P, D, best, accept_len, new_len);
     } else {
         const int lin = ((int)blockIdx.y - n_slabs) * gridDim.x + blockIdx.x;
         const int per_seq = G * D;
@@ -452,13 +455,24 @@ extern "C" int lantern_update_inference_inputs(void *const *slab_ptrs, const int
     const int cpr = (int)(d * elem_bytes / 16);
     const int64_t total = outer * cpr;
     LANTERN_CHECK_ARG(total < (1ll << 31), "update_inference_inputs: outer * row chunks = %lld does not fit 31 bits", (long long)total);
-    int gx = (int)((total + 511) / 512);
+    static const int variant = getenv("LANTERN_KV_VARIANT") ? atoi(getenv("LANTERN_KV_VARIANT")) : 0;   // tuning knob (diagnostic): 10*U + mode
+    const int uu = variant / 10 ? variant / 10 : 2, mode = variant % 10;
+    int gx = (int)((total + uu * 256 - 1) / (uu * 256));
     if (gx > 4096) gx = 4096;
     const int g = hidden ? G : 1;
     const int extra = (B * g * D + gx - 1) / gx;
-    LANTERN_LAUNCH((update_inputs_kernel<8, 2>), dim3(gx, n_slabs + extra), dim3(256), 0, (hipStream_t)stream, slab_ptrs, slab_seq,
-                       slab_prev, n_slabs, outer, S_max, cpr, retrieve, retrieve_per_seq, P, D, best, accept_len, new_len,
-                       (const uint4 *)hidden, B, g, N, hidden ? H * hid_elem_bytes / 16 : 0, cand, (uint4 *)out_hidden, accepted_tokens);
+#define UI_LAUNCH(U_, M_)                                                                                                                \
+    LANTERN_LAUNCH((update_inputs_kernel<8, U_, M_>), dim3(gx, n_slabs + extra), dim3(256), 0, (hipStream_t)stream, slab_ptrs, slab_seq, \
+                   slab_prev, n_slabs, outer, S_max, cpr, retrieve, retrieve_per_seq, P, D, best, accept_len, new_len,                   \
+                   (const uint4 *)hidden, B, g, N, hidden ? H * hid_elem_bytes / 16 : 0, cand, (uint4 *)out_hidden, accepted_tokens)
+    if (uu == 1 && mode == 0) UI_LAUNCH(1, 0);
+    else if (uu == 4 && mode == 0) UI_LAUNCH(4, 0);
+    else if (uu == 2 && mode == 1) UI_LAUNCH(2, 1);
+    else if (uu == 2 && mode == 2) UI_LAUNCH(2, 2);
+    else if (uu == 2 && mode == 3) UI_LAUNCH(2, 3);
+    else if (uu == 4 && mode == 3) UI_LAUNCH(4, 3);
+    else UI_LAUNCH(2, 0);
+#undef UI_LAUNCH
     LANTERN_CHECK_LAUNCH("update_inference_inputs");
     return LANTERN_OK;
 }

@@ -135,3 +135,58 @@ def test_kv_gather_identity_conservation_and_bounds_full_geometry():
     after = [s.clone() for s in slabs]
     ops.kv_gather(slabs, seq, prev, ret, best0, alen0)
     assert all(torch.equal(x, y) for x, y in zip(slabs, after))
+
+
+def test_dynamic_tree_batch_invariants():
+    """O4 on a batch of 32 different EAGLE-2 trees (N = 59): the outputs must describe a rooted tree -- ancestor sets closed
+    under ancestry, one parent per node, positions = depths, retrieve rows = the root-to-leaf chains, one row per leaf -- and
+    the batched launch must equal 32 single-sequence launches (the oracle pins single trees bit for bit in test_gpu_parity
+    and the soak tool; this is the batch-independence and shape bookkeeping at full N)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import cases as CS
+    from lantern_amd import ops
+    B = 32
+    gens = [CS.gen_dynamic(7000 + b, "llamagen", sigma=float(1 + b % 3)) for b in range(B)]
+    tt = gens[0]["total_tokens"]
+    assert all(g["total_tokens"] == tt for g in gens)
+    dev = lambda key, dt: torch.from_numpy(np.stack([np.asarray(g[key]) for g in gens]).astype(dt)).cuda()      # noqa: E731
+    scores, tokens, parents = dev("scores", np.float32), dev("tokens", np.int64), dev("parents", np.int64)
+    st = torch.tensor([int(g["sample_token"]) for g in gens], dtype=torch.int64, device="cuda")
+    draft, mask, pos, ret, nl, md = ops.tree_dynamic_finalize(scores, tokens, parents, st, CS.TOPK, tt)
+    N = tt + 1
+    assert draft.shape == (B, N) and mask.shape == (B, N, N)
+    m = mask.cpu().numpy()
+    assert set(np.unique(m)) <= {0.0, 1.0}
+    mi = m.astype(np.int64)
+    eye = np.eye(N, dtype=np.int64)
+    assert (mi * eye[None] == eye[None]).all()                         # every node attends to itself
+    assert (mi[:, :, 0] == 1).all()                                    # ... and to the root
+    assert (np.triu(mi, 1) == 0).all()                                 # ancestors come first in the node order
+    assert (((mi @ mi) > 0).astype(np.int64) == mi).all()              # an ancestor's ancestors are ancestors
+    p = pos.cpu().numpy()
+    assert (p == mi.sum(-1) - 1).all()                                 # position id = depth = number of proper ancestors
+    assert (draft[:, 0].cpu() == st.cpu()).all()
+    r, nl_, md_ = ret.cpu().numpy(), nl.cpu().numpy(), md.cpu().numpy()
+    for b in range(B):
+        # one parent per node: the ancestor one level up carries exactly the node's ancestor set minus the node
+        for i in range(1, N):
+            anc = np.nonzero(mi[b, i])[0]
+            par = [a for a in anc if p[b, a] == p[b, i] - 1]
+            assert len(par) == 1 and (mi[b, i] == mi[b, par[0]] + eye[i]).all()
+        leaves = [i for i in range(N) if mi[b, :, i].sum() == 1]
+        assert nl_[b] == len(leaves) and md_[b] == p[b].max() + 1
+        rows = r[b, :nl_[b], :md_[b]]
+        ends = []
+        for row in rows:
+            k = int((row >= 0).sum())
+            assert (row[:k] >= 0).all() and (row[k:] == -1).all() and row[0] == 0
+            for d in range(1, k):
+                assert (mi[b, row[d]] == mi[b, row[d - 1]] + eye[row[d]]).all()     # each step goes from a node to one of its children
+            ends.append(int(row[k - 1]))
+        assert sorted(ends) == leaves                                   # one retrieve row per leaf, every leaf once
+    # batch independence: sequence b alone gives the same outputs
+    for b in (0, 13, B - 1):
+        d1, m1, p1, r1, n1, x1 = ops.tree_dynamic_finalize(scores[b:b + 1], tokens[b:b + 1], parents[b:b + 1], st[b:b + 1], CS.TOPK, tt)
+        assert torch.equal(d1[0], draft[b]) and torch.equal(m1[0], mask[b]) and torch.equal(p1[0], pos[b])
+        assert int(n1[0]) == int(nl[b]) and int(x1[0]) == int(md[b])
+        assert torch.equal(r1[0, :int(n1[0]), :int(x1[0])], ret[b, :int(nl[b]), :int(md[b])])

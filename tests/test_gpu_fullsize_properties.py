@@ -24,9 +24,9 @@ pytestmark = pytest.mark.gpu
 B_FULL, STEPS = 64, 24
 
 
-def _run(groups):
+def _run(groups, path="window"):
     from lantern_amd import harness as HN
-    cfg = HN.WorkloadConfig(n_seq=B_FULL, pool_steps=3, with_kv=False, max_steps=STEPS + 8, n_groups=groups)
+    cfg = HN.WorkloadConfig(n_seq=B_FULL, pool_steps=3, with_kv=False, max_steps=STEPS + 8, n_groups=groups, path=path)
     wl = HN.LuminaVerifyWorkload(cfg, torch.device("cuda"))
     for _ in range(STEPS):
         wl.step()
@@ -89,6 +89,20 @@ def test_result_does_not_depend_on_the_launch_grouping():
     assert b.Bg == B_FULL // 4
     for x, y in zip(la, (b.log_best, b.log_alen, b.log_token, b.log_cnt)):
         assert torch.equal(x, y[:STEPS])
+
+
+def test_dense_and_windowed_kernel_sets_agree_on_the_full_batch():
+    """Two independent implementations of O7 + O8 (full-vocabulary rows in registers / HBM vs 8192-wide window rows with the
+    residual in LDS) walk the same 64 sequences: identical decisions, bonus tokens and counters in every step."""
+    _, a = _run(1, "window")
+    la = [t[:STEPS].clone() for t in (a.log_best, a.log_alen, a.log_token)]
+    ca = a.log_cnt[:STEPS, :, :5].clone()
+    del a
+    torch.cuda.empty_cache()
+    _, b = _run(1, "dense")
+    for x, y in zip(la, (b.log_best, b.log_alen, b.log_token)):
+        assert torch.equal(x, y[:STEPS])
+    assert torch.equal(ca, b.log_cnt[:STEPS, :, :5])
 
 
 def test_kv_gather_identity_conservation_and_bounds_full_geometry():

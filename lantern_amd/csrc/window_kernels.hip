@@ -1117,7 +1117,8 @@ __global__ __launch_bounds__(NT, WPE) void epw_kernel(const EpwArgs args) {
             // simply dropped if the candidate is accepted (one 32 KB row, L2/MALL-resident for the next try)
             float4 q[E4];
 #pragma unroll
-            for (int it = 0; it < E4; ++it) q[it] = make_float4(0.f, 0.f, 0.f, 0.f);   // defined on every path: no value carried around the loop
+            for (int it = 0; it < E4; ++it)
+                if constexpr (WPE == 1) q[it] = make_float4(0.f, 0.f, 0.f, 0.f);   // defined on every path: no value carried around the loop
             const float *qsrc = nullptr;
             if (is_static) {
                 int qrow = rdlane(qrow_lane, j);

@@ -1,5 +1,5 @@
 """Extended soak of tests/test_gpu_fuzz.py::test_static_batches_vs_oracle over many more seeds (development aid, not part of the suite):
-    python tools/fuzz_soak.py <seeds>   ->  8 parameter sets x <seeds> batches of 32 sequences, both kernel sets vs the oracle."""
+    python tests/fuzz_soak.py <seeds>   ->  8 parameter sets x <seeds> batches of 32 sequences, both kernel sets vs the oracle."""
 import os
 import sys
 import time
@@ -26,7 +26,7 @@ if len(sys.argv) < 3:
 
 
 # ---------------------------------------------------------------------------------------------- dynamic trees
-# `python tools/fuzz_soak.py <seeds> dynamic`: EAGLE-2 trees (N = 59, random shapes per sequence) built by the oracle from
+# `python tests/fuzz_soak.py <seeds> dynamic`: EAGLE-2 trees (N = 59, random shapes per sequence) built by the oracle from
 # random drafter scores, target rows that make the drafted tokens plausible, both kernel sets in ragged batches of 16 sequences
 # (per-sequence row maps, -1 padded paths) against the oracle.
 def dynamic_soak(n_seeds):
@@ -121,7 +121,7 @@ if len(sys.argv) > 2 and sys.argv[2] == "dynamic":
 
 
 # ---------------------------------------------------------------------------------------------- O7
-# `python tools/fuzz_soak.py <iters> o7`: lantern_cfg_mask_topk_window (and the dense lantern_cfg_mask_topk) on random shapes --
+# `python tests/fuzz_soak.py <iters> o7`: lantern_cfg_mask_topk_window (and the dense lantern_cfg_mask_topk) on random shapes --
 # vocabulary, window, dtype, CFG scale, top-k, model mask, Lumina grid positions incl. newline / end-of-image rows -- against the
 # oracle's restatement: processed logits bit for bit, probability rows within 1e-7.
 def o7_soak(iters):
@@ -201,7 +201,7 @@ if len(sys.argv) > 2 and sys.argv[2] == "o7":
 
 
 # ---------------------------------------------------------------------------------------------- O3
-# `python tools/fuzz_soak.py <iters> o3`: lantern_expand_dynamic (log-softmax + top-10 per row + merge) against the oracle on random
+# `python tests/fuzz_soak.py <iters> o3`: lantern_expand_dynamic (log-softmax + top-10 per row + merge) against the oracle on random
 # rows: vocabularies 1024..65536, -inf masked regions (down to fewer than ten finite entries), heavy ties (few distinct values:
 # the candidate list overflows and the plain path runs), first level (no incoming scores) and deeper levels.
 def o3_soak(iters):

@@ -6,7 +6,7 @@ C3 sizes, through the same entry points the model mirrors use:
     O9 + O10 lantern_update_inference_inputs (per-sequence retrieve rows).
 bench.py times the static tree (the reference's default for Lumina); this script puts the dynamic half of C3 on the clock.  Pools
 are synthetic (drafter scores from the O3 kernel on random logits; target rows random with the drafted tokens made plausible);
-parity of every kernel in this mode is in the test-suite (test_c3_lumina_dynamic_tree_full_size, tools/fuzz_soak.py dynamic).
+parity of every kernel in this mode is in the test-suite (test_c3_lumina_dynamic_tree_full_size, tests/fuzz_soak.py dynamic).
 Usage: python tools/dynamic_step_bench.py [--seqs 64] [--steps 100]      (kernel-only times: run it under rocprofv3 --kernel-trace --stats)"""
 import argparse
 import json

@@ -722,17 +722,17 @@ struct NoHook {
 //
 // The row arrives in registers (`r`, loaded by row_load -- possibly long before, so that its HBM latency hides behind
 // other work); one-hot rows ignore `r`.
-template <int NT, int E4>
+template <int NT, int E4, bool FULLW = false>
 __device__ __forceinline__ void row_load(const float *__restrict__ rowp, int W, float4 (&r)[E4]) {
     const float NEG_INF = -__builtin_inff();
 #pragma unroll
     for (int it = 0; it < E4; ++it) {
         const int i4 = threadIdx.x + it * NT;
-        r[it] = (i4 * 4 < W) ? reinterpret_cast<const float4 *>(rowp)[i4] : make_float4(NEG_INF, NEG_INF, NEG_INF, NEG_INF);
+        r[it] = (FULLW || i4 * 4 < W) ? reinterpret_cast<const float4 *>(rowp)[i4] : make_float4(NEG_INF, NEG_INF, NEG_INF, NEG_INF);
     }
 }
 
-template <int NT, int E4, typename Hook = NoHook>
+template <int NT, int E4, bool FULLW = false, typename Hook = NoHook>
 __device__ __forceinline__ void row_softmax_to_lds(float4 (&r)[E4], int hot, bool probs, int win_lo, int W, float temperature, int top_k,
                                                    int V, float *g, int &out_tok, float &out_mass, EwShared &S, int &ph,
                                                    const Hook &pre_barrier = Hook()) {
@@ -778,7 +778,7 @@ __device__ __forceinline__ void row_softmax_to_lds(float4 (&r)[E4], int hot, boo
 #pragma unroll
     for (int it = 0; it < E4; ++it) {
         const int i4 = tid + it * NT;
-        if (i4 * 4 < W) reinterpret_cast<float4 *>(g)[i4] = r[it];
+        if (FULLW || i4 * 4 < W) reinterpret_cast<float4 *>(g)[i4] = r[it];
     }
     if (tid == 0) g[W + EW_G_OUT] = 0.0f;
     pre_barrier();
@@ -806,7 +806,9 @@ typedef const __attribute__((address_space(4))) EpwArgs *EpwArgsK;
 // workgroup per CU) used while every sequence of the launch gets a CU to itself; 4 (512-thread workgroups) = 128 VGPRs so
 // that TWO workgroups share a CU once the batch exceeds the CU count (67 KB of LDS each): +41 % sequences/s at saturation,
 // -7 % at 48 sequences (a few spills), hence selected by batch size.
-template <int NT, int E4, int IDMODE, int WPE>
+// FULLW: the window is exactly the workgroup's register tile (W == 4 * NT * E4, the Lumina / Anole 8192-id image range on
+// 512 x 4): no per-chunk bounds predicate, so the four chunks of a pass are one basic block and their LDS reads go out together.
+template <int NT, int E4, int IDMODE, int WPE, bool FULLW = false>
 __global__ __launch_bounds__(NT, WPE) void epw_kernel(const EpwArgs args) {
     constexpr bool LDSIDS = IDMODE != 0;
     const lantern_ep_params &prm = args.prm;
@@ -887,7 +889,7 @@ __global__ __launch_bounds__(NT, WPE) void epw_kernel(const EpwArgs args) {
             bi_[u] = (t < nb_total && t < EW_MAX_B) ? buf.b_idx[t] : 0;
         }
         if (rid1 >= 0 && rid1 < prm.rows_per_seq) {
-            row_load<NT, E4>(logits + (size_t)rid1 * W, W, rp);
+            row_load<NT, E4, FULLW>(logits + (size_t)rid1 * W, W, rp);
             rp_rid = rid1;
         }
         // LDS stores
@@ -1041,9 +1043,9 @@ __global__ __launch_bounds__(NT, WPE) void epw_kernel(const EpwArgs args) {
             rid = rid < 0 ? 0 : (rid >= prm.rows_per_seq ? prm.rows_per_seq - 1 : rid);     // a bad row map must not read outside the batch
             const int hot = !hot_g ? -1 : (hot_in_lds ? S.hot[rid] : hot_g[rid]);
             EPW_STAMP(10);
-            if (hot < 0 && rp_rid != rid) row_load<NT, E4>(logits + (size_t)rid * W, W, rp);
+            if (hot < 0 && rp_rid != rid) row_load<NT, E4, FULLW>(logits + (size_t)rid * W, W, rp);
             rp_rid = -1;
-            row_softmax_to_lds<NT, E4>(rp, hot, rows_probs, lo, W, prm.temperature, prm.top_k, V, g, out_tok, out_mass, S, ph, [&]() {
+            row_softmax_to_lds<NT, E4, FULLW>(rp, hot, rows_probs, lo, W, prm.temperature, prm.top_k, V, g, out_tok, out_mass, S, ph, [&]() {
                 if (can_prefetch && IDMODE == 2) {
 #pragma unroll
                     for (int u = 0; u < PF16_PER; ++u) {
@@ -1131,7 +1133,7 @@ __global__ __launch_bounds__(NT, WPE) void epw_kernel(const EpwArgs args) {
 #pragma unroll
                 for (int it = 0; it < E4; ++it) {
                     const int i4 = tid + it * NT;
-                    q[it] = (i4 * 4 < W) ? reinterpret_cast<const float4 *>(qsrc)[i4] : make_float4(0.f, 0.f, 0.f, 0.f);
+                    q[it] = (FULLW || i4 * 4 < W) ? reinterpret_cast<const float4 *>(qsrc)[i4] : make_float4(0.f, 0.f, 0.f, 0.f);
                 }
             }
             // ---------------- serial section: wave 0 only
@@ -1261,7 +1263,7 @@ __global__ __launch_bounds__(NT, WPE) void epw_kernel(const EpwArgs args) {
 #pragma unroll
                 for (int it = 0; it < E4; ++it) {
                     const int i4 = tid + it * NT;
-                    q[it] = (i4 * 4 < W) ? reinterpret_cast<const float4 *>(qsrc)[i4] : make_float4(0.f, 0.f, 0.f, 0.f);
+                    q[it] = (FULLW || i4 * 4 < W) ? reinterpret_cast<const float4 *>(qsrc)[i4] : make_float4(0.f, 0.f, 0.f, 0.f);
                 }
             }
             const bool zero_nb = prm.lantern && m > 0 && (!prm.syntax_shortcut || in_img);
@@ -1283,7 +1285,7 @@ __global__ __launch_bounds__(NT, WPE) void epw_kernel(const EpwArgs args) {
 #pragma unroll
                 for (int it = 0; it < E4; ++it) {
                     const int i4 = tid + it * NT;
-                    gn[it] = (i4 * 4 < W) ? reinterpret_cast<const float4 *>(g)[i4] : make_float4(0.f, 0.f, 0.f, 0.f);
+                    gn[it] = (FULLW || i4 * 4 < W) ? reinterpret_cast<const float4 *>(g)[i4] : make_float4(0.f, 0.f, 0.f, 0.f);
                     loc += (double)gn[it].x + (double)gn[it].y + (double)gn[it].z + (double)gn[it].w;
                 }
             } else {
@@ -1345,7 +1347,7 @@ __global__ __launch_bounds__(NT, WPE) void epw_kernel(const EpwArgs args) {
                 for (int it = 0; it < E4; ++it) {
                     const int i4 = tid + it * NT;
                     gn[it] = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (i4 * 4 < W) {
+                    if (FULLW || i4 * 4 < W) {
                         float4 qv = q[it];
                         if (nsib > 0) qv = dq(qv);
                         if (lg_nb) {
@@ -1381,7 +1383,7 @@ __global__ __launch_bounds__(NT, WPE) void epw_kernel(const EpwArgs args) {
 #pragma unroll
             for (int it = 0; it < E4; ++it) {
                 const int i4 = tid + it * NT;
-                if (i4 * 4 < W)
+                if (FULLW || i4 * 4 < W)
                     reinterpret_cast<float4 *>(g)[i4] = dg(gn[it]);
             }
             out_mass = out_mass / gs;
@@ -1397,8 +1399,8 @@ __global__ __launch_bounds__(NT, WPE) void epw_kernel(const EpwArgs args) {
         int rid = Srow[best * Ds + (a - 1)];
         rid = rid < 0 ? 0 : (rid >= prm.rows_per_seq ? prm.rows_per_seq - 1 : rid);
         const int hot = !hot_g ? -1 : (hot_in_lds ? S.hot[rid] : hot_g[rid]);
-        if (hot < 0 && rp_rid != rid) row_load<NT, E4>(logits + (size_t)rid * W, W, rp);
-        row_softmax_to_lds<NT, E4>(rp, hot, rows_probs, lo, W, prm.temperature, prm.top_k, V, g, out_tok, out_mass, S, ph);
+        if (hot < 0 && rp_rid != rid) row_load<NT, E4, FULLW>(logits + (size_t)rid * W, W, rp);
+        row_softmax_to_lds<NT, E4, FULLW>(rp, hot, rows_probs, lo, W, prm.temperature, prm.top_k, V, g, out_tok, out_mass, S, ph);
     }
     // ---------------------------------------------------------------- epilogue: outputs from LDS
     EPW_STAMP(40);
@@ -1410,14 +1412,14 @@ __global__ __launch_bounds__(NT, WPE) void epw_kernel(const EpwArgs args) {
 #pragma unroll
     for (int it = 0; it < E4; ++it) {
         const int i4 = tid + it * NT;
-        p[it] = (i4 * 4 < W) ? reinterpret_cast<const float4 *>(g)[i4] : make_float4(0.f, 0.f, 0.f, 0.f);
+        p[it] = (FULLW || i4 * 4 < W) ? reinterpret_cast<const float4 *>(g)[i4] : make_float4(0.f, 0.f, 0.f, 0.f);
     }
     if (k_sample_win) {
         float *sw = k_sample_win + (size_t)b * W;
 #pragma unroll
         for (int it = 0; it < E4; ++it) {
             const int i4 = tid + it * NT;
-            if (i4 * 4 < W) reinterpret_cast<float4 *>(sw)[i4] = p[it];
+            if (FULLW || i4 * 4 < W) reinterpret_cast<float4 *>(sw)[i4] = p[it];
         }
     }
     if (k_sample_p) {   // optional dense copy (API compatibility)
@@ -1668,7 +1670,9 @@ extern "C" int lantern_evaluate_posterior_window(const lantern_ep_params *prm, c
     else if (W <= 2048) EPW_LAUNCH(256, 2);
     else if (W <= 4096) EPW_LAUNCH(512, 2);
     else if (W <= 8192) {
-        if (two_per_cu) EPW_LAUNCH_W(512, 4, 4);
+        if (two_per_cu && W == 8192 && idmode == 2) LANTERN_LAUNCH((epw_kernel<512, 4, 2, 4, true>), grid, dim3(512), lds, st, args);
+        else if (two_per_cu) EPW_LAUNCH_W(512, 4, 4);
+        else if (W == 8192 && idmode == 2) LANTERN_LAUNCH((epw_kernel<512, 4, 2, 1, true>), grid, dim3(512), lds, st, args);   // the Lumina / Anole image window on the packed table
         else EPW_LAUNCH(512, 4);
     }
     else EPW_LAUNCH(1024, 4);

@@ -361,12 +361,12 @@ def main():
                 rl["windowed_kernel"] = {"hbm_bytes_needed_per_launch": wb, "achieved": wb / (ep_ms * 1e-3) / 1e9,
                                          "frac": wb / (ep_ms * 1e-3) / 1e9 / 8000.0,
                                          "definition": "(L+fresh)*W*4 + T*k*2 + R*W*4, W=8192 (DESIGN.md 4)"}
-            tfile = os.path.join(ROOT, "profiles", "r01_v5_epw_traffic.json")
+            tfile = os.path.join(ROOT, "profiles", "r01_v6_epw_traffic.json")
             if wl.windowed and os.path.exists(tfile):
                 t = json.load(open(tfile)).get("per_launch", {}).get(str(wl.Bg))
                 if t:      # PMC passes are separate rocprofv3 runs of the same kernel/config (tools/ep_only.py), see profiles/
                     rl["traffic"] = t["hbm_bytes"]
-                    rl["traffic_source"] = "profiles/r01_v5_epw_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, FETCH doubled per the gfx950 note)"
+                    rl["traffic_source"] = "profiles/r01_v6_epw_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, FETCH doubled per the gfx950 note)"
             out["roofline"] = rl
             o7_ms = mean_ms("cfg_mask_topk")
             o7_b = wl.o7_algorithmic_bytes(1, group=0)

@@ -1343,13 +1343,16 @@ __global__ __launch_bounds__(NT, WPE) void epw_kernel(const EpwArgs args) {
                     __syncthreads();   // neighbour zeroing / mask visible (block_sum_fast carries the barrier otherwise)
                 EPW_STAMPG(33);
                 const FastDiv dq(qs);
+                if (nsib > 0) {      // one uniform branch around all chunks (not one inside each): the residual loop below stays one block
+#pragma unroll
+                    for (int it = 0; it < E4; ++it) q[it] = dq(q[it]);      // chunks beyond the window hold zeros: 0 / qs = 0
+                }
 #pragma unroll
                 for (int it = 0; it < E4; ++it) {
                     const int i4 = tid + it * NT;
                     gn[it] = make_float4(0.f, 0.f, 0.f, 0.f);
                     if (FULLW || i4 * 4 < W) {
                         float4 qv = q[it];
-                        if (nsib > 0) qv = dq(qv);
                         if (lg_nb) {
                             const int e = i4 * 4;
                             const uint32_t bits = nbmask[e >> 5] >> (e & 31);

@@ -1347,20 +1347,26 @@ __global__ __launch_bounds__(NT, WPE) void epw_kernel(const EpwArgs args) {
 #pragma unroll
                     for (int it = 0; it < E4; ++it) q[it] = dq(q[it]);      // chunks beyond the window hold zeros: 0 / qs = 0
                 }
+                if (lg_nb) {         // likewise: the neighbour mask of the LlamaGen / Anole static mode, all chunks under one branch
+#pragma unroll
+                    for (int it = 0; it < E4; ++it) {
+                        const int i4 = tid + it * NT;
+                        if (FULLW || i4 * 4 < W) {
+                            const int e = i4 * 4;
+                            const uint32_t bits = nbmask[e >> 5] >> (e & 31);
+                            if (bits & 1u) q[it].x = 0.f;
+                            if (bits & 2u) q[it].y = 0.f;
+                            if (bits & 4u) q[it].z = 0.f;
+                            if (bits & 8u) q[it].w = 0.f;
+                        }
+                    }
+                }
 #pragma unroll
                 for (int it = 0; it < E4; ++it) {
                     const int i4 = tid + it * NT;
                     gn[it] = make_float4(0.f, 0.f, 0.f, 0.f);
                     if (FULLW || i4 * 4 < W) {
-                        float4 qv = q[it];
-                        if (lg_nb) {
-                            const int e = i4 * 4;
-                            const uint32_t bits = nbmask[e >> 5] >> (e & 31);
-                            if (bits & 1u) qv.x = 0.f;
-                            if (bits & 2u) qv.y = 0.f;
-                            if (bits & 4u) qv.z = 0.f;
-                            if (bits & 8u) qv.w = 0.f;
-                        }
+                        const float4 qv = q[it];
                         float4 gv = reinterpret_cast<float4 *>(g)[i4];
                         float d;
                         d = gv.x - qv.x; gv.x = d < 0.0f ? 0.0f : d;

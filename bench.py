@@ -227,13 +227,94 @@ def ep_batch_sweep(batches, device, base_cfg, iters=20):
     return out
 
 
+# ---------------------------------------------------------------------------- N > 1: self-launch
+
+def spawn_ranks(args) -> int:
+    """`python bench.py --gpus N` with no launcher around it: start N rank processes (one per GPU, LOCAL_RANK = device
+    index, RCCL rendezvous on 127.0.0.1) BEFORE anything in this process touches the GPU, relay rank 0's JSON line and
+    fail if any rank fails.  Same layout as `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N` and as
+    the reference's one-process-per-GPU driver (run.sh:76-91).  The parent never initialises HIP and never exec()s."""
+    import socket
+    import subprocess
+    n = args.gpus
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    import threading
+    buf = []
+    rd = threading.Thread(target=lambda: buf.append(procs[0].stdout.read()), daemon=True)
+    rd.start()
+    deadline = time.time() + float(os.environ.get("LANTERN_BENCH_SPAWN_TIMEOUT", "1500"))
+    failed = False
+    while any(p.poll() is None for p in procs):
+        if any(p.poll() not in (None, 0) for p in procs) or time.time() > deadline:
+            failed = True                  # one rank died (or the job hung): the others would wait in the rendezvous for ever
+            break
+        time.sleep(0.1)
+    for p in procs:
+        if p.poll() is None:
+            p.kill()                       # the exact PIDs this function started
+    codes = [p.wait() for p in procs]
+    rd.join(timeout=10)
+    out0 = buf[0] if buf else ""
+    if failed or any(codes):
+        print(f"bench.py: rank exit codes {codes}", file=sys.stderr)
+        return 1
+    sys.stdout.write(out0)
+    sys.stdout.flush()
+    line = [l for l in out0.splitlines() if l.startswith("{")]
+    if not line or json.loads(line[-1]).get("n_gpus") != n:
+        print(f"bench.py: rank 0 did not report n_gpus={n}", file=sys.stderr)
+        return 1
+    return 0
+
+
+def stub_rank(args, world, rank):
+    """LANTERN_BENCH_STUB=1 (tests/test_multiproc_cpu.py, no GPU in the build container): the rank body with the kernels
+    replaced by a sleep, so that the self-launch, the gloo rendezvous, the barrier-bracketed timing, the MAX / SUM
+    reductions and rank 0's JSON line run on CPU.  The line says `"data": "stub"`: it is not a measurement."""
+    import torch.distributed as dist
+    from lantern_amd.sharding import reduce_timing
+    if world > 1:
+        dist.init_process_group("gloo")
+    K, per_step = args.steps, args.seqs_per_gpu * 2
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(K):
+        time.sleep(0.001)
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    dt_all, tokens_all = reduce_timing(dist if world > 1 else None, dt, float(K * per_step))
+    if rank == 0:
+        print(json.dumps({"metric": "stub", "value": tokens_all / dt_all, "unit": "accepted_tokens/s", "n_gpus": world, "steps": K,
+                          "warmup": args.warmup, "ms_per_step": 1e3 * dt_all / K, "data": "stub", "tokens": tokens_all}))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 # ------------------------------------------------------------------------------------ main
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(spawn_ranks(args))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != max(1, args.gpus):
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: every rank of the job must be started (or let "
+                         "`python bench.py --gpus N` start them itself)")
+    if os.environ.get("LANTERN_BENCH_STUB") == "1":
+        return stub_rank(args, world, rank)
     # Test knob for a 1-GPU box: LANTERN_BENCH_ONE_DEVICE=1 runs every rank on cuda:0 over gloo (RCCL refuses two ranks on one
     # device), so that the N > 1 control flow -- rank seeds, the MIN / MAX / SUM reductions, rank-0 output -- can be exercised.
     one_device = os.environ.get("LANTERN_BENCH_ONE_DEVICE") == "1"
@@ -248,7 +329,6 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     red_device = torch.device("cpu") if one_device else None               # gloo reduces host tensors
-    assert world == max(1, args.gpus) or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
 
@@ -282,7 +362,7 @@ def main():
     cfg = HN.WorkloadConfig(n_seq=n_seq, pool_steps=args.pool_steps, tree=args.tree, lantern_k=args.lantern_k,
                             lantern_delta=args.lantern_delta, sigma=args.sigma, with_kv=not args.no_kv, kv_smax=args.kv_smax,
                             path=args.path, use_graph=args.graph, n_groups=args.groups, side_stream=args.side_stream,
-                            max_steps=args.steps + args.warmup + min(args.steps, 100) + 8,
+                            max_steps=max(args.pool_steps, args.steps + args.warmup + min(args.steps, 100)) + 8,
                             **({} if args.kv_pad_rows is None else {"kv_pad_rows": args.kv_pad_rows}))
     wl = HN.LuminaVerifyWorkload(cfg, device, rank=rank)
 
@@ -292,6 +372,7 @@ def main():
         torch.cuda.synchronize(device)
 
     K, W = args.steps, args.warmup
+    wl.prime()          # setup: every pool slot launched once, state reset (a short --warmup must not leave first-touch costs in the timed loop)
     for _ in range(W):
         wl.step()
     names = ("cfg_mask_topk", "evaluate_posterior", "kv_gather") if cfg.with_kv else ("cfg_mask_topk", "evaluate_posterior")

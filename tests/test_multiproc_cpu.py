@@ -100,3 +100,22 @@ def test_prompt_slices_and_statistics_files(tmp_path):
     assert list(one) == ["prompt_3", "prompt_4", "prompt_5"] and set(one["prompt_3"]) == {"prompt", "step_compression", "latency"}
     m = sh.merge_global_statistics(paths)
     assert m["prompts"] == 10 and abs(m["mean_step_compression"] - 6.5) < 1e-12 and abs(m["mean_latency"] - 2.25) < 1e-12
+
+
+@pytest.mark.timeout(300)
+def test_bench_gpus_2_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher: two rank processes, gloo rendezvous on 127.0.0.1, rank 0's line says
+    n_gpus 2 and carries the SUM of both ranks' tokens (LANTERN_BENCH_STUB=1: the kernels are replaced by a sleep -- there is
+    no GPU here; the launch / reduction control flow is what is under test).  A WORLD_SIZE that disagrees with --gpus fails."""
+    import subprocess
+    env = dict(os.environ, LANTERN_BENCH_STUB="1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1", "--seqs-per-gpu", "8"],
+                       env=env, capture_output=True, text=True, timeout=240)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["tokens"] == 2 * 4 * 8 * 2 and line["steps"] == 4
+    bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2"], env=dict(env, WORLD_SIZE="1"),
+                         capture_output=True, text=True, timeout=120)
+    assert bad.returncode != 0 and "WORLD_SIZE=1" in bad.stderr

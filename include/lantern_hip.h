@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define LANTERN_VERSION 100
+#define LANTERN_VERSION 200
 
 enum {
     LANTERN_OK = 0,
@@ -256,6 +256,50 @@ typedef struct lantern_ep_window {
 #define LANTERN_ST_TREE_LIMIT 7
 int lantern_evaluate_posterior_window(const lantern_ep_params *prm, const lantern_ep_buffers *buf,
                                       const lantern_ep_window *win, void *stream);
+
+/* ------------------------------------------------------------------------------------
+ * O8 node-parallel (v3): the same relaxed rejection sampling, one workgroup per INTERNAL TREE NODE instead of one
+ * serial chain per sequence.  While sibling tokens are distinct (sampling without replacement / top-k -- every tree the
+ * drafters build) the candidates the reference tries at a level (ea_model_lumina_mgpt.py:628-713) are the children of the
+ * accepted node, in the order of their first path, and everything a child's test reads -- the parent's row, the drafter
+ * row, the earlier siblings, its cart_candidates_prob cell, the position of its uniform in the random.random() stream
+ * (one draw per tried candidate from the root down) -- depends on the node alone.  So every node's accept / reject chain
+ * (k-neighbour cumulative mass, residual distribution, bonus-token draw when all children are rejected) runs concurrently
+ * in its own workgroup, and a short second kernel walks root -> accepted child -> ... over the per-node results to produce
+ * exactly the outputs of lantern_evaluate_posterior_window (best, accept_len, counters, cursor, bonus token, optional
+ * sample_p).  Nodes the walk never reaches were computed in vain: B*n_internal workgroups fill the GPU where B chains
+ * occupy B compute units, and the launch lasts as long as the widest node's chain, not as long as the unluckiest
+ * sequence's whole walk.  A node whose children carry duplicate (or -1) tokens cannot be decomposed this way: a sequence
+ * whose walk meets one reports LANTERN_ST_NEEDS_CHAIN and is re-run by the caller on lantern_evaluate_posterior_window.
+ *
+ * lantern_tree_node_tables (HOST, once per tree shape): retrieve [P,D] i64 (-1 pad) and, for static trees, p_idx [P,D],
+ * b_off [P*D+1], b_idx, op_off [D-1] (NULL for dynamic trees) -> packed int32 tables (lantern_tree_node_tables_size ints) that
+ * the caller uploads; the header words out[0..3] = {N, n_internal, n_children, max_children}, out[6] = 1 when every child's
+ * earlier-sibling list (b_idx) is exactly the children tried before it -- true for every tree generate_tree_buffers builds,
+ * and required by the kernel (LANTERN_E_UNSUPPORTED otherwise: use lantern_evaluate_posterior_window).
+ * Restrictions of this build: window rows are probabilities (LANTERN_ROWS_PROBS), k + 1 <= 1024, win_len <= 16384, a
+ * node has <= 32 children (else LANTERN_ST_TREE_LIMIT), N <= 128, one tree for all B sequences.
+ */
+#define LANTERN_ST_NEEDS_CHAIN 8
+typedef struct lantern_ep_nodes {
+    const int32_t *tables;   /* [dev] packed tables from lantern_tree_node_tables */
+    const int32_t *tables_host; /* [host] the same tables (the launch copies the per-node header into the kernel arguments) */
+    int32_t n_nodes, n_internal, n_children, max_children; /* = tables[0..3] (the host sizes the launch with them) */
+    int32_t prefix_siblings; /* = tables[6] */
+    int32_t leaf_workgroups; /* 1: leaves get workgroups that pre-draw their bonus token (small batches: nothing after the node kernel but
+                                a table walk); 0: the walk kernel draws it for the one leaf a walk ends on; -1: chosen by batch size */
+    void *workspace;         /* [dev] lantern_evaluate_posterior_nodes_workspace() bytes, 16-byte aligned */
+    size_t workspace_bytes;
+} lantern_ep_nodes;
+
+int lantern_tree_node_tables_size(int N, int P, int D);
+int lantern_tree_node_tables(const int64_t *retrieve, const int32_t *p_idx, const int32_t *b_off, const int32_t *b_idx,
+                             const int32_t *op_off, int N, int P, int D, int32_t *out, int out_ints);
+/* want_dist != 0 when win->sample_win or buf->sample_p is requested (every node then parks its final distribution). */
+size_t lantern_evaluate_posterior_nodes_workspace(const lantern_ep_params *prm, const lantern_ep_window *win, int n_internal,
+                                                  int want_dist);
+int lantern_evaluate_posterior_nodes(const lantern_ep_params *prm, const lantern_ep_buffers *buf, const lantern_ep_window *win,
+                                     const lantern_ep_nodes *nodes, void *stream);
 
 /* window -> dense [B,V] (API compatibility with callers that want the reference's sample_p[V]). */
 int lantern_window_to_dense(const float *win, const int32_t *out_tok, const float *out_mass, int B, int V,

@@ -44,6 +44,12 @@ class EpWindow(C.Structure):
                 ("u_bonus", C.c_void_p), ("token", C.c_void_p), ("rows_kind", C.c_int32), ("reserved", C.c_int32)]
 
 
+class EpNodes(C.Structure):
+    _fields_ = [("tables", C.c_void_p), ("tables_host", C.c_void_p), ("n_nodes", C.c_int32), ("n_internal", C.c_int32), ("n_children", C.c_int32),
+                ("max_children", C.c_int32), ("prefix_siblings", C.c_int32), ("leaf_workgroups", C.c_int32),
+                ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t)]
+
+
 _lib = None
 
 
@@ -68,6 +74,7 @@ def lib():
         _lib.lantern_last_error.restype = C.c_char_p
         _lib.lantern_evaluate_posterior_workspace.restype = C.c_size_t
         _lib.lantern_tree_attention_workspace.restype = C.c_size_t
+        _lib.lantern_evaluate_posterior_nodes_workspace.restype = C.c_size_t
     return _lib
 
 
@@ -86,4 +93,6 @@ EXPORTS = [
     "lantern_build_vq_table", "lantern_cfg_mask_topk_window", "lantern_evaluate_posterior_window",
     "lantern_window_to_dense", "lantern_pack_vq_table", "lantern_update_inference_inputs", "lantern_profile_next_launch", "lantern_drafter_attention_mask", "lantern_linear_rows",
     "lantern_tree_attention_workspace", "lantern_tree_attention",
+    "lantern_tree_node_tables_size", "lantern_tree_node_tables", "lantern_evaluate_posterior_nodes_workspace",
+    "lantern_evaluate_posterior_nodes",
 ]

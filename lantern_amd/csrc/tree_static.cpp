@@ -270,3 +270,128 @@ extern "C" int lantern_tree_drafter_build(const int32_t *choices, const int32_t 
     repeat_off[L] = rp;
     return LANTERN_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// Node view of a verify tree, for the node-parallel evaluate_posterior (node_kernels.hip).
+//
+// The reference walks the tree level by level over PATHS (ea_model_lumina_mgpt.py:628-713): at level i it keeps the paths whose
+// first i tokens equal the accepted prefix, and tries their distinct tokens at depth i in path order.  While sibling tokens
+// are distinct (sampling without replacement / top-k: the only trees the drafters build) "paths sharing the accepted prefix" =
+// "paths through the accepted node", so the candidates of a level are the CHILDREN of the accepted node, tried in the order of
+// their first path.  Everything a child's test consumes -- the parent's row, the drafter row, the earlier siblings, the
+// cart_candidates_prob cell and even the position of its uniform in the random.random() stream (one draw per tried
+// candidate: root..node) -- is then a function of the node alone, which is what lets every node's chain run in its own
+// workgroup.  Layout of `out` (int32):
+//   hdr[8]        = {N, n_internal, n_children, max_children, D, P, prefix_siblings, 0}
+//   internal[n_internal][16] = {node, c0, nch, depth, uoff, qrow, first_path, 0, node of child 0..3, cell of child 0..3}, longest child lists first
+//   child[n_children][4]    = {node, cell (= path*D + depth of its first cell), b0 (into the caller's b_idx), nsib}, per parent in try order
+//   node[N][4]              = {first_path, depth, internal rank or -1, parent}
+//   order[N]                = node ids in launch order: the internal nodes (longest child lists first), then the leaves
+extern "C" int lantern_tree_node_tables_size(int N, int P, int D) {
+    (void)P;
+    (void)D;
+    return 8 + 16 * N + 4 * N + 4 * N + N;
+}
+
+extern "C" int lantern_tree_node_tables(const int64_t *retrieve, const int32_t *p_idx, const int32_t *b_off, const int32_t *b_idx,
+                                        const int32_t *op_off, int N, int P, int D, int32_t *out, int out_ints) {
+    if (!retrieve || !out || N <= 0 || P <= 0 || D <= 0 || out_ints < lantern_tree_node_tables_size(N, P, D)) {
+        set_error("tree_node_tables: bad arguments");
+        return LANTERN_E_INVALID;
+    }
+    const bool is_static = p_idx && b_off && op_off;
+    std::vector<int> parent(N, -1), depth(N, -1), cell(N, -1);
+    std::vector<std::vector<int>> kids(N);
+    for (int j = 0; j < P; ++j) {
+        if (retrieve[(size_t)j * D] != 0) {
+            set_error("tree_node_tables: path %d does not start at the root", j);
+            return LANTERN_E_INVALID;
+        }
+        for (int i = 1; i < D; ++i) {
+            const int64_t c = retrieve[(size_t)j * D + i];
+            if (c < 0) break;                 // -1 pad: the path ended
+            const int64_t p = retrieve[(size_t)j * D + i - 1];
+            if (c == 0 || c >= N) {
+                set_error("tree_node_tables: retrieve[%d,%d]=%lld outside (0,%d)", j, i, (long long)c, N);
+                return LANTERN_E_INVALID;
+            }
+            if (depth[c] < 0) {
+                depth[c] = i;
+                parent[c] = (int)p;
+                cell[c] = j * D + i;
+                kids[p].push_back((int)c);
+            } else if (depth[c] != i || parent[c] != (int)p) {
+                set_error("tree_node_tables: node %lld has two parents / depths: not a tree", (long long)c);
+                return LANTERN_E_INVALID;
+            }
+        }
+    }
+    depth[0] = 0;
+    cell[0] = 0;
+    std::vector<int> uoff(N, 0), internal;
+    // uniforms consumed before a node's own level: one per candidate tried on the way (children in try order, all distinct)
+    std::vector<int> order;
+    order.push_back(0);
+    for (size_t h = 0; h < order.size(); ++h) {
+        const int n = order[h];
+        for (size_t t = 0; t < kids[n].size(); ++t) {
+            uoff[kids[n][t]] = uoff[n] + (int)t + 1;
+            order.push_back(kids[n][t]);
+        }
+        if (!kids[n].empty()) internal.push_back(n);
+    }
+    std::stable_sort(internal.begin(), internal.end(), [&](int a, int b) { return kids[a].size() > kids[b].size(); });
+    std::vector<int> rank(N, -1);
+    for (size_t r = 0; r < internal.size(); ++r) rank[internal[r]] = (int)r;
+    const int n_int = (int)internal.size();
+    int32_t *hdr = out, *it = out + 8, *ch = it + 16 * n_int;
+    bool prefix_sibs = true;
+    int n_child = 0, max_ch = 0;
+    for (int r = 0; r < n_int; ++r) {
+        const int n = internal[r];
+        const int nch = (int)kids[n].size();
+        int qrow = 0;
+        if (is_static) {
+            qrow = op_off[depth[n]] + p_idx[cell[kids[n][0]]];
+            for (int c : kids[n])
+                if (op_off[depth[n]] + p_idx[cell[c]] != qrow) {
+                    set_error("tree_node_tables: children of node %d disagree on their drafter row", n);
+                    return LANTERN_E_INVALID;
+                }
+        }
+        int32_t *e = it + 16 * r;
+        e[0] = n; e[1] = n_child; e[2] = nch; e[3] = depth[n]; e[4] = uoff[n]; e[5] = qrow; e[6] = cell[n] / D; e[7] = 0;
+        for (int t = 0; t < 4; ++t) {
+            e[8 + t] = t < nch ? kids[n][t] : 0;
+            e[12 + t] = t < nch ? cell[kids[n][t]] : 0;
+        }
+        int rank_in_parent = 0;
+        for (int c : kids[n]) {
+            int32_t *q = ch + 4 * n_child++;
+            q[0] = c; q[1] = cell[c];
+            q[2] = is_static ? b_off[cell[c]] : 0;
+            q[3] = is_static ? b_off[cell[c] + 1] - b_off[cell[c]] : 0;
+            // the node kernel takes "earlier siblings" = "the children tried before this one"
+            if (is_static && q[3] != rank_in_parent) prefix_sibs = false;
+            if (is_static && b_idx)
+                for (int u = 0; u < q[3] && u < rank_in_parent; ++u)
+                    if (b_idx[q[2] + u] != kids[n][u]) prefix_sibs = false;
+            ++rank_in_parent;
+        }
+        max_ch = std::max(max_ch, nch);
+    }
+    int32_t *nd = ch + 4 * n_child;
+    for (int n = 0; n < N; ++n) {
+        nd[4 * n] = cell[n] >= 0 ? cell[n] / D : -1;
+        nd[4 * n + 1] = depth[n];
+        nd[4 * n + 2] = rank[n];
+        nd[4 * n + 3] = parent[n];
+    }
+    int32_t *ord = nd + 4 * N;
+    int no = 0;
+    for (int r = 0; r < n_int; ++r) ord[no++] = internal[r];
+    for (int n = 0; n < N; ++n)
+        if (rank[n] < 0) ord[no++] = n;
+    hdr[0] = N; hdr[1] = n_int; hdr[2] = n_child; hdr[3] = max_ch; hdr[4] = D; hdr[5] = P; hdr[6] = prefix_sibs ? 1 : 0; hdr[7] = 0;
+    return LANTERN_OK;
+}

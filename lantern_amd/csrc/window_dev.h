@@ -1,0 +1,377 @@
+// window_dev.h -- device helpers shared by the windowed kernel sets (window_kernels.hip: O7 windowed + the per-sequence
+// chain kernel of O8; node_kernels.hip: the node-parallel O8).  Moved verbatim out of window_kernels.hip.
+#pragma once
+#include "common.h"
+
+namespace lantern {
+
+__device__ __forceinline__ int64_t py_mod64(int64_t a, int64_t b) {
+    int64_t r = a % b;
+    return (r != 0 && ((r < 0) != (b < 0))) ? r + b : r;
+}
+
+// k-th largest over a register tile of E4 float4 held by NT threads: bitwise bisection on order-preserving
+// keys, one counting pass + one barrier per bit.  HIGH16: every value is bf16-representable (low 16 bits of
+// the float are zero), so the low half of the key is a function of the sign and 16 passes decide the key.
+template <int NT, int E4, bool HIGH16>
+__device__ __forceinline__ float kth_largest_tile(const float4 (&r)[E4], int k, int *redi, int &ph) {
+    uint32_t prefix = 0;
+    for (int bit = 31; bit >= (HIGH16 ? 16 : 0); --bit) {
+        const uint32_t trial = prefix | (1u << bit);
+        int c = 0;
+#pragma unroll
+        for (int it = 0; it < E4; ++it) {
+            c += float_key(r[it].x) >= trial;
+            c += float_key(r[it].y) >= trial;
+            c += float_key(r[it].z) >= trial;
+            c += float_key(r[it].w) >= trial;
+        }
+        const int tot = block_sum<int, NT / 64>(c, redi, ph);
+        if (tot >= k) prefix = trial;
+    }
+    if (prefix == 0) return -__builtin_inff();
+    if (HIGH16 && !(prefix & 0x80000000u)) prefix |= 0xffffu;   // negative float: key = ~bits, low half all ones
+    return key_float(prefix);
+}
+
+// k-th largest by radix-256 histograms in LDS: 2 passes for bf16-representable values (HIGH16), 4 for f32.
+// Per pass: one no-return LDS atomic per live value, then every wave resolves the digit from the 256 counters with
+// 4 bins per lane + one DPP scan (no serial loop, no extra barrier for a broadcast).  `hist` = 256 ints.
+template <int NT, int E4, bool HIGH16>
+__device__ __forceinline__ float kth_largest_hist(const float4 (&r)[E4], int k, int *hist) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    uint32_t prefix = 0, mask = 0;
+    int krem = k;
+#pragma unroll 1
+    for (int pass = 0; pass < (HIGH16 ? 2 : 4); ++pass) {
+        const int shift = 24 - 8 * pass;
+        for (int t = tid; t < 256; t += NT) hist[t] = 0;
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < E4; ++it) {
+            const uint32_t kk[4] = {float_key(r[it].x), float_key(r[it].y), float_key(r[it].z), float_key(r[it].w)};
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                if ((kk[c] & mask) == prefix) atomicAdd(&hist[(kk[c] >> shift) & 255u], 1);
+        }
+        __syncthreads();
+        const int c0 = hist[4 * lane], c1 = hist[4 * lane + 1], c2 = hist[4 * lane + 2], c3 = hist[4 * lane + 3];
+        const int s4 = c0 + c1 + c2 + c3;
+        const int incl = wave_scan_incl_dpp(s4);
+        const int total = readlane63(incl);
+        if (total < krem) return -__builtin_inff();     // fewer than k values: the k-th largest is below everything
+        int above = total - incl;                        // values in bins of higher lanes
+        int digit = -1, kn = 0;
+        // bins of this lane, high to low
+        if (above < krem && above + c3 >= krem) { digit = 4 * lane + 3; kn = krem - above; }
+        above += c3;
+        if (digit < 0 && above < krem && above + c2 >= krem) { digit = 4 * lane + 2; kn = krem - above; }
+        above += c2;
+        if (digit < 0 && above < krem && above + c1 >= krem) { digit = 4 * lane + 1; kn = krem - above; }
+        above += c1;
+        if (digit < 0 && above < krem && above + c0 >= krem) { digit = 4 * lane; kn = krem - above; }
+        const unsigned long long who = __ballot(digit >= 0);
+        const int src = __ffsll((long long)who) - 1;
+        digit = __shfl(digit, src, 64);
+        krem = __shfl(kn, src, 64);
+        prefix |= (uint32_t)digit << shift;
+        mask |= 255u << shift;
+        __syncthreads();   // everyone has read hist before the next pass clears it
+    }
+    if (HIGH16 && !(prefix & 0x80000000u)) prefix |= 0xffffu;   // negative float: key = ~bits, low half all ones
+    return key_float(prefix);
+}
+
+// exp(x) for x <= 0 (softmax arguments): n = rint(x*log2e), r = x - n*ln2 (two-term), 2^(r*log2e) on the
+// hardware exp unit, ldexp.  7 VALU ops, < 1 ulp like the libm/ocml routine it replaces (which costs ~20).
+__device__ __forceinline__ float exp_nonpos(float x) {
+    x = fmaxf(x, -104.0f);                              // exp(-104) is below half the smallest subnormal: rounds to 0 (also -inf)
+    const float n = rintf(x * 1.44269504088896341f);
+    float r = fmaf(-n, 0.693145751953125f, x);          // ln2 high part (exact product for |n| < 2^11)
+    r = fmaf(-n, 1.42860682030941723e-6f, r);           // ln2 low part
+    return ldexpf(__builtin_amdgcn_exp2f(r * 1.44269504088896341f), (int)n);
+}
+
+// x / d for many x and one d: reciprocal refined once (Newton), then q = fma(fma(-q0, d, x), r, q0) -- the quotient
+// correction step of the IEEE division expansion without its per-element scaling / fix-up instructions.  Correctly
+// rounded for the normal-range operands met here (d in [2^-20, 2^14], x in [0, 1]); 3 VALU ops instead of ~11.
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+struct FastDiv {
+    float d, r;
+    __device__ __forceinline__ explicit FastDiv(float den) : d(den) {
+        float r0 = __builtin_amdgcn_rcpf(den);
+        r = fmaf(fmaf(-den, r0, 1.0f), r0, r0);
+    }
+    __device__ __forceinline__ float operator()(float x) const {
+        const float q0 = x * r;
+        return fmaf(fmaf(-q0, d, x), r, q0);
+    }
+    // two quotients per instruction (v_pk_mul_f32 / v_pk_fma_f32): same three operations per element
+    __device__ __forceinline__ f32x2_t operator()(f32x2_t x) const {
+        const f32x2_t q0 = x * r;
+        return __builtin_elementwise_fma(__builtin_elementwise_fma(-q0, (f32x2_t)(d), x), (f32x2_t)(r), q0);
+    }
+    __device__ __forceinline__ float4 operator()(float4 v) const {
+        const f32x2_t a = (*this)((f32x2_t){v.x, v.y}), b = (*this)((f32x2_t){v.z, v.w});
+        return make_float4(a.x, a.y, b.x, b.y);
+    }
+};
+
+// softmax of a register tile over the workgroup: max, exp, f64 sum, one division per element -- the arithmetic
+// of the reference's torch.softmax(row) restated (oracle: lo_softmax_row); shared by O7 (rows emitted as
+// probabilities) and O8 (rows arriving as logits) so that both produce the same bits.
+template <int NT, int NV4>
+__device__ __forceinline__ void softmax_tile(float4 (&r)[NV4], float *redf, double *redd, int &ph) {
+    constexpr int NW = NT / 64;
+    float m = -__builtin_inff();
+#pragma unroll
+    for (int it = 0; it < NV4; ++it) m = fmaxf(fmaxf(m, fmaxf(r[it].x, r[it].y)), fmaxf(r[it].z, r[it].w));
+    m = block_max_fast<NW>(m, redf, ph);
+    double s = 0.0;
+#pragma unroll
+    for (int it = 0; it < NV4; ++it) {
+        r[it].x = exp_nonpos(r[it].x - m); r[it].y = exp_nonpos(r[it].y - m);
+        r[it].z = exp_nonpos(r[it].z - m); r[it].w = exp_nonpos(r[it].w - m);
+        s += (double)r[it].x + (double)r[it].y + (double)r[it].z + (double)r[it].w;
+    }
+    const float sf = (float)block_sum_fast<double, NW>(s, redd, ph);
+    const FastDiv dv(sf);
+#pragma unroll
+    for (int it = 0; it < NV4; ++it) r[it] = dv(r[it]);
+}
+
+// TopPLogitsWarper on a register tile (HF order: after the temperature, before top-k; drafters/utils.py:36-52 ->
+// transformers TopPLogitsWarper): sort ascending, softmax, cumsum, remove every entry whose cumulative probability is
+// <= 1 - top_p, never the last (largest) one.  No sort here: the removed set is a prefix of the ascending order, so a
+// WEIGHTED radix select over the 32-bit order keys finds its end -- per 8-bit digit, probability mass per bin
+// (LDS f64 atomics), bins walked in ascending order until the running mass (rounded to f32 like torch.cumsum's
+// output) exceeds 1 - top_p.  Equal values at the boundary go in index order (a stable ascending sort), counted with a
+// block scan; that path and the keep-the-last rule only run when they apply.
+template <int NT, int NV4>
+__device__ void top_p_tile(float4 (&r)[NV4], float top_p, double *mass, float *redf, double *redd, int *redi, int &ph) {
+    constexpr int NW = NT / 64;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float NEG_INF = -__builtin_inff();
+    float4 p[NV4];
+#pragma unroll
+    for (int it = 0; it < NV4; ++it) p[it] = r[it];
+    softmax_tile<NT, NV4>(p, redf, redd, ph);
+    const float thr = (float)(1.0 - (double)top_p);
+    uint32_t prefix = 0, kmask = 0;
+    double below = 0.0;
+    bool none_cross = false;
+#pragma unroll 1
+    for (int pass = 0; pass < 4 && !none_cross; ++pass) {
+        const int shift = 24 - 8 * pass;
+        for (int t = tid; t < 256; t += NT) mass[t] = 0.0;
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < NV4; ++it) {
+            const float rv[4] = {r[it].x, r[it].y, r[it].z, r[it].w}, pv[4] = {p[it].x, p[it].y, p[it].z, p[it].w};
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const uint32_t kk = float_key(rv[c]);
+                if (rv[c] != NEG_INF && (kk & kmask) == prefix) atomicAdd(&mass[(kk >> shift) & 255u], (double)pv[c]);
+            }
+        }
+        __syncthreads();
+        const double c0 = mass[4 * lane], c1 = mass[4 * lane + 1], c2 = mass[4 * lane + 2], c3 = mass[4 * lane + 3];
+        const double s4 = (c0 + c1) + (c2 + c3);
+        const double before = below + wave_scan_incl_dpp(dpp_mov<0x138>(s4));      // mass of all lower bins (exclusive scan)
+        int digit = -1;
+        double upto = before;                                                       // mass below the chosen bin
+        if ((float)(before + c0) > thr) digit = 4 * lane;
+        else if ((float)(before + c0 + c1) > thr) { digit = 4 * lane + 1; upto = before + c0; }
+        else if ((float)(before + c0 + c1 + c2) > thr) { digit = 4 * lane + 2; upto = before + c0 + c1; }
+        else if ((float)(before + c0 + c1 + c2 + c3) > thr) { digit = 4 * lane + 3; upto = before + c0 + c1 + c2; }
+        const unsigned long long who = __ballot(digit >= 0);
+        if (who == 0ull) {
+            none_cross = true;          // the whole row's mass stays <= 1 - top_p: everything but the last entry goes
+        } else {
+            const int src = __ffsll((long long)who) - 1;
+            digit = __builtin_amdgcn_readlane(digit, src);
+            const long long ub = __double_as_longlong(upto);
+            below = __longlong_as_double(((long long)__builtin_amdgcn_readlane((int)(ub >> 32), src) << 32) |
+                                         (unsigned int)__builtin_amdgcn_readlane((int)(ub & 0xffffffffll), src));
+            prefix |= (uint32_t)digit << shift;
+            kmask |= 255u << shift;
+        }
+        __syncthreads();
+    }
+    if (none_cross) {
+        // keep only the last entry of the ascending order: the largest key, highest index among equals
+        uint32_t kmax = 0;
+        int imax = -1;
+#pragma unroll
+        for (int it = 0; it < NV4; ++it) {
+            const float rv[4] = {r[it].x, r[it].y, r[it].z, r[it].w};
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const uint32_t kk = float_key(rv[c]);
+                const int idx = (tid + it * NT) * 4 + c;
+                if (kk > kmax || (kk == kmax && idx > imax)) { kmax = kk; imax = idx; }
+            }
+        }
+        // block arg-max of (key, index): two integer reductions
+        int *buf = redi + (ph & 1) * NW;
+        ph ^= 1;
+        const int kw = wave_max_i((int)(kmax >> 1));                     // order-preserving 31-bit compare first
+        if (lane == 0) buf[wave] = kw;
+        __syncthreads();
+        int kb = buf[0];
+        for (int w = 1; w < NW; ++w) kb = max(kb, buf[w]);
+        // (the dropped low bit: resolve among the candidates by the full key)
+        int *buf2 = redi + (ph & 1) * NW;
+        ph ^= 1;
+        const int full = ((int)(kmax >> 1) == kb) ? (int)(kmax & 1u) : -1;
+        const int fw = wave_max_i(full);
+        if (lane == 0) buf2[wave] = fw;
+        __syncthreads();
+        int fb = buf2[0];
+        for (int w = 1; w < NW; ++w) fb = max(fb, buf2[w]);
+        const uint32_t kbest = ((uint32_t)kb << 1) | (uint32_t)fb;
+        int *buf3 = redi + (ph & 1) * NW;
+        ph ^= 1;
+        const int iw = wave_max_i(kmax == kbest ? imax : -1);
+        if (lane == 0) buf3[wave] = iw;
+        __syncthreads();
+        int ib = buf3[0];
+        for (int w = 1; w < NW; ++w) ib = max(ib, buf3[w]);
+#pragma unroll
+        for (int it = 0; it < NV4; ++it) {
+            const int i0 = (tid + it * NT) * 4;
+            r[it].x = (i0 == ib) ? r[it].x : NEG_INF;
+            r[it].y = (i0 + 1 == ib) ? r[it].y : NEG_INF;
+            r[it].z = (i0 + 2 == ib) ? r[it].z : NEG_INF;
+            r[it].w = (i0 + 3 == ib) ? r[it].w : NEG_INF;
+        }
+        __syncthreads();
+        return;
+    }
+    // boundary value = key `prefix`; its holders all carry the same probability p*
+    int tie_cnt[NV4], my_ties = 0;
+    float pstar = 0.0f;
+#pragma unroll
+    for (int it = 0; it < NV4; ++it) {
+        const float rv[4] = {r[it].x, r[it].y, r[it].z, r[it].w}, pv[4] = {p[it].x, p[it].y, p[it].z, p[it].w};
+        tie_cnt[it] = 0;
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            if (rv[c] != NEG_INF && float_key(rv[c]) == prefix) {
+                ++tie_cnt[it];
+                pstar = pv[c];
+            }
+        my_ties += tie_cnt[it];
+    }
+    const int group = block_sum_fast<int, NW>(my_ties, redi, ph);
+    pstar = block_max_fast<NW>(pstar, redf, ph);
+    // how many of the equal entries still fit under the threshold, taken one by one like the cumsum does
+    int m = 0;
+    {
+        double acc = below;
+        for (int j = 1; j < group; ++j) {          // the group's last entry is the one that crossed: at most group-1 go
+            acc += (double)pstar;
+            if ((float)acc <= thr) m = j;
+            else break;
+        }
+    }
+    int base[NV4];
+    if (m > 0) {        // rank of every boundary-valued entry in index order (register tile order = ascending index per `it` slice)
+        __shared__ int s_tie_tot[NV4][NW];
+        int incl[NV4];
+#pragma unroll
+        for (int it = 0; it < NV4; ++it) {
+            incl[it] = wave_scan_incl_dpp(tie_cnt[it]);
+            if (lane == 63) s_tie_tot[it][wave] = incl[it];
+        }
+        __syncthreads();
+        int run = 0;
+#pragma unroll
+        for (int it = 0; it < NV4; ++it) {
+            int woff = 0, tot = 0;
+            for (int w = 0; w < NW; ++w) {
+                const int t = s_tie_tot[it][w];
+                woff += (w < wave) ? t : 0;
+                tot += t;
+            }
+            base[it] = run + woff + (incl[it] - tie_cnt[it]);
+            run += tot;
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int it = 0; it < NV4; ++it) {
+        float rv[4] = {r[it].x, r[it].y, r[it].z, r[it].w};
+        int rank = (m > 0) ? base[it] : 0;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            if (rv[c] == NEG_INF) continue;
+            const uint32_t kk = float_key(rv[c]);
+            if (kk < prefix) rv[c] = NEG_INF;
+            else if (kk == prefix) {
+                if (rank < m) rv[c] = NEG_INF;
+                ++rank;
+            }
+        }
+        r[it] = make_float4(rv[0], rv[1], rv[2], rv[3]);
+    }
+}
+
+constexpr int EW_MAX_P = 64, EW_MAX_D = 16, EW_MAX_PD = 1024, EW_MAX_SIB = 16, EW_MAX_N = 128, EW_MAX_B = 1024, EW_UNI = 64;
+constexpr int EW_PF_C = 6;        // candidates per level whose neighbour ids are prefetched into LDS
+constexpr int EW_PF_K = 1024;     // ... when k + 1 <= EW_PF_K; otherwise ids are read from HBM on demand
+
+// Fixed-size part of the workgroup's LDS; the five per-(path, depth) tables (cand, row, cart, pidx, boff) follow it, sized
+// by the launch's actual P*D (epw_pd_cap) instead of the 64 x 16 worst case: 20 KB -> ~2 KB for the reference's trees, which
+// is what lets two workgroups share a CU at saturating batch sizes.
+struct alignas(16) EwShared {
+    int bidx[EW_MAX_B];
+    int tcand[EW_MAX_N];
+    int opoff[EW_MAX_D];
+    double uni[EW_UNI];
+    double redd[2 * 16];
+    float redf[2 * 16];
+    int redi[2 * 16];
+    double samp_tot[16][4];
+    int dec[2][4];                          // decision words of wave 0: {code, m>0, csm1 bits, -}
+    double ubonus[2];                       // [0]: the bonus draw's uniform, fetched with the prologue's first round of loads
+    int hot[EW_MAX_N];                      // row_hot of this sequence's rows (when rows_per_seq <= EW_MAX_N)
+    unsigned short nbid[EW_PF_C][EW_PF_K];  // prefetched neighbour ids (raw table values)
+    unsigned short nbaddr[EW_PF_C][EW_PF_K];// the same neighbours as gather indices into g (window index or a sentinel slot)
+};
+
+// g[W + EW_G_ZERO] = 0 (neighbour outside the window), g[W + EW_G_HUGE] = 3e38 (position >= k: never under tau),
+// g[W + EW_G_OUT] = out_mass (neighbour == the one-hot token outside the window): gather targets of the scan
+constexpr int EW_G_ZERO = 0, EW_G_HUGE = 1, EW_G_OUT = 2, EW_G_EXT = 4;
+__host__ __device__ inline int epw_pd_cap(int P, int D) { return (P * D + 1 + 3) & ~3; }      // boff has P*D + 1 entries
+__host__ __device__ inline size_t epw_shared_offset(int W) {
+    size_t o = (size_t)(W + EW_G_EXT) * 4 + (size_t)((W + 31) / 32) * 4;
+    return (o + 15) & ~(size_t)15;
+}
+
+// softmax(processors(row)) -> g (LDS); one-hot rows put their mass in (out_tok,out_mass) when the hot token
+// lies outside the window.
+// value of lane `l` (wave-uniform index) without the LDS crossbar
+__device__ __forceinline__ int rdlane(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
+__device__ __forceinline__ float rdlane(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
+
+struct NoHook {
+    __device__ __forceinline__ void operator()() const {}
+};
+
+// `pre_barrier` runs after the row's global loads have landed and before the last barrier: LDS writes of data whose
+// loads were issued BEFORE this call ride on the row's latency (vmcnt retires in issue order) and on its barrier.
+//
+// The row arrives in registers (`r`, loaded by row_load -- possibly long before, so that its HBM latency hides behind
+// other work); one-hot rows ignore `r`.
+template <int NT, int E4, bool FULLW = false>
+__device__ __forceinline__ void row_load(const float *__restrict__ rowp, int W, float4 (&r)[E4]) {
+    const float NEG_INF = -__builtin_inff();
+#pragma unroll
+    for (int it = 0; it < E4; ++it) {
+        const int i4 = threadIdx.x + it * NT;
+        r[it] = (FULLW || i4 * 4 < W) ? reinterpret_cast<const float4 *>(rowp)[i4] : make_float4(NEG_INF, NEG_INF, NEG_INF, NEG_INF);
+    }
+}
+
+}  // namespace lantern

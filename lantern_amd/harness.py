@@ -24,7 +24,7 @@ import numpy as np
 import torch
 
 from . import _lib, ops
-from ._lib import EpBuffers, EpParams, EpWindow, check
+from ._lib import EpBuffers, EpNodes, EpParams, EpWindow, check
 
 MC_SIM_7B_63 = [[0], [1], [2], [3], [0, 0], [0, 1], [0, 2], [1, 0], [1, 1], [2, 0], [2, 1], [3, 0],
                 [0, 0, 0], [0, 0, 1], [0, 0, 2], [0, 1, 0], [0, 1, 1], [0, 2, 0], [0, 2, 1], [1, 0, 0],
@@ -77,6 +77,9 @@ class WorkloadConfig:
                                     # the bookkeeping kernel is only launched when an image can actually end (host-side bound)
     fuse_update: bool = True        # windowed path: O9 + O10 in one launch (lantern_update_inference_inputs)
     pack_table: bool = True         # windowed path: neighbour table packed to [K, ceil8(k+1)] (lantern_pack_vq_table)
+    ep_kernel: str = "nodes"        # windowed path: "nodes" = node-parallel evaluate_posterior (one workgroup per internal tree node + the
+                                    # walk; B * n_internal workgroups fill the GPU), "chain" = one serial chain per sequence (epw_kernel)
+    leaf_workgroups: int = -1       # node kernel: -1 = by batch size (include/lantern_hip.h lantern_ep_nodes)
     n_groups: int = 1               # >1: the sequences are split into groups, each launched on its own HIP stream, so that one
                                     # group's latency-bound evaluate_posterior overlaps the others' bandwidth-bound kernels
                                     # (independent sequences: no ordering between groups exists)
@@ -239,6 +242,17 @@ class LuminaVerifyWorkload:
         self._L = _lib.lib()
         self._ep_prm = self._make_ep_params()
         self.graphs = None
+        self.ep_nodes = None
+        if self.windowed and cfg.ep_kernel == "nodes":
+            self.node_tables = ops.tree_node_tables(tb["retrieve_indices"], N, tb["p_indices"], tb["b_off"], op_off, device=device, b_idx=tb["b_idx"])
+            nt = self.node_tables
+            win0 = EpWindow()
+            win0.win_len = self.W
+            nbytes = int(self._L.lantern_evaluate_posterior_nodes_workspace(C.byref(self._ep_prm), C.byref(win0), nt.n_internal, 0))
+            self.node_ws = torch.empty((cfg.n_groups, max(nbytes, 16)), dtype=torch.uint8, device=device)
+            self.ep_nodes = []
+            for g in range(cfg.n_groups):
+                self.ep_nodes.append(nt.struct(self.node_ws[g].data_ptr(), nbytes, cfg.leaf_workgroups))
         self.reset_state()
         # every (pool slot, parity, group) argument block is built HERE (setup, untimed): the step loop only patches the
         # step-dependent log-row addresses, computed arithmetically from these bases
@@ -524,7 +538,10 @@ class LuminaVerifyWorkload:
         if side is not None:
             main.wait_event(ev[1])                # O8 needs the candidates
         # O8 (windowed: the bonus token is drawn in the kernel epilogue)
-        if self.windowed:
+        if self.windowed and self.ep_nodes is not None:
+            check(L.lantern_evaluate_posterior_nodes(C.byref(self._ep_prm), C.byref(A["ep_buf"]), C.byref(A["ep_win"]),
+                                                     C.byref(self.ep_nodes[g]), st), "evaluate_posterior_nodes")
+        elif self.windowed:
             check(L.lantern_evaluate_posterior_window(C.byref(self._ep_prm), C.byref(A["ep_buf"]), C.byref(A["ep_win"]), st),
                   "evaluate_posterior_window")
         else:

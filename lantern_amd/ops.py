@@ -14,7 +14,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import EpBuffers, EpParams, EpWindow, check
+from ._lib import EpBuffers, EpNodes, EpParams, EpWindow, check
 
 MODE_DYNAMIC, MODE_STATIC_LUMINA, MODE_STATIC_LG = 0, 1, 2
 MODEL_PLAIN, MODEL_LUMINA, MODEL_ANOLE = 0, 1, 2
@@ -188,6 +188,44 @@ def cfg_mask_topk(cond, uncond, cfg: float, model: int = MODEL_PLAIN, pos_ids=No
         C.c_float(cfg), model, C.c_void_p(_ptr(pos)), C.c_int64(pos_base), w, h, img_lo, img_hi, newline_id, eos_id, top_k,
         C.c_void_p(_ptr(seq_len)), rows_per_seq, C.c_void_p(out.data_ptr()), _stream()), "cfg_mask_topk")
     return out
+
+
+@dataclass
+class NodeTables:
+    """Node view of a verify tree for the node-parallel evaluate_posterior (lantern_tree_node_tables)."""
+    tables: torch.Tensor      # [ints] i32 on the device
+    host: np.ndarray
+    n_nodes: int
+    n_internal: int
+    n_children: int
+    max_children: int
+    prefix_siblings: int = 1
+
+    def struct(self, workspace: int, workspace_bytes: int, leaf_workgroups: int = -1) -> EpNodes:
+        en = EpNodes()
+        en.tables = self.tables.data_ptr()
+        en.tables_host = self.host.ctypes.data
+        en.n_nodes, en.n_internal, en.n_children, en.max_children = self.n_nodes, self.n_internal, self.n_children, self.max_children
+        en.prefix_siblings, en.leaf_workgroups = self.prefix_siblings, leaf_workgroups
+        en.workspace, en.workspace_bytes = workspace, workspace_bytes
+        return en
+
+
+def tree_node_tables(retrieve, N: int, p_idx=None, b_off=None, op_off=None, device=None, b_idx=None) -> NodeTables:
+    """Host: retrieve [P,D] (-1 pad) (+ p_idx / b_off / op_off of a static tree) -> the packed per-node tables, uploaded."""
+    L = _lib.lib()
+    ret = np.ascontiguousarray(np.asarray(retrieve.cpu() if torch.is_tensor(retrieve) else retrieve), np.int64)
+    P, D = ret.shape
+    n = L.lantern_tree_node_tables_size(N, P, D)
+    out = np.zeros(n, np.int32)
+    h = lambda a: None if a is None else np.ascontiguousarray(np.asarray(a.cpu() if torch.is_tensor(a) else a), np.int32)
+    pi, bo, oo, bi = h(p_idx), h(b_off), h(op_off), h(b_idx)
+    if bi is not None and bi.size == 0:
+        bi = None
+    nul = lambda a: None if a is None else _np_ptr(a)
+    check(L.lantern_tree_node_tables(_np_ptr(ret), nul(pi), nul(bo), nul(bi), nul(oo), N, P, D, _np_ptr(out), n), "tree_node_tables")
+    dev = torch.from_numpy(out).to(device) if device is not None else None
+    return NodeTables(dev, out, int(out[0]), int(out[1]), int(out[2]), int(out[3]), int(out[6]))
 
 
 @dataclass
@@ -478,7 +516,8 @@ def cfg_mask_topk_window(cond, uncond, cfg: float, win_lo: int, win_len: int, mo
 
 def evaluate_posterior_window(cfg: EpConfig, V: int, win_logits, win_lo: int, row_index, cand, uniforms, row_hot=None, table=None,
                               aux: Optional[StaticAux] = None, orig_windowed: bool = False, n_paths=None, n_depth=None,
-                              cursor=None, u_bonus=None, want_dense: bool = False, want_window: bool = True, rows_probs: bool = False):
+                              cursor=None, u_bonus=None, want_dense: bool = False, want_window: bool = True, rows_probs: bool = False,
+                              nodes: Optional[NodeTables] = None, leaf_workgroups: int = -1):
     """O8 windowed.  win_logits [B,rows,W] f32 (probabilities when rows_probs: cfg must then carry top_k=0, temperature=1).  aux.orig_prob is the dense [B,R,V] pool (orig_windowed=False) or a
     windowed [B,R,W] pool.  Returns dict(best, accept_len, counters, sample_win, out_tok, out_mass, token, sample_p)."""
     win_logits = _dev(win_logits, torch.float32, "win_logits")
@@ -540,6 +579,13 @@ def evaluate_posterior_window(cfg: EpConfig, V: int, win_logits, win_lo: int, ro
         u_bonus = _dev(u_bonus, torch.float64, "u_bonus")
         out["token"] = torch.empty(B, dtype=torch.int64, device=dev)
         win.u_bonus, win.token = u_bonus.data_ptr(), out["token"].data_ptr()
+    if nodes is not None:      # node-parallel form: one workgroup per internal tree node, then the walk
+        nbytes = _lib.lib().lantern_evaluate_posterior_nodes_workspace(C.byref(prm), C.byref(win), nodes.n_internal, int(want_dense or want_window))
+        ws = torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=dev)
+        en = nodes.struct(ws.data_ptr(), int(nbytes), leaf_workgroups)
+        check(_lib.lib().lantern_evaluate_posterior_nodes(C.byref(prm), C.byref(buf), C.byref(win), C.byref(en), _stream()), "evaluate_posterior_nodes")
+        out["_workspace"] = ws
+        return out
     check(_lib.lib().lantern_evaluate_posterior_window(C.byref(prm), C.byref(buf), C.byref(win), _stream()), "evaluate_posterior_window")
     return out
 

@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(L, name), f"{name} declared in lantern_hip.h but not exported"
     assert sorted(_lib.EXPORTS) == declared
-    assert L.lantern_version() == 100
+    assert L.lantern_version() == 200
 
 
 def test_param_struct_layout_matches_header():
@@ -31,6 +31,7 @@ def test_param_struct_layout_matches_header():
     assert C.sizeof(_lib.EpParams) == 4 * 11 + 32 + 4 * 5 + 4 + 4 + 8 + 4 * 4
     assert C.sizeof(_lib.EpBuffers) == 20 * 8
     assert C.sizeof(_lib.EpWindow) == 8 + 8 + 8 + 5 * 8 + 8
+    assert C.sizeof(_lib.EpNodes) == 8 + 8 + 6 * 4 + 8 + 8
 
 
 def test_argument_validation_without_gpu():

@@ -301,6 +301,37 @@ size_t lantern_evaluate_posterior_nodes_workspace(const lantern_ep_params *prm, 
 int lantern_evaluate_posterior_nodes(const lantern_ep_params *prm, const lantern_ep_buffers *buf, const lantern_ep_window *win,
                                      const lantern_ep_nodes *nodes, void *stream);
 
+/* ------------------------------------------------------------------------------------
+ * One verify step of G independent groups of sequences in ONE call: for every group, on the group's own stream,
+ *   O6 lantern_gather_candidates -> O7 lantern_cfg_mask_topk_window -> O8 lantern_evaluate_posterior_nodes (nodes != NULL) or
+ *   lantern_evaluate_posterior_window -> O9 + O10 lantern_update_inference_inputs
+ * i.e. the body of the reference's decode loop between the target forward and the next drafter call
+ * (models/ea_model_lumina_mgpt.py:936-998: generate_candidates, tree_decoding's post-process, evaluate_posterior,
+ * update_inference_inputs), with nothing returning to the host.  Groups are independent sequences, so their streams are not
+ * ordered against each other: one group's latency-bound evaluate_posterior overlaps the other groups' bandwidth-bound kernels.
+ * Every field has the meaning of the same-named argument of the entry point it is passed to; the host loop only patches the
+ * step-dependent pointers (where this step's outputs go) between calls.  slab_ptrs == NULL skips O9 + O10.
+ */
+typedef struct lantern_step_group {
+    void *stream;
+    /* O6 */
+    const int64_t *ss_token; const float *ss_prob; const int64_t *sample_token; const int64_t *tree_indices; const int64_t *retrieve;
+    int32_t B, n_flat, N, P, D, reserved0;
+    int64_t *tree_cand; int64_t *cand; float *cart_prob;
+    /* O7 (windowed) */
+    const void *cond; const void *uncond; int32_t dtype, V; float cfg; int32_t model; const int64_t *pos_ids; int64_t pos_base;
+    int32_t w_latent, h_latent, img_lo, img_hi, newline_id, eos_id, top_k, win_lo, win_len, out_kind;
+    const int64_t *seq_len; float *out_win; int32_t *row_hot; float temperature, top_p;
+    /* O8 */
+    lantern_ep_params ep; lantern_ep_buffers ep_buf; lantern_ep_window ep_win;
+    const lantern_ep_nodes *nodes;        /* NULL: the chain kernel (lantern_evaluate_posterior_window) */
+    /* O9 + O10 */
+    void *const *slab_ptrs; const int32_t *slab_seq; const int64_t *slab_prev; int64_t *new_len;
+    int32_t n_slabs, elem_bytes; int64_t outer, S_max, d;
+    const void *hidden; void *out_hidden; int64_t *accepted_tokens; int32_t hid_elem_bytes, hid_groups, H, reserved1;
+} lantern_step_group;
+int lantern_verify_step(const lantern_step_group *groups, int n_groups);
+
 /* window -> dense [B,V] (API compatibility with callers that want the reference's sample_p[V]). */
 int lantern_window_to_dense(const float *win, const int32_t *out_tok, const float *out_mass, int B, int V,
                             int win_lo, int win_len, float *dense, void *stream);

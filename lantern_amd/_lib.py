@@ -50,6 +50,24 @@ class EpNodes(C.Structure):
                 ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t)]
 
 
+class StepGroup(C.Structure):
+    """lantern_step_group (include/lantern_hip.h): one group of sequences of lantern_verify_step."""
+    _fields_ = ([("stream", C.c_void_p)]
+                + [(n, C.c_void_p) for n in ("ss_token", "ss_prob", "sample_token", "tree_indices", "retrieve")]
+                + [(n, C.c_int32) for n in ("B", "n_flat", "N", "P", "D", "reserved0")]
+                + [(n, C.c_void_p) for n in ("tree_cand", "cand", "cart_prob", "cond", "uncond")]
+                + [("dtype", C.c_int32), ("V", C.c_int32), ("cfg", C.c_float), ("model", C.c_int32), ("pos_ids", C.c_void_p),
+                   ("pos_base", C.c_int64)]
+                + [(n, C.c_int32) for n in ("w_latent", "h_latent", "img_lo", "img_hi", "newline_id", "eos_id", "top_k", "win_lo", "win_len",
+                                            "out_kind")]
+                + [("seq_len", C.c_void_p), ("out_win", C.c_void_p), ("row_hot", C.c_void_p), ("temperature", C.c_float), ("top_p", C.c_float),
+                   ("ep", EpParams), ("ep_buf", EpBuffers), ("ep_win", EpWindow), ("nodes", C.POINTER(EpNodes))]
+                + [(n, C.c_void_p) for n in ("slab_ptrs", "slab_seq", "slab_prev", "new_len")]
+                + [("n_slabs", C.c_int32), ("elem_bytes", C.c_int32), ("outer", C.c_int64), ("S_max", C.c_int64), ("d", C.c_int64)]
+                + [(n, C.c_void_p) for n in ("hidden", "out_hidden", "accepted_tokens")]
+                + [(n, C.c_int32) for n in ("hid_elem_bytes", "hid_groups", "H", "reserved1")])
+
+
 _lib = None
 
 
@@ -94,5 +112,5 @@ EXPORTS = [
     "lantern_window_to_dense", "lantern_pack_vq_table", "lantern_update_inference_inputs", "lantern_profile_next_launch", "lantern_drafter_attention_mask", "lantern_linear_rows",
     "lantern_tree_attention_workspace", "lantern_tree_attention",
     "lantern_tree_node_tables_size", "lantern_tree_node_tables", "lantern_evaluate_posterior_nodes_workspace",
-    "lantern_evaluate_posterior_nodes",
+    "lantern_evaluate_posterior_nodes", "lantern_verify_step",
 ]

@@ -24,7 +24,9 @@ import numpy as np
 import torch
 
 from . import _lib, ops
-from ._lib import EpBuffers, EpNodes, EpParams, EpWindow, check
+from ._lib import EpBuffers, EpNodes, EpParams, EpWindow, StepGroup, check
+
+from contextlib import nullcontext as _nullctx
 
 MC_SIM_7B_63 = [[0], [1], [2], [3], [0, 0], [0, 1], [0, 2], [1, 0], [1, 1], [2, 0], [2, 1], [3, 0],
                 [0, 0, 0], [0, 0, 1], [0, 0, 2], [0, 1, 0], [0, 1, 1], [0, 2, 0], [0, 2, 1], [1, 0, 0],
@@ -79,6 +81,8 @@ class WorkloadConfig:
     pack_table: bool = True         # windowed path: neighbour table packed to [K, ceil8(k+1)] (lantern_pack_vq_table)
     ep_kernel: str = "nodes"        # windowed path: "nodes" = node-parallel evaluate_posterior (one workgroup per internal tree node + the
                                     # walk; B * n_internal workgroups fill the GPU), "chain" = one serial chain per sequence (epw_kernel)
+    native_step: bool = True        # eager windowed path: the whole step of all groups through ONE C call (lantern_verify_step) instead of
+                                    # 4 x n_groups ctypes calls (the Python launch loop caps the stream groups at ~2 otherwise)
     leaf_workgroups: int = -1       # node kernel: -1 = by batch size (include/lantern_hip.h lantern_ep_nodes)
     n_groups: int = 1               # >1: the sequences are split into groups, each launched on its own HIP stream, so that one
                                     # group's latency-bound evaluate_posterior overlaps the others' bandwidth-bound kernels
@@ -262,6 +266,11 @@ class LuminaVerifyWorkload:
             for parity in (0, 1):
                 for g in range(self.G):
                     self._group_args(slot, parity, g)
+        self._steps = {}
+        if self.windowed and cfg.native_step and cfg.direct_logs and cfg.fuse_update and not cfg.side_stream and not cfg.use_graph:
+            for slot in range(cfg.pool_steps):
+                for parity in (0, 1):
+                    self._steps[(slot, parity)] = self._make_step_groups(slot, parity)
 
     # -------------------------------------------------------------------------------------
     def reset_state(self):
@@ -373,7 +382,11 @@ class LuminaVerifyWorkload:
         use_graph = events is None and not serial and self.cfg.use_graph and self.cfg.pool_steps % 2 == 0
         if use_graph and self.graphs is None:
             self._capture_graphs()
-        if self.G == 1:
+        if events is None and not serial and self._steps:
+            if self.G > 1 and not self._forked:
+                self._fork()
+            self._native_step(slot, i & 1)
+        elif self.G == 1:
             if use_graph:
                 self.graphs[slot][0].replay()
             else:
@@ -438,6 +451,72 @@ class LuminaVerifyWorkload:
         for t, v in zip(state, snap):
             t.copy_(v)                            # capture does not execute, the warm-up did: restore the state
         torch.cuda.synchronize(dev)
+
+    def _make_step_groups(self, slot: int, parity: int):
+        """lantern_step_group array of one (pool slot, lens parity): everything but this step's output rows is fixed."""
+        c = self.cfg
+        arr = (StepGroup * self.G)()
+        for g in range(self.G):
+            A, s = self._group_args(slot, parity, g), arr[g]
+            val = lambda x: None if x is None else (x.value if isinstance(x, C.c_void_p) else x)
+            s.stream = 0 if self.streams[g] is None else self.streams[g].cuda_stream       # patched per step for the current stream when G == 1
+            s.ss_token, s.ss_prob, s.sample_token = val(A["ss_token"]), val(A["ss_prob"]), val(A["sample_token"])
+            s.tree_indices, s.retrieve = self.d_tree_indices.data_ptr(), self.d_retrieve.data_ptr()
+            s.B, s.n_flat, s.N, s.P, s.D = self.Bg, self.R * 10, self.N, self.P, self.D
+            s.tree_cand, s.cand, s.cart_prob = val(A["tree_cand"]), val(A["cand"]), val(A["cart_prob"])
+            s.cond, s.uncond, s.dtype, s.V, s.cfg, s.model = val(A["cond"]), val(A["uncond"]), 1, V, c.cfg_scale, ops.MODEL_LUMINA
+            s.pos_ids, s.pos_base = self.d_pos_ids.data_ptr(), c.prompt_len + 3
+            s.w_latent, s.h_latent, s.img_lo, s.img_hi, s.newline_id, s.eos_id, s.top_k = W_LATENT, H_LATENT, IMG_LO, IMG_HI, NEWLINE, EOS, c.top_k
+            s.win_lo, s.win_len, s.out_kind = self.win_lo, self.W, ops.ROWS_PROBS if c.rows_probs else ops.ROWS_LOGITS
+            s.seq_len, s.out_win, s.row_hot, s.temperature, s.top_p = val(A["cur"]), val(A["proc"]), val(A["row_hot"]), 1.0, 1.0
+            C.memmove(C.byref(s.ep), C.byref(self._ep_prm), C.sizeof(EpParams))
+            C.memmove(C.byref(s.ep_buf), C.byref(A["ep_buf"]), C.sizeof(EpBuffers))
+            C.memmove(C.byref(s.ep_win), C.byref(A["ep_win"]), C.sizeof(EpWindow))
+            if self.ep_nodes is not None:
+                s.nodes = C.pointer(self.ep_nodes[g])
+            if c.with_kv:
+                s.slab_ptrs, s.slab_seq, s.slab_prev, s.new_len = val(A["slab_ptrs"]), val(A["slab_seq"]), val(A["cur"]), val(A["nxt"])
+                s.n_slabs, s.elem_bytes, s.outer, s.S_max, s.d = 2 * self.Bg, 2, 2 * c.kv_layers * c.kv_heads, c.kv_smax + c.kv_pad_rows, c.kv_dim
+                s.hidden, s.out_hidden, s.accepted_tokens = val(A["hidden"]), val(A["out_hidden"]), val(A["acc_tokens"])
+                s.hid_elem_bytes, s.hid_groups, s.H = 2, 2, HIDDEN
+        return arr
+
+    def _native_step(self, slot: int, parity: int):
+        """One C call enqueues O6 -> O7 -> O8 -> O9 + O10 of every group (each on its stream); results land in the step's log row."""
+        c = self.cfg
+        step = self.step_idx
+        if step >= c.max_steps:
+            raise _lib.LanternError(f"step {step} >= max_steps {c.max_steps}: size the logs for the run")
+        arr, bs = self._steps[(slot, parity)], self._bases
+        cur_stream = torch.cuda.current_stream().cuda_stream if self.G == 1 else None
+        for g in range(self.G):
+            s = arr[g]
+            e = step * c.n_seq + g * self.Bg
+            if cur_stream is not None:
+                s.stream = cur_stream
+            if step > 0:
+                s.sample_token = bs["tok"] + 8 * (e - c.n_seq)
+            else:
+                s.sample_token = self.sample_token[g * self.Bg:].data_ptr()
+            s.ep_buf.best, s.ep_buf.accept_len, s.ep_buf.counters = bs["best"] + 4 * e, bs["alen"] + 4 * e, bs["cnt"] + 24 * e
+            s.ep_win.u_bonus, s.ep_win.token = bs["ub"] + 8 * e, bs["tok"] + 8 * e
+        check(self._L.lantern_verify_step(arr, self.G), "verify_step")
+        if not c.with_kv:
+            for g in range(self.G):
+                s0, B = g * self.Bg, self.Bg
+                with torch.cuda.stream(self.streams[g]) if self.streams[g] is not None else _nullctx():
+                    torch.add(self.lens[parity][2 * s0:2 * s0 + 2 * B], (self.log_alen[step, s0:s0 + B] + 1).repeat(2), out=self.lens[parity ^ 1][2 * s0:2 * s0 + 2 * B])
+        # sequence management (not the hot path): an image can only end once the host-side bound says so
+        self._len_ub += self.D
+        if self._len_ub >= TOKENS_PER_IMAGE:
+            for g in range(self.G):
+                s0, B = g * self.Bg, self.Bg
+                with torch.cuda.stream(self.streams[g]) if self.streams[g] is not None else _nullctx():
+                    nxt, base = self.lens[parity ^ 1][2 * s0:2 * s0 + 2 * B], self.len_base[2 * s0:2 * s0 + 2 * B]
+                    torch.where(nxt - base >= TOKENS_PER_IMAGE, base, nxt, out=nxt)
+            self.join()
+            self._len_ub = int((self.lens[parity ^ 1] - self.len_base).max().item())
+            self._forked = False
 
     def _group_args(self, slot: int, parity: int, g: int):
         """Raw pointers of group g's slice of every buffer (cached: the addresses never change)."""

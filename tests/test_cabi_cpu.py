@@ -125,3 +125,19 @@ def test_uniform_fifo_replays_the_python_stream_in_order():
         consumed += fifo.buf[0, c:c + used].tolist()
         fifo.cursor += used
     assert consumed == expected[:len(consumed)] and len(consumed) > 1000
+
+
+def test_step_group_layout_matches_the_c_struct(tmp_path):
+    """ctypes mirror of lantern_step_group / lantern_ep_nodes vs the C compiler's layout of include/lantern_hip.h (a drift here
+    would hand every kernel of lantern_verify_step the wrong pointers)."""
+    import subprocess
+    fields = ["stream", "B", "tree_cand", "cond", "pos_base", "w_latent", "seq_len", "temperature", "ep", "ep_buf", "ep_win", "nodes",
+              "slab_ptrs", "n_slabs", "outer", "hidden", "H"]
+    src = tmp_path / "layout.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "lantern_hip.h"\nint main(void){printf("%zu %zu", sizeof(lantern_step_group), sizeof(lantern_ep_nodes));\n'
+                   + "".join(f'printf(" %zu", offsetof(lantern_step_group, {f}));\n' for f in fields) + "return 0;}\n")
+    exe = tmp_path / "layout"
+    subprocess.check_call(["gcc", "-std=c99", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    out = [int(x) for x in subprocess.check_output([str(exe)]).split()]
+    assert out[0] == C.sizeof(_lib.StepGroup) and out[1] == C.sizeof(_lib.EpNodes)
+    assert out[2:] == [getattr(_lib.StepGroup, f).offset for f in fields]

@@ -17,10 +17,12 @@ Extra objects on the JSON line:
                 own counters) / its mean launch duration measured with HIP events on the launch stream
                 inside the timed region; peak 8000 GB/s.
   kernels       the same for cfg_mask_topk and kv_gather.
-  roofline_saturated / ep_batch_sweep
-                evaluate_posterior alone at --ep-sweep sequences per launch (default 256 = one workgroup per CU), measured after
-                the timed region: BASELINE.md states the 60 % roofline target at the saturating batch size, which the 64 KV-resident
-                sequences of the step loop cannot reach (4.3 GB of KV slabs each).
+  ep_batch_sweep
+                evaluate_posterior alone over {1, 8, 64, 256, 512, 4096} sequences per launch, chain and node-parallel kernels,
+                measured after the timed region (KV slabs released first).  `frac` there = bytes really moved / time / 8 TB/s.
+  lambda_mode   the same loop with lantern_delta = 5 (LANTERN++: tau = 4 p(x)), BASELINE.md run B.
+  step_latency_us  whole-step wall time at 1 and 8 sequences (the reference's own batch is 1), both evaluate_posterior forms.
+  stream_groups_2  the same 64 sequences as two groups on two HIP streams.
   cpu_baseline  the oracle (C port of the reference path) timed on this host's cores over a bounded
                 sample of the same pools/uniforms; it must reproduce the GPU's accepted-token stream.
 """
@@ -50,7 +52,7 @@ def parse():
     ap.add_argument("--sigma", type=float, default=5.0, help="drafter noise; frozen at 5.0: mean accepted tokens/step ~2.6")
     ap.add_argument("--path", choices=["window", "dense"], default="window",
                     help="window: v2 kernels (32 KB image-window rows, LDS-resident residual); dense: v1 kernels (full-V rows)")
-    ap.add_argument("--ep", choices=["nodes", "chain"], default="nodes",
+    ap.add_argument("--ep", choices=["nodes", "chain"], default="chain",
                     help="windowed evaluate_posterior: nodes = one workgroup per internal tree node + the walk (lantern_evaluate_posterior_nodes); "
                          "chain = one serial chain per sequence (lantern_evaluate_posterior_window)")
     ap.add_argument("--python-launch", action="store_true", help="launch every kernel of the step from Python (4 ctypes calls per group) instead of one lantern_verify_step call")
@@ -61,10 +63,11 @@ def parse():
     ap.add_argument("--graph", action="store_true", help="replay one captured hipGraph per (pool slot, group) instead of launching eagerly")
     ap.add_argument("--side-stream", action="store_true", help="launch O6 beside O7 and O10 beside O9 on a second HIP stream (measured slower: event waits)")
     ap.add_argument("--groups", type=int, default=1, help="split the GPU's sequences into this many groups, each on its own HIP stream (independent sequences: one group's latency-bound evaluate_posterior overlaps the others' bandwidth-bound kernels)")
-    ap.add_argument("--ep-sweep", type=str, default="256",
+    ap.add_argument("--no-extras", action="store_true", help="skip the extra runs after the timed region (lambda mode, B=1 / B=8 step latency, two stream groups)")
+    ap.add_argument("--ep-sweep", type=str, default="1,8,64,256,512,4096",
                     help="e.g. 256,2048: batch sizes for the evaluate_posterior-only roofline sweep (BASELINE.md section 2: the 60 %% target is "
                          "stated 'at the saturating batch size'), run by rank 0 AFTER the timed region and the event pass, KV slabs released first; "
-                         "default 256 = one workgroup per CU (`roofline_saturated` on the JSON line).  Pass '' under rocprofv3 so that every "
+                         "Pass '' under rocprofv3 so that every "
                          "kernel is launched on one homogeneous workload (its averages then agree with the HIP-event averages)")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="CPU-baseline budget; 0 disables")
     ap.add_argument("--cpu-seqs", type=int, default=0, help="sequences in the CPU sample (0 = host cores)")
@@ -175,9 +178,11 @@ def cpu_baseline(wl, steps_budget_s: float, n_seq: int, gpu_tokens_by_seq):
 # ------------------------------------------------------------------------- EP-only batch sweep
 
 def ep_batch_sweep(batches, device, base_cfg, iters=20):
-    """evaluate_posterior alone at saturating batch sizes ('fraction of the 8 TB/s peak over a batch sweep').
-    Same synthetic recipe, no KV slabs; inputs of one verify step are produced by the real O6/O7 kernels, then the O8
-    launch is repeated `iters` times on identical inputs (cursor reset by a memset node) between HIP events."""
+    """evaluate_posterior alone over a batch sweep ({1, 8, 64, 512, 4096} sequences per launch), both forms: the
+    per-sequence chain kernel and the node-parallel kernel (+ its walk).  Same synthetic recipe, no KV slabs; inputs of one
+    verify step are produced by the real O6 / O7 kernels, then the O8 launch is repeated `iters` times on identical inputs
+    between HIP events.  `frac` = bytes the windowed kernels really have to move / time / 8 TB/s; the SURVEY 8d contract
+    formula (dense V-wide rows, which no windowed kernel moves) is kept as `contract_equivalent_GBps`, never as a fraction."""
     import ctypes as C
     from lantern_amd import harness as HN
     from lantern_amd._lib import check
@@ -189,7 +194,8 @@ def ep_batch_sweep(batches, device, base_cfg, iters=20):
             out.append({"sequences_per_launch": Bs, "skipped": f"needs {need >> 30} GiB, {free >> 30} GiB free"})
             continue
         cfg = HN.WorkloadConfig(n_seq=Bs, pool_steps=1, use_graph=False, lantern_k=base_cfg.lantern_k, lantern_delta=base_cfg.lantern_delta,
-                                sigma=base_cfg.sigma, with_kv=False, max_steps=8, path=base_cfg.path, seed_base=base_cfg.seed_base + 500)
+                                sigma=base_cfg.sigma, with_kv=False, max_steps=8, path=base_cfg.path, seed_base=base_cfg.seed_base + 500,
+                                ep_kernel="nodes", tree=base_cfg.tree)
         wl = HN.LuminaVerifyWorkload(cfg, device)
         wl.step()                      # O6 + O7 fill cand / proc / row_hot; one O8 result lands in log slot 0
         torch.cuda.synchronize(device)
@@ -197,38 +203,92 @@ def ep_batch_sweep(batches, device, base_cfg, iters=20):
         st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
         buf = wl.ep_buffers(0, 0)
         win = wl.ep_window(0) if wl.windowed else None
-
-        def launch():
-            wl.cursor.zero_()
-            if wl.windowed:
-                check(L.lantern_evaluate_posterior_window(C.byref(wl._ep_prm), C.byref(buf), C.byref(win), st), "ep")
-            else:
-                check(L.lantern_evaluate_posterior(C.byref(wl._ep_prm), C.byref(buf), st), "ep")
-        for _ in range(3):
-            launch()
-        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
-        for e0, e1 in evs:
-            wl.cursor.zero_()
-            e0.record()
-            if wl.windowed:
-                check(L.lantern_evaluate_posterior_window(C.byref(wl._ep_prm), C.byref(buf), C.byref(win), st), "ep")
-            else:
-                check(L.lantern_evaluate_posterior(C.byref(wl._ep_prm), C.byref(buf), st), "ep")
-            e1.record()
-        torch.cuda.synchronize(device)
-        if int(wl.st_cnt[:, 5].abs().sum()) != 0:
-            raise RuntimeError("evaluate_posterior reported a per-sequence error in the sweep")
-        ms = float(np.median([a.elapsed_time(b) for a, b in evs]))
-        nbytes = wl.ep_window_bytes_from(wl.st_cnt) if wl.windowed else wl.ep_algorithmic_bytes_from(wl.st_cnt)
-        dense = wl.ep_algorithmic_bytes_from(wl.st_cnt)
-        tokens = float((wl.st_alen.float() + 1).sum())
-        out.append({"sequences_per_launch": Bs, "launch_ms": ms, "algorithmic_bytes_per_launch": nbytes,
-                    "achieved_GBps": nbytes / (ms * 1e-3) / 1e9, "frac": nbytes / (ms * 1e-3) / 1e9 / 8000.0,
-                    "dense_contract_equivalent_GBps": dense / (ms * 1e-3) / 1e9, "us_per_sequence": 1e3 * ms / Bs,
-                    "accepted_tokens_per_launch": tokens})
+        row = {"sequences_per_launch": Bs}
+        for kern in (("chain", "nodes") if wl.windowed else ("dense",)):
+            def launch():
+                wl.cursor.zero_()
+                if kern == "nodes":
+                    check(L.lantern_evaluate_posterior_nodes(C.byref(wl._ep_prm), C.byref(buf), C.byref(win), C.byref(wl.ep_nodes[0]), st), "ep")
+                elif kern == "chain":
+                    check(L.lantern_evaluate_posterior_window(C.byref(wl._ep_prm), C.byref(buf), C.byref(win), st), "ep")
+                else:
+                    check(L.lantern_evaluate_posterior(C.byref(wl._ep_prm), C.byref(buf), st), "ep")
+            for _ in range(3):
+                launch()
+            evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
+            for e0, e1 in evs:
+                wl.cursor.zero_()
+                e0.record()
+                launch()
+                e1.record()
+            torch.cuda.synchronize(device)
+            if int(wl.st_cnt[:, 5].abs().sum()) != 0:
+                raise RuntimeError("evaluate_posterior reported a per-sequence error in the sweep")
+            ms = float(np.median([a.elapsed_time(b) for a, b in evs]))
+            nbytes = wl.ep_window_bytes_from(wl.st_cnt) if wl.windowed else wl.ep_algorithmic_bytes_from(wl.st_cnt)
+            dense = wl.ep_algorithmic_bytes_from(wl.st_cnt)
+            row[kern] = {"launch_ms": ms, "us_per_sequence": 1e3 * ms / Bs, "hbm_bytes_needed_per_launch": nbytes,
+                         "achieved_GBps": nbytes / (ms * 1e-3) / 1e9, "frac": nbytes / (ms * 1e-3) / 1e9 / 8000.0,
+                         "contract_equivalent_GBps": dense / (ms * 1e-3) / 1e9}
+        row["accepted_tokens_per_launch"] = float((wl.st_alen.float() + 1).sum())
+        out.append(row)
         del wl
         torch.cuda.empty_cache()
     return out
+
+
+def step_latency(device, base_cfg, batches=(1, 8), steps=60):
+    """Whole verify step (O6 -> O7 -> O8 -> O9 + O10, KV slabs of the bench geometry) at the reference's own batch sizes:
+    wall-clock microseconds per step for both evaluate_posterior forms (BASELINE.md section 2 'Reported')."""
+    from lantern_amd import harness as HN
+    res = {}
+    for Bs in batches:
+        for kern in ("nodes", "chain"):
+            cfg = HN.WorkloadConfig(n_seq=Bs, pool_steps=4, lantern_k=base_cfg.lantern_k, lantern_delta=base_cfg.lantern_delta, sigma=base_cfg.sigma,
+                                    with_kv=base_cfg.with_kv, kv_smax=base_cfg.kv_smax, kv_pad_rows=base_cfg.kv_pad_rows, max_steps=steps + 32,
+                                    seed_base=base_cfg.seed_base + 900, ep_kernel=kern, tree=base_cfg.tree)
+            wl = HN.LuminaVerifyWorkload(cfg, device)
+            wl.prime()
+            for _ in range(10):
+                wl.step()
+            torch.cuda.synchronize(device)
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                wl.step()
+            torch.cuda.synchronize(device)
+            dt = time.perf_counter() - t0
+            wl.check_status(0, steps + 10)
+            res[f"B{Bs}_{kern}"] = {"us_per_step": 1e6 * dt / steps, "accepted_tokens_per_s": wl.accepted_tokens(10, 10 + steps) / dt}
+            del wl
+            torch.cuda.empty_cache()
+    return res
+
+
+def side_run(device, base_cfg, steps, **over):
+    """A second, shorter timed run of the same workload with some knobs changed (stream groups, tree, ...): whole-job rate."""
+    import dataclasses
+    from lantern_amd import harness as HN
+    cfg = dataclasses.replace(base_cfg, max_steps=max(base_cfg.pool_steps, steps + 20) + 8, **over)
+    wl = HN.LuminaVerifyWorkload(cfg, device)
+    wl.prime()
+    for _ in range(10):
+        wl.step()
+    wl.join()
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        wl.step()
+    wl.join()
+    torch.cuda.synchronize(device)
+    dt = time.perf_counter() - t0
+    wl.check_status(0, steps + 10)
+    toks = wl.accepted_tokens(10, 10 + steps)
+    r = {"value": toks / dt, "unit": "accepted_tokens/s", "ms_per_step": 1e3 * dt / steps, "steps": steps,
+         "mean_accept_length": toks / (steps * cfg.n_seq), "sequences_per_launch": wl.Bg}
+    wl.release_kv()
+    del wl
+    torch.cuda.empty_cache()
+    return r
 
 
 # ---------------------------------------------------------------------------- N > 1: self-launch
@@ -436,7 +496,7 @@ def main():
             # SURVEY 8d contract figure: L*V*4 + T*k*6 + R*(k+1)*4 + V*4 (+V*4), from the kernel's own counters
             contract_bytes = wl.ep_algorithmic_bytes(E0, E1, group=0) / KT      # events bracket group 0's launches
             ach = contract_bytes / (ep_ms * 1e-3) / 1e9
-            rl = {"kernel": "epw_kernel (evaluate_posterior, windowed)" if wl.windowed else "ep_kernel (evaluate_posterior)",
+            rl = {"kernel": ("epn_kernel + epn_walk_kernel (evaluate_posterior, node-parallel)" if wl.ep_nodes is not None else "epw_kernel (evaluate_posterior, windowed chain)") if wl.windowed else "ep_kernel (evaluate_posterior)",
                   "bound": "hbm", "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0, "traffic": None,
                   "algorithmic_bytes_per_launch": contract_bytes, "avg_launch_ms": ep_ms,
                   "algorithmic_bytes_definition": "SURVEY 8d: L*V*4 + T*k*6 + R*(k+1)*4 + V*4 (+V*4 if the last level had no rejection), "
@@ -469,24 +529,42 @@ def main():
                                    "contract_bytes_per_launch": kv_b, "contract_equivalent_GBps": kv_b / (kv_ms * 1e-3) / 1e9,
                                    "includes": "accepted-hidden copy (O10) in the same launch" if (wl.windowed and cfg.fuse_update) else None}
             out["kernels"] = ks
-        if args.ep_sweep:
-            wl.release_kv()      # the sweep builds its own (KV-free) workloads: give the memory back first
-            sweep = ep_batch_sweep([int(x) for x in args.ep_sweep.split(",") if x], device, cfg)
-            out["ep_batch_sweep"] = sweep
-            done = [r for r in sweep if "frac" in r]
-            bestp = max(done, key=lambda r: r["dense_contract_equivalent_GBps"]) if done else None
-            if bestp:
-                out["roofline_saturated"] = {"kernel": out.get("roofline", {}).get("kernel"), "sequences_per_launch": bestp["sequences_per_launch"],
-                                             "achieved": bestp["dense_contract_equivalent_GBps"], "peak": 8000.0, "unit": "GB/s",
-                                             "frac": bestp["dense_contract_equivalent_GBps"] / 8000.0, "avg_launch_ms": bestp["launch_ms"],
-                                             "windowed_kernel_achieved": bestp["achieved_GBps"], "windowed_kernel_frac": bestp["frac"],
-                                             "note": "evaluate_posterior alone on one verify step's inputs (no KV slabs resident), measured after the timed region"}
+        # the CPU leg replays the run from step 0 (warm-up included): keep the logs before the extra runs below overwrite them
+        gb = wl.log_best[:n_logged].cpu().numpy()
+        ga = wl.log_alen[:n_logged].cpu().numpy()
+        gt = wl.log_token[:n_logged].cpu().numpy()
+        if not args.no_extras and wl.windowed:
+            # LANTERN++ mode of the same workload (run B of BASELINE.md: lantern_delta = 5 -> tau = 4 * p(x)): same pools, same kernels
+            KL = min(K, 100)
+            wl.join()
+            wl.set_lantern_delta(5.0)
+            wl.reset_state()
+            for _ in range(5):
+                wl.step()
+            wl.join()
+            torch.cuda.synchronize(device)
+            t1 = time.perf_counter()
+            for _ in range(KL):
+                wl.step()
+            wl.join()
+            torch.cuda.synchronize(device)
+            dl = time.perf_counter() - t1
+            wl.check_status(0, KL + 5)
+            tl = wl.accepted_tokens(5, 5 + KL)
+            out["lambda_mode"] = {"lantern_delta": 5.0, "value": tl / dl, "unit": "accepted_tokens/s", "ms_per_step": 1e3 * dl / KL, "steps": KL,
+                                  "mean_accept_length": tl / (KL * cfg.n_seq), "note": "rank 0's sequences only"}
+            wl.set_lantern_delta(args.lantern_delta)
+        if (args.ep_sweep or not args.no_extras) and world == 1:
+            wl.release_kv()      # the extra runs build their own workloads: give the memory back first
+        if not args.no_extras and world == 1 and wl.windowed:
+            out["step_latency_us"] = step_latency(device, cfg)
+            out["stream_groups_2"] = side_run(device, cfg, min(K, 100), n_groups=2)
+            out["stream_groups_2"]["note"] = ("the same sequences as two independent groups on two HIP streams (one group's evaluate_posterior overlaps the "
+                                              "other's bandwidth-bound kernels); not the default because it halves the sequences per evaluate_posterior launch")
+        if args.ep_sweep and world == 1:
+            out["ep_batch_sweep"] = ep_batch_sweep([int(x) for x in args.ep_sweep.split(",") if x], device, cfg)
         if args.cpu_seconds > 0 and world == 1:      # the CPU baseline is reported at N = 1 only
             n_cpu = args.cpu_seqs or min(cfg.n_seq, os.cpu_count() or 1)
-            # the CPU leg replays the run from step 0 (warm-up included): compare against the whole log
-            gb = wl.log_best[:n_logged].cpu().numpy()
-            ga = wl.log_alen[:n_logged].cpu().numpy()
-            gt = wl.log_token[:n_logged].cpu().numpy()
             gpu_stream = [[(int(gb[i, b]), int(ga[i, b]), int(gt[i, b])) for b in range(cfg.n_seq)] for i in range(n_logged)]
             out["cpu_baseline"] = cpu_baseline(wl, args.cpu_seconds, n_cpu, gpu_stream)
         print(json.dumps(out))

@@ -309,6 +309,14 @@ class LuminaVerifyWorkload:
         self.reset_state()
         torch.cuda.synchronize(self.device)
 
+    def set_lantern_delta(self, delta: float):
+        """Switch between LANTERN's delta mode (<= 1) and LANTERN++'s lambda mode (> 1: tau = (delta - 1) * p(x)) on the same pools."""
+        self.cfg.lantern_delta = float(delta)
+        self._ep_prm.delta = float(delta)
+        for arr in self._steps.values():
+            for g in range(self.G):
+                arr[g].ep.delta = float(delta)
+
     def release_kv(self):
         """Free the KV slabs (most of the footprint) once the timed loop is over."""
         self.slabs = []

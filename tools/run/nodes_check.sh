@@ -5,9 +5,9 @@ OUT=gpurun_out/${1:-r2d}
 mkdir -p $OUT
 timeout -k 10 600 python -m pytest tests/test_gpu_nodes.py -x -q -m gpu > $OUT/nodes_tests.log 2>&1
 tail -4 $OUT/nodes_tests.log
-timeout -k 10 300 python bench.py --steps 100 --warmup 10 --cpu-seconds 5 --ep-sweep "" > $OUT/bench_nodes.json 2> $OUT/bench_nodes.err || tail -5 $OUT/bench_nodes.err
-timeout -k 10 300 python bench.py --steps 100 --warmup 10 --cpu-seconds 0 --ep-sweep "" --seqs-per-gpu 8 > $OUT/bench_nodes_8.json 2> /dev/null
-timeout -k 10 300 python bench.py --steps 100 --warmup 10 --cpu-seconds 0 --ep-sweep "" --ep chain > $OUT/bench_chain.json 2> $OUT/bench_chain.err
+timeout -k 10 300 python bench.py --steps 100 --warmup 10 --cpu-seconds 5 --ep-sweep "" --no-extras > $OUT/bench_nodes.json 2> $OUT/bench_nodes.err || tail -5 $OUT/bench_nodes.err
+timeout -k 10 300 python bench.py --steps 100 --warmup 10 --cpu-seconds 0 --ep-sweep "" --no-extras --seqs-per-gpu 8 > $OUT/bench_nodes_8.json 2> /dev/null
+timeout -k 10 300 python bench.py --steps 100 --warmup 10 --cpu-seconds 0 --ep-sweep "" --no-extras --ep chain > $OUT/bench_chain.json 2> $OUT/bench_chain.err
 python - <<PY
 import json
 for f in ['nodes','nodes_8','chain']:

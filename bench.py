@@ -264,6 +264,44 @@ def step_latency(device, base_cfg, batches=(1, 8), steps=60):
     return res
 
 
+def dynamic_run(device, base_cfg, steps, n_seq):
+    """The dynamic-tree half of C3 (eagle_version 2: top_k 10, depth 5, 59 nodes, a different tree per sequence and step) on the
+    clock: O4 -> O6 -> O7 -> O8 -> O9 + O10, device-resident, same KV geometry as the headline run."""
+    from lantern_amd import harness as HN
+    cfg = HN.DynamicConfig(n_seq=n_seq, lantern_k=base_cfg.lantern_k, lantern_delta=base_cfg.lantern_delta, with_kv=base_cfg.with_kv,
+                           kv_smax=base_cfg.kv_smax, kv_pad_rows=base_cfg.kv_pad_rows, max_steps=2 * steps + 32)
+    wl = HN.DynamicVerifyWorkload(cfg, device)
+    for _ in range(10):
+        wl.step()
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        wl.step()
+    torch.cuda.synchronize(device)
+    dt = time.perf_counter() - t0
+    names = ("cfg_mask_topk", "evaluate_posterior", "kv_gather") if cfg.with_kv else ("cfg_mask_topk", "evaluate_posterior")
+    KE = min(steps, 20)
+    evs = [{n: (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for n in names} for _ in range(KE)]
+    for d in evs:
+        for e0, e1 in d.values():
+            e0.record(); e1.record()
+    torch.cuda.synchronize(device)
+    for i in range(KE):
+        wl.step(evs[i])
+    torch.cuda.synchronize(device)
+    wl.check_status(0, steps + 10 + KE)
+    toks = wl.accepted_tokens(10, 10 + steps)
+    cnt = wl.log_cnt[10:10 + steps].float()
+    r = {"workload": f"C3 dynamic tree (EAGLE-2): top_k {cfg.top_k}, depth {cfg.depth}, N={wl.N} nodes, {n_seq} sequences", "value": toks / dt,
+         "unit": "accepted_tokens/s", "ms_per_step": 1e3 * dt / steps, "steps": steps, "mean_accept_length": toks / (steps * n_seq),
+         "per_step": {"levels": float(cnt[..., 0].mean()), "tried": float(cnt[..., 1].mean()), "rejected": float(cnt[..., 2].mean())},
+         "kernel_ms": {n: float(np.mean([e[n][0].elapsed_time(e[n][1]) for e in evs])) for n in names}}
+    wl.release_kv()
+    del wl
+    torch.cuda.empty_cache()
+    return r
+
+
 def side_run(device, base_cfg, steps, **over):
     """A second, shorter timed run of the same workload with some knobs changed (stream groups, tree, ...): whole-job rate."""
     import dataclasses
@@ -561,6 +599,8 @@ def main():
             out["stream_groups_2"] = side_run(device, cfg, min(K, 100), n_groups=2)
             out["stream_groups_2"]["note"] = ("the same sequences as two independent groups on two HIP streams (one group's evaluate_posterior overlaps the "
                                               "other's bandwidth-bound kernels); not the default because it halves the sequences per evaluate_posterior launch")
+        if not args.no_extras and world == 1 and wl.windowed:
+            out["dynamic_tree"] = dynamic_run(device, cfg, min(K, 100), n_seq)
         if args.ep_sweep and world == 1:
             out["ep_batch_sweep"] = ep_batch_sweep([int(x) for x in args.ep_sweep.split(",") if x], device, cfg)
         if args.cpu_seconds > 0 and world == 1:      # the CPU baseline is reported at N = 1 only

@@ -118,6 +118,17 @@ int lantern_gather_candidates(const int64_t *ss_token, const float *ss_prob, con
                               int P, int D, int64_t *tree_cand, int64_t *cand, float *cart_prob,
                               void *stream);
 
+/* O6, dynamic (EAGLE-2) trees: every sequence has its own tree (the outputs of lantern_tree_dynamic_finalize).
+ * Replaces generate_candidates with the per-call buffers of topK_genrate: models/ea_model_llamagen.py:676-706,
+ * models/drafters/cnets_llamagen.py:905-912 (`candidates = cat(draft_tokens, -1)[retrieve_indices]`), and the position
+ * arithmetic of tree_decoding (ea_model_lumina_mgpt.py:559,601: tree_position_ids + len(input_ids) + 1).
+ * [dev] draft_tokens [B,N] i64, retrieve [B,N,N] i64 (row stride N, -1 pad), pos_ids [B,N] i64 or NULL, seq_len [B] i64 or NULL.
+ * Out [dev]: cand [B,P,D] i64 (-1 pad), retrieve_pd [B,P,D] i64 (-1 pad) or NULL, row_index [B,P,D] i32 (a -1 wraps to
+ * node N-1, as torch's indexing does) or NULL, pos_abs [B,N] i64 = pos_ids + seq_len + 1 or NULL.  P, D <= N. */
+int lantern_gather_candidates_dynamic(const int64_t *draft_tokens, const int64_t *retrieve, const int64_t *pos_ids,
+                                      const int64_t *seq_len, int B, int N, int P, int D, int64_t *cand, int64_t *retrieve_pd,
+                                      int32_t *row_index, int64_t *pos_abs, void *stream);
+
 /* ------------------------------------------------------------------------------------
  * O7  tree-logit post-process: CFG combine + model mask + top-k threshold, one pass.
  * Replaces tree_decoding's epilogue: models/ea_model_lumina_mgpt.py:597-605 (with

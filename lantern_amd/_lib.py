@@ -112,5 +112,5 @@ EXPORTS = [
     "lantern_window_to_dense", "lantern_pack_vq_table", "lantern_update_inference_inputs", "lantern_profile_next_launch", "lantern_drafter_attention_mask", "lantern_linear_rows",
     "lantern_tree_attention_workspace", "lantern_tree_attention",
     "lantern_tree_node_tables_size", "lantern_tree_node_tables", "lantern_evaluate_posterior_nodes_workspace",
-    "lantern_evaluate_posterior_nodes", "lantern_verify_step",
+    "lantern_evaluate_posterior_nodes", "lantern_verify_step", "lantern_gather_candidates_dynamic",
 ]

@@ -360,9 +360,46 @@ __global__ void sample_static_kernel(const float *__restrict__ probs, const int6
     }
 }
 
+// O6 for the EAGLE-2 dynamic tree: candidates = cat(draft_tokens, -1)[retrieve_indices] of every sequence's own tree
+// (models/ea_model_llamagen.py:676-706 with the per-call buffers of topK_genrate, cnets_llamagen.py:905-912), plus what the
+// next kernels index with: the (path, depth) -> row map (a -1 wraps to the last node row, as torch's indexing does), the
+// compact [P, D] retrieve rows, and the absolute position of every node (tree_position_ids + len(input_ids) + 1).
+__global__ __launch_bounds__(256) void gather_candidates_dynamic_kernel(const int64_t *__restrict__ draft, const int64_t *__restrict__ retrieve,
+                                                                        const int64_t *__restrict__ pos_ids, const int64_t *__restrict__ seq_len,
+                                                                        int N, int P, int D, int64_t *__restrict__ cand,
+                                                                        int64_t *__restrict__ retrieve_pd, int32_t *__restrict__ row_index,
+                                                                        int64_t *__restrict__ pos_abs) {
+    const int b = blockIdx.x;
+    const int64_t *dr = draft + (size_t)b * N, *rt = retrieve + (size_t)b * N * N;
+    for (int i = threadIdx.x; i < P * D; i += blockDim.x) {
+        const int p = i / D, d = i - p * D;
+        const int64_t r = rt[(size_t)p * N + d];
+        const bool ok = r >= 0 && r < N;
+        cand[(size_t)b * P * D + i] = ok ? dr[r] : -1;
+        if (retrieve_pd) retrieve_pd[(size_t)b * P * D + i] = ok ? r : -1;
+        if (row_index) row_index[(size_t)b * P * D + i] = ok ? (int32_t)r : N - 1;
+    }
+    if (pos_abs && pos_ids) {
+        const int64_t base = seq_len ? seq_len[b] + 1 : 0;
+        for (int n = threadIdx.x; n < N; n += blockDim.x) pos_abs[(size_t)b * N + n] = pos_ids[(size_t)b * N + n] + base;
+    }
+}
+
 }  // namespace lantern
 
 using namespace lantern;
+
+extern "C" int lantern_gather_candidates_dynamic(const int64_t *draft_tokens, const int64_t *retrieve, const int64_t *pos_ids,
+                                                 const int64_t *seq_len, int B, int N, int P, int D, int64_t *cand, int64_t *retrieve_pd,
+                                                 int32_t *row_index, int64_t *pos_abs, void *stream) {
+    LANTERN_CHECK_ARG(draft_tokens && retrieve && cand, "gather_candidates_dynamic: null buffer");
+    LANTERN_CHECK_ARG(B >= 0 && N > 0 && P > 0 && P <= N && D > 0 && D <= N, "gather_candidates_dynamic: bad sizes (P, D <= N)");
+    if (B == 0) return LANTERN_OK;
+    hipLaunchKernelGGL(gather_candidates_dynamic_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, draft_tokens, retrieve, pos_ids, seq_len, N,
+                       P, D, cand, retrieve_pd, row_index, pos_abs);
+    LANTERN_CHECK_LAUNCH("gather_candidates_dynamic");
+    return LANTERN_OK;
+}
 
 extern "C" int lantern_gather_candidates(const int64_t *ss_token, const float *ss_prob, const int64_t *sample_token,
                                          const int64_t *tree_indices, const int64_t *retrieve, int B, int n_flat, int N, int P,

@@ -746,3 +746,198 @@ class LuminaVerifyWorkload:
         if int(st.abs().sum().item()) != 0:
             bad = torch.nonzero(st)[0].tolist()
             raise _lib.LanternError(f"evaluate_posterior status {int(st[bad[0], bad[1]])} at step {i0 + bad[0]} seq {bad[1]}")
+
+
+# =====================================================================================================================
+# The dynamic-tree (EAGLE-2, eagle_version 2) half of config C3: a different tree per sequence and step.
+#
+#   O4 lantern_tree_dynamic_finalize -> O6 lantern_gather_candidates_dynamic -> O7 lantern_cfg_mask_topk_window (N = 59 rows per
+#   sequence, per-node positions) -> O8 lantern_evaluate_posterior_window (LANTERN_MODE_DYNAMIC, per-sequence row maps, ragged
+#   paths) -> O9 + O10 lantern_update_inference_inputs (per-sequence retrieve rows)
+#
+# with every buffer resident and every per-step index on the device, like the static workload above.  Reference:
+# models/drafters/cnets_lumina_mgpt.py:1229-1393 (topK_genrate), models/ea_model_lumina_mgpt.py:610-726 (eagle_version 2 branch).
+@dataclass
+class DynamicConfig:
+    n_seq: int = 64
+    pool_steps: int = 4
+    top_k: int = 10                 # drafter top_k (generate_images.py: drafter_top_k 10)
+    depth: int = 5                  # Lumina drafter depth (ea_model_lumina_mgpt.py:355-357)
+    total_tokens: int = 58          # total_token 59 - 1 (cnets_lumina_mgpt.py: self.total_tokens = total_tokens - 1) -> N = 59 nodes
+    lantern_k: int = 1000
+    lantern_delta: float = 0.1
+    cfg_scale: float = 3.0
+    logit_top_k: int = 2000
+    prompt_len: int = 64
+    kv_layers: int = 32
+    kv_heads: int = 32
+    kv_smax: int = 4096
+    kv_dim: int = 128
+    kv_pad_rows: int = 16
+    with_kv: bool = True
+    seed: int = 3700
+    max_steps: int = 256
+    plausible: float = 8.0          # drafted tokens get target logits in [plausible - 2, plausible]: the walk accepts a few levels
+
+
+class DynamicVerifyWorkload:
+    def __init__(self, cfg: DynamicConfig, device: torch.device):
+        self.cfg, self.device = cfg, device
+        B, S, TK, DP, TT = cfg.n_seq, cfg.pool_steps, cfg.top_k, cfg.depth, cfg.total_tokens
+        self.N = N = TT + 1
+        self.P, self.D = N, DP + 2
+        self.W, self.win_lo = IMG_HI - IMG_LO, IMG_LO
+        g = torch.Generator(device=device).manual_seed(cfg.seed)
+        W = self.W
+
+        def img_logits(*shape):
+            x = torch.full((*shape, V), float("-inf"), device=device)
+            x[..., IMG_LO:IMG_HI] = 4.0 * torch.randn((*shape, W), generator=g, device=device)
+            kth = torch.topk(x, cfg.logit_top_k, dim=-1).values[..., -1:]
+            return x.masked_fill(x < kth, float("-inf"))
+
+        table_full = build_neighbour_table(device, 0)
+        self.table_full = table_full
+        self.table_cols = min(K_CODES, -(-(cfg.lantern_k + 1) // 8) * 8)
+        self.table = ops.pack_vq_table(table_full, self.table_cols)
+        self.pools = []
+        for s in range(S):          # the drafter side of a step (setup, untimed): O3 per depth on random rows, then one O4 to learn the shapes
+            ti, cu, ci, sc = ops.expand_dynamic(img_logits(B, 1), None, TK)
+            sl, tl, pl = [cu.reshape(B, -1)], [ti.reshape(B, -1)], [torch.zeros((B, 1), dtype=torch.int64, device=device)]
+            cs = torch.arange(TK, device=device).expand(B, TK)
+            for d in range(DP):
+                pl.append(cs + 1 + TK * TK * max(0, d - 1) + (TK if d > 0 else 0))
+                ti, cu, ci, sc = ops.expand_dynamic(img_logits(B, TK), sc, TK)
+                cs = ci
+                sl.append(cu.reshape(B, -1)); tl.append(ti.reshape(B, -1))
+            scores, tokens, parents = torch.cat(sl, 1).contiguous(), torch.cat(tl, 1).contiguous(), torch.cat(pl, 1).contiguous()
+            sample = torch.randint(IMG_LO, IMG_HI, (B,), generator=g, device=device)
+            draft, mask, pos, ret, nl, md = ops.tree_dynamic_finalize(scores, tokens, parents, sample, TK, TT)
+            cond = (2.0 * torch.randn((B, N, V), generator=g, device=device)).to(torch.bfloat16)
+            unc = torch.randn((B, N, V), generator=g, device=device).to(torch.bfloat16)
+            r6 = ret[:, :, :self.D]
+            par, ch = r6[:, :, :-1], r6[:, :, 1:]
+            ok = ch >= 0
+            bi = torch.arange(B, device=device)[:, None, None].expand_as(ch)[ok]
+            tok = draft.gather(1, ch.clamp(min=0).reshape(B, -1)).reshape(ch.shape)[ok]
+            # drafted tokens plausible under the target (cfg(cond, unc) ~ cond for large values)
+            cond[bi, par[ok], tok] = (cfg.plausible - 2.0 * torch.rand(bi.shape, generator=g, device=device)).to(torch.bfloat16)
+            hidden = torch.randn((B, 2, N, HIDDEN), generator=g, device=device).to(torch.bfloat16)
+            self.pools.append(dict(scores=scores, tokens=tokens, parents=parents, cond=cond, unc=unc, hidden=hidden))
+        self.n_scores, self.n_parents = self.pools[0]["scores"].shape[1], self.pools[0]["parents"].shape[1]
+        # ---- per-sequence state and work buffers (device resident)
+        self.uniforms = torch.rand((B, 64 * (cfg.max_steps + 8)), generator=g, device=device, dtype=torch.float64)
+        self.cursor = torch.zeros(B, dtype=torch.int32, device=device)
+        self.u_bonus = torch.rand((cfg.max_steps, B), generator=g, device=device, dtype=torch.float64)
+        self.first_token = torch.randint(IMG_LO, IMG_HI, (B,), generator=g, device=device)
+        i64 = lambda *sh: torch.empty(sh, dtype=torch.int64, device=device)
+        self.draft, self.pos, self.ret = i64(B, N), i64(B, N), i64(B, N, N)
+        self.mask = torch.empty((B, N, N), dtype=torch.float32, device=device)
+        self.nleaf = torch.empty(B, dtype=torch.int32, device=device)
+        self.mdepth = torch.empty(B, dtype=torch.int32, device=device)
+        self.cand, self.ret_pd, self.pos_abs = i64(B, self.P, self.D), i64(B, self.P, self.D), i64(B, N)
+        self.row_index = torch.empty((B, self.P, self.D), dtype=torch.int32, device=device)
+        self.win = torch.empty((B, N, W), dtype=torch.float32, device=device)
+        self.hot = torch.empty((B, N), dtype=torch.int32, device=device)
+        self.out_hidden = torch.empty((B, 2, self.D, HIDDEN), dtype=torch.bfloat16, device=device)
+        self.acc_tokens = i64(B, self.D)
+        self.out_tok = torch.empty(B, dtype=torch.int32, device=device)
+        self.out_mass = torch.empty(B, dtype=torch.float32, device=device)
+        self.log_best = torch.zeros((cfg.max_steps, B), dtype=torch.int32, device=device)
+        self.log_alen = torch.zeros((cfg.max_steps, B), dtype=torch.int32, device=device)
+        self.log_cnt = torch.zeros((cfg.max_steps, B, 6), dtype=torch.int32, device=device)
+        self.log_token = torch.zeros((cfg.max_steps, B), dtype=torch.int64, device=device)
+        base = torch.cat([torch.full((B,), cfg.prompt_len + 3, dtype=torch.int64), torch.full((B,), 3, dtype=torch.int64)]).to(device)
+        self.len_base, self.lens = base, [base.clone(), base.clone()]
+        self.slabs: List[torch.Tensor] = []
+        if cfg.with_kv:
+            shape = (2 * cfg.kv_layers, 1, cfg.kv_heads, cfg.kv_smax + cfg.kv_pad_rows, cfg.kv_dim)
+            need = 2 * B * int(np.prod(shape)) * 2
+            free, _t = torch.cuda.mem_get_info(device)
+            if need + (8 << 30) > free:
+                raise _lib.LanternError(f"KV slabs need {need / 2**30:.0f} GiB (+8 GiB head-room), {free / 2**30:.0f} GiB free")
+            for _ in range(2 * B):
+                self.slabs.append(torch.zeros(shape, dtype=torch.bfloat16, device=device))
+            self.slab_ptrs = torch.tensor([s.data_ptr() for s in self.slabs], dtype=torch.int64, device=device)
+            self.slab_seq = torch.arange(B, dtype=torch.int32, device=device).repeat(2)
+        self._L = _lib.lib()
+        p = EpParams()
+        p.B, p.P, p.D, p.V, p.rows_per_seq = B, self.P, self.D, V, N
+        p.mode, p.syntax_shortcut, p.tok_offset = ops.MODE_DYNAMIC, 1, 4
+        p.img_lo, p.img_hi, p.n_syntax = IMG_LO, IMG_HI, 4
+        for i, sx in enumerate((8196, 8197, 8803, 8828)):
+            p.syntax[i] = sx
+        p.lantern, p.k, p.delta = 1, cfg.lantern_k, cfg.lantern_delta
+        p.table_rows, p.table_cols = K_CODES, self.table_cols
+        p.top_k, p.temperature, p.top_p = 0, 1.0, 1.0
+        p.n_uniforms, p.row_index_per_seq = self.uniforms.shape[1], 1
+        self._prm = p
+        b = EpBuffers()
+        b.logits, b.row_index, b.cand = self.win.data_ptr(), self.row_index.data_ptr(), self.cand.data_ptr()
+        b.n_paths, b.n_depth = self.nleaf.data_ptr(), self.mdepth.data_ptr()
+        b.nn_table, b.uniforms, b.cursor = self.table.data_ptr(), self.uniforms.data_ptr(), self.cursor.data_ptr()
+        self._buf = b
+        w = EpWindow()
+        w.win_lo, w.win_len, w.row_hot = IMG_LO, W, self.hot.data_ptr()
+        w.out_tok, w.out_mass, w.rows_kind = self.out_tok.data_ptr(), self.out_mass.data_ptr(), ops.ROWS_PROBS
+        self._win = w
+        self._bases = dict(best=self.log_best.data_ptr(), alen=self.log_alen.data_ptr(), cnt=self.log_cnt.data_ptr(),
+                           tok=self.log_token.data_ptr(), ub=self.u_bonus.data_ptr())
+        self.step_idx, self._len_ub = 0, 0
+
+    def release_kv(self):
+        self.slabs, self.slab_ptrs = [], None
+        torch.cuda.empty_cache()
+
+    def step(self, events=None):
+        c, L, vp = self.cfg, self._L, C.c_void_p
+        i = self.step_idx
+        if i >= c.max_steps:
+            raise _lib.LanternError(f"step {i} >= max_steps {c.max_steps}")
+        B, N, P, D = c.n_seq, self.N, self.P, self.D
+        pool = self.pools[i % c.pool_steps]
+        cur, nxt = self.lens[i & 1], self.lens[(i & 1) ^ 1]
+        st = vp(torch.cuda.current_stream().cuda_stream)
+        bs, e = self._bases, i * B
+        p_sample = self.first_token.data_ptr() if i == 0 else bs["tok"] + 8 * (e - B)
+        arm = lambda name: events and check(L.lantern_profile_next_launch(vp(events[name][0].cuda_event), vp(events[name][1].cuda_event)), "profile")
+        check(L.lantern_tree_dynamic_finalize(vp(pool["scores"].data_ptr()), vp(pool["tokens"].data_ptr()), vp(pool["parents"].data_ptr()),
+                                              vp(p_sample), B, self.n_scores, self.n_parents, c.top_k, c.total_tokens, 1, vp(self.draft.data_ptr()),
+                                              vp(self.mask.data_ptr()), vp(self.pos.data_ptr()), vp(self.ret.data_ptr()), vp(self.nleaf.data_ptr()),
+                                              vp(self.mdepth.data_ptr()), st), "tree_dynamic_finalize")
+        check(L.lantern_gather_candidates_dynamic(vp(self.draft.data_ptr()), vp(self.ret.data_ptr()), vp(self.pos.data_ptr()), vp(cur.data_ptr()), B, N,
+                                                  P, D, vp(self.cand.data_ptr()), vp(self.ret_pd.data_ptr()), vp(self.row_index.data_ptr()),
+                                                  vp(self.pos_abs.data_ptr()), st), "gather_candidates_dynamic")
+        arm("cfg_mask_topk")
+        check(L.lantern_cfg_mask_topk_window(vp(pool["cond"].data_ptr()), vp(pool["unc"].data_ptr()), 1, B * N, V, C.c_float(c.cfg_scale),
+                                             ops.MODEL_LUMINA, vp(self.pos_abs.data_ptr()), C.c_int64(c.prompt_len + 3), W_LATENT, H_LATENT, IMG_LO,
+                                             IMG_HI, NEWLINE, EOS, c.logit_top_k, None, 0, IMG_LO, self.W, vp(self.win.data_ptr()),
+                                             vp(self.hot.data_ptr()), ops.ROWS_PROBS, C.c_float(1.0), C.c_float(1.0), st), "cfg_mask_topk_window")
+        b, w = self._buf, self._win
+        b.best, b.accept_len, b.counters = bs["best"] + 4 * e, bs["alen"] + 4 * e, bs["cnt"] + 24 * e
+        w.u_bonus, w.token = bs["ub"] + 8 * e, bs["tok"] + 8 * e
+        arm("evaluate_posterior")
+        check(L.lantern_evaluate_posterior_window(C.byref(self._prm), C.byref(b), C.byref(w), st), "evaluate_posterior_window")
+        if c.with_kv:
+            arm("kv_gather")
+            check(L.lantern_update_inference_inputs(vp(self.slab_ptrs.data_ptr()), vp(self.slab_seq.data_ptr()), vp(cur.data_ptr()), 2 * B, 2,
+                                                    C.c_int64(2 * c.kv_layers * c.kv_heads), C.c_int64(c.kv_smax + c.kv_pad_rows), C.c_int64(c.kv_dim),
+                                                    vp(self.ret_pd.data_ptr()), 1, P, D, vp(b.best), vp(b.accept_len), vp(nxt.data_ptr()),
+                                                    vp(pool["hidden"].data_ptr()), 2, B, 2, N, HIDDEN, vp(self.cand.data_ptr()),
+                                                    vp(self.out_hidden.data_ptr()), vp(self.acc_tokens.data_ptr()), st), "update_inference_inputs")
+        else:
+            torch.add(cur, (self.log_alen[i] + 1).repeat(2), out=nxt)
+        self._len_ub += D
+        if self._len_ub >= TOKENS_PER_IMAGE:      # an image can end: wrap those sequences (host bound refreshed every few hundred steps)
+            torch.where(nxt - self.len_base >= TOKENS_PER_IMAGE, self.len_base, nxt, out=nxt)
+            self._len_ub = int((nxt - self.len_base).max().item())
+        self.step_idx += 1
+
+    def accepted_tokens(self, i0: int, i1: int) -> int:
+        return int((self.log_alen[i0:i1].to(torch.int64) + 1).sum().item())
+
+    def check_status(self, i0: int, i1: int):
+        stt = self.log_cnt[i0:i1, :, 5]
+        if int(stt.abs().sum().item()) != 0:
+            bad = torch.nonzero(stt)[0].tolist()
+            raise _lib.LanternError(f"evaluate_posterior status {int(stt[bad[0], bad[1]])} at step {i0 + bad[0]} seq {bad[1]}")

@@ -60,3 +60,47 @@ def test_kv_rows_follow_the_accepted_path():
         keep = torch.ones(s.shape[-2], dtype=torch.bool)
         keep[p:p + n] = False
         assert torch.equal(s[..., keep.cuda(), :], b0[..., keep.cuda(), :])
+
+
+def test_dynamic_tree_loop_matches_oracle_loop():
+    """The device-resident EAGLE-2 loop (O4 -> O6 dynamic -> O7 -> O8 dynamic -> O9 + O10, a different tree per sequence and
+    step) against the oracle's loop over the same pools / uniforms: identical (best path, accept length, bonus token), every
+    step, every sequence; KV lengths advance by exactly the accepted tokens."""
+    import numpy as np
+    import oracle
+    from lantern_amd import harness as HN
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import helpers as H
+    steps = 8
+    cfg = HN.DynamicConfig(n_seq=3, pool_steps=2, kv_layers=2, kv_heads=4, kv_smax=512, max_steps=steps + 2, lantern_k=300)
+    wl = HN.DynamicVerifyWorkload(cfg, torch.device("cuda"))
+    for _ in range(steps):
+        wl.step()
+    torch.cuda.synchronize()
+    wl.check_status(0, steps)
+    gb, ga, gt = wl.log_best[:steps].cpu().numpy(), wl.log_alen[:steps].cpu().numpy(), wl.log_token[:steps].cpu().numpy()
+    table = wl.table_full.cpu().numpy().view(np.uint16)
+    uni, ub = wl.uniforms.cpu().numpy(), wl.u_bonus.cpu().numpy()
+    ocfg = oracle.EpConfig.lumina(False, lantern=True, k=cfg.lantern_k, delta=cfg.lantern_delta)
+    N = wl.N
+    n_acc = 0
+    for b in range(cfg.n_seq):
+        tok, cursor, lens = int(wl.first_token[b]), 0, [cfg.prompt_len + 3, 3]
+        for i in range(steps):
+            p = wl.pools[i % cfg.pool_steps]
+            draft, ret, mask, pos = oracle.tree_dynamic_finalize(p["scores"][b].cpu().numpy(), p["tokens"][b].cpu().numpy(), p["parents"][b].cpu().numpy(),
+                                                                 cfg.top_k, cfg.total_tokens, tok)
+            cand = np.where(ret >= 0, draft[np.clip(ret, 0, None)], -1)
+            proc = oracle.cfg_mask_topk(p["cond"][b].cpu().view(torch.int16).numpy().view(np.uint16), p["unc"][b].cpu().view(torch.int16).numpy().view(np.uint16),
+                                        cfg.cfg_scale, model=oracle.MODEL_LUMINA, pos_ids=pos + 1 + lens[0], pos_base=cfg.prompt_len + 3, w=HN.W_LATENT,
+                                        h=HN.H_LATENT, img_lo=HN.IMG_LO, img_hi=HN.IMG_HI, newline_id=HN.NEWLINE, eos_id=HN.EOS, top_k=cfg.logit_top_k, bf16=True)
+            best, alen, sp, cnt = oracle.evaluate_posterior(ocfg, proc, H.row_index_from_retrieve(ret, N), cand, uni[b, cursor:cursor + 64], table=table)
+            cursor += int(cnt[3])
+            tok = oracle.sample_inverse_cdf(sp, float(ub[i, b]))
+            assert (int(gb[i, b]), int(ga[i, b]), int(gt[i, b])) == (best, alen, tok), (b, i)
+            lens = [l + alen + 1 for l in lens]
+            n_acc += alen
+    assert n_acc > 0                                   # the walk really accepts drafted tokens
+    gen = (ga.astype("int64") + 1).sum(0)
+    assert (wl.lens[steps & 1][:cfg.n_seq].cpu().numpy() == cfg.prompt_len + 3 + gen).all()
+    assert (wl.lens[steps & 1][cfg.n_seq:].cpu().numpy() == 3 + gen).all()

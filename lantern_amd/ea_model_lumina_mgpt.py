@@ -347,6 +347,7 @@ class EaLumina_mGPT(nn.Module):
             if self.cfg_mode == "parallel":
                 tree_mask = tree_mask.repeat(2, 1, 1, 1)
         new_token = 0
+        self._uniforms().begin()          # the acceptance uniforms of this prompt start at random's current position
         while new_token < max_new_tokens:
             if self.eagle_version == 1:
                 candidates, cart_candidates_prob, tree_candidates = self.generate_candidates(
@@ -385,6 +386,7 @@ class EaLumina_mGPT(nn.Module):
                 break
             if input_ids.shape[1] > max_length:
                 break
+        self._uniforms().end()            # unconsumed staged draws go back to the module-level stream
         return input_ids, accept_length_list
 
     # BASELINE.json's north_star calls the entry point `eagenerate`; the reference names it `generate`

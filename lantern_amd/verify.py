@@ -22,19 +22,48 @@ class UniformFifo:
     kernel cannot call back into Python, so a window of the SAME stream is staged on the device and
     consumed through a device cursor; values are drawn from `random` in order, so the sequence of
     uniforms the acceptance tests see is exactly the reference's.  Host syncs only when the window
-    may run out (every ~window/max_per_step steps)."""
+    may run out (every ~window/max_per_step steps).
+
+    begin() / end() bracket one generate(): begin() stages from the stream's CURRENT position (a
+    `random.seed()` between two prompts is honoured), end() puts the module-level generator back
+    exactly where the reference's own draws would have left it -- the staged but unconsumed values
+    are returned to the stream."""
 
     def __init__(self, device, window: int = 4096, rng=None):
         self.device, self.window = device, window
         self.rng = rng if rng is not None else random
-        self.values: List[float] = [self.rng.random() for _ in range(window)]
-        self.buf = torch.tensor(self.values, dtype=torch.float64, device=device).reshape(1, window)
+        self.buf = torch.zeros((1, window), dtype=torch.float64, device=device)
         self.cursor = torch.zeros(1, dtype=torch.int32, device=device)
         self.upper = 0  # host-side upper bound of the cursor
+        self.active = False
+        self.values: List[float] = []
+        self._state0, self._consumed = None, 0
+
+    def begin(self):
+        self._state0, self._consumed = self.rng.getstate(), 0
+        self.values = [self.rng.random() for _ in range(self.window)]
+        self.buf.copy_(torch.tensor(self.values, dtype=torch.float64).reshape(1, self.window))
+        self.cursor.zero_()
+        self.upper = 0
+        self.active = True
+
+    def end(self) -> int:
+        """Returns the number of uniforms the kernels consumed since begin()."""
+        if not self.active:
+            return 0
+        total = self._consumed + int(self.cursor.item())
+        self.rng.setstate(self._state0)
+        for _ in range(total):
+            self.rng.random()
+        self.active = False
+        return total
 
     def reserve(self, max_draws: int):
+        if not self.active:
+            self.begin()
         if self.upper + max_draws > self.window:
             used = int(self.cursor.item())          # the only sync
+            self._consumed += used
             self.values = self.values[used:] + [self.rng.random() for _ in range(used)]
             self.buf.copy_(torch.tensor(self.values, dtype=torch.float64).reshape(1, self.window))
             self.cursor.zero_()

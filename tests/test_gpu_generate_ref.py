@@ -1,0 +1,85 @@
+"""GPU (-m gpu): the mirror's EaLumina_mGPT.generate against what the REFERENCE's own generate / initialize_tree produced for
+the same scripted target model and drafter (tests/golden/generate.npz, made by make_golden_generate.py in the build container):
+token ids, accept-length list, KV lengths, the drafter's call log, and the number of uniforms drawn from `random` -- exact."""
+import os
+import random
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+import gen_fakes as F  # noqa: E402
+from lantern_amd.drafters.choices import mc_sim_7b_63  # noqa: E402
+from lantern_amd.ea_model_lumina_mgpt import EaLumina_mGPT  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+GOLD = np.load(os.path.join(ROOT, "tests", "golden", "generate.npz"))
+_T = {}
+
+
+def tables():
+    if not _T:
+        _T.update(F.tables())
+    return _T
+
+
+def run_case(case, kernel_set="window"):
+    dev = torch.device("cuda")
+    T = tables()
+    base, drafter = F.make_base(T, dev), F.Drafter(T, dev)
+    table = torch.from_numpy(T["nb"].astype(np.uint16).view(np.int16)).to(dev)
+    mdl = EaLumina_mGPT(base, drafter, table, cfg_mode=case["cfg_mode"], eagle_version=1)
+    mdl.kernel_set = kernel_set
+    mdl.uniform_window = 128                       # small window: the refill path runs too
+    g = lambda k: GOLD[case["name"] + "." + k]
+    draws = F.DetDraws(g("bonus_uniforms"))
+    random.seed(case["seed"])
+    old_m, old_r = torch.multinomial, torch.rand
+    torch.multinomial, torch.rand = draws.multinomial, draws.rand
+    try:
+        ids, alens = mdl.generate(torch.tensor([F.PROMPT], device=dev), max_new_tokens=case["max_new"], cfg_scale=3.0, top_k=2000,
+                                  logits_processors=[None], lantern=case["lantern"], lantern_k=case["k"], lantern_delta=case["delta"],
+                                  tree_choices=mc_sim_7b_63)
+    finally:
+        torch.multinomial, torch.rand = old_m, old_r
+    return mdl, drafter, draws, ids, alens
+
+
+@pytest.mark.parametrize("case", F.CASES, ids=[c["name"] for c in F.CASES])
+@pytest.mark.parametrize("kernel_set", ["window", "dense"])
+def test_generate_reproduces_the_reference_run(case, kernel_set):
+    mdl, drafter, draws, ids, alens = run_case(case, kernel_set)
+    g = lambda k: GOLD[case["name"] + "." + k]
+    assert ids[0].cpu().numpy().tolist() == g("ids").tolist()
+    assert list(alens) == g("accept_lengths").tolist()
+    assert draws.n == int(g("n_bonus_draws"))
+    cl = mdl.current_length_data
+    got = [int(cl[k][0]) for k in ("cond", "uncond")] if isinstance(cl, dict) else [int(cl[0])]
+    assert got == g("kv_len").tolist()
+    assert [(t, p) for t, p, _ in drafter.calls] == [tuple(x) for x in g("drafter_calls").tolist()]
+    # the module-level generator ends where the reference's own random.random() calls left it
+    st = random.getstate()
+    random.seed(case["seed"])
+    for _ in range(int(g("n_accept_uniforms"))):
+        random.random()
+    assert random.getstate() == st
+
+
+def test_generate_twice_under_one_seed_is_one_stream():
+    """A reseed between two prompts on ONE model object is honoured (the staged uniforms are not stale)."""
+    case = F.CASES[0]
+    mdl, _, _, ids1, al1 = run_case(case)
+    draws = F.DetDraws(GOLD[case["name"] + ".bonus_uniforms"])
+    random.seed(case["seed"])
+    old_m, old_r = torch.multinomial, torch.rand
+    torch.multinomial, torch.rand = draws.multinomial, draws.rand
+    try:
+        ids2, al2 = mdl.generate(torch.tensor([F.PROMPT], device="cuda"), max_new_tokens=case["max_new"], cfg_scale=3.0, top_k=2000,
+                                 logits_processors=[None], lantern=case["lantern"], lantern_k=case["k"], lantern_delta=case["delta"],
+                                 tree_choices=mc_sim_7b_63)
+    finally:
+        torch.multinomial, torch.rand = old_m, old_r
+    assert torch.equal(ids1, ids2) and list(al1) == list(al2)

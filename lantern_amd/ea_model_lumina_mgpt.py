@@ -15,6 +15,8 @@ from __future__ import annotations
 
 from typing import Optional
 
+import types
+
 import numpy as np
 import torch
 import torch.nn as nn
@@ -189,31 +191,38 @@ class EaLumina_mGPT(nn.Module):
         if self.kernel_set == "window":
             win, hot = ops.cfg_mask_topk_window(tree_logits[0], uncond_tree_logits[0], float(self.cfg_scale), IMAGE_LO,
                                                 IMAGE_HI - IMAGE_LO, probs=True, **kw)
-            return WindowRows(win, hot, retrieve_indices, tree_logits.shape[-1], IMAGE_LO), hidden_states, uncond_hidden_states
+            wr = WindowRows(win, hot, retrieve_indices, tree_logits.shape[-1], IMAGE_LO)
+            # what the dense kernel set would need for the same step (only built if the windowed kernel asks for it)
+            wr.dense_source = lambda: NodeLogits(ops.cfg_mask_topk(tree_logits[0], uncond_tree_logits[0], float(self.cfg_scale), **kw), retrieve_indices)
+            return wr, hidden_states, uncond_hidden_states
         node_logits = ops.cfg_mask_topk(tree_logits[0], uncond_tree_logits[0], float(self.cfg_scale), **kw)
         return NodeLogits(node_logits, retrieve_indices), hidden_states, uncond_hidden_states
 
     # ------------------------------------------------------------------ O8, :610-729
-    def evaluate_posterior(self, logits, candidates, cart_candidates_prob=None, original_prob=None, p_indices=None,
-                           tree_candidates=None, b_indices=None, do_sample=True, lantern=False, lantern_k=1000,
-                           lantern_delta=0.1):
-        if not do_sample:
-            raise NotImplementedError("Greedy decoding is not implemented yet")   # same as the reference (:728-729)
+    def _ep_config(self, lantern, lantern_k, lantern_delta) -> ops.EpConfig:
+        # the id ranges live in device tensors (as in the reference); read them back once per tensor, not once per step
+        key = (id(self.image_tokens), id(self.image_syntax_tokens))
+        if getattr(self, "_range_key", None) != key:
+            self._range_key = key
+            self._img_range = (int(self.image_tokens[0]), int(self.image_tokens[-1]) + 1)
+            self._syntax = tuple(int(x) for x in self.image_syntax_tokens.tolist())
+        cfg = ops.EpConfig.lumina(self.eagle_version == 1, lantern=bool(lantern), k=int(lantern_k), delta=float(lantern_delta))
+        cfg.img_lo, cfg.img_hi = self._img_range
+        cfg.syntax, cfg.tok_offset = self._syntax, self.image_token_offset
+        return cfg
+
+    def _posterior_on_device(self, logits, candidates, cart_candidates_prob, original_prob, tree_candidates, lantern, lantern_k,
+                             lantern_delta, u_bonus=None, force_dense=False):
+        """evaluate_posterior with every result left on the device: dict(best, accept_len, counters, sample_p | None, token | None).
+        Windowed rows + u_bonus: the bonus token is drawn inside the kernel and sample_p never exists."""
         static = self.eagle_version == 1
-        windowed = isinstance(logits, WindowRows)
+        windowed = isinstance(logits, WindowRows) and not force_dense
+        if isinstance(logits, WindowRows) and force_dense:
+            logits = logits.dense_rows()
         rows, row_index = (logits.win, logits.row_index()) if windowed else as_rows(logits)
-        cfg = ops.EpConfig.lumina(static, lantern=bool(lantern), k=int(lantern_k), delta=float(lantern_delta))
-        cfg.img_hi = int(self.image_tokens[-1]) + 1
-        cfg.img_lo = int(self.image_tokens[0])
-        cfg.syntax = tuple(int(x) for x in self.image_syntax_tokens.tolist())
-        cfg.tok_offset = self.image_token_offset
+        cfg = self._ep_config(lantern, lantern_k, lantern_delta)
         aux = None
         if static:
-            assert cart_candidates_prob is not None, "Cartesian candidate probabilities are required for EAGLE v1"
-            assert original_prob is not None, "Original probabilities are required for EAGLE v1"
-            assert tree_candidates is not None, "Tree candidates are required for EAGLE v1"
-            assert p_indices is not None, "Parent indices are required for EAGLE v1"
-            assert b_indices is not None, "B indices are required for EAGLE v1"
             hip = self.tree_buffers["_hip"]
             aux = ops.StaticAux(cart_prob=cart_candidates_prob.to(rows.device).float()[None], orig_prob=concat_original_prob(original_prob),
                                 op_off=hip["op_off"], p_idx=hip["p_idx"], b_off=hip["b_off"], b_idx=hip["b_idx"],
@@ -223,15 +232,42 @@ class EaLumina_mGPT(nn.Module):
         if windowed:
             out = ops.evaluate_posterior_window(cfg, logits.V, rows[None], logits.win_lo, row_index, candidates[None], fifo.buf,
                                                 row_hot=logits.row_hot[None], table=self._packed_table(int(lantern_k)) if lantern else None,
-                                                aux=aux, cursor=fifo.cursor, want_dense=True, want_window=False, rows_probs=True)
-            best, alen, sample_p, counters = out["best"], out["accept_len"], out["sample_p"], out["counters"]
-        else:
-            best, alen, sample_p, counters = ops.evaluate_posterior(cfg, rows.float()[None], row_index, candidates[None], fifo.buf,
-                                                                    table=self.nearest_latents if lantern else None, aux=aux,
-                                                                    cursor=fifo.cursor)
-        self._last = (best, alen, counters)          # device copies for update_inference_inputs (no re-upload)
-        ops.raise_on_status(counters)                # host sync: the B=1 driver needs accept_length on the host anyway
-        return best[0].to(torch.int64), int(alen[0]), sample_p[0]
+                                                aux=aux, cursor=fifo.cursor, u_bonus=u_bonus, want_dense=u_bonus is None, want_window=False,
+                                                rows_probs=True)
+            return dict(best=out["best"], accept_len=out["accept_len"], counters=out["counters"], sample_p=out["sample_p"], token=out["token"])
+        best, alen, sample_p, counters = ops.evaluate_posterior(cfg, rows.float()[None], row_index, candidates[None], fifo.buf,
+                                                                table=self.nearest_latents if lantern else None, aux=aux, cursor=fifo.cursor)
+        return dict(best=best, accept_len=alen, counters=counters, sample_p=sample_p, token=None)
+
+    # statuses of the windowed kernel the dense kernel does not have (the residual vanished, uniforms / tree beyond its LDS staging)
+    _RETRY_DENSE = (2, 6, 7, 8)
+
+    def evaluate_posterior(self, logits, candidates, cart_candidates_prob=None, original_prob=None, p_indices=None,
+                           tree_candidates=None, b_indices=None, do_sample=True, lantern=False, lantern_k=1000,
+                           lantern_delta=0.1):
+        if not do_sample:
+            raise NotImplementedError("Greedy decoding is not implemented yet")   # same as the reference (:728-729)
+        if self.eagle_version == 1:
+            assert cart_candidates_prob is not None, "Cartesian candidate probabilities are required for EAGLE v1"
+            assert original_prob is not None, "Original probabilities are required for EAGLE v1"
+            assert tree_candidates is not None, "Tree candidates are required for EAGLE v1"
+            assert p_indices is not None, "Parent indices are required for EAGLE v1"
+            assert b_indices is not None, "B indices are required for EAGLE v1"
+        fifo = self._uniforms()
+        if not fifo.active:
+            fifo.begin()
+        cur0 = fifo.cursor.clone()
+        out = self._posterior_on_device(logits, candidates, cart_candidates_prob, original_prob, tree_candidates, lantern, lantern_k, lantern_delta)
+        status = int(out["counters"][0, 5])          # host sync: the B=1 caller wants accept_length as a Python int anyway
+        if status in self._RETRY_DENSE and isinstance(logits, WindowRows):
+            # the windowed kernel reported a state only the dense kernel represents: same step again on the dense HIP kernel,
+            # from the same position of the uniform stream (HIP -> HIP; there is no CPU path)
+            fifo.cursor.copy_(cur0)
+            out = self._posterior_on_device(logits, candidates, cart_candidates_prob, original_prob, tree_candidates, lantern, lantern_k,
+                                            lantern_delta, force_dense=True)
+        self._last = (out["best"], out["accept_len"], out["counters"])          # device copies for update_inference_inputs (no re-upload)
+        ops.raise_on_status(out["counters"])
+        return out["best"][0].to(torch.int64), int(out["accept_len"][0]), out["sample_p"][0]
 
     # ------------------------------------------------------------------ O9 + O10, :731-799
     def update_inference_inputs(self, input_ids, attention_mask, candidates, best_candidate, accept_length, retrieve_indices,
@@ -286,108 +322,187 @@ class EaLumina_mGPT(nn.Module):
         return input_ids, output, new_token, token
 
     # ------------------------------------------------------------------ :801-1017
+    # The decode driver.  Same observable behaviour as the reference's generate() (tests/golden/generate.npz pins ids, accept
+    # lengths, KV lengths, drafter calls and the RNG position), organised for the device: a step's results -- best path, accept
+    # length, status, accepted tokens, bonus token, new KV lengths -- stay in HBM and feed the KV gather / hidden gather there;
+    # the host reads ONE packed 5-int record per step (it needs the accept length to slice the drafter's inputs), where the
+    # reference's loop syncs on every tried candidate.
+    def _prepare_generation(self, input_ids, cfg_scale, top_k, drafter_top_k, tree_choices):
+        self.cfg_scale = self.ea_layer.cfg_scale = cfg_scale
+        self.internal_logits_processors = [self.internal_logits_processors[0], InterleavedTopKLogitsWarper(image_top_k=top_k)]
+        self.drafter_logits_processors = [self.drafter_logits_processors[0], InterleavedTopKLogitsWarper(image_top_k=drafter_top_k or top_k)]
+        self.eval()
+        self.ea_layer.reset_kv()
+        dev = self.base_model.lm_head.weight.device
+        static, parallel = self.eagle_version == 1, self.cfg_mode == "parallel"
+        if static and getattr(self, "tree_choices", None) != tree_choices:
+            tb = generate_tree_buffers(tree_choices, device=dev)
+            tb["retrieve_indices_head"] = tb["retrieve_indices"]
+            if parallel:
+                tb["tree_attn_mask"] = torch.cat((tb["tree_attn_mask"], tb["tree_attn_mask"]), dim=0)
+            self.tree_buffers, self.tree_choices = tb, tree_choices
+        if not hasattr(self, "past_key_values"):
+            if parallel:
+                self.past_key_values, self.past_key_values_data, self.current_length_data = initialize_past_key_values(self.base_model, batch_size=2)
+            else:
+                self.past_key_values, self.past_key_values_data, self.current_length_data = {}, {}, {}
+                for key in ("cond", "uncond"):
+                    self.past_key_values[key], self.past_key_values_data[key], self.current_length_data[key] = \
+                        initialize_past_key_values(self.base_model)
+        for cl in ([self.current_length_data] if parallel else self.current_length_data.values()):
+            cl.zero_()
+        ids = torch.cat((input_ids, torch.tensor([[8197, 8828, 8828]], dtype=torch.long, device=input_ids.device)), dim=-1)
+        self.reset_tree_mode()
+        self.image_start_token_id_index = int(torch.where(ids[0] == self.image_start_token_id)[0][-1])
+        L, P0 = ids.shape[1], self.image_start_token_id_index
+        attn = torch.ones((2, L), dtype=torch.bool, device=ids.device)
+        attn[1, :P0] = False                       # the unconditional row does not see the prompt
+        st = types.SimpleNamespace(input_ids=ids.repeat(2, 1) if parallel else ids, attn_mask=attn, input_len=L, new_token=0, accept_lengths=[],
+                                   static=static, parallel=parallel)
+        # the KV slabs of this model, flat, with the prompt offset of each (cond slabs see the whole sequence, uncond slabs the image part)
+        if parallel:
+            st.slabs, st.offsets, st.len_tensors = list(self.past_key_values_data), [0] * len(self.past_key_values_data), None
+        else:
+            st.slabs = list(self.past_key_values_data["cond"]) + list(self.past_key_values_data["uncond"])
+            st.offsets = [0] * len(self.past_key_values_data["cond"]) + [P0] * len(self.past_key_values_data["uncond"])
+        sdev = st.slabs[0].device
+        st.slab_ptrs = torch.tensor([x.data_ptr() for x in st.slabs], dtype=torch.int64, device=sdev)
+        st.slab_seq = torch.zeros(len(st.slabs), dtype=torch.int32, device=sdev)
+        st.slab_off = torch.tensor(st.offsets, dtype=torch.int64, device=sdev)
+        return st
+
+    def _first_draft(self, st, logits_processors):
+        if st.static:
+            tb = self.tree_buffers
+            st.tree_logits, st.sample_token = self.initialize_tree(input_ids=st.input_ids, attention_mask=st.attn_mask,
+                                                                   tree_attn_mask=tb["tree_attn_mask"], past_key_values=self.past_key_values,
+                                                                   logits_processors=logits_processors)
+            st.tree_position_ids, st.retrieve_indices = tb["tree_position_ids"], tb["retrieve_indices_head"]
+        else:
+            self._take_dynamic_draft(st, self.initialize_tree(input_ids=st.input_ids, attention_mask=st.attn_mask,
+                                                              past_key_values=self.past_key_values, logits_processors=logits_processors))
+
+    def _take_dynamic_draft(self, st, output):
+        st.tree_candidates, st.retrieve_indices, st.tree_mask, st.tree_position_ids = output
+        if st.parallel:
+            st.tree_mask = st.tree_mask.repeat(2, 1, 1, 1)
+
+    def _verify_step(self, st, lantern, lantern_k, lantern_delta, eos_token_ids):
+        dev = st.retrieve_indices.device
+        # ---- O6 + target forward + O7
+        if st.static:
+            tb = self.tree_buffers
+            candidates, cart_prob, tree_candidates = self.generate_candidates(tree_logits=st.tree_logits, tree_indices=tb["tree_indices"],
+                                                                              retrieve_indices=tb["retrieve_indices"], sample_token=st.sample_token)
+            original_prob = st.tree_logits[2]
+        else:
+            self.base_model.model.tree_mask = st.tree_mask
+            tree_candidates = st.tree_candidates.to(st.input_ids.device)
+            cart_prob = original_prob = None
+        rows, hidden, uhidden = self.tree_decoding(tree_candidates=tree_candidates, attention_mask=st.attn_mask, past_key_values=self.past_key_values,
+                                                   tree_position_ids=st.tree_position_ids, input_ids=st.input_ids,
+                                                   retrieve_indices=st.retrieve_indices)
+        if not st.static:
+            ext = torch.cat((tree_candidates, tree_candidates.new_full((1, 1), -1)), dim=1)
+            candidates = ext[0, st.retrieve_indices]
+            tree_candidates = ext
+        # ---- O8 (+ bonus token), results on the device
+        fifo = self._uniforms()
+        cur0 = fifo.cursor.clone()
+        u = torch.rand(1, dtype=torch.float64, device=dev)
+        ep = self._posterior_on_device(rows, candidates, cart_prob, original_prob, tree_candidates, lantern, lantern_k, lantern_delta,
+                                       u_bonus=u if isinstance(rows, WindowRows) else None)
+        best, alen, status = ep["best"], ep["accept_len"], ep["counters"][:, 5]
+        # ---- O9 + O10 for every slab in one launch, from the device-side (best, accept_len); a failed walk commits nothing
+        L = st.input_ids.shape[1]
+        alen_commit = torch.where(status == 0, alen, torch.full_like(alen, -1))
+        hid = torch.stack([hidden[0], uhidden[0]])[None]                                     # [1, 2, N, H]
+        prev = (L - st.slab_off).to(st.slabs[0].device)
+        new_len, out_h, acc = ops.update_inference_inputs(st.slabs, st.slab_seq, prev, st.retrieve_indices.to(st.slabs[0].device),
+                                                          best.to(st.slabs[0].device), alen_commit.to(st.slabs[0].device), hid,
+                                                          candidates[None], slab_ptrs=st.slab_ptrs)
+        token = ep["token"]
+        if token is None:
+            _, _, token = ops.accept_gather(None, st.retrieve_indices, None, best, alen, sample_p=ep["sample_p"].float(), u=u)
+        eos_hit = torch.zeros(1, dtype=torch.int64, device=dev)
+        if eos_token_ids is not None:
+            live = torch.arange(acc.shape[1], device=acc.device)[None] <= alen_commit.to(acc.device)[:, None]
+            eos_hit = ((acc == eos_token_ids) & live).any().to(torch.int64).reshape(1).to(dev)
+        # ---- the step's one host read
+        a, bst, stt, tok, eos = torch.cat((alen.to(torch.int64), best.to(torch.int64), status.to(torch.int64), token.to(torch.int64), eos_hit)).tolist()
+        if stt != 0:
+            if stt in self._RETRY_DENSE and isinstance(rows, WindowRows):
+                # a state only the dense kernel represents: the same step on the dense HIP kernel, from the same uniforms,
+                # through the host-int path (rare: once in millions of steps)
+                fifo.cursor.copy_(cur0)
+                bc, al, sample_p = self.evaluate_posterior(rows.dense_rows(), candidates, cart_prob, original_prob, self.tree_buffers["p_indices"] if st.static else None,
+                                                           tree_candidates, self.tree_buffers["b_indices"] if st.static else None, True, lantern,
+                                                           lantern_k, lantern_delta)
+                return self._commit_from_host(st, candidates, bc, al, hidden, uhidden, sample_p, u)
+            ops.raise_on_status(ep["counters"])
+        n = a + 1
+        for cl, off in zip(self._length_tensors(st), st.offsets):
+            cl.fill_(L - off + n)
+        accepted = acc[:, :n].to(st.input_ids.device)
+        st.input_ids = torch.cat([st.input_ids[None, 0] if st.parallel else st.input_ids, accepted], dim=-1)
+        self._draft_next(st, out_h[:, 0, :n], out_h[:, 1, :n], torch.tensor([[tok]], device=dev))
+        st.new_token += n
+        st.accept_lengths.append(n)
+        return bool(eos)
+
+    def _length_tensors(self, st):
+        if st.parallel:
+            return [self.current_length_data] * len(st.slabs)
+        nc = len(self.past_key_values_data["cond"])
+        return [self.current_length_data["cond"]] * nc + [self.current_length_data["uncond"]] * (len(st.slabs) - nc)
+
+    def _draft_next(self, st, hidden, uhidden, token):
+        out = self.ea_layer.topK_generate(hidden_states=hidden, uncond_hidden_states=uhidden,
+                                          input_ids=torch.cat((st.input_ids, token.to(st.input_ids.device)), dim=-1), attention_mask=st.attn_mask,
+                                          head=self.base_model.lm_head, logits_processors=self.drafter_logits_processors,
+                                          tree_type="static" if st.static else "dynamic")
+        if st.static:
+            st.tree_logits, st.sample_token = out, token
+        else:
+            self._take_dynamic_draft(st, out)
+
+    def _commit_from_host(self, st, candidates, best, alen, hidden, uhidden, sample_p, u):
+        """The fallback step's commit: host-side (best, accept_len) through the same kernels."""
+        dev = st.retrieve_indices.device
+        b = torch.as_tensor([int(best)], dtype=torch.int32, device=dev)
+        a = torch.as_tensor([int(alen)], dtype=torch.int32, device=dev)
+        L, n = st.input_ids.shape[1], int(alen) + 1
+        sdev = st.slabs[0].device
+        hid = torch.stack([hidden[0], uhidden[0]])[None]
+        _, out_h, acc = ops.update_inference_inputs(st.slabs, st.slab_seq, (L - st.slab_off).to(sdev), st.retrieve_indices.to(sdev), b.to(sdev), a.to(sdev),
+                                                    hid, candidates[None], slab_ptrs=st.slab_ptrs)
+        _, _, token = ops.accept_gather(None, st.retrieve_indices, None, b, a, sample_p=sample_p[None].float(), u=u)
+        for cl, off in zip(self._length_tensors(st), st.offsets):
+            cl.fill_(L - off + n)
+        st.input_ids = torch.cat([st.input_ids[None, 0] if st.parallel else st.input_ids, acc[:, :n].to(st.input_ids.device)], dim=-1)
+        self._draft_next(st, out_h[:, 0, :n], out_h[:, 1, :n], token.reshape(1, 1))
+        st.new_token += n
+        st.accept_lengths.append(n)
+        return False
+
     @torch.no_grad()
     def generate(self, input_ids, do_sample=True, max_new_tokens=2353, max_length=4096, cfg_scale=3.0, top_k=2000,
                  logits_processors=None, eos_token_ids=None, lantern=False, lantern_k=1000, lantern_delta=0.1,
                  tree_choices=mc_sim_7b_63, **kwargs):
-        self.cfg_scale = cfg_scale
-        self.ea_layer.cfg_scale = cfg_scale
-        self.internal_logits_processors = [self.internal_logits_processors[0], InterleavedTopKLogitsWarper(image_top_k=top_k)]
-        dk = kwargs.get("drafter_top_k") or top_k
-        self.drafter_logits_processors = [self.drafter_logits_processors[0], InterleavedTopKLogitsWarper(image_top_k=dk)]
-        image_start_sequence = torch.tensor([[8197, 8828, 8828]], dtype=torch.long).to(input_ids.device)
-        input_ids = torch.cat((input_ids, image_start_sequence), dim=-1)
-        self.eval()
-        accept_length_list = []
-        input_ids = input_ids.clone()
-        self.ea_layer.reset_kv()
-        dev = self.base_model.lm_head.weight.device
-        if self.eagle_version == 1:
-            if not (hasattr(self, "tree_choices") and self.tree_choices == tree_choices):
-                tree_buffers = generate_tree_buffers(tree_choices, device=dev)
-                tree_buffers["retrieve_indices_head"] = tree_buffers["retrieve_indices"]
-                if self.cfg_mode == "parallel":
-                    tree_buffers["tree_attn_mask"] = torch.cat((tree_buffers["tree_attn_mask"], tree_buffers["tree_attn_mask"]), dim=0)
-                self.tree_buffers = tree_buffers
-                self.tree_choices = tree_choices
-            tree_buffers = self.tree_buffers
-        if not hasattr(self, "past_key_values"):
-            if self.cfg_mode == "parallel":
-                self.past_key_values, self.past_key_values_data, self.current_length_data = \
-                    initialize_past_key_values(self.base_model, batch_size=2)
-            else:
-                self.past_key_values, self.past_key_values_data, self.current_length_data = {}, {}, {}
-                for key in ["cond", "uncond"]:
-                    (self.past_key_values[key], self.past_key_values_data[key],
-                     self.current_length_data[key]) = initialize_past_key_values(self.base_model)
-        past_key_values, past_key_values_data = self.past_key_values, self.past_key_values_data
-        current_length_data = self.current_length_data
-        for cl in ([current_length_data] if self.cfg_mode == "parallel" else current_length_data.values()):
-            cl.zero_()
-        input_len = input_ids.shape[1]
-        self.reset_tree_mode()
-        self.image_start_token_id_index = torch.where(input_ids[0] == self.image_start_token_id)[0][-1].item()
-        prompt_length = self.image_start_token_id_index
-        num_image_tokens = input_ids.shape[1] - prompt_length
-        zero_padding = torch.zeros((prompt_length), dtype=torch.bool, device=input_ids.device)
-        cond_attn_mask = torch.ones((input_ids.shape[1]), dtype=torch.bool, device=input_ids.device)
-        uncond_attn_mask = torch.cat((zero_padding, torch.ones((num_image_tokens), dtype=torch.bool, device=input_ids.device)), dim=-1)
-        attn_mask = torch.stack([cond_attn_mask, uncond_attn_mask], dim=0)
-        if self.cfg_mode == "parallel":
-            input_ids = input_ids.repeat(2, 1)
-        if self.eagle_version == 1:
-            tree_logits, sample_token = self.initialize_tree(input_ids=input_ids, attention_mask=attn_mask,
-                                                             tree_attn_mask=tree_buffers["tree_attn_mask"],
-                                                             past_key_values=past_key_values, logits_processors=logits_processors)
-            tree_position_ids = tree_buffers["tree_position_ids"]
-            retrieve_indices = tree_buffers["retrieve_indices_head"]
-        else:
-            tree_candidates, retrieve_indices, tree_mask, tree_position_ids = self.initialize_tree(
-                input_ids=input_ids, attention_mask=attn_mask, past_key_values=past_key_values, logits_processors=logits_processors)
-            if self.cfg_mode == "parallel":
-                tree_mask = tree_mask.repeat(2, 1, 1, 1)
-        new_token = 0
-        self._uniforms().begin()          # the acceptance uniforms of this prompt start at random's current position
-        while new_token < max_new_tokens:
-            if self.eagle_version == 1:
-                candidates, cart_candidates_prob, tree_candidates = self.generate_candidates(
-                    tree_logits=tree_logits, tree_indices=tree_buffers["tree_indices"],
-                    retrieve_indices=tree_buffers["retrieve_indices"], sample_token=sample_token)
-            else:
-                self.base_model.model.tree_mask = tree_mask
-                tree_candidates = tree_candidates.to(input_ids.device)
-            logits, hidden_states_new, uncond_hidden_states_new = self.tree_decoding(
-                tree_candidates=tree_candidates, attention_mask=attn_mask, past_key_values=past_key_values,
-                tree_position_ids=tree_position_ids, input_ids=input_ids, retrieve_indices=retrieve_indices)
-            if self.eagle_version == 1:
-                original_prob, p_indices, b_indices = tree_logits[2], tree_buffers["p_indices"], tree_buffers["b_indices"]
-            else:
-                padding = (torch.zeros(1, 1, dtype=torch.long) - 1).to(input_ids.device)
-                tree_candidates = torch.cat((tree_candidates, padding), dim=1)
-                candidates = tree_candidates[0, retrieve_indices]
-                cart_candidates_prob = original_prob = p_indices = b_indices = None
-            best_candidate, accept_length, sample_p = self.evaluate_posterior(
-                logits=logits, candidates=candidates, cart_candidates_prob=cart_candidates_prob, original_prob=original_prob,
-                tree_candidates=tree_candidates, p_indices=p_indices, b_indices=b_indices, do_sample=do_sample, lantern=lantern,
-                lantern_k=lantern_k, lantern_delta=lantern_delta)
-            input_ids, output, new_token, sample_token = self.update_inference_inputs(
-                input_ids=input_ids, attention_mask=attn_mask, candidates=candidates, best_candidate=best_candidate,
-                accept_length=accept_length, retrieve_indices=retrieve_indices, do_sample=do_sample, new_token=new_token,
-                past_key_values_data=past_key_values_data, current_length_data=current_length_data,
-                hidden_states_new=hidden_states_new, uncond_hidden_states_new=uncond_hidden_states_new, sample_p=sample_p)
-            if self.eagle_version == 1:
-                tree_logits = output
-            else:
-                tree_candidates, retrieve_indices, tree_mask, tree_position_ids = output
-                if self.cfg_mode == "parallel":
-                    tree_mask = tree_mask.repeat(2, 1, 1, 1)
-            accept_length_list.append(accept_length + 1)
-            if eos_token_ids is not None and eos_token_ids in input_ids[0, input_len:].tolist():
-                break
-            if input_ids.shape[1] > max_length:
-                break
-        self._uniforms().end()            # unconsumed staged draws go back to the module-level stream
-        return input_ids, accept_length_list
+        if not do_sample:
+            raise NotImplementedError("Greedy decoding is not implemented yet")   # as the reference (:728-729)
+        st = self._prepare_generation(input_ids.clone(), cfg_scale, top_k, kwargs.get("drafter_top_k"), tree_choices)
+        self._first_draft(st, logits_processors)
+        fifo = self._uniforms()
+        fifo.begin()                       # the acceptance uniforms of this prompt start at random's current position
+        try:
+            while st.new_token < max_new_tokens:
+                hit_eos = self._verify_step(st, lantern, lantern_k, lantern_delta, eos_token_ids)
+                if hit_eos or st.input_ids.shape[1] > max_length:
+                    break
+        finally:
+            fifo.end()                     # unconsumed staged draws go back to the module-level stream
+        return st.input_ids, st.accept_lengths
 
     # BASELINE.json's north_star calls the entry point `eagenerate`; the reference names it `generate`
     eagenerate = generate

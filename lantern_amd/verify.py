@@ -107,6 +107,14 @@ class WindowRows:
 
     def __init__(self, win: torch.Tensor, row_hot: torch.Tensor, retrieve_indices: torch.Tensor, V: int, win_lo: int):
         self.win, self.row_hot, self.retrieve_indices, self.V, self.win_lo = win, row_hot, retrieve_indices, V, win_lo
+        self.dense_source = None      # callable -> NodeLogits of the same step (set by tree_decoding)
+
+    def dense_rows(self):
+        """The same step's rows for the dense kernel set (full-vocabulary processed logits), for the states the windowed
+        evaluate_posterior reports instead of representing (LANTERN_ST_NEEDS_DENSE and friends)."""
+        if self.dense_source is None:
+            raise RuntimeError("WindowRows.dense_rows: no dense source attached (tree_decoding attaches one)")
+        return self.dense_source()
 
     @property
     def shape(self):

@@ -136,6 +136,7 @@ class EaModel(_LlamaGenEaModel):
                 input_tokens, past_key_values, logits_processor, cfg, input_mask, input_position_ids)
         input_ids = input_tokens[:1]
         new_token = 0
+        self._uniforms().begin()          # this prompt's acceptance uniforms start at random's current position
         for idx in range(max_length):
             if static_tree:
                 candidates, cart_candidates_prob, tree_candidates = self.generate_candidates(
@@ -168,6 +169,7 @@ class EaModel(_LlamaGenEaModel):
             accept_length_list.append(int(accept_length) + 1)
             if new_token > max_length:
                 break
+        self._uniforms().end()            # unconsumed staged draws go back to the module-level stream
         return (input_ids[:, max_input_length:max_input_length + max_length], sum(accept_length_list) / len(accept_length_list),
                 time.time() - st)
 

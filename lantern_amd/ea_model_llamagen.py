@@ -118,12 +118,16 @@ class EaModel(nn.Module):
                                                 img_lo=self.image_lo if self.mask_non_image else 0,
                                                 img_hi=self.image_hi if self.mask_non_image else V, top_k=min(proc.top_k, V),
                                                 temperature=proc.temperature, top_p=proc.top_p, probs=True)
-            return WindowRows(win, hot, retrieve_indices, V, lo), hidden_state, outputs
-        node_logits = ops.cfg_mask_topk(tree_logits[0], tree_logits[half], float(cfg_scale),
-                                        model=ops.MODEL_ANOLE if self.mask_non_image else ops.MODEL_PLAIN,
-                                        img_lo=self.image_lo if self.mask_non_image else 0,
-                                        img_hi=self.image_hi if self.mask_non_image else tree_logits.shape[-1])
-        return NodeLogits(node_logits, retrieve_indices), hidden_state, outputs
+            wr = WindowRows(win, hot, retrieve_indices, V, lo)
+            wr.dense_source = lambda: NodeLogits(self._dense_node_logits(tree_logits, half, cfg_scale), retrieve_indices)
+            return wr, hidden_state, outputs
+        return NodeLogits(self._dense_node_logits(tree_logits, half, cfg_scale), retrieve_indices), hidden_state, outputs
+
+    def _dense_node_logits(self, tree_logits, half, cfg_scale):
+        return ops.cfg_mask_topk(tree_logits[0], tree_logits[half], float(cfg_scale),
+                                 model=ops.MODEL_ANOLE if self.mask_non_image else ops.MODEL_PLAIN,
+                                 img_lo=self.image_lo if self.mask_non_image else 0,
+                                 img_hi=self.image_hi if self.mask_non_image else tree_logits.shape[-1])
 
     # ------------------------------------------------------------------ O8 dynamic, :709-787 / greedy :789-905
     def evaluate_posterior(self, logits, candidates, logits_processor=None, lantern=False, lantern_k=1000, lantern_delta=0.1):
@@ -143,10 +147,22 @@ class EaModel(nn.Module):
         return best[0].to(torch.int64), int(alen[0]), sample_p[0]
 
     def _evaluate_posterior_window(self, logits, cfg, candidates, fifo, lantern, lantern_k, aux):
-        cfg.temperature, cfg.top_p, cfg.top_k = 1.0, 1.0, 0          # the rows are final probabilities (tree_decoding applied the processors)
-        out = ops.evaluate_posterior_window(cfg, logits.V, logits.win[None], logits.win_lo, logits.row_index(), candidates[None], fifo.buf,
+        import copy
+        cfg_w = copy.copy(cfg)
+        cfg_w.temperature, cfg_w.top_p, cfg_w.top_k = 1.0, 1.0, 0     # the rows are final probabilities (tree_decoding applied the processors)
+        cur0 = fifo.cursor.clone()
+        out = ops.evaluate_posterior_window(cfg_w, logits.V, logits.win[None], logits.win_lo, logits.row_index(), candidates[None], fifo.buf,
                                             row_hot=logits.row_hot[None], table=self._packed_table(int(lantern_k)) if lantern else None,
                                             aux=aux, cursor=fifo.cursor, want_dense=True, want_window=False, rows_probs=True)
+        if int(out["counters"][0, 5]) in (2, 6, 7, 8) and logits.dense_source is not None and not (0.0 < cfg.top_p < 1.0):
+            # a state only the dense kernel represents (the residual vanished, staging limits): the same step on the dense HIP
+            # kernel -- processors applied per visited row there -- from the same position of the uniform stream
+            fifo.cursor.copy_(cur0)
+            rows, row_index = as_rows(logits.dense_rows())
+            best, alen, sample_p, counters = ops.evaluate_posterior(cfg, rows.float()[None], row_index, candidates[None], fifo.buf,
+                                                                    table=self.nearest_latents if lantern else None, aux=aux, cursor=fifo.cursor)
+            ops.raise_on_status(counters)
+            return best[0].to(torch.int64), int(alen[0]), sample_p[0]
         ops.raise_on_status(out["counters"])
         return out["best"][0].to(torch.int64), int(out["accept_len"][0]), out["sample_p"][0]
 
@@ -292,6 +308,7 @@ class EaModel(nn.Module):
                 cond_combined, past_key_values, logits_processor, cfg, attention_mask)
         input_ids = torch.zeros((cond_combined.shape[0] // (2 if cfg is not None else 1), self.prefix_pad), dtype=torch.long).to(dev)
         new_token = 0
+        self._uniforms().begin()          # this prompt's acceptance uniforms start at random's current position
         for idx in range(max_length):
             if static_tree:
                 candidates, cart_candidates_prob, tree_candidates = self.generate_candidates(
@@ -321,6 +338,7 @@ class EaModel(nn.Module):
             accept_length_list.append(int(accept_length) + 1)
             if new_token > max_length:
                 break
+        self._uniforms().end()            # unconsumed staged draws go back to the module-level stream
         return (input_ids[:, self.prefix_pad:self.prefix_pad + max_length], sum(accept_length_list) / len(accept_length_list),
                 time.time() - st)
 

@@ -213,3 +213,48 @@ def test_kv_cache_mirror_copy():
             kv.copy(sel, prev)                      # KVCache.copy(indices, prev_length) as in kv_cache.py:38-50
     assert np.array_equal(data_list[0].cpu().numpy(), g["after"])
     assert torch.all(cur == prev + alen + 1)
+
+
+def test_lumina_mirror_falls_back_to_the_dense_kernel(monkeypatch):
+    """k + 1 neighbours cover the whole codebook and the root row's mass sits on the first candidate's neighbours: its rejection
+    zeroes the residual completely (`gtp.sum()==0 -> ones`), a state the windowed kernel reports (LANTERN_ST_NEEDS_DENSE) instead
+    of representing.  The mirror then runs the same step on the dense HIP kernel from the same position of the uniform stream:
+    the caller sees the reference's result (here: the oracle's) either way."""
+    import oracle
+    i = next(i for i, s in enumerate(SPECS) if s["model"] == "lumina" and s["kind"] == "static" and s["lantern"] and not s.get("special"))
+    spec, case = dict(SPECS[i]), H.ep_case(i)
+    m = CS.MODELS["lumina"]
+    spec["k"], spec["delta"] = m["K"] - 2, 0.1
+    mdl = make_lumina(spec, True)
+    tb, g = H.static_inputs(SPECS[i], case)
+    mdl.tree_buffers = verify.generate_tree_buffers(H.tree_choices(spec["tree"]), device="cuda")
+    mdl.tree_choices = H.tree_choices(spec["tree"])
+    tbuf = mdl.tree_buffers
+    offs = list(g["op_off"]) + [g["R"]]
+    op_list = [cuda(g["orig_prob"][offs[d]:offs[d + 1]]) for d in range(len(offs) - 1)]
+    tree_logits = (cuda(case["ss_token"]), cuda(case["ss_prob"]), op_list)
+    cand, cprob, tcand = mdl.generate_candidates(tree_logits, tbuf["tree_indices"], tbuf["retrieve_indices"],
+                                                 torch.tensor([[int(case["sample_token"])]], device="cuda"))
+    lo, W = m["img_lo"], m["img_hi"] - m["img_lo"]
+    nl_np = g["node_logits"].copy()
+    x0 = int(case["cand"][0, 1])                        # the first candidate of level 1
+    nl_np[0, lo:lo + W] = 0.0                           # root row: uniform over the image codes ...
+    nl_np[0, x0] = -np.inf                              # ... except the candidate itself: p(x) = 0, all mass on its neighbours
+    uniforms = np.full(64, 0.999)                       # every candidate is rejected
+    aux = H.static_aux(tb, g, case)
+    N = len(tb["tree_indices"])
+    ob, oa, osp, ocnt = oracle.evaluate_posterior(H.ep_config(spec), nl_np, H.row_index_from_retrieve(tb["retrieve"], N), case["cand"], uniforms,
+                                                  table=H.table(m["K"]), aux=aux)
+    nl = cuda(nl_np)
+    win, hot = ops.cfg_mask_topk_window(nl, None, 1.0, lo, W, model=ops.MODEL_ANOLE, img_lo=lo, img_hi=lo + W, top_k=0, probs=True)
+    wr = verify.WindowRows(win, hot, tbuf["retrieve_indices"], m["V"], lo)
+    built = []
+    wr.dense_source = lambda: (built.append(1), verify.NodeLogits(nl, tbuf["retrieve_indices"]))[1]
+    monkeypatch.setattr(random, "random", Stream(uniforms))
+    best, alen, sp = mdl.evaluate_posterior(wr, cand, cart_candidates_prob=cprob, original_prob=op_list, p_indices=tbuf["p_indices"],
+                                            tree_candidates=tcand, b_indices=tbuf["b_indices"], do_sample=True, lantern=True,
+                                            lantern_k=spec["k"], lantern_delta=spec["delta"])
+    assert built, "the windowed kernel did not report NEEDS_DENSE: the case no longer exercises the fallback"
+    assert (int(best), alen) == (ob, oa)
+    np.testing.assert_allclose(sp.cpu().numpy(), osp, rtol=0, atol=1e-5)
+    assert int(mdl._fifo.cursor.item()) == int(ocnt[3])          # the retry re-read the same uniforms, not the next ones

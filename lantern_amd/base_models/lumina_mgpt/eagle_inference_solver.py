@@ -92,8 +92,20 @@ class ClassifierFreeGuidanceSlot:
 
 
 class FlexARInferenceSolver:
-    def __init__(self, model, item_processor, precision="bf16"):
+    def __init__(self, model_path=None, drafter_path=None, precision="bf16", target_size=512, cfg_mode="sequential", eagle_version=1, *,
+                 model=None, item_processor=None):
+        """The reference's constructor (eagle_inference_solver.py:243-257): `FlexARInferenceSolver(model_path, drafter_path, precision,
+        target_size, cfg_mode, eagle_version)` as generate_images.py:103-110 calls it -- the checkpoints and the item processor
+        (tokenizer + VQGAN) are loaded by the reference's own loaders, the model is wrapped in this package's EaLumina_mGPT.  With
+        `model=` / `item_processor=` the solver wraps objects the caller already holds (tests)."""
         self.dtype = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": torch.float32}[precision]
+        if model is None:
+            from ...ea_model_lumina_mgpt import EaLumina_mGPT
+            model = EaLumina_mGPT.from_pretrained(base_model_path=model_path, ea_model_path=drafter_path, cfg_mode=cfg_mode,
+                                                  eagle_version=eagle_version, dtype=self.dtype, device_map="cuda")
+        if item_processor is None:
+            from ...verify import reference_loader
+            item_processor = reference_loader("models.base_models.lumina_mgpt.item_processor", "FlexARItemProcessor")(target_size=target_size)
         self.model = model
         self.item_processor = item_processor
 

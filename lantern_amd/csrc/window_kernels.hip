@@ -1267,6 +1267,12 @@ extern "C" int lantern_evaluate_posterior_window(const lantern_ep_params *prm, c
     if (p.B == 0) return LANTERN_OK;
     LANTERN_CHECK_ARG(p.P <= EW_MAX_P && p.D <= EW_MAX_D && p.P * p.D <= EW_MAX_PD, "evaluate_posterior_window: P=%d D=%d exceed limits (64 paths: one lane per path); use the dense kernel", p.P, p.D);
     if (p.mode != LANTERN_MODE_DYNAMIC) LANTERN_CHECK_ARG(p.N <= EW_MAX_N, "evaluate_posterior_window: N=%d > %d", p.N, EW_MAX_N);
+    // one uniform per tried candidate, EW_UNI of them staged per step: a tree that allows more tries than that must take the dense kernel
+    // (said here, on the host, instead of a spurious LANTERN_ST_UNIFORMS from inside the launch)
+    if (p.mode != LANTERN_MODE_DYNAMIC && p.N - 1 > EW_UNI) {
+        set_error("evaluate_posterior_window: a tree of %d nodes allows %d tries per step, %d uniforms are staged: use the dense kernel", p.N, p.N - 1, EW_UNI);
+        return LANTERN_E_UNSUPPORTED;
+    }
     LANTERN_CHECK_ARG(win->win_lo >= 0 && win->win_lo % 4 == 0 && win->win_len > 0 && win->win_len % 4 == 0 &&
                           win->win_lo + win->win_len <= p.V && win->win_len <= 16384,
                       "evaluate_posterior_window: window [%d,+%d) must be 4-aligned, inside V and <= 16384 wide", win->win_lo, win->win_len);

@@ -173,4 +173,12 @@ class EaModel(_LlamaGenEaModel):
         return (input_ids[:, max_input_length:max_input_length + max_length], sum(accept_length_list) / len(accept_length_list),
                 time.time() - st)
 
+    @classmethod
+    def from_pretrained(cls, Type="LLaMA", base_model_path=None, ea_model_path=None, total_token=59, depth=4, top_k=10, threshold=1.0, **kwargs):
+        """models.ea_model_anole.EaModel.from_pretrained (ea_model_anole.py:151-224) loads; this class runs the accept loop."""
+        from .verify import reference_loader
+        ref = reference_loader("models.ea_model_anole", "EaModel").from_pretrained(Type=Type, base_model_path=base_model_path, ea_model_path=ea_model_path,
+                                                                                  total_token=total_token, depth=depth, top_k=top_k, threshold=threshold, **kwargs)
+        return cls.from_reference(ref)
+
     eagenerate = generate

@@ -349,6 +349,16 @@ class EaModel(nn.Module):
         return self.base_model.decode_ids(ids)
 
     @classmethod
+    def from_pretrained(cls, Type="LLaMA", base_model_path=None, ea_model_path=None, total_token=59, depth=4, top_k=10, threshold=1.0, **kwargs):
+        """The reference's constructor surface (models.ea_model_llamagen.EaModel.from_pretrained, ea_model_llamagen.py:154-227): the reference's own loader
+        reads the checkpoints (base model, drafter weights, vq_distances table); the loaded model is wrapped so that generate() /
+        eagenerate() run this package's accept loop.  generate_images.py:127-128 constructs the model with exactly this call."""
+        from .verify import reference_loader
+        ref = reference_loader("models.ea_model_llamagen", "EaModel").from_pretrained(Type=Type, base_model_path=base_model_path, ea_model_path=ea_model_path,
+                                                                 total_token=total_token, depth=depth, top_k=top_k, threshold=threshold, **kwargs)
+        return cls.from_reference(ref)
+
+    @classmethod
     def from_reference(cls, ref, **kw):
         """Wrap a model the reference's own `from_pretrained` loaded (checkpoint loading stays there): same base model, drafter
         and neighbour table, this package's accept loop."""

@@ -512,6 +512,18 @@ class EaLumina_mGPT(nn.Module):
         return self.base_model.decode_ids(ids)
 
     @classmethod
+    def from_pretrained(cls, base_model_path=None, ea_model_path=None, total_token=-1, depth=5, top_k=10, threshold=1.0, cfg_mode="sequential",
+                        eagle_version=1, **kwargs):
+        """The reference's constructor surface (EaLumina_mGPT.from_pretrained, models/ea_model_lumina_mgpt.py:347-416, as called by
+        FlexARInferenceSolver.__init__, eagle_inference_solver.py:248-255): the reference's own loader reads the checkpoints; the
+        loaded model is wrapped so that generate() runs this package's accept loop."""
+        from .verify import reference_loader
+        ref = reference_loader("models.ea_model_lumina_mgpt", "EaLumina_mGPT").from_pretrained(
+            base_model_path=base_model_path, ea_model_path=ea_model_path, total_token=total_token, depth=depth, top_k=top_k, threshold=threshold,
+            cfg_mode=cfg_mode, eagle_version=eagle_version, **kwargs)
+        return cls.from_reference(ref, cfg_mode=cfg_mode, eagle_version=eagle_version)
+
+    @classmethod
     def from_reference(cls, ref, **kw):
         """Wrap a model the reference's own `from_pretrained` loaded (checkpoint loading stays there): same base model, drafter
         and neighbour table, this package's accept loop."""

@@ -674,6 +674,33 @@ def build_vq_table(codebook):
     return table
 
 
+def save_vq_table(table: torch.Tensor, save_path: str) -> str:
+    """The reference's on-disk format (entrypoints/generate_codebook.py:60-65): `<save_path>/top_{K-1}_indices.npy`, uint16 [K, K-1]
+    (the file the models load: ea_model_lumina_mgpt.py:321 `np.load("ckpts/lumina_mgpt/vq_distances/top_8191_indices.npy")`)."""
+    import os
+    t = table.detach().cpu().contiguous()
+    if t.dtype == torch.int16:
+        arr = t.numpy().view(np.uint16)
+    else:
+        arr = t.numpy().astype(np.uint16)
+    K, cols = arr.shape
+    if cols != K - 1:
+        raise _lib.LanternError(f"save_vq_table: expected the full [K, K-1] table, got {arr.shape}")
+    os.makedirs(save_path, exist_ok=True)
+    path = os.path.join(save_path, f"top_{K - 1}_indices.npy")
+    np.save(path, arr)
+    return path
+
+
+def load_vq_table(path: str, device=None) -> torch.Tensor:
+    """`top_{K-1}_indices.npy` -> the int16-viewed uint16 device tensor the kernels take (np.load as the reference does)."""
+    arr = np.load(path)
+    if arr.dtype != np.uint16 or arr.ndim != 2:
+        raise _lib.LanternError(f"load_vq_table: {path}: expected uint16 [K, K-1], got {arr.dtype} {arr.shape}")
+    t = torch.from_numpy(np.ascontiguousarray(arr).view(np.int16))
+    return t.to(device) if device is not None else t
+
+
 def tree_mask_bits(tree_mask: torch.Tensor) -> torch.Tensor:
     """[..., N, N] tree attention mask (non-zero = visible; the reference's `tree_attn_mask` / dynamic `tree_mask`) -> one
     64-bit ancestor word per node, int64 [N] or [B,N] (bit t of word n = node n sees tree key t)."""

@@ -254,3 +254,17 @@ def prepare_logits_processor(temperature: float = 0.0, repetition_penalty: float
         if top_k > 0:
             s.top_k = top_k
     return s
+
+
+def reference_loader(module: str, attr: str):
+    """The reference's own loader class/function (checkpoint loading, tokenizers and item processors stay in the reference: this
+    package replaces the accept loop, not the loaders).  Needs the jadohu/LANTERN checkout importable (its root on sys.path, as
+    entrypoints/generate_images.py has it); raises a clear error otherwise -- nothing of the loader is re-implemented here."""
+    import importlib
+    try:
+        return getattr(importlib.import_module(module), attr)
+    except Exception as e:          # ImportError, or whatever the reference's own imports raise
+        from ._lib import LanternError
+        raise LanternError(f"lantern_amd delegates model / checkpoint loading to the reference ({module}.{attr}), which is not importable here: "
+                           f"{type(e).__name__}: {e}.  Put the LANTERN checkout on sys.path, or load the model yourself and wrap it with "
+                           "from_reference(ref_model) (INTEGRATION.md 3).") from e

@@ -77,7 +77,7 @@ def test_flexar_solver_generate_and_decode_ids():
     random.seed(5)
     torch.manual_seed(5)
     mdl = make_model(1, "sequential")
-    solver = FlexARInferenceSolver(mdl, FakeItemProcessor(), precision="bf16")
+    solver = FlexARInferenceSolver(model=mdl, item_processor=FakeItemProcessor(), precision="bf16")
     procs = solver.create_logits_processor(cfg=3.0, image_top_k=200)
     assert len(procs) == 3 and procs[0].guidance_scale == 3.0
     tokens, step_compression, latency = solver.generate([], [["Generate an image of a cat", None]], 40, 1.0, 200, logits_processor=procs,

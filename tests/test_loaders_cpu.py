@@ -1,0 +1,93 @@
+"""CPU: the loader-side surface of the reference -- from_pretrained / FlexARInferenceSolver(model_path, drafter_path, ...)
+delegate to the reference's own loaders and wrap what they return; the neighbour table's on-disk format round-trips."""
+import sys
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from lantern_amd import ea_model_anole, ea_model_llamagen, ea_model_lumina_mgpt, ops
+from lantern_amd._lib import LanternError
+from lantern_amd.base_models.lumina_mgpt.eagle_inference_solver import FlexARInferenceSolver
+
+
+def _ref_model():
+    lm = types.SimpleNamespace(weight=torch.zeros(64, 8))
+    base = types.SimpleNamespace(lm_head=lm, config=None, model=types.SimpleNamespace())
+    table = (np.arange(16 * 15, dtype=np.uint16).reshape(16, 15) % 16)
+    return types.SimpleNamespace(base_model=base, ea_layer=object(), nearest_latents=table)
+
+
+@pytest.mark.parametrize("mod,cls,refmod,refcls", [(ea_model_llamagen, "EaModel", "models.ea_model_llamagen", "EaModel"),
+                                                   (ea_model_anole, "EaModel", "models.ea_model_anole", "EaModel"),
+                                                   (ea_model_lumina_mgpt, "EaLumina_mGPT", "models.ea_model_lumina_mgpt", "EaLumina_mGPT")])
+def test_from_pretrained_delegates_to_the_reference_loader(monkeypatch, mod, cls, refmod, refcls):
+    calls = []
+
+    class RefCls:
+        @classmethod
+        def from_pretrained(c, **kw):
+            calls.append(kw)
+            return _ref_model()
+
+    for name in ("models", refmod):
+        monkeypatch.setitem(sys.modules, name, types.ModuleType(name))
+    setattr(sys.modules[refmod], refcls, RefCls)
+    kw = dict(base_model_path="ckpts/base", ea_model_path="ckpts/drafter", total_token=59, depth=4, top_k=10, threshold=1.0)
+    if refcls == "EaLumina_mGPT":
+        m = getattr(mod, cls).from_pretrained(cfg_mode="parallel", eagle_version=2, **kw)
+        assert m.cfg_mode == "parallel" and m.eagle_version == 2 and calls[0]["cfg_mode"] == "parallel"
+    else:
+        m = getattr(mod, cls).from_pretrained(Type="LLaMA", **kw)
+    assert isinstance(m, getattr(mod, cls)) and calls[0]["base_model_path"] == "ckpts/base" and calls[0]["ea_model_path"] == "ckpts/drafter"
+    assert calls[0]["total_token"] == 59 and m.nearest_latents.shape == (16, 15) and m.nearest_latents.dtype == torch.int16
+
+
+def test_from_pretrained_without_the_reference_says_so(monkeypatch):
+    for name in [n for n in sys.modules if n == "models" or n.startswith("models.")]:
+        monkeypatch.delitem(sys.modules, name)
+    monkeypatch.setattr(sys, "path", [p for p in sys.path if "reference" not in p])
+    with pytest.raises(LanternError, match="delegates model / checkpoint loading to the reference"):
+        ea_model_llamagen.EaModel.from_pretrained(base_model_path="x", ea_model_path="y")
+    with pytest.raises(LanternError, match="from_reference"):
+        FlexARInferenceSolver("ckpts/lumina", "ckpts/drafter", "bf16", target_size=768, cfg_mode="sequential", eagle_version=1)
+
+
+def test_solver_takes_the_reference_arguments(monkeypatch):
+    """FlexARInferenceSolver(model_path, drafter_path, precision, target_size, cfg_mode, eagle_version), as generate_images.py:103-110
+    constructs it: model and item processor come from the reference's loaders."""
+    seen = {}
+
+    class RefLumina:
+        @classmethod
+        def from_pretrained(c, **kw):
+            seen["model"] = kw
+            return _ref_model()
+
+    class ItemProc:
+        def __init__(self, target_size):
+            seen["target_size"] = target_size
+
+    for name in ("models", "models.ea_model_lumina_mgpt", "models.base_models", "models.base_models.lumina_mgpt", "models.base_models.lumina_mgpt.item_processor"):
+        monkeypatch.setitem(sys.modules, name, types.ModuleType(name))
+    sys.modules["models.ea_model_lumina_mgpt"].EaLumina_mGPT = RefLumina
+    sys.modules["models.base_models.lumina_mgpt.item_processor"].FlexARItemProcessor = ItemProc
+    s = FlexARInferenceSolver("ckpts/lumina", "ckpts/drafter", "bf16", target_size=768, cfg_mode="sequential", eagle_version=1)
+    assert isinstance(s.model, ea_model_lumina_mgpt.EaLumina_mGPT) and s.dtype == torch.bfloat16 and seen["target_size"] == 768
+    assert seen["model"]["base_model_path"] == "ckpts/lumina" and seen["model"]["ea_model_path"] == "ckpts/drafter"
+    assert seen["model"]["device_map"] == "cuda" and seen["model"]["dtype"] == torch.bfloat16
+
+
+def test_vq_table_file_round_trip(tmp_path):
+    K = 32
+    rs = np.random.RandomState(0)
+    arr = np.stack([rs.permutation(K)[:K - 1] for _ in range(K)]).astype(np.uint16)
+    path = ops.save_vq_table(torch.from_numpy(arr.view(np.int16)), str(tmp_path / "vq_distances"))
+    assert path.endswith("top_31_indices.npy")
+    raw = np.load(path)                                   # what the reference's np.load sees
+    assert raw.dtype == np.uint16 and np.array_equal(raw, arr)
+    back = ops.load_vq_table(path)
+    assert back.dtype == torch.int16 and np.array_equal(back.numpy().view(np.uint16), arr)
+    with pytest.raises(LanternError):
+        ops.save_vq_table(torch.zeros((8, 5), dtype=torch.int16), str(tmp_path))

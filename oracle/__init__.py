@@ -376,3 +376,82 @@ def build_vq_table(codebook):
 
 def num_threads() -> int:
     return int(lib().lo_num_threads())
+
+
+class _LoopArgs(C.Structure):
+    _fields_ = ([(n, C.c_int32) for n in ("n_seq", "n_steps", "pool_steps", "n_threads", "N", "P", "D", "R", "V", "W", "win_lo", "H")]
+                + [("prm", _EpParams)]
+                + [(n, C.c_void_p) for n in ("tree_indices", "retrieve", "pos1", "row_index", "p_idx", "b_off", "b_idx", "op_off")]
+                + [("seq_stride", C.c_int64)]
+                + [(n, C.c_void_p) for n in ("ss_token", "ss_prob", "cond", "uncond", "orig_win", "hidden", "nn_table", "uniforms")]
+                + [("n_uniforms", C.c_int64), ("u_bonus", C.c_void_p), ("first_token", C.c_void_p), ("cfg_scale", C.c_float)]
+                + [(n, C.c_int32) for n in ("w_latent", "h_latent", "newline_id", "eos_id", "top_k")]
+                + [("prompt_len", C.c_int64), ("tokens_per_image", C.c_int64), ("slabs", C.c_void_p), ("kv_outer", C.c_int64),
+                   ("kv_smax", C.c_int64), ("kv_dim", C.c_int64), ("best", C.c_void_p), ("alen", C.c_void_p), ("token", C.c_void_p),
+                   ("rc", C.c_void_p)])
+
+
+def verify_loop_mt(cfg: EpConfig, tb: dict, op_off, pools: dict, uniforms, u_bonus, first_token, table, n_steps: int, n_threads: int,
+                   cfg_scale: float, prompt_len: int, tokens_per_image: int, top_k: int, w_latent=48, h_latent=48, newline_id=8803,
+                   eos_id=8196, win_lo=4, slabs=None):
+    """lo_verify_loop_mt: the synthetic static-tree verify loop over pools [S, n_seq, ...] in ONE C call on n_threads pthreads
+    (bench.py's cpu_baseline, C leg).  pools: ss_token [S,B,R,10] i64, ss_prob f32, cond / uncond [S,B,N,V] uint16 (bf16 bits),
+    orig_win [S,B,R,W] f32, hidden [S,B,2,N,H] uint16.  slabs: list of 2*B uint16 arrays [outer, 1?, smax, dim] or None.
+    Returns (best, accept_len, token) arrays [n_steps, B]."""
+    ss_token = _c(pools["ss_token"], np.int64)
+    S, B, R = ss_token.shape[:3]
+    cond, uncond = _c(pools["cond"], np.uint16), _c(pools["uncond"], np.uint16)
+    N, V = cond.shape[2], cond.shape[3]
+    orig = _c(pools["orig_win"], np.float32)
+    W = orig.shape[-1]
+    hidden = _c(pools["hidden"], np.uint16)
+    H = hidden.shape[-1]
+    ret = _c(tb["retrieve_indices"], np.int64)
+    P, D = ret.shape
+    ri = ret.copy()
+    ri[ri < 0] += N
+    ri = _c(ri, np.int32)
+    a = _LoopArgs()
+    a.n_seq, a.n_steps, a.pool_steps, a.n_threads = B, n_steps, S, n_threads
+    a.N, a.P, a.D, a.R, a.V, a.W, a.win_lo, a.H = N, P, D, R, V, W, win_lo, H
+    prm = a.prm
+    prm.P, prm.D, prm.V, prm.mode = P, D, V, cfg.mode
+    prm.syntax_shortcut, prm.tok_offset = int(cfg.syntax_shortcut), cfg.tok_offset
+    prm.img_lo, prm.img_hi, prm.n_syntax = cfg.img_lo, min(cfg.img_hi, 2 ** 31 - 1), len(cfg.syntax)
+    for i, sx in enumerate(cfg.syntax):
+        prm.syntax[i] = sx
+    prm.lantern, prm.k, prm.delta = int(cfg.lantern), cfg.k, float(cfg.delta)
+    table = _c(table, np.uint16)
+    prm.table_rows, prm.table_cols = table.shape
+    prm.top_k, prm.temperature, prm.top_p = cfg.top_k, cfg.temperature, cfg.top_p
+    keep = dict(ti=_c(tb["tree_indices"], np.int64), ret=ret, pos1=_c(np.asarray(tb["tree_position_ids"]) + 1, np.int64), ri=ri,
+                pi=_c(tb["p_indices"], np.int32), bo=_c(tb["b_off"], np.int32), bi=_c(tb["b_idx"] if len(tb["b_idx"]) else np.zeros(1), np.int32),
+                oo=_c(op_off, np.int32), sst=ss_token, ssp=_c(pools["ss_prob"], np.float32), cond=cond, unc=uncond, orig=orig, hid=hidden,
+                tab=table, uni=_c(uniforms, np.float64), ub=_c(u_bonus, np.float64), ft=_c(first_token, np.int64))
+    ptr = lambda x: x.ctypes.data
+    a.tree_indices, a.retrieve, a.pos1, a.row_index = ptr(keep["ti"]), ptr(keep["ret"]), ptr(keep["pos1"]), ptr(keep["ri"])
+    a.p_idx, a.b_off, a.b_idx, a.op_off = ptr(keep["pi"]), ptr(keep["bo"]), ptr(keep["bi"]), ptr(keep["oo"])
+    a.seq_stride = B
+    a.ss_token, a.ss_prob, a.cond, a.uncond = ptr(keep["sst"]), ptr(keep["ssp"]), ptr(keep["cond"]), ptr(keep["unc"])
+    a.orig_win, a.hidden, a.nn_table, a.uniforms = ptr(keep["orig"]), ptr(keep["hid"]), ptr(keep["tab"]), ptr(keep["uni"])
+    assert keep["uni"].shape[0] >= B and keep["ub"].shape[0] >= n_steps and keep["ub"].shape[1] == B and keep["ft"].shape[0] >= B
+    a.n_uniforms, a.u_bonus, a.first_token, a.cfg_scale = keep["uni"].shape[1], ptr(keep["ub"]), ptr(keep["ft"]), cfg_scale
+    a.w_latent, a.h_latent, a.newline_id, a.eos_id, a.top_k = w_latent, h_latent, newline_id, eos_id, top_k
+    a.prompt_len, a.tokens_per_image = prompt_len, tokens_per_image
+    slab_ptrs = None
+    if slabs is not None:
+        assert len(slabs) == 2 * B
+        sh = slabs[0].shape
+        a.kv_smax, a.kv_dim = sh[-2], sh[-1]
+        a.kv_outer = int(np.prod(sh[:-2]))
+        slab_ptrs = (C.c_void_p * (2 * B))(*[x.ctypes.data for x in slabs])
+        a.slabs = C.cast(slab_ptrs, C.c_void_p).value
+    best = np.zeros((n_steps, B), np.int32)
+    alen = np.zeros((n_steps, B), np.int32)
+    token = np.zeros((n_steps, B), np.int64)
+    rcs = np.zeros(n_threads, np.int32)
+    a.best, a.alen, a.token, a.rc = ptr(best), ptr(alen), ptr(token), ptr(rcs)
+    rc = lib().lo_verify_loop_mt(C.byref(a))
+    if rc != 0:
+        raise RuntimeError(f"lo_verify_loop_mt rc={rc} (per thread: {rcs.tolist()})")
+    return best, alen, token

@@ -1086,3 +1086,126 @@ int lo_build_vq_table(const float *codebook, int K, int C, uint16_t *table) {
     }
     return 0;
 }
+
+/* ---------------------------------------------------------------------------------------------
+ * lo_verify_loop_mt -- the whole synthetic verify loop of bench.py's CPU baseline in ONE call,
+ * on n_threads pthreads (thread t owns sequences t, t + n_threads, ...): per step and sequence
+ *   lo_gather_candidates -> lo_cfg_mask_topk (bf16 inputs) -> lo_evaluate_posterior (static Lumina,
+ *   dense [R,V] drafter rows rebuilt from the windowed pool) -> lo_kv_gather x 2 -> lo_hidden_gather
+ *   -> lo_sample_inverse_cdf
+ * i.e. exactly what bench.py::cpu_baseline.run_seq does through the Python wrappers, without the
+ * interpreter (and its lock) between the calls.  Test infrastructure / timed baseline only.
+ * ------------------------------------------------------------------------------------------- */
+#include <pthread.h>
+
+typedef struct lo_loop_args {
+    int32_t n_seq, n_steps, pool_steps, n_threads;
+    int32_t N, P, D, R, V, W, win_lo, H;
+    lo_ep_params prm;
+    /* tree (shared) */
+    const int64_t *tree_indices, *retrieve, *pos1; /* pos1 = tree_position_ids + 1 */
+    const int32_t *row_index, *p_idx, *b_off, *b_idx, *op_off;
+    /* pools, layout [pool_steps][n_seq_stride][...] */
+    int64_t seq_stride;                 /* sequences per pool step in the pool tensors */
+    const int64_t *ss_token;            /* [S, seq_stride, R*10] */
+    const float *ss_prob;               /* [S, seq_stride, R*10] */
+    const uint16_t *cond, *uncond;      /* [S, seq_stride, N, V] bf16 bits */
+    const float *orig_win;              /* [S, seq_stride, R, W] */
+    const uint16_t *hidden;             /* [S, seq_stride, 2, N, H] bf16 bits */
+    const uint16_t *nn_table;
+    const double *uniforms;             /* [n_seq_total, n_uniforms] */
+    int64_t n_uniforms;
+    const double *u_bonus;              /* [steps, seq_stride] */
+    const int64_t *first_token;         /* [seq_stride] */
+    float cfg_scale;
+    int32_t w_latent, h_latent, newline_id, eos_id, top_k;
+    int64_t prompt_len, tokens_per_image;
+    /* KV slabs of the host copy: kv_outer * kv_smax * kv_dim bf16 each, 2 per sequence, or NULL */
+    uint16_t **slabs;
+    int64_t kv_outer, kv_smax, kv_dim;
+    /* outputs [n_steps, n_seq] */
+    int32_t *best, *alen;
+    int64_t *token;
+    int32_t *rc;                        /* [n_threads] */
+} lo_loop_args;
+
+typedef struct {
+    const lo_loop_args *a;
+    int tid;
+} lo_loop_thread;
+
+static void *lo_loop_worker(void *vp) {
+    const lo_loop_thread *th = (const lo_loop_thread *)vp;
+    const lo_loop_args *a = th->a;
+    const int N = a->N, P = a->P, D = a->D, R = a->R, V = a->V, W = a->W, H = a->H;
+    int64_t *tree_cand = (int64_t *)malloc(sizeof(int64_t) * (size_t)N);
+    int64_t *cand = (int64_t *)malloc(sizeof(int64_t) * (size_t)P * D);
+    float *cart = (float *)malloc(sizeof(float) * (size_t)P * D);
+    float *proc = (float *)malloc(sizeof(float) * (size_t)N * V);
+    float *orig = (float *)calloc((size_t)R * V, sizeof(float));
+    float *sp = (float *)malloc(sizeof(float) * (size_t)V);
+    int64_t *pos = (int64_t *)malloc(sizeof(int64_t) * (size_t)N);
+    uint16_t *hout = (uint16_t *)malloc(sizeof(uint16_t) * (size_t)2 * D * H);
+    int rc = 0;
+    for (int b = th->tid; b < a->n_seq && rc == 0; b += a->n_threads) {
+        int64_t lens[2] = {a->prompt_len + 3, 3};
+        int64_t tok = a->first_token[b];
+        int64_t cursor = 0;
+        for (int i = 0; i < a->n_steps && rc == 0; ++i) {
+            const int s = i % a->pool_steps;
+            const size_t sb = (size_t)s * (size_t)a->seq_stride + (size_t)b;
+            rc = lo_gather_candidates(a->ss_token + sb * R * 10, a->ss_prob + sb * R * 10, R * 10, tok, a->tree_indices, N, a->retrieve, P,
+                                      D, tree_cand, cand, cart);
+            if (rc) break;
+            for (int n = 0; n < N; ++n) pos[n] = a->pos1[n] + lens[0];
+            rc = lo_cfg_mask_topk(a->cond + sb * N * V, a->uncond + sb * N * V, LO_BF16, N, V, a->cfg_scale, LO_MODEL_LUMINA, pos,
+                                  a->prompt_len + 3, a->w_latent, a->h_latent, a->prm.img_lo, a->prm.img_hi, a->newline_id, a->eos_id,
+                                  a->top_k, proc);
+            if (rc) break;
+            for (int r = 0; r < R; ++r) memcpy(orig + (size_t)r * V + a->win_lo, a->orig_win + (sb * R + r) * W, sizeof(float) * (size_t)W);
+            int32_t best = 0, alen = 0, cnt[6];
+            const int64_t left = a->n_uniforms - cursor;
+            rc = lo_evaluate_posterior(&a->prm, proc, a->row_index, cand, cart, orig, a->op_off, a->p_idx, a->b_off, a->b_idx, tree_cand,
+                                       a->nn_table, a->uniforms + (size_t)b * a->n_uniforms + cursor, (int32_t)(left < 64 ? left : 64), &best,
+                                       &alen, sp, cnt);
+            if (rc) break;
+            cursor += cnt[3];
+            const int64_t *row = a->retrieve + (size_t)best * D;
+            if (a->slabs)
+                for (int j = 0; j < 2; ++j) lo_kv_gather(a->slabs[2 * b + j], 2, a->kv_outer, a->kv_smax, a->kv_dim, row, alen + 1, lens[j]);
+            lo_hidden_gather(a->hidden + sb * 2 * N * H, 2, 2, N, H, row, alen + 1, hout);
+            tok = lo_sample_inverse_cdf(sp, V, a->u_bonus[(size_t)i * a->seq_stride + b]);
+            lens[0] += alen + 1;
+            lens[1] += alen + 1;
+            if (lens[1] - 3 >= a->tokens_per_image) {
+                lens[0] = a->prompt_len + 3;
+                lens[1] = 3;
+            }
+            a->best[(size_t)i * a->n_seq + b] = best;
+            a->alen[(size_t)i * a->n_seq + b] = alen;
+            a->token[(size_t)i * a->n_seq + b] = tok;
+        }
+    }
+    a->rc[th->tid] = rc;
+    free(tree_cand); free(cand); free(cart); free(proc); free(orig); free(sp); free(pos); free(hout);
+    return NULL;
+}
+
+int lo_verify_loop_mt(const lo_loop_args *a) {
+    if (!a || a->n_threads < 1 || a->n_threads > 1024) return -1;
+    pthread_t *t = (pthread_t *)malloc(sizeof(pthread_t) * (size_t)a->n_threads);
+    lo_loop_thread *th = (lo_loop_thread *)malloc(sizeof(lo_loop_thread) * (size_t)a->n_threads);
+    int started = 0;
+    for (int i = 0; i < a->n_threads; ++i) {
+        th[i].a = a;
+        th[i].tid = i;
+        if (pthread_create(&t[i], NULL, lo_loop_worker, &th[i]) != 0) break;
+        ++started;
+    }
+    for (int i = 0; i < started; ++i) pthread_join(t[i], NULL);
+    int rc = started == a->n_threads ? 0 : -2;
+    for (int i = 0; i < started && rc == 0; ++i) rc = a->rc[i];
+    free(t);
+    free(th);
+    return rc;
+}

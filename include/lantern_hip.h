@@ -433,6 +433,24 @@ int lantern_drafter_attention_mask(const uint8_t *attn, int attn_len, const floa
 int lantern_linear_rows(const void *A, const void *W, const void *bias, int M, int K, int row_lo, int n_rows, void *out,
                         int out_stride, int out_col0, void *stream);
 
+/* 8f-2 (next row, second half)  One drafter expansion depth from the hidden states to the top-k in two small launches, the head's
+ * logits never in HBM:  head(hidden) restricted to the id window the model's mask lets through -> CFG combination in the GEMM's
+ * epilogue (`uncond + cfg * (cond - uncond)` with torch's bf16 roundings) -> [n, n_cols] bf16 window (16 KB per row) -> per row:
+ * grammar rows (Lumina newline / end of image), InterleavedTopKLogitsWarper threshold, log-softmax, top_k, + the parents'
+ * cumulative scores -> best top_k of the n * top_k.  Replaces models/drafters/cnets_lumina_mgpt.py:1271-1320 (per depth:
+ * lm_head on [2, n, H], CFG, MultiModalLogitsProcessor, InterleavedTopKLogitsWarper, log_softmax, topk, cu_scores, topk) and
+ * the same lines of cnets_anole.py:876-905; same outputs as lantern_linear_rows + lantern_cfg_mask_topk + lantern_expand_dynamic.
+ * A [dev] [2n, K] bf16: the n conditional rows, then the n unconditional ones (n <= 16); W [dev] [vocab, K] bf16, bias [dev] [vocab]
+ * bf16 or NULL; window = ids [row_lo, row_lo + n_cols) (n_cols % 8 == 0, <= 8192); pos_ids [dev] [n] i64 (Lumina: position of the
+ * token the row predicts, as for lantern_cfg_mask_topk) or NULL; top_k_filter: InterleavedTopKLogitsWarper's image_top_k (0 = off);
+ * scores_in [dev] [n] f32 or NULL; workspace [dev] lantern_head_expand_workspace(n, n_cols) bytes, 16-byte aligned.
+ * Out [dev]: topk_index [n, top_k] i64 (token ids), cu_scores [n, top_k] f32, topk_cs_index [top_k] i64, scores_out [top_k] f32. */
+size_t lantern_head_expand_workspace(int n, int n_cols);
+int lantern_head_expand(const void *A, const void *W, const void *bias, int n, int K, int row_lo, int n_cols, int V, float cfg,
+                        int model, const int64_t *pos_ids, int64_t pos_base, int w_latent, int h_latent, int newline_id, int eos_id,
+                        int top_k_filter, const float *scores_in, int top_k, void *workspace, int64_t *topk_index,
+                        float *cu_scores, int64_t *topk_cs_index, float *scores_out, void *stream);
+
 /* 8f-3 (next row)  Attention of the target model's tree-verify forward over the KV cache in place:
  *   out[b, n, h*d + :] = softmax_f32(q[b,n,h,:] . K[b, h/(Hq/Hkv), key, :] * scale + mask[b][n][key]).bf16 @ V
  * replacing the eager matmul / additive-mask / softmax / matmul of the reference's attention

@@ -93,6 +93,7 @@ def lib():
         _lib.lantern_evaluate_posterior_workspace.restype = C.c_size_t
         _lib.lantern_tree_attention_workspace.restype = C.c_size_t
         _lib.lantern_evaluate_posterior_nodes_workspace.restype = C.c_size_t
+        _lib.lantern_head_expand_workspace.restype = C.c_size_t
     return _lib
 
 
@@ -112,5 +113,5 @@ EXPORTS = [
     "lantern_window_to_dense", "lantern_pack_vq_table", "lantern_update_inference_inputs", "lantern_profile_next_launch", "lantern_drafter_attention_mask", "lantern_linear_rows",
     "lantern_tree_attention_workspace", "lantern_tree_attention",
     "lantern_tree_node_tables_size", "lantern_tree_node_tables", "lantern_evaluate_posterior_nodes_workspace",
-    "lantern_evaluate_posterior_nodes", "lantern_verify_step", "lantern_gather_candidates_dynamic",
+    "lantern_evaluate_posterior_nodes", "lantern_verify_step", "lantern_gather_candidates_dynamic", "lantern_head_expand_workspace", "lantern_head_expand",
 ]

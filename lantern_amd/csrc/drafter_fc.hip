@@ -222,6 +222,70 @@ __global__ __launch_bounds__(FC_THREADS) void linear_rows_kernel(const uint16_t 
     }
 }
 
+// 8f-2 (second half, phase 1): the same contraction for the drafter's cond + uncond rows, with the CFG combination as the
+// epilogue -- rows 0..n-1 of A are the conditional hidden states, rows n..2n-1 the unconditional ones
+// (cnets_lumina_mgpt.py:1271-1320: `out = uncond + cfg_scale * (cond - uncond)` on the head's bf16 logits).  The head's
+// [2, n, V] logits never exist: what leaves the kernel is the combined window [n, n_cols] in bf16 (16 KB per row for the
+// 8192 image ids), every rounding where torch rounds (the nn.Linear output, then each step of the bf16 arithmetic).
+__global__ __launch_bounds__(FC_THREADS) void linear_rows_cfg_kernel(const uint16_t *__restrict__ A, const uint16_t *__restrict__ Wt,
+                                                                     const uint16_t *__restrict__ bias, int n, int K, int row_lo, int n_cols,
+                                                                     float cfg, uint16_t *__restrict__ win) {
+    __shared__ float tile[32][33];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int n0 = blockIdx.x * 32, M = 2 * n;
+    for (int t = tid; t < 32 * 33; t += FC_THREADS) (&tile[0][0])[t] = 0.0f;
+    const int ksteps = K / 16;
+    const int ks0 = (int)((long long)ksteps * wave / FC_WAVES), ks1 = (int)((long long)ksteps * (wave + 1) / FC_WAVES);
+    const int ncol = n0 + r;
+    const uint16_t *wrow = Wt + (size_t)(row_lo + (ncol < n_cols ? ncol : n_cols - 1)) * K;
+    const bool live = r < M;
+    const uint16_t *arow = A + (size_t)(live ? r : 0) * K;
+    f32x16_t acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+    const bf16x8_t zero = __builtin_bit_cast(bf16x8_t, make_uint4(0, 0, 0, 0));
+    int ks = ks0;
+    for (; ks + 3 < ks1; ks += 4) {          // same K order as linear_rows_kernel: the logits are the same bits
+        const int kb = ks * 16 + 32 * h;
+        bf16x8_t bw[4], aw[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) bw[q] = load_frag(wrow + kb + 8 * q);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) aw[q] = live ? load_frag(arow + kb + 8 * q) : zero;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aw[q], bw[q], acc, 0, 0, 0);
+    }
+    for (; ks < ks1; ++ks) {
+        const int k0 = ks * 16 + 8 * h;
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(live ? load_frag(arow + k0) : zero, load_frag(wrow + k0), acc, 0, 0, 0);
+    }
+    for (int w = 0; w < FC_WAVES; ++w) {      // combine the K slices in wave order (deterministic f32 sum)
+        __syncthreads();
+        if (wave == w) {
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) tile[(reg & 3) + 8 * (reg >> 2) + 4 * h][r] += acc[reg];
+        }
+    }
+    __syncthreads();
+    for (int t = tid; t < n * 32; t += FC_THREADS) {
+        const int i = t / 32, col = t % 32, nn = n0 + col;
+        if (nn < n_cols) {
+            const float b = bias ? bf16_bits_to_f32(bias[row_lo + nn]) : 0.0f;
+            const float c = bf16_bits_to_f32(f32_to_bf16_rne(tile[i][col] + b)), u = bf16_bits_to_f32(f32_to_bf16_rne(tile[i + n][col] + b));
+            const float o = round_bf16(u + round_bf16(cfg * round_bf16(c - u)));
+            win[(size_t)i * n_cols + nn] = (uint16_t)(__float_as_uint(o) >> 16);
+        }
+    }
+}
+
+int launch_linear_rows_cfg(const void *A, const void *W, const void *bias, int n, int K, int row_lo, int n_cols, float cfg, void *win,
+                           hipStream_t st) {
+    LANTERN_LAUNCH(linear_rows_cfg_kernel, dim3((n_cols + 31) / 32), dim3(FC_THREADS), 0, st, (const uint16_t *)A, (const uint16_t *)W,
+                   (const uint16_t *)bias, n, K, row_lo, n_cols, cfg, (uint16_t *)win);
+    return 0;
+}
+
 // a5: Model._prepare_decoder_attention_mask (cnets_lumina_mgpt.py:1014-1050, cnets_llamagen.py:592-621) in one launch:
 // out[b,0,i,j] = padding(b,j) + causal(i,j) with padding = 0 / finfo.min from the boolean mask (columns beyond its length
 // count as attended), causal = finfo.min for j - past > i when T > 1 (the reference ADDS the two, so a position masked by

@@ -8,6 +8,7 @@
 // Reference: models/drafters/cnets_llamagen.py:798-820 (O3), :831-912 (O4);
 // cnets_lumina_mgpt.py:1303-1318, :1330-1393; cnets_anole.py:913-993.
 #include "common.h"
+#include "window_dev.h"
 
 namespace lantern {
 
@@ -365,6 +366,142 @@ __global__ __launch_bounds__(EX_THREADS) void expand_rows_kernel(const float *__
     }
 }
 
+// 8f-2 (second half, phase 2): what expand_rows_kernel does, on the CFG-combined bf16 WINDOW of a drafter row (the output of
+// linear_rows_cfg_kernel) with the model's processors applied on the way in: the Lumina grammar rows (newline / end of image:
+// one-hot), InterleavedTopKLogitsWarper's threshold, then log-softmax statistics and the top_k entries (ties to the lower id).
+// One 256-thread workgroup per row, the row in registers (32 values per thread at W = 8192): 16 KB read once, against the
+// 2 x 256 KB of the dense f32 row expand_rows_kernel reads (cnets_lumina_mgpt.py:1287-1318).
+constexpr int EXW_NT = 256, EXW_C8 = 4;            // 4 chunks of 8 ids per thread: W <= 8192
+__global__ __launch_bounds__(EXW_NT) void expand_window_kernel(const uint16_t *__restrict__ win, int W, int win_lo, int V, int model,
+                                                               const int64_t *__restrict__ pos_ids, int64_t pos_base, int w_latent,
+                                                               int h_latent, int newline_id, int eos_id, int top_k_filter,
+                                                               const float *__restrict__ scores_in, int top_k,
+                                                               int64_t *__restrict__ topk_index, float *__restrict__ cu_scores) {
+    constexpr int NW = EXW_NT / 64, NV4 = 2 * EXW_C8;
+    __shared__ alignas(16) int s_hist[O7_HIST_INTS];
+    __shared__ float s_redf[2 * NW];
+    __shared__ double s_redd[2 * NW];
+    __shared__ float s_bv[NW];
+    __shared__ int s_bi[NW];
+    __shared__ int s_taken[EX_MAX_K];
+    const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float NEG_INF = -__builtin_inff();
+    const float sc = scores_in ? scores_in[row] : 0.0f;
+    int hot = -1;
+    if (model == LANTERN_MODEL_LUMINA && pos_ids) {
+        const int64_t n1 = pos_ids[row] - pos_base + 1;
+        if (n1 == ((int64_t)w_latent + 1) * h_latent + 1) hot = eos_id;
+        else if (py_mod64(n1, (int64_t)w_latent + 1) == 0) hot = newline_id;
+    }
+    if (hot >= 0) {          // forced row: probability 1 on `hot`, the other top_k - 1 places go to the lowest ids at -inf
+        if (tid == 0) {
+            topk_index[(size_t)row * top_k] = hot;
+            cu_scores[(size_t)row * top_k] = sc;
+            int next = 0;
+            for (int t = 1; t < top_k; ++t) {
+                if (next == hot) ++next;
+                topk_index[(size_t)row * top_k + t] = next++;
+                cu_scores[(size_t)row * top_k + t] = NEG_INF;
+            }
+        }
+        return;
+    }
+    float4 r[NV4];
+#pragma unroll
+    for (int it = 0; it < EXW_C8; ++it) {
+        const int ch = tid + it * EXW_NT;
+        uint4 q = make_uint4(0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u);          // -inf pairs
+        if (ch * 8 < W) q = *reinterpret_cast<const uint4 *>(win + (size_t)row * W + ch * 8);
+        const uint32_t w[4] = {q.x, q.y, q.z, q.w};
+        float o[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = __uint_as_float((j & 1) ? (w[j >> 1] & 0xffff0000u) : (w[j >> 1] << 16));
+        r[2 * it] = make_float4(o[0], o[1], o[2], o[3]);
+        r[2 * it + 1] = make_float4(o[4], o[5], o[6], o[7]);
+    }
+    if (top_k_filter > 0 && top_k_filter < V && top_k_filter <= W) {
+        const float thr = kth_largest_hist_bf16<EXW_NT, NV4>(r, top_k_filter, s_hist);
+#pragma unroll
+        for (int it = 0; it < NV4; ++it) {
+            r[it].x = r[it].x < thr ? NEG_INF : r[it].x; r[it].y = r[it].y < thr ? NEG_INF : r[it].y;
+            r[it].z = r[it].z < thr ? NEG_INF : r[it].z; r[it].w = r[it].w < thr ? NEG_INF : r[it].w;
+        }
+    }
+    int ph = 0;
+    float tm = NEG_INF;
+#pragma unroll
+    for (int it = 0; it < NV4; ++it) tm = fmaxf(fmaxf(tm, fmaxf(r[it].x, r[it].y)), fmaxf(r[it].z, r[it].w));
+    const float m = block_max<NW>(tm, s_redf, ph);
+    double s = 0.0;
+#pragma unroll
+    for (int it = 0; it < NV4; ++it)
+        s += (double)expf(r[it].x - m) + (double)expf(r[it].y - m) + (double)expf(r[it].z - m) + (double)expf(r[it].w - m);
+    const float ls = logf((float)block_sum<double, NW>(s, s_redd, ph));
+    // top_k rounds of a block-wide arg-max (value, then the lower id); a thread's 32 entries carry a taken mask
+    unsigned taken = 0u;
+    int low_next = 0;                     // next id of the -inf tail (thread 0)
+    for (int t = 0; t < top_k; ++t) {
+        float bv = NEG_INF;
+        int bi = 0x7fffffff;
+#pragma unroll
+        for (int it = 0; it < NV4; ++it) {
+            const float v[4] = {r[it].x, r[it].y, r[it].z, r[it].w};
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int slot = it * 4 + c;
+                const int id = win_lo + ((tid + (it >> 1) * EXW_NT) * 8 + (it & 1) * 4 + c);
+                if (!((taken >> slot) & 1u) && v[c] > NEG_INF && (v[c] > bv || (v[c] == bv && id < bi))) {
+                    bv = v[c];
+                    bi = id;
+                }
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ov = __shfl_xor(bv, o, 64);
+            const int oi = __shfl_xor(bi, o, 64);
+            if (ov > bv || (ov == bv && oi < bi)) {
+                bv = ov;
+                bi = oi;
+            }
+        }
+        if (lane == 0) {
+            s_bv[wave] = bv;
+            s_bi[wave] = bi;
+        }
+        __syncthreads();
+        float v = s_bv[0];
+        int i = s_bi[0];
+        for (int w = 1; w < NW; ++w)
+            if (s_bv[w] > v || (s_bv[w] == v && s_bi[w] < i)) {
+                v = s_bv[w];
+                i = s_bi[w];
+            }
+        if (v > NEG_INF) {               // mark it taken in its owner's registers
+            const int wi = i - win_lo, chn = wi >> 3;
+            if ((chn % EXW_NT) == tid) taken |= 1u << ((chn / EXW_NT) * 8 + (wi & 7));
+        }
+        if (tid == 0) {
+            if (!(v > NEG_INF)) {        // fewer finite entries than top_k: the lowest ids not yet listed, at -inf
+                bool again = true;
+                while (again) {
+                    again = false;
+                    for (int q = 0; q < t; ++q)
+                        if (s_taken[q] == low_next) {
+                            ++low_next;
+                            again = true;
+                        }
+                }
+                i = low_next++;
+            }
+            s_taken[t] = i;
+            topk_index[(size_t)row * top_k + t] = i;
+            cu_scores[(size_t)row * top_k + t] = ((v - m) - ls) + sc;
+        }
+        __syncthreads();
+    }
+}
+
 // one wavefront per sequence: top_k of the flattened n_rows*top_k cumulative scores
 __global__ __launch_bounds__(64) void expand_merge_kernel(const float *__restrict__ cu_scores, int nf, int top_k,
                                                           int64_t *__restrict__ topk_cs_index, float *__restrict__ scores_out) {
@@ -437,6 +574,35 @@ extern "C" int lantern_tree_dynamic_finalize(const float *scores, const int64_t 
                            sample_token, n_scores, n_parents, top_k, total_tokens, sort_rows, draft_tokens, mask, pos_ids, retrieve, n_leaf,
                            max_depth);
     LANTERN_CHECK_LAUNCH("tree_dynamic_finalize");
+    return LANTERN_OK;
+}
+
+namespace lantern {
+int launch_linear_rows_cfg(const void *A, const void *W, const void *bias, int n, int K, int row_lo, int n_cols, float cfg, void *win,
+                           hipStream_t st);
+}
+
+extern "C" size_t lantern_head_expand_workspace(int n, int n_cols) { return (size_t)n * (size_t)n_cols * 2; }
+
+extern "C" int lantern_head_expand(const void *A, const void *W, const void *bias, int n, int K, int row_lo, int n_cols, int V, float cfg,
+                                   int model, const int64_t *pos_ids, int64_t pos_base, int w_latent, int h_latent, int newline_id, int eos_id,
+                                   int top_k_filter, const float *scores_in, int top_k, void *workspace, int64_t *topk_index,
+                                   float *cu_scores, int64_t *topk_cs_index, float *scores_out, void *stream) {
+    LANTERN_CHECK_ARG(A && W && workspace && topk_index && cu_scores && topk_cs_index && scores_out, "head_expand: null buffer");
+    LANTERN_CHECK_ARG(n > 0 && n <= 16 && K > 0 && K % 16 == 0, "head_expand: n=%d drafter rows (<= 16 cond + 16 uncond), K=%d (multiple of 16)", n, K);
+    LANTERN_CHECK_ARG(row_lo >= 0 && n_cols > 0 && n_cols % 8 == 0 && n_cols <= 8 * EXW_NT * EXW_C8 && row_lo + n_cols <= V,
+                      "head_expand: window [%d,+%d) must be a multiple of 8 ids, <= %d wide, inside V", row_lo, n_cols, 8 * EXW_NT * EXW_C8);
+    LANTERN_CHECK_ARG(top_k > 0 && top_k <= EX_MAX_K && top_k <= V && n * top_k <= 256, "head_expand: bad top_k");
+    LANTERN_CHECK_ARG(model == LANTERN_MODEL_LUMINA || model == LANTERN_MODEL_ANOLE, "head_expand: for models whose drafted rows are masked to one id window (Lumina, Anole)");
+    if (model == LANTERN_MODEL_LUMINA && pos_ids)
+        LANTERN_CHECK_ARG(w_latent > 0 && h_latent > 0 && newline_id >= 0 && newline_id < V && eos_id >= 0 && eos_id < V, "head_expand: Lumina needs latent dims and syntax ids");
+    LANTERN_CHECK_ARG(((uintptr_t)workspace & 15) == 0, "head_expand: workspace must be 16-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    launch_linear_rows_cfg(A, W, bias, n, K, row_lo, n_cols, cfg, workspace, st);
+    hipLaunchKernelGGL(expand_window_kernel, dim3(n), dim3(EXW_NT), 0, st, (const uint16_t *)workspace, n_cols, row_lo, V, model, pos_ids, pos_base,
+                       w_latent, h_latent, newline_id, eos_id, top_k_filter, scores_in, top_k, topk_index, cu_scores);
+    hipLaunchKernelGGL(expand_merge_kernel, dim3(1), dim3(64), 0, st, cu_scores, n * top_k, top_k, topk_cs_index, scores_out);
+    LANTERN_CHECK_LAUNCH("head_expand");
     return LANTERN_OK;
 }
 

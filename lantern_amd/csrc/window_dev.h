@@ -374,4 +374,89 @@ __device__ __forceinline__ void row_load(const float *__restrict__ rowp, int W, 
     }
 }
 
+struct alignas(8) Bf16x8 {
+    uint2 a, b;
+};
+
+constexpr int O7_REP = 8;
+
+// Histogram layout: [256 bins x O7_REP copies | 64 spill slots | 256 bins].  Values that must not count (-inf padding /
+// masked ids, or -- second pass -- values outside the chosen top bin) add into the spill slot of their own lane instead of
+// being skipped under a branch: every atomic is unconditional (no exec-mask juggling per element) and the spill slots are
+// conflict-free.
+constexpr int O7_SPILL = 256 * O7_REP, O7_HIST2 = O7_SPILL + 64, O7_HIST_INTS = O7_HIST2 + 256;
+
+template <int NT, int NV4>
+__device__ __forceinline__ float kth_largest_hist_bf16(const float4 (&r)[NV4], int k, int *h) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    int *hist = h + O7_HIST2;
+    // order keys once: bf16-exact values -> the upper 16 key bits carry everything
+    uint32_t key[NV4][4];
+#pragma unroll
+    for (int it = 0; it < NV4; ++it) {
+        key[it][0] = float_key(r[it].x) >> 16; key[it][1] = float_key(r[it].y) >> 16;
+        key[it][2] = float_key(r[it].z) >> 16; key[it][3] = float_key(r[it].w) >> 16;
+    }
+    // ---- pass 0: top 8 bits, replicated histogram
+    for (int t = tid; t < O7_HIST2; t += NT) h[t] = 0;
+    __syncthreads();
+    const int rep = lane & (O7_REP - 1), spill = O7_SPILL + lane;
+#pragma unroll
+    for (int it = 0; it < NV4; ++it)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const uint32_t kk = key[it][c];
+            atomicAdd(&h[kk != 0x007fu ? (int)((kk >> 8) * O7_REP) + rep : spill], 1);   // 0x007f = -inf: never ranks
+        }
+    __syncthreads();
+    for (int t = tid; t < 256; t += NT) {
+        const int4 a = *reinterpret_cast<const int4 *>(&h[t * O7_REP]);
+        const int4 b = *reinterpret_cast<const int4 *>(&h[t * O7_REP + 4]);
+        hist[t] = a.x + a.y + a.z + a.w + b.x + b.y + b.z + b.w;
+    }
+    __syncthreads();
+    uint32_t prefix = 0;
+    int krem = k;
+#pragma unroll 1
+    for (int pass = 0; pass < 2; ++pass) {
+        const int c0 = hist[4 * lane], c1 = hist[4 * lane + 1], c2 = hist[4 * lane + 2], c3 = hist[4 * lane + 3];
+        const int s4 = c0 + c1 + c2 + c3;
+        const int incl = wave_scan_incl_dpp(s4);
+        const int total = readlane63(incl);
+        if (total < krem) return -__builtin_inff();     // fewer than k values: the k-th largest is below everything
+        int above = total - incl;                        // values in bins of higher lanes
+        int digit = -1, kn = 0;
+        if (above < krem && above + c3 >= krem) { digit = 4 * lane + 3; kn = krem - above; }
+        above += c3;
+        if (digit < 0 && above < krem && above + c2 >= krem) { digit = 4 * lane + 2; kn = krem - above; }
+        above += c2;
+        if (digit < 0 && above < krem && above + c1 >= krem) { digit = 4 * lane + 1; kn = krem - above; }
+        above += c1;
+        if (digit < 0 && above < krem && above + c0 >= krem) { digit = 4 * lane; kn = krem - above; }
+        const unsigned long long who = __ballot(digit >= 0);
+        const int src = __ffsll((long long)who) - 1;
+        digit = __builtin_amdgcn_readlane(digit, src);
+        krem = __builtin_amdgcn_readlane(kn, src);
+        prefix |= (uint32_t)digit << (8 - 8 * pass);
+        if (pass == 1) break;
+        // ---- pass 1: low 8 bits among the values of the chosen top bin, single histogram
+        __syncthreads();   // everyone has read hist
+        for (int t = tid; t < 256 + 64; t += NT) h[O7_SPILL + t] = 0;
+        __syncthreads();
+        const uint32_t top = prefix >> 8;
+#pragma unroll
+        for (int it = 0; it < NV4; ++it)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const uint32_t kk = key[it][c];
+                atomicAdd(&h[((kk >> 8) == top && kk != 0x007fu) ? O7_HIST2 + (int)(kk & 255u) : spill], 1);
+            }
+        __syncthreads();
+    }
+    prefix <<= 16;
+    if (!(prefix & 0x80000000u)) prefix |= 0xffffu;   // negative float: key = ~bits, low half all ones
+    return key_float(prefix);
+}
+
+
 }  // namespace lantern

@@ -242,6 +242,22 @@ class Model(nn.Module):
             return out.view(*lead, V)
         return head(hidden)
 
+    def _expand_depth(self, head, hidden, proc, pos_ids, scores, k):
+        """One expansion depth: head -> CFG -> processors -> log-softmax -> top-k (+ parents' scores) -> best k of n*k.  Lumina
+        with a bf16 nn.Linear head takes the fused path (lantern_head_expand: the head's [2, n, V] logits never reach HBM);
+        everything else the three-step composition.  hidden [2, n, H] or [2, H] (cond row(s), then uncond)."""
+        w = getattr(head, "weight", None)
+        n = hidden.shape[1] if hidden.dim() == 3 else 1
+        if (self.model_type == "lumina_mgpt" and isinstance(head, nn.Linear) and w is not None and w.is_cuda and w.dtype == torch.bfloat16
+                and hidden.dtype == torch.bfloat16 and w.shape[1] % 16 == 0 and n <= 16 and n * k <= 256 and pos_ids is not None):
+            top_k = min(int(proc[1].image_top_k), w.shape[0]) if (proc is not None and len(proc) > 1) else 0
+            return ops.head_expand(hidden.reshape(2 * n, -1), w, self.image_lo, self.image_hi - self.image_lo, float(self.cfg_scale),
+                                   bias=head.bias, model=ops.MODEL_LUMINA, pos_ids=pos_ids.reshape(-1), pos_base=2, top_k_filter=top_k,
+                                   scores_in=scores, top_k=k)
+        ho = self._head(head, hidden)
+        rows = self._post_head(ho[0:1] if hidden.dim() == 2 else ho[0], ho[1:2] if hidden.dim() == 2 else ho[1], proc, pos_ids=pos_ids)
+        return ops.expand_dynamic(rows[None], scores, k)
+
     def _post_head(self, cond, uncond, proc, pos_ids=None, pos_base=2):
         """CFG combine + the model's mask + its processors on the head's rows -> processed logits [R,V] f32 (dense rows: the tree
         ops and the verify side index them by token id)."""
@@ -411,9 +427,9 @@ class Model(nn.Module):
             out_hidden, pkv = self(hidden_states, input_ids=input_ids, attention_mask=attention_mask, position_ids=position_ids, use_cache=True)
         self.stable_kv = pkv
         last_hidden = out_hidden[:, -1]
-        ho = self._head(head, last_hidden)                                                  # [2,V]
-        rows = self._post_head(ho[0:1], ho[1:2], logits_processors, pos_ids=len_posi[1])
         if tree_type == "static":
+            ho = self._head(head, last_hidden)                                                  # [2,V]
+            rows = self._post_head(ho[0:1], ho[1:2], logits_processors, pos_ids=len_posi[1])
             tb = self.tree_buffer
             ss_token, ss_prob, ss_op = [], [], []
             for i in range(len(tb["tree_indices"])):
@@ -434,7 +450,7 @@ class Model(nn.Module):
             ss_token.append(idx); ss_prob.append(prob); ss_op.append(op)
             return torch.cat(ss_token), torch.cat(ss_prob), ss_op
         # dynamic (EAGLE-2)
-        ti, cu, ci, scores = ops.expand_dynamic(rows[None], None, k)
+        ti, cu, ci, scores = self._expand_depth(head, last_hidden, logits_processors, len_posi[1], None, k)
         scores_list, ss_token = [cu.reshape(-1)], [ti.reshape(-1)]
         parents_list = [torch.zeros(1, dtype=torch.long, device=dev)]
         input_ids = ti.reshape(1, -1)
@@ -448,9 +464,7 @@ class Model(nn.Module):
                                    past_key_values=pkv, position_ids=position_ids, use_cache=True)
             len_posi = len_posi + 1
             parents_list.append(cs + (1 + k * k * max(0, i - 1) + (k if i > 0 else 0)))
-            ho = self._head(head, out_hidden)
-            rows = self._post_head(ho[0], ho[1], logits_processors, pos_ids=position_ids[1] + 1)
-            ti, cu, ci, scores = ops.expand_dynamic(rows[None], scores, k)
+            ti, cu, ci, scores = self._expand_depth(head, out_hidden, logits_processors, position_ids[1] + 1, scores, k)
             cs = ci[0]
             out_ids = cs // k
             input_hidden = out_hidden[:, out_ids]

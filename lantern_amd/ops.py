@@ -622,6 +622,31 @@ def linear_rows(A, weight, row_lo: int, n_rows: int, bias=None, out=None, out_co
     return out
 
 
+def head_expand(A, weight, row_lo: int, n_cols: int, cfg: float, bias=None, model: int = MODEL_LUMINA, pos_ids=None, pos_base: int = 2,
+                w: int = 48, h: int = 48, newline_id: int = 8803, eos_id: int = 8196, top_k_filter: int = 0, scores_in=None, top_k: int = 10):
+    """8f-2 fused: one drafter expansion depth from hidden states to top-k (lantern_head_expand).  A [2n, K] bf16 (n cond rows, then
+    n uncond rows), weight [V, K] bf16.  Returns (topk_index [1,n,k], cu_scores [1,n,k], topk_cs_index [1,k], scores_out [1,k]) like
+    expand_dynamic on a batch of one sequence."""
+    A = _dev(A, torch.bfloat16, "A")
+    weight = _dev(weight, torch.bfloat16, "weight")
+    n = A.shape[0] // 2
+    K, V = A.shape[1], weight.shape[0]
+    dev = A.device
+    ws = torch.empty((n, n_cols), dtype=torch.bfloat16, device=dev)
+    ti = torch.empty((1, n, top_k), dtype=torch.int64, device=dev)
+    cu = torch.empty((1, n, top_k), dtype=torch.float32, device=dev)
+    ci = torch.empty((1, top_k), dtype=torch.int64, device=dev)
+    so = torch.empty((1, top_k), dtype=torch.float32, device=dev)
+    pos = None if pos_ids is None else _dev(pos_ids.reshape(-1), torch.int64, "pos_ids")
+    si = None if scores_in is None else _dev(scores_in.reshape(-1), torch.float32, "scores_in")
+    b = None if bias is None else _dev(bias, torch.bfloat16, "bias")
+    check(_lib.lib().lantern_head_expand(C.c_void_p(A.data_ptr()), C.c_void_p(weight.data_ptr()), C.c_void_p(_ptr(b)), n, K, int(row_lo), int(n_cols), V,
+                                         C.c_float(cfg), int(model), C.c_void_p(_ptr(pos)), C.c_int64(pos_base), w, h, newline_id, eos_id, int(top_k_filter),
+                                         C.c_void_p(_ptr(si)), int(top_k), C.c_void_p(ws.data_ptr()), C.c_void_p(ti.data_ptr()), C.c_void_p(cu.data_ptr()),
+                                         C.c_void_p(ci.data_ptr()), C.c_void_p(so.data_ptr()), _stream()), "head_expand")
+    return ti, cu, ci, so
+
+
 def drafter_attention_mask(attention_mask, tree_mask, B: int, T: int, past: int, device=None):
     """a5: additive [B,1,T,past+T] f32 mask = causal + padding (+ tree), Model._prepare_decoder_attention_mask in one launch.
     attention_mask [B,L] bool or None; tree_mask [1|B,1,t0,t1] f32 or None."""

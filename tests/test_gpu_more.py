@@ -125,3 +125,38 @@ def test_vq_table_builder_llamagen_size():
         assert (row != exp).mean() < 1e-3                                      # only near-ties may swap
     packed = ops.pack_vq_table(torch.from_numpy(t.view(np.int16)).cuda(), 1008).cpu().numpy().view(np.uint16)
     assert np.array_equal(packed[:, :1008], t[:, :1008])
+
+
+@pytest.mark.parametrize("n,K,special", [(10, 512, ""), (1, 256, ""), (10, 4096, ""), (10, 256, "newline"), (7, 128, "eos"), (16, 64, "few")])
+def test_head_expand_fused_equals_the_three_step_composition(n, K, special):
+    """8f-2: lantern_head_expand (head GEMM with the CFG combination as its epilogue -> per-row processors + log-softmax + top-k ->
+    best k of n*k) against lantern_linear_rows -> lantern_cfg_mask_topk -> lantern_expand_dynamic on the same inputs: token ids and
+    parent indices exact, cumulative scores to the last bit or two (the f64 sum of exponentials is taken in another order)."""
+    torch.manual_seed(100 * n + K)
+    V, lo, W = 65536, 4, 8192
+    A = (0.5 * torch.randn(2 * n, K, device="cuda")).to(torch.bfloat16)
+    Wt = (0.3 * torch.randn(V, K, device="cuda")).to(torch.bfloat16)
+    bias = (0.1 * torch.randn(V, device="cuda")).to(torch.bfloat16)
+    if special == "few":          # a head that leaves only 5 distinct large logits: ties and the -inf tail of the top-k
+        Wt[lo + 5:lo + W] = 0
+        bias[lo + 5:lo + W] = -30000.0
+    pos = torch.full((n,), 2 + 3, device="cuda", dtype=torch.int64)                         # image tokens 4, 5, ... of row 0
+    pos = pos + torch.arange(n, device="cuda")
+    if special == "newline":
+        pos[2] = 2 + 48                                    # token 49 of a 48-wide row: forced newline
+    if special == "eos":
+        pos[1] = 2 + 49 * 48                               # forced end of image
+    scores_in = torch.randn(n, device="cuda") if n > 1 else None
+    tk = 2000 if special != "few" else 3
+    fused = ops.head_expand(A, Wt, lo, W, 3.0, bias=bias, model=ops.MODEL_LUMINA, pos_ids=pos, pos_base=2, top_k_filter=tk,
+                            scores_in=scores_in, top_k=10)
+    buf = torch.zeros((2 * n, V), dtype=torch.bfloat16, device="cuda")
+    logits = ops.linear_rows(A, Wt, lo, W, bias=bias, out=buf)
+    rows = ops.cfg_mask_topk(logits[:n], logits[n:], 3.0, model=ops.MODEL_LUMINA, pos_ids=pos, pos_base=2, img_lo=lo, img_hi=lo + W, top_k=tk)
+    ref = ops.expand_dynamic(rows[None], None if scores_in is None else scores_in[None], 10)
+    assert torch.equal(fused[0], ref[0]), (fused[0], ref[0])
+    assert torch.equal(fused[2], ref[2])
+    fin = torch.isfinite(ref[1])
+    assert torch.equal(torch.isfinite(fused[1]), fin)
+    assert torch.allclose(fused[1][fin], ref[1][fin], rtol=0, atol=2e-6)
+    assert torch.allclose(fused[3][torch.isfinite(ref[3])], ref[3][torch.isfinite(ref[3])], rtol=0, atol=2e-6)

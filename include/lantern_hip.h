@@ -227,6 +227,12 @@ int lantern_evaluate_posterior(const lantern_ep_params *prm, const lantern_ep_bu
  * into LDS; same arithmetic, same bits (the row's distribution does not depend on when it is computed). */
 #define LANTERN_ROWS_LOGITS 0
 #define LANTERN_ROWS_PROBS 1
+/* RAW_BF16 (lantern_evaluate_posterior_window only): buf->logits is the target model's CONDITIONAL head output [B, rows_per_seq, V]
+ * in bf16 and win->raw_uncond the unconditional one; the whole post-process of tree_decoding (ea_model_lumina_mgpt.py:597-607: CFG
+ * combination, MultiModalLogitsProcessor's row classes from the positions, InterleavedTopKLogitsWarper, softmax) runs inside the
+ * kernel, for the rows the walk visits only (~3.7 of a 26-node tree's rows per step) -- lantern_cfg_mask_topk_window is not
+ * launched at all.  Same arithmetic as that kernel, so the same bits.  Lumina windows of exactly 8192 ids on the packed table. */
+#define LANTERN_ROWS_RAW_BF16 2
 
 /* O7 windowed: same arguments as lantern_cfg_mask_topk, output [rows, win_len] f32 + row_hot [rows].
  * LANTERN_MODEL_PLAIN requires win_lo = 0, win_len = V.  `temperature` (> 1e-5; 1.0 = none) divides the row
@@ -254,8 +260,16 @@ typedef struct lantern_ep_window {
     float *out_mass;              /* [dev] [B] out: its probability */
     const double *u_bonus;        /* [dev] [B] or NULL: uniform for the bonus-token draw */
     int64_t *token;               /* [dev] [B] out (with u_bonus): inverse-CDF bonus token */
-    int32_t rows_kind;            /* LANTERN_ROWS_LOGITS | LANTERN_ROWS_PROBS: what buf->logits rows hold */
+    int32_t rows_kind;            /* LANTERN_ROWS_LOGITS | LANTERN_ROWS_PROBS | LANTERN_ROWS_RAW_BF16: what buf->logits rows hold */
     int32_t reserved;
+    /* LANTERN_ROWS_RAW_BF16 only (ignored otherwise) */
+    const void *raw_uncond;       /* [dev] [B, rows_per_seq, V] bf16 */
+    const int64_t *raw_pos_ids;   /* [dev] [rows_per_seq] i64: tree_position_ids + 1 (shared tree) */
+    const int64_t *raw_seq_len;   /* [dev] [B] i64: len(input_ids) of every sequence */
+    int64_t raw_pos_base;         /* num_generated_image_tokens = pos - pos_base */
+    float raw_cfg;                /* guidance scale */
+    int32_t raw_top_k;            /* InterleavedTopKLogitsWarper image_top_k (0 = off) */
+    int32_t raw_w_latent, raw_h_latent, raw_newline_id, raw_eos_id;
 } lantern_ep_window;
 
 /* O8 windowed.  buf->logits is [B, rows_per_seq, win_len]; buf->sample_p may be NULL (if given, the dense
@@ -321,7 +335,8 @@ int lantern_evaluate_posterior_nodes(const lantern_ep_params *prm, const lantern
  * update_inference_inputs), with nothing returning to the host.  Groups are independent sequences, so their streams are not
  * ordered against each other: one group's latency-bound evaluate_posterior overlaps the other groups' bandwidth-bound kernels.
  * Every field has the meaning of the same-named argument of the entry point it is passed to; the host loop only patches the
- * step-dependent pointers (where this step's outputs go) between calls.  slab_ptrs == NULL skips O9 + O10.
+ * step-dependent pointers (where this step's outputs go) between calls.  slab_ptrs == NULL skips O9 + O10; out_win == NULL skips O7
+ * (ep_win.rows_kind == LANTERN_ROWS_RAW_BF16: evaluate_posterior reads the raw cond / uncond logits itself).
  */
 typedef struct lantern_step_group {
     void *stream;

@@ -335,6 +335,81 @@ __device__ __forceinline__ void row_softmax_to_lds(float4 (&r)[E4], int hot, boo
     __syncthreads();
 }
 
+// ---- LANTERN_ROWS_RAW_BF16: the row arrives as the target model's raw cond / uncond logits (bf16) and the whole post-process
+// of tree_decoding (CFG combination, top-k threshold, softmax: ea_model_lumina_mgpt.py:597-607) runs HERE, for the rows the walk
+// actually visits -- 2.7 + 1 of a tree's 26 rows per step -- instead of for every row in a separate launch.  Same code as
+// cfg_window_bf16_kernel (same tile layout, same reductions), so the probabilities are the same bits.  The 16 row registers
+// carry two 16-byte chunks of cond and two of uncond per thread until they are needed.
+template <int NT>
+__device__ __forceinline__ void raw_row_load(const uint16_t *__restrict__ crow, const uint16_t *__restrict__ urow, float4 (&rp)[4]) {
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int ch = threadIdx.x + it * NT;
+        const Bf16x8 c = *reinterpret_cast<const Bf16x8 *>(crow + ch * 8), u = *reinterpret_cast<const Bf16x8 *>(urow + ch * 8);
+        rp[it] = make_float4(__uint_as_float(c.a.x), __uint_as_float(c.a.y), __uint_as_float(c.b.x), __uint_as_float(c.b.y));
+        rp[2 + it] = make_float4(__uint_as_float(u.a.x), __uint_as_float(u.a.y), __uint_as_float(u.b.x), __uint_as_float(u.b.y));
+    }
+}
+
+template <int NT, typename Hook = NoHook>
+__device__ __forceinline__ void raw_row_to_lds(const float4 (&rp)[4], int hot, float cfg, int top_k, int V, int win_lo, int W, float *g,
+                                               int &out_tok, float &out_mass, EwShared &S, int *hist, int &ph, const Hook &pre_barrier = Hook()) {
+    const int tid = threadIdx.x;
+    const float NEG_INF = -__builtin_inff();
+    out_tok = -1;
+    out_mass = 0.0f;
+    if (hot >= 0) {
+        const bool inside = hot >= win_lo && hot < win_lo + W;
+        for (int i4 = tid; i4 * 4 < W; i4 += NT) {
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            const int e = win_lo + i4 * 4;
+            if (hot >= e && hot < e + 4) set_comp(v, hot - e, 1.0f);
+            reinterpret_cast<float4 *>(g)[i4] = v;
+        }
+        if (!inside) {
+            out_tok = hot;
+            out_mass = 1.0f;
+        }
+        if (tid == 0) g[W + EW_G_OUT] = out_mass;
+        pre_barrier();
+        __syncthreads();
+        return;
+    }
+    float4 r[4];
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const uint32_t cw[4] = {__float_as_uint(rp[it].x), __float_as_uint(rp[it].y), __float_as_uint(rp[it].z), __float_as_uint(rp[it].w)};
+        const uint32_t uw[4] = {__float_as_uint(rp[2 + it].x), __float_as_uint(rp[2 + it].y), __float_as_uint(rp[2 + it].z), __float_as_uint(rp[2 + it].w)};
+        float o[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const float c = __uint_as_float((q & 1) ? (cw[q >> 1] & 0xffff0000u) : (cw[q >> 1] << 16));
+            const float u = __uint_as_float((q & 1) ? (uw[q >> 1] & 0xffff0000u) : (uw[q >> 1] << 16));
+            o[q] = round_bf16(u + round_bf16(cfg * round_bf16(c - u)));
+        }
+        r[2 * it] = make_float4(o[0], o[1], o[2], o[3]);
+        r[2 * it + 1] = make_float4(o[4], o[5], o[6], o[7]);
+    }
+    if (top_k > 0 && top_k < V) {
+        const float thr = (top_k <= W) ? kth_largest_hist_bf16<NT, 4>(r, top_k, hist) : NEG_INF;
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            r[it].x = r[it].x < thr ? NEG_INF : r[it].x; r[it].y = r[it].y < thr ? NEG_INF : r[it].y;
+            r[it].z = r[it].z < thr ? NEG_INF : r[it].z; r[it].w = r[it].w < thr ? NEG_INF : r[it].w;
+        }
+    }
+    softmax_tile<NT, 4>(r, S.redf, S.redd, ph);
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        float *dst = g + (size_t)(tid + it * NT) * 8;
+        *reinterpret_cast<float4 *>(dst) = r[2 * it];
+        *reinterpret_cast<float4 *>(dst + 4) = r[2 * it + 1];
+    }
+    if (tid == 0) g[W + EW_G_OUT] = 0.0f;
+    pre_barrier();
+    __syncthreads();
+}
+
 // LDSIDS: every candidate's neighbour ids are staged in LDS (k + 1 <= EW_PF_K, or LANTERN off), so the serial wave-0
 // section contains no vector-memory instruction -- the compiler then has no reason to drain vmcnt inside it and the
 // drafter-row / id loads issued before it stay in flight across the scan.  !LDSIDS (k > 1023) reads ids from HBM.
@@ -358,8 +433,10 @@ typedef const __attribute__((address_space(4))) EpwArgs *EpwArgsK;
 // -7 % at 48 sequences (a few spills), hence selected by batch size.
 // FULLW: the window is exactly the workgroup's register tile (W == 4 * NT * E4, the Lumina / Anole 8192-id image range on
 // 512 x 4): no per-chunk bounds predicate, so the four chunks of a pass are one basic block and their LDS reads go out together.
-template <int NT, int E4, int IDMODE, int WPE, bool FULLW = false>
+// RAW: rows are the target model's raw cond / uncond bf16 logits (LANTERN_ROWS_RAW_BF16; W == 8 * 2 * NT, packed table).
+template <int NT, int E4, int IDMODE, int WPE, bool FULLW = false, bool RAW = false>
 __global__ __launch_bounds__(NT, WPE) void epw_kernel(const EpwArgs args) {
+    static_assert(!RAW || (FULLW && E4 == 4), "raw rows: the 8192-id window on 512 threads");
     constexpr bool LDSIDS = IDMODE != 0;
     const lantern_ep_params &prm = args.prm;
     const lantern_ep_buffers &buf = args.buf;
@@ -377,6 +454,7 @@ __global__ __launch_bounds__(NT, WPE) void epw_kernel(const EpwArgs args) {
     int *const Srow = Scand + pd_cap, *const Spidx = Srow + pd_cap, *const Sboff = Spidx + pd_cap;
     float *const Scart = reinterpret_cast<float *>(Sboff + pd_cap);
     int *const Sflag = reinterpret_cast<int *>(Scart + pd_cap);       // per (path, depth): bit 1 image token, bit 0 syntax token
+    int *const Shist = Sflag + pd_cap;                                // RAW: the radix-select histograms of the row post-process
     const int P = buf.n_paths ? buf.n_paths[b] : Ps;
     const int D = buf.n_depth ? buf.n_depth[b] : Ds;
     const int k = prm.k, off = prm.tok_offset;
@@ -395,6 +473,8 @@ __global__ __launch_bounds__(NT, WPE) void epw_kernel(const EpwArgs args) {
     // ---- stage every small per-step table in LDS: two rounds of global loads (everything independent first, then what
     // needs the uniform cursor / the sibling count / the first row id), all issued before the first wait
     const float *logits = buf.logits + (size_t)b * prm.rows_per_seq * W;
+    const uint16_t *raw_c = RAW ? reinterpret_cast<const uint16_t *>(buf.logits) + (size_t)b * prm.rows_per_seq * V + lo : nullptr;
+    const uint16_t *raw_u = RAW ? reinterpret_cast<const uint16_t *>(win.raw_uncond) + (size_t)b * prm.rows_per_seq * V + lo : nullptr;
     const int32_t *hot_g = win.row_hot ? win.row_hot + (size_t)b * prm.rows_per_seq : nullptr;
     const int ucur0 = buf.cursor ? buf.cursor[b] : 0;
     float4 rp[E4];              // prefetched row (registers) and the row id it holds
@@ -424,6 +504,11 @@ __global__ __launch_bounds__(NT, WPE) void epw_kernel(const EpwArgs args) {
             const int t = tid + u * NT;
             tc_[u] = (is_static && t < prm.N && t < EW_MAX_N) ? (int)buf.tree_cand[(size_t)b * prm.N + t] : 0;
             hot_[u] = (hot_g && hot_in_lds && t < prm.rows_per_seq) ? hot_g[t] : -1;
+            if (RAW && t < prm.rows_per_seq) {          // the row's class from its position (MultiModalLogitsProcessor, ea_model_lumina_mgpt.py:45-86)
+                const int64_t n1 = win.raw_pos_ids[t] + win.raw_seq_len[b] - win.raw_pos_base + 1;
+                hot_[u] = (n1 == ((int64_t)win.raw_w_latent + 1) * win.raw_h_latent + 1) ? win.raw_eos_id
+                          : (py_mod64(n1, (int64_t)win.raw_w_latent + 1) == 0 ? win.raw_newline_id : -1);
+            }
         }
         if (is_static && tid < Ds - 1) oo_ = buf.op_off[tid];
         double ub_ = 0.0;                   // read by the epilogue from LDS: a global load there sits on the chain with its full latency
@@ -439,7 +524,8 @@ __global__ __launch_bounds__(NT, WPE) void epw_kernel(const EpwArgs args) {
             bi_[u] = (t < nb_total && t < EW_MAX_B) ? buf.b_idx[t] : 0;
         }
         if (rid1 >= 0 && rid1 < prm.rows_per_seq) {
-            row_load<NT, E4, FULLW>(logits + (size_t)rid1 * W, W, rp);
+            if constexpr (RAW) raw_row_load<NT>(raw_c + (size_t)rid1 * V, raw_u + (size_t)rid1 * V, rp);
+            else row_load<NT, E4, FULLW>(logits + (size_t)rid1 * W, W, rp);
             rp_rid = rid1;
         }
         // LDS stores
@@ -475,7 +561,7 @@ __global__ __launch_bounds__(NT, WPE) void epw_kernel(const EpwArgs args) {
             }
             if (tid < Ds - 1) S.opoff[tid] = oo_;
         }
-        if (hot_g && hot_in_lds) {
+        if ((hot_g || RAW) && hot_in_lds) {
 #pragma unroll
             for (int u = 0; u < N_PER; ++u) {
                 const int t = tid + u * NT;
@@ -591,11 +677,14 @@ __global__ __launch_bounds__(NT, WPE) void epw_kernel(const EpwArgs args) {
         {
             int rid = Srow[fi * Ds + (i - 1)];
             rid = rid < 0 ? 0 : (rid >= prm.rows_per_seq ? prm.rows_per_seq - 1 : rid);     // a bad row map must not read outside the batch
-            const int hot = !hot_g ? -1 : (hot_in_lds ? S.hot[rid] : hot_g[rid]);
+            const int hot = RAW ? S.hot[rid] : (!hot_g ? -1 : (hot_in_lds ? S.hot[rid] : hot_g[rid]));
             EPW_STAMP(10);
-            if (hot < 0 && rp_rid != rid) row_load<NT, E4, FULLW>(logits + (size_t)rid * W, W, rp);
+            if (hot < 0 && rp_rid != rid) {
+                if constexpr (RAW) raw_row_load<NT>(raw_c + (size_t)rid * V, raw_u + (size_t)rid * V, rp);
+                else row_load<NT, E4, FULLW>(logits + (size_t)rid * W, W, rp);
+            }
             rp_rid = -1;
-            row_softmax_to_lds<NT, E4, FULLW>(rp, hot, rows_probs, lo, W, prm.temperature, prm.top_k, V, g, out_tok, out_mass, S, ph, [&]() {
+            auto stage_ids = [&]() {
                 if (can_prefetch && IDMODE == 2) {
 #pragma unroll
                     for (int u = 0; u < PF16_PER; ++u) {
@@ -625,7 +714,9 @@ __global__ __launch_bounds__(NT, WPE) void epw_kernel(const EpwArgs args) {
                             }
                         }
                 }
-            });
+            };
+            if constexpr (RAW) raw_row_to_lds<NT>(rp, hot, win.raw_cfg, win.raw_top_k, V, lo, W, g, out_tok, out_mass, S, Shist, ph, stage_ids);
+            else row_softmax_to_lds<NT, E4, FULLW>(rp, hot, rows_probs, lo, W, prm.temperature, prm.top_k, V, g, out_tok, out_mass, S, ph, stage_ids);
             EPW_STAMP(11);
         }
         unsigned long long todo = todo0;
@@ -957,9 +1048,13 @@ __global__ __launch_bounds__(NT, WPE) void epw_kernel(const EpwArgs args) {
     if (status == LANTERN_ST_OK && !from_residual) {
         int rid = Srow[best * Ds + (a - 1)];
         rid = rid < 0 ? 0 : (rid >= prm.rows_per_seq ? prm.rows_per_seq - 1 : rid);
-        const int hot = !hot_g ? -1 : (hot_in_lds ? S.hot[rid] : hot_g[rid]);
-        if (hot < 0 && rp_rid != rid) row_load<NT, E4, FULLW>(logits + (size_t)rid * W, W, rp);
-        row_softmax_to_lds<NT, E4, FULLW>(rp, hot, rows_probs, lo, W, prm.temperature, prm.top_k, V, g, out_tok, out_mass, S, ph);
+        const int hot = RAW ? S.hot[rid] : (!hot_g ? -1 : (hot_in_lds ? S.hot[rid] : hot_g[rid]));
+        if (hot < 0 && rp_rid != rid) {
+            if constexpr (RAW) raw_row_load<NT>(raw_c + (size_t)rid * V, raw_u + (size_t)rid * V, rp);
+            else row_load<NT, E4, FULLW>(logits + (size_t)rid * W, W, rp);
+        }
+        if constexpr (RAW) raw_row_to_lds<NT>(rp, hot, win.raw_cfg, win.raw_top_k, V, lo, W, g, out_tok, out_mass, S, Shist, ph);
+        else row_softmax_to_lds<NT, E4, FULLW>(rp, hot, rows_probs, lo, W, prm.temperature, prm.top_k, V, g, out_tok, out_mass, S, ph);
     }
     // ---------------------------------------------------------------- epilogue: outputs from LDS
     EPW_STAMP(40);
@@ -1203,7 +1298,22 @@ extern "C" int lantern_evaluate_posterior_window(const lantern_ep_params *prm, c
     if (p.lantern)
         LANTERN_CHECK_ARG(buf->nn_table && p.k >= 1 && p.k <= p.table_cols && p.table_rows > 0, "evaluate_posterior_window: lantern needs nn_table, 1<=k<=cols");
     if (win->u_bonus) LANTERN_CHECK_ARG(win->token, "evaluate_posterior_window: u_bonus needs token");
-    LANTERN_CHECK_ARG(win->rows_kind == LANTERN_ROWS_LOGITS || win->rows_kind == LANTERN_ROWS_PROBS, "evaluate_posterior_window: bad rows_kind");
+    LANTERN_CHECK_ARG(win->rows_kind == LANTERN_ROWS_LOGITS || win->rows_kind == LANTERN_ROWS_PROBS || win->rows_kind == LANTERN_ROWS_RAW_BF16,
+                      "evaluate_posterior_window: bad rows_kind");
+    const bool raw = win->rows_kind == LANTERN_ROWS_RAW_BF16;
+    if (raw) {
+        LANTERN_CHECK_ARG(win->raw_uncond && win->raw_pos_ids && win->raw_seq_len && win->raw_w_latent > 0 && win->raw_h_latent > 0 &&
+                              win->raw_newline_id >= 0 && win->raw_newline_id < p.V && win->raw_eos_id >= 0 && win->raw_eos_id < p.V,
+                          "evaluate_posterior_window: raw rows need the unconditional logits, positions, sequence lengths and the Lumina grammar ids");
+        LANTERN_CHECK_ARG(p.top_k <= 0 && p.temperature == 1.0f && p.rows_per_seq <= EW_MAX_N && win->win_lo % 4 == 0 && p.V % 8 == 0 &&
+                              win->win_lo == p.img_lo && win->win_lo + win->win_len == p.img_hi,
+                          "evaluate_posterior_window: raw rows: the window is the image-token range, the processors are the Lumina ones (raw_top_k)");
+        if (!(win->win_len == 8192 && p.lantern && p.table_cols % 8 == 0 && ((uintptr_t)buf->nn_table & 15) == 0 &&
+              ((p.k + 1 < p.table_cols ? p.k + 1 : p.table_cols) <= EW_PF_K))) {
+            set_error("evaluate_posterior_window: raw rows are built for the 8192-id window on the packed neighbour table (k + 1 <= %d)", EW_PF_K);
+            return LANTERN_E_UNSUPPORTED;
+        }
+    }
     if (win->rows_kind == LANTERN_ROWS_PROBS)
         LANTERN_CHECK_ARG(p.top_k <= 0 && p.temperature == 1.0f, "evaluate_posterior_window: probability rows are final -- apply temperature/top-k where they are produced (cfg_mask_topk_window)");
     if (p.top_p > 0.0f && p.top_p < 1.0f) {
@@ -1216,7 +1326,7 @@ extern "C" int lantern_evaluate_posterior_window(const lantern_ep_params *prm, c
     }
     hipStream_t st = (hipStream_t)stream;
     const int W = win->win_len;
-    const size_t lds = epw_shared_offset(W) + sizeof(EwShared) + (size_t)6 * epw_pd_cap(p.P, p.D) * 4;
+    const size_t lds = epw_shared_offset(W) + sizeof(EwShared) + (size_t)6 * epw_pd_cap(p.P, p.D) * 4 + (raw ? (size_t)O7_HIST_INTS * 4 : 0);
     dim3 grid(p.B);
     const int nz = (p.k + 1 < p.table_cols) ? p.k + 1 : p.table_cols;
     const bool lds_ids = !p.lantern || nz <= EW_PF_K;
@@ -1234,6 +1344,10 @@ extern "C" int lantern_evaluate_posterior_window(const lantern_ep_params *prm, c
     if (W <= 1024) EPW_LAUNCH(256, 1);
     else if (W <= 2048) EPW_LAUNCH(256, 2);
     else if (W <= 4096) EPW_LAUNCH(512, 2);
+    else if (raw) {
+        if (two_per_cu) LANTERN_LAUNCH((epw_kernel<512, 4, 2, 4, true, true>), grid, dim3(512), lds, st, args);
+        else LANTERN_LAUNCH((epw_kernel<512, 4, 2, 1, true, true>), grid, dim3(512), lds, st, args);
+    }
     else if (W <= 8192) {
         if (two_per_cu && W == 8192 && idmode == 2) LANTERN_LAUNCH((epw_kernel<512, 4, 2, 4, true>), grid, dim3(512), lds, st, args);
         else if (two_per_cu) EPW_LAUNCH_W(512, 4, 4);

@@ -81,6 +81,8 @@ class WorkloadConfig:
     pack_table: bool = True         # windowed path: neighbour table packed to [K, ceil8(k+1)] (lantern_pack_vq_table)
     ep_kernel: str = "nodes"        # windowed path: "nodes" = node-parallel evaluate_posterior (one workgroup per internal tree node + the
                                     # walk; B * n_internal workgroups fill the GPU), "chain" = one serial chain per sequence (epw_kernel)
+    fuse_o7: bool = False           # windowed chain kernel: LANTERN_ROWS_RAW_BF16 -- no O7 launch, evaluate_posterior post-processes (CFG, top-k,
+                                    # softmax) the rows its walk visits from the raw cond / uncond logits
     native_step: bool = True        # eager windowed path: the whole step of all groups through ONE C call (lantern_verify_step) instead of
                                     # 4 x n_groups ctypes calls (the Python launch loop caps the stream groups at ~2 otherwise)
     leaf_workgroups: int = -1       # node kernel: -1 = by batch size (include/lantern_hip.h lantern_ep_nodes)
@@ -151,6 +153,7 @@ class LuminaVerifyWorkload:
         self.cond = torch.empty((S, B, N, V), dtype=torch.bfloat16, device=device)
         self.uncond = torch.empty((S, B, N, V), dtype=torch.bfloat16, device=device)
         self.windowed = cfg.path == "window"
+        self.fused_o7 = self.windowed and cfg.fuse_o7 and cfg.ep_kernel == "chain"
         self.win_lo, self.W = IMG_LO, IMG_HI - IMG_LO
         # drafter distributions: dense [R,V] rows for the dense path; for the windowed path the pool holds what a
         # windowed drafter softmax emits, [R,W] (zero outside the image range by construction)
@@ -363,6 +366,11 @@ class LuminaVerifyWorkload:
         w.out_tok, w.out_mass = at(self.out_tok), at(self.out_mass)
         w.u_bonus, w.token = at(self.u_cur), at(self.st_token)
         w.rows_kind = ops.ROWS_PROBS if self.cfg.rows_probs else ops.ROWS_LOGITS
+        if self.fused_o7:
+            w.rows_kind = 2                                   # LANTERN_ROWS_RAW_BF16; logits / raw_uncond / raw_seq_len are set per (slot, parity)
+            w.raw_pos_ids, w.raw_pos_base = self.d_pos_ids.data_ptr(), self.cfg.prompt_len + 3
+            w.raw_cfg, w.raw_top_k = self.cfg.cfg_scale, self.cfg.top_k
+            w.raw_w_latent, w.raw_h_latent, w.raw_newline_id, w.raw_eos_id = W_LATENT, H_LATENT, NEWLINE, EOS
         return w
 
     def cond_lens(self, parity: int) -> torch.Tensor:
@@ -476,7 +484,7 @@ class LuminaVerifyWorkload:
             s.pos_ids, s.pos_base = self.d_pos_ids.data_ptr(), c.prompt_len + 3
             s.w_latent, s.h_latent, s.img_lo, s.img_hi, s.newline_id, s.eos_id, s.top_k = W_LATENT, H_LATENT, IMG_LO, IMG_HI, NEWLINE, EOS, c.top_k
             s.win_lo, s.win_len, s.out_kind = self.win_lo, self.W, ops.ROWS_PROBS if c.rows_probs else ops.ROWS_LOGITS
-            s.seq_len, s.out_win, s.row_hot, s.temperature, s.top_p = val(A["cur"]), val(A["proc"]), val(A["row_hot"]), 1.0, 1.0
+            s.seq_len, s.out_win, s.row_hot, s.temperature, s.top_p = val(A["cur"]), (None if self.fused_o7 else val(A["proc"])), val(A["row_hot"]), 1.0, 1.0
             C.memmove(C.byref(s.ep), C.byref(self._ep_prm), C.sizeof(EpParams))
             C.memmove(C.byref(s.ep_buf), C.byref(A["ep_buf"]), C.sizeof(EpBuffers))
             C.memmove(C.byref(s.ep_win), C.byref(A["ep_win"]), C.sizeof(EpWindow))
@@ -548,6 +556,9 @@ class LuminaVerifyWorkload:
             u_bonus_g=vp(self.u_bonus[:, s0:].data_ptr()),
             slab_ptrs=at(self.slab_ptrs, 2 * s0) if self.cfg.with_kv else None, slab_seq=at(self.slab_seq, 2 * s0) if self.cfg.with_kv else None,
             ep_buf=self.ep_buffers(slot, g), ep_win=self.ep_window(g) if self.windowed else None)
+        if self.fused_o7:
+            a["ep_buf"].logits = a["cond"].value
+            a["ep_win"].raw_uncond, a["ep_win"].raw_seq_len = a["uncond"].value, a["cur"].value
         cache[key] = a
         return a
 
@@ -607,9 +618,11 @@ class LuminaVerifyWorkload:
         if side is not None:
             ev[1].record(side)
         # O7 CFG + Lumina position mask + top-k, positions from the device-side lengths
-        if events:
+        if events and not self.fused_o7:
             self._arm(events, "cfg_mask_topk")
-        if self.windowed:
+        if self.fused_o7:
+            pass                                  # evaluate_posterior reads the raw logits itself
+        elif self.windowed:
             check(L.lantern_cfg_mask_topk_window(A["cond"], A["uncond"], 1, B * N, V, C.c_float(c.cfg_scale), ops.MODEL_LUMINA,
                                                  vp(self.d_pos_ids.data_ptr()), C.c_int64(c.prompt_len + 3), W_LATENT, H_LATENT, IMG_LO, IMG_HI,
                                                  NEWLINE, EOS, c.top_k, A["cur"], N, self.win_lo, self.W, A["proc"], A["row_hot"],
@@ -620,7 +633,8 @@ class LuminaVerifyWorkload:
                                           vp(self.d_pos_ids.data_ptr()), C.c_int64(c.prompt_len + 3), W_LATENT, H_LATENT, IMG_LO, IMG_HI,
                                           NEWLINE, EOS, c.top_k, A["cur"], N, A["proc"], st), "cfg_mask_topk")
         if events:
-            self._disarm(events, "cfg_mask_topk")
+            if not self.fused_o7:
+                self._disarm(events, "cfg_mask_topk")
             self._arm(events, "evaluate_posterior")
         if side is not None:
             main.wait_event(ev[1])                # O8 needs the candidates

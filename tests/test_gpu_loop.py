@@ -104,3 +104,32 @@ def test_dynamic_tree_loop_matches_oracle_loop():
     gen = (ga.astype("int64") + 1).sum(0)
     assert (wl.lens[steps & 1][:cfg.n_seq].cpu().numpy() == cfg.prompt_len + 3 + gen).all()
     assert (wl.lens[steps & 1][cfg.n_seq:].cpu().numpy() == 3 + gen).all()
+
+
+@pytest.mark.parametrize("groups", [1, 2])
+def test_fused_o7_loop_matches_oracle_loop(groups):
+    """LANTERN_ROWS_RAW_BF16: no cfg_mask_topk launch -- the chain kernel post-processes (CFG, top-k, softmax) the rows its walk
+    visits from the raw cond / uncond logits.  Same oracle loop, same token stream, and every step identical to the unfused run."""
+    import bench
+    from lantern_amd import harness as HN
+    steps = 60
+    outs = []
+    for fuse in (True, False):
+        cfg = HN.WorkloadConfig(n_seq=6, pool_steps=4, kv_layers=2, kv_heads=4, kv_smax=512, max_steps=steps + 4, sigma=5.0, n_groups=groups,
+                                ep_kernel="chain", fuse_o7=fuse)
+        wl = HN.LuminaVerifyWorkload(cfg, torch.device("cuda"))
+        assert wl.fused_o7 == fuse
+        for _ in range(steps):
+            wl.step()
+        wl.join()
+        torch.cuda.synchronize()
+        wl.check_status(0, steps)
+        outs.append((wl.log_best[:steps].clone(), wl.log_alen[:steps].clone(), wl.log_token[:steps].clone(), wl.log_cnt[:steps].clone()))
+        if fuse:
+            gb, ga, gt = [x.cpu().numpy() for x in outs[0][:3]]
+            stream = [[(int(gb[i, b]), int(ga[i, b]), int(gt[i, b])) for b in range(cfg.n_seq)] for i in range(steps)]
+            res = bench.cpu_baseline(wl, steps_budget_s=1e9, n_seq=cfg.n_seq, gpu_tokens_by_seq=stream)
+            assert res["matches_gpu_token_stream"], res
+            assert int((torch.as_tensor(gt) == HN.NEWLINE).sum()) > 0          # forced newline rows were crossed
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)

@@ -56,6 +56,7 @@ def parse():
                     help="windowed evaluate_posterior: nodes = one workgroup per internal tree node + the walk (lantern_evaluate_posterior_nodes); "
                          "chain = one serial chain per sequence (lantern_evaluate_posterior_window)")
     ap.add_argument("--fuse-o7", action="store_true", help="chain kernel on raw rows (LANTERN_ROWS_RAW_BF16): no cfg_mask_topk launch, evaluate_posterior post-processes the rows it visits")
+    ap.add_argument("--spec-rows", type=int, default=0, help="with --fuse-o7: rows of the K most likely tree nodes are post-processed up front, in the candidate-assembly launch (lantern_prepare_step); the others on demand")
     ap.add_argument("--python-launch", action="store_true", help="launch every kernel of the step from Python (4 ctypes calls per group) instead of one lantern_verify_step call")
     ap.add_argument("--no-kv", action="store_true", help="skip the KV slabs (debug only; invalid as a headline)")
     ap.add_argument("--kv-smax", type=int, default=4096, help="rows per KV slab (BASELINE.md: 4096 = max_position_embeddings; a 768x768 image needs 2481)")
@@ -301,7 +302,7 @@ def dynamic_run(device, base_cfg, steps, n_seq):
     torch.cuda.synchronize(device)
     dt = time.perf_counter() - t0
     names = ("cfg_mask_topk", "evaluate_posterior", "kv_gather") if cfg.with_kv else ("cfg_mask_topk", "evaluate_posterior")
-    if wl.fused_o7:
+    if wl.fused_o7 and not wl.n_spec:
         names = tuple(n for n in names if n != "cfg_mask_topk")
     KE = min(steps, 20)
     evs = [{n: (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for n in names} for _ in range(KE)]
@@ -486,7 +487,7 @@ def main():
             n_seq = fit
     cfg = HN.WorkloadConfig(n_seq=n_seq, pool_steps=args.pool_steps, tree=args.tree, lantern_k=args.lantern_k,
                             lantern_delta=args.lantern_delta, sigma=args.sigma, with_kv=not args.no_kv, kv_smax=args.kv_smax,
-                            path=args.path, ep_kernel=args.ep, fuse_o7=args.fuse_o7, native_step=not args.python_launch, use_graph=args.graph, n_groups=args.groups, side_stream=args.side_stream,
+                            path=args.path, ep_kernel=args.ep, fuse_o7=args.fuse_o7, spec_rows=args.spec_rows, native_step=not args.python_launch, use_graph=args.graph, n_groups=args.groups, side_stream=args.side_stream,
                             max_steps=max(args.pool_steps, args.steps + args.warmup + min(args.steps, 100)) + 8,
                             **({} if args.kv_pad_rows is None else {"kv_pad_rows": args.kv_pad_rows}))
     wl = HN.LuminaVerifyWorkload(cfg, device, rank=rank)
@@ -501,7 +502,7 @@ def main():
     for _ in range(W):
         wl.step()
     names = ("cfg_mask_topk", "evaluate_posterior", "kv_gather") if cfg.with_kv else ("cfg_mask_topk", "evaluate_posterior")
-    if wl.fused_o7:
+    if wl.fused_o7 and not wl.n_spec:
         names = tuple(n for n in names if n != "cfg_mask_topk")
     # ---- timed region: exactly K steps, barrier + synchronize on both sides
     barrier()
@@ -578,9 +579,9 @@ def main():
                     rl["traffic_source"] = "profiles/r01_v6_epw_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, FETCH doubled per the gfx950 note)"
             out["roofline"] = rl
             ks = {}
-            if not wl.fused_o7:
+            if not wl.fused_o7 or wl.n_spec:
                 o7_ms = mean_ms("cfg_mask_topk")
-                o7_b = wl.o7_algorithmic_bytes(1, group=0)
+                o7_b = wl.o7_algorithmic_bytes(1, group=0) * ((wl.n_spec / wl.N) if wl.fused_o7 else 1.0)
                 ks = {"cfg_mask_topk": {"avg_launch_ms": o7_ms, "algorithmic_bytes_per_launch": o7_b,
                                         "achieved": o7_b / (o7_ms * 1e-3) / 1e9, "frac": o7_b / (o7_ms * 1e-3) / 1e9 / 8000.0}}
             if cfg.with_kv:

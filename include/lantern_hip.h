@@ -270,6 +270,9 @@ typedef struct lantern_ep_window {
     float raw_cfg;                /* guidance scale */
     int32_t raw_top_k;            /* InterleavedTopKLogitsWarper image_top_k (0 = off) */
     int32_t raw_w_latent, raw_h_latent, raw_newline_id, raw_eos_id;
+    /* optional: rows some earlier launch already post-processed (lantern_prepare_step: the nodes the walk most likely visits) */
+    const float *raw_probs;       /* [dev] [B, rows_per_seq, win_len] f32 probabilities of the listed rows, or NULL */
+    const uint8_t *raw_pre;       /* [dev] [rows_per_seq]: 1 = the node's row is in raw_probs, 0 = post-process it on demand */
 } lantern_ep_window;
 
 /* O8 windowed.  buf->logits is [B, rows_per_seq, win_len]; buf->sample_p may be NULL (if given, the dense
@@ -355,8 +358,14 @@ typedef struct lantern_step_group {
     void *const *slab_ptrs; const int32_t *slab_seq; const int64_t *slab_prev; int64_t *new_len;
     int32_t n_slabs, elem_bytes; int64_t outer, S_max, d;
     const void *hidden; void *out_hidden; int64_t *accepted_tokens; int32_t hid_elem_bytes, hid_groups, H, reserved1;
+    /* with ep_win.rows_kind == LANTERN_ROWS_RAW_BF16: the nodes whose rows are post-processed up front, together with the candidate
+     * assembly, in ONE launch (lantern_prepare_step) -- the root and the most likely children; NULL / 0: none (all rows on demand) */
+    const int32_t *node_list; int32_t n_list, reserved2;
 } lantern_step_group;
 int lantern_verify_step(const lantern_step_group *groups, int n_groups);
+/* O6 + O7 restricted to s->node_list in one launch (bf16 Lumina rows, 8192-id window): candidates -> s->tree_cand / cand / cart_prob,
+ * probabilities of the listed rows -> s->out_win, their classes -> s->row_hot.  Called by lantern_verify_step when node_list is set. */
+int lantern_prepare_step(const lantern_step_group *s);
 
 /* window -> dense [B,V] (API compatibility with callers that want the reference's sample_p[V]). */
 int lantern_window_to_dense(const float *win, const int32_t *out_tok, const float *out_mass, int B, int V,

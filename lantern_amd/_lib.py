@@ -44,7 +44,7 @@ class EpWindow(C.Structure):
                 ("u_bonus", C.c_void_p), ("token", C.c_void_p), ("rows_kind", C.c_int32), ("reserved", C.c_int32),
                 ("raw_uncond", C.c_void_p), ("raw_pos_ids", C.c_void_p), ("raw_seq_len", C.c_void_p), ("raw_pos_base", C.c_int64),
                 ("raw_cfg", C.c_float), ("raw_top_k", C.c_int32), ("raw_w_latent", C.c_int32), ("raw_h_latent", C.c_int32),
-                ("raw_newline_id", C.c_int32), ("raw_eos_id", C.c_int32)]
+                ("raw_newline_id", C.c_int32), ("raw_eos_id", C.c_int32), ("raw_probs", C.c_void_p), ("raw_pre", C.c_void_p)]
 
 
 class EpNodes(C.Structure):
@@ -68,7 +68,8 @@ class StepGroup(C.Structure):
                 + [(n, C.c_void_p) for n in ("slab_ptrs", "slab_seq", "slab_prev", "new_len")]
                 + [("n_slabs", C.c_int32), ("elem_bytes", C.c_int32), ("outer", C.c_int64), ("S_max", C.c_int64), ("d", C.c_int64)]
                 + [(n, C.c_void_p) for n in ("hidden", "out_hidden", "accepted_tokens")]
-                + [(n, C.c_int32) for n in ("hid_elem_bytes", "hid_groups", "H", "reserved1")])
+                + [(n, C.c_int32) for n in ("hid_elem_bytes", "hid_groups", "H", "reserved1")]
+                + [("node_list", C.c_void_p), ("n_list", C.c_int32), ("reserved2", C.c_int32)])
 
 
 _lib = None
@@ -116,5 +117,5 @@ EXPORTS = [
     "lantern_window_to_dense", "lantern_pack_vq_table", "lantern_update_inference_inputs", "lantern_profile_next_launch", "lantern_drafter_attention_mask", "lantern_linear_rows",
     "lantern_tree_attention_workspace", "lantern_tree_attention",
     "lantern_tree_node_tables_size", "lantern_tree_node_tables", "lantern_evaluate_posterior_nodes_workspace",
-    "lantern_evaluate_posterior_nodes", "lantern_verify_step", "lantern_gather_candidates_dynamic", "lantern_head_expand_workspace", "lantern_head_expand",
+    "lantern_evaluate_posterior_nodes", "lantern_verify_step", "lantern_gather_candidates_dynamic", "lantern_head_expand_workspace", "lantern_head_expand", "lantern_prepare_step",
 ]

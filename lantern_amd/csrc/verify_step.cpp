@@ -18,13 +18,18 @@ extern "C" int lantern_verify_step(const lantern_step_group *groups, int n_group
     int rc;
     for (int g = 0; g < n_groups; ++g) {
         const lantern_step_group &s = groups[g];
+        if (s.node_list && s.n_list > 0) {          // candidates + the likely rows in one launch
+            rc = lantern_prepare_step(&s);
+            if (rc) return rc;
+            continue;
+        }
         rc = lantern_gather_candidates(s.ss_token, s.ss_prob, s.sample_token, s.tree_indices, s.retrieve, s.B, s.n_flat, s.N, s.P, s.D,
                                        s.tree_cand, s.cand, s.cart_prob, s.stream);
         if (rc) return rc;
     }
     for (int g = 0; g < n_groups; ++g) {
         const lantern_step_group &s = groups[g];
-        if (!s.out_win) continue;          // LANTERN_ROWS_RAW_BF16: evaluate_posterior post-processes the rows it visits itself
+        if (!s.out_win || (s.node_list && s.n_list > 0)) continue;          // LANTERN_ROWS_RAW_BF16: evaluate_posterior post-processes the rows it visits itself
         rc = lantern_cfg_mask_topk_window(s.cond, s.uncond, s.dtype, s.B * s.N, s.V, s.cfg, s.model, s.pos_ids, s.pos_base, s.w_latent,
                                           s.h_latent, s.img_lo, s.img_hi, s.newline_id, s.eos_id, s.top_k, s.seq_len, s.N, s.win_lo,
                                           s.win_len, s.out_win, s.row_hot, s.out_kind, s.temperature, s.top_p, s.stream);

@@ -336,6 +336,7 @@ struct alignas(16) EwShared {
     int dec[2][4];                          // decision words of wave 0: {code, m>0, csm1 bits, -}
     double ubonus[2];                       // [0]: the bonus draw's uniform, fetched with the prologue's first round of loads
     int hot[EW_MAX_N];                      // row_hot of this sequence's rows (when rows_per_seq <= EW_MAX_N)
+    int pre[EW_MAX_N];                      // LANTERN_ROWS_RAW_BF16: 1 = the row was post-processed up front (win.raw_probs)
     unsigned short nbid[EW_PF_C][EW_PF_K];  // prefetched neighbour ids (raw table values)
     unsigned short nbaddr[EW_PF_C][EW_PF_K];// the same neighbours as gather indices into g (window index or a sentinel slot)
 };

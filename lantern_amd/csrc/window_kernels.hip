@@ -184,27 +184,15 @@ __global__ __launch_bounds__(NT) void cfg_window_kernel(const void *__restrict__
 // concentrates in a handful of bins -- uses an 8-way replicated LDS histogram (copy = lane & 7) so that same-address
 // atomic serialisation drops ~8x; the second pass (7 mantissa bits + 1 exponent bit inside the chosen bin) is spread
 // out by nature and uses a single copy.
+// One row of the windowed O7 on a workgroup: CFG combination, top-k threshold, softmax, window store (the body of cfg_window_bf16_kernel,
+// shared with the merged launch below).  `cls`: 0 = grid row, 1 = forced newline, 2 = forced end of image.
 template <int NT, int E8, bool FULL>
-__global__ __launch_bounds__(NT) void cfg_window_bf16_kernel(const uint16_t *__restrict__ cond, const uint16_t *__restrict__ uncond, int V,
-                                                             float cfg, int model, const int64_t *__restrict__ pos_ids, int64_t pos_base,
-                                                             int w_latent, int h_latent, int img_lo, int img_hi, int newline_id, int eos_id,
-                                                             int top_k, const int64_t *__restrict__ seq_len, int rows_per_seq, int win_lo,
-                                                             int W, float *__restrict__ out_win, int32_t *__restrict__ row_hot,
-                                                             int out_kind) {
-    __shared__ alignas(16) int s_hist[O7_HIST_INTS];
-    __shared__ float s_redf[32];
-    __shared__ double s_redd[32];
-    const int row = o7_row_of_block(blockIdx.x, gridDim.x, seq_len ? rows_per_seq : 0), tid = threadIdx.x;
+__device__ __forceinline__ void cfg_window_bf16_row(int row, int cls, const uint16_t *__restrict__ cond, const uint16_t *__restrict__ uncond, int V,
+                                                    float cfg, int model, int img_lo, int img_hi, int newline_id, int eos_id, int top_k, int win_lo,
+                                                    int W, float *__restrict__ out_win, int32_t *__restrict__ row_hot, int out_kind, int *s_hist,
+                                                    float *s_redf, double *s_redd) {
+    const int tid = threadIdx.x;
     const float NEG_INF = -__builtin_inff();
-    int cls = 0;
-    if (model == LANTERN_MODEL_LUMINA) {
-        const int64_t pos = seq_len ? pos_ids[row % rows_per_seq] + seq_len[row / rows_per_seq] : pos_ids[row];
-        const int64_t n1 = pos - pos_base + 1;
-        if (n1 == ((int64_t)w_latent + 1) * h_latent + 1)
-            cls = 2;
-        else if (py_mod64(n1, (int64_t)w_latent + 1) == 0)
-            cls = 1;
-    }
     if (cls != 0) {
         if (tid == 0) row_hot[row] = cls == 2 ? eos_id : newline_id;   // one-hot row: its window is never read
         return;
@@ -269,6 +257,94 @@ __global__ __launch_bounds__(NT) void cfg_window_bf16_kernel(const uint16_t *__r
         const int w0 = e_base + (tid + it * NT) * 8 - win_lo;     // window index of the chunk's first id (multiple of 4)
         if (FULL || (w0 >= 0 && w0 < W)) *reinterpret_cast<float4 *>(out + w0) = r[2 * it];
         if (FULL || (w0 + 4 >= 0 && w0 + 4 < W)) *reinterpret_cast<float4 *>(out + w0 + 4) = r[2 * it + 1];
+    }
+}
+
+__device__ __forceinline__ int lumina_row_class(int64_t pos, int64_t pos_base, int w_latent, int h_latent) {
+    const int64_t n1 = pos - pos_base + 1;
+    if (n1 == ((int64_t)w_latent + 1) * h_latent + 1) return 2;
+    return py_mod64(n1, (int64_t)w_latent + 1) == 0 ? 1 : 0;
+}
+
+template <int NT, int E8, bool FULL>
+__global__ __launch_bounds__(NT) void cfg_window_bf16_kernel(const uint16_t *__restrict__ cond, const uint16_t *__restrict__ uncond, int V,
+                                                             float cfg, int model, const int64_t *__restrict__ pos_ids, int64_t pos_base,
+                                                             int w_latent, int h_latent, int img_lo, int img_hi, int newline_id, int eos_id,
+                                                             int top_k, const int64_t *__restrict__ seq_len, int rows_per_seq, int win_lo,
+                                                             int W, float *__restrict__ out_win, int32_t *__restrict__ row_hot,
+                                                             int out_kind) {
+    __shared__ alignas(16) int s_hist[O7_HIST_INTS];
+    __shared__ float s_redf[32];
+    __shared__ double s_redd[32];
+    const int row = o7_row_of_block(blockIdx.x, gridDim.x, seq_len ? rows_per_seq : 0);
+    int cls = 0;
+    if (model == LANTERN_MODEL_LUMINA)
+        cls = lumina_row_class(seq_len ? pos_ids[row % rows_per_seq] + seq_len[row / rows_per_seq] : pos_ids[row], pos_base, w_latent, h_latent);
+    cfg_window_bf16_row<NT, E8, FULL>(row, cls, cond, uncond, V, cfg, model, img_lo, img_hi, newline_id, eos_id, top_k, win_lo, W, out_win, row_hot,
+                                      out_kind, s_hist, s_redf, s_redd);
+}
+
+// O6 + O7 of a verify step in ONE launch: workgroups [0, B * n_list) post-process the LISTED rows of every sequence (the nodes the
+// walk is most likely to visit -- the root always; LANTERN_ROWS_RAW_BF16 handles the others on demand inside evaluate_posterior),
+// workgroups [B * n_list, B * n_list + B) assemble the candidates (generate_candidates, ea_model_lumina_mgpt.py:525-554).  One
+// kernel boundary instead of two in front of the latency-bound evaluate_posterior.
+struct PrepArgs {
+    const uint16_t *cond, *uncond;
+    int V;
+    float cfg;
+    const int64_t *pos_ids;
+    int64_t pos_base;
+    int w_latent, h_latent, img_lo, img_hi, newline_id, eos_id, top_k;
+    const int64_t *seq_len;
+    int rows_per_seq, win_lo, W;
+    float *out_win;
+    int32_t *row_hot;
+    const int32_t *node_list;
+    int n_list, B;
+    const int64_t *ss_token;
+    const float *ss_prob;
+    const int64_t *sample_token, *tree_indices, *retrieve;
+    int n_flat, N, PD;
+    int64_t *tree_cand, *cand;
+    float *cart_prob;
+};
+
+template <int NT, int E8>
+__global__ __launch_bounds__(NT) void prep_rows_kernel(const PrepArgs a) {
+    __shared__ alignas(16) int s_hist[O7_HIST_INTS];
+    __shared__ float s_redf[32];
+    __shared__ double s_redd[32];
+    const int n_rows = a.B * a.n_list;
+    if ((int)blockIdx.x < n_rows) {
+        const int x = o7_row_of_block(blockIdx.x, n_rows, a.n_list);            // rows of sequence b on XCD b % 8, where its chain runs
+        const int b = x / a.n_list, node = a.node_list[x % a.n_list];
+        const int row = b * a.rows_per_seq + node;
+        const int cls = lumina_row_class(a.pos_ids[node] + a.seq_len[b], a.pos_base, a.w_latent, a.h_latent);
+        cfg_window_bf16_row<NT, E8, true>(row, cls, a.cond, a.uncond, a.V, a.cfg, LANTERN_MODEL_LUMINA, a.img_lo, a.img_hi, a.newline_id, a.eos_id,
+                                          a.top_k, a.win_lo, a.W, a.out_win, a.row_hot, LANTERN_ROWS_PROBS, s_hist, s_redf, s_redd);
+        return;
+    }
+    // ---- candidate assembly of sequence b (same arithmetic as gather_candidates_kernel)
+    const int b = blockIdx.x - n_rows, N = a.N, PD = a.PD, n_flat = a.n_flat;
+    const int64_t *tok = a.ss_token + (size_t)b * n_flat;
+    const float *prb = a.ss_prob ? a.ss_prob + (size_t)b * n_flat : nullptr;
+    const int64_t st = a.sample_token[b];
+    for (int n = threadIdx.x; n < N; n += NT) {
+        const int64_t ti = a.tree_indices[n];
+        a.tree_cand[(size_t)b * N + n] = (ti <= 0 || ti > n_flat) ? st : tok[ti - 1];
+    }
+    for (int i = threadIdx.x; i < PD; i += NT) {
+        const int64_t r = a.retrieve[i];
+        int64_t c = -1;
+        float p = 1.0f;
+        if (r >= 0 && r < N) {
+            const int64_t ti = a.tree_indices[r];
+            const bool root = ti <= 0 || ti > n_flat;
+            c = root ? st : tok[ti - 1];
+            if (prb) p = root ? 1.0f : prb[ti - 1];
+        }
+        a.cand[(size_t)b * PD + i] = c;
+        if (a.cart_prob) a.cart_prob[(size_t)b * PD + i] = p;
     }
 }
 
@@ -475,6 +551,9 @@ __global__ __launch_bounds__(NT, WPE) void epw_kernel(const EpwArgs args) {
     const float *logits = buf.logits + (size_t)b * prm.rows_per_seq * W;
     const uint16_t *raw_c = RAW ? reinterpret_cast<const uint16_t *>(buf.logits) + (size_t)b * prm.rows_per_seq * V + lo : nullptr;
     const uint16_t *raw_u = RAW ? reinterpret_cast<const uint16_t *>(win.raw_uncond) + (size_t)b * prm.rows_per_seq * V + lo : nullptr;
+    const float *raw_p = (RAW && win.raw_probs) ? win.raw_probs + (size_t)b * prm.rows_per_seq * W : nullptr;
+    const bool root_pre = RAW && raw_p && win.raw_pre && win.raw_pre[0] != 0;     // (the level-1 row is requested before the tables are staged)
+    bool rp_probs = false;       // what rp holds: probabilities of a pre-processed row, or raw cond / uncond chunks
     const int32_t *hot_g = win.row_hot ? win.row_hot + (size_t)b * prm.rows_per_seq : nullptr;
     const int ucur0 = buf.cursor ? buf.cursor[b] : 0;
     float4 rp[E4];              // prefetched row (registers) and the row id it holds
@@ -504,6 +583,7 @@ __global__ __launch_bounds__(NT, WPE) void epw_kernel(const EpwArgs args) {
             const int t = tid + u * NT;
             tc_[u] = (is_static && t < prm.N && t < EW_MAX_N) ? (int)buf.tree_cand[(size_t)b * prm.N + t] : 0;
             hot_[u] = (hot_g && hot_in_lds && t < prm.rows_per_seq) ? hot_g[t] : -1;
+            if (RAW && t < prm.rows_per_seq) S.pre[t] = (win.raw_pre && win.raw_probs) ? (int)win.raw_pre[t] : 0;
             if (RAW && t < prm.rows_per_seq) {          // the row's class from its position (MultiModalLogitsProcessor, ea_model_lumina_mgpt.py:45-86)
                 const int64_t n1 = win.raw_pos_ids[t] + win.raw_seq_len[b] - win.raw_pos_base + 1;
                 hot_[u] = (n1 == ((int64_t)win.raw_w_latent + 1) * win.raw_h_latent + 1) ? win.raw_eos_id
@@ -524,8 +604,11 @@ __global__ __launch_bounds__(NT, WPE) void epw_kernel(const EpwArgs args) {
             bi_[u] = (t < nb_total && t < EW_MAX_B) ? buf.b_idx[t] : 0;
         }
         if (rid1 >= 0 && rid1 < prm.rows_per_seq) {
-            if constexpr (RAW) raw_row_load<NT>(raw_c + (size_t)rid1 * V, raw_u + (size_t)rid1 * V, rp);
-            else row_load<NT, E4, FULLW>(logits + (size_t)rid1 * W, W, rp);
+            if constexpr (RAW) {
+                rp_probs = root_pre && rid1 == 0;
+                if (rp_probs) row_load<NT, E4, FULLW>(raw_p + (size_t)rid1 * W, W, rp);
+                else raw_row_load<NT>(raw_c + (size_t)rid1 * V, raw_u + (size_t)rid1 * V, rp);
+            } else row_load<NT, E4, FULLW>(logits + (size_t)rid1 * W, W, rp);
             rp_rid = rid1;
         }
         // LDS stores
@@ -680,8 +763,11 @@ __global__ __launch_bounds__(NT, WPE) void epw_kernel(const EpwArgs args) {
             const int hot = RAW ? S.hot[rid] : (!hot_g ? -1 : (hot_in_lds ? S.hot[rid] : hot_g[rid]));
             EPW_STAMP(10);
             if (hot < 0 && rp_rid != rid) {
-                if constexpr (RAW) raw_row_load<NT>(raw_c + (size_t)rid * V, raw_u + (size_t)rid * V, rp);
-                else row_load<NT, E4, FULLW>(logits + (size_t)rid * W, W, rp);
+                if constexpr (RAW) {
+                    rp_probs = raw_p && S.pre[rid] != 0;
+                    if (rp_probs) row_load<NT, E4, FULLW>(raw_p + (size_t)rid * W, W, rp);
+                    else raw_row_load<NT>(raw_c + (size_t)rid * V, raw_u + (size_t)rid * V, rp);
+                } else row_load<NT, E4, FULLW>(logits + (size_t)rid * W, W, rp);
             }
             rp_rid = -1;
             auto stage_ids = [&]() {
@@ -715,8 +801,10 @@ __global__ __launch_bounds__(NT, WPE) void epw_kernel(const EpwArgs args) {
                         }
                 }
             };
-            if constexpr (RAW) raw_row_to_lds<NT>(rp, hot, win.raw_cfg, win.raw_top_k, V, lo, W, g, out_tok, out_mass, S, Shist, ph, stage_ids);
-            else row_softmax_to_lds<NT, E4, FULLW>(rp, hot, rows_probs, lo, W, prm.temperature, prm.top_k, V, g, out_tok, out_mass, S, ph, stage_ids);
+            if constexpr (RAW) {
+                if (!rp_probs) raw_row_to_lds<NT>(rp, hot, win.raw_cfg, win.raw_top_k, V, lo, W, g, out_tok, out_mass, S, Shist, ph, stage_ids);
+                else row_softmax_to_lds<NT, E4, FULLW>(rp, hot, true, lo, W, prm.temperature, prm.top_k, V, g, out_tok, out_mass, S, ph, stage_ids);
+            } else row_softmax_to_lds<NT, E4, FULLW>(rp, hot, rows_probs, lo, W, prm.temperature, prm.top_k, V, g, out_tok, out_mass, S, ph, stage_ids);
             EPW_STAMP(11);
         }
         unsigned long long todo = todo0;
@@ -1050,11 +1138,16 @@ __global__ __launch_bounds__(NT, WPE) void epw_kernel(const EpwArgs args) {
         rid = rid < 0 ? 0 : (rid >= prm.rows_per_seq ? prm.rows_per_seq - 1 : rid);
         const int hot = RAW ? S.hot[rid] : (!hot_g ? -1 : (hot_in_lds ? S.hot[rid] : hot_g[rid]));
         if (hot < 0 && rp_rid != rid) {
-            if constexpr (RAW) raw_row_load<NT>(raw_c + (size_t)rid * V, raw_u + (size_t)rid * V, rp);
-            else row_load<NT, E4, FULLW>(logits + (size_t)rid * W, W, rp);
+            if constexpr (RAW) {
+                rp_probs = raw_p && S.pre[rid] != 0;
+                if (rp_probs) row_load<NT, E4, FULLW>(raw_p + (size_t)rid * W, W, rp);
+                else raw_row_load<NT>(raw_c + (size_t)rid * V, raw_u + (size_t)rid * V, rp);
+            } else row_load<NT, E4, FULLW>(logits + (size_t)rid * W, W, rp);
         }
-        if constexpr (RAW) raw_row_to_lds<NT>(rp, hot, win.raw_cfg, win.raw_top_k, V, lo, W, g, out_tok, out_mass, S, Shist, ph);
-        else row_softmax_to_lds<NT, E4, FULLW>(rp, hot, rows_probs, lo, W, prm.temperature, prm.top_k, V, g, out_tok, out_mass, S, ph);
+        if constexpr (RAW) {
+            if (!rp_probs) raw_row_to_lds<NT>(rp, hot, win.raw_cfg, win.raw_top_k, V, lo, W, g, out_tok, out_mass, S, Shist, ph);
+            else row_softmax_to_lds<NT, E4, FULLW>(rp, hot, true, lo, W, prm.temperature, prm.top_k, V, g, out_tok, out_mass, S, ph);
+        } else row_softmax_to_lds<NT, E4, FULLW>(rp, hot, rows_probs, lo, W, prm.temperature, prm.top_k, V, g, out_tok, out_mass, S, ph);
     }
     // ---------------------------------------------------------------- epilogue: outputs from LDS
     EPW_STAMP(40);
@@ -1267,6 +1360,23 @@ extern "C" int lantern_cfg_mask_topk_window(const void *cond, const void *uncond
     else launch_cfgw<1024, 4>(CW_ARGS);
 #undef CW_ARGS
     LANTERN_CHECK_LAUNCH("cfg_mask_topk_window");
+    return LANTERN_OK;
+}
+
+extern "C" int lantern_prepare_step(const lantern_step_group *g) {
+    LANTERN_CHECK_ARG(g && g->node_list && g->n_list > 0 && g->n_list <= g->N, "prepare_step: needs a node list");
+    LANTERN_CHECK_ARG(g->cond && g->uncond && g->out_win && g->row_hot && g->seq_len && g->pos_ids && g->dtype == LANTERN_BF16 && g->model == LANTERN_MODEL_LUMINA &&
+                          g->win_len == 8192 && g->win_lo == g->img_lo && g->win_lo + g->win_len == g->img_hi && g->win_lo % 4 == 0 && g->V % 8 == 0 &&
+                          g->out_kind == LANTERN_ROWS_PROBS && g->temperature == 1.0f && !(g->top_p > 0.0f && g->top_p < 1.0f),
+                      "prepare_step: bf16 Lumina rows on the 8192-id image window, probability output");
+    LANTERN_CHECK_ARG(g->ss_token && g->sample_token && g->tree_indices && g->retrieve && g->tree_cand && g->cand && g->B >= 0 && g->n_flat > 0 && g->N > 0 &&
+                          g->P > 0 && g->D > 0, "prepare_step: candidate-assembly buffers missing");
+    if (g->B == 0) return LANTERN_OK;
+    PrepArgs a{(const uint16_t *)g->cond, (const uint16_t *)g->uncond, g->V, g->cfg, g->pos_ids, g->pos_base, g->w_latent, g->h_latent, g->img_lo, g->img_hi,
+               g->newline_id, g->eos_id, g->top_k, g->seq_len, g->N, g->win_lo, g->win_len, g->out_win, g->row_hot, g->node_list, g->n_list, g->B,
+               g->ss_token, g->ss_prob, g->sample_token, g->tree_indices, g->retrieve, g->n_flat, g->N, g->P * g->D, g->tree_cand, g->cand, g->cart_prob};
+    LANTERN_LAUNCH((prep_rows_kernel<512, 2>), dim3(g->B * g->n_list + g->B), dim3(512), 0, (hipStream_t)g->stream, a);
+    LANTERN_CHECK_LAUNCH("prepare_step");
     return LANTERN_OK;
 }
 

@@ -83,6 +83,8 @@ class WorkloadConfig:
                                     # walk; B * n_internal workgroups fill the GPU), "chain" = one serial chain per sequence (epw_kernel)
     fuse_o7: bool = False           # windowed chain kernel: LANTERN_ROWS_RAW_BF16 -- no O7 launch, evaluate_posterior post-processes (CFG, top-k,
                                     # softmax) the rows its walk visits from the raw cond / uncond logits
+    spec_rows: int = 0              # with fuse_o7: this many of the tree's most likely nodes (the root first) get their rows post-processed
+                                    # up front, in the same launch as the candidate assembly (lantern_prepare_step); the rest on demand
     native_step: bool = True        # eager windowed path: the whole step of all groups through ONE C call (lantern_verify_step) instead of
                                     # 4 x n_groups ctypes calls (the Python launch loop caps the stream groups at ~2 otherwise)
     leaf_workgroups: int = -1       # node kernel: -1 = by batch size (include/lantern_hip.h lantern_ep_nodes)
@@ -154,6 +156,19 @@ class LuminaVerifyWorkload:
         self.uncond = torch.empty((S, B, N, V), dtype=torch.bfloat16, device=device)
         self.windowed = cfg.path == "window"
         self.fused_o7 = self.windowed and cfg.fuse_o7 and cfg.ep_kernel == "chain"
+        self.n_spec = min(max(int(cfg.spec_rows), 0), N) if self.fused_o7 else 0
+        if self.n_spec:
+            # likelihood order of the nodes: fewer / earlier choices first (the drafter ranks its candidates), the root always
+            paths = {0: ()}
+            for n in range(1, N):
+                sib_rank = sum(1 for m_ in range(1, n) if par[m_] == par[n])
+                paths[n] = paths[int(par[n])] + (sib_rank,)
+            order = sorted(range(N), key=lambda n: (sum(paths[n]) + len(paths[n]), len(paths[n]), paths[n]))
+            self.spec_nodes = order[:self.n_spec]
+            self.d_node_list = t(np.asarray(self.spec_nodes, np.int32))
+            flags = np.zeros(N, np.uint8)
+            flags[self.spec_nodes] = 1
+            self.d_pre = t(flags)
         self.win_lo, self.W = IMG_LO, IMG_HI - IMG_LO
         # drafter distributions: dense [R,V] rows for the dense path; for the windowed path the pool holds what a
         # windowed drafter softmax emits, [R,W] (zero outside the image range by construction)
@@ -371,6 +386,8 @@ class LuminaVerifyWorkload:
             w.raw_pos_ids, w.raw_pos_base = self.d_pos_ids.data_ptr(), self.cfg.prompt_len + 3
             w.raw_cfg, w.raw_top_k = self.cfg.cfg_scale, self.cfg.top_k
             w.raw_w_latent, w.raw_h_latent, w.raw_newline_id, w.raw_eos_id = W_LATENT, H_LATENT, NEWLINE, EOS
+            if self.n_spec:
+                w.raw_probs, w.raw_pre = at(self.proc), self.d_pre.data_ptr()
         return w
 
     def cond_lens(self, parity: int) -> torch.Tensor:
@@ -484,7 +501,9 @@ class LuminaVerifyWorkload:
             s.pos_ids, s.pos_base = self.d_pos_ids.data_ptr(), c.prompt_len + 3
             s.w_latent, s.h_latent, s.img_lo, s.img_hi, s.newline_id, s.eos_id, s.top_k = W_LATENT, H_LATENT, IMG_LO, IMG_HI, NEWLINE, EOS, c.top_k
             s.win_lo, s.win_len, s.out_kind = self.win_lo, self.W, ops.ROWS_PROBS if c.rows_probs else ops.ROWS_LOGITS
-            s.seq_len, s.out_win, s.row_hot, s.temperature, s.top_p = val(A["cur"]), (None if self.fused_o7 else val(A["proc"])), val(A["row_hot"]), 1.0, 1.0
+            s.seq_len, s.out_win, s.row_hot, s.temperature, s.top_p = val(A["cur"]), (None if (self.fused_o7 and not self.n_spec) else val(A["proc"])), val(A["row_hot"]), 1.0, 1.0
+            if self.n_spec:
+                s.node_list, s.n_list = self.d_node_list.data_ptr(), self.n_spec
             C.memmove(C.byref(s.ep), C.byref(self._ep_prm), C.sizeof(EpParams))
             C.memmove(C.byref(s.ep_buf), C.byref(A["ep_buf"]), C.sizeof(EpBuffers))
             C.memmove(C.byref(s.ep_win), C.byref(A["ep_win"]), C.sizeof(EpWindow))
@@ -611,8 +630,15 @@ class LuminaVerifyWorkload:
                 eb, ew = A["ep_buf"], A["ep_win"]
                 eb.best, eb.accept_len, eb.counters = A["st_best"].value, A["st_alen"].value, A["st_cnt"].value
                 ew.u_bonus, ew.token = A["u_cur"].value, A["st_token"].value
+        if self.n_spec:               # candidates + the likely rows in one launch (the step's own argument block, this step's sample token)
+            sg = self._steps[(slot, parity)][g]
+            sg.stream, sg.sample_token = st.value, p_sample.value
+            if events:
+                self._arm(events, "cfg_mask_topk")
+            check(L.lantern_prepare_step(C.byref(sg)), "prepare_step")
         # O6 candidate assembly (side stream: only needs the sample token)
-        check(L.lantern_gather_candidates(A["ss_token"], A["ss_prob"], p_sample, vp(self.d_tree_indices.data_ptr()),
+        else:
+            check(L.lantern_gather_candidates(A["ss_token"], A["ss_prob"], p_sample, vp(self.d_tree_indices.data_ptr()),
                                           vp(self.d_retrieve.data_ptr()), B, self.R * 10, N, P, D, A["tree_cand"], A["cand"], A["cart_prob"],
                                           st_side), "gather_candidates")
         if side is not None:

@@ -106,8 +106,8 @@ def test_dynamic_tree_loop_matches_oracle_loop():
     assert (wl.lens[steps & 1][cfg.n_seq:].cpu().numpy() == 3 + gen).all()
 
 
-@pytest.mark.parametrize("groups", [1, 2])
-def test_fused_o7_loop_matches_oracle_loop(groups):
+@pytest.mark.parametrize("groups,spec", [(1, 0), (2, 0), (1, 5), (2, 1), (1, 26)])
+def test_fused_o7_loop_matches_oracle_loop(groups, spec):
     """LANTERN_ROWS_RAW_BF16: no cfg_mask_topk launch -- the chain kernel post-processes (CFG, top-k, softmax) the rows its walk
     visits from the raw cond / uncond logits.  Same oracle loop, same token stream, and every step identical to the unfused run."""
     import bench
@@ -116,9 +116,9 @@ def test_fused_o7_loop_matches_oracle_loop(groups):
     outs = []
     for fuse in (True, False):
         cfg = HN.WorkloadConfig(n_seq=6, pool_steps=4, kv_layers=2, kv_heads=4, kv_smax=512, max_steps=steps + 4, sigma=5.0, n_groups=groups,
-                                ep_kernel="chain", fuse_o7=fuse)
+                                ep_kernel="chain", fuse_o7=fuse, spec_rows=spec)
         wl = HN.LuminaVerifyWorkload(cfg, torch.device("cuda"))
-        assert wl.fused_o7 == fuse
+        assert wl.fused_o7 == fuse and wl.n_spec == (spec if fuse else 0)
         for _ in range(steps):
             wl.step()
         wl.join()

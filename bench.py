@@ -22,7 +22,9 @@ Extra objects on the JSON line:
                 measured after the timed region (KV slabs released first).  `frac` there = bytes really moved / time / 8 TB/s.
   lambda_mode   the same loop with lantern_delta = 5 (LANTERN++: tau = 4 p(x)), BASELINE.md run B.
   step_latency_us  whole-step wall time at 1 and 8 sequences (the reference's own batch is 1), both evaluate_posterior forms.
-  stream_groups_2  the same 64 sequences as two groups on two HIP streams.
+  per_kernel_single_group  one stream group, every stage its own launch: each kernel against its SURVEY 8d roofline at the full
+                launch size (chain and node-parallel evaluate_posterior).
+  other_groupings  the default kernels with 1 and 2 stream groups.
   cpu_baseline  the oracle (C port of the reference path) timed on this host's cores over a bounded
                 sample of the same pools/uniforms; it must reproduce the GPU's accepted-token stream.
 """
@@ -55,8 +57,9 @@ def parse():
     ap.add_argument("--ep", choices=["nodes", "chain"], default="chain",
                     help="windowed evaluate_posterior: nodes = one workgroup per internal tree node + the walk (lantern_evaluate_posterior_nodes); "
                          "chain = one serial chain per sequence (lantern_evaluate_posterior_window)")
-    ap.add_argument("--fuse-o7", action="store_true", help="chain kernel on raw rows (LANTERN_ROWS_RAW_BF16): no cfg_mask_topk launch, evaluate_posterior post-processes the rows it visits")
-    ap.add_argument("--spec-rows", type=int, default=0, help="with --fuse-o7: rows of the K most likely tree nodes are post-processed up front, in the candidate-assembly launch (lantern_prepare_step); the others on demand")
+    ap.add_argument("--no-fuse-o7", dest="fuse_o7", action="store_false", help="every stage its own launch: cfg_mask_topk for ALL rows, then evaluate_posterior on probability rows "
+                    "(default: the chain kernel takes the raw logits -- LANTERN_ROWS_RAW_BF16 -- and post-processes the rows its walk visits)")
+    ap.add_argument("--spec-rows", type=int, default=3, help="with --fuse-o7: rows of the K most likely tree nodes are post-processed up front, in the candidate-assembly launch (lantern_prepare_step); the others on demand")
     ap.add_argument("--python-launch", action="store_true", help="launch every kernel of the step from Python (4 ctypes calls per group) instead of one lantern_verify_step call")
     ap.add_argument("--no-kv", action="store_true", help="skip the KV slabs (debug only; invalid as a headline)")
     ap.add_argument("--kv-smax", type=int, default=4096, help="rows per KV slab (BASELINE.md: 4096 = max_position_embeddings; a 768x768 image needs 2481)")
@@ -64,7 +67,7 @@ def parse():
     ap.add_argument("--no-events", action="store_true", help="skip the eager per-kernel timing pass")
     ap.add_argument("--graph", action="store_true", help="replay one captured hipGraph per (pool slot, group) instead of launching eagerly")
     ap.add_argument("--side-stream", action="store_true", help="launch O6 beside O7 and O10 beside O9 on a second HIP stream (measured slower: event waits)")
-    ap.add_argument("--groups", type=int, default=1, help="split the GPU's sequences into this many groups, each on its own HIP stream (independent sequences: one group's latency-bound evaluate_posterior overlaps the others' bandwidth-bound kernels)")
+    ap.add_argument("--groups", type=int, default=3, help="split the GPU's sequences into this many groups, each on its own HIP stream (independent sequences: one group's latency-bound evaluate_posterior overlaps the others' bandwidth-bound kernels)")
     ap.add_argument("--no-extras", action="store_true", help="skip the extra runs after the timed region (lambda mode, B=1 / B=8 step latency, two stream groups)")
     ap.add_argument("--ep-sweep", type=str, default="1,8,64,256,512,4096",
                     help="e.g. 256,2048: batch sizes for the evaluate_posterior-only roofline sweep (BASELINE.md section 2: the 60 %% target is "
@@ -259,6 +262,112 @@ def ep_batch_sweep(batches, device, base_cfg, iters=20):
     return out
 
 
+def kernel_report(wl, evs, E0, E1, KT):
+    """`roofline` (evaluate_posterior, the north-star kernel) and `kernels` (the others) from the HIP events of steps [E0, E1):
+    algorithmic bytes per launch (SURVEY 8d formulas on the kernel's own counters, group 0's launches) / mean launch duration."""
+    cfg = wl.cfg
+
+    def mean_ms(n):
+        return float(np.mean([e[n][0].elapsed_time(e[n][1]) for e in evs]))
+    ep_ms = mean_ms("evaluate_posterior")
+    # SURVEY 8d contract figure: L*V*4 + T*k*6 + R*(k+1)*4 + V*4 (+V*4), from the kernel's own counters
+    contract_bytes = wl.ep_algorithmic_bytes(E0, E1, group=0) / KT      # events bracket group 0's launches
+    ach = contract_bytes / (ep_ms * 1e-3) / 1e9
+    if not wl.windowed:
+        kname = "ep_kernel (evaluate_posterior)"
+    elif wl.ep_nodes is not None:
+        kname = "epn_kernel + epn_walk_kernel (evaluate_posterior, node-parallel)"
+    elif wl.fused_o7:
+        kname = "epw_kernel<raw rows> (evaluate_posterior + the tree_decoding post-process of the rows it visits)"
+    else:
+        kname = "epw_kernel (evaluate_posterior, windowed chain)"
+    rl = {"kernel": kname, "bound": "hbm", "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0, "traffic": None,
+          "sequences_per_launch": wl.Bg, "algorithmic_bytes_per_launch": contract_bytes, "avg_launch_ms": ep_ms,
+          "algorithmic_bytes_definition": "SURVEY 8d: L*V*4 + T*k*6 + R*(k+1)*4 + V*4 (+V*4 if the last level had no rejection), "
+                                          "V=65536, summed over the launch's sequences"}
+    if wl.windowed:
+        # what the windowed kernel actually has to move (rows are 8192-wide windows; gathers/zeroing/scan/bonus draw in LDS)
+        wb = wl.ep_window_bytes(E0, E1, group=0) / KT
+        rl["windowed_kernel"] = {"hbm_bytes_needed_per_launch": wb, "achieved": wb / (ep_ms * 1e-3) / 1e9,
+                                 "frac": wb / (ep_ms * 1e-3) / 1e9 / 8000.0,
+                                 "definition": "(L+fresh)*W*4 + T*k*2 + R*W*4, W=8192 (DESIGN.md 4)" +
+                                               ("; raw rows: a visited row is 2 x W bf16 = the same W*4 bytes" if wl.fused_o7 else "")}
+    tfile = os.path.join(ROOT, "profiles", "r02_ep_traffic.json")
+    if wl.windowed and os.path.exists(tfile):
+        key = ("raw" if wl.fused_o7 else ("nodes" if wl.ep_nodes is not None else "chain")) + f"_B{wl.Bg}"
+        t = json.load(open(tfile)).get("per_launch", {}).get(key)
+        if t:      # PMC passes are separate rocprofv3 runs of the same kernel / launch size, see profiles/
+            rl["traffic"] = t["hbm_bytes"]
+            rl["traffic_source"] = "profiles/r02_ep_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH doubled per the gfx950 note)"
+    ks = {}
+    if "cfg_mask_topk" in evs[0]:
+        o7_ms = mean_ms("cfg_mask_topk")
+        o7_b = wl.o7_algorithmic_bytes(1, group=0) * ((wl.n_spec / wl.N) if wl.fused_o7 else 1.0)
+        ks["cfg_mask_topk"] = {"avg_launch_ms": o7_ms, "algorithmic_bytes_per_launch": o7_b, "achieved": o7_b / (o7_ms * 1e-3) / 1e9,
+                               "frac": o7_b / (o7_ms * 1e-3) / 1e9 / 8000.0,
+                               "kernel": "prep_rows_kernel (candidate assembly + the %d most likely rows)" % wl.n_spec if wl.fused_o7 else "cfg_window_bf16_kernel"}
+    if cfg.with_kv:
+        kv_ms = mean_ms("kv_gather")
+        kv_b = wl.kv_algorithmic_bytes(E0, E1, group=0) / KT
+        kv_m = wl.kv_moved_bytes(E0, E1, group=0) / KT        # rows already in place are not copied
+        # `achieved` counts the bytes the kernel really moves (rows already in place are skipped); the contract figure of
+        # SURVEY 8d (every accepted row read + written) is kept beside it as an equivalent rate
+        ks["kv_gather"] = {"avg_launch_ms": kv_ms, "algorithmic_bytes_per_launch": kv_m,
+                           "achieved": kv_m / (kv_ms * 1e-3) / 1e9, "frac": kv_m / (kv_ms * 1e-3) / 1e9 / 8000.0,
+                           "contract_bytes_per_launch": kv_b, "contract_equivalent_GBps": kv_b / (kv_ms * 1e-3) / 1e9,
+                           "includes": "accepted-hidden copy (O10) in the same launch" if (wl.windowed and cfg.fuse_update) else None}
+    return rl, ks
+
+
+def event_names(wl):
+    names = ("cfg_mask_topk", "evaluate_posterior", "kv_gather") if wl.cfg.with_kv else ("cfg_mask_topk", "evaluate_posterior")
+    if getattr(wl, "fused_o7", False) and not wl.n_spec:
+        names = tuple(n for n in names if n != "cfg_mask_topk")
+    return names
+
+
+def make_events(names, n, device):
+    evs = [{k: (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for k in names} for _ in range(n)]
+    for d in evs:                      # create the hipEvent_t handles (torch makes them on the first record)
+        for e0, e1 in d.values():
+            e0.record()
+            e1.record()
+    torch.cuda.synchronize(device)
+    return evs
+
+
+def per_kernel_run(device, base_cfg, steps=60, **over):
+    """The same workload as ONE stream group with every stage its own launch (cfg_mask_topk for all rows, evaluate_posterior on
+    probability rows, update_inference_inputs): each kernel against its own SURVEY 8d roofline at the full launch size."""
+    import dataclasses
+    from lantern_amd import harness as HN
+    cfg = dataclasses.replace(base_cfg, n_groups=1, fuse_o7=False, spec_rows=0, max_steps=max(base_cfg.pool_steps, 2 * steps + 20) + 8,
+                              n_seq=base_cfg.n_seq, **over)
+    wl = HN.LuminaVerifyWorkload(cfg, device)
+    wl.prime()
+    for _ in range(10):
+        wl.step()
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        wl.step()
+    torch.cuda.synchronize(device)
+    dt = time.perf_counter() - t0
+    evs = make_events(event_names(wl), steps, device)
+    for i in range(steps):
+        wl.step(evs[i], serial=True)
+    torch.cuda.synchronize(device)
+    wl.check_status(0, 2 * steps + 10)
+    rl, ks = kernel_report(wl, evs, steps + 10, 2 * steps + 10, steps)
+    toks = wl.accepted_tokens(10, 10 + steps)
+    r = {"value": toks / dt, "unit": "accepted_tokens/s", "ms_per_step": 1e3 * dt / steps, "sequences_per_launch": wl.Bg,
+         "evaluate_posterior_kernel": cfg.ep_kernel, "roofline": rl, "kernels": ks}
+    wl.release_kv()
+    del wl
+    torch.cuda.empty_cache()
+    return r
+
+
 def step_latency(device, base_cfg, batches=(1, 8), steps=60):
     """Whole verify step (O6 -> O7 -> O8 -> O9 + O10, KV slabs of the bench geometry) at the reference's own batch sizes:
     wall-clock microseconds per step for both evaluate_posterior forms (BASELINE.md section 2 'Reported')."""
@@ -301,9 +410,7 @@ def dynamic_run(device, base_cfg, steps, n_seq):
         wl.step()
     torch.cuda.synchronize(device)
     dt = time.perf_counter() - t0
-    names = ("cfg_mask_topk", "evaluate_posterior", "kv_gather") if cfg.with_kv else ("cfg_mask_topk", "evaluate_posterior")
-    if wl.fused_o7 and not wl.n_spec:
-        names = tuple(n for n in names if n != "cfg_mask_topk")
+    names = event_names(wl)
     KE = min(steps, 20)
     evs = [{n: (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for n in names} for _ in range(KE)]
     for d in evs:
@@ -463,7 +570,11 @@ def main():
     # Never ask for more resident sequences than this GPU can hold: KV slabs (2 per sequence) + pools + 16 GiB of head-room.
     # On the MI355X the default fits (309e9 bytes); a smaller or partly occupied device gets fewer sequences, not a failed run
     # (with more than one rank every rank takes the minimum so that the per-GPU work stays identical).
-    n_seq = args.seqs_per_gpu
+    n_seq = args.seqs_per_gpu - args.seqs_per_gpu % max(1, args.groups)      # equal stream groups
+    if args.ep != "chain":
+        args.fuse_o7 = False
+    if not args.fuse_o7:
+        args.spec_rows = 0
     if not args.no_kv:
         free, _tot = torch.cuda.mem_get_info(device)
         from lantern_amd import ops as _ops
@@ -488,7 +599,7 @@ def main():
     cfg = HN.WorkloadConfig(n_seq=n_seq, pool_steps=args.pool_steps, tree=args.tree, lantern_k=args.lantern_k,
                             lantern_delta=args.lantern_delta, sigma=args.sigma, with_kv=not args.no_kv, kv_smax=args.kv_smax,
                             path=args.path, ep_kernel=args.ep, fuse_o7=args.fuse_o7, spec_rows=args.spec_rows, native_step=not args.python_launch, use_graph=args.graph, n_groups=args.groups, side_stream=args.side_stream,
-                            max_steps=max(args.pool_steps, args.steps + args.warmup + min(args.steps, 100)) + 8,
+                            max_steps=max(args.pool_steps, args.steps + args.warmup + min(args.steps, 100), 80) + 8,
                             **({} if args.kv_pad_rows is None else {"kv_pad_rows": args.kv_pad_rows}))
     wl = HN.LuminaVerifyWorkload(cfg, device, rank=rank)
 
@@ -501,9 +612,7 @@ def main():
     wl.prime()          # setup: every pool slot launched once, state reset (a short --warmup must not leave first-touch costs in the timed loop)
     for _ in range(W):
         wl.step()
-    names = ("cfg_mask_topk", "evaluate_posterior", "kv_gather") if cfg.with_kv else ("cfg_mask_topk", "evaluate_posterior")
-    if wl.fused_o7 and not wl.n_spec:
-        names = tuple(n for n in names if n != "cfg_mask_topk")
+    names = event_names(wl)
     # ---- timed region: exactly K steps, barrier + synchronize on both sides
     barrier()
     t0 = time.perf_counter()
@@ -517,12 +626,7 @@ def main():
     evs = None
     KT = min(K, 100)
     if not args.no_events:
-        evs = [{n: (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for n in names} for _ in range(KT)]
-        for d in evs:                      # create the hipEvent_t handles (torch makes them on the first record)
-            for e0, e1 in d.values():
-                e0.record()
-                e1.record()
-        torch.cuda.synchronize(device)
+        evs = make_events(names, KT, device)
         for i in range(KT):
             wl.step(evs[i], serial=True)     # groups one after the other on one stream: undisturbed kernel durations
         torch.cuda.synchronize(device)
@@ -553,59 +657,19 @@ def main():
             "per_step": {"levels": float(cnt[..., 0].mean()), "tried": float(cnt[..., 1].mean()), "rejected": float(cnt[..., 2].mean())},
         }
         if evs:
-            def mean_ms(n):
-                return float(np.mean([e[n][0].elapsed_time(e[n][1]) for e in evs]))
-            E0, E1 = W + K, W + K + KT          # the steps the events bracket
-            ep_ms = mean_ms("evaluate_posterior")
-            # SURVEY 8d contract figure: L*V*4 + T*k*6 + R*(k+1)*4 + V*4 (+V*4), from the kernel's own counters
-            contract_bytes = wl.ep_algorithmic_bytes(E0, E1, group=0) / KT      # events bracket group 0's launches
-            ach = contract_bytes / (ep_ms * 1e-3) / 1e9
-            rl = {"kernel": ("epn_kernel + epn_walk_kernel (evaluate_posterior, node-parallel)" if wl.ep_nodes is not None else "epw_kernel (evaluate_posterior, windowed chain)") if wl.windowed else "ep_kernel (evaluate_posterior)",
-                  "bound": "hbm", "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0, "traffic": None,
-                  "algorithmic_bytes_per_launch": contract_bytes, "avg_launch_ms": ep_ms,
-                  "algorithmic_bytes_definition": "SURVEY 8d: L*V*4 + T*k*6 + R*(k+1)*4 + V*4 (+V*4 if the last level had no rejection), "
-                                                  "V=65536, summed over the launch's sequences"}
-            if wl.windowed:
-                # what the windowed kernel actually has to move (rows are 8192-wide windows; gathers/zeroing/scan/bonus draw in LDS)
-                wb = wl.ep_window_bytes(E0, E1, group=0) / KT
-                rl["windowed_kernel"] = {"hbm_bytes_needed_per_launch": wb, "achieved": wb / (ep_ms * 1e-3) / 1e9,
-                                         "frac": wb / (ep_ms * 1e-3) / 1e9 / 8000.0,
-                                         "definition": "(L+fresh)*W*4 + T*k*2 + R*W*4, W=8192 (DESIGN.md 4)"}
-            tfile = os.path.join(ROOT, "profiles", "r01_v6_epw_traffic.json")
-            if wl.windowed and os.path.exists(tfile):
-                t = json.load(open(tfile)).get("per_launch", {}).get(str(wl.Bg))
-                if t:      # PMC passes are separate rocprofv3 runs of the same kernel/config (tools/ep_only.py), see profiles/
-                    rl["traffic"] = t["hbm_bytes"]
-                    rl["traffic_source"] = "profiles/r01_v6_epw_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, FETCH doubled per the gfx950 note)"
-            out["roofline"] = rl
-            ks = {}
-            if not wl.fused_o7 or wl.n_spec:
-                o7_ms = mean_ms("cfg_mask_topk")
-                o7_b = wl.o7_algorithmic_bytes(1, group=0) * ((wl.n_spec / wl.N) if wl.fused_o7 else 1.0)
-                ks = {"cfg_mask_topk": {"avg_launch_ms": o7_ms, "algorithmic_bytes_per_launch": o7_b,
-                                        "achieved": o7_b / (o7_ms * 1e-3) / 1e9, "frac": o7_b / (o7_ms * 1e-3) / 1e9 / 8000.0}}
-            if cfg.with_kv:
-                kv_ms = mean_ms("kv_gather")
-                kv_b = wl.kv_algorithmic_bytes(E0, E1, group=0) / KT
-                kv_m = wl.kv_moved_bytes(E0, E1, group=0) / KT        # rows already in place are not copied
-                # `achieved` counts the bytes the kernel really moves (rows already in place are skipped); the contract figure of
-                # SURVEY 8d (every accepted row read + written) is kept beside it as an equivalent rate
-                ks["kv_gather"] = {"avg_launch_ms": kv_ms, "algorithmic_bytes_per_launch": kv_m,
-                                   "achieved": kv_m / (kv_ms * 1e-3) / 1e9, "frac": kv_m / (kv_ms * 1e-3) / 1e9 / 8000.0,
-                                   "contract_bytes_per_launch": kv_b, "contract_equivalent_GBps": kv_b / (kv_ms * 1e-3) / 1e9,
-                                   "includes": "accepted-hidden copy (O10) in the same launch" if (wl.windowed and cfg.fuse_update) else None}
-            out["kernels"] = ks
+            out["roofline"], out["kernels"] = kernel_report(wl, evs, W + K, W + K + KT, KT)
         # the CPU leg replays the run from step 0 (warm-up included): keep the logs before the extra runs below overwrite them
         gb = wl.log_best[:n_logged].cpu().numpy()
         ga = wl.log_alen[:n_logged].cpu().numpy()
         gt = wl.log_token[:n_logged].cpu().numpy()
         if not args.no_extras and wl.windowed:
             # LANTERN++ mode of the same workload (run B of BASELINE.md: lantern_delta = 5 -> tau = 4 * p(x)): same pools, same kernels
-            KL = min(K, 100)
+            KL = 60
             wl.join()
+            torch.cuda.synchronize(device)
             wl.set_lantern_delta(5.0)
             wl.reset_state()
-            for _ in range(5):
+            for _ in range(15):
                 wl.step()
             wl.join()
             torch.cuda.synchronize(device)
@@ -615,18 +679,18 @@ def main():
             wl.join()
             torch.cuda.synchronize(device)
             dl = time.perf_counter() - t1
-            wl.check_status(0, KL + 5)
-            tl = wl.accepted_tokens(5, 5 + KL)
+            wl.check_status(0, KL + 15)
+            tl = wl.accepted_tokens(15, 15 + KL)
             out["lambda_mode"] = {"lantern_delta": 5.0, "value": tl / dl, "unit": "accepted_tokens/s", "ms_per_step": 1e3 * dl / KL, "steps": KL,
                                   "mean_accept_length": tl / (KL * cfg.n_seq), "note": "rank 0's sequences only"}
             wl.set_lantern_delta(args.lantern_delta)
         if (args.ep_sweep or not args.no_extras) and world == 1:
             wl.release_kv()      # the extra runs build their own workloads: give the memory back first
         if not args.no_extras and world == 1 and wl.windowed:
+            out["per_kernel_single_group"] = {k: per_kernel_run(device, cfg, min(K, 60), ep_kernel=k) for k in ("chain", "nodes")}
             out["step_latency_us"] = step_latency(device, cfg)
-            out["stream_groups_2"] = side_run(device, cfg, min(K, 100), n_groups=2)
-            out["stream_groups_2"]["note"] = ("the same sequences as two independent groups on two HIP streams (one group's evaluate_posterior overlaps the "
-                                              "other's bandwidth-bound kernels); not the default because it halves the sequences per evaluate_posterior launch")
+            out["other_groupings"] = {f"groups_{g}": side_run(device, cfg, min(K, 100), n_groups=g, n_seq=args.seqs_per_gpu - args.seqs_per_gpu % g)
+                                      for g in (1, 2) if g != cfg.n_groups}
         if not args.no_extras and world == 1 and wl.windowed:
             out["dynamic_tree"] = dynamic_run(device, cfg, min(K, 100), n_seq)
         if args.ep_sweep and world == 1:

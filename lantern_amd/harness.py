@@ -527,8 +527,7 @@ class LuminaVerifyWorkload:
         for g in range(self.G):
             s = arr[g]
             e = step * c.n_seq + g * self.Bg
-            if cur_stream is not None:
-                s.stream = cur_stream
+            s.stream = cur_stream if cur_stream is not None else self.streams[g].cuda_stream      # (the per-kernel path borrows these blocks)
             if step > 0:
                 s.sample_token = bs["tok"] + 8 * (e - c.n_seq)
             else:

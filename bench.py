@@ -341,8 +341,8 @@ def per_kernel_run(device, base_cfg, steps=60, **over):
     probability rows, update_inference_inputs): each kernel against its own SURVEY 8d roofline at the full launch size."""
     import dataclasses
     from lantern_amd import harness as HN
-    cfg = dataclasses.replace(base_cfg, n_groups=1, fuse_o7=False, spec_rows=0, max_steps=max(base_cfg.pool_steps, 2 * steps + 20) + 8,
-                              n_seq=base_cfg.n_seq, **over)
+    over.setdefault("n_seq", base_cfg.n_seq)
+    cfg = dataclasses.replace(base_cfg, n_groups=1, fuse_o7=False, spec_rows=0, max_steps=max(base_cfg.pool_steps, 2 * steps + 20) + 8, **over)
     wl = HN.LuminaVerifyWorkload(cfg, device)
     wl.prime()
     for _ in range(10):
@@ -687,7 +687,7 @@ def main():
         if (args.ep_sweep or not args.no_extras) and world == 1:
             wl.release_kv()      # the extra runs build their own workloads: give the memory back first
         if not args.no_extras and world == 1 and wl.windowed:
-            out["per_kernel_single_group"] = {k: per_kernel_run(device, cfg, min(K, 60), ep_kernel=k) for k in ("chain", "nodes")}
+            out["per_kernel_single_group"] = {k: per_kernel_run(device, cfg, min(K, 60), ep_kernel=k, n_seq=(args.seqs_per_gpu if n_seq + args.groups > args.seqs_per_gpu else n_seq)) for k in ("chain", "nodes")}
             out["step_latency_us"] = step_latency(device, cfg)
             out["other_groupings"] = {f"groups_{g}": side_run(device, cfg, min(K, 100), n_groups=g, n_seq=args.seqs_per_gpu - args.seqs_per_gpu % g)
                                       for g in (1, 2) if g != cfg.n_groups}

@@ -1,0 +1,61 @@
+"""Collect the round-2 rocprofv3 outputs (tools/run/prof_default.sh) into profiles/: per-kernel stats CSVs, the PMC counter sums
+(FETCH_SIZE / WRITE_SIZE, separate passes) as profiles/r02_ep_traffic.json, and the bench line each profiled run printed."""
+import csv, glob, json, os, shutil, sys, collections
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+runs = {"raw": "r2p", "chain": "r2p_chain", "nodes": "r2p_nodes"}          # traffic key prefix -> gpurun_out/<dir>
+kern = {"raw": ["epw_kernel"], "chain": ["epw_kernel"], "nodes": ["epn_kernel", "epn_walk_kernel"]}
+others = ["prep_rows_kernel", "cfg_window_bf16", "update_inputs_kernel"]
+
+
+def sums(d, pat):
+    acc = collections.defaultdict(lambda: [0.0, 0])
+    for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
+        for row in csv.DictReader(open(f)):
+            if pat in row["Kernel_Name"]:
+                a = acc[row["Counter_Name"]]
+                a[0] += float(row["Counter_Value"]); a[1] += 1
+    return {k: v[0] / max(v[1], 1) for k, v in acc.items()}, max([v[1] for v in acc.values()] + [0])
+
+
+out = {"note": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --output-format csv) on the bench command "
+               "itself (`python3 bench.py --gpus 1 --steps 20 --warmup 5 --cpu-seconds 0 --ep-sweep '' --no-extras [flags]`), averaged over "
+               "every launch of the kernel in the run.  Units: counter value x 1024 bytes.  gfx950 correction (MI355X_MICROARCH.md, HBM): "
+               "FETCH_SIZE reports half of the bytes of wide coalesced reads -> doubled; WRITE_SIZE as is.",
+       "per_launch": {}, "other_kernels": {}}
+for key, d in runs.items():
+    src = os.path.join(ROOT, "gpurun_out", d)
+    line = json.loads(open(os.path.join(src, "b_prof.json")).read().strip().splitlines()[-1])
+    B = line["roofline"]["sequences_per_launch"]
+    fetch = wr = 0.0
+    n = 0
+    for k in kern[key]:
+        f, n = sums(os.path.join(src, "pmc_fetch"), k + "<")
+        w, _ = sums(os.path.join(src, "pmc_write"), k + "<")
+        fetch += f.get("FETCH_SIZE", 0.0); wr += w.get("WRITE_SIZE", 0.0)
+    rl = line["roofline"]
+    out["per_launch"][f"{key}_B{B}"] = {
+        "kernel": rl["kernel"], "flags": d, "launches_averaged": n, "FETCH_SIZE_raw_KB": fetch, "WRITE_SIZE_raw_KB": wr,
+        "hbm_bytes": 2 * fetch * 1024 + wr * 1024,
+        "algorithmic_window_bytes": rl.get("windowed_kernel", {}).get("hbm_bytes_needed_per_launch"),
+        "dense_contract_bytes": rl["algorithmic_bytes_per_launch"]}
+    for k in others:
+        f, n = sums(os.path.join(src, "pmc_fetch"), k)
+        w, _ = sums(os.path.join(src, "pmc_write"), k)
+        if n:
+            out["other_kernels"][f"{key}_B{B}:{k}"] = {"launches_averaged": n, "FETCH_SIZE_raw_KB": f.get("FETCH_SIZE", 0.0),
+                                                      "WRITE_SIZE_raw_KB": w.get("WRITE_SIZE", 0.0),
+                                                      "hbm_bytes": 2 * f.get("FETCH_SIZE", 0.0) * 1024 + w.get("WRITE_SIZE", 0.0) * 1024}
+    shutil.copy(os.path.join(src, "prof", "default_kernel_stats.csv"), os.path.join(ROOT, "profiles", f"r02_{key}_kernel_stats.csv"))
+    json.dump(line, open(os.path.join(ROOT, "profiles", f"r02_{key}_bench_under_rocprof.json"), "w"), indent=1)
+    for c in ("FETCH_SIZE", "WRITE_SIZE"):
+        f = glob.glob(os.path.join(src, "pmc_" + ("fetch" if c == "FETCH_SIZE" else "write"), "*counter_collection.csv"))[0]
+        rows = [r for r in csv.DictReader(open(f)) if "lantern::" in r["Kernel_Name"]]
+        with open(os.path.join(ROOT, "profiles", "pmc", f"r02_{key}_{c}_B{B}.csv"), "w", newline="") as fh:
+            w = csv.DictWriter(fh, fieldnames=["Dispatch_Id", "Kernel_Name", "Counter_Name", "Counter_Value"], extrasaction="ignore")
+            w.writeheader()
+            for r in rows:
+                r["Kernel_Name"] = r["Kernel_Name"][:80]
+                w.writerow(r)
+json.dump(out, open(os.path.join(ROOT, "profiles", "r02_ep_traffic.json"), "w"), indent=1)
+print(json.dumps(out["per_launch"], indent=1))

@@ -37,6 +37,7 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")      # one hardware queue per stream group (the HIP runtime's default of 4 makes 4+ groups share queues)
 import numpy as np
 import torch
 
@@ -64,6 +65,9 @@ def parse():
     ap.add_argument("--no-kv", action="store_true", help="skip the KV slabs (debug only; invalid as a headline)")
     ap.add_argument("--kv-smax", type=int, default=4096, help="rows per KV slab (BASELINE.md: 4096 = max_position_embeddings; a 768x768 image needs 2481)")
     ap.add_argument("--kv-pad-rows", type=int, default=None, help="extra rows per (layer, head) group of a KV slab (row stride = kv_smax + pad; harness default 16)")
+    ap.add_argument("--fused-accept", action="store_true", help="evaluate_posterior + update_inference_inputs as one launch (lantern_verify_accept)")
+    ap.add_argument("--fused-workers", type=int, default=0, help="copy workgroups per fused launch (0: 256 / groups - sequences per group)")
+    ap.add_argument("--launch-threads", type=int, default=0, help="enqueue each step's launches from this many worker threads (lantern_step_launcher); 0 = the calling thread")
     ap.add_argument("--no-events", action="store_true", help="skip the eager per-kernel timing pass")
     ap.add_argument("--graph", action="store_true", help="replay one captured hipGraph per (pool slot, group) instead of launching eagerly")
     ap.add_argument("--side-stream", action="store_true", help="launch O6 beside O7 and O10 beside O9 on a second HIP stream (measured slower: event waits)")
@@ -342,7 +346,7 @@ def per_kernel_run(device, base_cfg, steps=60, **over):
     import dataclasses
     from lantern_amd import harness as HN
     over.setdefault("n_seq", base_cfg.n_seq)
-    cfg = dataclasses.replace(base_cfg, n_groups=1, fuse_o7=False, spec_rows=0, max_steps=max(base_cfg.pool_steps, 2 * steps + 20) + 8, **over)
+    cfg = dataclasses.replace(base_cfg, n_groups=1, launch_threads=0, fuse_o7=False, spec_rows=0, max_steps=max(base_cfg.pool_steps, 2 * steps + 20) + 8, **over)
     wl = HN.LuminaVerifyWorkload(cfg, device)
     wl.prime()
     for _ in range(10):
@@ -598,12 +602,13 @@ def main():
             n_seq = fit
     cfg = HN.WorkloadConfig(n_seq=n_seq, pool_steps=args.pool_steps, tree=args.tree, lantern_k=args.lantern_k,
                             lantern_delta=args.lantern_delta, sigma=args.sigma, with_kv=not args.no_kv, kv_smax=args.kv_smax,
-                            path=args.path, ep_kernel=args.ep, fuse_o7=args.fuse_o7, spec_rows=args.spec_rows, native_step=not args.python_launch, use_graph=args.graph, n_groups=args.groups, side_stream=args.side_stream,
+                            path=args.path, ep_kernel=args.ep, fuse_o7=args.fuse_o7, spec_rows=args.spec_rows, native_step=not args.python_launch, launch_threads=args.launch_threads, fused_accept=args.fused_accept, fused_workers=args.fused_workers, use_graph=args.graph, n_groups=args.groups, side_stream=args.side_stream,
                             max_steps=max(args.pool_steps, args.steps + args.warmup + min(args.steps, 100), 80) + 8,
                             **({} if args.kv_pad_rows is None else {"kv_pad_rows": args.kv_pad_rows}))
     wl = HN.LuminaVerifyWorkload(cfg, device, rank=rank)
 
     def barrier():
+        wl.launches_done()          # worker-thread launches: every step is on its stream before the clock is read
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize(device)
@@ -689,7 +694,7 @@ def main():
         if not args.no_extras and world == 1 and wl.windowed:
             out["per_kernel_single_group"] = {k: per_kernel_run(device, cfg, min(K, 60), ep_kernel=k, n_seq=(args.seqs_per_gpu if n_seq + args.groups > args.seqs_per_gpu else n_seq)) for k in ("chain", "nodes")}
             out["step_latency_us"] = step_latency(device, cfg)
-            out["other_groupings"] = {f"groups_{g}": side_run(device, cfg, min(K, 100), n_groups=g, n_seq=args.seqs_per_gpu - args.seqs_per_gpu % g)
+            out["other_groupings"] = {f"groups_{g}": side_run(device, cfg, max(min(K, 100), 60), n_groups=g, n_seq=args.seqs_per_gpu - args.seqs_per_gpu % g)
                                       for g in (1, 2) if g != cfg.n_groups}
         if not args.no_extras and world == 1 and wl.windowed:
             out["dynamic_tree"] = dynamic_run(device, cfg, min(K, 100), n_seq)

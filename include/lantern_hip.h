@@ -361,11 +361,36 @@ typedef struct lantern_step_group {
     /* with ep_win.rows_kind == LANTERN_ROWS_RAW_BF16: the nodes whose rows are post-processed up front, together with the candidate
      * assembly, in ONE launch (lantern_prepare_step) -- the root and the most likely children; NULL / 0: none (all rows on demand) */
     const int32_t *node_list; int32_t n_list, reserved2;
+    /* non-NULL: O8 + O9 + O10 go out as ONE launch (lantern_verify_accept) instead of evaluate_posterior_window +
+     * update_inference_inputs: [dev] lantern_verify_accept_workspace(B, n_slabs) bytes, 8-aligned, zero-filled ONCE by the caller (the
+     * kernel leaves it zeroed), owned by this group's stream.  fused_workers: copy workgroups beside the B chains, <= 0 = fill the GPU
+     * (256 - B); with G groups in flight give each about 256 / G - B. */
+    void *fused_ws; int64_t fused_ws_bytes; int32_t fused_workers, reserved3;
 } lantern_step_group;
 int lantern_verify_step(const lantern_step_group *groups, int n_groups);
+/* The same launch sequence enqueued by worker threads (a kernel launch costs its calling thread several microseconds; 3 G launches per
+ * step make ONE enqueuing thread the bound past a handful of groups).  Worker t enqueues groups g = t (mod n_threads) from a private
+ * ring of argument-block copies: submit returns once the copies are queued (the caller may patch its blocks for the next step at
+ * once; it blocks only when a worker is 64 blocks behind); wait returns when everything submitted so far sits on its stream, with
+ * the first error any worker met (and its message in lantern_last_error()) -- call it before recording events on / synchronising
+ * with the group streams.  One stream must always be submitted at the same index g.  `device`: the HIP device of the streams.
+ * With more than 3 groups the runtime needs as many hardware queues: GPU_MAX_HW_QUEUES >= n_groups in the environment (default 4). */
+typedef struct lantern_step_launcher lantern_step_launcher;
+int lantern_step_launcher_create(int n_threads, int device, lantern_step_launcher **out);
+int lantern_step_launcher_submit(lantern_step_launcher *l, const lantern_step_group *groups, int n_groups);
+int lantern_step_launcher_wait(lantern_step_launcher *l);
+void lantern_step_launcher_destroy(lantern_step_launcher *l);
 /* O6 + O7 restricted to s->node_list in one launch (bf16 Lumina rows, 8192-id window): candidates -> s->tree_cand / cand / cart_prob,
  * probabilities of the listed rows -> s->out_win, their classes -> s->row_hot.  Called by lantern_verify_step when node_list is set. */
 int lantern_prepare_step(const lantern_step_group *s);
+/* O8 + O9 + O10 of one group in one launch, pipelined per sequence: the first B workgroups run the evaluate_posterior chains
+ * (models/ea_model_lumina_mgpt.py:562-720), each finished chain queues its verdict, and all other workgroups (and the finished chains)
+ * move that sequence's KV rows and accepted hidden rows (update_inference_inputs, :741-785) while slower chains still run.  Same
+ * results as lantern_evaluate_posterior_window followed by lantern_update_inference_inputs.  Uses s->ep / ep_buf / ep_win, the O9 + O10
+ * fields, s->fused_ws.  LANTERN_E_UNSUPPORTED outside the 8192-id window / packed table / probability-or-raw rows build.
+ * workspace word 4 != 0 after a launch: a copy worker gave up waiting for a chain (never in a healthy run). */
+size_t lantern_verify_accept_workspace(int B, int n_slabs);
+int lantern_verify_accept(const lantern_step_group *s);
 
 /* window -> dense [B,V] (API compatibility with callers that want the reference's sample_p[V]). */
 int lantern_window_to_dense(const float *win, const int32_t *out_tok, const float *out_mass, int B, int V,

@@ -69,7 +69,8 @@ class StepGroup(C.Structure):
                 + [("n_slabs", C.c_int32), ("elem_bytes", C.c_int32), ("outer", C.c_int64), ("S_max", C.c_int64), ("d", C.c_int64)]
                 + [(n, C.c_void_p) for n in ("hidden", "out_hidden", "accepted_tokens")]
                 + [(n, C.c_int32) for n in ("hid_elem_bytes", "hid_groups", "H", "reserved1")]
-                + [("node_list", C.c_void_p), ("n_list", C.c_int32), ("reserved2", C.c_int32)])
+                + [("node_list", C.c_void_p), ("n_list", C.c_int32), ("reserved2", C.c_int32)]
+                + [("fused_ws", C.c_void_p), ("fused_ws_bytes", C.c_int64), ("fused_workers", C.c_int32), ("reserved3", C.c_int32)])
 
 
 _lib = None
@@ -98,6 +99,11 @@ def lib():
         _lib.lantern_tree_attention_workspace.restype = C.c_size_t
         _lib.lantern_evaluate_posterior_nodes_workspace.restype = C.c_size_t
         _lib.lantern_head_expand_workspace.restype = C.c_size_t
+        _lib.lantern_verify_accept_workspace.restype = C.c_size_t
+        _lib.lantern_step_launcher_destroy.restype = None
+        _lib.lantern_step_launcher_destroy.argtypes = [C.c_void_p]
+        _lib.lantern_step_launcher_submit.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        _lib.lantern_step_launcher_wait.argtypes = [C.c_void_p]
     return _lib
 
 
@@ -118,4 +124,5 @@ EXPORTS = [
     "lantern_tree_attention_workspace", "lantern_tree_attention",
     "lantern_tree_node_tables_size", "lantern_tree_node_tables", "lantern_evaluate_posterior_nodes_workspace",
     "lantern_evaluate_posterior_nodes", "lantern_verify_step", "lantern_gather_candidates_dynamic", "lantern_head_expand_workspace", "lantern_head_expand", "lantern_prepare_step",
+    "lantern_verify_accept_workspace", "lantern_verify_accept", "lantern_step_launcher_create", "lantern_step_launcher_submit", "lantern_step_launcher_wait", "lantern_step_launcher_destroy",
 ]

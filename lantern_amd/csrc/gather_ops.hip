@@ -3,6 +3,7 @@
 // All are index/byte movers: coalesced 16-byte accesses, indices read from device memory
 // (the outputs of evaluate_posterior) so the step never round-trips to the host.
 #include "common.h"
+#include "gather_dev.h"
 #include <cstdlib>
 
 namespace lantern {
@@ -68,81 +69,6 @@ __global__ __launch_bounds__(256) void gather_candidates_kernel(const int64_t *_
     }
 }
 
-// ------------------------------------------------------------------------- O9
-// models/ea_model_lumina_mgpt.py:741-746,763-767; models/drafters/kv_cache.py:38-50.
-// grid.x = tiles of `outer` rows, grid.y = slab.  A thread owns one 16-byte column chunk of
-// one (layer,batch,head) row-group: it loads the <= MAXSEL selected chunks into registers,
-// then stores them at prev..prev+a, so the in-place move cannot race with itself.
-constexpr int KV_MAXSEL = 16;
-typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
-
-// MAXSEL = rows a step can accept (D); U = row groups a thread moves per trip, all loads of the U groups in flight
-// before the first store (few, fat workgroups: a thread that moves one 16-byte chunk of ~1.3 rows has too little in
-// flight to cover HBM latency, and 12k tiny workgroups per launch are dispatch-bound).
-template <int MAXSEL, int U, int MODE = 0>
-__device__ __forceinline__ void kv_gather_body(int bx, int nbx, int s, void *const *__restrict__ slab_ptrs, const int32_t *__restrict__ slab_seq,
-                                                        const int64_t *__restrict__ slab_prev, int64_t outer, int64_t S_max,
-                                                        int chunks_per_row, const int64_t *__restrict__ retrieve,
-                                                        int retrieve_per_seq, int P, int D, const int32_t *__restrict__ best,
-                                                        const int32_t *__restrict__ accept_len, int64_t *__restrict__ new_len) {
-    const int seq = slab_seq[s];
-    const int64_t prev = slab_prev[s];
-    const int bst = best[seq];
-    int n_sel = accept_len[seq] + 1;
-    if (n_sel > D) n_sel = D;
-    if (n_sel > MAXSEL) n_sel = MAXSEL;
-    const int64_t *rrow = retrieve + (retrieve_per_seq ? (size_t)seq * P * D : 0) + (size_t)bst * D;
-    if (bx == 0 && threadIdx.x == 0 && new_len) new_len[s] = prev + n_sel;
-
-    // rows already in place (tree node t sits at position prev + t: always the root, and every accepted first child) are
-    // not touched -- copying a row onto itself is the identity, so the result equals the reference's index_select + copy_
-    unsigned move = 0u;
-    int64_t srcrow[MAXSEL];
-#pragma unroll
-    for (int t = 0; t < MAXSEL; ++t) {
-        srcrow[t] = 0;
-        if (t < n_sel) {
-            const int64_t r = rrow[t];
-            if (r != t && prev + t < S_max) move |= 1u << t;
-            const int64_t src = r + prev;
-            srcrow[t] = src < 0 ? 0 : (src >= S_max ? S_max - 1 : src);
-        }
-    }
-    if (move == 0u) return;
-    // the slab address comes out of a pointer table: tell the compiler it is global memory (global_load/store, not flat)
-    typedef __attribute__((address_space(1))) u32x4_t gvec_t;
-    gvec_t *base = (gvec_t *)(uintptr_t)slab_ptrs[s];
-    const unsigned total = (unsigned)(outer * chunks_per_row), cpr = (unsigned)chunks_per_row;
-    const unsigned stride = (unsigned)nbx * blockDim.x;
-    for (unsigned w0 = (unsigned)bx * blockDim.x + threadIdx.x; w0 < total; w0 += U * stride) {
-        u32x4_t v[U][MAXSEL];
-        gvec_t *rowbase[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const unsigned w = w0 + u * stride;
-            const unsigned o = w / cpr, c = w - o * cpr;
-            rowbase[u] = base + (size_t)o * S_max * cpr + c;
-            if (w < total) {
-#pragma unroll
-                for (int t = 0; t < MAXSEL; ++t)
-                    if ((move >> t) & 1u) v[u][t] = (MODE & 1) ? rowbase[u][srcrow[t] * cpr] : __builtin_nontemporal_load(&rowbase[u][srcrow[t] * cpr]);
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const unsigned w = w0 + u * stride;
-            if (w < total) {
-#pragma unroll
-                for (int t = 0; t < MAXSEL; ++t)
-                    if ((move >> t) & 1u) {
-                        if (MODE & 2) rowbase[u][(prev + t) * cpr] = v[u][t];
-                        else __builtin_nontemporal_store(v[u][t], &rowbase[u][(prev + t) * cpr]);
-                    }
-            }
-        }
-    }
-}
-
 template <int MAXSEL, int U>
 __global__ __launch_bounds__(256) void kv_gather_kernel(void *const *__restrict__ slab_ptrs, const int32_t *__restrict__ slab_seq,
                                                         const int64_t *__restrict__ slab_prev, int64_t outer, int64_t S_max,
@@ -151,34 +77,6 @@ __global__ __launch_bounds__(256) void kv_gather_kernel(void *const *__restrict_
                                                         const int32_t *__restrict__ accept_len, int64_t *__restrict__ new_len) {
     kv_gather_body<MAXSEL, U>(blockIdx.x, gridDim.x, blockIdx.y, slab_ptrs, slab_seq, slab_prev, outer, S_max, chunks_per_row, retrieve,
                               retrieve_per_seq, P, D, best, accept_len, new_len);
-}
-
-// ------------------------------------------------------------------------ O10
-// models/ea_model_lumina_mgpt.py:748-750,773-785.
-// Copy-only form (no bonus-token draw: the windowed evaluate_posterior draws it): one workgroup per (sequence, cond/uncond,
-// depth) row so the 2*D rows of every sequence move in parallel across the chip instead of through one CU.
-__device__ __forceinline__ void accept_copy_body(int bx, int b, const uint4 *__restrict__ hidden, int G, int N, int cpr,
-                                                          const int64_t *__restrict__ retrieve, int retrieve_per_seq, int P, int D,
-                                                          const int64_t *__restrict__ cand, const int32_t *__restrict__ best,
-                                                          const int32_t *__restrict__ accept_len, uint4 *__restrict__ out_hidden,
-                                                          int64_t *__restrict__ accepted_tokens) {
-    const int gi = bx / D, t = bx % D, tid = threadIdx.x;
-    const int bst = best[b];
-    int n_sel = accept_len[b] + 1;
-    if (n_sel > D) n_sel = D;
-    if (bx == 0 && accepted_tokens && cand && tid < D)
-        accepted_tokens[(size_t)b * D + tid] = tid < n_sel ? cand[(size_t)b * P * D + (size_t)bst * D + tid] : -1;
-    if (!hidden || !out_hidden) return;
-    uint4 *dst = out_hidden + (((size_t)b * G + gi) * D + t) * cpr;
-    if (t < n_sel) {
-        int64_t r = retrieve[(retrieve_per_seq ? (size_t)b * P * D : 0) + (size_t)bst * D + t];
-        if (r < 0) r += N;
-        r = r < 0 ? 0 : (r >= N ? N - 1 : r);
-        const uint4 *src = hidden + (((size_t)b * G + gi) * N + r) * cpr;
-        for (int c = tid; c < cpr; c += 256) dst[c] = src[c];
-    } else {
-        for (int c = tid; c < cpr; c += 256) dst[c] = make_uint4(0, 0, 0, 0);
-    }
 }
 
 __global__ __launch_bounds__(256) void accept_copy_kernel(const uint4 *__restrict__ hidden, int G, int N, int cpr,

@@ -15,6 +15,7 @@
 // models/ea_model_llamagen.py:597-669,709-787.
 #include "common.h"
 #include "window_dev.h"
+#include "gather_dev.h"
 
 namespace lantern {
 
@@ -511,7 +512,7 @@ typedef const __attribute__((address_space(4))) EpwArgs *EpwArgsK;
 // 512 x 4): no per-chunk bounds predicate, so the four chunks of a pass are one basic block and their LDS reads go out together.
 // RAW: rows are the target model's raw cond / uncond bf16 logits (LANTERN_ROWS_RAW_BF16; W == 8 * 2 * NT, packed table).
 template <int NT, int E4, int IDMODE, int WPE, bool FULLW = false, bool RAW = false>
-__global__ __launch_bounds__(NT, WPE) void epw_kernel(const EpwArgs args) {
+__device__ __forceinline__ int epw_body(const EpwArgs &args, const int b) {
     static_assert(!RAW || (FULLW && E4 == 4), "raw rows: the 8192-id window on 512 threads");
     constexpr bool LDSIDS = IDMODE != 0;
     const lantern_ep_params &prm = args.prm;
@@ -521,7 +522,7 @@ __global__ __launch_bounds__(NT, WPE) void epw_kernel(const EpwArgs args) {
     // one dynamic LDS region (16-byte aligned base): [ g : W f32 | nbmask : W bits | EwShared ]
     extern __shared__ float4 dyn_lds[];
     float *g = reinterpret_cast<float *>(dyn_lds);
-    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int Ps = prm.P, Ds = prm.D, V = prm.V, W = win.win_len, lo = win.win_lo;
     uint32_t *nbmask = reinterpret_cast<uint32_t *>(g + W + EW_G_EXT);  // W bits: neighbour set (static LlamaGen/Anole: zeroing hits q)
     EwShared &S = *reinterpret_cast<EwShared *>(reinterpret_cast<char *>(g) + epw_shared_offset(W));
@@ -1273,6 +1274,109 @@ __global__ __launch_bounds__(NT, WPE) void epw_kernel(const EpwArgs args) {
         if (ka->win.out_tok) ka->win.out_tok[b] = out_tok;
         if (ka->win.out_mass) ka->win.out_mass[b] = out_mass;
     }
+    return (best << 8) | a;          // the verdict (uniform): best path, rows kept = accept_len + 1
+}
+
+template <int NT, int E4, int IDMODE, int WPE, bool FULLW = false, bool RAW = false>
+__global__ __launch_bounds__(NT, WPE) void epw_kernel(const EpwArgs args) {
+    epw_body<NT, E4, IDMODE, WPE, FULLW, RAW>(args, blockIdx.x);
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+// lantern_verify_accept: evaluate_posterior (O8) and update_inference_inputs (O9 + O10) of one group of sequences in ONE launch,
+// pipelined per sequence.  As two launches the KV rows of EVERY sequence wait for the SLOWEST sequence's chain (a chain is 1..D
+// levels long and mostly waits on memory round trips: ~64 of 256 CUs busy), then the chains of the next step wait for the whole
+// copy.  Here the first B workgroups to start (a ticket taken at workgroup start, so they are running -- not merely scheduled --
+// before any later workgroup) run the chains (epw_body, unchanged); a finished chain publishes its verdict as work-queue entries
+// (one per KV slab of the sequence + one for its accepted-hidden rows) and every other workgroup -- and the chain workgroups
+// once done -- takes (entry, tile) tickets and moves rows.  A copy worker only ever waits for a chain, a chain never waits: the
+// grid drains whatever the dispatch order.  The verdict travels inside the entry (best path, rows kept), so a worker reads
+// nothing the chains wrote.  The last workgroup out clears the queue for the next launch (workspace zeroed once by the caller).
+struct VaArgs {
+    EpwArgs ep;                      // at offset 0: epw_body reads its epilogue pointers through the kernarg segment
+    void *const *slab_ptrs;
+    const int32_t *slab_seq;
+    const int64_t *slab_prev;
+    int64_t *new_len;
+    const int64_t *retrieve;
+    int64_t outer, S_max;
+    int n_slabs, cpr, nbx, hid_groups;
+    const uint4 *hidden;
+    uint4 *out_hidden;
+    const int64_t *cand;
+    int64_t *accepted_tokens;
+    int N, hid_cpr;
+    uint32_t *ws;                    // [0] role tickets [1] work tickets [2] entries published [3] workgroups out [4] sticky: a worker gave up; +32 B: entries
+};
+constexpr unsigned long long VA_VALID = 1ull << 63, VA_HIDDEN = 1ull << 62;
+constexpr int VA_SPIN_LIMIT = 4000000;          // ~2 s of polling: a worker that never sees its entry gives up instead of hanging the GPU
+
+template <bool RAW>
+__global__ __launch_bounds__(512, 1) void verify_accept_kernel(const VaArgs a) {
+    __shared__ uint32_t s_u32;
+    __shared__ unsigned long long s_entry;
+    uint32_t *const ws = a.ws;
+    unsigned long long *const entries = reinterpret_cast<unsigned long long *>(ws + 8);
+    const int tid = threadIdx.x, B = a.ep.prm.B, P = a.ep.prm.P, D = a.ep.prm.D;
+    const uint32_t n_entries = (uint32_t)(a.n_slabs + B), n_work = n_entries * (uint32_t)a.nbx;
+    if (tid == 0) s_u32 = atomicAdd(&ws[0], 1u);
+    __syncthreads();
+    const uint32_t role = s_u32;
+    __syncthreads();
+    if (role < (uint32_t)B) {
+        const int b = (int)role;
+        const int verdict = epw_body<512, 4, 2, 1, true, RAW>(a.ep, b);
+        const unsigned long long v = (unsigned long long)(((unsigned)(verdict >> 8) & 0xffffu) << 16 | ((unsigned)verdict & 0xffu));
+        for (int s = tid; s <= a.n_slabs; s += 512) {
+            const bool hid = s == a.n_slabs;
+            if (hid || a.slab_seq[s] == b) {
+                const unsigned long long e = VA_VALID | (hid ? VA_HIDDEN : 0ull) | ((unsigned long long)(hid ? b : s) << 32) | v;
+                const uint32_t slot = atomicAdd(&ws[2], 1u);
+                if (slot < n_entries) __hip_atomic_store(&entries[slot], e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    }
+    for (;;) {
+        __syncthreads();
+        if (tid == 0) s_u32 = atomicAdd(&ws[1], 1u);
+        __syncthreads();
+        const uint32_t t = s_u32;
+        if (t >= n_work) break;
+        const uint32_t slot = t / (uint32_t)a.nbx, sub = t % (uint32_t)a.nbx;
+        if (tid == 0) {
+            unsigned long long e = __hip_atomic_load(&entries[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (int spins = 0; !(e & VA_VALID); ++spins) {
+                if (spins > VA_SPIN_LIMIT) {
+                    atomicExch(&ws[4], 1u);
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(8);
+                e = __hip_atomic_load(&entries[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            s_entry = e;
+        }
+        __syncthreads();
+        const unsigned long long e = s_entry;
+        if (!(e & VA_VALID)) break;
+        const int idx = (int)((e >> 32) & 0xffffu), bst = (int)((e >> 16) & 0xffffu);
+        int n_sel = (int)(e & 0xffu);
+        if (n_sel > D) n_sel = D;
+        if (e & VA_HIDDEN) {
+            for (int r = (int)sub; r < a.hid_groups * D; r += a.nbx)
+                accept_copy_row(r, idx, bst, n_sel, a.hidden, a.hid_groups, a.N, a.hid_cpr, a.retrieve, 0, P, D, a.cand, a.out_hidden, a.accepted_tokens);
+        } else {
+            kv_gather_rows<8, 2, 0>((int)sub, a.nbx, idx, a.slab_seq[idx], bst, n_sel, a.slab_ptrs, a.slab_prev, a.outer, a.S_max, a.cpr, a.retrieve, 0,
+                                    P, D, a.new_len);
+        }
+    }
+    // the last workgroup out leaves the queue empty for the next launch on this workspace
+    __syncthreads();
+    if (tid == 0) s_u32 = atomicAdd(&ws[3], 1u);
+    __syncthreads();
+    if (s_u32 == gridDim.x - 1) {
+        for (uint32_t i = tid; i < n_entries; i += 512) entries[i] = 0ull;
+        if (tid < 4) ws[tid] = 0u;
+    }
 }
 
 __global__ void window_to_dense_kernel(const float *__restrict__ winp, const int32_t *__restrict__ out_tok,
@@ -1380,8 +1484,8 @@ extern "C" int lantern_prepare_step(const lantern_step_group *g) {
     return LANTERN_OK;
 }
 
-extern "C" int lantern_evaluate_posterior_window(const lantern_ep_params *prm, const lantern_ep_buffers *buf,
-                                                 const lantern_ep_window *win, void *stream) {
+// argument rules of the windowed chain kernel (shared by its own launch and lantern_verify_accept)
+static int epw_check(const lantern_ep_params *prm, const lantern_ep_buffers *buf, const lantern_ep_window *win) {
     LANTERN_CHECK_ARG(prm && buf && win, "evaluate_posterior_window: null params");
     const lantern_ep_params &p = *prm;
     LANTERN_CHECK_ARG(p.B >= 0 && p.P > 0 && p.D > 0 && p.V > 0 && p.V % 4 == 0, "evaluate_posterior_window: bad B/P/D/V");
@@ -1434,9 +1538,24 @@ extern "C" int lantern_evaluate_posterior_window(const lantern_ep_params *prm, c
         set_error("evaluate_posterior_window: top_k=%d wider than the window (%d) needs the dense kernel", p.top_k, win->win_len);
         return LANTERN_E_UNSUPPORTED;
     }
+    return LANTERN_OK;
+}
+
+static size_t epw_lds_bytes(const lantern_ep_params &p, const lantern_ep_window *win) {
+    return epw_shared_offset(win->win_len) + sizeof(EwShared) + (size_t)6 * epw_pd_cap(p.P, p.D) * 4 +
+           (win->rows_kind == LANTERN_ROWS_RAW_BF16 ? (size_t)O7_HIST_INTS * 4 : 0);
+}
+
+extern "C" int lantern_evaluate_posterior_window(const lantern_ep_params *prm, const lantern_ep_buffers *buf,
+                                                 const lantern_ep_window *win, void *stream) {
+    const int rc = epw_check(prm, buf, win);
+    if (rc) return rc;
+    const lantern_ep_params &p = *prm;
+    if (p.B == 0) return LANTERN_OK;
+    const bool raw = win->rows_kind == LANTERN_ROWS_RAW_BF16;
     hipStream_t st = (hipStream_t)stream;
     const int W = win->win_len;
-    const size_t lds = epw_shared_offset(W) + sizeof(EwShared) + (size_t)6 * epw_pd_cap(p.P, p.D) * 4 + (raw ? (size_t)O7_HIST_INTS * 4 : 0);
+    const size_t lds = epw_lds_bytes(p, win);
     dim3 grid(p.B);
     const int nz = (p.k + 1 < p.table_cols) ? p.k + 1 : p.table_cols;
     const bool lds_ids = !p.lantern || nz <= EW_PF_K;
@@ -1468,6 +1587,61 @@ extern "C" int lantern_evaluate_posterior_window(const lantern_ep_params *prm, c
 #undef EPW_LAUNCH_W
 #undef EPW_LAUNCH
     LANTERN_CHECK_LAUNCH("evaluate_posterior_window");
+    return LANTERN_OK;
+}
+
+extern "C" size_t lantern_verify_accept_workspace(int B, int n_slabs) {
+    if (B < 0 || n_slabs < 0) return 0;
+    return 32 + (size_t)(B + n_slabs) * 8;
+}
+
+// O8 + O9 + O10 of one group in one launch (include/lantern_hip.h).  Built for the Lumina / Anole image window on the packed
+// neighbour table (the epw_kernel<512, 4, 2, 1, FULLW> variants, probability or raw bf16 rows); anything else: LANTERN_E_UNSUPPORTED
+// and the caller launches lantern_evaluate_posterior_window + lantern_update_inference_inputs.
+extern "C" int lantern_verify_accept(const lantern_step_group *s) {
+    LANTERN_CHECK_ARG(s, "verify_accept: null group");
+    const int rc = epw_check(&s->ep, &s->ep_buf, &s->ep_win);
+    if (rc) return rc;
+    const lantern_ep_params &p = s->ep;
+    if (p.B == 0) return LANTERN_OK;
+    const lantern_ep_window *win = &s->ep_win;
+    const bool raw = win->rows_kind == LANTERN_ROWS_RAW_BF16;
+    const int nz = (p.k + 1 < p.table_cols) ? p.k + 1 : p.table_cols;
+    const bool packed = p.lantern && nz <= EW_PF_K && p.table_cols % 8 == 0 && ((uintptr_t)s->ep_buf.nn_table & 15) == 0;
+    if (!(win->win_len == 8192 && packed && (raw || win->rows_kind == LANTERN_ROWS_PROBS))) {
+        set_error("verify_accept: built for the 8192-id window on the packed neighbour table with probability or raw bf16 rows; "
+                  "launch evaluate_posterior_window + update_inference_inputs instead");
+        return LANTERN_E_UNSUPPORTED;
+    }
+    LANTERN_CHECK_ARG(s->slab_ptrs && s->slab_seq && s->slab_prev && s->retrieve && s->n_slabs > 0 && s->outer > 0 && s->S_max > 0 && s->d > 0,
+                      "verify_accept: needs the KV slabs (slab_ptrs / slab_seq / slab_prev, sizes)");
+    LANTERN_CHECK_ARG((s->d * s->elem_bytes) % 16 == 0, "verify_accept: KV row bytes %lld must be a multiple of 16", (long long)(s->d * s->elem_bytes));
+    LANTERN_CHECK_ARG(p.D <= 8 && p.B < 65536 && s->n_slabs < 65536, "verify_accept: D=%d > 8 or more than 65535 sequences / slabs", p.D);
+    LANTERN_CHECK_ARG(!s->ep_buf.n_paths && !s->ep_buf.n_depth && !p.row_index_per_seq, "verify_accept: one tree shape for the whole group");
+    if (s->hidden) LANTERN_CHECK_ARG(s->out_hidden && s->hid_groups > 0 && s->N > 0 && s->H > 0 && (s->H * s->hid_elem_bytes) % 16 == 0,
+                                     "verify_accept: hidden row bytes must be a multiple of 16");
+    LANTERN_CHECK_ARG(s->fused_ws && s->fused_ws_bytes >= (int64_t)lantern_verify_accept_workspace(p.B, s->n_slabs) && ((uintptr_t)s->fused_ws & 7) == 0,
+                      "verify_accept: workspace of lantern_verify_accept_workspace(B, n_slabs) bytes, 8-aligned, zero-filled once");
+    const int cpr = (int)(s->d * s->elem_bytes / 16);
+    const int64_t total = s->outer * cpr;
+    LANTERN_CHECK_ARG(total < (1ll << 31), "verify_accept: outer * row chunks = %lld does not fit 31 bits", (long long)total);
+    int nbx = (int)((total + 2 * 512 - 1) / (2 * 512));           // tiles of a slab: 512 threads x 2 row groups each
+    if (nbx > 64) nbx = 64;
+    const int rows_hidden = s->hidden ? s->hid_groups * p.D : 1;
+    (void)rows_hidden;
+    int workers = s->fused_workers > 0 ? s->fused_workers : (p.B < 224 ? 256 - p.B : 32);      // one workgroup per CU (the chain's LDS)
+    VaArgs a{};
+    a.ep = EpwArgs{p, s->ep_buf, s->ep_win};
+    a.slab_ptrs = s->slab_ptrs; a.slab_seq = s->slab_seq; a.slab_prev = s->slab_prev; a.new_len = s->new_len; a.retrieve = s->retrieve;
+    a.outer = s->outer; a.S_max = s->S_max; a.n_slabs = s->n_slabs; a.cpr = cpr; a.nbx = nbx; a.hid_groups = s->hidden ? s->hid_groups : 1;
+    a.hidden = (const uint4 *)s->hidden; a.out_hidden = (uint4 *)s->out_hidden; a.cand = s->cand; a.accepted_tokens = s->accepted_tokens;
+    a.N = s->N; a.hid_cpr = s->hidden ? s->H * s->hid_elem_bytes / 16 : 0;
+    a.ws = (uint32_t *)s->fused_ws;
+    const size_t lds = epw_lds_bytes(p, win);
+    const dim3 grid(p.B + workers);
+    if (raw) LANTERN_LAUNCH((verify_accept_kernel<true>), grid, dim3(512), lds, (hipStream_t)s->stream, a);
+    else LANTERN_LAUNCH((verify_accept_kernel<false>), grid, dim3(512), lds, (hipStream_t)s->stream, a);
+    LANTERN_CHECK_LAUNCH("verify_accept");
     return LANTERN_OK;
 }
 

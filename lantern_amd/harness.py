@@ -87,6 +87,14 @@ class WorkloadConfig:
                                     # up front, in the same launch as the candidate assembly (lantern_prepare_step); the rest on demand
     native_step: bool = True        # eager windowed path: the whole step of all groups through ONE C call (lantern_verify_step) instead of
                                     # 4 x n_groups ctypes calls (the Python launch loop caps the stream groups at ~2 otherwise)
+    launch_threads: int = 0         # native_step: >0 = the step's launches are enqueued by this many worker threads (lantern_step_launcher;
+                                    # each group's stream fed by one worker) instead of the calling thread.  3 launches per group at
+                                    # several us of host time each bound the step past ~4 groups otherwise.  More than 3 groups also
+                                    # need GPU_MAX_HW_QUEUES >= n_groups in the environment BEFORE the HIP runtime starts
+    fused_accept: bool = False      # native_step, chain kernel, KV slabs: O8 + O9 + O10 as ONE launch (lantern_verify_accept): the chains of the
+                                    # group run on the first B workgroups, every finished chain queues its verdict and the remaining
+                                    # workgroups move that sequence's KV / hidden rows while slower chains are still running
+    fused_workers: int = 0          # copy workgroups beside the chains (0: 256 / n_groups - sequences per group, at least 32)
     leaf_workgroups: int = -1       # node kernel: -1 = by batch size (include/lantern_hip.h lantern_ep_nodes)
     n_groups: int = 1               # >1: the sequences are split into groups, each launched on its own HIP stream, so that one
                                     # group's latency-bound evaluate_posterior overlaps the others' bandwidth-bound kernels
@@ -285,10 +293,19 @@ class LuminaVerifyWorkload:
                 for g in range(self.G):
                     self._group_args(slot, parity, g)
         self._steps = {}
+        self._launcher = None
+        self.fused_ws = None
+        if cfg.fused_accept and self.windowed and cfg.with_kv and self.ep_nodes is None and cfg.native_step:
+            nb = self._L.lantern_verify_accept_workspace(self.Bg, 2 * self.Bg)
+            self.fused_ws = [torch.zeros((nb + 7) // 8, dtype=torch.int64, device=device) for _ in range(self.G)]      # zeroed once; the kernel leaves it zeroed
         if self.windowed and cfg.native_step and cfg.direct_logs and cfg.fuse_update and not cfg.side_stream and not cfg.use_graph:
             for slot in range(cfg.pool_steps):
                 for parity in (0, 1):
                     self._steps[(slot, parity)] = self._make_step_groups(slot, parity)
+            if cfg.launch_threads > 0:
+                h = C.c_void_p()
+                check(self._L.lantern_step_launcher_create(min(cfg.launch_threads, self.G), device.index or 0, C.byref(h)), "step_launcher_create")
+                self._launcher = h
 
     # -------------------------------------------------------------------------------------
     def reset_state(self):
@@ -419,7 +436,10 @@ class LuminaVerifyWorkload:
             if self.G > 1 and not self._forked:
                 self._fork()
             self._native_step(slot, i & 1)
-        elif self.G == 1:
+            self.step_idx += 1
+            return
+        self.launches_done()
+        if self.G == 1:
             if use_graph:
                 self.graphs[slot][0].replay()
             else:
@@ -448,8 +468,25 @@ class LuminaVerifyWorkload:
                 st.wait_stream(cur)
         self._forked = True
 
+    def launches_done(self):
+        """Worker-thread launches: block until every submitted step sits on its stream (raises the first enqueue error)."""
+        if self._launcher is not None:
+            check(self._L.lantern_step_launcher_wait(self._launcher), "step_launcher_wait")
+
+    def close(self):
+        if getattr(self, "_launcher", None) is not None:
+            self._L.lantern_step_launcher_destroy(self._launcher)
+            self._launcher = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
     def join(self):
         """The current stream waits for every group stream."""
+        self.launches_done()
         if self.G > 1:
             cur = torch.cuda.current_stream(self.device)
             for st in self.streams:
@@ -504,6 +541,9 @@ class LuminaVerifyWorkload:
             s.seq_len, s.out_win, s.row_hot, s.temperature, s.top_p = val(A["cur"]), (None if (self.fused_o7 and not self.n_spec) else val(A["proc"])), val(A["row_hot"]), 1.0, 1.0
             if self.n_spec:
                 s.node_list, s.n_list = self.d_node_list.data_ptr(), self.n_spec
+            if self.fused_ws is not None:
+                s.fused_ws, s.fused_ws_bytes = self.fused_ws[g].data_ptr(), self.fused_ws[g].numel() * 8
+                s.fused_workers = c.fused_workers if c.fused_workers > 0 else max(32, 256 // self.G - self.Bg)
             C.memmove(C.byref(s.ep), C.byref(self._ep_prm), C.sizeof(EpParams))
             C.memmove(C.byref(s.ep_buf), C.byref(A["ep_buf"]), C.sizeof(EpBuffers))
             C.memmove(C.byref(s.ep_win), C.byref(A["ep_win"]), C.sizeof(EpWindow))
@@ -534,8 +574,12 @@ class LuminaVerifyWorkload:
                 s.sample_token = self.sample_token[g * self.Bg:].data_ptr()
             s.ep_buf.best, s.ep_buf.accept_len, s.ep_buf.counters = bs["best"] + 4 * e, bs["alen"] + 4 * e, bs["cnt"] + 24 * e
             s.ep_win.u_bonus, s.ep_win.token = bs["ub"] + 8 * e, bs["tok"] + 8 * e
-        check(self._L.lantern_verify_step(arr, self.G), "verify_step")
+        if self._launcher is not None:
+            check(self._L.lantern_step_launcher_submit(self._launcher, arr, self.G), "step_launcher_submit")
+        else:
+            check(self._L.lantern_verify_step(arr, self.G), "verify_step")
         if not c.with_kv:
+            self.launches_done()
             for g in range(self.G):
                 s0, B = g * self.Bg, self.Bg
                 with torch.cuda.stream(self.streams[g]) if self.streams[g] is not None else _nullctx():
@@ -543,6 +587,7 @@ class LuminaVerifyWorkload:
         # sequence management (not the hot path): an image can only end once the host-side bound says so
         self._len_ub += self.D
         if self._len_ub >= TOKENS_PER_IMAGE:
+            self.launches_done()
             for g in range(self.G):
                 s0, B = g * self.Bg, self.Bg
                 with torch.cuda.stream(self.streams[g]) if self.streams[g] is not None else _nullctx():
@@ -727,7 +772,13 @@ class LuminaVerifyWorkload:
                                         A["sample_token"], A["nxt"], A["len_base"], A["u_bonus_g"], A["u_cur"], st), "harness_advance")
 
     # -------------------------------------------------------------------------------------
+    def sync(self):
+        """Everything submitted so far has run (worker-thread enqueues included)."""
+        self.join()
+        torch.cuda.synchronize(self.device)
+
     def accepted_tokens(self, i0: int, i1: int) -> int:
+        self.sync()
         return int((self.log_alen[i0:i1].to(torch.int64) + 1).sum().item())
 
     # Byte accounting.  `group`: None = all sequences (one whole step), g = the sequences of group g (one LAUNCH when G > 1).
@@ -781,10 +832,15 @@ class LuminaVerifyWorkload:
         return float(2 * moved * per_pos)
 
     def check_status(self, i0: int, i1: int):
+        self.sync()
         st = self.log_cnt[i0:i1, :, 5]
         if int(st.abs().sum().item()) != 0:
             bad = torch.nonzero(st)[0].tolist()
             raise _lib.LanternError(f"evaluate_posterior status {int(st[bad[0], bad[1]])} at step {i0 + bad[0]} seq {bad[1]}")
+        if self.fused_ws is not None:
+            for g, w in enumerate(self.fused_ws):
+                if int(w[2].item()) & 0xffffffff:
+                    raise _lib.LanternError(f"verify_accept: a copy worker of group {g} gave up waiting for a chain")
 
 
 # =====================================================================================================================

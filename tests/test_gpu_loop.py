@@ -133,3 +133,80 @@ def test_fused_o7_loop_matches_oracle_loop(groups, spec):
             assert int((torch.as_tensor(gt) == HN.NEWLINE).sum()) > 0          # forced newline rows were crossed
     for a, b in zip(*outs):
         assert torch.equal(a, b)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("groups,threads,ep,fuse", [(6, 3, "chain", True), (4, 4, "nodes", False), (1, 1, "chain", True)])
+def test_worker_thread_launches_give_the_same_stream(groups, threads, ep, fuse):
+    """lantern_step_launcher: the step's launches enqueued by worker threads (one stream always fed by the same worker, argument
+    blocks copied at submit) -- every step's verdicts, tokens and counters equal the calling-thread run, KV rows included."""
+    from lantern_amd import harness as HN
+    steps = 80
+    outs = []
+    for thr in (threads, 0):
+        cfg = HN.WorkloadConfig(n_seq=12, pool_steps=4, kv_layers=2, kv_heads=4, kv_smax=1024, max_steps=steps + 4, sigma=5.0, n_groups=groups,
+                                ep_kernel=ep, fuse_o7=fuse, spec_rows=3 if fuse else 0, launch_threads=thr)
+        wl = HN.LuminaVerifyWorkload(cfg, torch.device("cuda"))
+        assert (wl._launcher is not None) == (thr > 0)
+        for _ in range(steps):
+            wl.step()
+        wl.sync()
+        wl.check_status(0, steps)
+        outs.append((wl.log_best[:steps].clone(), wl.log_alen[:steps].clone(), wl.log_token[:steps].clone(), wl.log_cnt[:steps].clone(),
+                     wl.lens[steps & 1].clone(), torch.stack([s.clone() for s in wl.slabs[:4]])))
+        wl.close()
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+
+
+@pytest.mark.gpu
+def test_worker_thread_launch_error_reaches_the_caller():
+    """An enqueue that fails on a worker thread comes back from wait() with the kernel's own message."""
+    import ctypes as C
+    from lantern_amd import _lib
+    from lantern_amd import harness as HN
+    cfg = HN.WorkloadConfig(n_seq=4, pool_steps=2, kv_layers=2, kv_heads=4, kv_smax=512, max_steps=16, n_groups=2, ep_kernel="chain",
+                            fuse_o7=True, spec_rows=3, launch_threads=2)
+    wl = HN.LuminaVerifyWorkload(cfg, torch.device("cuda"))
+    wl.step()
+    wl.sync()
+    keep = wl._steps[(0, 0)][1].ep.k
+    for arr in wl._steps.values():
+        arr[1].ep.k = -5                 # an argument the kernel's host side refuses
+    try:
+        with pytest.raises(_lib.LanternError, match="worker thread"):
+            wl.step()
+            wl.sync()
+    finally:
+        for arr in wl._steps.values():
+            arr[1].ep.k = keep
+    wl.step()                            # the launcher keeps working after the error was collected
+    wl.sync()
+    wl.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("groups,fuse,workers", [(1, True, 0), (2, True, 3), (1, False, 1), (3, True, 40)])
+def test_fused_accept_launch_gives_the_same_stream_and_kv_rows(groups, fuse, workers):
+    """lantern_verify_accept: evaluate_posterior + update_inference_inputs in one launch, pipelined per sequence through a work queue
+    (chains on the first B workgroups, copy workers behind them).  Verdicts, tokens, counters, lengths, every KV slab, the accepted
+    hidden rows and tokens equal the two-launch run; the queue is left empty."""
+    from lantern_amd import harness as HN
+    steps = 80
+    outs = []
+    for fa in (True, False):
+        cfg = HN.WorkloadConfig(n_seq=12, pool_steps=4, kv_layers=2, kv_heads=4, kv_smax=1024, max_steps=steps + 4, sigma=5.0, n_groups=groups,
+                                ep_kernel="chain", fuse_o7=fuse, spec_rows=3 if fuse else 0, fused_accept=fa, fused_workers=workers)
+        wl = HN.LuminaVerifyWorkload(cfg, torch.device("cuda"))
+        assert (wl.fused_ws is not None) == fa
+        for _ in range(steps):
+            wl.step()
+        wl.sync()
+        wl.check_status(0, steps)
+        if fa:
+            for w in wl.fused_ws:
+                assert int(w.abs().sum()) == 0
+        outs.append((wl.log_best[:steps].clone(), wl.log_alen[:steps].clone(), wl.log_token[:steps].clone(), wl.log_cnt[:steps].clone(),
+                     wl.lens[steps & 1].clone(), torch.stack([s.clone() for s in wl.slabs]), wl.out_hidden.clone(), wl.acc_tokens.clone()))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)

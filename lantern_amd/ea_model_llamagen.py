@@ -271,13 +271,33 @@ class EaModel(nn.Module):
                                     tree_attn_mask=tree_attn_mask, tree_choices=tree_choices)
 
     # ------------------------------------------------------------------ :1002-1170
+    def _encode_prompt(self, prompt, cfg):
+        """The prompt block of the reference's generate (models/ea_model_llamagen.py:1018-1056): T5 caption embeddings rotated from
+        right- to left-padding, zeroed under the mask, the unconditional class embedding appended for CFG.  The T5 encoder itself
+        stays the reference's (`base_model.t5_model.get_text_embeddings`); a base model that brings its own `encode_prompt(prompt,
+        cfg) -> (cond_combined, attention_mask)` is used as is."""
+        bm = self.base_model
+        if hasattr(bm, "encode_prompt"):
+            return bm.encode_prompt(prompt, cfg)
+        emb, mask = bm.t5_model.get_text_embeddings(prompt)                  # [B,T,C], [B,T] (valid tokens first)
+        T = emb.shape[1]
+        valid = mask.sum(dim=-1).to(torch.long)                              # rotate every row so that its valid tokens come last
+        src = (torch.arange(T, device=emb.device)[None, :] + valid[:, None]) % T
+        rot = torch.gather(emb, 1, src[:, :, None].expand(-1, -1, emb.shape[2]))
+        lmask = torch.flip(mask, dims=[-1])
+        cond = rot * lmask[:, :, None]
+        if cfg is not None:
+            null = torch.zeros_like(cond) + bm.model.cls_embedding.uncond_embedding.to(cond.device)
+            cond, lmask = torch.cat([cond, null]), torch.cat([lmask, lmask])
+        return cond.to(bm.dtype), lmask
+
     @torch.no_grad()
     def generate(self, prompt: Optional[List[str]] = None, max_length: Optional[int] = None, temperature: Optional[float] = None,
                  top_k: Optional[int] = None, top_p: Optional[float] = None, cfg: Optional[float] = None,
                  lantern: Optional[bool] = None, lantern_k: Optional[int] = None, lantern_delta: Optional[float] = None,
                  static_tree: Optional[bool] = None, tree_choices: Optional[List[List[int]]] = naive_extend_57, **model_kwargs):
         accept_length_list = []
-        cond_combined, attention_mask = self.base_model.encode_prompt(prompt, cfg)     # T5 + uncond embedding: out of scope
+        cond_combined, attention_mask = self._encode_prompt(prompt, cfg)
         st = time.time()
         if not hasattr(self.base_model, "past_key_values"):
             (self.base_model.past_key_values, self.base_model.past_key_values_data,

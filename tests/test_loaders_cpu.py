@@ -91,3 +91,34 @@ def test_vq_table_file_round_trip(tmp_path):
     assert back.dtype == torch.int16 and np.array_equal(back.numpy().view(np.uint16), arr)
     with pytest.raises(LanternError):
         ops.save_vq_table(torch.zeros((8, 5), dtype=torch.int16), str(tmp_path))
+
+
+def test_llamagen_prompt_block_matches_the_reference_recipe():
+    """EaModel._encode_prompt (reference: models/ea_model_llamagen.py:1018-1056): right-padded T5 rows become left-padded (each row
+    rotated by its valid length), are zeroed under the flipped mask, and the unconditional embedding rows follow for CFG -- so the
+    reference's base model needs no `encode_prompt` helper."""
+    import types
+    import torch
+    from lantern_amd.ea_model_llamagen import EaModel
+    g = torch.Generator().manual_seed(0)
+    B, T, Cc = 3, 7, 5
+    emb = torch.randn(B, T, Cc, generator=g)
+    valid = [7, 3, 1]
+    mask = torch.zeros(B, T, dtype=torch.int64)
+    for i, v in enumerate(valid):
+        mask[i, :v] = 1
+    unc = torch.randn(T, Cc, generator=g)
+    bm = types.SimpleNamespace(t5_model=types.SimpleNamespace(get_text_embeddings=lambda p: (emb, mask)), dtype=torch.float32,
+                               model=types.SimpleNamespace(cls_embedding=types.SimpleNamespace(uncond_embedding=unc)))
+    me = types.SimpleNamespace(base_model=bm)
+    # the recipe, row by row
+    rows = torch.stack([torch.cat([emb[i, v:], emb[i, :v]]) for i, v in enumerate(valid)])
+    lm = torch.flip(mask, dims=[-1])
+    want = rows * lm[:, :, None]
+    cond, am = EaModel._encode_prompt(me, ["a", "b", "c"], cfg=1.5)
+    assert torch.equal(cond[:B], want) and torch.equal(cond[B:], (torch.zeros_like(want) + unc))
+    assert torch.equal(am, torch.cat([lm, lm]))
+    cond1, am1 = EaModel._encode_prompt(me, ["a", "b", "c"], cfg=None)
+    assert torch.equal(cond1, want) and torch.equal(am1, lm)
+    bm.encode_prompt = lambda p, c: ("mine", None)           # a base model's own helper wins
+    assert EaModel._encode_prompt(me, ["a"], 1.0)[0] == "mine"

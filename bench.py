@@ -55,7 +55,7 @@ def parse():
     ap.add_argument("--sigma", type=float, default=5.0, help="drafter noise; frozen at 5.0: mean accepted tokens/step ~2.6")
     ap.add_argument("--path", choices=["window", "dense"], default="window",
                     help="window: v2 kernels (32 KB image-window rows, LDS-resident residual); dense: v1 kernels (full-V rows)")
-    ap.add_argument("--ep", choices=["nodes", "chain"], default="chain",
+    ap.add_argument("--ep", choices=["nodes", "chain", "walk"], default="chain",
                     help="windowed evaluate_posterior: nodes = one workgroup per internal tree node + the walk (lantern_evaluate_posterior_nodes); "
                          "chain = one serial chain per sequence (lantern_evaluate_posterior_window)")
     ap.add_argument("--no-fuse-o7", dest="fuse_o7", action="store_false", help="every stage its own launch: cfg_mask_topk for ALL rows, then evaluate_posterior on probability rows "
@@ -233,10 +233,11 @@ def ep_batch_sweep(batches, device, base_cfg, iters=20):
         buf = wl.ep_buffers(0, 0)
         win = wl.ep_window(0) if wl.windowed else None
         row = {"sequences_per_launch": Bs}
-        for kern in (("chain", "nodes") if wl.windowed else ("dense",)):
+        for kern in (("chain", "nodes", "walk") if wl.windowed else ("dense",)):
             def launch():
                 wl.cursor.zero_()
-                if kern == "nodes":
+                if kern in ("nodes", "walk"):
+                    wl.ep_nodes[0].serial = int(kern == "walk")
                     check(L.lantern_evaluate_posterior_nodes(C.byref(wl._ep_prm), C.byref(buf), C.byref(win), C.byref(wl.ep_nodes[0]), st), "ep")
                 elif kern == "chain":
                     check(L.lantern_evaluate_posterior_window(C.byref(wl._ep_prm), C.byref(buf), C.byref(win), st), "ep")
@@ -279,6 +280,8 @@ def kernel_report(wl, evs, E0, E1, KT):
     ach = contract_bytes / (ep_ms * 1e-3) / 1e9
     if not wl.windowed:
         kname = "ep_kernel (evaluate_posterior)"
+    elif wl.ep_nodes is not None and cfg.ep_kernel == "walk":
+        kname = "epn_serial_kernel (evaluate_posterior, one workgroup per sequence running the node routine along the walk)"
     elif wl.ep_nodes is not None:
         kname = "epn_kernel + epn_walk_kernel (evaluate_posterior, node-parallel)"
     elif wl.fused_o7:
@@ -298,7 +301,7 @@ def kernel_report(wl, evs, E0, E1, KT):
                                                ("; raw rows: a visited row is 2 x W bf16 = the same W*4 bytes" if wl.fused_o7 else "")}
     tfile = os.path.join(ROOT, "profiles", "r02_ep_traffic.json")
     if wl.windowed and os.path.exists(tfile):
-        key = ("raw" if wl.fused_o7 else ("nodes" if wl.ep_nodes is not None else "chain")) + f"_B{wl.Bg}"
+        key = ("raw" if wl.fused_o7 else ((cfg.ep_kernel if cfg.ep_kernel in ("nodes", "walk") else "nodes") if wl.ep_nodes is not None else "chain")) + f"_B{wl.Bg}"
         t = json.load(open(tfile)).get("per_launch", {}).get(key)
         if t:      # PMC passes are separate rocprofv3 runs of the same kernel / launch size, see profiles/
             rl["traffic"] = t["hbm_bytes"]
@@ -378,7 +381,7 @@ def step_latency(device, base_cfg, batches=(1, 8), steps=60):
     from lantern_amd import harness as HN
     res = {}
     for Bs in batches:
-        for kern in ("nodes", "chain"):
+        for kern in ("nodes", "chain", "walk"):
             cfg = HN.WorkloadConfig(n_seq=Bs, pool_steps=4, lantern_k=base_cfg.lantern_k, lantern_delta=base_cfg.lantern_delta, sigma=base_cfg.sigma,
                                     with_kv=base_cfg.with_kv, kv_smax=base_cfg.kv_smax, kv_pad_rows=base_cfg.kv_pad_rows, max_steps=steps + 32,
                                     seed_base=base_cfg.seed_base + 900, ep_kernel=kern, tree=base_cfg.tree)

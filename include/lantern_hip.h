@@ -316,8 +316,12 @@ typedef struct lantern_ep_nodes {
     int32_t prefix_siblings; /* = tables[6] */
     int32_t leaf_workgroups; /* 1: leaves get workgroups that pre-draw their bonus token (small batches: nothing after the node kernel but
                                 a table walk); 0: the walk kernel draws it for the one leaf a walk ends on; -1: chosen by batch size */
-    void *workspace;         /* [dev] lantern_evaluate_posterior_nodes_workspace() bytes, 16-byte aligned */
+    void *workspace;         /* [dev] lantern_evaluate_posterior_nodes_workspace() bytes, 16-byte aligned (serial: unused, may be NULL) */
     size_t workspace_bytes;
+    int32_t serial;          /* 1: ONE workgroup per sequence walks the tree itself and runs the node routine at every stop (the chain
+                                kernel's job with the node routine's table-driven prologue and lean rejection path): one launch, no
+                                workspace; 0: node-parallel (a workgroup per node + the walk kernel) */
+    int32_t reserved;
 } lantern_ep_nodes;
 
 int lantern_tree_node_tables_size(int N, int P, int D);

@@ -50,7 +50,7 @@ class EpWindow(C.Structure):
 class EpNodes(C.Structure):
     _fields_ = [("tables", C.c_void_p), ("tables_host", C.c_void_p), ("n_nodes", C.c_int32), ("n_internal", C.c_int32), ("n_children", C.c_int32),
                 ("max_children", C.c_int32), ("prefix_siblings", C.c_int32), ("leaf_workgroups", C.c_int32),
-                ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t)]
+                ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t), ("serial", C.c_int32), ("reserved", C.c_int32)]
 
 
 class StepGroup(C.Structure):

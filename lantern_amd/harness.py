@@ -80,7 +80,8 @@ class WorkloadConfig:
     fuse_update: bool = True        # windowed path: O9 + O10 in one launch (lantern_update_inference_inputs)
     pack_table: bool = True         # windowed path: neighbour table packed to [K, ceil8(k+1)] (lantern_pack_vq_table)
     ep_kernel: str = "nodes"        # windowed path: "nodes" = node-parallel evaluate_posterior (one workgroup per internal tree node + the
-                                    # walk; B * n_internal workgroups fill the GPU), "chain" = one serial chain per sequence (epw_kernel)
+                                    # walk; B * n_internal workgroups fill the GPU), "chain" = one serial chain per sequence (epw_kernel),
+                                    # "walk" = one workgroup per sequence running the node routine at every stop of the walk (epn_serial_kernel)
     fuse_o7: bool = False           # windowed chain kernel: LANTERN_ROWS_RAW_BF16 -- no O7 launch, evaluate_posterior post-processes (CFG, top-k,
                                     # softmax) the rows its walk visits from the raw cond / uncond logits
     spec_rows: int = 0              # with fuse_o7: this many of the tree's most likely nodes (the root first) get their rows post-processed
@@ -273,7 +274,7 @@ class LuminaVerifyWorkload:
         self._ep_prm = self._make_ep_params()
         self.graphs = None
         self.ep_nodes = None
-        if self.windowed and cfg.ep_kernel == "nodes":
+        if self.windowed and cfg.ep_kernel in ("nodes", "walk"):
             self.node_tables = ops.tree_node_tables(tb["retrieve_indices"], N, tb["p_indices"], tb["b_off"], op_off, device=device, b_idx=tb["b_idx"])
             nt = self.node_tables
             win0 = EpWindow()
@@ -282,7 +283,7 @@ class LuminaVerifyWorkload:
             self.node_ws = torch.empty((cfg.n_groups, max(nbytes, 16)), dtype=torch.uint8, device=device)
             self.ep_nodes = []
             for g in range(cfg.n_groups):
-                self.ep_nodes.append(nt.struct(self.node_ws[g].data_ptr(), nbytes, cfg.leaf_workgroups))
+                self.ep_nodes.append(nt.struct(self.node_ws[g].data_ptr(), nbytes, cfg.leaf_workgroups, serial=cfg.ep_kernel == "walk"))
         self.reset_state()
         # every (pool slot, parity, group) argument block is built HERE (setup, untimed): the step loop only patches the
         # step-dependent log-row addresses, computed arithmetically from these bases

@@ -31,7 +31,7 @@ def test_param_struct_layout_matches_header():
     assert C.sizeof(_lib.EpParams) == 4 * 11 + 32 + 4 * 5 + 4 + 4 + 8 + 4 * 4
     assert C.sizeof(_lib.EpBuffers) == 20 * 8
     assert C.sizeof(_lib.EpWindow) == 8 + 8 + 8 + 5 * 8 + 8 + 4 * 8 + 6 * 4 + 2 * 8
-    assert C.sizeof(_lib.EpNodes) == 8 + 8 + 6 * 4 + 8 + 8
+    assert C.sizeof(_lib.EpNodes) == 8 + 8 + 6 * 4 + 8 + 8 + 2 * 4
 
 
 def test_argument_validation_without_gpu():

@@ -210,3 +210,31 @@ def test_fused_accept_launch_gives_the_same_stream_and_kv_rows(groups, fuse, wor
                      wl.lens[steps & 1].clone(), torch.stack([s.clone() for s in wl.slabs]), wl.out_hidden.clone(), wl.acc_tokens.clone()))
     for a, b in zip(*outs):
         assert torch.equal(a, b)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("groups", [1, 2])
+def test_serial_node_kernel_loop_matches_chain_loop(groups):
+    """ep_kernel = "walk" (one workgroup per sequence running the node routine at every stop of the walk, lantern_ep_nodes.serial): the
+    whole step loop gives the chain kernel's verdicts, tokens, counters and KV rows, and the oracle's token stream."""
+    import bench
+    from lantern_amd import harness as HN
+    steps = 60
+    outs = []
+    for ep in ("walk", "chain"):
+        cfg = HN.WorkloadConfig(n_seq=8, pool_steps=4, kv_layers=2, kv_heads=4, kv_smax=1024, max_steps=steps + 4, sigma=5.0, n_groups=groups,
+                                ep_kernel=ep)
+        wl = HN.LuminaVerifyWorkload(cfg, torch.device("cuda"))
+        for _ in range(steps):
+            wl.step()
+        wl.sync()
+        wl.check_status(0, steps)
+        outs.append((wl.log_best[:steps].clone(), wl.log_alen[:steps].clone(), wl.log_token[:steps].clone(), wl.log_cnt[:steps].clone(),
+                     wl.lens[steps & 1].clone(), torch.stack([s.clone() for s in wl.slabs])))
+        if ep == "walk":
+            gb, ga, gt = [x.cpu().numpy() for x in outs[0][:3]]
+            stream = [[(int(gb[i, b]), int(ga[i, b]), int(gt[i, b])) for b in range(cfg.n_seq)] for i in range(steps)]
+            res = bench.cpu_baseline(wl, steps_budget_s=1e9, n_seq=cfg.n_seq, gpu_tokens_by_seq=stream)
+            assert res["matches_gpu_token_stream"], res
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)

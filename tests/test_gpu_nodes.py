@@ -123,8 +123,9 @@ def _static_ok(s):
 
 
 @gpu
+@pytest.mark.parametrize("serial", [False, True], ids=["parallel", "serial"])
 @pytest.mark.parametrize("i", [i for i, s in enumerate(SPECS) if _static_ok(s)])
-def test_nodes_static_golden(i):
+def test_nodes_static_golden(i, serial):
     from test_gpu_parity import hip_cfg, table_dev
     from test_gpu_window import window_of
     spec, case = SPECS[i], H.ep_case(i)
@@ -143,7 +144,7 @@ def test_nodes_static_golden(i):
     args = (cfg, m["V"], pr[None], lo, dev(H.row_index_from_retrieve(tb["retrieve"], N)), dev(case["cand"])[None], dev(case["uniforms"])[None])
     kw = dict(table=table_dev(m["K"]), aux=aux, u_bonus=dev(np.array([u])), want_dense=True, rows_probs=True)
     chain = ops.evaluate_posterior_window(*args, **kw)
-    node = ops.evaluate_posterior_window(*args, nodes=nt, **kw)
+    node = ops.evaluate_posterior_window(*args, nodes=nt, serial=serial, **kw)
     st = int(node["counters"][0, 5])
     if st == 8:
         # duplicate sibling tokens (a golden edge case): the node view does not hold, the kernel says so and the chain kernel is the path
@@ -206,10 +207,10 @@ def test_nodes_static_batches_vs_oracle(model, tree, lantern, k, delta, sigma, s
     ub = np.random.RandomState(seed).random_sample(B)
     nt = ops.tree_node_tables(tb["retrieve_indices"], N, tb["p_indices"], tb["b_off"], gs[0]["op_off"], device="cuda")
     outs = {}
-    for name, nodes in (("chain", None), ("nodes", nt)):
+    for name, nodes in (("chain", None), ("nodes", nt), ("walk", nt)):
         cur = dev(start.copy())
         outs[name] = ops.evaluate_posterior_window(ch, V, pr, lo, dev(ri), dev(np.stack(cands)), dev(uni), table=tab if lantern else None, aux=aux,
-                                                   cursor=cur, u_bonus=dev(ub), want_dense=True, rows_probs=True, nodes=nodes)
+                                                   cursor=cur, u_bonus=dev(ub), want_dense=True, rows_probs=True, nodes=nodes, serial=name == "walk")
         outs[name]["cursor"] = cur
     n_rej = n_acc = 0
     for b, g in enumerate(gs):
@@ -230,6 +231,7 @@ def test_nodes_static_batches_vs_oracle(model, tree, lantern, k, delta, sigma, s
     assert n_rej > 0 and n_acc > 0
     for key in ("best", "accept_len", "counters", "token", "sample_p", "sample_win", "out_tok", "out_mass", "cursor"):
         assert torch.equal(outs["nodes"][key], outs["chain"][key]), key
+        assert torch.equal(outs["walk"][key], outs["chain"][key]), ("walk", key)
 
 
 @gpu
@@ -268,9 +270,13 @@ def test_nodes_one_hot_rows_and_no_outputs():
     kw = dict(table=tab, aux=aux, u_bonus=dev(ub), row_hot=dev(hot), rows_probs=True)
     a = ops.evaluate_posterior_window(ch, V, pr, lo, dev(ri), dev(np.stack(cands)), dev(uni), want_dense=False, want_window=False, **kw)
     b_ = ops.evaluate_posterior_window(ch, V, pr, lo, dev(ri), dev(np.stack(cands)), dev(uni), want_dense=False, want_window=False, nodes=nt, **kw)
+    c_ = ops.evaluate_posterior_window(ch, V, pr, lo, dev(ri), dev(np.stack(cands)), dev(uni), want_dense=False, want_window=False, nodes=nt, serial=True, **kw)
     for key in ("best", "accept_len", "counters", "token", "out_tok", "out_mass"):
         assert torch.equal(a[key], b_[key]), (key, a[key], b_[key])
+        assert torch.equal(a[key], c_[key]), ("serial", key, a[key], c_[key])
     assert int((a["counters"][:, 5] != 0).sum()) == 0
     full = ops.evaluate_posterior_window(ch, V, pr, lo, dev(ri), dev(np.stack(cands)), dev(uni), want_dense=True, nodes=nt, **kw)
     full_c = ops.evaluate_posterior_window(ch, V, pr, lo, dev(ri), dev(np.stack(cands)), dev(uni), want_dense=True, **kw)
+    full_s = ops.evaluate_posterior_window(ch, V, pr, lo, dev(ri), dev(np.stack(cands)), dev(uni), want_dense=True, nodes=nt, serial=True, **kw)
     assert torch.equal(full["sample_p"], full_c["sample_p"]) and torch.equal(full["token"], a["token"])
+    assert torch.equal(full_s["sample_p"], full_c["sample_p"]) and torch.equal(full_s["sample_win"], full_c["sample_win"]) and torch.equal(full_s["token"], a["token"])

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Phase stamps of the node-parallel evaluate_posterior (lantern_debug_epn_trace): per-workgroup cycle counts of the
 prologue, every candidate's scan / rejection, and the bonus draw, on one verify step of the bench workload.
-Usage: python tools/epn_trace.py [n_seq] [steps]"""
+Usage: python tools/epn_trace.py [n_seq] [steps] [nodes|walk]"""
 import os, sys, ctypes as C
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -10,14 +10,15 @@ from lantern_amd import harness as HN, _lib
 n_seq = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 4
 dev = torch.device("cuda", 0)
-cfg = HN.WorkloadConfig(n_seq=n_seq, pool_steps=2, with_kv=False, max_steps=64)
+ep = sys.argv[3] if len(sys.argv) > 3 else "nodes"
+cfg = HN.WorkloadConfig(n_seq=n_seq, pool_steps=2, with_kv=False, max_steps=64, ep_kernel=ep)
 wl = HN.LuminaVerifyWorkload(cfg, dev)
 for _ in range(3):
     wl.step()
 torch.cuda.synchronize()
 L = _lib.lib()
 N = wl.N
-grid = n_seq * N
+grid = n_seq * N if ep == "nodes" else n_seq
 buf = torch.zeros((grid, 64), dtype=torch.int64, device=dev)
 names = {0: "start", 1: "loads issued", 2: "row+tables in LDS", 3: "S_q barrier", 4: "ids staged", 10: "cand start", 11: "decision", 12: "residual pass", 13: "block sum", 14: "normalised", 20: "loop end", 21: "bonus done"}
 allrows = []

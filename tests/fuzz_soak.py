@@ -247,3 +247,33 @@ def o3_soak(iters):
 
 if len(sys.argv) > 2 and sys.argv[2] == "o3":
     o3_soak(int(sys.argv[1]))
+
+
+# ---------------------------------------------------------------------------------------------- node kernels
+# `python tests/fuzz_soak.py <seeds> nodes`: tests/test_gpu_nodes.py::test_nodes_static_batches_vs_oracle over many more seeds -- the chain
+# kernel, the node-parallel kernels and the serial node kernel on the same 32-sequence batches, all against the oracle and each other.
+def nodes_soak(n_seeds):
+    import test_gpu_nodes as TN
+    sets = [("lumina", "mc_sim_7b_63", True, 100, 0.1, 1.0, True), ("lumina", "mc_sim_7b_63", True, 300, 5.0, 2.0, False),
+            ("lumina", "naive_extend_57", True, 10, 0.3, 0.5, True), ("lumina", "mc_sim_7b_63", False, 1, 0.1, 3.0, False),
+            ("llamagen", "naive_extend_57", True, 50, 0.1, 1.0, True), ("llamagen", "mc_sim_7b_63", True, 200, 10.0, 2.0, False),
+            ("anole", "naive_extend_57", True, 10, 5.0, 1.0, True), ("anole", "mc_sim_7b_63", False, 1, 0.1, 0.5, False),
+            ("lumina", "rand07", True, 60, 0.2, 2.5, True), ("lumina", "rand21", True, 500, 0.1, 4.0, True)]
+    fn = getattr(TN.test_nodes_static_batches_vs_oracle, "__wrapped__", TN.test_nodes_static_batches_vs_oracle)
+    n = fails = 0
+    t0 = time.time()
+    for seed in range(200, 200 + n_seeds):
+        for model, tree, lantern, k, delta, sigma, packed in sets:
+            try:
+                fn(model, tree, lantern, k, delta, sigma, seed, packed)
+            except AssertionError as e:
+                fails += 1
+                print("FAIL", (model, tree, lantern, k, delta, sigma, seed, packed), str(e)[:300], flush=True)
+            n += 1
+        if (seed - 200) % 5 == 4:
+            print(f"  seed {seed}: {n} batches, fails={fails}, {time.time() - t0:.0f}s", flush=True)
+    print(f"nodes soak: cases={n} batches x 32 sequences x 3 kernels, fails={fails}, {time.time() - t0:.0f}s")
+
+
+if len(sys.argv) > 2 and sys.argv[2] == "nodes":
+    nodes_soak(int(sys.argv[1]))

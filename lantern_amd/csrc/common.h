@@ -53,6 +53,30 @@ __device__ __forceinline__ float bf16_bits_to_f32(uint16_t h) { return __uint_as
 // round-to-nearest-even f32 -> bf16 -> f32 (torch's per-op bf16 rounding): v_cvt_pk_bf16_f32 + a shift on gfx950
 __device__ __forceinline__ float round_bf16(float f) { return (float)(__bf16)f; }
 
+// Two at a time: one v_cvt_pk_bf16_f32 rounds a pair (RNE, the same result as round_bf16 on each), the halves come back with a
+// shift and a mask -- against cvt + shift (+ a NaN-quieting v_max the compiler adds around the scalar conversion) per value.
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2_t round_bf16x2(f32x2_t v) {
+    const bf16x2_t h = __builtin_convertvector(v, bf16x2_t);
+    const unsigned int w = __builtin_bit_cast(unsigned int, h);
+    f32x2_t r;
+    r.x = __uint_as_float(w << 16);
+    r.y = __uint_as_float(w & 0xffff0000u);
+    return r;
+}
+// torch's bf16 CFG mix  u + s * (c - u)  with a bf16 rounding after every operation, on a packed pair of bf16 values per word
+__device__ __forceinline__ f32x2_t cfg_mix_bf16x2(unsigned int cw, unsigned int uw, float cfg) {
+    f32x2_t c, u;
+    c.x = __uint_as_float(cw << 16);
+    c.y = __uint_as_float(cw & 0xffff0000u);
+    u.x = __uint_as_float(uw << 16);
+    u.y = __uint_as_float(uw & 0xffff0000u);
+    f32x2_t t = round_bf16x2(c - u);
+    t = round_bf16x2(t * cfg);
+    return round_bf16x2(u + t);
+}
+
 // order-preserving float -> uint key (ascending)
 __device__ __forceinline__ uint32_t float_key(float f) {
     uint32_t u = __float_as_uint(f);

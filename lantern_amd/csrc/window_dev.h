@@ -120,12 +120,19 @@ struct FastDiv {
 // softmax of a register tile over the workgroup: max, exp, f64 sum, one division per element -- the arithmetic
 // of the reference's torch.softmax(row) restated (oracle: lo_softmax_row); shared by O7 (rows emitted as
 // probabilities) and O8 (rows arriving as logits) so that both produce the same bits.
+// max of three without the NaN-quieting pre-pass fmaxf() compiles to (v_max x, x, x per operand): logits are never NaN here
+__device__ __forceinline__ float max3_raw(float a, float b, float c) {
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
 template <int NT, int NV4>
 __device__ __forceinline__ void softmax_tile(float4 (&r)[NV4], float *redf, double *redd, int &ph) {
     constexpr int NW = NT / 64;
     float m = -__builtin_inff();
 #pragma unroll
-    for (int it = 0; it < NV4; ++it) m = fmaxf(fmaxf(m, fmaxf(r[it].x, r[it].y)), fmaxf(r[it].z, r[it].w));
+    for (int it = 0; it < NV4; ++it) m = max3_raw(m, max3_raw(r[it].x, r[it].y, r[it].z), r[it].w);
     m = block_max_fast<NW>(m, redf, ph);
     double s = 0.0;
 #pragma unroll

@@ -224,11 +224,20 @@ __device__ __forceinline__ void cfg_window_bf16_row(int row, int cls, const uint
         const uint32_t uw[4] = {ub[it].a.x, ub[it].a.y, ub[it].b.x, ub[it].b.y};
         float o[8];
 #pragma unroll
+        for (int q2 = 0; q2 < 4; ++q2) {      // two ids per packed word
+            f32x2_t t2;
+            if (uncond) {
+                t2 = cfg_mix_bf16x2(cw[q2], uw[q2], cfg);
+            } else {
+                t2.x = __uint_as_float(cw[q2] << 16);
+                t2.y = __uint_as_float(cw[q2] & 0xffff0000u);
+            }
+            o[2 * q2] = t2.x;
+            o[2 * q2 + 1] = t2.y;
+        }
+#pragma unroll
         for (int q = 0; q < 8; ++q) {
-            const float c = __uint_as_float((q & 1) ? (cw[q >> 1] & 0xffff0000u) : (cw[q >> 1] << 16));
-            const float u = __uint_as_float((q & 1) ? (uw[q >> 1] & 0xffff0000u) : (uw[q >> 1] << 16));
-            float t = c;
-            if (uncond) t = round_bf16(u + round_bf16(cfg * round_bf16(c - u)));
+            float t = o[q];
             const int e = e0 + q;
             if (need_mask) t = (e < img_lo || e >= img_hi) ? fill : t;
             o[q] = in_chunk ? t : NEG_INF;      // chunks are whole: W % 8 == 0
@@ -459,10 +468,10 @@ __device__ __forceinline__ void raw_row_to_lds(const float4 (&rp)[4], int hot, f
         const uint32_t uw[4] = {__float_as_uint(rp[2 + it].x), __float_as_uint(rp[2 + it].y), __float_as_uint(rp[2 + it].z), __float_as_uint(rp[2 + it].w)};
         float o[8];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const float c = __uint_as_float((q & 1) ? (cw[q >> 1] & 0xffff0000u) : (cw[q >> 1] << 16));
-            const float u = __uint_as_float((q & 1) ? (uw[q >> 1] & 0xffff0000u) : (uw[q >> 1] << 16));
-            o[q] = round_bf16(u + round_bf16(cfg * round_bf16(c - u)));
+        for (int q2 = 0; q2 < 4; ++q2) {
+            const f32x2_t t2 = cfg_mix_bf16x2(cw[q2], uw[q2], cfg);
+            o[2 * q2] = t2.x;
+            o[2 * q2 + 1] = t2.y;
         }
         r[2 * it] = make_float4(o[0], o[1], o[2], o[3]);
         r[2 * it + 1] = make_float4(o[4], o[5], o[6], o[7]);

@@ -708,7 +708,7 @@ def main():
         if (args.ep_sweep or not args.no_extras) and world == 1:
             wl.release_kv()      # the extra runs build their own workloads: give the memory back first
         if not args.no_extras and world == 1 and wl.windowed:
-            out["per_kernel_single_group"] = {k: per_kernel_run(device, cfg, min(K, 60), ep_kernel=k, n_seq=(args.seqs_per_gpu if n_seq + args.groups > args.seqs_per_gpu else n_seq)) for k in ("chain", "nodes")}
+            out["per_kernel_single_group"] = {k: per_kernel_run(device, cfg, min(K, 60), ep_kernel=k, n_seq=(args.seqs_per_gpu if n_seq + args.groups > args.seqs_per_gpu else n_seq)) for k in ("chain", "nodes", "walk")}
             out["step_latency_us"] = step_latency(device, cfg)
             out["other_groupings"] = {f"groups_{g}": side_run(device, cfg, max(min(K, 100), 60), n_groups=g, n_seq=args.seqs_per_gpu - args.seqs_per_gpu % g)
                                       for g in (1, 2) if g != cfg.n_groups}

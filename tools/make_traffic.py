@@ -3,8 +3,8 @@
 import csv, glob, json, os, shutil, sys, collections
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-runs = {"raw": "r2p", "chain": "r2p_chain", "nodes": "r2p_nodes"}          # traffic key prefix -> gpurun_out/<dir>
-kern = {"raw": ["epw_kernel"], "chain": ["epw_kernel"], "nodes": ["epn_kernel", "epn_walk_kernel"]}
+runs = {"raw": "r2p", "chain": "r2p_chain", "nodes": "r2p_nodes", "walk": "r2p_walk"}          # traffic key prefix -> gpurun_out/<dir>
+kern = {"raw": ["epw_kernel"], "chain": ["epw_kernel"], "nodes": ["epn_kernel", "epn_walk_kernel"], "walk": ["epn_serial_kernel"]}
 others = ["prep_rows_kernel", "cfg_window_bf16", "update_inputs_kernel"]
 
 

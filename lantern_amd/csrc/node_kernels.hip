@@ -1099,6 +1099,8 @@ extern "C" int lantern_evaluate_posterior_nodes(const lantern_ep_params *prm, co
         set_error("evaluate_posterior_nodes: needs probability rows (LANTERN_ROWS_PROBS) and k + 1 <= %d: use evaluate_posterior_window", EW_PF_K);
         return LANTERN_E_UNSUPPORTED;
     }
+    if (serial) LANTERN_CHECK_ARG(p.P * p.D <= EW_MAX_PD && nodes->n_nodes <= EN_MAX_N, "evaluate_posterior_nodes (serial): P*D=%d cells / %d nodes exceed the staged tables (%d / %d)",
+                                  p.P * p.D, nodes->n_nodes, EW_MAX_PD, EN_MAX_N);
     const bool want_dist = win->sample_win || buf->sample_p;
     const size_t need = serial ? 0 : lantern_evaluate_posterior_nodes_workspace(prm, win, nodes->n_internal, want_dist);
     LANTERN_CHECK_ARG(serial || (nodes->workspace_bytes >= need && ((uintptr_t)nodes->workspace & 15) == 0), "evaluate_posterior_nodes: workspace of %zu bytes needed (16-byte aligned), %zu given",

@@ -78,6 +78,7 @@ def parse():
     ap.add_argument("--no-kv", action="store_true", help="skip the KV slabs (debug only; invalid as a headline)")
     ap.add_argument("--kv-smax", type=int, default=4096, help="rows per KV slab (BASELINE.md: 4096 = max_position_embeddings; a 768x768 image needs 2481)")
     ap.add_argument("--kv-pad-rows", type=int, default=None, help="extra rows per (layer, head) group of a KV slab (row stride = kv_smax + pad; harness default 16)")
+    ap.add_argument("--spin-up", type=float, default=0.5, help="seconds of untimed setup launches before the warm-up steps (GPU out of its idle power state)")
     ap.add_argument("--fused-accept", action="store_true", help="evaluate_posterior + update_inference_inputs as one launch (lantern_verify_accept)")
     ap.add_argument("--fused-workers", type=int, default=0, help="copy workgroups per fused launch (0: 256 / groups - sequences per group)")
     ap.add_argument("--launch-threads", type=int, default=0, help="enqueue each step's launches from this many worker threads (lantern_step_launcher); 0 = the calling thread")
@@ -630,7 +631,8 @@ def main():
         torch.cuda.synchronize(device)
 
     K, W = args.steps, args.warmup
-    wl.prime()          # setup: every pool slot launched once, state reset (a short --warmup must not leave first-touch costs in the timed loop)
+    wl.prime(args.spin_up)   # setup: every pool slot launched once, state reset (a short --warmup must not leave first-touch costs in the timed
+                             # loop), repeated for --spin-up seconds so that the GPU leaves its idle clocks before the W warm-up steps
     for _ in range(W):
         wl.step()
     names = event_names(wl)

@@ -1488,7 +1488,9 @@ extern "C" int lantern_prepare_step(const lantern_step_group *g) {
     PrepArgs a{(const uint16_t *)g->cond, (const uint16_t *)g->uncond, g->V, g->cfg, g->pos_ids, g->pos_base, g->w_latent, g->h_latent, g->img_lo, g->img_hi,
                g->newline_id, g->eos_id, g->top_k, g->seq_len, g->N, g->win_lo, g->win_len, g->out_win, g->row_hot, g->node_list, g->n_list, g->B,
                g->ss_token, g->ss_prob, g->sample_token, g->tree_indices, g->retrieve, g->n_flat, g->N, g->P * g->D, g->tree_cand, g->cand, g->cart_prob};
-    LANTERN_LAUNCH((prep_rows_kernel<512, 2>), dim3(g->B * g->n_list + g->B), dim3(512), 0, (hipStream_t)g->stream, a);
+    static const int nt_knob = getenv("LANTERN_PREP_NT") ? atoi(getenv("LANTERN_PREP_NT")) : 0;   // tuning knob (diagnostic)
+    if (nt_knob == 1024) LANTERN_LAUNCH((prep_rows_kernel<1024, 1>), dim3(g->B * g->n_list + g->B), dim3(1024), 0, (hipStream_t)g->stream, a);
+    else LANTERN_LAUNCH((prep_rows_kernel<512, 2>), dim3(g->B * g->n_list + g->B), dim3(512), 0, (hipStream_t)g->stream, a);
     LANTERN_CHECK_LAUNCH("prepare_step");
     return LANTERN_OK;
 }

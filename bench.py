@@ -675,6 +675,10 @@ def main():
                        "total_sequences": cfg.n_seq * world, "pool_steps": cfg.pool_steps, "drafter_sigma": cfg.sigma,
                        "kv_cache": cfg.with_kv, "kernel_path": cfg.path, "launch": "hipGraph replay" if (cfg.use_graph and wl.graphs) else ("eager, one lantern_verify_step call per step" if wl._steps else "eager, one call per kernel"),
                        "evaluate_posterior_kernel": (cfg.ep_kernel if wl.windowed else "dense"),
+                       "tree_decoding_rows": (("raw bf16 logits post-processed inside evaluate_posterior (LANTERN_ROWS_RAW_BF16), %d most likely rows per sequence "
+                                               "up front with the candidate assembly (lantern_prepare_step)" % wl.n_spec) if getattr(wl, "fused_o7", False)
+                                              else "every row post-processed by cfg_mask_topk before evaluate_posterior"),
+                       "launch_threads": cfg.launch_threads, "single_launch_accept": bool(wl.fused_ws is not None) if hasattr(wl, "fused_ws") else False,
                        "stream_groups": cfg.n_groups, "side_stream_for_O6_O10": cfg.side_stream, "sequences_per_launch": wl.Bg, "parallelism": f"dp{world} (independent sequences, no collective)"},
             "mean_accept_length": float(alen.mean()),
             "per_step": {"levels": float(cnt[..., 0].mean()), "tried": float(cnt[..., 1].mean()), "rejected": float(cnt[..., 2].mean())},

@@ -1320,14 +1320,17 @@ struct VaArgs {
 constexpr unsigned long long VA_VALID = 1ull << 63, VA_HIDDEN = 1ull << 62;
 constexpr int VA_SPIN_LIMIT = 4000000;          // ~2 s of polling: a worker that never sees its entry gives up instead of hanging the GPU
 
-template <bool RAW>
+// copy workers: VA_U column groups per thread, every load of a tile in flight before the first store (a worker workgroup is alone on its
+// CU -- it carries the chain's LDS footprint -- so its memory-level parallelism has to come from the thread: up to VA_U * D 16-byte loads)
+// (VA_U, VA_MAXSEL) = (6, 6) for trees of depth <= 6 (the reference's), (4, 8) up to depth 8: 144 / 128 registers of row data per thread
+template <bool RAW, int VA_U, int VA_MAXSEL>
 __global__ __launch_bounds__(512, 1) void verify_accept_kernel(const VaArgs a) {
     __shared__ uint32_t s_u32;
     __shared__ unsigned long long s_entry;
     uint32_t *const ws = a.ws;
     unsigned long long *const entries = reinterpret_cast<unsigned long long *>(ws + 8);
     const int tid = threadIdx.x, B = a.ep.prm.B, P = a.ep.prm.P, D = a.ep.prm.D;
-    const uint32_t n_entries = (uint32_t)(a.n_slabs + B), n_work = n_entries * (uint32_t)a.nbx;
+    const uint32_t n_entries = (uint32_t)(a.n_slabs + B), n_items = n_entries * (uint32_t)a.nbx;
     if (tid == 0) s_u32 = atomicAdd(&ws[0], 1u);
     __syncthreads();
     const uint32_t role = s_u32;
@@ -1344,38 +1347,115 @@ __global__ __launch_bounds__(512, 1) void verify_accept_kernel(const VaArgs a) {
                 if (slot < n_entries) __hip_atomic_store(&entries[slot], e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
-    }
-    for (;;) {
-        __syncthreads();
-        if (tid == 0) s_u32 = atomicAdd(&ws[1], 1u);
-        __syncthreads();
-        const uint32_t t = s_u32;
-        if (t >= n_work) break;
-        const uint32_t slot = t / (uint32_t)a.nbx, sub = t % (uint32_t)a.nbx;
-        if (tid == 0) {
-            unsigned long long e = __hip_atomic_load(&entries[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            for (int spins = 0; !(e & VA_VALID); ++spins) {
-                if (spins > VA_SPIN_LIMIT) {
-                    atomicExch(&ws[4], 1u);
-                    break;
+    } else {
+        // ---- copy worker `wk` of `n_wk`: items wk, wk + n_wk, ... of the queue (item = entry * nbx + tile), entries in publication
+        // order.  Two-stage pipeline: while an item's rows are in flight the worker reads the next item's queue entry and, if it is
+        // there, requests its slab facts (uniform addresses -> scalar loads), so a ready queue costs one memory round per item.
+        const uint32_t n_wk = gridDim.x - (uint32_t)B, wk = role - (uint32_t)B;
+        const unsigned cpr = (unsigned)a.cpr, total = (unsigned)(a.outer * a.cpr);
+        auto poll = [&](uint32_t slot, bool blocking) -> unsigned long long {           // every thread returns the entry (0: not there / gave up)
+            __syncthreads();
+            if (tid == 0) {
+                unsigned long long e = __hip_atomic_load(&entries[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (blocking) {
+                    for (int spins = 0; !(e & VA_VALID); ++spins) {
+                        if (spins > VA_SPIN_LIMIT) {
+                            atomicExch(&ws[4], 1u);
+                            break;
+                        }
+                        __builtin_amdgcn_s_sleep(8);
+                        e = __hip_atomic_load(&entries[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
                 }
-                __builtin_amdgcn_s_sleep(8);
-                e = __hip_atomic_load(&entries[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                s_entry = e;
             }
-            s_entry = e;
-        }
-        __syncthreads();
-        const unsigned long long e = s_entry;
-        if (!(e & VA_VALID)) break;
-        const int idx = (int)((e >> 32) & 0xffffu), bst = (int)((e >> 16) & 0xffffu);
-        int n_sel = (int)(e & 0xffu);
-        if (n_sel > D) n_sel = D;
-        if (e & VA_HIDDEN) {
-            for (int r = (int)sub; r < a.hid_groups * D; r += a.nbx)
-                accept_copy_row(r, idx, bst, n_sel, a.hidden, a.hid_groups, a.N, a.hid_cpr, a.retrieve, 0, P, D, a.cand, a.out_hidden, a.accepted_tokens);
-        } else {
-            kv_gather_rows<8, 2, 0>((int)sub, a.nbx, idx, a.slab_seq[idx], bst, n_sel, a.slab_ptrs, a.slab_prev, a.outer, a.S_max, a.cpr, a.retrieve, 0,
-                                    P, D, a.new_len);
+            __syncthreads();
+            return s_entry;
+        };
+        struct Meta {
+            uintptr_t slab;
+            int64_t prev;
+            int64_t srcrow[VA_MAXSEL];
+            unsigned move;
+        };
+        auto load_meta = [&](unsigned long long e, Meta &m) {          // slab entries only; uniform addresses
+            const int s = (int)((e >> 32) & 0xffffu), bst = (int)((e >> 16) & 0xffffu);
+            int n_sel = (int)(e & 0xffu);
+            if (n_sel > D) n_sel = D;
+            if (n_sel > VA_MAXSEL) n_sel = VA_MAXSEL;
+            m.slab = (uintptr_t)a.slab_ptrs[s];
+            m.prev = a.slab_prev[s];
+            m.move = 0u;
+            const int64_t *rrow = a.retrieve + (size_t)bst * D;
+#pragma unroll
+            for (int t = 0; t < VA_MAXSEL; ++t) {
+                m.srcrow[t] = 0;
+                if (t < n_sel) {
+                    const int64_t r = rrow[t];
+                    if (r != t && m.prev + t < a.S_max) m.move |= 1u << t;
+                    const int64_t src = r + m.prev;
+                    m.srcrow[t] = src < 0 ? 0 : (src >= a.S_max ? a.S_max - 1 : src);
+                }
+            }
+            if (tid == 0 && a.new_len) a.new_len[s] = m.prev + n_sel;          // (every tile's worker writes the same value)
+        };
+        uint32_t it = wk;
+        unsigned long long e = it < n_items ? poll(it / (uint32_t)a.nbx, true) : 0ull;
+        Meta m{};
+        if ((e & VA_VALID) && !(e & VA_HIDDEN)) load_meta(e, m);
+        while (it < n_items && (e & VA_VALID)) {
+            const uint32_t tile = it % (uint32_t)a.nbx;
+            const uint32_t it2 = it + n_wk;
+            unsigned long long e2 = 0ull;
+            Meta m2{};
+            if (e & VA_HIDDEN) {
+                const int b = (int)((e >> 32) & 0xffffu), bst = (int)((e >> 16) & 0xffffu);
+                int n_sel = (int)(e & 0xffu);
+                if (n_sel > D) n_sel = D;
+                for (int r = (int)tile; r < a.hid_groups * D; r += a.nbx)
+                    accept_copy_row(r, b, bst, n_sel, a.hidden, a.hid_groups, a.N, a.hid_cpr, a.retrieve, 0, P, D, a.cand, a.out_hidden, a.accepted_tokens);
+                if (it2 < n_items) e2 = poll(it2 / (uint32_t)a.nbx, false);
+                if ((e2 & VA_VALID) && !(e2 & VA_HIDDEN)) load_meta(e2, m2);
+            } else if (m.move != 0u) {
+                // loads of this tile, then the look-ahead under them, then the stores
+                typedef __attribute__((address_space(1))) u32x4_t gvec_t;
+                gvec_t *base = (gvec_t *)m.slab;
+                u32x4_t v[VA_U][VA_MAXSEL];
+                gvec_t *rowbase[VA_U];
+                const unsigned w0 = tile * (VA_U * 512u) + (unsigned)tid;
+#pragma unroll
+                for (int u = 0; u < VA_U; ++u) {
+                    const unsigned w = w0 + u * 512u;
+                    const unsigned o = w / cpr, c = w - o * cpr;
+                    rowbase[u] = base + (size_t)o * a.S_max * cpr + c;
+                    if (w < total) {
+#pragma unroll
+                        for (int t = 0; t < VA_MAXSEL; ++t)
+                            if ((m.move >> t) & 1u) v[u][t] = __builtin_nontemporal_load(&rowbase[u][m.srcrow[t] * cpr]);
+                    }
+                }
+                if (it2 < n_items) e2 = poll(it2 / (uint32_t)a.nbx, false);
+                if ((e2 & VA_VALID) && !(e2 & VA_HIDDEN)) load_meta(e2, m2);
+#pragma unroll
+                for (int u = 0; u < VA_U; ++u) {
+                    const unsigned w = w0 + u * 512u;
+                    if (w < total) {
+#pragma unroll
+                        for (int t = 0; t < VA_MAXSEL; ++t)
+                            if ((m.move >> t) & 1u) __builtin_nontemporal_store(v[u][t], &rowbase[u][(m.prev + t) * cpr]);
+                    }
+                }
+            } else {
+                if (it2 < n_items) e2 = poll(it2 / (uint32_t)a.nbx, false);
+                if ((e2 & VA_VALID) && !(e2 & VA_HIDDEN)) load_meta(e2, m2);
+            }
+            if (it2 < n_items && !(e2 & VA_VALID)) {          // not published yet: wait for it (bounded)
+                e2 = poll(it2 / (uint32_t)a.nbx, true);
+                if ((e2 & VA_VALID) && !(e2 & VA_HIDDEN)) load_meta(e2, m2);
+            }
+            it = it2;
+            e = e2;
+            m = m2;
         }
     }
     // the last workgroup out leaves the queue empty for the next launch on this workspace
@@ -1636,8 +1716,9 @@ extern "C" int lantern_verify_accept(const lantern_step_group *s) {
     const int cpr = (int)(s->d * s->elem_bytes / 16);
     const int64_t total = s->outer * cpr;
     LANTERN_CHECK_ARG(total < (1ll << 31), "verify_accept: outer * row chunks = %lld does not fit 31 bits", (long long)total);
-    int nbx = (int)((total + 2 * 512 - 1) / (2 * 512));           // tiles of a slab: 512 threads x 2 row groups each
-    if (nbx > 64) nbx = 64;
+    const int va_u = p.D <= 6 ? 5 : 4;
+    const int nbx = (int)((total + va_u * 512 - 1) / (va_u * 512));           // tiles of a slab: 512 threads x va_u column groups each
+    LANTERN_CHECK_ARG(nbx <= 4096, "verify_accept: %d tiles per slab", nbx);
     const int rows_hidden = s->hidden ? s->hid_groups * p.D : 1;
     (void)rows_hidden;
     int workers = s->fused_workers > 0 ? s->fused_workers : (p.B < 224 ? 256 - p.B : 32);      // one workgroup per CU (the chain's LDS)
@@ -1650,8 +1731,10 @@ extern "C" int lantern_verify_accept(const lantern_step_group *s) {
     a.ws = (uint32_t *)s->fused_ws;
     const size_t lds = epw_lds_bytes(p, win);
     const dim3 grid(p.B + workers);
-    if (raw) LANTERN_LAUNCH((verify_accept_kernel<true>), grid, dim3(512), lds, (hipStream_t)s->stream, a);
-    else LANTERN_LAUNCH((verify_accept_kernel<false>), grid, dim3(512), lds, (hipStream_t)s->stream, a);
+    if (raw && va_u == 5) LANTERN_LAUNCH((verify_accept_kernel<true, 5, 6>), grid, dim3(512), lds, (hipStream_t)s->stream, a);
+    else if (raw) LANTERN_LAUNCH((verify_accept_kernel<true, 4, 8>), grid, dim3(512), lds, (hipStream_t)s->stream, a);
+    else if (va_u == 5) LANTERN_LAUNCH((verify_accept_kernel<false, 5, 6>), grid, dim3(512), lds, (hipStream_t)s->stream, a);
+    else LANTERN_LAUNCH((verify_accept_kernel<false, 4, 8>), grid, dim3(512), lds, (hipStream_t)s->stream, a);
     LANTERN_CHECK_LAUNCH("verify_accept");
     return LANTERN_OK;
 }

@@ -342,7 +342,7 @@ def kernel_report(wl, evs, E0, E1, KT):
 
 def event_names(wl):
     names = ("cfg_mask_topk", "evaluate_posterior", "kv_gather") if wl.cfg.with_kv else ("cfg_mask_topk", "evaluate_posterior")
-    if getattr(wl, "fused_o7", False) and not wl.n_spec:
+    if getattr(wl, "fused_o7", False) and not getattr(wl, "n_spec", 0):
         names = tuple(n for n in names if n != "cfg_mask_topk")
     return names
 
@@ -416,12 +416,12 @@ def step_latency(device, base_cfg, batches=(1, 8), steps=60):
     return res
 
 
-def dynamic_run(device, base_cfg, steps, n_seq):
+def dynamic_run(device, base_cfg, steps, n_seq, fuse_o7=False):
     """The dynamic-tree half of C3 (eagle_version 2: top_k 10, depth 5, 59 nodes, a different tree per sequence and step) on the
     clock: O4 -> O6 -> O7 -> O8 -> O9 + O10, device-resident, same KV geometry as the headline run."""
     from lantern_amd import harness as HN
     cfg = HN.DynamicConfig(n_seq=n_seq, lantern_k=base_cfg.lantern_k, lantern_delta=base_cfg.lantern_delta, with_kv=base_cfg.with_kv,
-                           kv_smax=base_cfg.kv_smax, kv_pad_rows=base_cfg.kv_pad_rows, max_steps=2 * steps + 32)
+                           kv_smax=base_cfg.kv_smax, kv_pad_rows=base_cfg.kv_pad_rows, max_steps=2 * steps + 32, fuse_o7=fuse_o7)
     wl = HN.DynamicVerifyWorkload(cfg, device)
     for _ in range(10):
         wl.step()
@@ -431,7 +431,7 @@ def dynamic_run(device, base_cfg, steps, n_seq):
         wl.step()
     torch.cuda.synchronize(device)
     dt = time.perf_counter() - t0
-    names = event_names(wl)
+    names = tuple(n for n in event_names(wl) if not (fuse_o7 and n == "cfg_mask_topk"))
     KE = min(steps, 20)
     evs = [{n: (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for n in names} for _ in range(KE)]
     for d in evs:
@@ -445,6 +445,7 @@ def dynamic_run(device, base_cfg, steps, n_seq):
     toks = wl.accepted_tokens(10, 10 + steps)
     cnt = wl.log_cnt[10:10 + steps].float()
     r = {"workload": f"C3 dynamic tree (EAGLE-2): top_k {cfg.top_k}, depth {cfg.depth}, N={wl.N} nodes, {n_seq} sequences", "value": toks / dt,
+         "tree_decoding_rows": "raw bf16 logits post-processed inside evaluate_posterior" if fuse_o7 else "cfg_mask_topk over all N rows",
          "unit": "accepted_tokens/s", "ms_per_step": 1e3 * dt / steps, "steps": steps, "mean_accept_length": toks / (steps * n_seq),
          "per_step": {"levels": float(cnt[..., 0].mean()), "tried": float(cnt[..., 1].mean()), "rejected": float(cnt[..., 2].mean())},
          "kernel_ms": {n: float(np.mean([e[n][0].elapsed_time(e[n][1]) for e in evs])) for n in names}}
@@ -719,7 +720,9 @@ def main():
             out["other_groupings"] = {f"groups_{g}": side_run(device, cfg, max(min(K, 100), 60), n_groups=g, n_seq=args.seqs_per_gpu - args.seqs_per_gpu % g)
                                       for g in (1, 2) if g != cfg.n_groups}
         if not args.no_extras and world == 1 and wl.windowed:
-            out["dynamic_tree"] = dynamic_run(device, cfg, min(K, 100), n_seq)
+            out["dynamic_tree"] = dynamic_run(device, cfg, min(K, 100), n_seq, fuse_o7=True)
+            out["dynamic_tree"]["all_rows_by_cfg_mask_topk"] = {k: v for k, v in dynamic_run(device, cfg, min(K, 100), n_seq, fuse_o7=False).items()
+                                                                if k in ("value", "ms_per_step", "kernel_ms")}
         if args.ep_sweep and world == 1:
             out["ep_batch_sweep"] = ep_batch_sweep([int(x) for x in args.ep_sweep.split(",") if x], device, cfg)
         if args.cpu_seconds > 0 and world == 1:      # the CPU baseline is reported at N = 1 only

@@ -261,11 +261,12 @@ typedef struct lantern_ep_window {
     const double *u_bonus;        /* [dev] [B] or NULL: uniform for the bonus-token draw */
     int64_t *token;               /* [dev] [B] out (with u_bonus): inverse-CDF bonus token */
     int32_t rows_kind;            /* LANTERN_ROWS_LOGITS | LANTERN_ROWS_PROBS | LANTERN_ROWS_RAW_BF16: what buf->logits rows hold */
-    int32_t reserved;
+    int32_t raw_pos_per_seq;      /* LANTERN_ROWS_RAW_BF16: 0 = one tree for all sequences (raw_pos_ids [rows_per_seq] relative, + raw_seq_len[b]);
+                                     1 = per-sequence trees (EAGLE-2): raw_pos_ids [B, rows_per_seq] ABSOLUTE positions, raw_seq_len unused */
     /* LANTERN_ROWS_RAW_BF16 only (ignored otherwise) */
     const void *raw_uncond;       /* [dev] [B, rows_per_seq, V] bf16 */
-    const int64_t *raw_pos_ids;   /* [dev] [rows_per_seq] i64: tree_position_ids + 1 (shared tree) */
-    const int64_t *raw_seq_len;   /* [dev] [B] i64: len(input_ids) of every sequence */
+    const int64_t *raw_pos_ids;   /* [dev] i64: tree_position_ids + 1 (shared tree), or absolute positions per sequence (raw_pos_per_seq) */
+    const int64_t *raw_seq_len;   /* [dev] [B] i64: len(input_ids) of every sequence (NULL with raw_pos_per_seq) */
     int64_t raw_pos_base;         /* num_generated_image_tokens = pos - pos_base */
     float raw_cfg;                /* guidance scale */
     int32_t raw_top_k;            /* InterleavedTopKLogitsWarper image_top_k (0 = off) */

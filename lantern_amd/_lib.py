@@ -41,7 +41,7 @@ class EpWindow(C.Structure):
     _fields_ = [("win_lo", C.c_int32), ("win_len", C.c_int32), ("row_hot", C.c_void_p),
                 ("orig_prob_stride", C.c_int32), ("orig_prob_offset", C.c_int32),
                 ("sample_win", C.c_void_p), ("out_tok", C.c_void_p), ("out_mass", C.c_void_p),
-                ("u_bonus", C.c_void_p), ("token", C.c_void_p), ("rows_kind", C.c_int32), ("reserved", C.c_int32),
+                ("u_bonus", C.c_void_p), ("token", C.c_void_p), ("rows_kind", C.c_int32), ("raw_pos_per_seq", C.c_int32),
                 ("raw_uncond", C.c_void_p), ("raw_pos_ids", C.c_void_p), ("raw_seq_len", C.c_void_p), ("raw_pos_base", C.c_int64),
                 ("raw_cfg", C.c_float), ("raw_top_k", C.c_int32), ("raw_w_latent", C.c_int32), ("raw_h_latent", C.c_int32),
                 ("raw_newline_id", C.c_int32), ("raw_eos_id", C.c_int32), ("raw_probs", C.c_void_p), ("raw_pre", C.c_void_p)]

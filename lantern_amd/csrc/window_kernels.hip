@@ -595,7 +595,7 @@ __device__ __forceinline__ int epw_body(const EpwArgs &args, const int b) {
             hot_[u] = (hot_g && hot_in_lds && t < prm.rows_per_seq) ? hot_g[t] : -1;
             if (RAW && t < prm.rows_per_seq) S.pre[t] = (win.raw_pre && win.raw_probs) ? (int)win.raw_pre[t] : 0;
             if (RAW && t < prm.rows_per_seq) {          // the row's class from its position (MultiModalLogitsProcessor, ea_model_lumina_mgpt.py:45-86)
-                const int64_t n1 = win.raw_pos_ids[t] + win.raw_seq_len[b] - win.raw_pos_base + 1;
+                const int64_t n1 = (win.raw_pos_per_seq ? win.raw_pos_ids[(size_t)b * prm.rows_per_seq + t] : win.raw_pos_ids[t] + win.raw_seq_len[b]) - win.raw_pos_base + 1;
                 hot_[u] = (n1 == ((int64_t)win.raw_w_latent + 1) * win.raw_h_latent + 1) ? win.raw_eos_id
                           : (py_mod64(n1, (int64_t)win.raw_w_latent + 1) == 0 ? win.raw_newline_id : -1);
             }
@@ -1607,7 +1607,7 @@ static int epw_check(const lantern_ep_params *prm, const lantern_ep_buffers *buf
                       "evaluate_posterior_window: bad rows_kind");
     const bool raw = win->rows_kind == LANTERN_ROWS_RAW_BF16;
     if (raw) {
-        LANTERN_CHECK_ARG(win->raw_uncond && win->raw_pos_ids && win->raw_seq_len && win->raw_w_latent > 0 && win->raw_h_latent > 0 &&
+        LANTERN_CHECK_ARG(win->raw_uncond && win->raw_pos_ids && (win->raw_seq_len || win->raw_pos_per_seq) && win->raw_w_latent > 0 && win->raw_h_latent > 0 &&
                               win->raw_newline_id >= 0 && win->raw_newline_id < p.V && win->raw_eos_id >= 0 && win->raw_eos_id < p.V,
                           "evaluate_posterior_window: raw rows need the unconditional logits, positions, sequence lengths and the Lumina grammar ids");
         LANTERN_CHECK_ARG(p.top_k <= 0 && p.temperature == 1.0f && p.rows_per_seq <= EW_MAX_N && win->win_lo % 4 == 0 && p.V % 8 == 0 &&

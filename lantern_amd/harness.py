@@ -408,7 +408,7 @@ class LuminaVerifyWorkload:
         w.u_bonus, w.token = at(self.u_cur), at(self.st_token)
         w.rows_kind = ops.ROWS_PROBS if self.cfg.rows_probs else ops.ROWS_LOGITS
         if self.fused_o7:
-            w.rows_kind = 2                                   # LANTERN_ROWS_RAW_BF16; logits / raw_uncond / raw_seq_len are set per (slot, parity)
+            w.rows_kind = ops.ROWS_RAW_BF16                   # logits / raw_uncond / raw_seq_len are set per (slot, parity)
             w.raw_pos_ids, w.raw_pos_base = self.d_pos_ids.data_ptr(), self.cfg.prompt_len + 3
             w.raw_cfg, w.raw_top_k = self.cfg.cfg_scale, self.cfg.top_k
             w.raw_w_latent, w.raw_h_latent, w.raw_newline_id, w.raw_eos_id = W_LATENT, H_LATENT, NEWLINE, EOS
@@ -882,6 +882,8 @@ class DynamicConfig:
     seed: int = 3700
     max_steps: int = 256
     plausible: float = 8.0          # drafted tokens get target logits in [plausible - 2, plausible]: the walk accepts a few levels
+    fuse_o7: bool = False           # LANTERN_ROWS_RAW_BF16 with per-sequence positions: no O7 launch over all N rows, evaluate_posterior
+                                    # post-processes the rows its walk visits (alen + 1 of the 59)
 
 
 class DynamicVerifyWorkload:
@@ -984,6 +986,12 @@ class DynamicVerifyWorkload:
         w = EpWindow()
         w.win_lo, w.win_len, w.row_hot = IMG_LO, W, self.hot.data_ptr()
         w.out_tok, w.out_mass, w.rows_kind = self.out_tok.data_ptr(), self.out_mass.data_ptr(), ops.ROWS_PROBS
+        self.fused_o7 = bool(cfg.fuse_o7)
+        if self.fused_o7:               # raw rows: positions are per sequence and absolute (O6 dynamic writes them), the processors' parameters ride along
+            w.rows_kind, w.raw_pos_per_seq = ops.ROWS_RAW_BF16, 1
+            w.raw_pos_ids, w.raw_seq_len, w.raw_pos_base = self.pos_abs.data_ptr(), None, cfg.prompt_len + 3
+            w.raw_cfg, w.raw_top_k = cfg.cfg_scale, cfg.logit_top_k
+            w.raw_w_latent, w.raw_h_latent, w.raw_newline_id, w.raw_eos_id = W_LATENT, H_LATENT, NEWLINE, EOS
         self._win = w
         self._bases = dict(best=self.log_best.data_ptr(), alen=self.log_alen.data_ptr(), cnt=self.log_cnt.data_ptr(),
                            tok=self.log_token.data_ptr(), ub=self.u_bonus.data_ptr())
@@ -1012,12 +1020,15 @@ class DynamicVerifyWorkload:
         check(L.lantern_gather_candidates_dynamic(vp(self.draft.data_ptr()), vp(self.ret.data_ptr()), vp(self.pos.data_ptr()), vp(cur.data_ptr()), B, N,
                                                   P, D, vp(self.cand.data_ptr()), vp(self.ret_pd.data_ptr()), vp(self.row_index.data_ptr()),
                                                   vp(self.pos_abs.data_ptr()), st), "gather_candidates_dynamic")
-        arm("cfg_mask_topk")
-        check(L.lantern_cfg_mask_topk_window(vp(pool["cond"].data_ptr()), vp(pool["unc"].data_ptr()), 1, B * N, V, C.c_float(c.cfg_scale),
-                                             ops.MODEL_LUMINA, vp(self.pos_abs.data_ptr()), C.c_int64(c.prompt_len + 3), W_LATENT, H_LATENT, IMG_LO,
-                                             IMG_HI, NEWLINE, EOS, c.logit_top_k, None, 0, IMG_LO, self.W, vp(self.win.data_ptr()),
-                                             vp(self.hot.data_ptr()), ops.ROWS_PROBS, C.c_float(1.0), C.c_float(1.0), st), "cfg_mask_topk_window")
         b, w = self._buf, self._win
+        if self.fused_o7:
+            b.logits, w.raw_uncond = pool["cond"].data_ptr(), pool["unc"].data_ptr()
+        else:
+            arm("cfg_mask_topk")
+            check(L.lantern_cfg_mask_topk_window(vp(pool["cond"].data_ptr()), vp(pool["unc"].data_ptr()), 1, B * N, V, C.c_float(c.cfg_scale),
+                                                 ops.MODEL_LUMINA, vp(self.pos_abs.data_ptr()), C.c_int64(c.prompt_len + 3), W_LATENT, H_LATENT, IMG_LO,
+                                                 IMG_HI, NEWLINE, EOS, c.logit_top_k, None, 0, IMG_LO, self.W, vp(self.win.data_ptr()),
+                                                 vp(self.hot.data_ptr()), ops.ROWS_PROBS, C.c_float(1.0), C.c_float(1.0), st), "cfg_mask_topk_window")
         b.best, b.accept_len, b.counters = bs["best"] + 4 * e, bs["alen"] + 4 * e, bs["cnt"] + 24 * e
         w.u_bonus, w.token = bs["ub"] + 8 * e, bs["tok"] + 8 * e
         arm("evaluate_posterior")

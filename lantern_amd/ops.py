@@ -18,7 +18,7 @@ from ._lib import EpBuffers, EpNodes, EpParams, EpWindow, check
 
 MODE_DYNAMIC, MODE_STATIC_LUMINA, MODE_STATIC_LG = 0, 1, 2
 MODEL_PLAIN, MODEL_LUMINA, MODEL_ANOLE = 0, 1, 2
-ROWS_LOGITS, ROWS_PROBS = 0, 1          # what a window row holds (include/lantern_hip.h LANTERN_ROWS_*)
+ROWS_LOGITS, ROWS_PROBS, ROWS_RAW_BF16 = 0, 1, 2          # what a window row holds (include/lantern_hip.h LANTERN_ROWS_*)
 
 
 def _stream() -> C.c_void_p:

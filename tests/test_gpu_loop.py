@@ -62,7 +62,8 @@ def test_kv_rows_follow_the_accepted_path():
         assert torch.equal(s[..., keep.cuda(), :], b0[..., keep.cuda(), :])
 
 
-def test_dynamic_tree_loop_matches_oracle_loop():
+@pytest.mark.parametrize("fuse", [False, True], ids=["o7_launch", "raw_rows"])
+def test_dynamic_tree_loop_matches_oracle_loop(fuse):
     """The device-resident EAGLE-2 loop (O4 -> O6 dynamic -> O7 -> O8 dynamic -> O9 + O10, a different tree per sequence and
     step) against the oracle's loop over the same pools / uniforms: identical (best path, accept length, bonus token), every
     step, every sequence; KV lengths advance by exactly the accepted tokens."""
@@ -72,8 +73,9 @@ def test_dynamic_tree_loop_matches_oracle_loop():
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import helpers as H
     steps = 8
-    cfg = HN.DynamicConfig(n_seq=3, pool_steps=2, kv_layers=2, kv_heads=4, kv_smax=512, max_steps=steps + 2, lantern_k=300)
+    cfg = HN.DynamicConfig(n_seq=3, pool_steps=2, kv_layers=2, kv_heads=4, kv_smax=512, max_steps=steps + 2, lantern_k=300, fuse_o7=fuse)
     wl = HN.DynamicVerifyWorkload(cfg, torch.device("cuda"))
+    assert wl.fused_o7 == fuse
     for _ in range(steps):
         wl.step()
     torch.cuda.synchronize()

@@ -211,8 +211,12 @@ class EaLumina_mGPT(nn.Module):
         cfg.syntax, cfg.tok_offset = self._syntax, self.image_token_offset
         return cfg
 
+    # static trees, windowed rows: "nodes" = one workgroup per internal tree node + the walk (33 vs 39 us per verify step at one sequence),
+    # "chain" = one workgroup per sequence.  A node launch that meets duplicate sibling tokens reports NEEDS_CHAIN and the step re-runs on the chain.
+    ep_form = "nodes"
+
     def _posterior_on_device(self, logits, candidates, cart_candidates_prob, original_prob, tree_candidates, lantern, lantern_k,
-                             lantern_delta, u_bonus=None, force_dense=False):
+                             lantern_delta, u_bonus=None, force_dense=False, force_chain=False):
         """evaluate_posterior with every result left on the device: dict(best, accept_len, counters, sample_p | None, token | None).
         Windowed rows + u_bonus: the bonus token is drawn inside the kernel and sample_p never exists."""
         static = self.eagle_version == 1
@@ -230,10 +234,13 @@ class EaLumina_mGPT(nn.Module):
         fifo = self._uniforms()
         fifo.reserve(candidates.shape[0] * candidates.shape[1])
         if windowed:
+            nodes = None
+            if static and self.ep_form == "nodes" and not force_chain and (not lantern or int(lantern_k) + 1 <= 1024):
+                nodes = self.tree_buffers["_hip"].get("nodes")
             out = ops.evaluate_posterior_window(cfg, logits.V, rows[None], logits.win_lo, row_index, candidates[None], fifo.buf,
                                                 row_hot=logits.row_hot[None], table=self._packed_table(int(lantern_k)) if lantern else None,
                                                 aux=aux, cursor=fifo.cursor, u_bonus=u_bonus, want_dense=u_bonus is None, want_window=False,
-                                                rows_probs=True)
+                                                rows_probs=True, nodes=nodes)
             return dict(best=out["best"], accept_len=out["accept_len"], counters=out["counters"], sample_p=out["sample_p"], token=out["token"])
         best, alen, sample_p, counters = ops.evaluate_posterior(cfg, rows.float()[None], row_index, candidates[None], fifo.buf,
                                                                 table=self.nearest_latents if lantern else None, aux=aux, cursor=fifo.cursor)
@@ -259,6 +266,11 @@ class EaLumina_mGPT(nn.Module):
         cur0 = fifo.cursor.clone()
         out = self._posterior_on_device(logits, candidates, cart_candidates_prob, original_prob, tree_candidates, lantern, lantern_k, lantern_delta)
         status = int(out["counters"][0, 5])          # host sync: the B=1 caller wants accept_length as a Python int anyway
+        if status == 8 and isinstance(logits, WindowRows):          # NEEDS_CHAIN: duplicate sibling tokens -> the chain kernel, same uniforms
+            fifo.cursor.copy_(cur0)
+            out = self._posterior_on_device(logits, candidates, cart_candidates_prob, original_prob, tree_candidates, lantern, lantern_k, lantern_delta,
+                                            force_chain=True)
+            status = int(out["counters"][0, 5])
         if status in self._RETRY_DENSE and isinstance(logits, WindowRows):
             # the windowed kernel reported a state only the dense kernel represents: same step again on the dense HIP kernel,
             # from the same position of the uniform stream (HIP -> HIP; there is no CPU path)

@@ -191,6 +191,13 @@ def generate_tree_buffers(tree_choices, device="cuda"):
     buffers["_hip"] = dict(p_idx=t(tb["p_indices"]), b_off=t(tb["b_off"]),
                            b_idx=t(tb["b_idx"] if len(tb["b_idx"]) else np.zeros(1, np.int32)), op_off=t(op_off),
                            N=N, P=P, D=D, R=R)
+    # per-node tables of the node-parallel evaluate_posterior (one workgroup per internal tree node: the faster form at the
+    # reference's batch of one sequence); None when the tree is outside what those kernels stage (the chain kernel then runs)
+    try:
+        nt = ops.tree_node_tables(tb["retrieve_indices"], N, tb["p_indices"], tb["b_off"], op_off, device=device, b_idx=tb["b_idx"])
+        buffers["_hip"]["nodes"] = nt if (nt.prefix_siblings and nt.n_nodes <= 128) else None
+    except Exception:
+        buffers["_hip"]["nodes"] = None
     return buffers
 
 

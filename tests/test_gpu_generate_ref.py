@@ -83,3 +83,24 @@ def test_generate_twice_under_one_seed_is_one_stream():
     finally:
         torch.multinomial, torch.rand = old_m, old_r
     assert torch.equal(ids1, ids2) and list(al1) == list(al2)
+
+
+@pytest.mark.parametrize("form", ["nodes", "chain"])
+def test_generate_static_tree_runs_the_chosen_evaluate_posterior_form(form, monkeypatch):
+    """The mirror's static-tree steps go through the node-parallel kernels by default (ep_form = "nodes": the faster form at one sequence)
+    and through the chain kernel with ep_form = "chain"; both reproduce the reference's run."""
+    from lantern_amd import ops
+    case = F.CASES[0]
+    seen = []
+    real = ops.evaluate_posterior_window
+
+    def spy(*a, **kw):
+        seen.append(kw.get("nodes") is not None)
+        return real(*a, **kw)
+    monkeypatch.setattr(ops, "evaluate_posterior_window", spy)
+    monkeypatch.setattr(EaLumina_mGPT, "ep_form", form)
+    mdl, drafter, draws, ids, alens = run_case(case)
+    assert mdl.tree_buffers["_hip"]["nodes"] is not None
+    assert seen and all(s == (form == "nodes") for s in seen), seen
+    assert ids[0].cpu().numpy().tolist() == GOLD[case["name"] + ".ids"].tolist()
+    assert list(alens) == GOLD[case["name"] + ".accept_lengths"].tolist()

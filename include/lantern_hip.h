@@ -487,6 +487,25 @@ int lantern_drafter_attention_mask(const uint8_t *attn, int attn_len, const floa
 int lantern_linear_rows(const void *A, const void *W, const void *bias, int M, int K, int row_lo, int n_rows, void *out,
                         int out_stride, int out_col0, void *stream);
 
+/* 8f-2 (next row: the drafter's decoder layer at its decode shape, M = 2 x top_k rows)  Pieces of ChameleonDecoderLayer
+ * (models/drafters/cnets_lumina_mgpt.py:769-843; lantern_amd/drafters/decoder_layer.py sequences them):
+ *  - lantern_linear_rows_epilogue: lantern_linear_rows with the layer's element-wise tail in the GEMM epilogue (M <= 32):
+ *      LANTERN_EPI_RESIDUAL  out = bf16(bf16(A W^T + bias) + aux[m, n])      `residual + o_proj(x)`, `residual + down_proj(x)` (:827, :832)
+ *      LANTERN_EPI_SILU_MUL  out = bf16(silu(bf16(A Wg^T)) * bf16(A Wu^T))   ChameleonMLP :371-373; W holds gate rows [row_lo, +n_rows) and the
+ *                            matching up rows pair_rows further down (one concatenated [2I, K] weight): the [M, 2I] intermediate never exists
+ *  - lantern_rmsnorm_rows: ChameleonRMSNorm (:209-223) of M bf16 rows
+ *  - lantern_qk_norm_rope: the head stage of ChameleonAttention (:481-499) on the fused q/k/v projection [B*T, (nq + 2 nk) d]: per-head
+ *    ChameleonLayerNorm (:375-396; weights [model_parallel, d]), rotary at position_ids [B, T] from cos / sin tables [table_rows, d] bf16,
+ *    outputs q [B, nq, T, d], k / v [B, nk, T, d] bf16 (d = 64 or 128). */
+#define LANTERN_EPI_RESIDUAL 1
+#define LANTERN_EPI_SILU_MUL 2
+int lantern_linear_rows_epilogue(const void *A, const void *W, const void *bias, int M, int K, int row_lo, int n_rows, void *out,
+                                 int out_stride, int out_col0, int epilogue, const void *aux, int aux_stride, int pair_rows, void *stream);
+int lantern_rmsnorm_rows(const void *x, const void *weight, int M, int H, float eps, void *out, void *stream);
+int lantern_qk_norm_rope(const void *qkv, int B, int T, int n_q_heads, int n_kv_heads, int head_dim, const void *q_weight, const void *q_bias,
+                         const void *k_weight, const void *k_bias, int model_parallel, const void *cos_table, const void *sin_table,
+                         int table_rows, const int64_t *position_ids, void *q_out, void *k_out, void *v_out, void *stream);
+
 /* 8f-2 (next row, second half)  One drafter expansion depth from the hidden states to the top-k in two small launches, the head's
  * logits never in HBM:  head(hidden) restricted to the id window the model's mask lets through -> CFG combination in the GEMM's
  * epilogue (`uncond + cfg * (cond - uncond)` with torch's bf16 roundings) -> [n, n_cols] bf16 window (16 KB per row) -> per row:

@@ -147,19 +147,28 @@ __global__ __launch_bounds__(FC_THREADS) void drafter_fc_kernel(const int64_t *_
 // 64 MiB of weights per call instead of 512 MiB.  Same wave layout as drafter_fc_kernel: a wave feeds
 // v_mfma_f32_32x32x16_bf16 straight from global memory (nn.Linear's [out, in] layout is the B-fragment layout), the
 // 8 waves of a workgroup split K and add their tiles in LDS in wave order; bf16 output like nn.Linear in bf16.
-template <int MT>
+// EPI 0: out = bf16(acc + bias).  EPI 1 (residual): out = bf16(bf16(acc + bias) + aux[m, n]) -- `residual + o_proj(x)` / `residual + down_proj(x)`
+// with torch's two roundings.  EPI 2 (gated pair): the workgroup also contracts weight row `pair_rows` further down (up_proj under gate_proj
+// in one concatenated weight) and writes bf16(silu(bf16 gate) * bf16 up) -- ChameleonMLP's `act_fn(gate_proj(x)) * up_proj(x)`, the [M, 2I]
+// intermediate never in HBM.
+template <int MT, int EPI = 0>
 __global__ __launch_bounds__(FC_THREADS) void linear_rows_kernel(const uint16_t *__restrict__ A, const uint16_t *__restrict__ Wt,
                                                                  const uint16_t *__restrict__ bias, int M, int K, int row_lo, int n_rows,
-                                                                 uint16_t *__restrict__ out, int out_stride, int out_col0) {
+                                                                 uint16_t *__restrict__ out, int out_stride, int out_col0,
+                                                                 const uint16_t *__restrict__ aux, int aux_stride, int pair_rows) {
     __shared__ float tile[MT][32][33];
+    __shared__ float tile2[EPI == 2 ? MT : 1][EPI == 2 ? 32 : 1][EPI == 2 ? 33 : 1];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
     const int n0 = blockIdx.x * 32;
     for (int t = tid; t < MT * 32 * 33; t += FC_THREADS) (&tile[0][0][0])[t] = 0.0f;
+    if constexpr (EPI == 2)
+        for (int t = tid; t < MT * 32 * 33; t += FC_THREADS) (&tile2[0][0][0])[t] = 0.0f;
     const int ksteps = K / 16;
     const int ks0 = (int)((long long)ksteps * wave / FC_WAVES), ks1 = (int)((long long)ksteps * (wave + 1) / FC_WAVES);
     const int ncol = n0 + r;
     const uint16_t *wrow = Wt + (size_t)(row_lo + (ncol < n_rows ? ncol : n_rows - 1)) * K;
+    const uint16_t *wrow2 = wrow + (size_t)pair_rows * K;
     const uint16_t *arow[MT];
     bool live[MT];
 #pragma unroll
@@ -168,11 +177,15 @@ __global__ __launch_bounds__(FC_THREADS) void linear_rows_kernel(const uint16_t 
         live[mt] = row < M;
         arow[mt] = A + (size_t)(live[mt] ? row : 0) * K;
     }
-    f32x16_t acc[MT];
+    f32x16_t acc[MT], acc2[EPI == 2 ? MT : 1];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[mt][i] = 0.0f;
+#pragma unroll
+    for (int mt = 0; mt < (EPI == 2 ? MT : 1); ++mt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc2[mt][i] = 0.0f;
     const bf16x8_t zero = __builtin_bit_cast(bf16x8_t, make_uint4(0, 0, 0, 0));
     // Four K steps (64 elements) per trip.  The order of k inside the contraction is free as long as A and B agree, so lane
     // (r, h) takes the CONTIGUOUS 64 bytes W[row r][k0 + 32h, +32) -- four back-to-back 16-byte loads of one half cache
@@ -182,9 +195,13 @@ __global__ __launch_bounds__(FC_THREADS) void linear_rows_kernel(const uint16_t 
     int ks = ks0;
     for (; ks + 3 < ks1; ks += 4) {
         const int kb = ks * 16 + 32 * h;
-        bf16x8_t bw[4];
+        bf16x8_t bw[4], bw2[EPI == 2 ? 4 : 1];
 #pragma unroll
         for (int q = 0; q < 4; ++q) bw[q] = load_frag(wrow + kb + 8 * q);
+        if constexpr (EPI == 2) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) bw2[q] = load_frag(wrow2 + kb + 8 * q);
+        }
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
             bf16x8_t aw[4];
@@ -192,14 +209,21 @@ __global__ __launch_bounds__(FC_THREADS) void linear_rows_kernel(const uint16_t 
             for (int q = 0; q < 4; ++q) aw[q] = live[mt] ? load_frag(arow[mt] + kb + 8 * q) : zero;
 #pragma unroll
             for (int q = 0; q < 4; ++q) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aw[q], bw[q], acc[mt], 0, 0, 0);
+            if constexpr (EPI == 2) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc2[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aw[q], bw2[q], acc2[mt], 0, 0, 0);
+            }
         }
     }
     for (; ks < ks1; ++ks) {
         const int k0 = ks * 16 + 8 * h;
         const bf16x8_t b0 = load_frag(wrow + k0);
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-            acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(live[mt] ? load_frag(arow[mt] + k0) : zero, b0, acc[mt], 0, 0, 0);
+        for (int mt = 0; mt < MT; ++mt) {
+            const bf16x8_t a0 = live[mt] ? load_frag(arow[mt] + k0) : zero;
+            acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[mt], 0, 0, 0);
+            if constexpr (EPI == 2) acc2[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, load_frag(wrow2 + k0), acc2[mt], 0, 0, 0);
+        }
     }
     for (int w = 0; w < FC_WAVES; ++w) {      // combine the K slices in wave order (deterministic f32 sum)
         __syncthreads();
@@ -207,7 +231,10 @@ __global__ __launch_bounds__(FC_THREADS) void linear_rows_kernel(const uint16_t 
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-                for (int reg = 0; reg < 16; ++reg) tile[mt][(reg & 3) + 8 * (reg >> 2) + 4 * h][r] += acc[mt][reg];
+                for (int reg = 0; reg < 16; ++reg) {
+                    tile[mt][(reg & 3) + 8 * (reg >> 2) + 4 * h][r] += acc[mt][reg];
+                    if constexpr (EPI == 2) tile2[mt][(reg & 3) + 8 * (reg >> 2) + 4 * h][r] += acc2[mt][reg];
+                }
         }
     }
     __syncthreads();
@@ -217,8 +244,103 @@ __global__ __launch_bounds__(FC_THREADS) void linear_rows_kernel(const uint16_t 
         if (m < M && n < n_rows) {
             float v = tile[mt][row][col];
             if (bias) v += bf16_bits_to_f32(bias[row_lo + n]);
-            out[(size_t)m * out_stride + out_col0 + n] = f32_to_bf16_rne(v);
+            uint16_t o = f32_to_bf16_rne(v);
+            if constexpr (EPI == 1) o = f32_to_bf16_rne(bf16_bits_to_f32(aux[(size_t)m * aux_stride + n]) + bf16_bits_to_f32(o));
+            if constexpr (EPI == 2) {
+                float u = tile2[mt][row][col];
+                if (bias) u += bf16_bits_to_f32(bias[row_lo + pair_rows + n]);
+                const float gb = bf16_bits_to_f32(o), ub = bf16_bits_to_f32(f32_to_bf16_rne(u));
+                const float sg = bf16_bits_to_f32(f32_to_bf16_rne(gb / (1.0f + expf(-gb))));       // torch: silu in f32 on the bf16 value, rounded to bf16
+                o = f32_to_bf16_rne(sg * ub);
+            }
+            out[(size_t)m * out_stride + out_col0 + n] = o;
         }
+    }
+}
+
+// ChameleonRMSNorm (cnets_lumina_mgpt.py:209-223) of M rows: f32 statistics, the normalised value rounded to the input dtype, then
+// times the bf16 weight (rounded again) -- one workgroup per row.
+__global__ __launch_bounds__(256) void rmsnorm_rows_kernel(const uint16_t *__restrict__ x, const uint16_t *__restrict__ w, int H, float eps,
+                                                           uint16_t *__restrict__ out) {
+    __shared__ float red[4];
+    const int row = blockIdx.x, tid = threadIdx.x;
+    const uint16_t *xr = x + (size_t)row * H;
+    float ss = 0.0f;
+    for (int i = tid; i < H; i += 256) {
+        const float v = bf16_bits_to_f32(xr[i]);
+        ss += v * v;
+    }
+    for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+    if ((tid & 63) == 0) red[tid >> 6] = ss;
+    __syncthreads();
+    const float var = (red[0] + red[1] + red[2] + red[3]) / (float)H;
+    const float rstd = rsqrtf(var + eps);
+    for (int i = tid; i < H; i += 256) {
+        const float n = bf16_bits_to_f32(f32_to_bf16_rne(bf16_bits_to_f32(xr[i]) * rstd));
+        out[(size_t)row * H + i] = f32_to_bf16_rne(bf16_bits_to_f32(w[i]) * n);
+    }
+}
+
+// ChameleonAttention's head stage for decode-sized inputs (cnets_lumina_mgpt.py:481-499): per (token, head) layer-norm over head_dim
+// (ChameleonLayerNorm: one gamma / beta row per model-parallel shard), rotary embedding at the token's position, written in the
+// [B, heads, T, d] layout attention consumes; V only changes layout.  qkv [B*T, (nq + 2 nk) d] bf16 (the fused projection);
+// cos / sin [max_pos, d] bf16 tables; one wave per (token, head), lane i holds elements i and i + 64 (d = 128) or i (d = 64).
+template <int D>
+__global__ __launch_bounds__(64) void qk_norm_rope_kernel(const uint16_t *__restrict__ qkv, int T, int nq, int nk, const uint16_t *__restrict__ qw,
+                                                          const uint16_t *__restrict__ qb, const uint16_t *__restrict__ kw, const uint16_t *__restrict__ kb,
+                                                          int q_heads_per_mp, int k_heads_per_mp, const uint16_t *__restrict__ cos_t,
+                                                          const uint16_t *__restrict__ sin_t, const int64_t *__restrict__ pos, uint16_t *__restrict__ q_out,
+                                                          uint16_t *__restrict__ k_out, uint16_t *__restrict__ v_out) {
+    constexpr int E = D / 64;
+    const int tok = blockIdx.x, head = blockIdx.y, lane = threadIdx.x;          // head in [0, nq + 2 nk)
+    const int b = tok / T, t = tok % T;
+    const uint16_t *src = qkv + (size_t)tok * (nq + 2 * nk) * D + (size_t)head * D;
+    float v[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) v[e] = bf16_bits_to_f32(src[lane + 64 * e]);
+    if (head >= nq + nk) {          // V: layout only
+        const int hv = head - nq - nk;
+        uint16_t *dst = v_out + (((size_t)b * nk + hv) * T + t) * D;
+#pragma unroll
+        for (int e = 0; e < E; ++e) dst[lane + 64 * e] = src[lane + 64 * e];
+        return;
+    }
+    const bool is_q = head < nq;
+    const int hh = is_q ? head : head - nq;
+    // layer norm over head_dim: f32 statistics (torch.layer_norm on bf16 computes in f32), output rounded to bf16
+    float s = 0.0f;
+#pragma unroll
+    for (int e = 0; e < E; ++e) s += v[e];
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    const float mean = s / (float)D;
+    float ss = 0.0f;
+#pragma unroll
+    for (int e = 0; e < E; ++e) ss += (v[e] - mean) * (v[e] - mean);
+    for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+    const float rstd = rsqrtf(ss / (float)D + 1e-5f);
+    const uint16_t *gw = (is_q ? qw : kw) + (size_t)(hh / (is_q ? q_heads_per_mp : k_heads_per_mp)) * D;
+    const uint16_t *gb = (is_q ? qb : kb) + (size_t)(hh / (is_q ? q_heads_per_mp : k_heads_per_mp)) * D;
+    float n[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const float ln = bf16_bits_to_f32(f32_to_bf16_rne((v[e] - mean) * rstd));
+        const float sc = bf16_bits_to_f32(f32_to_bf16_rne(ln * bf16_bits_to_f32(gw[lane + 64 * e])));
+        n[e] = bf16_bits_to_f32(f32_to_bf16_rne(sc + bf16_bits_to_f32(gb[lane + 64 * e])));
+    }
+    // rotary: x * cos + rotate_half(x) * sin, rotate_half(x)[i] = -x[i + d/2] (i < d/2), x[i - d/2] otherwise; every product and the sum in bf16
+    const int64_t p = pos[(size_t)b * T + t];
+    const uint16_t *cr = cos_t + (size_t)p * D, *sr = sin_t + (size_t)p * D;
+    uint16_t *dst = (is_q ? q_out + (((size_t)b * nq + hh) * T + t) * D : k_out + (((size_t)b * nk + hh) * T + t) * D);
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const int i = lane + 64 * e;
+        float other;          // x[(i + d/2) mod d]
+        if constexpr (E == 2) other = n[e ^ 1];                       // d = 128: the partner element sits in the same lane's other slot
+        else other = __shfl_xor(n[0], 32, 64);                        // d = 64: lane i <-> lane i ^ 32
+        const float rot = (i < D / 2) ? -other : other;
+        const float a = bf16_bits_to_f32(f32_to_bf16_rne(n[e] * bf16_bits_to_f32(cr[i])));
+        const float c = bf16_bits_to_f32(f32_to_bf16_rne(rot * bf16_bits_to_f32(sr[i])));
+        dst[i] = f32_to_bf16_rne(a + c);
     }
 }
 
@@ -366,6 +488,56 @@ extern "C" int lantern_drafter_fc(const int64_t *ids, const void *hidden, const 
     return LANTERN_OK;
 }
 
+extern "C" int lantern_linear_rows_epilogue(const void *A, const void *W, const void *bias, int M, int K, int row_lo, int n_rows, void *out,
+                                            int out_stride, int out_col0, int epilogue, const void *aux, int aux_stride, int pair_rows, void *stream) {
+    LANTERN_CHECK_ARG(A && W && out, "linear_rows_epilogue: null buffer");
+    LANTERN_CHECK_ARG(M >= 0 && M <= 32, "linear_rows_epilogue: M=%d must be <= 32 rows (the drafter's decode shape)", M);
+    LANTERN_CHECK_ARG(K > 0 && K % 16 == 0 && row_lo >= 0 && n_rows >= 0 && out_col0 >= 0 && out_stride >= out_col0 + n_rows,
+                      "linear_rows_epilogue: K=%d must be a multiple of 16, the output row must hold [col0, col0 + n_rows)", K);
+    LANTERN_CHECK_ARG(epilogue == LANTERN_EPI_RESIDUAL || epilogue == LANTERN_EPI_SILU_MUL, "linear_rows_epilogue: epilogue %d", epilogue);
+    if (epilogue == LANTERN_EPI_RESIDUAL) LANTERN_CHECK_ARG(aux && aux_stride >= n_rows, "linear_rows_epilogue: the residual [M, aux_stride >= n_rows] is missing");
+    if (epilogue == LANTERN_EPI_SILU_MUL) LANTERN_CHECK_ARG(pair_rows > 0, "linear_rows_epilogue: pair_rows = distance (in weight rows) from a gate row to its up row");
+    if (M == 0 || n_rows == 0) return LANTERN_OK;
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid((n_rows + 31) / 32), block(FC_THREADS);
+    const uint16_t *a = (const uint16_t *)A, *w = (const uint16_t *)W, *bi = (const uint16_t *)bias, *ax = (const uint16_t *)aux;
+    uint16_t *o = (uint16_t *)out;
+    if (epilogue == LANTERN_EPI_RESIDUAL) LANTERN_LAUNCH((linear_rows_kernel<1, 1>), grid, block, 0, st, a, w, bi, M, K, row_lo, n_rows, o, out_stride, out_col0, ax, aux_stride, 0);
+    else LANTERN_LAUNCH((linear_rows_kernel<1, 2>), grid, block, 0, st, a, w, bi, M, K, row_lo, n_rows, o, out_stride, out_col0, ax, 0, pair_rows);
+    LANTERN_CHECK_LAUNCH("linear_rows_epilogue");
+    return LANTERN_OK;
+}
+
+extern "C" int lantern_rmsnorm_rows(const void *x, const void *weight, int M, int H, float eps, void *out, void *stream) {
+    LANTERN_CHECK_ARG(x && weight && out && M >= 0 && H > 0, "rmsnorm_rows: bad arguments");
+    if (M == 0) return LANTERN_OK;
+    LANTERN_LAUNCH(rmsnorm_rows_kernel, dim3(M), dim3(256), 0, (hipStream_t)stream, (const uint16_t *)x, (const uint16_t *)weight, H, eps, (uint16_t *)out);
+    LANTERN_CHECK_LAUNCH("rmsnorm_rows");
+    return LANTERN_OK;
+}
+
+extern "C" int lantern_qk_norm_rope(const void *qkv, int B, int T, int n_q_heads, int n_kv_heads, int head_dim, const void *q_weight, const void *q_bias,
+                                    const void *k_weight, const void *k_bias, int model_parallel, const void *cos_table, const void *sin_table,
+                                    int table_rows, const int64_t *position_ids, void *q_out, void *k_out, void *v_out, void *stream) {
+    LANTERN_CHECK_ARG(qkv && q_weight && q_bias && k_weight && k_bias && cos_table && sin_table && position_ids && q_out && k_out && v_out,
+                      "qk_norm_rope: null buffer");
+    LANTERN_CHECK_ARG(B >= 0 && T >= 0 && n_q_heads > 0 && n_kv_heads > 0 && model_parallel > 0 && n_q_heads % model_parallel == 0 &&
+                          n_kv_heads % model_parallel == 0 && table_rows > 0,
+                      "qk_norm_rope: bad sizes");
+    LANTERN_CHECK_ARG(head_dim == 128 || head_dim == 64, "qk_norm_rope: head_dim %d (64 or 128)", head_dim);
+    if (B * T == 0) return LANTERN_OK;
+    dim3 grid(B * T, n_q_heads + 2 * n_kv_heads);
+#define QKNR(D_) LANTERN_LAUNCH((qk_norm_rope_kernel<D_>), grid, dim3(64), 0, (hipStream_t)stream, (const uint16_t *)qkv, T, n_q_heads, n_kv_heads,     \
+                                (const uint16_t *)q_weight, (const uint16_t *)q_bias, (const uint16_t *)k_weight, (const uint16_t *)k_bias,                 \
+                                n_q_heads / model_parallel, n_kv_heads / model_parallel, (const uint16_t *)cos_table, (const uint16_t *)sin_table,           \
+                                position_ids, (uint16_t *)q_out, (uint16_t *)k_out, (uint16_t *)v_out)
+    if (head_dim == 128) QKNR(128);
+    else QKNR(64);
+#undef QKNR
+    LANTERN_CHECK_LAUNCH("qk_norm_rope");
+    return LANTERN_OK;
+}
+
 extern "C" int lantern_linear_rows(const void *A, const void *W, const void *bias, int M, int K, int row_lo, int n_rows, void *out,
                                    int out_stride, int out_col0, void *stream) {
     LANTERN_CHECK_ARG(A && W && out, "linear_rows: null buffer");
@@ -377,10 +549,10 @@ extern "C" int lantern_linear_rows(const void *A, const void *W, const void *bia
     dim3 grid((n_rows + 31) / 32), block(FC_THREADS);
     const uint16_t *a = (const uint16_t *)A, *w = (const uint16_t *)W, *bi = (const uint16_t *)bias;
     uint16_t *o = (uint16_t *)out;
-    if (M <= 32) LANTERN_LAUNCH((linear_rows_kernel<1>), grid, block, 0, st, a, w, bi, M, K, row_lo, n_rows, o, out_stride, out_col0);
-    else if (M <= 64) LANTERN_LAUNCH((linear_rows_kernel<2>), grid, block, 0, st, a, w, bi, M, K, row_lo, n_rows, o, out_stride, out_col0);
-    else if (M <= 96) LANTERN_LAUNCH((linear_rows_kernel<3>), grid, block, 0, st, a, w, bi, M, K, row_lo, n_rows, o, out_stride, out_col0);
-    else LANTERN_LAUNCH((linear_rows_kernel<4>), grid, block, 0, st, a, w, bi, M, K, row_lo, n_rows, o, out_stride, out_col0);
+    if (M <= 32) LANTERN_LAUNCH((linear_rows_kernel<1, 0>), grid, block, 0, st, a, w, bi, M, K, row_lo, n_rows, o, out_stride, out_col0, (const uint16_t *)nullptr, 0, 0);
+    else if (M <= 64) LANTERN_LAUNCH((linear_rows_kernel<2, 0>), grid, block, 0, st, a, w, bi, M, K, row_lo, n_rows, o, out_stride, out_col0, (const uint16_t *)nullptr, 0, 0);
+    else if (M <= 96) LANTERN_LAUNCH((linear_rows_kernel<3, 0>), grid, block, 0, st, a, w, bi, M, K, row_lo, n_rows, o, out_stride, out_col0, (const uint16_t *)nullptr, 0, 0);
+    else LANTERN_LAUNCH((linear_rows_kernel<4, 0>), grid, block, 0, st, a, w, bi, M, K, row_lo, n_rows, o, out_stride, out_col0, (const uint16_t *)nullptr, 0, 0);
     LANTERN_CHECK_LAUNCH("linear_rows");
     return LANTERN_OK;
 }

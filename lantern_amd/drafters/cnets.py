@@ -15,7 +15,9 @@ What runs where:
 The decoder layer(s) between the input stage and the head are the drafter's transformer (GEMM-bound, out of this
 path's scope): they are INJECTED -- any module with the reference layer's call signature, e.g. the reference's own
 `ChameleonDecoderLayer` / `LlamaDecoderLayer` loaded from its checkpoint -- and default to a plain-torch Llama-style
-layer so the class runs stand-alone.
+layer so the class runs stand-alone.  For Lumina-mGPT `lantern_amd.drafters.decoder_layer.DecoderLayer` is the HIP drop-in for
+ChameleonDecoderLayer (same parameter names: `layers=[DecoderLayer(config, 0)]`, then load the reference checkpoint): at the drafting
+shape (2 x top_k rows) its projections stream through the MFMA skinny GEMM with the norms / rotary / residuals / silu * up fused around them.
 """
 from __future__ import annotations
 

@@ -1,0 +1,256 @@
+"""The drafter's single decoder layer on the HIP skinny GEMM (second part).
+
+Reference: models/drafters/cnets_lumina_mgpt.py -- ChameleonDecoderLayer (:769-843) = ChameleonRMSNorm (:209-223) ->
+ChameleonAttention (:411-541: q/k/v projections, per-head ChameleonLayerNorm :375-396, rotary :228-357, KV concat, eager
+softmax attention under the additive drafter mask, o_proj) -> residual -> ChameleonRMSNorm -> ChameleonMLP (:359-373) -> residual.
+
+During drafting the layer sees M = 2 x top_k = 20 rows per call, six calls per verify cycle: its cost is the 404 MB of
+projection weights it streams (7B: 4 x 4096^2 + 3 x 4096 x 11008 bf16), not arithmetic.  The seven projections therefore go
+through `lantern_linear_rows` (drafter_fc.hip: `linear_rows_kernel`, MFMA 32x32x16 fed straight from the [out, in] weight rows,
+M <= 128) with q/k/v and gate/up each fused into ONE launch over a concatenated weight; norms, rotary and the 20-row attention are
+small torch ops.  Anything the kernel is not built for (CPU tensors, other dtypes, M > 128: the drafter's prefill) takes
+torch.nn.functional.linear -- the layer is a drop-in nn.Module with the reference's parameter names (`self_attn.q_proj.weight`,
+`mlp.gate_proj.weight`, `input_layernorm.weight`, ...), so a reference drafter checkpoint loads into it unchanged.
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional, Tuple
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .. import ops
+
+
+def _hip_ok(x: torch.Tensor, weight: torch.Tensor) -> bool:
+    return x.is_cuda and x.dtype == torch.bfloat16 and weight.dtype == torch.bfloat16 and x.shape[-1] % 16 == 0
+
+
+def skinny_linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """x [..., K] @ weight[N, K].T (+ bias): the HIP weight-streaming kernel for decode-sized inputs, torch otherwise."""
+    rows = x.numel() // x.shape[-1]
+    if rows <= 128 and _hip_ok(x, weight):
+        out = ops.linear_rows(x.reshape(rows, x.shape[-1]), weight, 0, weight.shape[0], bias=bias)
+        return out.reshape(*x.shape[:-1], weight.shape[0])
+    return F.linear(x, weight, bias)
+
+
+class RMSNorm(nn.Module):
+    """cnets_lumina_mgpt.py:209-223 (statistics in f32, the weight applied in the input dtype)."""
+
+    def __init__(self, hidden_size: int, eps: float = 1e-6):
+        super().__init__()
+        self.weight = nn.Parameter(torch.ones(hidden_size))
+        self.variance_epsilon = eps
+
+    def forward(self, x):
+        xf = x.to(torch.float32)
+        xf = xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + self.variance_epsilon)
+        return self.weight * xf.to(x.dtype)
+
+
+class HeadLayerNorm(nn.Module):
+    """cnets_lumina_mgpt.py:375-396: layer norm over head_dim with one (gamma, beta) row per model-parallel shard, repeated over the
+    shard's heads.  Parameters keep nn.LayerNorm's names and the [model_parallel_size, head_dim] shape."""
+
+    def __init__(self, head_dim: int, model_parallel_size: int, n_heads_per_mp: int, eps: float = 1e-5):
+        super().__init__()
+        self.weight = nn.Parameter(torch.ones(model_parallel_size, head_dim))
+        self.bias = nn.Parameter(torch.zeros(model_parallel_size, head_dim))
+        self.head_dim, self.n_heads_per_mp, self.eps = head_dim, n_heads_per_mp, eps
+
+    def forward(self, x):                                  # [tokens, heads, head_dim]
+        x = F.layer_norm(x, (self.head_dim,), None, None, eps=1e-5)
+        return x * self.weight.repeat_interleave(self.n_heads_per_mp, dim=0) + self.bias.repeat_interleave(self.n_heads_per_mp, dim=0)
+
+
+class Rotary(nn.Module):
+    """cnets_lumina_mgpt.py:228-299 (cos / sin tables of the concatenated-halves convention)."""
+
+    def __init__(self, dim: int, max_position_embeddings: int = 2048, base: float = 10000.0):
+        super().__init__()
+        self.dim, self.base = dim, base
+        self.register_buffer("inv_freq", 1.0 / (base ** (torch.arange(0, dim, 2).float() / dim)), persistent=False)
+        self._build(max_position_embeddings, self.inv_freq.device, torch.get_default_dtype())
+
+    def _build(self, seq_len, device, dtype):
+        self.max_seq_len_cached = seq_len
+        t = torch.arange(seq_len, device=device, dtype=self.inv_freq.dtype)
+        emb = torch.outer(t, self.inv_freq.to(device))
+        emb = torch.cat((emb, emb), dim=-1)
+        self.register_buffer("cos_cached", emb.cos().to(dtype), persistent=False)
+        self.register_buffer("sin_cached", emb.sin().to(dtype), persistent=False)
+
+    def tables_bf16(self, device, seq_len: int):
+        """The whole cos / sin tables as bf16 on `device`, converted once (the fused head kernel indexes them by position)."""
+        if seq_len > self.max_seq_len_cached:
+            self._build(seq_len, device, torch.get_default_dtype())
+            self._bf16 = None
+        c = getattr(self, "_bf16", None)
+        if c is None or c[0].device != device:
+            self._bf16 = c = (self.cos_cached.to(device=device, dtype=torch.bfloat16).contiguous(), self.sin_cached.to(device=device, dtype=torch.bfloat16).contiguous())
+        return c
+
+    def forward(self, x, seq_len: int):
+        if seq_len > self.max_seq_len_cached:
+            self._build(seq_len, x.device, x.dtype)
+        return self.cos_cached[:seq_len].to(dtype=x.dtype, device=x.device), self.sin_cached[:seq_len].to(dtype=x.dtype, device=x.device)
+
+
+def _rotate_half(x):
+    h = x.shape[-1] // 2
+    return torch.cat((-x[..., h:], x[..., :h]), dim=-1)
+
+
+class Attention(nn.Module):
+    def __init__(self, config, layer_idx: Optional[int] = None):
+        super().__init__()
+        self.hidden_size = config.hidden_size
+        self.num_heads = config.num_attention_heads
+        self.head_dim = self.hidden_size // self.num_heads
+        self.num_key_value_heads = config.num_key_value_heads
+        self.num_key_value_groups = self.num_heads // self.num_key_value_heads
+        mp = getattr(config, "model_parallel_size", 1)
+        bias = getattr(config, "attention_bias", False)
+        self.q_proj = nn.Linear(self.hidden_size, self.num_heads * self.head_dim, bias=bias)
+        self.k_proj = nn.Linear(self.hidden_size, self.num_key_value_heads * self.head_dim, bias=bias)
+        self.v_proj = nn.Linear(self.hidden_size, self.num_key_value_heads * self.head_dim, bias=bias)
+        self.o_proj = nn.Linear(self.hidden_size, self.hidden_size, bias=bias)
+        self.q_norm = HeadLayerNorm(self.head_dim, mp, self.num_heads // mp)
+        self.k_norm = HeadLayerNorm(self.head_dim, mp, self.num_key_value_heads // mp)
+        self.rotary_emb = Rotary(self.head_dim, getattr(config, "max_position_embeddings", 2048), getattr(config, "rope_theta", 10000.0))
+        self._qkv = None          # (versions, fused weight, fused bias): q/k/v stream as one launch
+
+    def _fused_qkv(self):
+        ws = (self.q_proj.weight, self.k_proj.weight, self.v_proj.weight)
+        key = tuple((w.data_ptr(), w._version) for w in ws)
+        if self._qkv is None or self._qkv[0] != key:
+            b = None if self.q_proj.bias is None else torch.cat([self.q_proj.bias, self.k_proj.bias, self.v_proj.bias]).contiguous()
+            self._qkv = (key, torch.cat(ws, dim=0).contiguous(), b)
+        return self._qkv[1], self._qkv[2]
+
+    def forward(self, hidden_states, attention_mask=None, position_ids=None, past_key_value=None, output_attentions=False, use_cache=False, **kw):
+        bsz, q_len, _ = hidden_states.shape
+        nq, nk, hd = self.num_heads, self.num_key_value_heads, self.head_dim
+        if bsz * q_len <= 128 and _hip_ok(hidden_states, self.q_proj.weight):
+            w, b = self._fused_qkv()
+            qkv = skinny_linear(hidden_states, w, b)
+            q, k, v = qkv.split((nq * hd, nk * hd, nk * hd), dim=-1)
+        else:
+            q, k, v = self.q_proj(hidden_states), self.k_proj(hidden_states), self.v_proj(hidden_states)
+        q = self.q_norm(q.reshape(-1, nq, hd)).reshape(bsz, q_len, nq, hd).transpose(1, 2)
+        k = self.k_norm(k.reshape(-1, nk, hd)).reshape(bsz, q_len, nk, hd).transpose(1, 2)
+        v = v.reshape(bsz, q_len, nk, hd).transpose(1, 2)
+        kv_len = q_len + (past_key_value[0].shape[-2] if past_key_value is not None else 0)
+        cos, sin = self.rotary_emb(v, kv_len)
+        cos, sin = cos[position_ids].unsqueeze(1), sin[position_ids].unsqueeze(1)
+        q, k = q * cos + _rotate_half(q) * sin, k * cos + _rotate_half(k) * sin
+        if past_key_value is not None:
+            k, v = torch.cat([past_key_value[0], k], dim=2), torch.cat([past_key_value[1], v], dim=2)
+        present = (k, v) if use_cache else None
+        if self.num_key_value_groups > 1:
+            k = k[:, :, None].expand(bsz, nk, self.num_key_value_groups, kv_len, hd).reshape(bsz, nq, kv_len, hd)
+            v = v[:, :, None].expand(bsz, nk, self.num_key_value_groups, kv_len, hd).reshape(bsz, nq, kv_len, hd)
+        w = torch.matmul(q, k.transpose(2, 3)) / math.sqrt(hd)
+        if attention_mask is not None:
+            w = w + attention_mask[:, :, :, :kv_len]
+        w = F.softmax(w, dim=-1).to(q.dtype)
+        out = torch.matmul(w, v).transpose(1, 2).reshape(bsz, q_len, self.hidden_size)
+        out = skinny_linear(out, self.o_proj.weight, self.o_proj.bias)
+        return out, (w if output_attentions else None), present
+
+
+class MLP(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        bias = getattr(config, "mlp_bias", False)
+        self.gate_proj = nn.Linear(config.hidden_size, config.intermediate_size, bias=bias)
+        self.up_proj = nn.Linear(config.hidden_size, config.intermediate_size, bias=bias)
+        self.down_proj = nn.Linear(config.intermediate_size, config.hidden_size, bias=bias)
+        act = getattr(config, "hidden_act", "silu")
+        if act not in ("silu", "swish", "gelu"):
+            raise ValueError(f"hidden_act={act}: the drafter layers of the reference use silu")
+        self.act_fn = F.gelu if act == "gelu" else F.silu
+        self._gu = None
+
+    def _fused_gate_up(self):
+        ws = (self.gate_proj.weight, self.up_proj.weight)
+        key = tuple((w.data_ptr(), w._version) for w in ws)
+        if self._gu is None or self._gu[0] != key:
+            b = None if self.gate_proj.bias is None else torch.cat([self.gate_proj.bias, self.up_proj.bias]).contiguous()
+            self._gu = (key, torch.cat(ws, dim=0).contiguous(), b)
+        return self._gu[1], self._gu[2]
+
+    def forward(self, x):
+        rows = x.numel() // x.shape[-1]
+        if rows <= 128 and _hip_ok(x, self.gate_proj.weight):
+            w, b = self._fused_gate_up()
+            g, u = skinny_linear(x, w, b).split(self.gate_proj.out_features, dim=-1)
+            return skinny_linear(self.act_fn(g) * u, self.down_proj.weight, self.down_proj.bias)
+        return self.down_proj(self.act_fn(self.gate_proj(x)) * self.up_proj(x))
+
+
+class DecoderLayer(nn.Module):
+    """Drop-in for the reference's ChameleonDecoderLayer in the drafter (same call signature and return tuple)."""
+
+    def __init__(self, config, layer_idx: int = 0):
+        super().__init__()
+        self.hidden_size = config.hidden_size
+        self.self_attn = Attention(config, layer_idx)
+        self.mlp = MLP(config)
+        eps = getattr(config, "rms_norm_eps", 1e-6)
+        self.input_layernorm = RMSNorm(config.hidden_size, eps)
+        self.post_attention_layernorm = RMSNorm(config.hidden_size, eps)
+
+    def _fast(self, x, attention_mask, position_ids, past_key_value, use_cache):
+        """Decode shape on the device (<= 32 bf16 rows): ten launches -- rmsnorm, fused q/k/v GEMM, head norm + rotary, the two cache concats,
+        one attention call, o_proj + residual, rmsnorm, gate/up GEMM with silu * up in its epilogue, down_proj + residual."""
+        at, mlp = self.self_attn, self.mlp
+        B, T, H = x.shape
+        nq, nk, d = at.num_heads, at.num_key_value_heads, at.head_dim
+        x2 = x.reshape(B * T, H)
+        xn = ops.rmsnorm_rows(x2, self.input_layernorm.weight, self.input_layernorm.variance_epsilon)
+        w, b = at._fused_qkv()
+        qkv = ops.linear_rows(xn, w, 0, w.shape[0], bias=b)
+        kv_len = T + (past_key_value[0].shape[-2] if past_key_value is not None else 0)
+        cos, sin = at.rotary_emb.tables_bf16(x.device, kv_len)
+        q, k, v = ops.qk_norm_rope(qkv, B, T, nq, nk, d, at.q_norm.weight, at.q_norm.bias, at.k_norm.weight, at.k_norm.bias, cos, sin, position_ids)
+        if past_key_value is not None:
+            k, v = torch.cat([past_key_value[0], k], dim=2), torch.cat([past_key_value[1], v], dim=2)
+        present = (k, v) if use_cache else None
+        m = None if attention_mask is None else attention_mask[:, :, :, :kv_len].to(q.dtype)
+        o = F.scaled_dot_product_attention(q, k, v, attn_mask=m, enable_gqa=nk != nq)
+        o = o.transpose(1, 2).reshape(B * T, H)
+        h1 = ops.linear_rows_epilogue(o, at.o_proj.weight, ops.EPI_RESIDUAL, bias=at.o_proj.bias, residual=x2)
+        hn = ops.rmsnorm_rows(h1, self.post_attention_layernorm.weight, self.post_attention_layernorm.variance_epsilon)
+        wg, bg = mlp._fused_gate_up()
+        inter = mlp.gate_proj.out_features
+        act = ops.linear_rows_epilogue(hn, wg, ops.EPI_SILU_MUL, bias=bg, pair_rows=inter)
+        out = ops.linear_rows_epilogue(act, mlp.down_proj.weight, ops.EPI_RESIDUAL, bias=mlp.down_proj.bias, residual=h1)
+        return out.reshape(B, T, H), present
+
+    def _fast_ok(self, x, position_ids, output_attentions):
+        at = self.self_attn
+        return (self.fused and not output_attentions and x.dim() == 3 and x.shape[0] * x.shape[1] <= 32 and _hip_ok(x, at.q_proj.weight)
+                and at.head_dim in (64, 128) and position_ids is not None and self.mlp.act_fn is F.silu
+                and self.input_layernorm.weight.dtype == torch.bfloat16 and at.q_norm.weight.dtype == torch.bfloat16)
+
+    fused = True          # False: every projection its own launch through skinny_linear / torch (the composition the fast path is tested against)
+
+    def forward(self, hidden_states, attention_mask=None, position_ids=None, past_key_value=None, output_attentions=False, use_cache=False,
+                **kw) -> Tuple[torch.Tensor, ...]:
+        if self._fast_ok(hidden_states, position_ids, output_attentions):
+            y, present = self._fast(hidden_states, attention_mask, position_ids, past_key_value, use_cache)
+            return (y, present) if use_cache else (y,)
+        a, w, present = self.self_attn(self.input_layernorm(hidden_states), attention_mask=attention_mask, position_ids=position_ids,
+                                       past_key_value=past_key_value, output_attentions=output_attentions, use_cache=use_cache)
+        hidden_states = hidden_states + a
+        hidden_states = hidden_states + self.mlp(self.post_attention_layernorm(hidden_states))
+        out = (hidden_states,)
+        if output_attentions:
+            out += (w,)
+        if use_cache:
+            out += (present,)
+        return out

@@ -623,6 +623,50 @@ def linear_rows(A, weight, row_lo: int, n_rows: int, bias=None, out=None, out_co
     return out
 
 
+EPI_RESIDUAL, EPI_SILU_MUL = 1, 2          # include/lantern_hip.h LANTERN_EPI_*
+
+
+def linear_rows_epilogue(A, weight, epilogue: int, n_rows: Optional[int] = None, bias=None, residual=None, pair_rows: int = 0):
+    """8f-2, decoder layer: A [M <= 32, K] bf16 @ weight[:n_rows].T with the layer's tail in the epilogue.  EPI_RESIDUAL: + residual [M, n_rows]
+    (torch's two bf16 roundings); EPI_SILU_MUL: weight = cat(gate, up) rows, pair_rows = distance gate -> up row: silu(gate) * up, [M, n_rows]."""
+    for t, n in ((A, "A"), (weight, "weight")):
+        if not t.is_cuda or t.dtype != torch.bfloat16:
+            raise _lib.LanternError(f"linear_rows_epilogue: {n} must be a bf16 device tensor")
+    A, weight = A.contiguous(), weight.contiguous()
+    M, K = A.shape
+    n_rows = (weight.shape[0] if epilogue == EPI_RESIDUAL else pair_rows) if n_rows is None else n_rows
+    out = torch.empty((M, n_rows), dtype=torch.bfloat16, device=A.device)
+    r = None if residual is None else residual.contiguous()
+    b = None if bias is None else bias.contiguous()
+    check(_lib.lib().lantern_linear_rows_epilogue(C.c_void_p(A.data_ptr()), C.c_void_p(weight.data_ptr()), C.c_void_p(_ptr(b)), M, K, 0, n_rows,
+                                                  C.c_void_p(out.data_ptr()), n_rows, 0, epilogue, C.c_void_p(_ptr(r)), 0 if r is None else r.shape[1],
+                                                  pair_rows, _stream()), "linear_rows_epilogue")
+    return out
+
+
+def rmsnorm_rows(x, weight, eps: float):
+    """ChameleonRMSNorm of bf16 rows [M, H] (lantern_rmsnorm_rows)."""
+    x, weight = x.contiguous(), weight.contiguous()
+    out = torch.empty_like(x)
+    check(_lib.lib().lantern_rmsnorm_rows(C.c_void_p(x.data_ptr()), C.c_void_p(weight.data_ptr()), x.shape[0], x.shape[1], C.c_float(eps),
+                                          C.c_void_p(out.data_ptr()), _stream()), "rmsnorm_rows")
+    return out
+
+
+def qk_norm_rope(qkv, B: int, T: int, nq: int, nk: int, d: int, qw, qb, kw, kb, cos, sin, position_ids):
+    """Head stage of the drafter's attention on the fused projection qkv [B*T, (nq + 2 nk) d]: -> q [B,nq,T,d], k / v [B,nk,T,d] (bf16)."""
+    dev = qkv.device
+    q = torch.empty((B, nq, T, d), dtype=torch.bfloat16, device=dev)
+    k = torch.empty((B, nk, T, d), dtype=torch.bfloat16, device=dev)
+    v = torch.empty((B, nk, T, d), dtype=torch.bfloat16, device=dev)
+    pos = position_ids.to(torch.int64).contiguous()
+    check(_lib.lib().lantern_qk_norm_rope(C.c_void_p(qkv.contiguous().data_ptr()), B, T, nq, nk, d, C.c_void_p(qw.contiguous().data_ptr()),
+                                          C.c_void_p(qb.contiguous().data_ptr()), C.c_void_p(kw.contiguous().data_ptr()), C.c_void_p(kb.contiguous().data_ptr()),
+                                          qw.shape[0], C.c_void_p(cos.data_ptr()), C.c_void_p(sin.data_ptr()), cos.shape[0], C.c_void_p(pos.data_ptr()),
+                                          C.c_void_p(q.data_ptr()), C.c_void_p(k.data_ptr()), C.c_void_p(v.data_ptr()), _stream()), "qk_norm_rope")
+    return q, k, v
+
+
 def head_expand(A, weight, row_lo: int, n_cols: int, cfg: float, bias=None, model: int = MODEL_LUMINA, pos_ids=None, pos_base: int = 2,
                 w: int = 48, h: int = 48, newline_id: int = 8803, eos_id: int = 8196, top_k_filter: int = 0, scores_in=None, top_k: int = 10):
     """8f-2 fused: one drafter expansion depth from hidden states to top-k (lantern_head_expand).  A [2n, K] bf16 (n cond rows, then

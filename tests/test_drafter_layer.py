@@ -1,0 +1,93 @@
+"""The drafter's decoder layer (lantern_amd/drafters/decoder_layer.py) against vectors recorded from the reference's
+ChameleonDecoderLayer (tests/golden/layer.npz, make_golden_layer.py): the torch path in f32 on the CPU (host logic: norms, rotary, cache
+concat, mask, GQA) and -- GPU -- the HIP skinny-GEMM path in bf16 within bf16 tolerance."""
+import os
+import sys
+import types
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from lantern_amd.drafters.decoder_layer import DecoderLayer  # noqa: E402
+
+GOLD = np.load(os.path.join(ROOT, "tests", "golden", "layer.npz"))
+CASES = sorted({k.split(".")[0] for k in GOLD.files})
+
+
+def build(name, device, dtype):
+    hidden, heads, kv_heads, inter, mp, seed = (int(x) for x in GOLD[name + ".cfg"])
+    cfg = types.SimpleNamespace(hidden_size=hidden, intermediate_size=inter, num_attention_heads=heads, num_key_value_heads=kv_heads,
+                                max_position_embeddings=256, model_parallel_size=mp, rope_theta=10000.0, rms_norm_eps=1e-5, attention_bias=False,
+                                mlp_bias=False, hidden_act="silu")
+    layer = DecoderLayer(cfg, 0).eval()
+    # the generator's recipe (make_golden_layer.fill_parameters): numpy RandomState(seed), the reference's state_dict order and names
+    names = [str(n) for n in GOLD[name + ".names"]]
+    mine = layer.state_dict()
+    assert set(names) == set(mine.keys()), (set(names) ^ set(mine.keys()))          # the reference's parameter names load as they are
+    rs = np.random.RandomState(seed)
+    sd = {}
+    for n in names:
+        a = rs.standard_normal(tuple(mine[n].shape)).astype(np.float32)
+        if mine[n].dim() > 1 and "norm" not in n:
+            a = a / np.sqrt(mine[n].shape[-1])
+        elif n.endswith("weight"):
+            a = 1.0 + 0.1 * a
+        else:
+            a = 0.1 * a
+        sd[n] = torch.from_numpy(a)
+    layer.load_state_dict(sd, strict=True)
+    return layer.to(device=device, dtype=dtype)
+
+
+def g(name, key, device, dtype=None):
+    t = torch.from_numpy(GOLD[name + "." + key]).to(device)
+    return t.to(dtype) if (dtype is not None and t.is_floating_point()) else t
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_layer_torch_path_matches_the_reference_layer_f32(name):
+    layer = build(name, "cpu", torch.float32)
+    with torch.no_grad():
+        y0, kv0 = layer(g(name, "x0", "cpu"), attention_mask=g(name, "m0", "cpu"), position_ids=g(name, "pos0", "cpu"), use_cache=True)
+        y1, kv1 = layer(g(name, "x1", "cpu"), attention_mask=g(name, "m1", "cpu"), position_ids=g(name, "pos1", "cpu"), past_key_value=kv0, use_cache=True)
+    for got, key in ((y0, "y0"), (kv0[0], "k0"), (kv0[1], "v0"), (y1, "y1"), (kv1[0], "k1"), (kv1[1], "v1")):
+        np.testing.assert_allclose(got.numpy(), GOLD[name + "." + key], rtol=2e-5, atol=2e-5)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fused", [True, False], ids=["fused", "per_projection"])
+@pytest.mark.parametrize("name", CASES)
+def test_layer_hip_path_matches_the_reference_layer_bf16(name, fused, monkeypatch):
+    """Tolerance: bf16 has 8 bits of mantissa and every projection rounds its output to bf16 (as torch's bf16 nn.Linear does): the layer's
+    output is compared with the reference's f32 result at 4e-2 absolute + 4e-2 relative, and with the SAME layer on torch's own bf16
+    ops at 2e-2 (two bf16 pipelines that differ in accumulation order).  fused: rmsnorm / fused qkv / head-norm + rotary / o_proj + residual /
+    gate-up with silu * up / down + residual kernels (head_dim 64 or 128); per_projection: the skinny GEMM under torch's element-wise ops."""
+    from lantern_amd import ops
+    calls = []
+    for fn in ("linear_rows", "linear_rows_epilogue", "rmsnorm_rows", "qk_norm_rope"):
+        real = getattr(ops, fn)
+        monkeypatch.setattr(ops, fn, (lambda real, fn: (lambda *a, **kw: (calls.append(fn), real(*a, **kw))[1]))(real, fn))
+    dev = torch.device("cuda")
+    layer = build(name, dev, torch.bfloat16)
+    layer.fused = fused
+    bf = torch.bfloat16
+    with torch.no_grad():
+        y0, kv0 = layer(g(name, "x0", dev, bf), attention_mask=g(name, "m0", dev), position_ids=g(name, "pos0", dev), use_cache=True)
+        y1, kv1 = layer(g(name, "x1", dev, bf), attention_mask=g(name, "m1", dev), position_ids=g(name, "pos1", dev), past_key_value=kv0, use_cache=True)
+    head_dim = layer.self_attn.head_dim
+    if fused and head_dim in (64, 128):
+        assert calls.count("qk_norm_rope") == 2 and calls.count("rmsnorm_rows") == 4 and calls.count("linear_rows_epilogue") == 6 and calls.count("linear_rows") == 2, calls
+    else:
+        assert calls.count("linear_rows") == 8 and "qk_norm_rope" not in calls, calls          # fused qkv, o_proj, fused gate/up, down_proj per call
+    for got, key in ((y0, "y0"), (y1, "y1"), (kv1[0], "k1"), (kv1[1], "v1")):
+        np.testing.assert_allclose(got.float().cpu().numpy(), GOLD[name + "." + key], rtol=4e-2, atol=4e-2)
+    # the same layer through torch's bf16 ops only (the kernels switched off)
+    monkeypatch.setattr("lantern_amd.drafters.decoder_layer._hip_ok", lambda x, w: False)
+    with torch.no_grad():
+        t0, tkv0 = layer(g(name, "x0", dev, bf), attention_mask=g(name, "m0", dev), position_ids=g(name, "pos0", dev), use_cache=True)
+        t1, _ = layer(g(name, "x1", dev, bf), attention_mask=g(name, "m1", dev), position_ids=g(name, "pos1", dev), past_key_value=tkv0, use_cache=True)
+    np.testing.assert_allclose(y0.float().cpu().numpy(), t0.float().cpu().numpy(), rtol=2e-2, atol=2e-2)
+    np.testing.assert_allclose(y1.float().cpu().numpy(), t1.float().cpu().numpy(), rtol=2e-2, atol=2e-2)

@@ -220,9 +220,9 @@ class DecoderLayer(nn.Module):
         if past_key_value is not None:
             k, v = torch.cat([past_key_value[0], k], dim=2), torch.cat([past_key_value[1], v], dim=2)
         present = (k, v) if use_cache else None
+        # (a hand-written LDS-score attention kernel for this shape was measured at 156 us against 61 us for torch's fused attention: dropped)
         m = None if attention_mask is None else attention_mask[:, :, :, :kv_len].to(q.dtype)
-        o = F.scaled_dot_product_attention(q, k, v, attn_mask=m, enable_gqa=nk != nq)
-        o = o.transpose(1, 2).reshape(B * T, H)
+        o = F.scaled_dot_product_attention(q, k, v, attn_mask=m, enable_gqa=nk != nq).transpose(1, 2).reshape(B * T, H)
         h1 = ops.linear_rows_epilogue(o, at.o_proj.weight, ops.EPI_RESIDUAL, bias=at.o_proj.bias, residual=x2)
         hn = ops.rmsnorm_rows(h1, self.post_attention_layernorm.weight, self.post_attention_layernorm.variance_epsilon)
         wg, bg = mlp._fused_gate_up()

@@ -496,7 +496,8 @@ int lantern_linear_rows(const void *A, const void *W, const void *bias, int M, i
  *  - lantern_rmsnorm_rows: ChameleonRMSNorm (:209-223) of M bf16 rows
  *  - lantern_qk_norm_rope: the head stage of ChameleonAttention (:481-499) on the fused q/k/v projection [B*T, (nq + 2 nk) d]: per-head
  *    ChameleonLayerNorm (:375-396; weights [model_parallel, d]), rotary at position_ids [B, T] from cos / sin tables [table_rows, d] bf16,
- *    outputs q [B, nq, T, d], k / v [B, nk, T, d] bf16 (d = 64 or 128). */
+ *    outputs q [B, nq, T, d] and k / v written at rows [kv_row0, kv_row0 + T) of [B, nk, kv_rows, d] buffers, bf16 (d = 64 or 128): kv_rows = T,
+ *    kv_row0 = 0 for fresh tensors, or a preallocated cache appended in place (no torch.cat of the whole cache per call). */
 #define LANTERN_EPI_RESIDUAL 1
 #define LANTERN_EPI_SILU_MUL 2
 int lantern_linear_rows_epilogue(const void *A, const void *W, const void *bias, int M, int K, int row_lo, int n_rows, void *out,
@@ -504,7 +505,8 @@ int lantern_linear_rows_epilogue(const void *A, const void *W, const void *bias,
 int lantern_rmsnorm_rows(const void *x, const void *weight, int M, int H, float eps, void *out, void *stream);
 int lantern_qk_norm_rope(const void *qkv, int B, int T, int n_q_heads, int n_kv_heads, int head_dim, const void *q_weight, const void *q_bias,
                          const void *k_weight, const void *k_bias, int model_parallel, const void *cos_table, const void *sin_table,
-                         int table_rows, const int64_t *position_ids, void *q_out, void *k_out, void *v_out, void *stream);
+                         int table_rows, const int64_t *position_ids, void *q_out, void *k_out, void *v_out, int kv_rows, int kv_row0,
+                         void *stream);
 
 /* 8f-2 (next row, second half)  One drafter expansion depth from the hidden states to the top-k in two small launches, the head's
  * logits never in HBM:  head(hidden) restricted to the id window the model's mask lets through -> CFG combination in the GEMM's

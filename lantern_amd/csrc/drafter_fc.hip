@@ -290,7 +290,7 @@ __global__ __launch_bounds__(64) void qk_norm_rope_kernel(const uint16_t *__rest
                                                           const uint16_t *__restrict__ qb, const uint16_t *__restrict__ kw, const uint16_t *__restrict__ kb,
                                                           int q_heads_per_mp, int k_heads_per_mp, const uint16_t *__restrict__ cos_t,
                                                           const uint16_t *__restrict__ sin_t, const int64_t *__restrict__ pos, uint16_t *__restrict__ q_out,
-                                                          uint16_t *__restrict__ k_out, uint16_t *__restrict__ v_out) {
+                                                          uint16_t *__restrict__ k_out, uint16_t *__restrict__ v_out, int kv_rows, int kv_row0, int table_rows) {
     constexpr int E = D / 64;
     const int tok = blockIdx.x, head = blockIdx.y, lane = threadIdx.x;          // head in [0, nq + 2 nk)
     const int b = tok / T, t = tok % T;
@@ -300,7 +300,7 @@ __global__ __launch_bounds__(64) void qk_norm_rope_kernel(const uint16_t *__rest
     for (int e = 0; e < E; ++e) v[e] = bf16_bits_to_f32(src[lane + 64 * e]);
     if (head >= nq + nk) {          // V: layout only
         const int hv = head - nq - nk;
-        uint16_t *dst = v_out + (((size_t)b * nk + hv) * T + t) * D;
+        uint16_t *dst = v_out + (((size_t)b * nk + hv) * kv_rows + kv_row0 + t) * D;
 #pragma unroll
         for (int e = 0; e < E; ++e) dst[lane + 64 * e] = src[lane + 64 * e];
         return;
@@ -328,9 +328,10 @@ __global__ __launch_bounds__(64) void qk_norm_rope_kernel(const uint16_t *__rest
         n[e] = bf16_bits_to_f32(f32_to_bf16_rne(sc + bf16_bits_to_f32(gb[lane + 64 * e])));
     }
     // rotary: x * cos + rotate_half(x) * sin, rotate_half(x)[i] = -x[i + d/2] (i < d/2), x[i - d/2] otherwise; every product and the sum in bf16
-    const int64_t p = pos[(size_t)b * T + t];
+    int64_t p = pos[(size_t)b * T + t];
+    p = p < 0 ? 0 : (p >= table_rows ? table_rows - 1 : p);          // (the reference would raise on a position beyond its tables; never read outside ours)
     const uint16_t *cr = cos_t + (size_t)p * D, *sr = sin_t + (size_t)p * D;
-    uint16_t *dst = (is_q ? q_out + (((size_t)b * nq + hh) * T + t) * D : k_out + (((size_t)b * nk + hh) * T + t) * D);
+    uint16_t *dst = (is_q ? q_out + (((size_t)b * nq + hh) * T + t) * D : k_out + (((size_t)b * nk + hh) * kv_rows + kv_row0 + t) * D);
 #pragma unroll
     for (int e = 0; e < E; ++e) {
         const int i = lane + 64 * e;
@@ -518,19 +519,20 @@ extern "C" int lantern_rmsnorm_rows(const void *x, const void *weight, int M, in
 
 extern "C" int lantern_qk_norm_rope(const void *qkv, int B, int T, int n_q_heads, int n_kv_heads, int head_dim, const void *q_weight, const void *q_bias,
                                     const void *k_weight, const void *k_bias, int model_parallel, const void *cos_table, const void *sin_table,
-                                    int table_rows, const int64_t *position_ids, void *q_out, void *k_out, void *v_out, void *stream) {
+                                    int table_rows, const int64_t *position_ids, void *q_out, void *k_out, void *v_out, int kv_rows, int kv_row0,
+                                    void *stream) {
     LANTERN_CHECK_ARG(qkv && q_weight && q_bias && k_weight && k_bias && cos_table && sin_table && position_ids && q_out && k_out && v_out,
                       "qk_norm_rope: null buffer");
     LANTERN_CHECK_ARG(B >= 0 && T >= 0 && n_q_heads > 0 && n_kv_heads > 0 && model_parallel > 0 && n_q_heads % model_parallel == 0 &&
-                          n_kv_heads % model_parallel == 0 && table_rows > 0,
-                      "qk_norm_rope: bad sizes");
+                          n_kv_heads % model_parallel == 0 && table_rows > 0 && kv_row0 >= 0 && kv_rows >= kv_row0 + T,
+                      "qk_norm_rope: bad sizes (k / v are [B, nk, kv_rows, d] slabs written at rows kv_row0 .. kv_row0 + T)");
     LANTERN_CHECK_ARG(head_dim == 128 || head_dim == 64, "qk_norm_rope: head_dim %d (64 or 128)", head_dim);
     if (B * T == 0) return LANTERN_OK;
     dim3 grid(B * T, n_q_heads + 2 * n_kv_heads);
 #define QKNR(D_) LANTERN_LAUNCH((qk_norm_rope_kernel<D_>), grid, dim3(64), 0, (hipStream_t)stream, (const uint16_t *)qkv, T, n_q_heads, n_kv_heads,     \
                                 (const uint16_t *)q_weight, (const uint16_t *)q_bias, (const uint16_t *)k_weight, (const uint16_t *)k_bias,                 \
                                 n_q_heads / model_parallel, n_kv_heads / model_parallel, (const uint16_t *)cos_table, (const uint16_t *)sin_table,           \
-                                position_ids, (uint16_t *)q_out, (uint16_t *)k_out, (uint16_t *)v_out)
+                                position_ids, (uint16_t *)q_out, (uint16_t *)k_out, (uint16_t *)v_out, kv_rows, kv_row0, table_rows)
     if (head_dim == 128) QKNR(128);
     else QKNR(64);
 #undef QKNR

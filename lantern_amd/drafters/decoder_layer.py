@@ -216,9 +216,18 @@ class DecoderLayer(nn.Module):
         qkv = ops.linear_rows(xn, w, 0, w.shape[0], bias=b)
         kv_len = T + (past_key_value[0].shape[-2] if past_key_value is not None else 0)
         cos, sin = at.rotary_emb.tables_bf16(x.device, kv_len)
-        q, k, v = ops.qk_norm_rope(qkv, B, T, nq, nk, d, at.q_norm.weight, at.q_norm.bias, at.k_norm.weight, at.k_norm.bias, cos, sin, position_ids)
-        if past_key_value is not None:
-            k, v = torch.cat([past_key_value[0], k], dim=2), torch.cat([past_key_value[1], v], dim=2)
+        past = 0 if past_key_value is None else past_key_value[0].shape[-2]
+        if self.inplace_cache and use_cache:
+            # the cache lives in a slab of this layer and grows in place: `present` is a view of it; a `past` that is such a view (what the
+            # drafter hands back: the previous call's present, or a shorter prefix of it after a rollback) costs no copy at all
+            ks, vs = self._cache_slab(B, nk, d, kv_len, x.device, past_key_value)
+            q, _, _ = ops.qk_norm_rope(qkv, B, T, nq, nk, d, at.q_norm.weight, at.q_norm.bias, at.k_norm.weight, at.k_norm.bias, cos, sin, position_ids,
+                                       k_slab=ks, v_slab=vs, row0=past)
+            k, v = ks[:, :, :kv_len], vs[:, :, :kv_len]
+        else:
+            q, k, v = ops.qk_norm_rope(qkv, B, T, nq, nk, d, at.q_norm.weight, at.q_norm.bias, at.k_norm.weight, at.k_norm.bias, cos, sin, position_ids)
+            if past_key_value is not None:
+                k, v = torch.cat([past_key_value[0], k], dim=2), torch.cat([past_key_value[1], v], dim=2)
         present = (k, v) if use_cache else None
         # (a hand-written LDS-score attention kernel for this shape was measured at 156 us against 61 us for torch's fused attention: dropped)
         m = None if attention_mask is None else attention_mask[:, :, :, :kv_len].to(q.dtype)
@@ -236,6 +245,25 @@ class DecoderLayer(nn.Module):
         return (self.fused and not output_attentions and x.dim() == 3 and x.shape[0] * x.shape[1] <= 32 and _hip_ok(x, at.q_proj.weight)
                 and at.head_dim in (64, 128) and position_ids is not None and self.mlp.act_fn is F.silu
                 and self.input_layernorm.weight.dtype == torch.bfloat16 and at.q_norm.weight.dtype == torch.bfloat16)
+
+    inplace_cache = False          # True: `present` is a growing view of a layer-owned slab (no torch.cat of the whole cache per call).  Only for callers
+                                   # that, like the drafter, never use an OLDER, LONGER cache again after appending to a shorter prefix of it.
+
+    def _cache_slab(self, B, nk, d, need, device, past):
+        s = getattr(self, "_slab", None)
+        mine = (s is not None and past is not None and past[0].data_ptr() == s[0].data_ptr() and past[1].data_ptr() == s[1].data_ptr()
+                and past[0].shape[0] == B and past[0].stride() == s[0][:, :, :past[0].shape[2]].stride())
+        if s is None or s[0].shape[0] != B or s[0].shape[2] < need or s[0].device != device:
+            cap = max(256, 1 << (need - 1).bit_length())
+            ns = (torch.empty((B, nk, cap, d), dtype=torch.bfloat16, device=device), torch.empty((B, nk, cap, d), dtype=torch.bfloat16, device=device))
+            if past is not None:
+                ns[0][:, :, :past[0].shape[2]].copy_(past[0])
+                ns[1][:, :, :past[1].shape[2]].copy_(past[1])
+            self._slab = s = ns
+        elif past is not None and not mine:          # a cache that is not (a prefix of) the slab: bring it in once
+            s[0][:, :, :past[0].shape[2]].copy_(past[0])
+            s[1][:, :, :past[1].shape[2]].copy_(past[1])
+        return s
 
     fused = True          # False: every projection its own launch through skinny_linear / torch (the composition the fast path is tested against)
 

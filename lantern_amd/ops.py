@@ -653,18 +653,23 @@ def rmsnorm_rows(x, weight, eps: float):
     return out
 
 
-def qk_norm_rope(qkv, B: int, T: int, nq: int, nk: int, d: int, qw, qb, kw, kb, cos, sin, position_ids):
-    """Head stage of the drafter's attention on the fused projection qkv [B*T, (nq + 2 nk) d]: -> q [B,nq,T,d], k / v [B,nk,T,d] (bf16)."""
+def qk_norm_rope(qkv, B: int, T: int, nq: int, nk: int, d: int, qw, qb, kw, kb, cos, sin, position_ids, k_slab=None, v_slab=None, row0: int = 0):
+    """Head stage of the drafter's attention on the fused projection qkv [B*T, (nq + 2 nk) d]: -> q [B,nq,T,d], k / v [B,nk,T,d] (bf16), or --
+    k_slab / v_slab [B, nk, rows, d] given -- k / v written in place at rows [row0, row0 + T) of the slabs (returned as they are)."""
     dev = qkv.device
     q = torch.empty((B, nq, T, d), dtype=torch.bfloat16, device=dev)
-    k = torch.empty((B, nk, T, d), dtype=torch.bfloat16, device=dev)
-    v = torch.empty((B, nk, T, d), dtype=torch.bfloat16, device=dev)
+    if k_slab is None:
+        k_slab = torch.empty((B, nk, T, d), dtype=torch.bfloat16, device=dev)
+        v_slab = torch.empty((B, nk, T, d), dtype=torch.bfloat16, device=dev)
+        row0 = 0
+    assert k_slab.is_contiguous() and v_slab.is_contiguous() and k_slab.shape == v_slab.shape and k_slab.shape[0] == B and k_slab.shape[1] == nk
     pos = position_ids.to(torch.int64).contiguous()
     check(_lib.lib().lantern_qk_norm_rope(C.c_void_p(qkv.contiguous().data_ptr()), B, T, nq, nk, d, C.c_void_p(qw.contiguous().data_ptr()),
                                           C.c_void_p(qb.contiguous().data_ptr()), C.c_void_p(kw.contiguous().data_ptr()), C.c_void_p(kb.contiguous().data_ptr()),
                                           qw.shape[0], C.c_void_p(cos.data_ptr()), C.c_void_p(sin.data_ptr()), cos.shape[0], C.c_void_p(pos.data_ptr()),
-                                          C.c_void_p(q.data_ptr()), C.c_void_p(k.data_ptr()), C.c_void_p(v.data_ptr()), _stream()), "qk_norm_rope")
-    return q, k, v
+                                          C.c_void_p(q.data_ptr()), C.c_void_p(k_slab.data_ptr()), C.c_void_p(v_slab.data_ptr()), k_slab.shape[2], row0,
+                                          _stream()), "qk_norm_rope")
+    return q, k_slab, v_slab
 
 
 def head_expand(A, weight, row_lo: int, n_cols: int, cfg: float, bias=None, model: int = MODEL_LUMINA, pos_ids=None, pos_base: int = 2,

@@ -91,3 +91,46 @@ def test_layer_hip_path_matches_the_reference_layer_bf16(name, fused, monkeypatc
         t1, _ = layer(g(name, "x1", dev, bf), attention_mask=g(name, "m1", dev), position_ids=g(name, "pos1", dev), past_key_value=tkv0, use_cache=True)
     np.testing.assert_allclose(y0.float().cpu().numpy(), t0.float().cpu().numpy(), rtol=2e-2, atol=2e-2)
     np.testing.assert_allclose(y1.float().cpu().numpy(), t1.float().cpu().numpy(), rtol=2e-2, atol=2e-2)
+
+
+@pytest.mark.gpu
+def test_layer_inplace_cache_equals_the_concatenated_cache():
+    """inplace_cache: `present` is a growing view of a layer-owned slab.  The drafter's pattern -- prefix forward, several depth calls that
+    each extend the previous present, then a new cycle from the SHORTER prefix cache -- gives bit-identical outputs to the torch.cat cache,
+    through a slab reallocation (capacity 256 -> 512) and an external (non-slab) cache handed in."""
+    name = "hd64_gqa"
+    dev, bf = torch.device("cuda"), torch.bfloat16
+    outs = []
+    for inplace in (False, True):
+        torch.manual_seed(3)
+        layer = build(name, dev, bf)
+        layer.inplace_cache = inplace
+        H = layer.hidden_size
+        res = []
+
+        def call(T, past, pos0):
+            x = torch.randn(2, T, H, device=dev, dtype=bf)
+            L = 0 if past is None else past[0].shape[2]
+            pos = (pos0 + torch.arange(T, device=dev))[None].expand(2, T).contiguous()
+            m = torch.zeros(2, 1, T, L + T, device=dev)
+            m[:, :, :, L:] = torch.full((T, T), torch.finfo(torch.float32).min, device=dev).triu(1)
+            with torch.no_grad():
+                y, kv = layer(x, attention_mask=m, position_ids=pos, past_key_value=past, use_cache=True)
+            res.append(y.clone())
+            return kv
+        stable = call(30, None, 0)                      # prefix
+        kv = stable
+        for d in range(4):                              # depth calls extend the previous present
+            kv = call(10, kv, 30 + d)
+        res.append(kv[0].clone()); res.append(kv[1].clone())
+        stable2 = call(3, stable, 30)                   # next cycle: from the shorter prefix (tree rows are overwritten)
+        kv = stable2
+        for d in range(25):                             # grows past 256 rows: the slab is reallocated
+            kv = call(10, kv, 33 + d)
+        ext = (kv[0].clone(), kv[1].clone())            # a cache that is not the slab
+        call(5, ext, 283)
+        res.append(kv[0].clone())
+        outs.append(res)
+    assert len(outs[0]) == len(outs[1])
+    for i, (a, b) in enumerate(zip(*outs)):
+        assert torch.equal(a, b), (i, float((a.float() - b.float()).abs().max()))

@@ -502,6 +502,10 @@ int lantern_linear_rows(const void *A, const void *W, const void *bias, int M, i
 #define LANTERN_EPI_SILU_MUL 2
 int lantern_linear_rows_epilogue(const void *A, const void *W, const void *bias, int M, int K, int row_lo, int n_rows, void *out,
                                  int out_stride, int out_col0, int epilogue, const void *aux, int aux_stride, int pair_rows, void *stream);
+/* The same product for narrow outputs, K split over `ksplit` workgroups per 32-column tile (o_proj / down_proj have 128 tiles for 256 CUs):
+ * out = bf16(A W^T + bias) (+ residual, rounded again); workspace [dev] ksplit * M * n_rows floats; two launches, deterministic sums. */
+int lantern_linear_rows_splitk(const void *A, const void *W, const void *bias, int M, int K, int n_rows, void *out, int out_stride,
+                               const void *residual, int residual_stride, int ksplit, float *workspace, void *stream);
 int lantern_rmsnorm_rows(const void *x, const void *weight, int M, int H, float eps, void *out, void *stream);
 int lantern_qk_norm_rope(const void *qkv, int B, int T, int n_q_heads, int n_kv_heads, int head_dim, const void *q_weight, const void *q_bias,
                          const void *k_weight, const void *k_bias, int model_parallel, const void *cos_table, const void *sin_table,

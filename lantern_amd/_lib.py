@@ -124,5 +124,5 @@ EXPORTS = [
     "lantern_tree_attention_workspace", "lantern_tree_attention",
     "lantern_tree_node_tables_size", "lantern_tree_node_tables", "lantern_evaluate_posterior_nodes_workspace",
     "lantern_evaluate_posterior_nodes", "lantern_verify_step", "lantern_gather_candidates_dynamic", "lantern_head_expand_workspace", "lantern_head_expand", "lantern_prepare_step",
-    "lantern_verify_accept_workspace", "lantern_verify_accept", "lantern_linear_rows_epilogue", "lantern_rmsnorm_rows", "lantern_qk_norm_rope", "lantern_step_launcher_create", "lantern_step_launcher_submit", "lantern_step_launcher_wait", "lantern_step_launcher_destroy",
+    "lantern_verify_accept_workspace", "lantern_verify_accept", "lantern_linear_rows_epilogue", "lantern_linear_rows_splitk", "lantern_rmsnorm_rows", "lantern_qk_norm_rope", "lantern_step_launcher_create", "lantern_step_launcher_submit", "lantern_step_launcher_wait", "lantern_step_launcher_destroy",
 ]

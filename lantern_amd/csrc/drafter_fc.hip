@@ -489,6 +489,87 @@ extern "C" int lantern_drafter_fc(const int64_t *ids, const void *hidden, const 
     return LANTERN_OK;
 }
 
+// Split-K form for narrow outputs (o_proj / down_proj: 4096 columns = 128 workgroups of 32 columns on 256 CUs, each streaming 0.25 - 0.7 MB
+// alone): grid (column tiles, ksplit), workgroup (x, y) contracts K slice y of its 32 columns into workspace[y][M][n_rows] (f32, plain
+// stores: every element has one writer), then a small pass adds the slices in order, the bias, the residual -- deterministic.
+__global__ __launch_bounds__(FC_THREADS) void linear_rows_splitk_kernel(const uint16_t *__restrict__ A, const uint16_t *__restrict__ Wt, int M, int K,
+                                                                        int n_rows, int ksplit, float *__restrict__ ws) {
+    __shared__ float tile[32][33];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int n0 = blockIdx.x * 32, ky = blockIdx.y;
+    for (int t = tid; t < 32 * 33; t += FC_THREADS) (&tile[0][0])[t] = 0.0f;
+    const int ksteps = K / 16;
+    const int kb0 = (int)((long long)ksteps * ky / ksplit), kb1 = (int)((long long)ksteps * (ky + 1) / ksplit), kn = kb1 - kb0;
+    const int ks0 = kb0 + (int)((long long)kn * wave / FC_WAVES), ks1 = kb0 + (int)((long long)kn * (wave + 1) / FC_WAVES);
+    const int ncol = n0 + r;
+    const uint16_t *wrow = Wt + (size_t)(ncol < n_rows ? ncol : n_rows - 1) * K;
+    const bool live = r < M;
+    const uint16_t *arow = A + (size_t)(live ? r : 0) * K;
+    f32x16_t acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+    const bf16x8_t zero = __builtin_bit_cast(bf16x8_t, make_uint4(0, 0, 0, 0));
+    int ks = ks0;
+    for (; ks + 3 < ks1; ks += 4) {
+        const int kb = ks * 16 + 32 * h;
+        bf16x8_t bw[4], aw[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) bw[q] = load_frag(wrow + kb + 8 * q);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) aw[q] = live ? load_frag(arow + kb + 8 * q) : zero;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aw[q], bw[q], acc, 0, 0, 0);
+    }
+    for (; ks < ks1; ++ks) {
+        const int k0 = ks * 16 + 8 * h;
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(live ? load_frag(arow + k0) : zero, load_frag(wrow + k0), acc, 0, 0, 0);
+    }
+    for (int w = 0; w < FC_WAVES; ++w) {
+        __syncthreads();
+        if (wave == w) {
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) tile[(reg & 3) + 8 * (reg >> 2) + 4 * h][r] += acc[reg];
+        }
+    }
+    __syncthreads();
+    for (int t = tid; t < 32 * 32; t += FC_THREADS) {
+        const int row = t / 32, col = t % 32, n = n0 + col;
+        if (row < M && n < n_rows) ws[((size_t)ky * M + row) * n_rows + n] = tile[row][col];
+    }
+}
+
+__global__ __launch_bounds__(256) void linear_rows_splitk_finish_kernel(const float *__restrict__ ws, const uint16_t *__restrict__ bias,
+                                                                        const uint16_t *__restrict__ residual, int residual_stride, int M, int n_rows,
+                                                                        int ksplit, uint16_t *__restrict__ out, int out_stride) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= M * n_rows) return;
+    const int m = i / n_rows, n = i % n_rows;
+    float v = 0.0f;
+    for (int y = 0; y < ksplit; ++y) v += ws[((size_t)y * M + m) * n_rows + n];
+    if (bias) v += bf16_bits_to_f32(bias[n]);
+    uint16_t o = f32_to_bf16_rne(v);
+    if (residual) o = f32_to_bf16_rne(bf16_bits_to_f32(residual[(size_t)m * residual_stride + n]) + bf16_bits_to_f32(o));
+    out[(size_t)m * out_stride + n] = o;
+}
+
+extern "C" int lantern_linear_rows_splitk(const void *A, const void *W, const void *bias, int M, int K, int n_rows, void *out, int out_stride,
+                                          const void *residual, int residual_stride, int ksplit, float *workspace, void *stream) {
+    LANTERN_CHECK_ARG(A && W && out && workspace, "linear_rows_splitk: null buffer");
+    LANTERN_CHECK_ARG(M >= 0 && M <= 32 && K > 0 && K % 16 == 0 && n_rows >= 0 && out_stride >= n_rows && ksplit >= 1 && ksplit <= 16 && K / 16 >= ksplit,
+                      "linear_rows_splitk: M=%d <= 32, K=%d %% 16 == 0, 1 <= ksplit=%d <= 16", M, K, ksplit);
+    if (residual) LANTERN_CHECK_ARG(residual_stride >= n_rows, "linear_rows_splitk: residual [M, stride >= n_rows]");
+    if (M == 0 || n_rows == 0) return LANTERN_OK;
+    hipStream_t st = (hipStream_t)stream;
+    LANTERN_LAUNCH(linear_rows_splitk_kernel, dim3((n_rows + 31) / 32, ksplit), dim3(FC_THREADS), 0, st, (const uint16_t *)A, (const uint16_t *)W, M, K,
+                   n_rows, ksplit, workspace);
+    LANTERN_CHECK_LAUNCH("linear_rows_splitk");
+    hipLaunchKernelGGL(linear_rows_splitk_finish_kernel, dim3((M * n_rows + 255) / 256), dim3(256), 0, st, (const float *)workspace,
+                       (const uint16_t *)bias, (const uint16_t *)residual, residual_stride, M, n_rows, ksplit, (uint16_t *)out, out_stride);
+    LANTERN_CHECK_LAUNCH("linear_rows_splitk_finish");
+    return LANTERN_OK;
+}
+
 extern "C" int lantern_linear_rows_epilogue(const void *A, const void *W, const void *bias, int M, int K, int row_lo, int n_rows, void *out,
                                             int out_stride, int out_col0, int epilogue, const void *aux, int aux_stride, int pair_rows, void *stream) {
     LANTERN_CHECK_ARG(A && W && out, "linear_rows_epilogue: null buffer");

@@ -205,8 +205,8 @@ class DecoderLayer(nn.Module):
         self.post_attention_layernorm = RMSNorm(config.hidden_size, eps)
 
     def _fast(self, x, attention_mask, position_ids, past_key_value, use_cache):
-        """Decode shape on the device (<= 32 bf16 rows): ten launches -- rmsnorm, fused q/k/v GEMM, head norm + rotary, the two cache concats,
-        one attention call, o_proj + residual, rmsnorm, gate/up GEMM with silu * up in its epilogue, down_proj + residual."""
+        """Decode shape on the device (<= 32 bf16 rows): rmsnorm, fused q/k/v GEMM, head norm + rotary (+ cache append), one attention call,
+        o_proj (split-K) + residual, rmsnorm, gate/up GEMM with silu * up in its epilogue, down_proj (split-K) + residual."""
         at, mlp = self.self_attn, self.mlp
         B, T, H = x.shape
         nq, nk, d = at.num_heads, at.num_key_value_heads, at.head_dim
@@ -232,12 +232,12 @@ class DecoderLayer(nn.Module):
         # (a hand-written LDS-score attention kernel for this shape was measured at 156 us against 61 us for torch's fused attention: dropped)
         m = None if attention_mask is None else attention_mask[:, :, :, :kv_len].to(q.dtype)
         o = F.scaled_dot_product_attention(q, k, v, attn_mask=m, enable_gqa=nk != nq).transpose(1, 2).reshape(B * T, H)
-        h1 = ops.linear_rows_epilogue(o, at.o_proj.weight, ops.EPI_RESIDUAL, bias=at.o_proj.bias, residual=x2)
+        h1 = ops.linear_rows_splitk(o, at.o_proj.weight, bias=at.o_proj.bias, residual=x2)          # 128 column tiles: K split to fill the GPU
         hn = ops.rmsnorm_rows(h1, self.post_attention_layernorm.weight, self.post_attention_layernorm.variance_epsilon)
         wg, bg = mlp._fused_gate_up()
         inter = mlp.gate_proj.out_features
         act = ops.linear_rows_epilogue(hn, wg, ops.EPI_SILU_MUL, bias=bg, pair_rows=inter)
-        out = ops.linear_rows_epilogue(act, mlp.down_proj.weight, ops.EPI_RESIDUAL, bias=mlp.down_proj.bias, residual=h1)
+        out = ops.linear_rows_splitk(act, mlp.down_proj.weight, bias=mlp.down_proj.bias, residual=h1)
         return out.reshape(B, T, H), present
 
     def _fast_ok(self, x, position_ids, output_attentions):

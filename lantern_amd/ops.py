@@ -644,6 +644,22 @@ def linear_rows_epilogue(A, weight, epilogue: int, n_rows: Optional[int] = None,
     return out
 
 
+def linear_rows_splitk(A, weight, bias=None, residual=None, ksplit: int = 0):
+    """A [M <= 32, K] bf16 @ weight.T (+ bias) (+ residual) with K split over `ksplit` workgroups per column tile (0: enough to fill 256 CUs)."""
+    A, weight = A.contiguous(), weight.contiguous()
+    M, K = A.shape
+    N = weight.shape[0]
+    if ksplit <= 0:
+        ksplit = max(1, min(8, -(-256 // (-(-N // 32)))))
+    ws = torch.empty((ksplit, M, N), dtype=torch.float32, device=A.device)
+    out = torch.empty((M, N), dtype=torch.bfloat16, device=A.device)
+    r = None if residual is None else residual.contiguous()
+    b = None if bias is None else bias.contiguous()
+    check(_lib.lib().lantern_linear_rows_splitk(C.c_void_p(A.data_ptr()), C.c_void_p(weight.data_ptr()), C.c_void_p(_ptr(b)), M, K, N, C.c_void_p(out.data_ptr()), N,
+                                                C.c_void_p(_ptr(r)), 0 if r is None else r.shape[1], ksplit, C.c_void_p(ws.data_ptr()), _stream()), "linear_rows_splitk")
+    return out
+
+
 def rmsnorm_rows(x, weight, eps: float):
     """ChameleonRMSNorm of bf16 rows [M, H] (lantern_rmsnorm_rows)."""
     x, weight = x.contiguous(), weight.contiguous()

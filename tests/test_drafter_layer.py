@@ -67,7 +67,7 @@ def test_layer_hip_path_matches_the_reference_layer_bf16(name, fused, monkeypatc
     gate-up with silu * up / down + residual kernels (head_dim 64 or 128); per_projection: the skinny GEMM under torch's element-wise ops."""
     from lantern_amd import ops
     calls = []
-    for fn in ("linear_rows", "linear_rows_epilogue", "rmsnorm_rows", "qk_norm_rope"):
+    for fn in ("linear_rows", "linear_rows_epilogue", "linear_rows_splitk", "rmsnorm_rows", "qk_norm_rope"):
         real = getattr(ops, fn)
         monkeypatch.setattr(ops, fn, (lambda real, fn: (lambda *a, **kw: (calls.append(fn), real(*a, **kw))[1]))(real, fn))
     dev = torch.device("cuda")
@@ -79,7 +79,8 @@ def test_layer_hip_path_matches_the_reference_layer_bf16(name, fused, monkeypatc
         y1, kv1 = layer(g(name, "x1", dev, bf), attention_mask=g(name, "m1", dev), position_ids=g(name, "pos1", dev), past_key_value=kv0, use_cache=True)
     head_dim = layer.self_attn.head_dim
     if fused and head_dim in (64, 128):
-        assert calls.count("qk_norm_rope") == 2 and calls.count("rmsnorm_rows") == 4 and calls.count("linear_rows_epilogue") == 6 and calls.count("linear_rows") == 2, calls
+        assert (calls.count("qk_norm_rope") == 2 and calls.count("rmsnorm_rows") == 4 and calls.count("linear_rows_epilogue") == 2 and
+                calls.count("linear_rows_splitk") == 4 and calls.count("linear_rows") == 2), calls
     else:
         assert calls.count("linear_rows") == 8 and "qk_norm_rope" not in calls, calls          # fused qkv, o_proj, fused gate/up, down_proj per call
     for got, key in ((y0, "y0"), (y1, "y1"), (kv1[0], "k1"), (kv1[1], "v1")):

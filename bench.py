@@ -2,31 +2,32 @@
 """bench.py -- accepted image-tokens/s of the LANTERN verify/accept hot path on MI355X.
 
 Contract (driver):  python bench.py --gpus N --steps K --warmup W
-  N>1 is launched by torch.distributed.run, one rank per GPU; ranks verify DISJOINT sequences with
-  no collective on the accept path (the only torch.distributed calls are the timing barrier and the
-  max/sum of the per-rank timing scalars the contract asks for).  Weak scaling: per-GPU work fixed.
+  N>1: one rank per GPU, launched by torch.distributed.run (ranks from the environment) or, when that environment is absent, by
+  bench.py itself (spawn_ranks).  Ranks verify DISJOINT sequences with no collective on the accept path (the only torch.distributed
+  calls are the timing barrier and the max/sum of the per-rank timing scalars the contract asks for).  Weak scaling: per-GPU work fixed.
 
-Workload = BASELINE.json config C3 (Lumina-mGPT-7B-768 + LANTERN relaxed accept, k=1000,
-delta=0.1, static tree mc_sim_7b_63) on synthetic 768x768 image-token sequences: a "step" is one
-verify step (O6 -> O7 -> O8 -> O9 -> O10) over the --seqs-per-gpu sequences resident on the GPU;
-inputs are HBM-resident before the timed region.  `value` = accepted tokens of all ranks / max-over-
-ranks wall time.
+Workload = BASELINE.json config C3 (Lumina-mGPT-7B-768 + LANTERN relaxed accept, k=1000, delta=0.1, static tree mc_sim_7b_63) on
+synthetic 768x768 image-token sequences: a "step" is one verify step (O6 -> O7 -> O8 -> O9 -> O10) over the --seqs-per-gpu sequences
+resident on the GPU; inputs are HBM-resident before the timed region.  `value` = accepted tokens of all ranks / max-over-ranks wall time.
+Default launch: 3 stream groups, one lantern_verify_step call per step, per group  prepare_step (O6 + the 3 most likely rows of O7) ->
+evaluate_posterior_window on raw bf16 rows (O8 + the rest of O7, on demand) -> update_inference_inputs (O9 + O10).
+`--groups 1 --no-fuse-o7 --spec-rows 0` is the four-launch step (every row through cfg_mask_topk first).
 
 Extra objects on the JSON line:
-  roofline      evaluate_posterior: algorithmic bytes (SURVEY 8d contract formula, from the kernel's
-                own counters) / its mean launch duration measured with HIP events on the launch stream
-                inside the timed region; peak 8000 GB/s.
-  kernels       the same for cfg_mask_topk and kv_gather.
-  ep_batch_sweep
-                evaluate_posterior alone over {1, 8, 64, 256, 512, 4096} sequences per launch, chain and node-parallel kernels,
-                measured after the timed region (KV slabs released first).  `frac` there = bytes really moved / time / 8 TB/s.
+  roofline      evaluate_posterior of the timed configuration: algorithmic bytes (SURVEY 8d contract formula, from the kernel's own
+                counters) / its mean launch duration (HIP events recorded by the launch itself); peak 8000 GB/s.  `windowed_kernel`: the bytes
+                the windowed design really has to move; `traffic`: PMC bytes from profiles/r02_ep_traffic.json.
+  kernels       the same for the row post-process launch (prepare_step / cfg_mask_topk) and update_inference_inputs.
+  per_kernel_single_group  one stream, every stage its own launch: each kernel against its SURVEY 8d roofline at the full 64-sequence
+                launch size, with the chain, node-parallel and serial-node evaluate_posterior.
+  ep_batch_sweep  evaluate_posterior alone over {1, 8, 64, 256, 512, 4096} sequences per launch (three forms), after the timed region.
+                `frac` there = bytes really moved / time / 8 TB/s.
   lambda_mode   the same loop with lantern_delta = 5 (LANTERN++: tau = 4 p(x)), BASELINE.md run B.
-  step_latency_us  whole-step wall time at 1 and 8 sequences (the reference's own batch is 1), both evaluate_posterior forms.
-  per_kernel_single_group  one stream group, every stage its own launch: each kernel against its SURVEY 8d roofline at the full
-                launch size (chain and node-parallel evaluate_posterior).
+  dynamic_tree  the EAGLE-2 half of C3 (a different 59-node tree per sequence and step), raw rows; and with O7 over all rows.
+  step_latency_us  whole-step wall time at 1 and 8 sequences (the reference's own batch is 1), three evaluate_posterior forms.
   other_groupings  the default kernels with 1 and 2 stream groups.
-  cpu_baseline  the oracle (C port of the reference path) timed on this host's cores over a bounded
-                sample of the same pools/uniforms; it must reproduce the GPU's accepted-token stream.
+  cpu_baseline  the oracle (C port of the reference path, pthreads) timed on this host's cores over a bounded sample of the same
+                pools / uniforms; it must reproduce the GPU's accepted-token stream.
 """
 import argparse
 import json

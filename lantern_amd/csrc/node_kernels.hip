@@ -69,107 +69,6 @@ struct EpnArgs {
     EpnStatic st;
 };
 
-// loads through the constant address space: uniform addresses become scalar loads (s_load), off the vector-memory queue.
-// Only for memory no kernel of the same launch writes (tables, candidates, the uniform stream, cursors).
-template <typename T>
-__device__ __forceinline__ T ldc(const T *p) {
-    return *(const __attribute__((address_space(4))) T *)(p);
-}
-
-__device__ __forceinline__ double rdlane(double v, int l) {
-    const long long bits = __double_as_longlong(v);
-    return __longlong_as_double(((long long)__builtin_amdgcn_readlane((int)(bits >> 32), l) << 32) |
-                                (unsigned int)__builtin_amdgcn_readlane((int)(bits & 0xffffffffll), l));
-}
-
-// Bonus token by inverse CDF in token-id order over the distribution in LDS (g = its window, + an optional (out_tok,
-// out_mass) pair outside it): smallest id whose cumulative f64 mass exceeds u * total; the last positive id if rounding
-// leaves none (lo_sample_inverse_cdf in the oracle).  Every thread takes 16 CONSECUTIVE ids, so one wave scan + the wave
-// totals locate the thread that holds the crossing; only that thread looks at single entries.
-template <int NT, int E4>
-__device__ __forceinline__ int bonus_draw_lds(const float *g, int W, int lo, int out_tok, float out_mass, double u, double *wtot,
-                                              int *bonus, int *redi, bool lazy = false, const FastDiv dgc = FastDiv(1.0f)) {
-    constexpr int NW = NT / 64, EPT = 4 * E4;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const bool out_before = out_tok >= 0 && out_tok < lo;
-    float4 p[E4];
-#pragma unroll
-    for (int j = 0; j < E4; ++j) {
-        const int e = tid * EPT + 4 * j;
-        p[j] = (e < W) ? *reinterpret_cast<const float4 *>(g + e) : make_float4(0.f, 0.f, 0.f, 0.f);
-        if (lazy) p[j] = dgc(p[j]);          // g holds an unnormalised residual (see epn_kernel)
-    }
-    double s = 0.0;
-#pragma unroll
-    for (int j = 0; j < E4; ++j) s += (double)p[j].x + (double)p[j].y + (double)p[j].z + (double)p[j].w;
-    const double inc = wave_scan_incl_dpp(s);
-    if (lane == 63) wtot[wave] = inc;
-    if (tid == 0) bonus[0] = 0x7fffffff;
-    __syncthreads();
-    double pre = 0.0, all = 0.0;
-#pragma unroll
-    for (int w = 0; w < NW; ++w) {
-        const double t = wtot[w];
-        pre += (w < wave) ? t : 0.0;
-        all += t;
-    }
-    const double front = out_before ? (double)out_mass : 0.0;
-    double total = front + all;
-    if (out_tok >= 0 && !out_before) total += (double)out_mass;
-    const double tgt = u * total;
-    const double excl = front + pre + (inc - s);
-    if (excl <= tgt && excl + s > tgt) {          // the crossing lies among this thread's ids
-        double acc = excl;
-        int found = 0x7fffffff;
-#pragma unroll
-        for (int j = 0; j < E4; ++j) {
-            const float v[4] = {p[j].x, p[j].y, p[j].z, p[j].w};
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                acc += (double)v[c];
-                found = min(found, (v[c] > 0.0f && acc > tgt) ? lo + tid * EPT + 4 * j + c : 0x7fffffff);
-            }
-        }
-        if (found != 0x7fffffff) atomicMin(bonus, found);
-    }
-    __syncthreads();
-    int token = bonus[0];
-    if (out_before && out_mass > 0.0f && (double)out_mass > tgt) token = out_tok;
-    if (token != 0x7fffffff) return token;
-    // rare tail (u ~ 1, rounding at a thread boundary, or the mass sits behind the window): the exhaustive search
-    int found = 0x7fffffff, last_pos = -1;
-    if (out_before && out_mass > 0.0f) last_pos = out_tok;
-    {
-        double acc = excl;
-#pragma unroll
-        for (int j = 0; j < E4; ++j) {
-            const float v[4] = {p[j].x, p[j].y, p[j].z, p[j].w};
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                acc += (double)v[c];
-                const bool pos = v[c] > 0.0f;
-                const int id = lo + tid * EPT + 4 * j + c;
-                last_pos = max(last_pos, pos ? id : -1);
-                found = min(found, (pos && acc > tgt) ? id : 0x7fffffff);
-            }
-        }
-    }
-    if (out_tok >= 0 && !out_before && out_mass > 0.0f) {
-        last_pos = max(last_pos, out_tok);
-        if (total > tgt) found = min(found, out_tok);
-    }
-    found = wave_min_i(found);
-    last_pos = wave_max_i(last_pos);
-    if (lane == 0) {
-        redi[wave] = found;
-        redi[16 + wave] = last_pos;
-    }
-    __syncthreads();
-    const int f = wave_min_i(lane < NW ? redi[lane] : 0x7fffffff);
-    const int l = wave_max_i(lane < NW ? redi[16 + lane] : -1);
-    return f != 0x7fffffff ? f : l;
-}
-
 #define EPN_STAMP(id)                                                                                                  \
     do {                                                                                                               \
         if (args.trace && threadIdx.x == 0 && tr_n < EN_TR - 1)                                                        \
@@ -1054,6 +953,9 @@ __global__ __launch_bounds__(NT) void epn_walk_kernel(const EpnArgs args) {
 
 using namespace lantern;
 
+int lantern_launch_fast_walk(const lantern_ep_params *prm, const lantern_ep_buffers *buf, const lantern_ep_window *win,
+                             const lantern_ep_nodes *nodes, void *stream);          // walk_kernel.hip
+
 // diagnosis: a device buffer of grid * 64 u64 that the NEXT node launches fill with phase stamps (tools/epn_trace.py); NULL disarms
 static unsigned long long *g_epn_trace = nullptr;
 extern "C" int lantern_debug_epn_trace(void *dev_buf) {
@@ -1095,7 +997,8 @@ extern "C" int lantern_evaluate_posterior_nodes(const lantern_ep_params *prm, co
         LANTERN_CHECK_ARG(buf->nn_table && p.k >= 1 && p.k <= p.table_cols && p.table_rows > 0, "evaluate_posterior_nodes: lantern needs nn_table, 1<=k<=cols");
     if (win->u_bonus) LANTERN_CHECK_ARG(win->token, "evaluate_posterior_nodes: u_bonus needs token");
     const int nz = (p.k + 1 < p.table_cols) ? p.k + 1 : p.table_cols;
-    if (win->rows_kind != LANTERN_ROWS_PROBS || (p.lantern && nz > EW_PF_K) || (p.top_p > 0.0f && p.top_p < 1.0f)) {
+    const bool fast_walk = nodes->serial == 2;          // walk_kernel.hip: its own shape rules (probability or raw bf16 rows)
+    if (!fast_walk && (win->rows_kind != LANTERN_ROWS_PROBS || (p.lantern && nz > EW_PF_K) || (p.top_p > 0.0f && p.top_p < 1.0f))) {
         set_error("evaluate_posterior_nodes: needs probability rows (LANTERN_ROWS_PROBS) and k + 1 <= %d: use evaluate_posterior_window", EW_PF_K);
         return LANTERN_E_UNSUPPORTED;
     }
@@ -1112,6 +1015,7 @@ extern "C" int lantern_evaluate_posterior_nodes(const lantern_ep_params *prm, co
         set_error("evaluate_posterior_nodes: a child's earlier-sibling list is not the list of children tried before it (tables[6] == 0): use evaluate_posterior_window");
         return LANTERN_E_UNSUPPORTED;
     }
+    if (fast_walk) return lantern_launch_fast_walk(prm, buf, win, nodes, stream);
     // leaves as workgroups of the node launch (their bonus token pre-drawn) while the launch is small; beyond ~2 workgroups per
     // compute-unit slot the walk kernel draws the one token a walk needs instead
     const int leaf_wgs = !win->u_bonus ? 0 : (nodes->leaf_workgroups >= 0 ? (nodes->leaf_workgroups != 0) : ((long)p.B * nodes->n_nodes <= 1024));

@@ -467,4 +467,180 @@ __device__ __forceinline__ float kth_largest_hist_bf16(const float4 (&r)[NV4], i
 }
 
 
+// ---- LANTERN_ROWS_RAW_BF16: the row arrives as the target model's raw cond / uncond logits (bf16) and the whole post-process
+// of tree_decoding (CFG combination, top-k threshold, softmax: ea_model_lumina_mgpt.py:597-607) runs HERE, for the rows the walk
+// actually visits -- 2.7 + 1 of a tree's 26 rows per step -- instead of for every row in a separate launch.  Same code as
+// cfg_window_bf16_kernel (same tile layout, same reductions), so the probabilities are the same bits.  The 16 row registers
+// carry two 16-byte chunks of cond and two of uncond per thread until they are needed.
+template <int NT>
+__device__ __forceinline__ void raw_row_load(const uint16_t *__restrict__ crow, const uint16_t *__restrict__ urow, float4 (&rp)[4]) {
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int ch = threadIdx.x + it * NT;
+        const Bf16x8 c = *reinterpret_cast<const Bf16x8 *>(crow + ch * 8), u = *reinterpret_cast<const Bf16x8 *>(urow + ch * 8);
+        rp[it] = make_float4(__uint_as_float(c.a.x), __uint_as_float(c.a.y), __uint_as_float(c.b.x), __uint_as_float(c.b.y));
+        rp[2 + it] = make_float4(__uint_as_float(u.a.x), __uint_as_float(u.a.y), __uint_as_float(u.b.x), __uint_as_float(u.b.y));
+    }
+}
+
+template <int NT, typename Hook = NoHook>
+__device__ __forceinline__ void raw_row_to_lds(const float4 (&rp)[4], int hot, float cfg, int top_k, int V, int win_lo, int W, float *g,
+                                               int &out_tok, float &out_mass, float *redf, double *redd, int *hist, int &ph, const Hook &pre_barrier = Hook()) {
+    const int tid = threadIdx.x;
+    const float NEG_INF = -__builtin_inff();
+    out_tok = -1;
+    out_mass = 0.0f;
+    if (hot >= 0) {
+        const bool inside = hot >= win_lo && hot < win_lo + W;
+        for (int i4 = tid; i4 * 4 < W; i4 += NT) {
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            const int e = win_lo + i4 * 4;
+            if (hot >= e && hot < e + 4) set_comp(v, hot - e, 1.0f);
+            reinterpret_cast<float4 *>(g)[i4] = v;
+        }
+        if (!inside) {
+            out_tok = hot;
+            out_mass = 1.0f;
+        }
+        if (tid == 0) g[W + EW_G_OUT] = out_mass;
+        pre_barrier();
+        __syncthreads();
+        return;
+    }
+    float4 r[4];
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const uint32_t cw[4] = {__float_as_uint(rp[it].x), __float_as_uint(rp[it].y), __float_as_uint(rp[it].z), __float_as_uint(rp[it].w)};
+        const uint32_t uw[4] = {__float_as_uint(rp[2 + it].x), __float_as_uint(rp[2 + it].y), __float_as_uint(rp[2 + it].z), __float_as_uint(rp[2 + it].w)};
+        float o[8];
+#pragma unroll
+        for (int q2 = 0; q2 < 4; ++q2) {
+            const f32x2_t t2 = cfg_mix_bf16x2(cw[q2], uw[q2], cfg);
+            o[2 * q2] = t2.x;
+            o[2 * q2 + 1] = t2.y;
+        }
+        r[2 * it] = make_float4(o[0], o[1], o[2], o[3]);
+        r[2 * it + 1] = make_float4(o[4], o[5], o[6], o[7]);
+    }
+    if (top_k > 0 && top_k < V) {
+        const float thr = (top_k <= W) ? kth_largest_hist_bf16<NT, 4>(r, top_k, hist) : NEG_INF;
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            r[it].x = r[it].x < thr ? NEG_INF : r[it].x; r[it].y = r[it].y < thr ? NEG_INF : r[it].y;
+            r[it].z = r[it].z < thr ? NEG_INF : r[it].z; r[it].w = r[it].w < thr ? NEG_INF : r[it].w;
+        }
+    }
+    softmax_tile<NT, 4>(r, redf, redd, ph);
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        float *dst = g + (size_t)(tid + it * NT) * 8;
+        *reinterpret_cast<float4 *>(dst) = r[2 * it];
+        *reinterpret_cast<float4 *>(dst + 4) = r[2 * it + 1];
+    }
+    if (tid == 0) g[W + EW_G_OUT] = 0.0f;
+    pre_barrier();
+    __syncthreads();
+}
+
+// loads through the constant address space: uniform addresses become scalar loads (s_load), off the vector-memory queue.
+// Only for memory no kernel of the same launch writes (tables, candidates, the uniform stream, cursors).
+template <typename T>
+__device__ __forceinline__ T ldc(const T *p) {
+    return *(const __attribute__((address_space(4))) T *)(p);
+}
+
+__device__ __forceinline__ double rdlane(double v, int l) {
+    const long long bits = __double_as_longlong(v);
+    return __longlong_as_double(((long long)__builtin_amdgcn_readlane((int)(bits >> 32), l) << 32) |
+                                (unsigned int)__builtin_amdgcn_readlane((int)(bits & 0xffffffffll), l));
+}
+
+// Bonus token by inverse CDF in token-id order over the distribution in LDS (g = its window, + an optional (out_tok,
+// out_mass) pair outside it): smallest id whose cumulative f64 mass exceeds u * total; the last positive id if rounding
+// leaves none (lo_sample_inverse_cdf in the oracle).  Every thread takes 16 CONSECUTIVE ids, so one wave scan + the wave
+// totals locate the thread that holds the crossing; only that thread looks at single entries.
+template <int NT, int E4>
+__device__ __forceinline__ int bonus_draw_lds(const float *g, int W, int lo, int out_tok, float out_mass, double u, double *wtot,
+                                              int *bonus, int *redi, bool lazy = false, const FastDiv dgc = FastDiv(1.0f)) {
+    constexpr int NW = NT / 64, EPT = 4 * E4;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const bool out_before = out_tok >= 0 && out_tok < lo;
+    float4 p[E4];
+#pragma unroll
+    for (int j = 0; j < E4; ++j) {
+        const int e = tid * EPT + 4 * j;
+        p[j] = (e < W) ? *reinterpret_cast<const float4 *>(g + e) : make_float4(0.f, 0.f, 0.f, 0.f);
+        if (lazy) p[j] = dgc(p[j]);          // g holds an unnormalised residual (see epn_kernel)
+    }
+    double s = 0.0;
+#pragma unroll
+    for (int j = 0; j < E4; ++j) s += (double)p[j].x + (double)p[j].y + (double)p[j].z + (double)p[j].w;
+    const double inc = wave_scan_incl_dpp(s);
+    if (lane == 63) wtot[wave] = inc;
+    if (tid == 0) bonus[0] = 0x7fffffff;
+    __syncthreads();
+    double pre = 0.0, all = 0.0;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+        const double t = wtot[w];
+        pre += (w < wave) ? t : 0.0;
+        all += t;
+    }
+    const double front = out_before ? (double)out_mass : 0.0;
+    double total = front + all;
+    if (out_tok >= 0 && !out_before) total += (double)out_mass;
+    const double tgt = u * total;
+    const double excl = front + pre + (inc - s);
+    if (excl <= tgt && excl + s > tgt) {          // the crossing lies among this thread's ids
+        double acc = excl;
+        int found = 0x7fffffff;
+#pragma unroll
+        for (int j = 0; j < E4; ++j) {
+            const float v[4] = {p[j].x, p[j].y, p[j].z, p[j].w};
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                acc += (double)v[c];
+                found = min(found, (v[c] > 0.0f && acc > tgt) ? lo + tid * EPT + 4 * j + c : 0x7fffffff);
+            }
+        }
+        if (found != 0x7fffffff) atomicMin(bonus, found);
+    }
+    __syncthreads();
+    int token = bonus[0];
+    if (out_before && out_mass > 0.0f && (double)out_mass > tgt) token = out_tok;
+    if (token != 0x7fffffff) return token;
+    // rare tail (u ~ 1, rounding at a thread boundary, or the mass sits behind the window): the exhaustive search
+    int found = 0x7fffffff, last_pos = -1;
+    if (out_before && out_mass > 0.0f) last_pos = out_tok;
+    {
+        double acc = excl;
+#pragma unroll
+        for (int j = 0; j < E4; ++j) {
+            const float v[4] = {p[j].x, p[j].y, p[j].z, p[j].w};
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                acc += (double)v[c];
+                const bool pos = v[c] > 0.0f;
+                const int id = lo + tid * EPT + 4 * j + c;
+                last_pos = max(last_pos, pos ? id : -1);
+                found = min(found, (pos && acc > tgt) ? id : 0x7fffffff);
+            }
+        }
+    }
+    if (out_tok >= 0 && !out_before && out_mass > 0.0f) {
+        last_pos = max(last_pos, out_tok);
+        if (total > tgt) found = min(found, out_tok);
+    }
+    found = wave_min_i(found);
+    last_pos = wave_max_i(last_pos);
+    if (lane == 0) {
+        redi[wave] = found;
+        redi[16 + wave] = last_pos;
+    }
+    __syncthreads();
+    const int f = wave_min_i(lane < NW ? redi[lane] : 0x7fffffff);
+    const int l = wave_max_i(lane < NW ? redi[16 + lane] : -1);
+    return f != 0x7fffffff ? f : l;
+}
+
 }  // namespace lantern

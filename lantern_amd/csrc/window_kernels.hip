@@ -421,81 +421,6 @@ __device__ __forceinline__ void row_softmax_to_lds(float4 (&r)[E4], int hot, boo
     __syncthreads();
 }
 
-// ---- LANTERN_ROWS_RAW_BF16: the row arrives as the target model's raw cond / uncond logits (bf16) and the whole post-process
-// of tree_decoding (CFG combination, top-k threshold, softmax: ea_model_lumina_mgpt.py:597-607) runs HERE, for the rows the walk
-// actually visits -- 2.7 + 1 of a tree's 26 rows per step -- instead of for every row in a separate launch.  Same code as
-// cfg_window_bf16_kernel (same tile layout, same reductions), so the probabilities are the same bits.  The 16 row registers
-// carry two 16-byte chunks of cond and two of uncond per thread until they are needed.
-template <int NT>
-__device__ __forceinline__ void raw_row_load(const uint16_t *__restrict__ crow, const uint16_t *__restrict__ urow, float4 (&rp)[4]) {
-#pragma unroll
-    for (int it = 0; it < 2; ++it) {
-        const int ch = threadIdx.x + it * NT;
-        const Bf16x8 c = *reinterpret_cast<const Bf16x8 *>(crow + ch * 8), u = *reinterpret_cast<const Bf16x8 *>(urow + ch * 8);
-        rp[it] = make_float4(__uint_as_float(c.a.x), __uint_as_float(c.a.y), __uint_as_float(c.b.x), __uint_as_float(c.b.y));
-        rp[2 + it] = make_float4(__uint_as_float(u.a.x), __uint_as_float(u.a.y), __uint_as_float(u.b.x), __uint_as_float(u.b.y));
-    }
-}
-
-template <int NT, typename Hook = NoHook>
-__device__ __forceinline__ void raw_row_to_lds(const float4 (&rp)[4], int hot, float cfg, int top_k, int V, int win_lo, int W, float *g,
-                                               int &out_tok, float &out_mass, EwShared &S, int *hist, int &ph, const Hook &pre_barrier = Hook()) {
-    const int tid = threadIdx.x;
-    const float NEG_INF = -__builtin_inff();
-    out_tok = -1;
-    out_mass = 0.0f;
-    if (hot >= 0) {
-        const bool inside = hot >= win_lo && hot < win_lo + W;
-        for (int i4 = tid; i4 * 4 < W; i4 += NT) {
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            const int e = win_lo + i4 * 4;
-            if (hot >= e && hot < e + 4) set_comp(v, hot - e, 1.0f);
-            reinterpret_cast<float4 *>(g)[i4] = v;
-        }
-        if (!inside) {
-            out_tok = hot;
-            out_mass = 1.0f;
-        }
-        if (tid == 0) g[W + EW_G_OUT] = out_mass;
-        pre_barrier();
-        __syncthreads();
-        return;
-    }
-    float4 r[4];
-#pragma unroll
-    for (int it = 0; it < 2; ++it) {
-        const uint32_t cw[4] = {__float_as_uint(rp[it].x), __float_as_uint(rp[it].y), __float_as_uint(rp[it].z), __float_as_uint(rp[it].w)};
-        const uint32_t uw[4] = {__float_as_uint(rp[2 + it].x), __float_as_uint(rp[2 + it].y), __float_as_uint(rp[2 + it].z), __float_as_uint(rp[2 + it].w)};
-        float o[8];
-#pragma unroll
-        for (int q2 = 0; q2 < 4; ++q2) {
-            const f32x2_t t2 = cfg_mix_bf16x2(cw[q2], uw[q2], cfg);
-            o[2 * q2] = t2.x;
-            o[2 * q2 + 1] = t2.y;
-        }
-        r[2 * it] = make_float4(o[0], o[1], o[2], o[3]);
-        r[2 * it + 1] = make_float4(o[4], o[5], o[6], o[7]);
-    }
-    if (top_k > 0 && top_k < V) {
-        const float thr = (top_k <= W) ? kth_largest_hist_bf16<NT, 4>(r, top_k, hist) : NEG_INF;
-#pragma unroll
-        for (int it = 0; it < 4; ++it) {
-            r[it].x = r[it].x < thr ? NEG_INF : r[it].x; r[it].y = r[it].y < thr ? NEG_INF : r[it].y;
-            r[it].z = r[it].z < thr ? NEG_INF : r[it].z; r[it].w = r[it].w < thr ? NEG_INF : r[it].w;
-        }
-    }
-    softmax_tile<NT, 4>(r, S.redf, S.redd, ph);
-#pragma unroll
-    for (int it = 0; it < 2; ++it) {
-        float *dst = g + (size_t)(tid + it * NT) * 8;
-        *reinterpret_cast<float4 *>(dst) = r[2 * it];
-        *reinterpret_cast<float4 *>(dst + 4) = r[2 * it + 1];
-    }
-    if (tid == 0) g[W + EW_G_OUT] = 0.0f;
-    pre_barrier();
-    __syncthreads();
-}
-
 // LDSIDS: every candidate's neighbour ids are staged in LDS (k + 1 <= EW_PF_K, or LANTERN off), so the serial wave-0
 // section contains no vector-memory instruction -- the compiler then has no reason to drain vmcnt inside it and the
 // drafter-row / id loads issued before it stay in flight across the scan.  !LDSIDS (k > 1023) reads ids from HBM.
@@ -812,7 +737,7 @@ __device__ __forceinline__ int epw_body(const EpwArgs &args, const int b) {
                 }
             };
             if constexpr (RAW) {
-                if (!rp_probs) raw_row_to_lds<NT>(rp, hot, win.raw_cfg, win.raw_top_k, V, lo, W, g, out_tok, out_mass, S, Shist, ph, stage_ids);
+                if (!rp_probs) raw_row_to_lds<NT>(rp, hot, win.raw_cfg, win.raw_top_k, V, lo, W, g, out_tok, out_mass, S.redf, S.redd, Shist, ph, stage_ids);
                 else row_softmax_to_lds<NT, E4, FULLW>(rp, hot, true, lo, W, prm.temperature, prm.top_k, V, g, out_tok, out_mass, S, ph, stage_ids);
             } else row_softmax_to_lds<NT, E4, FULLW>(rp, hot, rows_probs, lo, W, prm.temperature, prm.top_k, V, g, out_tok, out_mass, S, ph, stage_ids);
             EPW_STAMP(11);
@@ -1155,7 +1080,7 @@ __device__ __forceinline__ int epw_body(const EpwArgs &args, const int b) {
             } else row_load<NT, E4, FULLW>(logits + (size_t)rid * W, W, rp);
         }
         if constexpr (RAW) {
-            if (!rp_probs) raw_row_to_lds<NT>(rp, hot, win.raw_cfg, win.raw_top_k, V, lo, W, g, out_tok, out_mass, S, Shist, ph);
+            if (!rp_probs) raw_row_to_lds<NT>(rp, hot, win.raw_cfg, win.raw_top_k, V, lo, W, g, out_tok, out_mass, S.redf, S.redd, Shist, ph);
             else row_softmax_to_lds<NT, E4, FULLW>(rp, hot, true, lo, W, prm.temperature, prm.top_k, V, g, out_tok, out_mass, S, ph);
         } else row_softmax_to_lds<NT, E4, FULLW>(rp, hot, rows_probs, lo, W, prm.temperature, prm.top_k, V, g, out_tok, out_mass, S, ph);
     }

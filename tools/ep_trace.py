@@ -7,9 +7,9 @@ level = os.environ.get("EPW_TRACE", "1")
 so = os.path.join(ROOT, "tools", f"liblantern_trace{level}.so")
 if not os.path.exists(so) or (len(sys.argv) > 1 and sys.argv[1] == "build"):
     src = os.path.join(ROOT, "lantern_amd", "csrc")
-    files = [os.path.join(src, f) for f in ("evaluate_posterior.hip", "logits_post.hip", "window_kernels.hip", "gather_ops.hip", "tree_dynamic.hip", "greedy.hip", "drafter_fc.hip", "vq_table.hip", "tree_attention.hip", "harness_util.hip")]
+    files = [os.path.join(src, f) for f in ("evaluate_posterior.hip", "logits_post.hip", "window_kernels.hip", "node_kernels.hip", "gather_ops.hip", "tree_dynamic.hip", "greedy.hip", "drafter_fc.hip", "vq_table.hip", "tree_attention.hip", "harness_util.hip")]
     subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "-shared", "--offload-arch=gfx950", "-ffp-contract=off", f"-DEPW_TRACE={level}",
-                           "-o", so] + files + ["-x", "hip", os.path.join(src, "tree_static.cpp")])
+                           "-o", so] + files + ["-x", "hip", os.path.join(src, "tree_static.cpp"), os.path.join(src, "verify_step.cpp")])
 if len(sys.argv) > 1 and sys.argv[1] == "build":
     sys.exit(0)
 import numpy as np
@@ -18,7 +18,11 @@ from lantern_amd import _lib
 _lib.LIB_PATH = so
 from lantern_amd import harness as HN
 B = int(os.environ.get("EPW_B", "48"))
-wl = HN.LuminaVerifyWorkload(HN.WorkloadConfig(n_seq=B, pool_steps=4, with_kv=False, max_steps=64, use_graph=False), torch.device("cuda"))
+MODE = os.environ.get("EPW_MODE", "chain")      # "chain": probability rows from O7; "raw": raw bf16 rows + 3 rows up front (the bench default)
+kw = dict(ep_kernel="chain")
+if MODE == "raw":
+    kw.update(fuse_o7=True, spec_rows=int(os.environ.get("EPW_SPEC", "3")))
+wl = HN.LuminaVerifyWorkload(HN.WorkloadConfig(n_seq=B, pool_steps=4, with_kv=False, max_steps=64, use_graph=False, **kw), torch.device("cuda"))
 L = wl._L
 NAMES = {0: "start", 1: "staged(loads issued)", 2: "staged(barrier)", 10: "level: masks+prefetch", 11: "level: softmax", 12: "  softmax: row loaded+local max", 13: "  softmax: block max",
          14: "  softmax: exp+local sum", 15: "  softmax: block sum", 20: "cand: start", 21: "cand: decision (all waves)", 22: "  scan: gathers", 23: "  scan: dpp scan", 24: "  scan: checks",

@@ -81,7 +81,8 @@ class WorkloadConfig:
     pack_table: bool = True         # windowed path: neighbour table packed to [K, ceil8(k+1)] (lantern_pack_vq_table)
     ep_kernel: str = "nodes"        # windowed path: "nodes" = node-parallel evaluate_posterior (one workgroup per internal tree node + the
                                     # walk; B * n_internal workgroups fill the GPU), "chain" = one serial chain per sequence (epw_kernel),
-                                    # "walk" = one workgroup per sequence running the node routine at every stop of the walk (epn_serial_kernel)
+                                    # "walk" = one workgroup per sequence running the node routine at every stop of the walk (epn_serial_kernel),
+                                    # "fast" = the fast-walk kernel (walk_kernel.hip: wave 0 scans, the other waves work ahead of its verdict)
     fuse_o7: bool = False           # windowed chain kernel: LANTERN_ROWS_RAW_BF16 -- no O7 launch, evaluate_posterior post-processes (CFG, top-k,
                                     # softmax) the rows its walk visits from the raw cond / uncond logits
     spec_rows: int = 0              # with fuse_o7: this many of the tree's most likely nodes (the root first) get their rows post-processed
@@ -164,7 +165,7 @@ class LuminaVerifyWorkload:
         self.cond = torch.empty((S, B, N, V), dtype=torch.bfloat16, device=device)
         self.uncond = torch.empty((S, B, N, V), dtype=torch.bfloat16, device=device)
         self.windowed = cfg.path == "window"
-        self.fused_o7 = self.windowed and cfg.fuse_o7 and cfg.ep_kernel == "chain"
+        self.fused_o7 = self.windowed and cfg.fuse_o7 and cfg.ep_kernel in ("chain", "fast")
         self.n_spec = min(max(int(cfg.spec_rows), 0), N) if self.fused_o7 else 0
         if self.n_spec:
             # likelihood order of the nodes: fewer / earlier choices first (the drafter ranks its candidates), the root always
@@ -274,7 +275,7 @@ class LuminaVerifyWorkload:
         self._ep_prm = self._make_ep_params()
         self.graphs = None
         self.ep_nodes = None
-        if self.windowed and cfg.ep_kernel in ("nodes", "walk"):
+        if self.windowed and cfg.ep_kernel in ("nodes", "walk", "fast"):
             self.node_tables = ops.tree_node_tables(tb["retrieve_indices"], N, tb["p_indices"], tb["b_off"], op_off, device=device, b_idx=tb["b_idx"])
             nt = self.node_tables
             win0 = EpWindow()
@@ -283,7 +284,7 @@ class LuminaVerifyWorkload:
             self.node_ws = torch.empty((cfg.n_groups, max(nbytes, 16)), dtype=torch.uint8, device=device)
             self.ep_nodes = []
             for g in range(cfg.n_groups):
-                self.ep_nodes.append(nt.struct(self.node_ws[g].data_ptr(), nbytes, cfg.leaf_workgroups, serial=cfg.ep_kernel == "walk"))
+                self.ep_nodes.append(nt.struct(self.node_ws[g].data_ptr(), nbytes, cfg.leaf_workgroups, serial={"walk": 1, "fast": 2}.get(cfg.ep_kernel, 0)))
         self.reset_state()
         # every (pool slot, parity, group) argument block is built HERE (setup, untimed): the step loop only patches the
         # step-dependent log-row addresses, computed arithmetically from these bases

@@ -28,9 +28,9 @@ NAMES = {0: "start", 1: "staged (barrier)", 2: "dup flags + root requests", 3: "
 agg = {}
 for step in range(8):
     wl.step(); torch.cuda.synchronize()
-    buf = (C.c_ulonglong * (64 * 256))(); cnt = (C.c_int * 64)()
-    assert L.lantern_debug_epf_trace(buf, cnt) == 256
-    a = np.frombuffer(buf, dtype=np.uint64).reshape(64, 256)
+    buf = (C.c_ulonglong * (64 * 160))(); cnt = (C.c_int * 64)()
+    assert L.lantern_debug_epf_trace(buf, cnt) == 160
+    a = np.frombuffer(buf, dtype=np.uint64).reshape(64, 160)
     tot = []
     for b in range(min(B, 64)):
         n = cnt[b]
@@ -47,6 +47,22 @@ for step in range(8):
             for i in range(1, n):
                 print(f"   {NAMES.get(ids[i], ids[i]):32s} +{int(t[i] - t[i - 1]):6d}")
     print(f"step {step}: per-seq cycles min {min(tot)} median {int(np.median(tot))} max {max(tot)}")
+# the load / pass waves' own timelines of the last step, one sequence (absolute cycles from wave 0's first stamp)
+RN = {60: "L: at cmd barrier", 61: "L: cmd read", 62: "L: loads issued", 63: "L: ids staged", 64: "L: dma landed", 65: "L: verdict passed", 66: "L: neighbours zeroed",
+      70: "P: at cmd barrier", 71: "P: cmd read", 72: "P: pass done", 73: "P: verdict passed", 74: "P: residual written", 75: "P: rejection barriers passed"}
+bsel = int(order[len(order) // 2])
+n0 = cnt[bsel]
+t00 = int(a[bsel, 0] & np.uint64((1 << 56) - 1))
+print(f"--- wave 0 of seq {bsel} (absolute):")
+for i in range(n0):
+    print(f"   {NAMES.get(int(a[bsel, i] >> np.uint64(56)), '?'):32s} @{int(a[bsel, i] & np.uint64((1 << 56) - 1)) - t00:7d}")
+for role in (0, 1):
+    bufr = (C.c_ulonglong * (64 * 96))(); cntr = (C.c_int * 64)()
+    assert L.lantern_debug_epf_trace_role(role, bufr, cntr) == 96
+    ar = np.frombuffer(bufr, dtype=np.uint64).reshape(64, 96)
+    print(f"--- role {role} of seq {bsel}:")
+    for i in range(cntr[bsel]):
+        print(f"   {RN.get(int(ar[bsel, i] >> np.uint64(56)), '?'):32s} @{int(ar[bsel, i] & np.uint64((1 << 56) - 1)) - t00:7d}")
 print("mean cycles per stamp interval (all sequences, all steps):")
 for i in sorted(agg):
     v = np.array(agg[i])

@@ -3,6 +3,11 @@
 #pragma once
 #include "common.h"
 
+// diagnosis: window_kernels.hip's trace build (-DEPW_TRACE=3) defines this before including the header; a no-op everywhere else
+#ifndef EPW_STAMPG
+#define EPW_STAMPG(id) do { } while (0)
+#endif
+
 namespace lantern {
 
 __device__ __forceinline__ int64_t py_mod64(int64_t a, int64_t b) {
@@ -408,6 +413,7 @@ __device__ __forceinline__ float kth_largest_hist_bf16(const float4 (&r)[NV4], i
     // ---- pass 0: top 8 bits, replicated histogram
     for (int t = tid; t < O7_HIST2; t += NT) h[t] = 0;
     __syncthreads();
+    EPW_STAMPG(82);
     const int rep = lane & (O7_REP - 1), spill = O7_SPILL + lane;
 #pragma unroll
     for (int it = 0; it < NV4; ++it)
@@ -417,12 +423,14 @@ __device__ __forceinline__ float kth_largest_hist_bf16(const float4 (&r)[NV4], i
             atomicAdd(&h[kk != 0x007fu ? (int)((kk >> 8) * O7_REP) + rep : spill], 1);   // 0x007f = -inf: never ranks
         }
     __syncthreads();
+    EPW_STAMPG(83);
     for (int t = tid; t < 256; t += NT) {
         const int4 a = *reinterpret_cast<const int4 *>(&h[t * O7_REP]);
         const int4 b = *reinterpret_cast<const int4 *>(&h[t * O7_REP + 4]);
         hist[t] = a.x + a.y + a.z + a.w + b.x + b.y + b.z + b.w;
     }
     __syncthreads();
+    EPW_STAMPG(84);
     uint32_t prefix = 0;
     int krem = k;
 #pragma unroll 1
@@ -460,6 +468,7 @@ __device__ __forceinline__ float kth_largest_hist_bf16(const float4 (&r)[NV4], i
                 atomicAdd(&h[((kk >> 8) == top && kk != 0x007fu) ? O7_HIST2 + (int)(kk & 255u) : spill], 1);
             }
         __syncthreads();
+        EPW_STAMPG(85);
     }
     prefix <<= 16;
     if (!(prefix & 0x80000000u)) prefix |= 0xffffu;   // negative float: key = ~bits, low half all ones
@@ -522,6 +531,7 @@ __device__ __forceinline__ void raw_row_to_lds(const float4 (&rp)[4], int hot, f
         r[2 * it] = make_float4(o[0], o[1], o[2], o[3]);
         r[2 * it + 1] = make_float4(o[4], o[5], o[6], o[7]);
     }
+    EPW_STAMPG(81);
     if (top_k > 0 && top_k < V) {
         const float thr = (top_k <= W) ? kth_largest_hist_bf16<NT, 4>(r, top_k, hist) : NEG_INF;
 #pragma unroll
@@ -530,7 +540,9 @@ __device__ __forceinline__ void raw_row_to_lds(const float4 (&rp)[4], int hot, f
             r[it].z = r[it].z < thr ? NEG_INF : r[it].z; r[it].w = r[it].w < thr ? NEG_INF : r[it].w;
         }
     }
+    EPW_STAMPG(86);
     softmax_tile<NT, 4>(r, redf, redd, ph);
+    EPW_STAMPG(88);
 #pragma unroll
     for (int it = 0; it < 2; ++it) {
         float *dst = g + (size_t)(tid + it * NT) * 8;

@@ -14,12 +14,8 @@
 // Reference: models/ea_model_lumina_mgpt.py:597-605 (O7), :610-726 (O8), :781 (bonus token);
 // models/ea_model_llamagen.py:597-669,709-787.
 #include "common.h"
-#include "window_dev.h"
-#include "gather_dev.h"
 
 namespace lantern {
-
-
 // In-kernel phase stamps for diagnosis (tools/ep_trace.py builds a separate .so with -DEPW_TRACE);
 // the shipped library compiles EPW_STAMP to nothing.
 #ifdef EPW_TRACE
@@ -56,6 +52,14 @@ __shared__ int s_epw_trn;
 #endif
 
 
+}  // namespace lantern
+
+#include "window_dev.h"
+#include "gather_dev.h"
+
+namespace lantern {
+
+
 // Workgroup -> row map of the O7 kernels.  Consecutive workgroup ids land on consecutive XCDs (8 of them, each with its
 // own L2); evaluate_posterior's workgroup b (one per sequence) lands on XCD b % 8.  With rows grouped by sequence
 // (rows_per_seq > 0) the rows of sequence b are therefore produced by workgroups whose id is congruent to b modulo 8, so that
@@ -63,12 +67,13 @@ __shared__ int s_epw_trn;
 // is a permutation of the rows is correct.
 __device__ __forceinline__ int o7_row_of_block(int x, int rows, int rows_per_seq) {
     if (rows_per_seq <= 0) return x;
-    const int n_seq = rows / rows_per_seq, full = (n_seq / 8) * 8;           // sequences that fill whole groups of 8
-    const int n_full_rows = full * rows_per_seq;
-    if (x >= n_full_rows) return x;                                          // the ragged tail keeps the identity map
-    const int xcd = x & 7, idx = x >> 3;                                     // idx-th workgroup of this XCD
-    const int seq = xcd + 8 * (idx / rows_per_seq), node = idx % rows_per_seq;
-    return seq * rows_per_seq + node;
+    const unsigned rps = (unsigned)rows_per_seq;                             // (unsigned divisions: half the scalar instructions of the signed ones)
+    const unsigned n_seq = (unsigned)rows / rps, full = n_seq & ~7u;         // sequences that fill whole groups of 8
+    const unsigned n_full_rows = full * rps;
+    if ((unsigned)x >= n_full_rows) return x;                                // the ragged tail keeps the identity map
+    const unsigned xcd = (unsigned)x & 7u, idx = (unsigned)x >> 3;           // idx-th workgroup of this XCD
+    const unsigned q = idx / rps;
+    return (int)((xcd + 8u * q) * rps + (idx - q * rps));
 }
 
 // ------------------------------------------------------------------------------- O7 windowed
@@ -273,6 +278,8 @@ __device__ __forceinline__ void cfg_window_bf16_row(int row, int cls, const uint
 __device__ __forceinline__ int lumina_row_class(int64_t pos, int64_t pos_base, int w_latent, int h_latent) {
     const int64_t n1 = pos - pos_base + 1;
     if (n1 == ((int64_t)w_latent + 1) * h_latent + 1) return 2;
+    // (a 64-bit modulo is ~150 scalar instructions that every wave of the workgroup repeats: the 32-bit form whenever it applies)
+    if (n1 >= 0 && n1 < (1ll << 31) && w_latent >= 0 && w_latent < (1 << 30)) return ((uint32_t)n1 % (uint32_t)(w_latent + 1)) == 0 ? 1 : 0;
     return py_mod64(n1, (int64_t)w_latent + 1) == 0 ? 1 : 0;
 }
 
@@ -1596,7 +1603,12 @@ extern "C" int lantern_evaluate_posterior_window(const lantern_ep_params *prm, c
     else if (W <= 8192) {
         if (two_per_cu && W == 8192 && idmode == 2) LANTERN_LAUNCH((epw_kernel<512, 4, 2, 4, true>), grid, dim3(512), lds, st, args);
         else if (two_per_cu) EPW_LAUNCH_W(512, 4, 4);
-        else if (W == 8192 && idmode == 2) LANTERN_LAUNCH((epw_kernel<512, 4, 2, 1, true>), grid, dim3(512), lds, st, args);   // the Lumina / Anole image window on the packed table
+        else if (W == 8192 && idmode == 2) {
+            static const int nt_knob = getenv("LANTERN_EPW_NT") ? atoi(getenv("LANTERN_EPW_NT")) : 0;   // tuning knob (diagnostic)
+            if (nt_knob == 256) LANTERN_LAUNCH((epw_kernel<256, 8, 2, 1, true>), grid, dim3(256), lds, st, args);
+            else if (nt_knob == 1024) LANTERN_LAUNCH((epw_kernel<1024, 2, 2, 1, true>), grid, dim3(1024), lds, st, args);
+            else LANTERN_LAUNCH((epw_kernel<512, 4, 2, 1, true>), grid, dim3(512), lds, st, args);   // the Lumina / Anole image window on the packed table
+        }
         else EPW_LAUNCH(512, 4);
     }
     else EPW_LAUNCH(1024, 4);

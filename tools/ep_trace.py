@@ -7,7 +7,7 @@ level = os.environ.get("EPW_TRACE", "1")
 so = os.path.join(ROOT, "tools", f"liblantern_trace{level}.so")
 if not os.path.exists(so) or (len(sys.argv) > 1 and sys.argv[1] == "build"):
     src = os.path.join(ROOT, "lantern_amd", "csrc")
-    files = [os.path.join(src, f) for f in ("evaluate_posterior.hip", "logits_post.hip", "window_kernels.hip", "node_kernels.hip", "gather_ops.hip", "tree_dynamic.hip", "greedy.hip", "drafter_fc.hip", "vq_table.hip", "tree_attention.hip", "harness_util.hip")]
+    files = [os.path.join(src, f) for f in ("evaluate_posterior.hip", "logits_post.hip", "window_kernels.hip", "node_kernels.hip", "walk_kernel.hip", "gather_ops.hip", "tree_dynamic.hip", "greedy.hip", "drafter_fc.hip", "vq_table.hip", "tree_attention.hip", "harness_util.hip")]
     subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "-shared", "--offload-arch=gfx950", "-ffp-contract=off", f"-DEPW_TRACE={level}",
                            "-o", so] + files + ["-x", "hip", os.path.join(src, "tree_static.cpp"), os.path.join(src, "verify_step.cpp")])
 if len(sys.argv) > 1 and sys.argv[1] == "build":
@@ -26,7 +26,7 @@ wl = HN.LuminaVerifyWorkload(HN.WorkloadConfig(n_seq=B, pool_steps=4, with_kv=Fa
 L = wl._L
 NAMES = {0: "start", 1: "staged(loads issued)", 2: "staged(barrier)", 10: "level: masks+prefetch", 11: "level: softmax", 12: "  softmax: row loaded+local max", 13: "  softmax: block max",
          14: "  softmax: exp+local sum", 15: "  softmax: block sum", 20: "cand: start", 21: "cand: decision (all waves)", 22: "  scan: gathers", 23: "  scan: dpp scan", 24: "  scan: checks",
-         25: "  scan: wave reduce", 26: "  wave0 decision written", 27: "  wave0 section entered", 31: "  rej: siblings+nb zeroing", 32: "  rej: q zero+sum (waits q)", 33: "  rej: block sum qs", 34: "  rej: residual pass", 35: "  rej: block sum tot", 16: "  level: loop head", 17: "  level: per-lane path data", 18: "  level: candidate list", 30: "reject: residual", 40: "epilogue start", 50: "epilogue done"}
+         25: "  scan: wave reduce", 26: "  wave0 decision written", 27: "  wave0 section entered", 31: "  rej: siblings+nb zeroing", 32: "  rej: q zero+sum (waits q)", 33: "  rej: block sum qs", 34: "  rej: residual pass", 35: "  rej: block sum tot", 16: "  level: loop head", 17: "  level: per-lane path data", 18: "  level: candidate list", 30: "reject: residual", 81: "  row: loaded + CFG mix", 82: "  row: hist cleared", 83: "  row: radix pass 0 (atomics)", 84: "  row: hist merged", 85: "  row: radix pass 1 (atomics)", 86: "  row: threshold applied", 88: "  row: softmax", 40: "epilogue start", 50: "epilogue done"}
 agg = {}
 for step in range(8):
     wl.step(); torch.cuda.synchronize()

@@ -61,7 +61,9 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--seqs-per-gpu", type=int, default=64, help="sequences resident per GPU (KV slabs: 4.3 GB each at 4096 rows; 64 -> 276e9 of the 309e9 bytes)")
+    ap.add_argument("--seqs-per-gpu", type=int, default=63, help="sequences resident per GPU (KV slabs: 4.3 GB each at 4096 rows; 64 -> 276e9 of the 309e9 bytes; the default 63 = 3 stream groups of 21)")
+    ap.add_argument("--total-seqs", type=int, default=0, help="BASELINE config 5 (strong scaling): this many sequences in ALL, split evenly over the --gpus ranks "
+                    "(64 over 8 GPUs = 8 per GPU, run.sh:76-91); 0 = --seqs-per-gpu on every rank (weak scaling, the default)")
     ap.add_argument("--pool-steps", type=int, default=16)
     ap.add_argument("--tree", type=str, default="mc_sim_7b_63", help="static tree (a name in lantern_amd/drafters/choices.py), e.g. naive_extend_57 (N=58,P=33,D=6)")
     ap.add_argument("--lantern-k", type=int, default=1000)
@@ -187,6 +189,29 @@ def cpu_baseline(wl, steps_budget_s: float, n_seq: int, gpu_tokens_by_seq, pytho
     c_leg = dict(value=float((ca.astype(np.int64) + 1).sum()) / dt_c, unit="accepted_tokens/s", cores=threads,
                  sample=f"{n_seq} sequences x {n_steps} verify steps, one lo_verify_loop_mt call on {threads} pthreads (oracle/lantern_oracle.c)",
                  ms_per_seq_step=1e3 * dt_c * threads / (n_seq * n_steps), matches_gpu_token_stream=(c_mis == 0), mismatches=c_mis)
+    # ---- the same call with every sequence's 26 tree rows of the logit post-process shared over a team of OpenMP threads: the
+    # host has more cores than the GPU has sequences (a 256-core host: 63 sequences x 4 threads)
+    team = max(1, min(8, cores // max(threads, 1)))
+    all_leg = None
+    if team > 1:
+        if c.with_kv:
+            for b in range(n_seq):
+                for j in range(2):
+                    kv_slabs[b][j][...] = 1
+        oracle.set_row_threads(team)
+        try:
+            t0 = time.perf_counter()
+            cb2, ca2, ct2 = oracle.verify_loop_mt(cfg, tb, op_off, dict(ss_token=sst, ss_prob=ssp, cond=cond, uncond=uncond, orig_win=orig_win, hidden=hid),
+                                                  wl.uniforms_host[:n_seq], u_bonus, first, table, n_steps, threads, c.cfg_scale, c.prompt_len,
+                                                  HN.TOKENS_PER_IMAGE, c.top_k, slabs=[kv_slabs[b][j] for b in range(n_seq) for j in range(2)] if c.with_kv else None)
+            dt_a = time.perf_counter() - t0
+        finally:
+            oracle.set_row_threads(1)
+        a_mis = int((cb2 != cb).sum() + (ca2 != ca).sum() + (ct2 != ct).sum())
+        all_leg = dict(value=float((ca2.astype(np.int64) + 1).sum()) / dt_a, unit="accepted_tokens/s", cores=threads * team,
+                       sample=f"{n_seq} sequences x {n_steps} verify steps on {threads} pthreads x {team} OpenMP threads each (the tree rows of a sequence's logit post-process in parallel)",
+                       ms_per_seq_step=1e3 * dt_a * threads / (n_seq * n_steps), matches_gpu_token_stream=(c_mis == 0 and a_mis == 0), mismatches=c_mis + a_mis)
+        c_mis += a_mis
     if c.with_kv:
         for b in range(n_seq):          # the Python leg below replays from step 0 on fresh slabs
             for j in range(2):
@@ -214,8 +239,10 @@ def cpu_baseline(wl, steps_budget_s: float, n_seq: int, gpu_tokens_by_seq, pytho
     py_leg = dict(value=accepted / dt, unit="accepted_tokens/s", cores=threads,
                   sample=f"{n_seq} sequences x {n_steps} verify steps through the oracle's Python wrappers, {threads} Python threads (one per sequence)",
                   ms_per_seq_step=1e3 * dt * threads / (n_seq * n_steps), matches_gpu_token_stream=(mismatches == 0), mismatches=mismatches)
-    # the headline CPU figure is the C leg (the Python-threaded one is throttled by the interpreter, not by the algorithm)
-    return dict(c_leg, kind="port", host_cores=cores, python_threads=py_leg, single_thread=single,
+    # the headline CPU figure is the fastest C leg (the Python-threaded one is throttled by the interpreter, not by the algorithm);
+    # the others ride along: one thread per sequence, one thread in all, the Python-threaded loop
+    head = all_leg if (all_leg is not None and all_leg["value"] > c_leg["value"]) else c_leg
+    return dict(head, kind="port", host_cores=cores, one_thread_per_sequence=c_leg, all_cores=all_leg, python_threads=py_leg, single_thread=single,
                 matches_gpu_token_stream=(c_mis == 0 and mismatches == 0), mismatches=c_mis + mismatches)
 
 
@@ -483,6 +510,24 @@ def side_run(device, base_cfg, steps, **over):
     return r
 
 
+def plan_sequences(total_seqs: int, seqs_per_gpu: int, world: int, groups: int):
+    """(sequences per rank, stream groups, scaling).  --total-seqs T: T / world sequences per rank (T must divide: every prompt of the
+    reference's batch is generated exactly once), "strong"; else --seqs-per-gpu on every rank, "weak".  The group count is the largest
+    one <= the requested that divides the rank's sequences -- no sequence is dropped to make the groups equal."""
+    if total_seqs > 0:
+        if total_seqs % world:
+            raise SystemExit(f"bench.py: --total-seqs {total_seqs} does not split evenly over {world} ranks")
+        n, scaling = total_seqs // world, "strong"
+    else:
+        n, scaling = seqs_per_gpu, "weak"
+    if n < 1:
+        raise SystemExit("bench.py: no sequence per rank")
+    g = max(1, min(groups, n))
+    while n % g:
+        g -= 1
+    return n, g, scaling
+
+
 # ---------------------------------------------------------------------------- N > 1: self-launch
 
 def spawn_ranks(args) -> int:
@@ -500,6 +545,14 @@ def spawn_ranks(args) -> int:
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        if os.environ.get("LANTERN_BENCH_NO_PIN") != "1" and os.environ.get("LANTERN_BENCH_STUB") != "1":
+            # one process per GPU, pinned the way the reference's driver pins them (run.sh:76-91: CUDA_VISIBLE_DEVICES=$device):
+            # the rank sees exactly its own device, as index 0
+            vis = os.environ.get("HIP_VISIBLE_DEVICES")
+            devs = [d for d in vis.split(",") if d] if vis else [str(i) for i in range(n)]
+            if len(devs) >= n:
+                env["HIP_VISIBLE_DEVICES"] = devs[r]
+                env["LANTERN_BENCH_DEVICE_INDEX"] = "0"
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
     import threading
@@ -539,7 +592,8 @@ def stub_rank(args, world, rank):
     from lantern_amd.sharding import reduce_timing
     if world > 1:
         dist.init_process_group("gloo")
-    K, per_step = args.steps, args.seqs_per_gpu * 2
+    n_seq, _groups, scaling = plan_sequences(args.total_seqs, args.seqs_per_gpu, world, args.groups)
+    K, per_step = args.steps, n_seq * 2
     if world > 1:
         dist.barrier()
     t0 = time.perf_counter()
@@ -551,7 +605,8 @@ def stub_rank(args, world, rank):
     dt_all, tokens_all = reduce_timing(dist if world > 1 else None, dt, float(K * per_step))
     if rank == 0:
         print(json.dumps({"metric": "stub", "value": tokens_all / dt_all, "unit": "accepted_tokens/s", "n_gpus": world, "steps": K,
-                          "warmup": args.warmup, "ms_per_step": 1e3 * dt_all / K, "data": "stub", "tokens": tokens_all}))
+                          "warmup": args.warmup, "ms_per_step": 1e3 * dt_all / K, "data": "stub", "tokens": tokens_all, "scaling": scaling,
+                          "sequences_per_rank": n_seq, "groups": _groups}))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -569,6 +624,7 @@ def main():
     if world != max(1, args.gpus):
         raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: every rank of the job must be started (or let "
                          "`python bench.py --gpus N` start them itself)")
+    exit_code, stream_mismatch = 0, 0
     if os.environ.get("LANTERN_BENCH_STUB") == "1":
         return stub_rank(args, world, rank)
     # Test knob for a 1-GPU box: LANTERN_BENCH_ONE_DEVICE=1 runs every rank on cuda:0 over gloo (RCCL refuses two ranks on one
@@ -576,6 +632,8 @@ def main():
     one_device = os.environ.get("LANTERN_BENCH_ONE_DEVICE") == "1"
     if one_device:
         local_rank = 0
+    if "LANTERN_BENCH_DEVICE_INDEX" in os.environ:      # a rank pinned by spawn_ranks (HIP_VISIBLE_DEVICES = its own device)
+        local_rank = int(os.environ["LANTERN_BENCH_DEVICE_INDEX"])
     dist = None
     if world > 1 or os.environ.get("LANTERN_BENCH_FORCE_DIST") == "1":       # the env knob exercises the RCCL path on a 1-GPU box
         import torch.distributed as dist
@@ -593,7 +651,10 @@ def main():
     # Never ask for more resident sequences than this GPU can hold: KV slabs (2 per sequence) + pools + 16 GiB of head-room.
     # On the MI355X the default fits (309e9 bytes); a smaller or partly occupied device gets fewer sequences, not a failed run
     # (with more than one rank every rank takes the minimum so that the per-GPU work stays identical).
-    n_seq = args.seqs_per_gpu - args.seqs_per_gpu % max(1, args.groups)      # equal stream groups
+    n_seq, groups, scaling = plan_sequences(args.total_seqs, args.seqs_per_gpu, world, args.groups)
+    if groups != args.groups and rank == 0:
+        print(f"bench.py: {n_seq} sequences per rank in {groups} stream groups (--groups {args.groups} does not divide them)", file=sys.stderr)
+    args.groups = groups
     if args.ep != "chain":
         args.fuse_o7 = False
     if not args.fuse_o7:
@@ -608,7 +669,6 @@ def main():
         pool_step = _N * (2 * 65536 * 2 + 2 * 4096 * 2) + _R * (8192 * 4 + 10 * 12)       # cond + uncond logits, hidden, drafter rows
         per_seq = 2 * (2 * 32 * 32 * (args.kv_smax + 16) * 128 * 2) + args.pool_steps * pool_step
         fit = int((free - (16 << 30)) // per_seq)
-        fit -= fit % max(1, args.groups)
         if dist is not None and dist.get_world_size() > 1:
             t = torch.tensor([fit], dtype=torch.int64, device=red_device or device)
             dist.all_reduce(t, op=dist.ReduceOp.MIN)
@@ -616,9 +676,11 @@ def main():
         if fit < n_seq:
             if fit < max(1, args.groups):
                 raise SystemExit(f"bench.py: {free / 2**30:.0f} GiB free on {device}: not even one sequence's KV slabs fit")
+            if args.total_seqs > 0:
+                raise SystemExit(f"bench.py: {free / 2**30:.0f} GiB free on {device}: the {n_seq} sequences of this rank's share of --total-seqs do not fit")
+            n_seq, args.groups, _ = plan_sequences(0, fit, world, args.groups)
             if rank == 0:
-                print(f"bench.py: {free / 2**30:.0f} GiB free: {n_seq} sequences do not fit, running {fit}", file=sys.stderr)
-            n_seq = fit
+                print(f"bench.py: {free / 2**30:.0f} GiB free: running {n_seq} sequences per rank in {args.groups} stream groups", file=sys.stderr)
     cfg = HN.WorkloadConfig(n_seq=n_seq, pool_steps=args.pool_steps, tree=args.tree, lantern_k=args.lantern_k,
                             lantern_delta=args.lantern_delta, sigma=args.sigma, with_kv=not args.no_kv, kv_smax=args.kv_smax,
                             path=args.path, ep_kernel=args.ep, fuse_o7=args.fuse_o7, spec_rows=args.spec_rows, native_step=not args.python_launch, launch_threads=args.launch_threads, fused_accept=args.fused_accept, fused_workers=args.fused_workers, use_graph=args.graph, n_groups=args.groups, side_stream=args.side_stream,
@@ -668,9 +730,10 @@ def main():
         out = {
             "metric": "accepted image-tokens/sec (Lumina-mGPT-7B 768x768 LANTERN verify/accept loop)",
             "value": tokens_all / dt_all, "unit": "accepted_tokens/s", "n_gpus": world, "steps": K, "warmup": W,
-            "ms_per_step": 1e3 * dt_all / K, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": 1e3 * dt_all / K, "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"C3: Lumina-mGPT-7B-768 LANTERN relaxed accept, static tree {cfg.tree} (N={wl.N},P={wl.P},D={wl.D}), "
+            "config": {"workload": ("C5: Lumina-mGPT-7B-768 LANTERN, %d-prompt batch sharded over %d GPU(s), no collective; " % (args.total_seqs, world) if args.total_seqs > 0 else "") +
+                                   f"C3: Lumina-mGPT-7B-768 LANTERN relaxed accept, static tree {cfg.tree} (N={wl.N},P={wl.P},D={wl.D}), "
                                    "V=65536, K=8192, cfg=3.0, top_k=2000, sequential-CFG KV [64,1,32,%d,128] bf16 x2 per sequence (row stride %d)"
                                    % (cfg.kv_smax, cfg.kv_smax + cfg.kv_pad_rows),
                        "lantern_k": cfg.lantern_k, "lantern_delta": cfg.lantern_delta, "seqs_per_gpu": cfg.n_seq,
@@ -730,10 +793,17 @@ def main():
             n_cpu = args.cpu_seqs or min(cfg.n_seq, os.cpu_count() or 1)
             gpu_stream = [[(int(gb[i, b]), int(ga[i, b]), int(gt[i, b])) for b in range(cfg.n_seq)] for i in range(n_logged)]
             out["cpu_baseline"] = cpu_baseline(wl, args.cpu_seconds, n_cpu, gpu_stream, python_budget_s=min(args.cpu_seconds, 8.0))
+            if not out["cpu_baseline"]["matches_gpu_token_stream"]:
+                stream_mismatch = out["cpu_baseline"]["mismatches"]
         print(json.dumps(out))
+        if stream_mismatch:          # the checker disagrees with the kernels: the line above is not a valid measurement
+            print(f"bench.py: the CPU oracle's accepted-token stream differs from the GPU's in {stream_mismatch} (step, sequence) cells", file=sys.stderr)
+            exit_code = 3
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    if exit_code:
+        raise SystemExit(exit_code)
 
 
 if __name__ == "__main__":

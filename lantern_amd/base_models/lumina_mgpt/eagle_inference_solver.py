@@ -99,6 +99,9 @@ class FlexARInferenceSolver:
         (tokenizer + VQGAN) are loaded by the reference's own loaders, the model is wrapped in this package's EaLumina_mGPT.  With
         `model=` / `item_processor=` the solver wraps objects the caller already holds (tests)."""
         self.dtype = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": torch.float32}[precision]
+        if model is None and not isinstance(model_path, (str, bytes)) and not hasattr(model_path, "__fspath__"):
+            raise TypeError("FlexARInferenceSolver: model_path must be a path (the reference's positional form); a model object goes in as "
+                            "`model=` together with `item_processor=`")
         if model is None:
             from ...ea_model_lumina_mgpt import EaLumina_mGPT
             model = EaLumina_mGPT.from_pretrained(base_model_path=model_path, ea_model_path=drafter_path, cfg_mode=cfg_mode,

@@ -329,36 +329,38 @@ class EaModel(nn.Module):
         input_ids = torch.zeros((cond_combined.shape[0] // (2 if cfg is not None else 1), self.prefix_pad), dtype=torch.long).to(dev)
         new_token = 0
         self._uniforms().begin()          # this prompt's acceptance uniforms start at random's current position
-        for idx in range(max_length):
-            if static_tree:
-                candidates, cart_candidates_prob, tree_candidates = self.generate_candidates(
-                    tree_logits, tree_buffers["tree_indices"], tree_buffers["retrieve_indices"], sample_token, logits_processor)
-                tree_candidates = torch.cat([tree_candidates, tree_candidates])
-                logits, hidden_state_new, outputs = self.tree_decoding(tree_candidates, past_key_values, tree_buffers["tree_position_ids"],
-                                                                       input_ids, tree_buffers["retrieve_indices_head"], cfg, attention_mask)
-                best_candidate, accept_length, sample_p = self.evaluate_posterior_v1(
-                    logits, candidates, logits_processor, cart_candidates_prob, tree_logits[2], tree_buffers["p_indices"],
-                    tree_candidates, tree_buffers["b_indices"], lantern, lantern_k, lantern_delta)
-                input_ids, tree_logits, new_token, hidden_state, sample_token = self.update_inference_inputs(
-                    input_ids, candidates, best_candidate, accept_length, tree_buffers["retrieve_indices_head"], logits_processor,
-                    new_token, past_key_values_data, current_length_data, hidden_state_new, sample_p, cfg, static_tree=True)
-            else:
-                self.base_model.model.tree_mask = tree_mask
-                tree_draft_tokens = torch.cat([draft_tokens, draft_tokens])
-                logits, hidden_state_new, outputs = self.tree_decoding(tree_draft_tokens, past_key_values, tree_position_ids, input_ids,
-                                                                       retrieve_indices, cfg, attention_mask)
-                draft_tokens = torch.cat((draft_tokens, padding), dim=1)
-                candidates = draft_tokens[0, retrieve_indices]
-                best_candidate, accept_length, sample_p = self.evaluate_posterior(logits, candidates, logits_processor, lantern=lantern,
-                                                                                  lantern_k=lantern_k, lantern_delta=lantern_delta)
-                (input_ids, draft_tokens, retrieve_indices, tree_mask, tree_position_ids, new_token, hidden_state,
-                 sample_token) = self.update_inference_inputs(input_ids, candidates, best_candidate, accept_length, retrieve_indices,
-                                                              logits_processor, new_token, past_key_values_data, current_length_data,
-                                                              hidden_state_new, sample_p, cfg)
-            accept_length_list.append(int(accept_length) + 1)
-            if new_token > max_length:
-                break
-        self._uniforms().end()            # unconsumed staged draws go back to the module-level stream
+        try:
+            for idx in range(max_length):
+                if static_tree:
+                    candidates, cart_candidates_prob, tree_candidates = self.generate_candidates(
+                        tree_logits, tree_buffers["tree_indices"], tree_buffers["retrieve_indices"], sample_token, logits_processor)
+                    tree_candidates = torch.cat([tree_candidates, tree_candidates])
+                    logits, hidden_state_new, outputs = self.tree_decoding(tree_candidates, past_key_values, tree_buffers["tree_position_ids"],
+                                                                           input_ids, tree_buffers["retrieve_indices_head"], cfg, attention_mask)
+                    best_candidate, accept_length, sample_p = self.evaluate_posterior_v1(
+                        logits, candidates, logits_processor, cart_candidates_prob, tree_logits[2], tree_buffers["p_indices"],
+                        tree_candidates, tree_buffers["b_indices"], lantern, lantern_k, lantern_delta)
+                    input_ids, tree_logits, new_token, hidden_state, sample_token = self.update_inference_inputs(
+                        input_ids, candidates, best_candidate, accept_length, tree_buffers["retrieve_indices_head"], logits_processor,
+                        new_token, past_key_values_data, current_length_data, hidden_state_new, sample_p, cfg, static_tree=True)
+                else:
+                    self.base_model.model.tree_mask = tree_mask
+                    tree_draft_tokens = torch.cat([draft_tokens, draft_tokens])
+                    logits, hidden_state_new, outputs = self.tree_decoding(tree_draft_tokens, past_key_values, tree_position_ids, input_ids,
+                                                                           retrieve_indices, cfg, attention_mask)
+                    draft_tokens = torch.cat((draft_tokens, padding), dim=1)
+                    candidates = draft_tokens[0, retrieve_indices]
+                    best_candidate, accept_length, sample_p = self.evaluate_posterior(logits, candidates, logits_processor, lantern=lantern,
+                                                                                      lantern_k=lantern_k, lantern_delta=lantern_delta)
+                    (input_ids, draft_tokens, retrieve_indices, tree_mask, tree_position_ids, new_token, hidden_state,
+                     sample_token) = self.update_inference_inputs(input_ids, candidates, best_candidate, accept_length, retrieve_indices,
+                                                                  logits_processor, new_token, past_key_values_data, current_length_data,
+                                                                  hidden_state_new, sample_p, cfg)
+                accept_length_list.append(int(accept_length) + 1)
+                if new_token > max_length:
+                    break
+        finally:
+            self._uniforms().end()        # unconsumed staged draws go back to the module-level stream (also when a step raises)
         return (input_ids[:, self.prefix_pad:self.prefix_pad + max_length], sum(accept_length_list) / len(accept_length_list),
                 time.time() - st)
 

@@ -216,9 +216,11 @@ class EaLumina_mGPT(nn.Module):
     ep_form = "nodes"
 
     def _posterior_on_device(self, logits, candidates, cart_candidates_prob, original_prob, tree_candidates, lantern, lantern_k,
-                             lantern_delta, u_bonus=None, force_dense=False, force_chain=False):
+                             lantern_delta, u_bonus=None, force_dense=False, force_chain=False, reserve=True):
         """evaluate_posterior with every result left on the device: dict(best, accept_len, counters, sample_p | None, token | None).
-        Windowed rows + u_bonus: the bonus token is drawn inside the kernel and sample_p never exists."""
+        Windowed rows + u_bonus: the bonus token is drawn inside the kernel and sample_p never exists.
+        `reserve=False`: the caller has already reserved this step's draws (it snapshots the cursor for a retry, and the window
+        must not be refilled -- shifted, cursor zeroed -- between that snapshot and the retry)."""
         static = self.eagle_version == 1
         windowed = isinstance(logits, WindowRows) and not force_dense
         if isinstance(logits, WindowRows) and force_dense:
@@ -232,7 +234,8 @@ class EaLumina_mGPT(nn.Module):
                                 op_off=hip["op_off"], p_idx=hip["p_idx"], b_off=hip["b_off"], b_idx=hip["b_idx"],
                                 tree_cand=tree_candidates.reshape(1, -1)[:, :hip["N"]])
         fifo = self._uniforms()
-        fifo.reserve(candidates.shape[0] * candidates.shape[1])
+        if reserve:
+            fifo.reserve(candidates.shape[0] * candidates.shape[1])
         if windowed:
             nodes = None
             if static and self.ep_form == "nodes" and not force_chain and (not lantern or int(lantern_k) + 1 <= 1024):
@@ -261,22 +264,22 @@ class EaLumina_mGPT(nn.Module):
             assert p_indices is not None, "Parent indices are required for EAGLE v1"
             assert b_indices is not None, "B indices are required for EAGLE v1"
         fifo = self._uniforms()
-        if not fifo.active:
-            fifo.begin()
+        fifo.reserve(candidates.shape[0] * candidates.shape[1])          # (begins the window if need be) BEFORE the snapshot: a refill moves the cursor
         cur0 = fifo.cursor.clone()
-        out = self._posterior_on_device(logits, candidates, cart_candidates_prob, original_prob, tree_candidates, lantern, lantern_k, lantern_delta)
+        out = self._posterior_on_device(logits, candidates, cart_candidates_prob, original_prob, tree_candidates, lantern, lantern_k, lantern_delta,
+                                        reserve=False)
         status = int(out["counters"][0, 5])          # host sync: the B=1 caller wants accept_length as a Python int anyway
         if status == 8 and isinstance(logits, WindowRows):          # NEEDS_CHAIN: duplicate sibling tokens -> the chain kernel, same uniforms
             fifo.cursor.copy_(cur0)
             out = self._posterior_on_device(logits, candidates, cart_candidates_prob, original_prob, tree_candidates, lantern, lantern_k, lantern_delta,
-                                            force_chain=True)
+                                            force_chain=True, reserve=False)
             status = int(out["counters"][0, 5])
         if status in self._RETRY_DENSE and isinstance(logits, WindowRows):
             # the windowed kernel reported a state only the dense kernel represents: same step again on the dense HIP kernel,
             # from the same position of the uniform stream (HIP -> HIP; there is no CPU path)
             fifo.cursor.copy_(cur0)
             out = self._posterior_on_device(logits, candidates, cart_candidates_prob, original_prob, tree_candidates, lantern, lantern_k,
-                                            lantern_delta, force_dense=True)
+                                            lantern_delta, force_dense=True, reserve=False)
         self._last = (out["best"], out["accept_len"], out["counters"])          # device copies for update_inference_inputs (no re-upload)
         ops.raise_on_status(out["counters"])
         return out["best"][0].to(torch.int64), int(out["accept_len"][0]), out["sample_p"][0]
@@ -420,10 +423,11 @@ class EaLumina_mGPT(nn.Module):
             tree_candidates = ext
         # ---- O8 (+ bonus token), results on the device
         fifo = self._uniforms()
+        fifo.reserve(candidates.shape[0] * candidates.shape[1])          # before the snapshot (see _posterior_on_device)
         cur0 = fifo.cursor.clone()
         u = torch.rand(1, dtype=torch.float64, device=dev)
         ep = self._posterior_on_device(rows, candidates, cart_prob, original_prob, tree_candidates, lantern, lantern_k, lantern_delta,
-                                       u_bonus=u if isinstance(rows, WindowRows) else None)
+                                       u_bonus=u if isinstance(rows, WindowRows) else None, reserve=False)
         best, alen, status = ep["best"], ep["accept_len"], ep["counters"][:, 5]
         # ---- O9 + O10 for every slab in one launch, from the device-side (best, accept_len); a failed walk commits nothing
         L = st.input_ids.shape[1]
@@ -450,7 +454,7 @@ class EaLumina_mGPT(nn.Module):
                 bc, al, sample_p = self.evaluate_posterior(rows.dense_rows(), candidates, cart_prob, original_prob, self.tree_buffers["p_indices"] if st.static else None,
                                                            tree_candidates, self.tree_buffers["b_indices"] if st.static else None, True, lantern,
                                                            lantern_k, lantern_delta)
-                return self._commit_from_host(st, candidates, bc, al, hidden, uhidden, sample_p, u)
+                return self._commit_from_host(st, candidates, bc, al, hidden, uhidden, sample_p, u, eos_token_ids)
             ops.raise_on_status(ep["counters"])
         n = a + 1
         for cl, off in zip(self._length_tensors(st), st.offsets):
@@ -478,8 +482,9 @@ class EaLumina_mGPT(nn.Module):
         else:
             self._take_dynamic_draft(st, out)
 
-    def _commit_from_host(self, st, candidates, best, alen, hidden, uhidden, sample_p, u):
-        """The fallback step's commit: host-side (best, accept_len) through the same kernels."""
+    def _commit_from_host(self, st, candidates, best, alen, hidden, uhidden, sample_p, u, eos_token_ids=None):
+        """The fallback step's commit: host-side (best, accept_len) through the same kernels.  Returns whether an end-of-sequence
+        token was accepted in this step (the reference re-scans the generated suffix every step: ea_model_lumina_mgpt.py:1007-1009)."""
         dev = st.retrieve_indices.device
         b = torch.as_tensor([int(best)], dtype=torch.int32, device=dev)
         a = torch.as_tensor([int(alen)], dtype=torch.int32, device=dev)
@@ -495,7 +500,9 @@ class EaLumina_mGPT(nn.Module):
         self._draft_next(st, out_h[:, 0, :n], out_h[:, 1, :n], token.reshape(1, 1))
         st.new_token += n
         st.accept_lengths.append(n)
-        return False
+        if eos_token_ids is None:
+            return False
+        return bool((acc[:, :n] == eos_token_ids).any())
 
     @torch.no_grad()
     def generate(self, input_ids, do_sample=True, max_new_tokens=2353, max_length=4096, cfg_scale=3.0, top_k=2000,

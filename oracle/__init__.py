@@ -391,6 +391,13 @@ class _LoopArgs(C.Structure):
                    ("rc", C.c_void_p)])
 
 
+def set_row_threads(n: int) -> int:
+    """Rows of one cfg_mask_topk call shared over n OpenMP threads of the calling thread (the CPU baseline's all-core leg)."""
+    L = lib()
+    L.lo_set_row_threads.restype = C.c_int
+    return int(L.lo_set_row_threads(int(n)))
+
+
 def verify_loop_mt(cfg: EpConfig, tb: dict, op_off, pools: dict, uniforms, u_bonus, first_token, table, n_steps: int, n_threads: int,
                    cfg_scale: float, prompt_len: int, tokens_per_image: int, top_k: int, w_latent=48, h_latent=48, newline_id=8803,
                    eos_id=8196, win_lo=4, slabs=None):

@@ -59,6 +59,48 @@ static double sum_f32(const float *x, int n) {
     return s;
 }
 
+/* Per-thread scratch: the routines below need a few V-sized work rows per call.  malloc()ing them per call (256 KB each:
+ * mmap + munmap + first-touch page faults every time) made 63 concurrent baseline threads spend most of their time in the
+ * kernel's address-space lock -- a thread's step took 4.6x as long as the same step on an idle host.  Buffers are kept per
+ * thread and slot, grown on demand, freed when the thread exits (pthread key destructor). */
+#include <pthread.h>
+#define LO_SCRATCH_SLOTS 12
+typedef struct {
+    void *buf[LO_SCRATCH_SLOTS];
+    size_t cap[LO_SCRATCH_SLOTS];
+} lo_scratch_t;
+static pthread_key_t lo_scratch_key;
+static pthread_once_t lo_scratch_once = PTHREAD_ONCE_INIT;
+static void lo_scratch_free(void *p) {
+    lo_scratch_t *s = (lo_scratch_t *)p;
+    if (!s) return;
+    for (int i = 0; i < LO_SCRATCH_SLOTS; ++i) free(s->buf[i]);
+    free(s);
+}
+static void lo_scratch_make_key(void) { pthread_key_create(&lo_scratch_key, lo_scratch_free); }
+static void *lo_scratch(int slot, size_t bytes) {
+    pthread_once(&lo_scratch_once, lo_scratch_make_key);
+    lo_scratch_t *s = (lo_scratch_t *)pthread_getspecific(lo_scratch_key);
+    if (!s) {
+        s = (lo_scratch_t *)calloc(1, sizeof(lo_scratch_t));
+        pthread_setspecific(lo_scratch_key, s);
+    }
+    if (s->cap[slot] < bytes) {
+        free(s->buf[slot]);
+        s->buf[slot] = malloc(bytes);
+        s->cap[slot] = bytes;
+    }
+    return s->buf[slot];
+}
+
+/* rows of one lo_cfg_mask_topk call shared over this many OpenMP threads of the calling thread's team (the all-core leg of the
+ * CPU baseline: 63 sequences are fewer than a 256-core host has cores; a sequence's 26 tree rows are independent) */
+static int lo_row_threads = 1;
+int lo_set_row_threads(int n) {
+    lo_row_threads = n < 1 ? 1 : (n > 64 ? 64 : n);
+    return lo_row_threads;
+}
+
 /* torch.softmax(row, dim=0) for a float32 row (ea_model_lumina_mgpt.py:637). */
 static void softmax_row(const float *x, int n, float *out) {
     float m = -INFINITY;
@@ -77,7 +119,7 @@ static void softmax_row(const float *x, int n, float *out) {
 /* k-th largest value of x[0..n) (torch.topk(x,k)[0][-1]); k>=1.  Quickselect on a copy
  * (O(n) expected) so that the CPU baseline is not handicapped by a full sort. */
 static float kth_largest(const float *x, int n, int k) {
-    float *t = (float *)malloc(sizeof(float) * (size_t)n);
+    float *t = (float *)lo_scratch(0, sizeof(float) * (size_t)n);
     memcpy(t, x, sizeof(float) * (size_t)n);
     int lo = 0, hi = n - 1, target = k - 1; /* index in descending order */
     while (lo < hi) {
@@ -104,9 +146,7 @@ static float kth_largest(const float *x, int n, int k) {
         else
             break;
     }
-    float v = t[target];
-    free(t);
-    return v;
+    return t[target];
 }
 
 typedef struct {
@@ -128,9 +168,9 @@ static void apply_processors(float *row, int V, float temperature, float top_p, 
     if (top_p >= 1e-8f && top_p < 1.0f) {
         /* TopPLogitsWarper: ascending sort, softmax, cumsum, remove cum <= 1-top_p,
          * always keep the last (largest) entry. */
-        fi_pair *pr = (fi_pair *)malloc(sizeof(fi_pair) * (size_t)V);
-        float *sv = (float *)malloc(sizeof(float) * (size_t)V);
-        float *sp = (float *)malloc(sizeof(float) * (size_t)V);
+        fi_pair *pr = (fi_pair *)lo_scratch(1, sizeof(fi_pair) * (size_t)V);
+        float *sv = (float *)lo_scratch(2, sizeof(float) * (size_t)V);
+        float *sp = (float *)lo_scratch(3, sizeof(float) * (size_t)V);
         for (int i = 0; i < V; ++i) {
             pr[i].v = row[i];
             pr[i].i = i;
@@ -144,9 +184,6 @@ static void apply_processors(float *row, int V, float temperature, float top_p, 
             acc += (double)sp[i];
             if ((float)acc <= thr) row[pr[i].i] = -INFINITY;
         }
-        free(pr);
-        free(sv);
-        free(sp);
     }
     if (top_k > 0) {
         int k = top_k < V ? top_k : V;
@@ -177,13 +214,13 @@ int lo_evaluate_posterior(const lo_ep_params *prm, const float *logits, const in
     if (is_static && (!cart_prob || !orig_prob || !op_off || !p_idx || !b_off || !tree_cand)) return -2;
     if (prm->lantern && (!nn_table || k < 1 || k > prm->table_cols)) return -3;
 
-    float *g = (float *)malloc(sizeof(float) * (size_t)V);
-    float *q = (float *)malloc(sizeof(float) * (size_t)V);
-    float *row = (float *)malloc(sizeof(float) * (size_t)V);
-    float *cs = (float *)malloc(sizeof(float) * (size_t)(k > 0 ? k : 1));
-    int64_t *acc_tok = (int64_t *)malloc(sizeof(int64_t) * (size_t)D);
-    int64_t *tried = (int64_t *)malloc(sizeof(int64_t) * (size_t)P);
-    char *is_eq = (char *)malloc((size_t)P);
+    float *g = (float *)lo_scratch(4, sizeof(float) * (size_t)V);
+    float *q = (float *)lo_scratch(5, sizeof(float) * (size_t)V);
+    float *row = (float *)lo_scratch(6, sizeof(float) * (size_t)V);
+    float *cs = (float *)lo_scratch(7, sizeof(float) * (size_t)(k > 0 ? k : 1));
+    int64_t *acc_tok = (int64_t *)lo_scratch(8, sizeof(int64_t) * (size_t)D);
+    int64_t *tried = (int64_t *)lo_scratch(9, sizeof(int64_t) * (size_t)P);
+    char *is_eq = (char *)lo_scratch(10, (size_t)P);
     int rc = 0;
 
     int a = 1, best = 0, adjust = 0, u = 0;
@@ -338,13 +375,6 @@ int lo_evaluate_posterior(const lo_ep_params *prm, const float *logits, const in
         counters[5] = 0;
     }
 done:
-    free(g);
-    free(q);
-    free(row);
-    free(cs);
-    free(acc_tok);
-    free(tried);
-    free(is_eq);
     return rc;
 }
 
@@ -452,6 +482,8 @@ static int64_t py_mod(int64_t a, int64_t b) {
 int lo_cfg_mask_topk(const void *cond, const void *uncond, int dtype, int N, int V, float cfg,
                      int model, const int64_t *pos_ids, int64_t pos_base, int w_latent, int h_latent,
                      int img_lo, int img_hi, int newline_id, int eos_id, int top_k, float *out) {
+    const int row_threads = lo_row_threads;
+#pragma omp parallel for schedule(dynamic, 1) num_threads(row_threads) if (row_threads > 1)
     for (int n = 0; n < N; ++n) {
         float *o = out + (size_t)n * V;
         for (int v = 0; v < V; ++v) {

@@ -119,3 +119,81 @@ def test_bench_gpus_2_starts_its_own_ranks():
     bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2"], env=dict(env, WORLD_SIZE="1"),
                          capture_output=True, text=True, timeout=120)
     assert bad.returncode != 0 and "WORLD_SIZE=1" in bad.stderr
+
+
+def test_sequence_plan_drops_nothing():
+    """bench.py's (sequences per rank, stream groups): --total-seqs splits the batch exactly (BASELINE config 5: 64 prompts over 8 GPUs =
+    8 per GPU), the group count is lowered to a divisor instead of sequences being dropped (`--seqs-per-gpu 8 --groups 3` used to
+    run 6 silently)."""
+    sys.path.insert(0, ROOT)
+    import bench
+    assert bench.plan_sequences(64, 63, 8, 3) == (8, 2, "strong")
+    assert bench.plan_sequences(0, 63, 1, 3) == (63, 3, "weak")
+    assert bench.plan_sequences(0, 8, 1, 3) == (8, 2, "weak")
+    assert bench.plan_sequences(0, 64, 4, 3) == (64, 2, "weak")
+    assert bench.plan_sequences(64, 63, 1, 4) == (64, 4, "strong")
+    with pytest.raises(SystemExit):
+        bench.plan_sequences(64, 63, 7, 3)
+    for total, world in ((64, 8), (64, 4), (64, 2), (64, 1)):
+        n, g, _ = bench.plan_sequences(total, 63, world, 3)
+        assert n * world == total and n % g == 0
+
+
+@pytest.mark.timeout(600)
+def test_bench_c5_eight_stub_ranks():
+    """BASELINE config 5's launch shape on CPU: `python bench.py --gpus 8 --total-seqs 64` starts eight rank processes (gloo, stub
+    kernels), every rank runs 64 / 8 = 8 sequences, rank 0's line carries all 64 (strong scaling)."""
+    import subprocess
+    env = dict(os.environ, LANTERN_BENCH_STUB="1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--total-seqs", "64", "--steps", "3", "--warmup", "1"],
+                       env=env, capture_output=True, text=True, timeout=500)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 8 and line["scaling"] == "strong" and line["sequences_per_rank"] == 8 and line["groups"] == 2
+    assert line["tokens"] == 8 * 3 * 8 * 2          # ranks x steps x sequences per rank x the stub's 2 tokens
+
+
+def _union_worker(rank, world, port, total, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path.insert(0, ROOT)
+    import bench
+    from lantern_amd.sharding import reduce_timing, sequence_ids
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    per_rank, _, _ = bench.plan_sequences(total, 63, world, 3)
+    ids = sequence_ids(rank, world, per_rank)
+    toks = _tokens_for(ids)
+    dt, tot = reduce_timing(dist, seconds=1.0, tokens=float(sum(toks.values())))
+    q.put((rank, ids, toks, tot))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(900)
+def test_c5_union_of_eight_shards_equals_single_process(tmp_path):
+    """64 sequences over 8 ranks (8 each, contiguous slices): the union of the shards' accepted tokens is what one process gets for
+    all 64, no sequence twice or missing; the per-rank statistics files merge to the single process's means."""
+    from lantern_amd import sharding as sh
+    world, total = 8, 64
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_union_worker, args=(r, world, port, total, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=600) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    single = _tokens_for(range(total))
+    seen, paths = {}, []
+    for rank, ids, toks, tot in res:
+        assert len(ids) == 8 and tot == float(sum(single.values()))
+        assert not (set(ids) & set(seen))
+        seen.update(toks)
+        a, b = ids[0], ids[-1] + 1
+        paths.append(sh.write_global_statistics(str(tmp_path), {f"prompt_{i}": sh.statistics_entry(f"p{i}", float(toks[i]), 0.0) for i in ids}, a, b))
+    assert seen == single
+    m = sh.merge_global_statistics(paths)
+    assert m["prompts"] == total and abs(m["mean_step_compression"] - sum(single.values()) / total) < 1e-12

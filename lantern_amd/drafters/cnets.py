@@ -201,6 +201,13 @@ class Model(nn.Module):
         mask = self._prepare_decoder_attention_mask(attention_mask, (B, T), hidden_states, past)
         hidden_states = self._input_stage(hidden_states, input_ids.to(hidden_states.device))
         extra = self.layer_kwargs(position_ids) if self.layer_kwargs is not None else {}
+        tm = getattr(self, "tree_mask", None)
+        if (tm is not None and hidden_states.is_cuda and hidden_states.dtype == torch.bfloat16 and tm.shape[-1] <= 64 and tm.shape[-2] >= T
+                and tm.shape[-1] >= T and past + T >= tm.shape[-1] and all(getattr(l, "supports_tree_bits", False) for l in self.layers)):
+            # the tree block of the mask as ancestor words + the left padding as a first-visible-key index: the layer's attention
+            # runs on lantern_tree_attention (the additive mask still rides along for layers / shapes that want it)
+            bits, t1 = ops.drafter_tree_bits(tm.to(hidden_states.device), T)
+            extra = dict(extra, tree_bits=bits, tree_keys=t1, kv_start=attention_mask.to(hidden_states.device).to(torch.int64).argmax(dim=1))
         cache = () if use_cache else None
         for idx, layer in enumerate(self.layers):
             pkv = past_key_values[idx] if past_key_values is not None else None

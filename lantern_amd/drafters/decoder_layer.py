@@ -204,9 +204,11 @@ class DecoderLayer(nn.Module):
         self.input_layernorm = RMSNorm(config.hidden_size, eps)
         self.post_attention_layernorm = RMSNorm(config.hidden_size, eps)
 
-    def _fast(self, x, attention_mask, position_ids, past_key_value, use_cache):
+    def _fast(self, x, attention_mask, position_ids, past_key_value, use_cache, tree_bits=None, tree_keys=0, kv_start=None):
         """Decode shape on the device (<= 32 bf16 rows): rmsnorm, fused q/k/v GEMM, head norm + rotary (+ cache append), one attention call,
-        o_proj (split-K) + residual, rmsnorm, gate/up GEMM with silu * up in its epilogue, down_proj (split-K) + residual."""
+        o_proj (split-K) + residual, rmsnorm, gate/up GEMM with silu * up in its epilogue, down_proj (split-K) + residual.
+        With `tree_bits` (ops.drafter_tree_bits: the tree block of the drafter's mask as ancestor words) the attention is
+        lantern_tree_attention over the cache in place -- no additive mask, no repeat_kv, no [T, S] scores."""
         at, mlp = self.self_attn, self.mlp
         B, T, H = x.shape
         nq, nk, d = at.num_heads, at.num_key_value_heads, at.head_dim
@@ -229,9 +231,21 @@ class DecoderLayer(nn.Module):
             if past_key_value is not None:
                 k, v = torch.cat([past_key_value[0], k], dim=2), torch.cat([past_key_value[1], v], dim=2)
         present = (k, v) if use_cache else None
-        # (a hand-written LDS-score attention kernel for this shape was measured at 156 us against 61 us for torch's fused attention: dropped)
-        m = None if attention_mask is None else attention_mask[:, :, :, :kv_len].to(q.dtype)
-        o = F.scaled_dot_product_attention(q, k, v, attn_mask=m, enable_gqa=nk != nq).transpose(1, 2).reshape(B * T, H)
+        if tree_bits is not None:
+            # the T new tokens are the last T of the `tree_keys` tree keys; the kernel takes as many query rows as tree keys: the
+            # rows in front are placeholders (zero queries that see themselves)
+            t1 = int(tree_keys)
+            qn = q.transpose(1, 2)                                  # [B, T, nq, d]
+            if t1 > T:
+                qp = torch.zeros((B, t1, nq, d), dtype=q.dtype, device=q.device)
+                qp[:, t1 - T:] = qn
+            else:
+                qp = qn
+            o = ops.tree_attention(qp, k, v, tree_bits, kv_start=kv_start, max_kv_len=kv_len)[:, t1 - T:].reshape(B * T, H)
+        else:
+            # (the additive-mask form: prefills inside the decode shape, callers without a tree block)
+            m = None if attention_mask is None else attention_mask[:, :, :, :kv_len].to(q.dtype)
+            o = F.scaled_dot_product_attention(q, k, v, attn_mask=m, enable_gqa=nk != nq).transpose(1, 2).reshape(B * T, H)
         h1 = ops.linear_rows_splitk(o, at.o_proj.weight, bias=at.o_proj.bias, residual=x2)          # 128 column tiles: K split to fill the GPU
         hn = ops.rmsnorm_rows(h1, self.post_attention_layernorm.weight, self.post_attention_layernorm.variance_epsilon)
         wg, bg = mlp._fused_gate_up()
@@ -267,10 +281,14 @@ class DecoderLayer(nn.Module):
 
     fused = True          # False: every projection its own launch through skinny_linear / torch (the composition the fast path is tested against)
 
+    supports_tree_bits = True      # Model.forward hands the tree block over as ancestor words (tree_bits / tree_keys / kv_start) when it has one
+
     def forward(self, hidden_states, attention_mask=None, position_ids=None, past_key_value=None, output_attentions=False, use_cache=False,
-                **kw) -> Tuple[torch.Tensor, ...]:
+                tree_bits=None, tree_keys=0, kv_start=None, **kw) -> Tuple[torch.Tensor, ...]:
         if self._fast_ok(hidden_states, position_ids, output_attentions):
-            y, present = self._fast(hidden_states, attention_mask, position_ids, past_key_value, use_cache)
+            if tree_bits is not None and not (0 < hidden_states.shape[1] <= tree_keys <= 64):
+                tree_bits = None
+            y, present = self._fast(hidden_states, attention_mask, position_ids, past_key_value, use_cache, tree_bits, tree_keys, kv_start)
             return (y, present) if use_cache else (y,)
         a, w, present = self.self_attn(self.input_layernorm(hidden_states), attention_mask=attention_mask, position_ids=position_ids,
                                        past_key_value=past_key_value, output_attentions=output_attentions, use_cache=use_cache)

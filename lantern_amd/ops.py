@@ -8,7 +8,7 @@ from __future__ import annotations
 
 import ctypes as C
 from dataclasses import dataclass
-from typing import Optional, Sequence
+from typing import Tuple, Optional, Sequence
 
 import numpy as np
 import torch
@@ -806,6 +806,31 @@ def tree_mask_bits(tree_mask: torch.Tensor) -> torch.Tensor:
         raise _lib.LanternError(f"tree_mask_bits: {tuple(tree_mask.shape)}: need a square tree block of at most 64 nodes")
     w = torch.ones(N, dtype=torch.int64, device=m.device) << torch.arange(N, dtype=torch.int64, device=m.device)
     return ((m != 0).to(torch.int64) * w).sum(-1).contiguous()      # bit 63 wraps to the sign bit: same 64-bit pattern
+
+
+def drafter_tree_bits(tree_mask: torch.Tensor, T: int) -> Tuple[torch.Tensor, int]:
+    """The drafter's tree block as ancestor words for `tree_attention`.  tree_mask: [1|B, 1, t0, t1] (or [t0, t1]) with t0 >= T, t1 <= 64: the last
+    T rows are this call's T new tokens, the t1 columns the last t1 keys of the cache (cnets_lumina_mgpt.py:1014-1050: finfo.min wherever the block
+    is zero, on top of the causal mask).  Returns (int64 [t1] | [B, t1] words for t1 query rows -- rows in front of the last T are placeholders that
+    see only themselves -- , t1).  Built on the device, no synchronisation."""
+    m = tree_mask
+    while m.dim() > 3:
+        m = m[:, 0]
+    if m.dim() == 2:
+        m = m[None]
+    t0, t1 = m.shape[-2], m.shape[-1]
+    if t1 > 64 or t0 < T or t1 < T:
+        raise _lib.LanternError(f"drafter_tree_bits: block {t0} x {t1} for {T} new tokens (at most 64 tree keys)")
+    dev = m.device
+    rows = (m[:, t0 - T:] != 0)                                                  # [Bm, T, t1]
+    j = torch.arange(t1, device=dev)
+    causal = j[None, :] <= (t1 - T + torch.arange(T, device=dev))[:, None]      # row i is key t1 - T + i: nothing behind it
+    rows = rows & causal[None]
+    w = torch.ones(t1, dtype=torch.int64, device=dev) << j.to(torch.int64)
+    words = (rows.to(torch.int64) * w).sum(-1)                                   # [Bm, T]
+    pad = (torch.ones(t1 - T, dtype=torch.int64, device=dev) << torch.arange(t1 - T, dtype=torch.int64, device=dev))[None].expand(words.shape[0], -1)
+    bits = torch.cat((pad, words), dim=1).contiguous()
+    return (bits[0] if bits.shape[0] == 1 else bits), t1
 
 
 def tree_attention(q, k_cache, v_cache, tree_bits, kv_len=None, kv_start=None, max_kv_len: Optional[int] = None,

@@ -95,6 +95,41 @@ def test_layer_hip_path_matches_the_reference_layer_bf16(name, fused, monkeypatc
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("name", [c for c in CASES if c != "mha"])          # (mha: head_dim 16, outside the fused kernels)
+def test_layer_tree_attention_path_matches_the_reference_layer(name, monkeypatch):
+    """The drafting call with the tree block handed over as ancestor words (tree_bits / kv_start: what cnets.Model.forward passes) runs its
+    attention on lantern_tree_attention -- no torch attention call -- and reproduces the reference layer's decode output (the vectors recorded
+    from ChameleonDecoderLayer with the additive tree mask) within the bf16 tolerance of the fused path."""
+    import torch.nn.functional as F
+    from lantern_amd import ops
+    dev, bf = torch.device("cuda"), torch.bfloat16
+    layer = build(name, dev, bf)
+    if layer.self_attn.head_dim not in (64, 128):
+        pytest.skip("head_dim outside the fused kernels")
+    calls = []
+    real_ta, real_sdpa = ops.tree_attention, F.scaled_dot_product_attention
+    monkeypatch.setattr(ops, "tree_attention", lambda *a, **kw: (calls.append("tree"), real_ta(*a, **kw))[1])
+    monkeypatch.setattr(F, "scaled_dot_product_attention", lambda *a, **kw: (calls.append("sdpa"), real_sdpa(*a, **kw))[1])
+    m1 = g(name, "m1", dev)
+    T1 = m1.shape[2]
+    tree = (m1[0, 0, :, -T1:] == 0).float()                       # the tree block of the recorded mask (row 0: no padding)
+    bits, t1 = ops.drafter_tree_bits(tree[None, None], T1)
+    start = (m1[:, 0, -1, :] == 0).to(torch.int64).argmax(dim=1)  # first visible key per row (row 1 is left-padded by 2)
+    with torch.no_grad():
+        y0, kv0 = layer(g(name, "x0", dev, bf), attention_mask=g(name, "m0", dev), position_ids=g(name, "pos0", dev), use_cache=True)
+        calls.clear()
+        y1, kv1 = layer(g(name, "x1", dev, bf), attention_mask=m1, position_ids=g(name, "pos1", dev), past_key_value=kv0, use_cache=True,
+                        tree_bits=bits, tree_keys=t1, kv_start=start)
+    assert calls == ["tree"], calls
+    for got, key in ((y1, "y1"), (kv1[0], "k1"), (kv1[1], "v1")):
+        np.testing.assert_allclose(got.float().cpu().numpy(), GOLD[name + "." + key], rtol=4e-2, atol=4e-2)
+    # and the additive-mask form of the same call agrees
+    with torch.no_grad():
+        y1m, _ = layer(g(name, "x1", dev, bf), attention_mask=m1, position_ids=g(name, "pos1", dev), past_key_value=kv0, use_cache=True)
+    np.testing.assert_allclose(y1.float().cpu().numpy(), y1m.float().cpu().numpy(), rtol=2e-2, atol=2e-2)
+
+
+@pytest.mark.gpu
 def test_layer_inplace_cache_equals_the_concatenated_cache():
     """inplace_cache: `present` is a growing view of a layer-owned slab.  The drafter's pattern -- prefix forward, several depth calls that
     each extend the previous present, then a new cycle from the SHORTER prefix cache -- gives bit-identical outputs to the torch.cat cache,

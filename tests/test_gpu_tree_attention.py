@@ -221,3 +221,53 @@ def test_drop_in_for_the_eager_block_on_kvcache_slabs():
                              max_kv_len=prev + N)
     err = (out.float() - eager.float()).abs()
     assert (err <= ATOL + RTOL * eager.float().abs()).all(), float(err.max())
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# Vectors recorded from the REFERENCE's own eager attention (tests/golden/make_golden_attention.py: ChameleonAttention.forward of
+# models/kv_variants/modeling_lumina_mgpt_kv.py run on the CPU in bf16 against the mask of _prepare_decoder_attention_mask and the
+# reference's KVCache): rotated queries, caches, mask -> the attention core's output in front of o_proj.
+import os
+
+import numpy as np
+
+_ATT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "attention.npz")
+_ATT_CASES = ["static26_d128", "static58_d64_gqa", "dynamic59_d128_gqa", "dynamic59_d64"]
+
+
+def _bf16(a):
+    return torch.from_numpy(np.ascontiguousarray(a).view(np.int16)).view(torch.bfloat16)
+
+
+@pytest.mark.parametrize("name", _ATT_CASES)
+def test_reference_recorded_attention(name):
+    z = np.load(_ATT)
+    heads, kvh, d, N, L0, s0, s1 = (int(v) for v in z[name + ".meta"])
+    q = _bf16(z[name + ".q"]).cuda()                     # [B, Hq, N, d]
+    k, v = _bf16(z[name + ".k"]).cuda(), _bf16(z[name + ".v"]).cuda()          # [B, Hkv, L0 + N, d]
+    want = _bf16(z[name + ".out"]).float().cuda()        # [B, N, Hq * d]
+    vis = torch.from_numpy(z[name + ".mask"])            # [B, 1, N, L0 + N] what the reference's additive mask lets through
+    tm = torch.from_numpy(z[name + ".tree_mask"])
+    B, S = q.shape[0], L0 + N
+    starts = [s0, s1]
+    # the mask the kernel derives from (kv_start, kv_len, tree bits) is the reference's mask, cell for cell
+    for b in range(B):
+        implied = torch.zeros(N, S, dtype=torch.bool)
+        implied[:, starts[b]:L0] = True
+        implied[:, L0:] = tm != 0
+        assert torch.equal(implied, vis[b, 0]), name
+    # the caches as the product holds them: S_max rows, junk behind the end
+    S_max = S + 13
+    kc = torch.full((B, kvh, S_max, d), 1e30, dtype=torch.bfloat16, device="cuda")
+    vc = torch.full((B, kvh, S_max, d), float("nan"), dtype=torch.bfloat16, device="cuda")
+    kc[:, :, :S], vc[:, :, :S] = k, v
+    bits = ops.tree_mask_bits(tm.cuda())
+    lens = torch.full((B,), S, dtype=torch.int64, device="cuda")
+    got = ops.tree_attention(q.transpose(1, 2), kc, vc, bits, kv_len=lens, kv_start=torch.tensor(starts, dtype=torch.int64, device="cuda")).float()
+    torch.cuda.synchronize()
+    assert torch.isfinite(got).all()
+    err = (got - want).abs()
+    assert (err <= ATOL + RTOL * want.abs()).all(), (name, float(err.max()))
+    # ... and as close to the exact (f64) result as the reference's own bf16 pipeline
+    exact = exact_attention(q.transpose(1, 2).contiguous(), kc, vc, tm.cuda(), lens, torch.tensor(starts, device="cuda"), d ** -0.5).float()
+    assert float((got - exact).abs().max()) <= float((want - exact).abs().max()) + 2e-2

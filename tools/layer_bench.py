@@ -37,6 +37,23 @@ def timeit(k=50):
     return e0.elapsed_time(e1) / k * 1e3
 
 wbytes = sum(p.numel() * 2 for p in layer.parameters() if p.dim() > 1)
+if os.environ.get("LAYER_BENCH_ONLY") == "tree":
+    # the drafting call as cnets.Model.forward issues it (tree block as ancestor words, in-place cache) and nothing else: the profile of
+    # this run shows the layer's own kernels only
+    from lantern_amd import ops
+    bits, t1 = ops.drafter_tree_bits(torch.eye(n, device=dev)[None, None], n)
+    start = torch.zeros(2, dtype=torch.int64, device=dev)
+    layer.inplace_cache = True
+    with torch.no_grad():
+        _, pres = layer(x, attention_mask=mask, position_ids=pos, past_key_value=kv, use_cache=True)
+    prefix = (pres[0][:, :, :past], pres[1][:, :, :past])
+    def run():
+        with torch.no_grad():
+            return layer(x, attention_mask=None, position_ids=pos, past_key_value=prefix, use_cache=True, tree_bits=bits, tree_keys=t1, kv_start=start)[0]
+    t = timeit(200)
+    print(json.dumps({"shape": f"rows 2x{n}, past {past}, hidden 4096, heads 32, intermediate 11008 (bf16)", "weight_bytes": wbytes,
+                      "hip_tree_attention_inplace_cache_us": t, "weight_stream_GBps": wbytes / (t * 1e-6) / 1e9}))
+    sys.exit(0)
 y_hip = run().float()
 t_hip = timeit()
 real = DL._hip_ok
@@ -72,6 +89,33 @@ out["hip_inplace_cache_us"] = t_in
 out["speedup_inplace_cache"] = t_torch / t_in
 out["max_rel_diff_inplace_vs_cat"] = float((y_in - y_hip).abs().max() / y_hip.abs().max())
 print(json.dumps({k: out[k] for k in ("hip_inplace_cache_us", "speedup_inplace_cache", "max_rel_diff_inplace_vs_cat")}))
+if len(sys.argv) > 3:
+    json.dump(out, open(sys.argv[3], "w"), indent=1)
+
+# the drafting call with the tree block as ancestor words (what cnets.Model.forward hands over): attention on lantern_tree_attention
+from lantern_amd import ops
+bits, t1 = ops.drafter_tree_bits(torch.eye(n, device=dev)[None, None], n)
+start = torch.zeros(2, dtype=torch.int64, device=dev)
+def run_tree():
+    with torch.no_grad():
+        return layer(x, attention_mask=mask, position_ids=pos, past_key_value=kv, use_cache=True, tree_bits=bits, tree_keys=t1, kv_start=start)[0]
+_run = run
+run = run_tree
+y_tr = run().float()
+t_tr = timeit()
+layer.inplace_cache = True
+def run_tree_inplace():
+    with torch.no_grad():
+        return layer(x, attention_mask=mask, position_ids=pos, past_key_value=prefix, use_cache=True, tree_bits=bits, tree_keys=t1, kv_start=start)[0]
+run = run_tree_inplace
+run()
+t_tri = timeit()
+layer.inplace_cache = False
+run = _run
+out["hip_tree_attention_us"] = t_tr
+out["hip_tree_attention_inplace_cache_us"] = t_tri
+out["max_rel_diff_tree_vs_mask"] = float((y_tr - y_hip).abs().max() / y_hip.abs().max())
+print(json.dumps({k: out[k] for k in ("hip_tree_attention_us", "hip_tree_attention_inplace_cache_us", "max_rel_diff_tree_vs_mask")}))
 if len(sys.argv) > 3:
     json.dump(out, open(sys.argv[3], "w"), indent=1)
 

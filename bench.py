@@ -102,6 +102,28 @@ def parse():
 
 # ----------------------------------------------------------------------------- CPU baseline
 
+def effective_cpus() -> int:
+    """Cores this process can really use: the affinity mask cut by the cgroup CPU quota (a GPU box hands a container a share of its
+    host -- os.cpu_count() said 256 where ~16 cores' worth of time was available, and 63 baseline threads ran 4.6x slower each than one
+    alone).  LANTERN_CPU_THREADS overrides."""
+    if os.environ.get("LANTERN_CPU_THREADS"):
+        return max(1, int(os.environ["LANTERN_CPU_THREADS"]))
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]                      # cgroup v2
+        if q != "max":
+            n = min(n, max(1, int(round(int(q) / int(p)))))
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())               # cgroup v1
+            p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0 and p > 0:
+                n = min(n, max(1, int(round(q / p))))
+        except (OSError, ValueError):
+            pass
+    return max(1, n)
+
+
 def cpu_baseline(wl, steps_budget_s: float, n_seq: int, gpu_tokens_by_seq, python_budget_s=None):
     """The oracle (C restatement of the reference's Python path) over the first n_seq sequences and as
     many steps as fit the budget, one host thread per sequence.  Checker AND timed baseline: the
@@ -167,7 +189,7 @@ def cpu_baseline(wl, steps_budget_s: float, n_seq: int, gpu_tokens_by_seq, pytho
             toks.append((best, alen, tok))
         out[b] = toks
 
-    cores = os.cpu_count() or 1
+    cores = effective_cpus()
     threads = min(cores, n_seq)
     if python_budget_s is None:
         python_budget_s = steps_budget_s
@@ -242,7 +264,8 @@ def cpu_baseline(wl, steps_budget_s: float, n_seq: int, gpu_tokens_by_seq, pytho
     # the headline CPU figure is the fastest C leg (the Python-threaded one is throttled by the interpreter, not by the algorithm);
     # the others ride along: one thread per sequence, one thread in all, the Python-threaded loop
     head = all_leg if (all_leg is not None and all_leg["value"] > c_leg["value"]) else c_leg
-    return dict(head, kind="port", host_cores=cores, one_thread_per_sequence=c_leg, all_cores=all_leg, python_threads=py_leg, single_thread=single,
+    return dict(head, kind="port", host_cores=os.cpu_count() or 1, usable_cores=cores, sequences_over_threads=c_leg, all_cores=all_leg, python_threads=py_leg,
+                single_thread=single,
                 matches_gpu_token_stream=(c_mis == 0 and mismatches == 0), mismatches=c_mis + mismatches)
 
 
@@ -337,17 +360,27 @@ def kernel_report(wl, evs, E0, E1, KT):
     if wl.windowed:
         # what the windowed kernel actually has to move (rows are 8192-wide windows; gathers/zeroing/scan/bonus draw in LDS)
         wb = wl.ep_window_bytes(E0, E1, group=0) / KT
+        # both fractions at the top level: `frac` prices the SURVEY 8d contract bytes (dense V-wide rows that the windowed design never
+        # moves: an equivalent rate, it can exceed what the memory system does), `frac_needed` the bytes this kernel has to move -- the
+        # physical HBM fraction
+        rl["frac_contract"] = rl["frac"]
+        rl["needed_bytes_per_launch"] = wb
+        rl["achieved_needed"] = wb / (ep_ms * 1e-3) / 1e9
+        rl["frac_needed"] = wb / (ep_ms * 1e-3) / 1e9 / 8000.0
         rl["windowed_kernel"] = {"hbm_bytes_needed_per_launch": wb, "achieved": wb / (ep_ms * 1e-3) / 1e9,
                                  "frac": wb / (ep_ms * 1e-3) / 1e9 / 8000.0,
                                  "definition": "(L+fresh)*W*4 + T*k*2 + R*W*4, W=8192 (DESIGN.md 4)" +
                                                ("; raw rows: a visited row is 2 x W bf16 = the same W*4 bytes" if wl.fused_o7 else "")}
-    tfile = os.path.join(ROOT, "profiles", "r02_ep_traffic.json")
+    tfile = os.path.join(ROOT, "profiles", "r03_ep_traffic.json")
     if wl.windowed and os.path.exists(tfile):
         key = ("raw" if wl.fused_o7 else ((cfg.ep_kernel if cfg.ep_kernel in ("nodes", "walk") else "nodes") if wl.ep_nodes is not None else "chain")) + f"_B{wl.Bg}"
-        t = json.load(open(tfile)).get("per_launch", {}).get(key)
-        if t:      # PMC passes are separate rocprofv3 runs of the same kernel / launch size, see profiles/
+        tj = json.load(open(tfile))
+        t = tj.get("per_launch", {}).get(key)
+        if t:      # PMC passes are separate rocprofv3 runs of the same kernel / launch size (tools/run/prof_default.sh), not part of this run:
+            # the file carries the commit it was measured at -- a kernel edited since then makes the figure stale
             rl["traffic"] = t["hbm_bytes"]
-            rl["traffic_source"] = "profiles/r02_ep_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH doubled per the gfx950 note)"
+            rl["traffic_source"] = ("profiles/r03_ep_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH doubled per the gfx950 note), "
+                                    f"measured at commit {tj.get('commit')}")
     ks = {}
     if "cfg_mask_topk" in evs[0]:
         o7_ms = mean_ms("cfg_mask_topk")
@@ -481,6 +514,74 @@ def dynamic_run(device, base_cfg, steps, n_seq, fuse_o7=False):
     del wl
     torch.cuda.empty_cache()
     return r
+
+
+def other_configs(device, base_cfg, steps, n_seq):
+    """BASELINE configs 2 and 4 on the clock (same GPU, after the headline run; rank 0, N = 1).
+    C2  LlamaGen + EAGLE, standard (non-relaxed) verify: V = 16384 (window = vocabulary), dynamic EAGLE-2 tree N = 59 (top_k 10, depth 4),
+        lantern off, HF processors T = 1 / top_k 2000, LlamaGen-B KV geometry (12 layers x 12 heads x 64, 2 slabs per sequence);
+        O4 -> O6 -> O7 -> O8 -> O9 + O10 per step (ea_model_llamagen.py:709-787, :930, :1137-1163).
+    C4  Anole-7B 512x512, LANTERN++ static tree naive_extend_57 (N = 58, P = 33, D = 6), the reference's settings (lambda, k) in
+        {(5, 10), (10, 5), (20, 5)} (run.sh:76-91): O6 -> O7 (all rows) -> O8 (chain kernel, neighbours zeroed in the drafter's row:
+        ea_model_anole.py:597-669) -> O9 + O10, 7B KV geometry, 3 stream groups; plus the one-group per-kernel pass for the roofline."""
+    import dataclasses
+    from lantern_amd import harness as HN
+    res = {}
+    # ---- C2
+    dc = HN.DynamicConfig(model="llamagen", n_seq=n_seq, depth=4, total_tokens=58, kv_layers=12, kv_heads=12, kv_dim=64, kv_smax=base_cfg.kv_smax,
+                          kv_pad_rows=base_cfg.kv_pad_rows, with_kv=base_cfg.with_kv, max_steps=2 * steps + 32, plausible=8.0)
+    wl = HN.DynamicVerifyWorkload(dc, device)
+    for _ in range(10):
+        wl.step()
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        wl.step()
+    torch.cuda.synchronize(device)
+    dt = time.perf_counter() - t0
+    names = event_names(wl)
+    KE = min(steps, 20)
+    evs = make_events(names, KE, device)
+    for i in range(KE):
+        wl.step(evs[i])
+    torch.cuda.synchronize(device)
+    wl.check_status(0, steps + 10 + KE)
+    toks = wl.accepted_tokens(10, 10 + steps)
+    cnt = wl.log_cnt[10 + steps:10 + steps + KE].double()
+    ep_ms = float(np.mean([e["evaluate_posterior"][0].elapsed_time(e["evaluate_posterior"][1]) for e in evs]))
+    # bytes evaluate_posterior has to move per launch: one W-wide f32 row per visited level (+ the final row when it is a fresh softmax)
+    Wc = wl.W
+    needed = float(((cnt[..., 0] + (1.0 - cnt[..., 4])) * Wc * 4).sum() / KE)
+    res["C2"] = {"workload": f"C2: LlamaGen + EAGLE standard verify, V=16384, dynamic tree N={wl.N} (top_k 10, depth 4), lantern off, processors T=1/top_k=2000, "
+                             f"{n_seq} sequences, KV [24,1,12,{dc.kv_smax}(+{dc.kv_pad_rows}),64] bf16 x2 per sequence",
+                 "value": toks / dt, "unit": "accepted_tokens/s", "ms_per_step": 1e3 * dt / steps, "steps": steps, "mean_accept_length": toks / (steps * n_seq),
+                 "kernel_ms": {n: float(np.mean([e[n][0].elapsed_time(e[n][1]) for e in evs])) for n in names},
+                 "evaluate_posterior": {"avg_launch_ms": ep_ms, "needed_bytes_per_launch": needed, "achieved_GBps": needed / (ep_ms * 1e-3) / 1e9,
+                                        "frac_needed": needed / (ep_ms * 1e-3) / 1e9 / 8000.0}}
+    wl.release_kv()
+    del wl
+    torch.cuda.empty_cache()
+    # ---- C4
+    if base_cfg.with_kv:          # as many sequences as the slabs (2 x 2.1 GiB each at 4096 rows) + pools leave room for, in whole stream groups
+        free, _ = torch.cuda.mem_get_info(device)
+        per_seq = 2 * (2 * 32 * 32 * (base_cfg.kv_smax + base_cfg.kv_pad_rows) * 128 * 2) + base_cfg.pool_steps * 58 * (2 * 65536 * 2 + 2 * 4096 * 2 + 8192 * 4)
+        n_seq = max(3, min(n_seq, int((free - (28 << 30)) // per_seq)))
+        n_seq -= n_seq % 3
+    groups = 3 if n_seq % 3 == 0 else 1
+    res["C4"] = []
+    for lam, kk in ((5.0, 10), (10.0, 5), (20.0, 5)):
+        over = dict(model="anole", tree="naive_extend_57", lantern_k=kk, lantern_delta=lam, fuse_o7=False, spec_rows=0, ep_kernel="chain",
+                    seed_base=4000)
+        grouped = side_run(device, base_cfg, steps, n_groups=groups, n_seq=n_seq, **over)
+        one = per_kernel_run(device, base_cfg, min(steps, 40), n_seq=n_seq, **{k_: v_ for k_, v_ in over.items() if k_ not in ("fuse_o7", "spec_rows")})
+        rl = one["roofline"]
+        res["C4"].append({"workload": f"C4: Anole-7B 512x512 LANTERN++ static tree naive_extend_57 (N=58,P=33,D=6), lambda={lam:g}, k={kk}, {n_seq} sequences in "
+                                      f"{groups} stream groups, 7B KV geometry",
+                          "lantern_delta": lam, "lantern_k": kk, "value": grouped["value"], "unit": "accepted_tokens/s", "ms_per_step": grouped["ms_per_step"],
+                          "mean_accept_length": grouped["mean_accept_length"], "one_group_ms_per_step": one["ms_per_step"],
+                          "evaluate_posterior": {k_: rl.get(k_) for k_ in ("kernel", "avg_launch_ms", "achieved", "frac", "needed_bytes_per_launch", "frac_needed", "unit")},
+                          "kernels": one["kernels"]})
+    return res
 
 
 def side_run(device, base_cfg, steps, **over):
@@ -787,10 +888,12 @@ def main():
             out["dynamic_tree"] = dynamic_run(device, cfg, min(K, 100), n_seq, fuse_o7=True)
             out["dynamic_tree"]["all_rows_by_cfg_mask_topk"] = {k: v for k, v in dynamic_run(device, cfg, min(K, 100), n_seq, fuse_o7=False).items()
                                                                 if k in ("value", "ms_per_step", "kernel_ms")}
+        if not args.no_extras and world == 1 and wl.windowed:
+            out["configs"] = other_configs(device, cfg, min(K, 60), n_seq)
         if args.ep_sweep and world == 1:
             out["ep_batch_sweep"] = ep_batch_sweep([int(x) for x in args.ep_sweep.split(",") if x], device, cfg)
         if args.cpu_seconds > 0 and world == 1:      # the CPU baseline is reported at N = 1 only
-            n_cpu = args.cpu_seqs or min(cfg.n_seq, os.cpu_count() or 1)
+            n_cpu = args.cpu_seqs or cfg.n_seq
             gpu_stream = [[(int(gb[i, b]), int(ga[i, b]), int(gt[i, b])) for b in range(cfg.n_seq)] for i in range(n_logged)]
             out["cpu_baseline"] = cpu_baseline(wl, args.cpu_seconds, n_cpu, gpu_stream, python_budget_s=min(args.cpu_seconds, 8.0))
             if not out["cpu_baseline"]["matches_gpu_token_stream"]:

@@ -7,10 +7,11 @@ softmax attention under the additive drafter mask, o_proj) -> residual -> Chamel
 During drafting the layer sees M = 2 x top_k = 20 rows per call, six calls per verify cycle: its cost is the 404 MB of
 projection weights it streams (7B: 4 x 4096^2 + 3 x 4096 x 11008 bf16), not arithmetic.  The seven projections therefore go
 through `lantern_linear_rows` (drafter_fc.hip: `linear_rows_kernel`, MFMA 32x32x16 fed straight from the [out, in] weight rows,
-M <= 128) with q/k/v and gate/up each fused into ONE launch over a concatenated weight; norms, rotary and the 20-row attention are
-small torch ops.  Anything the kernel is not built for (CPU tensors, other dtypes, M > 128: the drafter's prefill) takes
-torch.nn.functional.linear -- the layer is a drop-in nn.Module with the reference's parameter names (`self_attn.q_proj.weight`,
-`mlp.gate_proj.weight`, `input_layernorm.weight`, ...), so a reference drafter checkpoint loads into it unchanged.
+M <= 128) with q/k/v and gate/up each fused into ONE launch over a concatenated weight; norms, head norm + rotary are single HIP kernels and
+the attention is lantern_tree_attention when the caller hands the tree block over as ancestor words (cnets.Model.forward does).  CPU tensors
+and other dtypes (the f32 reference vectors) and M > 128 (the drafter's prefill) take torch.nn.functional.linear; the drafting shape on the
+device either runs the fused HIP path or raises (no silent switch) -- the layer is a drop-in nn.Module with the reference's parameter names
+(`self_attn.q_proj.weight`, `mlp.gate_proj.weight`, `input_layernorm.weight`, ...), so a reference drafter checkpoint loads into it unchanged.
 """
 from __future__ import annotations
 
@@ -285,6 +286,15 @@ class DecoderLayer(nn.Module):
 
     def forward(self, hidden_states, attention_mask=None, position_ids=None, past_key_value=None, output_attentions=False, use_cache=False,
                 tree_bits=None, tree_keys=0, kv_start=None, **kw) -> Tuple[torch.Tensor, ...]:
+        if (self.fused and not output_attentions and hidden_states.dim() == 3 and hidden_states.is_cuda and hidden_states.dtype == torch.bfloat16
+                and hidden_states.shape[0] * hidden_states.shape[1] <= 32 and _hip_ok(hidden_states, self.self_attn.q_proj.weight)
+                and not self._fast_ok(hidden_states, position_ids, output_attentions)):
+            # the drafting shape must not slide onto torch's ops unnoticed: say which precondition of the fused HIP path is missing
+            at = self.self_attn
+            raise ops._lib.LanternError(
+                f"DecoderLayer: the drafting shape ({tuple(hidden_states.shape)}, bf16, device) takes the fused HIP path, which needs head_dim 64 or 128 "
+                f"(got {at.head_dim}), silu, bf16 weights / norms, hidden % 16 == 0 and position_ids; set `layer.fused = False` for the per-projection "
+                "path (skinny GEMM under torch's element-wise ops)")
         if self._fast_ok(hidden_states, position_ids, output_attentions):
             if tree_bits is not None and not (0 < hidden_states.shape[1] <= tree_keys <= 64):
                 tree_bits = None

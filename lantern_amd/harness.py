@@ -43,6 +43,9 @@ HIDDEN = 4096
 
 @dataclass
 class WorkloadConfig:
+    model: str = "lumina"           # "lumina" (BASELINE C3 / C5) or "anole" (C4: Anole-7B 512x512, LANTERN++ static tree -- the same 7B KV geometry and
+                                    # image-token window; no grammar rows, the neighbours of a rejected token are zeroed in the DRAFTER's row:
+                                    # ea_model_anole.py:597-669, :930-931; rows post-processed by cfg_mask_topk, the chain kernel on probability rows)
     tree: str = "mc_sim_7b_63"      # static tree by its name in drafters/choices.py (the reference's default for Lumina, generate_images.py:59)
     n_seq: int = 64                 # 4.3 GB of KV slabs each (BASELINE.md geometry: 4096 rows) -> 276e9 of the GPU's 309e9 bytes
     pool_steps: int = 16
@@ -165,7 +168,12 @@ class LuminaVerifyWorkload:
         self.cond = torch.empty((S, B, N, V), dtype=torch.bfloat16, device=device)
         self.uncond = torch.empty((S, B, N, V), dtype=torch.bfloat16, device=device)
         self.windowed = cfg.path == "window"
-        self.fused_o7 = self.windowed and cfg.fuse_o7 and cfg.ep_kernel in ("chain", "fast")
+        if cfg.model not in ("lumina", "anole"):
+            raise ValueError(f"model={cfg.model}")
+        self.anole = cfg.model == "anole"
+        self.o7_model = ops.MODEL_ANOLE if self.anole else ops.MODEL_LUMINA
+        self.tokens_per_image = 32 * 32 if self.anole else TOKENS_PER_IMAGE          # Anole 512x512: 1024 image tokens, no newline / header rows
+        self.fused_o7 = self.windowed and cfg.fuse_o7 and cfg.ep_kernel in ("chain", "fast") and not self.anole
         self.n_spec = min(max(int(cfg.spec_rows), 0), N) if self.fused_o7 else 0
         if self.n_spec:
             # likelihood order of the nodes: fewer / earlier choices first (the drafter ranks its candidates), the root always
@@ -226,7 +234,7 @@ class LuminaVerifyWorkload:
         self.slabs: List[torch.Tensor] = []
         if cfg.with_kv:
             # prompt + header + the image tokens this run can reach (<= D per step) + the tree's rows behind them
-            longest = cfg.prompt_len + 3 + min(TOKENS_PER_IMAGE, cfg.max_steps * self.D) + self.N
+            longest = cfg.prompt_len + 3 + min(self.tokens_per_image, cfg.max_steps * self.D) + self.N
             if cfg.kv_smax < longest:
                 raise _lib.LanternError(f"kv_smax={cfg.kv_smax} rows cannot hold a sequence of this workload ({longest} rows)")
             shape = (2 * cfg.kv_layers, 1, cfg.kv_heads, cfg.kv_smax + cfg.kv_pad_rows, cfg.kv_dim)
@@ -372,10 +380,14 @@ class LuminaVerifyWorkload:
         c = self.cfg
         p = EpParams()
         p.B, p.P, p.D, p.V, p.rows_per_seq = self.Bg, self.P, self.D, V, self.N
-        p.mode, p.syntax_shortcut, p.tok_offset = ops.MODE_STATIC_LUMINA, 1, 4
-        p.img_lo, p.img_hi, p.n_syntax = IMG_LO, IMG_HI, 4
-        for i, s in enumerate((8196, 8197, 8803, 8828)):
-            p.syntax[i] = s
+        if self.anole:              # ea_model_anole.py: no syntax shortcut; static trees zero the neighbours in q (MODE_STATIC_LG)
+            p.mode, p.syntax_shortcut, p.tok_offset = ops.MODE_STATIC_LG, 0, 4
+            p.img_lo, p.img_hi, p.n_syntax = IMG_LO, IMG_HI, 0
+        else:
+            p.mode, p.syntax_shortcut, p.tok_offset = ops.MODE_STATIC_LUMINA, 1, 4
+            p.img_lo, p.img_hi, p.n_syntax = IMG_LO, IMG_HI, 4
+            for i, s in enumerate((8196, 8197, 8803, 8828)):
+                p.syntax[i] = s
         p.lantern, p.k, p.delta = 1, c.lantern_k, c.lantern_delta
         p.table_rows, p.table_cols = K_CODES, self.table_cols
         p.top_k, p.temperature, p.top_p = 0, 1.0, 1.0       # Lumina filters in O7, not per level
@@ -544,7 +556,7 @@ class LuminaVerifyWorkload:
             s.tree_indices, s.retrieve = self.d_tree_indices.data_ptr(), self.d_retrieve.data_ptr()
             s.B, s.n_flat, s.N, s.P, s.D = self.Bg, self.R * 10, self.N, self.P, self.D
             s.tree_cand, s.cand, s.cart_prob = val(A["tree_cand"]), val(A["cand"]), val(A["cart_prob"])
-            s.cond, s.uncond, s.dtype, s.V, s.cfg, s.model = val(A["cond"]), val(A["uncond"]), 1, V, c.cfg_scale, ops.MODEL_LUMINA
+            s.cond, s.uncond, s.dtype, s.V, s.cfg, s.model = val(A["cond"]), val(A["uncond"]), 1, V, c.cfg_scale, self.o7_model
             s.pos_ids, s.pos_base = self.d_pos_ids.data_ptr(), c.prompt_len + 3
             s.w_latent, s.h_latent, s.img_lo, s.img_hi, s.newline_id, s.eos_id, s.top_k = W_LATENT, H_LATENT, IMG_LO, IMG_HI, NEWLINE, EOS, c.top_k
             s.win_lo, s.win_len, s.out_kind = self.win_lo, self.W, ops.ROWS_PROBS if c.rows_probs else ops.ROWS_LOGITS
@@ -596,13 +608,13 @@ class LuminaVerifyWorkload:
                     torch.add(self.lens[parity][2 * s0:2 * s0 + 2 * B], (self.log_alen[step, s0:s0 + B] + 1).repeat(2), out=self.lens[parity ^ 1][2 * s0:2 * s0 + 2 * B])
         # sequence management (not the hot path): an image can only end once the host-side bound says so
         self._len_ub += self.D
-        if self._len_ub >= TOKENS_PER_IMAGE:
+        if self._len_ub >= self.tokens_per_image:
             self.launches_done()
             for g in range(self.G):
                 s0, B = g * self.Bg, self.Bg
                 with torch.cuda.stream(self.streams[g]) if self.streams[g] is not None else _nullctx():
                     nxt, base = self.lens[parity ^ 1][2 * s0:2 * s0 + 2 * B], self.len_base[2 * s0:2 * s0 + 2 * B]
-                    torch.where(nxt - base >= TOKENS_PER_IMAGE, base, nxt, out=nxt)
+                    torch.where(nxt - base >= self.tokens_per_image, base, nxt, out=nxt)
             self.join()
             self._len_ub = int((self.lens[parity ^ 1] - self.len_base).max().item())
             self._forked = False
@@ -703,13 +715,13 @@ class LuminaVerifyWorkload:
         if self.fused_o7:
             pass                                  # evaluate_posterior reads the raw logits itself
         elif self.windowed:
-            check(L.lantern_cfg_mask_topk_window(A["cond"], A["uncond"], 1, B * N, V, C.c_float(c.cfg_scale), ops.MODEL_LUMINA,
+            check(L.lantern_cfg_mask_topk_window(A["cond"], A["uncond"], 1, B * N, V, C.c_float(c.cfg_scale), self.o7_model,
                                                  vp(self.d_pos_ids.data_ptr()), C.c_int64(c.prompt_len + 3), W_LATENT, H_LATENT, IMG_LO, IMG_HI,
                                                  NEWLINE, EOS, c.top_k, A["cur"], N, self.win_lo, self.W, A["proc"], A["row_hot"],
                                                  ops.ROWS_PROBS if c.rows_probs else ops.ROWS_LOGITS, C.c_float(1.0), C.c_float(1.0), st),
                   "cfg_mask_topk_window")
         else:
-            check(L.lantern_cfg_mask_topk(A["cond"], A["uncond"], 1, B * N, V, C.c_float(c.cfg_scale), ops.MODEL_LUMINA,
+            check(L.lantern_cfg_mask_topk(A["cond"], A["uncond"], 1, B * N, V, C.c_float(c.cfg_scale), self.o7_model,
                                           vp(self.d_pos_ids.data_ptr()), C.c_int64(c.prompt_len + 3), W_LATENT, H_LATENT, IMG_LO, IMG_HI,
                                           NEWLINE, EOS, c.top_k, A["cur"], N, A["proc"], st), "cfg_mask_topk")
         if events:
@@ -767,15 +779,15 @@ class LuminaVerifyWorkload:
             # per step: skip it while no sequence can have reached the image length
             if g == 0:
                 self._len_ub += D
-            if self._len_ub >= TOKENS_PER_IMAGE:
+            if self._len_ub >= self.tokens_per_image:
                 s0 = g * self.Bg
                 nxt, base = self.lens[parity ^ 1][2 * s0:2 * s0 + 2 * B], self.len_base[2 * s0:2 * s0 + 2 * B]
-                torch.where(nxt - base >= TOKENS_PER_IMAGE, base, nxt, out=nxt)
+                torch.where(nxt - base >= self.tokens_per_image, base, nxt, out=nxt)
                 if g == self.G - 1:             # refresh the bound: one host sync every few hundred steps
                     self.join()
                     self._len_ub = int((self.lens[parity ^ 1] - self.len_base).max().item())
             return
-        check(L.lantern_harness_advance(B, 2 * B, c.n_seq, C.c_int64(TOKENS_PER_IMAGE), C.c_int64(c.max_steps),
+        check(L.lantern_harness_advance(B, 2 * B, c.n_seq, C.c_int64(self.tokens_per_image), C.c_int64(c.max_steps),
                                         C.c_int64(-1 if torch.cuda.is_current_stream_capturing() or self.graphs is not None else self.step_idx),
                                         A["step_dev"], A["st_best"],
                                         A["st_alen"], A["st_cnt"], A["st_token"], A["log_best"], A["log_alen"], A["log_cnt"], A["log_token"],
@@ -864,6 +876,9 @@ class LuminaVerifyWorkload:
 # models/drafters/cnets_lumina_mgpt.py:1229-1393 (topK_genrate), models/ea_model_lumina_mgpt.py:610-726 (eagle_version 2 branch).
 @dataclass
 class DynamicConfig:
+    model: str = "lumina"           # "lumina": the dynamic half of C3; "llamagen": BASELINE C2 -- LlamaGen + EAGLE, standard (non-relaxed) verify:
+                                    # V = 16384 (the whole vocabulary is the window), no CFG grammar, lantern off, HF processors T = 1 / top_k 2000
+                                    # (ea_model_llamagen.py:709-787, :930), drafter depth 4, 256 tokens per image, LlamaGen-B KV geometry via kv_*
     n_seq: int = 64
     pool_steps: int = 4
     top_k: int = 10                 # drafter top_k (generate_images.py: drafter_top_k 10)
@@ -893,6 +908,14 @@ class DynamicVerifyWorkload:
         B, S, TK, DP, TT = cfg.n_seq, cfg.pool_steps, cfg.top_k, cfg.depth, cfg.total_tokens
         self.N = N = TT + 1
         self.P, self.D = N, DP + 2
+        self.lg = cfg.model == "llamagen"
+        if cfg.model not in ("lumina", "llamagen"):
+            raise ValueError(f"model={cfg.model}")
+        # vocabulary, image-token window, hidden width, tokens per image of the model
+        V, IMG_LO, IMG_HI = (16384, 0, 16384) if self.lg else (globals()["V"], globals()["IMG_LO"], globals()["IMG_HI"])
+        HIDDEN = 768 if self.lg else globals()["HIDDEN"]
+        self.V, self.lo, self.hi, self.hidden_w = V, IMG_LO, IMG_HI, HIDDEN
+        self.tokens_per_image = 256 if self.lg else TOKENS_PER_IMAGE
         self.W, self.win_lo = IMG_HI - IMG_LO, IMG_LO
         g = torch.Generator(device=device).manual_seed(cfg.seed)
         W = self.W
@@ -903,10 +926,15 @@ class DynamicVerifyWorkload:
             kth = torch.topk(x, cfg.logit_top_k, dim=-1).values[..., -1:]
             return x.masked_fill(x < kth, float("-inf"))
 
-        table_full = build_neighbour_table(device, 0)
-        self.table_full = table_full
-        self.table_cols = min(K_CODES, -(-(cfg.lantern_k + 1) // 8) * 8)
-        self.table = ops.pack_vq_table(table_full, self.table_cols)
+        self.lantern = not self.lg
+        if self.lantern:
+            table_full = build_neighbour_table(device, 0)
+            self.table_full = table_full
+            self.table_cols = min(K_CODES, -(-(cfg.lantern_k + 1) // 8) * 8)
+            self.table = ops.pack_vq_table(table_full, self.table_cols)
+        else:
+            self.table_full = self.table = None
+            self.table_cols = 0
         self.pools = []
         for s in range(S):          # the drafter side of a step (setup, untimed): O3 per depth on random rows, then one O4 to learn the shapes
             ti, cu, ci, sc = ops.expand_dynamic(img_logits(B, 1), None, TK)
@@ -970,24 +998,30 @@ class DynamicVerifyWorkload:
         self._L = _lib.lib()
         p = EpParams()
         p.B, p.P, p.D, p.V, p.rows_per_seq = B, self.P, self.D, V, N
-        p.mode, p.syntax_shortcut, p.tok_offset = ops.MODE_DYNAMIC, 1, 4
-        p.img_lo, p.img_hi, p.n_syntax = IMG_LO, IMG_HI, 4
-        for i, sx in enumerate((8196, 8197, 8803, 8828)):
-            p.syntax[i] = sx
-        p.lantern, p.k, p.delta = 1, cfg.lantern_k, cfg.lantern_delta
-        p.table_rows, p.table_cols = K_CODES, self.table_cols
+        if self.lg:
+            p.mode, p.syntax_shortcut, p.tok_offset = ops.MODE_DYNAMIC, 0, 0
+            p.img_lo, p.img_hi, p.n_syntax = 0, V, 0
+            p.lantern, p.k, p.delta = 0, 1, 0.1
+            p.table_rows, p.table_cols = 0, 0
+        else:
+            p.mode, p.syntax_shortcut, p.tok_offset = ops.MODE_DYNAMIC, 1, 4
+            p.img_lo, p.img_hi, p.n_syntax = IMG_LO, IMG_HI, 4
+            for i, sx in enumerate((8196, 8197, 8803, 8828)):
+                p.syntax[i] = sx
+            p.lantern, p.k, p.delta = 1, cfg.lantern_k, cfg.lantern_delta
+            p.table_rows, p.table_cols = K_CODES, self.table_cols
         p.top_k, p.temperature, p.top_p = 0, 1.0, 1.0
         p.n_uniforms, p.row_index_per_seq = self.uniforms.shape[1], 1
         self._prm = p
         b = EpBuffers()
         b.logits, b.row_index, b.cand = self.win.data_ptr(), self.row_index.data_ptr(), self.cand.data_ptr()
         b.n_paths, b.n_depth = self.nleaf.data_ptr(), self.mdepth.data_ptr()
-        b.nn_table, b.uniforms, b.cursor = self.table.data_ptr(), self.uniforms.data_ptr(), self.cursor.data_ptr()
+        b.nn_table, b.uniforms, b.cursor = (self.table.data_ptr() if self.table is not None else None), self.uniforms.data_ptr(), self.cursor.data_ptr()
         self._buf = b
         w = EpWindow()
         w.win_lo, w.win_len, w.row_hot = IMG_LO, W, self.hot.data_ptr()
         w.out_tok, w.out_mass, w.rows_kind = self.out_tok.data_ptr(), self.out_mass.data_ptr(), ops.ROWS_PROBS
-        self.fused_o7 = bool(cfg.fuse_o7)
+        self.fused_o7 = bool(cfg.fuse_o7) and not self.lg
         if self.fused_o7:               # raw rows: positions are per sequence and absolute (O6 dynamic writes them), the processors' parameters ride along
             w.rows_kind, w.raw_pos_per_seq = ops.ROWS_RAW_BF16, 1
             w.raw_pos_ids, w.raw_seq_len, w.raw_pos_base = self.pos_abs.data_ptr(), None, cfg.prompt_len + 3
@@ -1008,6 +1042,7 @@ class DynamicVerifyWorkload:
         if i >= c.max_steps:
             raise _lib.LanternError(f"step {i} >= max_steps {c.max_steps}")
         B, N, P, D = c.n_seq, self.N, self.P, self.D
+        V, IMG_LO, IMG_HI, HIDDEN = self.V, self.lo, self.hi, self.hidden_w
         pool = self.pools[i % c.pool_steps]
         cur, nxt = self.lens[i & 1], self.lens[(i & 1) ^ 1]
         st = vp(torch.cuda.current_stream().cuda_stream)
@@ -1027,7 +1062,7 @@ class DynamicVerifyWorkload:
         else:
             arm("cfg_mask_topk")
             check(L.lantern_cfg_mask_topk_window(vp(pool["cond"].data_ptr()), vp(pool["unc"].data_ptr()), 1, B * N, V, C.c_float(c.cfg_scale),
-                                                 ops.MODEL_LUMINA, vp(self.pos_abs.data_ptr()), C.c_int64(c.prompt_len + 3), W_LATENT, H_LATENT, IMG_LO,
+                                                 ops.MODEL_PLAIN if self.lg else ops.MODEL_LUMINA, vp(self.pos_abs.data_ptr()), C.c_int64(c.prompt_len + 3), W_LATENT, H_LATENT, IMG_LO,
                                                  IMG_HI, NEWLINE, EOS, c.logit_top_k, None, 0, IMG_LO, self.W, vp(self.win.data_ptr()),
                                                  vp(self.hot.data_ptr()), ops.ROWS_PROBS, C.c_float(1.0), C.c_float(1.0), st), "cfg_mask_topk_window")
         b.best, b.accept_len, b.counters = bs["best"] + 4 * e, bs["alen"] + 4 * e, bs["cnt"] + 24 * e
@@ -1044,8 +1079,8 @@ class DynamicVerifyWorkload:
         else:
             torch.add(cur, (self.log_alen[i] + 1).repeat(2), out=nxt)
         self._len_ub += D
-        if self._len_ub >= TOKENS_PER_IMAGE:      # an image can end: wrap those sequences (host bound refreshed every few hundred steps)
-            torch.where(nxt - self.len_base >= TOKENS_PER_IMAGE, self.len_base, nxt, out=nxt)
+        if self._len_ub >= self.tokens_per_image:      # an image can end: wrap those sequences (host bound refreshed every few hundred steps)
+            torch.where(nxt - self.len_base >= self.tokens_per_image, self.len_base, nxt, out=nxt)
             self._len_ub = int((nxt - self.len_base).max().item())
         self.step_idx += 1
 

@@ -74,6 +74,12 @@ def test_layer_hip_path_matches_the_reference_layer_bf16(name, fused, monkeypatc
     layer = build(name, dev, torch.bfloat16)
     layer.fused = fused
     bf = torch.bfloat16
+    if fused and layer.self_attn.head_dim not in (64, 128):
+        # outside the fused kernels the drafting shape raises instead of sliding onto torch's ops unnoticed
+        from lantern_amd._lib import LanternError
+        with pytest.raises(LanternError, match="fused HIP path"):
+            layer(g(name, "x0", dev, bf), attention_mask=g(name, "m0", dev), position_ids=g(name, "pos0", dev), use_cache=True)
+        return
     with torch.no_grad():
         y0, kv0 = layer(g(name, "x0", dev, bf), attention_mask=g(name, "m0", dev), position_ids=g(name, "pos0", dev), use_cache=True)
         y1, kv1 = layer(g(name, "x1", dev, bf), attention_mask=g(name, "m1", dev), position_ids=g(name, "pos1", dev), past_key_value=kv0, use_cache=True)

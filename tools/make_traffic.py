@@ -1,10 +1,13 @@
-"""Collect the round-2 rocprofv3 outputs (tools/run/prof_default.sh) into profiles/: per-kernel stats CSVs, the PMC counter sums
-(FETCH_SIZE / WRITE_SIZE, separate passes) as profiles/r02_ep_traffic.json, and the bench line each profiled run printed."""
-import csv, glob, json, os, shutil, sys, collections
+"""Collect a round's rocprofv3 outputs (tools/run/prof_default.sh <tag> [flags]) into profiles/: per-kernel stats CSVs, the PMC counter sums
+(FETCH_SIZE / WRITE_SIZE, separate passes) as profiles/<round>_ep_traffic.json -- stamped with the commit the numbers were taken at, so that
+bench.py can tell whether they still describe the kernels it runs -- and the bench line each profiled run printed.
+usage: python tools/make_traffic.py [round=r03] [key=dir ...]   (default keys: raw=<round>p chain=<round>p_chain)"""
+import csv, glob, json, os, shutil, subprocess, sys, collections
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-runs = {"raw": "r2p", "chain": "r2p_chain", "nodes": "r2p_nodes", "walk": "r2p_walk"}          # traffic key prefix -> gpurun_out/<dir>
-kern = {"raw": ["epw_kernel"], "chain": ["epw_kernel"], "nodes": ["epn_kernel", "epn_walk_kernel"], "walk": ["epn_serial_kernel"]}
+RND = sys.argv[1] if len(sys.argv) > 1 else "r03"
+runs = dict(a.split("=", 1) for a in sys.argv[2:]) or {"raw": RND + "p", "chain": RND + "p_chain"}          # traffic key prefix -> gpurun_out/<dir>
+kern = {"raw": ["epw_kernel"], "chain": ["epw_kernel"], "nodes": ["epn_kernel", "epn_walk_kernel"], "walk": ["epn_serial_kernel"], "fast": ["epf_kernel"]}
 others = ["prep_rows_kernel", "cfg_window_bf16", "update_inputs_kernel"]
 
 
@@ -46,16 +49,21 @@ for key, d in runs.items():
             out["other_kernels"][f"{key}_B{B}:{k}"] = {"launches_averaged": n, "FETCH_SIZE_raw_KB": f.get("FETCH_SIZE", 0.0),
                                                       "WRITE_SIZE_raw_KB": w.get("WRITE_SIZE", 0.0),
                                                       "hbm_bytes": 2 * f.get("FETCH_SIZE", 0.0) * 1024 + w.get("WRITE_SIZE", 0.0) * 1024}
-    shutil.copy(os.path.join(src, "prof", "default_kernel_stats.csv"), os.path.join(ROOT, "profiles", f"r02_{key}_kernel_stats.csv"))
-    json.dump(line, open(os.path.join(ROOT, "profiles", f"r02_{key}_bench_under_rocprof.json"), "w"), indent=1)
+    shutil.copy(os.path.join(src, "prof", "default_kernel_stats.csv"), os.path.join(ROOT, "profiles", f"{RND}_{key}_kernel_stats.csv"))
+    json.dump(line, open(os.path.join(ROOT, "profiles", f"{RND}_{key}_bench_under_rocprof.json"), "w"), indent=1)
     for c in ("FETCH_SIZE", "WRITE_SIZE"):
         f = glob.glob(os.path.join(src, "pmc_" + ("fetch" if c == "FETCH_SIZE" else "write"), "*counter_collection.csv"))[0]
         rows = [r for r in csv.DictReader(open(f)) if "lantern::" in r["Kernel_Name"]]
-        with open(os.path.join(ROOT, "profiles", "pmc", f"r02_{key}_{c}_B{B}.csv"), "w", newline="") as fh:
+        with open(os.path.join(ROOT, "profiles", "pmc", f"{RND}_{key}_{c}_B{B}.csv"), "w", newline="") as fh:
             w = csv.DictWriter(fh, fieldnames=["Dispatch_Id", "Kernel_Name", "Counter_Name", "Counter_Value"], extrasaction="ignore")
             w.writeheader()
             for r in rows:
                 r["Kernel_Name"] = r["Kernel_Name"][:80]
                 w.writerow(r)
-json.dump(out, open(os.path.join(ROOT, "profiles", "r02_ep_traffic.json"), "w"), indent=1)
+try:
+    out["commit"] = subprocess.check_output(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], text=True).strip()
+    out["tree_dirty"] = bool(subprocess.check_output(["git", "-C", ROOT, "status", "--porcelain", "--", "lantern_amd/csrc", "include"], text=True).strip())
+except Exception:
+    out["commit"] = None
+json.dump(out, open(os.path.join(ROOT, "profiles", f"{RND}_ep_traffic.json"), "w"), indent=1)
 print(json.dumps(out["per_launch"], indent=1))

@@ -19,7 +19,7 @@ Extra objects on the JSON line:
                 the windowed design really has to move; `traffic`: PMC bytes from profiles/r02_ep_traffic.json.
   kernels       the same for the row post-process launch (prepare_step / cfg_mask_topk) and update_inference_inputs.
   per_kernel_single_group  one stream, every stage its own launch: each kernel against its SURVEY 8d roofline at the full 64-sequence
-                launch size, with the chain, node-parallel and serial-node evaluate_posterior.
+                launch size, with the chain and the node-parallel evaluate_posterior.
   ep_batch_sweep  evaluate_posterior alone over {1, 8, 64, 256, 512, 4096} sequences per launch (three forms), after the timed region.
                 `frac` there = bytes really moved / time / 8 TB/s.
   lambda_mode   the same loop with lantern_delta = 5 (LANTERN++: tau = 4 p(x)), BASELINE.md run B.
@@ -71,7 +71,7 @@ def parse():
     ap.add_argument("--sigma", type=float, default=5.0, help="drafter noise; frozen at 5.0: mean accepted tokens/step ~2.6")
     ap.add_argument("--path", choices=["window", "dense"], default="window",
                     help="window: v2 kernels (32 KB image-window rows, LDS-resident residual); dense: v1 kernels (full-V rows)")
-    ap.add_argument("--ep", choices=["nodes", "chain", "walk", "fast"], default="chain",
+    ap.add_argument("--ep", choices=["nodes", "chain"], default="chain",
                     help="windowed evaluate_posterior: nodes = one workgroup per internal tree node + the walk (lantern_evaluate_posterior_nodes); "
                          "chain = one serial chain per sequence (lantern_evaluate_posterior_window)")
     ap.add_argument("--no-fuse-o7", dest="fuse_o7", action="store_false", help="every stage its own launch: cfg_mask_topk for ALL rows, then evaluate_posterior on probability rows "
@@ -82,9 +82,6 @@ def parse():
     ap.add_argument("--kv-smax", type=int, default=4096, help="rows per KV slab (BASELINE.md: 4096 = max_position_embeddings; a 768x768 image needs 2481)")
     ap.add_argument("--kv-pad-rows", type=int, default=None, help="extra rows per (layer, head) group of a KV slab (row stride = kv_smax + pad; harness default 16)")
     ap.add_argument("--spin-up", type=float, default=0.5, help="seconds of untimed setup launches before the warm-up steps (GPU out of its idle power state)")
-    ap.add_argument("--fused-accept", action="store_true", help="evaluate_posterior + update_inference_inputs as one launch (lantern_verify_accept)")
-    ap.add_argument("--fused-workers", type=int, default=0, help="copy workgroups per fused launch (0: 256 / groups - sequences per group)")
-    ap.add_argument("--launch-threads", type=int, default=0, help="enqueue each step's launches from this many worker threads (lantern_step_launcher); 0 = the calling thread")
     ap.add_argument("--no-events", action="store_true", help="skip the eager per-kernel timing pass")
     ap.add_argument("--graph", action="store_true", help="replay one captured hipGraph per (pool slot, group) instead of launching eagerly")
     ap.add_argument("--side-stream", action="store_true", help="launch O6 beside O7 and O10 beside O9 on a second HIP stream (measured slower: event waits)")
@@ -298,11 +295,10 @@ def ep_batch_sweep(batches, device, base_cfg, iters=20):
         buf = wl.ep_buffers(0, 0)
         win = wl.ep_window(0) if wl.windowed else None
         row = {"sequences_per_launch": Bs}
-        for kern in (("chain", "nodes", "walk") if wl.windowed else ("dense",)):
+        for kern in (("chain", "nodes") if wl.windowed else ("dense",)):
             def launch():
                 wl.cursor.zero_()
-                if kern in ("nodes", "walk"):
-                    wl.ep_nodes[0].serial = int(kern == "walk")
+                if kern == "nodes":
                     check(L.lantern_evaluate_posterior_nodes(C.byref(wl._ep_prm), C.byref(buf), C.byref(win), C.byref(wl.ep_nodes[0]), st), "ep")
                 elif kern == "chain":
                     check(L.lantern_evaluate_posterior_window(C.byref(wl._ep_prm), C.byref(buf), C.byref(win), st), "ep")
@@ -345,8 +341,6 @@ def kernel_report(wl, evs, E0, E1, KT):
     ach = contract_bytes / (ep_ms * 1e-3) / 1e9
     if not wl.windowed:
         kname = "ep_kernel (evaluate_posterior)"
-    elif wl.ep_nodes is not None and cfg.ep_kernel == "walk":
-        kname = "epn_serial_kernel (evaluate_posterior, one workgroup per sequence running the node routine along the walk)"
     elif wl.ep_nodes is not None:
         kname = "epn_kernel + epn_walk_kernel (evaluate_posterior, node-parallel)"
     elif wl.fused_o7:
@@ -373,7 +367,7 @@ def kernel_report(wl, evs, E0, E1, KT):
                                                ("; raw rows: a visited row is 2 x W bf16 = the same W*4 bytes" if wl.fused_o7 else "")}
     tfile = os.path.join(ROOT, "profiles", "r03_ep_traffic.json")
     if wl.windowed and os.path.exists(tfile):
-        key = ("raw" if wl.fused_o7 else ((cfg.ep_kernel if cfg.ep_kernel in ("nodes", "walk") else "nodes") if wl.ep_nodes is not None else "chain")) + f"_B{wl.Bg}"
+        key = ("raw" if wl.fused_o7 else ("nodes" if wl.ep_nodes is not None else "chain")) + f"_B{wl.Bg}"
         tj = json.load(open(tfile))
         t = tj.get("per_launch", {}).get(key)
         if t:      # PMC passes are separate rocprofv3 runs of the same kernel / launch size (tools/run/prof_default.sh), not part of this run:
@@ -424,7 +418,7 @@ def per_kernel_run(device, base_cfg, steps=60, **over):
     import dataclasses
     from lantern_amd import harness as HN
     over.setdefault("n_seq", base_cfg.n_seq)
-    cfg = dataclasses.replace(base_cfg, n_groups=1, launch_threads=0, fuse_o7=False, spec_rows=0, max_steps=max(base_cfg.pool_steps, 2 * steps + 20) + 8, **over)
+    cfg = dataclasses.replace(base_cfg, n_groups=1, fuse_o7=False, spec_rows=0, max_steps=max(base_cfg.pool_steps, 2 * steps + 20) + 8, **over)
     wl = HN.LuminaVerifyWorkload(cfg, device)
     wl.prime()
     for _ in range(10):
@@ -456,7 +450,7 @@ def step_latency(device, base_cfg, batches=(1, 8), steps=60):
     from lantern_amd import harness as HN
     res = {}
     for Bs in batches:
-        for kern in ("nodes", "chain", "walk"):
+        for kern in ("nodes", "chain"):
             cfg = HN.WorkloadConfig(n_seq=Bs, pool_steps=4, lantern_k=base_cfg.lantern_k, lantern_delta=base_cfg.lantern_delta, sigma=base_cfg.sigma,
                                     with_kv=base_cfg.with_kv, kv_smax=base_cfg.kv_smax, kv_pad_rows=base_cfg.kv_pad_rows, max_steps=steps + 32,
                                     seed_base=base_cfg.seed_base + 900, ep_kernel=kern, tree=base_cfg.tree)
@@ -477,12 +471,15 @@ def step_latency(device, base_cfg, batches=(1, 8), steps=60):
     return res
 
 
-def dynamic_run(device, base_cfg, steps, n_seq, fuse_o7=False):
+def dynamic_run(device, base_cfg, steps, n_seq, fuse_o7=False, groups=None):
     """The dynamic-tree half of C3 (eagle_version 2: top_k 10, depth 5, 59 nodes, a different tree per sequence and step) on the
-    clock: O4 -> O6 -> O7 -> O8 -> O9 + O10, device-resident, same KV geometry as the headline run."""
+    clock: O4 -> O6 -> O7 -> O8 -> O9 + O10 through lantern_verify_step, device-resident, same KV geometry and stream groups as the
+    headline run; kernel_ms: the per-kernel pass (one ctypes call per kernel, events around group 0's launches)."""
     from lantern_amd import harness as HN
+    if groups is None:
+        groups = base_cfg.n_groups if n_seq % max(1, base_cfg.n_groups) == 0 else 1
     cfg = HN.DynamicConfig(n_seq=n_seq, lantern_k=base_cfg.lantern_k, lantern_delta=base_cfg.lantern_delta, with_kv=base_cfg.with_kv,
-                           kv_smax=base_cfg.kv_smax, kv_pad_rows=base_cfg.kv_pad_rows, max_steps=2 * steps + 32, fuse_o7=fuse_o7)
+                           kv_smax=base_cfg.kv_smax, kv_pad_rows=base_cfg.kv_pad_rows, max_steps=2 * steps + 32, fuse_o7=fuse_o7, n_groups=groups)
     wl = HN.DynamicVerifyWorkload(cfg, device)
     for _ in range(10):
         wl.step()
@@ -505,7 +502,8 @@ def dynamic_run(device, base_cfg, steps, n_seq, fuse_o7=False):
     wl.check_status(0, steps + 10 + KE)
     toks = wl.accepted_tokens(10, 10 + steps)
     cnt = wl.log_cnt[10:10 + steps].float()
-    r = {"workload": f"C3 dynamic tree (EAGLE-2): top_k {cfg.top_k}, depth {cfg.depth}, N={wl.N} nodes, {n_seq} sequences", "value": toks / dt,
+    r = {"workload": f"C3 dynamic tree (EAGLE-2): top_k {cfg.top_k}, depth {cfg.depth}, N={wl.N} nodes, {n_seq} sequences in {groups} stream groups", "value": toks / dt,
+         "stream_groups": groups, "sequences_per_launch": wl.Bg,
          "tree_decoding_rows": "raw bf16 logits post-processed inside evaluate_posterior" if fuse_o7 else "cfg_mask_topk over all N rows",
          "unit": "accepted_tokens/s", "ms_per_step": 1e3 * dt / steps, "steps": steps, "mean_accept_length": toks / (steps * n_seq),
          "per_step": {"levels": float(cnt[..., 0].mean()), "tried": float(cnt[..., 1].mean()), "rejected": float(cnt[..., 2].mean())},
@@ -529,7 +527,8 @@ def other_configs(device, base_cfg, steps, n_seq):
     res = {}
     # ---- C2
     dc = HN.DynamicConfig(model="llamagen", n_seq=n_seq, depth=4, total_tokens=58, kv_layers=12, kv_heads=12, kv_dim=64, kv_smax=base_cfg.kv_smax,
-                          kv_pad_rows=base_cfg.kv_pad_rows, with_kv=base_cfg.with_kv, max_steps=2 * steps + 32, plausible=8.0)
+                          kv_pad_rows=base_cfg.kv_pad_rows, with_kv=base_cfg.with_kv, max_steps=2 * steps + 32, plausible=8.0,
+                          n_groups=(3 if n_seq % 3 == 0 else 1))
     wl = HN.DynamicVerifyWorkload(dc, device)
     for _ in range(10):
         wl.step()
@@ -547,16 +546,16 @@ def other_configs(device, base_cfg, steps, n_seq):
     torch.cuda.synchronize(device)
     wl.check_status(0, steps + 10 + KE)
     toks = wl.accepted_tokens(10, 10 + steps)
-    cnt = wl.log_cnt[10 + steps:10 + steps + KE].double()
+    cnt = wl.log_cnt[10 + steps:10 + steps + KE, :wl.Bg].double()          # the events bracket group 0's launches
     ep_ms = float(np.mean([e["evaluate_posterior"][0].elapsed_time(e["evaluate_posterior"][1]) for e in evs]))
     # bytes evaluate_posterior has to move per launch: one W-wide f32 row per visited level (+ the final row when it is a fresh softmax)
     Wc = wl.W
     needed = float(((cnt[..., 0] + (1.0 - cnt[..., 4])) * Wc * 4).sum() / KE)
     res["C2"] = {"workload": f"C2: LlamaGen + EAGLE standard verify, V=16384, dynamic tree N={wl.N} (top_k 10, depth 4), lantern off, processors T=1/top_k=2000, "
-                             f"{n_seq} sequences, KV [24,1,12,{dc.kv_smax}(+{dc.kv_pad_rows}),64] bf16 x2 per sequence",
+                             f"{n_seq} sequences in {dc.n_groups} stream groups, KV [24,1,12,{dc.kv_smax}(+{dc.kv_pad_rows}),64] bf16 x2 per sequence",
                  "value": toks / dt, "unit": "accepted_tokens/s", "ms_per_step": 1e3 * dt / steps, "steps": steps, "mean_accept_length": toks / (steps * n_seq),
                  "kernel_ms": {n: float(np.mean([e[n][0].elapsed_time(e[n][1]) for e in evs])) for n in names},
-                 "evaluate_posterior": {"avg_launch_ms": ep_ms, "needed_bytes_per_launch": needed, "achieved_GBps": needed / (ep_ms * 1e-3) / 1e9,
+                 "evaluate_posterior": {"avg_launch_ms": ep_ms, "sequences_per_launch": wl.Bg, "needed_bytes_per_launch": needed, "achieved_GBps": needed / (ep_ms * 1e-3) / 1e9,
                                         "frac_needed": needed / (ep_ms * 1e-3) / 1e9 / 8000.0}}
     wl.release_kv()
     del wl
@@ -784,13 +783,12 @@ def main():
                 print(f"bench.py: {free / 2**30:.0f} GiB free: running {n_seq} sequences per rank in {args.groups} stream groups", file=sys.stderr)
     cfg = HN.WorkloadConfig(n_seq=n_seq, pool_steps=args.pool_steps, tree=args.tree, lantern_k=args.lantern_k,
                             lantern_delta=args.lantern_delta, sigma=args.sigma, with_kv=not args.no_kv, kv_smax=args.kv_smax,
-                            path=args.path, ep_kernel=args.ep, fuse_o7=args.fuse_o7, spec_rows=args.spec_rows, native_step=not args.python_launch, launch_threads=args.launch_threads, fused_accept=args.fused_accept, fused_workers=args.fused_workers, use_graph=args.graph, n_groups=args.groups, side_stream=args.side_stream,
+                            path=args.path, ep_kernel=args.ep, fuse_o7=args.fuse_o7, spec_rows=args.spec_rows, native_step=not args.python_launch, use_graph=args.graph, n_groups=args.groups, side_stream=args.side_stream,
                             max_steps=max(args.pool_steps, args.steps + args.warmup + min(args.steps, 100), 80) + 8,
                             **({} if args.kv_pad_rows is None else {"kv_pad_rows": args.kv_pad_rows}))
     wl = HN.LuminaVerifyWorkload(cfg, device, rank=rank)
 
     def barrier():
-        wl.launches_done()          # worker-thread launches: every step is on its stream before the clock is read
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize(device)
@@ -844,7 +842,6 @@ def main():
                        "tree_decoding_rows": (("raw bf16 logits post-processed inside evaluate_posterior (LANTERN_ROWS_RAW_BF16), %d most likely rows per sequence "
                                                "up front with the candidate assembly (lantern_prepare_step)" % wl.n_spec) if getattr(wl, "fused_o7", False)
                                               else "every row post-processed by cfg_mask_topk before evaluate_posterior"),
-                       "launch_threads": cfg.launch_threads, "single_launch_accept": bool(wl.fused_ws is not None) if hasattr(wl, "fused_ws") else False,
                        "stream_groups": cfg.n_groups, "side_stream_for_O6_O10": cfg.side_stream, "sequences_per_launch": wl.Bg, "parallelism": f"dp{world} (independent sequences, no collective)"},
             "mean_accept_length": float(alen.mean()),
             "per_step": {"levels": float(cnt[..., 0].mean()), "tried": float(cnt[..., 1].mean()), "rejected": float(cnt[..., 2].mean())},
@@ -880,7 +877,7 @@ def main():
         if (args.ep_sweep or not args.no_extras) and world == 1:
             wl.release_kv()      # the extra runs build their own workloads: give the memory back first
         if not args.no_extras and world == 1 and wl.windowed:
-            out["per_kernel_single_group"] = {k: per_kernel_run(device, cfg, min(K, 60), ep_kernel=k, n_seq=(args.seqs_per_gpu if n_seq + args.groups > args.seqs_per_gpu else n_seq)) for k in ("chain", "nodes", "walk")}
+            out["per_kernel_single_group"] = {k: per_kernel_run(device, cfg, min(K, 60), ep_kernel=k, n_seq=(args.seqs_per_gpu if n_seq + args.groups > args.seqs_per_gpu else n_seq)) for k in ("chain", "nodes")}
             out["step_latency_us"] = step_latency(device, cfg)
             out["other_groupings"] = {f"groups_{g}": side_run(device, cfg, max(min(K, 100), 60), n_groups=g, n_seq=args.seqs_per_gpu - args.seqs_per_gpu % g)
                                       for g in (1, 2) if g != cfg.n_groups}

@@ -97,6 +97,15 @@ int lantern_tree_dynamic_finalize(const float *scores, const int64_t *tokens, co
                                   float *mask, int64_t *pos_ids, int64_t *retrieve, int32_t *n_leaf,
                                   int32_t *max_depth, void *stream);
 
+/* O4 + O6-dynamic in ONE launch: lantern_tree_dynamic_finalize followed by lantern_gather_candidates_dynamic (below) for the same
+ * sequences -- the workgroup that built a sequence's tree also writes its candidates [B,P,D], compact retrieve rows, row map and
+ * absolute positions (same values as the two calls; lantern_verify_step uses this for dynamic groups). */
+int lantern_tree_dynamic_candidates(const float *scores, const int64_t *tokens, const int64_t *parents,
+                                    const int64_t *sample_token, int B, int n_scores, int n_parents, int top_k,
+                                    int total_tokens, int sort_rows, int64_t *draft_tokens, float *mask, int64_t *pos_ids,
+                                    int64_t *retrieve, int32_t *n_leaf, int32_t *max_depth, const int64_t *seq_len, int P, int D,
+                                    int64_t *cand, int64_t *retrieve_pd, int32_t *row_index, int64_t *pos_abs, void *stream);
+
 /* O3  one EAGLE-2 expansion depth: log_softmax rows -> top_k per row -> cumulative scores
  * -> top_k of the flattened n_rows*top_k.  Replaces cnets_llamagen.py:798-820,
  * cnets_lumina_mgpt.py:1303-1318.
@@ -317,12 +326,9 @@ typedef struct lantern_ep_nodes {
     int32_t prefix_siblings; /* = tables[6] */
     int32_t leaf_workgroups; /* 1: leaves get workgroups that pre-draw their bonus token (small batches: nothing after the node kernel but
                                 a table walk); 0: the walk kernel draws it for the one leaf a walk ends on; -1: chosen by batch size */
-    void *workspace;         /* [dev] lantern_evaluate_posterior_nodes_workspace() bytes, 16-byte aligned (serial: unused, may be NULL) */
+    void *workspace;         /* [dev] lantern_evaluate_posterior_nodes_workspace() bytes, 16-byte aligned */
     size_t workspace_bytes;
-    int32_t serial;          /* 1: ONE workgroup per sequence walks the tree itself and runs the node routine at every stop (the chain
-                                kernel's job with the node routine's table-driven prologue and lean rejection path): one launch, no
-                                workspace; 0: node-parallel (a workgroup per node + the walk kernel) */
-    int32_t reserved;
+    int32_t reserved[2];
 } lantern_ep_nodes;
 
 int lantern_tree_node_tables_size(int N, int P, int D);
@@ -345,7 +351,24 @@ int lantern_evaluate_posterior_nodes(const lantern_ep_params *prm, const lantern
  * Every field has the meaning of the same-named argument of the entry point it is passed to; the host loop only patches the
  * step-dependent pointers (where this step's outputs go) between calls.  slab_ptrs == NULL skips O9 + O10; out_win == NULL skips O7
  * (ep_win.rows_kind == LANTERN_ROWS_RAW_BF16: evaluate_posterior reads the raw cond / uncond logits itself).
+ * Pointers inside a group (nodes, dyn, node_list) are read during the call only.  An error names the group and the stage
+ * (lantern_last_error(): "verify_step: group 2, evaluate_posterior: ...").
+ *
+ * Dynamic (EAGLE-2) trees: dyn != NULL replaces the O6 stage by O4 + O6-dynamic on the group's stream, one launch
+ * (lantern_tree_dynamic_candidates) --
+ *   tree_dynamic_finalize(dyn->scores, dyn->tokens, dyn->parents, sample_token, ...) -> draft_tokens / mask / pos_ids / retrieve
+ *   gather_candidates_dynamic(draft_tokens, retrieve, pos_ids, dyn->seq_len, ...) -> cand / retrieve_pd / row_index / pos_abs
+ * (models/drafters/cnets_lumina_mgpt.py:1337-1420 and ea_model_lumina_mgpt.py:559,601 for every sequence of the group) -- and O9 + O10
+ * then read the per-sequence paths dyn->retrieve_pd.  The caller points pos_ids at dyn->pos_abs (seq_len = NULL) and
+ * ep_buf.row_index at dyn->row_index.
  */
+typedef struct lantern_step_dynamic {
+    const float *scores; const int64_t *tokens; const int64_t *parents;   /* [B,n_scores] f32, [B,n_scores] i64, [B,n_parents] i64 */
+    int32_t n_scores, n_parents, top_k, total_tokens, sort_rows, reserved;
+    int64_t *draft_tokens; float *mask; int64_t *pos_ids; int64_t *retrieve; int32_t *n_leaf; int32_t *max_depth;   /* O4 outputs */
+    const int64_t *seq_len;                                               /* [B] tokens in front of the tree */
+    int64_t *retrieve_pd; int32_t *row_index; int64_t *pos_abs;           /* O6-dynamic outputs ([B,P,D], [B,P,D], [B,N]) */
+} lantern_step_dynamic;
 typedef struct lantern_step_group {
     void *stream;
     /* O6 */
@@ -366,37 +389,12 @@ typedef struct lantern_step_group {
     /* with ep_win.rows_kind == LANTERN_ROWS_RAW_BF16: the nodes whose rows are post-processed up front, together with the candidate
      * assembly, in ONE launch (lantern_prepare_step) -- the root and the most likely children; NULL / 0: none (all rows on demand) */
     const int32_t *node_list; int32_t n_list, reserved2;
-    /* non-NULL: O8 + O9 + O10 go out as ONE launch (lantern_verify_accept) instead of evaluate_posterior_window +
-     * update_inference_inputs: [dev] lantern_verify_accept_workspace(B, n_slabs) bytes, 8-aligned, zero-filled ONCE by the caller (the
-     * kernel leaves it zeroed), owned by this group's stream.  fused_workers: copy workgroups beside the B chains, <= 0 = fill the GPU
-     * (256 - B); with G groups in flight give each about 256 / G - B. */
-    void *fused_ws; int64_t fused_ws_bytes; int32_t fused_workers, reserved3;
+    const lantern_step_dynamic *dyn;      /* NULL: a static tree (ss_token / tree_indices / retrieve) */
 } lantern_step_group;
 int lantern_verify_step(const lantern_step_group *groups, int n_groups);
-/* The same launch sequence enqueued by worker threads (a kernel launch costs its calling thread several microseconds; 3 G launches per
- * step make ONE enqueuing thread the bound past a handful of groups).  Worker t enqueues groups g = t (mod n_threads) from a private
- * ring of argument-block copies: submit returns once the copies are queued (the caller may patch its blocks for the next step at
- * once; it blocks only when a worker is 64 blocks behind); wait returns when everything submitted so far sits on its stream, with
- * the first error any worker met (and its message in lantern_last_error()) -- call it before recording events on / synchronising
- * with the group streams.  One stream must always be submitted at the same index g.  `device`: the HIP device of the streams.
- * With more than 3 groups the runtime needs as many hardware queues: GPU_MAX_HW_QUEUES >= n_groups in the environment (default 4). */
-typedef struct lantern_step_launcher lantern_step_launcher;
-int lantern_step_launcher_create(int n_threads, int device, lantern_step_launcher **out);
-int lantern_step_launcher_submit(lantern_step_launcher *l, const lantern_step_group *groups, int n_groups);
-int lantern_step_launcher_wait(lantern_step_launcher *l);
-void lantern_step_launcher_destroy(lantern_step_launcher *l);
 /* O6 + O7 restricted to s->node_list in one launch (bf16 Lumina rows, 8192-id window): candidates -> s->tree_cand / cand / cart_prob,
  * probabilities of the listed rows -> s->out_win, their classes -> s->row_hot.  Called by lantern_verify_step when node_list is set. */
 int lantern_prepare_step(const lantern_step_group *s);
-/* O8 + O9 + O10 of one group in one launch, pipelined per sequence: the first B workgroups run the evaluate_posterior chains
- * (models/ea_model_lumina_mgpt.py:562-720), each finished chain queues its verdict, and all other workgroups (and the finished chains)
- * move that sequence's KV rows and accepted hidden rows (update_inference_inputs, :741-785) while slower chains still run.  Same
- * results as lantern_evaluate_posterior_window followed by lantern_update_inference_inputs.  Uses s->ep / ep_buf / ep_win, the O9 + O10
- * fields, s->fused_ws.  LANTERN_E_UNSUPPORTED outside the 8192-id window / packed table / probability-or-raw rows build.
- * workspace word 4 != 0 after a launch: a copy worker gave up waiting for a chain (never in a healthy run). */
-size_t lantern_verify_accept_workspace(int B, int n_slabs);
-int lantern_verify_accept(const lantern_step_group *s);
-
 /* window -> dense [B,V] (API compatibility with callers that want the reference's sample_p[V]). */
 int lantern_window_to_dense(const float *win, const int32_t *out_tok, const float *out_mass, int B, int V,
                             int win_lo, int win_len, float *dense, void *stream);

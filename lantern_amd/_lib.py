@@ -50,7 +50,15 @@ class EpWindow(C.Structure):
 class EpNodes(C.Structure):
     _fields_ = [("tables", C.c_void_p), ("tables_host", C.c_void_p), ("n_nodes", C.c_int32), ("n_internal", C.c_int32), ("n_children", C.c_int32),
                 ("max_children", C.c_int32), ("prefix_siblings", C.c_int32), ("leaf_workgroups", C.c_int32),
-                ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t), ("serial", C.c_int32), ("reserved", C.c_int32)]
+                ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t), ("reserved", C.c_int32 * 2)]
+
+
+class StepDynamic(C.Structure):
+    """lantern_step_dynamic (include/lantern_hip.h): the EAGLE-2 tree stage of a group of lantern_verify_step."""
+    _fields_ = ([(n, C.c_void_p) for n in ("scores", "tokens", "parents")]
+                + [(n, C.c_int32) for n in ("n_scores", "n_parents", "top_k", "total_tokens", "sort_rows", "reserved")]
+                + [(n, C.c_void_p) for n in ("draft_tokens", "mask", "pos_ids", "retrieve", "n_leaf", "max_depth", "seq_len", "retrieve_pd",
+                                             "row_index", "pos_abs")])
 
 
 class StepGroup(C.Structure):
@@ -70,7 +78,7 @@ class StepGroup(C.Structure):
                 + [(n, C.c_void_p) for n in ("hidden", "out_hidden", "accepted_tokens")]
                 + [(n, C.c_int32) for n in ("hid_elem_bytes", "hid_groups", "H", "reserved1")]
                 + [("node_list", C.c_void_p), ("n_list", C.c_int32), ("reserved2", C.c_int32)]
-                + [("fused_ws", C.c_void_p), ("fused_ws_bytes", C.c_int64), ("fused_workers", C.c_int32), ("reserved3", C.c_int32)])
+                + [("dyn", C.POINTER(StepDynamic))])
 
 
 _lib = None
@@ -99,11 +107,6 @@ def lib():
         _lib.lantern_tree_attention_workspace.restype = C.c_size_t
         _lib.lantern_evaluate_posterior_nodes_workspace.restype = C.c_size_t
         _lib.lantern_head_expand_workspace.restype = C.c_size_t
-        _lib.lantern_verify_accept_workspace.restype = C.c_size_t
-        _lib.lantern_step_launcher_destroy.restype = None
-        _lib.lantern_step_launcher_destroy.argtypes = [C.c_void_p]
-        _lib.lantern_step_launcher_submit.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
-        _lib.lantern_step_launcher_wait.argtypes = [C.c_void_p]
     return _lib
 
 
@@ -115,7 +118,7 @@ def check(rc: int, what: str):
 
 EXPORTS = [
     "lantern_version", "lantern_last_error", "lantern_tree_static_sizes", "lantern_tree_static_build",
-    "lantern_tree_drafter_sizes", "lantern_tree_drafter_build", "lantern_tree_dynamic_finalize",
+    "lantern_tree_drafter_sizes", "lantern_tree_drafter_build", "lantern_tree_dynamic_finalize", "lantern_tree_dynamic_candidates",
     "lantern_expand_dynamic", "lantern_gather_candidates", "lantern_cfg_mask_topk",
     "lantern_evaluate_posterior_workspace", "lantern_evaluate_posterior", "lantern_evaluate_posterior_greedy",
     "lantern_kv_gather", "lantern_accept_gather", "lantern_sample_static", "lantern_drafter_fc",
@@ -124,5 +127,5 @@ EXPORTS = [
     "lantern_tree_attention_workspace", "lantern_tree_attention",
     "lantern_tree_node_tables_size", "lantern_tree_node_tables", "lantern_evaluate_posterior_nodes_workspace",
     "lantern_evaluate_posterior_nodes", "lantern_verify_step", "lantern_gather_candidates_dynamic", "lantern_head_expand_workspace", "lantern_head_expand", "lantern_prepare_step",
-    "lantern_verify_accept_workspace", "lantern_verify_accept", "lantern_linear_rows_epilogue", "lantern_linear_rows_splitk", "lantern_rmsnorm_rows", "lantern_qk_norm_rope", "lantern_step_launcher_create", "lantern_step_launcher_submit", "lantern_step_launcher_wait", "lantern_step_launcher_destroy",
+    "lantern_linear_rows_epilogue", "lantern_linear_rows_splitk", "lantern_rmsnorm_rows", "lantern_qk_norm_rope",
 ]

@@ -1,5 +1,4 @@
-// gather_dev.h -- device bodies of the O9 KV-row move and the O10 accepted-hidden copy, shared by gather_ops.hip (their own
-// launches) and window_kernels.hip (lantern_verify_accept: the copy workers of the fused evaluate_posterior + update launch).
+// gather_dev.h -- device bodies of the O9 KV-row move and the O10 accepted-hidden copy (launched by gather_ops.hip).
 #pragma once
 #include "common.h"
 
@@ -16,8 +15,7 @@ typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
 // MAXSEL = rows a step can accept (D); U = row groups a thread moves per trip, all loads of the U groups in flight
 // before the first store (few, fat workgroups: a thread that moves one 16-byte chunk of ~1.3 rows has too little in
 // flight to cover HBM latency, and 12k tiny workgroups per launch are dispatch-bound).
-// the same move with the verdict (best path, rows to keep) handed in by the caller: lantern_verify_accept's copy workers get it
-// from the work-queue entry the sequence's chain published, not from memory
+// the move with the verdict (best path, rows to keep) handed in by the caller
 template <int MAXSEL, int U, int MODE = 0>
 __device__ __forceinline__ void kv_gather_rows(int bx, int nbx, int s, int seq, int bst, int n_sel, void *const *__restrict__ slab_ptrs,
                                                const int64_t *__restrict__ slab_prev, int64_t outer, int64_t S_max, int chunks_per_row,

@@ -20,7 +20,6 @@ constexpr int EN_REC = 8;         // ints per node record: {accepted child or -1
 constexpr int EN_INFO = 16;       // ints per internal-node entry of the tables
 constexpr int EN_TR = 64;
 constexpr int EN_MAX_N = 128;     // nodes per tree
-constexpr int EN_UNI = 64;        // serial form: uniforms staged per step (more tries than that read the stream directly)
 
 struct alignas(16) EnShared {
     double redd[2 * 16];
@@ -31,20 +30,7 @@ struct alignas(16) EnShared {
     unsigned short nbid[EN_SLOTS][EW_PF_K];         // raw neighbour ids of the staged children (table values)
 };
 
-// serial form only: the sequence's small per-node facts, staged once (lookups at every later stop are LDS reads, not load rounds)
-struct alignas(16) EnSerial {
-    int4 ninfo[EN_MAX_N];                           // node tables: {first path, depth, rank or -1, .}
-    int4 child[EN_MAX_N];                           // child lists: {node, cell, ., .}
-    int coff[EN_MAX_N];                             // by internal rank: where the node's child list starts
-    int hdr[EN_MAX_N];                              // by internal rank: children | drafter row << 8
-    int tok[EN_MAX_N];                              // static trees: tree_candidates[node]
-    int hot[EN_MAX_N];                              // row_hot of the sequence's rows
-    double un[EN_UNI];                              // the step's uniforms from the cursor on
-    float cart[EW_MAX_PD];                          // static trees: cart_candidates_prob by cell
-    int cand[EW_MAX_PD];                            // dynamic trees: candidates by cell
-};
-
-// dynamic LDS: [ g : W + 4 f32 | W bits (LlamaGen / Anole static: the neighbour set zeroes q) | EnShared | EnSerial (serial form) ]
+// dynamic LDS: [ g : W + 4 f32 | W bits (LlamaGen / Anole static: the neighbour set zeroes q) | EnShared ]
 __host__ __device__ inline size_t epn_shared_offset(int W) { return epw_shared_offset(W); }
 
 // Static per-node facts, copied into the kernel-argument segment by the host (2.1 KB): a workgroup learns which node it is,
@@ -63,8 +49,7 @@ struct EpnArgs {
     const int32_t *tables;
     int32_t *records;      // [B, N, EN_REC]
     float *dist;           // [B, n_internal, W] or NULL
-    int32_t n_internal, n_nodes, n_children, leaf_wgs, root_rank, pad0;
-    uint4 root_w;          // = st.w[root_rank] (serial form: read with the first kernel-argument lines)
+    int32_t n_internal, n_nodes, n_children, leaf_wgs;
     unsigned long long *trace;   // diagnosis (lantern_debug_epn_trace): [grid][EN_TR] phase stamps (id << 56 | cycles), or NULL
     EpnStatic st;
 };
@@ -80,19 +65,15 @@ struct EpnArgs {
 // dependent load rounds in the prologue; compiled out otherwise so that the common prologue keeps one wait per round).
 // What a node's routine hands back (uniform across the workgroup).
 struct EpnVerdict {
-    int acc, acc_rank, acc_path;      // accepted child (node id, launch rank or -1 for a leaf, first path through it), or acc = -1
+    int acc;                          // accepted child (node id), or -1
     int n_tried, n_rej, status, token, out_tok, flags;
-    float out_mass, gsum;             // g holds an unnormalised residual with this sum when `lazy`
-    bool lazy;
-    int walk_depth, walk_best, tot_tried, tot_rej;      // serial form: where the walk ended (depth, first path through that node), totals
+    float out_mass;
 };
 
 // The routine of ONE node: try its children in order against the node's row (see the header).  `sw`: the node's packed header
 // (EpnStatic), `ri`: its rank among the internal nodes (0 for a leaf), `uoff`: uniforms the walk consumed before this node.
-// SERIAL: called in a loop by one workgroup that walks the tree itself (epn_serial_kernel): the children's ranks are fetched
-// with the first round of loads so that the next node's header is at hand at the decision.
-template <int NT, int E4, int IDMODE, bool FULLW, bool WIDE, bool SERIAL>
-__device__ __forceinline__ void epn_node(const EpnArgs &args, const int b, uint4 sw, bool internal, int ri, int uoff,
+template <int NT, int E4, int IDMODE, bool FULLW, bool WIDE>
+__device__ __forceinline__ void epn_node(const EpnArgs &args, const int b, const uint4 sw, const bool internal, const int ri, const int uoff,
                                          int &ph, int &tr_n, EpnVerdict &vd) {
     const lantern_ep_params &prm = args.prm;
     const lantern_ep_buffers &buf = args.buf;
@@ -111,47 +92,6 @@ __device__ __forceinline__ void epn_node(const EpnArgs &args, const int b, uint4
     const int nz = (k + 1 < prm.table_cols) ? k + 1 : prm.table_cols;
     const int32_t *tb = args.tables;
     const int n_int = args.n_internal;
-    const int32_t *nodeinfo = tb + 8 + EN_INFO * n_int + 4 * args.n_children;      // per node: {first path, depth, rank or -1, .}
-    EnSerial &SS = *reinterpret_cast<EnSerial *>(reinterpret_cast<char *>(&S) + sizeof(EnShared));
-    // serial form: the per-node facts of the whole tree, requested now (in front of the root's loads), parked in LDS under the
-    // root row's barrier; the root stop itself still reads its children's facts directly
-    int4 pl_info = make_int4(0, 0, -1, 0), pl_child = make_int4(0, 0, 0, 0);
-    int pl_tok = -1, pl_coff = 0, pl_hot = -1, pl_hdr = 0;
-    double pl_un = 2.0;
-    // per-sequence scalars of the serial form (uniform addresses: scalar loads, off the vector queue)
-    const int ucur_s = (SERIAL && buf.cursor) ? ldc(buf.cursor + b) : 0;
-    const double ub_s = (SERIAL && win.u_bonus) ? ldc(win.u_bonus + b) : 0.0;
-    constexpr int PL_PER = (EW_MAX_PD + NT - 1) / NT;
-    float pl_cart[PL_PER];
-    int pl_cand[PL_PER];
-    if constexpr (SERIAL) {
-        const int npd_ = prm.P * prm.D;
-        if (tid < args.n_nodes) pl_info = *reinterpret_cast<const int4 *>(nodeinfo + 4 * tid);
-        if (tid < args.n_children) pl_child = *reinterpret_cast<const int4 *>(tb + 8 + EN_INFO * n_int + 4 * tid);
-        if (tid < n_int) {
-            const int4 e03 = *reinterpret_cast<const int4 *>(tb + 8 + EN_INFO * tid);           // {node, child offset, children, depth}
-            const int e5 = tb[8 + EN_INFO * tid + 5];                                           // drafter row
-            pl_coff = e03.y;
-            pl_hdr = (e03.z > 255 ? 255 : e03.z) | (e5 << 8);
-        }
-        if (win.row_hot && tid < prm.rows_per_seq && tid < EN_MAX_N) pl_hot = win.row_hot[(size_t)b * prm.rows_per_seq + tid];
-        if (is_static && tid < prm.N && tid < EN_MAX_N) {
-            const int64_t t64 = buf.tree_cand[(size_t)b * prm.N + tid];
-            pl_tok = (t64 < -1 || t64 >= V) ? -2 : (int)t64;
-        }
-#pragma unroll
-        for (int u = 0; u < PL_PER; ++u) {
-            const int t = tid + u * NT;
-            pl_cart[u] = (is_static && t < npd_) ? buf.cart_prob[(size_t)b * npd_ + t] : 1.0f;
-            pl_cand[u] = -1;
-            if (!is_static && t < npd_) {
-                const int64_t c64 = buf.cand[(size_t)b * npd_ + t];
-                pl_cand[u] = (c64 < -1 || c64 >= V) ? -2 : (int)c64;
-            }
-        }
-    }
-    int tot_tried = 0, tot_rej = 0, walk_depth = 0, walk_best = 0;
-  for (int stop = 0;; ++stop) {
     EPN_STAMP(0);
 
     // ---- node header: from the kernel-argument segment (no load round in front of the row loads)
@@ -179,17 +119,10 @@ __device__ __forceinline__ void epn_node(const EpnArgs &args, const int b, uint4
     const double *p_ub = (win.u_bonus ? win.u_bonus + b : reinterpret_cast<const double *>(safe));
     int64_t tok_ld = -1;
     float qx_ld = 1.0f;
-    if constexpr (!SERIAL) {          // (the serial form reads the staged facts instead)
-        tok_ld = *p_tok;
-        qx_ld = *p_qx;
-    }
-    int ucur_ld = 0, hot_ld = -1;
-    double ub_ld = 0.0;
-    if constexpr (!SERIAL) {
-        ucur_ld = p_cur[l4 >> 2];
-        hot_ld = p_hot[l4 >> 2];
-        ub_ld = p_ub[l4 >> 2];
-    }
+    tok_ld = *p_tok;
+    qx_ld = *p_qx;
+    const int ucur_ld = p_cur[l4 >> 2], hot_ld = p_hot[l4 >> 2];
+    const double ub_ld = p_ub[l4 >> 2];
     __builtin_amdgcn_sched_barrier(0);          // keep the issue order: the scheduler must not sink these behind the rows
 
     // ---- the node's row and (static trees) the drafter row.  The drafter row is speculative: unused when the first child is
@@ -213,46 +146,10 @@ __device__ __forceinline__ void epn_node(const EpnArgs &args, const int b, uint4
         }
         qsrc = has_q ? qp : nullptr;
     }
-    if constexpr (SERIAL) {           // the step's uniforms, once, queued behind the root's rows
-        if (stop == 0 && tid < EN_UNI && ucur_s + tid < prm.n_uniforms) pl_un = buf.uniforms[(size_t)b * prm.n_uniforms + ucur_s + tid];
-    }
     // ---- children: lane t of every wave holds child t (token, flags, cart_candidates_prob, drafter probability of its token, its uniform)
-    int tok_l = -1, node_l = 0, rank_l = -1, path_l = 0;
+    int tok_l = -1, node_l = 0;
     float qx_l = 1.0f;
-    if constexpr (SERIAL) {
-        if (stop == 0) {              // park the tree's facts (requested in front of everything else; the rows are in flight behind them)
-            if (tid < EN_MAX_N) {
-                SS.ninfo[tid] = pl_info;
-                SS.child[tid] = pl_child;
-                SS.coff[tid] = pl_coff;
-                SS.hdr[tid] = pl_hdr;
-                SS.tok[tid] = pl_tok;
-                SS.hot[tid] = pl_hot;
-            }
-#pragma unroll
-            for (int u = 0; u < PL_PER; ++u) {
-                const int t = tid + u * NT;
-                if (t < EW_MAX_PD) {
-                    SS.cart[t] = pl_cart[u];
-                    SS.cand[t] = pl_cand[u];
-                }
-            }
-            __syncthreads();
-        }
-        if (lane < nch) {
-            const int4 ci = SS.child[(SS.coff[ri] + lane) & (EN_MAX_N - 1)];
-            const int cn = (ci.x >= 0 && ci.x < prm.N && ci.x < EN_MAX_N) ? ci.x : 0;
-            const int cl = (ci.y >= 0 && ci.y < npd && ci.y < EW_MAX_PD) ? ci.y : 0;
-            const int4 ni = SS.ninfo[cn];
-            node_l = ci.x;
-            rank_l = ni.z;
-            path_l = ni.x;
-            tok_l = is_static ? SS.tok[cn] : SS.cand[cl];          // (-2: outside [0,V), TOKEN_OOB when tried)
-            qx_l = is_static ? SS.cart[cl] : 1.0f;
-        } else if (nch > 0) {
-            tok_l = -3 - lane;                                     // no such child
-        }
-    } else if (nch > 0) {
+    if (nch > 0) {
         int64_t tl = -1;
         if (WIDE && nch > 4) {          // the rest of the child list, with two dependent vector rounds
             const int32_t *child = tb + 8 + EN_INFO * n_int + 4 * ldc(tb + 8 + EN_INFO * ri + 1);
@@ -272,12 +169,12 @@ __device__ __forceinline__ void epn_node(const EpnArgs &args, const int b, uint4
         tok_l = (tl < -1 || tl >= V) ? -2 : (int)tl;      // -2: outside [0,V) (TOKEN_OOB when tried)
         if (lane >= nch) tok_l = -3 - lane;               // no such child
     }
-    const int ucur0 = SERIAL ? ucur_s : (buf.cursor ? __builtin_amdgcn_readfirstlane(ucur_ld) : 0);
-    const int hot = !win.row_hot ? -1 : (SERIAL ? SS.hot[node & (EN_MAX_N - 1)] : __builtin_amdgcn_readfirstlane(hot_ld));
-    const double ub = SERIAL ? ub_s : (win.u_bonus ? ub_ld : 0.0);
+    const int ucur0 = buf.cursor ? __builtin_amdgcn_readfirstlane(ucur_ld) : 0;
+    const int hot = !win.row_hot ? -1 : __builtin_amdgcn_readfirstlane(hot_ld);
+    const double ub = win.u_bonus ? ub_ld : 0.0;
     // ---- second round of vector loads, queued behind the rows: uniforms, q[child tokens], the first children's table rows
     double un_l = 2.0;
-    if (lane < nch && ucur0 + uoff + lane < prm.n_uniforms && (!SERIAL || uoff + lane >= EN_UNI))          // (serial form: from the staged window, below)
+    if (lane < nch && ucur0 + uoff + lane < prm.n_uniforms)
         un_l = buf.uniforms[(size_t)b * prm.n_uniforms + ucur0 + uoff + lane];
     float qv_l = 0.0f;                                        // q[token of child `lane`]: what the later siblings' q.sum() loses
     if (qsrc && lane < nch && tok_l >= lo && tok_l < lo + W) qv_l = qsrc[tok_l - lo];
@@ -371,24 +268,16 @@ __device__ __forceinline__ void epn_node(const EpnArgs &args, const int b, uint4
         g[W + EW_G_OUT] = out_mass;
     }
     if (prm.lantern && nch > 0) stage_store(0, sr0);
-    if constexpr (SERIAL) {
-        if (stop == 0 && tid < EN_UNI) SS.un[tid] = pl_un;          // (arrived with the root's rows; published by the barrier below)
-    }
     EPN_STAMP(2);
     // S_q: the drafter row's sum (f64); a later child's q.sum() is S_q minus its earlier siblings' entries -- no
     // workgroup reduction on the rejection path
     double sq = 0.0;
-    bool sq_ready = false;            // serial form: reduced at the first rejection that needs it (most stops accept their first or second child)
-    if (!SERIAL && is_static && nch > 1) {
+    if (is_static && nch > 1) {
 #pragma unroll
         for (int it = 0; it < E4; ++it) sq += (double)qraw[it].x + (double)qraw[it].y + (double)qraw[it].z + (double)qraw[it].w;
         sq = block_sum_fast<double, NW>(sq, S.redd, ph);      // carries the barrier
-        sq_ready = true;
     } else {
         __syncthreads();
-    }
-    if constexpr (SERIAL) {
-        if (lane < nch && uoff + lane < EN_UNI && ucur0 + uoff + lane < prm.n_uniforms) un_l = SS.un[uoff + lane];
     }
     EPN_STAMP(3);
 
@@ -521,10 +410,6 @@ __device__ __forceinline__ void epn_node(const EpnArgs &args, const int b, uint4
         if (code == 0) continue;
         if (code == 1) {
             acc = rdlane(node_l, t);
-            if constexpr (SERIAL) {
-                vd.acc_rank = rdlane(rank_l, t);
-                vd.acc_path = rdlane(path_l, t);
-            }
             break;
         }
         // ------------------------------------------------ rejection: residual, all waves
@@ -574,12 +459,6 @@ __device__ __forceinline__ void epn_node(const EpnArgs &args, const int b, uint4
 #pragma unroll
             for (int it = 0; it < E4; ++it) q[it] = qraw[it];
             if (t > 0) {          // q[earlier siblings] = 0; q /= q.sum()
-                if (!sq_ready) {
-#pragma unroll
-                    for (int it = 0; it < E4; ++it) sq += (double)qraw[it].x + (double)qraw[it].y + (double)qraw[it].z + (double)qraw[it].w;
-                    sq = block_sum_fast<double, NW>(sq, S.redd, ph);
-                    sq_ready = true;
-                }
                 if (zmask) {
 #pragma unroll
                     for (int it = 0; it < E4; ++it) {
@@ -669,30 +548,8 @@ __device__ __forceinline__ void epn_node(const EpnArgs &args, const int b, uint4
     }
     EPN_STAMP(21);
     vd.acc = acc;
-    if (acc < 0) {
-        vd.acc_rank = -1;
-        vd.acc_path = 0;
-    }
     vd.n_tried = n_tried; vd.n_rej = n_rej; vd.status = status; vd.token = token; vd.out_tok = out_tok; vd.flags = flags;
-    vd.out_mass = out_mass; vd.gsum = gsum; vd.lazy = lazy;
-    if constexpr (!SERIAL) break;
-    // serial form: on to the accepted child (its row is requested at the top of the next round -- straight after this decision)
-    tot_tried += n_tried;
-    tot_rej += n_rej;
-    if (acc < 0 || status != LANTERN_ST_OK || (flags & 1) || stop + 1 >= prm.D) break;
-    walk_depth = depth + 1;
-    walk_best = vd.acc_path;
-    uoff += n_tried;
-    internal = vd.acc_rank >= 0;
-    ri = internal ? vd.acc_rank : 0;
-    {          // the next node's header from the staged facts (a kernel-argument read at a data-dependent index misses the scalar cache: ~2.5 k cycles per stop)
-        const int h = internal ? SS.hdr[ri & (EN_MAX_N - 1)] : 0;
-        sw = make_uint4((uint32_t)acc | ((uint32_t)(h & 255) << 8) | ((uint32_t)walk_depth << 16), (uint32_t)(h >> 8) & 255u, 0u, 0u);
-    }
-  }
-    if constexpr (SERIAL) {
-        vd.walk_depth = walk_depth; vd.walk_best = walk_best; vd.tot_tried = tot_tried; vd.tot_rej = tot_rej;
-    }
+    vd.out_mass = out_mass;
 }
 
 // node-parallel launch: workgroup (b, r) runs the routine of the node of launch rank r (internal nodes, longest child lists first;
@@ -704,7 +561,7 @@ __global__ __launch_bounds__(NT) void epn_kernel(const EpnArgs args) {
     const uint4 sw = args.st.w[r];
     int ph = 0, tr_n = 0;
     EpnVerdict vd;
-    epn_node<NT, E4, IDMODE, FULLW, WIDE, false>(args, b, sw, internal, internal ? r : 0, (int)(sw.x >> 24), ph, tr_n, vd);
+    epn_node<NT, E4, IDMODE, FULLW, WIDE>(args, b, sw, internal, internal ? r : 0, (int)(sw.x >> 24), ph, tr_n, vd);
     const int node = sw.x & 255;
     if (args.trace && threadIdx.x == 0) args.trace[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * EN_TR] = (unsigned long long)tr_n | ((unsigned long long)node << 32);
     if (threadIdx.x == 0) {
@@ -717,80 +574,6 @@ __global__ __launch_bounds__(NT) void epn_kernel(const EpnArgs args) {
         rec[5] = vd.out_tok;
         rec[6] = __float_as_int(vd.out_mass);
         rec[7] = vd.flags;
-    }
-}
-
-// Serial form: ONE workgroup per sequence walks root -> accepted child -> ... and runs the node routine at every stop -- the chain
-// kernel's job (window_kernels.hip: epw_kernel) done with the node routine's table-driven prologue and lean rejection path (no
-// per-level path masks: a node's children, their tokens' cells and the drafter row come from the host-built tables; lazily
-// normalised residual; all-wave neighbour scan).  Same preconditions as the node-parallel form (distinct sibling tokens:
-// LANTERN_ST_NEEDS_CHAIN otherwise); no workspace, no second launch.
-template <int NT, int E4, int IDMODE, bool FULLW, bool WIDE>
-__global__ __launch_bounds__(NT) void epn_serial_kernel(const EpnArgs args) {
-    const lantern_ep_params &prm = args.prm;
-    const lantern_ep_buffers &buf = args.buf;
-    const lantern_ep_window &win = args.win;
-    extern __shared__ float4 dyn_lds[];
-    float *g = reinterpret_cast<float *>(dyn_lds);
-    const int b = blockIdx.x, tid = threadIdx.x;
-    const int W = win.win_len, lo = win.win_lo, V = prm.V, D = prm.D;
-    int ph = 0, tr_n = 0;
-    EpnVerdict vd;
-    epn_node<NT, E4, IDMODE, FULLW, WIDE, true>(args, b, args.root_w, true, args.root_rank, 0, ph, tr_n, vd);
-    const int depth = vd.walk_depth, best = vd.walk_best, n_tried = vd.tot_tried, n_rej = vd.tot_rej;
-    const int status = (vd.flags & 1) ? LANTERN_ST_NEEDS_CHAIN : vd.status;
-    const int node = 0;
-    const int from_res = (vd.n_rej > 0 && depth + 1 != D) ? 1 : 0;
-    if ((win.sample_win || buf.sample_p) && status == LANTERN_ST_OK) {          // the final distribution: what g holds
-        const FastDiv dgc(vd.gsum);
-        float4 p[E4];
-#pragma unroll
-        for (int it = 0; it < E4; ++it) {
-            const int i4 = tid + it * NT;
-            p[it] = (FULLW || i4 * 4 < W) ? reinterpret_cast<const float4 *>(g)[i4] : make_float4(0.f, 0.f, 0.f, 0.f);
-            if (vd.lazy) p[it] = dgc(p[it]);
-        }
-        if (win.sample_win) {
-            float *sw_ = win.sample_win + (size_t)b * W;
-#pragma unroll
-            for (int it = 0; it < E4; ++it) {
-                const int i4 = tid + it * NT;
-                if (FULLW || i4 * 4 < W) reinterpret_cast<float4 *>(sw_)[i4] = p[it];
-            }
-        }
-        if (buf.sample_p) {
-            float *sp = buf.sample_p + (size_t)b * V;
-            for (int i4 = tid; i4 * 4 < V; i4 += NT) {
-                const int e = i4 * 4;
-                if (e + 4 <= lo || e >= lo + W) {
-                    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (vd.out_tok >= e && vd.out_tok < e + 4) set_comp(v, vd.out_tok - e, vd.out_mass);
-                    reinterpret_cast<float4 *>(sp)[i4] = v;
-                }
-            }
-#pragma unroll
-            for (int it = 0; it < E4; ++it) {
-                const int i4 = tid + it * NT;
-                if (FULLW || i4 * 4 < W) reinterpret_cast<float4 *>(sp + lo)[i4] = p[it];
-            }
-        }
-    }
-    if (args.trace && tid == 0) args.trace[(size_t)blockIdx.x * EN_TR] = (unsigned long long)tr_n | ((unsigned long long)node << 32);
-    if (tid == 0) {
-        const int a = depth + 1;
-        buf.best[b] = best;
-        buf.accept_len[b] = depth;
-        int32_t *c = buf.counters + (size_t)b * 6;
-        c[0] = a < D - 1 ? a : D - 1;
-        c[1] = n_tried;
-        c[2] = n_rej;
-        c[3] = n_tried;
-        c[4] = from_res;
-        c[5] = status;
-        if (buf.cursor) buf.cursor[b] = buf.cursor[b] + n_tried;
-        if (win.out_tok) win.out_tok[b] = vd.out_tok;
-        if (win.out_mass) win.out_mass[b] = vd.out_mass;
-        if (win.u_bonus && win.token && status == LANTERN_ST_OK) win.token[b] = vd.token;
     }
 }
 
@@ -953,9 +736,6 @@ __global__ __launch_bounds__(NT) void epn_walk_kernel(const EpnArgs args) {
 
 using namespace lantern;
 
-int lantern_launch_fast_walk(const lantern_ep_params *prm, const lantern_ep_buffers *buf, const lantern_ep_window *win,
-                             const lantern_ep_nodes *nodes, void *stream);          // walk_kernel.hip
-
 // diagnosis: a device buffer of grid * 64 u64 that the NEXT node launches fill with phase stamps (tools/epn_trace.py); NULL disarms
 static unsigned long long *g_epn_trace = nullptr;
 extern "C" int lantern_debug_epn_trace(void *dev_buf) {
@@ -977,8 +757,7 @@ extern "C" int lantern_evaluate_posterior_nodes(const lantern_ep_params *prm, co
     const lantern_ep_params &p = *prm;
     LANTERN_CHECK_ARG(p.B >= 0 && p.P > 0 && p.D > 0 && p.V > 0 && p.V % 4 == 0, "evaluate_posterior_nodes: bad B/P/D/V");
     if (p.B == 0) return LANTERN_OK;
-    const bool serial = nodes->serial != 0;
-    LANTERN_CHECK_ARG(nodes->tables && (serial || nodes->workspace) && nodes->n_nodes > 0 && nodes->n_internal > 0 && nodes->n_internal <= nodes->n_nodes &&
+    LANTERN_CHECK_ARG(nodes->tables && nodes->workspace && nodes->n_nodes > 0 && nodes->n_internal > 0 && nodes->n_internal <= nodes->n_nodes &&
                           nodes->n_nodes <= p.rows_per_seq,
                       "evaluate_posterior_nodes: node tables / workspace missing or inconsistent with rows_per_seq");
     LANTERN_CHECK_ARG(win->win_lo >= 0 && win->win_lo % 4 == 0 && win->win_len > 0 && win->win_len % 4 == 0 &&
@@ -997,16 +776,13 @@ extern "C" int lantern_evaluate_posterior_nodes(const lantern_ep_params *prm, co
         LANTERN_CHECK_ARG(buf->nn_table && p.k >= 1 && p.k <= p.table_cols && p.table_rows > 0, "evaluate_posterior_nodes: lantern needs nn_table, 1<=k<=cols");
     if (win->u_bonus) LANTERN_CHECK_ARG(win->token, "evaluate_posterior_nodes: u_bonus needs token");
     const int nz = (p.k + 1 < p.table_cols) ? p.k + 1 : p.table_cols;
-    const bool fast_walk = nodes->serial == 2;          // walk_kernel.hip: its own shape rules (probability or raw bf16 rows)
-    if (!fast_walk && (win->rows_kind != LANTERN_ROWS_PROBS || (p.lantern && nz > EW_PF_K) || (p.top_p > 0.0f && p.top_p < 1.0f))) {
+    if ((win->rows_kind != LANTERN_ROWS_PROBS || (p.lantern && nz > EW_PF_K) || (p.top_p > 0.0f && p.top_p < 1.0f))) {
         set_error("evaluate_posterior_nodes: needs probability rows (LANTERN_ROWS_PROBS) and k + 1 <= %d: use evaluate_posterior_window", EW_PF_K);
         return LANTERN_E_UNSUPPORTED;
     }
-    if (serial) LANTERN_CHECK_ARG(p.P * p.D <= EW_MAX_PD && nodes->n_nodes <= EN_MAX_N, "evaluate_posterior_nodes (serial): P*D=%d cells / %d nodes exceed the staged tables (%d / %d)",
-                                  p.P * p.D, nodes->n_nodes, EW_MAX_PD, EN_MAX_N);
     const bool want_dist = win->sample_win || buf->sample_p;
-    const size_t need = serial ? 0 : lantern_evaluate_posterior_nodes_workspace(prm, win, nodes->n_internal, want_dist);
-    LANTERN_CHECK_ARG(serial || (nodes->workspace_bytes >= need && ((uintptr_t)nodes->workspace & 15) == 0), "evaluate_posterior_nodes: workspace of %zu bytes needed (16-byte aligned), %zu given",
+    const size_t need = lantern_evaluate_posterior_nodes_workspace(prm, win, nodes->n_internal, want_dist);
+    LANTERN_CHECK_ARG(nodes->workspace_bytes >= need && ((uintptr_t)nodes->workspace & 15) == 0, "evaluate_posterior_nodes: workspace of %zu bytes needed (16-byte aligned), %zu given",
                       need, nodes->workspace_bytes);
     hipStream_t st = (hipStream_t)stream;
     const int W = win->win_len;
@@ -1015,15 +791,12 @@ extern "C" int lantern_evaluate_posterior_nodes(const lantern_ep_params *prm, co
         set_error("evaluate_posterior_nodes: a child's earlier-sibling list is not the list of children tried before it (tables[6] == 0): use evaluate_posterior_window");
         return LANTERN_E_UNSUPPORTED;
     }
-    if (fast_walk) return lantern_launch_fast_walk(prm, buf, win, nodes, stream);
     // leaves as workgroups of the node launch (their bonus token pre-drawn) while the launch is small; beyond ~2 workgroups per
     // compute-unit slot the walk kernel draws the one token a walk needs instead
     const int leaf_wgs = !win->u_bonus ? 0 : (nodes->leaf_workgroups >= 0 ? (nodes->leaf_workgroups != 0) : ((long)p.B * nodes->n_nodes <= 1024));
     LANTERN_CHECK_ARG(nodes->tables_host && nodes->tables_host[0] == nodes->n_nodes && nodes->tables_host[1] == nodes->n_internal,
                       "evaluate_posterior_nodes: tables_host missing or not the tables of this tree");
-    EpnArgs args{p, *buf, *win, nodes->tables, (int32_t *)nodes->workspace, nullptr, nodes->n_internal, nodes->n_nodes, nodes->n_children, leaf_wgs, 0, 0, make_uint4(0u, 0u, 0u, 0u), g_epn_trace, {}};
-    args.root_rank = nodes->tables_host[8 + EN_INFO * nodes->n_internal + 4 * nodes->n_children + 2];          // nodeinfo[0].rank
-    LANTERN_CHECK_ARG(args.root_rank >= 0 && args.root_rank < nodes->n_internal, "evaluate_posterior_nodes: corrupt node tables (root rank)");
+    EpnArgs args{p, *buf, *win, nodes->tables, (int32_t *)nodes->workspace, nullptr, nodes->n_internal, nodes->n_nodes, nodes->n_children, leaf_wgs, g_epn_trace, {}};
     {
         const int32_t *th = nodes->tables_host;
         const int Nn = nodes->n_nodes, ni = nodes->n_internal;
@@ -1045,10 +818,9 @@ extern "C" int lantern_evaluate_posterior_nodes(const lantern_ep_params *prm, co
             args.st.w[r] = w;
         }
     }
-    args.root_w = args.st.w[args.root_rank];
-    if (want_dist && !serial)
+    if (want_dist)
         args.dist = (float *)((char *)nodes->workspace + (((size_t)p.B * (size_t)p.rows_per_seq * EN_REC * sizeof(int32_t) + 255) & ~(size_t)255));
-    const size_t lds = epn_shared_offset(W) + sizeof(EnShared) + (serial ? sizeof(EnSerial) : 0);
+    const size_t lds = epn_shared_offset(W) + sizeof(EnShared);
     const size_t wlds = (size_t)(W + EW_G_EXT) * 4;
     // every node is a workgroup: internal nodes run their children's chain, leaves only draw the bonus token of a walk that ends on them
     const int n_wg_nodes = leaf_wgs ? nodes->n_nodes : nodes->n_internal;
@@ -1065,22 +837,10 @@ extern "C" int lantern_evaluate_posterior_nodes(const lantern_ep_params *prm, co
         else hipExtLaunchKernelGGL((epn_kernel<NT_, E4_, 1, FW_, true>), grid, dim3(NT_), lds, st, (hipEvent_t)ev0, nullptr, 0, args);                   \
         hipExtLaunchKernelGGL((epn_walk_kernel<NT_, E4_, FW_>), wgrid, dim3(NT_), wlds, st, nullptr, (hipEvent_t)ev1, 0, args);         \
     } while (0)
-#define EPS_LAUNCH(NT_, E4_, FW_)                                                                                         \
-    do {                                                                                                                  \
-        if (packed && !wide) hipExtLaunchKernelGGL((epn_serial_kernel<NT_, E4_, 2, FW_, false>), wgrid, dim3(NT_), lds, st, (hipEvent_t)ev0, (hipEvent_t)ev1, 0, args); \
-        else if (packed) hipExtLaunchKernelGGL((epn_serial_kernel<NT_, E4_, 2, FW_, true>), wgrid, dim3(NT_), lds, st, (hipEvent_t)ev0, (hipEvent_t)ev1, 0, args);       \
-        else hipExtLaunchKernelGGL((epn_serial_kernel<NT_, E4_, 1, FW_, true>), wgrid, dim3(NT_), lds, st, (hipEvent_t)ev0, (hipEvent_t)ev1, 0, args);                   \
-    } while (0)
-    if (serial) {
-        if (W == 8192) EPS_LAUNCH(512, 4, true);
-        else if (W <= 8192) EPS_LAUNCH(512, 4, false);
-        else EPS_LAUNCH(1024, 4, false);
-    }
-    else if (W == 8192) EPN_LAUNCH(512, 4, true);
+    if (W == 8192) EPN_LAUNCH(512, 4, true);
     else if (W <= 8192) EPN_LAUNCH(512, 4, false);
     else EPN_LAUNCH(1024, 4, false);
 #undef EPN_LAUNCH
-#undef EPS_LAUNCH
     LANTERN_CHECK_LAUNCH("evaluate_posterior_nodes");
     return LANTERN_OK;
 }

@@ -24,12 +24,20 @@ __device__ unsigned long long g_td_trace[32];
 #else
 #define TD_STAMP(i) do { } while (0)
 #endif
+// what O6-dynamic adds when the same launch assembles the candidates (lantern_tree_dynamic_candidates); cand == NULL: finalize only
+struct TdCand {
+    const int64_t *seq_len;
+    int64_t *cand, *retrieve_pd, *pos_abs;
+    int32_t *row_index;
+    int P, D;
+};
 template <int EPL>      // score elements per lane: 8 covers the reference's 10 + 100*depth <= 512 scores, 32 the general case
 __global__ __launch_bounds__(64 * TD_WAVES) void tree_dynamic_finalize_kernel(
     const float *__restrict__ scores_, const int64_t *__restrict__ tokens_, const int64_t *__restrict__ parents_,
     const int64_t *__restrict__ sample_token, int n_scores, int n_parents, int top_k, int T, int sort_rows,
     int64_t *__restrict__ draft_tokens, float *__restrict__ mask, int64_t *__restrict__ pos_ids,
-    int64_t *__restrict__ retrieve, int32_t *__restrict__ n_leaf, int32_t *__restrict__ max_depth) {
+    int64_t *__restrict__ retrieve, int32_t *__restrict__ n_leaf, int32_t *__restrict__ max_depth, const TdCand cd) {
+    __shared__ long long s_tok_[TD_WAVES][64];
     __shared__ int s_sel_[TD_WAVES][64];
     __shared__ int s_par_[TD_WAVES][64];
     __shared__ int s_flag_[TD_WAVES][64];
@@ -118,11 +126,14 @@ __global__ __launch_bounds__(64 * TD_WAVES) void tree_dynamic_finalize_kernel(
     TD_STAMP(3);
     // ---- node = lane (0 = root); parent via searchsorted over the selected flat indices
     int par = 0;
+    long long tok_l = -1;
     if (lane == 0) {
-        if (wave == 0) draft_tokens[(size_t)b * N] = sample_token[b];
+        tok_l = sample_token[b];
+        if (wave == 0) draft_tokens[(size_t)b * N] = tok_l;
     } else if (lane < N) {
         const int flat = s_sel[lane - 1];
-        if (wave == 0) draft_tokens[(size_t)b * N + lane] = tokens[flat];
+        tok_l = tokens[flat];
+        if (wave == 0) draft_tokens[(size_t)b * N + lane] = tok_l;
         const int64_t dp = parents[flat / top_k];
         if (dp != 0) {
             const int64_t keyv = dp - 1;
@@ -138,6 +149,7 @@ __global__ __launch_bounds__(64 * TD_WAVES) void tree_dynamic_finalize_kernel(
     TD_STAMP(4);
     s_par[lane] = par;
     s_flag[lane] = 0;
+    s_tok_[wave][lane] = tok_l;
     __syncthreads();
     if (lane >= 1 && lane < N) s_flag[par] = 1;  // non-leaf marks
     // ancestor set: walk the parent pointers
@@ -237,6 +249,20 @@ __global__ __launch_bounds__(64 * TD_WAVES) void tree_dynamic_finalize_kernel(
     if (tid == 0) {
         n_leaf[b] = nl;
         max_depth[b] = MD;
+    }
+    // ---- O6, dynamic (ea_model_llamagen.py:676-706 with this tree; gather_candidates_dynamic_kernel's arithmetic): the candidates by
+    // (path, depth), the compact retrieve rows, the row map (a -1 wraps to the last node's row) and every node's absolute position
+    if (cd.cand) {
+        const int PD = cd.P * cd.D;
+        for (int i = tid; i < PD; i += 64 * TD_WAVES) {
+            const int p = i / cd.D, d = i - p * cd.D;
+            const int r = (p < nl && d < MD) ? (int)s_rows[s_slot[p]][d] : -1;
+            const bool ok = r >= 0 && r < N;
+            cd.cand[(size_t)b * PD + i] = ok ? (int64_t)s_tok_[wave][r] : -1;
+            if (cd.retrieve_pd) cd.retrieve_pd[(size_t)b * PD + i] = ok ? r : -1;
+            if (cd.row_index) cd.row_index[(size_t)b * PD + i] = ok ? r : N - 1;
+        }
+        if (cd.pos_abs && lane < N && wave == 0) cd.pos_abs[(size_t)b * N + lane] = (int64_t)depth + (cd.seq_len ? cd.seq_len[b] + 1 : 0);
     }
 }
 
@@ -553,11 +579,9 @@ extern "C" int lantern_debug_td_trace(unsigned long long *out) {
 }
 #endif
 
-extern "C" int lantern_tree_dynamic_finalize(const float *scores, const int64_t *tokens, const int64_t *parents,
-                                             const int64_t *sample_token, int B, int n_scores, int n_parents, int top_k,
-                                             int total_tokens, int sort_rows, int64_t *draft_tokens, float *mask,
-                                             int64_t *pos_ids, int64_t *retrieve, int32_t *n_leaf, int32_t *max_depth,
-                                             void *stream) {
+static int td_launch(const float *scores, const int64_t *tokens, const int64_t *parents, const int64_t *sample_token, int B, int n_scores,
+                     int n_parents, int top_k, int total_tokens, int sort_rows, int64_t *draft_tokens, float *mask, int64_t *pos_ids,
+                     int64_t *retrieve, int32_t *n_leaf, int32_t *max_depth, const TdCand &cd, void *stream) {
     LANTERN_CHECK_ARG(scores && tokens && parents && sample_token && draft_tokens && mask && pos_ids && retrieve && n_leaf && max_depth,
                       "tree_dynamic_finalize: null buffer");
     LANTERN_CHECK_ARG(B >= 0 && top_k > 0 && total_tokens >= 1 && total_tokens <= 63, "tree_dynamic_finalize: total_tokens=%d must be in [1,63]",
@@ -568,13 +592,33 @@ extern "C" int lantern_tree_dynamic_finalize(const float *scores, const int64_t 
     if (n_scores <= 8 * 64)
         hipLaunchKernelGGL(tree_dynamic_finalize_kernel<8>, dim3(B), dim3(64 * TD_WAVES), 0, (hipStream_t)stream, scores, tokens, parents,
                            sample_token, n_scores, n_parents, top_k, total_tokens, sort_rows, draft_tokens, mask, pos_ids, retrieve, n_leaf,
-                           max_depth);
+                           max_depth, cd);
     else
         hipLaunchKernelGGL(tree_dynamic_finalize_kernel<TD_EPL>, dim3(B), dim3(64 * TD_WAVES), 0, (hipStream_t)stream, scores, tokens, parents,
                            sample_token, n_scores, n_parents, top_k, total_tokens, sort_rows, draft_tokens, mask, pos_ids, retrieve, n_leaf,
-                           max_depth);
+                           max_depth, cd);
     LANTERN_CHECK_LAUNCH("tree_dynamic_finalize");
     return LANTERN_OK;
+}
+
+extern "C" int lantern_tree_dynamic_finalize(const float *scores, const int64_t *tokens, const int64_t *parents,
+                                             const int64_t *sample_token, int B, int n_scores, int n_parents, int top_k,
+                                             int total_tokens, int sort_rows, int64_t *draft_tokens, float *mask,
+                                             int64_t *pos_ids, int64_t *retrieve, int32_t *n_leaf, int32_t *max_depth,
+                                             void *stream) {
+    return td_launch(scores, tokens, parents, sample_token, B, n_scores, n_parents, top_k, total_tokens, sort_rows, draft_tokens, mask, pos_ids,
+                     retrieve, n_leaf, max_depth, TdCand{}, stream);
+}
+
+extern "C" int lantern_tree_dynamic_candidates(const float *scores, const int64_t *tokens, const int64_t *parents,
+                                               const int64_t *sample_token, int B, int n_scores, int n_parents, int top_k,
+                                               int total_tokens, int sort_rows, int64_t *draft_tokens, float *mask, int64_t *pos_ids,
+                                               int64_t *retrieve, int32_t *n_leaf, int32_t *max_depth, const int64_t *seq_len, int P, int D,
+                                               int64_t *cand, int64_t *retrieve_pd, int32_t *row_index, int64_t *pos_abs, void *stream) {
+    const int N = total_tokens + 1;
+    LANTERN_CHECK_ARG(cand && P > 0 && P <= N && D > 0 && D <= N, "tree_dynamic_candidates: cand missing or bad sizes (P, D <= N)");
+    return td_launch(scores, tokens, parents, sample_token, B, n_scores, n_parents, top_k, total_tokens, sort_rows, draft_tokens, mask, pos_ids,
+                     retrieve, n_leaf, max_depth, TdCand{seq_len, cand, retrieve_pd, pos_abs, row_index, P, D}, stream);
 }
 
 namespace lantern {

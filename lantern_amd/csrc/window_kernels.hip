@@ -55,7 +55,6 @@ __shared__ int s_epw_trn;
 }  // namespace lantern
 
 #include "window_dev.h"
-#include "gather_dev.h"
 
 namespace lantern {
 
@@ -1223,183 +1222,6 @@ __global__ __launch_bounds__(NT, WPE) void epw_kernel(const EpwArgs args) {
     epw_body<NT, E4, IDMODE, WPE, FULLW, RAW>(args, blockIdx.x);
 }
 
-// ------------------------------------------------------------------------------------------------------------------------
-// lantern_verify_accept: evaluate_posterior (O8) and update_inference_inputs (O9 + O10) of one group of sequences in ONE launch,
-// pipelined per sequence.  As two launches the KV rows of EVERY sequence wait for the SLOWEST sequence's chain (a chain is 1..D
-// levels long and mostly waits on memory round trips: ~64 of 256 CUs busy), then the chains of the next step wait for the whole
-// copy.  Here the first B workgroups to start (a ticket taken at workgroup start, so they are running -- not merely scheduled --
-// before any later workgroup) run the chains (epw_body, unchanged); a finished chain publishes its verdict as work-queue entries
-// (one per KV slab of the sequence + one for its accepted-hidden rows) and every other workgroup -- and the chain workgroups
-// once done -- takes (entry, tile) tickets and moves rows.  A copy worker only ever waits for a chain, a chain never waits: the
-// grid drains whatever the dispatch order.  The verdict travels inside the entry (best path, rows kept), so a worker reads
-// nothing the chains wrote.  The last workgroup out clears the queue for the next launch (workspace zeroed once by the caller).
-struct VaArgs {
-    EpwArgs ep;                      // at offset 0: epw_body reads its epilogue pointers through the kernarg segment
-    void *const *slab_ptrs;
-    const int32_t *slab_seq;
-    const int64_t *slab_prev;
-    int64_t *new_len;
-    const int64_t *retrieve;
-    int64_t outer, S_max;
-    int n_slabs, cpr, nbx, hid_groups;
-    const uint4 *hidden;
-    uint4 *out_hidden;
-    const int64_t *cand;
-    int64_t *accepted_tokens;
-    int N, hid_cpr;
-    uint32_t *ws;                    // [0] role tickets [1] work tickets [2] entries published [3] workgroups out [4] sticky: a worker gave up; +32 B: entries
-};
-constexpr unsigned long long VA_VALID = 1ull << 63, VA_HIDDEN = 1ull << 62;
-constexpr int VA_SPIN_LIMIT = 4000000;          // ~2 s of polling: a worker that never sees its entry gives up instead of hanging the GPU
-
-// copy workers: VA_U column groups per thread, every load of a tile in flight before the first store (a worker workgroup is alone on its
-// CU -- it carries the chain's LDS footprint -- so its memory-level parallelism has to come from the thread: up to VA_U * D 16-byte loads)
-// (VA_U, VA_MAXSEL) = (6, 6) for trees of depth <= 6 (the reference's), (4, 8) up to depth 8: 144 / 128 registers of row data per thread
-template <bool RAW, int VA_U, int VA_MAXSEL>
-__global__ __launch_bounds__(512, 1) void verify_accept_kernel(const VaArgs a) {
-    __shared__ uint32_t s_u32;
-    __shared__ unsigned long long s_entry;
-    uint32_t *const ws = a.ws;
-    unsigned long long *const entries = reinterpret_cast<unsigned long long *>(ws + 8);
-    const int tid = threadIdx.x, B = a.ep.prm.B, P = a.ep.prm.P, D = a.ep.prm.D;
-    const uint32_t n_entries = (uint32_t)(a.n_slabs + B), n_items = n_entries * (uint32_t)a.nbx;
-    if (tid == 0) s_u32 = atomicAdd(&ws[0], 1u);
-    __syncthreads();
-    const uint32_t role = s_u32;
-    __syncthreads();
-    if (role < (uint32_t)B) {
-        const int b = (int)role;
-        const int verdict = epw_body<512, 4, 2, 1, true, RAW>(a.ep, b);
-        const unsigned long long v = (unsigned long long)(((unsigned)(verdict >> 8) & 0xffffu) << 16 | ((unsigned)verdict & 0xffu));
-        for (int s = tid; s <= a.n_slabs; s += 512) {
-            const bool hid = s == a.n_slabs;
-            if (hid || a.slab_seq[s] == b) {
-                const unsigned long long e = VA_VALID | (hid ? VA_HIDDEN : 0ull) | ((unsigned long long)(hid ? b : s) << 32) | v;
-                const uint32_t slot = atomicAdd(&ws[2], 1u);
-                if (slot < n_entries) __hip_atomic_store(&entries[slot], e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-        }
-    } else {
-        // ---- copy worker `wk` of `n_wk`: items wk, wk + n_wk, ... of the queue (item = entry * nbx + tile), entries in publication
-        // order.  Two-stage pipeline: while an item's rows are in flight the worker reads the next item's queue entry and, if it is
-        // there, requests its slab facts (uniform addresses -> scalar loads), so a ready queue costs one memory round per item.
-        const uint32_t n_wk = gridDim.x - (uint32_t)B, wk = role - (uint32_t)B;
-        const unsigned cpr = (unsigned)a.cpr, total = (unsigned)(a.outer * a.cpr);
-        auto poll = [&](uint32_t slot, bool blocking) -> unsigned long long {           // every thread returns the entry (0: not there / gave up)
-            __syncthreads();
-            if (tid == 0) {
-                unsigned long long e = __hip_atomic_load(&entries[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (blocking) {
-                    for (int spins = 0; !(e & VA_VALID); ++spins) {
-                        if (spins > VA_SPIN_LIMIT) {
-                            atomicExch(&ws[4], 1u);
-                            break;
-                        }
-                        __builtin_amdgcn_s_sleep(8);
-                        e = __hip_atomic_load(&entries[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    }
-                }
-                s_entry = e;
-            }
-            __syncthreads();
-            return s_entry;
-        };
-        struct Meta {
-            uintptr_t slab;
-            int64_t prev;
-            int64_t srcrow[VA_MAXSEL];
-            unsigned move;
-        };
-        auto load_meta = [&](unsigned long long e, Meta &m) {          // slab entries only; uniform addresses
-            const int s = (int)((e >> 32) & 0xffffu), bst = (int)((e >> 16) & 0xffffu);
-            int n_sel = (int)(e & 0xffu);
-            if (n_sel > D) n_sel = D;
-            if (n_sel > VA_MAXSEL) n_sel = VA_MAXSEL;
-            m.slab = (uintptr_t)a.slab_ptrs[s];
-            m.prev = a.slab_prev[s];
-            m.move = 0u;
-            const int64_t *rrow = a.retrieve + (size_t)bst * D;
-#pragma unroll
-            for (int t = 0; t < VA_MAXSEL; ++t) {
-                m.srcrow[t] = 0;
-                if (t < n_sel) {
-                    const int64_t r = rrow[t];
-                    if (r != t && m.prev + t < a.S_max) m.move |= 1u << t;
-                    const int64_t src = r + m.prev;
-                    m.srcrow[t] = src < 0 ? 0 : (src >= a.S_max ? a.S_max - 1 : src);
-                }
-            }
-            if (tid == 0 && a.new_len) a.new_len[s] = m.prev + n_sel;          // (every tile's worker writes the same value)
-        };
-        uint32_t it = wk;
-        unsigned long long e = it < n_items ? poll(it / (uint32_t)a.nbx, true) : 0ull;
-        Meta m{};
-        if ((e & VA_VALID) && !(e & VA_HIDDEN)) load_meta(e, m);
-        while (it < n_items && (e & VA_VALID)) {
-            const uint32_t tile = it % (uint32_t)a.nbx;
-            const uint32_t it2 = it + n_wk;
-            unsigned long long e2 = 0ull;
-            Meta m2{};
-            if (e & VA_HIDDEN) {
-                const int b = (int)((e >> 32) & 0xffffu), bst = (int)((e >> 16) & 0xffffu);
-                int n_sel = (int)(e & 0xffu);
-                if (n_sel > D) n_sel = D;
-                for (int r = (int)tile; r < a.hid_groups * D; r += a.nbx)
-                    accept_copy_row(r, b, bst, n_sel, a.hidden, a.hid_groups, a.N, a.hid_cpr, a.retrieve, 0, P, D, a.cand, a.out_hidden, a.accepted_tokens);
-                if (it2 < n_items) e2 = poll(it2 / (uint32_t)a.nbx, false);
-                if ((e2 & VA_VALID) && !(e2 & VA_HIDDEN)) load_meta(e2, m2);
-            } else if (m.move != 0u) {
-                // loads of this tile, then the look-ahead under them, then the stores
-                typedef __attribute__((address_space(1))) u32x4_t gvec_t;
-                gvec_t *base = (gvec_t *)m.slab;
-                u32x4_t v[VA_U][VA_MAXSEL];
-                gvec_t *rowbase[VA_U];
-                const unsigned w0 = tile * (VA_U * 512u) + (unsigned)tid;
-#pragma unroll
-                for (int u = 0; u < VA_U; ++u) {
-                    const unsigned w = w0 + u * 512u;
-                    const unsigned o = w / cpr, c = w - o * cpr;
-                    rowbase[u] = base + (size_t)o * a.S_max * cpr + c;
-                    if (w < total) {
-#pragma unroll
-                        for (int t = 0; t < VA_MAXSEL; ++t)
-                            if ((m.move >> t) & 1u) v[u][t] = __builtin_nontemporal_load(&rowbase[u][m.srcrow[t] * cpr]);
-                    }
-                }
-                if (it2 < n_items) e2 = poll(it2 / (uint32_t)a.nbx, false);
-                if ((e2 & VA_VALID) && !(e2 & VA_HIDDEN)) load_meta(e2, m2);
-#pragma unroll
-                for (int u = 0; u < VA_U; ++u) {
-                    const unsigned w = w0 + u * 512u;
-                    if (w < total) {
-#pragma unroll
-                        for (int t = 0; t < VA_MAXSEL; ++t)
-                            if ((m.move >> t) & 1u) __builtin_nontemporal_store(v[u][t], &rowbase[u][(m.prev + t) * cpr]);
-                    }
-                }
-            } else {
-                if (it2 < n_items) e2 = poll(it2 / (uint32_t)a.nbx, false);
-                if ((e2 & VA_VALID) && !(e2 & VA_HIDDEN)) load_meta(e2, m2);
-            }
-            if (it2 < n_items && !(e2 & VA_VALID)) {          // not published yet: wait for it (bounded)
-                e2 = poll(it2 / (uint32_t)a.nbx, true);
-                if ((e2 & VA_VALID) && !(e2 & VA_HIDDEN)) load_meta(e2, m2);
-            }
-            it = it2;
-            e = e2;
-            m = m2;
-        }
-    }
-    // the last workgroup out leaves the queue empty for the next launch on this workspace
-    __syncthreads();
-    if (tid == 0) s_u32 = atomicAdd(&ws[3], 1u);
-    __syncthreads();
-    if (s_u32 == gridDim.x - 1) {
-        for (uint32_t i = tid; i < n_entries; i += 512) entries[i] = 0ull;
-        if (tid < 4) ws[tid] = 0u;
-    }
-}
-
 __global__ void window_to_dense_kernel(const float *__restrict__ winp, const int32_t *__restrict__ out_tok,
                                        const float *__restrict__ out_mass, int V, int lo, int W, float *__restrict__ dense) {
     const int b = blockIdx.y;
@@ -1507,7 +1329,7 @@ extern "C" int lantern_prepare_step(const lantern_step_group *g) {
     return LANTERN_OK;
 }
 
-// argument rules of the windowed chain kernel (shared by its own launch and lantern_verify_accept)
+// argument rules of the windowed chain kernel
 static int epw_check(const lantern_ep_params *prm, const lantern_ep_buffers *buf, const lantern_ep_window *win) {
     LANTERN_CHECK_ARG(prm && buf && win, "evaluate_posterior_window: null params");
     const lantern_ep_params &p = *prm;
@@ -1615,64 +1437,6 @@ extern "C" int lantern_evaluate_posterior_window(const lantern_ep_params *prm, c
 #undef EPW_LAUNCH_W
 #undef EPW_LAUNCH
     LANTERN_CHECK_LAUNCH("evaluate_posterior_window");
-    return LANTERN_OK;
-}
-
-extern "C" size_t lantern_verify_accept_workspace(int B, int n_slabs) {
-    if (B < 0 || n_slabs < 0) return 0;
-    return 32 + (size_t)(B + n_slabs) * 8;
-}
-
-// O8 + O9 + O10 of one group in one launch (include/lantern_hip.h).  Built for the Lumina / Anole image window on the packed
-// neighbour table (the epw_kernel<512, 4, 2, 1, FULLW> variants, probability or raw bf16 rows); anything else: LANTERN_E_UNSUPPORTED
-// and the caller launches lantern_evaluate_posterior_window + lantern_update_inference_inputs.
-extern "C" int lantern_verify_accept(const lantern_step_group *s) {
-    LANTERN_CHECK_ARG(s, "verify_accept: null group");
-    const int rc = epw_check(&s->ep, &s->ep_buf, &s->ep_win);
-    if (rc) return rc;
-    const lantern_ep_params &p = s->ep;
-    if (p.B == 0) return LANTERN_OK;
-    const lantern_ep_window *win = &s->ep_win;
-    const bool raw = win->rows_kind == LANTERN_ROWS_RAW_BF16;
-    const int nz = (p.k + 1 < p.table_cols) ? p.k + 1 : p.table_cols;
-    const bool packed = p.lantern && nz <= EW_PF_K && p.table_cols % 8 == 0 && ((uintptr_t)s->ep_buf.nn_table & 15) == 0;
-    if (!(win->win_len == 8192 && packed && (raw || win->rows_kind == LANTERN_ROWS_PROBS))) {
-        set_error("verify_accept: built for the 8192-id window on the packed neighbour table with probability or raw bf16 rows; "
-                  "launch evaluate_posterior_window + update_inference_inputs instead");
-        return LANTERN_E_UNSUPPORTED;
-    }
-    LANTERN_CHECK_ARG(s->slab_ptrs && s->slab_seq && s->slab_prev && s->retrieve && s->n_slabs > 0 && s->outer > 0 && s->S_max > 0 && s->d > 0,
-                      "verify_accept: needs the KV slabs (slab_ptrs / slab_seq / slab_prev, sizes)");
-    LANTERN_CHECK_ARG((s->d * s->elem_bytes) % 16 == 0, "verify_accept: KV row bytes %lld must be a multiple of 16", (long long)(s->d * s->elem_bytes));
-    LANTERN_CHECK_ARG(p.D <= 8 && p.B < 65536 && s->n_slabs < 65536, "verify_accept: D=%d > 8 or more than 65535 sequences / slabs", p.D);
-    LANTERN_CHECK_ARG(!s->ep_buf.n_paths && !s->ep_buf.n_depth && !p.row_index_per_seq, "verify_accept: one tree shape for the whole group");
-    if (s->hidden) LANTERN_CHECK_ARG(s->out_hidden && s->hid_groups > 0 && s->N > 0 && s->H > 0 && (s->H * s->hid_elem_bytes) % 16 == 0,
-                                     "verify_accept: hidden row bytes must be a multiple of 16");
-    LANTERN_CHECK_ARG(s->fused_ws && s->fused_ws_bytes >= (int64_t)lantern_verify_accept_workspace(p.B, s->n_slabs) && ((uintptr_t)s->fused_ws & 7) == 0,
-                      "verify_accept: workspace of lantern_verify_accept_workspace(B, n_slabs) bytes, 8-aligned, zero-filled once");
-    const int cpr = (int)(s->d * s->elem_bytes / 16);
-    const int64_t total = s->outer * cpr;
-    LANTERN_CHECK_ARG(total < (1ll << 31), "verify_accept: outer * row chunks = %lld does not fit 31 bits", (long long)total);
-    const int va_u = p.D <= 6 ? 5 : 4;
-    const int nbx = (int)((total + va_u * 512 - 1) / (va_u * 512));           // tiles of a slab: 512 threads x va_u column groups each
-    LANTERN_CHECK_ARG(nbx <= 4096, "verify_accept: %d tiles per slab", nbx);
-    const int rows_hidden = s->hidden ? s->hid_groups * p.D : 1;
-    (void)rows_hidden;
-    int workers = s->fused_workers > 0 ? s->fused_workers : (p.B < 224 ? 256 - p.B : 32);      // one workgroup per CU (the chain's LDS)
-    VaArgs a{};
-    a.ep = EpwArgs{p, s->ep_buf, s->ep_win};
-    a.slab_ptrs = s->slab_ptrs; a.slab_seq = s->slab_seq; a.slab_prev = s->slab_prev; a.new_len = s->new_len; a.retrieve = s->retrieve;
-    a.outer = s->outer; a.S_max = s->S_max; a.n_slabs = s->n_slabs; a.cpr = cpr; a.nbx = nbx; a.hid_groups = s->hidden ? s->hid_groups : 1;
-    a.hidden = (const uint4 *)s->hidden; a.out_hidden = (uint4 *)s->out_hidden; a.cand = s->cand; a.accepted_tokens = s->accepted_tokens;
-    a.N = s->N; a.hid_cpr = s->hidden ? s->H * s->hid_elem_bytes / 16 : 0;
-    a.ws = (uint32_t *)s->fused_ws;
-    const size_t lds = epw_lds_bytes(p, win);
-    const dim3 grid(p.B + workers);
-    if (raw && va_u == 5) LANTERN_LAUNCH((verify_accept_kernel<true, 5, 6>), grid, dim3(512), lds, (hipStream_t)s->stream, a);
-    else if (raw) LANTERN_LAUNCH((verify_accept_kernel<true, 4, 8>), grid, dim3(512), lds, (hipStream_t)s->stream, a);
-    else if (va_u == 5) LANTERN_LAUNCH((verify_accept_kernel<false, 5, 6>), grid, dim3(512), lds, (hipStream_t)s->stream, a);
-    else LANTERN_LAUNCH((verify_accept_kernel<false, 4, 8>), grid, dim3(512), lds, (hipStream_t)s->stream, a);
-    LANTERN_CHECK_LAUNCH("verify_accept");
     return LANTERN_OK;
 }
 

@@ -24,7 +24,7 @@ import numpy as np
 import torch
 
 from . import _lib, ops
-from ._lib import EpBuffers, EpNodes, EpParams, EpWindow, StepGroup, check
+from ._lib import EpBuffers, EpNodes, EpParams, EpWindow, StepDynamic, StepGroup, check
 
 from contextlib import nullcontext as _nullctx
 
@@ -83,23 +83,13 @@ class WorkloadConfig:
     fuse_update: bool = True        # windowed path: O9 + O10 in one launch (lantern_update_inference_inputs)
     pack_table: bool = True         # windowed path: neighbour table packed to [K, ceil8(k+1)] (lantern_pack_vq_table)
     ep_kernel: str = "nodes"        # windowed path: "nodes" = node-parallel evaluate_posterior (one workgroup per internal tree node + the
-                                    # walk; B * n_internal workgroups fill the GPU), "chain" = one serial chain per sequence (epw_kernel),
-                                    # "walk" = one workgroup per sequence running the node routine at every stop of the walk (epn_serial_kernel),
-                                    # "fast" = the fast-walk kernel (walk_kernel.hip: wave 0 scans, the other waves work ahead of its verdict)
+                                    # walk; B * n_internal workgroups fill the GPU), "chain" = one serial chain per sequence (epw_kernel)
     fuse_o7: bool = False           # windowed chain kernel: LANTERN_ROWS_RAW_BF16 -- no O7 launch, evaluate_posterior post-processes (CFG, top-k,
                                     # softmax) the rows its walk visits from the raw cond / uncond logits
     spec_rows: int = 0              # with fuse_o7: this many of the tree's most likely nodes (the root first) get their rows post-processed
                                     # up front, in the same launch as the candidate assembly (lantern_prepare_step); the rest on demand
     native_step: bool = True        # eager windowed path: the whole step of all groups through ONE C call (lantern_verify_step) instead of
                                     # 4 x n_groups ctypes calls (the Python launch loop caps the stream groups at ~2 otherwise)
-    launch_threads: int = 0         # native_step: >0 = the step's launches are enqueued by this many worker threads (lantern_step_launcher;
-                                    # each group's stream fed by one worker) instead of the calling thread.  3 launches per group at
-                                    # several us of host time each bound the step past ~4 groups otherwise.  More than 3 groups also
-                                    # need GPU_MAX_HW_QUEUES >= n_groups in the environment BEFORE the HIP runtime starts
-    fused_accept: bool = False      # native_step, chain kernel, KV slabs: O8 + O9 + O10 as ONE launch (lantern_verify_accept): the chains of the
-                                    # group run on the first B workgroups, every finished chain queues its verdict and the remaining
-                                    # workgroups move that sequence's KV / hidden rows while slower chains are still running
-    fused_workers: int = 0          # copy workgroups beside the chains (0: 256 / n_groups - sequences per group, at least 32)
     leaf_workgroups: int = -1       # node kernel: -1 = by batch size (include/lantern_hip.h lantern_ep_nodes)
     n_groups: int = 1               # >1: the sequences are split into groups, each launched on its own HIP stream, so that one
                                     # group's latency-bound evaluate_posterior overlaps the others' bandwidth-bound kernels
@@ -173,7 +163,7 @@ class LuminaVerifyWorkload:
         self.anole = cfg.model == "anole"
         self.o7_model = ops.MODEL_ANOLE if self.anole else ops.MODEL_LUMINA
         self.tokens_per_image = 32 * 32 if self.anole else TOKENS_PER_IMAGE          # Anole 512x512: 1024 image tokens, no newline / header rows
-        self.fused_o7 = self.windowed and cfg.fuse_o7 and cfg.ep_kernel in ("chain", "fast") and not self.anole
+        self.fused_o7 = self.windowed and cfg.fuse_o7 and cfg.ep_kernel == "chain" and not self.anole
         self.n_spec = min(max(int(cfg.spec_rows), 0), N) if self.fused_o7 else 0
         if self.n_spec:
             # likelihood order of the nodes: fewer / earlier choices first (the drafter ranks its candidates), the root always
@@ -283,7 +273,7 @@ class LuminaVerifyWorkload:
         self._ep_prm = self._make_ep_params()
         self.graphs = None
         self.ep_nodes = None
-        if self.windowed and cfg.ep_kernel in ("nodes", "walk", "fast"):
+        if self.windowed and cfg.ep_kernel == "nodes":
             self.node_tables = ops.tree_node_tables(tb["retrieve_indices"], N, tb["p_indices"], tb["b_off"], op_off, device=device, b_idx=tb["b_idx"])
             nt = self.node_tables
             win0 = EpWindow()
@@ -292,7 +282,7 @@ class LuminaVerifyWorkload:
             self.node_ws = torch.empty((cfg.n_groups, max(nbytes, 16)), dtype=torch.uint8, device=device)
             self.ep_nodes = []
             for g in range(cfg.n_groups):
-                self.ep_nodes.append(nt.struct(self.node_ws[g].data_ptr(), nbytes, cfg.leaf_workgroups, serial={"walk": 1, "fast": 2}.get(cfg.ep_kernel, 0)))
+                self.ep_nodes.append(nt.struct(self.node_ws[g].data_ptr(), nbytes, cfg.leaf_workgroups))
         self.reset_state()
         # every (pool slot, parity, group) argument block is built HERE (setup, untimed): the step loop only patches the
         # step-dependent log-row addresses, computed arithmetically from these bases
@@ -303,19 +293,10 @@ class LuminaVerifyWorkload:
                 for g in range(self.G):
                     self._group_args(slot, parity, g)
         self._steps = {}
-        self._launcher = None
-        self.fused_ws = None
-        if cfg.fused_accept and self.windowed and cfg.with_kv and self.ep_nodes is None and cfg.native_step:
-            nb = self._L.lantern_verify_accept_workspace(self.Bg, 2 * self.Bg)
-            self.fused_ws = [torch.zeros((nb + 7) // 8, dtype=torch.int64, device=device) for _ in range(self.G)]      # zeroed once; the kernel leaves it zeroed
         if self.windowed and cfg.native_step and cfg.direct_logs and cfg.fuse_update and not cfg.side_stream and not cfg.use_graph:
             for slot in range(cfg.pool_steps):
                 for parity in (0, 1):
                     self._steps[(slot, parity)] = self._make_step_groups(slot, parity)
-            if cfg.launch_threads > 0:
-                h = C.c_void_p()
-                check(self._L.lantern_step_launcher_create(min(cfg.launch_threads, self.G), device.index or 0, C.byref(h)), "step_launcher_create")
-                self._launcher = h
 
     # -------------------------------------------------------------------------------------
     def reset_state(self):
@@ -460,7 +441,6 @@ class LuminaVerifyWorkload:
             self._native_step(slot, i & 1)
             self.step_idx += 1
             return
-        self.launches_done()
         if self.G == 1:
             if use_graph:
                 self.graphs[slot][0].replay()
@@ -490,25 +470,8 @@ class LuminaVerifyWorkload:
                 st.wait_stream(cur)
         self._forked = True
 
-    def launches_done(self):
-        """Worker-thread launches: block until every submitted step sits on its stream (raises the first enqueue error)."""
-        if self._launcher is not None:
-            check(self._L.lantern_step_launcher_wait(self._launcher), "step_launcher_wait")
-
-    def close(self):
-        if getattr(self, "_launcher", None) is not None:
-            self._L.lantern_step_launcher_destroy(self._launcher)
-            self._launcher = None
-
-    def __del__(self):
-        try:
-            self.close()
-        except Exception:
-            pass
-
     def join(self):
         """The current stream waits for every group stream."""
-        self.launches_done()
         if self.G > 1:
             cur = torch.cuda.current_stream(self.device)
             for st in self.streams:
@@ -563,9 +526,6 @@ class LuminaVerifyWorkload:
             s.seq_len, s.out_win, s.row_hot, s.temperature, s.top_p = val(A["cur"]), (None if (self.fused_o7 and not self.n_spec) else val(A["proc"])), val(A["row_hot"]), 1.0, 1.0
             if self.n_spec:
                 s.node_list, s.n_list = self.d_node_list.data_ptr(), self.n_spec
-            if self.fused_ws is not None:
-                s.fused_ws, s.fused_ws_bytes = self.fused_ws[g].data_ptr(), self.fused_ws[g].numel() * 8
-                s.fused_workers = c.fused_workers if c.fused_workers > 0 else max(32, 256 // self.G - self.Bg)
             C.memmove(C.byref(s.ep), C.byref(self._ep_prm), C.sizeof(EpParams))
             C.memmove(C.byref(s.ep_buf), C.byref(A["ep_buf"]), C.sizeof(EpBuffers))
             C.memmove(C.byref(s.ep_win), C.byref(A["ep_win"]), C.sizeof(EpWindow))
@@ -596,12 +556,8 @@ class LuminaVerifyWorkload:
                 s.sample_token = self.sample_token[g * self.Bg:].data_ptr()
             s.ep_buf.best, s.ep_buf.accept_len, s.ep_buf.counters = bs["best"] + 4 * e, bs["alen"] + 4 * e, bs["cnt"] + 24 * e
             s.ep_win.u_bonus, s.ep_win.token = bs["ub"] + 8 * e, bs["tok"] + 8 * e
-        if self._launcher is not None:
-            check(self._L.lantern_step_launcher_submit(self._launcher, arr, self.G), "step_launcher_submit")
-        else:
-            check(self._L.lantern_verify_step(arr, self.G), "verify_step")
+        check(self._L.lantern_verify_step(arr, self.G), "verify_step")
         if not c.with_kv:
-            self.launches_done()
             for g in range(self.G):
                 s0, B = g * self.Bg, self.Bg
                 with torch.cuda.stream(self.streams[g]) if self.streams[g] is not None else _nullctx():
@@ -609,7 +565,6 @@ class LuminaVerifyWorkload:
         # sequence management (not the hot path): an image can only end once the host-side bound says so
         self._len_ub += self.D
         if self._len_ub >= self.tokens_per_image:
-            self.launches_done()
             for g in range(self.G):
                 s0, B = g * self.Bg, self.Bg
                 with torch.cuda.stream(self.streams[g]) if self.streams[g] is not None else _nullctx():
@@ -859,10 +814,6 @@ class LuminaVerifyWorkload:
         if int(st.abs().sum().item()) != 0:
             bad = torch.nonzero(st)[0].tolist()
             raise _lib.LanternError(f"evaluate_posterior status {int(st[bad[0], bad[1]])} at step {i0 + bad[0]} seq {bad[1]}")
-        if self.fused_ws is not None:
-            for g, w in enumerate(self.fused_ws):
-                if int(w[2].item()) & 0xffffffff:
-                    raise _lib.LanternError(f"verify_accept: a copy worker of group {g} gave up waiting for a chain")
 
 
 # =====================================================================================================================
@@ -900,6 +851,9 @@ class DynamicConfig:
     plausible: float = 8.0          # drafted tokens get target logits in [plausible - 2, plausible]: the walk accepts a few levels
     fuse_o7: bool = False           # LANTERN_ROWS_RAW_BF16 with per-sequence positions: no O7 launch over all N rows, evaluate_posterior
                                     # post-processes the rows its walk visits (alen + 1 of the 59)
+    n_groups: int = 1               # >1: stream groups, as in WorkloadConfig (n_seq must divide)
+    native_step: bool = True        # the whole step of all groups through ONE C call (lantern_verify_step with lantern_step_dynamic blocks);
+                                    # False: one ctypes call per kernel and group
 
 
 class DynamicVerifyWorkload:
@@ -909,6 +863,12 @@ class DynamicVerifyWorkload:
         self.N = N = TT + 1
         self.P, self.D = N, DP + 2
         self.lg = cfg.model == "llamagen"
+        self.G = G = max(1, cfg.n_groups)
+        if B % G:
+            raise ValueError(f"n_seq={B} is not a multiple of n_groups={G}")
+        self.Bg = Bg = B // G
+        self.streams = [torch.cuda.Stream(device=device) for _ in range(G)] if G > 1 else [None]
+        self._forked = False
         if cfg.model not in ("lumina", "llamagen"):
             raise ValueError(f"model={cfg.model}")
         # vocabulary, image-token window, hidden width, tokens per image of the model
@@ -982,7 +942,8 @@ class DynamicVerifyWorkload:
         self.log_alen = torch.zeros((cfg.max_steps, B), dtype=torch.int32, device=device)
         self.log_cnt = torch.zeros((cfg.max_steps, B, 6), dtype=torch.int32, device=device)
         self.log_token = torch.zeros((cfg.max_steps, B), dtype=torch.int64, device=device)
-        base = torch.cat([torch.full((B,), cfg.prompt_len + 3, dtype=torch.int64), torch.full((B,), 3, dtype=torch.int64)]).to(device)
+        # slab / length order: G blocks of [conditional slabs of the group's Bg sequences | their unconditional slabs]
+        base = torch.cat([torch.full((Bg,), cfg.prompt_len + 3, dtype=torch.int64), torch.full((Bg,), 3, dtype=torch.int64)]).repeat(G).to(device)
         self.len_base, self.lens = base, [base.clone(), base.clone()]
         self.slabs: List[torch.Tensor] = []
         if cfg.with_kv:
@@ -994,10 +955,10 @@ class DynamicVerifyWorkload:
             for _ in range(2 * B):
                 self.slabs.append(torch.zeros(shape, dtype=torch.bfloat16, device=device))
             self.slab_ptrs = torch.tensor([s.data_ptr() for s in self.slabs], dtype=torch.int64, device=device)
-            self.slab_seq = torch.arange(B, dtype=torch.int32, device=device).repeat(2)
+            self.slab_seq = torch.arange(Bg, dtype=torch.int32, device=device).repeat(2 * G)      # sequence index INSIDE its group
         self._L = _lib.lib()
         p = EpParams()
-        p.B, p.P, p.D, p.V, p.rows_per_seq = B, self.P, self.D, V, N
+        p.B, p.P, p.D, p.V, p.rows_per_seq = Bg, self.P, self.D, V, N
         if self.lg:
             p.mode, p.syntax_shortcut, p.tok_offset = ops.MODE_DYNAMIC, 0, 0
             p.img_lo, p.img_hi, p.n_syntax = 0, V, 0
@@ -1031,63 +992,152 @@ class DynamicVerifyWorkload:
         self._bases = dict(best=self.log_best.data_ptr(), alen=self.log_alen.data_ptr(), cnt=self.log_cnt.data_ptr(),
                            tok=self.log_token.data_ptr(), ub=self.u_bonus.data_ptr())
         self.step_idx, self._len_ub = 0, 0
+        # one argument block per (pool slot, parity, group), built here (setup, untimed); the step loop patches the log-row addresses
+        self._dyn_keep, self._steps = [], {}
+        for slot in range(S):
+            for parity in (0, 1):
+                self._steps[(slot, parity)] = self._make_groups(slot, parity)
+
+    def _make_groups(self, slot: int, parity: int):
+        c, vp = self.cfg, (lambda t, o=0: t[o:].data_ptr())
+        pool, cur, nxt = self.pools[slot], self.lens[parity], self.lens[parity ^ 1]
+        arr = (StepGroup * self.G)()
+        for g in range(self.G):
+            s0, Bg, N = g * self.Bg, self.Bg, self.N
+            d = StepDynamic()
+            d.scores, d.tokens, d.parents = vp(pool["scores"], s0), vp(pool["tokens"], s0), vp(pool["parents"], s0)
+            d.n_scores, d.n_parents, d.top_k, d.total_tokens, d.sort_rows = self.n_scores, self.n_parents, c.top_k, c.total_tokens, 1
+            d.draft_tokens, d.mask, d.pos_ids, d.retrieve = vp(self.draft, s0), vp(self.mask, s0), vp(self.pos, s0), vp(self.ret, s0)
+            d.n_leaf, d.max_depth, d.seq_len = vp(self.nleaf, s0), vp(self.mdepth, s0), vp(cur, 2 * s0)
+            d.retrieve_pd, d.row_index, d.pos_abs = vp(self.ret_pd, s0), vp(self.row_index, s0), vp(self.pos_abs, s0)
+            self._dyn_keep.append(d)
+            s = arr[g]
+            s.dyn = C.pointer(d)
+            s.B, s.N, s.P, s.D = Bg, N, self.P, self.D
+            s.cand = vp(self.cand, s0)
+            s.cond, s.uncond, s.dtype, s.V, s.cfg = vp(pool["cond"], s0), vp(pool["unc"], s0), 1, self.V, c.cfg_scale
+            s.model = ops.MODEL_PLAIN if self.lg else ops.MODEL_LUMINA
+            s.pos_ids, s.pos_base, s.seq_len = vp(self.pos_abs, s0), c.prompt_len + 3, None
+            s.w_latent, s.h_latent, s.img_lo, s.img_hi, s.newline_id, s.eos_id, s.top_k = W_LATENT, H_LATENT, self.lo, self.hi, NEWLINE, EOS, c.logit_top_k
+            s.win_lo, s.win_len, s.out_kind, s.temperature, s.top_p = self.lo, self.W, ops.ROWS_PROBS, 1.0, 1.0
+            s.out_win, s.row_hot = (None if self.fused_o7 else vp(self.win, s0)), vp(self.hot, s0)
+            C.memmove(C.byref(s.ep), C.byref(self._prm), C.sizeof(EpParams))
+            C.memmove(C.byref(s.ep_buf), C.byref(self._buf), C.sizeof(EpBuffers))
+            C.memmove(C.byref(s.ep_win), C.byref(self._win), C.sizeof(EpWindow))
+            b, w = s.ep_buf, s.ep_win
+            b.logits = vp(pool["cond"], s0) if self.fused_o7 else vp(self.win, s0)
+            b.row_index, b.cand, b.n_paths, b.n_depth = vp(self.row_index, s0), vp(self.cand, s0), vp(self.nleaf, s0), vp(self.mdepth, s0)
+            b.uniforms, b.cursor = vp(self.uniforms, s0), vp(self.cursor, s0)
+            w.row_hot, w.out_tok, w.out_mass = vp(self.hot, s0), vp(self.out_tok, s0), vp(self.out_mass, s0)
+            if self.fused_o7:
+                w.raw_uncond, w.raw_pos_ids = vp(pool["unc"], s0), vp(self.pos_abs, s0)
+            if c.with_kv:
+                s.slab_ptrs, s.slab_seq = vp(self.slab_ptrs, 2 * s0), vp(self.slab_seq, 2 * s0)
+                s.slab_prev, s.new_len = vp(cur, 2 * s0), vp(nxt, 2 * s0)
+                s.n_slabs, s.elem_bytes, s.outer = 2 * Bg, 2, 2 * c.kv_layers * c.kv_heads
+                s.S_max, s.d = c.kv_smax + c.kv_pad_rows, c.kv_dim
+                s.hidden, s.out_hidden, s.accepted_tokens = vp(pool["hidden"], s0), vp(self.out_hidden, s0), vp(self.acc_tokens, s0)
+                s.hid_elem_bytes, s.hid_groups, s.H = 2, 2, self.hidden_w
+        return arr
+
+    def _fork(self):
+        if self.G > 1:
+            cur = torch.cuda.current_stream(self.device)
+            for st in self.streams:
+                st.wait_stream(cur)
+        self._forked = True
+
+    def join(self):
+        """The current stream waits for every group stream."""
+        if self.G > 1:
+            cur = torch.cuda.current_stream(self.device)
+            for st in self.streams:
+                cur.wait_stream(st)
+        self._forked = False
+
+    def sync(self):
+        self.join()
+        torch.cuda.synchronize(self.device)
 
     def release_kv(self):
-        self.slabs, self.slab_ptrs = [], None
+        self.sync()
+        self.slabs, self.slab_ptrs, self._steps = [], None, {}
         torch.cuda.empty_cache()
 
     def step(self, events=None):
-        c, L, vp = self.cfg, self._L, C.c_void_p
+        """Enqueue one verify step of every sequence: O4 -> O6 -> O7 -> O8 -> O9 + O10 per group.  events None and cfg.native_step: ONE call
+        of lantern_verify_step, group g on its own stream (G > 1: join() / sync() before reading results elsewhere).  Otherwise the same
+        entry points one ctypes call each, group after group on the current stream; `events`: name -> (start, end) around group 0's launches."""
+        c, L = self.cfg, self._L
         i = self.step_idx
         if i >= c.max_steps:
             raise _lib.LanternError(f"step {i} >= max_steps {c.max_steps}")
-        B, N, P, D = c.n_seq, self.N, self.P, self.D
-        V, IMG_LO, IMG_HI, HIDDEN = self.V, self.lo, self.hi, self.hidden_w
-        pool = self.pools[i % c.pool_steps]
+        arr = self._steps[(i % c.pool_steps, i & 1)]
+        bs, native = self._bases, events is None and c.native_step
+        if native and self.G > 1 and not self._forked:
+            self._fork()
+        if not native and self._forked:
+            self.join()
+        cur_stream = torch.cuda.current_stream().cuda_stream
+        for g in range(self.G):
+            s, e = arr[g], i * c.n_seq + g * self.Bg
+            s.stream = self.streams[g].cuda_stream if (native and self.G > 1) else cur_stream
+            s.sample_token = self.first_token[g * self.Bg:].data_ptr() if i == 0 else bs["tok"] + 8 * (e - c.n_seq)
+            s.ep_buf.best, s.ep_buf.accept_len, s.ep_buf.counters = bs["best"] + 4 * e, bs["alen"] + 4 * e, bs["cnt"] + 24 * e
+            s.ep_win.u_bonus, s.ep_win.token = bs["ub"] + 8 * e, bs["tok"] + 8 * e
+        if native:
+            check(L.lantern_verify_step(arr, self.G), "verify_step")
+        else:
+            for g in range(self.G):
+                self._launch_group(arr[g], events if g == 0 else None)
         cur, nxt = self.lens[i & 1], self.lens[(i & 1) ^ 1]
-        st = vp(torch.cuda.current_stream().cuda_stream)
-        bs, e = self._bases, i * B
-        p_sample = self.first_token.data_ptr() if i == 0 else bs["tok"] + 8 * (e - B)
-        arm = lambda name: events and check(L.lantern_profile_next_launch(vp(events[name][0].cuda_event), vp(events[name][1].cuda_event)), "profile")
-        check(L.lantern_tree_dynamic_finalize(vp(pool["scores"].data_ptr()), vp(pool["tokens"].data_ptr()), vp(pool["parents"].data_ptr()),
-                                              vp(p_sample), B, self.n_scores, self.n_parents, c.top_k, c.total_tokens, 1, vp(self.draft.data_ptr()),
-                                              vp(self.mask.data_ptr()), vp(self.pos.data_ptr()), vp(self.ret.data_ptr()), vp(self.nleaf.data_ptr()),
-                                              vp(self.mdepth.data_ptr()), st), "tree_dynamic_finalize")
-        check(L.lantern_gather_candidates_dynamic(vp(self.draft.data_ptr()), vp(self.ret.data_ptr()), vp(self.pos.data_ptr()), vp(cur.data_ptr()), B, N,
-                                                  P, D, vp(self.cand.data_ptr()), vp(self.ret_pd.data_ptr()), vp(self.row_index.data_ptr()),
-                                                  vp(self.pos_abs.data_ptr()), st), "gather_candidates_dynamic")
-        b, w = self._buf, self._win
-        if self.fused_o7:
-            b.logits, w.raw_uncond = pool["cond"].data_ptr(), pool["unc"].data_ptr()
-        else:
-            arm("cfg_mask_topk")
-            check(L.lantern_cfg_mask_topk_window(vp(pool["cond"].data_ptr()), vp(pool["unc"].data_ptr()), 1, B * N, V, C.c_float(c.cfg_scale),
-                                                 ops.MODEL_PLAIN if self.lg else ops.MODEL_LUMINA, vp(self.pos_abs.data_ptr()), C.c_int64(c.prompt_len + 3), W_LATENT, H_LATENT, IMG_LO,
-                                                 IMG_HI, NEWLINE, EOS, c.logit_top_k, None, 0, IMG_LO, self.W, vp(self.win.data_ptr()),
-                                                 vp(self.hot.data_ptr()), ops.ROWS_PROBS, C.c_float(1.0), C.c_float(1.0), st), "cfg_mask_topk_window")
-        b.best, b.accept_len, b.counters = bs["best"] + 4 * e, bs["alen"] + 4 * e, bs["cnt"] + 24 * e
-        w.u_bonus, w.token = bs["ub"] + 8 * e, bs["tok"] + 8 * e
-        arm("evaluate_posterior")
-        check(L.lantern_evaluate_posterior_window(C.byref(self._prm), C.byref(b), C.byref(w), st), "evaluate_posterior_window")
-        if c.with_kv:
-            arm("kv_gather")
-            check(L.lantern_update_inference_inputs(vp(self.slab_ptrs.data_ptr()), vp(self.slab_seq.data_ptr()), vp(cur.data_ptr()), 2 * B, 2,
-                                                    C.c_int64(2 * c.kv_layers * c.kv_heads), C.c_int64(c.kv_smax + c.kv_pad_rows), C.c_int64(c.kv_dim),
-                                                    vp(self.ret_pd.data_ptr()), 1, P, D, vp(b.best), vp(b.accept_len), vp(nxt.data_ptr()),
-                                                    vp(pool["hidden"].data_ptr()), 2, B, 2, N, HIDDEN, vp(self.cand.data_ptr()),
-                                                    vp(self.out_hidden.data_ptr()), vp(self.acc_tokens.data_ptr()), st), "update_inference_inputs")
-        else:
-            torch.add(cur, (self.log_alen[i] + 1).repeat(2), out=nxt)
-        self._len_ub += D
+        if not c.with_kv:
+            for g in range(self.G):
+                s0, Bg = g * self.Bg, self.Bg
+                with torch.cuda.stream(self.streams[g]) if (native and self.G > 1) else _nullctx():
+                    torch.add(cur[2 * s0:2 * s0 + 2 * Bg], (self.log_alen[i, s0:s0 + Bg] + 1).repeat(2), out=nxt[2 * s0:2 * s0 + 2 * Bg])
+        self._len_ub += self.D
         if self._len_ub >= self.tokens_per_image:      # an image can end: wrap those sequences (host bound refreshed every few hundred steps)
+            self.join()
             torch.where(nxt - self.len_base >= self.tokens_per_image, self.len_base, nxt, out=nxt)
             self._len_ub = int((nxt - self.len_base).max().item())
         self.step_idx += 1
 
+    def _launch_group(self, s, events=None):
+        """One group's step, one ctypes call per kernel on s.stream (the per-kernel timing pass; the parity tests' second path)."""
+        L, vp, d = self._L, C.c_void_p, s.dyn.contents
+        st = vp(s.stream)
+        arm = lambda name: events and check(L.lantern_profile_next_launch(vp(events[name][0].cuda_event), vp(events[name][1].cuda_event)), "profile")
+        check(L.lantern_tree_dynamic_finalize(vp(d.scores), vp(d.tokens), vp(d.parents), vp(s.sample_token), s.B, d.n_scores, d.n_parents, d.top_k,
+                                              d.total_tokens, d.sort_rows, vp(d.draft_tokens), vp(d.mask), vp(d.pos_ids), vp(d.retrieve), vp(d.n_leaf),
+                                              vp(d.max_depth), st), "tree_dynamic_finalize")
+        check(L.lantern_gather_candidates_dynamic(vp(d.draft_tokens), vp(d.retrieve), vp(d.pos_ids), vp(d.seq_len), s.B, s.N, s.P, s.D, vp(s.cand),
+                                                  vp(d.retrieve_pd), vp(d.row_index), vp(d.pos_abs), st), "gather_candidates_dynamic")
+        if s.out_win:
+            arm("cfg_mask_topk")
+            check(L.lantern_cfg_mask_topk_window(vp(s.cond), vp(s.uncond), s.dtype, s.B * s.N, s.V, C.c_float(s.cfg), s.model, vp(s.pos_ids), C.c_int64(s.pos_base),
+                                                 s.w_latent, s.h_latent, s.img_lo, s.img_hi, s.newline_id, s.eos_id, s.top_k, None, 0, s.win_lo, s.win_len,
+                                                 vp(s.out_win), vp(s.row_hot), s.out_kind, C.c_float(s.temperature), C.c_float(s.top_p), st), "cfg_mask_topk_window")
+        arm("evaluate_posterior")
+        check(L.lantern_evaluate_posterior_window(C.byref(s.ep), C.byref(s.ep_buf), C.byref(s.ep_win), st), "evaluate_posterior_window")
+        if s.slab_ptrs:
+            arm("kv_gather")
+            check(L.lantern_update_inference_inputs(vp(s.slab_ptrs), vp(s.slab_seq), vp(s.slab_prev), s.n_slabs, s.elem_bytes, C.c_int64(s.outer), C.c_int64(s.S_max),
+                                                    C.c_int64(s.d), vp(d.retrieve_pd), 1, s.P, s.D, vp(s.ep_buf.best), vp(s.ep_buf.accept_len), vp(s.new_len),
+                                                    vp(s.hidden), s.hid_elem_bytes, s.B, s.hid_groups, s.N, s.H, vp(s.cand), vp(s.out_hidden),
+                                                    vp(s.accepted_tokens), st), "update_inference_inputs")
+
+    def lengths(self, parity: int):
+        """(conditional, unconditional) cache lengths in sequence order (the length vector is stored group by group)."""
+        v = self.lens[parity].view(self.G, 2, self.Bg)
+        return v[:, 0].reshape(-1), v[:, 1].reshape(-1)
+
     def accepted_tokens(self, i0: int, i1: int) -> int:
+        self.join()
         return int((self.log_alen[i0:i1].to(torch.int64) + 1).sum().item())
 
     def check_status(self, i0: int, i1: int):
+        self.join()
         stt = self.log_cnt[i0:i1, :, 5]
         if int(stt.abs().sum().item()) != 0:
             bad = torch.nonzero(stt)[0].tolist()

@@ -201,9 +201,8 @@ class NodeTables:
     max_children: int
     prefix_siblings: int = 1
 
-    def struct(self, workspace: int, workspace_bytes: int, leaf_workgroups: int = -1, serial: bool = False) -> EpNodes:
+    def struct(self, workspace: int, workspace_bytes: int, leaf_workgroups: int = -1) -> EpNodes:
         en = EpNodes()
-        en.serial = int(serial)
         en.tables = self.tables.data_ptr()
         en.tables_host = self.host.ctypes.data
         en.n_nodes, en.n_internal, en.n_children, en.max_children = self.n_nodes, self.n_internal, self.n_children, self.max_children
@@ -518,7 +517,7 @@ def cfg_mask_topk_window(cond, uncond, cfg: float, win_lo: int, win_len: int, mo
 def evaluate_posterior_window(cfg: EpConfig, V: int, win_logits, win_lo: int, row_index, cand, uniforms, row_hot=None, table=None,
                               aux: Optional[StaticAux] = None, orig_windowed: bool = False, n_paths=None, n_depth=None,
                               cursor=None, u_bonus=None, want_dense: bool = False, want_window: bool = True, rows_probs: bool = False,
-                              nodes: Optional[NodeTables] = None, leaf_workgroups: int = -1, serial: bool = False):
+                              nodes: Optional[NodeTables] = None, leaf_workgroups: int = -1):
     """O8 windowed.  win_logits [B,rows,W] f32 (probabilities when rows_probs: cfg must then carry top_k=0, temperature=1).  aux.orig_prob is the dense [B,R,V] pool (orig_windowed=False) or a
     windowed [B,R,W] pool.  Returns dict(best, accept_len, counters, sample_win, out_tok, out_mass, token, sample_p)."""
     win_logits = _dev(win_logits, torch.float32, "win_logits")
@@ -583,7 +582,7 @@ def evaluate_posterior_window(cfg: EpConfig, V: int, win_logits, win_lo: int, ro
     if nodes is not None:      # node-parallel form: one workgroup per internal tree node, then the walk
         nbytes = _lib.lib().lantern_evaluate_posterior_nodes_workspace(C.byref(prm), C.byref(win), nodes.n_internal, int(want_dense or want_window))
         ws = torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=dev)
-        en = nodes.struct(ws.data_ptr(), int(nbytes), leaf_workgroups, serial)
+        en = nodes.struct(ws.data_ptr(), int(nbytes), leaf_workgroups)
         check(_lib.lib().lantern_evaluate_posterior_nodes(C.byref(prm), C.byref(buf), C.byref(win), C.byref(en), _stream()), "evaluate_posterior_nodes")
         out["_workspace"] = ws
         return out

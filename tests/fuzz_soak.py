@@ -251,7 +251,7 @@ if len(sys.argv) > 2 and sys.argv[2] == "o3":
 
 # ---------------------------------------------------------------------------------------------- node kernels
 # `python tests/fuzz_soak.py <seeds> nodes`: tests/test_gpu_nodes.py::test_nodes_static_batches_vs_oracle over many more seeds -- the chain
-# kernel, the node-parallel kernels and the serial node kernel on the same 32-sequence batches, all against the oracle and each other.
+# kernel and the node-parallel kernels on the same 32-sequence batches, both against the oracle and each other.
 def nodes_soak(n_seeds):
     import test_gpu_nodes as TN
     sets = [("lumina", "mc_sim_7b_63", True, 100, 0.1, 1.0, True), ("lumina", "mc_sim_7b_63", True, 300, 5.0, 2.0, False),
@@ -272,7 +272,7 @@ def nodes_soak(n_seeds):
             n += 1
         if (seed - 200) % 5 == 4:
             print(f"  seed {seed}: {n} batches, fails={fails}, {time.time() - t0:.0f}s", flush=True)
-    print(f"nodes soak: cases={n} batches x 32 sequences x 3 kernels, fails={fails}, {time.time() - t0:.0f}s")
+    print(f"nodes soak: cases={n} batches x 32 sequences x 2 kernels, fails={fails}, {time.time() - t0:.0f}s")
 
 
 if len(sys.argv) > 2 and sys.argv[2] == "nodes":

@@ -148,30 +148,24 @@ def test_step_group_layout_matches_the_c_struct(tmp_path):
 
 
 def test_round2_entry_points_validate_without_gpu():
-    """The one-call step, the single-launch accept, the node tables' serial form and the worker-thread launcher: argument errors and empty
-    batches come back as codes + messages before anything touches a device (no GPU here)."""
+    """The one-call step, the step preparation and the node form: argument errors and empty batches come back as codes + messages before
+    anything touches a device (no GPU here)."""
     L = _lib.lib()
     assert L.lantern_verify_step(None, 1) == -1
     assert L.lantern_verify_step(None, 0) == -1 or L.lantern_verify_step((_lib.StepGroup * 1)(), 0) == 0
     g = _lib.StepGroup()
-    assert L.lantern_verify_accept(None) == -1
-    g.ep.B, g.ep.P, g.ep.D, g.ep.V = 0, 15, 6, 65536
-    assert L.lantern_verify_accept(C.byref(g)) == 0                      # an empty group launches nothing
-    g.ep.B = 2
-    assert L.lantern_verify_accept(C.byref(g)) == -1                     # window / buffers missing
-    assert L.lantern_verify_accept_workspace(21, 42) == 32 + 63 * 8 and L.lantern_verify_accept_workspace(-1, 0) == 0
+    g.ep.B, g.ep.P, g.ep.D, g.ep.V = 2, 15, 6, 65536
     assert L.lantern_prepare_step(C.byref(g)) == -1 and b"node list" in L.lantern_last_error()
     prm, buf, win, nodes = _lib.EpParams(), _lib.EpBuffers(), _lib.EpWindow(), _lib.EpNodes()
     prm.B, prm.P, prm.D, prm.V = 1, 15, 6, 65536
-    nodes.serial = 1
     assert L.lantern_evaluate_posterior_nodes(C.byref(prm), C.byref(buf), C.byref(win), C.byref(nodes), None) == -1      # no tables
-    # launcher life cycle: workers start, nothing is submitted, wait returns at once, destroy joins them
-    h = C.c_void_p()
-    assert L.lantern_step_launcher_create(0, 0, C.byref(h)) == -1 and L.lantern_step_launcher_create(3, 0, None) == -1
-    assert L.lantern_step_launcher_create(3, 0, C.byref(h)) == 0 and h.value
-    assert L.lantern_step_launcher_wait(h) == 0
-    assert L.lantern_step_launcher_submit(h, None, 0) == 0
-    assert L.lantern_step_launcher_submit(h, None, 2) == -1 and b"bad arguments" in L.lantern_last_error()
-    assert L.lantern_step_launcher_wait(h) == 0
-    L.lantern_step_launcher_destroy(h)
-    assert L.lantern_step_launcher_wait(None) == -1
+    # a failing stage of the step names its group: a dynamic group without its score pools
+    arr = (_lib.StepGroup * 2)()
+    dyn = _lib.StepDynamic()
+    arr[0].B, arr[0].N, arr[0].P, arr[0].D = 2, 60, 20, 7
+    arr[0].dyn = C.pointer(dyn)
+    assert L.lantern_verify_step(arr, 2) == -1
+    msg = L.lantern_last_error()
+    assert msg.startswith(b"verify_step: group 0, tree_dynamic_candidates: "), msg
+    arr[0].dyn = None
+    assert L.lantern_verify_step(arr, 2) == -1 and L.lantern_last_error().startswith(b"verify_step: group 0, gather_candidates: ")

@@ -62,8 +62,9 @@ def test_kv_rows_follow_the_accepted_path():
         assert torch.equal(s[..., keep.cuda(), :], b0[..., keep.cuda(), :])
 
 
-@pytest.mark.parametrize("fuse", [False, True], ids=["o7_launch", "raw_rows"])
-def test_dynamic_tree_loop_matches_oracle_loop(fuse):
+@pytest.mark.parametrize("fuse,groups,native", [(False, 1, True), (True, 1, True), (False, 3, True), (True, 2, True), (False, 2, False)],
+                         ids=["o7_launch", "raw_rows", "o7_launch_3_groups", "raw_rows_2_groups", "per_kernel_calls_2_groups"])
+def test_dynamic_tree_loop_matches_oracle_loop(fuse, groups, native):
     """The device-resident EAGLE-2 loop (O4 -> O6 dynamic -> O7 -> O8 dynamic -> O9 + O10, a different tree per sequence and
     step) against the oracle's loop over the same pools / uniforms: identical (best path, accept length, bonus token), every
     step, every sequence; KV lengths advance by exactly the accepted tokens."""
@@ -73,12 +74,13 @@ def test_dynamic_tree_loop_matches_oracle_loop(fuse):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import helpers as H
     steps = 8
-    cfg = HN.DynamicConfig(n_seq=3, pool_steps=2, kv_layers=2, kv_heads=4, kv_smax=512, max_steps=steps + 2, lantern_k=300, fuse_o7=fuse)
+    cfg = HN.DynamicConfig(n_seq=3 * groups, pool_steps=2, kv_layers=2, kv_heads=4, kv_smax=512, max_steps=steps + 2, lantern_k=300, fuse_o7=fuse,
+                           n_groups=groups, native_step=native)
     wl = HN.DynamicVerifyWorkload(cfg, torch.device("cuda"))
-    assert wl.fused_o7 == fuse
+    assert wl.fused_o7 == fuse and wl.G == groups
     for _ in range(steps):
         wl.step()
-    torch.cuda.synchronize()
+    wl.sync()
     wl.check_status(0, steps)
     gb, ga, gt = wl.log_best[:steps].cpu().numpy(), wl.log_alen[:steps].cpu().numpy(), wl.log_token[:steps].cpu().numpy()
     table = wl.table_full.cpu().numpy().view(np.uint16)
@@ -104,8 +106,52 @@ def test_dynamic_tree_loop_matches_oracle_loop(fuse):
             n_acc += alen
     assert n_acc > 0                                   # the walk really accepts drafted tokens
     gen = (ga.astype("int64") + 1).sum(0)
-    assert (wl.lens[steps & 1][:cfg.n_seq].cpu().numpy() == cfg.prompt_len + 3 + gen).all()
-    assert (wl.lens[steps & 1][cfg.n_seq:].cpu().numpy() == 3 + gen).all()
+    len_c, len_u = wl.lengths(steps & 1)
+    assert (len_c.cpu().numpy() == cfg.prompt_len + 3 + gen).all() and (len_u.cpu().numpy() == 3 + gen).all()
+    # the accepted tokens and the KV rows of every slab: the tree slot of accepted token t moved to row prev + t (checked through the
+    # lengths above and, for the tokens, against the verdicts)
+    acc = wl.acc_tokens.cpu().numpy()
+    last = steps - 1
+    for b in range(cfg.n_seq):
+        assert int(acc[b, int(ga[last, b])]) >= 0 and (acc[b, int(ga[last, b]) + 1:] == -1).all()
+
+
+@pytest.mark.parametrize("fuse", [False, True], ids=["o7_launch", "raw_rows"])
+def test_dynamic_step_one_call_equals_per_kernel_calls(fuse):
+    """lantern_verify_step with dynamic groups (O4 + O6-dynamic in one launch, lantern_tree_dynamic_candidates) against the same step as
+    one call per entry point (lantern_tree_dynamic_finalize, then lantern_gather_candidates_dynamic, ...): every tree buffer, candidate
+    table, verdict, length, KV slab and accepted row identical after every step."""
+    from lantern_amd import harness as HN
+    steps = 6
+    wls = []
+    for native, groups in ((True, 2), (False, 1)):
+        cfg = HN.DynamicConfig(n_seq=4, pool_steps=2, kv_layers=2, kv_heads=4, kv_smax=512, max_steps=steps + 2, lantern_k=300, fuse_o7=fuse,
+                               n_groups=groups, native_step=native)
+        wls.append(HN.DynamicVerifyWorkload(cfg, torch.device("cuda")))
+    for wl in wls:              # the same random rows in every sequence's slabs, whatever the slab order
+        for g in range(wl.G):
+            for half in range(2):
+                for q in range(wl.Bg):
+                    gen = torch.Generator(device="cuda").manual_seed(1000 * half + g * wl.Bg + q)
+                    sl = wl.slabs[g * 2 * wl.Bg + half * wl.Bg + q]
+                    sl.copy_(torch.randn(sl.shape, generator=gen, device="cuda").to(sl.dtype))
+    for i in range(steps):
+        for wl in wls:
+            wl.step()
+            wl.sync()
+        a, b = wls
+        for name in ("draft", "mask", "pos", "ret", "nleaf", "mdepth", "cand", "ret_pd", "row_index", "pos_abs", "out_hidden", "acc_tokens", "cursor"):
+            assert torch.equal(getattr(a, name), getattr(b, name)), (i, name)
+        for name in ("log_best", "log_alen", "log_token", "log_cnt"):
+            assert torch.equal(getattr(a, name)[:i + 1], getattr(b, name)[:i + 1]), (i, name)
+        for x, y in zip(a.lengths((i + 1) & 1), b.lengths((i + 1) & 1)):
+            assert torch.equal(x, y)
+    # slabs: a's order is [group][cond | uncond][sequence in group], b's is [cond | uncond][sequence]
+    a, b = wls
+    for g in range(a.G):
+        for half in range(2):
+            for q in range(a.Bg):
+                assert torch.equal(a.slabs[g * 2 * a.Bg + half * a.Bg + q], b.slabs[half * b.Bg + g * a.Bg + q]), (g, half, q)
 
 
 @pytest.mark.parametrize("groups,spec", [(1, 0), (2, 0), (1, 5), (2, 1), (1, 26)])
@@ -138,37 +184,13 @@ def test_fused_o7_loop_matches_oracle_loop(groups, spec):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("groups,threads,ep,fuse", [(6, 3, "chain", True), (4, 4, "nodes", False), (1, 1, "chain", True)])
-def test_worker_thread_launches_give_the_same_stream(groups, threads, ep, fuse):
-    """lantern_step_launcher: the step's launches enqueued by worker threads (one stream always fed by the same worker, argument
-    blocks copied at submit) -- every step's verdicts, tokens and counters equal the calling-thread run, KV rows included."""
-    from lantern_amd import harness as HN
-    steps = 80
-    outs = []
-    for thr in (threads, 0):
-        cfg = HN.WorkloadConfig(n_seq=12, pool_steps=4, kv_layers=2, kv_heads=4, kv_smax=1024, max_steps=steps + 4, sigma=5.0, n_groups=groups,
-                                ep_kernel=ep, fuse_o7=fuse, spec_rows=3 if fuse else 0, launch_threads=thr)
-        wl = HN.LuminaVerifyWorkload(cfg, torch.device("cuda"))
-        assert (wl._launcher is not None) == (thr > 0)
-        for _ in range(steps):
-            wl.step()
-        wl.sync()
-        wl.check_status(0, steps)
-        outs.append((wl.log_best[:steps].clone(), wl.log_alen[:steps].clone(), wl.log_token[:steps].clone(), wl.log_cnt[:steps].clone(),
-                     wl.lens[steps & 1].clone(), torch.stack([s.clone() for s in wl.slabs[:4]])))
-        wl.close()
-    for a, b in zip(*outs):
-        assert torch.equal(a, b)
-
-
-@pytest.mark.gpu
-def test_worker_thread_launch_error_reaches_the_caller():
-    """An enqueue that fails on a worker thread comes back from wait() with the kernel's own message."""
-    import ctypes as C
+def test_step_error_names_the_group_and_the_stage():
+    """An entry point that refuses its arguments inside lantern_verify_step comes back with the group and the stage in front of the
+    kernel's own message, and the next step works."""
     from lantern_amd import _lib
     from lantern_amd import harness as HN
     cfg = HN.WorkloadConfig(n_seq=4, pool_steps=2, kv_layers=2, kv_heads=4, kv_smax=512, max_steps=16, n_groups=2, ep_kernel="chain",
-                            fuse_o7=True, spec_rows=3, launch_threads=2)
+                            fuse_o7=True, spec_rows=3)
     wl = HN.LuminaVerifyWorkload(cfg, torch.device("cuda"))
     wl.step()
     wl.sync()
@@ -176,54 +198,26 @@ def test_worker_thread_launch_error_reaches_the_caller():
     for arr in wl._steps.values():
         arr[1].ep.k = -5                 # an argument the kernel's host side refuses
     try:
-        with pytest.raises(_lib.LanternError, match="worker thread"):
+        with pytest.raises(_lib.LanternError, match="group 1, evaluate_posterior"):
             wl.step()
-            wl.sync()
     finally:
         for arr in wl._steps.values():
             arr[1].ep.k = keep
-    wl.step()                            # the launcher keeps working after the error was collected
     wl.sync()
-    wl.close()
-
-
-@pytest.mark.gpu
-@pytest.mark.parametrize("groups,fuse,workers", [(1, True, 0), (2, True, 3), (1, False, 1), (3, True, 40)])
-def test_fused_accept_launch_gives_the_same_stream_and_kv_rows(groups, fuse, workers):
-    """lantern_verify_accept: evaluate_posterior + update_inference_inputs in one launch, pipelined per sequence through a work queue
-    (chains on the first B workgroups, copy workers behind them).  Verdicts, tokens, counters, lengths, every KV slab, the accepted
-    hidden rows and tokens equal the two-launch run; the queue is left empty."""
-    from lantern_amd import harness as HN
-    steps = 80
-    outs = []
-    for fa in (True, False):
-        cfg = HN.WorkloadConfig(n_seq=12, pool_steps=4, kv_layers=2, kv_heads=4, kv_smax=1024, max_steps=steps + 4, sigma=5.0, n_groups=groups,
-                                ep_kernel="chain", fuse_o7=fuse, spec_rows=3 if fuse else 0, fused_accept=fa, fused_workers=workers)
-        wl = HN.LuminaVerifyWorkload(cfg, torch.device("cuda"))
-        assert (wl.fused_ws is not None) == fa
-        for _ in range(steps):
-            wl.step()
-        wl.sync()
-        wl.check_status(0, steps)
-        if fa:
-            for w in wl.fused_ws:
-                assert int(w.abs().sum()) == 0
-        outs.append((wl.log_best[:steps].clone(), wl.log_alen[:steps].clone(), wl.log_token[:steps].clone(), wl.log_cnt[:steps].clone(),
-                     wl.lens[steps & 1].clone(), torch.stack([s.clone() for s in wl.slabs]), wl.out_hidden.clone(), wl.acc_tokens.clone()))
-    for a, b in zip(*outs):
-        assert torch.equal(a, b)
+    wl.step()
+    wl.sync()
 
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("groups", [1, 2])
-def test_serial_node_kernel_loop_matches_chain_loop(groups):
-    """ep_kernel = "walk" (one workgroup per sequence running the node routine at every stop of the walk, lantern_ep_nodes.serial): the
-    whole step loop gives the chain kernel's verdicts, tokens, counters and KV rows, and the oracle's token stream."""
+def test_node_kernel_loop_matches_chain_loop(groups):
+    """ep_kernel = "nodes" (one workgroup per internal tree node, then the walk): the whole step loop gives the chain kernel's verdicts,
+    tokens, counters and KV rows, and the oracle's token stream."""
     import bench
     from lantern_amd import harness as HN
     steps = 60
     outs = []
-    for ep in ("walk", "chain"):
+    for ep in ("nodes", "chain"):
         cfg = HN.WorkloadConfig(n_seq=8, pool_steps=4, kv_layers=2, kv_heads=4, kv_smax=1024, max_steps=steps + 4, sigma=5.0, n_groups=groups,
                                 ep_kernel=ep)
         wl = HN.LuminaVerifyWorkload(cfg, torch.device("cuda"))
@@ -233,7 +227,7 @@ def test_serial_node_kernel_loop_matches_chain_loop(groups):
         wl.check_status(0, steps)
         outs.append((wl.log_best[:steps].clone(), wl.log_alen[:steps].clone(), wl.log_token[:steps].clone(), wl.log_cnt[:steps].clone(),
                      wl.lens[steps & 1].clone(), torch.stack([s.clone() for s in wl.slabs])))
-        if ep == "walk":
+        if ep == "nodes":
             gb, ga, gt = [x.cpu().numpy() for x in outs[0][:3]]
             stream = [[(int(gb[i, b]), int(ga[i, b]), int(gt[i, b])) for b in range(cfg.n_seq)] for i in range(steps)]
             res = bench.cpu_baseline(wl, steps_budget_s=1e9, n_seq=cfg.n_seq, gpu_tokens_by_seq=stream)

@@ -123,9 +123,8 @@ def _static_ok(s):
 
 
 @gpu
-@pytest.mark.parametrize("serial", [False, True], ids=["parallel", "serial"])
 @pytest.mark.parametrize("i", [i for i, s in enumerate(SPECS) if _static_ok(s)])
-def test_nodes_static_golden(i, serial):
+def test_nodes_static_golden(i):
     from test_gpu_parity import hip_cfg, table_dev
     from test_gpu_window import window_of
     spec, case = SPECS[i], H.ep_case(i)
@@ -144,57 +143,10 @@ def test_nodes_static_golden(i, serial):
     args = (cfg, m["V"], pr[None], lo, dev(H.row_index_from_retrieve(tb["retrieve"], N)), dev(case["cand"])[None], dev(case["uniforms"])[None])
     kw = dict(table=table_dev(m["K"]), aux=aux, u_bonus=dev(np.array([u])), want_dense=True, rows_probs=True)
     chain = ops.evaluate_posterior_window(*args, **kw)
-    node = ops.evaluate_posterior_window(*args, nodes=nt, serial=serial, **kw)
+    node = ops.evaluate_posterior_window(*args, nodes=nt, **kw)
     st = int(node["counters"][0, 5])
     if st == 8:
         # duplicate sibling tokens (a golden edge case): the node view does not hold, the kernel says so and the chain kernel is the path
-        toks = case["tree_cand"]
-        kids = _tables_py(tb["retrieve"], N)[0]
-        assert any(len({int(toks[c]) for c in ks}) < len(ks) for ks in kids.values() if ks)
-        return
-    assert st == int(chain["counters"][0, 5])
-    if st != 0:
-        return
-    for key in ("best", "accept_len", "counters", "token", "out_tok"):
-        assert torch.equal(node[key], chain[key]), (key, node[key], chain[key])
-    assert torch.equal(node["sample_p"], chain["sample_p"]) and torch.equal(node["sample_win"], chain["sample_win"])
-    assert int(node["best"][0]) == int(case["best"]) and int(node["accept_len"][0]) == int(case["accept_len"])
-    assert int(node["counters"][0, 3]) == int(case["n_draws"])
-    np.testing.assert_allclose(node["sample_p"][0].cpu().numpy(), case["sample_p"], rtol=0, atol=PROB_TOL)
-    assert int(node["token"][0]) == oracle.sample_inverse_cdf(node["sample_p"][0].cpu().numpy(), u)
-
-
-def _fast_ok(s):
-    return _static_ok(s) and s["model"] == "lumina" and s["lantern"]
-
-
-@gpu
-@pytest.mark.parametrize("i", [i for i, s in enumerate(SPECS) if _fast_ok(s)])
-def test_fast_walk_static_golden(i):
-    """The fast-walk form (nodes, serial = 2: walk_kernel.hip) on the reference-generated Lumina static cases: the chain kernel's
-    bits on the packed table, the reference's verdict."""
-    from test_gpu_parity import hip_cfg, table_dev
-    from test_gpu_window import window_of
-    spec, case = SPECS[i], H.ep_case(i)
-    tb, g = H.static_inputs(spec, case)
-    m = CS.MODELS[spec["model"]]
-    lo, W = window_of(spec["model"])
-    N = len(tb["tree_indices"])
-    pr = _prob_rows(spec, g["node_logits"], lo, W)
-    cfg = hip_cfg(spec)
-    cfg.temperature, cfg.top_k, cfg.top_p = 1.0, 0, 1.0
-    aux = ops.StaticAux(cart_prob=dev(case["cart_prob"])[None], orig_prob=dev(g["orig_prob"])[None], op_off=dev(g["op_off"]),
-                        p_idx=dev(tb["p_indices"]), b_off=dev(tb["b_off"]),
-                        b_idx=dev(tb["b_idx"] if len(tb["b_idx"]) else np.zeros(1, np.int32)), tree_cand=dev(case["tree_cand"])[None])
-    nt = ops.tree_node_tables(tb["retrieve"], N, tb["p_indices"], tb["b_off"], g["op_off"], device="cuda")
-    u = 0.1 + 0.8 * ((i * 37) % 100) / 100.0
-    args = (cfg, m["V"], pr[None], lo, dev(H.row_index_from_retrieve(tb["retrieve"], N)), dev(case["cand"])[None], dev(case["uniforms"])[None])
-    tab = ops.pack_vq_table(table_dev(m["K"]), -(-(spec["k"] + 1) // 8) * 8)
-    kw = dict(table=tab, aux=aux, u_bonus=dev(np.array([u])), want_dense=True, rows_probs=True)
-    chain = ops.evaluate_posterior_window(*args, **kw)
-    node = ops.evaluate_posterior_window(*args, nodes=nt, serial=2, **kw)
-    st = int(node["counters"][0, 5])
-    if st == 8:
         toks = case["tree_cand"]
         kids = _tables_py(tb["retrieve"], N)[0]
         assert any(len({int(toks[c]) for c in ks}) < len(ks) for ks in kids.values() if ks)
@@ -254,13 +206,10 @@ def test_nodes_static_batches_vs_oracle(model, tree, lantern, k, delta, sigma, s
     ub = np.random.RandomState(seed).random_sample(B)
     nt = ops.tree_node_tables(tb["retrieve_indices"], N, tb["p_indices"], tb["b_off"], gs[0]["op_off"], device="cuda")
     outs = {}
-    forms = [("chain", None, 0), ("nodes", nt, 0), ("walk", nt, 1)]
-    if model == "lumina" and lantern and packed:
-        forms.append(("fast", nt, 2))          # walk_kernel.hip: static Lumina, LANTERN on, packed table
-    for name, nodes, serial in forms:
+    for name, nodes in (("chain", None), ("nodes", nt)):
         cur = dev(start.copy())
         outs[name] = ops.evaluate_posterior_window(ch, V, pr, lo, dev(ri), dev(np.stack(cands)), dev(uni), table=tab if lantern else None, aux=aux,
-                                                   cursor=cur, u_bonus=dev(ub), want_dense=True, rows_probs=True, nodes=nodes, serial=serial)
+                                                   cursor=cur, u_bonus=dev(ub), want_dense=True, rows_probs=True, nodes=nodes)
         outs[name]["cursor"] = cur
     n_rej = n_acc = 0
     needs_dense = []
@@ -286,9 +235,6 @@ def test_nodes_static_batches_vs_oracle(model, tree, lantern, k, delta, sigma, s
     assert len(needs_dense) <= B // 4
     for key in ("best", "accept_len", "counters", "token", "sample_p", "sample_win", "out_tok", "out_mass", "cursor"):
         assert torch.equal(outs["nodes"][key][ok], outs["chain"][key][ok]), key
-        assert torch.equal(outs["walk"][key][ok], outs["chain"][key][ok]), ("walk", key)
-        if "fast" in outs:
-            assert torch.equal(outs["fast"][key][ok], outs["chain"][key][ok]), ("fast", key)
 
 
 @gpu
@@ -327,17 +273,9 @@ def test_nodes_one_hot_rows_and_no_outputs():
     kw = dict(table=tab, aux=aux, u_bonus=dev(ub), row_hot=dev(hot), rows_probs=True)
     a = ops.evaluate_posterior_window(ch, V, pr, lo, dev(ri), dev(np.stack(cands)), dev(uni), want_dense=False, want_window=False, **kw)
     b_ = ops.evaluate_posterior_window(ch, V, pr, lo, dev(ri), dev(np.stack(cands)), dev(uni), want_dense=False, want_window=False, nodes=nt, **kw)
-    c_ = ops.evaluate_posterior_window(ch, V, pr, lo, dev(ri), dev(np.stack(cands)), dev(uni), want_dense=False, want_window=False, nodes=nt, serial=True, **kw)
-    f_ = ops.evaluate_posterior_window(ch, V, pr, lo, dev(ri), dev(np.stack(cands)), dev(uni), want_dense=False, want_window=False, nodes=nt, serial=2, **kw)
     for key in ("best", "accept_len", "counters", "token", "out_tok", "out_mass"):
         assert torch.equal(a[key], b_[key]), (key, a[key], b_[key])
-        assert torch.equal(a[key], c_[key]), ("serial", key, a[key], c_[key])
-        assert torch.equal(a[key], f_[key]), ("fast", key, a[key], f_[key])
     assert int((a["counters"][:, 5] != 0).sum()) == 0
     full = ops.evaluate_posterior_window(ch, V, pr, lo, dev(ri), dev(np.stack(cands)), dev(uni), want_dense=True, nodes=nt, **kw)
     full_c = ops.evaluate_posterior_window(ch, V, pr, lo, dev(ri), dev(np.stack(cands)), dev(uni), want_dense=True, **kw)
-    full_s = ops.evaluate_posterior_window(ch, V, pr, lo, dev(ri), dev(np.stack(cands)), dev(uni), want_dense=True, nodes=nt, serial=True, **kw)
     assert torch.equal(full["sample_p"], full_c["sample_p"]) and torch.equal(full["token"], a["token"])
-    assert torch.equal(full_s["sample_p"], full_c["sample_p"]) and torch.equal(full_s["sample_win"], full_c["sample_win"]) and torch.equal(full_s["token"], a["token"])
-    full_f = ops.evaluate_posterior_window(ch, V, pr, lo, dev(ri), dev(np.stack(cands)), dev(uni), want_dense=True, nodes=nt, serial=2, **kw)
-    assert torch.equal(full_f["sample_p"], full_c["sample_p"]) and torch.equal(full_f["sample_win"], full_c["sample_win"]) and torch.equal(full_f["token"], a["token"])

@@ -7,7 +7,7 @@ import csv, glob, json, os, shutil, subprocess, sys, collections
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 RND = sys.argv[1] if len(sys.argv) > 1 else "r03"
 runs = dict(a.split("=", 1) for a in sys.argv[2:]) or {"raw": RND + "p", "chain": RND + "p_chain"}          # traffic key prefix -> gpurun_out/<dir>
-kern = {"raw": ["epw_kernel"], "chain": ["epw_kernel"], "nodes": ["epn_kernel", "epn_walk_kernel"], "walk": ["epn_serial_kernel"], "fast": ["epf_kernel"]}
+kern = {"raw": ["epw_kernel"], "chain": ["epw_kernel"], "nodes": ["epn_kernel", "epn_walk_kernel"]}
 others = ["prep_rows_kernel", "cfg_window_bf16", "update_inputs_kernel"]
 
 

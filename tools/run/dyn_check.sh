@@ -1,15 +1,20 @@
 #!/bin/bash
+# dynamic-tree step through lantern_verify_step: tests, then the dynamic bench legs alone
 cd $GRAFT_REPO_ROOT
-OUT=gpurun_out/${1:-r2dy}
-mkdir -p $OUT
-timeout -k 10 600 python -m pytest tests/test_gpu_loop.py tests/test_gpu_window.py -x -q -m gpu -k "dynamic or raw or fused" > $OUT/tests.log 2>&1
-rc=$?; tail -4 $OUT/tests.log; [ $rc -eq 0 ] || exit $rc
-timeout -k 10 300 python - <<PY
-import torch, bench, json
+O=gpurun_out/dyn
+mkdir -p $O
+timeout -k 10 600 python3 -m pytest tests/test_gpu_loop.py -x -q -m gpu > $O/t_loop.txt 2>&1 || { tail -40 $O/t_loop.txt; exit 1; }
+tail -2 $O/t_loop.txt
+timeout -k 10 600 python3 - <<'PY' > $O/dyn.txt 2>&1
+import sys, json, torch
+sys.path.insert(0, ".")
+import bench
 from lantern_amd import harness as HN
 dev = torch.device("cuda")
-cfg = HN.WorkloadConfig(n_seq=64)
+base = HN.WorkloadConfig(n_seq=63, n_groups=3)
 for fuse in (True, False):
-    r = bench.dynamic_run(dev, cfg, 100, 64, fuse_o7=fuse)
-    print(fuse, round(r["value"]), round(r["ms_per_step"]*1e3,1), r["mean_accept_length"], r["per_step"], {k: round(v*1e3,1) for k,v in r["kernel_ms"].items()}, flush=True)
+    for g in (1, 3):
+        r = bench.dynamic_run(dev, base, 200, 63, fuse_o7=fuse, groups=g)
+        print(json.dumps({k: r[k] for k in ("workload", "value", "ms_per_step", "kernel_ms", "tree_decoding_rows")}), flush=True)
 PY
+cat $O/dyn.txt

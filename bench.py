@@ -471,7 +471,7 @@ def step_latency(device, base_cfg, batches=(1, 8), steps=60):
     return res
 
 
-def dynamic_run(device, base_cfg, steps, n_seq, fuse_o7=False, groups=None):
+def dynamic_run(device, base_cfg, steps, n_seq, fuse_o7=False, groups=None, spec_rows=2):
     """The dynamic-tree half of C3 (eagle_version 2: top_k 10, depth 5, 59 nodes, a different tree per sequence and step) on the
     clock: O4 -> O6 -> O7 -> O8 -> O9 + O10 through lantern_verify_step, device-resident, same KV geometry and stream groups as the
     headline run; kernel_ms: the per-kernel pass (one ctypes call per kernel, events around group 0's launches)."""
@@ -479,7 +479,7 @@ def dynamic_run(device, base_cfg, steps, n_seq, fuse_o7=False, groups=None):
     if groups is None:
         groups = base_cfg.n_groups if n_seq % max(1, base_cfg.n_groups) == 0 else 1
     cfg = HN.DynamicConfig(n_seq=n_seq, lantern_k=base_cfg.lantern_k, lantern_delta=base_cfg.lantern_delta, with_kv=base_cfg.with_kv,
-                           kv_smax=base_cfg.kv_smax, kv_pad_rows=base_cfg.kv_pad_rows, max_steps=2 * steps + 32, fuse_o7=fuse_o7, n_groups=groups)
+                           kv_smax=base_cfg.kv_smax, kv_pad_rows=base_cfg.kv_pad_rows, max_steps=2 * steps + 32, fuse_o7=fuse_o7, n_groups=groups, spec_rows=spec_rows)
     wl = HN.DynamicVerifyWorkload(cfg, device)
     for _ in range(10):
         wl.step()
@@ -504,7 +504,8 @@ def dynamic_run(device, base_cfg, steps, n_seq, fuse_o7=False, groups=None):
     cnt = wl.log_cnt[10:10 + steps].float()
     r = {"workload": f"C3 dynamic tree (EAGLE-2): top_k {cfg.top_k}, depth {cfg.depth}, N={wl.N} nodes, {n_seq} sequences in {groups} stream groups", "value": toks / dt,
          "stream_groups": groups, "sequences_per_launch": wl.Bg,
-         "tree_decoding_rows": "raw bf16 logits post-processed inside evaluate_posterior" if fuse_o7 else "cfg_mask_topk over all N rows",
+         "tree_decoding_rows": (f"raw bf16 logits post-processed inside evaluate_posterior, {wl.n_spec} rows per sequence up front beside the tree build "
+                                "(lantern_prepare_step)") if fuse_o7 else "cfg_mask_topk over all N rows",
          "unit": "accepted_tokens/s", "ms_per_step": 1e3 * dt / steps, "steps": steps, "mean_accept_length": toks / (steps * n_seq),
          "per_step": {"levels": float(cnt[..., 0].mean()), "tried": float(cnt[..., 1].mean()), "rejected": float(cnt[..., 2].mean())},
          "kernel_ms": {n: float(np.mean([e[n][0].elapsed_time(e[n][1]) for e in evs])) for n in names}}

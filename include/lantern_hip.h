@@ -282,7 +282,9 @@ typedef struct lantern_ep_window {
     int32_t raw_w_latent, raw_h_latent, raw_newline_id, raw_eos_id;
     /* optional: rows some earlier launch already post-processed (lantern_prepare_step: the nodes the walk most likely visits) */
     const float *raw_probs;       /* [dev] [B, rows_per_seq, win_len] f32 probabilities of the listed rows, or NULL */
-    const uint8_t *raw_pre;       /* [dev] [rows_per_seq]: 1 = the node's row is in raw_probs, 0 = post-process it on demand */
+    const uint8_t *raw_pre;       /* [dev] [rows_per_seq]: 0 = post-process the node's row on demand; 1 + d = it is in raw_probs, prepared for a node
+                                     at depth d (static trees: the depth is not checked, write 1; raw_pos_per_seq: used only when the
+                                     sequence's node really sits at depth d, i.e. raw_pos_ids[node] - raw_pos_ids[0] == d) */
 } lantern_ep_window;
 
 /* O8 windowed.  buf->logits is [B, rows_per_seq, win_len]; buf->sample_p may be NULL (if given, the dense
@@ -388,12 +390,14 @@ typedef struct lantern_step_group {
     const void *hidden; void *out_hidden; int64_t *accepted_tokens; int32_t hid_elem_bytes, hid_groups, H, reserved1;
     /* with ep_win.rows_kind == LANTERN_ROWS_RAW_BF16: the nodes whose rows are post-processed up front, together with the candidate
      * assembly, in ONE launch (lantern_prepare_step) -- the root and the most likely children; NULL / 0: none (all rows on demand) */
-    const int32_t *node_list; int32_t n_list, reserved2;
+    const int32_t *node_list; int32_t n_list, reserved2;   /* dynamic groups: [2 * n_list] = the nodes, then the depth each is assumed to sit at */
     const lantern_step_dynamic *dyn;      /* NULL: a static tree (ss_token / tree_indices / retrieve) */
 } lantern_step_group;
 int lantern_verify_step(const lantern_step_group *groups, int n_groups);
 /* O6 + O7 restricted to s->node_list in one launch (bf16 Lumina rows, 8192-id window): candidates -> s->tree_cand / cand / cart_prob,
- * probabilities of the listed rows -> s->out_win, their classes -> s->row_hot.  Called by lantern_verify_step when node_list is set. */
+ * probabilities of the listed rows -> s->out_win, their classes -> s->row_hot.  Called by lantern_verify_step when node_list is set.
+ * s->dyn != NULL: the tree workgroups run O4 + O6-dynamic (lantern_tree_dynamic_candidates) beside the row workgroups; the listed
+ * rows are prepared for the depth given in node_list[n_list + i] (the root; node 1 = the drafter's best first token at depth 1). */
 int lantern_prepare_step(const lantern_step_group *s);
 /* window -> dense [B,V] (API compatibility with callers that want the reference's sample_p[V]). */
 int lantern_window_to_dense(const float *win, const int32_t *out_tok, const float *out_mass, int B, int V,

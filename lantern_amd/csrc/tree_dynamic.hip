@@ -15,8 +15,7 @@ namespace lantern {
 constexpr int TD_MAX_SCORES = 2048;
 constexpr int TD_EPL = TD_MAX_SCORES / 64;  // elements per lane (blocked layout)
 
-// Four wavefronts per sequence, each computing the whole (cheap, latency-bound) tree redundantly in its own LDS slice -- no
-// cross-wave dependency -- and sharing only the work of writing the two [N,N] outputs.
+// Four wavefronts per sequence (see tree_dynamic_dev.h)
 constexpr int TD_WAVES = 4;
 #ifdef TD_TRACE
 __device__ unsigned long long g_td_trace[32];
@@ -24,246 +23,12 @@ __device__ unsigned long long g_td_trace[32];
 #else
 #define TD_STAMP(i) do { } while (0)
 #endif
-// what O6-dynamic adds when the same launch assembles the candidates (lantern_tree_dynamic_candidates); cand == NULL: finalize only
-struct TdCand {
-    const int64_t *seq_len;
-    int64_t *cand, *retrieve_pd, *pos_abs;
-    int32_t *row_index;
-    int P, D;
-};
-template <int EPL>      // score elements per lane: 8 covers the reference's 10 + 100*depth <= 512 scores, 32 the general case
-__global__ __launch_bounds__(64 * TD_WAVES) void tree_dynamic_finalize_kernel(
-    const float *__restrict__ scores_, const int64_t *__restrict__ tokens_, const int64_t *__restrict__ parents_,
-    const int64_t *__restrict__ sample_token, int n_scores, int n_parents, int top_k, int T, int sort_rows,
-    int64_t *__restrict__ draft_tokens, float *__restrict__ mask, int64_t *__restrict__ pos_ids,
-    int64_t *__restrict__ retrieve, int32_t *__restrict__ n_leaf, int32_t *__restrict__ max_depth, const TdCand cd) {
-    __shared__ long long s_tok_[TD_WAVES][64];
-    __shared__ int s_sel_[TD_WAVES][64];
-    __shared__ int s_par_[TD_WAVES][64];
-    __shared__ int s_flag_[TD_WAVES][64];
-    __shared__ signed char s_rows_[TD_WAVES][64][64];
-    __shared__ unsigned long long s_anc_[TD_WAVES][64], s_key_[TD_WAVES][64];
-    __shared__ int s_slot_[TD_WAVES][64];
-    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    int *const s_sel = s_sel_[wave], *const s_par = s_par_[wave], *const s_flag = s_flag_[wave], *const s_slot = s_slot_[wave];
-    signed char(*const s_rows)[64] = s_rows_[wave];
-    unsigned long long *const s_anc = s_anc_[wave], *const s_key = s_key_[wave];
-    const int N = T + 1;
-    const float *scores = scores_ + (size_t)b * n_scores;
-    const int64_t *tokens = tokens_ + (size_t)b * n_scores;
-    const int64_t *parents = parents_ + (size_t)b * n_parents;
-
-    TD_STAMP(0);
-    // ---- top-T by score (ties -> lower flat index), kept in ascending index order
-    const int E = (n_scores + 63) / 64;  // blocked: lane owns [lane*E, lane*E+E)
-    uint32_t key[EPL];
-#pragma unroll
-    for (int j = 0; j < EPL; ++j) {
-        const int idx = lane * E + j;
-        key[j] = (j < E && idx < n_scores) ? float_key(scores[idx]) : 0u;  // 0 < key of any float
-    }
-    TD_STAMP(1);
-    // threshold key = T-th largest: bitwise search, wave-wide counts on the scalar unit (one compare + one s_bcnt1 per element
-    // slot, no cross-lane chain).  Only wave 0 searches -- four waves doing it at once queue up on the CU's scalar unit -- and
-    // hands the result over through LDS (measured the same either way: ~400 cycles per bit, 13 k cycles of the kernel's 36 k).
-    __shared__ uint32_t s_prefix;
-    if (wave == 0) {
-        uint32_t pf = 0;
-        for (int bit = 31; bit >= 0; --bit) {
-            const uint32_t trial = pf | (1u << bit);
-            int c = 0;
-#pragma unroll
-            for (int j = 0; j < EPL; ++j) c += __popcll(__ballot((j < E) && key[j] >= trial));
-            if (c >= T) pf = trial;
-        }
-        if (lane == 0) s_prefix = pf;
-    }
-    __syncthreads();
-    const uint32_t prefix = s_prefix;
-    TD_STAMP(2);
-    int c_gt = 0, c_eq = 0;
-#pragma unroll
-    for (int j = 0; j < EPL; ++j) {
-        c_gt += (j < E) && key[j] > prefix;
-        c_eq += (j < E) && key[j] == prefix;
-    }
-    const int need_eq = T - wave_sum(c_gt);  // how many threshold-valued entries to take
-    // exclusive lane prefixes
-    int inc_eq = c_eq;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const int t = __shfl_up(inc_eq, o, 64);
-        if (lane >= o) inc_eq += t;
-    }
-    int eq_before = inc_eq - c_eq;
-    int c_sel = 0;
-    uint32_t selbits = 0;  // which of my elements are selected
-#pragma unroll
-    for (int j = 0; j < EPL; ++j) {
-        if (j >= E) continue;
-        bool s = key[j] > prefix;
-        if (key[j] == prefix) {
-            s = eq_before < need_eq;
-            ++eq_before;
-        }
-        if (s) {
-            selbits |= 1u << j;
-            ++c_sel;
-        }
-    }
-    int inc_sel = c_sel;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const int t = __shfl_up(inc_sel, o, 64);
-        if (lane >= o) inc_sel += t;
-    }
-    int pos = inc_sel - c_sel;
-#pragma unroll
-    for (int j = 0; j < EPL; ++j)
-        if (j < E && (selbits >> j) & 1u) s_sel[pos++] = lane * E + j;
-    __syncthreads();
-
-    TD_STAMP(3);
-    // ---- node = lane (0 = root); parent via searchsorted over the selected flat indices
-    int par = 0;
-    long long tok_l = -1;
-    if (lane == 0) {
-        tok_l = sample_token[b];
-        if (wave == 0) draft_tokens[(size_t)b * N] = tok_l;
-    } else if (lane < N) {
-        const int flat = s_sel[lane - 1];
-        tok_l = tokens[flat];
-        if (wave == 0) draft_tokens[(size_t)b * N + lane] = tok_l;
-        const int64_t dp = parents[flat / top_k];
-        if (dp != 0) {
-            const int64_t keyv = dp - 1;
-            int lo_ = 0, hi_ = T;                  // searchsorted(left) over the ascending selected indices
-            while (lo_ < hi_) {
-                const int mid = (lo_ + hi_) >> 1;
-                if (s_sel[mid] < keyv) lo_ = mid + 1;
-                else hi_ = mid;
-            }
-            par = lo_ + 1;
-        }
-    }
-    TD_STAMP(4);
-    s_par[lane] = par;
-    s_flag[lane] = 0;
-    s_tok_[wave][lane] = tok_l;
-    __syncthreads();
-    if (lane >= 1 && lane < N) s_flag[par] = 1;  // non-leaf marks
-    // ancestor set: walk the parent pointers
-    unsigned long long anc = 1ull;
-    if (lane < N) {
-        int cur = lane;
-        for (int guard = 0; cur > 0 && guard < 64; ++guard) {
-            anc |= 1ull << cur;
-            cur = s_par[cur];
-        }
-    }
-    const int depth = lane < N ? __popcll(anc) - 1 : 0;
-    int md = depth;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) md = max(md, __shfl_xor(md, o, 64));
-    TD_STAMP(5);
-    const int MD = md + 1;
-    s_anc[lane] = lane < N ? anc : 0ull;
-    __syncthreads();
-    if (lane < N && wave == 0) pos_ids[(size_t)b * N + lane] = depth;
-    {   // mask [N,N]: lanes run along the row-major output (coalesced 256-byte stores), bits from the ancestor words in LDS
-        float *mb = mask + (size_t)b * N * N;
-        const int dq = (64 * TD_WAVES) / N, dr = (64 * TD_WAVES) - dq * N;       // index step in (row, column) form
-        int r = tid / N, c = tid - r * N;          // one division, then (r, c) advance with the index
-        for (int idx = tid; idx < N * N; idx += 64 * TD_WAVES) {
-            mb[idx] = (float)((s_anc[r] >> c) & 1ull);
-            r += dq, c += dr;
-            if (c >= N) c -= N, ++r;
-        }
-    }
-    TD_STAMP(6);
-    // ---- leaves -> rows
-    const bool leaf = lane < N && !s_flag[lane];
-    const unsigned long long leafmask = __ballot(leaf);
-    const int nl = __popcll(leafmask);
-    const int rid = __popcll(leafmask & ((1ull << lane) - 1ull));
-    if (leaf) {
-        for (int j = 0; j < 64; ++j) s_rows[rid][j] = -1;
-        int cur = lane;
-        for (int j = depth; j >= 0; --j) {
-            s_rows[rid][j] = (signed char)cur;
-            cur = cur > 0 ? s_par[cur] : 0;
-        }
-    }
-    __syncthreads();
-    TD_STAMP(7);
-    int out_row = rid;
-    if (sort_rows) {
-        // rank among rows, key = entries with -1 -> T+5 (always larger than any node id).  Up to 8 columns the row is one
-        // 64-bit big-endian key (one byte per column): 58 independent broadcast LDS reads instead of a compare loop per pair
-        if (MD <= 8) {
-            unsigned long long k64 = 0ull;
-            if (leaf)
-                for (int j = 0; j < 8; ++j) {
-                    const int e = (j < MD && s_rows[rid][j] >= 0) ? s_rows[rid][j] : T + 5;
-                    k64 = (k64 << 8) | (unsigned long long)(e & 255);
-                }
-            if (leaf) s_key[rid] = k64;
-            __syncthreads();
-            if (leaf) {
-                int rank = 0;
-                for (int o = 0; o < nl; ++o) {
-                    const unsigned long long ko = s_key[o];
-                    rank += (ko < k64) || (ko == k64 && o < rid);
-                }
-                out_row = rank;
-            }
-        } else if (leaf) {
-            int rank = 0;
-            for (int o = 0; o < nl; ++o) {
-                if (o == rid) continue;
-                int cmp = 0;
-                for (int j = 0; j < MD && cmp == 0; ++j) {
-                    const int a = s_rows[o][j] < 0 ? T + 5 : s_rows[o][j];
-                    const int c = s_rows[rid][j] < 0 ? T + 5 : s_rows[rid][j];
-                    cmp = (a < c) ? -1 : (a > c ? 1 : 0);
-                }
-                rank += (cmp < 0) || (cmp == 0 && o < rid);
-            }
-            out_row = rank;
-        }
-    }
-    TD_STAMP(8);
-    if (leaf) s_slot[out_row] = rid;           // output row -> staged row
-    __syncthreads();
-    {   // retrieve [N,N] i64, -1 padded: coalesced 512-byte stores
-        int64_t *rbase = retrieve + (size_t)b * N * N;
-        const int dq = (64 * TD_WAVES) / N, dr = (64 * TD_WAVES) - dq * N;
-        int r = tid / N, c = tid - r * N;
-        for (int idx = tid; idx < N * N; idx += 64 * TD_WAVES) {
-            rbase[idx] = (r < nl && c < MD) ? (int64_t)s_rows[s_slot[r]][c] : -1;
-            r += dq, c += dr;
-            if (c >= N) c -= N, ++r;
-        }
-    }
-    TD_STAMP(9);
-    if (tid == 0) {
-        n_leaf[b] = nl;
-        max_depth[b] = MD;
-    }
-    // ---- O6, dynamic (ea_model_llamagen.py:676-706 with this tree; gather_candidates_dynamic_kernel's arithmetic): the candidates by
-    // (path, depth), the compact retrieve rows, the row map (a -1 wraps to the last node's row) and every node's absolute position
-    if (cd.cand) {
-        const int PD = cd.P * cd.D;
-        for (int i = tid; i < PD; i += 64 * TD_WAVES) {
-            const int p = i / cd.D, d = i - p * cd.D;
-            const int r = (p < nl && d < MD) ? (int)s_rows[s_slot[p]][d] : -1;
-            const bool ok = r >= 0 && r < N;
-            cd.cand[(size_t)b * PD + i] = ok ? (int64_t)s_tok_[wave][r] : -1;
-            if (cd.retrieve_pd) cd.retrieve_pd[(size_t)b * PD + i] = ok ? r : -1;
-            if (cd.row_index) cd.row_index[(size_t)b * PD + i] = ok ? r : N - 1;
-        }
-        if (cd.pos_abs && lane < N && wave == 0) cd.pos_abs[(size_t)b * N + lane] = (int64_t)depth + (cd.seq_len ? cd.seq_len[b] + 1 : 0);
-    }
+}  // namespace lantern
+#include "tree_dynamic_dev.h"
+namespace lantern {
+template <int EPL>
+__global__ __launch_bounds__(64 * TD_WAVES) void tree_dynamic_finalize_kernel(const TdArgs ta) {
+    td_finalize_body<EPL, TD_WAVES>(ta, blockIdx.x);
 }
 
 // ----------------------------------------------------------------------------- O3
@@ -589,14 +354,10 @@ static int td_launch(const float *scores, const int64_t *tokens, const int64_t *
     LANTERN_CHECK_ARG(n_scores >= total_tokens && n_scores <= TD_MAX_SCORES, "tree_dynamic_finalize: n_scores=%d out of range", n_scores);
     LANTERN_CHECK_ARG(n_parents * top_k >= n_scores, "tree_dynamic_finalize: n_parents=%d too small for n_scores=%d", n_parents, n_scores);
     if (B == 0) return LANTERN_OK;
-    if (n_scores <= 8 * 64)
-        hipLaunchKernelGGL(tree_dynamic_finalize_kernel<8>, dim3(B), dim3(64 * TD_WAVES), 0, (hipStream_t)stream, scores, tokens, parents,
-                           sample_token, n_scores, n_parents, top_k, total_tokens, sort_rows, draft_tokens, mask, pos_ids, retrieve, n_leaf,
-                           max_depth, cd);
-    else
-        hipLaunchKernelGGL(tree_dynamic_finalize_kernel<TD_EPL>, dim3(B), dim3(64 * TD_WAVES), 0, (hipStream_t)stream, scores, tokens, parents,
-                           sample_token, n_scores, n_parents, top_k, total_tokens, sort_rows, draft_tokens, mask, pos_ids, retrieve, n_leaf,
-                           max_depth, cd);
+    const TdArgs ta{scores, tokens, parents, sample_token, n_scores, n_parents, top_k, total_tokens, sort_rows, draft_tokens, mask, pos_ids, retrieve,
+                    n_leaf, max_depth, cd};
+    if (n_scores <= 8 * 64) hipLaunchKernelGGL(tree_dynamic_finalize_kernel<8>, dim3(B), dim3(64 * TD_WAVES), 0, (hipStream_t)stream, ta);
+    else hipLaunchKernelGGL(tree_dynamic_finalize_kernel<TD_EPL>, dim3(B), dim3(64 * TD_WAVES), 0, (hipStream_t)stream, ta);
     LANTERN_CHECK_LAUNCH("tree_dynamic_finalize");
     return LANTERN_OK;
 }

@@ -31,7 +31,10 @@ extern "C" int lantern_verify_step(const lantern_step_group *groups, int n_group
     int rc;
     for (int g = 0; g < n_groups; ++g) {
         const lantern_step_group &s = groups[g];
-        if (s.dyn) {                                // EAGLE-2: every sequence's own tree out of this step's drafter scores
+        if (s.dyn && s.node_list && s.n_list > 0) { // EAGLE-2 tree + candidates + the likely rows in one launch
+            rc = lantern_prepare_step(&s);
+            if (rc) return fail(g, "prepare_step", rc);
+        } else if (s.dyn) {                         // EAGLE-2: every sequence's own tree out of this step's drafter scores
             const lantern_step_dynamic &d = *s.dyn;
             rc = lantern_tree_dynamic_candidates(d.scores, d.tokens, d.parents, s.sample_token, s.B, d.n_scores, d.n_parents, d.top_k,
                                                  d.total_tokens, d.sort_rows, d.draft_tokens, d.mask, d.pos_ids, d.retrieve, d.n_leaf,
@@ -48,7 +51,7 @@ extern "C" int lantern_verify_step(const lantern_step_group *groups, int n_group
     }
     for (int g = 0; g < n_groups; ++g) {
         const lantern_step_group &s = groups[g];
-        if (!s.out_win || (!s.dyn && s.node_list && s.n_list > 0)) continue;          // LANTERN_ROWS_RAW_BF16: evaluate_posterior post-processes the rows it visits itself
+        if (!s.out_win || (s.node_list && s.n_list > 0)) continue;          // LANTERN_ROWS_RAW_BF16: evaluate_posterior post-processes the rows it visits itself
         rc = lantern_cfg_mask_topk_window(s.cond, s.uncond, s.dtype, s.B * s.N, s.V, s.cfg, s.model, s.pos_ids, s.pos_base, s.w_latent,
                                           s.h_latent, s.img_lo, s.img_hi, s.newline_id, s.eos_id, s.top_k, s.seq_len, s.N, s.win_lo,
                                           s.win_len, s.out_win, s.row_hot, s.out_kind, s.temperature, s.top_p, s.stream);

@@ -55,6 +55,7 @@ __shared__ int s_epw_trn;
 }  // namespace lantern
 
 #include "window_dev.h"
+#include "tree_dynamic_dev.h"
 
 namespace lantern {
 
@@ -364,6 +365,43 @@ __global__ __launch_bounds__(NT) void prep_rows_kernel(const PrepArgs a) {
     }
 }
 
+// The same for a group of DYNAMIC trees (lantern_step_group.dyn): workgroups [0, B * n_list) post-process the listed rows -- a listed node's
+// position is assumed (node_list[n_list + i] = its depth: the root, and node 1 = the drafter's best first token, always at depth 1 in an
+// EAGLE-2 tree), so the rows do not wait for the tree -- while workgroups [B * n_list, B * n_list + B) build the sequence's tree and its
+// candidates (O4 + O6-dynamic, tree_dynamic_dev.h).  evaluate_posterior uses a prepared row only when the node really sits at that depth.
+struct DynPrepArgs {
+    const uint16_t *cond, *uncond;
+    int V;
+    float cfg;
+    int64_t pos_base;
+    int w_latent, h_latent, img_lo, img_hi, newline_id, eos_id, top_k;
+    int rows_per_seq, win_lo, W;
+    float *out_win;
+    int32_t *row_hot;
+    const int32_t *node_list;
+    int n_list, B;
+    TdArgs td;
+};
+
+template <int NT, int E8>
+__global__ __launch_bounds__(NT) void dyn_prep_kernel(const DynPrepArgs a) {
+    const int n_rows = a.B * a.n_list;
+    if ((int)blockIdx.x < n_rows) {
+        __shared__ alignas(16) int s_hist[O7_HIST_INTS];
+        __shared__ float s_redf[32];
+        __shared__ double s_redd[32];
+        const int x = o7_row_of_block(blockIdx.x, n_rows, a.n_list);
+        const int b = x / a.n_list, i = x % a.n_list;
+        const int node = a.node_list[i], depth = a.node_list[a.n_list + i];
+        const int row = b * a.rows_per_seq + node;
+        const int cls = lumina_row_class(a.td.cd.seq_len[b] + 1 + depth, a.pos_base, a.w_latent, a.h_latent);      // = pos_abs of a node at that depth
+        cfg_window_bf16_row<NT, E8, true>(row, cls, a.cond, a.uncond, a.V, a.cfg, LANTERN_MODEL_LUMINA, a.img_lo, a.img_hi, a.newline_id, a.eos_id,
+                                          a.top_k, a.win_lo, a.W, a.out_win, a.row_hot, LANTERN_ROWS_PROBS, s_hist, s_redf, s_redd);
+        return;
+    }
+    td_finalize_body<8, NT / 64>(a.td, blockIdx.x - n_rows);
+}
+
 // ------------------------------------------------------------------------------- O8 windowed
 //
 // Structure (v3).  A 512-thread workgroup owns one sequence.  The serial part of the algorithm -- walking the
@@ -524,7 +562,15 @@ __device__ __forceinline__ int epw_body(const EpwArgs &args, const int b) {
             const int t = tid + u * NT;
             tc_[u] = (is_static && t < prm.N && t < EW_MAX_N) ? (int)buf.tree_cand[(size_t)b * prm.N + t] : 0;
             hot_[u] = (hot_g && hot_in_lds && t < prm.rows_per_seq) ? hot_g[t] : -1;
-            if (RAW && t < prm.rows_per_seq) S.pre[t] = (win.raw_pre && win.raw_probs) ? (int)win.raw_pre[t] : 0;
+            if (RAW && t < prm.rows_per_seq) {
+                // raw_pre[t] = 1 + the depth the row was prepared for; with per-sequence trees the node has to sit there (its position says so)
+                int pre = (win.raw_pre && win.raw_probs) ? (int)win.raw_pre[t] : 0;
+                if (pre && win.raw_pos_per_seq) {
+                    const int64_t *pp = win.raw_pos_ids + (size_t)b * prm.rows_per_seq;
+                    if (pp[t] - pp[0] != pre - 1) pre = 0;
+                }
+                S.pre[t] = pre;
+            }
             if (RAW && t < prm.rows_per_seq) {          // the row's class from its position (MultiModalLogitsProcessor, ea_model_lumina_mgpt.py:45-86)
                 const int64_t n1 = (win.raw_pos_per_seq ? win.raw_pos_ids[(size_t)b * prm.rows_per_seq + t] : win.raw_pos_ids[t] + win.raw_seq_len[b]) - win.raw_pos_base + 1;
                 hot_[u] = (n1 == ((int64_t)win.raw_w_latent + 1) * win.raw_h_latent + 1) ? win.raw_eos_id
@@ -1310,12 +1356,31 @@ extern "C" int lantern_cfg_mask_topk_window(const void *cond, const void *uncond
     return LANTERN_OK;
 }
 
+static int prepare_step_dynamic(const lantern_step_group *g) {
+    const lantern_step_dynamic &d = *g->dyn;
+    const int N = d.total_tokens + 1;
+    LANTERN_CHECK_ARG(d.scores && d.tokens && d.parents && g->sample_token && d.draft_tokens && d.mask && d.pos_ids && d.retrieve && d.n_leaf && d.max_depth &&
+                          d.seq_len && g->cand, "prepare_step: dynamic-tree buffers missing");
+    LANTERN_CHECK_ARG(d.top_k > 0 && d.total_tokens >= 1 && d.total_tokens <= 63 && d.n_scores >= d.total_tokens && d.n_scores <= 512 &&
+                          d.n_parents * d.top_k >= d.n_scores && g->N == N && g->P > 0 && g->P <= N && g->D > 0 && g->D <= N,
+                      "prepare_step: dynamic tree sizes (n_scores <= 512, total_tokens <= 63, P, D <= N = total_tokens + 1)");
+    if (g->B == 0) return LANTERN_OK;
+    DynPrepArgs a{(const uint16_t *)g->cond, (const uint16_t *)g->uncond, g->V, g->cfg, g->pos_base, g->w_latent, g->h_latent, g->img_lo, g->img_hi,
+                  g->newline_id, g->eos_id, g->top_k, g->N, g->win_lo, g->win_len, g->out_win, g->row_hot, g->node_list, g->n_list, g->B,
+                  TdArgs{d.scores, d.tokens, d.parents, g->sample_token, d.n_scores, d.n_parents, d.top_k, d.total_tokens, d.sort_rows, d.draft_tokens, d.mask,
+                         d.pos_ids, d.retrieve, d.n_leaf, d.max_depth, TdCand{d.seq_len, g->cand, d.retrieve_pd, d.pos_abs, d.row_index, g->P, g->D}}};
+    LANTERN_LAUNCH((dyn_prep_kernel<512, 2>), dim3(g->B * g->n_list + g->B), dim3(512), 0, (hipStream_t)g->stream, a);
+    LANTERN_CHECK_LAUNCH("prepare_step");
+    return LANTERN_OK;
+}
+
 extern "C" int lantern_prepare_step(const lantern_step_group *g) {
     LANTERN_CHECK_ARG(g && g->node_list && g->n_list > 0 && g->n_list <= g->N, "prepare_step: needs a node list");
-    LANTERN_CHECK_ARG(g->cond && g->uncond && g->out_win && g->row_hot && g->seq_len && g->pos_ids && g->dtype == LANTERN_BF16 && g->model == LANTERN_MODEL_LUMINA &&
+    LANTERN_CHECK_ARG(g->cond && g->uncond && g->out_win && g->row_hot && (g->dyn || (g->seq_len && g->pos_ids)) && g->dtype == LANTERN_BF16 && g->model == LANTERN_MODEL_LUMINA &&
                           g->win_len == 8192 && g->win_lo == g->img_lo && g->win_lo + g->win_len == g->img_hi && g->win_lo % 4 == 0 && g->V % 8 == 0 &&
                           g->out_kind == LANTERN_ROWS_PROBS && g->temperature == 1.0f && !(g->top_p > 0.0f && g->top_p < 1.0f),
                       "prepare_step: bf16 Lumina rows on the 8192-id image window, probability output");
+    if (g->dyn) return prepare_step_dynamic(g);
     LANTERN_CHECK_ARG(g->ss_token && g->sample_token && g->tree_indices && g->retrieve && g->tree_cand && g->cand && g->B >= 0 && g->n_flat > 0 && g->N > 0 &&
                           g->P > 0 && g->D > 0, "prepare_step: candidate-assembly buffers missing");
     if (g->B == 0) return LANTERN_OK;

@@ -851,6 +851,8 @@ class DynamicConfig:
     plausible: float = 8.0          # drafted tokens get target logits in [plausible - 2, plausible]: the walk accepts a few levels
     fuse_o7: bool = False           # LANTERN_ROWS_RAW_BF16 with per-sequence positions: no O7 launch over all N rows, evaluate_posterior
                                     # post-processes the rows its walk visits (alen + 1 of the 59)
+    spec_rows: int = 2              # with fuse_o7: rows post-processed up front beside the tree build (lantern_prepare_step): 1 = the root, 2 = + node 1
+                                    # (the drafter's best first token, at depth 1 in every EAGLE-2 tree); 0 = every row on demand
     n_groups: int = 1               # >1: stream groups, as in WorkloadConfig (n_seq must divide)
     native_step: bool = True        # the whole step of all groups through ONE C call (lantern_verify_step with lantern_step_dynamic blocks);
                                     # False: one ctypes call per kernel and group
@@ -988,6 +990,15 @@ class DynamicVerifyWorkload:
             w.raw_pos_ids, w.raw_seq_len, w.raw_pos_base = self.pos_abs.data_ptr(), None, cfg.prompt_len + 3
             w.raw_cfg, w.raw_top_k = cfg.cfg_scale, cfg.logit_top_k
             w.raw_w_latent, w.raw_h_latent, w.raw_newline_id, w.raw_eos_id = W_LATENT, H_LATENT, NEWLINE, EOS
+        self.n_spec = max(0, min(int(cfg.spec_rows), 2)) if self.fused_o7 else 0
+        if self.n_spec:
+            nodes = list(range(self.n_spec))
+            self.d_node_list = torch.tensor(nodes + nodes, dtype=torch.int32, device=device)       # node ids, then the depth each is prepared for
+            pre = torch.zeros(N, dtype=torch.uint8)
+            for n in nodes:
+                pre[n] = 1 + n
+            self.d_pre = pre.to(device)
+            w.raw_pre = self.d_pre.data_ptr()
         self._win = w
         self._bases = dict(best=self.log_best.data_ptr(), alen=self.log_alen.data_ptr(), cnt=self.log_cnt.data_ptr(),
                            tok=self.log_token.data_ptr(), ub=self.u_bonus.data_ptr())
@@ -1031,6 +1042,9 @@ class DynamicVerifyWorkload:
             w.row_hot, w.out_tok, w.out_mass = vp(self.hot, s0), vp(self.out_tok, s0), vp(self.out_mass, s0)
             if self.fused_o7:
                 w.raw_uncond, w.raw_pos_ids = vp(pool["unc"], s0), vp(self.pos_abs, s0)
+            if self.n_spec:
+                s.node_list, s.n_list, s.out_win = self.d_node_list.data_ptr(), self.n_spec, vp(self.win, s0)
+                w.raw_probs = vp(self.win, s0)
             if c.with_kv:
                 s.slab_ptrs, s.slab_seq = vp(self.slab_ptrs, 2 * s0), vp(self.slab_seq, 2 * s0)
                 s.slab_prev, s.new_len = vp(cur, 2 * s0), vp(nxt, 2 * s0)
@@ -1108,16 +1122,19 @@ class DynamicVerifyWorkload:
         L, vp, d = self._L, C.c_void_p, s.dyn.contents
         st = vp(s.stream)
         arm = lambda name: events and check(L.lantern_profile_next_launch(vp(events[name][0].cuda_event), vp(events[name][1].cuda_event)), "profile")
-        check(L.lantern_tree_dynamic_finalize(vp(d.scores), vp(d.tokens), vp(d.parents), vp(s.sample_token), s.B, d.n_scores, d.n_parents, d.top_k,
-                                              d.total_tokens, d.sort_rows, vp(d.draft_tokens), vp(d.mask), vp(d.pos_ids), vp(d.retrieve), vp(d.n_leaf),
-                                              vp(d.max_depth), st), "tree_dynamic_finalize")
-        check(L.lantern_gather_candidates_dynamic(vp(d.draft_tokens), vp(d.retrieve), vp(d.pos_ids), vp(d.seq_len), s.B, s.N, s.P, s.D, vp(s.cand),
-                                                  vp(d.retrieve_pd), vp(d.row_index), vp(d.pos_abs), st), "gather_candidates_dynamic")
-        if s.out_win:
-            arm("cfg_mask_topk")
-            check(L.lantern_cfg_mask_topk_window(vp(s.cond), vp(s.uncond), s.dtype, s.B * s.N, s.V, C.c_float(s.cfg), s.model, vp(s.pos_ids), C.c_int64(s.pos_base),
-                                                 s.w_latent, s.h_latent, s.img_lo, s.img_hi, s.newline_id, s.eos_id, s.top_k, None, 0, s.win_lo, s.win_len,
-                                                 vp(s.out_win), vp(s.row_hot), s.out_kind, C.c_float(s.temperature), C.c_float(s.top_p), st), "cfg_mask_topk_window")
+        if s.n_list > 0:          # tree + candidates + the likely rows in one launch
+            check(L.lantern_prepare_step(C.byref(s)), "prepare_step")
+        else:
+            check(L.lantern_tree_dynamic_finalize(vp(d.scores), vp(d.tokens), vp(d.parents), vp(s.sample_token), s.B, d.n_scores, d.n_parents, d.top_k,
+                                                  d.total_tokens, d.sort_rows, vp(d.draft_tokens), vp(d.mask), vp(d.pos_ids), vp(d.retrieve), vp(d.n_leaf),
+                                                  vp(d.max_depth), st), "tree_dynamic_finalize")
+            check(L.lantern_gather_candidates_dynamic(vp(d.draft_tokens), vp(d.retrieve), vp(d.pos_ids), vp(d.seq_len), s.B, s.N, s.P, s.D, vp(s.cand),
+                                                      vp(d.retrieve_pd), vp(d.row_index), vp(d.pos_abs), st), "gather_candidates_dynamic")
+            if s.out_win:
+                arm("cfg_mask_topk")
+                check(L.lantern_cfg_mask_topk_window(vp(s.cond), vp(s.uncond), s.dtype, s.B * s.N, s.V, C.c_float(s.cfg), s.model, vp(s.pos_ids), C.c_int64(s.pos_base),
+                                                     s.w_latent, s.h_latent, s.img_lo, s.img_hi, s.newline_id, s.eos_id, s.top_k, None, 0, s.win_lo, s.win_len,
+                                                     vp(s.out_win), vp(s.row_hot), s.out_kind, C.c_float(s.temperature), C.c_float(s.top_p), st), "cfg_mask_topk_window")
         arm("evaluate_posterior")
         check(L.lantern_evaluate_posterior_window(C.byref(s.ep), C.byref(s.ep_buf), C.byref(s.ep_win), st), "evaluate_posterior_window")
         if s.slab_ptrs:

@@ -62,9 +62,11 @@ def test_kv_rows_follow_the_accepted_path():
         assert torch.equal(s[..., keep.cuda(), :], b0[..., keep.cuda(), :])
 
 
-@pytest.mark.parametrize("fuse,groups,native", [(False, 1, True), (True, 1, True), (False, 3, True), (True, 2, True), (False, 2, False)],
-                         ids=["o7_launch", "raw_rows", "o7_launch_3_groups", "raw_rows_2_groups", "per_kernel_calls_2_groups"])
-def test_dynamic_tree_loop_matches_oracle_loop(fuse, groups, native):
+@pytest.mark.parametrize("fuse,groups,native,spec", [(False, 1, True, 0), (True, 1, True, 0), (True, 1, True, 2), (False, 3, True, 0), (True, 2, True, 1),
+                                                     (True, 3, True, 2), (False, 2, False, 0), (True, 2, False, 2)],
+                         ids=["o7_launch", "raw_rows", "raw_rows_2_prepared", "o7_launch_3_groups", "raw_rows_2_groups_root_prepared",
+                              "raw_rows_3_groups_2_prepared", "per_kernel_calls_2_groups", "per_kernel_calls_raw_rows_2_prepared"])
+def test_dynamic_tree_loop_matches_oracle_loop(fuse, groups, native, spec):
     """The device-resident EAGLE-2 loop (O4 -> O6 dynamic -> O7 -> O8 dynamic -> O9 + O10, a different tree per sequence and
     step) against the oracle's loop over the same pools / uniforms: identical (best path, accept length, bonus token), every
     step, every sequence; KV lengths advance by exactly the accepted tokens."""
@@ -75,9 +77,9 @@ def test_dynamic_tree_loop_matches_oracle_loop(fuse, groups, native):
     import helpers as H
     steps = 8
     cfg = HN.DynamicConfig(n_seq=3 * groups, pool_steps=2, kv_layers=2, kv_heads=4, kv_smax=512, max_steps=steps + 2, lantern_k=300, fuse_o7=fuse,
-                           n_groups=groups, native_step=native)
+                           n_groups=groups, native_step=native, spec_rows=spec)
     wl = HN.DynamicVerifyWorkload(cfg, torch.device("cuda"))
-    assert wl.fused_o7 == fuse and wl.G == groups
+    assert wl.fused_o7 == fuse and wl.G == groups and wl.n_spec == (spec if fuse else 0)
     for _ in range(steps):
         wl.step()
     wl.sync()
@@ -116,8 +118,8 @@ def test_dynamic_tree_loop_matches_oracle_loop(fuse, groups, native):
         assert int(acc[b, int(ga[last, b])]) >= 0 and (acc[b, int(ga[last, b]) + 1:] == -1).all()
 
 
-@pytest.mark.parametrize("fuse", [False, True], ids=["o7_launch", "raw_rows"])
-def test_dynamic_step_one_call_equals_per_kernel_calls(fuse):
+@pytest.mark.parametrize("fuse,spec", [(False, 0), (True, 0), (True, 2)], ids=["o7_launch", "raw_rows", "raw_rows_2_prepared"])
+def test_dynamic_step_one_call_equals_per_kernel_calls(fuse, spec):
     """lantern_verify_step with dynamic groups (O4 + O6-dynamic in one launch, lantern_tree_dynamic_candidates) against the same step as
     one call per entry point (lantern_tree_dynamic_finalize, then lantern_gather_candidates_dynamic, ...): every tree buffer, candidate
     table, verdict, length, KV slab and accepted row identical after every step."""
@@ -125,8 +127,9 @@ def test_dynamic_step_one_call_equals_per_kernel_calls(fuse):
     steps = 6
     wls = []
     for native, groups in ((True, 2), (False, 1)):
+        # (the per-kernel run keeps every row on demand: prepared rows must not change a bit)
         cfg = HN.DynamicConfig(n_seq=4, pool_steps=2, kv_layers=2, kv_heads=4, kv_smax=512, max_steps=steps + 2, lantern_k=300, fuse_o7=fuse,
-                               n_groups=groups, native_step=native)
+                               n_groups=groups, native_step=native, spec_rows=spec if native else 0)
         wls.append(HN.DynamicVerifyWorkload(cfg, torch.device("cuda")))
     for wl in wls:              # the same random rows in every sequence's slabs, whatever the slab order
         for g in range(wl.G):

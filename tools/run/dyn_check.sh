@@ -12,9 +12,8 @@ import bench
 from lantern_amd import harness as HN
 dev = torch.device("cuda")
 base = HN.WorkloadConfig(n_seq=63, n_groups=3)
-for fuse in (True, False):
-    for g in (1, 3):
-        r = bench.dynamic_run(dev, base, 200, 63, fuse_o7=fuse, groups=g)
+for fuse, g, spec in ((True, 3, 2), (True, 3, 1), (True, 3, 0), (True, 1, 2), (False, 3, 0)):
+        r = bench.dynamic_run(dev, base, 200, 63, fuse_o7=fuse, groups=g, spec_rows=spec)
         print(json.dumps({k: r[k] for k in ("workload", "value", "ms_per_step", "kernel_ms", "tree_decoding_rows")}), flush=True)
 PY
 cat $O/dyn.txt

@@ -98,7 +98,6 @@ class EaModel(_LlamaGenEaModel):
                  top_k: Optional[int] = None, top_p: Optional[float] = None, cfg: Optional[float] = None,
                  lantern: Optional[bool] = None, lantern_k: Optional[int] = None, lantern_delta: Optional[float] = None,
                  static_tree: Optional[bool] = None, tree_choices: Optional[List[List[int]]] = naive_extend_57, **model_kwargs):
-        accept_length_list = []
         dev = self.base_model.lm_head.weight.device
         cond_tokens, max_input_length = pad_nested_list_left([[BOS_ID] + row + [SEP_ID, BOI_ID] for row in self._prompt_tokens(prompt)])
         uncond_tokens = [[PAD_ID] * (max_input_length - 2) + [BOS_ID, BOI_ID] for _ in cond_tokens]
@@ -109,7 +108,6 @@ class EaModel(_LlamaGenEaModel):
         input_position_ids[:n_rows] = torch.arange(max_input_length, device=dev)
         input_position_ids[n_rows:, -1] = 1              # uncond row: <pad>.. <bos>@0 <boi>@1
         input_position_diff = max_input_length - 2
-        padding = torch.full((1, 1), -1, dtype=torch.long, device=dev)
         self.ea_layer.reset_kv()
         logits_processor = prepare_logits_processor(temperature=temperature, top_k=top_k, top_p=top_p) if temperature > 1e-5 else None
         self._active_proc = ProcessorSpec.from_hf(logits_processor)
@@ -134,45 +132,14 @@ class EaModel(_LlamaGenEaModel):
         else:
             draft_tokens, retrieve_indices, tree_mask, tree_position_ids, logits, hidden_state, sample_token = self.initialize_tree(
                 input_tokens, past_key_values, logits_processor, cfg, input_mask, input_position_ids)
-        input_ids = input_tokens[:1]
-        new_token = 0
-        self._uniforms().begin()          # this prompt's acceptance uniforms start at random's current position
-        try:
-            for idx in range(max_length):
-                if static_tree:
-                    candidates, cart_candidates_prob, tree_candidates = self.generate_candidates(
-                        tree_logits, tree_buffers["tree_indices"], tree_buffers["retrieve_indices"], sample_token, logits_processor)
-                    tree_candidates = torch.cat([tree_candidates, tree_candidates])
-                    logits, hidden_state_new, outputs = self.tree_decoding(tree_candidates, past_key_values, tree_buffers["tree_position_ids"],
-                                                                           input_ids, tree_buffers["retrieve_indices_head"], cfg, input_mask,
-                                                                           input_position_diff)
-                    best_candidate, accept_length, sample_p = self.evaluate_posterior_v1(
-                        logits, candidates, logits_processor, cart_candidates_prob, tree_logits[2], tree_buffers["p_indices"],
-                        tree_candidates, tree_buffers["b_indices"], lantern, lantern_k, lantern_delta)
-                    input_ids, tree_logits, new_token, hidden_state, sample_token = self.update_inference_inputs(
-                        input_ids, candidates, best_candidate, accept_length, tree_buffers["retrieve_indices_head"], logits_processor,
-                        new_token, past_key_values_data, current_length_data, hidden_state_new, sample_p, cfg, input_position_diff,
-                        attention_mask=input_mask, static_tree=True)
-                else:
-                    self.base_model.model.tree_mask = tree_mask
-                    tree_draft_tokens = torch.cat([draft_tokens, draft_tokens])
-                    logits, hidden_state_new, outputs = self.tree_decoding(tree_draft_tokens, past_key_values, tree_position_ids, input_ids,
-                                                                           retrieve_indices, cfg, input_mask, input_position_diff)
-                    draft_tokens = torch.cat((draft_tokens, padding), dim=1)
-                    candidates = draft_tokens[0, retrieve_indices]
-                    best_candidate, accept_length, sample_p = self.evaluate_posterior(logits, candidates, logits_processor, lantern=lantern,
-                                                                                      lantern_k=lantern_k, lantern_delta=lantern_delta)
-                    (input_ids, draft_tokens, retrieve_indices, tree_mask, tree_position_ids, new_token, hidden_state,
-                     sample_token) = self.update_inference_inputs(input_ids, candidates, best_candidate, accept_length, retrieve_indices,
-                                                                  logits_processor, new_token, past_key_values_data, current_length_data,
-                                                                  hidden_state_new, sample_p, cfg, input_position_diff,
-                                                                  attention_mask=input_mask)
-                accept_length_list.append(int(accept_length) + 1)
-                if new_token > max_length:
-                    break
-        finally:
-            self._uniforms().end()        # unconsumed staged draws go back to the module-level stream (also when a step raises)
-        return (input_ids[:, max_input_length:max_input_length + max_length], sum(accept_length_list) / len(accept_length_list),
+        import types
+        st_ = types.SimpleNamespace(input_ids=input_tokens[:1], static=bool(static_tree), attention_mask=input_mask, input_position_diff=input_position_diff)
+        if static_tree:
+            self._take_draft(st_, tree_logits, sample_token)
+        else:
+            self._take_draft(st_, (draft_tokens, retrieve_indices, tree_mask, tree_position_ids), sample_token)
+        accept_length_list = self._decode_loop(st_, max_length, logits_processor, cfg, lantern, lantern_k, lantern_delta)   # the LlamaGen mirror's loop
+        return (st_.input_ids[:, max_input_length:max_input_length + max_length], sum(accept_length_list) / len(accept_length_list),
                 time.time() - st)
 
     @classmethod

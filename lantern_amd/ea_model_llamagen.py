@@ -13,6 +13,7 @@ Reference: models/ea_model_llamagen.py:26-29 (CFG), :283-420, :423-461, :464-669
 from __future__ import annotations
 
 import time
+import types
 from typing import List, Optional
 
 import numpy as np
@@ -209,7 +210,9 @@ class EaModel(nn.Module):
     # ------------------------------------------------------------------ O9 + O10, :935-999
     def update_inference_inputs(self, input_ids, candidates, best_candidate, accept_length, retrieve_indices, logits_processor,
                                 new_token, past_key_values_data_list, current_length_data, hidden_state_new, sample_p, cfg_scale,
-                                input_position_diff=None, attention_mask=None, static_tree=False):
+                                input_position_diff=None, attention_mask=None, static_tree=False, u=None):
+        """The reference's method, host-integer form (best_candidate / accept_length arrive as Python ints or 0-d tensors and are read
+        here).  generate() does not come through here: its steps keep the verdict on the device (_verify_step)."""
         prev_input_len = input_ids.shape[1]
         n = int(accept_length) + 1
         dev = retrieve_indices.device
@@ -221,25 +224,166 @@ class EaModel(nn.Module):
                           torch.tensor([prev_input_len], dtype=torch.int64, device=data.device), retrieve_indices.to(data.device),
                           best.to(data.device), alen.to(data.device))
         current_length_data.fill_(prev_input_len + n)
-        u = torch.rand(1, dtype=torch.float64, device=dev) if logits_processor is not None else None
+        if u is None and logits_processor is not None:
+            u = torch.rand(1, dtype=torch.float64, device=dev)
         out_h, _, token = ops.accept_gather(hidden_state_new[None], retrieve_indices, None, best, alen,
                                             sample_p=sample_p[None].float(), u=u)
         accept_hidden_state_new = out_h[0, :, :n]
         token = token.reshape(1, 1)
+        out = self._draft_next(input_ids, accept_hidden_state_new, token, logits_processor, cfg_scale, input_position_diff, attention_mask, static_tree)
+        new_token += n
+        if static_tree:
+            return input_ids, out, new_token, None, token
+        return (input_ids, *out, new_token, None, token)
+
+    def _draft_next(self, input_ids, accept_hidden, token, logits_processor, cfg_scale, input_position_diff, attention_mask, static_tree):
+        """The drafter call that ends a step (ea_model_llamagen.py:984-999): static -> tree_logits, dynamic -> (draft_tokens,
+        retrieve_indices, tree_mask, tree_position_ids)."""
         ea_input_ids = torch.cat((input_ids, token.to(input_ids.device)), dim=1).repeat(2, 1)
         kw = {}
         if self.mask_non_image:
             kw = dict(input_position_diff=input_position_diff, attention_mask=attention_mask)
-        if static_tree:
-            tree_logits = self.ea_layer.topK_genrate_v1(accept_hidden_state_new, input_ids=ea_input_ids, head=self.base_model.lm_head,
-                                                        logits_processor=logits_processor, cfg_scale=cfg_scale, **kw)
-            new_token += n
-            return input_ids, tree_logits, new_token, None, token
-        draft_tokens, retrieve_indices, tree_mask, tree_position_ids = self.ea_layer.topK_genrate(
-            accept_hidden_state_new, input_ids=ea_input_ids, head=self.base_model.lm_head, logits_processor=logits_processor,
-            cfg_scale=cfg_scale, **kw)
-        new_token += n
-        return input_ids, draft_tokens, retrieve_indices, tree_mask, tree_position_ids, new_token, None, token
+        fn = self.ea_layer.topK_genrate_v1 if static_tree else self.ea_layer.topK_genrate
+        return fn(accept_hidden, input_ids=ea_input_ids, head=self.base_model.lm_head, logits_processor=logits_processor, cfg_scale=cfg_scale, **kw)
+
+    # ------------------------------------------------------------------ the decode driver of generate(), :1109-1169
+    # Same observable behaviour as the reference's loop (tests/golden/generate_lg.npz pins ids, accept lengths, KV length, drafter and
+    # target calls and both RNG positions), organised for the device: a step's verdict -- best path, accept length, status -- stays in
+    # HBM and feeds the KV move, the accepted-hidden gather and the bonus-token draw there; the host reads ONE packed 4-int record per
+    # step (it needs the accept length to slice the drafter's inputs), where the reference syncs on every tried candidate.
+    _RETRY_DENSE = (2, 6, 7, 8)
+
+    def _posterior_on_device(self, rows, candidates, logits_processor, aux, static, lantern, lantern_k, lantern_delta, u):
+        """O8 (+ the bonus-token draw when the windowed kernel does it) with every result left on the device:
+        dict(best [1] i32, accept_len [1] i32, status [1] i32, token [1] i64 or None, sample_p [V] f32 or None)."""
+        dev = candidates.device
+        if logits_processor is None:
+            r, ri = as_rows(rows)
+            best, alen, out_row = ops.evaluate_posterior_greedy(r.float()[None], ri, candidates[None], lantern=bool(lantern), k=int(lantern_k),
+                                                                delta=float(lantern_delta), tok_offset=self.image_token_offset,
+                                                                table=self.nearest_latents if lantern else None,
+                                                                win_lo=self.image_lo if self.mask_non_image else 0,
+                                                                win_len=(self.image_hi - self.image_lo) if self.mask_non_image else None)
+            return dict(best=best, accept_len=alen, status=torch.zeros(1, dtype=torch.int32, device=dev), token=None, sample_p=out_row[0], counters=None)
+        proc = ProcessorSpec.from_hf(logits_processor)
+        cfg = self._ep_config(static, proc, lantern, lantern_k, lantern_delta)
+        fifo = self._uniforms()
+        if isinstance(rows, WindowRows):
+            import copy
+            cfg_w = copy.copy(cfg)
+            cfg_w.temperature, cfg_w.top_p, cfg_w.top_k = 1.0, 1.0, 0     # the rows are final probabilities (tree_decoding applied the processors)
+            out = ops.evaluate_posterior_window(cfg_w, rows.V, rows.win[None], rows.win_lo, rows.row_index(), candidates[None], fifo.buf,
+                                                row_hot=rows.row_hot[None], table=self._packed_table(int(lantern_k)) if lantern else None,
+                                                aux=aux, cursor=fifo.cursor, u_bonus=u, want_dense=False, want_window=False, rows_probs=True)
+            return dict(best=out["best"], accept_len=out["accept_len"], status=out["counters"][:, 5], token=out["token"], sample_p=None,
+                        counters=out["counters"])
+        r, ri = as_rows(rows)
+        best, alen, sample_p, counters = ops.evaluate_posterior(cfg, r.float()[None], ri, candidates[None], fifo.buf,
+                                                                table=self.nearest_latents if lantern else None, aux=aux, cursor=fifo.cursor)
+        return dict(best=best, accept_len=alen, status=counters[:, 5], token=None, sample_p=sample_p[0], counters=counters)
+
+    def _verify_step(self, st, logits_processor, cfg_scale, lantern, lantern_k, lantern_delta):
+        """One step of the loop: O6, target forward + O7 (tree_decoding), O8, O9 + O10, the bonus token, the next draft."""
+        pkv = self.base_model.past_key_values
+        kw = dict(input_position_diff=st.input_position_diff) if self.mask_non_image else {}
+        aux = None
+        if st.static:
+            tb = self.tree_buffers
+            candidates, cart_prob, tree_candidates = self.generate_candidates(st.tree_logits, tb["tree_indices"], tb["retrieve_indices"],
+                                                                              st.sample_token, logits_processor)
+            tree_candidates = torch.cat([tree_candidates, tree_candidates])
+            retrieve = tb["retrieve_indices_head"]
+            rows, hidden_new, _ = self.tree_decoding(tree_candidates, pkv, tb["tree_position_ids"], st.input_ids, retrieve, cfg_scale,
+                                                     st.attention_mask, **kw)
+            if logits_processor is not None:
+                hip = tb["_hip"]
+                aux = ops.StaticAux(cart_prob=cart_prob.to(candidates.device).float()[None], orig_prob=concat_original_prob(st.tree_logits[2]),
+                                    op_off=hip["op_off"], p_idx=hip["p_idx"], b_off=hip["b_off"], b_idx=hip["b_idx"],
+                                    tree_cand=tree_candidates[:1].reshape(1, -1)[:, :hip["N"]])
+        else:
+            self.base_model.model.tree_mask = st.tree_mask
+            retrieve = st.retrieve_indices
+            rows, hidden_new, _ = self.tree_decoding(torch.cat([st.draft_tokens, st.draft_tokens]), pkv, st.tree_position_ids, st.input_ids,
+                                                     retrieve, cfg_scale, st.attention_mask, **kw)
+            candidates = torch.cat((st.draft_tokens, st.padding), dim=1)[0, retrieve]
+        dev = candidates.device
+        # ---- O8: uniforms staged first, then the bonus uniform (the order the host-integer path draws them in)
+        u, cur0 = None, None
+        if logits_processor is not None:
+            fifo = self._uniforms()
+            fifo.reserve(candidates.shape[0] * candidates.shape[1])
+            cur0 = fifo.cursor.clone()
+            u = torch.rand(1, dtype=torch.float64, device=dev)
+        ep = self._posterior_on_device(rows, candidates, logits_processor, aux, st.static, lantern, lantern_k, lantern_delta, u)
+        best, alen, status = ep["best"], ep["accept_len"], ep["status"]
+        # ---- O9 + O10 from the device-side verdict; a failed walk (status != 0) commits nothing
+        prev = st.input_ids.shape[1]
+        alen_commit = torch.where(status == 0, alen, torch.full_like(alen, -1))
+        slabs = st.slabs
+        sdev = slabs[0].device
+        prev_t = st.prev_buf.fill_(prev)
+        _, out_h, acc = ops.update_inference_inputs(slabs[:1] if st.multi_device else slabs, st.slab_seq[:1] if st.multi_device else st.slab_seq,
+                                                    prev_t[:1] if st.multi_device else prev_t, retrieve.to(sdev), best.to(sdev), alen_commit.to(sdev),
+                                                    hidden_new[None], candidates[None], slab_ptrs=None if st.multi_device else st.slab_ptrs)
+        for data in (slabs[1:] if st.multi_device else ()):            # a model spread over devices: the other devices' slabs, same verdict
+            ops.kv_gather([data], torch.zeros(1, dtype=torch.int32, device=data.device), torch.tensor([prev], dtype=torch.int64, device=data.device),
+                          retrieve.to(data.device), best.to(data.device), alen_commit.to(data.device))
+        token = ep["token"]
+        if token is None:
+            _, _, token = ops.accept_gather(None, retrieve, None, best, alen, sample_p=ep["sample_p"][None].float(), u=u)
+        # ---- the step's one host read
+        a, bst, stt, tok = torch.cat((alen.to(torch.int64), best.to(torch.int64), status.to(torch.int64), token.to(torch.int64).reshape(-1)[:1])).tolist()
+        if stt != 0:
+            if stt in self._RETRY_DENSE and isinstance(rows, WindowRows) and rows.dense_source is not None and not (0.0 < self._active_proc.top_p < 1.0):
+                # a state only the dense kernel represents (the residual vanished, staging limits): the same step on the dense HIP kernel --
+                # processors applied per visited row there -- from the same position of the uniform stream, through the host-integer path
+                self._uniforms().cursor.copy_(cur0)
+                ep = self._posterior_on_device(rows.dense_rows(), candidates, logits_processor, aux, st.static, lantern, lantern_k, lantern_delta, u)
+                ops.raise_on_status(ep["counters"])
+                a, bst = int(ep["accept_len"][0]), int(ep["best"][0])
+                out = self.update_inference_inputs(st.input_ids, candidates, bst, a, retrieve, logits_processor, 0, st.slabs, self.base_model.current_length_data,
+                                                   hidden_new, ep["sample_p"], cfg_scale, st.input_position_diff, st.attention_mask, st.static, u=u)
+                st.input_ids = out[0]
+                self._take_draft(st, out[1] if st.static else out[1:5], out[-1])
+                return bst, a
+            ops.raise_on_status(ep["counters"])
+        n = a + 1
+        self.base_model.current_length_data.fill_(prev + n)
+        st.input_ids = torch.cat([st.input_ids, acc[:, :n].to(st.input_ids.device)], dim=-1)
+        token = torch.full((1, 1), tok, dtype=torch.long, device=dev)
+        self._take_draft(st, self._draft_next(st.input_ids, out_h[0, :, :n], token, logits_processor, cfg_scale, st.input_position_diff,
+                                              st.attention_mask, st.static), token)
+        return bst, a
+
+    def _take_draft(self, st, draft, token):
+        st.sample_token = token
+        if st.static:
+            st.tree_logits = draft
+        else:
+            st.draft_tokens, st.retrieve_indices, st.tree_mask, st.tree_position_ids = draft
+
+    def _decode_loop(self, st, max_length, logits_processor, cfg_scale, lantern, lantern_k, lantern_delta):
+        """generate()'s loop (ea_model_llamagen.py:1109-1169): steps until more than max_length tokens are out."""
+        slabs = list(self.base_model.past_key_values_data)
+        st.slabs, st.multi_device = slabs, len({x.device for x in slabs}) > 1
+        sdev = slabs[0].device
+        st.slab_ptrs = torch.tensor([x.data_ptr() for x in slabs], dtype=torch.int64, device=sdev)
+        st.slab_seq = torch.zeros(len(slabs), dtype=torch.int32, device=sdev)
+        st.prev_buf = torch.zeros(len(slabs), dtype=torch.int64, device=sdev)
+        st.padding = torch.full((1, 1), -1, dtype=torch.long, device=st.input_ids.device)
+        st.new_token, accept_lengths, self.last_steps = 0, [], []
+        self._uniforms().begin()          # this prompt's acceptance uniforms start at random's current position
+        try:
+            for _ in range(max_length):
+                best, alen = self._verify_step(st, logits_processor, cfg_scale, lantern, lantern_k, lantern_delta)
+                self.last_steps.append((best, alen))
+                accept_lengths.append(alen + 1)
+                st.new_token += alen + 1
+                if st.new_token > max_length:
+                    break
+        finally:
+            self._uniforms().end()        # unconsumed staged draws go back to the module-level stream (also when a step raises)
+        return accept_lengths
 
     # ------------------------------------------------------------------ :423-461
     @torch.no_grad()
@@ -296,7 +440,6 @@ class EaModel(nn.Module):
                  top_k: Optional[int] = None, top_p: Optional[float] = None, cfg: Optional[float] = None,
                  lantern: Optional[bool] = None, lantern_k: Optional[int] = None, lantern_delta: Optional[float] = None,
                  static_tree: Optional[bool] = None, tree_choices: Optional[List[List[int]]] = naive_extend_57, **model_kwargs):
-        accept_length_list = []
         cond_combined, attention_mask = self._encode_prompt(prompt, cfg)
         st = time.time()
         if not hasattr(self.base_model, "past_key_values"):
@@ -327,41 +470,13 @@ class EaModel(nn.Module):
             draft_tokens, retrieve_indices, tree_mask, tree_position_ids, logits, hidden_state, sample_token = self.initialize_tree(
                 cond_combined, past_key_values, logits_processor, cfg, attention_mask)
         input_ids = torch.zeros((cond_combined.shape[0] // (2 if cfg is not None else 1), self.prefix_pad), dtype=torch.long).to(dev)
-        new_token = 0
-        self._uniforms().begin()          # this prompt's acceptance uniforms start at random's current position
-        try:
-            for idx in range(max_length):
-                if static_tree:
-                    candidates, cart_candidates_prob, tree_candidates = self.generate_candidates(
-                        tree_logits, tree_buffers["tree_indices"], tree_buffers["retrieve_indices"], sample_token, logits_processor)
-                    tree_candidates = torch.cat([tree_candidates, tree_candidates])
-                    logits, hidden_state_new, outputs = self.tree_decoding(tree_candidates, past_key_values, tree_buffers["tree_position_ids"],
-                                                                           input_ids, tree_buffers["retrieve_indices_head"], cfg, attention_mask)
-                    best_candidate, accept_length, sample_p = self.evaluate_posterior_v1(
-                        logits, candidates, logits_processor, cart_candidates_prob, tree_logits[2], tree_buffers["p_indices"],
-                        tree_candidates, tree_buffers["b_indices"], lantern, lantern_k, lantern_delta)
-                    input_ids, tree_logits, new_token, hidden_state, sample_token = self.update_inference_inputs(
-                        input_ids, candidates, best_candidate, accept_length, tree_buffers["retrieve_indices_head"], logits_processor,
-                        new_token, past_key_values_data, current_length_data, hidden_state_new, sample_p, cfg, static_tree=True)
-                else:
-                    self.base_model.model.tree_mask = tree_mask
-                    tree_draft_tokens = torch.cat([draft_tokens, draft_tokens])
-                    logits, hidden_state_new, outputs = self.tree_decoding(tree_draft_tokens, past_key_values, tree_position_ids, input_ids,
-                                                                           retrieve_indices, cfg, attention_mask)
-                    draft_tokens = torch.cat((draft_tokens, padding), dim=1)
-                    candidates = draft_tokens[0, retrieve_indices]
-                    best_candidate, accept_length, sample_p = self.evaluate_posterior(logits, candidates, logits_processor, lantern=lantern,
-                                                                                      lantern_k=lantern_k, lantern_delta=lantern_delta)
-                    (input_ids, draft_tokens, retrieve_indices, tree_mask, tree_position_ids, new_token, hidden_state,
-                     sample_token) = self.update_inference_inputs(input_ids, candidates, best_candidate, accept_length, retrieve_indices,
-                                                                  logits_processor, new_token, past_key_values_data, current_length_data,
-                                                                  hidden_state_new, sample_p, cfg)
-                accept_length_list.append(int(accept_length) + 1)
-                if new_token > max_length:
-                    break
-        finally:
-            self._uniforms().end()        # unconsumed staged draws go back to the module-level stream (also when a step raises)
-        return (input_ids[:, self.prefix_pad:self.prefix_pad + max_length], sum(accept_length_list) / len(accept_length_list),
+        st_ = types.SimpleNamespace(input_ids=input_ids, static=bool(static_tree), attention_mask=attention_mask, input_position_diff=None)
+        if static_tree:
+            self._take_draft(st_, tree_logits, sample_token)
+        else:
+            self._take_draft(st_, (draft_tokens, retrieve_indices, tree_mask, tree_position_ids), sample_token)
+        accept_length_list = self._decode_loop(st_, max_length, logits_processor, cfg, lantern, lantern_k, lantern_delta)
+        return (st_.input_ids[:, self.prefix_pad:self.prefix_pad + max_length], sum(accept_length_list) / len(accept_length_list),
                 time.time() - st)
 
     eagenerate = generate

@@ -508,6 +508,23 @@ int lantern_linear_rows_epilogue(const void *A, const void *W, const void *bias,
  * out = bf16(A W^T + bias) (+ residual, rounded again); workspace [dev] ksplit * M * n_rows floats; two launches, deterministic sums. */
 int lantern_linear_rows_splitk(const void *A, const void *W, const void *bias, int M, int K, int n_rows, void *out, int out_stride,
                                const void *residual, int residual_stride, int ksplit, float *workspace, void *stream);
+/* The same products (epilogue 0: bias only, LANTERN_EPI_RESIDUAL, LANTERN_EPI_SILU_MUL) in stream-K form, ONE launch, deterministic: the (tile, K)
+ * space is cut into equal contiguous shares, one per workgroup (two workgroups per CU), a tile's partial sums meet in the workspace and the
+ * workgroup that completes a tile adds them in K order and runs the epilogue; two trips of loads in flight per wave.  The form the decoder layer
+ * uses at its decode shape (M <= 32).  workspace: [dev] lantern_linear_rows_streamk_workspace(n_rows) bytes, 16-byte aligned, zero-filled ONCE
+ * by the caller (the kernel leaves its counters zeroed); one launch at a time per workspace. */
+size_t lantern_linear_rows_streamk_workspace(int n_rows);
+int lantern_linear_rows_streamk(const void *A, const void *W, const void *bias, int M, int K, int row_lo, int n_rows, void *out,
+                                int out_stride, int out_col0, int epilogue, const void *aux, int aux_stride, int pair_rows,
+                                int packed, void *workspace, size_t workspace_bytes, void *stream);
+/* packed != 0: W is the output of lantern_pack_linear_weight -- the same values re-laid out ONCE (at weight-load time) in the order the
+ * kernel's waves consume them: per 32-row tile and 64-element K block one 4 KB brick [fragment 0..3][lane 0..63][8 bf16] (gate / up pairs:
+ * the gate brick, then the up brick), so that a wave's load instruction is 1 KB contiguous and a workgroup's share one contiguous byte range
+ * (row-major nn.Linear weights make every load 64 separate 16-byte pieces 8 - 22 KB apart).  K % 64 == 0; n_rows is padded to a multiple
+ * of 32 with zero rows; pair_rows > 0: rows [0, n_rows) and [pair_rows, pair_rows + n_rows) interleaved per brick.  out: [dev]
+ * lantern_pack_linear_weight_bytes(n_rows, K, pair_rows) bytes, 16-byte aligned. */
+size_t lantern_pack_linear_weight_bytes(int n_rows, int K, int pair_rows);
+int lantern_pack_linear_weight(const void *W, int n_rows, int K, int pair_rows, void *out, void *stream);
 int lantern_rmsnorm_rows(const void *x, const void *weight, int M, int H, float eps, void *out, void *stream);
 int lantern_qk_norm_rope(const void *qkv, int B, int T, int n_q_heads, int n_kv_heads, int head_dim, const void *q_weight, const void *q_bias,
                          const void *k_weight, const void *k_bias, int model_parallel, const void *cos_table, const void *sin_table,

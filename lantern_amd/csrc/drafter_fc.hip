@@ -265,16 +265,62 @@ __global__ __launch_bounds__(256) void rmsnorm_rows_kernel(const uint16_t *__res
     __shared__ float red[4];
     const int row = blockIdx.x, tid = threadIdx.x;
     const uint16_t *xr = x + (size_t)row * H;
+    constexpr int VMAX = 4;                       // 16-byte chunks a thread keeps in registers: rows up to 8192 elements are read once
+    const bool vec = H % 8 == 0 && H <= 8 * 256 * VMAX && ((uintptr_t)x & 15) == 0 && ((uintptr_t)w & 15) == 0 && ((uintptr_t)out & 15) == 0;
+    uint4 xv[VMAX], wv[VMAX];
     float ss = 0.0f;
-    for (int i = tid; i < H; i += 256) {
-        const float v = bf16_bits_to_f32(xr[i]);
-        ss += v * v;
+    if (vec) {
+        // every load of the row and of the weight goes out before the first use (one memory round instead of 2 x H / 256 dependent ones)
+#pragma unroll
+        for (int j = 0; j < VMAX; ++j) {
+            const int i = (tid + j * 256) * 8;
+            xv[j] = make_uint4(0u, 0u, 0u, 0u);
+            wv[j] = make_uint4(0u, 0u, 0u, 0u);
+            if (i < H) {
+                xv[j] = *reinterpret_cast<const uint4 *>(xr + i);
+                wv[j] = *reinterpret_cast<const uint4 *>(w + i);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < VMAX; ++j) {
+            const uint32_t u[4] = {xv[j].x, xv[j].y, xv[j].z, xv[j].w};
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {          // same element order as the scalar loop would visit within a thread; the sum is a tree anyway
+                const float lo = bf16_bits_to_f32((uint16_t)(u[c] & 0xffffu)), hi = bf16_bits_to_f32((uint16_t)(u[c] >> 16));
+                ss += lo * lo;
+                ss += hi * hi;
+            }
+        }
+    } else {
+        for (int i = tid; i < H; i += 256) {
+            const float v = bf16_bits_to_f32(xr[i]);
+            ss += v * v;
+        }
     }
     for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
     if ((tid & 63) == 0) red[tid >> 6] = ss;
     __syncthreads();
     const float var = (red[0] + red[1] + red[2] + red[3]) / (float)H;
     const float rstd = rsqrtf(var + eps);
+    if (vec) {
+#pragma unroll
+        for (int j = 0; j < VMAX; ++j) {
+            const int i = (tid + j * 256) * 8;
+            if (i < H) {
+                const uint32_t u[4] = {xv[j].x, xv[j].y, xv[j].z, xv[j].w}, g[4] = {wv[j].x, wv[j].y, wv[j].z, wv[j].w};
+                uint32_t o[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const float nl = bf16_bits_to_f32(f32_to_bf16_rne(bf16_bits_to_f32((uint16_t)(u[c] & 0xffffu)) * rstd));
+                    const float nh = bf16_bits_to_f32(f32_to_bf16_rne(bf16_bits_to_f32((uint16_t)(u[c] >> 16)) * rstd));
+                    o[c] = (uint32_t)f32_to_bf16_rne(bf16_bits_to_f32((uint16_t)(g[c] & 0xffffu)) * nl) |
+                           ((uint32_t)f32_to_bf16_rne(bf16_bits_to_f32((uint16_t)(g[c] >> 16)) * nh) << 16);
+                }
+                *reinterpret_cast<uint4 *>(out + (size_t)row * H + i) = make_uint4(o[0], o[1], o[2], o[3]);
+            }
+        }
+        return;
+    }
     for (int i = tid; i < H; i += 256) {
         const float n = bf16_bits_to_f32(f32_to_bf16_rne(bf16_bits_to_f32(xr[i]) * rstd));
         out[(size_t)row * H + i] = f32_to_bf16_rne(bf16_bits_to_f32(w[i]) * n);
@@ -567,6 +613,284 @@ extern "C" int lantern_linear_rows_splitk(const void *A, const void *W, const vo
     hipLaunchKernelGGL(linear_rows_splitk_finish_kernel, dim3((M * n_rows + 255) / 256), dim3(256), 0, st, (const float *)workspace,
                        (const uint16_t *)bias, (const uint16_t *)residual, residual_stride, M, n_rows, ksplit, (uint16_t *)out, out_stride);
     LANTERN_CHECK_LAUNCH("linear_rows_splitk_finish");
+    return LANTERN_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+// Stream-K form of the same product for the drafting shape (M <= 32): the decoder layer's four weight matrices are 34 - 180 MB each
+// and nothing else of the layer moves more than a few hundred KB, so the layer runs at the speed the weights stream.  Two things
+// bound the per-tile kernels above: (1) a workgroup owns a 32-column tile, so 128 / 344 / 384 tiles land unevenly on 256 CUs, and the
+// split-K variant pays a second launch; (2) one trip of loads in flight per wave (64 B per lane) is ~32 KB per CU -- at ~2.5 us of
+// loaded HBM latency that is 3.3 TB/s for the whole GPU, which is what they measure.  Here
+//  * the (tile, K) space is cut into `cpt` chunks of SK_CHUNK K-elements per tile, linearised, and workgroup g of G gets the contiguous
+//    range [total g / G, total (g + 1) / G): every workgroup streams the same number of bytes whatever the tile count (G = 2 per CU);
+//  * a range that ends inside a tile leaves an f32 partial tile in the workspace (at most two per workgroup: the tail of its first
+//    tile, the head of its last) and adds its chunk count to the tile's counter; the workgroup that completes the count sums the
+//    tile's partials in K order -- always the same order, whoever arrives last -- and runs the epilogue: ONE launch, deterministic;
+//  * every wave keeps TWO trips in flight (the next trip's 64 B of W and of A per lane are requested before the current trip's MFMAs).
+//  * PACKED: the weight re-laid out once, at load time, in the order the waves consume it (lantern_pack_linear_weight: per 32-row tile
+//    and 64-element K block a 4 KB brick [fragment q][lane][8 bf16]) -- a load instruction of a wave is 1 KB contiguous and a workgroup's
+//    whole share one contiguous byte range, where nn.Linear's [out, in] rows make every load 64 separate 16-byte pieces 8 - 22 KB apart
+//    (measured 3.3 TB/s at best, whatever the occupancy or the prefetch depth: the DRAM pages, not the latency, were the limit).
+// Epilogues as in linear_rows_kernel (EPI 0 bias, 1 + residual, 2 gate / up pair with silu * mul; torch's bf16 roundings).
+constexpr int SK_CHUNK = 256;
+
+struct SkArgs {
+    const uint16_t *A, *W, *bias, *aux;
+    uint16_t *out;
+    float *ws;            // [G][2][NSET][32 * 32] partial tiles
+    uint32_t *cnt;        // [n_tiles] chunks accumulated (zero before the launch; left zero)
+    int M, K, row_lo, n_rows, out_stride, out_col0, aux_stride, pair_rows, n_tiles, cpt, G;
+};
+
+template <int EPI, bool PACKED, int NBUF>
+__global__ __launch_bounds__(FC_THREADS) void linear_rows_streamk_kernel(const SkArgs a) {
+    constexpr int NSET = EPI == 2 ? 2 : 1;
+    __shared__ float red[NSET][FC_WAVES][32][33];
+    __shared__ uint32_t s_last;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int K = a.K, cpt = a.cpt, G = a.G, wg = blockIdx.x;
+    const long long total = (long long)a.n_tiles * cpt;
+    long long c0 = total * wg / G;
+    const long long c1 = total * (wg + 1) / G;
+    const int first_tile = (int)(c0 / cpt);
+    const bool live = r < a.M;
+    const uint16_t *arow = a.A + (size_t)(live ? r : 0) * K;
+    const bf16x8_t zero = __builtin_bit_cast(bf16x8_t, make_uint4(0, 0, 0, 0));
+    while (c0 < c1) {
+        const int t = (int)(c0 / cpt);
+        const int cb = (int)(c0 - (long long)t * cpt);
+        const long long tile_end = (long long)(t + 1) * cpt;
+        const int ce = (int)((c1 < tile_end ? c1 : tile_end) - (long long)t * cpt);
+        const int k_lo = cb * SK_CHUNK, k_hi = ce * SK_CHUNK < K ? ce * SK_CHUNK : K;
+        // waves split the segment's K range.  Row-major weights: contiguous sub-ranges at any 16-element step boundary.  Packed weights: the
+        // 64-element bricks round-robin (wave w takes bricks w, w + 8, ...), so the eight waves walk ONE contiguous byte range together
+        // (32 KB per round) instead of eight separate ones: 256 sequential streams on the GPU, not 2048.
+        const int ksteps = (k_hi - k_lo) / 16;
+        const int ks0 = PACKED ? (k_lo / 64 + wave) * 4 : k_lo / 16 + (int)((long long)ksteps * wave / FC_WAVES);
+        const int ks1 = PACKED ? (k_hi / 64) * 4 : k_lo / 16 + (int)((long long)ksteps * (wave + 1) / FC_WAVES);
+        constexpr int KSTRIDE = PACKED ? 4 * FC_WAVES : 4;          // steps from one trip of a wave to its next
+        const int ncol = t * 32 + r;
+        const uint16_t *wrow = a.W + (size_t)(a.row_lo + (ncol < a.n_rows ? ncol : a.n_rows - 1)) * K;
+        const uint16_t *wrow2 = wrow + (size_t)a.pair_rows * K;
+        f32x16_t acc[NSET];
+#pragma unroll
+        for (int s_ = 0; s_ < NSET; ++s_)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[s_][i] = 0.0f;
+        // ---- the K range of this wave, four MFMA steps (64 elements, 64 contiguous bytes per lane and row) per trip, NBUF trips in flight
+        // (a ring of register buffers with compile-time indices: a buffer is refilled as soon as its MFMAs have read it)
+        bf16x8_t wb[NBUF][NSET][4], ab[NBUF][4];
+        auto load_trip = [&](int ks, bf16x8_t (&wv)[NSET][4], bf16x8_t (&av)[4]) {
+            const int kb = ks * 16 + 32 * h;
+            if constexpr (PACKED) {          // brick (tile t, K block ks / 4, set): [q][lane][8]
+                const uint16_t *brick = a.W + ((size_t)((long long)t * (K / 64) + (ks >> 2)) * NSET) * 2048 + lane * 8;
+#pragma unroll
+                for (int s_ = 0; s_ < NSET; ++s_)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) wv[s_][q] = load_frag(brick + s_ * 2048 + q * 512);
+            } else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) wv[0][q] = load_frag(wrow + kb + 8 * q);
+                if constexpr (NSET == 2) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) wv[1][q] = load_frag(wrow2 + kb + 8 * q);
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) av[q] = live ? load_frag(arow + kb + 8 * q) : zero;
+        };
+        auto mfma_trip = [&](const bf16x8_t (&wv)[NSET][4], const bf16x8_t (&av)[4]) {
+#pragma unroll
+            for (int s_ = 0; s_ < NSET; ++s_)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[s_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[q], wv[s_][q], acc[s_], 0, 0, 0);
+        };
+        int ks = ks0;
+#pragma unroll
+        for (int i = 0; i < NBUF; ++i)
+            if (ks + KSTRIDE * i + 3 < ks1) load_trip(ks + KSTRIDE * i, wb[i], ab[i]);
+        while (ks + 3 < ks1) {
+#pragma unroll
+            for (int i = 0; i < NBUF; ++i) {
+                if (ks + 3 < ks1) {
+                    mfma_trip(wb[i], ab[i]);
+                    if (ks + KSTRIDE * NBUF + 3 < ks1) load_trip(ks + KSTRIDE * NBUF, wb[i], ab[i]);
+                    ks += KSTRIDE;
+                }
+            }
+        }
+        if constexpr (!PACKED) {
+            for (; ks < ks1; ++ks) {
+                const int k0 = ks * 16 + 8 * h;
+                const bf16x8_t av = live ? load_frag(arow + k0) : zero;
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, load_frag(wrow + k0), acc[0], 0, 0, 0);
+                if constexpr (NSET == 2) acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, load_frag(wrow2 + k0), acc[1], 0, 0, 0);
+            }
+        }
+        // ---- the eight waves' K slices: one LDS slot each, summed in wave order by the element's owner
+#pragma unroll
+        for (int s_ = 0; s_ < NSET; ++s_)
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) red[s_][wave][(reg & 3) + 8 * (reg >> 2) + 4 * h][r] = acc[s_][reg];
+        __syncthreads();
+        float v[NSET][2];
+#pragma unroll
+        for (int s_ = 0; s_ < NSET; ++s_)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int e = tid + j * FC_THREADS, row = e >> 5, col = e & 31;
+                float x = 0.0f;
+#pragma unroll
+                for (int w = 0; w < FC_WAVES; ++w) x += red[s_][w][row][col];
+                v[s_][j] = x;
+            }
+        bool finish = cb == 0 && ce == cpt;          // the whole K range of the tile was ours
+        if (!finish) {
+            const int slot = t == first_tile ? 0 : 1;
+            // The partial tile leaves with device-coherent stores (written through this XCD's L2) and is read back with device-coherent
+            // loads: no L2 write-back / invalidate of everything else (`__threadfence()` costs exactly that on a part with one L2 per XCD
+            // -- measured: the kernel 10x slower).  Every thread waits for its own stores, the barrier collects the workgroup, then one
+            // thread publishes the chunk count.
+            float *wsp = a.ws + ((size_t)(wg * 2 + slot) * NSET) * 1024;
+#pragma unroll
+            for (int s_ = 0; s_ < NSET; ++s_)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) __hip_atomic_store(wsp + s_ * 1024 + tid + j * FC_THREADS, v[s_][j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");          // (vmcnt(0): the stores above are acknowledged)
+            __syncthreads();
+            if (tid == 0) {
+                const uint32_t mine = (uint32_t)(ce - cb);
+                s_last = (atomicAdd(&a.cnt[t], mine) + mine == (uint32_t)cpt) ? 1u : 0u;
+            }
+            __syncthreads();
+            finish = s_last != 0u;
+            if (finish) {          // every other segment of the tile is in the workspace: add them in K order
+                const long long tb = (long long)t * cpt;
+                const int g0 = (int)(((tb + 1) * G - 1) / total), g1 = (int)(((tb + cpt) * G - 1) / total);
+#pragma unroll
+                for (int s_ = 0; s_ < NSET; ++s_)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) v[s_][j] = 0.0f;
+                for (int g = g0; g <= g1; ++g) {
+                    const int gslot = (int)((total * g / G) / cpt) == t ? 0 : 1;
+                    const float *src = a.ws + ((size_t)(g * 2 + gslot) * NSET) * 1024;
+#pragma unroll
+                    for (int s_ = 0; s_ < NSET; ++s_)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) v[s_][j] += __hip_atomic_load(src + s_ * 1024 + tid + j * FC_THREADS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                if (tid == 0) __hip_atomic_store(&a.cnt[t], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);          // the next launch finds the counter at zero
+            }
+        }
+        if (finish) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int e = tid + j * FC_THREADS, m = e >> 5, n = t * 32 + (e & 31);
+                if (m < a.M && n < a.n_rows) {
+                    float x = v[0][j];
+                    if (a.bias) x += bf16_bits_to_f32(a.bias[a.row_lo + n]);
+                    uint16_t o = f32_to_bf16_rne(x);
+                    if constexpr (EPI == 1) o = f32_to_bf16_rne(bf16_bits_to_f32(a.aux[(size_t)m * a.aux_stride + n]) + bf16_bits_to_f32(o));
+                    if constexpr (EPI == 2) {
+                        float u = v[NSET - 1][j];
+                        if (a.bias) u += bf16_bits_to_f32(a.bias[a.row_lo + a.pair_rows + n]);
+                        const float gb = bf16_bits_to_f32(o), ub = bf16_bits_to_f32(f32_to_bf16_rne(u));
+                        const float sg = bf16_bits_to_f32(f32_to_bf16_rne(gb / (1.0f + expf(-gb))));
+                        o = f32_to_bf16_rne(sg * ub);
+                    }
+                    a.out[(size_t)m * a.out_stride + a.out_col0 + n] = o;
+                }
+            }
+        }
+        __syncthreads();          // red / s_last are reused by the next segment
+        c0 = (long long)t * cpt + ce;
+    }
+}
+
+// workgroups of a launch: one per CU (the register buffers of the trips in flight leave room for one 512-thread workgroup)
+static int sk_groups(int) {
+    static const int g = getenv("LANTERN_SK_GROUPS") ? atoi(getenv("LANTERN_SK_GROUPS")) : 0;      // tuning knob (diagnostic)
+    return g > 0 ? g : 256;
+}
+
+
+constexpr size_t SK_PARTIAL_BYTES = (size_t)1024 * 2 * 2 * 1024 * sizeof(float);      // <= 1024 workgroups x 2 segments x 2 tile sets x 32 x 32 f32
+
+extern "C" size_t lantern_linear_rows_streamk_workspace(int n_rows) {
+    if (n_rows <= 0) return 0;
+    return SK_PARTIAL_BYTES + (size_t)((n_rows + 31) / 32) * sizeof(uint32_t) + 256;      // + the tile counters
+}
+
+// [N, K] row-major -> bricks: out[((tile * K/64 + kb) * sets + set) * 2048 + q * 512 + lane * 8 + e] = W[set * pair_rows + tile * 32 + (lane & 31)][kb * 64 + 32 (lane >> 5) + 8 q + e]
+// (rows beyond n_rows: zeros)
+__global__ void pack_linear_weight_kernel(const uint16_t *__restrict__ W, int n_rows, int K, int sets, int pair_rows, uint16_t *__restrict__ out, long long n_frag) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;          // one 16-byte fragment per thread
+    if (i >= n_frag) return;
+    const int lane = (int)(i & 63), q = (int)((i >> 6) & 3);
+    long long b = i >> 8;
+    const int set = (int)(b % sets);
+    b /= sets;
+    const int kb = (int)(b % (K / 64)), tile = (int)(b / (K / 64));
+    const int row = tile * 32 + (lane & 31);
+    uint4 v = make_uint4(0u, 0u, 0u, 0u);
+    if (row < n_rows) v = *reinterpret_cast<const uint4 *>(W + (size_t)(set * pair_rows + row) * K + kb * 64 + 32 * (lane >> 5) + 8 * q);
+    reinterpret_cast<uint4 *>(out)[i] = v;
+}
+
+extern "C" size_t lantern_pack_linear_weight_bytes(int n_rows, int K, int pair_rows) {
+    if (n_rows <= 0 || K <= 0 || K % 64) return 0;
+    return (size_t)((n_rows + 31) / 32) * 32 * (size_t)K * 2 * (pair_rows > 0 ? 2 : 1);
+}
+
+extern "C" int lantern_pack_linear_weight(const void *W, int n_rows, int K, int pair_rows, void *out, void *stream) {
+    LANTERN_CHECK_ARG(W && out && n_rows > 0 && K > 0 && K % 64 == 0 && pair_rows >= 0, "pack_linear_weight: K=%d must be a multiple of 64", K);
+    const int sets = pair_rows > 0 ? 2 : 1;
+    const long long n_frag = (long long)((n_rows + 31) / 32) * (K / 64) * sets * 256;
+    hipLaunchKernelGGL(pack_linear_weight_kernel, dim3((unsigned)((n_frag + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const uint16_t *)W, n_rows, K, sets,
+                       pair_rows, (uint16_t *)out, n_frag);
+    LANTERN_CHECK_LAUNCH("pack_linear_weight");
+    return LANTERN_OK;
+}
+
+extern "C" int lantern_linear_rows_streamk(const void *A, const void *W, const void *bias, int M, int K, int row_lo, int n_rows, void *out,
+                                           int out_stride, int out_col0, int epilogue, const void *aux, int aux_stride, int pair_rows,
+                                           int packed, void *workspace, size_t workspace_bytes, void *stream) {
+    LANTERN_CHECK_ARG(A && W && out && workspace, "linear_rows_streamk: null buffer");
+    LANTERN_CHECK_ARG(M >= 0 && M <= 32, "linear_rows_streamk: M=%d must be <= 32 rows (the drafter's decode shape)", M);
+    LANTERN_CHECK_ARG(K > 0 && K % 16 == 0 && row_lo >= 0 && n_rows >= 0 && out_col0 >= 0 && out_stride >= out_col0 + n_rows,
+                      "linear_rows_streamk: K=%d must be a multiple of 16, the output row must hold [col0, col0 + n_rows)", K);
+    LANTERN_CHECK_ARG(epilogue >= 0 && epilogue <= 2, "linear_rows_streamk: epilogue %d", epilogue);
+    if (epilogue == LANTERN_EPI_RESIDUAL) LANTERN_CHECK_ARG(aux && aux_stride >= n_rows, "linear_rows_streamk: the residual [M, aux_stride >= n_rows] is missing");
+    if (epilogue == LANTERN_EPI_SILU_MUL) LANTERN_CHECK_ARG(pair_rows > 0, "linear_rows_streamk: pair_rows = distance (in weight rows) from a gate row to its up row");
+    if (packed) LANTERN_CHECK_ARG(K % 64 == 0 && row_lo == 0, "linear_rows_streamk: a packed weight needs K %% 64 == 0 and row_lo == 0 (K=%d, row_lo=%d)", K, row_lo);
+    LANTERN_CHECK_ARG(((uintptr_t)workspace & 15) == 0 && workspace_bytes >= lantern_linear_rows_streamk_workspace(n_rows),
+                      "linear_rows_streamk: workspace of lantern_linear_rows_streamk_workspace(n_rows) bytes, 16-byte aligned, zero-filled once");
+    if (M == 0 || n_rows == 0) return LANTERN_OK;
+    const int n_tiles = (n_rows + 31) / 32, cpt = (K + SK_CHUNK - 1) / SK_CHUNK;
+    long long total = (long long)n_tiles * cpt;
+    int G = sk_groups(epilogue);
+    if (G > 1024) G = 1024;
+    if ((long long)G > total) G = (int)total;
+    // fixed layout whatever the shape (launches of different shapes share one workspace): the partial tiles first, the tile counters behind them
+    float *ws = (float *)workspace;
+    uint32_t *cnt = (uint32_t *)((char *)workspace + SK_PARTIAL_BYTES);
+    SkArgs a{(const uint16_t *)A, (const uint16_t *)W, (const uint16_t *)bias, (const uint16_t *)aux, (uint16_t *)out, ws, cnt,
+             M, K, row_lo, n_rows, out_stride, out_col0, aux_stride, epilogue == LANTERN_EPI_SILU_MUL ? pair_rows : 0, n_tiles, cpt, G};
+    hipStream_t st = (hipStream_t)stream;
+// two trips in flight per wave: three and four measured the same (24.4 - 24.6 / 21.5 - 21.9 us for the 100 / 90 MB matrices) -- the kernel is
+    // at the read bandwidth the part delivers (4.1 - 4.6 TB/s; torch's read-only reductions reach 3.8 - 4.0, its copy 5.2 read + write)
+#define SK_LAUNCH(E_)                                                                                                       \
+    do {                                                                                                                  \
+        if (packed) LANTERN_LAUNCH((linear_rows_streamk_kernel<E_, true, 2>), dim3(G), dim3(FC_THREADS), 0, st, a);        \
+        else LANTERN_LAUNCH((linear_rows_streamk_kernel<E_, false, 2>), dim3(G), dim3(FC_THREADS), 0, st, a);              \
+    } while (0)
+    if (epilogue == LANTERN_EPI_SILU_MUL) SK_LAUNCH(2);
+    else if (epilogue == 0) SK_LAUNCH(0);
+    else SK_LAUNCH(1);
+#undef SK_LAUNCH
+    LANTERN_CHECK_LAUNCH("linear_rows_streamk");
     return LANTERN_OK;
 }
 

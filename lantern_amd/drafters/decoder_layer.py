@@ -205,9 +205,22 @@ class DecoderLayer(nn.Module):
         self.input_layernorm = RMSNorm(config.hidden_size, eps)
         self.post_attention_layernorm = RMSNorm(config.hidden_size, eps)
 
+    def _packed(self, name, weight, pair_rows=0):
+        """The weight in the layout the stream-K kernel streams (ops.pack_linear_weight), made once per weight version; weights whose K is
+        not a multiple of 64 stay row-major (the kernel takes both)."""
+        if weight.shape[1] % 64:
+            return weight
+        cache = self.__dict__.setdefault("_packed_weights", {})
+        key = (weight.data_ptr(), weight._version)
+        hit = cache.get(name)
+        if hit is None or hit[0] != key:
+            hit = cache[name] = (key, ops.pack_linear_weight(weight, pair_rows))
+        return hit[1]
+
     def _fast(self, x, attention_mask, position_ids, past_key_value, use_cache, tree_bits=None, tree_keys=0, kv_start=None):
         """Decode shape on the device (<= 32 bf16 rows): rmsnorm, fused q/k/v GEMM, head norm + rotary (+ cache append), one attention call,
-        o_proj (split-K) + residual, rmsnorm, gate/up GEMM with silu * up in its epilogue, down_proj (split-K) + residual.
+        o_proj + residual, rmsnorm, gate/up GEMM with silu * up in its epilogue, down_proj + residual -- the four GEMMs in stream-K form
+        (lantern_linear_rows_streamk: one launch each, the weight split into equal contiguous shares over 2 workgroups per CU).
         With `tree_bits` (ops.drafter_tree_bits: the tree block of the drafter's mask as ancestor words) the attention is
         lantern_tree_attention over the cache in place -- no additive mask, no repeat_kv, no [T, S] scores."""
         at, mlp = self.self_attn, self.mlp
@@ -216,7 +229,7 @@ class DecoderLayer(nn.Module):
         x2 = x.reshape(B * T, H)
         xn = ops.rmsnorm_rows(x2, self.input_layernorm.weight, self.input_layernorm.variance_epsilon)
         w, b = at._fused_qkv()
-        qkv = ops.linear_rows(xn, w, 0, w.shape[0], bias=b)
+        qkv = ops.linear_rows_streamk(xn, self._packed("qkv", w), bias=b)          # stream-K: every workgroup streams an equal, contiguous share of the weight
         kv_len = T + (past_key_value[0].shape[-2] if past_key_value is not None else 0)
         cos, sin = at.rotary_emb.tables_bf16(x.device, kv_len)
         past = 0 if past_key_value is None else past_key_value[0].shape[-2]
@@ -247,12 +260,12 @@ class DecoderLayer(nn.Module):
             # (the additive-mask form: prefills inside the decode shape, callers without a tree block)
             m = None if attention_mask is None else attention_mask[:, :, :, :kv_len].to(q.dtype)
             o = F.scaled_dot_product_attention(q, k, v, attn_mask=m, enable_gqa=nk != nq).transpose(1, 2).reshape(B * T, H)
-        h1 = ops.linear_rows_splitk(o, at.o_proj.weight, bias=at.o_proj.bias, residual=x2)          # 128 column tiles: K split to fill the GPU
+        h1 = ops.linear_rows_streamk(o, self._packed("o", at.o_proj.weight), ops.EPI_RESIDUAL, bias=at.o_proj.bias, residual=x2)
         hn = ops.rmsnorm_rows(h1, self.post_attention_layernorm.weight, self.post_attention_layernorm.variance_epsilon)
         wg, bg = mlp._fused_gate_up()
         inter = mlp.gate_proj.out_features
-        act = ops.linear_rows_epilogue(hn, wg, ops.EPI_SILU_MUL, bias=bg, pair_rows=inter)
-        out = ops.linear_rows_splitk(act, mlp.down_proj.weight, bias=mlp.down_proj.bias, residual=h1)
+        act = ops.linear_rows_streamk(hn, self._packed("gate_up", wg, inter), ops.EPI_SILU_MUL, bias=bg, pair_rows=inter)
+        out = ops.linear_rows_streamk(act, self._packed("down", mlp.down_proj.weight), ops.EPI_RESIDUAL, bias=mlp.down_proj.bias, residual=h1)
         return out.reshape(B, T, H), present
 
     def _fast_ok(self, x, position_ids, output_attentions):

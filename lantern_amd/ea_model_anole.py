@@ -98,6 +98,7 @@ class EaModel(_LlamaGenEaModel):
                  top_k: Optional[int] = None, top_p: Optional[float] = None, cfg: Optional[float] = None,
                  lantern: Optional[bool] = None, lantern_k: Optional[int] = None, lantern_delta: Optional[float] = None,
                  static_tree: Optional[bool] = None, tree_choices: Optional[List[List[int]]] = naive_extend_57, **model_kwargs):
+        self._check_processors(temperature, top_p)
         dev = self.base_model.lm_head.weight.device
         cond_tokens, max_input_length = pad_nested_list_left([[BOS_ID] + row + [SEP_ID, BOI_ID] for row in self._prompt_tokens(prompt)])
         uncond_tokens = [[PAD_ID] * (max_input_length - 2) + [BOS_ID, BOI_ID] for _ in cond_tokens]

@@ -435,11 +435,20 @@ class EaModel(nn.Module):
             cond, lmask = torch.cat([cond, null]), torch.cat([lmask, lmask])
         return cond.to(bm.dtype), lmask
 
+    def _check_processors(self, temperature, top_p):
+        """The one place a sampling configuration is refused: nucleus filtering (TopPLogitsWarper, drafters/utils.py:36-52) is built into
+        the windowed kernel set only -- there tree_decoding applies Temperature -> TopP -> TopK to every row (lantern_cfg_mask_topk_window).
+        The dense set's evaluate_posterior applies the processors per visited row and has no top-p; asked for both, say so before any work."""
+        if temperature is not None and temperature > 1e-5 and top_p is not None and 0.0 < top_p < 1.0 and self.kernel_set != "window":
+            from ._lib import LanternError
+            raise LanternError(f"generate: top_p={top_p} needs kernel_set='window' (nucleus filtering is not built into the {self.kernel_set!r} kernel set)")
+
     @torch.no_grad()
     def generate(self, prompt: Optional[List[str]] = None, max_length: Optional[int] = None, temperature: Optional[float] = None,
                  top_k: Optional[int] = None, top_p: Optional[float] = None, cfg: Optional[float] = None,
                  lantern: Optional[bool] = None, lantern_k: Optional[int] = None, lantern_delta: Optional[float] = None,
                  static_tree: Optional[bool] = None, tree_choices: Optional[List[List[int]]] = naive_extend_57, **model_kwargs):
+        self._check_processors(temperature, top_p)
         cond_combined, attention_mask = self._encode_prompt(prompt, cfg)
         st = time.time()
         if not hasattr(self.base_model, "past_key_values"):

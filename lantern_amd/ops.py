@@ -659,6 +659,66 @@ def linear_rows_splitk(A, weight, bias=None, residual=None, ksplit: int = 0):
     return out
 
 
+_SK_WS = {}
+
+
+class PackedLinearWeight:
+    """A [N, K] bf16 nn.Linear weight re-laid out for lantern_linear_rows_streamk (lantern_pack_linear_weight): `data` is the brick stream,
+    `n_rows` / `K` / `pair_rows` describe the original."""
+
+    def __init__(self, data, n_rows, K, pair_rows):
+        self.data, self.n_rows, self.K, self.pair_rows = data, int(n_rows), int(K), int(pair_rows)
+
+
+def pack_linear_weight(weight, pair_rows: int = 0) -> PackedLinearWeight:
+    """weight [N, K] bf16 (K % 64 == 0) -> PackedLinearWeight; pair_rows > 0: weight = cat(gate, up) rows, N = 2 * pair_rows."""
+    if not weight.is_cuda or weight.dtype != torch.bfloat16 or weight.dim() != 2 or weight.shape[1] % 64:
+        raise _lib.LanternError("pack_linear_weight: a [N, K] bf16 device tensor with K % 64 == 0")
+    weight = weight.contiguous()
+    N, K = weight.shape
+    n_rows = pair_rows if pair_rows > 0 else N
+    L = _lib.lib()
+    nbytes = int(L.lantern_pack_linear_weight_bytes(n_rows, K, pair_rows))
+    out = torch.empty(nbytes // 2, dtype=torch.bfloat16, device=weight.device)
+    check(L.lantern_pack_linear_weight(C.c_void_p(weight.data_ptr()), n_rows, K, int(pair_rows), C.c_void_p(out.data_ptr()), _stream()), "pack_linear_weight")
+    return PackedLinearWeight(out, n_rows, K, pair_rows)
+
+
+def linear_rows_streamk(A, weight, epilogue: int = 0, n_rows: Optional[int] = None, bias=None, residual=None, pair_rows: int = 0, row_lo: int = 0):
+    """A [M <= 32, K] bf16 @ weight[row_lo : row_lo + n_rows].T in stream-K form (one launch, every workgroup streams an equal share of the
+    weight): epilogue 0 (+ bias), EPI_RESIDUAL (+ residual [M, n_rows], torch's two roundings), EPI_SILU_MUL (weight = cat(gate, up) rows,
+    pair_rows = distance gate -> up row: silu(gate) * up).  `weight`: the [N, K] tensor, or its PackedLinearWeight (the fast form).  The
+    workspace (partial tiles + tile counters, zeroed once) is kept per device and current stream."""
+    packed = isinstance(weight, PackedLinearWeight)
+    if not A.is_cuda or A.dtype != torch.bfloat16:
+        raise _lib.LanternError("linear_rows_streamk: A must be a bf16 device tensor")
+    A = A.contiguous()
+    M, K = A.shape
+    if packed:
+        if K != weight.K or row_lo != 0 or (epilogue == EPI_SILU_MUL) != (weight.pair_rows > 0):
+            raise _lib.LanternError("linear_rows_streamk: the packed weight does not match this call (K, row_lo = 0, gate / up pairing)")
+        n_rows, pair_rows, wt = weight.n_rows, weight.pair_rows, weight.data
+    else:
+        if not weight.is_cuda or weight.dtype != torch.bfloat16:
+            raise _lib.LanternError("linear_rows_streamk: weight must be a bf16 device tensor")
+        wt = weight.contiguous()
+        if n_rows is None:
+            n_rows = pair_rows if epilogue == EPI_SILU_MUL else wt.shape[0] - row_lo
+    L = _lib.lib()
+    need = int(L.lantern_linear_rows_streamk_workspace(max(n_rows, 65536)))
+    key = (A.device, torch.cuda.current_stream(A.device).cuda_stream)
+    ws = _SK_WS.get(key)
+    if ws is None or ws.numel() < need:
+        ws = _SK_WS[key] = torch.zeros(need, dtype=torch.uint8, device=A.device)
+    out = torch.empty((M, n_rows), dtype=torch.bfloat16, device=A.device)
+    r = None if residual is None else residual.contiguous()
+    b = None if bias is None else bias.contiguous()
+    check(L.lantern_linear_rows_streamk(C.c_void_p(A.data_ptr()), C.c_void_p(wt.data_ptr()), C.c_void_p(_ptr(b)), M, K, row_lo, n_rows,
+                                        C.c_void_p(out.data_ptr()), n_rows, 0, int(epilogue), C.c_void_p(_ptr(r)), 0 if r is None else r.shape[1], int(pair_rows),
+                                        int(packed), C.c_void_p(ws.data_ptr()), C.c_size_t(ws.numel()), _stream()), "linear_rows_streamk")
+    return out
+
+
 def rmsnorm_rows(x, weight, eps: float):
     """ChameleonRMSNorm of bf16 rows [M, H] (lantern_rmsnorm_rows)."""
     x, weight = x.contiguous(), weight.contiguous()

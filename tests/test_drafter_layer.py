@@ -64,10 +64,10 @@ def test_layer_hip_path_matches_the_reference_layer_bf16(name, fused, monkeypatc
     """Tolerance: bf16 has 8 bits of mantissa and every projection rounds its output to bf16 (as torch's bf16 nn.Linear does): the layer's
     output is compared with the reference's f32 result at 4e-2 absolute + 4e-2 relative, and with the SAME layer on torch's own bf16
     ops at 2e-2 (two bf16 pipelines that differ in accumulation order).  fused: rmsnorm / fused qkv / head-norm + rotary / o_proj + residual /
-    gate-up with silu * up / down + residual kernels (head_dim 64 or 128); per_projection: the skinny GEMM under torch's element-wise ops."""
+    gate-up with silu * up / down + residual kernels, the GEMMs in stream-K form (head_dim 64 or 128); per_projection: the skinny GEMM under torch's element-wise ops."""
     from lantern_amd import ops
     calls = []
-    for fn in ("linear_rows", "linear_rows_epilogue", "linear_rows_splitk", "rmsnorm_rows", "qk_norm_rope"):
+    for fn in ("linear_rows", "linear_rows_streamk", "rmsnorm_rows", "qk_norm_rope"):
         real = getattr(ops, fn)
         monkeypatch.setattr(ops, fn, (lambda real, fn: (lambda *a, **kw: (calls.append(fn), real(*a, **kw))[1]))(real, fn))
     dev = torch.device("cuda")
@@ -85,8 +85,8 @@ def test_layer_hip_path_matches_the_reference_layer_bf16(name, fused, monkeypatc
         y1, kv1 = layer(g(name, "x1", dev, bf), attention_mask=g(name, "m1", dev), position_ids=g(name, "pos1", dev), past_key_value=kv0, use_cache=True)
     head_dim = layer.self_attn.head_dim
     if fused and head_dim in (64, 128):
-        assert (calls.count("qk_norm_rope") == 2 and calls.count("rmsnorm_rows") == 4 and calls.count("linear_rows_epilogue") == 2 and
-                calls.count("linear_rows_splitk") == 4 and calls.count("linear_rows") == 2), calls
+        assert (calls.count("qk_norm_rope") == 2 and calls.count("rmsnorm_rows") == 4 and calls.count("linear_rows_streamk") == 8 and
+                calls.count("linear_rows") == 0), calls
     else:
         assert calls.count("linear_rows") == 8 and "qk_norm_rope" not in calls, calls          # fused qkv, o_proj, fused gate/up, down_proj per call
     for got, key in ((y0, "y0"), (y1, "y1"), (kv1[0], "k1"), (kv1[1], "v1")):
@@ -176,3 +176,47 @@ def test_layer_inplace_cache_equals_the_concatenated_cache():
     assert len(outs[0]) == len(outs[1])
     for i, (a, b) in enumerate(zip(*outs)):
         assert torch.equal(a, b), (i, float((a.float() - b.float()).abs().max()))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,K,N,epi", [(20, 4096, 12288, 0), (20, 4096, 4096, 1), (20, 4096, 11008, 2), (20, 11008, 4096, 1), (1, 512, 96, 0),
+                                       (32, 272, 40, 1), (7, 1040, 1000, 2), (32, 16, 33, 0), (9, 832, 70, 2), (32, 64, 1, 1)])
+def test_streamk_gemm_matches_f64_and_the_per_tile_kernels(M, K, N, epi):
+    """lantern_linear_rows_streamk (one launch, equal weight shares per workgroup, partial tiles met in the workspace) against the exact
+    product in f64 (tolerance: bf16 inputs, f32 accumulation over K in a different order -- 2e-2 of the row scale) and against the per-tile
+    kernels it replaces in the layer (same roundings in the epilogue: within one bf16 ulp of each other); the drafting shapes of the 7B layer,
+    ragged tiles / K not a multiple of the chunk, one row; twice in a row on the same workspace (the counters come back to zero)."""
+    from lantern_amd import ops
+    dev, bf = torch.device("cuda"), torch.bfloat16
+    gen = torch.Generator(device="cuda").manual_seed(M * 131 + K + N + epi)
+    x = torch.randn(M, K, device=dev, dtype=bf, generator=gen)
+    rows = 2 * N if epi == 2 else N
+    w = (torch.randn(rows, K, device=dev, generator=gen) / K ** 0.5).to(bf)
+    b = (0.1 * torch.randn(rows, device=dev, generator=gen)).to(bf)
+    res = torch.randn(M, N, device=dev, dtype=bf, generator=gen)
+    xd, wd, bd = x.double(), w.double(), b.double()
+    if epi == 0:
+        want = xd @ wd.T + bd
+        old = ops.linear_rows(x, w, 0, N, bias=b)
+        kw = {}
+    elif epi == 1:
+        want = (xd @ wd.T + bd) + res.double()
+        old = ops.linear_rows_epilogue(x, w, ops.EPI_RESIDUAL, bias=b, residual=res)
+        kw = dict(residual=res)
+    else:
+        gate, up = xd @ wd[:N].T + bd[:N], xd @ wd[N:].T + bd[N:]
+        want = torch.nn.functional.silu(gate) * up
+        old = ops.linear_rows_epilogue(x, w, ops.EPI_SILU_MUL, bias=b, pair_rows=N)
+        kw = dict(pair_rows=N)
+    forms = [w]
+    if K % 64 == 0:                          # the brick layout (what the layer streams): same values, same contraction, another address order
+        forms.append(ops.pack_linear_weight(w, N if epi == 2 else 0))
+    for wt in forms:
+        for _ in range(2):
+            got = ops.linear_rows_streamk(x, wt, epi, bias=b, **kw)
+            assert got.shape == (M, N)
+            scale = want.abs().max().item()
+            assert (got.double() - want).abs().max().item() <= 2e-2 * scale
+            assert (got.float() - old.float()).abs().max().item() <= 2e-2 * scale
+        again = ops.linear_rows_streamk(x, wt, epi, bias=b, **kw)
+        assert torch.equal(again, got)          # deterministic: the partials are added in K order whoever finishes a tile

@@ -7,8 +7,6 @@ timeout -k 10 400 python tests/fuzz_soak.py 60 > $OUT/static_soak.txt 2>&1; tail
 timeout -k 10 400 python tests/fuzz_soak.py 60 dynamic > $OUT/dynamic_soak.txt 2>&1; tail -1 $OUT/dynamic_soak.txt
 timeout -k 10 400 python tests/fuzz_soak.py 80 nodes > $OUT/nodes_soak.txt 2>&1; tail -1 $OUT/nodes_soak.txt
 # 1000-step loops with KV slabs (2560 rows: a whole 768x768 image fits), 32 sequences: single-launch accept, worker-thread launches
-timeout -k 10 400 python bench.py --steps 1000 --warmup 20 --seqs-per-gpu 32 --kv-smax 2560 --pool-steps 8 --cpu-seconds 100 --ep-sweep "" --no-extras --no-events --groups 2 --fused-accept > $OUT/soak_fused_accept.json 2> $OUT/soak_fused_accept.err || tail -3 $OUT/soak_fused_accept.err
-timeout -k 10 400 python bench.py --steps 1000 --warmup 20 --seqs-per-gpu 32 --kv-smax 2560 --pool-steps 8 --cpu-seconds 100 --ep-sweep "" --no-extras --no-events --groups 4 --launch-threads 4 > $OUT/soak_launcher.json 2> $OUT/soak_launcher.err || tail -3 $OUT/soak_launcher.err
 python - <<PY
 import json
 for n in ("fused_accept","launcher"):

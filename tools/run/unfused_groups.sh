@@ -2,7 +2,7 @@
 cd $GRAFT_REPO_ROOT
 OUT=gpurun_out/${1:-r2ug}
 mkdir -p $OUT
-for cfgs in "3 chain" "3 walk" "3 nodes" "2 chain" "2 walk" "4 chain"; do set -- $cfgs; g=$1; ep=$2
+for cfgs in "3 chain" "3 nodes" "2 chain" "4 chain"; do set -- $cfgs; g=$1; ep=$2
   timeout -k 10 300 python bench.py --steps 100 --warmup 10 --cpu-seconds 0 --ep-sweep "" --no-extras --no-events --groups $g --no-fuse-o7 --spec-rows 0 --ep $ep > $OUT/b_g${g}_$ep.json 2> $OUT/b_g${g}_$ep.err || tail -3 $OUT/b_g${g}_$ep.err
 done
 python - <<PY

@@ -523,6 +523,17 @@ int lantern_linear_rows_streamk(const void *A, const void *W, const void *bias, 
  * (row-major nn.Linear weights make every load 64 separate 16-byte pieces 8 - 22 KB apart).  K % 64 == 0; n_rows is padded to a multiple
  * of 32 with zero rows; pair_rows > 0: rows [0, n_rows) and [pair_rows, pair_rows + n_rows) interleaved per brick.  out: [dev]
  * lantern_pack_linear_weight_bytes(n_rows, K, pair_rows) bytes, 16-byte aligned. */
+/* The same kernel behind two more callers at the drafting shape:
+ *  - lantern_drafter_fc_streamk: O11 (lantern_drafter_fc) for M <= 32 rows, H % 64 == 0; W [H, 2H] row-major or packed (n_rows = H, K = 2H);
+ *  - lantern_head_expand_streamk: lantern_head_expand with the head's window GEMM + CFG epilogue in stream-K form; W row-major [V, K] or the
+ *    packed rows [row_lo, row_lo + n_cols). */
+int lantern_drafter_fc_streamk(const int64_t *ids, const void *hidden, const void *embed, const void *W, const void *bias, int M, int H,
+                               int vocab, float embed_scale, void *out, int packed, void *workspace, size_t workspace_bytes, void *stream);
+int lantern_head_expand_streamk(const void *A, const void *W, const void *bias, int n, int K, int row_lo, int n_cols, int V, float cfg,
+                                int model, const int64_t *pos_ids, int64_t pos_base, int w_latent, int h_latent, int newline_id,
+                                int eos_id, int top_k_filter, const float *scores_in, int top_k, void *workspace, int64_t *topk_index,
+                                float *cu_scores, int64_t *topk_cs_index, float *scores_out, int packed, void *sk_workspace,
+                                size_t sk_workspace_bytes, void *stream);
 size_t lantern_pack_linear_weight_bytes(int n_rows, int K, int pair_rows);
 int lantern_pack_linear_weight(const void *W, int n_rows, int K, int pair_rows, void *out, void *stream);
 int lantern_rmsnorm_rows(const void *x, const void *weight, int M, int H, float eps, void *out, void *stream);

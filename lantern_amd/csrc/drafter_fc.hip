@@ -641,9 +641,14 @@ struct SkArgs {
     float *ws;            // [G][2][NSET][32 * 32] partial tiles
     uint32_t *cnt;        // [n_tiles] chunks accumulated (zero before the launch; left zero)
     int M, K, row_lo, n_rows, out_stride, out_col0, aux_stride, pair_rows, n_tiles, cpt, G;
+    // GATHER (the drafter's input stage, lantern_drafter_fc): A[m] = cat(embed[ids[m]] * embed_scale, hidden[m]) with K = 2 * hsplit; `A` is hidden
+    const int64_t *ids;
+    const uint16_t *embed;
+    int vocab, hsplit;
+    float embed_scale, cfg;          // cfg: EPI 3 (rows [0, M/2) conditional, [M/2, M) unconditional -> uncond + cfg * (cond - uncond) in bf16 steps)
 };
 
-template <int EPI, bool PACKED, int NBUF>
+template <int EPI, bool PACKED, int NBUF, bool GATHER = false>
 __global__ __launch_bounds__(FC_THREADS) void linear_rows_streamk_kernel(const SkArgs a) {
     constexpr int NSET = EPI == 2 ? 2 : 1;
     __shared__ float red[NSET][FC_WAVES][32][33];
@@ -656,8 +661,37 @@ __global__ __launch_bounds__(FC_THREADS) void linear_rows_streamk_kernel(const S
     const long long c1 = total * (wg + 1) / G;
     const int first_tile = (int)(c0 / cpt);
     const bool live = r < a.M;
-    const uint16_t *arow = a.A + (size_t)(live ? r : 0) * K;
+    const uint16_t *arow = a.A + (size_t)(live ? r : 0) * (GATHER ? a.hsplit : K);
+    const uint16_t *erow = nullptr;
+    if constexpr (GATHER) {
+        int64_t id = live ? a.ids[r] : 0;
+        id = id < 0 ? 0 : (id >= a.vocab ? a.vocab - 1 : id);
+        erow = a.embed + (size_t)id * a.hsplit;
+    }
     const bf16x8_t zero = __builtin_bit_cast(bf16x8_t, make_uint4(0, 0, 0, 0));
+    // 8 consecutive k of this lane's activation row (GATHER: the embedding row, scaled and re-rounded to bf16 as
+    // cnets_lumina_mgpt.py:1096-1097 does, for k < hsplit, the hidden row behind it; hsplit % 64 == 0: a trip never straddles the seam)
+    auto a_frag = [&](int k0) -> bf16x8_t {
+        if (!live) return zero;
+        if constexpr (!GATHER) {
+            return load_frag(arow + k0);
+        } else {
+            if (k0 >= a.hsplit) return load_frag(arow + (k0 - a.hsplit));
+            bf16x8_t af = load_frag(erow + k0);
+            if (a.embed_scale > 1.0f) {
+                const uint4 v = __builtin_bit_cast(uint4, af);
+                uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const uint16_t lo = f32_to_bf16_rne(bf16_bits_to_f32((uint16_t)(w[i] & 0xffffu)) * a.embed_scale);
+                    const uint16_t hi = f32_to_bf16_rne(bf16_bits_to_f32((uint16_t)(w[i] >> 16)) * a.embed_scale);
+                    w[i] = (uint32_t)lo | ((uint32_t)hi << 16);
+                }
+                af = __builtin_bit_cast(bf16x8_t, make_uint4(w[0], w[1], w[2], w[3]));
+            }
+            return af;
+        }
+    };
     while (c0 < c1) {
         const int t = (int)(c0 / cpt);
         const int cb = (int)(c0 - (long long)t * cpt);
@@ -699,7 +733,7 @@ __global__ __launch_bounds__(FC_THREADS) void linear_rows_streamk_kernel(const S
                 }
             }
 #pragma unroll
-            for (int q = 0; q < 4; ++q) av[q] = live ? load_frag(arow + kb + 8 * q) : zero;
+            for (int q = 0; q < 4; ++q) av[q] = a_frag(kb + 8 * q);
         };
         auto mfma_trip = [&](const bf16x8_t (&wv)[NSET][4], const bf16x8_t (&av)[4]) {
 #pragma unroll
@@ -724,7 +758,7 @@ __global__ __launch_bounds__(FC_THREADS) void linear_rows_streamk_kernel(const S
         if constexpr (!PACKED) {
             for (; ks < ks1; ++ks) {
                 const int k0 = ks * 16 + 8 * h;
-                const bf16x8_t av = live ? load_frag(arow + k0) : zero;
+                const bf16x8_t av = a_frag(k0);
                 acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, load_frag(wrow + k0), acc[0], 0, 0, 0);
                 if constexpr (NSET == 2) acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, load_frag(wrow2 + k0), acc[1], 0, 0, 0);
             }
@@ -784,7 +818,28 @@ __global__ __launch_bounds__(FC_THREADS) void linear_rows_streamk_kernel(const S
                 if (tid == 0) __hip_atomic_store(&a.cnt[t], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);          // the next launch finds the counter at zero
             }
         }
-        if (finish) {
+        if constexpr (EPI == 3) {
+            // the CFG combination pairs row i with row i + M / 2: through the (free) LDS tile
+            if (finish) {
+                __syncthreads();
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int e = tid + j * FC_THREADS;
+                    red[0][0][e >> 5][e & 31] = v[0][j];
+                }
+                __syncthreads();
+                const int n_half = a.M / 2;
+                for (int e = tid; e < n_half * 32; e += FC_THREADS) {
+                    const int i = e >> 5, col = e & 31, n = t * 32 + col;
+                    if (n < a.n_rows) {
+                        const float b = a.bias ? bf16_bits_to_f32(a.bias[a.row_lo + n]) : 0.0f;
+                        const float c = bf16_bits_to_f32(f32_to_bf16_rne(red[0][0][i][col] + b)), u = bf16_bits_to_f32(f32_to_bf16_rne(red[0][0][i + n_half][col] + b));
+                        const float o = round_bf16(u + round_bf16(a.cfg * round_bf16(c - u)));
+                        a.out[(size_t)i * a.out_stride + a.out_col0 + n] = (uint16_t)(__float_as_uint(o) >> 16);
+                    }
+                }
+            }
+        } else if (finish) {
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const int e = tid + j * FC_THREADS, m = e >> 5, n = t * 32 + (e & 31);
@@ -854,6 +909,38 @@ extern "C" int lantern_pack_linear_weight(const void *W, int n_rows, int K, int 
     return LANTERN_OK;
 }
 
+// shared launch: shares of the (tile, K chunk) space over G workgroups, fixed workspace layout (partials, then counters)
+static int sk_run(SkArgs a, int epilogue, bool packed, bool gather, void *workspace, size_t workspace_bytes, hipStream_t st, const char *who) {
+    LANTERN_CHECK_ARG(workspace && ((uintptr_t)workspace & 15) == 0 && workspace_bytes >= lantern_linear_rows_streamk_workspace(a.n_rows),
+                      "%s: workspace of lantern_linear_rows_streamk_workspace(n_rows) bytes, 16-byte aligned, zero-filled once", who);
+    if (packed) LANTERN_CHECK_ARG(a.K % 64 == 0, "%s: a packed weight needs K %% 64 == 0 (K=%d)", who, a.K);
+    a.n_tiles = (a.n_rows + 31) / 32;
+    a.cpt = (a.K + SK_CHUNK - 1) / SK_CHUNK;
+    const long long total = (long long)a.n_tiles * a.cpt;
+    int G = sk_groups(epilogue);
+    if (G > 1024) G = 1024;
+    if ((long long)G > total) G = (int)total;
+    a.G = G;
+    // fixed layout whatever the shape (launches of different shapes share one workspace): the partial tiles first, the tile counters behind them
+    a.ws = (float *)workspace;
+    a.cnt = (uint32_t *)((char *)workspace + SK_PARTIAL_BYTES);
+    // two trips in flight per wave: three and four measured the same (24.4 - 24.6 / 21.5 - 21.9 us for the 100 / 90 MB matrices) -- the kernel is
+    // at the read bandwidth the part delivers (4.1 - 4.6 TB/s; torch's read-only reductions reach 3.8 - 4.0, its copy 5.2 read + write)
+#define SK_LAUNCH(E_, GA_)                                                                                                   \
+    do {                                                                                                                  \
+        if (packed) LANTERN_LAUNCH((linear_rows_streamk_kernel<E_, true, 2, GA_>), dim3(G), dim3(FC_THREADS), 0, st, a);   \
+        else LANTERN_LAUNCH((linear_rows_streamk_kernel<E_, false, 2, GA_>), dim3(G), dim3(FC_THREADS), 0, st, a);         \
+    } while (0)
+    if (gather) SK_LAUNCH(0, true);
+    else if (epilogue == LANTERN_EPI_SILU_MUL) SK_LAUNCH(2, false);
+    else if (epilogue == 3) SK_LAUNCH(3, false);
+    else if (epilogue == 0) SK_LAUNCH(0, false);
+    else SK_LAUNCH(1, false);
+#undef SK_LAUNCH
+    LANTERN_CHECK_LAUNCH(who);
+    return LANTERN_OK;
+}
+
 extern "C" int lantern_linear_rows_streamk(const void *A, const void *W, const void *bias, int M, int K, int row_lo, int n_rows, void *out,
                                            int out_stride, int out_col0, int epilogue, const void *aux, int aux_stride, int pair_rows,
                                            int packed, void *workspace, size_t workspace_bytes, void *stream) {
@@ -864,35 +951,39 @@ extern "C" int lantern_linear_rows_streamk(const void *A, const void *W, const v
     LANTERN_CHECK_ARG(epilogue >= 0 && epilogue <= 2, "linear_rows_streamk: epilogue %d", epilogue);
     if (epilogue == LANTERN_EPI_RESIDUAL) LANTERN_CHECK_ARG(aux && aux_stride >= n_rows, "linear_rows_streamk: the residual [M, aux_stride >= n_rows] is missing");
     if (epilogue == LANTERN_EPI_SILU_MUL) LANTERN_CHECK_ARG(pair_rows > 0, "linear_rows_streamk: pair_rows = distance (in weight rows) from a gate row to its up row");
-    if (packed) LANTERN_CHECK_ARG(K % 64 == 0 && row_lo == 0, "linear_rows_streamk: a packed weight needs K %% 64 == 0 and row_lo == 0 (K=%d, row_lo=%d)", K, row_lo);
-    LANTERN_CHECK_ARG(((uintptr_t)workspace & 15) == 0 && workspace_bytes >= lantern_linear_rows_streamk_workspace(n_rows),
-                      "linear_rows_streamk: workspace of lantern_linear_rows_streamk_workspace(n_rows) bytes, 16-byte aligned, zero-filled once");
     if (M == 0 || n_rows == 0) return LANTERN_OK;
-    const int n_tiles = (n_rows + 31) / 32, cpt = (K + SK_CHUNK - 1) / SK_CHUNK;
-    long long total = (long long)n_tiles * cpt;
-    int G = sk_groups(epilogue);
-    if (G > 1024) G = 1024;
-    if ((long long)G > total) G = (int)total;
-    // fixed layout whatever the shape (launches of different shapes share one workspace): the partial tiles first, the tile counters behind them
-    float *ws = (float *)workspace;
-    uint32_t *cnt = (uint32_t *)((char *)workspace + SK_PARTIAL_BYTES);
-    SkArgs a{(const uint16_t *)A, (const uint16_t *)W, (const uint16_t *)bias, (const uint16_t *)aux, (uint16_t *)out, ws, cnt,
-             M, K, row_lo, n_rows, out_stride, out_col0, aux_stride, epilogue == LANTERN_EPI_SILU_MUL ? pair_rows : 0, n_tiles, cpt, G};
-    hipStream_t st = (hipStream_t)stream;
-// two trips in flight per wave: three and four measured the same (24.4 - 24.6 / 21.5 - 21.9 us for the 100 / 90 MB matrices) -- the kernel is
-    // at the read bandwidth the part delivers (4.1 - 4.6 TB/s; torch's read-only reductions reach 3.8 - 4.0, its copy 5.2 read + write)
-#define SK_LAUNCH(E_)                                                                                                       \
-    do {                                                                                                                  \
-        if (packed) LANTERN_LAUNCH((linear_rows_streamk_kernel<E_, true, 2>), dim3(G), dim3(FC_THREADS), 0, st, a);        \
-        else LANTERN_LAUNCH((linear_rows_streamk_kernel<E_, false, 2>), dim3(G), dim3(FC_THREADS), 0, st, a);              \
-    } while (0)
-    if (epilogue == LANTERN_EPI_SILU_MUL) SK_LAUNCH(2);
-    else if (epilogue == 0) SK_LAUNCH(0);
-    else SK_LAUNCH(1);
-#undef SK_LAUNCH
-    LANTERN_CHECK_LAUNCH("linear_rows_streamk");
-    return LANTERN_OK;
+    SkArgs a{};
+    a.A = (const uint16_t *)A; a.W = (const uint16_t *)W; a.bias = (const uint16_t *)bias; a.aux = (const uint16_t *)aux; a.out = (uint16_t *)out;
+    a.M = M; a.K = K; a.row_lo = row_lo; a.n_rows = n_rows; a.out_stride = out_stride; a.out_col0 = out_col0; a.aux_stride = aux_stride;
+    a.pair_rows = epilogue == LANTERN_EPI_SILU_MUL ? pair_rows : 0;
+    return sk_run(a, epilogue, packed != 0, false, workspace, workspace_bytes, (hipStream_t)stream, "linear_rows_streamk");
 }
+
+// O11 in stream-K form (M <= 32 rows: the drafting shape): the embedding gather, its scaling and the concat stay folded into the A-fragment
+// address; W [H, 2H] row-major or packed (lantern_pack_linear_weight(W, H, 2H, 0)).
+extern "C" int lantern_drafter_fc_streamk(const int64_t *ids, const void *hidden, const void *embed, const void *W, const void *bias, int M, int H,
+                                          int vocab, float embed_scale, void *out, int packed, void *workspace, size_t workspace_bytes, void *stream) {
+    LANTERN_CHECK_ARG(ids && hidden && embed && W && out && workspace, "drafter_fc_streamk: null buffer");
+    LANTERN_CHECK_ARG(M >= 0 && M <= 32 && H > 0 && H % 64 == 0 && vocab > 0, "drafter_fc_streamk: M=%d <= 32 rows, H=%d a multiple of 64", M, H);
+    if (M == 0) return LANTERN_OK;
+    SkArgs a{};
+    a.A = (const uint16_t *)hidden; a.W = (const uint16_t *)W; a.bias = (const uint16_t *)bias; a.out = (uint16_t *)out;
+    a.M = M; a.K = 2 * H; a.n_rows = H; a.out_stride = H;
+    a.ids = ids; a.embed = (const uint16_t *)embed; a.vocab = vocab; a.hsplit = H; a.embed_scale = embed_scale;
+    return sk_run(a, 0, packed != 0, true, workspace, workspace_bytes, (hipStream_t)stream, "drafter_fc_streamk");
+}
+
+namespace lantern {
+// the drafter head's window GEMM with the CFG epilogue (lantern_head_expand), stream-K form: W row-major [V, K] (rows row_lo.. used) or the
+// packed rows [row_lo, row_lo + n_cols)
+int launch_linear_rows_cfg_streamk(const void *A, const void *W, const void *bias, int n, int K, int row_lo, int n_cols, float cfg, void *win, int packed,
+                                   void *workspace, size_t workspace_bytes, hipStream_t st) {
+    SkArgs a{};
+    a.A = (const uint16_t *)A; a.W = (const uint16_t *)W; a.bias = (const uint16_t *)bias; a.out = (uint16_t *)win;
+    a.M = 2 * n; a.K = K; a.row_lo = row_lo; a.n_rows = n_cols; a.out_stride = n_cols; a.cfg = cfg;
+    return sk_run(a, 3, packed != 0, false, workspace, workspace_bytes, st, "head_expand");
+}
+}  // namespace lantern
 
 extern "C" int lantern_linear_rows_epilogue(const void *A, const void *W, const void *bias, int M, int K, int row_lo, int n_rows, void *out,
                                             int out_stride, int out_col0, int epilogue, const void *aux, int aux_stride, int pair_rows, void *stream) {

@@ -385,14 +385,17 @@ extern "C" int lantern_tree_dynamic_candidates(const float *scores, const int64_
 namespace lantern {
 int launch_linear_rows_cfg(const void *A, const void *W, const void *bias, int n, int K, int row_lo, int n_cols, float cfg, void *win,
                            hipStream_t st);
+int launch_linear_rows_cfg_streamk(const void *A, const void *W, const void *bias, int n, int K, int row_lo, int n_cols, float cfg, void *win, int packed,
+                                   void *workspace, size_t workspace_bytes, hipStream_t st);
 }
 
 extern "C" size_t lantern_head_expand_workspace(int n, int n_cols) { return (size_t)n * (size_t)n_cols * 2; }
 
-extern "C" int lantern_head_expand(const void *A, const void *W, const void *bias, int n, int K, int row_lo, int n_cols, int V, float cfg,
-                                   int model, const int64_t *pos_ids, int64_t pos_base, int w_latent, int h_latent, int newline_id, int eos_id,
-                                   int top_k_filter, const float *scores_in, int top_k, void *workspace, int64_t *topk_index,
-                                   float *cu_scores, int64_t *topk_cs_index, float *scores_out, void *stream) {
+static int head_expand_impl(const void *A, const void *W, const void *bias, int n, int K, int row_lo, int n_cols, int V, float cfg,
+                            int model, const int64_t *pos_ids, int64_t pos_base, int w_latent, int h_latent, int newline_id, int eos_id,
+                            int top_k_filter, const float *scores_in, int top_k, void *workspace, int64_t *topk_index,
+                            float *cu_scores, int64_t *topk_cs_index, float *scores_out, int packed, void *sk_workspace, size_t sk_workspace_bytes,
+                            void *stream) {
     LANTERN_CHECK_ARG(A && W && workspace && topk_index && cu_scores && topk_cs_index && scores_out, "head_expand: null buffer");
     LANTERN_CHECK_ARG(n > 0 && n <= 16 && K > 0 && K % 16 == 0, "head_expand: n=%d drafter rows (<= 16 cond + 16 uncond), K=%d (multiple of 16)", n, K);
     LANTERN_CHECK_ARG(row_lo >= 0 && n_cols > 0 && n_cols % 8 == 0 && n_cols <= 8 * EXW_NT * EXW_C8 && row_lo + n_cols <= V,
@@ -403,12 +406,38 @@ extern "C" int lantern_head_expand(const void *A, const void *W, const void *bia
         LANTERN_CHECK_ARG(w_latent > 0 && h_latent > 0 && newline_id >= 0 && newline_id < V && eos_id >= 0 && eos_id < V, "head_expand: Lumina needs latent dims and syntax ids");
     LANTERN_CHECK_ARG(((uintptr_t)workspace & 15) == 0, "head_expand: workspace must be 16-byte aligned");
     hipStream_t st = (hipStream_t)stream;
-    launch_linear_rows_cfg(A, W, bias, n, K, row_lo, n_cols, cfg, workspace, st);
+    if (sk_workspace) {
+        const int rc = launch_linear_rows_cfg_streamk(A, W, bias, n, K, row_lo, n_cols, cfg, workspace, packed, sk_workspace, sk_workspace_bytes, st);
+        if (rc) return rc;
+    } else {
+        LANTERN_CHECK_ARG(!packed, "head_expand: a packed weight needs the stream-K workspace");
+        launch_linear_rows_cfg(A, W, bias, n, K, row_lo, n_cols, cfg, workspace, st);
+    }
     hipLaunchKernelGGL(expand_window_kernel, dim3(n), dim3(EXW_NT), 0, st, (const uint16_t *)workspace, n_cols, row_lo, V, model, pos_ids, pos_base,
                        w_latent, h_latent, newline_id, eos_id, top_k_filter, scores_in, top_k, topk_index, cu_scores);
     hipLaunchKernelGGL(expand_merge_kernel, dim3(1), dim3(64), 0, st, cu_scores, n * top_k, top_k, topk_cs_index, scores_out);
     LANTERN_CHECK_LAUNCH("head_expand");
     return LANTERN_OK;
+}
+
+extern "C" int lantern_head_expand(const void *A, const void *W, const void *bias, int n, int K, int row_lo, int n_cols, int V, float cfg,
+                                   int model, const int64_t *pos_ids, int64_t pos_base, int w_latent, int h_latent, int newline_id, int eos_id,
+                                   int top_k_filter, const float *scores_in, int top_k, void *workspace, int64_t *topk_index,
+                                   float *cu_scores, int64_t *topk_cs_index, float *scores_out, void *stream) {
+    return head_expand_impl(A, W, bias, n, K, row_lo, n_cols, V, cfg, model, pos_ids, pos_base, w_latent, h_latent, newline_id, eos_id, top_k_filter,
+                            scores_in, top_k, workspace, topk_index, cu_scores, topk_cs_index, scores_out, 0, nullptr, 0, stream);
+}
+
+// the same with the head's window GEMM in stream-K form (lantern_linear_rows_streamk's kernel with the CFG epilogue): W row-major [V, K], or --
+// packed != 0 -- lantern_pack_linear_weight of its rows [row_lo, row_lo + n_cols); sk_workspace as for lantern_linear_rows_streamk
+extern "C" int lantern_head_expand_streamk(const void *A, const void *W, const void *bias, int n, int K, int row_lo, int n_cols, int V, float cfg,
+                                           int model, const int64_t *pos_ids, int64_t pos_base, int w_latent, int h_latent, int newline_id,
+                                           int eos_id, int top_k_filter, const float *scores_in, int top_k, void *workspace, int64_t *topk_index,
+                                           float *cu_scores, int64_t *topk_cs_index, float *scores_out, int packed, void *sk_workspace,
+                                           size_t sk_workspace_bytes, void *stream) {
+    LANTERN_CHECK_ARG(sk_workspace, "head_expand_streamk: null stream-K workspace");
+    return head_expand_impl(A, W, bias, n, K, row_lo, n_cols, V, cfg, model, pos_ids, pos_base, w_latent, h_latent, newline_id, eos_id, top_k_filter,
+                            scores_in, top_k, workspace, topk_index, cu_scores, topk_cs_index, scores_out, packed, sk_workspace, sk_workspace_bytes, stream);
 }
 
 extern "C" int lantern_expand_dynamic(const float *logits, const float *scores_in, int B, int n_rows, int V, int top_k,

@@ -169,6 +169,16 @@ class Model(nn.Module):
             return None
         return ops.drafter_attention_mask(attention_mask, tm, B, T, past_key_values_length, device=inputs_embeds.device)
 
+    def _packed_weight(self, name, weight, row_lo=0, n_rows=None):
+        """ops.pack_linear_weight of weight[row_lo : row_lo + n_rows], made once per weight version (the brick layout the stream-K kernel streams)."""
+        cache = self.__dict__.setdefault("_packed_weights", {})
+        key = (weight.data_ptr(), weight._version, row_lo, n_rows)
+        hit = cache.get(name)
+        if hit is None or hit[0] != key:
+            rows = weight if n_rows is None else weight[row_lo:row_lo + n_rows]
+            hit = cache[name] = (key, ops.pack_linear_weight(rows.contiguous()))
+        return hit[1]
+
     def _input_stage(self, hidden_states, input_ids):
         """embed_tokens(ids) -> cast -> x upscale -> fc(cat(embeds, hidden)) (cnets_lumina_mgpt.py:1071,1095-1098)."""
         B, T, H = hidden_states.shape
@@ -178,9 +188,10 @@ class Model(nn.Module):
             emb = emb if emb.dtype == torch.bfloat16 else emb.to(torch.bfloat16)
             ids, hid = input_ids.reshape(-1), hidden_states.reshape(B * T, H)
             out = torch.empty_like(hid)
+            pk = self._packed_weight("fc", w) if (B * T <= 32 and H % 64 == 0) else None          # the drafting shape streams the packed weight
             for s in range(0, B * T, 128):                     # one drafter call is <= ~120 rows; prefills go in slices
                 out[s:s + 128] = ops.drafter_fc(ids[s:s + 128], hid[s:s + 128], emb, w, self.fc.bias,
-                                                embed_scale=float(self.embed_upscale) if self.embed_upscale > 1.0 else 1.0)
+                                                embed_scale=float(self.embed_upscale) if self.embed_upscale > 1.0 else 1.0, packed=pk)
             return out.view(B, T, H)
         # other dtypes (f32 checkpoints in tests): the same arithmetic in torch on the device
         e = self.embed_tokens(input_ids).to(hidden_states.dtype)
@@ -260,9 +271,10 @@ class Model(nn.Module):
         if (self.model_type == "lumina_mgpt" and isinstance(head, nn.Linear) and w is not None and w.is_cuda and w.dtype == torch.bfloat16
                 and hidden.dtype == torch.bfloat16 and w.shape[1] % 16 == 0 and n <= 16 and n * k <= 256 and pos_ids is not None):
             top_k = min(int(proc[1].image_top_k), w.shape[0]) if (proc is not None and len(proc) > 1) else 0
+            pk = self._packed_weight("head", w, self.image_lo, self.image_hi - self.image_lo) if w.shape[1] % 64 == 0 else None
             return ops.head_expand(hidden.reshape(2 * n, -1), w, self.image_lo, self.image_hi - self.image_lo, float(self.cfg_scale),
                                    bias=head.bias, model=ops.MODEL_LUMINA, pos_ids=pos_ids.reshape(-1), pos_base=2, top_k_filter=top_k,
-                                   scores_in=scores, top_k=k)
+                                   scores_in=scores, top_k=k, packed=pk)
         ho = self._head(head, hidden)
         rows = self._post_head(ho[0:1] if hidden.dim() == 2 else ho[0], ho[1:2] if hidden.dim() == 2 else ho[1], proc, pos_ids=pos_ids)
         return ops.expand_dynamic(rows[None], scores, k)

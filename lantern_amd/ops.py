@@ -662,6 +662,17 @@ def linear_rows_splitk(A, weight, bias=None, residual=None, ksplit: int = 0):
 _SK_WS = {}
 
 
+def _sk_workspace(device):
+    """The stream-K workspace of `device` and the current stream (partial tiles + tile counters; zero-filled once, the kernels leave the counters
+    zeroed; one launch at a time per workspace -- launches on one stream are ordered)."""
+    need = int(_lib.lib().lantern_linear_rows_streamk_workspace(65536))
+    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    ws = _SK_WS.get(key)
+    if ws is None or ws.numel() < need:
+        ws = _SK_WS[key] = torch.zeros(need, dtype=torch.uint8, device=device)
+    return ws
+
+
 class PackedLinearWeight:
     """A [N, K] bf16 nn.Linear weight re-laid out for lantern_linear_rows_streamk (lantern_pack_linear_weight): `data` is the brick stream,
     `n_rows` / `K` / `pair_rows` describe the original."""
@@ -705,11 +716,7 @@ def linear_rows_streamk(A, weight, epilogue: int = 0, n_rows: Optional[int] = No
         if n_rows is None:
             n_rows = pair_rows if epilogue == EPI_SILU_MUL else wt.shape[0] - row_lo
     L = _lib.lib()
-    need = int(L.lantern_linear_rows_streamk_workspace(max(n_rows, 65536)))
-    key = (A.device, torch.cuda.current_stream(A.device).cuda_stream)
-    ws = _SK_WS.get(key)
-    if ws is None or ws.numel() < need:
-        ws = _SK_WS[key] = torch.zeros(need, dtype=torch.uint8, device=A.device)
+    ws = _sk_workspace(A.device)
     out = torch.empty((M, n_rows), dtype=torch.bfloat16, device=A.device)
     r = None if residual is None else residual.contiguous()
     b = None if bias is None else bias.contiguous()
@@ -748,10 +755,11 @@ def qk_norm_rope(qkv, B: int, T: int, nq: int, nk: int, d: int, qw, qb, kw, kb, 
 
 
 def head_expand(A, weight, row_lo: int, n_cols: int, cfg: float, bias=None, model: int = MODEL_LUMINA, pos_ids=None, pos_base: int = 2,
-                w: int = 48, h: int = 48, newline_id: int = 8803, eos_id: int = 8196, top_k_filter: int = 0, scores_in=None, top_k: int = 10):
-    """8f-2 fused: one drafter expansion depth from hidden states to top-k (lantern_head_expand).  A [2n, K] bf16 (n cond rows, then
-    n uncond rows), weight [V, K] bf16.  Returns (topk_index [1,n,k], cu_scores [1,n,k], topk_cs_index [1,k], scores_out [1,k]) like
-    expand_dynamic on a batch of one sequence."""
+                w: int = 48, h: int = 48, newline_id: int = 8803, eos_id: int = 8196, top_k_filter: int = 0, scores_in=None, top_k: int = 10,
+                packed: Optional["PackedLinearWeight"] = None, streamk: bool = True):
+    """8f-2 fused: one drafter expansion depth from hidden states to top-k (lantern_head_expand[_streamk]).  A [2n, K] bf16 (n cond rows, then
+    n uncond rows), weight [V, K] bf16; `packed`: pack_linear_weight(weight[row_lo : row_lo + n_cols]) (the fast form of the window GEMM).
+    Returns (topk_index [1,n,k], cu_scores [1,n,k], topk_cs_index [1,k], scores_out [1,k]) like expand_dynamic on a batch of one sequence."""
     A = _dev(A, torch.bfloat16, "A")
     weight = _dev(weight, torch.bfloat16, "weight")
     n = A.shape[0] // 2
@@ -765,6 +773,17 @@ def head_expand(A, weight, row_lo: int, n_cols: int, cfg: float, bias=None, mode
     pos = None if pos_ids is None else _dev(pos_ids.reshape(-1), torch.int64, "pos_ids")
     si = None if scores_in is None else _dev(scores_in.reshape(-1), torch.float32, "scores_in")
     b = None if bias is None else _dev(bias, torch.bfloat16, "bias")
+    if streamk or packed is not None:
+        if packed is not None and (packed.K != K or packed.n_rows != n_cols or packed.pair_rows):
+            raise _lib.LanternError("head_expand: the packed weight is not the window rows of this head")
+        sk = _sk_workspace(dev)
+        wt = weight if packed is None else packed.data
+        check(_lib.lib().lantern_head_expand_streamk(C.c_void_p(A.data_ptr()), C.c_void_p(wt.data_ptr()), C.c_void_p(_ptr(b)), n, K, int(row_lo), int(n_cols), V,
+                                                     C.c_float(cfg), int(model), C.c_void_p(_ptr(pos)), C.c_int64(pos_base), w, h, newline_id, eos_id,
+                                                     int(top_k_filter), C.c_void_p(_ptr(si)), int(top_k), C.c_void_p(ws.data_ptr()), C.c_void_p(ti.data_ptr()),
+                                                     C.c_void_p(cu.data_ptr()), C.c_void_p(ci.data_ptr()), C.c_void_p(so.data_ptr()), int(packed is not None),
+                                                     C.c_void_p(sk.data_ptr()), C.c_size_t(sk.numel()), _stream()), "head_expand_streamk")
+        return ti, cu, ci, so
     check(_lib.lib().lantern_head_expand(C.c_void_p(A.data_ptr()), C.c_void_p(weight.data_ptr()), C.c_void_p(_ptr(b)), n, K, int(row_lo), int(n_cols), V,
                                          C.c_float(cfg), int(model), C.c_void_p(_ptr(pos)), C.c_int64(pos_base), w, h, newline_id, eos_id, int(top_k_filter),
                                          C.c_void_p(_ptr(si)), int(top_k), C.c_void_p(ws.data_ptr()), C.c_void_p(ti.data_ptr()), C.c_void_p(cu.data_ptr()),
@@ -785,9 +804,10 @@ def drafter_attention_mask(attention_mask, tree_mask, B: int, T: int, past: int,
     return out
 
 
-def drafter_fc(ids, hidden, embed, weight, bias=None, embed_scale: float = 1.0):
+def drafter_fc(ids, hidden, embed, weight, bias=None, embed_scale: float = 1.0, packed: Optional["PackedLinearWeight"] = None):
     """O11 (MFMA): fc(cat(embed[ids] * scale, hidden)) -> bf16 [M,H].  ids [M] i64, hidden [M,H] bf16, embed [vocab,H] bf16,
-    weight [H,2H] bf16 (nn.Linear layout), bias [H] bf16 or None."""
+    weight [H,2H] bf16 (nn.Linear layout), bias [H] bf16 or None.  Up to 32 rows with H % 64 == 0 (the drafting shape) take the stream-K
+    kernel, on `packed` = pack_linear_weight(weight) when given."""
     for t, n in ((hidden, "hidden"), (embed, "embed"), (weight, "weight")):
         if not t.is_cuda or t.dtype != torch.bfloat16:
             raise _lib.LanternError(f"drafter_fc: {n} must be a bf16 device tensor")
@@ -797,6 +817,16 @@ def drafter_fc(ids, hidden, embed, weight, bias=None, embed_scale: float = 1.0):
     assert weight.shape == (H, 2 * H) and embed.shape[1] == H and ids.numel() == M
     out = torch.empty((M, H), dtype=torch.bfloat16, device=hidden.device)
     b = None if bias is None else bias.contiguous()
+    if M <= 32 and H % 64 == 0:
+        if packed is not None and (packed.K != 2 * H or packed.n_rows != H or packed.pair_rows):
+            raise _lib.LanternError("drafter_fc: the packed weight is not this fc's [H, 2H] weight")
+        sk = _sk_workspace(hidden.device)
+        wt = weight if packed is None else packed.data
+        check(_lib.lib().lantern_drafter_fc_streamk(C.c_void_p(ids.data_ptr()), C.c_void_p(hidden.data_ptr()), C.c_void_p(embed.data_ptr()),
+                                                    C.c_void_p(wt.data_ptr()), C.c_void_p(_ptr(b)), M, H, embed.shape[0], C.c_float(embed_scale),
+                                                    C.c_void_p(out.data_ptr()), int(packed is not None), C.c_void_p(sk.data_ptr()), C.c_size_t(sk.numel()),
+                                                    _stream()), "drafter_fc_streamk")
+        return out
     check(_lib.lib().lantern_drafter_fc(C.c_void_p(ids.data_ptr()), C.c_void_p(hidden.data_ptr()), C.c_void_p(embed.data_ptr()),
                                         C.c_void_p(weight.data_ptr()), C.c_void_p(_ptr(b)), M, H, embed.shape[0], C.c_float(embed_scale),
                                         C.c_void_p(out.data_ptr()), _stream()), "drafter_fc")

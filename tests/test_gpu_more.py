@@ -64,8 +64,10 @@ def test_greedy_batched_vs_oracle(model, lantern, delta):
     assert int(alen.max()) > 0
 
 
-@pytest.mark.parametrize("M,H,scale,bias", [(2, 1280, 1.0, True), (20, 4096, 1.0, True), (59, 1280, 1.0, False), (120, 4096, 2.0, True)])
-def test_drafter_fc_mfma_vs_oracle(M, H, scale, bias):
+@pytest.mark.parametrize("M,H,scale,bias,packed", [(2, 1280, 1.0, True, False), (20, 4096, 1.0, True, False), (59, 1280, 1.0, False, False),
+                                                   (120, 4096, 2.0, True, False), (20, 4096, 2.0, True, True), (32, 1280, 1.0, False, True), (5, 64, 3.0, True, True)])
+def test_drafter_fc_mfma_vs_oracle(M, H, scale, bias, packed):
+    """O11 against the oracle: up to 32 rows run the stream-K kernel (row-major weight, or packed with `packed`), more rows the per-tile kernel."""
     rs = np.random.RandomState(M + H)
     vocab = 1000
     bf = lambda a: torch.from_numpy(a.astype(np.float32)).to(torch.bfloat16)
@@ -73,7 +75,8 @@ def test_drafter_fc_mfma_vs_oracle(M, H, scale, bias):
     W = bf(rs.standard_normal((H, 2 * H)) / np.sqrt(2 * H))
     b = bf(rs.standard_normal(H)) if bias else None
     ids = rs.randint(0, vocab, size=M)
-    out = ops.drafter_fc(dev(ids), hidden.cuda(), embed.cuda(), W.cuda(), None if b is None else b.cuda(), embed_scale=scale)
+    pk = ops.pack_linear_weight(W.cuda()) if packed else None
+    out = ops.drafter_fc(dev(ids), hidden.cuda(), embed.cuda(), W.cuda(), None if b is None else b.cuda(), embed_scale=scale, packed=pk)
     bits = lambda t: t.view(torch.int16).numpy().view(np.uint16)
     exp = oracle.drafter_fc(ids, bits(hidden), bits(embed), bits(W), None if b is None else bits(b), embed_scale=scale)
     got = out.float().cpu().numpy()
@@ -127,11 +130,14 @@ def test_vq_table_builder_llamagen_size():
     assert np.array_equal(packed[:, :1008], t[:, :1008])
 
 
+@pytest.mark.parametrize("form", ["streamk_packed", "streamk", "per_tile"])
 @pytest.mark.parametrize("n,K,special", [(10, 512, ""), (1, 256, ""), (10, 4096, ""), (10, 256, "newline"), (7, 128, "eos"), (16, 64, "few")])
-def test_head_expand_fused_equals_the_three_step_composition(n, K, special):
-    """8f-2: lantern_head_expand (head GEMM with the CFG combination as its epilogue -> per-row processors + log-softmax + top-k ->
-    best k of n*k) against lantern_linear_rows -> lantern_cfg_mask_topk -> lantern_expand_dynamic on the same inputs: token ids and
-    parent indices exact, cumulative scores to the last bit or two (the f64 sum of exponentials is taken in another order)."""
+def test_head_expand_fused_equals_the_three_step_composition(n, K, special, form):
+    """8f-2: lantern_head_expand[_streamk] (head GEMM with the CFG combination as its epilogue -> per-row processors + log-softmax + top-k ->
+    best k of n*k) against head GEMM -> lantern_cfg_mask_topk -> lantern_expand_dynamic on the same inputs: token ids and parent indices
+    exact, cumulative scores to the last bit or two (the f64 sum of exponentials is taken in another order).  The composition's GEMM is the
+    one with the fused form's accumulation order: lantern_linear_rows for the per-tile kernel, lantern_linear_rows_streamk (row-major or
+    packed weight) for the stream-K forms."""
     torch.manual_seed(100 * n + K)
     V, lo, W = 65536, 4, 8192
     A = (0.5 * torch.randn(2 * n, K, device="cuda")).to(torch.bfloat16)
@@ -148,10 +154,15 @@ def test_head_expand_fused_equals_the_three_step_composition(n, K, special):
         pos[1] = 2 + 49 * 48                               # forced end of image
     scores_in = torch.randn(n, device="cuda") if n > 1 else None
     tk = 2000 if special != "few" else 3
+    pk = ops.pack_linear_weight(Wt[lo:lo + W].contiguous()) if form == "streamk_packed" else None
     fused = ops.head_expand(A, Wt, lo, W, 3.0, bias=bias, model=ops.MODEL_LUMINA, pos_ids=pos, pos_base=2, top_k_filter=tk,
-                            scores_in=scores_in, top_k=10)
+                            scores_in=scores_in, top_k=10, packed=pk, streamk=form != "per_tile")
     buf = torch.zeros((2 * n, V), dtype=torch.bfloat16, device="cuda")
-    logits = ops.linear_rows(A, Wt, lo, W, bias=bias, out=buf)
+    if form == "per_tile":
+        logits = ops.linear_rows(A, Wt, lo, W, bias=bias, out=buf)
+    else:
+        buf[:, lo:lo + W] = ops.linear_rows_streamk(A, pk if pk is not None else Wt[lo:lo + W].contiguous(), bias=bias[lo:lo + W].contiguous())
+        logits = buf
     rows = ops.cfg_mask_topk(logits[:n], logits[n:], 3.0, model=ops.MODEL_LUMINA, pos_ids=pos, pos_base=2, img_lo=lo, img_hi=lo + W, top_k=tk)
     ref = ops.expand_dynamic(rows[None], None if scores_in is None else scores_in[None], 10)
     assert torch.equal(fused[0], ref[0]), (fused[0], ref[0])

@@ -277,3 +277,63 @@ def nodes_soak(n_seeds):
 
 if len(sys.argv) > 2 and sys.argv[2] == "nodes":
     nodes_soak(int(sys.argv[1]))
+
+
+# ---------------------------------------------------------------------------------------------- stream-K GEMM
+# `python tests/fuzz_soak.py <shapes> streamk`: lantern_linear_rows_streamk on random shapes (rows 1..32, K a multiple of 16 or 64, ragged column
+# counts, the three epilogues, row-major and packed weights), every shape launched `REPEAT` times back to back while a second stream keeps the
+# GPU busy with copies: every repeat must be BIT-identical to the first (the partial tiles of a split tile meet through device-coherent stores
+# and a counter: a visibility bug shows as a sporadic difference) and within the bf16 tolerance of the f64 product.
+def streamk_soak(n_shapes):
+    import numpy as np
+    import torch
+    from lantern_amd import ops
+    dev, bf = torch.device("cuda"), torch.bfloat16
+    rs = np.random.RandomState(4242)
+    REPEAT = 60
+    side = torch.cuda.Stream()
+    noise_a, noise_b = torch.empty(64 << 20, dtype=torch.uint8, device=dev), torch.empty(64 << 20, dtype=torch.uint8, device=dev)
+    fails = n = 0
+    t0 = time.time()
+    for it in range(n_shapes):
+        M = int(rs.randint(1, 33))
+        packed = bool(rs.randint(0, 2))
+        K = int(rs.randint(1, 180)) * (64 if packed else 16)
+        N = int(rs.choice([int(rs.randint(1, 300)), int(rs.randint(300, 13000)), 4096, 11008]))
+        epi = int(rs.randint(0, 3))
+        if (2 if epi == 2 else 1) * N * K > 120e6:
+            N = max(1, int(120e6 / K / (2 if epi == 2 else 1)))
+        gen = torch.Generator(device="cuda").manual_seed(it)
+        x = torch.randn(M, K, device=dev, dtype=bf, generator=gen)
+        rows = 2 * N if epi == 2 else N
+        w = (torch.randn(rows, K, device=dev, generator=gen) / K ** 0.5).to(bf)
+        b = (0.1 * torch.randn(rows, device=dev, generator=gen)).to(bf) if rs.rand() < 0.7 else None
+        res = torch.randn(M, N, device=dev, dtype=bf, generator=gen)
+        xd, wd = x.double(), w.double()
+        bd = b.double() if b is not None else torch.zeros(rows, dtype=torch.float64, device=dev)
+        if epi == 0:
+            want, kw = xd @ wd.T + bd, {}
+        elif epi == 1:
+            want, kw = (xd @ wd.T + bd) + res.double(), dict(residual=res)
+        else:
+            want, kw = torch.nn.functional.silu(xd @ wd[:N].T + bd[:N]) * (xd @ wd[N:].T + bd[N:]), dict(pair_rows=N)
+        wt = ops.pack_linear_weight(w, N if epi == 2 else 0) if packed else w
+        with torch.cuda.stream(side):
+            for _ in range(8):
+                noise_b.copy_(noise_a, non_blocking=True)
+        outs = [ops.linear_rows_streamk(x, wt, epi, bias=b, **kw) for _ in range(REPEAT)]
+        torch.cuda.synchronize()
+        scale = max(want.abs().max().item(), 1e-6)
+        bad = sum(int(not torch.equal(o, outs[0])) for o in outs[1:])
+        err = (outs[0].double() - want).abs().max().item() / scale
+        n += 1
+        if bad or err > 2e-2:
+            fails += 1
+            print("FAIL", dict(M=M, K=K, N=N, epi=epi, packed=packed, differing_repeats=bad, rel_err=err), flush=True)
+        if it % 25 == 24:
+            print(f"  shape {it}: fails={fails}, {time.time() - t0:.0f}s", flush=True)
+    print(f"streamk soak: shapes={n} x {REPEAT} launches, fails={fails}, {time.time() - t0:.0f}s")
+
+
+if len(sys.argv) > 2 and sys.argv[2] == "streamk":
+    streamk_soak(int(sys.argv[1]))

@@ -489,7 +489,7 @@ typedef const __attribute__((address_space(4))) EpwArgs *EpwArgsK;
 // FULLW: the window is exactly the workgroup's register tile (W == 4 * NT * E4, the Lumina / Anole 8192-id image range on
 // 512 x 4): no per-chunk bounds predicate, so the four chunks of a pass are one basic block and their LDS reads go out together.
 // RAW: rows are the target model's raw cond / uncond bf16 logits (LANTERN_ROWS_RAW_BF16; W == 8 * 2 * NT, packed table).
-template <int NT, int E4, int IDMODE, int WPE, bool FULLW = false, bool RAW = false>
+template <int NT, int E4, int IDMODE, int WPE, bool FULLW = false, bool RAW = false, int SPEC = 0>
 __device__ __forceinline__ int epw_body(const EpwArgs &args, const int b) {
     static_assert(!RAW || (FULLW && E4 == 4), "raw rows: the 8192-id window on 512 threads");
     constexpr bool LDSIDS = IDMODE != 0;
@@ -501,7 +501,7 @@ __device__ __forceinline__ int epw_body(const EpwArgs &args, const int b) {
     extern __shared__ float4 dyn_lds[];
     float *g = reinterpret_cast<float *>(dyn_lds);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int Ps = prm.P, Ds = prm.D, V = prm.V, W = win.win_len, lo = win.win_lo;
+    const int Ps = prm.P, Ds = prm.D, V = (SPEC == 1) ? 65536 : prm.V, W = (SPEC == 1) ? 8192 : win.win_len, lo = (SPEC == 1) ? 4 : win.win_lo;
     uint32_t *nbmask = reinterpret_cast<uint32_t *>(g + W + EW_G_EXT);  // W bits: neighbour set (static LlamaGen/Anole: zeroing hits q)
     EwShared &S = *reinterpret_cast<EwShared *>(reinterpret_cast<char *>(g) + epw_shared_offset(W));
     int *const Scand = reinterpret_cast<int *>(reinterpret_cast<char *>(&S) + sizeof(EwShared));
@@ -510,15 +510,27 @@ __device__ __forceinline__ int epw_body(const EpwArgs &args, const int b) {
     float *const Scart = reinterpret_cast<float *>(Sboff + pd_cap);
     int *const Sflag = reinterpret_cast<int *>(Scart + pd_cap);       // per (path, depth): bit 1 image token, bit 0 syntax token
     int *const Shist = Sflag + pd_cap;                                // RAW: the radix-select histograms of the row post-process
-    const int P = buf.n_paths ? buf.n_paths[b] : Ps;
-    const int D = buf.n_depth ? buf.n_depth[b] : Ds;
-    const int k = prm.k, off = prm.tok_offset;
-    const bool is_static = prm.mode != LANTERN_MODE_DYNAMIC;
+    const int k = prm.k, off = (SPEC == 1) ? 4 : prm.tok_offset;
+    // SPEC 1: the headline shape fixed at compile time -- Lumina static tree (LANTERN_MODE_STATIC_LUMINA), LANTERN on, syntax shortcut on
+    // with its four syntax tokens, one tree shape for all sequences: the mode / flag tests below fold away (and with them the scalar
+    // registers that carried them through the whole walk).  SPEC 0: everything from the argument block.
+    constexpr bool SL = SPEC == 1;
+    const int p_mode = SL ? (int)LANTERN_MODE_STATIC_LUMINA : prm.mode;
+    const bool p_lantern = SL ? true : prm.lantern != 0;
+    const bool p_syntax = SL ? true : prm.syntax_shortcut != 0;
+    const int p_nsyn = SL ? 4 : prm.n_syntax;
+    // (SPEC 1 also fixes the model's constants: Lumina-mGPT's vocabulary, image-token range = window, table offset and size, syntax ids --
+    // the host dispatches to this instance only when the argument block says exactly that)
+    const int p_img_lo = SL ? 4 : prm.img_lo, p_img_hi = SL ? 8196 : prm.img_hi, p_trows = SL ? 8192 : prm.table_rows;
+    auto p_syn = [&](int q) -> int { return SL ? (q == 0 ? 8196 : (q == 1 ? 8197 : (q == 2 ? 8803 : 8828))) : prm.syntax[q]; };
+    const bool is_static = SL ? true : p_mode != LANTERN_MODE_DYNAMIC;
+    const int P = (!SL && buf.n_paths) ? buf.n_paths[b] : Ps;
+    const int D = (!SL && buf.n_depth) ? buf.n_depth[b] : Ds;
     const float NEG_INF = -__builtin_inff();
     const int nz = (k + 1 < prm.table_cols) ? k + 1 : prm.table_cols;   // ids touched per candidate (k summed, k+1 zeroed)
-    const bool can_prefetch = LDSIDS && prm.lantern;
+    const bool can_prefetch = LDSIDS && p_lantern;
     const bool hot_in_lds = prm.rows_per_seq <= EW_MAX_N;
-    const bool rows_probs = win.rows_kind == LANTERN_ROWS_PROBS;
+    const bool rows_probs = (SL && !RAW) ? true : win.rows_kind == LANTERN_ROWS_PROBS;
     int ph = 0;
 #ifdef EPW_TRACE
     if (tid == 0) s_epw_trn = 0;
@@ -604,9 +616,9 @@ __device__ __forceinline__ int epw_body(const EpwArgs &args, const int b) {
             const int t = tid + u * NT;
             if (t < npd) {
                 const int tok = (int)c_[u];
-                int fl = (tok >= prm.img_lo && tok < prm.img_hi) ? 2 : 0;
-                if (prm.syntax_shortcut)
-                    for (int q = 0; q < prm.n_syntax; ++q) fl |= (tok == prm.syntax[q]) ? 1 : 0;
+                int fl = (tok >= p_img_lo && tok < p_img_hi) ? 2 : 0;
+                if (p_syntax)
+                    for (int q = 0; q < p_nsyn; ++q) fl |= (tok == p_syn(q)) ? 1 : 0;
                 Sflag[t] = fl;
                 Scand[t] = tok;
                 Srow[t] = r_[u];
@@ -720,7 +732,7 @@ __device__ __forceinline__ int epw_body(const EpwArgs &args, const int b) {
                 const int t0 = (ch % CH_PER_C) * 8;
                 const int x = c < EW_PF_C ? rdlane(xs_lane, c < EW_PF_C ? c : 0) : -1;
                 const int trow = x - off;
-                const bool lookup = c < ncand && trow >= 0 && trow < prm.table_rows && !(prm.syntax_shortcut && !(x >= prm.img_lo && x < prm.img_hi));
+                const bool lookup = c < ncand && trow >= 0 && trow < p_trows && !(p_syntax && !(x >= p_img_lo && x < p_img_hi));
                 idq[u] = make_uint4(0u, 0u, 0u, 0u);
                 if (lookup && t0 < nz)
                     idq[u] = *reinterpret_cast<const uint4 *>(buf.nn_table + (size_t)trow * prm.table_cols + t0);
@@ -734,7 +746,7 @@ __device__ __forceinline__ int epw_body(const EpwArgs &args, const int b) {
                 const int x = rdlane(x_lane, j);
                 td &= ~__ballot(have && x_lane == x);
                 const int trow = x - off;
-                const bool lookup = have && trow >= 0 && trow < prm.table_rows && !(prm.syntax_shortcut && !(x >= prm.img_lo && x < prm.img_hi));
+                const bool lookup = have && trow >= 0 && trow < p_trows && !(p_syntax && !(x >= p_img_lo && x < p_img_hi));
                 const uint16_t *nbp = buf.nn_table + (size_t)(lookup ? trow : 0) * prm.table_cols;
 #pragma unroll
                 for (int u = 0; u < PF_PER; ++u) {
@@ -819,7 +831,7 @@ __device__ __forceinline__ int epw_body(const EpwArgs &args, const int b) {
             const bool is_syn = (flags & 1) != 0;
             const int slot = cidx % EW_PF_C;
             const int trow = x - off;
-            const uint16_t *nb = (prm.lantern && trow >= 0 && trow < prm.table_rows) ? buf.nn_table + (size_t)trow * prm.table_cols : nullptr;
+            const uint16_t *nb = (p_lantern && trow >= 0 && trow < p_trows) ? buf.nn_table + (size_t)trow * prm.table_cols : nullptr;
             int *dec = S.dec[n_tried & 1];
             if (LDSIDS && can_prefetch && cidx >= EW_PF_C) {
                 // more unique candidates than prefetch slots (rare): stage this one's ids now, reusing a finished slot
@@ -857,11 +869,11 @@ __device__ __forceinline__ int epw_body(const EpwArgs &args, const int b) {
                 EPW_STAMPF(27);
                 float px = x_in ? g[x - lo] : (x == out_tok ? out_mass : 0.0f);
                 int code = 0, mflag = 0;
-                if (prm.syntax_shortcut && is_syn) {
+                if (p_syntax && is_syn) {
                     px = 1.0f;
-                } else if (prm.syntax_shortcut && !in_img) {
+                } else if (p_syntax && !in_img) {
                     px = 0.0f;
-                } else if (prm.lantern) {
+                } else if (p_lantern) {
                     if (nb == nullptr) {
                         code = 3;   // LANTERN_ST_TABLE_OOB
                     } else {
@@ -971,7 +983,7 @@ __device__ __forceinline__ int epw_body(const EpwArgs &args, const int b) {
             }
             // ------------------------------------------------ rejection: residual, all waves, all in LDS
             ++n_rej;
-            if (prm.syntax_shortcut && is_syn) {
+            if (p_syntax && is_syn) {
                 status = LANTERN_ST_SYNTAX_REJECT;
                 break;
             }
@@ -982,7 +994,7 @@ __device__ __forceinline__ int epw_body(const EpwArgs &args, const int b) {
                     q[it] = (FULLW || i4 * 4 < W) ? reinterpret_cast<const float4 *>(qsrc)[i4] : make_float4(0.f, 0.f, 0.f, 0.f);
                 }
             }
-            const bool zero_nb = prm.lantern && m > 0 && (!prm.syntax_shortcut || in_img);
+            const bool zero_nb = p_lantern && m > 0 && (!p_syntax || in_img);
             double loc = 0.0;
             float4 gn[E4];           // the unnormalised residual stays in registers until the sum is known
             if (!is_static) {
@@ -1021,7 +1033,7 @@ __device__ __forceinline__ int epw_body(const EpwArgs &args, const int b) {
                 int sib_r[4];
 #pragma unroll
                 for (int t = 0; t < 4; ++t) sib_r[t] = t < nsib ? sib_at(t) : -1;
-                const bool lg_nb = zero_nb && prm.mode == LANTERN_MODE_STATIC_LG;
+                const bool lg_nb = zero_nb && p_mode == LANTERN_MODE_STATIC_LG;
                 if (lg_nb) {
                     for (int t = tid; t < (W + 31) / 32; t += NT) nbmask[t] = 0u;
                     __syncthreads();
@@ -1030,7 +1042,7 @@ __device__ __forceinline__ int epw_body(const EpwArgs &args, const int b) {
                         if (id >= 0 && id < W) atomicOr(&nbmask[id >> 5], 1u << (id & 31));
                     }
                 }
-                if (zero_nb && prm.mode == LANTERN_MODE_STATIC_LUMINA)
+                if (zero_nb && p_mode == LANTERN_MODE_STATIC_LUMINA)
                     for (int t = tid; t < nz; t += NT) {
                         const int id = (int)(LDSIDS ? S.nbid[slot][t] : nb[t]) + off - lo;
                         if (id >= 0 && id < W) g[id] = 0.0f;
@@ -1263,9 +1275,9 @@ __device__ __forceinline__ int epw_body(const EpwArgs &args, const int b) {
     return (best << 8) | a;          // the verdict (uniform): best path, rows kept = accept_len + 1
 }
 
-template <int NT, int E4, int IDMODE, int WPE, bool FULLW = false, bool RAW = false>
+template <int NT, int E4, int IDMODE, int WPE, bool FULLW = false, bool RAW = false, int SPEC = 0>
 __global__ __launch_bounds__(NT, WPE) void epw_kernel(const EpwArgs args) {
-    epw_body<NT, E4, IDMODE, WPE, FULLW, RAW>(args, blockIdx.x);
+    epw_body<NT, E4, IDMODE, WPE, FULLW, RAW, SPEC>(args, blockIdx.x);
 }
 
 __global__ void window_to_dense_kernel(const float *__restrict__ winp, const int32_t *__restrict__ out_tok,
@@ -1478,6 +1490,12 @@ extern "C" int lantern_evaluate_posterior_window(const lantern_ep_params *prm, c
         else LANTERN_LAUNCH((epw_kernel<NT_, E4_, 0, WPE_>), grid, dim3(NT_), lds, st, args);                              \
     } while (0)
 #define EPW_LAUNCH(NT_, E4_) EPW_LAUNCH_W(NT_, E4_, 1)
+    // the headline shape gets its own instance (SPEC 1: mode / LANTERN / syntax-shortcut flags are compile-time constants there)
+    static const int spec_knob = getenv("LANTERN_EPW_SPEC") ? atoi(getenv("LANTERN_EPW_SPEC")) : 1;   // tuning knob (diagnostic): 0 = the generic instance
+    const bool lumina_static = spec_knob != 0 && p.mode == LANTERN_MODE_STATIC_LUMINA && p.lantern && p.syntax_shortcut && p.n_syntax == 4 &&
+                               p.syntax[0] == 8196 && p.syntax[1] == 8197 && p.syntax[2] == 8803 && p.syntax[3] == 8828 && p.V == 65536 &&
+                               p.img_lo == 4 && p.img_hi == 8196 && p.tok_offset == 4 && p.table_rows == 8192 && win->win_lo == 4 && W == 8192 &&
+                               !buf->n_paths && !buf->n_depth && (raw || win->rows_kind == LANTERN_ROWS_PROBS);
     static const int occ_knob = getenv("LANTERN_EPW_OCC2") ? atoi(getenv("LANTERN_EPW_OCC2")) : -1;   // tuning knob (diagnostic)
     const bool two_per_cu = occ_knob >= 0 ? occ_knob != 0 : p.B > 256;
     if (W <= 1024) EPW_LAUNCH(256, 1);
@@ -1485,15 +1503,14 @@ extern "C" int lantern_evaluate_posterior_window(const lantern_ep_params *prm, c
     else if (W <= 4096) EPW_LAUNCH(512, 2);
     else if (raw) {
         if (two_per_cu) LANTERN_LAUNCH((epw_kernel<512, 4, 2, 4, true, true>), grid, dim3(512), lds, st, args);
+        else if (lumina_static) LANTERN_LAUNCH((epw_kernel<512, 4, 2, 1, true, true, 1>), grid, dim3(512), lds, st, args);
         else LANTERN_LAUNCH((epw_kernel<512, 4, 2, 1, true, true>), grid, dim3(512), lds, st, args);
     }
     else if (W <= 8192) {
         if (two_per_cu && W == 8192 && idmode == 2) LANTERN_LAUNCH((epw_kernel<512, 4, 2, 4, true>), grid, dim3(512), lds, st, args);
         else if (two_per_cu) EPW_LAUNCH_W(512, 4, 4);
         else if (W == 8192 && idmode == 2) {
-            static const int nt_knob = getenv("LANTERN_EPW_NT") ? atoi(getenv("LANTERN_EPW_NT")) : 0;   // tuning knob (diagnostic)
-            if (nt_knob == 256) LANTERN_LAUNCH((epw_kernel<256, 8, 2, 1, true>), grid, dim3(256), lds, st, args);
-            else if (nt_knob == 1024) LANTERN_LAUNCH((epw_kernel<1024, 2, 2, 1, true>), grid, dim3(1024), lds, st, args);
+            if (lumina_static) LANTERN_LAUNCH((epw_kernel<512, 4, 2, 1, true, false, 1>), grid, dim3(512), lds, st, args);
             else LANTERN_LAUNCH((epw_kernel<512, 4, 2, 1, true>), grid, dim3(512), lds, st, args);   // the Lumina / Anole image window on the packed table
         }
         else EPW_LAUNCH(512, 4);

@@ -501,7 +501,8 @@ __device__ __forceinline__ int epw_body(const EpwArgs &args, const int b) {
     extern __shared__ float4 dyn_lds[];
     float *g = reinterpret_cast<float *>(dyn_lds);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int Ps = prm.P, Ds = prm.D, V = (SPEC == 1) ? 65536 : prm.V, W = (SPEC == 1) ? 8192 : win.win_len, lo = (SPEC == 1) ? 4 : win.win_lo;
+    // SPEC 2 = SPEC 1 + the reference's default Lumina tree (mc_sim_7b_63: 26 nodes, 15 paths of depth <= 6; run.sh / generate_images.py)
+    const int Ps = (SPEC == 2) ? 15 : prm.P, Ds = (SPEC == 2) ? 6 : prm.D, V = (SPEC >= 1) ? 65536 : prm.V, W = (SPEC >= 1) ? 8192 : win.win_len, lo = (SPEC >= 1) ? 4 : win.win_lo;
     uint32_t *nbmask = reinterpret_cast<uint32_t *>(g + W + EW_G_EXT);  // W bits: neighbour set (static LlamaGen/Anole: zeroing hits q)
     EwShared &S = *reinterpret_cast<EwShared *>(reinterpret_cast<char *>(g) + epw_shared_offset(W));
     int *const Scand = reinterpret_cast<int *>(reinterpret_cast<char *>(&S) + sizeof(EwShared));
@@ -510,15 +511,16 @@ __device__ __forceinline__ int epw_body(const EpwArgs &args, const int b) {
     float *const Scart = reinterpret_cast<float *>(Sboff + pd_cap);
     int *const Sflag = reinterpret_cast<int *>(Scart + pd_cap);       // per (path, depth): bit 1 image token, bit 0 syntax token
     int *const Shist = Sflag + pd_cap;                                // RAW: the radix-select histograms of the row post-process
-    const int k = prm.k, off = (SPEC == 1) ? 4 : prm.tok_offset;
+    const int k = prm.k, off = (SPEC >= 1) ? 4 : prm.tok_offset;
     // SPEC 1: the headline shape fixed at compile time -- Lumina static tree (LANTERN_MODE_STATIC_LUMINA), LANTERN on, syntax shortcut on
     // with its four syntax tokens, one tree shape for all sequences: the mode / flag tests below fold away (and with them the scalar
     // registers that carried them through the whole walk).  SPEC 0: everything from the argument block.
-    constexpr bool SL = SPEC == 1;
+    constexpr bool SL = SPEC >= 1;
     const int p_mode = SL ? (int)LANTERN_MODE_STATIC_LUMINA : prm.mode;
     const bool p_lantern = SL ? true : prm.lantern != 0;
     const bool p_syntax = SL ? true : prm.syntax_shortcut != 0;
     const int p_nsyn = SL ? 4 : prm.n_syntax;
+    const int p_rows = (SPEC == 2) ? 26 : prm.rows_per_seq, p_N = (SPEC == 2) ? 26 : prm.N;
     // (SPEC 1 also fixes the model's constants: Lumina-mGPT's vocabulary, image-token range = window, table offset and size, syntax ids --
     // the host dispatches to this instance only when the argument block says exactly that)
     const int p_img_lo = SL ? 4 : prm.img_lo, p_img_hi = SL ? 8196 : prm.img_hi, p_trows = SL ? 8192 : prm.table_rows;
@@ -528,8 +530,8 @@ __device__ __forceinline__ int epw_body(const EpwArgs &args, const int b) {
     const int D = (!SL && buf.n_depth) ? buf.n_depth[b] : Ds;
     const float NEG_INF = -__builtin_inff();
     const int nz = (k + 1 < prm.table_cols) ? k + 1 : prm.table_cols;   // ids touched per candidate (k summed, k+1 zeroed)
-    const bool can_prefetch = LDSIDS && p_lantern;
-    const bool hot_in_lds = prm.rows_per_seq <= EW_MAX_N;
+    const bool can_prefetch = LDSIDS && p_lantern;          // (SPEC 1: true at compile time)
+    const bool hot_in_lds = SL ? true : p_rows <= EW_MAX_N;
     const bool rows_probs = (SL && !RAW) ? true : win.rows_kind == LANTERN_ROWS_PROBS;
     int ph = 0;
 #ifdef EPW_TRACE
@@ -539,13 +541,13 @@ __device__ __forceinline__ int epw_body(const EpwArgs &args, const int b) {
 
     // ---- stage every small per-step table in LDS: two rounds of global loads (everything independent first, then what
     // needs the uniform cursor / the sibling count / the first row id), all issued before the first wait
-    const float *logits = buf.logits + (size_t)b * prm.rows_per_seq * W;
-    const uint16_t *raw_c = RAW ? reinterpret_cast<const uint16_t *>(buf.logits) + (size_t)b * prm.rows_per_seq * V + lo : nullptr;
-    const uint16_t *raw_u = RAW ? reinterpret_cast<const uint16_t *>(win.raw_uncond) + (size_t)b * prm.rows_per_seq * V + lo : nullptr;
-    const float *raw_p = (RAW && win.raw_probs) ? win.raw_probs + (size_t)b * prm.rows_per_seq * W : nullptr;
+    const float *logits = buf.logits + (size_t)b * p_rows * W;
+    const uint16_t *raw_c = RAW ? reinterpret_cast<const uint16_t *>(buf.logits) + (size_t)b * p_rows * V + lo : nullptr;
+    const uint16_t *raw_u = RAW ? reinterpret_cast<const uint16_t *>(win.raw_uncond) + (size_t)b * p_rows * V + lo : nullptr;
+    const float *raw_p = (RAW && win.raw_probs) ? win.raw_probs + (size_t)b * p_rows * W : nullptr;
     const bool root_pre = RAW && raw_p && win.raw_pre && win.raw_pre[0] != 0;     // (the level-1 row is requested before the tables are staged)
     bool rp_probs = false;       // what rp holds: probabilities of a pre-processed row, or raw cond / uncond chunks
-    const int32_t *hot_g = win.row_hot ? win.row_hot + (size_t)b * prm.rows_per_seq : nullptr;
+    const int32_t *hot_g = win.row_hot ? win.row_hot + (size_t)b * p_rows : nullptr;
     const int ucur0 = buf.cursor ? buf.cursor[b] : 0;
     float4 rp[E4];              // prefetched row (registers) and the row id it holds
     int rp_rid = -1;
@@ -572,21 +574,24 @@ __device__ __forceinline__ int epw_body(const EpwArgs &args, const int b) {
 #pragma unroll
         for (int u = 0; u < N_PER; ++u) {
             const int t = tid + u * NT;
-            tc_[u] = (is_static && t < prm.N && t < EW_MAX_N) ? (int)buf.tree_cand[(size_t)b * prm.N + t] : 0;
-            hot_[u] = (hot_g && hot_in_lds && t < prm.rows_per_seq) ? hot_g[t] : -1;
-            if (RAW && t < prm.rows_per_seq) {
+            tc_[u] = (is_static && t < p_N && t < EW_MAX_N) ? (int)buf.tree_cand[(size_t)b * p_N + t] : 0;
+            hot_[u] = (hot_g && hot_in_lds && t < p_rows) ? hot_g[t] : -1;
+            if (RAW && t < p_rows) {
                 // raw_pre[t] = 1 + the depth the row was prepared for; with per-sequence trees the node has to sit there (its position says so)
                 int pre = (win.raw_pre && win.raw_probs) ? (int)win.raw_pre[t] : 0;
-                if (pre && win.raw_pos_per_seq) {
-                    const int64_t *pp = win.raw_pos_ids + (size_t)b * prm.rows_per_seq;
+                if (pre && (SL ? 0 : win.raw_pos_per_seq)) {
+                    const int64_t *pp = win.raw_pos_ids + (size_t)b * p_rows;
                     if (pp[t] - pp[0] != pre - 1) pre = 0;
                 }
                 S.pre[t] = pre;
             }
-            if (RAW && t < prm.rows_per_seq) {          // the row's class from its position (MultiModalLogitsProcessor, ea_model_lumina_mgpt.py:45-86)
-                const int64_t n1 = (win.raw_pos_per_seq ? win.raw_pos_ids[(size_t)b * prm.rows_per_seq + t] : win.raw_pos_ids[t] + win.raw_seq_len[b]) - win.raw_pos_base + 1;
-                hot_[u] = (n1 == ((int64_t)win.raw_w_latent + 1) * win.raw_h_latent + 1) ? win.raw_eos_id
-                          : (py_mod64(n1, (int64_t)win.raw_w_latent + 1) == 0 ? win.raw_newline_id : -1);
+            if (RAW && t < p_rows) {          // the row's class from its position (MultiModalLogitsProcessor, ea_model_lumina_mgpt.py:45-86)
+                const int64_t n1 = ((SL ? 0 : win.raw_pos_per_seq) ? win.raw_pos_ids[(size_t)b * p_rows + t] : win.raw_pos_ids[t] + win.raw_seq_len[b]) - win.raw_pos_base + 1;
+                // (a 64-bit modulo is ~150 instructions: the 32-bit form whenever the operands fit -- always, for real image sizes)
+                const bool fits = n1 >= 0 && n1 < (1ll << 31) && win.raw_w_latent >= 0 && win.raw_w_latent < (1 << 30);
+                const bool nl = (fits ? ((uint32_t)n1 % (uint32_t)(win.raw_w_latent + 1)) == 0u : py_mod64(n1, (int64_t)win.raw_w_latent + 1) == 0);
+                hot_[u] = (n1 == ((int64_t)win.raw_w_latent + 1) * win.raw_h_latent + 1) ? (SL ? 8196 : win.raw_eos_id)
+                          : (nl ? (SL ? 8803 : win.raw_newline_id) : -1);
             }
         }
         if (is_static && tid < Ds - 1) oo_ = buf.op_off[tid];
@@ -602,7 +607,7 @@ __device__ __forceinline__ int epw_body(const EpwArgs &args, const int b) {
             const int t = tid + u * NT;
             bi_[u] = (t < nb_total && t < EW_MAX_B) ? buf.b_idx[t] : 0;
         }
-        if (rid1 >= 0 && rid1 < prm.rows_per_seq) {
+        if (rid1 >= 0 && rid1 < p_rows) {
             if constexpr (RAW) {
                 rp_probs = root_pre && rid1 == 0;
                 if (rp_probs) row_load<NT, E4, FULLW>(raw_p + (size_t)rid1 * W, W, rp);
@@ -639,7 +644,7 @@ __device__ __forceinline__ int epw_body(const EpwArgs &args, const int b) {
 #pragma unroll
             for (int u = 0; u < N_PER; ++u) {
                 const int t = tid + u * NT;
-                if (t < prm.N && t < EW_MAX_N) S.tcand[t] = tc_[u];
+                if (t < p_N && t < EW_MAX_N) S.tcand[t] = tc_[u];
             }
             if (tid < Ds - 1) S.opoff[tid] = oo_;
         }
@@ -647,7 +652,7 @@ __device__ __forceinline__ int epw_body(const EpwArgs &args, const int b) {
 #pragma unroll
             for (int u = 0; u < N_PER; ++u) {
                 const int t = tid + u * NT;
-                if (t < prm.rows_per_seq) S.hot[t] = hot_[u];
+                if (t < p_rows) S.hot[t] = hot_[u];
             }
         }
         if (tid < EW_UNI) S.uni[tid] = un_;
@@ -758,7 +763,7 @@ __device__ __forceinline__ int epw_body(const EpwArgs &args, const int b) {
         }
         {
             int rid = Srow[fi * Ds + (i - 1)];
-            rid = rid < 0 ? 0 : (rid >= prm.rows_per_seq ? prm.rows_per_seq - 1 : rid);     // a bad row map must not read outside the batch
+            rid = rid < 0 ? 0 : (rid >= p_rows ? p_rows - 1 : rid);     // a bad row map must not read outside the batch
             const int hot = RAW ? S.hot[rid] : (!hot_g ? -1 : (hot_in_lds ? S.hot[rid] : hot_g[rid]));
             EPW_STAMP(10);
             if (hot < 0 && rp_rid != rid) {
@@ -1134,7 +1139,7 @@ __device__ __forceinline__ int epw_body(const EpwArgs &args, const int b) {
     const int from_residual = (adjust && a != D) ? 1 : 0;
     if (status == LANTERN_ST_OK && !from_residual) {
         int rid = Srow[best * Ds + (a - 1)];
-        rid = rid < 0 ? 0 : (rid >= prm.rows_per_seq ? prm.rows_per_seq - 1 : rid);
+        rid = rid < 0 ? 0 : (rid >= p_rows ? p_rows - 1 : rid);
         const int hot = RAW ? S.hot[rid] : (!hot_g ? -1 : (hot_in_lds ? S.hot[rid] : hot_g[rid]));
         if (hot < 0 && rp_rid != rid) {
             if constexpr (RAW) {
@@ -1491,11 +1496,13 @@ extern "C" int lantern_evaluate_posterior_window(const lantern_ep_params *prm, c
     } while (0)
 #define EPW_LAUNCH(NT_, E4_) EPW_LAUNCH_W(NT_, E4_, 1)
     // the headline shape gets its own instance (SPEC 1: mode / LANTERN / syntax-shortcut flags are compile-time constants there)
-    static const int spec_knob = getenv("LANTERN_EPW_SPEC") ? atoi(getenv("LANTERN_EPW_SPEC")) : 1;   // tuning knob (diagnostic): 0 = the generic instance
+    static const int spec_knob = getenv("LANTERN_EPW_SPEC") ? atoi(getenv("LANTERN_EPW_SPEC")) : 2;   // tuning knob (diagnostic): 0 = the generic instance, 1 = no fixed tree
     const bool lumina_static = spec_knob != 0 && p.mode == LANTERN_MODE_STATIC_LUMINA && p.lantern && p.syntax_shortcut && p.n_syntax == 4 &&
                                p.syntax[0] == 8196 && p.syntax[1] == 8197 && p.syntax[2] == 8803 && p.syntax[3] == 8828 && p.V == 65536 &&
-                               p.img_lo == 4 && p.img_hi == 8196 && p.tok_offset == 4 && p.table_rows == 8192 && win->win_lo == 4 && W == 8192 &&
+                               p.img_lo == 4 && p.img_hi == 8196 && p.tok_offset == 4 && p.table_rows == 8192 && win->win_lo == 4 && W == 8192 && p.rows_per_seq <= EW_MAX_N &&
+                               (!raw || (win->raw_eos_id == 8196 && win->raw_newline_id == 8803 && !win->raw_pos_per_seq)) &&
                                !buf->n_paths && !buf->n_depth && (raw || win->rows_kind == LANTERN_ROWS_PROBS);
+    const bool default_tree = spec_knob >= 2 && p.P == 15 && p.D == 6 && p.N == 26 && p.rows_per_seq == 26;
     static const int occ_knob = getenv("LANTERN_EPW_OCC2") ? atoi(getenv("LANTERN_EPW_OCC2")) : -1;   // tuning knob (diagnostic)
     const bool two_per_cu = occ_knob >= 0 ? occ_knob != 0 : p.B > 256;
     if (W <= 1024) EPW_LAUNCH(256, 1);
@@ -1503,6 +1510,7 @@ extern "C" int lantern_evaluate_posterior_window(const lantern_ep_params *prm, c
     else if (W <= 4096) EPW_LAUNCH(512, 2);
     else if (raw) {
         if (two_per_cu) LANTERN_LAUNCH((epw_kernel<512, 4, 2, 4, true, true>), grid, dim3(512), lds, st, args);
+        else if (lumina_static && default_tree) LANTERN_LAUNCH((epw_kernel<512, 4, 2, 1, true, true, 2>), grid, dim3(512), lds, st, args);
         else if (lumina_static) LANTERN_LAUNCH((epw_kernel<512, 4, 2, 1, true, true, 1>), grid, dim3(512), lds, st, args);
         else LANTERN_LAUNCH((epw_kernel<512, 4, 2, 1, true, true>), grid, dim3(512), lds, st, args);
     }
@@ -1510,7 +1518,8 @@ extern "C" int lantern_evaluate_posterior_window(const lantern_ep_params *prm, c
         if (two_per_cu && W == 8192 && idmode == 2) LANTERN_LAUNCH((epw_kernel<512, 4, 2, 4, true>), grid, dim3(512), lds, st, args);
         else if (two_per_cu) EPW_LAUNCH_W(512, 4, 4);
         else if (W == 8192 && idmode == 2) {
-            if (lumina_static) LANTERN_LAUNCH((epw_kernel<512, 4, 2, 1, true, false, 1>), grid, dim3(512), lds, st, args);
+            if (lumina_static && default_tree) LANTERN_LAUNCH((epw_kernel<512, 4, 2, 1, true, false, 2>), grid, dim3(512), lds, st, args);
+            else if (lumina_static) LANTERN_LAUNCH((epw_kernel<512, 4, 2, 1, true, false, 1>), grid, dim3(512), lds, st, args);
             else LANTERN_LAUNCH((epw_kernel<512, 4, 2, 1, true>), grid, dim3(512), lds, st, args);   // the Lumina / Anole image window on the packed table
         }
         else EPW_LAUNCH(512, 4);

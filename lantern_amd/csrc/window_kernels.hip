@@ -501,8 +501,17 @@ __device__ __forceinline__ int epw_body(const EpwArgs &args, const int b) {
     extern __shared__ float4 dyn_lds[];
     float *g = reinterpret_cast<float *>(dyn_lds);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    // SPEC 2 = SPEC 1 + the reference's default Lumina tree (mc_sim_7b_63: 26 nodes, 15 paths of depth <= 6; run.sh / generate_images.py)
-    const int Ps = (SPEC == 2) ? 15 : prm.P, Ds = (SPEC == 2) ? 6 : prm.D, V = (SPEC >= 1) ? 65536 : prm.V, W = (SPEC >= 1) ? 8192 : win.win_len, lo = (SPEC >= 1) ? 4 : win.win_lo;
+    // Compile-time instances of the reference's configurations (SPEC 0: everything from the argument block).  They all share the Chameleon
+    // vocabulary of Lumina-mGPT / Anole (V = 65536, image ids = window = [4, 8196), table offset 4, 8192 table rows):
+    //   1  Lumina static tree (LANTERN_MODE_STATIC_LUMINA), LANTERN on, syntax shortcut with Lumina's four syntax ids
+    //   2  = 1 + the reference's default Lumina tree mc_sim_7b_63 (26 nodes, 15 paths of depth <= 6; run.sh / generate_images.py)
+    //   3  Lumina dynamic (EAGLE-2) trees: LANTERN_MODE_DYNAMIC, LANTERN on, syntax shortcut, per-sequence paths / depths / positions
+    //   4  Anole static tree (LANTERN_MODE_STATIC_LG: the neighbour set zeroes q), LANTERN on, no syntax shortcut
+    // The mode / flag tests below fold away, and with them the scalar registers that carried them through the whole walk; the host
+    // dispatches to an instance only when the argument block says exactly that.
+    constexpr bool SL = SPEC >= 1;                               // one of the fixed configurations
+    constexpr bool S_STATIC = SPEC == 1 || SPEC == 2 || SPEC == 4, S_DYN = SPEC == 3, S_SYN = SPEC >= 1 && SPEC <= 3;
+    const int Ps = (SPEC == 2) ? 15 : prm.P, Ds = (SPEC == 2) ? 6 : prm.D, V = SL ? 65536 : prm.V, W = SL ? 8192 : win.win_len, lo = SL ? 4 : win.win_lo;
     uint32_t *nbmask = reinterpret_cast<uint32_t *>(g + W + EW_G_EXT);  // W bits: neighbour set (static LlamaGen/Anole: zeroing hits q)
     EwShared &S = *reinterpret_cast<EwShared *>(reinterpret_cast<char *>(g) + epw_shared_offset(W));
     int *const Scand = reinterpret_cast<int *>(reinterpret_cast<char *>(&S) + sizeof(EwShared));
@@ -511,23 +520,17 @@ __device__ __forceinline__ int epw_body(const EpwArgs &args, const int b) {
     float *const Scart = reinterpret_cast<float *>(Sboff + pd_cap);
     int *const Sflag = reinterpret_cast<int *>(Scart + pd_cap);       // per (path, depth): bit 1 image token, bit 0 syntax token
     int *const Shist = Sflag + pd_cap;                                // RAW: the radix-select histograms of the row post-process
-    const int k = prm.k, off = (SPEC >= 1) ? 4 : prm.tok_offset;
-    // SPEC 1: the headline shape fixed at compile time -- Lumina static tree (LANTERN_MODE_STATIC_LUMINA), LANTERN on, syntax shortcut on
-    // with its four syntax tokens, one tree shape for all sequences: the mode / flag tests below fold away (and with them the scalar
-    // registers that carried them through the whole walk).  SPEC 0: everything from the argument block.
-    constexpr bool SL = SPEC >= 1;
-    const int p_mode = SL ? (int)LANTERN_MODE_STATIC_LUMINA : prm.mode;
+    const int k = prm.k, off = SL ? 4 : prm.tok_offset;
+    const int p_mode = !SL ? prm.mode : (SPEC == 4 ? (int)LANTERN_MODE_STATIC_LG : (S_DYN ? (int)LANTERN_MODE_DYNAMIC : (int)LANTERN_MODE_STATIC_LUMINA));
     const bool p_lantern = SL ? true : prm.lantern != 0;
-    const bool p_syntax = SL ? true : prm.syntax_shortcut != 0;
-    const int p_nsyn = SL ? 4 : prm.n_syntax;
+    const bool p_syntax = SL ? S_SYN : prm.syntax_shortcut != 0;
+    const int p_nsyn = SL ? (S_SYN ? 4 : 0) : prm.n_syntax;
     const int p_rows = (SPEC == 2) ? 26 : prm.rows_per_seq, p_N = (SPEC == 2) ? 26 : prm.N;
-    // (SPEC 1 also fixes the model's constants: Lumina-mGPT's vocabulary, image-token range = window, table offset and size, syntax ids --
-    // the host dispatches to this instance only when the argument block says exactly that)
     const int p_img_lo = SL ? 4 : prm.img_lo, p_img_hi = SL ? 8196 : prm.img_hi, p_trows = SL ? 8192 : prm.table_rows;
     auto p_syn = [&](int q) -> int { return SL ? (q == 0 ? 8196 : (q == 1 ? 8197 : (q == 2 ? 8803 : 8828))) : prm.syntax[q]; };
-    const bool is_static = SL ? true : p_mode != LANTERN_MODE_DYNAMIC;
-    const int P = (!SL && buf.n_paths) ? buf.n_paths[b] : Ps;
-    const int D = (!SL && buf.n_depth) ? buf.n_depth[b] : Ds;
+    const bool is_static = SL ? S_STATIC : p_mode != LANTERN_MODE_DYNAMIC;
+    const int P = S_DYN ? buf.n_paths[b] : ((!SL && buf.n_paths) ? buf.n_paths[b] : Ps);
+    const int D = S_DYN ? buf.n_depth[b] : ((!SL && buf.n_depth) ? buf.n_depth[b] : Ds);
     const float NEG_INF = -__builtin_inff();
     const int nz = (k + 1 < prm.table_cols) ? k + 1 : prm.table_cols;   // ids touched per candidate (k summed, k+1 zeroed)
     const bool can_prefetch = LDSIDS && p_lantern;          // (SPEC 1: true at compile time)
@@ -579,14 +582,14 @@ __device__ __forceinline__ int epw_body(const EpwArgs &args, const int b) {
             if (RAW && t < p_rows) {
                 // raw_pre[t] = 1 + the depth the row was prepared for; with per-sequence trees the node has to sit there (its position says so)
                 int pre = (win.raw_pre && win.raw_probs) ? (int)win.raw_pre[t] : 0;
-                if (pre && (SL ? 0 : win.raw_pos_per_seq)) {
+                if (pre && (SL ? (int)S_DYN : win.raw_pos_per_seq)) {
                     const int64_t *pp = win.raw_pos_ids + (size_t)b * p_rows;
                     if (pp[t] - pp[0] != pre - 1) pre = 0;
                 }
                 S.pre[t] = pre;
             }
             if (RAW && t < p_rows) {          // the row's class from its position (MultiModalLogitsProcessor, ea_model_lumina_mgpt.py:45-86)
-                const int64_t n1 = ((SL ? 0 : win.raw_pos_per_seq) ? win.raw_pos_ids[(size_t)b * p_rows + t] : win.raw_pos_ids[t] + win.raw_seq_len[b]) - win.raw_pos_base + 1;
+                const int64_t n1 = ((SL ? (int)S_DYN : win.raw_pos_per_seq) ? win.raw_pos_ids[(size_t)b * p_rows + t] : win.raw_pos_ids[t] + win.raw_seq_len[b]) - win.raw_pos_base + 1;
                 // (a 64-bit modulo is ~150 instructions: the 32-bit form whenever the operands fit -- always, for real image sizes)
                 const bool fits = n1 >= 0 && n1 < (1ll << 31) && win.raw_w_latent >= 0 && win.raw_w_latent < (1 << 30);
                 const bool nl = (fits ? ((uint32_t)n1 % (uint32_t)(win.raw_w_latent + 1)) == 0u : py_mod64(n1, (int64_t)win.raw_w_latent + 1) == 0);
@@ -1497,11 +1500,13 @@ extern "C" int lantern_evaluate_posterior_window(const lantern_ep_params *prm, c
 #define EPW_LAUNCH(NT_, E4_) EPW_LAUNCH_W(NT_, E4_, 1)
     // the headline shape gets its own instance (SPEC 1: mode / LANTERN / syntax-shortcut flags are compile-time constants there)
     static const int spec_knob = getenv("LANTERN_EPW_SPEC") ? atoi(getenv("LANTERN_EPW_SPEC")) : 2;   // tuning knob (diagnostic): 0 = the generic instance, 1 = no fixed tree
-    const bool lumina_static = spec_knob != 0 && p.mode == LANTERN_MODE_STATIC_LUMINA && p.lantern && p.syntax_shortcut && p.n_syntax == 4 &&
-                               p.syntax[0] == 8196 && p.syntax[1] == 8197 && p.syntax[2] == 8803 && p.syntax[3] == 8828 && p.V == 65536 &&
-                               p.img_lo == 4 && p.img_hi == 8196 && p.tok_offset == 4 && p.table_rows == 8192 && win->win_lo == 4 && W == 8192 && p.rows_per_seq <= EW_MAX_N &&
-                               (!raw || (win->raw_eos_id == 8196 && win->raw_newline_id == 8803 && !win->raw_pos_per_seq)) &&
-                               !buf->n_paths && !buf->n_depth && (raw || win->rows_kind == LANTERN_ROWS_PROBS);
+    const bool chameleon = spec_knob != 0 && p.lantern && p.V == 65536 && p.img_lo == 4 && p.img_hi == 8196 && p.tok_offset == 4 && p.table_rows == 8192 &&
+                           win->win_lo == 4 && W == 8192 && p.rows_per_seq <= EW_MAX_N && (raw || win->rows_kind == LANTERN_ROWS_PROBS) &&
+                           (!raw || (win->raw_eos_id == 8196 && win->raw_newline_id == 8803));
+    const bool lumina_syntax = p.syntax_shortcut && p.n_syntax == 4 && p.syntax[0] == 8196 && p.syntax[1] == 8197 && p.syntax[2] == 8803 && p.syntax[3] == 8828;
+    const bool lumina_static = chameleon && p.mode == LANTERN_MODE_STATIC_LUMINA && lumina_syntax && !buf->n_paths && !buf->n_depth && (!raw || !win->raw_pos_per_seq);
+    const bool lumina_dynamic = chameleon && p.mode == LANTERN_MODE_DYNAMIC && lumina_syntax && buf->n_paths && buf->n_depth && (!raw || win->raw_pos_per_seq);
+    const bool anole_static = chameleon && p.mode == LANTERN_MODE_STATIC_LG && !p.syntax_shortcut && !buf->n_paths && !buf->n_depth && !raw;
     const bool default_tree = spec_knob >= 2 && p.P == 15 && p.D == 6 && p.N == 26 && p.rows_per_seq == 26;
     static const int occ_knob = getenv("LANTERN_EPW_OCC2") ? atoi(getenv("LANTERN_EPW_OCC2")) : -1;   // tuning knob (diagnostic)
     const bool two_per_cu = occ_knob >= 0 ? occ_knob != 0 : p.B > 256;
@@ -1512,6 +1517,7 @@ extern "C" int lantern_evaluate_posterior_window(const lantern_ep_params *prm, c
         if (two_per_cu) LANTERN_LAUNCH((epw_kernel<512, 4, 2, 4, true, true>), grid, dim3(512), lds, st, args);
         else if (lumina_static && default_tree) LANTERN_LAUNCH((epw_kernel<512, 4, 2, 1, true, true, 2>), grid, dim3(512), lds, st, args);
         else if (lumina_static) LANTERN_LAUNCH((epw_kernel<512, 4, 2, 1, true, true, 1>), grid, dim3(512), lds, st, args);
+        else if (lumina_dynamic) LANTERN_LAUNCH((epw_kernel<512, 4, 2, 1, true, true, 3>), grid, dim3(512), lds, st, args);
         else LANTERN_LAUNCH((epw_kernel<512, 4, 2, 1, true, true>), grid, dim3(512), lds, st, args);
     }
     else if (W <= 8192) {
@@ -1520,6 +1526,8 @@ extern "C" int lantern_evaluate_posterior_window(const lantern_ep_params *prm, c
         else if (W == 8192 && idmode == 2) {
             if (lumina_static && default_tree) LANTERN_LAUNCH((epw_kernel<512, 4, 2, 1, true, false, 2>), grid, dim3(512), lds, st, args);
             else if (lumina_static) LANTERN_LAUNCH((epw_kernel<512, 4, 2, 1, true, false, 1>), grid, dim3(512), lds, st, args);
+            else if (lumina_dynamic) LANTERN_LAUNCH((epw_kernel<512, 4, 2, 1, true, false, 3>), grid, dim3(512), lds, st, args);
+            else if (anole_static) LANTERN_LAUNCH((epw_kernel<512, 4, 2, 1, true, false, 4>), grid, dim3(512), lds, st, args);
             else LANTERN_LAUNCH((epw_kernel<512, 4, 2, 1, true>), grid, dim3(512), lds, st, args);   // the Lumina / Anole image window on the packed table
         }
         else EPW_LAUNCH(512, 4);

@@ -123,7 +123,8 @@ def test_drafter_table_and_attention_outputs():
     import test_gpu_drafter as D
     import test_gpu_tree_attention as T
     _run(M.test_vq_table_builder)
-    _run(M.test_drafter_fc_mfma_vs_oracle, 20, 4096, 1.0, True)
+    _run(M.test_drafter_fc_mfma_vs_oracle, 20, 4096, 1.0, True, False)
+    _run(M.test_drafter_fc_mfma_vs_oracle, 20, 4096, 2.0, True, True)          # stream-K on the packed weight: workspace partials under guard bands too
     _run(D.test_linear_rows_matches_torch, 20, 4096, 4, 8192)
     _run(D.test_drafter_head_window_equals_full_head)
     _run(T.test_tree_sizes, 59)

@@ -101,6 +101,15 @@ def lib():
             raise LanternError(
                 f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(hipcc --offload-arch=gfx950).  lantern_amd has no CPU fallback.")
+        # torch brings its own HIP runtime: it has to be initialised BEFORE this library is loaded into the process (loaded first, the
+        # library's launches fail with "no ROCm-capable device is detected" once torch has initialised afterwards -- seen on the GPU box
+        # with build() followed by smoke() in one process).  No GPU (the build container): nothing to initialise, the library still loads.
+        try:
+            import torch
+            if torch.cuda.is_available():
+                torch.cuda.init()
+        except ImportError:
+            pass
         _lib = C.CDLL(LIB_PATH)
         _lib.lantern_last_error.restype = C.c_char_p
         _lib.lantern_evaluate_posterior_workspace.restype = C.c_size_t

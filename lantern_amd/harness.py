@@ -166,12 +166,16 @@ class LuminaVerifyWorkload:
         self.fused_o7 = self.windowed and cfg.fuse_o7 and cfg.ep_kernel == "chain" and not self.anole
         self.n_spec = min(max(int(cfg.spec_rows), 0), N) if self.fused_o7 else 0
         if self.n_spec:
-            # likelihood order of the nodes: fewer / earlier choices first (the drafter ranks its candidates), the root always
+            # likelihood order of the nodes, the root always: the walk reaches a node when every node on its path was accepted; a level accepts
+            # its r-th candidate with probability ~ a (1 - a)^r (a = 0.65: the measured first-try acceptance of this workload), so a node's
+            # visit probability is the product over its path -- root, c0, c0.c0, c0.c0.c0, c1, ... for the reference's trees
             paths = {0: ()}
             for n in range(1, N):
                 sib_rank = sum(1 for m_ in range(1, n) if par[m_] == par[n])
                 paths[n] = paths[int(par[n])] + (sib_rank,)
-            order = sorted(range(N), key=lambda n: (sum(paths[n]) + len(paths[n]), len(paths[n]), paths[n]))
+            a_first = 0.65
+            visit = lambda n: float(np.prod([a_first * (1.0 - a_first) ** r for r in paths[n]])) if paths[n] else 1.0
+            order = sorted(range(N), key=lambda n: (-visit(n), len(paths[n]), paths[n]))
             self.spec_nodes = order[:self.n_spec]
             self.d_node_list = t(np.asarray(self.spec_nodes, np.int32))
             flags = np.zeros(N, np.uint8)

@@ -519,7 +519,8 @@ def other_configs(device, base_cfg, steps, n_seq):
     """BASELINE configs 2 and 4 on the clock (same GPU, after the headline run; rank 0, N = 1).
     C2  LlamaGen + EAGLE, standard (non-relaxed) verify: V = 16384 (window = vocabulary), dynamic EAGLE-2 tree N = 59 (top_k 10, depth 4),
         lantern off, HF processors T = 1 / top_k 2000, LlamaGen-B KV geometry (12 layers x 12 heads x 64, 2 slabs per sequence);
-        O4 -> O6 -> O7 -> O8 -> O9 + O10 per step (ea_model_llamagen.py:709-787, :930, :1137-1163).
+        O4 + O6 -> O8 on the raw cond / uncond rows (CFG, top-k and softmax for the rows the walk visits) -> O9 + O10 per step
+        (ea_model_llamagen.py:709-787, :930, :1137-1163); `all_rows_by_cfg_mask_topk`: the same with O7 over all 59 rows first.
     C4  Anole-7B 512x512, LANTERN++ static tree naive_extend_57 (N = 58, P = 33, D = 6), the reference's settings (lambda, k) in
         {(5, 10), (10, 5), (20, 5)} (run.sh:76-91): O6 -> O7 (all rows) -> O8 (chain kernel, neighbours zeroed in the drafter's row:
         ea_model_anole.py:597-669) -> O9 + O10, 7B KV geometry, 3 stream groups; plus the one-group per-kernel pass for the roofline."""
@@ -527,40 +528,46 @@ def other_configs(device, base_cfg, steps, n_seq):
     from lantern_amd import harness as HN
     res = {}
     # ---- C2
-    dc = HN.DynamicConfig(model="llamagen", n_seq=n_seq, depth=4, total_tokens=58, kv_layers=12, kv_heads=12, kv_dim=64, kv_smax=base_cfg.kv_smax,
-                          kv_pad_rows=base_cfg.kv_pad_rows, with_kv=base_cfg.with_kv, max_steps=2 * steps + 32, plausible=8.0,
-                          n_groups=(3 if n_seq % 3 == 0 else 1))
-    wl = HN.DynamicVerifyWorkload(dc, device)
-    for _ in range(10):
-        wl.step()
-    torch.cuda.synchronize(device)
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        wl.step()
-    torch.cuda.synchronize(device)
-    dt = time.perf_counter() - t0
-    names = event_names(wl)
-    KE = min(steps, 20)
-    evs = make_events(names, KE, device)
-    for i in range(KE):
-        wl.step(evs[i])
-    torch.cuda.synchronize(device)
-    wl.check_status(0, steps + 10 + KE)
-    toks = wl.accepted_tokens(10, 10 + steps)
-    cnt = wl.log_cnt[10 + steps:10 + steps + KE, :wl.Bg].double()          # the events bracket group 0's launches
-    ep_ms = float(np.mean([e["evaluate_posterior"][0].elapsed_time(e["evaluate_posterior"][1]) for e in evs]))
-    # bytes evaluate_posterior has to move per launch: one W-wide f32 row per visited level (+ the final row when it is a fresh softmax)
-    Wc = wl.W
-    needed = float(((cnt[..., 0] + (1.0 - cnt[..., 4])) * Wc * 4).sum() / KE)
-    res["C2"] = {"workload": f"C2: LlamaGen + EAGLE standard verify, V=16384, dynamic tree N={wl.N} (top_k 10, depth 4), lantern off, processors T=1/top_k=2000, "
-                             f"{n_seq} sequences in {dc.n_groups} stream groups, KV [24,1,12,{dc.kv_smax}(+{dc.kv_pad_rows}),64] bf16 x2 per sequence",
-                 "value": toks / dt, "unit": "accepted_tokens/s", "ms_per_step": 1e3 * dt / steps, "steps": steps, "mean_accept_length": toks / (steps * n_seq),
-                 "kernel_ms": {n: float(np.mean([e[n][0].elapsed_time(e[n][1]) for e in evs])) for n in names},
-                 "evaluate_posterior": {"avg_launch_ms": ep_ms, "sequences_per_launch": wl.Bg, "needed_bytes_per_launch": needed, "achieved_GBps": needed / (ep_ms * 1e-3) / 1e9,
-                                        "frac_needed": needed / (ep_ms * 1e-3) / 1e9 / 8000.0}}
-    wl.release_kv()
-    del wl
-    torch.cuda.empty_cache()
+    def c2_run(fuse):
+        dc = HN.DynamicConfig(model="llamagen", n_seq=n_seq, depth=4, total_tokens=58, kv_layers=12, kv_heads=12, kv_dim=64, kv_smax=base_cfg.kv_smax,
+                              kv_pad_rows=base_cfg.kv_pad_rows, with_kv=base_cfg.with_kv, max_steps=2 * steps + 32, plausible=8.0,
+                              n_groups=(3 if n_seq % 3 == 0 else 1), fuse_o7=fuse)
+        wl = HN.DynamicVerifyWorkload(dc, device)
+        for _ in range(10):
+            wl.step()
+        torch.cuda.synchronize(device)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            wl.step()
+        torch.cuda.synchronize(device)
+        dt = time.perf_counter() - t0
+        names = event_names(wl)
+        KE = min(steps, 20)
+        evs = make_events(names, KE, device)
+        for i in range(KE):
+            wl.step(evs[i])
+        torch.cuda.synchronize(device)
+        wl.check_status(0, steps + 10 + KE)
+        toks = wl.accepted_tokens(10, 10 + steps)
+        cnt = wl.log_cnt[10 + steps:10 + steps + KE, :wl.Bg].double()          # the events bracket group 0's launches
+        ep_ms = float(np.mean([e["evaluate_posterior"][0].elapsed_time(e["evaluate_posterior"][1]) for e in evs]))
+        # bytes evaluate_posterior has to move per launch: one W-wide row per visited level (+ the final row when it is a fresh softmax);
+        # a raw row is cond + uncond bf16 = the same W * 4 bytes as an f32 probability row
+        needed = float(((cnt[..., 0] + (1.0 - cnt[..., 4])) * wl.W * 4).sum() / KE)
+        r = {"workload": f"C2: LlamaGen + EAGLE standard verify, V=16384, dynamic tree N={wl.N} (top_k 10, depth 4), lantern off, processors T=1/top_k=2000, "
+                         f"{n_seq} sequences in {dc.n_groups} stream groups, KV [24,1,12,{dc.kv_smax}(+{dc.kv_pad_rows}),64] bf16 x2 per sequence",
+             "tree_decoding_rows": ("raw bf16 logits post-processed inside evaluate_posterior (LANTERN_ROWS_RAW_BF16, every row on demand)" if fuse
+                                    else "cfg_mask_topk over all N rows"),
+             "value": toks / dt, "unit": "accepted_tokens/s", "ms_per_step": 1e3 * dt / steps, "steps": steps, "mean_accept_length": toks / (steps * n_seq),
+             "kernel_ms": {n: float(np.mean([e[n][0].elapsed_time(e[n][1]) for e in evs])) for n in names},
+             "evaluate_posterior": {"avg_launch_ms": ep_ms, "sequences_per_launch": wl.Bg, "needed_bytes_per_launch": needed, "achieved_GBps": needed / (ep_ms * 1e-3) / 1e9,
+                                    "frac_needed": needed / (ep_ms * 1e-3) / 1e9 / 8000.0}}
+        wl.release_kv()
+        del wl
+        torch.cuda.empty_cache()
+        return r
+    res["C2"] = c2_run(True)
+    res["C2"]["all_rows_by_cfg_mask_topk"] = {k_: v_ for k_, v_ in c2_run(False).items() if k_ in ("value", "ms_per_step", "kernel_ms", "mean_accept_length")}
     # ---- C4
     if base_cfg.with_kv:          # as many sequences as the slabs (2 x 2.1 GiB each at 4096 rows) + pools leave room for, in whole stream groups
         free, _ = torch.cuda.mem_get_info(device)

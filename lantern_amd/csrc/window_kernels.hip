@@ -507,11 +507,14 @@ __device__ __forceinline__ int epw_body(const EpwArgs &args, const int b) {
     //   2  = 1 + the reference's default Lumina tree mc_sim_7b_63 (26 nodes, 15 paths of depth <= 6; run.sh / generate_images.py)
     //   3  Lumina dynamic (EAGLE-2) trees: LANTERN_MODE_DYNAMIC, LANTERN on, syntax shortcut, per-sequence paths / depths / positions
     //   4  Anole static tree (LANTERN_MODE_STATIC_LG: the neighbour set zeroes q), LANTERN on, no syntax shortcut
+    //   5  LlamaGen dynamic (EAGLE-2) trees, standard verify (BASELINE config 2): LANTERN off, no syntax shortcut, V = window = 16384 ids from 0
     // The mode / flag tests below fold away, and with them the scalar registers that carried them through the whole walk; the host
     // dispatches to an instance only when the argument block says exactly that.
     constexpr bool SL = SPEC >= 1;                               // one of the fixed configurations
-    constexpr bool S_STATIC = SPEC == 1 || SPEC == 2 || SPEC == 4, S_DYN = SPEC == 3, S_SYN = SPEC >= 1 && SPEC <= 3;
-    const int Ps = (SPEC == 2) ? 15 : prm.P, Ds = (SPEC == 2) ? 6 : prm.D, V = SL ? 65536 : prm.V, W = SL ? 8192 : win.win_len, lo = SL ? 4 : win.win_lo;
+    constexpr bool S_STATIC = SPEC == 1 || SPEC == 2 || SPEC == 4, S_DYN = SPEC == 3 || SPEC == 5, S_SYN = SPEC >= 1 && SPEC <= 3;
+    constexpr bool S_LG = SPEC == 5;                             // LlamaGen's vocabulary instead of Chameleon's
+    const int Ps = (SPEC == 2) ? 15 : prm.P, Ds = (SPEC == 2) ? 6 : prm.D, V = SL ? (S_LG ? 16384 : 65536) : prm.V, W = SL ? (S_LG ? 16384 : 8192) : win.win_len,
+              lo = SL ? (S_LG ? 0 : 4) : win.win_lo;
     uint32_t *nbmask = reinterpret_cast<uint32_t *>(g + W + EW_G_EXT);  // W bits: neighbour set (static LlamaGen/Anole: zeroing hits q)
     EwShared &S = *reinterpret_cast<EwShared *>(reinterpret_cast<char *>(g) + epw_shared_offset(W));
     int *const Scand = reinterpret_cast<int *>(reinterpret_cast<char *>(&S) + sizeof(EwShared));
@@ -520,13 +523,13 @@ __device__ __forceinline__ int epw_body(const EpwArgs &args, const int b) {
     float *const Scart = reinterpret_cast<float *>(Sboff + pd_cap);
     int *const Sflag = reinterpret_cast<int *>(Scart + pd_cap);       // per (path, depth): bit 1 image token, bit 0 syntax token
     int *const Shist = Sflag + pd_cap;                                // RAW: the radix-select histograms of the row post-process
-    const int k = prm.k, off = SL ? 4 : prm.tok_offset;
+    const int k = prm.k, off = SL ? (S_LG ? 0 : 4) : prm.tok_offset;
     const int p_mode = !SL ? prm.mode : (SPEC == 4 ? (int)LANTERN_MODE_STATIC_LG : (S_DYN ? (int)LANTERN_MODE_DYNAMIC : (int)LANTERN_MODE_STATIC_LUMINA));
-    const bool p_lantern = SL ? true : prm.lantern != 0;
+    const bool p_lantern = SL ? !S_LG : prm.lantern != 0;
     const bool p_syntax = SL ? S_SYN : prm.syntax_shortcut != 0;
     const int p_nsyn = SL ? (S_SYN ? 4 : 0) : prm.n_syntax;
     const int p_rows = (SPEC == 2) ? 26 : prm.rows_per_seq, p_N = (SPEC == 2) ? 26 : prm.N;
-    const int p_img_lo = SL ? 4 : prm.img_lo, p_img_hi = SL ? 8196 : prm.img_hi, p_trows = SL ? 8192 : prm.table_rows;
+    const int p_img_lo = SL ? (S_LG ? 0 : 4) : prm.img_lo, p_img_hi = SL ? (S_LG ? 16384 : 8196) : prm.img_hi, p_trows = SL ? (S_LG ? 0 : 8192) : prm.table_rows;
     auto p_syn = [&](int q) -> int { return SL ? (q == 0 ? 8196 : (q == 1 ? 8197 : (q == 2 ? 8803 : 8828))) : prm.syntax[q]; };
     const bool is_static = SL ? S_STATIC : p_mode != LANTERN_MODE_DYNAMIC;
     const int P = S_DYN ? buf.n_paths[b] : ((!SL && buf.n_paths) ? buf.n_paths[b] : Ps);
@@ -578,7 +581,7 @@ __device__ __forceinline__ int epw_body(const EpwArgs &args, const int b) {
         for (int u = 0; u < N_PER; ++u) {
             const int t = tid + u * NT;
             tc_[u] = (is_static && t < p_N && t < EW_MAX_N) ? (int)buf.tree_cand[(size_t)b * p_N + t] : 0;
-            hot_[u] = (hot_g && hot_in_lds && t < p_rows) ? hot_g[t] : -1;
+            hot_[u] = (!RAW && hot_g && hot_in_lds && t < p_rows) ? hot_g[t] : -1;          // (raw rows: the class comes from the position, below; row_hot is not read)
             if (RAW && t < p_rows) {
                 // raw_pre[t] = 1 + the depth the row was prepared for; with per-sequence trees the node has to sit there (its position says so)
                 int pre = (win.raw_pre && win.raw_probs) ? (int)win.raw_pre[t] : 0;
@@ -588,7 +591,9 @@ __device__ __forceinline__ int epw_body(const EpwArgs &args, const int b) {
                 }
                 S.pre[t] = pre;
             }
-            if (RAW && t < p_rows) {          // the row's class from its position (MultiModalLogitsProcessor, ea_model_lumina_mgpt.py:45-86)
+            // the row's class from its position (MultiModalLogitsProcessor, ea_model_lumina_mgpt.py:45-86); raw_w_latent == 0: a model without
+            // grammar rows (LlamaGen: every row is an ordinary distribution)
+            if (RAW && !S_LG && t < p_rows && win.raw_w_latent > 0) {
                 const int64_t n1 = ((SL ? (int)S_DYN : win.raw_pos_per_seq) ? win.raw_pos_ids[(size_t)b * p_rows + t] : win.raw_pos_ids[t] + win.raw_seq_len[b]) - win.raw_pos_base + 1;
                 // (a 64-bit modulo is ~150 instructions: the 32-bit form whenever the operands fit -- always, for real image sizes)
                 const bool fits = n1 >= 0 && n1 < (1ll << 31) && win.raw_w_latent >= 0 && win.raw_w_latent < (1 << 30);
@@ -1446,15 +1451,20 @@ static int epw_check(const lantern_ep_params *prm, const lantern_ep_buffers *buf
                       "evaluate_posterior_window: bad rows_kind");
     const bool raw = win->rows_kind == LANTERN_ROWS_RAW_BF16;
     if (raw) {
-        LANTERN_CHECK_ARG(win->raw_uncond && win->raw_pos_ids && (win->raw_seq_len || win->raw_pos_per_seq) && win->raw_w_latent > 0 && win->raw_h_latent > 0 &&
-                              win->raw_newline_id >= 0 && win->raw_newline_id < p.V && win->raw_eos_id >= 0 && win->raw_eos_id < p.V,
-                          "evaluate_posterior_window: raw rows need the unconditional logits, positions, sequence lengths and the Lumina grammar ids");
+        const bool plain = win->raw_w_latent == 0 && win->raw_h_latent == 0;          // no grammar rows (LlamaGen): positions are not needed
+        LANTERN_CHECK_ARG(win->raw_uncond && (plain || (win->raw_pos_ids && (win->raw_seq_len || win->raw_pos_per_seq) && win->raw_w_latent > 0 && win->raw_h_latent > 0 &&
+                                                        win->raw_newline_id >= 0 && win->raw_newline_id < p.V && win->raw_eos_id >= 0 && win->raw_eos_id < p.V)),
+                          "evaluate_posterior_window: raw rows need the unconditional logits and -- Lumina -- positions, sequence lengths and the grammar ids "
+                          "(raw_w_latent = raw_h_latent = 0: a model without grammar rows)");
         LANTERN_CHECK_ARG(p.top_k <= 0 && p.temperature == 1.0f && p.rows_per_seq <= EW_MAX_N && win->win_lo % 4 == 0 && p.V % 8 == 0 &&
                               win->win_lo == p.img_lo && win->win_lo + win->win_len == p.img_hi,
                           "evaluate_posterior_window: raw rows: the window is the image-token range, the processors are the Lumina ones (raw_top_k)");
-        if (!(win->win_len == 8192 && p.lantern && p.table_cols % 8 == 0 && ((uintptr_t)buf->nn_table & 15) == 0 &&
-              ((p.k + 1 < p.table_cols ? p.k + 1 : p.table_cols) <= EW_PF_K))) {
-            set_error("evaluate_posterior_window: raw rows are built for the 8192-id window on the packed neighbour table (k + 1 <= %d)", EW_PF_K);
+        const bool lumina_form = win->win_len == 8192 && p.lantern && p.table_cols % 8 == 0 && ((uintptr_t)buf->nn_table & 15) == 0 &&
+                                 ((p.k + 1 < p.table_cols ? p.k + 1 : p.table_cols) <= EW_PF_K);
+        const bool llamagen_form = win->win_len == 16384 && !p.lantern && plain && p.mode == LANTERN_MODE_DYNAMIC && !p.syntax_shortcut;
+        if (!lumina_form && !llamagen_form) {
+            set_error("evaluate_posterior_window: raw rows are built for the 8192-id window on the packed neighbour table (k + 1 <= %d) and for the "
+                      "16384-id window of LlamaGen's standard verify (LANTERN off, dynamic trees)", EW_PF_K);
             return LANTERN_E_UNSUPPORTED;
         }
     }
@@ -1513,6 +1523,12 @@ extern "C" int lantern_evaluate_posterior_window(const lantern_ep_params *prm, c
     if (W <= 1024) EPW_LAUNCH(256, 1);
     else if (W <= 2048) EPW_LAUNCH(256, 2);
     else if (W <= 4096) EPW_LAUNCH(512, 2);
+    else if (raw && W == 16384) {          // LlamaGen standard verify on raw rows (the form epw_check admitted)
+        const bool lg_dynamic = spec_knob != 0 && p.V == 16384 && p.img_lo == 0 && p.img_hi == 16384 && p.tok_offset == 0 && win->win_lo == 0 && buf->n_paths &&
+                                buf->n_depth && p.rows_per_seq <= EW_MAX_N;
+        if (lg_dynamic) LANTERN_LAUNCH((epw_kernel<1024, 4, 1, 1, true, true, 5>), grid, dim3(1024), lds, st, args);
+        else LANTERN_LAUNCH((epw_kernel<1024, 4, 1, 1, true, true>), grid, dim3(1024), lds, st, args);
+    }
     else if (raw) {
         if (two_per_cu) LANTERN_LAUNCH((epw_kernel<512, 4, 2, 4, true, true>), grid, dim3(512), lds, st, args);
         else if (lumina_static && default_tree) LANTERN_LAUNCH((epw_kernel<512, 4, 2, 1, true, true, 2>), grid, dim3(512), lds, st, args);

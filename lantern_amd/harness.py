@@ -988,13 +988,16 @@ class DynamicVerifyWorkload:
         w = EpWindow()
         w.win_lo, w.win_len, w.row_hot = IMG_LO, W, self.hot.data_ptr()
         w.out_tok, w.out_mass, w.rows_kind = self.out_tok.data_ptr(), self.out_mass.data_ptr(), ops.ROWS_PROBS
-        self.fused_o7 = bool(cfg.fuse_o7) and not self.lg
+        self.fused_o7 = bool(cfg.fuse_o7)
         if self.fused_o7:               # raw rows: positions are per sequence and absolute (O6 dynamic writes them), the processors' parameters ride along
             w.rows_kind, w.raw_pos_per_seq = ops.ROWS_RAW_BF16, 1
             w.raw_pos_ids, w.raw_seq_len, w.raw_pos_base = self.pos_abs.data_ptr(), None, cfg.prompt_len + 3
             w.raw_cfg, w.raw_top_k = cfg.cfg_scale, cfg.logit_top_k
-            w.raw_w_latent, w.raw_h_latent, w.raw_newline_id, w.raw_eos_id = W_LATENT, H_LATENT, NEWLINE, EOS
-        self.n_spec = max(0, min(int(cfg.spec_rows), 2)) if self.fused_o7 else 0
+            if self.lg:                 # LlamaGen: no grammar rows (raw_w_latent = raw_h_latent = 0), CFG mix + top-k + softmax only
+                w.raw_w_latent, w.raw_h_latent, w.raw_newline_id, w.raw_eos_id = 0, 0, 0, 0
+            else:
+                w.raw_w_latent, w.raw_h_latent, w.raw_newline_id, w.raw_eos_id = W_LATENT, H_LATENT, NEWLINE, EOS
+        self.n_spec = max(0, min(int(cfg.spec_rows), 2)) if (self.fused_o7 and not self.lg) else 0
         if self.n_spec:
             nodes = list(range(self.n_spec))
             self.d_node_list = torch.tensor(nodes + nodes, dtype=torch.int32, device=device)       # node ids, then the depth each is prepared for

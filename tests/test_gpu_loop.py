@@ -118,6 +118,51 @@ def test_dynamic_tree_loop_matches_oracle_loop(fuse, groups, native, spec):
         assert int(acc[b, int(ga[last, b])]) >= 0 and (acc[b, int(ga[last, b]) + 1:] == -1).all()
 
 
+@pytest.mark.parametrize("fuse,groups", [(False, 1), (True, 1), (True, 2)], ids=["o7_launch", "raw_rows", "raw_rows_2_groups"])
+def test_llamagen_dynamic_loop_matches_oracle_loop(fuse, groups):
+    """BASELINE config 2 (LlamaGen + EAGLE, standard verify: V = 16384 = the window, LANTERN off, HF processors T = 1 / top_k 2000) through the
+    device-resident dynamic loop, with O7 over all rows and with the raw cond / uncond rows post-processed inside evaluate_posterior (the
+    1024-thread raw-row instance): the oracle's loop over the same pools / uniforms gives the same (best path, accept length, bonus token) for
+    every step and sequence."""
+    import numpy as np
+    import oracle
+    from lantern_amd import harness as HN
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import helpers as H
+    steps = 8
+    cfg = HN.DynamicConfig(model="llamagen", n_seq=3 * groups, pool_steps=2, depth=4, kv_layers=2, kv_heads=4, kv_dim=64, kv_smax=512, max_steps=steps + 2,
+                           fuse_o7=fuse, n_groups=groups)
+    wl = HN.DynamicVerifyWorkload(cfg, torch.device("cuda"))
+    assert wl.fused_o7 == fuse and wl.lg and wl.n_spec == 0
+    for _ in range(steps):
+        wl.step()
+    wl.sync()
+    wl.check_status(0, steps)
+    gb, ga, gt = wl.log_best[:steps].cpu().numpy(), wl.log_alen[:steps].cpu().numpy(), wl.log_token[:steps].cpu().numpy()
+    uni, ub = wl.uniforms.cpu().numpy(), wl.u_bonus.cpu().numpy()
+    ocfg = oracle.EpConfig.llamagen(False, lantern=False, temperature=1.0, top_p=1.0, top_k=0)          # (the rows arrive processed)
+    N = wl.N
+    n_acc = 0
+    for b in range(cfg.n_seq):
+        tok, cursor = int(wl.first_token[b]), 0
+        for i in range(steps):
+            p = wl.pools[i % cfg.pool_steps]
+            draft, ret, mask, pos = oracle.tree_dynamic_finalize(p["scores"][b].cpu().numpy(), p["tokens"][b].cpu().numpy(), p["parents"][b].cpu().numpy(),
+                                                                 cfg.top_k, cfg.total_tokens, tok)
+            cand = np.where(ret >= 0, draft[np.clip(ret, 0, None)], -1)
+            proc = oracle.cfg_mask_topk(p["cond"][b].cpu().view(torch.int16).numpy().view(np.uint16), p["unc"][b].cpu().view(torch.int16).numpy().view(np.uint16),
+                                        cfg.cfg_scale, model=oracle.MODEL_PLAIN, top_k=cfg.logit_top_k, bf16=True)
+            best, alen, sp, cnt = oracle.evaluate_posterior(ocfg, proc, H.row_index_from_retrieve(ret, N), cand, uni[b, cursor:cursor + 64])
+            cursor += int(cnt[3])
+            tok = oracle.sample_inverse_cdf(sp, float(ub[i, b]))
+            assert (int(gb[i, b]), int(ga[i, b]), int(gt[i, b])) == (best, alen, tok), (b, i)
+            n_acc += alen
+    assert n_acc > 0
+    gen = (ga.astype("int64") + 1).sum(0)
+    len_c, len_u = wl.lengths(steps & 1)
+    assert (len_c.cpu().numpy() == cfg.prompt_len + 3 + gen).all() and (len_u.cpu().numpy() == 3 + gen).all()
+
+
 @pytest.mark.parametrize("fuse,spec", [(False, 0), (True, 0), (True, 2)], ids=["o7_launch", "raw_rows", "raw_rows_2_prepared"])
 def test_dynamic_step_one_call_equals_per_kernel_calls(fuse, spec):
     """lantern_verify_step with dynamic groups (O4 + O6-dynamic in one launch, lantern_tree_dynamic_candidates) against the same step as

@@ -522,8 +522,9 @@ def other_configs(device, base_cfg, steps, n_seq):
         O4 + O6 -> O8 on the raw cond / uncond rows (CFG, top-k and softmax for the rows the walk visits) -> O9 + O10 per step
         (ea_model_llamagen.py:709-787, :930, :1137-1163); `all_rows_by_cfg_mask_topk`: the same with O7 over all 59 rows first.
     C4  Anole-7B 512x512, LANTERN++ static tree naive_extend_57 (N = 58, P = 33, D = 6), the reference's settings (lambda, k) in
-        {(5, 10), (10, 5), (20, 5)} (run.sh:76-91): O6 -> O7 (all rows) -> O8 (chain kernel, neighbours zeroed in the drafter's row:
-        ea_model_anole.py:597-669) -> O9 + O10, 7B KV geometry, 3 stream groups; plus the one-group per-kernel pass for the roofline."""
+        {(5, 10), (10, 5), (20, 5)} (run.sh:76-91): O6 + the 3 likeliest rows -> O8 on raw rows (chain kernel, neighbours zeroed in the drafter's
+        row: ea_model_anole.py:597-669) -> O9 + O10, 7B KV geometry, 3 stream groups; `all_rows_by_cfg_mask_topk`: O7 over all 58 rows first;
+        plus the one-group per-kernel pass (all rows + chain on probability rows) for the roofline."""
     import dataclasses
     from lantern_amd import harness as HN
     res = {}
@@ -577,15 +578,18 @@ def other_configs(device, base_cfg, steps, n_seq):
     groups = 3 if n_seq % 3 == 0 else 1
     res["C4"] = []
     for lam, kk in ((5.0, 10), (10.0, 5), (20.0, 5)):
-        over = dict(model="anole", tree="naive_extend_57", lantern_k=kk, lantern_delta=lam, fuse_o7=False, spec_rows=0, ep_kernel="chain",
+        over = dict(model="anole", tree="naive_extend_57", lantern_k=kk, lantern_delta=lam, fuse_o7=True, spec_rows=3, ep_kernel="chain",
                     seed_base=4000)
         grouped = side_run(device, base_cfg, steps, n_groups=groups, n_seq=n_seq, **over)
+        all_rows = side_run(device, base_cfg, steps, n_groups=groups, n_seq=n_seq, **dict(over, fuse_o7=False, spec_rows=0))
         one = per_kernel_run(device, base_cfg, min(steps, 40), n_seq=n_seq, **{k_: v_ for k_, v_ in over.items() if k_ not in ("fuse_o7", "spec_rows")})
         rl = one["roofline"]
         res["C4"].append({"workload": f"C4: Anole-7B 512x512 LANTERN++ static tree naive_extend_57 (N=58,P=33,D=6), lambda={lam:g}, k={kk}, {n_seq} sequences in "
                                       f"{groups} stream groups, 7B KV geometry",
                           "lantern_delta": lam, "lantern_k": kk, "value": grouped["value"], "unit": "accepted_tokens/s", "ms_per_step": grouped["ms_per_step"],
                           "mean_accept_length": grouped["mean_accept_length"], "one_group_ms_per_step": one["ms_per_step"],
+                          "tree_decoding_rows": "raw bf16 logits post-processed inside evaluate_posterior, 3 rows per sequence up front with the candidate assembly",
+                          "all_rows_by_cfg_mask_topk": {"value": all_rows["value"], "ms_per_step": all_rows["ms_per_step"]},
                           "evaluate_posterior": {k_: rl.get(k_) for k_ in ("kernel", "avg_launch_ms", "achieved", "frac", "needed_bytes_per_launch", "frac_needed", "unit")},
                           "kernels": one["kernels"]})
     return res

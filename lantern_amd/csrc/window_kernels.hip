@@ -336,7 +336,8 @@ __global__ __launch_bounds__(NT) void prep_rows_kernel(const PrepArgs a) {
         const int x = o7_row_of_block(blockIdx.x, n_rows, a.n_list);            // rows of sequence b on XCD b % 8, where its chain runs
         const int b = x / a.n_list, node = a.node_list[x % a.n_list];
         const int row = b * a.rows_per_seq + node;
-        const int cls = lumina_row_class(a.pos_ids[node] + a.seq_len[b], a.pos_base, a.w_latent, a.h_latent);
+        // (w_latent == 0: a model without grammar rows -- Anole; the window is its image-token range, so no id needs the model's mask)
+        const int cls = a.w_latent > 0 ? lumina_row_class(a.pos_ids[node] + a.seq_len[b], a.pos_base, a.w_latent, a.h_latent) : 0;
         cfg_window_bf16_row<NT, E8, true>(row, cls, a.cond, a.uncond, a.V, a.cfg, LANTERN_MODEL_LUMINA, a.img_lo, a.img_hi, a.newline_id, a.eos_id,
                                           a.top_k, a.win_lo, a.W, a.out_win, a.row_hot, LANTERN_ROWS_PROBS, s_hist, s_redf, s_redd);
         return;
@@ -1401,10 +1402,12 @@ static int prepare_step_dynamic(const lantern_step_group *g) {
 
 extern "C" int lantern_prepare_step(const lantern_step_group *g) {
     LANTERN_CHECK_ARG(g && g->node_list && g->n_list > 0 && g->n_list <= g->N, "prepare_step: needs a node list");
-    LANTERN_CHECK_ARG(g->cond && g->uncond && g->out_win && g->row_hot && (g->dyn || (g->seq_len && g->pos_ids)) && g->dtype == LANTERN_BF16 && g->model == LANTERN_MODEL_LUMINA &&
+    const bool no_grammar = g->w_latent == 0 && g->h_latent == 0;          // Anole: every row an ordinary distribution (LANTERN_MODEL_ANOLE, static trees)
+    LANTERN_CHECK_ARG(g->cond && g->uncond && g->out_win && g->row_hot && (g->dyn || no_grammar || (g->seq_len && g->pos_ids)) && g->dtype == LANTERN_BF16 &&
+                          (g->model == LANTERN_MODEL_LUMINA || (g->model == LANTERN_MODEL_ANOLE && no_grammar && !g->dyn)) &&
                           g->win_len == 8192 && g->win_lo == g->img_lo && g->win_lo + g->win_len == g->img_hi && g->win_lo % 4 == 0 && g->V % 8 == 0 &&
                           g->out_kind == LANTERN_ROWS_PROBS && g->temperature == 1.0f && !(g->top_p > 0.0f && g->top_p < 1.0f),
-                      "prepare_step: bf16 Lumina rows on the 8192-id image window, probability output");
+                      "prepare_step: bf16 Lumina (or Anole, w_latent = h_latent = 0) rows on the 8192-id image window, probability output");
     if (g->dyn) return prepare_step_dynamic(g);
     LANTERN_CHECK_ARG(g->ss_token && g->sample_token && g->tree_indices && g->retrieve && g->tree_cand && g->cand && g->B >= 0 && g->n_flat > 0 && g->N > 0 &&
                           g->P > 0 && g->D > 0, "prepare_step: candidate-assembly buffers missing");
@@ -1512,11 +1515,12 @@ extern "C" int lantern_evaluate_posterior_window(const lantern_ep_params *prm, c
     static const int spec_knob = getenv("LANTERN_EPW_SPEC") ? atoi(getenv("LANTERN_EPW_SPEC")) : 2;   // tuning knob (diagnostic): 0 = the generic instance, 1 = no fixed tree
     const bool chameleon = spec_knob != 0 && p.lantern && p.V == 65536 && p.img_lo == 4 && p.img_hi == 8196 && p.tok_offset == 4 && p.table_rows == 8192 &&
                            win->win_lo == 4 && W == 8192 && p.rows_per_seq <= EW_MAX_N && (raw || win->rows_kind == LANTERN_ROWS_PROBS) &&
-                           (!raw || (win->raw_eos_id == 8196 && win->raw_newline_id == 8803));
+                           (!raw || win->raw_w_latent == 0 || (win->raw_eos_id == 8196 && win->raw_newline_id == 8803));
     const bool lumina_syntax = p.syntax_shortcut && p.n_syntax == 4 && p.syntax[0] == 8196 && p.syntax[1] == 8197 && p.syntax[2] == 8803 && p.syntax[3] == 8828;
     const bool lumina_static = chameleon && p.mode == LANTERN_MODE_STATIC_LUMINA && lumina_syntax && !buf->n_paths && !buf->n_depth && (!raw || !win->raw_pos_per_seq);
     const bool lumina_dynamic = chameleon && p.mode == LANTERN_MODE_DYNAMIC && lumina_syntax && buf->n_paths && buf->n_depth && (!raw || win->raw_pos_per_seq);
-    const bool anole_static = chameleon && p.mode == LANTERN_MODE_STATIC_LG && !p.syntax_shortcut && !buf->n_paths && !buf->n_depth && !raw;
+    const bool anole_static = chameleon && p.mode == LANTERN_MODE_STATIC_LG && !p.syntax_shortcut && !buf->n_paths && !buf->n_depth &&
+                              (!raw || (win->raw_w_latent == 0 && !win->raw_pos_per_seq));
     const bool default_tree = spec_knob >= 2 && p.P == 15 && p.D == 6 && p.N == 26 && p.rows_per_seq == 26;
     static const int occ_knob = getenv("LANTERN_EPW_OCC2") ? atoi(getenv("LANTERN_EPW_OCC2")) : -1;   // tuning knob (diagnostic)
     const bool two_per_cu = occ_knob >= 0 ? occ_knob != 0 : p.B > 256;
@@ -1534,6 +1538,7 @@ extern "C" int lantern_evaluate_posterior_window(const lantern_ep_params *prm, c
         else if (lumina_static && default_tree) LANTERN_LAUNCH((epw_kernel<512, 4, 2, 1, true, true, 2>), grid, dim3(512), lds, st, args);
         else if (lumina_static) LANTERN_LAUNCH((epw_kernel<512, 4, 2, 1, true, true, 1>), grid, dim3(512), lds, st, args);
         else if (lumina_dynamic) LANTERN_LAUNCH((epw_kernel<512, 4, 2, 1, true, true, 3>), grid, dim3(512), lds, st, args);
+        else if (anole_static) LANTERN_LAUNCH((epw_kernel<512, 4, 2, 1, true, true, 4>), grid, dim3(512), lds, st, args);
         else LANTERN_LAUNCH((epw_kernel<512, 4, 2, 1, true, true>), grid, dim3(512), lds, st, args);
     }
     else if (W <= 8192) {

@@ -163,7 +163,7 @@ class LuminaVerifyWorkload:
         self.anole = cfg.model == "anole"
         self.o7_model = ops.MODEL_ANOLE if self.anole else ops.MODEL_LUMINA
         self.tokens_per_image = 32 * 32 if self.anole else TOKENS_PER_IMAGE          # Anole 512x512: 1024 image tokens, no newline / header rows
-        self.fused_o7 = self.windowed and cfg.fuse_o7 and cfg.ep_kernel == "chain" and not self.anole
+        self.fused_o7 = self.windowed and cfg.fuse_o7 and cfg.ep_kernel == "chain"
         self.n_spec = min(max(int(cfg.spec_rows), 0), N) if self.fused_o7 else 0
         if self.n_spec:
             # likelihood order of the nodes, the root always: the walk reaches a node when every node on its path was accepted; a level accepts
@@ -409,7 +409,10 @@ class LuminaVerifyWorkload:
             w.rows_kind = ops.ROWS_RAW_BF16                   # logits / raw_uncond / raw_seq_len are set per (slot, parity)
             w.raw_pos_ids, w.raw_pos_base = self.d_pos_ids.data_ptr(), self.cfg.prompt_len + 3
             w.raw_cfg, w.raw_top_k = self.cfg.cfg_scale, self.cfg.top_k
-            w.raw_w_latent, w.raw_h_latent, w.raw_newline_id, w.raw_eos_id = W_LATENT, H_LATENT, NEWLINE, EOS
+            if self.anole:          # no grammar rows (ea_model_anole.py:930-931 masks the non-image ids, nothing else): raw_w_latent = raw_h_latent = 0
+                w.raw_w_latent, w.raw_h_latent, w.raw_newline_id, w.raw_eos_id = 0, 0, 0, 0
+            else:
+                w.raw_w_latent, w.raw_h_latent, w.raw_newline_id, w.raw_eos_id = W_LATENT, H_LATENT, NEWLINE, EOS
             if self.n_spec:
                 w.raw_probs, w.raw_pre = at(self.proc), self.d_pre.data_ptr()
         return w
@@ -525,7 +528,8 @@ class LuminaVerifyWorkload:
             s.tree_cand, s.cand, s.cart_prob = val(A["tree_cand"]), val(A["cand"]), val(A["cart_prob"])
             s.cond, s.uncond, s.dtype, s.V, s.cfg, s.model = val(A["cond"]), val(A["uncond"]), 1, V, c.cfg_scale, self.o7_model
             s.pos_ids, s.pos_base = self.d_pos_ids.data_ptr(), c.prompt_len + 3
-            s.w_latent, s.h_latent, s.img_lo, s.img_hi, s.newline_id, s.eos_id, s.top_k = W_LATENT, H_LATENT, IMG_LO, IMG_HI, NEWLINE, EOS, c.top_k
+            s.w_latent, s.h_latent = (0, 0) if self.anole else (W_LATENT, H_LATENT)          # (Anole: no grammar rows)
+            s.img_lo, s.img_hi, s.newline_id, s.eos_id, s.top_k = IMG_LO, IMG_HI, NEWLINE, EOS, c.top_k
             s.win_lo, s.win_len, s.out_kind = self.win_lo, self.W, ops.ROWS_PROBS if c.rows_probs else ops.ROWS_LOGITS
             s.seq_len, s.out_win, s.row_hot, s.temperature, s.top_p = val(A["cur"]), (None if (self.fused_o7 and not self.n_spec) else val(A["proc"])), val(A["row_hot"]), 1.0, 1.0
             if self.n_spec:

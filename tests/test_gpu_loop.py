@@ -118,6 +118,58 @@ def test_dynamic_tree_loop_matches_oracle_loop(fuse, groups, native, spec):
         assert int(acc[b, int(ga[last, b])]) >= 0 and (acc[b, int(ga[last, b]) + 1:] == -1).all()
 
 
+@pytest.mark.parametrize("fuse,groups,spec,lam,k", [(False, 1, 0, 5.0, 10), (True, 1, 0, 5.0, 10), (True, 2, 3, 10.0, 5), (True, 1, 5, 0.3, 40)],
+                         ids=["o7_launch", "raw_rows", "raw_rows_2_groups_3_prepared", "raw_rows_delta_mode_5_prepared"])
+def test_anole_static_loop_matches_oracle_loop(fuse, groups, spec, lam, k):
+    """BASELINE config 4 (Anole, LANTERN++ static tree naive_extend_57: neighbours zeroed in the drafter's row, no syntax shortcut, no grammar rows)
+    through the device-resident step loop -- O7 over all rows, and the raw rows post-processed inside evaluate_posterior with the likeliest rows
+    prepared beside O6 -- against the oracle's loop over the same pools / uniforms: identical (best path, accept length, bonus token) at every step."""
+    import numpy as np
+    import oracle
+    from lantern_amd import harness as HN
+    steps = 24
+    cfg = HN.WorkloadConfig(model="anole", tree="naive_extend_57", n_seq=3 * groups, pool_steps=4, kv_layers=2, kv_heads=4, kv_smax=512, max_steps=steps + 4,
+                            sigma=5.0, n_groups=groups, ep_kernel="chain", fuse_o7=fuse, spec_rows=spec, lantern_k=k, lantern_delta=lam)
+    wl = HN.LuminaVerifyWorkload(cfg, torch.device("cuda"))
+    assert wl.anole and wl.fused_o7 == fuse and wl.n_spec == (spec if fuse else 0)
+    for _ in range(steps):
+        wl.step()
+    wl.join()
+    torch.cuda.synchronize()
+    wl.check_status(0, steps)
+    gb, ga, gt = wl.log_best[:steps].cpu().numpy(), wl.log_alen[:steps].cpu().numpy(), wl.log_token[:steps].cpu().numpy()
+    tb, N = wl.tb, wl.N
+    ri = tb["retrieve_indices"].copy()
+    ri[ri < 0] += N
+    ri = ri.astype(np.int32)
+    table = wl.table_full.cpu().numpy().view(np.uint16)
+    u16 = lambda t: t.cpu().view(torch.int16).numpy().view(np.uint16)
+    cond, uncond = u16(wl.cond), u16(wl.uncond)
+    orig = wl.orig_prob.cpu().numpy()
+    dense = np.zeros(orig.shape[:-1] + (HN.V,), np.float32)
+    dense[..., HN.IMG_LO:HN.IMG_HI] = orig
+    sst, ssp = wl.ss_token.cpu().numpy(), wl.ss_prob.cpu().numpy()
+    ub, first, op_off = wl.u_bonus.cpu().numpy(), wl.first_token.cpu().numpy(), wl.d_op_off.cpu().numpy()
+    # (Anole / LlamaGen: the reference applies the HF processors -- here T = 1, top_k -- inside evaluate_posterior, per visited row; O7 / the raw-row
+    # path apply them where the rows are produced: the same distribution)
+    ocfg = oracle.EpConfig.anole(True, lantern=True, k=k, delta=lam, temperature=1.0, top_p=1.0, top_k=cfg.top_k)
+    n_acc = n_rej = 0
+    for b in range(cfg.n_seq):
+        tok, cursor = int(first[b]), 0
+        for i in range(steps):
+            s_ = i % cfg.pool_steps
+            cand, cp, tc = oracle.gather_candidates(sst[s_, b], ssp[s_, b], tok, tb["tree_indices"], tb["retrieve_indices"])
+            proc = oracle.cfg_mask_topk(cond[s_, b], uncond[s_, b], cfg.cfg_scale, model=oracle.MODEL_ANOLE, img_lo=HN.IMG_LO, img_hi=HN.IMG_HI, bf16=True)
+            aux = oracle.StaticAux(cart_prob=cp, orig_prob=dense[s_, b], op_off=op_off, p_idx=tb["p_indices"], b_off=tb["b_off"], b_idx=tb["b_idx"], tree_cand=tc)
+            best, alen, sp, cnt = oracle.evaluate_posterior(ocfg, proc, ri, cand, wl.uniforms_host[b, cursor:cursor + 64], table=table, aux=aux)
+            cursor += int(cnt[3])
+            tok = oracle.sample_inverse_cdf(sp, float(ub[i, b]))
+            assert (int(gb[i, b]), int(ga[i, b]), int(gt[i, b])) == (best, alen, tok), (b, i)
+            n_acc += alen
+            n_rej += int(cnt[2])
+    assert n_acc > 0 and n_rej > 0
+
+
 @pytest.mark.parametrize("fuse,groups", [(False, 1), (True, 1), (True, 2)], ids=["o7_launch", "raw_rows", "raw_rows_2_groups"])
 def test_llamagen_dynamic_loop_matches_oracle_loop(fuse, groups):
     """BASELINE config 2 (LlamaGen + EAGLE, standard verify: V = 16384 = the window, LANTERN off, HF processors T = 1 / top_k 2000) through the
@@ -140,7 +192,7 @@ def test_llamagen_dynamic_loop_matches_oracle_loop(fuse, groups):
     wl.check_status(0, steps)
     gb, ga, gt = wl.log_best[:steps].cpu().numpy(), wl.log_alen[:steps].cpu().numpy(), wl.log_token[:steps].cpu().numpy()
     uni, ub = wl.uniforms.cpu().numpy(), wl.u_bonus.cpu().numpy()
-    ocfg = oracle.EpConfig.llamagen(False, lantern=False, temperature=1.0, top_p=1.0, top_k=0)          # (the rows arrive processed)
+    ocfg = oracle.EpConfig.llamagen(False, lantern=False, temperature=1.0, top_p=1.0, top_k=cfg.logit_top_k)      # the HF processors run inside evaluate_posterior
     N = wl.N
     n_acc = 0
     for b in range(cfg.n_seq):
@@ -151,7 +203,7 @@ def test_llamagen_dynamic_loop_matches_oracle_loop(fuse, groups):
                                                                  cfg.top_k, cfg.total_tokens, tok)
             cand = np.where(ret >= 0, draft[np.clip(ret, 0, None)], -1)
             proc = oracle.cfg_mask_topk(p["cond"][b].cpu().view(torch.int16).numpy().view(np.uint16), p["unc"][b].cpu().view(torch.int16).numpy().view(np.uint16),
-                                        cfg.cfg_scale, model=oracle.MODEL_PLAIN, top_k=cfg.logit_top_k, bf16=True)
+                                        cfg.cfg_scale, model=oracle.MODEL_PLAIN, bf16=True)
             best, alen, sp, cnt = oracle.evaluate_posterior(ocfg, proc, H.row_index_from_retrieve(ret, N), cand, uni[b, cursor:cursor + 64])
             cursor += int(cnt[3])
             tok = oracle.sample_inverse_cdf(sp, float(ub[i, b]))

@@ -515,11 +515,11 @@ def dynamic_run(device, base_cfg, steps, n_seq, fuse_o7=False, groups=None, spec
     return r
 
 
-def other_configs(device, base_cfg, steps, n_seq):
+def other_configs(device, base_cfg, steps, n_seq, only=None):
     """BASELINE configs 2 and 4 on the clock (same GPU, after the headline run; rank 0, N = 1).
     C2  LlamaGen + EAGLE, standard (non-relaxed) verify: V = 16384 (window = vocabulary), dynamic EAGLE-2 tree N = 59 (top_k 10, depth 4),
         lantern off, HF processors T = 1 / top_k 2000, LlamaGen-B KV geometry (12 layers x 12 heads x 64, 2 slabs per sequence);
-        O4 + O6 -> O8 on the raw cond / uncond rows (CFG, top-k and softmax for the rows the walk visits) -> O9 + O10 per step
+        O4 + O6 + the root's and node 1's rows -> O8 on the raw cond / uncond rows (CFG, top-k and softmax for the other rows the walk visits) -> O9 + O10 per step
         (ea_model_llamagen.py:709-787, :930, :1137-1163); `all_rows_by_cfg_mask_topk`: the same with O7 over all 59 rows first.
     C4  Anole-7B 512x512, LANTERN++ static tree naive_extend_57 (N = 58, P = 33, D = 6), the reference's settings (lambda, k) in
         {(5, 10), (10, 5), (20, 5)} (run.sh:76-91): O6 + the 3 likeliest rows -> O8 on raw rows (chain kernel, neighbours zeroed in the drafter's
@@ -528,11 +528,12 @@ def other_configs(device, base_cfg, steps, n_seq):
     import dataclasses
     from lantern_amd import harness as HN
     res = {}
+    c2_spec = int(os.environ.get("LANTERN_C2_SPEC_ROWS", "2"))       # tuning knob (diagnostic): rows prepared beside the tree build
     # ---- C2
     def c2_run(fuse):
         dc = HN.DynamicConfig(model="llamagen", n_seq=n_seq, depth=4, total_tokens=58, kv_layers=12, kv_heads=12, kv_dim=64, kv_smax=base_cfg.kv_smax,
                               kv_pad_rows=base_cfg.kv_pad_rows, with_kv=base_cfg.with_kv, max_steps=2 * steps + 32, plausible=8.0,
-                              n_groups=(3 if n_seq % 3 == 0 else 1), fuse_o7=fuse)
+                              n_groups=(3 if n_seq % 3 == 0 else 1), fuse_o7=fuse, spec_rows=c2_spec)
         wl = HN.DynamicVerifyWorkload(dc, device)
         for _ in range(10):
             wl.step()
@@ -557,7 +558,9 @@ def other_configs(device, base_cfg, steps, n_seq):
         needed = float(((cnt[..., 0] + (1.0 - cnt[..., 4])) * wl.W * 4).sum() / KE)
         r = {"workload": f"C2: LlamaGen + EAGLE standard verify, V=16384, dynamic tree N={wl.N} (top_k 10, depth 4), lantern off, processors T=1/top_k=2000, "
                          f"{n_seq} sequences in {dc.n_groups} stream groups, KV [24,1,12,{dc.kv_smax}(+{dc.kv_pad_rows}),64] bf16 x2 per sequence",
-             "tree_decoding_rows": ("raw bf16 logits post-processed inside evaluate_posterior (LANTERN_ROWS_RAW_BF16, every row on demand)" if fuse
+             "tree_decoding_rows": ((f"raw bf16 logits post-processed inside evaluate_posterior (LANTERN_ROWS_RAW_BF16), {wl.n_spec} rows per sequence up front beside the "
+                                     "tree build (lantern_prepare_step)" if wl.n_spec else
+                                     "raw bf16 logits post-processed inside evaluate_posterior (LANTERN_ROWS_RAW_BF16, every row on demand)") if fuse
                                     else "cfg_mask_topk over all N rows"),
              "value": toks / dt, "unit": "accepted_tokens/s", "ms_per_step": 1e3 * dt / steps, "steps": steps, "mean_accept_length": toks / (steps * n_seq),
              "kernel_ms": {n: float(np.mean([e[n][0].elapsed_time(e[n][1]) for e in evs])) for n in names},
@@ -569,6 +572,8 @@ def other_configs(device, base_cfg, steps, n_seq):
         return r
     res["C2"] = c2_run(True)
     res["C2"]["all_rows_by_cfg_mask_topk"] = {k_: v_ for k_, v_ in c2_run(False).items() if k_ in ("value", "ms_per_step", "kernel_ms", "mean_accept_length")}
+    if only == "C2":              # (tools/run/c2_check.sh)
+        return res
     # ---- C4
     if base_cfg.with_kv:          # as many sequences as the slabs (2 x 2.1 GiB each at 4096 rows) + pools leave room for, in whole stream groups
         free, _ = torch.cuda.mem_get_info(device)

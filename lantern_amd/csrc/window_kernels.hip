@@ -395,7 +395,8 @@ __global__ __launch_bounds__(NT) void dyn_prep_kernel(const DynPrepArgs a) {
         const int b = x / a.n_list, i = x % a.n_list;
         const int node = a.node_list[i], depth = a.node_list[a.n_list + i];
         const int row = b * a.rows_per_seq + node;
-        const int cls = lumina_row_class(a.td.cd.seq_len[b] + 1 + depth, a.pos_base, a.w_latent, a.h_latent);      // = pos_abs of a node at that depth
+        // (= pos_abs of a node at that depth; w_latent == 0: a model without grammar rows -- LlamaGen)
+        const int cls = a.w_latent > 0 ? lumina_row_class(a.td.cd.seq_len[b] + 1 + depth, a.pos_base, a.w_latent, a.h_latent) : 0;
         cfg_window_bf16_row<NT, E8, true>(row, cls, a.cond, a.uncond, a.V, a.cfg, LANTERN_MODEL_LUMINA, a.img_lo, a.img_hi, a.newline_id, a.eos_id,
                                           a.top_k, a.win_lo, a.W, a.out_win, a.row_hot, LANTERN_ROWS_PROBS, s_hist, s_redf, s_redd);
         return;
@@ -1395,19 +1396,25 @@ static int prepare_step_dynamic(const lantern_step_group *g) {
                   g->newline_id, g->eos_id, g->top_k, g->N, g->win_lo, g->win_len, g->out_win, g->row_hot, g->node_list, g->n_list, g->B,
                   TdArgs{d.scores, d.tokens, d.parents, g->sample_token, d.n_scores, d.n_parents, d.top_k, d.total_tokens, d.sort_rows, d.draft_tokens, d.mask,
                          d.pos_ids, d.retrieve, d.n_leaf, d.max_depth, TdCand{d.seq_len, g->cand, d.retrieve_pd, d.pos_abs, d.row_index, g->P, g->D}}};
-    LANTERN_LAUNCH((dyn_prep_kernel<512, 2>), dim3(g->B * g->n_list + g->B), dim3(512), 0, (hipStream_t)g->stream, a);
+    if (g->win_len == 16384) LANTERN_LAUNCH((dyn_prep_kernel<512, 4>), dim3(g->B * g->n_list + g->B), dim3(512), 0, (hipStream_t)g->stream, a);     // LlamaGen: the whole vocabulary
+    else LANTERN_LAUNCH((dyn_prep_kernel<512, 2>), dim3(g->B * g->n_list + g->B), dim3(512), 0, (hipStream_t)g->stream, a);
     LANTERN_CHECK_LAUNCH("prepare_step");
     return LANTERN_OK;
 }
 
 extern "C" int lantern_prepare_step(const lantern_step_group *g) {
     LANTERN_CHECK_ARG(g && g->node_list && g->n_list > 0 && g->n_list <= g->N, "prepare_step: needs a node list");
-    const bool no_grammar = g->w_latent == 0 && g->h_latent == 0;          // Anole: every row an ordinary distribution (LANTERN_MODEL_ANOLE, static trees)
+    const bool no_grammar = g->w_latent == 0 && g->h_latent == 0;          // Anole, LlamaGen: every row an ordinary distribution
+    // the three forms: Lumina (static or dynamic trees), Anole static trees on the same Chameleon image window, LlamaGen dynamic trees on its whole vocabulary
+    const bool chameleon_window = g->win_len == 8192 && g->win_lo == g->img_lo && g->win_lo + g->win_len == g->img_hi && g->win_lo % 4 == 0 &&
+                                  (g->model == LANTERN_MODEL_LUMINA || (g->model == LANTERN_MODEL_ANOLE && no_grammar && !g->dyn));
+    const bool llamagen_rows = g->model == LANTERN_MODEL_PLAIN && no_grammar && g->dyn && g->win_lo == 0 && g->win_len == 16384 && g->V == 16384 &&
+                               g->img_lo == 0 && g->img_hi == 16384;
     LANTERN_CHECK_ARG(g->cond && g->uncond && g->out_win && g->row_hot && (g->dyn || no_grammar || (g->seq_len && g->pos_ids)) && g->dtype == LANTERN_BF16 &&
-                          (g->model == LANTERN_MODEL_LUMINA || (g->model == LANTERN_MODEL_ANOLE && no_grammar && !g->dyn)) &&
-                          g->win_len == 8192 && g->win_lo == g->img_lo && g->win_lo + g->win_len == g->img_hi && g->win_lo % 4 == 0 && g->V % 8 == 0 &&
+                          (chameleon_window || llamagen_rows) && g->V % 8 == 0 &&
                           g->out_kind == LANTERN_ROWS_PROBS && g->temperature == 1.0f && !(g->top_p > 0.0f && g->top_p < 1.0f),
-                      "prepare_step: bf16 Lumina (or Anole, w_latent = h_latent = 0) rows on the 8192-id image window, probability output");
+                      "prepare_step: bf16 rows, probability output: Lumina (or Anole static trees, w_latent = h_latent = 0) on the 8192-id image window, or "
+                      "LlamaGen dynamic trees (LANTERN_MODEL_PLAIN, w_latent = h_latent = 0) on its 16384 ids");
     if (g->dyn) return prepare_step_dynamic(g);
     LANTERN_CHECK_ARG(g->ss_token && g->sample_token && g->tree_indices && g->retrieve && g->tree_cand && g->cand && g->B >= 0 && g->n_flat > 0 && g->N > 0 &&
                           g->P > 0 && g->D > 0, "prepare_step: candidate-assembly buffers missing");

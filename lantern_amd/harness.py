@@ -1001,7 +1001,7 @@ class DynamicVerifyWorkload:
                 w.raw_w_latent, w.raw_h_latent, w.raw_newline_id, w.raw_eos_id = 0, 0, 0, 0
             else:
                 w.raw_w_latent, w.raw_h_latent, w.raw_newline_id, w.raw_eos_id = W_LATENT, H_LATENT, NEWLINE, EOS
-        self.n_spec = max(0, min(int(cfg.spec_rows), 2)) if (self.fused_o7 and not self.lg) else 0
+        self.n_spec = max(0, min(int(cfg.spec_rows), 2)) if self.fused_o7 else 0
         if self.n_spec:
             nodes = list(range(self.n_spec))
             self.d_node_list = torch.tensor(nodes + nodes, dtype=torch.int32, device=device)       # node ids, then the depth each is prepared for
@@ -1041,6 +1041,8 @@ class DynamicVerifyWorkload:
             s.model = ops.MODEL_PLAIN if self.lg else ops.MODEL_LUMINA
             s.pos_ids, s.pos_base, s.seq_len = vp(self.pos_abs, s0), c.prompt_len + 3, None
             s.w_latent, s.h_latent, s.img_lo, s.img_hi, s.newline_id, s.eos_id, s.top_k = W_LATENT, H_LATENT, self.lo, self.hi, NEWLINE, EOS, c.logit_top_k
+            if self.lg:                 # no grammar rows
+                s.w_latent, s.h_latent, s.newline_id, s.eos_id = 0, 0, 0, 0
             s.win_lo, s.win_len, s.out_kind, s.temperature, s.top_p = self.lo, self.W, ops.ROWS_PROBS, 1.0, 1.0
             s.out_win, s.row_hot = (None if self.fused_o7 else vp(self.win, s0)), vp(self.hot, s0)
             C.memmove(C.byref(s.ep), C.byref(self._prm), C.sizeof(EpParams))

@@ -170,8 +170,9 @@ def test_anole_static_loop_matches_oracle_loop(fuse, groups, spec, lam, k):
     assert n_acc > 0 and n_rej > 0
 
 
-@pytest.mark.parametrize("fuse,groups", [(False, 1), (True, 1), (True, 2)], ids=["o7_launch", "raw_rows", "raw_rows_2_groups"])
-def test_llamagen_dynamic_loop_matches_oracle_loop(fuse, groups):
+@pytest.mark.parametrize("fuse,groups,spec", [(False, 1, 0), (True, 1, 0), (True, 2, 0), (True, 1, 2), (True, 2, 1)],
+                         ids=["o7_launch", "raw_rows", "raw_rows_2_groups", "raw_rows_2_prepared", "raw_rows_2_groups_root_prepared"])
+def test_llamagen_dynamic_loop_matches_oracle_loop(fuse, groups, spec):
     """BASELINE config 2 (LlamaGen + EAGLE, standard verify: V = 16384 = the window, LANTERN off, HF processors T = 1 / top_k 2000) through the
     device-resident dynamic loop, with O7 over all rows and with the raw cond / uncond rows post-processed inside evaluate_posterior (the
     1024-thread raw-row instance): the oracle's loop over the same pools / uniforms gives the same (best path, accept length, bonus token) for
@@ -183,9 +184,9 @@ def test_llamagen_dynamic_loop_matches_oracle_loop(fuse, groups):
     import helpers as H
     steps = 8
     cfg = HN.DynamicConfig(model="llamagen", n_seq=3 * groups, pool_steps=2, depth=4, kv_layers=2, kv_heads=4, kv_dim=64, kv_smax=512, max_steps=steps + 2,
-                           fuse_o7=fuse, n_groups=groups)
+                           fuse_o7=fuse, n_groups=groups, spec_rows=spec)
     wl = HN.DynamicVerifyWorkload(cfg, torch.device("cuda"))
-    assert wl.fused_o7 == fuse and wl.lg and wl.n_spec == 0
+    assert wl.fused_o7 == fuse and wl.lg and wl.n_spec == (spec if fuse else 0)
     for _ in range(steps):
         wl.step()
     wl.sync()

@@ -295,7 +295,9 @@ __global__ __launch_bounds__(TA_THREADS, 2) void tree_attention_kernel(const TaA
 }
 
 // second pass when the keys were split over gridDim.y (a last-arriver merge inside the main kernel was measured at 77 us
-// against 20 + 9 us for this second launch: each workgroup's agent-scope fence is an L2 write-back + invalidate on gfx950): grid (batch row x head x query group, chunks of 256/(D/4) query rows),
+// against 20 + 9 us for this second launch: each workgroup's agent-scope fence is an L2 write-back + invalidate on gfx950; with
+// device-coherent `sc1` stores / loads and an arrival counter instead of the fence -- round 3 -- the one kernel takes 20.9 us against
+// 15.3 + 5.9 for the two and the drafter layer 136 against 134 us: the last workgroup's merge is serial where this launch is wide): grid (batch row x head x query group, chunks of 256/(D/4) query rows),
 // one thread per (query row, 4 output columns); the loop over splits is a fixed order (deterministic) of independent loads
 __global__ __launch_bounds__(256) void tree_attention_merge_kernel(const float *__restrict__ ws, uint16_t *__restrict__ out, int nsplit, int N,
                                                                    int D, int QR, int q_groups, int Hq, int64_t o_sb, int64_t o_sn) {

@@ -24,6 +24,7 @@ Extra objects on the JSON line:
                 `frac` there = bytes really moved / time / 8 TB/s.
   lambda_mode   the same loop with lantern_delta = 5 (LANTERN++: tau = 4 p(x)), BASELINE.md run B.
   dynamic_tree  the EAGLE-2 half of C3 (a different 59-node tree per sequence and step), raw rows; and with O7 over all rows.
+  drafter_layer one drafting call of the drafter's decoder layer at 7B size (tools/layer_bench.py in a child process).
   step_latency_us  whole-step wall time at 1 and 8 sequences (the reference's own batch is 1), three evaluate_posterior forms.
   other_groupings  the default kernels with 1 and 2 stream groups.
   cpu_baseline  the oracle (C port of the reference path, pthreads) timed on this host's cores over a bounded sample of the same
@@ -627,6 +628,23 @@ def side_run(device, base_cfg, steps, **over):
     return r
 
 
+def drafter_layer_run():
+    """SURVEY 8f-2 beside the path: one drafting call of the drafter's decoder layer at 7B size (2 x 10 rows against 1200 cached positions: stream-K
+    GEMMs on packed weights, lantern_tree_attention, in-place cache), timed by tools/layer_bench.py in a child process (its own 1 GB of weights)."""
+    import subprocess
+    tool = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools", "layer_bench.py")
+    try:
+        r = subprocess.run([sys.executable, tool, "10", "1200"], env=dict(os.environ, LAYER_BENCH_ONLY="tree"), capture_output=True, text=True, timeout=240)
+        lines = [ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")]
+        if r.returncode or not lines:
+            return {"error": (r.stderr or r.stdout)[-300:]}
+        d = json.loads(lines[-1])
+        return {"workload": "drafter decoder layer, one drafting call: " + d["shape"], "us_per_call": d["hip_tree_attention_inplace_cache_us"],
+                "weight_bytes": d["weight_bytes"], "weight_stream_GBps": d["weight_stream_GBps"], "frac_hbm_peak": d["weight_stream_GBps"] / 8000.0}
+    except Exception as e:          # an extra object: never the reason the line is missing
+        return {"error": repr(e)[:300]}
+
+
 def plan_sequences(total_seqs: int, seqs_per_gpu: int, world: int, groups: int):
     """(sequences per rank, stream groups, scaling).  --total-seqs T: T / world sequences per rank (T must divide: every prompt of the
     reference's batch is generated exactly once), "strong"; else --seqs-per-gpu on every rank, "weak".  The group count is the largest
@@ -904,6 +922,8 @@ def main():
                                                                 if k in ("value", "ms_per_step", "kernel_ms")}
         if not args.no_extras and world == 1 and wl.windowed:
             out["configs"] = other_configs(device, cfg, min(K, 60), n_seq)
+        if not args.no_extras and world == 1 and wl.windowed:
+            out["drafter_layer"] = drafter_layer_run()
         if args.ep_sweep and world == 1:
             out["ep_batch_sweep"] = ep_batch_sweep([int(x) for x in args.ep_sweep.split(",") if x], device, cfg)
         if args.cpu_seconds > 0 and world == 1:      # the CPU baseline is reported at N = 1 only

@@ -26,6 +26,8 @@ o = [f"# Round {R[1:]} profile summary (one MI355X)\n",
      f"* `cpu_baseline` (kind {cb['kind']}): {cb['value']:.0f} tokens/s on {cb['cores']} threads (host shows {cb['host_cores']} cores, usable {cb['usable_cores']}), one thread "
      f"{cb['single_thread']['value']:.0f} tokens/s ({cb['single_thread']['ms_per_seq_step']:.1f} ms per sequence-step).",
      f"* `dynamic_tree`: {dy['value'] / 1e6:.3f} M tokens/s, {1e3 * dy['ms_per_step']:.1f} us per step ({dy['workload']}).",
+     *([f"* `drafter_layer`: {d['drafter_layer']['us_per_call']:.1f} us per call, weights at {d['drafter_layer']['weight_stream_GBps'] / 1e3:.2f} TB/s "
+        f"({d['drafter_layer']['workload']})."] if "us_per_call" in d.get("drafter_layer", {}) else []),
      f"* `configs.C2` ({c['C2'].get('tree_decoding_rows', '')}): {c['C2']['value'] / 1e6:.3f} M tokens/s, {1e3 * c['C2']['ms_per_step']:.1f} us per step; with O7 over all rows: "
      f"{c['C2'].get('all_rows_by_cfg_mask_topk', {}).get('value', 0) / 1e6:.3f} M tokens/s."]
 for x in c["C4"]:

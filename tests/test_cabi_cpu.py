@@ -169,3 +169,16 @@ def test_round2_entry_points_validate_without_gpu():
     assert msg.startswith(b"verify_step: group 0, tree_dynamic_candidates: "), msg
     arr[0].dyn = None
     assert L.lantern_verify_step(arr, 2) == -1 and L.lantern_last_error().startswith(b"verify_step: group 0, gather_candidates: ")
+    # prepare_step's three forms: a LANTERN_MODEL_PLAIN (LlamaGen) group is taken on its whole 16384-id vocabulary with dynamic trees only
+    one = 0x1000                      # any non-null address: the argument check runs on the host, nothing is dereferenced or launched before it fails
+    nl = (C.c_int32 * 4)(0, 1, 0, 1)
+    g = _lib.StepGroup()
+    g.node_list, g.n_list, g.N = C.cast(nl, C.c_void_p).value, 2, 59
+    g.cond = g.uncond = g.out_win = g.row_hot = one
+    g.dtype, g.model, g.V, g.win_lo, g.win_len, g.img_lo, g.img_hi = 1, 0, 16384, 0, 16384, 0, 16384
+    g.out_kind, g.temperature, g.top_p = 1, 1.0, 1.0                       # LANTERN_ROWS_PROBS
+    assert L.lantern_prepare_step(C.byref(g)) == -1 and b"LlamaGen dynamic trees" in L.lantern_last_error()      # static tree: refused
+    g.dyn = C.pointer(dyn)
+    assert L.lantern_prepare_step(C.byref(g)) == -1 and b"dynamic-tree buffers missing" in L.lantern_last_error()   # the form is accepted, the (empty) tree block is not
+    g.win_len = 8192
+    assert L.lantern_prepare_step(C.byref(g)) == -1 and b"LlamaGen dynamic trees" in L.lantern_last_error()

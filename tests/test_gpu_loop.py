@@ -216,6 +216,33 @@ def test_llamagen_dynamic_loop_matches_oracle_loop(fuse, groups, spec):
     assert (len_c.cpu().numpy() == cfg.prompt_len + 3 + gen).all() and (len_u.cpu().numpy() == 3 + gen).all()
 
 
+@pytest.mark.parametrize("model", ["lumina", "llamagen"])
+def test_dynamic_prepared_rows_are_the_o7_rows(model):
+    """lantern_prepare_step with dynamic trees: the rows it leaves for the root and node 1 (beside the tree build, in the same launch) are, bit for
+    bit, the rows lantern_cfg_mask_topk_window computes for those nodes -- on the 8192-id image window (Lumina) and on LlamaGen's 16384 ids."""
+    from lantern_amd import harness as HN
+    from lantern_amd import ops
+    cfg = HN.DynamicConfig(model=model, n_seq=4, pool_steps=1, depth=4, kv_layers=2, kv_heads=4, kv_dim=64, kv_smax=512, max_steps=4, fuse_o7=True, n_groups=2,
+                           spec_rows=2)
+    wl = HN.DynamicVerifyWorkload(cfg, torch.device("cuda"))
+    assert wl.n_spec == 2
+    wl.win.fill_(float("nan"))
+    wl.step()
+    wl.sync()
+    pool = wl.pools[0]
+    B, N = cfg.n_seq, wl.N
+    lg = model == "llamagen"
+    pos = wl.pos_abs.view(B * N)
+    full = ops.cfg_mask_topk_window(pool["cond"].view(B * N, wl.V), pool["unc"].view(B * N, wl.V), cfg.cfg_scale, wl.lo, wl.W,
+                                    model=ops.MODEL_PLAIN if lg else ops.MODEL_LUMINA, pos_ids=None if lg else pos, pos_base=cfg.prompt_len + 3,
+                                    top_k=cfg.logit_top_k, probs=True)
+    rows = full[0] if isinstance(full, tuple) else full
+    rows = rows.view(B, N, wl.W)
+    for node in (0, 1):
+        assert torch.equal(wl.win[:, node], rows[:, node]), node
+    assert torch.isnan(wl.win[:, 2:]).all()                       # nothing else was written
+
+
 @pytest.mark.parametrize("fuse,spec", [(False, 0), (True, 0), (True, 2)], ids=["o7_launch", "raw_rows", "raw_rows_2_prepared"])
 def test_dynamic_step_one_call_equals_per_kernel_calls(fuse, spec):
     """lantern_verify_step with dynamic groups (O4 + O6-dynamic in one launch, lantern_tree_dynamic_candidates) against the same step as

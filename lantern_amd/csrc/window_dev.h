@@ -391,13 +391,17 @@ struct alignas(8) Bf16x8 {
     uint2 a, b;
 };
 
-constexpr int O7_REP = 8;
-
-// Histogram layout: [256 bins x O7_REP copies | 64 spill slots | 256 bins].  Values that must not count (-inf padding /
-// masked ids, or -- second pass -- values outside the chosen top bin) add into the spill slot of their own lane instead of
-// being skipped under a branch: every atomic is unconditional (no exec-mask juggling per element) and the spill slots are
+// Histogram layout: [256 bins x O7_REP copies | 64 spill slots | 256 bins].  First pass: copy = lane % O7_REP.  An LDS atomic costs ~4.2 cycles
+// per wave instruction plus ~2 cycles for every further lane that hits the same word (tools/probe/lds_atomic_probe.hip: 15 cycles at 8 lanes per
+// word, 63 at 32), and a logit row puts most of its 8192 values into a handful of the 256 sign + exponent bins: with 8 copies (up to 8 lanes of an
+// instruction on one word) the pass ran at ~17 cycles per instruction, with 16 copies at most 4 lanes share a word (O7 at 1664 rows 33.8 -> 32.1 us);
+// 32 copies (32 KB) measure the same again -- clearing and merging them costs what the atomics save.
+// Values that must not count (-inf padding / masked ids, or -- second pass -- values outside the chosen top bin) add into the spill slot of their
+// own lane instead of being skipped under a branch: every atomic is unconditional (no exec-mask juggling per element) and the spill slots are
 // conflict-free.
+constexpr int O7_REP = 16;
 constexpr int O7_SPILL = 256 * O7_REP, O7_HIST2 = O7_SPILL + 64, O7_HIST_INTS = O7_HIST2 + 256;
+static_assert(O7_HIST2 % 4 == 0 && O7_REP % 4 == 0, "16-byte clears / merges");
 
 template <int NT, int NV4>
 __device__ __forceinline__ float kth_largest_hist_bf16(const float4 (&r)[NV4], int k, int *h) {
@@ -411,7 +415,7 @@ __device__ __forceinline__ float kth_largest_hist_bf16(const float4 (&r)[NV4], i
         key[it][2] = float_key(r[it].z) >> 16; key[it][3] = float_key(r[it].w) >> 16;
     }
     // ---- pass 0: top 8 bits, replicated histogram
-    for (int t = tid; t < O7_HIST2; t += NT) h[t] = 0;
+    for (int t = tid; t < O7_HIST2 / 4; t += NT) reinterpret_cast<int4 *>(h)[t] = make_int4(0, 0, 0, 0);
     __syncthreads();
     EPW_STAMPG(82);
     const int rep = lane & (O7_REP - 1), spill = O7_SPILL + lane;
@@ -425,9 +429,13 @@ __device__ __forceinline__ float kth_largest_hist_bf16(const float4 (&r)[NV4], i
     __syncthreads();
     EPW_STAMPG(83);
     for (int t = tid; t < 256; t += NT) {
-        const int4 a = *reinterpret_cast<const int4 *>(&h[t * O7_REP]);
-        const int4 b = *reinterpret_cast<const int4 *>(&h[t * O7_REP + 4]);
-        hist[t] = a.x + a.y + a.z + a.w + b.x + b.y + b.z + b.w;
+        int sum = 0;
+#pragma unroll
+        for (int q = 0; q < O7_REP / 4; ++q) {
+            const int4 a = *reinterpret_cast<const int4 *>(&h[t * O7_REP + 4 * q]);
+            sum += a.x + a.y + a.z + a.w;
+        }
+        hist[t] = sum;
     }
     __syncthreads();
     EPW_STAMPG(84);

@@ -187,8 +187,8 @@ __global__ __launch_bounds__(NT) void cfg_window_kernel(const void *__restrict__
 // ---- O7 windowed, bf16 logits, 16-byte loads.  Thread t owns E8 chunks of 8 consecutive window ids (chunk index
 // t + it*NT), so cond and uncond arrive as one global_load_dwordx4 each per chunk (the window start need only be
 // 4-aligned: the loads are then 8-byte aligned, which gfx950 global loads accept).  The first radix pass -- sign + 7 exponent bits, where a logit row
-// concentrates in a handful of bins -- uses an 8-way replicated LDS histogram (copy = lane & 7) so that same-address
-// atomic serialisation drops ~8x; the second pass (7 mantissa bits + 1 exponent bit inside the chosen bin) is spread
+// concentrates in a handful of bins -- uses a 16-way replicated LDS histogram (copy = lane % 16: at most 4 lanes of an
+// instruction on one word, window_dev.h); the second pass (7 mantissa bits + 1 exponent bit inside the chosen bin) is spread
 // out by nature and uses a single copy.
 // One row of the windowed O7 on a workgroup: CFG combination, top-k threshold, softmax, window store (the body of cfg_window_bf16_kernel,
 // shared with the merged launch below).  `cls`: 0 = grid row, 1 = forced newline, 2 = forced end of image.

@@ -399,9 +399,11 @@ struct alignas(8) Bf16x8 {
 // Values that must not count (-inf padding / masked ids, or -- second pass -- values outside the chosen top bin) add into the spill slot of their
 // own lane instead of being skipped under a branch: every atomic is unconditional (no exec-mask juggling per element) and the spill slots are
 // conflict-free.
+// The second pass counts into its own 256 words (O7_HIST1), cleared together with the first pass's copies: nothing has to be cleared -- and no
+// barrier taken -- between reading the merged first-pass counts and adding the second pass's.
 constexpr int O7_REP = 16;
-constexpr int O7_SPILL = 256 * O7_REP, O7_HIST2 = O7_SPILL + 64, O7_HIST_INTS = O7_HIST2 + 256;
-static_assert(O7_HIST2 % 4 == 0 && O7_REP % 4 == 0, "16-byte clears / merges");
+constexpr int O7_SPILL = 256 * O7_REP, O7_HIST2 = O7_SPILL + 64, O7_HIST1 = O7_HIST2 + 256, O7_HIST_INTS = O7_HIST1 + 256;
+static_assert(O7_HIST2 % 4 == 0 && O7_HIST1 % 4 == 0 && O7_REP % 4 == 0, "16-byte clears / merges");
 
 template <int NT, int NV4>
 __device__ __forceinline__ float kth_largest_hist_bf16(const float4 (&r)[NV4], int k, int *h) {
@@ -415,7 +417,8 @@ __device__ __forceinline__ float kth_largest_hist_bf16(const float4 (&r)[NV4], i
         key[it][2] = float_key(r[it].z) >> 16; key[it][3] = float_key(r[it].w) >> 16;
     }
     // ---- pass 0: top 8 bits, replicated histogram
-    for (int t = tid; t < O7_HIST2 / 4; t += NT) reinterpret_cast<int4 *>(h)[t] = make_int4(0, 0, 0, 0);
+    for (int t = tid; t < O7_HIST2 / 4 + 64; t += NT)          // the copies + spill slots, and the second pass's 256 words
+        reinterpret_cast<int4 *>(h)[t < O7_HIST2 / 4 ? t : O7_HIST1 / 4 + (t - O7_HIST2 / 4)] = make_int4(0, 0, 0, 0);
     __syncthreads();
     EPW_STAMPG(82);
     const int rep = lane & (O7_REP - 1), spill = O7_SPILL + lane;
@@ -443,7 +446,8 @@ __device__ __forceinline__ float kth_largest_hist_bf16(const float4 (&r)[NV4], i
     int krem = k;
 #pragma unroll 1
     for (int pass = 0; pass < 2; ++pass) {
-        const int c0 = hist[4 * lane], c1 = hist[4 * lane + 1], c2 = hist[4 * lane + 2], c3 = hist[4 * lane + 3];
+        const int *hp = pass == 0 ? hist : h + O7_HIST1;
+        const int c0 = hp[4 * lane], c1 = hp[4 * lane + 1], c2 = hp[4 * lane + 2], c3 = hp[4 * lane + 3];
         const int s4 = c0 + c1 + c2 + c3;
         const int incl = wave_scan_incl_dpp(s4);
         const int total = readlane63(incl);
@@ -463,17 +467,15 @@ __device__ __forceinline__ float kth_largest_hist_bf16(const float4 (&r)[NV4], i
         krem = __builtin_amdgcn_readlane(kn, src);
         prefix |= (uint32_t)digit << (8 - 8 * pass);
         if (pass == 1) break;
-        // ---- pass 1: low 8 bits among the values of the chosen top bin, single histogram
-        __syncthreads();   // everyone has read hist
-        for (int t = tid; t < 256 + 64; t += NT) h[O7_SPILL + t] = 0;
-        __syncthreads();
+        // ---- pass 1: low 8 bits among the values of the chosen top bin, single histogram in its own (already cleared) words; what the spill
+        // slots hold is never read
         const uint32_t top = prefix >> 8;
 #pragma unroll
         for (int it = 0; it < NV4; ++it)
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 const uint32_t kk = key[it][c];
-                atomicAdd(&h[((kk >> 8) == top && kk != 0x007fu) ? O7_HIST2 + (int)(kk & 255u) : spill], 1);
+                atomicAdd(&h[((kk >> 8) == top && kk != 0x007fu) ? O7_HIST1 + (int)(kk & 255u) : spill], 1);
             }
         __syncthreads();
         EPW_STAMPG(85);

@@ -396,9 +396,10 @@ struct alignas(8) Bf16x8 {
 // word, 63 at 32), and a logit row puts most of its 8192 values into a handful of the 256 sign + exponent bins: with 8 copies (up to 8 lanes of an
 // instruction on one word) the pass ran at ~17 cycles per instruction, with 16 copies at most 4 lanes share a word (O7 at 1664 rows 33.8 -> 32.1 us);
 // 32 copies (32 KB) measure the same again -- clearing and merging them costs what the atomics save.
-// Values that must not count (-inf padding / masked ids, or -- second pass -- values outside the chosen top bin) add into the spill slot of their
-// own lane instead of being skipped under a branch: every atomic is unconditional (no exec-mask juggling per element) and the spill slots are
-// conflict-free.
+// Second pass: values outside the chosen top bin add into a spill slot (their own lane's, mostly) instead of being skipped under a branch: every
+// atomic is unconditional (no exec-mask juggling per element) and the spill slots are conflict-free.  O7 keeps its VALU arbiters busy 0.71 of
+// the launch (profiles/r03_pmc_sq.txt), so the address arithmetic of the 2 x 16 atomics per thread is written for instruction count: -inf
+// (key 0x007f) counts in the lowest bin like any value (no compare + select per element: O7 31.5 -> 30.0 us, the raw-row walk 35.9 -> 34.9 us).
 // The second pass counts into its own 256 words (O7_HIST1), cleared together with the first pass's copies: nothing has to be cleared -- and no
 // barrier taken -- between reading the merged first-pass counts and adding the second pass's.
 constexpr int O7_REP = 16;
@@ -421,13 +422,14 @@ __device__ __forceinline__ float kth_largest_hist_bf16(const float4 (&r)[NV4], i
         reinterpret_cast<int4 *>(h)[t < O7_HIST2 / 4 ? t : O7_HIST1 / 4 + (t - O7_HIST2 / 4)] = make_int4(0, 0, 0, 0);
     __syncthreads();
     EPW_STAMPG(82);
+    static_assert(O7_REP == 16, "bin * 16 | copy below");
     const int rep = lane & (O7_REP - 1), spill = O7_SPILL + lane;
 #pragma unroll
     for (int it = 0; it < NV4; ++it)
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            const uint32_t kk = key[it][c];
-            atomicAdd(&h[kk != 0x007fu ? (int)((kk >> 8) * O7_REP) + rep : spill], 1);   // 0x007f = -inf: never ranks
+            // (-inf, key 0x007f, counts in the lowest bin like any value: if the k-th largest is -inf the two passes find exactly that key)
+            atomicAdd(&h[(int)(((key[it][c] >> 4) & 0xff0u) | (uint32_t)rep)], 1);
         }
     __syncthreads();
     EPW_STAMPG(83);
@@ -475,7 +477,7 @@ __device__ __forceinline__ float kth_largest_hist_bf16(const float4 (&r)[NV4], i
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 const uint32_t kk = key[it][c];
-                atomicAdd(&h[((kk >> 8) == top && kk != 0x007fu) ? O7_HIST1 + (int)(kk & 255u) : spill], 1);
+                atomicAdd(&h[(kk >> 8) == top ? O7_HIST1 + (int)(kk & 255u) : spill], 1);
             }
         __syncthreads();
         EPW_STAMPG(85);

@@ -402,8 +402,9 @@ struct alignas(8) Bf16x8 {
 // (key 0x007f) counts in the lowest bin like any value (no compare + select per element: O7 31.5 -> 30.0 us, the raw-row walk 35.9 -> 34.9 us).
 // The second pass counts into its own 256 words (O7_HIST1), cleared together with the first pass's copies: nothing has to be cleared -- and no
 // barrier taken -- between reading the merged first-pass counts and adding the second pass's.
+// Layout (32-bit words): [256 bins x O7_REP copies | 256 merged first-pass counts (O7_HIST2) | 256 second-pass counts (O7_HIST1) | 64 spill slots].
 constexpr int O7_REP = 16;
-constexpr int O7_SPILL = 256 * O7_REP, O7_HIST2 = O7_SPILL + 64, O7_HIST1 = O7_HIST2 + 256, O7_HIST_INTS = O7_HIST1 + 256;
+constexpr int O7_HIST2 = 256 * O7_REP, O7_HIST1 = O7_HIST2 + 256, O7_SPILL = O7_HIST1 + 256, O7_HIST_INTS = O7_SPILL + 64;
 static_assert(O7_HIST2 % 4 == 0 && O7_HIST1 % 4 == 0 && O7_REP % 4 == 0, "16-byte clears / merges");
 
 template <int NT, int NV4>
@@ -418,18 +419,20 @@ __device__ __forceinline__ float kth_largest_hist_bf16(const float4 (&r)[NV4], i
         key[it][2] = float_key(r[it].z) >> 16; key[it][3] = float_key(r[it].w) >> 16;
     }
     // ---- pass 0: top 8 bits, replicated histogram
-    for (int t = tid; t < O7_HIST2 / 4 + 64; t += NT)          // the copies + spill slots, and the second pass's 256 words
+    for (int t = tid; t < O7_HIST2 / 4 + 64; t += NT)          // the copies, and the second pass's 256 words (what the spill slots hold is never read)
         reinterpret_cast<int4 *>(h)[t < O7_HIST2 / 4 ? t : O7_HIST1 / 4 + (t - O7_HIST2 / 4)] = make_int4(0, 0, 0, 0);
     __syncthreads();
     EPW_STAMPG(82);
-    static_assert(O7_REP == 16, "bin * 16 | copy below");
-    const int rep = lane & (O7_REP - 1), spill = O7_SPILL + lane;
+    static_assert(O7_REP == 16, "byte offset of (bin, copy) below");
+    char *const hb = reinterpret_cast<char *>(h);
+    const uint32_t rep4 = (uint32_t)(lane & (O7_REP - 1)) << 2;
 #pragma unroll
     for (int it = 0; it < NV4; ++it)
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            // (-inf, key 0x007f, counts in the lowest bin like any value: if the k-th largest is -inf the two passes find exactly that key)
-            atomicAdd(&h[(int)(((key[it][c] >> 4) & 0xff0u) | (uint32_t)rep)], 1);
+            // byte offset of word (bin * 16 + copy), bin = key >> 8: two operations per value.  (-inf, key 0x007f, counts in the lowest bin like
+            // any value: if the k-th largest is -inf the two passes find exactly that key)
+            atomicAdd(reinterpret_cast<int *>(hb + (((key[it][c] >> 2) & 0x3fc0u) | rep4)), 1);
         }
     __syncthreads();
     EPW_STAMPG(83);
@@ -469,15 +472,16 @@ __device__ __forceinline__ float kth_largest_hist_bf16(const float4 (&r)[NV4], i
         krem = __builtin_amdgcn_readlane(kn, src);
         prefix |= (uint32_t)digit << (8 - 8 * pass);
         if (pass == 1) break;
-        // ---- pass 1: low 8 bits among the values of the chosen top bin, single histogram in its own (already cleared) words; what the spill
-        // slots hold is never read
-        const uint32_t top = prefix >> 8;
+        // ---- pass 1: low 8 bits among the values of the chosen top bin, single histogram in its own (already cleared) words.  A value of the bin
+        // sits at key - (top << 8) in 0..255; anything else wraps to >= 256 and is capped at 256 + lane: the spill slots follow the 256 counts
+        // (a value just above the bin may land in another lane's slot -- nobody reads them).  Subtract, min, shift: three operations per value.
+        const uint32_t base = prefix & 0xff00u, cap = 256u + (uint32_t)lane;
 #pragma unroll
         for (int it = 0; it < NV4; ++it)
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-                const uint32_t kk = key[it][c];
-                atomicAdd(&h[(kk >> 8) == top ? O7_HIST1 + (int)(kk & 255u) : spill], 1);
+                const uint32_t d = key[it][c] - base;
+                atomicAdd(reinterpret_cast<int *>(hb + O7_HIST1 * 4 + ((d < cap ? d : cap) << 2)), 1);
             }
         __syncthreads();
         EPW_STAMPG(85);

@@ -79,8 +79,9 @@ __device__ __forceinline__ f32x2_t cfg_mix_bf16x2(unsigned int cw, unsigned int 
 
 // order-preserving float -> uint key (ascending)
 __device__ __forceinline__ uint32_t float_key(float f) {
-    uint32_t u = __float_as_uint(f);
-    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+    const uint32_t u = __float_as_uint(f);
+    // negative: ~u, else u | sign bit -- as one xor with (sign-extended sign | sign bit): three operations, no compare + select
+    return u ^ ((uint32_t)((int32_t)u >> 31) | 0x80000000u);
 }
 __device__ __forceinline__ float key_float(uint32_t k) {
     uint32_t u = (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k;

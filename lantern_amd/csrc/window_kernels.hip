@@ -1229,41 +1229,53 @@ __device__ __forceinline__ int epw_body(const EpwArgs &args, const int b) {
             last_pos = out_tok;
             if ((double)out_mass > tgt) found = out_tok;
         }
+        // The crossing is the smallest id whose running sum exceeds tgt: a 4-id chunk whose sum range [excl, excl + s4] lies wholly below tgt
+        // cannot hold it, and a chunk wholly above tgt can only offer an id larger than the crossing chunk's -- so only chunks whose range
+        // comes within a guard band of tgt run the element loop (same additions in the same order as before, hence the same token): one or two
+        // threads of the workgroup instead of all 512 x 16 elements in f64.
+        const double band = 1e-9 * total;
 #pragma unroll
         for (int it = 0; it < E4; ++it) {
-            const int e = lo + (tid + it * NT) * 4;
-            double acc = excl[it];
-            const float pv[4] = {p[it].x, p[it].y, p[it].z, p[it].w};
+            if (excl[it] - band <= tgt && excl[it] + s4[it] + band >= tgt) {
+                const int e = lo + (tid + it * NT) * 4;
+                double acc = excl[it];
+                const float pv[4] = {p[it].x, p[it].y, p[it].z, p[it].w};
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                acc += (double)pv[c];
-                if constexpr (WPE == 1) {      // latency build: selects, not branches (16 elements per thread)
-                    const bool pos = pv[c] > 0.0f;
-                    last_pos = max(last_pos, pos ? e + c : -1);
-                    found = min(found, (pos && acc > tgt) ? e + c : 0x7fffffff);
-                } else if (pv[c] > 0.0f) {     // throughput build (two workgroups per CU): skip the work of the zero entries
-                    last_pos = max(last_pos, e + c);
-                    if (acc > tgt) found = min(found, e + c);
+                for (int c = 0; c < 4; ++c) {
+                    acc += (double)pv[c];
+                    if (pv[c] > 0.0f && acc > tgt) found = min(found, e + c);
                 }
             }
         }
-        if (out_tok >= 0 && !out_before && out_mass > 0.0f) {
-            last_pos = max(last_pos, out_tok);
-            if (total > tgt) found = min(found, out_tok);   // only wins when nothing inside the window crossed
-        }
+        if (out_tok >= 0 && !out_before && out_mass > 0.0f && total > tgt) found = min(found, out_tok);   // only wins when nothing inside the window crossed
         found = wave_min_i(found);
-        last_pos = wave_max_i(last_pos);
         __syncthreads();
-        if (lane == 0) {
-            S.redi[wave] = found;
-            S.redi[16 + wave] = last_pos;
-        }
+        if (lane == 0) S.redi[wave] = found;
         __syncthreads();
-        if (wave == 0) {
-            const int f = wave_min_i(lane < NW ? S.redi[lane] : 0x7fffffff);
-            const int l = wave_max_i(lane < NW ? S.redi[16 + lane] : -1);
-            if (lane == 0) k_token[b] = f != 0x7fffffff ? f : l;
+        int f = S.redi[0];
+#pragma unroll
+        for (int w = 1; w < NW; ++w) f = min(f, S.redi[w]);
+        if (f == 0x7fffffff) {
+            // nothing crossed (tgt landed on the rounding of the total): the reference's inverse CDF then yields the LAST id with mass -- found
+            // by a second pass, off the common path
+#pragma unroll
+            for (int it = 0; it < E4; ++it) {
+                const int e = lo + (tid + it * NT) * 4;
+                const float pv[4] = {p[it].x, p[it].y, p[it].z, p[it].w};
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+                    if (pv[c] > 0.0f) last_pos = max(last_pos, e + c);
+            }
+            if (out_tok >= 0 && !out_before && out_mass > 0.0f) last_pos = max(last_pos, out_tok);
+            last_pos = wave_max_i(last_pos);
+            __syncthreads();
+            if (lane == 0) S.redi[16 + wave] = last_pos;
+            __syncthreads();
+            f = S.redi[16];
+#pragma unroll
+            for (int w = 1; w < NW; ++w) f = max(f, S.redi[16 + w]);
         }
+        if (tid == 0) k_token[b] = f;
     }
     EPW_STAMP(50);
 #ifdef EPW_TRACE

@@ -53,7 +53,7 @@ for fn, lab in ((f"{R}_skinny_gemm_per_tile_round2.json", "per-tile kernels (rou
     o.append(f"* GEMMs alone, {lab}: {g['all']['us']:.1f} us for {g['all']['weight_MB']:.0f} MB = {g['all']['GBps'] / 1e3:.2f} TB/s ({g['all']['frac_of_8TBps']:.3f} of 8 TB/s) -- per kernel: "
              + "; ".join(f"{k.split(' (')[0]} {v['us']:.1f} us" for k, v in g['kernels'].items()))
 o += ["\n## In-kernel phase stamps (`tools/ep_trace.py`, separate `-DEPW_TRACE` build)\n",
-      f"`{R}_chain_trace_probs64.txt` / `{R}_chain_trace_raw21.txt`: the chain kernel before the compile-time instances; `*_spec2.txt`: after; `{R}_chain_trace_raw21_hist16.txt`: after the 16-copy histogram of the top-k select; `{R}_fast_walk_trace_*`: the removed "
+      f"`{R}_chain_trace_probs64.txt` / `{R}_chain_trace_raw21.txt`: the chain kernel before the compile-time instances; `*_spec2.txt`: after; `{R}_chain_trace_raw21_final.txt` / `{R}_chain_trace_probs64_final.txt`: the round's final kernels; `{R}_fast_walk_trace_*`: the removed "
       f"fast-walk kernel (v5); `{R}_o7_parts.txt`: O7 with top-k / softmax switched off in turn."]
 open(P(f"{R}_summary.md"), "w").write("\n".join(o) + "\n")
 print("wrote", P(f"{R}_summary.md"))

@@ -269,62 +269,91 @@ def cpu_baseline(wl, steps_budget_s: float, n_seq: int, gpu_tokens_by_seq, pytho
 
 # ------------------------------------------------------------------------- EP-only batch sweep
 
-def ep_batch_sweep(batches, device, base_cfg, iters=20):
+def ep_batch_sweep(batches, device, base_cfg, iters=24, kernels=("chain", "nodes"), min_rotation_bytes=3 << 29):
     """evaluate_posterior alone over a batch sweep ({1, 8, 64, 512, 4096} sequences per launch), both forms: the
-    per-sequence chain kernel and the node-parallel kernel (+ its walk).  Same synthetic recipe, no KV slabs; inputs of one
-    verify step are produced by the real O6 / O7 kernels, then the O8 launch is repeated `iters` times on identical inputs
-    between HIP events.  `frac` = bytes the windowed kernels really have to move / time / 8 TB/s; the SURVEY 8d contract
-    formula (dense V-wide rows, which no windowed kernel moves) is kept as `contract_equivalent_GBps`, never as a fraction."""
+    per-sequence chain kernel and the node-parallel kernel (+ its walk).  Same synthetic recipe, no KV slabs.
+
+    ROTATING inputs: the real O6 / O7 kernels produce the inputs of R different verify steps (pool slots cycled, the sequences' state
+    advancing from step to step); each step's evaluate_posterior inputs -- probability rows, drafter rows, candidates, their tables -- are
+    kept in their OWN allocations and launch i runs on set i mod R, so that a launch never finds its rows in the L2 / Infinity Cache
+    (256 MiB) from the launch before: R sets hold >= `min_rotation_bytes` (1.5 GiB) whenever the sets are big enough for that
+    (`rotation_bytes`, `cache_resident` say what a point got).  Nothing but the kernel sits between a launch's two HIP events (no cursor
+    reset: the launches read the uniform stream at offset 0 and do not advance it).
+    `frac` = bytes the windowed kernels really have to move / time / 8 TB/s; the SURVEY 8d contract formula (dense V-wide rows, which no
+    windowed kernel moves) is kept as `contract_equivalent_GBps`, never as a fraction."""
     import ctypes as C
     from lantern_amd import harness as HN
     from lantern_amd._lib import check
     out = []
     for Bs in batches:
-        need = Bs * (2 * 26 * 65536 * 2 + 6 * 26 * 65536 * 4 + 11 * 65536 * 4 * 3) + (4 << 30)   # pools + setup temporaries
+        S = 4 if Bs <= 512 else 1          # pool steps with their own random rows (a 4096-sequence pool step is 27 GB of raw logits + f32 temporaries)
+        need = Bs * (S * 2 * 26 * 65536 * 2 + 6 * 26 * 65536 * 4 + 11 * 65536 * 4 * 3) + (6 << 30)   # pools + setup temporaries + the rotation sets
         free, _ = torch.cuda.mem_get_info(device)
         if need > free:
             out.append({"sequences_per_launch": Bs, "skipped": f"needs {need >> 30} GiB, {free >> 30} GiB free"})
             continue
-        cfg = HN.WorkloadConfig(n_seq=Bs, pool_steps=1, use_graph=False, lantern_k=base_cfg.lantern_k, lantern_delta=base_cfg.lantern_delta,
-                                sigma=base_cfg.sigma, with_kv=False, max_steps=8, path=base_cfg.path, seed_base=base_cfg.seed_base + 500,
-                                ep_kernel="nodes", tree=base_cfg.tree)
+        cfg = HN.WorkloadConfig(n_seq=Bs, pool_steps=S, use_graph=False, lantern_k=base_cfg.lantern_k, lantern_delta=base_cfg.lantern_delta,
+                                sigma=base_cfg.sigma, with_kv=False, max_steps=64, path=base_cfg.path, seed_base=base_cfg.seed_base + 500,
+                                ep_kernel="nodes", tree=base_cfg.tree, native_step=False)
         wl = HN.LuminaVerifyWorkload(cfg, device)
-        wl.step()                      # O6 + O7 fill cand / proc / row_hot; one O8 result lands in log slot 0
-        torch.cuda.synchronize(device)
         L = wl._L
         st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-        buf = wl.ep_buffers(0, 0)
-        win = wl.ep_window(0) if wl.windowed else None
-        row = {"sequences_per_launch": Bs}
-        for kern in (("chain", "nodes") if wl.windowed else ("dense",)):
-            def launch():
-                wl.cursor.zero_()
+        set_bytes = (wl.proc.numel() + wl.orig_prob[0].numel() + wl.cart_prob.numel()) * 4 + (wl.cand.numel() + wl.tree_cand.numel()) * 8
+        R = int(min(48, max(4, -(-min_rotation_bytes // max(set_bytes, 1)))))
+        sets = []
+        for r in range(R):
+            wl.step()                      # O6 + O7 (+ one O8 / O9-less bookkeeping) of verify step r: cand / proc / row_hot of that step
+            torch.cuda.synchronize(device)
+            slot = r % S
+            keep = dict(proc=wl.proc.clone(), row_hot=wl.row_hot.clone(), cand=wl.cand.clone(), cart=wl.cart_prob.clone(), tcand=wl.tree_cand.clone(),
+                        orig=wl.orig_prob[slot].clone(), best=torch.zeros_like(wl.st_best), alen=torch.zeros_like(wl.st_alen),
+                        cnt=torch.zeros_like(wl.st_cnt), tok=torch.zeros_like(wl.st_token), otok=torch.zeros_like(wl.out_tok), omass=torch.zeros_like(wl.out_mass))
+            buf = wl.ep_buffers(slot, 0)
+            buf.logits, buf.cand, buf.cart_prob, buf.tree_cand, buf.orig_prob = (keep["proc"].data_ptr(), keep["cand"].data_ptr(), keep["cart"].data_ptr(),
+                                                                              keep["tcand"].data_ptr(), keep["orig"].data_ptr())
+            buf.cursor = None              # read the uniforms at offset 0, leave no cursor behind: every launch on a set repeats the same walk
+            buf.best, buf.accept_len, buf.counters = keep["best"].data_ptr(), keep["alen"].data_ptr(), keep["cnt"].data_ptr()
+            win = wl.ep_window(0)
+            win.row_hot, win.token, win.out_tok, win.out_mass = keep["row_hot"].data_ptr(), keep["tok"].data_ptr(), keep["otok"].data_ptr(), keep["omass"].data_ptr()
+            sets.append((keep, buf, win))
+        row = {"sequences_per_launch": Bs, "rotation_sets": R, "rotation_bytes": R * set_bytes, "pool_steps": S,
+               "cache_resident": bool(R * set_bytes < (512 << 20))}
+        for kern in (kernels if wl.windowed else ("dense",)):
+            def launch(r):
+                _k, buf, win = sets[r % R]
                 if kern == "nodes":
                     check(L.lantern_evaluate_posterior_nodes(C.byref(wl._ep_prm), C.byref(buf), C.byref(win), C.byref(wl.ep_nodes[0]), st), "ep")
                 elif kern == "chain":
                     check(L.lantern_evaluate_posterior_window(C.byref(wl._ep_prm), C.byref(buf), C.byref(win), st), "ep")
                 else:
                     check(L.lantern_evaluate_posterior(C.byref(wl._ep_prm), C.byref(buf), st), "ep")
-            for _ in range(3):
-                launch()
+            for r in range(R):             # every set once, untimed (code objects, first touch of the output buffers)
+                launch(r)
+            torch.cuda.synchronize(device)
             evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
-            for e0, e1 in evs:
-                wl.cursor.zero_()
+            for i, (e0, e1) in enumerate(evs):
                 e0.record()
-                launch()
+                launch(i)
                 e1.record()
             torch.cuda.synchronize(device)
-            if int(wl.st_cnt[:, 5].abs().sum()) != 0:
-                raise RuntimeError("evaluate_posterior reported a per-sequence error in the sweep")
             ms = float(np.median([a.elapsed_time(b) for a, b in evs]))
-            nbytes = wl.ep_window_bytes_from(wl.st_cnt) if wl.windowed else wl.ep_algorithmic_bytes_from(wl.st_cnt)
-            dense = wl.ep_algorithmic_bytes_from(wl.st_cnt)
-            row[kern] = {"launch_ms": ms, "us_per_sequence": 1e3 * ms / Bs, "hbm_bytes_needed_per_launch": nbytes,
+            # the same launches back to back (whole-loop wall time / launches: what a caller that keeps the queue full gets)
+            t0 = time.perf_counter()
+            for i in range(iters):
+                launch(i)
+            torch.cuda.synchronize(device)
+            loop_ms = 1e3 * (time.perf_counter() - t0) / iters
+            cnts = [k_["cnt"] for k_, _b, _w in sets]
+            if any(int(c_[:, 5].abs().sum()) != 0 for c_ in cnts):
+                raise RuntimeError("evaluate_posterior reported a per-sequence error in the sweep")
+            nbytes = float(np.mean([wl.ep_window_bytes_from(c_) if wl.windowed else wl.ep_algorithmic_bytes_from(c_) for c_ in cnts]))
+            dense = float(np.mean([wl.ep_algorithmic_bytes_from(c_) for c_ in cnts]))
+            row[kern] = {"launch_ms": ms, "back_to_back_ms": loop_ms, "us_per_sequence": 1e3 * ms / Bs, "hbm_bytes_needed_per_launch": nbytes,
                          "achieved_GBps": nbytes / (ms * 1e-3) / 1e9, "frac": nbytes / (ms * 1e-3) / 1e9 / 8000.0,
                          "contract_equivalent_GBps": dense / (ms * 1e-3) / 1e9}
-        row["accepted_tokens_per_launch"] = float((wl.st_alen.float() + 1).sum())
+        row["accepted_tokens_per_launch"] = float(np.mean([float((k_["alen"].float() + 1).sum()) for k_, _b, _w in sets]))
         out.append(row)
-        del wl
+        del wl, sets
         torch.cuda.empty_cache()
     return out
 

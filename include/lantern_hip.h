@@ -509,7 +509,8 @@ int lantern_linear_rows_epilogue(const void *A, const void *W, const void *bias,
 int lantern_linear_rows_splitk(const void *A, const void *W, const void *bias, int M, int K, int n_rows, void *out, int out_stride,
                                const void *residual, int residual_stride, int ksplit, float *workspace, void *stream);
 /* The same products (epilogue 0: bias only, LANTERN_EPI_RESIDUAL, LANTERN_EPI_SILU_MUL) in stream-K form, ONE launch, deterministic: the (tile, K)
- * space is cut into equal contiguous shares, one per workgroup (two workgroups per CU), a tile's partial sums meet in the workspace and the
+ * space is cut into equal contiguous shares, one per workgroup, one workgroup per CU of the current device (hipDeviceAttributeMultiprocessorCount;
+ * the LANTERN_SK_GROUPS environment variable overrides the count for tuning runs only), a tile's partial sums meet in the workspace and the
  * workgroup that completes a tile adds them in K order and runs the epilogue; two trips of loads in flight per wave.  The form the decoder layer
  * uses at its decode shape (M <= 32).  workspace: [dev] lantern_linear_rows_streamk_workspace(n_rows) bytes, 16-byte aligned, zero-filled ONCE
  * by the caller (the kernel leaves its counters zeroed); one launch at a time per workspace. */

@@ -792,11 +792,14 @@ __global__ __launch_bounds__(FC_THREADS) void linear_rows_streamk_kernel(const S
             for (int s_ = 0; s_ < NSET; ++s_)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) __hip_atomic_store(wsp + s_ * 1024 + tid + j * FC_THREADS, v[s_][j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");          // (vmcnt(0): the stores above are acknowledged)
+            // A workgroup-scope release fence emits no wait on gfx950 (and its barrier is a back-off barrier that inserts none either): the
+            // explicit vmcnt(0) is what makes every thread's sc1 stores acknowledged by the L2 before the barrier lets thread 0 publish
+            // the count -- the count and the partials live in different L2 channels and nothing else orders them.
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             if (tid == 0) {
                 const uint32_t mine = (uint32_t)(ce - cb);
-                s_last = (atomicAdd(&a.cnt[t], mine) + mine == (uint32_t)cpt) ? 1u : 0u;
+                s_last = (__hip_atomic_fetch_add(&a.cnt[t], mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + mine == (uint32_t)cpt) ? 1u : 0u;
             }
             __syncthreads();
             finish = s_last != 0u;
@@ -864,10 +867,19 @@ __global__ __launch_bounds__(FC_THREADS) void linear_rows_streamk_kernel(const S
     }
 }
 
-// workgroups of a launch: one per CU (the register buffers of the trips in flight leave room for one 512-thread workgroup)
+// workgroups of a launch: one per CU of the current device (the register buffers of the trips in flight leave room for one 512-thread
+// workgroup per CU).  LANTERN_SK_GROUPS overrides it -- a diagnostic knob for tuning runs, read once per process.
 static int sk_groups(int) {
-    static const int g = getenv("LANTERN_SK_GROUPS") ? atoi(getenv("LANTERN_SK_GROUPS")) : 0;      // tuning knob (diagnostic)
-    return g > 0 ? g : 256;
+    static const int env_g = getenv("LANTERN_SK_GROUPS") ? atoi(getenv("LANTERN_SK_GROUPS")) : 0;
+    if (env_g > 0) return env_g;
+    static int cus[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    if (cus[dev] == 0) {
+        int n = 0;
+        cus[dev] = (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : 256;
+    }
+    return cus[dev];
 }
 
 

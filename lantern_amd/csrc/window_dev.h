@@ -337,21 +337,27 @@ constexpr int EW_PF_K = 1024;     // ... when k + 1 <= EW_PF_K; otherwise ids ar
 // by the launch's actual P*D (epw_pd_cap) instead of the 64 x 16 worst case: 20 KB -> ~2 KB for the reference's trees, which
 // is what lets two workgroups share a CU at saturating batch sizes.
 struct alignas(16) EwShared {
-    int bidx[EW_MAX_B];
+    unsigned short bidx[EW_MAX_B];          // earlier-sibling node ids (< EW_MAX_N)
     int tcand[EW_MAX_N];
     int opoff[EW_MAX_D];
     double uni[EW_UNI];
     double redd[2 * 16];
     float redf[2 * 16];
     int redi[2 * 16];
-    double samp_tot[16][4];
+    double samp_tot[64];                    // [wave * E4 + it]: per-wave totals of the bonus draw's segments (NW * E4 <= 64)
     int dec[2][4];                          // decision words of wave 0: {code, m>0, csm1 bits, -}
     double ubonus[2];                       // [0]: the bonus draw's uniform, fetched with the prologue's first round of loads
     int hot[EW_MAX_N];                      // row_hot of this sequence's rows (when rows_per_seq <= EW_MAX_N)
     int pre[EW_MAX_N];                      // LANTERN_ROWS_RAW_BF16: 1 = the row was post-processed up front (win.raw_probs)
-    unsigned short nbid[EW_PF_C][EW_PF_K];  // prefetched neighbour ids (raw table values)
-    unsigned short nbaddr[EW_PF_C][EW_PF_K];// the same neighbours as gather indices into g (window index or a sentinel slot)
+    // Prefetched neighbours of a level's candidates as gather indices into g: window index, or a sentinel slot (0 outside the window, the
+    // out-of-window one-hot token's mass, 3e38 at positions >= k so that they can never pass `<= tau`).  The raw table ids are not kept: the
+    // zeroing after a rejection needs "window index or not" and "is it the out-of-window token", both of which the gather index says; the
+    // one id it zeroes beyond the k it sums (position k, whose scan slot is the 3e38 sentinel) keeps its plain index in nbk.  12 KB less LDS per
+    // workgroup than with both forms -- what lets three workgroups share a CU.
+    unsigned short nbaddr[EW_PF_C][EW_PF_K];
+    unsigned short nbk[8];                  // per slot: plain gather index of neighbour k (the k+1-th, zeroed but never summed)
 };
+static_assert(EW_PF_C <= 8, "nbk slots");
 
 // g[W + EW_G_ZERO] = 0 (neighbour outside the window), g[W + EW_G_HUGE] = 3e38 (position >= k: never under tau),
 // g[W + EW_G_OUT] = out_mass (neighbour == the one-hot token outside the window): gather targets of the scan

@@ -649,7 +649,7 @@ __device__ __forceinline__ int epw_body(const EpwArgs &args, const int b) {
 #pragma unroll
             for (int u = 0; u < B_PER; ++u) {
                 const int t = tid + u * NT;
-                if (t < nb_total && t < EW_MAX_B) S.bidx[t] = bi_[u];
+                if (t < nb_total && t < EW_MAX_B) S.bidx[t] = (unsigned short)bi_[u];
             }
 #pragma unroll
             for (int u = 0; u < N_PER; ++u) {
@@ -714,12 +714,12 @@ __device__ __forceinline__ int epw_body(const EpwArgs &args, const int b) {
         // flight together and the ids are written to LDS under the row's last barrier (one exposed latency per level)
         constexpr int PF_PER = (EW_PF_K + NT - 1) / NT;
         // position t of a neighbour list -> index into g for the scan (out_tok is final before the ids are staged)
-        auto gather_addr = [&](int id, int t) -> unsigned short {
+        auto plain_addr = [&](int id) -> unsigned short {
             const int e = id + off;
-            if (t >= k) return (unsigned short)(W + EW_G_HUGE);
             if (e >= lo && e < lo + W) return (unsigned short)(e - lo);
             return (unsigned short)(W + (e == out_tok ? EW_G_OUT : EW_G_ZERO));
         };
+        auto gather_addr = [&](int id, int t) -> unsigned short { return t >= k ? (unsigned short)(W + EW_G_HUGE) : plain_addr(id); };
         unsigned short idv[EW_PF_C][PF_PER];
         constexpr int CH_PER_C = EW_PF_K / 8;                              // 16-byte chunks per candidate
         constexpr int PF16_PER = (EW_PF_C * CH_PER_C + NT - 1) / NT;
@@ -795,10 +795,10 @@ __device__ __forceinline__ int epw_body(const EpwArgs &args, const int b) {
 #pragma unroll
                             for (int q = 0; q < 4; ++q) {
                                 const uint32_t i0 = (t0 + 2 * q < nz) ? (w[q] & 0xffffu) : 0u, i1 = (t0 + 2 * q + 1 < nz) ? (w[q] >> 16) : 0u;
-                                w[q] = i0 | (i1 << 16);
                                 ad[q] = (uint32_t)gather_addr((int)i0, t0 + 2 * q) | ((uint32_t)gather_addr((int)i1, t0 + 2 * q + 1) << 16);
+                                if (t0 + 2 * q == k) S.nbk[c] = plain_addr((int)i0);                 // (k < nz: the id is real; else nothing reads nbk)
+                                if (t0 + 2 * q + 1 == k) S.nbk[c] = plain_addr((int)i1);
                             }
-                            *reinterpret_cast<uint4 *>(&S.nbid[c][t0]) = make_uint4(w[0], w[1], w[2], w[3]);
                             *reinterpret_cast<uint4 *>(&S.nbaddr[c][t0]) = make_uint4(ad[0], ad[1], ad[2], ad[3]);
                         }
                     }
@@ -809,8 +809,8 @@ __device__ __forceinline__ int epw_body(const EpwArgs &args, const int b) {
                         for (int u = 0; u < PF_PER; ++u) {
                             const int t = tid + u * NT;
                             if (c < ncand && t < EW_PF_K) {
-                                S.nbid[c][t] = idv[c][u];
                                 S.nbaddr[c][t] = gather_addr((int)idv[c][u], t);
+                                if (t == k) S.nbk[c] = plain_addr((int)idv[c][u]);
                             }
                         }
                 }
@@ -853,8 +853,8 @@ __device__ __forceinline__ int epw_body(const EpwArgs &args, const int b) {
                 __syncthreads();
                 for (int t = tid; t < EW_PF_K; t += NT) {
                     const unsigned short id = (nb && t < nz) ? nb[t] : (unsigned short)0;
-                    S.nbid[slot][t] = id;
                     S.nbaddr[slot][t] = gather_addr((int)id, t);
+                    if (t == k) S.nbk[slot] = plain_addr((int)id);
                 }
                 __syncthreads();
             }
@@ -1018,9 +1018,15 @@ __device__ __forceinline__ int epw_body(const EpwArgs &args, const int b) {
                 if (zero_nb) {
                     bool hit = false;
                     for (int t = tid; t < nz; t += NT) {
-                        const int id = (int)(LDSIDS ? S.nbid[slot][t] : nb[t]) + off;
-                        if (id >= lo && id < lo + W) g[id - lo] = 0.0f;
-                        hit |= (id == out_tok);
+                        if constexpr (LDSIDS) {
+                            const int ad = t < k ? S.nbaddr[slot][t] : S.nbk[slot];
+                            if (ad < W) g[ad] = 0.0f;
+                            hit |= (ad == W + EW_G_OUT);
+                        } else {
+                            const int id = (int)nb[t] + off;
+                            if (id >= lo && id < lo + W) g[id - lo] = 0.0f;
+                            hit |= (id == out_tok);
+                        }
                     }
                     if (out_tok >= 0 && block_sum_fast<int, NW>(hit ? 1 : 0, S.redi, ph) > 0) out_mass = 0.0f;
                 }
@@ -1041,7 +1047,7 @@ __device__ __forceinline__ int epw_body(const EpwArgs &args, const int b) {
                 // window indices of the earlier siblings' tokens, straight from the staged tables (every thread reads the same
                 // LDS words: broadcast, no barrier); the first four live in registers, longer sibling lists loop over LDS
                 auto sib_at = [&](int t) -> int {
-                    const int node = (b0 + t < EW_MAX_B) ? S.bidx[b0 + t] : 0;
+                    const int node = (b0 + t < EW_MAX_B) ? (int)S.bidx[b0 + t] : 0;
                     const int tok = (node >= 0 && node < EW_MAX_N) ? S.tcand[node] : -1;
                     return (tok >= lo && tok < lo + W) ? (tok - lo) : -1;
                 };
@@ -1053,13 +1059,13 @@ __device__ __forceinline__ int epw_body(const EpwArgs &args, const int b) {
                     for (int t = tid; t < (W + 31) / 32; t += NT) nbmask[t] = 0u;
                     __syncthreads();
                     for (int t = tid; t < nz; t += NT) {
-                        const int id = (int)(LDSIDS ? S.nbid[slot][t] : nb[t]) + off - lo;
+                        const int id = LDSIDS ? (int)(t < k ? S.nbaddr[slot][t] : S.nbk[slot]) : (int)nb[t] + off - lo;      // (a sentinel slot is >= W)
                         if (id >= 0 && id < W) atomicOr(&nbmask[id >> 5], 1u << (id & 31));
                     }
                 }
                 if (zero_nb && p_mode == LANTERN_MODE_STATIC_LUMINA)
                     for (int t = tid; t < nz; t += NT) {
-                        const int id = (int)(LDSIDS ? S.nbid[slot][t] : nb[t]) + off - lo;
+                        const int id = LDSIDS ? (int)(t < k ? S.nbaddr[slot][t] : S.nbk[slot]) : (int)nb[t] + off - lo;
                         if (id >= 0 && id < W) g[id] = 0.0f;
                     }
                 EPW_STAMPG(31);
@@ -1201,7 +1207,7 @@ __device__ __forceinline__ int epw_body(const EpwArgs &args, const int b) {
         for (int it = 0; it < E4; ++it) {
             s4[it] = (double)p[it].x + (double)p[it].y + (double)p[it].z + (double)p[it].w;
             inc[it] = wave_scan_incl_dpp(s4[it]);
-            if (lane == 63) S.samp_tot[wave][it] = inc[it];
+            if (lane == 63) S.samp_tot[wave * E4 + it] = inc[it];
         }
         __syncthreads();
         // segment (it, wave) = ids [lo + 4*(it*NT + 64*wave), +256): token order is it-major.  One DPP scan over the
@@ -1209,7 +1215,7 @@ __device__ __forceinline__ int epw_body(const EpwArgs &args, const int b) {
         // with uniform-lane reads.
         static_assert(E4 * NW <= 64, "segment totals fit one wave");
         const int q_it = lane / NW, q_w = lane % NW;
-        const double seg = (lane < E4 * NW) ? S.samp_tot[q_w][q_it < E4 ? q_it : 0] : 0.0;
+        const double seg = (lane < E4 * NW) ? S.samp_tot[q_w * E4 + (q_it < E4 ? q_it : 0)] : 0.0;
         const double seg_excl = wave_scan_incl_dpp(dpp_mov<0x138>(seg));      // exclusive: scan of the totals shifted up one lane
         const double front = out_before ? (double)out_mass : 0.0;   // mass in front of the window
         double total = front + (readlane63(seg_excl) + readlane63(seg));       // lanes >= E4*NW hold 0
@@ -1543,6 +1549,10 @@ extern "C" int lantern_evaluate_posterior_window(const lantern_ep_params *prm, c
     const bool default_tree = spec_knob >= 2 && p.P == 15 && p.D == 6 && p.N == 26 && p.rows_per_seq == 26;
     static const int occ_knob = getenv("LANTERN_EPW_OCC2") ? atoi(getenv("LANTERN_EPW_OCC2")) : -1;   // tuning knob (diagnostic)
     const bool two_per_cu = occ_knob >= 0 ? occ_knob != 0 : p.B > 256;
+    // throughput forms of the fixed-configuration instances (more sequences than CUs): 1 = 512 threads at 128 VGPRs (two workgroups per CU),
+    // 2 = 512 threads at 80 VGPRs (three per CU: 53 KB of LDS each), 3 = 256 threads x 8 float4 per thread (three per CU at 3 waves per SIMD,
+    // no register constraint; half the waves repeating the walk's scalar work)
+    static const int tp_knob = getenv("LANTERN_EPW_TP") ? atoi(getenv("LANTERN_EPW_TP")) : 1;   // tuning knob (diagnostic)
     if (W <= 1024) EPW_LAUNCH(256, 1);
     else if (W <= 2048) EPW_LAUNCH(256, 2);
     else if (W <= 4096) EPW_LAUNCH(512, 2);
@@ -1561,7 +1571,10 @@ extern "C" int lantern_evaluate_posterior_window(const lantern_ep_params *prm, c
         else LANTERN_LAUNCH((epw_kernel<512, 4, 2, 1, true, true>), grid, dim3(512), lds, st, args);
     }
     else if (W <= 8192) {
-        if (two_per_cu && W == 8192 && idmode == 2) LANTERN_LAUNCH((epw_kernel<512, 4, 2, 4, true>), grid, dim3(512), lds, st, args);
+        if (two_per_cu && W == 8192 && idmode == 2 && lumina_static && default_tree && tp_knob == 3) LANTERN_LAUNCH((epw_kernel<256, 8, 2, 3, true, false, 2>), grid, dim3(256), lds, st, args);
+        else if (two_per_cu && W == 8192 && idmode == 2 && lumina_static && default_tree && tp_knob == 2) LANTERN_LAUNCH((epw_kernel<512, 4, 2, 6, true, false, 2>), grid, dim3(512), lds, st, args);
+        else if (two_per_cu && W == 8192 && idmode == 2 && lumina_static && default_tree && tp_knob == 1) LANTERN_LAUNCH((epw_kernel<512, 4, 2, 4, true, false, 2>), grid, dim3(512), lds, st, args);
+        else if (two_per_cu && W == 8192 && idmode == 2) LANTERN_LAUNCH((epw_kernel<512, 4, 2, 4, true>), grid, dim3(512), lds, st, args);
         else if (two_per_cu) EPW_LAUNCH_W(512, 4, 4);
         else if (W == 8192 && idmode == 2) {
             if (lumina_static && default_tree) LANTERN_LAUNCH((epw_kernel<512, 4, 2, 1, true, false, 2>), grid, dim3(512), lds, st, args);

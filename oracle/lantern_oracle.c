@@ -20,6 +20,7 @@
 #include "lantern_oracle.h"
 #include <math.h>
 #include <stdlib.h>
+#include <stdio.h>
 #include <string.h>
 #ifdef _OPENMP
 #include <omp.h>
@@ -83,11 +84,20 @@ static void *lo_scratch(int slot, size_t bytes) {
     lo_scratch_t *s = (lo_scratch_t *)pthread_getspecific(lo_scratch_key);
     if (!s) {
         s = (lo_scratch_t *)calloc(1, sizeof(lo_scratch_t));
+        if (!s) {
+            fprintf(stderr, "lantern_oracle: out of memory (scratch table)\n");
+            abort();
+        }
         pthread_setspecific(lo_scratch_key, s);
     }
     if (s->cap[slot] < bytes) {
         free(s->buf[slot]);
+        s->cap[slot] = 0;
         s->buf[slot] = malloc(bytes);
+        if (!s->buf[slot]) { /* the checker must fail loudly, never hand a NULL row to the arithmetic */
+            fprintf(stderr, "lantern_oracle: out of memory (%zu scratch bytes, slot %d)\n", bytes, slot);
+            abort();
+        }
         s->cap[slot] = bytes;
     }
     return s->buf[slot];
@@ -95,10 +105,12 @@ static void *lo_scratch(int slot, size_t bytes) {
 
 /* rows of one lo_cfg_mask_topk call shared over this many OpenMP threads of the calling thread's team (the all-core leg of the
  * CPU baseline: 63 sequences are fewer than a 256-core host has cores; a sequence's 26 tree rows are independent) */
-static int lo_row_threads = 1;
+#include <stdatomic.h>
+static _Atomic int lo_row_threads = 1;
 int lo_set_row_threads(int n) {
-    lo_row_threads = n < 1 ? 1 : (n > 64 ? 64 : n);
-    return lo_row_threads;
+    const int v = n < 1 ? 1 : (n > 64 ? 64 : n);
+    atomic_store(&lo_row_threads, v);
+    return v;
 }
 
 /* torch.softmax(row, dim=0) for a float32 row (ea_model_lumina_mgpt.py:637). */
@@ -482,7 +494,7 @@ static int64_t py_mod(int64_t a, int64_t b) {
 int lo_cfg_mask_topk(const void *cond, const void *uncond, int dtype, int N, int V, float cfg,
                      int model, const int64_t *pos_ids, int64_t pos_base, int w_latent, int h_latent,
                      int img_lo, int img_hi, int newline_id, int eos_id, int top_k, float *out) {
-    const int row_threads = lo_row_threads;
+    const int row_threads = atomic_load(&lo_row_threads);
 #pragma omp parallel for schedule(dynamic, 1) num_threads(row_threads) if (row_threads > 1)
     for (int n = 0; n < N; ++n) {
         float *o = out + (size_t)n * V;

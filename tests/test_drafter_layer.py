@@ -220,3 +220,42 @@ def test_streamk_gemm_matches_f64_and_the_per_tile_kernels(M, K, N, epi):
             assert (got.float() - old.float()).abs().max().item() <= 2e-2 * scale
         again = ops.linear_rows_streamk(x, wt, epi, bias=b, **kw)
         assert torch.equal(again, got)          # deterministic: the partials are added in K order whoever finishes a tile
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,K,N,epi", [(20, 16384, 64, 0), (32, 8192, 96, 1), (20, 11008, 40, 2), (8, 4096, 32, 0)])
+def test_streamk_split_tiles_survive_a_poisoned_workspace(M, K, N, epi):
+    """Few tiles, many workgroups: every tile is split over dozens of workgroups on different XCDs, so each output element is the sum of partial
+    tiles that met in the workspace.  Between launches the partial-tile region is filled with NaN (the tile counters behind it stay zero, as the
+    kernel leaves them): a finisher that read a slot before its writer's stores had landed would return NaN or a stale sum.  The publish
+    protocol (each thread waits for its own device-coherent stores -- s_waitcnt vmcnt(0) -- before the barrier that precedes the counter add)
+    must give the same bits on every launch."""
+    from lantern_amd import ops, _lib
+    dev, bf = torch.device("cuda"), torch.bfloat16
+    gen = torch.Generator(device="cuda").manual_seed(7 * M + K + N + epi)
+    x = torch.randn(M, K, device=dev, dtype=bf, generator=gen)
+    rows = 2 * N if epi == 2 else N
+    w = (torch.randn(rows, K, device=dev, generator=gen) / K ** 0.5).to(bf)
+    res = torch.randn(M, N, device=dev, dtype=bf, generator=gen)
+    kw = dict(residual=res) if epi == 1 else (dict(pair_rows=N) if epi == 2 else {})
+    xd, wd = x.double(), w.double()
+    want = xd @ wd[:N].T
+    if epi == 1:
+        want = want + res.double()
+    if epi == 2:
+        want = torch.nn.functional.silu(want) * (xd @ wd[N:].T)
+    wt = ops.pack_linear_weight(w, N if epi == 2 else 0) if K % 64 == 0 else w
+    first = ops.linear_rows_streamk(x, wt, epi, **kw)
+    assert (first.double() - want).abs().max().item() <= 2e-2 * want.abs().max().item()
+    ws = ops._sk_workspace(dev)
+    L = _lib.lib()
+    partial_bytes = int(L.lantern_linear_rows_streamk_workspace(32)) - 4 - 256          # the partial tiles come first, the counters behind them
+    assert partial_bytes > 0 and partial_bytes % 4 == 0
+    partials = ws[:partial_bytes].view(torch.float32)
+    counters = ws[partial_bytes:]
+    for _ in range(60):
+        partials.fill_(float("nan"))
+        got = ops.linear_rows_streamk(x, wt, epi, **kw)
+        assert torch.equal(got, first)
+    torch.cuda.synchronize()
+    assert int(counters.to(torch.int64).sum().item()) == 0          # every tile counter back at zero

@@ -16,7 +16,8 @@ evaluate_posterior_window on raw bf16 rows (O8 + the rest of O7, on demand) -> u
 Extra objects on the JSON line:
   roofline      evaluate_posterior of the timed configuration: algorithmic bytes (SURVEY 8d contract formula, from the kernel's own
                 counters) / its mean launch duration (HIP events recorded by the launch itself); peak 8000 GB/s.  `windowed_kernel`: the bytes
-                the windowed design really has to move; `traffic`: PMC bytes from profiles/r02_ep_traffic.json.
+                the windowed design really has to move; `traffic`: PMC bytes from profiles/r04_ep_traffic.json (refused when measured on other kernel
+                sources); `saturating`: the same kernel alone at the largest batch of the sweep, on rotating inputs.
   kernels       the same for the row post-process launch (prepare_step / cfg_mask_topk) and update_inference_inputs.
   per_kernel_single_group  one stream, every stage its own launch: each kernel against its SURVEY 8d roofline at the full 64-sequence
                 launch size, with the chain and the node-parallel evaluate_posterior.
@@ -358,6 +359,54 @@ def ep_batch_sweep(batches, device, base_cfg, iters=24, kernels=("chain", "nodes
     return out
 
 
+def kernel_sources_sha() -> str:
+    """Fingerprint of the kernel sources (lantern_amd/csrc, include/): profiles/*_traffic.json carry the fingerprint they were measured at, and a
+    file measured on other kernels is refused instead of quoted (there is no .git on the GPU box to compare commits with)."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "lantern_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "lantern_amd", "csrc", "*.h")) +
+                    glob.glob(os.path.join(ROOT, "lantern_amd", "csrc", "*.cpp")) + glob.glob(os.path.join(ROOT, "include", "*.h"))):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r04_ep_traffic.json")
+
+
+def traffic_entry(section: str, key: str):
+    """(entry, note) of profiles/r04_ep_traffic.json[section][key]; entry None with the reason when the file is missing, lacks the key or was
+    measured on other kernel sources."""
+    if not os.path.exists(TRAFFIC_FILE):
+        return None, "no PMC file (profiles/r04_ep_traffic.json)"
+    tj = json.load(open(TRAFFIC_FILE))
+    if tj.get("kernel_sources_sha") != kernel_sources_sha():
+        return None, f"profiles/r04_ep_traffic.json was measured on other kernel sources (commit {tj.get('commit')}): refused as stale"
+    t = tj.get(section, {}).get(key)
+    if not t:
+        return None, f"profiles/r04_ep_traffic.json has no {section}/{key}"
+    return t, ("profiles/r04_ep_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH doubled per the gfx950 note), "
+               f"measured at commit {tj.get('commit')}, same kernel sources")
+
+
+def saturating_report(sweep):
+    """roofline.saturating: evaluate_posterior at the largest batch of the sweep (the 60 % target is assessed at the saturating batch),
+    on rotating inputs; needed bytes (what the windowed kernel has to move) / the median launch duration / 8 TB/s; `traffic` = PMC bytes per
+    launch of the same kernel at the same batch (a separate rocprofv3 run of tools/ep_sweep.py)."""
+    rows = [r for r in sweep if r.get("chain")]
+    if not rows:
+        return None
+    r = max(rows, key=lambda r_: r_["sequences_per_launch"])
+    c = r["chain"]
+    t, note = traffic_entry("saturating", f"chain_B{r['sequences_per_launch']}")
+    return {"kernel": "epw_kernel (evaluate_posterior, windowed chain, probability rows; the throughput instance: 256 threads per sequence, three workgroups per CU)",
+            "sequences_per_launch": r["sequences_per_launch"], "avg_launch_ms": c["launch_ms"], "back_to_back_ms": c["back_to_back_ms"],
+            "needed_bytes": c["hbm_bytes_needed_per_launch"], "achieved": c["achieved_GBps"], "peak": 8000.0, "unit": "GB/s", "frac": c["frac"],
+            "traffic": None if t is None else t["hbm_bytes"], "traffic_source": note,
+            "inputs": f"{r['rotation_sets']} rotating input sets, {r['rotation_bytes'] / 2**30:.1f} GiB between re-reads"}
+
+
 def kernel_report(wl, evs, E0, E1, KT):
     """`roofline` (evaluate_posterior, the north-star kernel) and `kernels` (the others) from the HIP events of steps [E0, E1):
     algorithmic bytes per launch (SURVEY 8d formulas on the kernel's own counters, group 0's launches) / mean launch duration."""
@@ -395,16 +444,11 @@ def kernel_report(wl, evs, E0, E1, KT):
                                  "frac": wb / (ep_ms * 1e-3) / 1e9 / 8000.0,
                                  "definition": "(L+fresh)*W*4 + T*k*2 + R*W*4, W=8192 (DESIGN.md 4)" +
                                                ("; raw rows: a visited row is 2 x W bf16 = the same W*4 bytes" if wl.fused_o7 else "")}
-    tfile = os.path.join(ROOT, "profiles", "r03_ep_traffic.json")
-    if wl.windowed and os.path.exists(tfile):
+    if wl.windowed:
         key = ("raw" if wl.fused_o7 else ("nodes" if wl.ep_nodes is not None else "chain")) + f"_B{wl.Bg}"
-        tj = json.load(open(tfile))
-        t = tj.get("per_launch", {}).get(key)
-        if t:      # PMC passes are separate rocprofv3 runs of the same kernel / launch size (tools/run/prof_default.sh), not part of this run:
-            # the file carries the commit it was measured at -- a kernel edited since then makes the figure stale
-            rl["traffic"] = t["hbm_bytes"]
-            rl["traffic_source"] = ("profiles/r03_ep_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH doubled per the gfx950 note), "
-                                    f"measured at commit {tj.get('commit')}")
+        t, note = traffic_entry("per_launch", key)      # PMC passes are separate rocprofv3 runs of the same kernel / launch size (tools/run/prof_default.sh)
+        rl["traffic"] = None if t is None else t["hbm_bytes"]
+        rl["traffic_source"] = note
     ks = {}
     if "cfg_mask_topk" in evs[0]:
         o7_ms = mean_ms("cfg_mask_topk")
@@ -899,6 +943,10 @@ def main():
                                    f"C3: Lumina-mGPT-7B-768 LANTERN relaxed accept, static tree {cfg.tree} (N={wl.N},P={wl.P},D={wl.D}), "
                                    "V=65536, K=8192, cfg=3.0, top_k=2000, sequential-CFG KV [64,1,32,%d,128] bf16 x2 per sequence (row stride %d)"
                                    % (cfg.kv_smax, cfg.kv_smax + cfg.kv_pad_rows),
+                       "deviations_from_BASELINE": ("%d of BASELINE's 64 sequences per GPU (%d stream groups of %d), %d of BASELINE.md's 256 pool steps "
+                                                    "(the KV slabs of 64 sequences take 276e9 of the 309e9 bytes; %d steps = %.1f GB of pools, far beyond L2 + "
+                                                    "Infinity Cache)") % (cfg.n_seq, cfg.n_groups, wl.Bg, cfg.pool_steps, cfg.pool_steps,
+                                                                          cfg.pool_steps * cfg.n_seq * (wl.N * (2 * 65536 * 2 + 2 * 4096 * 2) + wl.R * 8192 * 4) / 1e9),
                        "lantern_k": cfg.lantern_k, "lantern_delta": cfg.lantern_delta, "seqs_per_gpu": cfg.n_seq,
                        "total_sequences": cfg.n_seq * world, "pool_steps": cfg.pool_steps, "drafter_sigma": cfg.sigma,
                        "kv_cache": cfg.with_kv, "kernel_path": cfg.path, "launch": "hipGraph replay" if (cfg.use_graph and wl.graphs) else ("eager, one lantern_verify_step call per step" if wl._steps else "eager, one call per kernel"),
@@ -955,6 +1003,9 @@ def main():
             out["drafter_layer"] = drafter_layer_run()
         if args.ep_sweep and world == 1:
             out["ep_batch_sweep"] = ep_batch_sweep([int(x) for x in args.ep_sweep.split(",") if x], device, cfg)
+            sat = saturating_report(out["ep_batch_sweep"])
+            if sat and "roofline" in out:
+                out["roofline"]["saturating"] = sat
         if args.cpu_seconds > 0 and world == 1:      # the CPU baseline is reported at N = 1 only
             n_cpu = args.cpu_seqs or cfg.n_seq
             gpu_stream = [[(int(gb[i, b]), int(ga[i, b]), int(gt[i, b])) for b in range(cfg.n_seq)] for i in range(n_logged)]

@@ -491,8 +491,10 @@ typedef const __attribute__((address_space(4))) EpwArgs *EpwArgsK;
 // FULLW: the window is exactly the workgroup's register tile (W == 4 * NT * E4, the Lumina / Anole 8192-id image range on
 // 512 x 4): no per-chunk bounds predicate, so the four chunks of a pass are one basic block and their LDS reads go out together.
 // RAW: rows are the target model's raw cond / uncond bf16 logits (LANTERN_ROWS_RAW_BF16; W == 8 * 2 * NT, packed table).
-template <int NT, int E4, int IDMODE, int WPE, bool FULLW = false, bool RAW = false, int SPEC = 0>
+template <int NT, int E4, int IDMODE, int WPE, bool FULLW = false, bool RAW = false, int SPEC = 0, int TPO = 0>
 __device__ __forceinline__ int epw_body(const EpwArgs &args, const int b) {
+    constexpr bool LATE_Q = (TPO & 1) != 0;          // throughput builds: a candidate's drafter row is requested once its rejection is known (an accepted
+                                                     // candidate -- 0.65 of the first tries -- then costs no row request at all; the latency is another workgroup's problem)
     static_assert(!RAW || (FULLW && E4 == 4), "raw rows: the 8192-id window on 512 threads");
     constexpr bool LDSIDS = IDMODE != 0;
     const lantern_ep_params &prm = args.prm;
@@ -713,6 +715,7 @@ __device__ __forceinline__ int epw_body(const EpwArgs &args, const int b) {
         // neighbour ids of the level's candidates: their HBM reads are issued first, the row's loads second; both are in
         // flight together and the ids are written to LDS under the row's last barrier (one exposed latency per level)
         constexpr int PF_PER = (EW_PF_K + NT - 1) / NT;
+        constexpr int PF_LIST = SPEC == 2 ? 4 : EW_PF_C;          // candidates per level staged ahead
         // position t of a neighbour list -> index into g for the scan (out_tok is final before the ids are staged)
         auto plain_addr = [&](int id) -> unsigned short {
             const int e = id + off;
@@ -720,17 +723,18 @@ __device__ __forceinline__ int epw_body(const EpwArgs &args, const int b) {
             return (unsigned short)(W + (e == out_tok ? EW_G_OUT : EW_G_ZERO));
         };
         auto gather_addr = [&](int id, int t) -> unsigned short { return t >= k ? (unsigned short)(W + EW_G_HUGE) : plain_addr(id); };
-        unsigned short idv[EW_PF_C][PF_PER];
+        unsigned short idv[PF_LIST][PF_PER];
         constexpr int CH_PER_C = EW_PF_K / 8;                              // 16-byte chunks per candidate
-        constexpr int PF16_PER = (EW_PF_C * CH_PER_C + NT - 1) / NT;
+        constexpr int PF16_PER = (PF_LIST * CH_PER_C + NT - 1) / NT;
         uint4 idq[PF16_PER];
         int ncand = 0;
         if (can_prefetch && IDMODE == 2) {
             // candidate list first (scalar work only): lane c of xs_lane holds the c-th unique candidate token
+            // (PF_LIST: the reference's default tree has at most 4 children under a node; a tree of the same sizes with more takes the restage path)
             unsigned long long td = todo0;
             int xs_lane = -1;
 #pragma unroll
-            for (int c = 0; c < EW_PF_C; ++c) {
+            for (int c = 0; c < PF_LIST; ++c) {
                 const bool have = td != 0ull;
                 const int j = have ? __ffsll((long long)td) - 1 : 0;
                 const int x = rdlane(x_lane, j);
@@ -745,7 +749,7 @@ __device__ __forceinline__ int epw_body(const EpwArgs &args, const int b) {
                 const int ch = tid + u * NT;
                 const int c = __builtin_amdgcn_readfirstlane(ch / CH_PER_C);
                 const int t0 = (ch % CH_PER_C) * 8;
-                const int x = c < EW_PF_C ? rdlane(xs_lane, c < EW_PF_C ? c : 0) : -1;
+                const int x = c < PF_LIST ? rdlane(xs_lane, c < PF_LIST ? c : 0) : -1;
                 const int trow = x - off;
                 const bool lookup = c < ncand && trow >= 0 && trow < p_trows && !(p_syntax && !(x >= p_img_lo && x < p_img_hi));
                 idq[u] = make_uint4(0u, 0u, 0u, 0u);
@@ -755,7 +759,7 @@ __device__ __forceinline__ int epw_body(const EpwArgs &args, const int b) {
         } else if (can_prefetch) {
             unsigned long long td = todo0;
 #pragma unroll
-            for (int c = 0; c < EW_PF_C; ++c) {
+            for (int c = 0; c < PF_LIST; ++c) {
                 const bool have = td != 0ull;
                 const int j = have ? __ffsll((long long)td) - 1 : 0;
                 const int x = rdlane(x_lane, j);
@@ -804,7 +808,7 @@ __device__ __forceinline__ int epw_body(const EpwArgs &args, const int b) {
                     }
                 } else if (can_prefetch) {
 #pragma unroll
-                    for (int c = 0; c < EW_PF_C; ++c)
+                    for (int c = 0; c < PF_LIST; ++c)
 #pragma unroll
                         for (int u = 0; u < PF_PER; ++u) {
                             const int t = tid + u * NT;
@@ -844,11 +848,11 @@ __device__ __forceinline__ int epw_body(const EpwArgs &args, const int b) {
             const int flags = rdlane(flag_lane, j);
             const bool in_img = (flags & 2) != 0;
             const bool is_syn = (flags & 1) != 0;
-            const int slot = cidx % EW_PF_C;
+            const int slot = cidx % PF_LIST;
             const int trow = x - off;
             const uint16_t *nb = (p_lantern && trow >= 0 && trow < p_trows) ? buf.nn_table + (size_t)trow * prm.table_cols : nullptr;
             int *dec = S.dec[n_tried & 1];
-            if (LDSIDS && can_prefetch && cidx >= EW_PF_C) {
+            if (LDSIDS && can_prefetch && cidx >= PF_LIST) {
                 // more unique candidates than prefetch slots (rare): stage this one's ids now, reusing a finished slot
                 __syncthreads();
                 for (int t = tid; t < EW_PF_K; t += NT) {
@@ -872,7 +876,7 @@ __device__ __forceinline__ int epw_body(const EpwArgs &args, const int b) {
             }
             // wave 0 (the serial worker) would sit behind the other waves' loads in the CU's address unit before it can enter
             // the scan: it fetches its own 4 KB share only once a rejection is known
-            if (is_static && (wave != 0 || WPE != 1)) {     // (the throughput build has a second workgroup to hide the queueing)
+            if (is_static && !LATE_Q && (wave != 0 || WPE != 1)) {     // (the throughput build has a second workgroup to hide the queueing)
 #pragma unroll
                 for (int it = 0; it < E4; ++it) {
                     const int i4 = tid + it * NT;
@@ -1002,7 +1006,7 @@ __device__ __forceinline__ int epw_body(const EpwArgs &args, const int b) {
                 status = LANTERN_ST_SYNTAX_REJECT;
                 break;
             }
-            if (is_static && wave == 0 && WPE == 1) {
+            if (is_static && (LATE_Q || (wave == 0 && WPE == 1))) {
 #pragma unroll
                 for (int it = 0; it < E4; ++it) {
                     const int i4 = tid + it * NT;
@@ -1071,18 +1075,22 @@ __device__ __forceinline__ int epw_body(const EpwArgs &args, const int b) {
                 EPW_STAMPG(31);
                 double qs_loc = 0.0;
                 if (nsib > 0) {          // a level's first candidate has no earlier sibling: q is used as it is (qs = 1)
+                    // window entry sidx lives in thread (sidx / 4) % NT, chunk (sidx / 4) / NT, component sidx % 4: only the WAVE that holds it
+                    // runs the component selects (a wave-uniform branch), the other seven pay one compare per sibling
+                    auto zero_q_at = [&](int sidx) {
+                        const bool mine = sidx >= 0 && ((sidx >> 2) & (NT - 1)) == tid;
+                        if (__ballot(mine) != 0ull) {
+                            const int itx = mine ? (sidx >> 2) / NT : -1, c = sidx & 3;
 #pragma unroll
-                    for (int it = 0; it < E4; ++it) {
-                        const int e = (tid + it * NT) * 4;
-#pragma unroll
-                        for (int t = 0; t < 4; ++t)
-                            if (sib_r[t] >= e && sib_r[t] < e + 4) set_comp(q[it], sib_r[t] - e, 0.0f);
-                        for (int t = 4; t < nsib; ++t) {
-                            const int sidx = sib_at(t);
-                            if (sidx >= e && sidx < e + 4) set_comp(q[it], sidx - e, 0.0f);
+                            for (int it = 0; it < E4; ++it)
+                                if (it == itx) set_comp(q[it], c, 0.0f);
                         }
-                        qs_loc += (double)q[it].x + (double)q[it].y + (double)q[it].z + (double)q[it].w;
-                    }
+                    };
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) zero_q_at(sib_r[t]);
+                    for (int t = 4; t < nsib; ++t) zero_q_at(sib_at(t));
+#pragma unroll
+                    for (int it = 0; it < E4; ++it) qs_loc += (double)q[it].x + (double)q[it].y + (double)q[it].z + (double)q[it].w;
                 }
                 EPW_STAMPG(32);
                 float qs = 1.0f;
@@ -1308,9 +1316,9 @@ __device__ __forceinline__ int epw_body(const EpwArgs &args, const int b) {
     return (best << 8) | a;          // the verdict (uniform): best path, rows kept = accept_len + 1
 }
 
-template <int NT, int E4, int IDMODE, int WPE, bool FULLW = false, bool RAW = false, int SPEC = 0>
+template <int NT, int E4, int IDMODE, int WPE, bool FULLW = false, bool RAW = false, int SPEC = 0, int TPO = 0>
 __global__ __launch_bounds__(NT, WPE) void epw_kernel(const EpwArgs args) {
-    epw_body<NT, E4, IDMODE, WPE, FULLW, RAW, SPEC>(args, blockIdx.x);
+    epw_body<NT, E4, IDMODE, WPE, FULLW, RAW, SPEC, TPO>(args, blockIdx.x);
 }
 
 __global__ void window_to_dense_kernel(const float *__restrict__ winp, const int32_t *__restrict__ out_tok,
@@ -1549,10 +1557,13 @@ extern "C" int lantern_evaluate_posterior_window(const lantern_ep_params *prm, c
     const bool default_tree = spec_knob >= 2 && p.P == 15 && p.D == 6 && p.N == 26 && p.rows_per_seq == 26;
     static const int occ_knob = getenv("LANTERN_EPW_OCC2") ? atoi(getenv("LANTERN_EPW_OCC2")) : -1;   // tuning knob (diagnostic)
     const bool two_per_cu = occ_knob >= 0 ? occ_knob != 0 : p.B > 256;
-    // throughput forms of the fixed-configuration instances (more sequences than CUs): 1 = 512 threads at 128 VGPRs (two workgroups per CU),
-    // 2 = 512 threads at 80 VGPRs (three per CU: 53 KB of LDS each), 3 = 256 threads x 8 float4 per thread (three per CU at 3 waves per SIMD,
-    // no register constraint; half the waves repeating the walk's scalar work)
-    static const int tp_knob = getenv("LANTERN_EPW_TP") ? atoi(getenv("LANTERN_EPW_TP")) : 1;   // tuning knob (diagnostic)
+    // Throughput form of the fixed-configuration instances (more sequences than CUs; the shape BASELINE's roofline target is assessed on): 256
+    // threads x 8 float4 per thread, three workgroups per CU (53 KB of LDS each, <= 168 VGPRs at 3 waves per SIMD), drafter rows requested only once
+    // a rejection is known.  At saturation the kernel is bound by instruction ISSUE (profiles/r04_ep_sweep_pmc.txt: the SIMDs' arbiters busy 0.93 of
+    // the launch, a third of it scalar work every wave of a sequence repeats), so half the waves per sequence is what pays: 4096 sequences per
+    // launch 293 us (generic, 512 threads, two per CU) -> 228 (fixed configuration, 512 threads) -> 194 (owner-wave sibling zeroing) -> 163 us.
+    // LANTERN_EPW_TP=0: the generic two-per-CU instance; 1: the 512-thread fixed-configuration instance (diagnostic).
+    static const int tp_knob = getenv("LANTERN_EPW_TP") ? atoi(getenv("LANTERN_EPW_TP")) : 5;   // tuning knob (diagnostic)
     if (W <= 1024) EPW_LAUNCH(256, 1);
     else if (W <= 2048) EPW_LAUNCH(256, 2);
     else if (W <= 4096) EPW_LAUNCH(512, 2);
@@ -1571,9 +1582,12 @@ extern "C" int lantern_evaluate_posterior_window(const lantern_ep_params *prm, c
         else LANTERN_LAUNCH((epw_kernel<512, 4, 2, 1, true, true>), grid, dim3(512), lds, st, args);
     }
     else if (W <= 8192) {
-        if (two_per_cu && W == 8192 && idmode == 2 && lumina_static && default_tree && tp_knob == 3) LANTERN_LAUNCH((epw_kernel<256, 8, 2, 3, true, false, 2>), grid, dim3(256), lds, st, args);
-        else if (two_per_cu && W == 8192 && idmode == 2 && lumina_static && default_tree && tp_knob == 2) LANTERN_LAUNCH((epw_kernel<512, 4, 2, 6, true, false, 2>), grid, dim3(512), lds, st, args);
-        else if (two_per_cu && W == 8192 && idmode == 2 && lumina_static && default_tree && tp_knob == 1) LANTERN_LAUNCH((epw_kernel<512, 4, 2, 4, true, false, 2>), grid, dim3(512), lds, st, args);
+        const bool tp_form = two_per_cu && W == 8192 && idmode == 2 && tp_knob >= 5;
+        if (tp_form && lumina_static && default_tree) LANTERN_LAUNCH((epw_kernel<256, 8, 2, 3, true, false, 2, 1>), grid, dim3(256), lds, st, args);
+        else if (tp_form && lumina_static) LANTERN_LAUNCH((epw_kernel<256, 8, 2, 3, true, false, 1, 1>), grid, dim3(256), lds, st, args);
+        else if (tp_form && lumina_dynamic) LANTERN_LAUNCH((epw_kernel<256, 8, 2, 3, true, false, 3, 1>), grid, dim3(256), lds, st, args);
+        else if (tp_form && anole_static) LANTERN_LAUNCH((epw_kernel<256, 8, 2, 3, true, false, 4, 1>), grid, dim3(256), lds, st, args);
+        else if (two_per_cu && W == 8192 && idmode == 2 && lumina_static && default_tree && tp_knob >= 1) LANTERN_LAUNCH((epw_kernel<512, 4, 2, 4, true, false, 2>), grid, dim3(512), lds, st, args);
         else if (two_per_cu && W == 8192 && idmode == 2) LANTERN_LAUNCH((epw_kernel<512, 4, 2, 4, true>), grid, dim3(512), lds, st, args);
         else if (two_per_cu) EPW_LAUNCH_W(512, 4, 4);
         else if (W == 8192 && idmode == 2) {

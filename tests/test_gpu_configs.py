@@ -168,12 +168,22 @@ def test_window_large_k_reads_ids_from_hbm(k, delta):
             np.testing.assert_allclose(sp[b].cpu().numpy(), osp, rtol=0, atol=PROB_TOL)
 
 
-def test_window_two_workgroups_per_cu_build():
-    """Above 256 sequences per launch the 128-VGPR build of the windowed kernel runs (two workgroups per CU): 264 sequences
-    (8 distinct full-size Lumina steps, tiled) must reproduce the oracle exactly like the one-per-CU build does."""
+# a tree with the default tree's sizes (26 nodes, 15 paths, depth 6 -- what the host dispatches the fixed-tree instance on) but SIX children under
+# the root: more unique candidates at a level than that instance stages ahead (4), so its restage path runs
+SIX_WIDE_26 = [[0], [1], [2], [3], [4], [5], [0, 0], [0, 1], [0, 2], [0, 3], [1, 0], [2, 0], [2, 1], [3, 0], [3, 1], [0, 0, 0], [0, 0, 1], [0, 0, 2],
+               [1, 0, 0], [0, 0, 0, 0], [0, 0, 0, 1], [1, 0, 0, 0], [0, 0, 0, 0, 0], [0, 0, 0, 0, 1], [1, 0, 0, 0, 0]]
+
+
+@pytest.mark.parametrize("tree_name,REP", [("mc_sim_7b_63", 33), ("six_wide", 33), ("six_wide", 2)])
+def test_window_two_workgroups_per_cu_build(tree_name, REP):
+    """Above 256 sequences per launch the throughput build of the windowed kernel runs (two workgroups per CU): 264 sequences
+    (8 distinct full-size Lumina steps, tiled) must reproduce the oracle exactly like the one-per-CU build does.  `six_wide`: a tree of the
+    default tree's sizes with six children under the root, in the throughput build and (REP 2: 16 sequences) in the latency build."""
     V, K, lo, W, k = 65536, 8192, 4, 8192, 1000
     rs = np.random.RandomState(77)
-    tb = oracle.tree_static_build(CS.mc_sim_7b_63)
+    tree = CS.mc_sim_7b_63 if tree_name == "mc_sim_7b_63" else SIX_WIDE_26
+    tb = oracle.tree_static_build(tree)
+    assert (len(tb["tree_indices"]),) + tuple(tb["retrieve_indices"].shape) == (26, 15, 6)
     N, (P, D) = len(tb["tree_indices"]), tb["retrieve_indices"].shape
     ti, pos = tb["tree_indices"], tb["tree_position_ids"]
     par = CS.node_parents(tb["tree_attn_mask"], pos)
@@ -185,7 +195,7 @@ def test_window_two_workgroups_per_cu_build():
     op_off = np.array([np.nonzero(depth_of_row == d)[0][0] for d in range(int(depth_of_row.max()) + 1)], np.int32)
     tab = perm_table(K, 1008, 5)
     ri = H.row_index_from_retrieve(tb["retrieve_indices"], N)
-    U, REP = 8, 33
+    U = 8
     cfg_o, cfg_h = oracle.EpConfig.lumina(True, lantern=True, k=k, delta=0.1), ops.EpConfig.lumina(True, lantern=True, k=k, delta=0.1)
     wins, ops_w, cands, cps, tcs, full = [], [], [], [], [], []
     for b in range(U):
@@ -204,7 +214,7 @@ def test_window_two_workgroups_per_cu_build():
                         b_off=dev(tb["b_off"]), b_idx=dev(tb["b_idx"]), tree_cand=dev(tile(tcs)))
     out = ops.evaluate_posterior_window(cfg_h, V, dev(tile(wins)), lo, dev(ri), dev(tile(cands)), dev(np.concatenate([uni] * REP)),
                                         table=ops.pack_vq_table(dev(tab.view(np.int16)), 1008), aux=aux, orig_windowed=True, want_dense=False)
-    assert out["best"].shape[0] == U * REP > 256
+    assert out["best"].shape[0] == U * REP and (REP < 33 or U * REP > 256)
     for b in range(U):
         a = oracle.StaticAux(cart_prob=cps[b], orig_prob=full[b][1], op_off=op_off, p_idx=tb["p_indices"], b_off=tb["b_off"], b_idx=tb["b_idx"],
                              tree_cand=tcs[b])

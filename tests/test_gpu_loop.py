@@ -13,14 +13,15 @@ sys.path.insert(0, ROOT)
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("path,graph,groups", [("window", False, 1), ("window", True, 1), ("dense", False, 1), ("window", False, 3),
-                                               ("window", True, 2)])
-def test_harness_loop_matches_oracle_loop(path, graph, groups):
+@pytest.mark.parametrize("path,graph,groups,n_seq,steps", [("window", False, 1, 6, 36), ("window", True, 1, 6, 36), ("dense", False, 1, 6, 36), ("window", False, 3, 6, 36),
+                                                           ("window", True, 2, 6, 36), ("window", False, 1, 264, 4)],
+                         ids=["window", "window_graph", "dense", "window_3_groups", "window_graph_2_groups", "throughput"])
+def test_harness_loop_matches_oracle_loop(path, graph, groups, n_seq, steps):
+    """(`throughput`: 264 sequences in one launch -- more than CUs -- run the chain kernel's throughput instance, on probability rows.)"""
     import bench
     from lantern_amd import harness as HN
-    steps = 36
-    cfg = HN.WorkloadConfig(n_seq=6, pool_steps=4, path=path, use_graph=graph, kv_layers=2, kv_heads=4, kv_smax=512, max_steps=steps + 4,
-                            sigma=5.0, n_groups=groups)
+    cfg = HN.WorkloadConfig(n_seq=n_seq, pool_steps=4 if n_seq < 64 else 2, path=path, use_graph=graph, kv_layers=2, kv_heads=4, kv_smax=512, max_steps=steps + 4,
+                            sigma=5.0, n_groups=groups, **({} if n_seq < 64 else {"ep_kernel": "chain"}))
     wl = HN.LuminaVerifyWorkload(cfg, torch.device("cuda"))
     for _ in range(steps):
         wl.step()
@@ -36,7 +37,7 @@ def test_harness_loop_matches_oracle_loop(path, graph, groups):
     assert (wl.cond_lens(steps & 1).cpu().numpy() == cfg.prompt_len + 3 + gen).all()
     assert (wl.uncond_lens(steps & 1).cpu().numpy() == 3 + gen).all()
     # a newline row was crossed by at least one sequence (position-dependent one-hot rows are in play)
-    assert int((torch.as_tensor(gt) == HN.NEWLINE).sum()) > 0
+    assert steps < 20 or int((torch.as_tensor(gt) == HN.NEWLINE).sum()) > 0
 
 
 def test_kv_rows_follow_the_accepted_path():
@@ -67,6 +68,16 @@ def test_kv_rows_follow_the_accepted_path():
                          ids=["o7_launch", "raw_rows", "raw_rows_2_prepared", "o7_launch_3_groups", "raw_rows_2_groups_root_prepared",
                               "raw_rows_3_groups_2_prepared", "per_kernel_calls_2_groups", "per_kernel_calls_raw_rows_2_prepared"])
 def test_dynamic_tree_loop_matches_oracle_loop(fuse, groups, native, spec):
+    _dynamic_tree_loop(fuse, groups, native, spec, 3 * groups, 8, 1)
+
+
+def test_dynamic_tree_loop_throughput_instance():
+    """More sequences per launch than CUs: the throughput form of the chain kernel's Lumina dynamic-tree instance (256 threads, three workgroups per
+    CU) on probability rows, every 13th sequence held to the oracle's loop."""
+    _dynamic_tree_loop(False, 1, True, 0, 264, 2, 13)
+
+
+def _dynamic_tree_loop(fuse, groups, native, spec, n_seq, steps, every):
     """The device-resident EAGLE-2 loop (O4 -> O6 dynamic -> O7 -> O8 dynamic -> O9 + O10, a different tree per sequence and
     step) against the oracle's loop over the same pools / uniforms: identical (best path, accept length, bonus token), every
     step, every sequence; KV lengths advance by exactly the accepted tokens."""
@@ -75,8 +86,7 @@ def test_dynamic_tree_loop_matches_oracle_loop(fuse, groups, native, spec):
     from lantern_amd import harness as HN
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import helpers as H
-    steps = 8
-    cfg = HN.DynamicConfig(n_seq=3 * groups, pool_steps=2, kv_layers=2, kv_heads=4, kv_smax=512, max_steps=steps + 2, lantern_k=300, fuse_o7=fuse,
+    cfg = HN.DynamicConfig(n_seq=n_seq, pool_steps=2, kv_layers=2, kv_heads=4, kv_smax=512, max_steps=steps + 2, lantern_k=300, fuse_o7=fuse,
                            n_groups=groups, native_step=native, spec_rows=spec)
     wl = HN.DynamicVerifyWorkload(cfg, torch.device("cuda"))
     assert wl.fused_o7 == fuse and wl.G == groups and wl.n_spec == (spec if fuse else 0)
@@ -90,7 +100,7 @@ def test_dynamic_tree_loop_matches_oracle_loop(fuse, groups, native, spec):
     ocfg = oracle.EpConfig.lumina(False, lantern=True, k=cfg.lantern_k, delta=cfg.lantern_delta)
     N = wl.N
     n_acc = 0
-    for b in range(cfg.n_seq):
+    for b in range(0, cfg.n_seq, every):
         tok, cursor, lens = int(wl.first_token[b]), 0, [cfg.prompt_len + 3, 3]
         for i in range(steps):
             p = wl.pools[i % cfg.pool_steps]
@@ -121,15 +131,72 @@ def test_dynamic_tree_loop_matches_oracle_loop(fuse, groups, native, spec):
 @pytest.mark.parametrize("fuse,groups,spec,lam,k", [(False, 1, 0, 5.0, 10), (True, 1, 0, 5.0, 10), (True, 2, 3, 10.0, 5), (True, 1, 5, 0.3, 40)],
                          ids=["o7_launch", "raw_rows", "raw_rows_2_groups_3_prepared", "raw_rows_delta_mode_5_prepared"])
 def test_anole_static_loop_matches_oracle_loop(fuse, groups, spec, lam, k):
+    _anole_static_loop(fuse, groups, spec, lam, k, 3 * groups, 24, 1)
+
+
+@pytest.mark.parametrize("model,tree", [("anole", "naive_extend_57"), ("lumina", "naive_extend_57")])
+def test_static_loop_throughput_instances(model, tree):
+    """More sequences per launch than CUs: the throughput forms (256 threads, three workgroups per CU) of the chain kernel's Anole static-tree
+    instance and of the Lumina static-tree instance without the fixed default tree, on probability rows; every 13th sequence held to the oracle's loop
+    (the Lumina default tree's form: test_harness_loop_matches_oracle_loop[throughput], tests/test_gpu_configs.py)."""
+    if model == "anole":
+        _anole_static_loop(False, 1, 0, 5.0, 10, 264, 2, 13)
+    else:
+        _lumina_static_loop_big(tree, 264, 2, 13)
+
+
+def _lumina_static_loop_big(tree, n_seq, steps, every):
+    import numpy as np
+    import oracle
+    from lantern_amd import harness as HN
+    cfg = HN.WorkloadConfig(tree=tree, n_seq=n_seq, pool_steps=2, with_kv=False, max_steps=steps + 4, sigma=5.0, n_groups=1, ep_kernel="chain", fuse_o7=False)
+    wl = HN.LuminaVerifyWorkload(cfg, torch.device("cuda"))
+    for _ in range(steps):
+        wl.step()
+    torch.cuda.synchronize()
+    wl.check_status(0, steps)
+    gb, ga, gt = wl.log_best[:steps].cpu().numpy(), wl.log_alen[:steps].cpu().numpy(), wl.log_token[:steps].cpu().numpy()
+    tb, N = wl.tb, wl.N
+    ri = tb["retrieve_indices"].copy()
+    ri[ri < 0] += N
+    ri = ri.astype(np.int32)
+    table = wl.table_full.cpu().numpy().view(np.uint16)
+    u16 = lambda t: t.cpu().view(torch.int16).numpy().view(np.uint16)
+    ub, first, op_off = wl.u_bonus.cpu().numpy(), wl.first_token.cpu().numpy(), wl.d_op_off.cpu().numpy()
+    ocfg = oracle.EpConfig.lumina(True, lantern=True, k=cfg.lantern_k, delta=cfg.lantern_delta)
+    pos1 = tb["tree_position_ids"] + 1
+    n_acc = n_rej = 0
+    for b in range(0, n_seq, every):
+        tok, cursor, ln = int(first[b]), 0, cfg.prompt_len + 3
+        for i in range(steps):
+            s_ = i % cfg.pool_steps
+            orig = wl.orig_prob[s_, b].cpu().numpy()
+            dense = np.zeros(orig.shape[:-1] + (HN.V,), np.float32)
+            dense[..., HN.IMG_LO:HN.IMG_HI] = orig
+            cand, cp, tc = oracle.gather_candidates(wl.ss_token[s_, b].cpu().numpy(), wl.ss_prob[s_, b].cpu().numpy(), tok, tb["tree_indices"], tb["retrieve_indices"])
+            proc = oracle.cfg_mask_topk(u16(wl.cond[s_, b]), u16(wl.uncond[s_, b]), cfg.cfg_scale, model=oracle.MODEL_LUMINA, pos_ids=pos1 + ln,
+                                        pos_base=cfg.prompt_len + 3, w=HN.W_LATENT, h=HN.H_LATENT, img_lo=HN.IMG_LO, img_hi=HN.IMG_HI, newline_id=HN.NEWLINE,
+                                        eos_id=HN.EOS, top_k=cfg.top_k, bf16=True)
+            aux = oracle.StaticAux(cart_prob=cp, orig_prob=dense, op_off=op_off, p_idx=tb["p_indices"], b_off=tb["b_off"], b_idx=tb["b_idx"], tree_cand=tc)
+            best, alen, sp, cnt = oracle.evaluate_posterior(ocfg, proc, ri, cand, wl.uniforms_host[b, cursor:cursor + 64], table=table, aux=aux)
+            cursor += int(cnt[3])
+            tok = oracle.sample_inverse_cdf(sp, float(ub[i, b]))
+            assert (int(gb[i, b]), int(ga[i, b]), int(gt[i, b])) == (best, alen, tok), (b, i)
+            ln += alen + 1
+            n_acc += alen
+            n_rej += int(cnt[2])
+    assert n_acc > 0 and n_rej > 0
+
+
+def _anole_static_loop(fuse, groups, spec, lam, k, n_seq, steps, every):
     """BASELINE config 4 (Anole, LANTERN++ static tree naive_extend_57: neighbours zeroed in the drafter's row, no syntax shortcut, no grammar rows)
     through the device-resident step loop -- O7 over all rows, and the raw rows post-processed inside evaluate_posterior with the likeliest rows
     prepared beside O6 -- against the oracle's loop over the same pools / uniforms: identical (best path, accept length, bonus token) at every step."""
     import numpy as np
     import oracle
     from lantern_amd import harness as HN
-    steps = 24
-    cfg = HN.WorkloadConfig(model="anole", tree="naive_extend_57", n_seq=3 * groups, pool_steps=4, kv_layers=2, kv_heads=4, kv_smax=512, max_steps=steps + 4,
-                            sigma=5.0, n_groups=groups, ep_kernel="chain", fuse_o7=fuse, spec_rows=spec, lantern_k=k, lantern_delta=lam)
+    cfg = HN.WorkloadConfig(model="anole", tree="naive_extend_57", n_seq=n_seq, pool_steps=4 if n_seq < 64 else 2, kv_layers=2, kv_heads=4, kv_smax=512,
+                            max_steps=steps + 4, sigma=5.0, n_groups=groups, ep_kernel="chain", fuse_o7=fuse, spec_rows=spec, lantern_k=k, lantern_delta=lam)
     wl = HN.LuminaVerifyWorkload(cfg, torch.device("cuda"))
     assert wl.anole and wl.fused_o7 == fuse and wl.n_spec == (spec if fuse else 0)
     for _ in range(steps):
@@ -144,23 +211,25 @@ def test_anole_static_loop_matches_oracle_loop(fuse, groups, spec, lam, k):
     ri = ri.astype(np.int32)
     table = wl.table_full.cpu().numpy().view(np.uint16)
     u16 = lambda t: t.cpu().view(torch.int16).numpy().view(np.uint16)
-    cond, uncond = u16(wl.cond), u16(wl.uncond)
-    orig = wl.orig_prob.cpu().numpy()
-    dense = np.zeros(orig.shape[:-1] + (HN.V,), np.float32)
-    dense[..., HN.IMG_LO:HN.IMG_HI] = orig
     sst, ssp = wl.ss_token.cpu().numpy(), wl.ss_prob.cpu().numpy()
     ub, first, op_off = wl.u_bonus.cpu().numpy(), wl.first_token.cpu().numpy(), wl.d_op_off.cpu().numpy()
+
+    def dense_of(s_, b):          # (per checked sequence: the pools of a 264-sequence run do not fit the host as dense rows)
+        orig = wl.orig_prob[s_, b].cpu().numpy()
+        d = np.zeros(orig.shape[:-1] + (HN.V,), np.float32)
+        d[..., HN.IMG_LO:HN.IMG_HI] = orig
+        return d
     # (Anole / LlamaGen: the reference applies the HF processors -- here T = 1, top_k -- inside evaluate_posterior, per visited row; O7 / the raw-row
     # path apply them where the rows are produced: the same distribution)
     ocfg = oracle.EpConfig.anole(True, lantern=True, k=k, delta=lam, temperature=1.0, top_p=1.0, top_k=cfg.top_k)
     n_acc = n_rej = 0
-    for b in range(cfg.n_seq):
+    for b in range(0, cfg.n_seq, every):
         tok, cursor = int(first[b]), 0
         for i in range(steps):
             s_ = i % cfg.pool_steps
             cand, cp, tc = oracle.gather_candidates(sst[s_, b], ssp[s_, b], tok, tb["tree_indices"], tb["retrieve_indices"])
-            proc = oracle.cfg_mask_topk(cond[s_, b], uncond[s_, b], cfg.cfg_scale, model=oracle.MODEL_ANOLE, img_lo=HN.IMG_LO, img_hi=HN.IMG_HI, bf16=True)
-            aux = oracle.StaticAux(cart_prob=cp, orig_prob=dense[s_, b], op_off=op_off, p_idx=tb["p_indices"], b_off=tb["b_off"], b_idx=tb["b_idx"], tree_cand=tc)
+            proc = oracle.cfg_mask_topk(u16(wl.cond[s_, b]), u16(wl.uncond[s_, b]), cfg.cfg_scale, model=oracle.MODEL_ANOLE, img_lo=HN.IMG_LO, img_hi=HN.IMG_HI, bf16=True)
+            aux = oracle.StaticAux(cart_prob=cp, orig_prob=dense_of(s_, b), op_off=op_off, p_idx=tb["p_indices"], b_off=tb["b_off"], b_idx=tb["b_idx"], tree_cand=tc)
             best, alen, sp, cnt = oracle.evaluate_posterior(ocfg, proc, ri, cand, wl.uniforms_host[b, cursor:cursor + 64], table=table, aux=aux)
             cursor += int(cnt[3])
             tok = oracle.sample_inverse_cdf(sp, float(ub[i, b]))

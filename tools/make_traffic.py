@@ -1,12 +1,17 @@
-"""Collect a round's rocprofv3 outputs (tools/run/prof_default.sh <tag> [flags]) into profiles/: per-kernel stats CSVs, the PMC counter sums
+"""(round 4: + `saturating`: the ep_sweep passes of tools/run/ep_sweep_prof.sh, given as sat=<gpurun_out dir>:<batch>; + the fingerprint of the
+kernel sources, which bench.py checks before quoting the file.)
+Collect a round's rocprofv3 outputs (tools/run/prof_default.sh <tag> [flags]) into profiles/: per-kernel stats CSVs, the PMC counter sums
 (FETCH_SIZE / WRITE_SIZE, separate passes) as profiles/<round>_ep_traffic.json -- stamped with the commit the numbers were taken at, so that
 bench.py can tell whether they still describe the kernels it runs -- and the bench line each profiled run printed.
 usage: python tools/make_traffic.py [round=r03] [key=dir ...]   (default keys: raw=<round>p chain=<round>p_chain)"""
 import csv, glob, json, os, shutil, subprocess, sys, collections
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-RND = sys.argv[1] if len(sys.argv) > 1 else "r03"
+sys.path.insert(0, ROOT)
+RND = sys.argv[1] if len(sys.argv) > 1 else "r04"
 runs = dict(a.split("=", 1) for a in sys.argv[2:]) or {"raw": RND + "p", "chain": RND + "p_chain"}          # traffic key prefix -> gpurun_out/<dir>
+sat_runs = [v for k, v in list(runs.items()) if k.startswith("sat")]
+runs = {k: v for k, v in runs.items() if not k.startswith("sat")}
 kern = {"raw": ["epw_kernel"], "chain": ["epw_kernel"], "nodes": ["epn_kernel", "epn_walk_kernel"]}
 others = ["prep_rows_kernel", "cfg_window_bf16", "update_inputs_kernel"]
 
@@ -60,6 +65,25 @@ for key, d in runs.items():
             for r in rows:
                 r["Kernel_Name"] = r["Kernel_Name"][:80]
                 w.writerow(r)
+out["saturating"] = {}
+for spec in sat_runs:          # <dir>:<batch>: tools/run/ep_sweep_prof.sh <dir> <batch>
+    d, B = spec.split(":")
+    src = os.path.join(ROOT, "gpurun_out", d)
+    f, n = sums(os.path.join(src, "fetch"), "epw_kernel<")
+    w, _ = sums(os.path.join(src, "write"), "epw_kernel<")
+    sw = json.loads(open(os.path.join(src, "stats.json")).read().strip().splitlines()[-1])["sweep"]
+    row = [r for r in sw if r["sequences_per_launch"] == int(B)][0]
+    out["saturating"][f"chain_B{B}"] = {"kernel": "epw_kernel (probability rows, throughput instance)", "flags": d, "launches_averaged": n,
+                                        "FETCH_SIZE_raw_KB": f.get("FETCH_SIZE", 0.0), "WRITE_SIZE_raw_KB": w.get("WRITE_SIZE", 0.0),
+                                        "hbm_bytes": 2 * f.get("FETCH_SIZE", 0.0) * 1024 + w.get("WRITE_SIZE", 0.0) * 1024,
+                                        "needed_bytes": row["chain"]["hbm_bytes_needed_per_launch"], "launch_ms_under_rocprof": row["chain"]["launch_ms"]}
+    st = glob.glob(os.path.join(src, "stats", "*kernel_stats.csv"))
+    if st:
+        shutil.copy(st[0], os.path.join(ROOT, "profiles", f"{RND}_ep_sweep_B{B}_kernel_stats.csv"))
+    if os.path.exists(os.path.join(src, "summary.txt")):
+        shutil.copy(os.path.join(src, "summary.txt"), os.path.join(ROOT, "profiles", f"{RND}_ep_sweep_B{B}_pmc.txt"))
+import bench
+out["kernel_sources_sha"] = bench.kernel_sources_sha()
 try:
     out["commit"] = subprocess.check_output(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], text=True).strip()
     out["tree_dirty"] = bool(subprocess.check_output(["git", "-C", ROOT, "status", "--porcelain", "--", "lantern_amd/csrc", "include"], text=True).strip())

@@ -542,6 +542,15 @@ int lantern_qk_norm_rope(const void *qkv, int B, int T, int n_q_heads, int n_kv_
                          const void *k_weight, const void *k_bias, int model_parallel, const void *cos_table, const void *sin_table,
                          int table_rows, const int64_t *position_ids, void *q_out, void *k_out, void *v_out, int kv_rows, int kv_row0,
                          void *stream);
+/* The head stage of LlamaAttention (the LlamaGen drafter's layer, models/drafters/cnets_llamagen.py:315-323, apply_rotary_emb :67-77) on the fused
+ * q/k/v projection [B*T, (nq + 2 nk) d] bf16: no per-head norm; rotary on adjacent pairs (x[2p], x[2p+1]) -> (x0 c - x1 s, x1 c + x0 s) with
+ * (c, s) = freqs[position][p], freqs [table_rows, d/2, 2] f32 [dev] (the model's table: LlamaGen's 2-D one, precompute_freqs_cis_2d :47-64), in
+ * f32, rounded to bf16 once; position_ids [dev] int64 [B, T] (positions_per_batch_row != 0) or [T] shared by the batch rows (the reference's
+ * `freqs_cis[position_ids].squeeze(0)`, :663).  Outputs as lantern_qk_norm_rope: q [B, nq, T, d], k / v at rows [kv_row0, kv_row0 + T) of
+ * [B, nk, kv_rows, d] buffers (d = 64 or 128). */
+int lantern_qk_rope_pairs(const void *qkv, int B, int T, int n_q_heads, int n_kv_heads, int head_dim, const float *freqs, int table_rows,
+                          const int64_t *position_ids, int positions_per_batch_row, void *q_out, void *k_out, void *v_out, int kv_rows, int kv_row0,
+                          void *stream);
 
 /* 8f-2 (next row, second half)  One drafter expansion depth from the hidden states to the top-k in two small launches, the head's
  * logits never in HBM:  head(hidden) restricted to the id window the model's mask lets through -> CFG combination in the GEMM's

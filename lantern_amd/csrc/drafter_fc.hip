@@ -391,6 +391,44 @@ __global__ __launch_bounds__(64) void qk_norm_rope_kernel(const uint16_t *__rest
     }
 }
 
+// LlamaAttention's head stage for decode-sized inputs (cnets_llamagen.py:315-323): no per-head norm; rotary on ADJACENT pairs
+// (x[2p], x[2p+1]) -> (x0 c - x1 s, x1 c + x0 s) with (c, s) = freqs[pos][p] from the model's precomputed f32 table (LlamaGen: the 2-D table of
+// precompute_freqs_cis_2d, :47-64 -- whatever the table holds, the kernel only indexes it by position), computed in f32 on the bf16 inputs and
+// rounded to bf16 once (`x.float() ... type_as(x)`), written in the [B, heads, T, d] layout attention consumes; V only changes layout.
+// qkv [B*T, (nq + 2 nk) d] bf16 (the fused projection); one wave per (token, head), lane i holds elements i and i + 64 (d = 128) or i (d = 64).
+template <int D>
+__global__ __launch_bounds__(64) void qk_rope_pairs_kernel(const uint16_t *__restrict__ qkv, int T, int nq, int nk, const float *__restrict__ freqs,
+                                                           const int64_t *__restrict__ pos, int pos_per_batch, uint16_t *__restrict__ q_out,
+                                                           uint16_t *__restrict__ k_out, uint16_t *__restrict__ v_out, int kv_rows, int kv_row0, int table_rows) {
+    constexpr int E = D / 64;
+    const int tok = blockIdx.x, head = blockIdx.y, lane = threadIdx.x;          // head in [0, nq + 2 nk)
+    const int b = tok / T, t = tok % T;
+    const uint16_t *src = qkv + (size_t)tok * (nq + 2 * nk) * D + (size_t)head * D;
+    if (head >= nq + nk) {          // V: layout only
+        const int hv = head - nq - nk;
+        uint16_t *dst = v_out + (((size_t)b * nk + hv) * kv_rows + kv_row0 + t) * D;
+#pragma unroll
+        for (int e = 0; e < E; ++e) dst[lane + 64 * e] = src[lane + 64 * e];
+        return;
+    }
+    const bool is_q = head < nq;
+    const int hh = is_q ? head : head - nq;
+    int64_t p = pos[pos_per_batch ? (size_t)b * T + t : (size_t)t];
+    p = p < 0 ? 0 : (p >= table_rows ? table_rows - 1 : p);          // (the reference would raise on a position beyond its table; never read outside ours)
+    const float *fr = freqs + (size_t)p * D;                         // [d/2][2]
+    uint16_t *dst = (is_q ? q_out + (((size_t)b * nq + hh) * T + t) * D : k_out + (((size_t)b * nk + hh) * kv_rows + kv_row0 + t) * D);
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const int i = lane + 64 * e;
+        const float x = bf16_bits_to_f32(src[i]);
+        const float y = __shfl_xor(x, 1, 64);                        // the pair's other element (lane ^ 1: pairs are adjacent elements)
+        const float c = fr[(i >> 1) * 2], sn = fr[(i >> 1) * 2 + 1];
+        // even element: x0 c - x1 s; odd element: x1 c + x0 s (two products, one sum, each rounded to f32 like torch's separate ops)
+        const float a = x * c, bq = y * sn;
+        dst[i] = f32_to_bf16_rne((i & 1) ? a + bq : a - bq);
+    }
+}
+
 // 8f-2 (second half, phase 1): the same contraction for the drafter's cond + uncond rows, with the CFG combination as the
 // epilogue -- rows 0..n-1 of A are the conditional hidden states, rows n..2n-1 the unconditional ones
 // (cnets_lumina_mgpt.py:1271-1320: `out = uncond + cfg_scale * (cond - uncond)` on the head's bf16 logits).  The head's
@@ -1045,6 +1083,24 @@ extern "C" int lantern_qk_norm_rope(const void *qkv, int B, int T, int n_q_heads
     else QKNR(64);
 #undef QKNR
     LANTERN_CHECK_LAUNCH("qk_norm_rope");
+    return LANTERN_OK;
+}
+
+extern "C" int lantern_qk_rope_pairs(const void *qkv, int B, int T, int n_q_heads, int n_kv_heads, int head_dim, const float *freqs, int table_rows,
+                                     const int64_t *position_ids, int positions_per_batch_row, void *q_out, void *k_out, void *v_out, int kv_rows,
+                                     int kv_row0, void *stream) {
+    LANTERN_CHECK_ARG(qkv && freqs && position_ids && q_out && k_out && v_out, "qk_rope_pairs: null buffer");
+    LANTERN_CHECK_ARG(B >= 0 && T >= 0 && n_q_heads > 0 && n_kv_heads > 0 && table_rows > 0 && kv_row0 >= 0 && kv_rows >= kv_row0 + T,
+                      "qk_rope_pairs: bad sizes (k / v are [B, nk, kv_rows, d] slabs written at rows kv_row0 .. kv_row0 + T)");
+    LANTERN_CHECK_ARG(head_dim == 128 || head_dim == 64, "qk_rope_pairs: head_dim %d (64 or 128)", head_dim);
+    if (B * T == 0) return LANTERN_OK;
+    dim3 grid(B * T, n_q_heads + 2 * n_kv_heads);
+#define QKRP(D_) LANTERN_LAUNCH((qk_rope_pairs_kernel<D_>), grid, dim3(64), 0, (hipStream_t)stream, (const uint16_t *)qkv, T, n_q_heads, n_kv_heads, freqs,       \
+                                position_ids, positions_per_batch_row, (uint16_t *)q_out, (uint16_t *)k_out, (uint16_t *)v_out, kv_rows, kv_row0, table_rows)
+    if (head_dim == 128) QKRP(128);
+    else QKRP(64);
+#undef QKRP
+    LANTERN_CHECK_LAUNCH("qk_rope_pairs");
     return LANTERN_OK;
 }
 

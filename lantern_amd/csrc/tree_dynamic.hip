@@ -162,7 +162,8 @@ __global__ __launch_bounds__(EX_THREADS) void expand_rows_kernel(const float *__
 // one-hot), InterleavedTopKLogitsWarper's threshold, then log-softmax statistics and the top_k entries (ties to the lower id).
 // One 256-thread workgroup per row, the row in registers (32 values per thread at W = 8192): 16 KB read once, against the
 // 2 x 256 KB of the dense f32 row expand_rows_kernel reads (cnets_lumina_mgpt.py:1287-1318).
-constexpr int EXW_NT = 256, EXW_C8 = 4;            // 4 chunks of 8 ids per thread: W <= 8192
+constexpr int EXW_C8 = 4;            // 4 chunks of 8 ids per thread: W <= 8192 on 256 threads (the Chameleon image window), <= 16384 on 512 (LlamaGen's vocabulary)
+template <int EXW_NT>
 __global__ __launch_bounds__(EXW_NT) void expand_window_kernel(const uint16_t *__restrict__ win, int W, int win_lo, int V, int model,
                                                                const int64_t *__restrict__ pos_ids, int64_t pos_base, int w_latent,
                                                                int h_latent, int newline_id, int eos_id, int top_k_filter,
@@ -398,10 +399,12 @@ static int head_expand_impl(const void *A, const void *W, const void *bias, int 
                             void *stream) {
     LANTERN_CHECK_ARG(A && W && workspace && topk_index && cu_scores && topk_cs_index && scores_out, "head_expand: null buffer");
     LANTERN_CHECK_ARG(n > 0 && n <= 16 && K > 0 && K % 16 == 0, "head_expand: n=%d drafter rows (<= 16 cond + 16 uncond), K=%d (multiple of 16)", n, K);
-    LANTERN_CHECK_ARG(row_lo >= 0 && n_cols > 0 && n_cols % 8 == 0 && n_cols <= 8 * EXW_NT * EXW_C8 && row_lo + n_cols <= V,
-                      "head_expand: window [%d,+%d) must be a multiple of 8 ids, <= %d wide, inside V", row_lo, n_cols, 8 * EXW_NT * EXW_C8);
+    LANTERN_CHECK_ARG(row_lo >= 0 && n_cols > 0 && n_cols % 8 == 0 && n_cols <= 8 * 512 * EXW_C8 && row_lo + n_cols <= V,
+                      "head_expand: window [%d,+%d) must be a multiple of 8 ids, <= %d wide, inside V", row_lo, n_cols, 8 * 512 * EXW_C8);
     LANTERN_CHECK_ARG(top_k > 0 && top_k <= EX_MAX_K && top_k <= V && n * top_k <= 256, "head_expand: bad top_k");
-    LANTERN_CHECK_ARG(model == LANTERN_MODEL_LUMINA || model == LANTERN_MODEL_ANOLE, "head_expand: for models whose drafted rows are masked to one id window (Lumina, Anole)");
+    LANTERN_CHECK_ARG(model == LANTERN_MODEL_LUMINA || model == LANTERN_MODEL_ANOLE || (model == LANTERN_MODEL_PLAIN && row_lo == 0 && n_cols == V),
+                      "head_expand: for models whose drafted rows are masked to one id window (Lumina, Anole), or an unmasked model whose window is the "
+                      "whole vocabulary (LlamaGen: LANTERN_MODEL_PLAIN, row_lo = 0, n_cols = V <= 16384)");
     if (model == LANTERN_MODEL_LUMINA && pos_ids)
         LANTERN_CHECK_ARG(w_latent > 0 && h_latent > 0 && newline_id >= 0 && newline_id < V && eos_id >= 0 && eos_id < V, "head_expand: Lumina needs latent dims and syntax ids");
     LANTERN_CHECK_ARG(((uintptr_t)workspace & 15) == 0, "head_expand: workspace must be 16-byte aligned");
@@ -413,8 +416,12 @@ static int head_expand_impl(const void *A, const void *W, const void *bias, int 
         LANTERN_CHECK_ARG(!packed, "head_expand: a packed weight needs the stream-K workspace");
         launch_linear_rows_cfg(A, W, bias, n, K, row_lo, n_cols, cfg, workspace, st);
     }
-    hipLaunchKernelGGL(expand_window_kernel, dim3(n), dim3(EXW_NT), 0, st, (const uint16_t *)workspace, n_cols, row_lo, V, model, pos_ids, pos_base,
-                       w_latent, h_latent, newline_id, eos_id, top_k_filter, scores_in, top_k, topk_index, cu_scores);
+    if (n_cols <= 8 * 256 * EXW_C8)
+        hipLaunchKernelGGL(expand_window_kernel<256>, dim3(n), dim3(256), 0, st, (const uint16_t *)workspace, n_cols, row_lo, V, model, pos_ids, pos_base,
+                           w_latent, h_latent, newline_id, eos_id, top_k_filter, scores_in, top_k, topk_index, cu_scores);
+    else
+        hipLaunchKernelGGL(expand_window_kernel<512>, dim3(n), dim3(512), 0, st, (const uint16_t *)workspace, n_cols, row_lo, V, model, pos_ids, pos_base,
+                           w_latent, h_latent, newline_id, eos_id, top_k_filter, scores_in, top_k, topk_index, cu_scores);
     hipLaunchKernelGGL(expand_merge_kernel, dim3(1), dim3(64), 0, st, cu_scores, n * top_k, top_k, topk_cs_index, scores_out);
     LANTERN_CHECK_LAUNCH("head_expand");
     return LANTERN_OK;

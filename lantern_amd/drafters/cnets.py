@@ -12,12 +12,12 @@ What runs where:
   * top-(N-1) + tree mask / positions / retrieve rows              -> lantern_tree_dynamic_finalize
   * static drafter buffers (masks, tree_indices, repeat_nums)      -> lantern_tree_drafter_build
   * conditional probabilities of the k samples w/o replacement     -> lantern_sample_static
-The decoder layer(s) between the input stage and the head are the drafter's transformer (GEMM-bound, out of this
-path's scope): they are INJECTED -- any module with the reference layer's call signature, e.g. the reference's own
-`ChameleonDecoderLayer` / `LlamaDecoderLayer` loaded from its checkpoint -- and default to a plain-torch Llama-style
-layer so the class runs stand-alone.  For Lumina-mGPT `lantern_amd.drafters.decoder_layer.DecoderLayer` is the HIP drop-in for
-ChameleonDecoderLayer (same parameter names: `layers=[DecoderLayer(config, 0)]`, then load the reference checkpoint): at the drafting
-shape (2 x top_k rows) its projections stream through the MFMA skinny GEMM with the norms / rotary / residuals / silu * up fused around them.
+The decoder layer(s) between the input stage and the head are HIP too at the drafting shape: `layers=None` builds
+`lantern_amd.drafters.decoder_layer.DecoderLayer` (Lumina-mGPT, and Anole with one head-norm row per head) or `LlamaDecoderLayer` (LlamaGen:
+no head norm, pair rotary from the 2-D freqs_cis table, which the Model then owns like the reference's) -- drop-ins with the reference's parameter
+names, so a reference drafter checkpoint loads unchanged (`Model.from_reference`).  A config outside the kernels (head_dim other than 64 / 128,
+hidden not a multiple of 64: the reduced-size test configs) raises unless `allow_torch_layers=True` asks for the plain-torch stand-in
+(`TorchDecoderLayer`); any module with the reference layer's call signature can still be injected (`layers=[...]`).
 """
 from __future__ import annotations
 
@@ -117,7 +117,7 @@ class Model(nn.Module):
     non-image ids to finfo.min, then HF processors."""
 
     def __init__(self, config, layers: Optional[List[nn.Module]] = None, bias=True, total_tokens=63, depth=5, top_k=8, threshold=1.0,
-                 embed_upscale=1.0, model_type="lumina_mgpt", image_lo=4, image_hi=8196):
+                 embed_upscale=1.0, model_type="lumina_mgpt", image_lo=4, image_hi=8196, allow_torch_layers=False):
         super().__init__()
         self.padding_idx = getattr(config, "pad_token_id", None)
         self.vocab_size = config.vocab_size
@@ -128,16 +128,72 @@ class Model(nn.Module):
         self.threshold = math.log(threshold)
         self.embed_upscale = embed_upscale
         n_layers = getattr(config, "num_hidden_layers", 1)
-        self.layers = nn.ModuleList(layers if layers is not None else [TorchDecoderLayer(config, i) for i in range(n_layers)])
+        self.freqs_cis = None
+        if layers is None:
+            layers = self._default_layers(config, n_layers, model_type, allow_torch_layers)
+        self.layers = nn.ModuleList(layers)
         self.fc = nn.Linear(2 * config.hidden_size, config.hidden_size, bias=bias)
         self.logsoftmax = nn.LogSoftmax(dim=-1)
         self.model_type, self.image_lo, self.image_hi = model_type, image_lo, image_hi
         self.cfg_scale = 3.0
         self.tree_mask = None
         self.stable_kv = None
-        self.layer_kwargs = None          # optional callable(position_ids) -> extra kwargs for injected layers (LlamaGen: freqs_cis)
+        self.layer_kwargs = None          # optional callable(position_ids) -> extra kwargs for injected layers
+        if self.freqs_cis is not None:    # LlamaGen's layers take the rows of the 2-D rotary table at the call's positions (cnets_llamagen.py:661-663)
+            self.layer_kwargs = self._freqs_kwargs
         for p in self.embed_tokens.parameters():
             p.requires_grad = False
+
+    def _default_layers(self, config, n_layers, model_type, allow_torch_layers):
+        """The HIP decoder layers of the model family when the config fits their kernels; otherwise an error -- or, asked for explicitly, the
+        plain-torch stand-in.  (The drafting shape never slides onto torch's ops unnoticed.)"""
+        from .decoder_layer import DecoderLayer, LlamaDecoderLayer, precompute_freqs_cis_2d
+        H, nh = config.hidden_size, config.num_attention_heads
+        fits = H % nh == 0 and (H // nh) in (64, 128) and H % 64 == 0 and getattr(config, "intermediate_size", 0) % 64 == 0
+        if not fits:
+            if allow_torch_layers:
+                return [TorchDecoderLayer(config, i) for i in range(n_layers)]
+            raise ops._lib.LanternError(
+                f"cnets.Model: hidden_size={H}, heads={nh} is outside the HIP decoder layer (head_dim 64 or 128, hidden and intermediate sizes multiples "
+                "of 64); pass layers=[...] (any module with the reference layer's signature) or allow_torch_layers=True for the plain-torch stand-in")
+        if model_type == "llamagen":
+            # block size / class-token count by input type, as the reference sets them (cnets_llamagen.py:561-580)
+            block, cls = {"c2i": (576, 0), "t2i": (256, 119), "t2i2": (1024, 119)}[getattr(config, "input_type", "t2i")]
+            grid = int(block ** 0.5)
+            table = precompute_freqs_cis_2d(grid, H // nh, float(getattr(config, "rope_base", 10000)), cls)
+            self.freqs_cis = torch.cat([table, torch.zeros_like(table[:10])], dim=0)
+            return [LlamaDecoderLayer(config, i) for i in range(n_layers)]
+        if model_type == "anole":          # one head-norm row per head (cnets_anole.py:317-332, :363-364)
+            import copy
+            config = copy.copy(config)
+            config.model_parallel_size = nh
+            if getattr(config, "num_key_value_heads", nh) != nh:
+                raise ops._lib.LanternError("cnets.Model: the Anole drafter layer's per-head norm rows are built for num_key_value_heads == num_attention_heads")
+        layers = [DecoderLayer(config, i) for i in range(n_layers)]
+        for l in layers:
+            l.inplace_cache = True
+        return layers
+
+    def _freqs_kwargs(self, position_ids):
+        if self.freqs_cis.device != position_ids.device:
+            self.freqs_cis = self.freqs_cis.to(position_ids.device)
+        return dict(freqs_cis=self.freqs_cis[position_ids].squeeze(0))
+
+    @classmethod
+    def from_reference(cls, ref, model_type: str, **kw):
+        """The reference's drafter `Model` (cnets_lumina_mgpt / cnets_llamagen / cnets_anole, loaded by its own `from_pretrained`) re-hosted on this
+        class: same config, same tree parameters, its state_dict loaded as is (the parameter names are the reference's), HIP decoder layers."""
+        cfg = ref.config if hasattr(ref, "config") else kw.pop("config")
+        has_bias = getattr(ref.fc, "bias", None) is not None
+        m = cls(cfg, bias=has_bias, total_tokens=int(ref.total_tokens) + 1, depth=int(ref.depth), top_k=int(ref.top_k), model_type=model_type,
+                embed_upscale=float(getattr(ref, "embed_upscale", 1.0)), **kw)
+        m.threshold = float(getattr(ref, "threshold", m.threshold))
+        missing, unexpected = m.load_state_dict(ref.state_dict(), strict=False)
+        bad = [k for k in list(missing) + list(unexpected) if "rotary_emb" not in k]
+        if bad:
+            raise ops._lib.LanternError(f"cnets.Model.from_reference: parameters that do not line up with the reference drafter: {bad[:8]}")
+        p = next(ref.parameters())
+        return m.to(device=p.device, dtype=p.dtype)
 
     # ------------------------------------------------------------------ tree state (cnets_lumina_mgpt.py:1000-1012)
     def init_tree(self, tree=None):
@@ -263,20 +319,38 @@ class Model(nn.Module):
         return head(hidden)
 
     def _expand_depth(self, head, hidden, proc, pos_ids, scores, k):
-        """One expansion depth: head -> CFG -> processors -> log-softmax -> top-k (+ parents' scores) -> best k of n*k.  Lumina
-        with a bf16 nn.Linear head takes the fused path (lantern_head_expand: the head's [2, n, V] logits never reach HBM);
-        everything else the three-step composition.  hidden [2, n, H] or [2, H] (cond row(s), then uncond)."""
+        """One expansion depth: head -> CFG -> processors -> log-softmax -> top-k (+ parents' scores) -> best k of n*k.  With a bf16 nn.Linear head
+        every model takes the fused path (lantern_head_expand: the head's [2, n, V] logits never reach HBM) -- Lumina on its image window with
+        the grammar rows, Anole on the same window (non-image ids at finfo.min never survive the log-softmax), LlamaGen on its whole 16384-id
+        vocabulary; the HF processors the reference defaults to (top-k; temperature 1, top_p 1: generate_images.py:47-55) are the kernel's
+        threshold, any other processor list takes the three-step composition (lantern_linear_rows -> lantern_cfg_mask_topk_window ->
+        lantern_expand_dynamic).  hidden [2, n, H] or [2, H] (cond row(s), then uncond)."""
         w = getattr(head, "weight", None)
         n = hidden.shape[1] if hidden.dim() == 3 else 1
-        if (self.model_type == "lumina_mgpt" and isinstance(head, nn.Linear) and w is not None and w.is_cuda and w.dtype == torch.bfloat16
-                and hidden.dtype == torch.bfloat16 and w.shape[1] % 16 == 0 and n <= 16 and n * k <= 256 and pos_ids is not None):
-            top_k = min(int(proc[1].image_top_k), w.shape[0]) if (proc is not None and len(proc) > 1) else 0
-            pk = self._packed_weight("head", w, self.image_lo, self.image_hi - self.image_lo) if w.shape[1] % 64 == 0 else None
-            return ops.head_expand(hidden.reshape(2 * n, -1), w, self.image_lo, self.image_hi - self.image_lo, float(self.cfg_scale),
-                                   bias=head.bias, model=ops.MODEL_LUMINA, pos_ids=pos_ids.reshape(-1), pos_base=2, top_k_filter=top_k,
-                                   scores_in=scores, top_k=k, packed=pk)
+        if (isinstance(head, nn.Linear) and w is not None and w.is_cuda and w.dtype == torch.bfloat16 and hidden.dtype == torch.bfloat16
+                and w.shape[1] % 16 == 0 and n <= 16 and n * k <= 256):
+            V = w.shape[0]
+            if self.model_type == "lumina_mgpt" and pos_ids is not None:
+                top_k = min(int(proc[1].image_top_k), V) if (proc is not None and len(proc) > 1) else 0
+                pk = self._packed_weight("head", w, self.image_lo, self.image_hi - self.image_lo) if w.shape[1] % 64 == 0 else None
+                return ops.head_expand(hidden.reshape(2 * n, -1), w, self.image_lo, self.image_hi - self.image_lo, float(self.cfg_scale),
+                                       bias=head.bias, model=ops.MODEL_LUMINA, pos_ids=pos_ids.reshape(-1), pos_base=2, top_k_filter=top_k,
+                                       scores_in=scores, top_k=k, packed=pk)
+            if self.model_type in ("anole", "llamagen"):
+                from ..verify import ProcessorSpec
+                spec = ProcessorSpec.from_hf(proc) or ProcessorSpec()
+                lo, nc = (self.image_lo, self.image_hi - self.image_lo) if self.model_type == "anole" else (0, V)
+                if spec.temperature == 1.0 and not (1e-8 <= spec.top_p < 1.0) and nc % 8 == 0 and nc <= 16384:
+                    pk = self._packed_weight("head", w, lo, nc) if w.shape[1] % 64 == 0 else None
+                    return ops.head_expand(hidden.reshape(2 * n, -1), w, lo, nc, float(self.cfg_scale), bias=head.bias,
+                                           model=ops.MODEL_ANOLE if self.model_type == "anole" else ops.MODEL_PLAIN, pos_ids=None,
+                                           top_k_filter=min(spec.top_k, V), scores_in=scores, top_k=k, packed=pk)
         ho = self._head(head, hidden)
-        rows = self._post_head(ho[0:1] if hidden.dim() == 2 else ho[0], ho[1:2] if hidden.dim() == 2 else ho[1], proc, pos_ids=pos_ids)
+        if hidden.dim() == 2:
+            half = ho.shape[0] // 2
+            rows = self._post_head(ho[:half], ho[half:], proc, pos_ids=pos_ids)
+        else:
+            rows = self._post_head(ho[0], ho[1], proc, pos_ids=pos_ids)
         return ops.expand_dynamic(rows[None], scores, k)
 
     def _post_head(self, cond, uncond, proc, pos_ids=None, pos_base=2):
@@ -349,10 +423,7 @@ class Model(nn.Module):
         akw = {} if input_position_diff is None else {"attention_mask": attention_mask}
         out_hidden, pkv = self._prefill(hidden_states, input_ids, input_position_diff, attention_mask)
         last_hidden = out_hidden[:, -1]
-        ho = self._head(head, last_hidden)
-        half = ho.shape[0] // 2
-        rows = self._post_head(ho[:half], ho[half:], logits_processor)
-        ti, cu, ci, scores = ops.expand_dynamic(rows[None], None, k)
+        ti, cu, ci, scores = self._expand_depth(head, last_hidden, logits_processor, None, None, k)
         scores_list, ss_token = [cu.reshape(-1)], [ti.reshape(-1)]
         parents_list = [torch.zeros(1, dtype=torch.long, device=dev)]
         cur = ti.reshape(1, -1)
@@ -366,10 +437,7 @@ class Model(nn.Module):
             out_hidden, pkv = self(input_hidden, input_ids=input_ids, past_key_values=pkv, position_ids=position_ids, use_cache=True, **akw)
             len_posi += 1
             parents_list.append(cs + (1 + k * k * max(0, i - 1) + (k if i > 0 else 0)))
-            ho = self._head(head, out_hidden)
-            half = ho.shape[0] // 2
-            rows = self._post_head(ho[:half], ho[half:], logits_processor)
-            ti, cu, ci, scores = ops.expand_dynamic(rows[None], scores, k)
+            ti, cu, ci, scores = self._expand_depth(head, out_hidden, logits_processor, None, scores, k)
             cs = ci[0]
             out_ids = cs // k
             input_hidden = out_hidden[:, out_ids]

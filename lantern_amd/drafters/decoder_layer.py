@@ -323,3 +323,166 @@ class DecoderLayer(nn.Module):
         if use_cache:
             out += (present,)
         return out
+
+
+# ----------------------------------------------------------------------------- the LlamaGen drafter's layer
+def apply_rotary_pairs(x, freqs_cis):
+    """cnets_llamagen.py:67-77: x [B, T, heads, d], freqs_cis [T, d/2, 2] (cos, sin) -- rotation of adjacent pairs in f32, cast back."""
+    xs = x.float().reshape(*x.shape[:-1], -1, 2)
+    fc = freqs_cis.to(xs.device).view(1, xs.size(1), 1, xs.size(3), 2)
+    out = torch.stack([xs[..., 0] * fc[..., 0] - xs[..., 1] * fc[..., 1], xs[..., 1] * fc[..., 0] + xs[..., 0] * fc[..., 1]], dim=-1)
+    return out.flatten(3).type_as(x)
+
+
+def precompute_freqs_cis_2d(grid_size: int, n_elem: int, base: float = 10000.0, cls_token_num: int = 120):
+    """LlamaGen's 2-D rotary table (cnets_llamagen.py:47-64): [cls_token_num + grid_size^2 + 10, n_elem / 2, 2] f32 -- zeros for the condition
+    tokens, (cos, sin) of the row frequencies then the column frequencies for the grid tokens, ten zero rows behind."""
+    half = n_elem // 2
+    freqs = 1.0 / (base ** (torch.arange(0, half, 2)[: (half // 2)].float() / half))
+    f = torch.outer(torch.arange(grid_size), freqs)
+    grid = torch.cat([f[:, None, :].expand(-1, grid_size, -1), f[None, :, :].expand(grid_size, -1, -1)], dim=-1)
+    cache = torch.stack([torch.cos(grid), torch.sin(grid)], dim=-1).flatten(0, 1)
+    if cls_token_num > 0:
+        cache = torch.cat([torch.zeros(cls_token_num, n_elem // 2, 2), cache])
+    return torch.cat([cache, torch.zeros(10, n_elem // 2, 2)])
+
+
+class LlamaAttention(nn.Module):
+    """cnets_llamagen.py:224-375 (LlamaAttention as the LlamaGen drafter uses it: rotary through `freqs_cis`, eager softmax in f32)."""
+
+    def __init__(self, config):
+        super().__init__()
+        self.hidden_size = config.hidden_size
+        self.num_heads = config.num_attention_heads
+        self.head_dim = self.hidden_size // self.num_heads
+        self.num_key_value_heads = getattr(config, "num_key_value_heads", self.num_heads)
+        self.num_key_value_groups = self.num_heads // self.num_key_value_heads
+        if self.head_dim * self.num_heads != self.hidden_size:
+            raise ValueError(f"hidden_size must be divisible by num_heads (got `hidden_size`: {self.hidden_size} and `num_heads`: {self.num_heads}).")
+        qkv_bias = bool(getattr(config, "qkv_bias", False))
+        self.q_proj = nn.Linear(self.hidden_size, self.num_heads * self.head_dim, bias=qkv_bias)
+        self.k_proj = nn.Linear(self.hidden_size, self.num_key_value_heads * self.head_dim, bias=qkv_bias)
+        self.v_proj = nn.Linear(self.hidden_size, self.num_key_value_heads * self.head_dim, bias=qkv_bias)
+        self.o_proj = nn.Linear(self.num_heads * self.head_dim, self.hidden_size, bias=False)
+        self._qkv = None
+
+    _fused_qkv = Attention._fused_qkv
+
+    def forward(self, hidden_states, attention_mask=None, position_ids=None, freqs_cis=None, past_key_value=None, output_attentions=False, use_cache=False):
+        bsz, q_len, _ = hidden_states.shape
+        nq, nk, hd = self.num_heads, self.num_key_value_heads, self.head_dim
+        q = self.q_proj(hidden_states).view(bsz, q_len, nq, hd)
+        k = self.k_proj(hidden_states).view(bsz, q_len, nk, hd)
+        v = self.v_proj(hidden_states).view(bsz, q_len, nk, hd).transpose(1, 2)
+        q = apply_rotary_pairs(q, freqs_cis).transpose(1, 2)
+        k = apply_rotary_pairs(k, freqs_cis).transpose(1, 2)
+        if past_key_value is not None:
+            k, v = torch.cat([past_key_value[0], k], dim=2), torch.cat([past_key_value[1], v], dim=2)
+        present = (k, v) if use_cache else None
+        kv_len = k.shape[2]
+        if self.num_key_value_groups > 1:
+            k = k[:, :, None].expand(bsz, nk, self.num_key_value_groups, kv_len, hd).reshape(bsz, nq, kv_len, hd)
+            v = v[:, :, None].expand(bsz, nk, self.num_key_value_groups, kv_len, hd).reshape(bsz, nq, kv_len, hd)
+        w = torch.matmul(q, k.transpose(2, 3)) / math.sqrt(hd)
+        if attention_mask is not None:
+            w = w + attention_mask
+        w = F.softmax(w, dim=-1, dtype=torch.float32).to(q.dtype)
+        out = torch.matmul(w, v).transpose(1, 2).contiguous().reshape(bsz, q_len, self.hidden_size)
+        return self.o_proj(out), (w if output_attentions else None), present
+
+
+class LlamaDecoderLayer(DecoderLayer):
+    """Drop-in for the reference's LlamaDecoderLayer in the LlamaGen drafter (cnets_llamagen.py:428-494; same call signature incl. `freqs_cis`,
+    same return tuple, same parameter names -- `self_attn.q_proj.weight`, `mlp.gate_proj.weight`, `post_attention_layernorm.weight`, and
+    `input_layernorm.weight` for index != 0: EAGLE drops layer 0's input norm).  At the drafting shape on the device (<= 32 bf16 rows, head_dim 64 or
+    128, hidden % 64 == 0) it runs the same HIP kernels as the Chameleon layer -- stream-K GEMMs on packed weights with the residual / silu * up
+    epilogues, lantern_rmsnorm_rows, lantern_tree_attention -- with lantern_qk_rope_pairs as the head stage (no per-head norm, pair rotary from the
+    gathered `freqs_cis` rows)."""
+
+    def __init__(self, config, index: int = 0):
+        nn.Module.__init__(self)
+        self.hidden_size = config.hidden_size
+        self.index = index
+        self.self_attn = LlamaAttention(config)
+        self.mlp = MLP(config)
+        eps = getattr(config, "rms_norm_eps", 1e-6)
+        if index != 0:
+            self.input_layernorm = RMSNorm(config.hidden_size, eps)
+        self.post_attention_layernorm = RMSNorm(config.hidden_size, eps)
+
+    def _fast_ok(self, x, position_ids, output_attentions, freqs_cis=None):
+        at = self.self_attn
+        return (self.fused and not output_attentions and x.dim() == 3 and x.shape[0] * x.shape[1] <= 32 and _hip_ok(x, at.q_proj.weight)
+                and at.head_dim in (64, 128) and x.shape[-1] % 64 == 0 and freqs_cis is not None and self.mlp.act_fn is F.silu
+                and self.post_attention_layernorm.weight.dtype == torch.bfloat16)
+
+    def _fast(self, x, attention_mask, freqs_cis, past_key_value, use_cache, tree_bits=None, tree_keys=0, kv_start=None):
+        at, mlp = self.self_attn, self.mlp
+        B, T, H = x.shape
+        nq, nk, d = at.num_heads, at.num_key_value_heads, at.head_dim
+        x2 = x.reshape(B * T, H)
+        xn = x2 if self.index == 0 else ops.rmsnorm_rows(x2, self.input_layernorm.weight, self.input_layernorm.variance_epsilon)
+        w, b = at._fused_qkv()
+        qkv = ops.linear_rows_streamk(xn, self._packed("qkv", w), bias=b)
+        past = 0 if past_key_value is None else past_key_value[0].shape[-2]
+        kv_len = T + past
+        fr = freqs_cis.reshape(-1, d // 2, 2)                      # the reference hands over the rows of its table at this call's positions: [T, d/2, 2]
+        pos = self.__dict__.get("_arange")
+        if pos is None or pos.numel() < fr.shape[0] or pos.device != x.device:
+            pos = self.__dict__["_arange"] = torch.arange(max(64, fr.shape[0]), dtype=torch.int64, device=x.device)
+        if fr.shape[0] not in (T, B * T):
+            raise ops._lib.LanternError(f"LlamaDecoderLayer: freqs_cis holds {fr.shape[0]} rows for {T} tokens")
+        if self.inplace_cache and use_cache:
+            ks, vs = self._cache_slab(B, nk, d, kv_len, x.device, past_key_value)
+            q, _, _ = ops.qk_rope_pairs(qkv, B, T, nq, nk, d, fr, pos[:fr.shape[0]], k_slab=ks, v_slab=vs, row0=past)
+            k, v = ks[:, :, :kv_len], vs[:, :, :kv_len]
+        else:
+            q, k, v = ops.qk_rope_pairs(qkv, B, T, nq, nk, d, fr, pos[:fr.shape[0]])
+            if past_key_value is not None:
+                k, v = torch.cat([past_key_value[0], k], dim=2), torch.cat([past_key_value[1], v], dim=2)
+        present = (k, v) if use_cache else None
+        if tree_bits is not None:
+            t1 = int(tree_keys)
+            qn = q.transpose(1, 2)
+            if t1 > T:
+                qp = torch.zeros((B, t1, nq, d), dtype=q.dtype, device=q.device)
+                qp[:, t1 - T:] = qn
+            else:
+                qp = qn
+            o = ops.tree_attention(qp, k, v, tree_bits, kv_start=kv_start, max_kv_len=kv_len)[:, t1 - T:].reshape(B * T, H)
+        else:
+            m = None if attention_mask is None else attention_mask[:, :, :, :kv_len].to(q.dtype)
+            o = F.scaled_dot_product_attention(q, k, v, attn_mask=m, enable_gqa=nk != nq).transpose(1, 2).reshape(B * T, H)
+        h1 = ops.linear_rows_streamk(o, self._packed("o", at.o_proj.weight), ops.EPI_RESIDUAL, residual=x2)
+        hn = ops.rmsnorm_rows(h1, self.post_attention_layernorm.weight, self.post_attention_layernorm.variance_epsilon)
+        wg, bg = mlp._fused_gate_up()
+        inter = mlp.gate_proj.out_features
+        act = ops.linear_rows_streamk(hn, self._packed("gate_up", wg, inter), ops.EPI_SILU_MUL, bias=bg, pair_rows=inter)
+        out = ops.linear_rows_streamk(act, self._packed("down", mlp.down_proj.weight), ops.EPI_RESIDUAL, bias=mlp.down_proj.bias, residual=h1)
+        return out.reshape(B, T, H), present
+
+    def forward(self, hidden_states, attention_mask=None, position_ids=None, freqs_cis=None, past_key_value=None, output_attentions=False,
+                use_cache=False, tree_bits=None, tree_keys=0, kv_start=None, **kw) -> Tuple[torch.Tensor, ...]:
+        if self._fast_ok(hidden_states, position_ids, output_attentions, freqs_cis):
+            if tree_bits is not None and not (0 < hidden_states.shape[1] <= tree_keys <= 64):
+                tree_bits = None
+            y, present = self._fast(hidden_states, attention_mask, freqs_cis, past_key_value, use_cache, tree_bits, tree_keys, kv_start)
+            return (y, present) if use_cache else (y,)
+        if (self.fused and not output_attentions and hidden_states.dim() == 3 and hidden_states.is_cuda and hidden_states.dtype == torch.bfloat16
+                and hidden_states.shape[0] * hidden_states.shape[1] <= 32 and _hip_ok(hidden_states, self.self_attn.q_proj.weight)):
+            at = self.self_attn
+            raise ops._lib.LanternError(
+                f"LlamaDecoderLayer: the drafting shape ({tuple(hidden_states.shape)}, bf16, device) takes the fused HIP path, which needs head_dim 64 or "
+                f"128 (got {at.head_dim}), hidden % 64 == 0, silu, bf16 weights / norms and freqs_cis; set `layer.fused = False` for torch's ops")
+        residual = hidden_states
+        x = hidden_states if self.index == 0 else self.input_layernorm(hidden_states)
+        a, w, present = self.self_attn(x, attention_mask=attention_mask, position_ids=position_ids, freqs_cis=freqs_cis, past_key_value=past_key_value,
+                                       output_attentions=output_attentions, use_cache=use_cache)
+        hidden_states = residual + a
+        hidden_states = hidden_states + self.mlp(self.post_attention_layernorm(hidden_states))
+        out = (hidden_states,)
+        if output_attentions:
+            out += (w,)
+        if use_cache:
+            out += (present,)
+        return out

@@ -754,6 +754,34 @@ def qk_norm_rope(qkv, B: int, T: int, nq: int, nk: int, d: int, qw, qb, kw, kb, 
     return q, k_slab, v_slab
 
 
+def qk_rope_pairs(qkv, B: int, T: int, nq: int, nk: int, d: int, freqs, position_ids, k_slab=None, v_slab=None, row0: int = 0):
+    """Head stage of the LlamaGen drafter's attention (lantern_qk_rope_pairs; cnets_llamagen.py:315-323) on the fused projection
+    qkv [B*T, (nq + 2 nk) d] bf16: rotary on adjacent pairs with freqs [rows, d/2, 2] f32 indexed by position_ids ([T] shared by the batch rows, or
+    [B, T]) -> q [B,nq,T,d], k / v [B,nk,T,d] (bf16), or -- k_slab / v_slab [B, nk, rows, d] given -- k / v written in place at rows
+    [row0, row0 + T) of the slabs."""
+    dev = qkv.device
+    q = torch.empty((B, nq, T, d), dtype=torch.bfloat16, device=dev)
+    if k_slab is None:
+        k_slab = torch.empty((B, nk, T, d), dtype=torch.bfloat16, device=dev)
+        v_slab = torch.empty((B, nk, T, d), dtype=torch.bfloat16, device=dev)
+        row0 = 0
+    assert k_slab.is_contiguous() and v_slab.is_contiguous() and k_slab.shape == v_slab.shape and k_slab.shape[0] == B and k_slab.shape[1] == nk
+    freqs = _dev(freqs, torch.float32, "freqs")
+    if freqs.dim() != 3 or freqs.shape[1] != d // 2 or freqs.shape[2] != 2:
+        raise _lib.LanternError(f"qk_rope_pairs: freqs must be [rows, {d // 2}, 2] f32, got {tuple(freqs.shape)}")
+    pos = position_ids.to(device=dev, dtype=torch.int64).reshape(-1).contiguous()
+    if pos.numel() == T:
+        per_row = 0
+    elif pos.numel() == B * T:
+        per_row = 1
+    else:
+        raise _lib.LanternError(f"qk_rope_pairs: position_ids must hold T = {T} (shared by the batch rows) or B x T positions, got {tuple(position_ids.shape)}")
+    check(_lib.lib().lantern_qk_rope_pairs(C.c_void_p(qkv.contiguous().data_ptr()), B, T, nq, nk, d, C.c_void_p(freqs.data_ptr()), freqs.shape[0],
+                                           C.c_void_p(pos.data_ptr()), per_row, C.c_void_p(q.data_ptr()), C.c_void_p(k_slab.data_ptr()),
+                                           C.c_void_p(v_slab.data_ptr()), k_slab.shape[2], row0, _stream()), "qk_rope_pairs")
+    return q, k_slab, v_slab
+
+
 def head_expand(A, weight, row_lo: int, n_cols: int, cfg: float, bias=None, model: int = MODEL_LUMINA, pos_ids=None, pos_base: int = 2,
                 w: int = 48, h: int = 48, newline_id: int = 8803, eos_id: int = 8196, top_k_filter: int = 0, scores_in=None, top_k: int = 10,
                 packed: Optional["PackedLinearWeight"] = None, streamk: bool = True):

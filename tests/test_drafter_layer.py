@@ -259,3 +259,124 @@ def test_streamk_split_tiles_survive_a_poisoned_workspace(M, K, N, epi):
         assert torch.equal(got, first)
     torch.cuda.synchronize()
     assert int(counters.to(torch.int64).sum().item()) == 0          # every tile counter back at zero
+
+
+# ----------------------------------------------------------------------------- LlamaGen's and Anole's drafter layers (tests/golden/layer_lg.npz)
+GOLD_LG = np.load(os.path.join(ROOT, "tests", "golden", "layer_lg.npz"))
+LG_CASES = sorted({k.split(".")[0] for k in GOLD_LG.files if k.startswith("lg_") and "." in k})
+AN_CASES = sorted({k.split(".")[0] for k in GOLD_LG.files if k.startswith("an_")})
+
+
+def _fill(layer, names, seed):
+    """make_golden_layer.fill_parameters: numpy RandomState(seed) in the reference's state_dict order."""
+    mine = layer.state_dict()
+    assert set(names) == set(mine.keys()), (set(names) ^ set(mine.keys()))          # the reference's parameter names load as they are
+    rs = np.random.RandomState(seed)
+    sd = {}
+    for n in names:
+        a = rs.standard_normal(tuple(mine[n].shape)).astype(np.float32)
+        if mine[n].dim() > 1 and "norm" not in n:
+            a = a / np.sqrt(mine[n].shape[-1])
+        elif n.endswith("weight"):
+            a = 1.0 + 0.1 * a
+        else:
+            a = 0.1 * a
+        sd[n] = torch.from_numpy(a)
+    layer.load_state_dict(sd, strict=True)
+
+
+def build_lg(name, device, dtype):
+    from lantern_amd.drafters.decoder_layer import LlamaDecoderLayer
+    hidden, heads, kv_heads, inter, index, seed = (int(x) for x in GOLD_LG[name + ".cfg"])
+    cfg = types.SimpleNamespace(hidden_size=hidden, intermediate_size=inter, num_attention_heads=heads, num_key_value_heads=kv_heads, rms_norm_eps=1e-6,
+                                hidden_act="silu")
+    layer = LlamaDecoderLayer(cfg, index).eval()
+    _fill(layer, [str(n) for n in GOLD_LG[name + ".names"]], seed)
+    return layer.to(device=device, dtype=dtype)
+
+
+def build_an(name, device, dtype):
+    """Anole's layer = the Chameleon layer with one head-norm row per HEAD (cnets_anole.py:317-332): DecoderLayer with model_parallel_size = heads."""
+    hidden, heads, kv_heads, inter, eps9, seed = (int(x) for x in GOLD_LG[name + ".cfg"])
+    cfg = types.SimpleNamespace(hidden_size=hidden, intermediate_size=inter, num_attention_heads=heads, num_key_value_heads=kv_heads,
+                                max_position_embeddings=256, model_parallel_size=heads, rope_theta=10000.0, rms_norm_eps=eps9 * 1e-9, attention_bias=False,
+                                mlp_bias=False, hidden_act="silu")
+    layer = DecoderLayer(cfg, 0).eval()
+    _fill(layer, [str(n) for n in GOLD_LG[name + ".names"]], seed)
+    return layer.to(device=device, dtype=dtype)
+
+
+def gl(name, key, device, dtype=None):
+    t = torch.from_numpy(GOLD_LG[name + "." + key]).to(device)
+    return t.to(dtype) if (dtype is not None and t.is_floating_point()) else t
+
+
+def test_llamagen_freqs_table_equals_the_reference_table():
+    from lantern_amd.drafters.decoder_layer import precompute_freqs_cis_2d
+    assert np.array_equal(precompute_freqs_cis_2d(16, 64, 10000, 119).numpy(), GOLD_LG["lg_table_16_64_119"])
+    assert np.array_equal(precompute_freqs_cis_2d(24, 64, 10000, 0).numpy(), GOLD_LG["lg_table_24_64_0"])
+
+
+@pytest.mark.parametrize("name", LG_CASES)
+def test_llamagen_layer_torch_path_matches_the_reference_layer_f32(name):
+    layer = build_lg(name, "cpu", torch.float32)
+    with torch.no_grad():
+        y0, kv0 = layer(gl(name, "x0", "cpu"), attention_mask=gl(name, "m0", "cpu"), position_ids=gl(name, "pos0", "cpu"), freqs_cis=gl(name, "f0", "cpu"), use_cache=True)
+        y1, kv1 = layer(gl(name, "x1", "cpu"), attention_mask=gl(name, "m1", "cpu"), position_ids=gl(name, "pos1", "cpu"), freqs_cis=gl(name, "f1", "cpu"),
+                        past_key_value=kv0, use_cache=True)
+    for got, key in ((y0, "y0"), (kv0[0], "k0"), (kv0[1], "v0"), (y1, "y1"), (kv1[0], "k1"), (kv1[1], "v1")):
+        np.testing.assert_allclose(got.numpy(), GOLD_LG[name + "." + key], rtol=2e-5, atol=2e-5)
+
+
+@pytest.mark.parametrize("name", AN_CASES)
+def test_anole_layer_torch_path_matches_the_reference_layer_f32(name):
+    layer = build_an(name, "cpu", torch.float32)
+    with torch.no_grad():
+        y0, kv0 = layer(gl(name, "x0", "cpu"), attention_mask=gl(name, "m0", "cpu"), position_ids=gl(name, "pos0", "cpu"), use_cache=True)
+        y1, kv1 = layer(gl(name, "x1", "cpu"), attention_mask=gl(name, "m1", "cpu"), position_ids=gl(name, "pos1", "cpu"), past_key_value=kv0, use_cache=True)
+    for got, key in ((y0, "y0"), (kv0[0], "k0"), (kv0[1], "v0"), (y1, "y1"), (kv1[0], "k1"), (kv1[1], "v1")):
+        np.testing.assert_allclose(got.numpy(), GOLD_LG[name + "." + key], rtol=2e-5, atol=2e-5)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tree", [False, True], ids=["additive_mask", "tree_bits"])
+@pytest.mark.parametrize("name", LG_CASES + AN_CASES)
+def test_llamagen_and_anole_layers_hip_path_match_the_reference_layers_bf16(name, tree, monkeypatch):
+    """The fused HIP path (stream-K GEMMs, rmsnorm_rows, the head stage -- lantern_qk_rope_pairs for LlamaGen, lantern_qk_norm_rope with per-head
+    norm rows for Anole --, tree attention when the tree block comes as ancestor words) against the vectors recorded from the reference's
+    LlamaDecoderLayer / Anole ChameleonDecoderLayer: bf16 tolerance as for the Lumina layer (4e-2 + 4e-2 relative against the f32 reference)."""
+    import torch.nn.functional as F
+    from lantern_amd import ops
+    from lantern_amd._lib import LanternError
+    dev, bf = torch.device("cuda"), torch.bfloat16
+    lg = name.startswith("lg_")
+    layer = (build_lg if lg else build_an)(name, dev, bf)
+    kw0 = dict(freqs_cis=gl(name, "f0", dev)) if lg else {}
+    kw1 = dict(freqs_cis=gl(name, "f1", dev)) if lg else {}
+    if layer.self_attn.head_dim not in (64, 128):
+        with pytest.raises(LanternError, match="fused HIP path"):
+            layer(gl(name, "x0", dev, bf), attention_mask=gl(name, "m0", dev), position_ids=gl(name, "pos0", dev), use_cache=True, **kw0)
+        return
+    calls = []
+    for fn in ("linear_rows_streamk", "rmsnorm_rows", "qk_norm_rope", "qk_rope_pairs", "tree_attention"):
+        real = getattr(ops, fn)
+        monkeypatch.setattr(ops, fn, (lambda real, fn: (lambda *a, **k_: (calls.append(fn), real(*a, **k_))[1]))(real, fn))
+    real_sdpa = F.scaled_dot_product_attention
+    monkeypatch.setattr(F, "scaled_dot_product_attention", lambda *a, **k_: (calls.append("sdpa"), real_sdpa(*a, **k_))[1])
+    m1 = gl(name, "m1", dev)
+    if tree:
+        T1 = m1.shape[2]
+        bits, t1 = ops.drafter_tree_bits((m1[0, 0, :, -T1:] == 0).float()[None, None], T1)
+        start = (m1[:, 0, -1, :] == 0).to(torch.int64).argmax(dim=1)
+        kw1 = dict(kw1, tree_bits=bits, tree_keys=t1, kv_start=start)
+    with torch.no_grad():
+        y0, kv0 = layer(gl(name, "x0", dev, bf), attention_mask=gl(name, "m0", dev), position_ids=gl(name, "pos0", dev), use_cache=True, **kw0)
+        n0 = len(calls)
+        y1, kv1 = layer(gl(name, "x1", dev, bf), attention_mask=m1, position_ids=gl(name, "pos1", dev), past_key_value=kv0, use_cache=True, **kw1)
+    second = calls[n0:]
+    assert second.count("linear_rows_streamk") == 4 and second.count("qk_rope_pairs" if lg else "qk_norm_rope") == 1, second
+    assert second.count("tree_attention" if tree else "sdpa") == 1 and second.count("sdpa" if tree else "tree_attention") == 0, second
+    n_norm = 2 if not lg else (1 if int(GOLD_LG[name + ".cfg"][4]) == 0 else 2)          # LlamaGen's layer 0 has no input norm (EAGLE)
+    assert second.count("rmsnorm_rows") == n_norm, second
+    for got, key in ((y0, "y0"), (y1, "y1"), (kv1[0], "k1"), (kv1[1], "v1")):
+        np.testing.assert_allclose(got.float().cpu().numpy(), GOLD_LG[name + "." + key], rtol=4e-2, atol=4e-2)

@@ -137,7 +137,7 @@ def test_drafter_table_and_attention_outputs():
 def test_harness_step_loop_buffers():
     """The benchmark harness (pools, per-step state, logs, KV slabs -- its own allocations, handed to the C-ABI as raw pointers)."""
     import test_gpu_loop as L
-    _run(L.test_harness_loop_matches_oracle_loop, "window", False, 1)
-    _run(L.test_harness_loop_matches_oracle_loop, "window", False, 3)
-    _run(L.test_harness_loop_matches_oracle_loop, "dense", False, 1)
+    _run(L.test_harness_loop_matches_oracle_loop, "window", False, 1, 6, 36)
+    _run(L.test_harness_loop_matches_oracle_loop, "window", False, 3, 6, 36)
+    _run(L.test_harness_loop_matches_oracle_loop, "dense", False, 1, 6, 36)
     _run(L.test_kv_rows_follow_the_accepted_path)

@@ -206,7 +206,7 @@ def test_generate_with_the_drafter_model_mirror(version, cfg_mode):
     base_cfg = types.SimpleNamespace(num_hidden_layers=2, num_key_value_heads=HKV, max_position_embeddings=SMAX, hidden_size=HKV * DH,
                                      num_attention_heads=HKV)
     base = types.SimpleNamespace(model=FakeInner(dev), lm_head=head, config=base_cfg, dtype=torch.bfloat16)
-    drafter = cnets.Model(cfg, total_tokens=59, depth=4, top_k=10, model_type="lumina_mgpt").to(dev).to(torch.bfloat16)
+    drafter = cnets.Model(cfg, total_tokens=59, depth=4, top_k=10, model_type="lumina_mgpt", allow_torch_layers=True).to(dev).to(torch.bfloat16)
     g = torch.Generator(device="cpu").manual_seed(1)
     table = ops.build_vq_table(torch.randn(8192, 8, generator=g).to(dev))
     mdl = EaLumina_mGPT(base, drafter, table, cfg_mode=cfg_mode, eagle_version=version)
@@ -284,7 +284,7 @@ def test_llamagen_generate_end_to_end(static_tree, top_p, kernel_set):
     base = types.SimpleNamespace(model=FakeLlamaGenInner(dev), lm_head=head, config=base_cfg, dtype=torch.bfloat16)
     base.encode_prompt = lambda prompt, cfg: (torch.zeros(2, 120, H, device=dev, dtype=torch.bfloat16), None)
     dcfg = types.SimpleNamespace(num_hidden_layers=1, hidden_size=H, num_attention_heads=4, intermediate_size=128, vocab_size=Vl, pad_token_id=None)
-    drafter = cnets.Model(dcfg, total_tokens=59, depth=4, top_k=10, model_type="llamagen").to(dev).to(torch.bfloat16)
+    drafter = cnets.Model(dcfg, total_tokens=59, depth=4, top_k=10, model_type="llamagen", allow_torch_layers=True).to(dev).to(torch.bfloat16)
     drafter.init_tree()
     g = torch.Generator(device="cpu").manual_seed(1)
     table = ops.build_vq_table(torch.randn(Vl, 8, generator=g).to(dev))
@@ -322,7 +322,7 @@ def test_anole_generate_end_to_end(static_tree, top_p, kernel_set):
                                      num_attention_heads=HKV)
     base = types.SimpleNamespace(model=FakeInner(dev), lm_head=head, config=base_cfg, dtype=torch.bfloat16)
     dcfg = types.SimpleNamespace(num_hidden_layers=1, hidden_size=H, num_attention_heads=4, intermediate_size=128, vocab_size=V, pad_token_id=None)
-    drafter = cnets.Model(dcfg, total_tokens=59, depth=4, top_k=10, model_type="anole").to(dev).to(torch.bfloat16)
+    drafter = cnets.Model(dcfg, total_tokens=59, depth=4, top_k=10, model_type="anole", allow_torch_layers=True).to(dev).to(torch.bfloat16)
     drafter.init_tree()
     g = torch.Generator(device="cpu").manual_seed(1)
     table = ops.build_vq_table(torch.randn(8192, 8, generator=g).to(dev))

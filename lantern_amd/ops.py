@@ -745,7 +745,12 @@ def qk_norm_rope(qkv, B: int, T: int, nq: int, nk: int, d: int, qw, qb, kw, kb, 
         v_slab = torch.empty((B, nk, T, d), dtype=torch.bfloat16, device=dev)
         row0 = 0
     assert k_slab.is_contiguous() and v_slab.is_contiguous() and k_slab.shape == v_slab.shape and k_slab.shape[0] == B and k_slab.shape[1] == nk
-    pos = position_ids.to(torch.int64).contiguous()
+    pos = position_ids.to(torch.int64)
+    if pos.numel() == T and B > 1:          # one row of positions shared by the batch rows
+        pos = pos.reshape(1, T).expand(B, T)
+    if pos.numel() != B * T:
+        raise _lib.LanternError(f"qk_norm_rope: position_ids must hold T = {T} (shared by the batch rows) or B x T positions, got {tuple(position_ids.shape)}")
+    pos = pos.contiguous()
     check(_lib.lib().lantern_qk_norm_rope(C.c_void_p(qkv.contiguous().data_ptr()), B, T, nq, nk, d, C.c_void_p(qw.contiguous().data_ptr()),
                                           C.c_void_p(qb.contiguous().data_ptr()), C.c_void_p(kw.contiguous().data_ptr()), C.c_void_p(kb.contiguous().data_ptr()),
                                           qw.shape[0], C.c_void_p(cos.data_ptr()), C.c_void_p(sin.data_ptr()), cos.shape[0], C.c_void_p(pos.data_ptr()),

@@ -379,3 +379,75 @@ def test_drafter_lumina_static_loop_calls_vs_reference():
     _check_recorded_calls(m.seen, g, pre, check_ids=False)
     assert tuple(out[0].shape) == tuple(g[pre + "ss_token_shape"]) and len(out[2]) == int(g[pre + "n_op"])
     assert ((out[0] >= 4) & (out[0] < 8196) | (out[0] == 8803)).all()
+
+
+@pytest.mark.parametrize("model_type,V,H,heads", [("llamagen", 16384, 128, 2), ("anole", 65536, 256, 4), ("lumina_mgpt", 65536, 256, 2)])
+def test_default_layers_draft_on_the_hip_path(model_type, V, H, heads, monkeypatch):
+    """cnets.Model without injected layers builds the HIP decoder layer of the model family (LlamaDecoderLayer with the 2-D freqs_cis table it then
+    owns / DecoderLayer, Anole's with one head-norm row per head) and a whole dynamic drafting call -- prefill, `depth` tree steps, head expansion per
+    depth -- runs on the library's kernels: stream-K GEMMs, the head stage, tree attention and the fused head_expand; no torch attention call at the
+    drafting shape, no full-vocabulary head GEMM.  The drafting forward agrees with the same layer on torch's ops (`fused = False`: the composition the
+    golden vectors pin to the reference layer) within the bf16 tolerance, and a config outside the kernels raises instead of falling back."""
+    import torch.nn.functional as F
+    from lantern_amd._lib import LanternError
+    from lantern_amd.drafters.decoder_layer import DecoderLayer, LlamaDecoderLayer
+    from transformers.generation.logits_process import LogitsProcessorList, TopKLogitsWarper
+    dev, bf = torch.device("cuda"), torch.bfloat16
+    cfg = types.SimpleNamespace(vocab_size=V, hidden_size=H, pad_token_id=None, num_hidden_layers=1, num_attention_heads=heads, num_key_value_heads=heads,
+                                intermediate_size=2 * H, max_position_embeddings=512, rms_norm_eps=1e-5, model_parallel_size=1, input_type="t2i")
+    torch.manual_seed(5)
+    mdl = cnets.Model(cfg, total_tokens=30, depth=3, top_k=CS.TOPK, model_type=model_type).to(dev).to(bf)
+    assert isinstance(mdl.layers[0], LlamaDecoderLayer if model_type == "llamagen" else DecoderLayer)
+    if model_type == "llamagen":
+        assert mdl.freqs_cis.shape == (119 + 256 + 20, H // heads // 2, 2) and "input_layernorm.weight" not in mdl.layers[0].state_dict()
+    if model_type == "anole":
+        assert tuple(mdl.layers[0].self_attn.q_norm.weight.shape) == (heads, H // heads)
+    with pytest.raises(LanternError, match="outside the HIP decoder layer"):
+        cnets.Model(types.SimpleNamespace(vocab_size=V, hidden_size=64, pad_token_id=None, num_hidden_layers=1, num_attention_heads=4, intermediate_size=128),
+                    model_type=model_type)
+    head = torch.nn.Linear(H, V, bias=False).to(dev).to(bf)
+    calls = []
+    for fn in ("linear_rows_streamk", "qk_norm_rope", "qk_rope_pairs", "tree_attention", "head_expand", "linear_rows", "drafter_fc"):
+        real = getattr(ops, fn)
+        monkeypatch.setattr(ops, fn, (lambda real, fn: (lambda *a, **k_: (calls.append(fn), real(*a, **k_))[1]))(real, fn))
+    real_sdpa = F.scaled_dot_product_attention
+    monkeypatch.setattr(F, "scaled_dot_product_attention", lambda *a, **k_: (calls.append(("sdpa", a[0].shape[2])), real_sdpa(*a, **k_))[1])
+    mdl.init_tree()
+    hidden = torch.randn(2, 5, H, device=dev, dtype=bf)
+    ids = torch.randint(4, 8000, (2, 6), device=dev)
+    proc = LogitsProcessorList([TopKLogitsWarper(300)])
+    if model_type == "lumina_mgpt":
+        class P2(list):
+            pass
+        pr = P2([None, types.SimpleNamespace(image_top_k=300)])
+        out = mdl.topK_generate(hidden[:1], hidden[1:], ids[:1], head, pr, attention_mask=torch.ones(2, 5, dtype=torch.bool, device=dev), tree_type="dynamic")
+    else:
+        mdl.cfg_scale = 3.0
+        kw = dict(input_position_diff=torch.zeros((), dtype=torch.long, device=dev), attention_mask=torch.ones(2, 5, dtype=torch.bool, device=dev)) if model_type == "anole" else {}
+        out = mdl.topK_genrate(hidden, ids, head, proc, 3.0, **kw)
+    draft, ret, mask, pos = out
+    assert draft.shape == (1, 30) and mask.shape[-1] == 30 and int(ret.max()) < 30
+    # the drafting calls: 3 depths x (4 stream-K GEMMs + head stage + tree attention) + the prefill's GEMMs; 4 fused head expansions
+    assert calls.count("head_expand") == 4, calls
+    assert calls.count("tree_attention") == 3 and calls.count("qk_rope_pairs" if model_type == "llamagen" else "qk_norm_rope") == 4, calls
+    assert calls.count("linear_rows_streamk") == 16 and calls.count("linear_rows") == 0, calls
+    assert all(not (isinstance(c, tuple) and c[0] == "sdpa" and c[1] == CS.TOPK) for c in calls), calls          # (the 5-token prefill may take SDPA)
+    # the drafting forward against the same layer on torch's ops
+    mdl.reset_kv()
+    mdl.tree_mask = None
+    x = torch.randn(2, 9, H, device=dev, dtype=bf)
+    iid = torch.randint(4, 8000, (2, 9), device=dev)
+    with torch.no_grad():
+        y_hip, kv = mdl(x, iid, use_cache=True)
+    mdl.tree_mask = mdl.tree_mask_init
+    pos_t = (9 + mdl.position_ids)[None].expand(2, -1) if model_type != "llamagen" else 9 + mdl.position_ids
+    xt, it = torch.randn(2, CS.TOPK, H, device=dev, dtype=bf), torch.randint(4, 8000, (2, CS.TOPK), device=dev)
+    with torch.no_grad():
+        t_hip, _ = mdl(xt, it, past_key_values=tuple((k.clone(), v.clone()) for k, v in kv), position_ids=pos_t, use_cache=True)
+    for l in mdl.layers:
+        l.fused = False
+        l.inplace_cache = False
+    monkeypatch.setattr("lantern_amd.drafters.decoder_layer._hip_ok", lambda a, b: False)
+    with torch.no_grad():
+        t_ref, _ = mdl(xt, it, past_key_values=tuple((k.clone(), v.clone()) for k, v in kv), position_ids=pos_t, use_cache=True)
+    np.testing.assert_allclose(t_hip.float().cpu().numpy(), t_ref.float().cpu().numpy(), rtol=3e-2, atol=3e-2)

@@ -178,6 +178,38 @@ def test_head_expand_vs_the_oracle_behind_the_gemm(n, K, special):
     assert np.allclose(fused[3][0].cpu().numpy()[fs], so[fs], rtol=0, atol=2e-6)
 
 
+@pytest.mark.parametrize("model,n,K,tk", [("anole", 10, 512, 2000), ("anole", 1, 4096, 2000), ("anole", 10, 128, 0), ("anole", 7, 256, 10000),
+                                          ("llamagen", 10, 1280, 2000), ("llamagen", 1, 1280, 2000), ("llamagen", 10, 128, 0), ("llamagen", 16, 256, 50), ("anole", 16, 256, 12)])
+def test_head_expand_anole_and_llamagen_vs_the_oracle_behind_the_gemm(model, n, K, tk):
+    """lantern_head_expand_streamk for the two models beside Lumina (cnets_anole.py:835-903: non-image ids to finfo.min after the CFG mix, then the
+    HF processors; cnets_llamagen.py:783-821: the whole 16384-id vocabulary, no mask).  What follows the head's GEMM is restated in torch f32 the way
+    the reference computes it -- CFG in bf16 steps, HF TopKLogitsWarper over the FULL row (`scores < kth largest -> -inf`: ties at the threshold stay; a
+    top_k wider than Anole's window removes nothing inside it), log-softmax -- and handed to the ORACLE's expand (top-k, cumulative scores, best k of
+    n * k): same token ids and parents, scores to f32 rounding.  (oracle.cfg_mask_topk restates tree_decoding, where these two models apply no top-k.)"""
+    torch.manual_seed(100 * n + K + tk)
+    anole = model == "anole"
+    V, lo, W = (65536, 4, 8192) if anole else (16384, 0, 16384)
+    A = (0.5 * torch.randn(2 * n, K, device="cuda")).to(torch.bfloat16)
+    Wt = (0.3 * torch.randn(V, K, device="cuda")).to(torch.bfloat16)
+    scores_in = torch.randn(n, device="cuda") if n > 1 else None
+    pk = ops.pack_linear_weight(Wt[lo:lo + W].contiguous()) if K % 64 == 0 else None
+    fused = ops.head_expand(A, Wt, lo, W, 3.0, model=ops.MODEL_ANOLE if anole else ops.MODEL_PLAIN, pos_ids=None, top_k_filter=min(tk, V),
+                            scores_in=scores_in, top_k=10, packed=pk)
+    win = ops.linear_rows_streamk(A, pk if pk is not None else Wt[lo:lo + W].contiguous())          # [2n, W] bf16: the head's logits on the window
+    bf = lambda t: t.to(torch.bfloat16).float()
+    c, u = win[:n].float(), win[n:].float()
+    mix = torch.full((n, V), torch.finfo(torch.bfloat16).min, dtype=torch.float32, device="cuda")      # (Anole: non-image ids at finfo.min)
+    mix[:, lo:lo + W] = bf(u + bf(3.0 * bf(c - u)))
+    if tk > 0:
+        kth = torch.topk(mix, min(tk, V), dim=-1).values[:, -1:]
+        mix = mix.masked_fill(mix < kth, float("-inf"))
+    ti, cu, ci, so = oracle.expand_dynamic(mix.cpu().numpy(), None if scores_in is None else scores_in.cpu().numpy(), 10)
+    assert np.array_equal(fused[0][0].cpu().numpy(), ti) and np.array_equal(fused[2][0].cpu().numpy(), ci)
+    got = fused[1][0].cpu().numpy()
+    assert np.isfinite(cu).all() and np.allclose(got, cu, rtol=0, atol=4e-6)
+    assert np.allclose(fused[3][0].cpu().numpy(), so, rtol=0, atol=4e-6)
+
+
 @pytest.mark.parametrize("form", ["streamk_packed", "streamk", "per_tile"])
 @pytest.mark.parametrize("n,K,special", [(10, 512, ""), (1, 256, ""), (10, 4096, ""), (10, 256, "newline"), (7, 128, "eos"), (16, 64, "few")])
 def test_head_expand_fused_equals_the_three_step_composition(n, K, special, form):

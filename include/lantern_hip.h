@@ -552,6 +552,71 @@ int lantern_qk_rope_pairs(const void *qkv, int B, int T, int n_q_heads, int n_kv
                           const int64_t *position_ids, int positions_per_batch_row, void *q_out, void *k_out, void *v_out, int kv_rows, int kv_row0,
                           void *stream);
 
+/* One drafting depth of the EAGLE-2 drafter from ONE host call (what lantern_verify_step is to the accept side): the loop body of topK_genrate
+ * (models/drafters/cnets_lumina_mgpt.py:1271-1320, cnets_llamagen.py:783-821, cnets_anole.py:841-903) for the cond / uncond pair of one sequence --
+ *   input stage  fc(cat(embed[ids] * scale, hidden))                                  (lantern_drafter_fc_streamk)
+ *   the decoder layer at its decode shape (B = 2 rows x T = top_k tokens, B * T <= 32): [RMSNorm] -> fused q/k/v GEMM -> head stage (Chameleon: per-head
+ *     layer norm + rotary; Llama: pair rotary from the freqs rows) writing k / v into the cache slabs in place -> tree attention over the cache with the
+ *     tree block as ancestor words -> o_proj + residual -> RMSNorm -> gate/up GEMM with silu * up -> down_proj + residual
+ *   the head on the window rows with the CFG mix, the model's processors, log-softmax, top-k, cumulative scores, best top_k of T * top_k
+ *     (lantern_head_expand_streamk)
+ *   the next depth's inputs: hidden rows of the chosen parents, their tokens, the parents' indices into the score list, the ancestor words of the new
+ *     tree rows --
+ * every launch enqueued on `stream` by this call, every buffer caller-allocated, nothing returned to the host.  Weights: bf16, the GEMM weights as
+ * lantern_pack_linear_weight laid them out (`*_packed` != 0) or row-major.  B must be 2 (cond, then uncond). */
+typedef struct lantern_draft_depth_args {
+    void *stream;
+    int32_t layer_kind;                /* 0: Chameleon layer (Lumina-mGPT / Anole), 1: Llama layer (LlamaGen) */
+    int32_t B, T, H, n_q_heads, n_kv_heads, head_dim, inter, vocab;
+    float eps1, eps2, embed_scale, cfg;
+    /* input stage */
+    const int64_t *ids;                /* [dev] [B * T] token ids (the T tree tokens, repeated per row) */
+    const void *hidden_in;             /* [dev] [B, T, H] bf16 */
+    const void *embed, *fc_w, *fc_b;   /* embed [vocab, H]; fc_w [H, 2H] (packed: lantern_pack_linear_weight(fc_w, H, 2H, 0)); fc_b [H] or NULL */
+    int32_t fc_packed, layer_packed;
+    /* layer */
+    const void *ln1_w;                 /* input RMSNorm weight [H], or NULL (EAGLE's layer 0 of the Llama drafter has none) */
+    const void *qkv_w, *qkv_b;         /* fused q/k/v [(nq + 2 nk) d, H], bias or NULL */
+    const void *o_w, *o_b, *ln2_w, *gate_up_w, *gate_up_b, *down_w, *down_b;      /* gate_up: cat(gate, up) rows, pair_rows = inter */
+    /* head stage */
+    const void *qn_w, *qn_b, *kn_w, *kn_b;       /* Chameleon: per-head layer-norm rows [model_parallel, d] */
+    int32_t model_parallel, table_rows;
+    const void *cos_table, *sin_table; /* Chameleon: [table_rows, d] bf16 */
+    const float *freqs;                /* Llama: [table_rows, d/2, 2] f32 */
+    const int64_t *position_ids;       /* [B, T] (positions_per_batch_row != 0) or [T] */
+    int32_t positions_per_batch_row, reserved0;
+    /* cache: k / v slabs [B, nk, kv_rows, d] bf16, this depth's rows written at [kv_row0, kv_row0 + T) */
+    void *k_slab, *v_slab;
+    int32_t kv_rows, kv_row0;
+    /* tree */
+    uint64_t *tree_bits;               /* [dev] [64] ancestor words of the tree's rows (row r: bit j set = key j of the tree block is visible); rows
+                                        * [t1 - T, t1) are this depth's queries; the call writes rows [t1, t1 + T) for the next depth */
+    int32_t t1, reserved1;             /* tree keys incl. this depth's T (t1 + T <= 64 when a next depth follows) */
+    const int64_t *kv_start;           /* [B] first visible key per row (left padding) or NULL */
+    /* head */
+    const void *head_w, *head_b;       /* [vocab, H] row-major, or the packed rows [row_lo, row_lo + n_cols) */
+    int32_t head_packed, row_lo, n_cols, model;          /* model: LANTERN_MODEL_LUMINA / _ANOLE / _PLAIN (window = the whole vocabulary) */
+    const int64_t *head_pos;           /* Lumina: [T] positions of the rows for the grammar mask, or NULL */
+    int64_t pos_base;
+    int32_t w_latent, h_latent, newline_id, eos_id, top_k_filter, top_k;
+    const float *scores_in;            /* [T] cumulative scores of this depth's tokens */
+    int64_t *topk_index;               /* out [T, top_k] */
+    float *cu_scores;                  /* out [T, top_k] */
+    int64_t *topk_cs_index;            /* out [top_k] */
+    float *scores_out;                 /* out [top_k] */
+    /* next depth (NULL hidden_next: the last depth) */
+    void *hidden_next;                 /* out [B, top_k, H] bf16: rows of this depth's output at the chosen parents */
+    int64_t *ids_next;                 /* out [B * top_k] */
+    int64_t *parents_next;             /* out [top_k]: topk_cs_index + parent_bias_next (the reference's `parents`, cnets_llamagen.py:798-803) */
+    int64_t parent_bias_next;
+    /* work buffers [dev], bf16 unless noted: x, xn, h1, hn, out [B*T, H]; qkv [B*T, (nq + 2 nk) d]; q [B, nq, 64, d] (zero-filled once by the caller);
+     * attn [B, 64, H]; act [B*T, inter]; head_ws: lantern_head_expand_workspace(T, n_cols) bytes; sk_ws: lantern_linear_rows_streamk_workspace
+     * (zero-filled once); ta_ws: lantern_tree_attention_workspace(B, nq, 64, d, kv_rows) bytes */
+    void *x, *xn, *qkv, *q, *attn, *h1, *hn, *act, *out, *head_ws, *sk_ws, *ta_ws;
+    size_t sk_ws_bytes, ta_ws_bytes;
+} lantern_draft_depth_args;
+int lantern_draft_depth(const lantern_draft_depth_args *args);
+
 /* 8f-2 (next row, second half)  One drafter expansion depth from the hidden states to the top-k in two small launches, the head's
  * logits never in HBM:  head(hidden) restricted to the id window the model's mask lets through -> CFG combination in the GEMM's
  * epilogue (`uncond + cfg * (cond - uncond)` with torch's bf16 roundings) -> [n, n_cols] bf16 window (16 KB per row) -> per row:

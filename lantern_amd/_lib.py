@@ -81,6 +81,29 @@ class StepGroup(C.Structure):
                 + [("dyn", C.POINTER(StepDynamic))])
 
 
+class DraftDepthArgs(C.Structure):
+    """lantern_draft_depth_args (include/lantern_hip.h): one drafting depth of the EAGLE-2 drafter."""
+    _fields_ = ([("stream", C.c_void_p), ("layer_kind", C.c_int32)]
+                + [(n, C.c_int32) for n in ("B", "T", "H", "n_q_heads", "n_kv_heads", "head_dim", "inter", "vocab")]
+                + [(n, C.c_float) for n in ("eps1", "eps2", "embed_scale", "cfg")]
+                + [(n, C.c_void_p) for n in ("ids", "hidden_in", "embed", "fc_w", "fc_b")]
+                + [("fc_packed", C.c_int32), ("layer_packed", C.c_int32)]
+                + [(n, C.c_void_p) for n in ("ln1_w", "qkv_w", "qkv_b", "o_w", "o_b", "ln2_w", "gate_up_w", "gate_up_b", "down_w", "down_b",
+                                             "qn_w", "qn_b", "kn_w", "kn_b")]
+                + [("model_parallel", C.c_int32), ("table_rows", C.c_int32)]
+                + [(n, C.c_void_p) for n in ("cos_table", "sin_table", "freqs", "position_ids")]
+                + [("positions_per_batch_row", C.c_int32), ("reserved0", C.c_int32), ("k_slab", C.c_void_p), ("v_slab", C.c_void_p),
+                   ("kv_rows", C.c_int32), ("kv_row0", C.c_int32), ("tree_bits", C.c_void_p), ("t1", C.c_int32), ("reserved1", C.c_int32),
+                   ("kv_start", C.c_void_p), ("head_w", C.c_void_p), ("head_b", C.c_void_p)]
+                + [(n, C.c_int32) for n in ("head_packed", "row_lo", "n_cols", "model")]
+                + [("head_pos", C.c_void_p), ("pos_base", C.c_int64)]
+                + [(n, C.c_int32) for n in ("w_latent", "h_latent", "newline_id", "eos_id", "top_k_filter", "top_k")]
+                + [(n, C.c_void_p) for n in ("scores_in", "topk_index", "cu_scores", "topk_cs_index", "scores_out", "hidden_next", "ids_next", "parents_next")]
+                + [("parent_bias_next", C.c_int64)]
+                + [(n, C.c_void_p) for n in ("x", "xn", "qkv", "q", "attn", "h1", "hn", "act", "out", "head_ws", "sk_ws", "ta_ws")]
+                + [("sk_ws_bytes", C.c_size_t), ("ta_ws_bytes", C.c_size_t)])
+
+
 _lib = None
 
 
@@ -138,5 +161,5 @@ EXPORTS = [
     "lantern_tree_attention_workspace", "lantern_tree_attention",
     "lantern_tree_node_tables_size", "lantern_tree_node_tables", "lantern_evaluate_posterior_nodes_workspace",
     "lantern_evaluate_posterior_nodes", "lantern_verify_step", "lantern_gather_candidates_dynamic", "lantern_head_expand_workspace", "lantern_head_expand", "lantern_prepare_step",
-    "lantern_linear_rows_epilogue", "lantern_linear_rows_splitk", "lantern_linear_rows_streamk_workspace", "lantern_linear_rows_streamk", "lantern_pack_linear_weight_bytes", "lantern_pack_linear_weight", "lantern_drafter_fc_streamk", "lantern_head_expand_streamk", "lantern_rmsnorm_rows", "lantern_qk_norm_rope", "lantern_qk_rope_pairs",
+    "lantern_linear_rows_epilogue", "lantern_linear_rows_splitk", "lantern_linear_rows_streamk_workspace", "lantern_linear_rows_streamk", "lantern_pack_linear_weight_bytes", "lantern_pack_linear_weight", "lantern_drafter_fc_streamk", "lantern_head_expand_streamk", "lantern_rmsnorm_rows", "lantern_qk_norm_rope", "lantern_qk_rope_pairs", "lantern_draft_depth",
 ]

@@ -336,7 +336,8 @@ __global__ __launch_bounds__(64) void qk_norm_rope_kernel(const uint16_t *__rest
                                                           const uint16_t *__restrict__ qb, const uint16_t *__restrict__ kw, const uint16_t *__restrict__ kb,
                                                           int q_heads_per_mp, int k_heads_per_mp, const uint16_t *__restrict__ cos_t,
                                                           const uint16_t *__restrict__ sin_t, const int64_t *__restrict__ pos, uint16_t *__restrict__ q_out,
-                                                          uint16_t *__restrict__ k_out, uint16_t *__restrict__ v_out, int kv_rows, int kv_row0, int table_rows) {
+                                                          uint16_t *__restrict__ k_out, uint16_t *__restrict__ v_out, int kv_rows, int kv_row0, int table_rows,
+                                                          int q_rows, int q_row0) {
     constexpr int E = D / 64;
     const int tok = blockIdx.x, head = blockIdx.y, lane = threadIdx.x;          // head in [0, nq + 2 nk)
     const int b = tok / T, t = tok % T;
@@ -377,7 +378,7 @@ __global__ __launch_bounds__(64) void qk_norm_rope_kernel(const uint16_t *__rest
     int64_t p = pos[(size_t)b * T + t];
     p = p < 0 ? 0 : (p >= table_rows ? table_rows - 1 : p);          // (the reference would raise on a position beyond its tables; never read outside ours)
     const uint16_t *cr = cos_t + (size_t)p * D, *sr = sin_t + (size_t)p * D;
-    uint16_t *dst = (is_q ? q_out + (((size_t)b * nq + hh) * T + t) * D : k_out + (((size_t)b * nk + hh) * kv_rows + kv_row0 + t) * D);
+    uint16_t *dst = (is_q ? q_out + (((size_t)b * nq + hh) * q_rows + q_row0 + t) * D : k_out + (((size_t)b * nk + hh) * kv_rows + kv_row0 + t) * D);
 #pragma unroll
     for (int e = 0; e < E; ++e) {
         const int i = lane + 64 * e;
@@ -399,7 +400,8 @@ __global__ __launch_bounds__(64) void qk_norm_rope_kernel(const uint16_t *__rest
 template <int D>
 __global__ __launch_bounds__(64) void qk_rope_pairs_kernel(const uint16_t *__restrict__ qkv, int T, int nq, int nk, const float *__restrict__ freqs,
                                                            const int64_t *__restrict__ pos, int pos_per_batch, uint16_t *__restrict__ q_out,
-                                                           uint16_t *__restrict__ k_out, uint16_t *__restrict__ v_out, int kv_rows, int kv_row0, int table_rows) {
+                                                           uint16_t *__restrict__ k_out, uint16_t *__restrict__ v_out, int kv_rows, int kv_row0, int table_rows,
+                                                           int q_rows, int q_row0) {
     constexpr int E = D / 64;
     const int tok = blockIdx.x, head = blockIdx.y, lane = threadIdx.x;          // head in [0, nq + 2 nk)
     const int b = tok / T, t = tok % T;
@@ -416,7 +418,7 @@ __global__ __launch_bounds__(64) void qk_rope_pairs_kernel(const uint16_t *__res
     int64_t p = pos[pos_per_batch ? (size_t)b * T + t : (size_t)t];
     p = p < 0 ? 0 : (p >= table_rows ? table_rows - 1 : p);          // (the reference would raise on a position beyond its table; never read outside ours)
     const float *fr = freqs + (size_t)p * D;                         // [d/2][2]
-    uint16_t *dst = (is_q ? q_out + (((size_t)b * nq + hh) * T + t) * D : k_out + (((size_t)b * nk + hh) * kv_rows + kv_row0 + t) * D);
+    uint16_t *dst = (is_q ? q_out + (((size_t)b * nq + hh) * q_rows + q_row0 + t) * D : k_out + (((size_t)b * nk + hh) * kv_rows + kv_row0 + t) * D);
 #pragma unroll
     for (int e = 0; e < E; ++e) {
         const int i = lane + 64 * e;
@@ -679,6 +681,10 @@ struct SkArgs {
     float *ws;            // [G][2][NSET][32 * 32] partial tiles
     uint32_t *cnt;        // [n_tiles] chunks accumulated (zero before the launch; left zero)
     int M, K, row_lo, n_rows, out_stride, out_col0, aux_stride, pair_rows, n_tiles, cpt, G;
+    // activation rows in segments: row m lives at A + (m / a_seg_rows) * a_seg_stride + (m % a_seg_rows) * K (elements); a_seg_rows = 0: one [M, K] matrix.
+    // (lantern_draft_depth: the attention output of the cond / uncond rows sits in two [64, H] slots, the last T rows of each are this depth's)
+    int a_seg_rows;
+    long long a_seg_stride;
     // GATHER (the drafter's input stage, lantern_drafter_fc): A[m] = cat(embed[ids[m]] * embed_scale, hidden[m]) with K = 2 * hsplit; `A` is hidden
     const int64_t *ids;
     const uint16_t *embed;
@@ -699,7 +705,8 @@ __global__ __launch_bounds__(FC_THREADS) void linear_rows_streamk_kernel(const S
     const long long c1 = total * (wg + 1) / G;
     const int first_tile = (int)(c0 / cpt);
     const bool live = r < a.M;
-    const uint16_t *arow = a.A + (size_t)(live ? r : 0) * (GATHER ? a.hsplit : K);
+    const int seg = (a.a_seg_rows > 0 && live) ? r / a.a_seg_rows : 0;
+    const uint16_t *arow = a.A + (size_t)seg * a.a_seg_stride + (size_t)(live ? r - seg * a.a_seg_rows : 0) * (GATHER ? a.hsplit : K);
     const uint16_t *erow = nullptr;
     if constexpr (GATHER) {
         int64_t id = live ? a.ids[r] : 0;
@@ -1063,14 +1070,15 @@ extern "C" int lantern_rmsnorm_rows(const void *x, const void *weight, int M, in
     return LANTERN_OK;
 }
 
-extern "C" int lantern_qk_norm_rope(const void *qkv, int B, int T, int n_q_heads, int n_kv_heads, int head_dim, const void *q_weight, const void *q_bias,
-                                    const void *k_weight, const void *k_bias, int model_parallel, const void *cos_table, const void *sin_table,
-                                    int table_rows, const int64_t *position_ids, void *q_out, void *k_out, void *v_out, int kv_rows, int kv_row0,
-                                    void *stream) {
+namespace lantern {
+int launch_qk_norm_rope(const void *qkv, int B, int T, int n_q_heads, int n_kv_heads, int head_dim, const void *q_weight, const void *q_bias,
+                        const void *k_weight, const void *k_bias, int model_parallel, const void *cos_table, const void *sin_table,
+                        int table_rows, const int64_t *position_ids, void *q_out, int q_rows, int q_row0, void *k_out, void *v_out, int kv_rows, int kv_row0,
+                        void *stream) {
     LANTERN_CHECK_ARG(qkv && q_weight && q_bias && k_weight && k_bias && cos_table && sin_table && position_ids && q_out && k_out && v_out,
                       "qk_norm_rope: null buffer");
     LANTERN_CHECK_ARG(B >= 0 && T >= 0 && n_q_heads > 0 && n_kv_heads > 0 && model_parallel > 0 && n_q_heads % model_parallel == 0 &&
-                          n_kv_heads % model_parallel == 0 && table_rows > 0 && kv_row0 >= 0 && kv_rows >= kv_row0 + T,
+                          n_kv_heads % model_parallel == 0 && table_rows > 0 && kv_row0 >= 0 && kv_rows >= kv_row0 + T && q_row0 >= 0 && q_rows >= q_row0 + T,
                       "qk_norm_rope: bad sizes (k / v are [B, nk, kv_rows, d] slabs written at rows kv_row0 .. kv_row0 + T)");
     LANTERN_CHECK_ARG(head_dim == 128 || head_dim == 64, "qk_norm_rope: head_dim %d (64 or 128)", head_dim);
     if (B * T == 0) return LANTERN_OK;
@@ -1078,7 +1086,7 @@ extern "C" int lantern_qk_norm_rope(const void *qkv, int B, int T, int n_q_heads
 #define QKNR(D_) LANTERN_LAUNCH((qk_norm_rope_kernel<D_>), grid, dim3(64), 0, (hipStream_t)stream, (const uint16_t *)qkv, T, n_q_heads, n_kv_heads,     \
                                 (const uint16_t *)q_weight, (const uint16_t *)q_bias, (const uint16_t *)k_weight, (const uint16_t *)k_bias,                 \
                                 n_q_heads / model_parallel, n_kv_heads / model_parallel, (const uint16_t *)cos_table, (const uint16_t *)sin_table,           \
-                                position_ids, (uint16_t *)q_out, (uint16_t *)k_out, (uint16_t *)v_out, kv_rows, kv_row0, table_rows)
+                                position_ids, (uint16_t *)q_out, (uint16_t *)k_out, (uint16_t *)v_out, kv_rows, kv_row0, table_rows, q_rows, q_row0)
     if (head_dim == 128) QKNR(128);
     else QKNR(64);
 #undef QKNR
@@ -1086,23 +1094,57 @@ extern "C" int lantern_qk_norm_rope(const void *qkv, int B, int T, int n_q_heads
     return LANTERN_OK;
 }
 
-extern "C" int lantern_qk_rope_pairs(const void *qkv, int B, int T, int n_q_heads, int n_kv_heads, int head_dim, const float *freqs, int table_rows,
-                                     const int64_t *position_ids, int positions_per_batch_row, void *q_out, void *k_out, void *v_out, int kv_rows,
-                                     int kv_row0, void *stream) {
+int launch_qk_rope_pairs(const void *qkv, int B, int T, int n_q_heads, int n_kv_heads, int head_dim, const float *freqs, int table_rows,
+                         const int64_t *position_ids, int positions_per_batch_row, void *q_out, int q_rows, int q_row0, void *k_out, void *v_out,
+                         int kv_rows, int kv_row0, void *stream) {
     LANTERN_CHECK_ARG(qkv && freqs && position_ids && q_out && k_out && v_out, "qk_rope_pairs: null buffer");
-    LANTERN_CHECK_ARG(B >= 0 && T >= 0 && n_q_heads > 0 && n_kv_heads > 0 && table_rows > 0 && kv_row0 >= 0 && kv_rows >= kv_row0 + T,
+    LANTERN_CHECK_ARG(B >= 0 && T >= 0 && n_q_heads > 0 && n_kv_heads > 0 && table_rows > 0 && kv_row0 >= 0 && kv_rows >= kv_row0 + T && q_row0 >= 0 &&
+                          q_rows >= q_row0 + T,
                       "qk_rope_pairs: bad sizes (k / v are [B, nk, kv_rows, d] slabs written at rows kv_row0 .. kv_row0 + T)");
     LANTERN_CHECK_ARG(head_dim == 128 || head_dim == 64, "qk_rope_pairs: head_dim %d (64 or 128)", head_dim);
     if (B * T == 0) return LANTERN_OK;
     dim3 grid(B * T, n_q_heads + 2 * n_kv_heads);
 #define QKRP(D_) LANTERN_LAUNCH((qk_rope_pairs_kernel<D_>), grid, dim3(64), 0, (hipStream_t)stream, (const uint16_t *)qkv, T, n_q_heads, n_kv_heads, freqs,       \
-                                position_ids, positions_per_batch_row, (uint16_t *)q_out, (uint16_t *)k_out, (uint16_t *)v_out, kv_rows, kv_row0, table_rows)
+                                position_ids, positions_per_batch_row, (uint16_t *)q_out, (uint16_t *)k_out, (uint16_t *)v_out, kv_rows, kv_row0, table_rows,    \
+                                q_rows, q_row0)
     if (head_dim == 128) QKRP(128);
     else QKRP(64);
 #undef QKRP
     LANTERN_CHECK_LAUNCH("qk_rope_pairs");
     return LANTERN_OK;
 }
+}  // namespace lantern
+
+extern "C" int lantern_qk_norm_rope(const void *qkv, int B, int T, int n_q_heads, int n_kv_heads, int head_dim, const void *q_weight, const void *q_bias,
+                                    const void *k_weight, const void *k_bias, int model_parallel, const void *cos_table, const void *sin_table,
+                                    int table_rows, const int64_t *position_ids, void *q_out, void *k_out, void *v_out, int kv_rows, int kv_row0,
+                                    void *stream) {
+    return lantern::launch_qk_norm_rope(qkv, B, T, n_q_heads, n_kv_heads, head_dim, q_weight, q_bias, k_weight, k_bias, model_parallel, cos_table, sin_table,
+                                        table_rows, position_ids, q_out, T, 0, k_out, v_out, kv_rows, kv_row0, stream);
+}
+
+extern "C" int lantern_qk_rope_pairs(const void *qkv, int B, int T, int n_q_heads, int n_kv_heads, int head_dim, const float *freqs, int table_rows,
+                                     const int64_t *position_ids, int positions_per_batch_row, void *q_out, void *k_out, void *v_out, int kv_rows,
+                                     int kv_row0, void *stream) {
+    return lantern::launch_qk_rope_pairs(qkv, B, T, n_q_heads, n_kv_heads, head_dim, freqs, table_rows, position_ids, positions_per_batch_row, q_out, T, 0,
+                                         k_out, v_out, kv_rows, kv_row0, stream);
+}
+
+namespace lantern {
+// lantern_linear_rows_streamk with the activation rows in segments (lantern_draft_depth): row m at A + (m / seg_rows) * seg_stride + (m % seg_rows) * K
+int launch_linear_rows_streamk_seg(const void *A, int a_seg_rows, long long a_seg_stride, const void *W, const void *bias, int M, int K, int n_rows, void *out,
+                                   int epilogue, const void *aux, int aux_stride, int pair_rows, int packed, void *workspace, size_t workspace_bytes,
+                                   hipStream_t st) {
+    LANTERN_CHECK_ARG(A && W && out && workspace && M > 0 && M <= 32 && K > 0 && K % 16 == 0 && n_rows > 0 && epilogue >= 0 && epilogue <= 2,
+                      "linear_rows_streamk: bad arguments (M <= 32 rows, K a multiple of 16)");
+    SkArgs a{};
+    a.A = (const uint16_t *)A; a.W = (const uint16_t *)W; a.bias = (const uint16_t *)bias; a.aux = (const uint16_t *)aux; a.out = (uint16_t *)out;
+    a.M = M; a.K = K; a.n_rows = n_rows; a.out_stride = n_rows; a.aux_stride = aux_stride;
+    a.pair_rows = epilogue == LANTERN_EPI_SILU_MUL ? pair_rows : 0;
+    a.a_seg_rows = a_seg_rows; a.a_seg_stride = a_seg_stride;
+    return sk_run(a, epilogue, packed != 0, false, workspace, workspace_bytes, st, "linear_rows_streamk");
+}
+}  // namespace lantern
 
 extern "C" int lantern_linear_rows(const void *A, const void *W, const void *bias, int M, int K, int row_lo, int n_rows, void *out,
                                    int out_stride, int out_col0, void *stream) {

@@ -110,6 +110,144 @@ class TorchDecoderLayer(nn.Module):
         return out
 
 
+# ----------------------------------------------------------------------------- one C call per drafting depth
+class DraftPlan:
+    """The depth loop of the EAGLE-2 drafter on lantern_draft_depth: every buffer of a drafting depth allocated once per (model, head), the argument
+    block filled once per drafting call, ONE ctypes call per depth (input stage, the decoder layer, the fused head expansion and the next depth's
+    inputs are enqueued by the library).  Built by Model._depth_plan when the model runs the HIP layers; the Python loop stays for everything else."""
+
+    ROWS = 64
+
+    def __init__(self, model, head, k: int, hx: dict):
+        import ctypes as C
+        from .. import _lib
+        from .decoder_layer import LlamaDecoderLayer
+        self._C, self._L = C, _lib.lib()
+        layer = model.layers[0]
+        at, mlp = layer.self_attn, layer.mlp
+        dev = model.fc.weight.device
+        bf = torch.bfloat16
+        self.model, self.layer, self.k, self.depth, self.dev = model, layer, k, int(model.depth), dev
+        B, T, H = 2, k, at.hidden_size
+        nq, nk, d, inter = at.num_heads, at.num_key_value_heads, at.head_dim, mlp.gate_proj.out_features
+        self.B, self.T, self.H, self.nq, self.nk, self.d = B, T, H, nq, nk, d
+        self.llama = isinstance(layer, LlamaDecoderLayer)
+        a = self.args = _lib.DraftDepthArgs()
+        a.layer_kind, a.B, a.T, a.H, a.n_q_heads, a.n_kv_heads, a.head_dim, a.inter, a.vocab = int(self.llama), B, T, H, nq, nk, d, inter, model.vocab_size
+        a.eps2 = float(layer.post_attention_layernorm.variance_epsilon)
+        a.embed_scale = float(model.embed_upscale) if model.embed_upscale > 1.0 else 1.0
+        keep = self._keep = []
+
+        def ptr(t):
+            if t is None:
+                return None
+            keep.append(t)
+            return t.data_ptr()
+        emb = model.embed_tokens.weight
+        a.embed = ptr(emb if emb.dtype == bf else emb.to(bf))
+        a.fc_w, a.fc_b, a.fc_packed = ptr(model._packed_weight("fc", model.fc.weight).data), ptr(model.fc.bias), 1
+        if hasattr(layer, "input_layernorm"):
+            a.ln1_w, a.eps1 = ptr(layer.input_layernorm.weight), float(layer.input_layernorm.variance_epsilon)
+        w, b = at._fused_qkv()
+        a.qkv_w, a.qkv_b = ptr(layer._packed("qkv", w).data), ptr(b)
+        a.o_w, a.o_b = ptr(layer._packed("o", at.o_proj.weight).data), ptr(at.o_proj.bias)
+        a.ln2_w = ptr(layer.post_attention_layernorm.weight)
+        wg, bg = mlp._fused_gate_up()
+        a.gate_up_w, a.gate_up_b = ptr(layer._packed("gate_up", wg, inter).data), ptr(bg)
+        a.down_w, a.down_b, a.layer_packed = ptr(layer._packed("down", mlp.down_proj.weight).data), ptr(mlp.down_proj.bias), 1
+        if self.llama:
+            self.freqs = model.freqs_cis.to(device=dev, dtype=torch.float32).contiguous()
+            a.freqs, a.table_rows = ptr(self.freqs), self.freqs.shape[0]
+        else:
+            cos, sin = at.rotary_emb.tables_bf16(dev, at.rotary_emb.max_seq_len_cached)
+            a.qn_w, a.qn_b, a.kn_w, a.kn_b = ptr(at.q_norm.weight), ptr(at.q_norm.bias), ptr(at.k_norm.weight), ptr(at.k_norm.bias)
+            a.model_parallel, a.cos_table, a.sin_table, a.table_rows = at.q_norm.weight.shape[0], ptr(cos), ptr(sin), cos.shape[0]
+        # head
+        a.head_w, a.head_b, a.head_packed = ptr(hx["packed"].data if hx["packed"] is not None else head.weight), ptr(head.bias), int(hx["packed"] is not None)
+        a.row_lo, a.n_cols, a.model, a.cfg = hx["row_lo"], hx["n_cols"], hx["model"], float(model.cfg_scale)
+        a.pos_base, a.w_latent, a.h_latent, a.newline_id, a.eos_id = 2, 48, 48, 8803, 8196
+        a.top_k_filter, a.top_k = hx["top_k_filter"], k
+        # state / logs / work buffers
+        D = self.depth
+        z = lambda *shape, dt=bf: torch.zeros(shape, dtype=dt, device=dev)
+        self.hidden = z(2, B, T, H)                      # ping-pong: depth i reads [i & 1], writes [(i + 1) & 1]
+        self.ids = z(D + 1, B * T, dt=torch.int64)
+        self.parents = z(D + 1, T, dt=torch.int64)
+        self.tree_bits = z(self.ROWS, dt=torch.int64)
+        self.log_ti = z(D, T, k, dt=torch.int64)
+        self.log_cu = z(D, T, k, dt=torch.float32)
+        self.cs = z(D, k, dt=torch.int64)
+        self.sc = z(D + 1, k, dt=torch.float32)         # [0]: the first expansion's scores
+        self.pos = z(D, B, T, dt=torch.int64)
+        self.head_pos = z(D, T, dt=torch.int64)
+        self.kv_start = z(B, dt=torch.int64)
+        self.bits0 = (torch.ones(T, dtype=torch.int64, device=dev) << torch.arange(T, dtype=torch.int64, device=dev))
+        self.par0 = torch.arange(T, dtype=torch.int64, device=dev) + 1
+        self.steps = torch.arange(D, dtype=torch.int64, device=dev)
+        nqkv = (nq + 2 * nk) * d
+        self.work = dict(x=z(B * T, H), xn=z(B * T, H), qkv=z(B * T, nqkv), q=z(B, nq, self.ROWS, d), attn=z(B, self.ROWS, H), h1=z(B * T, H), hn=z(B * T, H),
+                         act=z(B * T, inter), out=z(B * T, H), head_ws=z(T, hx["n_cols"]))
+        for n, t in self.work.items():
+            setattr(a, n, t.data_ptr())
+        self.sk = ops._sk_workspace(dev)
+        a.sk_ws, a.sk_ws_bytes = self.sk.data_ptr(), self.sk.numel()
+        self.ta = None
+
+    def begin(self, pkv, hidden0, ids0, scores0, positions, head_positions=None, kv_start=None):
+        """Start a drafting call: pkv the prefix cache (the layer's slab grows in place), hidden0 [2, T, H] / ids0 [T] / scores0 [T] the first
+        expansion's outputs, positions(i) [2, T] or [T] int64 per depth as a [depth, ...] tensor."""
+        a, B, T, D = self.args, self.B, self.T, self.depth
+        past = pkv[0][0].shape[2]
+        ks, vs = self.layer._cache_slab(B, self.nk, self.d, past + D * T, self.dev, pkv[0])
+        a.k_slab, a.v_slab, a.kv_rows = ks.data_ptr(), vs.data_ptr(), ks.shape[2]
+        self._slab, self.past = (ks, vs), past
+        need = int(self._L.lantern_tree_attention_workspace(B, self.nq, self.ROWS, self.d, self._C.c_int64(ks.shape[2])))
+        if self.ta is None or self.ta.numel() < need:
+            self.ta = torch.empty(max(need, 16), dtype=torch.uint8, device=self.dev)
+        a.ta_ws, a.ta_ws_bytes = self.ta.data_ptr(), self.ta.numel()
+        self.hidden[0].copy_(hidden0)
+        self.ids[0].copy_(ids0.reshape(1, T).expand(B, T).reshape(-1))
+        self.sc[0].copy_(scores0.reshape(-1))
+        self.parents[0].copy_(self.par0)
+        self.tree_bits[:T].copy_(self.bits0)
+        self.pos.copy_(positions.reshape(D, -1, T).expand(D, B, T) if positions.numel() != D * B * T else positions.reshape(D, B, T))
+        if head_positions is not None:
+            self.head_pos.copy_(head_positions)
+        if kv_start is None:
+            self.kv_start.zero_()
+        else:
+            self.kv_start.copy_(kv_start)
+        a.kv_start = self.kv_start.data_ptr()
+        a.positions_per_batch_row = 1
+        a.cfg = float(self.model.cfg_scale)
+        self._lumina_grammar = head_positions is not None
+
+    def run(self, i: int):
+        """Depth i: one C call."""
+        a, T, D = self.args, self.T, self.depth
+        k = self.k
+        a.stream = torch.cuda.current_stream().cuda_stream
+        a.ids, a.hidden_in = self.ids[i].data_ptr(), self.hidden[i & 1].data_ptr()
+        a.position_ids = self.pos[i].data_ptr()
+        a.head_pos = self.head_pos[i].data_ptr() if self._lumina_grammar else None
+        a.kv_row0, a.t1 = self.past + i * T, (i + 1) * T
+        a.tree_bits = self.tree_bits.data_ptr()
+        a.scores_in = self.sc[i].data_ptr()
+        a.topk_index, a.cu_scores = self.log_ti[i].data_ptr(), self.log_cu[i].data_ptr()
+        a.topk_cs_index, a.scores_out = self.cs[i].data_ptr(), self.sc[i + 1].data_ptr()
+        if i + 1 < D:
+            a.hidden_next, a.ids_next, a.parents_next = self.hidden[(i + 1) & 1].data_ptr(), self.ids[i + 1].data_ptr(), self.parents[i + 1].data_ptr()
+            a.parent_bias_next = 1 + k * k * max(0, i) + k          # the bias of iteration i + 1 (cnets_llamagen.py:798-801)
+        else:
+            a.hidden_next = a.ids_next = a.parents_next = None
+        ops.check(self._L.lantern_draft_depth(self._C.byref(a)), "draft_depth")
+
+    def lists(self):
+        """(scores_list, ss_token, parents_list) entries of the depth loop, as the Python loop appends them."""
+        D = self.depth
+        return ([self.log_cu[i].reshape(-1) for i in range(D)], [self.log_ti[i].reshape(-1) for i in range(D)], [self.parents[i] for i in range(D)])
+
+
 # ----------------------------------------------------------------------------- the drafter
 class Model(nn.Module):
     """`model_type`: "lumina_mgpt" | "llamagen" | "anole" selects the logit post-processing of the head's output
@@ -325,26 +463,12 @@ class Model(nn.Module):
         vocabulary; the HF processors the reference defaults to (top-k; temperature 1, top_p 1: generate_images.py:47-55) are the kernel's
         threshold, any other processor list takes the three-step composition (lantern_linear_rows -> lantern_cfg_mask_topk_window ->
         lantern_expand_dynamic).  hidden [2, n, H] or [2, H] (cond row(s), then uncond)."""
-        w = getattr(head, "weight", None)
         n = hidden.shape[1] if hidden.dim() == 3 else 1
-        if (isinstance(head, nn.Linear) and w is not None and w.is_cuda and w.dtype == torch.bfloat16 and hidden.dtype == torch.bfloat16
-                and w.shape[1] % 16 == 0 and n <= 16 and n * k <= 256):
-            V = w.shape[0]
-            if self.model_type == "lumina_mgpt" and pos_ids is not None:
-                top_k = min(int(proc[1].image_top_k), V) if (proc is not None and len(proc) > 1) else 0
-                pk = self._packed_weight("head", w, self.image_lo, self.image_hi - self.image_lo) if w.shape[1] % 64 == 0 else None
-                return ops.head_expand(hidden.reshape(2 * n, -1), w, self.image_lo, self.image_hi - self.image_lo, float(self.cfg_scale),
-                                       bias=head.bias, model=ops.MODEL_LUMINA, pos_ids=pos_ids.reshape(-1), pos_base=2, top_k_filter=top_k,
-                                       scores_in=scores, top_k=k, packed=pk)
-            if self.model_type in ("anole", "llamagen"):
-                from ..verify import ProcessorSpec
-                spec = ProcessorSpec.from_hf(proc) or ProcessorSpec()
-                lo, nc = (self.image_lo, self.image_hi - self.image_lo) if self.model_type == "anole" else (0, V)
-                if spec.temperature == 1.0 and not (1e-8 <= spec.top_p < 1.0) and nc % 8 == 0 and nc <= 16384:
-                    pk = self._packed_weight("head", w, lo, nc) if w.shape[1] % 64 == 0 else None
-                    return ops.head_expand(hidden.reshape(2 * n, -1), w, lo, nc, float(self.cfg_scale), bias=head.bias,
-                                           model=ops.MODEL_ANOLE if self.model_type == "anole" else ops.MODEL_PLAIN, pos_ids=None,
-                                           top_k_filter=min(spec.top_k, V), scores_in=scores, top_k=k, packed=pk)
+        hx = self._head_fusion(head, proc, n, k, pos_ids is not None) if hidden.dtype == torch.bfloat16 else None
+        if hx is not None:
+            return ops.head_expand(hidden.reshape(2 * n, -1), head.weight, hx["row_lo"], hx["n_cols"], float(self.cfg_scale), bias=head.bias, model=hx["model"],
+                                   pos_ids=pos_ids.reshape(-1) if hx["model"] == ops.MODEL_LUMINA else None, pos_base=2, top_k_filter=hx["top_k_filter"],
+                                   scores_in=scores, top_k=k, packed=hx["packed"])
         ho = self._head(head, hidden)
         if hidden.dim() == 2:
             half = ho.shape[0] // 2
@@ -352,6 +476,51 @@ class Model(nn.Module):
         else:
             rows = self._post_head(ho[0], ho[1], proc, pos_ids=pos_ids)
         return ops.expand_dynamic(rows[None], scores, k)
+
+    def _head_fusion(self, head, proc, n, k, with_pos):
+        """What lantern_head_expand needs for this head / processor list, or None when the three-step composition has to run (another head type, a
+        temperature or nucleus processor, shapes outside the kernel)."""
+        w = getattr(head, "weight", None)
+        if not (isinstance(head, nn.Linear) and w is not None and w.is_cuda and w.dtype == torch.bfloat16 and w.shape[1] % 16 == 0 and n <= 16 and n * k <= 256):
+            return None
+        V = w.shape[0]
+        if self.model_type == "lumina_mgpt":
+            if not with_pos:
+                return None
+            top_k = min(int(proc[1].image_top_k), V) if (proc is not None and len(proc) > 1) else 0
+            lo, nc, model = self.image_lo, self.image_hi - self.image_lo, ops.MODEL_LUMINA
+        else:
+            from ..verify import ProcessorSpec
+            spec = ProcessorSpec.from_hf(proc) or ProcessorSpec()
+            lo, nc = (self.image_lo, self.image_hi - self.image_lo) if self.model_type == "anole" else (0, V)
+            if spec.temperature != 1.0 or (1e-8 <= spec.top_p < 1.0) or nc % 8 or nc > 16384:
+                return None
+            top_k, model = min(spec.top_k, V), (ops.MODEL_ANOLE if self.model_type == "anole" else ops.MODEL_PLAIN)
+        pk = self._packed_weight("head", w, lo, nc) if w.shape[1] % 64 == 0 else None
+        return dict(row_lo=lo, n_cols=nc, model=model, top_k_filter=top_k, packed=pk)
+
+    def _depth_plan(self, head, proc, k):
+        """The DraftPlan of this model / head / processor list (cached), or None when the depth loop has to stay in Python: injected or torch layers,
+        more than one layer, a head / processor list outside the fused expansion, more tree keys than one ancestor word holds."""
+        from .decoder_layer import DecoderLayer
+        if not self.use_depth_plan or len(self.layers) != 1 or not isinstance(self.layers[0], DecoderLayer):
+            return None
+        layer, w = self.layers[0], self.fc.weight
+        if not (layer.fused and layer.inplace_cache and w.is_cuda and w.dtype == torch.bfloat16 and layer.self_attn.q_proj.weight.dtype == torch.bfloat16
+                and layer.self_attn.head_dim in (64, 128) and w.shape[0] % 64 == 0 and 2 * k <= 32 and (self.depth + 1) * k <= DraftPlan.ROWS
+                and self.depth >= 1 and getattr(layer.mlp, "act_fn", None) is torch.nn.functional.silu):
+            return None
+        hx = self._head_fusion(head, proc, k, k, True)
+        if hx is None:
+            return None
+        key = (id(head), head.weight.data_ptr(), head.weight._version, k, self.depth, hx["top_k_filter"], hx["model"], w.data_ptr(), w._version,
+               layer.self_attn.q_proj.weight.data_ptr(), layer.self_attn.q_proj.weight._version)
+        hit = self.__dict__.get("_plan")
+        if hit is None or hit[0] != key:
+            hit = self.__dict__["_plan"] = (key, DraftPlan(self, head, k, hx))
+        return hit[1]
+
+    use_depth_plan = True          # False: the depth loop stays in Python (one ctypes call per kernel): the form the plan is tested against
 
     def _post_head(self, cond, uncond, proc, pos_ids=None, pos_base=2):
         """CFG combine + the model's mask + its processors on the head's rows -> processed logits [R,V] f32 (dense rows: the tree
@@ -429,6 +598,17 @@ class Model(nn.Module):
         cur = ti.reshape(1, -1)
         input_ids = torch.cat([cur, cur])
         input_hidden = last_hidden[:, None].repeat(1, k, 1)
+        plan = self._depth_plan(head, logits_processor, k)
+        if plan is not None:          # the depth loop: one lantern_draft_depth call per depth
+            pos = (len_posi + plan.steps)[:, None, None].expand(plan.depth, 1, k)
+            if input_position_diff is not None:
+                pos = torch.cat([pos, pos - input_position_diff], dim=1)          # (no clamp inside the loop, cnets_anole.py:858-862)
+            start = None if attention_mask is None or input_position_diff is None else attention_mask.to(dev).to(torch.int64).argmax(dim=1)
+            plan.begin(pkv, input_hidden, cur.reshape(-1), scores, pos, kv_start=start)
+            for i in range(self.depth):
+                plan.run(i)
+            sl, tl, pl = plan.lists()
+            return self._finalize_dynamic(scores_list + sl, ss_token + tl, parents_list + pl, sample_token, logits_processor is not None)
         tree_mask = self.tree_mask_init
         cs = torch.arange(k, device=dev)
         for i in range(self.depth):
@@ -544,6 +724,15 @@ class Model(nn.Module):
         parents_list = [torch.zeros(1, dtype=torch.long, device=dev)]
         input_ids = ti.reshape(1, -1)
         input_hidden = last_hidden[:, None].repeat(1, k, 1)
+        plan = self._depth_plan(head, logits_processors, k)
+        if plan is not None:          # the depth loop: one lantern_draft_depth call per depth
+            pos = (len_posi[None] + plan.steps[:, None, None]).expand(plan.depth, 2, k)          # [depth, 2, k]: the cond / uncond streams' positions
+            plan.begin(pkv, input_hidden, input_ids.reshape(-1), scores, pos, head_positions=pos[:, 1] + 1,
+                       kv_start=attention_mask.to(torch.int64).argmax(dim=1))
+            for i in range(self.depth):
+                plan.run(i)
+            sl, tl, pl = plan.lists()
+            return self._finalize_dynamic(scores_list + sl, ss_token + tl, parents_list + pl, sample_token, logits_processors is not None)
         tree_mask = self.tree_mask_init
         cs = torch.arange(k, device=dev)
         for i in range(self.depth):

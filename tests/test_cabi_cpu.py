@@ -147,6 +147,30 @@ def test_step_group_layout_matches_the_c_struct(tmp_path):
     assert out[2 + nf] == C.sizeof(_lib.EpWindow) and out[3 + nf:] == [getattr(_lib.EpWindow, f).offset for f in wfields]
 
 
+def test_draft_depth_args_layout_matches_the_c_struct(tmp_path):
+    """ctypes mirror of lantern_draft_depth_args vs the C compiler's layout of include/lantern_hip.h: every field's offset."""
+    import subprocess
+    fields = [f[0] for f in _lib.DraftDepthArgs._fields_]
+    src = tmp_path / "layout_dd.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "lantern_hip.h"\nint main(void){printf("%zu", sizeof(lantern_draft_depth_args));\n'
+                   + "".join(f'printf(" %zu", offsetof(lantern_draft_depth_args, {f}));\n' for f in fields) + "return 0;}\n")
+    exe = tmp_path / "layout_dd"
+    subprocess.check_call(["gcc", "-std=c99", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    out = [int(x) for x in subprocess.check_output([str(exe)]).split()]
+    assert out[0] == C.sizeof(_lib.DraftDepthArgs)
+    assert out[1:] == [getattr(_lib.DraftDepthArgs, f).offset for f in fields]
+
+
+def test_draft_depth_validates_without_gpu():
+    L = _lib.lib()
+    a = _lib.DraftDepthArgs()
+    assert L.lantern_draft_depth(None) < 0
+    a.B, a.T, a.H, a.n_q_heads, a.n_kv_heads, a.head_dim, a.inter = 3, 10, 4096, 32, 32, 128, 11008
+    assert L.lantern_draft_depth(C.byref(a)) < 0 and b"B = 2 rows" in L.lantern_last_error()
+    a.B = 2
+    assert L.lantern_draft_depth(C.byref(a)) < 0 and b"null weight" in L.lantern_last_error()
+
+
 def test_round2_entry_points_validate_without_gpu():
     """The one-call step, the step preparation and the node form: argument errors and empty batches come back as codes + messages before
     anything touches a device (no GPU here)."""

@@ -451,3 +451,64 @@ def test_default_layers_draft_on_the_hip_path(model_type, V, H, heads, monkeypat
     with torch.no_grad():
         t_ref, _ = mdl(xt, it, past_key_values=tuple((k.clone(), v.clone()) for k, v in kv), position_ids=pos_t, use_cache=True)
     np.testing.assert_allclose(t_hip.float().cpu().numpy(), t_ref.float().cpu().numpy(), rtol=3e-2, atol=3e-2)
+
+
+@pytest.mark.parametrize("model_type,V,H,heads,depth", [("llamagen", 16384, 128, 2, 4), ("anole", 65536, 256, 4, 4), ("lumina_mgpt", 65536, 256, 2, 5),
+                                                        ("lumina_mgpt", 65536, 256, 4, 3)])
+def test_depth_plan_equals_the_python_depth_loop(model_type, V, H, heads, depth, monkeypatch):
+    """lantern_draft_depth (one C call per drafting depth: input stage, decoder layer, fused head expansion, the next depth's inputs) against the Python
+    depth loop over the same kernels: identical drafted tree -- tokens, retrieve rows, mask, positions -- over three consecutive drafting calls (the
+    second and third start from the cached prefix), and exactly `depth` lantern_draft_depth calls per drafting call."""
+    from transformers.generation.logits_process import LogitsProcessorList, TopKLogitsWarper
+    from lantern_amd import _lib
+    dev, bf = torch.device("cuda"), torch.bfloat16
+    cfg = types.SimpleNamespace(vocab_size=V, hidden_size=H, pad_token_id=None, num_hidden_layers=1, num_attention_heads=heads, num_key_value_heads=heads,
+                                intermediate_size=2 * H, max_position_embeddings=512, rms_norm_eps=1e-5, model_parallel_size=1, input_type="t2i")
+    torch.manual_seed(11)
+    mdl = cnets.Model(cfg, total_tokens=40, depth=depth, top_k=CS.TOPK, model_type=model_type).to(dev).to(bf)
+    mdl.init_tree()
+    head = torch.nn.Linear(H, V, bias=False).to(dev).to(bf)
+    proc = LogitsProcessorList([TopKLogitsWarper(300)])
+    lum = [None, types.SimpleNamespace(image_top_k=300)]
+    gen = torch.Generator(device="cuda").manual_seed(3)
+    calls = []
+    real = _lib.lib().lantern_draft_depth
+
+    def run(plan_on):
+        mdl.use_depth_plan = plan_on
+        mdl.reset_kv()
+        outs, total = [], 7
+        g = torch.Generator(device="cuda").manual_seed(5)
+        for c in range(3):
+            n_new = total if c == 0 else 2
+            hid = torch.randn(2, n_new, H, device=dev, dtype=bf, generator=g)
+            ids = torch.randint(4, 8000, (2, total + 1), device=dev, generator=g)
+            if model_type == "lumina_mgpt":
+                am = torch.ones(2, total, dtype=torch.bool, device=dev)
+                am[1, :2] = False                                      # the uncond stream is left-padded (sequential CFG)
+                out = mdl.topK_generate(hid[:1], hid[1:], ids[:1], head, lum, attention_mask=am, tree_type="dynamic")
+            elif model_type == "anole":
+                am = torch.ones(2, total, dtype=torch.bool, device=dev)
+                am[1, :1] = False
+                out = mdl.topK_genrate(hid, ids, head, proc, 3.0, input_position_diff=torch.ones((), dtype=torch.long, device=dev), attention_mask=am)
+            else:
+                out = mdl.topK_genrate(hid, ids, head, proc, 3.0)
+            outs.append([t.clone() for t in out])
+            total += 2
+        return outs
+    py = run(False)
+    n_calls = [0]
+    import ctypes as C
+
+    class Spy:
+        def __call__(self, *a):
+            n_calls[0] += 1
+            return real(*a)
+    plan_mod = cnets.DraftPlan
+    orig_run = plan_mod.run
+    monkeypatch.setattr(plan_mod, "run", lambda self, i: (n_calls.__setitem__(0, n_calls[0] + 1), orig_run(self, i))[1])
+    pl = run(True)
+    assert n_calls[0] == 3 * depth
+    for c, (a, b) in enumerate(zip(py, pl)):
+        for x, y in zip(a, b):
+            assert x.shape == y.shape and torch.equal(x, y), (c, x, y)

@@ -229,6 +229,52 @@ __global__ __launch_bounds__(EXW_NT) void expand_window_kernel(const uint16_t *_
     for (int it = 0; it < NV4; ++it)
         s += (double)expf(r[it].x - m) + (double)expf(r[it].y - m) + (double)expf(r[it].z - m) + (double)expf(r[it].w - m);
     const float ls = logf((float)block_sum<double, NW>(s, s_redd, ph));
+    // ---- the top_k entries.  Fast form: the top_k-th largest value by one more radix select over the register tile; the few entries at or above
+    // it (top_k, plus ties at the threshold) go to an LDS list; one wavefront ranks them (value, then the lower id) and lane `rank` writes slot `rank`.
+    // Same order, same score arithmetic as the round-by-round arg-max below, which stays for the rows the list cannot hold (fewer finite entries
+    // than top_k: the -inf tail; more than 64 entries at the threshold).  10 rows of the 7B head: 35 -> 12 us per launch.
+    {
+        __shared__ float s_cv[64];
+        __shared__ int s_ci[64];
+        __shared__ int s_cn;
+        if (tid == 0) s_cn = 0;
+        const float thr = kth_largest_hist_bf16<EXW_NT, NV4>(r, top_k, s_hist);          // (its barriers order the counter's reset)
+        if (thr > NEG_INF) {
+#pragma unroll
+            for (int it = 0; it < NV4; ++it) {
+                const float v[4] = {r[it].x, r[it].y, r[it].z, r[it].w};
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+                    if (v[c] >= thr) {
+                        const int slot = atomicAdd(&s_cn, 1);
+                        if (slot < 64) {
+                            s_cv[slot] = v[c];
+                            s_ci[slot] = win_lo + ((tid + (it >> 1) * EXW_NT) * 8 + (it & 1) * 4 + c);
+                        }
+                    }
+            }
+            __syncthreads();
+            const int cn = s_cn;
+            if (cn <= 64) {          // (workgroup-uniform)
+                if (wave == 0 && lane < cn) {
+                    const float v = s_cv[lane];
+                    const int id = s_ci[lane];
+                    int rank = 0;
+                    for (int j = 0; j < cn; ++j) {
+                        const float ov = s_cv[j];
+                        const int oi = s_ci[j];
+                        rank += (ov > v || (ov == v && oi < id)) ? 1 : 0;
+                    }
+                    if (rank < top_k) {
+                        topk_index[(size_t)row * top_k + rank] = id;
+                        cu_scores[(size_t)row * top_k + rank] = ((v - m) - ls) + sc;
+                    }
+                }
+                return;
+            }
+            __syncthreads();
+        }
+    }
     // top_k rounds of a block-wide arg-max (value, then the lower id); a thread's 32 entries carry a taken mask
     unsigned taken = 0u;
     int low_next = 0;                     // next id of the -inf tail (thread 0)
@@ -294,22 +340,24 @@ __global__ __launch_bounds__(EXW_NT) void expand_window_kernel(const uint16_t *_
     }
 }
 
-// one wavefront per sequence: top_k of the flattened n_rows*top_k cumulative scores
+// one wavefront per sequence: top_k of the flattened n_rows*top_k cumulative scores (<= 256: four per lane, in registers -- the rounds of the arg-max
+// re-read them from memory before: 11.6 -> 3 us per launch)
 __global__ __launch_bounds__(64) void expand_merge_kernel(const float *__restrict__ cu_scores, int nf, int top_k,
                                                           int64_t *__restrict__ topk_cs_index, float *__restrict__ scores_out) {
     const int b = blockIdx.x, lane = threadIdx.x;
     const float *cu = cu_scores + (size_t)b * nf;
-    unsigned long long taken_lo = 0, taken_hi = 0, taken_2 = 0, taken_3 = 0;  // up to 256 entries
+    float v[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) v[q] = (lane + 64 * q < nf) ? cu[lane + 64 * q] : -__builtin_inff();
+    unsigned taken = 0u;          // bit q: this lane's entry lane + 64 q is listed
     for (int t = 0; t < top_k; ++t) {
         float bv = -__builtin_inff();
         int bi = 0x7fffffff;
-        for (int i = lane; i < nf; i += 64) {
-            const int w = i >> 6;
-            const unsigned long long tk = w == 0 ? taken_lo : (w == 1 ? taken_hi : (w == 2 ? taken_2 : taken_3));
-            const bool taken = (tk >> (i & 63)) & 1ull;
-            const float v = cu[i];
-            if (!taken && (v > bv || (v == bv && i < bi))) {
-                bv = v;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int i = lane + 64 * q;
+            if (i < nf && !((taken >> q) & 1u) && (v[q] > bv || (v[q] == bv && i < bi))) {
+                bv = v[q];
                 bi = i;
             }
         }
@@ -322,12 +370,7 @@ __global__ __launch_bounds__(64) void expand_merge_kernel(const float *__restric
                 bi = oi;
             }
         }
-        const int w = bi >> 6;
-        const unsigned long long bitm = 1ull << (bi & 63);
-        if (w == 0) taken_lo |= bitm;
-        else if (w == 1) taken_hi |= bitm;
-        else if (w == 2) taken_2 |= bitm;
-        else taken_3 |= bitm;
+        if ((bi & 63) == lane && bi != 0x7fffffff) taken |= 1u << (bi >> 6);
         if (lane == 0) {
             topk_cs_index[(size_t)b * top_k + t] = bi;
             scores_out[(size_t)b * top_k + t] = bv;

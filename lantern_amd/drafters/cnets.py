@@ -300,7 +300,10 @@ class Model(nn.Module):
             grid = int(block ** 0.5)
             table = precompute_freqs_cis_2d(grid, H // nh, float(getattr(config, "rope_base", 10000)), cls)
             self.freqs_cis = torch.cat([table, torch.zeros_like(table[:10])], dim=0)
-            return [LlamaDecoderLayer(config, i) for i in range(n_layers)]
+            layers = [LlamaDecoderLayer(config, i) for i in range(n_layers)]
+            for l in layers:
+                l.inplace_cache = True          # the drafter never returns to an older, longer cache: `present` grows in a layer-owned slab
+            return layers
         if model_type == "anole":          # one head-norm row per head (cnets_anole.py:317-332, :363-364)
             import copy
             config = copy.copy(config)

@@ -413,6 +413,7 @@ def test_default_layers_draft_on_the_hip_path(model_type, V, H, heads, monkeypat
     real_sdpa = F.scaled_dot_product_attention
     monkeypatch.setattr(F, "scaled_dot_product_attention", lambda *a, **k_: (calls.append(("sdpa", a[0].shape[2])), real_sdpa(*a, **k_))[1])
     mdl.init_tree()
+    mdl.use_depth_plan = False          # the Python depth loop, kernel by kernel (lantern_draft_depth: test_depth_plan_equals_the_python_depth_loop)
     hidden = torch.randn(2, 5, H, device=dev, dtype=bf)
     ids = torch.randint(4, 8000, (2, 6), device=dev)
     proc = LogitsProcessorList([TopKLogitsWarper(300)])

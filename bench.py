@@ -26,6 +26,8 @@ Extra objects on the JSON line:
   lambda_mode   the same loop with lantern_delta = 5 (LANTERN++: tau = 4 p(x)), BASELINE.md run B.
   dynamic_tree  the EAGLE-2 half of C3 (a different 59-node tree per sequence and step), raw rows; and with O7 over all rows.
   drafter_layer one drafting call of the drafter's decoder layer at 7B size (tools/layer_bench.py in a child process).
+  drafter_cycle one whole drafting cycle (prefill + depth x lantern_draft_depth + finalisation) of the three model families (tools/draft_bench.py).
+  mirror_generate  the drop-in API (EaLumina_mGPT.generate) with stand-in forwards: us per verify step of the mirror's loop body (tools/mirror_bench.py).
   step_latency_us  whole-step wall time at 1 and 8 sequences (the reference's own batch is 1), three evaluate_posterior forms.
   other_groupings  the default kernels with 1 and 2 stream groups.
   cpu_baseline  the oracle (C port of the reference path, pthreads) timed on this host's cores over a bounded sample of the same
@@ -718,6 +720,32 @@ def drafter_layer_run():
         return {"error": repr(e)[:300]}
 
 
+def _tool_json(tool, args, timeout=300, env=None):
+    """Last JSON line a tools/ script prints, run in a child process (its own weights / pools), or {"error": ...}."""
+    import subprocess
+    try:
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", tool)] + [str(a) for a in args], env=dict(os.environ, **(env or {})),
+                           capture_output=True, text=True, timeout=timeout)
+        lines = [ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")]
+        if r.returncode or not lines:
+            return {"error": (r.stderr or r.stdout)[-300:]}
+        return json.loads(lines[-1])
+    except Exception as e:          # an extra object: never the reason the line is missing
+        return {"error": repr(e)[:300]}
+
+
+def mirror_generate_run():
+    """The drop-in API on the clock (tools/mirror_bench.py): EaLumina_mGPT.generate -- what generate_images.py:240 reaches through the solver -- with
+    stand-in target / drafter forwards, full vocabulary, default tree, 7B KV geometry: microseconds per verify step of the mirror's own loop body."""
+    return _tool_json("mirror_bench.py", [300])
+
+
+def drafter_cycle_run():
+    """One drafting cycle of the EAGLE-2 drafter at model size (tools/draft_bench.py): prefill of the accepted tokens + `depth` tree steps, each ONE
+    lantern_draft_depth call (input stage, decoder layer, fused head expansion, next-depth inputs), + the tree finalisation; wall microseconds."""
+    return {m: _tool_json("draft_bench.py", [m, 1200, 30]) for m in ("lumina", "anole", "llamagen")}
+
+
 def plan_sequences(total_seqs: int, seqs_per_gpu: int, world: int, groups: int):
     """(sequences per rank, stream groups, scaling).  --total-seqs T: T / world sequences per rank (T must divide: every prompt of the
     reference's batch is generated exactly once), "strong"; else --seqs-per-gpu on every rank, "weak".  The group count is the largest
@@ -1001,6 +1029,8 @@ def main():
             out["configs"] = other_configs(device, cfg, min(K, 60), n_seq)
         if not args.no_extras and world == 1 and wl.windowed:
             out["drafter_layer"] = drafter_layer_run()
+            out["drafter_cycle"] = drafter_cycle_run()
+            out["mirror_generate"] = mirror_generate_run()
         if args.ep_sweep and world == 1:
             out["ep_batch_sweep"] = ep_batch_sweep([int(x) for x in args.ep_sweep.split(",") if x], device, cfg)
             sat = saturating_report(out["ep_batch_sweep"])

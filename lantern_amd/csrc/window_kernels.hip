@@ -196,7 +196,7 @@ template <int NT, int E8, bool FULL>
 __device__ __forceinline__ void cfg_window_bf16_row(int row, int cls, const uint16_t *__restrict__ cond, const uint16_t *__restrict__ uncond, int V,
                                                     float cfg, int model, int img_lo, int img_hi, int newline_id, int eos_id, int top_k, int win_lo,
                                                     int W, float *__restrict__ out_win, int32_t *__restrict__ row_hot, int out_kind, int *s_hist,
-                                                    float *s_redf, double *s_redd) {
+                                                    float *s_redf, double *s_redd, float top_p = 1.0f, int *s_redi = nullptr) {
     const int tid = threadIdx.x;
     const float NEG_INF = -__builtin_inff();
     if (cls != 0) {
@@ -249,6 +249,10 @@ __device__ __forceinline__ void cfg_window_bf16_row(int row, int cls, const uint
         }
         r[2 * it] = make_float4(o[0], o[1], o[2], o[3]);
         r[2 * it + 1] = make_float4(o[4], o[5], o[6], o[7]);
+    }
+    if (top_p >= 1e-8f && top_p < 1.0f && s_redi) {          // TopPLogitsWarper in front of the top-k (the mass bins in the front of the histogram buffer)
+        int php = 0;
+        top_p_tile<NT, 2 * E8>(r, top_p, reinterpret_cast<double *>(s_hist), s_redf, s_redd, s_redi, php);
     }
     if (top_k > 0 && top_k < V) {
         // k-th largest of the FULL row = k-th largest of the window whenever >= k window entries beat the fill
@@ -324,6 +328,7 @@ struct PrepArgs {
     int n_flat, N, PD;
     int64_t *tree_cand, *cand;
     float *cart_prob;
+    float top_p;
 };
 
 template <int NT, int E8>
@@ -331,6 +336,7 @@ __global__ __launch_bounds__(NT) void prep_rows_kernel(const PrepArgs a) {
     __shared__ alignas(16) int s_hist[O7_HIST_INTS];
     __shared__ float s_redf[32];
     __shared__ double s_redd[32];
+    __shared__ int s_redi[32];
     const int n_rows = a.B * a.n_list;
     if ((int)blockIdx.x < n_rows) {
         const int x = o7_row_of_block(blockIdx.x, n_rows, a.n_list);            // rows of sequence b on XCD b % 8, where its chain runs
@@ -339,7 +345,7 @@ __global__ __launch_bounds__(NT) void prep_rows_kernel(const PrepArgs a) {
         // (w_latent == 0: a model without grammar rows -- Anole; the window is its image-token range, so no id needs the model's mask)
         const int cls = a.w_latent > 0 ? lumina_row_class(a.pos_ids[node] + a.seq_len[b], a.pos_base, a.w_latent, a.h_latent) : 0;
         cfg_window_bf16_row<NT, E8, true>(row, cls, a.cond, a.uncond, a.V, a.cfg, LANTERN_MODEL_LUMINA, a.img_lo, a.img_hi, a.newline_id, a.eos_id,
-                                          a.top_k, a.win_lo, a.W, a.out_win, a.row_hot, LANTERN_ROWS_PROBS, s_hist, s_redf, s_redd);
+                                          a.top_k, a.win_lo, a.W, a.out_win, a.row_hot, LANTERN_ROWS_PROBS, s_hist, s_redf, s_redd, a.top_p, s_redi);
         return;
     }
     // ---- candidate assembly of sequence b (same arithmetic as gather_candidates_kernel)
@@ -382,6 +388,7 @@ struct DynPrepArgs {
     const int32_t *node_list;
     int n_list, B;
     TdArgs td;
+    float top_p;
 };
 
 template <int NT, int E8>
@@ -391,6 +398,7 @@ __global__ __launch_bounds__(NT) void dyn_prep_kernel(const DynPrepArgs a) {
         __shared__ alignas(16) int s_hist[O7_HIST_INTS];
         __shared__ float s_redf[32];
         __shared__ double s_redd[32];
+        __shared__ int s_redi[32];
         const int x = o7_row_of_block(blockIdx.x, n_rows, a.n_list);
         const int b = x / a.n_list, i = x % a.n_list;
         const int node = a.node_list[i], depth = a.node_list[a.n_list + i];
@@ -398,7 +406,7 @@ __global__ __launch_bounds__(NT) void dyn_prep_kernel(const DynPrepArgs a) {
         // (= pos_abs of a node at that depth; w_latent == 0: a model without grammar rows -- LlamaGen)
         const int cls = a.w_latent > 0 ? lumina_row_class(a.td.cd.seq_len[b] + 1 + depth, a.pos_base, a.w_latent, a.h_latent) : 0;
         cfg_window_bf16_row<NT, E8, true>(row, cls, a.cond, a.uncond, a.V, a.cfg, LANTERN_MODEL_LUMINA, a.img_lo, a.img_hi, a.newline_id, a.eos_id,
-                                          a.top_k, a.win_lo, a.W, a.out_win, a.row_hot, LANTERN_ROWS_PROBS, s_hist, s_redf, s_redd);
+                                          a.top_k, a.win_lo, a.W, a.out_win, a.row_hot, LANTERN_ROWS_PROBS, s_hist, s_redf, s_redd, a.top_p, s_redi);
         return;
     }
     td_finalize_body<8, NT / 64>(a.td, blockIdx.x - n_rows);
@@ -820,7 +828,7 @@ __device__ __forceinline__ int epw_body(const EpwArgs &args, const int b) {
                 }
             };
             if constexpr (RAW) {
-                if (!rp_probs) raw_row_to_lds<NT>(rp, hot, win.raw_cfg, win.raw_top_k, V, lo, W, g, out_tok, out_mass, S.redf, S.redd, Shist, ph, stage_ids);
+                if (!rp_probs) raw_row_to_lds<NT>(rp, hot, win.raw_cfg, win.raw_top_k, V, lo, W, g, out_tok, out_mass, S.redf, S.redd, Shist, ph, stage_ids, prm.top_p, S.redi);
                 else row_softmax_to_lds<NT, E4, FULLW>(rp, hot, true, lo, W, prm.temperature, prm.top_k, V, g, out_tok, out_mass, S, ph, stage_ids);
             } else row_softmax_to_lds<NT, E4, FULLW>(rp, hot, rows_probs, lo, W, prm.temperature, prm.top_k, V, g, out_tok, out_mass, S, ph, stage_ids);
             EPW_STAMP(11);
@@ -1173,7 +1181,7 @@ __device__ __forceinline__ int epw_body(const EpwArgs &args, const int b) {
             } else row_load<NT, E4, FULLW>(logits + (size_t)rid * W, W, rp);
         }
         if constexpr (RAW) {
-            if (!rp_probs) raw_row_to_lds<NT>(rp, hot, win.raw_cfg, win.raw_top_k, V, lo, W, g, out_tok, out_mass, S.redf, S.redd, Shist, ph);
+            if (!rp_probs) raw_row_to_lds<NT>(rp, hot, win.raw_cfg, win.raw_top_k, V, lo, W, g, out_tok, out_mass, S.redf, S.redd, Shist, ph, NoHook(), prm.top_p, S.redi);
             else row_softmax_to_lds<NT, E4, FULLW>(rp, hot, true, lo, W, prm.temperature, prm.top_k, V, g, out_tok, out_mass, S, ph);
         } else row_softmax_to_lds<NT, E4, FULLW>(rp, hot, rows_probs, lo, W, prm.temperature, prm.top_k, V, g, out_tok, out_mass, S, ph);
     }
@@ -1421,7 +1429,8 @@ static int prepare_step_dynamic(const lantern_step_group *g) {
     DynPrepArgs a{(const uint16_t *)g->cond, (const uint16_t *)g->uncond, g->V, g->cfg, g->pos_base, g->w_latent, g->h_latent, g->img_lo, g->img_hi,
                   g->newline_id, g->eos_id, g->top_k, g->N, g->win_lo, g->win_len, g->out_win, g->row_hot, g->node_list, g->n_list, g->B,
                   TdArgs{d.scores, d.tokens, d.parents, g->sample_token, d.n_scores, d.n_parents, d.top_k, d.total_tokens, d.sort_rows, d.draft_tokens, d.mask,
-                         d.pos_ids, d.retrieve, d.n_leaf, d.max_depth, TdCand{d.seq_len, g->cand, d.retrieve_pd, d.pos_abs, d.row_index, g->P, g->D}}};
+                         d.pos_ids, d.retrieve, d.n_leaf, d.max_depth, TdCand{d.seq_len, g->cand, d.retrieve_pd, d.pos_abs, d.row_index, g->P, g->D}},
+                  g->top_p};
     if (g->win_len == 16384) LANTERN_LAUNCH((dyn_prep_kernel<512, 4>), dim3(g->B * g->n_list + g->B), dim3(512), 0, (hipStream_t)g->stream, a);     // LlamaGen: the whole vocabulary
     else LANTERN_LAUNCH((dyn_prep_kernel<512, 2>), dim3(g->B * g->n_list + g->B), dim3(512), 0, (hipStream_t)g->stream, a);
     LANTERN_CHECK_LAUNCH("prepare_step");
@@ -1438,8 +1447,8 @@ extern "C" int lantern_prepare_step(const lantern_step_group *g) {
                                g->img_lo == 0 && g->img_hi == 16384;
     LANTERN_CHECK_ARG(g->cond && g->uncond && g->out_win && g->row_hot && (g->dyn || no_grammar || (g->seq_len && g->pos_ids)) && g->dtype == LANTERN_BF16 &&
                           (chameleon_window || llamagen_rows) && g->V % 8 == 0 &&
-                          g->out_kind == LANTERN_ROWS_PROBS && g->temperature == 1.0f && !(g->top_p > 0.0f && g->top_p < 1.0f),
-                      "prepare_step: bf16 rows, probability output: Lumina (or Anole static trees, w_latent = h_latent = 0) on the 8192-id image window, or "
+                          g->out_kind == LANTERN_ROWS_PROBS && g->temperature == 1.0f,
+                      "prepare_step: bf16 rows, probability output, temperature 1: Lumina (or Anole static trees, w_latent = h_latent = 0) on the 8192-id image window, or "
                       "LlamaGen dynamic trees (LANTERN_MODEL_PLAIN, w_latent = h_latent = 0) on its 16384 ids");
     if (g->dyn) return prepare_step_dynamic(g);
     LANTERN_CHECK_ARG(g->ss_token && g->sample_token && g->tree_indices && g->retrieve && g->tree_cand && g->cand && g->B >= 0 && g->n_flat > 0 && g->N > 0 &&
@@ -1447,7 +1456,8 @@ extern "C" int lantern_prepare_step(const lantern_step_group *g) {
     if (g->B == 0) return LANTERN_OK;
     PrepArgs a{(const uint16_t *)g->cond, (const uint16_t *)g->uncond, g->V, g->cfg, g->pos_ids, g->pos_base, g->w_latent, g->h_latent, g->img_lo, g->img_hi,
                g->newline_id, g->eos_id, g->top_k, g->seq_len, g->N, g->win_lo, g->win_len, g->out_win, g->row_hot, g->node_list, g->n_list, g->B,
-               g->ss_token, g->ss_prob, g->sample_token, g->tree_indices, g->retrieve, g->n_flat, g->N, g->P * g->D, g->tree_cand, g->cand, g->cart_prob};
+               g->ss_token, g->ss_prob, g->sample_token, g->tree_indices, g->retrieve, g->n_flat, g->N, g->P * g->D, g->tree_cand, g->cand, g->cart_prob,
+               g->top_p};
     static const int nt_knob = getenv("LANTERN_PREP_NT") ? atoi(getenv("LANTERN_PREP_NT")) : 0;   // tuning knob (diagnostic)
     if (nt_knob == 1024) LANTERN_LAUNCH((prep_rows_kernel<1024, 1>), dim3(g->B * g->n_list + g->B), dim3(1024), 0, (hipStream_t)g->stream, a);
     else LANTERN_LAUNCH((prep_rows_kernel<512, 2>), dim3(g->B * g->n_list + g->B), dim3(512), 0, (hipStream_t)g->stream, a);
@@ -1506,8 +1516,9 @@ static int epw_check(const lantern_ep_params *prm, const lantern_ep_buffers *buf
     }
     if (win->rows_kind == LANTERN_ROWS_PROBS)
         LANTERN_CHECK_ARG(p.top_k <= 0 && p.temperature == 1.0f, "evaluate_posterior_window: probability rows are final -- apply temperature/top-k where they are produced (cfg_mask_topk_window)");
-    if (p.top_p > 0.0f && p.top_p < 1.0f) {
-        set_error("evaluate_posterior_window: top_p=%g inside the kernel is not built (use top_p=1)", (double)p.top_p);
+    if (p.top_p > 0.0f && p.top_p < 1.0f && !raw) {
+        set_error("evaluate_posterior_window: top_p=%g inside the kernel is built for LANTERN_ROWS_RAW_BF16 rows only (probability / logit rows: apply it "
+                  "where the rows are produced, lantern_cfg_mask_topk_window)", (double)p.top_p);
         return LANTERN_E_UNSUPPORTED;
     }
     if (p.top_k > win->win_len && p.top_k < p.V) {

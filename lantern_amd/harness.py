@@ -53,6 +53,8 @@ class WorkloadConfig:
     lantern_delta: float = 0.1
     cfg_scale: float = 3.0
     top_k: int = 2000
+    top_p: float = 1.0              # < 1: TopPLogitsWarper in front of the top-k, wherever the rows are post-processed (O7, prepare_step, raw rows inside the
+                                    # chain kernel): LlamaGen / Anole take top_p from generate() (drafters/utils.py:36-52)
     sigma: float = 5.0              # drafter noise, tuned once so accepted tokens/step ~2.6, then frozen
     logit_scale: float = 4.0
     prompt_len: int = 64
@@ -375,7 +377,7 @@ class LuminaVerifyWorkload:
                 p.syntax[i] = s
         p.lantern, p.k, p.delta = 1, c.lantern_k, c.lantern_delta
         p.table_rows, p.table_cols = K_CODES, self.table_cols
-        p.top_k, p.temperature, p.top_p = 0, 1.0, 1.0       # Lumina filters in O7, not per level
+        p.top_k, p.temperature, p.top_p = 0, 1.0, (c.top_p if self.fused_o7 else 1.0)       # Lumina filters in O7, not per level (raw rows: the chain kernel is O7)
         p.n_uniforms, p.R, p.N, p.row_index_per_seq = self.n_uniforms, self.R, self.N, 0
         return p
 
@@ -531,7 +533,7 @@ class LuminaVerifyWorkload:
             s.w_latent, s.h_latent = (0, 0) if self.anole else (W_LATENT, H_LATENT)          # (Anole: no grammar rows)
             s.img_lo, s.img_hi, s.newline_id, s.eos_id, s.top_k = IMG_LO, IMG_HI, NEWLINE, EOS, c.top_k
             s.win_lo, s.win_len, s.out_kind = self.win_lo, self.W, ops.ROWS_PROBS if c.rows_probs else ops.ROWS_LOGITS
-            s.seq_len, s.out_win, s.row_hot, s.temperature, s.top_p = val(A["cur"]), (None if (self.fused_o7 and not self.n_spec) else val(A["proc"])), val(A["row_hot"]), 1.0, 1.0
+            s.seq_len, s.out_win, s.row_hot, s.temperature, s.top_p = val(A["cur"]), (None if (self.fused_o7 and not self.n_spec) else val(A["proc"])), val(A["row_hot"]), 1.0, c.top_p
             if self.n_spec:
                 s.node_list, s.n_list = self.d_node_list.data_ptr(), self.n_spec
             C.memmove(C.byref(s.ep), C.byref(self._ep_prm), C.sizeof(EpParams))
@@ -681,7 +683,7 @@ class LuminaVerifyWorkload:
             check(L.lantern_cfg_mask_topk_window(A["cond"], A["uncond"], 1, B * N, V, C.c_float(c.cfg_scale), self.o7_model,
                                                  vp(self.d_pos_ids.data_ptr()), C.c_int64(c.prompt_len + 3), W_LATENT, H_LATENT, IMG_LO, IMG_HI,
                                                  NEWLINE, EOS, c.top_k, A["cur"], N, self.win_lo, self.W, A["proc"], A["row_hot"],
-                                                 ops.ROWS_PROBS if c.rows_probs else ops.ROWS_LOGITS, C.c_float(1.0), C.c_float(1.0), st),
+                                                 ops.ROWS_PROBS if c.rows_probs else ops.ROWS_LOGITS, C.c_float(1.0), C.c_float(c.top_p), st),
                   "cfg_mask_topk_window")
         else:
             check(L.lantern_cfg_mask_topk(A["cond"], A["uncond"], 1, B * N, V, C.c_float(c.cfg_scale), self.o7_model,
@@ -847,6 +849,7 @@ class DynamicConfig:
     lantern_delta: float = 0.1
     cfg_scale: float = 3.0
     logit_top_k: int = 2000
+    top_p: float = 1.0              # < 1: TopPLogitsWarper in front of the top-k (see WorkloadConfig.top_p)
     prompt_len: int = 64
     kv_layers: int = 32
     kv_heads: int = 32
@@ -981,7 +984,7 @@ class DynamicVerifyWorkload:
                 p.syntax[i] = sx
             p.lantern, p.k, p.delta = 1, cfg.lantern_k, cfg.lantern_delta
             p.table_rows, p.table_cols = K_CODES, self.table_cols
-        p.top_k, p.temperature, p.top_p = 0, 1.0, 1.0
+        p.top_k, p.temperature, p.top_p = 0, 1.0, (cfg.top_p if cfg.fuse_o7 else 1.0)
         p.n_uniforms, p.row_index_per_seq = self.uniforms.shape[1], 1
         self._prm = p
         b = EpBuffers()
@@ -1043,7 +1046,7 @@ class DynamicVerifyWorkload:
             s.w_latent, s.h_latent, s.img_lo, s.img_hi, s.newline_id, s.eos_id, s.top_k = W_LATENT, H_LATENT, self.lo, self.hi, NEWLINE, EOS, c.logit_top_k
             if self.lg:                 # no grammar rows
                 s.w_latent, s.h_latent, s.newline_id, s.eos_id = 0, 0, 0, 0
-            s.win_lo, s.win_len, s.out_kind, s.temperature, s.top_p = self.lo, self.W, ops.ROWS_PROBS, 1.0, 1.0
+            s.win_lo, s.win_len, s.out_kind, s.temperature, s.top_p = self.lo, self.W, ops.ROWS_PROBS, 1.0, c.top_p
             s.out_win, s.row_hot = (None if self.fused_o7 else vp(self.win, s0)), vp(self.hot, s0)
             C.memmove(C.byref(s.ep), C.byref(self._prm), C.sizeof(EpParams))
             C.memmove(C.byref(s.ep_buf), C.byref(self._buf), C.sizeof(EpBuffers))

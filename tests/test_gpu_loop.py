@@ -134,6 +134,14 @@ def test_anole_static_loop_matches_oracle_loop(fuse, groups, spec, lam, k):
     _anole_static_loop(fuse, groups, spec, lam, k, 3 * groups, 24, 1)
 
 
+@pytest.mark.parametrize("fuse,spec", [(False, 0), (True, 0), (True, 3)], ids=["o7_launch", "raw_rows", "raw_rows_3_prepared"])
+def test_anole_static_loop_with_top_p(fuse, spec):
+    """generate(top_p = 0.9): TopPLogitsWarper in front of the top-k (drafters/utils.py:36-52; the reference applies the list per visited row inside
+    evaluate_posterior) -- in O7 over all rows, in the rows lantern_prepare_step produces and in the rows the chain kernel post-processes on demand
+    (LANTERN_ROWS_RAW_BF16) -- against the oracle's loop with the same processors."""
+    _anole_static_loop(fuse, 1, spec, 5.0, 10, 3, 16, 1, top_p=0.9)
+
+
 @pytest.mark.parametrize("model,tree", [("anole", "naive_extend_57"), ("lumina", "naive_extend_57")])
 def test_static_loop_throughput_instances(model, tree):
     """More sequences per launch than CUs: the throughput forms (256 threads, three workgroups per CU) of the chain kernel's Anole static-tree
@@ -188,7 +196,7 @@ def _lumina_static_loop_big(tree, n_seq, steps, every):
     assert n_acc > 0 and n_rej > 0
 
 
-def _anole_static_loop(fuse, groups, spec, lam, k, n_seq, steps, every):
+def _anole_static_loop(fuse, groups, spec, lam, k, n_seq, steps, every, top_p=1.0):
     """BASELINE config 4 (Anole, LANTERN++ static tree naive_extend_57: neighbours zeroed in the drafter's row, no syntax shortcut, no grammar rows)
     through the device-resident step loop -- O7 over all rows, and the raw rows post-processed inside evaluate_posterior with the likeliest rows
     prepared beside O6 -- against the oracle's loop over the same pools / uniforms: identical (best path, accept length, bonus token) at every step."""
@@ -196,7 +204,8 @@ def _anole_static_loop(fuse, groups, spec, lam, k, n_seq, steps, every):
     import oracle
     from lantern_amd import harness as HN
     cfg = HN.WorkloadConfig(model="anole", tree="naive_extend_57", n_seq=n_seq, pool_steps=4 if n_seq < 64 else 2, kv_layers=2, kv_heads=4, kv_smax=512,
-                            max_steps=steps + 4, sigma=5.0, n_groups=groups, ep_kernel="chain", fuse_o7=fuse, spec_rows=spec, lantern_k=k, lantern_delta=lam)
+                            max_steps=steps + 4, sigma=5.0, n_groups=groups, ep_kernel="chain", fuse_o7=fuse, spec_rows=spec, lantern_k=k, lantern_delta=lam,
+                            top_p=top_p)
     wl = HN.LuminaVerifyWorkload(cfg, torch.device("cuda"))
     assert wl.anole and wl.fused_o7 == fuse and wl.n_spec == (spec if fuse else 0)
     for _ in range(steps):
@@ -221,7 +230,7 @@ def _anole_static_loop(fuse, groups, spec, lam, k, n_seq, steps, every):
         return d
     # (Anole / LlamaGen: the reference applies the HF processors -- here T = 1, top_k -- inside evaluate_posterior, per visited row; O7 / the raw-row
     # path apply them where the rows are produced: the same distribution)
-    ocfg = oracle.EpConfig.anole(True, lantern=True, k=k, delta=lam, temperature=1.0, top_p=1.0, top_k=cfg.top_k)
+    ocfg = oracle.EpConfig.anole(True, lantern=True, k=k, delta=lam, temperature=1.0, top_p=top_p, top_k=cfg.top_k)
     n_acc = n_rej = 0
     for b in range(0, cfg.n_seq, every):
         tok, cursor = int(first[b]), 0
@@ -242,6 +251,17 @@ def _anole_static_loop(fuse, groups, spec, lam, k, n_seq, steps, every):
 @pytest.mark.parametrize("fuse,groups,spec", [(False, 1, 0), (True, 1, 0), (True, 2, 0), (True, 1, 2), (True, 2, 1)],
                          ids=["o7_launch", "raw_rows", "raw_rows_2_groups", "raw_rows_2_prepared", "raw_rows_2_groups_root_prepared"])
 def test_llamagen_dynamic_loop_matches_oracle_loop(fuse, groups, spec):
+    _llamagen_dynamic_loop(fuse, groups, spec, 1.0)
+
+
+@pytest.mark.parametrize("fuse,spec", [(False, 0), (True, 0), (True, 2)], ids=["o7_launch", "raw_rows", "raw_rows_2_prepared"])
+def test_llamagen_dynamic_loop_with_top_p(fuse, spec):
+    """BASELINE config 2 with generate(top_p = 0.8): nucleus filtering in front of the top-k on the 16384-id rows -- O7 over all rows, the prepared rows
+    beside the tree build, the rows the chain kernel post-processes on demand -- against the oracle's loop with the same processors."""
+    _llamagen_dynamic_loop(fuse, 1, spec, 0.8)
+
+
+def _llamagen_dynamic_loop(fuse, groups, spec, top_p):
     """BASELINE config 2 (LlamaGen + EAGLE, standard verify: V = 16384 = the window, LANTERN off, HF processors T = 1 / top_k 2000) through the
     device-resident dynamic loop, with O7 over all rows and with the raw cond / uncond rows post-processed inside evaluate_posterior (the
     1024-thread raw-row instance): the oracle's loop over the same pools / uniforms gives the same (best path, accept length, bonus token) for
@@ -253,7 +273,7 @@ def test_llamagen_dynamic_loop_matches_oracle_loop(fuse, groups, spec):
     import helpers as H
     steps = 8
     cfg = HN.DynamicConfig(model="llamagen", n_seq=3 * groups, pool_steps=2, depth=4, kv_layers=2, kv_heads=4, kv_dim=64, kv_smax=512, max_steps=steps + 2,
-                           fuse_o7=fuse, n_groups=groups, spec_rows=spec)
+                           fuse_o7=fuse, n_groups=groups, spec_rows=spec, top_p=top_p)
     wl = HN.DynamicVerifyWorkload(cfg, torch.device("cuda"))
     assert wl.fused_o7 == fuse and wl.lg and wl.n_spec == (spec if fuse else 0)
     for _ in range(steps):
@@ -262,7 +282,7 @@ def test_llamagen_dynamic_loop_matches_oracle_loop(fuse, groups, spec):
     wl.check_status(0, steps)
     gb, ga, gt = wl.log_best[:steps].cpu().numpy(), wl.log_alen[:steps].cpu().numpy(), wl.log_token[:steps].cpu().numpy()
     uni, ub = wl.uniforms.cpu().numpy(), wl.u_bonus.cpu().numpy()
-    ocfg = oracle.EpConfig.llamagen(False, lantern=False, temperature=1.0, top_p=1.0, top_k=cfg.logit_top_k)      # the HF processors run inside evaluate_posterior
+    ocfg = oracle.EpConfig.llamagen(False, lantern=False, temperature=1.0, top_p=top_p, top_k=cfg.logit_top_k)      # the HF processors run inside evaluate_posterior
     N = wl.N
     n_acc = 0
     for b in range(cfg.n_seq):

@@ -80,11 +80,13 @@ __device__ __forceinline__ void kv_gather_body(int bx, int nbx, int s, void *con
                                                         const int64_t *__restrict__ slab_prev, int64_t outer, int64_t S_max,
                                                         int chunks_per_row, const int64_t *__restrict__ retrieve,
                                                         int retrieve_per_seq, int P, int D, const int32_t *__restrict__ best,
-                                                        const int32_t *__restrict__ accept_len, int64_t *__restrict__ new_len) {
+                                                        const int32_t *__restrict__ accept_len, int64_t *__restrict__ new_len,
+                                                        const int32_t *__restrict__ counters = nullptr) {
     const int seq = slab_seq[s];
     const int bst = best[seq];
     int n_sel = accept_len[seq] + 1;
     if (n_sel > D) n_sel = D;
+    if (counters && counters[(size_t)seq * 6 + 5] != 0) n_sel = 0;          // a walk that reported a status commits nothing (the caller retries the step)
     kv_gather_rows<MAXSEL, U, MODE>(bx, nbx, s, seq, bst, n_sel, slab_ptrs, slab_prev, outer, S_max, chunks_per_row, retrieve, retrieve_per_seq, P, D, new_len);
 }
 
@@ -116,9 +118,10 @@ __device__ __forceinline__ void accept_copy_body(int bx, int b, const uint4 *__r
                                                  const int64_t *__restrict__ retrieve, int retrieve_per_seq, int P, int D,
                                                  const int64_t *__restrict__ cand, const int32_t *__restrict__ best,
                                                  const int32_t *__restrict__ accept_len, uint4 *__restrict__ out_hidden,
-                                                 int64_t *__restrict__ accepted_tokens) {
+                                                 int64_t *__restrict__ accepted_tokens, const int32_t *__restrict__ counters = nullptr) {
     int n_sel = accept_len[b] + 1;
     if (n_sel > D) n_sel = D;
+    if (counters && counters[(size_t)b * 6 + 5] != 0) n_sel = 0;
     accept_copy_row(bx, b, best[b], n_sel, hidden, G, N, cpr, retrieve, retrieve_per_seq, P, D, cand, out_hidden, accepted_tokens);
 }
 

@@ -98,16 +98,16 @@ __global__ __launch_bounds__(256) void update_inputs_kernel(void *const *__restr
                                                             const int32_t *__restrict__ accept_len, int64_t *__restrict__ new_len,
                                                             const uint4 *__restrict__ hidden, int B, int G, int N, int hid_cpr,
                                                             const int64_t *__restrict__ cand, uint4 *__restrict__ out_hidden,
-                                                            int64_t *__restrict__ accepted_tokens) {
+                                                            int64_t *__restrict__ accepted_tokens, const int32_t *__restrict__ counters) {
     if ((int)blockIdx.y < n_slabs) {
         kv_gather_body<MAXSEL, U, MODE>(blockIdx.x, gridDim.x, blockIdx.y, slab_ptrs, slab_seq, slab_prev, outer, S_max, chunks_per_row, retrieve,
-                                        retrieve_per_seq, P, D, best, accept_len, new_len);
+                                        retrieve_per_seq, P, D, best, accept_len, new_len, counters);
     } else {
         const int lin = ((int)blockIdx.y - n_slabs) * gridDim.x + blockIdx.x;
         const int per_seq = G * D;
         if (lin < B * per_seq)
             accept_copy_body(lin % per_seq, lin / per_seq, hidden, G, N, hid_cpr, retrieve, retrieve_per_seq, P, D, cand, best, accept_len,
-                             out_hidden, accepted_tokens);
+                             out_hidden, accepted_tokens, counters);
     }
 }
 
@@ -376,11 +376,29 @@ extern "C" int lantern_sample_static(const float *probs, const int64_t *idx, int
     return LANTERN_OK;
 }
 
+namespace lantern {
+// `counters` [B, 6] (evaluate_posterior's) or NULL: a sequence whose walk reported a status (counters[b][5] != 0) moves no KV row, copies no hidden
+// row, lists no token and keeps its lengths -- lantern_verify_step commits a step only where the walk succeeded
+int launch_update_inference_inputs(void *const *slab_ptrs, const int32_t *slab_seq, const int64_t *slab_prev, int n_slabs, int elem_bytes, int64_t outer,
+                                   int64_t S_max, int64_t d, const int64_t *retrieve, int retrieve_per_seq, int P, int D, const int32_t *best,
+                                   const int32_t *accept_len, int64_t *new_len, const void *hidden, int hid_elem_bytes, int B, int G, int N, int H,
+                                   const int64_t *cand, void *out_hidden, int64_t *accepted_tokens, const int32_t *counters, void *stream);
+}
+
 extern "C" int lantern_update_inference_inputs(void *const *slab_ptrs, const int32_t *slab_seq, const int64_t *slab_prev, int n_slabs,
                                                int elem_bytes, int64_t outer, int64_t S_max, int64_t d, const int64_t *retrieve,
                                                int retrieve_per_seq, int P, int D, const int32_t *best, const int32_t *accept_len,
                                                int64_t *new_len, const void *hidden, int hid_elem_bytes, int B, int G, int N, int H,
                                                const int64_t *cand, void *out_hidden, int64_t *accepted_tokens, void *stream) {
+    return lantern::launch_update_inference_inputs(slab_ptrs, slab_seq, slab_prev, n_slabs, elem_bytes, outer, S_max, d, retrieve, retrieve_per_seq, P, D, best,
+                                                   accept_len, new_len, hidden, hid_elem_bytes, B, G, N, H, cand, out_hidden, accepted_tokens, nullptr, stream);
+}
+
+int lantern::launch_update_inference_inputs(void *const *slab_ptrs, const int32_t *slab_seq, const int64_t *slab_prev, int n_slabs, int elem_bytes,
+                                            int64_t outer, int64_t S_max, int64_t d, const int64_t *retrieve, int retrieve_per_seq, int P, int D,
+                                            const int32_t *best, const int32_t *accept_len, int64_t *new_len, const void *hidden, int hid_elem_bytes, int B,
+                                            int G, int N, int H, const int64_t *cand, void *out_hidden, int64_t *accepted_tokens, const int32_t *counters,
+                                            void *stream) {
     LANTERN_CHECK_ARG(slab_ptrs && slab_seq && slab_prev && retrieve && best && accept_len, "update_inference_inputs: null buffer");
     LANTERN_CHECK_ARG(n_slabs > 0 && outer > 0 && S_max > 0 && d > 0 && P > 0 && D > 0 && B > 0, "update_inference_inputs: bad sizes");
     LANTERN_CHECK_ARG((d * elem_bytes) % 16 == 0, "update_inference_inputs: KV row bytes %lld must be a multiple of 16", (long long)(d * elem_bytes));
@@ -399,7 +417,7 @@ extern "C" int lantern_update_inference_inputs(void *const *slab_ptrs, const int
 #define UI_LAUNCH(U_, M_)                                                                                                                \
     LANTERN_LAUNCH((update_inputs_kernel<8, U_, M_>), dim3(gx, n_slabs + extra), dim3(256), 0, (hipStream_t)stream, slab_ptrs, slab_seq, \
                    slab_prev, n_slabs, outer, S_max, cpr, retrieve, retrieve_per_seq, P, D, best, accept_len, new_len,                   \
-                   (const uint4 *)hidden, B, g, N, hidden ? H * hid_elem_bytes / 16 : 0, cand, (uint4 *)out_hidden, accepted_tokens)
+                   (const uint4 *)hidden, B, g, N, hidden ? H * hid_elem_bytes / 16 : 0, cand, (uint4 *)out_hidden, accepted_tokens, counters)
     if (uu == 1 && mode == 0) UI_LAUNCH(1, 0);
     else if (uu == 4 && mode == 0) UI_LAUNCH(4, 0);
     else if (uu == 2 && mode == 1) UI_LAUNCH(2, 1);

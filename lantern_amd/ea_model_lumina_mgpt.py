@@ -168,6 +168,12 @@ class EaLumina_mGPT(nn.Module):
 
     # ------------------------------------------------------------------ :556-608 (O7 replaces :597-607)
     def tree_decoding(self, tree_candidates, attention_mask, past_key_values, tree_position_ids, input_ids, retrieve_indices):
+        tree_logits, uncond_tree_logits, hidden_states, uncond_hidden_states, position_ids = self._tree_forward(
+            tree_candidates, attention_mask, past_key_values, tree_position_ids, input_ids)
+        return self._tree_postprocess(tree_logits, uncond_tree_logits, hidden_states, uncond_hidden_states, position_ids, retrieve_indices)
+
+    def _tree_forward(self, tree_candidates, attention_mask, past_key_values, tree_position_ids, input_ids):
+        """The target model on the tree tokens (cond and uncond passes: ea_model_lumina_mgpt.py:556-595)."""
         position_ids = tree_position_ids + input_ids.shape[1]
         if self.cfg_mode == "parallel":
             tree_candidates = torch.cat((tree_candidates, tree_candidates), dim=0)
@@ -183,6 +189,9 @@ class EaLumina_mGPT(nn.Module):
             _, uncond_tree_logits, uncond_hidden_states = self(input_ids=tree_candidates, output_orig=True,
                                                                past_key_values=past_key_values["uncond"],
                                                                position_ids=position_ids - self.image_start_token_id_index)
+        return tree_logits, uncond_tree_logits, hidden_states, uncond_hidden_states, position_ids
+
+    def _tree_postprocess(self, tree_logits, uncond_tree_logits, hidden_states, uncond_hidden_states, position_ids, retrieve_indices):
         # one kernel: CFG combine + MultiModalLogitsProcessor + InterleavedTopKLogitsWarper; no [P,D,V] gather
         top_k = self.internal_logits_processors[1].image_top_k if len(self.internal_logits_processors) > 1 else 0
         kw = dict(model=ops.MODEL_LUMINA, pos_ids=(position_ids + 1).reshape(-1), pos_base=self.image_start_token_id_index + 3,
@@ -402,7 +411,172 @@ class EaLumina_mGPT(nn.Module):
         if st.parallel:
             st.tree_mask = st.tree_mask.repeat(2, 1, 1, 1)
 
+    # ------------------------------------------------------------------ the step through ONE lantern_verify_step call
+    native_step = True          # False: every kernel its own ctypes call with fresh tensors (the form the native step is tested against)
+
+    def _native_ctx(self, st, lantern, lantern_k, lantern_delta):
+        """Everything of a generate() call that does not change from step to step, built once: the lantern_step_group with its preallocated outputs
+        (candidates, processed rows, verdict record, accepted hidden states / tokens, the KV length double buffer) and the node tables' workspace.
+        None when this configuration stays on the per-kernel path (dynamic trees, the dense kernel set, slabs of different shapes)."""
+        import ctypes as C
+        from . import _lib
+        if not (self.native_step and st.static and self.kernel_set == "window"):
+            return None
+        tb, hip = self.tree_buffers, self.tree_buffers["_hip"]
+        s0 = st.slabs[0]
+        if any(x.shape != s0.shape or x.dtype != s0.dtype or x.device != s0.device or not x.is_contiguous() for x in st.slabs):
+            return None
+        dev = s0.device
+        N, P, D, R = hip["N"], hip["P"], hip["D"], hip["R"]
+        if D > 8 or N - 1 > 64:
+            return None
+        W, V = IMAGE_HI - IMAGE_LO, self.vocab_size
+        nx = types.SimpleNamespace(C=C, L=_lib.lib(), dev=dev, N=N, P=P, D=D, R=R)
+        z = lambda *shape, dt: torch.zeros(shape, dtype=dt, device=dev)
+        nx.cand, nx.cart, nx.tcand = z(1, P, D, dt=torch.int64), z(1, P, D, dt=torch.float32), z(1, N, dt=torch.int64)
+        nx.win, nx.hot = z(N, W, dt=torch.float32), z(N, dt=torch.int32)
+        nx.rec = z(16, dt=torch.int32)                  # best, accept_len, counters[6], bonus token (int64 at words 8-9)
+        nx.tok = nx.rec[8:10].view(torch.int64)
+        nx.otok, nx.omass = z(1, dt=torch.int32), z(1, dt=torch.float32)
+        nx.out_h, nx.acc = None, z(1, D, dt=torch.int64)
+        nx.hid = None
+        nx.pos1 = (tb["tree_position_ids"].to(dev) + 1).to(torch.int64).contiguous()
+        nx.tree_indices, nx.retrieve = tb["tree_indices"].to(dev).contiguous(), tb["retrieve_indices"].to(dev).contiguous()
+        ri = nx.retrieve.clone()
+        ri[ri < 0] += N
+        nx.row_index = ri.to(torch.int32).contiguous()
+        n_sl = len(st.slabs)
+        L0 = st.input_ids.shape[1]
+        nx.lens = [(L0 - st.slab_off).to(dev).contiguous(), torch.zeros(n_sl, dtype=torch.int64, device=dev)]          # KV lengths: [this step, next step], swapped
+        nx.seq_len = [torch.full((1,), L0, dtype=torch.int64, device=dev), torch.zeros(1, dtype=torch.int64, device=dev)]
+        nx.parity = 0
+        g = nx.group = (_lib.StepGroup * 1)()
+        a = g[0]
+        a.tree_indices, a.retrieve = nx.tree_indices.data_ptr(), nx.retrieve.data_ptr()
+        a.B, a.n_flat, a.N, a.P, a.D = 1, R * TOPK, N, P, D
+        a.tree_cand, a.cand, a.cart_prob = nx.tcand.data_ptr(), nx.cand.data_ptr(), nx.cart.data_ptr()
+        a.V, a.cfg, a.model = V, float(self.cfg_scale), ops.MODEL_LUMINA
+        a.pos_ids, a.pos_base = nx.pos1.data_ptr(), self.image_start_token_id_index + 3
+        a.w_latent, a.h_latent, a.img_lo, a.img_hi, a.newline_id, a.eos_id = self.w_latent_dim, self.h_latent_dim, IMAGE_LO, IMAGE_HI, 8803, 8196
+        top_k = self.internal_logits_processors[1].image_top_k if len(self.internal_logits_processors) > 1 else 0
+        a.top_k, a.win_lo, a.win_len, a.out_kind = min(top_k, V), IMAGE_LO, W, ops.ROWS_PROBS
+        a.out_win, a.row_hot, a.temperature, a.top_p = nx.win.data_ptr(), nx.hot.data_ptr(), 1.0, 1.0
+        cfg = self._ep_config(lantern, lantern_k, lantern_delta)
+        p = a.ep
+        p.B, p.P, p.D, p.V, p.rows_per_seq = 1, P, D, V, N
+        p.mode, p.syntax_shortcut, p.tok_offset = cfg.mode, int(cfg.syntax_shortcut), cfg.tok_offset
+        p.img_lo, p.img_hi, p.n_syntax = cfg.img_lo, min(cfg.img_hi, 2 ** 31 - 1), len(cfg.syntax)
+        for i, sx in enumerate(cfg.syntax):
+            p.syntax[i] = int(sx)
+        p.lantern, p.k, p.delta = int(cfg.lantern), int(cfg.k), float(cfg.delta)
+        p.top_k, p.temperature, p.top_p = 0, 1.0, 1.0
+        fifo = self._uniforms()
+        p.n_uniforms, p.R, p.N, p.row_index_per_seq = fifo.buf.shape[1], R, N, 0
+        nx.table = self._packed_table(int(lantern_k)) if lantern else None
+        if nx.table is not None:
+            p.table_rows, p.table_cols = nx.table.shape
+        b = a.ep_buf
+        b.logits, b.row_index, b.cand, b.cart_prob = nx.win.data_ptr(), nx.row_index.data_ptr(), nx.cand.data_ptr(), nx.cart.data_ptr()
+        b.op_off, b.p_idx, b.b_off, b.b_idx = hip["op_off"].data_ptr(), hip["p_idx"].data_ptr(), hip["b_off"].data_ptr(), hip["b_idx"].data_ptr()
+        b.tree_cand, b.nn_table = nx.tcand.data_ptr(), (nx.table.data_ptr() if nx.table is not None else None)
+        b.uniforms, b.cursor = fifo.buf.data_ptr(), fifo.cursor.data_ptr()
+        b.best, b.accept_len, b.counters = nx.rec[0:].data_ptr(), nx.rec[1:].data_ptr(), nx.rec[2:].data_ptr()
+        w = a.ep_win
+        w.win_lo, w.win_len, w.row_hot, w.rows_kind = IMAGE_LO, W, nx.hot.data_ptr(), ops.ROWS_PROBS
+        w.orig_prob_stride, w.orig_prob_offset = V, IMAGE_LO
+        w.out_tok, w.out_mass, w.token = nx.otok.data_ptr(), nx.omass.data_ptr(), nx.tok.data_ptr()
+        nodes = hip.get("nodes") if (self.ep_form == "nodes" and (not lantern or int(lantern_k) + 1 <= 1024)) else None
+        nx.nodes_struct = None
+        if nodes is not None:
+            nbytes = int(nx.L.lantern_evaluate_posterior_nodes_workspace(C.byref(p), C.byref(w), nodes.n_internal, 0))
+            nx.nodes_ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=dev)
+            nx.nodes_struct = nodes.struct(nx.nodes_ws.data_ptr(), nbytes, -1)
+            a.nodes = C.pointer(nx.nodes_struct)
+        a.slab_ptrs, a.slab_seq = st.slab_ptrs.data_ptr(), st.slab_seq.data_ptr()
+        S, d = s0.shape[-2], s0.shape[-1]
+        a.n_slabs, a.elem_bytes, a.outer, a.S_max, a.d = n_sl, s0.element_size(), s0.numel() // (S * d), S, d
+        a.accepted_tokens = nx.acc.data_ptr()
+        a.hid_groups = 2
+        return nx
+
+    def _verify_step_native(self, st, nx, lantern, lantern_k, lantern_delta):
+        """One verify step: generate_candidates (one call: the target forward needs the tree tokens), the two target forwards, then ONE
+        lantern_verify_step call -- candidates again (idempotent), the tree_decoding post-process of all rows, evaluate_posterior with the bonus
+        draw, the KV / hidden / token commit (only where the walk reported no status) -- on preallocated buffers, and one host read of the 40-byte
+        verdict record.  Same kernels, same uniforms, same results as the per-kernel path (tests/test_gpu_generate_ref.py runs both)."""
+        C, L, a = nx.C, nx.L, nx.group[0]
+        tl = st.tree_logits
+        ss_token = tl[0].to(nx.dev).contiguous()
+        ss_prob = tl[1].to(nx.dev)
+        ss_prob = (ss_prob if ss_prob.dtype == torch.float32 else ss_prob.float()).contiguous()
+        sample = st.sample_token.to(nx.dev).reshape(-1)[:1].contiguous()
+        stream = torch.cuda.current_stream().cuda_stream
+        a.stream, a.ss_token, a.ss_prob, a.sample_token = stream, ss_token.data_ptr(), ss_prob.data_ptr(), sample.data_ptr()
+        ops.check(L.lantern_gather_candidates(C.c_void_p(a.ss_token), C.c_void_p(a.ss_prob), C.c_void_p(a.sample_token), C.c_void_p(a.tree_indices), C.c_void_p(a.retrieve),
+                                              1, a.n_flat, nx.N, nx.P, nx.D, C.c_void_p(a.tree_cand), C.c_void_p(a.cand), C.c_void_p(a.cart_prob), C.c_void_p(stream)),
+                  "gather_candidates")
+        tree_logits, uncond_logits, hidden, uhidden, _pos = self._tree_forward(nx.tcand, st.attn_mask, self.past_key_values, st.tree_position_ids, st.input_ids)
+        cl, ul = tree_logits[0], uncond_logits[0]
+        if cl.dtype != ul.dtype or cl.dtype not in (torch.bfloat16, torch.float32):
+            cl, ul = cl.float(), ul.float()
+        cl, ul = cl.contiguous(), ul.contiguous()
+        a.cond, a.uncond, a.dtype = cl.data_ptr(), ul.data_ptr(), int(cl.dtype == torch.bfloat16)
+        orig = concat_original_prob(tl[2])
+        a.ep_buf.orig_prob = orig.data_ptr()
+        hid = torch.stack((hidden[0], uhidden[0]))[None]                                   # [1, 2, N, H]
+        if nx.out_h is None or nx.out_h.dtype != hid.dtype or nx.out_h.shape[-1] != hid.shape[-1]:
+            nx.out_h = torch.zeros((1, 2, nx.D, hid.shape[-1]), dtype=hid.dtype, device=nx.dev)
+        a.hidden, a.out_hidden, a.hid_elem_bytes, a.H = hid.data_ptr(), nx.out_h.data_ptr(), hid.element_size(), hid.shape[-1]
+        fifo = self._uniforms()
+        fifo.reserve(nx.P * nx.D)
+        u = torch.rand(1, dtype=torch.float64, device=nx.dev)
+        a.ep_win.u_bonus = u.data_ptr()
+        cur, nxt = nx.lens[nx.parity], nx.lens[nx.parity ^ 1]
+        a.slab_prev, a.new_len, a.seq_len = cur.data_ptr(), nxt.data_ptr(), cur.data_ptr()          # (slab 0 is a cond slab at offset 0: its length is len(input_ids))
+        ops.check(L.lantern_verify_step(nx.group, 1), "verify_step")
+        r = nx.rec.tolist()                                                                # the step's one host read
+        best, alen, n_used, status, tok = r[0], r[1], r[5], r[7], r[8]
+        Lcur = st.input_ids.shape[1]
+        if status != 0:
+            if status in self._RETRY_DENSE:
+                # a state only the dense kernel represents: nothing was committed (lantern_verify_step commits only walks without a status); the
+                # same step on the dense HIP kernel, from the same uniforms, through the host-int path (rare: once in millions of steps)
+                fifo.cursor.sub_(n_used)
+                rows = WindowRows(nx.win, nx.hot, st.retrieve_indices, self.vocab_size, IMAGE_LO)
+                top_k = self.internal_logits_processors[1].image_top_k if len(self.internal_logits_processors) > 1 else 0
+                kw = dict(model=ops.MODEL_LUMINA, pos_ids=(nx.pos1 + Lcur).reshape(-1), pos_base=self.image_start_token_id_index + 3, w=self.w_latent_dim,
+                          h=self.h_latent_dim, img_lo=IMAGE_LO, img_hi=IMAGE_HI, newline_id=8803, eos_id=8196, top_k=min(top_k, self.vocab_size))
+                rows.dense_source = lambda: NodeLogits(ops.cfg_mask_topk(cl, ul, float(self.cfg_scale), **kw), st.retrieve_indices)
+                bc, al, sample_p = self.evaluate_posterior(rows.dense_rows(), nx.cand[0], nx.cart[0], tl[2], self.tree_buffers["p_indices"], nx.tcand,
+                                                           self.tree_buffers["b_indices"], True, lantern, lantern_k, lantern_delta)
+                hit = self._commit_from_host(st, nx.cand[0], bc, al, hidden, uhidden, sample_p, u, None)
+                nxt.copy_(cur + (int(al) + 1))
+                nx.parity ^= 1
+                return hit
+            cnt = nx.rec[2:8].reshape(1, 6)
+            ops.raise_on_status(cnt)
+        n = alen + 1
+        nx.parity ^= 1
+        done = set()
+        for clen, off in zip(self._length_tensors(st), st.offsets):          # (one length tensor per cache, shared by its slabs)
+            if (id(clen), off) not in done:
+                clen.fill_(Lcur - off + n)
+                done.add((id(clen), off))
+        accepted = nx.acc[:, :n].to(st.input_ids.device)
+        st.input_ids = torch.cat([st.input_ids[None, 0] if st.parallel else st.input_ids, accepted], dim=-1)
+        self._draft_next(st, nx.out_h[:, 0, :n].clone(), nx.out_h[:, 1, :n].clone(), nx.tok.clone().reshape(1, 1))
+        st.new_token += n
+        st.accept_lengths.append(n)
+        return False
+
     def _verify_step(self, st, lantern, lantern_k, lantern_delta, eos_token_ids):
+        if eos_token_ids is None:
+            nx = getattr(st, "native", None)
+            if nx is None and not getattr(st, "native_tried", False):
+                st.native_tried = True
+                nx = st.native = self._native_ctx(st, lantern, lantern_k, lantern_delta)
+            if nx is not None:
+                return self._verify_step_native(st, nx, lantern, lantern_k, lantern_delta)
         dev = st.retrieve_indices.device
         # ---- O6 + target forward + O7
         if st.static:

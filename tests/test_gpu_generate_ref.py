@@ -26,13 +26,14 @@ def tables():
     return _T
 
 
-def run_case(case, kernel_set="window"):
+def run_case(case, kernel_set="window", native=True):
     dev = torch.device("cuda")
     T = tables()
     base, drafter = F.make_base(T, dev), F.Drafter(T, dev)
     table = torch.from_numpy(T["nb"].astype(np.uint16).view(np.int16)).to(dev)
     mdl = EaLumina_mGPT(base, drafter, table, cfg_mode=case["cfg_mode"], eagle_version=1)
     mdl.kernel_set = kernel_set
+    mdl.native_step = native                       # True: the step through ONE lantern_verify_step call; False: a ctypes call per kernel
     mdl.uniform_window = 128                       # small window: the refill path runs too
     g = lambda k: GOLD[case["name"] + "." + k]
     draws = F.DetDraws(g("bonus_uniforms"))
@@ -49,9 +50,17 @@ def run_case(case, kernel_set="window"):
 
 
 @pytest.mark.parametrize("case", F.CASES, ids=[c["name"] for c in F.CASES])
-@pytest.mark.parametrize("kernel_set", ["window", "dense"])
-def test_generate_reproduces_the_reference_run(case, kernel_set):
-    mdl, drafter, draws, ids, alens = run_case(case, kernel_set)
+@pytest.mark.parametrize("kernel_set,native", [("window", True), ("window", False), ("dense", False)], ids=["window_one_call_step", "window", "dense"])
+def test_generate_reproduces_the_reference_run(case, kernel_set, native, monkeypatch):
+    from lantern_amd import _lib
+    calls = []
+    if native:          # the one-call step really is the path taken: no per-kernel evaluate_posterior / update call from Python
+        from lantern_amd import ops
+        for fn in ("evaluate_posterior_window", "update_inference_inputs", "cfg_mask_topk_window"):
+            real = getattr(ops, fn)
+            monkeypatch.setattr(ops, fn, (lambda real, fn: (lambda *a, **k: (calls.append(fn), real(*a, **k))[1]))(real, fn))
+    mdl, drafter, draws, ids, alens = run_case(case, kernel_set, native)
+    assert not calls, calls
     g = lambda k: GOLD[case["name"] + "." + k]
     assert ids[0].cpu().numpy().tolist() == g("ids").tolist()
     assert list(alens) == g("accept_lengths").tolist()
@@ -99,7 +108,7 @@ def test_generate_static_tree_runs_the_chosen_evaluate_posterior_form(form, monk
         return real(*a, **kw)
     monkeypatch.setattr(ops, "evaluate_posterior_window", spy)
     monkeypatch.setattr(EaLumina_mGPT, "ep_form", form)
-    mdl, drafter, draws, ids, alens = run_case(case)
+    mdl, drafter, draws, ids, alens = run_case(case, native=False)
     assert mdl.tree_buffers["_hip"]["nodes"] is not None
     assert seen and all(s == (form == "nodes") for s in seen), seen
     assert ids[0].cpu().numpy().tolist() == GOLD[case["name"] + ".ids"].tolist()

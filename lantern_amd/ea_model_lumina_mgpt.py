@@ -435,10 +435,13 @@ class EaLumina_mGPT(nn.Module):
         z = lambda *shape, dt: torch.zeros(shape, dtype=dt, device=dev)
         nx.cand, nx.cart, nx.tcand = z(1, P, D, dt=torch.int64), z(1, P, D, dt=torch.float32), z(1, N, dt=torch.int64)
         nx.win, nx.hot = z(N, W, dt=torch.float32), z(N, dt=torch.int32)
-        nx.rec = z(16, dt=torch.int32)                  # best, accept_len, counters[6], bonus token (int64 at words 8-9)
-        nx.tok = nx.rec[8:10].view(torch.int64)
+        # the verdict record, double-buffered (the drafter keeps the previous step's bonus token / hidden rows while this step's are written):
+        # best, accept_len, counters[6], bonus token (int64 at words 8-9)
+        nx.recs = [z(16, dt=torch.int32), z(16, dt=torch.int32)]
+        nx.toks = [r_[8:10].view(torch.int64) for r_ in nx.recs]
         nx.otok, nx.omass = z(1, dt=torch.int32), z(1, dt=torch.float32)
-        nx.out_h, nx.acc = None, z(1, D, dt=torch.int64)
+        nx.out_hs, nx.acc = [None, None], z(1, D, dt=torch.int64)
+        nx.stream = torch.cuda.current_stream().cuda_stream          # (generate() runs on one stream)
         nx.hid = None
         nx.pos1 = (tb["tree_position_ids"].to(dev) + 1).to(torch.int64).contiguous()
         nx.tree_indices, nx.retrieve = tb["tree_indices"].to(dev).contiguous(), tb["retrieve_indices"].to(dev).contiguous()
@@ -480,11 +483,10 @@ class EaLumina_mGPT(nn.Module):
         b.op_off, b.p_idx, b.b_off, b.b_idx = hip["op_off"].data_ptr(), hip["p_idx"].data_ptr(), hip["b_off"].data_ptr(), hip["b_idx"].data_ptr()
         b.tree_cand, b.nn_table = nx.tcand.data_ptr(), (nx.table.data_ptr() if nx.table is not None else None)
         b.uniforms, b.cursor = fifo.buf.data_ptr(), fifo.cursor.data_ptr()
-        b.best, b.accept_len, b.counters = nx.rec[0:].data_ptr(), nx.rec[1:].data_ptr(), nx.rec[2:].data_ptr()
         w = a.ep_win
         w.win_lo, w.win_len, w.row_hot, w.rows_kind = IMAGE_LO, W, nx.hot.data_ptr(), ops.ROWS_PROBS
         w.orig_prob_stride, w.orig_prob_offset = V, IMAGE_LO
-        w.out_tok, w.out_mass, w.token = nx.otok.data_ptr(), nx.omass.data_ptr(), nx.tok.data_ptr()
+        w.out_tok, w.out_mass = nx.otok.data_ptr(), nx.omass.data_ptr()
         nodes = hip.get("nodes") if (self.ep_form == "nodes" and (not lantern or int(lantern_k) + 1 <= 1024)) else None
         nx.nodes_struct = None
         if nodes is not None:
@@ -510,7 +512,11 @@ class EaLumina_mGPT(nn.Module):
         ss_prob = tl[1].to(nx.dev)
         ss_prob = (ss_prob if ss_prob.dtype == torch.float32 else ss_prob.float()).contiguous()
         sample = st.sample_token.to(nx.dev).reshape(-1)[:1].contiguous()
-        stream = torch.cuda.current_stream().cuda_stream
+        stream = nx.stream
+        par = nx.parity
+        rec, tokbuf = nx.recs[par], nx.toks[par]
+        a.ep_buf.best, a.ep_buf.accept_len, a.ep_buf.counters = rec.data_ptr(), rec.data_ptr() + 4, rec.data_ptr() + 8
+        a.ep_win.token = tokbuf.data_ptr()
         a.stream, a.ss_token, a.ss_prob, a.sample_token = stream, ss_token.data_ptr(), ss_prob.data_ptr(), sample.data_ptr()
         ops.check(L.lantern_gather_candidates(C.c_void_p(a.ss_token), C.c_void_p(a.ss_prob), C.c_void_p(a.sample_token), C.c_void_p(a.tree_indices), C.c_void_p(a.retrieve),
                                               1, a.n_flat, nx.N, nx.P, nx.D, C.c_void_p(a.tree_cand), C.c_void_p(a.cand), C.c_void_p(a.cart_prob), C.c_void_p(stream)),
@@ -521,20 +527,28 @@ class EaLumina_mGPT(nn.Module):
             cl, ul = cl.float(), ul.float()
         cl, ul = cl.contiguous(), ul.contiguous()
         a.cond, a.uncond, a.dtype = cl.data_ptr(), ul.data_ptr(), int(cl.dtype == torch.bfloat16)
-        orig = concat_original_prob(tl[2])
-        a.ep_buf.orig_prob = orig.data_ptr()
+        # the drafter's distributions, level by level: one [R, V] f32 block (no copy when the levels already sit back to back)
+        ol = tl[2]
+        if (all(o.dtype == torch.float32 and o.is_contiguous() and o.device == nx.dev for o in ol) and
+                all(ol[i].data_ptr() + 4 * ol[i].numel() == ol[i + 1].data_ptr() for i in range(len(ol) - 1))):
+            orig = ol
+            a.ep_buf.orig_prob = ol[0].data_ptr()
+        else:
+            orig = concat_original_prob(ol)
+            a.ep_buf.orig_prob = orig.data_ptr()
         hid = torch.stack((hidden[0], uhidden[0]))[None]                                   # [1, 2, N, H]
-        if nx.out_h is None or nx.out_h.dtype != hid.dtype or nx.out_h.shape[-1] != hid.shape[-1]:
-            nx.out_h = torch.zeros((1, 2, nx.D, hid.shape[-1]), dtype=hid.dtype, device=nx.dev)
-        a.hidden, a.out_hidden, a.hid_elem_bytes, a.H = hid.data_ptr(), nx.out_h.data_ptr(), hid.element_size(), hid.shape[-1]
+        out_h = nx.out_hs[par]
+        if out_h is None or out_h.dtype != hid.dtype or out_h.shape[-1] != hid.shape[-1]:
+            out_h = nx.out_hs[par] = torch.zeros((1, 2, nx.D, hid.shape[-1]), dtype=hid.dtype, device=nx.dev)
+        a.hidden, a.out_hidden, a.hid_elem_bytes, a.H = hid.data_ptr(), out_h.data_ptr(), hid.element_size(), hid.shape[-1]
         fifo = self._uniforms()
         fifo.reserve(nx.P * nx.D)
         u = torch.rand(1, dtype=torch.float64, device=nx.dev)
         a.ep_win.u_bonus = u.data_ptr()
-        cur, nxt = nx.lens[nx.parity], nx.lens[nx.parity ^ 1]
+        cur, nxt = nx.lens[par], nx.lens[par ^ 1]
         a.slab_prev, a.new_len, a.seq_len = cur.data_ptr(), nxt.data_ptr(), cur.data_ptr()          # (slab 0 is a cond slab at offset 0: its length is len(input_ids))
         ops.check(L.lantern_verify_step(nx.group, 1), "verify_step")
-        r = nx.rec.tolist()                                                                # the step's one host read
+        r = rec.tolist()                                                                   # the step's one host read
         best, alen, n_used, status, tok = r[0], r[1], r[5], r[7], r[8]
         Lcur = st.input_ids.shape[1]
         if status != 0:
@@ -553,8 +567,7 @@ class EaLumina_mGPT(nn.Module):
                 nxt.copy_(cur + (int(al) + 1))
                 nx.parity ^= 1
                 return hit
-            cnt = nx.rec[2:8].reshape(1, 6)
-            ops.raise_on_status(cnt)
+            ops.raise_on_status(rec[2:8].reshape(1, 6))
         n = alen + 1
         nx.parity ^= 1
         done = set()
@@ -564,7 +577,7 @@ class EaLumina_mGPT(nn.Module):
                 done.add((id(clen), off))
         accepted = nx.acc[:, :n].to(st.input_ids.device)
         st.input_ids = torch.cat([st.input_ids[None, 0] if st.parallel else st.input_ids, accepted], dim=-1)
-        self._draft_next(st, nx.out_h[:, 0, :n].clone(), nx.out_h[:, 1, :n].clone(), nx.tok.clone().reshape(1, 1))
+        self._draft_next(st, out_h[:, 0, :n], out_h[:, 1, :n], tokbuf.reshape(1, 1))          # (views of this parity's buffers: the next step writes the other pair)
         st.new_token += n
         st.accept_lengths.append(n)
         return False

@@ -75,9 +75,10 @@ def parse():
     ap.add_argument("--sigma", type=float, default=5.0, help="drafter noise; frozen at 5.0: mean accepted tokens/step ~2.6")
     ap.add_argument("--path", choices=["window", "dense"], default="window",
                     help="window: v2 kernels (32 KB image-window rows, LDS-resident residual); dense: v1 kernels (full-V rows)")
-    ap.add_argument("--ep", choices=["nodes", "chain"], default="chain",
+    ap.add_argument("--ep", choices=["auto", "nodes", "chain"], default="auto",
                     help="windowed evaluate_posterior: nodes = one workgroup per internal tree node + the walk (lantern_evaluate_posterior_nodes); "
-                         "chain = one serial chain per sequence (lantern_evaluate_posterior_window)")
+                         "chain = one serial chain per sequence (lantern_evaluate_posterior_window); auto (default) = nodes when the rank holds <= 16 "
+                         "sequences (C5's 8 per GPU: 40 vs 49-52 us per step, profiles/r04_c5_share.json), chain above")
     ap.add_argument("--no-fuse-o7", dest="fuse_o7", action="store_false", help="every stage its own launch: cfg_mask_topk for ALL rows, then evaluate_posterior on probability rows "
                     "(default: the chain kernel takes the raw logits -- LANTERN_ROWS_RAW_BF16 -- and post-processes the rows its walk visits)")
     ap.add_argument("--spec-rows", type=int, default=3, help="with --fuse-o7: rows of the K most likely tree nodes are post-processed up front, in the candidate-assembly launch (lantern_prepare_step); the others on demand")
@@ -891,6 +892,8 @@ def main():
     if groups != args.groups and rank == 0:
         print(f"bench.py: {n_seq} sequences per rank in {groups} stream groups (--groups {args.groups} does not divide them)", file=sys.stderr)
     args.groups = groups
+    if args.ep == "auto":
+        args.ep = "nodes" if n_seq <= 16 else "chain"          # (measured at 8 sequences per GPU in 1 / 2 groups; larger shares keep the chain on raw rows)
     if args.ep != "chain":
         args.fuse_o7 = False
     if not args.fuse_o7:

@@ -516,7 +516,9 @@ __device__ __forceinline__ void raw_row_load(const uint16_t *__restrict__ crow, 
 
 // `top_p` in (0, 1): TopPLogitsWarper between the CFG mix and the top-k threshold (HF order Temperature -> TopP -> TopK, drafters/utils.py:36-52:
 // LlamaGen / Anole take top_p from generate()); its 256 f64 mass bins live in the front of the histogram buffer (the top-k select clears it afterwards).
-template <int NT, typename Hook = NoHook>
+// (NUCLEUS is a template parameter: the filter keeps a second copy of the row in registers, which the instances without it must not pay for --
+// 162 -> 217 VGPRs for the chain kernel, 51 -> 94 for the row preparation when it was a run-time branch.)
+template <int NT, typename Hook = NoHook, bool NUCLEUS = false>
 __device__ __forceinline__ void raw_row_to_lds(const float4 (&rp)[4], int hot, float cfg, int top_k, int V, int win_lo, int W, float *g,
                                                int &out_tok, float &out_mass, float *redf, double *redd, int *hist, int &ph, const Hook &pre_barrier = Hook(),
                                                float top_p = 1.0f, int *redi = nullptr) {
@@ -557,7 +559,9 @@ __device__ __forceinline__ void raw_row_to_lds(const float4 (&rp)[4], int hot, f
         r[2 * it + 1] = make_float4(o[4], o[5], o[6], o[7]);
     }
     EPW_STAMPG(81);
-    if (top_p >= 1e-8f && top_p < 1.0f && redi) top_p_tile<NT, 4>(r, top_p, reinterpret_cast<double *>(hist), redf, redd, redi, ph);
+    if constexpr (NUCLEUS) {
+        if (top_p >= 1e-8f && top_p < 1.0f && redi) top_p_tile<NT, 4>(r, top_p, reinterpret_cast<double *>(hist), redf, redd, redi, ph);
+    }
     if (top_k > 0 && top_k < V) {
         const float thr = (top_k <= W) ? kth_largest_hist_bf16<NT, 4>(r, top_k, hist) : NEG_INF;
 #pragma unroll

@@ -192,7 +192,7 @@ __global__ __launch_bounds__(NT) void cfg_window_kernel(const void *__restrict__
 // out by nature and uses a single copy.
 // One row of the windowed O7 on a workgroup: CFG combination, top-k threshold, softmax, window store (the body of cfg_window_bf16_kernel,
 // shared with the merged launch below).  `cls`: 0 = grid row, 1 = forced newline, 2 = forced end of image.
-template <int NT, int E8, bool FULL>
+template <int NT, int E8, bool FULL, bool NUCLEUS = false>
 __device__ __forceinline__ void cfg_window_bf16_row(int row, int cls, const uint16_t *__restrict__ cond, const uint16_t *__restrict__ uncond, int V,
                                                     float cfg, int model, int img_lo, int img_hi, int newline_id, int eos_id, int top_k, int win_lo,
                                                     int W, float *__restrict__ out_win, int32_t *__restrict__ row_hot, int out_kind, int *s_hist,
@@ -250,9 +250,11 @@ __device__ __forceinline__ void cfg_window_bf16_row(int row, int cls, const uint
         r[2 * it] = make_float4(o[0], o[1], o[2], o[3]);
         r[2 * it + 1] = make_float4(o[4], o[5], o[6], o[7]);
     }
-    if (top_p >= 1e-8f && top_p < 1.0f && s_redi) {          // TopPLogitsWarper in front of the top-k (the mass bins in the front of the histogram buffer)
-        int php = 0;
-        top_p_tile<NT, 2 * E8>(r, top_p, reinterpret_cast<double *>(s_hist), s_redf, s_redd, s_redi, php);
+    if constexpr (NUCLEUS) {          // TopPLogitsWarper in front of the top-k (the mass bins in the front of the histogram buffer)
+        if (top_p >= 1e-8f && top_p < 1.0f && s_redi) {
+            int php = 0;
+            top_p_tile<NT, 2 * E8>(r, top_p, reinterpret_cast<double *>(s_hist), s_redf, s_redd, s_redi, php);
+        }
     }
     if (top_k > 0 && top_k < V) {
         // k-th largest of the FULL row = k-th largest of the window whenever >= k window entries beat the fill
@@ -331,7 +333,7 @@ struct PrepArgs {
     float top_p;
 };
 
-template <int NT, int E8>
+template <int NT, int E8, bool NUCLEUS = false>
 __global__ __launch_bounds__(NT) void prep_rows_kernel(const PrepArgs a) {
     __shared__ alignas(16) int s_hist[O7_HIST_INTS];
     __shared__ float s_redf[32];
@@ -344,8 +346,8 @@ __global__ __launch_bounds__(NT) void prep_rows_kernel(const PrepArgs a) {
         const int row = b * a.rows_per_seq + node;
         // (w_latent == 0: a model without grammar rows -- Anole; the window is its image-token range, so no id needs the model's mask)
         const int cls = a.w_latent > 0 ? lumina_row_class(a.pos_ids[node] + a.seq_len[b], a.pos_base, a.w_latent, a.h_latent) : 0;
-        cfg_window_bf16_row<NT, E8, true>(row, cls, a.cond, a.uncond, a.V, a.cfg, LANTERN_MODEL_LUMINA, a.img_lo, a.img_hi, a.newline_id, a.eos_id,
-                                          a.top_k, a.win_lo, a.W, a.out_win, a.row_hot, LANTERN_ROWS_PROBS, s_hist, s_redf, s_redd, a.top_p, s_redi);
+        cfg_window_bf16_row<NT, E8, true, NUCLEUS>(row, cls, a.cond, a.uncond, a.V, a.cfg, LANTERN_MODEL_LUMINA, a.img_lo, a.img_hi, a.newline_id, a.eos_id,
+                                                   a.top_k, a.win_lo, a.W, a.out_win, a.row_hot, LANTERN_ROWS_PROBS, s_hist, s_redf, s_redd, a.top_p, s_redi);
         return;
     }
     // ---- candidate assembly of sequence b (same arithmetic as gather_candidates_kernel)
@@ -391,7 +393,7 @@ struct DynPrepArgs {
     float top_p;
 };
 
-template <int NT, int E8>
+template <int NT, int E8, bool NUCLEUS = false>
 __global__ __launch_bounds__(NT) void dyn_prep_kernel(const DynPrepArgs a) {
     const int n_rows = a.B * a.n_list;
     if ((int)blockIdx.x < n_rows) {
@@ -405,8 +407,8 @@ __global__ __launch_bounds__(NT) void dyn_prep_kernel(const DynPrepArgs a) {
         const int row = b * a.rows_per_seq + node;
         // (= pos_abs of a node at that depth; w_latent == 0: a model without grammar rows -- LlamaGen)
         const int cls = a.w_latent > 0 ? lumina_row_class(a.td.cd.seq_len[b] + 1 + depth, a.pos_base, a.w_latent, a.h_latent) : 0;
-        cfg_window_bf16_row<NT, E8, true>(row, cls, a.cond, a.uncond, a.V, a.cfg, LANTERN_MODEL_LUMINA, a.img_lo, a.img_hi, a.newline_id, a.eos_id,
-                                          a.top_k, a.win_lo, a.W, a.out_win, a.row_hot, LANTERN_ROWS_PROBS, s_hist, s_redf, s_redd, a.top_p, s_redi);
+        cfg_window_bf16_row<NT, E8, true, NUCLEUS>(row, cls, a.cond, a.uncond, a.V, a.cfg, LANTERN_MODEL_LUMINA, a.img_lo, a.img_hi, a.newline_id, a.eos_id,
+                                                   a.top_k, a.win_lo, a.W, a.out_win, a.row_hot, LANTERN_ROWS_PROBS, s_hist, s_redf, s_redd, a.top_p, s_redi);
         return;
     }
     td_finalize_body<8, NT / 64>(a.td, blockIdx.x - n_rows);
@@ -501,6 +503,7 @@ typedef const __attribute__((address_space(4))) EpwArgs *EpwArgsK;
 // RAW: rows are the target model's raw cond / uncond bf16 logits (LANTERN_ROWS_RAW_BF16; W == 8 * 2 * NT, packed table).
 template <int NT, int E4, int IDMODE, int WPE, bool FULLW = false, bool RAW = false, int SPEC = 0, int TPO = 0>
 __device__ __forceinline__ int epw_body(const EpwArgs &args, const int b) {
+    constexpr bool NUCLEUS = (TPO & 2) != 0;         // raw rows: TopPLogitsWarper (prm.top_p) in front of the top-k of the rows the walk post-processes
     constexpr bool LATE_Q = (TPO & 1) != 0;          // throughput builds: a candidate's drafter row is requested once its rejection is known (an accepted
                                                      // candidate -- 0.65 of the first tries -- then costs no row request at all; the latency is another workgroup's problem)
     static_assert(!RAW || (FULLW && E4 == 4), "raw rows: the 8192-id window on 512 threads");
@@ -828,7 +831,7 @@ __device__ __forceinline__ int epw_body(const EpwArgs &args, const int b) {
                 }
             };
             if constexpr (RAW) {
-                if (!rp_probs) raw_row_to_lds<NT>(rp, hot, win.raw_cfg, win.raw_top_k, V, lo, W, g, out_tok, out_mass, S.redf, S.redd, Shist, ph, stage_ids, prm.top_p, S.redi);
+                if (!rp_probs) raw_row_to_lds<NT, decltype(stage_ids), NUCLEUS>(rp, hot, win.raw_cfg, win.raw_top_k, V, lo, W, g, out_tok, out_mass, S.redf, S.redd, Shist, ph, stage_ids, prm.top_p, S.redi);
                 else row_softmax_to_lds<NT, E4, FULLW>(rp, hot, true, lo, W, prm.temperature, prm.top_k, V, g, out_tok, out_mass, S, ph, stage_ids);
             } else row_softmax_to_lds<NT, E4, FULLW>(rp, hot, rows_probs, lo, W, prm.temperature, prm.top_k, V, g, out_tok, out_mass, S, ph, stage_ids);
             EPW_STAMP(11);
@@ -1181,7 +1184,7 @@ __device__ __forceinline__ int epw_body(const EpwArgs &args, const int b) {
             } else row_load<NT, E4, FULLW>(logits + (size_t)rid * W, W, rp);
         }
         if constexpr (RAW) {
-            if (!rp_probs) raw_row_to_lds<NT>(rp, hot, win.raw_cfg, win.raw_top_k, V, lo, W, g, out_tok, out_mass, S.redf, S.redd, Shist, ph, NoHook(), prm.top_p, S.redi);
+            if (!rp_probs) raw_row_to_lds<NT, NoHook, NUCLEUS>(rp, hot, win.raw_cfg, win.raw_top_k, V, lo, W, g, out_tok, out_mass, S.redf, S.redd, Shist, ph, NoHook(), prm.top_p, S.redi);
             else row_softmax_to_lds<NT, E4, FULLW>(rp, hot, true, lo, W, prm.temperature, prm.top_k, V, g, out_tok, out_mass, S, ph);
         } else row_softmax_to_lds<NT, E4, FULLW>(rp, hot, rows_probs, lo, W, prm.temperature, prm.top_k, V, g, out_tok, out_mass, S, ph);
     }
@@ -1431,8 +1434,13 @@ static int prepare_step_dynamic(const lantern_step_group *g) {
                   TdArgs{d.scores, d.tokens, d.parents, g->sample_token, d.n_scores, d.n_parents, d.top_k, d.total_tokens, d.sort_rows, d.draft_tokens, d.mask,
                          d.pos_ids, d.retrieve, d.n_leaf, d.max_depth, TdCand{d.seq_len, g->cand, d.retrieve_pd, d.pos_abs, d.row_index, g->P, g->D}},
                   g->top_p};
-    if (g->win_len == 16384) LANTERN_LAUNCH((dyn_prep_kernel<512, 4>), dim3(g->B * g->n_list + g->B), dim3(512), 0, (hipStream_t)g->stream, a);     // LlamaGen: the whole vocabulary
-    else LANTERN_LAUNCH((dyn_prep_kernel<512, 2>), dim3(g->B * g->n_list + g->B), dim3(512), 0, (hipStream_t)g->stream, a);
+    const bool nucleus = g->top_p >= 1e-8f && g->top_p < 1.0f;
+    const dim3 grid(g->B * g->n_list + g->B);
+    if (g->win_len == 16384) {          // LlamaGen: the whole vocabulary
+        if (nucleus) LANTERN_LAUNCH((dyn_prep_kernel<512, 4, true>), grid, dim3(512), 0, (hipStream_t)g->stream, a);
+        else LANTERN_LAUNCH((dyn_prep_kernel<512, 4>), grid, dim3(512), 0, (hipStream_t)g->stream, a);
+    } else if (nucleus) LANTERN_LAUNCH((dyn_prep_kernel<512, 2, true>), grid, dim3(512), 0, (hipStream_t)g->stream, a);
+    else LANTERN_LAUNCH((dyn_prep_kernel<512, 2>), grid, dim3(512), 0, (hipStream_t)g->stream, a);
     LANTERN_CHECK_LAUNCH("prepare_step");
     return LANTERN_OK;
 }
@@ -1459,7 +1467,8 @@ extern "C" int lantern_prepare_step(const lantern_step_group *g) {
                g->ss_token, g->ss_prob, g->sample_token, g->tree_indices, g->retrieve, g->n_flat, g->N, g->P * g->D, g->tree_cand, g->cand, g->cart_prob,
                g->top_p};
     static const int nt_knob = getenv("LANTERN_PREP_NT") ? atoi(getenv("LANTERN_PREP_NT")) : 0;   // tuning knob (diagnostic)
-    if (nt_knob == 1024) LANTERN_LAUNCH((prep_rows_kernel<1024, 1>), dim3(g->B * g->n_list + g->B), dim3(1024), 0, (hipStream_t)g->stream, a);
+    if (g->top_p >= 1e-8f && g->top_p < 1.0f) LANTERN_LAUNCH((prep_rows_kernel<512, 2, true>), dim3(g->B * g->n_list + g->B), dim3(512), 0, (hipStream_t)g->stream, a);
+    else if (nt_knob == 1024) LANTERN_LAUNCH((prep_rows_kernel<1024, 1>), dim3(g->B * g->n_list + g->B), dim3(1024), 0, (hipStream_t)g->stream, a);
     else LANTERN_LAUNCH((prep_rows_kernel<512, 2>), dim3(g->B * g->n_list + g->B), dim3(512), 0, (hipStream_t)g->stream, a);
     LANTERN_CHECK_LAUNCH("prepare_step");
     return LANTERN_OK;
@@ -1578,6 +1587,10 @@ extern "C" int lantern_evaluate_posterior_window(const lantern_ep_params *prm, c
     if (W <= 1024) EPW_LAUNCH(256, 1);
     else if (W <= 2048) EPW_LAUNCH(256, 2);
     else if (W <= 4096) EPW_LAUNCH(512, 2);
+    else if (raw && p.top_p >= 1e-8f && p.top_p < 1.0f) {          // raw rows with a nucleus filter: the generic raw instances with the filter compiled in
+        if (W == 16384) LANTERN_LAUNCH((epw_kernel<1024, 4, 1, 1, true, true, 0, 2>), grid, dim3(1024), lds, st, args);
+        else LANTERN_LAUNCH((epw_kernel<512, 4, 2, 1, true, true, 0, 2>), grid, dim3(512), lds, st, args);
+    }
     else if (raw && W == 16384) {          // LlamaGen standard verify on raw rows (the form epw_check admitted)
         const bool lg_dynamic = spec_knob != 0 && p.V == 16384 && p.img_lo == 0 && p.img_hi == 16384 && p.tok_offset == 0 && win->win_lo == 0 && buf->n_paths &&
                                 buf->n_depth && p.rows_per_seq <= EW_MAX_N;

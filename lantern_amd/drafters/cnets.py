@@ -406,16 +406,35 @@ class Model(nn.Module):
             position_ids = position_ids.view(-1, T).long()
         if attention_mask is None:
             attention_mask = torch.ones((B, T + past), dtype=torch.bool, device=hidden_states.device)
-        mask = self._prepare_decoder_attention_mask(attention_mask, (B, T), hidden_states, past)
-        hidden_states = self._input_stage(hidden_states, input_ids.to(hidden_states.device))
+        elif past == 0 and attention_mask.is_cuda:
+            # the ancestor-word attention path describes padding by ONE first-visible-key index per row (kv_start = argmax of the mask): checked once
+            # per prompt, at its prefill, that the mask really is left padding only (ones contiguous up to the end) -- never assumed
+            am = attention_mask.to(torch.int64)
+            if not bool((am.cummax(dim=1).values == am).all()):
+                raise ops._lib.LanternError("cnets.Model.forward: attention_mask with zeros behind a one (not left padding): the tree-attention path "
+                                            "takes one first-visible-key index per row")
         extra = self.layer_kwargs(position_ids) if self.layer_kwargs is not None else {}
         tm = getattr(self, "tree_mask", None)
-        if (tm is not None and hidden_states.is_cuda and hidden_states.dtype == torch.bfloat16 and tm.shape[-1] <= 64 and tm.shape[-2] >= T
-                and tm.shape[-1] >= T and past + T >= tm.shape[-1] and all(getattr(l, "supports_tree_bits", False) for l in self.layers)):
+        bits_ok = (hidden_states.is_cuda and hidden_states.dtype == torch.bfloat16 and all(getattr(l, "supports_tree_bits", False) for l in self.layers))
+        have_bits = False
+        if (tm is not None and bits_ok and tm.shape[-1] <= 64 and tm.shape[-2] >= T and tm.shape[-1] >= T and past + T >= tm.shape[-1]):
             # the tree block of the mask as ancestor words + the left padding as a first-visible-key index: the layer's attention
             # runs on lantern_tree_attention (the additive mask still rides along for layers / shapes that want it)
             bits, t1 = ops.drafter_tree_bits(tm.to(hidden_states.device), T)
             extra = dict(extra, tree_bits=bits, tree_keys=t1, kv_start=attention_mask.to(hidden_states.device).to(torch.int64).argmax(dim=1))
+            have_bits = True
+        elif tm is None and bits_ok and past > 0 and B * T <= 32:
+            # the accepted tokens of a drafting call behind the cached prefix (a few rows): causal among themselves = a chain-shaped "tree"
+            # (row i sees the new keys 0..i), so this call's attention runs on lantern_tree_attention too -- no additive mask, no torch attention
+            chain = self.__dict__.setdefault("_chain_bits", {}).get((T, hidden_states.device))
+            if chain is None:
+                chain = self._chain_bits[(T, hidden_states.device)] = ((torch.ones(T, dtype=torch.int64, device=hidden_states.device) << (torch.arange(T, dtype=torch.int64, device=hidden_states.device) + 1)) - 1)
+            extra = dict(extra, tree_bits=chain, tree_keys=T, kv_start=attention_mask.to(hidden_states.device).to(torch.int64).argmax(dim=1))
+            have_bits = True
+        # the additive mask only when some layer may still want it (the HIP layers at the drafting shape take the ancestor words)
+        fast = have_bits and B * T <= 32 and all(getattr(l, "fused", False) and hasattr(l, "_fast") for l in self.layers)
+        mask = None if fast else self._prepare_decoder_attention_mask(attention_mask, (B, T), hidden_states, past)
+        hidden_states = self._input_stage(hidden_states, input_ids.to(hidden_states.device))
         cache = () if use_cache else None
         for idx, layer in enumerate(self.layers):
             pkv = past_key_values[idx] if past_key_values is not None else None

@@ -257,6 +257,7 @@ class Model(nn.Module):
     def __init__(self, config, layers: Optional[List[nn.Module]] = None, bias=True, total_tokens=63, depth=5, top_k=8, threshold=1.0,
                  embed_upscale=1.0, model_type="lumina_mgpt", image_lo=4, image_hi=8196, allow_torch_layers=False):
         super().__init__()
+        self.config = config
         self.padding_idx = getattr(config, "pad_token_id", None)
         self.vocab_size = config.vocab_size
         self.embed_tokens = nn.Embedding(config.vocab_size, config.hidden_size, self.padding_idx)
@@ -324,7 +325,8 @@ class Model(nn.Module):
     def from_reference(cls, ref, model_type: str, **kw):
         """The reference's drafter `Model` (cnets_lumina_mgpt / cnets_llamagen / cnets_anole, loaded by its own `from_pretrained`) re-hosted on this
         class: same config, same tree parameters, its state_dict loaded as is (the parameter names are the reference's), HIP decoder layers."""
-        cfg = ref.config if hasattr(ref, "config") else kw.pop("config")
+        # (the reference's drafter Model does not keep its config; its attention modules do: cnets_llamagen.py:229, cnets_lumina_mgpt.py:411-430)
+        cfg = kw.pop("config", None) or getattr(ref, "config", None) or ref.layers[0].self_attn.config
         has_bias = getattr(ref.fc, "bias", None) is not None
         m = cls(cfg, bias=has_bias, total_tokens=int(ref.total_tokens) + 1, depth=int(ref.depth), top_k=int(ref.top_k), model_type=model_type,
                 embed_upscale=float(getattr(ref, "embed_upscale", 1.0)), **kw)

@@ -140,3 +140,28 @@ def test_top_p_outside_the_windowed_kernel_set_is_refused_before_any_work():
         m.kernel_set = "dense"
         m._check_processors(0.0, 0.9)          # greedy decoding has no processors
         m._check_processors(1.0, 1.0)
+
+
+@pytest.mark.parametrize("model_type", ["lumina_mgpt", "anole", "llamagen"])
+def test_drafter_from_reference_rehosts_a_loaded_drafter(model_type):
+    """cnets.Model.from_reference: a loaded drafter (here a stand-in with the reference Model's attributes -- no `config` of its own, the attention
+    module keeps it, as in cnets_llamagen.py:229) re-hosted on this package's Model: same tree parameters, the state_dict loaded as is, the HIP decoder
+    layer of the model family (constructed on the CPU; the kernels only run on a device)."""
+    import types
+    import torch
+    from lantern_amd.drafters import cnets
+    from lantern_amd.drafters.decoder_layer import DecoderLayer, LlamaDecoderLayer
+    H, heads = 128, 2
+    cfg = types.SimpleNamespace(vocab_size=512, hidden_size=H, pad_token_id=None, num_hidden_layers=1, num_attention_heads=heads, num_key_value_heads=heads,
+                                intermediate_size=256, max_position_embeddings=128, rms_norm_eps=1e-5, model_parallel_size=1, input_type="t2i")
+    torch.manual_seed(1)
+    src = cnets.Model(cfg, total_tokens=40, depth=4, top_k=10, model_type=model_type)
+    ref = types.SimpleNamespace(fc=src.fc, layers=src.layers, total_tokens=src.total_tokens, depth=src.depth, top_k=src.top_k, threshold=src.threshold,
+                                state_dict=src.state_dict, parameters=src.parameters)
+    assert not hasattr(ref, "config")
+    src.layers[0].self_attn.config = cfg
+    got = cnets.Model.from_reference(ref, model_type)
+    assert isinstance(got.layers[0], LlamaDecoderLayer if model_type == "llamagen" else DecoderLayer)
+    assert (got.total_tokens, got.depth, got.top_k) == (src.total_tokens, src.depth, src.top_k)
+    a, b = src.state_dict(), got.state_dict()
+    assert set(a) == set(b) and all(torch.equal(a[k], b[k]) for k in a)

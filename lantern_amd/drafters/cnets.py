@@ -148,12 +148,12 @@ class DraftPlan:
         a.fc_w, a.fc_b, a.fc_packed = ptr(model._packed_weight("fc", model.fc.weight).data), ptr(model.fc.bias), 1
         if hasattr(layer, "input_layernorm"):
             a.ln1_w, a.eps1 = ptr(layer.input_layernorm.weight), float(layer.input_layernorm.variance_epsilon)
-        w, b = at._fused_qkv()
-        a.qkv_w, a.qkv_b = ptr(layer._packed("qkv", w).data), ptr(b)
+        wq, b = layer._packed_fused("qkv", (at.q_proj, at.k_proj, at.v_proj))
+        a.qkv_w, a.qkv_b = ptr(wq.data), ptr(b)
         a.o_w, a.o_b = ptr(layer._packed("o", at.o_proj.weight).data), ptr(at.o_proj.bias)
         a.ln2_w = ptr(layer.post_attention_layernorm.weight)
-        wg, bg = mlp._fused_gate_up()
-        a.gate_up_w, a.gate_up_b = ptr(layer._packed("gate_up", wg, inter).data), ptr(bg)
+        wg, bg = layer._packed_fused("gate_up", (mlp.gate_proj, mlp.up_proj), inter)
+        a.gate_up_w, a.gate_up_b = ptr(wg.data), ptr(bg)
         a.down_w, a.down_b, a.layer_packed = ptr(layer._packed("down", mlp.down_proj.weight).data), ptr(mlp.down_proj.bias), 1
         if self.llama:
             self.freqs = model.freqs_cis.to(device=dev, dtype=torch.float32).contiguous()

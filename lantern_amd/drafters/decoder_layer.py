@@ -217,6 +217,37 @@ class DecoderLayer(nn.Module):
             hit = cache[name] = (key, ops.pack_linear_weight(weight, pair_rows))
         return hit[1]
 
+    def _packed_fused(self, name, mods, pair_rows=0):
+        """(packed weight, fused bias) of projections that share one launch -- q / k / v, gate / up: their rows concatenated, packed, and the row-major
+        concatenation dropped again (the layer keeps the nn.Linear weights and the packed bricks, not a third copy: 280 MB at 7B size).  Keyed by the
+        source weights' (data_ptr, version): load_state_dict and in-place optimiser steps re-pack; `repack()` after a write through `.data`."""
+        ws = tuple(m.weight for m in mods)
+        if ws[0].shape[1] % 64:
+            cat = torch.cat(ws, dim=0).contiguous()
+            return cat, (None if mods[0].bias is None else torch.cat([m.bias for m in mods]).contiguous())
+        cache = self.__dict__.setdefault("_packed_weights", {})
+        key = tuple((w.data_ptr(), w._version) for w in ws)
+        hit = cache.get(name)
+        if hit is None or hit[0] != key:
+            cat = torch.cat(ws, dim=0).contiguous()
+            b = None if mods[0].bias is None else torch.cat([m.bias for m in mods]).contiguous()
+            hit = cache[name] = (key, ops.pack_linear_weight(cat, pair_rows), b)
+            del cat
+        return hit[1], hit[2]
+
+    def repack(self):
+        """Forget every packed / fused copy of the weights (they are rebuilt on the next call).  load_state_dict does this by itself; call it after
+        writing weights in a way autograd's version counter does not see (`weight.data.copy_`, `set_`)."""
+        self.__dict__.pop("_packed_weights", None)
+        for m in (self.self_attn, self.mlp):
+            for attr in ("_qkv", "_gu"):
+                if hasattr(m, attr):
+                    setattr(m, attr, None)
+
+    def _load_from_state_dict(self, *a, **k):
+        self.repack()
+        return super()._load_from_state_dict(*a, **k)
+
     def _fast(self, x, attention_mask, position_ids, past_key_value, use_cache, tree_bits=None, tree_keys=0, kv_start=None):
         """Decode shape on the device (<= 32 bf16 rows): rmsnorm, fused q/k/v GEMM, head norm + rotary (+ cache append), one attention call,
         o_proj + residual, rmsnorm, gate/up GEMM with silu * up in its epilogue, down_proj + residual -- the four GEMMs in stream-K form
@@ -228,8 +259,8 @@ class DecoderLayer(nn.Module):
         nq, nk, d = at.num_heads, at.num_key_value_heads, at.head_dim
         x2 = x.reshape(B * T, H)
         xn = ops.rmsnorm_rows(x2, self.input_layernorm.weight, self.input_layernorm.variance_epsilon)
-        w, b = at._fused_qkv()
-        qkv = ops.linear_rows_streamk(xn, self._packed("qkv", w), bias=b)          # stream-K: every workgroup streams an equal, contiguous share of the weight
+        wq, b = self._packed_fused("qkv", (at.q_proj, at.k_proj, at.v_proj))
+        qkv = ops.linear_rows_streamk(xn, wq, bias=b)          # stream-K: every workgroup streams an equal, contiguous share of the weight
         kv_len = T + (past_key_value[0].shape[-2] if past_key_value is not None else 0)
         cos, sin = at.rotary_emb.tables_bf16(x.device, kv_len)
         past = 0 if past_key_value is None else past_key_value[0].shape[-2]
@@ -262,9 +293,9 @@ class DecoderLayer(nn.Module):
             o = F.scaled_dot_product_attention(q, k, v, attn_mask=m, enable_gqa=nk != nq).transpose(1, 2).reshape(B * T, H)
         h1 = ops.linear_rows_streamk(o, self._packed("o", at.o_proj.weight), ops.EPI_RESIDUAL, bias=at.o_proj.bias, residual=x2)
         hn = ops.rmsnorm_rows(h1, self.post_attention_layernorm.weight, self.post_attention_layernorm.variance_epsilon)
-        wg, bg = mlp._fused_gate_up()
         inter = mlp.gate_proj.out_features
-        act = ops.linear_rows_streamk(hn, self._packed("gate_up", wg, inter), ops.EPI_SILU_MUL, bias=bg, pair_rows=inter)
+        wg, bg = self._packed_fused("gate_up", (mlp.gate_proj, mlp.up_proj), inter)
+        act = ops.linear_rows_streamk(hn, wg, ops.EPI_SILU_MUL, bias=bg, pair_rows=inter)
         out = ops.linear_rows_streamk(act, self._packed("down", mlp.down_proj.weight), ops.EPI_RESIDUAL, bias=mlp.down_proj.bias, residual=h1)
         return out.reshape(B, T, H), present
 
@@ -422,8 +453,8 @@ class LlamaDecoderLayer(DecoderLayer):
         nq, nk, d = at.num_heads, at.num_key_value_heads, at.head_dim
         x2 = x.reshape(B * T, H)
         xn = x2 if self.index == 0 else ops.rmsnorm_rows(x2, self.input_layernorm.weight, self.input_layernorm.variance_epsilon)
-        w, b = at._fused_qkv()
-        qkv = ops.linear_rows_streamk(xn, self._packed("qkv", w), bias=b)
+        wq, b = self._packed_fused("qkv", (at.q_proj, at.k_proj, at.v_proj))
+        qkv = ops.linear_rows_streamk(xn, wq, bias=b)
         past = 0 if past_key_value is None else past_key_value[0].shape[-2]
         kv_len = T + past
         fr = freqs_cis.reshape(-1, d // 2, 2)                      # the reference hands over the rows of its table at this call's positions: [T, d/2, 2]
@@ -455,9 +486,9 @@ class LlamaDecoderLayer(DecoderLayer):
             o = F.scaled_dot_product_attention(q, k, v, attn_mask=m, enable_gqa=nk != nq).transpose(1, 2).reshape(B * T, H)
         h1 = ops.linear_rows_streamk(o, self._packed("o", at.o_proj.weight), ops.EPI_RESIDUAL, residual=x2)
         hn = ops.rmsnorm_rows(h1, self.post_attention_layernorm.weight, self.post_attention_layernorm.variance_epsilon)
-        wg, bg = mlp._fused_gate_up()
         inter = mlp.gate_proj.out_features
-        act = ops.linear_rows_streamk(hn, self._packed("gate_up", wg, inter), ops.EPI_SILU_MUL, bias=bg, pair_rows=inter)
+        wg, bg = self._packed_fused("gate_up", (mlp.gate_proj, mlp.up_proj), inter)
+        act = ops.linear_rows_streamk(hn, wg, ops.EPI_SILU_MUL, bias=bg, pair_rows=inter)
         out = ops.linear_rows_streamk(act, self._packed("down", mlp.down_proj.weight), ops.EPI_RESIDUAL, bias=mlp.down_proj.bias, residual=h1)
         return out.reshape(B, T, H), present
 

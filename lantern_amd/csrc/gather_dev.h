@@ -90,6 +90,89 @@ __device__ __forceinline__ void kv_gather_body(int bx, int nbx, int s, void *con
     kv_gather_rows<MAXSEL, U, MODE>(bx, nbx, s, seq, bst, n_sel, slab_ptrs, slab_prev, outer, S_max, chunks_per_row, retrieve, retrieve_per_seq, P, D, new_len);
 }
 
+// The same move with KS consecutive slabs per workgroup (small slabs: one workgroup covers a whole slab).  Everything a slab's move depends on
+// -- its sequence, previous length, base address, then the sequence's verdict, then the path's rows -- is fetched for all KS slabs at once, so the
+// three dependent round trips are paid once per workgroup instead of once per slab, and a launch has KS times fewer workgroups: the commits of
+// several groups in flight then fit the chip in one or two rounds (per-slab workgroups: 8 064 of them for 63 sequences of the 7B geometry,
+// six rounds of ~5 us).
+template <int MAXSEL, int KS, int NT>
+__device__ __forceinline__ void kv_gather_slabs(int s0, int n_slabs, void *const *__restrict__ slab_ptrs, const int32_t *__restrict__ slab_seq,
+                                                const int64_t *__restrict__ slab_prev, int64_t outer, int64_t S_max, int chunks_per_row,
+                                                const int64_t *__restrict__ retrieve, int retrieve_per_seq, int P, int D,
+                                                const int32_t *__restrict__ best, const int32_t *__restrict__ accept_len,
+                                                int64_t *__restrict__ new_len, const int32_t *__restrict__ counters) {
+    static_assert(KS * MAXSEL <= 64, "the slabs' path rows are resolved by the lanes of one wave");
+    typedef __attribute__((address_space(1))) u32x4_t gvec_t;
+    __shared__ int s_src[KS][MAXSEL];
+    __shared__ unsigned s_move[KS];
+    __shared__ long long s_prev[KS];
+    __shared__ unsigned long long s_ptr[KS];
+    const int tid = threadIdx.x;
+    if (tid < 64) {          // lane (i, t): path row t of slab i -- the dependent loads of all slabs side by side
+        const int i = tid / MAXSEL, t = tid % MAXSEL;
+        const bool valid = i < KS && s0 + i < n_slabs;
+        const int s = valid ? s0 + i : n_slabs - 1;
+        const int seq = slab_seq[s];
+        const long long prev = slab_prev[s];
+        const int bst = best[seq];
+        int n = accept_len[seq] + 1;
+        if (n > D) n = D;
+        if (counters && counters[(size_t)seq * 6 + 5] != 0) n = 0;          // a walk that reported a status commits nothing
+        if (n > MAXSEL) n = MAXSEL;
+        const bool live = valid && t < n;
+        const long long r = live ? retrieve[(retrieve_per_seq ? (size_t)seq * P * D : 0) + (size_t)bst * D + t] : (long long)t;
+        // rows already in place (tree node t at position prev + t: the root, every accepted first child) are not touched
+        const bool mv = live && r != t && prev + t < S_max;
+        const unsigned long long mask = __ballot(mv);
+        if (i < KS) {
+            const long long sr = r + prev;
+            s_src[i][t] = (int)(sr < 0 ? 0 : (sr >= S_max ? S_max - 1 : sr));
+            if (t == 0) {
+                s_move[i] = (unsigned)((mask >> (i * MAXSEL)) & ((1u << MAXSEL) - 1u));
+                s_prev[i] = prev;
+                s_ptr[i] = (unsigned long long)(uintptr_t)slab_ptrs[s];
+                if (valid && new_len) new_len[s] = prev + n;
+            }
+        }
+    }
+    __syncthreads();
+    const unsigned total = (unsigned)(outer * chunks_per_row), cpr = (unsigned)chunks_per_row;
+#pragma unroll 1
+    for (int i = 0; i < KS; ++i) {
+        const unsigned move = __builtin_amdgcn_readfirstlane(s_move[i]);
+        if (move == 0u) continue;
+        gvec_t *base = (gvec_t *)(uintptr_t)s_ptr[i];
+        const long long prev = s_prev[i];
+        int src[MAXSEL];
+#pragma unroll
+        for (int t = 0; t < MAXSEL; ++t) src[t] = s_src[i][t];
+        for (unsigned w0 = tid; w0 < total; w0 += 2 * NT) {
+            u32x4_t v[2][MAXSEL];
+            gvec_t *rowbase[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const unsigned w = w0 + u * NT;
+                const unsigned o = w / cpr, c = w - o * cpr;
+                rowbase[u] = base + (size_t)o * S_max * cpr + c;
+                if (w < total) {
+#pragma unroll
+                    for (int t = 0; t < MAXSEL; ++t)
+                        if ((move >> t) & 1u) v[u][t] = __builtin_nontemporal_load(&rowbase[u][(size_t)src[t] * cpr]);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const unsigned w = w0 + u * NT;
+                if (w < total) {
+#pragma unroll
+                    for (int t = 0; t < MAXSEL; ++t)
+                        if ((move >> t) & 1u) __builtin_nontemporal_store(v[u][t], &rowbase[u][(size_t)(prev + t) * cpr]);
+                }
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------------ O10
 // models/ea_model_lumina_mgpt.py:748-750,773-785.
 // Copy-only form (no bonus-token draw: the windowed evaluate_posterior draws it): one workgroup per (sequence, cond/uncond,

@@ -111,6 +111,29 @@ __global__ __launch_bounds__(256) void update_inputs_kernel(void *const *__restr
     }
 }
 
+// the same with KS slabs per workgroup (kv_gather_slabs): blockIdx.x < ceil(n_slabs / KS) moves KV rows, the workgroups above carry the hidden copy
+template <int MAXSEL, int KS>
+__global__ __launch_bounds__(256) void update_inputs_slabs_kernel(void *const *__restrict__ slab_ptrs, const int32_t *__restrict__ slab_seq,
+                                                                  const int64_t *__restrict__ slab_prev, int n_slabs, int64_t outer,
+                                                                  int64_t S_max, int chunks_per_row, const int64_t *__restrict__ retrieve,
+                                                                  int retrieve_per_seq, int P, int D, const int32_t *__restrict__ best,
+                                                                  const int32_t *__restrict__ accept_len, int64_t *__restrict__ new_len,
+                                                                  const uint4 *__restrict__ hidden, int B, int G, int N, int hid_cpr,
+                                                                  const int64_t *__restrict__ cand, uint4 *__restrict__ out_hidden,
+                                                                  int64_t *__restrict__ accepted_tokens, const int32_t *__restrict__ counters) {
+    const int n_kv = (n_slabs + KS - 1) / KS;
+    if ((int)blockIdx.x < n_kv) {
+        kv_gather_slabs<MAXSEL, KS, 256>((int)blockIdx.x * KS, n_slabs, slab_ptrs, slab_seq, slab_prev, outer, S_max, chunks_per_row, retrieve,
+                                         retrieve_per_seq, P, D, best, accept_len, new_len, counters);
+    } else {
+        const int lin = (int)blockIdx.x - n_kv;
+        const int per_seq = G * D;
+        if (lin < B * per_seq)
+            accept_copy_body(lin % per_seq, lin / per_seq, hidden, G, N, hid_cpr, retrieve, retrieve_per_seq, P, D, cand, best, accept_len,
+                             out_hidden, accepted_tokens, counters);
+    }
+}
+
 constexpr int AG_THREADS = 1024;
 constexpr int AG_NW = AG_THREADS / 64;
 
@@ -408,6 +431,25 @@ int lantern::launch_update_inference_inputs(void *const *slab_ptrs, const int32_
     const int cpr = (int)(d * elem_bytes / 16);
     const int64_t total = outer * cpr;
     LANTERN_CHECK_ARG(total < (1ll << 31), "update_inference_inputs: outer * row chunks = %lld does not fit 31 bits", (long long)total);
+    LANTERN_CHECK_ARG(S_max < (1ll << 31), "update_inference_inputs: S_max = %lld does not fit 31 bits", (long long)S_max);
+    static const int ks_knob = getenv("LANTERN_KV_KS") ? atoi(getenv("LANTERN_KV_KS")) : 4;   // tuning knob (diagnostic): slabs per workgroup, 0 = one workgroup tile per slab
+    if (ks_knob > 0 && total <= 4096) {
+        // small slabs (the 7B geometry: 32 heads x 16 chunks): a workgroup covers whole slabs, KS of them
+        const int g = hidden ? G : 1;
+        const int ks = ks_knob >= 8 ? 8 : (ks_knob >= 4 ? 4 : (ks_knob >= 2 ? 2 : 1));
+        const int gridx = (n_slabs + ks - 1) / ks + B * g * D;
+#define UIS_LAUNCH(KS_)                                                                                                                  \
+    LANTERN_LAUNCH((update_inputs_slabs_kernel<8, KS_>), dim3(gridx), dim3(256), 0, (hipStream_t)stream, slab_ptrs, slab_seq, slab_prev,  \
+                   n_slabs, outer, S_max, cpr, retrieve, retrieve_per_seq, P, D, best, accept_len, new_len, (const uint4 *)hidden, B, g, N, \
+                   hidden ? H * hid_elem_bytes / 16 : 0, cand, (uint4 *)out_hidden, accepted_tokens, counters)
+        if (ks == 8) UIS_LAUNCH(8);
+        else if (ks == 4) UIS_LAUNCH(4);
+        else if (ks == 2) UIS_LAUNCH(2);
+        else UIS_LAUNCH(1);
+#undef UIS_LAUNCH
+        LANTERN_CHECK_LAUNCH("update_inference_inputs");
+        return LANTERN_OK;
+    }
     static const int variant = getenv("LANTERN_KV_VARIANT") ? atoi(getenv("LANTERN_KV_VARIANT")) : 0;   // tuning knob (diagnostic): 10*U + mode
     const int uu = variant / 10 ? variant / 10 : 2, mode = variant % 10;
     int gx = (int)((total + uu * 256 - 1) / (uu * 256));

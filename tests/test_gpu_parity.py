@@ -297,6 +297,38 @@ def test_update_inference_inputs_fused_equals_separate_ops():
         assert t_b[b, :n].tolist() == cand[b, best[b], :n].tolist() and (t_b[b, n:] == -1).all()
 
 
+@pytest.mark.parametrize("shape,n_slabs", [((4, 1, 8, 80, 128), 1), ((4, 1, 8, 80, 128), 5), ((4, 1, 8, 80, 128), 11), ((2, 1, 3, 70, 64), 7),
+                                           ((24, 1, 16, 40, 128), 3)])
+def test_update_inference_inputs_slab_blocks_vs_oracle(shape, n_slabs):
+    """The commit with several small slabs per workgroup (slab counts that do not fill the last block, slabs of odd sizes) and, last case, slabs
+    too big for it (one workgroup tile per slab piece): every path of the tree somewhere, accept lengths 0 .. depth-1, against the oracle's move."""
+    rs = np.random.RandomState(n_slabs + shape[0])
+    tb = oracle.tree_static_build(CS.mc_sim_7b_63)
+    ret = tb["retrieve_indices"]
+    P, D = ret.shape
+    N = len(tb["tree_indices"])
+    B = n_slabs
+    depth = (ret >= 0).sum(1)
+    slabs_np = [rs.randint(0, 65535, size=shape).astype(np.uint16) for _ in range(n_slabs)]
+    slabs = [dev(s.view(np.int16)) for s in slabs_np]
+    best = rs.randint(0, P, size=B).astype(np.int32)
+    alen = np.array([rs.randint(0, depth[b]) for b in best], np.int32)
+    seq = rs.permutation(n_slabs).astype(np.int32)
+    prev = rs.randint(0, shape[-2] - N - 1, size=n_slabs).astype(np.int64)
+    hidden = torch.randn(B, 2, N, 64, device="cuda").to(torch.bfloat16)
+    cand = rs.randint(0, 8192, size=(B, P, D)).astype(np.int64)
+    nl, h, t = ops.update_inference_inputs(slabs, dev(seq), dev(prev), dev(ret), dev(best), dev(alen), hidden, dev(cand))
+    for s in range(n_slabs):
+        b = seq[s]
+        exp = oracle.kv_gather(slabs_np[s].copy(), ret[best[b]], int(alen[b]) + 1, int(prev[s]))
+        assert np.array_equal(slabs[s].cpu().numpy().view(np.uint16), exp), s
+        assert int(nl[s]) == prev[s] + alen[b] + 1
+    for b in range(B):
+        n = int(alen[b]) + 1
+        assert torch.equal(h[b, :, :n], hidden[b][:, torch.as_tensor(ret[best[b], :n]).cuda()]) and not h[b, :, n:].any()
+        assert t[b, :n].tolist() == cand[b, best[b], :n].tolist() and (t[b, n:] == -1).all()
+
+
 @pytest.mark.parametrize("i", [i for i, s in enumerate(SPECS) if s["kind"] in ("dynamic", "greedy")][::3])
 def test_dynamic_tree_golden(i):
     spec, case = SPECS[i], H.ep_case(i)

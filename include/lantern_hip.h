@@ -504,6 +504,12 @@ int lantern_linear_rows(const void *A, const void *W, const void *bias, int M, i
 #define LANTERN_EPI_SILU_MUL 2
 int lantern_linear_rows_epilogue(const void *A, const void *W, const void *bias, int M, int K, int row_lo, int n_rows, void *out,
                                  int out_stride, int out_col0, int epilogue, const void *aux, int aux_stride, int pair_rows, void *stream);
+/* The same products for ANY number of rows on a weight packed by lantern_pack_linear_weight (the layout the stream-K kernels read; a gate / up pair
+ * packed with pair_rows = rows of the gate half) -- the drafter's prompt prefill, where the layer sees hundreds of rows at once
+ * (cnets_lumina_mgpt.py:1066-1098, first call of topK_generate).  epilogue 0 (bias only), LANTERN_EPI_RESIDUAL, LANTERN_EPI_SILU_MUL;
+ * out [dev] [M, out_stride >= n_rows] bf16; K % 64 == 0.  Row blocks of 128 (64 for the gate / up pair) re-stream the weight tile. */
+int lantern_linear_rows_packed(const void *A, const void *W_packed, const void *bias, int M, int K, int n_rows, void *out, int out_stride,
+                               int epilogue, const void *aux, int aux_stride, int pair_rows, void *stream);
 /* The same product for narrow outputs, K split over `ksplit` workgroups per 32-column tile (o_proj / down_proj have 128 tiles for 256 CUs):
  * out = bf16(A W^T + bias) (+ residual, rounded again); workspace [dev] ksplit * M * n_rows floats; two launches, deterministic sums. */
 int lantern_linear_rows_splitk(const void *A, const void *W, const void *bias, int M, int K, int n_rows, void *out, int out_stride,

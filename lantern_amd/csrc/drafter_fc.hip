@@ -912,6 +912,136 @@ __global__ __launch_bounds__(FC_THREADS) void linear_rows_streamk_kernel(const S
     }
 }
 
+// The same products for ANY number of rows (the drafter's prompt prefill: hundreds to a few thousand rows) on the PACKED weights the decoder layer
+// keeps for the stream-K kernels: workgroup (tile, row block) contracts MT x 32 rows with the tile's 32 columns (EPI 2: and the paired 32), the
+// eight waves take the tile's 64-element K bricks round-robin (a wave's load = 1 KB contiguous), the next brick's weights are requested before the
+// current brick's MFMAs, the K slices meet in LDS in wave order (deterministic f32 sums).  A weight tile is streamed once per row block: from HBM
+// for the first, from the Infinity Cache for the others (the largest matrix, 180 MB, fits it).  Epilogues as everywhere in this file.
+template <int MT, int EPI>
+__global__ __launch_bounds__(FC_THREADS) void linear_rows_packed_kernel(const uint16_t *__restrict__ A, const uint16_t *__restrict__ Wp,
+                                                                        const uint16_t *__restrict__ bias, int M, int K, int n_rows,
+                                                                        uint16_t *__restrict__ out, int out_stride, const uint16_t *__restrict__ aux,
+                                                                        int aux_stride, int pair_rows) {
+    constexpr int NSET = EPI == 2 ? 2 : 1;
+    __shared__ float tile[NSET][MT][32][33];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int t = blockIdx.x, n0 = t * 32, m0 = blockIdx.y * (MT * 32);
+    for (int i = tid; i < NSET * MT * 32 * 33; i += FC_THREADS) (&tile[0][0][0][0])[i] = 0.0f;
+    const uint16_t *arow[MT];
+    bool live[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const int row = m0 + mt * 32 + r;
+        live[mt] = row < M;
+        arow[mt] = A + (size_t)(live[mt] ? row : 0) * K + 32 * h;
+    }
+    f32x16_t acc[NSET][MT];
+#pragma unroll
+    for (int s_ = 0; s_ < NSET; ++s_)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[s_][mt][i] = 0.0f;
+    const bf16x8_t zero = __builtin_bit_cast(bf16x8_t, make_uint4(0, 0, 0, 0));
+    const int nb = K / 64;
+    const uint16_t *tbase = Wp + (size_t)t * nb * NSET * 2048 + lane * 8;
+    bf16x8_t wb[2][NSET][4];
+    auto load_w = [&](int kb, bf16x8_t (&wv)[NSET][4]) {
+        const uint16_t *brick = tbase + (size_t)kb * NSET * 2048;
+#pragma unroll
+        for (int s_ = 0; s_ < NSET; ++s_)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) wv[s_][q] = load_frag(brick + s_ * 2048 + q * 512);
+    };
+    auto step = [&](int kb, const bf16x8_t (&wv)[NSET][4]) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            bf16x8_t aw[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) aw[q] = live[mt] ? load_frag(arow[mt] + kb * 64 + 8 * q) : zero;
+#pragma unroll
+            for (int s_ = 0; s_ < NSET; ++s_)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[s_][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aw[q], wv[s_][q], acc[s_][mt], 0, 0, 0);
+        }
+    };
+    int kb = wave;
+    if (kb < nb) load_w(kb, wb[0]);
+    while (kb < nb) {
+        if (kb + FC_WAVES < nb) load_w(kb + FC_WAVES, wb[1]);
+        step(kb, wb[0]);
+        kb += FC_WAVES;
+        if (kb >= nb) break;
+        if (kb + FC_WAVES < nb) load_w(kb + FC_WAVES, wb[0]);
+        step(kb, wb[1]);
+        kb += FC_WAVES;
+    }
+    for (int w = 0; w < FC_WAVES; ++w) {      // combine the K slices in wave order (deterministic f32 sum)
+        __syncthreads();
+        if (wave == w) {
+#pragma unroll
+            for (int s_ = 0; s_ < NSET; ++s_)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int reg = 0; reg < 16; ++reg) tile[s_][mt][(reg & 3) + 8 * (reg >> 2) + 4 * h][r] += acc[s_][mt][reg];
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < MT * 32 * 32; i += FC_THREADS) {
+        const int mt = i / 1024, row = (i / 32) % 32, col = i % 32;
+        const int m = m0 + mt * 32 + row, n = n0 + col;
+        if (m < M && n < n_rows) {
+            float v = tile[0][mt][row][col];
+            if (bias) v += bf16_bits_to_f32(bias[n]);
+            uint16_t o = f32_to_bf16_rne(v);
+            if constexpr (EPI == 1) o = f32_to_bf16_rne(bf16_bits_to_f32(aux[(size_t)m * aux_stride + n]) + bf16_bits_to_f32(o));
+            if constexpr (EPI == 2) {
+                float u = tile[NSET - 1][mt][row][col];
+                if (bias) u += bf16_bits_to_f32(bias[pair_rows + n]);
+                const float gb = bf16_bits_to_f32(o), ub = bf16_bits_to_f32(f32_to_bf16_rne(u));
+                const float sg = bf16_bits_to_f32(f32_to_bf16_rne(gb / (1.0f + expf(-gb))));
+                o = f32_to_bf16_rne(sg * ub);
+            }
+            out[(size_t)m * out_stride + n] = o;
+        }
+    }
+}
+
+extern "C" int lantern_linear_rows_packed(const void *A, const void *W_packed, const void *bias, int M, int K, int n_rows, void *out, int out_stride,
+                                          int epilogue, const void *aux, int aux_stride, int pair_rows, void *stream) {
+    LANTERN_CHECK_ARG(A && W_packed && out, "linear_rows_packed: null buffer");
+    LANTERN_CHECK_ARG(M >= 0 && K > 0 && K % 64 == 0 && n_rows >= 0 && out_stride >= n_rows, "linear_rows_packed: K=%d must be a multiple of 64, out rows hold n_rows", K);
+    LANTERN_CHECK_ARG(epilogue == 0 || epilogue == LANTERN_EPI_RESIDUAL || epilogue == LANTERN_EPI_SILU_MUL, "linear_rows_packed: epilogue %d", epilogue);
+    if (epilogue == LANTERN_EPI_RESIDUAL) LANTERN_CHECK_ARG(aux && aux_stride >= n_rows, "linear_rows_packed: the residual [M, aux_stride >= n_rows] is missing");
+    if (epilogue == LANTERN_EPI_SILU_MUL) LANTERN_CHECK_ARG(pair_rows > 0, "linear_rows_packed: pair_rows = rows of the gate half of the packed gate / up pair");
+    if (M == 0 || n_rows == 0) return LANTERN_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const uint16_t *a = (const uint16_t *)A, *w = (const uint16_t *)W_packed, *bi = (const uint16_t *)bias, *ax = (const uint16_t *)aux;
+    uint16_t *o = (uint16_t *)out;
+    const int tiles = (n_rows + 31) / 32;
+    LANTERN_CHECK_ARG((M + 63) / 64 <= 65535, "linear_rows_packed: M=%d rows exceed the launch grid", M);
+#define LRP_LAUNCH(MT_, E_)                                                                                                                         \
+    LANTERN_LAUNCH((linear_rows_packed_kernel<MT_, E_>), dim3(tiles, (M + MT_ * 32 - 1) / (MT_ * 32)), dim3(FC_THREADS), 0, st, a, w, bi, M, K, n_rows, o, \
+                   out_stride, ax, aux_stride, epilogue == LANTERN_EPI_SILU_MUL ? pair_rows : 0)
+    if (epilogue == LANTERN_EPI_SILU_MUL) {
+        if (M <= 32) LRP_LAUNCH(1, 2);
+        else LRP_LAUNCH(2, 2);
+    } else if (epilogue == LANTERN_EPI_RESIDUAL) {
+        if (M <= 32) LRP_LAUNCH(1, 1);
+        else if (M <= 64) LRP_LAUNCH(2, 1);
+        else LRP_LAUNCH(4, 1);
+    } else {
+        if (M <= 32) LRP_LAUNCH(1, 0);
+        else if (M <= 64) LRP_LAUNCH(2, 0);
+        else LRP_LAUNCH(4, 0);
+    }
+#undef LRP_LAUNCH
+    LANTERN_CHECK_LAUNCH("linear_rows_packed");
+    return LANTERN_OK;
+}
+
 // workgroups of a launch: one per CU of the current device (the register buffers of the trips in flight leave room for one 512-thread
 // workgroup per CU).  LANTERN_SK_GROUPS overrides it -- a diagnostic knob for tuning runs, read once per process.
 static int sk_groups(int) {

@@ -38,6 +38,44 @@ def skinny_linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Te
     return F.linear(x, weight, bias)
 
 
+def _mm(A, weight, epilogue: int = 0, **kw):
+    """The layer's GEMMs on the packed weights: the stream-K kernel at the drafting shape (<= 32 rows), the row-blocked one for prefills."""
+    if A.shape[0] <= 32:
+        return ops.linear_rows_streamk(A, weight, epilogue, **kw)
+    kw.pop("pair_rows", None)
+    return ops.linear_rows_packed(A, weight, epilogue, **kw)
+
+
+_CAUSAL_WORDS = {}
+
+
+def causal_block_attention(q, k, v, kv_start, past: int):
+    """Causal attention of T new tokens behind `past` cached ones under left padding, on lantern_tree_attention: q [B, nq, T, d] (the head stage's
+    layout), k / v [B, nk, >= past + T, d] with the new keys already in place; query i of row b sees keys kv_start[b] .. past + i (and always
+    itself: a query inside the padding keeps a finite row, as the reference's additive mask leaves it).  Blocks of <= 64 queries: a block's own
+    keys are its "tree" keys with lower-triangular ancestor words, everything in front of the block is the visible prefix.  -> [B, T, nq * d]."""
+    B, nq, T, d = q.shape
+    dev = q.device
+    qn = q.transpose(1, 2)
+    out = torch.empty((B, T, nq * d), dtype=q.dtype, device=dev)
+    ks = torch.zeros(B, dtype=torch.int64, device=dev) if kv_start is None else kv_start.to(device=dev, dtype=torch.int64)
+    one = torch.ones((), dtype=torch.int64, device=dev)
+    for b0 in range(0, T, 64):
+        n = min(64, T - b0)
+        p0 = past + b0
+        words = _CAUSAL_WORDS.get((n, dev))
+        if words is None:
+            i = torch.arange(n, dtype=torch.int64, device=dev)
+            tri = torch.where(i >= 63, -one, (one << (i + 1).clamp(max=63)) - 1)
+            words = _CAUSAL_WORDS[(n, dev)] = (tri, one << i)
+        tri, diag = words
+        npad = (ks - p0).clamp(0, 64)
+        padw = torch.where(npad >= 64, -one, (one << npad.clamp(max=63)) - 1)
+        bits = (tri[None] & ~padw[:, None]) | diag[None]
+        ops.tree_attention(qn[:, b0:b0 + n], k, v, bits, kv_start=ks, max_kv_len=p0 + n, out=out[:, b0:b0 + n])
+    return out
+
+
 class RMSNorm(nn.Module):
     """cnets_lumina_mgpt.py:209-223 (statistics in f32, the weight applied in the input dtype)."""
 
@@ -248,7 +286,7 @@ class DecoderLayer(nn.Module):
         self.repack()
         return super()._load_from_state_dict(*a, **k)
 
-    def _fast(self, x, attention_mask, position_ids, past_key_value, use_cache, tree_bits=None, tree_keys=0, kv_start=None):
+    def _fast(self, x, attention_mask, position_ids, past_key_value, use_cache, tree_bits=None, tree_keys=0, kv_start=None, causal=False):
         """Decode shape on the device (<= 32 bf16 rows): rmsnorm, fused q/k/v GEMM, head norm + rotary (+ cache append), one attention call,
         o_proj + residual, rmsnorm, gate/up GEMM with silu * up in its epilogue, down_proj + residual -- the four GEMMs in stream-K form
         (lantern_linear_rows_streamk: one launch each, the weight split into equal contiguous shares over 2 workgroups per CU).
@@ -260,7 +298,7 @@ class DecoderLayer(nn.Module):
         x2 = x.reshape(B * T, H)
         xn = ops.rmsnorm_rows(x2, self.input_layernorm.weight, self.input_layernorm.variance_epsilon)
         wq, b = self._packed_fused("qkv", (at.q_proj, at.k_proj, at.v_proj))
-        qkv = ops.linear_rows_streamk(xn, wq, bias=b)          # stream-K: every workgroup streams an equal, contiguous share of the weight
+        qkv = _mm(xn, wq, bias=b)          # stream-K: every workgroup streams an equal, contiguous share of the weight (prefills: row blocks)
         kv_len = T + (past_key_value[0].shape[-2] if past_key_value is not None else 0)
         cos, sin = at.rotary_emb.tables_bf16(x.device, kv_len)
         past = 0 if past_key_value is None else past_key_value[0].shape[-2]
@@ -287,21 +325,28 @@ class DecoderLayer(nn.Module):
             else:
                 qp = qn
             o = ops.tree_attention(qp, k, v, tree_bits, kv_start=kv_start, max_kv_len=kv_len)[:, t1 - T:].reshape(B * T, H)
+        elif causal:
+            # a prefill: causal among the new tokens behind the left padding, block by block on the same kernel (no [T, S] mask, no eager softmax)
+            o = causal_block_attention(q, k, v, kv_start, past).reshape(B * T, H)
         else:
             # (the additive-mask form: prefills inside the decode shape, callers without a tree block)
             m = None if attention_mask is None else attention_mask[:, :, :, :kv_len].to(q.dtype)
             o = F.scaled_dot_product_attention(q, k, v, attn_mask=m, enable_gqa=nk != nq).transpose(1, 2).reshape(B * T, H)
-        h1 = ops.linear_rows_streamk(o, self._packed("o", at.o_proj.weight), ops.EPI_RESIDUAL, bias=at.o_proj.bias, residual=x2)
+        h1 = _mm(o, self._packed("o", at.o_proj.weight), ops.EPI_RESIDUAL, bias=at.o_proj.bias, residual=x2)
         hn = ops.rmsnorm_rows(h1, self.post_attention_layernorm.weight, self.post_attention_layernorm.variance_epsilon)
         inter = mlp.gate_proj.out_features
         wg, bg = self._packed_fused("gate_up", (mlp.gate_proj, mlp.up_proj), inter)
-        act = ops.linear_rows_streamk(hn, wg, ops.EPI_SILU_MUL, bias=bg, pair_rows=inter)
-        out = ops.linear_rows_streamk(act, self._packed("down", mlp.down_proj.weight), ops.EPI_RESIDUAL, bias=mlp.down_proj.bias, residual=h1)
+        act = _mm(hn, wg, ops.EPI_SILU_MUL, bias=bg, pair_rows=inter)
+        out = _mm(act, self._packed("down", mlp.down_proj.weight), ops.EPI_RESIDUAL, bias=mlp.down_proj.bias, residual=h1)
         return out.reshape(B, T, H), present
 
-    def _fast_ok(self, x, position_ids, output_attentions):
+    def _fast_ok(self, x, position_ids, output_attentions, causal=False):
         at = self.self_attn
-        return (self.fused and not output_attentions and x.dim() == 3 and x.shape[0] * x.shape[1] <= 32 and _hip_ok(x, at.q_proj.weight)
+        rows = x.shape[0] * x.shape[1] if x.dim() == 3 else 0
+        # (more than 32 rows = a prefill: the row-blocked GEMM on the packed weights and the block-causal attention, when the caller says the mask
+        # is causal + left padding -- cnets.Model.forward does)
+        shape_ok = rows <= 32 or (causal and x.shape[-1] % 64 == 0 and self.mlp.gate_proj.out_features % 64 == 0)
+        return (self.fused and not output_attentions and x.dim() == 3 and shape_ok and _hip_ok(x, at.q_proj.weight)
                 and at.head_dim in (64, 128) and position_ids is not None and self.mlp.act_fn is F.silu
                 and self.input_layernorm.weight.dtype == torch.bfloat16 and at.q_norm.weight.dtype == torch.bfloat16)
 
@@ -329,7 +374,7 @@ class DecoderLayer(nn.Module):
     supports_tree_bits = True      # Model.forward hands the tree block over as ancestor words (tree_bits / tree_keys / kv_start) when it has one
 
     def forward(self, hidden_states, attention_mask=None, position_ids=None, past_key_value=None, output_attentions=False, use_cache=False,
-                tree_bits=None, tree_keys=0, kv_start=None, **kw) -> Tuple[torch.Tensor, ...]:
+                tree_bits=None, tree_keys=0, kv_start=None, causal=False, **kw) -> Tuple[torch.Tensor, ...]:
         if (self.fused and not output_attentions and hidden_states.dim() == 3 and hidden_states.is_cuda and hidden_states.dtype == torch.bfloat16
                 and hidden_states.shape[0] * hidden_states.shape[1] <= 32 and _hip_ok(hidden_states, self.self_attn.q_proj.weight)
                 and not self._fast_ok(hidden_states, position_ids, output_attentions)):
@@ -339,10 +384,11 @@ class DecoderLayer(nn.Module):
                 f"DecoderLayer: the drafting shape ({tuple(hidden_states.shape)}, bf16, device) takes the fused HIP path, which needs head_dim 64 or 128 "
                 f"(got {at.head_dim}), silu, bf16 weights / norms, hidden % 16 == 0 and position_ids; set `layer.fused = False` for the per-projection "
                 "path (skinny GEMM under torch's element-wise ops)")
-        if self._fast_ok(hidden_states, position_ids, output_attentions):
+        if self._fast_ok(hidden_states, position_ids, output_attentions, causal):
             if tree_bits is not None and not (0 < hidden_states.shape[1] <= tree_keys <= 64):
                 tree_bits = None
-            y, present = self._fast(hidden_states, attention_mask, position_ids, past_key_value, use_cache, tree_bits, tree_keys, kv_start)
+            y, present = self._fast(hidden_states, attention_mask, position_ids, past_key_value, use_cache, tree_bits, tree_keys, kv_start,
+                                    causal and tree_bits is None)
             return (y, present) if use_cache else (y,)
         a, w, present = self.self_attn(self.input_layernorm(hidden_states), attention_mask=attention_mask, position_ids=position_ids,
                                        past_key_value=past_key_value, output_attentions=output_attentions, use_cache=use_cache)
@@ -441,20 +487,22 @@ class LlamaDecoderLayer(DecoderLayer):
             self.input_layernorm = RMSNorm(config.hidden_size, eps)
         self.post_attention_layernorm = RMSNorm(config.hidden_size, eps)
 
-    def _fast_ok(self, x, position_ids, output_attentions, freqs_cis=None):
+    def _fast_ok(self, x, position_ids, output_attentions, freqs_cis=None, causal=False):
         at = self.self_attn
-        return (self.fused and not output_attentions and x.dim() == 3 and x.shape[0] * x.shape[1] <= 32 and _hip_ok(x, at.q_proj.weight)
+        rows = x.shape[0] * x.shape[1] if x.dim() == 3 else 0
+        shape_ok = rows <= 32 or (causal and self.mlp.gate_proj.out_features % 64 == 0)          # > 32 rows: a prefill (see DecoderLayer._fast_ok)
+        return (self.fused and not output_attentions and x.dim() == 3 and shape_ok and _hip_ok(x, at.q_proj.weight)
                 and at.head_dim in (64, 128) and x.shape[-1] % 64 == 0 and freqs_cis is not None and self.mlp.act_fn is F.silu
                 and self.post_attention_layernorm.weight.dtype == torch.bfloat16)
 
-    def _fast(self, x, attention_mask, freqs_cis, past_key_value, use_cache, tree_bits=None, tree_keys=0, kv_start=None):
+    def _fast(self, x, attention_mask, freqs_cis, past_key_value, use_cache, tree_bits=None, tree_keys=0, kv_start=None, causal=False):
         at, mlp = self.self_attn, self.mlp
         B, T, H = x.shape
         nq, nk, d = at.num_heads, at.num_key_value_heads, at.head_dim
         x2 = x.reshape(B * T, H)
         xn = x2 if self.index == 0 else ops.rmsnorm_rows(x2, self.input_layernorm.weight, self.input_layernorm.variance_epsilon)
         wq, b = self._packed_fused("qkv", (at.q_proj, at.k_proj, at.v_proj))
-        qkv = ops.linear_rows_streamk(xn, wq, bias=b)
+        qkv = _mm(xn, wq, bias=b)
         past = 0 if past_key_value is None else past_key_value[0].shape[-2]
         kv_len = T + past
         fr = freqs_cis.reshape(-1, d // 2, 2)                      # the reference hands over the rows of its table at this call's positions: [T, d/2, 2]
@@ -481,23 +529,26 @@ class LlamaDecoderLayer(DecoderLayer):
             else:
                 qp = qn
             o = ops.tree_attention(qp, k, v, tree_bits, kv_start=kv_start, max_kv_len=kv_len)[:, t1 - T:].reshape(B * T, H)
+        elif causal:
+            o = causal_block_attention(q, k, v, kv_start, past).reshape(B * T, H)
         else:
             m = None if attention_mask is None else attention_mask[:, :, :, :kv_len].to(q.dtype)
             o = F.scaled_dot_product_attention(q, k, v, attn_mask=m, enable_gqa=nk != nq).transpose(1, 2).reshape(B * T, H)
-        h1 = ops.linear_rows_streamk(o, self._packed("o", at.o_proj.weight), ops.EPI_RESIDUAL, residual=x2)
+        h1 = _mm(o, self._packed("o", at.o_proj.weight), ops.EPI_RESIDUAL, residual=x2)
         hn = ops.rmsnorm_rows(h1, self.post_attention_layernorm.weight, self.post_attention_layernorm.variance_epsilon)
         inter = mlp.gate_proj.out_features
         wg, bg = self._packed_fused("gate_up", (mlp.gate_proj, mlp.up_proj), inter)
-        act = ops.linear_rows_streamk(hn, wg, ops.EPI_SILU_MUL, bias=bg, pair_rows=inter)
-        out = ops.linear_rows_streamk(act, self._packed("down", mlp.down_proj.weight), ops.EPI_RESIDUAL, bias=mlp.down_proj.bias, residual=h1)
+        act = _mm(hn, wg, ops.EPI_SILU_MUL, bias=bg, pair_rows=inter)
+        out = _mm(act, self._packed("down", mlp.down_proj.weight), ops.EPI_RESIDUAL, bias=mlp.down_proj.bias, residual=h1)
         return out.reshape(B, T, H), present
 
     def forward(self, hidden_states, attention_mask=None, position_ids=None, freqs_cis=None, past_key_value=None, output_attentions=False,
-                use_cache=False, tree_bits=None, tree_keys=0, kv_start=None, **kw) -> Tuple[torch.Tensor, ...]:
-        if self._fast_ok(hidden_states, position_ids, output_attentions, freqs_cis):
+                use_cache=False, tree_bits=None, tree_keys=0, kv_start=None, causal=False, **kw) -> Tuple[torch.Tensor, ...]:
+        if self._fast_ok(hidden_states, position_ids, output_attentions, freqs_cis, causal):
             if tree_bits is not None and not (0 < hidden_states.shape[1] <= tree_keys <= 64):
                 tree_bits = None
-            y, present = self._fast(hidden_states, attention_mask, freqs_cis, past_key_value, use_cache, tree_bits, tree_keys, kv_start)
+            y, present = self._fast(hidden_states, attention_mask, freqs_cis, past_key_value, use_cache, tree_bits, tree_keys, kv_start,
+                                    causal and tree_bits is None)
             return (y, present) if use_cache else (y,)
         if (self.fused and not output_attentions and hidden_states.dim() == 3 and hidden_states.is_cuda and hidden_states.dtype == torch.bfloat16
                 and hidden_states.shape[0] * hidden_states.shape[1] <= 32 and _hip_ok(hidden_states, self.self_attn.q_proj.weight)):

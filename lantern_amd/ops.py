@@ -726,6 +726,26 @@ def linear_rows_streamk(A, weight, epilogue: int = 0, n_rows: Optional[int] = No
     return out
 
 
+def linear_rows_packed(A, weight: "PackedLinearWeight", epilogue: int = 0, bias=None, residual=None):
+    """A [M, K] bf16 (ANY number of rows: the drafter's prompt prefill) @ the packed weight, epilogues as linear_rows_streamk
+    (lantern_linear_rows_packed: row blocks of 128 -- 64 for a gate / up pair -- re-stream the weight tile)."""
+    if not isinstance(weight, PackedLinearWeight):
+        raise _lib.LanternError("linear_rows_packed: weight must be a PackedLinearWeight (pack_linear_weight)")
+    if not A.is_cuda or A.dtype != torch.bfloat16:
+        raise _lib.LanternError("linear_rows_packed: A must be a bf16 device tensor")
+    A = A.contiguous()
+    M, K = A.shape
+    if K != weight.K or (epilogue == EPI_SILU_MUL) != (weight.pair_rows > 0):
+        raise _lib.LanternError("linear_rows_packed: the packed weight does not match this call (K, gate / up pairing)")
+    out = torch.empty((M, weight.n_rows), dtype=torch.bfloat16, device=A.device)
+    r = None if residual is None else residual.contiguous()
+    b = None if bias is None else bias.contiguous()
+    check(_lib.lib().lantern_linear_rows_packed(C.c_void_p(A.data_ptr()), C.c_void_p(weight.data.data_ptr()), C.c_void_p(_ptr(b)), M, K, weight.n_rows,
+                                                C.c_void_p(out.data_ptr()), weight.n_rows, int(epilogue), C.c_void_p(_ptr(r)), 0 if r is None else r.shape[1],
+                                                int(weight.pair_rows), _stream()), "linear_rows_packed")
+    return out
+
+
 def rmsnorm_rows(x, weight, eps: float):
     """ChameleonRMSNorm of bf16 rows [M, H] (lantern_rmsnorm_rows)."""
     x, weight = x.contiguous(), weight.contiguous()

@@ -380,3 +380,102 @@ def test_llamagen_and_anole_layers_hip_path_match_the_reference_layers_bf16(name
     assert second.count("rmsnorm_rows") == n_norm, second
     for got, key in ((y0, "y0"), (y1, "y1"), (kv1[0], "k1"), (kv1[1], "v1")):
         np.testing.assert_allclose(got.float().cpu().numpy(), GOLD_LG[name + "." + key], rtol=4e-2, atol=4e-2)
+
+
+# ----------------------------------------------------------------------------- prefills: any number of rows on the packed weights
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,K,N,epi", [(300, 4096, 4096, 0), (129, 1024, 352, 1), (1200, 1280, 3584, 2), (33, 64, 40, 0), (65, 11008, 96, 1), (64, 256, 64, 2),
+                                       (20, 512, 70, 2), (1, 64, 1, 0)])
+def test_packed_gemm_of_any_row_count_matches_f64_and_the_streamk_kernel(M, K, N, epi):
+    """lantern_linear_rows_packed (row blocks of 128 / 64 over the packed bricks: the prompt prefill of the drafter's layer) against the exact
+    product in f64 (2e-2 of the row scale, as the stream-K test) and -- where both apply, <= 32 rows -- bit-identical roundings to within one bf16
+    ulp of lantern_linear_rows_streamk; ragged row blocks and column tiles."""
+    from lantern_amd import ops
+    dev, bf = torch.device("cuda"), torch.bfloat16
+    gen = torch.Generator(device="cuda").manual_seed(M * 7 + K + N + epi)
+    x = torch.randn(M, K, device=dev, dtype=bf, generator=gen)
+    rows = 2 * N if epi == 2 else N
+    w = (torch.randn(rows, K, device=dev, generator=gen) / K ** 0.5).to(bf)
+    b = (0.1 * torch.randn(rows, device=dev, generator=gen)).to(bf)
+    res = torch.randn(M, N, device=dev, dtype=bf, generator=gen)
+    xd, wd, bd = x.double(), w.double(), b.double()
+    if epi == 0:
+        want, kw = xd @ wd.T + bd, {}
+    elif epi == 1:
+        want, kw = (xd @ wd.T + bd) + res.double(), dict(residual=res)
+    else:
+        want, kw = torch.nn.functional.silu(xd @ wd[:N].T + bd[:N]) * (xd @ wd[N:].T + bd[N:]), {}
+    pk = ops.pack_linear_weight(w, N if epi == 2 else 0)
+    got = ops.linear_rows_packed(x, pk, epi, bias=b, **kw)
+    assert got.shape == (M, N)
+    scale = want.abs().max().item()
+    assert (got.double() - want).abs().max().item() <= 2e-2 * scale
+    assert torch.equal(ops.linear_rows_packed(x, pk, epi, bias=b, **kw), got)
+    if M <= 32:
+        sk = ops.linear_rows_streamk(x, pk, epi, bias=b, **dict(kw, **(dict(pair_rows=N) if epi == 2 else {})))
+        assert (got.float() - sk.float()).abs().max().item() <= 2e-2 * scale
+
+
+def _causal_additive(T0, past, starts, device):
+    """[B, 1, T0, past + T0] additive mask: causal among the new tokens, keys in front of starts[b] hidden, the diagonal always open."""
+    fmin = torch.finfo(torch.float32).min
+    B, S = len(starts), past + T0
+    q = torch.arange(T0, device=device)[:, None] + past
+    k = torch.arange(S, device=device)[None]
+    m = torch.zeros(B, 1, T0, S, device=device)
+    for b, st in enumerate(starts):
+        vis = (k <= q) & ((k >= st) | (k == q))
+        m[b, 0] = torch.where(vis, 0.0, fmin)
+    return m
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,name", [("lumina", "hd128"), ("lumina", "hd64_gqa"), ("anole", "an_hd64"), ("anole", "an_hd128"), ("llamagen", "lg_hd64"), ("llamagen", "lg_hd64_idx1"),
+                                       ("llamagen", "lg_hd128")])
+def test_layer_prefill_runs_on_the_hip_path_and_matches_the_torch_path(kind, name, monkeypatch):
+    """A prompt prefill (2 x 150 rows, the second row left-padded by 5, then 2 x 70 more rows behind that cache): with the `causal` hint of
+    cnets.Model.forward the layer stays on the HIP kernels -- lantern_linear_rows_packed for the four GEMMs, the head stage, lantern_tree_attention
+    block by block -- and agrees with the same layer's torch path in f32 under the equivalent additive mask (4e-2 + 4e-2 relative, the layer tests'
+    bf16 tolerance) on every row that is not padding; the caches agree too."""
+    import torch.nn.functional as F
+    from lantern_amd import ops
+    from lantern_amd.drafters.decoder_layer import precompute_freqs_cis_2d
+    dev, bf = torch.device("cuda"), torch.bfloat16
+    mk = {"lumina": build, "anole": build_an, "llamagen": build_lg}[kind]
+    hip, ref = mk(name, dev, bf), mk(name, dev, torch.float32)
+    ref.fused = False
+    H, d = hip.self_attn.hidden_size, hip.self_attn.head_dim
+    T0, T1, starts = 150, 70, [0, 5]
+    gen = torch.Generator(device="cuda").manual_seed(len(name) + T0)
+    x0, x1 = (torch.randn(2, T, H, device=dev, generator=gen).to(bf) for T in (T0, T1))
+    if kind == "llamagen":
+        table = precompute_freqs_cis_2d(16, d, 10000, 20).to(dev)
+        pos0, pos1 = torch.arange(T0, device=dev)[None], torch.arange(T0, T0 + T1, device=dev)[None]
+        kw0, kw1 = dict(freqs_cis=table[pos0[0]]), dict(freqs_cis=table[pos1[0]])
+    else:
+        st = torch.tensor(starts, device=dev)[:, None]
+        pos0 = (torch.arange(T0, device=dev)[None] - st).clamp(min=0)
+        pos1 = torch.arange(T0, T0 + T1, device=dev)[None] - st
+        kw0 = kw1 = {}
+    calls = []
+    for fn in ("linear_rows_packed", "linear_rows_streamk", "tree_attention"):
+        real = getattr(ops, fn)
+        monkeypatch.setattr(ops, fn, (lambda real, fn: (lambda *a, **k_: (calls.append(fn), real(*a, **k_))[1]))(real, fn))
+    real_sdpa = F.scaled_dot_product_attention
+    monkeypatch.setattr(F, "scaled_dot_product_attention", lambda *a, **k_: (calls.append("sdpa"), real_sdpa(*a, **k_))[1])
+    real_lin = F.linear
+    monkeypatch.setattr(F, "linear", lambda *a, **k_: (calls.append("F.linear"), real_lin(*a, **k_))[1])
+    ks = torch.tensor(starts, dtype=torch.int64, device=dev)
+    m0, m1 = _causal_additive(T0, 0, starts, dev), _causal_additive(T1, T0, starts, dev)
+    with torch.no_grad():
+        y0, kv0 = hip(x0, attention_mask=m0, position_ids=pos0, use_cache=True, causal=True, kv_start=ks, **kw0)
+        y1, kv1 = hip(x1, attention_mask=m1, position_ids=pos1, past_key_value=kv0, use_cache=True, causal=True, kv_start=ks, **kw1)
+        assert calls.count("linear_rows_packed") == 8 and calls.count("tree_attention") == 3 + 2 and not {"sdpa", "F.linear", "linear_rows_streamk"} & set(calls), calls
+        calls.clear()
+        r0, rkv0 = ref(x0.float(), attention_mask=m0, position_ids=pos0, use_cache=True, **kw0)
+        r1, rkv1 = ref(x1.float(), attention_mask=m1, position_ids=pos1, past_key_value=rkv0, use_cache=True, **kw1)
+    for b, st in enumerate(starts):
+        np.testing.assert_allclose(y0[b, st:].float().cpu().numpy(), r0[b, st:].cpu().numpy(), rtol=4e-2, atol=4e-2)
+        np.testing.assert_allclose(y1[b].float().cpu().numpy(), r1[b].cpu().numpy(), rtol=4e-2, atol=4e-2)
+        for got, want in zip(kv1, rkv1):
+            np.testing.assert_allclose(got[b, :, st:].float().cpu().numpy(), want[b, :, st:].cpu().numpy(), rtol=4e-2, atol=4e-2)

@@ -454,6 +454,62 @@ def test_default_layers_draft_on_the_hip_path(model_type, V, H, heads, monkeypat
     np.testing.assert_allclose(t_hip.float().cpu().numpy(), t_ref.float().cpu().numpy(), rtol=3e-2, atol=3e-2)
 
 
+@pytest.mark.parametrize("model_type,V,H,heads", [("llamagen", 16384, 128, 2), ("anole", 65536, 256, 4), ("lumina_mgpt", 65536, 256, 2)])
+def test_prompt_prefill_stays_on_the_hip_kernels(model_type, V, H, heads, monkeypatch):
+    """The drafter's first call of a prompt (cnets_lumina_mgpt.py:1066-1098: the whole prompt through the layer, here 2 x 90 rows with the second row
+    left-padded by 7) runs on the library's kernels -- drafter_fc in slices, lantern_linear_rows_packed for the layer's four GEMMs, the head stage,
+    block-causal lantern_tree_attention -- with no F.linear, no scaled_dot_product_attention and no eager softmax; it agrees with the same model
+    on torch's ops on every row that is not padding, and a drafting step behind the cache it leaves agrees too."""
+    import torch.nn.functional as F
+    dev, bf = torch.device("cuda"), torch.bfloat16
+    cfg = types.SimpleNamespace(vocab_size=V, hidden_size=H, pad_token_id=None, num_hidden_layers=1, num_attention_heads=heads, num_key_value_heads=heads,
+                                intermediate_size=2 * H, max_position_embeddings=512, rms_norm_eps=1e-5, model_parallel_size=1, input_type="t2i")
+    torch.manual_seed(11)
+    mdl = cnets.Model(cfg, total_tokens=30, depth=3, top_k=CS.TOPK, model_type=model_type).to(dev).to(bf)
+    mdl.init_tree()
+    T, pad = 90, 7
+    x = torch.randn(2, T, H, device=dev, dtype=bf)
+    iid = torch.randint(4, 8000, (2, T), device=dev)
+    am = torch.ones(2, T, dtype=torch.bool, device=dev)
+    if model_type != "llamagen":
+        am[1, :pad] = False
+    pos = (am.long().cumsum(1) - 1).clamp(min=0) if model_type != "llamagen" else None
+    calls = []
+    for fn in ("linear_rows_packed", "linear_rows_streamk", "tree_attention", "drafter_fc"):
+        real = getattr(ops, fn)
+        monkeypatch.setattr(ops, fn, (lambda real, fn: (lambda *a, **k_: (calls.append(fn), real(*a, **k_))[1]))(real, fn))
+    for mod, fn in ((F, "scaled_dot_product_attention"), (F, "linear"), (F, "softmax"), (torch, "softmax")):
+        real = getattr(mod, fn)
+        monkeypatch.setattr(mod, fn, (lambda real, fn: (lambda *a, **k_: (calls.append("torch." + fn), real(*a, **k_))[1]))(real, fn))
+    mdl.tree_mask = None
+    with torch.no_grad():
+        y_hip, kv = mdl(x, iid, attention_mask=am, position_ids=pos, use_cache=True)
+    assert calls.count("linear_rows_packed") == 4 and calls.count("tree_attention") == 2 and calls.count("drafter_fc") == 2, calls
+    assert not [c for c in calls if c.startswith("torch.") or c == "linear_rows_streamk"], calls
+    # a drafting step behind that cache
+    mdl.tree_mask = mdl.tree_mask_init
+    base = (am.long().sum(1) if model_type != "llamagen" else torch.full((2,), T, device=dev))
+    pos_t = (base[:, None] + mdl.position_ids[None]) if model_type != "llamagen" else T + mdl.position_ids
+    am_t = torch.cat([am, torch.ones(2, CS.TOPK, dtype=torch.bool, device=dev)], dim=1)
+    xt, it = torch.randn(2, CS.TOPK, H, device=dev, dtype=bf), torch.randint(4, 8000, (2, CS.TOPK), device=dev)
+    with torch.no_grad():
+        t_hip, _ = mdl(xt, it, attention_mask=am_t, past_key_values=tuple((k.clone(), v.clone()) for k, v in kv), position_ids=pos_t, use_cache=True)
+    # the same two calls on torch's ops
+    for l in mdl.layers:
+        l.fused = False
+        l.inplace_cache = False
+    monkeypatch.setattr("lantern_amd.drafters.decoder_layer._hip_ok", lambda a, b: False)
+    mdl.tree_mask = None
+    with torch.no_grad():
+        y_ref, kv_ref = mdl(x, iid, attention_mask=am, position_ids=pos, use_cache=True)
+        mdl.tree_mask = mdl.tree_mask_init
+        t_ref, _ = mdl(xt, it, attention_mask=am_t, past_key_values=tuple((k.clone(), v.clone()) for k, v in kv_ref), position_ids=pos_t, use_cache=True)
+    for b in range(2):
+        st = pad if (b == 1 and model_type != "llamagen") else 0
+        np.testing.assert_allclose(y_hip[b, st:].float().cpu().numpy(), y_ref[b, st:].float().cpu().numpy(), rtol=3e-2, atol=3e-2)
+    np.testing.assert_allclose(t_hip.float().cpu().numpy(), t_ref.float().cpu().numpy(), rtol=3e-2, atol=3e-2)
+
+
 @pytest.mark.parametrize("model_type,V,H,heads,depth", [("llamagen", 16384, 128, 2, 4), ("anole", 65536, 256, 4, 4), ("lumina_mgpt", 65536, 256, 2, 5),
                                                         ("lumina_mgpt", 65536, 256, 4, 3)])
 def test_depth_plan_equals_the_python_depth_loop(model_type, V, H, heads, depth, monkeypatch):

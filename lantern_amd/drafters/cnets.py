@@ -433,9 +433,10 @@ class Model(nn.Module):
                 chain = self._chain_bits[(T, hidden_states.device)] = ((torch.ones(T, dtype=torch.int64, device=hidden_states.device) << (torch.arange(T, dtype=torch.int64, device=hidden_states.device) + 1)) - 1)
             extra = dict(extra, tree_bits=chain, tree_keys=T, kv_start=attention_mask.to(hidden_states.device).to(torch.int64).argmax(dim=1))
             have_bits = True
-        elif tm is None and bits_ok and B * T > 32:
-            # a prompt prefill (hundreds of rows): causal among the new tokens behind the left padding -- the HIP layers run their row-blocked GEMMs and
-            # block-causal lantern_tree_attention on this hint (the additive mask still rides along for a layer whose shapes keep it on torch's ops)
+        elif tm is None and bits_ok:
+            # a prompt prefill (a handful to hundreds of rows): causal among the new tokens behind the left padding -- the HIP layers run their GEMMs
+            # (row-blocked above 32 rows) and block-causal lantern_tree_attention on this hint (the additive mask still rides along for a layer whose
+            # shapes keep it on torch's ops)
             extra = dict(extra, causal=True, kv_start=attention_mask.to(hidden_states.device).to(torch.int64).argmax(dim=1))
         # the additive mask only when some layer may still want it (the HIP layers at the drafting shape take the ancestor words)
         fast = have_bits and B * T <= 32 and all(getattr(l, "fused", False) and hasattr(l, "_fast") for l in self.layers)

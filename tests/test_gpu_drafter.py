@@ -430,9 +430,9 @@ def test_default_layers_draft_on_the_hip_path(model_type, V, H, heads, monkeypat
     assert draft.shape == (1, 30) and mask.shape[-1] == 30 and int(ret.max()) < 30
     # the drafting calls: 3 depths x (4 stream-K GEMMs + head stage + tree attention) + the prefill's GEMMs; 4 fused head expansions
     assert calls.count("head_expand") == 4, calls
-    assert calls.count("tree_attention") == 3 and calls.count("qk_rope_pairs" if model_type == "llamagen" else "qk_norm_rope") == 4, calls
+    assert calls.count("tree_attention") == 4 and calls.count("qk_rope_pairs" if model_type == "llamagen" else "qk_norm_rope") == 4, calls
     assert calls.count("linear_rows_streamk") == 16 and calls.count("linear_rows") == 0, calls
-    assert all(not (isinstance(c, tuple) and c[0] == "sdpa" and c[1] == CS.TOPK) for c in calls), calls          # (the 5-token prefill may take SDPA)
+    assert not [c for c in calls if isinstance(c, tuple) and c[0] == "sdpa"], calls          # (the 5-token prefill too: block-causal tree attention)
     # the drafting forward against the same layer on torch's ops
     mdl.reset_kv()
     mdl.tree_mask = None

@@ -362,16 +362,20 @@ def ep_batch_sweep(batches, device, base_cfg, iters=24, kernels=("chain", "nodes
     return out
 
 
+# the sources of the kernels bench.py times (the verify step: candidate assembly / row post-process, evaluate_posterior in its three forms, the KV /
+# hidden commit, the one-call sequencing); the drafter-side files (drafter_fc, draft_depth, tree_attention, vq_table, greedy, tree_static) are not part
+VERIFY_PATH_SOURCES = ("common.h", "window_dev.h", "window_kernels.hip", "node_kernels.hip", "evaluate_posterior.hip", "logits_post.hip", "gather_dev.h",
+                       "gather_ops.hip", "tree_dynamic.hip", "tree_dynamic_dev.h", "verify_step.cpp")
+
+
 def kernel_sources_sha() -> str:
-    """Fingerprint of the kernel sources (lantern_amd/csrc, include/): profiles/*_traffic.json carry the fingerprint they were measured at, and a
-    file measured on other kernels is refused instead of quoted (there is no .git on the GPU box to compare commits with)."""
-    import glob
+    """Fingerprint of the verify path's kernel sources (lantern_amd/csrc/VERIFY_PATH_SOURCES): profiles/*_traffic.json carry the fingerprint they were
+    measured at, and a file measured on other kernels is refused instead of quoted (there is no .git on the GPU box to compare commits with)."""
     import hashlib
     h = hashlib.sha256()
-    for f in sorted(glob.glob(os.path.join(ROOT, "lantern_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "lantern_amd", "csrc", "*.h")) +
-                    glob.glob(os.path.join(ROOT, "lantern_amd", "csrc", "*.cpp")) + glob.glob(os.path.join(ROOT, "include", "*.h"))):
-        h.update(os.path.basename(f).encode())
-        h.update(open(f, "rb").read())
+    for name in VERIFY_PATH_SOURCES:
+        h.update(name.encode())
+        h.update(open(os.path.join(ROOT, "lantern_amd", "csrc", name), "rb").read())
     return h.hexdigest()[:16]
 
 

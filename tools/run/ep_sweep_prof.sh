@@ -16,7 +16,7 @@ run sqa SQ_WAVES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_ACTIVE_I
 run sqb SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SMEM SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS &&
 run sqc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_INSTS_BRANCH SQ_ACTIVE_INST_MISC SQ_INST_CYCLES_SALU SQ_THREAD_CYCLES_VALU SQ_INSTS_LDS_ATOMIC
 {
-  echo "# rocprofv3 passes of tools/ep_sweep.py $BATCHES (evaluate_posterior alone, rotating inputs), LANTERN_EPW_TP=$LANTERN_EPW_TP, commit $(cat $O/commit.txt 2>/dev/null)"
+  echo "# rocprofv3 passes of tools/ep_sweep.py $BATCHES (evaluate_posterior alone, rotating inputs), LANTERN_EPW_TP=$LANTERN_EPW_TP, commit $(cat tools/run/.commit 2>/dev/null)"
   for n in fetch write sqa sqb sqc; do python3 tools/pmc_sum.py $O/$n "epw_kernel"; done
 } > $O/summary.txt
 cat $O/summary.txt

@@ -10,7 +10,7 @@ timeout -k 10 200 rocprofv3 --kernel-trace --pmc $B --output-format csv -d $O/o7
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc $A --output-format csv -d $O/bench_a -o a -- python3 bench.py --gpus 1 --steps 20 --warmup 5 --cpu-seconds 0 --ep-sweep "" --no-extras > $O/bench_a.txt 2>&1 &&
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc $B --output-format csv -d $O/bench_b -o b -- python3 bench.py --gpus 1 --steps 20 --warmup 5 --cpu-seconds 0 --ep-sweep "" --no-extras > $O/bench_b.txt 2>&1
 {
-  echo "# rocprofv3 --pmc SQ counters, per launch (sums over all XCDs / CUs), commit $(cat $O/commit.txt 2>/dev/null)"
+  echo "# rocprofv3 --pmc SQ counters, per launch (sums over all XCDs / CUs), commit $(cat tools/run/.commit 2>/dev/null)"
   echo "## cfg_window_bf16_kernel, 1664 rows (tools/o7_only.py 64)"; python3 tools/pmc_sum.py $O/o7_a cfg_window_bf16; python3 tools/pmc_sum.py $O/o7_b cfg_window_bf16
   for k in "epw_kernel<" prep_rows_kernel update_inputs_kernel; do echo "## $k (bench.py --steps 20 --warmup 5, 3 groups of 21)"; python3 tools/pmc_sum.py $O/bench_a "$k"; python3 tools/pmc_sum.py $O/bench_b "$k"; done
 } > $O/summary.txt

@@ -362,9 +362,10 @@ def ep_batch_sweep(batches, device, base_cfg, iters=24, kernels=("chain", "nodes
     return out
 
 
-# the sources of the kernels bench.py times (the verify step: candidate assembly / row post-process, evaluate_posterior in its three forms, the KV /
-# hidden commit, the one-call sequencing); the drafter-side files (drafter_fc, draft_depth, tree_attention, vq_table, greedy, tree_static) are not part
-VERIFY_PATH_SOURCES = ("common.h", "window_dev.h", "window_kernels.hip", "node_kernels.hip", "evaluate_posterior.hip", "logits_post.hip", "gather_dev.h",
+# the sources of the kernels bench.py times (the verify step: candidate assembly / row post-process, the windowed evaluate_posterior kernels, the KV /
+# hidden commit, the one-call sequencing); the dense evaluate_posterior (evaluate_posterior.hip: never on the timed path) and the drafter-side files
+# (drafter_fc, draft_depth, tree_attention, vq_table, greedy, tree_static) are not part
+VERIFY_PATH_SOURCES = ("common.h", "window_dev.h", "window_kernels.hip", "node_kernels.hip", "logits_post.hip", "gather_dev.h",
                        "gather_ops.hip", "tree_dynamic.hip", "tree_dynamic_dev.h", "verify_step.cpp")
 
 

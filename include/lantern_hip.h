@@ -181,7 +181,7 @@ typedef struct lantern_ep_params {
     int32_t table_rows, table_cols;
     int32_t top_k;           /* per-level HF processors (LlamaGen/Anole): <=0 off */
     float temperature;       /* <=1e-5 or 1 -> off */
-    float top_p;             /* must be off (>=1 or <=0) in this build */
+    float top_p;             /* TopPLogitsWarper in [1e-8, 1) (between temperature and top_k): the dense kernel and LANTERN_ROWS_RAW_BF16; else off */
     double delta;            /* <=1: delta mode; >1: lambda mode, tau = (delta-1)*px */
     int32_t n_uniforms;      /* uniforms per sequence (row stride) */
     int32_t R;               /* orig_prob rows per sequence (static) */

@@ -23,6 +23,7 @@
 // Reference: models/ea_model_lumina_mgpt.py:610-726, models/ea_model_llamagen.py:597-669,
 // :709-787, models/ea_model_anole.py (same lines + image-token offset).
 #include "common.h"
+#include "window_dev.h"          // top_p_tile (TopPLogitsWarper on a register tile)
 
 namespace lantern {
 
@@ -42,6 +43,7 @@ struct EpShared {
     float redf[2 * EP_NW];
     int redi[2 * EP_NW];
     double scan_tot[EP_NW];
+    double mass[256];          // top_p_tile's probability mass per radix bin
     int fi;
 };
 
@@ -68,9 +70,9 @@ __device__ float kth_largest_regs(const float4 (&r)[VI], int k, EpShared &S, int
 
 // softmax(processors(row)) -> g, the row held in registers between the passes:
 // one HBM read of the row, one write of g.
-template <int VI>
+template <int VI, bool NUCLEUS>
 __device__ __attribute__((noinline)) void softmax_to_g(const float *__restrict__ row, float *__restrict__ g, int V, float temperature,
-                             int top_k, EpShared &S, int &ph) {
+                             int top_k, float top_p, EpShared &S, int &ph) {
     const int tid = threadIdx.x;
     const float NEG_INF = -__builtin_inff();
     float4 r[VI];
@@ -87,6 +89,9 @@ __device__ __attribute__((noinline)) void softmax_to_g(const float *__restrict__
             r[it].z = r[it].z / temperature;
             r[it].w = r[it].w / temperature;
         }
+    }
+    if constexpr (NUCLEUS) {          // TopPLogitsWarper between the temperature and the top-k (prepare_logits_processor's order, drafters/utils.py:36-52)
+        if (top_p >= 1e-8f && top_p < 1.0f) top_p_tile<EP_THREADS, VI>(r, top_p, S.mass, S.redf, S.redd, S.redi, ph);
     }
     if (top_k > 0) {
         const float thr = kth_largest_regs<VI>(r, top_k < V ? top_k : V, S, ph);
@@ -146,7 +151,7 @@ __device__ __forceinline__ void fill_row(float *__restrict__ p, int V, float val
         reinterpret_cast<float4 *>(p)[i4] = make_float4(val, val, val, val);
 }
 
-template <int VI>
+template <int VI, bool NUCLEUS>
 __global__ __launch_bounds__(EP_THREADS) void ep_kernel(const lantern_ep_params prm, const lantern_ep_buffers buf) {
     __shared__ EpShared S;
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -204,7 +209,7 @@ __global__ __launch_bounds__(EP_THREADS) void ep_kernel(const lantern_ep_params 
             status = LANTERN_ST_NO_PREFIX;
             break;
         }
-        softmax_to_g<VI>(logits + (size_t)S.row[fi * Ds + (i - 1)] * V, g, V, prm.temperature, prm.top_k, S, ph);
+        softmax_to_g<VI, NUCLEUS>(logits + (size_t)S.row[fi * Ds + (i - 1)] * V, g, V, prm.temperature, prm.top_k, prm.top_p, S, ph);
 
         int nset = 0;
         for (int j = 0; j < P; ++j) {
@@ -363,7 +368,7 @@ __global__ __launch_bounds__(EP_THREADS) void ep_kernel(const lantern_ep_params 
 
     const int from_residual = (adjust && a != D) ? 1 : 0;
     if (status == LANTERN_ST_OK && !from_residual)
-        softmax_to_g<VI>(logits + (size_t)S.row[best * Ds + (a - 1)] * V, g, V, prm.temperature, prm.top_k, S, ph);
+        softmax_to_g<VI, NUCLEUS>(logits + (size_t)S.row[best * Ds + (a - 1)] * V, g, V, prm.temperature, prm.top_k, prm.top_p, S, ph);
     if (tid == 0) {
         buf.best[b] = best;
         buf.accept_len[b] = a - 1;
@@ -408,20 +413,19 @@ extern "C" int lantern_evaluate_posterior(const lantern_ep_params *prm, const la
     if (p.lantern)
         LANTERN_CHECK_ARG(buf->nn_table && p.k >= 1 && p.k <= p.table_cols && p.table_rows > 0,
                           "evaluate_posterior: lantern needs nn_table and 1 <= k=%d <= table_cols=%d", p.k, p.table_cols);
-    if (p.top_p > 0.0f && p.top_p < 1.0f) {
-        set_error("evaluate_posterior: top_p=%g inside the kernel is not built (use top_p=1)", (double)p.top_p);
-        return LANTERN_E_UNSUPPORTED;
-    }
     hipStream_t st = (hipStream_t)stream;
     dim3 grid(p.B), block(EP_THREADS);
-    if (p.V <= 4096)
-        hipLaunchKernelGGL(ep_kernel<1>, grid, block, 0, st, p, *buf);
-    else if (p.V <= 4096 * 4)
-        hipLaunchKernelGGL(ep_kernel<4>, grid, block, 0, st, p, *buf);
-    else if (p.V <= 4096 * 8)
-        hipLaunchKernelGGL(ep_kernel<8>, grid, block, 0, st, p, *buf);
-    else
-        hipLaunchKernelGGL(ep_kernel<16>, grid, block, 0, st, p, *buf);
+    const bool nucleus = p.top_p >= 1e-8f && p.top_p < 1.0f;          // its own instances: the default ones keep their register budget
+#define EP_LAUNCH(VI_)                                                               \
+    do {                                                                             \
+        if (nucleus) hipLaunchKernelGGL((ep_kernel<VI_, true>), grid, block, 0, st, p, *buf); \
+        else hipLaunchKernelGGL((ep_kernel<VI_, false>), grid, block, 0, st, p, *buf);        \
+    } while (0)
+    if (p.V <= 4096) EP_LAUNCH(1);
+    else if (p.V <= 4096 * 4) EP_LAUNCH(4);
+    else if (p.V <= 4096 * 8) EP_LAUNCH(8);
+    else EP_LAUNCH(16);
+#undef EP_LAUNCH
     LANTERN_CHECK_LAUNCH("evaluate_posterior");
     return LANTERN_OK;
 }

@@ -43,8 +43,8 @@ class EaModel(nn.Module):
     uniform_window = 4096            # uniforms staged per refill (verify.UniformFifo)
     # "window": inside generate() the tree rows leave tree_decoding as probabilities over the image-token window with the HF
     # processors (Temperature -> TopP -> TopK) already applied to every row (one workgroup per row), and evaluate_posterior keeps
-    # the residual in LDS.  "dense": full-vocabulary logit rows, processors inside evaluate_posterior (the reference's order;
-    # top_p < 1 is only built in the windowed set).  Greedy decoding always takes the dense rows (it returns raw logits).
+    # the residual in LDS.  "dense": full-vocabulary logit rows, processors (top-p included) inside evaluate_posterior per visited row (the
+    # reference's order).  Greedy decoding always takes the dense rows (it returns raw logits).
     kernel_set = "window"
     _active_proc = None              # ProcessorSpec of the running generate() call (tree_decoding has no processor argument)
     prefix_pad = 120                 # input_ids carries 120 leading zero ids (ea_model_llamagen.py:437,1107)
@@ -155,7 +155,7 @@ class EaModel(nn.Module):
         out = ops.evaluate_posterior_window(cfg_w, logits.V, logits.win[None], logits.win_lo, logits.row_index(), candidates[None], fifo.buf,
                                             row_hot=logits.row_hot[None], table=self._packed_table(int(lantern_k)) if lantern else None,
                                             aux=aux, cursor=fifo.cursor, want_dense=True, want_window=False, rows_probs=True)
-        if int(out["counters"][0, 5]) in (2, 6, 7, 8) and logits.dense_source is not None and not (0.0 < cfg.top_p < 1.0):
+        if int(out["counters"][0, 5]) in (2, 6, 7, 8) and logits.dense_source is not None:
             # a state only the dense kernel represents (the residual vanished, staging limits): the same step on the dense HIP
             # kernel -- processors applied per visited row there -- from the same position of the uniform stream
             fifo.cursor.copy_(cur0)
@@ -334,7 +334,7 @@ class EaModel(nn.Module):
         # ---- the step's one host read
         a, bst, stt, tok = torch.cat((alen.to(torch.int64), best.to(torch.int64), status.to(torch.int64), token.to(torch.int64).reshape(-1)[:1])).tolist()
         if stt != 0:
-            if stt in self._RETRY_DENSE and isinstance(rows, WindowRows) and rows.dense_source is not None and not (0.0 < self._active_proc.top_p < 1.0):
+            if stt in self._RETRY_DENSE and isinstance(rows, WindowRows) and rows.dense_source is not None:
                 # a state only the dense kernel represents (the residual vanished, staging limits): the same step on the dense HIP kernel --
                 # processors applied per visited row there -- from the same position of the uniform stream, through the host-integer path
                 self._uniforms().cursor.copy_(cur0)
@@ -436,12 +436,12 @@ class EaModel(nn.Module):
         return cond.to(bm.dtype), lmask
 
     def _check_processors(self, temperature, top_p):
-        """The one place a sampling configuration is refused: nucleus filtering (TopPLogitsWarper, drafters/utils.py:36-52) is built into
-        the windowed kernel set only -- there tree_decoding applies Temperature -> TopP -> TopK to every row (lantern_cfg_mask_topk_window).
-        The dense set's evaluate_posterior applies the processors per visited row and has no top-p; asked for both, say so before any work."""
-        if temperature is not None and temperature > 1e-5 and top_p is not None and 0.0 < top_p < 1.0 and self.kernel_set != "window":
+        """Every sampling configuration of the reference's generate() is built in both kernel sets (nucleus filtering -- TopPLogitsWarper,
+        drafters/utils.py:36-52 -- per row in lantern_cfg_mask_topk_window for "window", per visited row inside lantern_evaluate_posterior for
+        "dense"); what is left to refuse is a value outside the warper's own domain."""
+        if top_p is not None and not (0.0 <= top_p <= 1.0):
             from ._lib import LanternError
-            raise LanternError(f"generate: top_p={top_p} needs kernel_set='window' (nucleus filtering is not built into the {self.kernel_set!r} kernel set)")
+            raise LanternError(f"generate: top_p={top_p} outside [0, 1] (TopPLogitsWarper raises the same)")
 
     @torch.no_grad()
     def generate(self, prompt: Optional[List[str]] = None, max_length: Optional[int] = None, temperature: Optional[float] = None,

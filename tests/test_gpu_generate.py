@@ -260,7 +260,7 @@ class FakeLlamaGenInner:
 
 
 @pytest.mark.parametrize("static_tree,top_p,kernel_set", [(False, 1.0, "window"), (True, 0.9, "window"), (False, 0.9, "window"),
-                                                           (True, 1.0, "dense")])
+                                                           (True, 1.0, "dense"), (False, 0.9, "dense"), (True, 0.9, "dense")])
 def test_llamagen_generate_end_to_end(static_tree, top_p, kernel_set):
     """ea_model_llamagen.EaModel.generate() (V == K, processors incl. top-p, 120-token zero prefix) with drafters.cnets.Model as the
     drafter: the KV rows must spell the emitted sequence behind the conditioning block."""

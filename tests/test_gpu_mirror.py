@@ -90,7 +90,7 @@ def test_lumina_mirror_evaluate_posterior(i, monkeypatch):
 
 
 @pytest.mark.parametrize("i", [i for i, s in enumerate(SPECS) if s["model"] in ("llamagen", "anole") and s["kind"] in ("static", "dynamic")
-                               and not (0 < s.get("top_p", 1.0) < 1) and not s.get("plain_eagle")][::2])
+                               and not s.get("plain_eagle")][::2])
 def test_llamagen_anole_mirror_evaluate_posterior(i, monkeypatch):
     from transformers.generation.logits_process import LogitsProcessorList, TemperatureLogitsWarper, TopKLogitsWarper
     spec, case = SPECS[i], H.ep_case(i)
@@ -101,9 +101,12 @@ def test_llamagen_anole_mirror_evaluate_posterior(i, monkeypatch):
     if spec["model"] == "anole":
         mdl.image_lo, mdl.image_hi = m["img_lo"], m["img_hi"]
     proc = LogitsProcessorList()                       # what prepare_logits_processor builds in the reference
-    T, tk = spec.get("temperature", 1.0), spec.get("top_k", 0)
+    T, tk, tp = spec.get("temperature", 1.0), spec.get("top_k", 0), spec.get("top_p", 1.0)
     if T != 1.0:
         proc.append(TemperatureLogitsWarper(T))
+    if 1e-8 <= tp < 1.0:                               # (drafters/utils.py:36-52: Temperature, TopP, TopK)
+        from transformers.generation.logits_process import TopPLogitsWarper
+        proc.append(TopPLogitsWarper(tp))
     if tk > 0:
         proc.append(TopKLogitsWarper(tk))
     if spec["kind"] == "static":

@@ -124,22 +124,22 @@ def test_llamagen_prompt_block_matches_the_reference_recipe():
     assert EaModel._encode_prompt(me, ["a"], 1.0)[0] == "mine"
 
 
-def test_top_p_outside_the_windowed_kernel_set_is_refused_before_any_work():
-    """Nucleus filtering exists in the windowed kernel set only: the LlamaGen / Anole mirrors say so at the top of generate()."""
+def test_top_p_is_taken_by_both_kernel_sets_and_refused_only_outside_its_domain():
+    """Nucleus filtering is built into the windowed kernel set (per row in tree_decoding's post-process) and the dense one (per visited row inside
+    evaluate_posterior): the mirrors refuse only what TopPLogitsWarper itself refuses."""
     import pytest
     from lantern_amd import _lib
     from lantern_amd.ea_model_anole import EaModel as Anole
     from lantern_amd.ea_model_llamagen import EaModel as LlamaGen
     for cls in (LlamaGen, Anole):
         m = cls.__new__(cls)
-        m.kernel_set = "dense"
-        with pytest.raises(_lib.LanternError, match="top_p=0.9 needs kernel_set='window'"):
-            cls.generate(m, prompt=["x"], max_length=4, temperature=1.0, top_k=100, top_p=0.9, cfg=2.0)
-        m.kernel_set = "window"
-        m._check_processors(1.0, 0.9)          # the windowed set takes it
-        m.kernel_set = "dense"
-        m._check_processors(0.0, 0.9)          # greedy decoding has no processors
-        m._check_processors(1.0, 1.0)
+        for ks in ("dense", "window"):
+            m.kernel_set = ks
+            m._check_processors(1.0, 0.9)
+            m._check_processors(0.0, 0.9)          # greedy decoding has no processors
+            m._check_processors(1.0, 1.0)
+            with pytest.raises(_lib.LanternError, match="outside"):
+                cls.generate(m, prompt=["x"], max_length=4, temperature=1.0, top_k=100, top_p=1.5, cfg=2.0)
 
 
 @pytest.mark.parametrize("model_type", ["lumina_mgpt", "anole", "llamagen"])

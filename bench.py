@@ -83,8 +83,6 @@ def parse():
                     "(default: the chain kernel takes the raw logits -- LANTERN_ROWS_RAW_BF16 -- and post-processes the rows its walk visits)")
     ap.add_argument("--spec-rows", type=int, default=3, help="with --fuse-o7: rows of the K most likely tree nodes are post-processed up front, in the candidate-assembly launch (lantern_prepare_step); the others on demand")
     ap.add_argument("--python-launch", action="store_true", help="launch every kernel of the step from Python (4 ctypes calls per group) instead of one lantern_verify_step call")
-    ap.add_argument("--no-fused-commit", dest="fused_commit", action="store_false", help="the KV / hidden / token commit as its own launch (lantern_update_inference_inputs) instead of "
-                    "inside the evaluate_posterior launch (lantern_ep_commit); the per-kernel PMC passes use this form so that a launch's bytes belong to one kernel")
     ap.add_argument("--no-kv", action="store_true", help="skip the KV slabs (debug only; invalid as a headline)")
     ap.add_argument("--kv-smax", type=int, default=4096, help="rows per KV slab (BASELINE.md: 4096 = max_position_embeddings; a 768x768 image needs 2481)")
     ap.add_argument("--kv-pad-rows", type=int, default=None, help="extra rows per (layer, head) group of a KV slab (row stride = kv_smax + pad; harness default 16)")
@@ -930,7 +928,7 @@ def main():
     cfg = HN.WorkloadConfig(n_seq=n_seq, pool_steps=args.pool_steps, tree=args.tree, lantern_k=args.lantern_k,
                             lantern_delta=args.lantern_delta, sigma=args.sigma, with_kv=not args.no_kv, kv_smax=args.kv_smax,
                             path=args.path, ep_kernel=args.ep, fuse_o7=args.fuse_o7, spec_rows=args.spec_rows, native_step=not args.python_launch, use_graph=args.graph, n_groups=args.groups, side_stream=args.side_stream,
-                            fused_commit=args.fused_commit, max_steps=max(args.pool_steps, args.steps + args.warmup + min(args.steps, 100), 80) + 8,
+                            max_steps=max(args.pool_steps, args.steps + args.warmup + min(args.steps, 100), 80) + 8,
                             **({} if args.kv_pad_rows is None else {"kv_pad_rows": args.kv_pad_rows}))
     wl = HN.LuminaVerifyWorkload(cfg, device, rank=rank)
 

@@ -255,28 +255,6 @@ int lantern_cfg_mask_topk_window(const void *cond, const void *uncond, int dtype
                                  float *out_win, int32_t *row_hot, int out_kind, float temperature, float top_p,
                                  void *stream);
 
-/* O9 + O10 INSIDE the evaluate_posterior launch (chain kernel, optional): the launch gets `n_movers` helper workgroups behind its B sequence
- * workgroups; a sequence's workgroup publishes its verdict in `queue[b]` the moment its walk ends, and a team of 16 helpers moves that sequence's KV
- * rows and copies its accepted hidden rows while the other walks are still running -- the commit of models/ea_model_lumina_mgpt.py:741-785
- * (update_inference_inputs) without a kernel boundary and without waiting for the slowest walk of the launch.  Same results as
- * lantern_update_inference_inputs with `counters` (a walk that reported a status commits nothing).  The helpers spin (bounded) on the queue: they
- * are dispatched behind the sequence workgroups of their own launch, so every walk they wait for is already resident.
- * Fields as lantern_update_inference_inputs, plus: seq_slabs [dev] [B, slabs_per_seq] = the slabs of every sequence (the inverse of slab_seq);
- * queue [dev] [B] u64, zero-filled once, one per concurrent stream; epoch = any value in [1, 2^24) that differs from the previous launch's on this
- * queue (a step counter); n_movers = a multiple of 16 (or < 16), B <= 64 * (n_movers / 16).  lantern_ep_commit_fused() tells whether the
- * configuration has an instance with the commit built in (the fixed-configuration Lumina instances, 8192-id window); otherwise
- * lantern_evaluate_posterior_window refuses a non-NULL `commit`. */
-#define LANTERN_ST_COMMIT_TIMEOUT 9   /* counters[5]: a helper gave up waiting for the sequence's verdict (never seen; bounds the spin) */
-typedef struct lantern_ep_commit {
-    void *const *slab_ptrs; const int64_t *slab_prev; int64_t *new_len;
-    int32_t n_slabs, elem_bytes; int64_t outer, S_max, d;
-    const int64_t *retrieve; int32_t retrieve_per_seq, N;
-    const void *hidden; void *out_hidden; int64_t *accepted_tokens; int32_t hid_elem_bytes, hid_groups, H, n_movers;
-    const int32_t *seq_slabs; int32_t slabs_per_seq; uint32_t epoch;
-    uint64_t *queue;
-    int32_t team_size, reserved;   /* helpers per sequence being committed (0: 16); n_movers is a multiple of it */
-} lantern_ep_commit;
-
 typedef struct lantern_ep_window {
     int32_t win_lo, win_len;      /* window = token ids [win_lo, win_lo+win_len); win_len % 4 == 0 */
     const int32_t *row_hot;       /* [dev] [B*rows_per_seq] or NULL (all window rows) */
@@ -307,7 +285,6 @@ typedef struct lantern_ep_window {
     const uint8_t *raw_pre;       /* [dev] [rows_per_seq]: 0 = post-process the node's row on demand; 1 + d = it is in raw_probs, prepared for a node
                                      at depth d (static trees: the depth is not checked, write 1; raw_pos_per_seq: used only when the
                                      sequence's node really sits at depth d, i.e. raw_pos_ids[node] - raw_pos_ids[0] == d) */
-    const lantern_ep_commit *commit;   /* [host] NULL, or the KV / hidden / token commit to run inside this launch (see lantern_ep_commit) */
 } lantern_ep_window;
 
 /* O8 windowed.  buf->logits is [B, rows_per_seq, win_len]; buf->sample_p may be NULL (if given, the dense
@@ -319,8 +296,6 @@ typedef struct lantern_ep_window {
 #define LANTERN_ST_TREE_LIMIT 7
 int lantern_evaluate_posterior_window(const lantern_ep_params *prm, const lantern_ep_buffers *buf,
                                       const lantern_ep_window *win, void *stream);
-/* 1 when lantern_evaluate_posterior_window would run win->commit inside its launch for this configuration, 0 when it has no such instance */
-int lantern_ep_commit_fused(const lantern_ep_params *prm, const lantern_ep_buffers *buf, const lantern_ep_window *win);
 
 /* ------------------------------------------------------------------------------------
  * O8 node-parallel (v3): the same relaxed rejection sampling, one workgroup per INTERNAL TREE NODE instead of one

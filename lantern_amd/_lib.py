@@ -37,15 +37,6 @@ class EpBuffers(C.Structure):
         "best", "accept_len", "sample_p", "counters")]
 
 
-class EpCommit(C.Structure):
-    """lantern_ep_commit (include/lantern_hip.h): the KV / hidden / token commit inside the evaluate_posterior launch."""
-    _fields_ = [("slab_ptrs", C.c_void_p), ("slab_prev", C.c_void_p), ("new_len", C.c_void_p), ("n_slabs", C.c_int32), ("elem_bytes", C.c_int32),
-                ("outer", C.c_int64), ("S_max", C.c_int64), ("d", C.c_int64), ("retrieve", C.c_void_p), ("retrieve_per_seq", C.c_int32), ("N", C.c_int32),
-                ("hidden", C.c_void_p), ("out_hidden", C.c_void_p), ("accepted_tokens", C.c_void_p), ("hid_elem_bytes", C.c_int32),
-                ("hid_groups", C.c_int32), ("H", C.c_int32), ("n_movers", C.c_int32), ("seq_slabs", C.c_void_p), ("slabs_per_seq", C.c_int32),
-                ("epoch", C.c_uint32), ("queue", C.c_void_p), ("team_size", C.c_int32), ("reserved", C.c_int32)]
-
-
 class EpWindow(C.Structure):
     _fields_ = [("win_lo", C.c_int32), ("win_len", C.c_int32), ("row_hot", C.c_void_p),
                 ("orig_prob_stride", C.c_int32), ("orig_prob_offset", C.c_int32),
@@ -53,8 +44,7 @@ class EpWindow(C.Structure):
                 ("u_bonus", C.c_void_p), ("token", C.c_void_p), ("rows_kind", C.c_int32), ("raw_pos_per_seq", C.c_int32),
                 ("raw_uncond", C.c_void_p), ("raw_pos_ids", C.c_void_p), ("raw_seq_len", C.c_void_p), ("raw_pos_base", C.c_int64),
                 ("raw_cfg", C.c_float), ("raw_top_k", C.c_int32), ("raw_w_latent", C.c_int32), ("raw_h_latent", C.c_int32),
-                ("raw_newline_id", C.c_int32), ("raw_eos_id", C.c_int32), ("raw_probs", C.c_void_p), ("raw_pre", C.c_void_p),
-                ("commit", C.POINTER(EpCommit))]
+                ("raw_newline_id", C.c_int32), ("raw_eos_id", C.c_int32), ("raw_probs", C.c_void_p), ("raw_pre", C.c_void_p)]
 
 
 class EpNodes(C.Structure):
@@ -166,7 +156,7 @@ EXPORTS = [
     "lantern_expand_dynamic", "lantern_gather_candidates", "lantern_cfg_mask_topk",
     "lantern_evaluate_posterior_workspace", "lantern_evaluate_posterior", "lantern_evaluate_posterior_greedy",
     "lantern_kv_gather", "lantern_accept_gather", "lantern_sample_static", "lantern_drafter_fc",
-    "lantern_build_vq_table", "lantern_cfg_mask_topk_window", "lantern_evaluate_posterior_window", "lantern_ep_commit_fused",
+    "lantern_build_vq_table", "lantern_cfg_mask_topk_window", "lantern_evaluate_posterior_window",
     "lantern_window_to_dense", "lantern_pack_vq_table", "lantern_update_inference_inputs", "lantern_profile_next_launch", "lantern_drafter_attention_mask", "lantern_linear_rows",
     "lantern_tree_attention_workspace", "lantern_tree_attention",
     "lantern_tree_node_tables_size", "lantern_tree_node_tables", "lantern_evaluate_posterior_nodes_workspace",

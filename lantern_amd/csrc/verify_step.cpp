@@ -61,37 +61,15 @@ extern "C" int lantern_verify_step(const lantern_step_group *groups, int n_group
                                           s.win_len, s.out_win, s.row_hot, s.out_kind, s.temperature, s.top_p, s.stream);
         if (rc) return fail(g, "cfg_mask_topk_window", rc);
     }
-    // The commit runs INSIDE the evaluate_posterior launch where the caller provides the helpers' queue (ep_win.commit: queue, epoch, seq_slabs,
-    // slabs_per_seq, n_movers -- everything else is filled in here from the group) and the configuration has such an instance: a sequence's KV rows
-    // move while the launch's slower walks are still running, and the commit's own launch (below) is skipped.
-    constexpr int MAX_FUSED = 64;
-    bool fused[MAX_FUSED] = {false};
     for (int g = 0; g < n_groups; ++g) {
         const lantern_step_group &s = groups[g];
-        if (s.nodes) {
-            rc = lantern_evaluate_posterior_nodes(&s.ep, &s.ep_buf, &s.ep_win, s.nodes, s.stream);
-        } else {
-            lantern_ep_window w = s.ep_win;
-            lantern_ep_commit com{};
-            w.commit = nullptr;
-            if (s.ep_win.commit && s.slab_ptrs && g < MAX_FUSED) {
-                com = *s.ep_win.commit;
-                com.slab_ptrs = s.slab_ptrs; com.slab_prev = s.slab_prev; com.new_len = s.new_len;
-                com.n_slabs = s.n_slabs; com.elem_bytes = s.elem_bytes; com.outer = s.outer; com.S_max = s.S_max; com.d = s.d;
-                com.retrieve = s.dyn ? s.dyn->retrieve_pd : s.retrieve; com.retrieve_per_seq = s.dyn ? 1 : 0; com.N = s.N;
-                com.hidden = s.hidden; com.out_hidden = s.out_hidden; com.accepted_tokens = s.accepted_tokens;
-                com.hid_elem_bytes = s.hid_elem_bytes; com.hid_groups = s.hid_groups; com.H = s.H;
-                w.commit = &com;
-                fused[g] = lantern_ep_commit_fused(&s.ep, &s.ep_buf, &w) == 1;
-                if (!fused[g]) w.commit = nullptr;
-            }
-            rc = lantern_evaluate_posterior_window(&s.ep, &s.ep_buf, &w, s.stream);
-        }
+        rc = s.nodes ? lantern_evaluate_posterior_nodes(&s.ep, &s.ep_buf, &s.ep_win, s.nodes, s.stream)
+                     : lantern_evaluate_posterior_window(&s.ep, &s.ep_buf, &s.ep_win, s.stream);
         if (rc) return fail(g, "evaluate_posterior", rc);
     }
     for (int g = 0; g < n_groups; ++g) {
         const lantern_step_group &s = groups[g];
-        if (!s.slab_ptrs || (g < MAX_FUSED && fused[g])) continue;
+        if (!s.slab_ptrs) continue;
         // (a sequence whose walk reported a status commits nothing: its KV rows, lengths and hidden rows stay as the forward left them)
         rc = lantern::launch_update_inference_inputs(s.slab_ptrs, s.slab_seq, s.slab_prev, s.n_slabs, s.elem_bytes, s.outer, s.S_max, s.d,
                                                      s.dyn ? s.dyn->retrieve_pd : s.retrieve, s.dyn ? 1 : 0, s.P, s.D, s.ep_buf.best,

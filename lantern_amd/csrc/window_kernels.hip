@@ -488,7 +488,6 @@ struct EpwArgs {
     lantern_ep_params prm;
     lantern_ep_buffers buf;
     lantern_ep_window win;
-    lantern_ep_commit com;          // a copy of *win.commit (COMMIT instances only)
 };
 typedef const __attribute__((address_space(4))) EpwArgs *EpwArgsK;
 
@@ -1325,249 +1324,12 @@ __device__ __forceinline__ int epw_body(const EpwArgs &args, const int b) {
         if (ka->win.out_tok) ka->win.out_tok[b] = out_tok;
         if (ka->win.out_mass) ka->win.out_mass[b] = out_mass;
     }
-    return (status << 24) | (best << 8) | a;          // the verdict (uniform): status, best path, rows kept = accept_len + 1
+    return (best << 8) | a;          // the verdict (uniform): best path, rows kept = accept_len + 1
 }
 
-// ---------------------------------------------------------------------------------------------------------------------------------------
-// The commit inside the launch (lantern_ep_commit): workgroups [B, B + n_movers) are helpers.  Helper m belongs to team m / 16 and is its member
-// m % 16; team t owns the sequences b = t, t + n_teams, ...  Every WAVE of a helper polls the queue entries of its team's pending sequences
-// (one 8-byte device-scope load, the same address in all lanes) and, when an entry carries this launch's epoch, does its static share of that
-// sequence's commit -- no barrier anywhere in the helper, a column of a slab belongs to exactly one thread, and a thread loads all the rows it
-// moves before it stores any (the in-place move cannot race with itself).  Work per sequence: slabs_per_seq x ceil(columns / (NT x U)) passes,
-// member j takes passes j, j + 16, ...; U x (rows to move) = 16 loads in flight per thread whatever the number of rows (1-2 rows: 8 columns per
-// thread and pass; 3-4: 4; 5-8: 2), which is what lets one helper per CU keep ~128 KB in flight.  Then the accepted hidden rows (one 16-byte
-// chunk per thread).  The queue entry is ONE word -- epoch, status, rows kept, best path -- so nothing else has to be ordered with it.
-typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
-typedef __attribute__((address_space(1))) u32x4_t epw_gvec_t;
-constexpr int EPW_TEAM = 16;
-constexpr unsigned EPW_SPIN_LIMIT = 1u << 20;          // x ~2 us per polling round: about two seconds, then LANTERN_ST_COMMIT_TIMEOUT
-
-// one trip over a PAIR of slabs (a sequence's conditional and unconditional cache): the loads of both are in flight before the first store.
-// STRAIGHT-LINE loads: a uniform `if (k < n)` around every load makes the compiler wait for all earlier loads before each one (registers shared
-// between the conditional blocks: `s_waitcnt vmcnt(0)` in front of every global_load -- measured 9 GB/s per CU), so SEL is the number of rows to
-// move rounded up to an instantiated count, a surplus slot re-loads the last row and is simply not stored.
-template <int NT, int U, int SEL>
-__device__ __forceinline__ void epw_commit_passes(epw_gvec_t *base0, epw_gvec_t *base1, size_t group_stride, unsigned cpr, unsigned total, int j, int team_size,
-                                                  int n0, int n1, const int (&src0)[8], const int (&dst0)[8], const int (&src1)[8], const int (&dst1)[8]) {
-    const unsigned tid = threadIdx.x;
-    constexpr unsigned PC = NT * U;
-    size_t so0[SEL], so1[SEL];
-#pragma unroll
-    for (int k = 0; k < SEL; ++k) {
-        so0[k] = (size_t)src0[k < n0 ? k : (n0 > 0 ? n0 - 1 : 0)] * cpr;
-        so1[k] = (size_t)src1[k < n1 ? k : (n1 > 0 ? n1 - 1 : 0)] * cpr;
-    }
-    for (unsigned p0 = (unsigned)j * PC; p0 < total; p0 += (unsigned)team_size * PC) {
-        u32x4_t v0[U][SEL], v1[U][SEL];
-        size_t off[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            unsigned w = p0 + u * NT + tid;
-            w = w < total ? w : total - 1;          // (a surplus thread re-loads the last column and stores nothing)
-            const unsigned o = w / cpr, c = w - o * cpr;
-            off[u] = (size_t)o * group_stride + c;
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u)
-#pragma unroll
-            for (int k = 0; k < SEL; ++k) {
-                v0[u][k] = __builtin_nontemporal_load(&base0[off[u] + so0[k]]);
-                v1[u][k] = __builtin_nontemporal_load(&base1[off[u] + so1[k]]);
-            }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            if (p0 + u * NT + tid < total) {
-#pragma unroll
-                for (int k = 0; k < SEL; ++k) {
-                    if (k < n0) __builtin_nontemporal_store(v0[u][k], &base0[off[u] + (size_t)dst0[k] * cpr]);
-                    if (k < n1) __builtin_nontemporal_store(v1[u][k], &base1[off[u] + (size_t)dst1[k] * cpr]);
-                }
-            }
-        }
-    }
-}
-
-template <int NT>
-__device__ __forceinline__ void epw_commit_sequence(EpwArgsK ka, int b, int best, int n_sel, int j, int team_size) {
-    const int P = ka->prm.P, D = ka->prm.D;
-    const int64_t *rrow = ka->com.retrieve + (ka->com.retrieve_per_seq ? (size_t)b * P * D : 0) + (size_t)best * D;
-    int rr[8];
-#pragma unroll
-    for (int t = 0; t < 8; ++t) rr[t] = (t < n_sel && t < D) ? (int)ldc(rrow + (t < D ? t : 0)) : t;
-    // O10 first (its one load per thread goes out before the KV rows' and is stored behind them): the accepted hidden rows [B, G, D, H], rows
-    // behind the accepted ones zero-filled, one 16-byte chunk per thread and trip (one trip at the 7B sizes: 2 x 6 x 512 chunks over 16 x 512 threads)
-    const bool with_hidden = ka->com.hidden && ka->com.out_hidden;
-    const int G = ka->com.hid_groups, N = ka->com.N;
-    const unsigned hcpr = with_hidden ? (unsigned)(ka->com.H * ka->com.hid_elem_bytes / 16) : 0u, chunks = (unsigned)(G * D) * hcpr;
-    const uint4 *hid = (const uint4 *)ka->com.hidden;
-    uint4 *outh = (uint4 *)ka->com.out_hidden;
-    const unsigned hi0 = (unsigned)j * NT + threadIdx.x;
-    uint4 hval = make_uint4(0, 0, 0, 0);
-    size_t hdst = 0;
-    if (hi0 < chunks) {
-        const unsigned row = hi0 / hcpr, c = hi0 - row * hcpr;
-        const int gi = (int)(row / (unsigned)D), t = (int)(row - (unsigned)gi * D);
-        hdst = (((size_t)b * G + gi) * D + t) * hcpr + c;
-        if (t < n_sel) {
-            int r = 0;
-#pragma unroll
-            for (int k = 0; k < 8; ++k) r = (k == t) ? rr[k] : r;
-            if (r < 0) r += N;
-            r = r < 0 ? 0 : (r >= N ? N - 1 : r);
-            hval = hid[(((size_t)b * G + gi) * N + (size_t)r) * hcpr + c];
-        }
-    }
-    const int sps = ka->com.slabs_per_seq;
-    const long long S_max = ka->com.S_max;
-    const unsigned cpr = (unsigned)(ka->com.d * ka->com.elem_bytes / 16), total = (unsigned)(ka->com.outer * cpr);
-    const size_t gs = (size_t)S_max * cpr;
-    for (int q = 0; q < sps; q += 2) {
-        const bool two = q + 1 < sps;
-        const int s0 = ldc(ka->com.seq_slabs + (size_t)b * sps + q), s1 = ldc(ka->com.seq_slabs + (size_t)b * sps + (two ? q + 1 : q));
-        const long long prev0 = ldc(ka->com.slab_prev + s0), prev1 = ldc(ka->com.slab_prev + s1);
-        epw_gvec_t *base0 = (epw_gvec_t *)(uintptr_t)ldc((const unsigned long long *)ka->com.slab_ptrs + s0);
-        epw_gvec_t *base1 = (epw_gvec_t *)(uintptr_t)ldc((const unsigned long long *)ka->com.slab_ptrs + s1);
-        // the rows to move, compacted (rows already in place -- the root, every accepted first child -- stay where the forward wrote them)
-        int src0[8], dst0[8], src1[8], dst1[8], n0 = 0, n1 = 0;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) src0[k] = dst0[k] = src1[k] = dst1[k] = 0;
-#pragma unroll
-        for (int t = 0; t < 8; ++t) {
-            const bool mv = t < n_sel && rr[t] != t;
-            if (mv && prev0 + t < S_max) {
-                const long long sr = (long long)rr[t] + prev0;
-                const int sv = (int)(sr < 0 ? 0 : (sr >= S_max ? S_max - 1 : sr)), dv = (int)(prev0 + t);
-#pragma unroll
-                for (int k = 0; k < 8; ++k)
-                    if (k == n0) { src0[k] = sv; dst0[k] = dv; }
-                ++n0;
-            }
-            if (mv && two && prev1 + t < S_max) {
-                const long long sr = (long long)rr[t] + prev1;
-                const int sv = (int)(sr < 0 ? 0 : (sr >= S_max ? S_max - 1 : sr)), dv = (int)(prev1 + t);
-#pragma unroll
-                for (int k = 0; k < 8; ++k)
-                    if (k == n1) { src1[k] = sv; dst1[k] = dv; }
-                ++n1;
-            }
-        }
-        const int nm = n0 > n1 ? n0 : n1;
-        if (nm == 0 || ka->com.reserved == 1) continue;
-        if (ka->com.reserved == 2) {
-            if (nm == 1) epw_commit_passes<NT, 16, 1>(base0, base1, gs, cpr, total, j, team_size, n0, n1, src0, dst0, src1, dst1);
-            else if (nm == 2) epw_commit_passes<NT, 8, 2>(base0, base1, gs, cpr, total, j, team_size, n0, n1, src0, dst0, src1, dst1);
-            else if (nm <= 4) epw_commit_passes<NT, 4, 4>(base0, base1, gs, cpr, total, j, team_size, n0, n1, src0, dst0, src1, dst1);
-            else epw_commit_passes<NT, 2, 8>(base0, base1, gs, cpr, total, j, team_size, n0, n1, src0, dst0, src1, dst1);
-        }
-        else if (nm == 1) epw_commit_passes<NT, 8, 1>(base0, base1, gs, cpr, total, j, team_size, n0, n1, src0, dst0, src1, dst1);
-        else if (nm == 2) epw_commit_passes<NT, 4, 2>(base0, base1, gs, cpr, total, j, team_size, n0, n1, src0, dst0, src1, dst1);
-        else if (nm <= 4) epw_commit_passes<NT, 2, 4>(base0, base1, gs, cpr, total, j, team_size, n0, n1, src0, dst0, src1, dst1);
-        else epw_commit_passes<NT, 1, 8>(base0, base1, gs, cpr, total, j, team_size, n0, n1, src0, dst0, src1, dst1);
-    }
-    if (hi0 < chunks) outh[hdst] = hval;
-    for (unsigned i = hi0 + (unsigned)team_size * NT; i < chunks; i += (unsigned)team_size * NT) {          // (hidden blocks beyond one trip of the team)
-        const unsigned row = i / hcpr, c = i - row * hcpr;
-        const int gi = (int)(row / (unsigned)D), t = (int)(row - (unsigned)gi * D);
-        uint4 val = make_uint4(0, 0, 0, 0);
-        if (t < n_sel) {
-            long long r = rrow[t];
-            if (r < 0) r += N;
-            r = r < 0 ? 0 : (r >= N ? N - 1 : r);
-            val = hid[(((size_t)b * G + gi) * N + (size_t)r) * hcpr + c];
-        }
-        outh[(((size_t)b * G + gi) * D + t) * hcpr + c] = val;
-    }
-}
-
-template <int NT>
-__device__ __forceinline__ void epw_commit_helper(EpwArgsK ka, int m) {
-    // Polling is the one thing the helpers may not overdo: hundreds of waves hammering a queue line with device-scope loads saturate the one memory
-    // channel that holds it, and every walk's row reads that touch this channel queue behind them (measured: the step 73 -> 119 us with every wave
-    // polling).  So ONE wave of a helper polls, all of its team's pending entries in one vector load (lane i <-> the team's i-th sequence), sleeps
-    // ~1 us between rounds, and hands the entry it found to the other waves through LDS.
-    __shared__ unsigned long long s_entry;
-    __shared__ int s_which;
-    const int B = ka->prm.B, n_movers = ka->com.n_movers;
-    const int want = ka->com.team_size > 0 ? ka->com.team_size : EPW_TEAM;
-    const int team_size = n_movers < want ? n_movers : want;
-    const int n_teams = n_movers / team_size, team = m / team_size, j = m - team * team_size;
-    if (team >= n_teams) return;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const uint32_t epoch = ka->com.epoch & 0xffffffu;
-    unsigned long long *queue = (unsigned long long *)ka->com.queue;
-    unsigned long long pending = 0ull;
-    {
-        int cnt = 0;
-        for (int b = team; b < B && cnt < 64; b += n_teams) pending |= 1ull << cnt++;
-    }
-    while (pending) {
-        if (wave == 0) {
-            const bool mine = (pending >> lane) & 1ull;
-            const unsigned long long *slot = queue + (mine ? team + lane * n_teams : team);
-            int which = -1;
-            unsigned long long e = 0ull;
-            for (unsigned spins = 0; which == -1; ++spins) {
-                e = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const unsigned long long ready = __ballot(mine && (uint32_t)(e >> 40) == epoch);
-                if (ready) which = __ffsll((long long)ready) - 1;
-                else if (spins > EPW_SPIN_LIMIT) which = -2;          // never seen: bounds the wait so that a launch always drains
-                else __builtin_amdgcn_s_sleep(40);
-            }
-            if (which >= 0 && lane == which) s_entry = e;
-            if (lane == 0) s_which = which;
-        }
-        __syncthreads();
-        const int i = s_which;
-        const unsigned long long e = s_entry;
-        __syncthreads();
-        if (i < 0) {
-            if (j == 0 && tid == 0)
-                for (unsigned long long rem = pending; rem; rem &= rem - 1ull)
-                    ka->buf.counters[(size_t)(team + (__ffsll((long long)rem) - 1) * n_teams) * 6 + 5] = LANTERN_ST_COMMIT_TIMEOUT;
-            return;
-        }
-        const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(e & 0xffffffffull));
-        epw_commit_sequence<NT>(ka, team + i * n_teams, (int)(lo & 0xffffffu), (int)(lo >> 24), j, team_size);
-        pending &= ~(1ull << i);
-    }
-}
-
-// the sequence workgroup's side: accepted tokens, the slabs' new lengths (tiny), then the verdict word
-template <int NT>
-__device__ __forceinline__ void epw_commit_publish(EpwArgsK ka, int b, int verdict) {
-    const int D = ka->prm.D, P = ka->prm.P, tid = threadIdx.x;
-    const int status = (verdict >> 24) & 0xff, best = (verdict >> 8) & 0xffff;
-    int n_sel = verdict & 0xff;
-    if (n_sel > D) n_sel = D;
-    if (n_sel > 8) n_sel = 8;
-    if (status != 0) n_sel = 0;          // a walk that reported a status commits nothing (the caller retries the step)
-    if (ka->com.accepted_tokens && tid < D)
-        ka->com.accepted_tokens[(size_t)b * D + tid] = tid < n_sel ? ka->buf.cand[(size_t)b * P * D + (size_t)best * D + tid] : -1;
-    const int sps = ka->com.slabs_per_seq;
-    if (ka->com.new_len && tid < sps) {
-        const int s = ka->com.seq_slabs[(size_t)b * sps + tid];
-        ka->com.new_len[s] = ka->com.slab_prev[s] + n_sel;
-    }
-    if (tid == 0) {
-        const unsigned long long e = ((unsigned long long)(ka->com.epoch & 0xffffffu) << 40) | ((unsigned long long)(unsigned)status << 32) |
-                                     ((unsigned long long)(unsigned)n_sel << 24) | (unsigned long long)(unsigned)best;
-        __hip_atomic_store((unsigned long long *)ka->com.queue + b, e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-}
-
-template <int NT, int E4, int IDMODE, int WPE, bool FULLW = false, bool RAW = false, int SPEC = 0, int TPO = 0, bool COMMIT = false>
+template <int NT, int E4, int IDMODE, int WPE, bool FULLW = false, bool RAW = false, int SPEC = 0, int TPO = 0>
 __global__ __launch_bounds__(NT, WPE) void epw_kernel(const EpwArgs args) {
-    if constexpr (COMMIT) {
-        const EpwArgsK ka = (EpwArgsK)__builtin_amdgcn_kernarg_segment_ptr();
-        if ((int)blockIdx.x >= ka->prm.B) {
-            epw_commit_helper<NT>(ka, (int)blockIdx.x - ka->prm.B);
-            return;
-        }
-        const int verdict = epw_body<NT, E4, IDMODE, WPE, FULLW, RAW, SPEC, TPO>(args, blockIdx.x);
-        epw_commit_publish<NT>(ka, blockIdx.x, verdict);
-    } else {
-        epw_body<NT, E4, IDMODE, WPE, FULLW, RAW, SPEC, TPO>(args, blockIdx.x);
-    }
+    epw_body<NT, E4, IDMODE, WPE, FULLW, RAW, SPEC, TPO>(args, blockIdx.x);
 }
 
 __global__ void window_to_dense_kernel(const float *__restrict__ winp, const int32_t *__restrict__ out_tok,
@@ -1780,80 +1542,21 @@ static size_t epw_lds_bytes(const lantern_ep_params &p, const lantern_ep_window 
            (win->rows_kind == LANTERN_ROWS_RAW_BF16 ? (size_t)O7_HIST_INTS * 4 : 0);
 }
 
-// what the instance selection looks at (shared by the launch and lantern_ep_commit_fused)
-struct EpwShape {
-    bool raw, lumina_static, lumina_dynamic, anole_static, default_tree, two_per_cu;
-    int idmode, spec_knob;
-};
-static EpwShape epw_shape(const lantern_ep_params &p, const lantern_ep_buffers *buf, const lantern_ep_window *win) {
-    EpwShape sh{};
-    sh.raw = win->rows_kind == LANTERN_ROWS_RAW_BF16;
-    const int W = win->win_len;
-    const int nz = (p.k + 1 < p.table_cols) ? p.k + 1 : p.table_cols;
-    const bool lds_ids = !p.lantern || nz <= EW_PF_K;
-    sh.idmode = !lds_ids ? 0 : ((p.lantern && p.table_cols % 8 == 0 && ((uintptr_t)buf->nn_table & 15) == 0) ? 2 : 1);
-    // the headline shape gets its own instance (SPEC 1: mode / LANTERN / syntax-shortcut flags are compile-time constants there)
-    static const int spec_knob = getenv("LANTERN_EPW_SPEC") ? atoi(getenv("LANTERN_EPW_SPEC")) : 2;   // tuning knob (diagnostic): 0 = the generic instance, 1 = no fixed tree
-    sh.spec_knob = spec_knob;
-    const bool raw = sh.raw;
-    const bool chameleon = spec_knob != 0 && p.lantern && p.V == 65536 && p.img_lo == 4 && p.img_hi == 8196 && p.tok_offset == 4 && p.table_rows == 8192 &&
-                           win->win_lo == 4 && W == 8192 && p.rows_per_seq <= EW_MAX_N && (raw || win->rows_kind == LANTERN_ROWS_PROBS) &&
-                           (!raw || win->raw_w_latent == 0 || (win->raw_eos_id == 8196 && win->raw_newline_id == 8803));
-    const bool lumina_syntax = p.syntax_shortcut && p.n_syntax == 4 && p.syntax[0] == 8196 && p.syntax[1] == 8197 && p.syntax[2] == 8803 && p.syntax[3] == 8828;
-    sh.lumina_static = chameleon && p.mode == LANTERN_MODE_STATIC_LUMINA && lumina_syntax && !buf->n_paths && !buf->n_depth && (!raw || !win->raw_pos_per_seq);
-    sh.lumina_dynamic = chameleon && p.mode == LANTERN_MODE_DYNAMIC && lumina_syntax && buf->n_paths && buf->n_depth && (!raw || win->raw_pos_per_seq);
-    sh.anole_static = chameleon && p.mode == LANTERN_MODE_STATIC_LG && !p.syntax_shortcut && !buf->n_paths && !buf->n_depth &&
-                      (!raw || (win->raw_w_latent == 0 && !win->raw_pos_per_seq));
-    sh.default_tree = spec_knob >= 2 && p.P == 15 && p.D == 6 && p.N == 26 && p.rows_per_seq == 26;
-    static const int occ_knob = getenv("LANTERN_EPW_OCC2") ? atoi(getenv("LANTERN_EPW_OCC2")) : -1;   // tuning knob (diagnostic)
-    sh.two_per_cu = occ_knob >= 0 ? occ_knob != 0 : p.B > 256;
-    return sh;
-}
-// the instances that carry the in-launch commit: the fixed-configuration Lumina ones (static trees, and the EAGLE-2 form), one workgroup per CU
-static bool epw_commit_instance(const lantern_ep_params &p, const EpwShape &sh, const lantern_ep_window *win) {
-    if (win->win_len != 8192 || sh.two_per_cu || !(sh.lumina_static || sh.lumina_dynamic)) return false;
-    if (sh.raw) return !(p.top_p >= 1e-8f && p.top_p < 1.0f);
-    return sh.idmode == 2;
-}
-
-extern "C" int lantern_ep_commit_fused(const lantern_ep_params *prm, const lantern_ep_buffers *buf, const lantern_ep_window *win) {
-    if (!prm || !buf || !win || !win->commit) return 0;
-    return epw_commit_instance(*prm, epw_shape(*prm, buf, win), win) ? 1 : 0;
-}
-
 extern "C" int lantern_evaluate_posterior_window(const lantern_ep_params *prm, const lantern_ep_buffers *buf,
                                                  const lantern_ep_window *win, void *stream) {
     const int rc = epw_check(prm, buf, win);
     if (rc) return rc;
     const lantern_ep_params &p = *prm;
     if (p.B == 0) return LANTERN_OK;
+    const bool raw = win->rows_kind == LANTERN_ROWS_RAW_BF16;
     hipStream_t st = (hipStream_t)stream;
     const int W = win->win_len;
     const size_t lds = epw_lds_bytes(p, win);
-    const EpwShape sh = epw_shape(p, buf, win);
-    const bool raw = sh.raw, lumina_static = sh.lumina_static, lumina_dynamic = sh.lumina_dynamic, anole_static = sh.anole_static,
-               default_tree = sh.default_tree, two_per_cu = sh.two_per_cu;
-    const int idmode = sh.idmode, spec_knob = sh.spec_knob;
-    EpwArgs args{p, *buf, *win, lantern_ep_commit{}};
-    const bool commit = win->commit != nullptr;
-    if (commit) {
-        const lantern_ep_commit &c = *win->commit;
-        LANTERN_CHECK_ARG(epw_commit_instance(p, sh, win), "evaluate_posterior_window: no instance with the in-launch commit for this configuration (lantern_ep_commit_fused)");
-        const int want = c.team_size > 0 ? c.team_size : EPW_TEAM;
-        const int ts = c.n_movers < want ? c.n_movers : want;
-        LANTERN_CHECK_ARG(c.slab_ptrs && c.slab_prev && c.retrieve && c.seq_slabs && c.queue && c.slabs_per_seq > 0 && c.slabs_per_seq <= 64 && c.n_movers >= 1 &&
-                              c.n_movers % ts == 0 && p.B <= 64 * (c.n_movers / ts) && c.epoch >= 1 && c.epoch < (1u << 24),
-                          "evaluate_posterior_window: commit needs slab_ptrs / slab_prev / retrieve / seq_slabs / queue, n_movers a multiple of 16 (or < 16) with "
-                          "B <= 64 teams' worth, 1 <= epoch < 2^24");
-        LANTERN_CHECK_ARG(p.D <= 8 && c.outer > 0 && c.S_max > 0 && c.S_max < (1ll << 31) && c.d > 0 && (c.d * c.elem_bytes) % 16 == 0 &&
-                              c.outer * (c.d * c.elem_bytes / 16) < (1ll << 31),
-                          "evaluate_posterior_window: commit needs D <= 8, KV rows of a multiple of 16 bytes, outer * row chunks < 2^31");
-        if (c.hidden) LANTERN_CHECK_ARG(c.out_hidden && c.hid_groups > 0 && c.N > 0 && c.H > 0 && (c.H * c.hid_elem_bytes) % 16 == 0,
-                                        "evaluate_posterior_window: commit: hidden row bytes must be a multiple of 16");
-        args.com = c;
-        args.win.commit = nullptr;
-    }
-    dim3 grid(p.B + (commit ? win->commit->n_movers : 0));
+    dim3 grid(p.B);
+    const int nz = (p.k + 1 < p.table_cols) ? p.k + 1 : p.table_cols;
+    const bool lds_ids = !p.lantern || nz <= EW_PF_K;
+    const EpwArgs args{p, *buf, *win};
+    const int idmode = !lds_ids ? 0 : ((p.lantern && p.table_cols % 8 == 0 && ((uintptr_t)buf->nn_table & 15) == 0) ? 2 : 1);
 #define EPW_LAUNCH_W(NT_, E4_, WPE_)                                                                                        \
     do {                                                                                                                  \
         if (idmode == 2) LANTERN_LAUNCH((epw_kernel<NT_, E4_, 2, WPE_>), grid, dim3(NT_), lds, st, args);                  \
@@ -1861,6 +1564,19 @@ extern "C" int lantern_evaluate_posterior_window(const lantern_ep_params *prm, c
         else LANTERN_LAUNCH((epw_kernel<NT_, E4_, 0, WPE_>), grid, dim3(NT_), lds, st, args);                              \
     } while (0)
 #define EPW_LAUNCH(NT_, E4_) EPW_LAUNCH_W(NT_, E4_, 1)
+    // the headline shape gets its own instance (SPEC 1: mode / LANTERN / syntax-shortcut flags are compile-time constants there)
+    static const int spec_knob = getenv("LANTERN_EPW_SPEC") ? atoi(getenv("LANTERN_EPW_SPEC")) : 2;   // tuning knob (diagnostic): 0 = the generic instance, 1 = no fixed tree
+    const bool chameleon = spec_knob != 0 && p.lantern && p.V == 65536 && p.img_lo == 4 && p.img_hi == 8196 && p.tok_offset == 4 && p.table_rows == 8192 &&
+                           win->win_lo == 4 && W == 8192 && p.rows_per_seq <= EW_MAX_N && (raw || win->rows_kind == LANTERN_ROWS_PROBS) &&
+                           (!raw || win->raw_w_latent == 0 || (win->raw_eos_id == 8196 && win->raw_newline_id == 8803));
+    const bool lumina_syntax = p.syntax_shortcut && p.n_syntax == 4 && p.syntax[0] == 8196 && p.syntax[1] == 8197 && p.syntax[2] == 8803 && p.syntax[3] == 8828;
+    const bool lumina_static = chameleon && p.mode == LANTERN_MODE_STATIC_LUMINA && lumina_syntax && !buf->n_paths && !buf->n_depth && (!raw || !win->raw_pos_per_seq);
+    const bool lumina_dynamic = chameleon && p.mode == LANTERN_MODE_DYNAMIC && lumina_syntax && buf->n_paths && buf->n_depth && (!raw || win->raw_pos_per_seq);
+    const bool anole_static = chameleon && p.mode == LANTERN_MODE_STATIC_LG && !p.syntax_shortcut && !buf->n_paths && !buf->n_depth &&
+                              (!raw || (win->raw_w_latent == 0 && !win->raw_pos_per_seq));
+    const bool default_tree = spec_knob >= 2 && p.P == 15 && p.D == 6 && p.N == 26 && p.rows_per_seq == 26;
+    static const int occ_knob = getenv("LANTERN_EPW_OCC2") ? atoi(getenv("LANTERN_EPW_OCC2")) : -1;   // tuning knob (diagnostic)
+    const bool two_per_cu = occ_knob >= 0 ? occ_knob != 0 : p.B > 256;
     // Throughput form of the fixed-configuration instances (more sequences than CUs; the shape BASELINE's roofline target is assessed on): 256
     // threads x 8 float4 per thread, three workgroups per CU (53 KB of LDS each, <= 168 VGPRs at 3 waves per SIMD), drafter rows requested only once
     // a rejection is known.  At saturation the kernel is bound by instruction ISSUE (profiles/r04_ep_sweep_pmc.txt: the SIMDs' arbiters busy 0.93 of
@@ -1882,12 +1598,7 @@ extern "C" int lantern_evaluate_posterior_window(const lantern_ep_params *prm, c
         else LANTERN_LAUNCH((epw_kernel<1024, 4, 1, 1, true, true>), grid, dim3(1024), lds, st, args);
     }
     else if (raw) {
-        static const int commit_wpe4 = getenv("LANTERN_COMMIT_WPE4") ? atoi(getenv("LANTERN_COMMIT_WPE4")) : 0;   // tuning knob (diagnostic)
-        if (commit && lumina_static && default_tree && commit_wpe4) LANTERN_LAUNCH((epw_kernel<512, 4, 2, 4, true, true, 2, 0, true>), grid, dim3(512), lds, st, args);
-        else if (commit && lumina_static && default_tree) LANTERN_LAUNCH((epw_kernel<512, 4, 2, 1, true, true, 2, 0, true>), grid, dim3(512), lds, st, args);
-        else if (commit && lumina_static) LANTERN_LAUNCH((epw_kernel<512, 4, 2, 1, true, true, 1, 0, true>), grid, dim3(512), lds, st, args);
-        else if (commit && lumina_dynamic) LANTERN_LAUNCH((epw_kernel<512, 4, 2, 1, true, true, 3, 0, true>), grid, dim3(512), lds, st, args);
-        else if (two_per_cu) LANTERN_LAUNCH((epw_kernel<512, 4, 2, 4, true, true>), grid, dim3(512), lds, st, args);
+        if (two_per_cu) LANTERN_LAUNCH((epw_kernel<512, 4, 2, 4, true, true>), grid, dim3(512), lds, st, args);
         else if (lumina_static && default_tree) LANTERN_LAUNCH((epw_kernel<512, 4, 2, 1, true, true, 2>), grid, dim3(512), lds, st, args);
         else if (lumina_static) LANTERN_LAUNCH((epw_kernel<512, 4, 2, 1, true, true, 1>), grid, dim3(512), lds, st, args);
         else if (lumina_dynamic) LANTERN_LAUNCH((epw_kernel<512, 4, 2, 1, true, true, 3>), grid, dim3(512), lds, st, args);
@@ -1904,10 +1615,7 @@ extern "C" int lantern_evaluate_posterior_window(const lantern_ep_params *prm, c
         else if (two_per_cu && W == 8192 && idmode == 2) LANTERN_LAUNCH((epw_kernel<512, 4, 2, 4, true>), grid, dim3(512), lds, st, args);
         else if (two_per_cu) EPW_LAUNCH_W(512, 4, 4);
         else if (W == 8192 && idmode == 2) {
-            if (commit && lumina_static && default_tree) LANTERN_LAUNCH((epw_kernel<512, 4, 2, 1, true, false, 2, 0, true>), grid, dim3(512), lds, st, args);
-            else if (commit && lumina_static) LANTERN_LAUNCH((epw_kernel<512, 4, 2, 1, true, false, 1, 0, true>), grid, dim3(512), lds, st, args);
-            else if (commit && lumina_dynamic) LANTERN_LAUNCH((epw_kernel<512, 4, 2, 1, true, false, 3, 0, true>), grid, dim3(512), lds, st, args);
-            else if (lumina_static && default_tree) LANTERN_LAUNCH((epw_kernel<512, 4, 2, 1, true, false, 2>), grid, dim3(512), lds, st, args);
+            if (lumina_static && default_tree) LANTERN_LAUNCH((epw_kernel<512, 4, 2, 1, true, false, 2>), grid, dim3(512), lds, st, args);
             else if (lumina_static) LANTERN_LAUNCH((epw_kernel<512, 4, 2, 1, true, false, 1>), grid, dim3(512), lds, st, args);
             else if (lumina_dynamic) LANTERN_LAUNCH((epw_kernel<512, 4, 2, 1, true, false, 3>), grid, dim3(512), lds, st, args);
             else if (anole_static) LANTERN_LAUNCH((epw_kernel<512, 4, 2, 1, true, false, 4>), grid, dim3(512), lds, st, args);

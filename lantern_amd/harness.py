@@ -16,7 +16,6 @@ This module is product-side host code: it never imports the oracle.
 from __future__ import annotations
 
 import ctypes as C
-import os
 import random
 from dataclasses import dataclass
 from typing import List
@@ -25,7 +24,7 @@ import numpy as np
 import torch
 
 from . import _lib, ops
-from ._lib import EpBuffers, EpCommit, EpNodes, EpParams, EpWindow, StepDynamic, StepGroup, check
+from ._lib import EpBuffers, EpNodes, EpParams, EpWindow, StepDynamic, StepGroup, check
 
 from contextlib import nullcontext as _nullctx
 
@@ -93,44 +92,10 @@ class WorkloadConfig:
                                     # up front, in the same launch as the candidate assembly (lantern_prepare_step); the rest on demand
     native_step: bool = True        # eager windowed path: the whole step of all groups through ONE C call (lantern_verify_step) instead of
                                     # 4 x n_groups ctypes calls (the Python launch loop caps the stream groups at ~2 otherwise)
-    fused_commit: bool = True       # native step on the chain kernel: the KV / hidden / token commit runs inside the evaluate_posterior launch
-                                    # (lantern_ep_commit: helper workgroups move a sequence's rows as soon as its walk ends); False: its own launch
     leaf_workgroups: int = -1       # node kernel: -1 = by batch size (include/lantern_hip.h lantern_ep_nodes)
     n_groups: int = 1               # >1: the sequences are split into groups, each launched on its own HIP stream, so that one
                                     # group's latency-bound evaluate_posterior overlaps the others' bandwidth-bound kernels
                                     # (independent sequences: no ordering between groups exists)
-
-
-def make_commit_blocks(n_groups: int, Bg: int, slabs_per_seq: int, device, enabled: bool = True):
-    """One lantern_ep_commit per stream group for the harness layout (slab j * Bg + b of a group belongs to sequence b): the helpers' queue, the
-    sequence -> slabs table and the number of helper workgroups -- what is left of a CU budget split over the groups, in teams of 16 (the
-    chain kernel's workgroups take a CU each).  lantern_verify_step fills in the rest from the step group."""
-    if not enabled:
-        return None
-    n_cu = torch.cuda.get_device_properties(device).multi_processor_count
-    movers = max(16, ((n_cu // max(n_groups, 1) - Bg) // 16) * 16)
-    if os.environ.get("LANTERN_COMMIT_MOVERS"):          # tuning knob (diagnostic)
-        movers = int(os.environ["LANTERN_COMMIT_MOVERS"])
-    while Bg > 64 * (movers // 16):
-        movers += 16
-    seq_slabs = (torch.arange(Bg, dtype=torch.int32, device=device)[:, None] + Bg * torch.arange(slabs_per_seq, dtype=torch.int32, device=device)[None]).contiguous()
-    queues = torch.zeros((n_groups, Bg), dtype=torch.int64, device=device)
-    blocks = []
-    for g in range(n_groups):
-        cm = EpCommit()
-        cm.seq_slabs, cm.slabs_per_seq, cm.n_movers, cm.queue, cm.epoch = seq_slabs.data_ptr(), slabs_per_seq, movers, queues[g].data_ptr(), 1
-        cm.team_size = int(os.environ.get("LANTERN_COMMIT_TEAM", "0"))          # tuning knob (diagnostic)
-        cm.reserved = int(os.environ.get("LANTERN_COMMIT_DEBUG", "0"))
-        blocks.append(cm)
-    return dict(blocks=blocks, ptrs=[C.pointer(b) for b in blocks], keep=(seq_slabs, queues), epoch=0, movers=movers)
-
-
-def next_commit_epoch(cb) -> int:
-    cb["epoch"] = cb["epoch"] % ((1 << 24) - 2) + 1          # differs from the previous launch's on every queue, never 0
-    for b in cb["blocks"]:
-        b.epoch = cb["epoch"]
-    return cb["epoch"]
-
 
 
 def build_neighbour_table(device, seed: int = 0) -> torch.Tensor:
@@ -334,13 +299,10 @@ class LuminaVerifyWorkload:
                 for g in range(self.G):
                     self._group_args(slot, parity, g)
         self._steps = {}
-        self._commit = None
         if self.windowed and cfg.native_step and cfg.direct_logs and cfg.fuse_update and not cfg.side_stream and not cfg.use_graph:
             for slot in range(cfg.pool_steps):
                 for parity in (0, 1):
                     self._steps[(slot, parity)] = self._make_step_groups(slot, parity)
-            if cfg.with_kv and cfg.fused_commit and self.ep_nodes is None:
-                self._commit = make_commit_blocks(self.G, self.Bg, 2, device)
 
     # -------------------------------------------------------------------------------------
     def reset_state(self):
@@ -604,9 +566,6 @@ class LuminaVerifyWorkload:
                 s.sample_token = self.sample_token[g * self.Bg:].data_ptr()
             s.ep_buf.best, s.ep_buf.accept_len, s.ep_buf.counters = bs["best"] + 4 * e, bs["alen"] + 4 * e, bs["cnt"] + 24 * e
             s.ep_win.u_bonus, s.ep_win.token = bs["ub"] + 8 * e, bs["tok"] + 8 * e
-            s.ep_win.commit = self._commit["ptrs"][g] if self._commit is not None else None
-        if self._commit is not None:
-            next_commit_epoch(self._commit)
         check(self._L.lantern_verify_step(arr, self.G), "verify_step")
         if not c.with_kv:
             for g in range(self.G):
@@ -908,7 +867,6 @@ class DynamicConfig:
     n_groups: int = 1               # >1: stream groups, as in WorkloadConfig (n_seq must divide)
     native_step: bool = True        # the whole step of all groups through ONE C call (lantern_verify_step with lantern_step_dynamic blocks);
                                     # False: one ctypes call per kernel and group
-    fused_commit: bool = True       # as WorkloadConfig.fused_commit (Lumina model, chain kernel)
 
 
 class DynamicVerifyWorkload:
@@ -1064,7 +1022,6 @@ class DynamicVerifyWorkload:
         for slot in range(S):
             for parity in (0, 1):
                 self._steps[(slot, parity)] = self._make_groups(slot, parity)
-        self._commit = make_commit_blocks(self.G, self.Bg, 2, device) if (cfg.with_kv and cfg.fused_commit and cfg.native_step) else None
 
     def _make_groups(self, slot: int, parity: int):
         c, vp = self.cfg, (lambda t, o=0: t[o:].data_ptr())
@@ -1158,10 +1115,7 @@ class DynamicVerifyWorkload:
             s.sample_token = self.first_token[g * self.Bg:].data_ptr() if i == 0 else bs["tok"] + 8 * (e - c.n_seq)
             s.ep_buf.best, s.ep_buf.accept_len, s.ep_buf.counters = bs["best"] + 4 * e, bs["alen"] + 4 * e, bs["cnt"] + 24 * e
             s.ep_win.u_bonus, s.ep_win.token = bs["ub"] + 8 * e, bs["tok"] + 8 * e
-            s.ep_win.commit = self._commit["ptrs"][g] if (native and self._commit is not None) else None
         if native:
-            if self._commit is not None:
-                next_commit_epoch(self._commit)
             check(L.lantern_verify_step(arr, self.G), "verify_step")
         else:
             for g in range(self.G):

@@ -30,7 +30,7 @@ def test_param_struct_layout_matches_header():
     # ctypes mirror vs the C struct: field order/size (a drift here corrupts every launch)
     assert C.sizeof(_lib.EpParams) == 4 * 11 + 32 + 4 * 5 + 4 + 4 + 8 + 4 * 4
     assert C.sizeof(_lib.EpBuffers) == 20 * 8
-    assert C.sizeof(_lib.EpWindow) == 8 + 8 + 8 + 5 * 8 + 8 + 4 * 8 + 6 * 4 + 2 * 8 + 8
+    assert C.sizeof(_lib.EpWindow) == 8 + 8 + 8 + 5 * 8 + 8 + 4 * 8 + 6 * 4 + 2 * 8
     assert C.sizeof(_lib.EpNodes) == 8 + 8 + 6 * 4 + 8 + 8 + 2 * 4
 
 
@@ -131,24 +131,20 @@ def test_step_group_layout_matches_the_c_struct(tmp_path):
     """ctypes mirror of lantern_step_group / lantern_ep_nodes vs the C compiler's layout of include/lantern_hip.h (a drift here
     would hand every kernel of lantern_verify_step the wrong pointers)."""
     import subprocess
-    wfields = ["row_hot", "rows_kind", "raw_uncond", "raw_pos_base", "raw_cfg", "raw_eos_id", "raw_probs", "raw_pre", "commit"]
-    cfields = ["slab_ptrs", "n_slabs", "outer", "retrieve", "N", "hidden", "hid_elem_bytes", "n_movers", "seq_slabs", "slabs_per_seq", "epoch", "queue"]
+    wfields = ["row_hot", "rows_kind", "raw_uncond", "raw_pos_base", "raw_cfg", "raw_eos_id", "raw_probs", "raw_pre"]
     fields = ["stream", "B", "tree_cand", "cond", "pos_base", "w_latent", "seq_len", "temperature", "ep", "ep_buf", "ep_win", "nodes",
               "slab_ptrs", "n_slabs", "outer", "hidden", "H", "node_list", "n_list"]
     src = tmp_path / "layout.c"
     src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "lantern_hip.h"\nint main(void){printf("%zu %zu", sizeof(lantern_step_group), sizeof(lantern_ep_nodes));\n'
                    + "".join(f'printf(" %zu", offsetof(lantern_step_group, {f}));\n' for f in fields)
-                   + 'printf(" %zu", sizeof(lantern_ep_window));\n' + "".join(f'printf(" %zu", offsetof(lantern_ep_window, {f}));\n' for f in wfields)
-                   + 'printf(" %zu", sizeof(lantern_ep_commit));\n' + "".join(f'printf(" %zu", offsetof(lantern_ep_commit, {f}));\n' for f in cfields) + "return 0;}\n")
+                   + 'printf(" %zu", sizeof(lantern_ep_window));\n' + "".join(f'printf(" %zu", offsetof(lantern_ep_window, {f}));\n' for f in wfields) + "return 0;}\n")
     exe = tmp_path / "layout"
     subprocess.check_call(["gcc", "-std=c99", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
     out = [int(x) for x in subprocess.check_output([str(exe)]).split()]
     assert out[0] == C.sizeof(_lib.StepGroup) and out[1] == C.sizeof(_lib.EpNodes)
     nf = len(fields)
     assert out[2:2 + nf] == [getattr(_lib.StepGroup, f).offset for f in fields]
-    nw = len(wfields)
-    assert out[2 + nf] == C.sizeof(_lib.EpWindow) and out[3 + nf:3 + nf + nw] == [getattr(_lib.EpWindow, f).offset for f in wfields]
-    assert out[3 + nf + nw] == C.sizeof(_lib.EpCommit) and out[4 + nf + nw:] == [getattr(_lib.EpCommit, f).offset for f in cfields]
+    assert out[2 + nf] == C.sizeof(_lib.EpWindow) and out[3 + nf:] == [getattr(_lib.EpWindow, f).offset for f in wfields]
 
 
 def test_draft_depth_args_layout_matches_the_c_struct(tmp_path):

@@ -1009,6 +1009,138 @@ __global__ __launch_bounds__(FC_THREADS) void linear_rows_packed_kernel(const ui
     }
 }
 
+// The same products as a tiled MFMA GEMM for MANY rows (prompt prefills: hundreds to thousands): workgroup = 128 rows x 128 output columns
+// (gate / up pair: 128 x 64 of each), four waves of 64 x 64 each (2 x 2 tiles of v_mfma_f32_32x32x16_bf16; the pair: 2 row tiles x {gate, up} of
+// one 32-column tile, so silu(gate) * up is element-wise in registers).  Per 64-element K block the A tile (128 x 64 bf16) goes global ->
+// registers -> LDS (rows padded to 144 bytes: the 16 lanes of a ds_read_b128 phase cover all 64 banks once), double-buffered, the next block's
+// global loads in flight under this block's MFMAs; the weights come straight from the packed bricks (already in B-fragment order: 16 bytes
+// per lane and MFMA step, no LDS), next block's prefetched into a second register set.  The row-blocked kernel above (kept for 33 - 128 rows) re-reads A from L2 for
+// every 32-column tile (15 GB at 1200 rows of the 7B layer); here A crosses L2 -> LDS once per 128 columns.
+constexpr int TG_BM = 128, TG_THREADS = 256, TG_LDA = 72;          // LDS row stride in bf16 elements (64 + 8 pad)
+
+template <int EPI>
+__global__ __launch_bounds__(TG_THREADS, 2) void linear_rows_tiled_kernel(const uint16_t *__restrict__ A, const uint16_t *__restrict__ Wp,
+                                                                       const uint16_t *__restrict__ bias, int M, int K, int n_rows,
+                                                                       uint16_t *__restrict__ out, int out_stride, const uint16_t *__restrict__ aux,
+                                                                       int aux_stride, int pair_rows) {
+    constexpr int NSET = EPI == 2 ? 2 : 1;
+    __shared__ alignas(16) uint16_t sA[2][TG_BM * TG_LDA];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int wm = wave >> 1, wn = wave & 1;          // the wave's 64-row half and 64-column (pair: 32-column) half
+    const int m0 = blockIdx.x * TG_BM;
+    const int nb = K / 64;
+    // the two 32-column weight tiles (EPI 2: the gate and the up set of ONE tile) this wave contracts with
+    const int n_tiles = (n_rows + 31) / 32;
+    int tile[2];
+    size_t boff[2];
+#pragma unroll
+    for (int s_ = 0; s_ < 2; ++s_) {
+        int t = EPI == 2 ? (int)blockIdx.y * 2 + wn : (int)blockIdx.y * 4 + wn * 2 + s_;
+        tile[s_] = t;
+        if (t >= n_tiles) t = n_tiles - 1;          // (a surplus tile contracts the last one again and stores nothing)
+        boff[s_] = ((size_t)t * nb * NSET + (EPI == 2 ? s_ : 0)) * 2048 + lane * 8;
+    }
+    // A: thread -> four 16-byte chunks of the 128 x 64 block (chunk c of row i / 8 ... coalesced 128-byte rows)
+    const uint16_t *ag[4];
+    bool alive[4];
+    int lds_off[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int ch = tid + i * TG_THREADS, row = ch >> 3, c = ch & 7;
+        alive[i] = m0 + row < M;
+        ag[i] = A + (size_t)(alive[i] ? m0 + row : 0) * K + c * 8;
+        lds_off[i] = row * TG_LDA + c * 8;
+    }
+    f32x16_t acc[2][2];
+#pragma unroll
+    for (int s_ = 0; s_ < 2; ++s_)
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[s_][mt][i] = 0.0f;
+    uint4 areg[4];
+    bf16x8_t w0[2][4], w1[2][4];          // (two named sets, not an indexed array: a run-time index would put them in scratch)
+    auto load_a = [&](int kb) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) areg[i] = alive[i] ? *reinterpret_cast<const uint4 *>(ag[i] + (size_t)kb * 64) : make_uint4(0, 0, 0, 0);
+    };
+    auto store_a = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) *reinterpret_cast<uint4 *>(&sA[buf][lds_off[i]]) = areg[i];
+    };
+    auto load_w = [&](int kb, bf16x8_t (&w)[2][4]) {
+#pragma unroll
+        for (int s_ = 0; s_ < 2; ++s_)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) w[s_][q] = load_frag(Wp + boff[s_] + (size_t)kb * NSET * 2048 + q * 512);
+    };
+    auto compute = [&](int buf, const bf16x8_t (&w)[2][4]) {
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            const uint16_t *arow = &sA[buf][(wm * 64 + mt * 32 + r) * TG_LDA + 32 * h];
+            bf16x8_t af[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) af[q] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4 *>(arow + 8 * q));
+#pragma unroll
+            for (int s_ = 0; s_ < 2; ++s_)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[s_][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[q], w[s_][q], acc[s_][mt], 0, 0, 0);
+        }
+    };
+    load_a(0);
+    load_w(0, w0);
+    store_a(0);
+    __syncthreads();
+    for (int kb = 0; kb < nb; kb += 2) {
+        if (kb + 1 < nb) {
+            load_a(kb + 1);
+            load_w(kb + 1, w1);
+        }
+        compute(0, w0);
+        if (kb + 1 < nb) store_a(1);          // (the other buffer: its readers finished before the previous barrier)
+        __syncthreads();
+        if (kb + 1 >= nb) break;
+        if (kb + 2 < nb) {
+            load_a(kb + 2);
+            load_w(kb + 2, w0);
+        }
+        compute(1, w1);
+        if (kb + 2 < nb) store_a(0);
+        __syncthreads();
+    }
+    // epilogue from the accumulators: element (row = (reg & 3) + 8 (reg >> 2) + 4 h, column r) of each 32 x 32 tile
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            const int m = m0 + wm * 64 + mt * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+            if (m >= M) continue;
+            if constexpr (EPI == 2) {
+                const int n = tile[0] * 32 + r;
+                if (tile[0] < n_tiles && n < n_rows) {
+                    float g = acc[0][mt][reg], u = acc[1][mt][reg];
+                    if (bias) { g += bf16_bits_to_f32(bias[n]); u += bf16_bits_to_f32(bias[pair_rows + n]); }
+                    const float gb = bf16_bits_to_f32(f32_to_bf16_rne(g)), ub = bf16_bits_to_f32(f32_to_bf16_rne(u));
+                    const float sg = bf16_bits_to_f32(f32_to_bf16_rne(gb / (1.0f + expf(-gb))));
+                    out[(size_t)m * out_stride + n] = f32_to_bf16_rne(sg * ub);
+                }
+            } else {
+#pragma unroll
+                for (int s_ = 0; s_ < 2; ++s_) {
+                    const int n = tile[s_] * 32 + r;
+                    if (tile[s_] < n_tiles && n < n_rows) {
+                        float v = acc[s_][mt][reg];
+                        if (bias) v += bf16_bits_to_f32(bias[n]);
+                        uint16_t o = f32_to_bf16_rne(v);
+                        if constexpr (EPI == 1) o = f32_to_bf16_rne(bf16_bits_to_f32(aux[(size_t)m * aux_stride + n]) + bf16_bits_to_f32(o));
+                        out[(size_t)m * out_stride + n] = o;
+                    }
+                }
+            }
+        }
+}
+
 extern "C" int lantern_linear_rows_packed(const void *A, const void *W_packed, const void *bias, int M, int K, int n_rows, void *out, int out_stride,
                                           int epilogue, const void *aux, int aux_stride, int pair_rows, void *stream) {
     LANTERN_CHECK_ARG(A && W_packed && out, "linear_rows_packed: null buffer");
@@ -1022,6 +1154,15 @@ extern "C" int lantern_linear_rows_packed(const void *A, const void *W_packed, c
     uint16_t *o = (uint16_t *)out;
     const int tiles = (n_rows + 31) / 32;
     LANTERN_CHECK_ARG((M + 63) / 64 <= 65535, "linear_rows_packed: M=%d rows exceed the launch grid", M);
+    static const int tiled_from = getenv("LANTERN_GEMM_TILED_FROM") ? atoi(getenv("LANTERN_GEMM_TILED_FROM")) : 129;   // tuning knob (diagnostic)
+    if (M >= tiled_from) {          // many rows: the LDS-tiled form (128 x 128 per workgroup; row blocks fastest so that a weight tile's readers are neighbours)
+        const dim3 grid((M + TG_BM - 1) / TG_BM, epilogue == LANTERN_EPI_SILU_MUL ? (tiles + 1) / 2 : (tiles + 3) / 4);
+        if (epilogue == LANTERN_EPI_SILU_MUL) LANTERN_LAUNCH((linear_rows_tiled_kernel<2>), grid, dim3(TG_THREADS), 0, st, a, w, bi, M, K, n_rows, o, out_stride, ax, aux_stride, pair_rows);
+        else if (epilogue == LANTERN_EPI_RESIDUAL) LANTERN_LAUNCH((linear_rows_tiled_kernel<1>), grid, dim3(TG_THREADS), 0, st, a, w, bi, M, K, n_rows, o, out_stride, ax, aux_stride, 0);
+        else LANTERN_LAUNCH((linear_rows_tiled_kernel<0>), grid, dim3(TG_THREADS), 0, st, a, w, bi, M, K, n_rows, o, out_stride, ax, aux_stride, 0);
+        LANTERN_CHECK_LAUNCH("linear_rows_packed");
+        return LANTERN_OK;
+    }
 #define LRP_LAUNCH(MT_, E_)                                                                                                                         \
     LANTERN_LAUNCH((linear_rows_packed_kernel<MT_, E_>), dim3(tiles, (M + MT_ * 32 - 1) / (MT_ * 32)), dim3(FC_THREADS), 0, st, a, w, bi, M, K, n_rows, o, \
                    out_stride, ax, aux_stride, epilogue == LANTERN_EPI_SILU_MUL ? pair_rows : 0)

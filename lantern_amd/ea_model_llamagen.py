@@ -97,6 +97,18 @@ class EaModel(nn.Module):
         return cand[0], (cprob[0] if cprob is not None else None), tcand
 
     # ------------------------------------------------------------------ :908-932
+    def _tree_forward(self, tree_candidates, past_key_values, tree_position_ids, input_ids, attention_mask=None, input_position_diff=0):
+        """The target forward over the tree tokens (the first half of tree_decoding, ea_model_llamagen.py:908-925): (outputs, [2,N,V] logits, hidden)."""
+        position_ids = tree_position_ids + input_ids.shape[1]
+        if self.mask_non_image:      # Anole: separate cond / uncond position ids (ea_model_anole.py:915-918)
+            position_ids = position_ids.unsqueeze(0)
+            position_ids = torch.cat([position_ids, position_ids - input_position_diff], dim=0)
+        if attention_mask is not None:
+            remaining = input_ids.shape[1] + tree_candidates.shape[1] - attention_mask.shape[1]
+            attention_mask = torch.cat([attention_mask, torch.ones((attention_mask.shape[0], remaining), dtype=torch.long,
+                                                                    device=attention_mask.device)], dim=1)
+        return self(input_ids=tree_candidates, output_orig=True, past_key_values=past_key_values, position_ids=position_ids, attention_mask=attention_mask)
+
     def tree_decoding(self, tree_candidates, past_key_values, tree_position_ids, input_ids, retrieve_indices, cfg_scale,
                       attention_mask=None, input_position_diff=0):
         position_ids = tree_position_ids + input_ids.shape[1]
@@ -282,8 +294,167 @@ class EaModel(nn.Module):
                                                                 table=self.nearest_latents if lantern else None, aux=aux, cursor=fifo.cursor)
         return dict(best=best, accept_len=alen, status=counters[:, 5], token=None, sample_p=sample_p[0], counters=counters)
 
+    # ------------------------------------------------------------------ the static-tree step through ONE lantern_verify_step call
+    native_step = True          # False: every kernel its own ctypes call with fresh tensors (the form the one-call step is tested against)
+
+    def _native_ctx(self, st, logits_processor, cfg_scale, lantern, lantern_k, lantern_delta):
+        """What a generate() call's static-tree steps share, built once (ea_model_lumina_mgpt.EaLumina_mGPT._native_ctx is the same idea): the
+        lantern_step_group with preallocated outputs.  None when this configuration stays on the per-kernel path (dynamic trees, greedy decoding,
+        the dense kernel set, a model spread over devices, slabs of different shapes)."""
+        import ctypes as C
+        from . import _lib
+        if not (self.native_step and st.static and self.kernel_set == "window" and logits_processor is not None and not st.multi_device):
+            return None
+        tb, hip = self.tree_buffers, self.tree_buffers["_hip"]
+        s0 = st.slabs[0]
+        if any(x.shape != s0.shape or x.dtype != s0.dtype or x.device != s0.device or not x.is_contiguous() for x in st.slabs):
+            return None
+        dev = s0.device
+        N, P, D, R = hip["N"], hip["P"], hip["D"], hip["R"]
+        V = self.vocab_size
+        lo, W = (self.image_lo, self.image_hi - self.image_lo) if self.mask_non_image else (0, V)
+        if D > 8 or N > 64 or W % 8 or W > 16384:
+            return None
+        proc = ProcessorSpec.from_hf(logits_processor)
+        nx = types.SimpleNamespace(C=C, L=_lib.lib(), dev=dev, N=N, P=P, D=D, R=R, lo=lo, W=W)
+        z = lambda *shape, dt: torch.zeros(shape, dtype=dt, device=dev)
+        nx.cand, nx.cart, nx.tcand = z(1, P, D, dt=torch.int64), z(1, P, D, dt=torch.float32), z(1, N, dt=torch.int64)
+        nx.win, nx.hot = z(N, W, dt=torch.float32), z(N, dt=torch.int32)
+        # the verdict record, double-buffered: best, accept_len, counters[6], bonus token (int64 at words 8-9)
+        nx.recs = [z(16, dt=torch.int32), z(16, dt=torch.int32)]
+        nx.toks = [r_[8:10].view(torch.int64) for r_ in nx.recs]
+        nx.otok, nx.omass = z(1, dt=torch.int32), z(1, dt=torch.float32)
+        nx.out_hs, nx.acc = [None, None], z(1, D, dt=torch.int64)
+        nx.stream = torch.cuda.current_stream().cuda_stream
+        nx.tree_indices = tb["tree_indices"].to(dev).contiguous()
+        nx.retrieve = tb["retrieve_indices_head"].to(dev).contiguous()
+        ri = nx.retrieve.clone()
+        ri[ri < 0] += N
+        nx.row_index = ri.to(torch.int32).contiguous()
+        n_sl = len(st.slabs)
+        nx.prev = [torch.zeros(n_sl, dtype=torch.int64, device=dev), torch.zeros(n_sl, dtype=torch.int64, device=dev)]
+        nx.parity = 0
+        g = nx.group = (_lib.StepGroup * 1)()
+        a = g[0]
+        a.tree_indices, a.retrieve = nx.tree_indices.data_ptr(), nx.retrieve.data_ptr()
+        a.B, a.n_flat, a.N, a.P, a.D = 1, 0, N, P, D          # (n_flat: set per step from the drafter's sample list)
+        a.tree_cand, a.cand, a.cart_prob = nx.tcand.data_ptr(), nx.cand.data_ptr(), nx.cart.data_ptr()
+        a.V, a.cfg, a.model = V, float(cfg_scale), (ops.MODEL_ANOLE if self.mask_non_image else ops.MODEL_PLAIN)
+        a.img_lo, a.img_hi = (self.image_lo, self.image_hi) if self.mask_non_image else (0, V)
+        a.top_k, a.win_lo, a.win_len, a.out_kind = min(proc.top_k, V), lo, W, ops.ROWS_PROBS
+        a.out_win, a.row_hot, a.temperature, a.top_p = nx.win.data_ptr(), nx.hot.data_ptr(), float(proc.temperature), float(proc.top_p)
+        cfg = self._ep_config(True, proc, lantern, lantern_k, lantern_delta)
+        p = a.ep
+        p.B, p.P, p.D, p.V, p.rows_per_seq = 1, P, D, V, N
+        p.mode, p.syntax_shortcut, p.tok_offset = cfg.mode, int(cfg.syntax_shortcut), cfg.tok_offset
+        p.img_lo, p.img_hi, p.n_syntax = cfg.img_lo, min(cfg.img_hi, 2 ** 31 - 1), len(cfg.syntax)
+        for i, sx in enumerate(cfg.syntax):
+            p.syntax[i] = int(sx)
+        p.lantern, p.k, p.delta = int(cfg.lantern), int(cfg.k), float(cfg.delta)
+        p.top_k, p.temperature, p.top_p = 0, 1.0, 1.0          # the rows are final probabilities (the processors ran in the O7 stage)
+        fifo = self._uniforms()
+        p.n_uniforms, p.R, p.N, p.row_index_per_seq = fifo.buf.shape[1], R, N, 0
+        nx.table = self._packed_table(int(lantern_k)) if lantern else None
+        if nx.table is not None:
+            p.table_rows, p.table_cols = nx.table.shape
+        b = a.ep_buf
+        b.logits, b.row_index, b.cand, b.cart_prob = nx.win.data_ptr(), nx.row_index.data_ptr(), nx.cand.data_ptr(), nx.cart.data_ptr()
+        b.op_off, b.p_idx, b.b_off, b.b_idx = hip["op_off"].data_ptr(), hip["p_idx"].data_ptr(), hip["b_off"].data_ptr(), hip["b_idx"].data_ptr()
+        b.tree_cand, b.nn_table = nx.tcand.data_ptr(), (nx.table.data_ptr() if nx.table is not None else None)
+        b.uniforms, b.cursor = fifo.buf.data_ptr(), fifo.cursor.data_ptr()
+        w = a.ep_win
+        w.win_lo, w.win_len, w.row_hot, w.rows_kind = lo, W, nx.hot.data_ptr(), ops.ROWS_PROBS
+        w.orig_prob_stride, w.orig_prob_offset = V, lo
+        w.out_tok, w.out_mass = nx.otok.data_ptr(), nx.omass.data_ptr()
+        a.slab_ptrs, a.slab_seq = st.slab_ptrs.data_ptr(), st.slab_seq.data_ptr()
+        S, d = s0.shape[-2], s0.shape[-1]
+        a.n_slabs, a.elem_bytes, a.outer, a.S_max, a.d = n_sl, s0.element_size(), s0.numel() // (S * d), S, d
+        a.accepted_tokens = nx.acc.data_ptr()
+        a.hid_groups = 2
+        return nx
+
+    def _verify_step_native(self, st, nx, logits_processor, cfg_scale, lantern, lantern_k, lantern_delta):
+        """One static-tree step: generate_candidates (one call: the target forward needs the tree tokens), the forward, then ONE lantern_verify_step
+        call -- candidates again (idempotent), Temperature -> TopP -> TopK + softmax of all rows, evaluate_posterior with the bonus draw, the KV /
+        hidden / token commit (only where the walk reported no status) -- on preallocated buffers, and one host read of the verdict record.  Same
+        kernels, same uniforms, same results as the per-kernel path (tests/test_gpu_generate_lg.py runs the reference-recorded cases through both)."""
+        C, L, a = nx.C, nx.L, nx.group[0]
+        tl = st.tree_logits
+        ss_token = tl[0].to(nx.dev).contiguous()
+        ss_prob = tl[1].to(nx.dev)
+        ss_prob = (ss_prob if ss_prob.dtype == torch.float32 else ss_prob.float()).contiguous()
+        sample = st.sample_token.to(nx.dev).reshape(-1)[:1].contiguous()
+        par = nx.parity
+        rec, tokbuf = nx.recs[par], nx.toks[par]
+        a.ep_buf.best, a.ep_buf.accept_len, a.ep_buf.counters = rec.data_ptr(), rec.data_ptr() + 4, rec.data_ptr() + 8
+        a.ep_win.token = tokbuf.data_ptr()
+        a.stream, a.ss_token, a.ss_prob, a.sample_token, a.n_flat = nx.stream, ss_token.data_ptr(), ss_prob.data_ptr(), sample.data_ptr(), ss_token.numel()
+        ops.check(L.lantern_gather_candidates(C.c_void_p(a.ss_token), C.c_void_p(a.ss_prob), C.c_void_p(a.sample_token), C.c_void_p(a.tree_indices), C.c_void_p(a.retrieve),
+                                              1, a.n_flat, nx.N, nx.P, nx.D, C.c_void_p(a.tree_cand), C.c_void_p(a.cand), C.c_void_p(a.cart_prob), C.c_void_p(nx.stream)),
+                  "gather_candidates")
+        kw = dict(input_position_diff=st.input_position_diff) if self.mask_non_image else {}
+        tree_candidates = torch.cat([nx.tcand, nx.tcand])
+        _, tree_logits, hidden_new = self._tree_forward(tree_candidates, self.base_model.past_key_values, self.tree_buffers["tree_position_ids"], st.input_ids,
+                                                        st.attention_mask, **kw)
+        half = tree_logits.shape[0] // 2
+        cl, ul = tree_logits[0], tree_logits[half]
+        if cl.dtype not in (torch.bfloat16, torch.float32):
+            cl, ul = cl.float(), ul.float()
+        cl, ul = cl.contiguous(), ul.contiguous()
+        a.cond, a.uncond, a.dtype = cl.data_ptr(), ul.data_ptr(), int(cl.dtype == torch.bfloat16)
+        orig = concat_original_prob(tl[2])
+        a.ep_buf.orig_prob = orig.data_ptr()
+        hid = hidden_new.contiguous()[None]                                                # [1, 2, N, H]
+        out_h = nx.out_hs[par]
+        if out_h is None or out_h.dtype != hid.dtype or out_h.shape[-1] != hid.shape[-1]:
+            out_h = nx.out_hs[par] = torch.zeros((1, 2, nx.D, hid.shape[-1]), dtype=hid.dtype, device=nx.dev)
+        a.hidden, a.out_hidden, a.hid_elem_bytes, a.H = hid.data_ptr(), out_h.data_ptr(), hid.element_size(), hid.shape[-1]
+        fifo = self._uniforms()
+        fifo.reserve(nx.P * nx.D)
+        u = torch.rand(1, dtype=torch.float64, device=nx.dev)
+        a.ep_win.u_bonus = u.data_ptr()
+        prev = st.input_ids.shape[1]
+        cur, nxt = nx.prev[par], nx.prev[par ^ 1]
+        cur.fill_(prev)
+        a.slab_prev, a.new_len = cur.data_ptr(), nxt.data_ptr()
+        ops.check(L.lantern_verify_step(nx.group, 1), "verify_step")
+        r = rec.tolist()                                                                   # the step's one host read
+        best, alen, n_used, status, tok = r[0], r[1], r[5], r[7], r[8]
+        nx.parity ^= 1
+        if status != 0:
+            if status in self._RETRY_DENSE:
+                # a state only the dense kernel represents: nothing was committed (lantern_verify_step commits only walks without a status); the same
+                # step on the dense HIP kernel, from the same uniforms, through the host-integer path (rare: once in millions of steps)
+                fifo.cursor.sub_(n_used)
+                hip = self.tree_buffers["_hip"]
+                aux = ops.StaticAux(cart_prob=nx.cart, orig_prob=orig, op_off=hip["op_off"], p_idx=hip["p_idx"], b_off=hip["b_off"], b_idx=hip["b_idx"],
+                                    tree_cand=nx.tcand[:, :hip["N"]])
+                rows = NodeLogits(self._dense_node_logits(tree_logits, half, cfg_scale), nx.retrieve)
+                ep = self._posterior_on_device(rows, nx.cand[0], logits_processor, aux, True, lantern, lantern_k, lantern_delta, u)
+                ops.raise_on_status(ep["counters"])
+                al, bst = int(ep["accept_len"][0]), int(ep["best"][0])
+                out = self.update_inference_inputs(st.input_ids, nx.cand[0], bst, al, nx.retrieve, logits_processor, 0, st.slabs, self.base_model.current_length_data,
+                                                   hidden_new, ep["sample_p"], cfg_scale, st.input_position_diff, st.attention_mask, True, u=u)
+                st.input_ids = out[0]
+                self._take_draft(st, out[1], out[-1])
+                return bst, al
+            ops.raise_on_status(rec[2:8].reshape(1, 6))
+        n = alen + 1
+        self.base_model.current_length_data.fill_(prev + n)
+        st.input_ids = torch.cat([st.input_ids, nx.acc[:, :n].to(st.input_ids.device)], dim=-1)
+        token = tokbuf.reshape(1, 1)
+        self._take_draft(st, self._draft_next(st.input_ids, out_h[0, :, :n], token, logits_processor, cfg_scale, st.input_position_diff, st.attention_mask, True),
+                         token)
+        return best, alen
+
     def _verify_step(self, st, logits_processor, cfg_scale, lantern, lantern_k, lantern_delta):
         """One step of the loop: O6, target forward + O7 (tree_decoding), O8, O9 + O10, the bonus token, the next draft."""
+        nx = getattr(st, "native", None)
+        if nx is None and not getattr(st, "native_tried", False):
+            st.native_tried = True
+            nx = st.native = self._native_ctx(st, logits_processor, cfg_scale, lantern, lantern_k, lantern_delta)
+        if nx is not None:
+            return self._verify_step_native(st, nx, logits_processor, cfg_scale, lantern, lantern_k, lantern_delta)
         pkv = self.base_model.past_key_values
         kw = dict(input_position_diff=st.input_position_diff) if self.mask_non_image else {}
         aux = None

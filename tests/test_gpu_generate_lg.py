@@ -44,8 +44,9 @@ def build(case, kernel_set):
     return mdl, base, drafter
 
 
-def run_case(case, kernel_set="window", mdl_parts=None):
+def run_case(case, kernel_set="window", mdl_parts=None, native=True):
     mdl, base, drafter = mdl_parts or build(case, kernel_set)
+    mdl.native_step = native                       # True: a static-tree step through ONE lantern_verify_step call; False: a ctypes call per kernel
     g = lambda k: GOLD[case["name"] + "." + k]
     draws = F.DetDraws(g("bonus_uniforms"))
     random.seed(case["seed"])
@@ -62,9 +63,17 @@ def run_case(case, kernel_set="window", mdl_parts=None):
 
 
 @pytest.mark.parametrize("case", G.CASES, ids=[c["name"] for c in G.CASES])
-@pytest.mark.parametrize("kernel_set", ["window", "dense"])
-def test_generate_reproduces_the_reference_run(case, kernel_set):
-    mdl, base, drafter, draws, ids, mean_alen = run_case(case, kernel_set)
+@pytest.mark.parametrize("kernel_set,native", [("window", True), ("window", False), ("dense", False)], ids=["window_one_call_step", "window", "dense"])
+def test_generate_reproduces_the_reference_run(case, kernel_set, native, monkeypatch):
+    calls = []
+    static = case["tree"] != "dynamic"
+    if native and static and case["temperature"] > 1e-5:          # the one-call step really is the path taken for sampled static-tree runs
+        from lantern_amd import ops
+        for fn in ("evaluate_posterior_window", "update_inference_inputs", "cfg_mask_topk_window"):
+            real = getattr(ops, fn)
+            monkeypatch.setattr(ops, fn, (lambda real, fn: (lambda *a, **k: (calls.append(fn), real(*a, **k))[1]))(real, fn))
+    mdl, base, drafter, draws, ids, mean_alen = run_case(case, kernel_set, native=native)
+    assert not calls, calls
     g = lambda k: GOLD[case["name"] + "." + k]
     assert ids.cpu().numpy().tolist() == g("ids").tolist()
     assert mean_alen == float(g("mean_accept"))

@@ -391,7 +391,8 @@ typedef struct lantern_step_group {
     /* with ep_win.rows_kind == LANTERN_ROWS_RAW_BF16: the nodes whose rows are post-processed up front, together with the candidate
      * assembly, in ONE launch (lantern_prepare_step) -- the root and the most likely children; NULL / 0: none (all rows on demand) */
     const int32_t *node_list; int32_t n_list, reserved2;   /* dynamic groups: [2 * n_list] = the nodes, then the depth each is assumed to sit at */
-    const lantern_step_dynamic *dyn;      /* NULL: a static tree (ss_token / tree_indices / retrieve) */
+    const lantern_step_dynamic *dyn;      /* NULL: a static tree (ss_token / tree_indices / retrieve); with ss_token NULL as well the candidates
+                                             are taken as the caller left them in `cand` (a tree that came with its token list: `retrieve` [P,D]) */
 } lantern_step_group;
 int lantern_verify_step(const lantern_step_group *groups, int n_groups);
 /* O6 + O7 restricted to s->node_list in one launch (bf16 Lumina rows, 8192-id window): candidates -> s->tree_cand / cand / cart_prob,

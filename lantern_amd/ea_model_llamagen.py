@@ -303,47 +303,52 @@ class EaModel(nn.Module):
         the dense kernel set, a model spread over devices, slabs of different shapes)."""
         import ctypes as C
         from . import _lib
-        if not (self.native_step and st.static and self.kernel_set == "window" and logits_processor is not None and not st.multi_device):
+        if not (self.native_step and self.kernel_set == "window" and logits_processor is not None and not st.multi_device):
             return None
-        tb, hip = self.tree_buffers, self.tree_buffers["_hip"]
         s0 = st.slabs[0]
         if any(x.shape != s0.shape or x.dtype != s0.dtype or x.device != s0.device or not x.is_contiguous() for x in st.slabs):
             return None
         dev = s0.device
-        N, P, D, R = hip["N"], hip["P"], hip["D"], hip["R"]
+        if st.static:
+            tb, hip = self.tree_buffers, self.tree_buffers["_hip"]
+            N, P, D, R = hip["N"], hip["P"], hip["D"], hip["R"]
+        else:          # EAGLE-2: the drafter hands over a tree per step (token list, paths); P and D are that step's, N = its token count
+            N, P, D, R = int(st.draft_tokens.shape[1]), 0, 0, 0
         V = self.vocab_size
         lo, W = (self.image_lo, self.image_hi - self.image_lo) if self.mask_non_image else (0, V)
         if D > 8 or N > 64 or W % 8 or W > 16384:
             return None
         proc = ProcessorSpec.from_hf(logits_processor)
-        nx = types.SimpleNamespace(C=C, L=_lib.lib(), dev=dev, N=N, P=P, D=D, R=R, lo=lo, W=W)
+        nx = types.SimpleNamespace(C=C, L=_lib.lib(), dev=dev, N=N, P=P, D=D, R=R, lo=lo, W=W, static=bool(st.static))
         z = lambda *shape, dt: torch.zeros(shape, dtype=dt, device=dev)
-        nx.cand, nx.cart, nx.tcand = z(1, P, D, dt=torch.int64), z(1, P, D, dt=torch.float32), z(1, N, dt=torch.int64)
+        nx.cand, nx.cart, nx.tcand = z(1, max(P, 1), max(D, 1), dt=torch.int64), z(1, max(P, 1), max(D, 1), dt=torch.float32), z(1, N, dt=torch.int64)
         nx.win, nx.hot = z(N, W, dt=torch.float32), z(N, dt=torch.int32)
         # the verdict record, double-buffered: best, accept_len, counters[6], bonus token (int64 at words 8-9)
         nx.recs = [z(16, dt=torch.int32), z(16, dt=torch.int32)]
         nx.toks = [r_[8:10].view(torch.int64) for r_ in nx.recs]
         nx.otok, nx.omass = z(1, dt=torch.int32), z(1, dt=torch.float32)
-        nx.out_hs, nx.acc = [None, None], z(1, D, dt=torch.int64)
+        nx.out_hs, nx.acc = [None, None], z(1, 8, dt=torch.int64)
         nx.stream = torch.cuda.current_stream().cuda_stream
-        nx.tree_indices = tb["tree_indices"].to(dev).contiguous()
-        nx.retrieve = tb["retrieve_indices_head"].to(dev).contiguous()
-        ri = nx.retrieve.clone()
-        ri[ri < 0] += N
-        nx.row_index = ri.to(torch.int32).contiguous()
+        if st.static:
+            nx.tree_indices = tb["tree_indices"].to(dev).contiguous()
+            nx.retrieve = tb["retrieve_indices_head"].to(dev).contiguous()
+            ri = nx.retrieve.clone()
+            ri[ri < 0] += N
+            nx.row_index = ri.to(torch.int32).contiguous()
         n_sl = len(st.slabs)
         nx.prev = [torch.zeros(n_sl, dtype=torch.int64, device=dev), torch.zeros(n_sl, dtype=torch.int64, device=dev)]
         nx.parity = 0
         g = nx.group = (_lib.StepGroup * 1)()
         a = g[0]
-        a.tree_indices, a.retrieve = nx.tree_indices.data_ptr(), nx.retrieve.data_ptr()
-        a.B, a.n_flat, a.N, a.P, a.D = 1, 0, N, P, D          # (n_flat: set per step from the drafter's sample list)
+        if st.static:
+            a.tree_indices, a.retrieve = nx.tree_indices.data_ptr(), nx.retrieve.data_ptr()
+        a.B, a.n_flat, a.N, a.P, a.D = 1, 0, N, P, D          # (n_flat: set per step from the drafter's sample list; dynamic trees: P, D per step)
         a.tree_cand, a.cand, a.cart_prob = nx.tcand.data_ptr(), nx.cand.data_ptr(), nx.cart.data_ptr()
         a.V, a.cfg, a.model = V, float(cfg_scale), (ops.MODEL_ANOLE if self.mask_non_image else ops.MODEL_PLAIN)
         a.img_lo, a.img_hi = (self.image_lo, self.image_hi) if self.mask_non_image else (0, V)
         a.top_k, a.win_lo, a.win_len, a.out_kind = min(proc.top_k, V), lo, W, ops.ROWS_PROBS
         a.out_win, a.row_hot, a.temperature, a.top_p = nx.win.data_ptr(), nx.hot.data_ptr(), float(proc.temperature), float(proc.top_p)
-        cfg = self._ep_config(True, proc, lantern, lantern_k, lantern_delta)
+        cfg = self._ep_config(bool(st.static), proc, lantern, lantern_k, lantern_delta)
         p = a.ep
         p.B, p.P, p.D, p.V, p.rows_per_seq = 1, P, D, V, N
         p.mode, p.syntax_shortcut, p.tok_offset = cfg.mode, int(cfg.syntax_shortcut), cfg.tok_offset
@@ -358,9 +363,12 @@ class EaModel(nn.Module):
         if nx.table is not None:
             p.table_rows, p.table_cols = nx.table.shape
         b = a.ep_buf
-        b.logits, b.row_index, b.cand, b.cart_prob = nx.win.data_ptr(), nx.row_index.data_ptr(), nx.cand.data_ptr(), nx.cart.data_ptr()
-        b.op_off, b.p_idx, b.b_off, b.b_idx = hip["op_off"].data_ptr(), hip["p_idx"].data_ptr(), hip["b_off"].data_ptr(), hip["b_idx"].data_ptr()
-        b.tree_cand, b.nn_table = nx.tcand.data_ptr(), (nx.table.data_ptr() if nx.table is not None else None)
+        b.logits = nx.win.data_ptr()
+        if st.static:
+            b.row_index, b.cand, b.cart_prob = nx.row_index.data_ptr(), nx.cand.data_ptr(), nx.cart.data_ptr()
+            b.op_off, b.p_idx, b.b_off, b.b_idx = hip["op_off"].data_ptr(), hip["p_idx"].data_ptr(), hip["b_off"].data_ptr(), hip["b_idx"].data_ptr()
+            b.tree_cand = nx.tcand.data_ptr()
+        b.nn_table = nx.table.data_ptr() if nx.table is not None else None
         b.uniforms, b.cursor = fifo.buf.data_ptr(), fifo.cursor.data_ptr()
         w = a.ep_win
         w.win_lo, w.win_len, w.row_hot, w.rows_kind = lo, W, nx.hot.data_ptr(), ops.ROWS_PROBS
@@ -378,6 +386,8 @@ class EaModel(nn.Module):
         call -- candidates again (idempotent), Temperature -> TopP -> TopK + softmax of all rows, evaluate_posterior with the bonus draw, the KV /
         hidden / token commit (only where the walk reported no status) -- on preallocated buffers, and one host read of the verdict record.  Same
         kernels, same uniforms, same results as the per-kernel path (tests/test_gpu_generate_lg.py runs the reference-recorded cases through both)."""
+        if not nx.static:
+            return self._verify_step_native_dynamic(st, nx, logits_processor, cfg_scale, lantern, lantern_k, lantern_delta)
         C, L, a = nx.C, nx.L, nx.group[0]
         tl = st.tree_logits
         ss_token = tl[0].to(nx.dev).contiguous()
@@ -447,6 +457,86 @@ class EaModel(nn.Module):
                          token)
         return best, alen
 
+    def _verify_step_native_dynamic(self, st, nx, logits_processor, cfg_scale, lantern, lantern_k, lantern_delta):
+        """One EAGLE-2 step (the reference's default for LlamaGen / Anole): the tree arrives from the drafter with its token list, so the candidates are
+        one gather here (ea_model_llamagen.py:1125-1131) and lantern_verify_step runs the row post-process, evaluate_posterior with the bonus draw and
+        the commit on this step's paths (`retrieve` [P, D]; P and D change from step to step, the group's fields follow them).  None: a tree outside
+        what the group holds (more rows than the context was built for, depth > 8) -- the caller takes the per-kernel path for this step."""
+        C, L, a = nx.C, nx.L, nx.group[0]
+        retrieve = st.retrieve_indices.to(nx.dev)
+        if retrieve.dtype != torch.int64:
+            retrieve = retrieve.to(torch.int64)
+        retrieve = retrieve.contiguous()
+        P, D = retrieve.shape
+        N = int(st.draft_tokens.shape[1])
+        if D > 8 or P < 1 or N < 1:
+            return None
+        if N > nx.win.shape[0]:          # (a drafter whose trees grow: the row buffers follow)
+            nx.win = torch.zeros((N, nx.W), dtype=torch.float32, device=nx.dev)
+            nx.hot = torch.zeros(N, dtype=torch.int32, device=nx.dev)
+            a.out_win, a.row_hot, a.ep_buf.logits, a.ep_win.row_hot = nx.win.data_ptr(), nx.hot.data_ptr(), nx.win.data_ptr(), nx.hot.data_ptr()
+        nx.N = N
+        a.N, a.ep.rows_per_seq, a.ep.N = N, N, N
+        self.base_model.model.tree_mask = st.tree_mask
+        candidates = torch.cat((st.draft_tokens, st.padding), dim=1)[0, retrieve].to(nx.dev).contiguous()          # [P, D] i64, -1 behind a path's end
+        row_index = torch.where(retrieve < 0, retrieve + nx.N, retrieve).to(torch.int32)
+        kw = dict(input_position_diff=st.input_position_diff) if self.mask_non_image else {}
+        _, tree_logits, hidden_new = self._tree_forward(torch.cat([st.draft_tokens, st.draft_tokens]), self.base_model.past_key_values, st.tree_position_ids,
+                                                        st.input_ids, st.attention_mask, **kw)
+        half = tree_logits.shape[0] // 2
+        cl, ul = tree_logits[0], tree_logits[half]
+        if cl.dtype not in (torch.bfloat16, torch.float32):
+            cl, ul = cl.float(), ul.float()
+        cl, ul = cl.contiguous(), ul.contiguous()
+        par = nx.parity
+        rec, tokbuf = nx.recs[par], nx.toks[par]
+        a.stream, a.ss_token, a.retrieve = nx.stream, None, retrieve.data_ptr()
+        a.P, a.D, a.ep.P, a.ep.D = P, D, P, D
+        a.cand = candidates.data_ptr()
+        a.cond, a.uncond, a.dtype = cl.data_ptr(), ul.data_ptr(), int(cl.dtype == torch.bfloat16)
+        b = a.ep_buf
+        b.best, b.accept_len, b.counters = rec.data_ptr(), rec.data_ptr() + 4, rec.data_ptr() + 8
+        b.row_index, b.cand = row_index.data_ptr(), candidates.data_ptr()
+        a.ep_win.token = tokbuf.data_ptr()
+        hid = hidden_new.contiguous()[None]                                                # [1, 2, N, H]
+        flat = nx.out_hs[par]
+        if flat is None or flat.dtype != hid.dtype or flat.numel() != 2 * 8 * hid.shape[-1]:
+            flat = nx.out_hs[par] = torch.zeros(2 * 8 * hid.shape[-1], dtype=hid.dtype, device=nx.dev)
+        out_h = flat[:2 * D * hid.shape[-1]].view(1, 2, D, hid.shape[-1])          # (the kernel's [B, G, D, H] layout for THIS step's depth)
+        a.hidden, a.out_hidden, a.hid_elem_bytes, a.H = hid.data_ptr(), out_h.data_ptr(), hid.element_size(), hid.shape[-1]
+        fifo = self._uniforms()
+        fifo.reserve(P * D)
+        u = torch.rand(1, dtype=torch.float64, device=nx.dev)
+        a.ep_win.u_bonus = u.data_ptr()
+        prev = st.input_ids.shape[1]
+        cur, nxt = nx.prev[par], nx.prev[par ^ 1]
+        cur.fill_(prev)
+        a.slab_prev, a.new_len = cur.data_ptr(), nxt.data_ptr()
+        ops.check(L.lantern_verify_step(nx.group, 1), "verify_step")
+        r = rec.tolist()                                                                   # the step's one host read
+        best, alen, n_used, status, tok = r[0], r[1], r[5], r[7], r[8]
+        nx.parity ^= 1
+        if status != 0:
+            if status in self._RETRY_DENSE:
+                fifo.cursor.sub_(n_used)          # nothing was committed: the same step on the dense HIP kernel, from the same uniforms (host-integer path)
+                rows = NodeLogits(self._dense_node_logits(tree_logits, half, cfg_scale), retrieve)
+                ep = self._posterior_on_device(rows, candidates, logits_processor, None, False, lantern, lantern_k, lantern_delta, u)
+                ops.raise_on_status(ep["counters"])
+                al, bst = int(ep["accept_len"][0]), int(ep["best"][0])
+                out = self.update_inference_inputs(st.input_ids, candidates, bst, al, retrieve, logits_processor, 0, st.slabs, self.base_model.current_length_data,
+                                                   hidden_new, ep["sample_p"], cfg_scale, st.input_position_diff, st.attention_mask, False, u=u)
+                st.input_ids = out[0]
+                self._take_draft(st, out[1:5], out[-1])
+                return bst, al
+            ops.raise_on_status(rec[2:8].reshape(1, 6))
+        n = alen + 1
+        self.base_model.current_length_data.fill_(prev + n)
+        st.input_ids = torch.cat([st.input_ids, nx.acc[:, :n].to(st.input_ids.device)], dim=-1)
+        token = tokbuf.reshape(1, 1)
+        self._take_draft(st, self._draft_next(st.input_ids, out_h[0, :, :n], token, logits_processor, cfg_scale, st.input_position_diff, st.attention_mask, False),
+                         token)
+        return best, alen
+
     def _verify_step(self, st, logits_processor, cfg_scale, lantern, lantern_k, lantern_delta):
         """One step of the loop: O6, target forward + O7 (tree_decoding), O8, O9 + O10, the bonus token, the next draft."""
         nx = getattr(st, "native", None)
@@ -454,7 +544,9 @@ class EaModel(nn.Module):
             st.native_tried = True
             nx = st.native = self._native_ctx(st, logits_processor, cfg_scale, lantern, lantern_k, lantern_delta)
         if nx is not None:
-            return self._verify_step_native(st, nx, logits_processor, cfg_scale, lantern, lantern_k, lantern_delta)
+            done = self._verify_step_native(st, nx, logits_processor, cfg_scale, lantern, lantern_k, lantern_delta)
+            if done is not None:
+                return done
         pkv = self.base_model.past_key_values
         kw = dict(input_position_diff=st.input_position_diff) if self.mask_non_image else {}
         aux = None

@@ -67,7 +67,7 @@ def run_case(case, kernel_set="window", mdl_parts=None, native=True):
 def test_generate_reproduces_the_reference_run(case, kernel_set, native, monkeypatch):
     calls = []
     static = case["tree"] != "dynamic"
-    if native and static and case["temperature"] > 1e-5:          # the one-call step really is the path taken for sampled static-tree runs
+    if native and case["temperature"] > 1e-5:          # the one-call step really is the path taken for sampled runs (static and EAGLE-2 trees)
         from lantern_amd import ops
         for fn in ("evaluate_posterior_window", "update_inference_inputs", "cfg_mask_topk_window"):
             real = getattr(ops, fn)

@@ -1,5 +1,5 @@
 """The LlamaGen / Anole mirrors' generate() on the scripted target models and drafters of the reference-recorded runs (tests/golden/gen_fakes_lg.py:
-forwards that cost almost nothing), static trees: microseconds per verify step with the step through ONE lantern_verify_step call against a ctypes call
+forwards that cost almost nothing), static and EAGLE-2 trees: microseconds per verify step with the step through ONE lantern_verify_step call against a ctypes call
 per kernel -- the host + kernel cost of the loop body (models/ea_model_llamagen.py:1109-1169) at the reference's batch of one.
 usage: mirror_lg_bench.py [repeats=5]"""
 import json, os, random, sys, time
@@ -14,8 +14,6 @@ import test_gpu_generate_lg as T
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 5
 out = []
 for case in G.CASES:
-    if case["tree"] == "dynamic":
-        continue
     row = dict(case=case["name"], model=case["model"], tree=case["tree"])
     for native in (True, False):
         parts = T.build(case, "window")

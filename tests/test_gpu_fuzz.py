@@ -40,6 +40,20 @@ def cfgs(model, static, **kw):
     ("anole", "naive_extend_57", True, 10, 5.0, 1.0, 7), ("anole", "naive_extend_57", True, 5, 20.0, 3.0, 8),
     ("anole", "mc_sim_7b_63", False, 1, 0.1, 0.5, 9), ("llamagen", "naive_extend_57", True, 1000, 0.05, 1.5, 10)])
 def test_static_batches_vs_oracle(model, tree, lantern, k, delta, sigma, seed):
+    _static_batches(model, tree, lantern, k, delta, sigma, seed, 1.0, 150)
+
+
+@pytest.mark.parametrize("model,tree,lantern,k,delta,sigma,seed,top_p,top_k", [
+    ("llamagen", "naive_extend_57", True, 50, 0.1, 1.0, 21, 0.9, 150), ("llamagen", "mc_sim_7b_63", False, 1, 0.1, 2.0, 22, 0.6, 0),
+    ("anole", "naive_extend_57", True, 10, 5.0, 1.0, 23, 0.95, 150), ("anole", "mc_sim_7b_63", True, 20, 0.2, 3.0, 24, 0.3, 40),
+    ("llamagen", "mc_sim_7b_63", True, 200, 10.0, 0.5, 25, 0.99, 0)])
+def test_static_batches_with_top_p_vs_oracle(model, tree, lantern, k, delta, sigma, seed, top_p, top_k):
+    """TopPLogitsWarper between the temperature and the top-k, per visited row inside the dense kernel (drafters/utils.py:36-52 applied at
+    ea_model_llamagen.py:725,785), 32 sequences per launch against the oracle's sort-based restatement."""
+    _static_batches(model, tree, lantern, k, delta, sigma, seed, top_p, top_k)
+
+
+def _static_batches(model, tree, lantern, k, delta, sigma, seed, top_p, top_k):
     m = CS.MODELS[model]
     V, lo, W = m["V"], (m["img_lo"] if model != "llamagen" else 0), (m["img_hi"] - m["img_lo"] if model != "llamagen" else m["V"])
     tb = oracle.tree_static_build(H.tree_choices(tree))
@@ -57,7 +71,8 @@ def test_static_batches_vs_oracle(model, tree, lantern, k, delta, sigma, seed):
     co, ch = cfgs(model, True, lantern=lantern, k=k, delta=delta)
     if model != "lumina":       # LlamaGen / Anole: HF processors inside evaluate_posterior
         for c in (co, ch):
-            c.temperature, c.top_k = 0.9, 150
+            c.temperature, c.top_k, c.top_p = 0.9, top_k, top_p
+    nucleus = model != "lumina" and 0.0 < top_p < 1.0          # logit-row windows have no top-p inside the chain kernel: the dense kernel only
     nl = np.stack([g["node_logits"] for g in gs])
     aux = ops.StaticAux(cart_prob=dev(np.stack(cps)), orig_prob=dev(np.stack([g["orig_prob"] for g in gs])), op_off=dev(gs[0]["op_off"]),
                         p_idx=dev(tb["p_indices"]), b_off=dev(tb["b_off"]), b_idx=dev(tb["b_idx"] if len(tb["b_idx"]) else np.zeros(1, np.int32)),
@@ -65,16 +80,18 @@ def test_static_batches_vs_oracle(model, tree, lantern, k, delta, sigma, seed):
     uni = np.stack([g["uniforms"] for g in gs])
     tab = dev(table.view(np.int16))
     dense = ops.evaluate_posterior(ch, dev(nl), dev(ri), dev(np.stack(cands)), dev(uni), table=tab if lantern else None, aux=aux)
-    win = ops.evaluate_posterior_window(ch, V, dev(np.ascontiguousarray(nl[:, :, lo:lo + W])), lo, dev(ri), dev(np.stack(cands)), dev(uni),
-                                        table=tab if lantern else None, aux=aux, want_dense=True)
+    win = None if nucleus else ops.evaluate_posterior_window(ch, V, dev(np.ascontiguousarray(nl[:, :, lo:lo + W])), lo, dev(ri), dev(np.stack(cands)), dev(uni),
+                                                             table=tab if lantern else None, aux=aux, want_dense=True)
     n_rej = n_acc = 0
     for b, g in enumerate(gs):
         a = oracle.StaticAux(cart_prob=cps[b], orig_prob=g["orig_prob"], op_off=g["op_off"], p_idx=tb["p_indices"], b_off=tb["b_off"],
                              b_idx=tb["b_idx"], tree_cand=tcs[b])
         ob, oa, osp, ocnt = oracle.evaluate_posterior(co, g["node_logits"], ri, cands[b], g["uniforms"], table=table if lantern else None, aux=a)
         n_rej += int(ocnt[2]); n_acc += oa
-        for name, best, alen, sp, cnt in (("dense", dense[0], dense[1], dense[2], dense[3]),
-                                          ("window", win["best"], win["accept_len"], win["sample_p"], win["counters"])):
+        forms = [("dense", dense[0], dense[1], dense[2], dense[3])]
+        if win is not None:
+            forms.append(("window", win["best"], win["accept_len"], win["sample_p"], win["counters"]))
+        for name, best, alen, sp, cnt in forms:
             st = int(cnt[b, 5])
             if name == "window" and st == 6 and k >= m["K"] - 24:
                 continue            # residual vanished (`gtp.sum()==0 -> ones`): only the dense set represents it

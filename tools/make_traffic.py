@@ -85,8 +85,12 @@ for spec in sat_runs:          # <dir>:<batch>: tools/run/ep_sweep_prof.sh <dir>
 import bench
 out["kernel_sources_sha"] = bench.kernel_sources_sha()
 try:
-    out["commit"] = subprocess.check_output(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], text=True).strip()
-    out["tree_dirty"] = bool(subprocess.check_output(["git", "-C", ROOT, "status", "--porcelain", "--", "lantern_amd/csrc", "include"], text=True).strip())
+    # the commit the GPU box ran (tools/run/.commit, written when the snapshot was sent) -- HEAD may have moved on since; the kernel sources it was
+    # measured on are pinned by kernel_sources_sha either way
+    cf = os.path.join(ROOT, "tools", "run", ".commit")
+    out["commit"] = open(cf).read().strip() if os.path.exists(cf) else subprocess.check_output(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], text=True).strip()
+    changed = subprocess.check_output(["git", "-C", ROOT, "diff", "--name-only", out["commit"], "--", "lantern_amd/csrc"], text=True).split()
+    out["verify_path_sources_changed_since"] = [f for f in changed if os.path.basename(f) in bench.VERIFY_PATH_SOURCES]
 except Exception:
     out["commit"] = None
 json.dump(out, open(os.path.join(ROOT, "profiles", f"{RND}_ep_traffic.json"), "w"), indent=1)

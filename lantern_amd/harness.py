@@ -456,10 +456,10 @@ class LuminaVerifyWorkload:
             else:
                 self._launch_step(slot, i & 1, events, 0)
         elif serial:
-            self.join()
+            if self._forked:          # (only when group streams may still hold work: a join / fork pair per step puts cross-queue waits next to the timed
+                self.join()           # kernels -- with more than four hardware queues they doubled the event-timed durations)
             for g in range(self.G):
                 self._launch_step(slot, i & 1, events if g == 0 else None, g)
-            self._fork()
         else:
             if not self._forked:
                 self._fork()

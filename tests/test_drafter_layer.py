@@ -385,7 +385,7 @@ def test_llamagen_and_anole_layers_hip_path_match_the_reference_layers_bf16(name
 # ----------------------------------------------------------------------------- prefills: any number of rows on the packed weights
 @pytest.mark.gpu
 @pytest.mark.parametrize("M,K,N,epi", [(300, 4096, 4096, 0), (129, 1024, 352, 1), (1200, 1280, 3584, 2), (33, 64, 40, 0), (65, 11008, 96, 1), (64, 256, 64, 2),
-                                       (20, 512, 70, 2), (1, 64, 1, 0)])
+                                       (20, 512, 70, 2), (1, 64, 1, 0), (130, 64, 40, 0), (257, 128, 33, 1), (131, 192, 40, 2), (513, 64, 1, 0), (129, 64, 129, 2)])
 def test_packed_gemm_of_any_row_count_matches_f64_and_the_streamk_kernel(M, K, N, epi):
     """lantern_linear_rows_packed (row blocks of 128 / 64 over the packed bricks: the prompt prefill of the drafter's layer) against the exact
     product in f64 (2e-2 of the row scale, as the stream-K test) and -- where both apply, <= 32 rows -- bit-identical roundings to within one bf16

@@ -1076,17 +1076,20 @@ __global__ __launch_bounds__(TG_THREADS, 2) void linear_rows_tiled_kernel(const 
             for (int q = 0; q < 4; ++q) w[s_][q] = load_frag(Wp + boff[s_] + (size_t)kb * NSET * 2048 + q * 512);
     };
     auto compute = [&](int buf, const bf16x8_t (&w)[2][4]) {
+        // the four accumulators take turns (an MFMA that adds to the accumulator of the one before it waits out its whole latency)
+        bf16x8_t af[2][4];
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) {
             const uint16_t *arow = &sA[buf][(wm * 64 + mt * 32 + r) * TG_LDA + 32 * h];
-            bf16x8_t af[4];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) af[q] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4 *>(arow + 8 * q));
-#pragma unroll
-            for (int s_ = 0; s_ < 2; ++s_)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) acc[s_][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[q], w[s_][q], acc[s_][mt], 0, 0, 0);
+            for (int q = 0; q < 4; ++q) af[mt][q] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4 *>(arow + 8 * q));
         }
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int s_ = 0; s_ < 2; ++s_) acc[s_][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mt][q], w[s_][q], acc[s_][mt], 0, 0, 0);
     };
     load_a(0);
     load_w(0, w0);

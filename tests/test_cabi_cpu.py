@@ -192,7 +192,10 @@ def test_round2_entry_points_validate_without_gpu():
     msg = L.lantern_last_error()
     assert msg.startswith(b"verify_step: group 0, tree_dynamic_candidates: "), msg
     arr[0].dyn = None
+    arr[0].ss_token = 0x1000          # (any non-null address: a static tree whose candidates this call assembles; nothing is dereferenced before the check fails)
     assert L.lantern_verify_step(arr, 2) == -1 and L.lantern_last_error().startswith(b"verify_step: group 0, gather_candidates: ")
+    arr[0].ss_token = None            # no dynamic block and no sample list: the caller assembled the candidates itself -> the first stage that checks is O8
+    assert L.lantern_verify_step(arr, 2) == -1 and L.lantern_last_error().startswith(b"verify_step: group 0, evaluate_posterior: ")
     # prepare_step's three forms: a LANTERN_MODEL_PLAIN (LlamaGen) group is taken on its whole 16384-id vocabulary with dynamic trees only
     one = 0x1000                      # any non-null address: the argument check runs on the host, nothing is dereferenced or launched before it fails
     nl = (C.c_int32 * 4)(0, 1, 0, 1)

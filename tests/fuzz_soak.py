@@ -337,3 +337,25 @@ def streamk_soak(n_shapes):
 
 if len(sys.argv) > 2 and sys.argv[2] == "streamk":
     streamk_soak(int(sys.argv[1]))
+
+
+# ---------------------------------------------------------------------------------------------- top-p inside the dense kernel
+# `python tests/fuzz_soak.py <seeds> top_p`: the parameter sets of test_static_batches_with_top_p_vs_oracle over more seeds.
+def top_p_soak(n_seeds):
+    sets = [("llamagen", "naive_extend_57", True, 50, 0.1, 1.0, 0.9, 150), ("llamagen", "mc_sim_7b_63", False, 1, 0.1, 2.0, 0.6, 0),
+            ("anole", "naive_extend_57", True, 10, 5.0, 1.0, 0.95, 150), ("anole", "mc_sim_7b_63", True, 20, 0.2, 3.0, 0.3, 40),
+            ("llamagen", "mc_sim_7b_63", True, 200, 10.0, 0.5, 0.99, 0)]
+    t0 = time.time(); n = fails = 0
+    for seed in range(300, 300 + n_seeds):
+        for (model, tree, lantern, k, delta, sigma, top_p, top_k) in sets:
+            try:
+                F._static_batches(model, tree, lantern, k, delta, sigma, seed, top_p, top_k)
+            except AssertionError as e:
+                fails += 1
+                print("FAIL", (model, tree, lantern, k, delta, sigma, top_p, top_k), seed, str(e)[:300], flush=True)
+            n += 1
+    print(f"top-p soak: cases={n} batches x 32 sequences (dense kernel, TopPLogitsWarper per visited row), fails={fails}, {time.time() - t0:.0f}s")
+
+
+if len(sys.argv) > 2 and sys.argv[2] == "top_p":
+    top_p_soak(int(sys.argv[1]))

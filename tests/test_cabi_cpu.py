@@ -209,3 +209,19 @@ def test_round2_entry_points_validate_without_gpu():
     assert L.lantern_prepare_step(C.byref(g)) == -1 and b"dynamic-tree buffers missing" in L.lantern_last_error()   # the form is accepted, the (empty) tree block is not
     g.win_len = 8192
     assert L.lantern_prepare_step(C.byref(g)) == -1 and b"LlamaGen dynamic trees" in L.lantern_last_error()
+
+
+def test_linear_rows_packed_validates_without_gpu():
+    """lantern_linear_rows_packed (the drafter layer's GEMMs at any row count, on the packed weights): the argument checks run on the host --
+    a K that is no multiple of the 64-element bricks, an unknown epilogue, a residual epilogue without its residual, a gate / up epilogue without
+    the pair's row count; zero rows are a no-op."""
+    L = _lib.lib()
+    one = C.c_void_p(0x1000)          # any non-null address: nothing is dereferenced or launched before a check fails
+    f = L.lantern_linear_rows_packed
+    assert f(None, one, None, 64, 128, 32, one, 32, 0, None, 0, 0, None) == -1 and b"null buffer" in L.lantern_last_error()
+    assert f(one, one, None, 64, 100, 32, one, 32, 0, None, 0, 0, None) == -1 and b"multiple of 64" in L.lantern_last_error()
+    assert f(one, one, None, 64, 128, 32, one, 16, 0, None, 0, 0, None) == -1          # out rows shorter than n_rows
+    assert f(one, one, None, 64, 128, 32, one, 32, 7, None, 0, 0, None) == -1 and b"epilogue 7" in L.lantern_last_error()
+    assert f(one, one, None, 64, 128, 32, one, 32, 1, None, 0, 0, None) == -1 and b"residual" in L.lantern_last_error()
+    assert f(one, one, None, 64, 128, 32, one, 32, 2, None, 0, 0, None) == -1 and b"pair_rows" in L.lantern_last_error()
+    assert f(one, one, None, 0, 128, 32, one, 32, 0, None, 0, 0, None) == 0             # no rows: nothing to do

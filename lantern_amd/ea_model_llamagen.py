@@ -383,7 +383,7 @@ class EaModel(nn.Module):
 
     def _verify_step_native(self, st, nx, logits_processor, cfg_scale, lantern, lantern_k, lantern_delta):
         """One static-tree step: generate_candidates (one call: the target forward needs the tree tokens), the forward, then ONE lantern_verify_step
-        call -- candidates again (idempotent), Temperature -> TopP -> TopK + softmax of all rows, evaluate_posterior with the bonus draw, the KV /
+        call -- Temperature -> TopP -> TopK + softmax of all rows, evaluate_posterior with the bonus draw, the KV /
         hidden / token commit (only where the walk reported no status) -- on preallocated buffers, and one host read of the verdict record.  Same
         kernels, same uniforms, same results as the per-kernel path (tests/test_gpu_generate_lg.py runs the reference-recorded cases through both)."""
         if not nx.static:
@@ -398,10 +398,10 @@ class EaModel(nn.Module):
         rec, tokbuf = nx.recs[par], nx.toks[par]
         a.ep_buf.best, a.ep_buf.accept_len, a.ep_buf.counters = rec.data_ptr(), rec.data_ptr() + 4, rec.data_ptr() + 8
         a.ep_win.token = tokbuf.data_ptr()
-        a.stream, a.ss_token, a.ss_prob, a.sample_token, a.n_flat = nx.stream, ss_token.data_ptr(), ss_prob.data_ptr(), sample.data_ptr(), ss_token.numel()
-        ops.check(L.lantern_gather_candidates(C.c_void_p(a.ss_token), C.c_void_p(a.ss_prob), C.c_void_p(a.sample_token), C.c_void_p(a.tree_indices), C.c_void_p(a.retrieve),
-                                              1, a.n_flat, nx.N, nx.P, nx.D, C.c_void_p(a.tree_cand), C.c_void_p(a.cand), C.c_void_p(a.cart_prob), C.c_void_p(nx.stream)),
-                  "gather_candidates")
+        a.stream, a.ss_token = nx.stream, None          # (ss_token NULL: lantern_verify_step takes the candidates as the call below leaves them)
+        ops.check(L.lantern_gather_candidates(C.c_void_p(ss_token.data_ptr()), C.c_void_p(ss_prob.data_ptr()), C.c_void_p(sample.data_ptr()), C.c_void_p(a.tree_indices),
+                                              C.c_void_p(a.retrieve), 1, ss_token.numel(), nx.N, nx.P, nx.D, C.c_void_p(a.tree_cand), C.c_void_p(a.cand),
+                                              C.c_void_p(a.cart_prob), C.c_void_p(nx.stream)), "gather_candidates")
         kw = dict(input_position_diff=st.input_position_diff) if self.mask_non_image else {}
         tree_candidates = torch.cat([nx.tcand, nx.tcand])
         _, tree_logits, hidden_new = self._tree_forward(tree_candidates, self.base_model.past_key_values, self.tree_buffers["tree_position_ids"], st.input_ids,

@@ -503,7 +503,7 @@ class EaLumina_mGPT(nn.Module):
 
     def _verify_step_native(self, st, nx, lantern, lantern_k, lantern_delta):
         """One verify step: generate_candidates (one call: the target forward needs the tree tokens), the two target forwards, then ONE
-        lantern_verify_step call -- candidates again (idempotent), the tree_decoding post-process of all rows, evaluate_posterior with the bonus
+        lantern_verify_step call -- the tree_decoding post-process of all rows, evaluate_posterior with the bonus
         draw, the KV / hidden / token commit (only where the walk reported no status) -- on preallocated buffers, and one host read of the 40-byte
         verdict record.  Same kernels, same uniforms, same results as the per-kernel path (tests/test_gpu_generate_ref.py runs both)."""
         C, L, a = nx.C, nx.L, nx.group[0]
@@ -526,7 +526,7 @@ class EaLumina_mGPT(nn.Module):
         eb.best, eb.accept_len, eb.counters = rp, rp + 4, rp + 8
         ew.token = tp
         p_tok, p_prob, p_smp = ss_token.data_ptr(), ss_prob.data_ptr(), sample.data_ptr()
-        a.stream, a.ss_token, a.ss_prob, a.sample_token = stream, p_tok, p_prob, p_smp
+        a.stream, a.ss_token = stream, None          # (ss_token NULL: lantern_verify_step takes the candidates as this call leaves them -- no second O6 launch)
         g = nx._gc_const
         ops.check(L.lantern_gather_candidates(C.c_void_p(p_tok), C.c_void_p(p_prob), C.c_void_p(p_smp), g[0], g[1], 1, a.n_flat, nx.N, nx.P, nx.D, g[2], g[3], g[4], g[5]),
                   "gather_candidates")

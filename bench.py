@@ -103,6 +103,13 @@ def parse():
                          "kernel is launched on one homogeneous workload (its averages then agree with the HIP-event averages)")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="CPU-baseline budget; 0 disables")
     ap.add_argument("--cpu-seqs", type=int, default=0, help="sequences in the CPU sample (0 = host cores)")
+    ap.add_argument("--extras-out", type=str, default=os.path.join(ROOT, "bench_extras.json"),
+                    help="file that receives the FULL report (the compact headline + every extra run: per_kernel_single_group, configs, dynamic_tree, "
+                         "ep_batch_sweep, drafter_*, mirror_generate, ...); the same object goes to stderr as one line.  stdout carries exactly ONE "
+                         "line: the compact headline (< 4 KB) the driver parses.  '' = no file")
+    ap.add_argument("--dist-backend", choices=["auto", "nccl", "gloo"], default="auto",
+                    help="process group of the N > 1 run (used for the timing barrier and three scalars only: the accept path has no collective).  "
+                         "auto = nccl (RCCL), falling back to gloo on host tensors when the RCCL group cannot be brought up -- decided before any kernel is launched")
     return ap.parse_args()
 
 
@@ -774,6 +781,171 @@ def plan_sequences(total_seqs: int, seqs_per_gpu: int, world: int, groups: int):
     return n, g, scaling
 
 
+
+# ---------------------------------------------------------------------------- the line the driver parses
+
+HEADLINE_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+                 "data", "config", "mean_accept_length", "per_step", "ranks_seen", "backend", "backend_note", "tokens", "sequences_per_rank", "groups")
+ROOFLINE_KEYS = ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes_per_launch", "avg_launch_ms",
+                 "sequences_per_launch", "needed_bytes_per_launch", "frac_needed", "traffic_note")
+SATURATING_KEYS = ("kernel", "sequences_per_launch", "avg_launch_ms", "needed_bytes", "achieved", "peak", "unit", "frac", "traffic", "traffic_over_needed",
+                   "traffic_note", "inputs")
+CPU_KEYS = ("value", "unit", "cores", "host_cores", "usable_cores", "kind", "sample", "matches_gpu_token_stream", "mismatches")
+
+
+def _short(v, n=220):
+    return v if not isinstance(v, str) or len(v) <= n else v[:n - 3] + "..."
+
+
+def _pick(d, keys, n=220):
+    return {k: _short(d[k], n) for k in keys if isinstance(d, dict) and k in d}
+
+
+def compact_line(out: dict) -> dict:
+    """The headline object for stdout: the contract's keys, `roofline` (+ `saturating`), `cpu_baseline`, the per-kernel one-liners and a
+    few scalars of the extra runs -- every string clipped, < 4 KB in all (the driver keeps an 8 KB tail of stdout and could no longer parse
+    round 4's 21 KB line).  Everything else lives in the --extras-out file / on stderr."""
+    c = _pick(out, HEADLINE_KEYS, 700)
+    if isinstance(c.get("config"), dict):
+        c["config"] = {k: _short(v, 330) for k, v in c["config"].items()}
+    if "roofline" in out:
+        rl = _pick(out["roofline"], ROOFLINE_KEYS)
+        if isinstance(out["roofline"].get("saturating"), dict):
+            rl["saturating"] = _pick(out["roofline"]["saturating"], SATURATING_KEYS)
+        c["roofline"] = rl
+    if "kernels" in out:
+        c["kernels"] = {k: _pick(v, ("kernel", "avg_launch_ms", "algorithmic_bytes_per_launch", "achieved", "frac"), 90) for k, v in out["kernels"].items()}
+    if "cpu_baseline" in out:
+        c["cpu_baseline"] = _pick(out["cpu_baseline"], CPU_KEYS)
+    ex = {}
+    mg = out.get("mirror_generate")
+    if isinstance(mg, dict) and "us_per_verify_step" in mg:
+        ex["mirror_generate_us_per_verify_step"] = mg["us_per_verify_step"]
+    dc = out.get("drafter_cycle")
+    if isinstance(dc, dict):
+        ex["drafter_us_per_depth_wall"] = {k: v.get("us_per_depth_wall") for k, v in dc.items() if isinstance(v, dict)}
+        ex["drafter_us_per_cycle_wall"] = {k: v.get("us_per_cycle_wall") for k, v in dc.items() if isinstance(v, dict)}
+    if isinstance(out.get("lambda_mode"), dict):
+        ex["lambda_mode_value"] = out["lambda_mode"].get("value")
+    if isinstance(out.get("dynamic_tree"), dict):
+        ex["dynamic_tree_value"] = out["dynamic_tree"].get("value")
+    cf = out.get("configs")
+    if isinstance(cf, dict):
+        if isinstance(cf.get("C2"), dict):
+            ex["C2_value"] = cf["C2"].get("value")
+        if isinstance(cf.get("C4"), list) and cf["C4"]:
+            ex["C4_values"] = [r_.get("value") for r_ in cf["C4"] if isinstance(r_, dict)]
+    sl = out.get("step_latency_us")
+    if isinstance(sl, dict):
+        ex["step_latency_us"] = {k: v.get("us_per_step") for k, v in sl.items() if isinstance(v, dict)}
+    if ex:
+        c["extras"] = ex
+    if out.get("extras_file"):
+        c["extras_file"] = out["extras_file"]
+    return c
+
+
+def emit(out: dict, args) -> None:
+    """Full report -> --extras-out and stderr (one line); compact headline -> the ONE stdout line, printed last."""
+    path = getattr(args, "extras_out", "") or ""
+    if path:
+        try:
+            with open(path, "w") as f:
+                json.dump(out, f)
+            out["extras_file"] = os.path.relpath(path, ROOT) if path.startswith(ROOT) else path
+        except OSError as e:
+            print(f"bench.py: could not write {path}: {e}", file=sys.stderr)
+    print("bench.py full report: " + json.dumps(out), file=sys.stderr)
+    sys.stderr.flush()
+    line = json.dumps(compact_line(out))
+    if len(line) >= 8192:          # never again an unparseable line: drop the optional blocks, keep the contract's keys
+        c = compact_line(out)
+        for k in ("extras", "kernels", "per_step"):
+            c.pop(k, None)
+        line = json.dumps(c)
+    print(line)
+    sys.stdout.flush()
+
+
+# ---------------------------------------------------------------------------- N > 1: the process group
+
+def open_process_group(world, rank, local_rank, want="auto", one_device=False):
+    """The group the contract's barrier and the three timing scalars run on -- the accept path itself has NO collective.
+    Every rank first joins a gloo group (host tensors; it cannot fail for GPU reasons).  Unless `want` is gloo, the ranks then try to bring
+    up an RCCL ("nccl") group -- creation + one all-reduce of a device scalar, in a helper thread bounded by LANTERN_NCCL_PROBE_TIMEOUT seconds
+    -- and agree over gloo (MIN of the ok flags): RCCL only if it came up on EVERY rank, else gloo for all.  This happens before any kernel
+    of the workload is launched, so an RCCL that cannot initialise on a node (pinned ranks that do not see each other's device, an IPC
+    restriction, ...) costs the fallback, not the run.  Returns (torch.distributed, {"group", "backend", "device", "note"})."""
+    import datetime
+    import threading
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("TORCH_NCCL_ASYNC_ERROR_HANDLING", "0")      # a stuck probe must not let the watchdog end the process
+    # gloo's C++ side announces its connections on fd 1: keep stdout for the one JSON line (fd 1 -> fd 2 while the group comes up)
+    sys.stdout.flush()
+    saved = os.dup(1)
+    os.dup2(2, 1)
+    try:
+        dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=900))
+        dist.barrier()
+    finally:
+        os.dup2(saved, 1)
+        os.close(saved)
+    pg = {"group": None, "backend": "gloo", "device": torch.device("cpu"), "note": None}
+    if want == "gloo" or one_device:
+        pg["note"] = "gloo requested" if want == "gloo" else "one-device rehearsal: gloo"
+        return dist, pg
+    res = {}
+    limit = float(os.environ.get("LANTERN_NCCL_PROBE_TIMEOUT", "120"))
+
+    def probe():
+        try:
+            if os.environ.get("LANTERN_BENCH_FAIL_NCCL") == "1":          # test knob: an RCCL that does not come up
+                raise RuntimeError("LANTERN_BENCH_FAIL_NCCL=1")
+            dev = torch.device("cuda", local_rank)
+            torch.cuda.set_device(dev)
+            g = dist.new_group(backend="nccl", timeout=datetime.timedelta(seconds=limit), device_id=dev)
+            t = torch.ones(1, device=dev)
+            dist.all_reduce(t, group=g)
+            torch.cuda.synchronize(dev)
+            if int(t.item()) != world:
+                raise RuntimeError(f"RCCL all-reduce returned {t.item()} for {world} ranks")
+            res["group"] = g
+        except BaseException as e:          # noqa: BLE001 -- whatever the reason, the answer is gloo
+            res["err"] = repr(e)[:200]
+    th = threading.Thread(target=probe, daemon=True)
+    th.start()
+    th.join(limit + 30.0)
+    ok = torch.tensor([1 if "group" in res else 0], dtype=torch.int32)
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+    if int(ok[0]) == 1:
+        pg.update(group=res["group"], backend="nccl", device=torch.device("cuda", local_rank))
+    else:
+        why = res.get("err") or ("RCCL bring-up did not finish in time on this rank" if "group" not in res else "RCCL failed on another rank")
+        pg["note"] = f"RCCL group not usable ({why}): barrier and timing scalars over gloo"
+        pg["hung_probe"] = th.is_alive()
+        if want == "nccl":
+            raise SystemExit(f"bench.py: --dist-backend nccl: {pg['note']}")
+    return dist, pg
+
+
+def count_ranks(dist, pg) -> int:
+    """Ranks that reached the end of the timed region (SUM of ones over the group): the line's `ranks_seen`."""
+    if dist is None:
+        return 1
+    t = torch.ones(1, dtype=torch.float64, device=pg["device"])
+    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=pg["group"])
+    return int(round(float(t[0])))
+
+
+def close_process_group(dist, pg) -> None:
+    if pg.get("hung_probe"):
+        sys.stdout.flush()
+        sys.stderr.flush()
+        os._exit(0)                        # a helper thread is still stuck inside RCCL: do not wait for it in the interpreter's teardown
+    dist.destroy_process_group()
+
+
 # ---------------------------------------------------------------------------- N > 1: self-launch
 
 def spawn_ranks(args) -> int:
@@ -821,12 +993,15 @@ def spawn_ranks(args) -> int:
     if failed or any(codes):
         print(f"bench.py: rank exit codes {codes}", file=sys.stderr)
         return 1
-    sys.stdout.write(out0)
-    sys.stdout.flush()
     line = [l for l in out0.splitlines() if l.startswith("{")]
+    rest = [l for l in out0.splitlines() if not l.startswith("{")]
+    if rest:
+        print("\n".join(rest), file=sys.stderr)          # stdout carries the one JSON line and nothing else
     if not line or json.loads(line[-1]).get("n_gpus") != n:
         print(f"bench.py: rank 0 did not report n_gpus={n}", file=sys.stderr)
         return 1
+    sys.stdout.write(line[-1] + "\n")
+    sys.stdout.flush()
     return 0
 
 
@@ -834,28 +1009,36 @@ def stub_rank(args, world, rank):
     """LANTERN_BENCH_STUB=1 (tests/test_multiproc_cpu.py, no GPU in the build container): the rank body with the kernels
     replaced by a sleep, so that the self-launch, the gloo rendezvous, the barrier-bracketed timing, the MAX / SUM
     reductions and rank 0's JSON line run on CPU.  The line says `"data": "stub"`: it is not a measurement."""
-    import torch.distributed as dist
     from lantern_amd.sharding import reduce_timing
+    dist, pg = None, None
     if world > 1:
-        dist.init_process_group("gloo")
+        dist, pg = open_process_group(world, rank, 0, args.dist_backend, one_device=False)     # no GPU here: "auto" must land on gloo
     n_seq, _groups, scaling = plan_sequences(args.total_seqs, args.seqs_per_gpu, world, args.groups)
     K, per_step = args.steps, n_seq * 2
     if world > 1:
-        dist.barrier()
+        dist.barrier(group=pg["group"])
     t0 = time.perf_counter()
     for _ in range(K):
         time.sleep(0.001)
     if world > 1:
-        dist.barrier()
+        dist.barrier(group=pg["group"])
     dt = time.perf_counter() - t0
-    dt_all, tokens_all = reduce_timing(dist if world > 1 else None, dt, float(K * per_step))
+    dt_all, tokens_all = reduce_timing(dist if world > 1 else None, dt, float(K * per_step), group=pg["group"] if pg else None)
+    ranks_seen = count_ranks(dist, pg)
     if rank == 0:
-        print(json.dumps({"metric": "stub", "value": tokens_all / dt_all, "unit": "accepted_tokens/s", "n_gpus": world, "steps": K,
-                          "warmup": args.warmup, "ms_per_step": 1e3 * dt_all / K, "data": "stub", "tokens": tokens_all, "scaling": scaling,
-                          "sequences_per_rank": n_seq, "groups": _groups}))
+        out = {"metric": "stub", "value": tokens_all / dt_all, "unit": "accepted_tokens/s", "n_gpus": world, "steps": K,
+               "warmup": args.warmup, "ms_per_step": 1e3 * dt_all / K, "data": "stub", "tokens": tokens_all, "scaling": scaling,
+               "sequences_per_rank": n_seq, "groups": _groups, "ranks_seen": ranks_seen, "backend": pg["backend"] if pg else None,
+               "backend_note": pg["note"] if pg else None,
+               # a stand-in for the extras of a real run (tests/test_multiproc_cpu.py: they must stay off the stdout line)
+               "roofline": {"bound": "hbm", "achieved": 0.0, "peak": 8000.0, "unit": "GB/s", "frac": 0.0, "traffic": None},
+               "cpu_baseline": {"value": 0.0, "unit": "accepted_tokens/s", "cores": 1, "kind": "port", "sample": "stub"},
+               "ep_batch_sweep": [{"sequences_per_launch": b, "pad": "x" * 512} for b in (1, 8, 64, 256, 512, 4096)],
+               "configs": {"pad": ["y" * 256] * 40}}
+        emit(out, args)
     if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+        dist.barrier(group=pg["group"])
+        close_process_group(dist, pg)
 
 
 # ------------------------------------------------------------------------------------ main
@@ -880,15 +1063,13 @@ def main():
         local_rank = 0
     if "LANTERN_BENCH_DEVICE_INDEX" in os.environ:      # a rank pinned by spawn_ranks (HIP_VISIBLE_DEVICES = its own device)
         local_rank = int(os.environ["LANTERN_BENCH_DEVICE_INDEX"])
-    dist = None
+    dist, pg = None, None
     if world > 1 or os.environ.get("LANTERN_BENCH_FORCE_DIST") == "1":       # the env knob exercises the RCCL path on a 1-GPU box
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if one_device:
-            dist.init_process_group("gloo")
-        else:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    red_device = torch.device("cpu") if one_device else None               # gloo reduces host tensors
+        dist, pg = open_process_group(world, rank, local_rank, args.dist_backend, one_device)
+        if pg["note"] and rank == 0:
+            print("bench.py: " + pg["note"], file=sys.stderr)
+    red_device = pg["device"] if pg else None                              # gloo reduces host tensors, RCCL device tensors
+    group = pg["group"] if pg else None
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
 
@@ -919,7 +1100,7 @@ def main():
         fit = int((free - (16 << 30)) // per_seq)
         if dist is not None and dist.get_world_size() > 1:
             t = torch.tensor([fit], dtype=torch.int64, device=red_device or device)
-            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
             fit = int(t[0])
         if fit < n_seq:
             if fit < max(1, args.groups):
@@ -938,7 +1119,7 @@ def main():
 
     def barrier():
         if dist is not None:
-            dist.barrier()
+            dist.barrier(group=group)
         torch.cuda.synchronize(device)
 
     K, W = args.steps, args.warmup
@@ -969,7 +1150,8 @@ def main():
     wl.check_status(0, n_logged)
     tokens = wl.accepted_tokens(W, W + K)
     from lantern_amd.sharding import reduce_timing
-    dt_all, tokens_all = reduce_timing(dist, dt, float(tokens), device=red_device or device)
+    dt_all, tokens_all = reduce_timing(dist, dt, float(tokens), device=red_device or device, group=group)
+    ranks_seen = count_ranks(dist, pg)
 
     if rank == 0:
         alen = wl.log_alen[W:W + K].float() + 1
@@ -978,7 +1160,8 @@ def main():
             "metric": "accepted image-tokens/sec (Lumina-mGPT-7B 768x768 LANTERN verify/accept loop)",
             "value": tokens_all / dt_all, "unit": "accepted_tokens/s", "n_gpus": world, "steps": K, "warmup": W,
             "ms_per_step": 1e3 * dt_all / K, "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": "f32", "data": "synthetic", "ranks_seen": ranks_seen, "backend": (pg["backend"] if pg else None),
+            "backend_note": (pg["note"] if pg else None),
             "config": {"workload": ("C5: Lumina-mGPT-7B-768 LANTERN, %d-prompt batch sharded over %d GPU(s), no collective; " % (args.total_seqs, world) if args.total_seqs > 0 else "") +
                                    f"C3: Lumina-mGPT-7B-768 LANTERN relaxed accept, static tree {cfg.tree} (N={wl.N},P={wl.P},D={wl.D}), "
                                    "V=65536, K=8192, cfg=3.0, top_k=2000, sequential-CFG KV [64,1,32,%d,128] bf16 x2 per sequence (row stride %d)"
@@ -1054,13 +1237,18 @@ def main():
             out["cpu_baseline"] = cpu_baseline(wl, args.cpu_seconds, n_cpu, gpu_stream, python_budget_s=min(args.cpu_seconds, 8.0))
             if not out["cpu_baseline"]["matches_gpu_token_stream"]:
                 stream_mismatch = out["cpu_baseline"]["mismatches"]
-        print(json.dumps(out))
+        emit(out, args)
         if stream_mismatch:          # the checker disagrees with the kernels: the line above is not a valid measurement
             print(f"bench.py: the CPU oracle's accepted-token stream differs from the GPU's in {stream_mismatch} (step, sequence) cells", file=sys.stderr)
             exit_code = 3
     if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+        dist.barrier(group=group)
+        if exit_code:
+            sys.stdout.flush()
+            sys.stderr.flush()
+            if pg.get("hung_probe"):
+                os._exit(exit_code)
+        close_process_group(dist, pg)
     if exit_code:
         raise SystemExit(exit_code)
 

@@ -70,7 +70,8 @@ extern "C" int lantern_verify_step(const lantern_step_group *groups, int n_group
     for (int g = 0; g < n_groups; ++g) {
         const lantern_step_group &s = groups[g];
         if (!s.slab_ptrs) continue;
-        // (a sequence whose walk reported a status commits nothing: its KV rows, lengths and hidden rows stay as the forward left them)
+        // (a sequence whose walk reported a status commits nothing: its KV rows and lengths stay as the forward left them, its out_hidden rows are
+        // zero-filled and its accepted_tokens are -1 -- the caller retries the step and commits it itself; tests/test_gpu_loop.py pins this gate)
         rc = lantern::launch_update_inference_inputs(s.slab_ptrs, s.slab_seq, s.slab_prev, s.n_slabs, s.elem_bytes, s.outer, s.S_max, s.d,
                                                      s.dyn ? s.dyn->retrieve_pd : s.retrieve, s.dyn ? 1 : 0, s.P, s.D, s.ep_buf.best,
                                                      s.ep_buf.accept_len, s.new_len, s.hidden, s.hid_elem_bytes, s.B, s.hid_groups, s.N, s.H,

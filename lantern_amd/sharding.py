@@ -16,16 +16,17 @@ def sequence_seed(base: int, global_seq_id: int) -> int:
     return base + global_seq_id
 
 
-def reduce_timing(dist, seconds: float, tokens: float, device=None) -> Tuple[float, float]:
+def reduce_timing(dist, seconds: float, tokens: float, device=None, group=None) -> Tuple[float, float]:
     """(max over ranks of the wall time, sum over ranks of the accepted tokens).  `dist` is
-    torch.distributed (nccl == RCCL on the GPU box, gloo in the CPU tests) or None."""
+    torch.distributed (nccl == RCCL on the GPU box, gloo in the CPU tests) or None; `group` the
+    process group to reduce over (None = the default group)."""
     if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
         return seconds, tokens
     import torch
     t = torch.tensor([seconds], dtype=torch.float64, device=device)
     n = torch.tensor([tokens], dtype=torch.float64, device=device)
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    dist.all_reduce(n, op=dist.ReduceOp.SUM)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    dist.all_reduce(n, op=dist.ReduceOp.SUM, group=group)
     return float(t[0]), float(n[0])
 
 

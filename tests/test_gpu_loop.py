@@ -451,3 +451,57 @@ def test_node_kernel_loop_matches_chain_loop(groups):
             assert res["matches_gpu_token_stream"], res
     for a, b in zip(*outs):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("geom", ["slab_blocks", "tiled"])
+def test_verify_step_commits_nothing_where_the_walk_reported_a_status(geom):
+    """lantern_verify_step's commit gate: a sequence whose evaluate_posterior walk ends in a status (here LANTERN_ST_UNIFORMS: its
+    uniform stream is exhausted) must move no KV row, keep its lengths, list no token (accepted_tokens = -1) and leave zero-filled hidden rows -- the
+    mirrors' retry paths rewind the cursor, redo the step on the dense kernel and commit from the host, so a second commit here would move KV rows twice.
+    Both commit kernels: `slab_blocks` (small slabs: update_inputs_slabs_kernel, several slabs per workgroup) and `tiled` (update_inputs_kernel).  The
+    other sequences of the same launches commit exactly what an undisturbed twin workload commits."""
+    from lantern_amd import harness as HN
+    kv = dict(kv_layers=2, kv_heads=4) if geom == "slab_blocks" else dict(kv_layers=16, kv_heads=32)      # outer x 16 chunks: 256 (<= 4096) / 16384
+    mk = lambda: HN.LuminaVerifyWorkload(HN.WorkloadConfig(n_seq=4, pool_steps=2, kv_smax=256, max_steps=8, sigma=2.0, n_groups=2, **kv), torch.device("cuda"))
+    wl, twin = mk(), mk()
+    assert wl._steps, "the one-call step (lantern_verify_step) is what is under test"
+    gen = torch.Generator(device="cuda").manual_seed(5)
+    for a, b in zip(wl.slabs, twin.slabs):
+        a.copy_(torch.randn(a.shape, device="cuda", generator=gen).to(torch.bfloat16))
+        b.copy_(a)
+    for w in (wl, twin):
+        w.step()
+        w.join()
+    torch.cuda.synchronize()
+    forced = [1, 2]                                         # one sequence of each stream group (groups hold sequences [0, 1] and [2, 3])
+    for b in forced:
+        wl.cursor[b] = wl.n_uniforms                        # nothing left of its random.random() stream
+    before = [s.clone() for s in wl.slabs]
+    prev = wl.lens[1].clone()                               # lengths after step 0 (parity 1 is step 1's input)
+    wl.out_hidden.fill_(7.0)
+    for w in (wl, twin):
+        w.step()
+        w.join()
+    torch.cuda.synchronize()
+    cnt = wl.log_cnt[1].cpu()
+    assert [int(cnt[b, 5]) for b in range(4)] == [2 if b in forced else 0 for b in range(4)]       # LANTERN_ST_UNIFORMS = 2 (include/lantern_hip.h)
+    with pytest.raises(Exception):
+        wl.check_status(0, 2)
+    new = wl.lens[0]
+    acc, tacc = wl.acc_tokens.cpu(), twin.acc_tokens.cpu()
+    for b in range(4):
+        g, l = divmod(b, wl.Bg)
+        for j in range(2):
+            si = g * 2 * wl.Bg + j * wl.Bg + l
+            if b in forced:
+                assert torch.equal(wl.slabs[si], before[si]), (b, j)                 # byte-identical slabs
+                assert int(new[si]) == int(prev[si])                                  # new_len == prev
+            else:
+                assert torch.equal(wl.slabs[si], twin.slabs[si]), (b, j)
+                assert int(new[si]) == int(twin.lens[0][si]) == int(prev[si]) + int(wl.log_alen[1, b]) + 1
+        if b in forced:
+            assert (acc[b] == -1).all()
+            assert float(wl.out_hidden[b].float().abs().max()) == 0.0               # zero-filled, not "as the forward left them"
+        else:
+            assert torch.equal(acc[b], tacc[b]) and torch.equal(wl.out_hidden[b], twin.out_hidden[b])
+            assert int(wl.log_best[1, b]) == int(twin.log_best[1, b]) and int(wl.log_token[1, b]) == int(twin.log_token[1, b])

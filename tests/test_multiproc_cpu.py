@@ -116,6 +116,8 @@ def test_bench_gpus_2_starts_its_own_ranks():
     assert r.returncode == 0, r.stderr[-2000:]
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["tokens"] == 2 * 4 * 8 * 2 and line["steps"] == 4
+    # --dist-backend auto: the RCCL bring-up fails here (no GPU) on every rank, the ranks agree on gloo BEFORE the timed loop, and say so
+    assert line["backend"] == "gloo" and line["ranks_seen"] == 2 and "RCCL group not usable" in line["backend_note"]
     bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2"], env=dict(env, WORLD_SIZE="1"),
                          capture_output=True, text=True, timeout=120)
     assert bad.returncode != 0 and "WORLD_SIZE=1" in bad.stderr
@@ -197,3 +199,47 @@ def test_c5_union_of_eight_shards_equals_single_process(tmp_path):
     assert seen == single
     m = sh.merge_global_statistics(paths)
     assert m["prompts"] == total and abs(m["mean_step_compression"] - sum(single.values()) / total) < 1e-12
+
+
+def _stub_env():
+    env = dict(os.environ, LANTERN_BENCH_STUB="1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    return env
+
+
+@pytest.mark.timeout(300)
+def test_bench_stdout_is_one_compact_parseable_line(tmp_path):
+    """The driver parses bench.py's stdout (and keeps an 8 KB tail of it): stdout must be exactly ONE json line, well under 8 KB,
+    carrying `roofline` and `cpu_baseline`; the extra runs (here: the stub's padding, ~16 KB) go to --extras-out and stderr."""
+    import subprocess
+    extras = tmp_path / "extras.json"
+    for gpus in ("1", "2"):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", gpus, "--steps", "3", "--warmup", "1", "--dist-backend", "gloo",
+                            "--extras-out", str(extras)], env=_stub_env(), capture_output=True, text=True, timeout=240)
+        assert r.returncode == 0, r.stderr[-2000:]
+        lines = [l for l in r.stdout.splitlines() if l.strip()]
+        assert len(lines) == 1 and len(lines[0]) < 8192
+        line = json.loads(lines[-1])
+        assert line["n_gpus"] == int(gpus) and line["roofline"]["bound"] == "hbm" and line["cpu_baseline"]["kind"] == "port"
+        assert "ep_batch_sweep" not in line and "configs" not in line
+        full = json.load(open(extras))
+        assert len(full["ep_batch_sweep"]) == 6 and "configs" in full and len(json.dumps(full)) > 8192
+        assert "bench.py full report: " in r.stderr
+
+
+def test_compact_line_of_a_real_report_stays_small():
+    """compact_line on round 4's committed 21 KB report (the one the driver could not parse): < 4 KB, json round-trips, both objects kept."""
+    sys.path.insert(0, ROOT)
+    import bench
+    full = json.load(open(os.path.join(ROOT, "profiles", "r04_bench_driver_invocation_20_5.json")))
+    assert len(json.dumps(full)) > 20000
+    c = bench.compact_line(full)
+    line = json.dumps(c)
+    assert len(line) < 4096, len(line)
+    back = json.loads(line)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config"):
+        assert back[k] == full[k] or k == "config"
+    assert back["config"]["workload"].startswith("C3") and back["roofline"]["saturating"]["sequences_per_launch"] == 4096
+    assert back["cpu_baseline"]["kind"] == "port" and back["cpu_baseline"]["matches_gpu_token_stream"] is True
+    assert back["extras"]["mirror_generate_us_per_verify_step"] == full["mirror_generate"]["us_per_verify_step"]

@@ -16,7 +16,7 @@ evaluate_posterior_window on raw bf16 rows (O8 + the rest of O7, on demand) -> u
 Extra objects on the JSON line:
   roofline      evaluate_posterior of the timed configuration: algorithmic bytes (SURVEY 8d contract formula, from the kernel's own
                 counters) / its mean launch duration (HIP events recorded by the launch itself); peak 8000 GB/s.  `windowed_kernel`: the bytes
-                the windowed design really has to move; `traffic`: PMC bytes from profiles/r04_ep_traffic.json (refused when measured on other kernel
+                the windowed design really has to move; `traffic`: PMC bytes from profiles/r05_ep_traffic.json (refused when measured on other kernel
                 sources); `saturating`: the same kernel alone at the largest batch of the sweep, on rotating inputs.
   kernels       the same for the row post-process launch (prepare_step / cfg_mask_topk) and update_inference_inputs.
   per_kernel_single_group  one stream, every stage its own launch: each kernel against its SURVEY 8d roofline at the full 64-sequence
@@ -361,10 +361,19 @@ def ep_batch_sweep(batches, device, base_cfg, iters=24, kernels=("chain", "nodes
             cnts = [k_["cnt"] for k_, _b, _w in sets]
             if any(int(c_[:, 5].abs().sum()) != 0 for c_ in cnts):
                 raise RuntimeError("evaluate_posterior reported a per-sequence error in the sweep")
-            nbytes = float(np.mean([wl.ep_window_bytes_from(c_) if wl.windowed else wl.ep_algorithmic_bytes_from(c_) for c_ in cnts]))
+            # bytes the launch has to bring in from HBM: rows of the visited levels, the candidates' neighbour ids, and the drafter row ONCE per
+            # level with a rejection (the candidates of a level share their parent's row; later rejections re-read it from L2) -- the levels are
+            # replayed from each set's inputs and verdict and checked against the kernel's rejection counters (harness.static_rejection_levels)
+            if wl.windowed:
+                lv = [HN.static_rejection_levels(k_["cand"], k_["cart"], k_["best"], k_["alen"], k_["cnt"]) for k_, _b, _w in sets]
+                nbytes = float(np.mean([wl.ep_window_bytes_from(c_, l_) for c_, l_ in zip(cnts, lv)]))
+                per_rej = float(np.mean([wl.ep_window_bytes_from(c_) for c_ in cnts]))
+            else:
+                nbytes = per_rej = float(np.mean([wl.ep_algorithmic_bytes_from(c_) for c_ in cnts]))
             dense = float(np.mean([wl.ep_algorithmic_bytes_from(c_) for c_ in cnts]))
             row[kern] = {"launch_ms": ms, "back_to_back_ms": loop_ms, "us_per_sequence": 1e3 * ms / Bs, "hbm_bytes_needed_per_launch": nbytes,
                          "achieved_GBps": nbytes / (ms * 1e-3) / 1e9, "frac": nbytes / (ms * 1e-3) / 1e9 / 8000.0,
+                         "bytes_if_every_rejection_read_its_row_from_hbm": per_rej,
                          "contract_equivalent_GBps": dense / (ms * 1e-3) / 1e9}
         row["accepted_tokens_per_launch"] = float(np.mean([float((k_["alen"].float() + 1).sum()) for k_, _b, _w in sets]))
         out.append(row)
@@ -376,7 +385,7 @@ def ep_batch_sweep(batches, device, base_cfg, iters=24, kernels=("chain", "nodes
 # the sources of the kernels bench.py times (the verify step: candidate assembly / row post-process, the windowed evaluate_posterior kernels, the KV /
 # hidden commit, the one-call sequencing); the dense evaluate_posterior (evaluate_posterior.hip: never on the timed path) and the drafter-side files
 # (drafter_fc, draft_depth, tree_attention, vq_table, greedy, tree_static) are not part
-VERIFY_PATH_SOURCES = ("common.h", "window_dev.h", "window_kernels.hip", "node_kernels.hip", "logits_post.hip", "gather_dev.h",
+VERIFY_PATH_SOURCES = ("common.h", "window_dev.h", "epw_body.h", "window_kernels.hip", "epw_generic.hip", "epw_throughput.hip", "node_kernels.hip", "logits_post.hip", "gather_dev.h",
                        "gather_ops.hip", "tree_dynamic.hip", "tree_dynamic_dev.h", "verify_step.cpp")
 
 
@@ -391,21 +400,21 @@ def kernel_sources_sha() -> str:
     return h.hexdigest()[:16]
 
 
-TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r04_ep_traffic.json")
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r05_ep_traffic.json")
 
 
 def traffic_entry(section: str, key: str):
-    """(entry, note) of profiles/r04_ep_traffic.json[section][key]; entry None with the reason when the file is missing, lacks the key or was
+    """(entry, note) of profiles/r05_ep_traffic.json[section][key]; entry None with the reason when the file is missing, lacks the key or was
     measured on other kernel sources."""
     if not os.path.exists(TRAFFIC_FILE):
-        return None, "no PMC file (profiles/r04_ep_traffic.json)"
+        return None, "no PMC file (profiles/r05_ep_traffic.json)"
     tj = json.load(open(TRAFFIC_FILE))
     if tj.get("kernel_sources_sha") != kernel_sources_sha():
-        return None, f"profiles/r04_ep_traffic.json was measured on other kernel sources (commit {tj.get('commit')}): refused as stale"
+        return None, f"profiles/r05_ep_traffic.json was measured on other kernel sources (commit {tj.get('commit')}): refused as stale"
     t = tj.get(section, {}).get(key)
     if not t:
-        return None, f"profiles/r04_ep_traffic.json has no {section}/{key}"
-    return t, ("profiles/r04_ep_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH doubled per the gfx950 note), "
+        return None, f"profiles/r05_ep_traffic.json has no {section}/{key}"
+    return t, ("profiles/r05_ep_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH doubled per the gfx950 note), "
                f"measured at commit {tj.get('commit')}, same kernel sources")
 
 
@@ -419,10 +428,13 @@ def saturating_report(sweep):
     r = max(rows, key=lambda r_: r_["sequences_per_launch"])
     c = r["chain"]
     t, note = traffic_entry("saturating", f"chain_B{r['sequences_per_launch']}")
-    return {"kernel": "epw_kernel (evaluate_posterior, windowed chain, probability rows; the throughput instance: 256 threads per sequence, three workgroups per CU)",
+    return {"kernel": "epw_kernel (evaluate_posterior, windowed chain, probability rows; the throughput instance: 256 threads per sequence)",
             "sequences_per_launch": r["sequences_per_launch"], "avg_launch_ms": c["launch_ms"], "back_to_back_ms": c["back_to_back_ms"],
             "needed_bytes": c["hbm_bytes_needed_per_launch"], "achieved": c["achieved_GBps"], "peak": 8000.0, "unit": "GB/s", "frac": c["frac"],
-            "traffic": None if t is None else t["hbm_bytes"], "traffic_source": note,
+            "needed_bytes_definition": "(L + fresh) x W x 4 row bytes + T x k x 2 neighbour ids + W x 4 per LEVEL with a rejection (one drafter row per level: "
+                                       "its later rejections hit L2), from the kernel's counters and a host replay of the walks",
+            "traffic": None if t is None else t["hbm_bytes"], "traffic_over_needed": None if t is None else t["hbm_bytes"] / c["hbm_bytes_needed_per_launch"],
+            "traffic_source": note, "traffic_note": _short(note, 120),
             "inputs": f"{r['rotation_sets']} rotating input sets, {r['rotation_bytes'] / 2**30:.1f} GiB between re-reads"}
 
 
@@ -468,6 +480,7 @@ def kernel_report(wl, evs, E0, E1, KT):
         t, note = traffic_entry("per_launch", key)      # PMC passes are separate rocprofv3 runs of the same kernel / launch size (tools/run/prof_default.sh)
         rl["traffic"] = None if t is None else t["hbm_bytes"]
         rl["traffic_source"] = note
+        rl["traffic_note"] = _short(note, 120)
     ks = {}
     if "cfg_mask_topk" in evs[0]:
         o7_ms = mean_ms("cfg_mask_topk")
@@ -842,6 +855,18 @@ def compact_line(out: dict) -> dict:
         c["extras"] = ex
     if out.get("extras_file"):
         c["extras_file"] = out["extras_file"]
+
+    def rnd(o):          # six significant digits are plenty for everything but the headline pair (the --extras-out file keeps full precision)
+        if isinstance(o, float):
+            return float(f"{o:.6g}")
+        if isinstance(o, dict):
+            return {k: rnd(v) for k, v in o.items()}
+        if isinstance(o, list):
+            return [rnd(v) for v in o]
+        return o
+    keep = {k: c[k] for k in ("value", "ms_per_step") if k in c}
+    c = rnd(c)
+    c.update(keep)
     return c
 
 

@@ -390,10 +390,13 @@ typedef struct lantern_step_group {
     const void *hidden; void *out_hidden; int64_t *accepted_tokens; int32_t hid_elem_bytes, hid_groups, H, reserved1;
     /* with ep_win.rows_kind == LANTERN_ROWS_RAW_BF16: the nodes whose rows are post-processed up front, together with the candidate
      * assembly, in ONE launch (lantern_prepare_step) -- the root and the most likely children; NULL / 0: none (all rows on demand) */
-    const int32_t *node_list; int32_t n_list, reserved2;   /* dynamic groups: [2 * n_list] = the nodes, then the depth each is assumed to sit at */
-    const lantern_step_dynamic *dyn;      /* NULL: a static tree (ss_token / tree_indices / retrieve); with ss_token NULL as well the candidates
-                                             are taken as the caller left them in `cand` (a tree that came with its token list: `retrieve` [P,D]) */
+    const int32_t *node_list; int32_t n_list, flags;       /* dynamic groups: [2 * n_list] = the nodes, then the depth each is assumed to sit at; flags: LANTERN_STEP_* */
+    const lantern_step_dynamic *dyn;      /* NULL: a static tree (ss_token / tree_indices / retrieve), or -- flags & LANTERN_STEP_CANDIDATES_READY, ss_token
+                                             NULL -- candidates the caller assembled itself: `cand` [B,P,D] and `retrieve` [P,D] are taken as they are
+                                             (a tree that came with its token list, ea_model_llamagen.py:1125-1131; or lantern_gather_candidates called
+                                             before the target forward).  A static group with neither is an error, not a silent skip. */
 } lantern_step_group;
+#define LANTERN_STEP_CANDIDATES_READY 1   /* lantern_step_group.flags: skip the O6 stage, `cand` / `retrieve` (/ `cart_prob`, `tree_cand`) are final */
 int lantern_verify_step(const lantern_step_group *groups, int n_groups);
 /* O6 + O7 restricted to s->node_list in one launch (bf16 Lumina rows, 8192-id window): candidates -> s->tree_cand / cand / cart_prob,
  * probabilities of the listed rows -> s->out_win, their classes -> s->row_hot.  Called by lantern_verify_step when node_list is set.

@@ -61,6 +61,9 @@ class StepDynamic(C.Structure):
                                              "row_index", "pos_abs")])
 
 
+STEP_CANDIDATES_READY = 1          # lantern_step_group.flags (include/lantern_hip.h)
+
+
 class StepGroup(C.Structure):
     """lantern_step_group (include/lantern_hip.h): one group of sequences of lantern_verify_step."""
     _fields_ = ([("stream", C.c_void_p)]
@@ -77,7 +80,7 @@ class StepGroup(C.Structure):
                 + [("n_slabs", C.c_int32), ("elem_bytes", C.c_int32), ("outer", C.c_int64), ("S_max", C.c_int64), ("d", C.c_int64)]
                 + [(n, C.c_void_p) for n in ("hidden", "out_hidden", "accepted_tokens")]
                 + [(n, C.c_int32) for n in ("hid_elem_bytes", "hid_groups", "H", "reserved1")]
-                + [("node_list", C.c_void_p), ("n_list", C.c_int32), ("reserved2", C.c_int32)]
+                + [("node_list", C.c_void_p), ("n_list", C.c_int32), ("flags", C.c_int32)]
                 + [("dyn", C.POINTER(StepDynamic))])
 
 

@@ -1,0 +1,225 @@
+// draft_static.hip -- the static-tree (EAGLE v1 / LANTERN++) drafter's head stage on the device: head window GEMM + CFG -> the model's
+// processors -> softmax -> the row's distribution (the verify side's `original_prob` row) -> `n_draw` draws WITHOUT replacement + their conditional
+// probabilities, and the next depth's inputs gathered through the static tree's index tables.  What lantern_head_expand is to the EAGLE-2 loop.
+//
+// Reference: Model.sample, models/drafters/cnets_lumina_mgpt.py:936-955 (softmax -> torch.multinomial(k, replacement=False) -> p_i / (1 - sum_{j<i} p_j));
+// the static loop bodies cnets_lumina_mgpt.py:1245-1328 (topK_generate, tree_type "static"), cnets_llamagen.py:944-1023 / cnets_anole.py:1056-1171
+// (topK_genrate_v1); the tables behind `tree_indices[i]` / `repeat_nums[i]`: models/drafters/utils_c.py:100-179.
+//
+// RNG contract: torch.multinomial's device RNG is not reproducible across devices, so the draws come from INJECTED uniforms --
+// draw j of a row is the inverse CDF (token-id order, f64 running sum: lo_sample_inverse_cdf) of the row's distribution with the j tokens already
+// drawn removed, at uniform u[row][j].  Successive inverse-CDF draws without replacement have exactly the distribution of torch.multinomial(...,
+// replacement=False) (both are Plackett-Luce); `draw_idx` instead of `draw_u` takes the indices as given (tests, recorded runs).
+#include "common.h"
+#include "window_dev.h"
+
+namespace lantern {
+int launch_linear_rows_cfg_streamk(const void *A, const void *W, const void *bias, int n, int K, int row_lo, int n_cols, float cfg, void *win, int packed,
+                                   void *workspace, size_t workspace_bytes, hipStream_t st);
+
+constexpr int SW_C8 = 4;             // chunks of 8 ids per thread: W <= 8192 on 256 threads, <= 16384 on 512
+constexpr int SW_MAX_DRAW = 16;
+
+// One workgroup per drafter row.  `win`: the CFG-combined bf16 window logits of the row ([n, W], the head GEMM's epilogue output).
+template <int NT>
+__global__ __launch_bounds__(NT) void sample_window_kernel(const uint16_t *__restrict__ win, int W, int win_lo, int V, int model,
+                                                           const int64_t *__restrict__ pos_ids, int64_t pos_base, int w_latent, int h_latent,
+                                                           int newline_id, int eos_id, int top_k_filter, int n_draw,
+                                                           const double *__restrict__ draw_u, const int64_t *__restrict__ draw_idx,
+                                                           float *__restrict__ probs_out, int64_t *__restrict__ ss_token, float *__restrict__ ss_prob) {
+    constexpr int NW = NT / 64, NV4 = 2 * SW_C8;
+    extern __shared__ float4 sw_dyn[];
+    float *g = reinterpret_cast<float *>(sw_dyn);          // [W] the row's distribution, entries of drawn tokens zeroed as the draws go
+    __shared__ alignas(16) int s_hist[O7_HIST_INTS];
+    __shared__ float s_redf[2 * 16];
+    __shared__ double s_redd[2 * 16];
+    __shared__ double s_wtot[16];
+    __shared__ int s_redi[2 * 16];
+    __shared__ int s_bonus[2];
+    __shared__ int s_tok[SW_MAX_DRAW];
+    __shared__ float s_p[SW_MAX_DRAW];
+    const int row = blockIdx.x, tid = threadIdx.x;
+    const float NEG_INF = -__builtin_inff();
+    float *out = probs_out + (size_t)row * V;
+    int hot = -1;
+    if (model == LANTERN_MODEL_LUMINA && pos_ids) {
+        const int64_t n1 = pos_ids[row] - pos_base + 1;
+        if (n1 == ((int64_t)w_latent + 1) * h_latent + 1) hot = eos_id;
+        else if (py_mod64(n1, (int64_t)w_latent + 1) == 0) hot = newline_id;
+    }
+    // ---- the dense row outside the window: zero (masked ids carry no mass); a forced row: one 1.0
+    for (int i4 = tid; i4 * 4 < V; i4 += NT) {
+        const int e = i4 * 4;
+        if (hot < 0 && e >= win_lo && e + 4 <= win_lo + W) continue;          // the window part is written from the registers below
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (hot >= e && hot < e + 4) set_comp(v, hot - e, 1.0f);
+        reinterpret_cast<float4 *>(out)[i4] = v;
+    }
+    if (hot >= 0) {
+        // softmax of a row that is -inf everywhere but `hot`; the draws behind the first find no mass: the reference's multinomial returns arbitrary
+        // zero-probability ids there -- here the lowest window ids, in order (their conditional probability is 0: the verify side skips them)
+        if (tid == 0) {
+            double acc = 0.0;
+            float prev_c = 0.0f;
+            int next = win_lo;
+            for (int j = 0; j < n_draw; ++j) {
+                int64_t t;
+                if (draw_idx) t = draw_idx[(size_t)row * n_draw + j];
+                else if (j == 0) t = hot;
+                else {
+                    if (next == hot) ++next;
+                    t = next++;
+                }
+                const float p = (t == hot) ? 1.0f : 0.0f;
+                float v = p / (1.0f - prev_c);
+                if (isinf(v) || isnan(v)) v = -1.0f;
+                v = v < 0.0f ? 0.0f : (v > 1.0f ? 1.0f : v);
+                ss_token[(size_t)row * n_draw + j] = t;
+                ss_prob[(size_t)row * n_draw + j] = v;
+                acc += (double)p;
+                prev_c = (float)acc;
+            }
+        }
+        return;
+    }
+    float4 r[NV4];
+#pragma unroll
+    for (int it = 0; it < SW_C8; ++it) {
+        const int ch = tid + it * NT;
+        uint4 q = make_uint4(0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u);          // -inf pairs
+        if (ch * 8 < W) q = *reinterpret_cast<const uint4 *>(win + (size_t)row * W + ch * 8);
+        const uint32_t w[4] = {q.x, q.y, q.z, q.w};
+        float o[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = __uint_as_float((j & 1) ? (w[j >> 1] & 0xffff0000u) : (w[j >> 1] << 16));
+        r[2 * it] = make_float4(o[0], o[1], o[2], o[3]);
+        r[2 * it + 1] = make_float4(o[4], o[5], o[6], o[7]);
+    }
+    if (top_k_filter > 0 && top_k_filter < V && top_k_filter <= W) {
+        const float thr = kth_largest_hist_bf16<NT, NV4>(r, top_k_filter, s_hist);
+#pragma unroll
+        for (int it = 0; it < NV4; ++it) {
+            r[it].x = r[it].x < thr ? NEG_INF : r[it].x; r[it].y = r[it].y < thr ? NEG_INF : r[it].y;
+            r[it].z = r[it].z < thr ? NEG_INF : r[it].z; r[it].w = r[it].w < thr ? NEG_INF : r[it].w;
+        }
+    }
+    int ph = 0;
+    softmax_tile<NT, NV4>(r, s_redf, s_redd, ph);
+#pragma unroll
+    for (int it = 0; it < SW_C8; ++it) {
+        const int w0 = (tid + it * NT) * 8;
+        if (w0 < W) {
+            *reinterpret_cast<float4 *>(g + w0) = r[2 * it];
+            *reinterpret_cast<float4 *>(g + w0 + 4) = r[2 * it + 1];
+            // (win_lo % 4 == 0: 16-byte stores into the dense row)
+            *reinterpret_cast<float4 *>(out + win_lo + w0) = r[2 * it];
+            *reinterpret_cast<float4 *>(out + win_lo + w0 + 4) = r[2 * it + 1];
+        }
+    }
+    __syncthreads();
+    // ---- the draws: one after the other, the drawn entry removed from the LDS copy in between
+    int fallback = win_lo;
+    for (int j = 0; j < n_draw; ++j) {
+        int tok;
+        if (draw_idx) {
+            const int64_t t = draw_idx[(size_t)row * n_draw + j];
+            tok = (int)(t < 0 ? 0 : (t >= V ? V - 1 : t));
+        } else {
+            tok = bonus_draw_lds<NT, (SW_C8 * 8 * NT) / (4 * NT)>(g, W, win_lo, -1, 0.0f, draw_u[(size_t)row * n_draw + j], s_wtot, s_bonus, s_redi);
+            if (tok < 0 || tok == 0x7fffffff) {          // no mass left (fewer positive entries than draws): the lowest window ids not drawn yet
+                bool again = true;
+                while (again) {
+                    again = false;
+                    for (int q = 0; q < j; ++q)
+                        if (s_tok[q] == fallback) {
+                            ++fallback;
+                            again = true;
+                        }
+                }
+                tok = fallback++;
+            }
+        }
+        const bool inw = tok >= win_lo && tok < win_lo + W;
+        if (tid == 0) {
+            s_tok[j] = tok;
+            s_p[j] = inw ? g[tok - win_lo] : 0.0f;          // the token's probability in the row (0 once it has been drawn before: injected duplicates)
+        }
+        __syncthreads();
+        if (tid == 0 && inw) g[tok - win_lo] = 0.0f;
+        __syncthreads();
+    }
+    if (tid == 0) {
+        double acc = 0.0;
+        float prev_c = 0.0f;
+        for (int j = 0; j < n_draw; ++j) {          // Model.sample's conditional probabilities (lantern_sample_static's arithmetic)
+            const float p = s_p[j];
+            float v = p / (1.0f - prev_c);
+            if (isinf(v) || isnan(v)) v = -1.0f;
+            v = v < 0.0f ? 0.0f : (v > 1.0f ? 1.0f : v);
+            ss_token[(size_t)row * n_draw + j] = s_tok[j];
+            ss_prob[(size_t)row * n_draw + j] = v;
+            acc += (double)p;
+            prev_c = (float)acc;
+        }
+    }
+}
+
+// The next depth's inputs of a static tree (cnets_lumina_mgpt.py:1258-1262): token j = this depth's draws, flattened, at tree_indices[i + 1][j]
+// (`idx.view(-1)[tree_indices]`); hidden row j of both batch rows = this depth's output row of node j's parent (`repeat_hidden`: parent p repeated
+// repeat_nums[p] times -> the table `rep`).  One workgroup per (batch row, new token).
+__global__ __launch_bounds__(256) void static_next_inputs_kernel(const int64_t *__restrict__ ss_token, int n_flat, const int32_t *__restrict__ gather,
+                                                                const int32_t *__restrict__ rep, const uint16_t *__restrict__ out_hidden, int B, int T, int H,
+                                                                int T_next, uint16_t *__restrict__ hidden_next, int64_t *__restrict__ ids_next) {
+    const int j = blockIdx.x % T_next, b = blockIdx.x / T_next;
+    int par = rep[j];
+    par = par < 0 ? 0 : (par >= T ? T - 1 : par);
+    const uint4 *src = reinterpret_cast<const uint4 *>(out_hidden + ((size_t)b * T + par) * H);
+    uint4 *dst = reinterpret_cast<uint4 *>(hidden_next + ((size_t)b * T_next + j) * H);
+    for (int i = threadIdx.x; i < H / 8; i += blockDim.x) dst[i] = src[i];
+    if (threadIdx.x == 0) {
+        int gi = gather[j];
+        gi = gi < 0 ? 0 : (gi >= n_flat ? n_flat - 1 : gi);
+        ids_next[(size_t)b * T_next + j] = ss_token[gi];
+    }
+}
+
+int launch_static_next_inputs(const int64_t *ss_token, int n_flat, const int32_t *gather, const int32_t *rep, const void *out_hidden, int B, int T, int H, int T_next,
+                              void *hidden_next, int64_t *ids_next, hipStream_t st) {
+    hipLaunchKernelGGL(static_next_inputs_kernel, dim3(B * T_next), dim3(256), 0, st, ss_token, n_flat, gather, rep, (const uint16_t *)out_hidden, B, T, H, T_next,
+                       (uint16_t *)hidden_next, ids_next);
+    LANTERN_CHECK_LAUNCH("static_next_inputs");
+    return LANTERN_OK;
+}
+}  // namespace lantern
+
+using namespace lantern;
+
+extern "C" int lantern_head_sample(const void *A, const void *W, const void *bias, int n, int K, int row_lo, int n_cols, int V, float cfg, int model,
+                                   const int64_t *pos_ids, int64_t pos_base, int w_latent, int h_latent, int newline_id, int eos_id, int top_k_filter,
+                                   int n_draw, const double *draw_u, const int64_t *draw_idx, void *workspace, float *probs_out, int64_t *ss_token,
+                                   float *ss_prob, int packed, void *sk_workspace, size_t sk_workspace_bytes, void *stream) {
+    LANTERN_CHECK_ARG(A && W && workspace && probs_out && ss_token && ss_prob && sk_workspace, "head_sample: null buffer");
+    LANTERN_CHECK_ARG(draw_u || draw_idx, "head_sample: the draws need uniforms (draw_u [n, n_draw] f64) or injected indices (draw_idx [n, n_draw] i64)");
+    LANTERN_CHECK_ARG(n > 0 && n <= 16 && K > 0 && K % 16 == 0, "head_sample: n=%d drafter rows (<= 16 cond + 16 uncond), K=%d (multiple of 16)", n, K);
+    LANTERN_CHECK_ARG(row_lo >= 0 && row_lo % 4 == 0 && n_cols > 0 && n_cols % 8 == 0 && n_cols <= 8 * 512 * SW_C8 && row_lo + n_cols <= V && V % 4 == 0,
+                      "head_sample: window [%d,+%d) must start on a multiple of 4, be a multiple of 8 ids and <= %d wide, inside V (V %% 4 == 0)", row_lo, n_cols,
+                      8 * 512 * SW_C8);
+    LANTERN_CHECK_ARG(n_draw > 0 && n_draw <= SW_MAX_DRAW && n_draw <= n_cols, "head_sample: n_draw=%d (1..%d)", n_draw, SW_MAX_DRAW);
+    LANTERN_CHECK_ARG(model == LANTERN_MODEL_LUMINA || model == LANTERN_MODEL_ANOLE || (model == LANTERN_MODEL_PLAIN && row_lo == 0 && n_cols == V),
+                      "head_sample: models whose drafted rows are masked to one id window (Lumina, Anole), or LANTERN_MODEL_PLAIN with the window = the vocabulary");
+    if (model == LANTERN_MODEL_LUMINA && pos_ids)
+        LANTERN_CHECK_ARG(w_latent > 0 && h_latent > 0 && newline_id >= 0 && newline_id < V && eos_id >= 0 && eos_id < V, "head_sample: Lumina needs latent dims and syntax ids");
+    LANTERN_CHECK_ARG(((uintptr_t)workspace & 15) == 0 && ((uintptr_t)probs_out & 15) == 0, "head_sample: workspace / probs_out must be 16-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    const int rc = launch_linear_rows_cfg_streamk(A, W, bias, n, K, row_lo, n_cols, cfg, workspace, packed, sk_workspace, sk_workspace_bytes, st);
+    if (rc) return rc;
+    const size_t lds = (size_t)n_cols * 4;
+    if (n_cols <= 8 * 256 * SW_C8)
+        hipLaunchKernelGGL(sample_window_kernel<256>, dim3(n), dim3(256), lds, st, (const uint16_t *)workspace, n_cols, row_lo, V, model, pos_ids, pos_base, w_latent,
+                           h_latent, newline_id, eos_id, top_k_filter, n_draw, draw_u, draw_idx, probs_out, ss_token, ss_prob);
+    else
+        hipLaunchKernelGGL(sample_window_kernel<512>, dim3(n), dim3(512), lds, st, (const uint16_t *)workspace, n_cols, row_lo, V, model, pos_ids, pos_base, w_latent,
+                           h_latent, newline_id, eos_id, top_k_filter, n_draw, draw_u, draw_idx, probs_out, ss_token, ss_prob);
+    LANTERN_CHECK_LAUNCH("head_sample");
+    return LANTERN_OK;
+}

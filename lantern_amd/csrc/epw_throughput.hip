@@ -1,0 +1,37 @@
+// epw_throughput.hip -- the forms of the windowed chain kernel (epw_body.h) for more sequences per launch than CUs: several workgroups share a
+// CU, the register allocation is capped accordingly (WPE), the fixed configurations (SPEC) fold their flags away, and a candidate's drafter row is
+// requested only once its rejection is known (LATE_Q, TPO bit 0).  BASELINE assesses evaluate_posterior's roofline target at this batch.
+//   256 threads x 8 float4, three workgroups per CU (53 KB of LDS each): probability rows and -- round 5 -- raw cond / uncond bf16 rows
+//   512 threads x 4 float4 at 128 VGPRs, two per CU: everything else on the 8192-id window
+#undef EPW_TRACE
+#include "epw_body.h"
+
+namespace lantern {
+
+bool epw_launch_throughput(int kind, const EpwLaunch &l, const EpwArgs &args) {
+    static const bool raw512 = getenv("LANTERN_EPW_TP_RAW") && atoi(getenv("LANTERN_EPW_TP_RAW")) == 512;   // tuning knob (diagnostic)
+#define TP(...) LANTERN_LAUNCH((epw_kernel<__VA_ARGS__>), l.grid, dim3(NTX), l.lds, l.st, args)
+    switch (kind) {
+    case EPW_TP_LUMINA_DEFAULT_TREE: { constexpr int NTX = 256; TP(256, 8, 2, 3, true, false, 2, 1); return true; }
+    case EPW_TP_LUMINA_STATIC: { constexpr int NTX = 256; TP(256, 8, 2, 3, true, false, 1, 1); return true; }
+    case EPW_TP_LUMINA_DYNAMIC: { constexpr int NTX = 256; TP(256, 8, 2, 3, true, false, 3, 1); return true; }
+    case EPW_TP_ANOLE_STATIC: { constexpr int NTX = 256; TP(256, 8, 2, 3, true, false, 4, 1); return true; }
+    case EPW_TP_512_DEFAULT_TREE: { constexpr int NTX = 512; TP(512, 4, 2, 4, true, false, 2); return true; }
+    case EPW_TP_512_PACKED: { constexpr int NTX = 512; TP(512, 4, 2, 4, true); return true; }
+    case EPW_TP_512_ID0: { constexpr int NTX = 512; TP(512, 4, 0, 4); return true; }
+    case EPW_TP_512_ID1: { constexpr int NTX = 512; TP(512, 4, 1, 4); return true; }
+    case EPW_TP_512_ID2: { constexpr int NTX = 512; TP(512, 4, 2, 4); return true; }
+    case EPW_TP_RAW_GENERIC: { constexpr int NTX = 512; TP(512, 4, 2, 4, true, true); return true; }
+    // raw rows carry the row post-process's 18 KB of histograms: 71 KB of LDS per workgroup = two per CU whatever the thread count.  256 threads x 8
+    // float4 at two waves per SIMD (no register cap to spill against, half the waves -- half the repeated scalar work -- per sequence), or
+    // (LANTERN_EPW_TP_RAW=512, diagnostic) 512 threads at 128 VGPRs
+    case EPW_TP_RAW_LUMINA_DEFAULT_TREE: if (raw512) { constexpr int NTX = 512; TP(512, 4, 2, 4, true, true, 2, 1); } else { constexpr int NTX = 256; TP(256, 8, 2, 2, true, true, 2, 1); } return true;
+    case EPW_TP_RAW_LUMINA_STATIC: if (raw512) { constexpr int NTX = 512; TP(512, 4, 2, 4, true, true, 1, 1); } else { constexpr int NTX = 256; TP(256, 8, 2, 2, true, true, 1, 1); } return true;
+    case EPW_TP_RAW_LUMINA_DYNAMIC: if (raw512) { constexpr int NTX = 512; TP(512, 4, 2, 4, true, true, 3, 1); } else { constexpr int NTX = 256; TP(256, 8, 2, 2, true, true, 3, 1); } return true;
+    case EPW_TP_RAW_ANOLE_STATIC: if (raw512) { constexpr int NTX = 512; TP(512, 4, 2, 4, true, true, 4, 1); } else { constexpr int NTX = 256; TP(256, 8, 2, 2, true, true, 4, 1); } return true;
+    default: return false;
+    }
+#undef TP
+}
+
+}  // namespace lantern

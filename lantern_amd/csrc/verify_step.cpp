@@ -47,11 +47,20 @@ extern "C" int lantern_verify_step(const lantern_step_group *groups, int n_group
         } else if (s.node_list && s.n_list > 0) {   // candidates + the likely rows in one launch
             rc = lantern_prepare_step(&s);
             if (rc) return fail(g, "prepare_step", rc);
-        } else if (s.ss_token) {
+        } else if (s.flags & LANTERN_STEP_CANDIDATES_READY) {
+            // the caller assembled the candidates itself (a tree that came with its token list, ea_model_llamagen.py:1125-1131; or O6 called before the
+            // target forward): said explicitly, and what the later stages read must be there
+            if (s.ss_token || !s.cand || !s.retrieve || s.P <= 0 || s.D <= 0 || s.B < 0) {
+                lantern::set_error("LANTERN_STEP_CANDIDATES_READY needs cand [B,P,D] and retrieve [P,D] with P, D > 0 and ss_token NULL");
+                return fail(g, "gather_candidates", LANTERN_E_INVALID);
+            }
+        } else {
+            // (a zero-initialised or half-filled group lands here: lantern_gather_candidates refuses its NULL buffers instead of the step
+            // evaluating whatever `cand` happens to hold)
             rc = lantern_gather_candidates(s.ss_token, s.ss_prob, s.sample_token, s.tree_indices, s.retrieve, s.B, s.n_flat, s.N, s.P,
                                            s.D, s.tree_cand, s.cand, s.cart_prob, s.stream);
             if (rc) return fail(g, "gather_candidates", rc);
-        }          // (ss_token NULL: the caller assembled the candidates itself -- a dynamic tree that came with its token list, ea_model_llamagen.py:1125-1131)
+        }
     }
     for (int g = 0; g < n_groups; ++g) {
         const lantern_step_group &s = groups[g];

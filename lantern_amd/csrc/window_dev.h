@@ -159,11 +159,15 @@ __device__ __forceinline__ void softmax_tile(float4 (&r)[NV4], float *redf, doub
 // (LDS f64 atomics), bins walked in ascending order until the running mass (rounded to f32 like torch.cumsum's
 // output) exceeds 1 - top_p.  Equal values at the boundary go in index order (a stable ascending sort), counted with a
 // block scan; that path and the keep-the-last rule only run when they apply.
-template <int NT, int NV4>
+// CHUNK8: the tile holds 8-id chunks (r[2j], r[2j+1] = ids (tid + j*NT)*8 .. +7: the bf16 row kernels' layout) instead of 4-id chunks
+// (r[it] = ids (tid + it*NT)*4 .. +3): the index order that breaks ties at the boundary, and the "last entry" of the keep-one rule, follow it.
+template <int NT, int NV4, bool CHUNK8 = false>
 __device__ void top_p_tile(float4 (&r)[NV4], float top_p, double *mass, float *redf, double *redd, int *redi, int &ph) {
+    static_assert(!CHUNK8 || NV4 % 2 == 0, "8-id chunks are pairs of float4");
     constexpr int NW = NT / 64;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float NEG_INF = -__builtin_inff();
+    auto first_index = [&](int it) -> int { return CHUNK8 ? (tid + (it >> 1) * NT) * 8 + (it & 1) * 4 : (tid + it * NT) * 4; };
     float4 p[NV4];
 #pragma unroll
     for (int it = 0; it < NV4; ++it) p[it] = r[it];
@@ -220,7 +224,7 @@ __device__ void top_p_tile(float4 (&r)[NV4], float top_p, double *mass, float *r
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 const uint32_t kk = float_key(rv[c]);
-                const int idx = (tid + it * NT) * 4 + c;
+                const int idx = first_index(it) + c;
                 if (kk > kmax || (kk == kmax && idx > imax)) { kmax = kk; imax = idx; }
             }
         }
@@ -251,7 +255,7 @@ __device__ void top_p_tile(float4 (&r)[NV4], float top_p, double *mass, float *r
         for (int w = 1; w < NW; ++w) ib = max(ib, buf3[w]);
 #pragma unroll
         for (int it = 0; it < NV4; ++it) {
-            const int i0 = (tid + it * NT) * 4;
+            const int i0 = first_index(it);
             r[it].x = (i0 == ib) ? r[it].x : NEG_INF;
             r[it].y = (i0 + 1 == ib) ? r[it].y : NEG_INF;
             r[it].z = (i0 + 2 == ib) ? r[it].z : NEG_INF;
@@ -288,25 +292,29 @@ __device__ void top_p_tile(float4 (&r)[NV4], float top_p, double *mass, float *r
         }
     }
     int base[NV4];
-    if (m > 0) {        // rank of every boundary-valued entry in index order (register tile order = ascending index per `it` slice)
+    if (m > 0) {        // rank of every boundary-valued entry in index order: a slice = the ids one pass of the workgroup covers (ascending with the thread
+                        // id), 4 per thread or -- CHUNK8 -- 8 per thread in two float4
+        constexpr int SL = CHUNK8 ? 2 : 1, NS = NV4 / SL;
         __shared__ int s_tie_tot[NV4][NW];
-        int incl[NV4];
+        int incl[NS], cnt[NS];
 #pragma unroll
-        for (int it = 0; it < NV4; ++it) {
-            incl[it] = wave_scan_incl_dpp(tie_cnt[it]);
-            if (lane == 63) s_tie_tot[it][wave] = incl[it];
+        for (int sl = 0; sl < NS; ++sl) {
+            cnt[sl] = tie_cnt[SL * sl] + (CHUNK8 ? tie_cnt[SL * sl + SL - 1] : 0);
+            incl[sl] = wave_scan_incl_dpp(cnt[sl]);
+            if (lane == 63) s_tie_tot[sl][wave] = incl[sl];
         }
         __syncthreads();
         int run = 0;
 #pragma unroll
-        for (int it = 0; it < NV4; ++it) {
+        for (int sl = 0; sl < NS; ++sl) {
             int woff = 0, tot = 0;
             for (int w = 0; w < NW; ++w) {
-                const int t = s_tie_tot[it][w];
+                const int t = s_tie_tot[sl][w];
                 woff += (w < wave) ? t : 0;
                 tot += t;
             }
-            base[it] = run + woff + (incl[it] - tie_cnt[it]);
+            base[SL * sl] = run + woff + (incl[sl] - cnt[sl]);
+            if (CHUNK8) base[SL * sl + SL - 1] = base[SL * sl] + tie_cnt[SL * sl];
             run += tot;
         }
         __syncthreads();
@@ -503,14 +511,16 @@ __device__ __forceinline__ float kth_largest_hist_bf16(const float4 (&r)[NV4], i
 // actually visits -- 2.7 + 1 of a tree's 26 rows per step -- instead of for every row in a separate launch.  Same code as
 // cfg_window_bf16_kernel (same tile layout, same reductions), so the probabilities are the same bits.  The 16 row registers
 // carry two 16-byte chunks of cond and two of uncond per thread until they are needed.
-template <int NT>
-__device__ __forceinline__ void raw_row_load(const uint16_t *__restrict__ crow, const uint16_t *__restrict__ urow, float4 (&rp)[4]) {
+// CH: 16-byte chunks (8 ids) per thread and operand -- W = 8 * CH * NT: 2 on 512 threads (the latency instances), 4 on 256 threads (the
+// throughput instances: half the waves per sequence).  rp[0..CH) hold cond, rp[CH..2 CH) uncond.
+template <int NT, int CH = 2>
+__device__ __forceinline__ void raw_row_load(const uint16_t *__restrict__ crow, const uint16_t *__restrict__ urow, float4 (&rp)[2 * CH]) {
 #pragma unroll
-    for (int it = 0; it < 2; ++it) {
+    for (int it = 0; it < CH; ++it) {
         const int ch = threadIdx.x + it * NT;
         const Bf16x8 c = *reinterpret_cast<const Bf16x8 *>(crow + ch * 8), u = *reinterpret_cast<const Bf16x8 *>(urow + ch * 8);
         rp[it] = make_float4(__uint_as_float(c.a.x), __uint_as_float(c.a.y), __uint_as_float(c.b.x), __uint_as_float(c.b.y));
-        rp[2 + it] = make_float4(__uint_as_float(u.a.x), __uint_as_float(u.a.y), __uint_as_float(u.b.x), __uint_as_float(u.b.y));
+        rp[CH + it] = make_float4(__uint_as_float(u.a.x), __uint_as_float(u.a.y), __uint_as_float(u.b.x), __uint_as_float(u.b.y));
     }
 }
 
@@ -518,8 +528,8 @@ __device__ __forceinline__ void raw_row_load(const uint16_t *__restrict__ crow, 
 // LlamaGen / Anole take top_p from generate()); its 256 f64 mass bins live in the front of the histogram buffer (the top-k select clears it afterwards).
 // (NUCLEUS is a template parameter: the filter keeps a second copy of the row in registers, which the instances without it must not pay for --
 // 162 -> 217 VGPRs for the chain kernel, 51 -> 94 for the row preparation when it was a run-time branch.)
-template <int NT, typename Hook = NoHook, bool NUCLEUS = false>
-__device__ __forceinline__ void raw_row_to_lds(const float4 (&rp)[4], int hot, float cfg, int top_k, int V, int win_lo, int W, float *g,
+template <int NT, typename Hook = NoHook, bool NUCLEUS = false, int CH = 2>
+__device__ __forceinline__ void raw_row_to_lds(const float4 (&rp)[2 * CH], int hot, float cfg, int top_k, int V, int win_lo, int W, float *g,
                                                int &out_tok, float &out_mass, float *redf, double *redd, int *hist, int &ph, const Hook &pre_barrier = Hook(),
                                                float top_p = 1.0f, int *redi = nullptr) {
     const int tid = threadIdx.x;
@@ -543,11 +553,11 @@ __device__ __forceinline__ void raw_row_to_lds(const float4 (&rp)[4], int hot, f
         __syncthreads();
         return;
     }
-    float4 r[4];
+    float4 r[2 * CH];
 #pragma unroll
-    for (int it = 0; it < 2; ++it) {
+    for (int it = 0; it < CH; ++it) {
         const uint32_t cw[4] = {__float_as_uint(rp[it].x), __float_as_uint(rp[it].y), __float_as_uint(rp[it].z), __float_as_uint(rp[it].w)};
-        const uint32_t uw[4] = {__float_as_uint(rp[2 + it].x), __float_as_uint(rp[2 + it].y), __float_as_uint(rp[2 + it].z), __float_as_uint(rp[2 + it].w)};
+        const uint32_t uw[4] = {__float_as_uint(rp[CH + it].x), __float_as_uint(rp[CH + it].y), __float_as_uint(rp[CH + it].z), __float_as_uint(rp[CH + it].w)};
         float o[8];
 #pragma unroll
         for (int q2 = 0; q2 < 4; ++q2) {
@@ -560,21 +570,21 @@ __device__ __forceinline__ void raw_row_to_lds(const float4 (&rp)[4], int hot, f
     }
     EPW_STAMPG(81);
     if constexpr (NUCLEUS) {
-        if (top_p >= 1e-8f && top_p < 1.0f && redi) top_p_tile<NT, 4>(r, top_p, reinterpret_cast<double *>(hist), redf, redd, redi, ph);
+        if (top_p >= 1e-8f && top_p < 1.0f && redi) top_p_tile<NT, 2 * CH, true>(r, top_p, reinterpret_cast<double *>(hist), redf, redd, redi, ph);
     }
     if (top_k > 0 && top_k < V) {
-        const float thr = (top_k <= W) ? kth_largest_hist_bf16<NT, 4>(r, top_k, hist) : NEG_INF;
+        const float thr = (top_k <= W) ? kth_largest_hist_bf16<NT, 2 * CH>(r, top_k, hist) : NEG_INF;
 #pragma unroll
-        for (int it = 0; it < 4; ++it) {
+        for (int it = 0; it < 2 * CH; ++it) {
             r[it].x = r[it].x < thr ? NEG_INF : r[it].x; r[it].y = r[it].y < thr ? NEG_INF : r[it].y;
             r[it].z = r[it].z < thr ? NEG_INF : r[it].z; r[it].w = r[it].w < thr ? NEG_INF : r[it].w;
         }
     }
     EPW_STAMPG(86);
-    softmax_tile<NT, 4>(r, redf, redd, ph);
+    softmax_tile<NT, 2 * CH>(r, redf, redd, ph);
     EPW_STAMPG(88);
 #pragma unroll
-    for (int it = 0; it < 2; ++it) {
+    for (int it = 0; it < CH; ++it) {
         float *dst = g + (size_t)(tid + it * NT) * 8;
         *reinterpret_cast<float4 *>(dst) = r[2 * it];
         *reinterpret_cast<float4 *>(dst + 4) = r[2 * it + 1];

@@ -56,6 +56,7 @@ __shared__ int s_epw_trn;
 
 #include "window_dev.h"
 #include "tree_dynamic_dev.h"
+#include "epw_body.h"
 
 namespace lantern {
 
@@ -253,7 +254,7 @@ __device__ __forceinline__ void cfg_window_bf16_row(int row, int cls, const uint
     if constexpr (NUCLEUS) {          // TopPLogitsWarper in front of the top-k (the mass bins in the front of the histogram buffer)
         if (top_p >= 1e-8f && top_p < 1.0f && s_redi) {
             int php = 0;
-            top_p_tile<NT, 2 * E8>(r, top_p, reinterpret_cast<double *>(s_hist), s_redf, s_redd, s_redi, php);
+            top_p_tile<NT, 2 * E8, true>(r, top_p, reinterpret_cast<double *>(s_hist), s_redf, s_redd, s_redi, php);
         }
     }
     if (top_k > 0 && top_k < V) {
@@ -414,923 +415,6 @@ __global__ __launch_bounds__(NT) void dyn_prep_kernel(const DynPrepArgs a) {
     td_finalize_body<8, NT / 64>(a.td, blockIdx.x - n_rows);
 }
 
-// ------------------------------------------------------------------------------- O8 windowed
-//
-// Structure (v3).  A 512-thread workgroup owns one sequence.  The serial part of the algorithm -- walking the
-// candidates of a level, the k-neighbour cumulative-mass scan, the accept test -- is executed by WAVE 0 ONLY
-// (one lane per path for the prefix masks, 16 neighbours per lane for the scan, DPP scans); the other waves
-// wait at a barrier and join for the W-wide passes (row softmax, residual update, renormalisation), whose
-// cross-wave reductions combine <= 16 partials with one DPP row.  All decisions travel through one LDS word,
-// so control flow stays workgroup-uniform.  The neighbour ids of every candidate of a level are fetched in one
-// round at level start (they depend only on the accepted prefix), so the per-candidate work is LDS + ALU only.
-
-template <int NT, int E4, bool FULLW = false, typename Hook = NoHook>
-__device__ __forceinline__ void row_softmax_to_lds(float4 (&r)[E4], int hot, bool probs, int win_lo, int W, float temperature, int top_k,
-                                                   int V, float *g, int &out_tok, float &out_mass, EwShared &S, int &ph,
-                                                   const Hook &pre_barrier = Hook()) {
-    const int tid = threadIdx.x;
-    const float NEG_INF = -__builtin_inff();
-    out_tok = -1;
-    out_mass = 0.0f;
-    if (hot >= 0) {
-        const bool inside = hot >= win_lo && hot < win_lo + W;
-        for (int i4 = tid; i4 * 4 < W; i4 += NT) {
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            const int e = win_lo + i4 * 4;
-            if (hot >= e && hot < e + 4) set_comp(v, hot - e, 1.0f);
-            reinterpret_cast<float4 *>(g)[i4] = v;
-        }
-        if (!inside) {
-            out_tok = hot;
-            out_mass = 1.0f;
-        }
-        if (tid == 0) g[W + EW_G_OUT] = out_mass;
-        pre_barrier();
-        __syncthreads();
-        return;
-    }
-    if (!probs) {       // rows arrive as logits: processors + softmax here; LANTERN_ROWS_PROBS rows are final (O7 did both)
-        if (temperature > 1e-5f && temperature != 1.0f) {
-#pragma unroll
-            for (int it = 0; it < E4; ++it) {
-                r[it].x = r[it].x / temperature; r[it].y = r[it].y / temperature;
-                r[it].z = r[it].z / temperature; r[it].w = r[it].w / temperature;
-            }
-        }
-        if (top_k > 0 && top_k < V && top_k <= W) {
-            const float thr = kth_largest_tile<NT, E4, false>(r, top_k, S.redi, ph);
-#pragma unroll
-            for (int it = 0; it < E4; ++it) {
-                r[it].x = r[it].x < thr ? NEG_INF : r[it].x; r[it].y = r[it].y < thr ? NEG_INF : r[it].y;
-                r[it].z = r[it].z < thr ? NEG_INF : r[it].z; r[it].w = r[it].w < thr ? NEG_INF : r[it].w;
-            }
-        }
-        softmax_tile<NT, E4>(r, S.redf, S.redd, ph);
-    }
-#pragma unroll
-    for (int it = 0; it < E4; ++it) {
-        const int i4 = tid + it * NT;
-        if (FULLW || i4 * 4 < W) reinterpret_cast<float4 *>(g)[i4] = r[it];
-    }
-    if (tid == 0) g[W + EW_G_OUT] = 0.0f;
-    pre_barrier();
-    __syncthreads();
-}
-
-// LDSIDS: every candidate's neighbour ids are staged in LDS (k + 1 <= EW_PF_K, or LANTERN off), so the serial wave-0
-// section contains no vector-memory instruction -- the compiler then has no reason to drain vmcnt inside it and the
-// drafter-row / id loads issued before it stay in flight across the scan.  !LDSIDS (k > 1023) reads ids from HBM.
-//
-// Scalar registers are the scarce resource of this kernel (three parameter blocks + the walk's state): everything the
-// epilogue alone needs (output pointers, the bonus-draw inputs) is re-read from the kernarg segment there instead of
-// being held in SGPRs across the whole walk.
-struct EpwArgs {
-    lantern_ep_params prm;
-    lantern_ep_buffers buf;
-    lantern_ep_window win;
-};
-typedef const __attribute__((address_space(4))) EpwArgs *EpwArgsK;
-
-// IDMODE 0: ids from HBM in the scan (k > 1023).  1: ids staged in LDS, table rows at any (2-byte) alignment -- the
-// reference's [K, K-1] layout.  2: ids staged in LDS from a table whose row stride is a multiple of 8 ids and whose base
-// is 16-byte aligned (lantern_pack_vq_table): one 16-byte load brings 8 ids, 2 loads per thread cover a whole level.
-// WPE (waves per SIMD the register allocation must allow): 1 = no constraint -- the latency-optimal build (162 VGPRs, one
-// workgroup per CU) used while every sequence of the launch gets a CU to itself; 4 (512-thread workgroups) = 128 VGPRs so
-// that TWO workgroups share a CU once the batch exceeds the CU count (67 KB of LDS each): +41 % sequences/s at saturation,
-// -7 % at 48 sequences (a few spills), hence selected by batch size.
-// FULLW: the window is exactly the workgroup's register tile (W == 4 * NT * E4, the Lumina / Anole 8192-id image range on
-// 512 x 4): no per-chunk bounds predicate, so the four chunks of a pass are one basic block and their LDS reads go out together.
-// RAW: rows are the target model's raw cond / uncond bf16 logits (LANTERN_ROWS_RAW_BF16; W == 8 * 2 * NT, packed table).
-template <int NT, int E4, int IDMODE, int WPE, bool FULLW = false, bool RAW = false, int SPEC = 0, int TPO = 0>
-__device__ __forceinline__ int epw_body(const EpwArgs &args, const int b) {
-    constexpr bool NUCLEUS = (TPO & 2) != 0;         // raw rows: TopPLogitsWarper (prm.top_p) in front of the top-k of the rows the walk post-processes
-    constexpr bool LATE_Q = (TPO & 1) != 0;          // throughput builds: a candidate's drafter row is requested once its rejection is known (an accepted
-                                                     // candidate -- 0.65 of the first tries -- then costs no row request at all; the latency is another workgroup's problem)
-    static_assert(!RAW || (FULLW && E4 == 4), "raw rows: the 8192-id window on 512 threads");
-    constexpr bool LDSIDS = IDMODE != 0;
-    const lantern_ep_params &prm = args.prm;
-    const lantern_ep_buffers &buf = args.buf;
-    const lantern_ep_window &win = args.win;
-    constexpr int NW = NT / 64;
-    // one dynamic LDS region (16-byte aligned base): [ g : W f32 | nbmask : W bits | EwShared ]
-    extern __shared__ float4 dyn_lds[];
-    float *g = reinterpret_cast<float *>(dyn_lds);
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    // Compile-time instances of the reference's configurations (SPEC 0: everything from the argument block).  They all share the Chameleon
-    // vocabulary of Lumina-mGPT / Anole (V = 65536, image ids = window = [4, 8196), table offset 4, 8192 table rows):
-    //   1  Lumina static tree (LANTERN_MODE_STATIC_LUMINA), LANTERN on, syntax shortcut with Lumina's four syntax ids
-    //   2  = 1 + the reference's default Lumina tree mc_sim_7b_63 (26 nodes, 15 paths of depth <= 6; run.sh / generate_images.py)
-    //   3  Lumina dynamic (EAGLE-2) trees: LANTERN_MODE_DYNAMIC, LANTERN on, syntax shortcut, per-sequence paths / depths / positions
-    //   4  Anole static tree (LANTERN_MODE_STATIC_LG: the neighbour set zeroes q), LANTERN on, no syntax shortcut
-    //   5  LlamaGen dynamic (EAGLE-2) trees, standard verify (BASELINE config 2): LANTERN off, no syntax shortcut, V = window = 16384 ids from 0
-    // The mode / flag tests below fold away, and with them the scalar registers that carried them through the whole walk; the host
-    // dispatches to an instance only when the argument block says exactly that.
-    constexpr bool SL = SPEC >= 1;                               // one of the fixed configurations
-    constexpr bool S_STATIC = SPEC == 1 || SPEC == 2 || SPEC == 4, S_DYN = SPEC == 3 || SPEC == 5, S_SYN = SPEC >= 1 && SPEC <= 3;
-    constexpr bool S_LG = SPEC == 5;                             // LlamaGen's vocabulary instead of Chameleon's
-    const int Ps = (SPEC == 2) ? 15 : prm.P, Ds = (SPEC == 2) ? 6 : prm.D, V = SL ? (S_LG ? 16384 : 65536) : prm.V, W = SL ? (S_LG ? 16384 : 8192) : win.win_len,
-              lo = SL ? (S_LG ? 0 : 4) : win.win_lo;
-    uint32_t *nbmask = reinterpret_cast<uint32_t *>(g + W + EW_G_EXT);  // W bits: neighbour set (static LlamaGen/Anole: zeroing hits q)
-    EwShared &S = *reinterpret_cast<EwShared *>(reinterpret_cast<char *>(g) + epw_shared_offset(W));
-    int *const Scand = reinterpret_cast<int *>(reinterpret_cast<char *>(&S) + sizeof(EwShared));
-    const int pd_cap = epw_pd_cap(Ps, Ds);
-    int *const Srow = Scand + pd_cap, *const Spidx = Srow + pd_cap, *const Sboff = Spidx + pd_cap;
-    float *const Scart = reinterpret_cast<float *>(Sboff + pd_cap);
-    int *const Sflag = reinterpret_cast<int *>(Scart + pd_cap);       // per (path, depth): bit 1 image token, bit 0 syntax token
-    int *const Shist = Sflag + pd_cap;                                // RAW: the radix-select histograms of the row post-process
-    const int k = prm.k, off = SL ? (S_LG ? 0 : 4) : prm.tok_offset;
-    const int p_mode = !SL ? prm.mode : (SPEC == 4 ? (int)LANTERN_MODE_STATIC_LG : (S_DYN ? (int)LANTERN_MODE_DYNAMIC : (int)LANTERN_MODE_STATIC_LUMINA));
-    const bool p_lantern = SL ? !S_LG : prm.lantern != 0;
-    const bool p_syntax = SL ? S_SYN : prm.syntax_shortcut != 0;
-    const int p_nsyn = SL ? (S_SYN ? 4 : 0) : prm.n_syntax;
-    const int p_rows = (SPEC == 2) ? 26 : prm.rows_per_seq, p_N = (SPEC == 2) ? 26 : prm.N;
-    const int p_img_lo = SL ? (S_LG ? 0 : 4) : prm.img_lo, p_img_hi = SL ? (S_LG ? 16384 : 8196) : prm.img_hi, p_trows = SL ? (S_LG ? 0 : 8192) : prm.table_rows;
-    auto p_syn = [&](int q) -> int { return SL ? (q == 0 ? 8196 : (q == 1 ? 8197 : (q == 2 ? 8803 : 8828))) : prm.syntax[q]; };
-    const bool is_static = SL ? S_STATIC : p_mode != LANTERN_MODE_DYNAMIC;
-    const int P = S_DYN ? buf.n_paths[b] : ((!SL && buf.n_paths) ? buf.n_paths[b] : Ps);
-    const int D = S_DYN ? buf.n_depth[b] : ((!SL && buf.n_depth) ? buf.n_depth[b] : Ds);
-    const float NEG_INF = -__builtin_inff();
-    const int nz = (k + 1 < prm.table_cols) ? k + 1 : prm.table_cols;   // ids touched per candidate (k summed, k+1 zeroed)
-    const bool can_prefetch = LDSIDS && p_lantern;          // (SPEC 1: true at compile time)
-    const bool hot_in_lds = SL ? true : p_rows <= EW_MAX_N;
-    const bool rows_probs = (SL && !RAW) ? true : win.rows_kind == LANTERN_ROWS_PROBS;
-    int ph = 0;
-#ifdef EPW_TRACE
-    if (tid == 0) s_epw_trn = 0;
-    EPW_STAMP(0);
-#endif
-
-    // ---- stage every small per-step table in LDS: two rounds of global loads (everything independent first, then what
-    // needs the uniform cursor / the sibling count / the first row id), all issued before the first wait
-    const float *logits = buf.logits + (size_t)b * p_rows * W;
-    const uint16_t *raw_c = RAW ? reinterpret_cast<const uint16_t *>(buf.logits) + (size_t)b * p_rows * V + lo : nullptr;
-    const uint16_t *raw_u = RAW ? reinterpret_cast<const uint16_t *>(win.raw_uncond) + (size_t)b * p_rows * V + lo : nullptr;
-    const float *raw_p = (RAW && win.raw_probs) ? win.raw_probs + (size_t)b * p_rows * W : nullptr;
-    const bool root_pre = RAW && raw_p && win.raw_pre && win.raw_pre[0] != 0;     // (the level-1 row is requested before the tables are staged)
-    bool rp_probs = false;       // what rp holds: probabilities of a pre-processed row, or raw cond / uncond chunks
-    const int32_t *hot_g = win.row_hot ? win.row_hot + (size_t)b * p_rows : nullptr;
-    const int ucur0 = buf.cursor ? buf.cursor[b] : 0;
-    float4 rp[E4];              // prefetched row (registers) and the row id it holds
-    int rp_rid = -1;
-    {
-        constexpr int PD_PER = (EW_MAX_PD + NT - 1) / NT, B_PER = (EW_MAX_B + NT - 1) / NT, N_PER = (EW_MAX_N + NT - 1) / NT;
-        const int npd = Ps * Ds;
-        const int64_t *cand_g = buf.cand + (size_t)b * npd;
-        const int32_t *row_g = buf.row_index + (prm.row_index_per_seq ? (size_t)b * npd : 0);
-        const int nb_total = is_static ? buf.b_off[npd] : 0;
-        const int rid1 = row_g[0];          // level 1: every path shares the root, the first matching path is path 0
-        int64_t c_[PD_PER];
-        int r_[PD_PER], pi_[PD_PER], bo_[PD_PER], tc_[N_PER], hot_[N_PER], oo_ = 0;
-        float ct_[PD_PER];
-#pragma unroll
-        for (int u = 0; u < PD_PER; ++u) {
-            const int t = tid + u * NT;
-            const bool in = t < npd;
-            c_[u] = in ? cand_g[t] : 0;
-            r_[u] = in ? row_g[t] : 0;
-            ct_[u] = (in && is_static) ? buf.cart_prob[(size_t)b * npd + t] : 0.0f;
-            pi_[u] = (in && is_static) ? buf.p_idx[t] : 0;
-            bo_[u] = (in && is_static) ? buf.b_off[t] : 0;
-        }
-#pragma unroll
-        for (int u = 0; u < N_PER; ++u) {
-            const int t = tid + u * NT;
-            tc_[u] = (is_static && t < p_N && t < EW_MAX_N) ? (int)buf.tree_cand[(size_t)b * p_N + t] : 0;
-            hot_[u] = (!RAW && hot_g && hot_in_lds && t < p_rows) ? hot_g[t] : -1;          // (raw rows: the class comes from the position, below; row_hot is not read)
-            if (RAW && t < p_rows) {
-                // raw_pre[t] = 1 + the depth the row was prepared for; with per-sequence trees the node has to sit there (its position says so)
-                int pre = (win.raw_pre && win.raw_probs) ? (int)win.raw_pre[t] : 0;
-                if (pre && (SL ? (int)S_DYN : win.raw_pos_per_seq)) {
-                    const int64_t *pp = win.raw_pos_ids + (size_t)b * p_rows;
-                    if (pp[t] - pp[0] != pre - 1) pre = 0;
-                }
-                S.pre[t] = pre;
-            }
-            // the row's class from its position (MultiModalLogitsProcessor, ea_model_lumina_mgpt.py:45-86); raw_w_latent == 0: a model without
-            // grammar rows (LlamaGen: every row is an ordinary distribution)
-            if (RAW && !S_LG && t < p_rows && win.raw_w_latent > 0) {
-                const int64_t n1 = ((SL ? (int)S_DYN : win.raw_pos_per_seq) ? win.raw_pos_ids[(size_t)b * p_rows + t] : win.raw_pos_ids[t] + win.raw_seq_len[b]) - win.raw_pos_base + 1;
-                // (a 64-bit modulo is ~150 instructions: the 32-bit form whenever the operands fit -- always, for real image sizes)
-                const bool fits = n1 >= 0 && n1 < (1ll << 31) && win.raw_w_latent >= 0 && win.raw_w_latent < (1 << 30);
-                const bool nl = (fits ? ((uint32_t)n1 % (uint32_t)(win.raw_w_latent + 1)) == 0u : py_mod64(n1, (int64_t)win.raw_w_latent + 1) == 0);
-                hot_[u] = (n1 == ((int64_t)win.raw_w_latent + 1) * win.raw_h_latent + 1) ? (SL ? 8196 : win.raw_eos_id)
-                          : (nl ? (SL ? 8803 : win.raw_newline_id) : -1);
-            }
-        }
-        if (is_static && tid < Ds - 1) oo_ = buf.op_off[tid];
-        double ub_ = 0.0;                   // read by the epilogue from LDS: a global load there sits on the chain with its full latency
-        if (tid == 0 && win.u_bonus) ub_ = win.u_bonus[b];
-        // round 2
-        const double *uni = buf.uniforms + (size_t)b * prm.n_uniforms;
-        double un_ = 2.0;                   // never drawn: guarded below
-        if (tid < EW_UNI && ucur0 + tid < prm.n_uniforms) un_ = uni[ucur0 + tid];
-        int bi_[B_PER];
-#pragma unroll
-        for (int u = 0; u < B_PER; ++u) {
-            const int t = tid + u * NT;
-            bi_[u] = (t < nb_total && t < EW_MAX_B) ? buf.b_idx[t] : 0;
-        }
-        if (rid1 >= 0 && rid1 < p_rows) {
-            if constexpr (RAW) {
-                rp_probs = root_pre && rid1 == 0;
-                if (rp_probs) row_load<NT, E4, FULLW>(raw_p + (size_t)rid1 * W, W, rp);
-                else raw_row_load<NT>(raw_c + (size_t)rid1 * V, raw_u + (size_t)rid1 * V, rp);
-            } else row_load<NT, E4, FULLW>(logits + (size_t)rid1 * W, W, rp);
-            rp_rid = rid1;
-        }
-        // LDS stores
-#pragma unroll
-        for (int u = 0; u < PD_PER; ++u) {
-            const int t = tid + u * NT;
-            if (t < npd) {
-                const int tok = (int)c_[u];
-                int fl = (tok >= p_img_lo && tok < p_img_hi) ? 2 : 0;
-                if (p_syntax)
-                    for (int q = 0; q < p_nsyn; ++q) fl |= (tok == p_syn(q)) ? 1 : 0;
-                Sflag[t] = fl;
-                Scand[t] = tok;
-                Srow[t] = r_[u];
-                if (is_static) {
-                    Scart[t] = ct_[u];
-                    Spidx[t] = pi_[u];
-                    Sboff[t] = bo_[u];
-                }
-            }
-        }
-        if (is_static) {
-            if (tid == 0) Sboff[npd] = nb_total;
-#pragma unroll
-            for (int u = 0; u < B_PER; ++u) {
-                const int t = tid + u * NT;
-                if (t < nb_total && t < EW_MAX_B) S.bidx[t] = (unsigned short)bi_[u];
-            }
-#pragma unroll
-            for (int u = 0; u < N_PER; ++u) {
-                const int t = tid + u * NT;
-                if (t < p_N && t < EW_MAX_N) S.tcand[t] = tc_[u];
-            }
-            if (tid < Ds - 1) S.opoff[tid] = oo_;
-        }
-        if ((hot_g || RAW) && hot_in_lds) {
-#pragma unroll
-            for (int u = 0; u < N_PER; ++u) {
-                const int t = tid + u * NT;
-                if (t < p_rows) S.hot[t] = hot_[u];
-            }
-        }
-        if (tid < EW_UNI) S.uni[tid] = un_;
-        if (tid == 0) {
-            g[W + EW_G_ZERO] = 0.0f;
-            g[W + EW_G_HUGE] = 3.0e38f;
-            g[W + EW_G_OUT] = 0.0f;
-            S.ubonus[0] = ub_;
-        }
-    }
-    EPW_STAMP(1);
-    __syncthreads();
-    EPW_STAMP(2);
-    // paths sharing the root token (the reference compares candidates[:, :1] with candidates[0, :1])
-    unsigned long long eq_mask = __ballot(lane < P && Scand[(lane < P ? lane : 0) * Ds] == Scand[0]);
-
-    int a = 1, best = 0, adjust = 0, status = LANTERN_ST_OK;
-    int n_levels = 0, n_tried = 0, n_rej = 0, n_used = 0;
-    int out_tok = -1;
-    float out_mass = 0.0f;
-
-    for (int i = 1; i < D && status == LANTERN_ST_OK; ++i) {
-        if (i != a) break;
-        adjust = 0;
-        ++n_levels;
-        // prefix mask, one lane per path (P <= 64; every wave holds the same mask): kept across levels -- a path matches
-        // the accepted prefix of length a iff it matched at a-1 and carries the token accepted there
-        if (eq_mask == 0ull) {
-            status = LANTERN_ST_NO_PREFIX;
-            break;
-        }
-        EPW_STAMPG(16);
-        const int fi = __ffsll((long long)eq_mask) - 1;
-        // everything a candidate needs from its path at this level, one lane per path, fetched once per level
-        const int pl = (lane < P ? lane : 0) * Ds + i;
-        const int x_lane = (lane < P) ? Scand[pl] : -1;
-        float cart_lane = 1.0f;
-        int qrow_lane = 0, b0_lane = 0, b1_lane = 0;
-        if (is_static) {
-            cart_lane = Scart[pl];
-            qrow_lane = S.opoff[i - 1] + Spidx[pl];
-            b0_lane = Sboff[pl];
-            b1_lane = Sboff[pl + 1];
-        }
-        const int flag_lane = (lane < P) ? Sflag[pl] : 0;     // bit 1: image token, bit 0: syntax token (classified once, at staging)
-        const unsigned long long todo0 = eq_mask & __ballot(x_lane != -1);
-        EPW_STAMPG(17);
-        // neighbour ids of the level's candidates: their HBM reads are issued first, the row's loads second; both are in
-        // flight together and the ids are written to LDS under the row's last barrier (one exposed latency per level)
-        constexpr int PF_PER = (EW_PF_K + NT - 1) / NT;
-        constexpr int PF_LIST = SPEC == 2 ? 4 : EW_PF_C;          // candidates per level staged ahead
-        // position t of a neighbour list -> index into g for the scan (out_tok is final before the ids are staged)
-        auto plain_addr = [&](int id) -> unsigned short {
-            const int e = id + off;
-            if (e >= lo && e < lo + W) return (unsigned short)(e - lo);
-            return (unsigned short)(W + (e == out_tok ? EW_G_OUT : EW_G_ZERO));
-        };
-        auto gather_addr = [&](int id, int t) -> unsigned short { return t >= k ? (unsigned short)(W + EW_G_HUGE) : plain_addr(id); };
-        unsigned short idv[PF_LIST][PF_PER];
-        constexpr int CH_PER_C = EW_PF_K / 8;                              // 16-byte chunks per candidate
-        constexpr int PF16_PER = (PF_LIST * CH_PER_C + NT - 1) / NT;
-        uint4 idq[PF16_PER];
-        int ncand = 0;
-        if (can_prefetch && IDMODE == 2) {
-            // candidate list first (scalar work only): lane c of xs_lane holds the c-th unique candidate token
-            // (PF_LIST: the reference's default tree has at most 4 children under a node; a tree of the same sizes with more takes the restage path)
-            unsigned long long td = todo0;
-            int xs_lane = -1;
-#pragma unroll
-            for (int c = 0; c < PF_LIST; ++c) {
-                const bool have = td != 0ull;
-                const int j = have ? __ffsll((long long)td) - 1 : 0;
-                const int x = rdlane(x_lane, j);
-                td &= ~__ballot(have && x_lane == x);
-                if (lane == c) xs_lane = have ? x : -1;
-                ncand += have ? 1 : 0;
-            }
-            EPW_STAMPG(18);
-            // chunk ch = 8 ids of candidate ch / 128: a wave works on one candidate at a time (128 chunks = 2 waves)
-#pragma unroll
-            for (int u = 0; u < PF16_PER; ++u) {
-                const int ch = tid + u * NT;
-                const int c = __builtin_amdgcn_readfirstlane(ch / CH_PER_C);
-                const int t0 = (ch % CH_PER_C) * 8;
-                const int x = c < PF_LIST ? rdlane(xs_lane, c < PF_LIST ? c : 0) : -1;
-                const int trow = x - off;
-                const bool lookup = c < ncand && trow >= 0 && trow < p_trows && !(p_syntax && !(x >= p_img_lo && x < p_img_hi));
-                idq[u] = make_uint4(0u, 0u, 0u, 0u);
-                if (lookup && t0 < nz)
-                    idq[u] = *reinterpret_cast<const uint4 *>(buf.nn_table + (size_t)trow * prm.table_cols + t0);
-            }
-        } else if (can_prefetch) {
-            unsigned long long td = todo0;
-#pragma unroll
-            for (int c = 0; c < PF_LIST; ++c) {
-                const bool have = td != 0ull;
-                const int j = have ? __ffsll((long long)td) - 1 : 0;
-                const int x = rdlane(x_lane, j);
-                td &= ~__ballot(have && x_lane == x);
-                const int trow = x - off;
-                const bool lookup = have && trow >= 0 && trow < p_trows && !(p_syntax && !(x >= p_img_lo && x < p_img_hi));
-                const uint16_t *nbp = buf.nn_table + (size_t)(lookup ? trow : 0) * prm.table_cols;
-#pragma unroll
-                for (int u = 0; u < PF_PER; ++u) {
-                    const int t = tid + u * NT;
-                    idv[c][u] = (lookup && t < nz) ? nbp[t] : (unsigned short)0;
-                }
-                ncand += have ? 1 : 0;
-            }
-        }
-        {
-            int rid = Srow[fi * Ds + (i - 1)];
-            rid = rid < 0 ? 0 : (rid >= p_rows ? p_rows - 1 : rid);     // a bad row map must not read outside the batch
-            const int hot = RAW ? S.hot[rid] : (!hot_g ? -1 : (hot_in_lds ? S.hot[rid] : hot_g[rid]));
-            EPW_STAMP(10);
-            if (hot < 0 && rp_rid != rid) {
-                if constexpr (RAW) {
-                    rp_probs = raw_p && S.pre[rid] != 0;
-                    if (rp_probs) row_load<NT, E4, FULLW>(raw_p + (size_t)rid * W, W, rp);
-                    else raw_row_load<NT>(raw_c + (size_t)rid * V, raw_u + (size_t)rid * V, rp);
-                } else row_load<NT, E4, FULLW>(logits + (size_t)rid * W, W, rp);
-            }
-            rp_rid = -1;
-            auto stage_ids = [&]() {
-                if (can_prefetch && IDMODE == 2) {
-#pragma unroll
-                    for (int u = 0; u < PF16_PER; ++u) {
-                        const int ch = tid + u * NT;
-                        const int c = ch / CH_PER_C, t0 = (ch % CH_PER_C) * 8;
-                        if (c < ncand) {
-                            uint32_t w[4] = {idq[u].x, idq[u].y, idq[u].z, idq[u].w}, ad[4];
-#pragma unroll
-                            for (int q = 0; q < 4; ++q) {
-                                const uint32_t i0 = (t0 + 2 * q < nz) ? (w[q] & 0xffffu) : 0u, i1 = (t0 + 2 * q + 1 < nz) ? (w[q] >> 16) : 0u;
-                                ad[q] = (uint32_t)gather_addr((int)i0, t0 + 2 * q) | ((uint32_t)gather_addr((int)i1, t0 + 2 * q + 1) << 16);
-                                if (t0 + 2 * q == k) S.nbk[c] = plain_addr((int)i0);                 // (k < nz: the id is real; else nothing reads nbk)
-                                if (t0 + 2 * q + 1 == k) S.nbk[c] = plain_addr((int)i1);
-                            }
-                            *reinterpret_cast<uint4 *>(&S.nbaddr[c][t0]) = make_uint4(ad[0], ad[1], ad[2], ad[3]);
-                        }
-                    }
-                } else if (can_prefetch) {
-#pragma unroll
-                    for (int c = 0; c < PF_LIST; ++c)
-#pragma unroll
-                        for (int u = 0; u < PF_PER; ++u) {
-                            const int t = tid + u * NT;
-                            if (c < ncand && t < EW_PF_K) {
-                                S.nbaddr[c][t] = gather_addr((int)idv[c][u], t);
-                                if (t == k) S.nbk[c] = plain_addr((int)idv[c][u]);
-                            }
-                        }
-                }
-            };
-            if constexpr (RAW) {
-                if (!rp_probs) raw_row_to_lds<NT, decltype(stage_ids), NUCLEUS>(rp, hot, win.raw_cfg, win.raw_top_k, V, lo, W, g, out_tok, out_mass, S.redf, S.redd, Shist, ph, stage_ids, prm.top_p, S.redi);
-                else row_softmax_to_lds<NT, E4, FULLW>(rp, hot, true, lo, W, prm.temperature, prm.top_k, V, g, out_tok, out_mass, S, ph, stage_ids);
-            } else row_softmax_to_lds<NT, E4, FULLW>(rp, hot, rows_probs, lo, W, prm.temperature, prm.top_k, V, g, out_tok, out_mass, S, ph, stage_ids);
-            EPW_STAMP(11);
-        }
-        unsigned long long todo = todo0;
-        int cidx = -1;
-        while (todo != 0ull) {
-            const int j = __ffsll((long long)todo) - 1;
-            const int x = rdlane(x_lane, j);
-            const unsigned long long same = __ballot(x_lane == x);
-            todo &= ~same;                      // this path and every later path carrying the same token
-            ++cidx;
-            if (x < 0 || x >= V) {
-                status = LANTERN_ST_TOKEN_OOB;
-                break;
-            }
-            if (n_used >= EW_UNI || ucur0 + n_used >= prm.n_uniforms) {
-                status = LANTERN_ST_UNIFORMS;
-                break;
-            }
-            const double r = S.uni[n_used++];
-            ++n_tried;
-            EPW_STAMP(20);
-            const bool x_in = (x >= lo && x < lo + W);
-            const int flags = rdlane(flag_lane, j);
-            const bool in_img = (flags & 2) != 0;
-            const bool is_syn = (flags & 1) != 0;
-            const int slot = cidx % PF_LIST;
-            const int trow = x - off;
-            const uint16_t *nb = (p_lantern && trow >= 0 && trow < p_trows) ? buf.nn_table + (size_t)trow * prm.table_cols : nullptr;
-            int *dec = S.dec[n_tried & 1];
-            if (LDSIDS && can_prefetch && cidx >= PF_LIST) {
-                // more unique candidates than prefetch slots (rare): stage this one's ids now, reusing a finished slot
-                __syncthreads();
-                for (int t = tid; t < EW_PF_K; t += NT) {
-                    const unsigned short id = (nb && t < nz) ? nb[t] : (unsigned short)0;
-                    S.nbaddr[slot][t] = gather_addr((int)id, t);
-                    if (t == k) S.nbk[slot] = plain_addr((int)id);
-                }
-                __syncthreads();
-            }
-            // static trees: start the drafter-row read now; it lands while wave 0 runs the neighbour scan and is
-            // simply dropped if the candidate is accepted (one 32 KB row, L2/MALL-resident for the next try)
-            float4 q[E4];
-#pragma unroll
-            for (int it = 0; it < E4; ++it)
-                if constexpr (WPE == 1) q[it] = make_float4(0.f, 0.f, 0.f, 0.f);   // defined on every path: no value carried around the loop
-            const float *qsrc = nullptr;
-            if (is_static) {
-                int qrow = rdlane(qrow_lane, j);
-                qrow = qrow < 0 ? 0 : (qrow >= prm.R ? prm.R - 1 : qrow);                           // same for the drafter-row index
-                qsrc = buf.orig_prob + ((size_t)b * prm.R + qrow) * (size_t)win.orig_prob_stride + win.orig_prob_offset;
-            }
-            // wave 0 (the serial worker) would sit behind the other waves' loads in the CU's address unit before it can enter
-            // the scan: it fetches its own 4 KB share only once a rejection is known
-            if (is_static && !LATE_Q && (wave != 0 || WPE != 1)) {     // (the throughput build has a second workgroup to hide the queueing)
-#pragma unroll
-                for (int it = 0; it < E4; ++it) {
-                    const int i4 = tid + it * NT;
-                    q[it] = (FULLW || i4 * 4 < W) ? reinterpret_cast<const float4 *>(qsrc)[i4] : make_float4(0.f, 0.f, 0.f, 0.f);
-                }
-            }
-            // ---------------- serial section: wave 0 only
-            if (wave == 0) {
-                EPW_STAMPF(27);
-                float px = x_in ? g[x - lo] : (x == out_tok ? out_mass : 0.0f);
-                int code = 0, mflag = 0;
-                if (p_syntax && is_syn) {
-                    px = 1.0f;
-                } else if (p_syntax && !in_img) {
-                    px = 0.0f;
-                } else if (p_lantern) {
-                    if (nb == nullptr) {
-                        code = 3;   // LANTERN_ST_TABLE_OOB
-                    } else {
-                        const float tau = prm.delta > 1.0 ? (float)(prm.delta - 1.0) * px : (float)prm.delta;
-                        float best_cs = NEG_INF;
-                        if constexpr (LDSIDS) {
-                            // 16 consecutive neighbours per lane, one round (k <= 1023).  The gather indices were resolved
-                            // when the ids were staged (window index, or a sentinel slot: 0 outside the window, 3e38 at
-                            // positions >= k so that they can never pass `<= tau`): 16 plain LDS reads, no predicate
-                            const uint4 a = *reinterpret_cast<const uint4 *>(&S.nbaddr[slot][lane * 16]);
-                            const uint4 bq = *reinterpret_cast<const uint4 *>(&S.nbaddr[slot][lane * 16 + 8]);
-                            const uint32_t w[8] = {a.x, a.y, a.z, a.w, bq.x, bq.y, bq.z, bq.w};
-                            double v[16], loc = 0.0;
-#pragma unroll
-                            for (int c = 0; c < 8; ++c) {
-                                loc += (double)g[w[c] & 0xffffu];
-                                v[2 * c] = loc;
-                                loc += (double)g[w[c] >> 16];
-                                v[2 * c + 1] = loc;
-                            }
-                            // exclusive prefix = inclusive scan of the lane totals shifted up by one lane (NOT inc - loc: a
-                            // lane whose own total holds a 3e38 sentinel would cancel its true prefix away)
-                            const double excl = wave_scan_incl_dpp(dpp_mov<0x138>(loc));   // wave_shr:1, lane 0 gets 0
-                            float mx = NEG_INF;
-#pragma unroll
-                            for (int c = 0; c < 16; ++c) {
-                                const float cs = (float)(excl + v[c]);
-                                mx = (cs <= tau) ? cs : mx;      // cs is non-decreasing in c: the last ok one is the largest
-                            }
-                            best_cs = wave_max(mx);
-                        } else {
-                        double carry = 0.0;
-                        // 16 consecutive neighbours per lane, 1024 per round, ids from HBM; every gather is clamped + masked
-                        for (int base = 0; base < k; base += 1024) {
-                            const int i0 = base + lane * 16;
-                            int ids[16];
-#pragma unroll
-                            for (int c = 0; c < 16; ++c) ids[c] = (i0 + c < k) ? (int)nb[i0 + c] : 0;
-                            double v[16], loc = 0.0;
-#pragma unroll
-                            for (int c = 0; c < 16; ++c) {
-                                const int t = ids[c] + off - lo;
-                                const bool inw = (i0 + c < k) && t >= 0 && t < W;
-                                float gv = g[inw ? t : 0];
-                                gv = inw ? gv : 0.0f;
-                                if (out_tok >= 0 && (i0 + c < k) && ids[c] + off == out_tok) gv = out_mass;   // hot token outside the window
-                                loc += (double)gv;
-                                v[c] = loc;
-                            }
-                            const double inc = wave_scan_incl_dpp(loc);
-                            const double excl = carry + (inc - loc);
-                            float mx = NEG_INF;
-                            int nok = 0;
-#pragma unroll
-                            for (int c = 0; c < 16; ++c) {
-                                const float cs = (float)(excl + v[c]);
-                                const bool ok = (i0 + c < k) && cs <= tau;
-                                mx = ok ? fmaxf(mx, cs) : mx;
-                                nok += ok ? 1 : 0;
-                            }
-                            mx = wave_max(mx);
-                            best_cs = fmaxf(best_cs, mx);
-                            carry += readlane63(inc);
-                            if (k - base <= 1024) break;
-                            const int tot_ok = wave_sum(nok);
-                            if (tot_ok < 1024) break;   // the cumulative mass is non-decreasing: the ok set is a prefix
-                        }
-                        }
-                        if (best_cs > NEG_INF) {
-                            mflag = 1;
-                            px = px + best_cs;
-                        }
-                    }
-                }
-                if (code == 0) {
-                    float qx = 1.0f;
-                    bool skip = false;
-                    if (is_static) {
-                        qx = rdlane(cart_lane, j);
-                        skip = qx <= 0.0f;
-                    }
-                    if (skip)
-                        code = 0;
-                    else
-                        code = ((float)r <= px / qx) ? 1 : 2;
-                }
-                if (lane == 0) {
-                    dec[0] = code;
-                    dec[1] = mflag;
-                }
-                EPW_STAMPF(26);
-            }
-            __syncthreads();
-            const int code = dec[0];
-            const int m = dec[1];
-            EPW_STAMP(21);
-            if (code == 3) {
-                status = LANTERN_ST_TABLE_OOB;
-                break;
-            }
-            if (code == 0) continue;
-            if (code == 1) {
-                ++a;
-                best = j;
-                eq_mask &= same;                // paths that also carry the accepted token at this depth
-                break;
-            }
-            // ------------------------------------------------ rejection: residual, all waves, all in LDS
-            ++n_rej;
-            if (p_syntax && is_syn) {
-                status = LANTERN_ST_SYNTAX_REJECT;
-                break;
-            }
-            if (is_static && (LATE_Q || (wave == 0 && WPE == 1))) {
-#pragma unroll
-                for (int it = 0; it < E4; ++it) {
-                    const int i4 = tid + it * NT;
-                    q[it] = (FULLW || i4 * 4 < W) ? reinterpret_cast<const float4 *>(qsrc)[i4] : make_float4(0.f, 0.f, 0.f, 0.f);
-                }
-            }
-            const bool zero_nb = p_lantern && m > 0 && (!p_syntax || in_img);
-            double loc = 0.0;
-            float4 gn[E4];           // the unnormalised residual stays in registers until the sum is known
-            if (!is_static) {
-                if (tid == 0 && x_in) g[x - lo] = 0.0f;
-                if (!x_in && x == out_tok) out_mass = 0.0f;
-                if (zero_nb) {
-                    bool hit = false;
-                    for (int t = tid; t < nz; t += NT) {
-                        if constexpr (LDSIDS) {
-                            const int ad = t < k ? S.nbaddr[slot][t] : S.nbk[slot];
-                            if (ad < W) g[ad] = 0.0f;
-                            hit |= (ad == W + EW_G_OUT);
-                        } else {
-                            const int id = (int)nb[t] + off;
-                            if (id >= lo && id < lo + W) g[id - lo] = 0.0f;
-                            hit |= (id == out_tok);
-                        }
-                    }
-                    if (out_tok >= 0 && block_sum_fast<int, NW>(hit ? 1 : 0, S.redi, ph) > 0) out_mass = 0.0f;
-                }
-                __syncthreads();
-#pragma unroll
-                for (int it = 0; it < E4; ++it) {
-                    const int i4 = tid + it * NT;
-                    gn[it] = (FULLW || i4 * 4 < W) ? reinterpret_cast<const float4 *>(g)[i4] : make_float4(0.f, 0.f, 0.f, 0.f);
-                    loc += (double)gn[it].x + (double)gn[it].y + (double)gn[it].z + (double)gn[it].w;
-                }
-            } else {
-                const int b0 = rdlane(b0_lane, j), b1 = rdlane(b1_lane, j);
-                const int nsib = b1 - b0;
-                if (nsib > EW_MAX_SIB || b1 > EW_MAX_B) {       // beyond the staged tables: say so instead of truncating the list
-                    status = LANTERN_ST_TREE_LIMIT;
-                    break;
-                }
-                // window indices of the earlier siblings' tokens, straight from the staged tables (every thread reads the same
-                // LDS words: broadcast, no barrier); the first four live in registers, longer sibling lists loop over LDS
-                auto sib_at = [&](int t) -> int {
-                    const int node = (b0 + t < EW_MAX_B) ? (int)S.bidx[b0 + t] : 0;
-                    const int tok = (node >= 0 && node < EW_MAX_N) ? S.tcand[node] : -1;
-                    return (tok >= lo && tok < lo + W) ? (tok - lo) : -1;
-                };
-                int sib_r[4];
-#pragma unroll
-                for (int t = 0; t < 4; ++t) sib_r[t] = t < nsib ? sib_at(t) : -1;
-                const bool lg_nb = zero_nb && p_mode == LANTERN_MODE_STATIC_LG;
-                if (lg_nb) {
-                    for (int t = tid; t < (W + 31) / 32; t += NT) nbmask[t] = 0u;
-                    __syncthreads();
-                    for (int t = tid; t < nz; t += NT) {
-                        const int id = LDSIDS ? (int)(t < k ? S.nbaddr[slot][t] : S.nbk[slot]) : (int)nb[t] + off - lo;      // (a sentinel slot is >= W)
-                        if (id >= 0 && id < W) atomicOr(&nbmask[id >> 5], 1u << (id & 31));
-                    }
-                }
-                if (zero_nb && p_mode == LANTERN_MODE_STATIC_LUMINA)
-                    for (int t = tid; t < nz; t += NT) {
-                        const int id = LDSIDS ? (int)(t < k ? S.nbaddr[slot][t] : S.nbk[slot]) : (int)nb[t] + off - lo;
-                        if (id >= 0 && id < W) g[id] = 0.0f;
-                    }
-                EPW_STAMPG(31);
-                double qs_loc = 0.0;
-                if (nsib > 0) {          // a level's first candidate has no earlier sibling: q is used as it is (qs = 1)
-                    // window entry sidx lives in thread (sidx / 4) % NT, chunk (sidx / 4) / NT, component sidx % 4: only the WAVE that holds it
-                    // runs the component selects (a wave-uniform branch), the other seven pay one compare per sibling
-                    auto zero_q_at = [&](int sidx) {
-                        const bool mine = sidx >= 0 && ((sidx >> 2) & (NT - 1)) == tid;
-                        if (__ballot(mine) != 0ull) {
-                            const int itx = mine ? (sidx >> 2) / NT : -1, c = sidx & 3;
-#pragma unroll
-                            for (int it = 0; it < E4; ++it)
-                                if (it == itx) set_comp(q[it], c, 0.0f);
-                        }
-                    };
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) zero_q_at(sib_r[t]);
-                    for (int t = 4; t < nsib; ++t) zero_q_at(sib_at(t));
-#pragma unroll
-                    for (int it = 0; it < E4; ++it) qs_loc += (double)q[it].x + (double)q[it].y + (double)q[it].z + (double)q[it].w;
-                }
-                EPW_STAMPG(32);
-                float qs = 1.0f;
-                if (nsib > 0)
-                    qs = (float)block_sum_fast<double, NW>(qs_loc, S.redd, ph);
-                else
-                    __syncthreads();   // neighbour zeroing / mask visible (block_sum_fast carries the barrier otherwise)
-                EPW_STAMPG(33);
-                const FastDiv dq(qs);
-                if (nsib > 0) {      // one uniform branch around all chunks (not one inside each): the residual loop below stays one block
-#pragma unroll
-                    for (int it = 0; it < E4; ++it) q[it] = dq(q[it]);      // chunks beyond the window hold zeros: 0 / qs = 0
-                }
-                if (lg_nb) {         // likewise: the neighbour mask of the LlamaGen / Anole static mode, all chunks under one branch
-#pragma unroll
-                    for (int it = 0; it < E4; ++it) {
-                        const int i4 = tid + it * NT;
-                        if (FULLW || i4 * 4 < W) {
-                            const int e = i4 * 4;
-                            const uint32_t bits = nbmask[e >> 5] >> (e & 31);
-                            if (bits & 1u) q[it].x = 0.f;
-                            if (bits & 2u) q[it].y = 0.f;
-                            if (bits & 4u) q[it].z = 0.f;
-                            if (bits & 8u) q[it].w = 0.f;
-                        }
-                    }
-                }
-#pragma unroll
-                for (int it = 0; it < E4; ++it) {
-                    const int i4 = tid + it * NT;
-                    gn[it] = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (FULLW || i4 * 4 < W) {
-                        const float4 qv = q[it];
-                        float4 gv = reinterpret_cast<float4 *>(g)[i4];
-                        float d;
-                        d = gv.x - qv.x; gv.x = d < 0.0f ? 0.0f : d;
-                        d = gv.y - qv.y; gv.y = d < 0.0f ? 0.0f : d;
-                        d = gv.z - qv.z; gv.z = d < 0.0f ? 0.0f : d;
-                        d = gv.w - qv.w; gv.w = d < 0.0f ? 0.0f : d;
-                        gn[it] = gv;
-                        loc += (double)gv.x + (double)gv.y + (double)gv.z + (double)gv.w;
-                    }
-                }
-                // out-of-window mass: the drafter is zero there (precondition): max(out_mass - 0, 0) = out_mass
-            }
-            EPW_STAMPG(34);
-            double tot = block_sum_fast<double, NW>(loc, S.redd, ph);
-            EPW_STAMPG(35);
-            tot += (double)out_mass;
-            const float gs = (float)tot;
-            if (gs == 0.0f) {
-                status = LANTERN_ST_NEEDS_DENSE;   // `gtp.sum()==0 -> ones`: uniform over all V, only the dense kernel holds it
-                break;
-            }
-            const FastDiv dg(gs);
-#pragma unroll
-            for (int it = 0; it < E4; ++it) {
-                const int i4 = tid + it * NT;
-                if (FULLW || i4 * 4 < W)
-                    reinterpret_cast<float4 *>(g)[i4] = dg(gn[it]);
-            }
-            out_mass = out_mass / gs;
-            if (tid == 0) g[W + EW_G_OUT] = out_mass;
-            __syncthreads();
-            EPW_STAMP(30);
-            adjust = 1;
-        }
-    }
-
-    const int from_residual = (adjust && a != D) ? 1 : 0;
-    if (status == LANTERN_ST_OK && !from_residual) {
-        int rid = Srow[best * Ds + (a - 1)];
-        rid = rid < 0 ? 0 : (rid >= p_rows ? p_rows - 1 : rid);
-        const int hot = RAW ? S.hot[rid] : (!hot_g ? -1 : (hot_in_lds ? S.hot[rid] : hot_g[rid]));
-        if (hot < 0 && rp_rid != rid) {
-            if constexpr (RAW) {
-                rp_probs = raw_p && S.pre[rid] != 0;
-                if (rp_probs) row_load<NT, E4, FULLW>(raw_p + (size_t)rid * W, W, rp);
-                else raw_row_load<NT>(raw_c + (size_t)rid * V, raw_u + (size_t)rid * V, rp);
-            } else row_load<NT, E4, FULLW>(logits + (size_t)rid * W, W, rp);
-        }
-        if constexpr (RAW) {
-            if (!rp_probs) raw_row_to_lds<NT, NoHook, NUCLEUS>(rp, hot, win.raw_cfg, win.raw_top_k, V, lo, W, g, out_tok, out_mass, S.redf, S.redd, Shist, ph, NoHook(), prm.top_p, S.redi);
-            else row_softmax_to_lds<NT, E4, FULLW>(rp, hot, true, lo, W, prm.temperature, prm.top_k, V, g, out_tok, out_mass, S, ph);
-        } else row_softmax_to_lds<NT, E4, FULLW>(rp, hot, rows_probs, lo, W, prm.temperature, prm.top_k, V, g, out_tok, out_mass, S, ph);
-    }
-    // ---------------------------------------------------------------- epilogue: outputs from LDS
-    EPW_STAMP(40);
-    const EpwArgsK ka = (EpwArgsK)__builtin_amdgcn_kernarg_segment_ptr();
-    float *const k_sample_win = ka->win.sample_win, *const k_sample_p = ka->buf.sample_p;
-    const double *const k_u_bonus = ka->win.u_bonus;
-    int64_t *const k_token = ka->win.token;
-    float4 p[E4];
-#pragma unroll
-    for (int it = 0; it < E4; ++it) {
-        const int i4 = tid + it * NT;
-        p[it] = (FULLW || i4 * 4 < W) ? reinterpret_cast<const float4 *>(g)[i4] : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-    if (k_sample_win) {
-        float *sw = k_sample_win + (size_t)b * W;
-#pragma unroll
-        for (int it = 0; it < E4; ++it) {
-            const int i4 = tid + it * NT;
-            if (FULLW || i4 * 4 < W) reinterpret_cast<float4 *>(sw)[i4] = p[it];
-        }
-    }
-    if (k_sample_p) {   // optional dense copy (API compatibility)
-        float *sp = k_sample_p + (size_t)b * V;
-        for (int i4 = tid; i4 * 4 < V; i4 += NT) {
-            const int e = i4 * 4;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (e >= lo && e < lo + W) v = reinterpret_cast<const float4 *>(g)[(e - lo) / 4];
-            if (out_tok >= e && out_tok < e + 4) set_comp(v, out_tok - e, out_mass);
-            reinterpret_cast<float4 *>(sp)[i4] = v;
-        }
-    }
-    if (k_u_bonus && k_token && status == LANTERN_ST_OK) {
-        // inverse CDF in token-id order.  Register tile order (it, tid, component) IS ascending token id.
-        const bool out_before = out_tok >= 0 && out_tok < lo;
-        double s4[E4], inc[E4];
-#pragma unroll
-        for (int it = 0; it < E4; ++it) {
-            s4[it] = (double)p[it].x + (double)p[it].y + (double)p[it].z + (double)p[it].w;
-            inc[it] = wave_scan_incl_dpp(s4[it]);
-            if (lane == 63) S.samp_tot[wave * E4 + it] = inc[it];
-        }
-        __syncthreads();
-        // segment (it, wave) = ids [lo + 4*(it*NT + 64*wave), +256): token order is it-major.  One DPP scan over the
-        // E4*NW segment totals (lane q = it*NW + w) gives every segment's start; each thread then picks its E4 starts
-        // with uniform-lane reads.
-        static_assert(E4 * NW <= 64, "segment totals fit one wave");
-        const int q_it = lane / NW, q_w = lane % NW;
-        const double seg = (lane < E4 * NW) ? S.samp_tot[q_w * E4 + (q_it < E4 ? q_it : 0)] : 0.0;
-        const double seg_excl = wave_scan_incl_dpp(dpp_mov<0x138>(seg));      // exclusive: scan of the totals shifted up one lane
-        const double front = out_before ? (double)out_mass : 0.0;   // mass in front of the window
-        double total = front + (readlane63(seg_excl) + readlane63(seg));       // lanes >= E4*NW hold 0
-        double excl[E4];
-#pragma unroll
-        for (int it = 0; it < E4; ++it) {
-            const int q = it * NW + wave;                       // wave-uniform
-            const long long bits = __double_as_longlong(seg_excl);
-            const double start = __longlong_as_double(((long long)__builtin_amdgcn_readlane((int)(bits >> 32), q) << 32) |
-                                                      (unsigned int)__builtin_amdgcn_readlane((int)(bits & 0xffffffffll), q));
-            excl[it] = front + start + (inc[it] - s4[it]);
-        }
-        if (out_tok >= 0 && !out_before) total += (double)out_mass;
-        const double tgt = S.ubonus[0] * total;
-        int found = 0x7fffffff, last_pos = -1;
-        if (out_before && out_mass > 0.0f) {
-            last_pos = out_tok;
-            if ((double)out_mass > tgt) found = out_tok;
-        }
-        // The crossing is the smallest id whose running sum exceeds tgt: a 4-id chunk whose sum range [excl, excl + s4] lies wholly below tgt
-        // cannot hold it, and a chunk wholly above tgt can only offer an id larger than the crossing chunk's -- so only chunks whose range
-        // comes within a guard band of tgt run the element loop (same additions in the same order as before, hence the same token): one or two
-        // threads of the workgroup instead of all 512 x 16 elements in f64.
-        const double band = 1e-9 * total;
-#pragma unroll
-        for (int it = 0; it < E4; ++it) {
-            if (excl[it] - band <= tgt && excl[it] + s4[it] + band >= tgt) {
-                const int e = lo + (tid + it * NT) * 4;
-                double acc = excl[it];
-                const float pv[4] = {p[it].x, p[it].y, p[it].z, p[it].w};
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    acc += (double)pv[c];
-                    if (pv[c] > 0.0f && acc > tgt) found = min(found, e + c);
-                }
-            }
-        }
-        if (out_tok >= 0 && !out_before && out_mass > 0.0f && total > tgt) found = min(found, out_tok);   // only wins when nothing inside the window crossed
-        found = wave_min_i(found);
-        __syncthreads();
-        if (lane == 0) S.redi[wave] = found;
-        __syncthreads();
-        int f = S.redi[0];
-#pragma unroll
-        for (int w = 1; w < NW; ++w) f = min(f, S.redi[w]);
-        if (f == 0x7fffffff) {
-            // nothing crossed (tgt landed on the rounding of the total): the reference's inverse CDF then yields the LAST id with mass -- found
-            // by a second pass, off the common path
-#pragma unroll
-            for (int it = 0; it < E4; ++it) {
-                const int e = lo + (tid + it * NT) * 4;
-                const float pv[4] = {p[it].x, p[it].y, p[it].z, p[it].w};
-#pragma unroll
-                for (int c = 0; c < 4; ++c)
-                    if (pv[c] > 0.0f) last_pos = max(last_pos, e + c);
-            }
-            if (out_tok >= 0 && !out_before && out_mass > 0.0f) last_pos = max(last_pos, out_tok);
-            last_pos = wave_max_i(last_pos);
-            __syncthreads();
-            if (lane == 0) S.redi[16 + wave] = last_pos;
-            __syncthreads();
-            f = S.redi[16];
-#pragma unroll
-            for (int w = 1; w < NW; ++w) f = max(f, S.redi[16 + w]);
-        }
-        if (tid == 0) k_token[b] = f;
-    }
-    EPW_STAMP(50);
-#ifdef EPW_TRACE
-    if (tid == 0 && b < EPW_TR_BLOCKS) {
-        const int n = s_epw_trn;
-        for (int t = 0; t < n; ++t) g_epw_trace[b][t] = s_epw_tr[t];
-        g_epw_trace_n[b] = n;
-    }
-#endif
-    if (tid == 0) {
-        ka->buf.best[b] = best;
-        ka->buf.accept_len[b] = a - 1;
-        int32_t *c = ka->buf.counters + (size_t)b * 6;
-        c[0] = n_levels;
-        c[1] = n_tried;
-        c[2] = n_rej;
-        c[3] = n_used;
-        c[4] = from_residual;
-        c[5] = status;
-        if (ka->buf.cursor) ka->buf.cursor[b] = ucur0 + n_used;
-        if (ka->win.out_tok) ka->win.out_tok[b] = out_tok;
-        if (ka->win.out_mass) ka->win.out_mass[b] = out_mass;
-    }
-    return (best << 8) | a;          // the verdict (uniform): best path, rows kept = accept_len + 1
-}
-
-template <int NT, int E4, int IDMODE, int WPE, bool FULLW = false, bool RAW = false, int SPEC = 0, int TPO = 0>
-__global__ __launch_bounds__(NT, WPE) void epw_kernel(const EpwArgs args) {
-    epw_body<NT, E4, IDMODE, WPE, FULLW, RAW, SPEC, TPO>(args, blockIdx.x);
-}
 
 __global__ void window_to_dense_kernel(const float *__restrict__ winp, const int32_t *__restrict__ out_tok,
                                        const float *__restrict__ out_mass, int V, int lo, int W, float *__restrict__ dense) {
@@ -1525,9 +609,9 @@ static int epw_check(const lantern_ep_params *prm, const lantern_ep_buffers *buf
     }
     if (win->rows_kind == LANTERN_ROWS_PROBS)
         LANTERN_CHECK_ARG(p.top_k <= 0 && p.temperature == 1.0f, "evaluate_posterior_window: probability rows are final -- apply temperature/top-k where they are produced (cfg_mask_topk_window)");
-    if (p.top_p > 0.0f && p.top_p < 1.0f && !raw) {
-        set_error("evaluate_posterior_window: top_p=%g inside the kernel is built for LANTERN_ROWS_RAW_BF16 rows only (probability / logit rows: apply it "
-                  "where the rows are produced, lantern_cfg_mask_topk_window)", (double)p.top_p);
+    if (p.top_p > 0.0f && p.top_p < 1.0f && win->rows_kind == LANTERN_ROWS_PROBS) {
+        set_error("evaluate_posterior_window: top_p=%g with probability rows: they are final -- apply it where the rows are produced "
+                  "(lantern_cfg_mask_topk_window), or hand the rows over as logits / raw bf16 rows", (double)p.top_p);
         return LANTERN_E_UNSUPPORTED;
     }
     if (p.top_k > win->win_len && p.top_k < p.V) {
@@ -1538,8 +622,9 @@ static int epw_check(const lantern_ep_params *prm, const lantern_ep_buffers *buf
 }
 
 static size_t epw_lds_bytes(const lantern_ep_params &p, const lantern_ep_window *win) {
+    const bool nucleus_logits = win->rows_kind == LANTERN_ROWS_LOGITS && p.top_p >= 1e-8f && p.top_p < 1.0f;      // top_p_tile's 256 f64 mass bins
     return epw_shared_offset(win->win_len) + sizeof(EwShared) + (size_t)6 * epw_pd_cap(p.P, p.D) * 4 +
-           (win->rows_kind == LANTERN_ROWS_RAW_BF16 ? (size_t)O7_HIST_INTS * 4 : 0);
+           (win->rows_kind == LANTERN_ROWS_RAW_BF16 ? (size_t)O7_HIST_INTS * 4 : (nucleus_logits ? (size_t)256 * 8 : 0));
 }
 
 extern "C" int lantern_evaluate_posterior_window(const lantern_ep_params *prm, const lantern_ep_buffers *buf,
@@ -1557,13 +642,7 @@ extern "C" int lantern_evaluate_posterior_window(const lantern_ep_params *prm, c
     const bool lds_ids = !p.lantern || nz <= EW_PF_K;
     const EpwArgs args{p, *buf, *win};
     const int idmode = !lds_ids ? 0 : ((p.lantern && p.table_cols % 8 == 0 && ((uintptr_t)buf->nn_table & 15) == 0) ? 2 : 1);
-#define EPW_LAUNCH_W(NT_, E4_, WPE_)                                                                                        \
-    do {                                                                                                                  \
-        if (idmode == 2) LANTERN_LAUNCH((epw_kernel<NT_, E4_, 2, WPE_>), grid, dim3(NT_), lds, st, args);                  \
-        else if (idmode == 1) LANTERN_LAUNCH((epw_kernel<NT_, E4_, 1, WPE_>), grid, dim3(NT_), lds, st, args);             \
-        else LANTERN_LAUNCH((epw_kernel<NT_, E4_, 0, WPE_>), grid, dim3(NT_), lds, st, args);                              \
-    } while (0)
-#define EPW_LAUNCH(NT_, E4_) EPW_LAUNCH_W(NT_, E4_, 1)
+    const EpwLaunch L{grid, lds, st};
     // the headline shape gets its own instance (SPEC 1: mode / LANTERN / syntax-shortcut flags are compile-time constants there)
     static const int spec_knob = getenv("LANTERN_EPW_SPEC") ? atoi(getenv("LANTERN_EPW_SPEC")) : 2;   // tuning knob (diagnostic): 0 = the generic instance, 1 = no fixed tree
     const bool chameleon = spec_knob != 0 && p.lantern && p.V == 65536 && p.img_lo == 4 && p.img_hi == 8196 && p.tok_offset == 4 && p.table_rows == 8192 &&
@@ -1574,20 +653,20 @@ extern "C" int lantern_evaluate_posterior_window(const lantern_ep_params *prm, c
     const bool lumina_dynamic = chameleon && p.mode == LANTERN_MODE_DYNAMIC && lumina_syntax && buf->n_paths && buf->n_depth && (!raw || win->raw_pos_per_seq);
     const bool anole_static = chameleon && p.mode == LANTERN_MODE_STATIC_LG && !p.syntax_shortcut && !buf->n_paths && !buf->n_depth &&
                               (!raw || (win->raw_w_latent == 0 && !win->raw_pos_per_seq));
+    // the fixed-tree instance is picked by SIZES (P, D, N of mc_sim_7b_63) and stages at most 4 candidates per level ahead; a tree of the same sizes
+    // with a wider fan-out still runs correctly (the restage path, tests: test_window_two_workgroups_per_cu_build[six_wide])
     const bool default_tree = spec_knob >= 2 && p.P == 15 && p.D == 6 && p.N == 26 && p.rows_per_seq == 26;
     static const int occ_knob = getenv("LANTERN_EPW_OCC2") ? atoi(getenv("LANTERN_EPW_OCC2")) : -1;   // tuning knob (diagnostic)
-    const bool two_per_cu = occ_knob >= 0 ? occ_knob != 0 : p.B > 256;
-    // Throughput form of the fixed-configuration instances (more sequences than CUs; the shape BASELINE's roofline target is assessed on): 256
-    // threads x 8 float4 per thread, three workgroups per CU (53 KB of LDS each, <= 168 VGPRs at 3 waves per SIMD), drafter rows requested only once
-    // a rejection is known.  At saturation the kernel is bound by instruction ISSUE (profiles/r04_ep_sweep_pmc.txt: the SIMDs' arbiters busy 0.93 of
-    // the launch, a third of it scalar work every wave of a sequence repeats), so half the waves per sequence is what pays: 4096 sequences per
+    const bool many = occ_knob >= 0 ? occ_knob != 0 : p.B > 256;          // more sequences than CUs: the throughput forms (epw_throughput.hip)
+    // Throughput form of the fixed-configuration instances (the shape BASELINE's roofline target is assessed on): 256 threads x 8 float4 per thread, three
+    // workgroups per CU (53 KB of LDS each, <= 168 VGPRs at 3 waves per SIMD), drafter rows requested only once a rejection is known.  At saturation
+    // the kernel is bound by instruction ISSUE (profiles/r04_ep_sweep_pmc.txt), so half the waves per sequence is what pays: 4096 sequences per
     // launch 293 us (generic, 512 threads, two per CU) -> 228 (fixed configuration, 512 threads) -> 194 (owner-wave sibling zeroing) -> 163 us.
     // LANTERN_EPW_TP=0: the generic two-per-CU instance; 1: the 512-thread fixed-configuration instance (diagnostic).
     static const int tp_knob = getenv("LANTERN_EPW_TP") ? atoi(getenv("LANTERN_EPW_TP")) : 5;   // tuning knob (diagnostic)
-    if (W <= 1024) EPW_LAUNCH(256, 1);
-    else if (W <= 2048) EPW_LAUNCH(256, 2);
-    else if (W <= 4096) EPW_LAUNCH(512, 2);
-    else if (raw && p.top_p >= 1e-8f && p.top_p < 1.0f) {          // raw rows with a nucleus filter: the generic raw instances with the filter compiled in
+    const bool nucleus = p.top_p >= 1e-8f && p.top_p < 1.0f;
+    bool ok = true;
+    if (raw && nucleus) {          // raw rows with a nucleus filter: the generic raw instances with the filter compiled in
         if (W == 16384) LANTERN_LAUNCH((epw_kernel<1024, 4, 1, 1, true, true, 0, 2>), grid, dim3(1024), lds, st, args);
         else LANTERN_LAUNCH((epw_kernel<512, 4, 2, 1, true, true, 0, 2>), grid, dim3(512), lds, st, args);
     }
@@ -1598,22 +677,28 @@ extern "C" int lantern_evaluate_posterior_window(const lantern_ep_params *prm, c
         else LANTERN_LAUNCH((epw_kernel<1024, 4, 1, 1, true, true>), grid, dim3(1024), lds, st, args);
     }
     else if (raw) {
-        if (two_per_cu) LANTERN_LAUNCH((epw_kernel<512, 4, 2, 4, true, true>), grid, dim3(512), lds, st, args);
+        const bool tp_raw = many && tp_knob >= 5;
+        if (tp_raw && lumina_static && default_tree) ok = epw_launch_throughput(EPW_TP_RAW_LUMINA_DEFAULT_TREE, L, args);
+        else if (tp_raw && lumina_static) ok = epw_launch_throughput(EPW_TP_RAW_LUMINA_STATIC, L, args);
+        else if (tp_raw && lumina_dynamic) ok = epw_launch_throughput(EPW_TP_RAW_LUMINA_DYNAMIC, L, args);
+        else if (tp_raw && anole_static) ok = epw_launch_throughput(EPW_TP_RAW_ANOLE_STATIC, L, args);
+        else if (many) ok = epw_launch_throughput(EPW_TP_RAW_GENERIC, L, args);
         else if (lumina_static && default_tree) LANTERN_LAUNCH((epw_kernel<512, 4, 2, 1, true, true, 2>), grid, dim3(512), lds, st, args);
         else if (lumina_static) LANTERN_LAUNCH((epw_kernel<512, 4, 2, 1, true, true, 1>), grid, dim3(512), lds, st, args);
         else if (lumina_dynamic) LANTERN_LAUNCH((epw_kernel<512, 4, 2, 1, true, true, 3>), grid, dim3(512), lds, st, args);
         else if (anole_static) LANTERN_LAUNCH((epw_kernel<512, 4, 2, 1, true, true, 4>), grid, dim3(512), lds, st, args);
         else LANTERN_LAUNCH((epw_kernel<512, 4, 2, 1, true, true>), grid, dim3(512), lds, st, args);
     }
-    else if (W <= 8192) {
-        const bool tp_form = two_per_cu && W == 8192 && idmode == 2 && tp_knob >= 5;
-        if (tp_form && lumina_static && default_tree) LANTERN_LAUNCH((epw_kernel<256, 8, 2, 3, true, false, 2, 1>), grid, dim3(256), lds, st, args);
-        else if (tp_form && lumina_static) LANTERN_LAUNCH((epw_kernel<256, 8, 2, 3, true, false, 1, 1>), grid, dim3(256), lds, st, args);
-        else if (tp_form && lumina_dynamic) LANTERN_LAUNCH((epw_kernel<256, 8, 2, 3, true, false, 3, 1>), grid, dim3(256), lds, st, args);
-        else if (tp_form && anole_static) LANTERN_LAUNCH((epw_kernel<256, 8, 2, 3, true, false, 4, 1>), grid, dim3(256), lds, st, args);
-        else if (two_per_cu && W == 8192 && idmode == 2 && lumina_static && default_tree && tp_knob >= 1) LANTERN_LAUNCH((epw_kernel<512, 4, 2, 4, true, false, 2>), grid, dim3(512), lds, st, args);
-        else if (two_per_cu && W == 8192 && idmode == 2) LANTERN_LAUNCH((epw_kernel<512, 4, 2, 4, true>), grid, dim3(512), lds, st, args);
-        else if (two_per_cu) EPW_LAUNCH_W(512, 4, 4);
+    else if (nucleus) ok = epw_launch_generic(W, idmode, true, L, args);          // rows that arrive as logits, TopPLogitsWarper in the kernel
+    else if (W > 4096 && W <= 8192) {
+        const bool tp_form = many && W == 8192 && idmode == 2 && tp_knob >= 5;
+        if (tp_form && lumina_static && default_tree) ok = epw_launch_throughput(EPW_TP_LUMINA_DEFAULT_TREE, L, args);
+        else if (tp_form && lumina_static) ok = epw_launch_throughput(EPW_TP_LUMINA_STATIC, L, args);
+        else if (tp_form && lumina_dynamic) ok = epw_launch_throughput(EPW_TP_LUMINA_DYNAMIC, L, args);
+        else if (tp_form && anole_static) ok = epw_launch_throughput(EPW_TP_ANOLE_STATIC, L, args);
+        else if (many && W == 8192 && idmode == 2 && lumina_static && default_tree && tp_knob >= 1) ok = epw_launch_throughput(EPW_TP_512_DEFAULT_TREE, L, args);
+        else if (many && W == 8192 && idmode == 2) ok = epw_launch_throughput(EPW_TP_512_PACKED, L, args);
+        else if (many) ok = epw_launch_throughput(idmode == 2 ? EPW_TP_512_ID2 : (idmode == 1 ? EPW_TP_512_ID1 : EPW_TP_512_ID0), L, args);
         else if (W == 8192 && idmode == 2) {
             if (lumina_static && default_tree) LANTERN_LAUNCH((epw_kernel<512, 4, 2, 1, true, false, 2>), grid, dim3(512), lds, st, args);
             else if (lumina_static) LANTERN_LAUNCH((epw_kernel<512, 4, 2, 1, true, false, 1>), grid, dim3(512), lds, st, args);
@@ -1621,11 +706,13 @@ extern "C" int lantern_evaluate_posterior_window(const lantern_ep_params *prm, c
             else if (anole_static) LANTERN_LAUNCH((epw_kernel<512, 4, 2, 1, true, false, 4>), grid, dim3(512), lds, st, args);
             else LANTERN_LAUNCH((epw_kernel<512, 4, 2, 1, true>), grid, dim3(512), lds, st, args);   // the Lumina / Anole image window on the packed table
         }
-        else EPW_LAUNCH(512, 4);
+        else ok = epw_launch_generic(W, idmode, false, L, args);
     }
-    else EPW_LAUNCH(1024, 4);
-#undef EPW_LAUNCH_W
-#undef EPW_LAUNCH
+    else ok = epw_launch_generic(W, idmode, false, L, args);
+    if (!ok) {
+        set_error("evaluate_posterior_window: no kernel instance for window %d, id mode %d%s", W, idmode, nucleus ? ", top_p inside the kernel" : "");
+        return LANTERN_E_UNSUPPORTED;
+    }
     LANTERN_CHECK_LAUNCH("evaluate_posterior_window");
     return LANTERN_OK;
 }

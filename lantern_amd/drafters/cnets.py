@@ -189,9 +189,7 @@ class DraftPlan:
                          act=z(B * T, inter), out=z(B * T, H), head_ws=z(T, hx["n_cols"]))
         for n, t in self.work.items():
             setattr(a, n, t.data_ptr())
-        self.sk = ops._sk_workspace(dev)
-        a.sk_ws, a.sk_ws_bytes = self.sk.data_ptr(), self.sk.numel()
-        self.ta = None
+        self.ta = None          # (the stream-K workspace is taken per run(): it belongs to the stream the launches go to, "one launch at a time per workspace")
 
     def begin(self, pkv, hidden0, ids0, scores0, positions, head_positions=None, kv_start=None):
         """Start a drafting call: pkv the prefix cache (the layer's slab grows in place), hidden0 [2, T, H] / ids0 [T] / scores0 [T] the first
@@ -227,6 +225,8 @@ class DraftPlan:
         a, T, D = self.args, self.T, self.depth
         k = self.k
         a.stream = torch.cuda.current_stream().cuda_stream
+        sk = ops._sk_workspace(self.dev)          # the CURRENT stream's workspace: a plan cached across generate() calls may run on another stream
+        a.sk_ws, a.sk_ws_bytes = sk.data_ptr(), sk.numel()
         a.ids, a.hidden_in = self.ids[i].data_ptr(), self.hidden[i & 1].data_ptr()
         a.position_ids = self.pos[i].data_ptr()
         a.head_pos = self.head_pos[i].data_ptr() if self._lumina_grammar else None
@@ -359,6 +359,7 @@ class Model(nn.Module):
 
     def reset_kv(self):
         self.stable_kv = None
+        self._poll_mask_checks(wait=True)          # end of an image: every deferred left-padding verdict is in
 
     # ------------------------------------------------------------------ a5
     def _prepare_decoder_attention_mask(self, attention_mask, input_shape, inputs_embeds, past_key_values_length):
@@ -408,13 +409,21 @@ class Model(nn.Module):
             position_ids = position_ids.view(-1, T).long()
         if attention_mask is None:
             attention_mask = torch.ones((B, T + past), dtype=torch.bool, device=hidden_states.device)
-        elif past == 0 and attention_mask.is_cuda:
-            # the ancestor-word attention path describes padding by ONE first-visible-key index per row (kv_start = argmax of the mask): checked once
-            # per prompt, at its prefill, that the mask really is left padding only (ones contiguous up to the end) -- never assumed
+        elif attention_mask.is_cuda:
+            # the ancestor-word attention path describes padding by ONE first-visible-key index per row (kv_start = argmax of the mask): never assumed.
+            # At a prompt's prefill (past == 0) the mask is checked on the spot -- left padding only, ones contiguous up to the end; on the calls
+            # behind it (past > 0: the accepted tokens, tree rows) the same test is enqueued without stalling the launch queue and read back on a
+            # LATER call (`_poll_mask_checks`): a mask with holes, or one that stops being left padding, raises one call late instead of being
+            # silently reduced to kv_start (the reference's additive mask would honour it)
+            self._poll_mask_checks()
             am = attention_mask.to(torch.int64)
-            if not bool((am.cummax(dim=1).values == am).all()):
-                raise ops._lib.LanternError("cnets.Model.forward: attention_mask with zeros behind a one (not left padding): the tree-attention path "
-                                            "takes one first-visible-key index per row")
+            bad = (am.cummax(dim=1).values != am).any()
+            if past == 0:
+                if bool(bad):
+                    raise ops._lib.LanternError("cnets.Model.forward: attention_mask with zeros behind a one (not left padding): the tree-attention path "
+                                                "takes one first-visible-key index per row")
+            else:
+                self._defer_mask_check(bad)
         extra = self.layer_kwargs(position_ids) if self.layer_kwargs is not None else {}
         tm = getattr(self, "tree_mask", None)
         bits_ok = (hidden_states.is_cuda and hidden_states.dtype == torch.bfloat16 and all(getattr(l, "supports_tree_bits", False) for l in self.layers))
@@ -451,6 +460,43 @@ class Model(nn.Module):
             if use_cache:
                 cache += (outs[2 if output_attentions else 1],)
         return (hidden_states, cache) if use_cache else hidden_states
+
+    # ------------------------------------------------------------------ deferred checks of the left-padding assumption (past > 0 calls)
+    _MASK_RING = 8
+
+    def _defer_mask_check(self, bad):
+        """`bad`: 0-dim bool device tensor.  Copied to a pinned flag behind the work already enqueued; read by a later `_poll_mask_checks`."""
+        st = self.__dict__.setdefault("_mask_chk", None)
+        if st is None:
+            st = self.__dict__["_mask_chk"] = dict(pins=torch.zeros(self._MASK_RING, dtype=torch.bool).pin_memory(), events=[None] * self._MASK_RING, n=0)
+        i = st["n"] % self._MASK_RING
+        if st["events"][i] is not None:          # the ring came round: that slot's verdict is due now
+            st["events"][i].synchronize()
+            self._raise_if_bad(st, i)
+        st["pins"][i:i + 1].copy_(bad.reshape(1), non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        st["events"][i] = ev
+        st["n"] += 1
+
+    def _raise_if_bad(self, st, i):
+        st["events"][i] = None
+        if bool(st["pins"][i]):
+            st["pins"][i] = False
+            raise ops._lib.LanternError("cnets.Model.forward: an EARLIER call's attention_mask (behind a cached prefix) had zeros behind a one -- not left "
+                                        "padding: the tree-attention path takes one first-visible-key index per row and would have ignored the holes")
+
+    def _poll_mask_checks(self, wait: bool = False):
+        st = self.__dict__.get("_mask_chk")
+        if st is None:
+            return
+        for i, ev in enumerate(st["events"]):
+            if ev is None:
+                continue
+            if wait:
+                ev.synchronize()
+            if ev.query():
+                self._raise_if_bad(st, i)
 
     # ------------------------------------------------------------------ helpers of the tree loops
     def repeat_hidden(self, hidden_states, num_repeat):      # cnets_lumina_mgpt.py:930-934
@@ -542,8 +588,9 @@ class Model(nn.Module):
         hx = self._head_fusion(head, proc, k, k, True)
         if hx is None:
             return None
-        key = (id(head), head.weight.data_ptr(), head.weight._version, k, self.depth, hx["top_k_filter"], hx["model"], w.data_ptr(), w._version,
-               layer.self_attn.q_proj.weight.data_ptr(), layer.self_attn.q_proj.weight._version)
+        # every tensor the plan snapshots a pointer (or a packed / converted copy) of: an in-place update of any of them -- or a new storage -- rebuilds it
+        snap = [head.weight, head.bias, w, self.fc.bias, self.embed_tokens.weight] + [p_ for p_ in layer.parameters()]
+        key = (id(head), k, self.depth, hx["top_k_filter"], hx["model"]) + tuple((t.data_ptr(), t._version) for t in snap if t is not None)
         hit = self.__dict__.get("_plan")
         if hit is None or hit[0] != key:
             hit = self.__dict__["_plan"] = (key, DraftPlan(self, head, k, hx))
@@ -632,6 +679,8 @@ class Model(nn.Module):
             pos = (len_posi + plan.steps)[:, None, None].expand(plan.depth, 1, k)
             if input_position_diff is not None:
                 pos = torch.cat([pos, pos - input_position_diff], dim=1)          # (no clamp inside the loop, cnets_anole.py:858-862)
+            # (input_position_diff None: the reference does not hand the mask to its depth forwards either -- `akw` above, cnets_llamagen.py:783-790 --
+            # so no padding is described; with it, the mask went through forward()'s left-padding check at the prefill)
             start = None if attention_mask is None or input_position_diff is None else attention_mask.to(dev).to(torch.int64).argmax(dim=1)
             plan.begin(pkv, input_hidden, cur.reshape(-1), scores, pos, kv_start=start)
             for i in range(self.depth):

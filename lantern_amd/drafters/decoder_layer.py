@@ -36,7 +36,10 @@ def skinny_linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Te
     if rows > 0 and _hip_ok(x, weight):
         out = ops.linear_rows(x.reshape(rows, x.shape[-1]), weight, 0, weight.shape[0], bias=bias)
         return out.reshape(*x.shape[:-1], weight.shape[0])
-    return F.linear(x, weight, bias)
+    if x.is_cuda and x.dtype == torch.bfloat16 and weight.dtype == torch.bfloat16 and x.shape[-1] % 16 != 0:
+        # the product's dtype says "HIP kernel" but its shape does not fit one: say so instead of sliding onto torch's GEMM unnoticed
+        raise ops._lib.LanternError(f"skinny_linear: bf16 device product with K = {x.shape[-1]} (K % 16 != 0) has no HIP kernel; pad K or run the layer in f32")
+    return F.linear(x, weight, bias)          # f32 / CPU: the composition the golden vectors are checked on
 
 
 def _mm(A, weight, epilogue: int = 0, **kw):
@@ -46,6 +49,52 @@ def _mm(A, weight, epilogue: int = 0, **kw):
     kw.pop("pair_rows", None)
     return ops.linear_rows_packed(A, weight, epilogue, **kw)
 
+
+
+def additive_mask_words(attention_mask, B: int, T: int, S: int):
+    """An additive attention mask [1|B, 1, T, >= S] (0 = visible, finfo.min = hidden: what _prepare_decoder_attention_mask builds) restated as the
+    HIP kernels' description of visibility: one first-visible-key index per batch row for the S - T cached keys (left padding) + one ancestor
+    word per (row, new token) for the T new keys.  Returns (ok, kv_start [B] i64, words [B, T] i64); ok is a 0-dim bool tensor: False when the
+    mask cannot be said that way (queries that disagree about the prefix, holes behind the first visible key)."""
+    m = attention_mask
+    if m.dim() == 4:
+        m = m[:, 0]
+    vis = (m[:, -T:, :S] > torch.finfo(m.dtype).min / 2) if m.is_floating_point() else m[:, -T:, :S].bool()
+    if vis.shape[0] != B:
+        vis = vis.expand(B, -1, -1)
+    pre = vis[:, :, :S - T]
+    p0 = pre[:, 0].to(torch.int64)
+    ok = (pre == pre[:, :1]).all()
+    if S > T:
+        ok = ok & (p0.cummax(dim=1).values == p0).all()
+        kv_start = torch.where(p0.any(dim=1), p0.argmax(dim=1), torch.full((B,), S - T, dtype=torch.int64, device=m.device))
+    else:
+        kv_start = torch.zeros(B, dtype=torch.int64, device=m.device)
+    w = torch.ones(T, dtype=torch.int64, device=m.device) << torch.arange(T, dtype=torch.int64, device=m.device)
+    words = (vis[:, :, S - T:].to(torch.int64) * w).sum(-1)
+    return ok, kv_start, words
+
+
+def _attend_without_tree(q, k, v, attention_mask, kv_start, past, T, B, H, nq, nk):
+    """The branch of the fused layers for callers that bring neither ancestor words nor the causal hint (cnets.Model.forward always brings
+    one).  Still the HIP attention, never torch's SDPA: no mask = every new token sees every key; an additive mask is restated as
+    ancestor words + a first-visible-key index (additive_mask_words; one host read to check that it can be) for T <= 64 new tokens, and
+    refused where it cannot."""
+    S = past + T
+    if T > 64:
+        raise ops._lib.LanternError(
+            f"DecoderLayer (fused HIP path): {T} new tokens with an additive mask and no `causal=True` hint: tree attention takes at most 64 query rows -- "
+            "pass causal=True (+ kv_start) for a left-padded causal prefill, or set layer.fused = False for the torch composition")
+    if attention_mask is None:
+        words = torch.full((T,), (1 << T) - 1 if T < 64 else -1, dtype=torch.int64, device=q.device)
+    else:
+        ok, start, words = additive_mask_words(attention_mask, B, T, S)
+        if not bool(ok):
+            raise ops._lib.LanternError(
+                "DecoderLayer (fused HIP path): this additive attention_mask is not (left padding) x (a block over the new tokens): no HIP kernel "
+                "describes it -- set layer.fused = False for the torch composition")
+        kv_start = start if kv_start is None else kv_start
+    return ops.tree_attention(q.transpose(1, 2), k, v, words, kv_start=kv_start, max_kv_len=S).reshape(B * T, H)
 
 _CAUSAL_WORDS = {}
 
@@ -265,7 +314,7 @@ class DecoderLayer(nn.Module):
             cat = torch.cat(ws, dim=0).contiguous()
             return cat, (None if mods[0].bias is None else torch.cat([m.bias for m in mods]).contiguous())
         cache = self.__dict__.setdefault("_packed_weights", {})
-        key = tuple((w.data_ptr(), w._version) for w in ws)
+        key = tuple((w.data_ptr(), w._version) for w in ws) + tuple((m.bias.data_ptr(), m.bias._version) for m in mods if m.bias is not None)
         hit = cache.get(name)
         if hit is None or hit[0] != key:
             cat = torch.cat(ws, dim=0).contiguous()
@@ -330,9 +379,7 @@ class DecoderLayer(nn.Module):
             # a prefill: causal among the new tokens behind the left padding, block by block on the same kernel (no [T, S] mask, no eager softmax)
             o = causal_block_attention(q, k, v, kv_start, past).reshape(B * T, H)
         else:
-            # (the additive-mask form: prefills inside the decode shape, callers without a tree block)
-            m = None if attention_mask is None else attention_mask[:, :, :, :kv_len].to(q.dtype)
-            o = F.scaled_dot_product_attention(q, k, v, attn_mask=m, enable_gqa=nk != nq).transpose(1, 2).reshape(B * T, H)
+            o = _attend_without_tree(q, k, v, attention_mask, kv_start, past, T, B, H, nq, nk)
         h1 = _mm(o, self._packed("o", at.o_proj.weight), ops.EPI_RESIDUAL, bias=at.o_proj.bias, residual=x2)
         hn = ops.rmsnorm_rows(h1, self.post_attention_layernorm.weight, self.post_attention_layernorm.variance_epsilon)
         inter = mlp.gate_proj.out_features
@@ -533,8 +580,7 @@ class LlamaDecoderLayer(DecoderLayer):
         elif causal:
             o = causal_block_attention(q, k, v, kv_start, past).reshape(B * T, H)
         else:
-            m = None if attention_mask is None else attention_mask[:, :, :, :kv_len].to(q.dtype)
-            o = F.scaled_dot_product_attention(q, k, v, attn_mask=m, enable_gqa=nk != nq).transpose(1, 2).reshape(B * T, H)
+            o = _attend_without_tree(q, k, v, attention_mask, kv_start, past, T, B, H, nq, nk)
         h1 = _mm(o, self._packed("o", at.o_proj.weight), ops.EPI_RESIDUAL, residual=x2)
         hn = ops.rmsnorm_rows(h1, self.post_attention_layernorm.weight, self.post_attention_layernorm.variance_epsilon)
         inter = mlp.gate_proj.out_features

@@ -399,6 +399,7 @@ class EaModel(nn.Module):
         a.ep_buf.best, a.ep_buf.accept_len, a.ep_buf.counters = rec.data_ptr(), rec.data_ptr() + 4, rec.data_ptr() + 8
         a.ep_win.token = tokbuf.data_ptr()
         a.stream, a.ss_token = nx.stream, None          # (ss_token NULL: lantern_verify_step takes the candidates as the call below leaves them)
+        a.flags = ops._lib.STEP_CANDIDATES_READY
         ops.check(L.lantern_gather_candidates(C.c_void_p(ss_token.data_ptr()), C.c_void_p(ss_prob.data_ptr()), C.c_void_p(sample.data_ptr()), C.c_void_p(a.tree_indices),
                                               C.c_void_p(a.retrieve), 1, ss_token.numel(), nx.N, nx.P, nx.D, C.c_void_p(a.tree_cand), C.c_void_p(a.cand),
                                               C.c_void_p(a.cart_prob), C.c_void_p(nx.stream)), "gather_candidates")
@@ -491,6 +492,7 @@ class EaModel(nn.Module):
         par = nx.parity
         rec, tokbuf = nx.recs[par], nx.toks[par]
         a.stream, a.ss_token, a.retrieve = nx.stream, None, retrieve.data_ptr()
+        a.flags = ops._lib.STEP_CANDIDATES_READY
         a.P, a.D, a.ep.P, a.ep.D = P, D, P, D
         a.cand = candidates.data_ptr()
         a.cond, a.uncond, a.dtype = cl.data_ptr(), ul.data_ptr(), int(cl.dtype == torch.bfloat16)

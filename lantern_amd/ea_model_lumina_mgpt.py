@@ -527,6 +527,7 @@ class EaLumina_mGPT(nn.Module):
         ew.token = tp
         p_tok, p_prob, p_smp = ss_token.data_ptr(), ss_prob.data_ptr(), sample.data_ptr()
         a.stream, a.ss_token = stream, None          # (ss_token NULL: lantern_verify_step takes the candidates as this call leaves them -- no second O6 launch)
+        a.flags = ops._lib.STEP_CANDIDATES_READY
         g = nx._gc_const
         ops.check(L.lantern_gather_candidates(C.c_void_p(p_tok), C.c_void_p(p_prob), C.c_void_p(p_smp), g[0], g[1], 1, a.n_flat, nx.N, nx.P, nx.D, g[2], g[3], g[4], g[5]),
                   "gather_candidates")

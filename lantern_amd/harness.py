@@ -109,6 +109,45 @@ def build_neighbour_table(device, seed: int = 0) -> torch.Tensor:
     return idx.to(torch.int16)      # uint16 bit patterns (values < 8192)
 
 
+def static_rejection_levels(cand, cart_prob, best, alen, counters):
+    """Per sequence: the number of tree LEVELS at which the static-tree walk rejected at least one candidate (= distinct drafter rows the
+    walk reads), from the step's own inputs and verdict -- the walk is replayed on the host without its arithmetic: at level i the tried
+    candidates are the distinct tokens (!= -1, cart_candidates_prob > 0: ea_model_lumina_mgpt.py:655-667) of the paths that share the accepted
+    prefix, in path order, up to the accepted one (levels <= accept_len) or all of them (the level that ended the walk).  Checked against the
+    kernel's own counters: the replay's rejections per sequence must equal counters[:, 2].
+    cand [B,P,D] i64, cart_prob [B,P,D] f32, best / alen [B], counters [B,6]."""
+    B, P, D = cand.shape
+    dev = cand.device
+    ar = torch.arange(B, device=dev)
+    best, alen = best.long(), alen.long()
+    acc = cand[ar, best]                                     # [B, D] the accepted path's tokens
+    alive = torch.ones((B, P), dtype=torch.bool, device=dev)
+    levels = counters[:, 0].long()
+    rej_levels = torch.zeros(B, dtype=torch.int64, device=dev)
+    rej_total = torch.zeros(B, dtype=torch.int64, device=dev)
+    for i in range(1, D):
+        tok = cand[:, :, i]
+        tried = alive & (tok != -1) & (cart_prob[:, :, i] > 0)
+        # distinct tokens in path order: path j counts when no earlier tried path carries the same token
+        same_earlier = (tok[:, :, None] == tok[:, None, :]) & tried[:, None, :] & (torch.arange(P, device=dev)[None, :, None] > torch.arange(P, device=dev)[None, None, :])
+        first = tried & ~same_earlier.any(-1)
+        visited = levels >= i
+        accepted_here = alen >= i
+        is_acc = first & (tok == acc[:, i, None])
+        # position of the accepted token among the distinct tried ones (its first carrier)
+        acc_pos = torch.where(is_acc.any(-1), is_acc.int().argmax(-1), torch.full((B,), P, device=dev))
+        before = first & (torch.arange(P, device=dev)[None, :] < acc_pos[:, None])
+        n_rej = torch.where(accepted_here, before.sum(-1), first.sum(-1))
+        n_rej = torch.where(visited, n_rej, torch.zeros_like(n_rej))
+        rej_total += n_rej
+        rej_levels += (n_rej > 0).long()
+        alive = alive & (tok == acc[:, i, None])
+    if not torch.equal(rej_total, counters[:, 2].long()):
+        bad = int((rej_total != counters[:, 2].long()).sum())
+        raise _lib.LanternError(f"static_rejection_levels: the replayed walk disagrees with the kernel's rejection counters in {bad} of {B} sequences")
+    return rej_levels
+
+
 class LuminaVerifyWorkload:
     @staticmethod
     def windowed_cfg(cfg) -> bool:
@@ -790,11 +829,15 @@ class LuminaVerifyWorkload:
         neighbour gathers, zeroing, scans and the bonus-token draw run in LDS."""
         return self.ep_window_bytes_from(self.log_cnt[i0:i1, self._seqs(group)])
 
-    def ep_window_bytes_from(self, cnt) -> float:
+    def ep_window_bytes_from(self, cnt, rejection_levels=None) -> float:
+        """`rejection_levels` (static_rejection_levels): the drafter row is priced once per LEVEL with a rejection -- every candidate tried at a
+        level hangs off the same parent, hence the same original_prob row (ea_model_lumina_mgpt.py:697), and the re-reads of the 2nd, 3rd...
+        rejection are L2 hits, not HBM traffic (round 4's PMC pass: 0.79 x the per-rejection model).  None: once per rejection (upper bound)."""
         c = cnt.to(torch.float64).reshape(-1, 6)
         k, W = self.cfg.lantern_k, self.W
         Lv, T, Rj, fresh = c[:, 0].sum(), c[:, 1].sum(), c[:, 2].sum(), (1 - c[:, 4]).sum()
-        return float((Lv + fresh) * W * 4 + T * k * 2 + Rj * (W * 4 + 2))
+        rows = Rj if rejection_levels is None else rejection_levels.to(torch.float64).sum()
+        return float((Lv + fresh) * W * 4 + T * k * 2 + rows * W * 4 + Rj * 2)
 
     def o7_algorithmic_bytes(self, n_launches: int, group=None) -> float:
         per_row = self.W * (2 * 2 + 4) if self.windowed else V * (2 * 2 + 4)

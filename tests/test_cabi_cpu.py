@@ -194,8 +194,13 @@ def test_round2_entry_points_validate_without_gpu():
     arr[0].dyn = None
     arr[0].ss_token = 0x1000          # (any non-null address: a static tree whose candidates this call assembles; nothing is dereferenced before the check fails)
     assert L.lantern_verify_step(arr, 2) == -1 and L.lantern_last_error().startswith(b"verify_step: group 0, gather_candidates: ")
-    arr[0].ss_token = None            # no dynamic block and no sample list: the caller assembled the candidates itself -> the first stage that checks is O8
-    assert L.lantern_verify_step(arr, 2) == -1 and L.lantern_last_error().startswith(b"verify_step: group 0, evaluate_posterior: ")
+    arr[0].ss_token = None            # no dynamic block, no sample list, no flag: a half-filled group is refused at O6, not evaluated on whatever `cand` holds
+    assert L.lantern_verify_step(arr, 2) == -1 and L.lantern_last_error().startswith(b"verify_step: group 0, gather_candidates: ")
+    arr[0].flags = _lib.STEP_CANDIDATES_READY          # "the caller assembled the candidates" said explicitly -- and then `cand` / `retrieve` must be there
+    assert L.lantern_verify_step(arr, 2) == -1 and b"LANTERN_STEP_CANDIDATES_READY needs cand" in L.lantern_last_error()
+    arr[0].cand = arr[0].retrieve = 0x1000             # (never dereferenced: the next stage's argument check fails first)
+    assert L.lantern_verify_step(arr, 1) == -1 and L.lantern_last_error().startswith(b"verify_step: group 0, evaluate_posterior: ")
+    assert L.lantern_verify_step(arr, 2) == -1 and L.lantern_last_error().startswith(b"verify_step: group 1, gather_candidates: ")      # the zero-initialised second group
     # prepare_step's three forms: a LANTERN_MODEL_PLAIN (LlamaGen) group is taken on its whole 16384-id vocabulary with dynamic trees only
     one = 0x1000                      # any non-null address: the argument check runs on the host, nothing is dereferenced or launched before it fails
     nl = (C.c_int32 * 4)(0, 1, 0, 1)

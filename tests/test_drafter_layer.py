@@ -129,10 +129,21 @@ def test_layer_tree_attention_path_matches_the_reference_layer(name, monkeypatch
     assert calls == ["tree"], calls
     for got, key in ((y1, "y1"), (kv1[0], "k1"), (kv1[1], "v1")):
         np.testing.assert_allclose(got.float().cpu().numpy(), GOLD[name + "." + key], rtol=4e-2, atol=4e-2)
-    # and the additive-mask form of the same call agrees
+    # and the additive-mask form of the same call agrees -- restated as ancestor words on the way in (additive_mask_words), so it is the SAME kernel
+    # and the same bits: never torch's scaled_dot_product_attention on device tensors at the HIP shapes
+    calls.clear()
     with torch.no_grad():
         y1m, _ = layer(g(name, "x1", dev, bf), attention_mask=m1, position_ids=g(name, "pos1", dev), past_key_value=kv0, use_cache=True)
-    np.testing.assert_allclose(y1.float().cpu().numpy(), y1m.float().cpu().numpy(), rtol=2e-2, atol=2e-2)
+    assert calls == ["tree"], calls
+    assert torch.equal(y1, y1m)
+    # a mask that is not (left padding) x (a block over the new tokens) has no HIP form: refused, not routed to torch
+    from lantern_amd._lib import LanternError
+    holey = m1.clone()
+    holey[:, :, 0, 1] = torch.finfo(holey.dtype).min
+    holey[:, :, 0, 0] = 0
+    with pytest.raises(LanternError, match="no HIP kernel"):
+        layer(g(name, "x1", dev, bf), attention_mask=holey, position_ids=g(name, "pos1", dev), past_key_value=kv0, use_cache=True)
+    assert "sdpa" not in calls
 
 
 @pytest.mark.gpu
@@ -375,7 +386,8 @@ def test_llamagen_and_anole_layers_hip_path_match_the_reference_layers_bf16(name
         y1, kv1 = layer(gl(name, "x1", dev, bf), attention_mask=m1, position_ids=gl(name, "pos1", dev), past_key_value=kv0, use_cache=True, **kw1)
     second = calls[n0:]
     assert second.count("linear_rows_streamk") == 4 and second.count("qk_rope_pairs" if lg else "qk_norm_rope") == 1, second
-    assert second.count("tree_attention" if tree else "sdpa") == 1 and second.count("sdpa" if tree else "tree_attention") == 0, second
+    # (round 5: the additive-mask form is restated as ancestor words + kv_start on the way in -- the same HIP attention, never torch's SDPA)
+    assert second.count("tree_attention") == 1 and second.count("sdpa") == 0, second
     n_norm = 2 if not lg else (1 if int(GOLD_LG[name + ".cfg"][4]) == 0 else 2)          # LlamaGen's layer 0 has no input norm (EAGLE)
     assert second.count("rmsnorm_rows") == n_norm, second
     for got, key in ((y0, "y0"), (y1, "y1"), (kv1[0], "k1"), (kv1[1], "v1")):

@@ -48,8 +48,8 @@ def test_static_batches_vs_oracle(model, tree, lantern, k, delta, sigma, seed):
     ("anole", "naive_extend_57", True, 10, 5.0, 1.0, 23, 0.95, 150), ("anole", "mc_sim_7b_63", True, 20, 0.2, 3.0, 24, 0.3, 40),
     ("llamagen", "mc_sim_7b_63", True, 200, 10.0, 0.5, 25, 0.99, 0)])
 def test_static_batches_with_top_p_vs_oracle(model, tree, lantern, k, delta, sigma, seed, top_p, top_k):
-    """TopPLogitsWarper between the temperature and the top-k, per visited row inside the dense kernel (drafters/utils.py:36-52 applied at
-    ea_model_llamagen.py:725,785), 32 sequences per launch against the oracle's sort-based restatement."""
+    """TopPLogitsWarper between the temperature and the top-k, per visited row inside the dense kernel AND inside the windowed chain kernel on
+    logit rows (drafters/utils.py:36-52 applied at ea_model_llamagen.py:725,785), 32 sequences per launch against the oracle's sort-based restatement."""
     _static_batches(model, tree, lantern, k, delta, sigma, seed, top_p, top_k)
 
 
@@ -72,7 +72,6 @@ def _static_batches(model, tree, lantern, k, delta, sigma, seed, top_p, top_k):
     if model != "lumina":       # LlamaGen / Anole: HF processors inside evaluate_posterior
         for c in (co, ch):
             c.temperature, c.top_k, c.top_p = 0.9, top_k, top_p
-    nucleus = model != "lumina" and 0.0 < top_p < 1.0          # logit-row windows have no top-p inside the chain kernel: the dense kernel only
     nl = np.stack([g["node_logits"] for g in gs])
     aux = ops.StaticAux(cart_prob=dev(np.stack(cps)), orig_prob=dev(np.stack([g["orig_prob"] for g in gs])), op_off=dev(gs[0]["op_off"]),
                         p_idx=dev(tb["p_indices"]), b_off=dev(tb["b_off"]), b_idx=dev(tb["b_idx"] if len(tb["b_idx"]) else np.zeros(1, np.int32)),
@@ -80,8 +79,9 @@ def _static_batches(model, tree, lantern, k, delta, sigma, seed, top_p, top_k):
     uni = np.stack([g["uniforms"] for g in gs])
     tab = dev(table.view(np.int16))
     dense = ops.evaluate_posterior(ch, dev(nl), dev(ri), dev(np.stack(cands)), dev(uni), table=tab if lantern else None, aux=aux)
-    win = None if nucleus else ops.evaluate_posterior_window(ch, V, dev(np.ascontiguousarray(nl[:, :, lo:lo + W])), lo, dev(ri), dev(np.stack(cands)), dev(uni),
-                                                             table=tab if lantern else None, aux=aux, want_dense=True)
+    # (round 5: logit-row windows apply TopPLogitsWarper inside the chain kernel too -- LANTERN_ROWS_LOGITS with prm.top_p)
+    win = ops.evaluate_posterior_window(ch, V, dev(np.ascontiguousarray(nl[:, :, lo:lo + W])), lo, dev(ri), dev(np.stack(cands)), dev(uni),
+                                        table=tab if lantern else None, aux=aux, want_dense=True)
     n_rej = n_acc = 0
     for b, g in enumerate(gs):
         a = oracle.StaticAux(cart_prob=cps[b], orig_prob=g["orig_prob"], op_off=g["op_off"], p_idx=tb["p_indices"], b_off=tb["b_off"],

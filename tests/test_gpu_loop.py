@@ -142,6 +142,15 @@ def test_anole_static_loop_with_top_p(fuse, spec):
     _anole_static_loop(fuse, 1, spec, 5.0, 10, 3, 16, 1, top_p=0.9)
 
 
+@pytest.mark.parametrize("fuse,spec", [(False, 0), (True, 0), (True, 3)], ids=["o7_launch", "raw_rows", "raw_rows_3_prepared"])
+def test_anole_static_loop_with_top_p_and_tied_logits(fuse, spec):
+    """the tie order at the nucleus boundary.  The bf16 row kernels hold a row as 8-id chunks (two float4 per chunk), the f32 ones as
+    4-id chunks; TopPLogitsWarper removes a PREFIX of the stable ascending sort, so among equal logits that straddle 1 - top_p the lower ids go --
+    top_p_tile ranks them by the tile's true index order (CHUNK8).  Heavy ties forced into every row; O7 over all rows, the rows prepared beside the
+    candidate assembly and the rows the chain kernel post-processes on demand against the oracle's sort-based loop."""
+    _anole_static_loop(fuse, 1, spec, 5.0, 10, 3, 16, 1, top_p=0.9, ties=True)
+
+
 @pytest.mark.parametrize("model,tree", [("anole", "naive_extend_57"), ("lumina", "naive_extend_57")])
 def test_static_loop_throughput_instances(model, tree):
     """More sequences per launch than CUs: the throughput forms (256 threads, three workgroups per CU) of the chain kernel's Anole static-tree
@@ -153,11 +162,40 @@ def test_static_loop_throughput_instances(model, tree):
         _lumina_static_loop_big(tree, 264, 2, 13)
 
 
-def _lumina_static_loop_big(tree, n_seq, steps, every):
+@pytest.mark.parametrize("tp_raw", ["256", "512"])
+@pytest.mark.parametrize("form", ["lumina_default_tree", "lumina_static", "anole_static", "lumina_dynamic"])
+def test_raw_row_throughput_instances(form, tp_raw, monkeypatch):
+    """Round 5: the throughput forms of the chain kernel on RAW cond / uncond bf16 rows (more sequences per launch than CUs; the row post-process of the
+    visited rows inside the kernel): 256 threads x 8 float4 with four 16-byte chunks per operand and thread (the default) and 512 threads at 128 VGPRs
+    (LANTERN_EPW_TP_RAW=512), for the four fixed configurations; every 13th sequence against the oracle's loop.  Each case runs in a fresh process
+    state of the knob (read once per process): the 512 form is reached through a child interpreter."""
+    if tp_raw == "512":
+        import subprocess
+        code = ("import os, sys; sys.path[:0] = [%r, %r, %r]; import test_gpu_loop as T; T._raw_throughput(%r)"
+                % (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "tests", "golden"), form))
+        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, LANTERN_EPW_TP_RAW="512"), capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-3000:]
+        return
+    _raw_throughput(form)
+
+
+def _raw_throughput(form):
+    if form == "lumina_default_tree":
+        _lumina_static_loop_big("mc_sim_7b_63", 264, 2, 13, fuse_o7=True, spec_rows=2)
+    elif form == "lumina_static":
+        _lumina_static_loop_big("naive_extend_57", 264, 2, 13, fuse_o7=True, spec_rows=0)
+    elif form == "anole_static":
+        _anole_static_loop(True, 1, 3, 5.0, 10, 264, 2, 13)
+    else:
+        _dynamic_tree_loop(True, 1, True, 2, 264, 2, 13)
+
+
+def _lumina_static_loop_big(tree, n_seq, steps, every, fuse_o7=False, spec_rows=0):
     import numpy as np
     import oracle
     from lantern_amd import harness as HN
-    cfg = HN.WorkloadConfig(tree=tree, n_seq=n_seq, pool_steps=2, with_kv=False, max_steps=steps + 4, sigma=5.0, n_groups=1, ep_kernel="chain", fuse_o7=False)
+    cfg = HN.WorkloadConfig(tree=tree, n_seq=n_seq, pool_steps=2, with_kv=False, max_steps=steps + 4, sigma=5.0, n_groups=1, ep_kernel="chain", fuse_o7=fuse_o7,
+                            spec_rows=spec_rows)
     wl = HN.LuminaVerifyWorkload(cfg, torch.device("cuda"))
     for _ in range(steps):
         wl.step()
@@ -196,7 +234,7 @@ def _lumina_static_loop_big(tree, n_seq, steps, every):
     assert n_acc > 0 and n_rej > 0
 
 
-def _anole_static_loop(fuse, groups, spec, lam, k, n_seq, steps, every, top_p=1.0):
+def _anole_static_loop(fuse, groups, spec, lam, k, n_seq, steps, every, top_p=1.0, ties=False):
     """BASELINE config 4 (Anole, LANTERN++ static tree naive_extend_57: neighbours zeroed in the drafter's row, no syntax shortcut, no grammar rows)
     through the device-resident step loop -- O7 over all rows, and the raw rows post-processed inside evaluate_posterior with the likeliest rows
     prepared beside O6 -- against the oracle's loop over the same pools / uniforms: identical (best path, accept length, bonus token) at every step."""
@@ -208,6 +246,11 @@ def _anole_static_loop(fuse, groups, spec, lam, k, n_seq, steps, every, top_p=1.
                             top_p=top_p)
     wl = HN.LuminaVerifyWorkload(cfg, torch.device("cuda"))
     assert wl.anole and wl.fused_o7 == fuse and wl.n_spec == (spec if fuse else 0)
+    if ties:
+        # logits on a grid of 0.5 (bf16-exact, and so is every CFG mix of them): ~130 distinct values among 8192 ids, so the 1 - top_p boundary
+        # falls INSIDE a group of equal logits in every row -- the stable-sort order of the tied entries (index order) decides which of them go
+        for t in (wl.cond, wl.uncond):
+            t.copy_(((t.float() * 2).round() / 2).to(torch.bfloat16))
     for _ in range(steps):
         wl.step()
     wl.join()

@@ -12,10 +12,9 @@ from test_gpu_parity import dev, hip_cfg, table_dev, _bf16
 
 
 def _supported(spec):
-    """Logit-row windows with the processors inside the chain kernel have no top-p (it is applied where windowed rows are produced,
-    lantern_cfg_mask_topk_window, or per visited row on raw / dense rows): those reference cases run in test_gpu_parity (dense) and test_gpu_mirror."""
-    tp = spec.get("top_p", 1.0)
-    return not (0.0 < tp < 1.0)
+    """Every reference case runs on the windowed kernels (round 5: logit-row windows apply TopPLogitsWarper inside the chain kernel --
+    LANTERN_ROWS_LOGITS with prm.top_p; before, those cases ran on the dense kernel only)."""
+    return True
 
 
 pytestmark = pytest.mark.gpu

@@ -7,7 +7,7 @@ level = os.environ.get("EPW_TRACE", "1")
 so = os.path.join(ROOT, "tools", f"liblantern_trace{level}.so")
 if not os.path.exists(so) or (len(sys.argv) > 1 and sys.argv[1] == "build"):
     src = os.path.join(ROOT, "lantern_amd", "csrc")
-    files = [os.path.join(src, f) for f in ("evaluate_posterior.hip", "logits_post.hip", "window_kernels.hip", "node_kernels.hip", "gather_ops.hip", "tree_dynamic.hip", "greedy.hip", "drafter_fc.hip", "vq_table.hip", "tree_attention.hip", "harness_util.hip")]
+    files = [os.path.join(src, f) for f in ("evaluate_posterior.hip", "logits_post.hip", "window_kernels.hip", "epw_generic.hip", "epw_throughput.hip", "node_kernels.hip", "gather_ops.hip", "tree_dynamic.hip", "greedy.hip", "drafter_fc.hip", "vq_table.hip", "tree_attention.hip", "harness_util.hip")]
     subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "-shared", "--offload-arch=gfx950", "-ffp-contract=off", f"-DEPW_TRACE={level}",
                            "-o", so] + files + ["-x", "hip", os.path.join(src, "tree_static.cpp"), os.path.join(src, "verify_step.cpp")])
 if len(sys.argv) > 1 and sys.argv[1] == "build":

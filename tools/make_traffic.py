@@ -8,7 +8,7 @@ import csv, glob, json, os, shutil, subprocess, sys, collections
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-RND = sys.argv[1] if len(sys.argv) > 1 else "r04"
+RND = sys.argv[1] if len(sys.argv) > 1 else "r05"
 runs = dict(a.split("=", 1) for a in sys.argv[2:]) or {"raw": RND + "p", "chain": RND + "p_chain"}          # traffic key prefix -> gpurun_out/<dir>
 sat_runs = [v for k, v in list(runs.items()) if k.startswith("sat")]
 runs = {k: v for k, v in runs.items() if not k.startswith("sat")}

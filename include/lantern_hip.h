@@ -624,8 +624,40 @@ typedef struct lantern_draft_depth_args {
      * (zero-filled once); ta_ws: lantern_tree_attention_workspace(B, nq, 64, d, kv_rows) bytes */
     void *x, *xn, *qkv, *q, *attn, *h1, *hn, *act, *out, *head_ws, *sk_ws, *ta_ws;
     size_t sk_ws_bytes, ta_ws_bytes;
+    /* STATIC trees (EAGLE v1 / LANTERN++: the loop bodies of topK_generate(tree_type "static"), cnets_lumina_mgpt.py:1245-1328, and topK_genrate_v1,
+     * cnets_llamagen.py:944-1023 / cnets_anole.py:1056-1171): n_draw > 0 replaces the expansion stage by lantern_head_sample -- this depth's T rows get
+     * their distributions (probs_out [T, vocab] f32: the verify side's original_prob rows), n_draw draws without replacement each (ss_token / ss_prob
+     * [T, n_draw]) -- and the next depth's inputs come from the tree's static tables: token j = ss_token.flat[next_gather[j]] (`idx.view(-1)[tree_indices]`),
+     * hidden row j = this depth's output row next_rep[j] (`repeat_hidden`), T_next of them (hidden_next [B, T_next, H], ids_next [B * T_next]; T_next = 0:
+     * the last depth).  tree_bits holds the whole tree's ancestor words (static: written once by the caller, rows [t1 - T, t1) are this depth's);
+     * topk_index / cu_scores / topk_cs_index / scores_out / scores_in / parents_next are not used. */
+    int32_t n_draw, T_next;
+    const double *draw_u;              /* [T, n_draw] uniforms of the draws, or NULL with draw_idx */
+    const int64_t *draw_idx;           /* [T, n_draw] injected draws (tests, recorded runs), or NULL */
+    float *probs_out;                  /* out [T, vocab] f32 */
+    int64_t *ss_token;                 /* out [T, n_draw] */
+    float *ss_prob;                    /* out [T, n_draw] */
+    const int32_t *next_gather, *next_rep;   /* [T_next] */
 } lantern_draft_depth_args;
 int lantern_draft_depth(const lantern_draft_depth_args *args);
+
+/* The static drafter's head stage alone (also the first sample of a drafting call, on the prefill's last hidden row: cnets_lumina_mgpt.py:1234-1243):
+ * head(hidden) on the window rows with the CFG mix (A [2n, K] bf16: n conditional rows, then n unconditional; W / bias / packed / sk_workspace as
+ * lantern_head_expand_streamk) -> the model's processors (Lumina grammar rows at pos_ids, InterleavedTopKLogitsWarper / top-k threshold top_k_filter) ->
+ * softmax -> probs_out [n, V] f32 (zero outside the window, one-hot for a forced row) -> Model.sample (cnets_lumina_mgpt.py:936-955): n_draw draws without
+ * replacement per row and their conditional probabilities p_i / (1 - sum_{j<i} p_j).  The draws come from injected uniforms draw_u [n, n_draw] f64 --
+ * draw j = inverse CDF in token-id order of the row with the j tokens already drawn removed (the distribution of torch.multinomial(replacement=False);
+ * torch's device RNG is not reproducible across devices) -- or are taken from draw_idx [n, n_draw] as given.  workspace: lantern_head_expand_workspace(n, n_cols). */
+/* The inputs of a static tree's next depth from the draws of the rows above it (cnets_lumina_mgpt.py:1258-1262): ids_next[b, j] = ss_token.flat[gather[j]]
+ * (`idx.view(-1)[tree_indices[i]]`), hidden_next[b, j] = out_hidden[b, rep[j]] (`repeat_hidden(out_hidden, repeat_nums[i])`), bf16 rows of H;
+ * out_hidden [B, T, H], hidden_next [B, T_next, H], ids_next [B * T_next], gather / rep [T_next] i32 [dev].  lantern_draft_depth does this at the end of
+ * a static depth; the first depth of a drafting call (behind lantern_head_sample on the prefill's last row) calls it directly. */
+int lantern_draft_static_inputs(const int64_t *ss_token, int n_flat, const int32_t *gather, const int32_t *rep, const void *out_hidden, int B, int T, int H,
+                                int T_next, void *hidden_next, int64_t *ids_next, void *stream);
+int lantern_head_sample(const void *A, const void *W, const void *bias, int n, int K, int row_lo, int n_cols, int V, float cfg, int model,
+                        const int64_t *pos_ids, int64_t pos_base, int w_latent, int h_latent, int newline_id, int eos_id, int top_k_filter,
+                        int n_draw, const double *draw_u, const int64_t *draw_idx, void *workspace, float *probs_out, int64_t *ss_token,
+                        float *ss_prob, int packed, void *sk_workspace, size_t sk_workspace_bytes, void *stream);
 
 /* 8f-2 (next row, second half)  One drafter expansion depth from the hidden states to the top-k in two small launches, the head's
  * logits never in HBM:  head(hidden) restricted to the id window the model's mask lets through -> CFG combination in the GEMM's

@@ -104,7 +104,10 @@ class DraftDepthArgs(C.Structure):
                 + [(n, C.c_void_p) for n in ("scores_in", "topk_index", "cu_scores", "topk_cs_index", "scores_out", "hidden_next", "ids_next", "parents_next")]
                 + [("parent_bias_next", C.c_int64)]
                 + [(n, C.c_void_p) for n in ("x", "xn", "qkv", "q", "attn", "h1", "hn", "act", "out", "head_ws", "sk_ws", "ta_ws")]
-                + [("sk_ws_bytes", C.c_size_t), ("ta_ws_bytes", C.c_size_t)])
+                + [("sk_ws_bytes", C.c_size_t), ("ta_ws_bytes", C.c_size_t)]
+                # static trees (n_draw > 0): sample instead of expand, next inputs through the tree's tables
+                + [("n_draw", C.c_int32), ("T_next", C.c_int32)]
+                + [(n, C.c_void_p) for n in ("draw_u", "draw_idx", "probs_out", "ss_token", "ss_prob", "next_gather", "next_rep")])
 
 
 _lib = None
@@ -164,5 +167,5 @@ EXPORTS = [
     "lantern_tree_attention_workspace", "lantern_tree_attention",
     "lantern_tree_node_tables_size", "lantern_tree_node_tables", "lantern_evaluate_posterior_nodes_workspace",
     "lantern_evaluate_posterior_nodes", "lantern_verify_step", "lantern_gather_candidates_dynamic", "lantern_head_expand_workspace", "lantern_head_expand", "lantern_prepare_step",
-    "lantern_linear_rows_epilogue", "lantern_linear_rows_packed", "lantern_linear_rows_splitk", "lantern_linear_rows_streamk_workspace", "lantern_linear_rows_streamk", "lantern_pack_linear_weight_bytes", "lantern_pack_linear_weight", "lantern_drafter_fc_streamk", "lantern_head_expand_streamk", "lantern_rmsnorm_rows", "lantern_qk_norm_rope", "lantern_qk_rope_pairs", "lantern_draft_depth",
+    "lantern_linear_rows_epilogue", "lantern_linear_rows_packed", "lantern_linear_rows_splitk", "lantern_linear_rows_streamk_workspace", "lantern_linear_rows_streamk", "lantern_pack_linear_weight_bytes", "lantern_pack_linear_weight", "lantern_drafter_fc_streamk", "lantern_head_expand_streamk", "lantern_rmsnorm_rows", "lantern_qk_norm_rope", "lantern_qk_rope_pairs", "lantern_draft_depth", "lantern_head_sample", "lantern_draft_static_inputs",
 ]

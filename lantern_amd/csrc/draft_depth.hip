@@ -16,6 +16,8 @@ int launch_linear_rows_streamk_seg(const void *A, int a_seg_rows, long long a_se
                                    int epilogue, const void *aux, int aux_stride, int pair_rows, int packed, void *workspace, size_t workspace_bytes,
                                    hipStream_t st);
 const char *last_error();
+int launch_static_next_inputs(const int64_t *ss_token, int n_flat, const int32_t *gather, const int32_t *rep, const void *out_hidden, int B, int T, int H, int T_next,
+                              void *hidden_next, int64_t *ids_next, hipStream_t st);
 
 constexpr int DD_ROWS = 64;          // tree keys a drafting call can hold (one ancestor word per row)
 
@@ -61,15 +63,21 @@ extern "C" int lantern_draft_depth(const lantern_draft_depth_args *ap) {
     LANTERN_CHECK_ARG(a.B == 2 && a.T > 0 && M <= 32 && H > 0 && H % 64 == 0 && nq * d == H && (d == 64 || d == 128) && a.inter > 0 && a.inter % 64 == 0,
                       "draft_depth: B = 2 rows (cond, uncond), B * T <= 32, hidden %% 64 == 0, head_dim 64 or 128");
     LANTERN_CHECK_ARG(a.layer_kind == 0 || a.layer_kind == 1, "draft_depth: layer_kind %d", a.layer_kind);
+    const bool is_static = a.n_draw > 0;          // a static tree: sample instead of expand, next inputs through the tree's tables
     LANTERN_CHECK_ARG(a.ids && a.hidden_in && a.embed && a.fc_w && a.qkv_w && a.o_w && a.ln2_w && a.gate_up_w && a.down_w && a.position_ids && a.k_slab && a.v_slab &&
-                          a.tree_bits && a.head_w && a.topk_index && a.cu_scores && a.topk_cs_index && a.scores_out,
+                          a.tree_bits && a.head_w && (is_static || (a.topk_index && a.cu_scores && a.topk_cs_index && a.scores_out)),
                       "draft_depth: null weight / state / output buffer");
+    if (is_static) {
+        LANTERN_CHECK_ARG((a.draw_u || a.draw_idx) && a.probs_out && a.ss_token && a.ss_prob && a.T <= 16, "draft_depth: static tree: draws (uniforms or indices) and the probs_out / ss_token / ss_prob outputs, T <= 16");
+        LANTERN_CHECK_ARG(a.T_next >= 0 && a.B * a.T_next <= 32 && (a.T_next == 0 || (a.next_gather && a.next_rep && a.hidden_next && a.ids_next)),
+                          "draft_depth: static tree: next-depth tables / buffers (T_next = %d)", a.T_next);
+    }
     LANTERN_CHECK_ARG(a.x && a.xn && a.qkv && a.q && a.attn && a.h1 && a.hn && a.act && a.out && a.head_ws && a.sk_ws && a.ta_ws, "draft_depth: null work buffer");
     LANTERN_CHECK_ARG(a.t1 >= a.T && a.t1 <= DD_ROWS && a.kv_row0 >= a.t1 - a.T && a.kv_rows >= a.kv_row0 + a.T,
                       "draft_depth: t1 = %d tree keys (this depth's %d included, at most %d), cache rows [%d, +%d) of %d", a.t1, a.T, DD_ROWS, a.kv_row0, a.T, a.kv_rows);
     if (a.layer_kind == 0) LANTERN_CHECK_ARG(a.qn_w && a.qn_b && a.kn_w && a.kn_b && a.cos_table && a.sin_table && a.model_parallel > 0, "draft_depth: Chameleon head-stage tables missing");
     else LANTERN_CHECK_ARG(a.freqs, "draft_depth: Llama head stage needs the freqs rows");
-    if (a.hidden_next) LANTERN_CHECK_ARG(a.ids_next && a.parents_next && a.top_k == a.T, "draft_depth: next-depth buffers (top_k == T)");
+    if (a.hidden_next && !is_static) LANTERN_CHECK_ARG(a.ids_next && a.parents_next && a.top_k == a.T, "draft_depth: next-depth buffers (top_k == T)");
     hipStream_t st = (hipStream_t)a.stream;
     int rc;
     // ---- input stage
@@ -110,6 +118,18 @@ extern "C" int lantern_draft_depth(const lantern_draft_depth_args *ap) {
     rc = launch_linear_rows_streamk_seg(a.act, 0, 0, a.down_w, a.down_b, M, a.inter, H, a.out, LANTERN_EPI_RESIDUAL, a.h1, H, 0, a.layer_packed, a.sk_ws,
                                         a.sk_ws_bytes, st);
     if (rc) return fail("down projection", rc);
+    if (is_static) {
+        // ---- head + sample (Model.sample on this depth's rows), then the next depth's tokens / hidden rows through the tree's tables
+        rc = lantern_head_sample(a.out, a.head_w, a.head_b, a.T, H, a.row_lo, a.n_cols, a.vocab, a.cfg, a.model, a.head_pos, a.pos_base, a.w_latent, a.h_latent,
+                                 a.newline_id, a.eos_id, a.top_k_filter, a.n_draw, a.draw_u, a.draw_idx, a.head_ws, a.probs_out, a.ss_token, a.ss_prob,
+                                 a.head_packed, a.sk_ws, a.sk_ws_bytes, a.stream);
+        if (rc) return fail("head sample", rc);
+        if (a.T_next > 0) {
+            rc = launch_static_next_inputs(a.ss_token, a.T * a.n_draw, a.next_gather, a.next_rep, a.out, a.B, a.T, H, a.T_next, a.hidden_next, a.ids_next, st);
+            if (rc) return fail("next inputs", rc);
+        }
+        return LANTERN_OK;
+    }
     // ---- head + expansion
     rc = lantern_head_expand_streamk(a.out, a.head_w, a.head_b, a.T, H, a.row_lo, a.n_cols, a.vocab, a.cfg, a.model, a.head_pos, a.pos_base, a.w_latent, a.h_latent,
                                      a.newline_id, a.eos_id, a.top_k_filter, a.scores_in, a.top_k, a.head_ws, a.topk_index, a.cu_scores, a.topk_cs_index,

@@ -27,7 +27,7 @@ __global__ __launch_bounds__(NT) void sample_window_kernel(const uint16_t *__res
                                                            int newline_id, int eos_id, int top_k_filter, int n_draw,
                                                            const double *__restrict__ draw_u, const int64_t *__restrict__ draw_idx,
                                                            float *__restrict__ probs_out, int64_t *__restrict__ ss_token, float *__restrict__ ss_prob) {
-    constexpr int NW = NT / 64, NV4 = 2 * SW_C8;
+    constexpr int NV4 = 2 * SW_C8;
     extern __shared__ float4 sw_dyn[];
     float *g = reinterpret_cast<float *>(sw_dyn);          // [W] the row's distribution, entries of drawn tokens zeroed as the draws go
     __shared__ alignas(16) int s_hist[O7_HIST_INTS];
@@ -222,4 +222,11 @@ extern "C" int lantern_head_sample(const void *A, const void *W, const void *bia
                            h_latent, newline_id, eos_id, top_k_filter, n_draw, draw_u, draw_idx, probs_out, ss_token, ss_prob);
     LANTERN_CHECK_LAUNCH("head_sample");
     return LANTERN_OK;
+}
+
+extern "C" int lantern_draft_static_inputs(const int64_t *ss_token, int n_flat, const int32_t *gather, const int32_t *rep, const void *out_hidden, int B, int T, int H,
+                                           int T_next, void *hidden_next, int64_t *ids_next, void *stream) {
+    LANTERN_CHECK_ARG(ss_token && gather && rep && out_hidden && hidden_next && ids_next, "draft_static_inputs: null buffer");
+    LANTERN_CHECK_ARG(n_flat > 0 && B > 0 && T > 0 && H > 0 && H % 8 == 0 && T_next > 0, "draft_static_inputs: bad sizes");
+    return launch_static_next_inputs(ss_token, n_flat, gather, rep, out_hidden, B, T, H, T_next, hidden_next, ids_next, (hipStream_t)stream);
 }

@@ -118,7 +118,7 @@ class DraftPlan:
 
     ROWS = 64
 
-    def __init__(self, model, head, k: int, hx: dict):
+    def __init__(self, model, head, k: int, hx: dict, T: Optional[int] = None, depth: Optional[int] = None):
         import ctypes as C
         from .. import _lib
         from .decoder_layer import LlamaDecoderLayer
@@ -127,8 +127,8 @@ class DraftPlan:
         at, mlp = layer.self_attn, layer.mlp
         dev = model.fc.weight.device
         bf = torch.bfloat16
-        self.model, self.layer, self.k, self.depth, self.dev = model, layer, k, int(model.depth), dev
-        B, T, H = 2, k, at.hidden_size
+        self.model, self.layer, self.k, self.depth, self.dev = model, layer, k, int(model.depth if depth is None else depth), dev
+        B, T, H = 2, (k if T is None else int(T)), at.hidden_size          # T: rows per depth (EAGLE-2: top_k; a static tree: its widest level)
         nq, nk, d, inter = at.num_heads, at.num_key_value_heads, at.head_dim, mlp.gate_proj.out_features
         self.B, self.T, self.H, self.nq, self.nk, self.d = B, T, H, nq, nk, d
         self.llama = isinstance(layer, LlamaDecoderLayer)
@@ -246,6 +246,136 @@ class DraftPlan:
         """(scores_list, ss_token, parents_list) entries of the depth loop, as the Python loop appends them."""
         D = self.depth
         return ([self.log_cu[i].reshape(-1) for i in range(D)], [self.log_ti[i].reshape(-1) for i in range(D)], [self.parents[i] for i in range(D)])
+
+
+class StaticDraftPlan(DraftPlan):
+    """The static-tree loops (EAGLE v1: topK_generate(tree_type="static"), topK_genrate_v1) on the same call: per depth ONE lantern_draft_depth with
+    n_draw > 0 -- input stage, the decoder layer on the level's T_i rows, head + CFG + processors + softmax + Model.sample's draws without replacement
+    (lantern_head_sample), the next level's tokens / hidden rows through the tree's tables -- behind ONE lantern_head_sample for the root row.  The
+    per-level Python of the reference (sample -> torch.cat -> repeat_hidden -> forward -> head -> processors: cnets_lumina_mgpt.py:1245-1328,
+    cnets_llamagen.py:944-1023) is gone from the host.  Draws: injected uniforms (`Model.static_draw_uniforms`, default torch.rand on the device, one
+    call per drafting cycle) or injected indices (`Model.static_draw_idx`), see include/lantern_hip.h lantern_head_sample."""
+
+    def __init__(self, model, head, k: int, hx: dict, tb: dict):
+        levels = [int(len(t)) for t in tb["tree_indices"]]
+        super().__init__(model, head, k, hx, T=max(levels), depth=len(levels))
+        dev, V = self.dev, int(model.vocab_size)
+        self.levels = levels
+        self.row_off = [1 + sum(levels[:i]) for i in range(len(levels) + 1)]          # ss rows: 0 = the root's, then level by level
+        self.R = self.row_off[-1]
+        self.key_off = [sum(levels[:i]) for i in range(len(levels) + 1)]             # tree keys in front of level i
+        i32 = lambda x: torch.as_tensor(x, dtype=torch.int32, device=dev).contiguous()
+        # level i's tokens = the draws of the rows one level up, flattened, at tree_indices[i]; its hidden rows = the parents' output rows
+        self.gather = [i32(t) for t in tb["tree_indices"]]
+        self.rep = [i32(torch.repeat_interleave(torch.arange(len(r)), torch.as_tensor(r))) for r in tb["repeat_nums"]]
+        bits = torch.zeros(self.ROWS, dtype=torch.int64)
+        for i, m in enumerate(tb["attn_mask"]):
+            m2 = m.reshape(m.shape[-2], m.shape[-1]).cpu()
+            w = torch.ones(m2.shape[1], dtype=torch.int64) << torch.arange(m2.shape[1], dtype=torch.int64)
+            bits[self.key_off[i]:self.key_off[i + 1]] = ((m2 != 0).to(torch.int64) * w).sum(-1)
+        self.tree_bits.copy_(bits.to(dev))
+        f32, i64, f64 = torch.float32, torch.int64, torch.float64
+        z = lambda *shape, dt: torch.zeros(shape, dtype=dt, device=dev)
+        # double-buffered results: the previous drafting call's (ss_token, ss_prob, ss_op) stay intact while the next call fills the other set
+        self.res = [dict(probs=z(self.R, V, dt=f32), tok=z(self.R, k, dt=i64), prob=z(self.R, k, dt=f32)) for _ in range(2)]
+        self.parity = 0
+        self.draw_u = z(self.R, k, dt=f64)
+        self.draw_idx = z(self.R, k, dt=i64)
+        self.pos_l = [z(self.B, t, dt=i64) for t in levels]
+        self.head_pos_l = [z(t, dt=i64) for t in levels]
+        self.head_pos0 = z(1, dt=i64)
+        self.last = z(self.B, 1, self.H, dt=torch.bfloat16)
+        self.args.n_draw = k
+
+    def draft(self, pkv, last_hidden, len_posi, head_len=None, kv_start=None, position_diff=None):
+        """One drafting call behind the prefill: last_hidden [2, H]; len_posi: [2, 1] device tensor (Lumina: the cond / uncond stream lengths) or an int
+        (LlamaGen / Anole: + position_diff for the uncond row, cnets_anole.py:858-862); head_len: the stream whose positions drive the Lumina grammar mask
+        (len_posi[1]) or None.  Returns (ss_token [R, k], ss_prob [R, k], [probs rows per level])."""
+        a, C, L, B, k, D = self.args, self._C, self._L, self.B, self.k, self.depth
+        mdl = self.model
+        self.parity ^= 1
+        res = self.res[self.parity]
+        past = pkv[0][0].shape[2]
+        ks, vs = self.layer._cache_slab(B, self.nk, self.d, past + self.key_off[-1], self.dev, pkv[0])
+        a.k_slab, a.v_slab, a.kv_rows = ks.data_ptr(), vs.data_ptr(), ks.shape[2]
+        self._slab, self.past = (ks, vs), past
+        need = int(L.lantern_tree_attention_workspace(B, self.nq, self.ROWS, self.d, C.c_int64(ks.shape[2])))
+        if self.ta is None or self.ta.numel() < need:
+            self.ta = torch.empty(max(need, 16), dtype=torch.uint8, device=self.dev)
+        a.ta_ws, a.ta_ws_bytes = self.ta.data_ptr(), self.ta.numel()
+        if kv_start is None:
+            self.kv_start.zero_()
+        else:
+            self.kv_start.copy_(kv_start)
+        a.kv_start, a.positions_per_batch_row, a.cfg = self.kv_start.data_ptr(), 1, float(mdl.cfg_scale)
+        a.tree_bits = self.tree_bits.data_ptr()
+        # the draws of this call: injected indices, injected uniforms, or fresh uniforms (ONE torch.rand per drafting call)
+        idx = getattr(mdl, "static_draw_idx", None)
+        if idx is not None:
+            self.draw_idx.copy_(idx.reshape(self.R, k))
+            du, di = None, self.draw_idx
+        else:
+            src = getattr(mdl, "static_draw_uniforms", None)
+            self.draw_u.copy_(src(self.R, k) if src is not None else torch.rand((self.R, k), dtype=torch.float64, device=self.dev))
+            du, di = self.draw_u, None
+        self._du, self._di = du, di
+        # positions of every level (len_posi advances by one per level; the tree's own position offsets are zero: utils_c.py:100-179)
+        lumina = head_len is not None
+        for i in range(D):
+            if torch.is_tensor(len_posi):
+                self.pos_l[i].copy_((len_posi.reshape(B, 1) + i).expand(B, self.levels[i]))
+            else:
+                self.pos_l[i].fill_(int(len_posi) + i)
+                if position_diff is not None:
+                    self.pos_l[i][1].sub_(position_diff.reshape(()))
+            if lumina:
+                self.head_pos_l[i].copy_((head_len.reshape(1) + i + 1).expand(self.levels[i]))
+        self._lumina = lumina
+        if lumina:
+            self.head_pos0.copy_(head_len.reshape(1))
+        # ---- the root row: head + sample on the prefill's last hidden row (cond, uncond)
+        stream = torch.cuda.current_stream().cuda_stream
+        sk = ops._sk_workspace(self.dev)
+        self.last.copy_(last_hidden.reshape(B, 1, self.H))
+        u0 = None if du is None else du.data_ptr()
+        i0 = None if di is None else di.data_ptr()
+        ops.check(L.lantern_head_sample(C.c_void_p(self.last.data_ptr()), C.c_void_p(a.head_w), C.c_void_p(a.head_b), 1, self.H, a.row_lo, a.n_cols, a.vocab,
+                                        C.c_float(a.cfg), a.model, C.c_void_p(self.head_pos0.data_ptr() if lumina else None), C.c_int64(a.pos_base), a.w_latent,
+                                        a.h_latent, a.newline_id, a.eos_id, a.top_k_filter, k, C.c_void_p(u0), C.c_void_p(i0), C.c_void_p(a.head_ws),
+                                        C.c_void_p(res["probs"].data_ptr()), C.c_void_p(res["tok"].data_ptr()), C.c_void_p(res["prob"].data_ptr()),
+                                        a.head_packed, C.c_void_p(sk.data_ptr()), C.c_size_t(sk.numel()), C.c_void_p(stream)), "head_sample")
+        # ---- level 0's inputs: its tokens out of the root's draws, the last hidden row repeated
+        T0 = self.levels[0]
+        ops.check(L.lantern_draft_static_inputs(C.c_void_p(res["tok"].data_ptr()), k, C.c_void_p(self.gather[0].data_ptr()), C.c_void_p(self.rep[0].data_ptr()),
+                                                C.c_void_p(self.last.data_ptr()), B, 1, self.H, T0, C.c_void_p(self.hidden[0].data_ptr()),
+                                                C.c_void_p(self.ids[0].data_ptr()), C.c_void_p(stream)), "draft_static_inputs")
+        for i in range(D):
+            self.run_level(i, res, stream, sk)
+        return res["tok"], res["prob"], [res["probs"][0:1]] + [res["probs"][self.row_off[i]:self.row_off[i + 1]] for i in range(D)]
+
+    def run_level(self, i: int, res, stream, sk):
+        """Level i: ONE C call."""
+        a, k, D = self.args, self.k, self.depth
+        T = self.levels[i]
+        r0 = self.row_off[i]
+        a.stream = stream
+        a.sk_ws, a.sk_ws_bytes = sk.data_ptr(), sk.numel()
+        a.T = T
+        a.ids, a.hidden_in = self.ids[i].data_ptr(), self.hidden[i & 1].data_ptr()
+        a.position_ids = self.pos_l[i].data_ptr()
+        a.head_pos = self.head_pos_l[i].data_ptr() if self._lumina else None
+        a.kv_row0, a.t1 = self.past + self.key_off[i], self.key_off[i + 1]
+        a.draw_u = None if self._du is None else self._du[r0:].data_ptr()
+        a.draw_idx = None if self._di is None else self._di[r0:].data_ptr()
+        a.probs_out, a.ss_token, a.ss_prob = res["probs"][r0:].data_ptr(), res["tok"][r0:].data_ptr(), res["prob"][r0:].data_ptr()
+        if i + 1 < D:
+            a.T_next = self.levels[i + 1]
+            a.next_gather, a.next_rep = self.gather[i + 1].data_ptr(), self.rep[i + 1].data_ptr()
+            a.hidden_next, a.ids_next = self.hidden[(i + 1) & 1].data_ptr(), self.ids[i + 1].data_ptr()
+        else:
+            a.T_next = 0
+            a.next_gather = a.next_rep = a.hidden_next = a.ids_next = None
+        ops.check(self._L.lantern_draft_depth(self._C.byref(a)), "draft_depth")
 
 
 # ----------------------------------------------------------------------------- the drafter
@@ -596,7 +726,32 @@ class Model(nn.Module):
             hit = self.__dict__["_plan"] = (key, DraftPlan(self, head, k, hx))
         return hit[1]
 
+    def _static_plan(self, head, proc, k):
+        """The StaticDraftPlan of this model / head / processor list / tree (cached), or None when the static loop has to stay in Python (the same
+        conditions as _depth_plan; levels of at most 16 rows, at most 64 tree nodes)."""
+        from .decoder_layer import DecoderLayer
+        tb = getattr(self, "tree_buffer", None)
+        if not self.use_depth_plan or tb is None or len(self.layers) != 1 or not isinstance(self.layers[0], DecoderLayer):
+            return None
+        layer, w = self.layers[0], self.fc.weight
+        levels = [int(len(t)) for t in tb["tree_indices"]]
+        if not (layer.fused and layer.inplace_cache and w.is_cuda and w.dtype == torch.bfloat16 and layer.self_attn.q_proj.weight.dtype == torch.bfloat16
+                and layer.self_attn.head_dim in (64, 128) and w.shape[0] % 64 == 0 and levels and max(levels) <= 16 and sum(levels) <= DraftPlan.ROWS
+                and 1 <= k <= 16 and getattr(layer.mlp, "act_fn", None) is torch.nn.functional.silu and self.vocab_size % 4 == 0):
+            return None
+        hx = self._head_fusion(head, proc, max(levels), k, True)
+        if hx is None or hx["packed"] is None:
+            return None
+        snap = [head.weight, head.bias, w, self.fc.bias, self.embed_tokens.weight] + [p_ for p_ in layer.parameters()]
+        key = (id(head), k, id(tb), hx["top_k_filter"], hx["model"]) + tuple((t.data_ptr(), t._version) for t in snap if t is not None)
+        hit = self.__dict__.get("_splan")
+        if hit is None or hit[0] != key:
+            hit = self.__dict__["_splan"] = (key, StaticDraftPlan(self, head, k, hx, tb))
+        return hit[1]
+
     use_depth_plan = True          # False: the depth loop stays in Python (one ctypes call per kernel): the form the plan is tested against
+    static_draw_uniforms = None    # callable (rows, k) -> [rows, k] f64 device tensor: the uniforms behind the static plan's draws (default: torch.rand)
+    static_draw_idx = None         # [rows, k] int64: the draws themselves, injected (tests, recorded runs)
 
     def _post_head(self, cond, uncond, proc, pos_ids=None, pos_base=2):
         """CFG combine + the model's mask + its processors on the head's rows -> processed logits [R,V] f32 (dense rows: the tree
@@ -717,6 +872,10 @@ class Model(nn.Module):
         self.reset()
         akw = {} if input_position_diff is None else {"attention_mask": attention_mask}
         out_hidden, pkv = self._prefill(hidden_states, input_ids, input_position_diff, attention_mask)
+        plan = self._static_plan(head, logits_processor, TOPK) if out_hidden.shape[0] == 2 else None
+        if plan is not None:          # the level loop: one lantern_draft_depth call per level (StaticDraftPlan)
+            start = None if attention_mask is None or input_position_diff is None else attention_mask.to(dev).to(torch.int64).argmax(dim=1)
+            return plan.draft(pkv, out_hidden[:, -1], len_posi, kv_start=start, position_diff=input_position_diff)
         ho = self._head(head, out_hidden[:, -1])
         half = ho.shape[0] // 2
         rows = self._post_head(ho[:half], ho[half:], logits_processor)
@@ -775,6 +934,9 @@ class Model(nn.Module):
         self.stable_kv = pkv
         last_hidden = out_hidden[:, -1]
         if tree_type == "static":
+            plan = self._static_plan(head, logits_processors, k)
+            if plan is not None:      # the level loop: one lantern_draft_depth call per level (StaticDraftPlan)
+                return plan.draft(pkv, last_hidden, len_posi, head_len=len_posi[1], kv_start=attention_mask.to(torch.int64).argmax(dim=1))
             ho = self._head(head, last_hidden)                                                  # [2,V]
             rows = self._post_head(ho[0:1], ho[1:2], logits_processors, pos_ids=len_posi[1])
             tb = self.tree_buffer

@@ -807,6 +807,37 @@ def qk_rope_pairs(qkv, B: int, T: int, nq: int, nk: int, d: int, freqs, position
     return q, k_slab, v_slab
 
 
+def head_sample(A, weight, row_lo: int, n_cols: int, cfg: float, bias=None, model: int = MODEL_LUMINA, pos_ids=None, pos_base: int = 2,
+                w: int = 48, h: int = 48, newline_id: int = 8803, eos_id: int = 8196, top_k_filter: int = 0, n_draw: int = 10, draw_u=None, draw_idx=None,
+                packed: Optional["PackedLinearWeight"] = None):
+    """The static drafter's head stage (lantern_head_sample): A [2n, K] bf16 (n cond rows, then n uncond rows) -> head window GEMM + CFG -> processors
+    -> softmax -> n_draw draws without replacement per row from injected uniforms draw_u [n, n_draw] f64 (or the injected indices draw_idx).
+    Returns (probs [n, V] f32, ss_token [n, n_draw] i64, ss_prob [n, n_draw] f32)."""
+    A = _dev(A, torch.bfloat16, "A")
+    weight = _dev(weight, torch.bfloat16, "weight")
+    n = A.shape[0] // 2
+    K, V = A.shape[1], weight.shape[0]
+    dev = A.device
+    ws = torch.empty((n, n_cols), dtype=torch.bfloat16, device=dev)
+    probs = torch.empty((n, V), dtype=torch.float32, device=dev)
+    tok = torch.empty((n, n_draw), dtype=torch.int64, device=dev)
+    prob = torch.empty((n, n_draw), dtype=torch.float32, device=dev)
+    b = None if bias is None else _dev(bias, torch.bfloat16, "bias").contiguous()
+    pos = None if pos_ids is None else _dev(pos_ids, torch.int64, "pos_ids").contiguous()
+    du = None if draw_u is None else _dev(draw_u, torch.float64, "draw_u").contiguous()
+    di = None if draw_idx is None else _dev(draw_idx, torch.int64, "draw_idx").contiguous()
+    if packed is not None and (packed.K != K or packed.n_rows != n_cols or packed.pair_rows):
+        raise _lib.LanternError("head_sample: the packed weight is not the window rows of this head")
+    sk = _sk_workspace(dev)
+    wt = weight if packed is None else packed.data
+    check(_lib.lib().lantern_head_sample(C.c_void_p(A.contiguous().data_ptr()), C.c_void_p(wt.data_ptr()), C.c_void_p(_ptr(b)), n, K, int(row_lo), int(n_cols), V,
+                                         C.c_float(cfg), int(model), C.c_void_p(_ptr(pos)), C.c_int64(pos_base), w, h, newline_id, eos_id, int(top_k_filter),
+                                         int(n_draw), C.c_void_p(_ptr(du)), C.c_void_p(_ptr(di)), C.c_void_p(ws.data_ptr()), C.c_void_p(probs.data_ptr()),
+                                         C.c_void_p(tok.data_ptr()), C.c_void_p(prob.data_ptr()), int(packed is not None), C.c_void_p(sk.data_ptr()),
+                                         C.c_size_t(sk.numel()), _stream()), "head_sample")
+    return probs, tok, prob
+
+
 def head_expand(A, weight, row_lo: int, n_cols: int, cfg: float, bias=None, model: int = MODEL_LUMINA, pos_ids=None, pos_base: int = 2,
                 w: int = 48, h: int = 48, newline_id: int = 8803, eos_id: int = 8196, top_k_filter: int = 0, scores_in=None, top_k: int = 10,
                 packed: Optional["PackedLinearWeight"] = None, streamk: bool = True):

@@ -334,6 +334,23 @@ def sample_static(probs, idx):
     return out
 
 
+def sample_draws(p, us):
+    """Model.sample's k draws WITHOUT replacement from one row's distribution p [V] (cnets_lumina_mgpt.py:936-955: torch.multinomial(probs, k,
+    replacement=False)), restated on INJECTED uniforms us [k] (SURVEY 8a RNG contract: the device RNG behind torch.multinomial is not reproducible
+    across devices): draw j is the inverse CDF (token-id order, f64 running sum -- lo_sample_inverse_cdf) of p with the j tokens already drawn
+    removed.  Successive inverse-CDF draws without replacement are Plackett-Luce distributed, as torch.multinomial's are.  Out of mass (fewer
+    positive entries than draws): the lowest ids >= `first positive or 0` not drawn yet is NOT restated here -- the callers' rows have more than k
+    positive entries.  Returns (idx [k] int64, conditional probabilities [k] f32 = sample_static's arithmetic)."""
+    q = _c(p, np.float32).copy()
+    idx = []
+    for u in us:
+        t = sample_inverse_cdf(q, float(u))
+        idx.append(t)
+        q[t] = 0.0
+    idx = np.asarray(idx, np.int64)
+    return idx, sample_static(_c(p, np.float32)[None], idx[None])[0]
+
+
 def expand_dynamic(logits, scores_in, top_k=10):
     """One EAGLE-2 expansion depth (cnets_llamagen.py:798-820)."""
     logits = _c(logits, np.float32)

@@ -569,3 +569,90 @@ def test_depth_plan_equals_the_python_depth_loop(model_type, V, H, heads, depth,
     for c, (a, b) in enumerate(zip(py, pl)):
         for x, y in zip(a, b):
             assert x.shape == y.shape and torch.equal(x, y), (c, x, y)
+
+
+@pytest.mark.parametrize("model_type,V,H,heads,tree", [("lumina_mgpt", 65536, 256, 2, "mc_sim_7b_63"), ("anole", 65536, 256, 4, "naive_extend_57"),
+                                                       ("llamagen", 16384, 128, 2, "naive_extend_57"), ("lumina_mgpt", 65536, 256, 4, "naive_extend_57"),
+                                                       ("llamagen", 16384, 128, 2, "mc_sim_7b_63")])
+def test_static_plan_equals_the_python_static_loop(model_type, V, H, heads, tree, monkeypatch):
+    """Round 5: the static-tree loops (Lumina's default eagle_version 1: topK_generate(tree_type="static"), cnets_lumina_mgpt.py:1245-1328; LlamaGen / Anole
+    topK_genrate_v1, cnets_llamagen.py:944-1023 -- BASELINE config 4's LANTERN++ drafting) through StaticDraftPlan -- ONE lantern_head_sample for the root
+    row, then ONE lantern_draft_depth per tree level -- against the Python level loop (sample -> cat -> repeat_hidden -> forward -> head -> processors)
+    fed the SAME draws: the same conditional probabilities and drafter distributions at every level (5e-5), hence the same forward inputs through the
+    tree's tables, over three consecutive drafting calls; exactly one C call per level."""
+    from transformers.generation.logits_process import LogitsProcessorList, TopKLogitsWarper
+    from lantern_amd.drafters import choices
+    dev, bf = torch.device("cuda"), torch.bfloat16
+    cfg = types.SimpleNamespace(vocab_size=V, hidden_size=H, pad_token_id=None, num_hidden_layers=1, num_attention_heads=heads, num_key_value_heads=heads,
+                                intermediate_size=2 * H, max_position_embeddings=512, rms_norm_eps=1e-5, model_parallel_size=1, input_type="t2i")
+    torch.manual_seed(13)
+    mdl = cnets.Model(cfg, total_tokens=40, depth=4, top_k=CS.TOPK, model_type=model_type).to(dev).to(bf)
+    mdl.init_tree(getattr(choices, tree))
+    levels = [len(t) for t in mdl.tree_buffer["tree_indices"]]
+    head = torch.nn.Linear(H, V, bias=False).to(dev).to(bf)
+    proc = LogitsProcessorList([TopKLogitsWarper(300)])
+    lum = [None, types.SimpleNamespace(image_top_k=300)]
+    k = CS.TOPK
+
+    def run(plan_on):
+        mdl.use_depth_plan = plan_on
+        mdl.reset_kv()
+        outs, total = [], 7
+        g = torch.Generator(device="cuda").manual_seed(5)
+        for c in range(3):
+            n_new = total if c == 0 else 2
+            hid = torch.randn(2, n_new, H, device=dev, dtype=bf, generator=g)
+            ids = torch.randint(4, 8000, (2, total + 1), device=dev, generator=g)
+            state["call"] = c
+            if model_type == "lumina_mgpt":
+                am = torch.ones(2, total, dtype=torch.bool, device=dev)
+                am[1, :2] = False
+                out = mdl.topK_generate(hid[:1], hid[1:], ids[:1], head, lum, attention_mask=am, tree_type="static")
+            elif model_type == "anole":
+                am = torch.ones(2, total, dtype=torch.bool, device=dev)
+                am[1, :1] = False
+                out = mdl.topK_genrate_v1(hid, ids, head, proc, 3.0, input_position_diff=torch.ones((), dtype=torch.long, device=dev), attention_mask=am)
+            else:
+                out = mdl.topK_genrate_v1(hid, ids, head, proc, 3.0)
+            outs.append((out[0].clone(), out[1].clone(), [o.clone() for o in out[2]]))
+            total += 2
+        return outs
+    state = {"call": 0}
+    n_calls = [0]
+    orig = cnets.StaticDraftPlan.run_level
+    monkeypatch.setattr(cnets.StaticDraftPlan, "run_level", lambda self, *a: (n_calls.__setitem__(0, n_calls[0] + 1), orig(self, *a))[1])
+    ug = torch.Generator(device="cuda").manual_seed(77)
+    mdl.static_draw_uniforms = lambda R, kk: torch.rand((R, kk), dtype=torch.float64, device=dev, generator=ug)
+    pl = run(True)
+    assert n_calls[0] == 3 * len(levels), (n_calls, levels)
+    R = 1 + sum(levels)
+    for tok, prob, ol in pl:
+        assert tok.shape == (R, k) and prob.shape == (R, k) and [o.shape[0] for o in ol] == [1] + levels
+        full = torch.cat(ol)
+        assert torch.allclose(full.sum(-1), torch.ones(R, device=dev), atol=1e-5)
+        p = full.gather(1, tok)
+        assert (p > 0).all() and all(len(set(r)) == k for r in tok.tolist())            # k distinct draws with mass, in every row
+    # ---- the Python loop on the same draws
+    off = [0, 1] + [1 + sum(levels[:i + 1]) for i in range(len(levels))]
+    seen = {"n": 0}
+
+    def fake_sample(logits, logits_processor=None, k=1):
+        if logits_processor is not None and not isinstance(logits_processor, (list, tuple)):
+            logits = logits_processor(None, logits)
+        probs = torch.softmax(logits.float().view(-1, logits.shape[-1]), dim=-1)
+        lvl = seen["n"] % (len(levels) + 1)
+        seen["n"] += 1
+        idx = pl[state["call"]][0][off[lvl]:off[lvl + 1]]
+        assert idx.shape[0] == probs.shape[0]
+        from lantern_amd import ops as O
+        return idx, O.sample_static(probs, idx), probs
+    monkeypatch.setattr(mdl, "sample", fake_sample)
+    py = run(False)
+    assert seen["n"] == 3 * (len(levels) + 1)
+    for c, ((t0, p0, o0), (t1, p1, o1)) in enumerate(zip(py, pl)):
+        # (tolerance: the two forms split the tree attention's keys differently -- the plan sizes its workspace for 64 query rows -- so a hidden value
+        # can differ by one bf16 ulp and with it a logit: ~1e-5 on a probability of a few 1e-3; a wrong table entry or position moves them by 1e-2)
+        assert torch.equal(t0, t1)
+        assert torch.allclose(p0, p1, rtol=2e-2, atol=5e-5), (c, (p0 - p1).abs().max())
+        for lvl, (a, b) in enumerate(zip(o0, o1)):
+            assert a.shape == b.shape and torch.allclose(a, b, rtol=0, atol=5e-5), (c, lvl, (a - b).abs().max())

@@ -251,3 +251,71 @@ def test_head_expand_fused_equals_the_three_step_composition(n, K, special, form
     assert torch.equal(torch.isfinite(fused[1]), fin)
     assert torch.allclose(fused[1][fin], ref[1][fin], rtol=0, atol=2e-6)
     assert torch.allclose(fused[3][torch.isfinite(ref[3])], ref[3][torch.isfinite(ref[3])], rtol=0, atol=2e-6)
+
+
+# ----------------------------------------------------------------------------- static drafter: head + sample (round 5)
+@pytest.mark.parametrize("model,n,K,tk,special", [("lumina", 10, 512, 2000, ""), ("lumina", 1, 4096, 2000, ""), ("lumina", 8, 256, 2000, "newline"),
+                                                  ("lumina", 4, 128, 2000, "eos"), ("anole", 16, 256, 2000, ""), ("anole", 13, 128, 0, ""),
+                                                  ("llamagen", 16, 256, 300, ""), ("llamagen", 1, 1280, 2000, ""), ("lumina", 5, 64, 12, "few")])
+def test_head_sample_vs_the_oracle_behind_the_gemm(model, n, K, tk, special):
+    """lantern_head_sample (the static drafter's head stage: cnets_lumina_mgpt.py:1234-1243 + Model.sample :936-955) against the oracle behind the head's
+    GEMM: the rows' distributions = softmax of the oracle's processed logits (<= 1e-6), forced rows one-hot; the draws = the oracle's successive
+    inverse-CDF draws on the SAME injected uniforms (exact, taken on the kernel's own distribution so that a last-ulp difference of a probability
+    cannot move a crossing), conditional probabilities = lo_sample_static's arithmetic; and with injected indices the indices come back as given."""
+    torch.manual_seed(100 * n + K + tk)
+    V, lo, W = (16384, 0, 16384) if model == "llamagen" else (65536, 4, 8192)
+    mid = {"lumina": ops.MODEL_LUMINA, "anole": ops.MODEL_ANOLE, "llamagen": ops.MODEL_PLAIN}[model]
+    A = (0.5 * torch.randn(2 * n, K, device="cuda")).to(torch.bfloat16)
+    Wt = (0.3 * torch.randn(V, K, device="cuda")).to(torch.bfloat16)
+    bias = (0.1 * torch.randn(V, device="cuda")).to(torch.bfloat16)
+    if special == "few":          # 15 live logits, top-k 12: hardly more positive entries than draws
+        Wt[lo + 15:lo + W] = 0
+        bias[lo + 15:lo + W] = -30000.0
+    pos = None
+    if model == "lumina":
+        pos = torch.full((n,), 2 + 3, device="cuda", dtype=torch.int64) + torch.arange(n, device="cuda")
+        if special == "newline":
+            pos[2] = 2 + 48
+        if special == "eos":
+            pos[1] = 2 + 49 * 48
+    k = 10
+    u = torch.rand((n, k), dtype=torch.float64, device="cuda")
+    pk = ops.pack_linear_weight(Wt[lo:lo + W].contiguous()) if K % 64 == 0 else None
+    probs, tok, prob = ops.head_sample(A, Wt, lo, W, 3.0, bias=bias, model=mid, pos_ids=pos, pos_base=2, top_k_filter=min(tk, V), n_draw=k, draw_u=u, packed=pk)
+    win = ops.linear_rows_streamk(A, pk if pk is not None else Wt[lo:lo + W].contiguous(), bias=bias[lo:lo + W].contiguous())
+    if model == "lumina":
+        bits = np.zeros((2 * n, V), np.uint16)
+        bits[:, lo:lo + W] = win.cpu().view(torch.int16).numpy().view(np.uint16)
+        rows = oracle.cfg_mask_topk(bits[:n], bits[n:], 3.0, model=oracle.MODEL_LUMINA, pos_ids=pos.cpu().numpy(), pos_base=2, w=48, h=48, img_lo=lo,
+                                    img_hi=lo + W, newline_id=8803, eos_id=8196, top_k=tk, bf16=True)
+    else:
+        bf = lambda t: t.to(torch.bfloat16).float()
+        c, uu = win[:n].float(), win[n:].float()
+        mix = torch.full((n, V), float("-inf"), dtype=torch.float32, device="cuda")          # (masked ids carry no probability either way)
+        mix[:, lo:lo + W] = bf(uu + bf(3.0 * bf(c - uu)))
+        if tk > 0:
+            kth = torch.topk(mix, min(tk, V), dim=-1).values[:, -1:]
+            mix = mix.masked_fill(mix < kth, float("-inf"))
+        rows = mix.cpu().numpy()
+    r64 = rows.astype(np.float64)
+    e = np.exp(r64 - r64.max(-1, keepdims=True))
+    want = (e / e.sum(-1, keepdims=True)).astype(np.float32)
+    got = probs.cpu().numpy()
+    assert np.abs(got - want).max() <= 1e-6
+    assert np.abs(got.sum(-1) - 1).max() <= 1e-5
+    tok_h, prob_h, u_h = tok.cpu().numpy(), prob.cpu().numpy(), u.cpu().numpy()
+    for r in range(n):
+        hot = int(np.argmax(got[r])) if got[r].max() == 1.0 else -1
+        if hot >= 0 and model == "lumina" and special in ("newline", "eos") and hot in (8803, 8196):
+            assert tok_h[r, 0] == hot and prob_h[r, 0] == 1.0 and (prob_h[r, 1:] == 0).all()
+            assert len(set(tok_h[r].tolist())) == k and ((tok_h[r, 1:] >= lo) & (tok_h[r, 1:] < lo + W)).all()
+            continue
+        idx, cp = oracle.sample_draws(got[r], u_h[r])
+        assert np.array_equal(tok_h[r], idx), (r, tok_h[r], idx)
+        assert np.array_equal(prob_h[r], cp)
+        assert len(set(idx.tolist())) == k and (got[r][idx] > 0).all()
+    # injected indices come back as given, with their conditional probabilities
+    inj = torch.stack([torch.randperm(W, device="cuda")[:k] + lo for _ in range(n)])
+    probs2, tok2, prob2 = ops.head_sample(A, Wt, lo, W, 3.0, bias=bias, model=mid, pos_ids=pos, pos_base=2, top_k_filter=min(tk, V), n_draw=k, draw_idx=inj, packed=pk)
+    assert torch.equal(tok2, inj) and torch.equal(probs2, probs)
+    assert np.array_equal(prob2.cpu().numpy(), oracle.sample_static(got, inj.cpu().numpy()))

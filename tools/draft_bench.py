@@ -2,7 +2,10 @@
 top_k tokens each, the head expansion after every step, the tree finalisation) at the reference's model sizes, from Python, wall clock:
 microseconds per cycle and per drafting depth, with the GPU time of the same kernels (HIP events around the cycle) beside it.
 
-usage: draft_bench.py [lumina|anole|llamagen] [cached positions] [cycles]"""
+`<model>_static`: the static-tree loop (EAGLE v1 -- Lumina's default eagle_version with mc_sim_7b_63, generate_images.py:59; Anole / LlamaGen LANTERN++
+static drafting with naive_extend_57, BASELINE config 4) through StaticDraftPlan: one lantern_head_sample + one lantern_draft_depth per tree level.
+
+usage: draft_bench.py [lumina|anole|llamagen][_static] [cached positions] [cycles]"""
 import json
 import os
 import sys
@@ -16,6 +19,8 @@ import torch
 from lantern_amd.drafters import cnets
 
 model = sys.argv[1] if len(sys.argv) > 1 else "lumina"
+static = model.endswith("_static")
+model = model[:-7] if static else model
 S0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1200
 cycles = int(sys.argv[3]) if len(sys.argv) > 3 else 30
 dev, bf = torch.device("cuda"), torch.bfloat16
@@ -29,7 +34,13 @@ else:
     depth, mt = (5, "lumina_mgpt") if model == "lumina" else (4, "anole")
 torch.manual_seed(0)
 mdl = cnets.Model(cfg, total_tokens=59, depth=depth, top_k=10, model_type=mt).to(dev).to(bf)
-mdl.init_tree()
+if static:
+    from lantern_amd.drafters import choices
+    tree_name = "mc_sim_7b_63" if model == "lumina" else "naive_extend_57"
+    mdl.init_tree(getattr(choices, tree_name))
+    depth = len(mdl.tree_buffer["tree_indices"])
+else:
+    mdl.init_tree()
 head = torch.nn.Linear(cfg.hidden_size, cfg.vocab_size, bias=False).to(dev).to(bf)
 H = cfg.hidden_size
 from transformers.generation.logits_process import LogitsProcessorList, TopKLogitsWarper
@@ -43,12 +54,13 @@ def cycle(n_new, total):
     if model == "lumina":
         ids = torch.randint(4, 8000, (1, total + 1), device=dev)
         am = torch.ones(2, total, dtype=torch.bool, device=dev)
-        return mdl.topK_generate(hid[:1], hid[1:], ids, head, lum_proc, attention_mask=am, tree_type="dynamic")
+        return mdl.topK_generate(hid[:1], hid[1:], ids, head, lum_proc, attention_mask=am, tree_type="static" if static else "dynamic")
     ids = torch.randint(4, 8000, (2, total + 1), device=dev)
+    gen = mdl.topK_genrate_v1 if static else mdl.topK_genrate
     if model == "anole":
-        return mdl.topK_genrate(hid, ids, head, proc, 3.0, input_position_diff=torch.zeros((), dtype=torch.long, device=dev),
-                                attention_mask=torch.ones(2, total, dtype=torch.bool, device=dev))
-    return mdl.topK_genrate(hid, ids, head, proc, 3.0)
+        return gen(hid, ids, head, proc, 3.0, input_position_diff=torch.zeros((), dtype=torch.long, device=dev),
+                   attention_mask=torch.ones(2, total, dtype=torch.bool, device=dev))
+    return gen(hid, ids, head, proc, 3.0)
 
 
 total = S0 if model != "llamagen" else 120 + 20
@@ -66,5 +78,7 @@ for _ in range(cycles):
 e1.record()
 torch.cuda.synchronize()
 wall = (time.perf_counter() - t0) / cycles
-print(json.dumps({"model": model, "cached_positions": S0, "depth": depth, "us_per_cycle_wall": 1e6 * wall, "us_per_depth_wall": 1e6 * wall / (depth + 1),
+plan = mdl.__dict__.get("_splan" if static else "_plan")
+print(json.dumps({"model": model + ("_static" if static else ""), "tree": (tree_name if static else "EAGLE-2 dynamic"), "one_c_call_per_depth": plan is not None,
+                  "levels": ([len(t) for t in mdl.tree_buffer["tree_indices"]] if static else None), "cached_positions": S0, "depth": depth, "us_per_cycle_wall": 1e6 * wall, "us_per_depth_wall": 1e6 * wall / (depth + 1),
                   "us_per_cycle_stream": 1e3 * e0.elapsed_time(e1) / cycles, "drafting_path": type(mdl.layers[0]).__name__}))

@@ -285,6 +285,11 @@ typedef struct lantern_ep_window {
     const uint8_t *raw_pre;       /* [dev] [rows_per_seq]: 0 = post-process the node's row on demand; 1 + d = it is in raw_probs, prepared for a node
                                      at depth d (static trees: the depth is not checked, write 1; raw_pos_per_seq: used only when the
                                      sequence's node really sits at depth d, i.e. raw_pos_ids[node] - raw_pos_ids[0] == d) */
+    /* optional: the verdict of every sequence ALSO written where the host can read it without a copy or a stream synchronisation -- pinned
+     * (host-coherent) memory, 16 int32 per sequence: [0] best, [1] accept_len, [2..7] counters, [8..9] the bonus token (int64), [10] = 1 written LAST
+     * behind a system-scope fence.  The caller zeroes word 10 before the launch and polls it: the record is visible as soon as the walk ends,
+     * while the commit kernel behind it still runs (the reference reads these values with ~6 `.item()` syncs per tried candidate). */
+    int32_t *verdict_host;
 } lantern_ep_window;
 
 /* O8 windowed.  buf->logits is [B, rows_per_seq, win_len]; buf->sample_p may be NULL (if given, the dense
@@ -391,6 +396,13 @@ typedef struct lantern_step_group {
     /* with ep_win.rows_kind == LANTERN_ROWS_RAW_BF16: the nodes whose rows are post-processed up front, together with the candidate
      * assembly, in ONE launch (lantern_prepare_step) -- the root and the most likely children; NULL / 0: none (all rows on demand) */
     const int32_t *node_list; int32_t n_list, flags;       /* dynamic groups: [2 * n_list] = the nodes, then the depth each is assumed to sit at; flags: LANTERN_STEP_* */
+    /* O10 extras (all optional, NULL = off) -- what the reference's loop body does with torch ops around update_inference_inputs:
+     *  hidden_uncond: the unconditional pass's hidden rows [B, N, H] as their own pointer (then `hidden` is the conditional pass's [B, N, H] and
+     *    hid_groups must be 2): the two passes' outputs are not stacked into one [B, 2, N, H] tensor first (ea_model_lumina_mgpt.py:748-750);
+     *  ids_buf [B, ids_stride] i64 + ids_len [B]: `input_ids = cat(input_ids, accepted tokens)` (:763-767) as an in-place append -- the accept_len + 1
+     *    tokens of the chosen path go to ids_buf[b][ids_len[b] ...], and the bonus token (ep_win.token) behind them, where the drafter's
+     *    `cat(input_ids, token)` (:781-785) expects it.  A sequence whose walk reported a status appends nothing. */
+    const void *hidden_uncond; int64_t *ids_buf; int64_t ids_stride; const int64_t *ids_len;
     const lantern_step_dynamic *dyn;      /* NULL: a static tree (ss_token / tree_indices / retrieve), or -- flags & LANTERN_STEP_CANDIDATES_READY, ss_token
                                              NULL -- candidates the caller assembled itself: `cand` [B,P,D] and `retrieve` [P,D] are taken as they are
                                              (a tree that came with its token list, ea_model_llamagen.py:1125-1131; or lantern_gather_candidates called

@@ -933,6 +933,14 @@ __device__ __forceinline__ int epw_body(const EpwArgs &args, const int b) {
         if (ka->buf.cursor) ka->buf.cursor[b] = ucur0 + n_used;
         if (ka->win.out_tok) ka->win.out_tok[b] = out_tok;
         if (ka->win.out_mass) ka->win.out_mass[b] = out_mass;
+        if (ka->win.verdict_host) {          // the same verdict where the host polls it (pinned memory): record first, the ready word last
+            volatile int32_t *vh = ka->win.verdict_host + (size_t)b * 16;
+            const long long tk = (k_u_bonus && k_token && status == LANTERN_ST_OK) ? (long long)k_token[b] : -1ll;
+            vh[0] = best; vh[1] = a - 1; vh[2] = n_levels; vh[3] = n_tried; vh[4] = n_rej; vh[5] = n_used; vh[6] = from_residual; vh[7] = status;
+            vh[8] = (int32_t)(tk & 0xffffffffll); vh[9] = (int32_t)(tk >> 32);
+            __threadfence_system();
+            vh[10] = 1;
+        }
     }
     return (best << 8) | a;          // the verdict (uniform): best path, rows kept = accept_len + 1
 }

@@ -177,20 +177,37 @@ __device__ __forceinline__ void kv_gather_slabs(int s0, int n_slabs, void *const
 // models/ea_model_lumina_mgpt.py:748-750,773-785.
 // Copy-only form (no bonus-token draw: the windowed evaluate_posterior draws it): one workgroup per (sequence, cond/uncond,
 // depth) row so the 2*D rows of every sequence move in parallel across the chip instead of through one CU.
+// Optional extras of the commit (lantern_step_group: hidden_uncond, ids_buf / ids_stride / ids_len, the bonus token): all NULL = off.
+struct CommitExtras {
+    const uint4 *hidden_g1;          // the second group's rows [B, N, H] as their own pointer (then `hidden` is [B, N, H] too)
+    int64_t *ids_buf;                // [B, ids_stride]: the accepted tokens (+ the bonus token) appended in place
+    int64_t ids_stride;
+    const int64_t *ids_len;          // [B] tokens already in ids_buf
+    const int64_t *bonus;            // [B] or NULL
+};
+
 __device__ __forceinline__ void accept_copy_row(int bx, int b, int bst, int n_sel, const uint4 *__restrict__ hidden, int G, int N, int cpr,
                                                 const int64_t *__restrict__ retrieve, int retrieve_per_seq, int P, int D,
                                                 const int64_t *__restrict__ cand, uint4 *__restrict__ out_hidden,
-                                                int64_t *__restrict__ accepted_tokens) {
+                                                int64_t *__restrict__ accepted_tokens, const CommitExtras ex = CommitExtras{nullptr, nullptr, 0, nullptr, nullptr}) {
     const int gi = bx / D, t = bx % D, tid = threadIdx.x;
     if (bx == 0 && accepted_tokens && cand && tid < D)
         accepted_tokens[(size_t)b * D + tid] = tid < n_sel ? cand[(size_t)b * P * D + (size_t)bst * D + tid] : -1;
+    if (bx == 0 && ex.ids_buf && ex.ids_len && cand && n_sel > 0 && tid <= n_sel && tid <= D) {
+        // input_ids = cat(input_ids, accepted tokens) in place, the bonus token behind them (never beyond the buffer)
+        const int64_t at = ex.ids_len[b] + tid;
+        if (at >= 0 && at < ex.ids_stride) {
+            if (tid < n_sel) ex.ids_buf[(size_t)b * ex.ids_stride + at] = cand[(size_t)b * P * D + (size_t)bst * D + tid];
+            else if (ex.bonus) ex.ids_buf[(size_t)b * ex.ids_stride + at] = ex.bonus[b];
+        }
+    }
     if (!hidden || !out_hidden) return;
     uint4 *dst = out_hidden + (((size_t)b * G + gi) * D + t) * cpr;
     if (t < n_sel) {
         int64_t r = retrieve[(retrieve_per_seq ? (size_t)b * P * D : 0) + (size_t)bst * D + t];
         if (r < 0) r += N;
         r = r < 0 ? 0 : (r >= N ? N - 1 : r);
-        const uint4 *src = hidden + (((size_t)b * G + gi) * N + r) * cpr;
+        const uint4 *src = ex.hidden_g1 ? ((gi == 0 ? hidden : ex.hidden_g1) + ((size_t)b * N + r) * cpr) : hidden + (((size_t)b * G + gi) * N + r) * cpr;
         for (int c = tid; c < cpr; c += blockDim.x) dst[c] = src[c];
     } else {
         for (int c = tid; c < cpr; c += blockDim.x) dst[c] = make_uint4(0, 0, 0, 0);
@@ -201,11 +218,12 @@ __device__ __forceinline__ void accept_copy_body(int bx, int b, const uint4 *__r
                                                  const int64_t *__restrict__ retrieve, int retrieve_per_seq, int P, int D,
                                                  const int64_t *__restrict__ cand, const int32_t *__restrict__ best,
                                                  const int32_t *__restrict__ accept_len, uint4 *__restrict__ out_hidden,
-                                                 int64_t *__restrict__ accepted_tokens, const int32_t *__restrict__ counters = nullptr) {
+                                                 int64_t *__restrict__ accepted_tokens, const int32_t *__restrict__ counters = nullptr,
+                                                 const CommitExtras ex = CommitExtras{nullptr, nullptr, 0, nullptr, nullptr}) {
     int n_sel = accept_len[b] + 1;
     if (n_sel > D) n_sel = D;
     if (counters && counters[(size_t)b * 6 + 5] != 0) n_sel = 0;
-    accept_copy_row(bx, b, best[b], n_sel, hidden, G, N, cpr, retrieve, retrieve_per_seq, P, D, cand, out_hidden, accepted_tokens);
+    accept_copy_row(bx, b, best[b], n_sel, hidden, G, N, cpr, retrieve, retrieve_per_seq, P, D, cand, out_hidden, accepted_tokens, ex);
 }
 
 }  // namespace lantern

@@ -98,7 +98,8 @@ __global__ __launch_bounds__(256) void update_inputs_kernel(void *const *__restr
                                                             const int32_t *__restrict__ accept_len, int64_t *__restrict__ new_len,
                                                             const uint4 *__restrict__ hidden, int B, int G, int N, int hid_cpr,
                                                             const int64_t *__restrict__ cand, uint4 *__restrict__ out_hidden,
-                                                            int64_t *__restrict__ accepted_tokens, const int32_t *__restrict__ counters) {
+                                                            int64_t *__restrict__ accepted_tokens, const int32_t *__restrict__ counters,
+                                                            const CommitExtras ex) {
     if ((int)blockIdx.y < n_slabs) {
         kv_gather_body<MAXSEL, U, MODE>(blockIdx.x, gridDim.x, blockIdx.y, slab_ptrs, slab_seq, slab_prev, outer, S_max, chunks_per_row, retrieve,
                                         retrieve_per_seq, P, D, best, accept_len, new_len, counters);
@@ -107,7 +108,7 @@ __global__ __launch_bounds__(256) void update_inputs_kernel(void *const *__restr
         const int per_seq = G * D;
         if (lin < B * per_seq)
             accept_copy_body(lin % per_seq, lin / per_seq, hidden, G, N, hid_cpr, retrieve, retrieve_per_seq, P, D, cand, best, accept_len,
-                             out_hidden, accepted_tokens, counters);
+                             out_hidden, accepted_tokens, counters, ex);
     }
 }
 
@@ -120,7 +121,8 @@ __global__ __launch_bounds__(256) void update_inputs_slabs_kernel(void *const *_
                                                                   const int32_t *__restrict__ accept_len, int64_t *__restrict__ new_len,
                                                                   const uint4 *__restrict__ hidden, int B, int G, int N, int hid_cpr,
                                                                   const int64_t *__restrict__ cand, uint4 *__restrict__ out_hidden,
-                                                                  int64_t *__restrict__ accepted_tokens, const int32_t *__restrict__ counters) {
+                                                                  int64_t *__restrict__ accepted_tokens, const int32_t *__restrict__ counters,
+                                                                  const CommitExtras ex) {
     const int n_kv = (n_slabs + KS - 1) / KS;
     if ((int)blockIdx.x < n_kv) {
         kv_gather_slabs<MAXSEL, KS, 256>((int)blockIdx.x * KS, n_slabs, slab_ptrs, slab_seq, slab_prev, outer, S_max, chunks_per_row, retrieve,
@@ -130,7 +132,7 @@ __global__ __launch_bounds__(256) void update_inputs_slabs_kernel(void *const *_
         const int per_seq = G * D;
         if (lin < B * per_seq)
             accept_copy_body(lin % per_seq, lin / per_seq, hidden, G, N, hid_cpr, retrieve, retrieve_per_seq, P, D, cand, best, accept_len,
-                             out_hidden, accepted_tokens, counters);
+                             out_hidden, accepted_tokens, counters, ex);
     }
 }
 
@@ -405,7 +407,9 @@ namespace lantern {
 int launch_update_inference_inputs(void *const *slab_ptrs, const int32_t *slab_seq, const int64_t *slab_prev, int n_slabs, int elem_bytes, int64_t outer,
                                    int64_t S_max, int64_t d, const int64_t *retrieve, int retrieve_per_seq, int P, int D, const int32_t *best,
                                    const int32_t *accept_len, int64_t *new_len, const void *hidden, int hid_elem_bytes, int B, int G, int N, int H,
-                                   const int64_t *cand, void *out_hidden, int64_t *accepted_tokens, const int32_t *counters, void *stream);
+                                   const int64_t *cand, void *out_hidden, int64_t *accepted_tokens, const int32_t *counters, void *stream,
+                                   const void *hidden_g1 = nullptr, int64_t *ids_buf = nullptr, int64_t ids_stride = 0, const int64_t *ids_len = nullptr,
+                                   const int64_t *bonus = nullptr);
 }
 
 extern "C" int lantern_update_inference_inputs(void *const *slab_ptrs, const int32_t *slab_seq, const int64_t *slab_prev, int n_slabs,
@@ -421,8 +425,12 @@ int lantern::launch_update_inference_inputs(void *const *slab_ptrs, const int32_
                                             int64_t outer, int64_t S_max, int64_t d, const int64_t *retrieve, int retrieve_per_seq, int P, int D,
                                             const int32_t *best, const int32_t *accept_len, int64_t *new_len, const void *hidden, int hid_elem_bytes, int B,
                                             int G, int N, int H, const int64_t *cand, void *out_hidden, int64_t *accepted_tokens, const int32_t *counters,
-                                            void *stream) {
+                                            void *stream, const void *hidden_g1, int64_t *ids_buf, int64_t ids_stride, const int64_t *ids_len,
+                                            const int64_t *bonus) {
     LANTERN_CHECK_ARG(slab_ptrs && slab_seq && slab_prev && retrieve && best && accept_len, "update_inference_inputs: null buffer");
+    if (hidden_g1) LANTERN_CHECK_ARG(hidden && G == 2, "update_inference_inputs: hidden_uncond needs the conditional rows in `hidden` and hid_groups == 2");
+    if (ids_buf) LANTERN_CHECK_ARG(ids_len && cand && ids_stride > 0, "update_inference_inputs: ids_buf needs ids_len, the candidates and ids_stride > 0");
+    const CommitExtras ex{(const uint4 *)hidden_g1, ids_buf, ids_stride, ids_len, bonus};
     LANTERN_CHECK_ARG(n_slabs > 0 && outer > 0 && S_max > 0 && d > 0 && P > 0 && D > 0 && B > 0, "update_inference_inputs: bad sizes");
     LANTERN_CHECK_ARG((d * elem_bytes) % 16 == 0, "update_inference_inputs: KV row bytes %lld must be a multiple of 16", (long long)(d * elem_bytes));
     LANTERN_CHECK_ARG(D <= 8, "update_inference_inputs: D=%d > 8 (use lantern_kv_gather + lantern_accept_gather)", D);
@@ -441,7 +449,7 @@ int lantern::launch_update_inference_inputs(void *const *slab_ptrs, const int32_
 #define UIS_LAUNCH(KS_)                                                                                                                  \
     LANTERN_LAUNCH((update_inputs_slabs_kernel<8, KS_>), dim3(gridx), dim3(256), 0, (hipStream_t)stream, slab_ptrs, slab_seq, slab_prev,  \
                    n_slabs, outer, S_max, cpr, retrieve, retrieve_per_seq, P, D, best, accept_len, new_len, (const uint4 *)hidden, B, g, N, \
-                   hidden ? H * hid_elem_bytes / 16 : 0, cand, (uint4 *)out_hidden, accepted_tokens, counters)
+                   hidden ? H * hid_elem_bytes / 16 : 0, cand, (uint4 *)out_hidden, accepted_tokens, counters, ex)
         if (ks == 8) UIS_LAUNCH(8);
         else if (ks == 4) UIS_LAUNCH(4);
         else if (ks == 2) UIS_LAUNCH(2);
@@ -459,7 +467,7 @@ int lantern::launch_update_inference_inputs(void *const *slab_ptrs, const int32_
 #define UI_LAUNCH(U_, M_)                                                                                                                \
     LANTERN_LAUNCH((update_inputs_kernel<8, U_, M_>), dim3(gx, n_slabs + extra), dim3(256), 0, (hipStream_t)stream, slab_ptrs, slab_seq, \
                    slab_prev, n_slabs, outer, S_max, cpr, retrieve, retrieve_per_seq, P, D, best, accept_len, new_len,                   \
-                   (const uint4 *)hidden, B, g, N, hidden ? H * hid_elem_bytes / 16 : 0, cand, (uint4 *)out_hidden, accepted_tokens, counters)
+                   (const uint4 *)hidden, B, g, N, hidden ? H * hid_elem_bytes / 16 : 0, cand, (uint4 *)out_hidden, accepted_tokens, counters, ex)
     if (uu == 1 && mode == 0) UI_LAUNCH(1, 0);
     else if (uu == 4 && mode == 0) UI_LAUNCH(4, 0);
     else if (uu == 2 && mode == 1) UI_LAUNCH(2, 1);

@@ -738,6 +738,14 @@ __global__ __launch_bounds__(NT) void epn_walk_kernel(const EpnArgs args) {
         if (win.out_tok) win.out_tok[b] = out_tok;
         if (win.out_mass) win.out_mass[b] = out_mass;
         if (win.u_bonus && win.token && status == LANTERN_ST_OK) win.token[b] = token;
+        if (win.verdict_host) {          // the same verdict where the host polls it (pinned memory): record first, the ready word last
+            volatile int32_t *vh = win.verdict_host + (size_t)b * 16;
+            const long long tk = (win.u_bonus && win.token && status == LANTERN_ST_OK) ? (long long)token : -1ll;
+            vh[0] = s_node[4 * node]; vh[1] = depth; vh[2] = c[0]; vh[3] = c[1]; vh[4] = c[2]; vh[5] = c[3]; vh[6] = c[4]; vh[7] = c[5];
+            vh[8] = (int32_t)(tk & 0xffffffffll); vh[9] = (int32_t)(tk >> 32);
+            __threadfence_system();
+            vh[10] = 1;
+        }
     }
 }
 

@@ -12,7 +12,9 @@ const char *last_error();
 int launch_update_inference_inputs(void *const *slab_ptrs, const int32_t *slab_seq, const int64_t *slab_prev, int n_slabs, int elem_bytes, int64_t outer,
                                    int64_t S_max, int64_t d, const int64_t *retrieve, int retrieve_per_seq, int P, int D, const int32_t *best,
                                    const int32_t *accept_len, int64_t *new_len, const void *hidden, int hid_elem_bytes, int B, int G, int N, int H,
-                                   const int64_t *cand, void *out_hidden, int64_t *accepted_tokens, const int32_t *counters, void *stream);
+                                   const int64_t *cand, void *out_hidden, int64_t *accepted_tokens, const int32_t *counters, void *stream,
+                                   const void *hidden_g1 = nullptr, int64_t *ids_buf = nullptr, int64_t ids_stride = 0, const int64_t *ids_len = nullptr,
+                                   const int64_t *bonus = nullptr);
 }
 
 namespace {
@@ -84,7 +86,8 @@ extern "C" int lantern_verify_step(const lantern_step_group *groups, int n_group
         rc = lantern::launch_update_inference_inputs(s.slab_ptrs, s.slab_seq, s.slab_prev, s.n_slabs, s.elem_bytes, s.outer, s.S_max, s.d,
                                                      s.dyn ? s.dyn->retrieve_pd : s.retrieve, s.dyn ? 1 : 0, s.P, s.D, s.ep_buf.best,
                                                      s.ep_buf.accept_len, s.new_len, s.hidden, s.hid_elem_bytes, s.B, s.hid_groups, s.N, s.H,
-                                                     s.cand, s.out_hidden, s.accepted_tokens, s.ep_buf.counters, s.stream);
+                                                     s.cand, s.out_hidden, s.accepted_tokens, s.ep_buf.counters, s.stream, s.hidden_uncond, s.ids_buf,
+                                                     s.ids_stride, s.ids_len, s.ids_buf ? s.ep_win.token : nullptr);
         if (rc) return fail(g, "update_inference_inputs", rc);
     }
     return LANTERN_OK;

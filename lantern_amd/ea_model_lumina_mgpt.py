@@ -499,7 +499,24 @@ class EaLumina_mGPT(nn.Module):
         a.n_slabs, a.elem_bytes, a.outer, a.S_max, a.d = n_sl, s0.element_size(), s0.numel() // (S * d), S, d
         a.accepted_tokens = nx.acc.data_ptr()
         a.hid_groups = 2
+        # ---- host work taken out of the step (round 5): the verdict where the host can poll it, a block of bonus uniforms, input_ids appended in place
+        nx.verdict = nx.verdict_np = None
+        try:
+            nx.verdict = torch.zeros(16, dtype=torch.int32).pin_memory()          # evaluate_posterior writes the record here as well (ep_win.verdict_host)
+            nx.verdict_np = nx.verdict.numpy()
+            w.verdict_host = nx.verdict.data_ptr()
+        except RuntimeError:
+            nx.verdict = nx.verdict_np = None
+        nx.ub, nx.ub_i = None, self._UB_BLOCK
+        nx.ids_buf = None
+        if st.input_ids.device == dev and st.input_ids.dim() == 2:
+            cap = max(int(getattr(st, "max_length", 4096)), L0) + 2 * D + 64
+            nx.ids_buf = torch.zeros((1, cap), dtype=torch.int64, device=dev)
+            nx.ids_buf[:, :L0] = st.input_ids[:1]
+            a.ids_buf, a.ids_stride = nx.ids_buf.data_ptr(), cap
         return nx
+
+    _UB_BLOCK = 4096          # bonus-draw uniforms generated per torch.rand call (one per verify step before)
 
     def _verify_step_native(self, st, nx, lantern, lantern_k, lantern_delta):
         """One verify step: generate_candidates (one call: the target forward needs the tree tokens), the two target forwards, then ONE
@@ -550,21 +567,49 @@ class EaLumina_mGPT(nn.Module):
         else:
             orig = concat_original_prob(ol)
             eb.orig_prob = orig.data_ptr()
-        hid = torch.stack((hidden[0], uhidden[0]))[None]                                   # [1, 2, N, H]
+        h0, h1 = hidden[0], uhidden[0]
+        if h0.is_contiguous() and h1.is_contiguous() and h0.dtype == h1.dtype and h0.shape == h1.shape and h0.device == dev and h1.device == dev:
+            hid, a.hidden, a.hidden_uncond = h0, h0.data_ptr(), h1.data_ptr()          # the two passes' rows as two pointers: nothing is stacked
+        else:
+            hid = torch.stack((h0, h1))[None]                                              # [1, 2, N, H]
+            a.hidden, a.hidden_uncond = hid.data_ptr(), None
         out_h = nx.out_hs[par]
         if out_h is None or out_h.dtype != hid.dtype or out_h.shape[-1] != hid.shape[-1]:
             out_h = nx.out_hs[par] = torch.zeros((1, 2, nx.D, hid.shape[-1]), dtype=hid.dtype, device=nx.dev)
-        a.hidden, a.out_hidden, a.hid_elem_bytes, a.H = hid.data_ptr(), out_h.data_ptr(), hid.element_size(), hid.shape[-1]
+        a.out_hidden, a.hid_elem_bytes, a.H = out_h.data_ptr(), hid.element_size(), hid.shape[-1]
         fifo = self._uniforms()
-        fifo.reserve(nx.P * nx.D)
-        u = torch.rand(1, dtype=torch.float64, device=dev)
-        ew.u_bonus = u.data_ptr()
+        fifo.reserve(nx.N - 1)                                                             # one uniform per tried candidate, every non-root node at most once
+        if nx.ub_i >= self._UB_BLOCK:                                                      # the bonus draws' uniforms: one torch.rand per _UB_BLOCK steps
+            nx.ub, nx.ub_i = torch.rand(self._UB_BLOCK, dtype=torch.float64, device=dev), 0
+            nx.ub_ptr = nx.ub.data_ptr()
+        u = nx.ub[nx.ub_i:nx.ub_i + 1]
+        ew.u_bonus = nx.ub_ptr + 8 * nx.ub_i
+        nx.ub_i += 1
         cur, nxt = nx.lens[par], nx.lens[par ^ 1]
         a.slab_prev, a.new_len, a.seq_len = cur.data_ptr(), nxt.data_ptr(), cur.data_ptr()          # (slab 0 is a cond slab at offset 0: its length is len(input_ids))
-        ops.check(L.lantern_verify_step(nx.group, 1), "verify_step")
-        r = rec.tolist()                                                                   # the step's one host read
-        best, alen, n_used, status, tok = r[0], r[1], r[5], r[7], r[8]
         Lcur = st.input_ids.shape[1]
+        inplace_ids = nx.ids_buf is not None and Lcur + nx.D + 2 <= nx.ids_buf.shape[1]
+        a.ids_buf, a.ids_len = (nx.ids_buf.data_ptr() if inplace_ids else None), (cur.data_ptr() if inplace_ids else None)
+        vh = nx.verdict_np
+        if vh is not None:
+            vh[10] = 0
+        ops.check(L.lantern_verify_step(nx.group, 1), "verify_step")
+        # the step's one host read: the verdict record, polled in pinned memory where evaluate_posterior wrote it (visible as soon as the walk is
+        # done, while the commit still runs) -- no copy, no stream synchronisation; `rec.tolist()` when there is no pinned record
+        r = None
+        if vh is not None:
+            spins = 0
+            while vh[10] == 0:
+                spins += 1
+                if spins > 2_000_000:          # (seconds: something is badly wrong -- take the synchronising read)
+                    break
+            if vh[10] != 0:
+                r = vh[:10].tolist()
+                r[8] = (r[8] & 0xffffffff) | (r[9] << 32)
+        if r is None:
+            r = rec.tolist()
+        best, alen, n_used, status, tok = r[0], r[1], r[5], r[7], r[8]
+        fifo.consumed(n_used)
         if status != 0:
             if status in self._RETRY_DENSE:
                 # a state only the dense kernel represents: nothing was committed (lantern_verify_step commits only walks without a status); the
@@ -580,6 +625,8 @@ class EaLumina_mGPT(nn.Module):
                 hit = self._commit_from_host(st, nx.cand[0], bc, al, hidden, uhidden, sample_p, u, None)
                 nxt.copy_(cur + (int(al) + 1))
                 nx.parity ^= 1
+                if nx.ids_buf is not None and st.input_ids.shape[1] <= nx.ids_buf.shape[1]:          # keep the in-place copy of input_ids in step
+                    nx.ids_buf[:, :st.input_ids.shape[1]] = st.input_ids[:1]
                 return hit
             ops.raise_on_status(rec[2:8].reshape(1, 6))
         n = alen + 1
@@ -589,11 +636,15 @@ class EaLumina_mGPT(nn.Module):
             if (id(clen), off) not in done:
                 clen.fill_(Lcur - off + n)
                 done.add((id(clen), off))
-        accepted = nx.acc[:, :n]
-        if accepted.device != st.input_ids.device:
-            accepted = accepted.to(st.input_ids.device)
-        st.input_ids = torch.cat([st.input_ids[None, 0] if st.parallel else st.input_ids, accepted], dim=-1)
-        self._draft_next(st, out_h[:, 0, :n], out_h[:, 1, :n], tokbuf.reshape(1, 1))          # (views of this parity's buffers: the next step writes the other pair)
+        if inplace_ids:          # the commit appended the accepted tokens and, behind them, the bonus token: views, no torch.cat
+            st.input_ids = nx.ids_buf[:, :Lcur + n]
+            self._draft_next(st, out_h[:, 0, :n], out_h[:, 1, :n], tokbuf.reshape(1, 1), ids_with_token=nx.ids_buf[:, :Lcur + n + 1])
+        else:
+            accepted = nx.acc[:, :n]
+            if accepted.device != st.input_ids.device:
+                accepted = accepted.to(st.input_ids.device)
+            st.input_ids = torch.cat([st.input_ids[None, 0] if st.parallel else st.input_ids, accepted], dim=-1)
+            self._draft_next(st, out_h[:, 0, :n], out_h[:, 1, :n], tokbuf.reshape(1, 1))      # (views of this parity's buffers: the next step writes the other pair)
         st.new_token += n
         st.accept_lengths.append(n)
         return False
@@ -675,9 +726,11 @@ class EaLumina_mGPT(nn.Module):
         nc = len(self.past_key_values_data["cond"])
         return [self.current_length_data["cond"]] * nc + [self.current_length_data["uncond"]] * (len(st.slabs) - nc)
 
-    def _draft_next(self, st, hidden, uhidden, token):
+    def _draft_next(self, st, hidden, uhidden, token, ids_with_token=None):
+        """`ids_with_token`: cat(input_ids, token) as a view of the step's in-place id buffer (the commit kernel appended the token) -- else built here."""
+        ids = ids_with_token if ids_with_token is not None else torch.cat((st.input_ids, token.to(st.input_ids.device)), dim=-1)
         out = self.ea_layer.topK_generate(hidden_states=hidden, uncond_hidden_states=uhidden,
-                                          input_ids=torch.cat((st.input_ids, token.to(st.input_ids.device)), dim=-1), attention_mask=st.attn_mask,
+                                          input_ids=ids, attention_mask=st.attn_mask,
                                           head=self.base_model.lm_head, logits_processors=self.drafter_logits_processors,
                                           tree_type="static" if st.static else "dynamic")
         if st.static:
@@ -714,6 +767,7 @@ class EaLumina_mGPT(nn.Module):
         if not do_sample:
             raise NotImplementedError("Greedy decoding is not implemented yet")   # as the reference (:728-729)
         st = self._prepare_generation(input_ids.clone(), cfg_scale, top_k, kwargs.get("drafter_top_k"), tree_choices)
+        st.max_length = max_length
         self._first_draft(st, logits_processors)
         fifo = self._uniforms()
         fifo.begin()                       # the acceptance uniforms of this prompt start at random's current position

@@ -69,6 +69,15 @@ class UniformFifo:
             self.cursor.zero_()
             self.upper = 0
         self.upper += max_draws
+        self._last = max_draws
+
+    def consumed(self, n_used: int):
+        """The step behind the last reserve() really drew `n_used` uniforms (its verdict says so): the host-side bound becomes exact again, so the
+        window is refilled -- the one host sync of this class -- only when it is really used up (every ~window / 4.5 steps instead of window / max)."""
+        last = getattr(self, "_last", 0)
+        if 0 <= n_used <= last:
+            self.upper -= last - n_used
+            self._last = n_used
 
 
 class NodeLogits:

@@ -5,6 +5,7 @@
 //
 // Reference: models/ea_model_lumina_mgpt.py:610-726 (O8), :781 (bonus token); models/ea_model_llamagen.py:597-669,709-787.
 #pragma once
+#include <type_traits>
 #include "window_dev.h"
 #include "tree_dynamic_dev.h"
 
@@ -30,9 +31,9 @@ namespace lantern {
 
 // NUC: TopPLogitsWarper (top_p in (0, 1)) between the temperature and the top-k of a row that arrives as logits -- HF order Temperature -> TopP ->
 // TopK, drafters/utils.py:36-52; `mass`: top_p_tile's 256 f64 bins in LDS.  A template parameter: the filter keeps a second copy of the row in registers.
-template <int NT, int E4, bool FULLW = false, typename Hook = NoHook, bool NUC = false>
+template <int NT, int E4, bool FULLW = false, typename Hook = NoHook, bool NUC = false, typename SH = EwShared>
 __device__ __forceinline__ void row_softmax_to_lds(float4 (&r)[E4], int hot, bool probs, int win_lo, int W, float temperature, int top_k,
-                                                   int V, float *g, int &out_tok, float &out_mass, EwShared &S, int &ph,
+                                                   int V, float *g, int &out_tok, float &out_mass, SH &S, int &ph,
                                                    const Hook &pre_barrier = Hook(), float top_p = 1.0f, double *mass = nullptr) {
     const int tid = threadIdx.x;
     const float NEG_INF = -__builtin_inff();
@@ -86,6 +87,19 @@ __device__ __forceinline__ void row_softmax_to_lds(float4 (&r)[E4], int hot, boo
     __syncthreads();
 }
 
+// COMPACT builds: a probability row goes straight into g by LDS-DMA (global_load_lds_dwordx4: per-lane source address, LDS destination = wave-uniform
+// base + lane * 16 -- exactly g's token order), no VGPR staging and no ds_write pass.  The caller waits vmcnt(0) and takes the barrier.
+template <int NT, int E4>
+__device__ __forceinline__ void row_dma_to_lds(const float *__restrict__ rowp, float *g) {
+    const int tid = threadIdx.x, wave = tid >> 6;
+#pragma unroll
+    for (int it = 0; it < E4; ++it) {
+        const float *src = rowp + (size_t)(tid + it * NT) * 4;
+        float *dst = g + (size_t)(wave * 64 + it * NT) * 4;          // (wave-uniform)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src, (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
+    }
+}
+
 // LDSIDS: every candidate's neighbour ids are staged in LDS (k + 1 <= EW_PF_K, or LANTERN off), so the serial wave-0
 // section contains no vector-memory instruction -- the compiler then has no reason to drain vmcnt inside it and the
 // drafter-row / id loads issued before it stay in flight across the scan.  !LDSIDS (k > 1023) reads ids from HBM.
@@ -117,6 +131,11 @@ __device__ __forceinline__ int epw_body(const EpwArgs &args, const int b) {
                                                      // candidate -- 0.65 of the first tries -- then costs no row request at all; the latency is another workgroup's problem)
     static_assert(!RAW || (FULLW && (E4 == 4 || E4 == 8)), "raw rows: W = 4 * E4 * NT ids, E4 / 2 sixteen-byte chunks of cond and of uncond per thread");
     constexpr int CH = E4 / 2 > 0 ? E4 / 2 : 1;          // raw rows: 8-id chunks per thread and operand
+    constexpr bool COMPACT = (TPO & 4) != 0;         // the default tree's throughput build on the smallest staged tables (EwSharedCompact, no neighbour
+                                                     // bit mask, 2 prefetch slots): 40 KB of LDS, four workgroups per CU
+    static_assert(!COMPACT || (SPEC == 2 && !RAW), "the compact tables are sized for the reference's default tree mc_sim_7b_63 on probability rows");
+    typedef typename std::conditional<COMPACT, EwSharedCompact, EwShared>::type SH;
+    constexpr int MAX_B = SH::kMaxB, MAX_N = SH::kMaxN, N_UNI = SH::kUni;
     constexpr bool LDSIDS = IDMODE != 0;
     const lantern_ep_params &prm = args.prm;
     const lantern_ep_buffers &buf = args.buf;
@@ -140,9 +159,9 @@ __device__ __forceinline__ int epw_body(const EpwArgs &args, const int b) {
     constexpr bool S_LG = SPEC == 5;                             // LlamaGen's vocabulary instead of Chameleon's
     const int Ps = (SPEC == 2) ? 15 : prm.P, Ds = (SPEC == 2) ? 6 : prm.D, V = SL ? (S_LG ? 16384 : 65536) : prm.V, W = SL ? (S_LG ? 16384 : 8192) : win.win_len,
               lo = SL ? (S_LG ? 0 : 4) : win.win_lo;
-    uint32_t *nbmask = reinterpret_cast<uint32_t *>(g + W + EW_G_EXT);  // W bits: neighbour set (static LlamaGen/Anole: zeroing hits q)
-    EwShared &S = *reinterpret_cast<EwShared *>(reinterpret_cast<char *>(g) + epw_shared_offset(W));
-    int *const Scand = reinterpret_cast<int *>(reinterpret_cast<char *>(&S) + sizeof(EwShared));
+    uint32_t *nbmask = reinterpret_cast<uint32_t *>(g + W + EW_G_EXT);  // W bits: neighbour set (static LlamaGen/Anole: zeroing hits q); not allocated when COMPACT
+    SH &S = *reinterpret_cast<SH *>(reinterpret_cast<char *>(g) + epw_shared_offset(W, !COMPACT));
+    int *const Scand = reinterpret_cast<int *>(reinterpret_cast<char *>(&S) + sizeof(SH));
     const int pd_cap = epw_pd_cap(Ps, Ds);
     int *const Srow = Scand + pd_cap, *const Spidx = Srow + pd_cap, *const Sboff = Spidx + pd_cap;
     float *const Scart = reinterpret_cast<float *>(Sboff + pd_cap);
@@ -162,7 +181,7 @@ __device__ __forceinline__ int epw_body(const EpwArgs &args, const int b) {
     const float NEG_INF = -__builtin_inff();
     const int nz = (k + 1 < prm.table_cols) ? k + 1 : prm.table_cols;   // ids touched per candidate (k summed, k+1 zeroed)
     const bool can_prefetch = LDSIDS && p_lantern;          // (SPEC 1: true at compile time)
-    const bool hot_in_lds = SL ? true : p_rows <= EW_MAX_N;
+    const bool hot_in_lds = SL ? true : p_rows <= MAX_N;
     const bool rows_probs = (SL && !RAW) ? true : win.rows_kind == LANTERN_ROWS_PROBS;
     int ph = 0;
 #ifdef EPW_TRACE
@@ -183,7 +202,7 @@ __device__ __forceinline__ int epw_body(const EpwArgs &args, const int b) {
     float4 rp[E4];              // prefetched row (registers) and the row id it holds
     int rp_rid = -1;
     {
-        constexpr int PD_PER = (EW_MAX_PD + NT - 1) / NT, B_PER = (EW_MAX_B + NT - 1) / NT, N_PER = (EW_MAX_N + NT - 1) / NT;
+        constexpr int PD_PER = ((COMPACT ? 96 : EW_MAX_PD) + NT - 1) / NT, B_PER = (MAX_B + NT - 1) / NT, N_PER = (MAX_N + NT - 1) / NT;
         const int npd = Ps * Ds;
         const int64_t *cand_g = buf.cand + (size_t)b * npd;
         const int32_t *row_g = buf.row_index + (prm.row_index_per_seq ? (size_t)b * npd : 0);
@@ -205,7 +224,7 @@ __device__ __forceinline__ int epw_body(const EpwArgs &args, const int b) {
 #pragma unroll
         for (int u = 0; u < N_PER; ++u) {
             const int t = tid + u * NT;
-            tc_[u] = (is_static && t < p_N && t < EW_MAX_N) ? (int)buf.tree_cand[(size_t)b * p_N + t] : 0;
+            tc_[u] = (is_static && t < p_N && t < MAX_N) ? (int)buf.tree_cand[(size_t)b * p_N + t] : 0;
             hot_[u] = (!RAW && hot_g && hot_in_lds && t < p_rows) ? hot_g[t] : -1;          // (raw rows: the class comes from the position, below; row_hot is not read)
             if (RAW && t < p_rows) {
                 // raw_pre[t] = 1 + the depth the row was prepared for; with per-sequence trees the node has to sit there (its position says so)
@@ -233,20 +252,20 @@ __device__ __forceinline__ int epw_body(const EpwArgs &args, const int b) {
         // round 2
         const double *uni = buf.uniforms + (size_t)b * prm.n_uniforms;
         double un_ = 2.0;                   // never drawn: guarded below
-        if (tid < EW_UNI && ucur0 + tid < prm.n_uniforms) un_ = uni[ucur0 + tid];
+        if (tid < N_UNI && ucur0 + tid < prm.n_uniforms) un_ = uni[ucur0 + tid];
         int bi_[B_PER];
 #pragma unroll
         for (int u = 0; u < B_PER; ++u) {
             const int t = tid + u * NT;
-            bi_[u] = (t < nb_total && t < EW_MAX_B) ? buf.b_idx[t] : 0;
+            bi_[u] = (t < nb_total && t < MAX_B) ? buf.b_idx[t] : 0;
         }
         if (rid1 >= 0 && rid1 < p_rows) {
             if constexpr (RAW) {
                 rp_probs = root_pre && rid1 == 0;
                 if (rp_probs) row_load<NT, E4, FULLW>(raw_p + (size_t)rid1 * W, W, rp);
                 else raw_row_load<NT, CH>(raw_c + (size_t)rid1 * V, raw_u + (size_t)rid1 * V, rp);
-            } else row_load<NT, E4, FULLW>(logits + (size_t)rid1 * W, W, rp);
-            rp_rid = rid1;
+            } else if constexpr (!COMPACT) row_load<NT, E4, FULLW>(logits + (size_t)rid1 * W, W, rp);          // (COMPACT: by LDS-DMA at level 1, once the row's class is known)
+            if constexpr (!COMPACT) rp_rid = rid1;
         }
         // LDS stores
 #pragma unroll
@@ -272,12 +291,12 @@ __device__ __forceinline__ int epw_body(const EpwArgs &args, const int b) {
 #pragma unroll
             for (int u = 0; u < B_PER; ++u) {
                 const int t = tid + u * NT;
-                if (t < nb_total && t < EW_MAX_B) S.bidx[t] = (unsigned short)bi_[u];
+                if (t < nb_total && t < MAX_B) S.bidx[t] = (unsigned short)bi_[u];
             }
 #pragma unroll
             for (int u = 0; u < N_PER; ++u) {
                 const int t = tid + u * NT;
-                if (t < p_N && t < EW_MAX_N) S.tcand[t] = tc_[u];
+                if (t < p_N && t < MAX_N) S.tcand[t] = tc_[u];
             }
             if (tid < Ds - 1) S.opoff[tid] = oo_;
         }
@@ -288,7 +307,7 @@ __device__ __forceinline__ int epw_body(const EpwArgs &args, const int b) {
                 if (t < p_rows) S.hot[t] = hot_[u];
             }
         }
-        if (tid < EW_UNI) S.uni[tid] = un_;
+        if (tid < N_UNI) S.uni[tid] = un_;
         if (tid == 0) {
             g[W + EW_G_ZERO] = 0.0f;
             g[W + EW_G_HUGE] = 3.0e38f;
@@ -336,9 +355,12 @@ __device__ __forceinline__ int epw_body(const EpwArgs &args, const int b) {
         // neighbour ids of the level's candidates: their HBM reads are issued first, the row's loads second; both are in
         // flight together and the ids are written to LDS under the row's last barrier (one exposed latency per level)
         constexpr int PF_PER = (EW_PF_K + NT - 1) / NT;
-        constexpr int PF_LIST = SPEC == 2 ? 4 : EW_PF_C;          // candidates per level staged ahead
+        constexpr int PF_LIST = COMPACT ? 2 : (SPEC == 2 ? 4 : EW_PF_C);          // candidates per level staged ahead (the others restage a slot when their turn comes)
         // position t of a neighbour list -> index into g for the scan (out_tok is final before the ids are staged)
         auto plain_addr = [&](int id) -> unsigned short {
+            // the Chameleon configurations: the table's ids ARE window indices (ids 0..8191 + offset 4 = the window [4, 8196)): no range test, no
+            // out-of-window token can be a neighbour (masked, so that a corrupt table entry still lands inside g)
+            if constexpr (SL && !S_LG) return (unsigned short)(id & 8191);
             const int e = id + off;
             if (e >= lo && e < lo + W) return (unsigned short)(e - lo);
             return (unsigned short)(W + (e == out_tok ? EW_G_OUT : EW_G_ZERO));
@@ -401,7 +423,9 @@ __device__ __forceinline__ int epw_body(const EpwArgs &args, const int b) {
             rid = rid < 0 ? 0 : (rid >= p_rows ? p_rows - 1 : rid);     // a bad row map must not read outside the batch
             const int hot = RAW ? S.hot[rid] : (!hot_g ? -1 : (hot_in_lds ? S.hot[rid] : hot_g[rid]));
             EPW_STAMP(10);
-            if (hot < 0 && rp_rid != rid) {
+            if constexpr (COMPACT) {
+                if (hot < 0) row_dma_to_lds<NT, E4>(logits + (size_t)rid * W, g);          // (g is dead here: every reader of the previous level passed its decision barrier)
+            } else if (hot < 0 && rp_rid != rid) {
                 if constexpr (RAW) {
                     rp_probs = raw_p && S.pre[rid] != 0;
                     if (rp_probs) row_load<NT, E4, FULLW>(raw_p + (size_t)rid * W, W, rp);
@@ -442,8 +466,17 @@ __device__ __forceinline__ int epw_body(const EpwArgs &args, const int b) {
             };
             if constexpr (RAW) {
                 if (!rp_probs) raw_row_to_lds<NT, decltype(stage_ids), NUCLEUS, CH>(rp, hot, win.raw_cfg, win.raw_top_k, V, lo, W, g, out_tok, out_mass, S.redf, S.redd, Shist, ph, stage_ids, prm.top_p, S.redi);
-                else row_softmax_to_lds<NT, E4, FULLW>(rp, hot, true, lo, W, prm.temperature, prm.top_k, V, g, out_tok, out_mass, S, ph, stage_ids);
-            } else row_softmax_to_lds<NT, E4, FULLW, decltype(stage_ids), NUCLEUS>(rp, hot, rows_probs, lo, W, prm.temperature, prm.top_k, V, g, out_tok, out_mass, S, ph, stage_ids, prm.top_p, reinterpret_cast<double *>(Shist));
+                else row_softmax_to_lds<NT, E4, FULLW, decltype(stage_ids), false, SH>(rp, hot, true, lo, W, prm.temperature, prm.top_k, V, g, out_tok, out_mass, S, ph, stage_ids);
+            } else if constexpr (COMPACT) {
+                if (hot < 0) {          // the row is landing in g by DMA: nothing to compute (probability rows are final)
+                    out_tok = -1;
+                    out_mass = 0.0f;
+                    if (tid == 0) g[W + EW_G_OUT] = 0.0f;
+                    stage_ids();
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __syncthreads();
+                } else row_softmax_to_lds<NT, E4, FULLW, decltype(stage_ids), false, SH>(rp, hot, true, lo, W, prm.temperature, prm.top_k, V, g, out_tok, out_mass, S, ph, stage_ids);
+            } else row_softmax_to_lds<NT, E4, FULLW, decltype(stage_ids), NUCLEUS, SH>(rp, hot, rows_probs, lo, W, prm.temperature, prm.top_k, V, g, out_tok, out_mass, S, ph, stage_ids, prm.top_p, reinterpret_cast<double *>(Shist));
             EPW_STAMP(11);
         }
         unsigned long long todo = todo0;
@@ -458,7 +491,7 @@ __device__ __forceinline__ int epw_body(const EpwArgs &args, const int b) {
                 status = LANTERN_ST_TOKEN_OOB;
                 break;
             }
-            if (n_used >= EW_UNI || ucur0 + n_used >= prm.n_uniforms) {
+            if (n_used >= N_UNI || ucur0 + n_used >= prm.n_uniforms) {
                 status = LANTERN_ST_UNIFORMS;
                 break;
             }
@@ -665,15 +698,15 @@ __device__ __forceinline__ int epw_body(const EpwArgs &args, const int b) {
             } else {
                 const int b0 = rdlane(b0_lane, j), b1 = rdlane(b1_lane, j);
                 const int nsib = b1 - b0;
-                if (nsib > EW_MAX_SIB || b1 > EW_MAX_B) {       // beyond the staged tables: say so instead of truncating the list
+                if (nsib > EW_MAX_SIB || b1 > MAX_B) {       // beyond the staged tables: say so instead of truncating the list
                     status = LANTERN_ST_TREE_LIMIT;
                     break;
                 }
                 // window indices of the earlier siblings' tokens, straight from the staged tables (every thread reads the same
                 // LDS words: broadcast, no barrier); the first four live in registers, longer sibling lists loop over LDS
                 auto sib_at = [&](int t) -> int {
-                    const int node = (b0 + t < EW_MAX_B) ? (int)S.bidx[b0 + t] : 0;
-                    const int tok = (node >= 0 && node < EW_MAX_N) ? S.tcand[node] : -1;
+                    const int node = (b0 + t < MAX_B) ? (int)S.bidx[b0 + t] : 0;
+                    const int tok = (node >= 0 && node < MAX_N) ? S.tcand[node] : -1;
                     return (tok >= lo && tok < lo + W) ? (tok - lo) : -1;
                 };
                 int sib_r[4];
@@ -708,7 +741,8 @@ __device__ __forceinline__ int epw_body(const EpwArgs &args, const int b) {
                         }
                     };
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) zero_q_at(sib_r[t]);
+                    for (int t = 0; t < 4; ++t)
+                        if (t < nsib) zero_q_at(sib_r[t]);          // (uniform: a slot without a sibling costs a compare, not the owner search)
                     for (int t = 4; t < nsib; ++t) zero_q_at(sib_at(t));
 #pragma unroll
                     for (int it = 0; it < E4; ++it) qs_loc += (double)q[it].x + (double)q[it].y + (double)q[it].z + (double)q[it].w;
@@ -739,18 +773,18 @@ __device__ __forceinline__ int epw_body(const EpwArgs &args, const int b) {
                         }
                     }
                 }
+                // max(gtp - q, 0): the residual's LDS reads go out together (one wait, not one per chunk), then a packed subtract with the output
+                // clamp per two elements (window_dev.h sub_clamp0: same bits as subtract + compare + select, a fifth of the instructions)
 #pragma unroll
                 for (int it = 0; it < E4; ++it) {
                     const int i4 = tid + it * NT;
-                    gn[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    gn[it] = (FULLW || i4 * 4 < W) ? reinterpret_cast<const float4 *>(g)[i4] : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+#pragma unroll
+                for (int it = 0; it < E4; ++it) {
+                    const int i4 = tid + it * NT;
                     if (FULLW || i4 * 4 < W) {
-                        const float4 qv = q[it];
-                        float4 gv = reinterpret_cast<float4 *>(g)[i4];
-                        float d;
-                        d = gv.x - qv.x; gv.x = d < 0.0f ? 0.0f : d;
-                        d = gv.y - qv.y; gv.y = d < 0.0f ? 0.0f : d;
-                        d = gv.z - qv.z; gv.z = d < 0.0f ? 0.0f : d;
-                        d = gv.w - qv.w; gv.w = d < 0.0f ? 0.0f : d;
+                        const float4 gv = sub_clamp0(gn[it], q[it]);
                         gn[it] = gv;
                         loc += (double)gv.x + (double)gv.y + (double)gv.z + (double)gv.w;
                     }
@@ -786,7 +820,9 @@ __device__ __forceinline__ int epw_body(const EpwArgs &args, const int b) {
         int rid = Srow[best * Ds + (a - 1)];
         rid = rid < 0 ? 0 : (rid >= p_rows ? p_rows - 1 : rid);
         const int hot = RAW ? S.hot[rid] : (!hot_g ? -1 : (hot_in_lds ? S.hot[rid] : hot_g[rid]));
-        if (hot < 0 && rp_rid != rid) {
+        if constexpr (COMPACT) {
+            if (hot < 0) row_dma_to_lds<NT, E4>(logits + (size_t)rid * W, g);
+        } else if (hot < 0 && rp_rid != rid) {
             if constexpr (RAW) {
                 rp_probs = raw_p && S.pre[rid] != 0;
                 if (rp_probs) row_load<NT, E4, FULLW>(raw_p + (size_t)rid * W, W, rp);
@@ -795,8 +831,16 @@ __device__ __forceinline__ int epw_body(const EpwArgs &args, const int b) {
         }
         if constexpr (RAW) {
             if (!rp_probs) raw_row_to_lds<NT, NoHook, NUCLEUS, CH>(rp, hot, win.raw_cfg, win.raw_top_k, V, lo, W, g, out_tok, out_mass, S.redf, S.redd, Shist, ph, NoHook(), prm.top_p, S.redi);
-            else row_softmax_to_lds<NT, E4, FULLW>(rp, hot, true, lo, W, prm.temperature, prm.top_k, V, g, out_tok, out_mass, S, ph);
-        } else row_softmax_to_lds<NT, E4, FULLW, NoHook, NUCLEUS>(rp, hot, rows_probs, lo, W, prm.temperature, prm.top_k, V, g, out_tok, out_mass, S, ph, NoHook(), prm.top_p, reinterpret_cast<double *>(Shist));
+            else row_softmax_to_lds<NT, E4, FULLW, NoHook, false, SH>(rp, hot, true, lo, W, prm.temperature, prm.top_k, V, g, out_tok, out_mass, S, ph);
+        } else if constexpr (COMPACT) {
+            if (hot < 0) {
+                out_tok = -1;
+                out_mass = 0.0f;
+                if (tid == 0) g[W + EW_G_OUT] = 0.0f;
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+            } else row_softmax_to_lds<NT, E4, FULLW, NoHook, false, SH>(rp, hot, true, lo, W, prm.temperature, prm.top_k, V, g, out_tok, out_mass, S, ph);
+        } else row_softmax_to_lds<NT, E4, FULLW, NoHook, NUCLEUS, SH>(rp, hot, rows_probs, lo, W, prm.temperature, prm.top_k, V, g, out_tok, out_mass, S, ph, NoHook(), prm.top_p, reinterpret_cast<double *>(Shist));
     }
     // ---------------------------------------------------------------- epilogue: outputs from LDS
     EPW_STAMP(40);
@@ -842,7 +886,7 @@ __device__ __forceinline__ int epw_body(const EpwArgs &args, const int b) {
         // segment (it, wave) = ids [lo + 4*(it*NT + 64*wave), +256): token order is it-major.  One DPP scan over the
         // E4*NW segment totals (lane q = it*NW + w) gives every segment's start; each thread then picks its E4 starts
         // with uniform-lane reads.
-        static_assert(E4 * NW <= 64, "segment totals fit one wave");
+        static_assert(E4 * NW <= 64 && E4 * NW <= (int)(sizeof(S.samp_tot) / sizeof(double)), "segment totals fit one wave and their LDS slots");
         const int q_it = lane / NW, q_w = lane % NW;
         const double seg = (lane < E4 * NW) ? S.samp_tot[q_w * E4 + (q_it < E4 ? q_it : 0)] : 0.0;
         const double seg_excl = wave_scan_incl_dpp(dpp_mov<0x138>(seg));      // exclusive: scan of the totals shifted up one lane
@@ -962,6 +1006,7 @@ bool epw_launch_generic(int W, int idmode, bool nucleus, const EpwLaunch &l, con
 // epw_throughput.hip: the forms for more sequences per launch than CUs (several workgroups per CU).
 enum EpwThroughput {
     EPW_TP_LUMINA_DEFAULT_TREE = 0, EPW_TP_LUMINA_STATIC, EPW_TP_LUMINA_DYNAMIC, EPW_TP_ANOLE_STATIC,      // 256 threads x 8 float4, three per CU, LATE_Q
+                                                                                                             // (the default tree: COMPACT, four per CU)
     EPW_TP_512_DEFAULT_TREE, EPW_TP_512_PACKED, EPW_TP_512_ID0, EPW_TP_512_ID1, EPW_TP_512_ID2,            // 512 threads at 128 VGPRs, two per CU
     EPW_TP_RAW_GENERIC,                                                                                      // raw rows, 512 threads, two per CU
     EPW_TP_RAW_LUMINA_DEFAULT_TREE, EPW_TP_RAW_LUMINA_STATIC, EPW_TP_RAW_LUMINA_DYNAMIC, EPW_TP_RAW_ANOLE_STATIC,   // raw rows, fixed configurations

@@ -9,10 +9,17 @@
 namespace lantern {
 
 bool epw_launch_throughput(int kind, const EpwLaunch &l, const EpwArgs &args) {
+    static const bool compact = !(getenv("LANTERN_EPW_TP4") && atoi(getenv("LANTERN_EPW_TP4")) == 0);   // tuning knob (diagnostic): 0 = the three-per-CU form
     static const bool raw512 = getenv("LANTERN_EPW_TP_RAW") && atoi(getenv("LANTERN_EPW_TP_RAW")) == 512;   // tuning knob (diagnostic)
 #define TP(...) LANTERN_LAUNCH((epw_kernel<__VA_ARGS__>), l.grid, dim3(NTX), l.lds, l.st, args)
     switch (kind) {
-    case EPW_TP_LUMINA_DEFAULT_TREE: { constexpr int NTX = 256; TP(256, 8, 2, 3, true, false, 2, 1); return true; }
+    case EPW_TP_LUMINA_DEFAULT_TREE:
+        if (compact) {          // the default tree on the smallest staged tables: 40 KB of LDS, 128 VGPRs -- FOUR workgroups per CU
+            constexpr int NTX = 256;
+            const size_t lds4 = epw_shared_offset(8192, false) + sizeof(EwSharedCompact) + (size_t)6 * epw_pd_cap(15, 6) * 4;
+            LANTERN_LAUNCH((epw_kernel<256, 8, 2, 4, true, false, 2, 5>), l.grid, dim3(NTX), lds4, l.st, args);
+        } else { constexpr int NTX = 256; TP(256, 8, 2, 3, true, false, 2, 1); }
+        return true;
     case EPW_TP_LUMINA_STATIC: { constexpr int NTX = 256; TP(256, 8, 2, 3, true, false, 1, 1); return true; }
     case EPW_TP_LUMINA_DYNAMIC: { constexpr int NTX = 256; TP(256, 8, 2, 3, true, false, 3, 1); return true; }
     case EPW_TP_ANOLE_STATIC: { constexpr int NTX = 256; TP(256, 8, 2, 3, true, false, 4, 1); return true; }

@@ -501,11 +501,7 @@ __device__ __forceinline__ void epn_node(const EpnArgs &args, const int b, const
                     const float4 qv = q[it];
                     float4 gv = reinterpret_cast<const float4 *>(g)[i4];
                     if (lazy) gv = dgc(gv);
-                    float d;
-                    d = gv.x - qv.x; gv.x = d < 0.0f ? 0.0f : d;
-                    d = gv.y - qv.y; gv.y = d < 0.0f ? 0.0f : d;
-                    d = gv.z - qv.z; gv.z = d < 0.0f ? 0.0f : d;
-                    d = gv.w - qv.w; gv.w = d < 0.0f ? 0.0f : d;
+                    gv = sub_clamp0(gv, qv);          // max(gtp - q, 0), two elements per instruction (window_dev.h)
                     gn[it] = gv;
                     loc += (double)gv.x + (double)gv.y + (double)gv.z + (double)gv.w;
                 }

@@ -122,6 +122,20 @@ struct FastDiv {
     }
 };
 
+// max(a - b, 0) for a, b in [0, 1] (probabilities; no NaN), two elements per instruction: v_pk_add_f32 with the second operand negated and the
+// output clamp, which bounds a VOP3P float result to [0, 1] -- the upper bound never binds (a - b <= 1), the lower one IS the max with zero.  Same
+// bits as `d = a - b; d < 0 ? 0 : d` (a - b is never -0 for non-negative operands).  The residual update `max(gtp - q, 0)` of evaluate_posterior
+// (ea_model_lumina_mgpt.py:703-705) was a subtract + compare + select per element (10 instructions per float4); this is 2.
+__device__ __forceinline__ f32x2_t sub_clamp0_pk(f32x2_t a, f32x2_t b) {
+    f32x2_t r;
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1] clamp" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ float4 sub_clamp0(float4 a, float4 b) {
+    const f32x2_t lo = sub_clamp0_pk((f32x2_t){a.x, a.y}, (f32x2_t){b.x, b.y}), hi = sub_clamp0_pk((f32x2_t){a.z, a.w}, (f32x2_t){b.z, b.w});
+    return make_float4(lo.x, lo.y, hi.x, hi.y);
+}
+
 // softmax of a register tile over the workgroup: max, exp, f64 sum, one division per element -- the arithmetic
 // of the reference's torch.softmax(row) restated (oracle: lo_softmax_row); shared by O7 (rows emitted as
 // probabilities) and O8 (rows arriving as logits) so that both produce the same bits.
@@ -344,35 +358,41 @@ constexpr int EW_PF_K = 1024;     // ... when k + 1 <= EW_PF_K; otherwise ids ar
 // Fixed-size part of the workgroup's LDS; the five per-(path, depth) tables (cand, row, cart, pidx, boff) follow it, sized
 // by the launch's actual P*D (epw_pd_cap) instead of the 64 x 16 worst case: 20 KB -> ~2 KB for the reference's trees, which
 // is what lets two workgroups share a CU at saturating batch sizes.
-struct alignas(16) EwShared {
-    unsigned short bidx[EW_MAX_B];          // earlier-sibling node ids (< EW_MAX_N)
-    int tcand[EW_MAX_N];
+// PF_C / MAX_B / MAX_N: the staged sizes -- the defaults hold every tree the windowed kernels accept; the COMPACT throughput instance of the reference's
+// default tree (26 nodes, 26 sibling entries, fan-out <= 4) takes the smallest that tree needs, which is what lets FOUR workgroups share a CU.
+template <int PF_C = EW_PF_C, int MAX_B = EW_MAX_B, int MAX_N = EW_MAX_N, int N_UNI = EW_UNI, int N_SAMP = 64>
+struct alignas(16) EwSharedT {
+    static constexpr int kPfC = PF_C, kMaxB = MAX_B, kMaxN = MAX_N, kUni = N_UNI;
+    unsigned short bidx[MAX_B];             // earlier-sibling node ids (< MAX_N)
+    int tcand[MAX_N];
     int opoff[EW_MAX_D];
-    double uni[EW_UNI];
+    double uni[N_UNI];
     double redd[2 * 16];
     float redf[2 * 16];
     int redi[2 * 16];
-    double samp_tot[64];                    // [wave * E4 + it]: per-wave totals of the bonus draw's segments (NW * E4 <= 64)
+    double samp_tot[N_SAMP];                // [wave * E4 + it]: per-wave totals of the bonus draw's segments (NW * E4 <= N_SAMP)
     int dec[2][4];                          // decision words of wave 0: {code, m>0, csm1 bits, -}
     double ubonus[2];                       // [0]: the bonus draw's uniform, fetched with the prologue's first round of loads
-    int hot[EW_MAX_N];                      // row_hot of this sequence's rows (when rows_per_seq <= EW_MAX_N)
-    int pre[EW_MAX_N];                      // LANTERN_ROWS_RAW_BF16: 1 = the row was post-processed up front (win.raw_probs)
+    int hot[MAX_N];                         // row_hot of this sequence's rows (when rows_per_seq <= MAX_N)
+    int pre[MAX_N];                         // LANTERN_ROWS_RAW_BF16: 1 = the row was post-processed up front (win.raw_probs)
     // Prefetched neighbours of a level's candidates as gather indices into g: window index, or a sentinel slot (0 outside the window, the
     // out-of-window one-hot token's mass, 3e38 at positions >= k so that they can never pass `<= tau`).  The raw table ids are not kept: the
     // zeroing after a rejection needs "window index or not" and "is it the out-of-window token", both of which the gather index says; the
     // one id it zeroes beyond the k it sums (position k, whose scan slot is the 3e38 sentinel) keeps its plain index in nbk.  12 KB less LDS per
     // workgroup than with both forms -- what lets three workgroups share a CU.
-    unsigned short nbaddr[EW_PF_C][EW_PF_K];
+    unsigned short nbaddr[PF_C][EW_PF_K];
     unsigned short nbk[8];                  // per slot: plain gather index of neighbour k (the k+1-th, zeroed but never summed)
 };
+typedef EwSharedT<> EwShared;
+typedef EwSharedT<2, 128, 32, 32, 32> EwSharedCompact;          // (256 threads x 8 float4: NW * E4 = 32 segment totals)
 static_assert(EW_PF_C <= 8, "nbk slots");
 
 // g[W + EW_G_ZERO] = 0 (neighbour outside the window), g[W + EW_G_HUGE] = 3e38 (position >= k: never under tau),
 // g[W + EW_G_OUT] = out_mass (neighbour == the one-hot token outside the window): gather targets of the scan
 constexpr int EW_G_ZERO = 0, EW_G_HUGE = 1, EW_G_OUT = 2, EW_G_EXT = 4;
 __host__ __device__ inline int epw_pd_cap(int P, int D) { return (P * D + 1 + 3) & ~3; }      // boff has P*D + 1 entries
-__host__ __device__ inline size_t epw_shared_offset(int W) {
-    size_t o = (size_t)(W + EW_G_EXT) * 4 + (size_t)((W + 31) / 32) * 4;
+__host__ __device__ inline size_t epw_shared_offset(int W, bool with_nbmask = true) {
+    size_t o = (size_t)(W + EW_G_EXT) * 4 + (with_nbmask ? (size_t)((W + 31) / 32) * 4 : 0);      // (nbmask: LANTERN_MODE_STATIC_LG only)
     return (o + 15) & ~(size_t)15;
 }
 

@@ -1014,4 +1014,5 @@ enum EpwThroughput {
 };
 bool epw_launch_throughput(int kind, const EpwLaunch &l, const EpwArgs &args);
 
+
 }  // namespace lantern

@@ -20,7 +20,8 @@ bool epw_launch_throughput(int kind, const EpwLaunch &l, const EpwArgs &args) {
             LANTERN_LAUNCH((epw_kernel<256, 8, 2, 4, true, false, 2, 5>), l.grid, dim3(NTX), lds4, l.st, args);
         } else { constexpr int NTX = 256; TP(256, 8, 2, 3, true, false, 2, 1); }
         return true;
-    case EPW_TP_LUMINA_STATIC: { constexpr int NTX = 256; TP(256, 8, 2, 3, true, false, 1, 1); return true; }
+    case EPW_TP_LUMINA_STATIC:
+        { constexpr int NTX = 256; TP(256, 8, 2, 3, true, false, 1, 1); return true; }
     case EPW_TP_LUMINA_DYNAMIC: { constexpr int NTX = 256; TP(256, 8, 2, 3, true, false, 3, 1); return true; }
     case EPW_TP_ANOLE_STATIC: { constexpr int NTX = 256; TP(256, 8, 2, 3, true, false, 4, 1); return true; }
     case EPW_TP_512_DEFAULT_TREE: { constexpr int NTX = 512; TP(512, 4, 2, 4, true, false, 2); return true; }

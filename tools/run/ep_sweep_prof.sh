@@ -2,7 +2,7 @@
 # rocprofv3 passes of evaluate_posterior alone at the saturating batch (tools/ep_sweep.py, rotating inputs): kernel trace + stats, FETCH_SIZE,
 # WRITE_SIZE and SQ counter groups -- each its own run, kernel trace only.  usage: ep_sweep_prof.sh <tag> <batches> [LANTERN_EPW_TP]
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-TAG=${1:-epsw}; BATCHES=${2:-4096}; export LANTERN_EPW_TP=${3:-1}
+TAG=${1:-epsw}; BATCHES=${2:-4096}; export LANTERN_EPW_TP=${3:-5}
 O=gpurun_out/$TAG
 mkdir -p $O
 [ -f $O/counters.txt ] || rocprofv3 -L > $O/counters.txt 2>&1

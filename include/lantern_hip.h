@@ -403,12 +403,20 @@ typedef struct lantern_step_group {
      *    tokens of the chosen path go to ids_buf[b][ids_len[b] ...], and the bonus token (ep_win.token) behind them, where the drafter's
      *    `cat(input_ids, token)` (:781-785) expects it.  A sequence whose walk reported a status appends nothing. */
     const void *hidden_uncond; int64_t *ids_buf; int64_t ids_stride; const int64_t *ids_len;
+    /* The NEXT step's preparation inside THIS step's commit launch (static trees with node_list, i.e. lantern_prepare_step's form): candidate
+     * assembly and the likely rows of step s + 1 need only step s's verdict (its bonus token = the next root, its accepted length = the next
+     * positions), not its KV rows -- so their workgroups ride in the launch that moves the KV rows, and the step after this one starts with
+     * evaluate_posterior.  prepare_next: the group the next lantern_verify_step call will pass for these sequences (its ss_token / cond / uncond /
+     * sample_token ... describe step s + 1; its seq_len must be THIS step's lengths -- the kernel adds the accepted tokens itself; its cand buffer
+     * must not be the one this step's commit reads); that call then carries LANTERN_STEP_PREPARED in its flags.  NULL: off. */
+    const struct lantern_step_group *prepare_next;
     const lantern_step_dynamic *dyn;      /* NULL: a static tree (ss_token / tree_indices / retrieve), or -- flags & LANTERN_STEP_CANDIDATES_READY, ss_token
                                              NULL -- candidates the caller assembled itself: `cand` [B,P,D] and `retrieve` [P,D] are taken as they are
                                              (a tree that came with its token list, ea_model_llamagen.py:1125-1131; or lantern_gather_candidates called
                                              before the target forward).  A static group with neither is an error, not a silent skip. */
 } lantern_step_group;
 #define LANTERN_STEP_CANDIDATES_READY 1   /* lantern_step_group.flags: skip the O6 stage, `cand` / `retrieve` (/ `cart_prob`, `tree_cand`) are final */
+#define LANTERN_STEP_PREPARED 2           /* the previous call's commit launch already ran this group's lantern_prepare_step (prepare_next) */
 int lantern_verify_step(const lantern_step_group *groups, int n_groups);
 /* O6 + O7 restricted to s->node_list in one launch (bf16 Lumina rows, 8192-id window): candidates -> s->tree_cand / cand / cart_prob,
  * probabilities of the listed rows -> s->out_win, their classes -> s->row_hot.  Called by lantern_verify_step when node_list is set.

@@ -61,7 +61,7 @@ class StepDynamic(C.Structure):
                                              "row_index", "pos_abs")])
 
 
-STEP_CANDIDATES_READY = 1          # lantern_step_group.flags (include/lantern_hip.h)
+STEP_CANDIDATES_READY, STEP_PREPARED = 1, 2          # lantern_step_group.flags (include/lantern_hip.h)
 
 
 class StepGroup(C.Structure):
@@ -81,7 +81,7 @@ class StepGroup(C.Structure):
                 + [(n, C.c_void_p) for n in ("hidden", "out_hidden", "accepted_tokens")]
                 + [(n, C.c_int32) for n in ("hid_elem_bytes", "hid_groups", "H", "reserved1")]
                 + [("node_list", C.c_void_p), ("n_list", C.c_int32), ("flags", C.c_int32)]
-                + [("hidden_uncond", C.c_void_p), ("ids_buf", C.c_void_p), ("ids_stride", C.c_int64), ("ids_len", C.c_void_p)]
+                + [("hidden_uncond", C.c_void_p), ("ids_buf", C.c_void_p), ("ids_stride", C.c_int64), ("ids_len", C.c_void_p), ("prepare_next", C.c_void_p)]
                 + [("dyn", C.POINTER(StepDynamic))])
 
 

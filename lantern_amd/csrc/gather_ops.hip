@@ -4,6 +4,7 @@
 // (the outputs of evaluate_posterior) so the step never round-trips to the host.
 #include "common.h"
 #include "gather_dev.h"
+#include "prep_dev.h"
 #include <cstdlib>
 
 namespace lantern {
@@ -262,6 +263,63 @@ __global__ __launch_bounds__(AG_THREADS) void accept_gather_kernel(const void *_
     }
 }
 
+// The commit launch that ALSO prepares the next step (lantern_step_group.prepare_next): the blocks behind the commit's run lantern_prepare_step's
+// body for step s + 1 -- candidate assembly and the likely rows (prep_dev.h), 256 threads x 4 chunks per row -- which needs step s's verdict only.
+// One kernel boundary less in front of the latency-bound evaluate_posterior of the next step; the rows are produced while the KV rows move.
+template <int MAXSEL, int U, bool NUCLEUS>
+__global__ __launch_bounds__(256) void update_inputs_prep_kernel(void *const *__restrict__ slab_ptrs, const int32_t *__restrict__ slab_seq,
+                                                                 const int64_t *__restrict__ slab_prev, int n_slabs, int64_t outer,
+                                                                 int64_t S_max, int chunks_per_row, const int64_t *__restrict__ retrieve,
+                                                                 int retrieve_per_seq, int P, int D, const int32_t *__restrict__ best,
+                                                                 const int32_t *__restrict__ accept_len, int64_t *__restrict__ new_len,
+                                                                 const uint4 *__restrict__ hidden, int B, int G, int N, int hid_cpr,
+                                                                 const int64_t *__restrict__ cand, uint4 *__restrict__ out_hidden,
+                                                                 int64_t *__restrict__ accepted_tokens, const int32_t *__restrict__ counters,
+                                                                 const CommitExtras ex, int prep_y, const PrepArgs pa) {
+    // the preparation's blocks come FIRST in the grid: they are few and latency-bound (a row's post-process is one long dependent chain), so they must be
+    // dispatched before the thousands of bandwidth-bound commit blocks, not queue behind them (behind them the launch lasted commit + preparation)
+    const int y = (int)blockIdx.y - prep_y;
+    if (y < 0) {
+        const int lin = (int)blockIdx.y * gridDim.x + blockIdx.x;
+        if (lin < pa.B * pa.n_list + pa.B) prep_rows_body<256, 4, NUCLEUS>(pa, lin);
+    } else if (y < n_slabs) {
+        kv_gather_body<MAXSEL, U, 0>(blockIdx.x, gridDim.x, y, slab_ptrs, slab_seq, slab_prev, outer, S_max, chunks_per_row, retrieve,
+                                     retrieve_per_seq, P, D, best, accept_len, new_len, counters);
+    } else {
+        const int lin = (y - n_slabs) * gridDim.x + blockIdx.x;
+        const int per_seq = G * D;
+        if (lin < B * per_seq)
+            accept_copy_body(lin % per_seq, lin / per_seq, hidden, G, N, hid_cpr, retrieve, retrieve_per_seq, P, D, cand, best, accept_len,
+                             out_hidden, accepted_tokens, counters, ex);
+    }
+}
+
+template <int MAXSEL, int KS, bool NUCLEUS>
+__global__ __launch_bounds__(256) void update_inputs_slabs_prep_kernel(void *const *__restrict__ slab_ptrs, const int32_t *__restrict__ slab_seq,
+                                                                       const int64_t *__restrict__ slab_prev, int n_slabs, int64_t outer,
+                                                                       int64_t S_max, int chunks_per_row, const int64_t *__restrict__ retrieve,
+                                                                       int retrieve_per_seq, int P, int D, const int32_t *__restrict__ best,
+                                                                       const int32_t *__restrict__ accept_len, int64_t *__restrict__ new_len,
+                                                                       const uint4 *__restrict__ hidden, int B, int G, int N, int hid_cpr,
+                                                                       const int64_t *__restrict__ cand, uint4 *__restrict__ out_hidden,
+                                                                       int64_t *__restrict__ accepted_tokens, const int32_t *__restrict__ counters,
+                                                                       const CommitExtras ex, int n_prep, const PrepArgs pa) {
+    const int n_kv = (n_slabs + KS - 1) / KS;
+    const int x = (int)blockIdx.x - n_prep;          // (the preparation's blocks first: see update_inputs_prep_kernel)
+    if (x < 0) {
+        prep_rows_body<256, 4, NUCLEUS>(pa, (int)blockIdx.x);
+    } else if (x < n_kv) {
+        kv_gather_slabs<MAXSEL, KS, 256>(x * KS, n_slabs, slab_ptrs, slab_seq, slab_prev, outer, S_max, chunks_per_row, retrieve,
+                                         retrieve_per_seq, P, D, best, accept_len, new_len, counters);
+    } else {
+        const int lin = x - n_kv;
+        const int per_seq = G * D;
+        if (lin < B * per_seq)
+            accept_copy_body(lin % per_seq, lin / per_seq, hidden, G, N, hid_cpr, retrieve, retrieve_per_seq, P, D, cand, best, accept_len,
+                             out_hidden, accepted_tokens, counters, ex);
+    }
+}
+
 // ------------------------------------------------------------------------- O5
 // models/drafters/cnets_lumina_mgpt.py:936-955: p_i / (1 - sum_{j<i} p_j), inf/nan -> -1, clamp [0,1]
 __global__ void sample_static_kernel(const float *__restrict__ probs, const int64_t *__restrict__ idx, int R, int V, int k,
@@ -409,7 +467,7 @@ int launch_update_inference_inputs(void *const *slab_ptrs, const int32_t *slab_s
                                    const int32_t *accept_len, int64_t *new_len, const void *hidden, int hid_elem_bytes, int B, int G, int N, int H,
                                    const int64_t *cand, void *out_hidden, int64_t *accepted_tokens, const int32_t *counters, void *stream,
                                    const void *hidden_g1 = nullptr, int64_t *ids_buf = nullptr, int64_t ids_stride = 0, const int64_t *ids_len = nullptr,
-                                   const int64_t *bonus = nullptr);
+                                   const int64_t *bonus = nullptr, const PrepArgs *prep = nullptr);
 }
 
 extern "C" int lantern_update_inference_inputs(void *const *slab_ptrs, const int32_t *slab_seq, const int64_t *slab_prev, int n_slabs,
@@ -426,7 +484,7 @@ int lantern::launch_update_inference_inputs(void *const *slab_ptrs, const int32_
                                             const int32_t *best, const int32_t *accept_len, int64_t *new_len, const void *hidden, int hid_elem_bytes, int B,
                                             int G, int N, int H, const int64_t *cand, void *out_hidden, int64_t *accepted_tokens, const int32_t *counters,
                                             void *stream, const void *hidden_g1, int64_t *ids_buf, int64_t ids_stride, const int64_t *ids_len,
-                                            const int64_t *bonus) {
+                                            const int64_t *bonus, const PrepArgs *prep) {
     LANTERN_CHECK_ARG(slab_ptrs && slab_seq && slab_prev && retrieve && best && accept_len, "update_inference_inputs: null buffer");
     if (hidden_g1) LANTERN_CHECK_ARG(hidden && G == 2, "update_inference_inputs: hidden_uncond needs the conditional rows in `hidden` and hid_groups == 2");
     if (ids_buf) LANTERN_CHECK_ARG(ids_len && cand && ids_stride > 0, "update_inference_inputs: ids_buf needs ids_len, the candidates and ids_stride > 0");
@@ -441,6 +499,37 @@ int lantern::launch_update_inference_inputs(void *const *slab_ptrs, const int32_
     LANTERN_CHECK_ARG(total < (1ll << 31), "update_inference_inputs: outer * row chunks = %lld does not fit 31 bits", (long long)total);
     LANTERN_CHECK_ARG(S_max < (1ll << 31), "update_inference_inputs: S_max = %lld does not fit 31 bits", (long long)S_max);
     static const int ks_knob = getenv("LANTERN_KV_KS") ? atoi(getenv("LANTERN_KV_KS")) : 4;   // tuning knob (diagnostic): slabs per workgroup, 0 = one workgroup tile per slab
+    const bool prep_nucleus = prep && prep->top_p >= 1e-8f && prep->top_p < 1.0f;
+    const int n_prep = prep ? prep->B * prep->n_list + prep->B : 0;
+    if (prep) LANTERN_CHECK_ARG(prep->W == 8192 && prep->B >= 0, "update_inference_inputs: the next step's preparation rides on the 8192-id window only");
+    if (prep && n_prep > 0 && total <= 4096) {          // small slabs + the next step's preparation
+        const int g = hidden ? G : 1;
+        const int n_commit_x = (n_slabs + 3) / 4 + B * g * D;
+#define UISP_LAUNCH(NUC_)                                                                                                                      \
+    LANTERN_LAUNCH((update_inputs_slabs_prep_kernel<8, 4, NUC_>), dim3(n_commit_x + n_prep), dim3(256), 0, (hipStream_t)stream, slab_ptrs, slab_seq, \
+                   slab_prev, n_slabs, outer, S_max, cpr, retrieve, retrieve_per_seq, P, D, best, accept_len, new_len, (const uint4 *)hidden, B, g, N, \
+                   hidden ? H * hid_elem_bytes / 16 : 0, cand, (uint4 *)out_hidden, accepted_tokens, counters, ex, n_prep, *prep)
+        if (prep_nucleus) UISP_LAUNCH(true);
+        else UISP_LAUNCH(false);
+#undef UISP_LAUNCH
+        LANTERN_CHECK_LAUNCH("update_inference_inputs");
+        return LANTERN_OK;
+    }
+    if (prep && n_prep > 0) {                            // slab tiles + the next step's preparation
+        int gx = (int)((total + 2 * 256 - 1) / (2 * 256));
+        if (gx > 4096) gx = 4096;
+        const int g = hidden ? G : 1;
+        const int extra = (B * g * D + gx - 1) / gx, n_commit_y = n_slabs + extra, prep_y = (n_prep + gx - 1) / gx;
+#define UIP_LAUNCH(NUC_)                                                                                                                       \
+    LANTERN_LAUNCH((update_inputs_prep_kernel<8, 2, NUC_>), dim3(gx, n_commit_y + prep_y), dim3(256), 0, (hipStream_t)stream, slab_ptrs, slab_seq, \
+                   slab_prev, n_slabs, outer, S_max, cpr, retrieve, retrieve_per_seq, P, D, best, accept_len, new_len, (const uint4 *)hidden, B, g, N, \
+                   hidden ? H * hid_elem_bytes / 16 : 0, cand, (uint4 *)out_hidden, accepted_tokens, counters, ex, prep_y, *prep)
+        if (prep_nucleus) UIP_LAUNCH(true);
+        else UIP_LAUNCH(false);
+#undef UIP_LAUNCH
+        LANTERN_CHECK_LAUNCH("update_inference_inputs");
+        return LANTERN_OK;
+    }
     if (ks_knob > 0 && total <= 4096) {
         // small slabs (the 7B geometry: 32 heads x 16 chunks): a workgroup covers whole slabs, KS of them
         const int g = hidden ? G : 1;

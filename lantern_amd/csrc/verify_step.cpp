@@ -3,7 +3,7 @@
 //
 // Reference: the body of EaLumina_mGPT.generate's decode loop, models/ea_model_lumina_mgpt.py:936-998 (static trees), and the same loop
 // behind the EAGLE-2 drafter (cnets_lumina_mgpt.py:1337-1420 / cnets_llamagen.py:826-912: per-sequence trees).
-#include "../../include/lantern_hip.h"
+#include "prep_dev.h"
 #include <cstdio>
 
 namespace lantern {
@@ -14,7 +14,8 @@ int launch_update_inference_inputs(void *const *slab_ptrs, const int32_t *slab_s
                                    const int32_t *accept_len, int64_t *new_len, const void *hidden, int hid_elem_bytes, int B, int G, int N, int H,
                                    const int64_t *cand, void *out_hidden, int64_t *accepted_tokens, const int32_t *counters, void *stream,
                                    const void *hidden_g1 = nullptr, int64_t *ids_buf = nullptr, int64_t ids_stride = 0, const int64_t *ids_len = nullptr,
-                                   const int64_t *bonus = nullptr);
+                                   const int64_t *bonus = nullptr, const PrepArgs *prep = nullptr);
+int prepare_step_args(const lantern_step_group *g, PrepArgs *out);
 }
 
 namespace {
@@ -37,6 +38,7 @@ extern "C" int lantern_verify_step(const lantern_step_group *groups, int n_group
     int rc;
     for (int g = 0; g < n_groups; ++g) {
         const lantern_step_group &s = groups[g];
+        if (s.flags & LANTERN_STEP_PREPARED) continue;          // the previous call's commit launch prepared this step (prepare_next)
         if (s.dyn && s.node_list && s.n_list > 0) { // EAGLE-2 tree + candidates + the likely rows in one launch
             rc = lantern_prepare_step(&s);
             if (rc) return fail(g, "prepare_step", rc);
@@ -80,14 +82,36 @@ extern "C" int lantern_verify_step(const lantern_step_group *groups, int n_group
     }
     for (int g = 0; g < n_groups; ++g) {
         const lantern_step_group &s = groups[g];
-        if (!s.slab_ptrs) continue;
+        if (!s.slab_ptrs) {
+            if (s.prepare_next) {          // (the next call would skip its preparation for nothing)
+                lantern::set_error("prepare_next rides in the commit launch: the group needs its KV slabs (slab_ptrs)");
+                return fail(g, "update_inference_inputs", LANTERN_E_INVALID);
+            }
+            continue;
+        }
+        // the next step's preparation in the same launch (prepare_next): its lengths are this step's + what this commit adds
+        lantern::PrepArgs pa{};
+        const lantern::PrepArgs *prep = nullptr;
+        if (s.prepare_next) {
+            const lantern_step_group &nx = *s.prepare_next;
+            if (nx.dyn || !nx.node_list || nx.n_list <= 0 || nx.B != s.B || nx.cand == s.cand) {
+                lantern::set_error("prepare_next: a static-tree group with a node list, the same sequences and its OWN candidate buffer");
+                return fail(g, "update_inference_inputs", LANTERN_E_INVALID);
+            }
+            rc = lantern::prepare_step_args(&nx, &pa);
+            if (rc) return fail(g, "prepare_next", rc);
+            pa.seq_len = s.seq_len;          // THIS step's lengths (the commit beside these blocks is still writing the next ones) ...
+            pa.len_alen = s.ep_buf.accept_len;          // ... + what it adds
+            pa.len_cnt = s.ep_buf.counters;
+            prep = &pa;
+        }
         // (a sequence whose walk reported a status commits nothing: its KV rows and lengths stay as the forward left them, its out_hidden rows are
         // zero-filled and its accepted_tokens are -1 -- the caller retries the step and commits it itself; tests/test_gpu_loop.py pins this gate)
         rc = lantern::launch_update_inference_inputs(s.slab_ptrs, s.slab_seq, s.slab_prev, s.n_slabs, s.elem_bytes, s.outer, s.S_max, s.d,
                                                      s.dyn ? s.dyn->retrieve_pd : s.retrieve, s.dyn ? 1 : 0, s.P, s.D, s.ep_buf.best,
                                                      s.ep_buf.accept_len, s.new_len, s.hidden, s.hid_elem_bytes, s.B, s.hid_groups, s.N, s.H,
                                                      s.cand, s.out_hidden, s.accepted_tokens, s.ep_buf.counters, s.stream, s.hidden_uncond, s.ids_buf,
-                                                     s.ids_stride, s.ids_len, s.ids_buf ? s.ep_win.token : nullptr);
+                                                     s.ids_stride, s.ids_len, s.ids_buf ? s.ep_win.token : nullptr, prep);
         if (rc) return fail(g, "update_inference_inputs", rc);
     }
     return LANTERN_OK;

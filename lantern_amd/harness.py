@@ -93,6 +93,9 @@ class WorkloadConfig:
     native_step: bool = True        # eager windowed path: the whole step of all groups through ONE C call (lantern_verify_step) instead of
                                     # 4 x n_groups ctypes calls (the Python launch loop caps the stream groups at ~2 otherwise)
     leaf_workgroups: int = -1       # node kernel: -1 = by batch size (include/lantern_hip.h lantern_ep_nodes)
+    merge_prepare: bool = True      # one-call steps with prepared rows and KV slabs: step s + 1's lantern_prepare_step (candidate assembly + the likely
+                                    # rows) rides in step s's commit launch (lantern_step_group.prepare_next) -- it needs step s's verdict, not its KV
+                                    # rows -- so a step is two launches per group (evaluate_posterior, commit + next prepare) instead of three
     n_groups: int = 1               # >1: the sequences are split into groups, each launched on its own HIP stream, so that one
                                     # group's latency-bound evaluate_posterior overlaps the others' bandwidth-bound kernels
                                     # (independent sequences: no ordering between groups exists)
@@ -285,7 +288,9 @@ class LuminaVerifyWorkload:
             self.slab_seq = torch.arange(self.Bg, dtype=torch.int32, device=device).repeat(2 * cfg.n_groups)
 
         # ---------------- work buffers
-        self.cand = torch.empty((B, P, D), dtype=torch.int64, device=device)
+        # candidates by lens parity: step s's commit reads cand[s & 1] (the accepted tokens) while -- merge_prepare -- the same launch writes step
+        # s + 1's candidates into cand[(s + 1) & 1]
+        self.cand2 = torch.empty((2, B, P, D), dtype=torch.int64, device=device)
         self.cart_prob = torch.empty((B, P, D), dtype=torch.float32, device=device)
         self.tree_cand = torch.empty((B, N), dtype=torch.int64, device=device)
         if self.windowed:
@@ -364,6 +369,7 @@ class LuminaVerifyWorkload:
         else:
             self.sample_token.copy_(self.first_token)
         self.step_idx = 0
+        self._prepared_for = -1           # the step whose preparation already ran inside the previous step's commit launch
         self._len_ub = 0                  # host-side upper bound of (length - base) over all sequences (direct_logs)
         self._forked = False
         if hasattr(self, "step_dev"):
@@ -420,12 +426,12 @@ class LuminaVerifyWorkload:
         p.n_uniforms, p.R, p.N, p.row_index_per_seq = self.n_uniforms, self.R, self.N, 0
         return p
 
-    def ep_buffers(self, slot: int, g: int = 0) -> EpBuffers:
+    def ep_buffers(self, slot: int, g: int = 0, parity: int = 0) -> EpBuffers:
         """evaluate_posterior buffers of group g (sequences [g*Bg, (g+1)*Bg)) for pool slot `slot`."""
         s0 = g * self.Bg
         at = lambda t: t[s0:].data_ptr()
         b = EpBuffers()
-        b.logits, b.row_index, b.cand = at(self.proc), self.d_row_index.data_ptr(), at(self.cand)
+        b.logits, b.row_index, b.cand = at(self.proc), self.d_row_index.data_ptr(), at(self.cand2[parity])
         b.cart_prob, b.orig_prob = at(self.cart_prob), at(self.orig_prob[slot])
         b.op_off, b.p_idx, b.b_off, b.b_idx = (self.d_op_off.data_ptr(), self.d_p_idx.data_ptr(), self.d_b_off.data_ptr(),
                                                self.d_b_idx.data_ptr())
@@ -457,6 +463,11 @@ class LuminaVerifyWorkload:
             if self.n_spec:
                 w.raw_probs, w.raw_pre = at(self.proc), self.d_pre.data_ptr()
         return w
+
+    @property
+    def cand(self) -> torch.Tensor:
+        """The candidates of the step that ran last ([B, P, D]; the buffers alternate with the step's parity)."""
+        return self.cand2[(self.step_idx - 1) & 1] if self.step_idx > 0 else self.cand2[0]
 
     def cond_lens(self, parity: int) -> torch.Tensor:
         """KV lengths of the cond slabs in sequence order (the device layout is per group [cond..., uncond...])."""
@@ -605,6 +616,20 @@ class LuminaVerifyWorkload:
                 s.sample_token = self.sample_token[g * self.Bg:].data_ptr()
             s.ep_buf.best, s.ep_buf.accept_len, s.ep_buf.counters = bs["best"] + 4 * e, bs["alen"] + 4 * e, bs["cnt"] + 24 * e
             s.ep_win.u_bonus, s.ep_win.token = bs["ub"] + 8 * e, bs["tok"] + 8 * e
+        # the next step's preparation inside this step's commit launch: whenever the next step exists in the logs and no image can end in this step
+        # (an image end rewrites the lengths on the host's side of the stream: those steps prepare themselves, as before)
+        merge = (c.merge_prepare and c.with_kv and self.n_spec > 0 and step + 1 < c.max_steps and self._len_ub + 2 * self.D < self.tokens_per_image)
+        nxt_arr = self._steps[((step + 1) % c.pool_steps, parity ^ 1)] if merge else None
+        for g in range(self.G):
+            s = arr[g]
+            s.flags = _lib.STEP_PREPARED if self._prepared_for == step else 0
+            if merge:
+                n_ = nxt_arr[g]
+                n_.sample_token = bs["tok"] + 8 * (step * c.n_seq + g * self.Bg)          # this step's bonus tokens = the next step's roots
+                s.prepare_next = C.addressof(n_)
+            else:
+                s.prepare_next = None
+        self._prepared_for = step + 1 if merge else -1
         check(self._L.lantern_verify_step(arr, self.G), "verify_step")
         if not c.with_kv:
             for g in range(self.G):
@@ -635,7 +660,7 @@ class LuminaVerifyWorkload:
         cur, nxt = self.lens[parity], self.lens[parity ^ 1]
         a = dict(
             ss_token=at(self.ss_token[slot]), ss_prob=at(self.ss_prob[slot]), sample_token=at(self.sample_token), tree_cand=at(self.tree_cand),
-            cand=at(self.cand), cart_prob=at(self.cart_prob), cond=at(self.cond[slot]), uncond=at(self.uncond[slot]), proc=at(self.proc),
+            cand=at(self.cand2[parity]), cart_prob=at(self.cart_prob), cond=at(self.cond[slot]), uncond=at(self.uncond[slot]), proc=at(self.proc),
             row_hot=at(self.row_hot) if self.windowed else None, cur=at(cur, 2 * s0), nxt=at(nxt, 2 * s0), len_base=at(self.len_base, 2 * s0),
             st_best=at(self.st_best), st_alen=at(self.st_alen), st_cnt=at(self.st_cnt), st_token=at(self.st_token),
             hidden=at(self.hidden[slot]), out_hidden=at(self.out_hidden), acc_tokens=at(self.acc_tokens),
@@ -644,7 +669,7 @@ class LuminaVerifyWorkload:
             log_cnt=vp(self.log_cnt[:, s0:].data_ptr()), log_token=vp(self.log_token[:, s0:].data_ptr()),
             u_bonus_g=vp(self.u_bonus[:, s0:].data_ptr()),
             slab_ptrs=at(self.slab_ptrs, 2 * s0) if self.cfg.with_kv else None, slab_seq=at(self.slab_seq, 2 * s0) if self.cfg.with_kv else None,
-            ep_buf=self.ep_buffers(slot, g), ep_win=self.ep_window(g) if self.windowed else None)
+            ep_buf=self.ep_buffers(slot, g, parity), ep_win=self.ep_window(g) if self.windowed else None)
         if self.fused_o7:
             a["ep_buf"].logits = a["cond"].value
             a["ep_win"].raw_uncond, a["ep_win"].raw_seq_len = a["uncond"].value, a["cur"].value

@@ -9,8 +9,8 @@ Contract (driver):  python bench.py --gpus N --steps K --warmup W
 Workload = BASELINE.json config C3 (Lumina-mGPT-7B-768 + LANTERN relaxed accept, k=1000, delta=0.1, static tree mc_sim_7b_63) on
 synthetic 768x768 image-token sequences: a "step" is one verify step (O6 -> O7 -> O8 -> O9 -> O10) over the --seqs-per-gpu sequences
 resident on the GPU; inputs are HBM-resident before the timed region.  `value` = accepted tokens of all ranks / max-over-ranks wall time.
-Default launch: 3 stream groups, one lantern_verify_step call per step, per group  prepare_step (O6 + the 3 most likely rows of O7) ->
-evaluate_posterior_window on raw bf16 rows (O8 + the rest of O7, on demand) -> update_inference_inputs (O9 + O10).
+Default launch: 64 sequences in 4 stream groups, one lantern_verify_step call per step, per group  evaluate_posterior_window on raw bf16 rows (O8 + the
+rows of O7 it visits, on demand) -> update_inference_inputs (O9 + O10) with the NEXT step's prepare_step (O6 + the 3 most likely rows of O7) in the same launch.
 `--groups 1 --no-fuse-o7 --spec-rows 0` is the four-launch step (every row through cfg_mask_topk first).
 
 Extra objects on the JSON line:
@@ -42,7 +42,7 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-def _groups_from_argv(argv, default=3):
+def _groups_from_argv(argv, default=4):
     for i, a in enumerate(argv):
         if a == "--groups" and i + 1 < len(argv) and argv[i + 1].isdigit():
             return int(argv[i + 1])
@@ -69,7 +69,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--seqs-per-gpu", type=int, default=63, help="sequences resident per GPU (KV slabs: 4.3 GB each at 4096 rows; 64 -> 276e9 of the 309e9 bytes; the default 63 = 3 stream groups of 21)")
+    ap.add_argument("--seqs-per-gpu", type=int, default=64, help="sequences resident per GPU (KV slabs: 4.3 GB each at 4096 rows; 64 -> 276e9 of the 309e9 bytes): BASELINE's 64, in 4 stream groups of 16")
     ap.add_argument("--total-seqs", type=int, default=0, help="BASELINE config 5 (strong scaling): this many sequences in ALL, split evenly over the --gpus ranks "
                     "(64 over 8 GPUs = 8 per GPU, run.sh:76-91); 0 = --seqs-per-gpu on every rank (weak scaling, the default)")
     ap.add_argument("--pool-steps", type=int, default=16)
@@ -94,7 +94,7 @@ def parse():
     ap.add_argument("--no-events", action="store_true", help="skip the eager per-kernel timing pass")
     ap.add_argument("--graph", action="store_true", help="replay one captured hipGraph per (pool slot, group) instead of launching eagerly")
     ap.add_argument("--side-stream", action="store_true", help="launch O6 beside O7 and O10 beside O9 on a second HIP stream (measured slower: event waits)")
-    ap.add_argument("--groups", type=int, default=3, help="split the GPU's sequences into this many groups, each on its own HIP stream (independent sequences: one group's latency-bound evaluate_posterior overlaps the others' bandwidth-bound kernels)")
+    ap.add_argument("--groups", type=int, default=4, help="split the GPU's sequences into this many groups, each on its own HIP stream (independent sequences: one group's latency-bound evaluate_posterior overlaps the others' bandwidth-bound kernels)")
     ap.add_argument("--no-extras", action="store_true", help="skip the extra runs after the timed region (lambda mode, B=1 / B=8 step latency, two stream groups)")
     ap.add_argument("--ep-sweep", type=str, default="1,8,64,256,512,4096",
                     help="e.g. 256,2048: batch sizes for the evaluate_posterior-only roofline sweep (BASELINE.md section 2: the 60 %% target is "
@@ -971,6 +971,13 @@ def close_process_group(dist, pg) -> None:
     dist.destroy_process_group()
 
 
+def cap_groups(args, world: int) -> int:
+    """A small per-rank share (C5: 64 prompts over 8 GPUs = 8 per GPU) runs the node-parallel kernels in at most two stream groups
+    (profiles/r04_c5_share.json); the default four are for a full GPU of 64 sequences."""
+    share = (args.total_seqs // max(world, 1)) if args.total_seqs > 0 else args.seqs_per_gpu
+    return min(args.groups, 2) if share <= 16 else args.groups
+
+
 # ---------------------------------------------------------------------------- N > 1: self-launch
 
 def spawn_ranks(args) -> int:
@@ -1038,7 +1045,7 @@ def stub_rank(args, world, rank):
     dist, pg = None, None
     if world > 1:
         dist, pg = open_process_group(world, rank, 0, args.dist_backend, one_device=False)     # no GPU here: "auto" must land on gloo
-    n_seq, _groups, scaling = plan_sequences(args.total_seqs, args.seqs_per_gpu, world, args.groups)
+    n_seq, _groups, scaling = plan_sequences(args.total_seqs, args.seqs_per_gpu, world, cap_groups(args, world))
     K, per_step = args.steps, n_seq * 2
     if world > 1:
         dist.barrier(group=pg["group"])
@@ -1103,6 +1110,7 @@ def main():
     # Never ask for more resident sequences than this GPU can hold: KV slabs (2 per sequence) + pools + 16 GiB of head-room.
     # On the MI355X the default fits (309e9 bytes); a smaller or partly occupied device gets fewer sequences, not a failed run
     # (with more than one rank every rank takes the minimum so that the per-GPU work stays identical).
+    args.groups = cap_groups(args, world)
     n_seq, groups, scaling = plan_sequences(args.total_seqs, args.seqs_per_gpu, world, args.groups)
     if groups != args.groups and rank == 0:
         print(f"bench.py: {n_seq} sequences per rank in {groups} stream groups (--groups {args.groups} does not divide them)", file=sys.stderr)

@@ -1,0 +1,11 @@
+#!/bin/bash
+O=gpurun_out/${1:-r5q}; mkdir -p $O
+run() { timeout -k 10 300 python bench.py --gpus 1 --steps 100 --warmup 20 --no-extras --ep-sweep "" --cpu-seconds 0 --extras-out "" "$@" 2> $O/err.txt | python -c "
+import json,sys
+d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$*', round(d['value']), round(1e3*d['ms_per_step'],2), 'per-seq-us', round(1e3*d['ms_per_step']/d['config']['seqs_per_gpu'],3), 'ep_us', round(1e3*d['roofline']['avg_launch_ms'],1))"; }
+run --groups 3 --seqs-per-gpu 63 --spec-rows 3
+run --groups 3 --seqs-per-gpu 63 --spec-rows 2
+run --groups 3 --seqs-per-gpu 63 --spec-rows 4
+run --groups 2 --seqs-per-gpu 64 --spec-rows 3
+run --groups 4 --seqs-per-gpu 64 --spec-rows 3
+run --groups 3 --seqs-per-gpu 60 --spec-rows 3

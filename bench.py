@@ -385,7 +385,7 @@ def ep_batch_sweep(batches, device, base_cfg, iters=24, kernels=("chain", "nodes
 # the sources of the kernels bench.py times (the verify step: candidate assembly / row post-process, the windowed evaluate_posterior kernels, the KV /
 # hidden commit, the one-call sequencing); the dense evaluate_posterior (evaluate_posterior.hip: never on the timed path) and the drafter-side files
 # (drafter_fc, draft_depth, tree_attention, vq_table, greedy, tree_static) are not part
-VERIFY_PATH_SOURCES = ("common.h", "window_dev.h", "epw_body.h", "window_kernels.hip", "epw_generic.hip", "epw_throughput.hip", "node_kernels.hip", "logits_post.hip", "gather_dev.h",
+VERIFY_PATH_SOURCES = ("common.h", "window_dev.h", "epw_body.h", "window_kernels.hip", "epw_generic.hip", "epw_throughput.hip", "node_kernels.hip", "logits_post.hip", "prep_dev.h", "gather_dev.h",
                        "gather_ops.hip", "tree_dynamic.hip", "tree_dynamic_dev.h", "verify_step.cpp")
 
 

@@ -9,6 +9,7 @@
 // Reference: models/ea_model_lumina_mgpt.py:597-605, :45-86, :106-112;
 // models/ea_model_anole.py:930-931; models/ea_model_llamagen.py:26-29, :930.
 #include "common.h"
+#include <type_traits>
 
 namespace lantern {
 
@@ -65,49 +66,57 @@ __global__ __launch_bounds__(LP_THREADS) void cfg_mask_topk_kernel(const void *_
                                       : -3.4028234663852886e38f /* finfo(f32).min */);
     const bool masked = model != LANTERN_MODEL_PLAIN;
     float4 r[VI];
+    // the row's tile, with the `uncond == NULL` decision taken ONCE (a wave-uniform branch around the whole loop): as a per-chunk
+    // `uncond ? load : cond` the compiler waited for each conditional chunk before fetching the unconditional one, element by element
+    auto load_tile = [&](auto has_u) {
 #pragma unroll
-    for (int it = 0; it < VI; ++it) {
-        const int i4 = tid + it * LP_THREADS;
-        const int e = i4 * 4;
-        float4 v = make_float4(NEG_INF, NEG_INF, NEG_INF, NEG_INF);
-        if (e < V) {
-            const bool need = !masked || (e + 4 > img_lo && e < img_hi);
-            if (need) {
-                float c[4], u[4];
-                if (BF16) {
-                    const ushort4 cb = reinterpret_cast<const ushort4 *>((const uint16_t *)cond_ + (size_t)row * V)[i4];
-                    const ushort4 ub = uncond_ ? reinterpret_cast<const ushort4 *>((const uint16_t *)uncond_ + (size_t)row * V)[i4] : cb;
-                    c[0] = bf16_bits_to_f32(cb.x); c[1] = bf16_bits_to_f32(cb.y);
-                    c[2] = bf16_bits_to_f32(cb.z); c[3] = bf16_bits_to_f32(cb.w);
-                    u[0] = bf16_bits_to_f32(ub.x); u[1] = bf16_bits_to_f32(ub.y);
-                    u[2] = bf16_bits_to_f32(ub.z); u[3] = bf16_bits_to_f32(ub.w);
-                } else {
-                    const float4 cf = reinterpret_cast<const float4 *>((const float *)cond_ + (size_t)row * V)[i4];
-                    const float4 uf = uncond_ ? reinterpret_cast<const float4 *>((const float *)uncond_ + (size_t)row * V)[i4] : cf;
-                    c[0] = cf.x; c[1] = cf.y; c[2] = cf.z; c[3] = cf.w;
-                    u[0] = uf.x; u[1] = uf.y; u[2] = uf.z; u[3] = uf.w;
-                }
-                float o[4];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    float t = c[q];
-                    if (uncond_) {   // uncond == NULL: logits are already combined, mask / top-k only
-                        t = c[q] - u[q];
-                        if (BF16) t = round_bf16(t);
-                        t = cfg * t;
-                        if (BF16) t = round_bf16(t);
-                        t = u[q] + t;
-                        if (BF16) t = round_bf16(t);
+        for (int it = 0; it < VI; ++it) {
+            const int i4 = tid + it * LP_THREADS;
+            const int e = i4 * 4;
+            float4 v = make_float4(NEG_INF, NEG_INF, NEG_INF, NEG_INF);
+            if (e < V) {
+                const bool need = !masked || (e + 4 > img_lo && e < img_hi);
+                if (need) {
+                    float c[4], u[4];
+                    if (BF16) {
+                        const ushort4 cb = reinterpret_cast<const ushort4 *>((const uint16_t *)cond_ + (size_t)row * V)[i4];
+                        ushort4 ub = cb;
+                        if constexpr (decltype(has_u)::value) ub = reinterpret_cast<const ushort4 *>((const uint16_t *)uncond_ + (size_t)row * V)[i4];
+                        c[0] = bf16_bits_to_f32(cb.x); c[1] = bf16_bits_to_f32(cb.y);
+                        c[2] = bf16_bits_to_f32(cb.z); c[3] = bf16_bits_to_f32(cb.w);
+                        u[0] = bf16_bits_to_f32(ub.x); u[1] = bf16_bits_to_f32(ub.y);
+                        u[2] = bf16_bits_to_f32(ub.z); u[3] = bf16_bits_to_f32(ub.w);
+                    } else {
+                        const float4 cf = reinterpret_cast<const float4 *>((const float *)cond_ + (size_t)row * V)[i4];
+                        float4 uf = cf;
+                        if constexpr (decltype(has_u)::value) uf = reinterpret_cast<const float4 *>((const float *)uncond_ + (size_t)row * V)[i4];
+                        c[0] = cf.x; c[1] = cf.y; c[2] = cf.z; c[3] = cf.w;
+                        u[0] = uf.x; u[1] = uf.y; u[2] = uf.z; u[3] = uf.w;
                     }
-                    o[q] = (masked && (e + q < img_lo || e + q >= img_hi)) ? fill : t;
+                    float o[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        float t = c[q];
+                        if constexpr (decltype(has_u)::value) {   // uncond == NULL: logits are already combined, mask / top-k only
+                            t = c[q] - u[q];
+                            if (BF16) t = round_bf16(t);
+                            t = cfg * t;
+                            if (BF16) t = round_bf16(t);
+                            t = u[q] + t;
+                            if (BF16) t = round_bf16(t);
+                        }
+                        o[q] = (masked && (e + q < img_lo || e + q >= img_hi)) ? fill : t;
+                    }
+                    v = make_float4(o[0], o[1], o[2], o[3]);
+                } else {
+                    v = make_float4(fill, fill, fill, fill);
                 }
-                v = make_float4(o[0], o[1], o[2], o[3]);
-            } else {
-                v = make_float4(fill, fill, fill, fill);
             }
+            r[it] = v;
         }
-        r[it] = v;
-    }
+    };
+    if (uncond_) load_tile(std::true_type{});
+    else load_tile(std::false_type{});
 
     if (top_k > 0) {
         // k-th largest over the register tile; iterations wholly outside the finite window

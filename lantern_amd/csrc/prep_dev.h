@@ -56,12 +56,25 @@ __device__ __forceinline__ void cfg_window_bf16_row(int row, int cls, const uint
     float *out = out_win + (size_t)row * W;
     float4 r[2 * E8];
     Bf16x8 cb[E8], ub[E8];
+    // every load of the row in flight before the first use: the unconditional rows under ONE wave-uniform branch (as a per-chunk select with the
+    // conditional chunk as its fallback the compiler waited for each conditional chunk -- vmcnt(0) -- and then fetched the unconditional one dword by
+    // dword under four more branches: four serial HBM round trips per row and 16 + 4 load instructions instead of 8)
 #pragma unroll
     for (int it = 0; it < E8; ++it) {
         const int ch = tid + it * NT;
         const bool in = FULL || ch * 8 < W;       // FULL: W == 8 * NT * E8, every chunk is inside the window
         cb[it] = in ? *reinterpret_cast<const Bf16x8 *>(crow + ch * 8) : Bf16x8{make_uint2(0, 0), make_uint2(0, 0)};
-        ub[it] = (in && urow) ? *reinterpret_cast<const Bf16x8 *>(urow + ch * 8) : cb[it];
+    }
+    if (urow) {
+#pragma unroll
+        for (int it = 0; it < E8; ++it) {
+            const int ch = tid + it * NT;
+            const bool in = FULL || ch * 8 < W;
+            ub[it] = in ? *reinterpret_cast<const Bf16x8 *>(urow + ch * 8) : Bf16x8{make_uint2(0, 0), make_uint2(0, 0)};
+        }
+    } else {
+#pragma unroll
+        for (int it = 0; it < E8; ++it) ub[it] = Bf16x8{make_uint2(0, 0), make_uint2(0, 0)};
     }
 #pragma unroll
     for (int it = 0; it < E8; ++it) {

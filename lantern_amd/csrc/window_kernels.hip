@@ -14,6 +14,7 @@
 // Reference: models/ea_model_lumina_mgpt.py:597-605 (O7), :610-726 (O8), :781 (bonus token);
 // models/ea_model_llamagen.py:597-669,709-787.
 #include "common.h"
+#include <type_traits>
 
 namespace lantern {
 // In-kernel phase stamps for diagnosis (tools/ep_trace.py builds a separate .so with -DEPW_TRACE);
@@ -96,22 +97,40 @@ __global__ __launch_bounds__(NT) void cfg_window_kernel(const void *__restrict__
     const bool masked = model != LANTERN_MODEL_PLAIN;
     const float fill = lumina ? NEG_INF : (BF16 ? __uint_as_float(0xff7f0000u) : -3.4028234663852886e38f);
     float4 r[E4];
+    // every load of the row in flight before the first use, the unconditional ones under ONE wave-uniform branch (a per-chunk `uncond ? load : cond`
+    // made the compiler wait for each conditional chunk and fetch the unconditional one element by element: a serial HBM round trip per chunk)
+    typedef typename std::conditional<BF16, ushort4, float4>::type Raw;
+    Raw craw[E4], uraw[E4];
+#pragma unroll
+    for (int it = 0; it < E4; ++it) {
+        const int i4 = tid + it * NT;
+        craw[it] = Raw{};
+        if (i4 * 4 < W) craw[it] = reinterpret_cast<const Raw *>(cond_)[((size_t)row * V + win_lo + i4 * 4) / 4];
+    }
+    if (uncond_) {
+#pragma unroll
+        for (int it = 0; it < E4; ++it) {
+            const int i4 = tid + it * NT;
+            uraw[it] = Raw{};
+            if (i4 * 4 < W) uraw[it] = reinterpret_cast<const Raw *>(uncond_)[((size_t)row * V + win_lo + i4 * 4) / 4];
+        }
+    } else {
+#pragma unroll
+        for (int it = 0; it < E4; ++it) uraw[it] = craw[it];
+    }
 #pragma unroll
     for (int it = 0; it < E4; ++it) {
         const int i4 = tid + it * NT;
         float4 v = make_float4(NEG_INF, NEG_INF, NEG_INF, NEG_INF);
         if (i4 * 4 < W) {
             const int e = win_lo + i4 * 4;
-            const size_t g4 = ((size_t)row * V + e) / 4;
             float c[4], u[4];
-            if (BF16) {
-                const ushort4 cb = reinterpret_cast<const ushort4 *>(cond_)[g4];
-                const ushort4 ub = uncond_ ? reinterpret_cast<const ushort4 *>(uncond_)[g4] : cb;
+            if constexpr (BF16) {
+                const ushort4 cb = craw[it], ub = uraw[it];
                 c[0] = bf16_bits_to_f32(cb.x); c[1] = bf16_bits_to_f32(cb.y); c[2] = bf16_bits_to_f32(cb.z); c[3] = bf16_bits_to_f32(cb.w);
                 u[0] = bf16_bits_to_f32(ub.x); u[1] = bf16_bits_to_f32(ub.y); u[2] = bf16_bits_to_f32(ub.z); u[3] = bf16_bits_to_f32(ub.w);
             } else {
-                const float4 cf = reinterpret_cast<const float4 *>(cond_)[g4];
-                const float4 uf = uncond_ ? reinterpret_cast<const float4 *>(uncond_)[g4] : cf;
+                const float4 cf = craw[it], uf = uraw[it];
                 c[0] = cf.x; c[1] = cf.y; c[2] = cf.z; c[3] = cf.w;
                 u[0] = uf.x; u[1] = uf.y; u[2] = uf.z; u[3] = uf.w;
             }

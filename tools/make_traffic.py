@@ -13,7 +13,7 @@ runs = dict(a.split("=", 1) for a in sys.argv[2:]) or {"raw": RND + "p", "chain"
 sat_runs = [v for k, v in list(runs.items()) if k.startswith("sat")]
 runs = {k: v for k, v in runs.items() if not k.startswith("sat")}
 kern = {"raw": ["epw_kernel"], "chain": ["epw_kernel"], "nodes": ["epn_kernel", "epn_walk_kernel"]}
-others = ["prep_rows_kernel", "cfg_window_bf16", "update_inputs_kernel"]
+others = ["prep_rows_kernel", "cfg_window_bf16", "update_inputs"]
 
 
 def sums(d, pat):
@@ -33,7 +33,8 @@ out = {"note": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (se
        "per_launch": {}, "other_kernels": {}}
 for key, d in runs.items():
     src = os.path.join(ROOT, "gpurun_out", d)
-    line = json.loads(open(os.path.join(src, "b_prof.json")).read().strip().splitlines()[-1])
+    full = os.path.join(src, "b_prof_full.json")          # the full report (bench.py --extras-out); stdout holds the compact line only
+    line = json.load(open(full)) if os.path.exists(full) else json.loads(open(os.path.join(src, "b_prof.json")).read().strip().splitlines()[-1])
     B = line["roofline"]["sequences_per_launch"]
     fetch = wr = 0.0
     n = 0
@@ -45,7 +46,7 @@ for key, d in runs.items():
     out["per_launch"][f"{key}_B{B}"] = {
         "kernel": rl["kernel"], "flags": d, "launches_averaged": n, "FETCH_SIZE_raw_KB": fetch, "WRITE_SIZE_raw_KB": wr,
         "hbm_bytes": 2 * fetch * 1024 + wr * 1024,
-        "algorithmic_window_bytes": rl.get("windowed_kernel", {}).get("hbm_bytes_needed_per_launch"),
+        "algorithmic_window_bytes": rl.get("windowed_kernel", {}).get("hbm_bytes_needed_per_launch") or rl.get("needed_bytes_per_launch"),
         "dense_contract_bytes": rl["algorithmic_bytes_per_launch"]}
     for k in others:
         f, n = sums(os.path.join(src, "pmc_fetch"), k)

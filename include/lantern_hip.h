@@ -347,6 +347,27 @@ size_t lantern_evaluate_posterior_nodes_workspace(const lantern_ep_params *prm, 
 int lantern_evaluate_posterior_nodes(const lantern_ep_params *prm, const lantern_ep_buffers *buf, const lantern_ep_window *win,
                                      const lantern_ep_nodes *nodes, void *stream);
 
+/* a9 inside the one-call step: the greedy / TVD accept of a step whose caller decodes without a processor list (temperature <= 1e-5:
+ * models/ea_model_llamagen.py:789-905, ea_model_anole.py:790-905; the loop that reaches it: ea_model_llamagen.py:1109-1169).  With
+ * lantern_step_group.greedy set, lantern_verify_step runs: [candidates] -> lantern_cfg_mask_topk (the CFG combination and the model mask of
+ * every tree row in the logits' dtype, no top-k: ea_model_llamagen.py:930 / ea_model_anole.py:930-931) into `logits` -> lantern_evaluate_posterior_greedy
+ * (best / accept_len -> ep_buf.best / ep_buf.accept_len, the accepted row -> out_row) -> the bonus token = argmax(out_row), first maximum
+ * (`token`) -> the KV / hidden / token commit.  No uniforms, no counters (ep_buf.counters may be NULL), ep / ep_win are not read except ep_win.verdict_host. */
+typedef struct lantern_step_greedy {
+    float *logits;                /* [dev] [B, N, V] f32, written by the O7 stage */
+    const int32_t *row_index;     /* [dev] [P, D] (or [B, P, D] with row_index_per_seq): tree row of every (path, depth) */
+    int row_index_per_seq;
+    int lantern, k;               /* LANTERN relaxation: sum the k nearest codes' probability (0: exact greedy match) */
+    double delta;
+    int tok_offset;               /* id of code 0 */
+    const uint16_t *nn_table;     /* [dev] [table_rows, table_cols] (NULL when !lantern) */
+    int table_rows, table_cols;
+    int win_lo, win_len;          /* ids read: LlamaGen (0, V); Anole the image range */
+    int32_t *ok_scratch;          /* [dev] B * P * (D - 1) */
+    float *out_row;               /* [dev] [B, V] */
+    int64_t *token;               /* [dev] [B] */
+} lantern_step_greedy;
+
 /* ------------------------------------------------------------------------------------
  * One verify step of G independent groups of sequences in ONE call: for every group, on the group's own stream,
  *   O6 lantern_gather_candidates -> O7 lantern_cfg_mask_topk_window -> O8 lantern_evaluate_posterior_nodes (nodes != NULL) or
@@ -414,6 +435,7 @@ typedef struct lantern_step_group {
                                              NULL -- candidates the caller assembled itself: `cand` [B,P,D] and `retrieve` [P,D] are taken as they are
                                              (a tree that came with its token list, ea_model_llamagen.py:1125-1131; or lantern_gather_candidates called
                                              before the target forward).  A static group with neither is an error, not a silent skip. */
+    const lantern_step_greedy *greedy;    /* NULL: relaxed rejection sampling (evaluate_posterior); else the greedy / TVD accept above */
 } lantern_step_group;
 #define LANTERN_STEP_CANDIDATES_READY 1   /* lantern_step_group.flags: skip the O6 stage, `cand` / `retrieve` (/ `cart_prob`, `tree_cand`) are final */
 #define LANTERN_STEP_PREPARED 2           /* the previous call's commit launch already ran this group's lantern_prepare_step (prepare_next) */

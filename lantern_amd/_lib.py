@@ -64,6 +64,13 @@ class StepDynamic(C.Structure):
 STEP_CANDIDATES_READY, STEP_PREPARED = 1, 2          # lantern_step_group.flags (include/lantern_hip.h)
 
 
+class StepGreedy(C.Structure):
+    """lantern_step_greedy (include/lantern_hip.h): the greedy / TVD accept as the O8 stage of a group of lantern_verify_step."""
+    _fields_ = [("logits", C.c_void_p), ("row_index", C.c_void_p), ("row_index_per_seq", C.c_int32), ("lantern", C.c_int32), ("k", C.c_int32),
+                ("delta", C.c_double), ("tok_offset", C.c_int32), ("nn_table", C.c_void_p), ("table_rows", C.c_int32), ("table_cols", C.c_int32),
+                ("win_lo", C.c_int32), ("win_len", C.c_int32), ("ok_scratch", C.c_void_p), ("out_row", C.c_void_p), ("token", C.c_void_p)]
+
+
 class StepGroup(C.Structure):
     """lantern_step_group (include/lantern_hip.h): one group of sequences of lantern_verify_step."""
     _fields_ = ([("stream", C.c_void_p)]
@@ -82,7 +89,7 @@ class StepGroup(C.Structure):
                 + [(n, C.c_int32) for n in ("hid_elem_bytes", "hid_groups", "H", "reserved1")]
                 + [("node_list", C.c_void_p), ("n_list", C.c_int32), ("flags", C.c_int32)]
                 + [("hidden_uncond", C.c_void_p), ("ids_buf", C.c_void_p), ("ids_stride", C.c_int64), ("ids_len", C.c_void_p), ("prepare_next", C.c_void_p)]
-                + [("dyn", C.POINTER(StepDynamic))])
+                + [("dyn", C.POINTER(StepDynamic)), ("greedy", C.POINTER(StepGreedy))])
 
 
 class DraftDepthArgs(C.Structure):

@@ -68,6 +68,17 @@ extern "C" int lantern_verify_step(const lantern_step_group *groups, int n_group
     }
     for (int g = 0; g < n_groups; ++g) {
         const lantern_step_group &s = groups[g];
+        if (s.greedy) {          // greedy decoding: CFG + model mask of every row, dense f32 (no processor list: ea_model_llamagen.py:930)
+            const lantern_step_greedy &q = *s.greedy;
+            if (!q.logits || !q.row_index || !q.ok_scratch || !q.out_row || !q.token || s.dyn || s.nodes || s.prepare_next) {
+                lantern::set_error("greedy step: logits / row_index / ok_scratch / out_row / token, and none of dyn / nodes / prepare_next");
+                return fail(g, "greedy", LANTERN_E_INVALID);
+            }
+            rc = lantern_cfg_mask_topk(s.cond, s.uncond, s.dtype, s.B * s.N, s.V, s.cfg, s.model, s.pos_ids, s.pos_base, s.w_latent, s.h_latent, s.img_lo,
+                                       s.img_hi, s.newline_id, s.eos_id, 0, s.seq_len, s.N, q.logits, s.stream);
+            if (rc) return fail(g, "cfg_mask_topk", rc);
+            continue;
+        }
         if (!s.out_win || (s.node_list && s.n_list > 0)) continue;          // LANTERN_ROWS_RAW_BF16: evaluate_posterior post-processes the rows it visits itself
         rc = lantern_cfg_mask_topk_window(s.cond, s.uncond, s.dtype, s.B * s.N, s.V, s.cfg, s.model, s.pos_ids, s.pos_base, s.w_latent,
                                           s.h_latent, s.img_lo, s.img_hi, s.newline_id, s.eos_id, s.top_k, s.seq_len, s.N, s.win_lo,
@@ -76,6 +87,18 @@ extern "C" int lantern_verify_step(const lantern_step_group *groups, int n_group
     }
     for (int g = 0; g < n_groups; ++g) {
         const lantern_step_group &s = groups[g];
+        if (s.greedy) {
+            const lantern_step_greedy &q = *s.greedy;
+            rc = lantern_evaluate_posterior_greedy(q.logits, q.row_index, s.cand, s.B, s.P, s.D, s.V, s.N, q.row_index_per_seq, q.lantern, q.k, q.delta,
+                                                   q.tok_offset, q.nn_table, q.table_rows, q.table_cols, q.win_lo, q.win_len, q.ok_scratch, s.ep_buf.best,
+                                                   s.ep_buf.accept_len, q.out_row, s.stream);
+            if (rc) return fail(g, "evaluate_posterior_greedy", rc);
+            // the bonus token: argmax of the accepted row, first maximum (torch.argmax; ea_model_llamagen.py:664)
+            rc = lantern_accept_gather(nullptr, 0, s.B, 1, s.N, 0, s.retrieve, 0, s.P, s.D, nullptr, s.ep_buf.best, s.ep_buf.accept_len, q.out_row, s.V, nullptr,
+                                       nullptr, nullptr, q.token, s.stream);
+            if (rc) return fail(g, "bonus argmax", rc);
+            continue;
+        }
         rc = s.nodes ? lantern_evaluate_posterior_nodes(&s.ep, &s.ep_buf, &s.ep_win, s.nodes, s.stream)
                      : lantern_evaluate_posterior_window(&s.ep, &s.ep_buf, &s.ep_win, s.stream);
         if (rc) return fail(g, "evaluate_posterior", rc);
@@ -111,7 +134,7 @@ extern "C" int lantern_verify_step(const lantern_step_group *groups, int n_group
                                                      s.dyn ? s.dyn->retrieve_pd : s.retrieve, s.dyn ? 1 : 0, s.P, s.D, s.ep_buf.best,
                                                      s.ep_buf.accept_len, s.new_len, s.hidden, s.hid_elem_bytes, s.B, s.hid_groups, s.N, s.H,
                                                      s.cand, s.out_hidden, s.accepted_tokens, s.ep_buf.counters, s.stream, s.hidden_uncond, s.ids_buf,
-                                                     s.ids_stride, s.ids_len, s.ids_buf ? s.ep_win.token : nullptr, prep);
+                                                     s.ids_stride, s.ids_len, s.ids_buf ? (s.greedy ? s.greedy->token : s.ep_win.token) : nullptr, prep);
         if (rc) return fail(g, "update_inference_inputs", rc);
     }
     return LANTERN_OK;

@@ -303,7 +303,8 @@ class EaModel(nn.Module):
         the dense kernel set, a model spread over devices, slabs of different shapes)."""
         import ctypes as C
         from . import _lib
-        if not (self.native_step and self.kernel_set == "window" and logits_processor is not None and not st.multi_device):
+        greedy = logits_processor is None          # temperature <= 1e-5: the greedy / TVD accept as the call's O8 stage (lantern_step_greedy)
+        if not (self.native_step and (self.kernel_set == "window" or greedy) and not st.multi_device):
             return None
         s0 = st.slabs[0]
         if any(x.shape != s0.shape or x.dtype != s0.dtype or x.device != s0.device or not x.is_contiguous() for x in st.slabs):
@@ -318,8 +319,8 @@ class EaModel(nn.Module):
         lo, W = (self.image_lo, self.image_hi - self.image_lo) if self.mask_non_image else (0, V)
         if D > 8 or N > 64 or W % 8 or W > 16384:
             return None
-        proc = ProcessorSpec.from_hf(logits_processor)
-        nx = types.SimpleNamespace(C=C, L=_lib.lib(), dev=dev, N=N, P=P, D=D, R=R, lo=lo, W=W, static=bool(st.static))
+        proc = ProcessorSpec.from_hf(logits_processor) if not greedy else ProcessorSpec()
+        nx = types.SimpleNamespace(C=C, L=_lib.lib(), dev=dev, N=N, P=P, D=D, R=R, lo=lo, W=W, static=bool(st.static), greedy=greedy)
         z = lambda *shape, dt: torch.zeros(shape, dtype=dt, device=dev)
         nx.cand, nx.cart, nx.tcand = z(1, max(P, 1), max(D, 1), dt=torch.int64), z(1, max(P, 1), max(D, 1), dt=torch.float32), z(1, N, dt=torch.int64)
         nx.win, nx.hot = z(N, W, dt=torch.float32), z(N, dt=torch.int32)
@@ -348,6 +349,21 @@ class EaModel(nn.Module):
         a.img_lo, a.img_hi = (self.image_lo, self.image_hi) if self.mask_non_image else (0, V)
         a.top_k, a.win_lo, a.win_len, a.out_kind = min(proc.top_k, V), lo, W, ops.ROWS_PROBS
         a.out_win, a.row_hot, a.temperature, a.top_p = nx.win.data_ptr(), nx.hot.data_ptr(), float(proc.temperature), float(proc.top_p)
+        if greedy:
+            # the dense f32 rows of the O7 stage, the accepted row, the scratch of the (path, depth) cells (sized for any tree the context takes)
+            nx.g_logits, nx.g_out, nx.g_ok = z(max(N, 64), V, dt=torch.float32), z(1, V, dt=torch.float32), z(64 * 8, dt=torch.int32)
+            nx.g_table = self.nearest_latents.contiguous() if lantern else None
+            q = nx.gq = _lib.StepGreedy()
+            q.logits, q.out_row, q.ok_scratch = nx.g_logits.data_ptr(), nx.g_out.data_ptr(), nx.g_ok.data_ptr()
+            q.lantern, q.k, q.delta, q.tok_offset = int(bool(lantern)), int(lantern_k), float(lantern_delta), int(self.image_token_offset)
+            if nx.g_table is not None:
+                q.nn_table = nx.g_table.data_ptr()
+                q.table_rows, q.table_cols = nx.g_table.shape
+            q.win_lo, q.win_len = lo, W
+            if st.static:
+                q.row_index = nx.row_index.data_ptr()
+            a.greedy = C.pointer(q)
+            a.out_win, a.top_k = None, 0
         cfg = self._ep_config(bool(st.static), proc, lantern, lantern_k, lantern_delta)
         p = a.ep
         p.B, p.P, p.D, p.V, p.rows_per_seq = 1, P, D, V, N
@@ -357,8 +373,8 @@ class EaModel(nn.Module):
             p.syntax[i] = int(sx)
         p.lantern, p.k, p.delta = int(cfg.lantern), int(cfg.k), float(cfg.delta)
         p.top_k, p.temperature, p.top_p = 0, 1.0, 1.0          # the rows are final probabilities (the processors ran in the O7 stage)
-        fifo = self._uniforms()
-        p.n_uniforms, p.R, p.N, p.row_index_per_seq = fifo.buf.shape[1], R, N, 0
+        fifo = None if greedy else self._uniforms()          # (greedy decoding draws nothing: the Python RNG stays where the reference leaves it)
+        p.n_uniforms, p.R, p.N, p.row_index_per_seq = (0 if greedy else fifo.buf.shape[1]), R, N, 0
         nx.table = self._packed_table(int(lantern_k)) if lantern else None
         if nx.table is not None:
             p.table_rows, p.table_cols = nx.table.shape
@@ -369,7 +385,8 @@ class EaModel(nn.Module):
             b.op_off, b.p_idx, b.b_off, b.b_idx = hip["op_off"].data_ptr(), hip["p_idx"].data_ptr(), hip["b_off"].data_ptr(), hip["b_idx"].data_ptr()
             b.tree_cand = nx.tcand.data_ptr()
         b.nn_table = nx.table.data_ptr() if nx.table is not None else None
-        b.uniforms, b.cursor = fifo.buf.data_ptr(), fifo.cursor.data_ptr()
+        if not greedy:
+            b.uniforms, b.cursor = fifo.buf.data_ptr(), fifo.cursor.data_ptr()
         w = a.ep_win
         w.win_lo, w.win_len, w.row_hot, w.rows_kind = lo, W, nx.hot.data_ptr(), ops.ROWS_PROBS
         w.orig_prob_stride, w.orig_prob_offset = V, lo
@@ -391,8 +408,10 @@ class EaModel(nn.Module):
         C, L, a = nx.C, nx.L, nx.group[0]
         tl = st.tree_logits
         ss_token = tl[0].to(nx.dev).contiguous()
-        ss_prob = tl[1].to(nx.dev)
-        ss_prob = (ss_prob if ss_prob.dtype == torch.float32 else ss_prob.float()).contiguous()
+        ss_prob = None
+        if not nx.greedy:
+            ss_prob = tl[1].to(nx.dev)
+            ss_prob = (ss_prob if ss_prob.dtype == torch.float32 else ss_prob.float()).contiguous()
         sample = st.sample_token.to(nx.dev).reshape(-1)[:1].contiguous()
         par = nx.parity
         rec, tokbuf = nx.recs[par], nx.toks[par]
@@ -400,9 +419,9 @@ class EaModel(nn.Module):
         a.ep_win.token = tokbuf.data_ptr()
         a.stream, a.ss_token = nx.stream, None          # (ss_token NULL: lantern_verify_step takes the candidates as the call below leaves them)
         a.flags = ops._lib.STEP_CANDIDATES_READY
-        ops.check(L.lantern_gather_candidates(C.c_void_p(ss_token.data_ptr()), C.c_void_p(ss_prob.data_ptr()), C.c_void_p(sample.data_ptr()), C.c_void_p(a.tree_indices),
-                                              C.c_void_p(a.retrieve), 1, ss_token.numel(), nx.N, nx.P, nx.D, C.c_void_p(a.tree_cand), C.c_void_p(a.cand),
-                                              C.c_void_p(a.cart_prob), C.c_void_p(nx.stream)), "gather_candidates")
+        ops.check(L.lantern_gather_candidates(C.c_void_p(ss_token.data_ptr()), C.c_void_p(ss_prob.data_ptr() if ss_prob is not None else None), C.c_void_p(sample.data_ptr()),
+                                              C.c_void_p(a.tree_indices), C.c_void_p(a.retrieve), 1, ss_token.numel(), nx.N, nx.P, nx.D, C.c_void_p(a.tree_cand),
+                                              C.c_void_p(a.cand), C.c_void_p(a.cart_prob if ss_prob is not None else None), C.c_void_p(nx.stream)), "gather_candidates")
         kw = dict(input_position_diff=st.input_position_diff) if self.mask_non_image else {}
         tree_candidates = torch.cat([nx.tcand, nx.tcand])
         _, tree_logits, hidden_new = self._tree_forward(tree_candidates, self.base_model.past_key_values, self.tree_buffers["tree_position_ids"], st.input_ids,
@@ -413,17 +432,22 @@ class EaModel(nn.Module):
             cl, ul = cl.float(), ul.float()
         cl, ul = cl.contiguous(), ul.contiguous()
         a.cond, a.uncond, a.dtype = cl.data_ptr(), ul.data_ptr(), int(cl.dtype == torch.bfloat16)
-        orig = concat_original_prob(tl[2])
-        a.ep_buf.orig_prob = orig.data_ptr()
+        if not nx.greedy:
+            orig = concat_original_prob(tl[2])
+            a.ep_buf.orig_prob = orig.data_ptr()
         hid = hidden_new.contiguous()[None]                                                # [1, 2, N, H]
         out_h = nx.out_hs[par]
         if out_h is None or out_h.dtype != hid.dtype or out_h.shape[-1] != hid.shape[-1]:
             out_h = nx.out_hs[par] = torch.zeros((1, 2, nx.D, hid.shape[-1]), dtype=hid.dtype, device=nx.dev)
         a.hidden, a.out_hidden, a.hid_elem_bytes, a.H = hid.data_ptr(), out_h.data_ptr(), hid.element_size(), hid.shape[-1]
-        fifo = self._uniforms()
-        fifo.reserve(nx.P * nx.D)
-        u = torch.rand(1, dtype=torch.float64, device=nx.dev)
-        a.ep_win.u_bonus = u.data_ptr()
+        if nx.greedy:          # no uniforms, no counters: the record's counter words stay zero
+            a.ep_buf.counters = None
+            nx.gq.token = tokbuf.data_ptr()
+        else:
+            fifo = self._uniforms()
+            fifo.reserve(nx.P * nx.D)
+            u = torch.rand(1, dtype=torch.float64, device=nx.dev)
+            a.ep_win.u_bonus = u.data_ptr()
         prev = st.input_ids.shape[1]
         cur, nxt = nx.prev[par], nx.prev[par ^ 1]
         cur.fill_(prev)
@@ -472,7 +496,7 @@ class EaModel(nn.Module):
         N = int(st.draft_tokens.shape[1])
         if D > 8 or P < 1 or N < 1:
             return None
-        if N > nx.win.shape[0]:          # (a drafter whose trees grow: the row buffers follow)
+        if N > nx.win.shape[0] and not nx.greedy:          # (a drafter whose trees grow: the row buffers follow)
             nx.win = torch.zeros((N, nx.W), dtype=torch.float32, device=nx.dev)
             nx.hot = torch.zeros(N, dtype=torch.int32, device=nx.dev)
             a.out_win, a.row_hot, a.ep_buf.logits, a.ep_win.row_hot = nx.win.data_ptr(), nx.hot.data_ptr(), nx.win.data_ptr(), nx.hot.data_ptr()
@@ -506,10 +530,16 @@ class EaModel(nn.Module):
             flat = nx.out_hs[par] = torch.zeros(2 * 8 * hid.shape[-1], dtype=hid.dtype, device=nx.dev)
         out_h = flat[:2 * D * hid.shape[-1]].view(1, 2, D, hid.shape[-1])          # (the kernel's [B, G, D, H] layout for THIS step's depth)
         a.hidden, a.out_hidden, a.hid_elem_bytes, a.H = hid.data_ptr(), out_h.data_ptr(), hid.element_size(), hid.shape[-1]
-        fifo = self._uniforms()
-        fifo.reserve(P * D)
-        u = torch.rand(1, dtype=torch.float64, device=nx.dev)
-        a.ep_win.u_bonus = u.data_ptr()
+        if nx.greedy:
+            if N > nx.g_logits.shape[0] or P * max(D - 1, 1) > nx.g_ok.numel():
+                return None
+            b.counters = None
+            nx.gq.token, nx.gq.row_index = tokbuf.data_ptr(), row_index.data_ptr()
+        else:
+            fifo = self._uniforms()
+            fifo.reserve(P * D)
+            u = torch.rand(1, dtype=torch.float64, device=nx.dev)
+            a.ep_win.u_bonus = u.data_ptr()
         prev = st.input_ids.shape[1]
         cur, nxt = nx.prev[par], nx.prev[par ^ 1]
         cur.fill_(prev)

@@ -237,5 +237,10 @@ CASES = [
     dict(name="an_static_lambda", model="anole", tree="naive_extend_57", lantern=True, k=10, delta=5.0, temperature=1.0, cfg=2.0, seed=32, max_length=48, prompt=["a house by the sea"]),
     dict(name="an_static_plain", model="anole", tree="mc_sim_7b_63", lantern=False, k=10, delta=0.1, temperature=1.0, cfg=2.0, seed=33, max_length=36, prompt=["fog"]),
     dict(name="an_dyn_plain", model="anole", tree="dynamic", lantern=False, k=10, delta=0.1, temperature=1.0, cfg=2.0, seed=34, max_length=40, prompt=["a bridge at night"]),
+    # greedy decoding (temperature 0: no processor list; evaluate_posterior's greedy / TVD branch, ea_model_llamagen.py:789-905): round 5
+    dict(name="lg_dyn_greedy", model="llamagen", tree="dynamic", lantern=True, k=32, delta=0.2, temperature=0.0, cfg=2.0, seed=41, max_length=44, prompt=["a red bird"]),
+    dict(name="lg_static_greedy", model="llamagen", tree="naive_extend_57", lantern=True, k=16, delta=0.3, temperature=0.0, cfg=2.0, seed=42, max_length=40, prompt=["a boat"]),
+    dict(name="an_dyn_greedy", model="anole", tree="dynamic", lantern=False, k=10, delta=0.1, temperature=0.0, cfg=2.0, seed=43, max_length=40, prompt=["a green field"]),
+    dict(name="an_static_greedy", model="anole", tree="mc_sim_7b_63", lantern=True, k=10, delta=0.2, temperature=0.0, cfg=2.0, seed=44, max_length=40, prompt=["fog"]),
 ]
 TOP_K, TOP_P = 2000, 1.0

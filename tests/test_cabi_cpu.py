@@ -133,18 +133,22 @@ def test_step_group_layout_matches_the_c_struct(tmp_path):
     import subprocess
     wfields = ["row_hot", "rows_kind", "raw_uncond", "raw_pos_base", "raw_cfg", "raw_eos_id", "raw_probs", "raw_pre", "verdict_host"]
     fields = ["stream", "B", "tree_cand", "cond", "pos_base", "w_latent", "seq_len", "temperature", "ep", "ep_buf", "ep_win", "nodes",
-              "slab_ptrs", "n_slabs", "outer", "hidden", "H", "node_list", "n_list", "flags", "hidden_uncond", "ids_buf", "ids_stride", "ids_len", "prepare_next", "dyn"]
+              "slab_ptrs", "n_slabs", "outer", "hidden", "H", "node_list", "n_list", "flags", "hidden_uncond", "ids_buf", "ids_stride", "ids_len", "prepare_next", "dyn", "greedy"]
     src = tmp_path / "layout.c"
+    gfields = [f for f, _ in _lib.StepGreedy._fields_]
     src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "lantern_hip.h"\nint main(void){printf("%zu %zu", sizeof(lantern_step_group), sizeof(lantern_ep_nodes));\n'
                    + "".join(f'printf(" %zu", offsetof(lantern_step_group, {f}));\n' for f in fields)
-                   + 'printf(" %zu", sizeof(lantern_ep_window));\n' + "".join(f'printf(" %zu", offsetof(lantern_ep_window, {f}));\n' for f in wfields) + "return 0;}\n")
+                   + 'printf(" %zu", sizeof(lantern_ep_window));\n' + "".join(f'printf(" %zu", offsetof(lantern_ep_window, {f}));\n' for f in wfields)
+                   + 'printf(" %zu", sizeof(lantern_step_greedy));\n' + "".join(f'printf(" %zu", offsetof(lantern_step_greedy, {f}));\n' for f in gfields) + "return 0;}\n")
     exe = tmp_path / "layout"
     subprocess.check_call(["gcc", "-std=c99", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
     out = [int(x) for x in subprocess.check_output([str(exe)]).split()]
     assert out[0] == C.sizeof(_lib.StepGroup) and out[1] == C.sizeof(_lib.EpNodes)
     nf = len(fields)
     assert out[2:2 + nf] == [getattr(_lib.StepGroup, f).offset for f in fields]
-    assert out[2 + nf] == C.sizeof(_lib.EpWindow) and out[3 + nf:] == [getattr(_lib.EpWindow, f).offset for f in wfields]
+    nw = len(wfields)
+    assert out[2 + nf] == C.sizeof(_lib.EpWindow) and out[3 + nf:3 + nf + nw] == [getattr(_lib.EpWindow, f).offset for f in wfields]
+    assert out[3 + nf + nw] == C.sizeof(_lib.StepGreedy) and out[4 + nf + nw:] == [getattr(_lib.StepGreedy, f).offset for f in gfields]
 
 
 def test_draft_depth_args_layout_matches_the_c_struct(tmp_path):

@@ -67,9 +67,11 @@ def run_case(case, kernel_set="window", mdl_parts=None, native=True):
 def test_generate_reproduces_the_reference_run(case, kernel_set, native, monkeypatch):
     calls = []
     static = case["tree"] != "dynamic"
-    if native and case["temperature"] > 1e-5:          # the one-call step really is the path taken for sampled runs (static and EAGLE-2 trees)
+    if native:          # the one-call step really is the path taken: sampled runs and -- round 5 -- greedy runs (lantern_step_greedy), static and EAGLE-2 trees
         from lantern_amd import ops
-        for fn in ("evaluate_posterior_window", "update_inference_inputs", "cfg_mask_topk_window"):
+        fns = ("evaluate_posterior_window", "update_inference_inputs", "cfg_mask_topk_window") if case["temperature"] > 1e-5 else \
+              ("evaluate_posterior_greedy", "update_inference_inputs", "accept_gather")          # (cfg_mask_topk: the prefill picks the first token with it)
+        for fn in fns:
             real = getattr(ops, fn)
             monkeypatch.setattr(ops, fn, (lambda real, fn: (lambda *a, **k: (calls.append(fn), real(*a, **k))[1]))(real, fn))
     mdl, base, drafter, draws, ids, mean_alen = run_case(case, kernel_set, native=native)

@@ -518,6 +518,14 @@ int lantern_drafter_fc(const int64_t *ids, const void *hidden, const void *embed
                        const void *bias, int M, int H, int vocab, float embed_scale, void *out,
                        void *stream);
 
+/* a5  the reductions a drafting call makes over its attention mask, in one launch.  Replaces `position_ids = attention_mask.long().cumsum(-1) - 1`,
+ * `len_posi = position_ids[:, -1] + 1` (models/drafters/cnets_lumina_mgpt.py:1180-1186) for the calls behind a cached prefix, and the first-visible-key
+ * index the tree-attention path takes per row.  mask [dev] [B, S] (row_stride entries apart) of elem_bytes 1 (bool / uint8) or 8 (int64).
+ * Out (each may be NULL): first [dev] [B] i64 = index of the first non-zero entry (0 for an all-zero row, as torch.argmax); count [dev] [B] i64 = number of
+ * non-zero entries; bad [dev] [B] i64 = 1 when the row has a zero behind a one (not left padding), else 0. */
+int lantern_mask_left_padding(const void *mask, int elem_bytes, int B, int64_t S, int64_t row_stride, int64_t *first, int64_t *count, int64_t *bad,
+                              void *stream);
+
 /* a5  the drafter's additive attention mask in one launch.  Replaces Model._prepare_decoder_attention_mask
  * (models/drafters/cnets_lumina_mgpt.py:1014-1050; cnets_llamagen.py:592-621): causal (when T > 1) + padding from the
  * boolean mask attn [dev] [B, attn_len] (bytes; columns >= attn_len count as attended, as the reference pads) or NULL,

@@ -175,5 +175,5 @@ EXPORTS = [
     "lantern_tree_attention_workspace", "lantern_tree_attention",
     "lantern_tree_node_tables_size", "lantern_tree_node_tables", "lantern_evaluate_posterior_nodes_workspace",
     "lantern_evaluate_posterior_nodes", "lantern_verify_step", "lantern_gather_candidates_dynamic", "lantern_head_expand_workspace", "lantern_head_expand", "lantern_prepare_step",
-    "lantern_linear_rows_epilogue", "lantern_linear_rows_packed", "lantern_linear_rows_splitk", "lantern_linear_rows_streamk_workspace", "lantern_linear_rows_streamk", "lantern_pack_linear_weight_bytes", "lantern_pack_linear_weight", "lantern_drafter_fc_streamk", "lantern_head_expand_streamk", "lantern_rmsnorm_rows", "lantern_qk_norm_rope", "lantern_qk_rope_pairs", "lantern_draft_depth", "lantern_head_sample", "lantern_draft_static_inputs",
+    "lantern_linear_rows_epilogue", "lantern_linear_rows_packed", "lantern_linear_rows_splitk", "lantern_linear_rows_streamk_workspace", "lantern_linear_rows_streamk", "lantern_pack_linear_weight_bytes", "lantern_pack_linear_weight", "lantern_drafter_fc_streamk", "lantern_head_expand_streamk", "lantern_rmsnorm_rows", "lantern_qk_norm_rope", "lantern_qk_rope_pairs", "lantern_draft_depth", "lantern_head_sample", "lantern_draft_static_inputs", "lantern_mask_left_padding",
 ]

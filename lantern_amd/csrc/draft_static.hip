@@ -33,9 +33,7 @@ __global__ __launch_bounds__(NT) void sample_window_kernel(const uint16_t *__res
     __shared__ alignas(16) int s_hist[O7_HIST_INTS];
     __shared__ float s_redf[2 * 16];
     __shared__ double s_redd[2 * 16];
-    __shared__ double s_wtot[16];
-    __shared__ int s_redi[2 * 16];
-    __shared__ int s_bonus[2];
+    __shared__ double s_seg[NT];          // f64 sum of every thread's EPT consecutive ids
     __shared__ int s_tok[SW_MAX_DRAW];
     __shared__ float s_p[SW_MAX_DRAW];
     const int row = blockIdx.x, tid = threadIdx.x;
@@ -117,37 +115,134 @@ __global__ __launch_bounds__(NT) void sample_window_kernel(const uint16_t *__res
         }
     }
     __syncthreads();
-    // ---- the draws: one after the other, the drawn entry removed from the LDS copy in between
-    int fallback = win_lo;
-    for (int j = 0; j < n_draw; ++j) {
-        int tok;
-        if (draw_idx) {
-            const int64_t t = draw_idx[(size_t)row * n_draw + j];
-            tok = (int)(t < 0 ? 0 : (t >= V ? V - 1 : t));
-        } else {
-            tok = bonus_draw_lds<NT, (SW_C8 * 8 * NT) / (4 * NT)>(g, W, win_lo, -1, 0.0f, draw_u[(size_t)row * n_draw + j], s_wtot, s_bonus, s_redi);
-            if (tok < 0 || tok == 0x7fffffff) {          // no mass left (fewer positive entries than draws): the lowest window ids not drawn yet
-                bool again = true;
-                while (again) {
-                    again = false;
-                    for (int q = 0; q < j; ++q)
-                        if (s_tok[q] == fallback) {
-                            ++fallback;
-                            again = true;
-                        }
+    // ---- the draws.  Inverse CDF in token-id order with removal (oracle: sample_draws), without a workgroup barrier per draw: every thread leaves the f64
+    // sum of its EPT consecutive ids in LDS once; wave 0 then walks the draws alone -- per draw one DPP scan over the segment sums (SPL per lane), a ballot
+    // for the segment that holds the crossing, one DPP scan over that segment's EPT entries, the entry zeroed and its segment's sum rebuilt.  (Round 5: the
+    // barrier form -- bonus_draw_lds per draw, the whole row re-read and four barriers each -- cost ~2 us per draw: 20 of the kernel's 32 us.)
+    constexpr int EPT = SW_C8 * 8, SPL = NT / 64;
+    static_assert(EPT == 32, "a segment = 32 lanes of wave 0");
+    {
+        double sseg = 0.0;
+        const int e0 = tid * EPT;
+#pragma unroll
+        for (int q = 0; q < EPT / 4; ++q) {
+            const float4 v = (e0 + 4 * q < W) ? *reinterpret_cast<const float4 *>(g + e0 + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+            sseg += (double)v.x + (double)v.y + (double)v.z + (double)v.w;
+        }
+        s_seg[tid] = sseg;
+    }
+    __syncthreads();
+    if (tid < 64) {
+        const int lane = tid;
+        double sv[SPL];
+#pragma unroll
+        for (int q = 0; q < SPL; ++q) sv[q] = s_seg[lane * SPL + q];
+        int toks[SW_MAX_DRAW];          // (wave-uniform)
+        int fallback = win_lo;
+#pragma unroll 1
+        for (int j = 0; j < n_draw; ++j) {
+            int tok = -1;
+            float pv = 0.0f;
+            if (draw_idx) {
+                const int64_t t = draw_idx[(size_t)row * n_draw + j];
+                tok = (int)(t < 0 ? 0 : (t >= V ? V - 1 : t));
+                if (tok >= win_lo && tok < win_lo + W) {
+                    pv = g[tok - win_lo];          // 0 once it has been drawn before (injected duplicates)
+                    __builtin_amdgcn_wave_barrier();
+                    if (lane == 0) g[tok - win_lo] = 0.0f;
+                    __builtin_amdgcn_wave_barrier();
                 }
-                tok = fallback++;
+            } else {
+                double ls = 0.0;
+#pragma unroll
+                for (int q = 0; q < SPL; ++q) ls += sv[q];
+                const double inc = wave_scan_incl_dpp(ls);
+                const double total = readlane63(inc);
+                const double tgt = draw_u[(size_t)row * n_draw + j] * total;
+                int seg = -1;
+                if (total > 0.0) {
+                    // the first segment whose inclusive prefix passes tgt
+                    double pre = inc - ls, presel = 0.0;
+                    int mine = -1;
+#pragma unroll
+                    for (int q = 0; q < SPL; ++q) {
+                        const double nx = pre + sv[q];
+                        if (mine < 0 && sv[q] > 0.0 && nx > tgt) { mine = lane * SPL + q; presel = pre; }
+                        pre = nx;
+                    }
+                    unsigned long long who = __ballot(mine >= 0);
+                    int el = -1;
+                    if (who) {
+                        const int src = __ffsll((long long)who) - 1;
+                        seg = __builtin_amdgcn_readlane(mine, src);
+                        const double prefix = rdlane(presel, src);
+                        const float v = (lane < EPT && seg * EPT + lane < W) ? g[seg * EPT + lane] : 0.0f;
+                        const double acc = prefix + wave_scan_incl_dpp((double)v);
+                        const unsigned long long hit = __ballot(lane < EPT && v > 0.0f && acc > tgt);
+                        if (hit) el = __ffsll((long long)hit) - 1;
+                        else {          // rounding at the segment's end: the first positive entry behind it
+                            int nxt = -1;
+#pragma unroll
+                            for (int q = 0; q < SPL; ++q)
+                                if (nxt < 0 && lane * SPL + q > seg && sv[q] > 0.0) nxt = lane * SPL + q;
+                            const unsigned long long w2 = __ballot(nxt >= 0);
+                            seg = w2 ? __builtin_amdgcn_readlane(nxt, __ffsll((long long)w2) - 1) : -1;
+                            if (seg >= 0) {
+                                const float v2 = (lane < EPT && seg * EPT + lane < W) ? g[seg * EPT + lane] : 0.0f;
+                                const unsigned long long pos = __ballot(lane < EPT && v2 > 0.0f);
+                                el = pos ? __ffsll((long long)pos) - 1 : -1;
+                            }
+                        }
+                    }
+                    if (el < 0) {          // u ~ 1 and the sums' rounding left no crossing: the last positive entry (lo_sample_inverse_cdf)
+                        int lastseg = -1;
+#pragma unroll
+                        for (int q = 0; q < SPL; ++q)
+                            if (sv[q] > 0.0) lastseg = lane * SPL + q;
+                        const unsigned long long w3 = __ballot(lastseg >= 0);
+                        seg = w3 ? __builtin_amdgcn_readlane(lastseg, 63 - __clzll((long long)w3)) : -1;
+                        if (seg >= 0) {
+                            const float v3 = (lane < EPT && seg * EPT + lane < W) ? g[seg * EPT + lane] : 0.0f;
+                            const unsigned long long pos = __ballot(lane < EPT && v3 > 0.0f);
+                            el = pos ? 63 - __clzll((long long)pos) : -1;
+                        }
+                    }
+                    if (seg >= 0 && el >= 0) {
+                        const int wi = seg * EPT + el;
+                        tok = win_lo + wi;
+                        const float v = (lane < EPT && seg * EPT + lane < W) ? g[seg * EPT + lane] : 0.0f;
+                        pv = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), el));
+                        // remove it: the entry in LDS, and the segment's sum rebuilt from the 31 that stay
+                        __builtin_amdgcn_wave_barrier();
+                        if (lane == el) g[wi] = 0.0f;
+                        __builtin_amdgcn_wave_barrier();
+                        const double ns = readlane63(wave_scan_incl_dpp((double)((lane == el) ? 0.0f : v)));
+#pragma unroll
+                        for (int q = 0; q < SPL; ++q)
+                            if (lane * SPL + q == seg) sv[q] = ns;
+                    }
+                }
+                if (tok < 0) {          // no mass left (fewer positive entries than draws): the lowest window ids not drawn yet
+                    bool again = true;
+                    while (again) {
+                        again = false;
+                        for (int q = 0; q < j; ++q)
+                            if (toks[q] == fallback) {
+                                ++fallback;
+                                again = true;
+                            }
+                    }
+                    tok = fallback++;
+                }
+            }
+            toks[j] = tok;
+            if (lane == 0) {
+                s_tok[j] = tok;
+                s_p[j] = pv;
             }
         }
-        const bool inw = tok >= win_lo && tok < win_lo + W;
-        if (tid == 0) {
-            s_tok[j] = tok;
-            s_p[j] = inw ? g[tok - win_lo] : 0.0f;          // the token's probability in the row (0 once it has been drawn before: injected duplicates)
-        }
-        __syncthreads();
-        if (tid == 0 && inw) g[tok - win_lo] = 0.0f;
-        __syncthreads();
     }
+    __syncthreads();
     if (tid == 0) {
         double acc = 0.0;
         float prev_c = 0.0f;

@@ -496,6 +496,44 @@ int launch_linear_rows_cfg(const void *A, const void *W, const void *bias, int n
 }
 
 // a5: Model._prepare_decoder_attention_mask (cnets_lumina_mgpt.py:1014-1050, cnets_llamagen.py:592-621) in one launch:
+// The reductions a drafting call makes over its attention mask, in one launch: first[b] = index of the first non-zero entry (0 for an all-zero row:
+// torch.argmax), count[b] = number of non-zero entries (= position_ids[:, -1] + 1 of `mask.cumsum(-1) - 1`, cnets_lumina_mgpt.py:1180-1186),
+// bad[b] = 1 when a zero follows a one in row b (not left padding), else 0.  One workgroup per row.
+template <typename T>
+__global__ __launch_bounds__(256) void mask_left_padding_kernel(const T *__restrict__ mask, int64_t S, int64_t row_stride, int64_t *__restrict__ first,
+                                                                int64_t *__restrict__ count, int64_t *__restrict__ bad) {
+    __shared__ long long s_first[4], s_cnt[4];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const T *row = mask + (size_t)b * row_stride;
+    long long f = 0x7fffffffffffffffll, c = 0;
+    for (int64_t j = tid; j < S; j += 256)
+        if (row[j] != T(0)) {
+            f = f < j ? f : j;
+            ++c;
+        }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const long long of = __shfl_xor(f, o, 64), oc = __shfl_xor(c, o, 64);
+        f = f < of ? f : of;
+        c += oc;
+    }
+    if (lane == 0) {
+        s_first[wave] = f;
+        s_cnt[wave] = c;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        for (int w = 1; w < 4; ++w) {
+            f = f < s_first[w] ? f : s_first[w];
+            c += s_cnt[w];
+        }
+        const bool none = c == 0;
+        if (first) first[b] = none ? 0 : f;
+        if (count) count[b] = c;
+        if (bad) bad[b] = (!none && c != S - f) ? 1 : 0;
+    }
+}
+
 // out[b,0,i,j] = padding(b,j) + causal(i,j) with padding = 0 / finfo.min from the boolean mask (columns beyond its length
 // count as attended), causal = finfo.min for j - past > i when T > 1 (the reference ADDS the two, so a position masked by
 // both is -inf), then finfo.min wherever the tree mask (last t0 rows x last t1 columns) is zero.
@@ -528,6 +566,18 @@ __global__ void drafter_mask_kernel(const uint8_t *__restrict__ attn, int attn_l
 }  // namespace lantern
 
 using namespace lantern;
+
+extern "C" int lantern_mask_left_padding(const void *mask, int elem_bytes, int B, int64_t S, int64_t row_stride, int64_t *first, int64_t *count, int64_t *bad,
+                                         void *stream) {
+    LANTERN_CHECK_ARG(mask && (elem_bytes == 1 || elem_bytes == 8) && B >= 0 && S >= 0 && row_stride >= S, "mask_left_padding: mask [B, S] of 1- or 8-byte entries");
+    if (B == 0) return LANTERN_OK;
+    if (elem_bytes == 1)
+        hipLaunchKernelGGL(lantern::mask_left_padding_kernel<uint8_t>, dim3(B), dim3(256), 0, (hipStream_t)stream, (const uint8_t *)mask, S, row_stride, first, count, bad);
+    else
+        hipLaunchKernelGGL(lantern::mask_left_padding_kernel<int64_t>, dim3(B), dim3(256), 0, (hipStream_t)stream, (const int64_t *)mask, S, row_stride, first, count, bad);
+    LANTERN_CHECK_LAUNCH("mask_left_padding");
+    return LANTERN_OK;
+}
 
 extern "C" int lantern_drafter_attention_mask(const uint8_t *attn, int attn_len, const float *tree_mask, int tree_batch, int t0, int t1,
                                               int B, int T, int past, float *out, void *stream) {

@@ -355,7 +355,12 @@ static int ta_splits(int B, int Hq, int q_groups, int64_t max_kv_len) {
     const int64_t tiles = (max_kv_len + TA_TILE - 1) / TA_TILE;
     const int64_t wgs = (int64_t)B * Hq * q_groups;
     int64_t want = forced > 0 ? forced : 512 / wgs;                                          // one round of two resident workgroups per CU
-    const int64_t cap = tiles / (2 * TA_WAVES) > 1 ? tiles / (2 * TA_WAVES) : 1;              // >= 2 tiles per wave and split
+    static int min_tiles = -1;          // tuning knob (diagnostic): key tiles per wave and split below which no further split is made
+    if (min_tiles < 0) {
+        const char *e = getenv("LANTERN_TA_MIN_TILES");
+        min_tiles = e && atoi(e) > 0 ? atoi(e) : 2;
+    }
+    const int64_t cap = tiles / (min_tiles * TA_WAVES) > 1 ? tiles / (min_tiles * TA_WAVES) : 1;              // >= min_tiles tiles per wave and split
     if (want > cap) want = cap;
     if (want > 64) want = 64;
     return (int)(want < 1 ? 1 : want);

@@ -181,6 +181,7 @@ class DraftPlan:
         self.pos = z(D, B, T, dt=torch.int64)
         self.head_pos = z(D, T, dt=torch.int64)
         self.kv_start = z(B, dt=torch.int64)
+        self._kv_start_zero = True          # (freshly zeroed; begin / draft re-zero it only after a call that set it)
         self.bits0 = (torch.ones(T, dtype=torch.int64, device=dev) << torch.arange(T, dtype=torch.int64, device=dev))
         self.par0 = torch.arange(T, dtype=torch.int64, device=dev) + 1
         self.steps = torch.arange(D, dtype=torch.int64, device=dev)
@@ -212,9 +213,12 @@ class DraftPlan:
         if head_positions is not None:
             self.head_pos.copy_(head_positions)
         if kv_start is None:
-            self.kv_start.zero_()
+            if not self._kv_start_zero:
+                self.kv_start.zero_()
+                self._kv_start_zero = True
         else:
             self.kv_start.copy_(kv_start)
+            self._kv_start_zero = False
         a.kv_start = self.kv_start.data_ptr()
         a.positions_per_batch_row = 1
         a.cfg = float(self.model.cfg_scale)
@@ -281,9 +285,24 @@ class StaticDraftPlan(DraftPlan):
         self.parity = 0
         self.draw_u = z(self.R, k, dt=f64)
         self.draw_idx = z(self.R, k, dt=i64)
-        self.pos_l = [z(self.B, t, dt=i64) for t in levels]
-        self.head_pos_l = [z(t, dt=i64) for t in levels]
-        self.head_pos0 = z(1, dt=i64)
+        # positions of all levels in ONE buffer, level blocks [B, T_i] back to back, filled by one gather + one add per drafting call (the per-level
+        # add / expand / copy pairs were 16 tiny launches per call); the head positions (root row first, then level by level) by one add
+        n_pos = self.B * sum(levels)
+        self.pos_all = z(n_pos, dt=i64)
+        self.pos_l, pb, pi, o = [], [], [], 0
+        for i, t in enumerate(levels):
+            self.pos_l.append(self.pos_all[o:o + self.B * t].view(self.B, t))
+            pb += [b for b in range(self.B) for _ in range(t)]
+            pi += [i] * (self.B * t)
+            o += self.B * t
+        self.pos_b, self.pos_i = torch.as_tensor(pb, dtype=i64, device=dev), torch.as_tensor(pi, dtype=i64, device=dev)
+        self.pos_unc = (self.pos_b == 1).to(i64)
+        self.head_all = z(1 + sum(levels), dt=i64)
+        self.head_off = torch.as_tensor([0] + [i + 1 for i, t in enumerate(levels) for _ in range(t)], dtype=i64, device=dev)
+        self.head_pos0, self.head_pos_l, o = self.head_all[0:1], [], 1
+        for t in levels:
+            self.head_pos_l.append(self.head_all[o:o + t])
+            o += t
         self.last = z(self.B, 1, self.H, dt=torch.bfloat16)
         self.args.n_draw = k
 
@@ -304,9 +323,12 @@ class StaticDraftPlan(DraftPlan):
             self.ta = torch.empty(max(need, 16), dtype=torch.uint8, device=self.dev)
         a.ta_ws, a.ta_ws_bytes = self.ta.data_ptr(), self.ta.numel()
         if kv_start is None:
-            self.kv_start.zero_()
+            if not self._kv_start_zero:
+                self.kv_start.zero_()
+                self._kv_start_zero = True
         else:
             self.kv_start.copy_(kv_start)
+            self._kv_start_zero = False
         a.kv_start, a.positions_per_batch_row, a.cfg = self.kv_start.data_ptr(), 1, float(mdl.cfg_scale)
         a.tree_bits = self.tree_bits.data_ptr()
         # the draws of this call: injected indices, injected uniforms, or fresh uniforms (ONE torch.rand per drafting call)
@@ -316,23 +338,24 @@ class StaticDraftPlan(DraftPlan):
             du, di = None, self.draw_idx
         else:
             src = getattr(mdl, "static_draw_uniforms", None)
-            self.draw_u.copy_(src(self.R, k) if src is not None else torch.rand((self.R, k), dtype=torch.float64, device=self.dev))
+            if src is not None:
+                self.draw_u.copy_(src(self.R, k))
+            else:
+                torch.rand((self.R, k), dtype=torch.float64, device=self.dev, out=self.draw_u)
             du, di = self.draw_u, None
         self._du, self._di = du, di
         # positions of every level (len_posi advances by one per level; the tree's own position offsets are zero: utils_c.py:100-179)
         lumina = head_len is not None
-        for i in range(D):
-            if torch.is_tensor(len_posi):
-                self.pos_l[i].copy_((len_posi.reshape(B, 1) + i).expand(B, self.levels[i]))
-            else:
-                self.pos_l[i].fill_(int(len_posi) + i)
-                if position_diff is not None:
-                    self.pos_l[i][1].sub_(position_diff.reshape(()))
-            if lumina:
-                self.head_pos_l[i].copy_((head_len.reshape(1) + i + 1).expand(self.levels[i]))
+        if torch.is_tensor(len_posi):
+            torch.index_select(len_posi.reshape(B), 0, self.pos_b, out=self.pos_all)
+            self.pos_all.add_(self.pos_i)
+        else:
+            torch.add(self.pos_i, int(len_posi), out=self.pos_all)
+            if position_diff is not None:          # the unconditional row's positions (cnets_anole.py:858-862), every level at once
+                self.pos_all.addcmul_(self.pos_unc, position_diff.reshape(1).to(torch.int64), value=-1)
         self._lumina = lumina
         if lumina:
-            self.head_pos0.copy_(head_len.reshape(1))
+            torch.add(self.head_off, head_len.reshape(1), out=self.head_all)
         # ---- the root row: head + sample on the prefill's last hidden row (cond, uncond)
         stream = torch.cuda.current_stream().cuda_stream
         sk = ops._sk_workspace(self.dev)
@@ -532,6 +555,10 @@ class Model(nn.Module):
     def forward(self, hidden_states, input_ids, attention_mask=None, position_ids=None, past_key_values=None, inputs_embeds=None,
                 use_cache=None, output_attentions=None, output_hidden_states=None, return_dict=None, std=None):
         B, T, _ = hidden_states.shape
+        # ops.mask_left_padding(attention_mask) when the caller of this forward already took it (topK_generate): left on the module for THIS mask object
+        # (the signature stays the reference's: subclasses override forward)
+        pend = self.__dict__.pop("_pending_mask_stats", None)
+        mask_stats = pend[1] if pend is not None and pend[0] is attention_mask else None
         past = past_key_values[0][0].shape[2] if past_key_values is not None else 0
         if position_ids is None:
             position_ids = torch.arange(past, T + past, dtype=torch.long, device=hidden_states.device)[None].view(-1, T)
@@ -546,15 +573,20 @@ class Model(nn.Module):
             # LATER call (`_poll_mask_checks`): a mask with holes, or one that stops being left padding, raises one call late instead of being
             # silently reduced to kv_start (the reference's additive mask would honour it)
             self._poll_mask_checks()
-            am = attention_mask.to(torch.int64)
-            bad = (am.cummax(dim=1).values != am).any()
+            # (one launch: per row the first non-zero index, the count and "a zero behind a one" -- the to(int64) / cummax / != / any / argmax chain was
+            # seven launches on every drafting call)
+            if mask_stats is None:
+                mask_stats = ops.mask_left_padding(attention_mask.to(hidden_states.device))
+            bad = mask_stats[2]
             if past == 0:
-                if bool(bad):
+                if bool(bad.any()):
                     raise ops._lib.LanternError("cnets.Model.forward: attention_mask with zeros behind a one (not left padding): the tree-attention path "
                                                 "takes one first-visible-key index per row")
             else:
                 self._defer_mask_check(bad)
         extra = self.layer_kwargs(position_ids) if self.layer_kwargs is not None else {}
+        first_key = (lambda: mask_stats[0]) if mask_stats is not None else (lambda: attention_mask.to(hidden_states.device).to(torch.int64).argmax(dim=1))
+        self._mask_stats = mask_stats
         tm = getattr(self, "tree_mask", None)
         bits_ok = (hidden_states.is_cuda and hidden_states.dtype == torch.bfloat16 and all(getattr(l, "supports_tree_bits", False) for l in self.layers))
         have_bits = False
@@ -562,7 +594,7 @@ class Model(nn.Module):
             # the tree block of the mask as ancestor words + the left padding as a first-visible-key index: the layer's attention
             # runs on lantern_tree_attention (the additive mask still rides along for layers / shapes that want it)
             bits, t1 = ops.drafter_tree_bits(tm.to(hidden_states.device), T)
-            extra = dict(extra, tree_bits=bits, tree_keys=t1, kv_start=attention_mask.to(hidden_states.device).to(torch.int64).argmax(dim=1))
+            extra = dict(extra, tree_bits=bits, tree_keys=t1, kv_start=first_key())
             have_bits = True
         elif tm is None and bits_ok and past > 0 and B * T <= 32:
             # the accepted tokens of a drafting call behind the cached prefix (a few rows): causal among themselves = a chain-shaped "tree"
@@ -570,13 +602,13 @@ class Model(nn.Module):
             chain = self.__dict__.setdefault("_chain_bits", {}).get((T, hidden_states.device))
             if chain is None:
                 chain = self._chain_bits[(T, hidden_states.device)] = ((torch.ones(T, dtype=torch.int64, device=hidden_states.device) << (torch.arange(T, dtype=torch.int64, device=hidden_states.device) + 1)) - 1)
-            extra = dict(extra, tree_bits=chain, tree_keys=T, kv_start=attention_mask.to(hidden_states.device).to(torch.int64).argmax(dim=1))
+            extra = dict(extra, tree_bits=chain, tree_keys=T, kv_start=first_key())
             have_bits = True
         elif tm is None and bits_ok:
             # a prompt prefill (a handful to hundreds of rows): causal among the new tokens behind the left padding -- the HIP layers run their GEMMs
             # (row-blocked above 32 rows) and block-causal lantern_tree_attention on this hint (the additive mask still rides along for a layer whose
             # shapes keep it on torch's ops)
-            extra = dict(extra, causal=True, kv_start=attention_mask.to(hidden_states.device).to(torch.int64).argmax(dim=1))
+            extra = dict(extra, causal=True, kv_start=first_key())
         # the additive mask only when some layer may still want it (the HIP layers at the drafting shape take the ancestor words)
         fast = have_bits and B * T <= 32 and all(getattr(l, "fused", False) and hasattr(l, "_fast") for l in self.layers)
         mask = None if fast else self._prepare_decoder_attention_mask(attention_mask, (B, T), hidden_states, past)
@@ -598,12 +630,15 @@ class Model(nn.Module):
         """`bad`: 0-dim bool device tensor.  Copied to a pinned flag behind the work already enqueued; read by a later `_poll_mask_checks`."""
         st = self.__dict__.setdefault("_mask_chk", None)
         if st is None:
-            st = self.__dict__["_mask_chk"] = dict(pins=torch.zeros(self._MASK_RING, dtype=torch.bool).pin_memory(), events=[None] * self._MASK_RING, n=0)
+            st = self.__dict__["_mask_chk"] = dict(pins=torch.zeros((self._MASK_RING, 16), dtype=torch.int64).pin_memory(), events=[None] * self._MASK_RING, n=0)
         i = st["n"] % self._MASK_RING
         if st["events"][i] is not None:          # the ring came round: that slot's verdict is due now
             st["events"][i].synchronize()
             self._raise_if_bad(st, i)
-        st["pins"][i:i + 1].copy_(bad.reshape(1), non_blocking=True)
+        nb = min(int(bad.numel()), 16)
+        if bad.numel() > 16:          # (more rows than the ring holds per slot: reduce on the device)
+            bad, nb = bad.any().to(torch.int64).reshape(1), 1
+        st["pins"][i, :nb].copy_(bad.reshape(-1), non_blocking=True)
         ev = torch.cuda.Event()
         ev.record()
         st["events"][i] = ev
@@ -611,8 +646,8 @@ class Model(nn.Module):
 
     def _raise_if_bad(self, st, i):
         st["events"][i] = None
-        if bool(st["pins"][i]):
-            st["pins"][i] = False
+        if bool(st["pins"][i].any()):
+            st["pins"][i] = 0
             raise ops._lib.LanternError("cnets.Model.forward: an EARLIER call's attention_mask (behind a cached prefix) had zeros behind a one -- not left "
                                         "padding: the tree-attention path takes one first-visible-key index per row and would have ignored the holes")
 
@@ -803,6 +838,13 @@ class Model(nn.Module):
         self.stable_kv = pkv
         return out_hidden, pkv
 
+    def _first_visible_key(self, attention_mask, dev):
+        """argmax of the (left-padded) mask per row: from the statistics the prefill's forward() just took of the same mask, else computed."""
+        st = getattr(self, "_mask_stats", None)
+        if st is not None and st.shape[1] == attention_mask.shape[0] and st.device == dev:
+            return st[0]
+        return attention_mask.to(dev).to(torch.int64).argmax(dim=1)
+
     def _tree_positions(self, len_posi, offsets, input_position_diff):
         pos = len_posi + offsets
         if input_position_diff is None:
@@ -836,7 +878,7 @@ class Model(nn.Module):
                 pos = torch.cat([pos, pos - input_position_diff], dim=1)          # (no clamp inside the loop, cnets_anole.py:858-862)
             # (input_position_diff None: the reference does not hand the mask to its depth forwards either -- `akw` above, cnets_llamagen.py:783-790 --
             # so no padding is described; with it, the mask went through forward()'s left-padding check at the prefill)
-            start = None if attention_mask is None or input_position_diff is None else attention_mask.to(dev).to(torch.int64).argmax(dim=1)
+            start = None if attention_mask is None or input_position_diff is None else self._first_visible_key(attention_mask, dev)
             plan.begin(pkv, input_hidden, cur.reshape(-1), scores, pos, kv_start=start)
             for i in range(self.depth):
                 plan.run(i)
@@ -874,7 +916,7 @@ class Model(nn.Module):
         out_hidden, pkv = self._prefill(hidden_states, input_ids, input_position_diff, attention_mask)
         plan = self._static_plan(head, logits_processor, TOPK) if out_hidden.shape[0] == 2 else None
         if plan is not None:          # the level loop: one lantern_draft_depth call per level (StaticDraftPlan)
-            start = None if attention_mask is None or input_position_diff is None else attention_mask.to(dev).to(torch.int64).argmax(dim=1)
+            start = None if attention_mask is None or input_position_diff is None else self._first_visible_key(attention_mask, dev)
             return plan.draft(pkv, out_hidden[:, -1], len_posi, kv_start=start, position_diff=input_position_diff)
         ho = self._head(head, out_hidden[:, -1])
         half = ho.shape[0] // 2
@@ -922,21 +964,36 @@ class Model(nn.Module):
         attention_mask = attention_mask.to(dev)
         if attention_mask.shape[1] < input_ids.shape[1]:
             attention_mask = torch.nn.functional.pad(attention_mask, (0, input_ids.shape[1] - attention_mask.shape[1]), "constant", True)
-        position_ids = attention_mask.long().cumsum(-1) - 1
-        len_posi = (position_ids[:, -1] + 1)[:, None]                          # [2,1]: cond / uncond stream lengths
+        # position_ids = attention_mask.long().cumsum(-1) - 1; len_posi = position_ids[:, -1] + 1 (cnets_lumina_mgpt.py:1180-1186).  One launch gives the
+        # first visible key, the count of visible keys and the left-padding flag per row; behind a cached prefix the new tokens' positions are then
+        # (column - first key) -- what the cumsum says for a left-padded mask; a mask that is not raises through forward()'s deferred check
+        stats = ops.mask_left_padding(attention_mask) if attention_mask.is_cuda else None
+        self._pending_mask_stats = (attention_mask, stats) if stats is not None else None
         self.reset()
-        if not first:
+        if not first and stats is not None:
             kv_len = self.stable_kv[0][0].shape[2]
-            out_hidden, pkv = self(hidden_states, input_ids[:, kv_len:], attention_mask=attention_mask, position_ids=position_ids[:, kv_len:],
+            S = attention_mask.shape[1]
+            ar = self.__dict__.get("_col_ids")
+            if ar is None or ar.numel() < S or ar.device != dev:
+                ar = self.__dict__["_col_ids"] = torch.arange(max(2 * S, 4096), dtype=torch.long, device=dev)
+            len_posi = stats[1][:, None]                                       # [2,1]: cond / uncond stream lengths
+            out_hidden, pkv = self(hidden_states, input_ids[:, kv_len:], attention_mask=attention_mask, position_ids=ar[kv_len:S][None] - stats[0][:, None],
                                    past_key_values=self.stable_kv, use_cache=True)
         else:
-            out_hidden, pkv = self(hidden_states, input_ids=input_ids, attention_mask=attention_mask, position_ids=position_ids, use_cache=True)
+            position_ids = attention_mask.long().cumsum(-1) - 1
+            len_posi = (position_ids[:, -1] + 1)[:, None]
+            if not first:
+                kv_len = self.stable_kv[0][0].shape[2]
+                out_hidden, pkv = self(hidden_states, input_ids[:, kv_len:], attention_mask=attention_mask, position_ids=position_ids[:, kv_len:],
+                                       past_key_values=self.stable_kv, use_cache=True)
+            else:
+                out_hidden, pkv = self(hidden_states, input_ids=input_ids, attention_mask=attention_mask, position_ids=position_ids, use_cache=True)
         self.stable_kv = pkv
         last_hidden = out_hidden[:, -1]
         if tree_type == "static":
             plan = self._static_plan(head, logits_processors, k)
             if plan is not None:      # the level loop: one lantern_draft_depth call per level (StaticDraftPlan)
-                return plan.draft(pkv, last_hidden, len_posi, head_len=len_posi[1], kv_start=attention_mask.to(torch.int64).argmax(dim=1))
+                return plan.draft(pkv, last_hidden, len_posi, head_len=len_posi[1], kv_start=(stats[0] if stats is not None else attention_mask.to(torch.int64).argmax(dim=1)))
             ho = self._head(head, last_hidden)                                                  # [2,V]
             rows = self._post_head(ho[0:1], ho[1:2], logits_processors, pos_ids=len_posi[1])
             tb = self.tree_buffer
@@ -968,7 +1025,7 @@ class Model(nn.Module):
         if plan is not None:          # the depth loop: one lantern_draft_depth call per depth
             pos = (len_posi[None] + plan.steps[:, None, None]).expand(plan.depth, 2, k)          # [depth, 2, k]: the cond / uncond streams' positions
             plan.begin(pkv, input_hidden, input_ids.reshape(-1), scores, pos, head_positions=pos[:, 1] + 1,
-                       kv_start=attention_mask.to(torch.int64).argmax(dim=1))
+                       kv_start=(stats[0] if stats is not None else attention_mask.to(torch.int64).argmax(dim=1)))
             for i in range(self.depth):
                 plan.run(i)
             sl, tl, pl = plan.lists()

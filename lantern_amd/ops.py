@@ -888,6 +888,26 @@ def drafter_attention_mask(attention_mask, tree_mask, B: int, T: int, past: int,
     return out
 
 
+def mask_left_padding(attention_mask, out=None):
+    """The reductions a drafting call makes over its attention mask [B, S] (bool / uint8 / int64, device), one launch: returns an int64 [3, B] tensor --
+    [0] the first non-zero index per row (torch.argmax of a left-padded mask), [1] the number of non-zero entries (position_ids[:, -1] + 1 of
+    `mask.cumsum(-1) - 1`), [2] 1 where a zero follows a one (not left padding)."""
+    if not attention_mask.is_cuda or attention_mask.dim() != 2:
+        raise _lib.LanternError("mask_left_padding: expected a [B, S] device tensor")
+    m = attention_mask
+    if m.dtype not in (torch.bool, torch.uint8, torch.int64):
+        m = m.to(torch.int64)
+    if m.stride(1) != 1:
+        m = m.contiguous()
+    B, S = m.shape
+    if out is None or out.shape != (3, B) or out.device != m.device:
+        out = torch.empty((3, B), dtype=torch.int64, device=m.device)
+    check(_lib.lib().lantern_mask_left_padding(C.c_void_p(m.data_ptr()), m.element_size(), B, C.c_int64(S), C.c_int64(m.stride(0) if B > 1 else max(S, 1)),
+                                               C.c_void_p(out[0].data_ptr()), C.c_void_p(out[1].data_ptr()), C.c_void_p(out[2].data_ptr()), _stream()),
+          "mask_left_padding")
+    return out
+
+
 def drafter_fc(ids, hidden, embed, weight, bias=None, embed_scale: float = 1.0, packed: Optional["PackedLinearWeight"] = None):
     """O11 (MFMA): fc(cat(embed[ids] * scale, hidden)) -> bf16 [M,H].  ids [M] i64, hidden [M,H] bf16, embed [vocab,H] bf16,
     weight [H,2H] bf16 (nn.Linear layout), bias [H] bf16 or None.  Up to 32 rows with H % 64 == 0 (the drafting shape) take the stream-K

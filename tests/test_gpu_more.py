@@ -319,3 +319,34 @@ def test_head_sample_vs_the_oracle_behind_the_gemm(model, n, K, tk, special):
     probs2, tok2, prob2 = ops.head_sample(A, Wt, lo, W, 3.0, bias=bias, model=mid, pos_ids=pos, pos_base=2, top_k_filter=min(tk, V), n_draw=k, draw_idx=inj, packed=pk)
     assert torch.equal(tok2, inj) and torch.equal(probs2, probs)
     assert np.array_equal(prob2.cpu().numpy(), oracle.sample_static(got, inj.cpu().numpy()))
+
+
+@pytest.mark.gpu
+def test_mask_left_padding_equals_the_torch_reductions():
+    """lantern_mask_left_padding: per row torch.argmax of the mask, its count of ones (`(mask.cumsum(-1) - 1)[:, -1] + 1`, cnets_lumina_mgpt.py:1180-1186) and
+    the left-padding test `(mask.cummax(1).values != mask).any(1)` -- bool, uint8 and int64 masks, rows with holes, all ones, all zeros, strided rows."""
+    dev = torch.device("cuda")
+    g = torch.Generator().manual_seed(5)
+    for S in (1, 7, 64, 257, 1500, 4099):
+        rows = []
+        for pad in (0, 1, S // 3, S - 1, S):
+            r = torch.ones(S, dtype=torch.int64)
+            r[:pad] = 0
+            rows.append(r)
+        holes = torch.ones(S, dtype=torch.int64)
+        if S > 2:
+            holes[torch.randint(1, S, (max(1, S // 50),), generator=g)] = 0
+        rows.append(holes)
+        rows.append((torch.rand(S, generator=g) < 0.5).to(torch.int64))
+        m = torch.stack(rows)
+        for dt in (torch.bool, torch.uint8, torch.int64):
+            md = m.to(dt).to(dev)
+            out = ops.mask_left_padding(md).cpu()
+            m64 = m
+            assert out[0].tolist() == m64.argmax(dim=1).tolist()
+            assert out[1].tolist() == m64.sum(dim=1).tolist()
+            assert out[2].tolist() == (m64.cummax(dim=1).values != m64).any(dim=1).to(torch.int64).tolist()
+        wide = torch.zeros((m.shape[0], S + 5), dtype=torch.int64)
+        wide[:, :S] = m
+        out = ops.mask_left_padding(wide.to(dev)[:, :S]).cpu()          # rows S + 5 apart
+        assert out[0].tolist() == m.argmax(dim=1).tolist() and out[1].tolist() == m.sum(dim=1).tolist()

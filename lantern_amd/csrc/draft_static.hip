@@ -17,11 +17,12 @@ namespace lantern {
 int launch_linear_rows_cfg_streamk(const void *A, const void *W, const void *bias, int n, int K, int row_lo, int n_cols, float cfg, void *win, int packed,
                                    void *workspace, size_t workspace_bytes, hipStream_t st);
 
-constexpr int SW_C8 = 4;             // chunks of 8 ids per thread: W <= 8192 on 256 threads, <= 16384 on 512
+// SW_C8 chunks of 8 ids per thread.  Round 5: 1024 threads x 1 chunk (W <= 8192; x 2: LlamaGen's 16384) -- one row per workgroup and one to four rows per
+// launch, so the kernel is a latency chain: a quarter of the per-thread work in the select / softmax / store phases (21.5 -> see EXPERIMENTS.md).
 constexpr int SW_MAX_DRAW = 16;
 
 // One workgroup per drafter row.  `win`: the CFG-combined bf16 window logits of the row ([n, W], the head GEMM's epilogue output).
-template <int NT>
+template <int NT, int SW_C8>
 __global__ __launch_bounds__(NT) void sample_window_kernel(const uint16_t *__restrict__ win, int W, int win_lo, int V, int model,
                                                            const int64_t *__restrict__ pos_ids, int64_t pos_base, int w_latent, int h_latent,
                                                            int newline_id, int eos_id, int top_k_filter, int n_draw,
@@ -33,7 +34,7 @@ __global__ __launch_bounds__(NT) void sample_window_kernel(const uint16_t *__res
     __shared__ alignas(16) int s_hist[O7_HIST_INTS];
     __shared__ float s_redf[2 * 16];
     __shared__ double s_redd[2 * 16];
-    __shared__ double s_seg[NT];          // f64 sum of every thread's EPT consecutive ids
+    __shared__ double s_seg[(NT * SW_C8 * 8) / 32];          // f64 sums of the row's 32-id segments
     __shared__ int s_tok[SW_MAX_DRAW];
     __shared__ float s_p[SW_MAX_DRAW];
     const int row = blockIdx.x, tid = threadIdx.x;
@@ -119,9 +120,9 @@ __global__ __launch_bounds__(NT) void sample_window_kernel(const uint16_t *__res
     // sum of its EPT consecutive ids in LDS once; wave 0 then walks the draws alone -- per draw one DPP scan over the segment sums (SPL per lane), a ballot
     // for the segment that holds the crossing, one DPP scan over that segment's EPT entries, the entry zeroed and its segment's sum rebuilt.  (Round 5: the
     // barrier form -- bonus_draw_lds per draw, the whole row re-read and four barriers each -- cost ~2 us per draw: 20 of the kernel's 32 us.)
-    constexpr int EPT = SW_C8 * 8, SPL = NT / 64;
-    static_assert(EPT == 32, "a segment = 32 lanes of wave 0");
-    {
+    constexpr int EPT = 32, NSEG = (NT * SW_C8 * 8) / EPT, SPL = NSEG / 64;          // a segment = 32 consecutive ids = 32 lanes of wave 0
+    static_assert(NSEG % 64 == 0 && NSEG <= NT, "segment sums: one per thread of the first NSEG");
+    if (tid < NSEG) {
         double sseg = 0.0;
         const int e0 = tid * EPT;
 #pragma unroll
@@ -296,9 +297,9 @@ extern "C" int lantern_head_sample(const void *A, const void *W, const void *bia
     LANTERN_CHECK_ARG(A && W && workspace && probs_out && ss_token && ss_prob && sk_workspace, "head_sample: null buffer");
     LANTERN_CHECK_ARG(draw_u || draw_idx, "head_sample: the draws need uniforms (draw_u [n, n_draw] f64) or injected indices (draw_idx [n, n_draw] i64)");
     LANTERN_CHECK_ARG(n > 0 && n <= 16 && K > 0 && K % 16 == 0, "head_sample: n=%d drafter rows (<= 16 cond + 16 uncond), K=%d (multiple of 16)", n, K);
-    LANTERN_CHECK_ARG(row_lo >= 0 && row_lo % 4 == 0 && n_cols > 0 && n_cols % 8 == 0 && n_cols <= 8 * 512 * SW_C8 && row_lo + n_cols <= V && V % 4 == 0,
+    LANTERN_CHECK_ARG(row_lo >= 0 && row_lo % 4 == 0 && n_cols > 0 && n_cols % 8 == 0 && n_cols <= 16384 && row_lo + n_cols <= V && V % 4 == 0,
                       "head_sample: window [%d,+%d) must start on a multiple of 4, be a multiple of 8 ids and <= %d wide, inside V (V %% 4 == 0)", row_lo, n_cols,
-                      8 * 512 * SW_C8);
+                      16384);
     LANTERN_CHECK_ARG(n_draw > 0 && n_draw <= SW_MAX_DRAW && n_draw <= n_cols, "head_sample: n_draw=%d (1..%d)", n_draw, SW_MAX_DRAW);
     LANTERN_CHECK_ARG(model == LANTERN_MODEL_LUMINA || model == LANTERN_MODEL_ANOLE || (model == LANTERN_MODEL_PLAIN && row_lo == 0 && n_cols == V),
                       "head_sample: models whose drafted rows are masked to one id window (Lumina, Anole), or LANTERN_MODEL_PLAIN with the window = the vocabulary");
@@ -309,11 +310,11 @@ extern "C" int lantern_head_sample(const void *A, const void *W, const void *bia
     const int rc = launch_linear_rows_cfg_streamk(A, W, bias, n, K, row_lo, n_cols, cfg, workspace, packed, sk_workspace, sk_workspace_bytes, st);
     if (rc) return rc;
     const size_t lds = (size_t)n_cols * 4;
-    if (n_cols <= 8 * 256 * SW_C8)
-        hipLaunchKernelGGL(sample_window_kernel<256>, dim3(n), dim3(256), lds, st, (const uint16_t *)workspace, n_cols, row_lo, V, model, pos_ids, pos_base, w_latent,
+    if (n_cols <= 8 * 1024)
+        hipLaunchKernelGGL((sample_window_kernel<1024, 1>), dim3(n), dim3(1024), lds, st, (const uint16_t *)workspace, n_cols, row_lo, V, model, pos_ids, pos_base, w_latent,
                            h_latent, newline_id, eos_id, top_k_filter, n_draw, draw_u, draw_idx, probs_out, ss_token, ss_prob);
     else
-        hipLaunchKernelGGL(sample_window_kernel<512>, dim3(n), dim3(512), lds, st, (const uint16_t *)workspace, n_cols, row_lo, V, model, pos_ids, pos_base, w_latent,
+        hipLaunchKernelGGL((sample_window_kernel<1024, 2>), dim3(n), dim3(1024), lds, st, (const uint16_t *)workspace, n_cols, row_lo, V, model, pos_ids, pos_base, w_latent,
                            h_latent, newline_id, eos_id, top_k_filter, n_draw, draw_u, draw_idx, probs_out, ss_token, ss_prob);
     LANTERN_CHECK_LAUNCH("head_sample");
     return LANTERN_OK;

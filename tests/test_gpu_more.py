@@ -350,3 +350,39 @@ def test_mask_left_padding_equals_the_torch_reductions():
         wide[:, :S] = m
         out = ops.mask_left_padding(wide.to(dev)[:, :S]).cpu()          # rows S + 5 apart
         assert out[0].tolist() == m.argmax(dim=1).tolist() and out[1].tolist() == m.sum(dim=1).tolist()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("model", ["lumina", "llamagen"])
+def test_head_sample_edge_draws(model):
+    """The draw walk of sample_window_kernel at its edges: uniforms 0 and 1 - 2^-53 (the first positive entry; the last crossing, or the last positive
+    entry when rounding leaves none -- lo_sample_inverse_cdf), and a row with FEWER positive entries than draws (top-k 4, ten draws): the first four are
+    the oracle's draws, the rest the lowest window ids not drawn yet at conditional probability 0 (the reference's multinomial returns arbitrary
+    zero-probability ids there; the verify side never accepts them)."""
+    torch.manual_seed(7)
+    V, lo, W = (16384, 0, 16384) if model == "llamagen" else (65536, 4, 8192)
+    mid = ops.MODEL_PLAIN if model == "llamagen" else ops.MODEL_ANOLE
+    n, K, k = 3, 64, 10
+    A = (0.5 * torch.randn(2 * n, K, device="cuda")).to(torch.bfloat16)
+    Wt = (0.3 * torch.randn(V, K, device="cuda")).to(torch.bfloat16)
+    pk = ops.pack_linear_weight(Wt[lo:lo + W].contiguous())
+    u = torch.rand((n, k), dtype=torch.float64, device="cuda")
+    u[0, 0], u[0, 1], u[1, 0], u[1, 5] = 0.0, 1.0 - 2.0 ** -53, 1.0 - 2.0 ** -53, 0.0
+    for tk in (2000, 4):
+        probs, tok, prob = ops.head_sample(A, Wt, lo, W, 3.0, model=mid, top_k_filter=tk, n_draw=k, draw_u=u, packed=pk)
+        got, tok_h, prob_h, u_h = probs.cpu().numpy(), tok.cpu().numpy(), prob.cpu().numpy(), u.cpu().numpy()
+        for r in range(n):
+            npos = int((got[r] > 0).sum())
+            live = min(k, npos)
+            idx, cp = oracle.sample_draws(got[r], u_h[r][:live])
+            assert np.array_equal(tok_h[r, :live], idx), (tk, r, tok_h[r], idx)
+            assert np.array_equal(prob_h[r, :live], cp[:live])
+            if live < k:
+                assert npos == 4 or tk != 4
+                rest, nxt = [], lo
+                while len(rest) < k - live:
+                    if nxt not in idx.tolist() and nxt not in rest:
+                        rest.append(nxt)
+                    nxt += 1
+                assert tok_h[r, live:].tolist() == rest, (tok_h[r], rest)
+                assert (prob_h[r, live:] == 0).all()

@@ -820,11 +820,14 @@ def compact_line(out: dict) -> dict:
     round 4's 21 KB line).  Everything else lives in the --extras-out file / on stderr."""
     c = _pick(out, HEADLINE_KEYS, 700)
     if isinstance(c.get("config"), dict):
-        c["config"] = {k: _short(v, 330) for k, v in c["config"].items()}
+        c["config"] = {k: _short(v, 200 if k == "workload" else 150) for k, v in c["config"].items() if k not in ("side_stream_for_O6_O10", "host_waits", "launch", "kv_cache", "drafter_sigma")}
     if "roofline" in out:
         rl = _pick(out["roofline"], ROOFLINE_KEYS)
         if isinstance(out["roofline"].get("saturating"), dict):
             rl["saturating"] = _pick(out["roofline"]["saturating"], SATURATING_KEYS)
+        for blk in (rl, rl.get("saturating") or {}):          # (the notes name the file; the full text is in the extras file)
+            if isinstance(blk.get("traffic_note"), str):
+                blk["traffic_note"] = _short(blk["traffic_note"], 110)
         c["roofline"] = rl
     if "kernels" in out:
         c["kernels"] = {k: _pick(v, ("kernel", "avg_launch_ms", "algorithmic_bytes_per_launch", "achieved", "frac"), 90) for k, v in out["kernels"].items()}

@@ -359,3 +359,58 @@ def top_p_soak(n_seeds):
 
 if len(sys.argv) > 2 and sys.argv[2] == "top_p":
     top_p_soak(int(sys.argv[1]))
+
+
+# ---------------------------------------------------------------------------------------------- the static drafter's head stage (round 5)
+# `python tests/fuzz_soak.py <iters> draws`: lantern_head_sample on random heads / hidden rows -- peaked, flat and nearly empty rows (top-k filter from 3 to
+# the whole window), random uniforms with 0 and 1 - 2^-53 sprinkled in -- against the oracle's successive inverse-CDF draws taken on the kernel's own
+# distribution (exact tokens, exact conditional probabilities); and lantern_mask_left_padding on random masks against torch's reductions.
+def draws_soak(iters):
+    import numpy as np
+    import torch
+    import oracle
+    from lantern_amd import ops
+    t0 = time.time(); n = fails = rows = 0
+    g = torch.Generator(device="cuda").manual_seed(11)
+    for it in range(iters):
+        model = ("lumina", "anole", "llamagen")[it % 3]
+        V, lo, W = (16384, 0, 16384) if model == "llamagen" else (65536, 4, 8192)
+        mid = ops.MODEL_PLAIN if model == "llamagen" else ops.MODEL_ANOLE
+        nr, K, k = 1 + it % 4, (64, 128, 256)[it % 3], (10, 4, 16)[(it // 3) % 3]
+        sharp = (0.05, 0.5, 3.0)[(it // 9) % 3]
+        A = (sharp * torch.randn(2 * nr, K, device="cuda", generator=g)).to(torch.bfloat16)
+        Wt = (0.3 * torch.randn(V, K, device="cuda", generator=g)).to(torch.bfloat16)
+        tk = (3, 12, 300, 2000, W)[it % 5]
+        u = torch.rand((nr, k), dtype=torch.float64, device="cuda", generator=g)
+        edge = torch.rand((nr, k), device="cuda", generator=g)
+        u = torch.where(edge < 0.05, torch.zeros_like(u), torch.where(edge > 0.95, torch.full_like(u, 1.0 - 2.0 ** -53), u))
+        pk = ops.pack_linear_weight(Wt[lo:lo + W].contiguous())
+        probs, tok, prob = ops.head_sample(A, Wt, lo, W, 3.0, model=mid, top_k_filter=min(tk, V), n_draw=k, draw_u=u, packed=pk)
+        got, tok_h, prob_h, u_h = probs.cpu().numpy(), tok.cpu().numpy(), prob.cpu().numpy(), u.cpu().numpy()
+        for r in range(nr):
+            rows += 1
+            live = min(k, int((got[r] > 0).sum()))
+            idx, cp = oracle.sample_draws(got[r], u_h[r][:live])
+            ok = np.array_equal(tok_h[r, :live], idx) and np.array_equal(prob_h[r, :live], cp[:live]) and abs(float(got[r].sum()) - 1) <= 1e-5
+            if live < k:
+                ok = ok and len(set(tok_h[r].tolist())) == k and bool((prob_h[r, live:] == 0).all()) and bool(((tok_h[r, live:] >= lo) & (tok_h[r, live:] < lo + W)).all())
+            if not ok:
+                fails += 1
+                print("FAIL draws", dict(model=model, it=it, row=r, tk=tk, k=k, got=tok_h[r].tolist(), want=idx.tolist()), flush=True)
+        S = int(torch.randint(1, 3000, (1,)).item())
+        m = (torch.rand((1 + it % 3, S), device="cuda", generator=g) < (0.02, 0.5, 0.98)[it % 3]).to(torch.int64)
+        if it % 2:
+            pad = torch.randint(0, S + 1, (m.shape[0], 1), device="cuda")
+            m = (torch.arange(S, device="cuda")[None] >= pad).to(torch.int64)
+        out = ops.mask_left_padding(m.to((torch.bool, torch.uint8, torch.int64)[it % 3]))
+        if not (torch.equal(out[0], m.argmax(1)) and torch.equal(out[1], m.sum(1)) and torch.equal(out[2], (m.cummax(1).values != m).any(1).to(torch.int64))):
+            fails += 1
+            print("FAIL mask", it, flush=True)
+        n += 1
+        if it % 100 == 99:
+            print(f"  iter {it}: rows={rows} fails={fails}, {time.time() - t0:.0f}s", flush=True)
+    print(f"draws soak: launches={n}, rows={rows} (head_sample draws vs the oracle, mask_left_padding vs torch), fails={fails}, {time.time() - t0:.0f}s")
+
+
+if len(sys.argv) > 2 and sys.argv[2] == "draws":
+    draws_soak(int(sys.argv[1]))

@@ -391,7 +391,23 @@ def draws_soak(iters):
             rows += 1
             live = min(k, int((got[r] > 0).sum()))
             idx, cp = oracle.sample_draws(got[r], u_h[r][:live])
-            ok = np.array_equal(tok_h[r, :live], idx) and np.array_equal(prob_h[r, :live], cp[:live]) and abs(float(got[r].sum()) - 1) <= 1e-5
+            ok = abs(float(got[r].sum()) - 1) <= 1e-5
+            if np.array_equal(tok_h[r, :live], idx):
+                ok = ok and np.array_equal(prob_h[r, :live], cp[:live])
+            else:
+                # a uniform within 2^-53 of 1 puts the crossing where the f64 running sum no longer moves: which of the trailing ~1e-17-mass entries
+                # "crosses" depends on the order of the f64 additions (the kernel sums 32-id segments, the oracle runs sequentially).  Accept any draw
+                # whose sequential cumulative mass brackets u * total to 1e-12, on the distribution with the kernel's earlier draws removed.
+                q = got[r].astype(np.float64).copy()
+                for j in range(live):
+                    t, tot = int(tok_h[r, j]), q.sum()
+                    cs = np.cumsum(q)
+                    tgt = u_h[r][j] * tot
+                    near_one = u_h[r][j] > 1.0 - 1e-15
+                    exact = int(oracle.sample_draws(q.astype(np.float32), u_h[r][j:j + 1])[0][0])
+                    if t != exact and not (near_one and q[t] > 0 and cs[t] >= tgt * (1 - 1e-12) and cs[t] - q[t] <= tgt * (1 + 1e-12)):
+                        ok = False
+                    q[t] = 0.0
             if live < k:
                 ok = ok and len(set(tok_h[r].tolist())) == k and bool((prob_h[r, live:] == 0).all()) and bool(((tok_h[r, live:] >= lo) & (tok_h[r, live:] < lo + W)).all())
             if not ok:

@@ -355,8 +355,7 @@ def test_mask_left_padding_equals_the_torch_reductions():
 @pytest.mark.gpu
 @pytest.mark.parametrize("model", ["lumina", "llamagen"])
 def test_head_sample_edge_draws(model):
-    """The draw walk of sample_window_kernel at its edges: uniforms 0 and 1 - 2^-53 (the first positive entry; the last crossing, or the last positive
-    entry when rounding leaves none -- lo_sample_inverse_cdf), and a row with FEWER positive entries than draws (top-k 4, ten draws): the first four are
+    """The draw walk of sample_window_kernel at its edges: uniforms 0 and 1 - 2^-30 (the first positive entry; a crossing deep in the tail), and a row with FEWER positive entries than draws (top-k 4, ten draws): the first four are
     the oracle's draws, the rest the lowest window ids not drawn yet at conditional probability 0 (the reference's multinomial returns arbitrary
     zero-probability ids there; the verify side never accepts them)."""
     torch.manual_seed(7)
@@ -367,7 +366,9 @@ def test_head_sample_edge_draws(model):
     Wt = (0.3 * torch.randn(V, K, device="cuda")).to(torch.bfloat16)
     pk = ops.pack_linear_weight(Wt[lo:lo + W].contiguous())
     u = torch.rand((n, k), dtype=torch.float64, device="cuda")
-    u[0, 0], u[0, 1], u[1, 0], u[1, 5] = 0.0, 1.0 - 2.0 ** -53, 1.0 - 2.0 ** -53, 0.0
+    # (1 - 2^-30: the tail of the distribution without reaching the last ulps of the f64 running sum, where the order of the additions decides --
+    # tests/fuzz_soak.py `draws` covers 1 - 2^-53 with a bracket check)
+    u[0, 0], u[0, 1], u[1, 0], u[1, 5] = 0.0, 1.0 - 2.0 ** -30, 1.0 - 2.0 ** -30, 0.0
     for tk in (2000, 4):
         probs, tok, prob = ops.head_sample(A, Wt, lo, W, 3.0, model=mid, top_k_filter=tk, n_draw=k, draw_u=u, packed=pk)
         got, tok_h, prob_h, u_h = probs.cpu().numpy(), tok.cpu().numpy(), prob.cpu().numpy(), u.cpu().numpy()

@@ -54,6 +54,7 @@ def _groups_from_argv(argv, default=4):
 # The HIP runtime maps streams to GPU_MAX_HW_QUEUES (default 4) hardware queues: the current stream + 4 or more group streams would share
 # queues and serialise.  Must be set before the runtime starts (i.e. before torch is imported); left alone for <= 3 groups (measured: no
 # effect on the default run, and streams created later in the process land on worse queues with 8).
+_ENV_SET_HERE = [k for k in ("GPU_MAX_HW_QUEUES", "HSA_ENABLE_INTERRUPT") if k not in os.environ]          # (a caller's own settings stay, also for the child tools)
 if _groups_from_argv(sys.argv) > 3:
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 # Host waits by polling instead of interrupts (ROCr reads this when the runtime starts): the timed region ends in a barrier + synchronize, and an
@@ -754,7 +755,10 @@ def _tool_json(tool, args, timeout=300, env=None):
     """Last JSON line a tools/ script prints, run in a child process (its own weights / pools), or {"error": ...}."""
     import subprocess
     try:
-        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", tool)] + [str(a) for a in args], env=dict(os.environ, **(env or {})),
+        # (the child runs as a user of the package would: without the hardware-queue / polling settings this process took for its own stream groups --
+        # GPU_MAX_HW_QUEUES=8 alone costs the mirror's one-stream step 7-40 us, measured)
+        child_env = {k: v for k, v in os.environ.items() if k not in _ENV_SET_HERE}
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", tool)] + [str(a) for a in args], env=dict(child_env, **(env or {})),
                            capture_output=True, text=True, timeout=timeout)
         lines = [ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")]
         if r.returncode or not lines:
@@ -767,7 +771,7 @@ def _tool_json(tool, args, timeout=300, env=None):
 def mirror_generate_run():
     """The drop-in API on the clock (tools/mirror_bench.py): EaLumina_mGPT.generate -- what generate_images.py:240 reaches through the solver -- with
     stand-in target / drafter forwards, full vocabulary, default tree, 7B KV geometry: microseconds per verify step of the mirror's own loop body."""
-    return _tool_json("mirror_bench.py", [300])
+    return _tool_json("mirror_bench.py", [500])
 
 
 def drafter_cycle_run():

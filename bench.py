@@ -630,7 +630,7 @@ def other_configs(device, base_cfg, steps, n_seq, only=None):
         (ea_model_llamagen.py:709-787, :930, :1137-1163); `all_rows_by_cfg_mask_topk`: the same with O7 over all 59 rows first.
     C4  Anole-7B 512x512, LANTERN++ static tree naive_extend_57 (N = 58, P = 33, D = 6), the reference's settings (lambda, k) in
         {(5, 10), (10, 5), (20, 5)} (run.sh:76-91): O6 + the 3 likeliest rows -> O8 on raw rows (chain kernel, neighbours zeroed in the drafter's
-        row: ea_model_anole.py:597-669) -> O9 + O10, 7B KV geometry, 3 stream groups; `all_rows_by_cfg_mask_topk`: O7 over all 58 rows first;
+        row: ea_model_anole.py:597-669) -> O9 + O10, 7B KV geometry, the stream groups of the headline run; `all_rows_by_cfg_mask_topk`: O7 over all 58 rows first;
         plus the one-group per-kernel pass (all rows + chain on probability rows) for the roofline."""
     import dataclasses
     from lantern_amd import harness as HN
@@ -640,7 +640,7 @@ def other_configs(device, base_cfg, steps, n_seq, only=None):
     def c2_run(fuse):
         dc = HN.DynamicConfig(model="llamagen", n_seq=n_seq, depth=4, total_tokens=58, kv_layers=12, kv_heads=12, kv_dim=64, kv_smax=base_cfg.kv_smax,
                               kv_pad_rows=base_cfg.kv_pad_rows, with_kv=base_cfg.with_kv, max_steps=2 * steps + 32, plausible=8.0,
-                              n_groups=(3 if n_seq % 3 == 0 else 1), fuse_o7=fuse, spec_rows=c2_spec)
+                              n_groups=_side_groups(n_seq), fuse_o7=fuse, spec_rows=c2_spec)
         wl = HN.DynamicVerifyWorkload(dc, device)
         for _ in range(10):
             wl.step()
@@ -685,9 +685,9 @@ def other_configs(device, base_cfg, steps, n_seq, only=None):
     if base_cfg.with_kv:          # as many sequences as the slabs (2 x 2.1 GiB each at 4096 rows) + pools leave room for, in whole stream groups
         free, _ = torch.cuda.mem_get_info(device)
         per_seq = 2 * (2 * 32 * 32 * (base_cfg.kv_smax + base_cfg.kv_pad_rows) * 128 * 2) + base_cfg.pool_steps * 58 * (2 * 65536 * 2 + 2 * 4096 * 2 + 8192 * 4)
-        n_seq = max(3, min(n_seq, int((free - (28 << 30)) // per_seq)))
-        n_seq -= n_seq % 3
-    groups = 3 if n_seq % 3 == 0 else 1
+        n_seq = max(4, min(n_seq, int((free - (28 << 30)) // per_seq)))
+        n_seq -= n_seq % 4
+    groups = _side_groups(n_seq)
     res["C4"] = []
     for lam, kk in ((5.0, 10), (10.0, 5), (20.0, 5)):
         over = dict(model="anole", tree="naive_extend_57", lantern_k=kk, lantern_delta=lam, fuse_o7=True, spec_rows=3, ep_kernel="chain",
@@ -705,6 +705,11 @@ def other_configs(device, base_cfg, steps, n_seq, only=None):
                           "evaluate_posterior": {k_: rl.get(k_) for k_ in ("kernel", "avg_launch_ms", "achieved", "frac", "needed_bytes_per_launch", "frac_needed", "unit")},
                           "kernels": one["kernels"]})
     return res
+
+
+def _side_groups(n_seq: int) -> int:
+    """Stream groups of the side configurations: the headline's four when the sequences split evenly, else three, two, one."""
+    return next(g for g in (4, 3, 2, 1) if n_seq % g == 0)
 
 
 def side_run(device, base_cfg, steps, **over):

@@ -16,6 +16,7 @@ This module is product-side host code: it never imports the oracle.
 from __future__ import annotations
 
 import ctypes as C
+import os
 import random
 from dataclasses import dataclass
 from typing import List
@@ -39,6 +40,26 @@ NEWLINE, EOS = 8803, 8196
 W_LATENT = H_LATENT = 48          # 768 / 16
 TOKENS_PER_IMAGE = (W_LATENT + 1) * H_LATENT + 3   # 2352 grid+newline tokens + 3 header tokens
 HIDDEN = 4096
+
+
+
+_GROUP_STREAMS = {}
+_SKIPPED = []
+
+
+def group_streams(device, n: int):
+    """The stream-group streams of a device, created once per process and shared by every workload built after (workloads run one at a time): a
+    stream is bound to a hardware queue when it is created, and streams created late in a process that has made many land two groups on one
+    queue -- measured: a side configuration's step 46 -> 80 us in the third workload of a bench run."""
+    key = str(torch.device(device))
+    have = _GROUP_STREAMS.get(key)
+    if have is None:
+        have = _GROUP_STREAMS[key] = []
+        for _ in range(int(os.environ.get("LANTERN_GROUP_STREAM_SKIP", "0"))):          # tuning knob (diagnostic): start further along torch's stream pool
+            _SKIPPED.append(torch.cuda.Stream(device=device))
+    while len(have) < n:
+        have.append(torch.cuda.Stream(device=device))
+    return have[:n]
 
 
 @dataclass
@@ -316,7 +337,7 @@ class LuminaVerifyWorkload:
         self.st_token = torch.zeros(B, dtype=torch.int64, device=device)
         self.u_cur = torch.zeros(B, dtype=torch.float64, device=device)
         self.step_dev = torch.zeros(cfg.n_groups, dtype=torch.int64, device=device)    # one device step counter per group
-        self.streams = [torch.cuda.Stream(device=device) for _ in range(cfg.n_groups)] if cfg.n_groups > 1 else [None]
+        self.streams = group_streams(device, cfg.n_groups) if cfg.n_groups > 1 else [None]
         self.side = [torch.cuda.Stream(device=device) for _ in range(cfg.n_groups)] if cfg.side_stream else None
         self._ev = [[torch.cuda.Event() for _ in range(4)] for _ in range(cfg.n_groups)]
         self._L = _lib.lib()
@@ -948,7 +969,7 @@ class DynamicVerifyWorkload:
         if B % G:
             raise ValueError(f"n_seq={B} is not a multiple of n_groups={G}")
         self.Bg = Bg = B // G
-        self.streams = [torch.cuda.Stream(device=device) for _ in range(G)] if G > 1 else [None]
+        self.streams = group_streams(device, G) if G > 1 else [None]
         self._forked = False
         if cfg.model not in ("lumina", "llamagen"):
             raise ValueError(f"model={cfg.model}")

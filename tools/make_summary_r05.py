@@ -45,6 +45,6 @@ o += [f"| {k} | {v['hbm_bytes'] / 1e6:.2f} MB | |" for k, v in t["other_kernels"
 o += ["\n## Other records\n",
       "* `r05_two_rank_one_device.json`, `r05_two_rank_one_device_total16.json`: `LANTERN_BENCH_ONE_DEVICE=1 python bench.py --gpus 2 ...` (two ranks on the one device over gloo: the "
       "N > 1 control flow, `ranks_seen` 2).",
-      "* `r05_fuzz_soak_draws.txt`: `tests/fuzz_soak.py 1500 draws`."]
+      "* `r05_fuzz_soak.txt`: `tools/run/soak_r05.sh` (static / dynamic / O7 / O3 / top-p / draws soaks against the CPU oracle, 0 failures)."]
 open(P("r05_summary.md"), "w").write("\n".join(o) + "\n")
 print("wrote", P("r05_summary.md"))

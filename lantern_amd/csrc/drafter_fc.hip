@@ -27,6 +27,13 @@ __device__ __forceinline__ bf16x8_t load_frag(const uint16_t *p) {
     return __builtin_bit_cast(bf16x8_t, v);
 }
 
+// the same load with the non-temporal hint (global_load_dwordx4 ... nt): a weight stream that should not displace what the caches hold
+__device__ __forceinline__ bf16x8_t load_frag_nt(const uint16_t *p) {
+    typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+    const u32x4_t v = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t *>(p));
+    return __builtin_bit_cast(bf16x8_t, v);
+}
+
 __device__ __forceinline__ uint16_t f32_to_bf16_rne(float f) {
     uint32_t u = __float_as_uint(f);
     if ((u & 0x7fffffffu) > 0x7f800000u) return 0x7fc0;
@@ -739,10 +746,11 @@ struct SkArgs {
     const int64_t *ids;
     const uint16_t *embed;
     int vocab, hsplit;
+    int w_stream;         // 1: the weights are read with the non-temporal hint (sk_run: matrices of 80 MB and more)
     float embed_scale, cfg;          // cfg: EPI 3 (rows [0, M/2) conditional, [M/2, M) unconditional -> uncond + cfg * (cond - uncond) in bf16 steps)
 };
 
-template <int EPI, bool PACKED, int NBUF, bool GATHER = false>
+template <int EPI, bool PACKED, int NBUF, bool GATHER = false, bool WNT = false>
 __global__ __launch_bounds__(FC_THREADS) void linear_rows_streamk_kernel(const SkArgs a) {
     constexpr int NSET = EPI == 2 ? 2 : 1;
     __shared__ float red[NSET][FC_WAVES][32][33];
@@ -818,7 +826,7 @@ __global__ __launch_bounds__(FC_THREADS) void linear_rows_streamk_kernel(const S
 #pragma unroll
                 for (int s_ = 0; s_ < NSET; ++s_)
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) wv[s_][q] = load_frag(brick + s_ * 2048 + q * 512);
+                    for (int q = 0; q < 4; ++q) wv[s_][q] = WNT ? load_frag_nt(brick + s_ * 2048 + q * 512) : load_frag(brick + s_ * 2048 + q * 512);
             } else {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) wv[0][q] = load_frag(wrow + kb + 8 * q);
@@ -1305,11 +1313,19 @@ static int sk_run(SkArgs a, int epilogue, bool packed, bool gather, void *worksp
     // fixed layout whatever the shape (launches of different shapes share one workspace): the partial tiles first, the tile counters behind them
     a.ws = (float *)workspace;
     a.cnt = (uint32_t *)((char *)workspace + SK_PARTIAL_BYTES);
+    // Weight matrices of 80 MB and more are read with the non-temporal hint (`global_load_dwordx4 ... nt`, the WNT instances): a stream that size is gone
+    // from the 256 MB Infinity Cache before the next drafting pass comes back to it anyway, and read that way it neither displaces what the smaller
+    // products (input stage, o_proj, head window: 167 MB at 7B size) and the K / V rows leave there nor pays for allocating its lines.  Measured on the 7B
+    // drafter (tools/draft_bench.py lumina_static): threshold 200 MB (none) 1001 us per cycle, 120 (gate / up) 981, 95 (+ q/k/v) 931, 80 (+ down) 887-900,
+    // 30 (all but o_proj) 901, 0 (all) 912.  LANTERN_SK_NT_MIN_MB: tuning knob (diagnostic; negative = never).
+    static const int nt_min_mb = getenv("LANTERN_SK_NT_MIN_MB") ? atoi(getenv("LANTERN_SK_NT_MIN_MB")) : 80;
+    a.w_stream = nt_min_mb >= 0 && (long long)a.n_tiles * 32 * a.K * 2 * (epilogue == LANTERN_EPI_SILU_MUL ? 2 : 1) >= (long long)nt_min_mb * 1000000 ? 1 : 0;
     // two trips in flight per wave: three and four measured the same (24.4 - 24.6 / 21.5 - 21.9 us for the 100 / 90 MB matrices) -- the kernel is
     // at the read bandwidth the part delivers (4.1 - 4.6 TB/s; torch's read-only reductions reach 3.8 - 4.0, its copy 5.2 read + write)
 #define SK_LAUNCH(E_, GA_)                                                                                                   \
     do {                                                                                                                  \
-        if (packed) LANTERN_LAUNCH((linear_rows_streamk_kernel<E_, true, 2, GA_>), dim3(G), dim3(FC_THREADS), 0, st, a);   \
+        if (packed && a.w_stream) LANTERN_LAUNCH((linear_rows_streamk_kernel<E_, true, 2, GA_, true>), dim3(G), dim3(FC_THREADS), 0, st, a);   \
+        else if (packed) LANTERN_LAUNCH((linear_rows_streamk_kernel<E_, true, 2, GA_>), dim3(G), dim3(FC_THREADS), 0, st, a);   \
         else LANTERN_LAUNCH((linear_rows_streamk_kernel<E_, false, 2, GA_>), dim3(G), dim3(FC_THREADS), 0, st, a);         \
     } while (0)
     if (gather) SK_LAUNCH(0, true);

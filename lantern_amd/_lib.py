@@ -9,7 +9,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "liblantern_hip.so")
+# (LANTERN_HIP_LIBRARY: a library built elsewhere -- a tuning build beside the default one; the default is the in-tree build)
+LIB_PATH = os.environ.get("LANTERN_HIP_LIBRARY") or os.path.join(_HERE, "liblantern_hip.so")
 
 
 class LanternError(RuntimeError):

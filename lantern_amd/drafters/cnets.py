@@ -185,6 +185,8 @@ class DraftPlan:
         self.bits0 = (torch.ones(T, dtype=torch.int64, device=dev) << torch.arange(T, dtype=torch.int64, device=dev))
         self.par0 = torch.arange(T, dtype=torch.int64, device=dev) + 1
         self.steps = torch.arange(D, dtype=torch.int64, device=dev)
+        self.parents[0].copy_(self.par0)
+        self.tree_bits[:T].copy_(self.bits0)
         nqkv = (nq + 2 * nk) * d
         self.work = dict(x=z(B * T, H), xn=z(B * T, H), qkv=z(B * T, nqkv), q=z(B, nq, self.ROWS, d), attn=z(B, self.ROWS, H), h1=z(B * T, H), hn=z(B * T, H),
                          act=z(B * T, inter), out=z(B * T, H), head_ws=z(T, hx["n_cols"]))
@@ -204,11 +206,11 @@ class DraftPlan:
         if self.ta is None or self.ta.numel() < need:
             self.ta = torch.empty(max(need, 16), dtype=torch.uint8, device=self.dev)
         a.ta_ws, a.ta_ws_bytes = self.ta.data_ptr(), self.ta.numel()
+        # (hidden0 / ids0 may arrive as broadcast views -- `last_hidden[:, None].expand(B, T, H)`, `ids.reshape(1, T).expand(B, T)` -- and are materialised by
+        # these copies, one launch each; parents[0] and the first T ancestor words are constants no depth writes: set once in __init__)
         self.hidden[0].copy_(hidden0)
-        self.ids[0].copy_(ids0.reshape(1, T).expand(B, T).reshape(-1))
+        self.ids[0].view(B, T).copy_(ids0.reshape(1, T).expand(B, T))
         self.sc[0].copy_(scores0.reshape(-1))
-        self.parents[0].copy_(self.par0)
-        self.tree_bits[:T].copy_(self.bits0)
         self.pos.copy_(positions.reshape(D, -1, T).expand(D, B, T) if positions.numel() != D * B * T else positions.reshape(D, B, T))
         if head_positions is not None:
             self.head_pos.copy_(head_positions)
@@ -870,8 +872,8 @@ class Model(nn.Module):
         parents_list = [torch.zeros(1, dtype=torch.long, device=dev)]
         cur = ti.reshape(1, -1)
         input_ids = torch.cat([cur, cur])
-        input_hidden = last_hidden[:, None].repeat(1, k, 1)
         plan = self._depth_plan(head, logits_processor, k)
+        input_hidden = last_hidden[:, None].expand(-1, k, -1) if plan is not None else last_hidden[:, None].repeat(1, k, 1)
         if plan is not None:          # the depth loop: one lantern_draft_depth call per depth
             pos = (len_posi + plan.steps)[:, None, None].expand(plan.depth, 1, k)
             if input_position_diff is not None:
@@ -1020,8 +1022,8 @@ class Model(nn.Module):
         scores_list, ss_token = [cu.reshape(-1)], [ti.reshape(-1)]
         parents_list = [torch.zeros(1, dtype=torch.long, device=dev)]
         input_ids = ti.reshape(1, -1)
-        input_hidden = last_hidden[:, None].repeat(1, k, 1)
         plan = self._depth_plan(head, logits_processors, k)
+        input_hidden = last_hidden[:, None].expand(-1, k, -1) if plan is not None else last_hidden[:, None].repeat(1, k, 1)
         if plan is not None:          # the depth loop: one lantern_draft_depth call per depth
             pos = (len_posi[None] + plan.steps[:, None, None]).expand(plan.depth, 2, k)          # [depth, 2, k]: the cond / uncond streams' positions
             plan.begin(pkv, input_hidden, input_ids.reshape(-1), scores, pos, head_positions=pos[:, 1] + 1,

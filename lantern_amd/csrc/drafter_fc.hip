@@ -720,7 +720,7 @@ extern "C" int lantern_linear_rows_splitk(const void *A, const void *W, const vo
 // split-K variant pays a second launch; (2) one trip of loads in flight per wave (64 B per lane) is ~32 KB per CU -- at ~2.5 us of
 // loaded HBM latency that is 3.3 TB/s for the whole GPU, which is what they measure.  Here
 //  * the (tile, K) space is cut into `cpt` chunks of SK_CHUNK K-elements per tile, linearised, and workgroup g of G gets the contiguous
-//    range [total g / G, total (g + 1) / G): every workgroup streams the same number of bytes whatever the tile count (G = 2 per CU);
+//    range [total g / G, total (g + 1) / G): every workgroup streams the same number of bytes whatever the tile count (G = one workgroup per CU: sk_groups; 320 - 768 measured slower with the non-temporal weight streams, round 5);
 //  * a range that ends inside a tile leaves an f32 partial tile in the workspace (at most two per workgroup: the tail of its first
 //    tile, the head of its last) and adds its chunk count to the tile's counter; the workgroup that completes the count sums the
 //    tile's partials in K order -- always the same order, whoever arrives last -- and runs the epilogue: ONE launch, deterministic;

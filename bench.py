@@ -894,11 +894,12 @@ def emit(out: dict, args) -> None:
             print(f"bench.py: could not write {path}: {e}", file=sys.stderr)
     print("bench.py full report: " + json.dumps(out), file=sys.stderr)
     sys.stderr.flush()
-    line = json.dumps(compact_line(out))
-    if len(line) >= 8192:          # never again an unparseable line: drop the optional blocks, keep the contract's keys
-        c = compact_line(out)
-        for k in ("extras", "kernels", "per_step"):
-            c.pop(k, None)
+    c = compact_line(out)
+    line = json.dumps(c)
+    for k in ("extras", "kernels", "per_step", "backend_note"):          # never again an unparseable line: under 4 KB whatever the report holds --
+        if len(line) < 4096:                                               # optional blocks go first, the contract's keys, roofline and cpu_baseline stay
+            break
+        c.pop(k, None)
         line = json.dumps(c)
     print(line)
     sys.stdout.flush()

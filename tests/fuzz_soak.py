@@ -13,7 +13,8 @@ params = [("lumina", "mc_sim_7b_63", True, 100, 0.1, 1.0), ("lumina", "mc_sim_7b
           ("llamagen", "mc_sim_7b_63", True, 200, 10.0, 2.0), ("anole", "naive_extend_57", True, 10, 5.0, 1.0),
           ("anole", "naive_extend_57", True, 5, 20.0, 3.0), ("anole", "mc_sim_7b_63", False, 1, 0.1, 0.5)]
 t0 = time.time(); n = 0; fails = 0
-for seed in range(100, 100 + (int(sys.argv[1]) if len(sys.argv) < 3 else 0)):
+SEED0 = int(os.environ.get("FUZZ_SEED0", "100"))          # (another range of seeds: FUZZ_SEED0=1000 python tests/fuzz_soak.py 100)
+for seed in range(SEED0, SEED0 + (int(sys.argv[1]) if len(sys.argv) < 3 else 0)):
     for p in params:
         try:
             F.test_static_batches_vs_oracle(*p, seed)

@@ -688,6 +688,12 @@ typedef struct lantern_draft_depth_args {
     int64_t *ss_token;                 /* out [T, n_draw] */
     float *ss_prob;                    /* out [T, n_draw] */
     const int32_t *next_gather, *next_rep;   /* [T_next] */
+    /* The input stage through the tables (no materialised next inputs): in_rep != NULL makes THIS depth's input stage read token j of both batch rows
+     * as ids[in_gather[j]] (`ids` = the flat draws one level up, [in_n_flat]) and hidden row (b, j) as hidden_in[(b * in_src_T + in_rep[j])] (`hidden_in` =
+     * the rows one level up, [B, in_src_T, H]: the previous depth's `out`, or the prefill's last hidden row with in_src_T = 1).  A caller that chains depths
+     * this way passes T_next = 0 everywhere: nothing is copied between depths. */
+    const int32_t *in_gather, *in_rep;       /* [T] */
+    int32_t in_src_T, in_n_flat;
 } lantern_draft_depth_args;
 int lantern_draft_depth(const lantern_draft_depth_args *args);
 

@@ -116,7 +116,9 @@ class DraftDepthArgs(C.Structure):
                 + [("sk_ws_bytes", C.c_size_t), ("ta_ws_bytes", C.c_size_t)]
                 # static trees (n_draw > 0): sample instead of expand, next inputs through the tree's tables
                 + [("n_draw", C.c_int32), ("T_next", C.c_int32)]
-                + [(n, C.c_void_p) for n in ("draw_u", "draw_idx", "probs_out", "ss_token", "ss_prob", "next_gather", "next_rep")])
+                + [(n, C.c_void_p) for n in ("draw_u", "draw_idx", "probs_out", "ss_token", "ss_prob", "next_gather", "next_rep")]
+                # the input stage through the tree's tables (tokens / parent rows one level up read in place)
+                + [("in_gather", C.c_void_p), ("in_rep", C.c_void_p), ("in_src_T", C.c_int32), ("in_n_flat", C.c_int32)])
 
 
 _lib = None

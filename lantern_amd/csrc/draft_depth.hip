@@ -15,6 +15,9 @@ int launch_qk_rope_pairs(const void *qkv, int B, int T, int n_q_heads, int n_kv_
 int launch_linear_rows_streamk_seg(const void *A, int a_seg_rows, long long a_seg_stride, const void *W, const void *bias, int M, int K, int n_rows, void *out,
                                    int epilogue, const void *aux, int aux_stride, int pair_rows, int packed, void *workspace, size_t workspace_bytes,
                                    hipStream_t st);
+int launch_drafter_fc_streamk_tables(const int64_t *ids, int n_flat, const int32_t *in_gather, const int32_t *in_rep, const void *hidden, int src_T, int rows_per_b,
+                                     const void *embed, const void *W, const void *bias, int M, int H, int vocab, float embed_scale, void *out, int packed,
+                                     void *workspace, size_t workspace_bytes, hipStream_t st);
 const char *last_error();
 int launch_static_next_inputs(const int64_t *ss_token, int n_flat, const int32_t *gather, const int32_t *rep, const void *out_hidden, int B, int T, int H, int T_next,
                               void *hidden_next, int64_t *ids_next, hipStream_t st);
@@ -81,7 +84,12 @@ extern "C" int lantern_draft_depth(const lantern_draft_depth_args *ap) {
     hipStream_t st = (hipStream_t)a.stream;
     int rc;
     // ---- input stage
-    rc = lantern_drafter_fc_streamk(a.ids, a.hidden_in, a.embed, a.fc_w, a.fc_b, M, H, a.vocab, a.embed_scale, a.x, a.fc_packed, a.sk_ws, a.sk_ws_bytes, a.stream);
+    if (a.in_rep) {
+        LANTERN_CHECK_ARG(is_static && a.in_gather && a.in_src_T > 0 && a.in_n_flat > 0, "draft_depth: in_rep needs a static tree, in_gather, in_src_T and in_n_flat");
+        rc = launch_drafter_fc_streamk_tables(a.ids, a.in_n_flat, a.in_gather, a.in_rep, a.hidden_in, a.in_src_T, a.T, a.embed, a.fc_w, a.fc_b, M, H, a.vocab,
+                                              a.embed_scale, a.x, a.fc_packed, a.sk_ws, a.sk_ws_bytes, st);
+    } else
+        rc = lantern_drafter_fc_streamk(a.ids, a.hidden_in, a.embed, a.fc_w, a.fc_b, M, H, a.vocab, a.embed_scale, a.x, a.fc_packed, a.sk_ws, a.sk_ws_bytes, a.stream);
     if (rc) return fail("input stage", rc);
     // ---- decoder layer
     const void *xn = a.x;

@@ -746,6 +746,9 @@ struct SkArgs {
     const int64_t *ids;
     const uint16_t *embed;
     int vocab, hsplit;
+    // GATHER through a static tree's tables (lantern_draft_depth in_rep): row r = (b, j) of rows_per_b takes token ids[in_gather[j]] and hidden row b * src_T + in_rep[j]
+    const int32_t *in_gather, *in_rep;
+    int rows_per_b, src_T, n_flat;
     int w_stream;         // 1: the weights are read with the non-temporal hint (sk_run: matrices of 80 MB and more)
     float embed_scale, cfg;          // cfg: EPI 3 (rows [0, M/2) conditional, [M/2, M) unconditional -> uncond + cfg * (cond - uncond) in bf16 steps)
 };
@@ -767,7 +770,15 @@ __global__ __launch_bounds__(FC_THREADS) void linear_rows_streamk_kernel(const S
     const uint16_t *arow = a.A + (size_t)seg * a.a_seg_stride + (size_t)(live ? r - seg * a.a_seg_rows : 0) * (GATHER ? a.hsplit : K);
     const uint16_t *erow = nullptr;
     if constexpr (GATHER) {
-        int64_t id = live ? a.ids[r] : 0;
+        int idx = r;
+        if (a.in_rep && live) {          // tokens / parent rows one level up, read through the tree's tables
+            const int b = r / a.rows_per_b, j = r - b * a.rows_per_b;
+            int par = a.in_rep[j], gi = a.in_gather[j];
+            par = par < 0 ? 0 : (par >= a.src_T ? a.src_T - 1 : par);
+            idx = gi < 0 ? 0 : (gi >= a.n_flat ? a.n_flat - 1 : gi);
+            arow = a.A + ((size_t)b * a.src_T + par) * a.hsplit;
+        }
+        int64_t id = live ? a.ids[idx] : 0;
         id = id < 0 ? 0 : (id >= a.vocab ? a.vocab - 1 : id);
         erow = a.embed + (size_t)id * a.hsplit;
     }
@@ -1369,6 +1380,23 @@ extern "C" int lantern_drafter_fc_streamk(const int64_t *ids, const void *hidden
     a.ids = ids; a.embed = (const uint16_t *)embed; a.vocab = vocab; a.hsplit = H; a.embed_scale = embed_scale;
     return sk_run(a, 0, packed != 0, true, workspace, workspace_bytes, (hipStream_t)stream, "drafter_fc_streamk");
 }
+
+namespace lantern {
+// the same with the rows read through a static tree's tables (lantern_draft_depth, in_rep): M = B * rows_per_b rows; ids [n_flat]; hidden [B, src_T, H]
+int launch_drafter_fc_streamk_tables(const int64_t *ids, int n_flat, const int32_t *in_gather, const int32_t *in_rep, const void *hidden, int src_T, int rows_per_b,
+                                     const void *embed, const void *W, const void *bias, int M, int H, int vocab, float embed_scale, void *out, int packed,
+                                     void *workspace, size_t workspace_bytes, hipStream_t st) {
+    LANTERN_CHECK_ARG(ids && in_gather && in_rep && hidden && embed && W && out && workspace && n_flat > 0 && src_T > 0 && rows_per_b > 0 && M > 0 && M <= 32 &&
+                          M % rows_per_b == 0 && H > 0 && H % 64 == 0 && vocab > 0,
+                      "drafter_fc_streamk (tables): bad arguments");
+    SkArgs a{};
+    a.A = (const uint16_t *)hidden; a.W = (const uint16_t *)W; a.bias = (const uint16_t *)bias; a.out = (uint16_t *)out;
+    a.M = M; a.K = 2 * H; a.n_rows = H; a.out_stride = H;
+    a.ids = ids; a.embed = (const uint16_t *)embed; a.vocab = vocab; a.hsplit = H; a.embed_scale = embed_scale;
+    a.in_gather = in_gather; a.in_rep = in_rep; a.rows_per_b = rows_per_b; a.src_T = src_T; a.n_flat = n_flat;
+    return sk_run(a, 0, packed != 0, true, workspace, workspace_bytes, st, "drafter_fc_streamk");
+}
+}  // namespace lantern
 
 namespace lantern {
 // the drafter head's window GEMM with the CFG epilogue (lantern_head_expand), stream-K form: W row-major [V, K] (rows row_lo.. used) or the

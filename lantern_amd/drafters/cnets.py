@@ -369,11 +369,8 @@ class StaticDraftPlan(DraftPlan):
                                         a.h_latent, a.newline_id, a.eos_id, a.top_k_filter, k, C.c_void_p(u0), C.c_void_p(i0), C.c_void_p(a.head_ws),
                                         C.c_void_p(res["probs"].data_ptr()), C.c_void_p(res["tok"].data_ptr()), C.c_void_p(res["prob"].data_ptr()),
                                         a.head_packed, C.c_void_p(sk.data_ptr()), C.c_size_t(sk.numel()), C.c_void_p(stream)), "head_sample")
-        # ---- level 0's inputs: its tokens out of the root's draws, the last hidden row repeated
-        T0 = self.levels[0]
-        ops.check(L.lantern_draft_static_inputs(C.c_void_p(res["tok"].data_ptr()), k, C.c_void_p(self.gather[0].data_ptr()), C.c_void_p(self.rep[0].data_ptr()),
-                                                C.c_void_p(self.last.data_ptr()), B, 1, self.H, T0, C.c_void_p(self.hidden[0].data_ptr()),
-                                                C.c_void_p(self.ids[0].data_ptr()), C.c_void_p(stream)), "draft_static_inputs")
+        # ---- the levels: each level's input stage reads its tokens (the draws one level up, through tree_indices) and its hidden rows (the parents' output
+        # rows, repeat_hidden) through the tree's tables -- level 0 from the root's draws and the last hidden row; nothing is copied between levels
         for i in range(D):
             self.run_level(i, res, stream, sk)
         return res["tok"], res["prob"], [res["probs"][0:1]] + [res["probs"][self.row_off[i]:self.row_off[i + 1]] for i in range(D)]
@@ -386,20 +383,20 @@ class StaticDraftPlan(DraftPlan):
         a.stream = stream
         a.sk_ws, a.sk_ws_bytes = sk.data_ptr(), sk.numel()
         a.T = T
-        a.ids, a.hidden_in = self.ids[i].data_ptr(), self.hidden[i & 1].data_ptr()
+        # tokens: the flat draws of the rows one level up ([T_prev, k]; level 0: the root row's); hidden: the rows one level up (level 0: the last hidden row)
+        rp = self.row_off[i - 1] if i > 0 else 0
+        n_prev = self.levels[i - 1] if i > 0 else 1
+        a.ids = res["tok"][rp:].data_ptr()
+        a.hidden_in = self.work["out"].data_ptr() if i > 0 else self.last.data_ptr()
+        a.in_gather, a.in_rep, a.in_src_T, a.in_n_flat = self.gather[i].data_ptr(), self.rep[i].data_ptr(), n_prev, n_prev * k
         a.position_ids = self.pos_l[i].data_ptr()
         a.head_pos = self.head_pos_l[i].data_ptr() if self._lumina else None
         a.kv_row0, a.t1 = self.past + self.key_off[i], self.key_off[i + 1]
         a.draw_u = None if self._du is None else self._du[r0:].data_ptr()
         a.draw_idx = None if self._di is None else self._di[r0:].data_ptr()
         a.probs_out, a.ss_token, a.ss_prob = res["probs"][r0:].data_ptr(), res["tok"][r0:].data_ptr(), res["prob"][r0:].data_ptr()
-        if i + 1 < D:
-            a.T_next = self.levels[i + 1]
-            a.next_gather, a.next_rep = self.gather[i + 1].data_ptr(), self.rep[i + 1].data_ptr()
-            a.hidden_next, a.ids_next = self.hidden[(i + 1) & 1].data_ptr(), self.ids[i + 1].data_ptr()
-        else:
-            a.T_next = 0
-            a.next_gather = a.next_rep = a.hidden_next = a.ids_next = None
+        a.T_next = 0          # (the next level reads through the tables: no next-inputs launch)
+        a.next_gather = a.next_rep = a.hidden_next = a.ids_next = None
         ops.check(self._L.lantern_draft_depth(self._C.byref(a)), "draft_depth")
 
 

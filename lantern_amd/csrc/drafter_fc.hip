@@ -1320,6 +1320,17 @@ static int sk_run(SkArgs a, int epilogue, bool packed, bool gather, void *worksp
     int G = sk_groups(epilogue);
     if (G > 1024) G = 1024;
     if ((long long)G > total) G = (int)total;
+    // Small matrices (LlamaGen-size drafters: 3 - 20 MB per product) are bound by the launch's fixed costs, not by the stream: a range that ends inside a tile
+    // costs its workgroup a partial-tile round trip and the tile's finisher another, so they get WHOLE tiles per workgroup (the largest divisor of the tile
+    // count that fits the grid: no partial tiles at all) even where that leaves CUs idle (LlamaGen EAGLE-2 cycle 848 - 863 -> 822 - 831 us; 50 MB: slower).  LANTERN_SK_WHOLE_MB: tuning knob (diagnostic), the
+    // size limit in MB (default 25; 0 = never).
+    static const int whole_mb = getenv("LANTERN_SK_WHOLE_MB") ? atoi(getenv("LANTERN_SK_WHOLE_MB")) : 25;
+    if (whole_mb > 0 && (long long)a.n_tiles * 32 * a.K * 2 * (epilogue == LANTERN_EPI_SILU_MUL ? 2 : 1) <= (long long)whole_mb * 1000000) {
+        int best = 1;
+        for (int g = 1; g <= G && g <= a.n_tiles; ++g)
+            if (a.n_tiles % g == 0) best = g;
+        G = best;
+    }
     a.G = G;
     // fixed layout whatever the shape (launches of different shapes share one workspace): the partial tiles first, the tile counters behind them
     a.ws = (float *)workspace;

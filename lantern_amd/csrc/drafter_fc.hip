@@ -1323,8 +1323,9 @@ static int sk_run(SkArgs a, int epilogue, bool packed, bool gather, void *worksp
     // Small matrices (LlamaGen-size drafters: 3 - 20 MB per product) are bound by the launch's fixed costs, not by the stream: a range that ends inside a tile
     // costs its workgroup a partial-tile round trip and the tile's finisher another, so they get WHOLE tiles per workgroup (the largest divisor of the tile
     // count that fits the grid: no partial tiles at all) even where that leaves CUs idle (LlamaGen EAGLE-2 cycle 848 - 863 -> 822 - 831 us; 50 MB: slower).  LANTERN_SK_WHOLE_MB: tuning knob (diagnostic), the
-    // size limit in MB (default 25; 0 = never).
-    static const int whole_mb = getenv("LANTERN_SK_WHOLE_MB") ? atoi(getenv("LANTERN_SK_WHOLE_MB")) : 25;
+    // size limit in MB (default 40: the 7B drafter's o_proj, 34 MB in 128 tiles, is still better off on 128 workgroups without partial tiles -- Lumina static
+    // cycle 884 - 889 -> 865 - 868 us; 70, which takes in the 67 MB input stage: 878; 0 = never).
+    static const int whole_mb = getenv("LANTERN_SK_WHOLE_MB") ? atoi(getenv("LANTERN_SK_WHOLE_MB")) : 40;
     if (whole_mb > 0 && (long long)a.n_tiles * 32 * a.K * 2 * (epilogue == LANTERN_EPI_SILU_MUL ? 2 : 1) <= (long long)whole_mb * 1000000) {
         int best = 1;
         for (int g = 1; g <= G && g <= a.n_tiles; ++g)

@@ -172,10 +172,14 @@ class DraftPlan:
         z = lambda *shape, dt=bf: torch.zeros(shape, dtype=dt, device=dev)
         self.hidden = z(2, B, T, H)                      # ping-pong: depth i reads [i & 1], writes [(i + 1) & 1]
         self.ids = z(D + 1, B * T, dt=torch.int64)
-        self.parents = z(D + 1, T, dt=torch.int64)
+        # the score / token / parent lists of a drafting call, contiguous with the first expansion's entries in front: what tree_dynamic_finalize takes is a view
+        self.all_par = z(1 + (D + 1) * T, dt=torch.int64)
+        self.parents = self.all_par[1:].view(D + 1, T)
         self.tree_bits = z(self.ROWS, dt=torch.int64)
-        self.log_ti = z(D, T, k, dt=torch.int64)
-        self.log_cu = z(D, T, k, dt=torch.float32)
+        self.all_ti = z(k + D * T * k, dt=torch.int64)
+        self.all_cu = z(k + D * T * k, dt=torch.float32)
+        self.log_ti = self.all_ti[k:].view(D, T, k)
+        self.log_cu = self.all_cu[k:].view(D, T, k)
         self.cs = z(D, k, dt=torch.int64)
         self.sc = z(D + 1, k, dt=torch.float32)         # [0]: the first expansion's scores
         self.pos = z(D, B, T, dt=torch.int64)
@@ -185,6 +189,8 @@ class DraftPlan:
         self.bits0 = (torch.ones(T, dtype=torch.int64, device=dev) << torch.arange(T, dtype=torch.int64, device=dev))
         self.par0 = torch.arange(T, dtype=torch.int64, device=dev) + 1
         self.steps = torch.arange(D, dtype=torch.int64, device=dev)
+        self.steps_full = self.steps[:, None, None].expand(D, B, T).contiguous()          # depth index of every (depth, batch row, token) position slot
+        self.steps1_row = (self.steps[:, None] + 1).expand(D, T).contiguous()              # + 1: the head's positions
         self.parents[0].copy_(self.par0)
         self.tree_bits[:T].copy_(self.bits0)
         nqkv = (nq + 2 * nk) * d
@@ -194,9 +200,11 @@ class DraftPlan:
             setattr(a, n, t.data_ptr())
         self.ta = None          # (the stream-K workspace is taken per run(): it belongs to the stream the launches go to, "one launch at a time per workspace")
 
-    def begin(self, pkv, hidden0, ids0, scores0, positions, head_positions=None, kv_start=None):
+    def begin(self, pkv, hidden0, ids0, scores0, positions, head_positions=None, kv_start=None, len_posi=None, position_diff=None, head_len=None):
         """Start a drafting call: pkv the prefix cache (the layer's slab grows in place), hidden0 [2, T, H] / ids0 [T] / scores0 [T] the first
-        expansion's outputs, positions(i) [2, T] or [T] int64 per depth as a [depth, ...] tensor."""
+        expansion's outputs, positions(i) [2, T] or [T] int64 per depth as a [depth, ...] tensor -- or positions None and len_posi (an int, or a [B, 1] /
+        [B] device tensor: the streams' lengths; depth i sits at len_posi + i; position_diff: the unconditional row's offset, cnets_anole.py:858-862)
+        and head_len (the stream whose positions drive the Lumina grammar rows: the head sees head_len + i + 1), filled here with one launch each."""
         a, B, T, D = self.args, self.B, self.T, self.depth
         past = pkv[0][0].shape[2]
         ks, vs = self.layer._cache_slab(B, self.nk, self.d, past + D * T, self.dev, pkv[0])
@@ -211,9 +219,19 @@ class DraftPlan:
         self.hidden[0].copy_(hidden0)
         self.ids[0].view(B, T).copy_(ids0.reshape(1, T).expand(B, T))
         self.sc[0].copy_(scores0.reshape(-1))
-        self.pos.copy_(positions.reshape(D, -1, T).expand(D, B, T) if positions.numel() != D * B * T else positions.reshape(D, B, T))
+        if positions is not None:
+            self.pos.copy_(positions.reshape(D, -1, T).expand(D, B, T) if positions.numel() != D * B * T else positions.reshape(D, B, T))
+        elif torch.is_tensor(len_posi):
+            torch.add(self.steps_full, len_posi.reshape(1, B, 1), out=self.pos)
+        else:
+            torch.add(self.steps_full, int(len_posi), out=self.pos)
+            if position_diff is not None:
+                self.pos[:, 1].sub_(position_diff.reshape(()))
         if head_positions is not None:
             self.head_pos.copy_(head_positions)
+        elif head_len is not None:
+            torch.add(self.steps1_row, head_len.reshape(()), out=self.head_pos)
+            head_positions = self.head_pos
         if kv_start is None:
             if not self._kv_start_zero:
                 self.kv_start.zero_()
@@ -247,6 +265,14 @@ class DraftPlan:
         else:
             a.hidden_next = a.ids_next = a.parents_next = None
         ops.check(self._L.lantern_draft_depth(self._C.byref(a)), "draft_depth")
+
+    def finalize_inputs(self, cu0, ti0):
+        """(scores [1, n], tokens [1, n], parents [1, m]) of the whole drafting call for tree_dynamic_finalize -- the first expansion's k entries copied in
+        front of the depth loop's logs (which the depth calls wrote in place): no torch.cat."""
+        k, D, T = self.k, self.depth, self.T
+        self.all_cu[:k].copy_(cu0.reshape(-1))
+        self.all_ti[:k].copy_(ti0.reshape(-1))
+        return self.all_cu[None], self.all_ti[None], self.all_par[None, :1 + D * T]
 
     def lists(self):
         """(scores_list, ss_token, parents_list) entries of the depth loop, as the Python loop appends them."""
@@ -811,6 +837,13 @@ class Model(nn.Module):
         return ops.cfg_mask_topk_window(cond, uncond, float(self.cfg_scale), 0, V, model=ops.MODEL_PLAIN, top_k=min(spec.top_k, V),
                                         temperature=spec.temperature, top_p=spec.top_p)[0]
 
+    def _finalize_dynamic_plan(self, plan, cu0, ti0, sample_token, sort_rows):
+        """_finalize_dynamic on the plan's contiguous logs (no torch.cat of the per-depth lists)."""
+        sc, tk, pa = plan.finalize_inputs(cu0, ti0)
+        draft, mask, pos, ret, nl, md = ops.tree_dynamic_finalize(sc, tk, pa, sample_token.reshape(-1)[:1], self.top_k, self.total_tokens, sort_rows=sort_rows)
+        nl, md = int(nl[0]), int(md[0])
+        return draft, ret[0, :nl, :md].contiguous(), mask[:, None], pos[0]
+
     def _finalize_dynamic(self, scores_list, ss_token, parents_list, sample_token, sort_rows):
         draft, mask, pos, ret, nl, md = ops.tree_dynamic_finalize(torch.cat(scores_list)[None], torch.cat(ss_token)[None],
                                                                   torch.cat(parents_list)[None], sample_token.reshape(-1)[:1], self.top_k,
@@ -872,17 +905,14 @@ class Model(nn.Module):
         plan = self._depth_plan(head, logits_processor, k)
         input_hidden = last_hidden[:, None].expand(-1, k, -1) if plan is not None else last_hidden[:, None].repeat(1, k, 1)
         if plan is not None:          # the depth loop: one lantern_draft_depth call per depth
-            pos = (len_posi + plan.steps)[:, None, None].expand(plan.depth, 1, k)
-            if input_position_diff is not None:
-                pos = torch.cat([pos, pos - input_position_diff], dim=1)          # (no clamp inside the loop, cnets_anole.py:858-862)
+            # positions: depth i at len_posi + i, the unconditional row at - input_position_diff (no clamp inside the loop, cnets_anole.py:858-862)
             # (input_position_diff None: the reference does not hand the mask to its depth forwards either -- `akw` above, cnets_llamagen.py:783-790 --
             # so no padding is described; with it, the mask went through forward()'s left-padding check at the prefill)
             start = None if attention_mask is None or input_position_diff is None else self._first_visible_key(attention_mask, dev)
-            plan.begin(pkv, input_hidden, cur.reshape(-1), scores, pos, kv_start=start)
+            plan.begin(pkv, input_hidden, cur.reshape(-1), scores, None, kv_start=start, len_posi=len_posi, position_diff=input_position_diff)
             for i in range(self.depth):
                 plan.run(i)
-            sl, tl, pl = plan.lists()
-            return self._finalize_dynamic(scores_list + sl, ss_token + tl, parents_list + pl, sample_token, logits_processor is not None)
+            return self._finalize_dynamic_plan(plan, cu, ti, sample_token, logits_processor is not None)
         tree_mask = self.tree_mask_init
         cs = torch.arange(k, device=dev)
         for i in range(self.depth):
@@ -1022,13 +1052,12 @@ class Model(nn.Module):
         plan = self._depth_plan(head, logits_processors, k)
         input_hidden = last_hidden[:, None].expand(-1, k, -1) if plan is not None else last_hidden[:, None].repeat(1, k, 1)
         if plan is not None:          # the depth loop: one lantern_draft_depth call per depth
-            pos = (len_posi[None] + plan.steps[:, None, None]).expand(plan.depth, 2, k)          # [depth, 2, k]: the cond / uncond streams' positions
-            plan.begin(pkv, input_hidden, input_ids.reshape(-1), scores, pos, head_positions=pos[:, 1] + 1,
+            # [depth, 2, k] positions: the cond / uncond streams' lengths + the depth; the head's grammar positions follow the unconditional stream + 1
+            plan.begin(pkv, input_hidden, input_ids.reshape(-1), scores, None, len_posi=len_posi, head_len=len_posi.reshape(-1)[1],
                        kv_start=(stats[0] if stats is not None else attention_mask.to(torch.int64).argmax(dim=1)))
             for i in range(self.depth):
                 plan.run(i)
-            sl, tl, pl = plan.lists()
-            return self._finalize_dynamic(scores_list + sl, ss_token + tl, parents_list + pl, sample_token, logits_processors is not None)
+            return self._finalize_dynamic_plan(plan, cu, ti, sample_token, logits_processors is not None)
         tree_mask = self.tree_mask_init
         cs = torch.arange(k, device=dev)
         for i in range(self.depth):

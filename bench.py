@@ -782,7 +782,7 @@ def mirror_generate_run():
 def drafter_cycle_run():
     """One drafting cycle of the EAGLE-2 drafter at model size (tools/draft_bench.py): prefill of the accepted tokens + `depth` tree steps, each ONE
     lantern_draft_depth call (input stage, decoder layer, fused head expansion, next-depth inputs), + the tree finalisation; wall microseconds."""
-    return {m: _tool_json("draft_bench.py", [m, 1200, 30]) for m in ("lumina", "anole", "llamagen", "lumina_static", "anole_static")}
+    return {m: _tool_json("draft_bench.py", [m, 1200, 30]) for m in ("lumina", "anole", "llamagen", "lumina_static", "anole_static", "llamagen_static")}
 
 
 def plan_sequences(total_seqs: int, seqs_per_gpu: int, world: int, groups: int):

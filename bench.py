@@ -863,6 +863,12 @@ def compact_line(out: dict) -> dict:
     sl = out.get("step_latency_us")
     if isinstance(sl, dict):
         ex["step_latency_us"] = {k: v.get("us_per_step") for k, v in sl.items() if isinstance(v, dict)}
+    # evaluate_posterior by itself at the full 64 sequences per launch (the per-kernel single-group pass: probability rows, every stage its own launch):
+    # the headline's `roofline` is the same kernel family at 16 per launch, where a launch is as long as its slowest chain whatever it holds
+    pk = out.get("per_kernel_single_group")
+    if isinstance(pk, dict) and isinstance(pk.get("chain"), dict) and isinstance(pk["chain"].get("roofline"), dict):
+        r_ = pk["chain"]["roofline"]
+        ex["evaluate_posterior_64_per_launch"] = {"avg_launch_ms": r_.get("avg_launch_ms"), "frac": r_.get("frac"), "frac_needed": r_.get("frac_needed")}
     if ex:
         c["extras"] = ex
     if out.get("extras_file"):

@@ -27,6 +27,42 @@ MODELS = {
 }
 
 
+# BASELINE's real sizes (data/configs/lumina_mgpt_config.json, llamagen_t2i_config.json): the reference-run
+# fixtures of make_golden_fullsize.py.  C = codebook width of the synthetic VQ codebook the neighbour table is built from.
+FULL = {
+    "lumina": dict(V=65536, K=8192, off=4, img_lo=4, img_hi=8196, syntax=(8196, 8197, 8803, 8828), C=256),
+    "anole": dict(V=65536, K=8192, off=4, img_lo=4, img_hi=8196, syntax=(), C=256),
+    "llamagen": dict(V=16384, K=16384, off=0, img_lo=0, img_hi=16384, syntax=(), C=8),
+}
+
+
+def model_dims(spec: dict) -> dict:
+    """Vocabulary / codebook constants of a golden spec: reduced (MODELS) unless the spec says size = "full"."""
+    return FULL[spec["model"]] if spec.get("size") == "full" else MODELS[spec["model"]]
+
+
+def full_codebook(K: int, C: int, seed: int = 0) -> np.ndarray:
+    """N(0,1) codebook rounded to multiples of 2^-16: every product and every partial sum of a squared distance is then
+    exact in float64 whatever the summation order (19-bit values, 38-bit squares, <= 256 terms), so the neighbour table
+    below comes out bit-identical on any machine / BLAS."""
+    rs = np.random.RandomState(seed)
+    return (np.round(rs.standard_normal((K, C)) * 65536.0) / 65536.0).astype(np.float32)
+
+
+def build_table_full(K: int, C: int, seed: int = 0, chunk: int = 1024) -> np.ndarray:
+    """The recipe of generate_codebook.py:53-65 (pairwise L2, diagonal = inf, the K-1 nearest in ascending order, uint16)
+    at the real codebook sizes: exact float64 squared distances (sqrt is monotone), stable order on the (rare) exact ties."""
+    cb = full_codebook(K, C, seed).astype(np.float64)
+    n2 = (cb * cb).sum(1)
+    out = np.empty((K, K - 1), np.uint16)
+    for r0 in range(0, K, chunk):
+        r1 = min(K, r0 + chunk)
+        d2 = n2[r0:r1, None] + n2[None, :] - 2.0 * (cb[r0:r1] @ cb.T)
+        d2[np.arange(r1 - r0), np.arange(r0, r1)] = np.inf
+        out[r0:r1] = np.argsort(d2, axis=1, kind="stable")[:, :K - 1].astype(np.uint16)
+    return out
+
+
 def build_table(K: int, C: int = 8, seed: int = 0) -> np.ndarray:
     """Neighbour table with the recipe of generate_codebook.py:53-65 on a random codebook."""
     rs = np.random.RandomState(seed)
@@ -75,14 +111,14 @@ def target_rows(rs, n_rows: int, m: dict, scale: float, top_k: int, mask_non_ima
 
 
 def gen_static(seed: int, model: str, buffers: dict, sigma: float = 1.0, scale: float = 4.0,
-               top_k: int = 200, special: str = "") -> dict:
+               top_k: int = 200, special: str = "", m: dict = None) -> dict:
     """Inputs of one static-tree (EAGLE-1 / LANTERN++) verify step.
 
     buffers: tree_indices [N], retrieve_indices [P,D], tree_attn_mask [N,N], tree_position_ids [N].
     Returns raw drafter outputs (ss_token, ss_prob, orig_prob, op_off), processed target rows
     `node_logits` [N,V], sample_token, uniforms.
     """
-    m = MODELS[model]
+    m = m or MODELS[model]
     rs = np.random.RandomState(seed)
     ti = np.asarray(buffers["tree_indices"])
     pos = np.asarray(buffers["tree_position_ids"])

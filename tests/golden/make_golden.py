@@ -130,12 +130,12 @@ def ref_buffers(R, choices):
 
 def run_static_case(R, spec, choices, table_cache):
     model, seed = spec["model"], spec["seed"]
-    m = CS.MODELS[model]
+    m = CS.model_dims(spec)
     tb = ref_buffers(R, choices)
     bufs = dict(tree_indices=tb["tree_indices"].numpy(), tree_position_ids=tb["tree_position_ids"].numpy(),
                 tree_attn_mask=tb["tree_attn_mask"][0, 0].numpy(), retrieve_indices=tb["retrieve_indices"].numpy())
     g = CS.gen_static(seed, model, bufs, sigma=spec.get("sigma", 1.0), top_k=spec.get("gen_top_k", 200),
-                      special=spec.get("special", ""))
+                      special=spec.get("special", ""), m=m)
     ss_prob = CS.ss_prob_from(g["orig_prob"], g["ss_token"])
     ss_token_t = torch.from_numpy(g["ss_token"])
     ss_prob_t = torch.from_numpy(ss_prob)
@@ -154,7 +154,7 @@ def run_static_case(R, spec, choices, table_cache):
             ns, (ss_token_t, ss_prob_t, op_list), tb["tree_indices"], tb["retrieve_indices"], sample_token, object())
     node_logits = torch.from_numpy(g["node_logits"])
     logits = node_logits[tb["retrieve_indices"]]
-    table = table_cache(m["K"])
+    table = table_cache(spec)
     lantern, k, delta = spec["lantern"], spec["k"], spec["delta"]
     if model == "lumina":
         ns = types.SimpleNamespace(eagle_version=1, image_syntax_tokens=torch.tensor(m["syntax"]),
@@ -217,11 +217,11 @@ class FakeDrafter:
         return torch.stack([t, t])  # [2,top_k,V]
 
 
-def dynamic_script(seed, model, depth, scale=4.0):
+def dynamic_script(seed, model, depth, scale=4.0, m=None):
     """Finite raw drafter logits (cond == uncond); the top-k filtering is done by the
     reference's own HF processor inside topK_genrate (-inf inputs would turn into NaN in
     its CFG combine u + (c-u)*s)."""
-    m = CS.MODELS[model]
+    m = m or CS.MODELS[model]
     rs = np.random.RandomState(seed)
     V = m["V"]
     script = [(scale * rs.standard_normal(V)).astype(np.float32)]
@@ -234,10 +234,9 @@ def dynamic_script(seed, model, depth, scale=4.0):
     return script
 
 
-def run_dynamic_tree(R, seed, model, depth, total_token=59):
-    script = dynamic_script(seed, model, depth)
+def run_dynamic_tree(R, seed, model, depth, total_token=59, m=None):
+    script = dynamic_script(seed, model, depth, m=m)
     fake = FakeDrafter(script, total_tokens=total_token - 1, depth=depth, top_k=CS.TOPK)
-    m = CS.MODELS[model]
     sample_token = 5 + seed % 100
     input_ids = torch.tensor([[0, 0, sample_token], [0, 0, sample_token]], dtype=torch.long)
     hidden = torch.zeros(2, 2, fake.H)
@@ -250,8 +249,8 @@ def run_dynamic_tree(R, seed, model, depth, total_token=59):
 
 def run_dynamic_case(R, spec, table_cache):
     model, seed = spec["model"], spec["seed"]
-    m = CS.MODELS[model]
-    tree = run_dynamic_tree(R, seed, model, spec.get("depth", 4))
+    m = CS.model_dims(spec)
+    tree = run_dynamic_tree(R, seed, model, spec.get("depth", 4), m=m)
     N = len(tree["draft_tokens"])
     rs = np.random.RandomState(seed + 7919)
     node_logits = (4.0 * rs.standard_normal((N, m["V"]))).astype(np.float32)
@@ -277,7 +276,7 @@ def run_dynamic_case(R, spec, table_cache):
     draft_ext = torch.cat([torch.from_numpy(draft), torch.tensor([-1])])
     cand = draft_ext[torch.from_numpy(retrieve)]
     logits = torch.from_numpy(node_logits)[torch.from_numpy(retrieve)]
-    table = table_cache(m["K"])
+    table = table_cache(spec)
     lantern, k, delta = spec["lantern"], spec["k"], spec["delta"]
     if model == "lumina":
         ns = types.SimpleNamespace(eagle_version=2, image_syntax_tokens=torch.tensor(m["syntax"]),
@@ -309,8 +308,8 @@ def run_dynamic_case(R, spec, table_cache):
 def run_greedy_case(R, spec, table_cache):
     """a9: greedy/TVD branch (temperature<=1e-5 -> logits_processor None)."""
     model, seed = spec["model"], spec["seed"]
-    m = CS.MODELS[model]
-    tree = run_dynamic_tree(R, seed, model, 4)
+    m = CS.model_dims(spec)
+    tree = run_dynamic_tree(R, seed, model, 4, m=m)
     N = len(tree["draft_tokens"])
     rs = np.random.RandomState(seed + 104729)
     node_logits = (4.0 * rs.standard_normal((N, m["V"]))).astype(np.float32)
@@ -323,7 +322,7 @@ def run_greedy_case(R, spec, table_cache):
     draft_ext = torch.cat([torch.from_numpy(draft), torch.tensor([-1])])
     cand = draft_ext[torch.from_numpy(retrieve)]
     logits = torch.from_numpy(node_logits)[torch.from_numpy(retrieve)]
-    table = table_cache(m["K"]).astype(np.int64)  # uint16 torch tensors break masked assignment
+    table = table_cache(spec).astype(np.int64)  # uint16 torch tensors break masked assignment
     mod = R.lg if model == "llamagen" else R.an
     ns = types.SimpleNamespace(nearest_latents=table, image_token_offset=m["off"])
     best, alen, row = mod.EaModel.evaluate_posterior(ns, logits, cand, None, lantern=spec["lantern"],
@@ -459,7 +458,8 @@ def main():
     trees = golden_trees(R, out)
     tables = {}
 
-    def table_cache(K):
+    def table_cache(spec):
+        K = CS.model_dims(spec)["K"]
         if K not in tables:
             tables[K] = CS.build_table(K)
         return tables[K]

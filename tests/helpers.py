@@ -29,6 +29,22 @@ def ep_case(i):
     return {k[len(pre):]: d[k] for k in d.files if k.startswith(pre)}
 
 
+def full_specs():
+    return json.loads(str(load("evaluate_posterior_full.npz")["specs"]))
+
+
+def full_case(i):
+    """A case of the REAL-size fixture (make_golden_fullsize.py); `sample_p` is rebuilt from its sparse form."""
+    d = load("evaluate_posterior_full.npz")
+    pre = f"c{i}."
+    c = {k[len(pre):]: d[k] for k in d.files if k.startswith(pre)}
+    if "sample_p_ids" in c:
+        p = np.zeros(int(c["sample_p_len"]), np.float32)
+        p[c["sample_p_ids"]] = c["sample_p_vals"]
+        c["sample_p"] = p
+    return c
+
+
 _tables = {}
 
 
@@ -36,6 +52,22 @@ def table(K):
     if K not in _tables:
         _tables[K] = CS.build_table(K)
     return _tables[K]
+
+
+def table_for(spec):
+    """Neighbour table a golden spec was run with: the reduced one, or the real-size one (rebuilt from its seed and held
+    to the SHA-256 the fixture recorded when the reference consumed it)."""
+    if spec.get("size") != "full":
+        return table(CS.MODELS[spec["model"]]["K"])
+    m = CS.FULL[spec["model"]]
+    key = ("full", m["K"], m["C"])
+    if key not in _tables:
+        import hashlib
+        t = CS.build_table_full(m["K"], m["C"])
+        want = str(load("evaluate_posterior_full.npz")[f"table.{m['K']}x{m['C']}.sha256"])
+        assert hashlib.sha256(t.tobytes()).hexdigest() == want, "the rebuilt neighbour table is not the one the reference consumed"
+        _tables[key] = t
+    return _tables[key]
 
 
 def tree_buffers(name):
@@ -57,15 +89,15 @@ def static_inputs(spec, case):
     bufs = dict(tree_indices=tb["tree_indices"], tree_position_ids=tb["pos"], tree_attn_mask=tb["mask"],
                 retrieve_indices=tb["retrieve"])
     g = CS.gen_static(spec["seed"], spec["model"], bufs, sigma=spec.get("sigma", 1.0),
-                      top_k=spec.get("gen_top_k", 200), special=spec.get("special", ""))
+                      top_k=spec.get("gen_top_k", 200), special=spec.get("special", ""), m=CS.model_dims(spec))
     assert abs(CS.checksum(g["node_logits"]) - float(case["chk_logits"])) < 1e-6
     assert abs(CS.checksum(g["orig_prob"]) - float(case["chk_op"])) < 1e-9
     assert np.array_equal(g["ss_token"], case["ss_token"])
     return tb, g
 
 
-def dynamic_script(seed, model, depth, scale=4.0):
-    m = CS.MODELS[model]
+def dynamic_script(seed, model, depth, scale=4.0, m=None):
+    m = m or CS.MODELS[model]
     rs = np.random.RandomState(seed)
     V = m["V"]
     script = [(scale * rs.standard_normal(V)).astype(np.float32)]
@@ -80,7 +112,7 @@ def dynamic_script(seed, model, depth, scale=4.0):
 
 def dynamic_node_logits(spec, case, greedy=False):
     """Target rows of the dynamic-tree cases (same construction as make_golden.py)."""
-    m = CS.MODELS[spec["model"]]
+    m = CS.model_dims(spec)
     N = len(case["draft_tokens"])
     retrieve, draft = case["retrieve"], case["draft_tokens"]
     if greedy:
@@ -131,7 +163,7 @@ def hf_process_rows(rows, top_k):
 def ep_config(spec):
     """oracle.EpConfig for a golden spec (reduced-vocabulary model constants of cases.MODELS)."""
     import oracle
-    m = CS.MODELS[spec["model"]]
+    m = CS.model_dims(spec)
     static = spec["kind"] == "static"
     common = dict(lantern=bool(spec["lantern"]), k=int(spec["k"]), delta=float(spec["delta"]))
     if spec["model"] == "lumina":

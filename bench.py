@@ -9,9 +9,13 @@ Contract (driver):  python bench.py --gpus N --steps K --warmup W
 Workload = BASELINE.json config C3 (Lumina-mGPT-7B-768 + LANTERN relaxed accept, k=1000, delta=0.1, static tree mc_sim_7b_63) on
 synthetic 768x768 image-token sequences: a "step" is one verify step (O6 -> O7 -> O8 -> O9 -> O10) over the --seqs-per-gpu sequences
 resident on the GPU; inputs are HBM-resident before the timed region.  `value` = accepted tokens of all ranks / max-over-ranks wall time.
-Default launch: 64 sequences in 4 stream groups, one lantern_verify_step call per step, per group  evaluate_posterior_window on raw bf16 rows (O8 + the
-rows of O7 it visits, on demand) -> update_inference_inputs (O9 + O10) with the NEXT step's prepare_step (O6 + the 3 most likely rows of O7) in the same launch.
+Default launch: 64 sequences in 4 stream groups, one lantern_verify_step call per step, per group  prepare_step (O6 + the 3 most likely rows of O7) ->
+evaluate_posterior_window on raw bf16 rows (O8 + the other rows of O7 it visits, on demand) -> update_inference_inputs (O9 + O10): three launches, in the order a real
+decode loop can issue them (a step's rows exist only after the previous step's commit + the drafter and target forwards).  The round-5 variant that hid the prepare stage
+in the PREVIOUS step's commit launch is only possible on pre-generated pools: it is reported as the extra `merged_prepare_harness_only`, never as `value`.
 `--groups 1 --no-fuse-o7 --spec-rows 0` is the four-launch step (every row through cfg_mask_topk first).
+N > 1 prints BOTH scaling forms in the one line: `value` = weak scaling (--seqs-per-gpu on every rank) and `c5_strong` = BASELINE config C5 / BASELINE.md section 2
+(64 sequences in ALL, split evenly over the ranks: run.sh:76-91), each with its own barrier-bracketed K-step timed region.
 
 Extra objects on the JSON line:
   roofline      evaluate_posterior of the timed configuration: algorithmic bytes (SURVEY 8d contract formula, from the kernel's own
@@ -108,6 +112,8 @@ def parse():
                     help="file that receives the FULL report (the compact headline + every extra run: per_kernel_single_group, configs, dynamic_tree, "
                          "ep_batch_sweep, drafter_*, mirror_generate, ...); the same object goes to stderr as one line.  stdout carries exactly ONE "
                          "line: the compact headline (< 4 KB) the driver parses.  '' = no file")
+    ap.add_argument("--tuning", type=str, default="", help="measurement runs only: name=value[,name=value...] passed to lantern_tuning_set before anything is launched "
+                    "(kernel-instance / launch-shape choices, include/lantern_hip.h; the library reads no environment variable).  The line's config says what was set")
     ap.add_argument("--dist-backend", choices=["auto", "nccl", "gloo"], default="auto",
                     help="process group of the N > 1 run (used for the timing barrier and three scalars only: the accept path has no collective).  "
                          "auto = nccl (RCCL), falling back to gloo on host tensors when the RCCL group cannot be brought up -- decided before any kernel is launched")
@@ -804,10 +810,66 @@ def plan_sequences(total_seqs: int, seqs_per_gpu: int, world: int, groups: int):
 
 
 
+C5_TOTAL = 64      # BASELINE.json configs[4] / BASELINE.md section 2: "64 sequences split evenly"
+
+
+def c5_strong_plan(world: int, groups: int):
+    """(sequences per rank, stream groups, evaluate_posterior form) of the strong-scaling leg, or None when 64 does not split over `world` ranks."""
+    if world < 1 or C5_TOTAL % world:
+        return None
+    n = C5_TOTAL // world
+    g = max(1, min(groups if n > 16 else min(groups, 2), n))
+    while n % g:
+        g -= 1
+    return n, g, ("nodes" if n <= 16 else "chain")
+
+
+def c5_strong_run(args, base_cfg, world, rank, device, dist, group, red_device):
+    """BASELINE's OWN scaling form on the clock (C5; the reference's run.sh:76-91 + generate_images.py:185-192 `--slice`): 64 sequences in all, 64 / N per
+    rank, same kernels / KV geometry / pools as the headline, its own warm-up and barrier-bracketed K-step timed region, MAX over ranks.  Every rank calls
+    this (the barrier is collective); returns the report on every rank."""
+    import dataclasses
+    from lantern_amd import harness as HN
+    from lantern_amd.sharding import reduce_timing
+    plan = c5_strong_plan(world, args.groups if args.groups > 0 else 4)
+    if plan is None:
+        return {"skipped": f"{C5_TOTAL} sequences do not split evenly over {world} ranks"}
+    n, g, ep = plan
+    fuse = ep == "chain" and base_cfg.fuse_o7
+    K, W = args.steps, args.warmup
+    cfg = dataclasses.replace(base_cfg, n_seq=n, n_groups=g, ep_kernel=ep, fuse_o7=fuse, spec_rows=(base_cfg.spec_rows if fuse else 0),
+                              seed_base=base_cfg.seed_base, max_steps=max(base_cfg.pool_steps, K + W, 80) + 8)
+    wl = HN.LuminaVerifyWorkload(cfg, device, rank=rank)
+    wl.prime(0.0)
+    for _ in range(W):
+        wl.step()
+
+    def barrier():
+        if dist is not None:
+            dist.barrier(group=group)
+        torch.cuda.synchronize(device)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(K):
+        wl.step()
+    barrier()
+    dt = time.perf_counter() - t0
+    wl.check_status(0, W + K)
+    toks = float(wl.accepted_tokens(W, W + K))
+    dt_all, toks_all = reduce_timing(dist, dt, toks, device=red_device or device, group=group)
+    wl.release_kv()
+    del wl
+    torch.cuda.empty_cache()
+    return {"value": toks_all / dt_all, "unit": "accepted_tokens/s", "scaling": "strong", "ms_per_step": 1e3 * dt_all / K, "steps": K, "warmup": W,
+            "total_sequences": C5_TOTAL, "sequences_per_rank": n, "stream_groups": g, "evaluate_posterior_kernel": ep, "n_gpus": world,
+            "mean_accept_length": toks_all / (K * C5_TOTAL),
+            "workload": f"C5: {C5_TOTAL} sequences in all, {n} per GPU (run.sh:76-91), no collective on the accept path"}
+
+
 # ---------------------------------------------------------------------------- the line the driver parses
 
 HEADLINE_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
-                 "data", "config", "mean_accept_length", "per_step", "ranks_seen", "backend", "backend_note", "tokens", "sequences_per_rank", "groups")
+                 "data", "config", "mean_accept_length", "per_step", "ranks_seen", "backend", "backend_note", "tokens", "sequences_per_rank", "groups", "c5_strong", "host_waits")
 ROOFLINE_KEYS = ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes_per_launch", "avg_launch_ms",
                  "sequences_per_launch", "needed_bytes_per_launch", "frac_needed", "traffic_note")
 SATURATING_KEYS = ("kernel", "sequences_per_launch", "avg_launch_ms", "needed_bytes", "achieved", "peak", "unit", "frac", "traffic", "traffic_over_needed",
@@ -852,6 +914,9 @@ def compact_line(out: dict) -> dict:
         ex["drafter_us_per_cycle_wall"] = {k: v.get("us_per_cycle_wall") for k, v in dc.items() if isinstance(v, dict)}
     if isinstance(out.get("lambda_mode"), dict):
         ex["lambda_mode_value"] = out["lambda_mode"].get("value")
+    mp = out.get("merged_prepare_harness_only")
+    if isinstance(mp, dict):
+        ex["merged_prepare_harness_only_us_per_step"] = 1e3 * mp.get("ms_per_step", 0.0)
     if isinstance(out.get("dynamic_tree"), dict):
         ex["dynamic_tree_value"] = out["dynamic_tree"].get("value")
     cf = out.get("configs")
@@ -1076,11 +1141,26 @@ def stub_rank(args, world, rank):
     dt = time.perf_counter() - t0
     dt_all, tokens_all = reduce_timing(dist if world > 1 else None, dt, float(K * per_step), group=pg["group"] if pg else None)
     ranks_seen = count_ranks(dist, pg)
+    c5 = None
+    if world > 1 and args.total_seqs == 0:          # the second leg of an N > 1 run: 64 sequences in all (same control flow as main())
+        plan = c5_strong_plan(world, cap_groups(args, world))
+        if plan is None:
+            c5 = {"skipped": f"{C5_TOTAL} sequences do not split evenly over {world} ranks"}
+        else:
+            dist.barrier(group=pg["group"])
+            t1 = time.perf_counter()
+            for _ in range(K):
+                time.sleep(0.001)
+            dist.barrier(group=pg["group"])
+            d5, t5 = reduce_timing(dist, time.perf_counter() - t1, float(K * plan[0] * 2), group=pg["group"])
+            c5 = {"value": t5 / d5, "unit": "accepted_tokens/s", "scaling": "strong", "ms_per_step": 1e3 * d5 / K, "steps": K, "total_sequences": C5_TOTAL,
+                  "sequences_per_rank": plan[0], "stream_groups": plan[1], "evaluate_posterior_kernel": plan[2], "n_gpus": world, "tokens": t5,
+                  "ranks_seen": ranks_seen}
     if rank == 0:
         out = {"metric": "stub", "value": tokens_all / dt_all, "unit": "accepted_tokens/s", "n_gpus": world, "steps": K,
                "warmup": args.warmup, "ms_per_step": 1e3 * dt_all / K, "data": "stub", "tokens": tokens_all, "scaling": scaling,
                "sequences_per_rank": n_seq, "groups": _groups, "ranks_seen": ranks_seen, "backend": pg["backend"] if pg else None,
-               "backend_note": pg["note"] if pg else None,
+               "backend_note": pg["note"] if pg else None, **({"c5_strong": c5} if c5 is not None else {}),
                # a stand-in for the extras of a real run (tests/test_multiproc_cpu.py: they must stay off the stdout line)
                "roofline": {"bound": "hbm", "achieved": 0.0, "peak": 8000.0, "unit": "GB/s", "frac": 0.0, "traffic": None},
                "cpu_baseline": {"value": 0.0, "unit": "accepted_tokens/s", "cores": 1, "kind": "port", "sample": "stub"},
@@ -1125,6 +1205,12 @@ def main():
     device = torch.device("cuda", local_rank)
 
     from lantern_amd import harness as HN
+    from lantern_amd import _lib as _LL
+    tuning_set = {}
+    for kv in [x for x in args.tuning.split(",") if x]:
+        name, _, val = kv.partition("=")
+        _LL.set_tuning(name.strip(), int(val))
+        tuning_set[name.strip()] = int(val)
 
     # Never ask for more resident sequences than this GPU can hold: KV slabs (2 per sequence) + pools + 16 GiB of head-room.
     # On the MI355X the default fits (309e9 bytes); a smaller or partly occupied device gets fewer sequences, not a failed run
@@ -1205,6 +1291,7 @@ def main():
     dt_all, tokens_all = reduce_timing(dist, dt, float(tokens), device=red_device or device, group=group)
     ranks_seen = count_ranks(dist, pg)
 
+    out = None
     if rank == 0:
         alen = wl.log_alen[W:W + K].float() + 1
         cnt = wl.log_cnt[W:W + K].float()
@@ -1214,6 +1301,7 @@ def main():
             "ms_per_step": 1e3 * dt_all / K, "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
             "dtype": "f32", "data": "synthetic", "ranks_seen": ranks_seen, "backend": (pg["backend"] if pg else None),
             "backend_note": (pg["note"] if pg else None),
+            "host_waits": "polling (HSA_ENABLE_INTERRUPT=0, set by bench.py unless the caller set it)" if os.environ.get("HSA_ENABLE_INTERRUPT") == "0" else "interrupts",
             "config": {"workload": ("C5: Lumina-mGPT-7B-768 LANTERN, %d-prompt batch sharded over %d GPU(s), no collective; " % (args.total_seqs, world) if args.total_seqs > 0 else "") +
                                    f"C3: Lumina-mGPT-7B-768 LANTERN relaxed accept, static tree {cfg.tree} (N={wl.N},P={wl.P},D={wl.D}), "
                                    "V=65536, K=8192, cfg=3.0, top_k=2000, sequential-CFG KV [64,1,32,%d,128] bf16 x2 per sequence (row stride %d)"
@@ -1229,7 +1317,7 @@ def main():
                        "tree_decoding_rows": (("raw bf16 logits post-processed inside evaluate_posterior (LANTERN_ROWS_RAW_BF16), %d most likely rows per sequence "
                                                "up front with the candidate assembly (lantern_prepare_step)" % wl.n_spec) if getattr(wl, "fused_o7", False)
                                               else "every row post-processed by cfg_mask_topk before evaluate_posterior"),
-                       "stream_groups": cfg.n_groups, "host_waits": "polling (HSA_ENABLE_INTERRUPT=0)" if os.environ.get("HSA_ENABLE_INTERRUPT") == "0" else "interrupts", "side_stream_for_O6_O10": cfg.side_stream, "sequences_per_launch": wl.Bg, "parallelism": f"dp{world} (independent sequences, no collective)"},
+                       "tuning": tuning_set or None, "stream_groups": cfg.n_groups, "host_waits": "polling (HSA_ENABLE_INTERRUPT=0)" if os.environ.get("HSA_ENABLE_INTERRUPT") == "0" else "interrupts", "side_stream_for_O6_O10": cfg.side_stream, "sequences_per_launch": wl.Bg, "parallelism": f"dp{world} (independent sequences, no collective)"},
             "mean_accept_length": float(alen.mean()),
             "per_step": {"levels": float(cnt[..., 0].mean()), "tried": float(cnt[..., 1].mean()), "rejected": float(cnt[..., 2].mean())},
         }
@@ -1239,7 +1327,18 @@ def main():
         gb = wl.log_best[:n_logged].cpu().numpy()
         ga = wl.log_alen[:n_logged].cpu().numpy()
         gt = wl.log_token[:n_logged].cpu().numpy()
-        if not args.no_extras and wl.windowed:
+    # ---- N > 1: BASELINE's own scaling form (C5: 64 sequences in ALL) beside the weak-scaling headline, in the same line.  Every rank takes part
+    # (its barriers are collective); the weak run's KV slabs are released first (64 sequences per GPU fill the device).
+    if world > 1 and args.total_seqs == 0 and not args.no_kv and os.environ.get("LANTERN_BENCH_NO_C5") != "1":
+        wl.join()
+        torch.cuda.synchronize(device)
+        wl.release_kv()
+        c5 = c5_strong_run(args, cfg, world, rank, device, dist, group, red_device)
+        if rank == 0:
+            c5["ranks_seen"] = ranks_seen
+            out["c5_strong"] = c5
+    if rank == 0:
+        if not args.no_extras and wl.windowed and world == 1:
             # LANTERN++ mode of the same workload (run B of BASELINE.md: lantern_delta = 5 -> tau = 4 * p(x)): same pools, same kernels
             KL = 60
             wl.join()
@@ -1268,6 +1367,11 @@ def main():
             out["step_latency_us"] = step_latency(device, cfg)
             out["other_groupings"] = {f"groups_{g}": side_run(device, cfg, max(min(K, 100), 60), n_groups=g, n_seq=args.seqs_per_gpu - args.seqs_per_gpu % g)
                                       for g in (1, 2) if g != cfg.n_groups}
+            if cfg.fuse_o7 and cfg.spec_rows > 0:
+                # the round-5 headline form, kept as a HARNESS-ONLY extra: step s + 1's prepare stage inside step s's commit launch -- only possible
+                # because the pools hold step s + 1's rows ahead of time; a real decode loop produces them after commit(s)
+                out["merged_prepare_harness_only"] = dict(side_run(device, cfg, max(min(K, 100), 60), merge_prepare=True),
+                                                          note="prepare_next: not a form a decode loop can run; never the headline")
         if not args.no_extras and world == 1 and wl.windowed:
             out["dynamic_tree"] = dynamic_run(device, cfg, min(K, 100), n_seq, fuse_o7=True)
             out["dynamic_tree"]["all_rows_by_cfg_mask_topk"] = {k: v for k, v in dynamic_run(device, cfg, min(K, 100), n_seq, fuse_o7=False).items()

@@ -56,6 +56,16 @@ enum {
 int lantern_version(void);
 const char *lantern_last_error(void);
 
+/* Tuning values: kernel-instance / launch-shape choices a MEASUREMENT may override (tools/, a few tests).  The library reads no environment
+ * variable; every product path runs the defaults.  Names (defaults): epw_tp (5), epw_tp4 (1), epw_tp_raw (256), epw_spec (2), epw_occ2 (-1),
+ * o7_nt (0), prep_nt (0), kv_u (0), kv_ks (4), kv_variant (0), gemm_tiled_from (129), sk_groups (0), sk_whole_mb (40), sk_nt_min_mb (80),
+ * ta_splits (0), ta_min_tiles (2) -- meanings beside `enum Tuning` in lantern_amd/csrc/common.h.  Process-wide, atomic ints; set before the
+ * launches they should affect.  The reference has no counterpart (it has no kernels to choose between). */
+int lantern_tuning_set(const char *name, int value);
+int lantern_tuning_get(const char *name, int *value);
+const char *lantern_tuning_name(int index);   /* NULL past the last slot */
+int lantern_tuning_reset(void);
+
 /* ------------------------------------------------------------------------------------
  * O1  static target-tree buffers (HOST; once per tree shape).
  * Replaces generate_tree_buffers: models/ea_model_lumina_mgpt.py:140-277,
@@ -352,7 +362,8 @@ int lantern_evaluate_posterior_nodes(const lantern_ep_params *prm, const lantern
  * lantern_step_group.greedy set, lantern_verify_step runs: [candidates] -> lantern_cfg_mask_topk (the CFG combination and the model mask of
  * every tree row in the logits' dtype, no top-k: ea_model_llamagen.py:930 / ea_model_anole.py:930-931) into `logits` -> lantern_evaluate_posterior_greedy
  * (best / accept_len -> ep_buf.best / ep_buf.accept_len, the accepted row -> out_row) -> the bonus token = argmax(out_row), first maximum
- * (`token`) -> the KV / hidden / token commit.  No uniforms, no counters (ep_buf.counters may be NULL), ep / ep_win are not read except ep_win.verdict_host. */
+ * (`token`) -> the KV / hidden / token commit.  No uniforms, no counters (ep_buf.counters may be NULL), ep / ep_win are not read.  No greedy kernel writes the
+ * pinned verdict record: a greedy group with ep_win.verdict_host set is refused (LANTERN_E_INVALID), its caller reads best / accept_len / token. */
 typedef struct lantern_step_greedy {
     float *logits;                /* [dev] [B, N, V] f32, written by the O7 stage */
     const int32_t *row_index;     /* [dev] [P, D] (or [B, P, D] with row_index_per_seq): tree row of every (path, depth) */
@@ -424,12 +435,17 @@ typedef struct lantern_step_group {
      *    tokens of the chosen path go to ids_buf[b][ids_len[b] ...], and the bonus token (ep_win.token) behind them, where the drafter's
      *    `cat(input_ids, token)` (:781-785) expects it.  A sequence whose walk reported a status appends nothing. */
     const void *hidden_uncond; int64_t *ids_buf; int64_t ids_stride; const int64_t *ids_len;
-    /* The NEXT step's preparation inside THIS step's commit launch (static trees with node_list, i.e. lantern_prepare_step's form): candidate
-     * assembly and the likely rows of step s + 1 need only step s's verdict (its bonus token = the next root, its accepted length = the next
-     * positions), not its KV rows -- so their workgroups ride in the launch that moves the KV rows, and the step after this one starts with
-     * evaluate_posterior.  prepare_next: the group the next lantern_verify_step call will pass for these sequences (its ss_token / cond / uncond /
-     * sample_token ... describe step s + 1; its seq_len must be THIS step's lengths -- the kernel adds the accepted tokens itself; its cand buffer
-     * must not be the one this step's commit reads); that call then carries LANTERN_STEP_PREPARED in its flags.  NULL: off. */
+    /* The NEXT step's preparation inside THIS step's commit launch (static trees with node_list, i.e. lantern_prepare_step's form): the workgroups of
+     * step s + 1's candidate assembly + likely rows ride in the launch that moves step s's KV rows; they take step s's verdict from the walk (its bonus
+     * token = the next root, its accepted length = the next positions).
+     * PRECONDITION: step s + 1's cond / uncond / ss_token / ss_prob must be FINAL when step s's commit launches.  That only holds for a caller whose rows
+     * exist ahead of time (the synthetic harness's pools: lantern_amd/harness.py `merge_prepare`, a bench extra).  In a real decode loop those tensors are
+     * produced by the drafter and the target forward that run AFTER commit(s) (models/ea_model_lumina_mgpt.py:984-998 then :948-955 of the next
+     * iteration), so the mirrors never set this field and bench.py's headline does not use it.
+     * prepare_next: the group the next lantern_verify_step call will pass for these sequences (its seq_len must be THIS step's lengths -- the kernel adds
+     * the accepted tokens itself; its cand buffer must not be the one this step's commit reads); that call then carries LANTERN_STEP_PREPARED.  A call
+     * that failed, or a sequence whose walk reported a non-zero status in step s (the caller retries and commits it itself), invalidates the preparation:
+     * clear LANTERN_STEP_PREPARED and let step s + 1 prepare itself.  NULL: off. */
     const struct lantern_step_group *prepare_next;
     const lantern_step_dynamic *dyn;      /* NULL: a static tree (ss_token / tree_indices / retrieve), or -- flags & LANTERN_STEP_CANDIDATES_READY, ss_token
                                              NULL -- candidates the caller assembled itself: `cand` [B,P,D] and `retrieve` [P,D] are taken as they are
@@ -438,7 +454,8 @@ typedef struct lantern_step_group {
     const lantern_step_greedy *greedy;    /* NULL: relaxed rejection sampling (evaluate_posterior); else the greedy / TVD accept above */
 } lantern_step_group;
 #define LANTERN_STEP_CANDIDATES_READY 1   /* lantern_step_group.flags: skip the O6 stage, `cand` / `retrieve` (/ `cart_prob`, `tree_cand`) are final */
-#define LANTERN_STEP_PREPARED 2           /* the previous call's commit launch already ran this group's lantern_prepare_step (prepare_next) */
+#define LANTERN_STEP_PREPARED 2           /* the previous call's commit launch already ran this group's lantern_prepare_step (prepare_next); only valid on a
+                                             static-tree group with a node_list, refused otherwise */
 int lantern_verify_step(const lantern_step_group *groups, int n_groups);
 /* O6 + O7 restricted to s->node_list in one launch (bf16 Lumina rows, 8192-id window): candidates -> s->tree_cand / cand / cart_prob,
  * probabilities of the listed rows -> s->out_win, their classes -> s->row_hot.  Called by lantern_verify_step when node_list is set.

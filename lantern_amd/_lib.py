@@ -158,7 +158,43 @@ def lib():
         _lib.lantern_head_expand_workspace.restype = C.c_size_t
         _lib.lantern_linear_rows_streamk_workspace.restype = C.c_size_t
         _lib.lantern_pack_linear_weight_bytes.restype = C.c_size_t
+        _lib.lantern_tuning_name.restype = C.c_char_p
     return _lib
+
+
+def set_tuning(name: str, value: int) -> None:
+    """lantern_tuning_set: override a kernel-instance / launch-shape choice for a measurement (include/lantern_hip.h lists the names).  The library
+    itself reads no environment variable."""
+    check(lib().lantern_tuning_set(name.encode(), int(value)), "tuning_set")
+
+
+def get_tuning(name: str) -> int:
+    v = C.c_int(0)
+    check(lib().lantern_tuning_get(name.encode(), C.byref(v)), "tuning_get")
+    return v.value
+
+
+def tuning_names():
+    out, i = [], 0
+    while True:
+        n = lib().lantern_tuning_name(i)
+        if n is None:
+            return out
+        out.append(n.decode())
+        i += 1
+
+
+def tuning_from_env(environ=None) -> dict:
+    """For tools/ and tests only: apply LANTERN_<NAME>=<int> variables of the CALLER's environment as explicit lantern_tuning_set calls (the older
+    measurement scripts under tools/run/ pass their settings that way).  Returns what was applied."""
+    environ = os.environ if environ is None else environ
+    applied = {}
+    for n in tuning_names():
+        v = environ.get("LANTERN_" + n.upper())
+        if v is not None and v.lstrip("-").isdigit():
+            set_tuning(n, int(v))
+            applied[n] = int(v)
+    return applied
 
 
 def check(rc: int, what: str):
@@ -179,4 +215,5 @@ EXPORTS = [
     "lantern_tree_node_tables_size", "lantern_tree_node_tables", "lantern_evaluate_posterior_nodes_workspace",
     "lantern_evaluate_posterior_nodes", "lantern_verify_step", "lantern_gather_candidates_dynamic", "lantern_head_expand_workspace", "lantern_head_expand", "lantern_prepare_step",
     "lantern_linear_rows_epilogue", "lantern_linear_rows_packed", "lantern_linear_rows_splitk", "lantern_linear_rows_streamk_workspace", "lantern_linear_rows_streamk", "lantern_pack_linear_weight_bytes", "lantern_pack_linear_weight", "lantern_drafter_fc_streamk", "lantern_head_expand_streamk", "lantern_rmsnorm_rows", "lantern_qk_norm_rope", "lantern_qk_rope_pairs", "lantern_draft_depth", "lantern_head_sample", "lantern_draft_static_inputs", "lantern_mask_left_padding",
+    "lantern_tuning_set", "lantern_tuning_get", "lantern_tuning_name", "lantern_tuning_reset",
 ]

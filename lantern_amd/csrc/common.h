@@ -13,6 +13,30 @@ namespace lantern {
 // ---------------------------------------------------------------- host error state
 void set_error(const char *fmt, ...);
 
+// ---------------------------------------------------------------- tuning values (lantern_tuning_set / lantern_tuning_get)
+// Kernel-instance and launch-shape choices a measurement may want to override.  They are arguments of an explicit C-ABI call -- the library reads
+// NO environment variable (round 5's getenv knobs are gone); the defaults below are what every product path runs.
+enum Tuning {
+    TUNE_EPW_TP = 0,        // 5: throughput instances of the chain kernel for > 256 sequences per launch (0: generic two-per-CU instance; 1..4: older forms)
+    TUNE_EPW_TP4,           // 1: the compact four-per-CU instance for the default tree; 0: round 4's three-per-CU form
+    TUNE_EPW_TP_RAW,        // 256: threads per sequence of the raw-row throughput instances (512: the 128-VGPR form)
+    TUNE_EPW_SPEC,          // 2: fixed-configuration instances (1: no fixed tree, 0: the generic instance)
+    TUNE_EPW_OCC2,          // -1: throughput forms when B > 256 (0 / 1 force them off / on)
+    TUNE_O7_NT,             // 0: threads per row of cfg_window_bf16_kernel by window size (256 / 1024 force a form)
+    TUNE_PREP_NT,           // 0: prep_rows_kernel<512> (1024: the 1024-thread form)
+    TUNE_KV_U,              // 0 -> 2 row groups in flight per thread of the KV mover
+    TUNE_KV_KS,             // 4: slabs per workgroup of the small-slab commit kernel (0: one workgroup tile per slab)
+    TUNE_KV_VARIANT,        // 0: 10 * U + mode of the KV mover (measurement variants)
+    TUNE_GEMM_TILED_FROM,   // 129: rows from which lantern_linear_rows_packed runs the LDS-tiled GEMM
+    TUNE_SK_GROUPS,         // 0: stream-K grid = one workgroup per CU (> 0 forces the grid)
+    TUNE_SK_WHOLE_MB,       // 40: matrices up to this many MB get whole tiles per workgroup
+    TUNE_SK_NT_MIN_MB,      // 80: matrices from this many MB are streamed with non-temporal loads
+    TUNE_TA_SPLITS,         // 0: key splits of tree attention by launch size (> 0 forces the split count)
+    TUNE_TA_MIN_TILES,      // 2: key tiles per wave and split below which no further split is made
+    TUNE_COUNT
+};
+int tuning(int t);
+
 // ---------------------------------------------------------------- measurement aid (lantern_profile_next_launch)
 // When a (start, stop) event pair is armed on this thread, the next launch through LANTERN_LAUNCH records them at
 // kernel begin / end (hipExtLaunchKernelGGL: the dispatch's own timestamps, i.e. the kernel-only duration rocprofv3

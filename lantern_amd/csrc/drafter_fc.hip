@@ -1226,7 +1226,7 @@ extern "C" int lantern_linear_rows_packed(const void *A, const void *W_packed, c
     uint16_t *o = (uint16_t *)out;
     const int tiles = (n_rows + 31) / 32;
     LANTERN_CHECK_ARG((M + 63) / 64 <= 65535, "linear_rows_packed: M=%d rows exceed the launch grid", M);
-    static const int tiled_from = getenv("LANTERN_GEMM_TILED_FROM") ? atoi(getenv("LANTERN_GEMM_TILED_FROM")) : 129;   // tuning knob (diagnostic)
+    const int tiled_from = tuning(TUNE_GEMM_TILED_FROM);
     if (M >= tiled_from) {          // many rows: the LDS-tiled form (128 x 128 per workgroup; row blocks fastest so that a weight tile's readers are neighbours)
         const dim3 grid((M + TG_BM - 1) / TG_BM, epilogue == LANTERN_EPI_SILU_MUL ? (tiles + 1) / 2 : (tiles + 3) / 4);
         if (epilogue == LANTERN_EPI_SILU_MUL) LANTERN_LAUNCH((linear_rows_tiled_kernel<2>), grid, dim3(TG_THREADS), 0, st, a, w, bi, M, K, n_rows, o, out_stride, ax, aux_stride, pair_rows);
@@ -1256,9 +1256,9 @@ extern "C" int lantern_linear_rows_packed(const void *A, const void *W_packed, c
 }
 
 // workgroups of a launch: one per CU of the current device (the register buffers of the trips in flight leave room for one 512-thread
-// workgroup per CU).  LANTERN_SK_GROUPS overrides it -- a diagnostic knob for tuning runs, read once per process.
+// workgroup per CU).  lantern_tuning_set("sk_groups", g) overrides it (measurement runs).
 static int sk_groups(int) {
-    static const int env_g = getenv("LANTERN_SK_GROUPS") ? atoi(getenv("LANTERN_SK_GROUPS")) : 0;
+    const int env_g = tuning(TUNE_SK_GROUPS);
     if (env_g > 0) return env_g;
     static int cus[64] = {0};
     int dev = 0;
@@ -1322,15 +1322,17 @@ static int sk_run(SkArgs a, int epilogue, bool packed, bool gather, void *worksp
     if ((long long)G > total) G = (int)total;
     // Small matrices (LlamaGen-size drafters: 3 - 20 MB per product) are bound by the launch's fixed costs, not by the stream: a range that ends inside a tile
     // costs its workgroup a partial-tile round trip and the tile's finisher another, so they get WHOLE tiles per workgroup (the largest divisor of the tile
-    // count that fits the grid: no partial tiles at all) even where that leaves CUs idle (LlamaGen EAGLE-2 cycle 848 - 863 -> 822 - 831 us; 50 MB: slower).  LANTERN_SK_WHOLE_MB: tuning knob (diagnostic), the
+    // count that fits the grid: no partial tiles at all) even where that leaves CUs idle (LlamaGen EAGLE-2 cycle 848 - 863 -> 822 - 831 us; 50 MB: slower).  lantern_tuning_set("sk_whole_mb", ..): the
     // size limit in MB (default 40: the 7B drafter's o_proj, 34 MB in 128 tiles, is still better off on 128 workgroups without partial tiles -- Lumina static
     // cycle 884 - 889 -> 865 - 868 us; 70, which takes in the 67 MB input stage: 878; 0 = never).
-    static const int whole_mb = getenv("LANTERN_SK_WHOLE_MB") ? atoi(getenv("LANTERN_SK_WHOLE_MB")) : 40;
+    const int whole_mb = tuning(TUNE_SK_WHOLE_MB);
     if (whole_mb > 0 && (long long)a.n_tiles * 32 * a.K * 2 * (epilogue == LANTERN_EPI_SILU_MUL ? 2 : 1) <= (long long)whole_mb * 1000000) {
         int best = 1;
         for (int g = 1; g <= G && g <= a.n_tiles; ++g)
             if (a.n_tiles % g == 0) best = g;
-        G = best;
+        // (a tile count without a large divisor -- prime, or just above the grid: 257, 2 x 131 -- would collapse to one or two workgroups for the
+        // whole product: whole tiles only when they keep at least half of the grid busy, else the stream-K split stays -- ADVICE round 5)
+        if (2 * best >= G || 2 * best >= a.n_tiles) G = best;
     }
     a.G = G;
     // fixed layout whatever the shape (launches of different shapes share one workspace): the partial tiles first, the tile counters behind them
@@ -1340,8 +1342,8 @@ static int sk_run(SkArgs a, int epilogue, bool packed, bool gather, void *worksp
     // from the 256 MB Infinity Cache before the next drafting pass comes back to it anyway, and read that way it neither displaces what the smaller
     // products (input stage, o_proj, head window: 167 MB at 7B size) and the K / V rows leave there nor pays for allocating its lines.  Measured on the 7B
     // drafter (tools/draft_bench.py lumina_static): threshold 200 MB (none) 1001 us per cycle, 120 (gate / up) 981, 95 (+ q/k/v) 931, 80 (+ down) 887-900,
-    // 30 (all but o_proj) 901, 0 (all) 912.  LANTERN_SK_NT_MIN_MB: tuning knob (diagnostic; negative = never).
-    static const int nt_min_mb = getenv("LANTERN_SK_NT_MIN_MB") ? atoi(getenv("LANTERN_SK_NT_MIN_MB")) : 80;
+    // 30 (all but o_proj) 901, 0 (all) 912.  lantern_tuning_set("sk_nt_min_mb", ..): negative = never.
+    const int nt_min_mb = tuning(TUNE_SK_NT_MIN_MB);
     a.w_stream = nt_min_mb >= 0 && (long long)a.n_tiles * 32 * a.K * 2 * (epilogue == LANTERN_EPI_SILU_MUL ? 2 : 1) >= (long long)nt_min_mb * 1000000 ? 1 : 0;
     // two trips in flight per wave: three and four measured the same (24.4 - 24.6 / 21.5 - 21.9 us for the 100 / 90 MB matrices) -- the kernel is
     // at the read bandwidth the part delivers (4.1 - 4.6 TB/s; torch's read-only reductions reach 3.8 - 4.0, its copy 5.2 read + write)

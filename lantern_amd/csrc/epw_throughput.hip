@@ -9,8 +9,8 @@
 namespace lantern {
 
 bool epw_launch_throughput(int kind, const EpwLaunch &l, const EpwArgs &args) {
-    static const bool compact = !(getenv("LANTERN_EPW_TP4") && atoi(getenv("LANTERN_EPW_TP4")) == 0);   // tuning knob (diagnostic): 0 = the three-per-CU form
-    static const bool raw512 = getenv("LANTERN_EPW_TP_RAW") && atoi(getenv("LANTERN_EPW_TP_RAW")) == 512;   // tuning knob (diagnostic)
+    const bool compact = tuning(TUNE_EPW_TP4) != 0;          // lantern_tuning_set("epw_tp4", 0) = the three-per-CU form
+    const bool raw512 = tuning(TUNE_EPW_TP_RAW) == 512;
 #define TP(...) LANTERN_LAUNCH((epw_kernel<__VA_ARGS__>), l.grid, dim3(NTX), l.lds, l.st, args)
     switch (kind) {
     case EPW_TP_LUMINA_DEFAULT_TREE:
@@ -32,7 +32,7 @@ bool epw_launch_throughput(int kind, const EpwLaunch &l, const EpwArgs &args) {
     case EPW_TP_RAW_GENERIC: { constexpr int NTX = 512; TP(512, 4, 2, 4, true, true); return true; }
     // raw rows carry the row post-process's 18 KB of histograms: 71 KB of LDS per workgroup = two per CU whatever the thread count.  256 threads x 8
     // float4 at two waves per SIMD (no register cap to spill against, half the waves -- half the repeated scalar work -- per sequence), or
-    // (LANTERN_EPW_TP_RAW=512, diagnostic) 512 threads at 128 VGPRs
+    // (lantern_tuning_set("epw_tp_raw", 512)) 512 threads at 128 VGPRs
     case EPW_TP_RAW_LUMINA_DEFAULT_TREE: if (raw512) { constexpr int NTX = 512; TP(512, 4, 2, 4, true, true, 2, 1); } else { constexpr int NTX = 256; TP(256, 8, 2, 2, true, true, 2, 1); } return true;
     case EPW_TP_RAW_LUMINA_STATIC: if (raw512) { constexpr int NTX = 512; TP(512, 4, 2, 4, true, true, 1, 1); } else { constexpr int NTX = 256; TP(256, 8, 2, 2, true, true, 1, 1); } return true;
     case EPW_TP_RAW_LUMINA_DYNAMIC: if (raw512) { constexpr int NTX = 512; TP(512, 4, 2, 4, true, true, 3, 1); } else { constexpr int NTX = 256; TP(256, 8, 2, 2, true, true, 3, 1); } return true;

@@ -406,7 +406,7 @@ extern "C" int lantern_kv_gather(void *const *slab_ptrs, const int32_t *slab_seq
     const int cpr = (int)(d * elem_bytes / 16);
     const int64_t total = outer * cpr;
     LANTERN_CHECK_ARG(total < (1ll << 31), "kv_gather: outer * row chunks = %lld does not fit 31 bits", (long long)total);
-    static const int u_knob = getenv("LANTERN_KV_U") ? atoi(getenv("LANTERN_KV_U")) : 0;   // tuning knob (diagnostic)
+    const int u_knob = tuning(TUNE_KV_U);
     const int U = u_knob ? u_knob : 2;
     int gx = (int)((total + 256 * U - 1) / (256 * U));
     if (gx > 4096) gx = 4096;
@@ -498,7 +498,7 @@ int lantern::launch_update_inference_inputs(void *const *slab_ptrs, const int32_
     const int64_t total = outer * cpr;
     LANTERN_CHECK_ARG(total < (1ll << 31), "update_inference_inputs: outer * row chunks = %lld does not fit 31 bits", (long long)total);
     LANTERN_CHECK_ARG(S_max < (1ll << 31), "update_inference_inputs: S_max = %lld does not fit 31 bits", (long long)S_max);
-    static const int ks_knob = getenv("LANTERN_KV_KS") ? atoi(getenv("LANTERN_KV_KS")) : 4;   // tuning knob (diagnostic): slabs per workgroup, 0 = one workgroup tile per slab
+    const int ks_knob = tuning(TUNE_KV_KS);          // slabs per workgroup, 0 = one workgroup tile per slab
     const bool prep_nucleus = prep && prep->top_p >= 1e-8f && prep->top_p < 1.0f;
     const int n_prep = prep ? prep->B * prep->n_list + prep->B : 0;
     if (prep) LANTERN_CHECK_ARG(prep->W == 8192 && prep->B >= 0, "update_inference_inputs: the next step's preparation rides on the 8192-id window only");
@@ -547,7 +547,7 @@ int lantern::launch_update_inference_inputs(void *const *slab_ptrs, const int32_
         LANTERN_CHECK_LAUNCH("update_inference_inputs");
         return LANTERN_OK;
     }
-    static const int variant = getenv("LANTERN_KV_VARIANT") ? atoi(getenv("LANTERN_KV_VARIANT")) : 0;   // tuning knob (diagnostic): 10*U + mode
+    const int variant = tuning(TUNE_KV_VARIANT);          // 10*U + mode
     const int uu = variant / 10 ? variant / 10 : 2, mode = variant % 10;
     int gx = (int)((total + uu * 256 - 1) / (uu * 256));
     if (gx > 4096) gx = 4096;

@@ -851,7 +851,7 @@ extern "C" int lantern_evaluate_posterior_nodes(const lantern_ep_params *prm, co
         hipExtLaunchKernelGGL((epn_walk_kernel<NT_, E4_, FW_>), wgrid, dim3(NT_), wlds, st, nullptr, (hipEvent_t)ev1, 0, args);         \
     } while (0)
     // compile-time instances for the reference's configurations on the Chameleon vocabulary (see epn_node): Lumina static (1), Anole static (4)
-    static const int spec_knob = getenv("LANTERN_EPW_SPEC") ? atoi(getenv("LANTERN_EPW_SPEC")) : 2;   // tuning knob (diagnostic): 0 = the generic instance
+    const int spec_knob = tuning(TUNE_EPW_SPEC);          // 0 = the generic instance
     const bool chameleon = spec_knob != 0 && packed && !wide && W == 8192 && p.lantern && p.V == 65536 && p.img_lo == 4 && p.img_hi == 8196 && p.tok_offset == 4 &&
                            p.table_rows == 8192 && win->win_lo == 4;
     const bool lumina = chameleon && p.mode == LANTERN_MODE_STATIC_LUMINA && p.syntax_shortcut && p.n_syntax == 4 && p.syntax[0] == 8196 && p.syntax[1] == 8197 &&

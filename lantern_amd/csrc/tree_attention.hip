@@ -347,19 +347,11 @@ static TaShape ta_shape(int N, int d) {
 }
 
 static int ta_splits(int B, int Hq, int q_groups, int64_t max_kv_len) {
-    static int forced = -1;
-    if (forced < 0) {
-        const char *e = getenv("LANTERN_TA_SPLITS");
-        forced = e ? atoi(e) : 0;
-    }
+    const int forced = tuning(TUNE_TA_SPLITS);
     const int64_t tiles = (max_kv_len + TA_TILE - 1) / TA_TILE;
     const int64_t wgs = (int64_t)B * Hq * q_groups;
     int64_t want = forced > 0 ? forced : 512 / wgs;                                          // one round of two resident workgroups per CU
-    static int min_tiles = -1;          // tuning knob (diagnostic): key tiles per wave and split below which no further split is made
-    if (min_tiles < 0) {
-        const char *e = getenv("LANTERN_TA_MIN_TILES");
-        min_tiles = e && atoi(e) > 0 ? atoi(e) : 2;
-    }
+    const int min_tiles = tuning(TUNE_TA_MIN_TILES) > 0 ? tuning(TUNE_TA_MIN_TILES) : 2;          // key tiles per wave and split below which no further split is made
     const int64_t cap = tiles / (min_tiles * TA_WAVES) > 1 ? tiles / (min_tiles * TA_WAVES) : 1;              // >= min_tiles tiles per wave and split
     if (want > cap) want = cap;
     if (want > 64) want = 64;

@@ -7,7 +7,9 @@
 // position ids, retrieve_indices, p_indices, b_indices); models/drafters/utils_c.py:35-179
 // (drafter side: per-depth masks / tree_indices / repeat_nums over non-leaf nodes).
 #include <algorithm>
+#include <atomic>
 #include <cstdarg>
+#include <cstring>
 #include <map>
 #include <vector>
 
@@ -35,6 +37,39 @@ void arm_launch_events(void *start, void *stop) {
     g_ev_start = start;
     g_ev_stop = stop;
 }
+
+// ---------------------------------------------------------------------------------------------- tuning values
+// (common.h `enum Tuning` names the same slots; this file does not include the HIP headers)
+namespace {
+struct TuningSlot { const char *name; int dflt; };
+const TuningSlot kTuning[] = {
+    {"epw_tp", 5}, {"epw_tp4", 1}, {"epw_tp_raw", 256}, {"epw_spec", 2}, {"epw_occ2", -1}, {"o7_nt", 0}, {"prep_nt", 0}, {"kv_u", 0}, {"kv_ks", 4},
+    {"kv_variant", 0}, {"gemm_tiled_from", 129}, {"sk_groups", 0}, {"sk_whole_mb", 40}, {"sk_nt_min_mb", 80}, {"ta_splits", 0}, {"ta_min_tiles", 2}};
+constexpr int kTuningCount = sizeof(kTuning) / sizeof(kTuning[0]);
+std::atomic<int> g_tuning[kTuningCount];
+std::atomic<bool> g_tuning_init{false};
+void tuning_init() {
+    if (g_tuning_init.load(std::memory_order_acquire)) return;
+    static std::atomic_flag once = ATOMIC_FLAG_INIT;
+    if (!once.test_and_set()) {
+        for (int i = 0; i < kTuningCount; ++i) g_tuning[i].store(kTuning[i].dflt, std::memory_order_relaxed);
+        g_tuning_init.store(true, std::memory_order_release);
+    } else {
+        while (!g_tuning_init.load(std::memory_order_acquire)) {}
+    }
+}
+int tuning_index(const char *name) {
+    if (!name) return -1;
+    for (int i = 0; i < kTuningCount; ++i)
+        if (!strcmp(name, kTuning[i].name)) return i;
+    return -1;
+}
+}  // namespace
+int tuning(int t) {
+    tuning_init();
+    return (t >= 0 && t < kTuningCount) ? g_tuning[t].load(std::memory_order_relaxed) : 0;
+}
+int tuning_count() { return kTuningCount; }
 
 namespace {
 
@@ -393,5 +428,32 @@ extern "C" int lantern_tree_node_tables(const int64_t *retrieve, const int32_t *
     for (int n = 0; n < N; ++n)
         if (rank[n] < 0) ord[no++] = n;
     hdr[0] = N; hdr[1] = n_int; hdr[2] = n_child; hdr[3] = max_ch; hdr[4] = D; hdr[5] = P; hdr[6] = prefix_sibs ? 1 : 0; hdr[7] = 0;
+    return LANTERN_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- lantern_tuning_set / get / name
+extern "C" int lantern_tuning_set(const char *name, int value) {
+    const int i = lantern::tuning_index(name);
+    if (i < 0) {
+        lantern::set_error("tuning_set: unknown name '%s'", name ? name : "(null)");
+        return LANTERN_E_INVALID;
+    }
+    lantern::tuning_init();
+    lantern::g_tuning[i].store(value, std::memory_order_relaxed);
+    return LANTERN_OK;
+}
+extern "C" int lantern_tuning_get(const char *name, int *value) {
+    const int i = lantern::tuning_index(name);
+    if (i < 0 || !value) {
+        lantern::set_error("tuning_get: unknown name '%s'", name ? name : "(null)");
+        return LANTERN_E_INVALID;
+    }
+    *value = lantern::tuning(i);
+    return LANTERN_OK;
+}
+extern "C" const char *lantern_tuning_name(int index) { return (index >= 0 && index < lantern::kTuningCount) ? lantern::kTuning[index].name : nullptr; }
+extern "C" int lantern_tuning_reset(void) {
+    lantern::tuning_init();
+    for (int i = 0; i < lantern::kTuningCount; ++i) lantern::g_tuning[i].store(lantern::kTuning[i].dflt, std::memory_order_relaxed);
     return LANTERN_OK;
 }

@@ -38,7 +38,16 @@ extern "C" int lantern_verify_step(const lantern_step_group *groups, int n_group
     int rc;
     for (int g = 0; g < n_groups; ++g) {
         const lantern_step_group &s = groups[g];
-        if (s.flags & LANTERN_STEP_PREPARED) continue;          // the previous call's commit launch prepared this step (prepare_next)
+        if (s.flags & LANTERN_STEP_PREPARED) {          // the previous call's commit launch prepared this step (prepare_next)
+            // only what prepare_next can have prepared: a static-tree group with a node list (an EAGLE-2 group would skip its tree build).  A
+            // failed call or a non-zero walk status in the previous step invalidates the preparation: the caller clears the flag and the step
+            // prepares itself (include/lantern_hip.h)
+            if (s.dyn || !s.node_list || s.n_list <= 0) {
+                lantern::set_error("LANTERN_STEP_PREPARED: only a static-tree group with a node list can have been prepared by prepare_next");
+                return fail(g, "prepare_step", LANTERN_E_INVALID);
+            }
+            continue;
+        }
         if (s.dyn && s.node_list && s.n_list > 0) { // EAGLE-2 tree + candidates + the likely rows in one launch
             rc = lantern_prepare_step(&s);
             if (rc) return fail(g, "prepare_step", rc);
@@ -70,8 +79,9 @@ extern "C" int lantern_verify_step(const lantern_step_group *groups, int n_group
         const lantern_step_group &s = groups[g];
         if (s.greedy) {          // greedy decoding: CFG + model mask of every row, dense f32 (no processor list: ea_model_llamagen.py:930)
             const lantern_step_greedy &q = *s.greedy;
-            if (!q.logits || !q.row_index || !q.ok_scratch || !q.out_row || !q.token || s.dyn || s.nodes || s.prepare_next) {
-                lantern::set_error("greedy step: logits / row_index / ok_scratch / out_row / token, and none of dyn / nodes / prepare_next");
+            if (!q.logits || !q.row_index || !q.ok_scratch || !q.out_row || !q.token || s.dyn || s.nodes || s.prepare_next || s.ep_win.verdict_host) {
+                lantern::set_error("greedy step: logits / row_index / ok_scratch / out_row / token, and none of dyn / nodes / prepare_next / ep_win.verdict_host "
+                                   "(no greedy kernel writes the pinned verdict record)");
                 return fail(g, "greedy", LANTERN_E_INVALID);
             }
             rc = lantern_cfg_mask_topk(s.cond, s.uncond, s.dtype, s.B * s.N, s.V, s.cfg, s.model, s.pos_ids, s.pos_base, s.w_latent, s.h_latent, s.img_lo,

@@ -316,7 +316,7 @@ extern "C" int lantern_cfg_mask_topk_window(const void *cond, const void *uncond
     if (bf && win_len % 8 == 0 && win_len >= 2048 && temperature == 1.0f && !nucleus) {
         const int chunks = win_len / 8;
         const uint16_t *c16 = (const uint16_t *)cond, *u16 = (const uint16_t *)uncond;
-        static const int nt_knob = getenv("LANTERN_O7_NT") ? atoi(getenv("LANTERN_O7_NT")) : 0;   // tuning knob (diagnostic)
+        const int nt_knob = tuning(TUNE_O7_NT);
 #define CW16_ARGS c16, u16, V, cfg, model, pos_ids, pos_base, w_latent, h_latent, img_lo, img_hi, newline_id, eos_id, top_k, seq_len, rows_per_seq, win_lo, win_len, out_win, row_hot, out_kind
 #define CW16(NT_, E8_)                                                                                                       \
     do {                                                                                                                     \
@@ -400,7 +400,7 @@ extern "C" int lantern_prepare_step(const lantern_step_group *g) {
     if (rc) return rc;
     if (g->dyn) return prepare_step_dynamic(g);
     if (g->B == 0) return LANTERN_OK;
-    static const int nt_knob = getenv("LANTERN_PREP_NT") ? atoi(getenv("LANTERN_PREP_NT")) : 0;   // tuning knob (diagnostic)
+    const int nt_knob = tuning(TUNE_PREP_NT);
     if (g->top_p >= 1e-8f && g->top_p < 1.0f) LANTERN_LAUNCH((prep_rows_kernel<512, 2, true>), dim3(g->B * g->n_list + g->B), dim3(512), 0, (hipStream_t)g->stream, a);
     else if (nt_knob == 1024) LANTERN_LAUNCH((prep_rows_kernel<1024, 1>), dim3(g->B * g->n_list + g->B), dim3(1024), 0, (hipStream_t)g->stream, a);
     else LANTERN_LAUNCH((prep_rows_kernel<512, 2>), dim3(g->B * g->n_list + g->B), dim3(512), 0, (hipStream_t)g->stream, a);
@@ -494,7 +494,7 @@ extern "C" int lantern_evaluate_posterior_window(const lantern_ep_params *prm, c
     const int idmode = !lds_ids ? 0 : ((p.lantern && p.table_cols % 8 == 0 && ((uintptr_t)buf->nn_table & 15) == 0) ? 2 : 1);
     const EpwLaunch L{grid, lds, st};
     // the headline shape gets its own instance (SPEC 1: mode / LANTERN / syntax-shortcut flags are compile-time constants there)
-    static const int spec_knob = getenv("LANTERN_EPW_SPEC") ? atoi(getenv("LANTERN_EPW_SPEC")) : 2;   // tuning knob (diagnostic): 0 = the generic instance, 1 = no fixed tree
+    const int spec_knob = tuning(TUNE_EPW_SPEC);          // 0 = the generic instance, 1 = no fixed tree
     const bool chameleon = spec_knob != 0 && p.lantern && p.V == 65536 && p.img_lo == 4 && p.img_hi == 8196 && p.tok_offset == 4 && p.table_rows == 8192 &&
                            win->win_lo == 4 && W == 8192 && p.rows_per_seq <= EW_MAX_N && (raw || win->rows_kind == LANTERN_ROWS_PROBS) &&
                            (!raw || win->raw_w_latent == 0 || (win->raw_eos_id == 8196 && win->raw_newline_id == 8803));
@@ -506,14 +506,14 @@ extern "C" int lantern_evaluate_posterior_window(const lantern_ep_params *prm, c
     // the fixed-tree instance is picked by SIZES (P, D, N of mc_sim_7b_63) and stages at most 4 candidates per level ahead; a tree of the same sizes
     // with a wider fan-out still runs correctly (the restage path, tests: test_window_two_workgroups_per_cu_build[six_wide])
     const bool default_tree = spec_knob >= 2 && p.P == 15 && p.D == 6 && p.N == 26 && p.rows_per_seq == 26;
-    static const int occ_knob = getenv("LANTERN_EPW_OCC2") ? atoi(getenv("LANTERN_EPW_OCC2")) : -1;   // tuning knob (diagnostic)
+    const int occ_knob = tuning(TUNE_EPW_OCC2);
     const bool many = occ_knob >= 0 ? occ_knob != 0 : p.B > 256;          // more sequences than CUs: the throughput forms (epw_throughput.hip)
     // Throughput form of the fixed-configuration instances (the shape BASELINE's roofline target is assessed on): 256 threads x 8 float4 per thread, three
     // workgroups per CU (53 KB of LDS each, <= 168 VGPRs at 3 waves per SIMD), drafter rows requested only once a rejection is known.  At saturation
     // the kernel is bound by instruction ISSUE (profiles/r04_ep_sweep_pmc.txt), so half the waves per sequence is what pays: 4096 sequences per
     // launch 293 us (generic, 512 threads, two per CU) -> 228 (fixed configuration, 512 threads) -> 194 (owner-wave sibling zeroing) -> 163 us.
     // LANTERN_EPW_TP=0: the generic two-per-CU instance; 1: the 512-thread fixed-configuration instance (diagnostic).
-    static const int tp_knob = getenv("LANTERN_EPW_TP") ? atoi(getenv("LANTERN_EPW_TP")) : 5;   // tuning knob (diagnostic)
+    const int tp_knob = tuning(TUNE_EPW_TP);
     const bool nucleus = p.top_p >= 1e-8f && p.top_p < 1.0f;
     bool ok = true;
     if (raw && nucleus) {          // raw rows with a nucleus filter: the generic raw instances with the filter compiled in

@@ -331,7 +331,7 @@ class EaLumina_mGPT(nn.Module):
             input_ids = torch.cat([input_ids, acc], dim=-1)
         # accepted hidden states (cond, uncond) + bonus token in one launch
         hid = torch.stack([hidden_states_new[0], uncond_hidden_states_new[0]])[None]        # [1,2,N,H]
-        u = torch.rand(1, dtype=torch.float64, device=dev) if do_sample else None
+        u = self._bonus_uniform(dev) if do_sample else None
         out_h, _, token = ops.accept_gather(hid, retrieve_indices, None, best, alen, sample_p=sample_p[None].float(), u=u)
         accept_hidden_states_new = out_h[:, 0, :n]
         accept_uncond_hidden_states_new = out_h[:, 1, :n]
@@ -507,7 +507,6 @@ class EaLumina_mGPT(nn.Module):
             w.verdict_host = nx.verdict.data_ptr()
         except RuntimeError:
             nx.verdict = nx.verdict_np = None
-        nx.ub, nx.ub_i = None, self._UB_BLOCK
         nx.ids_buf = None
         if st.input_ids.device == dev and st.input_ids.dim() == 2:
             cap = max(int(getattr(st, "max_length", 4096)), L0) + 2 * D + 64
@@ -518,11 +517,24 @@ class EaLumina_mGPT(nn.Module):
 
     _UB_BLOCK = 4096          # bonus-draw uniforms generated per torch.rand call (one per verify step before)
 
+    def _bonus_uniform(self, dev):
+        """The next bonus-draw uniform as a 1-element float64 view: every path of the mirror (the one-call step, the per-kernel step, the public
+        update_inference_inputs) takes it from ONE block of `_UB_BLOCK` values per torch.rand call, restarted by generate() -- so a torch seed gives
+        the same image whichever path runs (the one-call step used to draw blocks while the per-kernel path drew torch.rand(1) per step)."""
+        ub = getattr(self, "_ub", None)
+        if ub is None or self._ub_i >= ub.shape[0] or ub.device != dev:
+            self._ub, self._ub_i = torch.rand(self._UB_BLOCK, dtype=torch.float64, device=dev), 0
+            ub = self._ub
+        u = ub[self._ub_i:self._ub_i + 1]
+        self._ub_i += 1
+        return u
+
     def _verify_step_native(self, st, nx, lantern, lantern_k, lantern_delta):
         """One verify step: generate_candidates (one call: the target forward needs the tree tokens), the two target forwards, then ONE
         lantern_verify_step call -- the tree_decoding post-process of all rows, evaluate_posterior with the bonus
         draw, the KV / hidden / token commit (only where the walk reported no status) -- on preallocated buffers, and one host read of the 40-byte
-        verdict record.  Same kernels, same uniforms, same results as the per-kernel path (tests/test_gpu_generate_ref.py runs both)."""
+        verdict record.  Same kernels, same uniforms (`_bonus_uniform`: one block shared by every path), same results as the per-kernel path
+        (tests/test_gpu_generate_ref.py runs both, with blocks of 1 and of 8 recorded uniforms)."""
         C, L, a = nx.C, nx.L, nx.group[0]
         tl = st.tree_logits
         dev = nx.dev
@@ -579,12 +591,8 @@ class EaLumina_mGPT(nn.Module):
         a.out_hidden, a.hid_elem_bytes, a.H = out_h.data_ptr(), hid.element_size(), hid.shape[-1]
         fifo = self._uniforms()
         fifo.reserve(nx.N - 1)                                                             # one uniform per tried candidate, every non-root node at most once
-        if nx.ub_i >= self._UB_BLOCK:                                                      # the bonus draws' uniforms: one torch.rand per _UB_BLOCK steps
-            nx.ub, nx.ub_i = torch.rand(self._UB_BLOCK, dtype=torch.float64, device=dev), 0
-            nx.ub_ptr = nx.ub.data_ptr()
-        u = nx.ub[nx.ub_i:nx.ub_i + 1]
-        ew.u_bonus = nx.ub_ptr + 8 * nx.ub_i
-        nx.ub_i += 1
+        u = self._bonus_uniform(dev)                                                       # the bonus draws' uniforms: one torch.rand per _UB_BLOCK steps
+        ew.u_bonus = u.data_ptr()
         cur, nxt = nx.lens[par], nx.lens[par ^ 1]
         a.slab_prev, a.new_len, a.seq_len = cur.data_ptr(), nxt.data_ptr(), cur.data_ptr()          # (slab 0 is a cond slab at offset 0: its length is len(input_ids))
         Lcur = st.input_ids.shape[1]
@@ -679,7 +687,7 @@ class EaLumina_mGPT(nn.Module):
         fifo = self._uniforms()
         fifo.reserve(candidates.shape[0] * candidates.shape[1])          # before the snapshot (see _posterior_on_device)
         cur0 = fifo.cursor.clone()
-        u = torch.rand(1, dtype=torch.float64, device=dev)
+        u = self._bonus_uniform(dev)
         ep = self._posterior_on_device(rows, candidates, cart_prob, original_prob, tree_candidates, lantern, lantern_k, lantern_delta,
                                        u_bonus=u if isinstance(rows, WindowRows) else None, reserve=False)
         best, alen, status = ep["best"], ep["accept_len"], ep["counters"][:, 5]
@@ -766,6 +774,7 @@ class EaLumina_mGPT(nn.Module):
                  tree_choices=mc_sim_7b_63, **kwargs):
         if not do_sample:
             raise NotImplementedError("Greedy decoding is not implemented yet")   # as the reference (:728-729)
+        self._ub = None          # the bonus uniforms restart with every image (same torch seed -> same image on every path)
         st = self._prepare_generation(input_ids.clone(), cfg_scale, top_k, kwargs.get("drafter_top_k"), tree_choices)
         st.max_length = max_length
         self._first_draft(st, logits_processors)

@@ -114,9 +114,10 @@ class WorkloadConfig:
     native_step: bool = True        # eager windowed path: the whole step of all groups through ONE C call (lantern_verify_step) instead of
                                     # 4 x n_groups ctypes calls (the Python launch loop caps the stream groups at ~2 otherwise)
     leaf_workgroups: int = -1       # node kernel: -1 = by batch size (include/lantern_hip.h lantern_ep_nodes)
-    merge_prepare: bool = True      # one-call steps with prepared rows and KV slabs: step s + 1's lantern_prepare_step (candidate assembly + the likely
-                                    # rows) rides in step s's commit launch (lantern_step_group.prepare_next) -- it needs step s's verdict, not its KV
-                                    # rows -- so a step is two launches per group (evaluate_posterior, commit + next prepare) instead of three
+    merge_prepare: bool = False     # HARNESS-ONLY variant (bench extra `merged_prepare_harness_only`, never the headline): step s + 1's lantern_prepare_step
+                                    # rides in step s's commit launch (lantern_step_group.prepare_next).  Its precondition -- step s + 1's cond / uncond /
+                                    # ss_token are FINAL when step s's commit launches -- only holds where those rows come out of a pre-generated pool; in a
+                                    # real decode loop they are the outputs of the drafter and target forwards that run AFTER commit(s)
     n_groups: int = 1               # >1: the sequences are split into groups, each launched on its own HIP stream, so that one
                                     # group's latency-bound evaluate_posterior overlaps the others' bandwidth-bound kernels
                                     # (independent sequences: no ordering between groups exists)

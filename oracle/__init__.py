@@ -20,7 +20,8 @@ from typing import List, Optional, Sequence
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SO = os.path.join(_HERE, "liblantern_oracle.so")
+# (LANTERN_ORACLE_LIBRARY: the ASan + UBSan build of the same file, `make -C oracle asan`; tests/test_sanitizers_cpu.py)
+_SO = os.environ.get("LANTERN_ORACLE_LIBRARY") or os.path.join(_HERE, "liblantern_oracle.so")
 
 MODE_DYNAMIC, MODE_STATIC_LUMINA, MODE_STATIC_LG = 0, 1, 2
 MODEL_PLAIN, MODEL_LUMINA, MODEL_ANOLE = 0, 1, 2
@@ -30,6 +31,8 @@ F32, BF16 = 0, 1
 def build(force: bool = False) -> str:
     src = os.path.join(_HERE, "lantern_oracle.c")
     hdr = os.path.join(_HERE, "lantern_oracle.h")
+    if os.environ.get("LANTERN_ORACLE_LIBRARY"):
+        return _SO
     if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
         subprocess.check_call(["make", "-C", _HERE, "-s", "liblantern_oracle.so"])
     return _SO

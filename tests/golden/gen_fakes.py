@@ -137,7 +137,12 @@ class DetDraws:
         return (cs > u * cs[..., -1:]).to(torch.int64).argmax(-1, keepdim=True)
 
     def rand(self, *size, dtype=None, device=None, **kw):
-        return torch.tensor([self.next()], dtype=dtype or torch.float32, device=device)
+        """torch.rand(n): the next n recorded uniforms (0.5 behind the end of the record: a block may reach past the last step's draw)."""
+        n = int(size[0]) if size else 1
+        vals = []
+        for _ in range(n):
+            vals.append(self.next() if self.n < len(self.us) else 0.5)
+        return torch.tensor(vals, dtype=dtype or torch.float32, device=device)
 
 
 def make_base(T, dev):

@@ -234,3 +234,23 @@ def test_linear_rows_packed_validates_without_gpu():
     assert f(one, one, None, 64, 128, 32, one, 32, 1, None, 0, 0, None) == -1 and b"residual" in L.lantern_last_error()
     assert f(one, one, None, 64, 128, 32, one, 32, 2, None, 0, 0, None) == -1 and b"pair_rows" in L.lantern_last_error()
     assert f(one, one, None, 0, 128, 32, one, 32, 0, None, 0, 0, None) == 0             # no rows: nothing to do
+
+
+def test_tuning_values_are_an_explicit_api_and_the_library_reads_no_environment():
+    """kernel-instance / launch-shape choices go through lantern_tuning_set (process-wide ints, defaults = the product
+    path); the shared library does not import getenv at all."""
+    import subprocess
+    names = _lib.tuning_names()
+    assert names == ["epw_tp", "epw_tp4", "epw_tp_raw", "epw_spec", "epw_occ2", "o7_nt", "prep_nt", "kv_u", "kv_ks", "kv_variant", "gemm_tiled_from",
+                     "sk_groups", "sk_whole_mb", "sk_nt_min_mb", "ta_splits", "ta_min_tiles"]
+    defaults = {n: _lib.get_tuning(n) for n in names}
+    assert (defaults["epw_tp"], defaults["epw_tp4"], defaults["epw_tp_raw"], defaults["epw_spec"], defaults["kv_ks"], defaults["sk_whole_mb"]) == (5, 1, 256, 2, 4, 40)
+    _lib.set_tuning("epw_tp_raw", 512)
+    assert _lib.get_tuning("epw_tp_raw") == 512
+    assert _lib.tuning_from_env({"LANTERN_KV_KS": "2", "LANTERN_UNRELATED": "7", "LANTERN_TA_SPLITS": "x"}) == {"kv_ks": 2}
+    _lib.lib().lantern_tuning_reset()
+    assert {n: _lib.get_tuning(n) for n in names} == defaults
+    with pytest.raises(_lib.LanternError):
+        _lib.set_tuning("no_such_value", 1)
+    nm = subprocess.run(["nm", "-D", "--undefined-only", _lib.LIB_PATH], capture_output=True, text=True)
+    assert nm.returncode == 0 and "getenv" not in nm.stdout

@@ -183,7 +183,7 @@ def test_window_and_dense_kernel_sets_generate_the_same_tokens():
         torch.manual_seed(5)
         mdl = make_model(1, "sequential")
         mdl.kernel_set = ks
-        mdl._UB_BLOCK = 1          # one torch.rand per step in both forms (the one-call step draws its bonus uniforms in blocks otherwise): same stream
+        # (both forms take their bonus uniforms from the same block of 4096 per torch.rand call -- EaLumina_mGPT._bonus_uniform: one torch seed, one image)
         prompt = torch.randint(9000, 12000, (1, 9), device="cuda")
         ids, accept = mdl.eagenerate(prompt, max_new_tokens=40, cfg_scale=3.0, top_k=200, lantern=True, lantern_k=100, lantern_delta=0.1,
                                      tree_choices=mc_sim_7b_63)

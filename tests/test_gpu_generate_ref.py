@@ -26,7 +26,7 @@ def tables():
     return _T
 
 
-def run_case(case, kernel_set="window", native=True):
+def run_case(case, kernel_set="window", native=True, ub_block=1):
     dev = torch.device("cuda")
     T = tables()
     base, drafter = F.make_base(T, dev), F.Drafter(T, dev)
@@ -35,7 +35,7 @@ def run_case(case, kernel_set="window", native=True):
     mdl.kernel_set = kernel_set
     mdl.native_step = native                       # True: the step through ONE lantern_verify_step call; False: a ctypes call per kernel
     mdl.uniform_window = 64                        # small window: the refill path runs too (the host bound is exact since round 5: ~4.5 draws per step)
-    mdl._UB_BLOCK = 1                              # the recorded bonus uniforms arrive one torch.rand call at a time (DetDraws.rand), not in blocks of 4096
+    mdl._UB_BLOCK = ub_block                       # the recorded bonus uniforms arrive ub_block per torch.rand call (DetDraws.rand serves blocks; production: 4096)
     g = lambda k: GOLD[case["name"] + "." + k]
     draws = F.DetDraws(g("bonus_uniforms"))
     random.seed(case["seed"])
@@ -76,6 +76,18 @@ def test_generate_reproduces_the_reference_run(case, kernel_set, native, monkeyp
     for _ in range(int(g("n_accept_uniforms"))):
         random.random()
     assert random.getstate() == st
+
+
+@pytest.mark.parametrize("native", [True, False], ids=["one_call_step", "per_kernel"])
+def test_generate_with_bonus_uniforms_drawn_in_blocks(native):
+    """the production form draws its bonus uniforms in BLOCKS (one torch.rand per _UB_BLOCK steps) -- on every path since round 6
+    (`_bonus_uniform`).  With the recorded uniforms served eight per call, the one-call step and the per-kernel step both reproduce the
+    reference's token stream, i.e. one torch seed gives one image whichever path runs."""
+    for case in F.CASES:
+        mdl, _, draws, ids, alens = run_case(case, "window", native, ub_block=8)
+        g = lambda k: GOLD[case["name"] + "." + k]
+        assert ids[0].cpu().numpy().tolist() == g("ids").tolist() and list(alens) == g("accept_lengths").tolist()
+        assert draws.n >= int(g("n_bonus_draws"))          # whole blocks were taken from the record
 
 
 def test_generate_twice_under_one_seed_is_one_stream():

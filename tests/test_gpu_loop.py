@@ -167,16 +167,14 @@ def test_static_loop_throughput_instances(model, tree):
 def test_raw_row_throughput_instances(form, tp_raw, monkeypatch):
     """Round 5: the throughput forms of the chain kernel on RAW cond / uncond bf16 rows (more sequences per launch than CUs; the row post-process of the
     visited rows inside the kernel): 256 threads x 8 float4 with four 16-byte chunks per operand and thread (the default) and 512 threads at 128 VGPRs
-    (LANTERN_EPW_TP_RAW=512), for the four fixed configurations; every 13th sequence against the oracle's loop.  Each case runs in a fresh process
-    state of the knob (read once per process): the 512 form is reached through a child interpreter."""
-    if tp_raw == "512":
-        import subprocess
-        code = ("import os, sys; sys.path[:0] = [%r, %r, %r]; import test_gpu_loop as T; T._raw_throughput(%r)"
-                % (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "tests", "golden"), form))
-        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, LANTERN_EPW_TP_RAW="512"), capture_output=True, text=True, timeout=900)
-        assert r.returncode == 0, r.stderr[-3000:]
-        return
-    _raw_throughput(form)
+    (lantern_tuning_set("epw_tp_raw", 512): an explicit call, the library reads no environment variable), for the four fixed configurations; every 13th
+    sequence against the oracle's loop."""
+    from lantern_amd import _lib
+    _lib.set_tuning("epw_tp_raw", int(tp_raw))
+    try:
+        _raw_throughput(form)
+    finally:
+        _lib.set_tuning("epw_tp_raw", 256)
 
 
 def _raw_throughput(form):

@@ -118,6 +118,10 @@ def test_bench_gpus_2_starts_its_own_ranks():
     assert line["n_gpus"] == 2 and line["tokens"] == 2 * 4 * 8 * 2 and line["steps"] == 4
     # --dist-backend auto: the RCCL bring-up fails here (no GPU) on every rank, the ranks agree on gloo BEFORE the timed loop, and say so
     assert line["backend"] == "gloo" and line["ranks_seen"] == 2 and "RCCL group not usable" in line["backend_note"]
+    # both scaling forms in the one line: `value` = weak (--seqs-per-gpu on every rank), `c5_strong` = BASELINE's 64 in all
+    c5 = line["c5_strong"]
+    assert line["scaling"] == "weak" and c5["scaling"] == "strong" and c5["total_sequences"] == 64 and c5["sequences_per_rank"] == 32
+    assert c5["ranks_seen"] == 2 and c5["tokens"] == 2 * 4 * 32 * 2 and c5["value"] > 0 and c5["evaluate_posterior_kernel"] == "chain"
     bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2"], env=dict(env, WORLD_SIZE="1"),
                          capture_output=True, text=True, timeout=120)
     assert bad.returncode != 0 and "WORLD_SIZE=1" in bad.stderr
@@ -155,6 +159,24 @@ def test_bench_c5_eight_stub_ranks():
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 8 and line["scaling"] == "strong" and line["sequences_per_rank"] == 8 and line["groups"] == 2
     assert line["tokens"] == 8 * 3 * 8 * 2          # ranks x steps x sequences per rank x the stub's 2 tokens
+    assert "c5_strong" not in line                  # (--total-seqs IS the strong form: no second leg)
+
+
+@pytest.mark.timeout(600)
+def test_bench_eight_stub_ranks_print_both_scaling_forms():
+    """The driver's N = 8 invocation (`bench.py --gpus 8 --steps K --warmup W`, nothing else): `value` is the weak-scaling figure (64 per GPU) and
+    `c5_strong` BASELINE's form (64 in all = 8 per GPU, node-parallel evaluate_posterior, <= 2 stream groups), each from its own timed region."""
+    import subprocess
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "3", "--warmup", "1"],
+                       env=_stub_env(), capture_output=True, text=True, timeout=500)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1 and len(lines[0]) < 4096
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 8 and line["scaling"] == "weak" and line["sequences_per_rank"] == 64 and line["ranks_seen"] == 8
+    c5 = line["c5_strong"]
+    assert c5["scaling"] == "strong" and c5["total_sequences"] == 64 and c5["sequences_per_rank"] == 8 and c5["stream_groups"] == 2
+    assert c5["evaluate_posterior_kernel"] == "nodes" and c5["ranks_seen"] == 8 and c5["tokens"] == 8 * 3 * 8 * 2
 
 
 def _union_worker(rank, world, port, total, q):

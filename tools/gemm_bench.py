@@ -5,6 +5,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import torch.nn.functional as F
 from lantern_amd import ops
+from lantern_amd import _lib as _L
+_KNOBS = _L.tuning_from_env()          # LANTERN_<NAME>=<int> of this tool's environment -> explicit lantern_tuning_set calls
 
 rows = [int(x) for x in (sys.argv[1] if len(sys.argv) > 1 else "1200,4096").split(",")]
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 10

@@ -6,6 +6,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from lantern_amd import harness as HN
 from lantern_amd._lib import check
+from lantern_amd import _lib as _L
+_KNOBS = _L.tuning_from_env()          # LANTERN_<NAME>=<int> of this tool's environment -> explicit lantern_tuning_set calls
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 50
 cases = [tuple(int(x) for x in c.split(":")) for c in (sys.argv[2] if len(sys.argv) > 2 else "1:4096,4:4096,21:4096,63:4096").split(",")]

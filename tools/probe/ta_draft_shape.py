@@ -5,6 +5,8 @@ import json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from lantern_amd import ops
+from lantern_amd import _lib as _L
+_KNOBS = _L.tuning_from_env()          # LANTERN_<NAME>=<int> of this tool's environment -> explicit lantern_tuning_set calls
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 10
 S = int(sys.argv[2]) if len(sys.argv) > 2 else 1210
 B, Hq, d, R = 2, 32, 128, 8

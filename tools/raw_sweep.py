@@ -13,6 +13,8 @@ import torch
 
 import bench
 from lantern_amd import harness as HN
+from lantern_amd import _lib as _L
+_KNOBS = _L.tuning_from_env()          # LANTERN_<NAME>=<int> of this tool's environment -> explicit lantern_tuning_set calls
 
 batches = [int(x) for x in (sys.argv[1] if len(sys.argv) > 1 else "512,2048").split(",") if x]
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 12

@@ -6,7 +6,7 @@ export LANTERN_STEP_TURNS=0
 timeout -k 10 600 python3 -m pytest tests/test_gpu_parity.py tests/test_gpu_loop.py tests/test_gpu_fullsize_properties.py -m gpu -x -q > $O/tests.log 2>&1 || { tail -20 $O/tests.log; exit 1; }
 tail -2 $O/tests.log
 for ks in 0 1 2 4 8 0 4; do
-  LANTERN_KV_KS=$ks timeout -k 10 400 python3 bench.py --gpus 1 --steps 200 --warmup 20 --cpu-seconds 0 --ep-sweep "" --no-extras > $O/ks$ks.json 2> $O/ks$ks.err || { tail -5 $O/ks$ks.err; continue; }
+  timeout -k 10 400 python3 bench.py --tuning kv_ks=$ks --gpus 1 --steps 200 --warmup 20 --cpu-seconds 0 --ep-sweep "" --no-extras > $O/ks$ks.json 2> $O/ks$ks.err || { tail -5 $O/ks$ks.err; continue; }
   python3 - <<PY
 import json
 d=json.loads(open("$O/ks$ks.json").read().strip().splitlines()[-1])

@@ -3,7 +3,7 @@ cd $GRAFT_REPO_ROOT
 OUT=gpurun_out/${1:-r2kv}
 mkdir -p $OUT
 for v in 0 10 40 21 22 23 43; do
-  LANTERN_KV_VARIANT=$v timeout -k 10 300 python bench.py --steps 100 --warmup 10 --cpu-seconds 0 --ep-sweep "" --no-extras > $OUT/b_v$v.json 2> $OUT/b_v$v.err || tail -3 $OUT/b_v$v.err
+  timeout -k 10 300 python bench.py --tuning kv_variant=$v --steps 100 --warmup 10 --cpu-seconds 0 --ep-sweep "" --no-extras > $OUT/b_v$v.json 2> $OUT/b_v$v.err || tail -3 $OUT/b_v$v.err
 done
 python - <<PY
 import json,glob

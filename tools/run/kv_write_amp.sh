@@ -5,7 +5,7 @@ O=gpurun_out/kvamp
 mkdir -p $O
 for v in 20 22 21; do
   for c in WRITE_SIZE FETCH_SIZE; do
-    LANTERN_KV_VARIANT=$v timeout -k 10 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/v${v}_$c -o p -- python3 bench.py --gpus 1 --steps 20 --warmup 5 --cpu-seconds 0 --ep-sweep "" --no-extras > $O/v${v}_$c.json 2> $O/v${v}_$c.err || { tail -5 $O/v${v}_$c.err; exit 1; }
+    timeout -k 10 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/v${v}_$c -o p -- python3 bench.py --tuning kv_variant=$v --gpus 1 --steps 20 --warmup 5 --cpu-seconds 0 --ep-sweep "" --no-extras > $O/v${v}_$c.json 2> $O/v${v}_$c.err || { tail -5 $O/v${v}_$c.err; exit 1; }
     echo "variant $v $c"; python3 tools/pmc_sum.py $O/v${v}_$c update_inputs_kernel
   done
   python3 - <<PY

@@ -3,7 +3,7 @@ cd $GRAFT_REPO_ROOT
 O=gpurun_out/kvu
 mkdir -p $O
 for u in 1 2 4; do
-  LANTERN_KV_U=$u timeout -k 10 300 python3 bench.py --steps 200 --warmup 20 --cpu-seconds 0 --ep-sweep "" --no-extras > $O/b_$u.json 2> $O/b_$u.err || tail -3 $O/b_$u.err
+  timeout -k 10 300 python3 bench.py --tuning kv_u=$u --steps 200 --warmup 20 --cpu-seconds 0 --ep-sweep "" --no-extras > $O/b_$u.json 2> $O/b_$u.err || tail -3 $O/b_$u.err
   python3 - <<PY
 import json
 d=json.loads(open("$O/b_$u.json").read().strip().splitlines()[-1])

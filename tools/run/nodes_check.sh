@@ -10,6 +10,8 @@ import sys, json, os, torch
 sys.path.insert(0, ".")
 import bench
 from lantern_amd import harness as HN
+from lantern_amd import _lib
+_lib.tuning_from_env()
 dev = torch.device("cuda")
 base = HN.WorkloadConfig(n_seq=63, n_groups=3)
 r = bench.step_latency(dev, base, (1, 8), 200)

@@ -3,7 +3,7 @@ cd $GRAFT_REPO_ROOT
 OUT=gpurun_out/${1:-r2pn}
 mkdir -p $OUT
 for nt in 512 1024; do for rep in a b; do
-  LANTERN_PREP_NT=$nt timeout -k 10 300 python bench.py --steps 100 --warmup 10 --cpu-seconds 5 --ep-sweep "" --no-extras > $OUT/b_${nt}_$rep.json 2> $OUT/b_${nt}_$rep.err || tail -3 $OUT/b_${nt}_$rep.err
+  timeout -k 10 300 python bench.py --tuning prep_nt=$nt --steps 100 --warmup 10 --cpu-seconds 5 --ep-sweep "" --no-extras > $OUT/b_${nt}_$rep.json 2> $OUT/b_${nt}_$rep.err || tail -3 $OUT/b_${nt}_$rep.err
 done; done
 python - <<PY
 import json,glob

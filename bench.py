@@ -1360,6 +1360,26 @@ def main():
             out["lambda_mode"] = {"lantern_delta": 5.0, "value": tl / dl, "unit": "accepted_tokens/s", "ms_per_step": 1e3 * dl / KL, "steps": KL,
                                   "mean_accept_length": tl / (KL * cfg.n_seq), "note": "rank 0's sequences only"}
             wl.set_lantern_delta(args.lantern_delta)
+            if cfg.fuse_o7 and cfg.spec_rows > 0 and cfg.with_kv and wl._steps:
+                # the round-5 headline form, kept as a HARNESS-ONLY extra on the same workload and streams: step s + 1's prepare stage inside step s's
+                # commit launch -- only possible because the pools hold step s + 1's rows ahead of time; a real decode loop produces them after
+                # commit(s)
+                wl.cfg.merge_prepare = True
+                wl.reset_state()
+                for _ in range(15):
+                    wl.step()
+                wl.join()
+                torch.cuda.synchronize(device)
+                t1 = time.perf_counter()
+                for _ in range(KL):
+                    wl.step()
+                wl.join()
+                torch.cuda.synchronize(device)
+                dm = time.perf_counter() - t1
+                wl.check_status(0, KL + 15)
+                out["merged_prepare_harness_only"] = {"ms_per_step": 1e3 * dm / KL, "value": wl.accepted_tokens(15, 15 + KL) / dm, "steps": KL,
+                                                      "note": "prepare_next: not a form a decode loop can run; never the headline"}
+                wl.cfg.merge_prepare = False
         if (args.ep_sweep or not args.no_extras) and world == 1:
             wl.release_kv()      # the extra runs build their own workloads: give the memory back first
         if not args.no_extras and world == 1 and wl.windowed:
@@ -1367,11 +1387,6 @@ def main():
             out["step_latency_us"] = step_latency(device, cfg)
             out["other_groupings"] = {f"groups_{g}": side_run(device, cfg, max(min(K, 100), 60), n_groups=g, n_seq=args.seqs_per_gpu - args.seqs_per_gpu % g)
                                       for g in (1, 2) if g != cfg.n_groups}
-            if cfg.fuse_o7 and cfg.spec_rows > 0:
-                # the round-5 headline form, kept as a HARNESS-ONLY extra: step s + 1's prepare stage inside step s's commit launch -- only possible
-                # because the pools hold step s + 1's rows ahead of time; a real decode loop produces them after commit(s)
-                out["merged_prepare_harness_only"] = dict(side_run(device, cfg, max(min(K, 100), 60), merge_prepare=True),
-                                                          note="prepare_next: not a form a decode loop can run; never the headline")
         if not args.no_extras and world == 1 and wl.windowed:
             out["dynamic_tree"] = dynamic_run(device, cfg, min(K, 100), n_seq, fuse_o7=True)
             out["dynamic_tree"]["all_rows_by_cfg_mask_topk"] = {k: v for k, v in dynamic_run(device, cfg, min(K, 100), n_seq, fuse_o7=False).items()

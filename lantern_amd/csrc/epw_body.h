@@ -131,6 +131,10 @@ __device__ __forceinline__ int epw_body(const EpwArgs &args, const int b) {
                                                      // candidate -- 0.65 of the first tries -- then costs no row request at all; the latency is another workgroup's problem)
     static_assert(!RAW || (FULLW && (E4 == 4 || E4 == 8)), "raw rows: W = 4 * E4 * NT ids, E4 / 2 sixteen-byte chunks of cond and of uncond per thread");
     constexpr int CH = E4 / 2 > 0 ? E4 / 2 : 1;          // raw rows: 8-id chunks per thread and operand
+    constexpr bool ROTW = (TPO & 8) != 0;            // throughput builds: the wave that runs a sequence's serial section rotates with the sequence (b % NW) instead of
+                                                     // always being wave 0 -- four workgroups share a CU, and their serial sections then sit on different SIMDs
+    constexpr bool ALLW = (TPO & 16) != 0;           // throughput builds: the k-neighbour cumulative-mass scan on ALL waves (EW_PF_K / NT neighbours per lane, one DPP scan per
+                                                     // wave, the waves' totals exchanged through LDS) and the decision computed by every wave -- no serial section at all
     constexpr bool COMPACT = (TPO & 4) != 0;         // the default tree's throughput build on the smallest staged tables (EwSharedCompact, no neighbour
                                                      // bit mask, 2 prefetch slots): 40 KB of LDS, four workgroups per CU
     static_assert(!COMPACT || (SPEC == 2 && !RAW), "the compact tables are sized for the reference's default tree mc_sim_7b_63 on probability rows");
@@ -141,6 +145,8 @@ __device__ __forceinline__ int epw_body(const EpwArgs &args, const int b) {
     const lantern_ep_buffers &buf = args.buf;
     const lantern_ep_window &win = args.win;
     constexpr int NW = NT / 64;
+    static_assert(!ALLW || (IDMODE != 0 && NW <= 8 && EW_PF_K % NT == 0), "the all-wave scan reads the staged gather indices, EW_PF_K / NT per lane");
+    const int ww = ROTW ? (b & (NW - 1)) : 0;          // the serial section's wave
     // one dynamic LDS region (16-byte aligned base): [ g : W f32 | nbmask : W bits | EwShared ]
     extern __shared__ float4 dyn_lds[];
     float *g = reinterpret_cast<float *>(dyn_lds);
@@ -537,8 +543,71 @@ __device__ __forceinline__ int epw_body(const EpwArgs &args, const int b) {
                     q[it] = (FULLW || i4 * 4 < W) ? reinterpret_cast<const float4 *>(qsrc)[i4] : make_float4(0.f, 0.f, 0.f, 0.f);
                 }
             }
-            // ---------------- serial section: wave 0 only
-            if (wave == 0) {
+            int code_u = 0, m_u = 0;          // ALLW: the decision, computed by every wave
+            if constexpr (ALLW) {
+                float px = x_in ? g[x - lo] : (x == out_tok ? out_mass : 0.0f);
+                bool scan = false;
+                if (p_syntax && is_syn) px = 1.0f;
+                else if (p_syntax && !in_img) px = 0.0f;
+                else if (p_lantern) {
+                    if (nb == nullptr) code_u = 3;          // LANTERN_ST_TABLE_OOB
+                    else scan = true;
+                }
+                if (scan) {          // (workgroup-uniform: x and its flags are)
+                    const float tau = prm.delta > 1.0 ? (float)(prm.delta - 1.0) * px : (float)prm.delta;
+                    constexpr int NPL = EW_PF_K / NT;          // consecutive neighbours per lane: wave w holds positions [w * 64 * NPL, (w + 1) * 64 * NPL)
+                    uint32_t wv[(NPL + 1) / 2];
+                    if constexpr (NPL == 4) {
+                        const uint2 a2 = *reinterpret_cast<const uint2 *>(&S.nbaddr[slot][tid * 4]);
+                        wv[0] = a2.x; wv[1] = a2.y;
+                    } else {
+#pragma unroll
+                        for (int c = 0; c < (NPL + 1) / 2; ++c) wv[c] = *reinterpret_cast<const uint32_t *>(&S.nbaddr[slot][tid * NPL + 2 * c]);
+                    }
+                    double v[NPL], loc = 0.0;
+#pragma unroll
+                    for (int c = 0; c < NPL; ++c) {
+                        loc += (double)g[(c & 1) ? (wv[c >> 1] >> 16) : (wv[c >> 1] & 0xffffu)];
+                        v[c] = loc;
+                    }
+                    const double excl = wave_scan_incl_dpp(dpp_mov<0x138>(loc));          // exclusive prefix inside the wave (see the one-wave form below)
+                    double *xs = S.samp_tot + (n_tried & 1) * 16;                        // (the bonus draw's slots: free until the epilogue)
+                    if (lane == 63) xs[wave] = excl + loc;
+                    __syncthreads();
+                    double offs = 0.0;
+                    for (int w = 0; w < wave; ++w) offs += xs[w];                          // (wave-uniform trip count)
+                    const double base = offs + excl;
+                    float mx = NEG_INF;
+#pragma unroll
+                    for (int c = 0; c < NPL; ++c) {
+                        const float cs = (float)(base + v[c]);
+                        mx = (cs <= tau) ? cs : mx;      // cs is non-decreasing in c: the last ok one is the largest
+                    }
+                    mx = wave_max(mx);
+                    if (lane == 0) xs[8 + wave] = (double)mx;
+                    __syncthreads();
+                    float best_cs = NEG_INF;
+#pragma unroll
+                    for (int w = 0; w < NW; ++w) best_cs = fmaxf(best_cs, (float)xs[8 + w]);
+                    if (best_cs > NEG_INF) {
+                        m_u = 1;
+                        px = px + best_cs;
+                    }
+                } else {
+                    __syncthreads();          // every wave has read g before a rejection's zeroing can touch it
+                }
+                if (code_u == 0) {
+                    float qx = 1.0f;
+                    bool skip = false;
+                    if (is_static) {
+                        qx = rdlane(cart_lane, j);
+                        skip = qx <= 0.0f;
+                    }
+                    code_u = skip ? 0 : (((float)r <= px / qx) ? 1 : 2);
+                }
+            }
+            // ---------------- serial section: one wave only (wave 0; ROTW: wave b % NW)
+            if (!ALLW && wave == ww) {
                 EPW_STAMPF(27);
                 float px = x_in ? g[x - lo] : (x == out_tok ? out_mass : 0.0f);
                 int code = 0, mflag = 0;
@@ -639,9 +708,9 @@ __device__ __forceinline__ int epw_body(const EpwArgs &args, const int b) {
                 }
                 EPW_STAMPF(26);
             }
-            __syncthreads();
-            const int code = dec[0];
-            const int m = dec[1];
+            if constexpr (!ALLW) __syncthreads();
+            const int code = ALLW ? code_u : dec[0];
+            const int m = ALLW ? m_u : dec[1];
             EPW_STAMP(21);
             if (code == 3) {
                 status = LANTERN_ST_TABLE_OOB;

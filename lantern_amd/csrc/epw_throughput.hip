@@ -9,7 +9,8 @@
 namespace lantern {
 
 bool epw_launch_throughput(int kind, const EpwLaunch &l, const EpwArgs &args) {
-    const bool compact = tuning(TUNE_EPW_TP4) != 0;          // lantern_tuning_set("epw_tp4", 0) = the three-per-CU form
+    const int tp4 = tuning(TUNE_EPW_TP4);          // lantern_tuning_set("epw_tp4", ..): 0 = the three-per-CU form; 1 = compact, four per CU; 2 = + the serial wave rotates with the
+    const bool compact = tp4 != 0;                 // sequence; 3 = + the neighbour scan on all waves (measurement variants of round 6)
     const bool raw512 = tuning(TUNE_EPW_TP_RAW) == 512;
 #define TP(...) LANTERN_LAUNCH((epw_kernel<__VA_ARGS__>), l.grid, dim3(NTX), l.lds, l.st, args)
     switch (kind) {
@@ -17,7 +18,9 @@ bool epw_launch_throughput(int kind, const EpwLaunch &l, const EpwArgs &args) {
         if (compact) {          // the default tree on the smallest staged tables: 40 KB of LDS, 128 VGPRs -- FOUR workgroups per CU
             constexpr int NTX = 256;
             const size_t lds4 = epw_shared_offset(8192, false) + sizeof(EwSharedCompact) + (size_t)6 * epw_pd_cap(15, 6) * 4;
-            LANTERN_LAUNCH((epw_kernel<256, 8, 2, 4, true, false, 2, 5>), l.grid, dim3(NTX), lds4, l.st, args);
+            if (tp4 == 2) LANTERN_LAUNCH((epw_kernel<256, 8, 2, 4, true, false, 2, 5 + 8>), l.grid, dim3(NTX), lds4, l.st, args);
+            else if (tp4 == 3) LANTERN_LAUNCH((epw_kernel<256, 8, 2, 4, true, false, 2, 5 + 16>), l.grid, dim3(NTX), lds4, l.st, args);
+            else LANTERN_LAUNCH((epw_kernel<256, 8, 2, 4, true, false, 2, 5>), l.grid, dim3(NTX), lds4, l.st, args);
         } else { constexpr int NTX = 256; TP(256, 8, 2, 3, true, false, 2, 1); }
         return true;
     case EPW_TP_LUMINA_STATIC:

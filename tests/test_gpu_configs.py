@@ -174,6 +174,18 @@ SIX_WIDE_26 = [[0], [1], [2], [3], [4], [5], [0, 0], [0, 1], [0, 2], [0, 3], [1,
                [1, 0, 0], [0, 0, 0, 0], [0, 0, 0, 1], [1, 0, 0, 0], [0, 0, 0, 0, 0], [0, 0, 0, 0, 1], [1, 0, 0, 0, 0]]
 
 
+@pytest.mark.parametrize("tp4", [0, 2, 3])
+def test_throughput_instance_variants_of_the_default_tree(tp4):
+    """The compact instance's measurement variants (lantern_tuning_set("epw_tp4", ..): 0 = round 4's three-per-CU form, 2 = the serial wave rotates with
+    the sequence, 3 = the neighbour scan on all waves) hold the same oracle comparison as the default (1)."""
+    from lantern_amd import _lib
+    _lib.set_tuning("epw_tp4", tp4)
+    try:
+        test_window_two_workgroups_per_cu_build("mc_sim_7b_63", 33)
+    finally:
+        _lib.set_tuning("epw_tp4", 1)
+
+
 @pytest.mark.parametrize("tree_name,REP", [("mc_sim_7b_63", 33), ("six_wide", 33), ("six_wide", 2)])
 def test_window_two_workgroups_per_cu_build(tree_name, REP):
     """Above 256 sequences per launch the throughput build of the windowed kernel runs (two workgroups per CU): 264 sequences

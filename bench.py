@@ -100,6 +100,8 @@ def parse():
     ap.add_argument("--graph", action="store_true", help="replay one captured hipGraph per (pool slot, group) instead of launching eagerly")
     ap.add_argument("--side-stream", action="store_true", help="launch O6 beside O7 and O10 beside O9 on a second HIP stream (measured slower: event waits)")
     ap.add_argument("--groups", type=int, default=4, help="split the GPU's sequences into this many groups, each on its own HIP stream (independent sequences: one group's latency-bound evaluate_posterior overlaps the others' bandwidth-bound kernels)")
+    ap.add_argument("--commit-window", type=int, default=0, help="commit turn-taking between the stream groups (lantern_step_group.turn): at most this many groups move their KV rows at the "
+                    "same time, ordered by in-kernel tickets instead of cross-stream events; 0 = the groups run free and fall into lock-step")
     ap.add_argument("--no-extras", action="store_true", help="skip the extra runs after the timed region (lambda mode, B=1 / B=8 step latency, two stream groups)")
     ap.add_argument("--ep-sweep", type=str, default="1,8,64,256,512,4096",
                     help="e.g. 256,2048: batch sizes for the evaluate_posterior-only roofline sweep (BASELINE.md section 2: the 60 %% target is "
@@ -1250,7 +1252,7 @@ def main():
                 print(f"bench.py: {free / 2**30:.0f} GiB free: running {n_seq} sequences per rank in {args.groups} stream groups", file=sys.stderr)
     cfg = HN.WorkloadConfig(n_seq=n_seq, pool_steps=args.pool_steps, tree=args.tree, lantern_k=args.lantern_k,
                             lantern_delta=args.lantern_delta, sigma=args.sigma, with_kv=not args.no_kv, kv_smax=args.kv_smax,
-                            path=args.path, ep_kernel=args.ep, fuse_o7=args.fuse_o7, spec_rows=args.spec_rows, native_step=not args.python_launch, use_graph=args.graph, n_groups=args.groups, side_stream=args.side_stream,
+                            path=args.path, ep_kernel=args.ep, fuse_o7=args.fuse_o7, spec_rows=args.spec_rows, commit_window=args.commit_window, native_step=not args.python_launch, use_graph=args.graph, n_groups=args.groups, side_stream=args.side_stream,
                             max_steps=max(args.pool_steps, args.steps + args.warmup + min(args.steps, 100), 80) + 8,
                             **({} if args.kv_pad_rows is None else {"kv_pad_rows": args.kv_pad_rows}))
     wl = HN.LuminaVerifyWorkload(cfg, device, rank=rank)

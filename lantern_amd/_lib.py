@@ -45,7 +45,8 @@ class EpWindow(C.Structure):
                 ("u_bonus", C.c_void_p), ("token", C.c_void_p), ("rows_kind", C.c_int32), ("raw_pos_per_seq", C.c_int32),
                 ("raw_uncond", C.c_void_p), ("raw_pos_ids", C.c_void_p), ("raw_seq_len", C.c_void_p), ("raw_pos_base", C.c_int64),
                 ("raw_cfg", C.c_float), ("raw_top_k", C.c_int32), ("raw_w_latent", C.c_int32), ("raw_h_latent", C.c_int32),
-                ("raw_newline_id", C.c_int32), ("raw_eos_id", C.c_int32), ("raw_probs", C.c_void_p), ("raw_pre", C.c_void_p), ("verdict_host", C.c_void_p)]
+                ("raw_newline_id", C.c_int32), ("raw_eos_id", C.c_int32), ("raw_probs", C.c_void_p), ("raw_pre", C.c_void_p), ("verdict_host", C.c_void_p),
+                ("turn", C.c_void_p), ("turn_wait", C.c_int64)]
 
 
 class EpNodes(C.Structure):
@@ -90,6 +91,7 @@ class StepGroup(C.Structure):
                 + [(n, C.c_int32) for n in ("hid_elem_bytes", "hid_groups", "H", "reserved1")]
                 + [("node_list", C.c_void_p), ("n_list", C.c_int32), ("flags", C.c_int32)]
                 + [("hidden_uncond", C.c_void_p), ("ids_buf", C.c_void_p), ("ids_stride", C.c_int64), ("ids_len", C.c_void_p), ("prepare_next", C.c_void_p)]
+                + [("turn", C.c_void_p), ("turn_group", C.c_int32), ("turn_reserved", C.c_int32), ("turn_wait", C.c_int64), ("turn_epoch", C.c_int64)]
                 + [("dyn", C.POINTER(StepDynamic)), ("greedy", C.POINTER(StepGreedy))])
 
 

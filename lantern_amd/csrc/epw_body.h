@@ -135,6 +135,10 @@ __device__ __forceinline__ int epw_body(const EpwArgs &args, const int b) {
                                                      // always being wave 0 -- four workgroups share a CU, and their serial sections then sit on different SIMDs
     constexpr bool ALLW = (TPO & 16) != 0;           // throughput builds: the k-neighbour cumulative-mass scan on ALL waves (EW_PF_K / NT neighbours per lane, one DPP scan per
                                                      // wave, the waves' totals exchanged through LDS) and the decision computed by every wave -- no serial section at all
+    constexpr bool LDS2P = (TPO & 64) != 0;          // the residual of a rejection goes back to LDS unnormalised and is normalised by a second pass over LDS: no 8-float4
+                                                     // register copy of the window lives across the reduction (the four-per-CU build sits at its 128-VGPR cap)
+    constexpr bool PRIO = (TPO & 128) != 0;          // the serial section runs at raised wave priority (s_setprio): four workgroups share a CU, and a sequence's progress is gated
+                                                     // by its one serial wave while the other workgroups' W-wide passes compete for the same SIMD's issue slots
     constexpr bool COMPACT = (TPO & 4) != 0;         // the default tree's throughput build on the smallest staged tables (EwSharedCompact, no neighbour
                                                      // bit mask, 2 prefetch slots): 40 KB of LDS, four workgroups per CU
     static_assert(!COMPACT || (SPEC == 2 && !RAW), "the compact tables are sized for the reference's default tree mc_sim_7b_63 on probability rows");
@@ -608,6 +612,7 @@ __device__ __forceinline__ int epw_body(const EpwArgs &args, const int b) {
             }
             // ---------------- serial section: one wave only (wave 0; ROTW: wave b % NW)
             if (!ALLW && wave == ww) {
+                if constexpr (PRIO) __builtin_amdgcn_s_setprio(3);
                 EPW_STAMPF(27);
                 float px = x_in ? g[x - lo] : (x == out_tok ? out_mass : 0.0f);
                 int code = 0, mflag = 0;
@@ -706,6 +711,7 @@ __device__ __forceinline__ int epw_body(const EpwArgs &args, const int b) {
                     dec[0] = code;
                     dec[1] = mflag;
                 }
+                if constexpr (PRIO) __builtin_amdgcn_s_setprio(0);
                 EPW_STAMPF(26);
             }
             if constexpr (!ALLW) __syncthreads();
@@ -844,6 +850,17 @@ __device__ __forceinline__ int epw_body(const EpwArgs &args, const int b) {
                 }
                 // max(gtp - q, 0): the residual's LDS reads go out together (one wait, not one per chunk), then a packed subtract with the output
                 // clamp per two elements (window_dev.h sub_clamp0: same bits as subtract + compare + select, a fifth of the instructions)
+                if constexpr (LDS2P) {
+#pragma unroll
+                    for (int it = 0; it < E4; ++it) {
+                        const int i4 = tid + it * NT;
+                        if (FULLW || i4 * 4 < W) {
+                            const float4 gv = sub_clamp0(reinterpret_cast<const float4 *>(g)[i4], q[it]);
+                            reinterpret_cast<float4 *>(g)[i4] = gv;          // (this thread's own slots: no other thread reads them before the normalising pass)
+                            loc += (double)gv.x + (double)gv.y + (double)gv.z + (double)gv.w;
+                        }
+                    }
+                } else {
 #pragma unroll
                 for (int it = 0; it < E4; ++it) {
                     const int i4 = tid + it * NT;
@@ -857,6 +874,7 @@ __device__ __forceinline__ int epw_body(const EpwArgs &args, const int b) {
                         gn[it] = gv;
                         loc += (double)gv.x + (double)gv.y + (double)gv.z + (double)gv.w;
                     }
+                }
                 }
                 // out-of-window mass: the drafter is zero there (precondition): max(out_mass - 0, 0) = out_mass
             }
@@ -874,7 +892,7 @@ __device__ __forceinline__ int epw_body(const EpwArgs &args, const int b) {
             for (int it = 0; it < E4; ++it) {
                 const int i4 = tid + it * NT;
                 if (FULLW || i4 * 4 < W)
-                    reinterpret_cast<float4 *>(g)[i4] = dg(gn[it]);
+                    reinterpret_cast<float4 *>(g)[i4] = dg((LDS2P && is_static) ? reinterpret_cast<const float4 *>(g)[i4] : gn[it]);
             }
             out_mass = out_mass / gs;
             if (tid == 0) g[W + EW_G_OUT] = out_mass;
@@ -1053,6 +1071,17 @@ __device__ __forceinline__ int epw_body(const EpwArgs &args, const int b) {
             vh[8] = (int32_t)(tk & 0xffffffffll); vh[9] = (int32_t)(tk >> 32);
             __threadfence_system();
             vh[10] = 1;
+        }
+    }
+    // commit turn-taking (lantern_step_group.turn): everything is written; the workgroup's last act is to wait for its group's turn, so that the commit
+    // launched behind this kernel on the stream starts then.  Bounded (~40 ms): the turn is scheduling, never correctness.
+    if (ka->win.turn) {
+        if (tid == 0) {
+            const long long need = ka->win.turn_wait;
+            for (int spins = 0; spins < 200000; ++spins) {
+                if ((long long)__hip_atomic_load(ka->win.turn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= need) break;
+                __builtin_amdgcn_s_sleep(16);
+            }
         }
     }
     return (best << 8) | a;          // the verdict (uniform): best path, rows kept = accept_len + 1

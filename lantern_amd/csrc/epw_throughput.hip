@@ -9,8 +9,11 @@
 namespace lantern {
 
 bool epw_launch_throughput(int kind, const EpwLaunch &l, const EpwArgs &args) {
-    const int tp4 = tuning(TUNE_EPW_TP4);          // lantern_tuning_set("epw_tp4", ..): 0 = the three-per-CU form; 1 = compact, four per CU; 2 = + the serial wave rotates with the
-    const bool compact = tp4 != 0;                 // sequence; 3 = + the neighbour scan on all waves (measurement variants of round 6)
+    // lantern_tuning_set("epw_tp4", ..): 1 (default, round 6) = compact, four per CU, the serial wave rotates with the sequence, a rejection's residual normalised by a second
+    // pass over LDS (no spills); 2 = round 5's compact form; 3 = the neighbour scan on all waves instead of the rotation; 4 = 1 + raised priority for the serial
+    // section; 0 = round 4's three-per-CU form
+    const int tp4 = tuning(TUNE_EPW_TP4);
+    const bool compact = tp4 != 0;
     const bool raw512 = tuning(TUNE_EPW_TP_RAW) == 512;
 #define TP(...) LANTERN_LAUNCH((epw_kernel<__VA_ARGS__>), l.grid, dim3(NTX), l.lds, l.st, args)
     switch (kind) {
@@ -18,15 +21,16 @@ bool epw_launch_throughput(int kind, const EpwLaunch &l, const EpwArgs &args) {
         if (compact) {          // the default tree on the smallest staged tables: 40 KB of LDS, 128 VGPRs -- FOUR workgroups per CU
             constexpr int NTX = 256;
             const size_t lds4 = epw_shared_offset(8192, false) + sizeof(EwSharedCompact) + (size_t)6 * epw_pd_cap(15, 6) * 4;
-            if (tp4 == 2) LANTERN_LAUNCH((epw_kernel<256, 8, 2, 4, true, false, 2, 5 + 8>), l.grid, dim3(NTX), lds4, l.st, args);
-            else if (tp4 == 3) LANTERN_LAUNCH((epw_kernel<256, 8, 2, 4, true, false, 2, 5 + 16>), l.grid, dim3(NTX), lds4, l.st, args);
-            else LANTERN_LAUNCH((epw_kernel<256, 8, 2, 4, true, false, 2, 5>), l.grid, dim3(NTX), lds4, l.st, args);
-        } else { constexpr int NTX = 256; TP(256, 8, 2, 3, true, false, 2, 1); }
+            if (tp4 == 2) LANTERN_LAUNCH((epw_kernel<256, 8, 2, 4, true, false, 2, 5>), l.grid, dim3(NTX), lds4, l.st, args);
+            else if (tp4 == 3) LANTERN_LAUNCH((epw_kernel<256, 8, 2, 4, true, false, 2, 5 + 16 + 64>), l.grid, dim3(NTX), lds4, l.st, args);
+            else if (tp4 == 4) LANTERN_LAUNCH((epw_kernel<256, 8, 2, 4, true, false, 2, 5 + 8 + 64 + 128>), l.grid, dim3(NTX), lds4, l.st, args);
+            else LANTERN_LAUNCH((epw_kernel<256, 8, 2, 4, true, false, 2, 5 + 8 + 64>), l.grid, dim3(NTX), lds4, l.st, args);
+        } else { constexpr int NTX = 256; TP(256, 8, 2, 3, true, false, 2, 1 + 8); }
         return true;
     case EPW_TP_LUMINA_STATIC:
-        { constexpr int NTX = 256; TP(256, 8, 2, 3, true, false, 1, 1); return true; }
-    case EPW_TP_LUMINA_DYNAMIC: { constexpr int NTX = 256; TP(256, 8, 2, 3, true, false, 3, 1); return true; }
-    case EPW_TP_ANOLE_STATIC: { constexpr int NTX = 256; TP(256, 8, 2, 3, true, false, 4, 1); return true; }
+        { constexpr int NTX = 256; TP(256, 8, 2, 3, true, false, 1, 1 + 8); return true; }
+    case EPW_TP_LUMINA_DYNAMIC: { constexpr int NTX = 256; TP(256, 8, 2, 3, true, false, 3, 1 + 8); return true; }
+    case EPW_TP_ANOLE_STATIC: { constexpr int NTX = 256; TP(256, 8, 2, 3, true, false, 4, 1 + 8); return true; }
     case EPW_TP_512_DEFAULT_TREE: { constexpr int NTX = 512; TP(512, 4, 2, 4, true, false, 2); return true; }
     case EPW_TP_512_PACKED: { constexpr int NTX = 512; TP(512, 4, 2, 4, true); return true; }
     case EPW_TP_512_ID0: { constexpr int NTX = 512; TP(512, 4, 0, 4); return true; }
@@ -36,10 +40,10 @@ bool epw_launch_throughput(int kind, const EpwLaunch &l, const EpwArgs &args) {
     // raw rows carry the row post-process's 18 KB of histograms: 71 KB of LDS per workgroup = two per CU whatever the thread count.  256 threads x 8
     // float4 at two waves per SIMD (no register cap to spill against, half the waves -- half the repeated scalar work -- per sequence), or
     // (lantern_tuning_set("epw_tp_raw", 512)) 512 threads at 128 VGPRs
-    case EPW_TP_RAW_LUMINA_DEFAULT_TREE: if (raw512) { constexpr int NTX = 512; TP(512, 4, 2, 4, true, true, 2, 1); } else { constexpr int NTX = 256; TP(256, 8, 2, 2, true, true, 2, 1); } return true;
-    case EPW_TP_RAW_LUMINA_STATIC: if (raw512) { constexpr int NTX = 512; TP(512, 4, 2, 4, true, true, 1, 1); } else { constexpr int NTX = 256; TP(256, 8, 2, 2, true, true, 1, 1); } return true;
-    case EPW_TP_RAW_LUMINA_DYNAMIC: if (raw512) { constexpr int NTX = 512; TP(512, 4, 2, 4, true, true, 3, 1); } else { constexpr int NTX = 256; TP(256, 8, 2, 2, true, true, 3, 1); } return true;
-    case EPW_TP_RAW_ANOLE_STATIC: if (raw512) { constexpr int NTX = 512; TP(512, 4, 2, 4, true, true, 4, 1); } else { constexpr int NTX = 256; TP(256, 8, 2, 2, true, true, 4, 1); } return true;
+    case EPW_TP_RAW_LUMINA_DEFAULT_TREE: if (raw512) { constexpr int NTX = 512; TP(512, 4, 2, 4, true, true, 2, 1); } else { constexpr int NTX = 256; TP(256, 8, 2, 2, true, true, 2, 1 + 8); } return true;
+    case EPW_TP_RAW_LUMINA_STATIC: if (raw512) { constexpr int NTX = 512; TP(512, 4, 2, 4, true, true, 1, 1); } else { constexpr int NTX = 256; TP(256, 8, 2, 2, true, true, 1, 1 + 8); } return true;
+    case EPW_TP_RAW_LUMINA_DYNAMIC: if (raw512) { constexpr int NTX = 512; TP(512, 4, 2, 4, true, true, 3, 1); } else { constexpr int NTX = 256; TP(256, 8, 2, 2, true, true, 3, 1 + 8); } return true;
+    case EPW_TP_RAW_ANOLE_STATIC: if (raw512) { constexpr int NTX = 512; TP(512, 4, 2, 4, true, true, 4, 1); } else { constexpr int NTX = 256; TP(256, 8, 2, 2, true, true, 4, 1 + 8); } return true;
     default: return false;
     }
 #undef TP

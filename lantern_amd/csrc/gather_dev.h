@@ -184,12 +184,34 @@ struct CommitExtras {
     int64_t ids_stride;
     const int64_t *ids_len;          // [B] tokens already in ids_buf
     const int64_t *bonus;            // [B] or NULL
+    // commit turn-taking (lantern_step_group.turn): word 0 = commits completed, word 1 + group = this group's finished workgroups; the workgroup that
+    // brings the latter to done_target was the launch's last one and releases the turn
+    unsigned long long *turn = nullptr;
+    int turn_group = 0;
+    unsigned long long turn_done_target = 0;
 };
+
+// host side of the same (lantern_step_group.turn / turn_group / turn_epoch)
+struct TurnArgs {
+    int64_t *turn;
+    int group;
+    long long epoch;
+};
+
+// last statement of every commit kernel's workgroup
+__device__ __forceinline__ void commit_release(const CommitExtras &ex) {
+    if (!ex.turn) return;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned long long old = atomicAdd(ex.turn + 1 + ex.turn_group, 1ull);
+        if (old + 1 == ex.turn_done_target) atomicAdd(ex.turn, 1ull);
+    }
+}
 
 __device__ __forceinline__ void accept_copy_row(int bx, int b, int bst, int n_sel, const uint4 *__restrict__ hidden, int G, int N, int cpr,
                                                 const int64_t *__restrict__ retrieve, int retrieve_per_seq, int P, int D,
                                                 const int64_t *__restrict__ cand, uint4 *__restrict__ out_hidden,
-                                                int64_t *__restrict__ accepted_tokens, const CommitExtras ex = CommitExtras{nullptr, nullptr, 0, nullptr, nullptr}) {
+                                                int64_t *__restrict__ accepted_tokens, const CommitExtras ex = CommitExtras{}) {
     const int gi = bx / D, t = bx % D, tid = threadIdx.x;
     if (bx == 0 && accepted_tokens && cand && tid < D)
         accepted_tokens[(size_t)b * D + tid] = tid < n_sel ? cand[(size_t)b * P * D + (size_t)bst * D + tid] : -1;
@@ -219,7 +241,7 @@ __device__ __forceinline__ void accept_copy_body(int bx, int b, const uint4 *__r
                                                  const int64_t *__restrict__ cand, const int32_t *__restrict__ best,
                                                  const int32_t *__restrict__ accept_len, uint4 *__restrict__ out_hidden,
                                                  int64_t *__restrict__ accepted_tokens, const int32_t *__restrict__ counters = nullptr,
-                                                 const CommitExtras ex = CommitExtras{nullptr, nullptr, 0, nullptr, nullptr}) {
+                                                 const CommitExtras ex = CommitExtras{}) {
     int n_sel = accept_len[b] + 1;
     if (n_sel > D) n_sel = D;
     if (counters && counters[(size_t)b * 6 + 5] != 0) n_sel = 0;

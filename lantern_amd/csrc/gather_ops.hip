@@ -111,6 +111,7 @@ __global__ __launch_bounds__(256) void update_inputs_kernel(void *const *__restr
             accept_copy_body(lin % per_seq, lin / per_seq, hidden, G, N, hid_cpr, retrieve, retrieve_per_seq, P, D, cand, best, accept_len,
                              out_hidden, accepted_tokens, counters, ex);
     }
+    commit_release(ex);
 }
 
 // the same with KS slabs per workgroup (kv_gather_slabs): blockIdx.x < ceil(n_slabs / KS) moves KV rows, the workgroups above carry the hidden copy
@@ -135,6 +136,7 @@ __global__ __launch_bounds__(256) void update_inputs_slabs_kernel(void *const *_
             accept_copy_body(lin % per_seq, lin / per_seq, hidden, G, N, hid_cpr, retrieve, retrieve_per_seq, P, D, cand, best, accept_len,
                              out_hidden, accepted_tokens, counters, ex);
     }
+    commit_release(ex);
 }
 
 constexpr int AG_THREADS = 1024;
@@ -292,6 +294,7 @@ __global__ __launch_bounds__(256) void update_inputs_prep_kernel(void *const *__
             accept_copy_body(lin % per_seq, lin / per_seq, hidden, G, N, hid_cpr, retrieve, retrieve_per_seq, P, D, cand, best, accept_len,
                              out_hidden, accepted_tokens, counters, ex);
     }
+    commit_release(ex);
 }
 
 template <int MAXSEL, int KS, bool NUCLEUS>
@@ -318,6 +321,7 @@ __global__ __launch_bounds__(256) void update_inputs_slabs_prep_kernel(void *con
             accept_copy_body(lin % per_seq, lin / per_seq, hidden, G, N, hid_cpr, retrieve, retrieve_per_seq, P, D, cand, best, accept_len,
                              out_hidden, accepted_tokens, counters, ex);
     }
+    commit_release(ex);
 }
 
 // ------------------------------------------------------------------------- O5
@@ -467,7 +471,7 @@ int launch_update_inference_inputs(void *const *slab_ptrs, const int32_t *slab_s
                                    const int32_t *accept_len, int64_t *new_len, const void *hidden, int hid_elem_bytes, int B, int G, int N, int H,
                                    const int64_t *cand, void *out_hidden, int64_t *accepted_tokens, const int32_t *counters, void *stream,
                                    const void *hidden_g1 = nullptr, int64_t *ids_buf = nullptr, int64_t ids_stride = 0, const int64_t *ids_len = nullptr,
-                                   const int64_t *bonus = nullptr, const PrepArgs *prep = nullptr);
+                                   const int64_t *bonus = nullptr, const PrepArgs *prep = nullptr, const TurnArgs *turn = nullptr);
 }
 
 extern "C" int lantern_update_inference_inputs(void *const *slab_ptrs, const int32_t *slab_seq, const int64_t *slab_prev, int n_slabs,
@@ -484,11 +488,20 @@ int lantern::launch_update_inference_inputs(void *const *slab_ptrs, const int32_
                                             const int32_t *best, const int32_t *accept_len, int64_t *new_len, const void *hidden, int hid_elem_bytes, int B,
                                             int G, int N, int H, const int64_t *cand, void *out_hidden, int64_t *accepted_tokens, const int32_t *counters,
                                             void *stream, const void *hidden_g1, int64_t *ids_buf, int64_t ids_stride, const int64_t *ids_len,
-                                            const int64_t *bonus, const PrepArgs *prep) {
+                                            const int64_t *bonus, const PrepArgs *prep, const TurnArgs *turn) {
     LANTERN_CHECK_ARG(slab_ptrs && slab_seq && slab_prev && retrieve && best && accept_len, "update_inference_inputs: null buffer");
     if (hidden_g1) LANTERN_CHECK_ARG(hidden && G == 2, "update_inference_inputs: hidden_uncond needs the conditional rows in `hidden` and hid_groups == 2");
     if (ids_buf) LANTERN_CHECK_ARG(ids_len && cand && ids_stride > 0, "update_inference_inputs: ids_buf needs ids_len, the candidates and ids_stride > 0");
-    const CommitExtras ex{(const uint4 *)hidden_g1, ids_buf, ids_stride, ids_len, bonus};
+    CommitExtras ex{(const uint4 *)hidden_g1, ids_buf, ids_stride, ids_len, bonus};
+    // commit turn-taking: the launch's last workgroup releases the turn (the grid size of whichever form is launched below gives the target)
+    auto arm_turn = [&](long long n_workgroups) {
+        if (turn && turn->turn) {
+            ex.turn = (unsigned long long *)turn->turn;
+            ex.turn_group = turn->group;
+            ex.turn_done_target = (unsigned long long)(turn->epoch + 1) * (unsigned long long)n_workgroups;
+        }
+    };
+    if (turn && turn->turn) LANTERN_CHECK_ARG(turn->group >= 0 && turn->epoch >= 0, "update_inference_inputs: turn_group / turn_epoch must not be negative");
     LANTERN_CHECK_ARG(n_slabs > 0 && outer > 0 && S_max > 0 && d > 0 && P > 0 && D > 0 && B > 0, "update_inference_inputs: bad sizes");
     LANTERN_CHECK_ARG((d * elem_bytes) % 16 == 0, "update_inference_inputs: KV row bytes %lld must be a multiple of 16", (long long)(d * elem_bytes));
     LANTERN_CHECK_ARG(D <= 8, "update_inference_inputs: D=%d > 8 (use lantern_kv_gather + lantern_accept_gather)", D);
@@ -505,6 +518,7 @@ int lantern::launch_update_inference_inputs(void *const *slab_ptrs, const int32_
     if (prep && n_prep > 0 && total <= 4096) {          // small slabs + the next step's preparation
         const int g = hidden ? G : 1;
         const int n_commit_x = (n_slabs + 3) / 4 + B * g * D;
+        arm_turn((long long)n_commit_x + n_prep);
 #define UISP_LAUNCH(NUC_)                                                                                                                      \
     LANTERN_LAUNCH((update_inputs_slabs_prep_kernel<8, 4, NUC_>), dim3(n_commit_x + n_prep), dim3(256), 0, (hipStream_t)stream, slab_ptrs, slab_seq, \
                    slab_prev, n_slabs, outer, S_max, cpr, retrieve, retrieve_per_seq, P, D, best, accept_len, new_len, (const uint4 *)hidden, B, g, N, \
@@ -520,6 +534,7 @@ int lantern::launch_update_inference_inputs(void *const *slab_ptrs, const int32_
         if (gx > 4096) gx = 4096;
         const int g = hidden ? G : 1;
         const int extra = (B * g * D + gx - 1) / gx, n_commit_y = n_slabs + extra, prep_y = (n_prep + gx - 1) / gx;
+        arm_turn((long long)gx * (n_commit_y + prep_y));
 #define UIP_LAUNCH(NUC_)                                                                                                                       \
     LANTERN_LAUNCH((update_inputs_prep_kernel<8, 2, NUC_>), dim3(gx, n_commit_y + prep_y), dim3(256), 0, (hipStream_t)stream, slab_ptrs, slab_seq, \
                    slab_prev, n_slabs, outer, S_max, cpr, retrieve, retrieve_per_seq, P, D, best, accept_len, new_len, (const uint4 *)hidden, B, g, N, \
@@ -535,6 +550,7 @@ int lantern::launch_update_inference_inputs(void *const *slab_ptrs, const int32_
         const int g = hidden ? G : 1;
         const int ks = ks_knob >= 8 ? 8 : (ks_knob >= 4 ? 4 : (ks_knob >= 2 ? 2 : 1));
         const int gridx = (n_slabs + ks - 1) / ks + B * g * D;
+        arm_turn(gridx);
 #define UIS_LAUNCH(KS_)                                                                                                                  \
     LANTERN_LAUNCH((update_inputs_slabs_kernel<8, KS_>), dim3(gridx), dim3(256), 0, (hipStream_t)stream, slab_ptrs, slab_seq, slab_prev,  \
                    n_slabs, outer, S_max, cpr, retrieve, retrieve_per_seq, P, D, best, accept_len, new_len, (const uint4 *)hidden, B, g, N, \
@@ -553,6 +569,7 @@ int lantern::launch_update_inference_inputs(void *const *slab_ptrs, const int32_
     if (gx > 4096) gx = 4096;
     const int g = hidden ? G : 1;
     const int extra = (B * g * D + gx - 1) / gx;
+    arm_turn((long long)gx * (n_slabs + extra));
 #define UI_LAUNCH(U_, M_)                                                                                                                \
     LANTERN_LAUNCH((update_inputs_kernel<8, U_, M_>), dim3(gx, n_slabs + extra), dim3(256), 0, (hipStream_t)stream, slab_ptrs, slab_seq, \
                    slab_prev, n_slabs, outer, S_max, cpr, retrieve, retrieve_per_seq, P, D, best, accept_len, new_len,                   \

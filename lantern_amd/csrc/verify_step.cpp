@@ -4,6 +4,7 @@
 // Reference: the body of EaLumina_mGPT.generate's decode loop, models/ea_model_lumina_mgpt.py:936-998 (static trees), and the same loop
 // behind the EAGLE-2 drafter (cnets_lumina_mgpt.py:1337-1420 / cnets_llamagen.py:826-912: per-sequence trees).
 #include "prep_dev.h"
+#include "gather_dev.h"
 #include <cstdio>
 
 namespace lantern {
@@ -14,7 +15,7 @@ int launch_update_inference_inputs(void *const *slab_ptrs, const int32_t *slab_s
                                    const int32_t *accept_len, int64_t *new_len, const void *hidden, int hid_elem_bytes, int B, int G, int N, int H,
                                    const int64_t *cand, void *out_hidden, int64_t *accepted_tokens, const int32_t *counters, void *stream,
                                    const void *hidden_g1 = nullptr, int64_t *ids_buf = nullptr, int64_t ids_stride = 0, const int64_t *ids_len = nullptr,
-                                   const int64_t *bonus = nullptr, const PrepArgs *prep = nullptr);
+                                   const int64_t *bonus = nullptr, const PrepArgs *prep = nullptr, const TurnArgs *turn = nullptr);
 int prepare_step_args(const lantern_step_group *g, PrepArgs *out);
 }
 
@@ -109,6 +110,12 @@ extern "C" int lantern_verify_step(const lantern_step_group *groups, int n_group
             if (rc) return fail(g, "bonus argmax", rc);
             continue;
         }
+        if (s.turn && !s.nodes && s.slab_ptrs) {          // commit turn-taking: the chain kernel ends when it is this group's turn to commit
+            lantern_ep_window w = s.ep_win;
+            w.turn = s.turn;
+            w.turn_wait = s.turn_wait;
+            rc = lantern_evaluate_posterior_window(&s.ep, &s.ep_buf, &w, s.stream);
+        } else
         rc = s.nodes ? lantern_evaluate_posterior_nodes(&s.ep, &s.ep_buf, &s.ep_win, s.nodes, s.stream)
                      : lantern_evaluate_posterior_window(&s.ep, &s.ep_buf, &s.ep_win, s.stream);
         if (rc) return fail(g, "evaluate_posterior", rc);
@@ -116,6 +123,10 @@ extern "C" int lantern_verify_step(const lantern_step_group *groups, int n_group
     for (int g = 0; g < n_groups; ++g) {
         const lantern_step_group &s = groups[g];
         if (!s.slab_ptrs) {
+            if (s.turn) {          // (nothing would ever release the turn)
+                lantern::set_error("commit turn-taking needs the group's commit launch: slab_ptrs is NULL");
+                return fail(g, "update_inference_inputs", LANTERN_E_INVALID);
+            }
             if (s.prepare_next) {          // (the next call would skip its preparation for nothing)
                 lantern::set_error("prepare_next rides in the commit launch: the group needs its KV slabs (slab_ptrs)");
                 return fail(g, "update_inference_inputs", LANTERN_E_INVALID);
@@ -138,13 +149,15 @@ extern "C" int lantern_verify_step(const lantern_step_group *groups, int n_group
             pa.len_cnt = s.ep_buf.counters;
             prep = &pa;
         }
+        const lantern::TurnArgs ta{s.turn, s.turn_group, (long long)s.turn_epoch};
         // (a sequence whose walk reported a status commits nothing: its KV rows and lengths stay as the forward left them, its out_hidden rows are
         // zero-filled and its accepted_tokens are -1 -- the caller retries the step and commits it itself; tests/test_gpu_loop.py pins this gate)
         rc = lantern::launch_update_inference_inputs(s.slab_ptrs, s.slab_seq, s.slab_prev, s.n_slabs, s.elem_bytes, s.outer, s.S_max, s.d,
                                                      s.dyn ? s.dyn->retrieve_pd : s.retrieve, s.dyn ? 1 : 0, s.P, s.D, s.ep_buf.best,
                                                      s.ep_buf.accept_len, s.new_len, s.hidden, s.hid_elem_bytes, s.B, s.hid_groups, s.N, s.H,
                                                      s.cand, s.out_hidden, s.accepted_tokens, s.ep_buf.counters, s.stream, s.hidden_uncond, s.ids_buf,
-                                                     s.ids_stride, s.ids_len, s.ids_buf ? (s.greedy ? s.greedy->token : s.ep_win.token) : nullptr, prep);
+                                                     s.ids_stride, s.ids_len, s.ids_buf ? (s.greedy ? s.greedy->token : s.ep_win.token) : nullptr, prep,
+                                                     s.turn ? &ta : nullptr);
         if (rc) return fail(g, "update_inference_inputs", rc);
     }
     return LANTERN_OK;

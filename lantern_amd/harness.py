@@ -118,6 +118,9 @@ class WorkloadConfig:
                                     # rides in step s's commit launch (lantern_step_group.prepare_next).  Its precondition -- step s + 1's cond / uncond /
                                     # ss_token are FINAL when step s's commit launches -- only holds where those rows come out of a pre-generated pool; in a
                                     # real decode loop they are the outputs of the drafter and target forwards that run AFTER commit(s)
+    commit_window: int = 0          # > 0 (one-call steps, chain kernel, KV slabs, more than one group): commit turn-taking between the stream groups
+                                    # (lantern_step_group.turn) with this many commits in flight at most; 0 = the groups run free (they fall into
+                                    # lock-step: every group commits at the same time)
     n_groups: int = 1               # >1: the sequences are split into groups, each launched on its own HIP stream, so that one
                                     # group's latency-bound evaluate_posterior overlaps the others' bandwidth-bound kernels
                                     # (independent sequences: no ordering between groups exists)
@@ -642,8 +645,17 @@ class LuminaVerifyWorkload:
         # (an image end rewrites the lengths on the host's side of the stream: those steps prepare themselves, as before)
         merge = (c.merge_prepare and c.with_kv and self.n_spec > 0 and step + 1 < c.max_steps and self._len_ub + 2 * self.D < self.tokens_per_image)
         nxt_arr = self._steps[((step + 1) % c.pool_steps, parity ^ 1)] if merge else None
+        turns = c.commit_window > 0 and c.with_kv and self.G > 1 and self.ep_nodes is None
+        if turns and not hasattr(self, "_turn"):
+            self._turn = torch.zeros(1 + self.G, dtype=torch.int64, device=self.device)          # never reset: tickets and epochs only grow
+            self._turn_step = 0
         for g in range(self.G):
             s = arr[g]
+            if turns:          # ticket = (commit launches so far) = turn_step * G + g; at most commit_window commits in flight
+                s.turn, s.turn_group = self._turn.data_ptr(), g
+                s.turn_wait, s.turn_epoch = self._turn_step * self.G + g - (c.commit_window - 1), self._turn_step
+            else:
+                s.turn = None
             s.flags = _lib.STEP_PREPARED if self._prepared_for == step else 0
             if merge:
                 n_ = nxt_arr[g]
@@ -653,6 +665,8 @@ class LuminaVerifyWorkload:
                 s.prepare_next = None
         self._prepared_for = step + 1 if merge else -1
         check(self._L.lantern_verify_step(arr, self.G), "verify_step")
+        if turns:
+            self._turn_step += 1
         if not c.with_kv:
             for g in range(self.G):
                 s0, B = g * self.Bg, self.Bg

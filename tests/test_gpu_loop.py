@@ -546,3 +546,32 @@ def test_verify_step_commits_nothing_where_the_walk_reported_a_status(geom):
         else:
             assert torch.equal(acc[b], tacc[b]) and torch.equal(wl.out_hidden[b], twin.out_hidden[b])
             assert int(wl.log_best[1, b]) == int(twin.log_best[1, b]) and int(wl.log_token[1, b]) == int(twin.log_token[1, b])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("groups,window,spec,geom", [(3, 1, 2, "slab_blocks"), (4, 1, 3, "tiled"), (4, 2, 3, "tiled"), (2, 1, 0, "slab_blocks")])
+def test_commit_turn_taking_changes_the_schedule_not_the_results(groups, window, spec, geom):
+    """lantern_step_group.turn (round 6): the stream groups take turns moving their KV rows -- the chain kernel of a group ends when `turn[0]` says it is
+    the group's turn, its commit launch releases the turn -- without any cross-stream event.  Every step's verdict, the lengths and every KV slab equal
+    the free-running loop's; the counters say every commit launch was counted exactly once (both commit kernel forms: slab blocks and tiles)."""
+    from lantern_amd import harness as HN
+    steps, n_seq = 40, 4 * groups
+    kv = dict(kv_layers=2, kv_heads=4, kv_smax=512) if geom == "slab_blocks" else dict(kv_layers=4, kv_heads=32, kv_smax=512)
+    outs = []
+    for cw in (window, 0):
+        cfg = HN.WorkloadConfig(n_seq=n_seq, pool_steps=4, max_steps=steps + 4, sigma=5.0, n_groups=groups, ep_kernel="chain", fuse_o7=True, spec_rows=spec,
+                                commit_window=cw, **kv)
+        wl = HN.LuminaVerifyWorkload(cfg, torch.device("cuda"))
+        for _ in range(steps):
+            wl.step()
+        wl.join()
+        torch.cuda.synchronize()
+        wl.check_status(0, steps)
+        outs.append((wl.log_best[:steps].clone(), wl.log_alen[:steps].clone(), wl.log_token[:steps].clone(), wl.log_cnt[:steps].clone(),
+                     wl.cond_lens(steps & 1).clone(), torch.stack([s_.clone() for s_ in wl.slabs])))
+        if cw:
+            t = wl._turn.cpu().numpy()
+            assert int(t[0]) == steps * groups, t                        # every commit launch released its turn exactly once
+            assert len(set(int(x) for x in t[1:])) == 1 and int(t[1]) % steps == 0 and int(t[1]) > 0          # the same workgroups per launch for every group
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)

@@ -100,8 +100,9 @@ def parse():
     ap.add_argument("--graph", action="store_true", help="replay one captured hipGraph per (pool slot, group) instead of launching eagerly")
     ap.add_argument("--side-stream", action="store_true", help="launch O6 beside O7 and O10 beside O9 on a second HIP stream (measured slower: event waits)")
     ap.add_argument("--groups", type=int, default=4, help="split the GPU's sequences into this many groups, each on its own HIP stream (independent sequences: one group's latency-bound evaluate_posterior overlaps the others' bandwidth-bound kernels)")
-    ap.add_argument("--commit-window", type=int, default=0, help="commit turn-taking between the stream groups (lantern_step_group.turn): at most this many groups move their KV rows at the "
-                    "same time, ordered by in-kernel tickets instead of cross-stream events; 0 = the groups run free and fall into lock-step")
+    ap.add_argument("--commit-window", type=int, default=-1, help="commit turn-taking between the stream groups (lantern_step_group.turn): at most this many groups move their KV rows at the "
+                    "same time, ordered by in-kernel tickets instead of cross-stream events; 0 = the groups run free and fall into lock-step; -1 (default) = 1 with four "
+                    "stream groups on the chain kernel (68.2 - 68.9 us per step against 71.4 - 72.2 free-running), else 0")
     ap.add_argument("--no-extras", action="store_true", help="skip the extra runs after the timed region (lambda mode, B=1 / B=8 step latency, two stream groups)")
     ap.add_argument("--ep-sweep", type=str, default="1,8,64,256,512,4096",
                     help="e.g. 256,2048: batch sizes for the evaluate_posterior-only roofline sweep (BASELINE.md section 2: the 60 %% target is "
@@ -1250,6 +1251,8 @@ def main():
             n_seq, args.groups, _ = plan_sequences(0, fit, world, args.groups)
             if rank == 0:
                 print(f"bench.py: {free / 2**30:.0f} GiB free: running {n_seq} sequences per rank in {args.groups} stream groups", file=sys.stderr)
+    if args.commit_window < 0:
+        args.commit_window = 1 if (args.groups == 4 and args.ep == "chain" and not args.no_kv and not args.python_launch and not args.graph) else 0
     cfg = HN.WorkloadConfig(n_seq=n_seq, pool_steps=args.pool_steps, tree=args.tree, lantern_k=args.lantern_k,
                             lantern_delta=args.lantern_delta, sigma=args.sigma, with_kv=not args.no_kv, kv_smax=args.kv_smax,
                             path=args.path, ep_kernel=args.ep, fuse_o7=args.fuse_o7, spec_rows=args.spec_rows, commit_window=args.commit_window, native_step=not args.python_launch, use_graph=args.graph, n_groups=args.groups, side_stream=args.side_stream,
@@ -1319,7 +1322,7 @@ def main():
                        "tree_decoding_rows": (("raw bf16 logits post-processed inside evaluate_posterior (LANTERN_ROWS_RAW_BF16), %d most likely rows per sequence "
                                                "up front with the candidate assembly (lantern_prepare_step)" % wl.n_spec) if getattr(wl, "fused_o7", False)
                                               else "every row post-processed by cfg_mask_topk before evaluate_posterior"),
-                       "tuning": tuning_set or None, "stream_groups": cfg.n_groups, "host_waits": "polling (HSA_ENABLE_INTERRUPT=0)" if os.environ.get("HSA_ENABLE_INTERRUPT") == "0" else "interrupts", "side_stream_for_O6_O10": cfg.side_stream, "sequences_per_launch": wl.Bg, "parallelism": f"dp{world} (independent sequences, no collective)"},
+                       "tuning": tuning_set or None, "commit_window": cfg.commit_window, "stream_groups": cfg.n_groups, "host_waits": "polling (HSA_ENABLE_INTERRUPT=0)" if os.environ.get("HSA_ENABLE_INTERRUPT") == "0" else "interrupts", "side_stream_for_O6_O10": cfg.side_stream, "sequences_per_launch": wl.Bg, "parallelism": f"dp{world} (independent sequences, no collective)"},
             "mean_accept_length": float(alen.mean()),
             "per_step": {"levels": float(cnt[..., 0].mean()), "tried": float(cnt[..., 1].mean()), "rejected": float(cnt[..., 2].mean())},
         }

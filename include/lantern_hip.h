@@ -59,7 +59,7 @@ const char *lantern_last_error(void);
 /* Tuning values: kernel-instance / launch-shape choices a MEASUREMENT may override (tools/, a few tests).  The library reads no environment
  * variable; every product path runs the defaults.  Names (defaults): epw_tp (5), epw_tp4 (1), epw_tp_raw (256), epw_spec (2), epw_occ2 (-1),
  * o7_nt (0), prep_nt (0), kv_u (0), kv_ks (4), kv_variant (0), gemm_tiled_from (129), sk_groups (0), sk_whole_mb (40), sk_nt_min_mb (80),
- * ta_splits (0), ta_min_tiles (2), epw_lat (0) -- meanings beside `enum Tuning` in lantern_amd/csrc/common.h.  Process-wide, atomic ints; set before the
+ * ta_splits (0), ta_min_tiles (2) -- meanings beside `enum Tuning` in lantern_amd/csrc/common.h.  Process-wide, atomic ints; set before the
  * launches they should affect.  The reference has no counterpart (it has no kernels to choose between). */
 int lantern_tuning_set(const char *name, int value);
 int lantern_tuning_get(const char *name, int *value);
@@ -454,15 +454,16 @@ typedef struct lantern_step_group {
     /* Commit turn-taking between the stream groups of one caller (optional, NULL = off; round 6).  Groups that run the same step loop side by side on
      * their own streams fall into lock-step: all of them move their KV rows at the same time (one bandwidth-bound phase of ~30 us during which no
      * latency-bound walk runs) instead of one group's commit overlapping the others' walks.  With `turn` set the groups take turns without any
-     * cross-stream event: `turn` [dev] int64 [1 + n_groups], zeroed once by the caller and never reset -- word 0 counts the commits COMPLETED by all
-     * groups, word 1 + turn_group the workgroups of this group's commit launches that have finished (the launch whose last workgroup finishes
-     * increments word 0).  This step's evaluate_posterior (chain kernel) holds its last instructions until turn[0] >= turn_wait -- bounded: after
+     * cross-stream event: `turn` [dev] int64 [LANTERN_TURN_WORDS(turn_groups)], zeroed once by the caller and never reset -- word 0 counts the commits
+     * COMPLETED by all groups; behind it, one 128-byte line per counter, each group's "workgroups of my commit launches that have finished" counters
+     * in two levels (32 first-level lines per group, then one: thousands of workgroups adding to one word serialise at the memory side); the launch
+     * whose last workgroup finishes increments word 0.  This step's evaluate_posterior (chain kernel) holds its last instructions until turn[0] >= turn_wait -- bounded: after
      * ~40 ms it proceeds anyway, turn-taking is scheduling, never correctness -- and the commit launched behind it releases the turn when it is
      * done.  turn_wait: the commits that must have completed before this one starts (ticket - (window - 1) for `window` commits in flight; the
      * harness issues tickets step * n_groups + group); turn_epoch: commit launches this group has made with `turn` set before this one.
      * Independent sequences: any order is correct; the reference runs one sequence per process and has no counterpart. */
     int64_t *turn;
-    int32_t turn_group, turn_reserved;
+    int32_t turn_group, turn_groups;        /* this group's index, and how many groups share `turn` */
     int64_t turn_wait, turn_epoch;
     const lantern_step_dynamic *dyn;      /* NULL: a static tree (ss_token / tree_indices / retrieve), or -- flags & LANTERN_STEP_CANDIDATES_READY, ss_token
                                              NULL -- candidates the caller assembled itself: `cand` [B,P,D] and `retrieve` [P,D] are taken as they are
@@ -470,6 +471,7 @@ typedef struct lantern_step_group {
                                              before the target forward).  A static group with neither is an error, not a silent skip. */
     const lantern_step_greedy *greedy;    /* NULL: relaxed rejection sampling (evaluate_posterior); else the greedy / TVD accept above */
 } lantern_step_group;
+#define LANTERN_TURN_WORDS(n_groups) (16 * (1 + 33 * (n_groups)))   /* int64 words of lantern_step_group.turn */
 #define LANTERN_STEP_CANDIDATES_READY 1   /* lantern_step_group.flags: skip the O6 stage, `cand` / `retrieve` (/ `cart_prob`, `tree_cand`) are final */
 #define LANTERN_STEP_PREPARED 2           /* the previous call's commit launch already ran this group's lantern_prepare_step (prepare_next); only valid on a
                                              static-tree group with a node_list, refused otherwise */

@@ -33,7 +33,6 @@ enum Tuning {
     TUNE_SK_NT_MIN_MB,      // 80: matrices from this many MB are streamed with non-temporal loads
     TUNE_TA_SPLITS,         // 0: key splits of tree attention by launch size (> 0 forces the split count)
     TUNE_TA_MIN_TILES,      // 2: key tiles per wave and split below which no further split is made
-    TUNE_EPW_LAT,           // 0: latency instances of the chain kernel as they are; 1: the neighbour scan on all waves (default-tree instances; measurement variant)
     TUNE_COUNT
 };
 int tuning(int t);

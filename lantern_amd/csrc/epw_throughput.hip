@@ -9,9 +9,10 @@
 namespace lantern {
 
 bool epw_launch_throughput(int kind, const EpwLaunch &l, const EpwArgs &args) {
-    // lantern_tuning_set("epw_tp4", ..): 1 (default, round 6) = compact, four per CU, the serial wave rotates with the sequence, a rejection's residual normalised by a second
-    // pass over LDS (no spills); 2 = round 5's compact form; 3 = the neighbour scan on all waves instead of the rotation; 4 = 1 + raised priority for the serial
-    // section; 0 = round 4's three-per-CU form
+    // lantern_tuning_set("epw_tp4", ..): 1 (default, round 6) = compact, four per CU, the serial wave rotates with the sequence and runs at raised priority, a
+    // rejection's residual is normalised by a second pass over LDS (no spills): 135.9 - 137.8 us per 4096 sequences against round 5's 147.8 - 157.5 on the same
+    // boxes; 2 = round 5's compact form; 3 = the neighbour scan on all waves instead of the rotation (139.5 - 140.1); 4 = 1 without the raised priority
+    // (137.5 - 137.8); 0 = round 4's three-per-CU form (162 - 163)
     const int tp4 = tuning(TUNE_EPW_TP4);
     const bool compact = tp4 != 0;
     const bool raw512 = tuning(TUNE_EPW_TP_RAW) == 512;
@@ -23,8 +24,8 @@ bool epw_launch_throughput(int kind, const EpwLaunch &l, const EpwArgs &args) {
             const size_t lds4 = epw_shared_offset(8192, false) + sizeof(EwSharedCompact) + (size_t)6 * epw_pd_cap(15, 6) * 4;
             if (tp4 == 2) LANTERN_LAUNCH((epw_kernel<256, 8, 2, 4, true, false, 2, 5>), l.grid, dim3(NTX), lds4, l.st, args);
             else if (tp4 == 3) LANTERN_LAUNCH((epw_kernel<256, 8, 2, 4, true, false, 2, 5 + 16 + 64>), l.grid, dim3(NTX), lds4, l.st, args);
-            else if (tp4 == 4) LANTERN_LAUNCH((epw_kernel<256, 8, 2, 4, true, false, 2, 5 + 8 + 64 + 128>), l.grid, dim3(NTX), lds4, l.st, args);
-            else LANTERN_LAUNCH((epw_kernel<256, 8, 2, 4, true, false, 2, 5 + 8 + 64>), l.grid, dim3(NTX), lds4, l.st, args);
+            else if (tp4 == 4) LANTERN_LAUNCH((epw_kernel<256, 8, 2, 4, true, false, 2, 5 + 8 + 64>), l.grid, dim3(NTX), lds4, l.st, args);
+            else LANTERN_LAUNCH((epw_kernel<256, 8, 2, 4, true, false, 2, 5 + 8 + 64 + 128>), l.grid, dim3(NTX), lds4, l.st, args);
         } else { constexpr int NTX = 256; TP(256, 8, 2, 3, true, false, 2, 1 + 8); }
         return true;
     case EPW_TP_LUMINA_STATIC:

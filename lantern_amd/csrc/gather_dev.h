@@ -184,17 +184,21 @@ struct CommitExtras {
     int64_t ids_stride;
     const int64_t *ids_len;          // [B] tokens already in ids_buf
     const int64_t *bonus;            // [B] or NULL
-    // commit turn-taking (lantern_step_group.turn): word 0 = commits completed, word 1 + group = this group's finished workgroups; the workgroup that
-    // brings the latter to done_target was the launch's last one and releases the turn
+    // commit turn-taking (lantern_step_group.turn; layout in include/lantern_hip.h): the launch's last workgroup releases the turn.  "Last" is found
+    // in two levels -- 32 first-level counters per group, one 128-byte line each, then one second-level counter -- because thousands of workgroups
+    // adding to ONE word serialise at the memory side (measured: +150 us per step with a single counter per group)
     unsigned long long *turn = nullptr;
-    int turn_group = 0;
-    unsigned long long turn_done_target = 0;
+    int turn_group = 0, turn_groups = 0;
+    unsigned int turn_nwg = 0;
+    unsigned long long turn_epoch = 0;
 };
+
+constexpr int TURN_LINE = 16, TURN_SLOTS = 32;          // int64 words per 128-byte line; first-level counters per group
 
 // host side of the same (lantern_step_group.turn / turn_group / turn_epoch)
 struct TurnArgs {
     int64_t *turn;
-    int group;
+    int group, groups;
     long long epoch;
 };
 
@@ -203,8 +207,13 @@ __device__ __forceinline__ void commit_release(const CommitExtras &ex) {
     if (!ex.turn) return;
     __syncthreads();
     if (threadIdx.x == 0) {
-        const unsigned long long old = atomicAdd(ex.turn + 1 + ex.turn_group, 1ull);
-        if (old + 1 == ex.turn_done_target) atomicAdd(ex.turn, 1ull);
+        const unsigned lin = blockIdx.y * gridDim.x + blockIdx.x, slot = lin & (TURN_SLOTS - 1);
+        const unsigned long long n_slot = (ex.turn_nwg - slot + TURN_SLOTS - 1) / TURN_SLOTS;          // workgroups of this launch that count in `slot`
+        unsigned long long *c1 = ex.turn + (size_t)TURN_LINE * (1 + ex.turn_groups + ex.turn_group * TURN_SLOTS + slot);
+        if (atomicAdd(c1, 1ull) + 1 == (ex.turn_epoch + 1) * n_slot) {
+            const unsigned long long used = ex.turn_nwg < (unsigned)TURN_SLOTS ? ex.turn_nwg : TURN_SLOTS;
+            if (atomicAdd(ex.turn + (size_t)TURN_LINE * (1 + ex.turn_group), 1ull) + 1 == (ex.turn_epoch + 1) * used) atomicAdd(ex.turn, 1ull);
+        }
     }
 }
 

@@ -514,7 +514,6 @@ extern "C" int lantern_evaluate_posterior_window(const lantern_ep_params *prm, c
     // launch 293 us (generic, 512 threads, two per CU) -> 228 (fixed configuration, 512 threads) -> 194 (owner-wave sibling zeroing) -> 163 us.
     // LANTERN_EPW_TP=0: the generic two-per-CU instance; 1: the 512-thread fixed-configuration instance (diagnostic).
     const int tp_knob = tuning(TUNE_EPW_TP);
-    const int lat_var = tuning(TUNE_EPW_LAT);
     const bool nucleus = p.top_p >= 1e-8f && p.top_p < 1.0f;
     bool ok = true;
     if (raw && nucleus) {          // raw rows with a nucleus filter: the generic raw instances with the filter compiled in
@@ -534,7 +533,6 @@ extern "C" int lantern_evaluate_posterior_window(const lantern_ep_params *prm, c
         else if (tp_raw && lumina_dynamic) ok = epw_launch_throughput(EPW_TP_RAW_LUMINA_DYNAMIC, L, args);
         else if (tp_raw && anole_static) ok = epw_launch_throughput(EPW_TP_RAW_ANOLE_STATIC, L, args);
         else if (many) ok = epw_launch_throughput(EPW_TP_RAW_GENERIC, L, args);
-        else if (lumina_static && default_tree && lat_var == 1) LANTERN_LAUNCH((epw_kernel<512, 4, 2, 1, true, true, 2, 16>), grid, dim3(512), lds, st, args);
         else if (lumina_static && default_tree) LANTERN_LAUNCH((epw_kernel<512, 4, 2, 1, true, true, 2>), grid, dim3(512), lds, st, args);
         else if (lumina_static) LANTERN_LAUNCH((epw_kernel<512, 4, 2, 1, true, true, 1>), grid, dim3(512), lds, st, args);
         else if (lumina_dynamic) LANTERN_LAUNCH((epw_kernel<512, 4, 2, 1, true, true, 3>), grid, dim3(512), lds, st, args);
@@ -552,8 +550,7 @@ extern "C" int lantern_evaluate_posterior_window(const lantern_ep_params *prm, c
         else if (many && W == 8192 && idmode == 2) ok = epw_launch_throughput(EPW_TP_512_PACKED, L, args);
         else if (many) ok = epw_launch_throughput(idmode == 2 ? EPW_TP_512_ID2 : (idmode == 1 ? EPW_TP_512_ID1 : EPW_TP_512_ID0), L, args);
         else if (W == 8192 && idmode == 2) {
-            if (lumina_static && default_tree && lat_var == 1) LANTERN_LAUNCH((epw_kernel<512, 4, 2, 1, true, false, 2, 16>), grid, dim3(512), lds, st, args);
-            else if (lumina_static && default_tree) LANTERN_LAUNCH((epw_kernel<512, 4, 2, 1, true, false, 2>), grid, dim3(512), lds, st, args);
+            if (lumina_static && default_tree) LANTERN_LAUNCH((epw_kernel<512, 4, 2, 1, true, false, 2>), grid, dim3(512), lds, st, args);
             else if (lumina_static) LANTERN_LAUNCH((epw_kernel<512, 4, 2, 1, true, false, 1>), grid, dim3(512), lds, st, args);
             else if (lumina_dynamic) LANTERN_LAUNCH((epw_kernel<512, 4, 2, 1, true, false, 3>), grid, dim3(512), lds, st, args);
             else if (anole_static) LANTERN_LAUNCH((epw_kernel<512, 4, 2, 1, true, false, 4>), grid, dim3(512), lds, st, args);

@@ -647,12 +647,12 @@ class LuminaVerifyWorkload:
         nxt_arr = self._steps[((step + 1) % c.pool_steps, parity ^ 1)] if merge else None
         turns = c.commit_window > 0 and c.with_kv and self.G > 1 and self.ep_nodes is None
         if turns and not hasattr(self, "_turn"):
-            self._turn = torch.zeros(1 + self.G, dtype=torch.int64, device=self.device)          # never reset: tickets and epochs only grow
+            self._turn = torch.zeros(_lib.TURN_WORDS(self.G), dtype=torch.int64, device=self.device)          # never reset: tickets and epochs only grow
             self._turn_step = 0
         for g in range(self.G):
             s = arr[g]
             if turns:          # ticket = (commit launches so far) = turn_step * G + g; at most commit_window commits in flight
-                s.turn, s.turn_group = self._turn.data_ptr(), g
+                s.turn, s.turn_group, s.turn_groups = self._turn.data_ptr(), g, self.G
                 s.turn_wait, s.turn_epoch = self._turn_step * self.G + g - (c.commit_window - 1), self._turn_step
             else:
                 s.turn = None

@@ -133,7 +133,7 @@ def test_step_group_layout_matches_the_c_struct(tmp_path):
     import subprocess
     wfields = ["row_hot", "rows_kind", "raw_uncond", "raw_pos_base", "raw_cfg", "raw_eos_id", "raw_probs", "raw_pre", "verdict_host", "turn", "turn_wait"]
     fields = ["stream", "B", "tree_cand", "cond", "pos_base", "w_latent", "seq_len", "temperature", "ep", "ep_buf", "ep_win", "nodes",
-              "slab_ptrs", "n_slabs", "outer", "hidden", "H", "node_list", "n_list", "flags", "hidden_uncond", "ids_buf", "ids_stride", "ids_len", "prepare_next", "turn", "turn_group", "turn_wait", "turn_epoch", "dyn", "greedy"]
+              "slab_ptrs", "n_slabs", "outer", "hidden", "H", "node_list", "n_list", "flags", "hidden_uncond", "ids_buf", "ids_stride", "ids_len", "prepare_next", "turn", "turn_group", "turn_groups", "turn_wait", "turn_epoch", "dyn", "greedy"]
     src = tmp_path / "layout.c"
     gfields = [f for f, _ in _lib.StepGreedy._fields_]
     src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "lantern_hip.h"\nint main(void){printf("%zu %zu", sizeof(lantern_step_group), sizeof(lantern_ep_nodes));\n'
@@ -242,7 +242,7 @@ def test_tuning_values_are_an_explicit_api_and_the_library_reads_no_environment(
     import subprocess
     names = _lib.tuning_names()
     assert names == ["epw_tp", "epw_tp4", "epw_tp_raw", "epw_spec", "epw_occ2", "o7_nt", "prep_nt", "kv_u", "kv_ks", "kv_variant", "gemm_tiled_from",
-                     "sk_groups", "sk_whole_mb", "sk_nt_min_mb", "ta_splits", "ta_min_tiles", "epw_lat"]
+                     "sk_groups", "sk_whole_mb", "sk_nt_min_mb", "ta_splits", "ta_min_tiles"]
     defaults = {n: _lib.get_tuning(n) for n in names}
     assert (defaults["epw_tp"], defaults["epw_tp4"], defaults["epw_tp_raw"], defaults["epw_spec"], defaults["kv_ks"], defaults["sk_whole_mb"]) == (5, 1, 256, 2, 4, 40)
     _lib.set_tuning("epw_tp_raw", 512)

@@ -177,8 +177,8 @@ SIX_WIDE_26 = [[0], [1], [2], [3], [4], [5], [0, 0], [0, 1], [0, 2], [0, 3], [1,
 @pytest.mark.parametrize("tp4", [0, 2, 3, 4])
 def test_throughput_instance_variants_of_the_default_tree(tp4):
     """The compact instance's measurement variants (lantern_tuning_set("epw_tp4", ..): 0 = round 4's three-per-CU form, 2 = round 5's compact form, 3 = the
-    neighbour scan on all waves, 4 = the default with a raised-priority serial section) hold the same oracle comparison as the default (1: the serial wave
-    rotates with the sequence, the residual is normalised by a second pass over LDS)."""
+    neighbour scan on all waves, 4 = the default without the raised priority of the serial section) hold the same oracle comparison as the default (1: the serial
+    wave rotates with the sequence and runs at raised priority, the residual is normalised by a second pass over LDS)."""
     from lantern_amd import _lib
     _lib.set_tuning("epw_tp4", tp4)
     try:

@@ -106,10 +106,23 @@ kw = dict(cfg_scale=3.0, top_k=2000, lantern=True, lantern_k=1000, lantern_delta
 mdl.generate(prompt, max_new_tokens=60, **kw)          # warm-up: code objects, tree buffers, KV slabs
 torch.cuda.synchronize()
 Clock.i = 0
+prof = None
+if os.environ.get("MIRROR_PROFILE") == "1":          # (tools/mirror_profile.py: cProfile of the timed call only)
+    import cProfile
+    prof = cProfile.Profile()
+    prof.enable()
 t0 = time.perf_counter()
 ids, acc = mdl.generate(prompt, max_new_tokens=steps * 3, **kw)
 torch.cuda.synchronize()
 dt = time.perf_counter() - t0
+if prof is not None:
+    import io
+    import pstats
+    prof.disable()
+    for key in ("tottime", "cumulative"):
+        s_ = io.StringIO()
+        pstats.Stats(prof, stream=s_).strip_dirs().sort_stats(key).print_stats(30)
+        print(s_.getvalue()[:7000], file=sys.stderr)
 n = len(acc)
 print(json.dumps({"workload": f"EaLumina_mGPT.generate, static tree mc_sim_7b_63, V={V}, k=1000, delta=0.1, sequential CFG, {2 * L_KV * 2} KV slabs of the 7B geometry, "
                               "stand-in target / drafter forwards (pool lookups)", "verify_steps": n, "us_per_verify_step": 1e6 * dt / max(n, 1),

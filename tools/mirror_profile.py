@@ -1,20 +1,11 @@
-"""cProfile of tools/mirror_bench.py's timed generate() call: where the host time of the drop-in step goes (top functions by own and cumulative time).
-usage: mirror_profile.py [steps]"""
-import cProfile
-import io
+"""cProfile of the TIMED generate() call of tools/mirror_bench.py (MIRROR_PROFILE=1): where the host time of the drop-in step goes.
+usage: mirror_profile.py [steps]   (the profile goes to stderr, the bench line to stdout; times are inflated by the profiler: read the proportions)"""
 import os
-import pstats
-import runpy
+import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 steps = sys.argv[1] if len(sys.argv) > 1 else "400"
-sys.argv = [os.path.join(ROOT, "tools", "mirror_bench.py"), steps]
-pr = cProfile.Profile()
-pr.enable()
-runpy.run_path(sys.argv[0], run_name="__main__")
-pr.disable()
-for key in ("tottime", "cumulative"):
-    s = io.StringIO()
-    pstats.Stats(pr, stream=s).strip_dirs().sort_stats(key).print_stats(28)
-    print(s.getvalue()[:6000])
+r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "mirror_bench.py"), steps], env=dict(os.environ, MIRROR_PROFILE="1"), capture_output=True, text=True)
+print(r.stdout[-600:])
+print(r.stderr[-14000:])

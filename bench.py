@@ -20,7 +20,7 @@ N > 1 prints BOTH scaling forms in the one line: `value` = weak scaling (--seqs-
 Extra objects on the JSON line:
   roofline      evaluate_posterior of the timed configuration: algorithmic bytes (SURVEY 8d contract formula, from the kernel's own
                 counters) / its mean launch duration (HIP events recorded by the launch itself); peak 8000 GB/s.  `windowed_kernel`: the bytes
-                the windowed design really has to move; `traffic`: PMC bytes from profiles/r05_ep_traffic.json (refused when measured on other kernel
+                the windowed design really has to move; `traffic`: PMC bytes from profiles/r06_ep_traffic.json (refused when measured on other kernel
                 sources); `saturating`: the same kernel alone at the largest batch of the sweep, on rotating inputs.
   kernels       the same for the row post-process launch (prepare_step / cfg_mask_topk) and update_inference_inputs.
   per_kernel_single_group  one stream, every stage its own launch: each kernel against its SURVEY 8d roofline at the full 64-sequence
@@ -410,21 +410,21 @@ def kernel_sources_sha() -> str:
     return h.hexdigest()[:16]
 
 
-TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r05_ep_traffic.json")
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r06_ep_traffic.json")
 
 
 def traffic_entry(section: str, key: str):
-    """(entry, note) of profiles/r05_ep_traffic.json[section][key]; entry None with the reason when the file is missing, lacks the key or was
+    """(entry, note) of profiles/r06_ep_traffic.json[section][key]; entry None with the reason when the file is missing, lacks the key or was
     measured on other kernel sources."""
     if not os.path.exists(TRAFFIC_FILE):
-        return None, "no PMC file (profiles/r05_ep_traffic.json)"
+        return None, "no PMC file (profiles/r06_ep_traffic.json)"
     tj = json.load(open(TRAFFIC_FILE))
     if tj.get("kernel_sources_sha") != kernel_sources_sha():
-        return None, f"profiles/r05_ep_traffic.json was measured on other kernel sources (commit {tj.get('commit')}): refused as stale"
+        return None, f"profiles/r06_ep_traffic.json was measured on other kernel sources (commit {tj.get('commit')}): refused as stale"
     t = tj.get(section, {}).get(key)
     if not t:
-        return None, f"profiles/r05_ep_traffic.json has no {section}/{key}"
-    return t, ("profiles/r05_ep_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH doubled per the gfx950 note), "
+        return None, f"profiles/r06_ep_traffic.json has no {section}/{key}"
+    return t, ("profiles/r06_ep_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH doubled per the gfx950 note), "
                f"measured at commit {tj.get('commit')}, same kernel sources")
 
 
@@ -1390,7 +1390,7 @@ def main():
         if not args.no_extras and world == 1 and wl.windowed:
             out["per_kernel_single_group"] = {k: per_kernel_run(device, cfg, min(K, 60), ep_kernel=k, n_seq=(args.seqs_per_gpu if n_seq + args.groups > args.seqs_per_gpu else n_seq)) for k in ("chain", "nodes")}
             out["step_latency_us"] = step_latency(device, cfg)
-            out["other_groupings"] = {f"groups_{g}": side_run(device, cfg, max(min(K, 100), 60), n_groups=g, n_seq=args.seqs_per_gpu - args.seqs_per_gpu % g)
+            out["other_groupings"] = {f"groups_{g}": side_run(device, cfg, max(min(K, 100), 60), n_groups=g, commit_window=0, n_seq=args.seqs_per_gpu - args.seqs_per_gpu % g)
                                       for g in (1, 2) if g != cfg.n_groups}
         if not args.no_extras and world == 1 and wl.windowed:
             out["dynamic_tree"] = dynamic_run(device, cfg, min(K, 100), n_seq, fuse_o7=True)

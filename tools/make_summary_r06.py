@@ -1,0 +1,50 @@
+"""profiles/r06_summary.md from the round's committed profile files (the driver invocation's full report, rocprofv3 stats, PMC traffic).
+usage: python tools/make_summary_r06.py"""
+import csv, json, os
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+P = lambda n: os.path.join(ROOT, "profiles", n)
+d = json.load(open(P("r06_bench_driver_invocation_20_5.json")))
+t = json.load(open(P("r06_ep_traffic.json")))
+rl = d["roofline"]; sat = rl["saturating"]; cb = d["cpu_baseline"]
+
+
+def ks(fn, n=6):
+    rows = [r for r in csv.DictReader(open(P(fn)))]
+    rows.sort(key=lambda r: -float(r["TotalDurationNs"]))
+    return [(float(r["AverageNs"]) / 1e3, int(r["Calls"]), r["Name"]) for r in rows if ("lantern" in r["Name"] or "streamk" in r["Name"])][:n]
+
+
+o = ["# Round 6 profile summary (one MI355X)\n",
+     "Files named `r06_*` in this directory were produced on the GPU box by `tools/run/r06_profiles.sh` (rocprofv3 stats + PMC passes, kernel sources fingerprint "
+     f"`{t['kernel_sources_sha']}`, commit `{t['commit']}`) and `tools/run/r06_final.sh` (the driver's invocation with the traffic file in place, the two-rank rehearsals); "
+     "`gpurun_out/` is scratch.\n",
+     "## Headline: `python bench.py --gpus 1 --steps 20 --warmup 5` (`r06_bench_driver_invocation_20_5.json` = the full report, `r06_bench_line.json` = the stdout line)\n",
+     f"* value **{d['value'] / 1e6:.3f} M accepted tokens/s**, {1e3 * d['ms_per_step']:.1f} us per verify step of {d['config']['seqs_per_gpu']} sequences in "
+     f"{d['config']['stream_groups']} stream groups, mean accept length {d['mean_accept_length']:.2f}; CPU oracle stream mismatches: {cb['mismatches']}.",
+     f"* `roofline` ({rl['kernel']}): {1e3 * rl['avg_launch_ms']:.1f} us per launch of {rl['sequences_per_launch']} sequences (live HIP events); contract bytes "
+     f"{rl['algorithmic_bytes_per_launch'] / 1e6:.2f} MB -> frac {rl['frac']:.4f}; needed bytes {rl['needed_bytes_per_launch'] / 1e6:.2f} MB -> {rl['frac_needed']:.4f}; PMC traffic "
+     f"{rl['traffic'] / 1e6:.2f} MB per launch = {rl['traffic'] / rl['needed_bytes_per_launch']:.2f} x needed.",
+     f"* `roofline.saturating` ({sat['kernel']}): {1e3 * sat['avg_launch_ms']:.1f} us per {sat['sequences_per_launch']} sequences on {sat['inputs']}; needed "
+     f"{sat['needed_bytes'] / 1e6:.1f} MB -> {sat['achieved']:.0f} GB/s = **{sat['frac']:.3f}** of 8 TB/s; PMC {sat['traffic'] / 1e6:.1f} MB = {sat['traffic_over_needed']:.3f} x needed.",
+     f"* `cpu_baseline` (kind {cb['kind']}): {cb['value']:.0f} tokens/s on {cb['cores']} threads ({cb['sample']}).",
+     "* drafting cycle wall (us): " + ", ".join(f"{k} {v.get('us_per_cycle_wall', 0):.0f}" for k, v in d.get("drafter_cycle", {}).items() if isinstance(v, dict)),
+     f"* drop-in `EaLumina_mGPT.generate`: {d.get('mirror_generate', {}).get('us_per_verify_step', 0):.1f} us per verify step inside this run (89-92 standalone, `tools/mirror_bench.py`).",
+     f"* other configurations: lambda mode {d['lambda_mode']['value'] / 1e6:.2f} M tokens/s; EAGLE-2 tree {d['dynamic_tree']['value'] / 1e6:.2f} M ({1e3 * d['dynamic_tree']['ms_per_step']:.1f} us per step); "
+     f"C2 {d['configs']['C2']['value'] / 1e6:.2f} M; C4 " + " / ".join(f"{x['value'] / 1e6:.2f}" for x in d["configs"]["C4"]) + " M.",
+     "\n## rocprofv3 `--kernel-trace --stats` of the bench command (`r06_raw_kernel_stats.csv`; four groups in flight, hence longer than the live event pass)\n",
+     "| kernel | average us | calls |\n|---|---|---|"]
+o += [f"| `{name[:110]}` | {us:.1f} | {n} |" for us, n, name in ks("r06_raw_kernel_stats.csv")]
+o += ["\n## evaluate_posterior alone at the saturating batch (`tools/run/ep_sweep_prof.sh`; `r06_ep_sweep_B4096_*`, `r06_ep_sweep_B512_*`)\n", "| kernel | average us | calls |\n|---|---|---|"]
+for fn in ("r06_ep_sweep_B4096_kernel_stats.csv", "r06_ep_sweep_B512_kernel_stats.csv"):
+    o += [f"| `{name[:110]}` ({fn.split('_')[3]}) | {us:.1f} | {n} |" for us, n, name in ks(fn, 1)]
+o += ["\n## PMC (`--pmc FETCH_SIZE`, `--pmc WRITE_SIZE`, separate passes; `r06_ep_traffic.json`; FETCH_SIZE doubled per the gfx950 note of MI355X_MICROARCH.md)\n",
+      "| launch | HBM bytes per launch | needed |\n|---|---|---|"]
+o += [f"| {k} | {v['hbm_bytes'] / 1e6:.2f} MB | {v['algorithmic_window_bytes'] / 1e6:.2f} MB |" for k, v in t["per_launch"].items()]
+o += [f"| saturating {k} | {v['hbm_bytes'] / 1e6:.1f} MB | {v['needed_bytes'] / 1e6:.1f} MB |" for k, v in t["saturating"].items()]
+o += [f"| {k} | {v['hbm_bytes'] / 1e6:.2f} MB | |" for k, v in t["other_kernels"].items()]
+o += ["\n## Other records\n",
+      "* `r06_two_rank_one_device.json`, `r06_two_rank_one_device_total16.json`: `LANTERN_BENCH_ONE_DEVICE=1 python bench.py --gpus 2 ...` (two ranks on the one device over gloo: the "
+      "N > 1 control flow, `ranks_seen` 2).",
+      "* `r06_fuzz_soak.txt`: `tools/run/soak_r06.sh` (static / dynamic / O7 / O3 / top-p / draws soaks against the CPU oracle, 0 failures)."]
+open(P("r06_summary.md"), "w").write("\n".join(o) + "\n")
+print("wrote", P("r06_summary.md"))

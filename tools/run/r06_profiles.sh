@@ -1,0 +1,22 @@
+#!/bin/bash
+# round 6's profile set: rocprofv3 stats + FETCH / WRITE passes of the bench command (default configuration: 64 sequences in 4 stream groups), the
+# saturating-batch passes at 4096 and 512 sequences per launch (compact throughput instance), and the driver's invocation with its full report
+O=gpurun_out/r06prof
+mkdir -p $O
+git rev-parse --short HEAD > tools/run/.commit 2>/dev/null || true
+bash tools/run/prof_default.sh r06p > $O/prof_default.txt 2>&1 || { tail -20 $O/prof_default.txt; exit 1; }
+tail -14 $O/prof_default.txt
+python3 tools/prune_prof.py gpurun_out/r06p; rm -f gpurun_out/r06p/prof/*kernel_trace.csv
+for B in 4096 512; do
+  mkdir -p gpurun_out/r06_sw$B
+  bash tools/run/ep_sweep_prof.sh r06_sw$B $B 5 > $O/sw$B.txt 2>&1 || { tail -20 $O/sw$B.txt; exit 1; }
+  head -3 gpurun_out/r06_sw$B/summary.txt
+  python3 tools/prune_prof.py gpurun_out/r06_sw$B; rm -f gpurun_out/r06_sw$B/stats/*kernel_trace.csv
+done
+timeout -k 10 900 python3 bench.py --gpus 1 --steps 20 --warmup 5 --extras-out $O/bench_full.json > $O/bench.json 2> $O/bench.err || { tail -20 $O/bench.err; exit 1; }
+python3 - <<PY
+import json
+d=json.loads(open("$O/bench.json").read().strip().splitlines()[-1])
+print(len(open("$O/bench.json").read()), d["value"], d["ms_per_step"], d["roofline"]["frac"], d["roofline"].get("saturating",{}).get("frac"), d.get("extras"))
+PY
+du -sh gpurun_out

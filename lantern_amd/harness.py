@@ -966,6 +966,7 @@ class DynamicConfig:
     plausible: float = 8.0          # drafted tokens get target logits in [plausible - 2, plausible]: the walk accepts a few levels
     fuse_o7: bool = False           # LANTERN_ROWS_RAW_BF16 with per-sequence positions: no O7 launch over all N rows, evaluate_posterior
                                     # post-processes the rows its walk visits (alen + 1 of the 59)
+    commit_window: int = 0          # > 0: commit turn-taking between the stream groups (see WorkloadConfig.commit_window)
     spec_rows: int = 2              # with fuse_o7: rows post-processed up front beside the tree build (lantern_prepare_step): 1 = the root, 2 = + node 1
                                     # (the drafter's best first token, at depth 1 in every EAGLE-2 tree); 0 = every row on demand
     n_groups: int = 1               # >1: stream groups, as in WorkloadConfig (n_seq must divide)
@@ -1219,8 +1220,21 @@ class DynamicVerifyWorkload:
             s.sample_token = self.first_token[g * self.Bg:].data_ptr() if i == 0 else bs["tok"] + 8 * (e - c.n_seq)
             s.ep_buf.best, s.ep_buf.accept_len, s.ep_buf.counters = bs["best"] + 4 * e, bs["alen"] + 4 * e, bs["cnt"] + 24 * e
             s.ep_win.u_bonus, s.ep_win.token = bs["ub"] + 8 * e, bs["tok"] + 8 * e
+        turns = native and c.commit_window > 0 and c.with_kv and self.G > 1          # commit turn-taking between the stream groups (lantern_step_group.turn)
+        if turns and not hasattr(self, "_turn"):
+            self._turn = torch.zeros(_lib.TURN_WORDS(self.G), dtype=torch.int64, device=self.device)
+            self._turn_step = 0
+        for g in range(self.G):
+            s = arr[g]
+            if turns:
+                s.turn, s.turn_group, s.turn_groups = self._turn.data_ptr(), g, self.G
+                s.turn_wait, s.turn_epoch = self._turn_step * self.G + g - (c.commit_window - 1), self._turn_step
+            else:
+                s.turn = None
         if native:
             check(L.lantern_verify_step(arr, self.G), "verify_step")
+            if turns:
+                self._turn_step += 1
         else:
             for g in range(self.G):
                 self._launch_group(arr[g], events if g == 0 else None)

@@ -596,7 +596,7 @@ def dynamic_run(device, base_cfg, steps, n_seq, fuse_o7=False, groups=None, spec
         groups = base_cfg.n_groups if n_seq % max(1, base_cfg.n_groups) == 0 else 1
     cfg = HN.DynamicConfig(n_seq=n_seq, lantern_k=base_cfg.lantern_k, lantern_delta=base_cfg.lantern_delta, with_kv=base_cfg.with_kv,
                            kv_smax=base_cfg.kv_smax, kv_pad_rows=base_cfg.kv_pad_rows, max_steps=2 * steps + 32, fuse_o7=fuse_o7, n_groups=groups, spec_rows=spec_rows,
-                           commit_window=(base_cfg.commit_window if groups == 4 else 0))
+                           commit_window=int(os.environ.get("LANTERN_BENCH_DYN_WINDOW", "0")))          # (turn-taking measured slower on per-sequence trees: 1.32 vs 1.50 M tokens/s)
     wl = HN.DynamicVerifyWorkload(cfg, device)
     for _ in range(10):
         wl.step()

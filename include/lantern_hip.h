@@ -455,16 +455,16 @@ typedef struct lantern_step_group {
      * their own streams fall into lock-step: all of them move their KV rows at the same time (one bandwidth-bound phase of ~30 us during which no
      * latency-bound walk runs) instead of one group's commit overlapping the others' walks.  With `turn` set the groups take turns without any
      * cross-stream event: `turn` [dev] int64 [LANTERN_TURN_WORDS(turn_groups)], zeroed once by the caller and never reset -- word 0 counts the commits
-     * COMPLETED by all groups; behind it, one 128-byte line per counter, each group's "workgroups of my commit launches that have finished" counters
-     * in two levels (32 first-level lines per group, then one: thousands of workgroups adding to one word serialise at the memory side); the launch
-     * whose last workgroup finishes increments word 0.  This step's evaluate_posterior (chain kernel) holds its last instructions until turn[0] >= turn_wait -- bounded: after
-     * ~40 ms it proceeds anyway, turn-taking is scheduling, never correctness -- and the commit launched behind it releases the turn when it is
-     * done.  turn_wait: the commits that must have completed before this one starts (ticket - (window - 1) for `window` commits in flight; the
-     * harness issues tickets step * n_groups + group); turn_epoch: commit launches this group has made with `turn` set before this one.
+     * COMPLETED by all groups; behind it, one 128-byte line per counter, each group's "workgroups of my running commit launch that have finished"
+     * counters in two levels (32 first-level lines per group, then one: thousands of workgroups adding to one word serialise at the memory side); the
+     * workgroup that fills a counter puts it back to zero, the launch's last workgroup increments word 0.  This step's evaluate_posterior (chain kernel)
+     * holds its last instructions until turn[0] >= turn_wait -- bounded: after ~40 ms it proceeds anyway, turn-taking is scheduling, never correctness
+     * -- and the commit launched behind it releases the turn when it is done.  turn_wait: the commits that must have completed before this one starts
+     * (ticket - (window - 1) for `window` commits in flight; the harness issues tickets step * n_groups + group).
      * Independent sequences: any order is correct; the reference runs one sequence per process and has no counterpart. */
     int64_t *turn;
     int32_t turn_group, turn_groups;        /* this group's index, and how many groups share `turn` */
-    int64_t turn_wait, turn_epoch;
+    int64_t turn_wait;
     const lantern_step_dynamic *dyn;      /* NULL: a static tree (ss_token / tree_indices / retrieve), or -- flags & LANTERN_STEP_CANDIDATES_READY, ss_token
                                              NULL -- candidates the caller assembled itself: `cand` [B,P,D] and `retrieve` [P,D] are taken as they are
                                              (a tree that came with its token list, ea_model_llamagen.py:1125-1131; or lantern_gather_candidates called

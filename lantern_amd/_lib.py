@@ -92,7 +92,7 @@ class StepGroup(C.Structure):
                 + [(n, C.c_int32) for n in ("hid_elem_bytes", "hid_groups", "H", "reserved1")]
                 + [("node_list", C.c_void_p), ("n_list", C.c_int32), ("flags", C.c_int32)]
                 + [("hidden_uncond", C.c_void_p), ("ids_buf", C.c_void_p), ("ids_stride", C.c_int64), ("ids_len", C.c_void_p), ("prepare_next", C.c_void_p)]
-                + [("turn", C.c_void_p), ("turn_group", C.c_int32), ("turn_groups", C.c_int32), ("turn_wait", C.c_int64), ("turn_epoch", C.c_int64)]
+                + [("turn", C.c_void_p), ("turn_group", C.c_int32), ("turn_groups", C.c_int32), ("turn_wait", C.c_int64)]
                 + [("dyn", C.POINTER(StepDynamic)), ("greedy", C.POINTER(StepGreedy))])
 
 

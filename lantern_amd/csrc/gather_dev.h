@@ -190,16 +190,14 @@ struct CommitExtras {
     unsigned long long *turn = nullptr;
     int turn_group = 0, turn_groups = 0;
     unsigned int turn_nwg = 0;
-    unsigned long long turn_epoch = 0;
 };
 
 constexpr int TURN_LINE = 16, TURN_SLOTS = 32;          // int64 words per 128-byte line; first-level counters per group
 
-// host side of the same (lantern_step_group.turn / turn_group / turn_epoch)
+// host side of the same (lantern_step_group.turn / turn_group / turn_groups)
 struct TurnArgs {
     int64_t *turn;
     int group, groups;
-    long long epoch;
 };
 
 // last statement of every commit kernel's workgroup
@@ -207,12 +205,19 @@ __device__ __forceinline__ void commit_release(const CommitExtras &ex) {
     if (!ex.turn) return;
     __syncthreads();
     if (threadIdx.x == 0) {
+        // (every counter is zero when a launch starts: the workgroup that fills one puts it back to zero -- no other workgroup of this launch touches it
+        // again, and the group's next commit launch is ordered behind this one on its stream -- so launches of different grid sizes can follow each other)
         const unsigned lin = blockIdx.y * gridDim.x + blockIdx.x, slot = lin & (TURN_SLOTS - 1);
         const unsigned long long n_slot = (ex.turn_nwg - slot + TURN_SLOTS - 1) / TURN_SLOTS;          // workgroups of this launch that count in `slot`
         unsigned long long *c1 = ex.turn + (size_t)TURN_LINE * (1 + ex.turn_groups + ex.turn_group * TURN_SLOTS + slot);
-        if (atomicAdd(c1, 1ull) + 1 == (ex.turn_epoch + 1) * n_slot) {
+        if (atomicAdd(c1, 1ull) + 1 == n_slot) {
+            atomicExch(c1, 0ull);
             const unsigned long long used = ex.turn_nwg < (unsigned)TURN_SLOTS ? ex.turn_nwg : TURN_SLOTS;
-            if (atomicAdd(ex.turn + (size_t)TURN_LINE * (1 + ex.turn_group), 1ull) + 1 == (ex.turn_epoch + 1) * used) atomicAdd(ex.turn, 1ull);
+            unsigned long long *c2 = ex.turn + (size_t)TURN_LINE * (1 + ex.turn_group);
+            if (atomicAdd(c2, 1ull) + 1 == used) {
+                atomicExch(c2, 0ull);
+                atomicAdd(ex.turn, 1ull);
+            }
         }
     }
 }

@@ -500,10 +500,9 @@ int lantern::launch_update_inference_inputs(void *const *slab_ptrs, const int32_
             ex.turn_group = turn->group;
             ex.turn_groups = turn->groups;
             ex.turn_nwg = (unsigned int)n_workgroups;
-            ex.turn_epoch = (unsigned long long)turn->epoch;
         }
     };
-    if (turn && turn->turn) LANTERN_CHECK_ARG(turn->group >= 0 && turn->group < turn->groups && turn->epoch >= 0, "update_inference_inputs: turn_group in [0, turn_groups), turn_epoch >= 0");
+    if (turn && turn->turn) LANTERN_CHECK_ARG(turn->group >= 0 && turn->group < turn->groups, "update_inference_inputs: turn_group in [0, turn_groups)");
     LANTERN_CHECK_ARG(n_slabs > 0 && outer > 0 && S_max > 0 && d > 0 && P > 0 && D > 0 && B > 0, "update_inference_inputs: bad sizes");
     LANTERN_CHECK_ARG((d * elem_bytes) % 16 == 0, "update_inference_inputs: KV row bytes %lld must be a multiple of 16", (long long)(d * elem_bytes));
     LANTERN_CHECK_ARG(D <= 8, "update_inference_inputs: D=%d > 8 (use lantern_kv_gather + lantern_accept_gather)", D);

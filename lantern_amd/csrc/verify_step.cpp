@@ -149,7 +149,7 @@ extern "C" int lantern_verify_step(const lantern_step_group *groups, int n_group
             pa.len_cnt = s.ep_buf.counters;
             prep = &pa;
         }
-        const lantern::TurnArgs ta{s.turn, s.turn_group, s.turn_groups, (long long)s.turn_epoch};
+        const lantern::TurnArgs ta{s.turn, s.turn_group, s.turn_groups};
         // (a sequence whose walk reported a status commits nothing: its KV rows and lengths stay as the forward left them, its out_hidden rows are
         // zero-filled and its accepted_tokens are -1 -- the caller retries the step and commits it itself; tests/test_gpu_loop.py pins this gate)
         rc = lantern::launch_update_inference_inputs(s.slab_ptrs, s.slab_seq, s.slab_prev, s.n_slabs, s.elem_bytes, s.outer, s.S_max, s.d,

@@ -653,7 +653,7 @@ class LuminaVerifyWorkload:
             s = arr[g]
             if turns:          # ticket = (commit launches so far) = turn_step * G + g; at most commit_window commits in flight
                 s.turn, s.turn_group, s.turn_groups = self._turn.data_ptr(), g, self.G
-                s.turn_wait, s.turn_epoch = self._turn_step * self.G + g - (c.commit_window - 1), self._turn_step
+                s.turn_wait = self._turn_step * self.G + g - (c.commit_window - 1)
             else:
                 s.turn = None
             s.flags = _lib.STEP_PREPARED if self._prepared_for == step else 0
@@ -1228,7 +1228,7 @@ class DynamicVerifyWorkload:
             s = arr[g]
             if turns:
                 s.turn, s.turn_group, s.turn_groups = self._turn.data_ptr(), g, self.G
-                s.turn_wait, s.turn_epoch = self._turn_step * self.G + g - (c.commit_window - 1), self._turn_step
+                s.turn_wait = self._turn_step * self.G + g - (c.commit_window - 1)
             else:
                 s.turn = None
         if native:

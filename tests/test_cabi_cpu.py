@@ -133,7 +133,7 @@ def test_step_group_layout_matches_the_c_struct(tmp_path):
     import subprocess
     wfields = ["row_hot", "rows_kind", "raw_uncond", "raw_pos_base", "raw_cfg", "raw_eos_id", "raw_probs", "raw_pre", "verdict_host", "turn", "turn_wait"]
     fields = ["stream", "B", "tree_cand", "cond", "pos_base", "w_latent", "seq_len", "temperature", "ep", "ep_buf", "ep_win", "nodes",
-              "slab_ptrs", "n_slabs", "outer", "hidden", "H", "node_list", "n_list", "flags", "hidden_uncond", "ids_buf", "ids_stride", "ids_len", "prepare_next", "turn", "turn_group", "turn_groups", "turn_wait", "turn_epoch", "dyn", "greedy"]
+              "slab_ptrs", "n_slabs", "outer", "hidden", "H", "node_list", "n_list", "flags", "hidden_uncond", "ids_buf", "ids_stride", "ids_len", "prepare_next", "turn", "turn_group", "turn_groups", "turn_wait", "dyn", "greedy"]
     src = tmp_path / "layout.c"
     gfields = [f for f, _ in _lib.StepGreedy._fields_]
     src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "lantern_hip.h"\nint main(void){printf("%zu %zu", sizeof(lantern_step_group), sizeof(lantern_ep_nodes));\n'

@@ -572,7 +572,6 @@ def test_commit_turn_taking_changes_the_schedule_not_the_results(groups, window,
         if cw:
             t = wl._turn.cpu().numpy()
             assert int(t[0]) == steps * groups, t[:64]                   # every commit launch released its turn exactly once
-            second = [int(t[16 * (1 + g)]) for g in range(groups)]       # per group: first-level counters that filled up, summed over the launches
-            assert len(set(second)) == 1 and second[0] % steps == 0 and 0 < second[0] <= 32 * steps, second
+            assert not t[1:].any(), "every completion counter is back at zero once its launch is done"
     for a, b in zip(*outs):
         assert torch.equal(a, b)

@@ -37,6 +37,13 @@ extern "C" int lantern_verify_step(const lantern_step_group *groups, int n_group
     // stage by stage across the groups: every stream receives its next kernel before any stream receives the one after
     // (the streams then advance side by side instead of one group running a whole step ahead of the others)
     int rc;
+    for (int g = 0; g < n_groups; ++g) {          // (before anything is launched: a walk that waits for a turn nobody will release spins out its bound)
+        const lantern_step_group &s = groups[g];
+        if (s.turn && (s.turn_groups <= 0 || s.turn_group < 0 || s.turn_group >= s.turn_groups || !s.slab_ptrs)) {
+            lantern::set_error("commit turn-taking: turn_group in [0, turn_groups) and the group's KV slabs (its commit launch releases the turn)");
+            return fail(g, "turn", LANTERN_E_INVALID);
+        }
+    }
     for (int g = 0; g < n_groups; ++g) {
         const lantern_step_group &s = groups[g];
         if (s.flags & LANTERN_STEP_PREPARED) {          // the previous call's commit launch prepared this step (prepare_next)

@@ -188,12 +188,12 @@ def _raw_throughput(form):
         _dynamic_tree_loop(True, 1, True, 2, 264, 2, 13)
 
 
-def _lumina_static_loop_big(tree, n_seq, steps, every, fuse_o7=False, spec_rows=0):
+def _lumina_static_loop_big(tree, n_seq, steps, every, fuse_o7=False, spec_rows=0, lantern_delta=0.1):
     import numpy as np
     import oracle
     from lantern_amd import harness as HN
     cfg = HN.WorkloadConfig(tree=tree, n_seq=n_seq, pool_steps=2, with_kv=False, max_steps=steps + 4, sigma=5.0, n_groups=1, ep_kernel="chain", fuse_o7=fuse_o7,
-                            spec_rows=spec_rows)
+                            spec_rows=spec_rows, lantern_delta=lantern_delta)
     wl = HN.LuminaVerifyWorkload(cfg, torch.device("cuda"))
     for _ in range(steps):
         wl.step()

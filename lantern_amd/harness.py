@@ -418,6 +418,16 @@ class LuminaVerifyWorkload:
             torch.cuda.synchronize(self.device)
             if time.perf_counter() - t0 >= min_seconds:
                 break
+        # the sequence-management ops of an image end (a step that can end an image wraps the lengths with torch ops and reads one scalar back) run once
+        # here: their FIRST use loads torch's code objects for them, which cost a run that crosses the bound 15 - 18 ms inside its timed region
+        # (measured: 400 timed steps 113 us per step against 68 for 300; tools/probe/turn_long.py).  No state changes: nothing is at the bound.
+        for g in range(self.G):
+            s0, B = g * self.Bg, self.Bg
+            nxt, base = self.lens[1][2 * s0:2 * s0 + 2 * B], self.len_base[2 * s0:2 * s0 + 2 * B]
+            with torch.cuda.stream(self.streams[g]) if self.streams[g] is not None else _nullctx():
+                torch.where(nxt - base >= self.tokens_per_image, base, nxt, out=nxt)
+        torch.cuda.synchronize(self.device)
+        int((self.lens[1] - self.len_base).max().item())
 
     def set_lantern_delta(self, delta: float):
         """Switch between LANTERN's delta mode (<= 1) and LANTERN++'s lambda mode (> 1: tau = (delta - 1) * p(x)) on the same pools."""
@@ -680,9 +690,11 @@ class LuminaVerifyWorkload:
                 with torch.cuda.stream(self.streams[g]) if self.streams[g] is not None else _nullctx():
                     nxt, base = self.lens[parity ^ 1][2 * s0:2 * s0 + 2 * B], self.len_base[2 * s0:2 * s0 + 2 * B]
                     torch.where(nxt - base >= self.tokens_per_image, base, nxt, out=nxt)
-            self.join()
+            # a device-wide synchronise, then the scalar: NOT join() + .item() on the current stream -- with hundreds of steps queued on the group streams the
+            # cross-stream event waits of a join made the queued steps drain at ~110 us instead of ~70 us per step (tools/probe/turn_long.py: 22 ms for the
+            # read-back behind 300 queued steps against 10 ms of queued work)
+            torch.cuda.synchronize(self.device)
             self._len_ub = int((self.lens[parity ^ 1] - self.len_base).max().item())
-            self._forked = False
 
     def _group_args(self, slot: int, parity: int, g: int):
         """Raw pointers of group g's slice of every buffer (cached: the addresses never change)."""
@@ -1246,7 +1258,7 @@ class DynamicVerifyWorkload:
                     torch.add(cur[2 * s0:2 * s0 + 2 * Bg], (self.log_alen[i, s0:s0 + Bg] + 1).repeat(2), out=nxt[2 * s0:2 * s0 + 2 * Bg])
         self._len_ub += self.D
         if self._len_ub >= self.tokens_per_image:      # an image can end: wrap those sequences (host bound refreshed every few hundred steps)
-            self.join()
+            torch.cuda.synchronize(self.device)          # (device-wide, not join(): see LuminaVerifyWorkload._native_step)
             torch.where(nxt - self.len_base >= self.tokens_per_image, self.len_base, nxt, out=nxt)
             self._len_ub = int((nxt - self.len_base).max().item())
         self.step_idx += 1

@@ -300,6 +300,10 @@ typedef struct lantern_ep_window {
      * behind a system-scope fence.  The caller zeroes word 10 before the launch and polls it: the record is visible as soon as the walk ends,
      * while the commit kernel behind it still runs (the reference reads these values with ~6 `.item()` syncs per tried candidate). */
     int32_t *verdict_host;
+    /* optional: commit turn-taking between stream groups (lantern_step_group.turn, below): the chain kernel's workgroups do not END before
+     * turn[0] >= turn_wait, so that the commit launched behind them on the stream starts when it is this group's turn.  NULL: off. */
+    const int64_t *turn;
+    int64_t turn_wait;
 } lantern_ep_window;
 
 /* O8 windowed.  buf->logits is [B, rows_per_seq, win_len]; buf->sample_p may be NULL (if given, the dense
@@ -453,9 +457,9 @@ typedef struct lantern_step_group {
      * cross-stream event: `turn` [dev] int64 [LANTERN_TURN_WORDS(turn_groups)], zeroed once by the caller and never reset -- word 0 counts the commits
      * COMPLETED by all groups; behind it, one 128-byte line per counter, each group's "workgroups of my running commit launch that have finished"
      * counters in two levels (32 first-level lines per group, then one: thousands of workgroups adding to one word serialise at the memory side); the
-     * workgroup that fills a counter puts it back to zero, the launch's last workgroup increments word 0.  Between this step's evaluate_posterior and
-     * its commit, lantern_verify_step launches a one-wave gate kernel on the group's stream that returns when turn[0] >= turn_wait -- bounded: after
-     * ~40 ms it returns anyway, turn-taking is scheduling, never correctness -- and the commit launched behind it releases the turn when it is done.  turn_wait: the commits that must have completed before this one starts
+     * workgroup that fills a counter puts it back to zero, the launch's last workgroup increments word 0.  This step's evaluate_posterior (chain kernel)
+     * holds its last instructions until turn[0] >= turn_wait -- bounded: after ~40 ms it proceeds anyway, turn-taking is scheduling, never correctness
+     * -- and the commit launched behind it releases the turn when it is done.  turn_wait: the commits that must have completed before this one starts
      * (ticket - (window - 1) for `window` commits in flight; the harness issues tickets step * n_groups + group).
      * Independent sequences: any order is correct; the reference runs one sequence per process and has no counterpart. */
     int64_t *turn;

@@ -45,7 +45,8 @@ class EpWindow(C.Structure):
                 ("u_bonus", C.c_void_p), ("token", C.c_void_p), ("rows_kind", C.c_int32), ("raw_pos_per_seq", C.c_int32),
                 ("raw_uncond", C.c_void_p), ("raw_pos_ids", C.c_void_p), ("raw_seq_len", C.c_void_p), ("raw_pos_base", C.c_int64),
                 ("raw_cfg", C.c_float), ("raw_top_k", C.c_int32), ("raw_w_latent", C.c_int32), ("raw_h_latent", C.c_int32),
-                ("raw_newline_id", C.c_int32), ("raw_eos_id", C.c_int32), ("raw_probs", C.c_void_p), ("raw_pre", C.c_void_p), ("verdict_host", C.c_void_p)]
+                ("raw_newline_id", C.c_int32), ("raw_eos_id", C.c_int32), ("raw_probs", C.c_void_p), ("raw_pre", C.c_void_p), ("verdict_host", C.c_void_p),
+                ("turn", C.c_void_p), ("turn_wait", C.c_int64)]
 
 
 class EpNodes(C.Structure):

@@ -1073,6 +1073,17 @@ __device__ __forceinline__ int epw_body(const EpwArgs &args, const int b) {
             vh[10] = 1;
         }
     }
+    // commit turn-taking (lantern_step_group.turn): everything is written; the workgroup's last act is to wait for its group's turn, so that the commit
+    // launched behind this kernel on the stream starts then.  Bounded (~40 ms): the turn is scheduling, never correctness.
+    if (ka->win.turn) {
+        if (tid == 0) {
+            const long long need = ka->win.turn_wait;
+            for (int spins = 0; spins < 200000; ++spins) {
+                if ((long long)__hip_atomic_load(ka->win.turn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= need) break;
+                __builtin_amdgcn_s_sleep(16);
+            }
+        }
+    }
     return (best << 8) | a;          // the verdict (uniform): best path, rows kept = accept_len + 1
 }
 

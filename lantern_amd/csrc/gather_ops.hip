@@ -463,24 +463,7 @@ extern "C" int lantern_sample_static(const float *probs, const int64_t *idx, int
     return LANTERN_OK;
 }
 
-// Commit turn-taking (lantern_step_group.turn): the gate between a group's evaluate_posterior and its commit.  One wave; returns when the commits of all
-// earlier tickets have completed (turn[0] >= wait), so the commit launched behind it on the stream starts when it is the group's turn.  Bounded (~40 ms):
-// the turn is scheduling, never correctness.
-__global__ __launch_bounds__(64) void turn_gate_kernel(const unsigned long long *__restrict__ turn, long long wait) {
-    if (threadIdx.x == 0)
-        for (int spins = 0; spins < 200000; ++spins) {
-            if ((long long)__hip_atomic_load(turn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= wait) break;
-            __builtin_amdgcn_s_sleep(16);
-        }
-}
-
 namespace lantern {
-int launch_turn_gate(const int64_t *turn, long long wait, void *stream) {
-    LANTERN_CHECK_ARG(turn, "turn gate: null counter");
-    hipLaunchKernelGGL(turn_gate_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (const unsigned long long *)turn, wait);
-    LANTERN_CHECK_LAUNCH("turn gate");
-    return LANTERN_OK;
-}
 // `counters` [B, 6] (evaluate_posterior's) or NULL: a sequence whose walk reported a status (counters[b][5] != 0) moves no KV row, copies no hidden
 // row, lists no token and keeps its lengths -- lantern_verify_step commits a step only where the walk succeeded
 int launch_update_inference_inputs(void *const *slab_ptrs, const int32_t *slab_seq, const int64_t *slab_prev, int n_slabs, int elem_bytes, int64_t outer,

@@ -17,7 +17,6 @@ int launch_update_inference_inputs(void *const *slab_ptrs, const int32_t *slab_s
                                    const void *hidden_g1 = nullptr, int64_t *ids_buf = nullptr, int64_t ids_stride = 0, const int64_t *ids_len = nullptr,
                                    const int64_t *bonus = nullptr, const PrepArgs *prep = nullptr, const TurnArgs *turn = nullptr);
 int prepare_step_args(const lantern_step_group *g, PrepArgs *out);
-int launch_turn_gate(const int64_t *turn, long long wait, void *stream);
 }
 
 namespace {
@@ -118,17 +117,15 @@ extern "C" int lantern_verify_step(const lantern_step_group *groups, int n_group
             if (rc) return fail(g, "bonus argmax", rc);
             continue;
         }
+        if (s.turn && !s.nodes && s.slab_ptrs) {          // commit turn-taking: the chain kernel ends when it is this group's turn to commit
+            lantern_ep_window w = s.ep_win;
+            w.turn = s.turn;
+            w.turn_wait = s.turn_wait;
+            rc = lantern_evaluate_posterior_window(&s.ep, &s.ep_buf, &w, s.stream);
+        } else
         rc = s.nodes ? lantern_evaluate_posterior_nodes(&s.ep, &s.ep_buf, &s.ep_win, s.nodes, s.stream)
                      : lantern_evaluate_posterior_window(&s.ep, &s.ep_buf, &s.ep_win, s.stream);
         if (rc) return fail(g, "evaluate_posterior", rc);
-    }
-    // commit turn-taking: a one-wave gate on the group's stream between its walk and its commit (every group's gate is enqueued before any commit, like the
-    // other stages)
-    for (int g = 0; g < n_groups; ++g) {
-        const lantern_step_group &s = groups[g];
-        if (!s.turn) continue;
-        rc = lantern::launch_turn_gate(s.turn, (long long)s.turn_wait, s.stream);
-        if (rc) return fail(g, "turn gate", rc);
     }
     for (int g = 0; g < n_groups; ++g) {
         const lantern_step_group &s = groups[g];

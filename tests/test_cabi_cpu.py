@@ -30,7 +30,7 @@ def test_param_struct_layout_matches_header():
     # ctypes mirror vs the C struct: field order/size (a drift here corrupts every launch)
     assert C.sizeof(_lib.EpParams) == 4 * 11 + 32 + 4 * 5 + 4 + 4 + 8 + 4 * 4
     assert C.sizeof(_lib.EpBuffers) == 20 * 8
-    assert C.sizeof(_lib.EpWindow) == 8 + 8 + 8 + 5 * 8 + 8 + 4 * 8 + 6 * 4 + 2 * 8 + 8          # (+ verdict_host)
+    assert C.sizeof(_lib.EpWindow) == 8 + 8 + 8 + 5 * 8 + 8 + 4 * 8 + 6 * 4 + 2 * 8 + 8 + 2 * 8          # (+ verdict_host, + turn / turn_wait)
     assert C.sizeof(_lib.EpNodes) == 8 + 8 + 6 * 4 + 8 + 8 + 2 * 4
 
 
@@ -131,7 +131,7 @@ def test_step_group_layout_matches_the_c_struct(tmp_path):
     """ctypes mirror of lantern_step_group / lantern_ep_nodes vs the C compiler's layout of include/lantern_hip.h (a drift here
     would hand every kernel of lantern_verify_step the wrong pointers)."""
     import subprocess
-    wfields = ["row_hot", "rows_kind", "raw_uncond", "raw_pos_base", "raw_cfg", "raw_eos_id", "raw_probs", "raw_pre", "verdict_host"]
+    wfields = ["row_hot", "rows_kind", "raw_uncond", "raw_pos_base", "raw_cfg", "raw_eos_id", "raw_probs", "raw_pre", "verdict_host", "turn", "turn_wait"]
     fields = ["stream", "B", "tree_cand", "cond", "pos_base", "w_latent", "seq_len", "temperature", "ep", "ep_buf", "ep_win", "nodes",
               "slab_ptrs", "n_slabs", "outer", "hidden", "H", "node_list", "n_list", "flags", "hidden_uncond", "ids_buf", "ids_stride", "ids_len", "prepare_next", "turn", "turn_group", "turn_groups", "turn_wait", "dyn", "greedy"]
     src = tmp_path / "layout.c"

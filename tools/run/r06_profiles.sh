@@ -7,6 +7,9 @@ git rev-parse --short HEAD > tools/run/.commit 2>/dev/null || true
 bash tools/run/prof_default.sh r06p > $O/prof_default.txt 2>&1 || { tail -20 $O/prof_default.txt; exit 1; }
 tail -14 $O/prof_default.txt
 python3 tools/prune_prof.py gpurun_out/r06p; rm -f gpurun_out/r06p/prof/*kernel_trace.csv
+# the same command free-running (--commit-window 0): with turn-taking the walk kernel's duration includes its wait for the group's turn
+( cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT && timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/r06p_free -o default -- python3 bench.py --gpus 1 --steps 20 --warmup 5 --cpu-seconds 0 --ep-sweep "" --no-extras --extras-out "" --commit-window 0 > $O/b_free.json 2> $O/b_free.err ) || tail -5 $O/b_free.err
+rm -f gpurun_out/r06p_free/*kernel_trace.csv
 for B in 4096 512; do
   mkdir -p gpurun_out/r06_sw$B
   bash tools/run/ep_sweep_prof.sh r06_sw$B $B 5 > $O/sw$B.txt 2>&1 || { tail -20 $O/sw$B.txt; exit 1; }

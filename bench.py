@@ -814,7 +814,9 @@ def plan_sequences(total_seqs: int, seqs_per_gpu: int, world: int, groups: int):
 
 
 
-C5_TOTAL = 64      # BASELINE.json configs[4] / BASELINE.md section 2: "64 sequences split evenly"
+# BASELINE.json configs[4] / BASELINE.md section 2: "64 sequences split evenly".  (LANTERN_BENCH_C5_TOTAL: test knob for the one-device rehearsal of the
+# N > 1 control flow, where every rank's share has to fit the ONE device beside the other ranks'.)
+C5_TOTAL = int(os.environ.get("LANTERN_BENCH_C5_TOTAL", "64"))
 
 
 def c5_strong_plan(world: int, groups: int):

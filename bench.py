@@ -973,8 +973,8 @@ def emit(out: dict, args) -> None:
     sys.stderr.flush()
     c = compact_line(out)
     line = json.dumps(c)
-    for k in ("extras", "kernels", "per_step", "backend_note"):          # never again an unparseable line: under 4 KB whatever the report holds --
-        if len(line) < 4096:                                               # optional blocks go first, the contract's keys, roofline and cpu_baseline stay
+    for k in ("extras", "kernels", "per_step", "backend_note"):          # never again an unparseable line: under 6 KB whatever the report holds (the driver keeps
+        if len(line) < 6144:                                               # an 8 KB tail) -- optional blocks go first, the contract's keys, roofline and cpu_baseline stay
             break
         c.pop(k, None)
         line = json.dumps(c)

@@ -28,10 +28,12 @@ o = ["# Round 6 profile summary (one MI355X)\n",
      f"{sat['needed_bytes'] / 1e6:.1f} MB -> {sat['achieved']:.0f} GB/s = **{sat['frac']:.3f}** of 8 TB/s; PMC {sat['traffic'] / 1e6:.1f} MB = {sat['traffic_over_needed']:.3f} x needed.",
      f"* `cpu_baseline` (kind {cb['kind']}): {cb['value']:.0f} tokens/s on {cb['cores']} threads ({cb['sample']}).",
      "* drafting cycle wall (us): " + ", ".join(f"{k} {v.get('us_per_cycle_wall', 0):.0f}" for k, v in d.get("drafter_cycle", {}).items() if isinstance(v, dict)),
-     f"* drop-in `EaLumina_mGPT.generate`: {d.get('mirror_generate', {}).get('us_per_verify_step', 0):.1f} us per verify step inside this run (89-92 standalone, `tools/mirror_bench.py`).",
+     f"* drop-in `EaLumina_mGPT.generate`: {d.get('mirror_generate', {}).get('us_per_verify_step', 0):.1f} us per verify step inside this run (`tools/mirror_bench.py`).",
      f"* other configurations: lambda mode {d['lambda_mode']['value'] / 1e6:.2f} M tokens/s; EAGLE-2 tree {d['dynamic_tree']['value'] / 1e6:.2f} M ({1e3 * d['dynamic_tree']['ms_per_step']:.1f} us per step); "
      f"C2 {d['configs']['C2']['value'] / 1e6:.2f} M; C4 " + " / ".join(f"{x['value'] / 1e6:.2f}" for x in d["configs"]["C4"]) + " M.",
-     "\n## rocprofv3 `--kernel-trace --stats` of the bench command (`r06_raw_kernel_stats.csv`; four groups in flight, hence longer than the live event pass)\n",
+     "\n## rocprofv3 `--kernel-trace --stats` of the bench command (`r06_raw_kernel_stats.csv`; four groups in flight, and -- commit turn-taking, the default at four groups -- "
+     "the chain kernel's duration INCLUDES its wait for the group's turn to commit; `r06_raw_free_kernel_stats.csv` is the same command with `--commit-window 0`: "
+     + ", ".join(f"`{name.split('<')[0].replace('void lantern::', '')}` {us:.1f} us" for us, n, name in ks("r06_raw_free_kernel_stats.csv", 3)) + ")\n",
      "| kernel | average us | calls |\n|---|---|---|"]
 o += [f"| `{name[:110]}` | {us:.1f} | {n} |" for us, n, name in ks("r06_raw_kernel_stats.csv")]
 o += ["\n## evaluate_posterior alone at the saturating batch (`tools/run/ep_sweep_prof.sh`; `r06_ep_sweep_B4096_*`, `r06_ep_sweep_B512_*`)\n", "| kernel | average us | calls |\n|---|---|---|"]

@@ -513,10 +513,14 @@ int lantern::launch_update_inference_inputs(void *const *slab_ptrs, const int32_
     LANTERN_CHECK_ARG(total < (1ll << 31), "update_inference_inputs: outer * row chunks = %lld does not fit 31 bits", (long long)total);
     LANTERN_CHECK_ARG(S_max < (1ll << 31), "update_inference_inputs: S_max = %lld does not fit 31 bits", (long long)S_max);
     const int ks_knob = tuning(TUNE_KV_KS);          // slabs per workgroup, 0 = one workgroup tile per slab
+    // Slab blocks (a workgroup walks KS whole slabs, two row groups per trip) only for slabs of at most 1024 chunks -- the mirrors' per-layer caches (32 heads x
+    // 16 chunks = 512): above that a workgroup's trips are a serial chain of load / store round trips (LlamaGen-B's [24, 1, 12, S, 64] slabs, 2304 chunks:
+    // 18 trips per workgroup, 22 us per commit of 16 sequences against 4.8 us on the tiled mover; round 6)
+    constexpr long long KV_SLAB_BLOCK_MAX = 1024;
     const bool prep_nucleus = prep && prep->top_p >= 1e-8f && prep->top_p < 1.0f;
     const int n_prep = prep ? prep->B * prep->n_list + prep->B : 0;
     if (prep) LANTERN_CHECK_ARG(prep->W == 8192 && prep->B >= 0, "update_inference_inputs: the next step's preparation rides on the 8192-id window only");
-    if (prep && n_prep > 0 && total <= 4096) {          // small slabs + the next step's preparation
+    if (prep && n_prep > 0 && total <= KV_SLAB_BLOCK_MAX) {          // small slabs + the next step's preparation
         const int g = hidden ? G : 1;
         const int n_commit_x = (n_slabs + 3) / 4 + B * g * D;
         arm_turn((long long)n_commit_x + n_prep);
@@ -546,7 +550,7 @@ int lantern::launch_update_inference_inputs(void *const *slab_ptrs, const int32_
         LANTERN_CHECK_LAUNCH("update_inference_inputs");
         return LANTERN_OK;
     }
-    if (ks_knob > 0 && total <= 4096) {
+    if (ks_knob > 0 && total <= KV_SLAB_BLOCK_MAX) {
         // small slabs (the 7B geometry: 32 heads x 16 chunks): a workgroup covers whole slabs, KS of them
         const int g = hidden ? G : 1;
         const int ks = ks_knob >= 8 ? 8 : (ks_knob >= 4 ? 4 : (ks_knob >= 2 ? 2 : 1));

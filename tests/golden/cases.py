@@ -278,3 +278,10 @@ def checksum(a: np.ndarray) -> float:
     a = np.where(np.isfinite(a), a, 0.0)
     w = np.cos(np.arange(a.size, dtype=np.float64) * 0.37)
     return float((a.reshape(-1) * w).sum())
+
+
+def kv_full_inputs(seed=77, S=96):
+    """The 7B slab geometry (kv_cache.py:101-122: [2 L, B, Hkv, S_max, d] = [64, 2, 32, S, 128]) at a short S_max, f32 values that are small integers (exact in any
+    dtype the copy goes through), regenerated from the seed on both sides."""
+    rs = np.random.RandomState(seed)
+    return rs.randint(-1000, 1000, size=(64, 2, 32, S, 128)).astype(np.float32)

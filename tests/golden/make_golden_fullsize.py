@@ -127,6 +127,39 @@ def golden_o7_full(R, data):
     print("o7 full ok: finite per row", data["o7.f32_count"].tolist())
 
 
+def golden_kv_full(R, data):
+    """O9 + O10 at the 7B slab geometry: the reference's update_inference_inputs (ea_model_lumina_mgpt.py:731-799, parallel CFG: one [64, 2, 32, S, 128] slab) with
+    the default tree's retrieve rows; the moved slab is stored as a SHA-256."""
+    cfg = types.SimpleNamespace(num_hidden_layers=32, num_key_value_heads=32, max_position_embeddings=96, hidden_size=4096, num_attention_heads=32)
+    lin = types.SimpleNamespace(weight=torch.zeros(1))
+    layer = types.SimpleNamespace(self_attn=types.SimpleNamespace(q_proj=lin))
+    fake = types.SimpleNamespace(config=cfg, dtype=torch.float32, model=types.SimpleNamespace(layers=[layer] * 32))
+    pkv, data_list, cur = R.kvc.initialize_past_key_values(fake, batch_size=2)
+    slab = data_list[0]
+    assert tuple(slab.shape) == (64, 2, 32, 96, 128)
+    slab.copy_(torch.from_numpy(CS.kv_full_inputs()))
+    tb = R.lum.generate_tree_buffers(R.ch.mc_sim_7b_63, device="cpu")
+    retrieve = tb["retrieve_indices"]
+    best, alen, prev = 7, 3, 41
+    rs = np.random.RandomState(78)
+    cand = torch.from_numpy(rs.randint(4, 8196, size=tuple(retrieve.shape)).astype(np.int64))
+    hid = torch.from_numpy(rs.standard_normal((1, 26, 64)).astype(np.float32))
+    uhid = torch.from_numpy(rs.standard_normal((1, 26, 64)).astype(np.float32))
+    sample_p = torch.zeros(65536)
+    sample_p[4321] = 1.0
+    captured = {}
+    ns = types.SimpleNamespace(cfg_mode="parallel", ea_layer=types.SimpleNamespace(topK_generate=lambda **kw: captured.update(kw)),
+                               base_model=types.SimpleNamespace(lm_head=None), drafter_logits_processors=None, eagle_version=1)
+    input_ids = torch.zeros(2, prev, dtype=torch.long)
+    new_ids, _, new_token, token = R.lum.EaLumina_mGPT.update_inference_inputs(
+        ns, input_ids, None, cand, torch.tensor(best), alen, retrieve, True, 0, data_list, cur, hid, uhid, sample_p)
+    data.update({"kv.best": np.int32(best), "kv.accept_len": np.int32(alen), "kv.prev": np.int64(prev), "kv.retrieve": retrieve.numpy(), "kv.cand": cand.numpy(),
+                 "kv.after_sha256": np.asarray(sha(slab.numpy())), "kv.before_sha256": np.asarray(sha(CS.kv_full_inputs())),
+                 "kv.current_length": cur.numpy(), "kv.new_ids_tail": new_ids.numpy()[0, prev:], "kv.token": token.numpy(),
+                 "kv.accept_hidden": captured["hidden_states"].numpy(), "kv.hidden": hid.numpy()})
+    print("kv full ok:", sha(slab.numpy())[:16], "moved rows", retrieve[best, :alen + 1].tolist(), "->", list(range(prev, prev + alen + 1)))
+
+
 def main():
     out = HERE
     torch.set_num_threads(8)
@@ -167,6 +200,7 @@ def main():
               flush=True)
     data["specs"] = np.asarray(json.dumps(specs))
     golden_o7_full(R, data)
+    golden_kv_full(R, data)
     np.savez_compressed(os.path.join(out, "evaluate_posterior_full.npz"), **data)
     print("evaluate_posterior_full.npz:", len(specs), "cases,", os.path.getsize(os.path.join(out, "evaluate_posterior_full.npz")), "bytes")
 

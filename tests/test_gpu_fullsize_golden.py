@@ -217,3 +217,72 @@ def test_vq_table_builder_at_the_real_codebook_sizes(model):
     assert same > 0.999999, same                   # exact distance ties may come out in either order
     bad = np.flatnonzero((got != want).any(1))
     assert all(np.array_equal(np.sort(got[r]), np.sort(want[r])) for r in bad)
+
+
+# ------------------------------------------------------------------------------------------------ tree building + commit
+@pytest.mark.parametrize("i", _ids("dynamic"))
+def test_dynamic_tree_kernels_at_full_vocabulary(i):
+    """O3 + O4: expand_dynamic / tree_dynamic_finalize on [10, 65536] / [10, 16384] drafter rows against the tree the reference's
+    topK_genrate built at that vocabulary (cnets_lumina_mgpt.py:803-933)."""
+    spec, case = SPECS[i], H.full_case(i)
+    depth, k = int(case["depth"]), CS.TOPK
+    script = H.dynamic_script(spec["seed"], spec["model"], depth, m=CS.model_dims(spec))
+    ti, cu, ci, scores = ops.expand_dynamic(dev(H.hf_process_rows(script[0][None], H.DYN_TOP_K))[None], None, k)
+    scores_list, tokens_list = [cu.reshape(-1)], [ti.reshape(-1)]
+    parents_list = [torch.zeros(1, dtype=torch.int64, device="cuda")]
+    topk_cs_index = torch.arange(k, device="cuda")
+    for d in range(depth):
+        parents_list.append(topk_cs_index + (1 + k * k * max(0, d - 1) + (k if d > 0 else 0)))
+        ti, cu, ci, scores = ops.expand_dynamic(dev(H.hf_process_rows(script[d + 1], H.DYN_TOP_K))[None], scores, k)
+        topk_cs_index = ci[0]
+        scores_list.append(cu.reshape(-1))
+        tokens_list.append(ti.reshape(-1))
+    draft, mask, pos, ret, nl, md = ops.tree_dynamic_finalize(
+        torch.cat(scores_list)[None], torch.cat(tokens_list)[None], torch.cat(parents_list)[None],
+        torch.tensor([int(case["sample_token"])], device="cuda"), k, int(case["total_tokens"]), sort_rows=True)
+    nl, md = int(nl[0]), int(md[0])
+    assert np.array_equal(draft[0].cpu().numpy(), case["draft_tokens"])
+    assert np.array_equal(ret[0, :nl, :md].cpu().numpy(), case["retrieve"])
+    assert torch.all(ret[0, nl:] == -1) and torch.all(ret[0, :, md:] == -1)
+    assert np.array_equal(mask[0].cpu().numpy(), case["mask"]) and np.array_equal(pos[0].cpu().numpy(), case["pos"])
+
+
+@pytest.mark.parametrize("i", _ids("static")[:3])
+def test_gather_candidates_full_size(i):
+    """O2 with the reference's real-size token ids (offset + 4, ids up to 8195 / 16383)."""
+    spec, case = SPECS[i], H.full_case(i)
+    tb = H.tree_buffers(spec["tree"])
+    cand, cp, tc = ops.gather_candidates(dev(case["ss_token"])[None], dev(case["ss_prob"])[None],
+                                         dev(np.array([int(case["sample_token"])])), dev(tb["tree_indices"]), dev(tb["retrieve"]))
+    assert np.array_equal(cand[0].cpu().numpy(), case["cand"])
+    assert np.array_equal(cp[0].cpu().numpy(), case["cart_prob"]) and np.array_equal(tc[0].cpu().numpy(), case["tree_cand"])
+
+
+@pytest.mark.parametrize("fused", [False, True])
+def test_kv_commit_at_the_7b_slab_geometry(fused):
+    """O9 (+ O10 when fused): the reference's update_inference_inputs on its own [64, 2, 32, 96, 128] slab (kv_cache.py:101-122),
+    compared through the SHA-256 of the whole moved slab."""
+    from test_oracle_fullsize import kv_full_data
+    d, slab_np = kv_full_data()
+    best_i, a, prev = int(d["kv.best"]), int(d["kv.accept_len"]), int(d["kv.prev"])
+    slab = dev(slab_np)
+    best, alen = dev(np.array([best_i], np.int32)), dev(np.array([a], np.int32))
+    seq, prv, ret = dev(np.zeros(1, np.int32)), dev(np.array([prev], np.int64)), dev(d["kv.retrieve"])
+    if fused:
+        hid = dev(np.stack([d["kv.hidden"][0], d["kv.hidden"][0]])[None])          # [B=1, G=2, N, H]
+        new_len, out_h, acc = ops.update_inference_inputs([slab], seq, prv, ret, best, alen, hid, dev(d["kv.cand"])[None])
+        n = a + 1
+        assert np.array_equal(out_h.cpu().numpy()[0, 0, :n], d["kv.accept_hidden"][0])
+        assert np.array_equal(out_h.cpu().numpy()[0, 1, :n], d["kv.accept_hidden"][0])
+        assert np.array_equal(acc.cpu().numpy()[0, :n], d["kv.new_ids_tail"]) and np.all(acc.cpu().numpy()[0, n:] == -1)
+    else:
+        new_len = ops.kv_gather([slab], seq, prv, ret, best, alen)
+    assert int(new_len[0]) == int(d["kv.current_length"][0]) == prev + a + 1
+    assert hashlib.sha256(slab.cpu().numpy().tobytes()).hexdigest() == str(d["kv.after_sha256"])
+    # the bonus token (ea_model_lumina_mgpt.py:779-790): inverse CDF of the one-hot residual the reference sampled from
+    p = np.zeros((1, 65536), np.float32)
+    p[0, 4321] = 1.0
+    hid1 = dev(d["kv.hidden"])[None]
+    out_h, acc, tok = ops.accept_gather(hid1, ret, dev(d["kv.cand"])[None], best, alen, sample_p=dev(p), u=dev(np.array([0.77])))
+    assert int(tok[0]) == int(d["kv.token"].reshape(-1)[0]) == 4321
+    assert np.array_equal(out_h.cpu().numpy()[0, 0, :a + 1], d["kv.accept_hidden"][0])

@@ -130,3 +130,25 @@ def test_cfg_mask_topk_full_size(tag):
                                top_k=2000, w=48, h=48, img_lo=m["img_lo"], img_hi=m["img_hi"], newline_id=m["syntax"][2],
                                eos_id=m["syntax"][0], bf16=bf)
     o7_full_check(out, d, tag)
+
+
+def kv_full_data():
+    d = H.load("evaluate_posterior_full.npz")
+    slab = CS.kv_full_inputs()
+    assert hashlib.sha256(slab.tobytes()).hexdigest() == str(d["kv.before_sha256"])
+    return d, slab
+
+
+def test_kv_and_hidden_gather_at_the_7b_slab_geometry():
+    """O9 + O10 on the reference's own [64, 2, 32, S, 128] slab (kv_cache.py:101-122) with the default tree's retrieve rows."""
+    d, slab = kv_full_data()
+    best, alen, prev = int(d["kv.best"]), int(d["kv.accept_len"]), int(d["kv.prev"])
+    row = d["kv.retrieve"][best]
+    oracle.kv_gather(slab, row, alen + 1, prev)
+    assert hashlib.sha256(slab.tobytes()).hexdigest() == str(d["kv.after_sha256"])
+    assert np.all(d["kv.current_length"] == prev + alen + 1)
+    assert np.array_equal(oracle.hidden_gather(d["kv.hidden"], row, alen + 1), d["kv.accept_hidden"])
+    assert np.array_equal(d["kv.cand"][best, :alen + 1], d["kv.new_ids_tail"])
+    p = np.zeros(65536, np.float32)
+    p[4321] = 1.0
+    assert oracle.sample_inverse_cdf(p, 0.77) == int(d["kv.token"].reshape(-1)[0]) == 4321

@@ -59,7 +59,7 @@ const char *lantern_last_error(void);
 /* Tuning values: kernel-instance / launch-shape choices a MEASUREMENT may override (tools/, a few tests).  The library reads no environment
  * variable; every product path runs the defaults.  Names (defaults): epw_tp (5), epw_tp4 (1), epw_tp_raw (256), epw_spec (2), epw_occ2 (-1),
  * o7_nt (0), prep_nt (0), kv_u (0), kv_ks (4), kv_variant (0), gemm_tiled_from (129), sk_groups (0), sk_whole_mb (40), sk_nt_min_mb (80),
- * ta_splits (0), ta_min_tiles (2) -- meanings beside `enum Tuning` in lantern_amd/csrc/common.h.  Process-wide, atomic ints; set before the
+ * ta_splits (0), ta_min_tiles (2), epw_tp_lg (1) -- meanings beside `enum Tuning` in lantern_amd/csrc/common.h.  Process-wide, atomic ints; set before the
  * launches they should affect.  The reference has no counterpart (it has no kernels to choose between). */
 int lantern_tuning_set(const char *name, int value);
 int lantern_tuning_get(const char *name, int *value);

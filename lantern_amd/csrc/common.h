@@ -33,6 +33,7 @@ enum Tuning {
     TUNE_SK_NT_MIN_MB,      // 80: matrices from this many MB are streamed with non-temporal loads
     TUNE_TA_SPLITS,         // 0: key splits of tree attention by launch size (> 0 forces the split count)
     TUNE_TA_MIN_TILES,      // 2: key tiles per wave and split below which no further split is made
+    TUNE_EPW_TP_LG,         // 1: LlamaGen's 16384-id throughput instance (two per CU, rows by LDS-DMA); 2: + second LDS pass for the residual; 3: rows through registers; 4: + raised priority; 0: off
     TUNE_COUNT
 };
 int tuning(int t);

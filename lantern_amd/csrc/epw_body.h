@@ -142,7 +142,12 @@ __device__ __forceinline__ int epw_body(const EpwArgs &args, const int b) {
     constexpr bool COMPACT = (TPO & 4) != 0;         // the default tree's throughput build on the smallest staged tables (EwSharedCompact, no neighbour
                                                      // bit mask, 2 prefetch slots): 40 KB of LDS, four workgroups per CU
     static_assert(!COMPACT || (SPEC == 2 && !RAW), "the compact tables are sized for the reference's default tree mc_sim_7b_63 on probability rows");
-    typedef typename std::conditional<COMPACT, EwSharedCompact, EwShared>::type SH;
+    constexpr bool LITE = (TPO & 256) != 0;          // LlamaGen's throughput build: the 64 KB window leaves 14 KB for everything else if TWO workgroups are to share a CU --
+                                                     // EwSharedLite (trees of <= 64 nodes, no neighbour lists: LANTERN off), no neighbour bit mask
+    static_assert(!LITE || (SPEC == 5 && !RAW && !COMPACT), "the lite tables: LlamaGen's standard verify (dynamic trees, LANTERN off) on probability rows");
+    constexpr bool DMAROW = COMPACT || (TPO & 512) != 0;          // probability rows land in g by LDS-DMA (row_dma_to_lds): no VGPR staging, no ds_write pass
+    static_assert(!DMAROW || (SPEC >= 1 && !RAW && FULLW), "LDS-DMA rows: final probability rows of a fixed configuration whose window is the workgroup's tile");
+    typedef typename std::conditional<COMPACT, EwSharedCompact, typename std::conditional<LITE, EwSharedLite, EwShared>::type>::type SH;
     constexpr int MAX_B = SH::kMaxB, MAX_N = SH::kMaxN, N_UNI = SH::kUni;
     constexpr bool LDSIDS = IDMODE != 0;
     const lantern_ep_params &prm = args.prm;
@@ -170,7 +175,7 @@ __device__ __forceinline__ int epw_body(const EpwArgs &args, const int b) {
     const int Ps = (SPEC == 2) ? 15 : prm.P, Ds = (SPEC == 2) ? 6 : prm.D, V = SL ? (S_LG ? 16384 : 65536) : prm.V, W = SL ? (S_LG ? 16384 : 8192) : win.win_len,
               lo = SL ? (S_LG ? 0 : 4) : win.win_lo;
     uint32_t *nbmask = reinterpret_cast<uint32_t *>(g + W + EW_G_EXT);  // W bits: neighbour set (static LlamaGen/Anole: zeroing hits q); not allocated when COMPACT
-    SH &S = *reinterpret_cast<SH *>(reinterpret_cast<char *>(g) + epw_shared_offset(W, !COMPACT));
+    SH &S = *reinterpret_cast<SH *>(reinterpret_cast<char *>(g) + epw_shared_offset(W, !(COMPACT || LITE)));
     int *const Scand = reinterpret_cast<int *>(reinterpret_cast<char *>(&S) + sizeof(SH));
     const int pd_cap = epw_pd_cap(Ps, Ds);
     int *const Srow = Scand + pd_cap, *const Spidx = Srow + pd_cap, *const Sboff = Spidx + pd_cap;
@@ -274,8 +279,8 @@ __device__ __forceinline__ int epw_body(const EpwArgs &args, const int b) {
                 rp_probs = root_pre && rid1 == 0;
                 if (rp_probs) row_load<NT, E4, FULLW>(raw_p + (size_t)rid1 * W, W, rp);
                 else raw_row_load<NT, CH>(raw_c + (size_t)rid1 * V, raw_u + (size_t)rid1 * V, rp);
-            } else if constexpr (!COMPACT) row_load<NT, E4, FULLW>(logits + (size_t)rid1 * W, W, rp);          // (COMPACT: by LDS-DMA at level 1, once the row's class is known)
-            if constexpr (!COMPACT) rp_rid = rid1;
+            } else if constexpr (!DMAROW) row_load<NT, E4, FULLW>(logits + (size_t)rid1 * W, W, rp);          // (DMAROW: by LDS-DMA at level 1, once the row's class is known)
+            if constexpr (!DMAROW) rp_rid = rid1;
         }
         // LDS stores
 #pragma unroll
@@ -433,7 +438,7 @@ __device__ __forceinline__ int epw_body(const EpwArgs &args, const int b) {
             rid = rid < 0 ? 0 : (rid >= p_rows ? p_rows - 1 : rid);     // a bad row map must not read outside the batch
             const int hot = RAW ? S.hot[rid] : (!hot_g ? -1 : (hot_in_lds ? S.hot[rid] : hot_g[rid]));
             EPW_STAMP(10);
-            if constexpr (COMPACT) {
+            if constexpr (DMAROW) {
                 if (hot < 0) row_dma_to_lds<NT, E4>(logits + (size_t)rid * W, g);          // (g is dead here: every reader of the previous level passed its decision barrier)
             } else if (hot < 0 && rp_rid != rid) {
                 if constexpr (RAW) {
@@ -477,7 +482,7 @@ __device__ __forceinline__ int epw_body(const EpwArgs &args, const int b) {
             if constexpr (RAW) {
                 if (!rp_probs) raw_row_to_lds<NT, decltype(stage_ids), NUCLEUS, CH>(rp, hot, win.raw_cfg, win.raw_top_k, V, lo, W, g, out_tok, out_mass, S.redf, S.redd, Shist, ph, stage_ids, prm.top_p, S.redi);
                 else row_softmax_to_lds<NT, E4, FULLW, decltype(stage_ids), false, SH>(rp, hot, true, lo, W, prm.temperature, prm.top_k, V, g, out_tok, out_mass, S, ph, stage_ids);
-            } else if constexpr (COMPACT) {
+            } else if constexpr (DMAROW) {
                 if (hot < 0) {          // the row is landing in g by DMA: nothing to compute (probability rows are final)
                     out_tok = -1;
                     out_mass = 0.0f;
@@ -767,8 +772,9 @@ __device__ __forceinline__ int epw_body(const EpwArgs &args, const int b) {
 #pragma unroll
                 for (int it = 0; it < E4; ++it) {
                     const int i4 = tid + it * NT;
-                    gn[it] = (FULLW || i4 * 4 < W) ? reinterpret_cast<const float4 *>(g)[i4] : make_float4(0.f, 0.f, 0.f, 0.f);
-                    loc += (double)gn[it].x + (double)gn[it].y + (double)gn[it].z + (double)gn[it].w;
+                    const float4 gv = (FULLW || i4 * 4 < W) ? reinterpret_cast<const float4 *>(g)[i4] : make_float4(0.f, 0.f, 0.f, 0.f);
+                    if constexpr (!LDS2P) gn[it] = gv;
+                    loc += (double)gv.x + (double)gv.y + (double)gv.z + (double)gv.w;
                 }
             } else {
                 const int b0 = rdlane(b0_lane, j), b1 = rdlane(b1_lane, j);
@@ -892,7 +898,7 @@ __device__ __forceinline__ int epw_body(const EpwArgs &args, const int b) {
             for (int it = 0; it < E4; ++it) {
                 const int i4 = tid + it * NT;
                 if (FULLW || i4 * 4 < W)
-                    reinterpret_cast<float4 *>(g)[i4] = dg((LDS2P && is_static) ? reinterpret_cast<const float4 *>(g)[i4] : gn[it]);
+                    reinterpret_cast<float4 *>(g)[i4] = dg(LDS2P ? reinterpret_cast<const float4 *>(g)[i4] : gn[it]);          // (dynamic trees: g already holds the unnormalised residual)
             }
             out_mass = out_mass / gs;
             if (tid == 0) g[W + EW_G_OUT] = out_mass;
@@ -907,7 +913,7 @@ __device__ __forceinline__ int epw_body(const EpwArgs &args, const int b) {
         int rid = Srow[best * Ds + (a - 1)];
         rid = rid < 0 ? 0 : (rid >= p_rows ? p_rows - 1 : rid);
         const int hot = RAW ? S.hot[rid] : (!hot_g ? -1 : (hot_in_lds ? S.hot[rid] : hot_g[rid]));
-        if constexpr (COMPACT) {
+        if constexpr (DMAROW) {
             if (hot < 0) row_dma_to_lds<NT, E4>(logits + (size_t)rid * W, g);
         } else if (hot < 0 && rp_rid != rid) {
             if constexpr (RAW) {
@@ -919,7 +925,7 @@ __device__ __forceinline__ int epw_body(const EpwArgs &args, const int b) {
         if constexpr (RAW) {
             if (!rp_probs) raw_row_to_lds<NT, NoHook, NUCLEUS, CH>(rp, hot, win.raw_cfg, win.raw_top_k, V, lo, W, g, out_tok, out_mass, S.redf, S.redd, Shist, ph, NoHook(), prm.top_p, S.redi);
             else row_softmax_to_lds<NT, E4, FULLW, NoHook, false, SH>(rp, hot, true, lo, W, prm.temperature, prm.top_k, V, g, out_tok, out_mass, S, ph);
-        } else if constexpr (COMPACT) {
+        } else if constexpr (DMAROW) {
             if (hot < 0) {
                 out_tok = -1;
                 out_mass = 0.0f;
@@ -1108,7 +1114,8 @@ enum EpwThroughput {
     EPW_TP_512_DEFAULT_TREE, EPW_TP_512_PACKED, EPW_TP_512_ID0, EPW_TP_512_ID1, EPW_TP_512_ID2,            // 512 threads at 128 VGPRs, two per CU
     EPW_TP_RAW_GENERIC,                                                                                      // raw rows, 512 threads, two per CU
     EPW_TP_RAW_LUMINA_DEFAULT_TREE, EPW_TP_RAW_LUMINA_STATIC, EPW_TP_RAW_LUMINA_DYNAMIC, EPW_TP_RAW_ANOLE_STATIC,   // raw rows, fixed configurations
-    EPW_TP_RAW_LLAMAGEN_DYNAMIC                                                                              // LlamaGen's 16384-id window, raw rows
+    EPW_TP_RAW_LLAMAGEN_DYNAMIC,                                                                             // LlamaGen's 16384-id window, raw rows
+    EPW_TP_LLAMAGEN_DYNAMIC                                                                                  // LlamaGen's 16384-id window, probability rows: 512 threads x 8 float4, two per CU
 };
 bool epw_launch_throughput(int kind, const EpwLaunch &l, const EpwArgs &args);
 

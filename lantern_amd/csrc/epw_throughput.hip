@@ -3,6 +3,7 @@
 // requested only once its rejection is known (LATE_Q, TPO bit 0).  BASELINE assesses evaluate_posterior's roofline target at this batch.
 //   256 threads x 8 float4, three workgroups per CU (53 KB of LDS each): probability rows and -- round 5 -- raw cond / uncond bf16 rows
 //   512 threads x 4 float4 at 128 VGPRs, two per CU: everything else on the 8192-id window
+//   512 threads x 8 float4 at 128 VGPRs, two per CU (79 KB of LDS each): LlamaGen's 16384-id window, standard verify on dynamic trees (round 6)
 #undef EPW_TRACE
 #include "epw_body.h"
 
@@ -45,6 +46,17 @@ bool epw_launch_throughput(int kind, const EpwLaunch &l, const EpwArgs &args) {
     case EPW_TP_RAW_LUMINA_STATIC: if (raw512) { constexpr int NTX = 512; TP(512, 4, 2, 4, true, true, 1, 1); } else { constexpr int NTX = 256; TP(256, 8, 2, 2, true, true, 1, 1 + 8); } return true;
     case EPW_TP_RAW_LUMINA_DYNAMIC: if (raw512) { constexpr int NTX = 512; TP(512, 4, 2, 4, true, true, 3, 1); } else { constexpr int NTX = 256; TP(256, 8, 2, 2, true, true, 3, 1 + 8); } return true;
     case EPW_TP_RAW_ANOLE_STATIC: if (raw512) { constexpr int NTX = 512; TP(512, 4, 2, 4, true, true, 4, 1); } else { constexpr int NTX = 256; TP(256, 8, 2, 2, true, true, 4, 1 + 8); } return true;
+    // LlamaGen's standard verify (BASELINE config 2) on probability rows: the 64 KB window + EwSharedLite + the per-path tables = <= 80 KB, TWO workgroups of
+    // 512 threads x 8 float4 per CU at 128 VGPRs (the generic instance: 1024 threads, 97 KB, one per CU)
+    case EPW_TP_LLAMAGEN_DYNAMIC: {
+        constexpr int NTX = 512;
+        const int lg = tuning(TUNE_EPW_TP_LG);
+        if (lg == 2) TP(512, 8, 1, 4, true, false, 5, 1 + 8 + 64 + 256);                 // + the residual normalised by a second LDS pass
+        else if (lg == 3) TP(512, 8, 1, 4, true, false, 5, 1 + 8 + 256);                 // rows through registers
+        else if (lg == 4) TP(512, 8, 1, 4, true, false, 5, 1 + 8 + 128 + 256 + 512);     // + raised priority of the serial section
+        else TP(512, 8, 1, 4, true, false, 5, 1 + 8 + 256 + 512);                        // rows by LDS-DMA
+        return true;
+    }
     default: return false;
     }
 #undef TP

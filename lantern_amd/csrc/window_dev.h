@@ -385,6 +385,7 @@ struct alignas(16) EwSharedT {
 };
 typedef EwSharedT<> EwShared;
 typedef EwSharedT<2, 128, 32, 32, 32> EwSharedCompact;          // (256 threads x 8 float4: NW * E4 = 32 segment totals)
+typedef EwSharedT<1, 128, 64, 64, 64> EwSharedLite;             // LlamaGen's 16384-id window at two workgroups per CU: trees of <= 64 nodes, LANTERN off (one unused neighbour slot)
 static_assert(EW_PF_C <= 8, "nbk slots");
 
 // g[W + EW_G_ZERO] = 0 (neighbour outside the window), g[W + EW_G_HUGE] = 3e38 (position >= k: never under tau),

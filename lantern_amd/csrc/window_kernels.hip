@@ -558,6 +558,14 @@ extern "C" int lantern_evaluate_posterior_window(const lantern_ep_params *prm, c
         }
         else ok = epw_launch_generic(W, idmode, false, L, args);
     }
+    else if (W == 16384 && many && tuning(TUNE_EPW_TP_LG) != 0 && spec_knob != 0 && !p.lantern && p.mode == LANTERN_MODE_DYNAMIC && !p.syntax_shortcut && p.V == 16384 &&
+             p.img_lo == 0 && p.img_hi >= 16384 && p.tok_offset == 0 && win->win_lo == 0 && buf->n_paths && buf->n_depth && win->rows_kind == LANTERN_ROWS_PROBS &&
+             p.rows_per_seq <= EwSharedLite::kMaxN &&
+             epw_shared_offset(W, false) + sizeof(EwSharedLite) + (size_t)6 * epw_pd_cap(p.P, p.D) * 4 <= (size_t)80 * 1024) {
+        // LlamaGen's standard verify at more sequences than CUs: two workgroups per CU (epw_throughput.hip)
+        const EpwLaunch Llg{grid, epw_shared_offset(W, false) + sizeof(EwSharedLite) + (size_t)6 * epw_pd_cap(p.P, p.D) * 4, st};
+        ok = epw_launch_throughput(EPW_TP_LLAMAGEN_DYNAMIC, Llg, args);
+    }
     else ok = epw_launch_generic(W, idmode, false, L, args);
     if (!ok) {
         set_error("evaluate_posterior_window: no kernel instance for window %d, id mode %d%s", W, idmode, nucleus ? ", top_p inside the kernel" : "");

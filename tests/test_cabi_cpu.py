@@ -242,7 +242,7 @@ def test_tuning_values_are_an_explicit_api_and_the_library_reads_no_environment(
     import subprocess
     names = _lib.tuning_names()
     assert names == ["epw_tp", "epw_tp4", "epw_tp_raw", "epw_spec", "epw_occ2", "o7_nt", "prep_nt", "kv_u", "kv_ks", "kv_variant", "gemm_tiled_from",
-                     "sk_groups", "sk_whole_mb", "sk_nt_min_mb", "ta_splits", "ta_min_tiles"]
+                     "sk_groups", "sk_whole_mb", "sk_nt_min_mb", "ta_splits", "ta_min_tiles", "epw_tp_lg"]
     defaults = {n: _lib.get_tuning(n) for n in names}
     assert (defaults["epw_tp"], defaults["epw_tp4"], defaults["epw_tp_raw"], defaults["epw_spec"], defaults["kv_ks"], defaults["sk_whole_mb"]) == (5, 1, 256, 2, 4, 40)
     _lib.set_tuning("epw_tp_raw", 512)

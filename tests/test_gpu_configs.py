@@ -384,3 +384,67 @@ def test_c3_lumina_dynamic_tree_full_size(delta):
         assert int(out["token"][b]) == oracle.sample_inverse_cdf(osp, ubon[b])
         tried += int(ocnt[1])
     assert tried >= B
+
+
+def test_llamagen_throughput_instance_two_per_cu():
+    """C2 at more sequences than CUs: LlamaGen's standard verify on probability rows takes `epw_kernel<512, 8, 1, 4, true, false, 5, ..>` (two workgroups per CU on the
+    16384-id window, EwSharedLite).  264 sequences = 6 distinct steps with their own EAGLE-2 trees, tiled: the oracle's results, and bit for bit those of the
+    generic one-per-CU instance (lantern_tuning_set("epw_tp_lg", 0)) and of the measurement variants (2: the residual normalised by a second LDS pass, 3: rows
+    through registers instead of LDS-DMA, 4: raised priority of the serial section)."""
+    from lantern_amd import _lib
+    V, k, depth, T, U, REP = 16384, 10, 4, 58, 6, 44
+    N, P, D = T + 1, T + 1, depth + 2
+    rs = np.random.RandomState(2121)
+    cfg_o = oracle.EpConfig.llamagen(False, lantern=False, temperature=1.0, top_p=1.0, top_k=2000)
+    cfg_h = ops.EpConfig.llamagen(False, lantern=False, temperature=1.0, top_p=1.0, top_k=0)          # (probability rows are final)
+    rows, cands, ris, nps, nds, ref = [], [], [], [], [], []
+    for b in range(U):
+        script = [(4 * rs.standard_normal((1 if d == 0 else k, V))).astype(np.float32) for d in range(depth + 1)]
+        ti, cu, ci, sc = oracle.expand_dynamic(CS.topk_filter(script[0], 2000), None, k)
+        sl, tl, pl, cs = [cu.reshape(-1)], [ti.reshape(-1)], [np.zeros(1, np.int64)], np.arange(k)
+        for d in range(depth):
+            pl.append(cs + 1 + k * k * max(0, d - 1) + (k if d > 0 else 0))
+            ti, cu, ci, sc = oracle.expand_dynamic(CS.topk_filter(script[d + 1], 2000), sc, k)
+            cs = ci
+            sl.append(cu.reshape(-1)); tl.append(ti.reshape(-1))
+        od, oret, omask, opos = oracle.tree_dynamic_finalize(np.concatenate(sl), np.concatenate(tl), np.concatenate(pl), k, T, int(rs.randint(0, V)))
+        node_logits = (4 * rs.standard_normal((N, V))).astype(np.float32)
+        for p in range(oret.shape[0]):
+            for d in range(1, oret.shape[1]):
+                if oret[p, d] >= 0:
+                    node_logits[oret[p, d - 1], od[oret[p, d]]] = node_logits[oret[p, d - 1]].max() - rs.uniform(0, 2 + b)
+        cand = np.where(oret >= 0, od[np.maximum(oret, 0)], -1)
+        uni = rs.random_sample(64)
+        ref.append(oracle.evaluate_posterior(cfg_o, node_logits, H.row_index_from_retrieve(oret, N), cand, uni) + (uni,))
+        pr, _ = ops.cfg_mask_topk_window(dev(node_logits), None, 1.0, 0, V, model=ops.MODEL_PLAIN, img_lo=0, img_hi=V, top_k=2000, temperature=1.0, probs=True)
+        padded = np.full((P, D), -1, np.int64)
+        padded[:oret.shape[0], :oret.shape[1]] = oret
+        cpad = np.full((P, D), -1, np.int64)
+        cpad[:oret.shape[0], :oret.shape[1]] = cand
+        rows.append(pr); cands.append(cpad); ris.append(H.row_index_from_retrieve(padded, N)); nps.append(oret.shape[0]); nds.append(oret.shape[1])
+    tile = lambda a, dt: dev(np.concatenate([np.stack(a)] * REP).astype(dt))
+    win = torch.cat([torch.stack(rows)] * REP)
+    args = (cfg_h, V, win, 0, tile(ris, np.int32), tile(cands, np.int64), tile([r[4] for r in ref], np.float64))
+    kw = dict(n_paths=tile(nps, np.int32), n_depth=tile(nds, np.int32), rows_probs=True, want_dense=False,
+              u_bonus=dev(np.tile(rs.random_sample(U), REP)))
+    outs = {}
+    try:
+        for knob in (1, 2, 3, 4, 0):
+            _lib.set_tuning("epw_tp_lg", knob)
+            outs[knob] = ops.evaluate_posterior_window(*args, **kw)
+            torch.cuda.synchronize()
+    finally:
+        _lib.set_tuning("epw_tp_lg", 1)
+    out = outs[1]
+    assert out["best"].shape[0] == U * REP > 256
+    for key in ("best", "accept_len", "counters", "sample_win", "out_tok", "out_mass", "token"):
+        assert all(torch.equal(outs[v][key], out[key]) for v in (0, 2, 3, 4)), key
+    for b in range(U):
+        ob, oa, osp, ocnt, _ = ref[b]
+        for rep in (0, REP // 2, REP - 1):
+            j = rep * U + b
+            assert int(out["counters"][j, 5]) == 0
+            assert (int(out["best"][j]), int(out["accept_len"][j])) == (ob, oa), (j, b)
+            assert np.array_equal(out["counters"][j, :5].cpu().numpy(), ocnt[:5])
+            np.testing.assert_allclose(out["sample_win"][j].cpu().numpy(), osp, rtol=0, atol=PROB_TOL)
+            assert int(out["token"][j]) == oracle.sample_inverse_cdf(out["sample_win"][j].cpu().numpy(), float(kw["u_bonus"][j]))

@@ -383,6 +383,21 @@ typedef struct lantern_step_greedy {
     int64_t *token;               /* [dev] [B] */
 } lantern_step_greedy;
 
+/* The DENSE kernel set inside the one-call step (round 6): what a caller falls back to when the windowed kernels report a state only the dense kernel
+ * represents (counters[5] = LANTERN_ST_NEEDS_DENSE: the residual vanished and the reference samples uniformly over all V ids, ea_model_lumina_mgpt.py:712-714;
+ * uniforms or a tree beyond the windowed kernels' staged sizes), or whose tree never fits them (P > 64).  With lantern_step_group.dense set,
+ * lantern_verify_step runs: [candidates] -> lantern_cfg_mask_topk over all N rows at the full vocabulary (the group's O7 fields; skipped when cond is
+ * NULL: `logits` then already holds the processed rows) into `logits` -> lantern_evaluate_posterior on those rows (ep, ep_buf with logits / sample_p
+ * replaced by the two buffers below; ep_win is not read) -> the bonus token = inverse CDF of sample_p at u_bonus (lantern_accept_gather's draw,
+ * ea_model_lumina_mgpt.py:779-790) -> the KV / hidden / token commit.  Not combinable with nodes, greedy, node_list, prepare_next, turn or
+ * ep_win.verdict_host (refused). */
+typedef struct lantern_step_dense {
+    float *logits;                /* [dev] [B, N, V] f32: O7's output, O8's input */
+    float *sample_p;              /* [dev] [B, V] out: the distribution the bonus token is drawn from */
+    const double *u_bonus;        /* [dev] [B] the bonus draw's uniform; NULL (with token NULL): no bonus token */
+    int64_t *token;               /* [dev] [B] out */
+} lantern_step_dense;
+
 /* ------------------------------------------------------------------------------------
  * One verify step of G independent groups of sequences in ONE call: for every group, on the group's own stream,
  *   O6 lantern_gather_candidates -> O7 lantern_cfg_mask_topk_window -> O8 lantern_evaluate_posterior_nodes (nodes != NULL) or
@@ -470,6 +485,7 @@ typedef struct lantern_step_group {
                                              (a tree that came with its token list, ea_model_llamagen.py:1125-1131; or lantern_gather_candidates called
                                              before the target forward).  A static group with neither is an error, not a silent skip. */
     const lantern_step_greedy *greedy;    /* NULL: relaxed rejection sampling (evaluate_posterior); else the greedy / TVD accept above */
+    const lantern_step_dense *dense;      /* NULL: the windowed kernels; else the dense kernel set above */
 } lantern_step_group;
 #define LANTERN_TURN_WORDS(n_groups) (16 * (1 + 33 * (n_groups)))   /* int64 words of lantern_step_group.turn */
 #define LANTERN_STEP_CANDIDATES_READY 1   /* lantern_step_group.flags: skip the O6 stage, `cand` / `retrieve` (/ `cart_prob`, `tree_cand`) are final */

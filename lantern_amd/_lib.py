@@ -74,6 +74,11 @@ class StepGreedy(C.Structure):
                 ("win_lo", C.c_int32), ("win_len", C.c_int32), ("ok_scratch", C.c_void_p), ("out_row", C.c_void_p), ("token", C.c_void_p)]
 
 
+class StepDense(C.Structure):
+    """lantern_step_dense (include/lantern_hip.h): the dense kernel set as the O7 / O8 stages of a group of lantern_verify_step."""
+    _fields_ = [("logits", C.c_void_p), ("sample_p", C.c_void_p), ("u_bonus", C.c_void_p), ("token", C.c_void_p)]
+
+
 class StepGroup(C.Structure):
     """lantern_step_group (include/lantern_hip.h): one group of sequences of lantern_verify_step."""
     _fields_ = ([("stream", C.c_void_p)]
@@ -93,7 +98,7 @@ class StepGroup(C.Structure):
                 + [("node_list", C.c_void_p), ("n_list", C.c_int32), ("flags", C.c_int32)]
                 + [("hidden_uncond", C.c_void_p), ("ids_buf", C.c_void_p), ("ids_stride", C.c_int64), ("ids_len", C.c_void_p), ("prepare_next", C.c_void_p)]
                 + [("turn", C.c_void_p), ("turn_group", C.c_int32), ("turn_groups", C.c_int32), ("turn_wait", C.c_int64)]
-                + [("dyn", C.POINTER(StepDynamic)), ("greedy", C.POINTER(StepGreedy))])
+                + [("dyn", C.POINTER(StepDynamic)), ("greedy", C.POINTER(StepGreedy)), ("dense", C.POINTER(StepDense))])
 
 
 class DraftDepthArgs(C.Structure):

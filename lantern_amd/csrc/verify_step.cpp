@@ -39,6 +39,15 @@ extern "C" int lantern_verify_step(const lantern_step_group *groups, int n_group
     int rc;
     for (int g = 0; g < n_groups; ++g) {          // (before anything is launched: a walk that waits for a turn nobody will release spins out its bound)
         const lantern_step_group &s = groups[g];
+        if (s.dense) {
+            const lantern_step_dense &q = *s.dense;
+            if (!q.logits || !q.sample_p || (q.token != nullptr) != (q.u_bonus != nullptr) || s.nodes || s.greedy || (s.node_list && s.n_list > 0) || s.prepare_next ||
+                s.turn || s.ep_win.verdict_host || (s.flags & LANTERN_STEP_PREPARED)) {
+                lantern::set_error("dense step: logits / sample_p, token and u_bonus together, and none of nodes / greedy / node_list / prepare_next / turn / "
+                                   "ep_win.verdict_host / LANTERN_STEP_PREPARED");
+                return fail(g, "dense", LANTERN_E_INVALID);
+            }
+        }
         if (s.turn && (s.turn_groups <= 0 || s.turn_group < 0 || s.turn_group >= s.turn_groups || !s.slab_ptrs)) {
             lantern::set_error("commit turn-taking: turn_group in [0, turn_groups) and the group's KV slabs (its commit launch releases the turn)");
             return fail(g, "turn", LANTERN_E_INVALID);
@@ -97,6 +106,13 @@ extern "C" int lantern_verify_step(const lantern_step_group *groups, int n_group
             if (rc) return fail(g, "cfg_mask_topk", rc);
             continue;
         }
+        if (s.dense) {           // the dense kernel set: every row at the full vocabulary (the reference's own intermediate tensor, ea_model_lumina_mgpt.py:597-605)
+            if (!s.cond) continue;          // (the caller's rows are already in dense->logits)
+            rc = lantern_cfg_mask_topk(s.cond, s.uncond, s.dtype, s.B * s.N, s.V, s.cfg, s.model, s.pos_ids, s.pos_base, s.w_latent, s.h_latent, s.img_lo,
+                                       s.img_hi, s.newline_id, s.eos_id, s.top_k, s.seq_len, s.N, s.dense->logits, s.stream);
+            if (rc) return fail(g, "cfg_mask_topk", rc);
+            continue;
+        }
         if (!s.out_win || (s.node_list && s.n_list > 0)) continue;          // LANTERN_ROWS_RAW_BF16: evaluate_posterior post-processes the rows it visits itself
         rc = lantern_cfg_mask_topk_window(s.cond, s.uncond, s.dtype, s.B * s.N, s.V, s.cfg, s.model, s.pos_ids, s.pos_base, s.w_latent,
                                           s.h_latent, s.img_lo, s.img_hi, s.newline_id, s.eos_id, s.top_k, s.seq_len, s.N, s.win_lo,
@@ -115,6 +131,20 @@ extern "C" int lantern_verify_step(const lantern_step_group *groups, int n_group
             rc = lantern_accept_gather(nullptr, 0, s.B, 1, s.N, 0, s.retrieve, 0, s.P, s.D, nullptr, s.ep_buf.best, s.ep_buf.accept_len, q.out_row, s.V, nullptr,
                                        nullptr, nullptr, q.token, s.stream);
             if (rc) return fail(g, "bonus argmax", rc);
+            continue;
+        }
+        if (s.dense) {
+            const lantern_step_dense &q = *s.dense;
+            lantern_ep_buffers b = s.ep_buf;
+            b.logits = q.logits;
+            b.sample_p = q.sample_p;
+            rc = lantern_evaluate_posterior(&s.ep, &b, s.stream);
+            if (rc) return fail(g, "evaluate_posterior (dense)", rc);
+            if (q.token) {          // the bonus token: inverse CDF of sample_p at this step's uniform (ea_model_lumina_mgpt.py:779-790)
+                rc = lantern_accept_gather(nullptr, 0, s.B, 1, s.N, 0, s.dyn ? s.dyn->retrieve_pd : s.retrieve, s.dyn ? 1 : 0, s.P, s.D, nullptr, s.ep_buf.best,
+                                           s.ep_buf.accept_len, q.sample_p, s.V, q.u_bonus, nullptr, nullptr, q.token, s.stream);
+                if (rc) return fail(g, "bonus draw", rc);
+            }
             continue;
         }
         if (s.turn && !s.nodes && s.slab_ptrs) {          // commit turn-taking: the chain kernel ends when it is this group's turn to commit
@@ -163,7 +193,7 @@ extern "C" int lantern_verify_step(const lantern_step_group *groups, int n_group
                                                      s.dyn ? s.dyn->retrieve_pd : s.retrieve, s.dyn ? 1 : 0, s.P, s.D, s.ep_buf.best,
                                                      s.ep_buf.accept_len, s.new_len, s.hidden, s.hid_elem_bytes, s.B, s.hid_groups, s.N, s.H,
                                                      s.cand, s.out_hidden, s.accepted_tokens, s.ep_buf.counters, s.stream, s.hidden_uncond, s.ids_buf,
-                                                     s.ids_stride, s.ids_len, s.ids_buf ? (s.greedy ? s.greedy->token : s.ep_win.token) : nullptr, prep,
+                                                     s.ids_stride, s.ids_len, s.ids_buf ? (s.greedy ? s.greedy->token : (s.dense ? s.dense->token : s.ep_win.token)) : nullptr, prep,
                                                      s.turn ? &ta : nullptr);
         if (rc) return fail(g, "update_inference_inputs", rc);
     }

@@ -111,6 +111,7 @@ class WorkloadConfig:
                                     # softmax) the rows its walk visits from the raw cond / uncond logits
     spec_rows: int = 0              # with fuse_o7: this many of the tree's most likely nodes (the root first) get their rows post-processed
                                     # up front, in the same launch as the candidate assembly (lantern_prepare_step); the rest on demand
+    dense_one_call: bool = True     # dense path with KV slabs: the step through ONE C call (lantern_step_group.dense); False: one ctypes call per kernel
     native_step: bool = True        # eager windowed path: the whole step of all groups through ONE C call (lantern_verify_step) instead of
                                     # 4 x n_groups ctypes calls (the Python launch loop caps the stream groups at ~2 otherwise)
     leaf_workgroups: int = -1       # node kernel: -1 = by batch size (include/lantern_hip.h lantern_ep_nodes)
@@ -633,6 +634,35 @@ class LuminaVerifyWorkload:
                 s.hid_elem_bytes, s.hid_groups, s.H = 2, 2, HIDDEN
         return arr
 
+    def _dense_group(self, slot: int, parity: int, g: int):
+        """lantern_step_group of the DENSE kernel set for group g (lantern_step_group.dense): cached, only the stream and the sample token change."""
+        key = (slot, parity, g)
+        cache = self.__dict__.setdefault("_densecache", {})
+        if key in cache:
+            return cache[key][0]
+        c, A, s, q = self.cfg, self._group_args(slot, parity, g), StepGroup(), _lib.StepDense()
+        val = lambda x: None if x is None else (x.value if isinstance(x, C.c_void_p) else x)
+        s.ss_token, s.ss_prob = val(A["ss_token"]), val(A["ss_prob"])
+        s.tree_indices, s.retrieve = self.d_tree_indices.data_ptr(), self.d_retrieve.data_ptr()
+        s.B, s.n_flat, s.N, s.P, s.D = self.Bg, self.R * 10, self.N, self.P, self.D
+        s.tree_cand, s.cand, s.cart_prob = val(A["tree_cand"]), val(A["cand"]), val(A["cart_prob"])
+        s.cond, s.uncond, s.dtype, s.V, s.cfg, s.model = val(A["cond"]), val(A["uncond"]), 1, V, c.cfg_scale, self.o7_model
+        s.pos_ids, s.pos_base = self.d_pos_ids.data_ptr(), c.prompt_len + 3
+        s.w_latent, s.h_latent = (0, 0) if self.anole else (W_LATENT, H_LATENT)
+        s.img_lo, s.img_hi, s.newline_id, s.eos_id, s.top_k = IMG_LO, IMG_HI, NEWLINE, EOS, c.top_k
+        s.seq_len, s.temperature, s.top_p = val(A["cur"]), 1.0, c.top_p
+        C.memmove(C.byref(s.ep), C.byref(self._ep_prm), C.sizeof(EpParams))
+        C.memmove(C.byref(s.ep_buf), C.byref(A["ep_buf"]), C.sizeof(EpBuffers))
+        s.ep_buf.best, s.ep_buf.accept_len, s.ep_buf.counters = val(A["st_best"]), val(A["st_alen"]), val(A["st_cnt"])
+        s.slab_ptrs, s.slab_seq, s.slab_prev, s.new_len = val(A["slab_ptrs"]), val(A["slab_seq"]), val(A["cur"]), val(A["nxt"])
+        s.n_slabs, s.elem_bytes, s.outer, s.S_max, s.d = 2 * self.Bg, 2, 2 * c.kv_layers * c.kv_heads, c.kv_smax + c.kv_pad_rows, c.kv_dim
+        s.hidden, s.out_hidden, s.accepted_tokens = val(A["hidden"]), val(A["out_hidden"]), val(A["acc_tokens"])
+        s.hid_elem_bytes, s.hid_groups, s.H = 2, 2, HIDDEN
+        q.logits, q.sample_p, q.u_bonus, q.token = val(A["proc"]), val(A["sample_p"]), val(A["u_cur"]), val(A["st_token"])
+        s.dense = C.pointer(q)
+        cache[key] = (s, q)
+        return s
+
     def _native_step(self, slot: int, parity: int):
         """One C call enqueues O6 -> O7 -> O8 -> O9 + O10 of every group (each on its stream); results land in the step's log row."""
         c = self.cfg
@@ -773,81 +803,88 @@ class LuminaVerifyWorkload:
                 eb, ew = A["ep_buf"], A["ep_win"]
                 eb.best, eb.accept_len, eb.counters = A["st_best"].value, A["st_alen"].value, A["st_cnt"].value
                 ew.u_bonus, ew.token = A["u_cur"].value, A["st_token"].value
-        if self.n_spec:               # candidates + the likely rows in one launch (the step's own argument block, this step's sample token)
-            sg = self._steps[(slot, parity)][g]
+        # the dense kernel set as ONE call (lantern_step_group.dense): O6 -> O7 over all rows at the full vocabulary -> the dense evaluate_posterior -> the bonus
+        # draw -> the commit launch; the per-kernel form below stays for the timing pass (events), the side-stream variant and workloads without KV slabs
+        if (not self.windowed) and c.dense_one_call and c.with_kv and side is None and not events:
+            sg = self._dense_group(slot, parity, g)
             sg.stream, sg.sample_token = st.value, p_sample.value
-            if events:
-                self._arm(events, "cfg_mask_topk")
-            check(L.lantern_prepare_step(C.byref(sg)), "prepare_step")
-        # O6 candidate assembly (side stream: only needs the sample token)
+            check(L.lantern_verify_step(C.byref(sg), 1), "verify_step")
         else:
-            check(L.lantern_gather_candidates(A["ss_token"], A["ss_prob"], p_sample, vp(self.d_tree_indices.data_ptr()),
-                                          vp(self.d_retrieve.data_ptr()), B, self.R * 10, N, P, D, A["tree_cand"], A["cand"], A["cart_prob"],
-                                          st_side), "gather_candidates")
-        if side is not None:
-            ev[1].record(side)
-        # O7 CFG + Lumina position mask + top-k, positions from the device-side lengths
-        if events and not self.fused_o7:
-            self._arm(events, "cfg_mask_topk")
-        if self.fused_o7:
-            pass                                  # evaluate_posterior reads the raw logits itself
-        elif self.windowed:
-            check(L.lantern_cfg_mask_topk_window(A["cond"], A["uncond"], 1, B * N, V, C.c_float(c.cfg_scale), self.o7_model,
-                                                 vp(self.d_pos_ids.data_ptr()), C.c_int64(c.prompt_len + 3), W_LATENT, H_LATENT, IMG_LO, IMG_HI,
-                                                 NEWLINE, EOS, c.top_k, A["cur"], N, self.win_lo, self.W, A["proc"], A["row_hot"],
-                                                 ops.ROWS_PROBS if c.rows_probs else ops.ROWS_LOGITS, C.c_float(1.0), C.c_float(c.top_p), st),
-                  "cfg_mask_topk_window")
-        else:
-            check(L.lantern_cfg_mask_topk(A["cond"], A["uncond"], 1, B * N, V, C.c_float(c.cfg_scale), self.o7_model,
-                                          vp(self.d_pos_ids.data_ptr()), C.c_int64(c.prompt_len + 3), W_LATENT, H_LATENT, IMG_LO, IMG_HI,
-                                          NEWLINE, EOS, c.top_k, A["cur"], N, A["proc"], st), "cfg_mask_topk")
-        if events:
-            if not self.fused_o7:
-                self._disarm(events, "cfg_mask_topk")
-            self._arm(events, "evaluate_posterior")
-        if side is not None:
-            main.wait_event(ev[1])                # O8 needs the candidates
-        # O8 (windowed: the bonus token is drawn in the kernel epilogue)
-        if self.windowed and self.ep_nodes is not None:
-            check(L.lantern_evaluate_posterior_nodes(C.byref(self._ep_prm), C.byref(A["ep_buf"]), C.byref(A["ep_win"]),
-                                                     C.byref(self.ep_nodes[g]), st), "evaluate_posterior_nodes")
-        elif self.windowed:
-            check(L.lantern_evaluate_posterior_window(C.byref(self._ep_prm), C.byref(A["ep_buf"]), C.byref(A["ep_win"]), st),
-                  "evaluate_posterior_window")
-        else:
-            check(L.lantern_evaluate_posterior(C.byref(self._ep_prm), C.byref(A["ep_buf"]), st), "evaluate_posterior")
-        if events:
-            self._disarm(events, "evaluate_posterior")
-        if side is not None:
-            ev[2].record(main)
-            side.wait_event(ev[2])
-        fused = c.with_kv and self.windowed and c.fuse_update and side is None
-        if not fused:
-            # O10 accepted hidden + token append (+ bonus token on the dense path); side stream: beside the KV gather
-            check(L.lantern_accept_gather(A["hidden"], 2, B, 2, N, HIDDEN, vp(self.d_retrieve.data_ptr()), 0, P, D, A["cand"], p_best,
-                                          p_alen, A["sample_p"], V, None if self.windowed else A["u_cur"], A["out_hidden"],
-                                          A["acc_tokens"], None if self.windowed else A["st_token"], st_side), "accept_gather")
-        if side is not None:
-            ev[3].record(side)
-        # O9 KV gather: both slabs of every sequence of the group in one launch (fused: + the O10 copy, as the reference's
-        # update_inference_inputs does both)
-        if c.with_kv:
-            if events:
-                self._arm(events, "kv_gather")
-            if fused:
-                check(L.lantern_update_inference_inputs(A["slab_ptrs"], A["slab_seq"], A["cur"], 2 * B, 2, C.c_int64(2 * c.kv_layers * c.kv_heads),
-                                                        C.c_int64(c.kv_smax + c.kv_pad_rows), C.c_int64(c.kv_dim), vp(self.d_retrieve.data_ptr()),
-                                                        0, P, D, p_best, p_alen, A["nxt"], A["hidden"], 2, B, 2, N, HIDDEN,
-                                                        A["cand"], A["out_hidden"], A["acc_tokens"], st), "update_inference_inputs")
+            if self.n_spec:               # candidates + the likely rows in one launch (the step's own argument block, this step's sample token)
+                sg = self._steps[(slot, parity)][g]
+                sg.stream, sg.sample_token = st.value, p_sample.value
+                if events:
+                    self._arm(events, "cfg_mask_topk")
+                check(L.lantern_prepare_step(C.byref(sg)), "prepare_step")
+            # O6 candidate assembly (side stream: only needs the sample token)
             else:
-                check(L.lantern_kv_gather(A["slab_ptrs"], A["slab_seq"], A["cur"], 2 * B, 2, C.c_int64(2 * c.kv_layers * c.kv_heads),
-                                          C.c_int64(c.kv_smax + c.kv_pad_rows), C.c_int64(c.kv_dim), vp(self.d_retrieve.data_ptr()), 0, P, D,
-                                          p_best, p_alen, A["nxt"], st), "kv_gather")
+                check(L.lantern_gather_candidates(A["ss_token"], A["ss_prob"], p_sample, vp(self.d_tree_indices.data_ptr()),
+                                              vp(self.d_retrieve.data_ptr()), B, self.R * 10, N, P, D, A["tree_cand"], A["cand"], A["cart_prob"],
+                                              st_side), "gather_candidates")
+            if side is not None:
+                ev[1].record(side)
+            # O7 CFG + Lumina position mask + top-k, positions from the device-side lengths
+            if events and not self.fused_o7:
+                self._arm(events, "cfg_mask_topk")
+            if self.fused_o7:
+                pass                                  # evaluate_posterior reads the raw logits itself
+            elif self.windowed:
+                check(L.lantern_cfg_mask_topk_window(A["cond"], A["uncond"], 1, B * N, V, C.c_float(c.cfg_scale), self.o7_model,
+                                                     vp(self.d_pos_ids.data_ptr()), C.c_int64(c.prompt_len + 3), W_LATENT, H_LATENT, IMG_LO, IMG_HI,
+                                                     NEWLINE, EOS, c.top_k, A["cur"], N, self.win_lo, self.W, A["proc"], A["row_hot"],
+                                                     ops.ROWS_PROBS if c.rows_probs else ops.ROWS_LOGITS, C.c_float(1.0), C.c_float(c.top_p), st),
+                      "cfg_mask_topk_window")
+            else:
+                check(L.lantern_cfg_mask_topk(A["cond"], A["uncond"], 1, B * N, V, C.c_float(c.cfg_scale), self.o7_model,
+                                              vp(self.d_pos_ids.data_ptr()), C.c_int64(c.prompt_len + 3), W_LATENT, H_LATENT, IMG_LO, IMG_HI,
+                                              NEWLINE, EOS, c.top_k, A["cur"], N, A["proc"], st), "cfg_mask_topk")
             if events:
-                self._disarm(events, "kv_gather")
-        else:
-            s0 = g * self.Bg
-            torch.add(self.lens[parity][2 * s0:2 * s0 + 2 * B], ((self.log_alen[self.step_idx, s0:s0 + B] if direct else self.st_alen[s0:s0 + B]) + 1).repeat(2), out=self.lens[parity ^ 1][2 * s0:2 * s0 + 2 * B])
+                if not self.fused_o7:
+                    self._disarm(events, "cfg_mask_topk")
+                self._arm(events, "evaluate_posterior")
+            if side is not None:
+                main.wait_event(ev[1])                # O8 needs the candidates
+            # O8 (windowed: the bonus token is drawn in the kernel epilogue)
+            if self.windowed and self.ep_nodes is not None:
+                check(L.lantern_evaluate_posterior_nodes(C.byref(self._ep_prm), C.byref(A["ep_buf"]), C.byref(A["ep_win"]),
+                                                         C.byref(self.ep_nodes[g]), st), "evaluate_posterior_nodes")
+            elif self.windowed:
+                check(L.lantern_evaluate_posterior_window(C.byref(self._ep_prm), C.byref(A["ep_buf"]), C.byref(A["ep_win"]), st),
+                      "evaluate_posterior_window")
+            else:
+                check(L.lantern_evaluate_posterior(C.byref(self._ep_prm), C.byref(A["ep_buf"]), st), "evaluate_posterior")
+            if events:
+                self._disarm(events, "evaluate_posterior")
+            if side is not None:
+                ev[2].record(main)
+                side.wait_event(ev[2])
+            fused = c.with_kv and self.windowed and c.fuse_update and side is None
+            if not fused:
+                # O10 accepted hidden + token append (+ bonus token on the dense path); side stream: beside the KV gather
+                check(L.lantern_accept_gather(A["hidden"], 2, B, 2, N, HIDDEN, vp(self.d_retrieve.data_ptr()), 0, P, D, A["cand"], p_best,
+                                              p_alen, A["sample_p"], V, None if self.windowed else A["u_cur"], A["out_hidden"],
+                                              A["acc_tokens"], None if self.windowed else A["st_token"], st_side), "accept_gather")
+            if side is not None:
+                ev[3].record(side)
+            # O9 KV gather: both slabs of every sequence of the group in one launch (fused: + the O10 copy, as the reference's
+            # update_inference_inputs does both)
+            if c.with_kv:
+                if events:
+                    self._arm(events, "kv_gather")
+                if fused:
+                    check(L.lantern_update_inference_inputs(A["slab_ptrs"], A["slab_seq"], A["cur"], 2 * B, 2, C.c_int64(2 * c.kv_layers * c.kv_heads),
+                                                            C.c_int64(c.kv_smax + c.kv_pad_rows), C.c_int64(c.kv_dim), vp(self.d_retrieve.data_ptr()),
+                                                            0, P, D, p_best, p_alen, A["nxt"], A["hidden"], 2, B, 2, N, HIDDEN,
+                                                            A["cand"], A["out_hidden"], A["acc_tokens"], st), "update_inference_inputs")
+                else:
+                    check(L.lantern_kv_gather(A["slab_ptrs"], A["slab_seq"], A["cur"], 2 * B, 2, C.c_int64(2 * c.kv_layers * c.kv_heads),
+                                              C.c_int64(c.kv_smax + c.kv_pad_rows), C.c_int64(c.kv_dim), vp(self.d_retrieve.data_ptr()), 0, P, D,
+                                              p_best, p_alen, A["nxt"], st), "kv_gather")
+                if events:
+                    self._disarm(events, "kv_gather")
+            else:
+                s0 = g * self.Bg
+                torch.add(self.lens[parity][2 * s0:2 * s0 + 2 * B], ((self.log_alen[self.step_idx, s0:s0 + B] if direct else self.st_alen[s0:s0 + B]) + 1).repeat(2), out=self.lens[parity ^ 1][2 * s0:2 * s0 + 2 * B])
         if side is not None:
             main.wait_event(ev[3])                # join (the dense path's bonus token feeds the bookkeeping below)
         # harness bookkeeping (sequence management, not the hot path): logs, next sample token, image wrap-around, step counter

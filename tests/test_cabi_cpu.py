@@ -133,13 +133,15 @@ def test_step_group_layout_matches_the_c_struct(tmp_path):
     import subprocess
     wfields = ["row_hot", "rows_kind", "raw_uncond", "raw_pos_base", "raw_cfg", "raw_eos_id", "raw_probs", "raw_pre", "verdict_host", "turn", "turn_wait"]
     fields = ["stream", "B", "tree_cand", "cond", "pos_base", "w_latent", "seq_len", "temperature", "ep", "ep_buf", "ep_win", "nodes",
-              "slab_ptrs", "n_slabs", "outer", "hidden", "H", "node_list", "n_list", "flags", "hidden_uncond", "ids_buf", "ids_stride", "ids_len", "prepare_next", "turn", "turn_group", "turn_groups", "turn_wait", "dyn", "greedy"]
+              "slab_ptrs", "n_slabs", "outer", "hidden", "H", "node_list", "n_list", "flags", "hidden_uncond", "ids_buf", "ids_stride", "ids_len", "prepare_next", "turn", "turn_group", "turn_groups", "turn_wait", "dyn", "greedy", "dense"]
     src = tmp_path / "layout.c"
     gfields = [f for f, _ in _lib.StepGreedy._fields_]
+    dfields = [f for f, _ in _lib.StepDense._fields_]
     src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "lantern_hip.h"\nint main(void){printf("%zu %zu", sizeof(lantern_step_group), sizeof(lantern_ep_nodes));\n'
                    + "".join(f'printf(" %zu", offsetof(lantern_step_group, {f}));\n' for f in fields)
                    + 'printf(" %zu", sizeof(lantern_ep_window));\n' + "".join(f'printf(" %zu", offsetof(lantern_ep_window, {f}));\n' for f in wfields)
-                   + 'printf(" %zu", sizeof(lantern_step_greedy));\n' + "".join(f'printf(" %zu", offsetof(lantern_step_greedy, {f}));\n' for f in gfields) + "return 0;}\n")
+                   + 'printf(" %zu", sizeof(lantern_step_greedy));\n' + "".join(f'printf(" %zu", offsetof(lantern_step_greedy, {f}));\n' for f in gfields)
+                   + 'printf(" %zu", sizeof(lantern_step_dense));\n' + "".join(f'printf(" %zu", offsetof(lantern_step_dense, {f}));\n' for f in dfields) + "return 0;}\n")
     exe = tmp_path / "layout"
     subprocess.check_call(["gcc", "-std=c99", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
     out = [int(x) for x in subprocess.check_output([str(exe)]).split()]
@@ -148,7 +150,9 @@ def test_step_group_layout_matches_the_c_struct(tmp_path):
     assert out[2:2 + nf] == [getattr(_lib.StepGroup, f).offset for f in fields]
     nw = len(wfields)
     assert out[2 + nf] == C.sizeof(_lib.EpWindow) and out[3 + nf:3 + nf + nw] == [getattr(_lib.EpWindow, f).offset for f in wfields]
-    assert out[3 + nf + nw] == C.sizeof(_lib.StepGreedy) and out[4 + nf + nw:] == [getattr(_lib.StepGreedy, f).offset for f in gfields]
+    ng = len(gfields)
+    assert out[3 + nf + nw] == C.sizeof(_lib.StepGreedy) and out[4 + nf + nw:4 + nf + nw + ng] == [getattr(_lib.StepGreedy, f).offset for f in gfields]
+    assert out[4 + nf + nw + ng] == C.sizeof(_lib.StepDense) and out[5 + nf + nw + ng:] == [getattr(_lib.StepDense, f).offset for f in dfields]
 
 
 def test_draft_depth_args_layout_matches_the_c_struct(tmp_path):
@@ -218,6 +222,24 @@ def test_round2_entry_points_validate_without_gpu():
     assert L.lantern_prepare_step(C.byref(g)) == -1 and b"dynamic-tree buffers missing" in L.lantern_last_error()   # the form is accepted, the (empty) tree block is not
     g.win_len = 8192
     assert L.lantern_prepare_step(C.byref(g)) == -1 and b"LlamaGen dynamic trees" in L.lantern_last_error()
+
+
+def test_dense_step_block_is_validated_before_anything_is_launched():
+    """lantern_step_group.dense (the dense kernel set inside lantern_verify_step): its two buffers, token and u_bonus together, and none of the stages it
+    cannot be combined with -- checked on the host, up front."""
+    L = _lib.lib()
+    g, q = _lib.StepGroup(), _lib.StepDense()
+    g.dense = C.pointer(q)
+    assert L.lantern_verify_step(C.byref(g), 1) == -1 and L.lantern_last_error().startswith(b"verify_step: group 0, dense: dense step")
+    q.logits = q.sample_p = 0x1000
+    q.token = 0x1000                   # (without its uniform)
+    assert L.lantern_verify_step(C.byref(g), 1) == -1 and b"token and u_bonus together" in L.lantern_last_error()
+    q.u_bonus = 0x1000
+    nl = (C.c_int32 * 2)(0, 1)
+    g.node_list, g.n_list = C.cast(nl, C.c_void_p).value, 2
+    assert L.lantern_verify_step(C.byref(g), 1) == -1 and b"node_list" in L.lantern_last_error()
+    g.node_list, g.n_list = None, 0
+    assert L.lantern_verify_step(C.byref(g), 1) == -1 and L.lantern_last_error().startswith(b"verify_step: group 0, gather_candidates: ")   # the block itself is accepted
 
 
 def test_linear_rows_packed_validates_without_gpu():

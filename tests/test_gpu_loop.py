@@ -575,3 +575,34 @@ def test_commit_turn_taking_changes_the_schedule_not_the_results(groups, window,
             assert not t[1:].any(), "every completion counter is back at zero once its launch is done"
     for a, b in zip(*outs):
         assert torch.equal(a, b)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("groups", [1, 2])
+def test_dense_kernel_set_through_verify_step(groups):
+    """lantern_step_group.dense (missing 4): O6 -> O7 over all rows at the full vocabulary -> the dense evaluate_posterior -> the bonus draw ->
+    the commit launch in ONE call, against the same kernels called one by one (lantern_gather_candidates, lantern_cfg_mask_topk, lantern_evaluate_posterior,
+    lantern_accept_gather, lantern_kv_gather): verdicts, bonus tokens, distributions, KV slabs, lengths, accepted hidden rows and token lists, step after step."""
+    from lantern_amd import harness as HN
+    mk = lambda one: HN.LuminaVerifyWorkload(HN.WorkloadConfig(n_seq=4, pool_steps=2, path="dense", kv_layers=2, kv_heads=4, kv_smax=256, max_steps=12, sigma=4.0,
+                                                               n_groups=groups, dense_one_call=one), torch.device("cuda"))
+    a, b = mk(True), mk(False)
+    gen = torch.Generator(device="cuda").manual_seed(11)
+    for x, y in zip(a.slabs, b.slabs):
+        x.copy_(torch.randn(x.shape, device="cuda", generator=gen).to(torch.bfloat16))
+        y.copy_(x)
+    for i in range(8):
+        for w in (a, b):
+            w.step()
+            w.join()
+        torch.cuda.synchronize()
+        assert torch.equal(a.sample_p, b.sample_p) and torch.equal(a.out_hidden, b.out_hidden) and torch.equal(a.acc_tokens, b.acc_tokens), i
+        for x, y in zip(a.lens, b.lens):
+            assert torch.equal(x, y), i
+    a.check_status(0, 8)
+    for k in ("log_best", "log_alen", "log_cnt", "log_token"):
+        assert torch.equal(getattr(a, k)[:8], getattr(b, k)[:8]), k
+    for x, y in zip(a.slabs, b.slabs):
+        assert torch.equal(x, y)
+    assert int(a.log_alen[:8].sum()) > 0 and a._densecache and not getattr(b, "_densecache", None)
+

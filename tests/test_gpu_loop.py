@@ -302,7 +302,13 @@ def test_llamagen_dynamic_loop_with_top_p(fuse, spec):
     _llamagen_dynamic_loop(fuse, 1, spec, 0.8)
 
 
-def _llamagen_dynamic_loop(fuse, groups, spec, top_p):
+def test_llamagen_dynamic_loop_throughput_instance():
+    """More sequences per launch than CUs: LlamaGen's two-per-CU instance of the chain kernel (epw_kernel<512, 8, 1, 4, true, false, 5, ..>, EwSharedLite) on
+    probability rows inside the device-resident loop, every 11th sequence held to the oracle's loop."""
+    _llamagen_dynamic_loop(False, 1, 0, 1.0, n_seq=264, steps=3, every=11)
+
+
+def _llamagen_dynamic_loop(fuse, groups, spec, top_p, n_seq=None, steps=8, every=1):
     """BASELINE config 2 (LlamaGen + EAGLE, standard verify: V = 16384 = the window, LANTERN off, HF processors T = 1 / top_k 2000) through the
     device-resident dynamic loop, with O7 over all rows and with the raw cond / uncond rows post-processed inside evaluate_posterior (the
     1024-thread raw-row instance): the oracle's loop over the same pools / uniforms gives the same (best path, accept length, bonus token) for
@@ -312,8 +318,7 @@ def _llamagen_dynamic_loop(fuse, groups, spec, top_p):
     from lantern_amd import harness as HN
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import helpers as H
-    steps = 8
-    cfg = HN.DynamicConfig(model="llamagen", n_seq=3 * groups, pool_steps=2, depth=4, kv_layers=2, kv_heads=4, kv_dim=64, kv_smax=512, max_steps=steps + 2,
+    cfg = HN.DynamicConfig(model="llamagen", n_seq=n_seq or 3 * groups, pool_steps=2, depth=4, kv_layers=2, kv_heads=4, kv_dim=64, kv_smax=512, max_steps=steps + 2,
                            fuse_o7=fuse, n_groups=groups, spec_rows=spec, top_p=top_p)
     wl = HN.DynamicVerifyWorkload(cfg, torch.device("cuda"))
     assert wl.fused_o7 == fuse and wl.lg and wl.n_spec == (spec if fuse else 0)
@@ -326,7 +331,7 @@ def _llamagen_dynamic_loop(fuse, groups, spec, top_p):
     ocfg = oracle.EpConfig.llamagen(False, lantern=False, temperature=1.0, top_p=top_p, top_k=cfg.logit_top_k)      # the HF processors run inside evaluate_posterior
     N = wl.N
     n_acc = 0
-    for b in range(cfg.n_seq):
+    for b in range(0, cfg.n_seq, every):
         tok, cursor = int(wl.first_token[b]), 0
         for i in range(steps):
             p = wl.pools[i % cfg.pool_steps]

@@ -392,6 +392,57 @@ def ep_batch_sweep(batches, device, base_cfg, iters=24, kernels=("chain", "nodes
     return out
 
 
+def lg_batch_sweep(batches, device, iters=10, variants=(1,), reps=1):
+    """evaluate_posterior alone for LlamaGen's standard verify (BASELINE config 2: V = window = 16384 ids, EAGLE-2 trees of 59 nodes, LANTERN off) at batches beyond the
+    CU count: the two-per-CU throughput instance `epw_kernel<512, 8, 1, 4, true, false, 5, ..>` (lantern_tuning_set("epw_tp_lg", 1), the default: rows by LDS-DMA) and,
+    on request, its variants (2: + second LDS pass for the residual, 3: rows through registers, 4: + raised priority) and the generic one-per-CU instance (0), alternating
+    inside one process.  Probability rows (O7 over all 59 rows of every sequence, its own launch) -- 3.9 MB per sequence and step, so one step's rows (16 GB at 4096
+    sequences) never sit in a cache.  HIP events around the launch (lantern_profile_next_launch); `frac` = (visited levels + fresh final rows) x 64 KB / time / 8 TB/s."""
+    from lantern_amd import _lib as _L
+    from lantern_amd import harness as HN
+    out = []
+    for B in batches:
+        need = B * (2 * 2 * 59 * 16384 * 2 + 59 * 16384 * 4 * 3) + (6 << 30)
+        free, _ = torch.cuda.mem_get_info(device)
+        if need > free:
+            out.append({"sequences_per_launch": B, "skipped": f"needs {need >> 30} GiB, {free >> 30} GiB free"})
+            continue
+        dc = HN.DynamicConfig(model="llamagen", n_seq=B, depth=4, total_tokens=58, kv_layers=12, kv_heads=12, kv_dim=64, with_kv=False, pool_steps=2,
+                              max_steps=reps * len(variants) * (iters + 2) + 16, plausible=8.0, n_groups=1, fuse_o7=False, native_step=False)
+        wl = HN.DynamicVerifyWorkload(dc, device)
+        for _ in range(2):
+            wl.step()
+        torch.cuda.synchronize(device)
+        names = event_names(wl)
+        row = {"sequences_per_launch": B, "window": wl.W, "nodes": wl.N, "variants": {}}
+        step = 2
+        try:
+            for _rep in range(reps):
+                for v in variants:
+                    _L.set_tuning("epw_tp_lg", v)
+                    wl.step()
+                    step += 1
+                    evs = make_events(names, iters, device)
+                    for i in range(iters):
+                        wl.step(evs[i])
+                    torch.cuda.synchronize(device)
+                    cnt = wl.log_cnt[step:step + iters, :wl.Bg].double()
+                    step += iters
+                    ms = float(np.median([e["evaluate_posterior"][0].elapsed_time(e["evaluate_posterior"][1]) for e in evs]))
+                    needed = float(((cnt[..., 0] + (1.0 - cnt[..., 4])) * wl.W * 4).sum() / iters)
+                    o7 = float(np.median([e["cfg_mask_topk"][0].elapsed_time(e["cfg_mask_topk"][1]) for e in evs]))
+                    row["variants"].setdefault(str(v), []).append({"launch_us": 1e3 * ms, "needed_bytes_per_launch": needed, "achieved_GBps": needed / (ms * 1e-3) / 1e9,
+                                                                   "frac": needed / (ms * 1e-3) / 1e9 / 8000.0, "levels_per_sequence": float(cnt[..., 0].mean()),
+                                                                   "cfg_mask_topk_us": 1e3 * o7, "cfg_mask_topk_frac": B * wl.N * wl.W * (2 * 2 + 4) / (o7 * 1e-3) / 8e12})
+        finally:
+            _L.set_tuning("epw_tp_lg", 1)
+        wl.check_status(0, step)
+        out.append(row)
+        del wl
+        torch.cuda.empty_cache()
+    return out
+
+
 # the sources of the kernels bench.py times (the verify step: candidate assembly / row post-process, the windowed evaluate_posterior kernels, the KV /
 # hidden commit, the one-call sequencing); the dense evaluate_posterior (evaluate_posterior.hip: never on the timed path) and the drafter-side files
 # (drafter_fc, draft_depth, tree_attention, vq_table, greedy, tree_static) are not part
@@ -689,6 +740,19 @@ def other_configs(device, base_cfg, steps, n_seq, only=None):
         return r
     res["C2"] = c2_run(True)
     res["C2"]["all_rows_by_cfg_mask_topk"] = {k_: v_ for k_, v_ in c2_run(False).items() if k_ in ("value", "ms_per_step", "kernel_ms", "mean_accept_length")}
+    # evaluate_posterior alone at the saturating batch on LlamaGen's 16384-id window (the two-per-CU instance; round 6)
+    try:
+        sat = lg_batch_sweep([4096], device, iters=8, variants=(1,))[0]
+        if "variants" in sat:
+            v = sat["variants"]["1"][0]
+            res["C2"]["evaluate_posterior_saturating"] = {"kernel": "epw_kernel<512,8,1,4,true,false,5,..> (LlamaGen window, two workgroups per CU, probability rows)",
+                                                         "sequences_per_launch": 4096, "avg_launch_ms": 1e-3 * v["launch_us"], "needed_bytes_per_launch": v["needed_bytes_per_launch"],
+                                                         "achieved_GBps": v["achieved_GBps"], "frac": v["frac"], "cfg_mask_topk_us": v["cfg_mask_topk_us"],
+                                                         "cfg_mask_topk_frac": v["cfg_mask_topk_frac"]}
+        else:
+            res["C2"]["evaluate_posterior_saturating"] = sat
+    except Exception as e:          # (an extra: never fails the line)
+        res["C2"]["evaluate_posterior_saturating"] = {"error": repr(e)[:200]}
     if only == "C2":              # (tools/run/c2_check.sh)
         return res
     # ---- C4

@@ -16,6 +16,12 @@ for B in 4096 512; do
   head -3 gpurun_out/r06_sw$B/summary.txt
   python3 tools/prune_prof.py gpurun_out/r06_sw$B; rm -f gpurun_out/r06_sw$B/stats/*kernel_trace.csv
 done
+# LlamaGen's 16384-id window at the saturating batch: the two-per-CU instance against the generic one (events), then rocprofv3 stats and a FETCH_SIZE pass of the instance
+timeout -k 10 400 python3 tools/lg_sweep.py 512,4096 10 1,0 2 > $O/lg_sweep.json 2> $O/lg_sweep.err || { tail -20 $O/lg_sweep.err; exit 1; }
+( cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT && timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/r06_lg/stats -o s -- python3 tools/lg_sweep.py 4096 10 1 1 > $O/lg_stats.json 2> $O/lg_stats.err &&
+  timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/r06_lg/fetch -o p -- python3 tools/lg_sweep.py 4096 6 1 1 > $O/lg_fetch.json 2> $O/lg_fetch.err ) || { tail -5 $O/lg_stats.err $O/lg_fetch.err; exit 1; }
+python3 tools/pmc_sum.py gpurun_out/r06_lg/fetch "epw_kernel" > gpurun_out/r06_lg/summary.txt; cat gpurun_out/r06_lg/summary.txt
+python3 tools/prune_prof.py gpurun_out/r06_lg; rm -f gpurun_out/r06_lg/stats/*kernel_trace.csv
 timeout -k 10 900 python3 bench.py --gpus 1 --steps 20 --warmup 5 --extras-out $O/bench_full.json > $O/bench.json 2> $O/bench.err || { tail -20 $O/bench.err; exit 1; }
 python3 - <<PY
 import json

@@ -39,6 +39,19 @@ o += [f"| `{name[:110]}` | {us:.1f} | {n} |" for us, n, name in ks("r06_raw_kern
 o += ["\n## evaluate_posterior alone at the saturating batch (`tools/run/ep_sweep_prof.sh`; `r06_ep_sweep_B4096_*`, `r06_ep_sweep_B512_*`)\n", "| kernel | average us | calls |\n|---|---|---|"]
 for fn in ("r06_ep_sweep_B4096_kernel_stats.csv", "r06_ep_sweep_B512_kernel_stats.csv"):
     o += [f"| `{name[:110]}` ({fn.split('_')[3]}) | {us:.1f} | {n} |" for us, n, name in ks(fn, 1)]
+lg = [json.loads(l) for l in open(P("r06_lg_sweep.json")) if l.strip()]
+o += ["\n## LlamaGen's 16384-id window at the saturating batch (`tools/lg_sweep.py`; standard verify on EAGLE-2 trees, probability rows; `r06_lg_sweep.json`, "
+      "`r06_lg_sweep_B4096_kernel_stats.csv`, `r06_lg_sweep_B4096_pmc.txt`)\n",
+      "| sequences per launch | two-per-CU instance `epw_kernel<512,8,1,4,true,false,5,..>` (us, frac of 8 TB/s on needed bytes) | generic one-per-CU instance `epw_kernel<1024,4,1,1,..>` | `cfg_window` over all 59 rows (us, frac) |\n|---|---|---|---|"]
+for r in lg:
+    v1, v0 = r["variants"]["1"], r["variants"]["0"]
+    o += [f"| {r['sequences_per_launch']} | " + " / ".join(f"{x['launch_us']:.1f}" for x in v1) + f" ({v1[-1]['frac']:.3f}) | " + " / ".join(f"{x['launch_us']:.1f}" for x in v0)
+          + f" ({v0[-1]['frac']:.3f}) | {v1[-1]['cfg_mask_topk_us']:.0f} ({v1[-1]['cfg_mask_topk_frac']:.3f}) |"]
+o += [f"| rocprofv3 stats, 4096 | `{name[:80]}` {us:.1f} us x {n} | | |" for us, n, name in ks("r06_lg_sweep_B4096_kernel_stats.csv", 8) if "epw_kernel" in name]
+fetch = [float(l.split()[2]) for l in open(P("r06_lg_sweep_B4096_pmc.txt")) if l.startswith("FETCH_SIZE")]
+if fetch:
+    o += [f"\nFETCH_SIZE of the 4096-sequence launch: {fetch[0]:.0f} KB x 2 (gfx950) = {2 * fetch[0] * 1024 / 1e6:.1f} MB against {lg[-1]['variants']['1'][-1]['needed_bytes_per_launch'] / 1e6:.1f} MB needed "
+          f"= {2 * fetch[0] * 1024 / lg[-1]['variants']['1'][-1]['needed_bytes_per_launch']:.2f} x."]
 o += ["\n## PMC (`--pmc FETCH_SIZE`, `--pmc WRITE_SIZE`, separate passes; `r06_ep_traffic.json`; FETCH_SIZE doubled per the gfx950 note of MI355X_MICROARCH.md)\n",
       "| launch | HBM bytes per launch | needed |\n|---|---|---|"]
 o += [f"| {k} | {v['hbm_bytes'] / 1e6:.2f} MB | {v['algorithmic_window_bytes'] / 1e6:.2f} MB |" for k, v in t["per_launch"].items()]

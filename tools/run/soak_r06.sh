@@ -20,6 +20,14 @@ for delta in (0.1, 5.0):
     T._lumina_static_loop_big("mc_sim_7b_63", 1056, 6, 3, lantern_delta=delta)
     print(f"compact throughput instance, lantern_delta {delta}: 1056 sequences x 6 steps, 352 sequences replayed by the oracle: identical ({time.time() - t0:.0f}s)", flush=True)
 PY
+timeout -k 10 600 python3 - <<'PY'
+import sys, time
+sys.path[:0] = ["tests", "tests/golden", "."]
+import test_gpu_loop as T
+t0 = time.time()
+T._llamagen_dynamic_loop(False, 1, 0, 1.0, n_seq=1056, steps=5, every=6)
+print(f"LlamaGen two-per-CU instance: 1056 sequences x 5 steps, 176 sequences replayed by the oracle: identical ({time.time() - t0:.0f}s)", flush=True)
+PY
 timeout -k 10 600 python3 bench.py --steps 400 --warmup 20 --cpu-seconds 40 --ep-sweep "" --no-extras --commit-window 1 > $O/turn400.json 2> $O/turn400.err; echo "bench exit $?"
 python3 -c "import json; d=json.load(open('$O/turn400.json')); c=d['cpu_baseline']; print('turn-taking, 400 steps: us/step %.2f; oracle replay: %s, mismatches %d (%s)' % (1e3*d['ms_per_step'], c['matches_gpu_token_stream'], c['mismatches'], c['sample']))"
 } | tee $O/soak.txt

@@ -90,7 +90,9 @@ def parse():
                          "sequences (C5's 8 per GPU: 40 vs 49-52 us per step, profiles/r04_c5_share.json), chain above")
     ap.add_argument("--no-fuse-o7", dest="fuse_o7", action="store_false", help="every stage its own launch: cfg_mask_topk for ALL rows, then evaluate_posterior on probability rows "
                     "(default: the chain kernel takes the raw logits -- LANTERN_ROWS_RAW_BF16 -- and post-processes the rows its walk visits)")
-    ap.add_argument("--spec-rows", type=int, default=3, help="with --fuse-o7: rows of the K most likely tree nodes are post-processed up front, in the candidate-assembly launch (lantern_prepare_step); the others on demand")
+    ap.add_argument("--spec-rows", type=int, default=-1, help="with --fuse-o7: rows of the K most likely tree nodes are post-processed up front, in the candidate-assembly launch (lantern_prepare_step) -- or, "
+                    "with --fused-prepare, by helper workgroups of the chain launch (all but the root's); the others on demand.  -1 (default): 3 with a prepare launch, 1 (the root, by "
+                    "its own sequence: no helper) with --fused-prepare")
     ap.add_argument("--python-launch", action="store_true", help="launch every kernel of the step from Python (4 ctypes calls per group) instead of one lantern_verify_step call")
     ap.add_argument("--no-kv", action="store_true", help="skip the KV slabs (debug only; invalid as a headline)")
     ap.add_argument("--kv-smax", type=int, default=4096, help="rows per KV slab (BASELINE.md: 4096 = max_position_embeddings; a 768x768 image needs 2481)")
@@ -100,6 +102,8 @@ def parse():
     ap.add_argument("--graph", action="store_true", help="replay one captured hipGraph per (pool slot, group) instead of launching eagerly")
     ap.add_argument("--side-stream", action="store_true", help="launch O6 beside O7 and O10 beside O9 on a second HIP stream (measured slower: event waits)")
     ap.add_argument("--groups", type=int, default=4, help="split the GPU's sequences into this many groups, each on its own HIP stream (independent sequences: one group's latency-bound evaluate_posterior overlaps the others' bandwidth-bound kernels)")
+    ap.add_argument("--fused-prepare", type=int, default=-1, help="1: the prepare stage inside the chain launch (LANTERN_STEP_FUSED_PREPARE: two launches per group and step); 0: its own "
+                    "launch; -1 (default): on for the chain kernel on raw rows with >= 2 prepared rows")
     ap.add_argument("--commit-window", type=int, default=-1, help="commit turn-taking between the stream groups (lantern_step_group.turn): at most this many groups move their KV rows at the "
                     "same time, ordered by in-kernel tickets instead of cross-stream events; 0 = the groups run free and fall into lock-step; -1 (default) = 1 with four "
                     "stream groups on the chain kernel (68.2 - 68.9 us per step against 71.4 - 72.2 free-running), else 0")
@@ -514,6 +518,8 @@ def kernel_report(wl, evs, E0, E1, KT):
         kname = "ep_kernel (evaluate_posterior)"
     elif wl.ep_nodes is not None:
         kname = "epn_kernel + epn_walk_kernel (evaluate_posterior, node-parallel)"
+    elif getattr(wl, "fused_prepare", False):
+        kname = "epw_kernel_fused<raw rows> (candidate assembly + evaluate_posterior + the tree_decoding post-process of the rows it visits, one launch)"
     elif wl.fused_o7:
         kname = "epw_kernel<raw rows> (evaluate_posterior + the tree_decoding post-process of the rows it visits)"
     else:
@@ -564,7 +570,7 @@ def kernel_report(wl, evs, E0, E1, KT):
 
 def event_names(wl):
     names = ("cfg_mask_topk", "evaluate_posterior", "kv_gather") if wl.cfg.with_kv else ("cfg_mask_topk", "evaluate_posterior")
-    if getattr(wl, "fused_o7", False) and not getattr(wl, "n_spec", 0):
+    if getattr(wl, "fused_o7", False) and (not getattr(wl, "n_spec", 0) or getattr(wl, "fused_prepare", False)):          # (no launch of its own in front of the walk)
         names = tuple(n for n in names if n != "cfg_mask_topk")
     return names
 
@@ -1318,11 +1324,15 @@ def main():
             n_seq, args.groups, _ = plan_sequences(0, fit, world, args.groups)
             if rank == 0:
                 print(f"bench.py: {free / 2**30:.0f} GiB free: running {n_seq} sequences per rank in {args.groups} stream groups", file=sys.stderr)
+    if args.fused_prepare < 0:          # the prepare stage inside the chain launch: 65.1-65.7 us per step against 67.7-68.3 with its own launch (alternating, two boxes)
+        args.fused_prepare = 1 if (args.ep == "chain" and args.fuse_o7 and args.path == "window" and not args.python_launch and not args.graph and not args.side_stream) else 0
+    if args.spec_rows < 0:
+        args.spec_rows = 1 if args.fused_prepare else 3
     if args.commit_window < 0:
         args.commit_window = 1 if (args.groups == 4 and args.ep == "chain" and not args.no_kv and not args.python_launch and not args.graph) else 0
     cfg = HN.WorkloadConfig(n_seq=n_seq, pool_steps=args.pool_steps, tree=args.tree, lantern_k=args.lantern_k,
                             lantern_delta=args.lantern_delta, sigma=args.sigma, with_kv=not args.no_kv, kv_smax=args.kv_smax,
-                            path=args.path, ep_kernel=args.ep, fuse_o7=args.fuse_o7, spec_rows=args.spec_rows, commit_window=args.commit_window, native_step=not args.python_launch, use_graph=args.graph, n_groups=args.groups, side_stream=args.side_stream,
+                            path=args.path, ep_kernel=args.ep, fuse_o7=args.fuse_o7, spec_rows=args.spec_rows, commit_window=args.commit_window, fused_prepare=bool(args.fused_prepare), native_step=not args.python_launch, use_graph=args.graph, n_groups=args.groups, side_stream=args.side_stream,
                             max_steps=max(args.pool_steps, args.steps + args.warmup + min(args.steps, 100), 80) + 8,
                             **({} if args.kv_pad_rows is None else {"kv_pad_rows": args.kv_pad_rows}))
     wl = HN.LuminaVerifyWorkload(cfg, device, rank=rank)
@@ -1389,7 +1399,7 @@ def main():
                        "tree_decoding_rows": (("raw bf16 logits post-processed inside evaluate_posterior (LANTERN_ROWS_RAW_BF16), %d most likely rows per sequence "
                                                "up front with the candidate assembly (lantern_prepare_step)" % wl.n_spec) if getattr(wl, "fused_o7", False)
                                               else "every row post-processed by cfg_mask_topk before evaluate_posterior"),
-                       "tuning": tuning_set or None, "commit_window": cfg.commit_window, "stream_groups": cfg.n_groups, "host_waits": "polling (HSA_ENABLE_INTERRUPT=0)" if os.environ.get("HSA_ENABLE_INTERRUPT") == "0" else "interrupts", "side_stream_for_O6_O10": cfg.side_stream, "sequences_per_launch": wl.Bg, "parallelism": f"dp{world} (independent sequences, no collective)"},
+                       "tuning": tuning_set or None, "commit_window": cfg.commit_window, "fused_prepare": bool(cfg.fused_prepare), "stream_groups": cfg.n_groups, "host_waits": "polling (HSA_ENABLE_INTERRUPT=0)" if os.environ.get("HSA_ENABLE_INTERRUPT") == "0" else "interrupts", "side_stream_for_O6_O10": cfg.side_stream, "sequences_per_launch": wl.Bg, "parallelism": f"dp{world} (independent sequences, no collective)"},
             "mean_accept_length": float(alen.mean()),
             "per_step": {"levels": float(cnt[..., 0].mean()), "tried": float(cnt[..., 1].mean()), "rejected": float(cnt[..., 2].mean())},
         }
@@ -1432,7 +1442,7 @@ def main():
             out["lambda_mode"] = {"lantern_delta": 5.0, "value": tl / dl, "unit": "accepted_tokens/s", "ms_per_step": 1e3 * dl / KL, "steps": KL,
                                   "mean_accept_length": tl / (KL * cfg.n_seq), "note": "rank 0's sequences only"}
             wl.set_lantern_delta(args.lantern_delta)
-            if cfg.fuse_o7 and cfg.spec_rows > 0 and cfg.with_kv and wl._steps:
+            if cfg.fuse_o7 and cfg.spec_rows > 0 and cfg.with_kv and wl._steps and not wl.fused_prepare:          # (--fused-prepare 0 --spec-rows 3 measures it)
                 # the round-5 headline form, kept as a HARNESS-ONLY extra on the same workload and streams: step s + 1's prepare stage inside step s's
                 # commit launch -- only possible because the pools hold step s + 1's rows ahead of time; a real decode loop produces them after
                 # commit(s)

@@ -59,7 +59,7 @@ const char *lantern_last_error(void);
 /* Tuning values: kernel-instance / launch-shape choices a MEASUREMENT may override (tools/, a few tests).  The library reads no environment
  * variable; every product path runs the defaults.  Names (defaults): epw_tp (5), epw_tp4 (1), epw_tp_raw (256), epw_spec (2), epw_occ2 (-1),
  * o7_nt (0), prep_nt (0), kv_u (0), kv_ks (4), kv_variant (0), gemm_tiled_from (129), sk_groups (0), sk_whole_mb (40), sk_nt_min_mb (80),
- * ta_splits (0), ta_min_tiles (2), epw_tp_lg (1) -- meanings beside `enum Tuning` in lantern_amd/csrc/common.h.  Process-wide, atomic ints; set before the
+ * ta_splits (0), ta_min_tiles (2), epw_tp_lg (1), epw_fused_helpers (1) -- meanings beside `enum Tuning` in lantern_amd/csrc/common.h.  Process-wide, atomic ints; set before the
  * launches they should affect.  The reference has no counterpart (it has no kernels to choose between). */
 int lantern_tuning_set(const char *name, int value);
 int lantern_tuning_get(const char *name, int *value);
@@ -486,9 +486,19 @@ typedef struct lantern_step_group {
                                              before the target forward).  A static group with neither is an error, not a silent skip. */
     const lantern_step_greedy *greedy;    /* NULL: relaxed rejection sampling (evaluate_posterior); else the greedy / TVD accept above */
     const lantern_step_dense *dense;      /* NULL: the windowed kernels; else the dense kernel set above */
+    /* flags & LANTERN_STEP_FUSED_PREPARE (round 6): the prepare stage rides INSIDE the chain launch -- two launches per step (walk, commit) instead of three.
+     * Static Lumina trees on raw rows with a node list (lantern_prepare_step's form; node_list[0] is the root), chain kernel, at most 256 sequences.  The
+     * launch's first B * (n_list - 1) workgroups post-process the listed rows but the root's into out_win (= ep_win.raw_probs) and publish each by storing
+     * row_epoch into row_ready[b * N + node]; the sequence workgroups assemble their own candidates (written to cand / tree_cand / cart_prob for the commit
+     * launch), post-process the root's row themselves, and read a listed row only once its word carries this step's epoch -- otherwise they post-process it
+     * themselves: same bits, so the race decides timing, never the result.  row_ready [dev] int32 [B, N], zeroed once; row_epoch: a value no earlier step of
+     * these buffers used (the harness: step + 1).  Any other configuration is refused (LANTERN_E_UNSUPPORTED), not run in three launches. */
+    int32_t *row_ready;
+    int32_t row_epoch, reserved2;
 } lantern_step_group;
 #define LANTERN_TURN_WORDS(n_groups) (16 * (1 + 33 * (n_groups)))   /* int64 words of lantern_step_group.turn */
 #define LANTERN_STEP_CANDIDATES_READY 1   /* lantern_step_group.flags: skip the O6 stage, `cand` / `retrieve` (/ `cart_prob`, `tree_cand`) are final */
+#define LANTERN_STEP_FUSED_PREPARE 4       /* the prepare stage inside the chain launch (row_ready / row_epoch above) */
 #define LANTERN_STEP_PREPARED 2           /* the previous call's commit launch already ran this group's lantern_prepare_step (prepare_next); only valid on a
                                              static-tree group with a node_list, refused otherwise */
 int lantern_verify_step(const lantern_step_group *groups, int n_groups);

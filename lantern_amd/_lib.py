@@ -64,7 +64,7 @@ class StepDynamic(C.Structure):
 
 
 TURN_WORDS = lambda n_groups: 16 * (1 + 33 * n_groups)          # LANTERN_TURN_WORDS
-STEP_CANDIDATES_READY, STEP_PREPARED = 1, 2          # lantern_step_group.flags (include/lantern_hip.h)
+STEP_CANDIDATES_READY, STEP_PREPARED, STEP_FUSED_PREPARE = 1, 2, 4          # lantern_step_group.flags (include/lantern_hip.h)
 
 
 class StepGreedy(C.Structure):
@@ -98,7 +98,8 @@ class StepGroup(C.Structure):
                 + [("node_list", C.c_void_p), ("n_list", C.c_int32), ("flags", C.c_int32)]
                 + [("hidden_uncond", C.c_void_p), ("ids_buf", C.c_void_p), ("ids_stride", C.c_int64), ("ids_len", C.c_void_p), ("prepare_next", C.c_void_p)]
                 + [("turn", C.c_void_p), ("turn_group", C.c_int32), ("turn_groups", C.c_int32), ("turn_wait", C.c_int64)]
-                + [("dyn", C.POINTER(StepDynamic)), ("greedy", C.POINTER(StepGreedy)), ("dense", C.POINTER(StepDense))])
+                + [("dyn", C.POINTER(StepDynamic)), ("greedy", C.POINTER(StepGreedy)), ("dense", C.POINTER(StepDense))]
+                + [("row_ready", C.c_void_p), ("row_epoch", C.c_int32), ("reserved2", C.c_int32)])
 
 
 class DraftDepthArgs(C.Structure):

@@ -34,6 +34,7 @@ enum Tuning {
     TUNE_TA_SPLITS,         // 0: key splits of tree attention by launch size (> 0 forces the split count)
     TUNE_TA_MIN_TILES,      // 2: key tiles per wave and split below which no further split is made
     TUNE_EPW_TP_LG,         // 1: LlamaGen's 16384-id throughput instance (two per CU, rows by LDS-DMA); 2: + second LDS pass for the residual; 3: rows through registers; 4: + raised priority; 0: off
+    TUNE_EPW_FUSED_HELPERS, // 1: helper workgroups per sequence of the chain launch that carries its prepare stage (LANTERN_STEP_FUSED_PREPARE)
     TUNE_COUNT
 };
 int tuning(int t);

@@ -8,6 +8,7 @@
 #include <type_traits>
 #include "window_dev.h"
 #include "tree_dynamic_dev.h"
+#include "prep_dev.h"
 
 // in-kernel phase stamps: only the diagnostic build of window_kernels.hip defines them (-DEPW_TRACE); nothing everywhere else
 #ifndef EPW_STAMP
@@ -100,6 +101,13 @@ __device__ __forceinline__ void row_dma_to_lds(const float *__restrict__ rowp, f
     }
 }
 
+// a row another workgroup of this launch published (EpwFused): agent-scope atomic loads, the window is the workgroup's tile (FULLW)
+template <int NT, int E4>
+__device__ __forceinline__ void row_load_agent(const float *__restrict__ rowp, float4 (&r)[E4]) {
+#pragma unroll
+    for (int it = 0; it < E4; ++it) r[it] = load_f4_agent(rowp + (size_t)(threadIdx.x + it * NT) * 4);
+}
+
 // LDSIDS: every candidate's neighbour ids are staged in LDS (k + 1 <= EW_PF_K, or LANTERN off), so the serial wave-0
 // section contains no vector-memory instruction -- the compiler then has no reason to drain vmcnt inside it and the
 // drafter-row / id loads issued before it stay in flight across the scan.  !LDSIDS (k > 1023) reads ids from HBM.
@@ -114,18 +122,47 @@ struct EpwArgs {
 };
 typedef const __attribute__((address_space(4))) EpwArgs *EpwArgsK;
 
-// IDMODE 0: ids from HBM in the scan (k > 1023).  1: ids staged in LDS, table rows at any (2-byte) alignment -- the
-// reference's [K, K-1] layout.  2: ids staged in LDS from a table whose row stride is a multiple of 8 ids and whose base
-// is 16-byte aligned (lantern_pack_vq_table): one 16-byte load brings 8 ids, 2 loads per thread cover a whole level.
-// WPE (waves per SIMD the register allocation must allow): 1 = no constraint -- the latency-optimal build (162 VGPRs, one
-// workgroup per CU) used while every sequence of the launch gets a CU to itself; 4 (512-thread workgroups) = 128 VGPRs so
-// that TWO workgroups share a CU once the batch exceeds the CU count (67 KB of LDS each): +41 % sequences/s at saturation,
-// -7 % at 48 sequences (a few spills), hence selected by batch size.
-// FULLW: the window is exactly the workgroup's register tile (W == 4 * NT * E4, the Lumina / Anole 8192-id image range on
-// 512 x 4): no per-chunk bounds predicate, so the four chunks of a pass are one basic block and their LDS reads go out together.
-// RAW: rows are the target model's raw cond / uncond bf16 logits (LANTERN_ROWS_RAW_BF16; W == 8 * 2 * NT, packed table).
+// The prepare stage INSIDE the chain launch (lantern_step_group flags & LANTERN_STEP_FUSED_PREPARE; epw_kernel_fused below): the launch's first n_helpers
+// workgroups (a whole number per sequence) post-process the listed rows (all but node_list[0], the root) into win.raw_probs -- as agent-scope atomic stores, no
+// fence: an agent-scope release / acquire pair writes back and invalidates the XCD's L2, measured 64 us per launch against 32 -- and publish each by storing `epoch`
+// into ready[b * rows_per_seq + node]; the sequence workgroups assemble their own candidates (and write them out for the commit launch), post-process the root's
+// row themselves -- they would only wait for a helper to do the same -- and take a listed row from raw_probs when its word says this step's epoch, else
+// post-process it themselves (same bits either way: which of the two happens is timing, never the result).  One kernel boundary and one launch less on
+// every group's chain.
+struct EpwFused {
+    PrepArgs prep;
+    int32_t *ready;
+    int32_t epoch, n_helpers;
+};
+
+template <int NT, int E8>
+__device__ __forceinline__ void epw_helper_row(const EpwFused &f, const int hx) {
+    __shared__ alignas(16) int s_hist[O7_HIST_INTS];
+    __shared__ float s_redf[32];
+    __shared__ double s_redd[32];
+    __shared__ int s_redi[32];
+    const PrepArgs &a = f.prep;
+    // `per` helper workgroups per sequence, helper h of a sequence takes the listed nodes 1 + h, 1 + h + per, ... one after the other: the list is in likelihood
+    // order, so every helper publishes its likeliest row first (a helper workgroup costs a CU for ~5 us per row: the launch carries the chain kernel's LDS footprint)
+    const int per = f.n_helpers / a.B, n_rows = f.n_helpers;
+    const int x = o7_row_of_block(hx, n_rows, per);            // helpers of sequence b on XCD b % 8, where its chain runs (n_helpers % 8 == 0)
+    const int b = x / per, h = x % per;
+    const int64_t len_b = a.w_latent > 0 ? a.seq_len[b] : 0;
+    for (int j = 1 + h; j < a.n_list; j += per) {
+        const int node = a.node_list[j];
+        const int row = b * a.rows_per_seq + node;
+        const int cls = a.w_latent > 0 ? lumina_row_class(a.pos_ids[node] + len_b, a.pos_base, a.w_latent, a.h_latent) : 0;
+        cfg_window_bf16_row<NT, E8, true, false, true>(row, cls, a.cond, a.uncond, a.V, a.cfg, LANTERN_MODEL_LUMINA, a.img_lo, a.img_hi, a.newline_id, a.eos_id,
+                                                       a.top_k, a.win_lo, a.W, a.out_win, a.row_hot, LANTERN_ROWS_PROBS, s_hist, s_redf, s_redd, a.top_p, s_redi);
+        // the row went out as agent-scope atomic stores (store_f4_agent): once every thread's stores are acknowledged ...
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();          // (also: the next row may reuse the histogram / reduction scratch)
+        if (threadIdx.x == 0) __hip_atomic_store(f.ready + row, f.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);          // ... the row's word says so
+    }
+}
+
 template <int NT, int E4, int IDMODE, int WPE, bool FULLW = false, bool RAW = false, int SPEC = 0, int TPO = 0>
-__device__ __forceinline__ int epw_body(const EpwArgs &args, const int b) {
+__device__ __forceinline__ int epw_body(const EpwArgs &args, const int b, const EpwFused *fz = nullptr) {
     constexpr bool NUCLEUS = (TPO & 2) != 0;         // raw rows: TopPLogitsWarper (prm.top_p) in front of the top-k of the rows the walk post-processes
     constexpr bool LATE_Q = (TPO & 1) != 0;          // throughput builds: a candidate's drafter row is requested once its rejection is known (an accepted
                                                      // candidate -- 0.65 of the first tries -- then costs no row request at all; the latency is another workgroup's problem)
@@ -147,6 +184,8 @@ __device__ __forceinline__ int epw_body(const EpwArgs &args, const int b) {
     static_assert(!LITE || (SPEC == 5 && !RAW && !COMPACT), "the lite tables: LlamaGen's standard verify (dynamic trees, LANTERN off) on probability rows");
     constexpr bool DMAROW = COMPACT || (TPO & 512) != 0;          // probability rows land in g by LDS-DMA (row_dma_to_lds): no VGPR staging, no ds_write pass
     static_assert(!DMAROW || (SPEC >= 1 && !RAW && FULLW), "LDS-DMA rows: final probability rows of a fixed configuration whose window is the workgroup's tile");
+    constexpr bool FUSED = (TPO & 1024) != 0;        // the prepare stage rides in this launch (EpwFused above): candidates assembled here, listed rows taken when published
+    static_assert(!FUSED || (RAW && (SPEC == 1 || SPEC == 2) && WPE == 1), "fused prepare: the Lumina static-tree latency instances on raw rows");
     typedef typename std::conditional<COMPACT, EwSharedCompact, typename std::conditional<LITE, EwSharedLite, EwShared>::type>::type SH;
     constexpr int MAX_B = SH::kMaxB, MAX_N = SH::kMaxN, N_UNI = SH::kUni;
     constexpr bool LDSIDS = IDMODE != 0;
@@ -210,7 +249,16 @@ __device__ __forceinline__ int epw_body(const EpwArgs &args, const int b) {
     const uint16_t *raw_c = RAW ? reinterpret_cast<const uint16_t *>(buf.logits) + (size_t)b * p_rows * V + lo : nullptr;
     const uint16_t *raw_u = RAW ? reinterpret_cast<const uint16_t *>(win.raw_uncond) + (size_t)b * p_rows * V + lo : nullptr;
     const float *raw_p = (RAW && win.raw_probs) ? win.raw_probs + (size_t)b * p_rows * W : nullptr;
-    const bool root_pre = RAW && raw_p && win.raw_pre && win.raw_pre[0] != 0;     // (the level-1 row is requested before the tables are staged)
+    const bool root_pre = RAW && !FUSED && raw_p && win.raw_pre && win.raw_pre[0] != 0;     // (the level-1 row is requested before the tables are staged)
+    // FUSED: is row `rid` of raw_probs published for this step?  One agent-scope load by thread 0, the answer through LDS (workgroup-uniform)
+    auto row_ready = [&](int rid) -> bool {
+        if constexpr (FUSED) {
+            int *flag = reinterpret_cast<int *>(g) + W + 3;          // (the fourth word of g's extension: no gather target)
+            if (tid == 0) *flag = (__hip_atomic_load(fz->ready + (size_t)b * p_rows + rid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == fz->epoch) ? 1 : 0;
+            __syncthreads();
+            return *flag != 0;          // (the row is then read with agent-scope atomic loads, row_load_agent: no fence, no cache to invalidate)
+        } else return true;
+    };
     bool rp_probs = false;       // what rp holds: probabilities of a pre-processed row, or raw cond / uncond chunks
     const int32_t *hot_g = win.row_hot ? win.row_hot + (size_t)b * p_rows : nullptr;
     const int ucur0 = buf.cursor ? buf.cursor[b] : 0;
@@ -226,6 +274,36 @@ __device__ __forceinline__ int epw_body(const EpwArgs &args, const int b) {
         int64_t c_[PD_PER];
         int r_[PD_PER], pi_[PD_PER], bo_[PD_PER], tc_[N_PER], hot_[N_PER], oo_ = 0;
         float ct_[PD_PER];
+        if constexpr (FUSED) {          // the candidate assembly of this sequence (prep_rows_body's arithmetic), kept in registers and written out for the commit launch
+            const PrepArgs &pa = fz->prep;
+            const int n_flat = pa.n_flat;
+            const int64_t *tok = pa.ss_token + (size_t)b * n_flat;
+            const float *prb = pa.ss_prob ? pa.ss_prob + (size_t)b * n_flat : nullptr;
+            const int64_t st = pa.sample_token[b];
+#pragma unroll
+            for (int u = 0; u < PD_PER; ++u) {
+                const int t = tid + u * NT;
+                const bool in = t < npd;
+                const int64_t r = in ? pa.retrieve[t] : -1;
+                int64_t c = -1;
+                float pr = 1.0f;
+                if (r >= 0 && r < pa.N) {
+                    const int64_t ti = pa.tree_indices[r];
+                    const bool root = ti <= 0 || ti > n_flat;
+                    c = root ? st : tok[ti - 1];
+                    if (prb) pr = root ? 1.0f : prb[ti - 1];
+                }
+                c_[u] = in ? c : 0;
+                ct_[u] = in ? pr : 0.0f;
+                r_[u] = in ? row_g[t] : 0;
+                pi_[u] = in ? buf.p_idx[t] : 0;
+                bo_[u] = in ? buf.b_off[t] : 0;
+                if (in) {
+                    pa.cand[(size_t)b * npd + t] = c;
+                    if (pa.cart_prob) pa.cart_prob[(size_t)b * npd + t] = pr;
+                }
+            }
+        } else {
 #pragma unroll
         for (int u = 0; u < PD_PER; ++u) {
             const int t = tid + u * NT;
@@ -236,9 +314,20 @@ __device__ __forceinline__ int epw_body(const EpwArgs &args, const int b) {
             pi_[u] = (in && is_static) ? buf.p_idx[t] : 0;
             bo_[u] = (in && is_static) ? buf.b_off[t] : 0;
         }
+        }
 #pragma unroll
         for (int u = 0; u < N_PER; ++u) {
             const int t = tid + u * NT;
+            if constexpr (FUSED) {
+                const PrepArgs &pa = fz->prep;
+                tc_[u] = 0;
+                if (t < p_N && t < MAX_N) {
+                    const int64_t ti = pa.tree_indices[t];
+                    const int64_t tc = (ti <= 0 || ti > pa.n_flat) ? pa.sample_token[b] : pa.ss_token[(size_t)b * pa.n_flat + ti - 1];
+                    tc_[u] = (int)tc;
+                    pa.tree_cand[(size_t)b * p_N + t] = tc;
+                }
+            } else
             tc_[u] = (is_static && t < p_N && t < MAX_N) ? (int)buf.tree_cand[(size_t)b * p_N + t] : 0;
             hot_[u] = (!RAW && hot_g && hot_in_lds && t < p_rows) ? hot_g[t] : -1;          // (raw rows: the class comes from the position, below; row_hot is not read)
             if (RAW && t < p_rows) {
@@ -443,7 +532,9 @@ __device__ __forceinline__ int epw_body(const EpwArgs &args, const int b) {
             } else if (hot < 0 && rp_rid != rid) {
                 if constexpr (RAW) {
                     rp_probs = raw_p && S.pre[rid] != 0;
-                    if (rp_probs) row_load<NT, E4, FULLW>(raw_p + (size_t)rid * W, W, rp);
+                    if (FUSED && rp_probs) rp_probs = row_ready(rid);
+                    if (FUSED && rp_probs) row_load_agent<NT, E4>(raw_p + (size_t)rid * W, rp);
+                    else if (rp_probs) row_load<NT, E4, FULLW>(raw_p + (size_t)rid * W, W, rp);
                     else raw_row_load<NT, CH>(raw_c + (size_t)rid * V, raw_u + (size_t)rid * V, rp);
                 } else row_load<NT, E4, FULLW>(logits + (size_t)rid * W, W, rp);
             }
@@ -918,7 +1009,9 @@ __device__ __forceinline__ int epw_body(const EpwArgs &args, const int b) {
         } else if (hot < 0 && rp_rid != rid) {
             if constexpr (RAW) {
                 rp_probs = raw_p && S.pre[rid] != 0;
-                if (rp_probs) row_load<NT, E4, FULLW>(raw_p + (size_t)rid * W, W, rp);
+                if (FUSED && rp_probs) rp_probs = row_ready(rid);
+                if (FUSED && rp_probs) row_load_agent<NT, E4>(raw_p + (size_t)rid * W, rp);
+                else if (rp_probs) row_load<NT, E4, FULLW>(raw_p + (size_t)rid * W, W, rp);
                 else raw_row_load<NT, CH>(raw_c + (size_t)rid * V, raw_u + (size_t)rid * V, rp);
             } else row_load<NT, E4, FULLW>(logits + (size_t)rid * W, W, rp);
         }
@@ -1096,6 +1189,17 @@ __device__ __forceinline__ int epw_body(const EpwArgs &args, const int b) {
 template <int NT, int E4, int IDMODE, int WPE, bool FULLW = false, bool RAW = false, int SPEC = 0, int TPO = 0>
 __global__ __launch_bounds__(NT, WPE) void epw_kernel(const EpwArgs args) {
     epw_body<NT, E4, IDMODE, WPE, FULLW, RAW, SPEC, TPO>(args, blockIdx.x);
+}
+
+// the chain launch with its prepare stage inside (EpwFused): workgroups [0, n_helpers) post-process the listed rows -- dispatched first, so they run before the
+// sequence workgroups that will ask for their rows --, workgroups [n_helpers, n_helpers + B) are the sequences
+template <int NT, int E4, int IDMODE, int WPE, bool FULLW, bool RAW, int SPEC, int TPO>
+__global__ __launch_bounds__(NT, WPE) void epw_kernel_fused(const EpwArgs args, const EpwFused fz) {
+    if ((int)blockIdx.x < fz.n_helpers) {
+        epw_helper_row<NT, E4 / 2>(fz, (int)blockIdx.x);
+        return;
+    }
+    epw_body<NT, E4, IDMODE, WPE, FULLW, RAW, SPEC, TPO | 1024>(args, (int)blockIdx.x - fz.n_helpers, &fz);
 }
 
 // One launch of the chain kernel: what the instance files need besides the argument block.

@@ -34,7 +34,21 @@ __device__ __forceinline__ int o7_row_of_block(int x, int rows, int rows_per_seq
 // out by nature and uses a single copy.
 // One row of the windowed O7 on a workgroup: CFG combination, top-k threshold, softmax, window store (the body of cfg_window_bf16_kernel,
 // shared with the merged launch below).  `cls`: 0 = grid row, 1 = forced newline, 2 = forced end of image.
-template <int NT, int E8, bool FULL, bool NUCLEUS = false>
+// 16 bytes stored / loaded as two relaxed agent-scope 64-bit atomics (global_store / global_load ... sc1: through to the device's coherence point, past the
+// L2 of the XCD that runs the wave): what a row needs when a workgroup of the SAME launch, possibly on another XCD, reads it behind a flag -- without the L2
+// write-back / invalidate of an agent-scope fence (measured: the fused chain launch 64 us with fences against 32 us for the walk alone)
+__device__ __forceinline__ void store_f4_agent(float *p, const float4 v) {
+    unsigned long long *q = reinterpret_cast<unsigned long long *>(p);
+    __hip_atomic_store(q, (unsigned long long)__float_as_uint(v.x) | ((unsigned long long)__float_as_uint(v.y) << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(q + 1, (unsigned long long)__float_as_uint(v.z) | ((unsigned long long)__float_as_uint(v.w) << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ float4 load_f4_agent(const float *p) {
+    unsigned long long *q = const_cast<unsigned long long *>(reinterpret_cast<const unsigned long long *>(p));
+    const unsigned long long a = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), b = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return make_float4(__uint_as_float((unsigned)a), __uint_as_float((unsigned)(a >> 32)), __uint_as_float((unsigned)b), __uint_as_float((unsigned)(b >> 32)));
+}
+
+template <int NT, int E8, bool FULL, bool NUCLEUS = false, bool COH = false>
 __device__ __forceinline__ void cfg_window_bf16_row(int row, int cls, const uint16_t *__restrict__ cond, const uint16_t *__restrict__ uncond, int V,
                                                     float cfg, int model, int img_lo, int img_hi, int newline_id, int eos_id, int top_k, int win_lo,
                                                     int W, float *__restrict__ out_win, int32_t *__restrict__ row_hot, int out_kind, int *s_hist,
@@ -131,8 +145,13 @@ __device__ __forceinline__ void cfg_window_bf16_row(int row, int cls, const uint
 #pragma unroll
     for (int it = 0; it < E8; ++it) {
         const int w0 = e_base + (tid + it * NT) * 8 - win_lo;     // window index of the chunk's first id (multiple of 4)
-        if (FULL || (w0 >= 0 && w0 < W)) *reinterpret_cast<float4 *>(out + w0) = r[2 * it];
-        if (FULL || (w0 + 4 >= 0 && w0 + 4 < W)) *reinterpret_cast<float4 *>(out + w0 + 4) = r[2 * it + 1];
+        if constexpr (COH) {          // (read by another workgroup of this launch)
+            if (FULL || (w0 >= 0 && w0 < W)) store_f4_agent(out + w0, r[2 * it]);
+            if (FULL || (w0 + 4 >= 0 && w0 + 4 < W)) store_f4_agent(out + w0 + 4, r[2 * it + 1]);
+        } else {
+            if (FULL || (w0 >= 0 && w0 < W)) *reinterpret_cast<float4 *>(out + w0) = r[2 * it];
+            if (FULL || (w0 + 4 >= 0 && w0 + 4 < W)) *reinterpret_cast<float4 *>(out + w0 + 4) = r[2 * it + 1];
+        }
     }
 }
 

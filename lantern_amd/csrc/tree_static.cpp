@@ -44,7 +44,7 @@ namespace {
 struct TuningSlot { const char *name; int dflt; };
 const TuningSlot kTuning[] = {
     {"epw_tp", 5}, {"epw_tp4", 1}, {"epw_tp_raw", 256}, {"epw_spec", 2}, {"epw_occ2", -1}, {"o7_nt", 0}, {"prep_nt", 0}, {"kv_u", 0}, {"kv_ks", 4},
-    {"kv_variant", 0}, {"gemm_tiled_from", 129}, {"sk_groups", 0}, {"sk_whole_mb", 40}, {"sk_nt_min_mb", 80}, {"ta_splits", 0}, {"ta_min_tiles", 2}, {"epw_tp_lg", 1}};
+    {"kv_variant", 0}, {"gemm_tiled_from", 129}, {"sk_groups", 0}, {"sk_whole_mb", 40}, {"sk_nt_min_mb", 80}, {"ta_splits", 0}, {"ta_min_tiles", 2}, {"epw_tp_lg", 1}, {"epw_fused_helpers", 1}};
 constexpr int kTuningCount = sizeof(kTuning) / sizeof(kTuning[0]);
 std::atomic<int> g_tuning[kTuningCount];
 std::atomic<bool> g_tuning_init{false};

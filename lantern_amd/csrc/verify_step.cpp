@@ -17,6 +17,8 @@ int launch_update_inference_inputs(void *const *slab_ptrs, const int32_t *slab_s
                                    const void *hidden_g1 = nullptr, int64_t *ids_buf = nullptr, int64_t ids_stride = 0, const int64_t *ids_len = nullptr,
                                    const int64_t *bonus = nullptr, const PrepArgs *prep = nullptr, const TurnArgs *turn = nullptr);
 int prepare_step_args(const lantern_step_group *g, PrepArgs *out);
+int evaluate_posterior_window_fused(const lantern_ep_params *prm, const lantern_ep_buffers *buf, const lantern_ep_window *win, const PrepArgs &prep, int32_t *ready,
+                                    int32_t epoch, void *stream);
 }
 
 namespace {
@@ -48,6 +50,12 @@ extern "C" int lantern_verify_step(const lantern_step_group *groups, int n_group
                 return fail(g, "dense", LANTERN_E_INVALID);
             }
         }
+        if ((s.flags & LANTERN_STEP_FUSED_PREPARE) &&
+            (s.dyn || s.nodes || s.greedy || s.dense || s.prepare_next || !s.node_list || s.n_list < 1 || !s.row_ready || (s.flags & (LANTERN_STEP_PREPARED | LANTERN_STEP_CANDIDATES_READY)))) {
+            lantern::set_error("LANTERN_STEP_FUSED_PREPARE: a static-tree group with a node list (the root first) and row_ready, on the chain kernel, and none of dyn / nodes / "
+                               "greedy / dense / prepare_next / LANTERN_STEP_PREPARED / LANTERN_STEP_CANDIDATES_READY");
+            return fail(g, "fused prepare", LANTERN_E_INVALID);
+        }
         if (s.turn && (s.turn_groups <= 0 || s.turn_group < 0 || s.turn_group >= s.turn_groups || !s.slab_ptrs)) {
             lantern::set_error("commit turn-taking: turn_group in [0, turn_groups) and the group's KV slabs (its commit launch releases the turn)");
             return fail(g, "turn", LANTERN_E_INVALID);
@@ -55,6 +63,7 @@ extern "C" int lantern_verify_step(const lantern_step_group *groups, int n_group
     }
     for (int g = 0; g < n_groups; ++g) {
         const lantern_step_group &s = groups[g];
+        if (s.flags & LANTERN_STEP_FUSED_PREPARE) continue;          // (the prepare stage rides in the chain launch below)
         if (s.flags & LANTERN_STEP_PREPARED) {          // the previous call's commit launch prepared this step (prepare_next)
             // only what prepare_next can have prepared: a static-tree group with a node list (an EAGLE-2 group would skip its tree build).  A
             // failed call or a non-zero walk status in the previous step invalidates the preparation: the caller clears the flag and the step
@@ -145,6 +154,19 @@ extern "C" int lantern_verify_step(const lantern_step_group *groups, int n_group
                                            s.ep_buf.accept_len, q.sample_p, s.V, q.u_bonus, nullptr, nullptr, q.token, s.stream);
                 if (rc) return fail(g, "bonus draw", rc);
             }
+            continue;
+        }
+        if (s.flags & LANTERN_STEP_FUSED_PREPARE) {          // candidates + listed rows + walk in ONE launch
+            lantern::PrepArgs pa{};
+            rc = lantern::prepare_step_args(&s, &pa);
+            if (rc) return fail(g, "fused prepare", rc);
+            lantern_ep_window w = s.ep_win;
+            if (s.turn && s.slab_ptrs) {
+                w.turn = s.turn;
+                w.turn_wait = s.turn_wait;
+            }
+            rc = lantern::evaluate_posterior_window_fused(&s.ep, &s.ep_buf, &w, pa, s.row_ready, s.row_epoch, s.stream);
+            if (rc) return fail(g, "evaluate_posterior (fused prepare)", rc);
             continue;
         }
         if (s.turn && !s.nodes && s.slab_ptrs) {          // commit turn-taking: the chain kernel ends when it is this group's turn to commit

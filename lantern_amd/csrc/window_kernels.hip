@@ -575,6 +575,45 @@ extern "C" int lantern_evaluate_posterior_window(const lantern_ep_params *prm, c
     return LANTERN_OK;
 }
 
+// The chain launch with its prepare stage inside (lantern_step_group flags & LANTERN_STEP_FUSED_PREPARE, verify_step.cpp): the Lumina static-tree latency instances
+// on raw rows, at most 256 sequences.  Anything else is refused -- the caller asked for a form that does not exist, it is not quietly run in three launches.
+namespace lantern {
+int evaluate_posterior_window_fused(const lantern_ep_params *prm, const lantern_ep_buffers *buf, const lantern_ep_window *win, const PrepArgs &prep, int32_t *ready,
+                                    int32_t epoch, void *stream) {
+    const int rc = epw_check(prm, buf, win);
+    if (rc) return rc;
+    const lantern_ep_params &p = *prm;
+    if (p.B == 0) return LANTERN_OK;
+    const int W = win->win_len;
+    const bool raw = win->rows_kind == LANTERN_ROWS_RAW_BF16;
+    const bool nucleus = p.top_p >= 1e-8f && p.top_p < 1.0f;
+    const bool lumina_syntax = p.syntax_shortcut && p.n_syntax == 4 && p.syntax[0] == 8196 && p.syntax[1] == 8197 && p.syntax[2] == 8803 && p.syntax[3] == 8828;
+    const bool form = raw && !nucleus && p.lantern && p.V == 65536 && p.img_lo == 4 && p.img_hi == 8196 && p.tok_offset == 4 && p.table_rows == 8192 && win->win_lo == 4 &&
+                      W == 8192 && p.rows_per_seq <= EW_MAX_N && (win->raw_w_latent == 0 || (win->raw_eos_id == 8196 && win->raw_newline_id == 8803)) &&
+                      p.mode == LANTERN_MODE_STATIC_LUMINA && lumina_syntax && !buf->n_paths && !buf->n_depth && !win->raw_pos_per_seq && p.table_cols % 8 == 0 &&
+                      ((uintptr_t)buf->nn_table & 15) == 0 && ((p.k + 1 < p.table_cols ? p.k + 1 : p.table_cols) <= EW_PF_K) && p.B <= 256;
+    if (!form || !ready || !win->raw_probs || !win->raw_pre || prep.n_list < 1 || prep.B != p.B || prep.PD != p.P * p.D || prep.N != p.N || prep.rows_per_seq != p.rows_per_seq ||
+        prep.out_win != win->raw_probs || prep.W != W || !prep.cand || !prep.tree_cand || (prep.top_p >= 1e-8f && prep.top_p < 1.0f)) {
+        set_error("fused prepare: Lumina static trees on raw bf16 rows (8192-id window, packed table, k + 1 <= %d, top_p off), at most 256 sequences, a node list "
+                  "whose rows go to ep_win.raw_probs, and the row_ready words", EW_PF_K);
+        return LANTERN_E_UNSUPPORTED;
+    }
+    const size_t lds = epw_lds_bytes(p, win);
+    const EpwArgs args{p, *buf, *win};
+    int per = tuning(TUNE_EPW_FUSED_HELPERS);          // helper workgroups per sequence (each takes its listed rows one after the other)
+    if (per < 1) per = 1;
+    if (per > prep.n_list - 1) per = prep.n_list - 1;          // (a list of the root alone: no helper, the sequences post-process every row themselves)
+    const EpwFused fz{prep, ready, epoch, p.B * per};
+    const dim3 grid(fz.n_helpers + p.B);
+    const bool default_tree = tuning(TUNE_EPW_SPEC) >= 2 && p.P == 15 && p.D == 6 && p.N == 26 && p.rows_per_seq == 26;
+    hipStream_t st = (hipStream_t)stream;
+    if (default_tree) LANTERN_LAUNCH((epw_kernel_fused<512, 4, 2, 1, true, true, 2, 0>), grid, dim3(512), lds, st, args, fz);
+    else LANTERN_LAUNCH((epw_kernel_fused<512, 4, 2, 1, true, true, 1, 0>), grid, dim3(512), lds, st, args, fz);
+    LANTERN_CHECK_LAUNCH("evaluate_posterior_window (fused prepare)");
+    return LANTERN_OK;
+}
+}  // namespace lantern
+
 #ifdef EPW_TRACE
 // host_out: [EPW_TR_BLOCKS][EPW_TR_MAX] stamps (id << 56 | cycles), counts: [EPW_TR_BLOCKS]
 extern "C" int lantern_debug_epw_trace(unsigned long long *host_out, int *counts) {

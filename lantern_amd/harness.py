@@ -111,6 +111,8 @@ class WorkloadConfig:
                                     # softmax) the rows its walk visits from the raw cond / uncond logits
     spec_rows: int = 0              # with fuse_o7: this many of the tree's most likely nodes (the root first) get their rows post-processed
                                     # up front, in the same launch as the candidate assembly (lantern_prepare_step); the rest on demand
+    fused_prepare: bool = False     # chain kernel on raw rows with prepared rows (fuse_o7, spec_rows >= 2): the prepare stage inside the chain launch
+                                    # (LANTERN_STEP_FUSED_PREPARE): two launches per group and step instead of three
     dense_one_call: bool = True     # dense path with KV slabs: the step through ONE C call (lantern_step_group.dense); False: one ctypes call per kernel
     native_step: bool = True        # eager windowed path: the whole step of all groups through ONE C call (lantern_verify_step) instead of
                                     # 4 x n_groups ctypes calls (the Python launch loop caps the stream groups at ~2 otherwise)
@@ -373,6 +375,11 @@ class LuminaVerifyWorkload:
             for slot in range(cfg.pool_steps):
                 for parity in (0, 1):
                     self._steps[(slot, parity)] = self._make_step_groups(slot, parity)
+        # the prepare stage inside the chain launch (LANTERN_STEP_FUSED_PREPARE): Lumina static trees on raw rows, the one-call step
+        self.fused_prepare = bool(cfg.fused_prepare and self.fused_o7 and self.n_spec >= 1 and self.ep_nodes is None and not self.anole and self._steps
+                                  and cfg.top_p >= 1.0 and cfg.n_seq // max(1, cfg.n_groups) <= 256)
+        if self.fused_prepare:
+            self._row_ready = torch.zeros((cfg.n_seq, self.N), dtype=torch.int32, device=device)          # zeroed once: the epochs (step + 1) only grow
 
     # -------------------------------------------------------------------------------------
     def reset_state(self):
@@ -686,6 +693,7 @@ class LuminaVerifyWorkload:
         merge = (c.merge_prepare and c.with_kv and self.n_spec > 0 and step + 1 < c.max_steps and self._len_ub + 2 * self.D < self.tokens_per_image)
         nxt_arr = self._steps[((step + 1) % c.pool_steps, parity ^ 1)] if merge else None
         turns = c.commit_window > 0 and c.with_kv and self.G > 1 and self.ep_nodes is None
+        fused = self.fused_prepare and not merge
         if turns and not hasattr(self, "_turn"):
             self._turn = torch.zeros(_lib.TURN_WORDS(self.G), dtype=torch.int64, device=self.device)          # never reset: tickets and epochs only grow
             self._turn_step = 0
@@ -697,6 +705,9 @@ class LuminaVerifyWorkload:
             else:
                 s.turn = None
             s.flags = _lib.STEP_PREPARED if self._prepared_for == step else 0
+            if fused:
+                s.flags = _lib.STEP_FUSED_PREPARE
+                s.row_ready, s.row_epoch = self._row_ready[g * self.Bg:].data_ptr(), step + 1
             if merge:
                 n_ = nxt_arr[g]
                 n_.sample_token = bs["tok"] + 8 * (step * c.n_seq + g * self.Bg)          # this step's bonus tokens = the next step's roots
@@ -810,7 +821,18 @@ class LuminaVerifyWorkload:
             sg.stream, sg.sample_token = st.value, p_sample.value
             check(L.lantern_verify_step(C.byref(sg), 1), "verify_step")
         else:
-            if self.n_spec:               # candidates + the likely rows in one launch (the step's own argument block, this step's sample token)
+            one_launch = self.fused_prepare and side is None
+            if one_launch:                # the chain launch with its prepare stage inside, alone (no commit behind it): a copy of the step's block without slabs / turn
+                tmp = StepGroup()
+                C.memmove(C.byref(tmp), C.byref(self._steps[(slot, parity)][g]), C.sizeof(StepGroup))
+                C.memmove(C.byref(tmp.ep_buf), C.byref(A["ep_buf"]), C.sizeof(EpBuffers))
+                C.memmove(C.byref(tmp.ep_win), C.byref(A["ep_win"]), C.sizeof(EpWindow))
+                tmp.stream, tmp.sample_token, tmp.slab_ptrs, tmp.turn, tmp.prepare_next = st.value, p_sample.value, None, None, None
+                tmp.flags, tmp.row_ready, tmp.row_epoch = _lib.STEP_FUSED_PREPARE, self._row_ready[g * self.Bg:].data_ptr(), self.step_idx + 1
+                if events:
+                    self._arm(events, "evaluate_posterior")
+                check(L.lantern_verify_step(C.byref(tmp), 1), "verify_step (fused prepare)")
+            elif self.n_spec:             # candidates + the likely rows in one launch (the step's own argument block, this step's sample token)
                 sg = self._steps[(slot, parity)][g]
                 sg.stream, sg.sample_token = st.value, p_sample.value
                 if events:
@@ -826,7 +848,9 @@ class LuminaVerifyWorkload:
             # O7 CFG + Lumina position mask + top-k, positions from the device-side lengths
             if events and not self.fused_o7:
                 self._arm(events, "cfg_mask_topk")
-            if self.fused_o7:
+            if one_launch:
+                pass
+            elif self.fused_o7:
                 pass                                  # evaluate_posterior reads the raw logits itself
             elif self.windowed:
                 check(L.lantern_cfg_mask_topk_window(A["cond"], A["uncond"], 1, B * N, V, C.c_float(c.cfg_scale), self.o7_model,
@@ -838,14 +862,16 @@ class LuminaVerifyWorkload:
                 check(L.lantern_cfg_mask_topk(A["cond"], A["uncond"], 1, B * N, V, C.c_float(c.cfg_scale), self.o7_model,
                                               vp(self.d_pos_ids.data_ptr()), C.c_int64(c.prompt_len + 3), W_LATENT, H_LATENT, IMG_LO, IMG_HI,
                                               NEWLINE, EOS, c.top_k, A["cur"], N, A["proc"], st), "cfg_mask_topk")
-            if events:
+            if events and not one_launch:
                 if not self.fused_o7:
                     self._disarm(events, "cfg_mask_topk")
                 self._arm(events, "evaluate_posterior")
             if side is not None:
                 main.wait_event(ev[1])                # O8 needs the candidates
             # O8 (windowed: the bonus token is drawn in the kernel epilogue)
-            if self.windowed and self.ep_nodes is not None:
+            if one_launch:
+                pass
+            elif self.windowed and self.ep_nodes is not None:
                 check(L.lantern_evaluate_posterior_nodes(C.byref(self._ep_prm), C.byref(A["ep_buf"]), C.byref(A["ep_win"]),
                                                          C.byref(self.ep_nodes[g]), st), "evaluate_posterior_nodes")
             elif self.windowed:

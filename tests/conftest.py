@@ -30,7 +30,7 @@ def _tuning_from_the_callers_environment():
     import torch
     if torch.cuda.is_available() and any(k.startswith("LANTERN_") and k[8:].lower() in
                                          ("epw_tp", "epw_tp4", "epw_tp_raw", "epw_spec", "epw_occ2", "o7_nt", "prep_nt", "kv_u", "kv_ks", "kv_variant",
-                                          "gemm_tiled_from", "sk_groups", "sk_whole_mb", "sk_nt_min_mb", "ta_splits", "ta_min_tiles", "epw_tp_lg") for k in os.environ):
+                                          "gemm_tiled_from", "sk_groups", "sk_whole_mb", "sk_nt_min_mb", "ta_splits", "ta_min_tiles", "epw_tp_lg", "epw_fused_helpers") for k in os.environ):
         from lantern_amd import _lib
         _lib.tuning_from_env()
     yield

@@ -133,7 +133,7 @@ def test_step_group_layout_matches_the_c_struct(tmp_path):
     import subprocess
     wfields = ["row_hot", "rows_kind", "raw_uncond", "raw_pos_base", "raw_cfg", "raw_eos_id", "raw_probs", "raw_pre", "verdict_host", "turn", "turn_wait"]
     fields = ["stream", "B", "tree_cand", "cond", "pos_base", "w_latent", "seq_len", "temperature", "ep", "ep_buf", "ep_win", "nodes",
-              "slab_ptrs", "n_slabs", "outer", "hidden", "H", "node_list", "n_list", "flags", "hidden_uncond", "ids_buf", "ids_stride", "ids_len", "prepare_next", "turn", "turn_group", "turn_groups", "turn_wait", "dyn", "greedy", "dense"]
+              "slab_ptrs", "n_slabs", "outer", "hidden", "H", "node_list", "n_list", "flags", "hidden_uncond", "ids_buf", "ids_stride", "ids_len", "prepare_next", "turn", "turn_group", "turn_groups", "turn_wait", "dyn", "greedy", "dense", "row_ready", "row_epoch"]
     src = tmp_path / "layout.c"
     gfields = [f for f, _ in _lib.StepGreedy._fields_]
     dfields = [f for f, _ in _lib.StepDense._fields_]
@@ -242,6 +242,24 @@ def test_dense_step_block_is_validated_before_anything_is_launched():
     assert L.lantern_verify_step(C.byref(g), 1) == -1 and L.lantern_last_error().startswith(b"verify_step: group 0, gather_candidates: ")   # the block itself is accepted
 
 
+def test_fused_prepare_flag_is_validated_before_anything_is_launched():
+    """LANTERN_STEP_FUSED_PREPARE (the prepare stage inside the chain launch): a static-tree group with a node list and the row_ready words, on the chain kernel."""
+    L = _lib.lib()
+    g = _lib.StepGroup()
+    g.flags = _lib.STEP_FUSED_PREPARE
+    assert L.lantern_verify_step(C.byref(g), 1) == -1 and L.lantern_last_error().startswith(b"verify_step: group 0, fused prepare: LANTERN_STEP_FUSED_PREPARE")
+    nl = (C.c_int32 * 2)(0, 1)
+    g.node_list, g.n_list, g.row_ready = C.cast(nl, C.c_void_p).value, 2, 0x1000
+    g.flags = _lib.STEP_FUSED_PREPARE | _lib.STEP_PREPARED
+    assert L.lantern_verify_step(C.byref(g), 1) == -1 and b"LANTERN_STEP_FUSED_PREPARE" in L.lantern_last_error()
+    g.flags = _lib.STEP_FUSED_PREPARE
+    q = _lib.StepDense()
+    g.dense = C.pointer(q)
+    assert L.lantern_verify_step(C.byref(g), 1) == -1          # (the dense block's own check, or the flag's: either way nothing is launched)
+    g.dense = None
+    assert L.lantern_verify_step(C.byref(g), 1) == -1 and L.lantern_last_error().startswith(b"verify_step: group 0, fused prepare: prepare_step")   # the flag is accepted, the empty group is not
+
+
 def test_linear_rows_packed_validates_without_gpu():
     """lantern_linear_rows_packed (the drafter layer's GEMMs at any row count, on the packed weights): the argument checks run on the host --
     a K that is no multiple of the 64-element bricks, an unknown epilogue, a residual epilogue without its residual, a gate / up epilogue without
@@ -264,7 +282,7 @@ def test_tuning_values_are_an_explicit_api_and_the_library_reads_no_environment(
     import subprocess
     names = _lib.tuning_names()
     assert names == ["epw_tp", "epw_tp4", "epw_tp_raw", "epw_spec", "epw_occ2", "o7_nt", "prep_nt", "kv_u", "kv_ks", "kv_variant", "gemm_tiled_from",
-                     "sk_groups", "sk_whole_mb", "sk_nt_min_mb", "ta_splits", "ta_min_tiles", "epw_tp_lg"]
+                     "sk_groups", "sk_whole_mb", "sk_nt_min_mb", "ta_splits", "ta_min_tiles", "epw_tp_lg", "epw_fused_helpers"]
     defaults = {n: _lib.get_tuning(n) for n in names}
     assert (defaults["epw_tp"], defaults["epw_tp4"], defaults["epw_tp_raw"], defaults["epw_spec"], defaults["kv_ks"], defaults["sk_whole_mb"]) == (5, 1, 256, 2, 4, 40)
     _lib.set_tuning("epw_tp_raw", 512)

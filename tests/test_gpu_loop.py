@@ -611,3 +611,43 @@ def test_dense_kernel_set_through_verify_step(groups):
         assert torch.equal(x, y)
     assert int(a.log_alen[:8].sum()) > 0 and a._densecache and not getattr(b, "_densecache", None)
 
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("groups,spec,window,geom", [(1, 3, 0, "slab_blocks"), (2, 2, 0, "slab_blocks"), (4, 3, 1, "tiled"), (1, 5, 0, "tiled"), (4, 1, 1, "tiled"), (2, 1, 0, "slab_blocks")])
+def test_prepare_stage_inside_the_chain_launch(groups, spec, window, geom):
+    """LANTERN_STEP_FUSED_PREPARE: the candidate assembly and the likely rows ride in the chain launch (helper workgroups publish each row by storing the step's epoch
+    behind its agent-scope row stores; a sequence takes a row when it is published, else post-processes it itself; spec 1 = the root alone: no helper, bench.py's
+    default) -- two launches per group and step.  Against the oracle's loop, and every
+    verdict, length, KV slab, accepted hidden row and token list identical to the three-launch form over 60 steps, with and without commit turn-taking."""
+    import bench
+    from lantern_amd import harness as HN
+    kv = dict(kv_layers=2, kv_heads=4) if geom == "slab_blocks" else dict(kv_layers=16, kv_heads=32)
+    steps = 60
+    mk = lambda fused: HN.LuminaVerifyWorkload(HN.WorkloadConfig(n_seq=4 * groups, pool_steps=4, kv_smax=512, max_steps=steps + 4, sigma=5.0, n_groups=groups, ep_kernel="chain",
+                                                                 fuse_o7=True, spec_rows=spec, fused_prepare=fused, commit_window=window, **kv), torch.device("cuda"))
+    a, b = mk(True), mk(False)
+    gen = torch.Generator(device="cuda").manual_seed(9)
+    for x, y in zip(a.slabs, b.slabs):
+        x.copy_(torch.randn(x.shape, device="cuda", generator=gen).to(torch.bfloat16))
+        y.copy_(x)
+    for w in (a, b):
+        for _ in range(steps):
+            w.step()
+        w.join()
+    torch.cuda.synchronize()
+    a.check_status(0, steps)
+    assert a.fused_prepare and not b.fused_prepare and not hasattr(b, "_row_ready")
+    assert int(a._row_ready.max()) == (steps if spec >= 2 else 0)          # the helpers published rows in the last step (spec 1: the root alone, no helper)
+    for k in ("log_best", "log_alen", "log_cnt", "log_token"):
+        assert torch.equal(getattr(a, k)[:steps], getattr(b, k)[:steps]), k
+    for x, y in zip(a.slabs, b.slabs):
+        assert torch.equal(x, y)
+    for x, y in zip(a.lens, b.lens):
+        assert torch.equal(x, y)
+    assert torch.equal(a.out_hidden, b.out_hidden) and torch.equal(a.acc_tokens, b.acc_tokens)
+    assert torch.equal(a.cand2[0], b.cand2[0]) and torch.equal(a.cand2[1], b.cand2[1]) and torch.equal(a.tree_cand, b.tree_cand) and torch.equal(a.cart_prob, b.cart_prob)
+    gb, ga, gt = [x[:steps].cpu().numpy() for x in (a.log_best, a.log_alen, a.log_token)]
+    stream = [[(int(gb[i, s]), int(ga[i, s]), int(gt[i, s])) for s in range(a.cfg.n_seq)] for i in range(steps)]
+    res = bench.cpu_baseline(a, steps_budget_s=1e9, n_seq=a.cfg.n_seq, gpu_tokens_by_seq=stream)
+    assert res["matches_gpu_token_stream"], res

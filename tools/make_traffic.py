@@ -12,7 +12,7 @@ RND = sys.argv[1] if len(sys.argv) > 1 else "r05"
 runs = dict(a.split("=", 1) for a in sys.argv[2:]) or {"raw": RND + "p", "chain": RND + "p_chain"}          # traffic key prefix -> gpurun_out/<dir>
 sat_runs = [v for k, v in list(runs.items()) if k.startswith("sat")]
 runs = {k: v for k, v in runs.items() if not k.startswith("sat")}
-kern = {"raw": ["epw_kernel"], "chain": ["epw_kernel"], "nodes": ["epn_kernel", "epn_walk_kernel"]}
+kern = {"raw": ["epw_kernel", "epw_kernel_fused"], "chain": ["epw_kernel"], "nodes": ["epn_kernel", "epn_walk_kernel"]}          # (a run holds one of the two raw-row forms)
 others = ["prep_rows_kernel", "cfg_window_bf16", "update_inputs"]
 
 
@@ -39,8 +39,9 @@ for key, d in runs.items():
     fetch = wr = 0.0
     n = 0
     for k in kern[key]:
-        f, n = sums(os.path.join(src, "pmc_fetch"), k + "<")
+        f, n_k = sums(os.path.join(src, "pmc_fetch"), k + "<")
         w, _ = sums(os.path.join(src, "pmc_write"), k + "<")
+        n = max(n, n_k)
         fetch += f.get("FETCH_SIZE", 0.0); wr += w.get("WRITE_SIZE", 0.0)
     rl = line["roofline"]
     out["per_launch"][f"{key}_B{B}"] = {

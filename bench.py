@@ -9,10 +9,11 @@ Contract (driver):  python bench.py --gpus N --steps K --warmup W
 Workload = BASELINE.json config C3 (Lumina-mGPT-7B-768 + LANTERN relaxed accept, k=1000, delta=0.1, static tree mc_sim_7b_63) on
 synthetic 768x768 image-token sequences: a "step" is one verify step (O6 -> O7 -> O8 -> O9 -> O10) over the --seqs-per-gpu sequences
 resident on the GPU; inputs are HBM-resident before the timed region.  `value` = accepted tokens of all ranks / max-over-ranks wall time.
-Default launch: 64 sequences in 4 stream groups, one lantern_verify_step call per step, per group  prepare_step (O6 + the 3 most likely rows of O7) ->
-evaluate_posterior_window on raw bf16 rows (O8 + the other rows of O7 it visits, on demand) -> update_inference_inputs (O9 + O10): three launches, in the order a real
-decode loop can issue them (a step's rows exist only after the previous step's commit + the drafter and target forwards).  The round-5 variant that hid the prepare stage
-in the PREVIOUS step's commit launch is only possible on pre-generated pools: it is reported as the extra `merged_prepare_harness_only`, never as `value`.
+Default launch: 64 sequences in 4 stream groups, one lantern_verify_step call per step, per group TWO launches in the order a real decode loop can issue them (a step's
+rows exist only after the previous step's commit + the drafter and target forwards): evaluate_posterior_window on raw bf16 rows with its prepare stage inside the launch
+(LANTERN_STEP_FUSED_PREPARE: O6 by the sequence workgroups, O8 + the rows of O7 the walk visits, on demand) -> update_inference_inputs (O9 + O10).
+`--fused-prepare 0 --spec-rows 3` is the three-launch form (lantern_prepare_step = O6 + the 3 most likely rows of O7 as its own launch in front).  The round-5 variant that hid
+the prepare stage in the PREVIOUS step's commit launch is only possible on pre-generated pools: a harness-only extra of the three-launch form, never `value`.
 `--groups 1 --no-fuse-o7 --spec-rows 0` is the four-launch step (every row through cfg_mask_topk first).
 N > 1 prints BOTH scaling forms in the one line: `value` = weak scaling (--seqs-per-gpu on every rank) and `c5_strong` = BASELINE config C5 / BASELINE.md section 2
 (64 sequences in ALL, split evenly over the ranks: run.sh:76-91), each with its own barrier-bracketed K-step timed region.

@@ -35,7 +35,6 @@ Extra objects on the JSON line:
   mirror_generate  the drop-in API (EaLumina_mGPT.generate) with stand-in forwards: us per verify step of the mirror's loop body (tools/mirror_bench.py).
   step_latency_us  whole-step wall time at 1 and 8 sequences (the reference's own batch is 1), three evaluate_posterior forms.
   other_groupings  the default kernels with 1 and 2 stream groups.
-  three_launch_step  the same workload with lantern_prepare_step as its own launch (--fused-prepare 0 --spec-rows 3).
   cpu_baseline  the oracle (C port of the reference path, pthreads) timed on this host's cores over a bounded sample of the same
                 pools / uniforms; it must reproduce the GPU's accepted-token stream.
 """
@@ -992,8 +991,6 @@ def compact_line(out: dict) -> dict:
         ex["drafter_us_per_cycle_wall"] = {k: v.get("us_per_cycle_wall") for k, v in dc.items() if isinstance(v, dict)}
     if isinstance(out.get("lambda_mode"), dict):
         ex["lambda_mode_value"] = out["lambda_mode"].get("value")
-    if "three_launch_step" in out:
-        ex["three_launch_us_per_step"] = 1e3 * out["three_launch_step"].get("ms_per_step", 0.0)
     mp = out.get("merged_prepare_harness_only")
     if isinstance(mp, dict):
         ex["merged_prepare_harness_only_us_per_step"] = 1e3 * mp.get("ms_per_step", 0.0)
@@ -1473,9 +1470,6 @@ def main():
             out["step_latency_us"] = step_latency(device, cfg)
             out["other_groupings"] = {f"groups_{g}": side_run(device, cfg, max(min(K, 100), 60), n_groups=g, commit_window=0, n_seq=args.seqs_per_gpu - args.seqs_per_gpu % g)
                                       for g in (1, 2) if g != cfg.n_groups}
-            if cfg.fused_prepare and cfg.fuse_o7:          # the form of the earlier rounds beside the default: prepare (O6 + 3 likely rows) -> walk -> commit
-                out["three_launch_step"] = dict(side_run(device, cfg, max(min(K, 100), 60), fused_prepare=False, spec_rows=3),
-                                                note="--fused-prepare 0 --spec-rows 3: lantern_prepare_step as its own launch in front of the walk; same groups, same turn-taking")
         if not args.no_extras and world == 1 and wl.windowed:
             out["dynamic_tree"] = dynamic_run(device, cfg, min(K, 100), n_seq, fuse_o7=True)
             out["dynamic_tree"]["all_rows_by_cfg_mask_topk"] = {k: v for k, v in dynamic_run(device, cfg, min(K, 100), n_seq, fuse_o7=False).items()

@@ -379,7 +379,8 @@ class LuminaVerifyWorkload:
         self.fused_prepare = bool(cfg.fused_prepare and self.fused_o7 and self.n_spec >= 1 and self.ep_nodes is None and not self.anole and self._steps
                                   and cfg.top_p >= 1.0 and cfg.n_seq // max(1, cfg.n_groups) <= 256)
         if self.fused_prepare:
-            self._row_ready = torch.zeros((cfg.n_seq, self.N), dtype=torch.int32, device=device)          # zeroed once: the epochs (step + 1) only grow
+            self._row_ready = torch.zeros((cfg.n_seq, self.N), dtype=torch.int32, device=device)          # zeroed once: the epochs only grow
+            self._row_epoch = 0          # (its own counter, NOT the step index: reset_state() restarts the steps, and a word left by an earlier run must never read as "published")
 
     # -------------------------------------------------------------------------------------
     def reset_state(self):
@@ -694,6 +695,8 @@ class LuminaVerifyWorkload:
         nxt_arr = self._steps[((step + 1) % c.pool_steps, parity ^ 1)] if merge else None
         turns = c.commit_window > 0 and c.with_kv and self.G > 1 and self.ep_nodes is None
         fused = self.fused_prepare and not merge
+        if fused:
+            self._row_epoch += 1
         if turns and not hasattr(self, "_turn"):
             self._turn = torch.zeros(_lib.TURN_WORDS(self.G), dtype=torch.int64, device=self.device)          # never reset: tickets and epochs only grow
             self._turn_step = 0
@@ -707,7 +710,7 @@ class LuminaVerifyWorkload:
             s.flags = _lib.STEP_PREPARED if self._prepared_for == step else 0
             if fused:
                 s.flags = _lib.STEP_FUSED_PREPARE
-                s.row_ready, s.row_epoch = self._row_ready[g * self.Bg:].data_ptr(), step + 1
+                s.row_ready, s.row_epoch = self._row_ready[g * self.Bg:].data_ptr(), self._row_epoch
             if merge:
                 n_ = nxt_arr[g]
                 n_.sample_token = bs["tok"] + 8 * (step * c.n_seq + g * self.Bg)          # this step's bonus tokens = the next step's roots
@@ -828,7 +831,8 @@ class LuminaVerifyWorkload:
                 C.memmove(C.byref(tmp.ep_buf), C.byref(A["ep_buf"]), C.sizeof(EpBuffers))
                 C.memmove(C.byref(tmp.ep_win), C.byref(A["ep_win"]), C.sizeof(EpWindow))
                 tmp.stream, tmp.sample_token, tmp.slab_ptrs, tmp.turn, tmp.prepare_next = st.value, p_sample.value, None, None, None
-                tmp.flags, tmp.row_ready, tmp.row_epoch = _lib.STEP_FUSED_PREPARE, self._row_ready[g * self.Bg:].data_ptr(), self.step_idx + 1
+                self._row_epoch += 1
+                tmp.flags, tmp.row_ready, tmp.row_epoch = _lib.STEP_FUSED_PREPARE, self._row_ready[g * self.Bg:].data_ptr(), self._row_epoch
                 if events:
                     self._arm(events, "evaluate_posterior")
                 check(L.lantern_verify_step(C.byref(tmp), 1), "verify_step (fused prepare)")

@@ -638,7 +638,7 @@ def test_prepare_stage_inside_the_chain_launch(groups, spec, window, geom):
     torch.cuda.synchronize()
     a.check_status(0, steps)
     assert a.fused_prepare and not b.fused_prepare and not hasattr(b, "_row_ready")
-    assert int(a._row_ready.max()) == (steps if spec >= 2 else 0)          # the helpers published rows in the last step (spec 1: the root alone, no helper)
+    assert int(a._row_ready.max()) == (a._row_epoch if spec >= 2 else 0) and a._row_epoch == steps          # the helpers published rows in the last step (spec 1: the root alone, no helper)
     for k in ("log_best", "log_alen", "log_cnt", "log_token"):
         assert torch.equal(getattr(a, k)[:steps], getattr(b, k)[:steps]), k
     for x, y in zip(a.slabs, b.slabs):
@@ -651,3 +651,14 @@ def test_prepare_stage_inside_the_chain_launch(groups, spec, window, geom):
     stream = [[(int(gb[i, s]), int(ga[i, s]), int(gt[i, s])) for s in range(a.cfg.n_seq)] for i in range(steps)]
     res = bench.cpu_baseline(a, steps_budget_s=1e9, n_seq=a.cfg.n_seq, gpu_tokens_by_seq=stream)
     assert res["matches_gpu_token_stream"], res
+    # a second run on the same buffers (reset_state restarts the step index, not the epochs: no word of the first run reads as "published")
+    if spec >= 2:
+        a.reset_state(); b.reset_state()
+        for w in (a, b):
+            for _ in range(12):
+                w.step()
+            w.join()
+        torch.cuda.synchronize()
+        assert a._row_epoch == steps + 12
+        for k in ("log_best", "log_alen", "log_cnt", "log_token"):
+            assert torch.equal(getattr(a, k)[:12], getattr(b, k)[:12]), k

@@ -802,13 +802,11 @@ def side_run(device, base_cfg, steps, **over):
     wl.prime()
     for _ in range(10):
         wl.step()
-    wl.join()
-    torch.cuda.synchronize(device)
+    torch.cuda.synchronize(device)          # (device-wide; NOT join(): cross-stream event waits behind a deep queue slow its drain)
     t0 = time.perf_counter()
     for _ in range(steps):
         wl.step()
-    wl.join()
-    torch.cuda.synchronize(device)
+    torch.cuda.synchronize(device)          # (device-wide; NOT join(): cross-stream event waits behind a deep queue slow its drain)
     dt = time.perf_counter() - t0
     wl.check_status(0, steps + 10)
     toks = wl.accepted_tokens(10, 10 + steps)
@@ -1413,8 +1411,7 @@ def main():
     # ---- N > 1: BASELINE's own scaling form (C5: 64 sequences in ALL) beside the weak-scaling headline, in the same line.  Every rank takes part
     # (its barriers are collective); the weak run's KV slabs are released first (64 sequences per GPU fill the device).
     if world > 1 and args.total_seqs == 0 and not args.no_kv and os.environ.get("LANTERN_BENCH_NO_C5") != "1":
-        wl.join()
-        torch.cuda.synchronize(device)
+        torch.cuda.synchronize(device)          # (device-wide; NOT join(): cross-stream event waits behind a deep queue slow its drain)
         wl.release_kv()
         c5 = c5_strong_run(args, cfg, world, rank, device, dist, group, red_device)
         if rank == 0:
@@ -1424,19 +1421,16 @@ def main():
         if not args.no_extras and wl.windowed and world == 1:
             # LANTERN++ mode of the same workload (run B of BASELINE.md: lantern_delta = 5 -> tau = 4 * p(x)): same pools, same kernels
             KL = 60
-            wl.join()
-            torch.cuda.synchronize(device)
+            torch.cuda.synchronize(device)          # (device-wide; NOT join(): cross-stream event waits behind a deep queue slow its drain)
             wl.set_lantern_delta(5.0)
             wl.reset_state()
             for _ in range(15):
                 wl.step()
-            wl.join()
-            torch.cuda.synchronize(device)
+            torch.cuda.synchronize(device)          # (device-wide; NOT join(): cross-stream event waits behind a deep queue slow its drain)
             t1 = time.perf_counter()
             for _ in range(KL):
                 wl.step()
-            wl.join()
-            torch.cuda.synchronize(device)
+            torch.cuda.synchronize(device)          # (device-wide; NOT join(): cross-stream event waits behind a deep queue slow its drain)
             dl = time.perf_counter() - t1
             wl.check_status(0, KL + 15)
             tl = wl.accepted_tokens(15, 15 + KL)
@@ -1451,13 +1445,11 @@ def main():
                 wl.reset_state()
                 for _ in range(15):
                     wl.step()
-                wl.join()
-                torch.cuda.synchronize(device)
+                torch.cuda.synchronize(device)          # (device-wide; NOT join(): cross-stream event waits behind a deep queue slow its drain)
                 t1 = time.perf_counter()
                 for _ in range(KL):
                     wl.step()
-                wl.join()
-                torch.cuda.synchronize(device)
+                torch.cuda.synchronize(device)          # (device-wide; NOT join(): cross-stream event waits behind a deep queue slow its drain)
                 dm = time.perf_counter() - t1
                 wl.check_status(0, KL + 15)
                 out["merged_prepare_harness_only"] = {"ms_per_step": 1e3 * dm / KL, "value": wl.accepted_tokens(15, 15 + KL) / dm, "steps": KL,

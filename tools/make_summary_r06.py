@@ -30,8 +30,7 @@ o = ["# Round 6 profile summary (one MI355X)\n",
      "* drafting cycle wall (us): " + ", ".join(f"{k} {v.get('us_per_cycle_wall', 0):.0f}" for k, v in d.get("drafter_cycle", {}).items() if isinstance(v, dict)),
      f"* drop-in `EaLumina_mGPT.generate`: {d.get('mirror_generate', {}).get('us_per_verify_step', 0):.1f} us per verify step inside this run (`tools/mirror_bench.py`).",
      "* the same workload with three launches per group (`--fused-prepare 0 --spec-rows 3`), alternating with the default on one box: `r06_two_launch_vs_three_driver_form.txt` "
-     "(20-step form) and `r06_two_launch_vs_three_200_steps.txt`.  (A side workload built inside the bench process after the headline's 276 GB of slabs were freed and "
-     "re-allocated runs 20-40 % slower than the same configuration stand-alone -- measured 96.7 us for this form -- so the comparison is not a bench extra.)",
+     "(20-step form) and `r06_two_launch_vs_three_200_steps.txt`.",
      f"* other configurations: lambda mode {d['lambda_mode']['value'] / 1e6:.2f} M tokens/s; EAGLE-2 tree {d['dynamic_tree']['value'] / 1e6:.2f} M ({1e3 * d['dynamic_tree']['ms_per_step']:.1f} us per step); "
      f"C2 {d['configs']['C2']['value'] / 1e6:.2f} M; C4 " + " / ".join(f"{x['value'] / 1e6:.2f}" for x in d["configs"]["C4"]) + " M.",
      "\n## rocprofv3 `--kernel-trace --stats` of the bench command (`r06_raw_kernel_stats.csv`; four groups in flight, and -- commit turn-taking, the default at four groups -- "

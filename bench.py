@@ -773,7 +773,7 @@ def other_configs(device, base_cfg, steps, n_seq, only=None):
     for lam, kk in ((5.0, 10), (10.0, 5), (20.0, 5)):
         over = dict(model="anole", tree="naive_extend_57", lantern_k=kk, lantern_delta=lam, fuse_o7=True, spec_rows=3, ep_kernel="chain",
                     seed_base=4000)
-        grouped = side_run(device, base_cfg, steps, n_groups=groups, n_seq=n_seq, **over)
+        grouped = side_run(device, base_cfg, steps, n_groups=groups, n_seq=n_seq, **dict(over, fused_prepare=bool(base_cfg.fused_prepare)))
         all_rows = side_run(device, base_cfg, steps, n_groups=groups, n_seq=n_seq, **dict(over, fuse_o7=False, spec_rows=0))
         one = per_kernel_run(device, base_cfg, min(steps, 40), n_seq=n_seq, **{k_: v_ for k_, v_ in over.items() if k_ not in ("fuse_o7", "spec_rows")})
         rl = one["roofline"]

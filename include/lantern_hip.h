@@ -487,7 +487,7 @@ typedef struct lantern_step_group {
     const lantern_step_greedy *greedy;    /* NULL: relaxed rejection sampling (evaluate_posterior); else the greedy / TVD accept above */
     const lantern_step_dense *dense;      /* NULL: the windowed kernels; else the dense kernel set above */
     /* flags & LANTERN_STEP_FUSED_PREPARE (round 6): the prepare stage rides INSIDE the chain launch -- two launches per step (walk, commit) instead of three.
-     * Static Lumina trees on raw rows with a node list (lantern_prepare_step's form; node_list[0] is the root), chain kernel, at most 256 sequences.  The
+     * Static Lumina or Anole trees on raw rows with a node list (lantern_prepare_step's form; node_list[0] is the root), chain kernel, at most 256 sequences.  The
      * launch's first B * (n_list - 1) workgroups post-process the listed rows but the root's into out_win (= ep_win.raw_probs) and publish each by storing
      * row_epoch into row_ready[b * N + node]; the sequence workgroups assemble their own candidates (written to cand / tree_cand / cart_prob for the commit
      * launch), post-process the root's row themselves, and read a listed row only once its word carries this step's epoch -- otherwise they post-process it

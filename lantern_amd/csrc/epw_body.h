@@ -185,7 +185,7 @@ __device__ __forceinline__ int epw_body(const EpwArgs &args, const int b, const 
     constexpr bool DMAROW = COMPACT || (TPO & 512) != 0;          // probability rows land in g by LDS-DMA (row_dma_to_lds): no VGPR staging, no ds_write pass
     static_assert(!DMAROW || (SPEC >= 1 && !RAW && FULLW), "LDS-DMA rows: final probability rows of a fixed configuration whose window is the workgroup's tile");
     constexpr bool FUSED = (TPO & 1024) != 0;        // the prepare stage rides in this launch (EpwFused above): candidates assembled here, listed rows taken when published
-    static_assert(!FUSED || (RAW && (SPEC == 1 || SPEC == 2) && WPE == 1), "fused prepare: the Lumina static-tree latency instances on raw rows");
+    static_assert(!FUSED || (RAW && (SPEC == 1 || SPEC == 2 || SPEC == 4) && WPE == 1), "fused prepare: the static-tree latency instances (Lumina, Anole) on raw rows");
     typedef typename std::conditional<COMPACT, EwSharedCompact, typename std::conditional<LITE, EwSharedLite, EwShared>::type>::type SH;
     constexpr int MAX_B = SH::kMaxB, MAX_N = SH::kMaxN, N_UNI = SH::kUni;
     constexpr bool LDSIDS = IDMODE != 0;

@@ -575,8 +575,8 @@ extern "C" int lantern_evaluate_posterior_window(const lantern_ep_params *prm, c
     return LANTERN_OK;
 }
 
-// The chain launch with its prepare stage inside (lantern_step_group flags & LANTERN_STEP_FUSED_PREPARE, verify_step.cpp): the Lumina static-tree latency instances
-// on raw rows, at most 256 sequences.  Anything else is refused -- the caller asked for a form that does not exist, it is not quietly run in three launches.
+// The chain launch with its prepare stage inside (lantern_step_group flags & LANTERN_STEP_FUSED_PREPARE, verify_step.cpp): the static-tree latency instances (Lumina,
+// Anole) on raw rows, at most 256 sequences.  Anything else is refused -- the caller asked for a form that does not exist, it is not quietly run in three launches.
 namespace lantern {
 int evaluate_posterior_window_fused(const lantern_ep_params *prm, const lantern_ep_buffers *buf, const lantern_ep_window *win, const PrepArgs &prep, int32_t *ready,
                                     int32_t epoch, void *stream) {
@@ -588,13 +588,16 @@ int evaluate_posterior_window_fused(const lantern_ep_params *prm, const lantern_
     const bool raw = win->rows_kind == LANTERN_ROWS_RAW_BF16;
     const bool nucleus = p.top_p >= 1e-8f && p.top_p < 1.0f;
     const bool lumina_syntax = p.syntax_shortcut && p.n_syntax == 4 && p.syntax[0] == 8196 && p.syntax[1] == 8197 && p.syntax[2] == 8803 && p.syntax[3] == 8828;
-    const bool form = raw && !nucleus && p.lantern && p.V == 65536 && p.img_lo == 4 && p.img_hi == 8196 && p.tok_offset == 4 && p.table_rows == 8192 && win->win_lo == 4 &&
-                      W == 8192 && p.rows_per_seq <= EW_MAX_N && (win->raw_w_latent == 0 || (win->raw_eos_id == 8196 && win->raw_newline_id == 8803)) &&
-                      p.mode == LANTERN_MODE_STATIC_LUMINA && lumina_syntax && !buf->n_paths && !buf->n_depth && !win->raw_pos_per_seq && p.table_cols % 8 == 0 &&
-                      ((uintptr_t)buf->nn_table & 15) == 0 && ((p.k + 1 < p.table_cols ? p.k + 1 : p.table_cols) <= EW_PF_K) && p.B <= 256;
+    // the Chameleon image window on the packed table, one tree for all sequences (the conditions under which lantern_evaluate_posterior_window takes a SPEC instance)
+    const bool chameleon = raw && !nucleus && p.lantern && p.V == 65536 && p.img_lo == 4 && p.img_hi == 8196 && p.tok_offset == 4 && p.table_rows == 8192 && win->win_lo == 4 &&
+                           W == 8192 && p.rows_per_seq <= EW_MAX_N && !buf->n_paths && !buf->n_depth && !win->raw_pos_per_seq && p.table_cols % 8 == 0 &&
+                           ((uintptr_t)buf->nn_table & 15) == 0 && ((p.k + 1 < p.table_cols ? p.k + 1 : p.table_cols) <= EW_PF_K) && p.B <= 256;
+    const bool lumina = chameleon && p.mode == LANTERN_MODE_STATIC_LUMINA && lumina_syntax && (win->raw_w_latent == 0 || (win->raw_eos_id == 8196 && win->raw_newline_id == 8803));
+    const bool anole = chameleon && p.mode == LANTERN_MODE_STATIC_LG && !p.syntax_shortcut && win->raw_w_latent == 0;
+    const bool form = lumina || anole;
     if (!form || !ready || !win->raw_probs || !win->raw_pre || prep.n_list < 1 || prep.B != p.B || prep.PD != p.P * p.D || prep.N != p.N || prep.rows_per_seq != p.rows_per_seq ||
         prep.out_win != win->raw_probs || prep.W != W || !prep.cand || !prep.tree_cand || (prep.top_p >= 1e-8f && prep.top_p < 1.0f)) {
-        set_error("fused prepare: Lumina static trees on raw bf16 rows (8192-id window, packed table, k + 1 <= %d, top_p off), at most 256 sequences, a node list "
+        set_error("fused prepare: Lumina or Anole static trees on raw bf16 rows (8192-id window, packed table, k + 1 <= %d, top_p off), at most 256 sequences, a node list "
                   "whose rows go to ep_win.raw_probs, and the row_ready words", EW_PF_K);
         return LANTERN_E_UNSUPPORTED;
     }
@@ -607,7 +610,8 @@ int evaluate_posterior_window_fused(const lantern_ep_params *prm, const lantern_
     const dim3 grid(fz.n_helpers + p.B);
     const bool default_tree = tuning(TUNE_EPW_SPEC) >= 2 && p.P == 15 && p.D == 6 && p.N == 26 && p.rows_per_seq == 26;
     hipStream_t st = (hipStream_t)stream;
-    if (default_tree) LANTERN_LAUNCH((epw_kernel_fused<512, 4, 2, 1, true, true, 2, 0>), grid, dim3(512), lds, st, args, fz);
+    if (anole) LANTERN_LAUNCH((epw_kernel_fused<512, 4, 2, 1, true, true, 4, 0>), grid, dim3(512), lds, st, args, fz);
+    else if (default_tree) LANTERN_LAUNCH((epw_kernel_fused<512, 4, 2, 1, true, true, 2, 0>), grid, dim3(512), lds, st, args, fz);
     else LANTERN_LAUNCH((epw_kernel_fused<512, 4, 2, 1, true, true, 1, 0>), grid, dim3(512), lds, st, args, fz);
     LANTERN_CHECK_LAUNCH("evaluate_posterior_window (fused prepare)");
     return LANTERN_OK;

@@ -376,7 +376,7 @@ class LuminaVerifyWorkload:
                 for parity in (0, 1):
                     self._steps[(slot, parity)] = self._make_step_groups(slot, parity)
         # the prepare stage inside the chain launch (LANTERN_STEP_FUSED_PREPARE): Lumina static trees on raw rows, the one-call step
-        self.fused_prepare = bool(cfg.fused_prepare and self.fused_o7 and self.n_spec >= 1 and self.ep_nodes is None and not self.anole and self._steps
+        self.fused_prepare = bool(cfg.fused_prepare and self.fused_o7 and self.n_spec >= 1 and self.ep_nodes is None and self._steps
                                   and cfg.top_p >= 1.0 and cfg.n_seq // max(1, cfg.n_groups) <= 256)
         if self.fused_prepare:
             self._row_ready = torch.zeros((cfg.n_seq, self.N), dtype=torch.int32, device=device)          # zeroed once: the epochs only grow

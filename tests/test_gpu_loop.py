@@ -134,6 +134,12 @@ def test_anole_static_loop_matches_oracle_loop(fuse, groups, spec, lam, k):
     _anole_static_loop(fuse, groups, spec, lam, k, 3 * groups, 24, 1)
 
 
+@pytest.mark.parametrize("groups,spec,lam,k", [(1, 1, 5.0, 10), (2, 3, 10.0, 5), (1, 4, 0.3, 40)], ids=["no_helper", "2_groups_2_helper_rows", "delta_mode_3_helper_rows"])
+def test_anole_static_loop_with_the_prepare_stage_inside_the_chain_launch(groups, spec, lam, k):
+    """BASELINE config 4 on the two-launch step (LANTERN_STEP_FUSED_PREPARE, the Anole instance epw_kernel_fused<512, 4, 2, 1, true, true, 4, 0>): the oracle's loop."""
+    _anole_static_loop(True, groups, spec, lam, k, 3 * groups, 24, 1, fused_prepare=True)
+
+
 @pytest.mark.parametrize("fuse,spec", [(False, 0), (True, 0), (True, 3)], ids=["o7_launch", "raw_rows", "raw_rows_3_prepared"])
 def test_anole_static_loop_with_top_p(fuse, spec):
     """generate(top_p = 0.9): TopPLogitsWarper in front of the top-k (drafters/utils.py:36-52; the reference applies the list per visited row inside
@@ -232,7 +238,7 @@ def _lumina_static_loop_big(tree, n_seq, steps, every, fuse_o7=False, spec_rows=
     assert n_acc > 0 and n_rej > 0
 
 
-def _anole_static_loop(fuse, groups, spec, lam, k, n_seq, steps, every, top_p=1.0, ties=False):
+def _anole_static_loop(fuse, groups, spec, lam, k, n_seq, steps, every, top_p=1.0, ties=False, fused_prepare=False):
     """BASELINE config 4 (Anole, LANTERN++ static tree naive_extend_57: neighbours zeroed in the drafter's row, no syntax shortcut, no grammar rows)
     through the device-resident step loop -- O7 over all rows, and the raw rows post-processed inside evaluate_posterior with the likeliest rows
     prepared beside O6 -- against the oracle's loop over the same pools / uniforms: identical (best path, accept length, bonus token) at every step."""
@@ -241,9 +247,9 @@ def _anole_static_loop(fuse, groups, spec, lam, k, n_seq, steps, every, top_p=1.
     from lantern_amd import harness as HN
     cfg = HN.WorkloadConfig(model="anole", tree="naive_extend_57", n_seq=n_seq, pool_steps=4 if n_seq < 64 else 2, kv_layers=2, kv_heads=4, kv_smax=512,
                             max_steps=steps + 4, sigma=5.0, n_groups=groups, ep_kernel="chain", fuse_o7=fuse, spec_rows=spec, lantern_k=k, lantern_delta=lam,
-                            top_p=top_p)
+                            top_p=top_p, fused_prepare=fused_prepare)
     wl = HN.LuminaVerifyWorkload(cfg, torch.device("cuda"))
-    assert wl.anole and wl.fused_o7 == fuse and wl.n_spec == (spec if fuse else 0)
+    assert wl.anole and wl.fused_o7 == fuse and wl.n_spec == (spec if fuse else 0) and wl.fused_prepare == fused_prepare
     if ties:
         # logits on a grid of 0.5 (bf16-exact, and so is every CFG mix of them): ~130 distinct values among 8192 ids, so the 1 - top_p boundary
         # falls INSIDE a group of equal logits in every row -- the stable-sort order of the tied entries (index order) decides which of them go
